@@ -1,0 +1,147 @@
+/*
+ * fvo.h -- CPU ORACLE for the FV3 dyn_core hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This directory is a plain-C, loop-for-loop restatement of the reference algorithm
+ * (NOAA-GFDL/GFDL_atmos_cubed_sphere release 202411; citations are file:line under
+ * /root/reference).  It exists so that the HIP kernels in gfdl_atmos_cubed_sphere_amd/csrc
+ * can be checked against an independent CPU statement of the same arithmetic.
+ *
+ *   * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it.
+ *   * The product (libfv3_mi355x.so) never links, loads or falls back to anything here.
+ *
+ * PINNING STATUS ("parity unpinned" unless listed):
+ *   pinned    : 1-D PPM flux operator xppm/yppm for hord 5, -5, 6, 8, 10 on a periodic
+ *               line -- checked against vectors produced by executing the reference's own
+ *               Python restatement docs/examples/tp_core.ipynb (tests/golden/ppm1d_*.npz,
+ *               generator tests/golden/make_ppm1d_golden.py).
+ *   unpinned  : everything else (fv_tp_2d, c_sw, d_sw, column solvers, remap).  The reference
+ *               ships no unit tests / golden vectors, and its Fortran
+ *               cannot be built here without writing stand-ins for the absent FMS library,
+ *               which the build rules forbid.  Those operators are pinned only by the
+ *               reference's conservation identities (tests/test_oracle_properties.py).
+ *
+ * Scope of the restated branches: grid_type >= 3 (doubly periodic / Cartesian branches) with
+ * general (array-valued) metric terms, bounded_domain = .false., no nesting, no regional BCs.
+ * The cubed-sphere edge/corner branches (grid_type < 3) return FVO_ERR_UNSUPPORTED.
+ *
+ * Array layout is the reference's (Fortran column-major, i fastest), with the exact
+ * lower/upper bounds of model/fv_arrays.F90:1521-1563; see the accessor macros below.
+ * Build: gcc -O2 -ffp-contract=off -fopenmp (no FMA contraction: results are the
+ * straightforward IEEE evaluation of the reference's expressions, left to right).
+ */
+#ifndef FVO_H
+#define FVO_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FVO_OK 0
+#define FVO_ERR_UNSUPPORTED 2
+
+/* fv_grid_bounds_type (model/fv_arrays.F90:1192-1200) + the gridstruct/flagstruct members
+ * that the hot path reads (model/fv_arrays.F90:75-205, shapes :1749-1881). */
+typedef struct fvo_grid {
+  int is, ie, js, je, isd, ied, jsd, jed, ng;
+  int npx, npy, grid_type;
+  int bounded_domain, sw_corner, se_corner, ne_corner, nw_corner, stretched_grid;
+  double da_min, da_min_c;
+  /* (isd:ied, jsd:jed) */
+  const double *area, *rarea, *dxa, *dya, *rdxa, *rdya, *cosa_s, *rsin2, *f0;
+  /* (isd:ied, jsd:jed+1) */
+  const double *dx, *rdx, *dyc, *rdyc, *cosa_v, *sina_v, *rsin_v, *divg_u, *del6_u;
+  /* (isd:ied+1, jsd:jed) */
+  const double *dy, *rdy, *dxc, *rdxc, *cosa_u, *sina_u, *rsin_u, *divg_v, *del6_v;
+  /* (isd:ied+1, jsd:jed+1) */
+  const double *rarea_c, *fC, *cosa, *sina;
+  /* (is:ie+1, js:je+1) */
+  const double *rsina;
+  /* (isd:ied, jsd:jed, 9) */
+  const double *sin_sg, *cos_sg;
+  /* flagstruct members used by the kernels (sw_core.F90:126-127,590-591,624,964,1250) */
+  double lim_fac;
+  int do_diss_est, prevent_diss_cooling, do_f3d;
+} fvo_grid;
+
+/* ---- tp_core (model/tp_core.F90) ------------------------------------------------------- */
+
+/* 1-D PPM face values on one line.  q1 is indexable on [is-3, ie+3] (pointer to element 0 of a
+ * virtual array), c and flux on [is, ie+1].  Doubly-periodic / bounded branch of
+ * xppm (tp_core.F90:324-712) == yppm (:715-1152) applied to one line. */
+int fvo_ppm_line(const double *q1, const double *c, double *flux, int is, int ie, int iord,
+                 double lim_fac);
+
+/* pert_ppm (tp_core.F90:1206-1264) */
+void fvo_pert_ppm(int im, const double *a0, double *al, double *ar, int iv);
+
+/* fv_tp_2d (tp_core.F90:85-241).  Optional arguments are nullable pointers; nord<0 means
+ * "nord/damp_c not present". */
+int fvo_fv_tp_2d(const fvo_grid *g, double *q, const double *crx, const double *cry, int hord,
+                 double *fx, double *fy, const double *xfx, const double *yfx, const double *ra_x,
+                 const double *ra_y, const double *mfx, const double *mfy, const double *mass,
+                 int nord, double damp_c);
+
+/* deln_flux (tp_core.F90:1267-1447), damp_Km absent. */
+int fvo_deln_flux(const fvo_grid *g, int nord, double damp, const double *q, double *fx, double *fy,
+                  const double *mass);
+
+/* ---- sw_core (model/sw_core.F90) ------------------------------------------------------- */
+
+int fvo_d2a2c_vect(const fvo_grid *g, const double *u, const double *v, double *ua, double *va,
+                   double *uc, double *vc, double *ut, double *vt, int dord4);
+int fvo_divergence_corner(const fvo_grid *g, const double *u, const double *v, const double *ua,
+                          const double *va, double *divg_d);
+int fvo_del6_vt_flux(const fvo_grid *g, int nord, double damp, const double *q, double *d2,
+                     double *fx2, double *fy2);
+int fvo_xtp_u(const fvo_grid *g, const double *c, const double *u, const double *v, double *flux,
+              int iord);
+int fvo_ytp_v(const fvo_grid *g, const double *c, const double *u, const double *v, double *flux,
+              int jord);
+int fvo_a2b_ord4(const fvo_grid *g, double *qin, double *qout, int replace);
+int fvo_smag_corner(const fvo_grid *g, double dt, const double *u, const double *v, double *smag_c);
+
+/* c_sw, one k-slab (sw_core.F90:79-488).  w/wc may be NULL when hydrostatic. */
+int fvo_c_sw(const fvo_grid *g, double *delpc, double *delp, double *ptc, double *pt, double *u,
+             double *v, double *w, double *uc, double *vc, double *ua, double *va, double *wc,
+             double *ut, double *vt, double *divg_d, int nord, double dt2, int hydrostatic,
+             int dord4);
+
+/* d_sw, one k-slab (sw_core.F90:494-1606); inline_q=.false., use_cond optional (q_con nullable). */
+typedef struct fvo_dsw_par {
+  double dt;
+  int hord_tr, hord_mt, hord_vt, hord_tm, hord_dp;
+  int nord, nord_v, nord_w, nord_t;
+  double dddmp, d2_bg, d4_bg, damp_v, damp_w, damp_t, d_con, kgb;
+  int hydrostatic, use_cond;
+} fvo_dsw_par;
+
+int fvo_d_sw(const fvo_grid *g, const fvo_dsw_par *p, double *delpc, double *delp, double *ptc,
+             double *pt, double *u, double *v, double *w, double *uc, double *vc, double *ua,
+             double *va, double *divg_d, double *xflux, double *yflux, double *cx, double *cy,
+             double *crx_adv, double *cry_adv, double *xfx_adv, double *yfx_adv, double *q_con,
+             double *heat_source, double *diss_est);
+
+/* all-k drivers (the OpenMP k-loops of dyn_core.F90:436-447 and :658-812).  3-D arrays are
+ * the 2-D slabs above stacked in k. Per-level coefficient arrays have length npz. */
+int fvo_c_sw_3d(const fvo_grid *g, int npz, double *delpc, double *delp, double *ptc, double *pt,
+                double *u, double *v, double *w, double *uc, double *vc, double *ua, double *va,
+                double *wc, double *ut, double *vt, double *divg_d, int nord, double dt2,
+                int hydrostatic, int dord4);
+
+typedef struct fvo_dsw_levels {
+  const int *nord_k, *nord_v, *nord_w, *nord_t;
+  const double *d2_divg, *damp_vt, *damp_w, *damp_t, *d_con_k;
+} fvo_dsw_levels;
+
+int fvo_d_sw_3d(const fvo_grid *g, int npz, const fvo_dsw_par *p, const fvo_dsw_levels *lv,
+                double *delpc, double *delp, double *ptc, double *pt, double *u, double *v,
+                double *w, double *uc, double *vc, double *ua, double *va, double *divg_d,
+                double *mfx, double *mfy, double *cx, double *cy, double *crx, double *cry,
+                double *xfx, double *yfx, double *q_con, double *heat_source, double *diss_est);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

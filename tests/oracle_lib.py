@@ -1,0 +1,153 @@
+"""ctypes binding of the CPU oracle (oracle/libfvo.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package never does (tests/test_product_isolation.py checks that).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = None
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+_A = ["area", "rarea", "dxa", "dya", "rdxa", "rdya", "cosa_s", "rsin2", "f0"]
+_U = ["dx", "rdx", "dyc", "rdyc", "cosa_v", "sina_v", "rsin_v", "divg_u", "del6_u"]
+_V = ["dy", "rdy", "dxc", "rdxc", "cosa_u", "sina_u", "rsin_u", "divg_v", "del6_v"]
+_B = ["rarea_c", "fC", "cosa", "sina"]
+
+
+class FvoGrid(C.Structure):
+    _fields_ = (
+        [(n, C.c_int) for n in ["is_", "ie", "js", "je", "isd", "ied", "jsd", "jed", "ng", "npx", "npy",
+                                "grid_type", "bounded_domain", "sw_corner", "se_corner", "ne_corner",
+                                "nw_corner", "stretched_grid"]]
+        + [("da_min", C.c_double), ("da_min_c", C.c_double)]
+        + [(n, _dp) for n in _A + _U + _V + _B + ["rsina", "sin_sg", "cos_sg"]]
+        + [("lim_fac", C.c_double), ("do_diss_est", C.c_int), ("prevent_diss_cooling", C.c_int),
+           ("do_f3d", C.c_int)]
+    )
+
+
+class DswPar(C.Structure):
+    _fields_ = [("dt", C.c_double)] + [(n, C.c_int) for n in
+                                       ["hord_tr", "hord_mt", "hord_vt", "hord_tm", "hord_dp", "nord", "nord_v",
+                                        "nord_w", "nord_t"]] + [(n, C.c_double) for n in
+                                                                ["dddmp", "d2_bg", "d4_bg", "damp_v", "damp_w",
+                                                                 "damp_t", "d_con", "kgb"]] + [
+                   ("hydrostatic", C.c_int), ("use_cond", C.c_int)]
+
+
+class DswLevels(C.Structure):
+    _fields_ = [(n, _ip) for n in ["nord_k", "nord_v", "nord_w", "nord_t"]] + [(n, _dp) for n in
+                                                                                 ["d2_divg", "damp_vt", "damp_w",
+                                                                                  "damp_t", "d_con_k"]]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_ORACLE_DIR, "libfvo.so")
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in os.listdir(_ORACLE_DIR) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+    return _LIB
+
+
+def p(a):
+    """double* of a Fortran-ordered float64 array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["F_CONTIGUOUS"], "oracle wants F-ordered float64"
+    return a.ctypes.data_as(_dp)
+
+
+def make_grid(g) -> FvoGrid:
+    """Build the oracle's grid struct from a gfdl_atmos_cubed_sphere_amd.grid.GridStruct."""
+    b = g.bd
+    s = FvoGrid()
+    s.is_, s.ie, s.js, s.je = b.is_, b.ie, b.js, b.je
+    s.isd, s.ied, s.jsd, s.jed, s.ng = b.isd, b.ied, b.jsd, b.jed, b.ng
+    s.npx, s.npy, s.grid_type = g.npx, g.npy, g.grid_type
+    s.bounded_domain = int(g.bounded_domain)
+    s.sw_corner, s.se_corner, s.ne_corner, s.nw_corner = (int(g.sw_corner), int(g.se_corner),
+                                                          int(g.ne_corner), int(g.nw_corner))
+    s.stretched_grid = int(g.stretched_grid)
+    s.da_min, s.da_min_c = g.da_min, g.da_min_c
+    for n in _A + _U + _V + _B + ["rsina", "sin_sg", "cos_sg"]:
+        setattr(s, n, p(g.m[n]))
+    s.lim_fac = g.lim_fac
+    s.do_diss_est, s.prevent_diss_cooling, s.do_f3d = int(g.do_diss_est), int(g.prevent_diss_cooling), int(g.do_f3d)
+    s._keep = g  # keep the numpy arrays alive
+    return s
+
+
+def ppm_line(q1: np.ndarray, c: np.ndarray, is_: int, ie: int, iord: int, lim_fac: float = 1.0) -> np.ndarray:
+    """q1 covers Fortran indices is-3..ie+3, c covers is..ie+1; returns flux on is..ie+1."""
+    q1 = np.ascontiguousarray(q1, dtype=np.float64)
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    assert q1.size == ie - is_ + 7 and c.size == ie - is_ + 2
+    flux = np.zeros_like(c)
+    # pass pointers to the virtual element 0
+    q0 = C.cast(C.c_void_p(q1.ctypes.data - 8 * (is_ - 3)), _dp)
+    c0 = C.cast(C.c_void_p(c.ctypes.data - 8 * is_), _dp)
+    f0 = C.cast(C.c_void_p(flux.ctypes.data - 8 * is_), _dp)
+    rc = lib().fvo_ppm_line(q0, c0, f0, C.c_int(is_), C.c_int(ie), C.c_int(iord), C.c_double(lim_fac))
+    assert rc == 0
+    return flux
+
+
+def fv_tp_2d(g, q, crx, cry, hord, xfx, yfx, ra_x, ra_y, mfx=None, mfy=None, mass=None, nord=-1, damp_c=0.0):
+    b = g.bd
+    fx, fy = b.zeros("FX"), b.zeros("FY")
+    gs = make_grid(g)
+    rc = lib().fvo_fv_tp_2d(C.byref(gs), p(q), p(crx), p(cry), C.c_int(hord), p(fx), p(fy), p(xfx), p(yfx),
+                            p(ra_x), p(ra_y), p(mfx), p(mfy), p(mass), C.c_int(nord), C.c_double(damp_c))
+    assert rc == 0, rc
+    return fx, fy
+
+
+def c_sw_3d(g, npz, f, nord, dt2, hydrostatic, dord4=True):
+    """f: dict of 3-D F-ordered arrays (delpc, delp, ptc, pt, u, v, w, uc, vc, ua, va, wc, ut, vt, divg_d);
+    modified in place exactly as the reference's k-loop over c_sw does."""
+    gs = make_grid(g)
+    rc = lib().fvo_c_sw_3d(C.byref(gs), C.c_int(npz), p(f["delpc"]), p(f["delp"]), p(f["ptc"]), p(f["pt"]),
+                           p(f["u"]), p(f["v"]), p(f.get("w")), p(f["uc"]), p(f["vc"]), p(f["ua"]), p(f["va"]),
+                           p(f.get("wc")), p(f["ut"]), p(f["vt"]), p(f["divg_d"]), C.c_int(nord),
+                           C.c_double(dt2), C.c_int(int(hydrostatic)), C.c_int(int(dord4)))
+    assert rc == 0, rc
+
+
+def d_sw_3d(g, npz, par: dict, lev: dict, f):
+    gs = make_grid(g)
+    pr = DswPar()
+    for k, v in par.items():
+        setattr(pr, k, v)
+    lv = DswLevels()
+    keep = []
+    for n in ["nord_k", "nord_v", "nord_w", "nord_t"]:
+        a = np.ascontiguousarray(lev[n], dtype=np.int32)
+        keep.append(a)
+        setattr(lv, n, a.ctypes.data_as(_ip))
+    for n in ["d2_divg", "damp_vt", "damp_w", "damp_t", "d_con_k"]:
+        a = np.ascontiguousarray(lev[n], dtype=np.float64)
+        keep.append(a)
+        setattr(lv, n, a.ctypes.data_as(_dp))
+    rc = lib().fvo_d_sw_3d(C.byref(gs), C.c_int(npz), C.byref(pr), C.byref(lv), p(f["delpc"]), p(f["delp"]),
+                           p(f["ptc"]), p(f["pt"]), p(f["u"]), p(f["v"]), p(f.get("w")), p(f["uc"]), p(f["vc"]),
+                           p(f["ua"]), p(f["va"]), p(f["divg_d"]), p(f["mfx"]), p(f["mfy"]), p(f["cx"]),
+                           p(f["cy"]), p(f["crx"]), p(f["cry"]), p(f["xfx"]), p(f["yfx"]), p(f.get("q_con")),
+                           p(f["heat_source"]), p(f["diss_est"]))
+    assert rc == 0, rc
