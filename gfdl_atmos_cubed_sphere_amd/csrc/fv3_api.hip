@@ -1,0 +1,396 @@
+// fv3_api.hip -- the C ABI of include/fv3_mi355x.h: context, gridstruct upload, kernel launches.
+// Compiled by hipcc --offload-arch=gfx950 into libfv3_mi355x.so (the product).  The same file is
+// also compiled by g++ -DFV3_HOST_EMU under tests/hostemu (logic-test harness only).
+#include "../../include/fv3_mi355x.h"
+
+#include <cstdarg>
+#include <new>
+
+#include "csw_kernel.h"
+#include "dsw_kernels.h"
+#include "fv3_common.h"
+#include "fv3_launch.h"
+#include "tp2d_tile.h"
+
+using namespace fv3;
+
+// Tile shapes (cells per workgroup).  Tuned on MI355X; see DESIGN.md.
+#ifndef FV3_CSW_TI
+#define FV3_CSW_TI 32
+#define FV3_CSW_TJ 8
+#endif
+#ifndef FV3_DSW_TI
+#define FV3_DSW_TI 32
+#define FV3_DSW_TJ 8
+#endif
+
+struct fv3_ctx {
+  fv3_domain dom;
+  Grid g;           // device view (pointers into dev_metrics)
+  stream_t stream;
+  double *dev_metrics;   // one allocation holding every metric array
+  bool grid_ready;
+  // per-level d_sw coefficients on the device
+  int *lev_i;      // 4*npz
+  double *lev_d;   // 5*npz
+  bool lev_ready;
+};
+
+static thread_local std::string g_err;
+
+static int fail(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+#define RT(call)                                                              \
+  do {                                                                        \
+    int e_ = (call);                                                          \
+    if (e_) return fail("%s failed: %s (%s:%d)", #call, rt_errstr(e_), __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" const char *fv3_last_error(void) { return g_err.c_str(); }
+
+extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
+  if (!dom || !out) return fail("fv3_create: null argument");
+  if (dom->ng != NG) return fail("fv3_create: ng must be %d", NG);
+  if (dom->grid_type < 4)
+    return fail("fv3_create: grid_type=%d not supported (only the grid_type=4 branches are built)", dom->grid_type);
+  if (dom->ie < dom->is || dom->je < dom->js || dom->npz < 1) return fail("fv3_create: empty domain");
+  fv3_ctx *c = new (std::nothrow) fv3_ctx();
+  if (!c) return fail("fv3_create: out of host memory");
+  c->dom = *dom;
+  Grid &g = c->g;
+  std::memset(&g, 0, sizeof g);
+  g.is = dom->is; g.ie = dom->ie; g.js = dom->js; g.je = dom->je;
+  g.isd = dom->is - NG; g.ied = dom->ie + NG; g.jsd = dom->js - NG; g.jed = dom->je + NG;
+  g.npx = dom->npx; g.npy = dom->npy; g.npz = dom->npz;
+  g.nid = g.ied - g.isd + 1; g.njd = g.jed - g.jsd + 1; g.nx = g.ie - g.is + 1; g.ny = g.je - g.js + 1;
+  g.grid_type = dom->grid_type;
+  g.do_diss_est = dom->do_diss_est; g.prevent_diss_cooling = dom->prevent_diss_cooling;
+  g.stretched_grid = dom->stretched_grid;
+  g.lim_fac = dom->lim_fac;
+  c->stream = nullptr;
+  c->dev_metrics = nullptr;
+  c->grid_ready = false;
+  c->lev_i = nullptr; c->lev_d = nullptr; c->lev_ready = false;
+  *out = c;
+  return 0;
+}
+
+extern "C" int fv3_destroy(fv3_ctx *c) {
+  if (!c) return 0;
+  if (c->dev_metrics) rt_free(c->dev_metrics);
+  if (c->lev_i) rt_free(c->lev_i);
+  if (c->lev_d) rt_free(c->lev_d);
+  delete c;
+  return 0;
+}
+
+extern "C" int fv3_set_stream(fv3_ctx *c, void *stream) {
+  if (!c) return fail("fv3_set_stream: null ctx");
+  c->stream = (stream_t)stream;
+  return 0;
+}
+
+extern "C" int fv3_malloc(void **dptr, size_t bytes) {
+  RT(rt_malloc(dptr, bytes));
+  return 0;
+}
+extern "C" int fv3_free(void *dptr) {
+  RT(rt_free(dptr));
+  return 0;
+}
+extern "C" int fv3_memcpy_h2d(fv3_ctx *c, void *dst, const void *src, size_t bytes) {
+  RT(rt_h2d(dst, src, bytes, c ? c->stream : nullptr));
+  return 0;
+}
+extern "C" int fv3_memcpy_d2h(fv3_ctx *c, void *dst, const void *src, size_t bytes) {
+  RT(rt_d2h(dst, src, bytes, c ? c->stream : nullptr));
+  return 0;
+}
+extern "C" int fv3_memset(fv3_ctx *c, void *dst, int value, size_t bytes) {
+  RT(rt_memset(dst, value, bytes, c ? c->stream : nullptr));
+  return 0;
+}
+extern "C" int fv3_sync(fv3_ctx *c) {
+  RT(rt_sync(c ? c->stream : nullptr));
+  return 0;
+}
+
+extern "C" int fv3_grid_upload(fv3_ctx *c, const fv3_grid_host *h) {
+  if (!c || !h) return fail("fv3_grid_upload: null argument");
+  Grid &g = c->g;
+  const size_t nA = g.nA(), nU = g.nU(), nV = g.nV(), nB = g.nB();
+  struct Item { const double *src; const double **dst; size_t n; };
+  Item items[] = {
+      {h->area, &g.area, nA}, {h->rarea, &g.rarea, nA}, {h->dxa, &g.dxa, nA}, {h->dya, &g.dya, nA},
+      {h->rdxa, &g.rdxa, nA}, {h->rdya, &g.rdya, nA}, {h->cosa_s, &g.cosa_s, nA}, {h->rsin2, &g.rsin2, nA},
+      {h->f0, &g.f0, nA},
+      {h->dx, &g.dx, nU}, {h->rdx, &g.rdx, nU}, {h->dyc, &g.dyc, nU}, {h->rdyc, &g.rdyc, nU},
+      {h->cosa_v, &g.cosa_v, nU}, {h->sina_v, &g.sina_v, nU}, {h->rsin_v, &g.rsin_v, nU},
+      {h->divg_u, &g.divg_u, nU}, {h->del6_u, &g.del6_u, nU},
+      {h->dy, &g.dy, nV}, {h->rdy, &g.rdy, nV}, {h->dxc, &g.dxc, nV}, {h->rdxc, &g.rdxc, nV},
+      {h->cosa_u, &g.cosa_u, nV}, {h->sina_u, &g.sina_u, nV}, {h->rsin_u, &g.rsin_u, nV},
+      {h->divg_v, &g.divg_v, nV}, {h->del6_v, &g.del6_v, nV},
+      {h->rarea_c, &g.rarea_c, nB}, {h->fC, &g.fC, nB}, {h->cosa, &g.cosa, nB}, {h->sina, &g.sina, nB},
+      {h->sin_sg, &g.sin_sg, 9 * nA}, {h->cos_sg, &g.cos_sg, 9 * nA},
+  };
+  size_t total = 0;
+  for (const Item &it : items) {
+    if (!it.src) return fail("fv3_grid_upload: a metric pointer is null");
+    total += (it.n + 7) & ~(size_t)7;
+  }
+  if (!c->dev_metrics) RT(rt_malloc((void **)&c->dev_metrics, total * sizeof(double)));
+  size_t off = 0;
+  for (const Item &it : items) {
+    RT(rt_h2d(c->dev_metrics + off, it.src, it.n * sizeof(double), c->stream));
+    *it.dst = c->dev_metrics + off;
+    off += (it.n + 7) & ~(size_t)7;
+  }
+  g.da_min = h->da_min;
+  g.da_min_c = h->da_min_c;
+  RT(rt_sync(c->stream));  // host buffers may go away after the call returns
+  c->grid_ready = true;
+  return 0;
+}
+
+extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
+  if (!c || !lv) return fail("fv3_dsw_levels_upload: null argument");
+  const int npz = c->g.npz;
+  if (!c->lev_i) RT(rt_malloc((void **)&c->lev_i, sizeof(int) * 4 * npz));
+  if (!c->lev_d) RT(rt_malloc((void **)&c->lev_d, sizeof(double) * 5 * npz));
+  const int *iv[4] = {lv->nord_k, lv->nord_v, lv->nord_w, lv->nord_t};
+  const double *dv[5] = {lv->d2_divg, lv->damp_vt, lv->damp_w, lv->damp_t, lv->d_con_k};
+  for (int n = 0; n < 4; n++) {
+    for (int k = 0; k < npz; k++) {
+      // divergence damping supports nord <= 3 (halo 3), deln/del6 damping nord <= 2 (sw_core.F90:1610)
+      if (iv[n][k] < 0 || iv[n][k] > (n == 0 ? 3 : 2)) return fail("fv3_dsw_levels_upload: nord out of range at k=%d", k);
+    }
+    RT(rt_h2d(c->lev_i + n * npz, iv[n], sizeof(int) * npz, c->stream));
+  }
+  for (int n = 0; n < 5; n++) RT(rt_h2d(c->lev_d + n * npz, dv[n], sizeof(double) * npz, c->stream));
+  RT(rt_sync(c->stream));
+  c->lev_ready = true;
+  return 0;
+}
+
+// ---- fv_tp_2d as a stand-alone kernel (unit-test surface; the fused d_sw kernels call the same
+// tile routine directly) --------------------------------------------------------------------
+template <int TI, int TJ>
+struct Tp2dKernel {
+  Grid g;
+  const double *q, *crx, *cry, *xfx, *yfx, *ra_x, *ra_y, *mfx, *mfy, *mass;
+  double *fx, *fy;
+  int hord, nord;
+  double damp_c;
+  using TS = Tp2dScratch<TI, TJ>;
+  using DS = DelnScratch<TI, TJ>;
+  static constexpr int nQ = (TI + 6) * (TJ + 6);
+  static constexpr int nScr = TS::total > DS::total ? TS::total : DS::total;
+  static constexpr int nFXt = (TI + 1) * TJ, nFYt = TI * (TJ + 1);
+  static constexpr int lds_doubles = 2 * nQ + nScr + nFXt + nFYt;
+
+  FV3_HD void operator()(int bx, int by, int bz, int tid, double *lds) const {
+    const int k = bz;
+    const TileBox b = make_box<TI, TJ>(g, bx, by);
+    const int i0 = b.i0, j0 = b.j0;
+    const size_t oA = (size_t)k * g.nA(), oCX = (size_t)k * g.nCX(), oCY = (size_t)k * g.nCY();
+    const size_t oFX = (size_t)k * g.nFX(), oFY = (size_t)k * g.nFY();
+    double *p = lds;
+    const Tile sq{p, i0 - 3, j0 - 3, TI + 6}; p += nQ;
+    const Tile sm{p, i0 - 3, j0 - 3, TI + 6}; p += nQ;
+    double *scr = p; p += nScr;
+    const Tile sfx{p, i0, j0, TI + 1}; p += nFXt;
+    const Tile sfy{p, i0, j0, TI}; p += nFYt;
+    load_tile<TI + 6, TJ + 6>(sq, q + oA, g.nid, g.isd, g.ied, g.jsd, g.jed, tid);
+    const bool damp_on = nord >= 0 && damp_c > 1.e-4;
+    const bool use_mass = (mfx && mfy && mass);
+    if (damp_on && use_mass) load_tile<TI + 6, TJ + 6>(sm, mass + oA, g.nid, g.isd, g.ied, g.jsd, g.jed, tid);
+    FV3_SYNC();
+    tp2d_tile<TI, TJ>(g, b, tid, sq, crx + oCX, cry + oCY, xfx + oCX, yfx + oCY,
+                      ra_x ? ra_x + (size_t)k * g.nRX() : nullptr, ra_y ? ra_y + (size_t)k * g.nRY() : nullptr, hord,
+                      scr, sfx, sfy);
+    for (int idx = tid; idx < nFXt; idx += kNT) {
+      const int i = i0 + idx % (TI + 1), j = j0 + idx / (TI + 1);
+      if (i > b.ilast + 1 || j > b.jlast) continue;
+      const double m = (mfx && mfy) ? mfx[oFX + g.iFX(i, j)] : xfx[oCX + g.iCX(i, j)];
+      sfx(i, j) = sfx(i, j) * m;
+    }
+    for (int idx = tid; idx < nFYt; idx += kNT) {
+      const int i = i0 + idx % TI, j = j0 + idx / TI;
+      if (i > b.ilast || j > b.jlast + 1) continue;
+      const double m = (mfx && mfy) ? mfy[oFY + g.iFY(i, j)] : yfx[oCY + g.iCY(i, j)];
+      sfy(i, j) = sfy(i, j) * m;
+    }
+    FV3_SYNC();
+    // deln_flux: with mfx/mfy it needs mass as well (tp_core.F90:201); without, mass is never passed
+    if (damp_on && ((mfx && mfy) ? (mass != nullptr) : true)) {
+      const double damp = ipow(damp_c * g.da_min, nord + 1);
+      Tile fxd, fyd;
+      const bool wm = use_mass;
+      deln_tile<TI, TJ>(g, b, tid, sq, nord, damp, !wm, scr, fxd, fyd);
+      const double damp2 = 0.5 * damp;
+      for (int idx = tid; idx < nFXt; idx += kNT) {
+        const int i = i0 + idx % (TI + 1), j = j0 + idx / (TI + 1);
+        if (i > b.ilast + 1 || j > b.jlast) continue;
+        sfx(i, j) = wm ? sfx(i, j) + damp2 * (sm(i - 1, j) + sm(i, j)) * fxd(i, j) : sfx(i, j) + fxd(i, j);
+      }
+      for (int idx = tid; idx < nFYt; idx += kNT) {
+        const int i = i0 + idx % TI, j = j0 + idx / TI;
+        if (i > b.ilast || j > b.jlast + 1) continue;
+        sfy(i, j) = wm ? sfy(i, j) + damp2 * (sm(i, j - 1) + sm(i, j)) * fyd(i, j) : sfy(i, j) + fyd(i, j);
+      }
+      FV3_SYNC();
+    }
+    for (int idx = tid; idx < nFXt; idx += kNT) {
+      const int i = i0 + idx % (TI + 1), j = j0 + idx / (TI + 1);
+      if (i > b.ilast + 1 || j > b.jlast) continue;
+      if (i == i0 + TI && i <= g.ie) continue;
+      fx[oFX + g.iFX(i, j)] = sfx(i, j);
+    }
+    for (int idx = tid; idx < nFYt; idx += kNT) {
+      const int i = i0 + idx % TI, j = j0 + idx / TI;
+      if (i > b.ilast || j > b.jlast + 1) continue;
+      if (j == j0 + TJ && j <= g.je) continue;
+      fy[oFY + g.iFY(i, j)] = sfy(i, j);
+    }
+  }
+};
+
+extern "C" int fv3_fv_tp_2d(fv3_ctx *c, int nk, const double *q, const double *crx, const double *cry, int hord,
+                            double *fx, double *fy, const double *xfx, const double *yfx, const double *ra_x,
+                            const double *ra_y, const double *mfx, const double *mfy, const double *mass, int nord,
+                            double damp_c) {
+  if (!c || !c->grid_ready) return fail("fv3_fv_tp_2d: context has no grid (call fv3_grid_upload)");
+  if (!tp_ord_supported(hord)) return fail("fv3_fv_tp_2d: hord=%d not supported (5,-5,6,8,10)", hord);
+  if (nord > 2) return fail("fv3_fv_tp_2d: nord=%d > 2", nord);
+  if ((mfx == nullptr) != (mfy == nullptr)) return fail("fv3_fv_tp_2d: mfx and mfy must be given together");
+  constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
+  Tp2dKernel<TI, TJ> kf{c->g, q, crx, cry, xfx, yfx, ra_x, ra_y, mfx, mfy, mass, fx, fy, hord, nord, damp_c};
+  Dim3 grid;
+  grid.x = (unsigned)((c->g.nx + TI - 1) / TI);
+  grid.y = (unsigned)((c->g.ny + TJ - 1) / TJ);
+  grid.z = (unsigned)nk;
+  RT(launch(grid, Tp2dKernel<TI, TJ>::lds_doubles, c->stream, kf));
+  return 0;
+}
+
+extern "C" int fv3_c_sw(fv3_ctx *c, double *delpc, const double *delp, double *ptc, const double *pt,
+                        const double *u, const double *v, const double *w, double *uc, double *vc, double *ua,
+                        double *va, double *wc, double *ut, double *vt, double *divg_d, int nord, double dt2,
+                        int hydrostatic, int dord4) {
+  (void)dord4;  // ua, va are produced on is-1:ie+1 (what c_sw/d_sw read); see header
+  if (!c || !c->grid_ready) return fail("fv3_c_sw: context has no grid (call fv3_grid_upload)");
+  if (!hydrostatic && (!w || !wc)) return fail("fv3_c_sw: nonhydrostatic call needs w and wc");
+  constexpr int TI = FV3_CSW_TI, TJ = FV3_CSW_TJ;
+  CswTile<TI, TJ> kf;
+  kf.g = c->g;
+  kf.a = CswArgs{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2};
+  Dim3 grid;
+  CswTile<TI, TJ>::grid_dims(c->g, grid.x, grid.y);
+  grid.z = (unsigned)c->g.npz;
+  RT(launch(grid, CswTile<TI, TJ>::lds_doubles, c->stream, kf));
+  return 0;
+}
+
+extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const double *delp, const double *pt,
+                        const double *u, const double *v, const double *w, const double *uc, const double *vc,
+                        const double *ua, const double *va, const double *divg_d, double *mfx, double *mfy,
+                        double *cx, double *cy, double *crx, double *cry, double *xfx, double *yfx,
+                        const double *q_con, double *delp_out, double *pt_out, double *u_out, double *v_out,
+                        double *w_out, double *q_con_out, double *heat_s, double *diss_e) {
+  if (!c || !c->grid_ready) return fail("fv3_d_sw: context has no grid (call fv3_grid_upload)");
+  if (!c->lev_ready) return fail("fv3_d_sw: per-level coefficients missing (call fv3_dsw_levels_upload)");
+  if (!p) return fail("fv3_d_sw: null params");
+  if (!tp_ord_supported(p->hord_dp) || !tp_ord_supported(p->hord_vt) || !tp_ord_supported(p->hord_tm))
+    return fail("fv3_d_sw: hord_dp/vt/tm must be one of 5,-5,6,8,10");
+  if (!sw_ord_supported(p->hord_mt)) return fail("fv3_d_sw: hord_mt must be in 5..11");
+  if (!p->hydrostatic && (!w || !w_out)) return fail("fv3_d_sw: nonhydrostatic call needs w and w_out");
+  if (p->use_cond && (!q_con || !q_con_out)) return fail("fv3_d_sw: use_cond needs q_con and q_con_out");
+  if (delp == delp_out || pt == pt_out || u == u_out || v == v_out || (w && w == w_out))
+    return fail("fv3_d_sw: *_out buffers must not alias the inputs");
+  const Grid &g = c->g;
+  const int npz = g.npz;
+  DswArgs a;
+  a.dt = p->dt;
+  a.hord_tr = p->hord_tr; a.hord_mt = p->hord_mt; a.hord_vt = p->hord_vt; a.hord_tm = p->hord_tm; a.hord_dp = p->hord_dp;
+  a.dddmp = p->dddmp; a.d4_bg = p->d4_bg; a.kgb = p->kgb;
+  a.hydrostatic = p->hydrostatic; a.use_cond = p->use_cond;
+  a.lv = DswLevels{c->lev_i, c->lev_i + npz, c->lev_i + 2 * npz, c->lev_i + 3 * npz,
+                   c->lev_d, c->lev_d + npz, c->lev_d + 2 * npz, c->lev_d + 3 * npz, c->lev_d + 4 * npz};
+  a.delp = delp; a.pt = pt; a.u = u; a.v = v; a.w = w; a.uc = uc; a.vc = vc; a.ua = ua; a.va = va;
+  a.divg_d = divg_d; a.q_con = q_con;
+  a.mfx = mfx; a.mfy = mfy; a.cx = cx; a.cy = cy; a.crx = crx; a.cry = cry; a.xfx = xfx; a.yfx = yfx;
+  a.delp_out = delp_out; a.pt_out = pt_out; a.u_out = u_out; a.v_out = v_out; a.w_out = w_out;
+  a.q_con_out = q_con_out; a.heat_s = heat_s; a.diss_e = diss_e; a.delpc = delpc;
+
+  {  // Courant numbers and area fluxes
+    DswCourant kf{g, a};
+    const size_t nmax = g.nCX() > g.nCY() ? g.nCX() : g.nCY();
+    Dim3 grid;
+    grid.x = (unsigned)((nmax + DswCourant::CH - 1) / DswCourant::CH);
+    grid.y = 1;
+    grid.z = (unsigned)npz;
+    RT(launch(grid, 0, c->stream, kf));
+  }
+  constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
+  {
+    DswTransport<TI, TJ> kf{g, a};
+    Dim3 grid;
+    DswTransport<TI, TJ>::grid_dims(g, grid.x, grid.y);
+    grid.z = (unsigned)npz;
+    RT(launch(grid, DswTransport<TI, TJ>::lds_doubles, c->stream, kf));
+  }
+  {
+    DswMomentum<TI, TJ> kf{g, a};
+    Dim3 grid;
+    DswMomentum<TI, TJ>::grid_dims(g, grid.x, grid.y);
+    grid.z = (unsigned)npz;
+    RT(launch(grid, DswMomentum<TI, TJ>::lds_doubles, c->stream, kf));
+  }
+  return 0;
+}
+
+// ---- periodic halo fill (single rank owns the whole doubly periodic tile) ------------------------
+struct HaloPeriodic {
+  Grid g;
+  double *f;
+  int kind;  // 0=A 1=U 2=V 3=B
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int ni = g.nid + ((kind == 2 || kind == 3) ? 1 : 0), nj = g.njd + ((kind == 1 || kind == 3) ? 1 : 0);
+    double *s = f + (size_t)bz * ni * nj;
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH; idx += kNT) {
+      if (idx >= ni * nj) continue;
+      const int i = g.isd + idx % ni, j = g.jsd + idx / ni;
+      // the staggered edge row/column (je+1 / ie+1) belongs to the compute domain of a
+      // north-east staggered field and is not a halo point
+      const int ihi = g.ie + ((kind == 2 || kind == 3) ? 1 : 0), jhi = g.je + ((kind == 1 || kind == 3) ? 1 : 0);
+      if (i >= g.is && i <= ihi && j >= g.js && j <= jhi) continue;
+      int si = i, sj = j;
+      if (si < g.is) si += g.nx; else if (si > ihi) si -= g.nx;
+      if (sj < g.js) sj += g.ny; else if (sj > jhi) sj -= g.ny;
+      s[idx] = s[(size_t)(sj - g.jsd) * ni + (si - g.isd)];
+    }
+  }
+};
+
+extern "C" int fv3_halo_fill_periodic(fv3_ctx *c, double *field, int kind, int nk) {
+  if (!c) return fail("fv3_halo_fill_periodic: null ctx");
+  if (kind < 0 || kind > 3) return fail("fv3_halo_fill_periodic: bad kind");
+  const Grid &g = c->g;
+  if (g.nx < NG + 1 || g.ny < NG + 1) return fail("fv3_halo_fill_periodic: tile smaller than the halo");
+  HaloPeriodic kf{g, field, kind};
+  const size_t n = (size_t)(g.nid + 1) * (g.njd + 1);
+  Dim3 grid;
+  grid.x = (unsigned)((n + HaloPeriodic::CH - 1) / HaloPeriodic::CH);
+  grid.y = 1;
+  grid.z = (unsigned)nk;
+  RT(launch(grid, 0, c->stream, kf));
+  return 0;
+}

@@ -1,0 +1,94 @@
+// fv3_common.h -- shared definitions of the HIP kernels (gfx950).
+//
+// The tile kernels are written as functors `void operator()(bx, by, bz, tid, lds)`.  In the
+// product build (hipcc) they run under the generic __global__ launcher in fv3_launch.h with
+// kNT threads per workgroup.  Every stage of a kernel is a data-parallel loop
+// `for (idx = tid; idx < n; idx += kNT)` separated by FV3_SYNC() barriers, so the same source
+// can also be compiled by g++ with -DFV3_HOST_EMU (kNT = 1, barrier = no-op) -- that build
+// exists ONLY under tests/hostemu as a kernel-logic test harness for the CPU-only container;
+// the shipped library is HIP-only and has no CPU path.
+#pragma once
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+
+#ifdef FV3_HOST_EMU
+#define FV3_HD inline
+#define FV3_SYNC() ((void)0)
+constexpr int kNT = 1;
+#else
+#include <hip/hip_runtime.h>
+#define FV3_HD __host__ __device__ __forceinline__
+#define FV3_SYNC() __syncthreads()
+constexpr int kNT = 256;
+#endif
+
+namespace fv3 {
+
+constexpr int NG = 3;  // halo width (tools/fv_mp_mod.F90:61)
+
+// Device-side view of the domain + gridstruct (all pointers are device pointers).
+struct Grid {
+  int is, ie, js, je, isd, ied, jsd, jed;
+  int npx, npy, npz;
+  int nid, njd, nx, ny;  // nid = ied-isd+1, nx = ie-is+1
+  int grid_type, do_diss_est, prevent_diss_cooling, stretched_grid;
+  double lim_fac, da_min, da_min_c;
+  const double *area, *rarea, *dxa, *dya, *rdxa, *rdya, *cosa_s, *rsin2, *f0;       // A
+  const double *dx, *rdx, *dyc, *rdyc, *cosa_v, *sina_v, *rsin_v, *divg_u, *del6_u; // U
+  const double *dy, *rdy, *dxc, *rdxc, *cosa_u, *sina_u, *rsin_u, *divg_v, *del6_v; // V
+  const double *rarea_c, *fC, *cosa, *sina;                                          // B
+  const double *sin_sg, *cos_sg;                                                     // A x 9
+
+  // flat index of (i,j) (Fortran indices) in one k-slab of each stagger kind
+  FV3_HD size_t iA(int i, int j) const { return (size_t)(j - jsd) * nid + (i - isd); }
+  FV3_HD size_t iU(int i, int j) const { return (size_t)(j - jsd) * nid + (i - isd); }
+  FV3_HD size_t iV(int i, int j) const { return (size_t)(j - jsd) * (nid + 1) + (i - isd); }
+  FV3_HD size_t iB(int i, int j) const { return (size_t)(j - jsd) * (nid + 1) + (i - isd); }
+  FV3_HD size_t iCX(int i, int j) const { return (size_t)(j - jsd) * (nx + 1) + (i - is); }
+  FV3_HD size_t iCY(int i, int j) const { return (size_t)(j - js) * nid + (i - isd); }
+  FV3_HD size_t iFX(int i, int j) const { return (size_t)(j - js) * (nx + 1) + (i - is); }
+  FV3_HD size_t iFY(int i, int j) const { return (size_t)(j - js) * nx + (i - is); }
+  FV3_HD size_t iCC(int i, int j) const { return (size_t)(j - js) * nx + (i - is); }
+  FV3_HD size_t iRX(int i, int j) const { return (size_t)(j - jsd) * nx + (i - is); }
+  FV3_HD size_t iRY(int i, int j) const { return (size_t)(j - js) * nid + (i - isd); }
+  // slab sizes
+  FV3_HD size_t nA() const { return (size_t)nid * njd; }
+  FV3_HD size_t nU() const { return (size_t)nid * (njd + 1); }
+  FV3_HD size_t nV() const { return (size_t)(nid + 1) * njd; }
+  FV3_HD size_t nB() const { return (size_t)(nid + 1) * (njd + 1); }
+  FV3_HD size_t nCX() const { return (size_t)(nx + 1) * njd; }
+  FV3_HD size_t nCY() const { return (size_t)nid * (ny + 1); }
+  FV3_HD size_t nFX() const { return (size_t)(nx + 1) * ny; }
+  FV3_HD size_t nFY() const { return (size_t)nx * (ny + 1); }
+  FV3_HD size_t nCC() const { return (size_t)nx * ny; }
+  FV3_HD size_t nRX() const { return (size_t)nx * njd; }
+  FV3_HD size_t nRY() const { return (size_t)nid * ny; }
+  // sin_sg(i,j,n), n = 1..9 (model/fv_grid_utils.F90:91-97)
+  FV3_HD double sinsg(int i, int j, int n) const { return sin_sg[(size_t)(n - 1) * nid * njd + iA(i, j)]; }
+  FV3_HD double cossg(int i, int j, int n) const { return cos_sg[(size_t)(n - 1) * nid * njd + iA(i, j)]; }
+};
+
+// ---- scalar helpers with the reference's semantics ----------------------------------------
+FV3_HD double dmin(double a, double b) { return a < b ? a : b; }
+FV3_HD double dmax(double a, double b) { return a > b ? a : b; }
+FV3_HD double dmin3(double a, double b, double c) { return dmin(dmin(a, b), c); }
+FV3_HD double dmax3(double a, double b, double c) { return dmax(dmax(a, b), c); }
+// Fortran sign(a, b)
+FV3_HD double fsign(double a, double b) { return copysign(fabs(a), b); }
+// Fortran x**n, integer n >= 1
+FV3_HD double ipow(double x, int n) {
+  double r = x;
+  for (int k = 1; k < n; k++) r = r * x;
+  return r;
+}
+
+// A 2-D tile in LDS (or any memory) addressed with global Fortran indices.
+struct Tile {
+  double *p;
+  int i0, j0, pitch;  // element (i,j) lives at p[(j-j0)*pitch + (i-i0)]
+  FV3_HD double &operator()(int i, int j) const { return p[(j - j0) * pitch + (i - i0)]; }
+};
+
+}  // namespace fv3

@@ -1,0 +1,94 @@
+// fv3_launch.h -- runtime shim: the generic tile-kernel launcher and memory helpers.
+// Product build: HIP (gfx950).  tests/hostemu build (-DFV3_HOST_EMU): plain C++ loops over the
+// workgroup grid with one "thread" per group -- a logic-checking harness, not a product path.
+#pragma once
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fv3_common.h"
+
+namespace fv3 {
+
+#ifdef FV3_HOST_EMU
+
+using stream_t = void *;
+struct Dim3 {
+  unsigned x, y, z;
+};
+
+template <class F>
+inline int launch(Dim3 grid, size_t lds_doubles, stream_t, const F &f) {
+  std::vector<double> lds(lds_doubles + 1, 0.);
+  for (unsigned z = 0; z < grid.z; z++)
+    for (unsigned y = 0; y < grid.y; y++)
+      for (unsigned x = 0; x < grid.x; x++) f((int)x, (int)y, (int)z, 0, lds.data());
+  return 0;
+}
+inline int rt_malloc(void **p, size_t n) {
+  *p = std::malloc(n);
+  return *p ? 0 : 1;
+}
+inline int rt_free(void *p) {
+  std::free(p);
+  return 0;
+}
+inline int rt_h2d(void *d, const void *s, size_t n, stream_t) {
+  std::memcpy(d, s, n);
+  return 0;
+}
+inline int rt_d2h(void *d, const void *s, size_t n, stream_t) {
+  std::memcpy(d, s, n);
+  return 0;
+}
+inline int rt_memset(void *d, int v, size_t n, stream_t) {
+  std::memset(d, v, n);
+  return 0;
+}
+inline int rt_sync(stream_t) { return 0; }
+inline const char *rt_errstr(int) { return "host-emu error"; }
+
+#else  // ---------------------------------------------------------------------------- HIP
+
+using stream_t = hipStream_t;
+using Dim3 = dim3;
+
+template <class F>
+__global__ void __launch_bounds__(kNT) tile_kernel(const F f) {
+  extern __shared__ double fv3_lds[];
+  f((int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)threadIdx.x, fv3_lds);
+}
+
+template <class F>
+inline int launch(Dim3 grid, size_t lds_doubles, stream_t s, const F &f) {
+  const size_t bytes = lds_doubles * sizeof(double);
+  if (bytes > 64 * 1024) {
+    static thread_local bool done = false;  // per functor type (template instantiation)
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_kernel<F>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e != hipSuccess) return (int)e;
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(tile_kernel<F>, grid, dim3(kNT), bytes, s, f);
+  return (int)hipGetLastError();
+}
+inline int rt_malloc(void **p, size_t n) { return (int)hipMalloc(p, n); }
+inline int rt_free(void *p) { return (int)hipFree(p); }
+inline int rt_h2d(void *d, const void *s, size_t n, stream_t st) {
+  return (int)hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st);
+}
+inline int rt_d2h(void *d, const void *s, size_t n, stream_t st) {
+  return (int)hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st);
+}
+inline int rt_memset(void *d, int v, size_t n, stream_t st) { return (int)hipMemsetAsync(d, v, n, st); }
+inline int rt_sync(stream_t st) { return (int)hipStreamSynchronize(st); }
+inline const char *rt_errstr(int e) { return hipGetErrorString((hipError_t)e); }
+
+#endif
+
+}  // namespace fv3

@@ -84,14 +84,17 @@ class Bounds:
         return arr[i0 - ilo : i1 - ilo + 1, j0 - jlo : j1 - jlo + 1]
 
 
-def periodic_fill(b: Bounds, arr: np.ndarray, kind: str) -> None:
+def periodic_fill(b: Bounds, arr: np.ndarray, kind: str, fill_edge: bool = False) -> None:
     """Fill the halo of a doubly periodic single-tile field in place (the FMS periodic contacts of
-    tools/fv_mp_mod.F90:473-483 applied to one rank).  For staggered kinds the duplicated
-    edge row/column (index ie+1 / je+1) is taken from index is / js."""
+    tools/fv_mp_mod.F90:473-483 applied to one rank).  For north-east staggered kinds the edge
+    row/column (index je+1 / ie+1) is part of the compute domain and is left alone unless
+    ``fill_edge`` (then it is copied from index js / is, which makes a synthetic input consistent)."""
     ilo, ihi, jlo, jhi = b.limits(kind)
     nx, ny = b.nx, b.ny
     ii = np.arange(ilo, ihi + 1)
     jj = np.arange(jlo, jhi + 1)
-    src_i = (ii - b.is_) % nx + b.is_ - ilo
-    src_j = (jj - b.js) % ny + b.js - jlo
+    ei = b.ie + (1 if (kind in ("V", "B") and not fill_edge) else 0)
+    ej = b.je + (1 if (kind in ("U", "B") and not fill_edge) else 0)
+    src_i = np.where(ii < b.is_, ii + nx, np.where(ii > ei, ii - nx, ii)) - ilo
+    src_j = np.where(jj < b.js, jj + ny, np.where(jj > ej, jj - ny, jj)) - jlo
     arr[...] = arr[np.ix_(src_i, src_j)] if arr.ndim == 2 else arr[src_i][:, src_j]

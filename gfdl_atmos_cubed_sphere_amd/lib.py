@@ -1,0 +1,247 @@
+"""ctypes binding of the product library libfv3_mi355x.so (C ABI: include/fv3_mi355x.h).
+
+There is NO CPU fallback: ``load()`` raises if the HIP library has not been built
+(``python -c "import __graft_entry__ as g; g.build()"``), and every entry point raises
+``Fv3Error`` on a non-zero status.  Device memory comes from the library's own ``fv3_malloc``
+(hipMalloc); ``DeviceArray`` exposes ``__cuda_array_interface__`` so that torch (used only for
+streams and torch.distributed) can alias a buffer without copying.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .grid import GridStruct
+from .layout import Bounds
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PRODUCT_SO = os.path.join(_HERE, "csrc", "libfv3_mi355x.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+_A = ["area", "rarea", "dxa", "dya", "rdxa", "rdya", "cosa_s", "rsin2", "f0"]
+_U = ["dx", "rdx", "dyc", "rdyc", "cosa_v", "sina_v", "rsin_v", "divg_u", "del6_u"]
+_V = ["dy", "rdy", "dxc", "rdxc", "cosa_u", "sina_u", "rsin_u", "divg_v", "del6_v"]
+_B = ["rarea_c", "fC", "cosa", "sina"]
+
+# every symbol include/fv3_mi355x.h declares (tests check the built library exports all of them)
+EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_malloc",
+           "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
+           "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_halo_fill_periodic"]
+
+
+class Fv3Error(RuntimeError):
+    pass
+
+
+class _Domain(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ["is_", "ie", "js", "je", "ng", "npx", "npy", "npz", "grid_type", "do_diss_est",
+                                       "prevent_diss_cooling", "stretched_grid"]] + [("lim_fac", C.c_double)]
+
+
+class _GridHost(C.Structure):
+    _fields_ = [("da_min", C.c_double), ("da_min_c", C.c_double)] + [(n, _dp) for n in
+                                                                      _A + _U + _V + _B + ["sin_sg", "cos_sg"]]
+
+
+class _DswParams(C.Structure):
+    _fields_ = [("dt", C.c_double)] + [(n, C.c_int) for n in ["hord_tr", "hord_mt", "hord_vt", "hord_tm", "hord_dp"]] + [
+        (n, C.c_double) for n in ["dddmp", "d4_bg", "kgb"]] + [("hydrostatic", C.c_int), ("use_cond", C.c_int)]
+
+
+class _DswLevels(C.Structure):
+    _fields_ = [(n, _ip) for n in ["nord_k", "nord_v", "nord_w", "nord_t"]] + [(n, _dp) for n in
+                                                                                 ["d2_divg", "damp_vt", "damp_w",
+                                                                                  "damp_t", "d_con_k"]]
+
+
+class Fv3Lib:
+    """A loaded shared object exporting the fv3_* C ABI."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise Fv3Error(f"{path} not found: the HIP library is not built (run __graft_entry__.build()); "
+                           "there is no CPU fallback")
+        self.path = path
+        self.dll = C.CDLL(path)
+        missing = [s for s in EXPORTS if not hasattr(self.dll, s)]
+        if missing:
+            raise Fv3Error(f"{path} does not export {missing}")
+        self.dll.fv3_last_error.restype = C.c_char_p
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            raise Fv3Error(f"{what}: {self.dll.fv3_last_error().decode()}")
+
+
+_PRODUCT: Fv3Lib | None = None
+
+
+def load() -> Fv3Lib:
+    """The product library (HIP, gfx950).  Raises if it is missing."""
+    global _PRODUCT
+    if _PRODUCT is None:
+        _PRODUCT = Fv3Lib(PRODUCT_SO)
+    return _PRODUCT
+
+
+class DeviceArray:
+    """A device buffer holding one field in the reference layout (Fortran order)."""
+
+    def __init__(self, ctx: "Context", shape):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.nbytes = int(np.prod(self.shape)) * 8
+        ptr = _vp()
+        ctx.lib.check(ctx.lib.dll.fv3_malloc(C.byref(ptr), C.c_size_t(self.nbytes)), "fv3_malloc")
+        self.ptr = ptr.value
+        ctx._buffers.append(self)
+
+    @property
+    def p(self):
+        return C.cast(_vp(self.ptr), _dp)
+
+    @property
+    def __cuda_array_interface__(self):
+        # Fortran-ordered strides
+        strides, acc = [], 8
+        for s in self.shape:
+            strides.append(acc)
+            acc *= s
+        return {"shape": self.shape, "typestr": "<f8", "data": (self.ptr, False), "version": 3,
+                "strides": tuple(strides)}
+
+    def upload(self, a: np.ndarray):
+        a = np.asfortranarray(a, dtype=np.float64)
+        assert a.shape == self.shape, (a.shape, self.shape)
+        self.ctx.lib.check(self.ctx.lib.dll.fv3_memcpy_h2d(self.ctx.h, _vp(self.ptr), a.ctypes.data_as(_vp),
+                                                           C.c_size_t(self.nbytes)), "fv3_memcpy_h2d")
+        self.ctx.sync()  # pageable host memory: keep `a` alive until the copy is done
+        return self
+
+    def download(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=np.float64, order="F")
+        self.ctx.lib.check(self.ctx.lib.dll.fv3_memcpy_d2h(self.ctx.h, out.ctypes.data_as(_vp), _vp(self.ptr),
+                                                           C.c_size_t(self.nbytes)), "fv3_memcpy_d2h")
+        self.ctx.sync()
+        return out
+
+    def zero(self):
+        self.ctx.lib.check(self.ctx.lib.dll.fv3_memset(self.ctx.h, _vp(self.ptr), 0, C.c_size_t(self.nbytes)),
+                           "fv3_memset")
+        return self
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.dll.fv3_free(_vp(self.ptr))
+            self.ptr = None
+
+
+def _pp(x):
+    return None if x is None else x.p
+
+
+class Context:
+    """fv3_ctx: one rank's block of the domain + its gridstruct on the device."""
+
+    def __init__(self, grid: GridStruct, npz: int, lib: Fv3Lib | None = None, stream: int | None = None):
+        self.lib = lib or load()
+        self.grid = grid
+        self.bd: Bounds = grid.bd
+        self.npz = npz
+        self._buffers: list[DeviceArray] = []
+        d = _Domain()
+        b = grid.bd
+        d.is_, d.ie, d.js, d.je, d.ng = b.is_, b.ie, b.js, b.je, b.ng
+        d.npx, d.npy, d.npz, d.grid_type = grid.npx, grid.npy, npz, grid.grid_type
+        d.do_diss_est, d.prevent_diss_cooling = int(grid.do_diss_est), int(grid.prevent_diss_cooling)
+        d.stretched_grid, d.lim_fac = int(grid.stretched_grid), grid.lim_fac
+        self.h = _vp()
+        self.lib.check(self.lib.dll.fv3_create(C.byref(d), C.byref(self.h)), "fv3_create")
+        if stream is not None:
+            self.set_stream(stream)
+        gh = _GridHost()
+        gh.da_min, gh.da_min_c = grid.da_min, grid.da_min_c
+        keep = []
+        for n in _A + _U + _V + _B + ["sin_sg", "cos_sg"]:
+            a = np.asfortranarray(grid.m[n], dtype=np.float64)
+            keep.append(a)
+            setattr(gh, n, a.ctypes.data_as(_dp))
+        self.lib.check(self.lib.dll.fv3_grid_upload(self.h, C.byref(gh)), "fv3_grid_upload")
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def set_stream(self, stream: int):
+        self.lib.check(self.lib.dll.fv3_set_stream(self.h, _vp(stream)), "fv3_set_stream")
+
+    def sync(self):
+        self.lib.check(self.lib.dll.fv3_sync(self.h), "fv3_sync")
+
+    def empty(self, kind: str, nk: int | None = None) -> DeviceArray:
+        return DeviceArray(self, self.bd.shape(kind, nk))
+
+    def zeros(self, kind: str, nk: int | None = None) -> DeviceArray:
+        return self.empty(kind, nk).zero()
+
+    def from_host(self, a: np.ndarray) -> DeviceArray:
+        return DeviceArray(self, a.shape).upload(a)
+
+    def close(self):
+        for b in self._buffers:
+            b.free()
+        self._buffers.clear()
+        if self.h:
+            self.lib.dll.fv3_destroy(self.h)
+            self.h = None
+
+    # -- operators (argument names follow the reference routines) ------------------------------------
+    def fv_tp_2d(self, q, crx, cry, hord, fx, fy, xfx, yfx, ra_x=None, ra_y=None, mfx=None, mfy=None, mass=None,
+                 nord=-1, damp_c=0.0, nk=None):
+        """model/tp_core.F90:85 fv_tp_2d for nk slabs."""
+        nk = self.npz if nk is None else nk
+        self.lib.check(self.lib.dll.fv3_fv_tp_2d(self.h, C.c_int(nk), q.p, crx.p, cry.p, C.c_int(hord), fx.p, fy.p,
+                                                 xfx.p, yfx.p, _pp(ra_x), _pp(ra_y), _pp(mfx), _pp(mfy), _pp(mass),
+                                                 C.c_int(nord), C.c_double(damp_c)), "fv3_fv_tp_2d")
+
+    def c_sw(self, delpc, delp, ptc, pt, u, v, w, uc, vc, ua, va, wc, ut, vt, divg_d, nord, dt2, hydrostatic,
+             dord4=True):
+        """model/sw_core.F90:79 c_sw over all levels (the k loop of dyn_core.F90:436-447)."""
+        self.lib.check(self.lib.dll.fv3_c_sw(self.h, delpc.p, delp.p, ptc.p, pt.p, u.p, v.p, _pp(w), uc.p, vc.p, ua.p,
+                                             va.p, _pp(wc), ut.p, vt.p, divg_d.p, C.c_int(nord), C.c_double(dt2),
+                                             C.c_int(int(hydrostatic)), C.c_int(int(dord4))), "fv3_c_sw")
+
+    def dsw_levels(self, lev: dict):
+        lv = _DswLevels()
+        keep = []
+        for n in ["nord_k", "nord_v", "nord_w", "nord_t"]:
+            a = np.ascontiguousarray(lev[n], dtype=np.int32)
+            assert a.size == self.npz
+            keep.append(a)
+            setattr(lv, n, a.ctypes.data_as(_ip))
+        for n in ["d2_divg", "damp_vt", "damp_w", "damp_t", "d_con_k"]:
+            a = np.ascontiguousarray(lev[n], dtype=np.float64)
+            assert a.size == self.npz
+            keep.append(a)
+            setattr(lv, n, a.ctypes.data_as(_dp))
+        self.lib.check(self.lib.dll.fv3_dsw_levels_upload(self.h, C.byref(lv)), "fv3_dsw_levels_upload")
+
+    def d_sw(self, par: dict, delpc, delp, pt, u, v, w, uc, vc, ua, va, divg_d, mfx, mfy, cx, cy, crx, cry, xfx, yfx,
+             q_con, delp_out, pt_out, u_out, v_out, w_out, q_con_out, heat_s, diss_e):
+        """model/sw_core.F90:494 d_sw over all levels (the k loop of dyn_core.F90:658-812)."""
+        pr = _DswParams()
+        for k in ["dt", "hord_tr", "hord_mt", "hord_vt", "hord_tm", "hord_dp", "dddmp", "d4_bg", "kgb", "hydrostatic",
+                  "use_cond"]:
+            setattr(pr, k, par[k])
+        self.lib.check(self.lib.dll.fv3_d_sw(self.h, C.byref(pr), _pp(delpc), delp.p, pt.p, u.p, v.p, _pp(w), uc.p,
+                                             vc.p, ua.p, va.p, divg_d.p, mfx.p, mfy.p, cx.p, cy.p, crx.p, cry.p, xfx.p,
+                                             yfx.p, _pp(q_con), delp_out.p, pt_out.p, u_out.p, v_out.p, _pp(w_out),
+                                             _pp(q_con_out), heat_s.p, diss_e.p), "fv3_d_sw")
+
+    def halo_fill_periodic(self, field: DeviceArray, kind: str):
+        code = {"A": 0, "U": 1, "V": 2, "B": 3}[kind]
+        nk = field.shape[2] if len(field.shape) == 3 else 1
+        self.lib.check(self.lib.dll.fv3_halo_fill_periodic(self.h, field.p, C.c_int(code), C.c_int(nk)),
+                       "fv3_halo_fill_periodic")

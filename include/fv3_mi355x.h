@@ -1,0 +1,144 @@
+/*
+ * fv3_mi355x.h -- C ABI of the MI355X-native FV3 dyn_core hot path (libfv3_mi355x.so).
+ *
+ * The reference (NOAA-GFDL/GFDL_atmos_cubed_sphere, release 202411) has no FFI: its boundary is
+ * the set of Fortran module procedures that dyn_core/fv_dynamics call.
+ * Each entry point below stands behind one of those call sites; the comment on each names the
+ * reference interface it replaces (file:line under the reference tree).  INTEGRATION.md shows
+ * the ISO_C_BINDING interface block a maintainer would add on the Fortran side.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  Every function returns 0 on success, non-zero
+ *     on error (the reference has no status codes: it calls mpp_error(FATAL); a Fortran shim
+ *     should `error stop` on non-zero).  fv3_last_error() returns a message.
+ *   - Field arguments are DEVICE pointers to arrays in the reference's own layout (Fortran
+ *     column-major, i fastest, then j, then k) with the exact bounds of model/fv_arrays.F90:
+ *     1521-1563 and model/dyn_core.F90:256-283; the "kind" tags below give the horizontal
+ *     extent of one k-slab:
+ *        A  (isd:ied,   jsd:jed)      U  (isd:ied,   jsd:jed+1)   V  (isd:ied+1, jsd:jed)
+ *        B  (isd:ied+1, jsd:jed+1)    CX (is:ie+1,   jsd:jed)     CY (isd:ied,   js:je+1)
+ *        FX (is:ie+1,   js:je)        FY (is:ie,     js:je+1)     CC (is:ie,     js:je)
+ *     All entry points process every level k = 1..npz in one call (the reference calls the 2-D
+ *     routines from an OpenMP k loop, model/dyn_core.F90:436-447,658-812).
+ *   - Fields the reference updates in place but whose halo other cells still have to read in
+ *     the same sweep (delp, pt, w, u, v, q_con in d_sw) have separate *_out arguments that must
+ *     not alias the inputs; only the compute domain of an *_out array is written, its halo is
+ *     the caller's to refresh (exactly where the reference calls start_group_halo_update,
+ *     model/dyn_core.F90:823-825,1169).
+ *   - Work is enqueued on the context's HIP stream (fv3_set_stream); nothing synchronises.
+ *   - Supported branch set in this version: grid_type = 4 (doubly periodic / Cartesian branches
+ *     of the reference) with array-valued metric terms, no nesting, no regional BCs.
+ */
+#ifndef FV3_MI355X_H
+#define FV3_MI355X_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fv3_ctx fv3_ctx;
+
+/* fv_grid_bounds_type (model/fv_arrays.F90:1192-1200) + the flagstruct members the kernels read
+ * (model/sw_core.F90:126-127,590-591,624,964,1250). */
+typedef struct fv3_domain {
+  int is, ie, js, je; /* compute domain (global indices of this rank's block) */
+  int ng;             /* halo width, 3 (tools/fv_mp_mod.F90:61) */
+  int npx, npy, npz;  /* global corner counts and number of levels */
+  int grid_type;      /* 4 */
+  int do_diss_est, prevent_diss_cooling, stretched_grid;
+  double lim_fac;
+} fv3_domain;
+
+/* gridstruct members (model/fv_arrays.F90:75-205; shapes :1749-1881).  HOST pointers; copied to
+ * the device once by fv3_grid_upload. */
+typedef struct fv3_grid_host {
+  double da_min, da_min_c;
+  const double *area, *rarea, *dxa, *dya, *rdxa, *rdya, *cosa_s, *rsin2, *f0;       /* A */
+  const double *dx, *rdx, *dyc, *rdyc, *cosa_v, *sina_v, *rsin_v, *divg_u, *del6_u; /* U */
+  const double *dy, *rdy, *dxc, *rdxc, *cosa_u, *sina_u, *rsin_u, *divg_v, *del6_v; /* V */
+  const double *rarea_c, *fC, *cosa, *sina;                                          /* B */
+  const double *sin_sg, *cos_sg;                                                     /* A x 9 */
+} fv3_grid_host;
+
+const char *fv3_last_error(void);
+int fv3_create(const fv3_domain *dom, fv3_ctx **out);
+int fv3_destroy(fv3_ctx *ctx);
+/* stream: a hipStream_t (NULL = default stream). */
+int fv3_set_stream(fv3_ctx *ctx, void *stream);
+int fv3_grid_upload(fv3_ctx *ctx, const fv3_grid_host *g);
+
+/* Device-memory helpers for callers that do not own a device allocator (a Fortran host). */
+int fv3_malloc(void **dptr, size_t bytes);
+int fv3_free(void *dptr);
+int fv3_memcpy_h2d(fv3_ctx *ctx, void *dst, const void *src, size_t bytes);
+int fv3_memcpy_d2h(fv3_ctx *ctx, void *dst, const void *src, size_t bytes);
+int fv3_memset(fv3_ctx *ctx, void *dst, int value, size_t bytes);
+int fv3_sync(fv3_ctx *ctx);
+
+/* fv_tp_2d -- model/tp_core.F90:85-87 (called from sw_core.F90:919,983,993,1014,1498,
+ * nh_utils.F90:279,289, fv_tracer2d.F90:504,509).  nk slabs.  q: A; crx,xfx: CX; cry,yfx: CY;
+ * ra_x: (is:ie, jsd:jed); ra_y: (isd:ied, js:je); fx,mfx: FX; fy,mfy: FY; mass: A.
+ * Optional arguments are NULL / nord < 0 when absent. */
+int fv3_fv_tp_2d(fv3_ctx *ctx, int nk, const double *q, const double *crx, const double *cry, int hord,
+                 double *fx, double *fy, const double *xfx, const double *yfx, const double *ra_x,
+                 const double *ra_y, const double *mfx, const double *mfy, const double *mass, int nord,
+                 double damp_c);
+
+/* c_sw -- model/sw_core.F90:79-81, the k loop of model/dyn_core.F90:436-447.
+ * in : delp, pt, w (A; w NULL if hydrostatic), u (U), v (V)
+ * out: delpc, ptc, wc (A, valid is-1:ie+1 x js-1:je+1); uc (V), vc (U): C-grid winds advanced half a
+ *      step on is:ie+1 x js:je / is:ie x js:je+1 and interpolated values on the one-cell ring around
+ *      that; ua, va (A, valid is-1:ie+1); ut, vt (A, time-scaled contravariant fluxes, valid
+ *      is-1:ie+2 x js-1:je+1 / is-1:ie+1 x js-1:je+2); divg_d (B, valid is-1:ie+2 x js-1:je+2; only
+ *      if nord > 0). */
+int fv3_c_sw(fv3_ctx *ctx, double *delpc, const double *delp, double *ptc, const double *pt, const double *u,
+             const double *v, const double *w, double *uc, double *vc, double *ua, double *va, double *wc,
+             double *ut, double *vt, double *divg_d, int nord, double dt2, int hydrostatic, int dord4);
+
+/* Scalars of d_sw's argument list (model/sw_core.F90:494-500) that do not vary with k ... */
+typedef struct fv3_dsw_params {
+  double dt;
+  int hord_tr, hord_mt, hord_vt, hord_tm, hord_dp;
+  double dddmp, d4_bg, kgb;
+  int hydrostatic, use_cond;
+} fv3_dsw_params;
+
+/* ... and the per-level ones dyn_core computes inside its k loop (model/dyn_core.F90:666-733):
+ * HOST arrays of length npz. */
+typedef struct fv3_dsw_levels {
+  const int *nord_k, *nord_v, *nord_w, *nord_t;
+  const double *d2_divg, *damp_vt, *damp_w, *damp_t, *d_con_k;
+} fv3_dsw_levels;
+
+/* Copies the per-level coefficients to the device; they stay valid for later fv3_d_sw calls. */
+int fv3_dsw_levels_upload(fv3_ctx *ctx, const fv3_dsw_levels *lv);
+
+/* d_sw -- model/sw_core.F90:494-500, the k loop of model/dyn_core.F90:658-812 (inline_q=.false.).
+ * in    : delp, pt, w, q_con (A), u (U), v (V), uc (V), vc (U), ua, va (A; read only when a level
+ *         has nord_k = 0), divg_d (B; read when nord_k > 0)
+ * inout : mfx (FX), mfy (FY), cx (CX), cy (CY)  -- the flux capacitors, accumulated
+ * out   : crx, xfx (CX), cry, yfx (CY); delp_out, pt_out, w_out, q_con_out (A, compute domain);
+ *         u_out (U, is:ie x js:je+1), v_out (V, is:ie+1 x js:je) -- still scaled by dx, dy exactly as
+ *         the reference leaves them (sw_core.F90:1233,1502); heat_s, diss_e (CC, the per-call 2-D
+ *         heat_source / diss_est of sw_core.F90:521-522, stacked in k); delpc (A, the saved
+ *         divergence on is:ie+1 x js:je+1; may be NULL).
+ * The reference's clobbering of uc, vc, divg_d as scratch (sw_core.F90:1394-1408) is not reproduced:
+ * those arrays are left unchanged. */
+int fv3_d_sw(fv3_ctx *ctx, const fv3_dsw_params *p, double *delpc, const double *delp, const double *pt,
+             const double *u, const double *v, const double *w, const double *uc, const double *vc,
+             const double *ua, const double *va, const double *divg_d, double *mfx, double *mfy, double *cx,
+             double *cy, double *crx, double *cry, double *xfx, double *yfx, const double *q_con,
+             double *delp_out, double *pt_out, double *u_out, double *v_out, double *w_out, double *q_con_out,
+             double *heat_s, double *diss_e);
+
+/* Periodic halo fill of one doubly periodic tile owned by a single rank (the two periodic contacts
+ * of tools/fv_mp_mod.F90:473-483 when layout = 1x1): the single-GPU replacement of
+ * start/complete_group_halo_update (tools/fv_mp_mod.F90:646-876).  kind: 0=A 1=U 2=V 3=B. */
+int fv3_halo_fill_periodic(fv3_ctx *ctx, double *field, int kind, int nk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -36,7 +36,7 @@ def smooth_state(bd: Bounds, npz: int, seed: int = SEED, hydrostatic: bool = Fal
         scale = {"u": 1.0, "v": 1.0, "delp": 8.0, "pt": 1.0, "w": 0.1}[n]
         a += noise * scale * rng.uniform(-1.0, 1.0, a.shape)
         for k in range(npz):
-            periodic_fill(bd, a[:, :, k], kind)
+            periodic_fill(bd, a[:, :, k], kind, fill_edge=True)
         out[n] = a
     if hydrostatic:
         out.pop("w")

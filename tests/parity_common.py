@@ -1,0 +1,213 @@
+"""Parity checks shared by the GPU tests (product library, -m gpu) and the host-emulation
+logic tests (tests/hostemu, CPU).  Each check runs the oracle and a library exporting the fv3_*
+C ABI on identical seeded inputs and compares on the index ranges where the reference defines
+the output.
+
+Tolerance (BASELINE.json north_star): relative RMS difference of every prognostic/output field
+< 1e-12 in fp64.  With FMA contraction off the kernels reproduce the oracle bit for bit, so the
+checks below use a much tighter bound (1e-14 relative to the field's RMS) and report the worst
+value; anything larger is an indexing or logic error, not round-off."""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle_lib as O
+from fields import smooth_state
+from gfdl_atmos_cubed_sphere_amd.grid import doubly_periodic, perturbed
+from gfdl_atmos_cubed_sphere_amd.layout import Bounds, periodic_fill
+from gfdl_atmos_cubed_sphere_amd.lib import Context
+from test_oracle_properties import _courant, default_levels
+
+TOL = 1e-14
+
+
+def rel_rms(a, b):
+    d = np.sqrt(np.mean((a - b) ** 2))
+    s = np.sqrt(np.mean(b ** 2))
+    return d / s if s > 0 else d
+
+
+def make_grid(bd, perturb):
+    g = doubly_periodic(bd, bd.ie - bd.is_ + 2, bd.je - bd.js + 2)
+    return perturbed(g) if perturb else g
+
+
+def assert_close(name, got, ref, tol=TOL):
+    assert np.all(np.isfinite(got)), f"{name}: non-finite values"
+    e = rel_rms(got, ref)
+    assert e <= tol, f"{name}: rel-rms {e:.3e} > {tol:.1e} (max abs diff {np.max(np.abs(got - ref)):.3e})"
+    return e
+
+
+# ------------------------------------------------------------------------------------------------
+def check_fv_tp_2d(lib, hord, nx=40, ny=19, nk=3, perturb=True, mode="plain", nord=-1, damp_c=0.0, seed=5):
+    bd = Bounds(1, nx, 1, ny)
+    g = make_grid(bd, perturb)
+    rng = np.random.default_rng(seed)
+    q = bd.zeros("A", nk)
+    arrs = {n: bd.zeros(k, nk) for n, k in (("crx", "CX"), ("xfx", "CX"), ("cry", "CY"), ("yfx", "CY"),
+                                             ("ra_x", "RX"), ("ra_y", "RY"), ("mfx", "FX"), ("mfy", "FY"),
+                                             ("mass", "A"))}
+    for k in range(nk):
+        q[:, :, k] = 1.0 + rng.uniform(0, 1, bd.shape("A")) + (k == 1) * 5.0 * (rng.uniform(0, 1, bd.shape("A")) > 0.7)
+        periodic_fill(bd, q[:, :, k], "A")
+        c = _courant(bd, g, rng)
+        for n, a in zip(("crx", "cry", "xfx", "yfx", "ra_x", "ra_y"), c):
+            arrs[n][:, :, k] = a
+        arrs["mfx"][:, :, k] = rng.uniform(-1, 1, bd.shape("FX")) * 1e5
+        arrs["mfy"][:, :, k] = rng.uniform(-1, 1, bd.shape("FY")) * 1e5
+        arrs["mass"][:, :, k] = 500.0 + 50 * rng.uniform(0, 1, bd.shape("A"))
+        periodic_fill(bd, arrs["mass"][:, :, k], "A")
+    use_mf = mode in ("mass_flux", "mass_flux_damp")
+    use_mass = mode == "mass_flux_damp"
+    # oracle
+    fx_ref, fy_ref = bd.zeros("FX", nk), bd.zeros("FY", nk)
+    for k in range(nk):
+        sl = lambda n: np.asfortranarray(arrs[n][:, :, k])
+        fx, fy = O.fv_tp_2d(g, np.asfortranarray(q[:, :, k]), sl("crx"), sl("cry"), hord, sl("xfx"), sl("yfx"),
+                            sl("ra_x"), sl("ra_y"), sl("mfx") if use_mf else None, sl("mfy") if use_mf else None,
+                            sl("mass") if use_mass else None, nord, damp_c)
+        fx_ref[:, :, k], fy_ref[:, :, k] = fx, fy
+    # library
+    ctx = Context(g, nk, lib=lib)
+    try:
+        d = {n: ctx.from_host(a) for n, a in arrs.items()}
+        dq = ctx.from_host(q)
+        dfx, dfy = ctx.zeros("FX", nk), ctx.zeros("FY", nk)
+        ctx.fv_tp_2d(dq, d["crx"], d["cry"], hord, dfx, dfy, d["xfx"], d["yfx"], d["ra_x"], d["ra_y"],
+                     d["mfx"] if use_mf else None, d["mfy"] if use_mf else None, d["mass"] if use_mass else None,
+                     nord, damp_c, nk=nk)
+        e1 = assert_close("fx", dfx.download(), fx_ref)
+        e2 = assert_close("fy", dfy.download(), fy_ref)
+    finally:
+        ctx.close()
+    return max(e1, e2)
+
+
+# ------------------------------------------------------------------------------------------------
+CSW_OUT = (("delpc", "A"), ("ptc", "A"), ("wc", "A"), ("uc", "V"), ("vc", "U"), ("ua", "A"), ("va", "A"),
+           ("ut", "A"), ("vt", "A"), ("divg_d", "B"))
+
+
+def csw_valid_ranges(bd):
+    i0, i1, j0, j1 = bd.is_, bd.ie, bd.js, bd.je
+    return {"delpc": (i0 - 1, i1 + 1, j0 - 1, j1 + 1), "ptc": (i0 - 1, i1 + 1, j0 - 1, j1 + 1),
+            "wc": (i0 - 1, i1 + 1, j0 - 1, j1 + 1), "uc": (i0 - 1, i1 + 2, j0 - 1, j1 + 1),
+            "vc": (i0 - 1, i1 + 1, j0 - 1, j1 + 2), "ua": (i0 - 1, i1 + 1, j0 - 1, j1 + 1),
+            "va": (i0 - 1, i1 + 1, j0 - 1, j1 + 1), "ut": (i0 - 1, i1 + 2, j0 - 1, j1 + 1),
+            "vt": (i0 - 1, i1 + 1, j0 - 1, j1 + 2), "divg_d": (i0 - 1, i1 + 2, j0 - 1, j1 + 2)}
+
+
+def run_c_sw_oracle(g, bd, npz, st, dt2, hydrostatic, nord=1):
+    f = {k: v.copy(order="F") for k, v in st.items()}
+    for n, kind in CSW_OUT:
+        f[n] = bd.zeros(kind, npz)
+    O.c_sw_3d(g, npz, f, nord=nord, dt2=dt2, hydrostatic=hydrostatic)
+    return f
+
+
+def run_c_sw_lib(ctx, bd, npz, st, dt2, hydrostatic, nord=1):
+    d = {k: ctx.from_host(v) for k, v in st.items()}
+    for n, kind in CSW_OUT:
+        d[n] = ctx.zeros(kind, npz)
+    ctx.c_sw(d["delpc"], d["delp"], d["ptc"], d["pt"], d["u"], d["v"], d.get("w"), d["uc"], d["vc"], d["ua"],
+             d["va"], None if hydrostatic else d["wc"], d["ut"], d["vt"], d["divg_d"], nord, dt2, hydrostatic)
+    return d
+
+
+def check_c_sw(lib, nx=40, ny=19, npz=3, hydrostatic=False, perturb=True, dt=6.0):
+    bd = Bounds(1, nx, 1, ny)
+    g = make_grid(bd, perturb)
+    st = smooth_state(bd, npz, hydrostatic=hydrostatic)
+    ref = run_c_sw_oracle(g, bd, npz, st, 0.5 * dt, hydrostatic)
+    ctx = Context(g, npz, lib=lib)
+    worst = 0.0
+    try:
+        d = run_c_sw_lib(ctx, bd, npz, st, 0.5 * dt, hydrostatic)
+        rng_ = csw_valid_ranges(bd)
+        for n, kind in CSW_OUT:
+            if hydrostatic and n == "wc":
+                continue
+            got = d[n].download()
+            r = rng_[n]
+            worst = max(worst, assert_close(n, bd.view(got, kind, *r), bd.view(ref[n], kind, *r)))
+    finally:
+        ctx.close()
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------
+DSW_PAR = dict(dt=6.0, hord_tr=8, hord_mt=10, hord_vt=10, hord_tm=10, hord_dp=10, dddmp=0.0, d4_bg=0.16, kgb=0.0)
+
+
+def check_d_sw(lib, nx=40, ny=19, npz=4, hydrostatic=False, perturb=True, par_over=None, lev_over=None,
+               flags=None, use_cond=False):
+    """c_sw (oracle) -> periodic halo of uc, vc, divg_d -> d_sw by oracle and by the library."""
+    bd = Bounds(1, nx, 1, ny)
+    g = make_grid(bd, perturb)
+    for k, v in (flags or {}).items():
+        setattr(g, k, v)
+    par = dict(DSW_PAR)
+    par.update(par_over or {})
+    par["hydrostatic"], par["use_cond"] = int(hydrostatic), int(use_cond)
+    dt = par["dt"]
+    st = smooth_state(bd, npz, hydrostatic=hydrostatic)
+    f = run_c_sw_oracle(g, bd, npz, st, 0.5 * dt, hydrostatic)
+    for n, kind in (("uc", "V"), ("vc", "U"), ("divg_d", "B")):
+        for k in range(npz):
+            periodic_fill(bd, f[n][:, :, k], kind, fill_edge=True)
+    rng = np.random.default_rng(99)
+    if use_cond:
+        f["q_con"] = np.asfortranarray(0.01 * rng.uniform(0, 1, bd.shape("A", npz)))
+        for k in range(npz):
+            periodic_fill(bd, f["q_con"][:, :, k], "A")
+    for n, kind in (("mfx", "FX"), ("mfy", "FY"), ("cx", "CX"), ("cy", "CY")):
+        f[n] = np.asfortranarray(rng.uniform(-1, 1, bd.shape(kind, npz)))  # non-zero: accumulation is checked
+    for n, kind in (("crx", "CX"), ("cry", "CY"), ("xfx", "CX"), ("yfx", "CY"), ("heat_source", "CC"),
+                    ("diss_est", "CC")):
+        f[n] = bd.zeros(kind, npz)
+    lev = default_levels(npz, **(lev_over or {}))
+    inp = {k: v.copy(order="F") for k, v in f.items()}
+
+    # ---- oracle (in place, reference semantics) ----
+    opar = dict(par)
+    opar.update(nord=1, nord_v=1, nord_w=1, nord_t=1, d2_bg=0.0, damp_v=0.0, damp_w=0.0, damp_t=0.0, d_con=0.0)
+    O.d_sw_3d(g, npz, opar, lev, f)
+
+    # ---- library ----
+    ctx = Context(g, npz, lib=lib)
+    worst = {}
+    try:
+        ctx.dsw_levels(lev)
+        d = {k: ctx.from_host(v) for k, v in inp.items() if k not in ("heat_source", "diss_est")}
+        out = {n: ctx.zeros(kind, npz) for n, kind in (("delp_out", "A"), ("pt_out", "A"), ("u_out", "U"),
+                                                       ("v_out", "V"), ("w_out", "A"), ("q_con_out", "A"),
+                                                       ("heat_s", "CC"), ("diss_e", "CC"), ("delpc_o", "A"))}
+        ctx.d_sw(par, out["delpc_o"], d["delp"], d["pt"], d["u"], d["v"], d.get("w"), d["uc"], d["vc"], d["ua"],
+                 d["va"], d["divg_d"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"],
+                 d.get("q_con"), out["delp_out"], out["pt_out"], out["u_out"], out["v_out"],
+                 None if hydrostatic else out["w_out"], out["q_con_out"] if use_cond else None, out["heat_s"],
+                 out["diss_e"])
+        i0, i1, j0, j1 = bd.is_, bd.ie, bd.js, bd.je
+        cmp = [("crx", d["crx"], "CX", None), ("cry", d["cry"], "CY", None), ("xfx", d["xfx"], "CX", None),
+               ("yfx", d["yfx"], "CY", None), ("cx", d["cx"], "CX", None), ("cy", d["cy"], "CY", None),
+               ("mfx", d["mfx"], "FX", None), ("mfy", d["mfy"], "FY", None),
+               ("delp", out["delp_out"], "A", (i0, i1, j0, j1)), ("pt", out["pt_out"], "A", (i0, i1, j0, j1)),
+               ("u", out["u_out"], "U", (i0, i1, j0, j1 + 1)), ("v", out["v_out"], "V", (i0, i1 + 1, j0, j1)),
+               ("heat_source", out["heat_s"], "CC", None), ("diss_est", out["diss_e"], "CC", None),
+               ("delpc", out["delpc_o"], "A", (i0, i1 + 1, j0, j1 + 1))]
+        if not hydrostatic:
+            cmp.append(("w", out["w_out"], "A", (i0, i1, j0, j1)))
+        if use_cond:
+            cmp.append(("q_con", out["q_con_out"], "A", (i0, i1, j0, j1)))
+        for name, dev, kind, r in cmp:
+            got, ref = dev.download(), f[name]
+            if r is not None:
+                got, ref = bd.view(got, kind, *r), bd.view(ref, kind, *r)
+            if not np.any(ref) and not np.any(got):
+                worst[name] = 0.0
+                continue
+            worst[name] = assert_close(name, got, ref)
+    finally:
+        ctx.close()
+    return worst

@@ -1,0 +1,80 @@
+"""Kernel-logic tests on the CPU: the HIP tile kernels compiled by g++ in host-emulation mode
+(tests/hostemu; one thread per workgroup) against the oracle.  This is a development harness for
+the GPU-less build container; the real parity gate is tests/test_gpu_parity.py (-m gpu)."""
+import os
+import subprocess
+
+import pytest
+
+import parity_common as P
+from gfdl_atmos_cubed_sphere_amd.lib import Fv3Lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostemu"), "-s"])
+    return Fv3Lib(os.path.join(HERE, "hostemu", "libfv3_hostemu.so"))
+
+
+@pytest.mark.parametrize("hord", [5, -5, 6, 8, 10])
+def test_fv_tp_2d_plain(emu, hord):
+    P.check_fv_tp_2d(emu, hord)
+
+
+@pytest.mark.parametrize("mode,nord,damp_c", [("mass_flux", -1, 0.0), ("mass_flux_damp", 1, 0.06),
+                                             ("mass_flux_damp", 2, 0.06), ("plain", 0, 0.05), ("plain", 2, 0.06)])
+def test_fv_tp_2d_modes(emu, mode, nord, damp_c):
+    P.check_fv_tp_2d(emu, 10, mode=mode, nord=nord, damp_c=damp_c)
+
+
+def test_fv_tp_2d_tile_multiple_and_ragged(emu):
+    P.check_fv_tp_2d(emu, 10, nx=64, ny=16)   # exact multiples of the tile
+    P.check_fv_tp_2d(emu, 8, nx=33, ny=9)     # one extra column/row
+    P.check_fv_tp_2d(emu, 10, nx=7, ny=5)     # smaller than a tile
+
+
+@pytest.mark.parametrize("hydrostatic", [False, True])
+@pytest.mark.parametrize("perturb", [False, True])
+def test_c_sw(emu, hydrostatic, perturb):
+    P.check_c_sw(emu, hydrostatic=hydrostatic, perturb=perturb)
+
+
+def test_c_sw_ragged(emu):
+    P.check_c_sw(emu, nx=28, ny=4, npz=2)
+    P.check_c_sw(emu, nx=64, ny=16, npz=1)
+    P.check_c_sw(emu, nx=61, ny=13, npz=1)
+
+
+@pytest.mark.parametrize("hydrostatic", [False, True])
+def test_d_sw_defaults(emu, hydrostatic):
+    P.check_d_sw(emu, hydrostatic=hydrostatic)
+
+
+def test_d_sw_cartesian_metrics(emu):
+    P.check_d_sw(emu, perturb=False)
+
+
+def test_d_sw_damping_heating(emu):
+    # do_vort_damp + d_con + Smagorinsky-type divergence damping + higher-order nord
+    P.check_d_sw(emu, par_over=dict(dddmp=0.2, kgb=1e-3),
+                 lev_over=dict(nord=2, do_vort_damp=True, vtdm4=0.06, d_con=1.0, d2_bg=0.0075))
+
+
+def test_d_sw_nord3_and_no_cooling_limiter(emu):
+    P.check_d_sw(emu, lev_over=dict(nord=3, do_vort_damp=True, vtdm4=0.03, d_con=0.5),
+                 flags=dict(prevent_diss_cooling=False, do_diss_est=True))
+
+
+def test_d_sw_dcon_without_vort_damp(emu):
+    P.check_d_sw(emu, lev_over=dict(nord=1, d_con=1.0))
+
+
+def test_d_sw_use_cond_low_order(emu):
+    P.check_d_sw(emu, use_cond=True, par_over=dict(hord_mt=6, hord_vt=6, hord_tm=5, hord_dp=-5))
+
+
+def test_d_sw_ragged(emu):
+    P.check_d_sw(emu, nx=33, ny=9, npz=2)
+    P.check_d_sw(emu, nx=64, ny=16, npz=2)
