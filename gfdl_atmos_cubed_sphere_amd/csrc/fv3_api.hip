@@ -34,6 +34,10 @@ struct fv3_ctx {
   int *lev_i;      // 4*npz
   double *lev_d;   // 5*npz
   bool lev_ready;
+  // optional per-kernel timing with HIP events on the launch stream (fv3_profile / fv3_profile_report)
+  bool prof_on;
+  struct ProfRec { const char *label; void *e0, *e1; };
+  std::vector<ProfRec> prof;
 };
 
 static thread_local std::string g_err;
@@ -54,6 +58,54 @@ static int fail(const char *fmt, ...) {
   } while (0)
 
 extern "C" const char *fv3_last_error(void) { return g_err.c_str(); }
+
+// launch + optional event pair around it
+template <class F>
+static int launch_p(fv3_ctx *c, const char *label, Dim3 grid, size_t lds_doubles, const F &f) {
+  void *e0 = nullptr, *e1 = nullptr;
+  if (c->prof_on) {
+    if (rt_event_create(&e0) || rt_event_create(&e1)) return 1;
+    rt_event_record(e0, c->stream);
+  }
+  int rc = launch(grid, lds_doubles, c->stream, f);
+  if (c->prof_on) {
+    rt_event_record(e1, c->stream);
+    c->prof.push_back({label, e0, e1});
+  }
+  return rc;
+}
+
+extern "C" int fv3_profile(fv3_ctx *c, int enable) {
+  if (!c) return fail("fv3_profile: null ctx");
+  c->prof_on = enable != 0;
+  return 0;
+}
+
+extern "C" int fv3_profile_report(fv3_ctx *c, char *out, size_t cap) {
+  if (!c || !out || cap == 0) return fail("fv3_profile_report: bad argument");
+  RT(rt_sync(c->stream));
+  struct Acc { const char *label; int n; double ms; };
+  std::vector<Acc> acc;
+  for (auto &r : c->prof) {
+    const double ms = rt_event_elapsed_ms(r.e0, r.e1);
+    rt_event_destroy(r.e0);
+    rt_event_destroy(r.e1);
+    bool found = false;
+    for (auto &a : acc)
+      if (std::strcmp(a.label, r.label) == 0) { a.n++; a.ms += ms; found = true; break; }
+    if (!found) acc.push_back({r.label, 1, ms});
+  }
+  c->prof.clear();
+  std::string txt;
+  char line[256];
+  for (auto &a : acc) {
+    snprintf(line, sizeof line, "%s %d %.6f\n", a.label, a.n, a.ms);
+    txt += line;
+  }
+  if (txt.size() + 1 > cap) return fail("fv3_profile_report: buffer too small");
+  std::memcpy(out, txt.c_str(), txt.size() + 1);
+  return 0;
+}
 
 extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   if (!dom || !out) return fail("fv3_create: null argument");
@@ -78,6 +130,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->dev_metrics = nullptr;
   c->grid_ready = false;
   c->lev_i = nullptr; c->lev_d = nullptr; c->lev_ready = false;
+  c->prof_on = false;
   *out = c;
   return 0;
 }
@@ -276,7 +329,7 @@ extern "C" int fv3_fv_tp_2d(fv3_ctx *c, int nk, const double *q, const double *c
   grid.x = (unsigned)((c->g.nx + TI - 1) / TI);
   grid.y = (unsigned)((c->g.ny + TJ - 1) / TJ);
   grid.z = (unsigned)nk;
-  RT(launch(grid, Tp2dKernel<TI, TJ>::lds_doubles, c->stream, kf));
+  RT(launch_p(c, "fv_tp_2d", grid, Tp2dKernel<TI, TJ>::lds_doubles, kf));
   return 0;
 }
 
@@ -294,7 +347,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, double *delpc, const double *delp, double *p
   Dim3 grid;
   CswTile<TI, TJ>::grid_dims(c->g, grid.x, grid.y);
   grid.z = (unsigned)c->g.npz;
-  RT(launch(grid, CswTile<TI, TJ>::lds_doubles, c->stream, kf));
+  RT(launch_p(c, "c_sw", grid, CswTile<TI, TJ>::lds_doubles, kf));
   return 0;
 }
 
@@ -336,7 +389,7 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, cons
     grid.x = (unsigned)((nmax + DswCourant::CH - 1) / DswCourant::CH);
     grid.y = 1;
     grid.z = (unsigned)npz;
-    RT(launch(grid, 0, c->stream, kf));
+    RT(launch_p(c, "d_sw_courant", grid, 0, kf));
   }
   constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
   {
@@ -344,14 +397,14 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, cons
     Dim3 grid;
     DswTransport<TI, TJ>::grid_dims(g, grid.x, grid.y);
     grid.z = (unsigned)npz;
-    RT(launch(grid, DswTransport<TI, TJ>::lds_doubles, c->stream, kf));
+    RT(launch_p(c, "d_sw_transport", grid, DswTransport<TI, TJ>::lds_doubles, kf));
   }
   {
     DswMomentum<TI, TJ> kf{g, a};
     Dim3 grid;
     DswMomentum<TI, TJ>::grid_dims(g, grid.x, grid.y);
     grid.z = (unsigned)npz;
-    RT(launch(grid, DswMomentum<TI, TJ>::lds_doubles, c->stream, kf));
+    RT(launch_p(c, "d_sw_momentum", grid, DswMomentum<TI, TJ>::lds_doubles, kf));
   }
   return 0;
 }
@@ -391,6 +444,6 @@ extern "C" int fv3_halo_fill_periodic(fv3_ctx *c, double *field, int kind, int n
   grid.x = (unsigned)((n + HaloPeriodic::CH - 1) / HaloPeriodic::CH);
   grid.y = 1;
   grid.z = (unsigned)nk;
-  RT(launch(grid, 0, c->stream, kf));
+  RT(launch_p(c, "halo_periodic", grid, 0, kf));
   return 0;
 }

@@ -50,6 +50,10 @@ inline int rt_memset(void *d, int v, size_t n, stream_t) {
 }
 inline int rt_sync(stream_t) { return 0; }
 inline const char *rt_errstr(int) { return "host-emu error"; }
+inline int rt_event_create(void **e) { *e = nullptr; return 0; }
+inline void rt_event_record(void *, stream_t) {}
+inline double rt_event_elapsed_ms(void *, void *) { return 0.; }
+inline void rt_event_destroy(void *) {}
 
 #else  // ---------------------------------------------------------------------------- HIP
 
@@ -88,6 +92,14 @@ inline int rt_d2h(void *d, const void *s, size_t n, stream_t st) {
 inline int rt_memset(void *d, int v, size_t n, stream_t st) { return (int)hipMemsetAsync(d, v, n, st); }
 inline int rt_sync(stream_t st) { return (int)hipStreamSynchronize(st); }
 inline const char *rt_errstr(int e) { return hipGetErrorString((hipError_t)e); }
+inline int rt_event_create(void **e) { return (int)hipEventCreate((hipEvent_t *)e); }
+inline void rt_event_record(void *e, stream_t s) { (void)hipEventRecord((hipEvent_t)e, s); }
+inline double rt_event_elapsed_ms(void *a, void *b) {
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b);
+  return (double)ms;
+}
+inline void rt_event_destroy(void *e) { (void)hipEventDestroy((hipEvent_t)e); }
 
 #endif
 

@@ -1,0 +1,134 @@
+"""Halo exchange of a doubly periodic domain block-decomposed over px x py ranks.
+
+Replaces the reference's ``start_group_halo_update`` / ``complete_group_halo_update``
+(tools/fv_mp_mod.F90:646-876, FMS mpp_domains underneath) for the ``grid_type=4`` domain whose two
+periodic contacts are defined in tools/fv_mp_mod.F90:473-483: halo width 3, eight neighbours
+(edges + corners), scalar and north-east staggered positions (CENTER, CORNER, DGRID_NE / CGRID_NE
+components -- on a Cartesian tile no vector rotation or sign change is involved).
+
+* one rank (1x1 layout): a device copy kernel (``fv3_halo_fill_periodic``).
+* several ranks: grouped peer send/recv over RCCL (torch.distributed backend "nccl"; xGMI links are
+  point to point, every neighbour is one hop) -- all fields of a "pack" travel in one batch, like
+  the reference's ``complete=.false./.true.`` grouping (model/dyn_core.F90:823-824).  The same code
+  runs on CPU tensors over gloo for the multi-process tests.
+
+Index conventions (per direction, stagger s = 1 for the north-east staggered direction):
+  the strip a rank sends to its WEST neighbour fills that neighbour's EAST halo: my columns
+  [is+s, is+s+2] -> their [ie+s+1, ie+s+3]; to the EAST neighbour: my [ie-2, ie] -> their
+  [is-3, is-1].  The staggered edge point ie+1 is a compute point of its owner and is never
+  overwritten (FMS symmetric-domain semantics).
+"""
+from __future__ import annotations
+
+from .layout import Bounds
+
+NG = 3
+_STAG = {"A": (0, 0), "U": (0, 1), "V": (1, 0), "B": (1, 1)}
+
+
+def choose_layout(world: int):
+    """px x py with px >= py and the squarest factorisation (1, 1x2 -> 2x1, 2x2, 4x2)."""
+    best = (world, 1)
+    for py in range(1, int(world ** 0.5) + 1):
+        if world % py == 0:
+            best = (world // py, py)
+    return best
+
+
+def _ranges(lo: int, hi: int, s: int):
+    """send/recv index ranges (inclusive, Fortran indices) along one direction for offset -1, 0, +1.
+    Returns {off: (send_lo, send_hi, recv_lo, recv_hi)}; off is the direction of the neighbour the
+    strip is SENT to (recv ranges are where the strip coming FROM that side lands)."""
+    return {
+        -1: (lo + s, lo + s + NG - 1, lo - NG, lo - 1),          # send to low side; low-side halo is filled
+        0: (lo, hi + s, lo, hi + s),
+        +1: (hi - NG + 1, hi, hi + s + 1, hi + s + NG),          # send to high side; high-side halo filled
+    }
+
+
+class HaloTopology:
+    def __init__(self, bd: Bounds, px: int, py: int, rank: int):
+        self.bd, self.px, self.py, self.rank = bd, px, py, rank
+        self.ix, self.iy = rank % px, rank // px
+
+    def neighbour(self, di: int, dj: int) -> int:
+        return ((self.iy + dj) % self.py) * self.px + (self.ix + di) % self.px
+
+    def strips(self, kind: str):
+        """{(di,dj): (send_slices, halo_slices)}: the interior strip adjacent to my (di,dj) boundary
+        (what the neighbour at offset (di,dj) needs) and my halo region on the (di,dj) side."""
+        si, sj = _STAG[kind]
+        b = self.bd
+        ilo, _, jlo, _ = b.limits(kind)
+        ri, rj = _ranges(b.is_, b.ie, si), _ranges(b.js, b.je, sj)
+        out = {}
+        for dj in (-1, 0, 1):
+            for di in (-1, 0, 1):
+                if di == 0 and dj == 0:
+                    continue
+                a, c = ri[di], rj[dj]
+                send = (slice(a[0] - ilo, a[1] - ilo + 1), slice(c[0] - jlo, c[1] - jlo + 1))
+                halo = (slice(a[2] - ilo, a[3] - ilo + 1), slice(c[2] - jlo, c[3] - jlo + 1))
+                out[(di, dj)] = (send, halo)
+        return out
+
+
+DIRECTIONS = [(di, dj) for dj in (-1, 0, 1) for di in (-1, 0, 1) if (di, dj) != (0, 0)]
+
+
+def exchange_tensors(topo: HaloTopology, fields, dist=None):
+    """fields: [(tensor(ni,nj[,nk]) strided view of the field, kind)].  Fills all halos in place.
+
+    For every direction d, in a fixed order: the strip adjacent to my d-side boundary goes to the
+    neighbour at offset d, and my (-d)-side halo is received from the neighbour at offset -d.  Two
+    ranks that are neighbours in several directions (e.g. east AND west on a 2-wide layout) thereby
+    post their sends and the matching receives in the same order, which is what send/recv matching
+    between a pair of ranks requires.  A rank that is its own neighbour copies locally."""
+    import torch
+
+    recvs, p2p = [], []
+    for t, kind in fields:
+        strips = topo.strips(kind)
+        for d in DIRECTIONS:
+            md = (-d[0], -d[1])
+            to, frm = topo.neighbour(*d), topo.neighbour(*md)
+            send_sl, halo_sl = strips[d][0], strips[md][1]
+            if to == topo.rank:
+                t[halo_sl] = t[send_sl]
+                continue
+            buf_s = t[send_sl].contiguous()
+            buf_r = torch.empty_like(t[halo_sl].contiguous())
+            recvs.append((t, halo_sl, buf_r))
+            p2p.append(dist.P2POp(dist.isend, buf_s, to))
+            p2p.append(dist.P2POp(dist.irecv, buf_r, frm))
+    if not p2p:
+        return
+    for w in dist.batch_isend_irecv(p2p):  # one group: ncclGroupStart ... ncclGroupEnd on RCCL
+        w.wait()
+    for t, halo_sl, buf_r in recvs:
+        t[halo_sl] = buf_r
+
+
+class HaloExchanger:
+    """Device-side exchanger bound to a lib.Context (GPU)."""
+
+    def __init__(self, ctx, px: int, py: int, rank: int, world: int):
+        self.ctx, self.px, self.py, self.rank, self.world = ctx, px, py, rank, world
+        self.topo = HaloTopology(ctx.bd, px, py, rank)
+        self._views = {}
+
+    def _tensor(self, dev):
+        import torch
+        key = dev.ptr
+        if key not in self._views:
+            self._views[key] = torch.as_tensor(dev, device="cuda")
+        return self._views[key]
+
+    def update(self, fields):
+        """fields: [(DeviceArray, kind)] -- one "pack"."""
+        if self.world == 1:
+            for dev, kind in fields:
+                self.ctx.halo_fill_periodic(dev, kind)
+            return
+        import torch.distributed as dist
+        exchange_tensors(self.topo, [(self._tensor(dev), kind) for dev, kind in fields], dist)

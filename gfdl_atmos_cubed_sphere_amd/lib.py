@@ -31,7 +31,7 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 # every symbol include/fv3_mi355x.h declares (tests check the built library exports all of them)
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
-           "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_halo_fill_periodic"]
+           "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_halo_fill_periodic", "fv3_profile", "fv3_profile_report"]
 
 
 class Fv3Error(RuntimeError):
@@ -239,6 +239,19 @@ class Context:
                                              vc.p, ua.p, va.p, divg_d.p, mfx.p, mfy.p, cx.p, cy.p, crx.p, cry.p, xfx.p,
                                              yfx.p, _pp(q_con), delp_out.p, pt_out.p, u_out.p, v_out.p, _pp(w_out),
                                              _pp(q_con_out), heat_s.p, diss_e.p), "fv3_d_sw")
+
+    def profile(self, enable: bool):
+        self.lib.check(self.lib.dll.fv3_profile(self.h, C.c_int(int(enable))), "fv3_profile")
+
+    def profile_report(self) -> dict:
+        """{label: (count, total_ms)} measured with HIP events on the launch stream."""
+        buf = C.create_string_buffer(1 << 16)
+        self.lib.check(self.lib.dll.fv3_profile_report(self.h, buf, C.c_size_t(len(buf))), "fv3_profile_report")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms = line.split()
+            out[name] = (int(n), float(ms))
+        return out
 
     def halo_fill_periodic(self, field: DeviceArray, kind: str):
         code = {"A": 0, "U": 1, "V": 2, "B": 3}[kind]

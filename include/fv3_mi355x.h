@@ -138,6 +138,12 @@ int fv3_d_sw(fv3_ctx *ctx, const fv3_dsw_params *p, double *delpc, const double 
  * start/complete_group_halo_update (tools/fv_mp_mod.F90:646-876).  kind: 0=A 1=U 2=V 3=B. */
 int fv3_halo_fill_periodic(fv3_ctx *ctx, double *field, int kind, int nk);
 
+/* Per-kernel timing with HIP events recorded on the context's stream around every kernel the
+ * library launches (this is what bench.py's roofline figures are measured with).  report: one line
+ * "label count total_ms" per kernel label since the last report; synchronises the stream. */
+int fv3_profile(fv3_ctx *ctx, int enable);
+int fv3_profile_report(fv3_ctx *ctx, char *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -211,3 +211,23 @@ def check_d_sw(lib, nx=40, ny=19, npz=4, hydrostatic=False, perturb=True, par_ov
     finally:
         ctx.close()
     return worst
+
+
+# ------------------------------------------------------------------------------------------------
+def check_halo_periodic(lib, nx=21, ny=10, nk=3):
+    bd = Bounds(1, nx, 1, ny)
+    g = make_grid(bd, False)
+    rng = np.random.default_rng(4)
+    ctx = Context(g, nk, lib=lib)
+    try:
+        for kind in ("A", "U", "V", "B"):
+            a = np.asfortranarray(rng.uniform(-1, 1, bd.shape(kind, nk)))
+            ref = a.copy(order="F")
+            for k in range(nk):
+                periodic_fill(bd, ref[:, :, k], kind)
+            dev = ctx.from_host(a)
+            ctx.halo_fill_periodic(dev, kind)
+            got = dev.download()
+            assert np.array_equal(got, ref), kind
+    finally:
+        ctx.close()

@@ -94,3 +94,7 @@ def test_errors_are_loud(prod):
             ctx.fv_tp_2d(a, a, a, 3, a, a, a, a)  # unsupported hord
     finally:
         ctx.close()
+
+
+def test_halo_fill_periodic(prod):
+    P.check_halo_periodic(prod)

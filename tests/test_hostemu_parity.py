@@ -78,3 +78,7 @@ def test_d_sw_use_cond_low_order(emu):
 def test_d_sw_ragged(emu):
     P.check_d_sw(emu, nx=33, ny=9, npz=2)
     P.check_d_sw(emu, nx=64, ny=16, npz=2)
+
+
+def test_halo_fill_periodic(emu):
+    P.check_halo_periodic(emu)
