@@ -1,0 +1,140 @@
+!> ISO_C_BINDING interface to libfv3_mi355x.so (include/fv3_mi355x.h) -- the binding a maintainer of
+!> the reference would add so that model/dyn_core.F90 can call the MI355X kernels where it calls
+!> c_sw / d_sw / fv_tp_2d today.  Device buffers are held as type(c_ptr); scalars go by value.
+!> Compile check: amdflang -c fv3_mi355x_mod.F90   (no FMS needed).
+module fv3_mi355x_mod
+  use iso_c_binding
+  implicit none
+  private
+  public :: fv3_domain, fv3_grid_host, fv3_dsw_params, fv3_dsw_levels
+  public :: fv3_create, fv3_destroy, fv3_set_stream, fv3_grid_upload, fv3_malloc, fv3_free
+  public :: fv3_memcpy_h2d, fv3_memcpy_d2h, fv3_sync, fv3_c_sw, fv3_d_sw, fv3_fv_tp_2d
+  public :: fv3_dsw_levels_upload, fv3_halo_fill_periodic, fv3_check
+
+  type, bind(C) :: fv3_domain
+    integer(c_int) :: is, ie, js, je, ng, npx, npy, npz, grid_type
+    integer(c_int) :: do_diss_est, prevent_diss_cooling, stretched_grid
+    real(c_double) :: lim_fac
+  end type
+
+  type, bind(C) :: fv3_grid_host      ! host addresses (c_loc) of the gridstruct members
+    real(c_double) :: da_min, da_min_c
+    type(c_ptr) :: area, rarea, dxa, dya, rdxa, rdya, cosa_s, rsin2, f0
+    type(c_ptr) :: dx, rdx, dyc, rdyc, cosa_v, sina_v, rsin_v, divg_u, del6_u
+    type(c_ptr) :: dy, rdy, dxc, rdxc, cosa_u, sina_u, rsin_u, divg_v, del6_v
+    type(c_ptr) :: rarea_c, fC, cosa, sina
+    type(c_ptr) :: sin_sg, cos_sg
+  end type
+
+  type, bind(C) :: fv3_dsw_params
+    real(c_double) :: dt
+    integer(c_int) :: hord_tr, hord_mt, hord_vt, hord_tm, hord_dp
+    real(c_double) :: dddmp, d4_bg, kgb
+    integer(c_int) :: hydrostatic, use_cond
+  end type
+
+  type, bind(C) :: fv3_dsw_levels     ! host arrays of length npz (dyn_core.F90:666-733)
+    type(c_ptr) :: nord_k, nord_v, nord_w, nord_t
+    type(c_ptr) :: d2_divg, damp_vt, damp_w, damp_t, d_con_k
+  end type
+
+  interface
+    integer(c_int) function fv3_create(dom, ctx) bind(C, name="fv3_create")
+      import :: c_int, c_ptr, fv3_domain
+      type(fv3_domain), intent(in) :: dom
+      type(c_ptr), intent(out) :: ctx
+    end function
+    integer(c_int) function fv3_destroy(ctx) bind(C, name="fv3_destroy")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function fv3_set_stream(ctx, stream) bind(C, name="fv3_set_stream")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx, stream
+    end function
+    integer(c_int) function fv3_grid_upload(ctx, g) bind(C, name="fv3_grid_upload")
+      import :: c_int, c_ptr, fv3_grid_host
+      type(c_ptr), value :: ctx
+      type(fv3_grid_host), intent(in) :: g
+    end function
+    integer(c_int) function fv3_malloc(dptr, bytes) bind(C, name="fv3_malloc")
+      import :: c_int, c_ptr, c_size_t
+      type(c_ptr), intent(out) :: dptr
+      integer(c_size_t), value :: bytes
+    end function
+    integer(c_int) function fv3_free(dptr) bind(C, name="fv3_free")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: dptr
+    end function
+    integer(c_int) function fv3_memcpy_h2d(ctx, dst, src, bytes) bind(C, name="fv3_memcpy_h2d")
+      import :: c_int, c_ptr, c_size_t
+      type(c_ptr), value :: ctx, dst, src
+      integer(c_size_t), value :: bytes
+    end function
+    integer(c_int) function fv3_memcpy_d2h(ctx, dst, src, bytes) bind(C, name="fv3_memcpy_d2h")
+      import :: c_int, c_ptr, c_size_t
+      type(c_ptr), value :: ctx, dst, src
+      integer(c_size_t), value :: bytes
+    end function
+    integer(c_int) function fv3_sync(ctx) bind(C, name="fv3_sync")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+    !> replaces: call c_sw(delpc, delp, ptc, pt, u, v, w, uc, vc, ua, va, wc, ut, vt, divg_d, nord, dt2,
+    !>                     hydrostatic, dord4, bd, gridstruct, flagstruct)   sw_core.F90:79, dyn_core.F90:439-447
+    integer(c_int) function fv3_c_sw(ctx, delpc, delp, ptc, pt, u, v, w, uc, vc, ua, va, wc, ut, vt, divg_d, &
+                                     nord, dt2, hydrostatic, dord4) bind(C, name="fv3_c_sw")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, delpc, delp, ptc, pt, u, v, w, uc, vc, ua, va, wc, ut, vt, divg_d
+      integer(c_int), value :: nord, hydrostatic, dord4
+      real(c_double), value :: dt2
+    end function
+    integer(c_int) function fv3_dsw_levels_upload(ctx, lv) bind(C, name="fv3_dsw_levels_upload")
+      import :: c_int, c_ptr, fv3_dsw_levels
+      type(c_ptr), value :: ctx
+      type(fv3_dsw_levels), intent(in) :: lv
+    end function
+    !> replaces: call d_sw(...)   sw_core.F90:494, dyn_core.F90:762-772
+    integer(c_int) function fv3_d_sw(ctx, p, delpc, delp, pt, u, v, w, uc, vc, ua, va, divg_d, mfx, mfy, cx, cy, &
+                                     crx, cry, xfx, yfx, q_con, delp_out, pt_out, u_out, v_out, w_out, q_con_out, &
+                                     heat_s, diss_e) bind(C, name="fv3_d_sw")
+      import :: c_int, c_ptr, fv3_dsw_params
+      type(c_ptr), value :: ctx
+      type(fv3_dsw_params), intent(in) :: p
+      type(c_ptr), value :: delpc, delp, pt, u, v, w, uc, vc, ua, va, divg_d, mfx, mfy, cx, cy, crx, cry, xfx, yfx
+      type(c_ptr), value :: q_con, delp_out, pt_out, u_out, v_out, w_out, q_con_out, heat_s, diss_e
+    end function
+    !> replaces: call fv_tp_2d(q, crx, cry, npx, npy, hord, fx, fy, xfx, yfx, gridstruct, bd, ra_x, ra_y, lim_fac,
+    !>                         mfx, mfy, mass, nord, damp_c)   tp_core.F90:85
+    integer(c_int) function fv3_fv_tp_2d(ctx, nk, q, crx, cry, hord, fx, fy, xfx, yfx, ra_x, ra_y, mfx, mfy, mass, &
+                                         nord, damp_c) bind(C, name="fv3_fv_tp_2d")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, q, crx, cry, fx, fy, xfx, yfx, ra_x, ra_y, mfx, mfy, mass
+      integer(c_int), value :: nk, hord, nord
+      real(c_double), value :: damp_c
+    end function
+    !> replaces start/complete_group_halo_update on a single-rank doubly periodic tile (fv_mp_mod.F90:646-876)
+    integer(c_int) function fv3_halo_fill_periodic(ctx, field, kind, nk) bind(C, name="fv3_halo_fill_periodic")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx, field
+      integer(c_int), value :: kind, nk
+    end function
+    function fv3_last_error() bind(C, name="fv3_last_error") result(msg)
+      import :: c_ptr
+      type(c_ptr) :: msg
+    end function
+  end interface
+
+contains
+
+  !> the reference aborts through mpp_error(FATAL); the C ABI returns a status instead
+  subroutine fv3_check(rc, where)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: where
+    if (rc /= 0) then
+      write(*,*) 'FATAL in ', where, ': fv3_mi355x status ', rc
+      error stop 1
+    end if
+  end subroutine
+
+end module fv3_mi355x_mod

@@ -1,0 +1,26 @@
+"""The ISO_C_BINDING interface module compiles with the image's Fortran compiler and
+declares a binding for every compute entry point of the C ABI."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MOD = os.path.join(ROOT, "gfdl_atmos_cubed_sphere_amd", "fortran", "fv3_mi355x_mod.F90")
+
+
+def test_bindings_cover_the_header():
+    src = open(MOD).read()
+    bound = set(re.findall(r'bind\(C, name="(fv3_[a-z0-9_]+)"\)', src))
+    for need in ("fv3_create", "fv3_grid_upload", "fv3_c_sw", "fv3_d_sw", "fv3_fv_tp_2d", "fv3_dsw_levels_upload",
+                 "fv3_halo_fill_periodic", "fv3_malloc", "fv3_memcpy_h2d", "fv3_memcpy_d2h"):
+        assert need in bound, need
+
+
+def test_module_compiles(tmp_path):
+    fc = shutil.which("amdflang") or "/opt/rocm/bin/amdflang"
+    if not os.path.exists(fc):
+        pytest.skip("no Fortran compiler in this image")
+    subprocess.check_call([fc, "-c", MOD, "-o", str(tmp_path / "m.o"), "-module-dir", str(tmp_path)])
