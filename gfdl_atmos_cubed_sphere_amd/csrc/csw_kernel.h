@@ -77,23 +77,23 @@ struct CswTile {
     FV3_SYNC();
 
     // ---- P1: D -> A interpolation (d2a2c_vect :3099-3108), divergence at corners ----------
-    for (int idx = tid; idx < nUT; idx += kNT) {
-      const int i = i0 - 3 + idx % (TI + 5), j = j0 - 1 + idx / (TI + 5);
+    FV3_TILE_FOR((TI + 5), (nUT) / (TI + 5), li_, lj_) {
+      const int i = i0 - 3 + li_, j = j0 - 1 + lj_;
       double val = 0.;
       if (i >= g.isd && i <= g.ied && j >= js - 1 && j <= je + 1)
         val = a2 * (su(i, j - 1) + su(i, j + 2)) + a1 * (su(i, j) + su(i, j + 1));
       sutmp(i, j) = val;
     }
-    for (int idx = tid; idx < nVT; idx += kNT) {
-      const int i = i0 - 1 + idx % (TI + 2), j = j0 - 3 + idx / (TI + 2);
+    FV3_TILE_FOR((TI + 2), (nVT) / (TI + 2), li_, lj_) {
+      const int i = i0 - 1 + li_, j = j0 - 3 + lj_;
       double val = 0.;
       if (j >= g.jsd && j <= g.jed && i >= is - 1 && i <= ie + 1)
         val = a2 * (sv(i - 1, j) + sv(i + 2, j)) + a1 * (sv(i, j) + sv(i + 1, j));
       svtmp(i, j) = val;
     }
     if (a.nord > 0) {  // divergence_corner, grid_type > 3 branch (:1781-1796)
-      for (int idx = tid; idx < TI * TJ; idx += kNT) {
-        const int i = i0 + idx % TI, j = j0 + idx / TI;
+      FV3_TILE_FOR(TI, (TI * TJ) / TI, li_, lj_) {
+        const int i = i0 + li_, j = j0 + lj_;
         if (i > ie + 2 || j > je + 2) continue;
         const double uf0 = su(i - 1, j) * g.dyc[g.iU(i - 1, j)], uf1 = su(i, j) * g.dyc[g.iU(i, j)];
         const double vf0 = sv(i, j - 1) * g.dxc[g.iV(i, j - 1)], vf1 = sv(i, j) * g.dxc[g.iV(i, j)];
@@ -103,8 +103,8 @@ struct CswTile {
     FV3_SYNC();
 
     // ---- P2: A-grid contravariant winds (:3152-3157); A -> C interpolation (:3197-3202,3337-3342)
-    for (int idx = tid; idx < nA1; idx += kNT) {
-      const int i = i0 - 1 + idx % (TI + 1), j = j0 - 1 + idx / (TI + 1);
+    FV3_TILE_FOR((TI + 1), (nA1) / (TI + 1), li_, lj_) {
+      const int i = i0 - 1 + li_, j = j0 - 1 + lj_;
       double uav = 0., vav = 0.;
       if (i >= is - 1 && i <= ie + 1 && j >= js - 1 && j <= je + 1) {
         const double cs = g.cosa_s[g.iA(i, j)], rs = g.rsin2[g.iA(i, j)];
@@ -118,8 +118,8 @@ struct CswTile {
       sua(i, j) = uav;
       sva(i, j) = vav;
     }
-    for (int idx = tid; idx < nC; idx += kNT) {
-      const int i = i0 - 1 + idx % (TI + 2), j = j0 - 1 + idx / (TI + 2);
+    FV3_TILE_FOR((TI + 2), (nC) / (TI + 2), li_, lj_) {
+      const int i = i0 - 1 + li_, j = j0 - 1 + lj_;
       double ucv = 0., vcv = 0.;
       if (i >= is - 1 && i <= ie + 2 && j >= js - 1 && j <= je + 1)
         ucv = a2 * (sutmp(i - 2, j) + sutmp(i + 1, j)) + a1 * (sutmp(i - 1, j) + sutmp(i, j));
@@ -131,8 +131,8 @@ struct CswTile {
     FV3_SYNC();
 
     // ---- P3: time-scaled fluxes ut, vt (:159-176); KE (:297-315,361-366); abs. vorticity (:372-403)
-    for (int idx = tid; idx < (TI + 1) * TJ; idx += kNT) {
-      const int i = i0 + idx % (TI + 1), j = j0 + idx / (TI + 1);
+    FV3_TILE_FOR((TI + 1), ((TI + 1) * TJ) / (TI + 1), li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       double val = 0.;
       if (i <= ie + 2 && j <= je + 1) {
         // d2a2c: ut = (uc - v*cosa_u)*rsin_u (:3200)
@@ -145,8 +145,8 @@ struct CswTile {
       }
       sut(i, j) = val;
     }
-    for (int idx = tid; idx < TI * (TJ + 1); idx += kNT) {
-      const int i = i0 + idx % TI, j = j0 + idx / TI;
+    FV3_TILE_FOR(TI, (TI * (TJ + 1)) / TI, li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       double val = 0.;
       if (i <= ie + 1 && j <= je + 2) {
         val = svc(i, j);  // grid_type >= 3: vt = vc (:3340)
@@ -160,8 +160,8 @@ struct CswTile {
     }
     {
       const double dt4 = 0.5 * dt2;
-      for (int idx = tid; idx < nA1; idx += kNT) {
-        const int i = i0 - 1 + idx % (TI + 1), j = j0 - 1 + idx / (TI + 1);
+      FV3_TILE_FOR((TI + 1), (nA1) / (TI + 1), li_, lj_) {
+        const int i = i0 - 1 + li_, j = j0 - 1 + lj_;
         double kev = 0.;
         if (i >= is - 1 && i <= ie + 1 && j >= js - 1 && j <= je + 1) {
           const double uav = sua(i, j), vav = sva(i, j);
@@ -172,8 +172,8 @@ struct CswTile {
         ske(i, j) = kev;
       }
     }
-    for (int idx = tid; idx < nA1; idx += kNT) {
-      const int i = i0 + idx % (TI + 1), j = j0 + idx / (TI + 1);
+    FV3_TILE_FOR((TI + 1), (nA1) / (TI + 1), li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       double vo = 0.;
       if (i >= is && i <= ie + 1 && j >= js && j <= je + 1) {
         const double fxm = suc(i, j - 1) * g.dxc[g.iV(i, j - 1)], fx0 = suc(i, j) * g.dxc[g.iV(i, j)];
@@ -186,8 +186,8 @@ struct CswTile {
     FV3_SYNC();
 
     // ---- P4: owned cells: upwind transport (:182-286) and the C-grid wind update (:414-486) ----
-    for (int idx = tid; idx < TI * TJ; idx += kNT) {
-      const int i = i0 + idx % TI, j = j0 + idx / TI;
+    FV3_TILE_FOR(TI, (TI * TJ) / TI, li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       if (i > ie + 2 || j > je + 2) continue;
       if (i <= ie + 1 && j <= je + 1) {
         const double ut0 = sut(i, j), ut1 = sut(i + 1, j), vt0 = svt(i, j), vt1 = svt(i, j + 1);

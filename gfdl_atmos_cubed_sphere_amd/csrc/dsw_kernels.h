@@ -110,16 +110,16 @@ struct DswTransport {
     Tile fxd, fyd;
     deln_tile<TI, TJ>(g, b, tid, sq, nord, damp, smass == nullptr, scr, fxd, fyd);
     const double damp2 = 0.5 * damp;
-    for (int idx = tid; idx < nFXt; idx += kNT) {
-      const int i = b.i0 + idx % (TI + 1), j = b.j0 + idx / (TI + 1);
+    FV3_TILE_FOR((TI + 1), (nFXt) / (TI + 1), li_, lj_) {
+      const int i = b.i0 + li_, j = b.j0 + lj_;
       if (i > b.ilast + 1 || j > b.jlast) continue;
       if (smass)
         sfx(i, j) = sfx(i, j) + damp2 * ((*smass)(i - 1, j) + (*smass)(i, j)) * fxd(i, j);
       else
         sfx(i, j) = sfx(i, j) + fxd(i, j);
     }
-    for (int idx = tid; idx < nFYt; idx += kNT) {
-      const int i = b.i0 + idx % TI, j = b.j0 + idx / TI;
+    FV3_TILE_FOR(TI, (nFYt) / TI, li_, lj_) {
+      const int i = b.i0 + li_, j = b.j0 + lj_;
       if (i > b.ilast || j > b.jlast + 1) continue;
       if (smass)
         sfy(i, j) = sfy(i, j) + damp2 * ((*smass)(i, j - 1) + (*smass)(i, j)) * fyd(i, j);
@@ -155,13 +155,13 @@ struct DswTransport {
     load_tile<TI + 6, TJ + 6>(sdp, a.delp + oA, g.nid, g.isd, g.ied, g.jsd, g.jed, tid);
     FV3_SYNC();
     tp2d_tile<TI, TJ>(g, b, tid, sdp, crx, cry, xfx, yfx, nullptr, nullptr, a.hord_dp, scr, smx, smy);
-    for (int idx = tid; idx < nFXt; idx += kNT) {  // tp_core.F90:217-226
-      const int i = i0 + idx % (TI + 1), j = j0 + idx / (TI + 1);
+    FV3_TILE_FOR((TI + 1), (nFXt) / (TI + 1), li_, lj_) {  // tp_core.F90:217-226
+      const int i = i0 + li_, j = j0 + lj_;
       if (i > b.ilast + 1 || j > b.jlast) continue;
       smx(i, j) = smx(i, j) * xfx[g.iCX(i, j)];
     }
-    for (int idx = tid; idx < nFYt; idx += kNT) {
-      const int i = i0 + idx % TI, j = j0 + idx / TI;
+    FV3_TILE_FOR(TI, (nFYt) / TI, li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       if (i > b.ilast || j > b.jlast + 1) continue;
       smy(i, j) = smy(i, j) * yfx[g.iCY(i, j)];
     }
@@ -169,22 +169,22 @@ struct DswTransport {
     if (damp_v > 1.E-4) add_deln(b, tid, sdp, nullptr, nord_v, damp_v, scr, smx, smy);
     // flux capacitors (:928-940); a face is accumulated by the tile that owns its cell, the last
     // face of the domain (ie+1 / je+1) by the last tile.
-    for (int idx = tid; idx < nFXt; idx += kNT) {
-      const int i = i0 + idx % (TI + 1), j = j0 + idx / (TI + 1);
+    FV3_TILE_FOR((TI + 1), (nFXt) / (TI + 1), li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       if (i > b.ilast + 1 || j > b.jlast) continue;
       if (i == i0 + TI && i <= g.ie) continue;  // owned by the next tile
       a.mfx[oFX + g.iFX(i, j)] = a.mfx[oFX + g.iFX(i, j)] + smx(i, j);
     }
-    for (int idx = tid; idx < nFYt; idx += kNT) {
-      const int i = i0 + idx % TI, j = j0 + idx / TI;
+    FV3_TILE_FOR(TI, (nFYt) / TI, li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       if (i > b.ilast || j > b.jlast + 1) continue;
       if (j == j0 + TJ && j <= g.je) continue;
       a.mfy[oFY + g.iFY(i, j)] = a.mfy[oFY + g.iFY(i, j)] + smy(i, j);
     }
 
     // heat_source = diss_est = 0 (:943-948)
-    for (int idx = tid; idx < nCell; idx += kNT) {
-      const int i = i0 + idx % TI, j = j0 + idx / TI;
+    FV3_TILE_FOR(TI, (nCell) / TI, li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       if (i > b.ilast || j > b.jlast) continue;
       a.heat_s[oCC + g.iCC(i, j)] = 0.;
       a.diss_e[oCC + g.iCC(i, j)] = 0.;
@@ -200,8 +200,8 @@ struct DswTransport {
         const double damp4 = ipow(damp_w * g.da_min_c, nord_w + 1);
         Tile fxd, fyd;
         deln_tile<TI, TJ>(g, b, tid, sq, nord_w, damp4, true, scr, fxd, fyd);
-        for (int idx = tid; idx < nCell; idx += kNT) {
-          const int i = i0 + idx % TI, j = j0 + idx / TI;
+        FV3_TILE_FOR(TI, (nCell) / TI, li_, lj_) {
+          const int i = i0 + li_, j = j0 + lj_;
           if (i > b.ilast || j > b.jlast) continue;
           const double dw = (fxd(i, j) - fxd(i + 1, j) + fyd(i, j) - fyd(i, j + 1)) * g.rarea[g.iA(i, j)];
           cdw(i, j) = dw;
@@ -218,8 +218,8 @@ struct DswTransport {
         FV3_SYNC();
       }
       tp2d_tile<TI, TJ>(g, b, tid, sq, crx, cry, xfx, yfx, nullptr, nullptr, a.hord_vt, scr, sfx, sfy);
-      for (int idx = tid; idx < nCell; idx += kNT) {  // :985-989 with tp_core.F90:191-200
-        const int i = i0 + idx % TI, j = j0 + idx / TI;
+      FV3_TILE_FOR(TI, (nCell) / TI, li_, lj_) {  // :985-989 with tp_core.F90:191-200
+        const int i = i0 + li_, j = j0 + lj_;
         if (i > b.ilast || j > b.jlast) continue;
         const double gx0 = sfx(i, j) * smx(i, j), gx1 = sfx(i + 1, j) * smx(i + 1, j);
         const double gy0 = sfy(i, j) * smy(i, j), gy1 = sfy(i, j + 1) * smy(i, j + 1);
@@ -233,20 +233,20 @@ struct DswTransport {
       load_tile<TI + 6, TJ + 6>(sq, a.q_con + oA, g.nid, g.isd, g.ied, g.jsd, g.jed, tid);
       FV3_SYNC();
       tp2d_tile<TI, TJ>(g, b, tid, sq, crx, cry, xfx, yfx, nullptr, nullptr, a.hord_dp, scr, sfx, sfy);
-      for (int idx = tid; idx < nFXt; idx += kNT) {
-        const int i = i0 + idx % (TI + 1), j = j0 + idx / (TI + 1);
+      FV3_TILE_FOR((TI + 1), (nFXt) / (TI + 1), li_, lj_) {
+        const int i = i0 + li_, j = j0 + lj_;
         if (i > b.ilast + 1 || j > b.jlast) continue;
         sfx(i, j) = sfx(i, j) * smx(i, j);
       }
-      for (int idx = tid; idx < nFYt; idx += kNT) {
-        const int i = i0 + idx % TI, j = j0 + idx / TI;
+      FV3_TILE_FOR(TI, (nFYt) / TI, li_, lj_) {
+        const int i = i0 + li_, j = j0 + lj_;
         if (i > b.ilast || j > b.jlast + 1) continue;
         sfy(i, j) = sfy(i, j) * smy(i, j);
       }
       FV3_SYNC();
       if (damp_t > 1.e-4) add_deln(b, tid, sq, &sdp, nord_t, damp_t, scr, sfx, sfy);
-      for (int idx = tid; idx < nCell; idx += kNT) {
-        const int i = i0 + idx % TI, j = j0 + idx / TI;
+      FV3_TILE_FOR(TI, (nCell) / TI, li_, lj_) {
+        const int i = i0 + li_, j = j0 + lj_;
         if (i > b.ilast || j > b.jlast) continue;
         cq(i, j) = sdp(i, j) * sq(i, j) +
                    (sfx(i, j) - sfx(i + 1, j) + sfy(i, j) - sfy(i, j + 1)) * g.rarea[g.iA(i, j)];
@@ -258,20 +258,20 @@ struct DswTransport {
     load_tile<TI + 6, TJ + 6>(sq, a.pt + oA, g.nid, g.isd, g.ied, g.jsd, g.jed, tid);
     FV3_SYNC();
     tp2d_tile<TI, TJ>(g, b, tid, sq, crx, cry, xfx, yfx, nullptr, nullptr, a.hord_tm, scr, sfx, sfy);
-    for (int idx = tid; idx < nFXt; idx += kNT) {
-      const int i = i0 + idx % (TI + 1), j = j0 + idx / (TI + 1);
+    FV3_TILE_FOR((TI + 1), (nFXt) / (TI + 1), li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       if (i > b.ilast + 1 || j > b.jlast) continue;
       sfx(i, j) = sfx(i, j) * smx(i, j);
     }
-    for (int idx = tid; idx < nFYt; idx += kNT) {
-      const int i = i0 + idx % TI, j = j0 + idx / TI;
+    FV3_TILE_FOR(TI, (nFYt) / TI, li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       if (i > b.ilast || j > b.jlast + 1) continue;
       sfy(i, j) = sfy(i, j) * smy(i, j);
     }
     FV3_SYNC();
     if (damp_t > 1.e-4) add_deln(b, tid, sq, &sdp, nord_t, damp_t, scr, sfx, sfy);
-    for (int idx = tid; idx < nCell; idx += kNT) {
-      const int i = i0 + idx % TI, j = j0 + idx / TI;
+    FV3_TILE_FOR(TI, (nCell) / TI, li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       if (i > b.ilast || j > b.jlast) continue;
       const double ra = g.rarea[g.iA(i, j)];
       double ptn = sq(i, j) * sdp(i, j) + (sfx(i, j) - sfx(i + 1, j) + sfy(i, j) - sfy(i, j + 1)) * ra;
@@ -344,8 +344,8 @@ struct DswMomentum {
     // ---- KE fluxes at corners [i0, il+2] x [j0, jl+2] clipped to [is,ie+1] x [js,je+1] (:1078-1198)
     {
       const double dt5 = 0.5 * dt;
-      for (int idx = tid; idx < nKE; idx += kNT) {
-        const int i = i0 + idx % (TI + 2), j = j0 + idx / (TI + 2);
+      FV3_TILE_FOR((TI + 2), (nKE) / (TI + 2), li_, lj_) {
+        const int i = i0 + li_, j = j0 + lj_;
         double kev = 0.;
         if (i <= il + 1 && j <= jl + 1) {
           const double vb = dt5 * (vc[g.iU(i - 1, j)] + vc[g.iU(i, j)]);                       // :1129
@@ -362,8 +362,8 @@ struct DswMomentum {
       }
     }
     // ---- relative vorticity wk on E(3) (:1231-1247) and absolute vorticity (:1476-1495) ----------
-    for (int idx = tid; idx < nQ; idx += kNT) {
-      const int i = i0 - 3 + idx % (TI + 6), j = j0 - 3 + idx / (TI + 6);
+    FV3_TILE_FOR((TI + 6), (nQ) / (TI + 6), li_, lj_) {
+      const int i = i0 - 3 + li_, j = j0 - 3 + lj_;
       double wkv = 0., vo = 0.;
       if (i <= il + 3 && j <= jl + 3) {
         const double vt0 = su(i, j) * g.dx[g.iU(i, j)], vt1 = su(i, j + 1) * g.dx[g.iU(i, j + 1)];
@@ -381,8 +381,8 @@ struct DswMomentum {
     const int ic1 = il + 1, jc1 = jl + 1;
     if (nord == 0) {  // :1290-1371 with the global-index edge rules of the non-nested branch
       const int npx = g.npx, npy = g.npy;
-      for (int idx = tid; idx < nKE; idx += kNT) {
-        const int i = i0 + idx % (TI + 2), j = j0 + idx / (TI + 2);
+      FV3_TILE_FOR((TI + 2), (nKE) / (TI + 2), li_, lj_) {
+        const int i = i0 + li_, j = j0 + lj_;
         if (i > ic1 || j > jc1) continue;
         // ptc(i-1,j), ptc(i,j), vort(i,j-1), vort(i,j)
         double ptc2[2], vor2[2];
@@ -418,8 +418,8 @@ struct DswMomentum {
       }
     } else {  // :1372-1460
       // work copy of divg_d on corners [i0-nt0, ic1+nt0], nt0 = nord-1
-      for (int idx = tid; idx < nDV; idx += kNT) {
-        const int i = i0 - 3 + idx % (TI + 8), j = j0 - 3 + idx / (TI + 8);
+      FV3_TILE_FOR((TI + 8), (nDV) / (TI + 8), li_, lj_) {
+        const int i = i0 - 3 + li_, j = j0 - 3 + lj_;
         double val = 0.;
         if (i >= g.isd && i <= g.ied + 1 && j >= g.jsd && j <= g.jed + 1) val = a.divg_d[oB + g.iB(i, j)];
         sdv(i, j) = val;
@@ -429,16 +429,16 @@ struct DswMomentum {
         const int nt = nord - n;
         // vc(i,j), j in [j0-nt, jc1+nt], i in [i0-1-nt, ic1+nt]  (:1392-1396)
         // uc(i,j), j in [j0-1-nt, jc1+nt], i in [i0-nt, ic1+nt]  (:1399-1403)
-        for (int idx = tid; idx < nDV; idx += kNT) {
-          const int i = i0 - 3 + idx % (TI + 8), j = j0 - 3 + idx / (TI + 8);
+        FV3_TILE_FOR((TI + 8), (nDV) / (TI + 8), li_, lj_) {
+          const int i = i0 - 3 + li_, j = j0 - 3 + lj_;
           if (j >= j0 - nt && j <= jc1 + nt && i >= i0 - 1 - nt && i <= ic1 + nt)
             svc2(i, j) = (sdv(i + 1, j) - sdv(i, j)) * g.divg_u[g.iU(i, j)];
           if (j >= j0 - 1 - nt && j <= jc1 + nt && i >= i0 - nt && i <= ic1 + nt)
             suc2(i, j) = (sdv(i, j + 1) - sdv(i, j)) * g.divg_v[g.iV(i, j)];
         }
         FV3_SYNC();
-        for (int idx = tid; idx < nDV; idx += kNT) {  // :1406-1424
-          const int i = i0 - 3 + idx % (TI + 8), j = j0 - 3 + idx / (TI + 8);
+        FV3_TILE_FOR((TI + 8), (nDV) / (TI + 8), li_, lj_) {  // :1406-1424
+          const int i = i0 - 3 + li_, j = j0 - 3 + lj_;
           if (j >= j0 - nt && j <= jc1 + nt && i >= i0 - nt && i <= ic1 + nt) {
             double d = suc2(i, j - 1) - suc2(i, j) + svc2(i - 1, j) - svc2(i, j);
             if (!g.stretched_grid) d = d * g.rarea_c[g.iB(i, j)];
@@ -451,8 +451,8 @@ struct DswMomentum {
       const bool smag = !(a.dddmp < 1.E-5);
       Tile ssh{scr, i0 - 3, j0 - 3, TI + 6};  // shear strain "wk" of smag_corner on E(2) (scratch is free here)
       if (smag) {
-        for (int idx = tid; idx < nQ; idx += kNT) {
-          const int i = i0 - 3 + idx % (TI + 6), j = j0 - 3 + idx / (TI + 6);
+        FV3_TILE_FOR((TI + 6), (nQ) / (TI + 6), li_, lj_) {
+          const int i = i0 - 3 + li_, j = j0 - 3 + lj_;
           double val = 0.;
           if (i >= i0 - 2 && i <= il + 3 && j >= j0 - 2 && j <= jl + 3 && i <= g.ied && j <= g.jed) {
             const double vt0 = su(i, j) * g.dx[g.iU(i, j)], vt1 = su(i, j + 1) * g.dx[g.iU(i, j + 1)];
@@ -465,8 +465,8 @@ struct DswMomentum {
       }
       const int n2 = nord + 1;
       const double dd8 = g.stretched_grid ? g.da_min * ipow(a.d4_bg, n2) : ipow(g.da_min_c * a.d4_bg, n2);
-      for (int idx = tid; idx < nKE; idx += kNT) {
-        const int i = i0 + idx % (TI + 2), j = j0 + idx / (TI + 2);
+      FV3_TILE_FOR((TI + 2), (nKE) / (TI + 2), li_, lj_) {
+        const int i = i0 + li_, j = j0 + lj_;
         if (i > ic1 || j > jc1) continue;
         const double dpc = a.divg_d[oB + g.iB(i, j)];  // delpc = saved divergence (:1376-1381)
         double vs = 0.;
@@ -511,8 +511,8 @@ struct DswMomentum {
     // ---- wind update (:1500-1509, :1589-1600) and heating (:1523-1586) for owned cells ---------------
     // A thread evaluates, for cell (i,j): u_new at (i,j) and (i,j+1), v_new at (i,j) and (i+1,j)
     // (the far ones feed the cell-mean heating term; only the owned ones are stored).
-    for (int idx = tid; idx < TI * TJ; idx += kNT) {
-      const int i = i0 + idx % TI, j = j0 + idx / TI;
+    FV3_TILE_FOR(TI, (TI * TJ) / TI, li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       if (i > il || j > jl) continue;
       double un[2], vn[2], ubn[2], vbn[2], fyh[2], fxh[2];
       for (int s = 0; s < 2; s++) {

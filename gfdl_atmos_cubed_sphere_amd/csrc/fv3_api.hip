@@ -10,6 +10,7 @@
 #include "dsw_kernels.h"
 #include "fv3_common.h"
 #include "fv3_launch.h"
+#include "nh_kernels.h"
 #include "tp2d_tile.h"
 
 using namespace fv3;
@@ -35,6 +36,14 @@ struct fv3_ctx {
   double *lev_d;   // 5*npz
   bool lev_ready;
   // optional per-kernel timing with HIP events on the launch stream (fv3_profile / fv3_profile_report)
+  // nonhydrostatic path: dp_ref + edge_profile coefficients, scratch slabs (A x (npz+1) each)
+  double *dp0;        // device, npz
+  double *edge_dev;   // device, 3*npz: gk, bet, gam
+  EdgeCoef ec;
+  bool dp0_ready;
+  double *scratch[8];
+  double *lev_ext_d;  // damp(npz+1) for update_dz_d
+  int *lev_ext_i;     // ndif(npz+1)
   bool prof_on;
   struct ProfRec { const char *label; void *e0, *e1; };
   std::vector<ProfRec> prof;
@@ -131,6 +140,9 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->grid_ready = false;
   c->lev_i = nullptr; c->lev_d = nullptr; c->lev_ready = false;
   c->prof_on = false;
+  c->dp0 = nullptr; c->edge_dev = nullptr; c->dp0_ready = false;
+  for (auto &s : c->scratch) s = nullptr;
+  c->lev_ext_d = nullptr; c->lev_ext_i = nullptr;
   *out = c;
   return 0;
 }
@@ -140,6 +152,11 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   if (c->dev_metrics) rt_free(c->dev_metrics);
   if (c->lev_i) rt_free(c->lev_i);
   if (c->lev_d) rt_free(c->lev_d);
+  if (c->dp0) rt_free(c->dp0);
+  if (c->edge_dev) rt_free(c->edge_dev);
+  if (c->lev_ext_d) rt_free(c->lev_ext_d);
+  if (c->lev_ext_i) rt_free(c->lev_ext_i);
+  for (auto &s : c->scratch) if (s) rt_free(s);
   delete c;
   return 0;
 }
@@ -227,6 +244,18 @@ extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
     RT(rt_h2d(c->lev_i + n * npz, iv[n], sizeof(int) * npz, c->stream));
   }
   for (int n = 0; n < 5; n++) RT(rt_h2d(c->lev_d + n * npz, dv[n], sizeof(double) * npz, c->stream));
+  {  // ndif(km+1), damp(km+1) of update_dz_d: entry km+1 repeats entry km (nh_utils.F90:240-241)
+    std::vector<int> ni(npz + 1);
+    std::vector<double> nd(npz + 1);
+    for (int k = 0; k < npz; k++) { ni[k] = lv->nord_v[k]; nd[k] = lv->damp_vt[k]; }
+    ni[npz] = ni[npz - 1];
+    nd[npz] = nd[npz - 1];
+    if (!c->lev_ext_i) RT(rt_malloc((void **)&c->lev_ext_i, sizeof(int) * (npz + 1)));
+    if (!c->lev_ext_d) RT(rt_malloc((void **)&c->lev_ext_d, sizeof(double) * (npz + 1)));
+    RT(rt_h2d(c->lev_ext_i, ni.data(), sizeof(int) * (npz + 1), c->stream));
+    RT(rt_h2d(c->lev_ext_d, nd.data(), sizeof(double) * (npz + 1), c->stream));
+    RT(rt_sync(c->stream));
+  }
   RT(rt_sync(c->stream));
   c->lev_ready = true;
   return 0;
@@ -268,14 +297,14 @@ struct Tp2dKernel {
     tp2d_tile<TI, TJ>(g, b, tid, sq, crx + oCX, cry + oCY, xfx + oCX, yfx + oCY,
                       ra_x ? ra_x + (size_t)k * g.nRX() : nullptr, ra_y ? ra_y + (size_t)k * g.nRY() : nullptr, hord,
                       scr, sfx, sfy);
-    for (int idx = tid; idx < nFXt; idx += kNT) {
-      const int i = i0 + idx % (TI + 1), j = j0 + idx / (TI + 1);
+    FV3_TILE_FOR((TI + 1), (nFXt) / (TI + 1), li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       if (i > b.ilast + 1 || j > b.jlast) continue;
       const double m = (mfx && mfy) ? mfx[oFX + g.iFX(i, j)] : xfx[oCX + g.iCX(i, j)];
       sfx(i, j) = sfx(i, j) * m;
     }
-    for (int idx = tid; idx < nFYt; idx += kNT) {
-      const int i = i0 + idx % TI, j = j0 + idx / TI;
+    FV3_TILE_FOR(TI, (nFYt) / TI, li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       if (i > b.ilast || j > b.jlast + 1) continue;
       const double m = (mfx && mfy) ? mfy[oFY + g.iFY(i, j)] : yfx[oCY + g.iCY(i, j)];
       sfy(i, j) = sfy(i, j) * m;
@@ -288,26 +317,26 @@ struct Tp2dKernel {
       const bool wm = use_mass;
       deln_tile<TI, TJ>(g, b, tid, sq, nord, damp, !wm, scr, fxd, fyd);
       const double damp2 = 0.5 * damp;
-      for (int idx = tid; idx < nFXt; idx += kNT) {
-        const int i = i0 + idx % (TI + 1), j = j0 + idx / (TI + 1);
+      FV3_TILE_FOR((TI + 1), (nFXt) / (TI + 1), li_, lj_) {
+        const int i = i0 + li_, j = j0 + lj_;
         if (i > b.ilast + 1 || j > b.jlast) continue;
         sfx(i, j) = wm ? sfx(i, j) + damp2 * (sm(i - 1, j) + sm(i, j)) * fxd(i, j) : sfx(i, j) + fxd(i, j);
       }
-      for (int idx = tid; idx < nFYt; idx += kNT) {
-        const int i = i0 + idx % TI, j = j0 + idx / TI;
+      FV3_TILE_FOR(TI, (nFYt) / TI, li_, lj_) {
+        const int i = i0 + li_, j = j0 + lj_;
         if (i > b.ilast || j > b.jlast + 1) continue;
         sfy(i, j) = wm ? sfy(i, j) + damp2 * (sm(i, j - 1) + sm(i, j)) * fyd(i, j) : sfy(i, j) + fyd(i, j);
       }
       FV3_SYNC();
     }
-    for (int idx = tid; idx < nFXt; idx += kNT) {
-      const int i = i0 + idx % (TI + 1), j = j0 + idx / (TI + 1);
+    FV3_TILE_FOR((TI + 1), (nFXt) / (TI + 1), li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       if (i > b.ilast + 1 || j > b.jlast) continue;
       if (i == i0 + TI && i <= g.ie) continue;
       fx[oFX + g.iFX(i, j)] = sfx(i, j);
     }
-    for (int idx = tid; idx < nFYt; idx += kNT) {
-      const int i = i0 + idx % TI, j = j0 + idx / TI;
+    FV3_TILE_FOR(TI, (nFYt) / TI, li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
       if (i > b.ilast || j > b.jlast + 1) continue;
       if (j == j0 + TJ && j <= g.je) continue;
       fy[oFY + g.iFY(i, j)] = sfy(i, j);
@@ -445,5 +474,201 @@ extern "C" int fv3_halo_fill_periodic(fv3_ctx *c, double *field, int kind, int n
   grid.y = 1;
   grid.z = (unsigned)nk;
   RT(launch_p(c, "halo_periodic", grid, 0, kf));
+  return 0;
+}
+
+// ================================================================================================
+// nonhydrostatic column path
+// ================================================================================================
+static int need_scratch(fv3_ctx *c, int n) {
+  const size_t bytes = c->g.nA() * (size_t)(c->g.npz + 1) * sizeof(double);
+  for (int s = 0; s < n; s++)
+    if (!c->scratch[s]) RT(rt_malloc((void **)&c->scratch[s], bytes));
+  return 0;
+}
+
+static Dim3 col_grid(int ncol) {
+  Dim3 gr;
+  gr.x = (unsigned)((ncol + 255) / 256);
+  gr.y = 1;
+  gr.z = 1;
+  return gr;
+}
+
+extern "C" int fv3_set_dp_ref(fv3_ctx *c, const double *dp0) {
+  if (!c || !dp0) return fail("fv3_set_dp_ref: null argument");
+  const int km = c->g.npz;
+  if (km < 2) return fail("fv3_set_dp_ref: needs npz >= 2");
+  if (!c->dp0) RT(rt_malloc((void **)&c->dp0, sizeof(double) * km));
+  if (!c->edge_dev) RT(rt_malloc((void **)&c->edge_dev, sizeof(double) * 3 * km));
+  RT(rt_h2d(c->dp0, dp0, sizeof(double) * km, c->stream));
+  // edge_profile coefficients, same arithmetic as nh_utils.F90:1640-1662
+  std::vector<double> co(3 * km, 0.);
+  double *gk = co.data(), *bet = gk + km, *gam = bet + km;
+  const double g0 = dp0[1] / dp0[0];
+  c->ec.xt1_top = 2. * g0 * (g0 + 1.);
+  c->ec.bet_top = g0 * (g0 + 0.5);
+  gam[0] = (1. + g0 * (g0 + 1.5)) / c->ec.bet_top;
+  double gkk = 0.;
+  for (int k = 2; k <= km; k++) {
+    gkk = dp0[k - 2] / dp0[k - 1];
+    gk[k - 1] = gkk;
+    bet[k - 1] = 2. + 2. * gkk - gam[k - 2];
+    gam[k - 1] = gkk / bet[k - 1];
+  }
+  c->ec.a_bot = 1. + gkk * (gkk + 1.5);
+  c->ec.xt1_bot = 2. * gkk * (gkk + 1.);
+  c->ec.gk_bot = gkk;
+  RT(rt_h2d(c->edge_dev, co.data(), sizeof(double) * 3 * km, c->stream));
+  RT(rt_sync(c->stream));
+  c->ec.gk = c->edge_dev;
+  c->ec.bet = c->edge_dev + km;
+  c->ec.gam = c->edge_dev + 2 * km;
+  c->dp0_ready = true;
+  return 0;
+}
+
+extern "C" int fv3_update_dz_c(fv3_ctx *c, double dt, const double *zs, const double *ut, const double *vt,
+                               const double *gz_in, double *gz, double *ws) {
+  if (!c || !c->grid_ready) return fail("fv3_update_dz_c: context has no grid");
+  if (!c->dp0_ready) return fail("fv3_update_dz_c: call fv3_set_dp_ref first");
+  if (gz_in == gz) return fail("fv3_update_dz_c: gz_in and gz must not alias");
+  UpdateDzC kf{c->g, c->g.npz, dt, c->dp0, zs, ut, vt, gz_in, gz, ws};
+  RT(launch_p(c, "update_dz_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), 0, kf));
+  return 0;
+}
+
+static NhConsts to_consts(const fv3_nh_consts *cn) {
+  return NhConsts{cn->grav, cn->rdgas, cn->cp_air, cn->akap, cn->ptop, cn->p_fac, cn->a_imp};
+}
+
+extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn, const double *hs, const double *w3,
+                                 const double *pt, const double *delp, double *gz, double *pef, const double *ws) {
+  if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver_c: bad context/arguments");
+  if (cn->a_imp <= 0.5) return fail("fv3_riem_solver_c: a_imp <= 0.5 (RIM_2D / SIM3p0) is not built");
+  if (need_scratch(c, 4)) return 1;
+  RiemSolverC kf{c->g, c->g.npz, dt, to_consts(cn), hs, w3, pt, delp, ws, gz, pef,
+                 c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3]};
+  RT(launch_p(c, "riem_solver_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), 0, kf));
+  return 0;
+}
+
+extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, const double *zs, double *w,
+                                double *delz, const double *pt, const double *delp, double *zh, double *pe, double *ppe,
+                                double *pk3, double *pk, double *peln, const double *ws, int use_logp, int last_call,
+                                int fp_out) {
+  if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver3: bad context/arguments");
+  if (cn->a_imp <= 0.5) return fail("fv3_riem_solver3: a_imp <= 0.5 (RIM_2D / SIM3 / SIM3p0) is not built");
+  if (last_call && (!pe || !pk || !peln)) return fail("fv3_riem_solver3: last_call needs pe, pk, peln");
+  if (need_scratch(c, 4)) return 1;
+  RiemSolver3 kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, delz, zh, pe, ppe, pk3, pk, peln,
+                 use_logp, last_call, fp_out, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3]};
+  RT(launch_p(c, "riem_solver3", col_grid(c->g.nx * c->g.ny), 0, kf));
+  return 0;
+}
+
+extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const double *zh_in, double *zh_out,
+                               const double *crx, const double *cry, const double *xfx, const double *yfx, double *ws,
+                               double rdt) {
+  if (!c || !c->grid_ready) return fail("fv3_update_dz_d: context has no grid");
+  if (!c->dp0_ready) return fail("fv3_update_dz_d: call fv3_set_dp_ref first");
+  if (!c->lev_ready) return fail("fv3_update_dz_d: call fv3_dsw_levels_upload first");
+  if (!tp_ord_supported(hord)) return fail("fv3_update_dz_d: hord=%d not supported", hord);
+  if (zh_in == zh_out) return fail("fv3_update_dz_d: zh_in and zh_out must not alias");
+  if (need_scratch(c, 4)) return 1;  // crx_adv, xfx_adv (CX x (km+1)), cry_adv, yfx_adv (CY x (km+1)) fit in A x (km+1)
+  const Grid &g = c->g;
+  const int km = g.npz;
+  double *cxa = c->scratch[0], *xfa = c->scratch[1], *cya = c->scratch[2], *yfa = c->scratch[3];
+  {
+    EdgeProfile kf{g, km, c->ec, crx, xfx, cxa, xfa, (int)g.nCX()};
+    RT(launch_p(c, "edge_profile", col_grid((int)g.nCX()), 0, kf));
+    EdgeProfile kf2{g, km, c->ec, cry, yfx, cya, yfa, (int)g.nCY()};
+    RT(launch_p(c, "edge_profile", col_grid((int)g.nCY()), 0, kf2));
+  }
+  constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
+  {
+    ZhTransport<TI, TJ> kf{g, hord, zh_in, cxa, cya, xfa, yfa, c->lev_ext_i, c->lev_ext_d, zh_out};
+    Dim3 grid;
+    grid.x = (unsigned)((g.nx + TI - 1) / TI);
+    grid.y = (unsigned)((g.ny + TJ - 1) / TJ);
+    grid.z = (unsigned)(km + 1);
+    RT(launch_p(c, "zh_transport", grid, ZhTransport<TI, TJ>::lds_doubles, kf));
+  }
+  {
+    ZhLimit kf{g, km, rdt, zs, zh_out, ws};
+    RT(launch_p(c, "zh_limit", col_grid(g.nx * g.ny), 0, kf));
+  }
+  return 0;
+}
+
+extern "C" int fv3_p_grad_c(fv3_ctx *c, double dt2, const double *delpc, const double *pkc, const double *gz,
+                            double *uc, double *vc, int hydrostatic) {
+  if (!c || !c->grid_ready) return fail("fv3_p_grad_c: context has no grid");
+  const Grid &g = c->g;
+  PGradC kf{g, dt2, hydrostatic, delpc, pkc, gz, uc, vc};
+  Dim3 grid;
+  grid.x = (unsigned)(((g.nx + 1) * (g.ny + 1) + PGradC::CH - 1) / PGradC::CH);
+  grid.y = 1;
+  grid.z = (unsigned)g.npz;
+  RT(launch_p(c, "p_grad_c", grid, 0, kf));
+  return 0;
+}
+
+extern "C" int fv3_nh_p_grad(fv3_ctx *c, double *u, double *v, const double *pp, const double *gz, const double *delp,
+                             const double *pk, double dt, double top_value) {
+  if (!c || !c->grid_ready) return fail("fv3_nh_p_grad: context has no grid");
+  if (need_scratch(c, 4)) return 1;
+  const Grid &g = c->g;
+  const int km = g.npz;
+  constexpr int TI = 32, TJ = 8;
+  {
+    A2BCorners<TI, TJ> kf;
+    kf.g = g;
+    kf.in[0] = pp; kf.in[1] = pk; kf.in[2] = gz; kf.in[3] = delp;
+    for (int f = 0; f < 4; f++) kf.out[f] = c->scratch[f];
+    kf.nlev[0] = kf.nlev[1] = kf.nlev[2] = km + 1;
+    kf.nlev[3] = km;
+    kf.nf = 4;
+    kf.top_pp = 0.;
+    kf.top_pk = top_value;
+    kf.override1 = 1;
+    Dim3 grid;
+    grid.x = (unsigned)((g.nx + 1 + TI - 1) / TI);
+    grid.y = (unsigned)((g.ny + 1 + TJ - 1) / TJ);
+    grid.z = (unsigned)(km + 1);
+    RT(launch_p(c, "a2b_corners", grid, A2BCorners<TI, TJ>::lds_doubles, kf));
+  }
+  {
+    NhPGrad kf{g, dt, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], u, v};
+    Dim3 grid;
+    grid.x = (unsigned)(((g.nx + 1) * (g.ny + 1) + NhPGrad::CH - 1) / NhPGrad::CH);
+    grid.y = 1;
+    grid.z = (unsigned)km;
+    RT(launch_p(c, "nh_p_grad", grid, 0, kf));
+  }
+  return 0;
+}
+
+extern "C" int fv3_pk3_halo(fv3_ctx *c, double ptop, double akap, double *pk3, const double *delp, int use_logp) {
+  if (!c || !c->grid_ready) return fail("fv3_pk3_halo: context has no grid");
+  Pk3Halo kf{c->g, c->g.npz, use_logp, ptop, akap, delp, pk3};
+  RT(launch_p(c, "pk3_halo", col_grid((c->g.nx + 4) * (c->g.ny + 4)), 0, kf));
+  return 0;
+}
+
+extern "C" int fv3_pe_halo(fv3_ctx *c, double ptop, double *pe, const double *delp) {
+  if (!c || !c->grid_ready) return fail("fv3_pe_halo: context has no grid");
+  PeHalo kf{c->g, c->g.npz, ptop, delp, pe};
+  RT(launch_p(c, "pe_halo", col_grid((c->g.nx + 2) * (c->g.ny + 2)), 0, kf));
+  return 0;
+}
+
+extern "C" int fv3_geopk(fv3_ctx *c, double ptop, double akap, double cp_air, double ptk, double *pe, double *peln,
+                         const double *delp, double *pk, double *gz, const double *hs, const double *pt, double *pkz,
+                         int CG) {
+  if (!c || !c->grid_ready) return fail("fv3_geopk: context has no grid");
+  const int e = CG ? 1 : 2;
+  Geopk kf{c->g, c->g.npz, CG, ptop, akap, cp_air, ptk, delp, hs, pt, pe, peln, pk, gz, pkz};
+  RT(launch_p(c, "geopk", col_grid((c->g.nx + 2 * e) * (c->g.ny + 2 * e)), 0, kf));
   return 0;
 }

@@ -42,17 +42,17 @@ struct Grid {
   const double *sin_sg, *cos_sg;                                                     // A x 9
 
   // flat index of (i,j) (Fortran indices) in one k-slab of each stagger kind
-  FV3_HD size_t iA(int i, int j) const { return (size_t)(j - jsd) * nid + (i - isd); }
-  FV3_HD size_t iU(int i, int j) const { return (size_t)(j - jsd) * nid + (i - isd); }
-  FV3_HD size_t iV(int i, int j) const { return (size_t)(j - jsd) * (nid + 1) + (i - isd); }
-  FV3_HD size_t iB(int i, int j) const { return (size_t)(j - jsd) * (nid + 1) + (i - isd); }
-  FV3_HD size_t iCX(int i, int j) const { return (size_t)(j - jsd) * (nx + 1) + (i - is); }
-  FV3_HD size_t iCY(int i, int j) const { return (size_t)(j - js) * nid + (i - isd); }
-  FV3_HD size_t iFX(int i, int j) const { return (size_t)(j - js) * (nx + 1) + (i - is); }
-  FV3_HD size_t iFY(int i, int j) const { return (size_t)(j - js) * nx + (i - is); }
-  FV3_HD size_t iCC(int i, int j) const { return (size_t)(j - js) * nx + (i - is); }
-  FV3_HD size_t iRX(int i, int j) const { return (size_t)(j - jsd) * nx + (i - is); }
-  FV3_HD size_t iRY(int i, int j) const { return (size_t)(j - js) * nid + (i - isd); }
+  FV3_HD int iA(int i, int j) const { return (j - jsd) * nid + (i - isd); }
+  FV3_HD int iU(int i, int j) const { return (j - jsd) * nid + (i - isd); }
+  FV3_HD int iV(int i, int j) const { return (j - jsd) * (nid + 1) + (i - isd); }
+  FV3_HD int iB(int i, int j) const { return (j - jsd) * (nid + 1) + (i - isd); }
+  FV3_HD int iCX(int i, int j) const { return (j - jsd) * (nx + 1) + (i - is); }
+  FV3_HD int iCY(int i, int j) const { return (j - js) * nid + (i - isd); }
+  FV3_HD int iFX(int i, int j) const { return (j - js) * (nx + 1) + (i - is); }
+  FV3_HD int iFY(int i, int j) const { return (j - js) * nx + (i - is); }
+  FV3_HD int iCC(int i, int j) const { return (j - js) * nx + (i - is); }
+  FV3_HD int iRX(int i, int j) const { return (j - jsd) * nx + (i - is); }
+  FV3_HD int iRY(int i, int j) const { return (j - js) * nid + (i - isd); }
   // slab sizes
   FV3_HD size_t nA() const { return (size_t)nid * njd; }
   FV3_HD size_t nU() const { return (size_t)nid * (njd + 1); }
@@ -66,8 +66,8 @@ struct Grid {
   FV3_HD size_t nRX() const { return (size_t)nx * njd; }
   FV3_HD size_t nRY() const { return (size_t)nid * ny; }
   // sin_sg(i,j,n), n = 1..9 (model/fv_grid_utils.F90:91-97)
-  FV3_HD double sinsg(int i, int j, int n) const { return sin_sg[(size_t)(n - 1) * nid * njd + iA(i, j)]; }
-  FV3_HD double cossg(int i, int j, int n) const { return cos_sg[(size_t)(n - 1) * nid * njd + iA(i, j)]; }
+  FV3_HD double sinsg(int i, int j, int n) const { return sin_sg[(n - 1) * nid * njd + iA(i, j)]; }
+  FV3_HD double cossg(int i, int j, int n) const { return cos_sg[(n - 1) * nid * njd + iA(i, j)]; }
 };
 
 // ---- scalar helpers with the reference's semantics ----------------------------------------
@@ -83,6 +83,12 @@ FV3_HD double ipow(double x, int n) {
   for (int k = 1; k < n; k++) r = r * x;
   return r;
 }
+
+// Data-parallel loop of a workgroup over a W x H index box: (li, lj) are advanced incrementally
+// (no division per iteration).  W, H should be compile-time constants.
+#define FV3_TILE_FOR(W, H, li, lj)                                                              \
+  for (int idx_ = tid, li = tid % (W), lj = tid / (W); idx_ < (W) * (H);                        \
+       idx_ += kNT, li += kNT % (W), lj += kNT / (W), lj += (li >= (W)) ? 1 : 0, li -= (li >= (W)) ? (W) : 0)
 
 // A 2-D tile in LDS (or any memory) addressed with global Fortran indices.
 struct Tile {

@@ -25,7 +25,7 @@ inline int launch(Dim3 grid, size_t lds_doubles, stream_t, const F &f) {
   std::vector<double> lds(lds_doubles + 1, 0.);
   for (unsigned z = 0; z < grid.z; z++)
     for (unsigned y = 0; y < grid.y; y++)
-      for (unsigned x = 0; x < grid.x; x++) f((int)x, (int)y, (int)z, 0, lds.data());
+      for (unsigned x = 0; x < grid.x; x++) f((int)x, (int)y, (int)z, 0, lds.data());  // order irrelevant here
   return 0;
 }
 inline int rt_malloc(void **p, size_t n) {
@@ -63,7 +63,11 @@ using Dim3 = dim3;
 template <class F>
 __global__ void __launch_bounds__(kNT) tile_kernel(const F f) {
   extern __shared__ double fv3_lds[];
-  f((int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)threadIdx.x, fv3_lds);
+  // The hardware grid is (nk, nbx, nby): the level index k varies fastest over consecutively
+  // dispatched workgroups, which land round-robin on the 8 XCDs -- so each XCD's L2 sees the
+  // same (i,j) tile for ~nk/8 levels in a row and the 2-D metric terms / tile halos are re-used
+  // from L2 instead of being re-fetched per level.  Functors still see (bx, by, bz=k).
+  f((int)blockIdx.y, (int)blockIdx.z, (int)blockIdx.x, (int)threadIdx.x, fv3_lds);
 }
 
 template <class F>
@@ -78,7 +82,7 @@ inline int launch(Dim3 grid, size_t lds_doubles, stream_t s, const F &f) {
       done = true;
     }
   }
-  hipLaunchKernelGGL(tile_kernel<F>, grid, dim3(kNT), bytes, s, f);
+  hipLaunchKernelGGL(tile_kernel<F>, dim3(grid.z, grid.x, grid.y), dim3(kNT), bytes, s, f);
   return (int)hipGetLastError();
 }
 inline int rt_malloc(void **p, size_t n) { return (int)hipMalloc(p, n); }

@@ -1,0 +1,699 @@
+// nh_kernels.h -- the nonhydrostatic column path of the acoustic substep.
+//
+//   UpdateDzC     update_dz_c      model/nh_utils.F90:59-201     (column kernel)
+//   RiemSolverC   Riem_Solver_c    model/nh_utils.F90:323-480    (column kernel, SIM1_solver :1277-1394)
+//   EdgeProfile   edge_profile     model/nh_utils.F90:1590-1696  (column kernel, part of update_dz_d)
+//   ZhTransport   update_dz_d      model/nh_utils.F90:256-301    (tile kernel: fv_tp_2d per interface)
+//   ZhLimit       update_dz_d      model/nh_utils.F90:303-319    (column kernel)
+//   RiemSolver3   Riem_Solver3     model/nh_core.F90:47-241      (column kernel, SIM1/SIM_solver)
+//   PGradC        p_grad_c         model/dyn_core.F90:1635-1694  (pointwise)
+//   A2BCorners/NhPGrad  nh_p_grad  model/dyn_core.F90:1697-1792  (tile kernel + pointwise)
+//   Pk3Halo/PeHalo pk3_halo, pln_halo, pe_halo  model/dyn_core.F90:1395-1526 (strip columns)
+//   Geopk         geopk            model/dyn_core.F90:2202-2353  (column kernel)
+//
+// Column kernels: one thread per (i,j) column, consecutive threads = consecutive i (coalesced
+// 512-B rows per wavefront at every level), k sequential.  The tridiagonal sweeps keep their
+// O(km) intermediates in context-owned scratch slabs laid out like the fields (i fastest), so every
+// scratch access is coalesced too.  Branches: use_cond = moist_kappa = .false., fast_tau_w_sec = 0,
+// d2bg_zq = 0.
+#pragma once
+
+#include "fv3_common.h"
+#include "tp2d_tile.h"
+
+namespace fv3 {
+
+constexpr double kDzMin = 2.;  // nh_utils.F90:49
+
+struct NhConsts {
+  double grav, rdgas, cp_air, akap, ptop, p_fac, a_imp;
+};
+
+#define FV3_COL_FOR(c, ncol) for (int c = bx * 256 + tid; c < (bx + 1) * 256 && c < (ncol); c += kNT)
+
+// ------------------------------------------------------------------------------------------------
+struct UpdateDzC {
+  Grid g;
+  int km;
+  double dt;
+  const double *dp0;  // device, km
+  const double *zs, *ut, *vt, *gz_in;
+  double *gz, *ws;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int w = g.nx + 2, ncol = w * (g.ny + 2);
+    const int nA = (int)g.nA();
+    const double rdt = 1. / dt;
+    const double top_ratio = dp0[0] / (dp0[0] + dp0[1]);
+    const double bot_ratio = dp0[km - 1] / (dp0[km - 2] + dp0[km - 1]);
+    FV3_COL_FOR(c, ncol) {
+      const int i = g.is - 1 + c % w, j = g.js - 1 + c / w;
+      const int o = g.iA(i, j), oe = g.iA(i + 1, j), on = g.iA(i, j + 1), ow = g.iA(i - 1, j), os = g.iA(i, j - 1);
+      const double ar = g.area[o];
+      for (int k = 1; k <= km + 1; k++) {
+        double x0, x1, y0, y1;
+        if (k == 1) {
+          const double *a = ut, *b = ut + nA, *cc = vt, *d = vt + nA;
+          x0 = a[o] + (a[o] - b[o]) * top_ratio;
+          x1 = a[oe] + (a[oe] - b[oe]) * top_ratio;
+          y0 = cc[o] + (cc[o] - d[o]) * top_ratio;
+          y1 = cc[on] + (cc[on] - d[on]) * top_ratio;
+        } else if (k == km + 1) {
+          const double *a = ut + (size_t)(km - 1) * nA, *b = ut + (size_t)(km - 2) * nA;
+          const double *cc = vt + (size_t)(km - 1) * nA, *d = vt + (size_t)(km - 2) * nA;
+          x0 = a[o] + (a[o] - b[o]) * bot_ratio;
+          x1 = a[oe] + (a[oe] - b[oe]) * bot_ratio;
+          y0 = cc[o] + (cc[o] - d[o]) * bot_ratio;
+          y1 = cc[on] + (cc[on] - d[on]) * bot_ratio;
+        } else {
+          const double int_ratio = 1. / (dp0[k - 2] + dp0[k - 1]);
+          const double *a = ut + (size_t)(k - 2) * nA, *b = ut + (size_t)(k - 1) * nA;
+          const double *cc = vt + (size_t)(k - 2) * nA, *d = vt + (size_t)(k - 1) * nA;
+          x0 = (dp0[k - 1] * a[o] + dp0[k - 2] * b[o]) * int_ratio;
+          x1 = (dp0[k - 1] * a[oe] + dp0[k - 2] * b[oe]) * int_ratio;
+          y0 = (dp0[k - 1] * cc[o] + dp0[k - 2] * d[o]) * int_ratio;
+          y1 = (dp0[k - 1] * cc[on] + dp0[k - 2] * d[on]) * int_ratio;
+        }
+        const double *z = gz_in + (size_t)(k - 1) * nA;
+        const double zc = z[o];
+        const double fx0 = x0 * ((x0 > 0.) ? z[ow] : zc), fx1 = x1 * ((x1 > 0.) ? zc : z[oe]);
+        const double fy0 = y0 * ((y0 > 0.) ? z[os] : zc), fy1 = y1 * ((y1 > 0.) ? zc : z[on]);
+        gz[(size_t)(k - 1) * nA + o] = (zc * ar + fx0 - fx1 + fy0 - fy1) / (ar + x0 - x1 + y0 - y1);
+      }
+      double below = gz[(size_t)km * nA + o];
+      ws[o] = (zs[o] - below) * rdt;
+      for (int k = km; k >= 1; k--) {
+        const double v = dmax(gz[(size_t)(k - 1) * nA + o], below + kDzMin);
+        gz[(size_t)(k - 1) * nA + o] = v;
+        below = v;
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// The semi-implicit solver for one column (SIM1_solver nh_utils.F90:1277-1394 when sim1, SIM_solver
+// :1396-1537 otherwise).  Column data are addressed as base[(k-1)*ls] (k = 1..km).  Scratch slabs
+// s_gam, s_pp, s_w, s_pm (each (km+1) levels, same addressing).  On exit: s_pp[k] = pe2(k) (k=1..km+1)
+// -- the nonhydrostatic pressure perturbation -- s_w[k] = w2(k), and dz2 is returned through the
+// callback-free convention: s_gam[k] = dz2(k) (k = 1..km).
+struct ColIn {
+  const double *delp, *pt, *w, *zlev;  // zlev: gz (C) or zh (D) interface heights, km+1 levels
+  double zscale;                       // dz2 = (zlev(k+1)-zlev(k)) * zscale   (1 for both; kept for clarity)
+};
+
+FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhConsts &cn, bool sim1, bool c_grid,
+                       double ws, double *s_gam, double *s_pp, double *s_w, double *s_pm) {
+  constexpr double r3 = 1. / 3.;
+  const double rgrav = 1. / cn.grav, rgas = cn.rdgas;
+  const double gm2 = 1. / (1. - cn.akap), cp2 = cn.akap;
+  const double alpha = cn.a_imp, beta = 1. - alpha, ra = 1. / alpha, t2 = beta / alpha;
+  const double t1g = sim1 ? 2. * dt * dt : 2. * ((alpha * dt) * (alpha * dt));
+  const double rdt = 1. / dt;
+#define L(p, k) (p)[(size_t)((k)-1) * ls]
+  // ---- pass A: pe(k), pm2(k); forward elimination for pp (:1297-1326) ----
+  double pem_k = cn.ptop, peln_k = log(cn.ptop);
+  auto level = [&](int k, double &dm2, double &dz2, double &pm2, double &pe, double &pem_next, double &peln_next) {
+    const double dmr = L(in.delp, k);
+    pem_next = pem_k + dmr;
+    if (c_grid) {
+      pm2 = dmr / log(pem_next / pem_k);  // nh_utils.F90:440
+      peln_next = 0.;
+    } else {
+      peln_next = log(pem_next);          // nh_core.F90:140,159
+      pm2 = dmr / (peln_next - peln_k);
+    }
+    dm2 = dmr * rgrav;
+    dz2 = L(in.zlev, k + 1) - L(in.zlev, k);
+    pe = exp(gm2 * log(-dm2 / dz2 * rgas * L(in.pt, k))) - pm2;
+  };
+  double dm_c, dz_c, pm_c, pe_c, pem_n, peln_n;
+  level(1, dm_c, dz_c, pm_c, pe_c, pem_n, peln_n);
+  L(s_pm, 1) = pm_c;
+  double bet = 0., pp_k = 0., g_rat_prev = 0.;
+  L(s_pp, 1) = 0.;
+  for (int k = 1; k <= km; k++) {
+    double dm_n = 0., dz_n = 0., pm_n = 0., pe_n = 0., pem_nn = 0., peln_nn = 0.;
+    double bb, dd, g_rat = 0.;
+    if (k < km) {
+      pem_k = pem_n;
+      peln_k = peln_n;
+      level(k + 1, dm_n, dz_n, pm_n, pe_n, pem_nn, peln_nn);
+      L(s_pm, k + 1) = pm_n;
+      g_rat = dm_c / dm_n;
+      bb = 2. * (1. + g_rat);
+      dd = 3. * (pe_c + g_rat * pe_n);
+    } else {
+      bb = 2.;
+      dd = 3. * pe_c;
+    }
+    if (k == 1) {
+      bet = bb;
+      pp_k = dd / bet;  // pp(2)
+    } else {
+      const double gam = g_rat_prev / bet;
+      bet = bb - gam;
+      L(s_gam, k) = gam;
+      pp_k = (dd - pp_k) / bet;  // pp(k+1)
+    }
+    L(s_pp, k + 1) = pp_k;
+    g_rat_prev = g_rat;
+    dm_c = dm_n; dz_c = dz_n; pm_c = pm_n; pe_c = pe_n; pem_n = pem_nn; peln_n = peln_nn;
+  }
+  // ---- pass B: back substitution (:1328-1332) ----
+  {
+    double pp_next = L(s_pp, km + 1);
+    for (int k = km; k >= 2; k--) {
+      const double v = L(s_pp, k) - L(s_gam, k) * pp_next;
+      L(s_pp, k) = v;
+      pp_next = v;
+    }
+  }
+  // ---- pass C: forward sweep of the w solver (:1335-1356 / :1463-1491) ----
+  {
+    double pem = cn.ptop;                       // pem(k)
+    double dz_prev = 0., w_prev = 0., w1_prev = 0., aa_k = 0., wk_k = 0.;
+    double dm1 = 0.;
+    for (int k = 1; k <= km; k++) {
+      const double dmr = L(in.delp, k), dm2 = dmr * rgrav;
+      const double dz2 = L(in.zlev, k + 1) - L(in.zlev, k);
+      const double w1 = L(in.w, k);
+      if (k == 1) dm1 = dm2;
+      // aa(k+1), wk(k+1) need level k+1
+      double aa_n = 0., wk_n = 0., pem_next = pem + dmr;
+      if (k < km) {
+        const double dz_n = L(in.zlev, k + 2) - L(in.zlev, k + 1);
+        aa_n = t1g * 0.5 * (gm2 + gm2) / (dz2 + dz_n) * pem_next;
+        if (!sim1) {
+          wk_n = t2 * aa_n * (w1 - L(in.w, k + 1));
+          aa_n = aa_n - 0.0 * dm1;  // scale_m = 0 (nh_utils.F90:1467)
+        }
+      }
+      double w2;
+      if (k == 1) {
+        bet = dm2 - aa_n;
+        w2 = sim1 ? (dm2 * w1 + dt * L(s_pp, 2)) / bet : (dm2 * w1 + dt * L(s_pp, 2) + wk_n) / bet;
+      } else if (k < km) {
+        const double gam = aa_k / bet;
+        bet = dm2 - (aa_k + aa_n + aa_k * gam);
+        L(s_gam, k) = gam;
+        w2 = sim1 ? (dm2 * w1 + dt * (L(s_pp, k + 1) - L(s_pp, k)) - aa_k * w_prev) / bet
+                  : (dm2 * w1 + dt * (L(s_pp, k + 1) - L(s_pp, k)) + wk_n - wk_k - aa_k * w_prev) / bet;
+      } else {
+        const double p1 = t1g * gm2 / dz2 * pem_next;  // pem(km+1)
+        const double gam = aa_k / bet;
+        bet = dm2 - (aa_k + p1 + aa_k * gam);
+        L(s_gam, k) = gam;
+        w2 = sim1 ? (dm2 * w1 + dt * (L(s_pp, k + 1) - L(s_pp, k)) - p1 * ws - aa_k * w_prev) / bet
+                  : (dm2 * w1 + dt * (L(s_pp, k + 1) - L(s_pp, k)) - wk_k + p1 * (t2 * w1 - ra * ws) - aa_k * w_prev) / bet;
+      }
+      L(s_w, k) = w2;
+      w_prev = w2;
+      w1_prev = w1;
+      dz_prev = dz2;
+      aa_k = aa_n;
+      wk_k = wk_n;
+      pem = pem_next;
+    }
+    (void)w1_prev; (void)dz_prev;
+  }
+  // ---- pass D: back substitution for w (:1357-1361) ----
+  {
+    double w_next = L(s_w, km);
+    for (int k = km - 1; k >= 1; k--) {
+      const double v = L(s_w, k) - L(s_gam, k + 1) * w_next;
+      L(s_w, k) = v;
+      w_next = v;
+    }
+  }
+  // ---- pass E: pe(k+1) = pe(k) + dm2*(w2-w1)*rdt (:1373-1380 / :1508-1516); pp kept for the SIM blend ----
+  {
+    double pe = 0.;
+    double pp_k2 = L(s_pp, 1);
+    // s_gam is free now: keep pp there for the final blend of SIM_solver (:1531-1535)
+    for (int k = 1; k <= km; k++) {
+      const double dm2 = L(in.delp, k) * rgrav;
+      const double pp_n = L(s_pp, k + 1);
+      L(s_pp, k) = pe;
+      if (!sim1) L(s_gam, k) = pp_k2;
+      if (sim1)
+        pe = pe + dm2 * (L(s_w, k) - L(in.w, k)) * rdt;
+      else
+        pe = pe + (dm2 * (L(s_w, k) - L(in.w, k)) * rdt - beta * (pp_n - pp_k2)) * ra;
+      pp_k2 = pp_n;
+    }
+    L(s_pp, km + 1) = pe;
+    if (!sim1) L(s_gam, km + 1) = pp_k2;
+  }
+  // ---- pass F: new layer thickness (:1382-1392 / :1518-1529); dz2 -> s_pm (pm2 consumed level by level)
+  {
+    double p1 = (L(s_pp, km) + 2. * L(s_pp, km + 1)) * r3;
+    double dm_below = 0.;
+    for (int k = km; k >= 1; k--) {
+      const double dm2 = L(in.delp, k) * rgrav, pm2 = L(s_pm, k);
+      if (k < km) {
+        const double g_rat = dm2 / dm_below, bb = 2. * (1. + g_rat);
+        p1 = (L(s_pp, k) + bb * L(s_pp, k + 1) + g_rat * L(s_pp, k + 2)) * r3 - g_rat * p1;
+      }
+      L(s_pm, k) = -dm2 * rgas * L(in.pt, k) * exp((cp2 - 1.) * log(dmax(cn.p_fac * pm2, p1 + pm2)));
+      dm_below = dm2;
+    }
+  }
+  if (!sim1) {  // pe2 = pe2 + beta*(pp - pe2) (:1531-1535)
+    for (int k = 1; k <= km + 1; k++) L(s_pp, k) = L(s_pp, k) + beta * (L(s_gam, k) - L(s_pp, k));
+  }
+#undef L
+}
+
+struct RiemSolverC {
+  Grid g;
+  int km;
+  double dt;
+  NhConsts cn;
+  const double *hs, *w3, *pt, *delp, *ws;
+  double *gz, *pef;
+  double *s0, *s1, *s2, *s3;  // scratch slabs, A x (km+1)
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int w = g.nx + 2, ncol = w * (g.ny + 2);
+    const size_t nA = g.nA();
+    FV3_COL_FOR(c, ncol) {
+      const int i = g.is - 1 + c % w, j = g.js - 1 + c / w;
+      const int o = g.iA(i, j);
+      ColIn in{delp + o, pt + o, w3 + o, gz + o, 1.};
+      sim_column(km, nA, in, dt, cn, true, true, ws[o], s0 + o, s1 + o, s2 + o, s3 + o);
+      // pef = pe2 + pem (:461-465); gz = hs - sum dz2*grav (:468-476)
+      double pem = cn.ptop;
+      pef[o] = cn.ptop;
+      for (int k = 2; k <= km + 1; k++) {
+        pem = pem + delp[(size_t)(k - 2) * nA + o];
+        pef[(size_t)(k - 1) * nA + o] = s1[(size_t)(k - 1) * nA + o] + pem;
+      }
+      double zb = hs[o];
+      gz[(size_t)km * nA + o] = zb;
+      for (int k = km; k >= 1; k--) {
+        zb = zb - s3[(size_t)(k - 1) * nA + o] * cn.grav;
+        gz[(size_t)(k - 1) * nA + o] = zb;
+      }
+    }
+  }
+};
+
+struct RiemSolver3 {
+  Grid g;
+  int km;
+  double dt;
+  NhConsts cn;
+  const double *zs, *pt, *delp, *ws;
+  double *w, *delz, *zh, *pe, *ppe, *pk3, *pk, *peln;
+  int use_logp, last_call, fp_out;
+  double *s0, *s1, *s2, *s3;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int ncol = g.nx * g.ny;
+    const size_t nA = g.nA(), nCC = g.nCC();
+    const bool sim1 = cn.a_imp > 0.999;
+    const double peln1 = log(cn.ptop), ptk = exp(cn.akap * peln1);
+    FV3_COL_FOR(c, ncol) {
+      const int i = g.is + c % g.nx, j = g.js + c / g.nx;
+      const int o = g.iA(i, j), occ = g.iCC(i, j);
+      ColIn in{delp + o, pt + o, w + o, zh + o, 1.};
+      sim_column(km, nA, in, dt, cn, sim1, false, ws[occ], s0 + o, s1 + o, s2 + o, s3 + o);
+      // hydrostatic pressure functions (:132-143), outputs (:191-237)
+      double pem = cn.ptop;
+      pk3[o] = ptk;
+      if (last_call) {
+        peln[(size_t)(j - g.js) * g.nx * (km + 1) + (i - g.is)] = peln1;
+        pk[occ] = ptk;
+        pe[(size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1))] = cn.ptop;
+      }
+      ppe[o] = fp_out ? s1[o] + pem : s1[o];
+      for (int k = 2; k <= km + 1; k++) {
+        pem = pem + delp[(size_t)(k - 2) * nA + o];
+        const double pl = log(pem), pkv = exp(cn.akap * pl);
+        pk3[(size_t)(k - 1) * nA + o] = use_logp ? pl : pkv;
+        if (last_call) {
+          peln[(size_t)(j - g.js) * g.nx * (km + 1) + (size_t)(k - 1) * g.nx + (i - g.is)] = pl;
+          pk[(size_t)(k - 1) * nCC + occ] = pkv;
+          pe[(size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (size_t)(k - 1) * (g.nx + 2) + (i - (g.is - 1))] = pem;
+        }
+        const double p2 = s1[(size_t)(k - 1) * nA + o];
+        ppe[(size_t)(k - 1) * nA + o] = fp_out ? p2 + pem : p2;
+      }
+      double zb = zs[o];
+      zh[(size_t)km * nA + o] = zb;
+      for (int k = km; k >= 1; k--) {
+        const double dz = s3[(size_t)(k - 1) * nA + o];
+        w[(size_t)(k - 1) * nA + o] = s2[(size_t)(k - 1) * nA + o];
+        delz[(size_t)(k - 1) * nCC + occ] = dz;
+        zb = zb - dz;
+        zh[(size_t)(k - 1) * nA + o] = zb;
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// edge_profile (non-uniform branch, limiter=0).  gk[k], bet[k], gam[k] (k = 1..km, index k-1) and the
+// end coefficients depend only on dp0 and are precomputed on the host with the reference's arithmetic.
+struct EdgeCoef {
+  const double *gk, *bet, *gam;  // device, km each (gk[0] unused)
+  double xt1_top, bet_top, xt1_bot, a_bot, gk_bot;
+};
+
+struct EdgeProfile {
+  Grid g;
+  int km;
+  EdgeCoef ec;
+  const double *q1, *q2;  // km levels
+  double *q1e, *q2e;      // km+1 levels
+  int n2d;                // points per level (nCX or nCY)
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    FV3_COL_FOR(c, n2d) {
+      const size_t ls = (size_t)n2d;
+      double a_prev = q1[c], b_prev = q2[c];
+      double a_cur = q1[ls + c], b_cur = q2[ls + c];
+      double e1 = (ec.xt1_top * a_prev + a_cur) / ec.bet_top, e2 = (ec.xt1_top * b_prev + b_cur) / ec.bet_top;
+      q1e[c] = e1;
+      q2e[c] = e2;
+      for (int k = 2; k <= km; k++) {
+        a_cur = q1[(size_t)(k - 1) * ls + c];
+        b_cur = q2[(size_t)(k - 1) * ls + c];
+        const double gk = ec.gk[k - 1], bet = ec.bet[k - 1];
+        e1 = (3. * (a_prev + gk * a_cur) - e1) / bet;
+        e2 = (3. * (b_prev + gk * b_cur) - e2) / bet;
+        q1e[(size_t)(k - 1) * ls + c] = e1;
+        q2e[(size_t)(k - 1) * ls + c] = e2;
+        if (k < km) {
+          a_prev = a_cur;
+          b_prev = b_cur;
+        }
+      }
+      // a_prev = q(km-1), a_cur = q(km)
+      const double xt2 = ec.gk_bot * (ec.gk_bot + 0.5) - ec.a_bot * ec.gam[km - 1];
+      e1 = (ec.xt1_bot * a_cur + a_prev - ec.a_bot * e1) / xt2;
+      e2 = (ec.xt1_bot * b_cur + b_prev - ec.a_bot * e2) / xt2;
+      q1e[(size_t)km * ls + c] = e1;
+      q2e[(size_t)km * ls + c] = e2;
+      for (int k = km; k >= 1; k--) {
+        e1 = q1e[(size_t)(k - 1) * ls + c] - ec.gam[k - 1] * e1;
+        e2 = q2e[(size_t)(k - 1) * ls + c] - ec.gam[k - 1] * e2;
+        q1e[(size_t)(k - 1) * ls + c] = e1;
+        q2e[(size_t)(k - 1) * ls + c] = e2;
+      }
+    }
+  }
+};
+
+// fv_tp_2d of every interface height + the flux-form update (update_dz_d :256-301)
+template <int TI, int TJ>
+struct ZhTransport {
+  Grid g;
+  int hord;
+  const double *zh, *crx, *cry, *xfx, *yfx;  // interface-level Courant numbers / fluxes (km+1 levels)
+  const int *ndif;                            // device, km+1
+  const double *damp;                         // device, km+1
+  double *zh_out;
+  using TS = Tp2dScratch<TI, TJ>;
+  using DS = DelnScratch<TI, TJ>;
+  static constexpr int nQ = (TI + 6) * (TJ + 6);
+  static constexpr int nScr = TS::total > DS::total ? TS::total : DS::total;
+  static constexpr int nFXt = (TI + 1) * TJ, nFYt = TI * (TJ + 1);
+  static constexpr int lds_doubles = nQ + nScr + nFXt + nFYt + TI * TJ;
+  FV3_HD void operator()(int bx, int by, int bz, int tid, double *lds) const {
+    const int k = bz;
+    const TileBox b = make_box<TI, TJ>(g, bx, by);
+    const int i0 = b.i0, j0 = b.j0;
+    const size_t oA = (size_t)k * g.nA(), oCX = (size_t)k * g.nCX(), oCY = (size_t)k * g.nCY();
+    const double *cx = crx + oCX, *xf = xfx + oCX, *cy = cry + oCY, *yf = yfx + oCY;
+    double *p = lds;
+    const Tile sq{p, i0 - 3, j0 - 3, TI + 6}; p += nQ;
+    double *scr = p; p += nScr;
+    const Tile sfx{p, i0, j0, TI + 1}; p += nFXt;
+    const Tile sfy{p, i0, j0, TI}; p += nFYt;
+    const Tile cz{p, i0, j0, TI}; p += TI * TJ;
+    load_tile<TI + 6, TJ + 6>(sq, zh + oA, g.nid, g.isd, g.ied, g.jsd, g.jed, tid);
+    FV3_SYNC();
+    tp2d_tile<TI, TJ>(g, b, tid, sq, cx, cy, xf, yf, nullptr, nullptr, hord, scr, sfx, sfy);
+    FV3_TILE_FOR(TI, TJ, li_, lj_) {
+      const int i = i0 + li_, j = j0 + lj_;
+      if (i > b.ilast || j > b.jlast) continue;
+      const double ar = g.area[g.iA(i, j)];
+      const double x0 = xf[g.iCX(i, j)], x1 = xf[g.iCX(i + 1, j)], y0 = yf[g.iCY(i, j)], y1 = yf[g.iCY(i, j + 1)];
+      const double fx0 = sfx(i, j) * x0, fx1 = sfx(i + 1, j) * x1, fy0 = sfy(i, j) * y0, fy1 = sfy(i, j + 1) * y1;
+      const double rax = ar + x0 - x1, ray = ar + y0 - y1;
+      cz(i, j) = (sq(i, j) * ar + fx0 - fx1 + fy0 - fy1) / (rax + ray - ar);
+    }
+    FV3_SYNC();
+    const double dmp = damp[k];
+    if (dmp > 1.E-5) {
+      Tile fxd, fyd;
+      deln_tile<TI, TJ>(g, b, tid, sq, ndif[k], dmp, true, scr, fxd, fyd);
+      FV3_TILE_FOR(TI, TJ, li_, lj_) {
+        const int i = i0 + li_, j = j0 + lj_;
+        if (i > b.ilast || j > b.jlast) continue;
+        zh_out[oA + g.iA(i, j)] =
+            cz(i, j) + (fxd(i, j) - fxd(i + 1, j) + fyd(i, j) - fyd(i, j + 1)) * g.rarea[g.iA(i, j)];
+      }
+    } else {
+      FV3_TILE_FOR(TI, TJ, li_, lj_) {
+        const int i = i0 + li_, j = j0 + lj_;
+        if (i > b.ilast || j > b.jlast) continue;
+        zh_out[oA + g.iA(i, j)] = cz(i, j);
+      }
+    }
+  }
+};
+
+struct ZhLimit {  // update_dz_d :303-319
+  Grid g;
+  int km;
+  double rdt;
+  const double *zs;
+  double *zh, *ws;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int ncol = g.nx * g.ny;
+    const size_t nA = g.nA();
+    FV3_COL_FOR(c, ncol) {
+      const int i = g.is + c % g.nx, j = g.js + c / g.nx;
+      const int o = g.iA(i, j);
+      double below = zh[(size_t)km * nA + o];
+      ws[g.iCC(i, j)] = (zs[o] - below) * rdt;
+      for (int k = km; k >= 1; k--) {
+        const double v = dmax(zh[(size_t)(k - 1) * nA + o], below + kDzMin);
+        zh[(size_t)(k - 1) * nA + o] = v;
+        below = v;
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+struct PGradC {  // p_grad_c, dyn_core.F90:1635-1694
+  Grid g;
+  double dt2;
+  int hydrostatic;
+  const double *delpc, *pkc, *gz;
+  double *uc, *vc;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int k = bz;  // 0-based level
+    const size_t nA = g.nA();
+    const double *pk0 = pkc + (size_t)k * nA, *pk1 = pk0 + nA, *gz0 = gz + (size_t)k * nA, *gz1 = gz0 + nA;
+    const double *dpc = delpc + (size_t)k * nA;
+    const int w = g.nx + 1, n = w * (g.ny + 1);
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.is + idx % w, j = g.js + idx / w;
+      const int o = g.iA(i, j), ow = g.iA(i - 1, j), os = g.iA(i, j - 1);
+      const double wk0 = hydrostatic ? pk1[o] - pk0[o] : dpc[o];
+      if (j <= g.je) {
+        const double wkw = hydrostatic ? pk1[ow] - pk0[ow] : dpc[ow];
+        double *p = uc + (size_t)k * g.nV() + g.iV(i, j);
+        *p = *p + dt2 * g.rdxc[g.iV(i, j)] / (wkw + wk0) *
+                      ((gz1[ow] - gz0[o]) * (pk1[o] - pk0[ow]) + (gz0[ow] - gz1[o]) * (pk1[ow] - pk0[o]));
+      }
+      if (i <= g.ie) {
+        const double wks = hydrostatic ? pk1[os] - pk0[os] : dpc[os];
+        double *p = vc + (size_t)k * g.nU() + g.iU(i, j);
+        *p = *p + dt2 * g.rdyc[g.iU(i, j)] / (wks + wk0) *
+                      ((gz1[os] - gz0[o]) * (pk1[o] - pk0[os]) + (gz0[os] - gz1[o]) * (pk1[os] - pk0[o]));
+      }
+    }
+  }
+};
+
+// a2b_ord4, doubly periodic branch (a2b_edge.F90:292-315), for up to 4 fields of one level: corner values on
+// [is, ie+1] x [js, je+1] written to separate B-position slabs stored with the A layout (corner (i,j) at iA(i,j)).
+template <int TI, int TJ>
+struct A2BCorners {
+  Grid g;
+  const double *in[4];
+  double *out[4];
+  int nlev[4];      // number of levels of each field (npz+1 or npz)
+  int nf;
+  double top_pp, top_pk;  // level-1 overrides of fields 0 and 1 (nh_p_grad :1732-1738); used when override1 != 0
+  int override1;
+  static constexpr int W = TI + 5, H = TJ + 5;  // corners [i0, i0+TI] need cells [i0-2, i0+TI+1]
+  static constexpr int lds_doubles = W * H;
+  FV3_HD void operator()(int bx, int by, int bz, int tid, double *lds) const {
+    constexpr double a1 = 0.5625, a2 = -0.0625, b1 = 7. / 12., b2 = -1. / 12.;
+    const int k = bz;
+    const int i0 = g.is + bx * TI, j0 = g.js + by * TJ;
+    const Tile s{lds, i0 - 2, j0 - 2, W};
+    for (int f = 0; f < nf; f++) {
+      if (k >= nlev[f]) continue;
+      double *o = out[f] + (size_t)k * g.nA();
+      if (override1 && k == 0 && f < 2) {
+        FV3_TILE_FOR(TI, TJ, li_, lj_) {
+          const int i = i0 + li_, j = j0 + lj_;
+          if (i > g.ie + 1 || j > g.je + 1) continue;
+          o[g.iA(i, j)] = (f == 0) ? top_pp : top_pk;
+        }
+        continue;
+      }
+      FV3_SYNC();
+      load_tile<W, H>(s, in[f] + (size_t)k * g.nA(), g.nid, g.isd, g.ied, g.jsd, g.jed, tid);
+      FV3_SYNC();
+      FV3_TILE_FOR(TI, TJ, li_, lj_) {
+        const int i = i0 + li_, j = j0 + lj_;
+        if (i > g.ie + 1 || j > g.je + 1) continue;
+        double qx[4], qy[4];
+        for (int t = 0; t < 4; t++) {
+          const int jj = j - 2 + t, ii = i - 2 + t;
+          qx[t] = b1 * (s(i - 1, jj) + s(i, jj)) + b2 * (s(i - 2, jj) + s(i + 1, jj));
+          qy[t] = b1 * (s(ii, j - 1) + s(ii, j)) + b2 * (s(ii, j - 2) + s(ii, j + 1));
+        }
+        o[g.iA(i, j)] = 0.5 * (a1 * (qx[1] + qx[2] + qy[1] + qy[2]) + a2 * (qx[0] + qx[3] + qy[0] + qy[3]));
+      }
+    }
+  }
+};
+
+struct NhPGrad {  // nh_p_grad :1746-1790 on precomputed corner values
+  Grid g;
+  double dt;
+  const double *pp, *pk, *gz, *dpc;  // corner slabs: pp, pk, gz (npz+1 levels), delp (npz levels)
+  double *u, *v;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int k = bz;
+    const size_t nA = g.nA();
+    const double *pp0 = pp + (size_t)k * nA, *pp1 = pp0 + nA, *pk0 = pk + (size_t)k * nA, *pk1 = pk0 + nA;
+    const double *gz0 = gz + (size_t)k * nA, *gz1 = gz0 + nA, *w1 = dpc + (size_t)k * nA;
+    const int w = g.nx + 1, n = w * (g.ny + 1);
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.is + idx % w, j = g.js + idx / w;
+      const int o = g.iA(i, j), oe = g.iA(i + 1, j), on = g.iA(i, j + 1);
+      const double wk0 = pk1[o] - pk0[o];
+      if (i <= g.ie) {
+        const double wke = pk1[oe] - pk0[oe];
+        const double du1 = dt / (wk0 + wke) * ((gz1[o] - gz0[oe]) * (pk1[oe] - pk0[o]) + (gz0[o] - gz1[oe]) * (pk1[o] - pk0[oe]));
+        double *p = u + (size_t)k * g.nU() + g.iU(i, j);
+        *p = (*p + du1 +
+              dt / (w1[o] + w1[oe]) * ((gz1[o] - gz0[oe]) * (pp1[oe] - pp0[o]) + (gz0[o] - gz1[oe]) * (pp1[o] - pp0[oe]))) *
+             g.rdx[g.iU(i, j)];
+      }
+      if (j <= g.je) {
+        const double wkn = pk1[on] - pk0[on];
+        const double dv1 = dt / (wk0 + wkn) * ((gz1[o] - gz0[on]) * (pk1[on] - pk0[o]) + (gz0[o] - gz1[on]) * (pk1[o] - pk0[on]));
+        double *p = v + (size_t)k * g.nV() + g.iV(i, j);
+        *p = (*p + dv1 +
+              dt / (w1[o] + w1[on]) * ((gz1[o] - gz0[on]) * (pp1[on] - pp0[o]) + (gz0[o] - gz1[on]) * (pp1[o] - pp0[on]))) *
+             g.rdy[g.iV(i, j)];
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// pk3_halo / pln_halo: the 2-wide ring [is-2,ie+2]^2 minus the compute domain (dyn_core.F90:1395-1496)
+struct Pk3Halo {
+  Grid g;
+  int npz, use_logp;
+  double ptop, akap;
+  const double *delp;
+  double *pk3;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int w = g.nx + 4, ncol = w * (g.ny + 4);
+    const size_t nA = g.nA();
+    FV3_COL_FOR(c, ncol) {
+      const int i = g.is - 2 + c % w, j = g.js - 2 + c / w;
+      if (i >= g.is && i <= g.ie && j >= g.js && j <= g.je) continue;
+      const int o = g.iA(i, j);
+      double pet = ptop;
+      for (int k = 1; k <= npz; k++) {
+        pet = pet + delp[(size_t)(k - 1) * nA + o];
+        pk3[(size_t)k * nA + o] = use_logp ? log(pet) : exp(akap * log(pet));
+      }
+    }
+  }
+};
+
+struct PeHalo {  // pe_halo, dyn_core.F90:1498-1526: the 1-wide ring of pe(is-1:ie+1, npz+1, js-1:je+1)
+  Grid g;
+  int npz;
+  double ptop;
+  const double *delp;
+  double *pe;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int w = g.nx + 2, ncol = w * (g.ny + 2);
+    const size_t nA = g.nA();
+    FV3_COL_FOR(c, ncol) {
+      const int i = g.is - 1 + c % w, j = g.js - 1 + c / w;
+      if (i >= g.is && i <= g.ie && j >= g.js && j <= g.je) continue;
+      // the reference fills (is-1|ie+1, js:je) and (is-1:ie+1, js-1|je+1): all ring points
+      const int o = g.iA(i, j);
+      const size_t pb = (size_t)(j - (g.js - 1)) * (g.nx + 2) * (npz + 1) + (i - (g.is - 1));
+      double p = ptop;
+      pe[pb] = p;
+      for (int k = 1; k <= npz; k++) {
+        p = p + delp[(size_t)(k - 1) * nA + o];
+        pe[pb + (size_t)k * (g.nx + 2)] = p;
+      }
+    }
+  }
+};
+
+struct Geopk {  // geopk, dyn_core.F90:2202-2353 (use_cond = .false.)
+  Grid g;
+  int km, CG;
+  double ptop, akap, cp_air, ptk;
+  const double *delp, *hs, *pt;
+  double *pe, *peln, *pk, *gz, *pkz;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int e = CG ? 1 : 2;
+    const int w = g.nx + 2 * e, ncol = w * (g.ny + 2 * e);
+    const size_t nA = g.nA(), nCC = g.nCC();
+    const double peln1 = log(ptop);
+    FV3_COL_FOR(c, ncol) {
+      const int i = g.is - e + c % w, j = g.js - e + c / w;
+      const int o = g.iA(i, j);
+      const bool in_pe = (j > g.js - 2 && j < g.je + 2 && i >= g.is - 1 && i <= g.ie + 1);
+      const bool in_c = (j >= g.js && j <= g.je && i >= g.is && i <= g.ie);
+      const size_t pb = in_pe ? (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1)) : 0;
+      const size_t lb = in_c ? (size_t)(j - g.js) * g.nx * (km + 1) + (i - g.is) : 0;
+      double p1d = ptop;
+      pk[o] = ptk;
+      if (in_c) peln[lb] = peln1;
+      if (in_pe) pe[pb] = ptop;
+      for (int k = 2; k <= km + 1; k++) {
+        p1d = p1d + delp[(size_t)(k - 2) * nA + o];
+        const double logp = log(p1d);
+        pk[(size_t)(k - 1) * nA + o] = exp(akap * logp);
+        if (in_pe) pe[pb + (size_t)(k - 1) * (g.nx + 2)] = p1d;
+        if (in_c) peln[lb + (size_t)(k - 1) * g.nx] = logp;
+      }
+      double zb = hs[o];
+      gz[(size_t)km * nA + o] = zb;
+      for (int k = km; k >= 1; k--) {
+        zb = zb + cp_air * pt[(size_t)(k - 1) * nA + o] * (pk[(size_t)k * nA + o] - pk[(size_t)(k - 1) * nA + o]);
+        gz[(size_t)(k - 1) * nA + o] = zb;
+      }
+      if (!CG && in_c) {
+        for (int k = 1; k <= km; k++)
+          pkz[(size_t)(k - 1) * nCC + g.iCC(i, j)] =
+              (pk[(size_t)k * nA + o] - pk[(size_t)(k - 1) * nA + o]) /
+              (akap * (peln[lb + (size_t)k * g.nx] - peln[lb + (size_t)(k - 1) * g.nx]));
+      }
+    }
+  }
+};
+
+}  // namespace fv3

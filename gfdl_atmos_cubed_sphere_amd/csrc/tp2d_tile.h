@@ -33,11 +33,10 @@ FV3_HD TileBox make_box(const Grid &g, int bx, int by) {
 // array are set to 0 (they are never used for a value that is kept).
 template <int W, int H>
 FV3_HD void load_tile(const Tile &t, const double *src, int ld, int ilo, int ihi, int jlo, int jhi, int tid) {
-  for (int idx = tid; idx < W * H; idx += kNT) {
-    const int li = idx % W, lj = idx / W;
+  FV3_TILE_FOR(W, H, li, lj) {
     const int i = t.i0 + li, j = t.j0 + lj;
     double v = 0.;
-    if (i >= ilo && i <= ihi && j >= jlo && j <= jhi) v = src[(size_t)(j - jlo) * ld + (i - ilo)];
+    if (i >= ilo && i <= ihi && j >= jlo && j <= jhi) v = src[(j - jlo) * ld + (i - ilo)];
     t.p[lj * t.pitch + li] = v;
   }
 }
@@ -72,28 +71,28 @@ FV3_HD void tp2d_tile(const Grid &g, const TileBox &b, int tid, const Tile &sq, 
   const double lim = g.lim_fac;
 
   // S1: inner sweeps on the unmodified field (tp_core.F90:147 and :168)
-  for (int idx = tid; idx < WQ * (TJ + 1); idx += kNT) {
-    const int i = i0 - 3 + idx % WQ, j = j0 + idx / WQ;
+  FV3_TILE_FOR(WQ, (WQ * (TJ + 1)) / WQ, li_, lj_) {
+    const int i = i0 - 3 + li_, j = j0 + lj_;
     if (i > b.ilast + 3 || j > b.jlast + 1) continue;
     sfy2(i, j) = ppm_face_tp(&sq(i, j), sq.pitch, cry[g.iCY(i, j)], ord_in, lim);
   }
-  for (int idx = tid; idx < (TI + 1) * HQ; idx += kNT) {
-    const int i = i0 + idx % (TI + 1), j = j0 - 3 + idx / (TI + 1);
+  FV3_TILE_FOR((TI + 1), ((TI + 1) * HQ) / (TI + 1), li_, lj_) {
+    const int i = i0 + li_, j = j0 - 3 + lj_;
     if (i > b.ilast + 1 || j > b.jlast + 3) continue;
     sfx2(i, j) = ppm_face_tp(&sq(i, j), 1, crx[g.iCX(i, j)], ord_in, lim);
   }
   FV3_SYNC();
   // S2: intermediate fields q_i (:150-159) and q_j (:171-178)
-  for (int idx = tid; idx < WQ * TJ; idx += kNT) {
-    const int i = i0 - 3 + idx % WQ, j = j0 + idx / WQ;
+  FV3_TILE_FOR(WQ, (WQ * TJ) / WQ, li_, lj_) {
+    const int i = i0 - 3 + li_, j = j0 + lj_;
     if (i > b.ilast + 3 || j > b.jlast) continue;
     const double y0 = yfx[g.iCY(i, j)], y1 = yfx[g.iCY(i, j + 1)], ar = g.area[g.iA(i, j)];
     const double fyy0 = y0 * sfy2(i, j), fyy1 = y1 * sfy2(i, j + 1);
     const double ray = ra_y ? ra_y[g.iRY(i, j)] : (ar + y0 - y1);
     sqi(i, j) = (sq(i, j) * ar + fyy0 - fyy1) / ray;
   }
-  for (int idx = tid; idx < TI * HQ; idx += kNT) {
-    const int i = i0 + idx % TI, j = j0 - 3 + idx / TI;
+  FV3_TILE_FOR(TI, (TI * HQ) / TI, li_, lj_) {
+    const int i = i0 + li_, j = j0 - 3 + lj_;
     if (i > b.ilast || j > b.jlast + 3) continue;
     const double x0 = xfx[g.iCX(i, j)], x1 = xfx[g.iCX(i + 1, j)], ar = g.area[g.iA(i, j)];
     const double fx10 = x0 * sfx2(i, j), fx11 = x1 * sfx2(i + 1, j);
@@ -102,14 +101,14 @@ FV3_HD void tp2d_tile(const Grid &g, const TileBox &b, int tid, const Tile &sq, 
   }
   FV3_SYNC();
   // S3: outer sweeps (:161, :180) and flux averaging
-  for (int idx = tid; idx < (TI + 1) * TJ; idx += kNT) {
-    const int i = i0 + idx % (TI + 1), j = j0 + idx / (TI + 1);
+  FV3_TILE_FOR((TI + 1), ((TI + 1) * TJ) / (TI + 1), li_, lj_) {
+    const int i = i0 + li_, j = j0 + lj_;
     if (i > b.ilast + 1 || j > b.jlast) continue;
     const double f = ppm_face_tp(&sqi(i, j), 1, crx[g.iCX(i, j)], ord_ou, lim);
     sfx(i, j) = 0.5 * (f + sfx2(i, j));
   }
-  for (int idx = tid; idx < TI * (TJ + 1); idx += kNT) {
-    const int i = i0 + idx % TI, j = j0 + idx / TI;
+  FV3_TILE_FOR(TI, (TI * (TJ + 1)) / TI, li_, lj_) {
+    const int i = i0 + li_, j = j0 + lj_;
     if (i > b.ilast || j > b.jlast + 1) continue;
     const double f = ppm_face_tp(&sqj(i, j), sqj.pitch, cry[g.iCY(i, j)], ord_ou, lim);
     sfy(i, j) = 0.5 * (f + sfy2(i, j));
@@ -139,39 +138,39 @@ FV3_HD void deln_tile(const Grid &g, const TileBox &b, int tid, const Tile &sq, 
   const int il = b.ilast, jl = b.jlast;
   {
     const int e = 1 + nord;
-    for (int idx = tid; idx < (TI + 6) * (TJ + 6); idx += kNT) {
-      const int i = i0 - 3 + idx % (TI + 6), j = j0 - 3 + idx / (TI + 6);
+    FV3_TILE_FOR((TI + 6), ((TI + 6) * (TJ + 6)) / (TI + 6), li_, lj_) {
+      const int i = i0 - 3 + li_, j = j0 - 3 + lj_;
       if (i < i0 - e || i > il + e || j < j0 - e || j > jl + e) continue;
       d2(i, j) = premul ? damp * sq(i, j) : sq(i, j);
     }
   }
   FV3_SYNC();
-  for (int idx = tid; idx < (TI + 7) * (TJ + 6); idx += kNT) {
-    const int i = i0 - 3 + idx % (TI + 7), j = j0 - 3 + idx / (TI + 7);
+  FV3_TILE_FOR((TI + 7), ((TI + 7) * (TJ + 6)) / (TI + 7), li_, lj_) {
+    const int i = i0 - 3 + li_, j = j0 - 3 + lj_;
     if (i < i0 - nord || i > il + nord + 1 || j < j0 - nord || j > jl + nord) continue;
     fxd(i, j) = g.del6_v[g.iV(i, j)] * (d2(i - 1, j) - d2(i, j));
   }
-  for (int idx = tid; idx < (TI + 6) * (TJ + 7); idx += kNT) {
-    const int i = i0 - 3 + idx % (TI + 6), j = j0 - 3 + idx / (TI + 6);
+  FV3_TILE_FOR((TI + 6), ((TI + 6) * (TJ + 7)) / (TI + 6), li_, lj_) {
+    const int i = i0 - 3 + li_, j = j0 - 3 + lj_;
     if (i < i0 - nord || i > il + nord || j < j0 - nord || j > jl + nord + 1) continue;
     fyd(i, j) = g.del6_u[g.iU(i, j)] * (d2(i, j - 1) - d2(i, j));
   }
   FV3_SYNC();
   for (int n = 1; n <= nord; n++) {
     const int nt = nord - n;
-    for (int idx = tid; idx < (TI + 6) * (TJ + 6); idx += kNT) {
-      const int i = i0 - 3 + idx % (TI + 6), j = j0 - 3 + idx / (TI + 6);
+    FV3_TILE_FOR((TI + 6), ((TI + 6) * (TJ + 6)) / (TI + 6), li_, lj_) {
+      const int i = i0 - 3 + li_, j = j0 - 3 + lj_;
       if (i < i0 - nt - 1 || i > il + nt + 1 || j < j0 - nt - 1 || j > jl + nt + 1) continue;
       d2(i, j) = (fxd(i, j) - fxd(i + 1, j) + fyd(i, j) - fyd(i, j + 1)) * g.rarea[g.iA(i, j)];
     }
     FV3_SYNC();
-    for (int idx = tid; idx < (TI + 7) * (TJ + 6); idx += kNT) {
-      const int i = i0 - 3 + idx % (TI + 7), j = j0 - 3 + idx / (TI + 7);
+    FV3_TILE_FOR((TI + 7), ((TI + 7) * (TJ + 6)) / (TI + 7), li_, lj_) {
+      const int i = i0 - 3 + li_, j = j0 - 3 + lj_;
       if (i < i0 - nt || i > il + nt + 1 || j < j0 - nt || j > jl + nt) continue;
       fxd(i, j) = g.del6_v[g.iV(i, j)] * (d2(i, j) - d2(i - 1, j));
     }
-    for (int idx = tid; idx < (TI + 6) * (TJ + 7); idx += kNT) {
-      const int i = i0 - 3 + idx % (TI + 6), j = j0 - 3 + idx / (TI + 6);
+    FV3_TILE_FOR((TI + 6), ((TI + 6) * (TJ + 7)) / (TI + 6), li_, lj_) {
+      const int i = i0 - 3 + li_, j = j0 - 3 + lj_;
       if (i < i0 - nt || i > il + nt || j < j0 - nt || j > jl + nt + 1) continue;
       fyd(i, j) = g.del6_u[g.iU(i, j)] * (d2(i, j) - d2(i, j - 1));
     }

@@ -31,7 +31,9 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 # every symbol include/fv3_mi355x.h declares (tests check the built library exports all of them)
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
-           "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_halo_fill_periodic", "fv3_profile", "fv3_profile_report"]
+           "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_halo_fill_periodic", "fv3_profile", "fv3_profile_report",
+           "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
+           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk"]
 
 
 class Fv3Error(RuntimeError):
@@ -57,6 +59,19 @@ class _DswLevels(C.Structure):
     _fields_ = [(n, _ip) for n in ["nord_k", "nord_v", "nord_w", "nord_t"]] + [(n, _dp) for n in
                                                                                  ["d2_divg", "damp_vt", "damp_w",
                                                                                   "damp_t", "d_con_k"]]
+
+
+class _NhConsts(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ["grav", "rdgas", "cp_air", "akap", "ptop", "p_fac", "a_imp"]]
+
+
+# FMS constants_mod (GFDL defaults, FMS 2024.03 constants/gfdl_constants.fh): not in the reference tree
+GRAV, RDGAS, KAPPA = 9.80, 287.04, 2.0 / 7.0
+CP_AIR = RDGAS / KAPPA
+
+
+def nh_consts(ptop, p_fac=0.05, a_imp=1.0, akap=KAPPA, grav=GRAV, rdgas=RDGAS, cp_air=CP_AIR):
+    return dict(grav=grav, rdgas=rdgas, cp_air=cp_air, akap=akap, ptop=ptop, p_fac=p_fac, a_imp=a_imp)
 
 
 class Fv3Lib:
@@ -85,7 +100,8 @@ def load() -> Fv3Lib:
     """The product library (HIP, gfx950).  Raises if it is missing."""
     global _PRODUCT
     if _PRODUCT is None:
-        _PRODUCT = Fv3Lib(PRODUCT_SO)
+        # FV3_MI355X_SO selects another build of the same HIP library (e.g. a contraction-on build)
+        _PRODUCT = Fv3Lib(os.environ.get("FV3_MI355X_SO", PRODUCT_SO))
     return _PRODUCT
 
 
@@ -252,6 +268,66 @@ class Context:
             name, n, ms = line.split()
             out[name] = (int(n), float(ms))
         return out
+
+    # -- nonhydrostatic column path -------------------------------------------------------------------
+    def _cn(self, cn: dict):
+        s = _NhConsts()
+        for k, val in cn.items():
+            setattr(s, k, val)
+        return s
+
+    def set_dp_ref(self, dp0):
+        a = np.ascontiguousarray(dp0, dtype=np.float64)
+        assert a.size == self.npz
+        self.lib.check(self.lib.dll.fv3_set_dp_ref(self.h, a.ctypes.data_as(_dp)), "fv3_set_dp_ref")
+
+    def update_dz_c(self, dt, zs, ut, vt, gz_in, gz, ws):
+        """model/nh_utils.F90:59 update_dz_c"""
+        self.lib.check(self.lib.dll.fv3_update_dz_c(self.h, C.c_double(dt), zs.p, ut.p, vt.p, gz_in.p, gz.p, ws.p),
+                       "fv3_update_dz_c")
+
+    def riem_solver_c(self, dt, cn, hs, w3, pt, delp, gz, pef, ws):
+        """model/nh_utils.F90:323 Riem_Solver_c"""
+        s = self._cn(cn)
+        self.lib.check(self.lib.dll.fv3_riem_solver_c(self.h, C.c_double(dt), C.byref(s), hs.p, w3.p, pt.p, delp.p,
+                                                      gz.p, pef.p, ws.p), "fv3_riem_solver_c")
+
+    def update_dz_d(self, hord, zs, zh_in, zh_out, crx, cry, xfx, yfx, ws, rdt):
+        """model/nh_utils.F90:204 update_dz_d"""
+        self.lib.check(self.lib.dll.fv3_update_dz_d(self.h, C.c_int(hord), zs.p, zh_in.p, zh_out.p, crx.p, cry.p,
+                                                    xfx.p, yfx.p, ws.p, C.c_double(rdt)), "fv3_update_dz_d")
+
+    def riem_solver3(self, dt, cn, zs, w, delz, pt, delp, zh, pe, ppe, pk3, pk, peln, ws, use_logp=False,
+                     last_call=False, fp_out=False):
+        """model/nh_core.F90:47 Riem_Solver3"""
+        s = self._cn(cn)
+        self.lib.check(self.lib.dll.fv3_riem_solver3(self.h, C.c_double(dt), C.byref(s), zs.p, w.p, delz.p, pt.p,
+                                                     delp.p, zh.p, _pp(pe), ppe.p, pk3.p, _pp(pk), _pp(peln), ws.p,
+                                                     C.c_int(int(use_logp)), C.c_int(int(last_call)),
+                                                     C.c_int(int(fp_out))), "fv3_riem_solver3")
+
+    def p_grad_c(self, dt2, delpc, pkc, gz, uc, vc, hydrostatic):
+        """model/dyn_core.F90:1635 p_grad_c"""
+        self.lib.check(self.lib.dll.fv3_p_grad_c(self.h, C.c_double(dt2), delpc.p, pkc.p, gz.p, uc.p, vc.p,
+                                                 C.c_int(int(hydrostatic))), "fv3_p_grad_c")
+
+    def nh_p_grad(self, u, v, pp, gz, delp, pk, dt, top_value):
+        """model/dyn_core.F90:1697 nh_p_grad"""
+        self.lib.check(self.lib.dll.fv3_nh_p_grad(self.h, u.p, v.p, pp.p, gz.p, delp.p, pk.p, C.c_double(dt),
+                                                  C.c_double(top_value)), "fv3_nh_p_grad")
+
+    def pk3_halo(self, ptop, akap, pk3, delp, use_logp=False):
+        self.lib.check(self.lib.dll.fv3_pk3_halo(self.h, C.c_double(ptop), C.c_double(akap), pk3.p, delp.p,
+                                                 C.c_int(int(use_logp))), "fv3_pk3_halo")
+
+    def pe_halo(self, ptop, pe, delp):
+        self.lib.check(self.lib.dll.fv3_pe_halo(self.h, C.c_double(ptop), pe.p, delp.p), "fv3_pe_halo")
+
+    def geopk(self, ptop, akap, cp_air, pe, peln, delp, pk, gz, hs, pt, pkz, CG):
+        """model/dyn_core.F90:2202 geopk"""
+        self.lib.check(self.lib.dll.fv3_geopk(self.h, C.c_double(ptop), C.c_double(akap), C.c_double(cp_air),
+                                              C.c_double(ptop ** akap), _pp(pe), _pp(peln), delp.p, pk.p, gz.p, hs.p,
+                                              pt.p, _pp(pkz), C.c_int(int(CG))), "fv3_geopk")
 
     def halo_fill_periodic(self, field: DeviceArray, kind: str):
         code = {"A": 0, "U": 1, "V": 2, "B": 3}[kind]

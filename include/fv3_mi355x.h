@@ -138,6 +138,60 @@ int fv3_d_sw(fv3_ctx *ctx, const fv3_dsw_params *p, double *delpc, const double 
  * start/complete_group_halo_update (tools/fv_mp_mod.F90:646-876).  kind: 0=A 1=U 2=V 3=B. */
 int fv3_halo_fill_periodic(fv3_ctx *ctx, double *field, int kind, int nk);
 
+/* ---- nonhydrostatic column path --------------------------------------------------------------------
+ * Physical constants live in FMS constants_mod (not part of the reference tree); the caller passes them. */
+typedef struct fv3_nh_consts {
+  double grav, rdgas, cp_air, akap, ptop, p_fac, a_imp;
+} fv3_nh_consts;
+
+/* dp_ref(k) = ak(k+1)-ak(k) + (bk(k+1)-bk(k))*1e5 (model/dyn_core.F90:241-244), HOST array of length npz.
+ * Also precomputes the level-only coefficients of edge_profile (model/nh_utils.F90:1640-1662). */
+int fv3_set_dp_ref(fv3_ctx *ctx, const double *dp0);
+
+/* update_dz_c -- model/nh_utils.F90:59, call site model/dyn_core.F90:525.  gz_in/gz: A x (npz+1) (the
+ * reference advects gz in place after copying zh into it, dyn_core.F90:491-521; pass zh as gz_in);
+ * ut, vt: A x npz (c_sw outputs); zs, ws: A.  Outputs valid on is-1:ie+1 x js-1:je+1. */
+int fv3_update_dz_c(fv3_ctx *ctx, double dt, const double *zs, const double *ut, const double *vt,
+                    const double *gz_in, double *gz, double *ws);
+
+/* Riem_Solver_c -- model/nh_utils.F90:323, call site model/dyn_core.F90:531 (a_imp > 0.5: SIM1_solver).
+ * hs, ws: A; w3 (=omga), pt (=ptc), delp (=delpc): A x npz; gz (in/out), pef (=pkc, out): A x (npz+1). */
+int fv3_riem_solver_c(fv3_ctx *ctx, double dt, const fv3_nh_consts *cn, const double *hs, const double *w3,
+                      const double *pt, const double *delp, double *gz, double *pef, const double *ws);
+
+/* update_dz_d -- model/nh_utils.F90:204, call site model/dyn_core.F90:911.  Uses the per-level nord_v /
+ * damp_vt uploaded with fv3_dsw_levels_upload (entry npz+1 = entry npz, nh_utils.F90:240-241).
+ * zh_in -> zh_out (A x (npz+1), compute domain written; must not alias); crx, xfx: CX x npz; cry, yfx:
+ * CY x npz; zs: A; ws: CC. */
+int fv3_update_dz_d(fv3_ctx *ctx, int hord, const double *zs, const double *zh_in, double *zh_out,
+                    const double *crx, const double *cry, const double *xfx, const double *yfx, double *ws,
+                    double rdt);
+
+/* Riem_Solver3 -- model/nh_core.F90:47, call site model/dyn_core.F90:932 (a_imp > 0.999: SIM1_solver, else
+ * SIM_solver).  w, zh in/out; delz (CC x npz), ppe (=pkc), pk3 (A x (npz+1)) out; pe (is-1:ie+1, npz+1,
+ * js-1:je+1), pk (CC x (npz+1)), peln (is:ie, npz+1, js:je) written when last_call. */
+int fv3_riem_solver3(fv3_ctx *ctx, double dt, const fv3_nh_consts *cn, const double *zs, double *w, double *delz,
+                     const double *pt, const double *delp, double *zh, double *pe, double *ppe, double *pk3,
+                     double *pk, double *peln, const double *ws, int use_logp, int last_call, int fp_out);
+
+/* p_grad_c -- model/dyn_core.F90:1635, call site :562.  uc (V x npz), vc (U x npz) updated in place. */
+int fv3_p_grad_c(fv3_ctx *ctx, double dt2, const double *delpc, const double *pkc, const double *gz, double *uc,
+                 double *vc, int hydrostatic);
+
+/* nh_p_grad -- model/dyn_core.F90:1697, call site :1032.  u (U x npz), v (V x npz) updated in place (and
+ * multiplied by rdx, rdy).  pp (=pkc), pk (=pk3), gz, delp are NOT modified (the reference overwrites them
+ * with their corner interpolants, which nothing reads afterwards). top_value = ptk or peln1 (:1723-1727). */
+int fv3_nh_p_grad(fv3_ctx *ctx, double *u, double *v, const double *pp, const double *gz, const double *delp,
+                  const double *pk, double dt, double top_value);
+
+/* pk3_halo / pln_halo (use_logp) and pe_halo -- model/dyn_core.F90:1395,1449,1498; call sites :953-958. */
+int fv3_pk3_halo(fv3_ctx *ctx, double ptop, double akap, double *pk3, const double *delp, int use_logp);
+int fv3_pe_halo(fv3_ctx *ctx, double ptop, double *pe, const double *delp);
+
+/* geopk -- model/dyn_core.F90:2202 (hydrostatic path; call sites :481 (CG=1), :906 (CG=0)).  ptk = ptop**akap. */
+int fv3_geopk(fv3_ctx *ctx, double ptop, double akap, double cp_air, double ptk, double *pe, double *peln,
+              const double *delp, double *pk, double *gz, const double *hs, const double *pt, double *pkz, int CG);
+
 /* Per-kernel timing with HIP events recorded on the context's stream around every kernel the
  * library launches (this is what bench.py's roofline figures are measured with).  report: one line
  * "label count total_ms" per kernel label since the last report; synchronises the stream. */

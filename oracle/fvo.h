@@ -141,6 +141,28 @@ int fvo_d_sw_3d(const fvo_grid *g, int npz, const fvo_dsw_par *p, const fvo_dsw_
                 double *mfx, double *mfy, double *cx, double *cy, double *crx, double *cry,
                 double *xfx, double *yfx, double *q_con, double *heat_source, double *diss_est);
 
+/* ---- nonhydrostatic column path (oracle/nh_core.c) ------------------------------------------ */
+int fvo_update_dz_c(const fvo_grid *g, int km, double dt, const double *dp0, const double *zs,
+                    const double *ut, const double *vt, double *gz, double *ws);
+int fvo_riem_solver_c(const fvo_grid *g, int km, double dt, double akap, double ptop, const double *hs,
+                      const double *w3, const double *pt, const double *delp, double *gz, double *pef,
+                      const double *ws, double p_fac, double a_imp, double grav, double rdgas);
+int fvo_riem_solver3(const fvo_grid *g, int km, double dt, double akap, double ptop, const double *zs, double *w,
+                     double *delz, const double *pt, const double *delp, double *zh, double *pe, double *ppe,
+                     double *pk3, double *pk, double *peln, const double *ws, double p_fac, double a_imp,
+                     int use_logp, int last_call, int fp_out, double grav, double rdgas);
+int fvo_update_dz_d(const fvo_grid *g, int km, int *ndif, double *damp, int hord, const double *dp0, const double *zs,
+                    double *zh, const double *crx, const double *cry, const double *xfx, const double *yfx, double *ws,
+                    double rdt);
+int fvo_p_grad_c(const fvo_grid *g, int npz, double dt2, const double *delpc, const double *pkc, const double *gz,
+                 double *uc, double *vc, int hydrostatic);
+int fvo_nh_p_grad(const fvo_grid *g, int npz, double *u, double *v, double *pp, double *gz, double *delp, double *pk,
+                  double dt, double top_value);
+int fvo_pk3_halo(const fvo_grid *g, int npz, double ptop, double akap, double *pk3, const double *delp, int use_logp);
+int fvo_pe_halo(const fvo_grid *g, int npz, double ptop, double *pe, const double *delp);
+int fvo_geopk(const fvo_grid *g, int km, double ptop, double akap, double cp_air, double *pe, double *peln,
+              const double *delp, double *pk, double *gz, const double *hs, const double *pt, double *pkz, int CG);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,617 @@
+/*
+ * oracle/nh_core.c -- CPU oracle (test infrastructure, see fvo.h) for the nonhydrostatic column
+ * path of the acoustic substep: model/nh_utils.F90 (update_dz_c, update_dz_d, edge_profile,
+ * Riem_Solver_c, SIM1_solver, SIM_solver), model/nh_core.F90 (Riem_Solver3) and the pressure
+ * gradient / halo-recompute helpers of model/dyn_core.F90 (p_grad_c, nh_p_grad, pk3_halo, pln_halo,
+ * pe_halo, geopk).  Branches: use_cond = moist_kappa = .false., fast_tau_w_sec = 0, d2bg_zq = 0,
+ * grid_type >= 3.  Physical constants (grav, rdgas, cp_air) come from FMS constants_mod, which is
+ * not part of the reference tree; they are passed in by the caller (GFDL defaults: grav=9.80,
+ * rdgas=287.04, kappa=2/7, cp_air=rdgas/kappa).
+ */
+#include "fvo.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static const double r3 = 1. / 3.;
+static const double dz_min = 2.; /* nh_utils.F90:49 */
+
+static inline double dmax(double a, double b) { return a > b ? a : b; }
+static double *dalloc(size_t n) { return (double *)calloc(n, sizeof(double)); }
+
+#define BOUNDS(g)                                                                         \
+  const int is = (g)->is, ie = (g)->ie, js = (g)->js, je = (g)->je;                       \
+  const int isd = (g)->isd, ied = (g)->ied, jsd = (g)->jsd, jed = (g)->jed;               \
+  const int nid = ied - isd + 1, njd = jed - jsd + 1, nx = ie - is + 1, ny = je - js + 1; \
+  (void)nid; (void)njd; (void)nx; (void)ny; (void)is; (void)ie; (void)js; (void)je;       \
+  (void)isd; (void)ied; (void)jsd; (void)jed
+#define IA(i, j) ((size_t)((j)-jsd) * nid + ((i)-isd))
+#define IU(i, j) ((size_t)((j)-jsd) * nid + ((i)-isd))
+#define IV(i, j) ((size_t)((j)-jsd) * (nid + 1) + ((i)-isd))
+#define IB(i, j) ((size_t)((j)-jsd) * (nid + 1) + ((i)-isd))
+#define ICX(i, j) ((size_t)((j)-jsd) * (nx + 1) + ((i)-is))
+#define ICY(i, j) ((size_t)((j)-js) * nid + ((i)-isd))
+#define IFX(i, j) ((size_t)((j)-js) * (nx + 1) + ((i)-is))
+#define IFY(i, j) ((size_t)((j)-js) * nx + ((i)-is))
+#define ICC(i, j) ((size_t)((j)-js) * nx + ((i)-is))
+#define A3(i, j, k) ((size_t)((k)-1) * nid * njd + IA(i, j))
+
+/* update_dz_c, nh_utils.F90:59-201.  ut, vt: A x km; gz: A x (km+1); zs, ws: A. */
+int fvo_update_dz_c(const fvo_grid *g, int km, double dt, const double *dp0, const double *zs,
+                    const double *ut, const double *vt, double *gz, double *ws) {
+  BOUNDS(g);
+  int i, j, k;
+  if (g->grid_type < 3) return FVO_ERR_UNSUPPORTED;
+  const double rdt = 1. / dt;
+  const double top_ratio = dp0[0] / (dp0[0] + dp0[1]);
+  const double bot_ratio = dp0[km - 1] / (dp0[km - 2] + dp0[km - 1]);
+  const int is1 = is - 1, js1 = js - 1, ie1 = ie + 1, je1 = je + 1, ie2 = ie + 2, je2 = je + 2;
+  const size_t nA = (size_t)nid * njd;
+#pragma omp parallel for private(i, j) schedule(dynamic)
+  for (k = 1; k <= km + 1; k++) {
+    double *gz2 = dalloc(nA), *xfx = dalloc(nA), *yfx = dalloc(nA), *fx = dalloc(nA), *fy = dalloc(nA);
+    if (k == 1) {
+      for (j = js1; j <= je1; j++)
+        for (i = is1; i <= ie2; i++) xfx[IA(i, j)] = ut[A3(i, j, 1)] + (ut[A3(i, j, 1)] - ut[A3(i, j, 2)]) * top_ratio;
+      for (j = js1; j <= je2; j++)
+        for (i = is1; i <= ie1; i++) yfx[IA(i, j)] = vt[A3(i, j, 1)] + (vt[A3(i, j, 1)] - vt[A3(i, j, 2)]) * top_ratio;
+    } else if (k == km + 1) {
+      for (j = js1; j <= je1; j++)
+        for (i = is1; i <= ie2; i++)
+          xfx[IA(i, j)] = ut[A3(i, j, km)] + (ut[A3(i, j, km)] - ut[A3(i, j, km - 1)]) * bot_ratio;
+      for (j = js1; j <= je2; j++)
+        for (i = is1; i <= ie1; i++)
+          yfx[IA(i, j)] = vt[A3(i, j, km)] + (vt[A3(i, j, km)] - vt[A3(i, j, km - 1)]) * bot_ratio;
+    } else {
+      const double int_ratio = 1. / (dp0[k - 2] + dp0[k - 1]);
+      for (j = js1; j <= je1; j++)
+        for (i = is1; i <= ie2; i++)
+          xfx[IA(i, j)] = (dp0[k - 1] * ut[A3(i, j, k - 1)] + dp0[k - 2] * ut[A3(i, j, k)]) * int_ratio;
+      for (j = js1; j <= je2; j++)
+        for (i = is1; i <= ie1; i++)
+          yfx[IA(i, j)] = (dp0[k - 1] * vt[A3(i, j, k - 1)] + dp0[k - 2] * vt[A3(i, j, k)]) * int_ratio;
+    }
+    for (j = jsd; j <= jed; j++)
+      for (i = isd; i <= ied; i++) gz2[IA(i, j)] = gz[A3(i, j, k)];
+    for (j = js1; j <= je1; j++)
+      for (i = is1; i <= ie2; i++) {
+        if (xfx[IA(i, j)] > 0.)
+          fx[IA(i, j)] = gz2[IA(i - 1, j)];
+        else
+          fx[IA(i, j)] = gz2[IA(i, j)];
+        fx[IA(i, j)] = xfx[IA(i, j)] * fx[IA(i, j)];
+      }
+    for (j = js1; j <= je2; j++)
+      for (i = is1; i <= ie1; i++) {
+        if (yfx[IA(i, j)] > 0.)
+          fy[IA(i, j)] = gz2[IA(i, j - 1)];
+        else
+          fy[IA(i, j)] = gz2[IA(i, j)];
+        fy[IA(i, j)] = yfx[IA(i, j)] * fy[IA(i, j)];
+      }
+    for (j = js1; j <= je1; j++)
+      for (i = is1; i <= ie1; i++)
+        gz[A3(i, j, k)] = (gz2[IA(i, j)] * g->area[IA(i, j)] + fx[IA(i, j)] - fx[IA(i + 1, j)] + fy[IA(i, j)] - fy[IA(i, j + 1)]) /
+                          (g->area[IA(i, j)] + xfx[IA(i, j)] - xfx[IA(i + 1, j)] + yfx[IA(i, j)] - yfx[IA(i, j + 1)]);
+    free(gz2); free(xfx); free(yfx); free(fx); free(fy);
+  }
+  for (j = js1; j <= je1; j++) {
+    for (i = is1; i <= ie1; i++) ws[IA(i, j)] = (zs[IA(i, j)] - gz[A3(i, j, km + 1)]) * rdt;
+    for (k = km; k >= 1; k--)
+      for (i = is1; i <= ie1; i++) gz[A3(i, j, k)] = dmax(gz[A3(i, j, k)], gz[A3(i, j, k + 1)] + dz_min);
+  }
+  return FVO_OK;
+}
+
+/* SIM1_solver, nh_utils.F90:1277-1394, one column (fast_tau_w_sec = 0).  Arrays are 1-based
+ * [1..km] / [1..km+1] (element 0 unused). */
+static void sim1_column(int km, double dt, double rgas, const double *gm2, const double *cp2, double *pe,
+                        const double *dm2, const double *pm2, const double *pem, double *w2, double *dz2,
+                        const double *pt2, double ws, double p_fac) {
+  int k;
+  double *aa = dalloc(km + 2), *bb = dalloc(km + 2), *dd = dalloc(km + 2), *w1 = dalloc(km + 2),
+         *g_rat = dalloc(km + 2), *gam = dalloc(km + 2), *pp = dalloc(km + 3);
+  double p1, bet;
+  const double t1g = 2. * dt * dt, rdt = 1. / dt;
+  for (k = 1; k <= km; k++) {
+    pe[k] = exp(gm2[k] * log(-dm2[k] / dz2[k] * rgas * pt2[k])) - pm2[k];
+    w1[k] = w2[k];
+  }
+  for (k = 1; k <= km - 1; k++) {
+    g_rat[k] = dm2[k] / dm2[k + 1];
+    bb[k] = 2. * (1. + g_rat[k]);
+    dd[k] = 3. * (pe[k] + g_rat[k] * pe[k + 1]);
+  }
+  bet = bb[1];
+  pp[1] = 0.;
+  pp[2] = dd[1] / bet;
+  bb[km] = 2.;
+  dd[km] = 3. * pe[km];
+  for (k = 2; k <= km; k++) {
+    gam[k] = g_rat[k - 1] / bet;
+    bet = bb[k] - gam[k];
+    pp[k + 1] = (dd[k] - pp[k]) / bet;
+  }
+  for (k = km; k >= 2; k--) pp[k] = pp[k] - gam[k] * pp[k + 1];
+  for (k = 2; k <= km; k++) aa[k] = t1g * 0.5 * (gm2[k - 1] + gm2[k]) / (dz2[k - 1] + dz2[k]) * (pem[k]);
+  bet = dm2[1] - aa[2];
+  w2[1] = (dm2[1] * w1[1] + dt * pp[2]) / bet;
+  for (k = 2; k <= km - 1; k++) {
+    gam[k] = aa[k] / bet;
+    bet = dm2[k] - (aa[k] + aa[k + 1] + aa[k] * gam[k]);
+    w2[k] = (dm2[k] * w1[k] + dt * (pp[k + 1] - pp[k]) - aa[k] * w2[k - 1]) / bet;
+  }
+  p1 = t1g * gm2[km] / dz2[km] * (pem[km + 1]);
+  gam[km] = aa[km] / bet;
+  bet = dm2[km] - (aa[km] + p1 + aa[km] * gam[km]);
+  w2[km] = (dm2[km] * w1[km] + dt * (pp[km + 1] - pp[km]) - p1 * ws - aa[km] * w2[km - 1]) / bet;
+  for (k = km - 1; k >= 1; k--) w2[k] = w2[k] - gam[k + 1] * w2[k + 1];
+  pe[1] = 0.;
+  for (k = 1; k <= km; k++) pe[k + 1] = pe[k] + dm2[k] * (w2[k] - w1[k]) * rdt;
+  p1 = (pe[km] + 2. * pe[km + 1]) * r3;
+  dz2[km] = -dm2[km] * rgas * pt2[km] * exp((cp2[km] - 1.) * log(dmax(p_fac * pm2[km], p1 + pm2[km])));
+  for (k = km - 1; k >= 1; k--) {
+    p1 = (pe[k] + bb[k] * pe[k + 1] + g_rat[k] * pe[k + 2]) * r3 - g_rat[k] * p1;
+    dz2[k] = -dm2[k] * rgas * pt2[k] * exp((cp2[k] - 1.) * log(dmax(p_fac * pm2[k], p1 + pm2[k])));
+  }
+  free(aa); free(bb); free(dd); free(w1); free(g_rat); free(gam); free(pp);
+}
+
+/* SIM_solver, nh_utils.F90:1396-1537, one column (scale_m = 0, fast_tau_w_sec = 0). */
+static void sim_column(int km, double dt, double rgas, const double *gm2, const double *cp2, double *pe2,
+                       const double *dm2, const double *pm2, const double *pem, double *w2, double *dz2,
+                       const double *pt2, double ws, double alpha, double p_fac, double scale_m) {
+  int k;
+  double *aa = dalloc(km + 2), *bb = dalloc(km + 2), *dd = dalloc(km + 2), *w1 = dalloc(km + 2),
+         *wk = dalloc(km + 2), *g_rat = dalloc(km + 2), *gam = dalloc(km + 2), *pp = dalloc(km + 3);
+  double p1, wk1, bet;
+  const double beta = 1. - alpha, ra = 1. / alpha, t2 = beta / alpha, t1g = 2. * ((alpha * dt) * (alpha * dt)),
+               rdt = 1. / dt;
+  for (k = 1; k <= km; k++) {
+    w1[k] = w2[k];
+    pe2[k] = exp(gm2[k] * log(-dm2[k] / dz2[k] * rgas * pt2[k])) - pm2[k];
+  }
+  for (k = 1; k <= km - 1; k++) {
+    g_rat[k] = dm2[k] / dm2[k + 1];
+    bb[k] = 2. * (1. + g_rat[k]);
+    dd[k] = 3. * (pe2[k] + g_rat[k] * pe2[k + 1]);
+  }
+  bet = bb[1];
+  pp[1] = 0.;
+  pp[2] = dd[1] / bet;
+  bb[km] = 2.;
+  dd[km] = 3. * pe2[km];
+  for (k = 2; k <= km; k++) {
+    gam[k] = g_rat[k - 1] / bet;
+    bet = bb[k] - gam[k];
+    pp[k + 1] = (dd[k] - pp[k]) / bet;
+  }
+  for (k = km; k >= 2; k--) pp[k] = pp[k] - gam[k] * pp[k + 1];
+  for (k = 1; k <= km + 1; k++) pe2[k] = pem[k];
+  for (k = 2; k <= km; k++) {
+    aa[k] = t1g * 0.5 * (gm2[k - 1] + gm2[k]) / (dz2[k - 1] + dz2[k]) * pe2[k];
+    wk[k] = t2 * aa[k] * (w1[k - 1] - w1[k]);
+    aa[k] = aa[k] - scale_m * dm2[1];
+  }
+  bet = dm2[1] - aa[2];
+  w2[1] = (dm2[1] * w1[1] + dt * pp[2] + wk[2]) / bet;
+  for (k = 2; k <= km - 1; k++) {
+    gam[k] = aa[k] / bet;
+    bet = dm2[k] - (aa[k] + aa[k + 1] + aa[k] * gam[k]);
+    w2[k] = (dm2[k] * w1[k] + dt * (pp[k + 1] - pp[k]) + wk[k + 1] - wk[k] - aa[k] * w2[k - 1]) / bet;
+  }
+  wk1 = t1g * gm2[km] / dz2[km] * pe2[km + 1];
+  gam[km] = aa[km] / bet;
+  bet = dm2[km] - (aa[km] + wk1 + aa[km] * gam[km]);
+  w2[km] = (dm2[km] * w1[km] + dt * (pp[km + 1] - pp[km]) - wk[km] + wk1 * (t2 * w1[km] - ra * ws) - aa[km] * w2[km - 1]) / bet;
+  for (k = km - 1; k >= 1; k--) w2[k] = w2[k] - gam[k + 1] * w2[k + 1];
+  pe2[1] = 0.;
+  for (k = 1; k <= km; k++) pe2[k + 1] = pe2[k] + (dm2[k] * (w2[k] - w1[k]) * rdt - beta * (pp[k + 1] - pp[k])) * ra;
+  p1 = (pe2[km] + 2. * pe2[km + 1]) * r3;
+  dz2[km] = -dm2[km] * rgas * pt2[km] * exp((cp2[km] - 1.) * log(dmax(p_fac * pm2[km], p1 + pm2[km])));
+  for (k = km - 1; k >= 1; k--) {
+    p1 = (pe2[k] + bb[k] * pe2[k + 1] + g_rat[k] * pe2[k + 2]) * r3 - g_rat[k] * p1;
+    dz2[k] = -dm2[k] * rgas * pt2[k] * exp((cp2[k] - 1.) * log(dmax(p_fac * pm2[k], p1 + pm2[k])));
+  }
+  for (k = 1; k <= km + 1; k++) pe2[k] = pe2[k] + beta * (pp[k] - pe2[k]);
+  free(aa); free(bb); free(dd); free(w1); free(wk); free(g_rat); free(gam); free(pp);
+}
+
+/* Riem_Solver_c, nh_utils.F90:323-480 (use_cond = .false.; a_imp > 0.5 -> SIM1_solver).
+ * hs, ws: A; w3, pt, delp: A x km; gz, pef: A x (km+1). */
+int fvo_riem_solver_c(const fvo_grid *g, int km, double dt, double akap, double ptop, const double *hs,
+                      const double *w3, const double *pt, const double *delp, double *gz, double *pef,
+                      const double *ws, double p_fac, double a_imp, double grav, double rdgas) {
+  BOUNDS(g);
+  int j;
+  if (a_imp <= 0.5) return FVO_ERR_UNSUPPORTED;
+  const double rgrav = 1. / grav;
+  const int is1 = is - 1, ie1 = ie + 1;
+#pragma omp parallel for schedule(dynamic)
+  for (j = js - 1; j <= je + 1; j++) {
+    int i, k;
+    double *dm = dalloc(km + 2), *dz2 = dalloc(km + 2), *w2 = dalloc(km + 2), *pm2 = dalloc(km + 2),
+           *gm2 = dalloc(km + 2), *cp2 = dalloc(km + 2), *pem = dalloc(km + 3), *pe2 = dalloc(km + 3),
+           *pt2 = dalloc(km + 2);
+    for (i = is1; i <= ie1; i++) {
+      for (k = 1; k <= km; k++) dm[k] = delp[A3(i, j, k)];
+      pef[A3(i, j, 1)] = ptop;
+      pem[1] = ptop;
+      for (k = 2; k <= km + 1; k++) pem[k] = pem[k - 1] + dm[k - 1];
+      for (k = 1; k <= km; k++) {
+        dz2[k] = gz[A3(i, j, k + 1)] - gz[A3(i, j, k)];
+        pm2[k] = dm[k] / log(pem[k + 1] / pem[k]);
+        cp2[k] = akap;
+        gm2[k] = 1. / (1. - cp2[k]);
+        dm[k] = dm[k] * rgrav;
+        w2[k] = w3[A3(i, j, k)];
+        pt2[k] = pt[A3(i, j, k)];
+      }
+      sim1_column(km, dt, rdgas, gm2, cp2, pe2, dm, pm2, pem, w2, dz2, pt2, ws[IA(i, j)], p_fac);
+      for (k = 2; k <= km + 1; k++) pef[A3(i, j, k)] = pe2[k] + pem[k];
+      gz[A3(i, j, km + 1)] = hs[IA(i, j)];
+      for (k = km; k >= 1; k--) gz[A3(i, j, k)] = gz[A3(i, j, k + 1)] - dz2[k] * grav;
+    }
+    free(dm); free(dz2); free(w2); free(pm2); free(gm2); free(cp2); free(pem); free(pe2); free(pt2);
+  }
+  return FVO_OK;
+}
+
+/* Riem_Solver3, nh_core.F90:47-241 (use_cond = moist_kappa = .false., d2bg_zq = 0).
+ * zs: A; ws: CC; w, delp, pt: A x km; zh, ppe, pk3: A x (km+1); delz: CC x km; pk: CC x (km+1);
+ * pe: (is-1:ie+1, km+1, js-1:je+1); peln: (is:ie, km+1, js:je). */
+int fvo_riem_solver3(const fvo_grid *g, int km, double dt, double akap, double ptop, const double *zs, double *w,
+                     double *delz, const double *pt, const double *delp, double *zh, double *pe, double *ppe,
+                     double *pk3, double *pk, double *peln, const double *ws, double p_fac, double a_imp,
+                     int use_logp, int last_call, int fp_out, double grav, double rdgas) {
+  BOUNDS(g);
+  int j;
+  if (a_imp <= 0.5) return FVO_ERR_UNSUPPORTED;
+  const double rgrav = 1. / grav;
+  const double peln1 = log(ptop);
+  const double ptk = exp(akap * peln1);
+#pragma omp parallel for schedule(dynamic)
+  for (j = js; j <= je; j++) {
+    int i, k;
+    double *dm = dalloc(km + 2), *dz2 = dalloc(km + 2), *w2 = dalloc(km + 2), *pm2 = dalloc(km + 2),
+           *gm2 = dalloc(km + 2), *cp2 = dalloc(km + 2), *pem = dalloc(km + 3), *pe2 = dalloc(km + 3),
+           *peln2 = dalloc(km + 3), *pt2 = dalloc(km + 2);
+    for (i = is; i <= ie; i++) {
+      for (k = 1; k <= km; k++) {
+        dm[k] = delp[A3(i, j, k)];
+        cp2[k] = akap;
+      }
+      pem[1] = ptop;
+      peln2[1] = peln1;
+      pk3[A3(i, j, 1)] = ptk;
+      for (k = 2; k <= km + 1; k++) {
+        pem[k] = pem[k - 1] + dm[k - 1];
+        peln2[k] = log(pem[k]);
+        pk3[A3(i, j, k)] = exp(akap * peln2[k]);
+      }
+      for (k = 1; k <= km; k++) {
+        pm2[k] = dm[k] / (peln2[k + 1] - peln2[k]);
+        gm2[k] = 1. / (1. - cp2[k]);
+        dm[k] = dm[k] * rgrav;
+        dz2[k] = zh[A3(i, j, k + 1)] - zh[A3(i, j, k)];
+        w2[k] = w[A3(i, j, k)];
+        pt2[k] = pt[A3(i, j, k)];
+      }
+      if (a_imp > 0.999)
+        sim1_column(km, dt, rdgas, gm2, cp2, pe2, dm, pm2, pem, w2, dz2, pt2, ws[ICC(i, j)], p_fac);
+      else
+        sim_column(km, dt, rdgas, gm2, cp2, pe2, dm, pm2, pem, w2, dz2, pt2, ws[ICC(i, j)], a_imp, p_fac, 0.0);
+      for (k = 1; k <= km; k++) {
+        w[A3(i, j, k)] = w2[k];
+        delz[(size_t)(k - 1) * nx * ny + ICC(i, j)] = dz2[k];
+      }
+      if (last_call) {
+        for (k = 1; k <= km + 1; k++) {
+          peln[(size_t)(j - js) * nx * (km + 1) + (size_t)(k - 1) * nx + (i - is)] = peln2[k];
+          pk[(size_t)(k - 1) * nx * ny + ICC(i, j)] = pk3[A3(i, j, k)];
+          pe[(size_t)(j - (js - 1)) * (nx + 2) * (km + 1) + (size_t)(k - 1) * (nx + 2) + (i - (is - 1))] = pem[k];
+        }
+      }
+      for (k = 1; k <= km + 1; k++) ppe[A3(i, j, k)] = fp_out ? pe2[k] + pem[k] : pe2[k];
+      if (use_logp)
+        for (k = 2; k <= km + 1; k++) pk3[A3(i, j, k)] = peln2[k];
+      zh[A3(i, j, km + 1)] = zs[IA(i, j)];
+      for (k = km; k >= 1; k--) zh[A3(i, j, k)] = zh[A3(i, j, k + 1)] - dz2[k];
+    }
+    free(dm); free(dz2); free(w2); free(pm2); free(gm2); free(cp2); free(pem); free(pe2); free(peln2); free(pt2);
+  }
+  return FVO_OK;
+}
+
+/* edge_profile, nh_utils.F90:1590-1696, non-uniform branch, limiter = 0, one (i,j) column of two
+ * fields.  q1, q2 point at level 1 with level stride ks; outputs have stride kse. */
+static void edge_profile_col(int km, const double *dp0, const double *q1, const double *q2, size_t ks, double *q1e,
+                             double *q2e, size_t kse) {
+  int k;
+  double *qe1 = dalloc(km + 2), *qe2 = dalloc(km + 2), *gam = dalloc(km + 2);
+  double g0, gk = 0., xt1, xt2, a_bot, bet;
+#define Q1(k) q1[(size_t)((k)-1) * ks]
+#define Q2(k) q2[(size_t)((k)-1) * ks]
+  g0 = dp0[1] / dp0[0];
+  xt1 = 2. * g0 * (g0 + 1.);
+  bet = g0 * (g0 + 0.5);
+  qe1[1] = (xt1 * Q1(1) + Q1(2)) / bet;
+  qe2[1] = (xt1 * Q2(1) + Q2(2)) / bet;
+  gam[1] = (1. + g0 * (g0 + 1.5)) / bet;
+  for (k = 2; k <= km; k++) {
+    gk = dp0[k - 2] / dp0[k - 1];
+    bet = 2. + 2. * gk - gam[k - 1];
+    qe1[k] = (3. * (Q1(k - 1) + gk * Q1(k)) - qe1[k - 1]) / bet;
+    qe2[k] = (3. * (Q2(k - 1) + gk * Q2(k)) - qe2[k - 1]) / bet;
+    gam[k] = gk / bet;
+  }
+  a_bot = 1. + gk * (gk + 1.5);
+  xt1 = 2. * gk * (gk + 1.);
+  xt2 = gk * (gk + 0.5) - a_bot * gam[km];
+  qe1[km + 1] = (xt1 * Q1(km) + Q1(km - 1) - a_bot * qe1[km]) / xt2;
+  qe2[km + 1] = (xt1 * Q2(km) + Q2(km - 1) - a_bot * qe2[km]) / xt2;
+  for (k = km; k >= 1; k--) {
+    qe1[k] = qe1[k] - gam[k] * qe1[k + 1];
+    qe2[k] = qe2[k] - gam[k] * qe2[k + 1];
+  }
+  for (k = 1; k <= km + 1; k++) {
+    q1e[(size_t)(k - 1) * kse] = qe1[k];
+    q2e[(size_t)(k - 1) * kse] = qe2[k];
+  }
+#undef Q1
+#undef Q2
+  free(qe1); free(qe2); free(gam);
+}
+
+int fvo_del6_vt_flux(const fvo_grid *g, int nord, double damp, const double *q, double *d2, double *fx2, double *fy2);
+
+/* update_dz_d, nh_utils.F90:204-321.  ndif, damp: length km+1 (entry km+1 is set here, :240-241);
+ * zs: A; zh: A x (km+1); crx, xfx: CX x km; cry, yfx: CY x km; ws: CC. */
+int fvo_update_dz_d(const fvo_grid *g, int km, int *ndif, double *damp, int hord, const double *dp0, const double *zs,
+                    double *zh, const double *crx, const double *cry, const double *xfx, const double *yfx, double *ws,
+                    double rdt) {
+  BOUNDS(g);
+  int i, j, k;
+  if (g->grid_type < 3) return FVO_ERR_UNSUPPORTED;
+  const size_t nCX = (size_t)(nx + 1) * njd, nCY = (size_t)nid * (ny + 1), nA = (size_t)nid * njd;
+  double *crx_adv = dalloc(nCX * (km + 1)), *xfx_adv = dalloc(nCX * (km + 1));
+  double *cry_adv = dalloc(nCY * (km + 1)), *yfx_adv = dalloc(nCY * (km + 1));
+  damp[km] = damp[km - 1];
+  ndif[km] = ndif[km - 1];
+  for (j = jsd; j <= jed; j++) {
+    for (i = is; i <= ie + 1; i++)
+      edge_profile_col(km, dp0, crx + ICX(i, j), xfx + ICX(i, j), nCX, crx_adv + ICX(i, j), xfx_adv + ICX(i, j), nCX);
+    if (j <= je + 1 && j >= js)
+      for (i = isd; i <= ied; i++)
+        edge_profile_col(km, dp0, cry + ICY(i, j), yfx + ICY(i, j), nCY, cry_adv + ICY(i, j), yfx_adv + ICY(i, j), nCY);
+  }
+#pragma omp parallel for private(i, j) schedule(dynamic)
+  for (k = 1; k <= km + 1; k++) {
+    double *ra_x = dalloc((size_t)nx * njd), *ra_y = dalloc((size_t)nid * ny);
+    double *fx = dalloc((size_t)(nx + 1) * ny), *fy = dalloc((size_t)nx * (ny + 1));
+    const double *cxa = crx_adv + nCX * (k - 1), *xfa = xfx_adv + nCX * (k - 1);
+    const double *cya = cry_adv + nCY * (k - 1), *yfa = yfx_adv + nCY * (k - 1);
+    double *zk = zh + nA * (k - 1);
+    for (j = jsd; j <= jed; j++)
+      for (i = is; i <= ie; i++)
+        ra_x[(size_t)(j - jsd) * nx + (i - is)] = g->area[IA(i, j)] + xfa[ICX(i, j)] - xfa[ICX(i + 1, j)];
+    for (j = js; j <= je; j++)
+      for (i = isd; i <= ied; i++) ra_y[ICY(i, j)] = g->area[IA(i, j)] + yfa[ICY(i, j)] - yfa[ICY(i, j + 1)];
+    if (damp[k - 1] > 1.E-5) {
+      double *z2 = dalloc(nA), *wk2 = dalloc(nA), *fx2 = dalloc((size_t)(nid + 1) * njd), *fy2 = dalloc((size_t)nid * (njd + 1));
+      memcpy(z2, zk, sizeof(double) * nA);
+      fvo_fv_tp_2d(g, z2, cxa, cya, hord, fx, fy, xfa, yfa, ra_x, ra_y, NULL, NULL, NULL, -1, 0.);
+      fvo_del6_vt_flux(g, ndif[k - 1], damp[k - 1], z2, wk2, fx2, fy2);
+      for (j = js; j <= je; j++)
+        for (i = is; i <= ie; i++)
+          zk[IA(i, j)] = (z2[IA(i, j)] * g->area[IA(i, j)] + fx[IFX(i, j)] - fx[IFX(i + 1, j)] + fy[IFY(i, j)] - fy[IFY(i, j + 1)]) /
+                             (ra_x[(size_t)(j - jsd) * nx + (i - is)] + ra_y[ICY(i, j)] - g->area[IA(i, j)]) +
+                         (fx2[IV(i, j)] - fx2[IV(i + 1, j)] + fy2[IU(i, j)] - fy2[IU(i, j + 1)]) * g->rarea[IA(i, j)];
+      free(z2); free(wk2); free(fx2); free(fy2);
+    } else {
+      fvo_fv_tp_2d(g, zk, cxa, cya, hord, fx, fy, xfa, yfa, ra_x, ra_y, NULL, NULL, NULL, -1, 0.);
+      for (j = js; j <= je; j++)
+        for (i = is; i <= ie; i++)
+          zk[IA(i, j)] = (zk[IA(i, j)] * g->area[IA(i, j)] + fx[IFX(i, j)] - fx[IFX(i + 1, j)] + fy[IFY(i, j)] - fy[IFY(i, j + 1)]) /
+                         (ra_x[(size_t)(j - jsd) * nx + (i - is)] + ra_y[ICY(i, j)] - g->area[IA(i, j)]);
+    }
+    free(ra_x); free(ra_y); free(fx); free(fy);
+  }
+  for (j = js; j <= je; j++) {
+    for (i = is; i <= ie; i++) ws[ICC(i, j)] = (zs[IA(i, j)] - zh[A3(i, j, km + 1)]) * rdt;
+    for (k = km; k >= 1; k--)
+      for (i = is; i <= ie; i++) zh[A3(i, j, k)] = dmax(zh[A3(i, j, k)], zh[A3(i, j, k + 1)] + dz_min);
+  }
+  free(crx_adv); free(xfx_adv); free(cry_adv); free(yfx_adv);
+  return FVO_OK;
+}
+
+/* p_grad_c, dyn_core.F90:1635-1694.  delpc: A x npz; pkc, gz: A x (npz+1); uc: V x npz; vc: U x npz. */
+int fvo_p_grad_c(const fvo_grid *g, int npz, double dt2, const double *delpc, const double *pkc, const double *gz,
+                 double *uc, double *vc, int hydrostatic) {
+  BOUNDS(g);
+  int k;
+  const size_t nA = (size_t)nid * njd, nV = (size_t)(nid + 1) * njd, nU = (size_t)nid * (njd + 1);
+#pragma omp parallel for schedule(dynamic)
+  for (k = 1; k <= npz; k++) {
+    int i, j;
+    double *wk = dalloc(nA);
+    for (j = js - 1; j <= je + 1; j++)
+      for (i = is - 1; i <= ie + 1; i++)
+        wk[IA(i, j)] = hydrostatic ? pkc[A3(i, j, k + 1)] - pkc[A3(i, j, k)] : delpc[A3(i, j, k)];
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie + 1; i++)
+        uc[nV * (k - 1) + IV(i, j)] =
+            uc[nV * (k - 1) + IV(i, j)] + dt2 * g->rdxc[IV(i, j)] / (wk[IA(i - 1, j)] + wk[IA(i, j)]) *
+                                              ((gz[A3(i - 1, j, k + 1)] - gz[A3(i, j, k)]) * (pkc[A3(i, j, k + 1)] - pkc[A3(i - 1, j, k)]) +
+                                               (gz[A3(i - 1, j, k)] - gz[A3(i, j, k + 1)]) * (pkc[A3(i - 1, j, k + 1)] - pkc[A3(i, j, k)]));
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie; i++)
+        vc[nU * (k - 1) + IU(i, j)] =
+            vc[nU * (k - 1) + IU(i, j)] + dt2 * g->rdyc[IU(i, j)] / (wk[IA(i, j - 1)] + wk[IA(i, j)]) *
+                                              ((gz[A3(i, j - 1, k + 1)] - gz[A3(i, j, k)]) * (pkc[A3(i, j, k + 1)] - pkc[A3(i, j - 1, k)]) +
+                                               (gz[A3(i, j - 1, k)] - gz[A3(i, j, k + 1)]) * (pkc[A3(i, j - 1, k + 1)] - pkc[A3(i, j, k)]));
+    free(wk);
+  }
+  return FVO_OK;
+}
+
+/* nh_p_grad, dyn_core.F90:1697-1792.  pp, pk, gz: A x (npz+1), converted to corner values in place
+ * (a2b_ord4 with replace=.true.) exactly as the reference does; delp: A x npz; u: U x npz; v: V x npz. */
+int fvo_nh_p_grad(const fvo_grid *g, int npz, double *u, double *v, double *pp, double *gz, double *delp, double *pk,
+                  double dt, double top_value) {
+  BOUNDS(g);
+  int k;
+  const size_t nA = (size_t)nid * njd, nV = (size_t)(nid + 1) * njd, nU = (size_t)nid * (njd + 1);
+#pragma omp parallel for schedule(dynamic)
+  for (k = 1; k <= npz + 1; k++) {
+    int i, j;
+    double *wk1 = dalloc(nA);
+    if (k == 1) {
+      for (j = js; j <= je + 1; j++)
+        for (i = is; i <= ie + 1; i++) {
+          pp[A3(i, j, 1)] = 0.;
+          pk[A3(i, j, 1)] = top_value;
+        }
+    } else {
+      fvo_a2b_ord4(g, pp + nA * (k - 1), wk1, 1);
+      fvo_a2b_ord4(g, pk + nA * (k - 1), wk1, 1);
+    }
+    fvo_a2b_ord4(g, gz + nA * (k - 1), wk1, 1);
+    free(wk1);
+  }
+#pragma omp parallel for schedule(dynamic)
+  for (k = 1; k <= npz; k++) {
+    int i, j;
+    double *wk1 = dalloc(nA), *wk = dalloc(nA);
+    double du1, dv1;
+    fvo_a2b_ord4(g, delp + nA * (k - 1), wk1, 0);
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie + 1; i++) wk[IA(i, j)] = pk[A3(i, j, k + 1)] - pk[A3(i, j, k)];
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie; i++) {
+        du1 = dt / (wk[IA(i, j)] + wk[IA(i + 1, j)]) *
+              ((gz[A3(i, j, k + 1)] - gz[A3(i + 1, j, k)]) * (pk[A3(i + 1, j, k + 1)] - pk[A3(i, j, k)]) +
+               (gz[A3(i, j, k)] - gz[A3(i + 1, j, k + 1)]) * (pk[A3(i, j, k + 1)] - pk[A3(i + 1, j, k)]));
+        u[nU * (k - 1) + IU(i, j)] =
+            (u[nU * (k - 1) + IU(i, j)] + du1 +
+             dt / (wk1[IA(i, j)] + wk1[IA(i + 1, j)]) *
+                 ((gz[A3(i, j, k + 1)] - gz[A3(i + 1, j, k)]) * (pp[A3(i + 1, j, k + 1)] - pp[A3(i, j, k)]) +
+                  (gz[A3(i, j, k)] - gz[A3(i + 1, j, k + 1)]) * (pp[A3(i, j, k + 1)] - pp[A3(i + 1, j, k)]))) *
+            g->rdx[IU(i, j)];
+      }
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie + 1; i++) {
+        dv1 = dt / (wk[IA(i, j)] + wk[IA(i, j + 1)]) *
+              ((gz[A3(i, j, k + 1)] - gz[A3(i, j + 1, k)]) * (pk[A3(i, j + 1, k + 1)] - pk[A3(i, j, k)]) +
+               (gz[A3(i, j, k)] - gz[A3(i, j + 1, k + 1)]) * (pk[A3(i, j, k + 1)] - pk[A3(i, j + 1, k)]));
+        v[nV * (k - 1) + IV(i, j)] =
+            (v[nV * (k - 1) + IV(i, j)] + dv1 +
+             dt / (wk1[IA(i, j)] + wk1[IA(i, j + 1)]) *
+                 ((gz[A3(i, j, k + 1)] - gz[A3(i, j + 1, k)]) * (pp[A3(i, j + 1, k + 1)] - pp[A3(i, j, k)]) +
+                  (gz[A3(i, j, k)] - gz[A3(i, j + 1, k + 1)]) * (pp[A3(i, j, k + 1)] - pp[A3(i, j + 1, k)]))) *
+            g->rdy[IV(i, j)];
+      }
+    free(wk1); free(wk);
+  }
+  return FVO_OK;
+}
+
+/* pk3_halo (dyn_core.F90:1395-1446) / pln_halo (:1449-1496): use_logp selects log(p). */
+int fvo_pk3_halo(const fvo_grid *g, int npz, double ptop, double akap, double *pk3, const double *delp, int use_logp) {
+  BOUNDS(g);
+  int i, j, k, n;
+  double pet;
+  for (j = js; j <= je; j++) {
+    const int ii[4] = {is - 2, is - 1, ie + 1, ie + 2};
+    for (n = 0; n < 4; n++) {
+      i = ii[n];
+      pet = ptop;
+      for (k = 1; k <= npz; k++) {
+        pet = pet + delp[A3(i, j, k)];
+        pk3[A3(i, j, k + 1)] = use_logp ? log(pet) : exp(akap * log(pet));
+      }
+    }
+  }
+  for (i = is - 2; i <= ie + 2; i++) {
+    const int jj[4] = {js - 2, js - 1, je + 1, je + 2};
+    for (n = 0; n < 4; n++) {
+      j = jj[n];
+      pet = ptop;
+      for (k = 1; k <= npz; k++) {
+        pet = pet + delp[A3(i, j, k)];
+        pk3[A3(i, j, k + 1)] = use_logp ? log(pet) : exp(akap * log(pet));
+      }
+    }
+  }
+  return FVO_OK;
+}
+
+/* pe_halo, dyn_core.F90:1498-1526.  pe: (is-1:ie+1, npz+1, js-1:je+1). */
+int fvo_pe_halo(const fvo_grid *g, int npz, double ptop, double *pe, const double *delp) {
+  BOUNDS(g);
+  int i, j, k;
+#define PE(i, k, j) pe[(size_t)((j) - (js - 1)) * (nx + 2) * (npz + 1) + (size_t)((k)-1) * (nx + 2) + ((i) - (is - 1))]
+  for (j = js; j <= je; j++) {
+    PE(is - 1, 1, j) = ptop;
+    PE(ie + 1, 1, j) = ptop;
+    for (k = 1; k <= npz; k++) {
+      PE(is - 1, k + 1, j) = PE(is - 1, k, j) + delp[A3(is - 1, j, k)];
+      PE(ie + 1, k + 1, j) = PE(ie + 1, k, j) + delp[A3(ie + 1, j, k)];
+    }
+  }
+  for (i = is - 1; i <= ie + 1; i++) {
+    PE(i, 1, js - 1) = ptop;
+    PE(i, 1, je + 1) = ptop;
+    for (k = 1; k <= npz; k++) {
+      PE(i, k + 1, js - 1) = PE(i, k, js - 1) + delp[A3(i, js - 1, k)];
+      PE(i, k + 1, je + 1) = PE(i, k, je + 1) + delp[A3(i, je + 1, k)];
+    }
+  }
+#undef PE
+  return FVO_OK;
+}
+
+/* geopk, dyn_core.F90:2202-2353 (use_cond = .false., not bounded_domain).  hs: A; pt, delp: A x km;
+ * gz, pk: A x (km+1); pe (is-1:ie+1, km+1, js-1:je+1); peln (is:ie, km+1, js:je); pkz CC x km. */
+int fvo_geopk(const fvo_grid *g, int km, double ptop, double akap, double cp_air, double *pe, double *peln,
+              const double *delp, double *pk, double *gz, const double *hs, const double *pt, double *pkz, int CG) {
+  BOUNDS(g);
+  int j;
+  const double peln1 = log(ptop);
+  const double ptk = pow(ptop, akap); /* dyn_core.F90:222 (the one place the reference uses **) */
+  const int ifirst = CG ? is - 1 : is - 2, ilast = CG ? ie + 1 : ie + 2;
+  const int jfirst = CG ? js - 1 : js - 2, jlast = CG ? je + 1 : je + 2;
+#define PE(i, k, j) pe[(size_t)((j) - (js - 1)) * (nx + 2) * (km + 1) + (size_t)((k)-1) * (nx + 2) + ((i) - (is - 1))]
+#define PELN(i, k, j) peln[(size_t)((j)-js) * nx * (km + 1) + (size_t)((k)-1) * nx + ((i)-is)]
+#pragma omp parallel for schedule(dynamic)
+  for (j = jfirst; j <= jlast; j++) {
+    int i, k;
+    for (i = ifirst; i <= ilast; i++) {
+      double p1d = ptop, logp;
+      pk[A3(i, j, 1)] = ptk;
+      gz[A3(i, j, km + 1)] = hs[IA(i, j)];
+      if (j >= js && j <= je && i >= is && i <= ie) PELN(i, 1, j) = peln1;
+      if (j > js - 2 && j < je + 2 && i >= is - 1 && i <= ie + 1) PE(i, 1, j) = ptop;
+      for (k = 2; k <= km + 1; k++) {
+        p1d = p1d + delp[A3(i, j, k - 1)];
+        logp = log(p1d);
+        pk[A3(i, j, k)] = exp(akap * logp);
+        if (j > js - 2 && j < je + 2) {
+          if (i >= is - 1 && i <= ie + 1) PE(i, k, j) = p1d;
+          if (j >= js && j <= je && i >= is && i <= ie) PELN(i, k, j) = logp;
+        }
+      }
+      for (k = km; k >= 1; k--)
+        gz[A3(i, j, k)] = gz[A3(i, j, k + 1)] + cp_air * pt[A3(i, j, k)] * (pk[A3(i, j, k + 1)] - pk[A3(i, j, k)]);
+      if (!CG && j >= js && j <= je && i >= is && i <= ie)
+        for (k = 1; k <= km; k++)
+          pkz[(size_t)(k - 1) * nx * ny + ICC(i, j)] =
+              (pk[A3(i, j, k + 1)] - pk[A3(i, j, k)]) / (akap * (PELN(i, k + 1, j) - PELN(i, k, j)));
+    }
+  }
+#undef PE
+#undef PELN
+  return FVO_OK;
+}

@@ -151,3 +151,73 @@ def d_sw_3d(g, npz, par: dict, lev: dict, f):
                            p(f["cy"]), p(f["crx"]), p(f["cry"]), p(f["xfx"]), p(f["yfx"]), p(f.get("q_con")),
                            p(f["heat_source"]), p(f["diss_est"]))
     assert rc == 0, rc
+
+
+# ---- nonhydrostatic column path (oracle/nh_core.c) ----------------------------------------------
+def _d(x):
+    return C.c_double(x)
+
+
+def update_dz_c(g, km, dt, dp0, zs, ut, vt, gz, ws):
+    gs = make_grid(g)
+    dp0 = np.ascontiguousarray(dp0, dtype=np.float64)
+    rc = lib().fvo_update_dz_c(C.byref(gs), C.c_int(km), _d(dt), dp0.ctypes.data_as(_dp), p(zs), p(ut), p(vt), p(gz), p(ws))
+    assert rc == 0, rc
+
+
+def riem_solver_c(g, km, dt, cn, hs, w3, pt, delp, gz, pef, ws):
+    gs = make_grid(g)
+    rc = lib().fvo_riem_solver_c(C.byref(gs), C.c_int(km), _d(dt), _d(cn["akap"]), _d(cn["ptop"]), p(hs), p(w3), p(pt),
+                                 p(delp), p(gz), p(pef), p(ws), _d(cn["p_fac"]), _d(cn["a_imp"]), _d(cn["grav"]),
+                                 _d(cn["rdgas"]))
+    assert rc == 0, rc
+
+
+def riem_solver3(g, km, dt, cn, zs, w, delz, pt, delp, zh, pe, ppe, pk3, pk, peln, ws, use_logp, last_call, fp_out):
+    gs = make_grid(g)
+    rc = lib().fvo_riem_solver3(C.byref(gs), C.c_int(km), _d(dt), _d(cn["akap"]), _d(cn["ptop"]), p(zs), p(w), p(delz),
+                                p(pt), p(delp), p(zh), p(pe), p(ppe), p(pk3), p(pk), p(peln), p(ws), _d(cn["p_fac"]),
+                                _d(cn["a_imp"]), C.c_int(int(use_logp)), C.c_int(int(last_call)), C.c_int(int(fp_out)),
+                                _d(cn["grav"]), _d(cn["rdgas"]))
+    assert rc == 0, rc
+
+
+def update_dz_d(g, km, ndif, damp, hord, dp0, zs, zh, crx, cry, xfx, yfx, ws, rdt):
+    gs = make_grid(g)
+    ndif = np.ascontiguousarray(ndif, dtype=np.int32)
+    damp = np.ascontiguousarray(damp, dtype=np.float64)
+    dp0 = np.ascontiguousarray(dp0, dtype=np.float64)
+    assert ndif.size == km + 1 and damp.size == km + 1
+    rc = lib().fvo_update_dz_d(C.byref(gs), C.c_int(km), ndif.ctypes.data_as(_ip), damp.ctypes.data_as(_dp),
+                               C.c_int(hord), dp0.ctypes.data_as(_dp), p(zs), p(zh), p(crx), p(cry), p(xfx), p(yfx),
+                               p(ws), _d(rdt))
+    assert rc == 0, rc
+
+
+def p_grad_c(g, npz, dt2, delpc, pkc, gz, uc, vc, hydrostatic):
+    gs = make_grid(g)
+    rc = lib().fvo_p_grad_c(C.byref(gs), C.c_int(npz), _d(dt2), p(delpc), p(pkc), p(gz), p(uc), p(vc),
+                            C.c_int(int(hydrostatic)))
+    assert rc == 0, rc
+
+
+def nh_p_grad(g, npz, u, v, pp, gz, delp, pk, dt, top_value):
+    gs = make_grid(g)
+    rc = lib().fvo_nh_p_grad(C.byref(gs), C.c_int(npz), p(u), p(v), p(pp), p(gz), p(delp), p(pk), _d(dt), _d(top_value))
+    assert rc == 0, rc
+
+
+def pk3_halo(g, npz, ptop, akap, pk3, delp, use_logp):
+    gs = make_grid(g)
+    assert lib().fvo_pk3_halo(C.byref(gs), C.c_int(npz), _d(ptop), _d(akap), p(pk3), p(delp), C.c_int(int(use_logp))) == 0
+
+
+def pe_halo(g, npz, ptop, pe, delp):
+    gs = make_grid(g)
+    assert lib().fvo_pe_halo(C.byref(gs), C.c_int(npz), _d(ptop), p(pe), p(delp)) == 0
+
+
+def geopk(g, km, ptop, akap, cp_air, pe, peln, delp, pk, gz, hs, pt, pkz, CG):
+    gs = make_grid(g)
+    assert lib().fvo_geopk(C.byref(gs), C.c_int(km), _d(ptop), _d(akap), _d(cp_air), p(pe), p(peln), p(delp), p(pk),
+                           p(gz), p(hs), p(pt), p(pkz), C.c_int(int(CG))) == 0

@@ -1,0 +1,253 @@
+"""Parity checks of the nonhydrostatic column path (library vs oracle), shared by the GPU tests and
+the host-emulation logic tests.  exp/log are evaluated by different math libraries on the host
+(glibc) and the device (ROCm ocml), neither correctly rounded, so these kernels cannot be bit-exact
+on the GPU: the tolerance is the one BASELINE.json states (relative RMS < 1e-12); the host-emulation
+build shares glibc with the oracle and is checked at 1e-14."""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle_lib as O
+import parity_common as P
+from fields import smooth_state
+from gfdl_atmos_cubed_sphere_amd.layout import Bounds, periodic_fill
+from gfdl_atmos_cubed_sphere_amd.lib import CP_AIR, GRAV, KAPPA, RDGAS, Context, nh_consts
+from test_oracle_properties import default_levels
+
+PTOP = 300.0
+
+
+def nh_state(bd: Bounds, km: int, seed: int = 11, pert: float = 0.02):
+    """A nearly hydrostatic column state on the reference layout with valid halos."""
+    rng = np.random.default_rng(seed)
+    sig = np.linspace(0.0, 1.0, km + 1) ** 1.5
+    shapeA = bd.shape("A")
+    ps = 1.0e5 * (1.0 + 0.01 * rng.uniform(-1, 1, shapeA))
+    periodic_fill(bd, ps, "A")
+    pe = PTOP + (ps[:, :, None] - PTOP) * sig[None, None, :]
+    delp = np.asfortranarray(np.diff(pe, axis=2))
+    pm = delp / np.log(pe[:, :, 1:] / pe[:, :, :-1])
+    T = 300.0 - 60.0 * (1.0 - sig[None, None, 1:]) + 2.0 * rng.uniform(-1, 1, delp.shape)
+    pt = np.asfortranarray(T * pm ** (-KAPPA))
+    dz = -delp / GRAV * RDGAS * pt * pm ** (KAPPA - 1.0) * (1.0 + pert * rng.uniform(-1, 1, delp.shape))
+    zs = np.asfortranarray(50.0 * rng.uniform(0, 1, shapeA))
+    periodic_fill(bd, zs, "A")
+    for k in range(km):
+        periodic_fill(bd, pt[:, :, k], "A")
+        periodic_fill(bd, dz[:, :, k], "A")
+    zh = np.zeros(bd.shape("A", km + 1), order="F")
+    zh[:, :, km] = zs
+    for k in range(km - 1, -1, -1):
+        zh[:, :, k] = zh[:, :, k + 1] - dz[:, :, k]
+    w = np.asfortranarray(0.5 * rng.uniform(-1, 1, delp.shape))
+    for k in range(km):
+        periodic_fill(bd, w[:, :, k], "A")
+    dp0 = np.diff(PTOP + (1.0e5 - PTOP) * sig)
+    return dict(delp=delp, pt=pt, w=w, zh=zh, zs=zs, dp0=dp0)
+
+
+def _tol(lib):
+    return 1e-14 if "hostemu" in lib.path else 1e-12
+
+
+def check_update_dz_c(lib, nx=24, ny=13, km=6):
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, True)
+    s = nh_state(bd, km)
+    st = smooth_state(bd, km)
+    f = P.run_c_sw_oracle(g, bd, km, st, 3.0, False)
+    gz = s["zh"].copy(order="F")
+    ws = bd.zeros("A")
+    O.update_dz_c(g, km, 3.0, s["dp0"], s["zs"], f["ut"], f["vt"], gz, ws)
+    ctx = Context(g, km, lib=lib)
+    try:
+        ctx.set_dp_ref(s["dp0"])
+        d_gz, d_ws = ctx.zeros("A", km + 1), ctx.zeros("A")
+        ctx.update_dz_c(3.0, ctx.from_host(s["zs"]), ctx.from_host(f["ut"]), ctx.from_host(f["vt"]),
+                        ctx.from_host(s["zh"]), d_gz, d_ws)
+        r = (bd.is_ - 1, bd.ie + 1, bd.js - 1, bd.je + 1)
+        P.assert_close("gz", bd.view(d_gz.download(), "A", *r), bd.view(gz, "A", *r), _tol(lib))
+        P.assert_close("ws", bd.view(d_ws.download(), "A", *r), bd.view(ws, "A", *r), _tol(lib))
+    finally:
+        ctx.close()
+
+
+def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0):
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    s = nh_state(bd, km)
+    cn = nh_consts(PTOP, a_imp=a_imp)
+    rng = np.random.default_rng(3)
+    ws = np.asfortranarray(0.1 * rng.uniform(-1, 1, bd.shape("A")))
+    hs = np.asfortranarray(s["zs"] * GRAV)
+    gz = s["zh"].copy(order="F")
+    pef = bd.zeros("A", km + 1)
+    O.riem_solver_c(g, km, 3.0, cn, hs, s["w"], s["pt"], s["delp"], gz, pef, ws)
+    ctx = Context(g, km, lib=lib)
+    try:
+        d_gz, d_pef = ctx.from_host(s["zh"]), ctx.zeros("A", km + 1)
+        ctx.riem_solver_c(3.0, cn, ctx.from_host(hs), ctx.from_host(s["w"]), ctx.from_host(s["pt"]),
+                          ctx.from_host(s["delp"]), d_gz, d_pef, ctx.from_host(ws))
+        r = (bd.is_ - 1, bd.ie + 1, bd.js - 1, bd.je + 1)
+        P.assert_close("gz", bd.view(d_gz.download(), "A", *r), bd.view(gz, "A", *r), _tol(lib))
+        P.assert_close("pef", bd.view(d_pef.download(), "A", *r), bd.view(pef, "A", *r), _tol(lib))
+    finally:
+        ctx.close()
+
+
+def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_call=True, fp_out=False):
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    s = nh_state(bd, km)
+    cn = nh_consts(PTOP, a_imp=a_imp)
+    rng = np.random.default_rng(4)
+    ws = np.asfortranarray(0.1 * rng.uniform(-1, 1, bd.shape("CC")))
+    o = dict(w=s["w"].copy(order="F"), zh=s["zh"].copy(order="F"), delz=bd.zeros("CC", km),
+             ppe=bd.zeros("A", km + 1), pk3=bd.full("A", 1e40, km + 1), pk=bd.zeros("CC", km + 1),
+             pe=np.zeros((nx + 2, km + 1, ny + 2), order="F"), peln=np.zeros((nx, km + 1, ny), order="F"))
+    O.riem_solver3(g, km, 6.0, cn, s["zs"], o["w"], o["delz"], s["pt"], s["delp"], o["zh"], o["pe"], o["ppe"],
+                   o["pk3"], o["pk"], o["peln"], ws, use_logp, last_call, fp_out)
+    ctx = Context(g, km, lib=lib)
+    try:
+        d = {k: ctx.from_host(v) for k, v in dict(w=s["w"], zh=s["zh"], delz=bd.zeros("CC", km),
+                                                   ppe=bd.zeros("A", km + 1), pk3=bd.full("A", 1e40, km + 1),
+                                                   pk=bd.zeros("CC", km + 1),
+                                                   pe=np.zeros((nx + 2, km + 1, ny + 2), order="F"),
+                                                   peln=np.zeros((nx, km + 1, ny), order="F")).items()}
+        ctx.riem_solver3(6.0, cn, ctx.from_host(s["zs"]), d["w"], d["delz"], ctx.from_host(s["pt"]),
+                         ctx.from_host(s["delp"]), d["zh"], d["pe"], d["ppe"], d["pk3"], d["pk"], d["peln"],
+                         ctx.from_host(ws), use_logp, last_call, fp_out)
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        tol = _tol(lib)
+        for n in ("w", "zh", "ppe", "pk3"):
+            P.assert_close(n, bd.view(d[n].download(), "A", *r), bd.view(o[n], "A", *r), tol)
+        P.assert_close("delz", d["delz"].download(), o["delz"], tol)
+        if last_call:
+            P.assert_close("pk", d["pk"].download(), o["pk"], tol)
+            P.assert_close("peln", d["peln"].download(), o["peln"], tol)
+            P.assert_close("pe", d["pe"].download()[1:-1, :, 1:-1], o["pe"][1:-1, :, 1:-1], tol)
+    finally:
+        ctx.close()
+
+
+def check_update_dz_d(lib, nx=40, ny=19, km=5, lev_over=None, hord=10):
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, True)
+    s = nh_state(bd, km)
+    rng = np.random.default_rng(8)
+    arr = {n: bd.zeros(k, km) for n, k in (("crx", "CX"), ("xfx", "CX"), ("cry", "CY"), ("yfx", "CY"))}
+    for k in range(km):
+        c = P._courant(bd, g, rng, cmax=0.4)
+        for n, a in zip(("crx", "cry", "xfx", "yfx"), c[:4]):
+            arr[n][:, :, k] = a
+    lev = default_levels(km, **(lev_over or {}))
+    ndif = np.concatenate([lev["nord_v"], lev["nord_v"][-1:]]).astype(np.int32)
+    damp = np.concatenate([lev["damp_vt"], lev["damp_vt"][-1:]])
+    zh = s["zh"].copy(order="F")
+    ws = bd.zeros("CC")
+    rdt = 1.0 / 6.0
+    O.update_dz_d(g, km, ndif, damp, hord, s["dp0"], s["zs"], zh, arr["crx"], arr["cry"], arr["xfx"], arr["yfx"], ws, rdt)
+    ctx = Context(g, km, lib=lib)
+    try:
+        ctx.set_dp_ref(s["dp0"])
+        ctx.dsw_levels(lev)
+        d_out, d_ws = ctx.zeros("A", km + 1), ctx.zeros("CC")
+        ctx.update_dz_d(hord, ctx.from_host(s["zs"]), ctx.from_host(s["zh"]), d_out, ctx.from_host(arr["crx"]),
+                        ctx.from_host(arr["cry"]), ctx.from_host(arr["xfx"]), ctx.from_host(arr["yfx"]), d_ws, rdt)
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        P.assert_close("zh", bd.view(d_out.download(), "A", *r), bd.view(zh, "A", *r), _tol(lib))
+        P.assert_close("ws", d_ws.download(), ws, _tol(lib))
+    finally:
+        ctx.close()
+
+
+def _pressure_fields(bd, km, s, rng):
+    pe = PTOP + np.concatenate([np.zeros(bd.shape("A") + (1,)), np.cumsum(s["delp"], axis=2)], axis=2)
+    pk = np.asfortranarray(pe ** KAPPA)
+    pp = np.asfortranarray(50.0 * rng.uniform(-1, 1, pe.shape))
+    pp[:, :, 0] = 0.0
+    gz = np.asfortranarray(s["zh"] * GRAV)
+    return np.asfortranarray(pe), pk, pp, gz
+
+
+def check_p_grad_c(lib, nx=24, ny=13, km=5, hydrostatic=False):
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, True)
+    s = nh_state(bd, km)
+    rng = np.random.default_rng(5)
+    pe, pk, pp, gz = _pressure_fields(bd, km, s, rng)
+    pkc = pk if hydrostatic else np.asfortranarray(pe + pp)
+    st = smooth_state(bd, km)
+    uc = np.asfortranarray(rng.uniform(-10, 10, bd.shape("V", km)))
+    vc = np.asfortranarray(rng.uniform(-10, 10, bd.shape("U", km)))
+    uc_o, vc_o = uc.copy(order="F"), vc.copy(order="F")
+    O.p_grad_c(g, km, 3.0, s["delp"], pkc, gz, uc_o, vc_o, hydrostatic)
+    ctx = Context(g, km, lib=lib)
+    try:
+        d_uc, d_vc = ctx.from_host(uc), ctx.from_host(vc)
+        ctx.p_grad_c(3.0, ctx.from_host(s["delp"]), ctx.from_host(pkc), ctx.from_host(gz), d_uc, d_vc, hydrostatic)
+        P.assert_close("uc", d_uc.download(), uc_o, _tol(lib))
+        P.assert_close("vc", d_vc.download(), vc_o, _tol(lib))
+    finally:
+        ctx.close()
+
+
+def check_nh_p_grad(lib, nx=40, ny=19, km=5):
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, True)
+    s = nh_state(bd, km)
+    rng = np.random.default_rng(6)
+    pe, pk, pp, gz = _pressure_fields(bd, km, s, rng)
+    u = np.asfortranarray(rng.uniform(-1e4, 1e4, bd.shape("U", km)))
+    v = np.asfortranarray(rng.uniform(-1e4, 1e4, bd.shape("V", km)))
+    top = PTOP ** KAPPA
+    o = dict(u=u.copy(order="F"), v=v.copy(order="F"), pp=pp.copy(order="F"), gz=gz.copy(order="F"),
+             delp=s["delp"].copy(order="F"), pk=pk.copy(order="F"))
+    O.nh_p_grad(g, km, o["u"], o["v"], o["pp"], o["gz"], o["delp"], o["pk"], 6.0, top)
+    ctx = Context(g, km, lib=lib)
+    try:
+        d_u, d_v = ctx.from_host(u), ctx.from_host(v)
+        ctx.nh_p_grad(d_u, d_v, ctx.from_host(pp), ctx.from_host(gz), ctx.from_host(s["delp"]), ctx.from_host(pk), 6.0, top)
+        P.assert_close("u", bd.view(d_u.download(), "U", bd.is_, bd.ie, bd.js, bd.je + 1),
+                       bd.view(o["u"], "U", bd.is_, bd.ie, bd.js, bd.je + 1), _tol(lib))
+        P.assert_close("v", bd.view(d_v.download(), "V", bd.is_, bd.ie + 1, bd.js, bd.je),
+                       bd.view(o["v"], "V", bd.is_, bd.ie + 1, bd.js, bd.je), _tol(lib))
+    finally:
+        ctx.close()
+
+
+def check_halos_and_geopk(lib, nx=24, ny=13, km=6):
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    s = nh_state(bd, km)
+    tol = _tol(lib)
+    ctx = Context(g, km, lib=lib)
+    try:
+        d_delp = ctx.from_host(s["delp"])
+        for use_logp in (False, True):
+            pk3 = bd.full("A", 7.0, km + 1)
+            ref = pk3.copy(order="F")
+            O.pk3_halo(g, km, PTOP, KAPPA, ref, s["delp"], use_logp)
+            d = ctx.from_host(pk3)
+            ctx.pk3_halo(PTOP, KAPPA, d, d_delp, use_logp)
+            P.assert_close("pk3_halo", d.download(), ref, tol)
+        pe = np.full((nx + 2, km + 1, ny + 2), 3.0, order="F")
+        ref = pe.copy(order="F")
+        O.pe_halo(g, km, PTOP, ref, s["delp"])
+        d = ctx.from_host(pe)
+        ctx.pe_halo(PTOP, d, d_delp)
+        got = d.download()
+        # the four corner columns of the ring are not written by the reference either way they agree
+        P.assert_close("pe_halo", got, ref, tol)
+        for CG in (True, False):
+            o = dict(pe=np.zeros((nx + 2, km + 1, ny + 2), order="F"), peln=np.zeros((nx, km + 1, ny), order="F"),
+                     pk=bd.zeros("A", km + 1), gz=bd.zeros("A", km + 1), pkz=bd.zeros("CC", km))
+            hs = np.asfortranarray(s["zs"] * GRAV)
+            O.geopk(g, km, PTOP, KAPPA, CP_AIR, o["pe"], o["peln"], s["delp"], o["pk"], o["gz"], hs, s["pt"], o["pkz"], CG)
+            dd = {k: ctx.from_host(np.zeros_like(v)) for k, v in o.items()}
+            ctx.geopk(PTOP, KAPPA, CP_AIR, dd["pe"], dd["peln"], d_delp, dd["pk"], dd["gz"], ctx.from_host(hs),
+                      ctx.from_host(s["pt"]), dd["pkz"], CG)
+            for n in ("pk", "gz", "pe", "peln") + (() if CG else ("pkz",)):
+                P.assert_close(f"geopk {n} CG={CG}", dd[n].download(), o[n], tol)
+    finally:
+        ctx.close()

@@ -98,3 +98,47 @@ def test_errors_are_loud(prod):
 
 def test_halo_fill_periodic(prod):
     P.check_halo_periodic(prod)
+
+
+# ---- nonhydrostatic column path (exp/log differ between glibc and the device library: tol 1e-12) ----
+import parity_nh as N
+
+
+def test_nh_update_dz_c(prod):
+    N.check_update_dz_c(prod)
+    N.check_update_dz_c(prod, nx=96, ny=96, km=16)
+
+
+@pytest.mark.parametrize("a_imp", [1.0, 0.75])
+def test_nh_riem_solver_c(prod, a_imp):
+    N.check_riem_solver_c(prod, a_imp=a_imp)
+    N.check_riem_solver_c(prod, nx=96, ny=64, km=32, a_imp=a_imp)
+
+
+@pytest.mark.parametrize("a_imp,use_logp,last_call,fp_out", [(1.0, False, True, False), (0.75, False, True, False),
+                                                            (1.0, True, False, True), (0.75, True, True, True)])
+def test_nh_riem_solver3(prod, a_imp, use_logp, last_call, fp_out):
+    N.check_riem_solver3(prod, a_imp=a_imp, use_logp=use_logp, last_call=last_call, fp_out=fp_out)
+    N.check_riem_solver3(prod, nx=96, ny=64, km=32, a_imp=a_imp, use_logp=use_logp, last_call=last_call, fp_out=fp_out)
+
+
+def test_nh_update_dz_d(prod):
+    N.check_update_dz_d(prod)
+    N.check_update_dz_d(prod, lev_over=dict(nord=2, do_vort_damp=True, vtdm4=0.06), hord=8)
+    N.check_update_dz_d(prod, nx=33, ny=9, km=3)
+    N.check_update_dz_d(prod, nx=96, ny=96, km=16)
+
+
+@pytest.mark.parametrize("hydrostatic", [False, True])
+def test_nh_p_grad_c(prod, hydrostatic):
+    N.check_p_grad_c(prod, hydrostatic=hydrostatic)
+
+
+def test_nh_p_grad(prod):
+    N.check_nh_p_grad(prod)
+    N.check_nh_p_grad(prod, nx=33, ny=9, km=3)
+    N.check_nh_p_grad(prod, nx=96, ny=96, km=16)
+
+
+def test_nh_halos_and_geopk(prod):
+    N.check_halos_and_geopk(prod)

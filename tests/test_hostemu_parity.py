@@ -82,3 +82,42 @@ def test_d_sw_ragged(emu):
 
 def test_halo_fill_periodic(emu):
     P.check_halo_periodic(emu)
+
+
+# ---- nonhydrostatic column path ------------------------------------------------------------------
+import parity_nh as N
+
+
+def test_nh_update_dz_c(emu):
+    N.check_update_dz_c(emu)
+
+
+@pytest.mark.parametrize("a_imp", [1.0, 0.75])
+def test_nh_riem_solver_c(emu, a_imp):
+    N.check_riem_solver_c(emu, a_imp=a_imp)
+
+
+@pytest.mark.parametrize("a_imp,use_logp,last_call,fp_out", [(1.0, False, True, False), (0.75, False, True, False),
+                                                            (1.0, True, False, True), (0.75, True, True, True)])
+def test_nh_riem_solver3(emu, a_imp, use_logp, last_call, fp_out):
+    N.check_riem_solver3(emu, a_imp=a_imp, use_logp=use_logp, last_call=last_call, fp_out=fp_out)
+
+
+def test_nh_update_dz_d(emu):
+    N.check_update_dz_d(emu)
+    N.check_update_dz_d(emu, lev_over=dict(nord=2, do_vort_damp=True, vtdm4=0.06), hord=8)
+    N.check_update_dz_d(emu, nx=33, ny=9, km=3)
+
+
+@pytest.mark.parametrize("hydrostatic", [False, True])
+def test_nh_p_grad_c(emu, hydrostatic):
+    N.check_p_grad_c(emu, hydrostatic=hydrostatic)
+
+
+def test_nh_p_grad(emu):
+    N.check_nh_p_grad(emu)
+    N.check_nh_p_grad(emu, nx=33, ny=9, km=3)
+
+
+def test_nh_halos_and_geopk(emu):
+    N.check_halos_and_geopk(emu)
