@@ -614,8 +614,15 @@ extern "C" int fv3_p_grad_c(fv3_ctx *c, double dt2, const double *delpc, const d
   return 0;
 }
 
-extern "C" int fv3_nh_p_grad(fv3_ctx *c, double *u, double *v, const double *pp, const double *gz, const double *delp,
-                             const double *pk, double dt, double top_value) {
+extern "C" int fv3_zh_from_delz(fv3_ctx *c, const double *zs, const double *delz, double *zh) {
+  if (!c || !c->grid_ready) return fail("fv3_zh_from_delz: context has no grid");
+  ZhFromDelz kf{c->g, c->g.npz, zs, delz, zh};
+  RT(launch_p(c, "zh_from_delz", col_grid(c->g.nx * c->g.ny), 0, kf));
+  return 0;
+}
+
+extern "C" int fv3_nh_p_grad(fv3_ctx *c, double *u, double *v, const double *pp, const double *gz, double gz_scale,
+                             const double *delp, const double *pk, double dt, double top_value) {
   if (!c || !c->grid_ready) return fail("fv3_nh_p_grad: context has no grid");
   if (need_scratch(c, 4)) return 1;
   const Grid &g = c->g;
@@ -629,6 +636,8 @@ extern "C" int fv3_nh_p_grad(fv3_ctx *c, double *u, double *v, const double *pp,
     kf.nlev[0] = kf.nlev[1] = kf.nlev[2] = km + 1;
     kf.nlev[3] = km;
     kf.nf = 4;
+    kf.scale[0] = kf.scale[1] = kf.scale[3] = 1.0;
+    kf.scale[2] = gz_scale;
     kf.top_pp = 0.;
     kf.top_pk = top_value;
     kf.override1 = 1;

@@ -485,6 +485,27 @@ struct ZhLimit {  // update_dz_d :303-319
   }
 };
 
+struct ZhFromDelz {  // dyn_core.F90:370-385: gz(npz+1) = zs; gz(k) = gz(k+1) - delz(k)  (compute domain)
+  Grid g;
+  int km;
+  const double *zs, *delz;
+  double *zh;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int ncol = g.nx * g.ny;
+    const size_t nA = g.nA(), nCC = g.nCC();
+    FV3_COL_FOR(c, ncol) {
+      const int i = g.is + c % g.nx, j = g.js + c / g.nx;
+      const int o = g.iA(i, j), occ = g.iCC(i, j);
+      double z = zs[o];
+      zh[(size_t)km * nA + o] = z;
+      for (int k = km; k >= 1; k--) {
+        z = z - delz[(size_t)(k - 1) * nCC + occ];
+        zh[(size_t)(k - 1) * nA + o] = z;
+      }
+    }
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 struct PGradC {  // p_grad_c, dyn_core.F90:1635-1694
   Grid g;
@@ -528,6 +549,7 @@ struct A2BCorners {
   double *out[4];
   int nlev[4];      // number of levels of each field (npz+1 or npz)
   int nf;
+  double scale[4];        // value = in * scale at load time (gz = zh*grav, dyn_core.F90:982-989); 1.0 = none
   double top_pp, top_pk;  // level-1 overrides of fields 0 and 1 (nh_p_grad :1732-1738); used when override1 != 0
   int override1;
   static constexpr int W = TI + 5, H = TJ + 5;  // corners [i0, i0+TI] need cells [i0-2, i0+TI+1]
@@ -550,6 +572,10 @@ struct A2BCorners {
       }
       FV3_SYNC();
       load_tile<W, H>(s, in[f] + (size_t)k * g.nA(), g.nid, g.isd, g.ied, g.jsd, g.jed, tid);
+      if (scale[f] != 1.0) {
+        FV3_SYNC();
+        FV3_TILE_FOR(W, H, li, lj) { s.p[lj * W + li] = s.p[lj * W + li] * scale[f]; }
+      }
       FV3_SYNC();
       FV3_TILE_FOR(TI, TJ, li_, lj_) {
         const int i = i0 + li_, j = j0 + lj_;

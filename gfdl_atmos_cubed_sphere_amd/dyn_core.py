@@ -1,0 +1,193 @@
+"""Host orchestration of the acoustic substep loop -- the build's counterpart of ``dyn_core``
+(model/dyn_core.F90:94-1393), nonhydrostatic branch, non-nested, ``grid_type=4``.
+
+The order of kernel calls and halo updates follows model/dyn_core.F90:313-1286 line by line (cited at
+each step).  All fields are device resident (``lib.DeviceArray``); fields that ``d_sw`` /
+``update_dz_d`` update in place in the reference are ping-pong pairs here (``cur``/``nxt``), swapped
+after the call -- the halo update that follows in the reference fills the new buffer's halo.
+
+Not reproduced (off in every BASELINE config): nesting / regional BCs, ``breed_vortex_inline``,
+``do_fast_phys``, ``Ray_fast``, ``beta > 0`` (split_p_grad), ``use_old_omega`` omega diagnostics,
+``d_ext`` (hydrostatic one_grad_p only).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .halo import HaloExchanger
+from .lib import CP_AIR, GRAV, KAPPA, RDGAS, Context, nh_consts
+
+
+@dataclass
+class DynFlags:
+    """The fv_flags_type members the substep reads (defaults: model/fv_arrays.F90:207-906)."""
+    n_split: int = 1
+    nord: int = 1
+    d4_bg: float = 0.16
+    d2_bg: float = 0.0
+    d2_bg_k1: float = 0.20   # fv_control.F90:1031-1034 when n_sponge == 0 ... reference default 4. -> 0.20
+    d2_bg_k2: float = 0.015
+    dddmp: float = 0.0
+    vtdm4: float = 0.0
+    do_vort_damp: bool = False
+    d_con: float = 0.0
+    ke_bg: float = 0.0
+    hord_mt: int = 10
+    hord_vt: int = 10
+    hord_tm: int = 10
+    hord_dp: int = 10
+    hord_tr: int = 8
+    a_imp: float = 1.0       # > 0.999: SIM1_solver in Riem_Solver3 (BASELINE north_star); reference default 0.75
+    p_fac: float = 0.05
+    use_logp: bool = False
+    n_sponge: int = 1
+    is_ideal_case: bool = False
+    ptop: float = 300.0
+    akap: float = KAPPA
+    grav: float = GRAV
+    rdgas: float = RDGAS
+    cp_air: float = CP_AIR
+
+
+def level_coefficients(npz: int, fl: DynFlags) -> dict:
+    """nord_k, nord_v, nord_w, nord_t, d2_divg, damp_vt, damp_w, damp_t, d_con_k per level, exactly as the
+    k loop of model/dyn_core.F90:666-733 computes them."""
+    lev = {k: np.zeros(npz, dtype=np.int32) for k in ("nord_k", "nord_v", "nord_w", "nord_t")}
+    lev.update({k: np.zeros(npz) for k in ("d2_divg", "damp_vt", "damp_w", "damp_t", "d_con_k")})
+    for k in range(1, npz + 1):
+        nord_k = fl.nord
+        nord_v = min(2, fl.nord)
+        d2_divg = min(0.20, fl.d2_bg)
+        damp_vt = fl.vtdm4 if fl.do_vort_damp else 0.0
+        nord_w, nord_t, damp_w, damp_t, d_con_k = nord_v, nord_v, damp_vt, damp_vt, fl.d_con
+        if npz == 1 or fl.n_sponge < 0:
+            d2_divg = fl.d2_bg
+        else:
+            if k == 1:
+                nord_k = 0
+                d2_divg = max(fl.d2_bg, fl.d2_bg_k1) if fl.is_ideal_case else max(0.01, fl.d2_bg, fl.d2_bg_k1)
+                nord_w, damp_w = 0, d2_divg
+                if fl.do_vort_damp:
+                    nord_v, damp_vt = 0, 0.5 * d2_divg
+                d_con_k = 0.0
+            elif k == 2 and fl.d2_bg_k2 > 0.01:
+                nord_k = 0
+                d2_divg = max(fl.d2_bg, fl.d2_bg_k2)
+                nord_w, damp_w = 0, d2_divg
+                if fl.do_vort_damp:
+                    nord_v, damp_vt = 0, 0.5 * d2_divg
+                d_con_k = 0.0
+            elif k == 3 and fl.d2_bg_k2 > 0.05:
+                nord_k = 0
+                d2_divg = max(fl.d2_bg, 0.2 * fl.d2_bg_k2)
+                nord_w, damp_w = 0, d2_divg
+                d_con_k = 0.0
+        i = k - 1
+        lev["nord_k"][i], lev["nord_v"][i], lev["nord_w"][i], lev["nord_t"][i] = nord_k, nord_v, nord_w, nord_t
+        lev["d2_divg"][i], lev["damp_vt"][i], lev["damp_w"][i], lev["damp_t"][i] = d2_divg, damp_vt, damp_w, damp_t
+        lev["d_con_k"][i] = d_con_k
+    return lev
+
+
+class DynCore:
+    """Device-resident state + work arrays of one rank and the substep loop."""
+
+    PROGNOSTIC = (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"))
+
+    def __init__(self, ctx: Context, flags: DynFlags, dp_ref, px: int = 1, py: int = 1, rank: int = 0, world: int = 1):
+        self.ctx, self.fl = ctx, flags
+        self.npz = ctx.npz
+        self.halo = HaloExchanger(ctx, px, py, rank, world)
+        npz = self.npz
+        z = ctx.zeros
+        d = self.d = {}
+        for n, kind in self.PROGNOSTIC:
+            d[n] = z(kind, npz)
+            d[n + "_nxt"] = z(kind, npz)
+        d["delz"] = z("CC", npz)
+        d["phis"] = z("A")
+        d["zs"] = z("A")
+        # dyn_core work arrays (dyn_core.F90:256-283) and fv_atmos_type auxiliaries
+        for n, kind, nk in (("delpc", "A", npz), ("ptc", "A", npz), ("uc", "V", npz), ("vc", "U", npz),
+                            ("ua", "A", npz), ("va", "A", npz), ("omga", "A", npz), ("ut", "A", npz),
+                            ("vt", "A", npz), ("divgd", "B", npz), ("gz", "A", npz + 1), ("pkc", "A", npz + 1),
+                            ("zh", "A", npz + 1), ("zh_nxt", "A", npz + 1), ("pk3", "A", npz + 1),
+                            ("crx", "CX", npz), ("xfx", "CX", npz), ("cry", "CY", npz), ("yfx", "CY", npz),
+                            ("mfx", "FX", npz), ("mfy", "FY", npz), ("cx", "CX", npz), ("cy", "CY", npz),
+                            ("heat_s", "CC", npz), ("diss_e", "CC", npz), ("pk", "CC", npz + 1),
+                            ("ws3", "A", None), ("ws", "CC", None)):
+            d[n] = z(kind, nk)
+        b = ctx.bd
+        d["pe"] = ctx.from_host(np.zeros((b.nx + 2, npz + 1, b.ny + 2), order="F"))
+        d["peln"] = ctx.from_host(np.zeros((b.nx, npz + 1, b.ny), order="F"))
+        self.lev = level_coefficients(npz, flags)
+        ctx.dsw_levels(self.lev)
+        ctx.set_dp_ref(dp_ref)
+        self.cn = nh_consts(flags.ptop, p_fac=flags.p_fac, a_imp=flags.a_imp, akap=flags.akap, grav=flags.grav,
+                            rdgas=flags.rdgas, cp_air=flags.cp_air)
+
+    # -- state I/O ------------------------------------------------------------------------------------
+    def set_state(self, u, v, w, delp, pt, delz, phis):
+        d = self.d
+        for n, a in (("u", u), ("v", v), ("w", w), ("delp", delp), ("pt", pt), ("delz", delz), ("phis", phis)):
+            d[n].upload(a)
+        d["zs"].upload(np.asfortranarray(phis * (1.0 / self.fl.grav)))  # dyn_core.F90:246-251
+
+    def get_state(self):
+        return {n: self.d[n].download() for n in ("u", "v", "w", "delp", "pt", "delz", "zh", "mfx", "mfy", "cx", "cy")}
+
+    def _swap(self, name):
+        self.d[name], self.d[name + "_nxt"] = self.d[name + "_nxt"], self.d[name]
+
+    # -- the substep loop (dyn_core.F90:313-1286) ------------------------------------------------------
+    def run(self, bdt: float, end_step: bool = True):
+        fl, d, ctx, halo = self.fl, self.d, self.ctx, self.halo
+        n_split = fl.n_split
+        dt = bdt / float(n_split)
+        dt2 = 0.5 * dt
+        rdt = 1.0 / dt
+        ptk = fl.ptop ** fl.akap             # dyn_core.F90:222
+        peln1 = np.log(fl.ptop)
+        for a in ("mfx", "mfy", "cx", "cy"):  # :289-292 empty the flux capacitors
+            d[a].zero()
+        par = dict(dt=dt, hord_tr=fl.hord_tr, hord_mt=fl.hord_mt, hord_vt=fl.hord_vt, hord_tm=fl.hord_tm,
+                   hord_dp=fl.hord_dp, dddmp=fl.dddmp, d4_bg=fl.d4_bg, kgb=fl.ke_bg, hydrostatic=0, use_cond=0)
+        # fv_dynamics.F90:467-470: halo of delp, pt (pack 1) and u, v (pack 8) before the first substep
+        halo.update([(d["delp"], "A"), (d["pt"], "A")])
+        halo.update([(d["u"], "U"), (d["v"], "V")])
+        for it in range(1, n_split + 1):
+            remap_step = it == n_split
+            halo.update([(d["w"], "A")])                                      # :350 / :432 (pack 7)
+            if it == 1:                                                       # :353-389
+                ctx.zh_from_delz(d["zs"], d["delz"], d["zh"])
+                halo.update([(d["zh"], "A")])                                 # gz halo (pack 5), then zh = gz (:491-499)
+            ctx.c_sw(d["delpc"], d["delp"], d["ptc"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"],
+                     d["va"], d["omga"], d["ut"], d["vt"], d["divgd"], fl.nord, dt2, False)   # :439-447
+            if fl.nord > 0:
+                halo.update([(d["divgd"], "B")])                              # :451 / :577 (pack 3, CORNER)
+            ctx.update_dz_c(dt2, d["zs"], d["ut"], d["vt"], d["zh"], d["gz"], d["ws3"])       # :514-527
+            ctx.riem_solver_c(dt2, self.cn, d["phis"], d["omga"], d["ptc"], d["delpc"], d["gz"], d["pkc"], d["ws3"])  # :531
+            ctx.p_grad_c(dt2, d["delpc"], d["pkc"], d["gz"], d["uc"], d["vc"], False)         # :562
+            halo.update([(d["uc"], "V"), (d["vc"], "U")])                     # :565 / :578 (pack 9, CGRID_NE)
+            ctx.d_sw(par, d["vt"], d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"],
+                     d["divgd"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
+                     d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], d["w_nxt"], None, d["heat_s"], d["diss_e"])  # :762
+            for n in ("delp", "pt", "u", "v", "w"):
+                self._swap(n)
+            halo.update([(d["delp"], "A"), (d["pt"], "A")])                   # :823-824 / :851 (pack 1)
+            ctx.update_dz_d(fl.hord_tm, d["zs"], d["zh"], d["zh_nxt"], d["crx"], d["cry"], d["xfx"], d["yfx"],
+                            d["ws"], rdt)                                     # :911
+            self._swap("zh")
+            ctx.riem_solver3(dt, self.cn, d["zs"], d["w"], d["delz"], d["pt"], d["delp"], d["zh"], d["pe"], d["pkc"],
+                             d["pk3"], d["pk"], d["peln"], d["ws"], fl.use_logp, remap_step, False)   # :932
+            halo.update([(d["zh"], "A"), (d["pkc"], "A")])                    # :944-950 (packs 4, 5)
+            if remap_step:
+                ctx.pe_halo(fl.ptop, d["pe"], d["delp"])                      # :952-953
+            ctx.pk3_halo(fl.ptop, fl.akap, d["pk3"], d["delp"], fl.use_logp)  # :955-959
+            # :982-989 gz = zh*grav is fused into nh_p_grad (gz_scale)
+            ctx.nh_p_grad(d["u"], d["v"], d["pkc"], d["zh"], d["delp"], d["pk3"], dt,
+                          peln1 if fl.use_logp else ptk, gz_scale=fl.grav)    # :1032
+            if it != n_split:
+                halo.update([(d["u"], "U"), (d["v"], "V")])                   # :1168-1169 (pack 8)

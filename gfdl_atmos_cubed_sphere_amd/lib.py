@@ -33,7 +33,7 @@ EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_halo_fill_periodic", "fv3_profile", "fv3_profile_report",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
-           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk"]
+           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz"]
 
 
 class Fv3Error(RuntimeError):
@@ -311,10 +311,13 @@ class Context:
         self.lib.check(self.lib.dll.fv3_p_grad_c(self.h, C.c_double(dt2), delpc.p, pkc.p, gz.p, uc.p, vc.p,
                                                  C.c_int(int(hydrostatic))), "fv3_p_grad_c")
 
-    def nh_p_grad(self, u, v, pp, gz, delp, pk, dt, top_value):
-        """model/dyn_core.F90:1697 nh_p_grad"""
-        self.lib.check(self.lib.dll.fv3_nh_p_grad(self.h, u.p, v.p, pp.p, gz.p, delp.p, pk.p, C.c_double(dt),
-                                                  C.c_double(top_value)), "fv3_nh_p_grad")
+    def nh_p_grad(self, u, v, pp, gz, delp, pk, dt, top_value, gz_scale=1.0):
+        """model/dyn_core.F90:1697 nh_p_grad (gz_scale: read gz*gz_scale, fusing gz = zh*grav of :982-989)"""
+        self.lib.check(self.lib.dll.fv3_nh_p_grad(self.h, u.p, v.p, pp.p, gz.p, C.c_double(gz_scale), delp.p, pk.p,
+                                                  C.c_double(dt), C.c_double(top_value)), "fv3_nh_p_grad")
+
+    def zh_from_delz(self, zs, delz, zh):
+        self.lib.check(self.lib.dll.fv3_zh_from_delz(self.h, zs.p, delz.p, zh.p), "fv3_zh_from_delz")
 
     def pk3_halo(self, ptop, akap, pk3, delp, use_logp=False):
         self.lib.check(self.lib.dll.fv3_pk3_halo(self.h, C.c_double(ptop), C.c_double(akap), pk3.p, delp.p,

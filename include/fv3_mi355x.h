@@ -180,9 +180,14 @@ int fv3_p_grad_c(fv3_ctx *ctx, double dt2, const double *delpc, const double *pk
 
 /* nh_p_grad -- model/dyn_core.F90:1697, call site :1032.  u (U x npz), v (V x npz) updated in place (and
  * multiplied by rdx, rdy).  pp (=pkc), pk (=pk3), gz, delp are NOT modified (the reference overwrites them
- * with their corner interpolants, which nothing reads afterwards). top_value = ptk or peln1 (:1723-1727). */
-int fv3_nh_p_grad(fv3_ctx *ctx, double *u, double *v, const double *pp, const double *gz, const double *delp,
-                  const double *pk, double dt, double top_value);
+ * with their corner interpolants, which nothing reads afterwards). top_value = ptk or peln1 (:1723-1727).
+ * gz_scale: the kernel reads gz*gz_scale (pass zh and grav to fuse "gz = zh*grav", dyn_core.F90:982-989;
+ * 1.0 for a plain gz). */
+int fv3_nh_p_grad(fv3_ctx *ctx, double *u, double *v, const double *pp, const double *gz, double gz_scale,
+                  const double *delp, const double *pk, double dt, double top_value);
+
+/* zh(npz+1) = zs; zh(k) = zh(k+1) - delz(k) on the compute domain -- model/dyn_core.F90:370-385 (it == 1). */
+int fv3_zh_from_delz(fv3_ctx *ctx, const double *zs, const double *delz, double *zh);
 
 /* pk3_halo / pln_halo (use_logp) and pe_halo -- model/dyn_core.F90:1395,1449,1498; call sites :953-958. */
 int fv3_pk3_halo(fv3_ctx *ctx, double ptop, double akap, double *pk3, const double *delp, int use_logp);

@@ -1,0 +1,90 @@
+"""The acoustic substep loop (model/dyn_core.F90:313-1286, nonhydrostatic, non-nested, grid_type=4)
+orchestrated over the ORACLE's routines with numpy arrays and in-place reference semantics.  Test
+infrastructure: the CPU side of the whole-substep parity tests."""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle_lib as O
+from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags, level_coefficients
+from gfdl_atmos_cubed_sphere_amd.layout import Bounds, periodic_fill
+
+
+def _fill(bd, a, kind):
+    if a.ndim == 2:
+        periodic_fill(bd, a, kind)
+    else:
+        for k in range(a.shape[2]):
+            periodic_fill(bd, a[:, :, k], kind)
+
+
+def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
+    """st: u, v, w, delp, pt (halo'd), delz (CC x npz), phis (A).  Returns the updated state dict."""
+    bd: Bounds = g.bd
+    f = {k: np.asfortranarray(v.copy()) for k, v in st.items()}
+    nx, ny = bd.nx, bd.ny
+    for n, kind, nk in (("delpc", "A", npz), ("ptc", "A", npz), ("uc", "V", npz), ("vc", "U", npz), ("ua", "A", npz),
+                        ("va", "A", npz), ("omga", "A", npz), ("ut", "A", npz), ("vt", "A", npz), ("divgd", "B", npz),
+                        ("gz", "A", npz + 1), ("pkc", "A", npz + 1), ("zh", "A", npz + 1), ("pk3", "A", npz + 1),
+                        ("crx", "CX", npz), ("xfx", "CX", npz), ("cry", "CY", npz), ("yfx", "CY", npz),
+                        ("mfx", "FX", npz), ("mfy", "FY", npz), ("cx", "CX", npz), ("cy", "CY", npz),
+                        ("heat_s", "CC", npz), ("diss_e", "CC", npz), ("pk", "CC", npz + 1)):
+        f[n] = bd.zeros(kind, nk)
+    f["ws3"], f["ws"] = bd.zeros("A"), bd.zeros("CC")
+    f["pe"] = np.zeros((nx + 2, npz + 1, ny + 2), order="F")
+    f["peln"] = np.zeros((nx, npz + 1, ny), order="F")
+    zs = np.asfortranarray(f["phis"] * (1.0 / fl.grav))
+    lev = level_coefficients(npz, fl)
+    cn = dict(grav=fl.grav, rdgas=fl.rdgas, cp_air=fl.cp_air, akap=fl.akap, ptop=fl.ptop, p_fac=fl.p_fac, a_imp=fl.a_imp)
+    n_split = fl.n_split
+    dt = bdt / float(n_split)
+    dt2, rdt = 0.5 * dt, 1.0 / dt
+    ptk, peln1 = fl.ptop ** fl.akap, np.log(fl.ptop)
+    par = dict(dt=dt, hord_tr=fl.hord_tr, hord_mt=fl.hord_mt, hord_vt=fl.hord_vt, hord_tm=fl.hord_tm,
+               hord_dp=fl.hord_dp, nord=1, nord_v=1, nord_w=1, nord_t=1, dddmp=fl.dddmp, d2_bg=0.0, d4_bg=fl.d4_bg,
+               damp_v=0.0, damp_w=0.0, damp_t=0.0, d_con=0.0, kgb=fl.ke_bg, hydrostatic=0, use_cond=0)
+    ndif = np.concatenate([lev["nord_v"], lev["nord_v"][-1:]]).astype(np.int32)
+    damp = np.concatenate([lev["damp_vt"], lev["damp_vt"][-1:]])
+    _fill(bd, f["delp"], "A"); _fill(bd, f["pt"], "A"); _fill(bd, f["u"], "U"); _fill(bd, f["v"], "V")
+    for it in range(1, n_split + 1):
+        remap_step = it == n_split
+        _fill(bd, f["w"], "A")
+        if it == 1:
+            gz = f["gz"]
+            i0, j0 = bd.ng, bd.ng
+            gz[i0:i0 + nx, j0:j0 + ny, npz] = zs[i0:i0 + nx, j0:j0 + ny]
+            for k in range(npz - 1, -1, -1):
+                gz[i0:i0 + nx, j0:j0 + ny, k] = gz[i0:i0 + nx, j0:j0 + ny, k + 1] - f["delz"][:, :, k]
+            _fill(bd, gz, "A")
+            f["zh"][...] = gz
+        else:
+            f["gz"][...] = f["zh"]
+        cs = dict(delpc=f["delpc"], delp=f["delp"], ptc=f["ptc"], pt=f["pt"], u=f["u"], v=f["v"], w=f["w"], uc=f["uc"],
+                  vc=f["vc"], ua=f["ua"], va=f["va"], wc=f["omga"], ut=f["ut"], vt=f["vt"], divg_d=f["divgd"])
+        O.c_sw_3d(g, npz, cs, nord=fl.nord, dt2=dt2, hydrostatic=False)
+        if fl.nord > 0:
+            _fill(bd, f["divgd"], "B")
+        O.update_dz_c(g, npz, dt2, dp_ref, zs, f["ut"], f["vt"], f["gz"], f["ws3"])
+        O.riem_solver_c(g, npz, dt2, cn, f["phis"], f["omga"], f["ptc"], f["delpc"], f["gz"], f["pkc"], f["ws3"])
+        O.p_grad_c(g, npz, dt2, f["delpc"], f["pkc"], f["gz"], f["uc"], f["vc"], False)
+        _fill(bd, f["uc"], "V"); _fill(bd, f["vc"], "U")
+        ds = dict(delpc=f["vt"], delp=f["delp"], ptc=f["ptc"], pt=f["pt"], u=f["u"], v=f["v"], w=f["w"], uc=f["uc"],
+                  vc=f["vc"], ua=f["ua"], va=f["va"], divg_d=f["divgd"], mfx=f["mfx"], mfy=f["mfy"], cx=f["cx"],
+                  cy=f["cy"], crx=f["crx"], cry=f["cry"], xfx=f["xfx"], yfx=f["yfx"], heat_source=f["heat_s"],
+                  diss_est=f["diss_e"])
+        O.d_sw_3d(g, npz, par, lev, ds)
+        _fill(bd, f["delp"], "A"); _fill(bd, f["pt"], "A")
+        O.update_dz_d(g, npz, ndif.copy(), damp.copy(), fl.hord_tm, dp_ref, zs, f["zh"], f["crx"], f["cry"], f["xfx"],
+                      f["yfx"], f["ws"], rdt)
+        O.riem_solver3(g, npz, dt, cn, zs, f["w"], f["delz"], f["pt"], f["delp"], f["zh"], f["pe"], f["pkc"], f["pk3"],
+                       f["pk"], f["peln"], f["ws"], fl.use_logp, remap_step, False)
+        _fill(bd, f["zh"], "A"); _fill(bd, f["pkc"], "A")
+        if remap_step:
+            O.pe_halo(g, npz, fl.ptop, f["pe"], f["delp"])
+        O.pk3_halo(g, npz, fl.ptop, fl.akap, f["pk3"], f["delp"], fl.use_logp)
+        i0, i1, j0, j1 = bd.ng - 2, bd.ng + nx + 2, bd.ng - 2, bd.ng + ny + 2
+        f["gz"][i0:i1, j0:j1, :] = f["zh"][i0:i1, j0:j1, :] * fl.grav
+        O.nh_p_grad(g, npz, f["u"], f["v"], f["pkc"], f["gz"], f["delp"], f["pk3"], dt, peln1 if fl.use_logp else ptk)
+        if it != n_split:
+            _fill(bd, f["u"], "U"); _fill(bd, f["v"], "V")
+    return f

@@ -142,3 +142,19 @@ def test_nh_p_grad(prod):
 
 def test_nh_halos_and_geopk(prod):
     N.check_halos_and_geopk(prod)
+
+
+# ---- whole acoustic substeps ---------------------------------------------------------------------
+import parity_dyn as D
+
+
+def test_dyn_core_substeps(prod):
+    D.check_substeps(prod, n_split=2)
+
+
+def test_dyn_core_substeps_sim_solver_damping(prod):
+    D.check_substeps(prod, n_split=3, flags=dict(a_imp=0.75, nord=2, do_vort_damp=True, vtdm4=0.06, dddmp=0.2))
+
+
+def test_dyn_core_substeps_larger(prod):
+    D.check_substeps(prod, nx=96, ny=64, npz=32, n_split=2)

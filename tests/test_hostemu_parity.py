@@ -121,3 +121,15 @@ def test_nh_p_grad(emu):
 
 def test_nh_halos_and_geopk(emu):
     N.check_halos_and_geopk(emu)
+
+
+# ---- whole acoustic substeps ---------------------------------------------------------------------
+import parity_dyn as D
+
+
+def test_dyn_core_substeps(emu):
+    print(D.check_substeps(emu, n_split=2))
+
+
+def test_dyn_core_substeps_sim_solver_damping(emu):
+    D.check_substeps(emu, n_split=3, flags=dict(a_imp=0.75, nord=2, do_vort_damp=True, vtdm4=0.06, dddmp=0.2))
