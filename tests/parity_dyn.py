@@ -21,6 +21,19 @@ def make_state(bd, npz, seed=21):
                 phis=np.asfortranarray(s["zs"] * GRAV)), s["dp0"]
 
 
+def ulp_sensitivity(g, npz, fl, dp0, st, bdt, ref):
+    """rel-RMS change of the ORACLE's own result when pt is perturbed by +-1 ulp: the conditioning floor of
+    each output.  w is the sensitive one: the nonhydrostatic pressure perturbation is the difference of two
+    O(1e5 Pa) numbers obtained through exp/log (nh_utils.F90:1299), so one ulp in them is O(1e-11) in w --
+    the reference itself warns that this routine is not reproducible across transcendental implementations
+    (nh_utils.F90:483-484)."""
+    rng = np.random.default_rng(0)
+    st2 = {k: v.copy() for k, v in st.items()}
+    st2["pt"] = np.asfortranarray(st["pt"] * (1.0 + 2.2e-16 * rng.choice([-1, 0, 1], st["pt"].shape)))
+    pert = OD.run(g, npz, fl, dp0, st2, bdt)
+    return {n: P.rel_rms(pert[n], ref[n]) for n in ("u", "v", "w", "delp", "pt", "zh", "delz", "mfx", "mfy", "cx", "cy")}
+
+
 def check_substeps(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None, tol=None):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
@@ -33,15 +46,21 @@ def check_substeps(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None, tol
         dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
         dc.run(bdt)
         got = dc.get_state()
-        tol = tol or (1e-13 if "hostemu" in lib.path else 1e-12)
+        emu = "hostemu" in lib.path
+        tol = tol or (1e-13 if emu else 1e-12)
+        # On the GPU exp/log come from a different math library than the oracle's glibc (neither is correctly
+        # rounded), so each output is allowed 1e-12 or 5x its own 1-ulp conditioning floor, whichever is larger
+        # (in practice only w exceeds 1e-12: floor ~5e-12 at 32 levels).
+        sens = {} if emu else ulp_sensitivity(g, npz, fl, dp0, st, bdt, ref)
+        tols = {n: max(tol, 5.0 * sens.get(n, 0.0)) for n in ("u", "v", "w", "delp", "pt", "zh", "delz", "mfx", "mfy", "cx", "cy")}
         r = (bd.is_, bd.ie, bd.js, bd.je)
         out = {}
         for n, kind, rr in (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)),
                             ("w", "A", r), ("delp", "A", r), ("pt", "A", r), ("zh", "A", r)):
-            out[n] = P.assert_close(n, bd.view(got[n], kind, *rr), bd.view(ref[n], kind, *rr), tol)
-        out["delz"] = P.assert_close("delz", got["delz"], ref["delz"], tol)
+            out[n] = P.assert_close(n, bd.view(got[n], kind, *rr), bd.view(ref[n], kind, *rr), tols[n])
+        out["delz"] = P.assert_close("delz", got["delz"], ref["delz"], tols["delz"])
         for n in ("mfx", "mfy", "cx", "cy"):
-            out[n] = P.assert_close(n, got[n], ref[n], tol)
+            out[n] = P.assert_close(n, got[n], ref[n], tols[n])
         # sanity: the step did something and stayed sane
         assert np.all(ref["delz"] < 0) and np.max(np.abs(ref["w"])) < 50.0
     finally:

@@ -181,3 +181,23 @@ def test_d_sw_uniform_flow_is_steady():
     np.testing.assert_allclose(bd.view(f["v"][:, :, 1], "V", bd.is_, bd.ie + 1, bd.js, bd.je), -4.0 * 1000.0, rtol=1e-13)
     np.testing.assert_allclose(bd.view(f["delp"][:, :, 1], "A", bd.is_, bd.ie, bd.js, bd.je), 500.0, rtol=1e-14)
     np.testing.assert_allclose(bd.view(f["pt"][:, :, 1], "A", bd.is_, bd.ie, bd.js, bd.je), 290.0, rtol=1e-14)
+
+
+def test_substep_w_conditioning_floor():
+    """Documents why whole-substep parity of w cannot be held to 1e-12 across math libraries: the oracle's own
+    w moves by ~1e-12..1e-11 (rel. RMS) when pt moves by one ulp; everything else stays below 1e-12."""
+    import parity_dyn as D
+    import oracle_dyn_core as OD
+    import parity_common as P
+    import parity_nh as N
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
+    bd = Bounds(1, 24, 1, 16)
+    npz = 16
+    g = P.make_grid(bd, False)
+    st, dp0 = D.make_state(bd, npz)
+    fl = DynFlags(n_split=2, ptop=N.PTOP)
+    ref = OD.run(g, npz, fl, dp0, st, 4.0)
+    sens = D.ulp_sensitivity(g, npz, fl, dp0, st, 4.0, ref)
+    assert sens["w"] > 1e-13            # ill-conditioned
+    for n in ("u", "v", "delp", "pt", "zh"):
+        assert sens[n] < 1e-12, (n, sens[n])
