@@ -11,6 +11,7 @@
 #include "fv3_common.h"
 #include "fv3_launch.h"
 #include "nh_kernels.h"
+#include "remap_kernels.h"
 #include "tp2d_tile.h"
 
 using namespace fv3;
@@ -44,6 +45,9 @@ struct fv3_ctx {
   double *scratch[8];
   double *lev_ext_d;  // damp(npz+1) for update_dz_d
   int *lev_ext_i;     // ndif(npz+1)
+  double *akbk;       // device, 2*(npz+1)
+  int *kord_tr_dev;   // device, up to 64 tracers
+  bool akbk_ready;
   bool prof_on;
   struct ProfRec { const char *label; void *e0, *e1; };
   std::vector<ProfRec> prof;
@@ -141,6 +145,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->lev_i = nullptr; c->lev_d = nullptr; c->lev_ready = false;
   c->prof_on = false;
   c->dp0 = nullptr; c->edge_dev = nullptr; c->dp0_ready = false;
+  c->akbk = nullptr; c->kord_tr_dev = nullptr; c->akbk_ready = false;
   for (auto &s : c->scratch) s = nullptr;
   c->lev_ext_d = nullptr; c->lev_ext_i = nullptr;
   *out = c;
@@ -153,6 +158,8 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   if (c->lev_i) rt_free(c->lev_i);
   if (c->lev_d) rt_free(c->lev_d);
   if (c->dp0) rt_free(c->dp0);
+  if (c->akbk) rt_free(c->akbk);
+  if (c->kord_tr_dev) rt_free(c->kord_tr_dev);
   if (c->edge_dev) rt_free(c->edge_dev);
   if (c->lev_ext_d) rt_free(c->lev_ext_d);
   if (c->lev_ext_i) rt_free(c->lev_ext_i);
@@ -679,5 +686,64 @@ extern "C" int fv3_geopk(fv3_ctx *c, double ptop, double akap, double cp_air, do
   const int e = CG ? 1 : 2;
   Geopk kf{c->g, c->g.npz, CG, ptop, akap, cp_air, ptk, delp, hs, pt, pe, peln, pk, gz, pkz};
   RT(launch_p(c, "geopk", col_grid((c->g.nx + 2 * e) * (c->g.ny + 2 * e)), 0, kf));
+  return 0;
+}
+
+// ================================================================================================
+// vertical remap
+// ================================================================================================
+extern "C" int fv3_set_ak_bk(fv3_ctx *c, const double *ak, const double *bk) {
+  if (!c || !ak || !bk) return fail("fv3_set_ak_bk: null argument");
+  const int n = c->g.npz + 1;
+  if (!c->akbk) RT(rt_malloc((void **)&c->akbk, sizeof(double) * 2 * n));
+  RT(rt_h2d(c->akbk, ak, sizeof(double) * n, c->stream));
+  RT(rt_h2d(c->akbk + n, bk, sizeof(double) * n, c->stream));
+  RT(rt_sync(c->stream));
+  c->akbk_ready = true;
+  return 0;
+}
+
+extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p, const int *kord_tr, double *ps,
+                                          double *pe, double *delp, double *pkz, double *pk, double *u, double *v,
+                                          double *w, double *delz, double *pt, double *q, double *peln, double *omga,
+                                          const double *ws) {
+  if (!c || !c->grid_ready || !p) return fail("fv3_lagrangian_to_eulerian: bad context/arguments");
+  if (!c->akbk_ready) return fail("fv3_lagrangian_to_eulerian: call fv3_set_ak_bk first");
+  if (p->nq < 0 || p->nq > 64) return fail("fv3_lagrangian_to_eulerian: nq out of range");
+  if (p->nq > 0 && (!kord_tr || !q)) return fail("fv3_lagrangian_to_eulerian: tracers need q and kord_tr");
+  if (!kord_supported(p->kord_mt) || !kord_supported(p->kord_tm) || (!p->hydrostatic && !kord_supported(p->kord_wz)))
+    return fail("fv3_lagrangian_to_eulerian: |kord| must be one of 8,9,10,11,13");
+  if (!p->hydrostatic && p->kord_wz < 0)
+    return fail("fv3_lagrangian_to_eulerian: kord_wz < 0 (iv=-3) reads an unset array element in the reference; not built");
+  for (int n = 0; n < p->nq; n++)
+    if (!kord_supported(kord_tr[n])) return fail("fv3_lagrangian_to_eulerian: kord_tr(%d) unsupported", n + 1);
+  if (c->g.npz < 5) return fail("fv3_lagrangian_to_eulerian: needs npz > 4 (fv_dynamics.F90:574)");
+  if (need_scratch(c, 8)) return 1;
+  const Grid &g = c->g;
+  const int km = g.npz;
+  if (p->nq > 0) {
+    if (!c->kord_tr_dev) RT(rt_malloc((void **)&c->kord_tr_dev, sizeof(int) * 64));
+    RT(rt_h2d(c->kord_tr_dev, kord_tr, sizeof(int) * p->nq, c->stream));
+    RT(rt_sync(c->stream));
+  }
+  RemapPar rp{p->last_step, p->hydrostatic, p->adiabatic, p->nq, p->kord_mt, p->kord_wz, p->kord_tm, p->sphum,
+              p->akap, p->ptop, p->rdgas, p->grav, p->cv_air, p->r_vir, p->cp, p->t_min};
+  ColScr s{c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->scratch[4], c->scratch[5], c->scratch[6],
+           c->scratch[7], g.nA(), 0};
+  const double *ak = c->akbk, *bk = c->akbk + (km + 1);
+  {
+    RemapScalars kf{g, km, rp, ak, bk, c->kord_tr_dev, ps, delp, pkz, pk, w, delz, pt, q, peln, omga, pe, ws, s};
+    RT(launch_p(c, "remap_scalars", col_grid(g.nx * g.ny), 0, kf));
+  }
+  {
+    RemapWinds ku{g, km, rp, ak, bk, pe, u, v, s, 0};
+    RT(launch_p(c, "remap_u", col_grid(g.nx * (g.ny + 1)), 0, ku));
+    RemapWinds kv{g, km, rp, ak, bk, pe, u, v, s, 1};
+    RT(launch_p(c, "remap_v", col_grid((g.nx + 1) * g.ny), 0, kv));
+  }
+  {
+    RemapPe kf{g, km, ak, bk, pe};
+    RT(launch_p(c, "remap_pe", col_grid(g.nx * g.ny), 0, kf));
+  }
   return 0;
 }

@@ -1,0 +1,490 @@
+// remap_kernels.h -- the vertical remap Lagrangian_to_Eulerian (model/fv_mapz.F90:56-845) and the
+// profile / mapping operators it uses (model/fv_operators.F90: scalar_profile :546-916, cs_profile
+// :919-1300, cs_limiters :1303-1378, map_scalar :40, map1_ppm :137, mapn_tracer :234, map1_q2 :352).
+//
+// One thread per column, consecutive threads = consecutive i.  The piecewise-parabolic coefficients
+// a4(1:4,k), the interface values and the two pressure coordinates of a column live in context-owned
+// scratch slabs laid out like the fields (level stride = one A slab), so every sweep over k is a
+// coalesced access across the wavefront; the data-dependent search of the mapping loop only moves
+// forward (k0 carry) and neighbouring columns move together.
+// Branches: remap_te = .false., use_cond = moist_kappa = .false., consv = 0, fill = .false.;
+// |kord| in {8,9,10,11,13}; iv in {-2,-1,0,1} (iv=-3 is undefined behaviour in the reference).
+#pragma once
+
+#include "fv3_common.h"
+
+namespace fv3 {
+
+struct ColScr {
+  double *a1, *q, *a2, *a3, *a4, *pe1, *pe2, *gam;  // slabs, (km+1) levels each
+  size_t ls;                                         // level stride
+  int o;                                             // column offset inside a slab
+};
+#define CS(p, k) (c.p)[(size_t)((k)-1) * c.ls + c.o]
+
+FV3_HD bool kord_supported(int kord) {
+  const int a = kord < 0 ? -kord : kord;
+  return a == 8 || a == 9 || a == 10 || a == 11 || a == 13;
+}
+
+// cs_limiters for one cell (fv_operators.F90:1303-1378)
+FV3_HD void cs_limit(bool extm, double a1, double &a2, double &a3, double &a4, int iv) {
+  constexpr double r12 = 1. / 12.;
+  if (iv == 0) {
+    if (a1 <= 0.) {
+      a2 = a1; a3 = a1; a4 = 0.;
+    } else if (fabs(a3 - a2) < -a4) {
+      if ((a1 + 0.25 * ((a3 - a2) * (a3 - a2)) / a4 + a4 * r12) < 0.) {
+        if (a1 < a3 && a1 < a2) {
+          a3 = a1; a2 = a1; a4 = 0.;
+        } else if (a3 > a2) {
+          a4 = 3. * (a2 - a1); a3 = a2 - a4;
+        } else {
+          a4 = 3. * (a3 - a1); a2 = a3 - a4;
+        }
+      }
+    }
+    return;
+  }
+  bool flat;
+  if (iv == 1)
+    flat = (a1 - a2) * (a1 - a3) >= 0.;
+  else
+    flat = extm;
+  if (flat) {
+    a2 = a1; a3 = a1; a4 = 0.;
+  } else {
+    const double da1 = a3 - a2, da2 = da1 * da1, a6da = a4 * da1;
+    if (a6da < -da2) {
+      a4 = 3. * (a2 - a1); a3 = a2 - a4;
+    } else if (a6da > da2) {
+      a4 = 3. * (a3 - a1); a2 = a3 - a4;
+    }
+  }
+}
+
+// scalar_profile (is_scalar) / cs_profile for the column whose a4(1,:) is in c.a1 and whose source
+// coordinate is in c.pe1.  Writes c.a2, c.a3, c.a4 (and uses c.q, c.gam).
+FV3_HD void profile_col(const ColScr &c, int km, bool is_scalar, double qs, int iv, int kord, double qmin) {
+  const int ak = kord < 0 ? -kord : kord;
+#define DP(k) (CS(pe1, (k) + 1) - CS(pe1, k))
+  // ---- interface values: cubic spline tridiagonal ----
+  if (iv == -2) {  // :572-595 / :941-964
+    double gam = 0.5, qk = 1.5 * CS(a1, 1);
+    CS(q, 1) = qk;
+    CS(gam, 2) = gam;
+    for (int k = 2; k <= km - 1; k++) {
+      const double grat = DP(k - 1) / DP(k);
+      const double bet = 2. + grat + grat - gam;
+      qk = (3. * (CS(a1, k - 1) + CS(a1, k)) - qk) / bet;
+      gam = grat / bet;
+      CS(q, k) = qk;
+      CS(gam, k + 1) = gam;
+    }
+    const double grat = DP(km - 1) / DP(km);
+    qk = (3. * (CS(a1, km - 1) + CS(a1, km)) - grat * qs - qk) / (2. + grat + grat - gam);
+    CS(q, km) = qk;
+    CS(q, km + 1) = qs;
+    for (int k = km - 1; k >= 1; k--) {
+      qk = CS(q, k) - CS(gam, k + 1) * qk;
+      CS(q, k) = qk;
+    }
+  } else {  // :597-623 / :967-1016
+    double grat = DP(2) / DP(1);
+    double bet = grat * (grat + 0.5);
+    double qk = ((grat + grat) * (grat + 1.) * CS(a1, 1) + CS(a1, 2)) / bet;
+    double gam = (1. + grat * (grat + 1.5)) / bet;
+    CS(q, 1) = qk;
+    CS(gam, 1) = gam;
+    double d4 = 0.;
+    for (int k = 2; k <= km; k++) {
+      d4 = DP(k - 1) / DP(k);
+      bet = 2. + d4 + d4 - gam;
+      qk = (3. * (CS(a1, k - 1) + d4 * CS(a1, k)) - qk) / bet;
+      gam = d4 / bet;
+      CS(q, k) = qk;
+      CS(gam, k) = gam;
+    }
+    const double a_bot = 1. + d4 * (d4 + 1.5);
+    qk = (2. * d4 * (d4 + 1.) * CS(a1, km) + CS(a1, km - 1) - a_bot * qk) / (d4 * (d4 + 0.5) - a_bot * gam);
+    CS(q, km + 1) = qk;
+    for (int k = km; k >= 1; k--) {
+      qk = CS(q, k) - CS(gam, k) * qk;
+      CS(q, k) = qk;
+    }
+  }
+#undef DP
+  // ---- large-scale constraints on the interface values (:643-680 / :1037-1073) ----
+  {
+    const double a_1 = CS(a1, 1), a_2 = CS(a1, 2);
+    double v = dmin(CS(q, 2), dmax(a_1, a_2));
+    CS(q, 2) = dmax(v, dmin(a_1, a_2));
+    for (int k = 3; k <= km - 1; k++) {
+      const double am2 = CS(a1, k - 2), am1 = CS(a1, k - 1), a0 = CS(a1, k), ap1 = CS(a1, k + 1);
+      const double gm = am1 - am2, gp = ap1 - a0;  // gam(k-1), gam(k+1)
+      double qk = CS(q, k);
+      if (ak >= 14 || gm * gp > 0.) {
+        qk = dmin(qk, dmax(am1, a0));
+        qk = dmax(qk, dmin(am1, a0));
+      } else if (gm > 0.) {
+        qk = dmax(qk, dmin(am1, a0));
+      } else {
+        qk = dmin(qk, dmax(am1, a0));
+        if (iv == 0) qk = dmax(0., qk);
+      }
+      CS(q, k) = qk;
+    }
+    const double b1 = CS(a1, km - 1), b0 = CS(a1, km);
+    v = dmin(CS(q, km), dmax(b1, b0));
+    CS(q, km) = dmax(v, dmin(b1, b0));
+  }
+  // ---- subgrid constraints (:691-914 / :1082-1298) ----
+  auto dq = [&](int k) { return CS(a1, k) - CS(a1, k - 1); };                     // gam(k) after :650
+  auto extm = [&](int k) {
+    if (k == 1 || k == km) return (CS(q, k) - CS(a1, k)) * (CS(q, k + 1) - CS(a1, k)) > 0.;
+    return dq(k) * dq(k + 1) < 0.;
+  };
+  auto ext5 = [&](int k) {
+    const double x0 = 2. * CS(a1, k) - (CS(q, k) + CS(q, k + 1));
+    return fabs(x0) > fabs(CS(q, k) - CS(q, k + 1));
+  };
+  for (int k = 1; k <= km; k++) {
+    const double a1v = CS(a1, k);
+    double a2v = CS(q, k), a3v = CS(q, k + 1), a4v;
+    if (k == 1) {
+      const bool e = extm(1);
+      if (iv == 0) a2v = dmax(0., a2v);
+      if (iv == -1 && a2v * a1v <= 0.) a2v = 0.;
+      a4v = 3. * (2. * a1v - (a2v + a3v));
+      cs_limit(e, a1v, a2v, a3v, a4v, 1);
+    } else if (k == 2) {
+      a4v = 3. * (2. * a1v - (a2v + a3v));
+      cs_limit(extm(2), a1v, a2v, a3v, a4v, 2);
+    } else if (k <= km - 2) {
+      const double g_k = dq(k), g_p1 = dq(k + 1), g_p2 = dq(k + 2), g_m1 = dq(k - 1);
+      auto huynh = [&]() {
+        const double pmp_1 = a1v - 2. * g_p1, lac_1 = pmp_1 + 1.5 * g_p2;
+        a2v = dmin(dmax(a2v, dmin3(a1v, pmp_1, lac_1)), dmax3(a1v, pmp_1, lac_1));
+        const double pmp_2 = a1v + 2. * g_k, lac_2 = pmp_2 - 1.5 * g_m1;
+        a3v = dmin(dmax(a3v, dmin3(a1v, pmp_2, lac_2)), dmax3(a1v, pmp_2, lac_2));
+      };
+      if (ak <= 8) {
+        huynh();
+        a4v = 3. * (2. * a1v - (a2v + a3v));
+      } else if (ak == 9) {
+        const bool e = extm(k);
+        if ((e && extm(k - 1)) || (e && extm(k + 1)) || (is_scalar && e && a1v < qmin)) {
+          a2v = a1v; a3v = a1v; a4v = 0.;
+        } else {
+          a4v = is_scalar ? 3. * (2. * a1v - (a2v + a3v)) : 6. * a1v - 3. * (a2v + a3v);
+          if (fabs(a4v) > fabs(a2v - a3v)) {
+            huynh();
+            a4v = is_scalar ? 3. * (2. * a1v - (a2v + a3v)) : 6. * a1v - 3. * (a2v + a3v);
+          }
+        }
+      } else if (ak == 10) {
+        if (extm(k)) {
+          if ((is_scalar && a1v < qmin) || extm(k - 1) || extm(k + 1)) {
+            a2v = a1v; a3v = a1v; a4v = 0.;
+          } else {
+            a4v = 6. * a1v - 3. * (a2v + a3v);
+          }
+        } else {
+          a4v = 6. * a1v - 3. * (a2v + a3v);
+          if (fabs(a4v) > fabs(a2v - a3v)) {
+            huynh();
+            a4v = 6. * a1v - 3. * (a2v + a3v);
+          }
+        }
+      } else if (ak == 11) {
+        if (ext5(k) && (ext5(k - 1) || ext5(k + 1) || (is_scalar && a1v < qmin))) {
+          a2v = a1v; a3v = a1v; a4v = 0.;
+        } else {
+          a4v = 3. * (2. * a1v - (a2v + a3v));
+        }
+      } else {  // 13
+        a4v = 3. * (2. * a1v - (a2v + a3v));
+      }
+      if (iv == 0 && ak <= 13) cs_limit(false, a1v, a2v, a3v, a4v, 0);
+    } else {
+      if (k == km) {
+        if (iv == 0) a3v = dmax(0., a3v);
+        if (iv == -1 && a3v * a1v <= 0.) a3v = 0.;
+      }
+      a4v = 3. * (2. * a1v - (a2v + a3v));
+      cs_limit(extm(k), a1v, a2v, a3v, a4v, k == km ? 1 : 2);
+    }
+    CS(a2, k) = a2v;
+    CS(a3, k) = a3v;
+    CS(a4, k) = a4v;
+  }
+}
+
+// the search-and-integrate loop (fv_operators.F90:93-132 == :188-227 == :402-441; tracer_form: :277-335)
+template <class Out>
+FV3_HD void map_col(const ColScr &c, int km, bool tracer_form, const Out &out) {
+  constexpr double r3 = 1. / 3., r23 = 2. / 3.;
+  int k0 = 1;
+  double qsum = 0.;
+  for (int k = 1; k <= km; k++) {
+    const double p2t = CS(pe2, k), p2b = CS(pe2, k + 1);
+    int done = 0;
+    for (int l = k0; l <= km && !done; l++) {
+      const double p1t = CS(pe1, l), p1b = CS(pe1, l + 1);
+      if (p2t >= p1t && p2t <= p1b) {
+        const double dp1 = p1b - p1t;
+        const double pl = (p2t - p1t) / dp1;
+        const double b2 = CS(a2, l), b3 = CS(a3, l), b4 = CS(a4, l);
+        if (p2b <= p1b) {
+          const double pr = (p2b - p1t) / dp1;
+          double val;
+          if (tracer_form) {
+            double fac1 = pr + pl;
+            const double fac2 = r3 * (pr * fac1 + pl * pl);
+            fac1 = 0.5 * fac1;
+            val = b2 + (b4 + b3 - b2) * fac1 - b4 * fac2;
+          } else {
+            val = b2 + 0.5 * (b4 + b3 - b2) * (pr + pl) - b4 * r3 * (pr * (pr + pl) + pl * pl);
+          }
+          out(k, val);
+          k0 = l;
+          done = 2;
+        } else {
+          if (tracer_form) {
+            const double dp = p1b - p2t;
+            double fac1 = 1. + pl;
+            const double fac2 = r3 * (1. + pl * fac1);
+            fac1 = 0.5 * fac1;
+            qsum = dp * (b2 + (b4 + b3 - b2) * fac1 - b4 * fac2);
+          } else {
+            qsum = (p1b - p2t) * (b2 + 0.5 * (b4 + b3 - b2) * (1. + pl) - b4 * (r3 * (1. + pl * (1. + pl))));
+          }
+          for (int m = l + 1; m <= km; m++) {
+            const double mt = CS(pe1, m), mb = CS(pe1, m + 1);
+            if (p2b > mb) {
+              qsum = qsum + (mb - mt) * CS(a1, m);
+            } else {
+              const double dp = p2b - mt;
+              const double esl = dp / (mb - mt);
+              const double m2 = CS(a2, m), m3 = CS(a3, m), m4 = CS(a4, m);
+              if (tracer_form) {
+                const double fac1 = 0.5 * esl, fac2 = 1. - r23 * esl;
+                qsum = qsum + dp * (m2 + fac1 * (m3 - m2 + m4 * fac2));
+              } else {
+                qsum = qsum + dp * (m2 + 0.5 * esl * (m3 - m2 + m4 * (1. - r23 * esl)));
+              }
+              k0 = m;
+              break;
+            }
+          }
+          done = 1;
+        }
+      }
+    }
+    if (done != 2) out(k, qsum / (p2b - p2t));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct RemapPar {
+  int last_step, hydrostatic, adiabatic, nq, kord_mt, kord_wz, kord_tm, sphum;
+  double akap, ptop, rdgas, grav, cv_air, r_vir, cp, t_min;
+};
+
+#define FV3_COL_FOR2(c, ncol) for (int c = bx * 256 + tid; c < (bx + 1) * 256 && c < (ncol); c += kNT)
+
+// cell-centred fields of one column: pt, tracers, w, delz, delp, pk, peln, pkz, ps, omga (fv_mapz.F90:184-528)
+struct RemapScalars {
+  Grid g;
+  int km;
+  RemapPar p;
+  const double *ak, *bk;  // device, km+1
+  const int *kord_tr;     // device, nq
+  double *ps, *delp, *pkz, *pk, *w, *delz, *pt, *q, *peln, *omga;
+  const double *pe, *ws;
+  ColScr s;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int ncol = g.nx * g.ny;
+    const size_t nA = g.nA(), nCC = g.nCC();
+    const double k1k = p.rdgas / p.cv_air, rrg = -p.rdgas / p.grav, akap = p.akap;
+    const int akt = p.kord_tm < 0 ? -p.kord_tm : p.kord_tm;
+    FV3_COL_FOR2(col, ncol) {
+      const int i = g.is + col % g.nx, j = g.js + col / g.nx;
+      ColScr c = s;
+      c.o = g.iA(i, j);
+      const int occ = g.iCC(i, j);
+      const size_t peb = (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1));
+      const size_t lnb = (size_t)(j - g.js) * g.nx * (km + 1) + (i - g.is);
+      auto PE = [&](int k) { return pe[peb + (size_t)(k - 1) * (g.nx + 2)]; };
+      auto PELN = [&](int k) -> double & { return peln[lnb + (size_t)(k - 1) * g.nx]; };
+      const double psfc = PE(km + 1);
+      // ---- 0) temperature transform (:200-229), specific volume (:292) ----
+      for (int k = 1; k <= km; k++) {
+        double t = pt[(size_t)(k - 1) * nA + c.o];
+        const double dpo = delp[(size_t)(k - 1) * nA + c.o];
+        if (p.kord_tm < 0) {
+          if (p.hydrostatic)
+            t = t * (pk[(size_t)k * nCC + occ] - pk[(size_t)(k - 1) * nCC + occ]) / (akap * (PELN(k + 1) - PELN(k)));
+          else
+            t = t * exp(k1k * log(rrg * dpo / delz[(size_t)(k - 1) * nCC + occ] * t));
+        }
+        CS(a1, k) = t;
+        if (!p.hydrostatic) delz[(size_t)(k - 1) * nCC + occ] = -delz[(size_t)(k - 1) * nCC + occ] / dpo;
+      }
+      ps[c.o] = psfc;  // :298-300
+      // ---- 1) remap T_v (log-p coordinate, :363-368) or theta_v (:370-374) ----
+      if (p.kord_tm < 0) {
+        for (int k = 1; k <= km + 1; k++) {
+          CS(pe1, k) = PELN(k);
+          const double pe2k = (k == 1) ? p.ptop : (k == km + 1 ? psfc : ak[k - 1] + bk[k - 1] * psfc);
+          CS(pe2, k) = (k == 1) ? PELN(1) : (k == km + 1 ? PELN(km + 1) : log(pe2k));
+        }
+        profile_col(c, km, true, 0., 1, akt, p.t_min);
+      } else {
+        for (int k = 1; k <= km + 1; k++) {
+          CS(pe1, k) = PE(k);
+          CS(pe2, k) = (k == 1) ? p.ptop : (k == km + 1 ? psfc : ak[k - 1] + bk[k - 1] * psfc);
+        }
+        profile_col(c, km, false, 0., 1, akt, 0.);
+      }
+      map_col(c, km, false, [&](int k, double v) { pt[(size_t)(k - 1) * nA + c.o] = v; });
+      // ---- 3.3) omega (:432-443, :506-526): needs the old peln (= pe1 here when kord_tm < 0) ----
+      if (p.last_step) {
+        CS(gam, 1) = 0.;
+        for (int k = 2; k <= km + 1; k++) CS(gam, k) = omga[(size_t)(k - 2) * nA + c.o];  // pe3
+        int k_next = 1;
+        for (int n = 1; n <= km; n++) {
+          const double pn_t = (n == 1) ? PELN(1) : log(ak[n - 1] + bk[n - 1] * psfc);
+          const double pn_b = (n + 1 == km + 1) ? PELN(km + 1) : log(ak[n] + bk[n] * psfc);
+          const double mid = 0.5 * (pn_t + pn_b);
+          for (int k = k_next; k <= km; k++) {
+            const double e0 = PELN(k), e1 = PELN(k + 1);
+            if (mid <= e1 && mid >= e0) {
+              omga[(size_t)(n - 1) * nA + c.o] = CS(gam, k) + (CS(gam, k + 1) - CS(gam, k)) * (mid - e0) / (e1 - e0);
+              k_next = k;
+              break;
+            }
+          }
+        }
+      }
+      // ---- pressure coordinates for everything else (:304-345) ----
+      for (int k = 1; k <= km + 1; k++) {
+        CS(pe1, k) = PE(k);
+        CS(pe2, k) = (k == 1) ? p.ptop : (k == km + 1 ? psfc : ak[k - 1] + bk[k - 1] * psfc);
+      }
+      // ---- 2) constituents (:380-397) ----
+      for (int iq = 0; iq < p.nq; iq++) {
+        double *qq = q + (size_t)iq * nA * km;
+        for (int k = 1; k <= km; k++) CS(a1, k) = qq[(size_t)(k - 1) * nA + c.o];
+        profile_col(c, km, true, 0., 0, kord_tr[iq], 0.);
+        map_col(c, km, p.nq > 5, [&](int k, double v) { qq[(size_t)(k - 1) * nA + c.o] = v; });
+      }
+      // ---- 3) w and delz (:400-423) ----
+      if (!p.hydrostatic) {
+        for (int k = 1; k <= km; k++) CS(a1, k) = w[(size_t)(k - 1) * nA + c.o];
+        profile_col(c, km, false, ws[occ], -2, p.kord_wz, 0.);
+        map_col(c, km, false, [&](int k, double v) { w[(size_t)(k - 1) * nA + c.o] = v; });
+        for (int k = 1; k <= km; k++) CS(a1, k) = delz[(size_t)(k - 1) * nCC + occ];
+        profile_col(c, km, false, 0., 1, akt, 0.);
+        map_col(c, km, false, [&](int k, double v) {
+          delz[(size_t)(k - 1) * nCC + occ] = -v * (CS(pe2, k + 1) - CS(pe2, k));
+        });
+      }
+      // ---- delp, pk, peln, pkz (:318-322, :426-430, :445-503) ----
+      double pn_prev = PELN(1), pk_prev = pk[occ];
+      for (int k = 1; k <= km; k++) {
+        const double dp2 = CS(pe2, k + 1) - CS(pe2, k);
+        delp[(size_t)(k - 1) * nA + c.o] = dp2;
+        double pn_next, pk_next;
+        if (k + 1 == km + 1) {
+          pn_next = PELN(km + 1);
+          pk_next = pk[(size_t)km * nCC + occ];
+        } else {
+          pn_next = log(CS(pe2, k + 1));
+          pk_next = exp(akap * pn_next);
+          PELN(k + 1) = pn_next;
+          pk[(size_t)k * nCC + occ] = pk_next;
+        }
+        double pkzv;
+        const double tv = pt[(size_t)(k - 1) * nA + c.o];
+        if (p.hydrostatic)
+          pkzv = (pk_next - pk_prev) / (akap * (pn_next - pn_prev));
+        else if (p.kord_tm < 0)
+          pkzv = exp(akap * log(rrg * dp2 / delz[(size_t)(k - 1) * nCC + occ] * tv));
+        else
+          pkzv = exp(k1k * log(rrg * dp2 / delz[(size_t)(k - 1) * nCC + occ] * tv));
+        pkz[(size_t)(k - 1) * nCC + occ] = pkzv;
+        double tnew = tv;
+        if (p.kord_tm > 0) tnew = tnew * pkzv;  // :496-502
+        if (p.last_step) {                      // :793-821 (dtmp = 0)
+          if (!p.adiabatic) {
+            const double qv = p.sphum > 0 ? q[(size_t)(p.sphum - 1) * nA * km + (size_t)(k - 1) * nA + c.o] : 0.;
+            tnew = (tnew + 0. / (p.hydrostatic ? p.cp : p.cv_air) * pkzv) / (1. + p.r_vir * qv);
+          }
+        } else {
+          tnew = tnew / pkzv;                   // :833-841
+        }
+        pt[(size_t)(k - 1) * nA + c.o] = tnew;
+        pn_prev = pn_next;
+        pk_prev = pk_next;
+      }
+    }
+  }
+};
+
+// D-grid winds: u on (is:ie, js:je+1), v on (is:ie+1, js:je)  (fv_mapz.F90:530-573)
+struct RemapWinds {
+  Grid g;
+  int km;
+  RemapPar p;
+  const double *ak, *bk;
+  const double *pe;
+  double *u, *v;
+  ColScr s;
+  int which;  // 0 = u, 1 = v
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int wdt = which == 0 ? g.nx : g.nx + 1, hgt = which == 0 ? g.ny + 1 : g.ny;
+    const int ncol = wdt * hgt;
+    const size_t nU = g.nU(), nV = g.nV();
+    FV3_COL_FOR2(col, ncol) {
+      const int i = g.is + col % wdt, j = g.js + col / wdt;
+      ColScr c = s;
+      c.o = g.iA(i, j);
+      auto PE = [&](int ii, int k, int jj) {
+        return pe[(size_t)(jj - (g.js - 1)) * (g.nx + 2) * (km + 1) + (size_t)(k - 1) * (g.nx + 2) + (ii - (g.is - 1))];
+      };
+      const int i2 = which == 0 ? i : i - 1, j2 = which == 0 ? j - 1 : j;  // the other cell sharing the face
+      const double psum = PE(i2, km + 1, j2) + PE(i, km + 1, j);
+      for (int k = 1; k <= km + 1; k++) {
+        CS(pe1, k) = (k == 1) ? PE(i, 1, j) : 0.5 * (PE(i2, k, j2) + PE(i, k, j));
+        const double bkh = 0.5 * bk[k - 1];
+        CS(pe2, k) = (which == 1 && k == 1) ? ak[0] : ak[k - 1] + bkh * psum;
+      }
+      double *f = which == 0 ? u + g.iU(i, j) : v + g.iV(i, j);
+      const size_t fs = which == 0 ? nU : nV;
+      for (int k = 1; k <= km; k++) CS(a1, k) = f[(size_t)(k - 1) * fs];
+      profile_col(c, km, false, 0., -1, p.kord_mt, 0.);
+      map_col(c, km, false, [&](int k, double val) { f[(size_t)(k - 1) * fs] = val; });
+    }
+  }
+};
+
+// pe(i,k,j) = pe2(i,k) for k = 2..km (fv_mapz.F90:624-641)
+struct RemapPe {
+  Grid g;
+  int km;
+  const double *ak, *bk;
+  double *pe;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int ncol = g.nx * g.ny;
+    FV3_COL_FOR2(col, ncol) {
+      const int i = g.is + col % g.nx, j = g.js + col / g.nx;
+      const size_t peb = (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1));
+      const double psfc = pe[peb + (size_t)km * (g.nx + 2)];
+      for (int k = 2; k <= km; k++) pe[peb + (size_t)(k - 1) * (g.nx + 2)] = ak[k - 1] + bk[k - 1] * psfc;
+    }
+  }
+};
+
+#undef CS
+}  // namespace fv3

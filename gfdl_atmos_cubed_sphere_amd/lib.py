@@ -33,7 +33,7 @@ EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_halo_fill_periodic", "fv3_profile", "fv3_profile_report",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
-           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz"]
+           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_lagrangian_to_eulerian"]
 
 
 class Fv3Error(RuntimeError):
@@ -72,6 +72,12 @@ CP_AIR = RDGAS / KAPPA
 
 def nh_consts(ptop, p_fac=0.05, a_imp=1.0, akap=KAPPA, grav=GRAV, rdgas=RDGAS, cp_air=CP_AIR):
     return dict(grav=grav, rdgas=rdgas, cp_air=cp_air, akap=akap, ptop=ptop, p_fac=p_fac, a_imp=a_imp)
+
+
+class _RemapParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ["last_step", "hydrostatic", "adiabatic", "nq", "kord_mt", "kord_wz", "kord_tm",
+                                       "sphum"]] + [(n, C.c_double) for n in ["akap", "ptop", "rdgas", "grav", "cv_air",
+                                                                              "r_vir", "cp", "t_min"]]
 
 
 class Fv3Lib:
@@ -331,6 +337,24 @@ class Context:
         self.lib.check(self.lib.dll.fv3_geopk(self.h, C.c_double(ptop), C.c_double(akap), C.c_double(cp_air),
                                               C.c_double(ptop ** akap), _pp(pe), _pp(peln), delp.p, pk.p, gz.p, hs.p,
                                               pt.p, _pp(pkz), C.c_int(int(CG))), "fv3_geopk")
+
+    # -- vertical remap ---------------------------------------------------------------------------------
+    def set_ak_bk(self, ak, bk):
+        a = np.ascontiguousarray(ak, dtype=np.float64)
+        b = np.ascontiguousarray(bk, dtype=np.float64)
+        assert a.size == self.npz + 1 and b.size == self.npz + 1
+        self.lib.check(self.lib.dll.fv3_set_ak_bk(self.h, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp)), "fv3_set_ak_bk")
+
+    def lagrangian_to_eulerian(self, par: dict, ps, pe, delp, pkz, pk, u, v, w, delz, pt, q, peln, omga, ws):
+        """model/fv_mapz.F90:56 Lagrangian_to_Eulerian"""
+        s = _RemapParams()
+        for k in ["last_step", "hydrostatic", "adiabatic", "nq", "kord_mt", "kord_wz", "kord_tm", "sphum", "akap", "ptop",
+                  "rdgas", "grav", "cv_air", "r_vir", "cp", "t_min"]:
+            setattr(s, k, par[k])
+        kt = np.ascontiguousarray(par.get("kord_tr", []), dtype=np.int32)
+        self.lib.check(self.lib.dll.fv3_lagrangian_to_eulerian(
+            self.h, C.byref(s), kt.ctypes.data_as(_ip) if kt.size else None, ps.p, pe.p, delp.p, pkz.p, pk.p, u.p, v.p,
+            _pp(w), _pp(delz), pt.p, _pp(q), peln.p, omga.p, _pp(ws)), "fv3_lagrangian_to_eulerian")
 
     def halo_fill_periodic(self, field: DeviceArray, kind: str):
         code = {"A": 0, "U": 1, "V": 2, "B": 3}[kind]

@@ -197,6 +197,23 @@ int fv3_pe_halo(fv3_ctx *ctx, double ptop, double *pe, const double *delp);
 int fv3_geopk(fv3_ctx *ctx, double ptop, double akap, double cp_air, double ptk, double *pe, double *peln,
               const double *delp, double *pk, double *gz, const double *hs, const double *pt, double *pkz, int CG);
 
+/* ---- vertical remap ------------------------------------------------------------------------------------
+ * Lagrangian_to_Eulerian -- model/fv_mapz.F90:56-64, call site model/fv_dynamics.F90:607.  Branches built:
+ * remap_te=.false., use_cond=moist_kappa=.false., consv=0, fill=.false., |kord| in {8,9,10,11,13}, kord_wz>0.
+ * All fields are updated in place (every column is independent): ps (A), pe (is-1:ie+1, npz+1, js-1:je+1),
+ * delp, pt, w, omga (A x npz), q (A x npz x nq), u (U x npz), v (V x npz), delz, pkz (CC x npz),
+ * pk (CC x (npz+1)), peln (is:ie, npz+1, js:je); ws (CC, in).  On return pt is theta_v again
+ * (or T_v when last_step), exactly as the reference leaves it. */
+typedef struct fv3_remap_params {
+  int last_step, hydrostatic, adiabatic, nq, kord_mt, kord_wz, kord_tm, sphum;
+  double akap, ptop, rdgas, grav, cv_air, r_vir, cp, t_min;
+} fv3_remap_params;
+/* ak, bk: HOST arrays of length npz+1 (the hybrid coordinate, tools/fv_eta.F90). */
+int fv3_set_ak_bk(fv3_ctx *ctx, const double *ak, const double *bk);
+int fv3_lagrangian_to_eulerian(fv3_ctx *ctx, const fv3_remap_params *p, const int *kord_tr, double *ps, double *pe,
+                               double *delp, double *pkz, double *pk, double *u, double *v, double *w, double *delz,
+                               double *pt, double *q, double *peln, double *omga, const double *ws);
+
 /* Per-kernel timing with HIP events recorded on the context's stream around every kernel the
  * library launches (this is what bench.py's roofline figures are measured with).  report: one line
  * "label count total_ms" per kernel label since the last report; synchronises the stream. */

@@ -163,6 +163,23 @@ int fvo_pe_halo(const fvo_grid *g, int npz, double ptop, double *pe, const doubl
 int fvo_geopk(const fvo_grid *g, int km, double ptop, double akap, double cp_air, double *pe, double *peln,
               const double *delp, double *pk, double *gz, const double *hs, const double *pt, double *pkz, int CG);
 
+/* ---- vertical remap (oracle/mapz.c) ------------------------------------------------------------- */
+/* scalar_profile (is_scalar=1) / cs_profile (0) for one column; a4 is [4][km+2] (index (n-1)*(km+2)+k). */
+int fvo_profile_column(int is_scalar, double qs, double *a4, const double *delp, int km, int iv, int kord, double qmin);
+/* which: 0 map_scalar, 1 map1_ppm, 2 map1_q2, 3 mapn_tracer.  1-based columns (element 0 unused). */
+int fvo_remap_column(int which, int km, const double *pe1, const double *pe2, const double *q1, double *q2, double qs,
+                     int iv, int kord, double qmin);
+typedef struct fvo_remap_par {
+  int last_step, hydrostatic, adiabatic, nq, kord_mt, kord_wz, kord_tm;
+  const int *kord_tr;
+  double akap, ptop, rdgas, grav, cv_air, r_vir, cp, t_min;
+  int sphum;
+} fvo_remap_par;
+int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p, double *ps, double *pe, double *delp,
+                               double *pkz, double *pk, double *u, double *v, double *w, double *delz, double *pt,
+                               double *q, double *peln, double *omga, const double *ws, const double *ak,
+                               const double *bk);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,490 @@
+/*
+ * oracle/mapz.c -- CPU oracle (test infrastructure, see fvo.h) for the vertical remap:
+ * model/fv_operators.F90 (scalar_profile :546-916, cs_profile :919-1300, cs_limiters :1303-1378,
+ * map_scalar :40-134, map1_ppm :137-229, mapn_tracer :234-348, map1_q2 :352-443) and
+ * model/fv_mapz.F90 Lagrangian_to_Eulerian :56-845.
+ * Branches restated: remap_te = .false., moist_kappa = use_cond = .false., consv = 0 (no energy fixer),
+ * fill = .false., do_intermediate_phys = .false.; abs(kord) in {8, 9, 10, 11, 13}; iv in {-2,-1,0,1}.
+ * (iv = -3, i.e. kord_wz < 0, is not restated: the reference's back-substitution reads gam(i,km), which
+ * that branch never sets -- fv_operators.F90:974-993,1012-1016.)
+ */
+#include "fvo.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static const double r3 = 1. / 3., r23 = 2. / 3., r12 = 1. / 12.;
+
+static inline double dmin(double a, double b) { return a < b ? a : b; }
+static inline double dmax(double a, double b) { return a > b ? a : b; }
+static inline double dmin3(double a, double b, double c) { return dmin(dmin(a, b), c); }
+static inline double dmax3(double a, double b, double c) { return dmax(dmax(a, b), c); }
+static double *dalloc(size_t n) { return (double *)calloc(n, sizeof(double)); }
+
+/* a4 is stored [n][k] with n = 1..4, k = 1..km for ONE column: A4(n,k) */
+#define A4(n, k) a4[((n)-1) * (km + 2) + (k)]
+
+/* cs_limiters for one cell, fv_operators.F90:1303-1378 */
+static void cs_limiter_cell(int extm, double *a1, double *a2, double *a3, double *a4v, int iv) {
+  double da1, da2, a6da;
+  if (iv == 0) {
+    if (*a1 <= 0.) {
+      *a2 = *a1;
+      *a3 = *a1;
+      *a4v = 0.;
+    } else {
+      if (fabs(*a3 - *a2) < -*a4v) {
+        if ((*a1 + 0.25 * ((*a3 - *a2) * (*a3 - *a2)) / *a4v + *a4v * r12) < 0.) {
+          if (*a1 < *a3 && *a1 < *a2) {
+            *a3 = *a1;
+            *a2 = *a1;
+            *a4v = 0.;
+          } else if (*a3 > *a2) {
+            *a4v = 3. * (*a2 - *a1);
+            *a3 = *a2 - *a4v;
+          } else {
+            *a4v = 3. * (*a3 - *a1);
+            *a2 = *a3 - *a4v;
+          }
+        }
+      }
+    }
+  } else if (iv == 1) {
+    if ((*a1 - *a2) * (*a1 - *a3) >= 0.) {
+      *a2 = *a1;
+      *a3 = *a1;
+      *a4v = 0.;
+    } else {
+      da1 = *a3 - *a2;
+      da2 = da1 * da1;
+      a6da = *a4v * da1;
+      if (a6da < -da2) {
+        *a4v = 3. * (*a2 - *a1);
+        *a3 = *a2 - *a4v;
+      } else if (a6da > da2) {
+        *a4v = 3. * (*a3 - *a1);
+        *a2 = *a3 - *a4v;
+      }
+    }
+  } else {
+    if (extm) {
+      *a2 = *a1;
+      *a3 = *a1;
+      *a4v = 0.;
+    } else {
+      da1 = *a3 - *a2;
+      da2 = da1 * da1;
+      a6da = *a4v * da1;
+      if (a6da < -da2) {
+        *a4v = 3. * (*a2 - *a1);
+        *a3 = *a2 - *a4v;
+      } else if (a6da > da2) {
+        *a4v = 3. * (*a3 - *a1);
+        *a2 = *a3 - *a4v;
+      }
+    }
+  }
+}
+#define LIM(k, mode) cs_limiter_cell(extm[k], &A4(1, k), &A4(2, k), &A4(3, k), &A4(4, k), mode)
+
+/* scalar_profile (is_scalar=1, :546-916) / cs_profile (is_scalar=0, :919-1300) for one column.
+ * delp[1..km], a4 as above (A4(1,k) on entry). Returns 0 or FVO_ERR_UNSUPPORTED. */
+int fvo_profile_column(int is_scalar, double qs, double *a4, const double *delp, int km, int iv, int kord, double qmin) {
+  int k;
+  const int ak = abs(kord);
+  if (!(ak == 8 || ak == 9 || ak == 10 || ak == 11 || ak == 13)) return FVO_ERR_UNSUPPORTED;
+  if (!(iv == -2 || iv == -1 || iv == 0 || iv == 1)) return FVO_ERR_UNSUPPORTED;
+  double *gam = dalloc(km + 3), *q = dalloc(km + 3);
+  unsigned char *extm = (unsigned char *)calloc(km + 3, 1), *ext5 = (unsigned char *)calloc(km + 3, 1),
+                *ext6 = (unsigned char *)calloc(km + 3, 1);
+  double bet, a_bot, grat, d4 = 0., pmp_1, lac_1, pmp_2, lac_2, x0, x1;
+  if (iv == -2) { /* :572-595 / :941-964 */
+    gam[2] = 0.5;
+    q[1] = 1.5 * A4(1, 1);
+    for (k = 2; k <= km - 1; k++) {
+      grat = delp[k - 1] / delp[k];
+      bet = 2. + grat + grat - gam[k];
+      q[k] = (3. * (A4(1, k - 1) + A4(1, k)) - q[k - 1]) / bet;
+      gam[k + 1] = grat / bet;
+    }
+    grat = delp[km - 1] / delp[km];
+    q[km] = (3. * (A4(1, km - 1) + A4(1, km)) - grat * qs - q[km - 1]) / (2. + grat + grat - gam[km]);
+    q[km + 1] = qs;
+    for (k = km - 1; k >= 1; k--) q[k] = q[k] - gam[k + 1] * q[k + 1];
+  } else { /* :597-623 / :967-1016 */
+    grat = delp[2] / delp[1];
+    bet = grat * (grat + 0.5);
+    q[1] = ((grat + grat) * (grat + 1.) * A4(1, 1) + A4(1, 2)) / bet;
+    gam[1] = (1. + grat * (grat + 1.5)) / bet;
+    for (k = 2; k <= km; k++) {
+      d4 = delp[k - 1] / delp[k];
+      bet = 2. + d4 + d4 - gam[k - 1];
+      q[k] = (3. * (A4(1, k - 1) + d4 * A4(1, k)) - q[k - 1]) / bet;
+      gam[k] = d4 / bet;
+    }
+    a_bot = 1. + d4 * (d4 + 1.5);
+    q[km + 1] = (2. * d4 * (d4 + 1.) * A4(1, km) + A4(1, km - 1) - a_bot * q[km]) / (d4 * (d4 + 0.5) - a_bot * gam[km]);
+    for (k = km; k >= 1; k--) q[k] = q[k] - gam[k] * q[k + 1];
+  }
+  /* large-scale constraints, :643-680 / :1037-1073 */
+  q[2] = dmin(q[2], dmax(A4(1, 1), A4(1, 2)));
+  q[2] = dmax(q[2], dmin(A4(1, 1), A4(1, 2)));
+  for (k = 2; k <= km; k++) gam[k] = A4(1, k) - A4(1, k - 1);
+  for (k = 3; k <= km - 1; k++) {
+    if (ak >= 14 || gam[k - 1] * gam[k + 1] > 0.) {
+      q[k] = dmin(q[k], dmax(A4(1, k - 1), A4(1, k)));
+      q[k] = dmax(q[k], dmin(A4(1, k - 1), A4(1, k)));
+    } else {
+      if (gam[k - 1] > 0.) {
+        q[k] = dmax(q[k], dmin(A4(1, k - 1), A4(1, k)));
+      } else {
+        q[k] = dmin(q[k], dmax(A4(1, k - 1), A4(1, k)));
+        if (iv == 0) q[k] = dmax(0., q[k]);
+      }
+    }
+  }
+  q[km] = dmin(q[km], dmax(A4(1, km - 1), A4(1, km)));
+  q[km] = dmax(q[km], dmin(A4(1, km - 1), A4(1, km)));
+  for (k = 1; k <= km; k++) {
+    A4(2, k) = q[k];
+    A4(3, k) = q[k + 1];
+  }
+  for (k = 1; k <= km; k++) { /* :693-712 / :1082-1101 */
+    if (k == 1 || k == km)
+      extm[k] = (A4(2, k) - A4(1, k)) * (A4(3, k) - A4(1, k)) > 0.;
+    else
+      extm[k] = gam[k] * gam[k + 1] < 0.;
+    if (ak > 9) {
+      x0 = 2. * A4(1, k) - (A4(2, k) + A4(3, k));
+      x1 = fabs(A4(2, k) - A4(3, k));
+      A4(4, k) = 3. * x0;
+      ext5[k] = fabs(x0) > x1;
+      ext6[k] = fabs(A4(4, k)) > x1;
+    }
+  }
+  /* top, :718-747 / :1109-1137 */
+  if (iv == 0) A4(2, 1) = dmax(0., A4(2, 1));
+  if (iv == -1) {
+    if (A4(2, 1) * A4(1, 1) <= 0.) A4(2, 1) = 0.;
+  }
+  A4(4, 1) = 3. * (2. * A4(1, 1) - (A4(2, 1) + A4(3, 1)));
+  LIM(1, 1);
+  A4(4, 2) = 3. * (2. * A4(1, 2) - (A4(2, 2) + A4(3, 2)));
+  LIM(2, 2);
+  /* interior, :752-892 / :1142-1276 */
+  for (k = 3; k <= km - 2; k++) {
+#define HUYNH()                                                                                          \
+  do {                                                                                                   \
+    pmp_1 = A4(1, k) - 2. * gam[k + 1];                                                                  \
+    lac_1 = pmp_1 + 1.5 * gam[k + 2];                                                                    \
+    A4(2, k) = dmin(dmax(A4(2, k), dmin3(A4(1, k), pmp_1, lac_1)), dmax3(A4(1, k), pmp_1, lac_1));       \
+    pmp_2 = A4(1, k) + 2. * gam[k];                                                                      \
+    lac_2 = pmp_2 - 1.5 * gam[k - 1];                                                                    \
+    A4(3, k) = dmin(dmax(A4(3, k), dmin3(A4(1, k), pmp_2, lac_2)), dmax3(A4(1, k), pmp_2, lac_2));       \
+  } while (0)
+    if (ak <= 8) {
+      HUYNH();
+      A4(4, k) = 3. * (2. * A4(1, k) - (A4(2, k) + A4(3, k)));
+    } else if (ak == 9) {
+      if ((extm[k] && extm[k - 1]) || (extm[k] && extm[k + 1]) || (is_scalar && extm[k] && A4(1, k) < qmin)) {
+        A4(2, k) = A4(1, k);
+        A4(3, k) = A4(1, k);
+        A4(4, k) = 0.;
+      } else {
+        /* scalar_profile: 3*(2a-(l+r)) (:789,800); cs_profile: 6a-3(l+r) (:1173,1184) */
+        A4(4, k) = is_scalar ? 3. * (2. * A4(1, k) - (A4(2, k) + A4(3, k))) : 6. * A4(1, k) - 3. * (A4(2, k) + A4(3, k));
+        if (fabs(A4(4, k)) > fabs(A4(2, k) - A4(3, k))) {
+          HUYNH();
+          A4(4, k) = is_scalar ? 3. * (2. * A4(1, k) - (A4(2, k) + A4(3, k))) : 6. * A4(1, k) - 3. * (A4(2, k) + A4(3, k));
+        }
+      }
+    } else if (ak == 10) {
+      if (extm[k]) {
+        if ((is_scalar && A4(1, k) < qmin) || extm[k - 1] || extm[k + 1]) {
+          A4(2, k) = A4(1, k);
+          A4(3, k) = A4(1, k);
+          A4(4, k) = 0.;
+        } else {
+          A4(4, k) = 6. * A4(1, k) - 3. * (A4(2, k) + A4(3, k));
+        }
+      } else {
+        A4(4, k) = 6. * A4(1, k) - 3. * (A4(2, k) + A4(3, k));
+        if (fabs(A4(4, k)) > fabs(A4(2, k) - A4(3, k))) {
+          HUYNH();
+          A4(4, k) = 6. * A4(1, k) - 3. * (A4(2, k) + A4(3, k));
+        }
+      }
+    } else if (ak == 11) {
+      if (ext5[k] && (ext5[k - 1] || ext5[k + 1] || (is_scalar && A4(1, k) < qmin))) {
+        A4(2, k) = A4(1, k);
+        A4(3, k) = A4(1, k);
+        A4(4, k) = 0.;
+      } else {
+        A4(4, k) = 3. * (2. * A4(1, k) - (A4(2, k) + A4(3, k)));
+      }
+    } else { /* 13 */
+      A4(4, k) = 3. * (2. * A4(1, k) - (A4(2, k) + A4(3, k)));
+    }
+    if (iv == 0 && ak <= 13) LIM(k, 0);
+  }
+  /* bottom, :897-914 / :1281-1298 */
+  if (iv == 0) A4(3, km) = dmax(0., A4(3, km));
+  if (iv == -1) {
+    if (A4(3, km) * A4(1, km) <= 0.) A4(3, km) = 0.;
+  }
+  for (k = km - 1; k <= km; k++) {
+    A4(4, k) = 3. * (2. * A4(1, k) - (A4(2, k) + A4(3, k)));
+    if (k == km - 1) LIM(k, 2);
+    if (k == km) LIM(k, 1);
+  }
+  free(gam); free(q); free(extm); free(ext5); free(ext6);
+  return FVO_OK;
+}
+
+/* The search-and-integrate loop shared by map_scalar / map1_ppm / map1_q2 (:93-132, :188-227, :402-441) for one
+ * column.  pe1[1..km+1], pe2[1..kn+1], dp1[1..km]; q2[1..kn] out; div: 0 -> /(pe2(k+1)-pe2(k)), else /dp2[k].
+ * tracer_form: the factored expressions of mapn_tracer (:283-333). */
+static void map_column(int km, int kn, const double *pe1, const double *pe2, const double *dp1, const double *a4,
+                       double *q2, const double *dp2, int tracer_form) {
+  int k, l, m, k0 = 1;
+  double pl, pr, qsum = 0., dp, esl, fac1, fac2;
+  for (k = 1; k <= kn; k++) {
+    int done = 0;
+    for (l = k0; l <= km && !done; l++) {
+      if (pe2[k] >= pe1[l] && pe2[k] <= pe1[l + 1]) {
+        pl = (pe2[k] - pe1[l]) / dp1[l];
+        if (pe2[k + 1] <= pe1[l + 1]) {
+          pr = (pe2[k + 1] - pe1[l]) / dp1[l];
+          if (tracer_form) {
+            fac1 = pr + pl;
+            fac2 = r3 * (pr * fac1 + pl * pl);
+            fac1 = 0.5 * fac1;
+            q2[k] = A4(2, l) + (A4(4, l) + A4(3, l) - A4(2, l)) * fac1 - A4(4, l) * fac2;
+          } else {
+            q2[k] = A4(2, l) + 0.5 * (A4(4, l) + A4(3, l) - A4(2, l)) * (pr + pl) - A4(4, l) * r3 * (pr * (pr + pl) + pl * pl);
+          }
+          k0 = l;
+          done = 2; /* goto 555 */
+        } else {
+          if (tracer_form) {
+            dp = pe1[l + 1] - pe2[k];
+            fac1 = 1. + pl;
+            fac2 = r3 * (1. + pl * fac1);
+            fac1 = 0.5 * fac1;
+            qsum = dp * (A4(2, l) + (A4(4, l) + A4(3, l) - A4(2, l)) * fac1 - A4(4, l) * fac2);
+          } else {
+            qsum = (pe1[l + 1] - pe2[k]) *
+                   (A4(2, l) + 0.5 * (A4(4, l) + A4(3, l) - A4(2, l)) * (1. + pl) - A4(4, l) * (r3 * (1. + pl * (1. + pl))));
+          }
+          for (m = l + 1; m <= km; m++) {
+            if (pe2[k + 1] > pe1[m + 1]) {
+              qsum = qsum + dp1[m] * A4(1, m);
+            } else {
+              dp = pe2[k + 1] - pe1[m];
+              esl = dp / dp1[m];
+              if (tracer_form) {
+                fac1 = 0.5 * esl;
+                fac2 = 1. - r23 * esl;
+                qsum = qsum + dp * (A4(2, m) + fac1 * (A4(3, m) - A4(2, m) + A4(4, m) * fac2));
+              } else {
+                qsum = qsum + dp * (A4(2, m) + 0.5 * esl * (A4(3, m) - A4(2, m) + A4(4, m) * (1. - r23 * esl)));
+              }
+              k0 = m;
+              break;
+            }
+          }
+          done = 1; /* goto 123 */
+        }
+      }
+    }
+    if (done != 2) q2[k] = dp2 ? qsum / dp2[k] : qsum / (pe2[k + 1] - pe2[k]);
+  }
+}
+
+/* Remap one column: which = 0 map_scalar (scalar_profile), 1 map1_ppm (cs_profile), 2 map1_q2 (scalar_profile,
+ * /dp2), 3 mapn_tracer arithmetic.  q1[1..km] in, q2[1..kn] out (may alias q1: a4(1,:) is a copy). */
+int fvo_remap_column(int which, int km, const double *pe1, const double *pe2, const double *q1, double *q2, double qs,
+                     int iv, int kord, double qmin) {
+  int k, rc;
+  double *a4 = dalloc(4 * (size_t)(km + 2)), *dp1 = dalloc(km + 2), *dp2 = dalloc(km + 2);
+  for (k = 1; k <= km; k++) {
+    dp1[k] = pe1[k + 1] - pe1[k];
+    dp2[k] = pe2[k + 1] - pe2[k];
+    A4(1, k) = q1[k];
+  }
+  rc = fvo_profile_column(which != 1, qs, a4, dp1, km, iv, kord, qmin);
+  if (!rc) map_column(km, km, pe1, pe2, dp1, a4, q2, which >= 2 ? dp2 : NULL, which == 3);
+  free(a4); free(dp1); free(dp2);
+  return rc;
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * Lagrangian_to_Eulerian, fv_mapz.F90:56-845 (branches listed in the file header).
+ * ps: A; pe (is-1:ie+1, km+1, js-1:je+1); delp, pt, w, omga: A x km; q: A x km x nq; u: U x km; v: V x km;
+ * delz, pkz: CC x km; pk: CC x (km+1); peln (is:ie, km+1, js:je); ws: CC; ak, bk: km+1.
+ * ------------------------------------------------------------------------------------------------- */
+
+
+int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p, double *ps, double *pe, double *delp,
+                               double *pkz, double *pk, double *u, double *v, double *w, double *delz, double *pt,
+                               double *q, double *peln, double *omga, const double *ws, const double *ak,
+                               const double *bk) {
+  const int is = g->is, ie = g->ie, js = g->js, je = g->je, isd = g->isd, ied = g->ied, jsd = g->jsd, jed = g->jed;
+  const int nid = ied - isd + 1, njd = jed - jsd + 1, nx = ie - is + 1, ny = je - js + 1;
+  const size_t nA = (size_t)nid * njd, nU = (size_t)nid * (njd + 1), nV = (size_t)(nid + 1) * njd, nCC = (size_t)nx * ny;
+  int i, j, k, n, iq, rc = 0;
+  const double k1k = p->rdgas / p->cv_air, rrg = -p->rdgas / p->grav, akap = p->akap;
+  if (p->kord_wz < 0) return FVO_ERR_UNSUPPORTED;
+#define IA3(i, j, k) ((size_t)((k)-1) * nA + (size_t)((j)-jsd) * nid + ((i)-isd))
+#define IU3(i, j, k) ((size_t)((k)-1) * nU + (size_t)((j)-jsd) * nid + ((i)-isd))
+#define IV3(i, j, k) ((size_t)((k)-1) * nV + (size_t)((j)-jsd) * (nid + 1) + ((i)-isd))
+#define ICC3(i, j, k) ((size_t)((k)-1) * nCC + (size_t)((j)-js) * nx + ((i)-is))
+#define PE(i, k, j) pe[(size_t)((j) - (js - 1)) * (nx + 2) * (km + 1) + (size_t)((k)-1) * (nx + 2) + ((i) - (is - 1))]
+#define PELN(i, k, j) peln[(size_t)((j)-js) * nx * (km + 1) + (size_t)((k)-1) * nx + ((i)-is)]
+  double *pe4 = dalloc(nA * km);
+  double *c1 = dalloc(km + 3), *c2 = dalloc(km + 3), *pe1 = dalloc(km + 3), *pe2 = dalloc(km + 3), *pn1 = dalloc(km + 3),
+         *pn2 = dalloc(km + 3), *pk2 = dalloc(km + 3), *dp2 = dalloc(km + 3), *pe0 = dalloc(km + 3), *pe3 = dalloc(km + 3);
+  for (j = js; j <= je + 1; j++) {
+    for (i = is; i <= ie + 1; i++) {
+      if (i <= ie) {
+        for (k = 1; k <= km + 1; k++) pe1[k] = PE(i, k, j);
+        pe2[1] = p->ptop;
+        pe2[km + 1] = PE(i, km + 1, j);
+      }
+      if (j != je + 1 && i <= ie) {
+        if (p->kord_tm < 0) { /* :200-229 */
+          for (k = 1; k <= km; k++) {
+            if (p->hydrostatic)
+              pt[IA3(i, j, k)] = pt[IA3(i, j, k)] * (pk[ICC3(i, j, k + 1)] - pk[ICC3(i, j, k)]) /
+                                 (akap * (PELN(i, k + 1, j) - PELN(i, k, j)));
+            else
+              pt[IA3(i, j, k)] = pt[IA3(i, j, k)] *
+                                 exp(k1k * log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
+          }
+        }
+        if (!p->hydrostatic)
+          for (k = 1; k <= km; k++) delz[ICC3(i, j, k)] = -delz[ICC3(i, j, k)] / delp[IA3(i, j, k)]; /* :292 */
+        ps[(size_t)(j - jsd) * nid + (i - isd)] = pe1[km + 1];
+        for (k = 2; k <= km; k++) pe2[k] = ak[k - 1] + bk[k - 1] * PE(i, km + 1, j);
+        for (k = 1; k <= km; k++) dp2[k] = pe2[k + 1] - pe2[k];
+        for (k = 1; k <= km; k++) delp[IA3(i, j, k)] = dp2[k];
+        pn2[1] = PELN(i, 1, j);
+        pn2[km + 1] = PELN(i, km + 1, j);
+        pk2[1] = pk[ICC3(i, j, 1)];
+        pk2[km + 1] = pk[ICC3(i, j, km + 1)];
+        for (k = 2; k <= km; k++) {
+          pn2[k] = log(pe2[k]);
+          pk2[k] = exp(akap * pn2[k]);
+        }
+        /* 1) remap Tv / thetav, :362-376 */
+        for (k = 1; k <= km; k++) c1[k] = pt[IA3(i, j, k)];
+        if (p->kord_tm < 0) {
+          for (k = 1; k <= km + 1; k++) pn1[k] = PELN(i, k, j);
+          rc |= fvo_remap_column(0, km, pn1, pn2, c1, c2, 0., 1, abs(p->kord_tm), p->t_min);
+        } else {
+          rc |= fvo_remap_column(1, km, pe1, pe2, c1, c2, 0., 1, abs(p->kord_tm), 0.);
+        }
+        for (k = 1; k <= km; k++) pt[IA3(i, j, k)] = c2[k];
+        /* 2) constituents, :380-397 */
+        for (iq = 1; iq <= p->nq; iq++) {
+          double *qq = q + (size_t)(iq - 1) * nA * km;
+          for (k = 1; k <= km; k++) c1[k] = qq[IA3(i, j, k)];
+          rc |= fvo_remap_column(p->nq > 5 ? 3 : 2, km, pe1, pe2, c1, c2, 0., 0, p->kord_tr[iq - 1], 0.);
+          for (k = 1; k <= km; k++) qq[IA3(i, j, k)] = c2[k];
+        }
+        /* 3) w and delz, :400-423 */
+        if (!p->hydrostatic) {
+          for (k = 1; k <= km; k++) c1[k] = w[IA3(i, j, k)];
+          rc |= fvo_remap_column(1, km, pe1, pe2, c1, c2, ws[(size_t)(j - js) * nx + (i - is)], -2, abs(p->kord_wz), 0.);
+          for (k = 1; k <= km; k++) w[IA3(i, j, k)] = c2[k];
+          for (k = 1; k <= km; k++) c1[k] = delz[ICC3(i, j, k)];
+          rc |= fvo_remap_column(1, km, pe1, pe2, c1, c2, 0., 1, abs(p->kord_tm), 0.);
+          for (k = 1; k <= km; k++) delz[ICC3(i, j, k)] = -c2[k] * dp2[k];
+        }
+        for (k = 1; k <= km + 1; k++) pk[ICC3(i, j, k)] = pk2[k]; /* :426-430 */
+        if (p->last_step) {                                        /* :432-443 */
+          pe3[1] = 0.;
+          for (k = 2; k <= km + 1; k++) pe3[k] = omga[IA3(i, j, k - 1)];
+        }
+        for (k = 1; k <= km + 1; k++) { /* :445-450 */
+          pe0[k] = PELN(i, k, j);
+          PELN(i, k, j) = pn2[k];
+        }
+        /* 3.2) pkz, :453-503 */
+        for (k = 1; k <= km; k++) {
+          if (p->hydrostatic)
+            pkz[ICC3(i, j, k)] = (pk2[k + 1] - pk2[k]) / (akap * (PELN(i, k + 1, j) - PELN(i, k, j)));
+          else if (p->kord_tm < 0)
+            pkz[ICC3(i, j, k)] = exp(akap * log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
+          else
+            pkz[ICC3(i, j, k)] = exp(k1k * log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
+        }
+        if (p->kord_tm > 0)
+          for (k = 1; k <= km; k++) pt[IA3(i, j, k)] = pt[IA3(i, j, k)] * pkz[ICC3(i, j, k)];
+        /* 3.3) omega, :506-526 */
+        if (p->last_step) {
+          int k_next = 1, kp;
+          for (k = 1; k <= km; k++) dp2[k] = 0.5 * (PELN(i, k, j) + PELN(i, k + 1, j));
+          for (n = 1; n <= km; n++) {
+            kp = k_next;
+            for (k = kp; k <= km; k++) {
+              if (dp2[n] <= pe0[k + 1] && dp2[n] >= pe0[k]) {
+                omga[IA3(i, j, n)] = pe3[k] + (pe3[k + 1] - pe3[k]) * (dp2[n] - pe0[k]) / (pe0[k + 1] - pe0[k]);
+                k_next = k;
+                break;
+              }
+            }
+          }
+        }
+      }
+      /* 4.1) u, :530-553 */
+      if (i <= ie) {
+        pe0[1] = PE(i, 1, j);
+        for (k = 2; k <= km + 1; k++) pe0[k] = 0.5 * (PE(i, k, j - 1) + pe1[k]);
+        for (k = 1; k <= km + 1; k++) {
+          const double bkh = 0.5 * bk[k - 1];
+          pe3[k] = ak[k - 1] + bkh * (PE(i, km + 1, j - 1) + pe1[km + 1]);
+        }
+        for (k = 1; k <= km; k++) c1[k] = u[IU3(i, j, k)];
+        rc |= fvo_remap_column(1, km, pe0, pe3, c1, c2, 0., -1, p->kord_mt, 0.);
+        for (k = 1; k <= km; k++) u[IU3(i, j, k)] = c2[k];
+      }
+      /* 4.2) v, :555-573 */
+      if (j < je + 1) {
+        pe0[1] = PE(i, 1, j);
+        pe3[1] = ak[0];
+        for (k = 2; k <= km + 1; k++) {
+          const double bkh = 0.5 * bk[k - 1];
+          pe0[k] = 0.5 * (PE(i - 1, k, j) + PE(i, k, j));
+          pe3[k] = ak[k - 1] + bkh * (PE(i - 1, km + 1, j) + PE(i, km + 1, j));
+        }
+        for (k = 1; k <= km; k++) c1[k] = v[IV3(i, j, k)];
+        rc |= fvo_remap_column(1, km, pe0, pe3, c1, c2, 0., -1, p->kord_mt, 0.);
+        for (k = 1; k <= km; k++) v[IV3(i, j, k)] = c2[k];
+      }
+      if (i <= ie && j <= je)
+        for (k = 1; k <= km; k++) pe4[IA3(i, j, k)] = pe2[k + 1]; /* :624-628 */
+    }
+  }
+  for (k = 2; k <= km; k++) /* :635-641 */
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie; i++) PE(i, k, j) = pe4[IA3(i, j, k - 1)];
+  if (p->last_step) { /* :793-821: dtmp = 0; only the non-adiabatic dry branch changes pt */
+    if (!p->adiabatic) {
+      for (k = 1; k <= km; k++)
+        for (j = js; j <= je; j++)
+          for (i = is; i <= ie; i++) {
+            const double qv = p->sphum > 0 ? q[(size_t)(p->sphum - 1) * nA * km + IA3(i, j, k)] : 0.;
+            const double den = p->hydrostatic ? p->cp : p->cv_air;
+            pt[IA3(i, j, k)] = (pt[IA3(i, j, k)] + 0. / den * pkz[ICC3(i, j, k)]) / (1. + p->r_vir * qv);
+          }
+    }
+  } else { /* :833-841 */
+    for (k = 1; k <= km; k++)
+      for (j = js; j <= je; j++)
+        for (i = is; i <= ie; i++) pt[IA3(i, j, k)] = pt[IA3(i, j, k)] / pkz[ICC3(i, j, k)];
+  }
+  free(pe4); free(c1); free(c2); free(pe1); free(pe2); free(pn1); free(pn2); free(pk2); free(dp2); free(pe0); free(pe3);
+  return rc;
+}

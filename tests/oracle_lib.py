@@ -221,3 +221,39 @@ def geopk(g, km, ptop, akap, cp_air, pe, peln, delp, pk, gz, hs, pt, pkz, CG):
     gs = make_grid(g)
     assert lib().fvo_geopk(C.byref(gs), C.c_int(km), _d(ptop), _d(akap), _d(cp_air), p(pe), p(peln), p(delp), p(pk),
                            p(gz), p(hs), p(pt), p(pkz), C.c_int(int(CG))) == 0
+
+
+# ---- vertical remap (oracle/mapz.c) -----------------------------------------------------------------
+class RemapPar(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ["last_step", "hydrostatic", "adiabatic", "nq", "kord_mt", "kord_wz", "kord_tm"]] + [
+        ("kord_tr", _ip)] + [(n, C.c_double) for n in ["akap", "ptop", "rdgas", "grav", "cv_air", "r_vir", "cp", "t_min"]] + [
+        ("sphum", C.c_int)]
+
+
+def remap_column(which, pe1, pe2, q1, qs, iv, kord, qmin=0.0):
+    """0-based numpy columns in, 0-based out (the C routine is 1-based)."""
+    km = q1.size
+    a = lambda x: np.concatenate([[0.0], np.asarray(x, dtype=np.float64)])
+    p1, p2, qq = a(pe1), a(pe2), a(q1)
+    out = np.zeros(km + 1)
+    rc = lib().fvo_remap_column(C.c_int(which), C.c_int(km), p1.ctypes.data_as(_dp), p2.ctypes.data_as(_dp),
+                                qq.ctypes.data_as(_dp), out.ctypes.data_as(_dp), _d(qs), C.c_int(iv), C.c_int(kord), _d(qmin))
+    assert rc == 0, rc
+    return out[1:]
+
+
+def lagrangian_to_eulerian(g, km, par: dict, f: dict, ak, bk):
+    gs = make_grid(g)
+    pr = RemapPar()
+    kt = np.ascontiguousarray(par.get("kord_tr", []), dtype=np.int32)
+    for k, v in par.items():
+        if k != "kord_tr":
+            setattr(pr, k, v)
+    pr.kord_tr = kt.ctypes.data_as(_ip)
+    ak = np.ascontiguousarray(ak, dtype=np.float64)
+    bk = np.ascontiguousarray(bk, dtype=np.float64)
+    rc = lib().fvo_lagrangian_to_eulerian(C.byref(gs), C.c_int(km), C.byref(pr), p(f["ps"]), p(f["pe"]), p(f["delp"]),
+                                          p(f["pkz"]), p(f["pk"]), p(f["u"]), p(f["v"]), p(f.get("w")), p(f.get("delz")),
+                                          p(f["pt"]), p(f.get("q")), p(f["peln"]), p(f["omga"]), p(f.get("ws")),
+                                          ak.ctypes.data_as(_dp), bk.ctypes.data_as(_dp))
+    assert rc == 0, rc

@@ -1,0 +1,88 @@
+"""Parity of the vertical remap (Lagrangian_to_Eulerian) library vs oracle on a deformed-coordinate state."""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle_lib as O
+import parity_common as P
+import parity_nh as N
+from fields import smooth_state
+from gfdl_atmos_cubed_sphere_amd.layout import Bounds, periodic_fill
+from gfdl_atmos_cubed_sphere_amd.lib import CP_AIR, GRAV, KAPPA, RDGAS, Context
+
+
+def remap_state(bd, km, nq, seed=31):
+    rng = np.random.default_rng(seed)
+    s = N.nh_state(bd, km, seed=seed)
+    sig = np.linspace(0.0, 1.0, km + 1) ** 1.5
+    ak, bk = N.PTOP * (1.0 - sig), sig.copy()
+    delp = np.asfortranarray(s["delp"] * (1.0 + 0.04 * rng.uniform(-1, 1, s["delp"].shape)))
+    for k in range(km):
+        periodic_fill(bd, delp[:, :, k], "A")
+    nx, ny, ng = bd.nx, bd.ny, bd.ng
+    pe_full = N.PTOP + np.concatenate([np.zeros(bd.shape("A") + (1,)), np.cumsum(delp, axis=2)], axis=2)
+    # pe(is-1:ie+1, km+1, js-1:je+1): k in the middle
+    pe = np.asfortranarray(np.transpose(pe_full[ng - 1:ng + nx + 1, ng - 1:ng + ny + 1, :], (0, 2, 1)))
+    pc = pe_full[ng:ng + nx, ng:ng + ny, :]
+    peln = np.asfortranarray(np.transpose(np.log(pc), (0, 2, 1)))
+    pk = np.asfortranarray(np.exp(KAPPA * np.log(pc)))
+    w = smooth_state(bd, km, noise=0.2)
+    delz = np.asfortranarray(np.diff(s["zh"], axis=2)[ng:ng + nx, ng:ng + ny, :])
+    q = np.asfortranarray(rng.uniform(0.0, 1.0, bd.shape("A", km) + (nq,)) ** 3) if nq else None
+    f = dict(ps=bd.zeros("A"), pe=pe, delp=delp, pkz=bd.zeros("CC", km), pk=pk, u=w["u"], v=w["v"],
+             w=np.asfortranarray(w["w"] * 3.0), delz=delz, pt=s["pt"].copy(order="F"), peln=peln,
+             omga=np.asfortranarray(rng.uniform(-1, 1, bd.shape("A", km))),
+             ws=np.asfortranarray(0.05 * rng.uniform(-1, 1, bd.shape("CC"))))
+    if nq:
+        f["q"] = q
+    return f, ak, bk
+
+
+def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=False, kord_tm=-8, kord=8, adiabatic=True):
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    f, ak, bk = remap_state(bd, km, nq)
+    par = dict(last_step=int(last_step), hydrostatic=int(hydrostatic), adiabatic=int(adiabatic), nq=nq, kord_mt=kord,
+               kord_wz=kord, kord_tm=kord_tm, sphum=1 if nq else 0, akap=KAPPA, ptop=N.PTOP, rdgas=RDGAS, grav=GRAV,
+               cv_air=CP_AIR - RDGAS, r_vir=0.6077, cp=CP_AIR, t_min=184.0, kord_tr=[kord if n % 2 == 0 else 9 for n in range(nq)])
+    ref = {k: (v.copy(order="F") if v is not None else None) for k, v in f.items()}
+    if hydrostatic:
+        ref.pop("w"); ref.pop("delz"); ref.pop("ws")
+    O.lagrangian_to_eulerian(g, km, par, ref, ak, bk)
+    ctx = Context(g, km, lib=lib)
+    try:
+        ctx.set_ak_bk(ak, bk)
+        d = {k: ctx.from_host(v) for k, v in f.items()}
+        ctx.lagrangian_to_eulerian(par, d["ps"], d["pe"], d["delp"], d["pkz"], d["pk"], d["u"], d["v"],
+                                   None if hydrostatic else d["w"], None if hydrostatic else d["delz"], d["pt"],
+                                   d.get("q"), d["peln"], d["omga"], None if hydrostatic else d["ws"])
+        tol = 1e-14 if "hostemu" in lib.path else 1e-12
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        names = [("pt", "A", r), ("delp", "A", r), ("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)),
+                 ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)), ("ps", "A", r)]
+        if not hydrostatic:
+            names.append(("w", "A", r))
+        if last_step:
+            names.append(("omga", "A", r))
+        worst = 0.0
+        for n, kind, rr in names:
+            worst = max(worst, P.assert_close(n, bd.view(d[n].download(), kind, *rr), bd.view(ref[n], kind, *rr), tol))
+        for n in ("pkz", "pk", "peln") + (() if hydrostatic else ("delz",)):
+            worst = max(worst, P.assert_close(n, d[n].download(), ref[n], tol))
+        worst = max(worst, P.assert_close("pe", d["pe"].download()[1:-1, :, 1:-1], ref["pe"][1:-1, :, 1:-1], tol))
+        if nq:
+            got = d["q"].download()
+            for iq in range(nq):
+                worst = max(worst, P.assert_close(f"q{iq}", bd.view(got[:, :, :, iq], "A", *r),
+                                                  bd.view(ref["q"][:, :, :, iq], "A", *r), tol))
+        # conservation identity of the remap (fv_operators.F90:130): column mass of each tracer
+        if nq:
+            dp_old = bd.view(f["delp"], "A", *r)
+            dp_new = bd.view(d["delp"].download(), "A", *r)
+            for iq in range(nq):
+                m0 = np.sum(bd.view(f["q"][:, :, :, iq], "A", *r) * dp_old, axis=2)
+                m1 = np.sum(bd.view(got[:, :, :, iq], "A", *r) * dp_new, axis=2)
+                assert np.max(np.abs(m1 - m0) / np.abs(m0)) < 1e-12
+    finally:
+        ctx.close()
+    return worst

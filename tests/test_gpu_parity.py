@@ -158,3 +158,18 @@ def test_dyn_core_substeps_sim_solver_damping(prod):
 
 def test_dyn_core_substeps_larger(prod):
     D.check_substeps(prod, nx=96, ny=64, npz=32, n_split=2)
+
+
+# ---- vertical remap -----------------------------------------------------------------------------
+import parity_remap as R
+
+
+@pytest.mark.parametrize("hydrostatic,last_step,kord_tm,kord,nq", [(False, False, -8, 8, 2), (False, True, -9, 9, 6),
+                                                                    (True, False, -8, 8, 1), (False, False, 8, 10, 0),
+                                                                    (True, True, 10, 11, 3), (False, True, -10, 13, 2)])
+def test_remap(prod, hydrostatic, last_step, kord_tm, kord, nq):
+    R.check_remap(prod, hydrostatic=hydrostatic, last_step=last_step, kord_tm=kord_tm, kord=kord, nq=nq)
+
+
+def test_remap_larger(prod):
+    R.check_remap(prod, nx=96, ny=64, km=32, nq=2)

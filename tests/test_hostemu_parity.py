@@ -133,3 +133,14 @@ def test_dyn_core_substeps(emu):
 
 def test_dyn_core_substeps_sim_solver_damping(emu):
     D.check_substeps(emu, n_split=3, flags=dict(a_imp=0.75, nord=2, do_vort_damp=True, vtdm4=0.06, dddmp=0.2))
+
+
+# ---- vertical remap -----------------------------------------------------------------------------
+import parity_remap as R
+
+
+@pytest.mark.parametrize("hydrostatic,last_step,kord_tm,kord,nq", [(False, False, -8, 8, 2), (False, True, -9, 9, 6),
+                                                                    (True, False, -8, 8, 1), (False, False, 8, 10, 0),
+                                                                    (True, True, 10, 11, 3), (False, True, -10, 13, 2)])
+def test_remap(emu, hydrostatic, last_step, kord_tm, kord, nq):
+    R.check_remap(emu, hydrostatic=hydrostatic, last_step=last_step, kord_tm=kord_tm, kord=kord, nq=nq)
