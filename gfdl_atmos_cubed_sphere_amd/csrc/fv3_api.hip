@@ -12,6 +12,7 @@
 #include "fv3_launch.h"
 #include "nh_kernels.h"
 #include "remap_kernels.h"
+#include "tracer_kernels.h"
 #include "tp2d_tile.h"
 
 using namespace fv3;
@@ -45,6 +46,8 @@ struct fv3_ctx {
   double *scratch[8];
   double *lev_ext_d;  // damp(npz+1) for update_dz_d
   int *lev_ext_i;     // ndif(npz+1)
+  double *trc_d;      // device, 2*npz: cmax, frac
+  int *trc_i;         // device, npz: ksplt
   double *akbk;       // device, 2*(npz+1)
   int *kord_tr_dev;   // device, up to 64 tracers
   bool akbk_ready;
@@ -146,6 +149,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->prof_on = false;
   c->dp0 = nullptr; c->edge_dev = nullptr; c->dp0_ready = false;
   c->akbk = nullptr; c->kord_tr_dev = nullptr; c->akbk_ready = false;
+  c->trc_d = nullptr; c->trc_i = nullptr;
   for (auto &s : c->scratch) s = nullptr;
   c->lev_ext_d = nullptr; c->lev_ext_i = nullptr;
   *out = c;
@@ -159,6 +163,8 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   if (c->lev_d) rt_free(c->lev_d);
   if (c->dp0) rt_free(c->dp0);
   if (c->akbk) rt_free(c->akbk);
+  if (c->trc_d) rt_free(c->trc_d);
+  if (c->trc_i) rt_free(c->trc_i);
   if (c->kord_tr_dev) rt_free(c->kord_tr_dev);
   if (c->edge_dev) rt_free(c->edge_dev);
   if (c->lev_ext_d) rt_free(c->lev_ext_d);
@@ -745,5 +751,77 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
     RemapPe kf{g, km, ak, bk, pe};
     RT(launch_p(c, "remap_pe", col_grid(g.nx * g.ny), 0, kf));
   }
+  return 0;
+}
+
+// ================================================================================================
+// tracer_2d
+// ================================================================================================
+static int need_trc(fv3_ctx *c) {
+  const int npz = c->g.npz;
+  if (!c->trc_d) RT(rt_malloc((void **)&c->trc_d, sizeof(double) * 2 * npz));
+  if (!c->trc_i) RT(rt_malloc((void **)&c->trc_i, sizeof(int) * npz));
+  return 0;
+}
+
+extern "C" int fv3_tracer_2d_prep(fv3_ctx *c, int q_split, const double *cx, const double *cy, double *xfx,
+                                  double *yfx, double *cmax_host) {
+  if (!c || !c->grid_ready) return fail("fv3_tracer_2d_prep: context has no grid");
+  if (need_trc(c)) return 1;
+  const Grid &g = c->g;
+  RT(rt_memset(c->trc_d, 0, sizeof(double) * g.npz, c->stream));
+  TracerPrep kf{g, g.npz, q_split, cx, cy, xfx, yfx, c->trc_d};
+  const size_t nmax = g.nCX() > g.nCY() ? g.nCX() : g.nCY();
+  Dim3 grid;
+  grid.x = (unsigned)((nmax + TracerPrep::CH - 1) / TracerPrep::CH);
+  grid.y = 1;
+  grid.z = (unsigned)g.npz;
+  RT(launch_p(c, "tracer_prep", grid, 0, kf));
+  if (cmax_host) {
+    RT(rt_d2h(cmax_host, c->trc_d, sizeof(double) * g.npz, c->stream));
+    RT(rt_sync(c->stream));
+  }
+  return 0;
+}
+
+extern "C" int fv3_tracer_2d_scale(fv3_ctx *c, const double *frac_host, double *cx, double *xfx, double *mfx,
+                                   double *cy, double *yfx, double *mfy) {
+  if (!c || !c->grid_ready || !frac_host) return fail("fv3_tracer_2d_scale: bad context/arguments");
+  if (need_trc(c)) return 1;
+  const Grid &g = c->g;
+  RT(rt_h2d(c->trc_d + g.npz, frac_host, sizeof(double) * g.npz, c->stream));
+  RT(rt_sync(c->stream));
+  TracerScale kf{g, c->trc_d + g.npz, cx, xfx, mfx, cy, yfx, mfy};
+  const size_t nmax = g.nCX() > g.nCY() ? g.nCX() : g.nCY();
+  Dim3 grid;
+  grid.x = (unsigned)((nmax + TracerScale::CH - 1) / TracerScale::CH);
+  grid.y = 1;
+  grid.z = (unsigned)g.npz;
+  RT(launch_p(c, "tracer_scale", grid, 0, kf));
+  return 0;
+}
+
+extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *ksplt_host, int nq, int hord, int nord_tr,
+                                  double trdm, const double *q, double *q_out, const double *dp1, double *dp1_out,
+                                  const double *mfx, const double *mfy, const double *cx, const double *cy,
+                                  const double *xfx, const double *yfx) {
+  if (!c || !c->grid_ready || !ksplt_host) return fail("fv3_tracer_2d_step: bad context/arguments");
+  if (!tp_ord_supported(hord)) return fail("fv3_tracer_2d_step: hord=%d not supported (5,-5,6,8,10)", hord);
+  if (q == q_out || dp1 == dp1_out) return fail("fv3_tracer_2d_step: *_out buffers must not alias the inputs");
+  if (trdm > 1.e-4 && nord_tr > 2) return fail("fv3_tracer_2d_step: nord_tr > 2");
+  if (need_trc(c)) return 1;
+  const Grid &g = c->g;
+  if (it == 1) {
+    RT(rt_h2d(c->trc_i, ksplt_host, sizeof(int) * g.npz, c->stream));
+    RT(rt_sync(c->stream));
+  }
+  constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
+  TracerStep<TI, TJ> kf{g, g.npz, nq, it, nsplt, hord, nord_tr, trdm, c->trc_i, q, dp1, mfx, mfy, cx, cy, xfx, yfx,
+                        q_out, dp1_out};
+  Dim3 grid;
+  grid.x = (unsigned)((g.nx + TI - 1) / TI);
+  grid.y = (unsigned)((g.ny + TJ - 1) / TJ);
+  grid.z = (unsigned)g.npz;
+  RT(launch_p(c, "tracer_step", grid, TracerStep<TI, TJ>::lds_doubles, kf));
   return 0;
 }

@@ -33,7 +33,8 @@ EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_halo_fill_periodic", "fv3_profile", "fv3_profile_report",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
-           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_lagrangian_to_eulerian"]
+           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_lagrangian_to_eulerian",
+           "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
 
 
 class Fv3Error(RuntimeError):
@@ -356,8 +357,27 @@ class Context:
             self.h, C.byref(s), kt.ctypes.data_as(_ip) if kt.size else None, ps.p, pe.p, delp.p, pkz.p, pk.p, u.p, v.p,
             _pp(w), _pp(delz), pt.p, _pp(q), peln.p, omga.p, _pp(ws)), "fv3_lagrangian_to_eulerian")
 
+    # -- tracer_2d ---------------------------------------------------------------------------------------
+    def tracer_2d_prep(self, q_split, cx, cy, xfx, yfx) -> np.ndarray:
+        cmax = np.zeros(self.npz)
+        self.lib.check(self.lib.dll.fv3_tracer_2d_prep(self.h, C.c_int(q_split), cx.p, cy.p, xfx.p, yfx.p,
+                                                       cmax.ctypes.data_as(_dp)), "fv3_tracer_2d_prep")
+        return cmax
+
+    def tracer_2d_scale(self, frac, cx, xfx, mfx, cy, yfx, mfy):
+        f = np.ascontiguousarray(frac, dtype=np.float64)
+        self.lib.check(self.lib.dll.fv3_tracer_2d_scale(self.h, f.ctypes.data_as(_dp), cx.p, xfx.p, mfx.p, cy.p, yfx.p,
+                                                        mfy.p), "fv3_tracer_2d_scale")
+
+    def tracer_2d_step(self, it, nsplt, ksplt, nq, hord, nord_tr, trdm, q, q_out, dp1, dp1_out, mfx, mfy, cx, cy, xfx, yfx):
+        ks = np.ascontiguousarray(ksplt, dtype=np.int32)
+        self.lib.check(self.lib.dll.fv3_tracer_2d_step(self.h, C.c_int(it), C.c_int(nsplt), ks.ctypes.data_as(_ip),
+                                                       C.c_int(nq), C.c_int(hord), C.c_int(nord_tr), C.c_double(trdm),
+                                                       q.p, q_out.p, dp1.p, dp1_out.p, mfx.p, mfy.p, cx.p, cy.p, xfx.p,
+                                                       yfx.p), "fv3_tracer_2d_step")
+
     def halo_fill_periodic(self, field: DeviceArray, kind: str):
         code = {"A": 0, "U": 1, "V": 2, "B": 3}[kind]
-        nk = field.shape[2] if len(field.shape) == 3 else 1
+        nk = int(np.prod(field.shape[2:])) if len(field.shape) > 2 else 1
         self.lib.check(self.lib.dll.fv3_halo_fill_periodic(self.h, field.p, C.c_int(code), C.c_int(nk)),
                        "fv3_halo_fill_periodic")

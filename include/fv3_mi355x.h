@@ -214,6 +214,21 @@ int fv3_lagrangian_to_eulerian(fv3_ctx *ctx, const fv3_remap_params *p, const in
                                double *delp, double *pkz, double *pk, double *u, double *v, double *w, double *delz,
                                double *pt, double *q, double *peln, double *omga, const double *ws);
 
+/* ---- tracer_2d -- model/fv_tracer2d.F90:297, call site model/fv_dynamics.F90:531 -------------------------
+ * The routine is split at the point where it needs a cross-rank reduction (mp_reduce_max, :405): the caller
+ * (host) runs prep, reduces cmax(npz) over ranks, chooses nsplt / ksplt(k) / frac(k) exactly as :404-430 do,
+ * then scale (if nsplt != 1) and nsplt times [halo update of q; step].
+ * q, q_out: A x npz x nq; dp1, dp1_out: A x npz; mfx: FX x npz; mfy: FY x npz; cx, xfx: CX x npz; cy, yfx: CY x npz. */
+int fv3_tracer_2d_prep(fv3_ctx *ctx, int q_split, const double *cx, const double *cy, double *xfx, double *yfx,
+                       double *cmax_host /* npz, out */);
+int fv3_tracer_2d_scale(fv3_ctx *ctx, const double *frac_host /* npz */, double *cx, double *xfx, double *mfx,
+                        double *cy, double *yfx, double *mfy);
+/* one sub-cycle `it` (1-based) of nsplt; q -> q_out and (if it != nsplt) dp1 -> dp1_out on the compute domain. */
+int fv3_tracer_2d_step(fv3_ctx *ctx, int it, int nsplt, const int *ksplt_host /* npz */, int nq, int hord,
+                       int nord_tr, double trdm, const double *q, double *q_out, const double *dp1, double *dp1_out,
+                       const double *mfx, const double *mfy, const double *cx, const double *cy, const double *xfx,
+                       const double *yfx);
+
 /* Per-kernel timing with HIP events recorded on the context's stream around every kernel the
  * library launches (this is what bench.py's roofline figures are measured with).  report: one line
  * "label count total_ms" per kernel label since the last report; synchronises the stream. */

@@ -180,6 +180,10 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
                                double *q, double *peln, double *omga, const double *ws, const double *ak,
                                const double *bk);
 
+/* ---- tracer_2d (oracle/tracer2d.c) ---------------------------------------------------------------- */
+int fvo_tracer_2d(const fvo_grid *g, int npz, int nq, double *q, double *dp1, double *mfx, double *mfy, double *cx,
+                  double *cy, int hord, int q_split, int nord_tr, double trdm);
+
 #ifdef __cplusplus
 }
 #endif

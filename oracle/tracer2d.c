@@ -1,0 +1,147 @@
+/*
+ * oracle/tracer2d.c -- CPU oracle (test infrastructure, see fvo.h) for tracer_2d, model/fv_tracer2d.F90:297-557
+ * (sub-cycled tracer transport with the accumulated mass fluxes / Courant numbers of the acoustic loop).
+ * Single rank of a doubly periodic tile: mp_reduce_max (:405) is the identity and the q halo updates (:474,536)
+ * are the periodic contacts of tools/fv_mp_mod.F90:473-483.  id_divg_mean = 0, GLOBAL_CFL not defined.
+ */
+#include "fvo.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static double *dalloc(size_t n) { return (double *)calloc(n, sizeof(double)); }
+
+static void periodic_fill_A(const fvo_grid *g, double *a) {
+  const int is = g->is, ie = g->ie, js = g->js, je = g->je, isd = g->isd, ied = g->ied, jsd = g->jsd, jed = g->jed;
+  const int nid = ied - isd + 1, nx = ie - is + 1, ny = je - js + 1;
+  int i, j;
+  for (j = jsd; j <= jed; j++)
+    for (i = isd; i <= ied; i++) {
+      int si = i, sj = j;
+      if (i >= is && i <= ie && j >= js && j <= je) continue;
+      if (si < is) si += nx; else if (si > ie) si -= nx;
+      if (sj < js) sj += ny; else if (sj > je) sj -= ny;
+      a[(size_t)(j - jsd) * nid + (i - isd)] = a[(size_t)(sj - jsd) * nid + (si - isd)];
+    }
+}
+
+/* q: A x npz x nq; dp1: A x npz; mfx: FX x npz; mfy: FY x npz; cx: CX x npz; cy: CY x npz.  Returns nsplt (>0)
+ * or a negative error. */
+int fvo_tracer_2d(const fvo_grid *g, int npz, int nq, double *q, double *dp1, double *mfx, double *mfy, double *cx,
+                  double *cy, int hord, int q_split, int nord_tr, double trdm) {
+  const int is = g->is, ie = g->ie, js = g->js, je = g->je, isd = g->isd, ied = g->ied, jsd = g->jsd, jed = g->jed;
+  const int nid = ied - isd + 1, njd = jed - jsd + 1, nx = ie - is + 1, ny = je - js + 1;
+  const size_t nA = (size_t)nid * njd, nCX = (size_t)(nx + 1) * njd, nCY = (size_t)nid * (ny + 1),
+               nFX = (size_t)(nx + 1) * ny, nFY = (size_t)nx * (ny + 1);
+  int i, j, k, it, iq, nsplt;
+  if (g->grid_type < 3) return -FVO_ERR_UNSUPPORTED;
+#define IA(i, j) ((size_t)((j)-jsd) * nid + ((i)-isd))
+#define IV(i, j) ((size_t)((j)-jsd) * (nid + 1) + ((i)-isd))
+#define ICX(i, j) ((size_t)((j)-jsd) * (nx + 1) + ((i)-is))
+#define ICY(i, j) ((size_t)((j)-js) * nid + ((i)-isd))
+#define IFX(i, j) ((size_t)((j)-js) * (nx + 1) + ((i)-is))
+#define IFY(i, j) ((size_t)((j)-js) * nx + ((i)-is))
+#define SIN_SG(i, j, n) g->sin_sg[(size_t)((n)-1) * nA + IA(i, j)]
+  double *xfx = dalloc(nCX * npz), *yfx = dalloc(nCY * npz), *cmax = dalloc(npz), *frac = dalloc(npz);
+  int *ksplt = (int *)calloc(npz, sizeof(int));
+  for (k = 0; k < npz; k++) { /* :362-400 */
+    double *cxk = cx + nCX * k, *cyk = cy + nCY * k, *xk = xfx + nCX * k, *yk = yfx + nCY * k;
+    for (j = jsd; j <= jed; j++)
+      for (i = is; i <= ie + 1; i++) {
+        if (cxk[ICX(i, j)] > 0.)
+          xk[ICX(i, j)] = cxk[ICX(i, j)] * g->dxa[IA(i - 1, j)] * g->dy[IV(i, j)] * SIN_SG(i - 1, j, 3);
+        else
+          xk[ICX(i, j)] = cxk[ICX(i, j)] * g->dxa[IA(i, j)] * g->dy[IV(i, j)] * SIN_SG(i, j, 1);
+      }
+    for (j = js; j <= je + 1; j++)
+      for (i = isd; i <= ied; i++) {
+        if (cyk[ICY(i, j)] > 0.)
+          yk[ICY(i, j)] = cyk[ICY(i, j)] * g->dya[IA(i, j - 1)] * g->dx[IA(i, j)] * SIN_SG(i, j - 1, 4);
+        else
+          yk[ICY(i, j)] = cyk[ICY(i, j)] * g->dya[IA(i, j)] * g->dx[IA(i, j)] * SIN_SG(i, j, 2);
+      }
+    if (q_split == 0) {
+      cmax[k] = 0.;
+      if (k + 1 < npz / 6) {
+        for (j = js; j <= je; j++)
+          for (i = is; i <= ie; i++) cmax[k] = fmax(cmax[k], fmax(fabs(cxk[ICX(i, j)]), fabs(cyk[ICY(i, j)])));
+      } else {
+        for (j = js; j <= je; j++)
+          for (i = is; i <= ie; i++)
+            cmax[k] = fmax(cmax[k], fmax(fabs(cxk[ICX(i, j)]), fabs(cyk[ICY(i, j)])) + 1. - SIN_SG(i, j, 5));
+      }
+    }
+    ksplt[k] = 1;
+  }
+  if (q_split == 0) { /* :404-417 */
+    double c_global = cmax[0];
+    if (npz != 1)
+      for (k = 1; k < npz; k++) c_global = fmax(cmax[k], c_global);
+    nsplt = (int)(1. + c_global);
+  } else {
+    nsplt = q_split;
+  }
+  if (nsplt != 1) { /* :421-461 */
+    for (k = 0; k < npz; k++) {
+      size_t n;
+      ksplt[k] = (int)(1. + cmax[k]);
+      frac[k] = 1. / (double)ksplt[k];
+      for (j = jsd; j <= jed; j++)
+        for (i = is; i <= ie + 1; i++) {
+          cx[nCX * k + ICX(i, j)] = cx[nCX * k + ICX(i, j)] * frac[k];
+          xfx[nCX * k + ICX(i, j)] = xfx[nCX * k + ICX(i, j)] * frac[k];
+        }
+      for (n = 0; n < nFX; n++) mfx[nFX * k + n] = mfx[nFX * k + n] * frac[k];
+      for (j = js; j <= je + 1; j++)
+        for (i = isd; i <= ied; i++) {
+          cy[nCY * k + ICY(i, j)] = cy[nCY * k + ICY(i, j)] * frac[k];
+          yfx[nCY * k + ICY(i, j)] = yfx[nCY * k + ICY(i, j)] * frac[k];
+        }
+      for (n = 0; n < nFY; n++) mfy[nFY * k + n] = mfy[nFY * k + n] * frac[k];
+    }
+  } else {
+    for (k = 0; k < npz; k++) frac[k] = 1.0;
+  }
+  if (trdm > 1.e-4)
+    for (k = 0; k < npz; k++) periodic_fill_A(g, dp1 + nA * k);
+  for (it = 1; it <= nsplt; it++) { /* :471-541 */
+    for (iq = 0; iq < nq; iq++)
+      for (k = 0; k < npz; k++) periodic_fill_A(g, q + ((size_t)iq * npz + k) * nA);
+#pragma omp parallel for private(i, j, iq) schedule(dynamic)
+    for (k = 0; k < npz; k++) {
+      if (it <= ksplt[k]) {
+        double *dp2 = dalloc((size_t)nx * ny), *fx = dalloc(nFX), *fy = dalloc(nFY);
+        double *ra_x = dalloc((size_t)nx * njd), *ra_y = dalloc((size_t)nid * ny);
+        const double *xk = xfx + nCX * k, *yk = yfx + nCY * k, *mx = mfx + nFX * k, *my = mfy + nFY * k;
+        double *d1 = dp1 + nA * k;
+        for (j = js; j <= je; j++)
+          for (i = is; i <= ie; i++)
+            dp2[(size_t)(j - js) * nx + (i - is)] =
+                d1[IA(i, j)] + (mx[IFX(i, j)] - mx[IFX(i + 1, j)] + my[IFY(i, j)] - my[IFY(i, j + 1)]) * g->rarea[IA(i, j)];
+        for (j = jsd; j <= jed; j++)
+          for (i = is; i <= ie; i++) ra_x[(size_t)(j - jsd) * nx + (i - is)] = g->area[IA(i, j)] + xk[ICX(i, j)] - xk[ICX(i + 1, j)];
+        for (j = js; j <= je; j++)
+          for (i = isd; i <= ied; i++) ra_y[ICY(i, j)] = g->area[IA(i, j)] + yk[ICY(i, j)] - yk[ICY(i, j + 1)];
+        for (iq = 0; iq < nq; iq++) {
+          double *qk = q + ((size_t)iq * npz + k) * nA;
+          if (it == 1 && trdm > 1.e-4)
+            fvo_fv_tp_2d(g, qk, cx + nCX * k, cy + nCY * k, hord, fx, fy, xk, yk, ra_x, ra_y, mx, my, d1, nord_tr, trdm);
+          else
+            fvo_fv_tp_2d(g, qk, cx + nCX * k, cy + nCY * k, hord, fx, fy, xk, yk, ra_x, ra_y, mx, my, NULL, -1, 0.);
+          for (j = js; j <= je; j++)
+            for (i = is; i <= ie; i++)
+              qk[IA(i, j)] = (qk[IA(i, j)] * d1[IA(i, j)] +
+                              (fx[IFX(i, j)] - fx[IFX(i + 1, j)] + fy[IFY(i, j)] - fy[IFY(i, j + 1)]) * g->rarea[IA(i, j)]) /
+                             dp2[(size_t)(j - js) * nx + (i - is)];
+        }
+        if (it != nsplt)
+          for (j = js; j <= je; j++)
+            for (i = is; i <= ie; i++) d1[IA(i, j)] = dp2[(size_t)(j - js) * nx + (i - is)];
+        free(dp2); free(fx); free(fy); free(ra_x); free(ra_y);
+      }
+    }
+  }
+  free(xfx); free(yfx); free(cmax); free(frac); free(ksplt);
+  return nsplt;
+}

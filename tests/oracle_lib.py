@@ -257,3 +257,11 @@ def lagrangian_to_eulerian(g, km, par: dict, f: dict, ak, bk):
                                           p(f["pt"]), p(f.get("q")), p(f["peln"]), p(f["omga"]), p(f.get("ws")),
                                           ak.ctypes.data_as(_dp), bk.ctypes.data_as(_dp))
     assert rc == 0, rc
+
+
+def tracer_2d(g, npz, nq, q, dp1, mfx, mfy, cx, cy, hord, q_split, nord_tr, trdm):
+    gs = make_grid(g)
+    rc = lib().fvo_tracer_2d(C.byref(gs), C.c_int(npz), C.c_int(nq), p(q), p(dp1), p(mfx), p(mfy), p(cx), p(cy),
+                             C.c_int(hord), C.c_int(q_split), C.c_int(nord_tr), _d(trdm))
+    assert rc > 0, rc
+    return rc

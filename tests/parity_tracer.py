@@ -1,0 +1,50 @@
+"""Parity of tracer_2d (library + host orchestration) vs the oracle on accumulated fluxes from d_sw."""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle_lib as O
+import parity_common as P
+from gfdl_atmos_cubed_sphere_amd.halo import HaloExchanger
+from gfdl_atmos_cubed_sphere_amd.layout import Bounds, periodic_fill
+from gfdl_atmos_cubed_sphere_amd.lib import Context
+from gfdl_atmos_cubed_sphere_amd.tracer2d import tracer_2d
+from test_oracle_properties import run_pair
+
+
+def check_tracer_2d(lib, nx=40, ny=19, npz=4, nq=3, hord=8, q_split=0, trdm=0.0, nord_tr=1, big_courant=False):
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    before, after = run_pair(bd, npz, g, True, dt=8.0)    # oracle c_sw + d_sw: realistic mfx, mfy, cx, cy
+    rng = np.random.default_rng(17)
+    scale = 3.0 if big_courant else 1.0                   # > 1 forces sub-cycling (nsplt > 1)
+    mfx, mfy = np.asfortranarray(after["mfx"] * scale), np.asfortranarray(after["mfy"] * scale)
+    cx, cy = np.asfortranarray(after["cx"] * scale * 3.0), np.asfortranarray(after["cy"] * scale * 3.0)
+    dp1 = before["delp"].copy(order="F")
+    q = np.asfortranarray(rng.uniform(0, 1, bd.shape("A", npz) + (nq,)))
+    ref = dict(q=q.copy(order="F"), dp1=dp1.copy(order="F"), mfx=mfx.copy(order="F"), mfy=mfy.copy(order="F"),
+               cx=cx.copy(order="F"), cy=cy.copy(order="F"))
+    nsplt_ref = O.tracer_2d(g, npz, nq, ref["q"], ref["dp1"], ref["mfx"], ref["mfy"], ref["cx"], ref["cy"], hord, q_split,
+                            nord_tr, trdm)
+    ctx = Context(g, npz, lib=lib)
+    try:
+        halo = HaloExchanger(ctx, 1, 1, 0, 1)
+        d = dict(q=ctx.from_host(q), q_nxt=ctx.from_host(np.zeros_like(q)), dp1=ctx.from_host(dp1),
+                 dp1_nxt=ctx.from_host(np.zeros_like(dp1)), mfx=ctx.from_host(mfx), mfy=ctx.from_host(mfy),
+                 cx=ctx.from_host(cx), cy=ctx.from_host(cy), xfx=ctx.zeros("CX", npz), yfx=ctx.zeros("CY", npz))
+        qf, dpf, nsplt = tracer_2d(ctx, halo, d["q"], d["q_nxt"], d["dp1"], d["dp1_nxt"], d["mfx"], d["mfy"], d["cx"],
+                                   d["cy"], d["xfx"], d["yfx"], nq, hord, q_split, nord_tr, trdm)
+        assert nsplt == nsplt_ref, (nsplt, nsplt_ref)
+        tol = 1e-14 if "hostemu" in lib.path else 1e-12
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        got = qf.download()
+        worst = 0.0
+        for iq in range(nq):
+            worst = max(worst, P.assert_close(f"q{iq}", bd.view(got[:, :, :, iq], "A", *r),
+                                              bd.view(ref["q"][:, :, :, iq], "A", *r), tol))
+        worst = max(worst, P.assert_close("dp1", bd.view(dpf.download(), "A", *r), bd.view(ref["dp1"], "A", *r), tol))
+        for n in ("mfx", "mfy", "cx", "cy"):
+            worst = max(worst, P.assert_close(n, d[n].download(), ref[n], tol))
+    finally:
+        ctx.close()
+    return worst, nsplt

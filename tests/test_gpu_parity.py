@@ -173,3 +173,42 @@ def test_remap(prod, hydrostatic, last_step, kord_tm, kord, nq):
 
 def test_remap_larger(prod):
     R.check_remap(prod, nx=96, ny=64, km=32, nq=2)
+
+
+# ---- tracer_2d -------------------------------------------------------------------------------------
+import parity_tracer as T
+
+
+def test_tracer_2d(prod):
+    T.check_tracer_2d(prod)
+    _, nsplt = T.check_tracer_2d(prod, big_courant=True, hord=-5)
+    assert nsplt > 1
+    T.check_tracer_2d(prod, q_split=2, trdm=0.06, nord_tr=1, hord=10)
+    T.check_tracer_2d(prod, nx=33, ny=9, npz=7, nq=7, big_courant=True)
+    T.check_tracer_2d(prod, nx=96, ny=96, npz=16, nq=4)
+
+
+def test_torch_alias_of_device_array_and_exchange_path(prod):
+    """The multi-GPU halo path aliases library-owned buffers as torch tensors (__cuda_array_interface__) and
+    packs/unpacks with strided torch ops: check the alias is zero-copy, Fortran-strided and coherent with the
+    kernels, by running the exchange code with a single rank (local periodic copies) against the device kernel."""
+    import torch
+    from gfdl_atmos_cubed_sphere_amd.grid import doubly_periodic
+    from gfdl_atmos_cubed_sphere_amd.halo import HaloTopology, exchange_tensors
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    bd = Bounds(1, 20, 1, 12)
+    g = doubly_periodic(bd, 21, 13)
+    ctx = L.Context(g, 3, lib=prod, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        rng = np.random.default_rng(2)
+        for kind in ("A", "U", "V", "B"):
+            a = np.asfortranarray(rng.uniform(-1, 1, bd.shape(kind, 3)))
+            d1, d2 = ctx.from_host(a), ctx.from_host(a)
+            t = torch.as_tensor(d1, device="cuda")
+            assert t.data_ptr() == d1.ptr and tuple(t.shape) == d1.shape and t.stride()[0] == 1
+            exchange_tensors(HaloTopology(bd, 1, 1, 0), [(t, kind)])
+            torch.cuda.synchronize()
+            ctx.halo_fill_periodic(d2, kind)
+            assert np.array_equal(d1.download(), d2.download()), kind
+    finally:
+        ctx.close()

@@ -144,3 +144,16 @@ import parity_remap as R
                                                                     (True, True, 10, 11, 3), (False, True, -10, 13, 2)])
 def test_remap(emu, hydrostatic, last_step, kord_tm, kord, nq):
     R.check_remap(emu, hydrostatic=hydrostatic, last_step=last_step, kord_tm=kord_tm, kord=kord, nq=nq)
+
+
+# ---- tracer_2d -------------------------------------------------------------------------------------
+import parity_tracer as T
+
+
+def test_tracer_2d(emu):
+    _, nsplt = T.check_tracer_2d(emu)
+    assert nsplt == 1
+    _, nsplt = T.check_tracer_2d(emu, big_courant=True, hord=-5)
+    assert nsplt > 1
+    T.check_tracer_2d(emu, q_split=2, trdm=0.06, nord_tr=1, hord=10)
+    T.check_tracer_2d(emu, nx=33, ny=9, npz=7, nq=7, big_courant=True)
