@@ -121,7 +121,15 @@ class HaloExchanger:
         import torch
         key = dev.ptr
         if key not in self._views:
-            self._views[key] = torch.as_tensor(dev, device="cuda")
+            if getattr(self.ctx.lib, "host_memory", False):
+                # tests/hostemu harness: "device" buffers are host memory
+                import ctypes
+                import numpy as np
+                n = int(np.prod(dev.shape))
+                flat = np.ctypeslib.as_array(ctypes.cast(ctypes.c_void_p(dev.ptr), ctypes.POINTER(ctypes.c_double)), (n,))
+                self._views[key] = torch.from_numpy(flat.reshape(dev.shape, order="F"))
+            else:
+                self._views[key] = torch.as_tensor(dev, device="cuda")
         return self._views[key]
 
     def update(self, fields):

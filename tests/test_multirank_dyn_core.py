@@ -1,0 +1,85 @@
+"""The N>1 path of the substep loop: two ranks (gloo, CPU) each own half of a doubly periodic domain and run the
+product's DynCore orchestration + halo exchange on the host-emulation build of the kernels; the union of their
+blocks must equal the oracle's single-domain result.  (On GPUs the same code runs over RCCL.)"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _block(a, kind, bd_g, bd_l):
+    """slice the local block (with halo) out of a global halo'd array"""
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    ilo_g, _, jlo_g, _ = bd_g.limits(kind)
+    ilo, ihi, jlo, jhi = bd_l.limits(kind)
+    return np.asfortranarray(a[ilo - ilo_g:ihi - ilo_g + 1, jlo - jlo_g:jhi - jlo_g + 1].copy())
+
+
+def _worker(rank, world, port, ok):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_dyn_core as OD
+        import parity_common as P
+        import parity_dyn as D
+        import parity_nh as N
+        from gfdl_atmos_cubed_sphere_amd.dyn_core import DynCore, DynFlags
+        from gfdl_atmos_cubed_sphere_amd.grid import doubly_periodic
+        from gfdl_atmos_cubed_sphere_amd.halo import choose_layout
+        from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+        from gfdl_atmos_cubed_sphere_amd.lib import Context, Fv3Lib
+        emu = Fv3Lib(os.path.join(HERE, "hostemu", "libfv3_hostemu.so"))
+        nx, ny, npz = 12, 10, 6
+        px, py = choose_layout(world)
+        bd_g = Bounds(1, nx * px, 1, ny * py)
+        g_g = P.make_grid(bd_g, False)
+        st, dp0 = D.make_state(bd_g, npz)
+        fl = DynFlags(n_split=2, ptop=N.PTOP)
+        ref = OD.run(g_g, npz, fl, dp0, st, 4.0)
+        ix, iy = rank % px, rank // px
+        bd = Bounds(1 + ix * nx, (ix + 1) * nx, 1 + iy * ny, (iy + 1) * ny)
+        g = doubly_periodic(bd, nx * px + 1, ny * py + 1)
+        ctx = Context(g, npz, lib=emu)
+        dc = DynCore(ctx, fl, dp0, px=px, py=py, rank=rank, world=world)
+        loc = {n: _block(st[n], k, bd_g, bd) for n, k in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"),
+                                                         ("phis", "A"))}
+        delz = np.asfortranarray(st["delz"][ix * nx:(ix + 1) * nx, iy * ny:(iy + 1) * ny, :].copy())
+        dc.set_state(loc["u"], loc["v"], loc["w"], loc["delp"], loc["pt"], delz, loc["phis"])
+        dc.run(4.0)
+        got = dc.get_state()
+        good = True
+        for n, kind, rr in (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)),
+                            ("w", "A", (bd.is_, bd.ie, bd.js, bd.je)), ("delp", "A", (bd.is_, bd.ie, bd.js, bd.je)),
+                            ("pt", "A", (bd.is_, bd.ie, bd.js, bd.je)), ("zh", "A", (bd.is_, bd.ie, bd.js, bd.je))):
+            a = bd.view(got[n], kind, *rr)
+            b = bd_g.view(ref[n], kind, *rr)
+            e = P.rel_rms(a, b)
+            if not (e <= 1e-13):
+                print("rank", rank, n, e, flush=True)
+                good = False
+        ok[rank] = 1 if good else 0
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_dyn_core_two_ranks_match_single_domain(world):
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostemu"), "-s"])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ok = mp.get_context("spawn").Array("i", [0] * world)
+    mp.spawn(_worker, args=(world, port, ok), nprocs=world, join=True)
+    assert list(ok) == [1] * world
