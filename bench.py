@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--npz", type=int, default=127)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-model-step", action="store_true", help="skip the SYPD (whole model step) leg")
+    ap.add_argument("--nq", type=int, default=4, help="advected tracers in the SYPD leg")
     return ap.parse_args()
 
 
@@ -91,6 +93,58 @@ def cpu_baseline(nx, seconds):
                       f"({t_used:.1f} s CPU wall), OpenMP over k on {cores} threads"}
 
 
+def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream):
+    """SYPD leg: whole nonhydrostatic model steps (fv_dynamics.F90:460-665 k_split loop: n_split acoustic substeps,
+    tracer_2d, Lagrangian_to_Eulerian) on the same tile, dt_atmos=225 s, k_split=2, n_split=5 (C384 settings)."""
+    import parity_dyn as D
+    import parity_nh as N
+    from gfdl_atmos_cubed_sphere_amd import lib as L
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    nx, npz, nq = a.nx, a.npz, a.nq
+    ctx = L.Context(g, npz, stream=stream.cuda_stream)
+    st, _ = D.make_state(Bounds(1, nx, 1, nx), npz)
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+    ak, bk = N.PTOP * (1.0 - sig), sig.copy()
+    k_split, n_split, dt_atmos = 2, 5, 225.0
+    fv = FvDynamics(ctx, DynFlags(n_split=n_split, ptop=N.PTOP), ak, bk, nq=nq, k_split=k_split, px=px, py=py,
+                    rank=rank, world=world, dist=dist if world > 1 else None)
+    fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
+    if nq:
+        fv.set_tracers(np.asfortranarray(np.random.default_rng(1).uniform(0, 1, bd.shape("A", npz) + (nq,))))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    fv.step(dt_atmos)
+    fence()
+    nrep = 3
+    t0 = time.perf_counter()
+    for _ in range(nrep):
+        fv.step(dt_atmos)
+    fence()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    wall = el / nrep
+    w = fv.dc.d["w"].download()
+    ctx.profile(True)
+    fv.step(dt_atmos)
+    rep = ctx.profile_report()
+    ctx.profile(False)
+    ctx.close()
+    return {"sypd": dt_atmos / (365.0 * wall), "wall_s_per_dt_atmos": wall, "dt_atmos_s": dt_atmos, "k_split": k_split,
+            "n_split": n_split, "nq": nq, "dx_m": 26000.0, "finite": bool(np.isfinite(w).all()),
+            "note": f"one {nx}x{nx}x{npz} doubly periodic tile per GPU ({world} tile(s)); a C384 sphere is 6 such tiles, "
+                    "so this is the SYPD of a 6-GPU one-face-per-GPU run before cube-edge exchange cost",
+            "kernels_ms_per_dt_atmos": {k: round(v[1], 3) for k, v in rep.items()}}
+
+
 def main():
     a = parse()
     import torch
@@ -118,7 +172,7 @@ def main():
     ix, iy = rank % px, rank // px
     bd = Bounds(1 + ix * nx, (ix + 1) * nx, 1 + iy * nx, (iy + 1) * nx)
     from gfdl_atmos_cubed_sphere_amd.grid import doubly_periodic
-    g = doubly_periodic(bd, nx * px + 1, nx * py + 1)
+    g = doubly_periodic(bd, nx * px + 1, nx * py + 1, dx_const=26000.0, dy_const=26000.0)
     stream = torch.cuda.current_stream()
     ctx = L.Context(g, npz, stream=stream.cuda_stream)
     halo = HaloExchanger(ctx, px, py, rank, world)
@@ -133,7 +187,7 @@ def main():
                     ("v_out", "V"), ("w_out", "A"), ("heat_s", "CC"), ("diss_e", "CC")):
         d[n] = ctx.zeros(kind, npz)
     ctx.dsw_levels(default_levels(npz))
-    dt = 4.0
+    dt = 22.5   # C384 acoustic step: dt_atmos 225 s / k_split 2 / n_split 5
     par = dict(P.DSW_PAR)
     par.update(dt=dt, hydrostatic=0, use_cond=0)
 
@@ -203,13 +257,16 @@ def main():
                                   f"c_sw+d_sw pair, hord 10/10/10/10, nord=1, d4_bg=0.16",
                       "layout": f"{px}x{py}", "halo": "periodic copy" if world == 1 else "RCCL send/recv"},
            "finite": finite, "roofline": roof}
+    ctx.close()
+    ctx = None
+    del d
+    out["model_step"] = None if a.no_model_step else model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream)
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(nx, a.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
-    ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -196,6 +196,10 @@ extern "C" int fv3_memcpy_d2h(fv3_ctx *c, void *dst, const void *src, size_t byt
   RT(rt_d2h(dst, src, bytes, c ? c->stream : nullptr));
   return 0;
 }
+extern "C" int fv3_memcpy_d2d(fv3_ctx *c, void *dst, const void *src, size_t bytes) {
+  RT(rt_d2d(dst, src, bytes, c ? c->stream : nullptr));
+  return 0;
+}
 extern "C" int fv3_memset(fv3_ctx *c, void *dst, int value, size_t bytes) {
   RT(rt_memset(dst, value, bytes, c ? c->stream : nullptr));
   return 0;

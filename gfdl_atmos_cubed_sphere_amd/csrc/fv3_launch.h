@@ -48,6 +48,10 @@ inline int rt_memset(void *d, int v, size_t n, stream_t) {
   std::memset(d, v, n);
   return 0;
 }
+inline int rt_d2d(void *d, const void *s, size_t n, stream_t) {
+  std::memcpy(d, s, n);
+  return 0;
+}
 inline int rt_sync(stream_t) { return 0; }
 inline const char *rt_errstr(int) { return "host-emu error"; }
 inline int rt_event_create(void **e) { *e = nullptr; return 0; }
@@ -94,6 +98,9 @@ inline int rt_d2h(void *d, const void *s, size_t n, stream_t st) {
   return (int)hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st);
 }
 inline int rt_memset(void *d, int v, size_t n, stream_t st) { return (int)hipMemsetAsync(d, v, n, st); }
+inline int rt_d2d(void *d, const void *s, size_t n, stream_t st) {
+  return (int)hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st);
+}
 inline int rt_sync(stream_t st) { return (int)hipStreamSynchronize(st); }
 inline const char *rt_errstr(int e) { return hipGetErrorString((hipError_t)e); }
 inline int rt_event_create(void **e) { return (int)hipEventCreate((hipEvent_t *)e); }

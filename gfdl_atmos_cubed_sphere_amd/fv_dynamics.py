@@ -1,0 +1,60 @@
+"""Host orchestration of one atmospheric time step -- the build's counterpart of the k_split loop of
+``fv_dynamics`` (model/fv_dynamics.F90:460-665): for each remapping cycle the acoustic substeps (``dyn_core``),
+the sub-cycled tracer transport (``tracer_2d``) and the vertical remap (``Lagrangian_to_Eulerian``).
+
+The state is expected in the form ``dyn_core`` works on (pt = theta_v, delz < 0); the T <-> theta_v conversions
+and diagnostics around the loop (fv_dynamics.F90:284-399, 669-803) are SURVEY section 8(f) "next" items.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .dyn_core import DynCore, DynFlags
+from .lib import CP_AIR, Context
+from .tracer2d import tracer_2d
+
+
+class FvDynamics:
+    def __init__(self, ctx: Context, flags: DynFlags, ak, bk, nq: int = 0, k_split: int = 1, kord_tm: int = -8,
+                 kord_mt: int = 8, kord_wz: int = 8, kord_tr: int = 8, q_split: int = 0, nord_tr: int = 0, trdm2: float = 0.0, adiabatic: bool = True,
+                 px: int = 1, py: int = 1, rank: int = 0, world: int = 1, dist=None):
+        ak, bk = np.asarray(ak, dtype=np.float64), np.asarray(bk, dtype=np.float64)
+        dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5          # dyn_core.F90:241-244
+        self.ctx, self.fl, self.nq, self.k_split, self.q_split, self.dist = ctx, flags, nq, k_split, q_split, dist
+        self.nord_tr, self.trdm2 = nord_tr, trdm2
+        self.dc = DynCore(ctx, flags, dp_ref, px, py, rank, world)
+        ctx.set_ak_bk(ak, bk)
+        npz = ctx.npz
+        d = self.dc.d
+        d["ps"], d["pkz"] = ctx.zeros("A"), ctx.zeros("CC", npz)
+        d["dp1"], d["dp1_nxt"] = ctx.zeros("A", npz), ctx.zeros("A", npz)
+        if nq:
+            shp = ctx.bd.shape("A", npz) + (nq,)
+            d["q"], d["q_nxt"] = ctx.from_host(np.zeros(shp, order="F")), ctx.from_host(np.zeros(shp, order="F"))
+        self.remap_par = dict(hydrostatic=0, adiabatic=int(adiabatic), nq=nq, kord_mt=kord_mt, kord_wz=kord_wz,
+                              kord_tm=kord_tm, sphum=1 if nq else 0, akap=flags.akap, ptop=flags.ptop,
+                              rdgas=flags.rdgas, grav=flags.grav, cv_air=flags.cp_air - flags.rdgas, r_vir=0.6077,
+                              cp=flags.cp_air, t_min=184.0, kord_tr=[kord_tr] * nq)
+
+    def set_tracers(self, q: np.ndarray):
+        self.dc.d["q"].upload(q)
+
+    def step(self, bdt: float, last_cycle_is_last_step: bool = False):
+        """One dt_atmos: k_split x (n_split acoustic substeps, tracer transport, vertical remap)."""
+        d, ctx = self.dc.d, self.ctx
+        mdt = bdt / float(self.k_split)
+        for n_map in range(1, self.k_split + 1):
+            last_step = last_cycle_is_last_step and n_map == self.k_split
+            d["dp1"].copy_from(d["delp"])                                      # fv_dynamics.F90:475-481
+            self.dc.run(mdt)                                                   # :493
+            if self.nq:                                                        # :500-533
+                q, dp1, _ = tracer_2d(ctx, self.dc.halo, d["q"], d["q_nxt"], d["dp1"], d["dp1_nxt"], d["mfx"], d["mfy"],
+                                      d["cx"], d["cy"], d["crx"], d["cry"], self.nq, self.fl.hord_tr, self.q_split,
+                                      self.nord_tr, self.trdm2, dist=self.dist)
+                if q is not d["q"]:
+                    d["q"], d["q_nxt"] = d["q_nxt"], d["q"]
+                if dp1 is not d["dp1"]:
+                    d["dp1"], d["dp1_nxt"] = d["dp1_nxt"], d["dp1"]
+            par = dict(self.remap_par, last_step=int(last_step))
+            ctx.lagrangian_to_eulerian(par, d["ps"], d["pe"], d["delp"], d["pkz"], d["pk"], d["u"], d["v"], d["w"],
+                                       d["delz"], d["pt"], d.get("q"), d["peln"], d["omga"], d["ws"])   # :607

@@ -30,7 +30,7 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 
 # every symbol include/fv3_mi355x.h declares (tests check the built library exports all of them)
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_malloc",
-           "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
+           "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_halo_fill_periodic", "fv3_profile", "fv3_profile_report",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_lagrangian_to_eulerian",
@@ -153,6 +153,12 @@ class DeviceArray:
                                                            C.c_size_t(self.nbytes)), "fv3_memcpy_d2h")
         self.ctx.sync()
         return out
+
+    def copy_from(self, other: "DeviceArray"):
+        assert other.nbytes == self.nbytes
+        self.ctx.lib.check(self.ctx.lib.dll.fv3_memcpy_d2d(self.ctx.h, _vp(self.ptr), _vp(other.ptr),
+                                                           C.c_size_t(self.nbytes)), "fv3_memcpy_d2d")
+        return self
 
     def zero(self):
         self.ctx.lib.check(self.ctx.lib.dll.fv3_memset(self.ctx.h, _vp(self.ptr), 0, C.c_size_t(self.nbytes)),

@@ -75,6 +75,7 @@ int fv3_free(void *dptr);
 int fv3_memcpy_h2d(fv3_ctx *ctx, void *dst, const void *src, size_t bytes);
 int fv3_memcpy_d2h(fv3_ctx *ctx, void *dst, const void *src, size_t bytes);
 int fv3_memset(fv3_ctx *ctx, void *dst, int value, size_t bytes);
+int fv3_memcpy_d2d(fv3_ctx *ctx, void *dst, const void *src, size_t bytes);
 int fv3_sync(fv3_ctx *ctx);
 
 /* fv_tp_2d -- model/tp_core.F90:85-87 (called from sw_core.F90:919,983,993,1014,1498,

@@ -66,3 +66,69 @@ def check_substeps(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None, tol
     finally:
         ctx.close()
     return out
+
+
+def oracle_fv_step(g, npz, fl, dp0, st, ak, bk, q, bdt, k_split, remap_par):
+    """Oracle-orchestrated k_split loop (fv_dynamics.F90:460-665): dyn_core -> tracer_2d -> Lagrangian_to_Eulerian."""
+    import oracle_lib as O
+    bd = g.bd
+    mdt = bdt / float(k_split)
+    cur = {k: v.copy(order="F") for k, v in st.items()}
+    nq = 0 if q is None else q.shape[3]
+    q = None if q is None else q.copy(order="F")
+    out = None
+    for n_map in range(1, k_split + 1):
+        dp1 = cur["delp"].copy(order="F")
+        OD._fill(bd, dp1, "A")
+        f = OD.run(g, npz, fl, dp0, cur, mdt)
+        if nq:
+            O.tracer_2d(g, npz, nq, q, dp1, f["mfx"], f["mfy"], f["cx"], f["cy"], fl.hord_tr, 0, 0, 0.0)
+        rf = dict(ps=bd.zeros("A"), pe=f["pe"], delp=f["delp"], pkz=bd.zeros("CC", npz), pk=f["pk"], u=f["u"], v=f["v"],
+                  w=f["w"], delz=f["delz"], pt=f["pt"], peln=f["peln"], omga=f["omga"], ws=f["ws"])
+        if nq:
+            rf["q"] = q
+        O.lagrangian_to_eulerian(g, npz, dict(remap_par, last_step=0), rf, ak, bk)
+        cur = dict(u=rf["u"], v=rf["v"], w=rf["w"], delp=rf["delp"], pt=rf["pt"], delz=rf["delz"], phis=st["phis"])
+        out = dict(cur, q=q, pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"])
+    return out
+
+
+def check_fv_step(lib, nx=24, ny=16, npz=10, nq=2, k_split=2, n_split=2, bdt=8.0):
+    """Whole model step (k_split x [substeps, tracer_2d, remap]) library vs oracle."""
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    st, dp0 = make_state(bd, npz)
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+    ak, bk = N.PTOP * (1.0 - sig), sig.copy()
+    dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP)
+    rng = np.random.default_rng(5)
+    q = np.asfortranarray(rng.uniform(0.0, 1.0, bd.shape("A", npz) + (nq,))) if nq else None
+    ctx = Context(g, npz, lib=lib)
+    try:
+        fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=k_split)
+        ref = oracle_fv_step(g, npz, fl, dp_ref, st, ak, bk, q, bdt, k_split, fv.remap_par)
+        fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
+        if nq:
+            fv.set_tracers(q)
+        fv.step(bdt)
+        d = fv.dc.d
+        emu = "hostemu" in lib.path
+        tol = 1e-13 if emu else 1e-10      # GPU: w conditioning floor (see check_substeps) compounds over cycles
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        out = {}
+        for n, kind, rr in (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)),
+                            ("w", "A", r), ("delp", "A", r), ("pt", "A", r), ("ps", "A", r)):
+            t = tol if n == "w" else (tol if emu else 1e-12)
+            out[n] = P.assert_close(n, bd.view(d[n].download(), kind, *rr), bd.view(ref[n], kind, *rr), t)
+        for n in ("delz", "pkz", "pk", "peln"):
+            out[n] = P.assert_close(n, d[n].download(), ref[n], tol if emu else 1e-12)
+        if nq:
+            got = d["q"].download()
+            for iq in range(nq):
+                out[f"q{iq}"] = P.assert_close(f"q{iq}", bd.view(got[:, :, :, iq], "A", *r),
+                                               bd.view(ref["q"][:, :, :, iq], "A", *r), tol if emu else 1e-12)
+    finally:
+        ctx.close()
+    return out

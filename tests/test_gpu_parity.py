@@ -212,3 +212,10 @@ def test_torch_alias_of_device_array_and_exchange_path(prod):
             assert np.array_equal(d1.download(), d2.download()), kind
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,k_split", [(2, 2), (0, 1)])
+def test_fv_dynamics_step(gpulib, nq, k_split):
+    import parity_dyn as D
+    D.check_fv_step(gpulib, nq=nq, k_split=k_split)

@@ -157,3 +157,9 @@ def test_tracer_2d(emu):
     assert nsplt > 1
     T.check_tracer_2d(emu, q_split=2, trdm=0.06, nord_tr=1, hord=10)
     T.check_tracer_2d(emu, nx=33, ny=9, npz=7, nq=7, big_courant=True)
+
+
+@pytest.mark.parametrize("nq,k_split", [(2, 2), (0, 1)])
+def test_fv_dynamics_step(emu, nq, k_split):
+    import parity_dyn as D
+    D.check_fv_step(emu, nq=nq, k_split=k_split)
