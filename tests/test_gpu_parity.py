@@ -214,8 +214,6 @@ def test_torch_alias_of_device_array_and_exchange_path(prod):
         ctx.close()
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize("nq,k_split", [(2, 2), (0, 1)])
-def test_fv_dynamics_step(gpulib, nq, k_split):
-    import parity_dyn as D
-    D.check_fv_step(gpulib, nq=nq, k_split=k_split)
+def test_fv_dynamics_step(prod, nq, k_split):
+    D.check_fv_step(prod, nq=nq, k_split=k_split)
