@@ -90,6 +90,7 @@ template <int TI, int TJ>
 struct DswTransport {
   Grid g;
   DswArgs a;
+  const int *klist;  // level of the bz-th slab, or null = identity
   using TS = Tp2dScratch<TI, TJ>;
   using DS = DelnScratch<TI, TJ>;
   static constexpr int nQ = (TI + 6) * (TJ + 6);
@@ -130,7 +131,7 @@ struct DswTransport {
   }
 
   FV3_HD void operator()(int bx, int by, int bz, int tid, double *lds) const {
-    const int k = bz;
+    const int k = klist ? klist[bz] : bz;
     const TileBox b = make_box<TI, TJ>(g, bx, by);
     const int i0 = b.i0, j0 = b.j0;
     const size_t oA = (size_t)k * g.nA(), oCX = (size_t)k * g.nCX(), oCY = (size_t)k * g.nCY();

@@ -5,9 +5,11 @@
 
 #include <cstdarg>
 #include <new>
+#include <type_traits>
 
 #include "csw_kernel.h"
 #include "dsw_kernels.h"
+#include "dsw_march.h"
 #include "fv3_common.h"
 #include "fv3_launch.h"
 #include "nh_kernels.h"
@@ -51,6 +53,12 @@ struct fv3_ctx {
   double *akbk;       // device, 2*(npz+1)
   int *kord_tr_dev;   // device, up to 64 tracers
   bool akbk_ready;
+  // levels with del-2n damping of delp / w / pt go to the LDS-tile transport kernel, the others march
+  int *klist;            // device, npz: [plain levels..., damped levels...]
+  int n_plain, n_damp;
+  double *mflux[2];      // mass-flux scratch of the marching transports: FX kind, FY kind (npz levels)
+  int march_tj;          // rows per wavefront segment of the marching kernels
+  int use_march;         // 0: LDS-tile kernels only (FV3_MI355X_MARCH=0)
   bool prof_on;
   struct ProfRec { const char *label; void *e0, *e1; };
   std::vector<ProfRec> prof;
@@ -84,6 +92,21 @@ static int launch_p(fv3_ctx *c, const char *label, Dim3 grid, size_t lds_doubles
     rt_event_record(e0, c->stream);
   }
   int rc = launch(grid, lds_doubles, c->stream, f);
+  if (c->prof_on) {
+    rt_event_record(e1, c->stream);
+    c->prof.push_back({label, e0, e1});
+  }
+  return rc;
+}
+
+template <class F>
+static int launch_w(fv3_ctx *c, const char *label, int nwaves, const F &f) {
+  void *e0 = nullptr, *e1 = nullptr;
+  if (c->prof_on) {
+    if (rt_event_create(&e0) || rt_event_create(&e1)) return 1;
+    rt_event_record(e0, c->stream);
+  }
+  int rc = launch_waves(nwaves, c->stream, f);
   if (c->prof_on) {
     rt_event_record(e1, c->stream);
     c->prof.push_back({label, e0, e1});
@@ -147,6 +170,15 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->grid_ready = false;
   c->lev_i = nullptr; c->lev_d = nullptr; c->lev_ready = false;
   c->prof_on = false;
+  c->klist = nullptr; c->n_plain = c->n_damp = 0;
+  c->mflux[0] = c->mflux[1] = nullptr;
+  {  // tuning / fallback knobs
+    const char *e = std::getenv("FV3_MI355X_MARCH");
+    c->use_march = e ? std::atoi(e) : 1;
+    e = std::getenv("FV3_MI355X_MARCH_TJ");
+    c->march_tj = e ? std::atoi(e) : 48;
+    if (c->march_tj < 1) c->march_tj = 48;
+  }
   c->dp0 = nullptr; c->edge_dev = nullptr; c->dp0_ready = false;
   c->akbk = nullptr; c->kord_tr_dev = nullptr; c->akbk_ready = false;
   c->trc_d = nullptr; c->trc_i = nullptr;
@@ -170,6 +202,8 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   if (c->lev_ext_d) rt_free(c->lev_ext_d);
   if (c->lev_ext_i) rt_free(c->lev_ext_i);
   for (auto &s : c->scratch) if (s) rt_free(s);
+  for (auto &s : c->mflux) if (s) rt_free(s);
+  if (c->klist) rt_free(c->klist);
   delete c;
   return 0;
 }
@@ -274,6 +308,17 @@ extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
     RT(rt_sync(c->stream));
   }
   RT(rt_sync(c->stream));
+  {
+    std::vector<int> plain, damped;
+    for (int k = 0; k < npz; k++)
+      ((lv->damp_vt[k] > 1.E-4 || lv->damp_w[k] > 1.E-5 || lv->damp_t[k] > 1.E-4) ? damped : plain).push_back(k);
+    c->n_plain = (int)plain.size();
+    c->n_damp = (int)damped.size();
+    plain.insert(plain.end(), damped.begin(), damped.end());
+    if (!c->klist) RT(rt_malloc((void **)&c->klist, sizeof(int) * npz));
+    RT(rt_h2d(c->klist, plain.data(), sizeof(int) * npz, c->stream));
+    RT(rt_sync(c->stream));
+  }
   c->lev_ready = true;
   return 0;
 }
@@ -397,6 +442,50 @@ extern "C" int fv3_c_sw(fv3_ctx *c, double *delpc, const double *delp, double *p
   return 0;
 }
 
+// compile-time scheme dispatch for the marching kernels
+template <class Fn>
+static int dispatch_hord(int hord, Fn &&fn) {
+  switch (hord) {
+    case 5: return fn(std::integral_constant<int, 5>());
+    case -5: return fn(std::integral_constant<int, -5>());
+    case 6: return fn(std::integral_constant<int, 6>());
+    case 8: return fn(std::integral_constant<int, 8>());
+    case 10: return fn(std::integral_constant<int, 10>());
+  }
+  return fail("unsupported hord %d", hord);
+}
+
+static int ensure_mflux(fv3_ctx *c) {
+  const Grid &g = c->g;
+  if (!c->mflux[0]) RT(rt_malloc((void **)&c->mflux[0], sizeof(double) * g.nFX() * g.npz));
+  if (!c->mflux[1]) RT(rt_malloc((void **)&c->mflux[1], sizeof(double) * g.nFY() * g.npz));
+  return 0;
+}
+
+// d_sw transports on the wave-marching fv_tp_2d (dsw_march.h)
+static int dsw_transport_march(fv3_ctx *c, const DswArgs &a) {
+  const Grid &g = c->g;
+  if (ensure_mflux(c)) return 1;
+  MarchDims md = make_march_dims(g, c->march_tj);
+  md.klist = c->klist;
+  const int nw = md.nwaves(c->n_plain);
+  double *fxs = c->mflux[0], *fys = c->mflux[1];
+  int rc = dispatch_hord(a.hord_dp, [&](auto H) {
+    DswDelpMarch<decltype(H)::value> kf{g, a, md, fxs, fys, 1};
+    return launch_w(c, "d_sw_delp", nw, kf);
+  });
+  if (rc) return rc;
+  auto scalar = [&](const char *label, int hord, const double *q, double *q_out) {
+    return dispatch_hord(hord, [&](auto H) {
+      DswScalarMarch<decltype(H)::value> kf{g, a, md, fxs, fys, q, q_out};
+      return launch_w(c, label, nw, kf);
+    });
+  };
+  if (!a.hydrostatic && (rc = scalar("d_sw_w", a.hord_vt, a.w, a.w_out))) return rc;
+  if (a.use_cond && (rc = scalar("d_sw_qcon", a.hord_dp, a.q_con, a.q_con_out))) return rc;
+  return scalar("d_sw_pt", a.hord_tm, a.pt, a.pt_out);
+}
+
 extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const double *delp, const double *pt,
                         const double *u, const double *v, const double *w, const double *uc, const double *vc,
                         const double *ua, const double *va, const double *divg_d, double *mfx, double *mfy,
@@ -438,11 +527,13 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, cons
     RT(launch_p(c, "d_sw_courant", grid, 0, kf));
   }
   constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
-  {
-    DswTransport<TI, TJ> kf{g, a};
+  const bool march = c->use_march != 0;
+  if (march && c->n_plain > 0) RT(dsw_transport_march(c, a));
+  if (!march || c->n_damp > 0) {
+    DswTransport<TI, TJ> kf{g, a, march ? c->klist + c->n_plain : nullptr};
     Dim3 grid;
     DswTransport<TI, TJ>::grid_dims(g, grid.x, grid.y);
-    grid.z = (unsigned)npz;
+    grid.z = (unsigned)(march ? c->n_damp : npz);
     RT(launch_p(c, "d_sw_transport", grid, DswTransport<TI, TJ>::lds_doubles, kf));
   }
   {

@@ -15,11 +15,13 @@
 
 #ifdef FV3_HOST_EMU
 #define FV3_HD inline
+#define FV3_D inline
 #define FV3_SYNC() ((void)0)
 constexpr int kNT = 1;
 #else
 #include <hip/hip_runtime.h>
 #define FV3_HD __host__ __device__ __forceinline__
+#define FV3_D __device__ __forceinline__
 #define FV3_SYNC() __syncthreads()
 constexpr int kNT = 256;
 #endif
@@ -71,8 +73,9 @@ struct Grid {
 };
 
 // ---- scalar helpers with the reference's semantics ----------------------------------------
-FV3_HD double dmin(double a, double b) { return a < b ? a : b; }
-FV3_HD double dmax(double a, double b) { return a > b ? a : b; }
+// v_min_f64 / v_max_f64: identical to the Fortran min/max intrinsics for non-NaN data
+FV3_HD double dmin(double a, double b) { return __builtin_fmin(a, b); }
+FV3_HD double dmax(double a, double b) { return __builtin_fmax(a, b); }
 FV3_HD double dmin3(double a, double b, double c) { return dmin(dmin(a, b), c); }
 FV3_HD double dmax3(double a, double b, double c) { return dmax(dmax(a, b), c); }
 // Fortran sign(a, b)

@@ -28,6 +28,12 @@ inline int launch(Dim3 grid, size_t lds_doubles, stream_t, const F &f) {
       for (unsigned x = 0; x < grid.x; x++) f((int)x, (int)y, (int)z, 0, lds.data());  // order irrelevant here
   return 0;
 }
+// wave functors: one call per wavefront, the functor's vd values are 64-lane arrays (spmd.h)
+template <class F>
+inline int launch_waves(int nwaves, stream_t, const F &f) {
+  for (int w = 0; w < nwaves; w++) f(w);
+  return 0;
+}
 inline int rt_malloc(void **p, size_t n) {
   *p = std::malloc(n);
   return *p ? 0 : 1;
@@ -87,6 +93,20 @@ inline int launch(Dim3 grid, size_t lds_doubles, stream_t s, const F &f) {
     }
   }
   hipLaunchKernelGGL(tile_kernel<F>, dim3(grid.z, grid.x, grid.y), dim3(kNT), bytes, s, f);
+  return (int)hipGetLastError();
+}
+// wave functors (spmd.h): independent wavefronts, 4 per workgroup, no LDS, no barriers
+template <class F>
+__global__ void __launch_bounds__(kNT) wave_kernel(const F f, int nwaves) {
+  // readfirstlane: tell the compiler the wave index is uniform, so everything derived from it
+  // (level, strip, row offsets) lives in SGPRs and loads use the scalar-base addressing form
+  const int gid = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (kNT / 64) + (int)(threadIdx.x >> 6));
+  if (gid < nwaves) f(gid);
+}
+template <class F>
+inline int launch_waves(int nwaves, stream_t s, const F &f) {
+  const int wpb = kNT / 64;
+  hipLaunchKernelGGL(wave_kernel<F>, dim3((unsigned)((nwaves + wpb - 1) / wpb)), dim3(kNT), 0, s, f, nwaves);
   return (int)hipGetLastError();
 }
 inline int rt_malloc(void **p, size_t n) { return (int)hipMalloc(p, n); }

@@ -1,0 +1,126 @@
+// tp2d_march.h -- fv_tp_2d (model/tp_core.F90:85-241) as a wave-marching stencil.
+//
+// One wavefront owns a strip of 64 consecutive i-columns (lane 0 = column ilo) and a segment of rows
+// [jA, jB]; it loads one row of q per step and keeps everything else in registers:
+//
+//   step r (r = jA-3 .. jB+3), after loading q(:, r):
+//     fx2(r)  = xppm(q(:, r), crx(:, r), ord_in)              -- lanes talk through DPP shifts
+//     q_j(r)  = (q*area + xfx*fx2 - xfx(i+1)*fx2(i+1)) / ra_x                       (:171-178)
+//     push q(r) -> PpmY A,   push q_j(r) -> PpmY B
+//     fy2(r-2) = A.face(cry(r-2))  (ord_in)    fy(r-2) = B.face(cry(r-2))  (ord_ou)  (:147, :180)
+//     q_i(r-3) = (q*area + yfx(r-3)*fy2(r-3) - yfx(r-2)*fy2(r-2)) / ra_y             (:150-159)
+//     fx(r-3)  = xppm(q_i(:, r-3), crx(:, r-3), ord_ou)                              (:161)
+//     sink.row(j = r-3, 0.5*(fx + fx2)(j), 0.5*(fy + fy2)(j), 0.5*(fy + fy2)(j+1))
+//
+// so each of the four PPM sweeps is evaluated once per cell (plus a 6-row warm-up per segment and a
+// 6-lane overlap per strip), nothing is staged through LDS and there are no barriers.
+// Lane validity: q on all lanes it could be loaded for; x-faces on lanes 3..61, cells on lanes 3..60.
+#pragma once
+
+#include "ppm_march.h"
+
+namespace fv3 {
+
+constexpr int kStripCells = kW - 6;  // 58 cells per strip (lanes 3..60)
+
+struct StripGeom {
+  int ilo;         // i index of lane 0  (= first cell of the strip - 3)
+  int lA0, lA1;    // lanes whose column lies inside the halo'd array  [isd, ied]
+  int lF0, lF1;    // lanes whose x-face exists                        [is, ie+1]
+  int lC0, lC1;    // lanes of the cells this strip owns (subset of 3..60, inside [is, ie])
+  vl A, F, C;      // the same three ranges as clamped lane indices for vload
+};
+
+FV3_D StripGeom make_strip(const Grid &g, int strip) {
+  StripGeom s;
+  const int ic0 = g.is + strip * kStripCells;
+  s.ilo = ic0 - 3;
+  auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+  s.lA0 = clampi(g.isd - s.ilo, 0, kW - 1);
+  s.lA1 = clampi(g.ied - s.ilo, 0, kW - 1);
+  s.lF0 = clampi(g.is - s.ilo, 0, kW - 1);
+  s.lF1 = clampi(g.ie + 1 - s.ilo, 0, kW - 1);
+  s.lC0 = 3;
+  s.lC1 = clampi(g.ie - s.ilo, 0, kW - 4);
+  s.A = make_lanes(s.lA0, s.lA1);
+  s.F = make_lanes(s.lF0, s.lF1);
+  s.C = make_lanes(s.lC0, s.lC1);
+  return s;
+}
+inline int num_strips(const Grid &g) { return (g.nx + kStripCells - 1) / kStripCells; }
+
+// ra_x = area + xfx(i) - xfx(i+1) is formed on the fly (sw_core.F90:908-917); so is ra_y.
+//
+// Software pipelining: the loads of step r+1 (and the sink's loads of its next row) are issued before
+// the arithmetic of step r, so a wavefront never waits for the memory it has just asked for.
+struct MarchIn {
+  vd qn, ar, cx, xf;  // row r:   q, area, crx, xfx
+  vd cy, yf;          // face r-2: cry, yfx
+  vd arj, cxj;        // row r-3: area, crx
+};
+
+template <int HORD, class Sink>
+FV3_D void tp2d_march(const Grid &g, const StripGeom &s, int jA, int jB, const double *q, const double *crx,
+                      const double *cry, const double *xfx, const double *yfx, Sink &sink) {
+  constexpr int ORD_IN = (HORD == 10) ? 8 : HORD;  // tp_core.F90:136-141
+  constexpr int ORD_OU = HORD;
+  PpmY<ORD_IN> ya;
+  PpmY<ORD_OU> yb;
+  ya.init();
+  yb.init();
+  vd fx2_0(0.), fx2_1(0.), fx2_2(0.), fx2_3(0.);  // fx2 of rows r, r-1, r-2, r-3
+  vd fy2y_prev(0.), yf_prev(0.), fyv_prev(0.);
+  const int ilo = s.ilo;
+  const int rlast = jB + 3;
+  auto load_in = [&](int r) {
+    MarchIn in;
+    const long oA = (long)g.iA(ilo, r), oCX = (long)g.iCX(ilo, r);
+    in.qn = vload(q, oA, s.A);
+    in.ar = vload(g.area, oA, s.A);
+    in.cx = vload(crx, oCX, s.F);
+    in.xf = vload(xfx, oCX, s.F);
+    // rows before the segment's first face / cell are clamped: loaded but never used
+    const int jf = (r - 2 < jA) ? jA : r - 2, j = (r - 3 < jA) ? jA : r - 3;
+    const long oCY = (long)g.iCY(ilo, jf);
+    in.cy = vload(cry, oCY, s.A);
+    in.yf = vload(yfx, oCY, s.A);
+    in.arj = vload(g.area, (long)g.iA(ilo, j), s.A);
+    in.cxj = vload(crx, (long)g.iCX(ilo, j), s.F);
+    return in;
+  };
+  MarchIn nxt = load_in(jA - 3);
+  typename Sink::In snxt = sink.load(jA);
+  for (int r = jA - 3; r <= rlast; r++) {
+    const MarchIn in = nxt;
+    nxt = load_in(r < rlast ? r + 1 : rlast);
+    // ---- row r: inner x sweep and q_j --------------------------------------------------------------
+    fx2_3 = fx2_2; fx2_2 = fx2_1; fx2_1 = fx2_0;
+    fx2_0 = ppm_faces_x<ORD_IN>(in.qn, in.cx);
+    const vd t = in.xf * fx2_0;
+    const vd qj = (in.qn * in.ar + t - shl1(t)) / (in.ar + in.xf - shl1(in.xf));
+    ya.push(in.qn);
+    yb.push(qj);
+    // ---- face r-2: inner and outer y sweeps ------------------------------------------------------------
+    const int jf = r - 2;
+    if (jf < jA) continue;
+    const vd fy2 = ya.face(in.cy);
+    const vd fyo = yb.face(in.cy);
+    const vd fy2y = in.yf * fy2;
+    const vd fyv = 0.5 * (fyo + fy2);
+    // ---- row j = r-3: q_i, outer x sweep, hand the face values to the sink ---------------------------
+    const int j = r - 3;
+    if (j >= jA) {
+      const typename Sink::In sin = snxt;
+      snxt = sink.load(j < jB ? j + 1 : jB);
+      const vd qi = (ya.row_m3() * in.arj + fy2y_prev - fy2y) / (in.arj + yf_prev - in.yf);
+      const vd fxo = ppm_faces_x<ORD_OU>(qi, in.cxj);
+      const vd fxv = 0.5 * (fxo + fx2_3);
+      sink.row(j, sin, fxv, fyv_prev, fyv);
+    }
+    fy2y_prev = fy2y;
+    yf_prev = in.yf;
+    fyv_prev = fyv;
+  }
+}
+
+}  // namespace fv3
