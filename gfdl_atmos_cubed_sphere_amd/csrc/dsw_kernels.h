@@ -295,6 +295,7 @@ template <int TI, int TJ>
 struct DswMomentum {
   Grid g;
   DswArgs a;
+  const int *klist;  // level of the bz-th slab, or null = identity
   using TS = Tp2dScratch<TI, TJ>;
   using DS = DelnScratch<TI, TJ>;
   static constexpr int nSU = (TI + 6) * (TJ + 7), nSV = (TI + 7) * (TJ + 6), nQ = (TI + 6) * (TJ + 6);
@@ -311,7 +312,7 @@ struct DswMomentum {
 
   FV3_HD void operator()(int bx, int by, int bz, int tid, double *lds) const {
     constexpr double a1 = 0.5625, a2 = -0.0625, b1 = 7. / 12., b2 = -1. / 12.;  // a2b_edge.F90:34-40
-    const int k = bz;
+    const int k = klist ? klist[bz] : bz;
     const TileBox b = make_box<TI, TJ>(g, bx, by);
     const int i0 = b.i0, j0 = b.j0, il = b.ilast, jl = b.jlast;
     const int is = g.is, ie = g.ie, js = g.js, je = g.je;

@@ -158,3 +158,160 @@ struct DswScalarMarch {
 };
 
 }  // namespace fv3
+
+// =====================================================================================================
+// d_sw momentum on the marching stencils, for the levels with nord_k == 1, no vorticity damping, no
+// Smagorinsky coefficient (dddmp < 1e-5) and no dissipative heating -- the reference defaults below the
+// sponge.  Other levels run in the LDS-tile kernel DswMomentum.
+//
+//   DswKeMarch<SWC>   : kinetic-energy flux at the corners via ytp_v / xtp_u (sw_core.F90:1078-1198) plus the
+//                       del-4 divergence damping term (:1372-1460, nord = 1) -> ke scratch (B kind), delpc.
+//   DswVortMarch<HORD>: absolute vorticity (:1231-1247, :1476-1495) computed row by row from u, v, its
+//                       fv_tp_2d (:1498) and the D-grid wind update (:1500-1509).
+namespace fv3 {
+
+template <int SWC>
+struct DswKeMarch {
+  Grid g;
+  DswArgs a;
+  MarchDims md;   // nsegs counts segments of corner rows js..je+1
+  double *ke;     // B kind scratch, npz levels
+
+  FV3_D void operator()(int gid) const {
+    const int strip = gid % md.nstrips, seg = (gid / md.nstrips) % md.nsegs, kk = gid / (md.nstrips * md.nsegs);
+    const int k = md.klist ? md.klist[kk] : kk;
+    const StripGeom s = make_strip(g, strip);
+    const int ilo = s.ilo;
+    const int jA = g.js + seg * md.tj;
+    int jB = (jA + md.tj - 1 < g.je) ? jA + md.tj - 1 : g.je;
+    if (jB == g.je) jB = g.je + 1;  // the last segment also owns corner row je+1
+    const int lFx1 = (ilo + s.lC1 == g.ie) ? s.lC1 + 1 : s.lC1;
+    const double *u = a.u + (size_t)k * g.nU(), *v = a.v + (size_t)k * g.nV();
+    const double *uc = a.uc + (size_t)k * g.nV(), *vc = a.vc + (size_t)k * g.nU();
+    const double *dv = a.divg_d + (size_t)k * g.nB();
+    double *kek = ke + (size_t)k * g.nB();
+    double *dpc = a.delpc ? a.delpc + (size_t)k * g.nA() : nullptr;
+    const double dt5 = 0.5 * a.dt;
+    const double d2_bg = a.lv.d2_divg[k];
+    const double damp2 = g.da_min_c * dmax(d2_bg, dmin(0.20, a.dddmp * 0.));            // :1454 with vort = 0
+    const double dd8 = g.stretched_grid ? g.da_min * ipow(a.d4_bg, 2) : ipow(g.da_min_c * a.d4_bg, 2);  // :1446-1450
+    PpmYsw<SWC> yv;
+    yv.init();
+    for (int r = jA - 3; r <= jB + 2; r++) {
+      yv.push(vload(v, (long)g.iV(ilo, r), s.A));
+      const int jc = r - 2;
+      if (jc < jA) continue;
+      // ---- ytp_v: v advected by vb along y (:1129-1139) ---------------------------------------------------
+      const long oU = (long)g.iU(ilo, jc), oV = (long)g.iV(ilo, jc), oVm = (long)g.iV(ilo, jc - 1);
+      const vd vcr = vload(vc, oU, s.A);
+      const vd vb = dt5 * (shr1(vcr) + vcr);
+      const vd ub = yv.face(vb, vload(g.rdy, oVm, s.A), vload(g.rdy, oV, s.A));
+      const vd kev = vb * ub;
+      // ---- xtp_u: u advected by ub along x (:1186-1196) ------------------------------------------------------
+      const vd ub2 = dt5 * (vload(uc, oVm, s.A) + vload(uc, oV, s.A));
+      const vd vb2 = ppm_faces_x_sw<SWC>(vload(u, oU, s.A), ub2, vload(g.rdx, oU, s.A));
+      vd kex = 0.5 * (kev + ub2 * vb2);
+      // ---- divergence damping, nord = 1 (:1372-1460) -------------------------------------------------------------
+      const long oB = (long)g.iB(ilo, jc);
+      const vd d0 = vload(dv, oB, s.A), dm = vload(dv, (long)g.iB(ilo, jc - 1), s.A),
+               dp = vload(dv, (long)g.iB(ilo, jc + 1), s.A);
+      const vd vc2 = (shl1(d0) - d0) * vload(g.divg_u, oU, s.A);      // :1392-1396
+      const vd uc2m = (d0 - dm) * vload(g.divg_v, oVm, s.A);          // :1399-1403
+      const vd uc2 = (dp - d0) * vload(g.divg_v, oV, s.A);
+      vd lap = uc2m - uc2 + shr1(vc2) - vc2;                          // :1406-1424
+      if (!g.stretched_grid) lap = lap * vload(g.rarea_c, oB, s.A);
+      const vd vdmp = damp2 * d0 + dd8 * lap;                         // :1455
+      kex = kex + vdmp;
+      vstore(kek, oB, kex, s.lC0, lFx1);
+      if (dpc) vstore(dpc, (long)g.iA(ilo, jc), d0, s.lC0, lFx1);     // delpc = saved divergence (:1376-1381)
+    }
+  }
+};
+
+template <int HORD>
+struct DswVortMarch {
+  Grid g;
+  DswArgs a;
+  MarchDims md;
+  const double *ke;  // B kind scratch written by DswKeMarch
+
+  struct Src {
+    const DswVortMarch &K;
+    const StripGeom &s;
+    int k;
+    struct In {
+      vd u0, u1, v0, v1, dx0, dx1, dy0, dy1, ra, f0;
+    };
+    FV3_D In load(int r) const {
+      const Grid &g = K.g;
+      const double *u = K.a.u + (size_t)k * g.nU(), *v = K.a.v + (size_t)k * g.nV();
+      const long oU = (long)g.iU(s.ilo, r), oU1 = (long)g.iU(s.ilo, r + 1), oV = (long)g.iV(s.ilo, r);
+      const long oA = (long)g.iA(s.ilo, r);
+      In in;
+      in.u0 = vload(u, oU, s.A);   in.dx0 = vload(g.dx, oU, s.A);
+      in.u1 = vload(u, oU1, s.A);  in.dx1 = vload(g.dx, oU1, s.A);
+      in.v0 = vload(v, oV, s.A);   in.dy0 = vload(g.dy, oV, s.A);
+      in.v1 = vload(v, oV + 1, s.A);  in.dy1 = vload(g.dy, oV + 1, s.A);  // V kind has the extra column ied+1
+      in.ra = vload(g.rarea, oA, s.A);
+      in.f0 = vload(g.f0, oA, s.A);
+      return in;
+    }
+    FV3_D vd value(const In &in) const {  // :1231-1247, :1476-1495
+      const vd vt0 = in.u0 * in.dx0, vt1 = in.u1 * in.dx1, ut0 = in.v0 * in.dy0, ut1 = in.v1 * in.dy1;
+      return in.ra * (vt0 - vt1 - ut0 + ut1) + in.f0;
+    }
+  };
+
+  struct Sink {
+    const DswVortMarch &K;
+    const StripGeom &s;
+    int k, lFx1;
+    struct In {
+      vd u, dx, v, dy, ke0, ke1, xf, yf;
+    };
+    FV3_D In load(int j) const {
+      const Grid &g = K.g;
+      const long oU = (long)g.iU(s.ilo, j), oV = (long)g.iV(s.ilo, j);
+      In in;
+      in.u = vload(K.a.u + (size_t)k * g.nU(), oU, s.A);
+      in.dx = vload(g.dx, oU, s.A);
+      in.v = vload(K.a.v + (size_t)k * g.nV(), oV, s.A);
+      in.dy = vload(g.dy, oV, s.A);
+      in.ke0 = vload(K.ke + (size_t)k * g.nB(), (long)g.iB(s.ilo, j), s.A);
+      in.ke1 = vload(K.ke + (size_t)k * g.nB(), (long)g.iB(s.ilo, j + 1), s.A);
+      in.xf = vload(K.a.xfx + (size_t)k * g.nCX(), (long)g.iCX(s.ilo, j), s.F);
+      in.yf = vload(K.a.yfx + (size_t)k * g.nCY(), (long)g.iCY(s.ilo, j), s.A);
+      return in;
+    }
+    FV3_D void row(int j, const In &in, const vd &fxv, const vd &fyv0, const vd &fyv1) const {
+      const Grid &g = K.g;
+      double *uo = K.a.u_out + (size_t)k * g.nU(), *vo = K.a.v_out + (size_t)k * g.nV();
+      // u = vt + ke(i,j) - ke(i+1,j) + fy (:1500-1504);  v = ut + ke(i,j) - ke(i,j+1) - fx (:1505-1509)
+      const vd un = in.u * in.dx + in.ke0 - shl1(in.ke0) + fyv0 * in.yf;
+      const vd vn = in.v * in.dy + in.ke0 - in.ke1 - fxv * in.xf;
+      vstore(uo, (long)g.iU(s.ilo, j), un, s.lC0, s.lC1);
+      vstore(vo, (long)g.iV(s.ilo, j), vn, s.lC0, lFx1);
+      if (j == g.je) {  // the north edge row of u
+        const long oU1 = (long)g.iU(s.ilo, j + 1);
+        const vd u1 = vload(K.a.u + (size_t)k * g.nU(), oU1, s.A), dx1 = vload(g.dx, oU1, s.A);
+        const vd yf1 = vload(K.a.yfx + (size_t)k * g.nCY(), (long)g.iCY(s.ilo, j + 1), s.A);
+        vstore(uo, oU1, u1 * dx1 + in.ke1 - shl1(in.ke1) + fyv1 * yf1, s.lC0, s.lC1);
+      }
+    }
+  };
+
+  FV3_D void operator()(int gid) const {
+    const int strip = gid % md.nstrips, seg = (gid / md.nstrips) % md.nsegs, kk = gid / (md.nstrips * md.nsegs);
+    const int k = md.klist ? md.klist[kk] : kk;
+    const StripGeom s = make_strip(g, strip);
+    const int jA = g.js + seg * md.tj;
+    const int jB = (jA + md.tj - 1 < g.je) ? jA + md.tj - 1 : g.je;
+    const int lFx1 = (s.ilo + s.lC1 == g.ie) ? s.lC1 + 1 : s.lC1;
+    const Src src{*this, s, k};
+    Sink sink{*this, s, k, lFx1};
+    tp2d_march_src<HORD>(g, s, jA, jB, src, a.crx + (size_t)k * g.nCX(), a.cry + (size_t)k * g.nCY(),
+                         a.xfx + (size_t)k * g.nCX(), a.yfx + (size_t)k * g.nCY(), sink);
+  }
+};
+
+}  // namespace fv3

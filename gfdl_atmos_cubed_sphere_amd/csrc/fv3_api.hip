@@ -56,6 +56,10 @@ struct fv3_ctx {
   // levels with del-2n damping of delp / w / pt go to the LDS-tile transport kernel, the others march
   int *klist;            // device, npz: [plain levels..., damped levels...]
   int n_plain, n_damp;
+  // same split for the momentum part: marching needs nord_k == 1, no vorticity damping, d_con = 0
+  int *klist_m;
+  int n_plain_m, n_rest_m;
+  double *ke_scr;        // B kind, npz levels: KE + damping term at the corners
   double *mflux[2];      // mass-flux scratch of the marching transports: FX kind, FY kind (npz levels)
   int march_tj;          // rows per wavefront segment of the marching kernels
   int use_march;         // 0: LDS-tile kernels only (FV3_MI355X_MARCH=0)
@@ -171,6 +175,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->lev_i = nullptr; c->lev_d = nullptr; c->lev_ready = false;
   c->prof_on = false;
   c->klist = nullptr; c->n_plain = c->n_damp = 0;
+  c->klist_m = nullptr; c->n_plain_m = c->n_rest_m = 0; c->ke_scr = nullptr;
   c->mflux[0] = c->mflux[1] = nullptr;
   {  // tuning / fallback knobs
     const char *e = std::getenv("FV3_MI355X_MARCH");
@@ -204,6 +209,8 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   for (auto &s : c->scratch) if (s) rt_free(s);
   for (auto &s : c->mflux) if (s) rt_free(s);
   if (c->klist) rt_free(c->klist);
+  if (c->klist_m) rt_free(c->klist_m);
+  if (c->ke_scr) rt_free(c->ke_scr);
   delete c;
   return 0;
 }
@@ -317,6 +324,14 @@ extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
     plain.insert(plain.end(), damped.begin(), damped.end());
     if (!c->klist) RT(rt_malloc((void **)&c->klist, sizeof(int) * npz));
     RT(rt_h2d(c->klist, plain.data(), sizeof(int) * npz, c->stream));
+    std::vector<int> pm, rm;
+    for (int k = 0; k < npz; k++)
+      ((lv->nord_k[k] == 1 && !(lv->damp_vt[k] > 1.E-5) && !(lv->d_con_k[k] > 1.E-5)) ? pm : rm).push_back(k);
+    c->n_plain_m = (int)pm.size();
+    c->n_rest_m = (int)rm.size();
+    pm.insert(pm.end(), rm.begin(), rm.end());
+    if (!c->klist_m) RT(rt_malloc((void **)&c->klist_m, sizeof(int) * npz));
+    RT(rt_h2d(c->klist_m, pm.data(), sizeof(int) * npz, c->stream));
     RT(rt_sync(c->stream));
   }
   c->lev_ready = true;
@@ -486,6 +501,27 @@ static int dsw_transport_march(fv3_ctx *c, const DswArgs &a) {
   return scalar("d_sw_pt", a.hord_tm, a.pt, a.pt_out);
 }
 
+// d_sw momentum on the marching stencils (dsw_march.h) for the levels in klist_m[0 : n_plain_m]
+static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a) {
+  const Grid &g = c->g;
+  if (!c->ke_scr) RT(rt_malloc((void **)&c->ke_scr, sizeof(double) * g.nB() * g.npz));
+  MarchDims md = make_march_dims(g, c->march_tj);
+  md.klist = c->klist_m;
+  const int nw = md.nwaves(c->n_plain_m);
+  int rc;
+  switch (sw_class(a.hord_mt)) {
+    case 5: rc = launch_w(c, "d_sw_ke", nw, DswKeMarch<5>{g, a, md, c->ke_scr}); break;
+    case 6: rc = launch_w(c, "d_sw_ke", nw, DswKeMarch<6>{g, a, md, c->ke_scr}); break;
+    default: rc = launch_w(c, "d_sw_ke", nw, DswKeMarch<8>{g, a, md, c->ke_scr}); break;
+  }
+  if (rc) return rc;
+  const double *ke = c->ke_scr;
+  return dispatch_hord(a.hord_vt, [&](auto H) {
+    DswVortMarch<decltype(H)::value> kf{g, a, md, ke};
+    return launch_w(c, "d_sw_vort", nw, kf);
+  });
+}
+
 extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const double *delp, const double *pt,
                         const double *u, const double *v, const double *w, const double *uc, const double *vc,
                         const double *ua, const double *va, const double *divg_d, double *mfx, double *mfy,
@@ -536,11 +572,14 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, cons
     grid.z = (unsigned)(march ? c->n_damp : npz);
     RT(launch_p(c, "d_sw_transport", grid, DswTransport<TI, TJ>::lds_doubles, kf));
   }
-  {
-    DswMomentum<TI, TJ> kf{g, a};
+  // marching momentum: no Smagorinsky coefficient, no dissipation estimate (level conditions in klist_m)
+  const bool march_m = march && a.dddmp < 1.E-5 && !g.do_diss_est;
+  if (march_m && c->n_plain_m > 0) RT(dsw_momentum_march(c, a));
+  if (!march_m || c->n_rest_m > 0) {
+    DswMomentum<TI, TJ> kf{g, a, march_m ? c->klist_m + c->n_plain_m : nullptr};
     Dim3 grid;
     DswMomentum<TI, TJ>::grid_dims(g, grid.x, grid.y);
-    grid.z = (unsigned)npz;
+    grid.z = (unsigned)(march_m ? c->n_rest_m : npz);
     RT(launch_p(c, "d_sw_momentum", grid, DswMomentum<TI, TJ>::lds_doubles, kf));
   }
   return 0;

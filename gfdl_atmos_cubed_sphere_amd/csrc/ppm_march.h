@@ -228,4 +228,67 @@ struct PpmY {
   FV3_D const vd &row_m3() const { return q1; }  // q(r-3)
 };
 
+// =====================================================================================================
+// sw_core flavour (xtp_u / ytp_v).  SWC = scheme class: 5 (iord 5), 6 (iord 6, 7), 8 (iord >= 8).
+constexpr int sw_class(int iord) { return iord >= 8 ? 8 : (iord == 5 ? 5 : 6); }
+
+template <int SWC>
+FV3_D PCell ppm_cells_x_sw(const vd &q) {
+  const vd qm1 = shr1(q), qp1 = shl1(q);
+  const vd qm2 = shr1(qm1), qp2 = shl1(qp1);
+  if (SWC >= 8) {
+    const vd dm0 = ppm_dm_v(qm1, q, qp1);
+    const vd al0 = ppm_al_mono(qm1, q, shr1(dm0), dm0);
+    return ppm_cell_sw_mono(qm2, qm1, q, qp1, qp2, al0, shl1(al0));
+  } else {
+    const vd al0 = ppm_al_unlim<5>(qm2, qm1, q, qp1);
+    return ppm_cell_sw_unlim<SWC>(q, al0, shl1(al0));
+  }
+}
+// face l between lanes l-1 and l; c = advective displacement at the face, rd = 1/dx of the cells
+template <int SWC>
+FV3_D vd ppm_faces_x_sw(const vd &q, const vd &c, const vd &rd) {
+  const PCell p = ppm_cells_x_sw<SWC>(q);
+  const PCell m = shift_cell_r(p, SWC < 8);
+  return ppm_face_sw_v<(SWC >= 8 ? 8 : 5)>(m, p, c, shr1(rd), rd);
+}
+
+template <int SWC>
+struct PpmYsw {
+  vd q0, q1, q2, q3, q4;
+  vd dm2, dm3;
+  vd al2, al3;
+  PCell prev, cur;
+  FV3_D void init() {
+    q0 = q1 = q2 = q3 = q4 = vd(0.);
+    dm2 = dm3 = vd(0.);
+    al2 = al3 = vd(0.);
+    prev.q = prev.bl = prev.br = vd(0.);
+    cur = prev;
+#ifdef FV3_HOST_EMU
+    for (int l = 0; l < kW; l++) prev.smt.v[l] = cur.smt.v[l] = false;
+#else
+    prev.smt = cur.smt = false;
+#endif
+  }
+  FV3_D void push(const vd &qn) {
+    q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = qn;
+    prev = cur;
+    al2 = al3;
+    if (SWC >= 8) {
+      dm2 = dm3;
+      dm3 = ppm_dm_v(q2, q3, q4);
+      al3 = ppm_al_mono(q2, q3, dm2, dm3);
+      cur = ppm_cell_sw_mono(q0, q1, q2, q3, q4, al2, al3);
+    } else {
+      al3 = ppm_al_unlim<5>(q1, q2, q3, q4);
+      cur = ppm_cell_sw_unlim<SWC>(q2, al2, al3);
+    }
+  }
+  // face r-2 (between rows r-3 and r-2); rdm / rdp = 1/dy of those two rows
+  FV3_D vd face(const vd &c, const vd &rdm, const vd &rdp) const {
+    return ppm_face_sw_v<(SWC >= 8 ? 8 : 5)>(prev, cur, c, rdm, rdp);
+  }
+};
+
 }  // namespace fv3

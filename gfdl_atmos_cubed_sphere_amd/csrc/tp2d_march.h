@@ -50,49 +50,31 @@ FV3_D StripGeom make_strip(const Grid &g, int strip) {
 inline int num_strips(const Grid &g) { return (g.nx + kStripCells - 1) / kStripCells; }
 
 // ra_x = area + xfx(i) - xfx(i+1) is formed on the fly (sw_core.F90:908-917); so is ra_y.
-//
-// Software pipelining: the loads of step r+1 (and the sink's loads of its next row) are issued before
-// the arithmetic of step r, so a wavefront never waits for the memory it has just asked for.
 struct MarchIn {
   vd qn, ar, cx, xf;  // row r:   q, area, crx, xfx
   vd cy, yf;          // face r-2: cry, yfx
   vd arj, cxj;        // row r-3: area, crx
 };
 
-template <int HORD, class Sink>
-FV3_D void tp2d_march(const Grid &g, const StripGeom &s, int jA, int jB, const double *q, const double *crx,
-                      const double *cry, const double *xfx, const double *yfx, Sink &sink) {
-  constexpr int ORD_IN = (HORD == 10) ? 8 : HORD;  // tp_core.F90:136-141
-  constexpr int ORD_OU = HORD;
+// The register state of one fv_tp_2d march.  step(r) consumes row r; have_face says that face r-2 is
+// wanted (r-2 >= jA), have_row that row r-3 is (r-3 >= jA); in the latter case fxv / fyv0 / fyv1 return
+// 0.5*(fx + fx2)(j), 0.5*(fy + fy2)(j) and 0.5*(fy + fy2)(j+1) for j = r-3.
+template <int HORD>
+struct Tp2dState {
+  static constexpr int ORD_IN = (HORD == 10) ? 8 : HORD;  // tp_core.F90:136-141
+  static constexpr int ORD_OU = HORD;
   PpmY<ORD_IN> ya;
   PpmY<ORD_OU> yb;
-  ya.init();
-  yb.init();
-  vd fx2_0(0.), fx2_1(0.), fx2_2(0.), fx2_3(0.);  // fx2 of rows r, r-1, r-2, r-3
-  vd fy2y_prev(0.), yf_prev(0.), fyv_prev(0.);
-  const int ilo = s.ilo;
-  const int rlast = jB + 3;
-  auto load_in = [&](int r) {
-    MarchIn in;
-    const long oA = (long)g.iA(ilo, r), oCX = (long)g.iCX(ilo, r);
-    in.qn = vload(q, oA, s.A);
-    in.ar = vload(g.area, oA, s.A);
-    in.cx = vload(crx, oCX, s.F);
-    in.xf = vload(xfx, oCX, s.F);
-    // rows before the segment's first face / cell are clamped: loaded but never used
-    const int jf = (r - 2 < jA) ? jA : r - 2, j = (r - 3 < jA) ? jA : r - 3;
-    const long oCY = (long)g.iCY(ilo, jf);
-    in.cy = vload(cry, oCY, s.A);
-    in.yf = vload(yfx, oCY, s.A);
-    in.arj = vload(g.area, (long)g.iA(ilo, j), s.A);
-    in.cxj = vload(crx, (long)g.iCX(ilo, j), s.F);
-    return in;
-  };
-  MarchIn nxt = load_in(jA - 3);
-  typename Sink::In snxt = sink.load(jA);
-  for (int r = jA - 3; r <= rlast; r++) {
-    const MarchIn in = nxt;
-    nxt = load_in(r < rlast ? r + 1 : rlast);
+  vd fx2_0, fx2_1, fx2_2, fx2_3;  // fx2 of rows r, r-1, r-2, r-3
+  vd fy2y_prev, yf_prev, fyv_prev;
+
+  FV3_D void init() {
+    ya.init();
+    yb.init();
+    fx2_0 = fx2_1 = fx2_2 = fx2_3 = vd(0.);
+    fy2y_prev = yf_prev = fyv_prev = vd(0.);
+  }
+  FV3_D void step(const MarchIn &in, bool have_face, bool have_row, vd &fxv, vd &fyv0, vd &fyv1) {
     // ---- row r: inner x sweep and q_j --------------------------------------------------------------
     fx2_3 = fx2_2; fx2_2 = fx2_1; fx2_1 = fx2_0;
     fx2_0 = ppm_faces_x<ORD_IN>(in.qn, in.cx);
@@ -100,27 +82,88 @@ FV3_D void tp2d_march(const Grid &g, const StripGeom &s, int jA, int jB, const d
     const vd qj = (in.qn * in.ar + t - shl1(t)) / (in.ar + in.xf - shl1(in.xf));
     ya.push(in.qn);
     yb.push(qj);
+    if (!have_face) return;
     // ---- face r-2: inner and outer y sweeps ------------------------------------------------------------
-    const int jf = r - 2;
-    if (jf < jA) continue;
     const vd fy2 = ya.face(in.cy);
     const vd fyo = yb.face(in.cy);
     const vd fy2y = in.yf * fy2;
     const vd fyv = 0.5 * (fyo + fy2);
-    // ---- row j = r-3: q_i, outer x sweep, hand the face values to the sink ---------------------------
-    const int j = r - 3;
-    if (j >= jA) {
-      const typename Sink::In sin = snxt;
-      snxt = sink.load(j < jB ? j + 1 : jB);
+    // ---- row j = r-3: q_i and the outer x sweep ---------------------------------------------------------
+    if (have_row) {
       const vd qi = (ya.row_m3() * in.arj + fy2y_prev - fy2y) / (in.arj + yf_prev - in.yf);
       const vd fxo = ppm_faces_x<ORD_OU>(qi, in.cxj);
-      const vd fxv = 0.5 * (fxo + fx2_3);
-      sink.row(j, sin, fxv, fyv_prev, fyv);
+      fxv = 0.5 * (fxo + fx2_3);
+      fyv0 = fyv_prev;
+      fyv1 = fyv;
     }
     fy2y_prev = fy2y;
     yf_prev = in.yf;
     fyv_prev = fyv;
   }
+};
+
+// loads of one step except the transported field itself (crx/xfx: CX kind, cry/yfx: CY kind slabs)
+FV3_D void march_load_metrics(MarchIn &in, const Grid &g, const StripGeom &s, int jA, int r, const double *crx,
+                              const double *cry, const double *xfx, const double *yfx) {
+  const int ilo = s.ilo;
+  const long oCX = (long)g.iCX(ilo, r);
+  in.ar = vload(g.area, (long)g.iA(ilo, r), s.A);
+  in.cx = vload(crx, oCX, s.F);
+  in.xf = vload(xfx, oCX, s.F);
+  // rows before the segment's first face / cell are clamped: loaded but never used
+  const int jf = (r - 2 < jA) ? jA : r - 2, j = (r - 3 < jA) ? jA : r - 3;
+  const long oCY = (long)g.iCY(ilo, jf);
+  in.cy = vload(cry, oCY, s.A);
+  in.yf = vload(yfx, oCY, s.A);
+  in.arj = vload(g.area, (long)g.iA(ilo, j), s.A);
+  in.cxj = vload(crx, (long)g.iCX(ilo, j), s.F);
+}
+
+// Row source of a stored field q (A kind slab).
+struct FieldSrc {
+  const Grid &g;
+  const StripGeom &s;
+  const double *q;
+  using In = vd;
+  FV3_D In load(int r) const { return vload(q, (long)g.iA(s.ilo, r), s.A); }
+  FV3_D vd value(const In &in) const { return in; }
+};
+
+// fv_tp_2d of the field produced row by row by `src`.  Software pipelining: the loads of step r+1 (and
+// the sink's loads of its next row) are issued before the arithmetic of step r.
+template <int HORD, class Src, class Sink>
+FV3_D void tp2d_march_src(const Grid &g, const StripGeom &s, int jA, int jB, const Src &src, const double *crx,
+                          const double *cry, const double *xfx, const double *yfx, Sink &sink) {
+  Tp2dState<HORD> st;
+  st.init();
+  const int rlast = jB + 3;
+  MarchIn nxt;
+  march_load_metrics(nxt, g, s, jA, jA - 3, crx, cry, xfx, yfx);
+  typename Src::In qnxt = src.load(jA - 3);
+  typename Sink::In snxt = sink.load(jA);
+  for (int r = jA - 3; r <= rlast; r++) {
+    MarchIn in = nxt;
+    const typename Src::In qin = qnxt;
+    const int rn = r < rlast ? r + 1 : rlast;
+    march_load_metrics(nxt, g, s, jA, rn, crx, cry, xfx, yfx);
+    qnxt = src.load(rn);
+    in.qn = src.value(qin);
+    const int j = r - 3;
+    vd fxv, fyv0, fyv1;
+    st.step(in, r - 2 >= jA, j >= jA, fxv, fyv0, fyv1);
+    if (j >= jA) {
+      const typename Sink::In sin = snxt;
+      snxt = sink.load(j < jB ? j + 1 : jB);
+      sink.row(j, sin, fxv, fyv0, fyv1);
+    }
+  }
+}
+
+template <int HORD, class Sink>
+FV3_D void tp2d_march(const Grid &g, const StripGeom &s, int jA, int jB, const double *q, const double *crx,
+                      const double *cry, const double *xfx, const double *yfx, Sink &sink) {
+  const FieldSrc src{g, s, q};
+  tp2d_march_src<HORD>(g, s, jA, jB, src, crx, cry, xfx, yfx, sink);
 }
 
 }  // namespace fv3

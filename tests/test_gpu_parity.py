@@ -217,3 +217,9 @@ def test_torch_alias_of_device_array_and_exchange_path(prod):
 @pytest.mark.parametrize("nq,k_split", [(2, 2), (0, 1)])
 def test_fv_dynamics_step(prod, nq, k_split):
     D.check_fv_step(prod, nq=nq, k_split=k_split)
+
+
+@pytest.mark.parametrize("hord,hord_mt", [(10, 10), (8, 6), (5, 5), (6, 8)])
+def test_d_sw_multi_strip_march(prod, hord, hord_mt):
+    """several 58-column strips and several row segments of the wave-marching kernels"""
+    P.check_d_sw(prod, nx=130, ny=100, npz=3, par_over=dict(hord_dp=hord, hord_tm=hord, hord_vt=hord, hord_mt=hord_mt))

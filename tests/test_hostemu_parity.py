@@ -163,3 +163,9 @@ def test_tracer_2d(emu):
 def test_fv_dynamics_step(emu, nq, k_split):
     import parity_dyn as D
     D.check_fv_step(emu, nq=nq, k_split=k_split)
+
+
+@pytest.mark.parametrize("hord,hord_mt", [(10, 10), (8, 6), (5, 5), (6, 8)])
+def test_d_sw_multi_strip_march(emu, hord, hord_mt):
+    """several 58-column strips and several row segments of the wave-marching kernels"""
+    P.check_d_sw(emu, nx=130, ny=100, npz=3, par_over=dict(hord_dp=hord, hord_tm=hord, hord_vt=hord, hord_mt=hord_mt))
