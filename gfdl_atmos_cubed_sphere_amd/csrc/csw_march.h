@@ -1,0 +1,171 @@
+// csw_march.h -- c_sw (model/sw_core.F90:79-488) as a wave-marching stencil (grid_type >= 3 branches).
+//
+// One wavefront owns 59 output columns (lanes 3..61 of a 64-column strip) of the box
+// [is-1, ie+2] x [js-1, je+2] and marches along j.  Step t loads u(:, t), v(:, t-1), delp/pt/w(:, t-2) and
+// finishes row R = t-2 of the interpolated winds and row Q = t-3 of every output:
+//
+//   utmp(R), vtmp(t-1)         D -> A interpolation               d2a2c_vect :3099-3108
+//   ua, va (R)                 contravariant A-grid winds          :3152-3157
+//   uc(R) (x shifts), vc(R)    A -> C interpolation                :3197-3202, :3337-3342
+//   ut(R), vt(R)               time-scaled area fluxes             :159-176
+//   vort(R)                    absolute vorticity at the corners   :372-403
+//   ke(Q)                      upstream kinetic energy             :297-366
+//   delpc, ptc, wc (Q)         first-order upwind transport        :182-286
+//   uc, vc (Q)                 C-grid wind half-step update        :414-486
+//   divg_d(Q)                  divergence_corner                   :1781-1796
+//
+// x-neighbours come from DPP wavefront shifts, y-neighbours from small register windows; no LDS.
+#pragma once
+
+#include "csw_kernel.h"
+#include "tp2d_march.h"
+
+namespace fv3 {
+
+constexpr int kCswCols = 59;  // owned columns per strip: lanes 3..61
+
+inline MarchDims make_csw_dims(const Grid &g, int tj) {
+  MarchDims d;
+  d.tj = tj;
+  d.klist = nullptr;
+  d.nstrips = (g.nx + 4 + kCswCols - 1) / kCswCols;
+  d.nsegs = (g.ny + 4 + tj - 1) / tj;
+  return d;
+}
+
+struct CswMarch {
+  Grid g;
+  CswArgs a;
+  MarchDims md;
+
+  FV3_D void operator()(int gid) const {
+    constexpr double a1 = 0.5625, a2 = -0.0625;  // sw_core.F90:53-54
+    const int strip = gid % md.nstrips, seg = (gid / md.nstrips) % md.nsegs, k = gid / (md.nstrips * md.nsegs);
+    const int is = g.is, ie = g.ie, js = g.js, je = g.je;
+    const int ilo = is - 1 + strip * kCswCols - 3;  // column of lane 0
+    auto cl = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    const vl cA = make_lanes(cl(g.isd - ilo, 0, kW - 1), cl(g.ied - ilo, 0, kW - 1));      // nid-wide rows
+    const vl cV = make_lanes(cl(g.isd - ilo, 0, kW - 1), cl(g.ied + 1 - ilo, 0, kW - 1));  // (nid+1)-wide rows
+    const int l0 = 3;
+    const int l2 = cl(ie + 2 - ilo, 0, kW - 3), l1 = cl(ie + 1 - ilo, 0, kW - 3);  // last owned lane: i <= ie+2 / ie+1
+    const int jA = js - 1 + seg * md.tj;
+    const int jB = (jA + md.tj - 1 < je + 2) ? jA + md.tj - 1 : je + 2;
+    const size_t oA = (size_t)k * g.nA(), oU = (size_t)k * g.nU(), oV = (size_t)k * g.nV(), oB = (size_t)k * g.nB();
+    const double *u = a.u + oU, *v = a.v + oV, *delp = a.delp + oA, *pt = a.pt + oA;
+    const double *w = a.hydrostatic ? nullptr : a.w + oA;
+    const double dt2 = a.dt2, dt4 = 0.5 * dt2;
+    const long nAp = (long)g.nA();  // one sin_sg plane
+    // row loaders (row index clamped into the array; clamped rows are never used for a kept value)
+    auto LA = [&](const double *p, int j, long shift = 0) { return vload(p, (long)g.iA(ilo, cl(j, g.jsd, g.jed)) + shift, cA); };
+    auto LU = [&](const double *p, int j) { return vload(p, (long)g.iU(ilo, cl(j, g.jsd, g.jed + 1)), cA); };
+    auto LV = [&](const double *p, int j) { return vload(p, (long)g.iV(ilo, cl(j, g.jsd, g.jed)), cV); };
+    auto LB = [&](const double *p, int j) { return vload(p, (long)g.iB(ilo, cl(j, g.jsd, g.jed + 1)), cV); };
+    const vb m_uc = lane_mask(is - ilo, ie + 1 - ilo);  // columns where uc is advanced (:414-447)
+    const vb m_vc = lane_mask(is - ilo, ie - ilo);      // columns where vc is advanced (:452-486)
+
+    vd u0(0.), u1(0.), u2(0.), u3(0.);          // u(t-3 .. t)
+    vd v0(0.), v1(0.), v2(0.), v3(0.);          // v(t-4 .. t-1)
+    vd vt0(0.), vt1(0.), vt2(0.), vt3(0.);      // vtmp(t-4 .. t-1)
+    vd dpm(0.), dp0(0.), dpp(0.), ptm(0.), pt0(0.), ptp(0.), wm(0.), w0(0.), wp(0.);  // rows Q-1, Q, Q+1
+    vd ua_p(0.), va_p(0.), uc_p(0.), vc_p(0.), ut_p(0.), vt_p(0.);  // row Q = t-3 (previous step's row R)
+    vd ucdx_p(0.), vort_p(0.), ke_p(0.), vdxc_p(0.);
+    vd fy1_p(0.), fyp_p(0.), fyw_p(0.);         // upwind fluxes through y-face Q (delp, pt, w)
+
+    for (int t = jA - 2; t <= jB + 3; t++) {
+      const int R = t - 2, Q = t - 3;
+      // ---- loads ---------------------------------------------------------------------------------------
+      u0 = u1; u1 = u2; u2 = u3; u3 = LU(u, t);
+      v0 = v1; v1 = v2; v2 = v3; v3 = LV(v, t - 1);
+      dpm = dp0; dp0 = dpp; dpp = LA(delp, R);
+      ptm = pt0; pt0 = ptp; ptp = LA(pt, R);
+      if (w) { wm = w0; w0 = wp; wp = LA(w, R); }
+      // ---- row R: interpolated winds, fluxes, vorticity ----------------------------------------------------
+      const vd utmp = a2 * (u0 + u3) + a1 * (u1 + u2);                       // :3099-3103
+      const vd v3p = shl1(v3);
+      vt0 = vt1; vt1 = vt2; vt2 = vt3;
+      vt3 = a2 * (shr1(v3) + shl1(v3p)) + a1 * (v3 + v3p);                   // vtmp(t-1), :3104-3108
+      const vd cs = LA(g.cosa_s, R), rs = LA(g.rsin2, R);
+      const vd ua = (utmp - vt2 * cs) * rs, va = (vt2 - utmp * cs) * rs;     // :3152-3157
+      const vd um1 = shr1(utmp);
+      const vd uc = a2 * (shr1(um1) + shl1(utmp)) + a1 * (um1 + utmp);       // :3197-3199
+      const vd vc = a2 * (vt0 + vt3) + a1 * (vt1 + vt2);                     // :3337-3339
+      vd ut = (uc - v2 * LV(g.cosa_u, R)) * LV(g.rsin_u, R);                 // :3200
+      {
+        const vd dyr = LV(g.dy, R);
+        const vd sg3 = LA(g.sin_sg + 2 * nAp, R, -1), sg1 = LA(g.sin_sg, R);  // sin_sg(i-1,j,3), sin_sg(i,j,1)
+        ut = vsel(ut > 0., dt2 * ut * dyr * sg3, dt2 * ut * dyr * sg1);      // :159-167
+      }
+      vd vt;
+      {
+        const vd dxr = LU(g.dx, R);
+        const vd sg4 = LA(g.sin_sg + 3 * nAp, R - 1), sg2 = LA(g.sin_sg + nAp, R);  // sin_sg(i,j-1,4), sin_sg(i,j,2)
+        vt = vsel(vc > 0., dt2 * vc * dxr * sg4, dt2 * vc * dxr * sg2);      // :168-176 (vt = vc, :3340)
+      }
+      const vd ucdx = uc * LV(g.dxc, R);
+      const vd dycr = LU(g.dyc, R);
+      const vd vcdy = vc * dycr;
+      const vd rac = LB(g.rarea_c, R);
+      const vd vort = LB(g.fC, R) + rac * (ucdx_p - ucdx - shr1(vcdy) + vcdy);  // :372-403
+      if (R >= jA && R <= jB) {
+        const long iAr = (long)g.iA(ilo, R);
+        if (R <= je + 1) {
+          vstore(a.ua + oA, iAr, ua, l0, l1);
+          vstore(a.va + oA, iAr, va, l0, l1);
+          vstore(a.ut + oA, iAr, ut, l0, l2);
+        }
+        vstore(a.vt + oA, iAr, vt, l0, l1);
+      }
+      // ---- row Q: KE, transport, wind update, divergence -------------------------------------------------------
+      const vd ke = dt4 * (ua_p * vsel(ua_p > 0., uc_p, shl1(uc_p)) + va_p * vsel(va_p > 0., vc_p, vc));  // :297-366
+      // upwind fluxes through y-face Q+1 (= R) and x-face i (:182-286)
+      const vb vpos = vt > 0.;
+      const vd fy1_n = vt * vsel(vpos, dp0, dpp);
+      const vd fyp_n = fy1_n * vsel(vpos, pt0, ptp);
+      const vd fyw_n = w ? fy1_n * vsel(vpos, w0, wp) : vd(0.);
+      if (Q >= jA && Q <= jB) {
+        const long iAq = (long)g.iA(ilo, Q);
+        if (Q <= je + 1) {
+          const vb upos = ut_p > 0.;
+          const vd fx1 = ut_p * vsel(upos, shr1(dp0), dp0);
+          const vd fxp = fx1 * vsel(upos, shr1(pt0), pt0);
+          const vd ra = LA(g.rarea, Q);
+          const vd dpc = dp0 + (fx1 - shl1(fx1) + fy1_p - fy1_n) * ra;
+          vstore(a.delpc + oA, iAq, dpc, l0, l1);
+          vstore(a.ptc + oA, iAq, (pt0 * dp0 + (fxp - shl1(fxp) + fyp_p - fyp_n) * ra) / dpc, l0, l1);
+          if (w) {
+            const vd fxw = fx1 * vsel(upos, shr1(w0), w0);
+            vstore(a.wc + oA, iAq, (w0 * dp0 + (fxw - shl1(fxw) + fyw_p - fyw_n) * ra) / dpc, l0, l1);
+          }
+          // uc: interpolated value, advanced on [is, ie+1] x [js, je] (:414-447)
+          vd ucv = uc_p;
+          if (Q >= js && Q <= je) {
+            const vd fy1 = dt2 * (v1 - ucv * LV(g.cosa_u, Q)) / LV(g.sina_u, Q);
+            const vd fy = vsel(fy1 > 0., vort_p, vort);
+            ucv = vsel(m_uc, ucv + fy1 * fy + LV(g.rdxc, Q) * (shr1(ke) - ke), ucv);
+          }
+          vstore(a.uc + oV, (long)g.iV(ilo, Q), ucv, l0, l2);
+        }
+        // vc: interpolated value, advanced on [is, ie] x [js, je+1] (:452-486)
+        vd vcv = vc_p;
+        if (Q >= js && Q <= je + 1) {
+          const vd fx1 = dt2 * (u0 - vcv * LU(g.cosa_v, Q)) / LU(g.sina_v, Q);
+          const vd fx = vsel(fx1 > 0., vort_p, shl1(vort_p));
+          vcv = vsel(m_vc, vcv - fx1 * fx + LU(g.rdyc, Q) * (ke_p - ke), vcv);
+        }
+        vstore(a.vc + oU, (long)g.iU(ilo, Q), vcv, l0, l1);
+      }
+      // divergence at the corners of row Q (:1781-1796); v0 = v(Q-1), v1 = v(Q), u0 = u(Q)
+      const vd vdxc = v1 * LV(g.dxc, Q);
+      if (a.nord > 0 && Q >= jA && Q <= jB) {
+        const vd uf = u0 * LU(g.dyc, Q);
+        vstore(a.divg_d + oB, (long)g.iB(ilo, Q), LB(g.rarea_c, Q) * (vdxc_p - vdxc + shr1(uf) - uf), l0, l2);
+      }
+      // ---- rotate the row state ------------------------------------------------------------------------------------
+      ua_p = ua; va_p = va; uc_p = uc; vc_p = vc; ut_p = ut; vt_p = vt;
+      ucdx_p = ucdx; vort_p = vort; ke_p = ke; vdxc_p = vdxc;
+      fy1_p = fy1_n; fyp_p = fyp_n; fyw_p = fyw_n;
+    }
+  }
+};
+
+}  // namespace fv3

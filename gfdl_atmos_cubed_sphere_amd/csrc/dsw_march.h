@@ -16,20 +16,6 @@
 
 namespace fv3 {
 
-struct MarchDims {
-  int nstrips, nsegs, tj;
-  const int *klist;  // level of the n-th marching slab (device), or null = identity
-  FV3_HD int nwaves(int npz) const { return nstrips * nsegs * npz; }
-};
-inline MarchDims make_march_dims(const Grid &g, int tj) {
-  MarchDims d;
-  d.tj = tj;
-  d.klist = nullptr;
-  d.nstrips = num_strips(g);
-  d.nsegs = (g.ny + tj - 1) / tj;
-  return d;
-}
-
 template <int HORD>
 struct DswDelpMarch {
   Grid g;

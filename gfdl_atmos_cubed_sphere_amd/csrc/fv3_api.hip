@@ -8,6 +8,7 @@
 #include <type_traits>
 
 #include "csw_kernel.h"
+#include "csw_march.h"
 #include "dsw_kernels.h"
 #include "dsw_march.h"
 #include "fv3_common.h"
@@ -62,6 +63,7 @@ struct fv3_ctx {
   double *ke_scr;        // B kind, npz levels: KE + damping term at the corners
   double *mflux[2];      // mass-flux scratch of the marching transports: FX kind, FY kind (npz levels)
   int march_tj;          // rows per wavefront segment of the marching kernels
+  int march_tj_csw;
   int use_march;         // 0: LDS-tile kernels only (FV3_MI355X_MARCH=0)
   bool prof_on;
   struct ProfRec { const char *label; void *e0, *e1; };
@@ -183,6 +185,9 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_MARCH_TJ");
     c->march_tj = e ? std::atoi(e) : 48;
     if (c->march_tj < 1) c->march_tj = 48;
+    e = std::getenv("FV3_MI355X_MARCH_TJ_CSW");
+    c->march_tj_csw = e ? std::atoi(e) : 48;
+    if (c->march_tj_csw < 1) c->march_tj_csw = 48;
   }
   c->dp0 = nullptr; c->edge_dev = nullptr; c->dp0_ready = false;
   c->akbk = nullptr; c->kord_tr_dev = nullptr; c->akbk_ready = false;
@@ -446,6 +451,14 @@ extern "C" int fv3_c_sw(fv3_ctx *c, double *delpc, const double *delp, double *p
   (void)dord4;  // ua, va are produced on is-1:ie+1 (what c_sw/d_sw read); see header
   if (!c || !c->grid_ready) return fail("fv3_c_sw: context has no grid (call fv3_grid_upload)");
   if (!hydrostatic && (!w || !wc)) return fail("fv3_c_sw: nonhydrostatic call needs w and wc");
+  if (c->use_march) {
+    CswMarch kf;
+    kf.g = c->g;
+    kf.a = CswArgs{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2};
+    kf.md = make_csw_dims(c->g, c->march_tj_csw);
+    RT(launch_w(c, "c_sw", kf.md.nwaves(c->g.npz), kf));
+    return 0;
+  }
   constexpr int TI = FV3_CSW_TI, TJ = FV3_CSW_TJ;
   CswTile<TI, TJ> kf;
   kf.g = c->g;

@@ -155,7 +155,12 @@ inline void vstore(double *p, long off, const vd &x, int lmin, int lmax) {
   for (int l = 0; l < kW; l++)
     if (l >= lmin && l <= lmax) p[off + l] = x.v[l];
 }
-inline int wave_lane0() { return 0; }
+// predicate: lane in [l0, l1]
+inline vb lane_mask(int l0, int l1) {
+  vb r;
+  for (int l = 0; l < kW; l++) r.v[l] = l >= l0 && l <= l1;
+  return r;
+}
 
 #else
 // ------------------------------------------------------------------------------------------ gfx950
@@ -194,6 +199,13 @@ __device__ __forceinline__ vd vload(const double *p, long off, vl li) {
 __device__ __forceinline__ void vstore(double *p, long off, vd x, int lmin, int lmax) {
   const int l = (int)(threadIdx.x & (kW - 1));
   if (l >= lmin && l <= lmax) (p + off)[l] = x;
+}
+#endif
+
+#ifndef FV3_HOST_EMU
+__device__ __forceinline__ vb lane_mask(int l0, int l1) {
+  const int l = (int)(threadIdx.x & (kW - 1));
+  return l >= l0 && l <= l1;
 }
 #endif
 

@@ -49,6 +49,22 @@ FV3_D StripGeom make_strip(const Grid &g, int strip) {
 }
 inline int num_strips(const Grid &g) { return (g.nx + kStripCells - 1) / kStripCells; }
 
+// wave index -> (strip, row segment, level)
+struct MarchDims {
+  int nstrips, nsegs, tj;
+  const int *klist;  // level of the n-th marching slab (device), or null = identity
+  FV3_HD int nwaves(int npz) const { return nstrips * nsegs * npz; }
+};
+inline MarchDims make_march_dims(const Grid &g, int tj) {
+  MarchDims d;
+  d.tj = tj;
+  d.klist = nullptr;
+  d.nstrips = num_strips(g);
+  d.nsegs = (g.ny + tj - 1) / tj;
+  return d;
+}
+
+
 // ra_x = area + xfx(i) - xfx(i+1) is formed on the fly (sw_core.F90:908-917); so is ra_y.
 struct MarchIn {
   vd qn, ar, cx, xf;  // row r:   q, area, crx, xfx

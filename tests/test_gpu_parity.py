@@ -223,3 +223,8 @@ def test_fv_dynamics_step(prod, nq, k_split):
 def test_d_sw_multi_strip_march(prod, hord, hord_mt):
     """several 58-column strips and several row segments of the wave-marching kernels"""
     P.check_d_sw(prod, nx=130, ny=100, npz=3, par_over=dict(hord_dp=hord, hord_tm=hord, hord_vt=hord, hord_mt=hord_mt))
+
+
+@pytest.mark.parametrize("nx,ny,hydro", [(130, 100, False), (55, 44, True)])
+def test_c_sw_multi_strip_march(prod, nx, ny, hydro):
+    P.check_c_sw(prod, nx=nx, ny=ny, npz=2, hydrostatic=hydro)

@@ -169,3 +169,8 @@ def test_fv_dynamics_step(emu, nq, k_split):
 def test_d_sw_multi_strip_march(emu, hord, hord_mt):
     """several 58-column strips and several row segments of the wave-marching kernels"""
     P.check_d_sw(emu, nx=130, ny=100, npz=3, par_over=dict(hord_dp=hord, hord_tm=hord, hord_vt=hord, hord_mt=hord_mt))
+
+
+@pytest.mark.parametrize("nx,ny,hydro", [(130, 100, False), (55, 44, True)])
+def test_c_sw_multi_strip_march(emu, nx, ny, hydro):
+    P.check_c_sw(emu, nx=nx, ny=ny, npz=2, hydrostatic=hydro)
