@@ -66,46 +66,63 @@ struct CswMarch {
     vd u0(0.), u1(0.), u2(0.), u3(0.);          // u(t-3 .. t)
     vd v0(0.), v1(0.), v2(0.), v3(0.);          // v(t-4 .. t-1)
     vd vt0(0.), vt1(0.), vt2(0.), vt3(0.);      // vtmp(t-4 .. t-1)
-    vd dpm(0.), dp0(0.), dpp(0.), ptm(0.), pt0(0.), ptp(0.), wm(0.), w0(0.), wp(0.);  // rows Q-1, Q, Q+1
+    vd dp0(0.), dpp(0.), pt0(0.), ptp(0.), w0(0.), wp(0.);  // rows Q, Q+1
     vd ua_p(0.), va_p(0.), uc_p(0.), vc_p(0.), ut_p(0.), vt_p(0.);  // row Q = t-3 (previous step's row R)
     vd ucdx_p(0.), vort_p(0.), ke_p(0.), vdxc_p(0.);
     vd fy1_p(0.), fyp_p(0.), fyw_p(0.);         // upwind fluxes through y-face Q (delp, pt, w)
+    // metric rows that are needed again one step later (row R becomes row Q)
+    vd cosau_p(0.), dxc_p(0.), dyc_p(0.), rac_p(0.);
 
+    // everything step t reads from memory; loaded one step ahead (software pipelining)
+    struct In {
+      vd u, v, dp, pt, w;
+      vd cs, rs, cosau, rsinu, dy, sg3, sg1, dx, sg4, sg2, dxc, dyc, rac, fc;  // row R
+      vd ra, sinau, rdxc, cosav, sinav, rdyc;                                    // row Q
+    };
+    auto load_step = [&](int t) {
+      const int R = t - 2, Q = t - 3;
+      In in;
+      in.u = LU(u, t);
+      in.v = LV(v, t - 1);
+      in.dp = LA(delp, R);
+      in.pt = LA(pt, R);
+      in.w = w ? LA(w, R) : vd(0.);
+      in.cs = LA(g.cosa_s, R);  in.rs = LA(g.rsin2, R);
+      in.cosau = LV(g.cosa_u, R);  in.rsinu = LV(g.rsin_u, R);  in.dy = LV(g.dy, R);
+      in.sg3 = LA(g.sin_sg + 2 * nAp, R, -1);  in.sg1 = LA(g.sin_sg, R);      // sin_sg(i-1,j,3), sin_sg(i,j,1)
+      in.dx = LU(g.dx, R);
+      in.sg4 = LA(g.sin_sg + 3 * nAp, R - 1);  in.sg2 = LA(g.sin_sg + nAp, R);  // sin_sg(i,j-1,4), sin_sg(i,j,2)
+      in.dxc = LV(g.dxc, R);  in.dyc = LU(g.dyc, R);  in.rac = LB(g.rarea_c, R);  in.fc = LB(g.fC, R);
+      in.ra = LA(g.rarea, Q);
+      in.sinau = LV(g.sina_u, Q);  in.rdxc = LV(g.rdxc, Q);
+      in.cosav = LU(g.cosa_v, Q);  in.sinav = LU(g.sina_v, Q);  in.rdyc = LU(g.rdyc, Q);
+      return in;
+    };
+    In nxt = load_step(jA - 2);
     for (int t = jA - 2; t <= jB + 3; t++) {
       const int R = t - 2, Q = t - 3;
-      // ---- loads ---------------------------------------------------------------------------------------
-      u0 = u1; u1 = u2; u2 = u3; u3 = LU(u, t);
-      v0 = v1; v1 = v2; v2 = v3; v3 = LV(v, t - 1);
-      dpm = dp0; dp0 = dpp; dpp = LA(delp, R);
-      ptm = pt0; pt0 = ptp; ptp = LA(pt, R);
-      if (w) { wm = w0; w0 = wp; wp = LA(w, R); }
+      const In in = nxt;
+      nxt = load_step(t < jB + 3 ? t + 1 : t);
+      u0 = u1; u1 = u2; u2 = u3; u3 = in.u;
+      v0 = v1; v1 = v2; v2 = v3; v3 = in.v;
+      dp0 = dpp; dpp = in.dp;
+      pt0 = ptp; ptp = in.pt;
+      w0 = wp; wp = in.w;
       // ---- row R: interpolated winds, fluxes, vorticity ----------------------------------------------------
       const vd utmp = a2 * (u0 + u3) + a1 * (u1 + u2);                       // :3099-3103
       const vd v3p = shl1(v3);
       vt0 = vt1; vt1 = vt2; vt2 = vt3;
       vt3 = a2 * (shr1(v3) + shl1(v3p)) + a1 * (v3 + v3p);                   // vtmp(t-1), :3104-3108
-      const vd cs = LA(g.cosa_s, R), rs = LA(g.rsin2, R);
-      const vd ua = (utmp - vt2 * cs) * rs, va = (vt2 - utmp * cs) * rs;     // :3152-3157
+            const vd ua = (utmp - vt2 * in.cs) * in.rs, va = (vt2 - utmp * in.cs) * in.rs;     // :3152-3157
       const vd um1 = shr1(utmp);
       const vd uc = a2 * (shr1(um1) + shl1(utmp)) + a1 * (um1 + utmp);       // :3197-3199
       const vd vc = a2 * (vt0 + vt3) + a1 * (vt1 + vt2);                     // :3337-3339
-      vd ut = (uc - v2 * LV(g.cosa_u, R)) * LV(g.rsin_u, R);                 // :3200
-      {
-        const vd dyr = LV(g.dy, R);
-        const vd sg3 = LA(g.sin_sg + 2 * nAp, R, -1), sg1 = LA(g.sin_sg, R);  // sin_sg(i-1,j,3), sin_sg(i,j,1)
-        ut = vsel(ut > 0., dt2 * ut * dyr * sg3, dt2 * ut * dyr * sg1);      // :159-167
-      }
-      vd vt;
-      {
-        const vd dxr = LU(g.dx, R);
-        const vd sg4 = LA(g.sin_sg + 3 * nAp, R - 1), sg2 = LA(g.sin_sg + nAp, R);  // sin_sg(i,j-1,4), sin_sg(i,j,2)
-        vt = vsel(vc > 0., dt2 * vc * dxr * sg4, dt2 * vc * dxr * sg2);      // :168-176 (vt = vc, :3340)
-      }
-      const vd ucdx = uc * LV(g.dxc, R);
-      const vd dycr = LU(g.dyc, R);
-      const vd vcdy = vc * dycr;
-      const vd rac = LB(g.rarea_c, R);
-      const vd vort = LB(g.fC, R) + rac * (ucdx_p - ucdx - shr1(vcdy) + vcdy);  // :372-403
+      vd ut = (uc - v2 * in.cosau) * in.rsinu;                 // :3200
+      ut = vsel(ut > 0., dt2 * ut * in.dy * in.sg3, dt2 * ut * in.dy * in.sg1);  // :159-167
+      const vd vt = vsel(vc > 0., dt2 * vc * in.dx * in.sg4, dt2 * vc * in.dx * in.sg2);  // :168-176 (vt = vc, :3340)
+      const vd ucdx = uc * in.dxc;
+      const vd vcdy = vc * in.dyc;
+      const vd vort = in.fc + in.rac * (ucdx_p - ucdx - shr1(vcdy) + vcdy);  // :372-403
       if (R >= jA && R <= jB) {
         const long iAr = (long)g.iA(ilo, R);
         if (R <= je + 1) {
@@ -128,7 +145,7 @@ struct CswMarch {
           const vb upos = ut_p > 0.;
           const vd fx1 = ut_p * vsel(upos, shr1(dp0), dp0);
           const vd fxp = fx1 * vsel(upos, shr1(pt0), pt0);
-          const vd ra = LA(g.rarea, Q);
+          const vd ra = in.ra;
           const vd dpc = dp0 + (fx1 - shl1(fx1) + fy1_p - fy1_n) * ra;
           vstore(a.delpc + oA, iAq, dpc, l0, l1);
           vstore(a.ptc + oA, iAq, (pt0 * dp0 + (fxp - shl1(fxp) + fyp_p - fyp_n) * ra) / dpc, l0, l1);
@@ -139,31 +156,32 @@ struct CswMarch {
           // uc: interpolated value, advanced on [is, ie+1] x [js, je] (:414-447)
           vd ucv = uc_p;
           if (Q >= js && Q <= je) {
-            const vd fy1 = dt2 * (v1 - ucv * LV(g.cosa_u, Q)) / LV(g.sina_u, Q);
+            const vd fy1 = dt2 * (v1 - ucv * cosau_p) / in.sinau;
             const vd fy = vsel(fy1 > 0., vort_p, vort);
-            ucv = vsel(m_uc, ucv + fy1 * fy + LV(g.rdxc, Q) * (shr1(ke) - ke), ucv);
+            ucv = vsel(m_uc, ucv + fy1 * fy + in.rdxc * (shr1(ke) - ke), ucv);
           }
           vstore(a.uc + oV, (long)g.iV(ilo, Q), ucv, l0, l2);
         }
         // vc: interpolated value, advanced on [is, ie] x [js, je+1] (:452-486)
         vd vcv = vc_p;
         if (Q >= js && Q <= je + 1) {
-          const vd fx1 = dt2 * (u0 - vcv * LU(g.cosa_v, Q)) / LU(g.sina_v, Q);
+          const vd fx1 = dt2 * (u0 - vcv * in.cosav) / in.sinav;
           const vd fx = vsel(fx1 > 0., vort_p, shl1(vort_p));
-          vcv = vsel(m_vc, vcv - fx1 * fx + LU(g.rdyc, Q) * (ke_p - ke), vcv);
+          vcv = vsel(m_vc, vcv - fx1 * fx + in.rdyc * (ke_p - ke), vcv);
         }
         vstore(a.vc + oU, (long)g.iU(ilo, Q), vcv, l0, l1);
       }
       // divergence at the corners of row Q (:1781-1796); v0 = v(Q-1), v1 = v(Q), u0 = u(Q)
-      const vd vdxc = v1 * LV(g.dxc, Q);
+      const vd vdxc = v1 * dxc_p;
       if (a.nord > 0 && Q >= jA && Q <= jB) {
-        const vd uf = u0 * LU(g.dyc, Q);
-        vstore(a.divg_d + oB, (long)g.iB(ilo, Q), LB(g.rarea_c, Q) * (vdxc_p - vdxc + shr1(uf) - uf), l0, l2);
+        const vd uf = u0 * dyc_p;
+        vstore(a.divg_d + oB, (long)g.iB(ilo, Q), rac_p * (vdxc_p - vdxc + shr1(uf) - uf), l0, l2);
       }
       // ---- rotate the row state ------------------------------------------------------------------------------------
       ua_p = ua; va_p = va; uc_p = uc; vc_p = vc; ut_p = ut; vt_p = vt;
       ucdx_p = ucdx; vort_p = vort; ke_p = ke; vdxc_p = vdxc;
       fy1_p = fy1_n; fyp_p = fyp_n; fyw_p = fyw_n;
+      cosau_p = in.cosau; dxc_p = in.dxc; dyc_p = in.dyc; rac_p = in.rac;
     }
   }
 };
