@@ -1,7 +1,7 @@
 """Time the full nonhydrostatic model step (k_split x [n_split substeps + tracer_2d + remap]) at C384L127 size
 with per-kernel HIP events; prints one JSON line.  usage: tools_substep_timing.py [nx] [npz] [nq]"""
 import json, sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, "tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import parity_common as P, parity_dyn as D, parity_nh as N
 from gfdl_atmos_cubed_sphere_amd import lib as L
