@@ -301,3 +301,124 @@ struct DswVortMarch {
 };
 
 }  // namespace fv3
+
+// =====================================================================================================
+// The other two fv_tp_2d users on the marching stencil (undamped levels / sub-steps; the LDS-tile kernels
+// ZhTransport and TracerStep keep the del-2n damped cases).
+namespace fv3 {
+
+// update_dz_d, model/nh_utils.F90:256-301: fv_tp_2d of one interface height + flux-form update
+template <int HORD>
+struct ZhMarch {
+  Grid g;
+  MarchDims md;
+  const double *zh, *crx, *cry, *xfx, *yfx;  // interface-level Courant numbers / fluxes (km+1 levels)
+  double *zh_out;
+
+  struct Sink {
+    const ZhMarch &K;
+    const StripGeom &s;
+    int k;
+    struct In {
+      vd z, ar, x0, y0, y1;
+    };
+    FV3_D In load(int j) const {
+      const Grid &g = K.g;
+      const long iA = (long)g.iA(s.ilo, j);
+      In in;
+      in.z = vload(K.zh + (size_t)k * g.nA(), iA, s.A);
+      in.ar = vload(g.area, iA, s.A);
+      in.x0 = vload(K.xfx + (size_t)k * g.nCX(), (long)g.iCX(s.ilo, j), s.F);
+      in.y0 = vload(K.yfx + (size_t)k * g.nCY(), (long)g.iCY(s.ilo, j), s.A);
+      in.y1 = vload(K.yfx + (size_t)k * g.nCY(), (long)g.iCY(s.ilo, j + 1), s.A);
+      return in;
+    }
+    FV3_D void row(int j, const In &in, const vd &fxv, const vd &fyv0, const vd &fyv1) const {
+      const Grid &g = K.g;
+      const vd x1 = shl1(in.x0);
+      const vd fx0 = fxv * in.x0, fy0 = fyv0 * in.y0, fy1 = fyv1 * in.y1;
+      const vd rax = in.ar + in.x0 - x1, ray = in.ar + in.y0 - in.y1;
+      const vd zn = (in.z * in.ar + fx0 - shl1(fx0) + fy0 - fy1) / (rax + ray - in.ar);  // :283-299
+      vstore(K.zh_out + (size_t)k * g.nA(), (long)g.iA(s.ilo, j), zn, s.lC0, s.lC1);
+    }
+  };
+
+  FV3_D void operator()(int gid) const {
+    const int strip = gid % md.nstrips, seg = (gid / md.nstrips) % md.nsegs, kk = gid / (md.nstrips * md.nsegs);
+    const int k = md.klist ? md.klist[kk] : kk;
+    const StripGeom s = make_strip(g, strip);
+    const int jA = g.js + seg * md.tj;
+    const int jB = (jA + md.tj - 1 < g.je) ? jA + md.tj - 1 : g.je;
+    Sink sink{*this, s, k};
+    tp2d_march<HORD>(g, s, jA, jB, zh + (size_t)k * g.nA(), crx + (size_t)k * g.nCX(), cry + (size_t)k * g.nCY(),
+                     xfx + (size_t)k * g.nCX(), yfx + (size_t)k * g.nCY(), sink);
+  }
+};
+
+// one sub-cycle of tracer_2d for every (tracer, level), model/fv_tracer2d.F90:471-541, without the del-2n
+// damping of the first sub-cycle (trdm <= 1e-4)
+template <int HORD>
+struct TracerMarch {
+  Grid g;
+  MarchDims md;
+  int npz, nq, it, nsplt;
+  const int *ksplt;  // device, npz
+  const double *q, *dp1, *mfx, *mfy, *cx, *cy, *xfx, *yfx;
+  double *q_out, *dp1_out;
+
+  struct Sink {
+    const TracerMarch &K;
+    const StripGeom &s;
+    int k, iq;
+    struct In {
+      vd q, d1, ra, mx, my0, my1;
+    };
+    FV3_D In load(int j) const {
+      const Grid &g = K.g;
+      const long iA = (long)g.iA(s.ilo, j);
+      In in;
+      in.q = vload(K.q + ((size_t)iq * K.npz + k) * g.nA(), iA, s.A);
+      in.d1 = vload(K.dp1 + (size_t)k * g.nA(), iA, s.A);
+      in.ra = vload(g.rarea, iA, s.A);
+      in.mx = vload(K.mfx + (size_t)k * g.nFX(), (long)g.iFX(s.ilo, j), s.F);
+      in.my0 = vload(K.mfy + (size_t)k * g.nFY(), (long)g.iFY(s.ilo, j), s.C);
+      in.my1 = vload(K.mfy + (size_t)k * g.nFY(), (long)g.iFY(s.ilo, j + 1), s.C);
+      return in;
+    }
+    FV3_D void row(int j, const In &in, const vd &fxv, const vd &fyv0, const vd &fyv1) const {
+      const Grid &g = K.g;
+      const long iA = (long)g.iA(s.ilo, j);
+      const vd gx = fxv * in.mx, gy0 = fyv0 * in.my0, gy1 = fyv1 * in.my1;
+      const vd dp2 = in.d1 + (in.mx - shl1(in.mx) + in.my0 - in.my1) * in.ra;                 // :517-522
+      const vd qn = (in.q * in.d1 + (gx - shl1(gx) + gy0 - gy1) * in.ra) / dp2;              // :523-531
+      vstore(K.q_out + ((size_t)iq * K.npz + k) * g.nA(), iA, qn, s.lC0, s.lC1);
+      if (iq == K.nq - 1 && K.it != K.nsplt) vstore(K.dp1_out + (size_t)k * g.nA(), iA, dp2, s.lC0, s.lC1);
+    }
+  };
+
+  FV3_D void operator()(int gid) const {
+    const int strip = gid % md.nstrips;
+    int rest = gid / md.nstrips;
+    const int seg = rest % md.nsegs;
+    rest /= md.nsegs;
+    const int k = rest % npz, iq = rest / npz;
+    const StripGeom s = make_strip(g, strip);
+    const int jA = g.js + seg * md.tj;
+    const int jB = (jA + md.tj - 1 < g.je) ? jA + md.tj - 1 : g.je;
+    const size_t oq = ((size_t)iq * npz + k) * g.nA();
+    if (it > ksplt[k]) {  // the level is finished: carry q (and dp1) over to the output buffers
+      for (int j = jA; j <= jB; j++) {
+        const long iA = (long)g.iA(s.ilo, j);
+        vstore(q_out + oq, iA, vload(q + oq, iA, s.A), s.lC0, s.lC1);
+        if (iq == nq - 1 && it != nsplt)
+          vstore(dp1_out + (size_t)k * g.nA(), iA, vload(dp1 + (size_t)k * g.nA(), iA, s.A), s.lC0, s.lC1);
+      }
+      return;
+    }
+    Sink sink{*this, s, k, iq};
+    tp2d_march<HORD>(g, s, jA, jB, q + oq, cx + (size_t)k * g.nCX(), cy + (size_t)k * g.nCY(),
+                     xfx + (size_t)k * g.nCX(), yfx + (size_t)k * g.nCY(), sink);
+  }
+};
+
+}  // namespace fv3

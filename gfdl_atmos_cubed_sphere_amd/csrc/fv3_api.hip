@@ -60,6 +60,8 @@ struct fv3_ctx {
   // same split for the momentum part: marching needs nord_k == 1, no vorticity damping, d_con = 0
   int *klist_m;
   int n_plain_m, n_rest_m;
+  int *klist_z;          // npz+1 interfaces of update_dz_d: [undamped..., damped...]
+  int n_plain_z, n_damp_z;
   double *ke_scr;        // B kind, npz levels: KE + damping term at the corners
   double *mflux[2];      // mass-flux scratch of the marching transports: FX kind, FY kind (npz levels)
   int march_tj;          // rows per wavefront segment of the marching kernels
@@ -178,6 +180,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->prof_on = false;
   c->klist = nullptr; c->n_plain = c->n_damp = 0;
   c->klist_m = nullptr; c->n_plain_m = c->n_rest_m = 0; c->ke_scr = nullptr;
+  c->klist_z = nullptr; c->n_plain_z = c->n_damp_z = 0;
   c->mflux[0] = c->mflux[1] = nullptr;
   {  // tuning / fallback knobs
     const char *e = std::getenv("FV3_MI355X_MARCH");
@@ -215,6 +218,7 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   for (auto &s : c->mflux) if (s) rt_free(s);
   if (c->klist) rt_free(c->klist);
   if (c->klist_m) rt_free(c->klist_m);
+  if (c->klist_z) rt_free(c->klist_z);
   if (c->ke_scr) rt_free(c->ke_scr);
   delete c;
   return 0;
@@ -315,6 +319,13 @@ extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
     nd[npz] = nd[npz - 1];
     if (!c->lev_ext_i) RT(rt_malloc((void **)&c->lev_ext_i, sizeof(int) * (npz + 1)));
     if (!c->lev_ext_d) RT(rt_malloc((void **)&c->lev_ext_d, sizeof(double) * (npz + 1)));
+    std::vector<int> pz, dz;
+    for (int k = 0; k <= npz; k++) ((nd[k] > 1.E-5) ? dz : pz).push_back(k);
+    c->n_plain_z = (int)pz.size();
+    c->n_damp_z = (int)dz.size();
+    pz.insert(pz.end(), dz.begin(), dz.end());
+    if (!c->klist_z) RT(rt_malloc((void **)&c->klist_z, sizeof(int) * (npz + 1)));
+    RT(rt_h2d(c->klist_z, pz.data(), sizeof(int) * (npz + 1), c->stream));
     RT(rt_h2d(c->lev_ext_i, ni.data(), sizeof(int) * (npz + 1), c->stream));
     RT(rt_h2d(c->lev_ext_d, nd.data(), sizeof(double) * (npz + 1), c->stream));
     RT(rt_sync(c->stream));
@@ -746,12 +757,22 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
     RT(launch_p(c, "edge_profile", col_grid((int)g.nCY()), 0, kf2));
   }
   constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
-  {
-    ZhTransport<TI, TJ> kf{g, hord, zh_in, cxa, cya, xfa, yfa, c->lev_ext_i, c->lev_ext_d, zh_out};
+  const bool march = c->use_march != 0;
+  if (march && c->n_plain_z > 0) {
+    MarchDims md = make_march_dims(g, c->march_tj);
+    md.klist = c->klist_z;
+    RT(dispatch_hord(hord, [&](auto H) {
+      ZhMarch<decltype(H)::value> kf{g, md, zh_in, cxa, cya, xfa, yfa, zh_out};
+      return launch_w(c, "zh_transport", md.nwaves(c->n_plain_z), kf);
+    }));
+  }
+  if (!march || c->n_damp_z > 0) {
+    ZhTransport<TI, TJ> kf{g, hord, zh_in, cxa, cya, xfa, yfa, c->lev_ext_i, c->lev_ext_d, zh_out,
+                           march ? c->klist_z + c->n_plain_z : nullptr};
     Dim3 grid;
     grid.x = (unsigned)((g.nx + TI - 1) / TI);
     grid.y = (unsigned)((g.ny + TJ - 1) / TJ);
-    grid.z = (unsigned)(km + 1);
+    grid.z = (unsigned)(march ? c->n_damp_z : km + 1);
     RT(launch_p(c, "zh_transport", grid, ZhTransport<TI, TJ>::lds_doubles, kf));
   }
   {
@@ -961,6 +982,14 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
   if (it == 1) {
     RT(rt_h2d(c->trc_i, ksplt_host, sizeof(int) * g.npz, c->stream));
     RT(rt_sync(c->stream));
+  }
+  if (c->use_march && !(it == 1 && trdm > 1.e-4)) {
+    const MarchDims md = make_march_dims(g, c->march_tj);
+    return dispatch_hord(hord, [&](auto H) {
+      TracerMarch<decltype(H)::value> kf{g, md, g.npz, nq, it, nsplt, c->trc_i, q, dp1, mfx, mfy, cx, cy, xfx, yfx,
+                                         q_out, dp1_out};
+      return launch_w(c, "tracer_step", md.nwaves(g.npz) * nq, kf);
+    });
   }
   constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
   TracerStep<TI, TJ> kf{g, g.npz, nq, it, nsplt, hord, nord_tr, trdm, c->trc_i, q, dp1, mfx, mfy, cx, cy, xfx, yfx,

@@ -411,6 +411,7 @@ struct ZhTransport {
   const int *ndif;                            // device, km+1
   const double *damp;                         // device, km+1
   double *zh_out;
+  const int *klist;                           // level of the bz-th slab, or null = identity
   using TS = Tp2dScratch<TI, TJ>;
   using DS = DelnScratch<TI, TJ>;
   static constexpr int nQ = (TI + 6) * (TJ + 6);
@@ -418,7 +419,7 @@ struct ZhTransport {
   static constexpr int nFXt = (TI + 1) * TJ, nFYt = TI * (TJ + 1);
   static constexpr int lds_doubles = nQ + nScr + nFXt + nFYt + TI * TJ;
   FV3_HD void operator()(int bx, int by, int bz, int tid, double *lds) const {
-    const int k = bz;
+    const int k = klist ? klist[bz] : bz;
     const TileBox b = make_box<TI, TJ>(g, bx, by);
     const int i0 = b.i0, j0 = b.j0;
     const size_t oA = (size_t)k * g.nA(), oCX = (size_t)k * g.nCX(), oCY = (size_t)k * g.nCY();

@@ -228,3 +228,10 @@ def test_d_sw_multi_strip_march(prod, hord, hord_mt):
 @pytest.mark.parametrize("nx,ny,hydro", [(130, 100, False), (55, 44, True)])
 def test_c_sw_multi_strip_march(prod, nx, ny, hydro):
     P.check_c_sw(prod, nx=nx, ny=ny, npz=2, hydrostatic=hydro)
+
+
+def test_update_dz_d_and_tracers_multi_strip_march(prod):
+    import parity_tracer as T
+    N.check_update_dz_d(prod, nx=130, ny=100, km=3)
+    T.check_tracer_2d(prod, nx=130, ny=100, npz=3, nq=2)
+    T.check_tracer_2d(prod, nx=70, ny=60, npz=3, nq=2, big_courant=True)

@@ -174,3 +174,10 @@ def test_d_sw_multi_strip_march(emu, hord, hord_mt):
 @pytest.mark.parametrize("nx,ny,hydro", [(130, 100, False), (55, 44, True)])
 def test_c_sw_multi_strip_march(emu, nx, ny, hydro):
     P.check_c_sw(emu, nx=nx, ny=ny, npz=2, hydrostatic=hydro)
+
+
+def test_update_dz_d_and_tracers_multi_strip_march(emu):
+    import parity_tracer as T
+    N.check_update_dz_d(emu, nx=130, ny=100, km=3)
+    T.check_tracer_2d(emu, nx=130, ny=100, npz=3, nq=2)
+    T.check_tracer_2d(emu, nx=70, ny=60, npz=3, nq=2, big_courant=True)
