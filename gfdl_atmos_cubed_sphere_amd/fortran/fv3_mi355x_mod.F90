@@ -10,6 +10,10 @@ module fv3_mi355x_mod
   public :: fv3_create, fv3_destroy, fv3_set_stream, fv3_grid_upload, fv3_malloc, fv3_free
   public :: fv3_memcpy_h2d, fv3_memcpy_d2h, fv3_sync, fv3_c_sw, fv3_d_sw, fv3_fv_tp_2d
   public :: fv3_dsw_levels_upload, fv3_halo_fill_periodic, fv3_check
+  public :: fv3_nh_consts, fv3_remap_params, fv3_memcpy_d2d, fv3_set_dp_ref, fv3_update_dz_c, fv3_riem_solver_c
+  public :: fv3_update_dz_d, fv3_riem_solver3, fv3_p_grad_c, fv3_nh_p_grad, fv3_zh_from_delz, fv3_pk3_halo
+  public :: fv3_pe_halo, fv3_geopk, fv3_set_ak_bk, fv3_lagrangian_to_eulerian, fv3_tracer_2d_prep
+  public :: fv3_tracer_2d_scale, fv3_tracer_2d_step
 
   type, bind(C) :: fv3_domain
     integer(c_int) :: is, ie, js, je, ng, npx, npy, npz, grid_type
@@ -36,6 +40,15 @@ module fv3_mi355x_mod
   type, bind(C) :: fv3_dsw_levels     ! host arrays of length npz (dyn_core.F90:666-733)
     type(c_ptr) :: nord_k, nord_v, nord_w, nord_t
     type(c_ptr) :: d2_divg, damp_vt, damp_w, damp_t, d_con_k
+  end type
+
+  type, bind(C) :: fv3_nh_consts      ! FMS constants_mod values + namelist scalars
+    real(c_double) :: grav, rdgas, cp_air, akap, ptop, p_fac, a_imp
+  end type
+
+  type, bind(C) :: fv3_remap_params   ! Lagrangian_to_Eulerian scalars (fv_mapz.F90:56-64)
+    integer(c_int) :: last_step, hydrostatic, adiabatic, nq, kord_mt, kord_wz, kord_tm, sphum
+    real(c_double) :: akap, ptop, rdgas, grav, cv_air, r_vir, cp, t_min
   end type
 
   interface
@@ -122,6 +135,109 @@ module fv3_mi355x_mod
     function fv3_last_error() bind(C, name="fv3_last_error") result(msg)
       import :: c_ptr
       type(c_ptr) :: msg
+    end function
+    ! ---- nonhydrostatic column path, vertical remap, tracer transport --------------------------------
+    integer(c_int) function fv3_memcpy_d2d(ctx, dst, src, bytes) bind(C, name="fv3_memcpy_d2d")
+      import :: c_int, c_ptr, c_size_t
+      type(c_ptr), value :: ctx, dst, src
+      integer(c_size_t), value :: bytes
+    end function
+    integer(c_int) function fv3_set_dp_ref(ctx, dp0) bind(C, name="fv3_set_dp_ref")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), intent(in) :: dp0(*)          ! host, npz
+    end function
+    integer(c_int) function fv3_update_dz_c(ctx, dt, zs, ut, vt, gz_in, gz, ws) bind(C, name="fv3_update_dz_c")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, zs, ut, vt, gz_in, gz, ws
+      real(c_double), value :: dt
+    end function
+    integer(c_int) function fv3_riem_solver_c(ctx, dt, cn, hs, w3, pt, delp, gz, pef, ws) &
+        bind(C, name="fv3_riem_solver_c")
+      import :: c_int, c_ptr, c_double, fv3_nh_consts
+      type(c_ptr), value :: ctx, hs, w3, pt, delp, gz, pef, ws
+      real(c_double), value :: dt
+      type(fv3_nh_consts), intent(in) :: cn
+    end function
+    integer(c_int) function fv3_update_dz_d(ctx, hord, zs, zh_in, zh_out, crx, cry, xfx, yfx, ws, rdt) &
+        bind(C, name="fv3_update_dz_d")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, zs, zh_in, zh_out, crx, cry, xfx, yfx, ws
+      integer(c_int), value :: hord
+      real(c_double), value :: rdt
+    end function
+    integer(c_int) function fv3_riem_solver3(ctx, dt, cn, zs, w, delz, pt, delp, zh, pe, ppe, pk3, pk, peln, ws, &
+                                             use_logp, last_call, fp_out) bind(C, name="fv3_riem_solver3")
+      import :: c_int, c_ptr, c_double, fv3_nh_consts
+      type(c_ptr), value :: ctx, zs, w, delz, pt, delp, zh, pe, ppe, pk3, pk, peln, ws
+      real(c_double), value :: dt
+      type(fv3_nh_consts), intent(in) :: cn
+      integer(c_int), value :: use_logp, last_call, fp_out
+    end function
+    integer(c_int) function fv3_p_grad_c(ctx, dt2, delpc, pkc, gz, uc, vc, hydrostatic) bind(C, name="fv3_p_grad_c")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, delpc, pkc, gz, uc, vc
+      real(c_double), value :: dt2
+      integer(c_int), value :: hydrostatic
+    end function
+    integer(c_int) function fv3_nh_p_grad(ctx, u, v, pp, gz, gz_scale, delp, pk, dt, top_value) &
+        bind(C, name="fv3_nh_p_grad")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, u, v, pp, gz, delp, pk
+      real(c_double), value :: gz_scale, dt, top_value
+    end function
+    integer(c_int) function fv3_zh_from_delz(ctx, zs, delz, zh) bind(C, name="fv3_zh_from_delz")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx, zs, delz, zh
+    end function
+    integer(c_int) function fv3_pk3_halo(ctx, ptop, akap, pk3, delp, use_logp) bind(C, name="fv3_pk3_halo")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, pk3, delp
+      real(c_double), value :: ptop, akap
+      integer(c_int), value :: use_logp
+    end function
+    integer(c_int) function fv3_pe_halo(ctx, ptop, pe, delp) bind(C, name="fv3_pe_halo")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, pe, delp
+      real(c_double), value :: ptop
+    end function
+    integer(c_int) function fv3_geopk(ctx, ptop, akap, cp_air, ptk, pe, peln, delp, pk, gz, hs, pt, pkz, cg) &
+        bind(C, name="fv3_geopk")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, pe, peln, delp, pk, gz, hs, pt, pkz
+      real(c_double), value :: ptop, akap, cp_air, ptk
+      integer(c_int), value :: cg
+    end function
+    integer(c_int) function fv3_set_ak_bk(ctx, ak, bk) bind(C, name="fv3_set_ak_bk")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), intent(in) :: ak(*), bk(*)    ! host, npz+1
+    end function
+    integer(c_int) function fv3_lagrangian_to_eulerian(ctx, p, kord_tr, ps, pe, delp, pkz, pk, u, v, w, delz, pt, q, &
+                                                       peln, omga, ws) bind(C, name="fv3_lagrangian_to_eulerian")
+      import :: c_int, c_ptr, fv3_remap_params
+      type(c_ptr), value :: ctx, ps, pe, delp, pkz, pk, u, v, w, delz, pt, q, peln, omga, ws
+      type(fv3_remap_params), intent(in) :: p
+      integer(c_int), intent(in) :: kord_tr(*)      ! host, nq
+    end function
+    integer(c_int) function fv3_tracer_2d_prep(ctx, q_split, cx, cy, xfx, yfx, cmax) bind(C, name="fv3_tracer_2d_prep")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, cx, cy, xfx, yfx
+      integer(c_int), value :: q_split
+      real(c_double), intent(out) :: cmax(*)        ! host, npz
+    end function
+    integer(c_int) function fv3_tracer_2d_scale(ctx, frac, cx, xfx, mfx, cy, yfx, mfy) bind(C, name="fv3_tracer_2d_scale")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, cx, xfx, mfx, cy, yfx, mfy
+      real(c_double), intent(in) :: frac(*)         ! host, npz
+    end function
+    integer(c_int) function fv3_tracer_2d_step(ctx, it, nsplt, ksplt, nq, hord, nord_tr, trdm, q, q_out, dp1, dp1_out, &
+                                               mfx, mfy, cx, cy, xfx, yfx) bind(C, name="fv3_tracer_2d_step")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, q, q_out, dp1, dp1_out, mfx, mfy, cx, cy, xfx, yfx
+      integer(c_int), value :: it, nsplt, nq, hord, nord_tr
+      integer(c_int), intent(in) :: ksplt(*)        ! host, npz
+      real(c_double), value :: trdm
     end function
   end interface
 

@@ -14,9 +14,11 @@ MOD = os.path.join(ROOT, "gfdl_atmos_cubed_sphere_amd", "fortran", "fv3_mi355x_m
 def test_bindings_cover_the_header():
     src = open(MOD).read()
     bound = set(re.findall(r'bind\(C, name="(fv3_[a-z0-9_]+)"\)', src))
-    for need in ("fv3_create", "fv3_grid_upload", "fv3_c_sw", "fv3_d_sw", "fv3_fv_tp_2d", "fv3_dsw_levels_upload",
-                 "fv3_halo_fill_periodic", "fv3_malloc", "fv3_memcpy_h2d", "fv3_memcpy_d2h"):
-        assert need in bound, need
+    hdr = open(os.path.join(ROOT, "include", "fv3_mi355x.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*(fv3_[a-z0-9_]+)\(", hdr, flags=re.M))
+    # everything the header declares is bound, except the two profiling helpers and memset (host-tool only)
+    missing = declared - bound - {"fv3_profile", "fv3_profile_report", "fv3_memset"}
+    assert not missing, missing
 
 
 def test_module_compiles(tmp_path):
