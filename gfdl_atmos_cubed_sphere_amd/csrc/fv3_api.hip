@@ -648,6 +648,108 @@ extern "C" int fv3_halo_fill_periodic(fv3_ctx *c, double *field, int kind, int n
   return 0;
 }
 
+// ---- multi-rank halo exchange: pack / unpack ---------------------------------------------------------
+struct HaloStrip {  // one (message, field) pair
+  double *field;
+  long buf_off;             // element offset of this field's strip inside the message buffer
+  int i0, ni, j0, nj;       // strip origin (array indices) and extent
+  int pitch, slab, nk, dir; // array leading dimension, k-slab size, levels, message index
+};
+struct HaloCopy {
+  HaloStrip st[8 * FV3_HALO_MAX_FIELDS];
+  double *buf[8];
+  int pack;  // 1: field -> buffer, 0: buffer -> field
+  static constexpr int CH = 2048;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const HaloStrip &s = st[bz];
+    const long n = (long)s.ni * s.nj * s.nk;
+    double *b = buf[s.dir] + s.buf_off;
+    for (long idx = (long)bx * CH + tid; idx < (long)(bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = (int)(idx % s.ni), j = (int)((idx / s.ni) % s.nj), k = (int)(idx / ((long)s.ni * s.nj));
+      double *f = s.field + (size_t)k * s.slab + (size_t)(s.j0 + j) * s.pitch + (s.i0 + i);
+      if (pack) b[idx] = *f; else *f = b[idx];
+    }
+  }
+};
+
+// index ranges along one direction (Fortran indices), off = -1, 0, +1; s = stagger of that direction
+static void halo_range(int lo, int hi, int s, int off, bool send, int &a, int &b) {
+  if (off == 0) { a = lo; b = hi + s; return; }
+  if (send) {
+    if (off < 0) { a = lo + s; b = lo + s + NG - 1; } else { a = hi - NG + 1; b = hi; }
+  } else {
+    if (off < 0) { a = lo - NG; b = lo - 1; } else { a = hi + s + 1; b = hi + s + NG; }
+  }
+}
+
+static int halo_build(fv3_ctx *c, int nfields, const fv3_halo_field *fields, bool pack, HaloCopy &hc, size_t elems[8],
+                      long &maxn) {
+  if (!c || !c->grid_ready) return fail("fv3_halo: context has no grid");
+  if (nfields < 1 || nfields > FV3_HALO_MAX_FIELDS) return fail("fv3_halo: 1..%d fields per group", FV3_HALO_MAX_FIELDS);
+  const Grid &g = c->g;
+  if (g.nx < NG + 1 || g.ny < NG + 1) return fail("fv3_halo: block smaller than the halo");
+  maxn = 0;
+  int n = 0, d = 0;
+  for (int dj = -1; dj <= 1; dj++)
+    for (int di = -1; di <= 1; di++) {
+      if (di == 0 && dj == 0) continue;
+      long off = 0;
+      for (int f = 0; f < nfields; f++) {
+        const int kind = fields[f].kind;
+        if (kind < 0 || kind > 3 || !fields[f].field) return fail("fv3_halo: bad field %d", f);
+        const int si = (kind == 2 || kind == 3) ? 1 : 0, sj = (kind == 1 || kind == 3) ? 1 : 0;
+        int ia, ib, ja, jb;
+        // pack: the send strip of side d; unpack: message d fills the halo of side -d
+        halo_range(g.is, g.ie, si, pack ? di : -di, pack, ia, ib);
+        halo_range(g.js, g.je, sj, pack ? dj : -dj, pack, ja, jb);
+        HaloStrip &s = hc.st[n++];
+        s.field = fields[f].field;
+        s.buf_off = off;
+        s.i0 = ia - g.isd; s.ni = ib - ia + 1;
+        s.j0 = ja - g.jsd; s.nj = jb - ja + 1;
+        s.pitch = g.nid + si;
+        s.slab = (g.nid + si) * (g.njd + sj);
+        s.nk = fields[f].nk;
+        s.dir = d;
+        const long cnt = (long)s.ni * s.nj * s.nk;
+        if (cnt > maxn) maxn = cnt;
+        off += cnt;
+      }
+      elems[d++] = (size_t)off;
+    }
+  hc.pack = pack ? 1 : 0;
+  return 0;
+}
+
+extern "C" int fv3_halo_message_elems(fv3_ctx *c, int nfields, const fv3_halo_field *fields, size_t elems[8]) {
+  HaloCopy hc;
+  long maxn;
+  return halo_build(c, nfields, fields, true, hc, elems, maxn);
+}
+
+static int halo_copy(fv3_ctx *c, int nfields, const fv3_halo_field *fields, double *const buf[8], bool pack) {
+  HaloCopy hc;
+  size_t elems[8];
+  long maxn;
+  if (halo_build(c, nfields, fields, pack, hc, elems, maxn)) return 1;
+  for (int d = 0; d < 8; d++) {
+    if (!buf[d]) return fail("fv3_halo: null message buffer %d", d);
+    hc.buf[d] = buf[d];
+  }
+  Dim3 grid;
+  grid.x = (unsigned)((maxn + HaloCopy::CH - 1) / HaloCopy::CH);
+  grid.y = 1;
+  grid.z = (unsigned)(8 * nfields);
+  RT(launch_p(c, pack ? "halo_pack" : "halo_unpack", grid, 0, hc));
+  return 0;
+}
+extern "C" int fv3_halo_pack(fv3_ctx *c, int nfields, const fv3_halo_field *fields, double *const sendbuf[8]) {
+  return halo_copy(c, nfields, fields, sendbuf, true);
+}
+extern "C" int fv3_halo_unpack(fv3_ctx *c, int nfields, const fv3_halo_field *fields, const double *const recvbuf[8]) {
+  return halo_copy(c, nfields, fields, const_cast<double *const *>(recvbuf), false);
+}
+
 // ================================================================================================
 // nonhydrostatic column path
 // ================================================================================================

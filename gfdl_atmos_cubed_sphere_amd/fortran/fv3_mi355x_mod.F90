@@ -14,6 +14,7 @@ module fv3_mi355x_mod
   public :: fv3_update_dz_d, fv3_riem_solver3, fv3_p_grad_c, fv3_nh_p_grad, fv3_zh_from_delz, fv3_pk3_halo
   public :: fv3_pe_halo, fv3_geopk, fv3_set_ak_bk, fv3_lagrangian_to_eulerian, fv3_tracer_2d_prep
   public :: fv3_tracer_2d_scale, fv3_tracer_2d_step
+  public :: fv3_halo_field, fv3_halo_message_elems, fv3_halo_pack, fv3_halo_unpack
 
   type, bind(C) :: fv3_domain
     integer(c_int) :: is, ie, js, je, ng, npx, npy, npz, grid_type
@@ -40,6 +41,11 @@ module fv3_mi355x_mod
   type, bind(C) :: fv3_dsw_levels     ! host arrays of length npz (dyn_core.F90:666-733)
     type(c_ptr) :: nord_k, nord_v, nord_w, nord_t
     type(c_ptr) :: d2_divg, damp_vt, damp_w, damp_t, d_con_k
+  end type
+
+  type, bind(C) :: fv3_halo_field     ! one field of a halo-update group (kind 0=A, 1=U, 2=V, 3=B)
+    type(c_ptr) :: field
+    integer(c_int) :: kind, nk
   end type
 
   type, bind(C) :: fv3_nh_consts      ! FMS constants_mod values + namelist scalars
@@ -135,6 +141,27 @@ module fv3_mi355x_mod
     function fv3_last_error() bind(C, name="fv3_last_error") result(msg)
       import :: c_ptr
       type(c_ptr) :: msg
+    end function
+    integer(c_int) function fv3_halo_message_elems(ctx, nfields, fields, elems) bind(C, name="fv3_halo_message_elems")
+      import :: c_int, c_ptr, c_size_t, fv3_halo_field
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nfields
+      type(fv3_halo_field), intent(in) :: fields(*)
+      integer(c_size_t), intent(out) :: elems(8)
+    end function
+    integer(c_int) function fv3_halo_pack(ctx, nfields, fields, sendbuf) bind(C, name="fv3_halo_pack")
+      import :: c_int, c_ptr, fv3_halo_field
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nfields
+      type(fv3_halo_field), intent(in) :: fields(*)
+      type(c_ptr), intent(in) :: sendbuf(8)
+    end function
+    integer(c_int) function fv3_halo_unpack(ctx, nfields, fields, recvbuf) bind(C, name="fv3_halo_unpack")
+      import :: c_int, c_ptr, fv3_halo_field
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nfields
+      type(fv3_halo_field), intent(in) :: fields(*)
+      type(c_ptr), intent(in) :: recvbuf(8)
     end function
     ! ---- nonhydrostatic column path, vertical remap, tracer transport --------------------------------
     integer(c_int) function fv3_memcpy_d2d(ctx, dst, src, bytes) bind(C, name="fv3_memcpy_d2d")

@@ -112,10 +112,12 @@ def exchange_tensors(topo: HaloTopology, fields, dist=None):
 class HaloExchanger:
     """Device-side exchanger bound to a lib.Context (GPU)."""
 
-    def __init__(self, ctx, px: int, py: int, rank: int, world: int):
+    def __init__(self, ctx, px: int, py: int, rank: int, world: int, packed_single: bool = False):
         self.ctx, self.px, self.py, self.rank, self.world = ctx, px, py, rank, world
+        self.packed_single = packed_single  # one rank: run the pack/unpack kernels instead of the copy kernel
         self.topo = HaloTopology(ctx.bd, px, py, rank)
         self._views = {}
+        self._groups = {}
 
     def _tensor(self, dev):
         import torch
@@ -132,11 +134,46 @@ class HaloExchanger:
                 self._views[key] = torch.as_tensor(dev, device="cuda")
         return self._views[key]
 
+    def _group(self, fields):
+        """message buffers of one field group (cached): 8 send + 8 receive DeviceArrays and their tensor views"""
+        key = tuple((dev.ptr, kind, dev.shape) for dev, kind in fields)
+        grp = self._groups.get(key)
+        if grp is None:
+            elems = self.ctx.halo_message_elems(fields)
+            from .lib import DeviceArray
+            send = [DeviceArray(self.ctx, (n,)) for n in elems]
+            recv = []
+            for n, d in zip(elems, DIRECTIONS):
+                # a rank that is its own neighbour in direction d reads back what it packed
+                recv.append(send[DIRECTIONS.index(d)] if self.topo.neighbour(*d) == self.rank else DeviceArray(self.ctx, (n,)))
+            grp = self._groups[key] = (send, recv, [self._tensor(b) for b in send], [self._tensor(b) for b in recv])
+        return grp
+
     def update(self, fields):
-        """fields: [(DeviceArray, kind)] -- one "pack"."""
-        if self.world == 1:
+        """fields: [(DeviceArray, kind)] -- one "pack" (the reference's group halo update).
+
+        One rank: periodic copy kernel per field.  Several ranks: ONE pack kernel for all fields and directions,
+        one send + one receive per neighbour offset (8 messages whatever the number of fields), ONE unpack
+        kernel.  Message d goes to the neighbour at offset d and is matched there by the receive posted for the
+        same d (from its neighbour at -d), posted in the same fixed order on both sides."""
+        if self.world == 1 and not self.packed_single:
             for dev, kind in fields:
                 self.ctx.halo_fill_periodic(dev, kind)
             return
         import torch.distributed as dist
-        exchange_tensors(self.topo, [(self._tensor(dev), kind) for dev, kind in fields], dist)
+        fields = list(fields)
+        for n in range(0, len(fields), 8):          # FV3_HALO_MAX_FIELDS per group
+            part = fields[n:n + 8]
+            send, recv, tsend, trecv = self._group(part)
+            self.ctx.halo_pack(part, send)
+            p2p = []
+            for m, d in enumerate(DIRECTIONS):
+                to, frm = self.topo.neighbour(*d), self.topo.neighbour(-d[0], -d[1])
+                if to == self.rank:
+                    continue
+                p2p.append(dist.P2POp(dist.isend, tsend[m], to))
+                p2p.append(dist.P2POp(dist.irecv, trecv[m], frm))
+            if p2p:
+                for w in dist.batch_isend_irecv(p2p):   # ncclGroupStart ... ncclGroupEnd on RCCL
+                    w.wait()
+            self.ctx.halo_unpack(part, recv)

@@ -31,7 +31,8 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 # every symbol include/fv3_mi355x.h declares (tests check the built library exports all of them)
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
-           "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_halo_fill_periodic", "fv3_profile", "fv3_profile_report",
+           "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
+           "fv3_halo_unpack", "fv3_profile", "fv3_profile_report",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
@@ -111,6 +112,10 @@ def load() -> Fv3Lib:
         # FV3_MI355X_SO selects another build of the same HIP library (e.g. a contraction-on build)
         _PRODUCT = Fv3Lib(os.environ.get("FV3_MI355X_SO", PRODUCT_SO))
     return _PRODUCT
+
+
+class HaloField(C.Structure):
+    _fields_ = [("field", C.POINTER(C.c_double)), ("kind", C.c_int), ("nk", C.c_int)]
 
 
 class DeviceArray:
@@ -382,6 +387,31 @@ class Context:
                                                        C.c_int(nq), C.c_int(hord), C.c_int(nord_tr), C.c_double(trdm),
                                                        q.p, q_out.p, dp1.p, dp1_out.p, mfx.p, mfy.p, cx.p, cy.p, xfx.p,
                                                        yfx.p), "fv3_tracer_2d_step")
+
+    # ---- multi-rank halo exchange: pack / unpack (the transfers are halo.py's) ---------------------------
+    def _halo_fields(self, fields):
+        arr = (HaloField * len(fields))()
+        for n, (dev, kind) in enumerate(fields):
+            arr[n].field = C.cast(_vp(dev.ptr), _dp)
+            arr[n].kind = {"A": 0, "U": 1, "V": 2, "B": 3}[kind]
+            arr[n].nk = int(np.prod(dev.shape[2:])) if len(dev.shape) > 2 else 1
+        return arr
+
+    def halo_message_elems(self, fields):
+        out = (C.c_size_t * 8)()
+        self.lib.check(self.lib.dll.fv3_halo_message_elems(self.h, C.c_int(len(fields)), self._halo_fields(fields), out),
+                       "fv3_halo_message_elems")
+        return [int(v) for v in out]
+
+    def halo_pack(self, fields, bufs):
+        ptrs = (_dp * 8)(*[b.p for b in bufs])
+        self.lib.check(self.lib.dll.fv3_halo_pack(self.h, C.c_int(len(fields)), self._halo_fields(fields), ptrs),
+                       "fv3_halo_pack")
+
+    def halo_unpack(self, fields, bufs):
+        ptrs = (_dp * 8)(*[b.p for b in bufs])
+        self.lib.check(self.lib.dll.fv3_halo_unpack(self.h, C.c_int(len(fields)), self._halo_fields(fields), ptrs),
+                       "fv3_halo_unpack")
 
     def halo_fill_periodic(self, field: DeviceArray, kind: str):
         code = {"A": 0, "U": 1, "V": 2, "B": 3}[kind]

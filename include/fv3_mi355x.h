@@ -139,6 +139,24 @@ int fv3_d_sw(fv3_ctx *ctx, const fv3_dsw_params *p, double *delpc, const double 
  * start/complete_group_halo_update (tools/fv_mp_mod.F90:646-876).  kind: 0=A 1=U 2=V 3=B. */
 int fv3_halo_fill_periodic(fv3_ctx *ctx, double *field, int kind, int nk);
 
+/* Multi-rank halo exchange of a block-decomposed domain: pack / unpack kernels that replace the buffer side of
+ * mpp_update_domains (tools/fv_mp_mod.F90:646-876 group updates; FMS mpp_domains underneath).  Message d
+ * (0..7: the neighbour offsets (di,dj), dj = -1,0,1 outer, di = -1,0,1 inner, (0,0) skipped) carries, for every
+ * field of the group, the 3-wide interior strip adjacent to the d-side boundary; it is received into the halo of
+ * the opposite side (-d) of the neighbour at offset d.  fv3_halo_message_elems gives the length of each message;
+ * pack fills the 8 send buffers from the fields, unpack scatters the 8 received buffers into the halos (message
+ * d lands in the (-d)-side halo).  The transfers themselves are the caller's (RCCL send/recv, see halo.py).
+ * kind: 0 = A (CENTER), 1 = U (y-staggered), 2 = V (x-staggered), 3 = B (CORNER); the staggered edge row /
+ * column ie+1 / je+1 belongs to its owner and is never overwritten. */
+#define FV3_HALO_MAX_FIELDS 8
+typedef struct fv3_halo_field {
+  double *field;
+  int kind, nk;
+} fv3_halo_field;
+int fv3_halo_message_elems(fv3_ctx *ctx, int nfields, const fv3_halo_field *fields, size_t elems[8]);
+int fv3_halo_pack(fv3_ctx *ctx, int nfields, const fv3_halo_field *fields, double *const sendbuf[8]);
+int fv3_halo_unpack(fv3_ctx *ctx, int nfields, const fv3_halo_field *fields, const double *const recvbuf[8]);
+
 /* ---- nonhydrostatic column path --------------------------------------------------------------------
  * Physical constants live in FMS constants_mod (not part of the reference tree); the caller passes them. */
 typedef struct fv3_nh_consts {

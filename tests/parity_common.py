@@ -231,3 +231,27 @@ def check_halo_periodic(lib, nx=21, ny=10, nk=3):
             assert np.array_equal(got, ref), kind
     finally:
         ctx.close()
+
+
+def check_halo_packed(lib, nx=20, ny=12, nk=3):
+    """pack -> (self messages) -> unpack on one rank == the periodic fill"""
+    from gfdl_atmos_cubed_sphere_amd.halo import HaloExchanger
+    bd = Bounds(1, nx, 1, ny)
+    g = make_grid(bd, False)
+    ctx = Context(g, nk, lib=lib)
+    try:
+        halo = HaloExchanger(ctx, 1, 1, 0, 1, packed_single=True)
+        rng = np.random.default_rng(4)
+        fields, exps = [], []
+        for kind in ("A", "U", "V", "B"):
+            a = np.asfortranarray(rng.uniform(-1, 1, bd.shape(kind, nk)))
+            e = a.copy(order="F")
+            for k in range(nk):
+                periodic_fill(bd, e[:, :, k], kind)
+            fields.append((ctx.from_host(a), kind))
+            exps.append(e)
+        halo.update(fields)
+        for (f, kind), e in zip(fields, exps):
+            np.testing.assert_array_equal(f.download(), e, err_msg=kind)
+    finally:
+        ctx.close()

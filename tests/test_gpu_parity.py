@@ -235,3 +235,7 @@ def test_update_dz_d_and_tracers_multi_strip_march(prod):
     N.check_update_dz_d(prod, nx=130, ny=100, km=3)
     T.check_tracer_2d(prod, nx=130, ny=100, npz=3, nq=2)
     T.check_tracer_2d(prod, nx=70, ny=60, npz=3, nq=2, big_courant=True)
+
+
+def test_halo_pack_unpack_kernels(prod):
+    P.check_halo_packed(prod)

@@ -91,3 +91,54 @@ def test_multi_rank_gloo(world):
     ok = mp.get_context("spawn").Array("i", [0] * world)
     mp.spawn(_worker, args=(world, port, 8, 6, 3, ok), nprocs=world, join=True)
     assert list(ok) == [1] * world
+
+
+def _worker_packed(rank, world, port, nx, ny, nk, ok, so):
+    """the product path: pack kernel -> 8 grouped messages -> unpack kernel (host-emulation build of the kernels)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gfdl_atmos_cubed_sphere_amd.grid import doubly_periodic
+        from gfdl_atmos_cubed_sphere_amd.halo import HaloExchanger
+        from gfdl_atmos_cubed_sphere_amd.lib import Context, Fv3Lib
+        px, py = choose_layout(world)
+        ix, iy = rank % px, rank // px
+        bd = Bounds(1 + ix * nx, (ix + 1) * nx, 1 + iy * ny, (iy + 1) * ny)
+        ctx = Context(doubly_periodic(bd, nx * px + 1, ny * py + 1), nk, lib=Fv3Lib(so))
+        halo = HaloExchanger(ctx, px, py, rank, world)
+        fields, exps = [], []
+        for n, kind in enumerate(["A", "U", "V", "B", "A"]):
+            levels = nk + (1 if n == 4 else 0)          # mixed level counts in one group
+            G = _global_field(nx * px, ny * py, levels, kind, 10 + n)
+            exp = _local_expected(G, bd, kind, nx * px, ny * py)
+            a = np.asfortranarray(exp.copy())
+            si, sj = _STAG[kind]
+            mask = np.zeros(a.shape[:2], bool)
+            mask[3:3 + nx + si, 3:3 + ny + sj] = True
+            a[~mask] = -777.0
+            fields.append((ctx.from_host(a), kind))
+            exps.append(exp)
+        halo.update(fields[:2])
+        halo.update(fields[2:])
+        halo.update(fields[:2])                         # cached group buffers are reused
+        good = all(np.array_equal(f.download(), e) for (f, _), e in zip(fields, exps))
+        ok[rank] = 1 if good else 0
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_packed_exchange(world):
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(here, "hostemu")])
+    so = os.path.join(here, "hostemu", "libfv3_hostemu.so")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ok = mp.get_context("spawn").Array("i", [0] * world)
+    mp.spawn(_worker_packed, args=(world, port, 8, 6, 3, ok, so), nprocs=world, join=True)
+    assert list(ok) == [1] * world

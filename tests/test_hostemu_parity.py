@@ -181,3 +181,7 @@ def test_update_dz_d_and_tracers_multi_strip_march(emu):
     N.check_update_dz_d(emu, nx=130, ny=100, km=3)
     T.check_tracer_2d(emu, nx=130, ny=100, npz=3, nq=2)
     T.check_tracer_2d(emu, nx=70, ny=60, npz=3, nq=2, big_courant=True)
+
+
+def test_halo_pack_unpack_kernels(emu):
+    P.check_halo_packed(emu)
