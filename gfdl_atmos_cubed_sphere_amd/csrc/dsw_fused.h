@@ -1,0 +1,231 @@
+// dsw_fused.h -- the d_sw transports of delp, w and pt in ONE marching kernel (sw_core.F90:908-1066, :1249-1283).
+//
+// The per-field kernels of dsw_march.h re-read the Courant numbers / area fluxes for every field and pass the
+// mass fluxes through a scratch pair: 272 B of HBM traffic per cell-update for the three transports.  Here one
+// wavefront carries the three fv_tp_2d marches side by side, so every input row is read once and the mass fluxes
+// stay in registers: delp, w, pt, crx, xfx, cry, yfx, mfx, mfy in; delp, w, pt, mfx, mfy (+ zeroed heat_source,
+// diss_est) out = 128 B per cell-update (the algorithmic figure of SURVEY section 8d).  The price is registers:
+// the three marches need ~100 live doubles per lane, so the kernel runs at one or two wavefronts per SIMD and
+// relies on the three independent instruction streams (and one-row-ahead loads) for latency hiding.
+// Used when hord_dp == hord_vt == hord_tm, use_cond = .false.; otherwise the per-field kernels run.
+#pragma once
+
+#include "dsw_march.h"
+
+namespace fv3 {
+
+// what the three marches share at one step
+struct Tp2dShared {
+  vd cx, xf, ar, rax;   // row r: crx, xfx, area, ra_x = area + xfx(i) - xfx(i+1)
+  vd cy, yf;            // face r-2: cry, yfx
+  vd arj, cxj, ray;     // row r-3: area, crx, ra_y = area + yfx(j) - yfx(j+1)
+};
+
+// per-field register state of one fv_tp_2d march (same pipeline as Tp2dState::step)
+template <int HORD>
+struct Tp2dField {
+  static constexpr int ORD_IN = (HORD == 10) ? 8 : HORD;
+  static constexpr int ORD_OU = HORD;
+  PpmY<ORD_IN> ya;
+  PpmY<ORD_OU> yb;
+  vd fx2_0, fx2_1, fx2_2, fx2_3;
+  vd fy2y_prev, fyv_prev;
+  FV3_D void init() {
+    ya.init();
+    yb.init();
+    fx2_0 = fx2_1 = fx2_2 = fx2_3 = vd(0.);
+    fy2y_prev = fyv_prev = vd(0.);
+  }
+  FV3_D void step(const vd &qn, const Tp2dShared &sh, bool have_face, bool have_row, vd &fxv, vd &fyv0, vd &fyv1) {
+    fx2_3 = fx2_2; fx2_2 = fx2_1; fx2_1 = fx2_0;
+    fx2_0 = ppm_faces_x<ORD_IN>(qn, sh.cx);
+    const vd t = sh.xf * fx2_0;
+    const vd qj = (qn * sh.ar + t - shl1(t)) / sh.rax;
+    ya.push(qn);
+    yb.push(qj);
+    if (!have_face) return;
+    const vd fy2 = ya.face(sh.cy);
+    const vd fyo = yb.face(sh.cy);
+    const vd fy2y = sh.yf * fy2;
+    const vd fyv = 0.5 * (fyo + fy2);
+    fyv1 = fyv;
+    if (have_row) {
+      const vd qi = (ya.row_m3() * sh.arj + fy2y_prev - fy2y) / sh.ray;
+      const vd fxo = ppm_faces_x<ORD_OU>(qi, sh.cxj);
+      fxv = 0.5 * (fxo + fx2_3);
+      fyv0 = fyv_prev;
+    }
+    fy2y_prev = fy2y;
+    fyv_prev = fyv;
+  }
+};
+
+// COURANT: the kernel also does DswCourant's work (sw_core.F90:850-902, :923-936): Courant numbers / area fluxes are
+// formed from uc, vc on the fly, used, and stored for the later consumers (crx, xfx, cry, yfx; cx, cy accumulated).
+template <int HORD, bool NH, bool COURANT>
+struct DswTransportFused {
+  Grid g;
+  DswArgs a;
+  MarchDims md;
+
+  struct In {  // everything one step reads
+    vd dp, w, pt;          // row r
+    vd ar, cx, xf;         // row r (COURANT: cx = uc row, xf unused)
+    vd cy, yf;             // face r-2 (COURANT: cy = vc row)
+    vd xfj, mx, my0, ra;   // row r-3: xfx, mfx, mfy, rarea
+    // COURANT only: metric rows and the accumulators
+    vd rdxa, dyr, sg3, sg1, cxa;       // row r: rdxa, dy, sin_sg(.,3), sin_sg(.,1); cx
+    vd rdya0, rdya1, dxr, sg4, sg2, cya;  // face r-2: rdya(j-1), rdya(j), dx, sin_sg(j-1,4), sin_sg(j,2); cy
+  };
+
+  FV3_D void operator()(int gid) const {
+    const int strip = gid % md.nstrips, seg = (gid / md.nstrips) % md.nsegs, kk = gid / (md.nstrips * md.nsegs);
+    const int k = md.klist ? md.klist[kk] : kk;
+    const StripGeom s = make_strip(g, strip);
+    const int ilo = s.ilo;
+    const int jA = g.js + seg * md.tj;
+    const int jB = (jA + md.tj - 1 < g.je) ? jA + md.tj - 1 : g.je;
+    const int rlast = jB + 3;
+    const int lFx1 = (ilo + s.lC1 == g.ie) ? s.lC1 + 1 : s.lC1;
+    const vl Fx = make_lanes(s.lC0, lFx1);
+    const size_t oA = (size_t)k * g.nA(), oCX = (size_t)k * g.nCX(), oCY = (size_t)k * g.nCY();
+    const size_t oFX = (size_t)k * g.nFX(), oFY = (size_t)k * g.nFY(), oCC = (size_t)k * g.nCC();
+    const double *delp = a.delp + oA, *pt = a.pt + oA, *w = NH ? a.w + oA : nullptr;
+    double *crx = a.crx + oCX, *xfx = a.xfx + oCX, *cry = a.cry + oCY, *yfx = a.yfx + oCY;
+    double *mfx = a.mfx + oFX, *mfy = a.mfy + oFY;
+    // COURANT: rows / columns of the Courant arrays this wavefront stores (the segment's own rows plus the halo rows
+    // at the south / north end of the tile; the strip's own faces plus the halo columns at the west / east end)
+    const int seg_last = (jB == g.je);
+    const int rowA = (seg == 0) ? g.jsd : jA, rowB = seg_last ? g.jed : jB;
+    const int lY0 = (strip == 0) ? s.lA0 : s.lC0, lY1 = (ilo + s.lC1 == g.ie) ? s.lA1 : s.lC1;
+    const double dt = a.dt;
+
+    auto load_in = [&](int r) {
+      In in;
+      const long iA = (long)g.iA(ilo, r), iCX = (long)g.iCX(ilo, r);
+      in.dp = vload(delp, iA, s.A);
+      in.pt = vload(pt, iA, s.A);
+      in.w = NH ? vload(w, iA, s.A) : vd(0.);
+      in.ar = vload(g.area, iA, s.A);
+      const int jf = (r - 2 < jA) ? jA : r - 2, j = (r - 3 < jA) ? jA : r - 3;
+      const long iCY = (long)g.iCY(ilo, jf);
+      if (COURANT) {
+        const long nAp = (long)g.nA();
+        in.cx = vload(a.uc + (size_t)k * g.nV(), (long)g.iV(ilo, r), s.A);
+        in.rdxa = vload(g.rdxa, iA, s.A);
+        in.dyr = vload(g.dy, (long)g.iV(ilo, r), s.A);
+        in.sg3 = vload(g.sin_sg + 2 * nAp, iA, s.A);
+        in.sg1 = vload(g.sin_sg, iA, s.A);
+        in.cxa = vload(a.cx + oCX, iCX, s.F);
+        const long iAf = (long)g.iA(ilo, jf), iAm = (long)g.iA(ilo, jf - 1), iUf = (long)g.iU(ilo, jf);
+        in.cy = vload(a.vc + (size_t)k * g.nU(), iUf, s.A);
+        in.rdya0 = vload(g.rdya, iAm, s.A);
+        in.rdya1 = vload(g.rdya, iAf, s.A);
+        in.dxr = vload(g.dx, iUf, s.A);
+        in.sg4 = vload(g.sin_sg + 3 * nAp, iAm, s.A);
+        in.sg2 = vload(g.sin_sg + nAp, iAf, s.A);
+        in.cya = vload(a.cy + oCY, iCY, s.A);
+      } else {
+        in.cx = vload(crx, iCX, s.F);
+        in.xf = vload(xfx, iCX, s.F);
+        in.cy = vload(cry, iCY, s.A);
+        in.yf = vload(yfx, iCY, s.A);
+        in.xfj = vload(xfx, (long)g.iCX(ilo, j), s.F);
+      }
+      in.mx = vload(mfx, (long)g.iFX(ilo, j), Fx);
+      in.my0 = vload(mfy, (long)g.iFY(ilo, j), s.C);
+      in.ra = vload(g.rarea, (long)g.iA(ilo, j), s.C);
+      return in;
+    };
+
+    Tp2dField<HORD> fd, fw, fp;  // delp, w, pt
+    fd.init();
+    fp.init();
+    if (NH) fw.init();
+    vd ar_1(1.), ar_2(1.), ar_3(1.), cx_1(0.), cx_2(0.), cx_3(0.);  // area / crx of rows r-1 .. r-3
+    vd xf_1(0.), xf_2(0.), xf_3(0.);                                 // COURANT: xfx of rows r-1 .. r-3
+    vd yf_prev(0.), fym_prev(0.);
+    In nxt = load_in(jA - 3);
+    for (int r = jA - 3; r <= rlast; r++) {
+      const In in = nxt;
+      nxt = load_in(r < rlast ? r + 1 : rlast);
+      const int j = r - 3;
+      const bool have_face = r - 2 >= jA, have_row = j >= jA;
+      Tp2dShared sh;
+      vd xfj = in.xfj;
+      if (COURANT) {
+        // x faces of row r (sw_core.F90:865, :882-888, :923-927)
+        const vd x = dt * in.cx;
+        const vb xpos = x > 0.;
+        sh.cx = vsel(xpos, x * shr1(in.rdxa), x * in.rdxa);
+        sh.xf = vsel(xpos, in.dyr * x * shr1(in.sg3), in.dyr * x * in.sg1);
+        if (r >= rowA && r <= rowB) {
+          const long iCX = (long)g.iCX(ilo, r);
+          vstore(crx, iCX, sh.cx, s.lC0, lFx1);
+          vstore(xfx, iCX, sh.xf, s.lC0, lFx1);
+          vstore(a.cx + oCX, iCX, in.cxa + sh.cx, s.lC0, lFx1);
+        }
+        // y faces of row r-2 (:894-900, :933-936)
+        const vd y = dt * in.cy;
+        const vb ypos = y > 0.;
+        sh.cy = vsel(ypos, y * in.rdya0, y * in.rdya1);
+        sh.yf = vsel(ypos, in.dxr * y * in.sg4, in.dxr * y * in.sg2);
+        const int jf = r - 2;
+        if (jf >= jA && (jf <= jB || (seg_last && jf == g.je + 1))) {
+          const long iCY = (long)g.iCY(ilo, jf);
+          vstore(cry, iCY, sh.cy, lY0, lY1);
+          vstore(yfx, iCY, sh.yf, lY0, lY1);
+          vstore(a.cy + oCY, iCY, in.cya + sh.cy, lY0, lY1);
+        }
+        xfj = xf_3;
+        xf_3 = xf_2; xf_2 = xf_1; xf_1 = sh.xf;
+      } else {
+        sh.cx = in.cx; sh.xf = in.xf;
+        sh.cy = in.cy; sh.yf = in.yf;
+      }
+      sh.ar = in.ar;
+      sh.rax = in.ar + sh.xf - shl1(sh.xf);
+      sh.arj = ar_3; sh.cxj = cx_3;
+      sh.ray = ar_3 + yf_prev - sh.yf;
+      ar_3 = ar_2; ar_2 = ar_1; ar_1 = in.ar;
+      cx_3 = cx_2; cx_2 = cx_1; cx_1 = sh.cx;
+      vd fxd, fyd0, fyd1, fxw, fyw0, fyw1, fxp, fyp0, fyp1;
+      fd.step(in.dp, sh, have_face, have_row, fxd, fyd0, fyd1);
+      if (NH) fw.step(in.w, sh, have_face, have_row, fxw, fyw0, fyw1);
+      fp.step(in.pt, sh, have_face, have_row, fxp, fyp0, fyp1);
+      if (have_face) {
+        // mass flux through y-face r-2 (tp_core.F90:222-226); carried to the next row as its south face
+        const vd fym = fyd1 * sh.yf;
+        if (have_row) {
+          const vd fxm = fxd * xfj;  // tp_core.F90:217-221
+          const vd fym0 = fym_prev, fym1 = fym;
+          const long iFX = (long)g.iFX(ilo, j), iFY0 = (long)g.iFY(ilo, j), iA = (long)g.iA(ilo, j);
+          vstore(mfx, iFX, in.mx + fxm, s.lC0, lFx1);  // sw_core.F90:928-940
+          vstore(mfy, iFY0, in.my0 + fym0, s.lC0, s.lC1);
+          if (j == g.je) {
+            const long iFY1 = (long)g.iFY(ilo, j + 1);
+            vstore(mfy, iFY1, vload(mfy, iFY1, s.C) + fym1, s.lC0, s.lC1);
+          }
+          const vd dp = fd.ya.row_m3();
+          const vd dpn = dp + (fxm - shl1(fxm) + fym0 - fym1) * in.ra;
+          vstore(a.delp_out + oA, iA, dpn, s.lC0, s.lC1);
+          {  // pt (sw_core.F90:1053-1066)
+            const vd gx = fxp * fxm, gy0 = fyp0 * fym0, gy1 = fyp1 * fym1;
+            vstore(a.pt_out + oA, iA, (fp.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra) / dpn, s.lC0, s.lC1);
+          }
+          if (NH) {  // w (:985-989, :1262-1274)
+            const vd gx = fxw * fxm, gy0 = fyw0 * fym0, gy1 = fyw1 * fym1;
+            vstore(a.w_out + oA, iA, (fw.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra) / dpn, s.lC0, s.lC1);
+          }
+          const long iCC = (long)g.iCC(ilo, j);  // :943-948
+          vstore(a.heat_s + oCC, iCC, vd(0.), s.lC0, s.lC1);
+          vstore(a.diss_e + oCC, iCC, vd(0.), s.lC0, s.lC1);
+        }
+        fym_prev = fym;
+      }
+      if (have_face) yf_prev = sh.yf;
+    }
+  }
+};
+
+}  // namespace fv3

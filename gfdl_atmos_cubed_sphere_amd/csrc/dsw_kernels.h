@@ -41,9 +41,10 @@ struct DswArgs {
 struct DswCourant {
   Grid g;
   DswArgs a;
+  const int *klist;  // level of the bz-th slab, or null = identity
   static constexpr int CH = 1024;  // points per workgroup
   FV3_HD void operator()(int bx, int /*by*/, int bz, int tid, double * /*lds*/) const {
-    const int k = bz;
+    const int k = klist ? klist[bz] : bz;
     const double dt = a.dt;
     const size_t oV = (size_t)k * g.nV(), oU = (size_t)k * g.nU();
     const size_t oCX = (size_t)k * g.nCX(), oCY = (size_t)k * g.nCY();

@@ -11,6 +11,7 @@
 #include "csw_march.h"
 #include "dsw_kernels.h"
 #include "dsw_march.h"
+#include "dsw_fused.h"
 #include "fv3_common.h"
 #include "fv3_launch.h"
 #include "nh_kernels.h"
@@ -65,7 +66,8 @@ struct fv3_ctx {
   double *ke_scr;        // B kind, npz levels: KE + damping term at the corners
   double *mflux[2];      // mass-flux scratch of the marching transports: FX kind, FY kind (npz levels)
   int march_tj;          // rows per wavefront segment of the marching kernels
-  int march_tj_csw;
+  int march_tj_csw, march_tj_ke, march_tj_fused;
+  int use_fused;         // 1: delp + w + pt in one marching kernel when the schemes allow (FV3_MI355X_FUSED=0: off)
   int use_march;         // 0: LDS-tile kernels only (FV3_MI355X_MARCH=0)
   bool prof_on;
   struct ProfRec { const char *label; void *e0, *e1; };
@@ -188,6 +190,14 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_MARCH_TJ");
     c->march_tj = e ? std::atoi(e) : 48;
     if (c->march_tj < 1) c->march_tj = 48;
+    e = std::getenv("FV3_MI355X_FUSED");
+    c->use_fused = e ? std::atoi(e) : 1;
+    e = std::getenv("FV3_MI355X_MARCH_TJ_FUSED");
+    c->march_tj_fused = e ? std::atoi(e) : 48;
+    if (c->march_tj_fused < 1) c->march_tj_fused = 48;
+    e = std::getenv("FV3_MI355X_MARCH_TJ_KE");
+    c->march_tj_ke = e ? std::atoi(e) : 48;
+    if (c->march_tj_ke < 1) c->march_tj_ke = 48;
     e = std::getenv("FV3_MI355X_MARCH_TJ_CSW");
     c->march_tj_csw = e ? std::atoi(e) : 48;
     if (c->march_tj_csw < 1) c->march_tj_csw = 48;
@@ -508,6 +518,17 @@ static int dsw_transport_march(fv3_ctx *c, const DswArgs &a) {
   MarchDims md = make_march_dims(g, c->march_tj);
   md.klist = c->klist;
   const int nw = md.nwaves(c->n_plain);
+  if (c->use_fused && !a.use_cond && a.hord_dp == a.hord_tm && (a.hydrostatic || a.hord_dp == a.hord_vt)) {
+    if (c->n_plain == 0) return 0;
+    MarchDims mf = make_march_dims(g, c->march_tj_fused);
+    mf.klist = c->klist;
+    const int nwf = mf.nwaves(c->n_plain);
+    return dispatch_hord(a.hord_dp, [&](auto H) {
+      constexpr int HORD = decltype(H)::value;
+      if (a.hydrostatic) return launch_w(c, "d_sw_fused", nwf, DswTransportFused<HORD, false, true>{g, a, mf});
+      return launch_w(c, "d_sw_fused", nwf, DswTransportFused<HORD, true, true>{g, a, mf});
+    });
+  }
   double *fxs = c->mflux[0], *fys = c->mflux[1];
   int rc = dispatch_hord(a.hord_dp, [&](auto H) {
     DswDelpMarch<decltype(H)::value> kf{g, a, md, fxs, fys, 1};
@@ -529,16 +550,19 @@ static int dsw_transport_march(fv3_ctx *c, const DswArgs &a) {
 static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a) {
   const Grid &g = c->g;
   if (!c->ke_scr) RT(rt_malloc((void **)&c->ke_scr, sizeof(double) * g.nB() * g.npz));
+  MarchDims mk = make_march_dims(g, c->march_tj_ke);
+  mk.klist = c->klist_m;
+  const int nwk = mk.nwaves(c->n_plain_m);
+  int rc;
+  switch (sw_class(a.hord_mt)) {
+    case 5: rc = launch_w(c, "d_sw_ke", nwk, DswKeMarch<5>{g, a, mk, c->ke_scr}); break;
+    case 6: rc = launch_w(c, "d_sw_ke", nwk, DswKeMarch<6>{g, a, mk, c->ke_scr}); break;
+    default: rc = launch_w(c, "d_sw_ke", nwk, DswKeMarch<8>{g, a, mk, c->ke_scr}); break;
+  }
+  if (rc) return rc;
   MarchDims md = make_march_dims(g, c->march_tj);
   md.klist = c->klist_m;
   const int nw = md.nwaves(c->n_plain_m);
-  int rc;
-  switch (sw_class(a.hord_mt)) {
-    case 5: rc = launch_w(c, "d_sw_ke", nw, DswKeMarch<5>{g, a, md, c->ke_scr}); break;
-    case 6: rc = launch_w(c, "d_sw_ke", nw, DswKeMarch<6>{g, a, md, c->ke_scr}); break;
-    default: rc = launch_w(c, "d_sw_ke", nw, DswKeMarch<8>{g, a, md, c->ke_scr}); break;
-  }
-  if (rc) return rc;
   const double *ke = c->ke_scr;
   return dispatch_hord(a.hord_vt, [&](auto H) {
     DswVortMarch<decltype(H)::value> kf{g, a, md, ke};
@@ -577,13 +601,16 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, cons
   a.delp_out = delp_out; a.pt_out = pt_out; a.u_out = u_out; a.v_out = v_out; a.w_out = w_out;
   a.q_con_out = q_con_out; a.heat_s = heat_s; a.diss_e = diss_e; a.delpc = delpc;
 
-  {  // Courant numbers and area fluxes
-    DswCourant kf{g, a};
+  // the fused marching kernel forms the Courant numbers itself for its levels
+  const bool fused = c->use_march && c->use_fused && !a.use_cond && a.hord_dp == a.hord_tm &&
+                     (a.hydrostatic || a.hord_dp == a.hord_vt);
+  if (!fused || c->n_damp > 0) {  // Courant numbers and area fluxes
+    DswCourant kf{g, a, fused ? c->klist + c->n_plain : nullptr};
     const size_t nmax = g.nCX() > g.nCY() ? g.nCX() : g.nCY();
     Dim3 grid;
     grid.x = (unsigned)((nmax + DswCourant::CH - 1) / DswCourant::CH);
     grid.y = 1;
-    grid.z = (unsigned)npz;
+    grid.z = (unsigned)(fused ? c->n_damp : npz);
     RT(launch_p(c, "d_sw_courant", grid, 0, kf));
   }
   constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;

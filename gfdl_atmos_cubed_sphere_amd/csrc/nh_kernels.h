@@ -101,8 +101,18 @@ struct ColIn {
   double zscale;                       // dz2 = (zlev(k+1)-zlev(k)) * zscale   (1 for both; kept for clarity)
 };
 
+#ifdef FV3_HOST_EMU
+#define FV3_RESTRICT
+#define FV3_UNROLL4
+#else
+#define FV3_RESTRICT __restrict__
+#define FV3_UNROLL4 _Pragma("unroll 4")
+#endif
+// The scratch slabs never alias the inputs or each other: with that stated (and the k loops unrolled by 4) the
+// compiler issues the loads of the next levels ahead of the dependent recurrence instead of one level at a time.
 FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhConsts &cn, bool sim1, bool c_grid,
-                       double ws, double *s_gam, double *s_pp, double *s_w, double *s_pm) {
+                       double ws, double *FV3_RESTRICT s_gam, double *FV3_RESTRICT s_pp, double *FV3_RESTRICT s_w,
+                       double *FV3_RESTRICT s_pm) {
   constexpr double r3 = 1. / 3.;
   const double rgrav = 1. / cn.grav, rgas = cn.rdgas;
   const double gm2 = 1. / (1. - cn.akap), cp2 = cn.akap;
@@ -131,6 +141,7 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
   L(s_pm, 1) = pm_c;
   double bet = 0., pp_k = 0., g_rat_prev = 0.;
   L(s_pp, 1) = 0.;
+  FV3_UNROLL4
   for (int k = 1; k <= km; k++) {
     double dm_n = 0., dz_n = 0., pm_n = 0., pe_n = 0., pem_nn = 0., peln_nn = 0.;
     double bb, dd, g_rat = 0.;
@@ -162,6 +173,7 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
   // ---- pass B: back substitution (:1328-1332) ----
   {
     double pp_next = L(s_pp, km + 1);
+    FV3_UNROLL4
     for (int k = km; k >= 2; k--) {
       const double v = L(s_pp, k) - L(s_gam, k) * pp_next;
       L(s_pp, k) = v;
@@ -173,6 +185,7 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
     double pem = cn.ptop;                       // pem(k)
     double dz_prev = 0., w_prev = 0., w1_prev = 0., aa_k = 0., wk_k = 0.;
     double dm1 = 0.;
+    FV3_UNROLL4
     for (int k = 1; k <= km; k++) {
       const double dmr = L(in.delp, k), dm2 = dmr * rgrav;
       const double dz2 = L(in.zlev, k + 1) - L(in.zlev, k);
@@ -219,6 +232,7 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
   // ---- pass D: back substitution for w (:1357-1361) ----
   {
     double w_next = L(s_w, km);
+    FV3_UNROLL4
     for (int k = km - 1; k >= 1; k--) {
       const double v = L(s_w, k) - L(s_gam, k + 1) * w_next;
       L(s_w, k) = v;
@@ -230,6 +244,7 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
     double pe = 0.;
     double pp_k2 = L(s_pp, 1);
     // s_gam is free now: keep pp there for the final blend of SIM_solver (:1531-1535)
+    FV3_UNROLL4
     for (int k = 1; k <= km; k++) {
       const double dm2 = L(in.delp, k) * rgrav;
       const double pp_n = L(s_pp, k + 1);
@@ -248,6 +263,7 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
   {
     double p1 = (L(s_pp, km) + 2. * L(s_pp, km + 1)) * r3;
     double dm_below = 0.;
+    FV3_UNROLL4
     for (int k = km; k >= 1; k--) {
       const double dm2 = L(in.delp, k) * rgrav, pm2 = L(s_pm, k);
       if (k < km) {

@@ -69,7 +69,6 @@ inline MarchDims make_march_dims(const Grid &g, int tj) {
 struct MarchIn {
   vd qn, ar, cx, xf;  // row r:   q, area, crx, xfx
   vd cy, yf;          // face r-2: cry, yfx
-  vd arj, cxj;        // row r-3: area, crx
 };
 
 // The register state of one fv_tp_2d march.  step(r) consumes row r; have_face says that face r-2 is
@@ -83,16 +82,21 @@ struct Tp2dState {
   PpmY<ORD_OU> yb;
   vd fx2_0, fx2_1, fx2_2, fx2_3;  // fx2 of rows r, r-1, r-2, r-3
   vd fy2y_prev, yf_prev, fyv_prev;
+  vd ar_1, ar_2, ar_3, cx_1, cx_2, cx_3;  // area and crx of rows r-1, r-2, r-3 (read once, used again at r-3)
 
   FV3_D void init() {
     ya.init();
     yb.init();
     fx2_0 = fx2_1 = fx2_2 = fx2_3 = vd(0.);
     fy2y_prev = yf_prev = fyv_prev = vd(0.);
+    ar_1 = ar_2 = ar_3 = cx_1 = cx_2 = cx_3 = vd(1.);
   }
   FV3_D void step(const MarchIn &in, bool have_face, bool have_row, vd &fxv, vd &fyv0, vd &fyv1) {
     // ---- row r: inner x sweep and q_j --------------------------------------------------------------
     fx2_3 = fx2_2; fx2_2 = fx2_1; fx2_1 = fx2_0;
+    const vd arj = ar_3, cxj = cx_3;  // rows r-3 (valid once three rows have been consumed)
+    ar_3 = ar_2; ar_2 = ar_1; ar_1 = in.ar;
+    cx_3 = cx_2; cx_2 = cx_1; cx_1 = in.cx;
     fx2_0 = ppm_faces_x<ORD_IN>(in.qn, in.cx);
     const vd t = in.xf * fx2_0;
     const vd qj = (in.qn * in.ar + t - shl1(t)) / (in.ar + in.xf - shl1(in.xf));
@@ -106,8 +110,8 @@ struct Tp2dState {
     const vd fyv = 0.5 * (fyo + fy2);
     // ---- row j = r-3: q_i and the outer x sweep ---------------------------------------------------------
     if (have_row) {
-      const vd qi = (ya.row_m3() * in.arj + fy2y_prev - fy2y) / (in.arj + yf_prev - in.yf);
-      const vd fxo = ppm_faces_x<ORD_OU>(qi, in.cxj);
+      const vd qi = (ya.row_m3() * arj + fy2y_prev - fy2y) / (arj + yf_prev - in.yf);
+      const vd fxo = ppm_faces_x<ORD_OU>(qi, cxj);
       fxv = 0.5 * (fxo + fx2_3);
       fyv0 = fyv_prev;
       fyv1 = fyv;
@@ -127,12 +131,10 @@ FV3_D void march_load_metrics(MarchIn &in, const Grid &g, const StripGeom &s, in
   in.cx = vload(crx, oCX, s.F);
   in.xf = vload(xfx, oCX, s.F);
   // rows before the segment's first face / cell are clamped: loaded but never used
-  const int jf = (r - 2 < jA) ? jA : r - 2, j = (r - 3 < jA) ? jA : r - 3;
+  const int jf = (r - 2 < jA) ? jA : r - 2;
   const long oCY = (long)g.iCY(ilo, jf);
   in.cy = vload(cry, oCY, s.A);
   in.yf = vload(yfx, oCY, s.A);
-  in.arj = vload(g.area, (long)g.iA(ilo, j), s.A);
-  in.cxj = vload(crx, (long)g.iCX(ilo, j), s.F);
 }
 
 // Row source of a stored field q (A kind slab).
