@@ -33,14 +33,44 @@ inline MarchDims make_csw_dims(const Grid &g, int tj) {
   return d;
 }
 
+// metric rows one step reads (shared by the KPW levels a wavefront carries)
+struct CswMetrics {
+  vd cs, rs, cosau, rsinu, dy, sg3, sg1, dx, sg4, sg2, dxc, dyc, rac, fc;  // row R
+  vd ra, sinau, rdxc, cosav, sinav, rdyc;                                    // row Q
+};
+struct CswFields {
+  vd u, v, dp, pt, w;
+};
+
+// register state of one level
+struct CswLevel {
+  vd u0, u1, u2, u3;          // u(t-3 .. t)
+  vd v0, v1, v2, v3;          // v(t-4 .. t-1)
+  vd vt0, vt1, vt2, vt3;      // vtmp(t-4 .. t-1)
+  vd dp0, dpp, pt0, ptp, w0, wp;  // rows Q, Q+1
+  vd ua_p, va_p, uc_p, vc_p, ut_p, vt_p;  // row Q = t-3 (previous step's row R)
+  vd ucdx_p, vort_p, ke_p, vdxc_p;
+  vd fy1_p, fyp_p, fyw_p;     // upwind fluxes through y-face Q (delp, pt, w)
+  FV3_D void init() {
+    u0 = u1 = u2 = u3 = v0 = v1 = v2 = v3 = vt0 = vt1 = vt2 = vt3 = vd(0.);
+    dp0 = dpp = pt0 = ptp = w0 = wp = vd(0.);
+    ua_p = va_p = uc_p = vc_p = ut_p = vt_p = ucdx_p = vort_p = ke_p = vdxc_p = vd(0.);
+    fy1_p = fyp_p = fyw_p = vd(0.);
+  }
+};
+
+// KPW = levels per wavefront: the ~20 metric rows of a step are loaded once and used for KPW levels, which
+// cuts the L2 traffic per cell (the kernel is bound by it, not by HBM or VALU) at the price of registers.
+template <int KPW>
 struct CswMarch {
   Grid g;
   CswArgs a;
   MarchDims md;
+  int nkg;  // level groups = ceil(npz / KPW)
 
   FV3_D void operator()(int gid) const {
     constexpr double a1 = 0.5625, a2 = -0.0625;  // sw_core.F90:53-54
-    const int strip = gid % md.nstrips, seg = (gid / md.nstrips) % md.nsegs, k = gid / (md.nstrips * md.nsegs);
+    const int strip = gid % md.nstrips, seg = (gid / md.nstrips) % md.nsegs, kg = gid / (md.nstrips * md.nsegs);
     const int is = g.is, ie = g.ie, js = g.js, je = g.je;
     const int ilo = is - 1 + strip * kCswCols - 3;  // column of lane 0
     auto cl = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
@@ -50,9 +80,7 @@ struct CswMarch {
     const int l2 = cl(ie + 2 - ilo, 0, kW - 3), l1 = cl(ie + 1 - ilo, 0, kW - 3);  // last owned lane: i <= ie+2 / ie+1
     const int jA = js - 1 + seg * md.tj;
     const int jB = (jA + md.tj - 1 < je + 2) ? jA + md.tj - 1 : je + 2;
-    const size_t oA = (size_t)k * g.nA(), oU = (size_t)k * g.nU(), oV = (size_t)k * g.nV(), oB = (size_t)k * g.nB();
-    const double *u = a.u + oU, *v = a.v + oV, *delp = a.delp + oA, *pt = a.pt + oA;
-    const double *w = a.hydrostatic ? nullptr : a.w + oA;
+    const bool nh = !a.hydrostatic;
     const double dt2 = a.dt2, dt4 = 0.5 * dt2;
     const long nAp = (long)g.nA();  // one sin_sg plane
     // row loaders (row index clamped into the array; clamped rows are never used for a kept value)
@@ -63,30 +91,18 @@ struct CswMarch {
     const vb m_uc = lane_mask(is - ilo, ie + 1 - ilo);  // columns where uc is advanced (:414-447)
     const vb m_vc = lane_mask(is - ilo, ie - ilo);      // columns where vc is advanced (:452-486)
 
-    vd u0(0.), u1(0.), u2(0.), u3(0.);          // u(t-3 .. t)
-    vd v0(0.), v1(0.), v2(0.), v3(0.);          // v(t-4 .. t-1)
-    vd vt0(0.), vt1(0.), vt2(0.), vt3(0.);      // vtmp(t-4 .. t-1)
-    vd dp0(0.), dpp(0.), pt0(0.), ptp(0.), w0(0.), wp(0.);  // rows Q, Q+1
-    vd ua_p(0.), va_p(0.), uc_p(0.), vc_p(0.), ut_p(0.), vt_p(0.);  // row Q = t-3 (previous step's row R)
-    vd ucdx_p(0.), vort_p(0.), ke_p(0.), vdxc_p(0.);
-    vd fy1_p(0.), fyp_p(0.), fyw_p(0.);         // upwind fluxes through y-face Q (delp, pt, w)
-    // metric rows that are needed again one step later (row R becomes row Q)
-    vd cosau_p(0.), dxc_p(0.), dyc_p(0.), rac_p(0.);
-
-    // everything step t reads from memory; loaded one step ahead (software pipelining)
-    struct In {
-      vd u, v, dp, pt, w;
-      vd cs, rs, cosau, rsinu, dy, sg3, sg1, dx, sg4, sg2, dxc, dyc, rac, fc;  // row R
-      vd ra, sinau, rdxc, cosav, sinav, rdyc;                                    // row Q
-    };
-    auto load_step = [&](int t) {
+    // the levels of this wavefront (the last group may be short: the surplus slot repeats the last level and
+    // does not store)
+    int kl[KPW];
+    bool live[KPW];
+    for (int m = 0; m < KPW; m++) {
+      const int k = kg * KPW + m;
+      live[m] = k < g.npz;
+      kl[m] = live[m] ? k : g.npz - 1;
+    }
+    auto load_metrics = [&](int t) {
       const int R = t - 2, Q = t - 3;
-      In in;
-      in.u = LU(u, t);
-      in.v = LV(v, t - 1);
-      in.dp = LA(delp, R);
-      in.pt = LA(pt, R);
-      in.w = w ? LA(w, R) : vd(0.);
+      CswMetrics in;
       in.cs = LA(g.cosa_s, R);  in.rs = LA(g.rsin2, R);
       in.cosau = LV(g.cosa_u, R);  in.rsinu = LV(g.rsin_u, R);  in.dy = LV(g.dy, R);
       in.sg3 = LA(g.sin_sg + 2 * nAp, R, -1);  in.sg1 = LA(g.sin_sg, R);      // sin_sg(i-1,j,3), sin_sg(i,j,1)
@@ -98,89 +114,116 @@ struct CswMarch {
       in.cosav = LU(g.cosa_v, Q);  in.sinav = LU(g.sina_v, Q);  in.rdyc = LU(g.rdyc, Q);
       return in;
     };
-    In nxt = load_step(jA - 2);
+    auto load_fields = [&](int t, int k) {
+      const int R = t - 2;
+      CswFields f;
+      f.u = LU(a.u + (size_t)k * g.nU(), t);
+      f.v = LV(a.v + (size_t)k * g.nV(), t - 1);
+      f.dp = LA(a.delp + (size_t)k * g.nA(), R);
+      f.pt = LA(a.pt + (size_t)k * g.nA(), R);
+      f.w = nh ? LA(a.w + (size_t)k * g.nA(), R) : vd(0.);
+      return f;
+    };
+
+    CswLevel st[KPW];
+    for (int m = 0; m < KPW; m++) st[m].init();
+    // metric rows that are needed again one step later (row R becomes row Q)
+    vd cosau_p(0.), dxc_p(0.), dyc_p(0.), rac_p(0.);
+
+    // everything step t reads from memory is loaded one step ahead (software pipelining)
+    CswMetrics mnxt = load_metrics(jA - 2);
+    CswFields fnxt[KPW];
+    for (int m = 0; m < KPW; m++) fnxt[m] = load_fields(jA - 2, kl[m]);
     for (int t = jA - 2; t <= jB + 3; t++) {
       const int R = t - 2, Q = t - 3;
-      const In in = nxt;
-      nxt = load_step(t < jB + 3 ? t + 1 : t);
-      u0 = u1; u1 = u2; u2 = u3; u3 = in.u;
-      v0 = v1; v1 = v2; v2 = v3; v3 = in.v;
-      dp0 = dpp; dpp = in.dp;
-      pt0 = ptp; ptp = in.pt;
-      w0 = wp; wp = in.w;
-      // ---- row R: interpolated winds, fluxes, vorticity ----------------------------------------------------
-      const vd utmp = a2 * (u0 + u3) + a1 * (u1 + u2);                       // :3099-3103
-      const vd v3p = shl1(v3);
-      vt0 = vt1; vt1 = vt2; vt2 = vt3;
-      vt3 = a2 * (shr1(v3) + shl1(v3p)) + a1 * (v3 + v3p);                   // vtmp(t-1), :3104-3108
-            const vd ua = (utmp - vt2 * in.cs) * in.rs, va = (vt2 - utmp * in.cs) * in.rs;     // :3152-3157
-      const vd um1 = shr1(utmp);
-      const vd uc = a2 * (shr1(um1) + shl1(utmp)) + a1 * (um1 + utmp);       // :3197-3199
-      const vd vc = a2 * (vt0 + vt3) + a1 * (vt1 + vt2);                     // :3337-3339
-      vd ut = (uc - v2 * in.cosau) * in.rsinu;                 // :3200
-      ut = vsel(ut > 0., dt2 * ut * in.dy * in.sg3, dt2 * ut * in.dy * in.sg1);  // :159-167
-      const vd vt = vsel(vc > 0., dt2 * vc * in.dx * in.sg4, dt2 * vc * in.dx * in.sg2);  // :168-176 (vt = vc, :3340)
-      const vd ucdx = uc * in.dxc;
-      const vd vcdy = vc * in.dyc;
-      const vd vort = in.fc + in.rac * (ucdx_p - ucdx - shr1(vcdy) + vcdy);  // :372-403
-      if (R >= jA && R <= jB) {
-        const long iAr = (long)g.iA(ilo, R);
-        if (R <= je + 1) {
-          vstore(a.ua + oA, iAr, ua, l0, l1);
-          vstore(a.va + oA, iAr, va, l0, l1);
-          vstore(a.ut + oA, iAr, ut, l0, l2);
-        }
-        vstore(a.vt + oA, iAr, vt, l0, l1);
-      }
-      // ---- row Q: KE, transport, wind update, divergence -------------------------------------------------------
-      const vd ke = dt4 * (ua_p * vsel(ua_p > 0., uc_p, shl1(uc_p)) + va_p * vsel(va_p > 0., vc_p, vc));  // :297-366
-      // upwind fluxes through y-face Q+1 (= R) and x-face i (:182-286)
-      const vb vpos = vt > 0.;
-      const vd fy1_n = vt * vsel(vpos, dp0, dpp);
-      const vd fyp_n = fy1_n * vsel(vpos, pt0, ptp);
-      const vd fyw_n = w ? fy1_n * vsel(vpos, w0, wp) : vd(0.);
-      if (Q >= jA && Q <= jB) {
-        const long iAq = (long)g.iA(ilo, Q);
-        if (Q <= je + 1) {
-          const vb upos = ut_p > 0.;
-          const vd fx1 = ut_p * vsel(upos, shr1(dp0), dp0);
-          const vd fxp = fx1 * vsel(upos, shr1(pt0), pt0);
-          const vd ra = in.ra;
-          const vd dpc = dp0 + (fx1 - shl1(fx1) + fy1_p - fy1_n) * ra;
-          vstore(a.delpc + oA, iAq, dpc, l0, l1);
-          vstore(a.ptc + oA, iAq, (pt0 * dp0 + (fxp - shl1(fxp) + fyp_p - fyp_n) * ra) / dpc, l0, l1);
-          if (w) {
-            const vd fxw = fx1 * vsel(upos, shr1(w0), w0);
-            vstore(a.wc + oA, iAq, (w0 * dp0 + (fxw - shl1(fxw) + fyw_p - fyw_n) * ra) / dpc, l0, l1);
+      const int tn = t < jB + 3 ? t + 1 : t;
+      const CswMetrics in = mnxt;
+      mnxt = load_metrics(tn);
+      for (int m = 0; m < KPW; m++) {
+        CswLevel &S = st[m];
+        const int k = kl[m];
+        const size_t oA = (size_t)k * g.nA(), oU = (size_t)k * g.nU(), oV = (size_t)k * g.nV(), oB = (size_t)k * g.nB();
+        const CswFields f = fnxt[m];
+        fnxt[m] = load_fields(tn, k);
+        S.u0 = S.u1; S.u1 = S.u2; S.u2 = S.u3; S.u3 = f.u;
+        S.v0 = S.v1; S.v1 = S.v2; S.v2 = S.v3; S.v3 = f.v;
+        S.dp0 = S.dpp; S.dpp = f.dp;
+        S.pt0 = S.ptp; S.ptp = f.pt;
+        S.w0 = S.wp; S.wp = f.w;
+        // ---- row R: interpolated winds, fluxes, vorticity ----------------------------------------------------
+        const vd utmp = a2 * (S.u0 + S.u3) + a1 * (S.u1 + S.u2);                 // :3099-3103
+        const vd v3p = shl1(S.v3);
+        S.vt0 = S.vt1; S.vt1 = S.vt2; S.vt2 = S.vt3;
+        S.vt3 = a2 * (shr1(S.v3) + shl1(v3p)) + a1 * (S.v3 + v3p);               // vtmp(t-1), :3104-3108
+        const vd ua = (utmp - S.vt2 * in.cs) * in.rs, va = (S.vt2 - utmp * in.cs) * in.rs;  // :3152-3157
+        const vd um1 = shr1(utmp);
+        const vd uc = a2 * (shr1(um1) + shl1(utmp)) + a1 * (um1 + utmp);         // :3197-3199
+        const vd vc = a2 * (S.vt0 + S.vt3) + a1 * (S.vt1 + S.vt2);               // :3337-3339
+        vd ut = (uc - S.v2 * in.cosau) * in.rsinu;                                // :3200
+        ut = vsel(ut > 0., dt2 * ut * in.dy * in.sg3, dt2 * ut * in.dy * in.sg1);  // :159-167
+        const vd vt = vsel(vc > 0., dt2 * vc * in.dx * in.sg4, dt2 * vc * in.dx * in.sg2);  // :168-176 (vt = vc, :3340)
+        const vd ucdx = uc * in.dxc;
+        const vd vcdy = vc * in.dyc;
+        const vd vort = in.fc + in.rac * (S.ucdx_p - ucdx - shr1(vcdy) + vcdy);  // :372-403
+        if (live[m] && R >= jA && R <= jB) {
+          const long iAr = (long)g.iA(ilo, R);
+          if (R <= je + 1) {
+            vstore(a.ua + oA, iAr, ua, l0, l1);
+            vstore(a.va + oA, iAr, va, l0, l1);
+            vstore(a.ut + oA, iAr, ut, l0, l2);
           }
-          // uc: interpolated value, advanced on [is, ie+1] x [js, je] (:414-447)
-          vd ucv = uc_p;
-          if (Q >= js && Q <= je) {
-            const vd fy1 = dt2 * (v1 - ucv * cosau_p) / in.sinau;
-            const vd fy = vsel(fy1 > 0., vort_p, vort);
-            ucv = vsel(m_uc, ucv + fy1 * fy + in.rdxc * (shr1(ke) - ke), ucv);
+          vstore(a.vt + oA, iAr, vt, l0, l1);
+        }
+        // ---- row Q: KE, transport, wind update, divergence -------------------------------------------------------
+        const vd ke = dt4 * (S.ua_p * vsel(S.ua_p > 0., S.uc_p, shl1(S.uc_p)) + S.va_p * vsel(S.va_p > 0., S.vc_p, vc));  // :297-366
+        // upwind fluxes through y-face Q+1 (= R) and x-face i (:182-286)
+        const vb vpos = vt > 0.;
+        const vd fy1_n = vt * vsel(vpos, S.dp0, S.dpp);
+        const vd fyp_n = fy1_n * vsel(vpos, S.pt0, S.ptp);
+        const vd fyw_n = nh ? fy1_n * vsel(vpos, S.w0, S.wp) : vd(0.);
+        if (live[m] && Q >= jA && Q <= jB) {
+          const long iAq = (long)g.iA(ilo, Q);
+          if (Q <= je + 1) {
+            const vb upos = S.ut_p > 0.;
+            const vd fx1 = S.ut_p * vsel(upos, shr1(S.dp0), S.dp0);
+            const vd fxp = fx1 * vsel(upos, shr1(S.pt0), S.pt0);
+            const vd ra = in.ra;
+            const vd dpc = S.dp0 + (fx1 - shl1(fx1) + S.fy1_p - fy1_n) * ra;
+            vstore(a.delpc + oA, iAq, dpc, l0, l1);
+            vstore(a.ptc + oA, iAq, (S.pt0 * S.dp0 + (fxp - shl1(fxp) + S.fyp_p - fyp_n) * ra) / dpc, l0, l1);
+            if (nh) {
+              const vd fxw = fx1 * vsel(upos, shr1(S.w0), S.w0);
+              vstore(a.wc + oA, iAq, (S.w0 * S.dp0 + (fxw - shl1(fxw) + S.fyw_p - fyw_n) * ra) / dpc, l0, l1);
+            }
+            // uc: interpolated value, advanced on [is, ie+1] x [js, je] (:414-447)
+            vd ucv = S.uc_p;
+            if (Q >= js && Q <= je) {
+              const vd fy1 = dt2 * (S.v1 - ucv * cosau_p) / in.sinau;
+              const vd fy = vsel(fy1 > 0., S.vort_p, vort);
+              ucv = vsel(m_uc, ucv + fy1 * fy + in.rdxc * (shr1(ke) - ke), ucv);
+            }
+            vstore(a.uc + oV, (long)g.iV(ilo, Q), ucv, l0, l2);
           }
-          vstore(a.uc + oV, (long)g.iV(ilo, Q), ucv, l0, l2);
+          // vc: interpolated value, advanced on [is, ie] x [js, je+1] (:452-486)
+          vd vcv = S.vc_p;
+          if (Q >= js && Q <= je + 1) {
+            const vd fx1 = dt2 * (S.u0 - vcv * in.cosav) / in.sinav;
+            const vd fx = vsel(fx1 > 0., S.vort_p, shl1(S.vort_p));
+            vcv = vsel(m_vc, vcv - fx1 * fx + in.rdyc * (S.ke_p - ke), vcv);
+          }
+          vstore(a.vc + oU, (long)g.iU(ilo, Q), vcv, l0, l1);
         }
-        // vc: interpolated value, advanced on [is, ie] x [js, je+1] (:452-486)
-        vd vcv = vc_p;
-        if (Q >= js && Q <= je + 1) {
-          const vd fx1 = dt2 * (u0 - vcv * in.cosav) / in.sinav;
-          const vd fx = vsel(fx1 > 0., vort_p, shl1(vort_p));
-          vcv = vsel(m_vc, vcv - fx1 * fx + in.rdyc * (ke_p - ke), vcv);
+        // divergence at the corners of row Q (:1781-1796); v0 = v(Q-1), v1 = v(Q), u0 = u(Q)
+        const vd vdxc = S.v1 * dxc_p;
+        if (live[m] && a.nord > 0 && Q >= jA && Q <= jB) {
+          const vd uf = S.u0 * dyc_p;
+          vstore(a.divg_d + oB, (long)g.iB(ilo, Q), rac_p * (S.vdxc_p - vdxc + shr1(uf) - uf), l0, l2);
         }
-        vstore(a.vc + oU, (long)g.iU(ilo, Q), vcv, l0, l1);
+        // ---- rotate the row state ------------------------------------------------------------------------------------
+        S.ua_p = ua; S.va_p = va; S.uc_p = uc; S.vc_p = vc; S.ut_p = ut; S.vt_p = vt;
+        S.ucdx_p = ucdx; S.vort_p = vort; S.ke_p = ke; S.vdxc_p = vdxc;
+        S.fy1_p = fy1_n; S.fyp_p = fyp_n; S.fyw_p = fyw_n;
       }
-      // divergence at the corners of row Q (:1781-1796); v0 = v(Q-1), v1 = v(Q), u0 = u(Q)
-      const vd vdxc = v1 * dxc_p;
-      if (a.nord > 0 && Q >= jA && Q <= jB) {
-        const vd uf = u0 * dyc_p;
-        vstore(a.divg_d + oB, (long)g.iB(ilo, Q), rac_p * (vdxc_p - vdxc + shr1(uf) - uf), l0, l2);
-      }
-      // ---- rotate the row state ------------------------------------------------------------------------------------
-      ua_p = ua; va_p = va; uc_p = uc; vc_p = vc; ut_p = ut; vt_p = vt;
-      ucdx_p = ucdx; vort_p = vort; ke_p = ke; vdxc_p = vdxc;
-      fy1_p = fy1_n; fyp_p = fyp_n; fyw_p = fyw_n;
       cosau_p = in.cosau; dxc_p = in.dxc; dyc_p = in.dyc; rac_p = in.rac;
     }
   }

@@ -67,6 +67,7 @@ struct fv3_ctx {
   double *mflux[2];      // mass-flux scratch of the marching transports: FX kind, FY kind (npz levels)
   int march_tj;          // rows per wavefront segment of the marching kernels
   int march_tj_csw, march_tj_ke, march_tj_fused;
+  int csw_kpw;           // levels per wavefront in CswMarch (1 or 2; FV3_MI355X_CSW_KPW)
   int use_fused;         // 1: delp + w + pt in one marching kernel when the schemes allow (FV3_MI355X_FUSED=0: off)
   int use_march;         // 0: LDS-tile kernels only (FV3_MI355X_MARCH=0)
   bool prof_on;
@@ -190,6 +191,9 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_MARCH_TJ");
     c->march_tj = e ? std::atoi(e) : 48;
     if (c->march_tj < 1) c->march_tj = 48;
+    e = std::getenv("FV3_MI355X_CSW_KPW");
+    c->csw_kpw = e ? std::atoi(e) : 2;
+    if (c->csw_kpw < 1 || c->csw_kpw > 3) c->csw_kpw = 2;
     e = std::getenv("FV3_MI355X_FUSED");
     c->use_fused = e ? std::atoi(e) : 1;
     e = std::getenv("FV3_MI355X_MARCH_TJ_FUSED");
@@ -199,8 +203,8 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     c->march_tj_ke = e ? std::atoi(e) : 48;
     if (c->march_tj_ke < 1) c->march_tj_ke = 48;
     e = std::getenv("FV3_MI355X_MARCH_TJ_CSW");
-    c->march_tj_csw = e ? std::atoi(e) : 48;
-    if (c->march_tj_csw < 1) c->march_tj_csw = 48;
+    c->march_tj_csw = e ? std::atoi(e) : 64;
+    if (c->march_tj_csw < 1) c->march_tj_csw = 64;
   }
   c->dp0 = nullptr; c->edge_dev = nullptr; c->dp0_ready = false;
   c->akbk = nullptr; c->kord_tr_dev = nullptr; c->akbk_ready = false;
@@ -473,11 +477,17 @@ extern "C" int fv3_c_sw(fv3_ctx *c, double *delpc, const double *delp, double *p
   if (!c || !c->grid_ready) return fail("fv3_c_sw: context has no grid (call fv3_grid_upload)");
   if (!hydrostatic && (!w || !wc)) return fail("fv3_c_sw: nonhydrostatic call needs w and wc");
   if (c->use_march) {
-    CswMarch kf;
-    kf.g = c->g;
-    kf.a = CswArgs{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2};
-    kf.md = make_csw_dims(c->g, c->march_tj_csw);
-    RT(launch_w(c, "c_sw", kf.md.nwaves(c->g.npz), kf));
+    const CswArgs ca{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2};
+    const MarchDims md = make_csw_dims(c->g, c->march_tj_csw);
+    if (c->csw_kpw == 3) {
+      const int nkg = (c->g.npz + 2) / 3;
+      RT(launch_w(c, "c_sw", md.nwaves(nkg), CswMarch<3>{c->g, ca, md, nkg}));
+    } else if (c->csw_kpw == 2) {
+      const int nkg = (c->g.npz + 1) / 2;
+      RT(launch_w(c, "c_sw", md.nwaves(nkg), CswMarch<2>{c->g, ca, md, nkg}));
+    } else {
+      RT(launch_w(c, "c_sw", md.nwaves(c->g.npz), CswMarch<1>{c->g, ca, md, c->g.npz}));
+    }
     return 0;
   }
   constexpr int TI = FV3_CSW_TI, TJ = FV3_CSW_TJ;
