@@ -28,6 +28,8 @@ inline MarchDims make_csw_dims(const Grid &g, int tj) {
   MarchDims d;
   d.tj = tj;
   d.klist = nullptr;
+  d.nk = 0;
+  d.k_fast = march_k_fast();
   d.nstrips = (g.nx + 4 + kCswCols - 1) / kCswCols;
   d.nsegs = (g.ny + 4 + tj - 1) / tj;
   return d;
@@ -70,7 +72,8 @@ struct CswMarch {
 
   FV3_D void operator()(int gid) const {
     constexpr double a1 = 0.5625, a2 = -0.0625;  // sw_core.F90:53-54
-    const int strip = gid % md.nstrips, seg = (gid / md.nstrips) % md.nsegs, kg = gid / (md.nstrips * md.nsegs);
+    int strip, seg, kg;
+    md.decode(gid, strip, seg, kg);
     const int is = g.is, ie = g.ie, js = g.js, je = g.je;
     const int ilo = is - 1 + strip * kCswCols - 3;  // column of lane 0
     auto cl = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };

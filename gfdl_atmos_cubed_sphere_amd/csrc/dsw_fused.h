@@ -79,7 +79,8 @@ struct DswTransportFused {
   };
 
   FV3_D void operator()(int gid) const {
-    const int strip = gid % md.nstrips, seg = (gid / md.nstrips) % md.nsegs, kk = gid / (md.nstrips * md.nsegs);
+    int strip, seg, kk;
+    md.decode(gid, strip, seg, kk);
     const int k = md.klist ? md.klist[kk] : kk;
     const StripGeom s = make_strip(g, strip);
     const int ilo = s.ilo;

@@ -78,7 +78,8 @@ struct DswDelpMarch {
   };
 
   FV3_D void operator()(int gid) const {
-    const int strip = gid % md.nstrips, seg = (gid / md.nstrips) % md.nsegs, kk = gid / (md.nstrips * md.nsegs);
+    int strip, seg, kk;
+    md.decode(gid, strip, seg, kk);
     const int k = md.klist ? md.klist[kk] : kk;
     const StripGeom s = make_strip(g, strip);
     const int jA = g.js + seg * md.tj;
@@ -132,7 +133,8 @@ struct DswScalarMarch {
   };
 
   FV3_D void operator()(int gid) const {
-    const int strip = gid % md.nstrips, seg = (gid / md.nstrips) % md.nsegs, kk = gid / (md.nstrips * md.nsegs);
+    int strip, seg, kk;
+    md.decode(gid, strip, seg, kk);
     const int k = md.klist ? md.klist[kk] : kk;
     const StripGeom s = make_strip(g, strip);
     const int jA = g.js + seg * md.tj;
@@ -164,7 +166,8 @@ struct DswKeMarch {
   double *ke;     // B kind scratch, npz levels
 
   FV3_D void operator()(int gid) const {
-    const int strip = gid % md.nstrips, seg = (gid / md.nstrips) % md.nsegs, kk = gid / (md.nstrips * md.nsegs);
+    int strip, seg, kk;
+    md.decode(gid, strip, seg, kk);
     const int k = md.klist ? md.klist[kk] : kk;
     const StripGeom s = make_strip(g, strip);
     const int ilo = s.ilo;
@@ -287,7 +290,8 @@ struct DswVortMarch {
   };
 
   FV3_D void operator()(int gid) const {
-    const int strip = gid % md.nstrips, seg = (gid / md.nstrips) % md.nsegs, kk = gid / (md.nstrips * md.nsegs);
+    int strip, seg, kk;
+    md.decode(gid, strip, seg, kk);
     const int k = md.klist ? md.klist[kk] : kk;
     const StripGeom s = make_strip(g, strip);
     const int jA = g.js + seg * md.tj;
@@ -344,7 +348,8 @@ struct ZhMarch {
   };
 
   FV3_D void operator()(int gid) const {
-    const int strip = gid % md.nstrips, seg = (gid / md.nstrips) % md.nsegs, kk = gid / (md.nstrips * md.nsegs);
+    int strip, seg, kk;
+    md.decode(gid, strip, seg, kk);
     const int k = md.klist ? md.klist[kk] : kk;
     const StripGeom s = make_strip(g, strip);
     const int jA = g.js + seg * md.tj;
@@ -397,11 +402,9 @@ struct TracerMarch {
   };
 
   FV3_D void operator()(int gid) const {
-    const int strip = gid % md.nstrips;
-    int rest = gid / md.nstrips;
-    const int seg = rest % md.nsegs;
-    rest /= md.nsegs;
-    const int k = rest % npz, iq = rest / npz;
+    int strip, seg, kq;
+    md.decode(gid, strip, seg, kq);
+    const int k = kq % npz, iq = kq / npz;
     const StripGeom s = make_strip(g, strip);
     const int jA = g.js + seg * md.tj;
     const int jB = (jA + md.tj - 1 < g.je) ? jA + md.tj - 1 : g.je;

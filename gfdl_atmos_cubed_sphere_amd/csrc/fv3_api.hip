@@ -478,15 +478,16 @@ extern "C" int fv3_c_sw(fv3_ctx *c, double *delpc, const double *delp, double *p
   if (!hydrostatic && (!w || !wc)) return fail("fv3_c_sw: nonhydrostatic call needs w and wc");
   if (c->use_march) {
     const CswArgs ca{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2};
-    const MarchDims md = make_csw_dims(c->g, c->march_tj_csw);
-    if (c->csw_kpw == 3) {
-      const int nkg = (c->g.npz + 2) / 3;
-      RT(launch_w(c, "c_sw", md.nwaves(nkg), CswMarch<3>{c->g, ca, md, nkg}));
-    } else if (c->csw_kpw == 2) {
-      const int nkg = (c->g.npz + 1) / 2;
-      RT(launch_w(c, "c_sw", md.nwaves(nkg), CswMarch<2>{c->g, ca, md, nkg}));
+    MarchDims md = make_csw_dims(c->g, c->march_tj_csw);
+    const int kpw = c->csw_kpw;
+    const int nkg = (c->g.npz + kpw - 1) / kpw;
+    const int nw = md.nwaves(nkg);
+    if (kpw == 3) {
+      RT(launch_w(c, "c_sw", nw, CswMarch<3>{c->g, ca, md, nkg}));
+    } else if (kpw == 2) {
+      RT(launch_w(c, "c_sw", nw, CswMarch<2>{c->g, ca, md, nkg}));
     } else {
-      RT(launch_w(c, "c_sw", md.nwaves(c->g.npz), CswMarch<1>{c->g, ca, md, c->g.npz}));
+      RT(launch_w(c, "c_sw", nw, CswMarch<1>{c->g, ca, md, nkg}));
     }
     return 0;
   }
@@ -900,9 +901,10 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
   if (march && c->n_plain_z > 0) {
     MarchDims md = make_march_dims(g, c->march_tj);
     md.klist = c->klist_z;
+    const int nwz = md.nwaves(c->n_plain_z);
     RT(dispatch_hord(hord, [&](auto H) {
       ZhMarch<decltype(H)::value> kf{g, md, zh_in, cxa, cya, xfa, yfa, zh_out};
-      return launch_w(c, "zh_transport", md.nwaves(c->n_plain_z), kf);
+      return launch_w(c, "zh_transport", nwz, kf);
     }));
   }
   if (!march || c->n_damp_z > 0) {
@@ -1123,11 +1125,12 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
     RT(rt_sync(c->stream));
   }
   if (c->use_march && !(it == 1 && trdm > 1.e-4)) {
-    const MarchDims md = make_march_dims(g, c->march_tj);
+    MarchDims md = make_march_dims(g, c->march_tj);
+    const int nwt = md.nwaves(g.npz * nq);
     return dispatch_hord(hord, [&](auto H) {
       TracerMarch<decltype(H)::value> kf{g, md, g.npz, nq, it, nsplt, c->trc_i, q, dp1, mfx, mfy, cx, cy, xfx, yfx,
                                          q_out, dp1_out};
-      return launch_w(c, "tracer_step", md.nwaves(g.npz) * nq, kf);
+      return launch_w(c, "tracer_step", nwt, kf);
     });
   }
   constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;

@@ -17,6 +17,8 @@
 // Lane validity: q on all lanes it could be loaded for; x-faces on lanes 3..61, cells on lanes 3..60.
 #pragma once
 
+#include <cstdlib>
+
 #include "ppm_march.h"
 
 namespace fv3 {
@@ -53,12 +55,40 @@ inline int num_strips(const Grid &g) { return (g.nx + kStripCells - 1) / kStripC
 struct MarchDims {
   int nstrips, nsegs, tj;
   const int *klist;  // level of the n-th marching slab (device), or null = identity
-  FV3_HD int nwaves(int npz) const { return nstrips * nsegs * npz; }
+  int nk;            // number of level slots of the launch (set by nwaves)
+  int k_fast;        // 1: consecutive wavefronts = consecutive levels of the same (strip, segment)
+  FV3_HD int nwaves(int npz) {
+    nk = npz;
+    return nstrips * nsegs * npz;
+  }
+  // k fastest: the workgroups that are in flight together (round-robin over the 8 XCDs) work on the same
+  // (strip, segment) at different levels, so the 2-D metric rows they all read are served by each XCD's L2
+  FV3_HD void decode(int gid, int &strip, int &seg, int &kk) const {
+    if (k_fast) {
+      kk = gid % nk;
+      const int t = gid / nk;
+      strip = t % nstrips;
+      seg = t / nstrips;
+    } else {
+      strip = gid % nstrips;
+      seg = (gid / nstrips) % nsegs;
+      kk = gid / (nstrips * nsegs);
+    }
+  }
 };
+inline int march_k_fast() {
+  static const int v = [] {
+    const char *e = std::getenv("FV3_MI355X_K_FAST");
+    return e ? std::atoi(e) : 0;  // measured: no gain on MI355X (metric rows are served by L2 / Infinity Cache either way)
+  }();
+  return v;
+}
 inline MarchDims make_march_dims(const Grid &g, int tj) {
   MarchDims d;
   d.tj = tj;
   d.klist = nullptr;
+  d.nk = 0;
+  d.k_fast = march_k_fast();
   d.nstrips = num_strips(g);
   d.nsegs = (g.ny + tj - 1) / tj;
   return d;
