@@ -34,7 +34,7 @@ ALG_BYTES = {
 }
 # kernels that together do the work of one logical kernel (the marching transports are one launch per field)
 GROUP = {"d_sw_delp": "d_sw_transport", "d_sw_w": "d_sw_transport", "d_sw_pt": "d_sw_transport",
-         "d_sw_qcon": "d_sw_transport", "d_sw_fused": "d_sw_transport", "d_sw_ke": "d_sw_momentum", "d_sw_vort": "d_sw_momentum"}
+         "d_sw_qcon": "d_sw_transport", "d_sw_fused": "d_sw_transport", "d_sw_ke": "d_sw_momentum", "d_sw_mom_fused": "d_sw_momentum", "d_sw_vort": "d_sw_momentum"}
 PAIR_ALG_BYTES = 336.0       # perfectly fused c_sw+d_sw, NH
 
 

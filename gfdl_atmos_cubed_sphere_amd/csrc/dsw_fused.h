@@ -230,3 +230,146 @@ struct DswTransportFused {
 };
 
 }  // namespace fv3
+
+// =====================================================================================================
+// DswMomentumFused: DswKeMarch + DswVortMarch in one marching kernel (same level conditions).  The KE / damping
+// term of corner rows j and j+1 is formed in registers right when the wind update of row j needs it, so the ke
+// scratch round trip and the second pass over u, v, crx, xfx, cry, yfx disappear:
+// u, v, uc, vc, divg_d, crx, xfx, cry, yfx in; u, v, delpc out = 96 B per cell-update (was 136).
+namespace fv3 {
+
+template <int SWC, int HORD>
+struct DswMomentumFused {
+  Grid g;
+  DswArgs a;
+  MarchDims md;
+
+  struct In {
+    vd u1, v0, v1, dx1, dy0, dy1, ra, f0;          // vorticity of row r: u(r+1), v(r), v(r)@i+1, dx(r+1), dy(r), dy@i+1, rarea, f0
+    vd ar, cx, xf, cy, yf;                         // fv_tp_2d: area, crx, xfx of row r; cry, yfx of face r-2
+    vd vc, uc, ukc, rdy, rdx, dv, dgu, dgv, rac;   // corner row jc = r-2 (dv = divg_d(jc+1))
+  };
+
+  FV3_D void operator()(int gid) const {
+    int strip, seg, kk;
+    md.decode(gid, strip, seg, kk);
+    const int k = md.klist ? md.klist[kk] : kk;
+    const StripGeom s = make_strip(g, strip);
+    const int ilo = s.ilo;
+    const int jA = g.js + seg * md.tj;
+    const int jB = (jA + md.tj - 1 < g.je) ? jA + md.tj - 1 : g.je;
+    const int rlast = jB + 3;
+    const int lFx1 = (ilo + s.lC1 == g.ie) ? s.lC1 + 1 : s.lC1;
+    const double *u = a.u + (size_t)k * g.nU(), *v = a.v + (size_t)k * g.nV();
+    const double *uc = a.uc + (size_t)k * g.nV(), *vc = a.vc + (size_t)k * g.nU();
+    const double *dv = a.divg_d + (size_t)k * g.nB();
+    const double *crx = a.crx + (size_t)k * g.nCX(), *xfx = a.xfx + (size_t)k * g.nCX();
+    const double *cry = a.cry + (size_t)k * g.nCY(), *yfx = a.yfx + (size_t)k * g.nCY();
+    double *uo = a.u_out + (size_t)k * g.nU(), *vo = a.v_out + (size_t)k * g.nV();
+    double *dpc = a.delpc ? a.delpc + (size_t)k * g.nA() : nullptr;
+    const double dt5 = 0.5 * a.dt;
+    const double d2_bg = a.lv.d2_divg[k];
+    const double damp2 = g.da_min_c * dmax(d2_bg, dmin(0.20, a.dddmp * 0.));            // :1454 with vort = 0
+    const double dd8 = g.stretched_grid ? g.da_min * ipow(a.d4_bg, 2) : ipow(g.da_min_c * a.d4_bg, 2);  // :1446-1450
+
+    auto load_in = [&](int r) {
+      In in;
+      const long oU1 = (long)g.iU(ilo, r + 1), oV = (long)g.iV(ilo, r), oA = (long)g.iA(ilo, r);
+      in.u1 = vload(u, oU1, s.A);   in.dx1 = vload(g.dx, oU1, s.A);
+      in.v0 = vload(v, oV, s.A);    in.dy0 = vload(g.dy, oV, s.A);
+      in.v1 = vload(v, oV + 1, s.A);  in.dy1 = vload(g.dy, oV + 1, s.A);  // V kind has the extra column ied+1
+      in.ra = vload(g.rarea, oA, s.A);
+      in.f0 = vload(g.f0, oA, s.A);
+      in.ar = vload(g.area, oA, s.A);
+      const long oCX = (long)g.iCX(ilo, r);
+      in.cx = vload(crx, oCX, s.F);
+      in.xf = vload(xfx, oCX, s.F);
+      const int jf = (r - 2 < jA) ? jA : r - 2;
+      const long oCY = (long)g.iCY(ilo, jf);
+      in.cy = vload(cry, oCY, s.A);
+      in.yf = vload(yfx, oCY, s.A);
+      // corner row jc = r-2; before the segment's first corner row the row below it is loaded, whose values become
+      // the "previous row" carries of the first one
+      const int jc = (r - 2 < jA - 1) ? jA - 1 : r - 2;
+      const long oUc = (long)g.iU(ilo, jc), oVc = (long)g.iV(ilo, jc), oBc = (long)g.iB(ilo, jc);
+      in.vc = vload(vc, oUc, s.A);
+      in.uc = vload(uc, oVc, s.A);
+      in.ukc = vload(u, oUc, s.A);
+      in.rdy = vload(g.rdy, oVc, s.A);
+      in.rdx = vload(g.rdx, oUc, s.A);
+      in.dv = vload(dv, (long)g.iB(ilo, jc + 1), s.A);
+      in.dgu = vload(g.divg_u, oUc, s.A);
+      in.dgv = vload(g.divg_v, oVc, s.A);
+      in.rac = vload(g.rarea_c, oBc, s.A);
+      return in;
+    };
+
+    Tp2dState<HORD> st;
+    st.init();
+    PpmYsw<SWC> yv;
+    yv.init();
+    vd vtdx_n(0.);                                  // u(r)*dx(r): the "vt1" of the previous step
+    vd vtdx_1(0.), vtdx_2(0.), vtdx_3(0.);          // u*dx of rows r-1, r-2, r-3
+    vd utdy_1(0.), utdy_2(0.), utdy_3(0.);          // v*dy of rows r-1, r-2, r-3
+    vd xf_1(0.), xf_2(0.), xf_3(0.);                // xfx of rows r-1 .. r-3
+    vd uc_p(0.), rdy_p(0.), dgv_p(0.), d_m(0.), d_0(0.);  // corner row jc-1 carries; divg_d(jc-1), divg_d(jc)
+    vd ke_p(0.), yf_p(0.);
+    {  // u(jA-3)*dx(jA-3) and divg_d(jA-1) for the first steps
+      const long oU = (long)g.iU(ilo, jA - 3);
+      vtdx_n = vload(u, oU, s.A) * vload(g.dx, oU, s.A);
+      d_0 = vload(dv, (long)g.iB(ilo, jA - 1), s.A);
+    }
+    In nxt = load_in(jA - 3);
+    for (int r = jA - 3; r <= rlast; r++) {
+      const In in = nxt;
+      nxt = load_in(r < rlast ? r + 1 : rlast);
+      const int j = r - 3, jc = r - 2;
+      // ---- absolute vorticity of row r (sw_core.F90:1231-1247, :1476-1495) -> fv_tp_2d march ---------------------------
+      const vd vt0 = vtdx_n, vt1 = in.u1 * in.dx1, ut0 = in.v0 * in.dy0, ut1 = in.v1 * in.dy1;
+      MarchIn mi;
+      mi.qn = in.ra * (vt0 - vt1 - ut0 + ut1) + in.f0;
+      mi.ar = in.ar; mi.cx = in.cx; mi.xf = in.xf; mi.cy = in.cy; mi.yf = in.yf;
+      vd fxv, fyv0, fyv1;
+      st.step(mi, jc >= jA, j >= jA, fxv, fyv0, fyv1);
+      // ---- KE flux + divergence damping at corner row jc (:1078-1198, :1372-1460) -----------------------------------------
+      yv.push(in.v0);
+      vd ke(0.);
+      if (jc >= jA) {
+        const vd vb = dt5 * (shr1(in.vc) + in.vc);                         // :1129
+        const vd ub = yv.face(vb, rdy_p, in.rdy);                          // ytp_v :1134
+        const vd kev = vb * ub;                                            // :1139
+        const vd ub2 = dt5 * (uc_p + in.uc);                               // :1186
+        const vd vb2 = ppm_faces_x_sw<SWC>(in.ukc, ub2, in.rdx);           // xtp_u :1191
+        ke = 0.5 * (kev + ub2 * vb2);                                      // :1196
+        const vd vc2 = (shl1(d_0) - d_0) * in.dgu;                         // :1392-1396
+        const vd uc2m = (d_0 - d_m) * dgv_p;                               // :1399-1403
+        const vd uc2 = (in.dv - d_0) * in.dgv;
+        vd lap = uc2m - uc2 + shr1(vc2) - vc2;                             // :1406-1424
+        if (!g.stretched_grid) lap = lap * in.rac;
+        ke = ke + (damp2 * d_0 + dd8 * lap);                               // :1455
+        if (dpc && (jc <= jB || jc == g.je + 1))
+          vstore(dpc, (long)g.iA(ilo, jc), d_0, s.lC0, lFx1);              // delpc = saved divergence (:1376-1381)
+      }
+      // ---- D-grid wind update of row j (:1500-1509) ------------------------------------------------------------------------------
+      if (j >= jA) {
+        const vd ke0 = ke_p, ke1 = ke;
+        vstore(uo, (long)g.iU(ilo, j), vtdx_3 + ke0 - shl1(ke0) + fyv0 * yf_p, s.lC0, s.lC1);
+        vstore(vo, (long)g.iV(ilo, j), utdy_3 + ke0 - ke1 - fxv * xf_3, s.lC0, lFx1);
+        if (j == g.je)  // the north edge row of u
+          vstore(uo, (long)g.iU(ilo, j + 1), vtdx_2 + ke1 - shl1(ke1) + fyv1 * in.yf, s.lC0, s.lC1);
+      }
+      // ---- rotate ----------------------------------------------------------------------------------------------------------------------
+      vtdx_3 = vtdx_2; vtdx_2 = vtdx_1; vtdx_1 = vt0; vtdx_n = vt1;
+      utdy_3 = utdy_2; utdy_2 = utdy_1; utdy_1 = ut0;
+      xf_3 = xf_2; xf_2 = xf_1; xf_1 = in.xf;
+      if (r >= jA + 1) {  // the corner row loaded at this step was a real one (jA-1 or later)
+        uc_p = in.uc; rdy_p = in.rdy; dgv_p = in.dgv;
+        d_m = d_0; d_0 = in.dv;
+      }
+      ke_p = ke;
+      if (jc >= jA) yf_p = in.yf;
+    }
+  }
+};
+
+}  // namespace fv3

@@ -560,7 +560,20 @@ static int dsw_transport_march(fv3_ctx *c, const DswArgs &a) {
 // d_sw momentum on the marching stencils (dsw_march.h) for the levels in klist_m[0 : n_plain_m]
 static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a) {
   const Grid &g = c->g;
-  if (!c->ke_scr) RT(rt_malloc((void **)&c->ke_scr, sizeof(double) * g.nB() * g.npz));
+  if (!c->use_fused && !c->ke_scr) RT(rt_malloc((void **)&c->ke_scr, sizeof(double) * g.nB() * g.npz));
+  if (c->use_fused) {
+    MarchDims mf = make_march_dims(g, c->march_tj_fused);
+    mf.klist = c->klist_m;
+    const int nwf = mf.nwaves(c->n_plain_m);
+    return dispatch_hord(a.hord_vt, [&](auto H) {
+      constexpr int HORD = decltype(H)::value;
+      switch (sw_class(a.hord_mt)) {
+        case 5: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<5, HORD>{g, a, mf});
+        case 6: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<6, HORD>{g, a, mf});
+        default: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<8, HORD>{g, a, mf});
+      }
+    });
+  }
   MarchDims mk = make_march_dims(g, c->march_tj_ke);
   mk.klist = c->klist_m;
   const int nwk = mk.nwaves(c->n_plain_m);
