@@ -35,6 +35,12 @@ struct fv3_ctx {
   fv3_domain dom;
   Grid g;           // device view (pointers into dev_metrics)
   stream_t stream;
+  // side stream: the few levels that take the LDS-tile kernels in d_sw (sponge layers) run concurrently with
+  // the marching kernels of the other levels (different levels = disjoint data)
+  stream_t stream2;
+  void *ev_fork, *ev_join;
+  bool side_ok;          // transport and momentum route the same levels to the tile kernels
+  int use_side;          // FV3_MI355X_SIDE_STREAM=0 disables
   double *dev_metrics;   // one allocation holding every metric array
   bool grid_ready;
   // per-level d_sw coefficients on the device
@@ -111,6 +117,21 @@ static int launch_p(fv3_ctx *c, const char *label, Dim3 grid, size_t lds_doubles
 }
 
 template <class F>
+static int launch_c(fv3_ctx *c, const char *label, Dim3 grid, const F &f) {
+  void *e0 = nullptr, *e1 = nullptr;
+  if (c->prof_on) {
+    if (rt_event_create(&e0) || rt_event_create(&e1)) return 1;
+    rt_event_record(e0, c->stream);
+  }
+  int rc = launch_cols(grid, c->stream, f);
+  if (c->prof_on) {
+    rt_event_record(e1, c->stream);
+    c->prof.push_back({label, e0, e1});
+  }
+  return rc;
+}
+
+template <class F>
 static int launch_w(fv3_ctx *c, const char *label, int nwaves, const F &f) {
   void *e0 = nullptr, *e1 = nullptr;
   if (c->prof_on) {
@@ -177,6 +198,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   g.stretched_grid = dom->stretched_grid;
   g.lim_fac = dom->lim_fac;
   c->stream = nullptr;
+  c->stream2 = nullptr; c->ev_fork = c->ev_join = nullptr; c->side_ok = false;
   c->dev_metrics = nullptr;
   c->grid_ready = false;
   c->lev_i = nullptr; c->lev_d = nullptr; c->lev_ready = false;
@@ -188,6 +210,8 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   {  // tuning / fallback knobs
     const char *e = std::getenv("FV3_MI355X_MARCH");
     c->use_march = e ? std::atoi(e) : 1;
+    e = std::getenv("FV3_MI355X_SIDE_STREAM");
+    c->use_side = e ? std::atoi(e) : 1;
     e = std::getenv("FV3_MI355X_MARCH_TJ");
     c->march_tj = e ? std::atoi(e) : 48;
     if (c->march_tj < 1) c->march_tj = 48;
@@ -230,6 +254,9 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   if (c->lev_ext_i) rt_free(c->lev_ext_i);
   for (auto &s : c->scratch) if (s) rt_free(s);
   for (auto &s : c->mflux) if (s) rt_free(s);
+  if (c->stream2) rt_stream_destroy(c->stream2);
+  if (c->ev_fork) rt_event_destroy(c->ev_fork);
+  if (c->ev_join) rt_event_destroy(c->ev_join);
   if (c->klist) rt_free(c->klist);
   if (c->klist_m) rt_free(c->klist_m);
   if (c->klist_z) rt_free(c->klist_z);
@@ -360,6 +387,7 @@ extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
     c->n_plain_m = (int)pm.size();
     c->n_rest_m = (int)rm.size();
     pm.insert(pm.end(), rm.begin(), rm.end());
+    c->side_ok = (rm == damped);
     if (!c->klist_m) RT(rt_malloc((void **)&c->klist_m, sizeof(int) * npz));
     RT(rt_h2d(c->klist_m, pm.data(), sizeof(int) * npz, c->stream));
     RT(rt_sync(c->stream));
@@ -628,35 +656,68 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, cons
   // the fused marching kernel forms the Courant numbers itself for its levels
   const bool fused = c->use_march && c->use_fused && !a.use_cond && a.hord_dp == a.hord_tm &&
                      (a.hydrostatic || a.hord_dp == a.hord_vt);
-  if (!fused || c->n_damp > 0) {  // Courant numbers and area fluxes
+  constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
+  const bool march = c->use_march != 0;
+  // marching momentum: no Smagorinsky coefficient, no dissipation estimate (level conditions in klist_m)
+  const bool march_m = march && a.dddmp < 1.E-5 && !g.do_diss_est;
+
+  auto courant = [&]() -> int {  // Courant numbers and area fluxes of the levels the fused kernel does not take
+    if (fused && c->n_damp == 0) return 0;
     DswCourant kf{g, a, fused ? c->klist + c->n_plain : nullptr};
     const size_t nmax = g.nCX() > g.nCY() ? g.nCX() : g.nCY();
     Dim3 grid;
     grid.x = (unsigned)((nmax + DswCourant::CH - 1) / DswCourant::CH);
     grid.y = 1;
     grid.z = (unsigned)(fused ? c->n_damp : npz);
-    RT(launch_p(c, "d_sw_courant", grid, 0, kf));
-  }
-  constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
-  const bool march = c->use_march != 0;
-  if (march && c->n_plain > 0) RT(dsw_transport_march(c, a));
-  if (!march || c->n_damp > 0) {
+    return launch_p(c, "d_sw_courant", grid, 0, kf);
+  };
+  auto tile_transport = [&]() -> int {
+    if (march && c->n_damp == 0) return 0;
     DswTransport<TI, TJ> kf{g, a, march ? c->klist + c->n_plain : nullptr};
     Dim3 grid;
     DswTransport<TI, TJ>::grid_dims(g, grid.x, grid.y);
     grid.z = (unsigned)(march ? c->n_damp : npz);
-    RT(launch_p(c, "d_sw_transport", grid, DswTransport<TI, TJ>::lds_doubles, kf));
-  }
-  // marching momentum: no Smagorinsky coefficient, no dissipation estimate (level conditions in klist_m)
-  const bool march_m = march && a.dddmp < 1.E-5 && !g.do_diss_est;
-  if (march_m && c->n_plain_m > 0) RT(dsw_momentum_march(c, a));
-  if (!march_m || c->n_rest_m > 0) {
+    return launch_p(c, "d_sw_transport", grid, DswTransport<TI, TJ>::lds_doubles, kf);
+  };
+  auto tile_momentum = [&]() -> int {
+    if (march_m && c->n_rest_m == 0) return 0;
     DswMomentum<TI, TJ> kf{g, a, march_m ? c->klist_m + c->n_plain_m : nullptr};
     Dim3 grid;
     DswMomentum<TI, TJ>::grid_dims(g, grid.x, grid.y);
     grid.z = (unsigned)(march_m ? c->n_rest_m : npz);
-    RT(launch_p(c, "d_sw_momentum", grid, DswMomentum<TI, TJ>::lds_doubles, kf));
+    return launch_p(c, "d_sw_momentum", grid, DswMomentum<TI, TJ>::lds_doubles, kf);
+  };
+
+  // Side stream: when the tile kernels only take a few levels (the sponge layers) and both halves of d_sw route the
+  // same levels there, their chain courant -> transport -> momentum touches data disjoint from the marching kernels'
+  // and runs concurrently with them.  (Not while profiling: the per-kernel events live on the main stream.)
+  const bool side = fused && march_m && c->side_ok && c->use_side && !c->prof_on && c->n_damp > 0 && c->n_plain > 0;
+  if (side) {
+    if (!c->stream2) {
+      RT(rt_stream_create(&c->stream2));
+      RT(rt_event_create(&c->ev_fork));
+      RT(rt_event_create(&c->ev_join));
+    }
+    const stream_t main_stream = c->stream;
+    rt_event_record(c->ev_fork, main_stream);
+    rt_stream_wait_event(c->stream2, c->ev_fork);
+    c->stream = c->stream2;
+    int rc = courant();
+    if (!rc) rc = tile_transport();
+    if (!rc) rc = tile_momentum();
+    rt_event_record(c->ev_join, c->stream2);
+    c->stream = main_stream;
+    RT(rc);
+    RT(dsw_transport_march(c, a));
+    RT(dsw_momentum_march(c, a));
+    rt_stream_wait_event(main_stream, c->ev_join);
+    return 0;
   }
+  RT(courant());
+  if (march && c->n_plain > 0) RT(dsw_transport_march(c, a));
+  RT(tile_transport());
+  if (march_m && c->n_plain_m > 0) RT(dsw_momentum_march(c, a));
+  RT(tile_momentum());
   return 0;
 }
 
@@ -858,7 +919,7 @@ extern "C" int fv3_update_dz_c(fv3_ctx *c, double dt, const double *zs, const do
   if (!c->dp0_ready) return fail("fv3_update_dz_c: call fv3_set_dp_ref first");
   if (gz_in == gz) return fail("fv3_update_dz_c: gz_in and gz must not alias");
   UpdateDzC kf{c->g, c->g.npz, dt, c->dp0, zs, ut, vt, gz_in, gz, ws};
-  RT(launch_p(c, "update_dz_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), 0, kf));
+  RT(launch_c(c, "update_dz_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), kf));
   return 0;
 }
 
@@ -873,7 +934,7 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn,
   if (need_scratch(c, 4)) return 1;
   RiemSolverC kf{c->g, c->g.npz, dt, to_consts(cn), hs, w3, pt, delp, ws, gz, pef,
                  c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3]};
-  RT(launch_p(c, "riem_solver_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), 0, kf));
+  RT(launch_c(c, "riem_solver_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), kf));
   return 0;
 }
 
@@ -887,7 +948,7 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
   if (need_scratch(c, 4)) return 1;
   RiemSolver3 kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, delz, zh, pe, ppe, pk3, pk, peln,
                  use_logp, last_call, fp_out, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3]};
-  RT(launch_p(c, "riem_solver3", col_grid(c->g.nx * c->g.ny), 0, kf));
+  RT(launch_c(c, "riem_solver3", col_grid(c->g.nx * c->g.ny), kf));
   return 0;
 }
 
@@ -905,9 +966,9 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
   double *cxa = c->scratch[0], *xfa = c->scratch[1], *cya = c->scratch[2], *yfa = c->scratch[3];
   {
     EdgeProfile kf{g, km, c->ec, crx, xfx, cxa, xfa, (int)g.nCX()};
-    RT(launch_p(c, "edge_profile", col_grid((int)g.nCX()), 0, kf));
+    RT(launch_c(c, "edge_profile", col_grid((int)g.nCX()), kf));
     EdgeProfile kf2{g, km, c->ec, cry, yfx, cya, yfa, (int)g.nCY()};
-    RT(launch_p(c, "edge_profile", col_grid((int)g.nCY()), 0, kf2));
+    RT(launch_c(c, "edge_profile", col_grid((int)g.nCY()), kf2));
   }
   constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
   const bool march = c->use_march != 0;
@@ -931,7 +992,7 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
   }
   {
     ZhLimit kf{g, km, rdt, zs, zh_out, ws};
-    RT(launch_p(c, "zh_limit", col_grid(g.nx * g.ny), 0, kf));
+    RT(launch_c(c, "zh_limit", col_grid(g.nx * g.ny), kf));
   }
   return 0;
 }
@@ -952,7 +1013,7 @@ extern "C" int fv3_p_grad_c(fv3_ctx *c, double dt2, const double *delpc, const d
 extern "C" int fv3_zh_from_delz(fv3_ctx *c, const double *zs, const double *delz, double *zh) {
   if (!c || !c->grid_ready) return fail("fv3_zh_from_delz: context has no grid");
   ZhFromDelz kf{c->g, c->g.npz, zs, delz, zh};
-  RT(launch_p(c, "zh_from_delz", col_grid(c->g.nx * c->g.ny), 0, kf));
+  RT(launch_c(c, "zh_from_delz", col_grid(c->g.nx * c->g.ny), kf));
   return 0;
 }
 
@@ -996,14 +1057,14 @@ extern "C" int fv3_nh_p_grad(fv3_ctx *c, double *u, double *v, const double *pp,
 extern "C" int fv3_pk3_halo(fv3_ctx *c, double ptop, double akap, double *pk3, const double *delp, int use_logp) {
   if (!c || !c->grid_ready) return fail("fv3_pk3_halo: context has no grid");
   Pk3Halo kf{c->g, c->g.npz, use_logp, ptop, akap, delp, pk3};
-  RT(launch_p(c, "pk3_halo", col_grid((c->g.nx + 4) * (c->g.ny + 4)), 0, kf));
+  RT(launch_c(c, "pk3_halo", col_grid((c->g.nx + 4) * (c->g.ny + 4)), kf));
   return 0;
 }
 
 extern "C" int fv3_pe_halo(fv3_ctx *c, double ptop, double *pe, const double *delp) {
   if (!c || !c->grid_ready) return fail("fv3_pe_halo: context has no grid");
   PeHalo kf{c->g, c->g.npz, ptop, delp, pe};
-  RT(launch_p(c, "pe_halo", col_grid((c->g.nx + 2) * (c->g.ny + 2)), 0, kf));
+  RT(launch_c(c, "pe_halo", col_grid((c->g.nx + 2) * (c->g.ny + 2)), kf));
   return 0;
 }
 
@@ -1013,7 +1074,7 @@ extern "C" int fv3_geopk(fv3_ctx *c, double ptop, double akap, double cp_air, do
   if (!c || !c->grid_ready) return fail("fv3_geopk: context has no grid");
   const int e = CG ? 1 : 2;
   Geopk kf{c->g, c->g.npz, CG, ptop, akap, cp_air, ptk, delp, hs, pt, pe, peln, pk, gz, pkz};
-  RT(launch_p(c, "geopk", col_grid((c->g.nx + 2 * e) * (c->g.ny + 2 * e)), 0, kf));
+  RT(launch_c(c, "geopk", col_grid((c->g.nx + 2 * e) * (c->g.ny + 2 * e)), kf));
   return 0;
 }
 
@@ -1061,17 +1122,17 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   const double *ak = c->akbk, *bk = c->akbk + (km + 1);
   {
     RemapScalars kf{g, km, rp, ak, bk, c->kord_tr_dev, ps, delp, pkz, pk, w, delz, pt, q, peln, omga, pe, ws, s};
-    RT(launch_p(c, "remap_scalars", col_grid(g.nx * g.ny), 0, kf));
+    RT(launch_c(c, "remap_scalars", col_grid(g.nx * g.ny), kf));
   }
   {
     RemapWinds ku{g, km, rp, ak, bk, pe, u, v, s, 0};
-    RT(launch_p(c, "remap_u", col_grid(g.nx * (g.ny + 1)), 0, ku));
+    RT(launch_c(c, "remap_u", col_grid(g.nx * (g.ny + 1)), ku));
     RemapWinds kv{g, km, rp, ak, bk, pe, u, v, s, 1};
-    RT(launch_p(c, "remap_v", col_grid((g.nx + 1) * g.ny), 0, kv));
+    RT(launch_c(c, "remap_v", col_grid((g.nx + 1) * g.ny), kv));
   }
   {
     RemapPe kf{g, km, ak, bk, pe};
-    RT(launch_p(c, "remap_pe", col_grid(g.nx * g.ny), 0, kf));
+    RT(launch_c(c, "remap_pe", col_grid(g.nx * g.ny), kf));
   }
   return 0;
 }

@@ -28,6 +28,9 @@ inline int launch(Dim3 grid, size_t lds_doubles, stream_t, const F &f) {
       for (unsigned x = 0; x < grid.x; x++) f((int)x, (int)y, (int)z, 0, lds.data());  // order irrelevant here
   return 0;
 }
+// column kernels (one thread per column)
+template <class F>
+inline int launch_cols(Dim3 grid, stream_t s, const F &f) { return launch(grid, 0, s, f); }
 // wave functors: one call per wavefront, the functor's vd values are 64-lane arrays (spmd.h)
 template <class F>
 inline int launch_waves(int nwaves, stream_t, const F &f) {
@@ -60,6 +63,9 @@ inline int rt_d2d(void *d, const void *s, size_t n, stream_t) {
 }
 inline int rt_sync(stream_t) { return 0; }
 inline const char *rt_errstr(int) { return "host-emu error"; }
+inline int rt_stream_create(stream_t *s) { *s = nullptr; return 0; }
+inline void rt_stream_destroy(stream_t) {}
+inline void rt_stream_wait_event(stream_t, void *) {}
 inline int rt_event_create(void **e) { *e = nullptr; return 0; }
 inline void rt_event_record(void *, stream_t) {}
 inline double rt_event_elapsed_ms(void *, void *) { return 0.; }
@@ -95,6 +101,18 @@ inline int launch(Dim3 grid, size_t lds_doubles, stream_t s, const F &f) {
   hipLaunchKernelGGL(tile_kernel<F>, dim3(grid.z, grid.x, grid.y), dim3(kNT), bytes, s, f);
   return (int)hipGetLastError();
 }
+// Column kernels (one thread per (i,j) column, long serial k loops, no LDS): launched as 64-thread workgroups so that
+// the ~2300 wavefronts of a 384 x 384 tile spread evenly over the 1024 SIMDs (256-thread groups would give the 256
+// CUs 2 or 3 groups each).  The functor still sees the (group of 256, thread) numbering of the tile launcher.
+template <class F>
+__global__ void __launch_bounds__(64) col_kernel(const F f) {
+  f((int)(blockIdx.x >> 2), 0, 0, (int)(((blockIdx.x & 3) << 6) + threadIdx.x), nullptr);
+}
+template <class F>
+inline int launch_cols(Dim3 grid, stream_t s, const F &f) {
+  hipLaunchKernelGGL(col_kernel<F>, dim3(grid.x * 4), dim3(64), 0, s, f);
+  return (int)hipGetLastError();
+}
 // wave functors (spmd.h): independent wavefronts, 4 per workgroup, no LDS, no barriers
 template <class F>
 __global__ void __launch_bounds__(kNT) wave_kernel(const F f, int nwaves) {
@@ -123,6 +141,9 @@ inline int rt_d2d(void *d, const void *s, size_t n, stream_t st) {
 }
 inline int rt_sync(stream_t st) { return (int)hipStreamSynchronize(st); }
 inline const char *rt_errstr(int e) { return hipGetErrorString((hipError_t)e); }
+inline int rt_stream_create(stream_t *s) { return (int)hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+inline void rt_stream_destroy(stream_t s) { (void)hipStreamDestroy(s); }
+inline void rt_stream_wait_event(stream_t s, void *e) { (void)hipStreamWaitEvent(s, (hipEvent_t)e, 0); }
 inline int rt_event_create(void **e) { return (int)hipEventCreate((hipEvent_t *)e); }
 inline void rt_event_record(void *e, stream_t s) { (void)hipEventRecord((hipEvent_t)e, s); }
 inline double rt_event_elapsed_ms(void *a, void *b) {

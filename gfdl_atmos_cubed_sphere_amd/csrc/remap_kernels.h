@@ -63,57 +63,23 @@ FV3_HD void cs_limit(bool extm, double a1, double &a2, double &a3, double &a4, i
   }
 }
 
-// scalar_profile (is_scalar) / cs_profile for the column whose a4(1,:) is in c.a1 and whose source
-// coordinate is in c.pe1.  Writes c.a2, c.a3, c.a4 (and uses c.q, c.gam).
-FV3_HD void profile_col(const ColScr &c, int km, bool is_scalar, double qs, int iv, int kord, double qmin) {
-  const int ak = kord < 0 ? -kord : kord;
-#define DP(k) (CS(pe1, (k) + 1) - CS(pe1, k))
-  // ---- interface values: cubic spline tridiagonal ----
-  if (iv == -2) {  // :572-595 / :941-964
-    double gam = 0.5, qk = 1.5 * CS(a1, 1);
-    CS(q, 1) = qk;
-    CS(gam, 2) = gam;
-    for (int k = 2; k <= km - 1; k++) {
-      const double grat = DP(k - 1) / DP(k);
-      const double bet = 2. + grat + grat - gam;
-      qk = (3. * (CS(a1, k - 1) + CS(a1, k)) - qk) / bet;
-      gam = grat / bet;
-      CS(q, k) = qk;
-      CS(gam, k + 1) = gam;
-    }
-    const double grat = DP(km - 1) / DP(km);
-    qk = (3. * (CS(a1, km - 1) + CS(a1, km)) - grat * qs - qk) / (2. + grat + grat - gam);
-    CS(q, km) = qk;
-    CS(q, km + 1) = qs;
-    for (int k = km - 1; k >= 1; k--) {
-      qk = CS(q, k) - CS(gam, k + 1) * qk;
-      CS(q, k) = qk;
-    }
-  } else {  // :597-623 / :967-1016
-    double grat = DP(2) / DP(1);
-    double bet = grat * (grat + 0.5);
-    double qk = ((grat + grat) * (grat + 1.) * CS(a1, 1) + CS(a1, 2)) / bet;
-    double gam = (1. + grat * (grat + 1.5)) / bet;
-    CS(q, 1) = qk;
-    CS(gam, 1) = gam;
-    double d4 = 0.;
-    for (int k = 2; k <= km; k++) {
-      d4 = DP(k - 1) / DP(k);
-      bet = 2. + d4 + d4 - gam;
-      qk = (3. * (CS(a1, k - 1) + d4 * CS(a1, k)) - qk) / bet;
-      gam = d4 / bet;
-      CS(q, k) = qk;
-      CS(gam, k) = gam;
-    }
-    const double a_bot = 1. + d4 * (d4 + 1.5);
-    qk = (2. * d4 * (d4 + 1.) * CS(a1, km) + CS(a1, km - 1) - a_bot * qk) / (d4 * (d4 + 0.5) - a_bot * gam);
-    CS(q, km + 1) = qk;
-    for (int k = km; k >= 1; k--) {
-      qk = CS(q, k) - CS(gam, k) * qk;
-      CS(q, k) = qk;
+// the unfused back-substitution + constraint + limiter sweeps (|kord| = 11 only)
+FV3_HD void profile_col_tail_unfused(const ColScr &c, int km, bool is_scalar, int iv, int ak, double qmin) {
+  {  // back-substitution
+    double qk = CS(q, km + 1);
+    if (iv == -2) {
+      qk = CS(q, km);
+      for (int k = km - 1; k >= 1; k--) {
+        qk = CS(q, k) - CS(gam, k + 1) * qk;
+        CS(q, k) = qk;
+      }
+    } else {
+      for (int k = km; k >= 1; k--) {
+        qk = CS(q, k) - CS(gam, k) * qk;
+        CS(q, k) = qk;
+      }
     }
   }
-#undef DP
   // ---- large-scale constraints on the interface values (:643-680 / :1037-1073) ----
   {
     const double a_1 = CS(a1, 1), a_2 = CS(a1, 2);
@@ -220,6 +186,207 @@ FV3_HD void profile_col(const ColScr &c, int km, bool is_scalar, double qs, int 
   }
 }
 
+
+// scalar_profile (is_scalar) / cs_profile of one column.  src(k) yields the layer mean a4(1,k) of the field (it is
+// called once per level, in order, and the value is kept in c.a1 for the mapping loop); the source coordinate is in
+// c.pe1.  Writes c.a2, c.a3, c.a4 (and uses c.q, c.gam).
+//
+// Two sweeps over k instead of the reference's five loop nests: (1) forward elimination of the cubic-spline
+// tridiagonal, fused with fetching the field; (2) ONE backward sweep that does the back-substitution, the large-scale
+// constraints on the interface values (:643-680 / :1037-1073) and the subgrid limiters (:691-914 / :1082-1298) with a
+// sliding 5-level register window of a1 -- every operation is the reference's, only the loop nests are merged, so the
+// results are bit-identical while the scratch-slab traffic drops from ~18 to ~11 accesses per level.
+// (|kord| = 11 tests the monotonicity of the NEXT-higher cell's interface values, which a descending sweep has not
+// produced yet; it keeps the unfused sweeps below.)
+template <class Src>
+FV3_HD void profile_col(const ColScr &c, int km, bool is_scalar, double qs, int iv, int kord, double qmin, const Src &src) {
+  const int ak = kord < 0 ? -kord : kord;
+#define DP(k) (CS(pe1, (k) + 1) - CS(pe1, k))
+  // ---- interface values: cubic spline tridiagonal, forward elimination ----
+  if (iv == -2) {  // :572-595 / :941-964
+    double a_prev = src(1);
+    CS(a1, 1) = a_prev;
+    double gam = 0.5, qk = 1.5 * a_prev;
+    CS(q, 1) = qk;
+    CS(gam, 2) = gam;
+    double pe_a = CS(pe1, 1), pe_b = CS(pe1, 2);
+    double dp_prev = pe_b - pe_a;
+    for (int k = 2; k <= km - 1; k++) {
+      const double a_k = src(k);
+      CS(a1, k) = a_k;
+      pe_a = pe_b;
+      pe_b = CS(pe1, k + 1);
+      const double dp_k = pe_b - pe_a;
+      const double grat = dp_prev / dp_k;
+      const double bet = 2. + grat + grat - gam;
+      qk = (3. * (a_prev + a_k) - qk) / bet;
+      gam = grat / bet;
+      CS(q, k) = qk;
+      CS(gam, k + 1) = gam;
+      a_prev = a_k;
+      dp_prev = dp_k;
+    }
+    const double a_km = src(km);
+    CS(a1, km) = a_km;
+    const double grat = dp_prev / (CS(pe1, km + 1) - pe_b);
+    qk = (3. * (a_prev + a_km) - grat * qs - qk) / (2. + grat + grat - gam);
+    CS(q, km) = qk;
+    CS(q, km + 1) = qs;
+  } else {  // :597-623 / :967-1016
+    const double a_1 = src(1), a_2 = src(2);
+    CS(a1, 1) = a_1;
+    CS(a1, 2) = a_2;
+    double pe_a = CS(pe1, 2), pe_b = CS(pe1, 3);
+    double dp_prev = pe_a - CS(pe1, 1), dp_k = pe_b - pe_a;  // DP(1), DP(2)
+    double grat = dp_k / dp_prev;
+    double bet = grat * (grat + 0.5);
+    double qk = ((grat + grat) * (grat + 1.) * a_1 + a_2) / bet;
+    double gam = (1. + grat * (grat + 1.5)) / bet;
+    CS(q, 1) = qk;
+    CS(gam, 1) = gam;
+    double d4 = 0.;
+    double a_prev = a_1, a_k = a_2;
+    for (int k = 2; k <= km; k++) {
+      if (k > 2) {
+        a_prev = a_k;
+        a_k = src(k);
+        CS(a1, k) = a_k;
+        dp_prev = dp_k;
+        pe_a = pe_b;
+        pe_b = CS(pe1, k + 1);
+        dp_k = pe_b - pe_a;
+      }
+      d4 = dp_prev / dp_k;
+      bet = 2. + d4 + d4 - gam;
+      qk = (3. * (a_prev + d4 * a_k) - qk) / bet;
+      gam = d4 / bet;
+      CS(q, k) = qk;
+      CS(gam, k) = gam;
+    }
+    const double a_bot = 1. + d4 * (d4 + 1.5);
+    qk = (2. * d4 * (d4 + 1.) * a_k + a_prev - a_bot * qk) / (d4 * (d4 + 0.5) - a_bot * gam);
+    CS(q, km + 1) = qk;
+  }
+#undef DP
+  if (ak == 11) {
+    profile_col_tail_unfused(c, km, is_scalar, iv, ak, qmin);
+    return;
+  }
+  // ---- backward sweep: back-substitution + constraints + subgrid limiters -------------------------------------------
+  // window of layer means: w_m2 = a1(k-2) .. w_p2 = a1(k+2) for the cell k being finished
+  double qraw = CS(q, km + 1);            // unconstrained q(k+1) of the recurrence
+  double qc_next = qraw;                  // constrained q(k+1)  (q(km+1) is never constrained)
+  double w_p2 = 0., w_p1 = 0., w_0 = CS(a1, km), w_m1 = CS(a1, km - 1), w_m2 = km >= 3 ? CS(a1, km - 2) : 0.;
+  auto cell = [&](int k, double a2v, double a3v, double am2, double am1, double a1v, double ap1, double ap2) {
+    // cell k with interface values a2v = q(k), a3v = q(k+1) and layer means a1(k-2..k+2)
+    double a4v;
+    const double g_m1 = am1 - am2, g_k = a1v - am1, g_p1 = ap1 - a1v, g_p2 = ap2 - ap1;  // dq(k-1), dq(k), dq(k+1), dq(k+2)
+    auto extm_q = [&]() { return (a2v - a1v) * (a3v - a1v) > 0.; };  // k == 1 or km (:691, :1082)
+    if (k == 1) {
+      const bool e = extm_q();
+      if (iv == 0) a2v = dmax(0., a2v);
+      if (iv == -1 && a2v * a1v <= 0.) a2v = 0.;
+      a4v = 3. * (2. * a1v - (a2v + a3v));
+      cs_limit(e, a1v, a2v, a3v, a4v, 1);
+    } else if (k == 2) {
+      a4v = 3. * (2. * a1v - (a2v + a3v));
+      cs_limit(g_k * g_p1 < 0., a1v, a2v, a3v, a4v, 2);
+    } else if (k <= km - 2) {
+      auto huynh = [&]() {
+        const double pmp_1 = a1v - 2. * g_p1, lac_1 = pmp_1 + 1.5 * g_p2;
+        a2v = dmin(dmax(a2v, dmin3(a1v, pmp_1, lac_1)), dmax3(a1v, pmp_1, lac_1));
+        const double pmp_2 = a1v + 2. * g_k, lac_2 = pmp_2 - 1.5 * g_m1;
+        a3v = dmin(dmax(a3v, dmin3(a1v, pmp_2, lac_2)), dmax3(a1v, pmp_2, lac_2));
+      };
+      // extm(k-1), extm(k), extm(k+1) for 3 <= k <= km-2: k-1 >= 2 and k+1 <= km-1 are interior (a1-based) except
+      // k+1 == km ... which cannot happen here (k <= km-2)
+      const bool e_k = g_k * g_p1 < 0.;
+      if (ak <= 8) {
+        huynh();
+        a4v = 3. * (2. * a1v - (a2v + a3v));
+      } else if (ak == 9) {
+        const bool e_m = g_m1 * g_k < 0., e_p = g_p1 * g_p2 < 0.;
+        if ((e_k && e_m) || (e_k && e_p) || (is_scalar && e_k && a1v < qmin)) {
+          a2v = a1v; a3v = a1v; a4v = 0.;
+        } else {
+          a4v = is_scalar ? 3. * (2. * a1v - (a2v + a3v)) : 6. * a1v - 3. * (a2v + a3v);
+          if (fabs(a4v) > fabs(a2v - a3v)) {
+            huynh();
+            a4v = is_scalar ? 3. * (2. * a1v - (a2v + a3v)) : 6. * a1v - 3. * (a2v + a3v);
+          }
+        }
+      } else if (ak == 10) {
+        const bool e_m = g_m1 * g_k < 0., e_p = g_p1 * g_p2 < 0.;
+        if (e_k) {
+          if ((is_scalar && a1v < qmin) || e_m || e_p) {
+            a2v = a1v; a3v = a1v; a4v = 0.;
+          } else {
+            a4v = 6. * a1v - 3. * (a2v + a3v);
+          }
+        } else {
+          a4v = 6. * a1v - 3. * (a2v + a3v);
+          if (fabs(a4v) > fabs(a2v - a3v)) {
+            huynh();
+            a4v = 6. * a1v - 3. * (a2v + a3v);
+          }
+        }
+      } else {  // 13
+        a4v = 3. * (2. * a1v - (a2v + a3v));
+      }
+      if (iv == 0 && ak <= 13) cs_limit(false, a1v, a2v, a3v, a4v, 0);
+    } else {
+      bool e;
+      if (k == km) {
+        e = extm_q();  // uses q(km), q(km+1) before the iv adjustments of a3 (:700 / :1091 come first)
+        if (iv == 0) a3v = dmax(0., a3v);
+        if (iv == -1 && a3v * a1v <= 0.) a3v = 0.;
+      } else {
+        e = g_k * g_p1 < 0.;
+      }
+      a4v = 3. * (2. * a1v - (a2v + a3v));
+      cs_limit(e, a1v, a2v, a3v, a4v, k == km ? 1 : 2);
+    }
+    CS(a2, k) = a2v;
+    CS(a3, k) = a3v;
+    CS(a4, k) = a4v;
+  };
+  for (int k = km; k >= 1; k--) {
+    // back-substitution (:590-595 / :1010-1016); gam index differs between the two eliminations
+    double qk;
+    if (iv == -2)
+      qk = (k == km) ? CS(q, km) : CS(q, k) - CS(gam, k + 1) * qraw;
+    else
+      qk = CS(q, k) - CS(gam, k) * qraw;
+    qraw = qk;
+    // large-scale constraint on q(k) (:643-680 / :1037-1073); window: w_m2 = a1(k-2), w_m1 = a1(k-1), w_0 = a1(k), w_p1 = a1(k+1)
+    double qc = qk;
+    if (k == 2) {
+      const double v = dmin(qc, dmax(w_m1, w_0));
+      qc = dmax(v, dmin(w_m1, w_0));
+    } else if (k == km && km >= 3) {
+      const double v = dmin(qc, dmax(w_m1, w_0));
+      qc = dmax(v, dmin(w_m1, w_0));
+    } else if (k >= 3 && k <= km - 1) {
+      const double gm = w_m1 - w_m2, gp = w_p1 - w_0;  // gam(k-1), gam(k+1)
+      if (ak >= 14 || gm * gp > 0.) {
+        qc = dmin(qc, dmax(w_m1, w_0));
+        qc = dmax(qc, dmin(w_m1, w_0));
+      } else if (gm > 0.) {
+        qc = dmax(qc, dmin(w_m1, w_0));
+      } else {
+        qc = dmin(qc, dmax(w_m1, w_0));
+        if (iv == 0) qc = dmax(0., qc);
+      }
+    }
+    // cell k: interfaces (qc, qc_next), layer means a1(k-2 .. k+2)
+    cell(k, qc, qc_next, w_m2, w_m1, w_0, w_p1, w_p2);
+    qc_next = qc;
+    // slide the window down one level
+    w_p2 = w_p1; w_p1 = w_0; w_0 = w_m1; w_m1 = w_m2;
+    w_m2 = (k - 3 >= 1) ? CS(a1, k - 3) : 0.;
+  }
+}
+
 // the search-and-integrate loop (fv_operators.F90:93-132 == :188-227 == :402-441; tracer_form: :277-335)
 template <class Out>
 FV3_HD void map_col(const ColScr &c, int km, bool tracer_form, const Out &out) {
@@ -318,8 +485,9 @@ struct RemapScalars {
       auto PE = [&](int k) { return pe[peb + (size_t)(k - 1) * (g.nx + 2)]; };
       auto PELN = [&](int k) -> double & { return peln[lnb + (size_t)(k - 1) * g.nx]; };
       const double psfc = PE(km + 1);
-      // ---- 0) temperature transform (:200-229), specific volume (:292) ----
-      for (int k = 1; k <= km; k++) {
+      // ---- 0) temperature transform (:200-229), specific volume (:292): done level by level as the profile
+      //         sweep fetches the field (src is called once per level, in order)
+      auto src_pt = [&](int k) {
         double t = pt[(size_t)(k - 1) * nA + c.o];
         const double dpo = delp[(size_t)(k - 1) * nA + c.o];
         if (p.kord_tm < 0) {
@@ -328,9 +496,9 @@ struct RemapScalars {
           else
             t = t * exp(k1k * log(rrg * dpo / delz[(size_t)(k - 1) * nCC + occ] * t));
         }
-        CS(a1, k) = t;
         if (!p.hydrostatic) delz[(size_t)(k - 1) * nCC + occ] = -delz[(size_t)(k - 1) * nCC + occ] / dpo;
-      }
+        return t;
+      };
       ps[c.o] = psfc;  // :298-300
       // ---- 1) remap T_v (log-p coordinate, :363-368) or theta_v (:370-374) ----
       if (p.kord_tm < 0) {
@@ -339,13 +507,13 @@ struct RemapScalars {
           const double pe2k = (k == 1) ? p.ptop : (k == km + 1 ? psfc : ak[k - 1] + bk[k - 1] * psfc);
           CS(pe2, k) = (k == 1) ? PELN(1) : (k == km + 1 ? PELN(km + 1) : log(pe2k));
         }
-        profile_col(c, km, true, 0., 1, akt, p.t_min);
+        profile_col(c, km, true, 0., 1, akt, p.t_min, src_pt);
       } else {
         for (int k = 1; k <= km + 1; k++) {
           CS(pe1, k) = PE(k);
           CS(pe2, k) = (k == 1) ? p.ptop : (k == km + 1 ? psfc : ak[k - 1] + bk[k - 1] * psfc);
         }
-        profile_col(c, km, false, 0., 1, akt, 0.);
+        profile_col(c, km, false, 0., 1, akt, 0., src_pt);
       }
       map_col(c, km, false, [&](int k, double v) { pt[(size_t)(k - 1) * nA + c.o] = v; });
       // ---- 3.3) omega (:432-443, :506-526): needs the old peln (= pe1 here when kord_tm < 0) ----
@@ -375,17 +543,14 @@ struct RemapScalars {
       // ---- 2) constituents (:380-397) ----
       for (int iq = 0; iq < p.nq; iq++) {
         double *qq = q + (size_t)iq * nA * km;
-        for (int k = 1; k <= km; k++) CS(a1, k) = qq[(size_t)(k - 1) * nA + c.o];
-        profile_col(c, km, true, 0., 0, kord_tr[iq], 0.);
+        profile_col(c, km, true, 0., 0, kord_tr[iq], 0., [&](int k) { return qq[(size_t)(k - 1) * nA + c.o]; });
         map_col(c, km, p.nq > 5, [&](int k, double v) { qq[(size_t)(k - 1) * nA + c.o] = v; });
       }
       // ---- 3) w and delz (:400-423) ----
       if (!p.hydrostatic) {
-        for (int k = 1; k <= km; k++) CS(a1, k) = w[(size_t)(k - 1) * nA + c.o];
-        profile_col(c, km, false, ws[occ], -2, p.kord_wz, 0.);
+        profile_col(c, km, false, ws[occ], -2, p.kord_wz, 0., [&](int k) { return w[(size_t)(k - 1) * nA + c.o]; });
         map_col(c, km, false, [&](int k, double v) { w[(size_t)(k - 1) * nA + c.o] = v; });
-        for (int k = 1; k <= km; k++) CS(a1, k) = delz[(size_t)(k - 1) * nCC + occ];
-        profile_col(c, km, false, 0., 1, akt, 0.);
+        profile_col(c, km, false, 0., 1, akt, 0., [&](int k) { return delz[(size_t)(k - 1) * nCC + occ]; });
         map_col(c, km, false, [&](int k, double v) {
           delz[(size_t)(k - 1) * nCC + occ] = -v * (CS(pe2, k + 1) - CS(pe2, k));
         });
@@ -462,8 +627,7 @@ struct RemapWinds {
       }
       double *f = which == 0 ? u + g.iU(i, j) : v + g.iV(i, j);
       const size_t fs = which == 0 ? nU : nV;
-      for (int k = 1; k <= km; k++) CS(a1, k) = f[(size_t)(k - 1) * fs];
-      profile_col(c, km, false, 0., -1, p.kord_mt, 0.);
+      profile_col(c, km, false, 0., -1, p.kord_mt, 0., [&](int k) { return f[(size_t)(k - 1) * fs]; });
       map_col(c, km, false, [&](int k, double val) { f[(size_t)(k - 1) * fs] = val; });
     }
   }
