@@ -239,3 +239,59 @@ def test_update_dz_d_and_tracers_multi_strip_march(prod):
 
 def test_halo_pack_unpack_kernels(prod):
     P.check_halo_packed(prod)
+
+
+def test_c384_tile_vs_oracle(prod):
+    """the C384 horizontal tile (7 strips x 8 segments of the marching kernels), a few levels: bit-level parity"""
+    assert P.check_c_sw(prod, nx=384, ny=384, npz=5) <= P.TOL
+    assert max(P.check_d_sw(prod, nx=384, ny=384, npz=5).values()) <= P.TOL
+
+
+def test_c384l127_flux_form_properties(prod):
+    """BASELINE size 384 x 384 x 127 on the GPU alone: size-independent properties of the pair --
+    mass conservation of d_sw (sw_core.F90:1059-1060) and consistency of the flux capacitors with the delp update"""
+    import numpy as np
+    from fields import smooth_state
+    from gfdl_atmos_cubed_sphere_amd.halo import HaloExchanger
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    from test_oracle_properties import default_levels
+    nx, npz = 384, 127
+    bd = Bounds(1, nx, 1, nx)
+    g = P.make_grid(bd, False)   # constant metrics: a truly periodic tile
+    ctx = Context(g, npz, lib=prod)
+    try:
+        halo = HaloExchanger(ctx, 1, 1, 0, 1)
+        st = smooth_state(bd, npz, noise=0.05)
+        d = {k: ctx.from_host(v) for k, v in st.items()}
+        for n, kind in P.CSW_OUT:
+            d[n] = ctx.zeros(kind, npz)
+        for n, kind in (("mfx", "FX"), ("mfy", "FY"), ("cx", "CX"), ("cy", "CY"), ("crx", "CX"), ("cry", "CY"),
+                        ("xfx", "CX"), ("yfx", "CY"), ("delp_out", "A"), ("pt_out", "A"), ("u_out", "U"),
+                        ("v_out", "V"), ("w_out", "A"), ("heat_s", "CC"), ("diss_e", "CC")):
+            d[n] = ctx.zeros(kind, npz)
+        ctx.dsw_levels(default_levels(npz))
+        par = dict(P.DSW_PAR)
+        par.update(hydrostatic=0, use_cond=0)
+        dt = par["dt"]
+        halo.update([(d["delp"], "A"), (d["pt"], "A"), (d["w"], "A"), (d["u"], "U"), (d["v"], "V")])  # periodic state
+        st["delp"] = d["delp"].download()
+        ctx.c_sw(d["delpc"], d["delp"], d["ptc"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"],
+                 d["wc"], d["ut"], d["vt"], d["divg_d"], 1, 0.5 * dt, False)
+        halo.update([(d["uc"], "V"), (d["vc"], "U"), (d["divg_d"], "B")])
+        ctx.d_sw(par, None, d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"], d["divg_d"],
+                 d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None, d["delp_out"],
+                 d["pt_out"], d["u_out"], d["v_out"], d["w_out"], None, d["heat_s"], d["diss_e"])
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        dp0 = bd.view(st["delp"], "A", *r)
+        dp1 = bd.view(d["delp_out"].download(), "A", *r)
+        area = bd.view(g.area, "A", *r)[:, :, None]
+        m0, m1 = np.sum(dp0 * area, axis=(0, 1)), np.sum(dp1 * area, axis=(0, 1))
+        assert np.all(np.isfinite(dp1)) and np.max(np.abs(m1 - m0) / m0) < 1e-13        # per level, periodic domain
+        mfx, mfy = d["mfx"].download(), d["mfy"].download()                                # started from zero
+        div = (mfx[:-1] - mfx[1:] + mfy[:, :-1] - mfy[:, 1:]) * bd.view(g.rarea, "A", *r)[:, :, None]
+        assert np.max(np.abs((dp1 - dp0) - div)) <= 1e-12 * np.max(np.abs(dp0))
+        for n in ("pt_out", "w_out", "u_out", "v_out"):
+            assert np.all(np.isfinite(d[n].download())), n
+    finally:
+        ctx.close()
