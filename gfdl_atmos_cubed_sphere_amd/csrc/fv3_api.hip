@@ -74,6 +74,7 @@ struct fv3_ctx {
   int march_tj;          // rows per wavefront segment of the marching kernels
   int march_tj_csw, march_tj_ke, march_tj_fused;
   int csw_kpw;           // levels per wavefront in CswMarch (1 or 2; FV3_MI355X_CSW_KPW)
+  int mom_overlap;       // 1: unfused momentum with its KE kernel on the side stream, concurrent with the transports
   int use_fused;         // 1: delp + w + pt in one marching kernel when the schemes allow (FV3_MI355X_FUSED=0: off)
   int use_march;         // 0: LDS-tile kernels only (FV3_MI355X_MARCH=0)
   bool prof_on;
@@ -218,6 +219,8 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_CSW_KPW");
     c->csw_kpw = e ? std::atoi(e) : 2;
     if (c->csw_kpw < 1 || c->csw_kpw > 3) c->csw_kpw = 2;
+    e = std::getenv("FV3_MI355X_MOM_OVERLAP");
+    c->mom_overlap = e ? std::atoi(e) : 0;
     e = std::getenv("FV3_MI355X_FUSED");
     c->use_fused = e ? std::atoi(e) : 1;
     e = std::getenv("FV3_MI355X_MARCH_TJ_FUSED");
@@ -586,10 +589,12 @@ static int dsw_transport_march(fv3_ctx *c, const DswArgs &a) {
 }
 
 // d_sw momentum on the marching stencils (dsw_march.h) for the levels in klist_m[0 : n_plain_m]
-static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a) {
+// part = 0: everything; 1: only the KE / damping kernel (unfused path); 2: only the vorticity kernel
+static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
   const Grid &g = c->g;
-  if (!c->use_fused && !c->ke_scr) RT(rt_malloc((void **)&c->ke_scr, sizeof(double) * g.nB() * g.npz));
-  if (c->use_fused) {
+  const bool fused_m = c->use_fused && !c->mom_overlap;
+  if (!fused_m && !c->ke_scr) RT(rt_malloc((void **)&c->ke_scr, sizeof(double) * g.nB() * g.npz));
+  if (fused_m) {
     MarchDims mf = make_march_dims(g, c->march_tj_fused);
     mf.klist = c->klist_m;
     const int nwf = mf.nwaves(c->n_plain_m);
@@ -602,16 +607,18 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a) {
       }
     });
   }
-  MarchDims mk = make_march_dims(g, c->march_tj_ke);
-  mk.klist = c->klist_m;
-  const int nwk = mk.nwaves(c->n_plain_m);
-  int rc;
-  switch (sw_class(a.hord_mt)) {
-    case 5: rc = launch_w(c, "d_sw_ke", nwk, DswKeMarch<5>{g, a, mk, c->ke_scr}); break;
-    case 6: rc = launch_w(c, "d_sw_ke", nwk, DswKeMarch<6>{g, a, mk, c->ke_scr}); break;
-    default: rc = launch_w(c, "d_sw_ke", nwk, DswKeMarch<8>{g, a, mk, c->ke_scr}); break;
+  if (part != 2) {
+    MarchDims mk = make_march_dims(g, c->march_tj_ke);
+    mk.klist = c->klist_m;
+    const int nwk = mk.nwaves(c->n_plain_m);
+    int rc;
+    switch (sw_class(a.hord_mt)) {
+      case 5: rc = launch_w(c, "d_sw_ke", nwk, DswKeMarch<5>{g, a, mk, c->ke_scr}); break;
+      case 6: rc = launch_w(c, "d_sw_ke", nwk, DswKeMarch<6>{g, a, mk, c->ke_scr}); break;
+      default: rc = launch_w(c, "d_sw_ke", nwk, DswKeMarch<8>{g, a, mk, c->ke_scr}); break;
+    }
+    if (rc || part == 1) return rc;
   }
-  if (rc) return rc;
   MarchDims md = make_march_dims(g, c->march_tj);
   md.klist = c->klist_m;
   const int nw = md.nwaves(c->n_plain_m);
@@ -705,12 +712,20 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, cons
     int rc = courant();
     if (!rc) rc = tile_transport();
     if (!rc) rc = tile_momentum();
+    // the KE / damping kernel of the marching levels reads only u, v, uc, vc, divg_d: it can share the machine with
+    // the register-heavy fused transport kernel (96 + 336 VGPRs fit one SIMD together)
+    if (!rc && c->mom_overlap) rc = dsw_momentum_march(c, a, 1);
     rt_event_record(c->ev_join, c->stream2);
     c->stream = main_stream;
     RT(rc);
     RT(dsw_transport_march(c, a));
-    RT(dsw_momentum_march(c, a));
-    rt_stream_wait_event(main_stream, c->ev_join);
+    if (c->mom_overlap) {
+      rt_stream_wait_event(main_stream, c->ev_join);
+      RT(dsw_momentum_march(c, a, 2));
+    } else {
+      RT(dsw_momentum_march(c, a));
+      rt_stream_wait_event(main_stream, c->ev_join);
+    }
     return 0;
   }
   RT(courant());
