@@ -1025,6 +1025,56 @@ extern "C" int fv3_p_grad_c(fv3_ctx *c, double dt2, const double *delpc, const d
   return 0;
 }
 
+extern "C" int fv3_heat_source_accum(fv3_ctx *c, double *heat_source, const double *heat_s) {
+  if (!c || !c->grid_ready || !heat_source || !heat_s) return fail("fv3_heat_source_accum: bad context/arguments");
+  const Grid &g = c->g;
+  HeatAccum kf{g, heat_source, heat_s};
+  Dim3 grid;
+  grid.x = (unsigned)((g.nx * g.ny + HeatAccum::CH - 1) / HeatAccum::CH);
+  grid.y = 1;
+  grid.z = (unsigned)g.npz;
+  RT(launch_p(c, "heat_accum", grid, 0, kf));
+  return 0;
+}
+
+extern "C" int fv3_del2_cubed(fv3_ctx *c, double *q, int nk, double cd, int nmax) {
+  if (!c || !c->grid_ready || !q) return fail("fv3_del2_cubed: bad context/arguments");
+  if (nk < 1 || nk > c->g.npz + 1) return fail("fv3_del2_cubed: nk out of range");
+  if (need_scratch(c, 1)) return 1;
+  const Grid &g = c->g;
+  const int ntimes = nmax < 3 ? nmax : 3;
+  double *src = q, *dst = c->scratch[0];
+  for (int n = 1; n <= ntimes; n++) {
+    Del2Pass kf{g, src, dst, cd, ntimes - n};
+    Dim3 grid;
+    grid.x = (unsigned)((g.nid * g.njd + Del2Pass::CH - 1) / Del2Pass::CH);
+    grid.y = 1;
+    grid.z = (unsigned)nk;
+    RT(launch_p(c, "del2_cubed", grid, 0, kf));
+    double *t = src; src = dst; dst = t;
+  }
+  if (src != q) RT(rt_d2d(q, src, sizeof(double) * g.nA() * nk, c->stream));
+  return 0;
+}
+
+extern "C" int fv3_apply_heat_source(fv3_ctx *c, int n_con, int hydrostatic, double bdt, double delt_max, double cp_air,
+                                     double cv_air, double rdgas, double grav, double *pt, double *heat_source,
+                                     const double *delp, const double *delz, double *pkz) {
+  if (!c || !c->grid_ready) return fail("fv3_apply_heat_source: context has no grid");
+  if (!pt || !heat_source || !delp || !pkz || (!hydrostatic && !delz)) return fail("fv3_apply_heat_source: null field");
+  const Grid &g = c->g;
+  if (n_con < 0 || n_con > g.npz) return fail("fv3_apply_heat_source: n_con out of range");
+  if (n_con == 0) return 0;
+  HeatApply kf{g, n_con, hydrostatic, bdt, delt_max, cp_air, cv_air, -rdgas / grav, rdgas / cv_air, pt, heat_source, delp,
+               delz, pkz};
+  Dim3 grid;
+  grid.x = (unsigned)((g.nx * g.ny + HeatApply::CH - 1) / HeatApply::CH);
+  grid.y = 1;
+  grid.z = (unsigned)n_con;
+  RT(launch_p(c, "heat_apply", grid, 0, kf));
+  return 0;
+}
+
 extern "C" int fv3_zh_from_delz(fv3_ctx *c, const double *zs, const double *delz, double *zh) {
   if (!c || !c->grid_ready) return fail("fv3_zh_from_delz: context has no grid");
   ZhFromDelz kf{c->g, c->g.npz, zs, delz, zh};

@@ -739,4 +739,85 @@ struct Geopk {  // geopk, dyn_core.F90:2202-2353 (use_cond = .false.)
   }
 };
 
+// ------------------------------------------------------------------------------------------------
+// dissipative heating after the substep loop (dyn_core.F90:798-803, :1300-1355, del2_cubed :2356-2465)
+struct HeatAccum {
+  Grid g;
+  double *hs3;        // A x npz
+  const double *hs2;  // CC x npz
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int n = g.nx * g.ny;
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.is + idx % g.nx, j = g.js + idx / g.nx;
+      double *p = hs3 + (size_t)bz * g.nA() + g.iA(i, j);
+      *p = *p + hs2[(size_t)bz * g.nCC() + idx];
+    }
+  }
+};
+
+struct Del2Pass {  // one pass of del2_cubed on the box [is-nt, ie+nt] x [js-nt, je+nt], out of place
+  Grid g;
+  const double *qi;
+  double *qo;
+  double cd;
+  int nt;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int n = g.nid * g.njd;
+    const double *q = qi + (size_t)bz * g.nA();
+    double *o = qo + (size_t)bz * g.nA();
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.isd + idx % g.nid, j = g.jsd + idx / g.nid;
+      double v = q[idx];
+      if (i >= g.is - nt && i <= g.ie + nt && j >= g.js - nt && j <= g.je + nt) {
+        const double fx0 = g.del6_v[g.iV(i, j)] * (q[g.iA(i - 1, j)] - v);
+        const double fx1 = g.del6_v[g.iV(i + 1, j)] * (v - q[g.iA(i + 1, j)]);
+        const double fy0 = g.del6_u[g.iU(i, j)] * (q[g.iA(i, j - 1)] - v);
+        const double fy1 = g.del6_u[g.iU(i, j + 1)] * (v - q[g.iA(i, j + 1)]);
+        v = v + cd * g.rarea[idx] * (fx0 - fx1 + fy0 - fy1);
+      }
+      o[idx] = v;
+    }
+  }
+};
+
+struct HeatApply {
+  Grid g;
+  int n_con, hydrostatic;
+  double bdt, delt_max, cp_air, cv_air, rdg, k1k;
+  double *pt, *hs;
+  const double *delp, *delz;
+  double *pkz;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int k = bz + 1, n = g.nx * g.ny;
+    if (k > n_con) return;
+    double delt = fabs(bdt * delt_max);
+    if (!hydrostatic) {
+      if (k == 1) delt = 0.1 * delt;
+      if (k == 2) delt = 0.5 * delt;
+    }
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.is + idx % g.nx, j = g.js + idx / g.nx;
+      const size_t o = (size_t)bz * g.nA() + g.iA(i, j), c = (size_t)bz * g.nCC() + idx;
+      if (hydrostatic) {
+        if (k < 3) {
+          pt[o] = pt[o] + hs[o] / (cp_air * delp[o] * pkz[c]);
+        } else {
+          const double dtmp = hs[o] / (cp_air * delp[o]);
+          pt[o] = pt[o] + fsign(dmin(fabs(bdt) * delt_max, fabs(dtmp)), dtmp) / pkz[c];
+          hs[o] = dtmp;
+        }
+      } else {
+        const double pz = exp(k1k * log(rdg * delp[o] / delz[c] * pt[o]));
+        pkz[c] = pz;
+        const double dtmp = hs[o] / (cv_air * delp[o]);
+        pt[o] = pt[o] + fsign(dmin(delt, fabs(dtmp)), dtmp) / pz;
+        hs[o] = dtmp;
+      }
+    }
+  }
+};
+
 }  // namespace fv3

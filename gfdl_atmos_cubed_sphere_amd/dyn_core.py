@@ -33,6 +33,8 @@ class DynFlags:
     vtdm4: float = 0.0
     do_vort_damp: bool = False
     d_con: float = 0.0
+    delt_max: float = 1.0    # K/s, fv_arrays.F90:667
+    convert_ke: bool = False
     ke_bg: float = 0.0
     hord_mt: int = 10
     hord_vt: int = 10
@@ -152,6 +154,13 @@ class DynCore:
         peln1 = np.log(fl.ptop)
         for a in ("mfx", "mfy", "cx", "cy"):  # :289-292 empty the flux capacitors
             d[a].zero()
+        heating = fl.d_con > 1.0e-5
+        if heating:                            # :294
+            if "heat_source" not in d:
+                d["heat_source"] = ctx.zeros("A", self.npz)
+            if "pkz" not in d:
+                d["pkz"] = ctx.zeros("CC", self.npz)
+            d["heat_source"].zero()
         par = dict(dt=dt, hord_tr=fl.hord_tr, hord_mt=fl.hord_mt, hord_vt=fl.hord_vt, hord_tm=fl.hord_tm,
                    hord_dp=fl.hord_dp, dddmp=fl.dddmp, d4_bg=fl.d4_bg, kgb=fl.ke_bg, hydrostatic=0, use_cond=0)
         # fv_dynamics.F90:467-470: halo of delp, pt (pack 1) and u, v (pack 8) before the first substep
@@ -174,6 +183,8 @@ class DynCore:
             ctx.d_sw(par, d["vt"], d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"],
                      d["divgd"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
                      d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], d["w_nxt"], None, d["heat_s"], d["diss_e"])  # :762
+            if heating:
+                ctx.heat_source_accum(d["heat_source"], d["heat_s"])          # :798-803
             for n in ("delp", "pt", "u", "v", "w"):
                 self._swap(n)
             halo.update([(d["delp"], "A"), (d["pt"], "A")])                   # :823-824 / :851 (pack 1)
@@ -191,3 +202,19 @@ class DynCore:
                           peln1 if fl.use_logp else ptk, gz_scale=fl.grav)    # :1032
             if it != n_split:
                 halo.update([(d["u"], "U"), (d["v"], "V")])                   # :1168-1169 (pack 8)
+        # ---- dissipative heating (:296-308, :1300-1355) ----
+        n_con = self.n_con()
+        if n_con != 0 and heating:
+            halo.update([(d["heat_source"], "A")])                            # del2_cubed's mpp_update_domains, :2399
+            ctx.del2_cubed(d["heat_source"], 0.20 * ctx.grid.da_min, min(3, fl.nord + 1))    # :1301-1303
+            ctx.apply_heat_source(n_con, False, bdt, fl.delt_max, fl.cp_air, fl.cp_air - fl.rdgas, fl.rdgas, fl.grav,
+                                  d["pt"], d["heat_source"], d["delp"], d["delz"], d["pkz"])
+
+    def n_con(self) -> int:
+        """number of levels that receive the dissipative heating (dyn_core.F90:296-308)"""
+        fl = self.fl
+        if fl.convert_ke or (fl.do_vort_damp and fl.vtdm4 > 1.0e-4):
+            return self.npz
+        if fl.d2_bg_k1 < 1.0e-3:
+            return 0
+        return 1 if fl.d2_bg_k2 < 1.0e-3 else 2

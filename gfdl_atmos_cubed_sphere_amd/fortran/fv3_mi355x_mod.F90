@@ -15,6 +15,7 @@ module fv3_mi355x_mod
   public :: fv3_pe_halo, fv3_geopk, fv3_set_ak_bk, fv3_lagrangian_to_eulerian, fv3_tracer_2d_prep
   public :: fv3_tracer_2d_scale, fv3_tracer_2d_step
   public :: fv3_halo_field, fv3_halo_message_elems, fv3_halo_pack, fv3_halo_unpack
+  public :: fv3_heat_source_accum, fv3_del2_cubed, fv3_apply_heat_source
 
   type, bind(C) :: fv3_domain
     integer(c_int) :: is, ie, js, je, ng, npx, npy, npz, grid_type
@@ -162,6 +163,23 @@ module fv3_mi355x_mod
       integer(c_int), value :: nfields
       type(fv3_halo_field), intent(in) :: fields(*)
       type(c_ptr), intent(in) :: recvbuf(8)
+    end function
+    integer(c_int) function fv3_heat_source_accum(ctx, heat_source, heat_s) bind(C, name="fv3_heat_source_accum")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx, heat_source, heat_s
+    end function
+    integer(c_int) function fv3_del2_cubed(ctx, q, nk, cd, nmax) bind(C, name="fv3_del2_cubed")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, q
+      integer(c_int), value :: nk, nmax
+      real(c_double), value :: cd
+    end function
+    integer(c_int) function fv3_apply_heat_source(ctx, n_con, hydrostatic, bdt, delt_max, cp_air, cv_air, rdgas, grav, &
+                                                  pt, heat_source, delp, delz, pkz) bind(C, name="fv3_apply_heat_source")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, pt, heat_source, delp, delz, pkz
+      integer(c_int), value :: n_con, hydrostatic
+      real(c_double), value :: bdt, delt_max, cp_air, cv_air, rdgas, grav
     end function
     ! ---- nonhydrostatic column path, vertical remap, tracer transport --------------------------------
     integer(c_int) function fv3_memcpy_d2d(ctx, dst, src, bytes) bind(C, name="fv3_memcpy_d2d")

@@ -32,7 +32,7 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
-           "fv3_halo_unpack", "fv3_profile", "fv3_profile_report",
+           "fv3_halo_unpack", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
@@ -387,6 +387,21 @@ class Context:
                                                        C.c_int(nq), C.c_int(hord), C.c_int(nord_tr), C.c_double(trdm),
                                                        q.p, q_out.p, dp1.p, dp1_out.p, mfx.p, mfy.p, cx.p, cy.p, xfx.p,
                                                        yfx.p), "fv3_tracer_2d_step")
+
+    # ---- dissipative heating after the substep loop (dyn_core.F90:798-803, :1300-1355) ---------------------------
+    def heat_source_accum(self, heat_source, heat_s):
+        self.lib.check(self.lib.dll.fv3_heat_source_accum(self.h, heat_source.p, heat_s.p), "fv3_heat_source_accum")
+
+    def del2_cubed(self, q, cd: float, nmax: int):
+        nk = int(np.prod(q.shape[2:])) if len(q.shape) > 2 else 1
+        self.lib.check(self.lib.dll.fv3_del2_cubed(self.h, q.p, C.c_int(nk), C.c_double(cd), C.c_int(nmax)), "fv3_del2_cubed")
+
+    def apply_heat_source(self, n_con, hydrostatic, bdt, delt_max, cp_air, cv_air, rdgas, grav, pt, heat_source, delp, delz,
+                          pkz):
+        self.lib.check(self.lib.dll.fv3_apply_heat_source(
+            self.h, C.c_int(n_con), C.c_int(int(hydrostatic)), C.c_double(bdt), C.c_double(delt_max), C.c_double(cp_air),
+            C.c_double(cv_air), C.c_double(rdgas), C.c_double(grav), pt.p, heat_source.p, delp.p,
+            delz.p if delz is not None else None, pkz.p), "fv3_apply_heat_source")
 
     # ---- multi-rank halo exchange: pack / unpack (the transfers are halo.py's) ---------------------------
     def _halo_fields(self, fields):

@@ -216,6 +216,19 @@ int fv3_pe_halo(fv3_ctx *ctx, double ptop, double *pe, const double *delp);
 int fv3_geopk(fv3_ctx *ctx, double ptop, double akap, double cp_air, double ptk, double *pe, double *peln,
               const double *delp, double *pk, double *gz, const double *hs, const double *pt, double *pkz, int CG);
 
+/* ---- dissipative heating after the substep loop (model/dyn_core.F90:798-803, :1300-1355) -------------------------
+ * heat_source: A x npz (the caller zeroes it at the start of dyn_core, :294).
+ * accum: heat_source += heat_s on the compute domain after every d_sw (d_con > 1e-5).
+ * del2_cubed -- model/dyn_core.F90:2356: min(3, nmax) smoothing passes on shrinking boxes; the halo of q must be up
+ *   to date on entry (the reference calls mpp_update_domains first, :2399); uses one context scratch slab.
+ * apply: pt += sign(min(delt, |dT|), dT)/pkz etc. for k = 1..n_con (moist_kappa = .false.); nonhydrostatic: pkz is
+ *   recomputed from delp, delz, pt (:1347); delz, pkz: CC x npz. */
+int fv3_heat_source_accum(fv3_ctx *ctx, double *heat_source, const double *heat_s);
+int fv3_del2_cubed(fv3_ctx *ctx, double *q, int nk, double cd, int nmax);
+int fv3_apply_heat_source(fv3_ctx *ctx, int n_con, int hydrostatic, double bdt, double delt_max, double cp_air,
+                          double cv_air, double rdgas, double grav, double *pt, double *heat_source, const double *delp,
+                          const double *delz, double *pkz);
+
 /* ---- vertical remap ------------------------------------------------------------------------------------
  * Lagrangian_to_Eulerian -- model/fv_mapz.F90:56-64, call site model/fv_dynamics.F90:607.  Branches built:
  * remap_te=.false., use_cond=moist_kappa=.false., consv=0, fill=.false., |kord| in {8,9,10,11,13}, kord_wz>0.

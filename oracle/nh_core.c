@@ -615,3 +615,76 @@ int fvo_geopk(const fvo_grid *g, int km, double ptop, double akap, double cp_air
 #undef PELN
   return FVO_OK;
 }
+
+/* del2_cubed, model/dyn_core.F90:2356-2465 (grid_type >= 3: no cube corners, no copy_corners; the halo of q
+ * must be up to date on entry -- the reference calls mpp_update_domains first, :2399).  q: A x km, in place. */
+int fvo_del2_cubed(const fvo_grid *g, int km, double cd, int nmax, double *q) {
+  BOUNDS(g);
+  int k;
+  if (g->grid_type < 3) return FVO_ERR_UNSUPPORTED;
+  const int ntimes = nmax < 3 ? nmax : 3;
+#pragma omp parallel for schedule(dynamic)
+  for (k = 1; k <= km; k++) {
+    int i, j, n;
+    double *fx = dalloc((size_t)(nid + 1) * njd), *fy = dalloc((size_t)nid * (njd + 1));
+    for (n = 1; n <= ntimes; n++) {
+      const int nt = ntimes - n;
+      for (j = js - nt; j <= je + nt; j++)
+        for (i = is - nt; i <= ie + 1 + nt; i++)
+          fx[IV(i, j)] = g->del6_v[IV(i, j)] * (q[A3(i - 1, j, k)] - q[A3(i, j, k)]); /* :2440 */
+      for (j = js - nt; j <= je + 1 + nt; j++)
+        for (i = is - nt; i <= ie + nt; i++)
+          fy[IU(i, j)] = g->del6_u[IU(i, j)] * (q[A3(i, j - 1, k)] - q[A3(i, j, k)]); /* :2452 */
+      for (j = js - nt; j <= je + nt; j++)
+        for (i = is - nt; i <= ie + nt; i++)
+          q[A3(i, j, k)] = q[A3(i, j, k)] +
+                           cd * g->rarea[IA(i, j)] * (fx[IV(i, j)] - fx[IV(i + 1, j)] + fy[IU(i, j)] - fy[IU(i, j + 1)]);
+    }
+    free(fx);
+    free(fy);
+  }
+  return FVO_OK;
+}
+
+/* Application of the dissipative heating after the substep loop, model/dyn_core.F90:1306-1355
+ * (moist_kappa = .false.).  pt, delp, heat_source: A x npz; delz, pkz: CC x npz.  heat_source is overwritten
+ * with the applied rate where the reference does so. */
+int fvo_apply_heat_source(const fvo_grid *g, int npz, int n_con, int hydrostatic, double bdt, double delt_max,
+                          double cp_air, double cv_air, double rdgas, double grav, double *pt, double *heat_source,
+                          const double *delp, const double *delz, double *pkz) {
+  BOUNDS(g);
+  int i, j, k;
+  const double rdg = -rdgas / grav, k1k = rdgas / cv_air;
+  if (hydrostatic) {
+    for (j = js; j <= je; j++)
+      for (k = 1; k <= n_con; k++) {
+        if (k < 3) {
+          for (i = is; i <= ie; i++)
+            pt[A3(i, j, k)] = pt[A3(i, j, k)] +
+                              heat_source[A3(i, j, k)] / (cp_air * delp[A3(i, j, k)] * pkz[(size_t)(k - 1) * nx * ny + ICC(i, j)]);
+        } else {
+          for (i = is; i <= ie; i++) {
+            const double dtmp = heat_source[A3(i, j, k)] / (cp_air * delp[A3(i, j, k)]);
+            const double lim = fmin(fabs(bdt) * delt_max, fabs(dtmp));
+            pt[A3(i, j, k)] = pt[A3(i, j, k)] + copysign(lim, dtmp) / pkz[(size_t)(k - 1) * nx * ny + ICC(i, j)];
+            heat_source[A3(i, j, k)] = dtmp;
+          }
+        }
+      }
+  } else {
+    for (k = 1; k <= n_con; k++) {
+      double delt = fabs(bdt * delt_max);
+      if (k == 1) delt = 0.1 * delt;
+      if (k == 2) delt = 0.5 * delt;
+      for (j = js; j <= je; j++)
+        for (i = is; i <= ie; i++) {
+          const size_t c = (size_t)(k - 1) * nx * ny + ICC(i, j);
+          pkz[c] = exp(k1k * log(rdg * delp[A3(i, j, k)] / delz[c] * pt[A3(i, j, k)]));
+          const double dtmp = heat_source[A3(i, j, k)] / (cv_air * delp[A3(i, j, k)]);
+          pt[A3(i, j, k)] = pt[A3(i, j, k)] + copysign(fmin(delt, fabs(dtmp)), dtmp) / pkz[c];
+          heat_source[A3(i, j, k)] = dtmp;
+        }
+    }
+  }
+  return FVO_OK;
+}

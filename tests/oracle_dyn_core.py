@@ -46,6 +46,9 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
     ndif = np.concatenate([lev["nord_v"], lev["nord_v"][-1:]]).astype(np.int32)
     damp = np.concatenate([lev["damp_vt"], lev["damp_vt"][-1:]])
     _fill(bd, f["delp"], "A"); _fill(bd, f["pt"], "A"); _fill(bd, f["u"], "U"); _fill(bd, f["v"], "V")
+    heating = fl.d_con > 1.0e-5
+    f["heat_source"] = bd.zeros("A", npz)
+    f["pkz"] = bd.zeros("CC", npz)
     for it in range(1, n_split + 1):
         remap_step = it == n_split
         _fill(bd, f["w"], "A")
@@ -73,6 +76,9 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
                   cy=f["cy"], crx=f["crx"], cry=f["cry"], xfx=f["xfx"], yfx=f["yfx"], heat_source=f["heat_s"],
                   diss_est=f["diss_e"])
         O.d_sw_3d(g, npz, par, lev, ds)
+        if heating:                                                        # dyn_core.F90:798-803
+            i0, j0 = bd.ng, bd.ng
+            f["heat_source"][i0:i0 + nx, j0:j0 + ny, :] += f["heat_s"]
         _fill(bd, f["delp"], "A"); _fill(bd, f["pt"], "A")
         O.update_dz_d(g, npz, ndif.copy(), damp.copy(), fl.hord_tm, dp_ref, zs, f["zh"], f["crx"], f["cry"], f["xfx"],
                       f["yfx"], f["ws"], rdt)
@@ -87,4 +93,16 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
         O.nh_p_grad(g, npz, f["u"], f["v"], f["pkc"], f["gz"], f["delp"], f["pk3"], dt, peln1 if fl.use_logp else ptk)
         if it != n_split:
             _fill(bd, f["u"], "U"); _fill(bd, f["v"], "V")
+    # dissipative heating (dyn_core.F90:296-308, :1300-1355)
+    if fl.convert_ke or (fl.do_vort_damp and fl.vtdm4 > 1.0e-4):
+        n_con = npz
+    elif fl.d2_bg_k1 < 1.0e-3:
+        n_con = 0
+    else:
+        n_con = 1 if fl.d2_bg_k2 < 1.0e-3 else 2
+    if n_con != 0 and heating:
+        _fill(bd, f["heat_source"], "A")
+        O.del2_cubed(g, npz, 0.20 * g.da_min, min(3, fl.nord + 1), f["heat_source"])
+        O.apply_heat_source(g, npz, n_con, False, bdt, fl.delt_max, fl.cp_air, fl.cp_air - fl.rdgas, fl.rdgas, fl.grav,
+                            f["pt"], f["heat_source"], f["delp"], f["delz"], f["pkz"])
     return f

@@ -212,6 +212,19 @@ def pk3_halo(g, npz, ptop, akap, pk3, delp, use_logp):
     assert lib().fvo_pk3_halo(C.byref(gs), C.c_int(npz), _d(ptop), _d(akap), p(pk3), p(delp), C.c_int(int(use_logp))) == 0
 
 
+def del2_cubed(g, km, cd, nmax, q):
+    gs = make_grid(g)
+    assert lib().fvo_del2_cubed(C.byref(gs), C.c_int(km), _d(cd), C.c_int(nmax), p(q)) == 0
+
+
+def apply_heat_source(g, npz, n_con, hydrostatic, bdt, delt_max, cp_air, cv_air, rdgas, grav, pt, heat_source, delp, delz,
+                      pkz):
+    gs = make_grid(g)
+    assert lib().fvo_apply_heat_source(C.byref(gs), C.c_int(npz), C.c_int(n_con), C.c_int(int(hydrostatic)), _d(bdt),
+                                       _d(delt_max), _d(cp_air), _d(cv_air), _d(rdgas), _d(grav), p(pt), p(heat_source),
+                                       p(delp), p(delz), p(pkz)) == 0
+
+
 def pe_halo(g, npz, ptop, pe, delp):
     gs = make_grid(g)
     assert lib().fvo_pe_halo(C.byref(gs), C.c_int(npz), _d(ptop), p(pe), p(delp)) == 0

@@ -251,3 +251,47 @@ def check_halos_and_geopk(lib, nx=24, ny=13, km=6):
                 P.assert_close(f"geopk {n} CG={CG}", dd[n].download(), o[n], tol)
     finally:
         ctx.close()
+
+
+def check_heat_source_path(lib, nx=24, ny=13, km=6, hydrostatic=False, n_con=None, nmax=2):
+    """heat_source accumulation, del2_cubed and the heating application against the oracle"""
+    from gfdl_atmos_cubed_sphere_amd.layout import periodic_fill
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, True)
+    s = nh_state(bd, km, seed=5)
+    rng = np.random.default_rng(8)
+    n_con = km if n_con is None else n_con
+    hs3 = np.asfortranarray(rng.uniform(-1, 1, bd.shape("A", km)) * 1.0e3)
+    hs2 = np.asfortranarray(rng.uniform(-1, 1, bd.shape("CC", km)) * 1.0e3)
+    delz = np.asfortranarray(np.diff(s["zh"], axis=2)[bd.ng:bd.ng + nx, bd.ng:bd.ng + ny, :])
+    pkz = np.asfortranarray(rng.uniform(0.9, 1.1, bd.shape("CC", km)))
+    pt = s["pt"].copy(order="F")
+    # oracle
+    r_hs = hs3.copy(order="F")
+    r_hs[bd.ng:bd.ng + nx, bd.ng:bd.ng + ny, :] += hs2
+    for k in range(km):
+        periodic_fill(bd, r_hs[:, :, k], "A")
+    filled = r_hs.copy(order="F")
+    O.del2_cubed(g, km, 0.20 * g.da_min, nmax, r_hs)
+    r_pt, r_pkz = pt.copy(order="F"), pkz.copy(order="F")
+    O.apply_heat_source(g, km, n_con, hydrostatic, 37.5, 1.0, CP_AIR, CP_AIR - RDGAS, RDGAS, GRAV, r_pt, r_hs, s["delp"], delz,
+                        r_pkz)
+    ctx = Context(g, km, lib=lib)
+    try:
+        d_hs, d_hs2 = ctx.from_host(hs3), ctx.from_host(hs2)
+        ctx.heat_source_accum(d_hs, d_hs2)
+        got = d_hs.download()
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        P.assert_close("accum", bd.view(got, "A", *r), bd.view(filled, "A", *r), 0.0 + 1e-300)
+        d_hs.upload(filled)
+        ctx.del2_cubed(d_hs, 0.20 * g.da_min, nmax)
+        d_pt, d_pkz = ctx.from_host(pt), ctx.from_host(pkz)
+        ctx.apply_heat_source(n_con, hydrostatic, 37.5, 1.0, CP_AIR, CP_AIR - RDGAS, RDGAS, GRAV, d_pt, d_hs,
+                              ctx.from_host(s["delp"]), ctx.from_host(delz), d_pkz)
+        tol = 1e-14 if "hostemu" in lib.path else 1e-12
+        worst = P.assert_close("heat_source", bd.view(d_hs.download(), "A", *r), bd.view(r_hs, "A", *r), tol)
+        worst = max(worst, P.assert_close("pt", bd.view(d_pt.download(), "A", *r), bd.view(r_pt, "A", *r), tol))
+        worst = max(worst, P.assert_close("pkz", d_pkz.download(), r_pkz, tol))
+    finally:
+        ctx.close()
+    return worst

@@ -295,3 +295,13 @@ def test_c384l127_flux_form_properties(prod):
             assert np.all(np.isfinite(d[n].download())), n
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("hydro,n_con,nmax", [(False, None, 2), (True, None, 3), (False, 2, 1)])
+def test_heat_source_path(prod, hydro, n_con, nmax):
+    N.check_heat_source_path(prod, hydrostatic=hydro, n_con=n_con, nmax=nmax)
+
+
+def test_dyn_core_substeps_with_dissipative_heating(prod):
+    D.check_substeps(prod, n_split=2, flags=dict(d_con=1.0, do_vort_damp=True, vtdm4=0.06, nord=2))
+    D.check_substeps(prod, n_split=2, flags=dict(d_con=0.5))

@@ -185,3 +185,13 @@ def test_update_dz_d_and_tracers_multi_strip_march(emu):
 
 def test_halo_pack_unpack_kernels(emu):
     P.check_halo_packed(emu)
+
+
+@pytest.mark.parametrize("hydro,n_con,nmax", [(False, None, 2), (True, None, 3), (False, 2, 1)])
+def test_heat_source_path(emu, hydro, n_con, nmax):
+    N.check_heat_source_path(emu, hydrostatic=hydro, n_con=n_con, nmax=nmax)
+
+
+def test_dyn_core_substeps_with_dissipative_heating(emu):
+    D.check_substeps(emu, n_split=2, flags=dict(d_con=1.0, do_vort_damp=True, vtdm4=0.06, nord=2))
+    D.check_substeps(emu, n_split=2, flags=dict(d_con=0.5))
