@@ -1099,9 +1099,8 @@ extern "C" int fv3_nh_p_grad(fv3_ctx *c, double *u, double *v, const double *pp,
     kf.nf = 4;
     kf.scale[0] = kf.scale[1] = kf.scale[3] = 1.0;
     kf.scale[2] = gz_scale;
-    kf.top_pp = 0.;
-    kf.top_pk = top_value;
-    kf.override1 = 1;
+    kf.top[0] = 0.; kf.top[1] = top_value; kf.top[2] = kf.top[3] = 0.;
+    kf.override_mask = 3;
     Dim3 grid;
     grid.x = (unsigned)((g.nx + 1 + TI - 1) / TI);
     grid.y = (unsigned)((g.ny + 1 + TJ - 1) / TJ);
@@ -1116,6 +1115,64 @@ extern "C" int fv3_nh_p_grad(fv3_ctx *c, double *u, double *v, const double *pp,
     grid.z = (unsigned)km;
     RT(launch_p(c, "nh_p_grad", grid, 0, kf));
   }
+  return 0;
+}
+
+extern "C" int fv3_divg2_ext(fv3_ctx *c, double d_ext, const double *delp, const double *vt, double *divg2) {
+  if (!c || !c->grid_ready || !delp || !vt || !divg2) return fail("fv3_divg2_ext: bad context/arguments");
+  const Grid &g = c->g;
+  RT(rt_memset(divg2, 0, sizeof(double) * g.nA(), c->stream));
+  if (!(d_ext > 0.)) return 0;
+  Divg2Ext kf{g, g.npz, d_ext * g.da_min_c, delp, vt, divg2};
+  RT(launch_c(c, "divg2_ext", col_grid((g.nx + 1) * (g.ny + 1)), kf));
+  return 0;
+}
+
+extern "C" int fv3_one_grad_p(fv3_ctx *c, double *u, double *v, const double *pk, const double *gz, const double *divg2,
+                              double dt, double ptk) {
+  if (!c || !c->grid_ready) return fail("fv3_one_grad_p: context has no grid");
+  if (!u || !v || !pk || !gz) return fail("fv3_one_grad_p: null field");
+  if (need_scratch(c, 2)) return 1;
+  const Grid &g = c->g;
+  const int km = g.npz;
+  constexpr int TI = 32, TJ = 8;
+  {
+    A2BCorners<TI, TJ> kf;
+    kf.g = g;
+    kf.in[0] = pk; kf.in[1] = gz; kf.in[2] = kf.in[3] = nullptr;
+    kf.out[0] = c->scratch[0]; kf.out[1] = c->scratch[1]; kf.out[2] = kf.out[3] = nullptr;
+    kf.nlev[0] = kf.nlev[1] = km + 1;
+    kf.nlev[2] = kf.nlev[3] = 0;
+    kf.nf = 2;
+    for (int f = 0; f < 4; f++) { kf.scale[f] = 1.0; kf.top[f] = 0.; }
+    kf.top[0] = ptk;          // pk(i,j,1) = top_value (:1950-1955)
+    kf.override_mask = 1;
+    Dim3 grid;
+    grid.x = (unsigned)((g.nx + 1 + TI - 1) / TI);
+    grid.y = (unsigned)((g.ny + 1 + TJ - 1) / TJ);
+    grid.z = (unsigned)(km + 1);
+    RT(launch_p(c, "a2b_corners", grid, A2BCorners<TI, TJ>::lds_doubles, kf));
+  }
+  {
+    OneGradPHydro kf{g, dt, c->scratch[0], c->scratch[1], divg2, u, v};
+    Dim3 grid;
+    grid.x = (unsigned)(((g.nx + 1) * (g.ny + 1) + OneGradPHydro::CH - 1) / OneGradPHydro::CH);
+    grid.y = 1;
+    grid.z = (unsigned)km;
+    RT(launch_p(c, "one_grad_p", grid, 0, kf));
+  }
+  return 0;
+}
+
+extern "C" int fv3_copy_a_to_cc(fv3_ctx *c, const double *src, double *dst, int nk) {
+  if (!c || !c->grid_ready || !src || !dst) return fail("fv3_copy_a_to_cc: bad context/arguments");
+  const Grid &g = c->g;
+  CopyAtoCC kf{g, src, dst};
+  Dim3 grid;
+  grid.x = (unsigned)((g.nx * g.ny + CopyAtoCC::CH - 1) / CopyAtoCC::CH);
+  grid.y = 1;
+  grid.z = (unsigned)nk;
+  RT(launch_p(c, "copy_a_to_cc", grid, 0, kf));
   return 0;
 }
 

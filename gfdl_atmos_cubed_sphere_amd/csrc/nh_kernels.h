@@ -567,8 +567,8 @@ struct A2BCorners {
   int nlev[4];      // number of levels of each field (npz+1 or npz)
   int nf;
   double scale[4];        // value = in * scale at load time (gz = zh*grav, dyn_core.F90:982-989); 1.0 = none
-  double top_pp, top_pk;  // level-1 overrides of fields 0 and 1 (nh_p_grad :1732-1738); used when override1 != 0
-  int override1;
+  double top[4];          // level-1 overrides (nh_p_grad :1732-1738, one_grad_p :1950-1955) ...
+  int override_mask;      // ... of the fields whose bit is set
   static constexpr int W = TI + 5, H = TJ + 5;  // corners [i0, i0+TI] need cells [i0-2, i0+TI+1]
   static constexpr int lds_doubles = W * H;
   FV3_HD void operator()(int bx, int by, int bz, int tid, double *lds) const {
@@ -579,11 +579,11 @@ struct A2BCorners {
     for (int f = 0; f < nf; f++) {
       if (k >= nlev[f]) continue;
       double *o = out[f] + (size_t)k * g.nA();
-      if (override1 && k == 0 && f < 2) {
+      if (k == 0 && ((override_mask >> f) & 1)) {
         FV3_TILE_FOR(TI, TJ, li_, lj_) {
           const int i = i0 + li_, j = j0 + lj_;
           if (i > g.ie + 1 || j > g.je + 1) continue;
-          o[g.iA(i, j)] = (f == 0) ? top_pp : top_pk;
+          o[g.iA(i, j)] = top[f];
         }
         continue;
       }
@@ -817,6 +817,83 @@ struct HeatApply {
         hs[o] = dtmp;
       }
     }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// hydrostatic pressure gradient: external-mode divergence coefficient and one_grad_p on corner values
+struct Divg2Ext {  // dyn_core.F90:745-747, :791-797, :828-848
+  Grid g;
+  int npz;
+  double d2_divg;
+  const double *delp, *vt;
+  double *divg2;  // A kind 2-D, corner indices
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int w = g.nx + 1, ncol = w * (g.ny + 1);
+    const size_t nA = g.nA();
+    FV3_COL_FOR(c, ncol) {
+      const int i = g.is + c % w, j = g.js + c / w;
+      const int o = g.iA(i, j), o00 = g.iA(i - 1, j - 1), o10 = g.iA(i, j - 1), o01 = g.iA(i - 1, j);
+      double wk = 0., d2 = 0.;
+      for (int k = 0; k < npz; k++) {
+        const double *dp = delp + (size_t)k * nA;
+        const double ptc = 0.25 * (dp[o00] + dp[o10] + dp[o01] + dp[o]);  // a2b_ord2, a2b_edge.F90:427-433
+        if (k == 0) {
+          wk = ptc;
+          d2 = wk * vt[o];
+        } else {
+          wk = wk + ptc;
+          d2 = d2 + ptc * vt[(size_t)k * nA + o];
+        }
+      }
+      divg2[o] = d2_divg * d2 / wk;
+    }
+  }
+};
+
+struct OneGradPHydro {  // dyn_core.F90:2002-2028 on precomputed corner values of pk, gz
+  Grid g;
+  double dt;
+  const double *pk, *gz;   // corner slabs, npz+1 levels
+  const double *divg2;     // null = no external-mode damping
+  double *u, *v;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int k = bz;
+    const size_t nA = g.nA();
+    const double *pk0 = pk + (size_t)k * nA, *pk1 = pk0 + nA, *gz0 = gz + (size_t)k * nA, *gz1 = gz0 + nA;
+    const int w = g.nx + 1, n = w * (g.ny + 1);
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.is + idx % w, j = g.js + idx / w;
+      const int o = g.iA(i, j), oe = g.iA(i + 1, j), on = g.iA(i, j + 1);
+      const double wk0 = pk1[o] - pk0[o];
+      if (i <= g.ie) {
+        const double wke = pk1[oe] - pk0[oe];
+        const double wk2 = divg2 ? divg2[o] - divg2[oe] : 0.;
+        double *p = u + (size_t)k * g.nU() + g.iU(i, j);
+        *p = g.rdx[g.iU(i, j)] * (wk2 + *p + dt / (wk0 + wke) * ((gz1[o] - gz0[oe]) * (pk1[oe] - pk0[o]) +
+                                                                (gz0[o] - gz1[oe]) * (pk1[o] - pk0[oe])));
+      }
+      if (j <= g.je) {
+        const double wkn = pk1[on] - pk0[on];
+        const double wk1 = divg2 ? divg2[o] - divg2[on] : 0.;
+        double *p = v + (size_t)k * g.nV() + g.iV(i, j);
+        *p = g.rdy[g.iV(i, j)] * (wk1 + *p + dt / (wk0 + wkn) * ((gz1[o] - gz0[on]) * (pk1[on] - pk0[o]) +
+                                                                (gz0[o] - gz1[on]) * (pk1[o] - pk0[on])));
+      }
+    }
+  }
+};
+
+struct CopyAtoCC {  // compute-domain copy of an A-kind field into a CC-kind one (pk = pkc, dyn_core.F90:1001-1010)
+  Grid g;
+  const double *src;
+  double *dst;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int n = g.nx * g.ny;
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT)
+      dst[(size_t)bz * g.nCC() + idx] = src[(size_t)bz * g.nA() + g.iA(g.is + idx % g.nx, g.js + idx / g.nx)];
   }
 };
 

@@ -34,6 +34,8 @@ class DynFlags:
     do_vort_damp: bool = False
     d_con: float = 0.0
     delt_max: float = 1.0    # K/s, fv_arrays.F90:667
+    hydrostatic: bool = False
+    d_ext: float = 0.02      # external-mode damping (hydrostatic one_grad_p only), fv_arrays.F90:452
     convert_ke: bool = False
     ke_bg: float = 0.0
     hord_mt: int = 10
@@ -143,8 +145,65 @@ class DynCore:
     def _swap(self, name):
         self.d[name], self.d[name + "_nxt"] = self.d[name + "_nxt"], self.d[name]
 
+    # -- the substep loop, hydrostatic branch (dyn_core.F90:313-1286 with hydrostatic = .true., beta = 0) ----------
+    def run_hydrostatic(self, bdt: float):
+        fl, d, ctx, halo = self.fl, self.d, self.ctx, self.halo
+        n_split = fl.n_split
+        dt = bdt / float(n_split)
+        dt2 = 0.5 * dt
+        ptk = fl.ptop ** fl.akap
+        for a in ("mfx", "mfy", "cx", "cy"):
+            d[a].zero()
+        for n, kind, nk in (("pkz", "CC", self.npz), ("divg2", "A", None)):
+            if n not in d:
+                d[n] = ctx.zeros(kind, nk)
+        heating = fl.d_con > 1.0e-5
+        if heating:
+            if "heat_source" not in d:
+                d["heat_source"] = ctx.zeros("A", self.npz)
+            d["heat_source"].zero()
+        par = dict(dt=dt, hord_tr=fl.hord_tr, hord_mt=fl.hord_mt, hord_vt=fl.hord_vt, hord_tm=fl.hord_tm,
+                   hord_dp=fl.hord_dp, dddmp=fl.dddmp, d4_bg=fl.d4_bg, kgb=fl.ke_bg, hydrostatic=1, use_cond=0)
+        halo.update([(d["delp"], "A"), (d["pt"], "A")])
+        halo.update([(d["u"], "U"), (d["v"], "V")])
+        for it in range(1, n_split + 1):
+            remap_step = it == n_split
+            ctx.c_sw(d["delpc"], d["delp"], d["ptc"], d["pt"], d["u"], d["v"], None, d["uc"], d["vc"], d["ua"],
+                     d["va"], None, d["ut"], d["vt"], d["divgd"], fl.nord, dt2, True)         # :439-447
+            if fl.nord > 0:
+                halo.update([(d["divgd"], "B")])
+            ctx.geopk(fl.ptop, fl.akap, fl.cp_air, d["pe"], d["peln"], d["delpc"], d["pkc"], d["gz"], d["phis"], d["ptc"],
+                      d["pkz"], True)                                         # :480-482 (CG)
+            ctx.p_grad_c(dt2, d["delpc"], d["pkc"], d["gz"], d["uc"], d["vc"], True)           # :562
+            halo.update([(d["uc"], "V"), (d["vc"], "U")])
+            ctx.d_sw(par, d["vt"], d["delp"], d["pt"], d["u"], d["v"], None, d["uc"], d["vc"], d["ua"], d["va"],
+                     d["divgd"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
+                     d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], None, None, d["heat_s"], d["diss_e"])  # :762
+            if heating:
+                ctx.heat_source_accum(d["heat_source"], d["heat_s"])
+            # external-mode damping field from the delp BEFORE d_sw (:745-747) and d_sw's divergence output (:791-848)
+            ctx.divg2_ext(fl.d_ext, d["delp"], d["vt"], d["divg2"])
+            for n in ("delp", "pt", "u", "v"):
+                self._swap(n)
+            halo.update([(d["delp"], "A"), (d["pt"], "A")])                   # :823-824 / :851
+            ctx.geopk(fl.ptop, fl.akap, fl.cp_air, d["pe"], d["peln"], d["delp"], d["pkc"], d["gz"], d["phis"], d["pt"],
+                      d["pkz"], False)                                        # :905-907
+            if remap_step:
+                ctx.copy_a_to_cc(d["pkc"], d["pk"])                           # pk = pkc, :1001-1010
+            ctx.one_grad_p(d["u"], d["v"], d["pkc"], d["gz"], d["divg2"] if fl.d_ext > 0.0 else None, dt, ptk)  # :1021
+            if it != n_split:
+                halo.update([(d["u"], "U"), (d["v"], "V")])
+        n_con = self.n_con()
+        if n_con != 0 and heating:
+            halo.update([(d["heat_source"], "A")])
+            ctx.del2_cubed(d["heat_source"], 0.20 * ctx.grid.da_min, min(3, fl.nord + 1))
+            ctx.apply_heat_source(n_con, True, bdt, fl.delt_max, fl.cp_air, fl.cp_air - fl.rdgas, fl.rdgas, fl.grav,
+                                  d["pt"], d["heat_source"], d["delp"], None, d["pkz"])
+
     # -- the substep loop (dyn_core.F90:313-1286) ------------------------------------------------------
     def run(self, bdt: float, end_step: bool = True):
+        if self.fl.hydrostatic:
+            return self.run_hydrostatic(bdt)
         fl, d, ctx, halo = self.fl, self.d, self.ctx, self.halo
         n_split = fl.n_split
         dt = bdt / float(n_split)

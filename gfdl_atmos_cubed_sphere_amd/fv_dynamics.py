@@ -31,7 +31,7 @@ class FvDynamics:
         if nq:
             shp = ctx.bd.shape("A", npz) + (nq,)
             d["q"], d["q_nxt"] = ctx.from_host(np.zeros(shp, order="F")), ctx.from_host(np.zeros(shp, order="F"))
-        self.remap_par = dict(hydrostatic=0, adiabatic=int(adiabatic), nq=nq, kord_mt=kord_mt, kord_wz=kord_wz,
+        self.remap_par = dict(hydrostatic=int(flags.hydrostatic), adiabatic=int(adiabatic), nq=nq, kord_mt=kord_mt, kord_wz=kord_wz,
                               kord_tm=kord_tm, sphum=1 if nq else 0, akap=flags.akap, ptop=flags.ptop,
                               rdgas=flags.rdgas, grav=flags.grav, cv_air=flags.cp_air - flags.rdgas, r_vir=0.6077,
                               cp=flags.cp_air, t_min=184.0, kord_tr=[kord_tr] * nq)
@@ -56,5 +56,7 @@ class FvDynamics:
                 if dp1 is not d["dp1"]:
                     d["dp1"], d["dp1_nxt"] = d["dp1_nxt"], d["dp1"]
             par = dict(self.remap_par, last_step=int(last_step))
-            ctx.lagrangian_to_eulerian(par, d["ps"], d["pe"], d["delp"], d["pkz"], d["pk"], d["u"], d["v"], d["w"],
-                                       d["delz"], d["pt"], d.get("q"), d["peln"], d["omga"], d["ws"])   # :607
+            hyd = self.fl.hydrostatic
+            ctx.lagrangian_to_eulerian(par, d["ps"], d["pe"], d["delp"], d["pkz"], d["pk"], d["u"], d["v"],
+                                       None if hyd else d["w"], None if hyd else d["delz"], d["pt"], d.get("q"),
+                                       d["peln"], d["omga"], None if hyd else d["ws"])   # :607

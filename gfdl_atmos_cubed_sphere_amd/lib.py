@@ -32,7 +32,7 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
-           "fv3_halo_unpack", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report",
+           "fv3_halo_unpack", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
@@ -387,6 +387,18 @@ class Context:
                                                        C.c_int(nq), C.c_int(hord), C.c_int(nord_tr), C.c_double(trdm),
                                                        q.p, q_out.p, dp1.p, dp1_out.p, mfx.p, mfy.p, cx.p, cy.p, xfx.p,
                                                        yfx.p), "fv3_tracer_2d_step")
+
+    # ---- hydrostatic pressure gradient (dyn_core.F90:828-848, :1021, :1001-1010) ------------------------------------
+    def divg2_ext(self, d_ext, delp, vt, divg2):
+        self.lib.check(self.lib.dll.fv3_divg2_ext(self.h, C.c_double(d_ext), delp.p, vt.p, divg2.p), "fv3_divg2_ext")
+
+    def one_grad_p(self, u, v, pk, gz, divg2, dt, ptk):
+        self.lib.check(self.lib.dll.fv3_one_grad_p(self.h, u.p, v.p, pk.p, gz.p, divg2.p if divg2 is not None else None,
+                                                   C.c_double(dt), C.c_double(ptk)), "fv3_one_grad_p")
+
+    def copy_a_to_cc(self, src, dst):
+        nk = int(np.prod(src.shape[2:])) if len(src.shape) > 2 else 1
+        self.lib.check(self.lib.dll.fv3_copy_a_to_cc(self.h, src.p, dst.p, C.c_int(nk)), "fv3_copy_a_to_cc")
 
     # ---- dissipative heating after the substep loop (dyn_core.F90:798-803, :1300-1355) ---------------------------
     def heat_source_accum(self, heat_source, heat_s):

@@ -205,6 +205,19 @@ int fv3_p_grad_c(fv3_ctx *ctx, double dt2, const double *delpc, const double *pk
 int fv3_nh_p_grad(fv3_ctx *ctx, double *u, double *v, const double *pp, const double *gz, double gz_scale,
                   const double *delp, const double *pk, double dt, double top_value);
 
+/* Hydrostatic pressure gradient.
+ * divg2_ext -- model/dyn_core.F90:745-747, :791-797, :828-848: external-mode divergence damping field at the corners,
+ *   divg2 = d_ext*da_min_c * sum_k ptc*vt / sum_k ptc with ptc = a2b_ord2(delp BEFORE d_sw) and vt = d_sw's delpc
+ *   output; divg2: A-kind 2-D array addressed with corner indices (zeros when d_ext <= 0).
+ * one_grad_p -- model/dyn_core.F90:1909, call site :1021, hydrostatic form (pk = pe**kappa, ptk = ptop**kappa):
+ *   u, v updated in place (and multiplied by rdx, rdy); pk, gz (A x (npz+1)) are NOT modified (the reference
+ *   replaces them by their corner interpolants, which nothing reads afterwards); divg2 may be NULL (d_ext <= 0).
+ * copy_a_to_cc -- "pk = pkc" on the last substep (:1001-1010). */
+int fv3_divg2_ext(fv3_ctx *ctx, double d_ext, const double *delp, const double *vt, double *divg2);
+int fv3_one_grad_p(fv3_ctx *ctx, double *u, double *v, const double *pk, const double *gz, const double *divg2,
+                   double dt, double ptk);
+int fv3_copy_a_to_cc(fv3_ctx *ctx, const double *src, double *dst, int nk);
+
 /* zh(npz+1) = zs; zh(k) = zh(k+1) - delz(k) on the compute domain -- model/dyn_core.F90:370-385 (it == 1). */
 int fv3_zh_from_delz(fv3_ctx *ctx, const double *zs, const double *delz, double *zh);
 

@@ -688,3 +688,83 @@ int fvo_apply_heat_source(const fvo_grid *g, int npz, int n_con, int hydrostatic
   }
   return FVO_OK;
 }
+
+/* External-mode divergence damping coefficient field divg2 (model/dyn_core.F90:745-747, :791-797, :828-848):
+ * ptc(k) = a2b_ord2(delp(k)) (grid_type >= 3: 4-point mean, a2b_edge.F90:427-433) with the delp BEFORE d_sw,
+ * divg2 = d_ext*da_min_c * sum_k ptc*vt / sum_k ptc at the corners is:ie+1 x js:je+1; vt = d_sw's delpc output.
+ * divg2: A-kind 2-D array (corner indices).  d_ext <= 0: zeros. */
+int fvo_divg2_ext(const fvo_grid *g, int npz, double d_ext, const double *delp, const double *vt, double *divg2) {
+  BOUNDS(g);
+  int i, j, k;
+  for (j = jsd; j <= jed; j++)
+    for (i = isd; i <= ied; i++) divg2[IA(i, j)] = 0.;
+  if (!(d_ext > 0.)) return FVO_OK;
+  if (g->grid_type < 3) return FVO_ERR_UNSUPPORTED;
+  const double d2_divg = d_ext * g->da_min_c;
+  for (j = js; j <= je + 1; j++)
+    for (i = is; i <= ie + 1; i++) {
+      double wk = 0., d2 = 0.;
+      for (k = 1; k <= npz; k++) {
+        const double ptc = 0.25 * (delp[A3(i - 1, j - 1, k)] + delp[A3(i, j - 1, k)] + delp[A3(i - 1, j, k)] + delp[A3(i, j, k)]);
+        if (k == 1) {
+          wk = ptc;
+          d2 = wk * vt[A3(i, j, 1)];
+        } else {
+          wk = wk + ptc;
+          d2 = d2 + ptc * vt[A3(i, j, k)];
+        }
+      }
+      divg2[IA(i, j)] = d2_divg * d2 / wk;
+    }
+  return FVO_OK;
+}
+
+/* one_grad_p, hydrostatic form (model/dyn_core.F90:1909-2030, call site :1021): pk = pe**kappa.  pk, gz are replaced
+ * by their corner interpolants like in the reference; divg2 as produced by fvo_divg2_ext (zeros when d_ext <= 0). */
+int fvo_one_grad_p_hydro(const fvo_grid *g, int npz, double dt, double ptk, const double *divg2, double *u, double *v,
+                         double *pk, double *gz) {
+  BOUNDS(g);
+  int k;
+  const size_t nA = (size_t)nid * njd, nV = (size_t)(nid + 1) * njd, nU = (size_t)nid * (njd + 1);
+  {
+    int i, j;
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie + 1; i++) pk[A3(i, j, 1)] = ptk;
+  }
+#pragma omp parallel for schedule(dynamic)
+  for (k = 1; k <= npz + 1; k++) {
+    double *wk = dalloc(nA);
+    if (k >= 2) fvo_a2b_ord4(g, pk + nA * (k - 1), wk, 1);
+    fvo_a2b_ord4(g, gz + nA * (k - 1), wk, 1);
+    free(wk);
+  }
+#pragma omp parallel for schedule(dynamic)
+  for (k = 1; k <= npz; k++) {
+    int i, j;
+    double *wk = dalloc(nA);
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie + 1; i++) wk[IA(i, j)] = pk[A3(i, j, k + 1)] - pk[A3(i, j, k)];
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie; i++) {
+        const double wk2 = divg2[IA(i, j)] - divg2[IA(i + 1, j)];
+        u[nU * (k - 1) + IU(i, j)] =
+            g->rdx[IU(i, j)] *
+            (wk2 + u[nU * (k - 1) + IU(i, j)] +
+             dt / (wk[IA(i, j)] + wk[IA(i + 1, j)]) *
+                 ((gz[A3(i, j, k + 1)] - gz[A3(i + 1, j, k)]) * (pk[A3(i + 1, j, k + 1)] - pk[A3(i, j, k)]) +
+                  (gz[A3(i, j, k)] - gz[A3(i + 1, j, k + 1)]) * (pk[A3(i, j, k + 1)] - pk[A3(i + 1, j, k)])));
+      }
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie + 1; i++) {
+        const double wk1 = divg2[IA(i, j)] - divg2[IA(i, j + 1)];
+        v[nV * (k - 1) + IV(i, j)] =
+            g->rdy[IV(i, j)] *
+            (wk1 + v[nV * (k - 1) + IV(i, j)] +
+             dt / (wk[IA(i, j)] + wk[IA(i, j + 1)]) *
+                 ((gz[A3(i, j, k + 1)] - gz[A3(i, j + 1, k)]) * (pk[A3(i, j + 1, k + 1)] - pk[A3(i, j, k)]) +
+                  (gz[A3(i, j, k)] - gz[A3(i, j + 1, k + 1)]) * (pk[A3(i, j, k + 1)] - pk[A3(i, j + 1, k)])));
+      }
+    free(wk);
+  }
+  return FVO_OK;
+}

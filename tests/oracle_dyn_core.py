@@ -106,3 +106,70 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
         O.apply_heat_source(g, npz, n_con, False, bdt, fl.delt_max, fl.cp_air, fl.cp_air - fl.rdgas, fl.rdgas, fl.grav,
                             f["pt"], f["heat_source"], f["delp"], f["delz"], f["pkz"])
     return f
+
+
+def run_hydrostatic(g, npz: int, fl: DynFlags, st: dict, bdt: float):
+    """hydrostatic branch of the substep loop (beta = 0) over the oracle's routines.  st: u, v, delp, pt (halo'd), phis."""
+    bd: Bounds = g.bd
+    f = {k: np.asfortranarray(v.copy()) for k, v in st.items()}
+    nx, ny = bd.nx, bd.ny
+    for n, kind, nk in (("delpc", "A", npz), ("ptc", "A", npz), ("uc", "V", npz), ("vc", "U", npz), ("ua", "A", npz),
+                        ("va", "A", npz), ("ut", "A", npz), ("vt", "A", npz), ("divgd", "B", npz),
+                        ("gz", "A", npz + 1), ("pkc", "A", npz + 1), ("crx", "CX", npz), ("xfx", "CX", npz),
+                        ("cry", "CY", npz), ("yfx", "CY", npz), ("mfx", "FX", npz), ("mfy", "FY", npz), ("cx", "CX", npz),
+                        ("cy", "CY", npz), ("heat_s", "CC", npz), ("diss_e", "CC", npz), ("pk", "CC", npz + 1),
+                        ("pkz", "CC", npz), ("heat_source", "A", npz)):
+        f[n] = bd.zeros(kind, nk)
+    f["divg2"] = bd.zeros("A")
+    f["pe"] = np.zeros((nx + 2, npz + 1, ny + 2), order="F")
+    f["peln"] = np.zeros((nx, npz + 1, ny), order="F")
+    lev = level_coefficients(npz, fl)
+    n_split = fl.n_split
+    dt = bdt / float(n_split)
+    dt2 = 0.5 * dt
+    ptk = fl.ptop ** fl.akap
+    par = dict(dt=dt, hord_tr=fl.hord_tr, hord_mt=fl.hord_mt, hord_vt=fl.hord_vt, hord_tm=fl.hord_tm,
+               hord_dp=fl.hord_dp, nord=1, nord_v=1, nord_w=1, nord_t=1, dddmp=fl.dddmp, d2_bg=0.0, d4_bg=fl.d4_bg,
+               damp_v=0.0, damp_w=0.0, damp_t=0.0, d_con=0.0, kgb=fl.ke_bg, hydrostatic=1, use_cond=0)
+    heating = fl.d_con > 1.0e-5
+    _fill(bd, f["delp"], "A"); _fill(bd, f["pt"], "A"); _fill(bd, f["u"], "U"); _fill(bd, f["v"], "V")
+    i0, j0 = bd.ng, bd.ng
+    for it in range(1, n_split + 1):
+        remap_step = it == n_split
+        cs = dict(delpc=f["delpc"], delp=f["delp"], ptc=f["ptc"], pt=f["pt"], u=f["u"], v=f["v"], uc=f["uc"], vc=f["vc"],
+                  ua=f["ua"], va=f["va"], ut=f["ut"], vt=f["vt"], divg_d=f["divgd"])
+        O.c_sw_3d(g, npz, cs, nord=fl.nord, dt2=dt2, hydrostatic=True)
+        if fl.nord > 0:
+            _fill(bd, f["divgd"], "B")
+        O.geopk(g, npz, fl.ptop, fl.akap, fl.cp_air, f["pe"], f["peln"], f["delpc"], f["pkc"], f["gz"], f["phis"], f["ptc"],
+                f["pkz"], True)
+        O.p_grad_c(g, npz, dt2, f["delpc"], f["pkc"], f["gz"], f["uc"], f["vc"], True)
+        _fill(bd, f["uc"], "V"); _fill(bd, f["vc"], "U")
+        delp_old = f["delp"].copy(order="F")
+        ds = dict(delpc=f["vt"], delp=f["delp"], ptc=f["ptc"], pt=f["pt"], u=f["u"], v=f["v"], uc=f["uc"], vc=f["vc"],
+                  ua=f["ua"], va=f["va"], divg_d=f["divgd"], mfx=f["mfx"], mfy=f["mfy"], cx=f["cx"], cy=f["cy"],
+                  crx=f["crx"], cry=f["cry"], xfx=f["xfx"], yfx=f["yfx"], heat_source=f["heat_s"], diss_est=f["diss_e"])
+        O.d_sw_3d(g, npz, par, lev, ds)
+        if heating:
+            f["heat_source"][i0:i0 + nx, j0:j0 + ny, :] += f["heat_s"]
+        O.divg2_ext(g, npz, fl.d_ext, delp_old, f["vt"], f["divg2"])
+        _fill(bd, f["delp"], "A"); _fill(bd, f["pt"], "A")
+        O.geopk(g, npz, fl.ptop, fl.akap, fl.cp_air, f["pe"], f["peln"], f["delp"], f["pkc"], f["gz"], f["phis"], f["pt"],
+                f["pkz"], False)
+        if remap_step:
+            f["pk"][...] = f["pkc"][i0:i0 + nx, j0:j0 + ny, :]
+        O.one_grad_p_hydro(g, npz, dt, ptk, f["divg2"], f["u"], f["v"], f["pkc"], f["gz"])
+        if it != n_split:
+            _fill(bd, f["u"], "U"); _fill(bd, f["v"], "V")
+    if fl.convert_ke or (fl.do_vort_damp and fl.vtdm4 > 1.0e-4):
+        n_con = npz
+    elif fl.d2_bg_k1 < 1.0e-3:
+        n_con = 0
+    else:
+        n_con = 1 if fl.d2_bg_k2 < 1.0e-3 else 2
+    if n_con != 0 and heating:
+        _fill(bd, f["heat_source"], "A")
+        O.del2_cubed(g, npz, 0.20 * g.da_min, min(3, fl.nord + 1), f["heat_source"])
+        O.apply_heat_source(g, npz, n_con, True, bdt, fl.delt_max, fl.cp_air, fl.cp_air - fl.rdgas, fl.rdgas, fl.grav,
+                            f["pt"], f["heat_source"], f["delp"], f["pkz"], f["pkz"])
+    return f

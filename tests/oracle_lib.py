@@ -212,6 +212,16 @@ def pk3_halo(g, npz, ptop, akap, pk3, delp, use_logp):
     assert lib().fvo_pk3_halo(C.byref(gs), C.c_int(npz), _d(ptop), _d(akap), p(pk3), p(delp), C.c_int(int(use_logp))) == 0
 
 
+def divg2_ext(g, npz, d_ext, delp, vt, divg2):
+    gs = make_grid(g)
+    assert lib().fvo_divg2_ext(C.byref(gs), C.c_int(npz), _d(d_ext), p(delp), p(vt), p(divg2)) == 0
+
+
+def one_grad_p_hydro(g, npz, dt, ptk, divg2, u, v, pk, gz):
+    gs = make_grid(g)
+    assert lib().fvo_one_grad_p_hydro(C.byref(gs), C.c_int(npz), _d(dt), _d(ptk), p(divg2), p(u), p(v), p(pk), p(gz)) == 0
+
+
 def del2_cubed(g, km, cd, nmax, q):
     gs = make_grid(g)
     assert lib().fvo_del2_cubed(C.byref(gs), C.c_int(km), _d(cd), C.c_int(nmax), p(q)) == 0

@@ -68,6 +68,68 @@ def check_substeps(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None, tol
     return out
 
 
+def oracle_fv_step_hydro(g, npz, fl, st, ak, bk, q, bdt, k_split, remap_par):
+    """hydrostatic k_split loop over the oracle: dyn_core -> tracer_2d -> Lagrangian_to_Eulerian"""
+    import oracle_lib as O
+    bd = g.bd
+    mdt = bdt / float(k_split)
+    cur = {k: st[k].copy(order="F") for k in ("u", "v", "delp", "pt", "phis")}
+    nq = 0 if q is None else q.shape[3]
+    q = None if q is None else q.copy(order="F")
+    out = None
+    for n_map in range(1, k_split + 1):
+        dp1 = cur["delp"].copy(order="F")
+        OD._fill(bd, dp1, "A")
+        f = OD.run_hydrostatic(g, npz, fl, cur, mdt)
+        if nq:
+            O.tracer_2d(g, npz, nq, q, dp1, f["mfx"], f["mfy"], f["cx"], f["cy"], fl.hord_tr, 0, 0, 0.0)
+        rf = dict(ps=bd.zeros("A"), pe=f["pe"], delp=f["delp"], pkz=f["pkz"], pk=f["pk"], u=f["u"], v=f["v"],
+                  pt=f["pt"], peln=f["peln"], omga=bd.zeros("A", npz))
+        if nq:
+            rf["q"] = q
+        O.lagrangian_to_eulerian(g, npz, dict(remap_par, last_step=0), rf, ak, bk)
+        cur = dict(u=rf["u"], v=rf["v"], delp=rf["delp"], pt=rf["pt"], phis=st["phis"])
+        out = dict(cur, q=q, pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"])
+    return out
+
+
+def check_fv_step_hydrostatic(lib, nx=24, ny=16, npz=10, nq=2, k_split=2, n_split=2, bdt=8.0):
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    st, dp0 = make_state(bd, npz)
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+    ak, bk = N.PTOP * (1.0 - sig), sig.copy()
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=True)
+    rng = np.random.default_rng(5)
+    q = np.asfortranarray(rng.uniform(0.0, 1.0, bd.shape("A", npz) + (nq,))) if nq else None
+    ctx = Context(g, npz, lib=lib)
+    try:
+        fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=k_split)
+        ref = oracle_fv_step_hydro(g, npz, fl, st, ak, bk, q, bdt, k_split, fv.remap_par)
+        fv.dc.set_state(st["u"], st["v"], np.zeros_like(st["w"]), st["delp"], st["pt"], st["delz"], st["phis"])
+        if nq:
+            fv.set_tracers(q)
+        fv.step(bdt)
+        d = fv.dc.d
+        tol = 1e-13 if "hostemu" in lib.path else 1e-12
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        out = {}
+        for n, kind, rr in (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)),
+                            ("delp", "A", r), ("pt", "A", r), ("ps", "A", r)):
+            out[n] = P.assert_close(n, bd.view(d[n].download(), kind, *rr), bd.view(ref[n], kind, *rr), tol)
+        for n in ("pkz", "pk", "peln"):
+            out[n] = P.assert_close(n, d[n].download(), ref[n], tol)
+        if nq:
+            got = d["q"].download()
+            for iq in range(nq):
+                out[f"q{iq}"] = P.assert_close(f"q{iq}", bd.view(got[:, :, :, iq], "A", *r),
+                                               bd.view(ref["q"][:, :, :, iq], "A", *r), tol)
+    finally:
+        ctx.close()
+    return out
+
+
 def oracle_fv_step(g, npz, fl, dp0, st, ak, bk, q, bdt, k_split, remap_par):
     """Oracle-orchestrated k_split loop (fv_dynamics.F90:460-665): dyn_core -> tracer_2d -> Lagrangian_to_Eulerian."""
     import oracle_lib as O
@@ -129,6 +191,35 @@ def check_fv_step(lib, nx=24, ny=16, npz=10, nq=2, k_split=2, n_split=2, bdt=8.0
             for iq in range(nq):
                 out[f"q{iq}"] = P.assert_close(f"q{iq}", bd.view(got[:, :, :, iq], "A", *r),
                                                bd.view(ref["q"][:, :, :, iq], "A", *r), tol if emu else 1e-12)
+    finally:
+        ctx.close()
+    return out
+
+
+def check_substeps_hydrostatic(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None):
+    """hydrostatic substep loop (c_sw, geopk, p_grad_c, d_sw, geopk, one_grad_p with external-mode damping)"""
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    st, dp0 = make_state(bd, npz)
+    hst = {k: st[k] for k in ("u", "v", "delp", "pt", "phis")}
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=True, **(flags or {}))
+    ref = OD.run_hydrostatic(g, npz, fl, hst, bdt)
+    ctx = Context(g, npz, lib=lib)
+    try:
+        dc = DynCore(ctx, fl, dp0)
+        z = np.zeros_like(st["w"])
+        dc.set_state(st["u"], st["v"], z, st["delp"], st["pt"], st["delz"], st["phis"])
+        dc.run(bdt)
+        d = dc.d
+        tol = 1e-13 if "hostemu" in lib.path else 1e-12
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        out = {}
+        for n, kind, rr in (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)),
+                            ("delp", "A", r), ("pt", "A", r)):
+            out[n] = P.assert_close(n, bd.view(d[n].download(), kind, *rr), bd.view(ref[n], kind, *rr), tol)
+        for n in ("mfx", "mfy", "cx", "cy", "pk", "pkz", "peln"):
+            out[n] = P.assert_close(n, d[n].download(), ref[n], tol)
+        out["pe"] = P.assert_close("pe", d["pe"].download()[1:-1, :, 1:-1], ref["pe"][1:-1, :, 1:-1], tol)
     finally:
         ctx.close()
     return out

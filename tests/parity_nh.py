@@ -295,3 +295,34 @@ def check_heat_source_path(lib, nx=24, ny=13, km=6, hydrostatic=False, n_con=Non
     finally:
         ctx.close()
     return worst
+
+
+def check_one_grad_p(lib, nx=40, ny=19, km=5, d_ext=0.02):
+    """external-mode divergence field + hydrostatic one_grad_p against the oracle"""
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, True)
+    s = nh_state(bd, km)
+    rng = np.random.default_rng(16)
+    pe, pk, pp, gz = _pressure_fields(bd, km, s, rng)
+    u = np.asfortranarray(rng.uniform(-1e4, 1e4, bd.shape("U", km)))
+    v = np.asfortranarray(rng.uniform(-1e4, 1e4, bd.shape("V", km)))
+    vt = np.asfortranarray(rng.uniform(-1e-5, 1e-5, bd.shape("A", km)))
+    top = PTOP ** KAPPA
+    o = dict(u=u.copy(order="F"), v=v.copy(order="F"), pk=pk.copy(order="F"), gz=gz.copy(order="F"))
+    divg2 = bd.zeros("A")
+    O.divg2_ext(g, km, d_ext, s["delp"], vt, divg2)
+    O.one_grad_p_hydro(g, km, 6.0, top, divg2, o["u"], o["v"], o["pk"], o["gz"])
+    ctx = Context(g, km, lib=lib)
+    try:
+        d_u, d_v, d_d2 = ctx.from_host(u), ctx.from_host(v), ctx.zeros("A")
+        ctx.divg2_ext(d_ext, ctx.from_host(s["delp"]), ctx.from_host(vt), d_d2)
+        r = (bd.is_, bd.ie + 1, bd.js, bd.je + 1)
+        if d_ext > 0:
+            P.assert_close("divg2", bd.view(d_d2.download(), "A", *r), bd.view(divg2, "A", *r), _tol(lib))
+        ctx.one_grad_p(d_u, d_v, ctx.from_host(pk), ctx.from_host(gz), d_d2 if d_ext > 0 else None, 6.0, top)
+        P.assert_close("u", bd.view(d_u.download(), "U", bd.is_, bd.ie, bd.js, bd.je + 1),
+                       bd.view(o["u"], "U", bd.is_, bd.ie, bd.js, bd.je + 1), _tol(lib))
+        P.assert_close("v", bd.view(d_v.download(), "V", bd.is_, bd.ie + 1, bd.js, bd.je),
+                       bd.view(o["v"], "V", bd.is_, bd.ie + 1, bd.js, bd.je), _tol(lib))
+    finally:
+        ctx.close()

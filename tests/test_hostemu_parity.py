@@ -195,3 +195,18 @@ def test_heat_source_path(emu, hydro, n_con, nmax):
 def test_dyn_core_substeps_with_dissipative_heating(emu):
     D.check_substeps(emu, n_split=2, flags=dict(d_con=1.0, do_vort_damp=True, vtdm4=0.06, nord=2))
     D.check_substeps(emu, n_split=2, flags=dict(d_con=0.5))
+
+
+@pytest.mark.parametrize("d_ext", [0.02, 0.0])
+def test_one_grad_p_hydrostatic(emu, d_ext):
+    N.check_one_grad_p(emu, d_ext=d_ext)
+
+
+def test_dyn_core_substeps_hydrostatic(emu):
+    D.check_substeps_hydrostatic(emu)
+    D.check_substeps_hydrostatic(emu, nx=70, ny=60, npz=6, flags=dict(d_ext=0.0))
+    D.check_substeps_hydrostatic(emu, n_split=3, flags=dict(d_con=1.0, do_vort_damp=True, vtdm4=0.06, nord=2))
+
+
+def test_fv_dynamics_step_hydrostatic(emu):
+    D.check_fv_step_hydrostatic(emu)
