@@ -1025,6 +1025,20 @@ extern "C" int fv3_p_grad_c(fv3_ctx *c, double dt2, const double *delpc, const d
   return 0;
 }
 
+extern "C" int fv3_pt_to_theta_v(fv3_ctx *c, int hydrostatic, double zvir, double kappa, double rdgas, double grav,
+                                 double *pt, const double *delp, const double *delz, const double *qv, double *pkz) {
+  if (!c || !c->grid_ready) return fail("fv3_pt_to_theta_v: context has no grid");
+  if (!pt || !pkz || (!hydrostatic && (!delp || !delz))) return fail("fv3_pt_to_theta_v: null field");
+  const Grid &g = c->g;
+  PtToThetaV kf{g, hydrostatic, zvir, kappa, -rdgas / grav, pt, delp, delz, qv, pkz};
+  Dim3 grid;
+  grid.x = (unsigned)((g.nx * g.ny + PtToThetaV::CH - 1) / PtToThetaV::CH);
+  grid.y = 1;
+  grid.z = (unsigned)g.npz;
+  RT(launch_p(c, "pt_to_theta_v", grid, 0, kf));
+  return 0;
+}
+
 extern "C" int fv3_heat_source_accum(fv3_ctx *c, double *heat_source, const double *heat_s) {
   if (!c || !c->grid_ready || !heat_source || !heat_s) return fail("fv3_heat_source_accum: bad context/arguments");
   const Grid &g = c->g;

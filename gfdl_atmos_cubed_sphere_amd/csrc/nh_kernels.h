@@ -897,4 +897,30 @@ struct CopyAtoCC {  // compute-domain copy of an A-kind field into a CC-kind one
   }
 };
 
+struct PtToThetaV {  // fv_dynamics.F90:296-329, :379-399 (use_cond = moist_kappa = .false.)
+  Grid g;
+  int hydrostatic;
+  double zvir, kappa, rdg;
+  double *pt;
+  const double *delp, *delz, *qv;
+  double *pkz;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int n = g.nx * g.ny;
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.is + idx % g.nx, j = g.js + idx / g.nx;
+      const size_t o = (size_t)bz * g.nA() + g.iA(i, j), c = (size_t)bz * g.nCC() + idx;
+      const double dp1 = qv ? zvir * qv[o] : 0.;
+      double pz;
+      if (hydrostatic) {
+        pz = pkz[c];
+      } else {
+        pz = exp(kappa * log(rdg * delp[o] * pt[o] * (1. + dp1) / delz[c]));
+        pkz[c] = pz;
+      }
+      pt[o] = pt[o] * (1. + dp1) / pz;
+    }
+  }
+};
+
 }  // namespace fv3

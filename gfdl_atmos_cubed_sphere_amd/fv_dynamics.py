@@ -39,6 +39,16 @@ class FvDynamics:
     def set_tracers(self, q: np.ndarray):
         self.dc.d["q"].upload(q)
 
+    def step_from_temperature(self, bdt: float):
+        """A whole fv_dynamics call for the adiabatic core: pt holds T (T_v) on entry and on return.
+        fv_dynamics.F90:284-399 (T -> theta_v), the k_split loop, and the theta_v -> T conversion that the last remap
+        does (fv_mapz.F90:793-821, last_step)."""
+        d, ctx, fl = self.dc.d, self.ctx, self.fl
+        qv = d["q"].ptr if (self.nq and self.remap_par["sphum"] > 0 and not self.remap_par["adiabatic"]) else None
+        ctx.pt_to_theta_v(fl.hydrostatic, self.remap_par["r_vir"] if qv else 0.0, fl.akap, fl.rdgas, fl.grav, d["pt"],
+                          d["delp"], None if fl.hydrostatic else d["delz"], qv, d["pkz"])
+        self.step(bdt, last_cycle_is_last_step=True)
+
     def step(self, bdt: float, last_cycle_is_last_step: bool = False):
         """One dt_atmos: k_split x (n_split acoustic substeps, tracer transport, vertical remap)."""
         d, ctx = self.dc.d, self.ctx

@@ -242,6 +242,14 @@ int fv3_apply_heat_source(fv3_ctx *ctx, int n_con, int hydrostatic, double bdt, 
                           double cv_air, double rdgas, double grav, double *pt, double *heat_source, const double *delp,
                           const double *delz, double *pkz);
 
+/* ---- fv_dynamics: T -> theta_v before the k_split loop (model/fv_dynamics.F90:284-329, :379-399; use_cond =
+ * moist_kappa = .false.).  nonhydrostatic: pkz = exp(kappa*log(rdg*delp*pt*(1+zvir*qv)/delz)) is (re)computed;
+ * hydrostatic: pkz is taken as given (p_var / the previous remap).  Then pt = pt*(1+zvir*qv)/pkz on the compute
+ * domain.  qv: A x npz specific humidity or NULL (dry: zvir*qv = 0).  The way back (theta_v -> T) is part of
+ * fv3_lagrangian_to_eulerian with last_step = 1, as in the reference (fv_mapz.F90:793-821). */
+int fv3_pt_to_theta_v(fv3_ctx *ctx, int hydrostatic, double zvir, double kappa, double rdgas, double grav, double *pt,
+                      const double *delp, const double *delz, const double *qv, double *pkz);
+
 /* ---- vertical remap ------------------------------------------------------------------------------------
  * Lagrangian_to_Eulerian -- model/fv_mapz.F90:56-64, call site model/fv_dynamics.F90:607.  Branches built:
  * remap_te=.false., use_cond=moist_kappa=.false., consv=0, fill=.false., |kord| in {8,9,10,11,13}, kord_wz>0.

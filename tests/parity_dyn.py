@@ -130,7 +130,7 @@ def check_fv_step_hydrostatic(lib, nx=24, ny=16, npz=10, nq=2, k_split=2, n_spli
     return out
 
 
-def oracle_fv_step(g, npz, fl, dp0, st, ak, bk, q, bdt, k_split, remap_par):
+def oracle_fv_step(g, npz, fl, dp0, st, ak, bk, q, bdt, k_split, remap_par, last_step=False):
     """Oracle-orchestrated k_split loop (fv_dynamics.F90:460-665): dyn_core -> tracer_2d -> Lagrangian_to_Eulerian."""
     import oracle_lib as O
     bd = g.bd
@@ -149,9 +149,55 @@ def oracle_fv_step(g, npz, fl, dp0, st, ak, bk, q, bdt, k_split, remap_par):
                   w=f["w"], delz=f["delz"], pt=f["pt"], peln=f["peln"], omga=f["omga"], ws=f["ws"])
         if nq:
             rf["q"] = q
-        O.lagrangian_to_eulerian(g, npz, dict(remap_par, last_step=0), rf, ak, bk)
+        O.lagrangian_to_eulerian(g, npz, dict(remap_par, last_step=int(last_step and n_map == k_split)), rf, ak, bk)
         cur = dict(u=rf["u"], v=rf["v"], w=rf["w"], delp=rf["delp"], pt=rf["pt"], delz=rf["delz"], phis=st["phis"])
         out = dict(cur, q=q, pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"])
+    return out
+
+
+def check_fv_cycle_from_temperature(lib, nx=24, ny=16, npz=10, k_split=2, n_split=2, bdt=8.0):
+    """A whole adiabatic fv_dynamics call: T -> theta_v (fv_dynamics.F90:284-399), k_split loop, last remap back to T.
+    Oracle side: the same conversion in numpy, then the oracle-orchestrated loop with last_step on the final cycle."""
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.lib import GRAV, KAPPA, RDGAS
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    st, dp0 = make_state(bd, npz)
+    r = (bd.is_, bd.ie, bd.js, bd.je)
+    ng = bd.ng
+    # a temperature field consistent with the balanced theta_v state: T = theta_v * pkz(theta_v state)
+    th = st["pt"]
+    dpc, thc = bd.view(st["delp"], "A", *r), bd.view(th, "A", *r)
+    gm = 1.0 / (1.0 - KAPPA)
+    pkz0 = np.exp(KAPPA * gm * np.log((-RDGAS / GRAV) * dpc * thc / st["delz"]))     # p**kappa of the theta state
+    T = th.copy(order="F")
+    T[ng:ng + nx, ng:ng + ny, :] = thc * pkz0
+    # oracle side conversion (fv_dynamics.F90:323-329, :389-397 with dp1 = 0)
+    Tc = bd.view(T, "A", *r)
+    pkz = np.exp(KAPPA * np.log((-RDGAS / GRAV) * dpc * Tc * (1.0 + 0.0) / st["delz"]))
+    th2 = T.copy(order="F")
+    th2[ng:ng + nx, ng:ng + ny, :] = Tc * (1.0 + 0.0) / pkz
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+    ak, bk = N.PTOP * (1.0 - sig), sig.copy()
+    dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP)
+    ctx = Context(g, npz, lib=lib)
+    try:
+        fv = FvDynamics(ctx, fl, ak, bk, nq=0, k_split=k_split)
+        ref = oracle_fv_step(g, npz, fl, dp_ref, dict(st, pt=th2), ak, bk, None, bdt, k_split, fv.remap_par, last_step=True)
+        fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], T, st["delz"], st["phis"])
+        fv.step_from_temperature(bdt)
+        d = fv.dc.d
+        emu = "hostemu" in lib.path
+        out = {}
+        # the T -> theta_v conversion goes through exp/log of a different math library on each side (numpy vs libm /
+        # device): 1-ulp differences there, and w sits on its conditioning floor (see check_substeps)
+        for n, kind, tol in (("pt", "A", 1e-12), ("delp", "A", 1e-12), ("w", "A", 1e-10)):
+            out[n] = P.assert_close(n, bd.view(d[n].download(), kind, *r), bd.view(ref[n], kind, *r), tol)
+        Tn = bd.view(d["pt"].download(), "A", *r)
+        assert 150.0 < Tn.min() and Tn.max() < 400.0      # it is a temperature again
+    finally:
+        ctx.close()
     return out
 
 

@@ -320,3 +320,12 @@ def test_dyn_core_substeps_hydrostatic(prod):
 
 def test_fv_dynamics_step_hydrostatic(prod):
     D.check_fv_step_hydrostatic(prod)
+
+
+def test_fv_dynamics_cycle_from_temperature(prod):
+    D.check_fv_cycle_from_temperature(prod)
+
+
+def test_baseline_config1_shape_hydrostatic(prod):
+    """BASELINE configs[0] shape (doubly periodic 48 x 48 x 32, hydrostatic): two substeps vs the oracle"""
+    D.check_substeps_hydrostatic(prod, nx=48, ny=48, npz=32, n_split=2)

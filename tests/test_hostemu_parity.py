@@ -210,3 +210,7 @@ def test_dyn_core_substeps_hydrostatic(emu):
 
 def test_fv_dynamics_step_hydrostatic(emu):
     D.check_fv_step_hydrostatic(emu)
+
+
+def test_fv_dynamics_cycle_from_temperature(emu):
+    D.check_fv_cycle_from_temperature(emu)
