@@ -198,10 +198,18 @@ def main():
     def step():
         ctx.c_sw(d["delpc"], d["delp"], d["ptc"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"],
                  d["va"], d["wc"], d["ut"], d["vt"], d["divg_d"], 1, 0.5 * dt, False)
-        halo.update([(d["uc"], "V"), (d["vc"], "U"), (d["divg_d"], "B")])
-        ctx.d_sw(par, None, d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"],
-                 d["divg_d"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
-                 d["delp_out"], d["pt_out"], d["u_out"], d["v_out"], d["w_out"], None, d["heat_s"], d["diss_e"])
+        dsw_args = (par, None, d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"],
+                    d["divg_d"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
+                    d["delp_out"], d["pt_out"], d["u_out"], d["v_out"], d["w_out"], None, d["heat_s"], d["diss_e"])
+        # start the exchange, run the part of d_sw that reads no halo while it is in flight, complete, do the rest
+        if halo.overlaps:
+            pending = halo.start([(d["uc"], "V"), (d["vc"], "U"), (d["divg_d"], "B")])
+            ctx.d_sw(*dsw_args, phase="interior")
+            halo.finish(pending)
+            ctx.d_sw(*dsw_args, phase="rest")
+        else:
+            halo.update([(d["uc"], "V"), (d["vc"], "U"), (d["divg_d"], "B")])
+            ctx.d_sw(*dsw_args)
 
     def fence():
         torch.cuda.synchronize()

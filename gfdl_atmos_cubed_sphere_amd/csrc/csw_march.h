@@ -32,6 +32,7 @@ inline MarchDims make_csw_dims(const Grid &g, int tj) {
   d.k_fast = march_k_fast();
   d.nstrips = (g.nx + 4 + kCswCols - 1) / kCswCols;
   d.nsegs = (g.ny + 4 + tj - 1) / tj;
+  d.set_box(0, d.nstrips, 0, d.nsegs);
   return d;
 }
 

@@ -74,7 +74,6 @@ struct fv3_ctx {
   int march_tj;          // rows per wavefront segment of the marching kernels
   int march_tj_csw, march_tj_ke, march_tj_fused;
   int csw_kpw;           // levels per wavefront in CswMarch (1 or 2; FV3_MI355X_CSW_KPW)
-  int mom_overlap;       // 1: unfused momentum with its KE kernel on the side stream, concurrent with the transports
   int use_fused;         // 1: delp + w + pt in one marching kernel when the schemes allow (FV3_MI355X_FUSED=0: off)
   int use_march;         // 0: LDS-tile kernels only (FV3_MI355X_MARCH=0)
   bool prof_on;
@@ -219,8 +218,6 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_CSW_KPW");
     c->csw_kpw = e ? std::atoi(e) : 2;
     if (c->csw_kpw < 1 || c->csw_kpw > 3) c->csw_kpw = 2;
-    e = std::getenv("FV3_MI355X_MOM_OVERLAP");
-    c->mom_overlap = e ? std::atoi(e) : 0;
     e = std::getenv("FV3_MI355X_FUSED");
     c->use_fused = e ? std::atoi(e) : 1;
     e = std::getenv("FV3_MI355X_MARCH_TJ_FUSED");
@@ -554,7 +551,14 @@ static int ensure_mflux(fv3_ctx *c) {
 }
 
 // d_sw transports on the wave-marching fv_tp_2d (dsw_march.h)
-static int dsw_transport_march(fv3_ctx *c, const DswArgs &a) {
+// region (fused kernel only): 0 = every strip / segment, 1 = those that do not touch the halo (interior box),
+// 2 = the frame around the interior box
+static bool dsw_has_interior(const fv3_ctx *c) {
+  const MarchDims mf = make_march_dims(c->g, c->march_tj_fused);
+  return mf.nstrips >= 3 && mf.nsegs >= 3;
+}
+
+static int dsw_transport_march(fv3_ctx *c, const DswArgs &a, int region = 0) {
   const Grid &g = c->g;
   if (ensure_mflux(c)) return 1;
   MarchDims md = make_march_dims(g, c->march_tj);
@@ -564,6 +568,20 @@ static int dsw_transport_march(fv3_ctx *c, const DswArgs &a) {
     if (c->n_plain == 0) return 0;
     MarchDims mf = make_march_dims(g, c->march_tj_fused);
     mf.klist = c->klist;
+    const int NS = mf.nstrips, NG = mf.nsegs;
+    auto box = [&](int s0, int ns, int g0, int ng) -> int {
+      if (ns <= 0 || ng <= 0) return 0;
+      mf.set_box(s0, ns, g0, ng);
+      const int nwf = mf.nwaves(c->n_plain);
+      return dispatch_hord(a.hord_dp, [&](auto H) {
+        constexpr int HORD = decltype(H)::value;
+        if (a.hydrostatic) return launch_w(c, "d_sw_fused", nwf, DswTransportFused<HORD, false, true>{g, a, mf});
+        return launch_w(c, "d_sw_fused", nwf, DswTransportFused<HORD, true, true>{g, a, mf});
+      });
+    };
+    if (region == 0 || !dsw_has_interior(c)) return region == 1 ? 0 : box(0, NS, 0, NG);
+    if (region == 1) return box(1, NS - 2, 1, NG - 2);
+    mf.set_frame();                            // south / north rows and west / east columns in one launch
     const int nwf = mf.nwaves(c->n_plain);
     return dispatch_hord(a.hord_dp, [&](auto H) {
       constexpr int HORD = decltype(H)::value;
@@ -571,6 +589,7 @@ static int dsw_transport_march(fv3_ctx *c, const DswArgs &a) {
       return launch_w(c, "d_sw_fused", nwf, DswTransportFused<HORD, true, true>{g, a, mf});
     });
   }
+  if (region == 1) return 0;  // the per-field kernels are not split
   double *fxs = c->mflux[0], *fys = c->mflux[1];
   int rc = dispatch_hord(a.hord_dp, [&](auto H) {
     DswDelpMarch<decltype(H)::value> kf{g, a, md, fxs, fys, 1};
@@ -592,7 +611,7 @@ static int dsw_transport_march(fv3_ctx *c, const DswArgs &a) {
 // part = 0: everything; 1: only the KE / damping kernel (unfused path); 2: only the vorticity kernel
 static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
   const Grid &g = c->g;
-  const bool fused_m = c->use_fused && !c->mom_overlap;
+  const bool fused_m = c->use_fused != 0;
   if (!fused_m && !c->ke_scr) RT(rt_malloc((void **)&c->ke_scr, sizeof(double) * g.nB() * g.npz));
   if (fused_m) {
     MarchDims mf = make_march_dims(g, c->march_tj_fused);
@@ -629,12 +648,14 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
   });
 }
 
-extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const double *delp, const double *pt,
-                        const double *u, const double *v, const double *w, const double *uc, const double *vc,
-                        const double *ua, const double *va, const double *divg_d, double *mfx, double *mfy,
-                        double *cx, double *cy, double *crx, double *cry, double *xfx, double *yfx,
-                        const double *q_con, double *delp_out, double *pt_out, double *u_out, double *v_out,
-                        double *w_out, double *q_con_out, double *heat_s, double *diss_e) {
+// phase 0: the whole routine; 1: only the part that needs no halo of uc, vc, divg_d (interior strips / segments of the
+// fused transport kernel); 2: everything else, after phase 1
+static int d_sw_impl(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const double *delp, const double *pt,
+                     const double *u, const double *v, const double *w, const double *uc, const double *vc,
+                     const double *ua, const double *va, const double *divg_d, double *mfx, double *mfy,
+                     double *cx, double *cy, double *crx, double *cry, double *xfx, double *yfx,
+                     const double *q_con, double *delp_out, double *pt_out, double *u_out, double *v_out,
+                     double *w_out, double *q_con_out, double *heat_s, double *diss_e, int phase) {
   if (!c || !c->grid_ready) return fail("fv3_d_sw: context has no grid (call fv3_grid_upload)");
   if (!c->lev_ready) return fail("fv3_d_sw: per-level coefficients missing (call fv3_dsw_levels_upload)");
   if (!p) return fail("fv3_d_sw: null params");
@@ -698,6 +719,13 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, cons
   // Side stream: when the tile kernels only take a few levels (the sponge layers) and both halves of d_sw route the
   // same levels there, their chain courant -> transport -> momentum touches data disjoint from the marching kernels'
   // and runs concurrently with them.  (Not while profiling: the per-kernel events live on the main stream.)
+  // region of the fused transport kernel this call runs (phases 1/2 split it only when it is the active path)
+  const bool split = fused && march && c->n_plain > 0 && dsw_has_interior(c);
+  if (phase == 1) {
+    if (split) RT(dsw_transport_march(c, a, 1));
+    return 0;
+  }
+  const int region = (phase == 2 && split) ? 2 : 0;
   const bool side = fused && march_m && c->side_ok && c->use_side && !c->prof_on && c->n_damp > 0 && c->n_plain > 0;
   if (side) {
     if (!c->stream2) {
@@ -712,29 +740,34 @@ extern "C" int fv3_d_sw(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, cons
     int rc = courant();
     if (!rc) rc = tile_transport();
     if (!rc) rc = tile_momentum();
-    // the KE / damping kernel of the marching levels reads only u, v, uc, vc, divg_d: it can share the machine with
-    // the register-heavy fused transport kernel (96 + 336 VGPRs fit one SIMD together)
-    if (!rc && c->mom_overlap) rc = dsw_momentum_march(c, a, 1);
     rt_event_record(c->ev_join, c->stream2);
     c->stream = main_stream;
     RT(rc);
-    RT(dsw_transport_march(c, a));
-    if (c->mom_overlap) {
-      rt_stream_wait_event(main_stream, c->ev_join);
-      RT(dsw_momentum_march(c, a, 2));
-    } else {
-      RT(dsw_momentum_march(c, a));
-      rt_stream_wait_event(main_stream, c->ev_join);
-    }
+    RT(dsw_transport_march(c, a, region));
+    RT(dsw_momentum_march(c, a));
+    rt_stream_wait_event(main_stream, c->ev_join);
     return 0;
   }
   RT(courant());
-  if (march && c->n_plain > 0) RT(dsw_transport_march(c, a));
+  if (march && c->n_plain > 0) RT(dsw_transport_march(c, a, region));
   RT(tile_transport());
   if (march_m && c->n_plain_m > 0) RT(dsw_momentum_march(c, a));
   RT(tile_momentum());
   return 0;
 }
+
+#define FV3_DSW_ARGS                                                                                                      \
+  c, p, delpc, delp, pt, u, v, w, uc, vc, ua, va, divg_d, mfx, mfy, cx, cy, crx, cry, xfx, yfx, q_con, delp_out, pt_out, \
+      u_out, v_out, w_out, q_con_out, heat_s, diss_e
+#define FV3_DSW_PARAMS                                                                                                  \
+  fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const double *delp, const double *pt, const double *u,           \
+      const double *v, const double *w, const double *uc, const double *vc, const double *ua, const double *va,        \
+      const double *divg_d, double *mfx, double *mfy, double *cx, double *cy, double *crx, double *cry, double *xfx,   \
+      double *yfx, const double *q_con, double *delp_out, double *pt_out, double *u_out, double *v_out, double *w_out, \
+      double *q_con_out, double *heat_s, double *diss_e
+extern "C" int fv3_d_sw(FV3_DSW_PARAMS) { return d_sw_impl(FV3_DSW_ARGS, 0); }
+extern "C" int fv3_d_sw_interior(FV3_DSW_PARAMS) { return d_sw_impl(FV3_DSW_ARGS, 1); }
+extern "C" int fv3_d_sw_rest(FV3_DSW_PARAMS) { return d_sw_impl(FV3_DSW_ARGS, 2); }
 
 // ---- periodic halo fill (single rank owns the whole doubly periodic tile) ------------------------
 struct HaloPeriodic {

@@ -57,22 +57,44 @@ struct MarchDims {
   const int *klist;  // level of the n-th marching slab (device), or null = identity
   int nk;            // number of level slots of the launch (set by nwaves)
   int k_fast;        // 1: consecutive wavefronts = consecutive levels of the same (strip, segment)
+  // sub-box of the (strip, segment) grid this launch covers (default: all) -- lets a caller run the strips /
+  // segments that do not touch the halo while the halo exchange is still in flight, and the frame afterwards
+  int s0, ns, g0, ng;
+  int frame;         // 1: the launch covers the frame of the whole grid around its interior box instead of a box
+  FV3_HD void set_box(int s0_, int ns_, int g0_, int ng_) { s0 = s0_; ns = ns_; g0 = g0_; ng = ng_; frame = 0; }
+  FV3_HD void set_frame() { s0 = 0; ns = nstrips; g0 = 0; ng = nsegs; frame = 1; }
+  FV3_HD int ncells() const { return frame ? nstrips * nsegs - (nstrips - 2) * (nsegs - 2) : ns * ng; }
   FV3_HD int nwaves(int npz) {
     nk = npz;
-    return nstrips * nsegs * npz;
+    return ncells() * npz;
+  }
+  // t-th cell of the frame: south row, north row, then the west and east columns between them
+  FV3_HD void frame_cell(int t, int &strip, int &seg) const {
+    if (t < nstrips) { strip = t; seg = 0; return; }
+    t -= nstrips;
+    if (t < nstrips) { strip = t; seg = nsegs - 1; return; }
+    t -= nstrips;
+    if (t < nsegs - 2) { strip = 0; seg = 1 + t; return; }
+    t -= nsegs - 2;
+    strip = nstrips - 1;
+    seg = 1 + t;
   }
   // k fastest: the workgroups that are in flight together (round-robin over the 8 XCDs) work on the same
   // (strip, segment) at different levels, so the 2-D metric rows they all read are served by each XCD's L2
   FV3_HD void decode(int gid, int &strip, int &seg, int &kk) const {
-    if (k_fast) {
+    if (frame) {
+      const int nc = ncells();
+      kk = gid / nc;
+      frame_cell(gid % nc, strip, seg);
+    } else if (k_fast) {
       kk = gid % nk;
       const int t = gid / nk;
-      strip = t % nstrips;
-      seg = t / nstrips;
+      strip = s0 + t % ns;
+      seg = g0 + t / ns;
     } else {
-      strip = gid % nstrips;
-      seg = (gid / nstrips) % nsegs;
-      kk = gid / (nstrips * nsegs);
+      strip = s0 + gid % ns;
+      seg = g0 + (gid / ns) % ng;
+      kk = gid / (ns * ng);
     }
   }
 };
@@ -91,6 +113,7 @@ inline MarchDims make_march_dims(const Grid &g, int tj) {
   d.k_fast = march_k_fast();
   d.nstrips = num_strips(g);
   d.nsegs = (g.ny + tj - 1) / tj;
+  d.set_box(0, d.nstrips, 0, d.nsegs);
   return d;
 }
 

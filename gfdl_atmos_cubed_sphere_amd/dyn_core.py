@@ -238,10 +238,18 @@ class DynCore:
             ctx.update_dz_c(dt2, d["zs"], d["ut"], d["vt"], d["zh"], d["gz"], d["ws3"])       # :514-527
             ctx.riem_solver_c(dt2, self.cn, d["phis"], d["omga"], d["ptc"], d["delpc"], d["gz"], d["pkc"], d["ws3"])  # :531
             ctx.p_grad_c(dt2, d["delpc"], d["pkc"], d["gz"], d["uc"], d["vc"], False)         # :562
-            halo.update([(d["uc"], "V"), (d["vc"], "U")])                     # :565 / :578 (pack 9, CGRID_NE)
-            ctx.d_sw(par, d["vt"], d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"],
-                     d["divgd"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
-                     d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], d["w_nxt"], None, d["heat_s"], d["diss_e"])  # :762
+            # :565 / :578 (pack 9, CGRID_NE) overlapped with the interior of d_sw (:762): start ... complete
+            dsw_args = (par, d["vt"], d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"],
+                        d["divgd"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
+                        d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], d["w_nxt"], None, d["heat_s"], d["diss_e"])
+            if halo.overlaps:
+                pending = halo.start([(d["uc"], "V"), (d["vc"], "U")])
+                ctx.d_sw(*dsw_args, phase="interior")
+                halo.finish(pending)
+                ctx.d_sw(*dsw_args, phase="rest")
+            else:
+                halo.update([(d["uc"], "V"), (d["vc"], "U")])
+                ctx.d_sw(*dsw_args)
             if heating:
                 ctx.heat_source_accum(d["heat_source"], d["heat_s"])          # :798-803
             for n in ("delp", "pt", "u", "v", "w"):

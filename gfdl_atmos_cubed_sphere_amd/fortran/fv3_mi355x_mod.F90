@@ -16,6 +16,7 @@ module fv3_mi355x_mod
   public :: fv3_tracer_2d_scale, fv3_tracer_2d_step
   public :: fv3_halo_field, fv3_halo_message_elems, fv3_halo_pack, fv3_halo_unpack
   public :: fv3_heat_source_accum, fv3_del2_cubed, fv3_apply_heat_source
+  public :: fv3_d_sw_interior, fv3_d_sw_rest
   public :: fv3_divg2_ext, fv3_one_grad_p, fv3_copy_a_to_cc, fv3_pt_to_theta_v
 
   type, bind(C) :: fv3_domain
@@ -119,6 +120,24 @@ module fv3_mi355x_mod
     integer(c_int) function fv3_d_sw(ctx, p, delpc, delp, pt, u, v, w, uc, vc, ua, va, divg_d, mfx, mfy, cx, cy, &
                                      crx, cry, xfx, yfx, q_con, delp_out, pt_out, u_out, v_out, w_out, q_con_out, &
                                      heat_s, diss_e) bind(C, name="fv3_d_sw")
+      import :: c_int, c_ptr, fv3_dsw_params
+      type(c_ptr), value :: ctx
+      type(fv3_dsw_params), intent(in) :: p
+      type(c_ptr), value :: delpc, delp, pt, u, v, w, uc, vc, ua, va, divg_d, mfx, mfy, cx, cy, crx, cry, xfx, yfx
+      type(c_ptr), value :: q_con, delp_out, pt_out, u_out, v_out, w_out, q_con_out, heat_s, diss_e
+    end function
+    integer(c_int) function fv3_d_sw_interior(ctx, p, delpc, delp, pt, u, v, w, uc, vc, ua, va, divg_d, mfx, mfy, cx, cy, &
+                                     crx, cry, xfx, yfx, q_con, delp_out, pt_out, u_out, v_out, w_out, q_con_out, &
+                                     heat_s, diss_e) bind(C, name="fv3_d_sw_interior")
+      import :: c_int, c_ptr, fv3_dsw_params
+      type(c_ptr), value :: ctx
+      type(fv3_dsw_params), intent(in) :: p
+      type(c_ptr), value :: delpc, delp, pt, u, v, w, uc, vc, ua, va, divg_d, mfx, mfy, cx, cy, crx, cry, xfx, yfx
+      type(c_ptr), value :: q_con, delp_out, pt_out, u_out, v_out, w_out, q_con_out, heat_s, diss_e
+    end function
+    integer(c_int) function fv3_d_sw_rest(ctx, p, delpc, delp, pt, u, v, w, uc, vc, ua, va, divg_d, mfx, mfy, cx, cy, &
+                                     crx, cry, xfx, yfx, q_con, delp_out, pt_out, u_out, v_out, w_out, q_con_out, &
+                                     heat_s, diss_e) bind(C, name="fv3_d_sw_rest")
       import :: c_int, c_ptr, fv3_dsw_params
       type(c_ptr), value :: ctx
       type(fv3_dsw_params), intent(in) :: p

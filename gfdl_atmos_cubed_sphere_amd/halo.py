@@ -149,19 +149,23 @@ class HaloExchanger:
             grp = self._groups[key] = (send, recv, [self._tensor(b) for b in send], [self._tensor(b) for b in recv])
         return grp
 
-    def update(self, fields):
-        """fields: [(DeviceArray, kind)] -- one "pack" (the reference's group halo update).
+    @property
+    def overlaps(self) -> bool:
+        """True when start()/finish() leave a window in which transfers are in flight (several ranks): callers split
+        d_sw into interior + rest only then -- on one rank the split would just cost launch granularity."""
+        return self.world > 1 or self.packed_single
 
-        One rank: periodic copy kernel per field.  Several ranks: ONE pack kernel for all fields and directions,
-        one send + one receive per neighbour offset (8 messages whatever the number of fields), ONE unpack
-        kernel.  Message d goes to the neighbour at offset d and is matched there by the receive posted for the
-        same d (from its neighbour at -d), posted in the same fixed order on both sides."""
+    def start(self, fields):
+        """Begin a group halo update (the reference's start_group_halo_update): pack and post the messages.  Returns a
+        handle for finish().  Compute that does not read these halos may be launched in between: the transfers run on
+        RCCL's own stream and only finish() makes the launch stream wait for them."""
+        fields = list(fields)
         if self.world == 1 and not self.packed_single:
             for dev, kind in fields:
                 self.ctx.halo_fill_periodic(dev, kind)
-            return
+            return None
         import torch.distributed as dist
-        fields = list(fields)
+        pending = []
         for n in range(0, len(fields), 8):          # FV3_HALO_MAX_FIELDS per group
             part = fields[n:n + 8]
             send, recv, tsend, trecv = self._group(part)
@@ -173,7 +177,24 @@ class HaloExchanger:
                     continue
                 p2p.append(dist.P2POp(dist.isend, tsend[m], to))
                 p2p.append(dist.P2POp(dist.irecv, trecv[m], frm))
-            if p2p:
-                for w in dist.batch_isend_irecv(p2p):   # ncclGroupStart ... ncclGroupEnd on RCCL
-                    w.wait()
+            works = dist.batch_isend_irecv(p2p) if p2p else []   # ncclGroupStart ... ncclGroupEnd on RCCL
+            pending.append((part, recv, works))
+        return pending
+
+    def finish(self, pending):
+        """complete_group_halo_update: wait for the messages of start() and unpack them into the halos."""
+        if pending is None:
+            return
+        for part, recv, works in pending:
+            for w in works:
+                w.wait()
             self.ctx.halo_unpack(part, recv)
+
+    def update(self, fields):
+        """fields: [(DeviceArray, kind)] -- one "pack" (the reference's group halo update).
+
+        One rank: periodic copy kernel per field.  Several ranks: ONE pack kernel for all fields and directions,
+        one send + one receive per neighbour offset (8 messages whatever the number of fields), ONE unpack
+        kernel.  Message d goes to the neighbour at offset d and is matched there by the receive posted for the
+        same d (from its neighbour at -d), posted in the same fixed order on both sides."""
+        self.finish(self.start(fields))

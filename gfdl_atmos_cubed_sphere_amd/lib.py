@@ -31,7 +31,7 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 # every symbol include/fv3_mi355x.h declares (tests check the built library exports all of them)
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
-           "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
+           "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
            "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_lagrangian_to_eulerian",
@@ -264,16 +264,18 @@ class Context:
         self.lib.check(self.lib.dll.fv3_dsw_levels_upload(self.h, C.byref(lv)), "fv3_dsw_levels_upload")
 
     def d_sw(self, par: dict, delpc, delp, pt, u, v, w, uc, vc, ua, va, divg_d, mfx, mfy, cx, cy, crx, cry, xfx, yfx,
-             q_con, delp_out, pt_out, u_out, v_out, w_out, q_con_out, heat_s, diss_e):
-        """model/sw_core.F90:494 d_sw over all levels (the k loop of dyn_core.F90:658-812)."""
+             q_con, delp_out, pt_out, u_out, v_out, w_out, q_con_out, heat_s, diss_e, phase: str = "all"):
+        """model/sw_core.F90:494 d_sw over all levels (the k loop of dyn_core.F90:658-812).
+        phase: "all", or "interior" (the part that needs no halo of uc, vc, divg_d) followed by "rest"."""
+        fn = {"all": "fv3_d_sw", "interior": "fv3_d_sw_interior", "rest": "fv3_d_sw_rest"}[phase]
         pr = _DswParams()
         for k in ["dt", "hord_tr", "hord_mt", "hord_vt", "hord_tm", "hord_dp", "dddmp", "d4_bg", "kgb", "hydrostatic",
                   "use_cond"]:
             setattr(pr, k, par[k])
-        self.lib.check(self.lib.dll.fv3_d_sw(self.h, C.byref(pr), _pp(delpc), delp.p, pt.p, u.p, v.p, _pp(w), uc.p,
-                                             vc.p, ua.p, va.p, divg_d.p, mfx.p, mfy.p, cx.p, cy.p, crx.p, cry.p, xfx.p,
-                                             yfx.p, _pp(q_con), delp_out.p, pt_out.p, u_out.p, v_out.p, _pp(w_out),
-                                             _pp(q_con_out), heat_s.p, diss_e.p), "fv3_d_sw")
+        self.lib.check(getattr(self.lib.dll, fn)(self.h, C.byref(pr), _pp(delpc), delp.p, pt.p, u.p, v.p, _pp(w), uc.p,
+                                                 vc.p, ua.p, va.p, divg_d.p, mfx.p, mfy.p, cx.p, cy.p, crx.p, cry.p,
+                                                 xfx.p, yfx.p, _pp(q_con), delp_out.p, pt_out.p, u_out.p, v_out.p,
+                                                 _pp(w_out), _pp(q_con_out), heat_s.p, diss_e.p), fn)
 
     def profile(self, enable: bool):
         self.lib.check(self.lib.dll.fv3_profile(self.h, C.c_int(int(enable))), "fv3_profile")

@@ -133,6 +133,23 @@ int fv3_d_sw(fv3_ctx *ctx, const fv3_dsw_params *p, double *delpc, const double 
              double *cy, double *crx, double *cry, double *xfx, double *yfx, const double *q_con,
              double *delp_out, double *pt_out, double *u_out, double *v_out, double *w_out, double *q_con_out,
              double *heat_s, double *diss_e);
+/* The same routine in two calls, for overlapping the halo exchange of uc, vc, divg_d (dyn_core.F90:451, :565-578 --
+ * where the reference overlaps its start/complete_group_halo_update pairs with compute) with the part of d_sw that
+ * does not read those halos: fv3_d_sw_interior runs the interior strips / segments of the fused transport kernel and
+ * may be called before the halos are complete; fv3_d_sw_rest (same arguments) does everything else afterwards.
+ * interior + rest == fv3_d_sw bit for bit; when the fused kernel is not the active path interior is a no-op. */
+int fv3_d_sw_interior(fv3_ctx *ctx, const fv3_dsw_params *p, double *delpc, const double *delp, const double *pt,
+             const double *u, const double *v, const double *w, const double *uc, const double *vc,
+             const double *ua, const double *va, const double *divg_d, double *mfx, double *mfy, double *cx,
+             double *cy, double *crx, double *cry, double *xfx, double *yfx, const double *q_con,
+             double *delp_out, double *pt_out, double *u_out, double *v_out, double *w_out, double *q_con_out,
+             double *heat_s, double *diss_e);
+int fv3_d_sw_rest(fv3_ctx *ctx, const fv3_dsw_params *p, double *delpc, const double *delp, const double *pt,
+             const double *u, const double *v, const double *w, const double *uc, const double *vc,
+             const double *ua, const double *va, const double *divg_d, double *mfx, double *mfy, double *cx,
+             double *cy, double *crx, double *cry, double *xfx, double *yfx, const double *q_con,
+             double *delp_out, double *pt_out, double *u_out, double *v_out, double *w_out, double *q_con_out,
+             double *heat_s, double *diss_e);
 
 /* Periodic halo fill of one doubly periodic tile owned by a single rank (the two periodic contacts
  * of tools/fv_mp_mod.F90:473-483 when layout = 1x1): the single-GPU replacement of

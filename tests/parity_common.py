@@ -141,7 +141,7 @@ DSW_PAR = dict(dt=6.0, hord_tr=8, hord_mt=10, hord_vt=10, hord_tm=10, hord_dp=10
 
 
 def check_d_sw(lib, nx=40, ny=19, npz=4, hydrostatic=False, perturb=True, par_over=None, lev_over=None,
-               flags=None, use_cond=False):
+               flags=None, use_cond=False, phases=False):
     """c_sw (oracle) -> periodic halo of uc, vc, divg_d -> d_sw by oracle and by the library."""
     bd = Bounds(1, nx, 1, ny)
     g = make_grid(bd, perturb)
@@ -183,11 +183,16 @@ def check_d_sw(lib, nx=40, ny=19, npz=4, hydrostatic=False, perturb=True, par_ov
         out = {n: ctx.zeros(kind, npz) for n, kind in (("delp_out", "A"), ("pt_out", "A"), ("u_out", "U"),
                                                        ("v_out", "V"), ("w_out", "A"), ("q_con_out", "A"),
                                                        ("heat_s", "CC"), ("diss_e", "CC"), ("delpc_o", "A"))}
-        ctx.d_sw(par, out["delpc_o"], d["delp"], d["pt"], d["u"], d["v"], d.get("w"), d["uc"], d["vc"], d["ua"],
-                 d["va"], d["divg_d"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"],
-                 d.get("q_con"), out["delp_out"], out["pt_out"], out["u_out"], out["v_out"],
-                 None if hydrostatic else out["w_out"], out["q_con_out"] if use_cond else None, out["heat_s"],
-                 out["diss_e"])
+        args = (par, out["delpc_o"], d["delp"], d["pt"], d["u"], d["v"], d.get("w"), d["uc"], d["vc"], d["ua"],
+                d["va"], d["divg_d"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"],
+                d.get("q_con"), out["delp_out"], out["pt_out"], out["u_out"], out["v_out"],
+                None if hydrostatic else out["w_out"], out["q_con_out"] if use_cond else None, out["heat_s"],
+                out["diss_e"])
+        if phases:   # the halo-overlap form: interior strips / segments first, then the rest
+            ctx.d_sw(*args, phase="interior")
+            ctx.d_sw(*args, phase="rest")
+        else:
+            ctx.d_sw(*args)
         i0, i1, j0, j1 = bd.is_, bd.ie, bd.js, bd.je
         cmp = [("crx", d["crx"], "CX", None), ("cry", d["cry"], "CY", None), ("xfx", d["xfx"], "CX", None),
                ("yfx", d["yfx"], "CY", None), ("cx", d["cx"], "CX", None), ("cy", d["cy"], "CY", None),

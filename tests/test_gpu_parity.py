@@ -329,3 +329,10 @@ def test_fv_dynamics_cycle_from_temperature(prod):
 def test_baseline_config1_shape_hydrostatic(prod):
     """BASELINE configs[0] shape (doubly periodic 48 x 48 x 32, hydrostatic): two substeps vs the oracle"""
     D.check_substeps_hydrostatic(prod, nx=48, ny=48, npz=32, n_split=2)
+
+
+def test_d_sw_interior_then_rest_equals_d_sw(prod):
+    """3 x 3 strips/segments: the interior box first, the frame afterwards (halo-exchange overlap form)"""
+    assert max(P.check_d_sw(prod, nx=130, ny=100, npz=3, phases=True).values()) <= P.TOL
+    assert max(P.check_d_sw(prod, nx=130, ny=100, npz=3, hydrostatic=True, phases=True).values()) <= P.TOL
+    assert max(P.check_d_sw(prod, nx=40, ny=19, npz=3, phases=True).values()) <= P.TOL      # no interior: rest does all

@@ -214,3 +214,10 @@ def test_fv_dynamics_step_hydrostatic(emu):
 
 def test_fv_dynamics_cycle_from_temperature(emu):
     D.check_fv_cycle_from_temperature(emu)
+
+
+def test_d_sw_interior_then_rest_equals_d_sw(emu):
+    """3 x 3 strips/segments: the interior box first, the frame afterwards (halo-exchange overlap form)"""
+    assert max(P.check_d_sw(emu, nx=130, ny=100, npz=3, phases=True).values()) <= P.TOL
+    assert max(P.check_d_sw(emu, nx=130, ny=100, npz=3, hydrostatic=True, phases=True).values()) <= P.TOL
+    assert max(P.check_d_sw(emu, nx=40, ny=19, npz=3, phases=True).values()) <= P.TOL      # no interior: rest does all

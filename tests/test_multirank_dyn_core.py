@@ -22,7 +22,9 @@ def _block(a, kind, bd_g, bd_l):
     return np.asfortranarray(a[ilo - ilo_g:ihi - ilo_g + 1, jlo - jlo_g:jhi - jlo_g + 1].copy())
 
 
-def _worker(rank, world, port, ok):
+def _worker(rank, world, port, ok, nx=12, ny=10, npz=6, tj_fused=None):
+    if tj_fused:
+        os.environ["FV3_MI355X_MARCH_TJ_FUSED"] = str(tj_fused)   # short segments: several per block
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,7 +41,6 @@ def _worker(rank, world, port, ok):
         from gfdl_atmos_cubed_sphere_amd.layout import Bounds
         from gfdl_atmos_cubed_sphere_amd.lib import Context, Fv3Lib
         emu = Fv3Lib(os.path.join(HERE, "hostemu", "libfv3_hostemu.so"))
-        nx, ny, npz = 12, 10, 6
         px, py = choose_layout(world)
         bd_g = Bounds(1, nx * px, 1, ny * py)
         g_g = P.make_grid(bd_g, False)
@@ -82,4 +83,18 @@ def test_dyn_core_two_ranks_match_single_domain(world):
     s.close()
     ok = mp.get_context("spawn").Array("i", [0] * world)
     mp.spawn(_worker, args=(world, port, ok), nprocs=world, join=True)
+    assert list(ok) == [1] * world
+
+
+def test_two_ranks_with_exchange_overlap_split():
+    """blocks of 3 x 3 strips/segments per rank: d_sw's interior box runs between start and finish of the uc/vc
+    exchange, the frame afterwards (DynCore.run); the result must still equal the single-domain oracle"""
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostemu"), "-s"])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    ok = mp.get_context("spawn").Array("i", [0] * world)
+    mp.spawn(_worker, args=(world, port, ok, 120, 22, 3, 8), nprocs=world, join=True)
     assert list(ok) == [1] * world
