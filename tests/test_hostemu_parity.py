@@ -221,3 +221,11 @@ def test_d_sw_interior_then_rest_equals_d_sw(emu):
     assert max(P.check_d_sw(emu, nx=130, ny=100, npz=3, phases=True).values()) <= P.TOL
     assert max(P.check_d_sw(emu, nx=130, ny=100, npz=3, hydrostatic=True, phases=True).values()) <= P.TOL
     assert max(P.check_d_sw(emu, nx=40, ny=19, npz=3, phases=True).values()) <= P.TOL      # no interior: rest does all
+
+
+@pytest.mark.parametrize("nx,ny", [(6, 5), (58, 48), (59, 49), (117, 97), (8, 64), (61, 4)])
+def test_march_strip_and_segment_boundaries(emu, nx, ny):
+    """tiny tiles, exactly one strip / segment, one column / row more than a strip / segment, ragged last ones"""
+    assert P.check_c_sw(emu, nx=nx, ny=ny, npz=2) <= P.TOL
+    assert max(P.check_d_sw(emu, nx=nx, ny=ny, npz=3).values()) <= P.TOL
+    assert max(P.check_d_sw(emu, nx=nx, ny=ny, npz=3, hydrostatic=True, phases=True).values()) <= P.TOL
