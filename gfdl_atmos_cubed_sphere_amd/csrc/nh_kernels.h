@@ -110,9 +110,14 @@ struct ColIn {
 #endif
 // The scratch slabs never alias the inputs or each other: with that stated (and the k loops unrolled by 4) the
 // compiler issues the loads of the next levels ahead of the dependent recurrence instead of one level at a time.
+// Results are handed to the caller's sinks while the last two sweeps run (no extra passes over the scratch slabs):
+//   on_pe(k, pe2(k)), k = 1..km+1 ascending  -- the nonhydrostatic pressure perturbation at the interfaces,
+//   on_w(k, w2(k)),  k = 1..km               -- the new vertical velocity (may overwrite in.w: level k is not read again),
+//   on_dz(k, dz2(k)), k = km..1 descending   -- the new layer thickness (may overwrite in.zlev: not read after pass C).
+template <class OnPe, class OnW, class OnDz>
 FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhConsts &cn, bool sim1, bool c_grid,
                        double ws, double *FV3_RESTRICT s_gam, double *FV3_RESTRICT s_pp, double *FV3_RESTRICT s_w,
-                       double *FV3_RESTRICT s_pm) {
+                       double *FV3_RESTRICT s_pm, const OnPe &on_pe, const OnW &on_w, const OnDz &on_dz) {
   constexpr double r3 = 1. / 3.;
   const double rgrav = 1. / cn.grav, rgas = cn.rdgas;
   const double gm2 = 1. / (1. - cn.akap), cp2 = cn.akap;
@@ -250,13 +255,18 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
       const double pp_n = L(s_pp, k + 1);
       L(s_pp, k) = pe;
       if (!sim1) L(s_gam, k) = pp_k2;
-      if (sim1)
-        pe = pe + dm2 * (L(s_w, k) - L(in.w, k)) * rdt;
-      else
-        pe = pe + (dm2 * (L(s_w, k) - L(in.w, k)) * rdt - beta * (pp_n - pp_k2)) * ra;
+      const double w2 = L(s_w, k), w1 = L(in.w, k);
+      if (sim1) {
+        on_pe(k, pe);      // SIM1: pe2 is final here (no blend)
+        pe = pe + dm2 * (w2 - w1) * rdt;
+      } else {
+        pe = pe + (dm2 * (w2 - w1) * rdt - beta * (pp_n - pp_k2)) * ra;
+      }
+      on_w(k, w2);
       pp_k2 = pp_n;
     }
     L(s_pp, km + 1) = pe;
+    if (sim1) on_pe(km + 1, pe);
     if (!sim1) L(s_gam, km + 1) = pp_k2;
   }
   // ---- pass F: new layer thickness (:1382-1392 / :1518-1529); dz2 -> s_pm (pm2 consumed level by level)
@@ -270,12 +280,12 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
         const double g_rat = dm2 / dm_below, bb = 2. * (1. + g_rat);
         p1 = (L(s_pp, k) + bb * L(s_pp, k + 1) + g_rat * L(s_pp, k + 2)) * r3 - g_rat * p1;
       }
-      L(s_pm, k) = -dm2 * rgas * L(in.pt, k) * exp((cp2 - 1.) * log(dmax(cn.p_fac * pm2, p1 + pm2)));
+      on_dz(k, -dm2 * rgas * L(in.pt, k) * exp((cp2 - 1.) * log(dmax(cn.p_fac * pm2, p1 + pm2))));
       dm_below = dm2;
     }
   }
   if (!sim1) {  // pe2 = pe2 + beta*(pp - pe2) (:1531-1535)
-    for (int k = 1; k <= km + 1; k++) L(s_pp, k) = L(s_pp, k) + beta * (L(s_gam, k) - L(s_pp, k));
+    for (int k = 1; k <= km + 1; k++) on_pe(k, L(s_pp, k) + beta * (L(s_gam, k) - L(s_pp, k)));
   }
 #undef L
 }
@@ -295,20 +305,25 @@ struct RiemSolverC {
       const int i = g.is - 1 + c % w, j = g.js - 1 + c / w;
       const int o = g.iA(i, j);
       ColIn in{delp + o, pt + o, w3 + o, gz + o, 1.};
-      sim_column(km, nA, in, dt, cn, true, true, ws[o], s0 + o, s1 + o, s2 + o, s3 + o);
-      // pef = pe2 + pem (:461-465); gz = hs - sum dz2*grav (:468-476)
+      // pef = pe2 + pem (:461-465); gz = hs - sum dz2*grav (:468-476), formed inside the solver's last two sweeps
       double pem = cn.ptop;
-      pef[o] = cn.ptop;
-      for (int k = 2; k <= km + 1; k++) {
-        pem = pem + delp[(size_t)(k - 2) * nA + o];
-        pef[(size_t)(k - 1) * nA + o] = s1[(size_t)(k - 1) * nA + o] + pem;
-      }
       double zb = hs[o];
-      gz[(size_t)km * nA + o] = zb;
-      for (int k = km; k >= 1; k--) {
-        zb = zb - s3[(size_t)(k - 1) * nA + o] * cn.grav;
-        gz[(size_t)(k - 1) * nA + o] = zb;
-      }
+      sim_column(
+          km, nA, in, dt, cn, true, true, ws[o], s0 + o, s1 + o, s2 + o, s3 + o,
+          [&](int k, double pe2) {
+            if (k == 1) {
+              pef[o] = cn.ptop;
+            } else {
+              pem = pem + delp[(size_t)(k - 2) * nA + o];
+              pef[(size_t)(k - 1) * nA + o] = pe2 + pem;
+            }
+          },
+          [&](int, double) {},
+          [&](int k, double dz2) {
+            if (k == km) gz[(size_t)km * nA + o] = zb;
+            zb = zb - dz2 * cn.grav;
+            gz[(size_t)(k - 1) * nA + o] = zb;
+          });
     }
   }
 };
@@ -331,37 +346,39 @@ struct RiemSolver3 {
       const int i = g.is + c % g.nx, j = g.js + c / g.nx;
       const int o = g.iA(i, j), occ = g.iCC(i, j);
       ColIn in{delp + o, pt + o, w + o, zh + o, 1.};
-      sim_column(km, nA, in, dt, cn, sim1, false, ws[occ], s0 + o, s1 + o, s2 + o, s3 + o);
-      // hydrostatic pressure functions (:132-143), outputs (:191-237)
+      // hydrostatic pressure functions (:132-143) and the outputs (:191-237) are formed inside the solver's last sweeps
       double pem = cn.ptop;
-      pk3[o] = ptk;
-      if (last_call) {
-        peln[(size_t)(j - g.js) * g.nx * (km + 1) + (i - g.is)] = peln1;
-        pk[occ] = ptk;
-        pe[(size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1))] = cn.ptop;
-      }
-      ppe[o] = fp_out ? s1[o] + pem : s1[o];
-      for (int k = 2; k <= km + 1; k++) {
-        pem = pem + delp[(size_t)(k - 2) * nA + o];
-        const double pl = log(pem), pkv = exp(cn.akap * pl);
-        pk3[(size_t)(k - 1) * nA + o] = use_logp ? pl : pkv;
-        if (last_call) {
-          peln[(size_t)(j - g.js) * g.nx * (km + 1) + (size_t)(k - 1) * g.nx + (i - g.is)] = pl;
-          pk[(size_t)(k - 1) * nCC + occ] = pkv;
-          pe[(size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (size_t)(k - 1) * (g.nx + 2) + (i - (g.is - 1))] = pem;
-        }
-        const double p2 = s1[(size_t)(k - 1) * nA + o];
-        ppe[(size_t)(k - 1) * nA + o] = fp_out ? p2 + pem : p2;
-      }
       double zb = zs[o];
-      zh[(size_t)km * nA + o] = zb;
-      for (int k = km; k >= 1; k--) {
-        const double dz = s3[(size_t)(k - 1) * nA + o];
-        w[(size_t)(k - 1) * nA + o] = s2[(size_t)(k - 1) * nA + o];
-        delz[(size_t)(k - 1) * nCC + occ] = dz;
-        zb = zb - dz;
-        zh[(size_t)(k - 1) * nA + o] = zb;
-      }
+      sim_column(
+          km, nA, in, dt, cn, sim1, false, ws[occ], s0 + o, s1 + o, s2 + o, s3 + o,
+          [&](int k, double pe2) {
+            if (k == 1) {
+              pk3[o] = ptk;
+              if (last_call) {
+                peln[(size_t)(j - g.js) * g.nx * (km + 1) + (i - g.is)] = peln1;
+                pk[occ] = ptk;
+                pe[(size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1))] = cn.ptop;
+              }
+              ppe[o] = fp_out ? pe2 + pem : pe2;
+              return;
+            }
+            pem = pem + delp[(size_t)(k - 2) * nA + o];
+            const double pl = log(pem), pkv = exp(cn.akap * pl);
+            pk3[(size_t)(k - 1) * nA + o] = use_logp ? pl : pkv;
+            if (last_call) {
+              peln[(size_t)(j - g.js) * g.nx * (km + 1) + (size_t)(k - 1) * g.nx + (i - g.is)] = pl;
+              pk[(size_t)(k - 1) * nCC + occ] = pkv;
+              pe[(size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (size_t)(k - 1) * (g.nx + 2) + (i - (g.is - 1))] = pem;
+            }
+            ppe[(size_t)(k - 1) * nA + o] = fp_out ? pe2 + pem : pe2;
+          },
+          [&](int k, double w2) { w[(size_t)(k - 1) * nA + o] = w2; },
+          [&](int k, double dz) {
+            if (k == km) zh[(size_t)km * nA + o] = zb;
+            delz[(size_t)(k - 1) * nCC + occ] = dz;
+            zb = zb - dz;
+            zh[(size_t)(k - 1) * nA + o] = zb;
+          });
     }
   }
 };
