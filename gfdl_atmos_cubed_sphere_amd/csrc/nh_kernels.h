@@ -127,6 +127,7 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
 #define L(p, k) (p)[(size_t)((k)-1) * ls]
   // ---- pass A: pe(k), pm2(k); forward elimination for pp (:1297-1326) ----
   double pem_k = cn.ptop, peln_k = log(cn.ptop);
+  double z_top = L(in.zlev, 1);  // zlev(k) of the level being set up: each interface height is loaded once
   auto level = [&](int k, double &dm2, double &dz2, double &pm2, double &pe, double &pem_next, double &peln_next) {
     const double dmr = L(in.delp, k);
     pem_next = pem_k + dmr;
@@ -138,7 +139,9 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
       pm2 = dmr / (peln_next - peln_k);
     }
     dm2 = dmr * rgrav;
-    dz2 = L(in.zlev, k + 1) - L(in.zlev, k);
+    const double z_bot = L(in.zlev, k + 1);
+    dz2 = z_bot - z_top;
+    z_top = z_bot;
     pe = exp(gm2 * log(-dm2 / dz2 * rgas * L(in.pt, k))) - pm2;
   };
   double dm_c, dz_c, pm_c, pe_c, pem_n, peln_n;
@@ -190,39 +193,49 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
     double pem = cn.ptop;                       // pem(k)
     double dz_prev = 0., w_prev = 0., w1_prev = 0., aa_k = 0., wk_k = 0.;
     double dm1 = 0.;
+    // every interface height, pp and w value is loaded once and carried to the next level
+    double z_lo = L(in.zlev, 2);
+    double dz_c2 = z_lo - L(in.zlev, 1);
+    double pp_lo = L(s_pp, 1), w_c = L(in.w, 1);
     FV3_UNROLL4
     for (int k = 1; k <= km; k++) {
       const double dmr = L(in.delp, k), dm2 = dmr * rgrav;
-      const double dz2 = L(in.zlev, k + 1) - L(in.zlev, k);
-      const double w1 = L(in.w, k);
+      const double dz2 = dz_c2;
+      const double w1 = w_c;
+      const double pp_k0 = pp_lo, pp_k1 = L(s_pp, k + 1);
+      pp_lo = pp_k1;
       if (k == 1) dm1 = dm2;
       // aa(k+1), wk(k+1) need level k+1
       double aa_n = 0., wk_n = 0., pem_next = pem + dmr;
       if (k < km) {
-        const double dz_n = L(in.zlev, k + 2) - L(in.zlev, k + 1);
+        const double z_n = L(in.zlev, k + 2);
+        const double dz_n = z_n - z_lo;
+        z_lo = z_n;
+        dz_c2 = dz_n;
+        w_c = L(in.w, k + 1);
         aa_n = t1g * 0.5 * (gm2 + gm2) / (dz2 + dz_n) * pem_next;
         if (!sim1) {
-          wk_n = t2 * aa_n * (w1 - L(in.w, k + 1));
+          wk_n = t2 * aa_n * (w1 - w_c);
           aa_n = aa_n - 0.0 * dm1;  // scale_m = 0 (nh_utils.F90:1467)
         }
       }
       double w2;
       if (k == 1) {
         bet = dm2 - aa_n;
-        w2 = sim1 ? (dm2 * w1 + dt * L(s_pp, 2)) / bet : (dm2 * w1 + dt * L(s_pp, 2) + wk_n) / bet;
+        w2 = sim1 ? (dm2 * w1 + dt * pp_k1) / bet : (dm2 * w1 + dt * pp_k1 + wk_n) / bet;
       } else if (k < km) {
         const double gam = aa_k / bet;
         bet = dm2 - (aa_k + aa_n + aa_k * gam);
         L(s_gam, k) = gam;
-        w2 = sim1 ? (dm2 * w1 + dt * (L(s_pp, k + 1) - L(s_pp, k)) - aa_k * w_prev) / bet
-                  : (dm2 * w1 + dt * (L(s_pp, k + 1) - L(s_pp, k)) + wk_n - wk_k - aa_k * w_prev) / bet;
+        w2 = sim1 ? (dm2 * w1 + dt * (pp_k1 - pp_k0) - aa_k * w_prev) / bet
+                  : (dm2 * w1 + dt * (pp_k1 - pp_k0) + wk_n - wk_k - aa_k * w_prev) / bet;
       } else {
         const double p1 = t1g * gm2 / dz2 * pem_next;  // pem(km+1)
         const double gam = aa_k / bet;
         bet = dm2 - (aa_k + p1 + aa_k * gam);
         L(s_gam, k) = gam;
-        w2 = sim1 ? (dm2 * w1 + dt * (L(s_pp, k + 1) - L(s_pp, k)) - p1 * ws - aa_k * w_prev) / bet
-                  : (dm2 * w1 + dt * (L(s_pp, k + 1) - L(s_pp, k)) - wk_k + p1 * (t2 * w1 - ra * ws) - aa_k * w_prev) / bet;
+        w2 = sim1 ? (dm2 * w1 + dt * (pp_k1 - pp_k0) - p1 * ws - aa_k * w_prev) / bet
+                  : (dm2 * w1 + dt * (pp_k1 - pp_k0) - wk_k + p1 * (t2 * w1 - ra * ws) - aa_k * w_prev) / bet;
       }
       L(s_w, k) = w2;
       w_prev = w2;
@@ -271,14 +284,18 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
   }
   // ---- pass F: new layer thickness (:1382-1392 / :1518-1529); dz2 -> s_pm (pm2 consumed level by level)
   {
-    double p1 = (L(s_pp, km) + 2. * L(s_pp, km + 1)) * r3;
+    double pp_1 = L(s_pp, km), pp_2 = L(s_pp, km + 1), pp_0 = 0.;  // pe2(k+1), pe2(k+2) carried downwards
+    double p1 = (pp_1 + 2. * pp_2) * r3;
     double dm_below = 0.;
     FV3_UNROLL4
     for (int k = km; k >= 1; k--) {
       const double dm2 = L(in.delp, k) * rgrav, pm2 = L(s_pm, k);
       if (k < km) {
+        pp_0 = L(s_pp, k);
         const double g_rat = dm2 / dm_below, bb = 2. * (1. + g_rat);
-        p1 = (L(s_pp, k) + bb * L(s_pp, k + 1) + g_rat * L(s_pp, k + 2)) * r3 - g_rat * p1;
+        p1 = (pp_0 + bb * pp_1 + g_rat * pp_2) * r3 - g_rat * p1;
+        pp_2 = pp_1;
+        pp_1 = pp_0;
       }
       on_dz(k, -dm2 * rgas * L(in.pt, k) * exp((cp2 - 1.) * log(dmax(cn.p_fac * pm2, p1 + pm2))));
       dm_below = dm2;
