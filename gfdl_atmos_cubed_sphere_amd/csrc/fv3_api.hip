@@ -1165,6 +1165,14 @@ extern "C" int fv3_nh_p_grad(fv3_ctx *c, double *u, double *v, const double *pp,
   return 0;
 }
 
+extern "C" int fv3_omga_update(fv3_ctx *c, double rdt, double ptop, const double *pe, const double *delp_before,
+                               double *omga) {
+  if (!c || !c->grid_ready || !pe || !delp_before || !omga) return fail("fv3_omga_update: bad context/arguments");
+  OmgaUpdate kf{c->g, c->g.npz, rdt, ptop, pe, delp_before, omga};
+  RT(launch_c(c, "omga_update", col_grid(c->g.nx * c->g.ny), kf));
+  return 0;
+}
+
 extern "C" int fv3_divg2_ext(fv3_ctx *c, double d_ext, const double *delp, const double *vt, double *divg2) {
   if (!c || !c->grid_ready || !delp || !vt || !divg2) return fail("fv3_divg2_ext: bad context/arguments");
   const Grid &g = c->g;

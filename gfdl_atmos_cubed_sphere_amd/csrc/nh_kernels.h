@@ -957,4 +957,26 @@ struct PtToThetaV {  // fv_dynamics.F90:296-329, :379-399 (use_cond = moist_kapp
   }
 };
 
+struct OmgaUpdate {  // dyn_core.F90:409-421, :1182-1191
+  Grid g;
+  int km;
+  double rdt, ptop;
+  const double *pe, *delp0;
+  double *omga;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int ncol = g.nx * g.ny;
+    const size_t nA = g.nA();
+    FV3_COL_FOR(c, ncol) {
+      const int i = g.is + c % g.nx, j = g.js + c / g.nx;
+      const int o = g.iA(i, j);
+      const size_t peb = (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1));
+      double pem = ptop;
+      for (int k = 1; k <= km; k++) {
+        pem = pem + delp0[(size_t)(k - 1) * nA + o];
+        omga[(size_t)(k - 1) * nA + o] = (pe[peb + (size_t)k * (g.nx + 2)] - pem) * rdt;
+      }
+    }
+  }
+};
+
 }  // namespace fv3

@@ -46,6 +46,7 @@ class DynFlags:
     a_imp: float = 1.0       # > 0.999: SIM1_solver in Riem_Solver3 (BASELINE north_star); reference default 0.75
     p_fac: float = 0.05
     use_logp: bool = False
+    use_old_omega: bool = True
     n_sponge: int = 1
     is_ideal_case: bool = False
     ptop: float = 300.0
@@ -269,6 +270,10 @@ class DynCore:
                           peln1 if fl.use_logp else ptk, gz_scale=fl.grav)    # :1032
             if it != n_split:
                 halo.update([(d["u"], "U"), (d["v"], "V")])                   # :1168-1169 (pack 8)
+            elif fl.use_old_omega:
+                # :1182-1191: omga = (pe - pem)*rdt; pem = p of the delp this substep started from (:409-421), which the
+                # ping-pong left in delp_nxt
+                ctx.omga_update(rdt, fl.ptop, d["pe"], d["delp_nxt"], d["omga"])
         # ---- dissipative heating (:296-308, :1300-1355) ----
         n_con = self.n_con()
         if n_con != 0 and heating:

@@ -17,7 +17,7 @@ module fv3_mi355x_mod
   public :: fv3_halo_field, fv3_halo_message_elems, fv3_halo_pack, fv3_halo_unpack
   public :: fv3_heat_source_accum, fv3_del2_cubed, fv3_apply_heat_source
   public :: fv3_d_sw_interior, fv3_d_sw_rest
-  public :: fv3_divg2_ext, fv3_one_grad_p, fv3_copy_a_to_cc, fv3_pt_to_theta_v
+  public :: fv3_divg2_ext, fv3_one_grad_p, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
 
   type, bind(C) :: fv3_domain
     integer(c_int) :: is, ie, js, je, ng, npx, npy, npz, grid_type
@@ -183,6 +183,11 @@ module fv3_mi355x_mod
       integer(c_int), value :: nfields
       type(fv3_halo_field), intent(in) :: fields(*)
       type(c_ptr), intent(in) :: recvbuf(8)
+    end function
+    integer(c_int) function fv3_omga_update(ctx, rdt, ptop, pe, delp_before, omga) bind(C, name="fv3_omga_update")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, pe, delp_before, omga
+      real(c_double), value :: rdt, ptop
     end function
     integer(c_int) function fv3_pt_to_theta_v(ctx, hydrostatic, zvir, kappa, rdgas, grav, pt, delp, delz, qv, pkz) &
         bind(C, name="fv3_pt_to_theta_v")

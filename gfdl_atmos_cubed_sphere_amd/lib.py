@@ -32,7 +32,7 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
-           "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report",
+           "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
@@ -389,6 +389,11 @@ class Context:
                                                        C.c_int(nq), C.c_int(hord), C.c_int(nord_tr), C.c_double(trdm),
                                                        q.p, q_out.p, dp1.p, dp1_out.p, mfx.p, mfy.p, cx.p, cy.p, xfx.p,
                                                        yfx.p), "fv3_tracer_2d_step")
+
+    def omga_update(self, rdt, ptop, pe, delp_before, omga):
+        """dyn_core.F90:1182-1191: omga = (pe - pem)*rdt on the last substep (local part, see the header)"""
+        self.lib.check(self.lib.dll.fv3_omga_update(self.h, C.c_double(rdt), C.c_double(ptop), pe.p, delp_before.p, omga.p),
+                       "fv3_omga_update")
 
     def pt_to_theta_v(self, hydrostatic, zvir, kappa, rdgas, grav, pt, delp, delz, qv, pkz):
         """fv_dynamics.F90:284-329, :379-399: T -> theta_v before the k_split loop"""

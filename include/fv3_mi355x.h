@@ -222,6 +222,13 @@ int fv3_p_grad_c(fv3_ctx *ctx, double dt2, const double *delpc, const double *pk
 int fv3_nh_p_grad(fv3_ctx *ctx, double *u, double *v, const double *pp, const double *gz, double gz_scale,
                   const double *delp, const double *pk, double dt, double top_value);
 
+/* omega of the last acoustic substep, local part (model/dyn_core.F90:409-421, :1182-1191, use_old_omega):
+ * omga(i,j,k) = (pe(i,k+1,j) - pem(i,k+1,j)) * rdt with pem = ptop + cumulative sum of the delp the substep started
+ * from (pass the pre-d_sw buffer as delp_before).  The advective term adv_pe (:1195, :1529-1630) projects on the unit
+ * vectors en1/en2, which the reference only sets for grid_type < 3 (fv_grid_utils.F90:628-643); for the grid_type = 4
+ * domains built here that term is undefined in the reference and is not added. */
+int fv3_omga_update(fv3_ctx *ctx, double rdt, double ptop, const double *pe, const double *delp_before, double *omga);
+
 /* Hydrostatic pressure gradient.
  * divg2_ext -- model/dyn_core.F90:745-747, :791-797, :828-848: external-mode divergence damping field at the corners,
  *   divg2 = d_ext*da_min_c * sum_k ptc*vt / sum_k ptc with ptc = a2b_ord2(delp BEFORE d_sw) and vt = d_sw's delpc

@@ -71,6 +71,7 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
         O.riem_solver_c(g, npz, dt2, cn, f["phis"], f["omga"], f["ptc"], f["delpc"], f["gz"], f["pkc"], f["ws3"])
         O.p_grad_c(g, npz, dt2, f["delpc"], f["pkc"], f["gz"], f["uc"], f["vc"], False)
         _fill(bd, f["uc"], "V"); _fill(bd, f["vc"], "U")
+        delp_start = f["delp"].copy(order="F")
         ds = dict(delpc=f["vt"], delp=f["delp"], ptc=f["ptc"], pt=f["pt"], u=f["u"], v=f["v"], w=f["w"], uc=f["uc"],
                   vc=f["vc"], ua=f["ua"], va=f["va"], divg_d=f["divgd"], mfx=f["mfx"], mfy=f["mfy"], cx=f["cx"],
                   cy=f["cy"], crx=f["crx"], cry=f["cry"], xfx=f["xfx"], yfx=f["yfx"], heat_source=f["heat_s"],
@@ -93,6 +94,11 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
         O.nh_p_grad(g, npz, f["u"], f["v"], f["pkc"], f["gz"], f["delp"], f["pk3"], dt, peln1 if fl.use_logp else ptk)
         if it != n_split:
             _fill(bd, f["u"], "U"); _fill(bd, f["v"], "V")
+        elif fl.use_old_omega:                                             # dyn_core.F90:409-421, :1182-1191
+            i0, j0 = bd.ng, bd.ng
+            pem = fl.ptop + np.cumsum(delp_start[i0:i0 + nx, j0:j0 + ny, :], axis=2)
+            pe_c = np.transpose(f["pe"][1:-1, 1:, 1:-1], (0, 2, 1))
+            f["omga"][i0:i0 + nx, j0:j0 + ny, :] = (pe_c - pem) * rdt
     # dissipative heating (dyn_core.F90:296-308, :1300-1355)
     if fl.convert_ke or (fl.do_vort_damp and fl.vtdm4 > 1.0e-4):
         n_con = npz
