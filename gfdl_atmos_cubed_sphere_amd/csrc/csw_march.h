@@ -66,6 +66,9 @@ struct CswLevel {
 // cuts the L2 traffic per cell (the kernel is bound by it, not by HBM or VALU) at the price of registers.
 template <int KPW>
 struct CswMarch {
+#ifdef FV3_CSW_TWO_WAVES
+  static constexpr int kTwoWavesPerSimd = 1;
+#endif
   Grid g;
   CswArgs a;
   MarchDims md;

@@ -64,6 +64,9 @@ struct Tp2dField {
 // formed from uc, vc on the fly, used, and stored for the later consumers (crx, xfx, cry, yfx; cx, cy accumulated).
 template <int HORD, bool NH, bool COURANT>
 struct DswTransportFused {
+#ifdef FV3_TRN_TWO_WAVES
+  static constexpr int kTwoWavesPerSimd = 1;
+#endif
   Grid g;
   DswArgs a;
   MarchDims md;
@@ -240,6 +243,8 @@ namespace fv3 {
 
 template <int SWC, int HORD>
 struct DswMomentumFused {
+  // 266 VGPRs natural: squeezing into 256 (8 spilled) buys the second wavefront per SIMD, measured 0.735 -> 0.65 ms
+  static constexpr int kTwoWavesPerSimd = 1;
   Grid g;
   DswArgs a;
   MarchDims md;

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "fv3_common.h"
@@ -121,10 +122,26 @@ __global__ void __launch_bounds__(kNT) wave_kernel(const F f, int nwaves) {
   const int gid = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (kNT / 64) + (int)(threadIdx.x >> 6));
   if (gid < nwaves) f(gid);
 }
+// the same with a register budget of two wavefronts per SIMD (<= 256 VGPRs) for functors that ask for it with
+// `static constexpr int kTwoWavesPerSimd = 1;` -- only worth it when the functor needs a few registers too many
+template <class F>
+__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) wave_kernel_2w(const F f, int nwaves) {
+  const int gid = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (kNT / 64) + (int)(threadIdx.x >> 6));
+  if (gid < nwaves) f(gid);
+}
+template <class F, class = void>
+struct wants_two_waves : std::false_type {};
+template <class F>
+struct wants_two_waves<F, std::enable_if_t<(F::kTwoWavesPerSimd > 0)>> : std::true_type {};
+
 template <class F>
 inline int launch_waves(int nwaves, stream_t s, const F &f) {
   const int wpb = kNT / 64;
-  hipLaunchKernelGGL(wave_kernel<F>, dim3((unsigned)((nwaves + wpb - 1) / wpb)), dim3(kNT), 0, s, f, nwaves);
+  const dim3 grid((unsigned)((nwaves + wpb - 1) / wpb));
+  if constexpr (wants_two_waves<F>::value)
+    hipLaunchKernelGGL(wave_kernel_2w<F>, grid, dim3(kNT), 0, s, f, nwaves);
+  else
+    hipLaunchKernelGGL(wave_kernel<F>, grid, dim3(kNT), 0, s, f, nwaves);
   return (int)hipGetLastError();
 }
 inline int rt_malloc(void **p, size_t n) { return (int)hipMalloc(p, n); }
