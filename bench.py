@@ -178,8 +178,8 @@ def main():
     g = doubly_periodic(bd, nx * px + 1, nx * py + 1, dx_const=26000.0, dy_const=26000.0)
     stream = torch.cuda.current_stream()
     ctx = L.Context(g, npz, stream=stream.cuda_stream)
-    # FV3_BENCH_PACKED=1: exercise the multi-rank pack/unpack kernels on one GPU (self messages) to see their cost
-    halo = HaloExchanger(ctx, px, py, rank, world, packed_single=os.environ.get("FV3_BENCH_PACKED") == "1")
+    # FV3_BENCH_SPLIT=1: exercise the multi-rank flow (start / d_sw interior / finish / d_sw rest) on one GPU to see its cost
+    halo = HaloExchanger(ctx, px, py, rank, world, split_single=os.environ.get("FV3_BENCH_SPLIT") == "1")
 
     st = smooth_state(Bounds(1, nx, 1, nx), npz, noise=0.05)  # same synthetic block on every rank
     d = {k: ctx.from_host(v) for k, v in st.items()}
