@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--npz", type=int, default=127)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--hord", type=int, default=10, help="hord_mt = hord_vt = hord_tm = hord_dp (reference default 10)")
     ap.add_argument("--no-model-step", action="store_true", help="skip the SYPD (whole model step) leg")
     ap.add_argument("--nq", type=int, default=4, help="advected tracers in the SYPD leg")
     return ap.parse_args()
@@ -193,7 +194,7 @@ def main():
     ctx.dsw_levels(default_levels(npz))
     dt = 22.5   # C384 acoustic step: dt_atmos 225 s / k_split 2 / n_split 5
     par = dict(P.DSW_PAR)
-    par.update(dt=dt, hydrostatic=0, use_cond=0)
+    par.update(dt=dt, hydrostatic=0, use_cond=0, hord_mt=a.hord, hord_vt=a.hord, hord_tm=a.hord, hord_dp=a.hord)
 
     def step():
         ctx.c_sw(d["delpc"], d["delp"], d["ptc"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"],
@@ -275,7 +276,7 @@ def main():
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"doubly periodic {nx}x{nx}x{npz} tile per GPU (C384L127-sized), nonhydrostatic, "
-                                  f"c_sw+d_sw pair, hord 10/10/10/10, nord=1, d4_bg=0.16",
+                                  f"c_sw+d_sw pair, hord {a.hord}/{a.hord}/{a.hord}/{a.hord}, nord=1, d4_bg=0.16",
                       "layout": f"{px}x{py}", "halo": "periodic copy" if world == 1 else "RCCL send/recv"},
            "finite": finite, "roofline": roof}
     ctx.close()
