@@ -115,10 +115,32 @@ def run_c_sw_lib(ctx, bd, npz, st, dt2, hydrostatic, nord=1):
     return d
 
 
-def check_c_sw(lib, nx=40, ny=19, npz=3, hydrostatic=False, perturb=True, dt=6.0):
+def degenerate_state(bd, npz, hydrostatic, kind):
+    """states that sit on the branch points of the limiters: "rest" = no wind, constant scalars (every Courant number
+    and slope exactly 0, the flat / tie branches); "tophat" = piecewise-constant fields with jumps (extrema detection,
+    Huynh constraints active nearly everywhere); "checker" = 2-cell oscillations (every cell a local extremum)"""
+    from gfdl_atmos_cubed_sphere_amd.layout import periodic_fill
+    st = smooth_state(bd, npz, hydrostatic=hydrostatic, noise=0.0)
+    for n, a in st.items():
+        stag = {"u": "U", "v": "V"}.get(n, "A")
+        i = np.arange(a.shape[0])[:, None, None]
+        j = np.arange(a.shape[1])[None, :, None]
+        base = {"u": 8.0, "v": -5.0, "delp": 900.0, "pt": 300.0, "w": 0.3}[n]
+        if kind == "rest":
+            a[...] = 0.0 if n in ("u", "v", "w") else base
+        elif kind == "tophat":
+            a[...] = base * (1.0 + 0.25 * (((i // 5) + (j // 4)) % 2))
+        elif kind == "checker":
+            a[...] = base * (1.0 + 0.1 * ((i + j) % 2))
+        for k in range(npz):
+            periodic_fill(bd, a[:, :, k], stag, fill_edge=True)
+    return st
+
+
+def check_c_sw(lib, nx=40, ny=19, npz=3, hydrostatic=False, perturb=True, dt=6.0, state=None):
     bd = Bounds(1, nx, 1, ny)
     g = make_grid(bd, perturb)
-    st = smooth_state(bd, npz, hydrostatic=hydrostatic)
+    st = degenerate_state(bd, npz, hydrostatic, state) if state else smooth_state(bd, npz, hydrostatic=hydrostatic)
     ref = run_c_sw_oracle(g, bd, npz, st, 0.5 * dt, hydrostatic)
     ctx = Context(g, npz, lib=lib)
     worst = 0.0
@@ -141,7 +163,7 @@ DSW_PAR = dict(dt=6.0, hord_tr=8, hord_mt=10, hord_vt=10, hord_tm=10, hord_dp=10
 
 
 def check_d_sw(lib, nx=40, ny=19, npz=4, hydrostatic=False, perturb=True, par_over=None, lev_over=None,
-               flags=None, use_cond=False, phases=False):
+               flags=None, use_cond=False, phases=False, state=None):
     """c_sw (oracle) -> periodic halo of uc, vc, divg_d -> d_sw by oracle and by the library."""
     bd = Bounds(1, nx, 1, ny)
     g = make_grid(bd, perturb)
@@ -151,7 +173,7 @@ def check_d_sw(lib, nx=40, ny=19, npz=4, hydrostatic=False, perturb=True, par_ov
     par.update(par_over or {})
     par["hydrostatic"], par["use_cond"] = int(hydrostatic), int(use_cond)
     dt = par["dt"]
-    st = smooth_state(bd, npz, hydrostatic=hydrostatic)
+    st = degenerate_state(bd, npz, hydrostatic, state) if state else smooth_state(bd, npz, hydrostatic=hydrostatic)
     f = run_c_sw_oracle(g, bd, npz, st, 0.5 * dt, hydrostatic)
     for n, kind in (("uc", "V"), ("vc", "U"), ("divg_d", "B")):
         for k in range(npz):

@@ -229,3 +229,12 @@ def test_march_strip_and_segment_boundaries(emu, nx, ny):
     assert P.check_c_sw(emu, nx=nx, ny=ny, npz=2) <= P.TOL
     assert max(P.check_d_sw(emu, nx=nx, ny=ny, npz=3).values()) <= P.TOL
     assert max(P.check_d_sw(emu, nx=nx, ny=ny, npz=3, hydrostatic=True, phases=True).values()) <= P.TOL
+
+
+@pytest.mark.parametrize("state", ["rest", "tophat", "checker"])
+@pytest.mark.parametrize("hord", [10, 5])
+def test_limiter_branch_point_states(emu, state, hord):
+    """no wind + constant scalars (all Courant numbers / slopes exactly zero), top-hats, 2-cell oscillations"""
+    assert P.check_c_sw(emu, nx=64, ny=40, npz=2, state=state) <= P.TOL
+    over = dict(hord_dp=hord, hord_tm=hord, hord_vt=hord, hord_mt=hord)
+    assert max(P.check_d_sw(emu, nx=64, ny=40, npz=3, state=state, par_over=over).values()) <= P.TOL
