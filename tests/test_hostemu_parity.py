@@ -238,3 +238,36 @@ def test_limiter_branch_point_states(emu, state, hord):
     assert P.check_c_sw(emu, nx=64, ny=40, npz=2, state=state) <= P.TOL
     over = dict(hord_dp=hord, hord_tm=hord, hord_vt=hord, hord_mt=hord)
     assert max(P.check_d_sw(emu, nx=64, ny=40, npz=3, state=state, par_over=over).values()) <= P.TOL
+
+
+def test_error_behaviour_of_the_c_abi(emu):
+    """the reference aborts through mpp_error(FATAL); the C ABI returns a status and a message instead"""
+    import ctypes as C
+    from gfdl_atmos_cubed_sphere_amd import lib as L
+    from gfdl_atmos_cubed_sphere_amd.grid import doubly_periodic
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    bd = Bounds(1, 8, 1, 8)
+    g = doubly_periodic(bd, 9, 9)
+    ctx = L.Context(g, 2, lib=emu)
+    try:
+        a, b = ctx.zeros("A", 2), ctx.zeros("A", 2)
+        with pytest.raises(L.Fv3Error, match="hord"):
+            ctx.fv_tp_2d(a, a, a, 3, a, a, a, a)                       # unsupported scheme
+        par = dict(P.DSW_PAR, hydrostatic=1, use_cond=0)
+        u, v = ctx.zeros("U", 2), ctx.zeros("V", 2)
+        cx, cy = ctx.zeros("CX", 2), ctx.zeros("CY", 2)
+        fx, fy, cc = ctx.zeros("FX", 2), ctx.zeros("FY", 2), ctx.zeros("CC", 2)
+        dv = ctx.zeros("B", 2)
+        args = [par, None, a, a, u, v, None, v, u, a, a, dv, fx, fy, cx, cy, cx, cy, cx, cy, None, b, b, u, v, None, None,
+                cc, cc]
+        with pytest.raises(L.Fv3Error, match="coefficients"):
+            ctx.d_sw(*args)                                            # per-level coefficients not uploaded
+        from test_oracle_properties import default_levels
+        ctx.dsw_levels(default_levels(2))
+        with pytest.raises(L.Fv3Error, match="alias"):
+            ctx.d_sw(*args)                                            # u_out aliases u
+    finally:
+        ctx.close()
+    g.grid_type = 0                                                    # cubed-sphere branches are not built
+    with pytest.raises(L.Fv3Error, match="grid_type"):
+        L.Context(g, 2, lib=emu)
