@@ -64,7 +64,10 @@ struct CswLevel {
 
 // KPW = levels per wavefront: the ~20 metric rows of a step are loaded once and used for KPW levels, which
 // cuts the L2 traffic per cell (the kernel is bound by it, not by HBM or VALU) at the price of registers.
-template <int KPW>
+// GM = geometry mode of the gridstruct (Grid::geom): 0 = every metric row is read; 1 = orthogonal grid (the angle
+// terms cosa_* = 0, sin* = rsin* = 1 are not read: x*1 and x - y*0 are exact); 2 = orthogonal and uniform (the
+// length / area terms are wave-uniform scalars, only fC is read).
+template <int KPW, int GM = 0>
 struct CswMarch {
 #ifdef FV3_CSW_TWO_WAVES
   static constexpr int kTwoWavesPerSimd = 1;
@@ -110,15 +113,23 @@ struct CswMarch {
     auto load_metrics = [&](int t) {
       const int R = t - 2, Q = t - 3;
       CswMetrics in;
-      in.cs = LA(g.cosa_s, R);  in.rs = LA(g.rsin2, R);
-      in.cosau = LV(g.cosa_u, R);  in.rsinu = LV(g.rsin_u, R);  in.dy = LV(g.dy, R);
-      in.sg3 = LA(g.sin_sg + 2 * nAp, R, -1);  in.sg1 = LA(g.sin_sg, R);      // sin_sg(i-1,j,3), sin_sg(i,j,1)
-      in.dx = LU(g.dx, R);
-      in.sg4 = LA(g.sin_sg + 3 * nAp, R - 1);  in.sg2 = LA(g.sin_sg + nAp, R);  // sin_sg(i,j-1,4), sin_sg(i,j,2)
-      in.dxc = LV(g.dxc, R);  in.dyc = LU(g.dyc, R);  in.rac = LB(g.rarea_c, R);  in.fc = LB(g.fC, R);
-      in.ra = LA(g.rarea, Q);
-      in.sinau = LV(g.sina_u, Q);  in.rdxc = LV(g.rdxc, Q);
-      in.cosav = LU(g.cosa_v, Q);  in.sinav = LU(g.sina_v, Q);  in.rdyc = LU(g.rdyc, Q);
+      if constexpr (GM == 0) {
+        in.cs = LA(g.cosa_s, R);  in.rs = LA(g.rsin2, R);
+        in.cosau = LV(g.cosa_u, R);  in.rsinu = LV(g.rsin_u, R);
+        in.sg3 = LA(g.sin_sg + 2 * nAp, R, -1);  in.sg1 = LA(g.sin_sg, R);      // sin_sg(i-1,j,3), sin_sg(i,j,1)
+        in.sg4 = LA(g.sin_sg + 3 * nAp, R - 1);  in.sg2 = LA(g.sin_sg + nAp, R);  // sin_sg(i,j-1,4), sin_sg(i,j,2)
+        in.sinau = LV(g.sina_u, Q);  in.cosav = LU(g.cosa_v, Q);  in.sinav = LU(g.sina_v, Q);
+      }
+      if constexpr (GM <= 1) {
+        in.dy = LV(g.dy, R);  in.dx = LU(g.dx, R);
+        in.dxc = LV(g.dxc, R);  in.dyc = LU(g.dyc, R);  in.rac = LB(g.rarea_c, R);
+        in.ra = LA(g.rarea, Q);  in.rdxc = LV(g.rdxc, Q);  in.rdyc = LU(g.rdyc, Q);
+      } else {
+        in.dy = vd(g.c_dy);  in.dx = vd(g.c_dx);
+        in.dxc = vd(g.c_dxc);  in.dyc = vd(g.c_dyc);  in.rac = vd(g.c_rarea_c);
+        in.ra = vd(g.c_rarea);  in.rdxc = vd(g.c_rdxc);  in.rdyc = vd(g.c_rdyc);
+      }
+      in.fc = LB(g.fC, R);
       return in;
     };
     auto load_fields = [&](int t, int k) {
@@ -162,13 +173,22 @@ struct CswMarch {
         const vd v3p = shl1(S.v3);
         S.vt0 = S.vt1; S.vt1 = S.vt2; S.vt2 = S.vt3;
         S.vt3 = a2 * (shr1(S.v3) + shl1(v3p)) + a1 * (S.v3 + v3p);               // vtmp(t-1), :3104-3108
-        const vd ua = (utmp - S.vt2 * in.cs) * in.rs, va = (S.vt2 - utmp * in.cs) * in.rs;  // :3152-3157
+        vd ua = utmp, va = S.vt2;
+        if constexpr (GM == 0) {
+          ua = (utmp - S.vt2 * in.cs) * in.rs;  va = (S.vt2 - utmp * in.cs) * in.rs;  // :3152-3157
+        }
         const vd um1 = shr1(utmp);
         const vd uc = a2 * (shr1(um1) + shl1(utmp)) + a1 * (um1 + utmp);         // :3197-3199
         const vd vc = a2 * (S.vt0 + S.vt3) + a1 * (S.vt1 + S.vt2);               // :3337-3339
-        vd ut = (uc - S.v2 * in.cosau) * in.rsinu;                                // :3200
-        ut = vsel(ut > 0., dt2 * ut * in.dy * in.sg3, dt2 * ut * in.dy * in.sg1);  // :159-167
-        const vd vt = vsel(vc > 0., dt2 * vc * in.dx * in.sg4, dt2 * vc * in.dx * in.sg2);  // :168-176 (vt = vc, :3340)
+        vd ut = uc, vt = vc;
+        if constexpr (GM == 0) {
+          ut = (uc - S.v2 * in.cosau) * in.rsinu;                                   // :3200
+          ut = vsel(ut > 0., dt2 * ut * in.dy * in.sg3, dt2 * ut * in.dy * in.sg1);  // :159-167
+          vt = vsel(vc > 0., dt2 * vc * in.dx * in.sg4, dt2 * vc * in.dx * in.sg2);  // :168-176 (vt = vc, :3340)
+        } else {
+          ut = dt2 * ut * in.dy;
+          vt = dt2 * vc * in.dx;
+        }
         const vd ucdx = uc * in.dxc;
         const vd vcdy = vc * in.dyc;
         const vd vort = in.fc + in.rac * (S.ucdx_p - ucdx - shr1(vcdy) + vcdy);  // :372-403
@@ -205,7 +225,8 @@ struct CswMarch {
             // uc: interpolated value, advanced on [is, ie+1] x [js, je] (:414-447)
             vd ucv = S.uc_p;
             if (Q >= js && Q <= je) {
-              const vd fy1 = dt2 * (S.v1 - ucv * cosau_p) / in.sinau;
+              vd fy1 = dt2 * S.v1;
+              if constexpr (GM == 0) fy1 = dt2 * (S.v1 - ucv * cosau_p) / in.sinau;
               const vd fy = vsel(fy1 > 0., S.vort_p, vort);
               ucv = vsel(m_uc, ucv + fy1 * fy + in.rdxc * (shr1(ke) - ke), ucv);
             }
@@ -214,24 +235,28 @@ struct CswMarch {
           // vc: interpolated value, advanced on [is, ie] x [js, je+1] (:452-486)
           vd vcv = S.vc_p;
           if (Q >= js && Q <= je + 1) {
-            const vd fx1 = dt2 * (S.u0 - vcv * in.cosav) / in.sinav;
+            vd fx1 = dt2 * S.u0;
+            if constexpr (GM == 0) fx1 = dt2 * (S.u0 - vcv * in.cosav) / in.sinav;
             const vd fx = vsel(fx1 > 0., S.vort_p, shl1(S.vort_p));
             vcv = vsel(m_vc, vcv - fx1 * fx + in.rdyc * (S.ke_p - ke), vcv);
           }
           vstore(a.vc + oU, (long)g.iU(ilo, Q), vcv, l0, l1);
         }
         // divergence at the corners of row Q (:1781-1796); v0 = v(Q-1), v1 = v(Q), u0 = u(Q)
-        const vd vdxc = S.v1 * dxc_p;
+        const vd dxc_q = GM == 2 ? vd(g.c_dxc) : dxc_p, dyc_q = GM == 2 ? vd(g.c_dyc) : dyc_p;
+        const vd rac_q = GM == 2 ? vd(g.c_rarea_c) : rac_p;
+        const vd vdxc = S.v1 * dxc_q;
         if (live[m] && a.nord > 0 && Q >= jA && Q <= jB) {
-          const vd uf = S.u0 * dyc_p;
-          vstore(a.divg_d + oB, (long)g.iB(ilo, Q), rac_p * (S.vdxc_p - vdxc + shr1(uf) - uf), l0, l2);
+          const vd uf = S.u0 * dyc_q;
+          vstore(a.divg_d + oB, (long)g.iB(ilo, Q), rac_q * (S.vdxc_p - vdxc + shr1(uf) - uf), l0, l2);
         }
         // ---- rotate the row state ------------------------------------------------------------------------------------
         S.ua_p = ua; S.va_p = va; S.uc_p = uc; S.vc_p = vc; S.ut_p = ut; S.vt_p = vt;
         S.ucdx_p = ucdx; S.vort_p = vort; S.ke_p = ke; S.vdxc_p = vdxc;
         S.fy1_p = fy1_n; S.fyp_p = fyp_n; S.fyw_p = fyw_n;
       }
-      cosau_p = in.cosau; dxc_p = in.dxc; dyc_p = in.dyc; rac_p = in.rac;
+      if constexpr (GM == 0) cosau_p = in.cosau;
+      if constexpr (GM <= 1) { dxc_p = in.dxc; dyc_p = in.dyc; rac_p = in.rac; }
     }
   }
 };

@@ -62,11 +62,13 @@ struct Tp2dField {
 
 // COURANT: the kernel also does DswCourant's work (sw_core.F90:850-902, :923-936): Courant numbers / area fluxes are
 // formed from uc, vc on the fly, used, and stored for the later consumers (crx, xfx, cry, yfx; cx, cy accumulated).
-template <int HORD, bool NH, bool COURANT>
+// GM: geometry mode (Grid::geom); 2 = orthogonal and uniform: the metric terms are wave-uniform scalars and the
+// sin_sg factors (= 1) drop out -- x*1 is exact, so the results are the ones of the general kernel
+template <int HORD, bool NH, bool COURANT, int GM = 0>
 struct DswTransportFused {
-#ifdef FV3_TRN_TWO_WAVES
-  static constexpr int kTwoWavesPerSimd = 1;
-#endif
+  static constexpr bool UNI = (GM == 2);
+  // 330 registers with the metric rows, 272 without: one wavefront per SIMD either way (squeezing the latter into the
+  // 256 of two wavefronts costs 14 spills, gains nothing and leaves no room for the sponge-level kernels of the side stream)
   Grid g;
   DswArgs a;
   MarchDims md;
@@ -110,25 +112,27 @@ struct DswTransportFused {
       in.dp = vload(delp, iA, s.A);
       in.pt = vload(pt, iA, s.A);
       in.w = NH ? vload(w, iA, s.A) : vd(0.);
-      in.ar = vload(g.area, iA, s.A);
+      in.ar = UNI ? vd(g.c_area) : vload(g.area, iA, s.A);
       const int jf = (r - 2 < jA) ? jA : r - 2, j = (r - 3 < jA) ? jA : r - 3;
       const long iCY = (long)g.iCY(ilo, jf);
       if (COURANT) {
         const long nAp = (long)g.nA();
         in.cx = vload(a.uc + (size_t)k * g.nV(), (long)g.iV(ilo, r), s.A);
-        in.rdxa = vload(g.rdxa, iA, s.A);
-        in.dyr = vload(g.dy, (long)g.iV(ilo, r), s.A);
-        in.sg3 = vload(g.sin_sg + 2 * nAp, iA, s.A);
-        in.sg1 = vload(g.sin_sg, iA, s.A);
         in.cxa = vload(a.cx + oCX, iCX, s.F);
         const long iAf = (long)g.iA(ilo, jf), iAm = (long)g.iA(ilo, jf - 1), iUf = (long)g.iU(ilo, jf);
         in.cy = vload(a.vc + (size_t)k * g.nU(), iUf, s.A);
-        in.rdya0 = vload(g.rdya, iAm, s.A);
-        in.rdya1 = vload(g.rdya, iAf, s.A);
-        in.dxr = vload(g.dx, iUf, s.A);
-        in.sg4 = vload(g.sin_sg + 3 * nAp, iAm, s.A);
-        in.sg2 = vload(g.sin_sg + nAp, iAf, s.A);
         in.cya = vload(a.cy + oCY, iCY, s.A);
+        if constexpr (!UNI) {
+          in.rdxa = vload(g.rdxa, iA, s.A);
+          in.dyr = vload(g.dy, (long)g.iV(ilo, r), s.A);
+          in.sg3 = vload(g.sin_sg + 2 * nAp, iA, s.A);
+          in.sg1 = vload(g.sin_sg, iA, s.A);
+          in.rdya0 = vload(g.rdya, iAm, s.A);
+          in.rdya1 = vload(g.rdya, iAf, s.A);
+          in.dxr = vload(g.dx, iUf, s.A);
+          in.sg4 = vload(g.sin_sg + 3 * nAp, iAm, s.A);
+          in.sg2 = vload(g.sin_sg + nAp, iAf, s.A);
+        }
       } else {
         in.cx = vload(crx, iCX, s.F);
         in.xf = vload(xfx, iCX, s.F);
@@ -138,7 +142,7 @@ struct DswTransportFused {
       }
       in.mx = vload(mfx, (long)g.iFX(ilo, j), Fx);
       in.my0 = vload(mfy, (long)g.iFY(ilo, j), s.C);
-      in.ra = vload(g.rarea, (long)g.iA(ilo, j), s.C);
+      in.ra = UNI ? vd(g.c_rarea) : vload(g.rarea, (long)g.iA(ilo, j), s.C);
       return in;
     };
 
@@ -152,7 +156,7 @@ struct DswTransportFused {
     In nxt = load_in(jA - 3);
     for (int r = jA - 3; r <= rlast; r++) {
       const In in = nxt;
-      nxt = load_in(r < rlast ? r + 1 : rlast);
+      nxt = load_in(r < rlast ? r + 1 : rlast);  // (loading two to four rows ahead was measured: no gain)
       const int j = r - 3;
       const bool have_face = r - 2 >= jA, have_row = j >= jA;
       Tp2dShared sh;
@@ -161,25 +165,35 @@ struct DswTransportFused {
         // x faces of row r (sw_core.F90:865, :882-888, :923-927)
         const vd x = dt * in.cx;
         const vb xpos = x > 0.;
-        sh.cx = vsel(xpos, x * shr1(in.rdxa), x * in.rdxa);
-        sh.xf = vsel(xpos, in.dyr * x * shr1(in.sg3), in.dyr * x * in.sg1);
+        if constexpr (UNI) {
+          sh.cx = x * g.c_rdxa;
+          sh.xf = g.c_dy * x;
+        } else {
+          sh.cx = vsel(xpos, x * shr1(in.rdxa), x * in.rdxa);
+          sh.xf = vsel(xpos, in.dyr * x * shr1(in.sg3), in.dyr * x * in.sg1);
+        }
         if (r >= rowA && r <= rowB) {
           const long iCX = (long)g.iCX(ilo, r);
-          vstore(crx, iCX, sh.cx, s.lC0, lFx1);
-          vstore(xfx, iCX, sh.xf, s.lC0, lFx1);
-          vstore(a.cx + oCX, iCX, in.cxa + sh.cx, s.lC0, lFx1);
+          vstore_nt(crx, iCX, sh.cx, s.lC0, lFx1);
+          vstore_nt(xfx, iCX, sh.xf, s.lC0, lFx1);
+          vstore_nt(a.cx + oCX, iCX, in.cxa + sh.cx, s.lC0, lFx1);
         }
         // y faces of row r-2 (:894-900, :933-936)
         const vd y = dt * in.cy;
         const vb ypos = y > 0.;
-        sh.cy = vsel(ypos, y * in.rdya0, y * in.rdya1);
-        sh.yf = vsel(ypos, in.dxr * y * in.sg4, in.dxr * y * in.sg2);
+        if constexpr (UNI) {
+          sh.cy = y * g.c_rdya;
+          sh.yf = g.c_dx * y;
+        } else {
+          sh.cy = vsel(ypos, y * in.rdya0, y * in.rdya1);
+          sh.yf = vsel(ypos, in.dxr * y * in.sg4, in.dxr * y * in.sg2);
+        }
         const int jf = r - 2;
         if (jf >= jA && (jf <= jB || (seg_last && jf == g.je + 1))) {
           const long iCY = (long)g.iCY(ilo, jf);
-          vstore(cry, iCY, sh.cy, lY0, lY1);
-          vstore(yfx, iCY, sh.yf, lY0, lY1);
-          vstore(a.cy + oCY, iCY, in.cya + sh.cy, lY0, lY1);
+          vstore_nt(cry, iCY, sh.cy, lY0, lY1);
+          vstore_nt(yfx, iCY, sh.yf, lY0, lY1);
+          vstore_nt(a.cy + oCY, iCY, in.cya + sh.cy, lY0, lY1);
         }
         xfj = xf_3;
         xf_3 = xf_2; xf_2 = xf_1; xf_1 = sh.xf;
@@ -189,9 +203,9 @@ struct DswTransportFused {
       }
       sh.ar = in.ar;
       sh.rax = in.ar + sh.xf - shl1(sh.xf);
-      sh.arj = ar_3; sh.cxj = cx_3;
-      sh.ray = ar_3 + yf_prev - sh.yf;
-      ar_3 = ar_2; ar_2 = ar_1; ar_1 = in.ar;
+      sh.arj = UNI ? in.ar : ar_3; sh.cxj = cx_3;
+      sh.ray = sh.arj + yf_prev - sh.yf;
+      if constexpr (!UNI) { ar_3 = ar_2; ar_2 = ar_1; ar_1 = in.ar; }
       cx_3 = cx_2; cx_2 = cx_1; cx_1 = sh.cx;
       vd fxd, fyd0, fyd1, fxw, fyw0, fyw1, fxp, fyp0, fyp1;
       fd.step(in.dp, sh, have_face, have_row, fxd, fyd0, fyd1);
@@ -204,26 +218,26 @@ struct DswTransportFused {
           const vd fxm = fxd * xfj;  // tp_core.F90:217-221
           const vd fym0 = fym_prev, fym1 = fym;
           const long iFX = (long)g.iFX(ilo, j), iFY0 = (long)g.iFY(ilo, j), iA = (long)g.iA(ilo, j);
-          vstore(mfx, iFX, in.mx + fxm, s.lC0, lFx1);  // sw_core.F90:928-940
-          vstore(mfy, iFY0, in.my0 + fym0, s.lC0, s.lC1);
+          vstore_nt(mfx, iFX, in.mx + fxm, s.lC0, lFx1);  // sw_core.F90:928-940
+          vstore_nt(mfy, iFY0, in.my0 + fym0, s.lC0, s.lC1);
           if (j == g.je) {
             const long iFY1 = (long)g.iFY(ilo, j + 1);
-            vstore(mfy, iFY1, vload(mfy, iFY1, s.C) + fym1, s.lC0, s.lC1);
+            vstore_nt(mfy, iFY1, vload(mfy, iFY1, s.C) + fym1, s.lC0, s.lC1);
           }
           const vd dp = fd.ya.row_m3();
           const vd dpn = dp + (fxm - shl1(fxm) + fym0 - fym1) * in.ra;
-          vstore(a.delp_out + oA, iA, dpn, s.lC0, s.lC1);
+          vstore_nt(a.delp_out + oA, iA, dpn, s.lC0, s.lC1);
           {  // pt (sw_core.F90:1053-1066)
             const vd gx = fxp * fxm, gy0 = fyp0 * fym0, gy1 = fyp1 * fym1;
-            vstore(a.pt_out + oA, iA, (fp.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra) / dpn, s.lC0, s.lC1);
+            vstore_nt(a.pt_out + oA, iA, (fp.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra) / dpn, s.lC0, s.lC1);
           }
           if (NH) {  // w (:985-989, :1262-1274)
             const vd gx = fxw * fxm, gy0 = fyw0 * fym0, gy1 = fyw1 * fym1;
-            vstore(a.w_out + oA, iA, (fw.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra) / dpn, s.lC0, s.lC1);
+            vstore_nt(a.w_out + oA, iA, (fw.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra) / dpn, s.lC0, s.lC1);
           }
           const long iCC = (long)g.iCC(ilo, j);  // :943-948
-          vstore(a.heat_s + oCC, iCC, vd(0.), s.lC0, s.lC1);
-          vstore(a.diss_e + oCC, iCC, vd(0.), s.lC0, s.lC1);
+          vstore_nt(a.heat_s + oCC, iCC, vd(0.), s.lC0, s.lC1);
+          vstore_nt(a.diss_e + oCC, iCC, vd(0.), s.lC0, s.lC1);
         }
         fym_prev = fym;
       }
@@ -241,8 +255,9 @@ struct DswTransportFused {
 // u, v, uc, vc, divg_d, crx, xfx, cry, yfx in; u, v, delpc out = 96 B per cell-update (was 136).
 namespace fv3 {
 
-template <int SWC, int HORD>
+template <int SWC, int HORD, int GM = 0>
 struct DswMomentumFused {
+  static constexpr bool UNI = (GM == 2);  // orthogonal + uniform metrics: scalars instead of metric rows
   // 266 VGPRs natural: squeezing into 256 (8 spilled) buys the second wavefront per SIMD, measured 0.735 -> 0.65 ms
   static constexpr int kTwoWavesPerSimd = 1;
   Grid g;
@@ -280,12 +295,19 @@ struct DswMomentumFused {
     auto load_in = [&](int r) {
       In in;
       const long oU1 = (long)g.iU(ilo, r + 1), oV = (long)g.iV(ilo, r), oA = (long)g.iA(ilo, r);
-      in.u1 = vload(u, oU1, s.A);   in.dx1 = vload(g.dx, oU1, s.A);
-      in.v0 = vload(v, oV, s.A);    in.dy0 = vload(g.dy, oV, s.A);
-      in.v1 = vload(v, oV + 1, s.A);  in.dy1 = vload(g.dy, oV + 1, s.A);  // V kind has the extra column ied+1
-      in.ra = vload(g.rarea, oA, s.A);
+      in.u1 = vload(u, oU1, s.A);
+      in.v0 = vload(v, oV, s.A);
+      in.v1 = vload(v, oV + 1, s.A);  // V kind has the extra column ied+1
       in.f0 = vload(g.f0, oA, s.A);
-      in.ar = vload(g.area, oA, s.A);
+      if constexpr (UNI) {
+        in.dx1 = vd(g.c_dx);  in.dy0 = in.dy1 = vd(g.c_dy);
+        in.ra = vd(g.c_rarea);  in.ar = vd(g.c_area);
+      } else {
+        in.dx1 = vload(g.dx, oU1, s.A);
+        in.dy0 = vload(g.dy, oV, s.A);  in.dy1 = vload(g.dy, oV + 1, s.A);
+        in.ra = vload(g.rarea, oA, s.A);
+        in.ar = vload(g.area, oA, s.A);
+      }
       const long oCX = (long)g.iCX(ilo, r);
       in.cx = vload(crx, oCX, s.F);
       in.xf = vload(xfx, oCX, s.F);
@@ -300,35 +322,44 @@ struct DswMomentumFused {
       in.vc = vload(vc, oUc, s.A);
       in.uc = vload(uc, oVc, s.A);
       in.ukc = vload(u, oUc, s.A);
-      in.rdy = vload(g.rdy, oVc, s.A);
-      in.rdx = vload(g.rdx, oUc, s.A);
       in.dv = vload(dv, (long)g.iB(ilo, jc + 1), s.A);
-      in.dgu = vload(g.divg_u, oUc, s.A);
-      in.dgv = vload(g.divg_v, oVc, s.A);
-      in.rac = vload(g.rarea_c, oBc, s.A);
+      if constexpr (UNI) {
+        in.rdy = vd(g.c_rdy);  in.rdx = vd(g.c_rdx);
+        in.dgu = vd(g.c_divg_u);  in.dgv = vd(g.c_divg_v);  in.rac = vd(g.c_rarea_c);
+      } else {
+        in.rdy = vload(g.rdy, oVc, s.A);
+        in.rdx = vload(g.rdx, oUc, s.A);
+        in.dgu = vload(g.divg_u, oUc, s.A);
+        in.dgv = vload(g.divg_v, oVc, s.A);
+        in.rac = vload(g.rarea_c, oBc, s.A);
+      }
       return in;
     };
 
-    Tp2dState<HORD> st;
+    Tp2dState<HORD, UNI> st;
     st.init();
     PpmYsw<SWC> yv;
     yv.init();
     vd vtdx_n(0.);                                  // u(r)*dx(r): the "vt1" of the previous step
-    vd vtdx_1(0.), vtdx_2(0.), vtdx_3(0.);          // u*dx of rows r-1, r-2, r-3
-    vd utdy_1(0.), utdy_2(0.), utdy_3(0.);          // v*dy of rows r-1, r-2, r-3
-    vd xf_1(0.), xf_2(0.), xf_3(0.);                // xfx of rows r-1 .. r-3
     vd uc_p(0.), rdy_p(0.), dgv_p(0.), d_m(0.), d_0(0.);  // corner row jc-1 carries; divg_d(jc-1), divg_d(jc)
     vd ke_p(0.), yf_p(0.);
     {  // u(jA-3)*dx(jA-3) and divg_d(jA-1) for the first steps
       const long oU = (long)g.iU(ilo, jA - 3);
-      vtdx_n = vload(u, oU, s.A) * vload(g.dx, oU, s.A);
+      vtdx_n = vload(u, oU, s.A) * (UNI ? vd(g.c_dx) : vload(g.dx, oU, s.A));
       d_0 = vload(dv, (long)g.iB(ilo, jA - 1), s.A);
     }
     In nxt = load_in(jA - 3);
     for (int r = jA - 3; r <= rlast; r++) {
       const In in = nxt;
-      nxt = load_in(r < rlast ? r + 1 : rlast);
       const int j = r - 3, jc = r - 2;
+      // u, dx, v, dy, xfx of row j for the wind update at the end of this step: re-read (L1/L2 hits, issued first so
+      // they are back long before they are used) rather than carried in registers for three steps
+      const int jw = j >= jA ? j : jA;
+      const long oUj = (long)g.iU(ilo, jw), oVj = (long)g.iV(ilo, jw);
+      const vd u_j = vload(u, oUj, s.A), dx_j = UNI ? vd(g.c_dx) : vload(g.dx, oUj, s.A);
+      const vd v_j = vload(v, oVj, s.A), dy_j = UNI ? vd(g.c_dy) : vload(g.dy, oVj, s.A);
+      const vd xf_j = vload(xfx, (long)g.iCX(ilo, jw), s.F);
+      nxt = load_in(r < rlast ? r + 1 : rlast);
       // ---- absolute vorticity of row r (sw_core.F90:1231-1247, :1476-1495) -> fv_tp_2d march ---------------------------
       const vd vt0 = vtdx_n, vt1 = in.u1 * in.dx1, ut0 = in.v0 * in.dy0, ut1 = in.v1 * in.dy1;
       MarchIn mi;
@@ -341,13 +372,13 @@ struct DswMomentumFused {
       vd ke(0.);
       if (jc >= jA) {
         const vd vb = dt5 * (shr1(in.vc) + in.vc);                         // :1129
-        const vd ub = yv.face(vb, rdy_p, in.rdy);                          // ytp_v :1134
+        const vd ub = yv.face(vb, UNI ? in.rdy : rdy_p, in.rdy);           // ytp_v :1134
         const vd kev = vb * ub;                                            // :1139
         const vd ub2 = dt5 * (uc_p + in.uc);                               // :1186
         const vd vb2 = ppm_faces_x_sw<SWC>(in.ukc, ub2, in.rdx);           // xtp_u :1191
         ke = 0.5 * (kev + ub2 * vb2);                                      // :1196
         const vd vc2 = (shl1(d_0) - d_0) * in.dgu;                         // :1392-1396
-        const vd uc2m = (d_0 - d_m) * dgv_p;                               // :1399-1403
+        const vd uc2m = (d_0 - d_m) * (UNI ? in.dgv : dgv_p);              // :1399-1403
         const vd uc2 = (in.dv - d_0) * in.dgv;
         vd lap = uc2m - uc2 + shr1(vc2) - vc2;                             // :1406-1424
         if (!g.stretched_grid) lap = lap * in.rac;
@@ -358,17 +389,20 @@ struct DswMomentumFused {
       // ---- D-grid wind update of row j (:1500-1509) ------------------------------------------------------------------------------
       if (j >= jA) {
         const vd ke0 = ke_p, ke1 = ke;
-        vstore(uo, (long)g.iU(ilo, j), vtdx_3 + ke0 - shl1(ke0) + fyv0 * yf_p, s.lC0, s.lC1);
-        vstore(vo, (long)g.iV(ilo, j), utdy_3 + ke0 - ke1 - fxv * xf_3, s.lC0, lFx1);
-        if (j == g.je)  // the north edge row of u
-          vstore(uo, (long)g.iU(ilo, j + 1), vtdx_2 + ke1 - shl1(ke1) + fyv1 * in.yf, s.lC0, s.lC1);
+        const vd vtdx_j = u_j * dx_j, utdy_j = v_j * dy_j;
+        vstore(uo, oUj, vtdx_j + ke0 - shl1(ke0) + fyv0 * yf_p, s.lC0, s.lC1);
+        vstore(vo, oVj, utdy_j + ke0 - ke1 - fxv * xf_j, s.lC0, lFx1);
+        if (j == g.je) {  // the north edge row of u
+          const long oU1 = (long)g.iU(ilo, j + 1);
+          const vd dx_n = UNI ? vd(g.c_dx) : vload(g.dx, oU1, s.A);
+          vstore(uo, oU1, vload(u, oU1, s.A) * dx_n + ke1 - shl1(ke1) + fyv1 * in.yf, s.lC0, s.lC1);
+        }
       }
       // ---- rotate ----------------------------------------------------------------------------------------------------------------------
-      vtdx_3 = vtdx_2; vtdx_2 = vtdx_1; vtdx_1 = vt0; vtdx_n = vt1;
-      utdy_3 = utdy_2; utdy_2 = utdy_1; utdy_1 = ut0;
-      xf_3 = xf_2; xf_2 = xf_1; xf_1 = in.xf;
+      vtdx_n = vt1;
       if (r >= jA + 1) {  // the corner row loaded at this step was a real one (jA-1 or later)
-        uc_p = in.uc; rdy_p = in.rdy; dgv_p = in.dgv;
+        uc_p = in.uc;
+        if constexpr (!UNI) { rdy_p = in.rdy; dgv_p = in.dgv; }
         d_m = d_0; d_0 = in.dv;
       }
       ke_p = ke;

@@ -3,6 +3,7 @@
 // also compiled by g++ -DFV3_HOST_EMU under tests/hostemu (logic-test harness only).
 #include "../../include/fv3_mi355x.h"
 
+#include <algorithm>
 #include <cstdarg>
 #include <new>
 #include <type_traits>
@@ -72,8 +73,8 @@ struct fv3_ctx {
   double *ke_scr;        // B kind, npz levels: KE + damping term at the corners
   double *mflux[2];      // mass-flux scratch of the marching transports: FX kind, FY kind (npz levels)
   int march_tj;          // rows per wavefront segment of the marching kernels
-  int march_tj_csw, march_tj_ke, march_tj_fused;
-  int csw_kpw;           // levels per wavefront in CswMarch (1 or 2; FV3_MI355X_CSW_KPW)
+  int march_tj_csw, march_tj_ke, march_tj_fused, march_tj_mom;
+  int csw_kpw;           // levels per wavefront in CswMarch (1 .. 4; FV3_MI355X_CSW_KPW)
   int use_fused;         // 1: delp + w + pt in one marching kernel when the schemes allow (FV3_MI355X_FUSED=0: off)
   int use_march;         // 0: LDS-tile kernels only (FV3_MI355X_MARCH=0)
   bool prof_on;
@@ -216,13 +217,16 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     c->march_tj = e ? std::atoi(e) : 48;
     if (c->march_tj < 1) c->march_tj = 48;
     e = std::getenv("FV3_MI355X_CSW_KPW");
-    c->csw_kpw = e ? std::atoi(e) : 2;
-    if (c->csw_kpw < 1 || c->csw_kpw > 3) c->csw_kpw = 2;
+    c->csw_kpw = e ? std::atoi(e) : 0;   // 0 = by geometry mode (fv3_c_sw)
+    if (c->csw_kpw < 0 || c->csw_kpw > 4) c->csw_kpw = 0;
     e = std::getenv("FV3_MI355X_FUSED");
     c->use_fused = e ? std::atoi(e) : 1;
     e = std::getenv("FV3_MI355X_MARCH_TJ_FUSED");
-    c->march_tj_fused = e ? std::atoi(e) : 48;
-    if (c->march_tj_fused < 1) c->march_tj_fused = 48;
+    c->march_tj_fused = e ? std::atoi(e) : 55;
+    if (c->march_tj_fused < 1) c->march_tj_fused = 55;
+    e = std::getenv("FV3_MI355X_MARCH_TJ_MOM");
+    c->march_tj_mom = e ? std::atoi(e) : c->march_tj_fused;
+    if (c->march_tj_mom < 1) c->march_tj_mom = c->march_tj_fused;
     e = std::getenv("FV3_MI355X_MARCH_TJ_KE");
     c->march_tj_ke = e ? std::atoi(e) : 48;
     if (c->march_tj_ke < 1) c->march_tj_ke = 48;
@@ -332,10 +336,37 @@ extern "C" int fv3_grid_upload(fv3_ctx *c, const fv3_grid_host *h) {
   }
   g.da_min = h->da_min;
   g.da_min_c = h->da_min_c;
+  {  // geometry mode from the arrays themselves (Grid::geom); FV3_MI355X_GEOM caps it (0 = always the general kernels)
+    auto all_eq = [](const double *p, size_t n, double v) {
+      for (size_t i = 0; i < n; i++)
+        if (p[i] != v) return false;
+      return true;
+    };
+    bool ortho = all_eq(h->cosa_s, nA, 0.) && all_eq(h->rsin2, nA, 1.) && all_eq(h->cosa_u, nV, 0.) &&
+                 all_eq(h->sina_u, nV, 1.) && all_eq(h->rsin_u, nV, 1.) && all_eq(h->cosa_v, nU, 0.) &&
+                 all_eq(h->sina_v, nU, 1.) && all_eq(h->rsin_v, nU, 1.) && all_eq(h->sin_sg, 4 * nA, 1.);
+    struct Uni { const double *src; size_t n; double *dst; };
+    const Uni uni[] = {
+        {h->area, nA, &g.c_area}, {h->rarea, nA, &g.c_rarea}, {h->dxa, nA, &g.c_dxa}, {h->dya, nA, &g.c_dya},
+        {h->rdxa, nA, &g.c_rdxa}, {h->rdya, nA, &g.c_rdya}, {h->dx, nU, &g.c_dx}, {h->rdx, nU, &g.c_rdx},
+        {h->dyc, nU, &g.c_dyc}, {h->rdyc, nU, &g.c_rdyc}, {h->dy, nV, &g.c_dy}, {h->rdy, nV, &g.c_rdy},
+        {h->dxc, nV, &g.c_dxc}, {h->rdxc, nV, &g.c_rdxc}, {h->divg_u, nU, &g.c_divg_u}, {h->divg_v, nV, &g.c_divg_v},
+        {h->del6_u, nU, &g.c_del6_u}, {h->del6_v, nV, &g.c_del6_v}, {h->rarea_c, nB, &g.c_rarea_c},
+    };
+    bool uniform = ortho;
+    for (const Uni &u : uni) {
+      *u.dst = u.src[0];
+      uniform = uniform && all_eq(u.src, u.n, u.src[0]);
+    }
+    g.geom = uniform ? 2 : (ortho ? 1 : 0);
+    if (const char *e = std::getenv("FV3_MI355X_GEOM")) g.geom = std::min(g.geom, std::max(0, std::atoi(e)));
+  }
   RT(rt_sync(c->stream));  // host buffers may go away after the call returns
   c->grid_ready = true;
   return 0;
 }
+
+extern "C" int fv3_grid_geom(const fv3_ctx *c) { return (c && c->grid_ready) ? c->g.geom : -1; }
 
 extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
   if (!c || !lv) return fail("fv3_dsw_levels_upload: null argument");
@@ -497,6 +528,16 @@ extern "C" int fv3_fv_tp_2d(fv3_ctx *c, int nk, const double *q, const double *c
   return 0;
 }
 
+// geometry mode (Grid::geom) as a compile-time constant
+template <class F>
+static int dispatch_geom(int geom, F &&f) {
+  switch (geom) {
+    case 2: return f(std::integral_constant<int, 2>{});
+    case 1: return f(std::integral_constant<int, 1>{});
+    default: return f(std::integral_constant<int, 0>{});
+  }
+}
+
 extern "C" int fv3_c_sw(fv3_ctx *c, double *delpc, const double *delp, double *ptc, const double *pt,
                         const double *u, const double *v, const double *w, double *uc, double *vc, double *ua,
                         double *va, double *wc, double *ut, double *vt, double *divg_d, int nord, double dt2,
@@ -507,17 +548,18 @@ extern "C" int fv3_c_sw(fv3_ctx *c, double *delpc, const double *delp, double *p
   if (c->use_march) {
     const CswArgs ca{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2};
     MarchDims md = make_csw_dims(c->g, c->march_tj_csw);
-    const int kpw = c->csw_kpw;
+    // uniform metrics: nothing to share between levels, one level per wavefront at four wavefronts per SIMD is faster
+    const int kpw = c->csw_kpw ? c->csw_kpw : (c->g.geom == 2 ? 1 : 2);
     const int nkg = (c->g.npz + kpw - 1) / kpw;
     const int nw = md.nwaves(nkg);
-    if (kpw == 3) {
-      RT(launch_w(c, "c_sw", nw, CswMarch<3>{c->g, ca, md, nkg}));
-    } else if (kpw == 2) {
-      RT(launch_w(c, "c_sw", nw, CswMarch<2>{c->g, ca, md, nkg}));
-    } else {
-      RT(launch_w(c, "c_sw", nw, CswMarch<1>{c->g, ca, md, nkg}));
-    }
-    return 0;
+    auto go = [&](auto GMc) -> int {
+      constexpr int GM = decltype(GMc)::value;
+      if (kpw == 4) return launch_w(c, "c_sw", nw, CswMarch<4, GM>{c->g, ca, md, nkg});
+      if (kpw == 3) return launch_w(c, "c_sw", nw, CswMarch<3, GM>{c->g, ca, md, nkg});
+      if (kpw == 2) return launch_w(c, "c_sw", nw, CswMarch<2, GM>{c->g, ca, md, nkg});
+      return launch_w(c, "c_sw", nw, CswMarch<1, GM>{c->g, ca, md, nkg});
+    };
+    return dispatch_geom(c->g.geom, go);
   }
   constexpr int TI = FV3_CSW_TI, TJ = FV3_CSW_TJ;
   CswTile<TI, TJ> kf;
@@ -575,6 +617,10 @@ static int dsw_transport_march(fv3_ctx *c, const DswArgs &a, int region = 0) {
       const int nwf = mf.nwaves(c->n_plain);
       return dispatch_hord(a.hord_dp, [&](auto H) {
         constexpr int HORD = decltype(H)::value;
+        if (g.geom == 2) {
+          if (a.hydrostatic) return launch_w(c, "d_sw_fused", nwf, DswTransportFused<HORD, false, true, 2>{g, a, mf});
+          return launch_w(c, "d_sw_fused", nwf, DswTransportFused<HORD, true, true, 2>{g, a, mf});
+        }
         if (a.hydrostatic) return launch_w(c, "d_sw_fused", nwf, DswTransportFused<HORD, false, true>{g, a, mf});
         return launch_w(c, "d_sw_fused", nwf, DswTransportFused<HORD, true, true>{g, a, mf});
       });
@@ -585,6 +631,10 @@ static int dsw_transport_march(fv3_ctx *c, const DswArgs &a, int region = 0) {
     const int nwf = mf.nwaves(c->n_plain);
     return dispatch_hord(a.hord_dp, [&](auto H) {
       constexpr int HORD = decltype(H)::value;
+      if (g.geom == 2) {
+        if (a.hydrostatic) return launch_w(c, "d_sw_fused", nwf, DswTransportFused<HORD, false, true, 2>{g, a, mf});
+        return launch_w(c, "d_sw_fused", nwf, DswTransportFused<HORD, true, true, 2>{g, a, mf});
+      }
       if (a.hydrostatic) return launch_w(c, "d_sw_fused", nwf, DswTransportFused<HORD, false, true>{g, a, mf});
       return launch_w(c, "d_sw_fused", nwf, DswTransportFused<HORD, true, true>{g, a, mf});
     });
@@ -614,11 +664,18 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
   const bool fused_m = c->use_fused != 0;
   if (!fused_m && !c->ke_scr) RT(rt_malloc((void **)&c->ke_scr, sizeof(double) * g.nB() * g.npz));
   if (fused_m) {
-    MarchDims mf = make_march_dims(g, c->march_tj_fused);
+    MarchDims mf = make_march_dims(g, c->march_tj_mom);
     mf.klist = c->klist_m;
     const int nwf = mf.nwaves(c->n_plain_m);
     return dispatch_hord(a.hord_vt, [&](auto H) {
       constexpr int HORD = decltype(H)::value;
+      if (g.geom == 2) {
+        switch (sw_class(a.hord_mt)) {
+          case 5: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<5, HORD, 2>{g, a, mf});
+          case 6: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<6, HORD, 2>{g, a, mf});
+          default: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<8, HORD, 2>{g, a, mf});
+        }
+      }
       switch (sw_class(a.hord_mt)) {
         case 5: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<5, HORD>{g, a, mf});
         case 6: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<6, HORD>{g, a, mf});

@@ -42,6 +42,12 @@ struct Grid {
   const double *dy, *rdy, *dxc, *rdxc, *cosa_u, *sina_u, *rsin_u, *divg_v, *del6_v; // V
   const double *rarea_c, *fC, *cosa, *sina;                                          // B
   const double *sin_sg, *cos_sg;                                                     // A x 9
+  // geometry mode, found by fv3_grid_upload from the metric arrays themselves: 0 = general; 1 = orthogonal (cosa* = 0,
+  // sin* = rsin* = 1 everywhere, as fv_grid_utils.F90:427 sets them for grid_type >= 3); 2 = orthogonal and every length /
+  // area term spatially constant (Cartesian doubly periodic, fv_grid_tools.F90:1202-1221): the constants are below
+  int geom;
+  double c_area, c_rarea, c_dxa, c_dya, c_rdxa, c_rdya, c_dx, c_rdx, c_dyc, c_rdyc, c_dy, c_rdy, c_dxc, c_rdxc;
+  double c_divg_u, c_divg_v, c_del6_u, c_del6_v, c_rarea_c;
 
   // flat index of (i,j) (Fortran indices) in one k-slab of each stagger kind
   FV3_HD int iA(int i, int j) const { return (j - jsd) * nid + (i - isd); }

@@ -114,19 +114,36 @@ inline int launch_cols(Dim3 grid, stream_t s, const F &f) {
   hipLaunchKernelGGL(col_kernel<F>, dim3(grid.x * 4), dim3(64), 0, s, f);
   return (int)hipGetLastError();
 }
-// wave functors (spmd.h): independent wavefronts, 4 per workgroup, no LDS, no barriers
+// wave functors (spmd.h): independent wavefronts, 4 per workgroup, no LDS, no barriers.
+// Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8).  With chunk > 0 (= workgroups per
+// XCD) workgroup b takes the logical index (b % 8) * chunk + b / 8, so each XCD works through one contiguous range of
+// wavefront indices: the strips / segments that share halo rows and cache lines are neighbours in that order and meet
+// in the same L2 instead of in eight different ones.
+constexpr int kXcds = 8;
+__device__ __forceinline__ int wave_index(int chunk) {
+  const int b = (int)blockIdx.x;
+  const int lb = chunk > 0 ? (b % kXcds) * chunk + b / kXcds : b;
+  return lb * (kNT / 64) + (int)(threadIdx.x >> 6);
+}
+inline int xcd_remap() {
+  static const int v = [] {
+    const char *e = std::getenv("FV3_MI355X_XCD_REMAP");
+    return e ? std::atoi(e) : 1;
+  }();
+  return v;
+}
 template <class F>
-__global__ void __launch_bounds__(kNT) wave_kernel(const F f, int nwaves) {
+__global__ void __launch_bounds__(kNT) wave_kernel(const F f, int nwaves, int chunk) {
   // readfirstlane: tell the compiler the wave index is uniform, so everything derived from it
   // (level, strip, row offsets) lives in SGPRs and loads use the scalar-base addressing form
-  const int gid = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (kNT / 64) + (int)(threadIdx.x >> 6));
+  const int gid = __builtin_amdgcn_readfirstlane(wave_index(chunk));
   if (gid < nwaves) f(gid);
 }
 // the same with a register budget of two wavefronts per SIMD (<= 256 VGPRs) for functors that ask for it with
 // `static constexpr int kTwoWavesPerSimd = 1;` -- only worth it when the functor needs a few registers too many
 template <class F>
-__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) wave_kernel_2w(const F f, int nwaves) {
-  const int gid = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (kNT / 64) + (int)(threadIdx.x >> 6));
+__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) wave_kernel_2w(const F f, int nwaves, int chunk) {
+  const int gid = __builtin_amdgcn_readfirstlane(wave_index(chunk));
   if (gid < nwaves) f(gid);
 }
 template <class F, class = void>
@@ -137,11 +154,16 @@ struct wants_two_waves<F, std::enable_if_t<(F::kTwoWavesPerSimd > 0)>> : std::tr
 template <class F>
 inline int launch_waves(int nwaves, stream_t s, const F &f) {
   const int wpb = kNT / 64;
-  const dim3 grid((unsigned)((nwaves + wpb - 1) / wpb));
+  int nblocks = (nwaves + wpb - 1) / wpb, chunk = 0;
+  if (xcd_remap() && nblocks >= 4 * kXcds) {
+    chunk = (nblocks + kXcds - 1) / kXcds;
+    nblocks = chunk * kXcds;
+  }
+  const dim3 grid((unsigned)nblocks);
   if constexpr (wants_two_waves<F>::value)
-    hipLaunchKernelGGL(wave_kernel_2w<F>, grid, dim3(kNT), 0, s, f, nwaves);
+    hipLaunchKernelGGL(wave_kernel_2w<F>, grid, dim3(kNT), 0, s, f, nwaves, chunk);
   else
-    hipLaunchKernelGGL(wave_kernel<F>, grid, dim3(kNT), 0, s, f, nwaves);
+    hipLaunchKernelGGL(wave_kernel<F>, grid, dim3(kNT), 0, s, f, nwaves, chunk);
   return (int)hipGetLastError();
 }
 inline int rt_malloc(void **p, size_t n) { return (int)hipMalloc(p, n); }

@@ -127,7 +127,8 @@ struct MarchIn {
 // The register state of one fv_tp_2d march.  step(r) consumes row r; have_face says that face r-2 is
 // wanted (r-2 >= jA), have_row that row r-3 is (r-3 >= jA); in the latter case fxv / fyv0 / fyv1 return
 // 0.5*(fx + fx2)(j), 0.5*(fy + fy2)(j) and 0.5*(fy + fy2)(j+1) for j = r-3.
-template <int HORD>
+// UNI_AREA: the cell area is the same everywhere (Grid::geom == 2), so the area of row r-3 is the one of row r
+template <int HORD, bool UNI_AREA = false>
 struct Tp2dState {
   static constexpr int ORD_IN = (HORD == 10) ? 8 : HORD;  // tp_core.F90:136-141
   static constexpr int ORD_OU = HORD;
@@ -147,8 +148,8 @@ struct Tp2dState {
   FV3_D void step(const MarchIn &in, bool have_face, bool have_row, vd &fxv, vd &fyv0, vd &fyv1) {
     // ---- row r: inner x sweep and q_j --------------------------------------------------------------
     fx2_3 = fx2_2; fx2_2 = fx2_1; fx2_1 = fx2_0;
-    const vd arj = ar_3, cxj = cx_3;  // rows r-3 (valid once three rows have been consumed)
-    ar_3 = ar_2; ar_2 = ar_1; ar_1 = in.ar;
+    const vd arj = UNI_AREA ? in.ar : ar_3, cxj = cx_3;  // rows r-3 (valid once three rows have been consumed)
+    if constexpr (!UNI_AREA) { ar_3 = ar_2; ar_2 = ar_1; ar_1 = in.ar; }
     cx_3 = cx_2; cx_2 = cx_1; cx_1 = in.cx;
     fx2_0 = ppm_faces_x<ORD_IN>(in.qn, in.cx);
     const vd t = in.xf * fx2_0;

@@ -13,7 +13,7 @@ module fv3_mi355x_mod
   public :: fv3_nh_consts, fv3_remap_params, fv3_memcpy_d2d, fv3_set_dp_ref, fv3_update_dz_c, fv3_riem_solver_c
   public :: fv3_update_dz_d, fv3_riem_solver3, fv3_p_grad_c, fv3_nh_p_grad, fv3_zh_from_delz, fv3_pk3_halo
   public :: fv3_pe_halo, fv3_geopk, fv3_set_ak_bk, fv3_lagrangian_to_eulerian, fv3_tracer_2d_prep
-  public :: fv3_tracer_2d_scale, fv3_tracer_2d_step
+  public :: fv3_tracer_2d_scale, fv3_tracer_2d_step, fv3_grid_geom
   public :: fv3_halo_field, fv3_halo_message_elems, fv3_halo_pack, fv3_halo_unpack
   public :: fv3_heat_source_accum, fv3_del2_cubed, fv3_apply_heat_source
   public :: fv3_d_sw_interior, fv3_d_sw_rest
@@ -78,6 +78,10 @@ module fv3_mi355x_mod
       import :: c_int, c_ptr, fv3_grid_host
       type(c_ptr), value :: ctx
       type(fv3_grid_host), intent(in) :: g
+    end function
+    integer(c_int) function fv3_grid_geom(ctx) bind(C, name="fv3_grid_geom")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
     end function
     integer(c_int) function fv3_malloc(dptr, bytes) bind(C, name="fv3_malloc")
       import :: c_int, c_ptr, c_size_t

@@ -91,10 +91,14 @@ def doubly_periodic(bd: Bounds, npx: int, npy: int, dx_const: float = 1000.0, dy
     return g
 
 
-def perturbed(g: GridStruct, seed: int = 7, amp: float = 0.05) -> GridStruct:
+ANGLE_TERMS = ("cosa", "cosa_s", "cosa_u", "cosa_v", "sina", "rsina", "rsin2", "sina_u", "sina_v", "rsin_u", "rsin_v")
+
+
+def perturbed(g: GridStruct, seed: int = 7, amp: float = 0.05, ortho: bool = False) -> GridStruct:
     """Smoothly perturb every metric term of a doubly periodic gridstruct (test helper).  The
     result is not a geometrically consistent grid; it is a set of positive, smooth arrays that
-    makes every metric read by the kernels matter in a parity comparison."""
+    makes every metric read by the kernels matter in a parity comparison.  ortho=True leaves the
+    angle terms (cosa* = 0, sin* = 1) exact: an orthogonal grid with varying lengths and areas."""
     bd = g.bd
     rng = np.random.default_rng(seed)
     out = GridStruct(bd=bd, npx=g.npx, npy=g.npy, grid_type=g.grid_type, da_min=g.da_min,
@@ -113,7 +117,10 @@ def perturbed(g: GridStruct, seed: int = 7, amp: float = 0.05) -> GridStruct:
     m = out.m
     for name, kind in METRIC_KINDS.items():
         base = g.m[name]
-        if name in ("cosa", "cosa_s", "cosa_u", "cosa_v"):
+        if ortho and name in ANGLE_TERMS:
+            smooth(base.shape)  # keep the random stream of the other terms
+            m[name] = np.asfortranarray(base.copy())
+        elif name in ("cosa", "cosa_s", "cosa_u", "cosa_v"):
             m[name] = np.asfortranarray(amp * smooth(base.shape))
         else:
             m[name] = np.asfortranarray(base * (1.0 + amp * smooth(base.shape)))
@@ -122,5 +129,8 @@ def perturbed(g: GridStruct, seed: int = 7, amp: float = 0.05) -> GridStruct:
     for n in range(9):
         sg[:, :, n] = 1.0 - 0.5 * amp * (1.0 + smooth(sg.shape))  # in (1-amp*..., 1]
         cg[:, :, n] = amp * smooth(cg.shape)
+    if ortho:
+        sg[...] = 1.0
+        cg[...] = 0.0
     m["sin_sg"], m["cos_sg"] = sg, cg
     return out

@@ -68,6 +68,13 @@ int fv3_destroy(fv3_ctx *ctx);
 /* stream: a hipStream_t (NULL = default stream). */
 int fv3_set_stream(fv3_ctx *ctx, void *stream);
 int fv3_grid_upload(fv3_ctx *ctx, const fv3_grid_host *g);
+/* Geometry mode fv3_grid_upload found in the metric arrays (or -1 without a grid): 0 = general (every metric row is
+ * read); 1 = orthogonal: cosa_s, cosa_u, cosa_v = 0 and rsin2, sina_u, sina_v, rsin_u, rsin_v, sin_sg(:,:,1:4) = 1
+ * in every element, what fv_grid_utils.F90:427 / fv_grid_tools.F90:1202-1221 set for grid_type >= 3 -- the kernels
+ * then skip those rows (x*1 and x - y*0 are exact, so the results do not change); 2 = orthogonal and every length /
+ * area array spatially constant (Cartesian doubly periodic, dx_const / dy_const): they travel as scalars.
+ * FV3_MI355X_GEOM=<n> in the environment caps the mode (0 forces the general kernels). */
+int fv3_grid_geom(const fv3_ctx *ctx);
 
 /* Device-memory helpers for callers that do not own a device allocator (a Fortran host). */
 int fv3_malloc(void **dptr, size_t bytes);

@@ -29,6 +29,8 @@ def rel_rms(a, b):
 
 def make_grid(bd, perturb):
     g = doubly_periodic(bd, bd.ie - bd.is_ + 2, bd.je - bd.js + 2)
+    if perturb == "ortho":  # varying lengths / areas, exact angle terms (Grid::geom == 1)
+        return perturbed(g, ortho=True)
     return perturbed(g) if perturb else g
 
 

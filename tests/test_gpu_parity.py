@@ -35,7 +35,7 @@ def test_fv_tp_2d_shapes(prod):
 
 
 @pytest.mark.parametrize("hydrostatic", [False, True])
-@pytest.mark.parametrize("perturb", [False, True])
+@pytest.mark.parametrize("perturb", [False, True, "ortho"])
 def test_c_sw(prod, hydrostatic, perturb):
     P.check_c_sw(prod, hydrostatic=hydrostatic, perturb=perturb)
 
@@ -225,6 +225,22 @@ def test_d_sw_multi_strip_march(prod, hord, hord_mt):
     P.check_d_sw(prod, nx=130, ny=100, npz=3, par_over=dict(hord_dp=hord, hord_tm=hord, hord_vt=hord, hord_mt=hord_mt))
 
 
+@pytest.mark.parametrize("hydrostatic", [False, True])
+@pytest.mark.parametrize("hord,hord_mt", [(10, 10), (8, 6), (5, 5), (-5, 8), (6, 8)])
+def test_d_sw_uniform_metrics(prod, hord, hord_mt, hydrostatic):
+    """Cartesian doubly periodic gridstruct (Grid::geom == 2): the kernels that carry the metric terms as scalars"""
+    P.check_d_sw(prod, nx=130, ny=64, npz=3, perturb=False, hydrostatic=hydrostatic,
+                 par_over=dict(hord_dp=hord, hord_tm=hord, hord_vt=hord, hord_mt=hord_mt))
+
+
+@pytest.mark.parametrize("perturb", [False, "ortho"])
+def test_geometry_modes_off_same_result(prod, perturb, monkeypatch):
+    """FV3_MI355X_GEOM=0 sends an orthogonal / uniform gridstruct through the general kernels: same parity"""
+    monkeypatch.setenv("FV3_MI355X_GEOM", "0")
+    P.check_c_sw(prod, nx=70, ny=30, npz=2, perturb=perturb)
+    P.check_d_sw(prod, nx=70, ny=30, npz=2, perturb=perturb)
+
+
 @pytest.mark.parametrize("nx,ny,hydro", [(130, 100, False), (55, 44, True)])
 def test_c_sw_multi_strip_march(prod, nx, ny, hydro):
     P.check_c_sw(prod, nx=nx, ny=ny, npz=2, hydrostatic=hydro)
@@ -353,3 +369,16 @@ def test_limiter_branch_point_states(prod, state, hord):
     assert P.check_c_sw(prod, nx=64, ny=40, npz=2, state=state) <= P.TOL
     over = dict(hord_dp=hord, hord_tm=hord, hord_vt=hord, hord_mt=hord)
     assert max(P.check_d_sw(prod, nx=64, ny=40, npz=3, state=state, par_over=over).values()) <= P.TOL
+
+
+def test_geometry_mode_detection(prod):
+    """fv3_grid_upload classifies the gridstruct from its arrays (general / orthogonal / orthogonal + uniform)."""
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    bd = Bounds(1, 12, 1, 9)
+    for perturb, want in ((True, 0), ("ortho", 1), (False, 2)):
+        ctx = Context(P.make_grid(bd, perturb), 2, lib=prod)
+        try:
+            assert ctx.geom == want
+        finally:
+            ctx.close()

@@ -36,7 +36,7 @@ def test_fv_tp_2d_tile_multiple_and_ragged(emu):
 
 
 @pytest.mark.parametrize("hydrostatic", [False, True])
-@pytest.mark.parametrize("perturb", [False, True])
+@pytest.mark.parametrize("perturb", [False, True, "ortho"])
 def test_c_sw(emu, hydrostatic, perturb):
     P.check_c_sw(emu, hydrostatic=hydrostatic, perturb=perturb)
 
@@ -171,6 +171,22 @@ def test_d_sw_multi_strip_march(emu, hord, hord_mt):
     P.check_d_sw(emu, nx=130, ny=100, npz=3, par_over=dict(hord_dp=hord, hord_tm=hord, hord_vt=hord, hord_mt=hord_mt))
 
 
+@pytest.mark.parametrize("hydrostatic", [False, True])
+@pytest.mark.parametrize("hord,hord_mt", [(10, 10), (8, 6), (5, 5), (-5, 8), (6, 8)])
+def test_d_sw_uniform_metrics(emu, hord, hord_mt, hydrostatic):
+    """Cartesian doubly periodic gridstruct (Grid::geom == 2): the kernels that carry the metric terms as scalars"""
+    P.check_d_sw(emu, nx=130, ny=64, npz=3, perturb=False, hydrostatic=hydrostatic,
+                 par_over=dict(hord_dp=hord, hord_tm=hord, hord_vt=hord, hord_mt=hord_mt))
+
+
+@pytest.mark.parametrize("perturb", [False, "ortho"])
+def test_geometry_modes_off_same_result(emu, perturb, monkeypatch):
+    """FV3_MI355X_GEOM=0 sends an orthogonal / uniform gridstruct through the general kernels: same parity"""
+    monkeypatch.setenv("FV3_MI355X_GEOM", "0")
+    P.check_c_sw(emu, nx=70, ny=30, npz=2, perturb=perturb)
+    P.check_d_sw(emu, nx=70, ny=30, npz=2, perturb=perturb)
+
+
 @pytest.mark.parametrize("nx,ny,hydro", [(130, 100, False), (55, 44, True)])
 def test_c_sw_multi_strip_march(emu, nx, ny, hydro):
     P.check_c_sw(emu, nx=nx, ny=ny, npz=2, hydrostatic=hydro)
@@ -271,3 +287,16 @@ def test_error_behaviour_of_the_c_abi(emu):
     g.grid_type = 0                                                    # cubed-sphere branches are not built
     with pytest.raises(L.Fv3Error, match="grid_type"):
         L.Context(g, 2, lib=emu)
+
+
+def test_geometry_mode_detection(emu):
+    """fv3_grid_upload classifies the gridstruct from its arrays (general / orthogonal / orthogonal + uniform)."""
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    bd = Bounds(1, 12, 1, 9)
+    for perturb, want in ((True, 0), ("ortho", 1), (False, 2)):
+        ctx = Context(P.make_grid(bd, perturb), 2, lib=emu)
+        try:
+            assert ctx.geom == want
+        finally:
+            ctx.close()
