@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--hord", type=int, default=10, help="hord_mt = hord_vt = hord_tm = hord_dp (reference default 10)")
     ap.add_argument("--no-model-step", action="store_true", help="skip the SYPD (whole model step) leg")
     ap.add_argument("--nq", type=int, default=4, help="advected tracers in the SYPD leg")
+    ap.add_argument("--general-metrics", action="store_true",
+                    help="FV3_MI355X_GEOM=0: read every metric row (what a cubed-sphere gridstruct needs) instead of "
+                         "using the uniform-Cartesian kernels the library selects for this doubly periodic gridstruct")
     return ap.parse_args()
 
 
@@ -178,7 +181,10 @@ def main():
     from gfdl_atmos_cubed_sphere_amd.grid import doubly_periodic
     g = doubly_periodic(bd, nx * px + 1, nx * py + 1, dx_const=26000.0, dy_const=26000.0)
     stream = torch.cuda.current_stream()
+    if a.general_metrics:
+        os.environ["FV3_MI355X_GEOM"] = "0"
     ctx = L.Context(g, npz, stream=stream.cuda_stream)
+    geom = ctx.geom
     # FV3_BENCH_SPLIT=1: exercise the multi-rank flow (start / d_sw interior / finish / d_sw rest) on one GPU to see its cost
     halo = HaloExchanger(ctx, px, py, rank, world, split_single=os.environ.get("FV3_BENCH_SPLIT") == "1")
 
@@ -277,7 +283,10 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"doubly periodic {nx}x{nx}x{npz} tile per GPU (C384L127-sized), nonhydrostatic, "
                                   f"c_sw+d_sw pair, hord {a.hord}/{a.hord}/{a.hord}/{a.hord}, nord=1, d4_bg=0.16",
-                      "layout": f"{px}x{py}", "halo": "periodic copy" if world == 1 else "RCCL send/recv"},
+                      "layout": f"{px}x{py}", "halo": "periodic copy" if world == 1 else "RCCL send/recv",
+                      # what fv3_grid_upload found in the metric arrays (fv3_grid_geom)
+                      "gridstruct": {0: "general metric rows", 1: "orthogonal (angle terms not read)",
+                                     2: "orthogonal + uniform (metric terms as scalars)"}[geom]},
            "finite": finite, "roofline": roof}
     ctx.close()
     ctx = None
