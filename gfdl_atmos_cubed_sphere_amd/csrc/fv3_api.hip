@@ -55,6 +55,8 @@ struct fv3_ctx {
   EdgeCoef ec;
   bool dp0_ready;
   double *scratch[8];
+  double *remap_scr;     // coordinate + profile slabs of the vertical remap (fv3_lagrangian_to_eulerian)
+  size_t remap_scr_n;
   double *lev_ext_d;  // damp(npz+1) for update_dz_d
   int *lev_ext_i;     // ndif(npz+1)
   double *trc_d;      // device, 2*npz: cmax, frac
@@ -236,6 +238,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   }
   c->dp0 = nullptr; c->edge_dev = nullptr; c->dp0_ready = false;
   c->akbk = nullptr; c->kord_tr_dev = nullptr; c->akbk_ready = false;
+  c->remap_scr = nullptr; c->remap_scr_n = 0;
   c->trc_d = nullptr; c->trc_i = nullptr;
   for (auto &s : c->scratch) s = nullptr;
   c->lev_ext_d = nullptr; c->lev_ext_i = nullptr;
@@ -250,6 +253,7 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   if (c->lev_d) rt_free(c->lev_d);
   if (c->dp0) rt_free(c->dp0);
   if (c->akbk) rt_free(c->akbk);
+  if (c->remap_scr) rt_free(c->remap_scr);
   if (c->trc_d) rt_free(c->trc_d);
   if (c->trc_i) rt_free(c->trc_i);
   if (c->kord_tr_dev) rt_free(c->kord_tr_dev);
@@ -1341,7 +1345,6 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   for (int n = 0; n < p->nq; n++)
     if (!kord_supported(kord_tr[n])) return fail("fv3_lagrangian_to_eulerian: kord_tr(%d) unsupported", n + 1);
   if (c->g.npz < 5) return fail("fv3_lagrangian_to_eulerian: needs npz > 4 (fv_dynamics.F90:574)");
-  if (need_scratch(c, 8)) return 1;
   const Grid &g = c->g;
   const int km = g.npz;
   if (p->nq > 0) {
@@ -1351,18 +1354,42 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   }
   RemapPar rp{p->last_step, p->hydrostatic, p->adiabatic, p->nq, p->kord_mt, p->kord_wz, p->kord_tm, p->sphum,
               p->akap, p->ptop, p->rdgas, p->grav, p->cv_air, p->r_vir, p->cp, p->t_min};
-  ColScr s{c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->scratch[4], c->scratch[5], c->scratch[6],
-           c->scratch[7], g.nA(), 0};
   const double *ak = c->akbk, *bk = c->akbk + (km + 1);
+  // field tasks: T_v, nq tracers, w (nonhydrostatic), u, v -- at most kRemapSets of them per launch, each with its own six
+  // profile slabs; eight coordinate slabs (p, log p, and the face-averaged p of u and of v) in front of them
+  constexpr int kRemapSets = 8;
+  const int ntask = 1 + p->nq + (p->hydrostatic ? 0 : 1) + 2;
+  const int nsets = ntask < kRemapSets ? ntask : kRemapSets;
+  const size_t slab = g.nA() * (size_t)(km + 1);
+  const size_t need = slab * (size_t)(8 + 6 * nsets);
+  if (c->remap_scr_n < need) {
+    if (c->remap_scr) rt_free(c->remap_scr);
+    c->remap_scr = nullptr;
+    c->remap_scr_n = 0;
+    RT(rt_malloc((void **)&c->remap_scr, need * sizeof(double)));
+    c->remap_scr_n = need;
+  }
+  double *co = c->remap_scr, *sets = c->remap_scr + 8 * slab;
   {
-    RemapScalars kf{g, km, rp, ak, bk, c->kord_tr_dev, ps, delp, pkz, pk, w, delz, pt, q, peln, omga, pe, ws, s};
-    RT(launch_c(c, "remap_scalars", col_grid(g.nx * g.ny), kf));
+    RemapCoords kf{g, km, rp, ak, bk, pe, peln, ps, co, co + slab, co + 2 * slab, co + 3 * slab};
+    RT(launch_c(c, "remap_coords", col_grid(g.nx * g.ny), kf));
   }
   {
-    RemapWinds ku{g, km, rp, ak, bk, pe, u, v, s, 0};
-    RT(launch_c(c, "remap_u", col_grid(g.nx * (g.ny + 1)), ku));
-    RemapWinds kv{g, km, rp, ak, bk, pe, u, v, s, 1};
-    RT(launch_c(c, "remap_v", col_grid((g.nx + 1) * g.ny), kv));
+    const int nblk = ((g.nx + 1) * (g.ny + 1) + 255) / 256;  // covers the u and v columns too
+    for (int t0 = 0; t0 < ntask; t0 += nsets) {
+      const int nt = ntask - t0 < nsets ? ntask - t0 : nsets;
+      RemapFields kf{g, km, rp, ak, bk, c->kord_tr_dev, delp, pk, delz, peln, pe, ws, w, pt, q, omga, u, v,
+                     co, co + slab, co + 2 * slab, co + 3 * slab, co + 4 * slab, co + 5 * slab, co + 6 * slab,
+                     co + 7 * slab, sets, slab, t0, nblk};
+      Dim3 gr = col_grid(256 * nblk * nt);
+      RT(launch_c(c, "remap_fields", gr, kf));
+    }
+  }
+  {
+    ColScr s0{sets, sets + slab, sets + 2 * slab, sets + 3 * slab, sets + 4 * slab, co, co + slab, sets + 5 * slab,
+              g.nA(), 0};
+    RemapDelzFinal kf{g, km, rp, delp, pkz, pk, delz, pt, peln, q, s0};
+    RT(launch_c(c, "remap_delz_final", col_grid(g.nx * g.ny), kf));
   }
   {
     RemapPe kf{g, km, ak, bk, pe};

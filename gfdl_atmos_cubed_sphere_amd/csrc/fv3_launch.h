@@ -105,13 +105,27 @@ inline int launch(Dim3 grid, size_t lds_doubles, stream_t s, const F &f) {
 // Column kernels (one thread per (i,j) column, long serial k loops, no LDS): launched as 64-thread workgroups so that
 // the ~2300 wavefronts of a 384 x 384 tile spread evenly over the 1024 SIMDs (256-thread groups would give the 256
 // CUs 2 or 3 groups each).  The functor still sees the (group of 256, thread) numbering of the tile launcher.
+// Their k loops are chains of dependent, data-dependent loads, so what bounds them is the number of wavefronts a SIMD can
+// switch between, not lanes: with `lanes` < 64 only the first `lanes` threads of each 64-thread group take a column, which
+// multiplies the wavefronts in flight by 64 / lanes (FV3_MI355X_COL_LANES, measured best value is the default).
 template <class F>
-__global__ void __launch_bounds__(64) col_kernel(const F f) {
-  f((int)(blockIdx.x >> 2), 0, 0, (int)(((blockIdx.x & 3) << 6) + threadIdx.x), nullptr);
+__global__ void __launch_bounds__(64) col_kernel(const F f, int lanes) {
+  if ((int)threadIdx.x >= lanes) return;
+  const int vt = (int)blockIdx.x * lanes + (int)threadIdx.x;  // virtual thread = column slot
+  f(vt >> 8, 0, 0, vt & 255, nullptr);
+}
+inline int col_lanes() {
+  static const int v = [] {
+    const char *e = std::getenv("FV3_MI355X_COL_LANES");
+    const int n = e ? std::atoi(e) : 64;
+    return (n == 16 || n == 32) ? n : 64;
+  }();
+  return v;
 }
 template <class F>
 inline int launch_cols(Dim3 grid, stream_t s, const F &f) {
-  hipLaunchKernelGGL(col_kernel<F>, dim3(grid.x * 4), dim3(64), 0, s, f);
+  const int lanes = col_lanes();
+  hipLaunchKernelGGL(col_kernel<F>, dim3(grid.x * (256 / lanes)), dim3(64), 0, s, f, lanes);
   return (int)hipGetLastError();
 }
 // wave functors (spmd.h): independent wavefronts, 4 per workgroup, no LDS, no barriers.

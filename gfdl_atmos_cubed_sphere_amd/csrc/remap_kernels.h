@@ -460,16 +460,170 @@ struct RemapPar {
 
 #define FV3_COL_FOR2(c, ncol) for (int c = bx * 256 + tid; c < (bx + 1) * 256 && c < (ncol); c += kNT)
 
-// cell-centred fields of one column: pt, tracers, w, delz, delp, pk, peln, pkz, ps, omga (fv_mapz.F90:184-528)
-struct RemapScalars {
+// The remap of one time step is four launches:
+//   RemapCoords    -- per column: ps and the source / target coordinates of the cell-centred fields (p, and log p for T_v)
+//   RemapFields    -- one thread per (column, field): T_v / theta_v (+ omega), every tracer, w, u, v are remapped side by
+//                     side, each with its own set of profile slabs.  A column kernel has only nx*ny threads and long
+//                     serial k loops with data-dependent loads; running the fields concurrently instead of one after
+//                     the other in the same thread multiplies the loads in flight by the number of fields.
+//   RemapDelzFinal -- per column: delz (its source is -delz/delp of the OLD delp and it is overwritten in place, so it
+//                     must follow the T_v task, which reads the old delz) and delp, pk, peln, pkz, pt (:426-503, :793-841)
+//   RemapPe        -- pe(k) = ak + bk*ps
+
+// source / target coordinates of the cell-centred fields (fv_mapz.F90:298-345, :363-374)
+struct RemapCoords {
   Grid g;
   int km;
   RemapPar p;
-  const double *ak, *bk;  // device, km+1
-  const int *kord_tr;     // device, nq
-  double *ps, *delp, *pkz, *pk, *w, *delz, *pt, *q, *peln, *omga;
-  const double *pe, *ws;
-  ColScr s;
+  const double *ak, *bk, *pe, *peln;
+  double *ps;
+  double *pe1p, *pe2p, *pe1l, *pe2l;  // slabs: pressure coordinates; log-pressure coordinates (kord_tm < 0)
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int ncol = g.nx * g.ny;
+    const size_t nA = g.nA();
+    FV3_COL_FOR2(col, ncol) {
+      const int i = g.is + col % g.nx, j = g.js + col / g.nx;
+      const int o = g.iA(i, j);
+      const size_t peb = (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1));
+      const size_t lnb = (size_t)(j - g.js) * g.nx * (km + 1) + (i - g.is);
+      const double psfc = pe[peb + (size_t)km * (g.nx + 2)];
+      ps[o] = psfc;  // :298-300
+      for (int k = 1; k <= km + 1; k++) {
+        const size_t so = (size_t)(k - 1) * nA + o;
+        const double pe2k = (k == 1) ? p.ptop : (k == km + 1 ? psfc : ak[k - 1] + bk[k - 1] * psfc);
+        pe1p[so] = pe[peb + (size_t)(k - 1) * (g.nx + 2)];
+        pe2p[so] = pe2k;
+        if (p.kord_tm < 0) {
+          const double pl = peln[lnb + (size_t)(k - 1) * g.nx];
+          pe1l[so] = pl;
+          pe2l[so] = (k == 1 || k == km + 1) ? pl : log(pe2k);
+        }
+      }
+    }
+  }
+};
+
+// one thread per (column, field task); tasks: 0 = T_v / theta_v (+ omega on the last step), 1 .. nq = tracers,
+// nq+1 = w (nonhydrostatic), then u, v.  Task t of this launch uses profile-slab set t - task0.
+struct RemapFields {
+  Grid g;
+  int km;
+  RemapPar p;
+  const double *ak, *bk;
+  const int *kord_tr;  // device, nq
+  const double *delp, *pk, *delz, *peln, *pe, *ws;
+  double *w, *pt, *q, *omga, *u, *v;
+  double *pe1p, *pe2p, *pe1l, *pe2l, *pe1u, *pe2u, *pe1v, *pe2v;  // coordinate slabs
+  double *sets;                                                     // 6 profile slabs per task of this launch
+  size_t slab;                                                      // doubles per slab
+  int task0, nblk;                                                  // first task of this launch; workgroups per task
+
+  FV3_HD void operator()(int bxg, int, int, int tid, double *) const {
+    const int task = task0 + bxg / nblk, bx = bxg % nblk;
+    const size_t nA = g.nA(), nCC = g.nCC();
+    double *base = sets + (size_t)(task - task0) * 6 * slab;
+    ColScr c{base, base + slab, base + 2 * slab, base + 3 * slab, base + 4 * slab, pe1p, pe2p, base + 5 * slab, nA, 0};
+    const int t_w = p.hydrostatic ? -1 : p.nq + 1, t_u = p.hydrostatic ? p.nq + 1 : p.nq + 2, t_v = t_u + 1;
+    const int akt = p.kord_tm < 0 ? -p.kord_tm : p.kord_tm;
+    if (task == t_u || task == t_v) {  // D-grid winds: u on (is:ie, js:je+1), v on (is:ie+1, js:je)  (fv_mapz.F90:530-573)
+      const int which = task == t_u ? 0 : 1;
+      const int wdt = which == 0 ? g.nx : g.nx + 1, hgt = which == 0 ? g.ny + 1 : g.ny;
+      const int ncol = wdt * hgt;
+      c.pe1 = which == 0 ? pe1u : pe1v;
+      c.pe2 = which == 0 ? pe2u : pe2v;
+      FV3_COL_FOR2(col, ncol) {
+        const int i = g.is + col % wdt, j = g.js + col / wdt;
+        c.o = g.iA(i, j);
+        auto PE = [&](int ii, int k, int jj) {
+          return pe[(size_t)(jj - (g.js - 1)) * (g.nx + 2) * (km + 1) + (size_t)(k - 1) * (g.nx + 2) + (ii - (g.is - 1))];
+        };
+        const int i2 = which == 0 ? i : i - 1, j2 = which == 0 ? j - 1 : j;  // the other cell sharing the face
+        const double psum = PE(i2, km + 1, j2) + PE(i, km + 1, j);
+        for (int k = 1; k <= km + 1; k++) {
+          CS(pe1, k) = (k == 1) ? PE(i, 1, j) : 0.5 * (PE(i2, k, j2) + PE(i, k, j));
+          const double bkh = 0.5 * bk[k - 1];
+          CS(pe2, k) = (which == 1 && k == 1) ? ak[0] : ak[k - 1] + bkh * psum;
+        }
+        double *f = which == 0 ? u + g.iU(i, j) : v + g.iV(i, j);
+        const size_t fs = which == 0 ? g.nU() : g.nV();
+        profile_col(c, km, false, 0., -1, p.kord_mt, 0., [&](int k) { return f[(size_t)(k - 1) * fs]; });
+        map_col(c, km, false, [&](int k, double val) { f[(size_t)(k - 1) * fs] = val; });
+      }
+      return;
+    }
+    const int ncol = g.nx * g.ny;
+    FV3_COL_FOR2(col, ncol) {
+      const int i = g.is + col % g.nx, j = g.js + col / g.nx;
+      c.o = g.iA(i, j);
+      const int occ = g.iCC(i, j);
+      if (task == 0) {
+        const double k1k = p.rdgas / p.cv_air, rrg = -p.rdgas / p.grav, akap = p.akap;
+        const size_t lnb = (size_t)(j - g.js) * g.nx * (km + 1) + (i - g.is);
+        auto PELN = [&](int k) { return peln[lnb + (size_t)(k - 1) * g.nx]; };
+        // temperature transform (:200-229), level by level as the profile sweep fetches the field
+        auto src_pt = [&](int k) {
+          double t = pt[(size_t)(k - 1) * nA + c.o];
+          if (p.kord_tm < 0) {
+            if (p.hydrostatic) {
+              t = t * (pk[(size_t)k * nCC + occ] - pk[(size_t)(k - 1) * nCC + occ]) / (akap * (PELN(k + 1) - PELN(k)));
+            } else {
+              const double dpo = delp[(size_t)(k - 1) * nA + c.o];
+              t = t * exp(k1k * log(rrg * dpo / delz[(size_t)(k - 1) * nCC + occ] * t));
+            }
+          }
+          return t;
+        };
+        // remap T_v (log-p coordinate, :363-368) or theta_v (:370-374)
+        if (p.kord_tm < 0) {
+          c.pe1 = pe1l;
+          c.pe2 = pe2l;
+          profile_col(c, km, true, 0., 1, akt, p.t_min, src_pt);
+        } else {
+          profile_col(c, km, false, 0., 1, akt, 0., src_pt);
+        }
+        map_col(c, km, false, [&](int k, double v_) { pt[(size_t)(k - 1) * nA + c.o] = v_; });
+        // omega (:432-443, :506-526): interpolated in the old log-p coordinate
+        if (p.last_step) {
+          const size_t peb = (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1));
+          const double psfc = pe[peb + (size_t)km * (g.nx + 2)];
+          CS(gam, 1) = 0.;
+          for (int k = 2; k <= km + 1; k++) CS(gam, k) = omga[(size_t)(k - 2) * nA + c.o];  // pe3
+          int k_next = 1;
+          for (int n = 1; n <= km; n++) {
+            const double pn_t = (n == 1) ? PELN(1) : log(ak[n - 1] + bk[n - 1] * psfc);
+            const double pn_b = (n + 1 == km + 1) ? PELN(km + 1) : log(ak[n] + bk[n] * psfc);
+            const double mid = 0.5 * (pn_t + pn_b);
+            for (int k = k_next; k <= km; k++) {
+              const double e0 = PELN(k), e1 = PELN(k + 1);
+              if (mid <= e1 && mid >= e0) {
+                omga[(size_t)(n - 1) * nA + c.o] = CS(gam, k) + (CS(gam, k + 1) - CS(gam, k)) * (mid - e0) / (e1 - e0);
+                k_next = k;
+                break;
+              }
+            }
+          }
+        }
+      } else if (task == t_w) {  // w (:400-411)
+        profile_col(c, km, false, ws[occ], -2, p.kord_wz, 0., [&](int k) { return w[(size_t)(k - 1) * nA + c.o]; });
+        map_col(c, km, false, [&](int k, double v_) { w[(size_t)(k - 1) * nA + c.o] = v_; });
+      } else {  // constituents (:380-397)
+        const int iq = task - 1;
+        double *qq = q + (size_t)iq * nA * km;
+        profile_col(c, km, true, 0., 0, kord_tr[iq], 0., [&](int k) { return qq[(size_t)(k - 1) * nA + c.o]; });
+        map_col(c, km, p.nq > 5, [&](int k, double v_) { qq[(size_t)(k - 1) * nA + c.o] = v_; });
+      }
+    }
+  }
+};
+
+// delz (:292, :412-423), then delp, pk, peln, pkz, pt of the column (:318-322, :426-430, :445-503, :793-841)
+struct RemapDelzFinal {
+  Grid g;
+  int km;
+  RemapPar p;
+  double *delp, *pkz, *pk, *delz, *pt, *peln;
+  const double *q;
+  ColScr s;  // profile slabs of set 0 with the pressure coordinates
   FV3_HD void operator()(int bx, int, int, int tid, double *) const {
     const int ncol = g.nx * g.ny;
     const size_t nA = g.nA(), nCC = g.nCC();
@@ -480,82 +634,16 @@ struct RemapScalars {
       ColScr c = s;
       c.o = g.iA(i, j);
       const int occ = g.iCC(i, j);
-      const size_t peb = (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1));
       const size_t lnb = (size_t)(j - g.js) * g.nx * (km + 1) + (i - g.is);
-      auto PE = [&](int k) { return pe[peb + (size_t)(k - 1) * (g.nx + 2)]; };
       auto PELN = [&](int k) -> double & { return peln[lnb + (size_t)(k - 1) * g.nx]; };
-      const double psfc = PE(km + 1);
-      // ---- 0) temperature transform (:200-229), specific volume (:292): done level by level as the profile
-      //         sweep fetches the field (src is called once per level, in order)
-      auto src_pt = [&](int k) {
-        double t = pt[(size_t)(k - 1) * nA + c.o];
-        const double dpo = delp[(size_t)(k - 1) * nA + c.o];
-        if (p.kord_tm < 0) {
-          if (p.hydrostatic)
-            t = t * (pk[(size_t)k * nCC + occ] - pk[(size_t)(k - 1) * nCC + occ]) / (akap * (PELN(k + 1) - PELN(k)));
-          else
-            t = t * exp(k1k * log(rrg * dpo / delz[(size_t)(k - 1) * nCC + occ] * t));
-        }
-        if (!p.hydrostatic) delz[(size_t)(k - 1) * nCC + occ] = -delz[(size_t)(k - 1) * nCC + occ] / dpo;
-        return t;
-      };
-      ps[c.o] = psfc;  // :298-300
-      // ---- 1) remap T_v (log-p coordinate, :363-368) or theta_v (:370-374) ----
-      if (p.kord_tm < 0) {
-        for (int k = 1; k <= km + 1; k++) {
-          CS(pe1, k) = PELN(k);
-          const double pe2k = (k == 1) ? p.ptop : (k == km + 1 ? psfc : ak[k - 1] + bk[k - 1] * psfc);
-          CS(pe2, k) = (k == 1) ? PELN(1) : (k == km + 1 ? PELN(km + 1) : log(pe2k));
-        }
-        profile_col(c, km, true, 0., 1, akt, p.t_min, src_pt);
-      } else {
-        for (int k = 1; k <= km + 1; k++) {
-          CS(pe1, k) = PE(k);
-          CS(pe2, k) = (k == 1) ? p.ptop : (k == km + 1 ? psfc : ak[k - 1] + bk[k - 1] * psfc);
-        }
-        profile_col(c, km, false, 0., 1, akt, 0., src_pt);
-      }
-      map_col(c, km, false, [&](int k, double v) { pt[(size_t)(k - 1) * nA + c.o] = v; });
-      // ---- 3.3) omega (:432-443, :506-526): needs the old peln (= pe1 here when kord_tm < 0) ----
-      if (p.last_step) {
-        CS(gam, 1) = 0.;
-        for (int k = 2; k <= km + 1; k++) CS(gam, k) = omga[(size_t)(k - 2) * nA + c.o];  // pe3
-        int k_next = 1;
-        for (int n = 1; n <= km; n++) {
-          const double pn_t = (n == 1) ? PELN(1) : log(ak[n - 1] + bk[n - 1] * psfc);
-          const double pn_b = (n + 1 == km + 1) ? PELN(km + 1) : log(ak[n] + bk[n] * psfc);
-          const double mid = 0.5 * (pn_t + pn_b);
-          for (int k = k_next; k <= km; k++) {
-            const double e0 = PELN(k), e1 = PELN(k + 1);
-            if (mid <= e1 && mid >= e0) {
-              omga[(size_t)(n - 1) * nA + c.o] = CS(gam, k) + (CS(gam, k + 1) - CS(gam, k)) * (mid - e0) / (e1 - e0);
-              k_next = k;
-              break;
-            }
-          }
-        }
-      }
-      // ---- pressure coordinates for everything else (:304-345) ----
-      for (int k = 1; k <= km + 1; k++) {
-        CS(pe1, k) = PE(k);
-        CS(pe2, k) = (k == 1) ? p.ptop : (k == km + 1 ? psfc : ak[k - 1] + bk[k - 1] * psfc);
-      }
-      // ---- 2) constituents (:380-397) ----
-      for (int iq = 0; iq < p.nq; iq++) {
-        double *qq = q + (size_t)iq * nA * km;
-        profile_col(c, km, true, 0., 0, kord_tr[iq], 0., [&](int k) { return qq[(size_t)(k - 1) * nA + c.o]; });
-        map_col(c, km, p.nq > 5, [&](int k, double v) { qq[(size_t)(k - 1) * nA + c.o] = v; });
-      }
-      // ---- 3) w and delz (:400-423) ----
       if (!p.hydrostatic) {
-        profile_col(c, km, false, ws[occ], -2, p.kord_wz, 0., [&](int k) { return w[(size_t)(k - 1) * nA + c.o]; });
-        map_col(c, km, false, [&](int k, double v) { w[(size_t)(k - 1) * nA + c.o] = v; });
-        profile_col(c, km, false, 0., 1, akt, 0., [&](int k) { return delz[(size_t)(k - 1) * nCC + occ]; });
-        map_col(c, km, false, [&](int k, double v) {
-          delz[(size_t)(k - 1) * nCC + occ] = -v * (CS(pe2, k + 1) - CS(pe2, k));
+        profile_col(c, km, false, 0., 1, akt, 0., [&](int k) {
+          return -delz[(size_t)(k - 1) * nCC + occ] / delp[(size_t)(k - 1) * nA + c.o];  // :292
+        });
+        map_col(c, km, false, [&](int k, double v_) {
+          delz[(size_t)(k - 1) * nCC + occ] = -v_ * (CS(pe2, k + 1) - CS(pe2, k));
         });
       }
-      // ---- delp, pk, peln, pkz (:318-322, :426-430, :445-503) ----
       double pn_prev = PELN(1), pk_prev = pk[occ];
       for (int k = 1; k <= km; k++) {
         const double dp2 = CS(pe2, k + 1) - CS(pe2, k);
@@ -593,42 +681,6 @@ struct RemapScalars {
         pn_prev = pn_next;
         pk_prev = pk_next;
       }
-    }
-  }
-};
-
-// D-grid winds: u on (is:ie, js:je+1), v on (is:ie+1, js:je)  (fv_mapz.F90:530-573)
-struct RemapWinds {
-  Grid g;
-  int km;
-  RemapPar p;
-  const double *ak, *bk;
-  const double *pe;
-  double *u, *v;
-  ColScr s;
-  int which;  // 0 = u, 1 = v
-  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
-    const int wdt = which == 0 ? g.nx : g.nx + 1, hgt = which == 0 ? g.ny + 1 : g.ny;
-    const int ncol = wdt * hgt;
-    const size_t nU = g.nU(), nV = g.nV();
-    FV3_COL_FOR2(col, ncol) {
-      const int i = g.is + col % wdt, j = g.js + col / wdt;
-      ColScr c = s;
-      c.o = g.iA(i, j);
-      auto PE = [&](int ii, int k, int jj) {
-        return pe[(size_t)(jj - (g.js - 1)) * (g.nx + 2) * (km + 1) + (size_t)(k - 1) * (g.nx + 2) + (ii - (g.is - 1))];
-      };
-      const int i2 = which == 0 ? i : i - 1, j2 = which == 0 ? j - 1 : j;  // the other cell sharing the face
-      const double psum = PE(i2, km + 1, j2) + PE(i, km + 1, j);
-      for (int k = 1; k <= km + 1; k++) {
-        CS(pe1, k) = (k == 1) ? PE(i, 1, j) : 0.5 * (PE(i2, k, j2) + PE(i, k, j));
-        const double bkh = 0.5 * bk[k - 1];
-        CS(pe2, k) = (which == 1 && k == 1) ? ak[0] : ak[k - 1] + bkh * psum;
-      }
-      double *f = which == 0 ? u + g.iU(i, j) : v + g.iV(i, j);
-      const size_t fs = which == 0 ? nU : nV;
-      profile_col(c, km, false, 0., -1, p.kord_mt, 0., [&](int k) { return f[(size_t)(k - 1) * fs]; });
-      map_col(c, km, false, [&](int k, double val) { f[(size_t)(k - 1) * fs] = val; });
     }
   }
 };
