@@ -55,6 +55,7 @@ struct fv3_ctx {
   EdgeCoef ec;
   bool dp0_ready;
   double *scratch[8];
+  double *ray_d;         // pm(k), rf(k) of Rayleigh_Friction
   double *remap_scr;     // coordinate + profile slabs of the vertical remap (fv3_lagrangian_to_eulerian)
   size_t remap_scr_n;
   double *lev_ext_d;  // damp(npz+1) for update_dz_d
@@ -238,7 +239,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   }
   c->dp0 = nullptr; c->edge_dev = nullptr; c->dp0_ready = false;
   c->akbk = nullptr; c->kord_tr_dev = nullptr; c->akbk_ready = false;
-  c->remap_scr = nullptr; c->remap_scr_n = 0;
+  c->remap_scr = nullptr; c->remap_scr_n = 0; c->ray_d = nullptr;
   c->trc_d = nullptr; c->trc_i = nullptr;
   for (auto &s : c->scratch) s = nullptr;
   c->lev_ext_d = nullptr; c->lev_ext_i = nullptr;
@@ -254,6 +255,7 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   if (c->dp0) rt_free(c->dp0);
   if (c->akbk) rt_free(c->akbk);
   if (c->remap_scr) rt_free(c->remap_scr);
+  if (c->ray_d) rt_free(c->ray_d);
   if (c->trc_d) rt_free(c->trc_d);
   if (c->trc_i) rt_free(c->trc_i);
   if (c->kord_tr_dev) rt_free(c->kord_tr_dev);
@@ -1122,7 +1124,8 @@ extern "C" int fv3_p_grad_c(fv3_ctx *c, double dt2, const double *delpc, const d
 extern "C" int fv3_pt_to_theta_v(fv3_ctx *c, int hydrostatic, double zvir, double kappa, double rdgas, double grav,
                                  double *pt, const double *delp, const double *delz, const double *qv, double *pkz) {
   if (!c || !c->grid_ready) return fail("fv3_pt_to_theta_v: context has no grid");
-  if (!pt || !pkz || (!hydrostatic && (!delp || !delz))) return fail("fv3_pt_to_theta_v: null field");
+  if (!pt || !pkz || (hydrostatic <= 0 && (!delp || !delz))) return fail("fv3_pt_to_theta_v: null field");
+  if (hydrostatic < -1 || hydrostatic > 1) return fail("fv3_pt_to_theta_v: hydrostatic must be 0, 1 or -1 (pkz only)");
   const Grid &g = c->g;
   PtToThetaV kf{g, hydrostatic, zvir, kappa, -rdgas / grav, pt, delp, delz, qv, pkz};
   Dim3 grid;
@@ -1130,6 +1133,60 @@ extern "C" int fv3_pt_to_theta_v(fv3_ctx *c, int hydrostatic, double zvir, doubl
   grid.y = 1;
   grid.z = (unsigned)g.npz;
   RT(launch_p(c, "pt_to_theta_v", grid, 0, kf));
+  return 0;
+}
+
+extern "C" int fv3_c2l(fv3_ctx *c, int ord, const double *u, const double *v, double *ua, double *va) {
+  if (!c || !c->grid_ready) return fail("fv3_c2l: context has no grid");
+  if (!u || !v || !ua || !va) return fail("fv3_c2l: null field");
+  if (ord != 2 && ord != 4) return fail("fv3_c2l: c2l_ord must be 2 or 4");
+  const Grid &g = c->g;
+  if (g.grid_type < 4) return fail("fv3_c2l: only the Cartesian (grid_type = 4) branches are built");
+  C2L kf{g, ord, 1, u, v, nullptr, ua, va, nullptr};
+  Dim3 grid;
+  grid.x = (unsigned)((g.nx * g.ny + C2L::CH - 1) / C2L::CH);
+  grid.y = 1;
+  grid.z = (unsigned)g.npz;
+  RT(launch_p(c, "c2l", grid, 0, kf));
+  return 0;
+}
+
+extern "C" int fv3_rayleigh_u2f(fv3_ctx *c, int kmax, int hydrostatic, const double *u, const double *v,
+                                const double *w, double *ua, double *va, double *u2f) {
+  if (!c || !c->grid_ready) return fail("fv3_rayleigh_u2f: context has no grid");
+  if (!u || !v || !ua || !va || !u2f || (!hydrostatic && !w)) return fail("fv3_rayleigh_u2f: null field");
+  const Grid &g = c->g;
+  if (g.grid_type < 4) return fail("fv3_rayleigh_u2f: only the Cartesian (grid_type = 4) branch is built");
+  if (kmax < 0 || kmax > g.npz) return fail("fv3_rayleigh_u2f: kmax out of range");
+  if (kmax == 0) return 0;
+  C2L kf{g, 2, hydrostatic, u, v, w, ua, va, u2f};
+  Dim3 grid;
+  grid.x = (unsigned)((g.nx * g.ny + C2L::CH - 1) / C2L::CH);
+  grid.y = 1;
+  grid.z = (unsigned)kmax;
+  RT(launch_p(c, "rayleigh_u2f", grid, 0, kf));
+  return 0;
+}
+
+extern "C" int fv3_rayleigh_apply(fv3_ctx *c, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,
+                                  const double *pm, const double *rf, const double *u2f, double *pt, double *delz,
+                                  double *u, double *v, double *w) {
+  if (!c || !c->grid_ready) return fail("fv3_rayleigh_apply: context has no grid");
+  if (!pm || !rf || !u2f || !pt || !u || !v || (!hydrostatic && (!w || !delz)))
+    return fail("fv3_rayleigh_apply: null argument");
+  const Grid &g = c->g;
+  if (kmax < 0 || kmax > g.npz) return fail("fv3_rayleigh_apply: kmax out of range");
+  if (kmax == 0) return 0;
+  if (!c->ray_d) RT(rt_malloc((void **)&c->ray_d, sizeof(double) * 2 * g.npz));
+  RT(rt_h2d(c->ray_d, pm, sizeof(double) * kmax, c->stream));
+  RT(rt_h2d(c->ray_d + g.npz, rf, sizeof(double) * kmax, c->stream));
+  RT(rt_sync(c->stream));  // pm / rf are the caller's host arrays
+  RayleighApply kf{g, conserve, hydrostatic, cp, rg, ptop, c->ray_d, c->ray_d + g.npz, u2f, pt, delz, u, v, w};
+  Dim3 grid;
+  grid.x = (unsigned)(((g.nx + 1) * (g.ny + 1) + RayleighApply::CH - 1) / RayleighApply::CH);
+  grid.y = 1;
+  grid.z = (unsigned)kmax;
+  RT(launch_p(c, "rayleigh_apply", grid, 0, kf));
   return 0;
 }
 

@@ -933,7 +933,7 @@ struct CopyAtoCC {  // compute-domain copy of an A-kind field into a CC-kind one
 
 struct PtToThetaV {  // fv_dynamics.F90:296-329, :379-399 (use_cond = moist_kappa = .false.)
   Grid g;
-  int hydrostatic;
+  int hydrostatic;  // 1: pkz given; 0: pkz computed, pt converted; -1: pkz computed only (:323-326; Rayleigh_Friction follows)
   double zvir, kappa, rdg;
   double *pt;
   const double *delp, *delz, *qv;
@@ -946,13 +946,94 @@ struct PtToThetaV {  // fv_dynamics.F90:296-329, :379-399 (use_cond = moist_kapp
       const size_t o = (size_t)bz * g.nA() + g.iA(i, j), c = (size_t)bz * g.nCC() + idx;
       const double dp1 = qv ? zvir * qv[o] : 0.;
       double pz;
-      if (hydrostatic) {
+      if (hydrostatic > 0) {
         pz = pkz[c];
       } else {
         pz = exp(kappa * log(rdg * delp[o] * pt[o] * (1. + dp1) / delz[c]));
         pkz[c] = pz;
       }
-      pt[o] = pt[o] * (1. + dp1) / pz;
+      if (hydrostatic >= 0) pt[o] = pt[o] * (1. + dp1) / pz;
+    }
+  }
+};
+
+// cubed_to_latlon on a Cartesian domain (grid_type >= 4): c2l_ord2 (fv_grid_utils.F90:2551-2558) or c2l_ord4 (:2468-2475;
+// the halo of u, v must be current).  With u2f != nullptr also the squared wind speed of Rayleigh_Friction
+// (fv_dynamics.F90:1190-1205).
+struct C2L {
+  Grid g;
+  int ord, hydrostatic;
+  const double *u, *v, *w;
+  double *ua, *va, *u2f;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    constexpr double a1 = 0.5625, a2 = -0.0625;
+    const int n = g.nx * g.ny;
+    const double *uk = u + (size_t)bz * g.nU(), *vk = v + (size_t)bz * g.nV();
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.is + idx % g.nx, j = g.js + idx / g.nx;
+      const size_t o = (size_t)bz * g.nA() + g.iA(i, j);
+      double a, b;
+      if (ord == 2) {
+        a = 0.5 * (uk[g.iU(i, j)] + uk[g.iU(i, j + 1)]);
+        b = 0.5 * (vk[g.iV(i, j)] + vk[g.iV(i + 1, j)]);
+      } else {
+        a = a2 * (uk[g.iU(i, j - 1)] + uk[g.iU(i, j + 2)]) + a1 * (uk[g.iU(i, j)] + uk[g.iU(i, j + 1)]);
+        b = a2 * (vk[g.iV(i - 1, j)] + vk[g.iV(i + 2, j)]) + a1 * (vk[g.iV(i, j)] + vk[g.iV(i + 1, j)]);
+      }
+      ua[o] = a;
+      va[o] = b;
+      if (u2f) u2f[o] = hydrostatic ? a * a + b * b : a * a + b * b + w[o] * w[o];
+    }
+  }
+};
+
+// Rayleigh_Friction after the halo update of u2f (fv_dynamics.F90:1211-1260): frictional heating and the implicit
+// damping of u, v, w on the levels above rf_cutoff.  The reference overwrites its local u2f with rf*sqrt(u2f/u000) on
+// is-1:ie+1; here that value is formed where it is used and u2f stays an input.
+struct RayleighApply {
+  Grid g;
+  int conserve, hydrostatic;
+  double cp, rg, ptop;
+  const double *pm, *rf;  // device, kmax
+  const double *u2f;
+  double *pt, *delz, *u, *v, *w;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    constexpr double u000 = 4900.;
+    const int wdt = g.nx + 1, n = wdt * (g.ny + 1);
+    const double rfk = rf[bz], rcv = 1. / (cp - rg);
+    const double *f = u2f + (size_t)bz * g.nA();
+    auto damp = [&](int i, int j) { return rfk * sqrt(f[g.iA(i, j)] / u000); };
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.is + idx % wdt, j = g.js + idx / wdt;
+      const bool in_i = i <= g.ie, in_j = j <= g.je;
+      const double d0 = damp(i, j);
+      if (in_i && in_j) {
+        const size_t o = (size_t)bz * g.nA() + g.iA(i, j);
+        if (conserve) {
+          const double x = f[g.iA(i, j)];
+          const double d = 1. + d0;
+          if (hydrostatic) {
+            pt[o] = pt[o] + 0.5 * x / (cp - rg * ptop / pm[bz]) * (1. - 1. / (d * d));
+          } else {
+            const size_t c = (size_t)bz * g.nCC() + g.iCC(i, j);
+            const double dz = delz[c] / pt[o];
+            const double t = pt[o] + 0.5 * x * rcv * (1. - 1. / (d * d));
+            pt[o] = t;
+            delz[c] = dz * t;
+          }
+        }
+        if (!hydrostatic) w[o] = w[o] / (1. + d0);
+      }
+      if (in_i) {
+        const size_t ou = (size_t)bz * g.nU() + g.iU(i, j);
+        u[ou] = u[ou] / (1. + 0.5 * (damp(i, j - 1) + d0));
+      }
+      if (in_j) {
+        const size_t ov = (size_t)bz * g.nV() + g.iV(i, j);
+        v[ov] = v[ov] / (1. + 0.5 * (damp(i - 1, j) + d0));
+      }
     }
   }
 };

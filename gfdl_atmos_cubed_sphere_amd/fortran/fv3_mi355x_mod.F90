@@ -18,6 +18,7 @@ module fv3_mi355x_mod
   public :: fv3_heat_source_accum, fv3_del2_cubed, fv3_apply_heat_source
   public :: fv3_d_sw_interior, fv3_d_sw_rest
   public :: fv3_divg2_ext, fv3_one_grad_p, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
+  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply
 
   type, bind(C) :: fv3_domain
     integer(c_int) :: is, ie, js, je, ng, npx, npy, npz, grid_type
@@ -199,6 +200,24 @@ module fv3_mi355x_mod
       type(c_ptr), value :: ctx, pt, delp, delz, qv, pkz
       integer(c_int), value :: hydrostatic
       real(c_double), value :: zvir, kappa, rdgas, grav
+    end function
+    integer(c_int) function fv3_c2l(ctx, c2l_ord, u, v, ua, va) bind(C, name="fv3_c2l")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx, u, v, ua, va
+      integer(c_int), value :: c2l_ord
+    end function
+    integer(c_int) function fv3_rayleigh_u2f(ctx, kmax, hydrostatic, u, v, w, ua, va, u2f) bind(C, name="fv3_rayleigh_u2f")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx, u, v, w, ua, va, u2f
+      integer(c_int), value :: kmax, hydrostatic
+    end function
+    integer(c_int) function fv3_rayleigh_apply(ctx, kmax, conserve, hydrostatic, cp, rg, ptop, pm, rf, u2f, pt, delz, &
+                                               u, v, w) bind(C, name="fv3_rayleigh_apply")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, u2f, pt, delz, u, v, w
+      integer(c_int), value :: kmax, conserve, hydrostatic
+      real(c_double), value :: cp, rg, ptop
+      real(c_double), intent(in) :: pm(*), rf(*)
     end function
     integer(c_int) function fv3_divg2_ext(ctx, d_ext, delp, vt, divg2) bind(C, name="fv3_divg2_ext")
       import :: c_int, c_ptr, c_double

@@ -2,8 +2,10 @@
 ``fv_dynamics`` (model/fv_dynamics.F90:460-665): for each remapping cycle the acoustic substeps (``dyn_core``),
 the sub-cycled tracer transport (``tracer_2d``) and the vertical remap (``Lagrangian_to_Eulerian``).
 
-The state is expected in the form ``dyn_core`` works on (pt = theta_v, delz < 0); the T <-> theta_v conversions
-and diagnostics around the loop (fv_dynamics.F90:284-399, 669-803) are SURVEY section 8(f) "next" items.
+``step`` expects the state in the form ``dyn_core`` works on (pt = theta_v, delz < 0); ``step_from_temperature`` is a whole
+``fv_dynamics`` call of the adiabatic core on a Cartesian domain: T -> theta_v (fv_dynamics.F90:296-399), Rayleigh_Friction
+when tau > 0 (:368-376, :1126-1264), the k_split loop, theta_v -> T in the last remap, cubed_to_latlon (:911).
+compute_total_energy / consv_te, the angular-momentum fixer and the diagnostics are SURVEY section 8(f) items not built.
 """
 from __future__ import annotations
 
@@ -17,11 +19,15 @@ from .tracer2d import tracer_2d
 class FvDynamics:
     def __init__(self, ctx: Context, flags: DynFlags, ak, bk, nq: int = 0, k_split: int = 1, kord_tm: int = -8,
                  kord_mt: int = 8, kord_wz: int = 8, kord_tr: int = 8, q_split: int = 0, nord_tr: int = 0, trdm2: float = 0.0, adiabatic: bool = True,
-                 px: int = 1, py: int = 1, rank: int = 0, world: int = 1, dist=None):
+                 px: int = 1, py: int = 1, rank: int = 0, world: int = 1, dist=None, tau: float = 0.0,
+                 rf_cutoff: float = 30.0e2, c2l_ord: int = 4):
         ak, bk = np.asarray(ak, dtype=np.float64), np.asarray(bk, dtype=np.float64)
         dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5          # dyn_core.F90:241-244
         self.ctx, self.fl, self.nq, self.k_split, self.q_split, self.dist = ctx, flags, nq, k_split, q_split, dist
         self.nord_tr, self.trdm2 = nord_tr, trdm2
+        self.tau, self.rf_cutoff, self.c2l_ord = tau, rf_cutoff, c2l_ord
+        self.ak, self.bk = ak, bk
+        self._rf = None                                                    # (rf, pm, kmax): set on first use, as RF_initialized
         self.dc = DynCore(ctx, flags, dp_ref, px, py, rank, world)
         ctx.set_ak_bk(ak, bk)
         npz = ctx.npz
@@ -45,9 +51,56 @@ class FvDynamics:
         does (fv_mapz.F90:793-821, last_step)."""
         d, ctx, fl = self.dc.d, self.ctx, self.fl
         qv = d["q"].ptr if (self.nq and self.remap_par["sphum"] > 0 and not self.remap_par["adiabatic"]) else None
-        ctx.pt_to_theta_v(fl.hydrostatic, self.remap_par["r_vir"] if qv else 0.0, fl.akap, fl.rdgas, fl.grav, d["pt"],
-                          d["delp"], None if fl.hydrostatic else d["delz"], qv, d["pkz"])
+        zvir = self.remap_par["r_vir"] if qv else 0.0
+        conv = lambda mode: ctx.pt_to_theta_v(mode, zvir, fl.akap, fl.rdgas, fl.grav, d["pt"], d["delp"],
+                                              None if fl.hydrostatic else d["delz"], qv, d["pkz"])
+        if self.tau > 0.0:                                                 # :368-376 (grid_type = 4: Rayleigh_Friction)
+            if not fl.hydrostatic:
+                conv(-1)                                                   # pkz from the T, delz before the friction (:323-326)
+            self.rayleigh_friction(bdt)
+            conv(1)                                                        # :389-397 with that pkz
+        else:
+            conv(int(fl.hydrostatic))
         self.step(bdt, last_cycle_is_last_step=True)
+        self.cubed_to_latlon()                                             # :911
+
+    def rayleigh_profile(self, dt: float):
+        """rf(k), kmax of Rayleigh_Friction (fv_dynamics.F90:1169-1182) with pfull of fv_dynamics.F90:254-262 (p_ref = 1e5)"""
+        ak, bk, ptop, akap = self.ak, self.bk, self.fl.ptop, self.fl.akap
+        ph = ak + bk * 1.0e5
+        pfull = (ph[1:] - ph[:-1]) / np.log(ph[1:] / ph[:-1])
+        rf = np.zeros(len(pfull))
+        kmax = 0
+        for k, pm in enumerate(pfull):
+            if pm < self.rf_cutoff:
+                rf[k] = dt / (self.tau * 86400.0) * np.sin(0.5 * np.pi * np.log(self.rf_cutoff / pm) / np.log(self.rf_cutoff / ptop)) ** 2
+                kmax = k + 1
+            else:
+                break
+        return rf, pfull, kmax
+
+    def rayleigh_friction(self, bdt: float, conserve: bool = True):
+        """Rayleigh_Friction (fv_dynamics.F90:1126-1264): two kernels around the halo update of u2f"""
+        d, ctx, fl = self.dc.d, self.ctx, self.fl
+        if self._rf is None:
+            self._rf = self.rayleigh_profile(abs(bdt))
+        rf, pm, kmax = self._rf
+        if kmax == 0:
+            return
+        if "u2f" not in d:
+            d["u2f"] = ctx.zeros("A", ctx.npz)
+        hyd = fl.hydrostatic
+        ctx.rayleigh_u2f(kmax, hyd, d["u"], d["v"], None if hyd else d["w"], d["ua"], d["va"], d["u2f"])
+        self.dc.halo.update([(d["u2f"], "A")])                             # :1207-1209
+        ctx.rayleigh_apply(kmax, conserve, hyd, fl.cp_air, fl.rdgas, fl.ptop, pm[:kmax], rf[:kmax], d["u2f"], d["pt"],
+                           None if hyd else d["delz"], d["u"], d["v"], None if hyd else d["w"])
+
+    def cubed_to_latlon(self):
+        """A-grid winds for the physics (fv_dynamics.F90:911; c2l_ord4 updates the halo of u, v first, :2372-2376)"""
+        d = self.dc.d
+        if self.c2l_ord == 4:
+            self.dc.halo.update([(d["u"], "U"), (d["v"], "V")])
+        self.ctx.c2l(self.c2l_ord, d["u"], d["v"], d["ua"], d["va"])
 
     def step(self, bdt: float, last_cycle_is_last_step: bool = False):
         """One dt_atmos: k_split x (n_split acoustic substeps, tracer transport, vertical remap)."""

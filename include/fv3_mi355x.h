@@ -273,10 +273,29 @@ int fv3_apply_heat_source(fv3_ctx *ctx, int n_con, int hydrostatic, double bdt, 
                           double cv_air, double rdgas, double grav, double *pt, double *heat_source, const double *delp,
                           const double *delz, double *pkz);
 
+/* ---- fv_dynamics around the k_split loop, Cartesian (grid_type = 4) branches -------------------------------------
+ * fv3_c2l = cubed_to_latlon (model/fv_grid_utils.F90:2319): c2l_ord = 2 -> c2l_ord2 (:2551-2558), 4 -> c2l_ord4
+ *   (:2468-2475; the halo update of u, v that the reference does first with mode > 0, :2372-2376, is the caller's).
+ *   u: U x npz, v: V x npz in; ua, va: A x npz out on the compute domain.  Called at fv_dynamics.F90:911.
+ * Rayleigh_Friction (model/fv_dynamics.F90:1126-1264; the branch of :368-376 for grid_type = 4) is two calls around
+ *   the halo update of u2f (:1207-1209), which the caller performs with its halo exchanger:
+ *   fv3_rayleigh_u2f: ua, va by c2l_ord2 and u2f = ua^2 + va^2 (+ w^2) on levels 1..kmax (:1186-1205);
+ *   fv3_rayleigh_apply: frictional heating of pt (and delz) if conserve, then u, v, w /= 1 + rf(k)*sqrt(u2f/4900)
+ *   averaged to their points (:1211-1260).  pm, rf: HOST arrays of length kmax (layer-mean pressure and the damping
+ *   profile of :1169-1182, which the caller evaluates once); u2f: A x kmax, read only; cp = cp_air, rg = rdgas. */
+int fv3_c2l(fv3_ctx *ctx, int c2l_ord, const double *u, const double *v, double *ua, double *va);
+int fv3_rayleigh_u2f(fv3_ctx *ctx, int kmax, int hydrostatic, const double *u, const double *v, const double *w,
+                     double *ua, double *va, double *u2f);
+int fv3_rayleigh_apply(fv3_ctx *ctx, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,
+                       const double *pm, const double *rf, const double *u2f, double *pt, double *delz, double *u,
+                       double *v, double *w);
+
 /* ---- fv_dynamics: T -> theta_v before the k_split loop (model/fv_dynamics.F90:284-329, :379-399; use_cond =
  * moist_kappa = .false.).  nonhydrostatic: pkz = exp(kappa*log(rdg*delp*pt*(1+zvir*qv)/delz)) is (re)computed;
  * hydrostatic: pkz is taken as given (p_var / the previous remap).  Then pt = pt*(1+zvir*qv)/pkz on the compute
- * domain.  qv: A x npz specific humidity or NULL (dry: zvir*qv = 0).  The way back (theta_v -> T) is part of
+ * domain.  hydrostatic = -1: only pkz is computed and pt is left alone -- the reference evaluates pkz (:323-326) before
+ * Rayleigh_Friction changes T and delz and converts afterwards with that pkz (:389-397): call with -1, apply the
+ * friction, call with 1.  qv: A x npz specific humidity or NULL (dry: zvir*qv = 0).  The way back (theta_v -> T) is part of
  * fv3_lagrangian_to_eulerian with last_step = 1, as in the reference (fv_mapz.F90:793-821). */
 int fv3_pt_to_theta_v(fv3_ctx *ctx, int hydrostatic, double zvir, double kappa, double rdgas, double grav, double *pt,
                       const double *delp, const double *delz, const double *qv, double *pkz);

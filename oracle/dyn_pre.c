@@ -1,0 +1,113 @@
+/*
+ * oracle/dyn_pre.c -- CPU oracle (test infrastructure, see fvo.h) for the pieces of fv_dynamics around the
+ * k_split loop that touch the prognostic state on a doubly periodic domain (grid_type = 4):
+ *   cubed_to_latlon   tools-free part of model/fv_grid_utils.F90:2319-2561 (c2l_ord2 :2551-2558 and
+ *                     c2l_ord4 :2468-2475, the "simple Cartesian geometry" branches)
+ *   Rayleigh_Friction model/fv_dynamics.F90:1126-1264 (the branch fv_dynamics takes for grid_type = 4,
+ *                     :368-376), split at the halo update of u2f (:1207-1209) that the caller performs
+ * Plain IEEE evaluation of the reference's expressions, no FMA contraction.
+ */
+#include "fvo.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+#define BOUNDS(g)                                                                         \
+  const int is = (g)->is, ie = (g)->ie, js = (g)->js, je = (g)->je;                       \
+  const int isd = (g)->isd, ied = (g)->ied, jsd = (g)->jsd, jed = (g)->jed;               \
+  const int nid = ied - isd + 1, njd = jed - jsd + 1, nx = ie - is + 1, ny = je - js + 1; \
+  (void)nx; (void)ny; (void)ied; (void)jed
+#define A3(i, j, k) ((size_t)((k)-1) * nid * njd + (size_t)((j)-jsd) * nid + ((i)-isd))
+#define U3(i, j, k) ((size_t)((k)-1) * nid * (njd + 1) + (size_t)((j)-jsd) * nid + ((i)-isd))
+#define V3(i, j, k) ((size_t)((k)-1) * (nid + 1) * njd + (size_t)((j)-jsd) * (nid + 1) + ((i)-isd))
+#define CC3(i, j, k) ((size_t)((k)-1) * nx * ny + (size_t)((j)-js) * nx + ((i)-is))
+
+/* cubed_to_latlon for grid_type >= 4.  ord 2: c2l_ord2 (:2551-2558); ord 4: c2l_ord4 (:2468-2475), which needs the
+ * halo of u, v up to date (the reference's mode > 0 update, :2372-2376, is the caller's).  u: U x km, v: V x km,
+ * ua, va: A x km (written on is:ie, js:je). */
+int fvo_c2l(const fvo_grid *g, int km, int ord, const double *u, const double *v, double *ua, double *va) {
+  BOUNDS(g);
+  const double a1 = 0.5625, a2 = -0.0625;
+  int i, j, k;
+  if (g->grid_type < 4) return FVO_ERR_UNSUPPORTED;
+  for (k = 1; k <= km; k++)
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie; i++) {
+        if (ord == 2) {
+          ua[A3(i, j, k)] = 0.5 * (u[U3(i, j, k)] + u[U3(i, j + 1, k)]);
+          va[A3(i, j, k)] = 0.5 * (v[V3(i, j, k)] + v[V3(i + 1, j, k)]);
+        } else {
+          ua[A3(i, j, k)] = a2 * (u[U3(i, j - 1, k)] + u[U3(i, j + 2, k)]) + a1 * (u[U3(i, j, k)] + u[U3(i, j + 1, k)]);
+          va[A3(i, j, k)] = a2 * (v[V3(i - 1, j, k)] + v[V3(i + 2, j, k)]) + a1 * (v[V3(i, j, k)] + v[V3(i + 1, j, k)]);
+        }
+      }
+  return FVO_OK;
+}
+
+/* the damping profile rf(k) and kmax (fv_dynamics.F90:1169-1182); pm: layer-mean pressure (npz).  Returns kmax. */
+int fvo_rayleigh_rf(int npz, double dt, double tau, double rf_cutoff, double ptop, const double *pm, double *rf) {
+  const double sday = 86400., pi = 3.1415926535897931; /* constants_mod PI */
+  int k, kmax = 0;
+  for (k = 1; k <= npz; k++) {
+    if (pm[k - 1] < rf_cutoff) {
+      const double s = sin(0.5 * pi * log(rf_cutoff / pm[k - 1]) / log(rf_cutoff / ptop));
+      rf[k - 1] = dt / (tau * sday) * (s * s);
+      kmax = k;
+    } else {
+      break;
+    }
+  }
+  return kmax;
+}
+
+/* :1186-1205: A-grid winds (c2l_ord2) and the squared wind speed u2f on is:ie, js:je for k <= kmax.  u2f: A x kmax. */
+int fvo_rayleigh_u2f(const fvo_grid *g, int kmax, int hydrostatic, const double *u, const double *v, const double *w,
+                     double *ua, double *va, double *u2f) {
+  BOUNDS(g);
+  int i, j, k, rc;
+  if ((rc = fvo_c2l(g, kmax, 2, u, v, ua, va)) != FVO_OK) return rc;
+  for (k = 1; k <= kmax; k++)
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie; i++) {
+        const double a = ua[A3(i, j, k)], b = va[A3(i, j, k)];
+        u2f[A3(i, j, k)] = hydrostatic ? a * a + b * b : a * a + b * b + w[A3(i, j, k)] * w[A3(i, j, k)];
+      }
+  return FVO_OK;
+}
+
+/* :1211-1260 with the halo of u2f filled by the caller: frictional heating (conserve) and the implicit damping of
+ * u, v, w.  u2f is overwritten with rf*sqrt(u2f/u000) on is-1:ie+1, js-1:je+1 as in the reference. */
+int fvo_rayleigh_apply(const fvo_grid *g, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,
+                       const double *pm, const double *rf, double *u2f, double *pt, double *delz, double *u, double *v,
+                       double *w) {
+  BOUNDS(g);
+  const double u000 = 4900., rcv = 1. / (cp - rg);
+  int i, j, k;
+  for (k = 1; k <= kmax; k++) {
+    const double rfk = rf[k - 1];
+    if (conserve) {
+      for (j = js; j <= je; j++)
+        for (i = is; i <= ie; i++) {
+          const double x = u2f[A3(i, j, k)];
+          const double d = 1. + rfk * sqrt(x / u000);
+          if (hydrostatic) {
+            pt[A3(i, j, k)] = pt[A3(i, j, k)] + 0.5 * x / (cp - rg * ptop / pm[k - 1]) * (1. - 1. / (d * d));
+          } else {
+            delz[CC3(i, j, k)] = delz[CC3(i, j, k)] / pt[A3(i, j, k)];
+            pt[A3(i, j, k)] = pt[A3(i, j, k)] + 0.5 * x * rcv * (1. - 1. / (d * d));
+            delz[CC3(i, j, k)] = delz[CC3(i, j, k)] * pt[A3(i, j, k)];
+          }
+        }
+    }
+    for (j = js - 1; j <= je + 1; j++)
+      for (i = is - 1; i <= ie + 1; i++) u2f[A3(i, j, k)] = rfk * sqrt(u2f[A3(i, j, k)] / u000);
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie; i++) u[U3(i, j, k)] = u[U3(i, j, k)] / (1. + 0.5 * (u2f[A3(i, j - 1, k)] + u2f[A3(i, j, k)]));
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie + 1; i++) v[V3(i, j, k)] = v[V3(i, j, k)] / (1. + 0.5 * (u2f[A3(i - 1, j, k)] + u2f[A3(i, j, k)]));
+    if (!hydrostatic)
+      for (j = js; j <= je; j++)
+        for (i = is; i <= ie; i++) w[A3(i, j, k)] = w[A3(i, j, k)] / (1. + u2f[A3(i, j, k)]);
+  }
+  return FVO_OK;
+}

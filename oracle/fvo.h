@@ -194,4 +194,13 @@ int fvo_tracer_2d(const fvo_grid *g, int npz, int nq, double *q, double *dp1, do
 #ifdef __cplusplus
 }
 #endif
+/* ---- fv_dynamics around the k_split loop (oracle/dyn_pre.c) ------------------------------------- */
+int fvo_c2l(const fvo_grid *g, int km, int ord, const double *u, const double *v, double *ua, double *va);
+int fvo_rayleigh_rf(int npz, double dt, double tau, double rf_cutoff, double ptop, const double *pm, double *rf);
+int fvo_rayleigh_u2f(const fvo_grid *g, int kmax, int hydrostatic, const double *u, const double *v, const double *w,
+                     double *ua, double *va, double *u2f);
+int fvo_rayleigh_apply(const fvo_grid *g, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,
+                       const double *pm, const double *rf, double *u2f, double *pt, double *delz, double *u, double *v,
+                       double *w);
+
 #endif

@@ -288,3 +288,36 @@ def tracer_2d(g, npz, nq, q, dp1, mfx, mfy, cx, cy, hord, q_split, nord_tr, trdm
                              C.c_int(hord), C.c_int(q_split), C.c_int(nord_tr), _d(trdm))
     assert rc > 0, rc
     return rc
+
+
+# ---- fv_dynamics around the k_split loop (oracle/dyn_pre.c) -----------------------------------------
+def c2l(g, km, ord_, u, v, ua, va):
+    gs = make_grid(g)
+    assert lib().fvo_c2l(C.byref(gs), C.c_int(km), C.c_int(ord_), p(u), p(v), p(ua), p(va)) == 0
+
+
+def rayleigh_rf(npz, dt, tau, rf_cutoff, ptop, pm):
+    """-> (rf[npz], kmax)  (fv_dynamics.F90:1169-1182)"""
+    import numpy as np
+    pm = np.ascontiguousarray(pm, dtype=np.float64)
+    rf = np.zeros(npz)
+    fn = lib().fvo_rayleigh_rf
+    fn.restype = C.c_int
+    kmax = fn(C.c_int(npz), _d(dt), _d(tau), _d(rf_cutoff), _d(ptop), p(pm), p(rf))
+    return rf, int(kmax)
+
+
+def rayleigh_u2f(g, kmax, hydrostatic, u, v, w, ua, va, u2f):
+    gs = make_grid(g)
+    assert lib().fvo_rayleigh_u2f(C.byref(gs), C.c_int(kmax), C.c_int(int(hydrostatic)), p(u), p(v),
+                                  p(w) if w is not None else None, p(ua), p(va), p(u2f)) == 0
+
+
+def rayleigh_apply(g, kmax, conserve, hydrostatic, cp, rg, ptop, pm, rf, u2f, pt, delz, u, v, w):
+    import numpy as np
+    gs = make_grid(g)
+    pm = np.ascontiguousarray(pm, dtype=np.float64)
+    rf = np.ascontiguousarray(rf, dtype=np.float64)
+    assert lib().fvo_rayleigh_apply(C.byref(gs), C.c_int(kmax), C.c_int(int(conserve)), C.c_int(int(hydrostatic)), _d(cp),
+                                    _d(rg), _d(ptop), p(pm), p(rf), p(u2f), p(pt), p(delz) if delz is not None else None,
+                                    p(u), p(v), p(w) if w is not None else None) == 0

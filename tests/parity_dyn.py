@@ -5,6 +5,7 @@ from __future__ import annotations
 import numpy as np
 
 import oracle_dyn_core as OD
+import oracle_lib as O
 import parity_common as P
 import parity_nh as N
 from fields import smooth_state
@@ -158,7 +159,7 @@ def oracle_fv_step(g, npz, fl, dp0, st, ak, bk, q, bdt, k_split, remap_par, last
     return out
 
 
-def check_fv_cycle_from_temperature(lib, nx=24, ny=16, npz=10, k_split=2, n_split=2, bdt=8.0):
+def check_fv_cycle_from_temperature(lib, nx=24, ny=16, npz=10, k_split=2, n_split=2, bdt=8.0, tau=0.0):
     """A whole adiabatic fv_dynamics call: T -> theta_v (fv_dynamics.F90:284-399), k_split loop, last remap back to T.
     Oracle side: the same conversion in numpy, then the oracle-orchestrated loop with last_step on the final cycle."""
     from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
@@ -184,15 +185,47 @@ def check_fv_cycle_from_temperature(lib, nx=24, ny=16, npz=10, k_split=2, n_spli
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
     dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
     fl = DynFlags(n_split=n_split, ptop=N.PTOP)
+    rf_cutoff = 0.5 * (ak[npz // 2] + bk[npz // 2] * 1.0e5)          # the upper half of the column is damped
+    ost = dict(st, pt=th2)
+    if tau > 0.0:
+        # Rayleigh_Friction between the pkz evaluation and the conversion (fv_dynamics.F90:323-326, :368-376, :389-397)
+        from gfdl_atmos_cubed_sphere_amd.layout import periodic_fill
+        ph = ak + bk * 1.0e5
+        pfull = (ph[1:] - ph[:-1]) / np.log(ph[1:] / ph[:-1])
+        rf, kmax = O.rayleigh_rf(npz, abs(bdt), tau, rf_cutoff, N.PTOP, pfull)
+        assert 0 < kmax < npz
+        o_u, o_v, o_w = st["u"].copy(order="F"), st["v"].copy(order="F"), st["w"].copy(order="F")
+        o_T, o_dz = T.copy(order="F"), st["delz"].copy(order="F")
+        o_ua, o_va, o_u2f = bd.zeros("A", npz), bd.zeros("A", npz), bd.zeros("A", kmax)
+        O.rayleigh_u2f(g, kmax, False, o_u, o_v, o_w, o_ua, o_va, o_u2f)
+        for k in range(kmax):
+            periodic_fill(bd, o_u2f[:, :, k], "A")
+        O.rayleigh_apply(g, kmax, True, False, fl.cp_air, fl.rdgas, N.PTOP, pfull, rf, o_u2f, o_T, o_dz, o_u, o_v, o_w)
+        th3 = o_T.copy(order="F")
+        th3[ng:ng + nx, ng:ng + ny, :] = bd.view(o_T, "A", *r) * (1.0 + 0.0) / pkz
+        for a, kind in ((o_u, "U"), (o_v, "V"), (o_w, "A"), (th3, "A")):
+            for k in range(npz):
+                periodic_fill(bd, a[:, :, k], kind)
+        ost = dict(st, u=o_u, v=o_v, w=o_w, pt=th3, delz=o_dz)
     ctx = Context(g, npz, lib=lib)
     try:
-        fv = FvDynamics(ctx, fl, ak, bk, nq=0, k_split=k_split)
-        ref = oracle_fv_step(g, npz, fl, dp_ref, dict(st, pt=th2), ak, bk, None, bdt, k_split, fv.remap_par, last_step=True)
+        fv = FvDynamics(ctx, fl, ak, bk, nq=0, k_split=k_split, tau=tau, rf_cutoff=rf_cutoff)
+        ref = oracle_fv_step(g, npz, fl, dp_ref, ost, ak, bk, None, bdt, k_split, fv.remap_par, last_step=True)
         fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], T, st["delz"], st["phis"])
         fv.step_from_temperature(bdt)
         d = fv.dc.d
         emu = "hostemu" in lib.path
         out = {}
+        # cubed_to_latlon at the end (fv_dynamics.F90:911): c2l_ord4 of the final winds after their halo update
+        from gfdl_atmos_cubed_sphere_amd.layout import periodic_fill as pfill
+        fu, fvv = d["u"].download(), d["v"].download()
+        for k in range(npz):
+            pfill(bd, fu[:, :, k], "U")
+            pfill(bd, fvv[:, :, k], "V")
+        r_ua, r_va = bd.zeros("A", npz), bd.zeros("A", npz)
+        O.c2l(g, npz, 4, fu, fvv, r_ua, r_va)
+        for n, refa in (("ua", r_ua), ("va", r_va)):
+            out[n] = P.assert_close(n, bd.view(d[n].download(), "A", *r), bd.view(refa, "A", *r), 1e-13)
         # the T -> theta_v conversion goes through exp/log of a different math library on each side (numpy vs libm /
         # device): 1-ulp differences there, and w sits on its conditioning floor (see check_substeps)
         for n, kind, tol in (("pt", "A", 1e-12), ("delp", "A", 1e-12), ("w", "A", 1e-10)):

@@ -326,3 +326,74 @@ def check_one_grad_p(lib, nx=40, ny=19, km=5, d_ext=0.02):
                        bd.view(o["v"], "V", bd.is_, bd.ie + 1, bd.js, bd.je), _tol(lib))
     finally:
         ctx.close()
+
+
+def check_c2l_and_rayleigh(lib, nx=70, ny=33, km=12, hydrostatic=False, conserve=True, tau=0.02, rf_cutoff=30.e2):
+    """cubed_to_latlon (c2l_ord 2 and 4) and Rayleigh_Friction (grid_type = 4 branches) against the oracle"""
+    from gfdl_atmos_cubed_sphere_amd.layout import periodic_fill
+    from fields import smooth_state
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    st = smooth_state(bd, km, hydrostatic=hydrostatic, noise=0.05)
+    rng = np.random.default_rng(21)
+    ptop = 100.0
+    pm = ptop * np.exp(np.linspace(0.1, 5.0, km))          # layer-mean pressures, increasing downwards
+    dt = 225.0
+    rf, kmax = O.rayleigh_rf(km, dt, tau, rf_cutoff, ptop, pm)
+    assert 0 < kmax < km
+    u, v, pt = st["u"].copy(order="F"), st["v"].copy(order="F"), st["pt"].copy(order="F")
+    w = None if hydrostatic else np.asfortranarray(st["w"] * 10.0)
+    for a, kind in ((u, "U"), (v, "V")):
+        a *= 6.0                                              # strong winds: a damping of a few per cent
+        for k in range(km):
+            periodic_fill(bd, a[:, :, k], kind)
+    delz = None if hydrostatic else np.asfortranarray(-rng.uniform(200., 400., bd.shape("CC", km)))
+    r = (bd.is_, bd.ie, bd.js, bd.je)
+    tol = 1e-14 if "hostemu" in lib.path else 1e-13
+    # ---- oracle ----
+    ref = {}
+    for o in (2, 4):
+        ua, va = bd.zeros("A", km), bd.zeros("A", km)
+        O.c2l(g, km, o, u, v, ua, va)
+        ref[o] = (ua, va)
+    r_u, r_v, r_pt = u.copy(order="F"), v.copy(order="F"), pt.copy(order="F")
+    r_w = None if hydrostatic else w.copy(order="F")
+    r_dz = None if hydrostatic else delz.copy(order="F")
+    r_ua, r_va, r_u2f = bd.zeros("A", km), bd.zeros("A", km), bd.zeros("A", kmax)
+    O.rayleigh_u2f(g, kmax, hydrostatic, r_u, r_v, r_w, r_ua, r_va, r_u2f)
+    for k in range(kmax):
+        periodic_fill(bd, r_u2f[:, :, k], "A")               # mpp_update_domains(u2f), fv_dynamics.F90:1208
+    u2f_in = r_u2f.copy(order="F")
+    O.rayleigh_apply(g, kmax, conserve, hydrostatic, CP_AIR, RDGAS, ptop, pm, rf, r_u2f, r_pt, r_dz, r_u, r_v, r_w)
+    assert np.max(np.abs(r_u[:, :, 0] - u[:, :, 0])) > 1e-3 * np.max(np.abs(u[:, :, 0]))  # the test does something
+    # ---- library ----
+    ctx = Context(g, km, lib=lib)
+    worst = 0.0
+    try:
+        d_u, d_v = ctx.from_host(u), ctx.from_host(v)
+        for o in (2, 4):
+            d_ua, d_va = ctx.zeros("A", km), ctx.zeros("A", km)
+            ctx.c2l(o, d_u, d_v, d_ua, d_va)
+            worst = max(worst, P.assert_close(f"ua{o}", bd.view(d_ua.download(), "A", *r), bd.view(ref[o][0], "A", *r), tol))
+            worst = max(worst, P.assert_close(f"va{o}", bd.view(d_va.download(), "A", *r), bd.view(ref[o][1], "A", *r), tol))
+        d_pt = ctx.from_host(pt)
+        d_w = None if hydrostatic else ctx.from_host(w)
+        d_dz = None if hydrostatic else ctx.from_host(delz)
+        d_ua, d_va, d_u2f = ctx.zeros("A", km), ctx.zeros("A", km), ctx.zeros("A", km)
+        ctx.rayleigh_u2f(kmax, hydrostatic, d_u, d_v, d_w, d_ua, d_va, d_u2f)
+        got = d_u2f.download()
+        worst = max(worst, P.assert_close("u2f", bd.view(got[:, :, :kmax], "A", *r), bd.view(u2f_in, "A", *r), tol))
+        ctx.halo_fill_periodic(d_u2f, "A")
+        ctx.rayleigh_apply(kmax, conserve, hydrostatic, CP_AIR, RDGAS, ptop, pm[:kmax], rf[:kmax], d_u2f, d_pt, d_dz, d_u,
+                           d_v, d_w)
+        worst = max(worst, P.assert_close("u", bd.view(d_u.download(), "U", bd.is_, bd.ie, bd.js, bd.je + 1),
+                                          bd.view(r_u, "U", bd.is_, bd.ie, bd.js, bd.je + 1), tol))
+        worst = max(worst, P.assert_close("v", bd.view(d_v.download(), "V", bd.is_, bd.ie + 1, bd.js, bd.je),
+                                          bd.view(r_v, "V", bd.is_, bd.ie + 1, bd.js, bd.je), tol))
+        worst = max(worst, P.assert_close("pt", bd.view(d_pt.download(), "A", *r), bd.view(r_pt, "A", *r), tol))
+        if not hydrostatic:
+            worst = max(worst, P.assert_close("w", bd.view(d_w.download(), "A", *r), bd.view(r_w, "A", *r), tol))
+            worst = max(worst, P.assert_close("delz", d_dz.download(), r_dz, tol))
+    finally:
+        ctx.close()
+    return worst

@@ -382,3 +382,14 @@ def test_geometry_mode_detection(prod):
             assert ctx.geom == want
         finally:
             ctx.close()
+
+
+@pytest.mark.parametrize("hydrostatic,conserve", [(False, True), (True, True), (False, False)])
+def test_c2l_and_rayleigh_friction(prod, hydrostatic, conserve):
+    """fv_dynamics around the k_split loop: cubed_to_latlon (ord 2, 4) and Rayleigh_Friction, grid_type = 4"""
+    N.check_c2l_and_rayleigh(prod, hydrostatic=hydrostatic, conserve=conserve)
+
+
+def test_fv_dynamics_call_with_rayleigh_friction(prod):
+    """T -> pkz, Rayleigh_Friction, theta_v, k_split loop, last remap back to T, cubed_to_latlon"""
+    D.check_fv_cycle_from_temperature(prod, tau=0.01)
