@@ -154,6 +154,11 @@ def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream):
 
 def main():
     a = parse()
+    # the contract is ONE JSON line on stdout: native libraries (RCCL prints a version banner on fd 1 when a communicator
+    # is created) must not get there, so everything but that line goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -163,8 +168,15 @@ def main():
     if world != a.gpus and world > 1:
         a.gpus = world
     torch.cuda.set_device(local)
+    # FV3_BENCH_LOOPBACK=1 (one GPU): every halo message goes through RCCL to this same rank and d_sw runs in its
+    # interior / rest form -- the per-step flow of the N-GPU runs, to see what the message path costs
+    loopback = world == 1 and os.environ.get("FV3_BENCH_LOOPBACK") == "1"
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif loopback:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
 
     import parity_common as P
     from fields import smooth_state
@@ -186,7 +198,8 @@ def main():
     ctx = L.Context(g, npz, stream=stream.cuda_stream)
     geom = ctx.geom
     # FV3_BENCH_SPLIT=1: exercise the multi-rank flow (start / d_sw interior / finish / d_sw rest) on one GPU to see its cost
-    halo = HaloExchanger(ctx, px, py, rank, world, split_single=os.environ.get("FV3_BENCH_SPLIT") == "1")
+    halo = HaloExchanger(ctx, px, py, rank, world, split_single=loopback or os.environ.get("FV3_BENCH_SPLIT") == "1",
+                         loopback=loopback)
 
     st = smooth_state(Bounds(1, nx, 1, nx), npz, noise=0.05)  # same synthetic block on every rank
     d = {k: ctx.from_host(v) for k, v in st.items()}
@@ -283,7 +296,7 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"doubly periodic {nx}x{nx}x{npz} tile per GPU (C384L127-sized), nonhydrostatic, "
                                   f"c_sw+d_sw pair, hord {a.hord}/{a.hord}/{a.hord}/{a.hord}, nord=1, d4_bg=0.16",
-                      "layout": f"{px}x{py}", "halo": "periodic copy" if world == 1 else "RCCL send/recv",
+                      "layout": f"{px}x{py}", "halo": ("RCCL send/recv (loopback)" if loopback else "periodic copy") if world == 1 else "RCCL send/recv",
                       # what fv3_grid_upload found in the metric arrays (fv3_grid_geom)
                       "gridstruct": {0: "general metric rows", 1: "orthogonal (angle terms not read)",
                                      2: "orthogonal + uniform (metric terms as scalars)"}[geom]},
@@ -297,8 +310,8 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or loopback:
         dist.destroy_process_group()
 
 

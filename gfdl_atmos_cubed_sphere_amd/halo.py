@@ -113,12 +113,15 @@ class HaloExchanger:
     """Device-side exchanger bound to a lib.Context (GPU)."""
 
     def __init__(self, ctx, px: int, py: int, rank: int, world: int, packed_single: bool = True,
-                 split_single: bool = False):
+                 split_single: bool = False, loopback: bool = False):
         self.ctx, self.px, self.py, self.rank, self.world = ctx, px, py, rank, world
         # one rank: the pack/unpack kernel pair (2 launches per field group, every message is a self message) instead
         # of one periodic-copy launch per field -- fewer, larger launches (41 vs 75 us for uc+vc+divg_d at C384L127)
         self.packed_single = packed_single
         self.split_single = split_single    # one rank: still report overlaps (exercises the d_sw interior/rest split)
+        # test mode: messages to myself also travel through torch.distributed (RCCL self send/recv), so the whole
+        # multi-rank message path can be exercised on one GPU
+        self.loopback = loopback
         self.topo = HaloTopology(ctx.bd, px, py, rank)
         self._views = {}
         self._groups = {}
@@ -149,7 +152,8 @@ class HaloExchanger:
             recv = []
             for n, d in zip(elems, DIRECTIONS):
                 # a rank that is its own neighbour in direction d reads back what it packed
-                recv.append(send[DIRECTIONS.index(d)] if self.topo.neighbour(*d) == self.rank else DeviceArray(self.ctx, (n,)))
+                local = self.topo.neighbour(*d) == self.rank and not self.loopback
+                recv.append(send[DIRECTIONS.index(d)] if local else DeviceArray(self.ctx, (n,)))
             grp = self._groups[key] = (send, recv, [self._tensor(b) for b in send], [self._tensor(b) for b in recv])
         return grp
 
@@ -164,7 +168,7 @@ class HaloExchanger:
         handle for finish().  Compute that does not read these halos may be launched in between: the transfers run on
         RCCL's own stream and only finish() makes the launch stream wait for them."""
         fields = list(fields)
-        if self.world == 1 and not self.packed_single:
+        if self.world == 1 and not self.packed_single and not self.loopback:
             for dev, kind in fields:
                 self.ctx.halo_fill_periodic(dev, kind)
             return None
@@ -177,7 +181,7 @@ class HaloExchanger:
             p2p = []
             for m, d in enumerate(DIRECTIONS):
                 to, frm = self.topo.neighbour(*d), self.topo.neighbour(-d[0], -d[1])
-                if to == self.rank:
+                if to == self.rank and not self.loopback:
                     continue
                 p2p.append(dist.P2POp(dist.isend, tsend[m], to))
                 p2p.append(dist.P2POp(dist.irecv, trecv[m], frm))

@@ -2,6 +2,8 @@
 C ABI against the CPU oracle, same seeded inputs.  Tolerance: see parity_common (BASELINE.json asks
 for rel-RMS < 1e-12; the kernels are built without FMA contraction and reproduce the oracle to
 1e-14 or better)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -393,3 +395,13 @@ def test_c2l_and_rayleigh_friction(prod, hydrostatic, conserve):
 def test_fv_dynamics_call_with_rayleigh_friction(prod):
     """T -> pkz, Rayleigh_Friction, theta_v, k_split loop, last remap back to T, cubed_to_latlon"""
     D.check_fv_cycle_from_temperature(prod, tau=0.01)
+
+
+def test_halo_messages_through_rccl_loopback():
+    """the N-GPU message path (pack -> RCCL batch_isend_irecv -> unpack) on one GPU: every message is a self message"""
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "rccl_loopback_worker.py"), "29541"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl loopback ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
