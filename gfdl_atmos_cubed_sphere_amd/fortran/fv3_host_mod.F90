@@ -1,0 +1,461 @@
+!> Fortran host orchestration over the C ABI of libfv3_mi355x.so (include/fv3_mi355x.h): the counterparts of
+!> dyn_core (model/dyn_core.F90:94-1393, nonhydrostatic branch, non-nested, grid_type = 4), of tracer_2d's host part
+!> (model/fv_tracer2d.F90:382-417, :466-541) and of the k_split loop of fv_dynamics (model/fv_dynamics.F90:460-665),
+!> written the way a maintainer would rewrite those routines around the kernels: the same order of calls and halo
+!> updates (cited line by line), every field device resident (type(c_ptr) handles from fv3_malloc), the fields that
+!> d_sw / update_dz_d / tracer_2d update in place in the reference held as ping-pong pairs.
+!>
+!> One rank of a doubly periodic domain: the group halo updates are fv3_halo_fill_periodic.  On several ranks the same
+!> places call fv3_halo_pack / the peer exchange / fv3_halo_unpack (see INTEGRATION.md); the Python host in
+!> gfdl_atmos_cubed_sphere_amd/halo.py is that exchange over RCCL.
+!>
+!> Not reproduced (off in every BASELINE config): nesting / regional BCs, breed_vortex_inline, do_fast_phys, Ray_fast,
+!> beta > 0 (split_p_grad), the hydrostatic branch (the Python host has it), d_con heating.
+module fv3_host_mod
+  use iso_c_binding
+  use fv3_mi355x_mod
+  implicit none
+  private
+  public :: fv3_flags, fv3_atmos
+  public :: fv3_host_init, fv3_host_final, fv3_host_upload, fv3_host_download
+  public :: fv3_dyn_core, fv3_tracer_2d, fv3_fv_dynamics
+
+  integer(c_int), parameter :: KIND_A = 0, KIND_U = 1, KIND_V = 2, KIND_B = 3
+  integer, parameter :: NG = 3
+
+  !> the fv_flags_type members the substep reads (defaults: model/fv_arrays.F90:207-906)
+  type fv3_flags
+    integer :: n_split = 1, k_split = 1, q_split = 0
+    integer :: nord = 1
+    real(c_double) :: d4_bg = 0.16d0, d2_bg = 0.d0, d2_bg_k1 = 0.20d0, d2_bg_k2 = 0.015d0
+    real(c_double) :: dddmp = 0.d0, vtdm4 = 0.d0, d_con = 0.d0, ke_bg = 0.d0
+    logical :: do_vort_damp = .false., use_logp = .false., use_old_omega = .true., is_ideal_case = .false.
+    integer :: n_sponge = 1
+    integer :: hord_mt = 10, hord_vt = 10, hord_tm = 10, hord_dp = 10, hord_tr = 8
+    integer :: kord_tm = -8, kord_mt = 8, kord_wz = 8, kord_tr = 8
+    integer :: nord_tr = 0
+    real(c_double) :: trdm2 = 0.d0
+    real(c_double) :: a_imp = 1.d0, p_fac = 0.05d0
+    real(c_double) :: ptop = 300.d0
+    real(c_double) :: grav = 9.80d0, rdgas = 287.04d0, akap = 2.d0/7.d0, cp_air = 287.04d0/(2.d0/7.d0)   ! constants_mod
+    real(c_double) :: r_vir = 0.6077d0, t_min = 184.d0
+    logical :: adiabatic = .true.
+  end type
+
+  !> device-resident state and work arrays of one rank (fv_atmos_type members + dyn_core.F90:256-283)
+  type fv3_atmos
+    type(c_ptr) :: ctx = c_null_ptr
+    type(fv3_flags) :: fl
+    integer :: is, ie, js, je, isd, ied, jsd, jed, npz, nq, nx, ny
+    integer(c_size_t) :: nA, nU, nV, nB, nCC, nCX, nCY, nFX, nFY
+    type(fv3_nh_consts) :: cn
+    ! prognostic fields and their ping-pong partners
+    type(c_ptr) :: u, v, w, delp, pt, u_n, v_n, w_n, delp_n, pt_n
+    type(c_ptr) :: delz, phis, zs, q, q_n, dp1, dp1_n
+    ! work arrays
+    type(c_ptr) :: delpc, ptc, uc, vc, ua, va, omga, ut, vt, divgd, gz, pkc, zh, zh_n, pk3
+    type(c_ptr) :: crx, xfx, cry, yfx, mfx, mfy, cx, cy, heat_s, diss_e, pk, ws3, ws, pe, peln, ps, pkz
+    real(c_double), allocatable :: ak(:), bk(:)
+  end type
+
+contains
+
+  subroutine dmalloc(p, n)
+    type(c_ptr), intent(out) :: p
+    integer(c_size_t), intent(in) :: n
+    call fv3_check(fv3_malloc(p, n * 8_c_size_t), 'fv3_malloc')
+  end subroutine
+
+  subroutine dzero(at, p, n)
+    type(fv3_atmos), intent(in) :: at
+    type(c_ptr), intent(in) :: p
+    integer(c_size_t), intent(in) :: n
+    real(c_double), allocatable, target :: z(:)
+    allocate(z(n)); z = 0.d0
+    call fv3_check(fv3_memcpy_h2d(at%ctx, p, c_loc(z), n * 8_c_size_t), 'fv3_memcpy_h2d')
+    call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
+  end subroutine
+
+  subroutine swap(a, b)
+    type(c_ptr), intent(inout) :: a, b
+    type(c_ptr) :: t
+    t = a; a = b; b = t
+  end subroutine
+
+  !> group halo update on one rank of the doubly periodic domain (fv_mp_mod.F90:646-876, contacts :473-483)
+  subroutine halo(at, field, kind, nk)
+    type(fv3_atmos), intent(in) :: at
+    type(c_ptr), intent(in) :: field
+    integer(c_int), intent(in) :: kind
+    integer, intent(in) :: nk
+    call fv3_check(fv3_halo_fill_periodic(at%ctx, field, kind, int(nk, c_int)), 'fv3_halo_fill_periodic')
+  end subroutine
+
+  !> Create the context, build and upload the gridstruct of the doubly periodic Cartesian tile (what
+  !> fv_grid_tools.F90:1202-1221 and fv_grid_utils.F90:426-437,614-683 set for grid_type = 4), allocate the device
+  !> arrays, upload the per-level damping coefficients (dyn_core.F90:666-733), dp_ref (:241-244) and ak, bk.
+  subroutine fv3_host_init(at, nx, ny, npz, nq, dx_const, dy_const, f0_const, fl, ak, bk)
+    type(fv3_atmos), intent(out) :: at
+    integer, intent(in) :: nx, ny, npz, nq
+    real(c_double), intent(in) :: dx_const, dy_const, f0_const
+    type(fv3_flags), intent(in) :: fl
+    real(c_double), intent(in) :: ak(npz+1), bk(npz+1)
+    type(fv3_domain) :: dom
+    type(fv3_grid_host) :: gh
+    integer :: nid, njd, k
+    integer(c_size_t) :: n1, nk, nk1
+    real(c_double), allocatable, target :: m_dx(:), m_dy(:), m_rdx(:), m_rdy(:), m_area(:), m_rarea(:), m_one(:), m_zero(:), &
+                                           m_f0(:), m_sg(:), m_cg(:), dp_ref(:), r_u(:), r6_u(:), r_v(:), r6_v(:)
+
+    at%fl = fl
+    at%is = 1; at%ie = nx; at%js = 1; at%je = ny
+    at%isd = 1 - NG; at%ied = nx + NG; at%jsd = 1 - NG; at%jed = ny + NG
+    at%npz = npz; at%nq = nq; at%nx = nx; at%ny = ny
+    nid = nx + 2*NG; njd = ny + 2*NG
+    at%nA = int(nid, c_size_t) * njd;        at%nU = int(nid, c_size_t) * (njd + 1)
+    at%nV = int(nid + 1, c_size_t) * njd;    at%nB = int(nid + 1, c_size_t) * (njd + 1)
+    at%nCC = int(nx, c_size_t) * ny;         at%nCX = int(nx + 1, c_size_t) * njd
+    at%nCY = int(nid, c_size_t) * (ny + 1);  at%nFX = int(nx + 1, c_size_t) * ny
+    at%nFY = int(nx, c_size_t) * (ny + 1)
+    allocate(at%ak(npz+1), at%bk(npz+1)); at%ak = ak; at%bk = bk
+
+    dom%is = 1; dom%ie = nx; dom%js = 1; dom%je = ny; dom%ng = NG
+    dom%npx = nx + 1; dom%npy = ny + 1; dom%npz = npz; dom%grid_type = 4
+    dom%do_diss_est = 0; dom%prevent_diss_cooling = 1; dom%stretched_grid = 0; dom%lim_fac = 1.d0
+    call fv3_check(fv3_create(dom, at%ctx), 'fv3_create')
+
+    ! ---- gridstruct: every metric term is a constant on this domain; one host array per distinct value is enough,
+    !      sized for the largest stagger (B) -- fv3_grid_upload copies the leading part it needs
+    n1 = at%nB
+    allocate(m_dx(n1), m_dy(n1), m_rdx(n1), m_rdy(n1), m_area(n1), m_rarea(n1), m_one(n1), m_zero(n1), m_f0(n1))
+    allocate(m_sg(9 * at%nA), m_cg(9 * at%nA))
+    m_dx = dx_const; m_dy = dy_const; m_rdx = 1.d0 / dx_const; m_rdy = 1.d0 / dy_const
+    m_area = dx_const * dy_const; m_rarea = 1.d0 / (dx_const * dy_const)
+    m_one = 1.d0; m_zero = 0.d0; m_f0 = f0_const; m_sg = 1.d0; m_cg = 0.d0
+    gh%da_min = dx_const * dy_const; gh%da_min_c = dx_const * dy_const
+    gh%area = c_loc(m_area);   gh%rarea = c_loc(m_rarea)
+    gh%dxa = c_loc(m_dx);      gh%dya = c_loc(m_dy);     gh%rdxa = c_loc(m_rdx);  gh%rdya = c_loc(m_rdy)
+    gh%cosa_s = c_loc(m_zero); gh%rsin2 = c_loc(m_one);  gh%f0 = c_loc(m_f0)
+    gh%dx = c_loc(m_dx);       gh%rdx = c_loc(m_rdx);    gh%dyc = c_loc(m_dy);    gh%rdyc = c_loc(m_rdy)
+    gh%cosa_v = c_loc(m_zero); gh%sina_v = c_loc(m_one); gh%rsin_v = c_loc(m_one)
+    gh%dy = c_loc(m_dy);       gh%rdy = c_loc(m_rdy);    gh%dxc = c_loc(m_dx);    gh%rdxc = c_loc(m_rdx)
+    gh%cosa_u = c_loc(m_zero); gh%sina_u = c_loc(m_one); gh%rsin_u = c_loc(m_one)
+    ! divg_u = sina_v*dyc/dx, del6_u = sina_v*dx/dyc, divg_v = sina_u*dxc/dy, del6_v = sina_u*dy/dxc (fv_grid_utils.F90:656-665)
+    allocate(r_u(n1), r6_u(n1), r_v(n1), r6_v(n1))
+    r_u = 1.d0 * dy_const / dx_const;  r6_u = 1.d0 * dx_const / dy_const
+    r_v = 1.d0 * dx_const / dy_const;  r6_v = 1.d0 * dy_const / dx_const
+    gh%divg_u = c_loc(r_u); gh%del6_u = c_loc(r6_u); gh%divg_v = c_loc(r_v); gh%del6_v = c_loc(r6_v)
+    gh%rarea_c = c_loc(m_rarea); gh%fC = c_loc(m_f0); gh%cosa = c_loc(m_zero); gh%sina = c_loc(m_one)
+    gh%sin_sg = c_loc(m_sg);     gh%cos_sg = c_loc(m_cg)
+    call fv3_check(fv3_grid_upload(at%ctx, gh), 'fv3_grid_upload')
+
+    ! ---- device arrays ----
+    nk = int(npz, c_size_t); nk1 = nk + 1
+    call dmalloc(at%u, at%nU*nk);     call dmalloc(at%u_n, at%nU*nk)
+    call dmalloc(at%v, at%nV*nk);     call dmalloc(at%v_n, at%nV*nk)
+    call dmalloc(at%w, at%nA*nk);     call dmalloc(at%w_n, at%nA*nk)
+    call dmalloc(at%delp, at%nA*nk);  call dmalloc(at%delp_n, at%nA*nk)
+    call dmalloc(at%pt, at%nA*nk);    call dmalloc(at%pt_n, at%nA*nk)
+    call dmalloc(at%delz, at%nCC*nk); call dmalloc(at%phis, at%nA);       call dmalloc(at%zs, at%nA)
+    call dmalloc(at%delpc, at%nA*nk); call dmalloc(at%ptc, at%nA*nk)
+    call dmalloc(at%uc, at%nV*nk);    call dmalloc(at%vc, at%nU*nk)
+    call dmalloc(at%ua, at%nA*nk);    call dmalloc(at%va, at%nA*nk);      call dmalloc(at%omga, at%nA*nk)
+    call dmalloc(at%ut, at%nA*nk);    call dmalloc(at%vt, at%nA*nk);      call dmalloc(at%divgd, at%nB*nk)
+    call dmalloc(at%gz, at%nA*nk1);   call dmalloc(at%pkc, at%nA*nk1)
+    call dmalloc(at%zh, at%nA*nk1);   call dmalloc(at%zh_n, at%nA*nk1);   call dmalloc(at%pk3, at%nA*nk1)
+    call dmalloc(at%crx, at%nCX*nk);  call dmalloc(at%xfx, at%nCX*nk)
+    call dmalloc(at%cry, at%nCY*nk);  call dmalloc(at%yfx, at%nCY*nk)
+    call dmalloc(at%mfx, at%nFX*nk);  call dmalloc(at%mfy, at%nFY*nk)
+    call dmalloc(at%cx, at%nCX*nk);   call dmalloc(at%cy, at%nCY*nk)
+    call dmalloc(at%heat_s, at%nCC*nk); call dmalloc(at%diss_e, at%nCC*nk); call dmalloc(at%pk, at%nCC*nk1)
+    call dmalloc(at%ws3, at%nA);      call dmalloc(at%ws, at%nCC)
+    call dmalloc(at%pe, int(nx+2, c_size_t)*nk1*(ny+2));  call dmalloc(at%peln, int(nx, c_size_t)*nk1*ny)
+    call dmalloc(at%ps, at%nA);       call dmalloc(at%pkz, at%nCC*nk)
+    call dmalloc(at%dp1, at%nA*nk);   call dmalloc(at%dp1_n, at%nA*nk)
+    at%q = c_null_ptr; at%q_n = c_null_ptr
+    if (nq > 0) then
+      call dmalloc(at%q, at%nA*nk*nq); call dmalloc(at%q_n, at%nA*nk*nq)
+      call dzero(at, at%q_n, at%nA*nk*nq)
+    end if
+    ! the arrays the kernels read before anything writes them (halos, accumulators) start from zero like ctx.zeros
+    call dzero(at, at%u_n, at%nU*nk);   call dzero(at, at%v_n, at%nV*nk);  call dzero(at, at%w_n, at%nA*nk)
+    call dzero(at, at%delp_n, at%nA*nk); call dzero(at, at%pt_n, at%nA*nk)
+    call dzero(at, at%delpc, at%nA*nk); call dzero(at, at%ptc, at%nA*nk)
+    call dzero(at, at%uc, at%nV*nk);    call dzero(at, at%vc, at%nU*nk)
+    call dzero(at, at%ua, at%nA*nk);    call dzero(at, at%va, at%nA*nk);   call dzero(at, at%omga, at%nA*nk)
+    call dzero(at, at%ut, at%nA*nk);    call dzero(at, at%vt, at%nA*nk);   call dzero(at, at%divgd, at%nB*nk)
+    call dzero(at, at%gz, at%nA*nk1);   call dzero(at, at%pkc, at%nA*nk1)
+    call dzero(at, at%zh, at%nA*nk1);   call dzero(at, at%zh_n, at%nA*nk1); call dzero(at, at%pk3, at%nA*nk1)
+    call dzero(at, at%crx, at%nCX*nk);  call dzero(at, at%xfx, at%nCX*nk)
+    call dzero(at, at%cry, at%nCY*nk);  call dzero(at, at%yfx, at%nCY*nk)
+    call dzero(at, at%mfx, at%nFX*nk);  call dzero(at, at%mfy, at%nFY*nk)
+    call dzero(at, at%cx, at%nCX*nk);   call dzero(at, at%cy, at%nCY*nk)
+    call dzero(at, at%heat_s, at%nCC*nk); call dzero(at, at%diss_e, at%nCC*nk); call dzero(at, at%pk, at%nCC*nk1)
+    call dzero(at, at%ws3, at%nA);      call dzero(at, at%ws, at%nCC)
+    call dzero(at, at%pe, int(nx+2, c_size_t)*nk1*(ny+2)); call dzero(at, at%peln, int(nx, c_size_t)*nk1*ny)
+    call dzero(at, at%ps, at%nA);       call dzero(at, at%pkz, at%nCC*nk)
+    call dzero(at, at%dp1, at%nA*nk);   call dzero(at, at%dp1_n, at%nA*nk)
+
+    call upload_levels(at)
+    allocate(dp_ref(npz))
+    do k = 1, npz
+      dp_ref(k) = (ak(k+1) - ak(k)) + (bk(k+1) - bk(k)) * 1.d5          ! dyn_core.F90:241-244
+    end do
+    call fv3_check(fv3_set_dp_ref(at%ctx, dp_ref), 'fv3_set_dp_ref')
+    call fv3_check(fv3_set_ak_bk(at%ctx, at%ak, at%bk), 'fv3_set_ak_bk')
+    at%cn%grav = fl%grav; at%cn%rdgas = fl%rdgas; at%cn%cp_air = fl%cp_air; at%cn%akap = fl%akap
+    at%cn%ptop = fl%ptop; at%cn%p_fac = fl%p_fac; at%cn%a_imp = fl%a_imp
+  end subroutine
+
+  !> nord_k, nord_v, nord_w, nord_t, d2_divg, damp_vt, damp_w, damp_t, d_con_k per level: the k loop of dyn_core.F90:666-733
+  subroutine upload_levels(at)
+    type(fv3_atmos), intent(in) :: at
+    integer(c_int), allocatable, target :: nord_k(:), nord_v(:), nord_w(:), nord_t(:)
+    real(c_double), allocatable, target :: d2_divg(:), damp_vt(:), damp_w(:), damp_t(:), d_con_k(:)
+    type(fv3_dsw_levels) :: lv
+    integer :: k, npz
+    npz = at%npz
+    allocate(nord_k(npz), nord_v(npz), nord_w(npz), nord_t(npz), d2_divg(npz), damp_vt(npz), damp_w(npz), damp_t(npz), &
+             d_con_k(npz))
+    do k = 1, npz
+      nord_k(k) = at%fl%nord
+      nord_v(k) = min(2, at%fl%nord)
+      d2_divg(k) = min(0.20d0, at%fl%d2_bg)
+      damp_vt(k) = 0.d0
+      if (at%fl%do_vort_damp) damp_vt(k) = at%fl%vtdm4
+      nord_w(k) = nord_v(k); nord_t(k) = nord_v(k); damp_w(k) = damp_vt(k); damp_t(k) = damp_vt(k)
+      d_con_k(k) = at%fl%d_con
+      if (npz == 1 .or. at%fl%n_sponge < 0) then
+        d2_divg(k) = at%fl%d2_bg
+      else if (k == 1) then
+        nord_k(k) = 0
+        if (at%fl%is_ideal_case) then
+          d2_divg(k) = max(at%fl%d2_bg, at%fl%d2_bg_k1)
+        else
+          d2_divg(k) = max(0.01d0, at%fl%d2_bg, at%fl%d2_bg_k1)
+        end if
+        nord_w(k) = 0; damp_w(k) = d2_divg(k)
+        if (at%fl%do_vort_damp) then
+          nord_v(k) = 0; damp_vt(k) = 0.5d0 * d2_divg(k)
+        end if
+        d_con_k(k) = 0.d0
+      else if (k == 2 .and. at%fl%d2_bg_k2 > 0.01d0) then
+        nord_k(k) = 0
+        d2_divg(k) = max(at%fl%d2_bg, at%fl%d2_bg_k2)
+        nord_w(k) = 0; damp_w(k) = d2_divg(k)
+        if (at%fl%do_vort_damp) then
+          nord_v(k) = 0; damp_vt(k) = 0.5d0 * d2_divg(k)
+        end if
+        d_con_k(k) = 0.d0
+      else if (k == 3 .and. at%fl%d2_bg_k2 > 0.05d0) then
+        nord_k(k) = 0
+        d2_divg(k) = max(at%fl%d2_bg, 0.2d0 * at%fl%d2_bg_k2)
+        nord_w(k) = 0; damp_w(k) = d2_divg(k)
+        d_con_k(k) = 0.d0
+      end if
+    end do
+    lv%nord_k = c_loc(nord_k); lv%nord_v = c_loc(nord_v); lv%nord_w = c_loc(nord_w); lv%nord_t = c_loc(nord_t)
+    lv%d2_divg = c_loc(d2_divg); lv%damp_vt = c_loc(damp_vt); lv%damp_w = c_loc(damp_w); lv%damp_t = c_loc(damp_t)
+    lv%d_con_k = c_loc(d_con_k)
+    call fv3_check(fv3_dsw_levels_upload(at%ctx, lv), 'fv3_dsw_levels_upload')
+  end subroutine
+
+  !> host arrays with the reference's shapes (fv_arrays.F90:1521-1563) -> device
+  subroutine fv3_host_upload(at, u, v, w, delp, pt, delz, phis, q)
+    type(fv3_atmos), intent(inout) :: at
+    real(c_double), intent(in), target :: u(at%isd:at%ied, at%jsd:at%jed+1, at%npz), v(at%isd:at%ied+1, at%jsd:at%jed, at%npz)
+    real(c_double), intent(in), target :: w(at%isd:at%ied, at%jsd:at%jed, at%npz), delp(at%isd:at%ied, at%jsd:at%jed, at%npz)
+    real(c_double), intent(in), target :: pt(at%isd:at%ied, at%jsd:at%jed, at%npz), delz(at%is:at%ie, at%js:at%je, at%npz)
+    real(c_double), intent(in), target :: phis(at%isd:at%ied, at%jsd:at%jed)
+    real(c_double), intent(in), target, optional :: q(at%isd:at%ied, at%jsd:at%jed, at%npz, *)
+    real(c_double), allocatable, target :: zs(:,:)
+    integer(c_size_t) :: nk
+    nk = int(at%npz, c_size_t)
+    call put(at%u, c_loc(u), at%nU*nk);       call put(at%v, c_loc(v), at%nV*nk);   call put(at%w, c_loc(w), at%nA*nk)
+    call put(at%delp, c_loc(delp), at%nA*nk); call put(at%pt, c_loc(pt), at%nA*nk)
+    call put(at%delz, c_loc(delz), at%nCC*nk); call put(at%phis, c_loc(phis), at%nA)
+    allocate(zs(at%isd:at%ied, at%jsd:at%jed))
+    zs = phis * (1.d0 / at%fl%grav)                                       ! dyn_core.F90:246-251
+    call put(at%zs, c_loc(zs), at%nA)
+    if (present(q) .and. at%nq > 0) call put(at%q, c_loc(q), at%nA*nk*at%nq)
+    call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
+  contains
+    subroutine put(d, h, n)
+      type(c_ptr), intent(in) :: d, h
+      integer(c_size_t), intent(in) :: n
+      call fv3_check(fv3_memcpy_h2d(at%ctx, d, h, n * 8_c_size_t), 'fv3_memcpy_h2d')
+    end subroutine
+  end subroutine
+
+  subroutine fv3_host_download(at, u, v, w, delp, pt, delz, q, ua, va)
+    type(fv3_atmos), intent(in) :: at
+    real(c_double), intent(out), target :: u(at%isd:at%ied, at%jsd:at%jed+1, at%npz), v(at%isd:at%ied+1, at%jsd:at%jed, at%npz)
+    real(c_double), intent(out), target :: w(at%isd:at%ied, at%jsd:at%jed, at%npz), delp(at%isd:at%ied, at%jsd:at%jed, at%npz)
+    real(c_double), intent(out), target :: pt(at%isd:at%ied, at%jsd:at%jed, at%npz), delz(at%is:at%ie, at%js:at%je, at%npz)
+    real(c_double), intent(out), target, optional :: q(at%isd:at%ied, at%jsd:at%jed, at%npz, *)
+    real(c_double), intent(out), target, optional :: ua(at%isd:at%ied, at%jsd:at%jed, at%npz), va(at%isd:at%ied, at%jsd:at%jed, at%npz)
+    integer(c_size_t) :: nk
+    nk = int(at%npz, c_size_t)
+    call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
+    call get(c_loc(u), at%u, at%nU*nk);       call get(c_loc(v), at%v, at%nV*nk);   call get(c_loc(w), at%w, at%nA*nk)
+    call get(c_loc(delp), at%delp, at%nA*nk); call get(c_loc(pt), at%pt, at%nA*nk)
+    call get(c_loc(delz), at%delz, at%nCC*nk)
+    if (present(q) .and. at%nq > 0) call get(c_loc(q), at%q, at%nA*nk*at%nq)
+    if (present(ua)) call get(c_loc(ua), at%ua, at%nA*nk)
+    if (present(va)) call get(c_loc(va), at%va, at%nA*nk)
+    call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
+  contains
+    subroutine get(h, d, n)
+      type(c_ptr), intent(in) :: d, h
+      integer(c_size_t), intent(in) :: n
+      call fv3_check(fv3_memcpy_d2h(at%ctx, h, d, n * 8_c_size_t), 'fv3_memcpy_d2h')
+    end subroutine
+  end subroutine
+
+  !> the acoustic substep loop, nonhydrostatic branch (dyn_core.F90:313-1286)
+  subroutine fv3_dyn_core(at, bdt)
+    type(fv3_atmos), intent(inout) :: at
+    real(c_double), intent(in) :: bdt
+    type(fv3_dsw_params) :: par
+    real(c_double) :: dt, dt2, rdt, ptk, peln1, top
+    integer :: it, n_split, npz
+    logical :: remap_step
+    integer(c_int) :: last_call, use_logp
+    type(c_ptr) :: ctx
+    ctx = at%ctx; npz = at%npz
+    n_split = at%fl%n_split
+    dt = bdt / real(n_split, c_double)
+    dt2 = 0.5d0 * dt
+    rdt = 1.d0 / dt
+    ptk = at%fl%ptop ** at%fl%akap                                        ! dyn_core.F90:222
+    peln1 = log(at%fl%ptop)
+    use_logp = merge(1_c_int, 0_c_int, at%fl%use_logp)
+    top = merge(peln1, ptk, at%fl%use_logp)
+    call dzero(at, at%mfx, at%nFX*npz); call dzero(at, at%mfy, at%nFY*npz)        ! :289-292
+    call dzero(at, at%cx, at%nCX*npz);  call dzero(at, at%cy, at%nCY*npz)
+    par%dt = dt; par%hord_tr = at%fl%hord_tr; par%hord_mt = at%fl%hord_mt; par%hord_vt = at%fl%hord_vt
+    par%hord_tm = at%fl%hord_tm; par%hord_dp = at%fl%hord_dp; par%dddmp = at%fl%dddmp; par%d4_bg = at%fl%d4_bg
+    par%kgb = at%fl%ke_bg; par%hydrostatic = 0; par%use_cond = 0
+    ! fv_dynamics.F90:467-470: halo of delp, pt (pack 1) and u, v (pack 8) before the first substep
+    call halo(at, at%delp, KIND_A, npz); call halo(at, at%pt, KIND_A, npz)
+    call halo(at, at%u, KIND_U, npz);    call halo(at, at%v, KIND_V, npz)
+    do it = 1, n_split
+      remap_step = it == n_split
+      last_call = merge(1_c_int, 0_c_int, remap_step)
+      call halo(at, at%w, KIND_A, npz)                                                    ! :350 / :432 (pack 7)
+      if (it == 1) then                                                                   ! :353-389
+        call fv3_check(fv3_zh_from_delz(ctx, at%zs, at%delz, at%zh), 'zh_from_delz')
+        call halo(at, at%zh, KIND_A, npz + 1)                                             ! gz halo (pack 5); zh = gz (:491-499)
+      end if
+      call fv3_check(fv3_c_sw(ctx, at%delpc, at%delp, at%ptc, at%pt, at%u, at%v, at%w, at%uc, at%vc, at%ua, at%va, &
+                              at%omga, at%ut, at%vt, at%divgd, int(at%fl%nord, c_int), dt2, 0_c_int, 1_c_int), 'c_sw')  ! :439-447
+      if (at%fl%nord > 0) call halo(at, at%divgd, KIND_B, npz)                            ! :451 / :577 (pack 3, CORNER)
+      call fv3_check(fv3_update_dz_c(ctx, dt2, at%zs, at%ut, at%vt, at%zh, at%gz, at%ws3), 'update_dz_c')   ! :514-527
+      call fv3_check(fv3_riem_solver_c(ctx, dt2, at%cn, at%phis, at%omga, at%ptc, at%delpc, at%gz, at%pkc, at%ws3), &
+                     'riem_solver_c')                                                     ! :531
+      call fv3_check(fv3_p_grad_c(ctx, dt2, at%delpc, at%pkc, at%gz, at%uc, at%vc, 0_c_int), 'p_grad_c')    ! :562
+      call halo(at, at%uc, KIND_V, npz); call halo(at, at%vc, KIND_U, npz)                ! :565 / :578 (pack 9, CGRID_NE)
+      call fv3_check(fv3_d_sw(ctx, par, at%vt, at%delp, at%pt, at%u, at%v, at%w, at%uc, at%vc, at%ua, at%va, at%divgd, &
+                              at%mfx, at%mfy, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
+                              at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, c_null_ptr, at%heat_s, at%diss_e), 'd_sw')  ! :762
+      call swap(at%delp, at%delp_n); call swap(at%pt, at%pt_n)
+      call swap(at%u, at%u_n); call swap(at%v, at%v_n); call swap(at%w, at%w_n)
+      call halo(at, at%delp, KIND_A, npz); call halo(at, at%pt, KIND_A, npz)              ! :823-824 / :851 (pack 1)
+      call fv3_check(fv3_update_dz_d(ctx, int(at%fl%hord_tm, c_int), at%zs, at%zh, at%zh_n, at%crx, at%cry, at%xfx, &
+                                     at%yfx, at%ws, rdt), 'update_dz_d')                  ! :911
+      call swap(at%zh, at%zh_n)
+      call fv3_check(fv3_riem_solver3(ctx, dt, at%cn, at%zs, at%w, at%delz, at%pt, at%delp, at%zh, at%pe, at%pkc, &
+                                      at%pk3, at%pk, at%peln, at%ws, use_logp, last_call, 0_c_int), 'riem_solver3')  ! :932
+      call halo(at, at%zh, KIND_A, npz + 1); call halo(at, at%pkc, KIND_A, npz + 1)       ! :944-950 (packs 4, 5)
+      if (remap_step) call fv3_check(fv3_pe_halo(ctx, at%fl%ptop, at%pe, at%delp), 'pe_halo')   ! :952-953
+      call fv3_check(fv3_pk3_halo(ctx, at%fl%ptop, at%fl%akap, at%pk3, at%delp, use_logp), 'pk3_halo')   ! :955-959
+      ! :982-989 gz = zh*grav is fused into nh_p_grad (gz_scale)
+      call fv3_check(fv3_nh_p_grad(ctx, at%u, at%v, at%pkc, at%zh, at%fl%grav, at%delp, at%pk3, dt, top), 'nh_p_grad')  ! :1032
+      if (it /= n_split) then
+        call halo(at, at%u, KIND_U, npz); call halo(at, at%v, KIND_V, npz)                ! :1168-1169 (pack 8)
+      else if (at%fl%use_old_omega) then
+        ! :1182-1191: omga = (pe - pem)*rdt; pem from the delp this substep started with (:409-421) = delp_n after the swap
+        call fv3_check(fv3_omga_update(ctx, rdt, at%fl%ptop, at%pe, at%delp_n, at%omga), 'omga_update')
+      end if
+    end do
+  end subroutine
+
+  !> tracer_2d (fv_tracer2d.F90:297-557): the host keeps the part with the cross-rank reduction and the integer
+  !> bookkeeping (:382-456), the arithmetic runs in the kernels
+  subroutine fv3_tracer_2d(at)
+    type(fv3_atmos), intent(inout) :: at
+    real(c_double), allocatable :: cmax(:), frac(:)
+    integer(c_int), allocatable :: ksplt(:)
+    real(c_double) :: c_global
+    integer :: nsplt, it, npz, k
+    npz = at%npz
+    allocate(cmax(npz), frac(npz), ksplt(npz))
+    call fv3_check(fv3_tracer_2d_prep(at%ctx, int(at%fl%q_split, c_int), at%cx, at%cy, at%xfx, at%yfx, cmax), &
+                   'tracer_2d_prep')                                                     ! :362-400
+    if (at%fl%q_split == 0) then
+      ! mp_reduce_max(cmax, npz) goes here on several ranks (:405)
+      if (npz /= 1) then                                                                 ! :407-412
+        c_global = maxval(cmax)
+      else
+        c_global = cmax(1)
+      end if
+      nsplt = int(1.d0 + c_global)
+    else
+      nsplt = at%fl%q_split
+    end if
+    if (nsplt /= 1) then                                                                 ! :421-456
+      do k = 1, npz
+        ksplt(k) = int(1.d0 + cmax(k), c_int)
+        frac(k) = 1.d0 / real(ksplt(k), c_double)
+      end do
+      call fv3_check(fv3_tracer_2d_scale(at%ctx, frac, at%cx, at%xfx, at%mfx, at%cy, at%yfx, at%mfy), 'tracer_2d_scale')
+    else
+      ksplt = 1
+    end if
+    if (at%fl%trdm2 > 1.d-4) call halo(at, at%dp1, KIND_A, npz)                           ! dp1_pack, :466
+    do it = 1, nsplt                                                                      ! :471-541
+      call halo(at, at%q, KIND_A, npz * at%nq)                                            ! q_pack, :474 / :536
+      call fv3_check(fv3_tracer_2d_step(at%ctx, int(it, c_int), int(nsplt, c_int), ksplt, int(at%nq, c_int), &
+                                        int(at%fl%hord_tr, c_int), int(at%fl%nord_tr, c_int), at%fl%trdm2, at%q, at%q_n, &
+                                        at%dp1, at%dp1_n, at%mfx, at%mfy, at%cx, at%cy, at%xfx, at%yfx), 'tracer_2d_step')
+      call swap(at%q, at%q_n)
+      if (it /= nsplt) call swap(at%dp1, at%dp1_n)
+    end do
+  end subroutine
+
+  !> one dt_atmos: the k_split loop of fv_dynamics (fv_dynamics.F90:460-665): acoustic substeps, tracer transport,
+  !> vertical remap.  pt holds theta_v (what dyn_core works on); last_step makes the final remap return T (fv_mapz.F90:793-821).
+  subroutine fv3_fv_dynamics(at, bdt, last_step)
+    type(fv3_atmos), intent(inout) :: at
+    real(c_double), intent(in) :: bdt
+    logical, intent(in) :: last_step
+    type(fv3_remap_params) :: rp
+    integer(c_int), allocatable :: kord_tr(:)
+    real(c_double) :: mdt
+    integer :: n_map
+    mdt = bdt / real(at%fl%k_split, c_double)
+    allocate(kord_tr(max(1, at%nq))); kord_tr = int(at%fl%kord_tr, c_int)
+    rp%hydrostatic = 0; rp%adiabatic = merge(1_c_int, 0_c_int, at%fl%adiabatic); rp%nq = int(at%nq, c_int)
+    rp%kord_mt = int(at%fl%kord_mt, c_int); rp%kord_wz = int(at%fl%kord_wz, c_int); rp%kord_tm = int(at%fl%kord_tm, c_int)
+    rp%sphum = merge(1_c_int, 0_c_int, at%nq > 0)
+    rp%akap = at%fl%akap; rp%ptop = at%fl%ptop; rp%rdgas = at%fl%rdgas; rp%grav = at%fl%grav
+    rp%cv_air = at%fl%cp_air - at%fl%rdgas; rp%r_vir = at%fl%r_vir; rp%cp = at%fl%cp_air; rp%t_min = at%fl%t_min
+    do n_map = 1, at%fl%k_split
+      call fv3_check(fv3_memcpy_d2d(at%ctx, at%dp1, at%delp, at%nA * at%npz * 8_c_size_t), 'dp1 = delp')   ! :475-481
+      call fv3_dyn_core(at, mdt)                                                                           ! :493
+      if (at%nq > 0) call fv3_tracer_2d(at)                                                                ! :500-533
+      rp%last_step = merge(1_c_int, 0_c_int, last_step .and. n_map == at%fl%k_split)
+      call fv3_check(fv3_lagrangian_to_eulerian(at%ctx, rp, kord_tr, at%ps, at%pe, at%delp, at%pkz, at%pk, at%u, at%v, &
+                                                at%w, at%delz, at%pt, at%q, at%peln, at%omga, at%ws), &
+                     'lagrangian_to_eulerian')                                                             ! :607
+    end do
+  end subroutine
+
+  subroutine fv3_host_final(at)
+    type(fv3_atmos), intent(inout) :: at
+    call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
+    call fv3_check(fv3_destroy(at%ctx), 'fv3_destroy')     ! device arrays from fv3_malloc are the caller's: freed with the process
+    at%ctx = c_null_ptr
+  end subroutine
+
+end module fv3_host_mod

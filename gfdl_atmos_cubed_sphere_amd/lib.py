@@ -91,6 +91,15 @@ class Fv3Lib:
                            "there is no CPU fallback")
         self.path = path
         self.host_memory = "hostemu" in os.path.basename(path)   # the tests' logic harness, never the product
+        if not self.host_memory:
+            # torch (streams, torch.distributed for the halo exchange) ships its own libamdhip64 with the same SONAME as
+            # the one this library is linked to; whichever is mapped first serves the whole process.  Map torch's first:
+            # the other order (this library's runtime initialised, torch importing later) leaves torch without a device
+            # ("No HIP GPUs are available").
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         self.dll = C.CDLL(path)
         missing = [s for s in EXPORTS if not hasattr(self.dll, s)]
         if missing:

@@ -1,0 +1,107 @@
+"""Build and run the Fortran host (gfdl_atmos_cubed_sphere_amd/fortran: fv3_mi355x_mod + fv3_host_mod + fv3_solo) and
+compare what it leaves in the state with the Python host driving the same library through the same C ABI."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FDIR = os.path.join(ROOT, "gfdl_atmos_cubed_sphere_amd", "fortran")
+CSRC = os.path.join(ROOT, "gfdl_atmos_cubed_sphere_amd", "csrc")
+
+
+def fortran_compiler():
+    fc = shutil.which("amdflang") or "/opt/rocm/bin/amdflang"
+    return fc if os.path.exists(fc) else None
+
+
+def build_solo(workdir, libdir=CSRC, libname="fv3_mi355x"):
+    """amdflang: interface module + host module + driver, linked against the product library"""
+    fc = fortran_compiler()
+    exe = os.path.join(str(workdir), "fv3_solo")
+    srcs = [os.path.join(FDIR, f) for f in ("fv3_mi355x_mod.F90", "fv3_host_mod.F90", "fv3_solo.F90")]
+    subprocess.check_call([fc, "-O1", "-module-dir", str(workdir)] + srcs +
+                          ["-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def write_input(path, bd, npz, nq, n_split, k_split, nsteps, last_step, dx, dy, f0, bdt, ptop, ak, bk, st, q):
+    with open(path, "wb") as f:
+        np.array([bd.nx, bd.ny, npz, nq, n_split, k_split, nsteps, int(last_step)], dtype=np.int32).tofile(f)
+        np.array([dx, dy, f0, bdt, ptop], dtype=np.float64).tofile(f)
+        np.asarray(ak, dtype=np.float64).tofile(f)
+        np.asarray(bk, dtype=np.float64).tofile(f)
+        for n in ("u", "v", "w", "delp", "pt", "delz", "phis"):
+            np.asfortranarray(st[n], dtype=np.float64).ravel(order="F").tofile(f)
+        if nq:
+            np.asfortranarray(q, dtype=np.float64).ravel(order="F").tofile(f)
+
+
+def read_output(path, bd, npz, nq):
+    out = {}
+    with open(path, "rb") as f:
+        for n, kind in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC")):
+            shp = bd.shape(kind, npz)
+            out[n] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+        if nq:
+            shp = bd.shape("A", npz) + (nq,)
+            out["q"] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+    return out
+
+
+def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0):
+    """the same initial state through (a) the Python host and (b) the Fortran host: bit-identical states"""
+    import parity_common as P
+    import parity_dyn as D
+    import parity_nh as N
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    st, _ = D.make_state(bd, npz)
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+    ak, bk = N.PTOP * (1.0 - sig), sig.copy()
+    rng = np.random.default_rng(5)
+    q = np.asfortranarray(rng.uniform(0.0, 1.0, bd.shape("A", npz) + (nq,))) if nq else None
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP)
+    # ---- (a) Python host ----
+    ctx = Context(g, npz, lib=lib)
+    try:
+        fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=k_split)
+        fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
+        if nq:
+            fv.set_tracers(q)
+        for _ in range(nsteps):
+            fv.step(bdt)
+        d = fv.dc.d
+        ref = {n: d[n].download() for n in ("u", "v", "w", "delp", "pt", "delz")}
+        if nq:
+            ref["q"] = d["q"].download()
+    finally:
+        ctx.close()
+    # ---- (b) Fortran host ----
+    exe = build_solo(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
+    fin, fout = os.path.join(str(workdir), "in.bin"), os.path.join(str(workdir), "out.bin")
+    write_input(fin, bd, npz, nq, n_split, k_split, nsteps, False, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak,
+                bk, st, q)
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "geometry mode 2" in r.stdout, r.stdout
+    got = read_output(fout, bd, npz, nq)
+    i0, i1, j0, j1 = bd.is_, bd.ie, bd.js, bd.je
+    rng_ = {"u": ("U", i0, i1, j0, j1 + 1), "v": ("V", i0, i1 + 1, j0, j1), "w": ("A", i0, i1, j0, j1),
+            "delp": ("A", i0, i1, j0, j1), "pt": ("A", i0, i1, j0, j1)}
+    for n in ref:
+        if n in rng_:
+            kind, *r4 = rng_[n]
+            a, b = bd.view(got[n], kind, *r4), bd.view(ref[n], kind, *r4)
+        elif n == "q":
+            a, b = got[n][bd.ng:bd.ng + nx, bd.ng:bd.ng + ny], ref[n][bd.ng:bd.ng + nx, bd.ng:bd.ng + ny]
+        else:
+            a, b = got[n], ref[n]
+        assert np.all(np.isfinite(a)), n
+        assert np.array_equal(a, b), f"{n}: Fortran host and Python host differ (max abs {np.max(np.abs(a - b)):.3e})"
+    return r.stdout

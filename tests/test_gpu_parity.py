@@ -405,3 +405,13 @@ def test_halo_messages_through_rccl_loopback():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "rccl_loopback_worker.py"), "29541"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "rccl loopback ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_fortran_host_drives_the_library(prod, tmp_path):
+    """Host orchestration in Fortran (fv3_host_mod: dyn_core, tracer_2d, the k_split loop) over ISO_C_BINDING -> C ABI ->
+    HIP, compiled with the image's amdflang and run on the GPU: the state equals the Python host's bit for bit"""
+    import fortran_host as F
+    if F.fortran_compiler() is None:
+        pytest.skip("no Fortran compiler in this image")
+    out = F.check_fortran_host(prod, tmp_path)
+    assert "fv3_solo: done" in out

@@ -311,3 +311,12 @@ def test_c2l_and_rayleigh_friction(emu, hydrostatic, conserve):
 def test_fv_dynamics_call_with_rayleigh_friction(emu):
     """T -> pkz, Rayleigh_Friction, theta_v, k_split loop, last remap back to T, cubed_to_latlon"""
     D.check_fv_cycle_from_temperature(emu, tau=0.01)
+
+
+def test_fortran_host_drives_the_library(emu, tmp_path):
+    """the Fortran host (fv3_host_mod + fv3_solo, amdflang) against the host-emulation build of the same C ABI"""
+    import fortran_host as F
+    if F.fortran_compiler() is None:
+        pytest.skip("no Fortran compiler in this image")
+    out = F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=8, nq=1)
+    assert "fv3_solo: done" in out
