@@ -56,6 +56,7 @@ struct fv3_ctx {
   bool dp0_ready;
   double *scratch[8];
   double *ray_d;         // pm(k), rf(k) of Rayleigh_Friction
+  const double *q_con, *cappa;  // fv3_set_condensate: use_cond / moist_kappa arrays of the Riemann solvers (or null)
   double *remap_scr;     // coordinate + profile slabs of the vertical remap (fv3_lagrangian_to_eulerian)
   size_t remap_scr_n;
   double *lev_ext_d;  // damp(npz+1) for update_dz_d
@@ -240,6 +241,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->dp0 = nullptr; c->edge_dev = nullptr; c->dp0_ready = false;
   c->akbk = nullptr; c->kord_tr_dev = nullptr; c->akbk_ready = false;
   c->remap_scr = nullptr; c->remap_scr_n = 0; c->ray_d = nullptr;
+  c->q_con = nullptr; c->cappa = nullptr;
   c->trc_d = nullptr; c->trc_i = nullptr;
   for (auto &s : c->scratch) s = nullptr;
   c->lev_ext_d = nullptr; c->lev_ext_i = nullptr;
@@ -1038,13 +1040,20 @@ static NhConsts to_consts(const fv3_nh_consts *cn) {
   return NhConsts{cn->grav, cn->rdgas, cn->cp_air, cn->akap, cn->ptop, cn->p_fac, cn->a_imp};
 }
 
+extern "C" int fv3_set_condensate(fv3_ctx *c, const double *q_con, const double *cappa) {
+  if (!c) return fail("fv3_set_condensate: null context");
+  c->q_con = q_con;
+  c->cappa = cappa;
+  return 0;
+}
+
 extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn, const double *hs, const double *w3,
                                  const double *pt, const double *delp, double *gz, double *pef, const double *ws) {
   if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver_c: bad context/arguments");
   if (cn->a_imp <= 0.5) return fail("fv3_riem_solver_c: a_imp <= 0.5 (RIM_2D / SIM3p0) is not built");
   if (need_scratch(c, 4)) return 1;
   RiemSolverC kf{c->g, c->g.npz, dt, to_consts(cn), hs, w3, pt, delp, ws, gz, pef,
-                 c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3]};
+                 c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->q_con, c->cappa};
   RT(launch_c(c, "riem_solver_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), kf));
   return 0;
 }
@@ -1058,7 +1067,8 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
   if (last_call && (!pe || !pk || !peln)) return fail("fv3_riem_solver3: last_call needs pe, pk, peln");
   if (need_scratch(c, 4)) return 1;
   RiemSolver3 kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, delz, zh, pe, ppe, pk3, pk, peln,
-                 use_logp, last_call, fp_out, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3]};
+                 use_logp, last_call, fp_out, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->q_con,
+                 c->cappa};
   RT(launch_c(c, "riem_solver3", col_grid(c->g.nx * c->g.ny), kf));
   return 0;
 }

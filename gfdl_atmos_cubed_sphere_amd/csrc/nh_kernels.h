@@ -99,6 +99,9 @@ struct UpdateDzC {
 struct ColIn {
   const double *delp, *pt, *w, *zlev;  // zlev: gz (C) or zh (D) interface heights, km+1 levels
   double zscale;                       // dz2 = (zlev(k+1)-zlev(k)) * zscale   (1 for both; kept for clarity)
+  // MOIST columns only (same level stride): q_con (use_cond: the hydrostatic pressure of pm2 excludes the condensates,
+  // nh_core.F90:113-131,145-154 / nh_utils.F90:383-396,413-438) and cappa (moist_kappa: per-cell kappa) or null
+  const double *qcon = nullptr, *cappa = nullptr;
 };
 
 #ifdef FV3_HOST_EMU
@@ -114,19 +117,24 @@ struct ColIn {
 //   on_pe(k, pe2(k)), k = 1..km+1 ascending  -- the nonhydrostatic pressure perturbation at the interfaces,
 //   on_w(k, w2(k)),  k = 1..km               -- the new vertical velocity (may overwrite in.w: level k is not read again),
 //   on_dz(k, dz2(k)), k = km..1 descending   -- the new layer thickness (may overwrite in.zlev: not read after pass C).
-template <class OnPe, class OnW, class OnDz>
+template <bool MOIST = false, class OnPe, class OnW, class OnDz>
 FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhConsts &cn, bool sim1, bool c_grid,
                        double ws, double *FV3_RESTRICT s_gam, double *FV3_RESTRICT s_pp, double *FV3_RESTRICT s_w,
                        double *FV3_RESTRICT s_pm, const OnPe &on_pe, const OnW &on_w, const OnDz &on_dz) {
   constexpr double r3 = 1. / 3.;
   const double rgrav = 1. / cn.grav, rgas = cn.rdgas;
-  const double gm2 = 1. / (1. - cn.akap), cp2 = cn.akap;
+  const double gm2c = 1. / (1. - cn.akap), cp2c = cn.akap;
+  // gm2(k), cp2(k): constants unless the column carries cappa (C grid: only together with q_con, nh_utils.F90:413-425)
+  const bool has_cappa = MOIST && in.cappa && (!c_grid || in.qcon);
+  auto cp2_at = [&](int k) { return has_cappa ? in.cappa[(size_t)(k - 1) * ls] : cp2c; };
+  auto gm2_at = [&](int k) { return has_cappa ? 1. / (1. - in.cappa[(size_t)(k - 1) * ls]) : gm2c; };
   const double alpha = cn.a_imp, beta = 1. - alpha, ra = 1. / alpha, t2 = beta / alpha;
   const double t1g = sim1 ? 2. * dt * dt : 2. * ((alpha * dt) * (alpha * dt));
   const double rdt = 1. / dt;
 #define L(p, k) (p)[(size_t)((k)-1) * ls]
   // ---- pass A: pe(k), pm2(k); forward elimination for pp (:1297-1326) ----
   double pem_k = cn.ptop, peln_k = log(cn.ptop);
+  double peg_k = cn.ptop, pelng_k = peln_k;  // MOIST + q_con: dry-gas + vapour hydrostatic pressure and its log
   double z_top = L(in.zlev, 1);  // zlev(k) of the level being set up: each interface height is loaded once
   auto level = [&](int k, double &dm2, double &dz2, double &pm2, double &pe, double &pem_next, double &peln_next) {
     const double dmr = L(in.delp, k);
@@ -138,11 +146,22 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
       peln_next = log(pem_next);          // nh_core.F90:140,159
       pm2 = dmr / (peln_next - peln_k);
     }
+    if (MOIST && in.qcon) {               // excluding the contribution from condensates
+      const double peg_next = peg_k + dmr * (1. - L(in.qcon, k));
+      if (c_grid) {
+        pm2 = (peg_next - peg_k) / log(peg_next / peg_k);      // nh_utils.F90:418,429
+      } else {
+        const double pelng_next = log(peg_next);               // nh_core.F90:126-127
+        pm2 = (peg_next - peg_k) / (pelng_next - pelng_k);     // :148
+        pelng_k = pelng_next;
+      }
+      peg_k = peg_next;
+    }
     dm2 = dmr * rgrav;
     const double z_bot = L(in.zlev, k + 1);
     dz2 = z_bot - z_top;
     z_top = z_bot;
-    pe = exp(gm2 * log(-dm2 / dz2 * rgas * L(in.pt, k))) - pm2;
+    pe = exp(gm2_at(k) * log(-dm2 / dz2 * rgas * L(in.pt, k))) - pm2;
   };
   double dm_c, dz_c, pm_c, pe_c, pem_n, peln_n;
   level(1, dm_c, dz_c, pm_c, pe_c, pem_n, peln_n);
@@ -213,7 +232,7 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
         z_lo = z_n;
         dz_c2 = dz_n;
         w_c = L(in.w, k + 1);
-        aa_n = t1g * 0.5 * (gm2 + gm2) / (dz2 + dz_n) * pem_next;
+        aa_n = t1g * 0.5 * (gm2_at(k) + gm2_at(k + 1)) / (dz2 + dz_n) * pem_next;
         if (!sim1) {
           wk_n = t2 * aa_n * (w1 - w_c);
           aa_n = aa_n - 0.0 * dm1;  // scale_m = 0 (nh_utils.F90:1467)
@@ -230,7 +249,7 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
         w2 = sim1 ? (dm2 * w1 + dt * (pp_k1 - pp_k0) - aa_k * w_prev) / bet
                   : (dm2 * w1 + dt * (pp_k1 - pp_k0) + wk_n - wk_k - aa_k * w_prev) / bet;
       } else {
-        const double p1 = t1g * gm2 / dz2 * pem_next;  // pem(km+1)
+        const double p1 = t1g * gm2_at(km) / dz2 * pem_next;  // pem(km+1)
         const double gam = aa_k / bet;
         bet = dm2 - (aa_k + p1 + aa_k * gam);
         L(s_gam, k) = gam;
@@ -297,7 +316,7 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
         pp_2 = pp_1;
         pp_1 = pp_0;
       }
-      on_dz(k, -dm2 * rgas * L(in.pt, k) * exp((cp2 - 1.) * log(dmax(cn.p_fac * pm2, p1 + pm2))));
+      on_dz(k, -dm2 * rgas * L(in.pt, k) * exp((cp2_at(k) - 1.) * log(dmax(cn.p_fac * pm2, p1 + pm2))));
       dm_below = dm2;
     }
   }
@@ -315,17 +334,26 @@ struct RiemSolverC {
   const double *hs, *w3, *pt, *delp, *ws;
   double *gz, *pef;
   double *s0, *s1, *s2, *s3;  // scratch slabs, A x (km+1)
+  const double *q_con, *cappa;  // A x km or null (use_cond / moist_kappa)
   FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    if (q_con) run<true>(bx, tid); else run<false>(bx, tid);
+  }
+  template <bool MOIST>
+  FV3_HD void run(int bx, int tid) const {
     const int w = g.nx + 2, ncol = w * (g.ny + 2);
     const size_t nA = g.nA();
     FV3_COL_FOR(c, ncol) {
       const int i = g.is - 1 + c % w, j = g.js - 1 + c / w;
       const int o = g.iA(i, j);
       ColIn in{delp + o, pt + o, w3 + o, gz + o, 1.};
+      if (MOIST) {
+        in.qcon = q_con + o;
+        in.cappa = cappa ? cappa + o : nullptr;
+      }
       // pef = pe2 + pem (:461-465); gz = hs - sum dz2*grav (:468-476), formed inside the solver's last two sweeps
       double pem = cn.ptop;
       double zb = hs[o];
-      sim_column(
+      sim_column<MOIST>(
           km, nA, in, dt, cn, true, true, ws[o], s0 + o, s1 + o, s2 + o, s3 + o,
           [&](int k, double pe2) {
             if (k == 1) {
@@ -354,7 +382,12 @@ struct RiemSolver3 {
   double *w, *delz, *zh, *pe, *ppe, *pk3, *pk, *peln;
   int use_logp, last_call, fp_out;
   double *s0, *s1, *s2, *s3;
+  const double *q_con, *cappa;  // A x km or null (use_cond / moist_kappa, nh_core.F90:96-166)
   FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    if (q_con || cappa) run<true>(bx, tid); else run<false>(bx, tid);
+  }
+  template <bool MOIST>
+  FV3_HD void run(int bx, int tid) const {
     const int ncol = g.nx * g.ny;
     const size_t nA = g.nA(), nCC = g.nCC();
     const bool sim1 = cn.a_imp > 0.999;
@@ -363,10 +396,14 @@ struct RiemSolver3 {
       const int i = g.is + c % g.nx, j = g.js + c / g.nx;
       const int o = g.iA(i, j), occ = g.iCC(i, j);
       ColIn in{delp + o, pt + o, w + o, zh + o, 1.};
+      if (MOIST) {
+        in.qcon = q_con ? q_con + o : nullptr;
+        in.cappa = cappa ? cappa + o : nullptr;
+      }
       // hydrostatic pressure functions (:132-143) and the outputs (:191-237) are formed inside the solver's last sweeps
       double pem = cn.ptop;
       double zb = zs[o];
-      sim_column(
+      sim_column<MOIST>(
           km, nA, in, dt, cn, sim1, false, ws[occ], s0 + o, s1 + o, s2 + o, s3 + o,
           [&](int k, double pe2) {
             if (k == 1) {

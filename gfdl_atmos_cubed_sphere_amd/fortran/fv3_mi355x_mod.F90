@@ -18,7 +18,7 @@ module fv3_mi355x_mod
   public :: fv3_heat_source_accum, fv3_del2_cubed, fv3_apply_heat_source
   public :: fv3_d_sw_interior, fv3_d_sw_rest
   public :: fv3_divg2_ext, fv3_one_grad_p, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
-  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply
+  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_set_condensate
 
   type, bind(C) :: fv3_domain
     integer(c_int) :: is, ie, js, je, ng, npx, npy, npz, grid_type
@@ -266,6 +266,10 @@ module fv3_mi355x_mod
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: ctx, zs, ut, vt, gz_in, gz, ws
       real(c_double), value :: dt
+    end function
+    integer(c_int) function fv3_set_condensate(ctx, q_con, cappa) bind(C, name="fv3_set_condensate")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx, q_con, cappa
     end function
     integer(c_int) function fv3_riem_solver_c(ctx, dt, cn, hs, w3, pt, delp, gz, pef, ws) &
         bind(C, name="fv3_riem_solver_c")

@@ -33,7 +33,7 @@ EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
            "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report",
-           "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
+           "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
 
@@ -327,6 +327,11 @@ class Context:
         """model/nh_utils.F90:204 update_dz_d"""
         self.lib.check(self.lib.dll.fv3_update_dz_d(self.h, C.c_int(hord), zs.p, zh_in.p, zh_out.p, crx.p, cry.p,
                                                     xfx.p, yfx.p, ws.p, C.c_double(rdt)), "fv3_update_dz_d")
+
+    def set_condensate(self, q_con=None, cappa=None):
+        """use_cond / moist_kappa arrays of the following riem_solver_c / riem_solver3 calls (None = .false.)"""
+        self.lib.check(self.lib.dll.fv3_set_condensate(self.h, q_con.p if q_con is not None else None,
+                                                       cappa.p if cappa is not None else None), "fv3_set_condensate")
 
     def riem_solver3(self, dt, cn, zs, w, delz, pt, delp, zh, pe, ppe, pk3, pk, peln, ws, use_logp=False,
                      last_call=False, fp_out=False):

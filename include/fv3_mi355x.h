@@ -197,6 +197,13 @@ int fv3_set_dp_ref(fv3_ctx *ctx, const double *dp0);
 int fv3_update_dz_c(fv3_ctx *ctx, double dt, const double *zs, const double *ut, const double *vt,
                     const double *gz_in, double *gz, double *ws);
 
+/* use_cond / moist_kappa of Riem_Solver_c (nh_utils.F90:383-396, :413-438) and Riem_Solver3 (nh_core.F90:96-166): the
+ * device arrays q_con (A x npz, condensate mixing ratio: pm2 is then formed from the hydrostatic pressure without the
+ * condensates) and cappa (A x npz, moist kappa: gm2 = 1/(1-cappa), cp2 = cappa per cell) that the following
+ * fv3_riem_solver_c / fv3_riem_solver3 calls read.  NULL = .false. (the default).  As in the reference, Riem_Solver_c
+ * uses cappa only together with q_con. */
+int fv3_set_condensate(fv3_ctx *ctx, const double *q_con, const double *cappa);
+
 /* Riem_Solver_c -- model/nh_utils.F90:323, call site model/dyn_core.F90:531 (a_imp > 0.5: SIM1_solver).
  * hs, ws: A; w3 (=omga), pt (=ptc), delp (=delpc): A x npz; gz (in/out), pef (=pkc, out): A x (npz+1). */
 int fv3_riem_solver_c(fv3_ctx *ctx, double dt, const fv3_nh_consts *cn, const double *hs, const double *w3,

@@ -3,7 +3,8 @@
  * path of the acoustic substep: model/nh_utils.F90 (update_dz_c, update_dz_d, edge_profile,
  * Riem_Solver_c, SIM1_solver, SIM_solver), model/nh_core.F90 (Riem_Solver3) and the pressure
  * gradient / halo-recompute helpers of model/dyn_core.F90 (p_grad_c, nh_p_grad, pk3_halo, pln_halo,
- * pe_halo, geopk).  Branches: use_cond = moist_kappa = .false., fast_tau_w_sec = 0, d2bg_zq = 0,
+ * pe_halo, geopk).  Branches: use_cond / moist_kappa in the Riemann solvers only (q_con, cappa arguments; .false.
+ * elsewhere), fast_tau_w_sec = 0, d2bg_zq = 0,
  * grid_type >= 3.  Physical constants (grav, rdgas, cp_air) come from FMS constants_mod, which is
  * not part of the reference tree; they are passed in by the caller (GFDL defaults: grav=9.80,
  * rdgas=287.04, kappa=2/7, cp_air=rdgas/kappa).
@@ -218,11 +219,13 @@ static void sim_column(int km, double dt, double rgas, const double *gm2, const 
   free(aa); free(bb); free(dd); free(w1); free(wk); free(g_rat); free(gam); free(pp);
 }
 
-/* Riem_Solver_c, nh_utils.F90:323-480 (use_cond = .false.; a_imp > 0.5 -> SIM1_solver).
- * hs, ws: A; w3, pt, delp: A x km; gz, pef: A x (km+1). */
+/* Riem_Solver_c, nh_utils.F90:323-480 (a_imp > 0.5 -> SIM1_solver).  q_con != NULL: use_cond = .true. (:383-396,
+ * :413-438); cappa != NULL (with q_con): moist_kappa = .true. (:414-424).  hs, ws: A; w3, pt, delp, q_con, cappa: A x km;
+ * gz, pef: A x (km+1). */
 int fvo_riem_solver_c(const fvo_grid *g, int km, double dt, double akap, double ptop, const double *hs,
                       const double *w3, const double *pt, const double *delp, double *gz, double *pef,
-                      const double *ws, double p_fac, double a_imp, double grav, double rdgas) {
+                      const double *ws, double p_fac, double a_imp, double grav, double rdgas, const double *q_con,
+                      const double *cappa) {
   BOUNDS(g);
   int j;
   if (a_imp <= 0.5) return FVO_ERR_UNSUPPORTED;
@@ -233,16 +236,23 @@ int fvo_riem_solver_c(const fvo_grid *g, int km, double dt, double akap, double 
     int i, k;
     double *dm = dalloc(km + 2), *dz2 = dalloc(km + 2), *w2 = dalloc(km + 2), *pm2 = dalloc(km + 2),
            *gm2 = dalloc(km + 2), *cp2 = dalloc(km + 2), *pem = dalloc(km + 3), *pe2 = dalloc(km + 3),
-           *pt2 = dalloc(km + 2);
+           *pt2 = dalloc(km + 2), *peg = dalloc(km + 3);
     for (i = is1; i <= ie1; i++) {
       for (k = 1; k <= km; k++) dm[k] = delp[A3(i, j, k)];
       pef[A3(i, j, 1)] = ptop;
       pem[1] = ptop;
-      for (k = 2; k <= km + 1; k++) pem[k] = pem[k - 1] + dm[k - 1];
+      peg[1] = ptop;
+      for (k = 2; k <= km + 1; k++) {
+        pem[k] = pem[k - 1] + dm[k - 1];
+        if (q_con) peg[k] = peg[k - 1] + dm[k - 1] * (1. - q_con[A3(i, j, k - 1)]); /* :394 */
+      }
       for (k = 1; k <= km; k++) {
         dz2[k] = gz[A3(i, j, k + 1)] - gz[A3(i, j, k)];
-        pm2[k] = dm[k] / log(pem[k + 1] / pem[k]);
-        cp2[k] = akap;
+        if (q_con)
+          pm2[k] = (peg[k + 1] - peg[k]) / log(peg[k + 1] / peg[k]);
+        else
+          pm2[k] = dm[k] / log(pem[k + 1] / pem[k]);
+        cp2[k] = (q_con && cappa) ? cappa[A3(i, j, k)] : akap;
         gm2[k] = 1. / (1. - cp2[k]);
         dm[k] = dm[k] * rgrav;
         w2[k] = w3[A3(i, j, k)];
@@ -253,18 +263,20 @@ int fvo_riem_solver_c(const fvo_grid *g, int km, double dt, double akap, double 
       gz[A3(i, j, km + 1)] = hs[IA(i, j)];
       for (k = km; k >= 1; k--) gz[A3(i, j, k)] = gz[A3(i, j, k + 1)] - dz2[k] * grav;
     }
-    free(dm); free(dz2); free(w2); free(pm2); free(gm2); free(cp2); free(pem); free(pe2); free(pt2);
+    free(dm); free(dz2); free(w2); free(pm2); free(gm2); free(cp2); free(pem); free(pe2); free(pt2); free(peg);
   }
   return FVO_OK;
 }
 
-/* Riem_Solver3, nh_core.F90:47-241 (use_cond = moist_kappa = .false., d2bg_zq = 0).
+/* Riem_Solver3, nh_core.F90:47-241 (d2bg_zq = 0).  q_con != NULL: use_cond = .true. (:113-131, :145-154); cappa != NULL:
+ * moist_kappa = .true. (:96-102).  q_con, cappa: A x km.
  * zs: A; ws: CC; w, delp, pt: A x km; zh, ppe, pk3: A x (km+1); delz: CC x km; pk: CC x (km+1);
  * pe: (is-1:ie+1, km+1, js-1:je+1); peln: (is:ie, km+1, js:je). */
 int fvo_riem_solver3(const fvo_grid *g, int km, double dt, double akap, double ptop, const double *zs, double *w,
                      double *delz, const double *pt, const double *delp, double *zh, double *pe, double *ppe,
                      double *pk3, double *pk, double *peln, const double *ws, double p_fac, double a_imp,
-                     int use_logp, int last_call, int fp_out, double grav, double rdgas) {
+                     int use_logp, int last_call, int fp_out, double grav, double rdgas, const double *q_con,
+                     const double *cappa) {
   BOUNDS(g);
   int j;
   if (a_imp <= 0.5) return FVO_ERR_UNSUPPORTED;
@@ -276,22 +288,31 @@ int fvo_riem_solver3(const fvo_grid *g, int km, double dt, double akap, double p
     int i, k;
     double *dm = dalloc(km + 2), *dz2 = dalloc(km + 2), *w2 = dalloc(km + 2), *pm2 = dalloc(km + 2),
            *gm2 = dalloc(km + 2), *cp2 = dalloc(km + 2), *pem = dalloc(km + 3), *pe2 = dalloc(km + 3),
-           *peln2 = dalloc(km + 3), *pt2 = dalloc(km + 2);
+           *peln2 = dalloc(km + 3), *pt2 = dalloc(km + 2), *peg = dalloc(km + 3), *pelng = dalloc(km + 3);
     for (i = is; i <= ie; i++) {
       for (k = 1; k <= km; k++) {
         dm[k] = delp[A3(i, j, k)];
-        cp2[k] = akap;
+        cp2[k] = cappa ? cappa[A3(i, j, k)] : akap;
       }
       pem[1] = ptop;
       peln2[1] = peln1;
       pk3[A3(i, j, 1)] = ptk;
+      peg[1] = ptop;
+      pelng[1] = peln1;
       for (k = 2; k <= km + 1; k++) {
         pem[k] = pem[k - 1] + dm[k - 1];
         peln2[k] = log(pem[k]);
+        if (q_con) { /* excluding the contribution from condensates, :125-127 */
+          peg[k] = peg[k - 1] + dm[k - 1] * (1. - q_con[A3(i, j, k - 1)]);
+          pelng[k] = log(peg[k]);
+        }
         pk3[A3(i, j, k)] = exp(akap * peln2[k]);
       }
       for (k = 1; k <= km; k++) {
-        pm2[k] = dm[k] / (peln2[k + 1] - peln2[k]);
+        if (q_con)
+          pm2[k] = (peg[k + 1] - peg[k]) / (pelng[k + 1] - pelng[k]);
+        else
+          pm2[k] = dm[k] / (peln2[k + 1] - peln2[k]);
         gm2[k] = 1. / (1. - cp2[k]);
         dm[k] = dm[k] * rgrav;
         dz2[k] = zh[A3(i, j, k + 1)] - zh[A3(i, j, k)];
@@ -320,6 +341,7 @@ int fvo_riem_solver3(const fvo_grid *g, int km, double dt, double akap, double p
       for (k = km; k >= 1; k--) zh[A3(i, j, k)] = zh[A3(i, j, k + 1)] - dz2[k];
     }
     free(dm); free(dz2); free(w2); free(pm2); free(gm2); free(cp2); free(pem); free(pe2); free(peln2); free(pt2);
+    free(peg); free(pelng);
   }
   return FVO_OK;
 }

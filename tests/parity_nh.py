@@ -72,7 +72,15 @@ def check_update_dz_c(lib, nx=24, ny=13, km=6):
         ctx.close()
 
 
-def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0):
+def moist_fields(bd, km, seed=17):
+    """q_con in [0, 0.02] and cappa around kappa: the use_cond / moist_kappa inputs of the Riemann solvers"""
+    rng = np.random.default_rng(seed)
+    q_con = np.asfortranarray(0.02 * rng.uniform(0, 1, bd.shape("A", km)))
+    cappa = np.asfortranarray((2.0 / 7.0) * (1.0 - 0.1 * rng.uniform(0, 1, bd.shape("A", km))))
+    return q_con, cappa
+
+
+def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, moist_kappa=False):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     s = nh_state(bd, km)
@@ -82,10 +90,17 @@ def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0):
     hs = np.asfortranarray(s["zs"] * GRAV)
     gz = s["zh"].copy(order="F")
     pef = bd.zeros("A", km + 1)
-    O.riem_solver_c(g, km, 3.0, cn, hs, s["w"], s["pt"], s["delp"], gz, pef, ws)
+    q_con, cappa = moist_fields(bd, km)
+    q_con, cappa = (q_con if use_cond else None), (cappa if moist_kappa else None)
+    O.riem_solver_c(g, km, 3.0, cn, hs, s["w"], s["pt"], s["delp"], gz, pef, ws, q_con, cappa)
+    if use_cond:   # the moist branch really changes the answer
+        gz0, pef0 = s["zh"].copy(order="F"), bd.zeros("A", km + 1)
+        O.riem_solver_c(g, km, 3.0, cn, hs, s["w"], s["pt"], s["delp"], gz0, pef0, ws)
+        assert P.rel_rms(pef0, pef) > 1e-8
     ctx = Context(g, km, lib=lib)
     try:
         d_gz, d_pef = ctx.from_host(s["zh"]), ctx.zeros("A", km + 1)
+        ctx.set_condensate(ctx.from_host(q_con) if use_cond else None, ctx.from_host(cappa) if moist_kappa else None)
         ctx.riem_solver_c(3.0, cn, ctx.from_host(hs), ctx.from_host(s["w"]), ctx.from_host(s["pt"]),
                           ctx.from_host(s["delp"]), d_gz, d_pef, ctx.from_host(ws))
         r = (bd.is_ - 1, bd.ie + 1, bd.js - 1, bd.je + 1)
@@ -95,20 +110,31 @@ def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0):
         ctx.close()
 
 
-def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_call=True, fp_out=False):
+def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_call=True, fp_out=False, use_cond=False,
+                       moist_kappa=False):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     s = nh_state(bd, km)
     cn = nh_consts(PTOP, a_imp=a_imp)
     rng = np.random.default_rng(4)
     ws = np.asfortranarray(0.1 * rng.uniform(-1, 1, bd.shape("CC")))
+    q_con, cappa = moist_fields(bd, km)
+    q_con, cappa = (q_con if use_cond else None), (cappa if moist_kappa else None)
     o = dict(w=s["w"].copy(order="F"), zh=s["zh"].copy(order="F"), delz=bd.zeros("CC", km),
              ppe=bd.zeros("A", km + 1), pk3=bd.full("A", 1e40, km + 1), pk=bd.zeros("CC", km + 1),
              pe=np.zeros((nx + 2, km + 1, ny + 2), order="F"), peln=np.zeros((nx, km + 1, ny), order="F"))
     O.riem_solver3(g, km, 6.0, cn, s["zs"], o["w"], o["delz"], s["pt"], s["delp"], o["zh"], o["pe"], o["ppe"],
-                   o["pk3"], o["pk"], o["peln"], ws, use_logp, last_call, fp_out)
+                   o["pk3"], o["pk"], o["peln"], ws, use_logp, last_call, fp_out, q_con, cappa)
+    if use_cond or moist_kappa:   # the moist branches really change the answer
+        o0 = dict(w=s["w"].copy(order="F"), zh=s["zh"].copy(order="F"), delz=bd.zeros("CC", km),
+                  ppe=bd.zeros("A", km + 1), pk3=bd.full("A", 1e40, km + 1), pk=bd.zeros("CC", km + 1),
+                  pe=np.zeros((nx + 2, km + 1, ny + 2), order="F"), peln=np.zeros((nx, km + 1, ny), order="F"))
+        O.riem_solver3(g, km, 6.0, cn, s["zs"], o0["w"], o0["delz"], s["pt"], s["delp"], o0["zh"], o0["pe"], o0["ppe"],
+                       o0["pk3"], o0["pk"], o0["peln"], ws, use_logp, last_call, fp_out)
+        assert P.rel_rms(o0["delz"], o["delz"]) > 1e-8
     ctx = Context(g, km, lib=lib)
     try:
+        ctx.set_condensate(ctx.from_host(q_con) if use_cond else None, ctx.from_host(cappa) if moist_kappa else None)
         d = {k: ctx.from_host(v) for k, v in dict(w=s["w"], zh=s["zh"], delz=bd.zeros("CC", km),
                                                    ppe=bd.zeros("A", km + 1), pk3=bd.full("A", 1e40, km + 1),
                                                    pk=bd.zeros("CC", km + 1),

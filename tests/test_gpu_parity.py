@@ -415,3 +415,12 @@ def test_fortran_host_drives_the_library(prod, tmp_path):
         pytest.skip("no Fortran compiler in this image")
     out = F.check_fortran_host(prod, tmp_path)
     assert "fv3_solo: done" in out
+
+
+@pytest.mark.parametrize("use_cond,moist_kappa", [(True, False), (True, True), (False, True)])
+@pytest.mark.parametrize("a_imp", [1.0, 0.75])
+def test_riem_solvers_moist(prod, use_cond, moist_kappa, a_imp):
+    """use_cond / moist_kappa branches of Riem_Solver3 (nh_core.F90:96-166) and Riem_Solver_c (nh_utils.F90:383-438)"""
+    N.check_riem_solver3(prod, a_imp=a_imp, use_cond=use_cond, moist_kappa=moist_kappa)
+    if a_imp > 0.999 and use_cond:
+        N.check_riem_solver_c(prod, use_cond=True, moist_kappa=moist_kappa)
