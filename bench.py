@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--hord", type=int, default=10, help="hord_mt = hord_vt = hord_tm = hord_dp (reference default 10)")
     ap.add_argument("--no-model-step", action="store_true", help="skip the SYPD (whole model step) leg")
     ap.add_argument("--nq", type=int, default=4, help="advected tracers in the SYPD leg")
+    ap.add_argument("--model-step-multi", action="store_true", help="run the SYPD leg on N > 1 GPUs too")
     ap.add_argument("--general-metrics", action="store_true",
                     help="FV3_MI355X_GEOM=0: read every metric row (what a cubed-sphere gridstruct needs) instead of "
                          "using the uniform-Cartesian kernels the library selects for this doubly periodic gridstruct")
@@ -304,9 +305,19 @@ def main():
     ctx.close()
     ctx = None
     del d
-    out["model_step"] = None if a.no_model_step else model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream)
+    # the secondary legs must never cost the headline line: a failure there is reported, not raised
+    out["model_step"] = None
+    # N > 1: the SYPD leg is off unless asked for (a failure on one rank would leave the others in a collective)
+    if not a.no_model_step and (world == 1 or a.model_step_multi):
+        try:
+            out["model_step"] = model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream)
+        except Exception as e:  # noqa: BLE001
+            out["model_step"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not a.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(nx, a.cpu_seconds)
+        try:
+            out["cpu_baseline"] = cpu_baseline(nx, a.cpu_seconds)
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
