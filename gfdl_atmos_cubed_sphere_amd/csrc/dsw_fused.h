@@ -258,7 +258,8 @@ namespace fv3 {
 template <int SWC, int HORD, int GM = 0>
 struct DswMomentumFused {
   static constexpr bool UNI = (GM == 2);  // orthogonal + uniform metrics: scalars instead of metric rows
-  // 266 VGPRs natural: squeezing into 256 (8 spilled) buys the second wavefront per SIMD, measured 0.735 -> 0.65 ms
+  // two wavefronts per SIMD: 254 VGPRs with the general metric rows (the row-j values of the wind update are re-read at
+  // the top of the step instead of being carried for three steps), 188 with uniform metrics; measured 0.735 -> 0.57 -> 0.49 ms
   static constexpr int kTwoWavesPerSimd = 1;
   Grid g;
   DswArgs a;
