@@ -56,6 +56,9 @@ struct fv3_ctx {
   bool dp0_ready;
   double *scratch[8];
   double *ray_d;         // pm(k), rf(k) of Rayleigh_Friction
+  bool moist_on;         // fv3_set_moist: moist thermodynamics of the remap
+  fv3_moist_params moist;
+  double *moist_qcon, *moist_cappa;
   const double *q_con, *cappa;  // fv3_set_condensate: use_cond / moist_kappa arrays of the Riemann solvers (or null)
   double *remap_scr;     // coordinate + profile slabs of the vertical remap (fv3_lagrangian_to_eulerian)
   size_t remap_scr_n;
@@ -242,6 +245,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->akbk = nullptr; c->kord_tr_dev = nullptr; c->akbk_ready = false;
   c->remap_scr = nullptr; c->remap_scr_n = 0; c->ray_d = nullptr;
   c->q_con = nullptr; c->cappa = nullptr;
+  c->moist_on = false; c->moist_qcon = nullptr; c->moist_cappa = nullptr;
   c->trc_d = nullptr; c->trc_i = nullptr;
   for (auto &s : c->scratch) s = nullptr;
   c->lev_ext_d = nullptr; c->lev_ext_i = nullptr;
@@ -1137,7 +1141,26 @@ extern "C" int fv3_pt_to_theta_v(fv3_ctx *c, int hydrostatic, double zvir, doubl
   if (!pt || !pkz || (hydrostatic <= 0 && (!delp || !delz))) return fail("fv3_pt_to_theta_v: null field");
   if (hydrostatic < -1 || hydrostatic > 1) return fail("fv3_pt_to_theta_v: hydrostatic must be 0, 1 or -1 (pkz only)");
   const Grid &g = c->g;
-  PtToThetaV kf{g, hydrostatic, zvir, kappa, -rdgas / grav, pt, delp, delz, qv, pkz};
+  RemapPar mp{};
+  const double *mq = nullptr;
+  if (c->moist_on && (c->moist.moist_kappa || c->moist.use_cond)) {
+    const fv3_moist_params &m = c->moist;
+    if (m.use_cond && !c->moist_qcon) return fail("fv3_pt_to_theta_v: use_cond needs q_con (fv3_set_moist)");
+    mp.use_cond = m.use_cond;
+    mp.q_con = c->moist_qcon;
+    mp.cappa = c->moist_cappa;
+    if (m.moist_kappa && hydrostatic <= 0) {
+      if (!qv || m.sphum < 1 || !c->moist_qcon || !c->moist_cappa)
+        return fail("fv3_pt_to_theta_v: moist_kappa needs qv = &q(.,.,1,sphum), sphum, q_con and cappa (fv3_set_moist)");
+      mp.moist_kappa = 1;
+      mp.nwat = m.nwat; mp.sphum = m.sphum; mp.liq_wat = m.liq_wat; mp.rainwat = m.rainwat; mp.ice_wat = m.ice_wat;
+      mp.snowwat = m.snowwat; mp.graupel = m.graupel;
+      mp.cv_vap = m.cv_vap; mp.c_liq = m.c_liq; mp.c_ice = m.c_ice;
+      mp.rdgas = rdgas; mp.cv_air = rdgas / kappa - rdgas;   // cp_air - rdgas with cp_air = rdgas / kappa (constants_mod)
+      mq = qv - (size_t)(m.sphum - 1) * g.nA() * g.npz;
+    }
+  }
+  PtToThetaV kf{g, hydrostatic, zvir, kappa, -rdgas / grav, pt, delp, delz, qv, pkz, mp, mq};
   Dim3 grid;
   grid.x = (unsigned)((g.nx * g.ny + PtToThetaV::CH - 1) / PtToThetaV::CH);
   grid.y = 1;
@@ -1397,6 +1420,15 @@ extern "C" int fv3_set_ak_bk(fv3_ctx *c, const double *ak, const double *bk) {
   return 0;
 }
 
+extern "C" int fv3_set_moist(fv3_ctx *c, const fv3_moist_params *m, double *q_con, double *cappa) {
+  if (!c) return fail("fv3_set_moist: null context");
+  c->moist_on = m != nullptr;
+  if (m) c->moist = *m;
+  c->moist_qcon = m ? q_con : nullptr;
+  c->moist_cappa = m ? cappa : nullptr;
+  return 0;
+}
+
 extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p, const int *kord_tr, double *ps,
                                           double *pe, double *delp, double *pkz, double *pk, double *u, double *v,
                                           double *w, double *delz, double *pt, double *q, double *peln, double *omga,
@@ -1420,7 +1452,24 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
     RT(rt_sync(c->stream));
   }
   RemapPar rp{p->last_step, p->hydrostatic, p->adiabatic, p->nq, p->kord_mt, p->kord_wz, p->kord_tm, p->sphum,
-              p->akap, p->ptop, p->rdgas, p->grav, p->cv_air, p->r_vir, p->cp, p->t_min};
+              p->akap, p->ptop, p->rdgas, p->grav, p->cv_air, p->r_vir, p->cp, p->t_min,
+              0, 0, 0, 0, 0, 0, 0, 0, 0., 0., 0., nullptr, nullptr};
+  const bool moist = c->moist_on && (c->moist.moist_kappa || c->moist.use_cond);
+  if (moist) {
+    const fv3_moist_params &m = c->moist;
+    if (p->hydrostatic) return fail("fv3_lagrangian_to_eulerian: moist_kappa / use_cond are nonhydrostatic branches");
+    if (p->sphum < 1 || p->sphum > p->nq || (m.sphum > 0 && m.sphum != p->sphum))
+      return fail("fv3_lagrangian_to_eulerian: moist branches need sphum (the same in both parameter sets)");
+    const int idx[5] = {m.liq_wat, m.rainwat, m.ice_wat, m.snowwat, m.graupel};
+    for (int n = 0; n < 5; n++)
+      if (idx[n] < 0 || idx[n] > p->nq) return fail("fv3_lagrangian_to_eulerian: water species index out of range");
+    if (m.moist_kappa && (!c->moist_qcon || !c->moist_cappa))
+      return fail("fv3_lagrangian_to_eulerian: moist_kappa needs q_con and cappa (fv3_set_moist)");
+    rp.moist_kappa = m.moist_kappa; rp.use_cond = m.use_cond; rp.nwat = m.nwat;
+    rp.liq_wat = m.liq_wat; rp.rainwat = m.rainwat; rp.ice_wat = m.ice_wat; rp.snowwat = m.snowwat; rp.graupel = m.graupel;
+    rp.cv_vap = m.cv_vap; rp.c_liq = m.c_liq; rp.c_ice = m.c_ice;
+    rp.q_con = c->moist_qcon; rp.cappa = c->moist_cappa;
+  }
   const double *ak = c->akbk, *bk = c->akbk + (km + 1);
   // field tasks: T_v, nq tracers, w (nonhydrostatic), u, v -- at most kRemapSets of them per launch, each with its own six
   // profile slabs; eight coordinate slabs (p, log p, and the face-averaged p of u and of v) in front of them
@@ -1443,13 +1492,18 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   }
   {
     const int nblk = ((g.nx + 1) * (g.ny + 1) + 255) / 256;  // covers the u and v columns too
-    for (int t0 = 0; t0 < ntask; t0 += nsets) {
-      const int nt = ntask - t0 < nsets ? ntask - t0 : nsets;
+    // task order: T_v, w, u, v, tracers.  With moist_kappa the T_v task reads the un-remapped tracers (moist_cv in its
+    // source transform), so the tracer tasks go into launches of their own after it.
+    const int n_head = 1 + (p->hydrostatic ? 0 : 1) + 2;
+    for (int t0 = 0; t0 < ntask;) {
+      int nt = ntask - t0 < nsets ? ntask - t0 : nsets;
+      if (rp.moist_kappa && t0 < n_head && t0 + nt > n_head) nt = n_head - t0;
       RemapFields kf{g, km, rp, ak, bk, c->kord_tr_dev, delp, pk, delz, peln, pe, ws, w, pt, q, omga, u, v,
                      co, co + slab, co + 2 * slab, co + 3 * slab, co + 4 * slab, co + 5 * slab, co + 6 * slab,
                      co + 7 * slab, sets, slab, t0, nblk};
       Dim3 gr = col_grid(256 * nblk * nt);
       RT(launch_c(c, "remap_fields", gr, kf));
+      t0 += nt;
     }
   }
   {

@@ -19,6 +19,7 @@
 #pragma once
 
 #include "fv3_common.h"
+#include "remap_kernels.h"  // RemapPar, moist_cv
 #include "tp2d_tile.h"
 
 namespace fv3 {
@@ -968,13 +969,17 @@ struct CopyAtoCC {  // compute-domain copy of an A-kind field into a CC-kind one
   }
 };
 
-struct PtToThetaV {  // fv_dynamics.F90:296-329, :379-399 (use_cond = moist_kappa = .false.)
+struct PtToThetaV {  // fv_dynamics.F90:296-329, :379-399
   Grid g;
   int hydrostatic;  // 1: pkz given; 0: pkz computed, pt converted; -1: pkz computed only (:323-326; Rayleigh_Friction follows)
   double zvir, kappa, rdg;
   double *pt;
   const double *delp, *delz, *qv;
   double *pkz;
+  // moist thermodynamics (fv3_set_moist): moist_kappa -> cappa, q_con from moist_cv and pkz with them (:305-317);
+  // use_cond -> the conversion carries (1 - q_con) (:381-388).  mq = &q(isd,jsd,1,1) when moist_kappa
+  RemapPar mp;
+  const double *mq;
   static constexpr int CH = 1024;
   FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
     const int n = g.nx * g.ny;
@@ -982,14 +987,23 @@ struct PtToThetaV {  // fv_dynamics.F90:296-329, :379-399 (use_cond = moist_kapp
       const int i = g.is + idx % g.nx, j = g.js + idx / g.nx;
       const size_t o = (size_t)bz * g.nA() + g.iA(i, j), c = (size_t)bz * g.nCC() + idx;
       const double dp1 = qv ? zvir * qv[o] : 0.;
-      double pz;
+      double pz, qc = 0.;
       if (hydrostatic > 0) {
         pz = pkz[c];
+        if (mp.use_cond) qc = mp.q_con[o];
+      } else if (mp.moist_kappa) {
+        const double cvm = moist_cv(mp, mq + o, g.nA() * g.npz, qc);
+        const double cap = mp.rdgas / (mp.rdgas + cvm / (1. + dp1));
+        mp.q_con[o] = qc;
+        mp.cappa[o] = cap;
+        pz = exp(cap * log(rdg * delp[o] * pt[o] * (1. + dp1) * (1. - qc) / delz[c]));
+        pkz[c] = pz;
       } else {
         pz = exp(kappa * log(rdg * delp[o] * pt[o] * (1. + dp1) / delz[c]));
         pkz[c] = pz;
+        if (mp.use_cond) qc = mp.q_con[o];
       }
-      if (hydrostatic >= 0) pt[o] = pt[o] * (1. + dp1) / pz;
+      if (hydrostatic >= 0) pt[o] = mp.use_cond ? pt[o] * (1. + dp1) * (1. - qc) / pz : pt[o] * (1. + dp1) / pz;
     }
   }
 };

@@ -456,7 +456,44 @@ FV3_HD void map_col(const ColScr &c, int km, bool tracer_form, const Out &out) {
 struct RemapPar {
   int last_step, hydrostatic, adiabatic, nq, kord_mt, kord_wz, kord_tm, sphum;
   double akap, ptop, rdgas, grav, cv_air, r_vir, cp, t_min;
+  // thermostruct%moist_kappa / use_cond (nonhydrostatic) and the inputs of moist_cv (fv3_set_moist)
+  int moist_kappa, use_cond, nwat, liq_wat, rainwat, ice_wat, snowwat, graupel;
+  double cv_vap, c_liq, c_ice;
+  double *q_con, *cappa;  // A x km, written where the reference writes them (fv_mapz.F90:212-219, :463-478)
 };
+
+// moist_cv of one cell (fv_thermodynamics.F90:250-325 without the t1 special case): returns cvm, sets q_con.
+// qk = &q(i,j,k,1), ns = stride between species
+FV3_HD double moist_cv(const RemapPar &p, const double *qk, size_t ns, double &q_con) {
+  auto Q = [&](int n) { return n > 0 ? qk[(size_t)(n - 1) * ns] : 0.; };
+  double qv, ql, qs;
+  switch (p.nwat) {
+    case 2:
+      qv = dmax(0., Q(p.sphum));
+      qs = dmax(0., Q(p.liq_wat));
+      q_con = qs;
+      return (1. - qv) * p.cv_air + qv * p.cv_vap;
+    case 3:
+      qv = Q(p.sphum); ql = Q(p.liq_wat); qs = Q(p.ice_wat);
+      q_con = ql + qs;
+      return (1. - (qv + q_con)) * p.cv_air + qv * p.cv_vap + ql * p.c_liq + qs * p.c_ice;
+    case 4:
+      qv = Q(p.sphum);
+      q_con = Q(p.liq_wat) + Q(p.rainwat);
+      return (1. - (qv + q_con)) * p.cv_air + qv * p.cv_vap + q_con * p.c_liq;
+    case 5:
+      qv = Q(p.sphum); ql = Q(p.liq_wat) + Q(p.rainwat); qs = Q(p.ice_wat) + Q(p.snowwat);
+      q_con = ql + qs;
+      return (1. - (qv + q_con)) * p.cv_air + qv * p.cv_vap + ql * p.c_liq + qs * p.c_ice;
+    case 6:
+      qv = Q(p.sphum); ql = Q(p.liq_wat) + Q(p.rainwat); qs = Q(p.ice_wat) + Q(p.snowwat) + Q(p.graupel);
+      q_con = ql + qs;
+      return (1. - (qv + q_con)) * p.cv_air + qv * p.cv_vap + ql * p.c_liq + qs * p.c_ice;
+    default:
+      q_con = 0.;
+      return p.cv_air;
+  }
+}
 
 #define FV3_COL_FOR2(c, ncol) for (int c = bx * 256 + tid; c < (bx + 1) * 256 && c < (ncol); c += kNT)
 
@@ -503,8 +540,10 @@ struct RemapCoords {
   }
 };
 
-// one thread per (column, field task); tasks: 0 = T_v / theta_v (+ omega on the last step), 1 .. nq = tracers,
-// nq+1 = w (nonhydrostatic), then u, v.  Task t of this launch uses profile-slab set t - task0.
+// one thread per (column, field task); tasks: 0 = T_v / theta_v (+ omega on the last step), w (nonhydrostatic), u, v,
+// then the nq tracers.  Task t of this launch uses profile-slab set t - task0.  (The tracers come last so that, with
+// moist_kappa, the T_v task -- whose source transform reads the un-remapped tracers through moist_cv -- can be launched
+// before them.)
 struct RemapFields {
   Grid g;
   int km;
@@ -523,7 +562,7 @@ struct RemapFields {
     const size_t nA = g.nA(), nCC = g.nCC();
     double *base = sets + (size_t)(task - task0) * 6 * slab;
     ColScr c{base, base + slab, base + 2 * slab, base + 3 * slab, base + 4 * slab, pe1p, pe2p, base + 5 * slab, nA, 0};
-    const int t_w = p.hydrostatic ? -1 : p.nq + 1, t_u = p.hydrostatic ? p.nq + 1 : p.nq + 2, t_v = t_u + 1;
+    const int t_w = p.hydrostatic ? -1 : 1, t_u = p.hydrostatic ? 1 : 2, t_v = t_u + 1;
     const int akt = p.kord_tm < 0 ? -p.kord_tm : p.kord_tm;
     if (task == t_u || task == t_v) {  // D-grid winds: u on (is:ie, js:je+1), v on (is:ie+1, js:je)  (fv_mapz.F90:530-573)
       const int which = task == t_u ? 0 : 1;
@@ -568,7 +607,17 @@ struct RemapFields {
               t = t * (pk[(size_t)k * nCC + occ] - pk[(size_t)(k - 1) * nCC + occ]) / (akap * (PELN(k + 1) - PELN(k)));
             } else {
               const double dpo = delp[(size_t)(k - 1) * nA + c.o];
-              t = t * exp(k1k * log(rrg * dpo / delz[(size_t)(k - 1) * nCC + occ] * t));
+              if (p.moist_kappa) {  // :212-219
+                const size_t o3 = (size_t)(k - 1) * nA + c.o;
+                double qc;
+                const double cvm = moist_cv(p, q + o3, nA * km, qc);
+                const double cap = p.rdgas / (p.rdgas + cvm / (1. + p.r_vir * q[(size_t)(p.sphum - 1) * nA * km + o3]));
+                p.q_con[o3] = qc;
+                p.cappa[o3] = cap;
+                t = t * exp(cap / (1. - cap) * log(rrg * dpo / delz[(size_t)(k - 1) * nCC + occ] * t));
+              } else {
+                t = t * exp(k1k * log(rrg * dpo / delz[(size_t)(k - 1) * nCC + occ] * t));
+              }
             }
           }
           return t;
@@ -607,7 +656,7 @@ struct RemapFields {
         profile_col(c, km, false, ws[occ], -2, p.kord_wz, 0., [&](int k) { return w[(size_t)(k - 1) * nA + c.o]; });
         map_col(c, km, false, [&](int k, double v_) { w[(size_t)(k - 1) * nA + c.o] = v_; });
       } else {  // constituents (:380-397)
-        const int iq = task - 1;
+        const int iq = task - (t_v + 1);
         double *qq = q + (size_t)iq * nA * km;
         profile_col(c, km, true, 0., 0, kord_tr[iq], 0., [&](int k) { return qq[(size_t)(k - 1) * nA + c.o]; });
         map_col(c, km, p.nq > 5, [&](int k, double v_) { qq[(size_t)(k - 1) * nA + c.o] = v_; });
@@ -662,7 +711,15 @@ struct RemapDelzFinal {
         const double tv = pt[(size_t)(k - 1) * nA + c.o];
         if (p.hydrostatic)
           pkzv = (pk_next - pk_prev) / (akap * (pn_next - pn_prev));
-        else if (p.kord_tm < 0)
+        else if (p.moist_kappa) {  // :463-478: q holds the remapped tracers
+          const size_t o3 = (size_t)(k - 1) * nA + c.o;
+          double qc;
+          const double cvm = moist_cv(p, q + o3, nA * km, qc);
+          const double cap = p.rdgas / (p.rdgas + cvm / (1. + p.r_vir * q[(size_t)(p.sphum - 1) * nA * km + o3]));
+          p.q_con[o3] = qc;
+          p.cappa[o3] = cap;
+          pkzv = exp((p.kord_tm < 0 ? cap : cap / (1. - cap)) * log(rrg * dp2 / delz[(size_t)(k - 1) * nCC + occ] * tv));
+        } else if (p.kord_tm < 0)
           pkzv = exp(akap * log(rrg * dp2 / delz[(size_t)(k - 1) * nCC + occ] * tv));
         else
           pkzv = exp(k1k * log(rrg * dp2 / delz[(size_t)(k - 1) * nCC + occ] * tv));
@@ -670,7 +727,12 @@ struct RemapDelzFinal {
         double tnew = tv;
         if (p.kord_tm > 0) tnew = tnew * pkzv;  // :496-502
         if (p.last_step) {                      // :793-821 (dtmp = 0)
-          if (!p.adiabatic) {
+          if (!p.hydrostatic && p.use_cond) {   // :806-811
+            const size_t o3 = (size_t)(k - 1) * nA + c.o;
+            double qc;
+            const double cvm = moist_cv(p, q + o3, nA * km, qc);
+            tnew = (tnew + 0. / cvm * pkzv) / ((1. + p.r_vir * q[(size_t)(p.sphum - 1) * nA * km + o3]) * (1. - qc));
+          } else if (!p.adiabatic) {
             const double qv = p.sphum > 0 ? q[(size_t)(p.sphum - 1) * nA * km + (size_t)(k - 1) * nA + c.o] : 0.;
             tnew = (tnew + 0. / (p.hydrostatic ? p.cp : p.cv_air) * pkzv) / (1. + p.r_vir * qv);
           }

@@ -18,7 +18,7 @@ module fv3_mi355x_mod
   public :: fv3_heat_source_accum, fv3_del2_cubed, fv3_apply_heat_source
   public :: fv3_d_sw_interior, fv3_d_sw_rest
   public :: fv3_divg2_ext, fv3_one_grad_p, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
-  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_set_condensate
+  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_set_condensate, fv3_set_moist, fv3_moist_params
 
   type, bind(C) :: fv3_domain
     integer(c_int) :: is, ie, js, je, ng, npx, npy, npz, grid_type
@@ -54,6 +54,11 @@ module fv3_mi355x_mod
 
   type, bind(C) :: fv3_nh_consts      ! FMS constants_mod values + namelist scalars
     real(c_double) :: grav, rdgas, cp_air, akap, ptop, p_fac, a_imp
+  end type
+
+  type, bind(C) :: fv3_moist_params   ! moist_kappa / use_cond of the remap + the inputs of moist_cv
+    integer(c_int) :: moist_kappa, use_cond, nwat, sphum, liq_wat, rainwat, ice_wat, snowwat, graupel
+    real(c_double) :: cv_vap, c_liq, c_ice
   end type
 
   type, bind(C) :: fv3_remap_params   ! Lagrangian_to_Eulerian scalars (fv_mapz.F90:56-64)
@@ -326,6 +331,11 @@ module fv3_mi355x_mod
       type(c_ptr), value :: ctx, pe, peln, delp, pk, gz, hs, pt, pkz
       real(c_double), value :: ptop, akap, cp_air, ptk
       integer(c_int), value :: cg
+    end function
+    integer(c_int) function fv3_set_moist(ctx, m, q_con, cappa) bind(C, name="fv3_set_moist")
+      import :: c_int, c_ptr, fv3_moist_params
+      type(c_ptr), value :: ctx, q_con, cappa
+      type(fv3_moist_params), intent(in) :: m
     end function
     integer(c_int) function fv3_set_ak_bk(ctx, ak, bk) bind(C, name="fv3_set_ak_bk")
       import :: c_int, c_ptr, c_double

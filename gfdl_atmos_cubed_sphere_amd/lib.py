@@ -34,7 +34,7 @@ EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
            "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
-           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_lagrangian_to_eulerian",
+           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
 
 
@@ -80,6 +80,11 @@ class _RemapParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ["last_step", "hydrostatic", "adiabatic", "nq", "kord_mt", "kord_wz", "kord_tm",
                                        "sphum"]] + [(n, C.c_double) for n in ["akap", "ptop", "rdgas", "grav", "cv_air",
                                                                               "r_vir", "cp", "t_min"]]
+
+
+class _MoistParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ["moist_kappa", "use_cond", "nwat", "sphum", "liq_wat", "rainwat", "ice_wat",
+                                       "snowwat", "graupel"]] + [(n, C.c_double) for n in ["cv_vap", "c_liq", "c_ice"]]
 
 
 class Fv3Lib:
@@ -375,6 +380,17 @@ class Context:
         assert a.size == self.npz + 1 and b.size == self.npz + 1
         self.lib.check(self.lib.dll.fv3_set_ak_bk(self.h, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp)), "fv3_set_ak_bk")
 
+    def set_moist(self, par: dict | None, q_con=None, cappa=None):
+        """moist_kappa / use_cond branches of the remap (fv_mapz.F90:212-219, :463-478, :806-811); None = off"""
+        if par is None:
+            self.lib.check(self.lib.dll.fv3_set_moist(self.h, None, None, None), "fv3_set_moist")
+            return
+        m = _MoistParams()
+        for k, _ in _MoistParams._fields_:
+            setattr(m, k, par.get(k, 0))
+        self.lib.check(self.lib.dll.fv3_set_moist(self.h, C.byref(m), q_con.p if q_con is not None else None,
+                                                  cappa.p if cappa is not None else None), "fv3_set_moist")
+
     def lagrangian_to_eulerian(self, par: dict, ps, pe, delp, pkz, pk, u, v, w, delz, pt, q, peln, omga, ws):
         """model/fv_mapz.F90:56 Lagrangian_to_Eulerian"""
         s = _RemapParams()
@@ -415,7 +431,7 @@ class Context:
         self.lib.check(self.lib.dll.fv3_pt_to_theta_v(
             self.h, C.c_int(int(hydrostatic)), C.c_double(zvir), C.c_double(kappa), C.c_double(rdgas), C.c_double(grav),
             pt.p, delp.p if delp is not None else None, delz.p if delz is not None else None,
-            C.cast(_vp(qv), _dp) if qv is not None else None, pkz.p), "fv3_pt_to_theta_v")
+            C.cast(_vp(getattr(qv, "ptr", qv)), _dp) if qv is not None else None, pkz.p), "fv3_pt_to_theta_v")
 
     def c2l(self, c2l_ord, u, v, ua, va):
         """cubed_to_latlon (fv_grid_utils.F90:2319), grid_type = 4 branches; ord 4 needs the halo of u, v"""

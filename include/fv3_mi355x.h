@@ -318,6 +318,19 @@ typedef struct fv3_remap_params {
   int last_step, hydrostatic, adiabatic, nq, kord_mt, kord_wz, kord_tm, sphum;
   double akap, ptop, rdgas, grav, cv_air, r_vir, cp, t_min;
 } fv3_remap_params;
+/* thermostruct%moist_kappa / use_cond in the remap (nonhydrostatic): the T_v <-> T_m transforms use the moist kappa
+ * cappa = rdgas / (rdgas + cvm/(1 + r_vir*qv)) with cvm, q_con from moist_cv (fv_thermodynamics.F90:250-325; nwat and the
+ * 1-based tracer indices of the water species, 0 = absent; cv_vap = 3*rvgas, c_liq, c_ice of gfdl_mp.F90:136-137), q_con
+ * and cappa (A x npz, device) are rewritten (fv_mapz.F90:212-219, :463-478), and with use_cond the last step returns
+ * T = T_m / ((1 + r_vir*qv)(1 - q_con)) (:806-811).  fv3_pt_to_theta_v follows the same switches (fv_dynamics.F90:305-317,
+ * :381-388): with moist_kappa its qv argument must be &q(isd,jsd,1,sphum) of the full tracer array, pkz uses cappa and
+ * (1 - q_con) and both arrays are written; with use_cond the conversion carries (1 - q_con).  m = NULL switches the moist
+ * branches off (the default). */
+typedef struct fv3_moist_params {
+  int moist_kappa, use_cond, nwat, sphum, liq_wat, rainwat, ice_wat, snowwat, graupel;
+  double cv_vap, c_liq, c_ice;
+} fv3_moist_params;
+int fv3_set_moist(fv3_ctx *ctx, const fv3_moist_params *m, double *q_con, double *cappa);
 /* ak, bk: HOST arrays of length npz+1 (the hybrid coordinate, tools/fv_eta.F90). */
 int fv3_set_ak_bk(fv3_ctx *ctx, const double *ak, const double *bk);
 int fv3_lagrangian_to_eulerian(fv3_ctx *ctx, const fv3_remap_params *p, const int *kord_tr, double *ps, double *pe,

@@ -183,11 +183,19 @@ typedef struct fvo_remap_par {
   const int *kord_tr;
   double akap, ptop, rdgas, grav, cv_air, r_vir, cp, t_min;
   int sphum;
+  /* thermostruct%moist_kappa / use_cond (nonhydrostatic only) and what moist_cv needs (fv_thermodynamics.F90:250-325):
+   * nwat and the 1-based tracer indices of the water species (0 = absent), cv_vap = 3*rvgas, c_liq, c_ice (gfdl_mp) */
+  int moist_kappa, use_cond, nwat, liq_wat, rainwat, ice_wat, snowwat, graupel;
+  double cv_vap, c_liq, c_ice;
 } fvo_remap_par;
+/* q_con, cappa: A x km, written when moist_kappa (fv_mapz.F90:212-219, :463-478); may be NULL otherwise */
 int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p, double *ps, double *pe, double *delp,
                                double *pkz, double *pk, double *u, double *v, double *w, double *delz, double *pt,
                                double *q, double *peln, double *omga, const double *ws, const double *ak,
-                               const double *bk);
+                               const double *bk, double *q_con, double *cappa);
+/* moist_cv for one cell (fv_thermodynamics.F90:250-325, without the t1 special case): returns cvm, sets *q_con.
+ * qk points at q(i,j,k,1); species stride ns. */
+double fvo_moist_cv(const fvo_remap_par *p, const double *qk, size_t ns, double *q_con);
 
 /* ---- tracer_2d (oracle/tracer2d.c) ---------------------------------------------------------------- */
 int fvo_tracer_2d(const fvo_grid *g, int npz, int nq, double *q, double *dp1, double *mfx, double *mfy, double *cx,

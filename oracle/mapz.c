@@ -326,16 +326,50 @@ int fvo_remap_column(int which, int km, const double *pe1, const double *pe2, co
  * ------------------------------------------------------------------------------------------------- */
 
 
+double fvo_moist_cv(const fvo_remap_par *p, const double *qk, size_t ns, double *q_con) {
+#define Q(n) ((n) > 0 ? qk[(size_t)((n)-1) * ns] : 0.)
+  double qv, ql, qs;
+  switch (p->nwat) {
+    case 2: /* :279-285 (no t1) */
+      qv = fmax(0., Q(p->sphum));
+      qs = fmax(0., Q(p->liq_wat));
+      *q_con = qs;
+      return (1. - qv) * p->cv_air + qv * p->cv_vap;
+    case 3:
+      qv = Q(p->sphum); ql = Q(p->liq_wat); qs = Q(p->ice_wat);
+      *q_con = ql + qs;
+      return (1. - (qv + *q_con)) * p->cv_air + qv * p->cv_vap + ql * p->c_liq + qs * p->c_ice;
+    case 4:
+      qv = Q(p->sphum);
+      *q_con = Q(p->liq_wat) + Q(p->rainwat);
+      return (1. - (qv + *q_con)) * p->cv_air + qv * p->cv_vap + *q_con * p->c_liq;
+    case 5:
+      qv = Q(p->sphum); ql = Q(p->liq_wat) + Q(p->rainwat); qs = Q(p->ice_wat) + Q(p->snowwat);
+      *q_con = ql + qs;
+      return (1. - (qv + *q_con)) * p->cv_air + qv * p->cv_vap + ql * p->c_liq + qs * p->c_ice;
+    case 6:
+      qv = Q(p->sphum); ql = Q(p->liq_wat) + Q(p->rainwat); qs = Q(p->ice_wat) + Q(p->snowwat) + Q(p->graupel);
+      *q_con = ql + qs;
+      return (1. - (qv + *q_con)) * p->cv_air + qv * p->cv_vap + ql * p->c_liq + qs * p->c_ice;
+    default:
+      *q_con = 0.;
+      return p->cv_air;
+  }
+#undef Q
+}
+
 int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p, double *ps, double *pe, double *delp,
                                double *pkz, double *pk, double *u, double *v, double *w, double *delz, double *pt,
                                double *q, double *peln, double *omga, const double *ws, const double *ak,
-                               const double *bk) {
+                               const double *bk, double *q_con, double *cappa) {
   const int is = g->is, ie = g->ie, js = g->js, je = g->je, isd = g->isd, ied = g->ied, jsd = g->jsd, jed = g->jed;
   const int nid = ied - isd + 1, njd = jed - jsd + 1, nx = ie - is + 1, ny = je - js + 1;
   const size_t nA = (size_t)nid * njd, nU = (size_t)nid * (njd + 1), nV = (size_t)(nid + 1) * njd, nCC = (size_t)nx * ny;
   int i, j, k, n, iq, rc = 0;
   const double k1k = p->rdgas / p->cv_air, rrg = -p->rdgas / p->grav, akap = p->akap;
   if (p->kord_wz < 0) return FVO_ERR_UNSUPPORTED;
+  if ((p->moist_kappa || p->use_cond) && (p->hydrostatic || !q || (p->moist_kappa && (!q_con || !cappa))))
+    return FVO_ERR_UNSUPPORTED;
 #define IA3(i, j, k) ((size_t)((k)-1) * nA + (size_t)((j)-jsd) * nid + ((i)-isd))
 #define IU3(i, j, k) ((size_t)((k)-1) * nU + (size_t)((j)-jsd) * nid + ((i)-isd))
 #define IV3(i, j, k) ((size_t)((k)-1) * nV + (size_t)((j)-jsd) * (nid + 1) + ((i)-isd))
@@ -358,7 +392,15 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
             if (p->hydrostatic)
               pt[IA3(i, j, k)] = pt[IA3(i, j, k)] * (pk[ICC3(i, j, k + 1)] - pk[ICC3(i, j, k)]) /
                                  (akap * (PELN(i, k + 1, j) - PELN(i, k, j)));
-            else
+            else if (p->moist_kappa) { /* :212-219 */
+              double qc;
+              const double cvm = fvo_moist_cv(p, q + IA3(i, j, k), nA * km, &qc);
+              const double qv = q[(size_t)(p->sphum - 1) * nA * km + IA3(i, j, k)];
+              q_con[IA3(i, j, k)] = qc;
+              cappa[IA3(i, j, k)] = p->rdgas / (p->rdgas + cvm / (1. + p->r_vir * qv));
+              pt[IA3(i, j, k)] = pt[IA3(i, j, k)] * exp(cappa[IA3(i, j, k)] / (1. - cappa[IA3(i, j, k)]) *
+                                                      log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
+            } else
               pt[IA3(i, j, k)] = pt[IA3(i, j, k)] *
                                  exp(k1k * log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
           }
@@ -415,7 +457,16 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
         for (k = 1; k <= km; k++) {
           if (p->hydrostatic)
             pkz[ICC3(i, j, k)] = (pk2[k + 1] - pk2[k]) / (akap * (PELN(i, k + 1, j) - PELN(i, k, j)));
-          else if (p->kord_tm < 0)
+          else if (p->moist_kappa) { /* :463-478; q holds the remapped tracers here */
+            double qc;
+            const double cvm = fvo_moist_cv(p, q + IA3(i, j, k), nA * km, &qc);
+            const double qv = q[(size_t)(p->sphum - 1) * nA * km + IA3(i, j, k)];
+            const double cap = p->rdgas / (p->rdgas + cvm / (1. + p->r_vir * qv));
+            q_con[IA3(i, j, k)] = qc;
+            cappa[IA3(i, j, k)] = cap;
+            pkz[ICC3(i, j, k)] = exp((p->kord_tm < 0 ? cap : cap / (1. - cap)) *
+                                     log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
+          } else if (p->kord_tm < 0)
             pkz[ICC3(i, j, k)] = exp(akap * log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
           else
             pkz[ICC3(i, j, k)] = exp(k1k * log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
@@ -470,8 +521,17 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
   for (k = 2; k <= km; k++) /* :635-641 */
     for (j = js; j <= je; j++)
       for (i = is; i <= ie; i++) PE(i, k, j) = pe4[IA3(i, j, k - 1)];
-  if (p->last_step) { /* :793-821: dtmp = 0; only the non-adiabatic dry branch changes pt */
-    if (!p->adiabatic) {
+  if (p->last_step) { /* :793-821 with dtmp = 0 */
+    if (!p->hydrostatic && p->use_cond) { /* :806-811 */
+      for (k = 1; k <= km; k++)
+        for (j = js; j <= je; j++)
+          for (i = is; i <= ie; i++) {
+            double qc;
+            const double cvm = fvo_moist_cv(p, q + IA3(i, j, k), nA * km, &qc);
+            const double qv = q[(size_t)(p->sphum - 1) * nA * km + IA3(i, j, k)];
+            pt[IA3(i, j, k)] = (pt[IA3(i, j, k)] + 0. / cvm * pkz[ICC3(i, j, k)]) / ((1. + p->r_vir * qv) * (1. - qc));
+          }
+    } else if (!p->adiabatic) {
       for (k = 1; k <= km; k++)
         for (j = js; j <= je; j++)
           for (i = is; i <= ie; i++) {

@@ -251,7 +251,9 @@ def geopk(g, km, ptop, akap, cp_air, pe, peln, delp, pk, gz, hs, pt, pkz, CG):
 class RemapPar(C.Structure):
     _fields_ = [(n, C.c_int) for n in ["last_step", "hydrostatic", "adiabatic", "nq", "kord_mt", "kord_wz", "kord_tm"]] + [
         ("kord_tr", _ip)] + [(n, C.c_double) for n in ["akap", "ptop", "rdgas", "grav", "cv_air", "r_vir", "cp", "t_min"]] + [
-        ("sphum", C.c_int)]
+        ("sphum", C.c_int)] + [(n, C.c_int) for n in ["moist_kappa", "use_cond", "nwat", "liq_wat", "rainwat", "ice_wat",
+                                                        "snowwat", "graupel"]] + [
+        (n, C.c_double) for n in ["cv_vap", "c_liq", "c_ice"]]
 
 
 def remap_column(which, pe1, pe2, q1, qs, iv, kord, qmin=0.0):
@@ -279,7 +281,8 @@ def lagrangian_to_eulerian(g, km, par: dict, f: dict, ak, bk):
     rc = lib().fvo_lagrangian_to_eulerian(C.byref(gs), C.c_int(km), C.byref(pr), p(f["ps"]), p(f["pe"]), p(f["delp"]),
                                           p(f["pkz"]), p(f["pk"]), p(f["u"]), p(f["v"]), p(f.get("w")), p(f.get("delz")),
                                           p(f["pt"]), p(f.get("q")), p(f["peln"]), p(f["omga"]), p(f.get("ws")),
-                                          ak.ctypes.data_as(_dp), bk.ctypes.data_as(_dp))
+                                          ak.ctypes.data_as(_dp), bk.ctypes.data_as(_dp), p(f.get("q_con")),
+                                          p(f.get("cappa")))
     assert rc == 0, rc
 
 

@@ -423,3 +423,85 @@ def check_c2l_and_rayleigh(lib, nx=70, ny=33, km=12, hydrostatic=False, conserve
     finally:
         ctx.close()
     return worst
+
+
+def np_moist_cv(q, mp, cv_air):
+    """moist_cv (fv_thermodynamics.F90:250-325) on whole arrays; q: (.., nq); returns cvm, q_con"""
+    Q = lambda n: q[..., n - 1] if n > 0 else 0.0
+    qv = Q(mp["sphum"])
+    nwat = mp["nwat"]
+    if nwat == 6:
+        ql = Q(mp["liq_wat"]) + Q(mp["rainwat"])
+        qs = Q(mp["ice_wat"]) + Q(mp["snowwat"]) + Q(mp["graupel"])
+    elif nwat == 3:
+        ql, qs = Q(mp["liq_wat"]), Q(mp["ice_wat"])
+    else:
+        raise NotImplementedError(nwat)
+    q_con = ql + qs
+    cvm = (1.0 - (qv + q_con)) * cv_air + qv * mp["cv_vap"] + ql * mp["c_liq"] + qs * mp["c_ice"]
+    return cvm, q_con
+
+
+def check_pt_to_theta_v(lib, nx=30, ny=17, km=6, hydrostatic=False, moist_kappa=False, use_cond=False, with_qv=True,
+                        split=False):
+    """fv3_pt_to_theta_v (fv_dynamics.F90:296-329, :379-399) against the same expressions in numpy; split = the
+    pkz-only call followed by the conversion with that pkz (the order around Rayleigh_Friction)"""
+    import parity_remap as R
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    s = nh_state(bd, km, seed=9)
+    rng = np.random.default_rng(12)
+    nq = 7
+    q = np.asfortranarray(rng.uniform(0.0, 1.0, bd.shape("A", km) + (nq,)))
+    q[..., 0] *= 0.02
+    q[..., 1:6] *= 0.002
+    mp = dict(R.MOIST6, sphum=1, moist_kappa=int(moist_kappa), use_cond=int(use_cond))
+    zvir = 0.6077 if with_qv else 0.0
+    r = (bd.is_, bd.ie, bd.js, bd.je)
+    ng = bd.ng
+    c = (slice(ng, ng + nx), slice(ng, ng + ny))
+    delz = np.asfortranarray(np.diff(s["zh"], axis=2)[c])
+    T = s["pt"].copy(order="F")
+    T[c] = 250.0 + 30.0 * rng.uniform(0, 1, (nx, ny, km))
+    pkz_in = np.asfortranarray(rng.uniform(0.9, 1.1, bd.shape("CC", km)))
+    q_con0 = np.asfortranarray(0.01 * rng.uniform(0, 1, bd.shape("A", km)))
+    # ---- numpy reference ----
+    rdg = -RDGAS / GRAV
+    dp1 = zvir * q[c + (slice(None), 0)] if with_qv else 0.0
+    Tc, dpc = T[c], s["delp"][c]
+    q_con_ref, cappa_ref = q_con0.copy(order="F"), bd.zeros("A", km)
+    if hydrostatic:
+        pkz_ref = pkz_in.copy(order="F")
+    elif moist_kappa:
+        cvm, qc = np_moist_cv(q[c], mp, CP_AIR - RDGAS)
+        cap = RDGAS / (RDGAS + cvm / (1.0 + dp1))
+        q_con_ref[c], cappa_ref[c] = qc, cap
+        pkz_ref = np.exp(cap * np.log(rdg * dpc * Tc * (1.0 + dp1) * (1.0 - qc) / delz))
+    else:
+        pkz_ref = np.exp((2.0 / 7.0) * np.log(rdg * dpc * Tc * (1.0 + dp1) / delz))
+    th_ref = T.copy(order="F")
+    th_ref[c] = Tc * (1.0 + dp1) * (1.0 - q_con_ref[c]) / pkz_ref if use_cond else Tc * (1.0 + dp1) / pkz_ref
+    # ---- library ----
+    ctx = Context(g, km, lib=lib)
+    try:
+        d_q, d_qcon, d_cappa = ctx.from_host(q), ctx.from_host(q_con0), ctx.zeros("A", km)
+        if moist_kappa or use_cond:
+            ctx.set_moist(mp, d_qcon, d_cappa)
+        d_pt, d_pkz = ctx.from_host(T), ctx.from_host(pkz_in)
+        args = (zvir, 2.0 / 7.0, RDGAS, GRAV, d_pt, ctx.from_host(s["delp"]), None if hydrostatic else ctx.from_host(delz),
+                d_q if with_qv else None, d_pkz)
+        if split and not hydrostatic:
+            ctx.pt_to_theta_v(-1, *args)
+            assert np.array_equal(d_pt.download(), T)          # pkz only: pt untouched
+            ctx.pt_to_theta_v(1, *args)
+        else:
+            ctx.pt_to_theta_v(int(hydrostatic), *args)
+        tol = 1e-13
+        worst = P.assert_close("pt", bd.view(d_pt.download(), "A", *r), bd.view(th_ref, "A", *r), tol)
+        worst = max(worst, P.assert_close("pkz", d_pkz.download(), pkz_ref, tol))
+        if moist_kappa and not hydrostatic:
+            worst = max(worst, P.assert_close("q_con", bd.view(d_qcon.download(), "A", *r), bd.view(q_con_ref, "A", *r), tol))
+            worst = max(worst, P.assert_close("cappa", bd.view(d_cappa.download(), "A", *r), bd.view(cappa_ref, "A", *r), tol))
+    finally:
+        ctx.close()
+    return worst

@@ -38,21 +38,44 @@ def remap_state(bd, km, nq, seed=31):
     return f, ak, bk
 
 
-def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=False, kord_tm=-8, kord=8, adiabatic=True):
+MOIST6 = dict(nwat=6, liq_wat=2, rainwat=3, ice_wat=4, snowwat=5, graupel=6, cv_vap=3.0 * 461.50, c_liq=4.218e3,
+              c_ice=2.106e3)
+
+
+def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=False, kord_tm=-8, kord=8, adiabatic=True,
+                moist_kappa=False, use_cond=False, nwat=6):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
+    moist = moist_kappa or use_cond
+    if moist:
+        nq = max(nq, 7)
     f, ak, bk = remap_state(bd, km, nq)
+    if moist:   # water species: small mixing ratios (q(1) = sphum, 2..6 = condensates)
+        f["q"][:, :, :, 0] *= 0.02
+        f["q"][:, :, :, 1:6] *= 0.002
+        f["q_con"], f["cappa"] = bd.zeros("A", km), bd.zeros("A", km)
     par = dict(last_step=int(last_step), hydrostatic=int(hydrostatic), adiabatic=int(adiabatic), nq=nq, kord_mt=kord,
                kord_wz=kord, kord_tm=kord_tm, sphum=1 if nq else 0, akap=KAPPA, ptop=N.PTOP, rdgas=RDGAS, grav=GRAV,
                cv_air=CP_AIR - RDGAS, r_vir=0.6077, cp=CP_AIR, t_min=184.0, kord_tr=[kord if n % 2 == 0 else 9 for n in range(nq)])
+    mpar = dict(MOIST6, nwat=nwat, moist_kappa=int(moist_kappa), use_cond=int(use_cond)) if moist else {}
+    if moist and nwat == 3:
+        mpar.update(liq_wat=2, ice_wat=3, rainwat=0, snowwat=0, graupel=0)
+    opar = dict(par, **mpar)
     ref = {k: (v.copy(order="F") if v is not None else None) for k, v in f.items()}
     if hydrostatic:
         ref.pop("w"); ref.pop("delz"); ref.pop("ws")
-    O.lagrangian_to_eulerian(g, km, par, ref, ak, bk)
+    O.lagrangian_to_eulerian(g, km, opar, ref, ak, bk)
+    if moist:   # the moist branches really change the answer
+        dry = {k: (v.copy(order="F") if v is not None else None) for k, v in f.items()}
+        O.lagrangian_to_eulerian(g, km, par, dry, ak, bk)
+        n_chk = "pkz" if moist_kappa else "pt"
+        assert P.rel_rms(dry[n_chk], ref[n_chk]) > 1e-6
     ctx = Context(g, km, lib=lib)
     try:
         ctx.set_ak_bk(ak, bk)
         d = {k: ctx.from_host(v) for k, v in f.items()}
+        if moist:
+            ctx.set_moist(mpar, d["q_con"], d["cappa"])
         ctx.lagrangian_to_eulerian(par, d["ps"], d["pe"], d["delp"], d["pkz"], d["pk"], d["u"], d["v"],
                                    None if hydrostatic else d["w"], None if hydrostatic else d["delz"], d["pt"],
                                    d.get("q"), d["peln"], d["omga"], None if hydrostatic else d["ws"])
@@ -70,6 +93,9 @@ def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=Fal
         for n in ("pkz", "pk", "peln") + (() if hydrostatic else ("delz",)):
             worst = max(worst, P.assert_close(n, d[n].download(), ref[n], tol))
         worst = max(worst, P.assert_close("pe", d["pe"].download()[1:-1, :, 1:-1], ref["pe"][1:-1, :, 1:-1], tol))
+        if moist_kappa:
+            for n in ("q_con", "cappa"):
+                worst = max(worst, P.assert_close(n, bd.view(d[n].download(), "A", *r), bd.view(ref[n], "A", *r), tol))
         if nq:
             got = d["q"].download()
             for iq in range(nq):

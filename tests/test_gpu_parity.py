@@ -424,3 +424,19 @@ def test_riem_solvers_moist(prod, use_cond, moist_kappa, a_imp):
     N.check_riem_solver3(prod, a_imp=a_imp, use_cond=use_cond, moist_kappa=moist_kappa)
     if a_imp > 0.999 and use_cond:
         N.check_riem_solver_c(prod, use_cond=True, moist_kappa=moist_kappa)
+
+
+@pytest.mark.parametrize("moist_kappa,use_cond,last_step,kord_tm,nwat", [(True, True, False, -9, 6), (True, True, True, -8, 6),
+                                                                          (False, True, True, -8, 6), (True, False, False, 9, 3)])
+def test_remap_moist(prod, moist_kappa, use_cond, last_step, kord_tm, nwat):
+    """moist_kappa / use_cond branches of Lagrangian_to_Eulerian (fv_mapz.F90:212-219, :463-478, :806-811) with moist_cv"""
+    R.check_remap(prod, moist_kappa=moist_kappa, use_cond=use_cond, last_step=last_step, kord_tm=kord_tm, nwat=nwat,
+                  adiabatic=False)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(with_qv=False), dict(hydrostatic=True), dict(split=True),
+                                dict(moist_kappa=True, use_cond=True), dict(moist_kappa=True, use_cond=True, split=True),
+                                dict(use_cond=True), dict(hydrostatic=True, use_cond=True)])
+def test_pt_to_theta_v(prod, kw):
+    """T -> theta_v before the k_split loop (fv_dynamics.F90:296-329, :379-399), dry / zvir / moist_kappa / use_cond"""
+    N.check_pt_to_theta_v(prod, **kw)
