@@ -3,7 +3,8 @@
  * model/fv_operators.F90 (scalar_profile :546-916, cs_profile :919-1300, cs_limiters :1303-1378,
  * map_scalar :40-134, map1_ppm :137-229, mapn_tracer :234-348, map1_q2 :352-443) and
  * model/fv_mapz.F90 Lagrangian_to_Eulerian :56-845.
- * Branches restated: remap_te = .false., moist_kappa = use_cond = .false., consv = 0 (no energy fixer),
+ * Branches restated: remap_te = .false., moist_kappa / use_cond both ways (moist_cv: fv_thermodynamics.F90:250-325),
+ * consv = 0 (no energy fixer),
  * fill = .false., do_intermediate_phys = .false.; abs(kord) in {8, 9, 10, 11, 13}; iv in {-2,-1,0,1}.
  * (iv = -3, i.e. kord_wz < 0, is not restated: the reference's back-substitution reads gam(i,km), which
  * that branch never sets -- fv_operators.F90:974-993,1012-1016.)
