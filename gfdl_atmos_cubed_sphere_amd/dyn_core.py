@@ -35,6 +35,8 @@ class DynFlags:
     d_con: float = 0.0
     delt_max: float = 1.0    # K/s, fv_arrays.F90:667
     hydrostatic: bool = False
+    use_cond: bool = False     # thermostruct%use_cond: q_con is transported by d_sw and enters the Riemann solvers' pm2
+    moist_kappa: bool = False  # thermostruct%moist_kappa: per-cell cappa in the Riemann solvers (and the remap)
     d_ext: float = 0.02      # external-mode damping (hydrostatic one_grad_p only), fv_arrays.F90:452
     convert_ke: bool = False
     ke_bg: float = 0.0
@@ -127,6 +129,10 @@ class DynCore:
         b = ctx.bd
         d["pe"] = ctx.from_host(np.zeros((b.nx + 2, npz + 1, b.ny + 2), order="F"))
         d["peln"] = ctx.from_host(np.zeros((b.nx, npz + 1, b.ny), order="F"))
+        if flags.use_cond:
+            d["q_con"], d["q_con_nxt"] = z("A", npz), z("A", npz)
+        if flags.moist_kappa:
+            d["cappa"] = z("A", npz)
         self.lev = level_coefficients(npz, flags)
         ctx.dsw_levels(self.lev)
         ctx.set_dp_ref(dp_ref)
@@ -222,7 +228,9 @@ class DynCore:
                 d["pkz"] = ctx.zeros("CC", self.npz)
             d["heat_source"].zero()
         par = dict(dt=dt, hord_tr=fl.hord_tr, hord_mt=fl.hord_mt, hord_vt=fl.hord_vt, hord_tm=fl.hord_tm,
-                   hord_dp=fl.hord_dp, dddmp=fl.dddmp, d4_bg=fl.d4_bg, kgb=fl.ke_bg, hydrostatic=0, use_cond=0)
+                   hord_dp=fl.hord_dp, dddmp=fl.dddmp, d4_bg=fl.d4_bg, kgb=fl.ke_bg, hydrostatic=0,
+                   use_cond=int(fl.use_cond))
+        cond = lambda: ctx.set_condensate(d["q_con"] if fl.use_cond else None, d["cappa"] if fl.moist_kappa else None)
         # fv_dynamics.F90:467-470: halo of delp, pt (pack 1) and u, v (pack 8) before the first substep
         halo.update([(d["delp"], "A"), (d["pt"], "A")])
         halo.update([(d["u"], "U"), (d["v"], "V")])
@@ -237,12 +245,15 @@ class DynCore:
             if fl.nord > 0:
                 halo.update([(d["divgd"], "B")])                              # :451 / :577 (pack 3, CORNER)
             ctx.update_dz_c(dt2, d["zs"], d["ut"], d["vt"], d["zh"], d["gz"], d["ws3"])       # :514-527
+            cond()
             ctx.riem_solver_c(dt2, self.cn, d["phis"], d["omga"], d["ptc"], d["delpc"], d["gz"], d["pkc"], d["ws3"])  # :531
             ctx.p_grad_c(dt2, d["delpc"], d["pkc"], d["gz"], d["uc"], d["vc"], False)         # :562
             # :565 / :578 (pack 9, CGRID_NE) overlapped with the interior of d_sw (:762): start ... complete
             dsw_args = (par, d["vt"], d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"],
-                        d["divgd"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
-                        d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], d["w_nxt"], None, d["heat_s"], d["diss_e"])
+                        d["divgd"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"],
+                        d["q_con"] if fl.use_cond else None,
+                        d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], d["w_nxt"],
+                        d["q_con_nxt"] if fl.use_cond else None, d["heat_s"], d["diss_e"])
             if halo.overlaps:
                 pending = halo.start([(d["uc"], "V"), (d["vc"], "U")])
                 ctx.d_sw(*dsw_args, phase="interior")
@@ -253,9 +264,12 @@ class DynCore:
                 ctx.d_sw(*dsw_args)
             if heating:
                 ctx.heat_source_accum(d["heat_source"], d["heat_s"])          # :798-803
-            for n in ("delp", "pt", "u", "v", "w"):
+            for n in ("delp", "pt", "u", "v", "w") + (("q_con",) if fl.use_cond else ()):
                 self._swap(n)
             halo.update([(d["delp"], "A"), (d["pt"], "A")])                   # :823-824 / :851 (pack 1)
+            if fl.use_cond:
+                halo.update([(d["q_con"], "A")])                              # :825 / :852 (pack 11)
+                cond()
             ctx.update_dz_d(fl.hord_tm, d["zs"], d["zh"], d["zh_nxt"], d["crx"], d["cry"], d["xfx"], d["yfx"],
                             d["ws"], rdt)                                     # :911
             self._swap("zh")

@@ -20,7 +20,7 @@ class FvDynamics:
     def __init__(self, ctx: Context, flags: DynFlags, ak, bk, nq: int = 0, k_split: int = 1, kord_tm: int = -8,
                  kord_mt: int = 8, kord_wz: int = 8, kord_tr: int = 8, q_split: int = 0, nord_tr: int = 0, trdm2: float = 0.0, adiabatic: bool = True,
                  px: int = 1, py: int = 1, rank: int = 0, world: int = 1, dist=None, tau: float = 0.0,
-                 rf_cutoff: float = 30.0e2, c2l_ord: int = 4):
+                 rf_cutoff: float = 30.0e2, c2l_ord: int = 4, moist: dict | None = None):
         ak, bk = np.asarray(ak, dtype=np.float64), np.asarray(bk, dtype=np.float64)
         dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5          # dyn_core.F90:241-244
         self.ctx, self.fl, self.nq, self.k_split, self.q_split, self.dist = ctx, flags, nq, k_split, q_split, dist
@@ -28,6 +28,11 @@ class FvDynamics:
         self.tau, self.rf_cutoff, self.c2l_ord = tau, rf_cutoff, c2l_ord
         self.ak, self.bk = ak, bk
         self._rf = None                                                    # (rf, pm, kmax): set on first use, as RF_initialized
+        # moist thermodynamics (flags.use_cond / flags.moist_kappa): nwat and the water-species indices for moist_cv,
+        # cv_vap, c_liq, c_ice (lib.Context.set_moist)
+        self.moist = None
+        if flags.use_cond or flags.moist_kappa:
+            self.moist = dict(moist or {}, moist_kappa=int(flags.moist_kappa), use_cond=int(flags.use_cond), sphum=1)
         self.dc = DynCore(ctx, flags, dp_ref, px, py, rank, world)
         ctx.set_ak_bk(ak, bk)
         npz = ctx.npz
@@ -52,6 +57,8 @@ class FvDynamics:
         d, ctx, fl = self.dc.d, self.ctx, self.fl
         qv = d["q"].ptr if (self.nq and self.remap_par["sphum"] > 0 and not self.remap_par["adiabatic"]) else None
         zvir = self.remap_par["r_vir"] if qv else 0.0
+        if self.moist:
+            ctx.set_moist(self.moist, d.get("q_con"), d.get("cappa"))
         conv = lambda mode: ctx.pt_to_theta_v(mode, zvir, fl.akap, fl.rdgas, fl.grav, d["pt"], d["delp"],
                                               None if fl.hydrostatic else d["delz"], qv, d["pkz"])
         if self.tau > 0.0:                                                 # :368-376 (grid_type = 4: Rayleigh_Friction)
@@ -109,6 +116,10 @@ class FvDynamics:
         for n_map in range(1, self.k_split + 1):
             last_step = last_cycle_is_last_step and n_map == self.k_split
             d["dp1"].copy_from(d["delp"])                                      # fv_dynamics.F90:475-481
+            if self.fl.use_cond:
+                self.dc.halo.update([(d["q_con"], "A")])                       # :464 / :487 (pack 11)
+            if self.fl.moist_kappa:
+                self.dc.halo.update([(d["cappa"], "A")])                       # :465 / :488 (pack 12)
             self.dc.run(mdt)                                                   # :493
             if self.nq:                                                        # :500-533
                 q, dp1, _ = tracer_2d(ctx, self.dc.halo, d["q"], d["q_nxt"], d["dp1"], d["dp1_nxt"], d["mfx"], d["mfy"],
@@ -120,6 +131,8 @@ class FvDynamics:
                     d["dp1"], d["dp1_nxt"] = d["dp1_nxt"], d["dp1"]
             par = dict(self.remap_par, last_step=int(last_step))
             hyd = self.fl.hydrostatic
+            if self.moist:                                                     # q_con is a ping-pong pair: current buffer
+                ctx.set_moist(self.moist, d.get("q_con"), d.get("cappa"))
             ctx.lagrangian_to_eulerian(par, d["ps"], d["pe"], d["delp"], d["pkz"], d["pk"], d["u"], d["v"],
                                        None if hyd else d["w"], None if hyd else d["delz"], d["pt"], d.get("q"),
                                        d["peln"], d["omga"], None if hyd else d["ws"])   # :607

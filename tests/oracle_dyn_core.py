@@ -42,7 +42,9 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
     ptk, peln1 = fl.ptop ** fl.akap, np.log(fl.ptop)
     par = dict(dt=dt, hord_tr=fl.hord_tr, hord_mt=fl.hord_mt, hord_vt=fl.hord_vt, hord_tm=fl.hord_tm,
                hord_dp=fl.hord_dp, nord=1, nord_v=1, nord_w=1, nord_t=1, dddmp=fl.dddmp, d2_bg=0.0, d4_bg=fl.d4_bg,
-               damp_v=0.0, damp_w=0.0, damp_t=0.0, d_con=0.0, kgb=fl.ke_bg, hydrostatic=0, use_cond=0)
+               damp_v=0.0, damp_w=0.0, damp_t=0.0, d_con=0.0, kgb=fl.ke_bg, hydrostatic=0, use_cond=int(fl.use_cond))
+    qc = lambda: f["q_con"] if fl.use_cond else None
+    cap = lambda: f["cappa"] if fl.moist_kappa else None
     ndif = np.concatenate([lev["nord_v"], lev["nord_v"][-1:]]).astype(np.int32)
     damp = np.concatenate([lev["damp_vt"], lev["damp_vt"][-1:]])
     _fill(bd, f["delp"], "A"); _fill(bd, f["pt"], "A"); _fill(bd, f["u"], "U"); _fill(bd, f["v"], "V")
@@ -68,7 +70,7 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
         if fl.nord > 0:
             _fill(bd, f["divgd"], "B")
         O.update_dz_c(g, npz, dt2, dp_ref, zs, f["ut"], f["vt"], f["gz"], f["ws3"])
-        O.riem_solver_c(g, npz, dt2, cn, f["phis"], f["omga"], f["ptc"], f["delpc"], f["gz"], f["pkc"], f["ws3"])
+        O.riem_solver_c(g, npz, dt2, cn, f["phis"], f["omga"], f["ptc"], f["delpc"], f["gz"], f["pkc"], f["ws3"], qc(), cap())
         O.p_grad_c(g, npz, dt2, f["delpc"], f["pkc"], f["gz"], f["uc"], f["vc"], False)
         _fill(bd, f["uc"], "V"); _fill(bd, f["vc"], "U")
         delp_start = f["delp"].copy(order="F")
@@ -76,7 +78,11 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
                   vc=f["vc"], ua=f["ua"], va=f["va"], divg_d=f["divgd"], mfx=f["mfx"], mfy=f["mfy"], cx=f["cx"],
                   cy=f["cy"], crx=f["crx"], cry=f["cry"], xfx=f["xfx"], yfx=f["yfx"], heat_source=f["heat_s"],
                   diss_est=f["diss_e"])
+        if fl.use_cond:
+            ds["q_con"] = f["q_con"]
         O.d_sw_3d(g, npz, par, lev, ds)
+        if fl.use_cond:
+            _fill(bd, f["q_con"], "A")                                       # dyn_core.F90:825 / :852
         if heating:                                                        # dyn_core.F90:798-803
             i0, j0 = bd.ng, bd.ng
             f["heat_source"][i0:i0 + nx, j0:j0 + ny, :] += f["heat_s"]
@@ -84,7 +90,7 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
         O.update_dz_d(g, npz, ndif.copy(), damp.copy(), fl.hord_tm, dp_ref, zs, f["zh"], f["crx"], f["cry"], f["xfx"],
                       f["yfx"], f["ws"], rdt)
         O.riem_solver3(g, npz, dt, cn, zs, f["w"], f["delz"], f["pt"], f["delp"], f["zh"], f["pe"], f["pkc"], f["pk3"],
-                       f["pk"], f["peln"], f["ws"], fl.use_logp, remap_step, False)
+                       f["pk"], f["peln"], f["ws"], fl.use_logp, remap_step, False, qc(), cap())
         _fill(bd, f["zh"], "A"); _fill(bd, f["pkc"], "A")
         if remap_step:
             O.pe_halo(g, npz, fl.ptop, f["pe"], f["delp"])

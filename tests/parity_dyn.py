@@ -146,6 +146,10 @@ def oracle_fv_step(g, npz, fl, dp0, st, ak, bk, q, bdt, k_split, remap_par, last
     for n_map in range(1, k_split + 1):
         dp1 = cur["delp"].copy(order="F")
         OD._fill(bd, dp1, "A")
+        if fl.use_cond:
+            OD._fill(bd, cur["q_con"], "A")                                  # fv_dynamics.F90:464 / :487
+        if fl.moist_kappa:
+            OD._fill(bd, cur["cappa"], "A")                                  # :465 / :488
         f = OD.run(g, npz, fl, dp0, cur, mdt)
         if nq:
             O.tracer_2d(g, npz, nq, q, dp1, f["mfx"], f["mfy"], f["cx"], f["cy"], fl.hord_tr, 0, 0, 0.0)
@@ -153,9 +157,96 @@ def oracle_fv_step(g, npz, fl, dp0, st, ak, bk, q, bdt, k_split, remap_par, last
                   w=f["w"], delz=f["delz"], pt=f["pt"], peln=f["peln"], omga=f["omga"], ws=f["ws"])
         if nq:
             rf["q"] = q
+        for n in ("q_con", "cappa"):
+            if n in f:
+                rf[n] = f[n]
         O.lagrangian_to_eulerian(g, npz, dict(remap_par, last_step=int(last_step and n_map == k_split)), rf, ak, bk)
         cur = dict(u=rf["u"], v=rf["v"], w=rf["w"], delp=rf["delp"], pt=rf["pt"], delz=rf["delz"], phis=st["phis"])
+        for n in ("q_con", "cappa"):
+            if n in rf:
+                cur[n] = rf[n]
         out = dict(cur, q=q, pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"])
+    return out
+
+
+def check_fv_cycle_moist(lib, nx=24, ny=16, npz=10, k_split=2, n_split=2, bdt=8.0, moist_kappa=True):
+    """A whole fv_dynamics call with use_cond (+ moist_kappa): T -> theta_m with moist_cv, q_con transported by d_sw and
+    entering the Riemann solvers, moist remap, back to T on the last step.  Oracle side: the conversion in numpy, then
+    the oracle-orchestrated loop."""
+    import parity_remap as R
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.lib import CP_AIR, GRAV, KAPPA, RDGAS
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    st, dp0 = make_state(bd, npz)
+    r = (bd.is_, bd.ie, bd.js, bd.je)
+    ng = bd.ng
+    c = (slice(ng, ng + nx), slice(ng, ng + ny))
+    nq = 7
+    rng = np.random.default_rng(8)
+    q = np.asfortranarray(rng.uniform(0.0, 1.0, bd.shape("A", npz) + (nq,)))
+    q[..., 0] *= 0.02
+    q[..., 1:6] *= 0.002
+    for iq in range(nq):
+        for k in range(npz):
+            from gfdl_atmos_cubed_sphere_amd.layout import periodic_fill
+            periodic_fill(bd, q[:, :, k, iq], "A")
+    mp = dict(R.MOIST6, sphum=1)
+    zvir = 0.6077
+    # a temperature consistent with the balanced theta state
+    th = st["pt"]
+    dpc, thc = st["delp"][c], th[c]
+    gm = 1.0 / (1.0 - KAPPA)
+    T = th.copy(order="F")
+    T[c] = thc * np.exp(KAPPA * gm * np.log((-RDGAS / GRAV) * dpc * thc / st["delz"]))
+    # ---- oracle side: fv_dynamics.F90:305-317 / :323-326 and :381-388 in numpy ----
+    dp1 = zvir * q[c + (slice(None), 0)]
+    q_con, cappa = bd.zeros("A", npz), bd.zeros("A", npz)
+    cvm, qc = N.np_moist_cv(q[c], mp, CP_AIR - RDGAS)
+    q_con[c] = qc
+    if moist_kappa:
+        cappa[c] = RDGAS / (RDGAS + cvm / (1.0 + dp1))
+        pkz = np.exp(cappa[c] * np.log((-RDGAS / GRAV) * dpc * T[c] * (1.0 + dp1) * (1.0 - qc) / st["delz"]))
+    else:
+        pkz = np.exp(KAPPA * np.log((-RDGAS / GRAV) * dpc * T[c] * (1.0 + dp1) / st["delz"]))
+    th2 = T.copy(order="F")
+    th2[c] = T[c] * (1.0 + dp1) * (1.0 - qc) / pkz
+    for k in range(npz):
+        periodic_fill(bd, th2[:, :, k], "A")
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+    ak, bk = N.PTOP * (1.0 - sig), sig.copy()
+    dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, use_cond=True, moist_kappa=moist_kappa)
+    ost = dict(st, pt=th2, q_con=q_con)
+    if moist_kappa:
+        ost["cappa"] = cappa
+    ctx = Context(g, npz, lib=lib)
+    try:
+        fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=k_split, adiabatic=False, moist=mp, c2l_ord=2)
+        opar = dict(fv.remap_par, **dict(mp, moist_kappa=int(moist_kappa), use_cond=1))
+        opar.pop("sphum")
+        opar["sphum"] = 1
+        ref = oracle_fv_step(g, npz, fl, dp_ref, ost, ak, bk, q, bdt, k_split, opar, last_step=True)
+        if not moist_kappa:   # use_cond alone: the library is told q_con (the reference keeps it from the previous step)
+            pass
+        fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], T, st["delz"], st["phis"])
+        fv.set_tracers(q)
+        if not moist_kappa:
+            fv.dc.d["q_con"].upload(q_con)
+        fv.step_from_temperature(bdt)
+        d = fv.dc.d
+        out = {}
+        for n, kind, tol in (("pt", "A", 1e-12), ("delp", "A", 1e-12), ("w", "A", 1e-10), ("u", "U", 1e-12)):
+            rr = r if kind == "A" else (bd.is_, bd.ie, bd.js, bd.je + 1)
+            out[n] = P.assert_close(n, bd.view(d[n].download(), kind, *rr), bd.view(ref[n], kind, *rr), tol)
+        got_q = d["q"].download()
+        for iq in (0, 1, 5):
+            out[f"q{iq}"] = P.assert_close(f"q{iq}", bd.view(got_q[:, :, :, iq], "A", *r),
+                                           bd.view(ref["q"][:, :, :, iq], "A", *r), 1e-12)
+        Tn = bd.view(d["pt"].download(), "A", *r)
+        assert 150.0 < Tn.min() and Tn.max() < 400.0
+    finally:
+        ctx.close()
     return out
 
 

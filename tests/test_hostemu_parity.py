@@ -345,3 +345,10 @@ def test_remap_moist(emu, moist_kappa, use_cond, last_step, kord_tm, nwat):
 def test_pt_to_theta_v(emu, kw):
     """T -> theta_v before the k_split loop (fv_dynamics.F90:296-329, :379-399), dry / zvir / moist_kappa / use_cond"""
     N.check_pt_to_theta_v(emu, **kw)
+
+
+@pytest.mark.parametrize("moist_kappa", [True, False])
+def test_fv_dynamics_call_moist(emu, moist_kappa):
+    """whole fv_dynamics call with use_cond (+ moist_kappa): moist_cv conversions, q_con through d_sw and the Riemann
+    solvers, moist remap, T on return"""
+    D.check_fv_cycle_moist(emu, moist_kappa=moist_kappa)
