@@ -1056,9 +1056,15 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn,
   if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver_c: bad context/arguments");
   if (cn->a_imp <= 0.5) return fail("fv3_riem_solver_c: a_imp <= 0.5 (RIM_2D / SIM3p0) is not built");
   if (need_scratch(c, 4)) return 1;
-  RiemSolverC kf{c->g, c->g.npz, dt, to_consts(cn), hs, w3, pt, delp, ws, gz, pef,
-                 c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->q_con, c->cappa};
-  RT(launch_c(c, "riem_solver_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), kf));
+  if (c->q_con) {
+    RiemSolverC<true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, w3, pt, delp, ws, gz, pef,
+                         c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->q_con, c->cappa};
+    RT(launch_c(c, "riem_solver_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), kf));
+  } else {
+    RiemSolverC<false> kf{c->g, c->g.npz, dt, to_consts(cn), hs, w3, pt, delp, ws, gz, pef,
+                          c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], nullptr, nullptr};
+    RT(launch_c(c, "riem_solver_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), kf));
+  }
   return 0;
 }
 
@@ -1070,10 +1076,17 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
   if (cn->a_imp <= 0.5) return fail("fv3_riem_solver3: a_imp <= 0.5 (RIM_2D / SIM3 / SIM3p0) is not built");
   if (last_call && (!pe || !pk || !peln)) return fail("fv3_riem_solver3: last_call needs pe, pk, peln");
   if (need_scratch(c, 4)) return 1;
-  RiemSolver3 kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, delz, zh, pe, ppe, pk3, pk, peln,
-                 use_logp, last_call, fp_out, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->q_con,
-                 c->cappa};
-  RT(launch_c(c, "riem_solver3", col_grid(c->g.nx * c->g.ny), kf));
+  if (c->q_con || c->cappa) {
+    RiemSolver3<true> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, delz, zh, pe, ppe, pk3, pk, peln,
+                         use_logp, last_call, fp_out, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3],
+                         c->q_con, c->cappa};
+    RT(launch_c(c, "riem_solver3", col_grid(c->g.nx * c->g.ny), kf));
+  } else {
+    RiemSolver3<false> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, delz, zh, pe, ppe, pk3, pk, peln,
+                          use_logp, last_call, fp_out, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3],
+                          nullptr, nullptr};
+    RT(launch_c(c, "riem_solver3", col_grid(c->g.nx * c->g.ny), kf));
+  }
   return 0;
 }
 

@@ -327,6 +327,8 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
 #undef L
 }
 
+// MOIST is a launch-time choice (separate kernels): the dry kernel must not carry the registers of the moist branches
+template <bool MOIST>
 struct RiemSolverC {
   Grid g;
   int km;
@@ -337,10 +339,6 @@ struct RiemSolverC {
   double *s0, *s1, *s2, *s3;  // scratch slabs, A x (km+1)
   const double *q_con, *cappa;  // A x km or null (use_cond / moist_kappa)
   FV3_HD void operator()(int bx, int, int, int tid, double *) const {
-    if (q_con) run<true>(bx, tid); else run<false>(bx, tid);
-  }
-  template <bool MOIST>
-  FV3_HD void run(int bx, int tid) const {
     const int w = g.nx + 2, ncol = w * (g.ny + 2);
     const size_t nA = g.nA();
     FV3_COL_FOR(c, ncol) {
@@ -374,6 +372,7 @@ struct RiemSolverC {
   }
 };
 
+template <bool MOIST>
 struct RiemSolver3 {
   Grid g;
   int km;
@@ -385,10 +384,6 @@ struct RiemSolver3 {
   double *s0, *s1, *s2, *s3;
   const double *q_con, *cappa;  // A x km or null (use_cond / moist_kappa, nh_core.F90:96-166)
   FV3_HD void operator()(int bx, int, int, int tid, double *) const {
-    if (q_con || cappa) run<true>(bx, tid); else run<false>(bx, tid);
-  }
-  template <bool MOIST>
-  FV3_HD void run(int bx, int tid) const {
     const int ncol = g.nx * g.ny;
     const size_t nA = g.nA(), nCC = g.nCC();
     const bool sim1 = cn.a_imp > 0.999;

@@ -187,6 +187,91 @@ FV3_HD void profile_col_tail_unfused(const ColScr &c, int km, bool is_scalar, in
 }
 
 
+// Subgrid constraints of one cell (scalar_profile :691-914 / cs_profile :1082-1298): cell k with the constrained
+// interface values a2v = q(k), a3v = q(k+1) (in / out) and the layer means a1(k-2 .. k+2) (0 outside 1..km); a4o = a4(4,k).
+struct ProfCfg {
+  int km, iv, ak;
+  bool is_scalar;
+  double qmin;
+  bool streamed;  // true: c.q holds the constrained interface values and the mapping loop calls cs_cell on demand;
+                  // false (|kord| = 11): a2, a3, a4 are in their slabs
+};
+FV3_HD void cs_cell(const ProfCfg &pc, int k, double &a2v, double &a3v, double am2, double am1, double a1v, double ap1,
+                    double ap2, double &a4o) {
+  const int km = pc.km, iv = pc.iv, ak = pc.ak;
+  const bool is_scalar = pc.is_scalar;
+  const double qmin = pc.qmin;
+    // cell k with interface values a2v = q(k), a3v = q(k+1) and layer means a1(k-2..k+2)
+    double a4v;
+    const double g_m1 = am1 - am2, g_k = a1v - am1, g_p1 = ap1 - a1v, g_p2 = ap2 - ap1;  // dq(k-1), dq(k), dq(k+1), dq(k+2)
+    auto extm_q = [&]() { return (a2v - a1v) * (a3v - a1v) > 0.; };  // k == 1 or km (:691, :1082)
+    if (k == 1) {
+      const bool e = extm_q();
+      if (iv == 0) a2v = dmax(0., a2v);
+      if (iv == -1 && a2v * a1v <= 0.) a2v = 0.;
+      a4v = 3. * (2. * a1v - (a2v + a3v));
+      cs_limit(e, a1v, a2v, a3v, a4v, 1);
+    } else if (k == 2) {
+      a4v = 3. * (2. * a1v - (a2v + a3v));
+      cs_limit(g_k * g_p1 < 0., a1v, a2v, a3v, a4v, 2);
+    } else if (k <= km - 2) {
+      auto huynh = [&]() {
+        const double pmp_1 = a1v - 2. * g_p1, lac_1 = pmp_1 + 1.5 * g_p2;
+        a2v = dmin(dmax(a2v, dmin3(a1v, pmp_1, lac_1)), dmax3(a1v, pmp_1, lac_1));
+        const double pmp_2 = a1v + 2. * g_k, lac_2 = pmp_2 - 1.5 * g_m1;
+        a3v = dmin(dmax(a3v, dmin3(a1v, pmp_2, lac_2)), dmax3(a1v, pmp_2, lac_2));
+      };
+      // extm(k-1), extm(k), extm(k+1) for 3 <= k <= km-2: k-1 >= 2 and k+1 <= km-1 are interior (a1-based) except
+      // k+1 == km ... which cannot happen here (k <= km-2)
+      const bool e_k = g_k * g_p1 < 0.;
+      if (ak <= 8) {
+        huynh();
+        a4v = 3. * (2. * a1v - (a2v + a3v));
+      } else if (ak == 9) {
+        const bool e_m = g_m1 * g_k < 0., e_p = g_p1 * g_p2 < 0.;
+        if ((e_k && e_m) || (e_k && e_p) || (is_scalar && e_k && a1v < qmin)) {
+          a2v = a1v; a3v = a1v; a4v = 0.;
+        } else {
+          a4v = is_scalar ? 3. * (2. * a1v - (a2v + a3v)) : 6. * a1v - 3. * (a2v + a3v);
+          if (fabs(a4v) > fabs(a2v - a3v)) {
+            huynh();
+            a4v = is_scalar ? 3. * (2. * a1v - (a2v + a3v)) : 6. * a1v - 3. * (a2v + a3v);
+          }
+        }
+      } else if (ak == 10) {
+        const bool e_m = g_m1 * g_k < 0., e_p = g_p1 * g_p2 < 0.;
+        if (e_k) {
+          if ((is_scalar && a1v < qmin) || e_m || e_p) {
+            a2v = a1v; a3v = a1v; a4v = 0.;
+          } else {
+            a4v = 6. * a1v - 3. * (a2v + a3v);
+          }
+        } else {
+          a4v = 6. * a1v - 3. * (a2v + a3v);
+          if (fabs(a4v) > fabs(a2v - a3v)) {
+            huynh();
+            a4v = 6. * a1v - 3. * (a2v + a3v);
+          }
+        }
+      } else {  // 13
+        a4v = 3. * (2. * a1v - (a2v + a3v));
+      }
+      if (iv == 0 && ak <= 13) cs_limit(false, a1v, a2v, a3v, a4v, 0);
+    } else {
+      bool e;
+      if (k == km) {
+        e = extm_q();  // uses q(km), q(km+1) before the iv adjustments of a3 (:700 / :1091 come first)
+        if (iv == 0) a3v = dmax(0., a3v);
+        if (iv == -1 && a3v * a1v <= 0.) a3v = 0.;
+      } else {
+        e = g_k * g_p1 < 0.;
+      }
+      a4v = 3. * (2. * a1v - (a2v + a3v));
+      cs_limit(e, a1v, a2v, a3v, a4v, k == km ? 1 : 2);
+    }
+    a4o = a4v;
+}
+
 // scalar_profile (is_scalar) / cs_profile of one column.  src(k) yields the layer mean a4(1,k) of the field (it is
 // called once per level, in order, and the value is kept in c.a1 for the mapping loop); the source coordinate is in
 // c.pe1.  Writes c.a2, c.a3, c.a4 (and uses c.q, c.gam).
@@ -195,12 +280,15 @@ FV3_HD void profile_col_tail_unfused(const ColScr &c, int km, bool is_scalar, in
 // tridiagonal, fused with fetching the field; (2) ONE backward sweep that does the back-substitution, the large-scale
 // constraints on the interface values (:643-680 / :1037-1073) and the subgrid limiters (:691-914 / :1082-1298) with a
 // sliding 5-level register window of a1 -- every operation is the reference's, only the loop nests are merged, so the
-// results are bit-identical while the scratch-slab traffic drops from ~18 to ~11 accesses per level.
+// results are bit-identical while the scratch-slab traffic drops from ~18 to ~11 accesses per level.  The backward sweep
+// leaves the CONSTRAINED interface values in c.q; the subgrid limiters (cs_cell) run in the mapping loop, so a2/a3/a4 are
+// never stored (another 4 accesses per level).
 // (|kord| = 11 tests the monotonicity of the NEXT-higher cell's interface values, which a descending sweep has not
 // produced yet; it keeps the unfused sweeps below.)
 template <class Src>
-FV3_HD void profile_col(const ColScr &c, int km, bool is_scalar, double qs, int iv, int kord, double qmin, const Src &src) {
+FV3_HD ProfCfg profile_col(const ColScr &c, int km, bool is_scalar, double qs, int iv, int kord, double qmin, const Src &src) {
   const int ak = kord < 0 ? -kord : kord;
+  ProfCfg pc{km, iv, ak, is_scalar, qmin, ak != 11};
 #define DP(k) (CS(pe1, (k) + 1) - CS(pe1, k))
   // ---- interface values: cubic spline tridiagonal, forward elimination ----
   if (iv == -2) {  // :572-595 / :941-964
@@ -270,86 +358,12 @@ FV3_HD void profile_col(const ColScr &c, int km, bool is_scalar, double qs, int 
 #undef DP
   if (ak == 11) {
     profile_col_tail_unfused(c, km, is_scalar, iv, ak, qmin);
-    return;
+    return pc;
   }
   // ---- backward sweep: back-substitution + constraints + subgrid limiters -------------------------------------------
   // window of layer means: w_m2 = a1(k-2) .. w_p2 = a1(k+2) for the cell k being finished
   double qraw = CS(q, km + 1);            // unconstrained q(k+1) of the recurrence
-  double qc_next = qraw;                  // constrained q(k+1)  (q(km+1) is never constrained)
-  double w_p2 = 0., w_p1 = 0., w_0 = CS(a1, km), w_m1 = CS(a1, km - 1), w_m2 = km >= 3 ? CS(a1, km - 2) : 0.;
-  auto cell = [&](int k, double a2v, double a3v, double am2, double am1, double a1v, double ap1, double ap2) {
-    // cell k with interface values a2v = q(k), a3v = q(k+1) and layer means a1(k-2..k+2)
-    double a4v;
-    const double g_m1 = am1 - am2, g_k = a1v - am1, g_p1 = ap1 - a1v, g_p2 = ap2 - ap1;  // dq(k-1), dq(k), dq(k+1), dq(k+2)
-    auto extm_q = [&]() { return (a2v - a1v) * (a3v - a1v) > 0.; };  // k == 1 or km (:691, :1082)
-    if (k == 1) {
-      const bool e = extm_q();
-      if (iv == 0) a2v = dmax(0., a2v);
-      if (iv == -1 && a2v * a1v <= 0.) a2v = 0.;
-      a4v = 3. * (2. * a1v - (a2v + a3v));
-      cs_limit(e, a1v, a2v, a3v, a4v, 1);
-    } else if (k == 2) {
-      a4v = 3. * (2. * a1v - (a2v + a3v));
-      cs_limit(g_k * g_p1 < 0., a1v, a2v, a3v, a4v, 2);
-    } else if (k <= km - 2) {
-      auto huynh = [&]() {
-        const double pmp_1 = a1v - 2. * g_p1, lac_1 = pmp_1 + 1.5 * g_p2;
-        a2v = dmin(dmax(a2v, dmin3(a1v, pmp_1, lac_1)), dmax3(a1v, pmp_1, lac_1));
-        const double pmp_2 = a1v + 2. * g_k, lac_2 = pmp_2 - 1.5 * g_m1;
-        a3v = dmin(dmax(a3v, dmin3(a1v, pmp_2, lac_2)), dmax3(a1v, pmp_2, lac_2));
-      };
-      // extm(k-1), extm(k), extm(k+1) for 3 <= k <= km-2: k-1 >= 2 and k+1 <= km-1 are interior (a1-based) except
-      // k+1 == km ... which cannot happen here (k <= km-2)
-      const bool e_k = g_k * g_p1 < 0.;
-      if (ak <= 8) {
-        huynh();
-        a4v = 3. * (2. * a1v - (a2v + a3v));
-      } else if (ak == 9) {
-        const bool e_m = g_m1 * g_k < 0., e_p = g_p1 * g_p2 < 0.;
-        if ((e_k && e_m) || (e_k && e_p) || (is_scalar && e_k && a1v < qmin)) {
-          a2v = a1v; a3v = a1v; a4v = 0.;
-        } else {
-          a4v = is_scalar ? 3. * (2. * a1v - (a2v + a3v)) : 6. * a1v - 3. * (a2v + a3v);
-          if (fabs(a4v) > fabs(a2v - a3v)) {
-            huynh();
-            a4v = is_scalar ? 3. * (2. * a1v - (a2v + a3v)) : 6. * a1v - 3. * (a2v + a3v);
-          }
-        }
-      } else if (ak == 10) {
-        const bool e_m = g_m1 * g_k < 0., e_p = g_p1 * g_p2 < 0.;
-        if (e_k) {
-          if ((is_scalar && a1v < qmin) || e_m || e_p) {
-            a2v = a1v; a3v = a1v; a4v = 0.;
-          } else {
-            a4v = 6. * a1v - 3. * (a2v + a3v);
-          }
-        } else {
-          a4v = 6. * a1v - 3. * (a2v + a3v);
-          if (fabs(a4v) > fabs(a2v - a3v)) {
-            huynh();
-            a4v = 6. * a1v - 3. * (a2v + a3v);
-          }
-        }
-      } else {  // 13
-        a4v = 3. * (2. * a1v - (a2v + a3v));
-      }
-      if (iv == 0 && ak <= 13) cs_limit(false, a1v, a2v, a3v, a4v, 0);
-    } else {
-      bool e;
-      if (k == km) {
-        e = extm_q();  // uses q(km), q(km+1) before the iv adjustments of a3 (:700 / :1091 come first)
-        if (iv == 0) a3v = dmax(0., a3v);
-        if (iv == -1 && a3v * a1v <= 0.) a3v = 0.;
-      } else {
-        e = g_k * g_p1 < 0.;
-      }
-      a4v = 3. * (2. * a1v - (a2v + a3v));
-      cs_limit(e, a1v, a2v, a3v, a4v, k == km ? 1 : 2);
-    }
-    CS(a2, k) = a2v;
-    CS(a3, k) = a3v;
-    CS(a4, k) = a4v;
-  };
+  double w_p1 = 0., w_0 = CS(a1, km), w_m1 = CS(a1, km - 1), w_m2 = km >= 3 ? CS(a1, km - 2) : 0.;
   for (int k = km; k >= 1; k--) {
     // back-substitution (:590-595 / :1010-1016); gam index differs between the two eliminations
     double qk;
@@ -378,21 +392,40 @@ FV3_HD void profile_col(const ColScr &c, int km, bool is_scalar, double qs, int 
         if (iv == 0) qc = dmax(0., qc);
       }
     }
-    // cell k: interfaces (qc, qc_next), layer means a1(k-2 .. k+2)
-    cell(k, qc, qc_next, w_m2, w_m1, w_0, w_p1, w_p2);
-    qc_next = qc;
+    // the constrained interface value replaces the raw one (already consumed by the recurrence); the cell coefficients
+    // a4(2:4,k) are formed from it by the mapping loop (cs_cell) instead of being stored and re-read
+    CS(q, k) = qc;
     // slide the window down one level
-    w_p2 = w_p1; w_p1 = w_0; w_0 = w_m1; w_m1 = w_m2;
+    w_p1 = w_0; w_0 = w_m1; w_m1 = w_m2;
     w_m2 = (k - 3 >= 1) ? CS(a1, k - 3) : 0.;
   }
+  return pc;
 }
 
 // the search-and-integrate loop (fv_operators.F90:93-132 == :188-227 == :402-441; tracer_form: :277-335)
 template <class Out>
-FV3_HD void map_col(const ColScr &c, int km, bool tracer_form, const Out &out) {
+FV3_HD void map_col(const ColScr &c, int km, bool tracer_form, const ProfCfg &pc, const Out &out) {
   constexpr double r3 = 1. / 3., r23 = 2. / 3.;
   int k0 = 1;
   double qsum = 0.;
+  // a4(2:4, l): from the slabs, or formed here from the constrained interface values and the layer means around l (the
+  // cell a target layer ends in is the one the next target layer starts in: keep the last one)
+  int c_l = 0;
+  double c_2 = 0., c_3 = 0., c_4 = 0.;
+  auto coef = [&](int l, double &b2, double &b3, double &b4) {
+    if (!pc.streamed) {
+      b2 = CS(a2, l); b3 = CS(a3, l); b4 = CS(a4, l);
+      return;
+    }
+    if (l != c_l) {
+      double a2v = CS(q, l), a3v = CS(q, l + 1), a4v;
+      const double am2 = l - 2 >= 1 ? CS(a1, l - 2) : 0., am1 = l - 1 >= 1 ? CS(a1, l - 1) : 0.;
+      const double ap1 = l + 1 <= km ? CS(a1, l + 1) : 0., ap2 = l + 2 <= km ? CS(a1, l + 2) : 0.;
+      cs_cell(pc, l, a2v, a3v, am2, am1, CS(a1, l), ap1, ap2, a4v);
+      c_l = l; c_2 = a2v; c_3 = a3v; c_4 = a4v;
+    }
+    b2 = c_2; b3 = c_3; b4 = c_4;
+  };
   for (int k = 1; k <= km; k++) {
     const double p2t = CS(pe2, k), p2b = CS(pe2, k + 1);
     int done = 0;
@@ -401,7 +434,8 @@ FV3_HD void map_col(const ColScr &c, int km, bool tracer_form, const Out &out) {
       if (p2t >= p1t && p2t <= p1b) {
         const double dp1 = p1b - p1t;
         const double pl = (p2t - p1t) / dp1;
-        const double b2 = CS(a2, l), b3 = CS(a3, l), b4 = CS(a4, l);
+        double b2, b3, b4;
+        coef(l, b2, b3, b4);
         if (p2b <= p1b) {
           const double pr = (p2b - p1t) / dp1;
           double val;
@@ -433,7 +467,8 @@ FV3_HD void map_col(const ColScr &c, int km, bool tracer_form, const Out &out) {
             } else {
               const double dp = p2b - mt;
               const double esl = dp / (mb - mt);
-              const double m2 = CS(a2, m), m3 = CS(a3, m), m4 = CS(a4, m);
+              double m2, m3, m4;
+              coef(m, m2, m3, m4);
               if (tracer_form) {
                 const double fac1 = 0.5 * esl, fac2 = 1. - r23 * esl;
                 qsum = qsum + dp * (m2 + fac1 * (m3 - m2 + m4 * fac2));
@@ -585,8 +620,8 @@ struct RemapFields {
         }
         double *f = which == 0 ? u + g.iU(i, j) : v + g.iV(i, j);
         const size_t fs = which == 0 ? g.nU() : g.nV();
-        profile_col(c, km, false, 0., -1, p.kord_mt, 0., [&](int k) { return f[(size_t)(k - 1) * fs]; });
-        map_col(c, km, false, [&](int k, double val) { f[(size_t)(k - 1) * fs] = val; });
+        const ProfCfg pc = profile_col(c, km, false, 0., -1, p.kord_mt, 0., [&](int k) { return f[(size_t)(k - 1) * fs]; });
+        map_col(c, km, false, pc, [&](int k, double val) { f[(size_t)(k - 1) * fs] = val; });
       }
       return;
     }
@@ -623,14 +658,15 @@ struct RemapFields {
           return t;
         };
         // remap T_v (log-p coordinate, :363-368) or theta_v (:370-374)
+        ProfCfg pc;
         if (p.kord_tm < 0) {
           c.pe1 = pe1l;
           c.pe2 = pe2l;
-          profile_col(c, km, true, 0., 1, akt, p.t_min, src_pt);
+          pc = profile_col(c, km, true, 0., 1, akt, p.t_min, src_pt);
         } else {
-          profile_col(c, km, false, 0., 1, akt, 0., src_pt);
+          pc = profile_col(c, km, false, 0., 1, akt, 0., src_pt);
         }
-        map_col(c, km, false, [&](int k, double v_) { pt[(size_t)(k - 1) * nA + c.o] = v_; });
+        map_col(c, km, false, pc, [&](int k, double v_) { pt[(size_t)(k - 1) * nA + c.o] = v_; });
         // omega (:432-443, :506-526): interpolated in the old log-p coordinate
         if (p.last_step) {
           const size_t peb = (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1));
@@ -653,13 +689,13 @@ struct RemapFields {
           }
         }
       } else if (task == t_w) {  // w (:400-411)
-        profile_col(c, km, false, ws[occ], -2, p.kord_wz, 0., [&](int k) { return w[(size_t)(k - 1) * nA + c.o]; });
-        map_col(c, km, false, [&](int k, double v_) { w[(size_t)(k - 1) * nA + c.o] = v_; });
+        const ProfCfg pc = profile_col(c, km, false, ws[occ], -2, p.kord_wz, 0., [&](int k) { return w[(size_t)(k - 1) * nA + c.o]; });
+        map_col(c, km, false, pc, [&](int k, double v_) { w[(size_t)(k - 1) * nA + c.o] = v_; });
       } else {  // constituents (:380-397)
         const int iq = task - (t_v + 1);
         double *qq = q + (size_t)iq * nA * km;
-        profile_col(c, km, true, 0., 0, kord_tr[iq], 0., [&](int k) { return qq[(size_t)(k - 1) * nA + c.o]; });
-        map_col(c, km, p.nq > 5, [&](int k, double v_) { qq[(size_t)(k - 1) * nA + c.o] = v_; });
+        const ProfCfg pc = profile_col(c, km, true, 0., 0, kord_tr[iq], 0., [&](int k) { return qq[(size_t)(k - 1) * nA + c.o]; });
+        map_col(c, km, p.nq > 5, pc, [&](int k, double v_) { qq[(size_t)(k - 1) * nA + c.o] = v_; });
       }
     }
   }
@@ -686,10 +722,10 @@ struct RemapDelzFinal {
       const size_t lnb = (size_t)(j - g.js) * g.nx * (km + 1) + (i - g.is);
       auto PELN = [&](int k) -> double & { return peln[lnb + (size_t)(k - 1) * g.nx]; };
       if (!p.hydrostatic) {
-        profile_col(c, km, false, 0., 1, akt, 0., [&](int k) {
+        const ProfCfg pc = profile_col(c, km, false, 0., 1, akt, 0., [&](int k) {
           return -delz[(size_t)(k - 1) * nCC + occ] / delp[(size_t)(k - 1) * nA + c.o];  // :292
         });
-        map_col(c, km, false, [&](int k, double v_) {
+        map_col(c, km, false, pc, [&](int k, double v_) {
           delz[(size_t)(k - 1) * nCC + occ] = -v_ * (CS(pe2, k + 1) - CS(pe2, k));
         });
       }
