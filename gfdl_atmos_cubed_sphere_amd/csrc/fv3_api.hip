@@ -1466,7 +1466,7 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   }
   RemapPar rp{p->last_step, p->hydrostatic, p->adiabatic, p->nq, p->kord_mt, p->kord_wz, p->kord_tm, p->sphum,
               p->akap, p->ptop, p->rdgas, p->grav, p->cv_air, p->r_vir, p->cp, p->t_min,
-              0, 0, 0, 0, 0, 0, 0, 0, 0., 0., 0., nullptr, nullptr};
+              0, 0, 0, 0, 0, 0, 0, 0, 0., 0., 0., nullptr, nullptr, p->fill};
   const bool moist = c->moist_on && (c->moist.moist_kappa || c->moist.use_cond);
   if (moist) {
     const fv3_moist_params &m = c->moist;

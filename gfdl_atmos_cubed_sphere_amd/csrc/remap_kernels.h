@@ -495,7 +495,51 @@ struct RemapPar {
   int moist_kappa, use_cond, nwat, liq_wat, rainwat, ice_wat, snowwat, graupel;
   double cv_vap, c_liq, c_ice;
   double *q_con, *cappa;  // A x km, written where the reference writes them (fv_mapz.F90:212-219, :463-478)
+  int fill;               // flagstruct%fill: fillz on the remapped tracers
 };
+
+// fillz of one tracer column (fv_fill.F90:34-137, default branch): q(k) at q[(k-1)*qs], dp2(k) = pe2(k+1) - pe2(k) through
+// dp(k).  In place; the borrowing steps are sequential in k exactly as in the reference.
+template <class Dp>
+FV3_HD void fillz_col(int km, double *q, size_t qs, const Dp &dp) {
+#define QK(k) q[(size_t)((k)-1) * qs]
+  bool zfix = false;
+  if (QK(1) < 0.) {
+    QK(2) = QK(2) + QK(1) * dp(1) / dp(2);
+    QK(1) = 0.;
+  }
+  for (int k = 2; k <= km - 1; k++) {
+    if (QK(k) < 0.) {
+      zfix = true;
+      if (QK(k - 1) > 0.) {
+        const double dq = dmin(QK(k - 1) * dp(k - 1), -QK(k) * dp(k));
+        QK(k - 1) = QK(k - 1) - dq / dp(k - 1);
+        QK(k) = QK(k) + dq / dp(k);
+      }
+      if (QK(k) < 0.0 && QK(k + 1) > 0.) {
+        const double dq = dmin(QK(k + 1) * dp(k + 1), -QK(k) * dp(k));
+        QK(k + 1) = QK(k + 1) - dq / dp(k + 1);
+        QK(k) = QK(k) + dq / dp(k);
+      }
+    }
+  }
+  if (QK(km) < 0. && QK(km - 1) > 0.) {
+    const double qup = QK(km - 1) * dp(km - 1), qly = -QK(km) * dp(km), dup = dmin(qly, qup);
+    zfix = true;
+    QK(km - 1) = QK(km - 1) - dup / dp(km - 1);
+    QK(km) = QK(km) + dup / dp(km);
+  }
+  if (zfix) {
+    double sum0 = 0., sum1 = 0.;
+    for (int k = 2; k <= km; k++) sum0 = sum0 + QK(k) * dp(k);
+    if (sum0 > 0.) {
+      for (int k = 2; k <= km; k++) sum1 = sum1 + dmax(0., QK(k) * dp(k));
+      const double fac = sum0 / sum1;
+      for (int k = 2; k <= km; k++) QK(k) = dmax(0., fac * (QK(k) * dp(k)) / dp(k));
+    }
+  }
+#undef QK
+}
 
 // moist_cv of one cell (fv_thermodynamics.F90:250-325 without the t1 special case): returns cvm, sets q_con.
 // qk = &q(i,j,k,1), ns = stride between species
@@ -696,6 +740,8 @@ struct RemapFields {
         double *qq = q + (size_t)iq * nA * km;
         const ProfCfg pc = profile_col(c, km, true, 0., 0, kord_tr[iq], 0., [&](int k) { return qq[(size_t)(k - 1) * nA + c.o]; });
         map_col(c, km, p.nq > 5, pc, [&](int k, double v_) { qq[(size_t)(k - 1) * nA + c.o] = v_; });
+        if (p.fill)  // fv_operators.F90:337 / fv_mapz.F90:390
+          fillz_col(km, qq + c.o, nA, [&](int k) { return CS(pe2, k + 1) - CS(pe2, k); });
       }
     }
   }

@@ -39,7 +39,7 @@ module fv3_host_mod
     real(c_double) :: ptop = 300.d0
     real(c_double) :: grav = 9.80d0, rdgas = 287.04d0, akap = 2.d0/7.d0, cp_air = 287.04d0/(2.d0/7.d0)   ! constants_mod
     real(c_double) :: r_vir = 0.6077d0, t_min = 184.d0
-    logical :: adiabatic = .true.
+    logical :: adiabatic = .true., fill = .false.
   end type
 
   !> device-resident state and work arrays of one rank (fv_atmos_type members + dyn_core.F90:256-283)
@@ -437,7 +437,7 @@ contains
     allocate(kord_tr(max(1, at%nq))); kord_tr = int(at%fl%kord_tr, c_int)
     rp%hydrostatic = 0; rp%adiabatic = merge(1_c_int, 0_c_int, at%fl%adiabatic); rp%nq = int(at%nq, c_int)
     rp%kord_mt = int(at%fl%kord_mt, c_int); rp%kord_wz = int(at%fl%kord_wz, c_int); rp%kord_tm = int(at%fl%kord_tm, c_int)
-    rp%sphum = merge(1_c_int, 0_c_int, at%nq > 0)
+    rp%sphum = merge(1_c_int, 0_c_int, at%nq > 0); rp%fill = merge(1_c_int, 0_c_int, at%fl%fill)
     rp%akap = at%fl%akap; rp%ptop = at%fl%ptop; rp%rdgas = at%fl%rdgas; rp%grav = at%fl%grav
     rp%cv_air = at%fl%cp_air - at%fl%rdgas; rp%r_vir = at%fl%r_vir; rp%cp = at%fl%cp_air; rp%t_min = at%fl%t_min
     do n_map = 1, at%fl%k_split

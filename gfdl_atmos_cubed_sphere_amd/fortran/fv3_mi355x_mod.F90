@@ -64,6 +64,7 @@ module fv3_mi355x_mod
   type, bind(C) :: fv3_remap_params   ! Lagrangian_to_Eulerian scalars (fv_mapz.F90:56-64)
     integer(c_int) :: last_step, hydrostatic, adiabatic, nq, kord_mt, kord_wz, kord_tm, sphum
     real(c_double) :: akap, ptop, rdgas, grav, cv_air, r_vir, cp, t_min
+    integer(c_int) :: fill          ! flagstruct%fill: fillz on the remapped tracers
   end type
 
   interface

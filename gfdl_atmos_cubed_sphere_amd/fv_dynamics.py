@@ -20,7 +20,7 @@ class FvDynamics:
     def __init__(self, ctx: Context, flags: DynFlags, ak, bk, nq: int = 0, k_split: int = 1, kord_tm: int = -8,
                  kord_mt: int = 8, kord_wz: int = 8, kord_tr: int = 8, q_split: int = 0, nord_tr: int = 0, trdm2: float = 0.0, adiabatic: bool = True,
                  px: int = 1, py: int = 1, rank: int = 0, world: int = 1, dist=None, tau: float = 0.0,
-                 rf_cutoff: float = 30.0e2, c2l_ord: int = 4, moist: dict | None = None):
+                 rf_cutoff: float = 30.0e2, c2l_ord: int = 4, moist: dict | None = None, fill: bool = False):
         ak, bk = np.asarray(ak, dtype=np.float64), np.asarray(bk, dtype=np.float64)
         dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5          # dyn_core.F90:241-244
         self.ctx, self.fl, self.nq, self.k_split, self.q_split, self.dist = ctx, flags, nq, k_split, q_split, dist
@@ -45,7 +45,7 @@ class FvDynamics:
         self.remap_par = dict(hydrostatic=int(flags.hydrostatic), adiabatic=int(adiabatic), nq=nq, kord_mt=kord_mt, kord_wz=kord_wz,
                               kord_tm=kord_tm, sphum=1 if nq else 0, akap=flags.akap, ptop=flags.ptop,
                               rdgas=flags.rdgas, grav=flags.grav, cv_air=flags.cp_air - flags.rdgas, r_vir=0.6077,
-                              cp=flags.cp_air, t_min=184.0, kord_tr=[kord_tr] * nq)
+                              cp=flags.cp_air, t_min=184.0, kord_tr=[kord_tr] * nq, fill=int(fill))
 
     def set_tracers(self, q: np.ndarray):
         self.dc.d["q"].upload(q)

@@ -79,7 +79,8 @@ def nh_consts(ptop, p_fac=0.05, a_imp=1.0, akap=KAPPA, grav=GRAV, rdgas=RDGAS, c
 class _RemapParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ["last_step", "hydrostatic", "adiabatic", "nq", "kord_mt", "kord_wz", "kord_tm",
                                        "sphum"]] + [(n, C.c_double) for n in ["akap", "ptop", "rdgas", "grav", "cv_air",
-                                                                              "r_vir", "cp", "t_min"]]
+                                                                              "r_vir", "cp", "t_min"]] + [
+        ("fill", C.c_int)]
 
 
 class _MoistParams(C.Structure):
@@ -397,6 +398,7 @@ class Context:
         for k in ["last_step", "hydrostatic", "adiabatic", "nq", "kord_mt", "kord_wz", "kord_tm", "sphum", "akap", "ptop",
                   "rdgas", "grav", "cv_air", "r_vir", "cp", "t_min"]:
             setattr(s, k, par[k])
+        s.fill = int(par.get("fill", 0))
         kt = np.ascontiguousarray(par.get("kord_tr", []), dtype=np.int32)
         self.lib.check(self.lib.dll.fv3_lagrangian_to_eulerian(
             self.h, C.byref(s), kt.ctypes.data_as(_ip) if kt.size else None, ps.p, pe.p, delp.p, pkz.p, pk.p, u.p, v.p,

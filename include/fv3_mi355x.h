@@ -317,6 +317,7 @@ int fv3_pt_to_theta_v(fv3_ctx *ctx, int hydrostatic, double zvir, double kappa, 
 typedef struct fv3_remap_params {
   int last_step, hydrostatic, adiabatic, nq, kord_mt, kord_wz, kord_tm, sphum;
   double akap, ptop, rdgas, grav, cv_air, r_vir, cp, t_min;
+  int fill;   /* flagstruct%fill: fillz (fv_fill.F90:34-137) on every remapped tracer column (fv_operators.F90:337) */
 } fv3_remap_params;
 /* thermostruct%moist_kappa / use_cond in the remap (nonhydrostatic): the T_v <-> T_m transforms use the moist kappa
  * cappa = rdgas / (rdgas + cvm/(1 + r_vir*qv)) with cvm, q_con from moist_cv (fv_thermodynamics.F90:250-325; nwat and the

@@ -187,7 +187,10 @@ typedef struct fvo_remap_par {
    * nwat and the 1-based tracer indices of the water species (0 = absent), cv_vap = 3*rvgas, c_liq, c_ice (gfdl_mp) */
   int moist_kappa, use_cond, nwat, liq_wat, rainwat, ice_wat, snowwat, graupel;
   double cv_vap, c_liq, c_ice;
+  int fill; /* flagstruct%fill: fillz on the remapped tracers (fv_operators.F90:337, fv_fill.F90:34-137) */
 } fvo_remap_par;
+/* fillz of one column of one tracer (fv_fill.F90:34-137, the default (not DEV_GFS_PHYS) branch); q, dp: 1-based [1..km] */
+void fvo_fillz_column(int km, double *q, const double *dp);
 /* q_con, cappa: A x km, written when moist_kappa (fv_mapz.F90:212-219, :463-478); may be NULL otherwise */
 int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p, double *ps, double *pe, double *delp,
                                double *pkz, double *pk, double *u, double *v, double *w, double *delz, double *pt,

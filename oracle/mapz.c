@@ -327,6 +327,46 @@ int fvo_remap_column(int which, int km, const double *pe1, const double *pe2, co
  * ------------------------------------------------------------------------------------------------- */
 
 
+void fvo_fillz_column(int km, double *q, const double *dp) {
+  int k, zfix = 0;
+  double dq;
+  if (q[1] < 0.) { /* top layer, :67-73 */
+    q[2] = q[2] + q[1] * dp[1] / dp[2];
+    q[1] = 0.;
+  }
+  for (k = 2; k <= km - 1; k++) { /* interior, :76-96 */
+    if (q[k] < 0.) {
+      zfix = 1;
+      if (q[k - 1] > 0.) { /* borrow from above */
+        dq = dmin(q[k - 1] * dp[k - 1], -q[k] * dp[k]);
+        q[k - 1] = q[k - 1] - dq / dp[k - 1];
+        q[k] = q[k] + dq / dp[k];
+      }
+      if (q[k] < 0.0 && q[k + 1] > 0.) { /* borrow from below */
+        dq = dmin(q[k + 1] * dp[k + 1], -q[k] * dp[k]);
+        q[k + 1] = q[k + 1] - dq / dp[k + 1];
+        q[k] = q[k] + dq / dp[k];
+      }
+    }
+  }
+  k = km; /* bottom layer, :99-110 */
+  if (q[k] < 0. && q[k - 1] > 0.) {
+    const double qup = q[k - 1] * dp[k - 1], qly = -q[k] * dp[k], dup = dmin(qly, qup);
+    zfix = 1;
+    q[k - 1] = q[k - 1] - dup / dp[k - 1];
+    q[k] = q[k] + dup / dp[k];
+  }
+  if (zfix) { /* final check and non-local fix, :113-133 */
+    double sum0 = 0., sum1 = 0., fac;
+    for (k = 2; k <= km; k++) sum0 = sum0 + q[k] * dp[k];
+    if (sum0 > 0.) {
+      for (k = 2; k <= km; k++) sum1 = sum1 + dmax(0., q[k] * dp[k]);
+      fac = sum0 / sum1;
+      for (k = 2; k <= km; k++) q[k] = dmax(0., fac * (q[k] * dp[k]) / dp[k]);
+    }
+  }
+}
+
 double fvo_moist_cv(const fvo_remap_par *p, const double *qk, size_t ns, double *q_con) {
 #define Q(n) ((n) > 0 ? qk[(size_t)((n)-1) * ns] : 0.)
   double qv, ql, qs;
@@ -434,6 +474,7 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
           double *qq = q + (size_t)(iq - 1) * nA * km;
           for (k = 1; k <= km; k++) c1[k] = qq[IA3(i, j, k)];
           rc |= fvo_remap_column(p->nq > 5 ? 3 : 2, km, pe1, pe2, c1, c2, 0., 0, p->kord_tr[iq - 1], 0.);
+          if (p->fill) fvo_fillz_column(km, c2, dp2); /* fv_operators.F90:337 / fv_mapz.F90:390 */
           for (k = 1; k <= km; k++) qq[IA3(i, j, k)] = c2[k];
         }
         /* 3) w and delz, :400-423 */

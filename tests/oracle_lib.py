@@ -253,7 +253,7 @@ class RemapPar(C.Structure):
         ("kord_tr", _ip)] + [(n, C.c_double) for n in ["akap", "ptop", "rdgas", "grav", "cv_air", "r_vir", "cp", "t_min"]] + [
         ("sphum", C.c_int)] + [(n, C.c_int) for n in ["moist_kappa", "use_cond", "nwat", "liq_wat", "rainwat", "ice_wat",
                                                         "snowwat", "graupel"]] + [
-        (n, C.c_double) for n in ["cv_vap", "c_liq", "c_ice"]]
+        (n, C.c_double) for n in ["cv_vap", "c_liq", "c_ice"]] + [("fill", C.c_int)]
 
 
 def remap_column(which, pe1, pe2, q1, qs, iv, kord, qmin=0.0):

@@ -43,7 +43,7 @@ MOIST6 = dict(nwat=6, liq_wat=2, rainwat=3, ice_wat=4, snowwat=5, graupel=6, cv_
 
 
 def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=False, kord_tm=-8, kord=8, adiabatic=True,
-                moist_kappa=False, use_cond=False, nwat=6):
+                moist_kappa=False, use_cond=False, nwat=6, fill=False):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     moist = moist_kappa or use_cond
@@ -57,6 +57,14 @@ def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=Fal
     par = dict(last_step=int(last_step), hydrostatic=int(hydrostatic), adiabatic=int(adiabatic), nq=nq, kord_mt=kord,
                kord_wz=kord, kord_tm=kord_tm, sphum=1 if nq else 0, akap=KAPPA, ptop=N.PTOP, rdgas=RDGAS, grav=GRAV,
                cv_air=CP_AIR - RDGAS, r_vir=0.6077, cp=CP_AIR, t_min=184.0, kord_tr=[kord if n % 2 == 0 else 9 for n in range(nq)])
+    if fill:   # negative undershoots for fillz to repair: isolated, paired and bottom / top-layer cases
+        rng = np.random.default_rng(77)
+        qn = f["q"]
+        mask = rng.uniform(0, 1, qn.shape) > 0.93
+        qn[mask] = -0.3 * qn[mask] - 0.01
+        qn[:, :, 0, 0] = -0.02
+        qn[:, :, -1, 0] = -0.05
+        par["fill"] = 1
     mpar = dict(MOIST6, nwat=nwat, moist_kappa=int(moist_kappa), use_cond=int(use_cond)) if moist else {}
     if moist and nwat == 3:
         mpar.update(liq_wat=2, ice_wat=3, rainwat=0, snowwat=0, graupel=0)
@@ -65,6 +73,12 @@ def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=Fal
     if hydrostatic:
         ref.pop("w"); ref.pop("delz"); ref.pop("ws")
     O.lagrangian_to_eulerian(g, km, opar, ref, ak, bk)
+    if fill:    # fillz really acted, and left no negative values where the column could afford it
+        nofill = {k: (v.copy(order="F") if v is not None else None) for k, v in f.items()}
+        O.lagrangian_to_eulerian(g, km, dict(opar, fill=0), nofill, ak, bk)
+        rr = (bd.is_, bd.ie, bd.js, bd.je)
+        assert np.min(bd.view(nofill["q"][:, :, :, 0], "A", *rr)) < 0.0
+        assert P.rel_rms(bd.view(nofill["q"][:, :, :, 0], "A", *rr), bd.view(ref["q"][:, :, :, 0], "A", *rr)) > 1e-6
     if moist:   # the moist branches really change the answer
         dry = {k: (v.copy(order="F") if v is not None else None) for k, v in f.items()}
         O.lagrangian_to_eulerian(g, km, par, dry, ak, bk)

@@ -447,3 +447,9 @@ def test_fv_dynamics_call_moist(prod, moist_kappa):
     """whole fv_dynamics call with use_cond (+ moist_kappa): moist_cv conversions, q_con through d_sw and the Riemann
     solvers, moist remap, T on return"""
     D.check_fv_cycle_moist(prod, moist_kappa=moist_kappa)
+
+
+@pytest.mark.parametrize("nq", [2, 6])
+def test_remap_fillz(prod, nq):
+    """flagstruct%fill: fillz (fv_fill.F90:34-137) on the remapped tracers, both tracer remap forms (nq <= 5, nq > 5)"""
+    R.check_remap(prod, nq=nq, fill=True)

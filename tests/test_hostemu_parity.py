@@ -352,3 +352,9 @@ def test_fv_dynamics_call_moist(emu, moist_kappa):
     """whole fv_dynamics call with use_cond (+ moist_kappa): moist_cv conversions, q_con through d_sw and the Riemann
     solvers, moist remap, T on return"""
     D.check_fv_cycle_moist(emu, moist_kappa=moist_kappa)
+
+
+@pytest.mark.parametrize("nq", [2, 6])
+def test_remap_fillz(emu, nq):
+    """flagstruct%fill: fillz (fv_fill.F90:34-137) on the remapped tracers, both tracer remap forms (nq <= 5, nq > 5)"""
+    R.check_remap(emu, nq=nq, fill=True)
