@@ -81,6 +81,7 @@ struct fv3_ctx {
   double *mflux[2];      // mass-flux scratch of the marching transports: FX kind, FY kind (npz levels)
   int march_tj;          // rows per wavefront segment of the marching kernels
   int march_tj_csw, march_tj_ke, march_tj_fused, march_tj_mom;
+  int tj_fixed;          // an FV3_MI355X_MARCH_TJ* variable is set: take the rows per segment as given
   int csw_kpw;           // levels per wavefront in CswMarch (1 .. 4; FV3_MI355X_CSW_KPW)
   int use_fused;         // 1: delp + w + pt in one marching kernel when the schemes allow (FV3_MI355X_FUSED=0: off)
   int use_march;         // 0: LDS-tile kernels only (FV3_MI355X_MARCH=0)
@@ -220,6 +221,10 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     c->use_march = e ? std::atoi(e) : 1;
     e = std::getenv("FV3_MI355X_SIDE_STREAM");
     c->use_side = e ? std::atoi(e) : 1;
+    c->tj_fixed = 0;
+    for (const char *v : {"FV3_MI355X_MARCH_TJ", "FV3_MI355X_MARCH_TJ_FUSED", "FV3_MI355X_MARCH_TJ_MOM",
+                          "FV3_MI355X_MARCH_TJ_KE", "FV3_MI355X_MARCH_TJ_CSW"})
+      if (std::getenv(v)) c->tj_fixed = 1;
     e = std::getenv("FV3_MI355X_MARCH_TJ");
     c->march_tj = e ? std::atoi(e) : 48;
     if (c->march_tj < 1) c->march_tj = 48;
@@ -540,6 +545,20 @@ extern "C" int fv3_fv_tp_2d(fv3_ctx *c, int nk, const double *q, const double *c
   return 0;
 }
 
+// Rows per wavefront segment: the configured value, shortened on small domains so that a launch still has a few
+// thousand wavefronts (a wavefront marches tj + 6 rows one after the other: with too few of them the launch time is that
+// serial march, not throughput).  Never below 8 rows (the 6 warm-up rows of every segment are overhead).
+static int seg_rows(const fv3_ctx *c, int tj_conf, int nlev_slots) {
+  const Grid &g = c->g;
+  if (c->tj_fixed) return tj_conf;
+  const int nstrips = num_strips(g);
+  const long have = (long)nstrips * (nlev_slots > 0 ? nlev_slots : 1);
+  const int want_segs = (int)((2048 + have - 1) / have);
+  int tj = (g.ny + want_segs - 1) / want_segs;
+  if (tj < 8) tj = 8;
+  return tj < tj_conf ? tj : tj_conf;
+}
+
 // geometry mode (Grid::geom) as a compile-time constant
 template <class F>
 static int dispatch_geom(int geom, F &&f) {
@@ -559,7 +578,7 @@ extern "C" int fv3_c_sw(fv3_ctx *c, double *delpc, const double *delp, double *p
   if (!hydrostatic && (!w || !wc)) return fail("fv3_c_sw: nonhydrostatic call needs w and wc");
   if (c->use_march) {
     const CswArgs ca{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2};
-    MarchDims md = make_csw_dims(c->g, c->march_tj_csw);
+    MarchDims md = make_csw_dims(c->g, seg_rows(c, c->march_tj_csw, c->g.npz));
     // uniform metrics: nothing to share between levels, one level per wavefront at four wavefronts per SIMD is faster
     const int kpw = c->csw_kpw ? c->csw_kpw : (c->g.geom == 2 ? 1 : 2);
     const int nkg = (c->g.npz + kpw - 1) / kpw;
@@ -608,19 +627,19 @@ static int ensure_mflux(fv3_ctx *c) {
 // region (fused kernel only): 0 = every strip / segment, 1 = those that do not touch the halo (interior box),
 // 2 = the frame around the interior box
 static bool dsw_has_interior(const fv3_ctx *c) {
-  const MarchDims mf = make_march_dims(c->g, c->march_tj_fused);
+  const MarchDims mf = make_march_dims(c->g, seg_rows(c, c->march_tj_fused, c->g.npz));
   return mf.nstrips >= 3 && mf.nsegs >= 3;
 }
 
 static int dsw_transport_march(fv3_ctx *c, const DswArgs &a, int region = 0) {
   const Grid &g = c->g;
   if (ensure_mflux(c)) return 1;
-  MarchDims md = make_march_dims(g, c->march_tj);
+  MarchDims md = make_march_dims(g, seg_rows(c, c->march_tj, g.npz));
   md.klist = c->klist;
   const int nw = md.nwaves(c->n_plain);
   if (c->use_fused && !a.use_cond && a.hord_dp == a.hord_tm && (a.hydrostatic || a.hord_dp == a.hord_vt)) {
     if (c->n_plain == 0) return 0;
-    MarchDims mf = make_march_dims(g, c->march_tj_fused);
+    MarchDims mf = make_march_dims(g, seg_rows(c, c->march_tj_fused, g.npz));
     mf.klist = c->klist;
     const int NS = mf.nstrips, NG = mf.nsegs;
     auto box = [&](int s0, int ns, int g0, int ng) -> int {
@@ -676,7 +695,7 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
   const bool fused_m = c->use_fused != 0;
   if (!fused_m && !c->ke_scr) RT(rt_malloc((void **)&c->ke_scr, sizeof(double) * g.nB() * g.npz));
   if (fused_m) {
-    MarchDims mf = make_march_dims(g, c->march_tj_mom);
+    MarchDims mf = make_march_dims(g, seg_rows(c, c->march_tj_mom, g.npz));
     mf.klist = c->klist_m;
     const int nwf = mf.nwaves(c->n_plain_m);
     return dispatch_hord(a.hord_vt, [&](auto H) {
@@ -696,7 +715,7 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
     });
   }
   if (part != 2) {
-    MarchDims mk = make_march_dims(g, c->march_tj_ke);
+    MarchDims mk = make_march_dims(g, seg_rows(c, c->march_tj_ke, g.npz));
     mk.klist = c->klist_m;
     const int nwk = mk.nwaves(c->n_plain_m);
     int rc;
@@ -707,7 +726,7 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
     }
     if (rc || part == 1) return rc;
   }
-  MarchDims md = make_march_dims(g, c->march_tj);
+  MarchDims md = make_march_dims(g, seg_rows(c, c->march_tj, g.npz));
   md.klist = c->klist_m;
   const int nw = md.nwaves(c->n_plain_m);
   const double *ke = c->ke_scr;
@@ -1111,7 +1130,7 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
   constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
   const bool march = c->use_march != 0;
   if (march && c->n_plain_z > 0) {
-    MarchDims md = make_march_dims(g, c->march_tj);
+    MarchDims md = make_march_dims(g, seg_rows(c, c->march_tj, g.npz));
     md.klist = c->klist_z;
     const int nwz = md.nwaves(c->n_plain_z);
     RT(dispatch_hord(hord, [&](auto H) {
@@ -1594,7 +1613,7 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
     RT(rt_sync(c->stream));
   }
   if (c->use_march && !(it == 1 && trdm > 1.e-4)) {
-    MarchDims md = make_march_dims(g, c->march_tj);
+    MarchDims md = make_march_dims(g, seg_rows(c, c->march_tj, g.npz));
     const int nwt = md.nwaves(g.npz * nq);
     return dispatch_hord(hord, [&](auto H) {
       TracerMarch<decltype(H)::value> kf{g, md, g.npz, nq, it, nsplt, c->trc_i, q, dp1, mfx, mfy, cx, cy, xfx, yfx,
