@@ -255,8 +255,9 @@ class DynCore:
                         d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], d["w_nxt"],
                         d["q_con_nxt"] if fl.use_cond else None, d["heat_s"], d["diss_e"])
             if halo.overlaps:
-                pending = halo.start([(d["uc"], "V"), (d["vc"], "U")])
+                pending = halo.start([(d["uc"], "V"), (d["vc"], "U")], defer=True)
                 ctx.d_sw(*dsw_args, phase="interior")
+                halo.post(pending)
                 halo.finish(pending)
                 ctx.d_sw(*dsw_args, phase="rest")
             else:

@@ -125,6 +125,7 @@ class HaloExchanger:
         self.topo = HaloTopology(ctx.bd, px, py, rank)
         self._views = {}
         self._groups = {}
+        self._comm_stream = None
 
     def _tensor(self, dev):
         import torch
@@ -163,10 +164,16 @@ class HaloExchanger:
         d_sw into interior + rest only then -- on one rank the split would just cost launch granularity."""
         return self.world > 1 or self.split_single
 
-    def start(self, fields):
+    def start(self, fields, defer: bool = False):
         """Begin a group halo update (the reference's start_group_halo_update): pack and post the messages.  Returns a
         handle for finish().  Compute that does not read these halos may be launched in between: the transfers run on
-        RCCL's own stream and only finish() makes the launch stream wait for them."""
+        RCCL's own stream and only finish() makes the launch stream wait for them.
+
+        defer=True: only pack; the caller launches its overlapping kernels FIRST and then calls post(handle).  Posting
+        eight send/recv pairs costs the host ~0.2 ms; done in this order the GPU is already busy with the overlapping
+        kernel during that time instead of idling in front of it.  The messages are then issued from a communication
+        stream that waits for the pack kernel only (an event recorded right after it), not for the kernels launched in
+        between."""
         fields = list(fields)
         if self.world == 1 and not self.packed_single and not self.loopback:
             for dev, kind in fields:
@@ -185,18 +192,48 @@ class HaloExchanger:
                     continue
                 p2p.append(dist.P2POp(dist.isend, tsend[m], to))
                 p2p.append(dist.P2POp(dist.irecv, trecv[m], frm))
-            works = dist.batch_isend_irecv(p2p) if p2p else []   # ncclGroupStart ... ncclGroupEnd on RCCL
-            pending.append((part, recv, works))
+            entry = {"part": part, "recv": recv, "p2p": p2p, "works": None, "packed": None}
+            if defer and p2p and not getattr(self.ctx.lib, "host_memory", False):
+                import torch
+                entry["packed"] = torch.cuda.Event()
+                entry["packed"].record(torch.cuda.current_stream())
+            else:
+                self._post(entry)
+            pending.append(entry)
         return pending
+
+    def _post(self, entry):
+        import torch.distributed as dist
+        if entry["works"] is not None:
+            return
+        if not entry["p2p"]:
+            entry["works"] = []
+        elif entry["packed"] is not None:
+            import torch
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream()
+            self._comm_stream.wait_event(entry["packed"])
+            with torch.cuda.stream(self._comm_stream):
+                entry["works"] = dist.batch_isend_irecv(entry["p2p"])
+        else:
+            entry["works"] = dist.batch_isend_irecv(entry["p2p"])   # ncclGroupStart ... ncclGroupEnd on RCCL
+
+    def post(self, pending):
+        """Issue the messages of a start(..., defer=True) handle (no-op for the ones already posted)."""
+        if pending is None:
+            return
+        for entry in pending:
+            self._post(entry)
 
     def finish(self, pending):
         """complete_group_halo_update: wait for the messages of start() and unpack them into the halos."""
         if pending is None:
             return
-        for part, recv, works in pending:
-            for w in works:
+        for entry in pending:
+            self._post(entry)
+            for w in entry["works"]:
                 w.wait()
-            self.ctx.halo_unpack(part, recv)
+            self.ctx.halo_unpack(entry["part"], entry["recv"])
 
     def update(self, fields):
         """fields: [(DeviceArray, kind)] -- one "pack" (the reference's group halo update).

@@ -39,7 +39,8 @@ def main():
         fields.append((ctx.from_host(a), kind))
         refs.append(ref)
     for rep in range(3):                       # repeated use of the cached message buffers
-        pend = halo.start(fields[:3])          # overlapped form: start ... finish
+        pend = halo.start(fields[:3], defer=(rep == 1))   # overlapped form: start [... post] ... finish
+        halo.post(pend)
         halo.finish(pend)
         halo.update(fields[3:])
     ctx.sync()
