@@ -41,8 +41,8 @@ PAIR_ALG_BYTES = 336.0       # perfectly fused c_sw+d_sw, 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--nx", type=int, default=384)
     ap.add_argument("--npz", type=int, default=127)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
