@@ -78,6 +78,7 @@ struct DswTransportFused {
     vd ar, cx, xf;         // row r (COURANT: cx = uc row, xf unused)
     vd cy, yf;             // face r-2 (COURANT: cy = vc row)
     vd xfj, mx, my0, ra;   // row r-3: xfx, mfx, mfy, rarea
+    vd ucj;                // UNI + COURANT: uc of row r-3
     // COURANT only: metric rows and the accumulators
     vd rdxa, dyr, sg3, sg1, cxa;       // row r: rdxa, dy, sin_sg(.,3), sin_sg(.,1); cx
     vd rdya0, rdya1, dxr, sg4, sg2, cya;  // face r-2: rdya(j-1), rdya(j), dx, sin_sg(j-1,4), sin_sg(j,2); cy
@@ -118,10 +119,10 @@ struct DswTransportFused {
       if (COURANT) {
         const long nAp = (long)g.nA();
         in.cx = vload(a.uc + (size_t)k * g.nV(), (long)g.iV(ilo, r), s.A);
-        in.cxa = vload(a.cx + oCX, iCX, s.F);
+        if constexpr (!UNI) in.cxa = vload(a.cx + oCX, iCX, s.F);
         const long iAf = (long)g.iA(ilo, jf), iAm = (long)g.iA(ilo, jf - 1), iUf = (long)g.iU(ilo, jf);
         in.cy = vload(a.vc + (size_t)k * g.nU(), iUf, s.A);
-        in.cya = vload(a.cy + oCY, iCY, s.A);
+        if constexpr (!UNI) in.cya = vload(a.cy + oCY, iCY, s.A);
         if constexpr (!UNI) {
           in.rdxa = vload(g.rdxa, iA, s.A);
           in.dyr = vload(g.dy, (long)g.iV(ilo, r), s.A);
@@ -140,8 +141,12 @@ struct DswTransportFused {
         in.yf = vload(yfx, iCY, s.A);
         in.xfj = vload(xfx, (long)g.iCX(ilo, j), s.F);
       }
-      in.mx = vload(mfx, (long)g.iFX(ilo, j), Fx);
-      in.my0 = vload(mfy, (long)g.iFY(ilo, j), s.C);
+      if constexpr (!UNI) {
+        in.mx = vload(mfx, (long)g.iFX(ilo, j), Fx);
+        in.my0 = vload(mfy, (long)g.iFY(ilo, j), s.C);
+      } else if (COURANT) {
+        in.ucj = vload(a.uc + (size_t)k * g.nV(), (long)g.iV(ilo, j), s.A);  // uc of row r-3: its crx, xfx are re-formed
+      }
       in.ra = UNI ? vd(g.c_rarea) : vload(g.rarea, (long)g.iA(ilo, j), s.C);
       return in;
     };
@@ -160,7 +165,7 @@ struct DswTransportFused {
       const int j = r - 3;
       const bool have_face = r - 2 >= jA, have_row = j >= jA;
       Tp2dShared sh;
-      vd xfj = in.xfj;
+      vd xfj = in.xfj, cxj_uni(0.);
       if (COURANT) {
         // x faces of row r (sw_core.F90:865, :882-888, :923-927)
         const vd x = dt * in.cx;
@@ -176,7 +181,8 @@ struct DswTransportFused {
           const long iCX = (long)g.iCX(ilo, r);
           vstore_nt(crx, iCX, sh.cx, s.lC0, lFx1);
           vstore_nt(xfx, iCX, sh.xf, s.lC0, lFx1);
-          vstore_nt(a.cx + oCX, iCX, in.cxa + sh.cx, s.lC0, lFx1);
+          if constexpr (UNI) vaccum(a.cx + oCX, iCX, sh.cx, s.lC0, lFx1);
+          else vstore_nt(a.cx + oCX, iCX, in.cxa + sh.cx, s.lC0, lFx1);
         }
         // y faces of row r-2 (:894-900, :933-936)
         const vd y = dt * in.cy;
@@ -193,20 +199,28 @@ struct DswTransportFused {
           const long iCY = (long)g.iCY(ilo, jf);
           vstore_nt(cry, iCY, sh.cy, lY0, lY1);
           vstore_nt(yfx, iCY, sh.yf, lY0, lY1);
-          vstore_nt(a.cy + oCY, iCY, in.cya + sh.cy, lY0, lY1);
+          if constexpr (UNI) vaccum(a.cy + oCY, iCY, sh.cy, lY0, lY1);
+          else vstore_nt(a.cy + oCY, iCY, in.cya + sh.cy, lY0, lY1);
         }
-        xfj = xf_3;
-        xf_3 = xf_2; xf_2 = xf_1; xf_1 = sh.xf;
+        if constexpr (UNI) {  // crx, xfx of row r-3 from its uc again (same expressions as at step r-3): no 3-row windows
+          const vd xj = dt * in.ucj;
+          xfj = g.c_dy * xj;
+          cxj_uni = xj * g.c_rdxa;
+        } else {
+          xfj = xf_3;
+          xf_3 = xf_2; xf_2 = xf_1; xf_1 = sh.xf;
+        }
       } else {
         sh.cx = in.cx; sh.xf = in.xf;
         sh.cy = in.cy; sh.yf = in.yf;
       }
       sh.ar = in.ar;
       sh.rax = in.ar + sh.xf - shl1(sh.xf);
-      sh.arj = UNI ? in.ar : ar_3; sh.cxj = cx_3;
+      sh.arj = UNI ? in.ar : ar_3;
+      sh.cxj = (UNI && COURANT) ? cxj_uni : cx_3;
       sh.ray = sh.arj + yf_prev - sh.yf;
       if constexpr (!UNI) { ar_3 = ar_2; ar_2 = ar_1; ar_1 = in.ar; }
-      cx_3 = cx_2; cx_2 = cx_1; cx_1 = sh.cx;
+      if constexpr (!(UNI && COURANT)) { cx_3 = cx_2; cx_2 = cx_1; cx_1 = sh.cx; }
       vd fxd, fyd0, fyd1, fxw, fyw0, fyw1, fxp, fyp0, fyp1;
       fd.step(in.dp, sh, have_face, have_row, fxd, fyd0, fyd1);
       if (NH) fw.step(in.w, sh, have_face, have_row, fxw, fyw0, fyw1);
@@ -218,8 +232,13 @@ struct DswTransportFused {
           const vd fxm = fxd * xfj;  // tp_core.F90:217-221
           const vd fym0 = fym_prev, fym1 = fym;
           const long iFX = (long)g.iFX(ilo, j), iFY0 = (long)g.iFY(ilo, j), iA = (long)g.iA(ilo, j);
-          vstore_nt(mfx, iFX, in.mx + fxm, s.lC0, lFx1);  // sw_core.F90:928-940
-          vstore_nt(mfy, iFY0, in.my0 + fym0, s.lC0, s.lC1);
+          if constexpr (UNI) {
+            vaccum(mfx, iFX, fxm, s.lC0, lFx1);            // sw_core.F90:928-940
+            vaccum(mfy, iFY0, fym0, s.lC0, s.lC1);
+          } else {
+            vstore_nt(mfx, iFX, in.mx + fxm, s.lC0, lFx1);
+            vstore_nt(mfy, iFY0, in.my0 + fym0, s.lC0, s.lC1);
+          }
           if (j == g.je) {
             const long iFY1 = (long)g.iFY(ilo, j + 1);
             vstore_nt(mfy, iFY1, vload(mfy, iFY1, s.C) + fym1, s.lC0, s.lC1);

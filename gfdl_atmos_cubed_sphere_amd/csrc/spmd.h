@@ -156,6 +156,10 @@ inline void vstore(double *p, long off, const vd &x, int lmin, int lmax) {
     if (l >= lmin && l <= lmax) p[off + l] = x.v[l];
 }
 inline void vstore_nt(double *p, long off, const vd &x, int lmin, int lmax) { vstore(p, off, x, lmin, lmax); }
+inline void vaccum(double *p, long off, const vd &x, int lmin, int lmax) {
+  for (int l = 0; l < kW; l++)
+    if (l >= lmin && l <= lmax) p[off + l] = p[off + l] + x.v[l];
+}
 // predicate: lane in [l0, l1]
 inline vb lane_mask(int l0, int l1) {
   vb r;
@@ -203,6 +207,13 @@ __device__ __forceinline__ void vstore(double *p, long off, vd x, int lmin, int 
 }
 // streaming store (global_store ... nt): for kernels that write many more rows than they re-read, so that the output
 // does not push the input rows of the neighbouring wavefronts out of L2 (measured on the fused transport: -7 %)
+// p[off + lane] += x as one read-modify-write in L2 (global_atomic_add_f64, no return value): the accumulators of the
+// flux capacitors (cx, cy, mfx, mfy) need no registers for their old value and no load.  Every element is updated by
+// exactly one lane of one wavefront, so the result is the plain IEEE sum.
+__device__ __forceinline__ void vaccum(double *p, long off, vd x, int lmin, int lmax) {
+  const int l = (int)(threadIdx.x & (kW - 1));
+  if (l >= lmin && l <= lmax) unsafeAtomicAdd(p + off + l, x);
+}
 __device__ __forceinline__ void vstore_nt(double *p, long off, vd x, int lmin, int lmax) {
   const int l = (int)(threadIdx.x & (kW - 1));
   if (l >= lmin && l <= lmax) __builtin_nontemporal_store(x, p + off + l);
