@@ -19,6 +19,7 @@ struct Tp2dShared {
   vd cx, xf, ar, rax;   // row r: crx, xfx, area, ra_x = area + xfx(i) - xfx(i+1)
   vd cy, yf;            // face r-2: cry, yfx
   vd arj, cxj, ray;     // row r-3: area, crx, ra_y = area + yfx(j) - yfx(j+1)
+  vd rrax, rray;        // RN(1/ra_x), RN(1/ra_y): the three fields divide by the same ra_x, ra_y (vdiv_r)
 };
 
 // per-field register state of one fv_tp_2d march (same pipeline as Tp2dState::step)
@@ -40,7 +41,7 @@ struct Tp2dField {
     fx2_3 = fx2_2; fx2_2 = fx2_1; fx2_1 = fx2_0;
     fx2_0 = ppm_faces_x<ORD_IN>(qn, sh.cx);
     const vd t = sh.xf * fx2_0;
-    const vd qj = (qn * sh.ar + t - shl1(t)) / sh.rax;
+    const vd qj = vdiv_r(qn * sh.ar + t - shl1(t), sh.rax, sh.rrax);
     ya.push(qn);
     yb.push(qj);
     if (!have_face) return;
@@ -50,7 +51,7 @@ struct Tp2dField {
     const vd fyv = 0.5 * (fyo + fy2);
     fyv1 = fyv;
     if (have_row) {
-      const vd qi = (ya.row_m3() * sh.arj + fy2y_prev - fy2y) / sh.ray;
+      const vd qi = vdiv_r(ya.row_m3() * sh.arj + fy2y_prev - fy2y, sh.ray, sh.rray);
       const vd fxo = ppm_faces_x<ORD_OU>(qi, sh.cxj);
       fxv = 0.5 * (fxo + fx2_3);
       fyv0 = fyv_prev;
@@ -219,6 +220,8 @@ struct DswTransportFused {
       sh.arj = UNI ? in.ar : ar_3;
       sh.cxj = (UNI && COURANT) ? cxj_uni : cx_3;
       sh.ray = sh.arj + yf_prev - sh.yf;
+      sh.rrax = vrecip(sh.rax);
+      sh.rray = vrecip(sh.ray);
       if constexpr (!UNI) { ar_3 = ar_2; ar_2 = ar_1; ar_1 = in.ar; }
       if constexpr (!(UNI && COURANT)) { cx_3 = cx_2; cx_2 = cx_1; cx_1 = sh.cx; }
       vd fxd, fyd0, fyd1, fxw, fyw0, fyw1, fxp, fyp0, fyp1;
@@ -246,13 +249,14 @@ struct DswTransportFused {
           const vd dp = fd.ya.row_m3();
           const vd dpn = dp + (fxm - shl1(fxm) + fym0 - fym1) * in.ra;
           vstore_nt(a.delp_out + oA, iA, dpn, s.lC0, s.lC1);
+          const vd rdpn = vrecip(dpn);
           {  // pt (sw_core.F90:1053-1066)
             const vd gx = fxp * fxm, gy0 = fyp0 * fym0, gy1 = fyp1 * fym1;
-            vstore_nt(a.pt_out + oA, iA, (fp.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra) / dpn, s.lC0, s.lC1);
+            vstore_nt(a.pt_out + oA, iA, vdiv_r(fp.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra, dpn, rdpn), s.lC0, s.lC1);
           }
           if (NH) {  // w (:985-989, :1262-1274)
             const vd gx = fxw * fxm, gy0 = fyw0 * fym0, gy1 = fyw1 * fym1;
-            vstore_nt(a.w_out + oA, iA, (fw.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra) / dpn, s.lC0, s.lC1);
+            vstore_nt(a.w_out + oA, iA, vdiv_r(fw.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra, dpn, rdpn), s.lC0, s.lC1);
           }
           const long iCC = (long)g.iCC(ilo, j);  // :943-948
           vstore_nt(a.heat_s + oCC, iCC, vd(0.), s.lC0, s.lC1);

@@ -55,11 +55,12 @@ FV3_D PCell ppm_cell_mono(const vd &qm2, const vd &qm1, const vd &q0, const vd &
     const vd bl0 = al0 - q0, br0 = al1 - q0;
     const vb flat = vabs(dmm) + vabs(dm0) + vabs(dmp) < near_zero;
     const vb steep = vabs(3. * (bl0 + br0)) > vabs(bl0 - br0);
+    // 0.75*(2.*d) of the reference (tp_core.F90:587,597) is 1.5*d bit for bit: 2.*d is exact, so both round 1.5*d once
     const vd pmp_2 = 2. * (q0 - qm1);
-    const vd lac_2 = pmp_2 - 0.75 * (2. * (qm1 - qm2));
+    const vd lac_2 = pmp_2 - 1.5 * (qm1 - qm2);
     const vd brl = vmin(vmax3(vd(0.), pmp_2, lac_2), vmax(br0, vmin3(vd(0.), pmp_2, lac_2)));
     const vd pmp_1 = -(2. * (qp1 - q0));
-    const vd lac_1 = pmp_1 + 0.75 * (2. * (qp2 - qp1));
+    const vd lac_1 = pmp_1 + 1.5 * (qp2 - qp1);
     const vd bll = vmin(vmax3(vd(0.), pmp_1, lac_1), vmax(bl0, vmin3(vd(0.), pmp_1, lac_1)));
     c.bl = vsel(flat, vd(0.), vsel(steep, bll, bl0));
     c.br = vsel(flat, vd(0.), vsel(steep, brl, br0));

@@ -156,6 +156,13 @@ inline void vstore(double *p, long off, const vd &x, int lmin, int lmax) {
     if (l >= lmin && l <= lmax) p[off + l] = x.v[l];
 }
 inline void vstore_nt(double *p, long off, const vd &x, int lmin, int lmax) { vstore(p, off, x, lmin, lmax); }
+// correctly rounded a / b with a shared reciprocal (see the device version); the harness just divides
+inline vd vrecip(const vd &b) {
+  vd r;
+  for (int l = 0; l < kW; l++) r.v[l] = 1. / b.v[l];
+  return r;
+}
+inline vd vdiv_r(const vd &a, const vd &b, const vd &) { return a / b; }
 inline void vaccum(double *p, long off, const vd &x, int lmin, int lmax) {
   for (int l = 0; l < kW; l++)
     if (l >= lmin && l <= lmax) p[off + l] = p[off + l] + x.v[l];
@@ -207,6 +214,24 @@ __device__ __forceinline__ void vstore(double *p, long off, vd x, int lmin, int 
 }
 // streaming store (global_store ... nt): for kernels that write many more rows than they re-read, so that the output
 // does not push the input rows of the neighbouring wavefronts out of L2 (measured on the fused transport: -7 %)
+// Division by a denominator that several numerators share (ra_x, ra_y, the new delp of a cell): y = RN(1/b) once
+// (v_rcp_f64 + two Newton steps, the sequence the compiler's own fdiv expansion uses), then per numerator
+// q0 = RN(a*y), r = a - b*q0 (exact in an fma), q = RN(q0 + r*y).  With y correctly rounded q is the correctly rounded
+// quotient (Markstein 1990) -- the IEEE result of a / b for operands in the normal range (no v_div_scale / v_div_fixup
+// rescue here: the operands are areas, pressure thicknesses and tracer masses) -- at 3 instructions per numerator instead
+// of 11.
+__device__ __forceinline__ vd vrecip(vd b) {
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ vd vdiv_r(vd a, vd b, vd y) {
+  const double q0 = a * y;
+  const double r = __builtin_fma(-b, q0, a);
+  return __builtin_fma(r, y, q0);
+}
 // p[off + lane] += x as one read-modify-write in L2 (global_atomic_add_f64, no return value): the accumulators of the
 // flux capacitors (cx, cy, mfx, mfy) need no registers for their old value and no load.  Every element is updated by
 // exactly one lane of one wavefront, so the result is the plain IEEE sum.
