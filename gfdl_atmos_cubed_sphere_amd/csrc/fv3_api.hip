@@ -243,8 +243,8 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     c->march_tj_ke = e ? std::atoi(e) : 48;
     if (c->march_tj_ke < 1) c->march_tj_ke = 48;
     e = std::getenv("FV3_MI355X_MARCH_TJ_CSW");
-    c->march_tj_csw = e ? std::atoi(e) : 64;
-    if (c->march_tj_csw < 1) c->march_tj_csw = 64;
+    c->march_tj_csw = e ? std::atoi(e) : 0;   // 0 = by geometry mode (fv3_c_sw)
+    if (c->march_tj_csw < 0) c->march_tj_csw = 0;
   }
   c->dp0 = nullptr; c->edge_dev = nullptr; c->dp0_ready = false;
   c->akbk = nullptr; c->kord_tr_dev = nullptr; c->akbk_ready = false;
@@ -578,7 +578,10 @@ extern "C" int fv3_c_sw(fv3_ctx *c, double *delpc, const double *delp, double *p
   if (!hydrostatic && (!w || !wc)) return fail("fv3_c_sw: nonhydrostatic call needs w and wc");
   if (c->use_march) {
     const CswArgs ca{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2};
-    MarchDims md = make_csw_dims(c->g, seg_rows(c, c->march_tj_csw, c->g.npz));
+    // rows per segment: 64 for the two-levels-per-wavefront kernel (one wavefront per SIMD); the uniform-metric kernel
+    // (one level per wavefront, four per SIMD, bandwidth-bound) does better with many short segments (measured 16-40: 24)
+    const int tj_csw = c->march_tj_csw ? c->march_tj_csw : (c->g.geom == 2 ? 24 : 64);
+    MarchDims md = make_csw_dims(c->g, seg_rows(c, tj_csw, c->g.npz));
     // uniform metrics: nothing to share between levels, one level per wavefront at four wavefronts per SIMD is faster
     const int kpw = c->csw_kpw ? c->csw_kpw : (c->g.geom == 2 ? 1 : 2);
     const int nkg = (c->g.npz + kpw - 1) / kpw;
