@@ -78,11 +78,11 @@ struct DswTransportFused {
     vd dp, w, pt;          // row r
     vd ar, cx, xf;         // row r (COURANT: cx = uc row, xf unused)
     vd cy, yf;             // face r-2 (COURANT: cy = vc row)
-    vd xfj, mx, my0, ra;   // row r-3: xfx, mfx, mfy, rarea
+    vd xfj, ra;            // row r-3: xfx, rarea (mfx, mfy, cx, cy are accumulated in L2: vaccum)
     vd ucj;                // UNI + COURANT: uc of row r-3
     // COURANT only: metric rows and the accumulators
-    vd rdxa, dyr, sg3, sg1, cxa;       // row r: rdxa, dy, sin_sg(.,3), sin_sg(.,1); cx
-    vd rdya0, rdya1, dxr, sg4, sg2, cya;  // face r-2: rdya(j-1), rdya(j), dx, sin_sg(j-1,4), sin_sg(j,2); cy
+    vd rdxa, dyr, sg3, sg1;            // row r: rdxa, dy, sin_sg(.,3), sin_sg(.,1)
+    vd rdya0, rdya1, dxr, sg4, sg2;       // face r-2: rdya(j-1), rdya(j), dx, sin_sg(j-1,4), sin_sg(j,2)
   };
 
   FV3_D void operator()(int gid) const {
@@ -95,7 +95,6 @@ struct DswTransportFused {
     const int jB = (jA + md.tj - 1 < g.je) ? jA + md.tj - 1 : g.je;
     const int rlast = jB + 3;
     const int lFx1 = (ilo + s.lC1 == g.ie) ? s.lC1 + 1 : s.lC1;
-    const vl Fx = make_lanes(s.lC0, lFx1);
     const size_t oA = (size_t)k * g.nA(), oCX = (size_t)k * g.nCX(), oCY = (size_t)k * g.nCY();
     const size_t oFX = (size_t)k * g.nFX(), oFY = (size_t)k * g.nFY(), oCC = (size_t)k * g.nCC();
     const double *delp = a.delp + oA, *pt = a.pt + oA, *w = NH ? a.w + oA : nullptr;
@@ -120,10 +119,8 @@ struct DswTransportFused {
       if (COURANT) {
         const long nAp = (long)g.nA();
         in.cx = vload(a.uc + (size_t)k * g.nV(), (long)g.iV(ilo, r), s.A);
-        if constexpr (!UNI) in.cxa = vload(a.cx + oCX, iCX, s.F);
         const long iAf = (long)g.iA(ilo, jf), iAm = (long)g.iA(ilo, jf - 1), iUf = (long)g.iU(ilo, jf);
         in.cy = vload(a.vc + (size_t)k * g.nU(), iUf, s.A);
-        if constexpr (!UNI) in.cya = vload(a.cy + oCY, iCY, s.A);
         if constexpr (!UNI) {
           in.rdxa = vload(g.rdxa, iA, s.A);
           in.dyr = vload(g.dy, (long)g.iV(ilo, r), s.A);
@@ -142,10 +139,7 @@ struct DswTransportFused {
         in.yf = vload(yfx, iCY, s.A);
         in.xfj = vload(xfx, (long)g.iCX(ilo, j), s.F);
       }
-      if constexpr (!UNI) {
-        in.mx = vload(mfx, (long)g.iFX(ilo, j), Fx);
-        in.my0 = vload(mfy, (long)g.iFY(ilo, j), s.C);
-      } else if (COURANT) {
+      if constexpr (UNI && COURANT) {
         in.ucj = vload(a.uc + (size_t)k * g.nV(), (long)g.iV(ilo, j), s.A);  // uc of row r-3: its crx, xfx are re-formed
       }
       in.ra = UNI ? vd(g.c_rarea) : vload(g.rarea, (long)g.iA(ilo, j), s.C);
@@ -182,8 +176,7 @@ struct DswTransportFused {
           const long iCX = (long)g.iCX(ilo, r);
           vstore_nt(crx, iCX, sh.cx, s.lC0, lFx1);
           vstore_nt(xfx, iCX, sh.xf, s.lC0, lFx1);
-          if constexpr (UNI) vaccum(a.cx + oCX, iCX, sh.cx, s.lC0, lFx1);
-          else vstore_nt(a.cx + oCX, iCX, in.cxa + sh.cx, s.lC0, lFx1);
+          vaccum(a.cx + oCX, iCX, sh.cx, s.lC0, lFx1);
         }
         // y faces of row r-2 (:894-900, :933-936)
         const vd y = dt * in.cy;
@@ -200,8 +193,7 @@ struct DswTransportFused {
           const long iCY = (long)g.iCY(ilo, jf);
           vstore_nt(cry, iCY, sh.cy, lY0, lY1);
           vstore_nt(yfx, iCY, sh.yf, lY0, lY1);
-          if constexpr (UNI) vaccum(a.cy + oCY, iCY, sh.cy, lY0, lY1);
-          else vstore_nt(a.cy + oCY, iCY, in.cya + sh.cy, lY0, lY1);
+          vaccum(a.cy + oCY, iCY, sh.cy, lY0, lY1);
         }
         if constexpr (UNI) {  // crx, xfx of row r-3 from its uc again (same expressions as at step r-3): no 3-row windows
           const vd xj = dt * in.ucj;
@@ -235,13 +227,8 @@ struct DswTransportFused {
           const vd fxm = fxd * xfj;  // tp_core.F90:217-221
           const vd fym0 = fym_prev, fym1 = fym;
           const long iFX = (long)g.iFX(ilo, j), iFY0 = (long)g.iFY(ilo, j), iA = (long)g.iA(ilo, j);
-          if constexpr (UNI) {
-            vaccum(mfx, iFX, fxm, s.lC0, lFx1);            // sw_core.F90:928-940
-            vaccum(mfy, iFY0, fym0, s.lC0, s.lC1);
-          } else {
-            vstore_nt(mfx, iFX, in.mx + fxm, s.lC0, lFx1);
-            vstore_nt(mfy, iFY0, in.my0 + fym0, s.lC0, s.lC1);
-          }
+          vaccum(mfx, iFX, fxm, s.lC0, lFx1);            // sw_core.F90:928-940
+          vaccum(mfy, iFY0, fym0, s.lC0, s.lC1);
           if (j == g.je) {
             const long iFY1 = (long)g.iFY(ilo, j + 1);
             vstore_nt(mfy, iFY1, vload(mfy, iFY1, s.C) + fym1, s.lC0, s.lC1);
