@@ -153,7 +153,8 @@ struct Tp2dState {
     cx_3 = cx_2; cx_2 = cx_1; cx_1 = in.cx;
     fx2_0 = ppm_faces_x<ORD_IN>(in.qn, in.cx);
     const vd t = in.xf * fx2_0;
-    const vd qj = (in.qn * in.ar + t - shl1(t)) / (in.ar + in.xf - shl1(in.xf));
+    const vd rax = in.ar + in.xf - shl1(in.xf);
+    const vd qj = vdiv_r(in.qn * in.ar + t - shl1(t), rax, vrecip(rax));  // correctly rounded, 8 instructions instead of 11
     ya.push(in.qn);
     yb.push(qj);
     if (!have_face) return;
@@ -164,7 +165,8 @@ struct Tp2dState {
     const vd fyv = 0.5 * (fyo + fy2);
     // ---- row j = r-3: q_i and the outer x sweep ---------------------------------------------------------
     if (have_row) {
-      const vd qi = (ya.row_m3() * arj + fy2y_prev - fy2y) / (arj + yf_prev - in.yf);
+      const vd ray = arj + yf_prev - in.yf;
+      const vd qi = vdiv_r(ya.row_m3() * arj + fy2y_prev - fy2y, ray, vrecip(ray));
       const vd fxo = ppm_faces_x<ORD_OU>(qi, cxj);
       fxv = 0.5 * (fxo + fx2_3);
       fyv0 = fyv_prev;
