@@ -453,3 +453,11 @@ def test_fv_dynamics_call_moist(prod, moist_kappa):
 def test_remap_fillz(prod, nq):
     """flagstruct%fill: fillz (fv_fill.F90:34-137) on the remapped tracers, both tracer remap forms (nq <= 5, nq > 5)"""
     R.check_remap(prod, nq=nq, fill=True)
+
+
+def test_baseline_config2_tile_shape(prod):
+    """one 96 x 96 x 79 tile (the face size of BASELINE configs[1], C96L79, hydrostatic) on a Cartesian and on a general
+    gridstruct: c_sw and d_sw against the oracle"""
+    for perturb in (False, True):
+        P.check_c_sw(prod, nx=96, ny=96, npz=79, hydrostatic=True, perturb=perturb)
+        P.check_d_sw(prod, nx=96, ny=96, npz=79, hydrostatic=True, perturb=perturb)
