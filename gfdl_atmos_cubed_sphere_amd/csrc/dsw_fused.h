@@ -423,3 +423,119 @@ struct DswMomentumFused {
 };
 
 }  // namespace fv3
+
+// =====================================================================================================
+// TracerMarchFused: one sub-cycle of tracer_2d (fv_tracer2d.F90:471-541, trdm <= 1e-4) for NT tracers of one level per
+// wavefront.  TracerMarch (dsw_march.h) runs one (tracer, level) per wavefront and re-reads dp1, mfx, mfy, crx, cry, xfx,
+// yfx, area, rarea for every tracer: 92 B per cell and tracer measured against 16 + 64/nq algorithmic.  Here the NT marches
+// share those rows (and the reciprocals of ra_x, ra_y, dp2), so a tracer costs its own row in and out.
+namespace fv3 {
+
+template <int HORD, int NT>
+struct TracerMarchFused {
+  Grid g;
+  MarchDims md;
+  int npz, nq, it, nsplt, ngrp;  // ngrp = ceil(nq / NT) tracer groups
+  const int *ksplt;              // device, npz
+  const double *q, *dp1, *mfx, *mfy, *cx, *cy, *xfx, *yfx;
+  double *q_out, *dp1_out;
+
+  template <int NL>
+  struct In {
+    vd q[NL];              // row r of each tracer
+    vd ar, cx, xf;         // row r: area, crx, xfx
+    vd cy, yf;             // face r-2
+    vd cxj, d1, ra, mx, my0, my1;  // row j = r-3: crx, dp1, rarea, mfx, mfy(j), mfy(j+1)
+  };
+
+  FV3_D void operator()(int gid) const {
+    int strip, seg, kq;
+    md.decode(gid, strip, seg, kq);
+    const int k = kq % npz, grp = kq / npz;
+    // the nq tracers are dealt evenly to the ngrp groups (4 tracers: 2 + 2, not 3 + 1 -- a one-tracer march at the
+    // occupancy of this kernel is slow); a group runs the march instantiated for its size
+    const int base = nq / ngrp, rem = nq % ngrp;
+    const int nl = base + (grp < rem ? 1 : 0), iq0 = grp * base + (grp < rem ? grp : rem);
+    if (nl == NT) { run<NT>(strip, seg, k, grp, iq0); return; }
+    if constexpr (NT > 1) if (nl == 1) { run<1>(strip, seg, k, grp, iq0); return; }
+    if constexpr (NT > 2) if (nl == 2) { run<2>(strip, seg, k, grp, iq0); return; }
+    if constexpr (NT > 3) if (nl == 3) { run<3>(strip, seg, k, grp, iq0); return; }
+  }
+
+  template <int NL>
+  FV3_D void run(int strip, int seg, int k, int grp, int iq0) const {
+    const StripGeom s = make_strip(g, strip);
+    const int ilo = s.ilo;
+    const int jA = g.js + seg * md.tj;
+    const int jB = (jA + md.tj - 1 < g.je) ? jA + md.tj - 1 : g.je;
+    const int rlast = jB + 3;
+    const size_t oA = (size_t)k * g.nA(), oCX = (size_t)k * g.nCX(), oCY = (size_t)k * g.nCY();
+    auto qoff = [&](int t) { return ((size_t)(iq0 + t) * npz + k) * g.nA(); };
+    const bool write_dp = (grp == ngrp - 1) && it != nsplt;   // as TracerMarch: the last tracer's wavefront carries dp1
+    if (it > ksplt[k]) {  // the level is finished: carry q (and dp1) over to the output buffers
+      for (int j = jA; j <= jB; j++) {
+        const long iA = (long)g.iA(ilo, j);
+        for (int t = 0; t < NL; t++) vstore(q_out + qoff(t), iA, vload(q + qoff(t), iA, s.A), s.lC0, s.lC1);
+        if (write_dp) vstore(dp1_out + oA, iA, vload(dp1 + oA, iA, s.A), s.lC0, s.lC1);
+      }
+      return;
+    }
+    auto load_in = [&](int r) {
+      In<NL> in;
+      const long iA = (long)g.iA(ilo, r), iCX = (long)g.iCX(ilo, r);
+      for (int t = 0; t < NL; t++) in.q[t] = vload(q + qoff(t), iA, s.A);
+      in.ar = g.geom == 2 ? vd(g.c_area) : vload(g.area, iA, s.A);
+      in.cx = vload(cx + oCX, iCX, s.F);
+      in.xf = vload(xfx + oCX, iCX, s.F);
+      const int jf = (r - 2 < jA) ? jA : r - 2, j = (r - 3 < jA) ? jA : r - 3;
+      const long iCY = (long)g.iCY(ilo, jf);
+      in.cy = vload(cy + oCY, iCY, s.A);
+      in.yf = vload(yfx + oCY, iCY, s.A);
+      const long iAj = (long)g.iA(ilo, j);
+      in.cxj = vload(cx + oCX, (long)g.iCX(ilo, j), s.F);
+      in.d1 = vload(dp1 + oA, iAj, s.A);
+      in.ra = g.geom == 2 ? vd(g.c_rarea) : vload(g.rarea, iAj, s.A);
+      in.mx = vload(mfx + (size_t)k * g.nFX(), (long)g.iFX(ilo, j), s.F);
+      in.my0 = vload(mfy + (size_t)k * g.nFY(), (long)g.iFY(ilo, j), s.C);
+      in.my1 = vload(mfy + (size_t)k * g.nFY(), (long)g.iFY(ilo, j + 1), s.C);
+      return in;
+    };
+
+    Tp2dField<HORD> fd[NL];
+    for (int t = 0; t < NL; t++) fd[t].init();
+    vd ar_1(1.), ar_2(1.), ar_3(1.);  // area of rows r-1 .. r-3
+    vd yf_prev(0.);
+    In<NL> nxt = load_in(jA - 3);
+    for (int r = jA - 3; r <= rlast; r++) {
+      const In<NL> in = nxt;
+      nxt = load_in(r < rlast ? r + 1 : rlast);
+      const int j = r - 3;
+      const bool have_face = r - 2 >= jA, have_row = j >= jA;
+      Tp2dShared sh;
+      sh.cx = in.cx; sh.xf = in.xf; sh.cy = in.cy; sh.yf = in.yf;
+      sh.ar = in.ar;
+      sh.rax = in.ar + sh.xf - shl1(sh.xf);
+      sh.arj = ar_3; sh.cxj = in.cxj;
+      sh.ray = sh.arj + yf_prev - sh.yf;
+      sh.rrax = vrecip(sh.rax);
+      sh.rray = vrecip(sh.ray);
+      ar_3 = ar_2; ar_2 = ar_1; ar_1 = in.ar;
+      vd fx[NL], fy0[NL], fy1[NL];
+      for (int t = 0; t < NL; t++) fd[t].step(in.q[t], sh, have_face, have_row, fx[t], fy0[t], fy1[t]);
+      if (have_face && have_row) {
+        const long iA = (long)g.iA(ilo, j);
+        const vd dp2 = in.d1 + (in.mx - shl1(in.mx) + in.my0 - in.my1) * in.ra;                 // :517-522
+        const vd rdp2 = vrecip(dp2);
+        for (int t = 0; t < NL; t++) {
+          const vd gx = fx[t] * in.mx, gy0 = fy0[t] * in.my0, gy1 = fy1[t] * in.my1;
+          const vd qn = vdiv_r(fd[t].ya.row_m3() * in.d1 + (gx - shl1(gx) + gy0 - gy1) * in.ra, dp2, rdp2);  // :523-531
+          vstore(q_out + qoff(t), iA, qn, s.lC0, s.lC1);
+        }
+        if (write_dp) vstore(dp1_out + oA, iA, dp2, s.lC0, s.lC1);
+      }
+      if (have_face) yf_prev = sh.yf;
+    }
+  }
+};
+
+}  // namespace fv3

@@ -81,6 +81,7 @@ struct fv3_ctx {
   double *mflux[2];      // mass-flux scratch of the marching transports: FX kind, FY kind (npz levels)
   int march_tj;          // rows per wavefront segment of the marching kernels
   int march_tj_csw, march_tj_ke, march_tj_fused, march_tj_mom;
+  int trc_nt;  // tracers per wavefront in the sub-cycle kernel (FV3_MI355X_TRACER_NT: 1..4, default 3)
   int tj_fixed;          // an FV3_MI355X_MARCH_TJ* variable is set: take the rows per segment as given
   int csw_kpw;           // levels per wavefront in CswMarch (1 .. 4; FV3_MI355X_CSW_KPW)
   int use_fused;         // 1: delp + w + pt in one marching kernel when the schemes allow (FV3_MI355X_FUSED=0: off)
@@ -239,6 +240,9 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_MARCH_TJ_MOM");
     c->march_tj_mom = e ? std::atoi(e) : c->march_tj_fused;
     if (c->march_tj_mom < 1) c->march_tj_mom = c->march_tj_fused;
+    e = std::getenv("FV3_MI355X_TRACER_NT");
+    c->trc_nt = e ? std::atoi(e) : 3;
+    if (c->trc_nt < 1 || c->trc_nt > 4) c->trc_nt = 3;
     e = std::getenv("FV3_MI355X_MARCH_TJ_KE");
     c->march_tj_ke = e ? std::atoi(e) : 48;
     if (c->march_tj_ke < 1) c->march_tj_ke = 48;
@@ -1616,6 +1620,24 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
     RT(rt_sync(c->stream));
   }
   if (c->use_march && !(it == 1 && trdm > 1.e-4)) {
+    const int trc_nt = c->trc_nt;   // tracers per wavefront (1: one (tracer, level) per wavefront, TracerMarch)
+    if (trc_nt > 1 && nq > 1) {
+      auto go = [&](auto H, auto NTc) -> int {
+        constexpr int NT = decltype(NTc)::value;
+        const int ngrp = (nq + NT - 1) / NT;
+        MarchDims md = make_march_dims(g, seg_rows(c, c->march_tj_fused, g.npz * ngrp));
+        const int nwt = md.nwaves(g.npz * ngrp);
+        TracerMarchFused<decltype(H)::value, NT> kf{g, md, g.npz, nq, it, nsplt, ngrp, c->trc_i, q, dp1, mfx, mfy, cx,
+                                                    cy, xfx, yfx, q_out, dp1_out};
+        return launch_w(c, "tracer_step", nwt, kf);
+      };
+      return dispatch_hord(hord, [&](auto H) {
+        const int nt = nq < trc_nt ? nq : trc_nt;
+        if (nt == 4) return go(H, std::integral_constant<int, 4>{});
+        if (nt == 3) return go(H, std::integral_constant<int, 3>{});
+        return go(H, std::integral_constant<int, 2>{});
+      });
+    }
     MarchDims md = make_march_dims(g, seg_rows(c, c->march_tj, g.npz));
     const int nwt = md.nwaves(g.npz * nq);
     return dispatch_hord(hord, [&](auto H) {

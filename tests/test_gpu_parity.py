@@ -190,6 +190,15 @@ def test_tracer_2d(prod):
     T.check_tracer_2d(prod, nx=96, ny=96, npz=16, nq=4)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nt", [1, 2, 3, 4])
+def test_tracer_2d_tracers_per_wavefront(prod, nt, monkeypatch):
+    """the sub-cycle kernel with 1..4 tracers per wavefront (short last group, finished levels, sub-cycling)"""
+    monkeypatch.setenv("FV3_MI355X_TRACER_NT", str(nt))
+    T.check_tracer_2d(prod, nx=70, ny=21, npz=3, nq=5, big_courant=True)
+    T.check_tracer_2d(prod, nx=96, ny=96, npz=16, nq=7, hord=10)
+
+
 def test_torch_alias_of_device_array_and_exchange_path(prod):
     """The multi-GPU halo path aliases library-owned buffers as torch tensors (__cuda_array_interface__) and
     packs/unpacks with strided torch ops: check the alias is zero-copy, Fortran-strided and coherent with the

@@ -159,6 +159,14 @@ def test_tracer_2d(emu):
     T.check_tracer_2d(emu, nx=33, ny=9, npz=7, nq=7, big_courant=True)
 
 
+@pytest.mark.parametrize("nt", [1, 2, 3, 4])
+def test_tracer_2d_tracers_per_wavefront(emu, nt, monkeypatch):
+    """the sub-cycle kernel with 1..4 tracers per wavefront (short last group, finished levels, sub-cycling)"""
+    monkeypatch.setenv("FV3_MI355X_TRACER_NT", str(nt))
+    T.check_tracer_2d(emu, nx=70, ny=21, npz=3, nq=5, big_courant=True)
+    T.check_tracer_2d(emu, nq=4, hord=10)
+
+
 @pytest.mark.parametrize("nq,k_split", [(2, 2), (0, 1)])
 def test_fv_dynamics_step(emu, nq, k_split):
     import parity_dyn as D
