@@ -126,14 +126,14 @@ static int launch_p(fv3_ctx *c, const char *label, Dim3 grid, size_t lds_doubles
   return rc;
 }
 
-template <class F>
+template <int W = 0, class F>
 static int launch_c(fv3_ctx *c, const char *label, Dim3 grid, const F &f) {
   void *e0 = nullptr, *e1 = nullptr;
   if (c->prof_on) {
     if (rt_event_create(&e0) || rt_event_create(&e1)) return 1;
     rt_event_record(e0, c->stream);
   }
-  int rc = launch_cols(grid, c->stream, f);
+  int rc = launch_cols<W>(grid, c->stream, f);
   if (c->prof_on) {
     rt_event_record(e1, c->stream);
     c->prof.push_back({label, e0, e1});
@@ -1541,7 +1541,10 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
                      co, co + slab, co + 2 * slab, co + 3 * slab, co + 4 * slab, co + 5 * slab, co + 6 * slab,
                      co + 7 * slab, sets, slab, t0, nblk};
       Dim3 gr = col_grid(256 * nblk * nt);
-      RT(launch_c(c, "remap_fields", gr, kf));
+      // 248 VGPRs unconstrained (2 wavefronts per SIMD); under the budget of 4 (128 VGPRs, 96 spilled) the k-sequential,
+      // latency-bound kernel is 27 % faster (measured: 3 -> 12.6 ms per dt_atmos, 4 -> 11.9, 5 -> 12.5, 6 -> 13.4, 8 -> 15.4,
+      // unconstrained 16.4); the Riemann solvers and RemapDelzFinal lose under tighter budgets (spills in their sweeps)
+      RT(launch_c<4>(c, "remap_fields", gr, kf));
       t0 += nt;
     }
   }

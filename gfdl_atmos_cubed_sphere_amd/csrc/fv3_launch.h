@@ -30,7 +30,7 @@ inline int launch(Dim3 grid, size_t lds_doubles, stream_t, const F &f) {
   return 0;
 }
 // column kernels (one thread per column)
-template <class F>
+template <int W = 0, class F>
 inline int launch_cols(Dim3 grid, stream_t s, const F &f) { return launch(grid, 0, s, f); }
 // wave functors: one call per wavefront, the functor's vd values are 64-lane arrays (spmd.h)
 template <class F>
@@ -122,10 +122,21 @@ inline int col_lanes() {
   }();
   return v;
 }
-template <class F>
+// the same under a register budget of W wavefronts per SIMD (512 / W VGPRs): the column kernels wait on memory in a loop
+// that is sequential in k, so for some of them more wavefronts in flight are worth a few spilled registers
+template <class F, int W>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) col_kernel_w(const F f, int lanes) {
+  if ((int)threadIdx.x >= lanes) return;
+  const int vt = (int)blockIdx.x * lanes + (int)threadIdx.x;
+  f(vt >> 8, 0, 0, vt & 255, nullptr);
+}
+template <int W = 0, class F>
 inline int launch_cols(Dim3 grid, stream_t s, const F &f) {
   const int lanes = col_lanes();
-  hipLaunchKernelGGL(col_kernel<F>, dim3(grid.x * (256 / lanes)), dim3(64), 0, s, f, lanes);
+  if constexpr (W > 0)
+    hipLaunchKernelGGL((col_kernel_w<F, W>), dim3(grid.x * (256 / lanes)), dim3(64), 0, s, f, lanes);
+  else
+    hipLaunchKernelGGL(col_kernel<F>, dim3(grid.x * (256 / lanes)), dim3(64), 0, s, f, lanes);
   return (int)hipGetLastError();
 }
 // wave functors (spmd.h): independent wavefronts, 4 per workgroup, no LDS, no barriers.
