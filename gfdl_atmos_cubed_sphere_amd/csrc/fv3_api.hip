@@ -82,6 +82,8 @@ struct fv3_ctx {
   int march_tj;          // rows per wavefront segment of the marching kernels
   int march_tj_csw, march_tj_ke, march_tj_fused, march_tj_mom;
   int trc_nt;  // tracers per wavefront in the sub-cycle kernel (FV3_MI355X_TRACER_NT: 1..4, default 3)
+  int remap_nt;  // tracers per thread in the remap (FV3_MI355X_REMAP_NT: 1..3, default 3)
+  int remap_blocked;  // scratch slabs of the remap in per-wavefront blocks (FV3_MI355X_REMAP_SCR: 0 / 1, default 1)
   int tj_fixed;          // an FV3_MI355X_MARCH_TJ* variable is set: take the rows per segment as given
   int csw_kpw;           // levels per wavefront in CswMarch (1 .. 4; FV3_MI355X_CSW_KPW)
   int use_fused;         // 1: delp + w + pt in one marching kernel when the schemes allow (FV3_MI355X_FUSED=0: off)
@@ -127,13 +129,13 @@ static int launch_p(fv3_ctx *c, const char *label, Dim3 grid, size_t lds_doubles
 }
 
 template <int W = 0, class F>
-static int launch_c(fv3_ctx *c, const char *label, Dim3 grid, const F &f) {
+static int launch_c(fv3_ctx *c, const char *label, Dim3 grid, const F &f, int lanes = 0) {
   void *e0 = nullptr, *e1 = nullptr;
   if (c->prof_on) {
     if (rt_event_create(&e0) || rt_event_create(&e1)) return 1;
     rt_event_record(e0, c->stream);
   }
-  int rc = launch_cols<W>(grid, c->stream, f);
+  int rc = launch_cols<W>(grid, c->stream, f, lanes);
   if (c->prof_on) {
     rt_event_record(e1, c->stream);
     c->prof.push_back({label, e0, e1});
@@ -243,6 +245,11 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_TRACER_NT");
     c->trc_nt = e ? std::atoi(e) : 3;
     if (c->trc_nt < 1 || c->trc_nt > 4) c->trc_nt = 3;
+    e = std::getenv("FV3_MI355X_REMAP_NT");
+    c->remap_nt = e ? std::atoi(e) : 3;
+    if (c->remap_nt < 1 || c->remap_nt > RemapFields::kGroupMax) c->remap_nt = 3;
+    e = std::getenv("FV3_MI355X_REMAP_SCR");
+    c->remap_blocked = e ? (std::atoi(e) != 0) : 1;
     e = std::getenv("FV3_MI355X_MARCH_TJ_KE");
     c->march_tj_ke = e ? std::atoi(e) : 48;
     if (c->march_tj_ke < 1) c->march_tj_ke = 48;
@@ -1492,7 +1499,7 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   }
   RemapPar rp{p->last_step, p->hydrostatic, p->adiabatic, p->nq, p->kord_mt, p->kord_wz, p->kord_tm, p->sphum,
               p->akap, p->ptop, p->rdgas, p->grav, p->cv_air, p->r_vir, p->cp, p->t_min,
-              0, 0, 0, 0, 0, 0, 0, 0, 0., 0., 0., nullptr, nullptr, p->fill};
+              0, 0, 0, 0, 0, 0, 0, 0, 0., 0., 0., nullptr, nullptr, p->fill, c->remap_blocked};
   const bool moist = c->moist_on && (c->moist.moist_kappa || c->moist.use_cond);
   if (moist) {
     const fv3_moist_params &m = c->moist;
@@ -1510,13 +1517,17 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
     rp.q_con = c->moist_qcon; rp.cappa = c->moist_cappa;
   }
   const double *ak = c->akbk, *bk = c->akbk + (km + 1);
-  // field tasks: T_v, nq tracers, w (nonhydrostatic), u, v -- at most kRemapSets of them per launch, each with its own six
-  // profile slabs; eight coordinate slabs (p, log p, and the face-averaged p of u and of v) in front of them
-  constexpr int kRemapSets = 8;
-  const int ntask = 1 + p->nq + (p->hydrostatic ? 0 : 1) + 2;
+  // field tasks: T_v, w (nonhydrostatic), u, v, tracer groups -- at most kRemapSets of them per launch, each with its own
+  // seven profile slabs; eight coordinate slabs (p, log p, and the face-averaged p of u and of v) in front of them
+  // the tracers run in groups of up to c->remap_nt per thread (remap_tracers_col), dealt evenly
+  constexpr int kRemapSets = 7, kSetSlabs = RemapFields::kSetSlabs;
+  const int ngrp = p->nq > 0 ? (p->nq + c->remap_nt - 1) / c->remap_nt : 0;
+  const int ntask = 1 + ngrp + (p->hydrostatic ? 0 : 1) + 2;
   const int nsets = ntask < kRemapSets ? ntask : kRemapSets;
-  const size_t slab = g.nA() * (size_t)(km + 1);
-  const size_t need = slab * (size_t)(8 + 6 * nsets);
+  // a slab holds km+1 levels of every column a task may own (u, v: (nx+1) x (ny+1), in blocks of 64: scr_col)
+  const size_t ncol_max = (((size_t)(g.nx + 1) * (g.ny + 1) + 63) / 64) * 64;
+  const size_t slab = (g.nA() > ncol_max ? g.nA() : ncol_max) * (size_t)(km + 1);
+  const size_t need = slab * (size_t)(8 + kSetSlabs * nsets);
   if (c->remap_scr_n < need) {
     if (c->remap_scr) rt_free(c->remap_scr);
     c->remap_scr = nullptr;
@@ -1539,7 +1550,7 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
       if (rp.moist_kappa && t0 < n_head && t0 + nt > n_head) nt = n_head - t0;
       RemapFields kf{g, km, rp, ak, bk, c->kord_tr_dev, delp, pk, delz, peln, pe, ws, w, pt, q, omga, u, v,
                      co, co + slab, co + 2 * slab, co + 3 * slab, co + 4 * slab, co + 5 * slab, co + 6 * slab,
-                     co + 7 * slab, sets, slab, t0, nblk};
+                     co + 7 * slab, sets, slab, t0, nblk, ngrp > 0 ? ngrp : 1};
       Dim3 gr = col_grid(256 * nblk * nt);
       // 248 VGPRs unconstrained (2 wavefronts per SIMD); under the budget of 4 (128 VGPRs, 96 spilled) the k-sequential,
       // latency-bound kernel is 27 % faster (measured: 3 -> 12.6 ms per dt_atmos, 4 -> 11.9, 5 -> 12.5, 6 -> 13.4, 8 -> 15.4,

@@ -31,7 +31,7 @@ inline int launch(Dim3 grid, size_t lds_doubles, stream_t, const F &f) {
 }
 // column kernels (one thread per column)
 template <int W = 0, class F>
-inline int launch_cols(Dim3 grid, stream_t s, const F &f) { return launch(grid, 0, s, f); }
+inline int launch_cols(Dim3 grid, stream_t s, const F &f, int = 0) { return launch(grid, 0, s, f); }
 // wave functors: one call per wavefront, the functor's vd values are 64-lane arrays (spmd.h)
 template <class F>
 inline int launch_waves(int nwaves, stream_t, const F &f) {
@@ -130,13 +130,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W)))
   const int vt = (int)blockIdx.x * lanes + (int)threadIdx.x;
   f(vt >> 8, 0, 0, vt & 255, nullptr);
 }
+// lanes_req > 0: columns per wavefront of this launch (any value <= 64; the default is col_lanes())
 template <int W = 0, class F>
-inline int launch_cols(Dim3 grid, stream_t s, const F &f) {
-  const int lanes = col_lanes();
+inline int launch_cols(Dim3 grid, stream_t s, const F &f, int lanes_req = 0) {
+  const int lanes = (lanes_req > 0 && lanes_req <= 64) ? lanes_req : col_lanes();
+  const unsigned nb = (unsigned)(((size_t)grid.x * 256 + lanes - 1) / lanes);
   if constexpr (W > 0)
-    hipLaunchKernelGGL((col_kernel_w<F, W>), dim3(grid.x * (256 / lanes)), dim3(64), 0, s, f, lanes);
+    hipLaunchKernelGGL((col_kernel_w<F, W>), dim3(nb), dim3(64), 0, s, f, lanes);
   else
-    hipLaunchKernelGGL(col_kernel<F>, dim3(grid.x * (256 / lanes)), dim3(64), 0, s, f, lanes);
+    hipLaunchKernelGGL(col_kernel<F>, dim3(nb), dim3(64), 0, s, f, lanes);
   return (int)hipGetLastError();
 }
 // wave functors (spmd.h): independent wavefronts, 4 per workgroup, no LDS, no barriers.

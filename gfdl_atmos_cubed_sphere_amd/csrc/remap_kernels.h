@@ -21,6 +21,18 @@ struct ColScr {
   int o;                                             // column offset inside a slab
 };
 #define CS(p, k) (c.p)[(size_t)((k)-1) * c.ls + c.o]
+// where column `col` of a kernel keeps its scratch levels.  blocked: the 64 columns of a wavefront are one contiguous
+// (km+1) x 64 block per slab, so the k loop of a wavefront walks through 64 KB of consecutive addresses instead of
+// touching one 512-byte piece in each of km+1 planes megabytes apart; otherwise the slabs have the layout of the fields.
+FV3_HD void scr_col(ColScr &c, int col, int fo, int km, size_t nA, int blocked) {
+  if (blocked) {
+    c.ls = 64;
+    c.o = (col >> 6) * 64 * (km + 1) + (col & 63);
+  } else {
+    c.ls = nA;
+    c.o = fo;
+  }
+}
 
 FV3_HD bool kord_supported(int kord) {
   const int a = kord < 0 ? -kord : kord;
@@ -487,6 +499,217 @@ FV3_HD void map_col(const ColScr &c, int km, bool tracer_form, const ProfCfg &pc
   }
 }
 
+// ---- several tracers of one column side by side -------------------------------------------------------------------
+// The elimination coefficients of the spline (grat, bet, gam), the search of the mapping loop and its fractional
+// positions depend on the coordinates only: a group of NT tracers forms them once (one reciprocal per divisor, the
+// quotients through it -- correctly rounded, see spmd.h vrecip / vdiv_r) and runs NT recurrences / limiters / integrals
+// on them.  Same arithmetic per tracer as profile_col + map_col (iv = 0), streamed coefficients only (|kord| != 11).
+FV3_HD double rcp_rn(double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  return __builtin_fma(y, e, y);
+#else
+  return 1. / b;
+#endif
+}
+FV3_HD double div_rn(double a, double b, double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double q0 = a * y;
+  const double r = __builtin_fma(-b, q0, a);
+  return __builtin_fma(r, y, q0);
+#else
+  (void)y;
+  return a / b;
+#endif
+}
+
+template <int NT>
+struct TrcGroup {
+  double *a1[NT], *q[NT];  // profile slabs of each tracer: layer means, interface values
+  double *f[NT];           // the tracer columns (element of level 1; level stride fs)
+  int ak[NT];              // |kord_tr|
+};
+
+template <int NT>
+FV3_HD void remap_tracers_col(const ColScr &c, const TrcGroup<NT> &t, size_t fs, int km, bool tracer_form) {
+#define TA1(i, k) t.a1[i][(size_t)((k)-1) * c.ls + c.o]
+#define TQ(i, k) t.q[i][(size_t)((k)-1) * c.ls + c.o]
+#define TF(i, k) t.f[i][(size_t)((k)-1) * fs]
+  // ---- forward elimination (fv_operators.F90:597-623 / :967-1016) ----
+  {
+    double a_prev[NT], a_k[NT], qk[NT];
+    for (int i = 0; i < NT; i++) {
+      a_prev[i] = TF(i, 1);
+      a_k[i] = TF(i, 2);
+      TA1(i, 1) = a_prev[i];
+      TA1(i, 2) = a_k[i];
+    }
+    double pe_a = CS(pe1, 2), pe_b = CS(pe1, 3);
+    double dp_prev = pe_a - CS(pe1, 1), dp_k = pe_b - pe_a;
+    const double grat = dp_k / dp_prev;
+    double bet = grat * (grat + 0.5);
+    double rb = rcp_rn(bet);
+    const double c1 = (grat + grat) * (grat + 1.);
+    for (int i = 0; i < NT; i++) {
+      qk[i] = div_rn(c1 * a_prev[i] + a_k[i], bet, rb);
+      TQ(i, 1) = qk[i];
+    }
+    double gam = div_rn(1. + grat * (grat + 1.5), bet, rb);
+    CS(gam, 1) = gam;
+    double d4 = 0.;
+    for (int k = 2; k <= km; k++) {
+      if (k > 2) {
+        for (int i = 0; i < NT; i++) {
+          a_prev[i] = a_k[i];
+          a_k[i] = TF(i, k);
+          TA1(i, k) = a_k[i];
+        }
+        dp_prev = dp_k;
+        pe_a = pe_b;
+        pe_b = CS(pe1, k + 1);
+        dp_k = pe_b - pe_a;
+      }
+      d4 = dp_prev / dp_k;
+      bet = 2. + d4 + d4 - gam;
+      rb = rcp_rn(bet);
+      for (int i = 0; i < NT; i++) {
+        qk[i] = div_rn(3. * (a_prev[i] + d4 * a_k[i]) - qk[i], bet, rb);
+        TQ(i, k) = qk[i];
+      }
+      gam = div_rn(d4, bet, rb);
+      CS(gam, k) = gam;
+    }
+    const double a_bot = 1. + d4 * (d4 + 1.5);
+    const double den = d4 * (d4 + 0.5) - a_bot * gam, rden = rcp_rn(den);
+    const double c2 = 2. * d4 * (d4 + 1.);
+    for (int i = 0; i < NT; i++) TQ(i, km + 1) = div_rn(c2 * a_k[i] + a_prev[i] - a_bot * qk[i], den, rden);
+  }
+  // ---- backward sweep: back-substitution + large-scale constraints (:643-680 / :1037-1073), as profile_col ----
+  {
+    double qraw[NT], w_p1[NT], w_0[NT], w_m1[NT], w_m2[NT];
+    for (int i = 0; i < NT; i++) {
+      qraw[i] = TQ(i, km + 1);
+      w_p1[i] = 0.;
+      w_0[i] = TA1(i, km);
+      w_m1[i] = TA1(i, km - 1);
+      w_m2[i] = km >= 3 ? TA1(i, km - 2) : 0.;
+    }
+    for (int k = km; k >= 1; k--) {
+      const double gam = CS(gam, k);
+      for (int i = 0; i < NT; i++) {
+        const double qk = TQ(i, k) - gam * qraw[i];
+        qraw[i] = qk;
+        double qc = qk;
+        if (k == 2 || (k == km && km >= 3)) {
+          const double v = dmin(qc, dmax(w_m1[i], w_0[i]));
+          qc = dmax(v, dmin(w_m1[i], w_0[i]));
+        } else if (k >= 3 && k <= km - 1) {
+          const double gm = w_m1[i] - w_m2[i], gp = w_p1[i] - w_0[i];
+          if (t.ak[i] >= 14 || gm * gp > 0.) {
+            qc = dmin(qc, dmax(w_m1[i], w_0[i]));
+            qc = dmax(qc, dmin(w_m1[i], w_0[i]));
+          } else if (gm > 0.) {
+            qc = dmax(qc, dmin(w_m1[i], w_0[i]));
+          } else {
+            qc = dmin(qc, dmax(w_m1[i], w_0[i]));
+            qc = dmax(0., qc);  // iv = 0
+          }
+        }
+        TQ(i, k) = qc;
+        w_p1[i] = w_0[i]; w_0[i] = w_m1[i]; w_m1[i] = w_m2[i];
+        w_m2[i] = (k - 3 >= 1) ? TA1(i, k - 3) : 0.;
+      }
+    }
+  }
+  // ---- search and integrate (fv_operators.F90:277-335 mapn_tracer / :402-441 map1_q2), as map_col ----
+  {
+    constexpr double r3 = 1. / 3., r23 = 2. / 3.;
+    int k0 = 1, c_l = 0;
+    double qsum[NT], c_2[NT], c_3[NT], c_4[NT];
+    for (int i = 0; i < NT; i++) qsum[i] = c_2[i] = c_3[i] = c_4[i] = 0.;
+    auto coef = [&](int l) {
+      if (l == c_l) return;
+      for (int i = 0; i < NT; i++) {
+        const ProfCfg pc{km, 0, t.ak[i], true, 0., true};
+        double a2v = TQ(i, l), a3v = TQ(i, l + 1), a4v;
+        const double am2 = l - 2 >= 1 ? TA1(i, l - 2) : 0., am1 = l - 1 >= 1 ? TA1(i, l - 1) : 0.;
+        const double ap1 = l + 1 <= km ? TA1(i, l + 1) : 0., ap2 = l + 2 <= km ? TA1(i, l + 2) : 0.;
+        cs_cell(pc, l, a2v, a3v, am2, am1, TA1(i, l), ap1, ap2, a4v);
+        c_2[i] = a2v; c_3[i] = a3v; c_4[i] = a4v;
+      }
+      c_l = l;
+    };
+    for (int k = 1; k <= km; k++) {
+      const double p2t = CS(pe2, k), p2b = CS(pe2, k + 1);
+      int done = 0;
+      for (int l = k0; l <= km && !done; l++) {
+        const double p1t = CS(pe1, l), p1b = CS(pe1, l + 1);
+        if (p2t >= p1t && p2t <= p1b) {
+          const double dp1 = p1b - p1t, rdp1 = rcp_rn(dp1);
+          const double pl = div_rn(p2t - p1t, dp1, rdp1);
+          coef(l);
+          if (p2b <= p1b) {
+            const double pr = div_rn(p2b - p1t, dp1, rdp1);
+            if (tracer_form) {
+              double fac1 = pr + pl;
+              const double fac2 = r3 * (pr * fac1 + pl * pl);
+              fac1 = 0.5 * fac1;
+              for (int i = 0; i < NT; i++) TF(i, k) = c_2[i] + (c_4[i] + c_3[i] - c_2[i]) * fac1 - c_4[i] * fac2;
+            } else {
+              const double s1 = pr + pl, s2 = pr * (pr + pl) + pl * pl;
+              for (int i = 0; i < NT; i++) TF(i, k) = c_2[i] + 0.5 * (c_4[i] + c_3[i] - c_2[i]) * s1 - c_4[i] * r3 * s2;
+            }
+            k0 = l;
+            done = 2;
+          } else {
+            if (tracer_form) {
+              const double dp = p1b - p2t;
+              double fac1 = 1. + pl;
+              const double fac2 = r3 * (1. + pl * fac1);
+              fac1 = 0.5 * fac1;
+              for (int i = 0; i < NT; i++) qsum[i] = dp * (c_2[i] + (c_4[i] + c_3[i] - c_2[i]) * fac1 - c_4[i] * fac2);
+            } else {
+              const double dp = p1b - p2t, s1 = 1. + pl, s2 = r3 * (1. + pl * (1. + pl));
+              for (int i = 0; i < NT; i++) qsum[i] = dp * (c_2[i] + 0.5 * (c_4[i] + c_3[i] - c_2[i]) * s1 - c_4[i] * s2);
+            }
+            for (int m = l + 1; m <= km; m++) {
+              const double mt = CS(pe1, m), mb = CS(pe1, m + 1);
+              if (p2b > mb) {
+                const double dm = mb - mt;
+                for (int i = 0; i < NT; i++) qsum[i] = qsum[i] + dm * TA1(i, m);
+              } else {
+                const double dp = p2b - mt;
+                const double esl = dp / (mb - mt);
+                coef(m);
+                if (tracer_form) {
+                  const double fac1 = 0.5 * esl, fac2 = 1. - r23 * esl;
+                  for (int i = 0; i < NT; i++) qsum[i] = qsum[i] + dp * (c_2[i] + fac1 * (c_3[i] - c_2[i] + c_4[i] * fac2));
+                } else {
+                  const double s1 = 0.5 * esl, s2 = 1. - r23 * esl;
+                  for (int i = 0; i < NT; i++) qsum[i] = qsum[i] + dp * (c_2[i] + s1 * (c_3[i] - c_2[i] + c_4[i] * s2));
+                }
+                k0 = m;
+                break;
+              }
+            }
+            done = 1;
+          }
+        }
+      }
+      if (done != 2) {
+        const double dp2 = p2b - p2t, rdp2 = rcp_rn(dp2);
+        for (int i = 0; i < NT; i++) TF(i, k) = div_rn(qsum[i], dp2, rdp2);
+      }
+    }
+  }
+#undef TA1
+#undef TQ
+#undef TF
+}
+
 // ------------------------------------------------------------------------------------------------
 struct RemapPar {
   int last_step, hydrostatic, adiabatic, nq, kord_mt, kord_wz, kord_tm, sphum;
@@ -496,6 +719,7 @@ struct RemapPar {
   double cv_vap, c_liq, c_ice;
   double *q_con, *cappa;  // A x km, written where the reference writes them (fv_mapz.F90:212-219, :463-478)
   int fill;               // flagstruct%fill: fillz on the remapped tracers
+  int scr_blocked;        // layout of the scratch slabs (scr_col)
 };
 
 // fillz of one tracer column (fv_fill.F90:34-137, default branch): q(k) at q[(k-1)*qs], dp2(k) = pe2(k+1) - pe2(k) through
@@ -600,12 +824,14 @@ struct RemapCoords {
     FV3_COL_FOR2(col, ncol) {
       const int i = g.is + col % g.nx, j = g.js + col / g.nx;
       const int o = g.iA(i, j);
+      ColScr c{};
+      scr_col(c, col, o, km, nA, p.scr_blocked);
       const size_t peb = (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1));
       const size_t lnb = (size_t)(j - g.js) * g.nx * (km + 1) + (i - g.is);
       const double psfc = pe[peb + (size_t)km * (g.nx + 2)];
       ps[o] = psfc;  // :298-300
       for (int k = 1; k <= km + 1; k++) {
-        const size_t so = (size_t)(k - 1) * nA + o;
+        const size_t so = (size_t)(k - 1) * c.ls + c.o;
         const double pe2k = (k == 1) ? p.ptop : (k == km + 1 ? psfc : ak[k - 1] + bk[k - 1] * psfc);
         pe1p[so] = pe[peb + (size_t)(k - 1) * (g.nx + 2)];
         pe2p[so] = pe2k;
@@ -632,14 +858,17 @@ struct RemapFields {
   const double *delp, *pk, *delz, *peln, *pe, *ws;
   double *w, *pt, *q, *omga, *u, *v;
   double *pe1p, *pe2p, *pe1l, *pe2l, *pe1u, *pe2u, *pe1v, *pe2v;  // coordinate slabs
-  double *sets;                                                     // 6 profile slabs per task of this launch
+  double *sets;                                                     // kSetSlabs profile slabs per task of this launch
   size_t slab;                                                      // doubles per slab
   int task0, nblk;                                                  // first task of this launch; workgroups per task
+  int ngrp;                                                         // tracer groups (tasks after T_v, w, u, v): the nq
+                                                                    // tracers dealt evenly, at most kGroupMax per group
+  static constexpr int kSetSlabs = 7, kGroupMax = 3;
 
   FV3_HD void operator()(int bxg, int, int, int tid, double *) const {
     const int task = task0 + bxg / nblk, bx = bxg % nblk;
     const size_t nA = g.nA(), nCC = g.nCC();
-    double *base = sets + (size_t)(task - task0) * 6 * slab;
+    double *base = sets + (size_t)(task - task0) * kSetSlabs * slab;
     ColScr c{base, base + slab, base + 2 * slab, base + 3 * slab, base + 4 * slab, pe1p, pe2p, base + 5 * slab, nA, 0};
     const int t_w = p.hydrostatic ? -1 : 1, t_u = p.hydrostatic ? 1 : 2, t_v = t_u + 1;
     const int akt = p.kord_tm < 0 ? -p.kord_tm : p.kord_tm;
@@ -651,7 +880,7 @@ struct RemapFields {
       c.pe2 = which == 0 ? pe2u : pe2v;
       FV3_COL_FOR2(col, ncol) {
         const int i = g.is + col % wdt, j = g.js + col / wdt;
-        c.o = g.iA(i, j);
+        scr_col(c, col, g.iA(i, j), km, nA, p.scr_blocked);
         auto PE = [&](int ii, int k, int jj) {
           return pe[(size_t)(jj - (g.js - 1)) * (g.nx + 2) * (km + 1) + (size_t)(k - 1) * (g.nx + 2) + (ii - (g.is - 1))];
         };
@@ -672,7 +901,8 @@ struct RemapFields {
     const int ncol = g.nx * g.ny;
     FV3_COL_FOR2(col, ncol) {
       const int i = g.is + col % g.nx, j = g.js + col / g.nx;
-      c.o = g.iA(i, j);
+      const int fo = g.iA(i, j);
+      scr_col(c, col, fo, km, nA, p.scr_blocked);
       const int occ = g.iCC(i, j);
       if (task == 0) {
         const double k1k = p.rdgas / p.cv_air, rrg = -p.rdgas / p.grav, akap = p.akap;
@@ -680,14 +910,14 @@ struct RemapFields {
         auto PELN = [&](int k) { return peln[lnb + (size_t)(k - 1) * g.nx]; };
         // temperature transform (:200-229), level by level as the profile sweep fetches the field
         auto src_pt = [&](int k) {
-          double t = pt[(size_t)(k - 1) * nA + c.o];
+          double t = pt[(size_t)(k - 1) * nA + fo];
           if (p.kord_tm < 0) {
             if (p.hydrostatic) {
               t = t * (pk[(size_t)k * nCC + occ] - pk[(size_t)(k - 1) * nCC + occ]) / (akap * (PELN(k + 1) - PELN(k)));
             } else {
-              const double dpo = delp[(size_t)(k - 1) * nA + c.o];
+              const double dpo = delp[(size_t)(k - 1) * nA + fo];
               if (p.moist_kappa) {  // :212-219
-                const size_t o3 = (size_t)(k - 1) * nA + c.o;
+                const size_t o3 = (size_t)(k - 1) * nA + fo;
                 double qc;
                 const double cvm = moist_cv(p, q + o3, nA * km, qc);
                 const double cap = p.rdgas / (p.rdgas + cvm / (1. + p.r_vir * q[(size_t)(p.sphum - 1) * nA * km + o3]));
@@ -710,13 +940,13 @@ struct RemapFields {
         } else {
           pc = profile_col(c, km, false, 0., 1, akt, 0., src_pt);
         }
-        map_col(c, km, false, pc, [&](int k, double v_) { pt[(size_t)(k - 1) * nA + c.o] = v_; });
+        map_col(c, km, false, pc, [&](int k, double v_) { pt[(size_t)(k - 1) * nA + fo] = v_; });
         // omega (:432-443, :506-526): interpolated in the old log-p coordinate
         if (p.last_step) {
           const size_t peb = (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1));
           const double psfc = pe[peb + (size_t)km * (g.nx + 2)];
           CS(gam, 1) = 0.;
-          for (int k = 2; k <= km + 1; k++) CS(gam, k) = omga[(size_t)(k - 2) * nA + c.o];  // pe3
+          for (int k = 2; k <= km + 1; k++) CS(gam, k) = omga[(size_t)(k - 2) * nA + fo];  // pe3
           int k_next = 1;
           for (int n = 1; n <= km; n++) {
             const double pn_t = (n == 1) ? PELN(1) : log(ak[n - 1] + bk[n - 1] * psfc);
@@ -725,7 +955,7 @@ struct RemapFields {
             for (int k = k_next; k <= km; k++) {
               const double e0 = PELN(k), e1 = PELN(k + 1);
               if (mid <= e1 && mid >= e0) {
-                omga[(size_t)(n - 1) * nA + c.o] = CS(gam, k) + (CS(gam, k + 1) - CS(gam, k)) * (mid - e0) / (e1 - e0);
+                omga[(size_t)(n - 1) * nA + fo] = CS(gam, k) + (CS(gam, k + 1) - CS(gam, k)) * (mid - e0) / (e1 - e0);
                 k_next = k;
                 break;
               }
@@ -733,15 +963,50 @@ struct RemapFields {
           }
         }
       } else if (task == t_w) {  // w (:400-411)
-        const ProfCfg pc = profile_col(c, km, false, ws[occ], -2, p.kord_wz, 0., [&](int k) { return w[(size_t)(k - 1) * nA + c.o]; });
-        map_col(c, km, false, pc, [&](int k, double v_) { w[(size_t)(k - 1) * nA + c.o] = v_; });
-      } else {  // constituents (:380-397)
-        const int iq = task - (t_v + 1);
-        double *qq = q + (size_t)iq * nA * km;
-        const ProfCfg pc = profile_col(c, km, true, 0., 0, kord_tr[iq], 0., [&](int k) { return qq[(size_t)(k - 1) * nA + c.o]; });
-        map_col(c, km, p.nq > 5, pc, [&](int k, double v_) { qq[(size_t)(k - 1) * nA + c.o] = v_; });
-        if (p.fill)  // fv_operators.F90:337 / fv_mapz.F90:390
-          fillz_col(km, qq + c.o, nA, [&](int k) { return CS(pe2, k + 1) - CS(pe2, k); });
+        const ProfCfg pc = profile_col(c, km, false, ws[occ], -2, p.kord_wz, 0., [&](int k) { return w[(size_t)(k - 1) * nA + fo]; });
+        map_col(c, km, false, pc, [&](int k, double v_) { w[(size_t)(k - 1) * nA + fo] = v_; });
+      } else {  // constituents (:380-397): the tracers of group grp
+        const int grp = task - (t_v + 1);
+        const int gb = p.nq / ngrp, gr = p.nq % ngrp;
+        const int nl = gb + (grp < gr ? 1 : 0), iq0 = grp * gb + (grp < gr ? grp : gr);
+        bool side_by_side = nl > 1;
+        for (int n = 0; n < nl; n++) {
+          const int a = kord_tr[iq0 + n] < 0 ? -kord_tr[iq0 + n] : kord_tr[iq0 + n];
+          if (a == 11) side_by_side = false;  // |kord| = 11 keeps a2, a3, a4 in slabs (profile_col_tail_unfused)
+        }
+        if (side_by_side) {
+          ColScr cg = c;
+          cg.gam = base + 6 * slab;
+          if (nl == 2) {
+            TrcGroup<2> t;
+            for (int n = 0; n < 2; n++) {
+              t.a1[n] = base + (size_t)(2 * n) * slab;
+              t.q[n] = base + (size_t)(2 * n + 1) * slab;
+              t.f[n] = q + (size_t)(iq0 + n) * nA * km + fo;
+              t.ak[n] = kord_tr[iq0 + n] < 0 ? -kord_tr[iq0 + n] : kord_tr[iq0 + n];
+            }
+            remap_tracers_col<2>(cg, t, nA, km, p.nq > 5);
+          } else {
+            TrcGroup<3> t;
+            for (int n = 0; n < 3; n++) {
+              t.a1[n] = base + (size_t)(2 * n) * slab;
+              t.q[n] = base + (size_t)(2 * n + 1) * slab;
+              t.f[n] = q + (size_t)(iq0 + n) * nA * km + fo;
+              t.ak[n] = kord_tr[iq0 + n] < 0 ? -kord_tr[iq0 + n] : kord_tr[iq0 + n];
+            }
+            remap_tracers_col<3>(cg, t, nA, km, p.nq > 5);
+          }
+        }
+        for (int n = 0; n < nl; n++) {
+          const int iq = iq0 + n;
+          double *qq = q + (size_t)iq * nA * km;
+          if (!side_by_side) {
+            const ProfCfg pc = profile_col(c, km, true, 0., 0, kord_tr[iq], 0., [&](int k) { return qq[(size_t)(k - 1) * nA + fo]; });
+            map_col(c, km, p.nq > 5, pc, [&](int k, double v_) { qq[(size_t)(k - 1) * nA + fo] = v_; });
+          }
+          if (p.fill)  // fv_operators.F90:337 / fv_mapz.F90:390
+            fillz_col(km, qq + fo, nA, [&](int k) { return CS(pe2, k + 1) - CS(pe2, k); });
+        }
       }
     }
   }
@@ -763,13 +1028,14 @@ struct RemapDelzFinal {
     FV3_COL_FOR2(col, ncol) {
       const int i = g.is + col % g.nx, j = g.js + col / g.nx;
       ColScr c = s;
-      c.o = g.iA(i, j);
+      const int fo = g.iA(i, j);
+      scr_col(c, col, fo, km, nA, p.scr_blocked);
       const int occ = g.iCC(i, j);
       const size_t lnb = (size_t)(j - g.js) * g.nx * (km + 1) + (i - g.is);
       auto PELN = [&](int k) -> double & { return peln[lnb + (size_t)(k - 1) * g.nx]; };
       if (!p.hydrostatic) {
         const ProfCfg pc = profile_col(c, km, false, 0., 1, akt, 0., [&](int k) {
-          return -delz[(size_t)(k - 1) * nCC + occ] / delp[(size_t)(k - 1) * nA + c.o];  // :292
+          return -delz[(size_t)(k - 1) * nCC + occ] / delp[(size_t)(k - 1) * nA + fo];  // :292
         });
         map_col(c, km, false, pc, [&](int k, double v_) {
           delz[(size_t)(k - 1) * nCC + occ] = -v_ * (CS(pe2, k + 1) - CS(pe2, k));
@@ -778,7 +1044,7 @@ struct RemapDelzFinal {
       double pn_prev = PELN(1), pk_prev = pk[occ];
       for (int k = 1; k <= km; k++) {
         const double dp2 = CS(pe2, k + 1) - CS(pe2, k);
-        delp[(size_t)(k - 1) * nA + c.o] = dp2;
+        delp[(size_t)(k - 1) * nA + fo] = dp2;
         double pn_next, pk_next;
         if (k + 1 == km + 1) {
           pn_next = PELN(km + 1);
@@ -790,11 +1056,11 @@ struct RemapDelzFinal {
           pk[(size_t)k * nCC + occ] = pk_next;
         }
         double pkzv;
-        const double tv = pt[(size_t)(k - 1) * nA + c.o];
+        const double tv = pt[(size_t)(k - 1) * nA + fo];
         if (p.hydrostatic)
           pkzv = (pk_next - pk_prev) / (akap * (pn_next - pn_prev));
         else if (p.moist_kappa) {  // :463-478: q holds the remapped tracers
-          const size_t o3 = (size_t)(k - 1) * nA + c.o;
+          const size_t o3 = (size_t)(k - 1) * nA + fo;
           double qc;
           const double cvm = moist_cv(p, q + o3, nA * km, qc);
           const double cap = p.rdgas / (p.rdgas + cvm / (1. + p.r_vir * q[(size_t)(p.sphum - 1) * nA * km + o3]));
@@ -810,18 +1076,18 @@ struct RemapDelzFinal {
         if (p.kord_tm > 0) tnew = tnew * pkzv;  // :496-502
         if (p.last_step) {                      // :793-821 (dtmp = 0)
           if (!p.hydrostatic && p.use_cond) {   // :806-811
-            const size_t o3 = (size_t)(k - 1) * nA + c.o;
+            const size_t o3 = (size_t)(k - 1) * nA + fo;
             double qc;
             const double cvm = moist_cv(p, q + o3, nA * km, qc);
             tnew = (tnew + 0. / cvm * pkzv) / ((1. + p.r_vir * q[(size_t)(p.sphum - 1) * nA * km + o3]) * (1. - qc));
           } else if (!p.adiabatic) {
-            const double qv = p.sphum > 0 ? q[(size_t)(p.sphum - 1) * nA * km + (size_t)(k - 1) * nA + c.o] : 0.;
+            const double qv = p.sphum > 0 ? q[(size_t)(p.sphum - 1) * nA * km + (size_t)(k - 1) * nA + fo] : 0.;
             tnew = (tnew + 0. / (p.hydrostatic ? p.cp : p.cv_air) * pkzv) / (1. + p.r_vir * qv);
           }
         } else {
           tnew = tnew / pkzv;                   // :833-841
         }
-        pt[(size_t)(k - 1) * nA + c.o] = tnew;
+        pt[(size_t)(k - 1) * nA + fo] = tnew;
         pn_prev = pn_next;
         pk_prev = pk_next;
       }

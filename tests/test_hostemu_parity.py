@@ -146,6 +146,15 @@ def test_remap(emu, hydrostatic, last_step, kord_tm, kord, nq):
     R.check_remap(emu, hydrostatic=hydrostatic, last_step=last_step, kord_tm=kord_tm, kord=kord, nq=nq)
 
 
+@pytest.mark.parametrize("nt,nq,kord", [(1, 4, 9), (2, 5, 10), (3, 4, 9), (3, 5, 8), (3, 7, 10), (3, 7, 11), (3, 3, 13)])
+def test_remap_tracer_groups(emu, nt, nq, kord, monkeypatch):
+    """tracers remapped side by side in groups of up to nt per thread (remap_tracers_col): even dealing (4 = 2 + 2,
+    7 = 3 + 2 + 2), both tracer forms (nq <= 5, nq > 5), |kord| = 11 falling back to one tracer at a time"""
+    monkeypatch.setenv("FV3_MI355X_REMAP_NT", str(nt))
+    R.check_remap(emu, nq=nq, kord=kord, last_step=True)
+    R.check_remap(emu, nq=nq, kord=kord, hydrostatic=True, kord_tm=-kord if kord != 13 else -10, fill=(nq == 7))
+
+
 # ---- tracer_2d -------------------------------------------------------------------------------------
 import parity_tracer as T
 

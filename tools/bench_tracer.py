@@ -15,12 +15,13 @@ import parity_nh as N
 from gfdl_atmos_cubed_sphere_amd import lib as L
 from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
 from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+from gfdl_atmos_cubed_sphere_amd.grid import doubly_periodic
 from gfdl_atmos_cubed_sphere_amd.layout import Bounds
 
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 384
 npz = int(sys.argv[2]) if len(sys.argv) > 2 else 127
 bd = Bounds(1, nx, 1, nx)
-g = P.make_grid(bd, False)
+g = doubly_periodic(bd, nx + 1, nx + 1, dx_const=26000.0, dy_const=26000.0)
 st, _ = D.make_state(bd, npz)
 sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
 ak, bk = N.PTOP * (1.0 - sig), sig.copy()
