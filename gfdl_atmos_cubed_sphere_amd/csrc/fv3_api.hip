@@ -83,6 +83,7 @@ struct fv3_ctx {
   int march_tj_csw, march_tj_ke, march_tj_fused, march_tj_mom;
   int trc_nt;  // tracers per wavefront in the sub-cycle kernel (FV3_MI355X_TRACER_NT: 1..4, default 3)
   int remap_nt;  // tracers per thread in the remap (FV3_MI355X_REMAP_NT: 1..3, default 3)
+  int riem_blocked;   // the same for the Riemann solvers' four slabs (FV3_MI355X_RIEM_SCR: 0 / 1, default 1)
   int remap_blocked;  // scratch slabs of the remap in per-wavefront blocks (FV3_MI355X_REMAP_SCR: 0 / 1, default 1)
   int tj_fixed;          // an FV3_MI355X_MARCH_TJ* variable is set: take the rows per segment as given
   int csw_kpw;           // levels per wavefront in CswMarch (1 .. 4; FV3_MI355X_CSW_KPW)
@@ -248,6 +249,8 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_REMAP_NT");
     c->remap_nt = e ? std::atoi(e) : 3;
     if (c->remap_nt < 1 || c->remap_nt > RemapFields::kGroupMax) c->remap_nt = 3;
+    e = std::getenv("FV3_MI355X_RIEM_SCR");
+    c->riem_blocked = e ? (std::atoi(e) != 0) : 1;
     e = std::getenv("FV3_MI355X_REMAP_SCR");
     c->remap_blocked = e ? (std::atoi(e) != 0) : 1;
     e = std::getenv("FV3_MI355X_MARCH_TJ_KE");
@@ -1016,7 +1019,9 @@ extern "C" int fv3_halo_unpack(fv3_ctx *c, int nfields, const fv3_halo_field *fi
 // nonhydrostatic column path
 // ================================================================================================
 static int need_scratch(fv3_ctx *c, int n) {
-  const size_t bytes = c->g.nA() * (size_t)(c->g.npz + 1) * sizeof(double);
+  // A x (km+1), and room for the (nx+2) x (ny+2) columns of the C-grid solver in blocks of 64 (scr_col layout)
+  const size_t nblk = (((size_t)(c->g.nx + 2) * (c->g.ny + 2) + 63) / 64) * 64;
+  const size_t bytes = (c->g.nA() > nblk ? c->g.nA() : nblk) * (size_t)(c->g.npz + 1) * sizeof(double);
   for (int s = 0; s < n; s++)
     if (!c->scratch[s]) RT(rt_malloc((void **)&c->scratch[s], bytes));
   return 0;
@@ -1091,11 +1096,11 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn,
   if (need_scratch(c, 4)) return 1;
   if (c->q_con) {
     RiemSolverC<true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, w3, pt, delp, ws, gz, pef,
-                         c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->q_con, c->cappa};
+                         c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->q_con, c->cappa, c->riem_blocked};
     RT(launch_c(c, "riem_solver_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), kf));
   } else {
     RiemSolverC<false> kf{c->g, c->g.npz, dt, to_consts(cn), hs, w3, pt, delp, ws, gz, pef,
-                          c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], nullptr, nullptr};
+                          c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], nullptr, nullptr, c->riem_blocked};
     RT(launch_c(c, "riem_solver_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), kf));
   }
   return 0;
@@ -1112,12 +1117,12 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
   if (c->q_con || c->cappa) {
     RiemSolver3<true> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, delz, zh, pe, ppe, pk3, pk, peln,
                          use_logp, last_call, fp_out, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3],
-                         c->q_con, c->cappa};
+                         c->q_con, c->cappa, c->riem_blocked};
     RT(launch_c(c, "riem_solver3", col_grid(c->g.nx * c->g.ny), kf));
   } else {
     RiemSolver3<false> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, delz, zh, pe, ppe, pk3, pk, peln,
                           use_logp, last_call, fp_out, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3],
-                          nullptr, nullptr};
+                          nullptr, nullptr, c->riem_blocked};
     RT(launch_c(c, "riem_solver3", col_grid(c->g.nx * c->g.ny), kf));
   }
   return 0;

@@ -119,7 +119,7 @@ struct ColIn {
 //   on_w(k, w2(k)),  k = 1..km               -- the new vertical velocity (may overwrite in.w: level k is not read again),
 //   on_dz(k, dz2(k)), k = km..1 descending   -- the new layer thickness (may overwrite in.zlev: not read after pass C).
 template <bool MOIST = false, class OnPe, class OnW, class OnDz>
-FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhConsts &cn, bool sim1, bool c_grid,
+FV3_HD void sim_column(int km, size_t ls, size_t ss, const ColIn &in, double dt, const NhConsts &cn, bool sim1, bool c_grid,
                        double ws, double *FV3_RESTRICT s_gam, double *FV3_RESTRICT s_pp, double *FV3_RESTRICT s_w,
                        double *FV3_RESTRICT s_pm, const OnPe &on_pe, const OnW &on_w, const OnDz &on_dz) {
   constexpr double r3 = 1. / 3.;
@@ -133,6 +133,7 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
   const double t1g = sim1 ? 2. * dt * dt : 2. * ((alpha * dt) * (alpha * dt));
   const double rdt = 1. / dt;
 #define L(p, k) (p)[(size_t)((k)-1) * ls]
+#define S(p, k) (p)[(size_t)((k)-1) * ss]   // scratch slabs: level stride ss (64 in per-wavefront blocks, see scr_col)
   // ---- pass A: pe(k), pm2(k); forward elimination for pp (:1297-1326) ----
   double pem_k = cn.ptop, peln_k = log(cn.ptop);
   double peg_k = cn.ptop, pelng_k = peln_k;  // MOIST + q_con: dry-gas + vapour hydrostatic pressure and its log
@@ -166,9 +167,9 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
   };
   double dm_c, dz_c, pm_c, pe_c, pem_n, peln_n;
   level(1, dm_c, dz_c, pm_c, pe_c, pem_n, peln_n);
-  L(s_pm, 1) = pm_c;
+  S(s_pm, 1) = pm_c;
   double bet = 0., pp_k = 0., g_rat_prev = 0.;
-  L(s_pp, 1) = 0.;
+  S(s_pp, 1) = 0.;
   FV3_UNROLL4
   for (int k = 1; k <= km; k++) {
     double dm_n = 0., dz_n = 0., pm_n = 0., pe_n = 0., pem_nn = 0., peln_nn = 0.;
@@ -177,7 +178,7 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
       pem_k = pem_n;
       peln_k = peln_n;
       level(k + 1, dm_n, dz_n, pm_n, pe_n, pem_nn, peln_nn);
-      L(s_pm, k + 1) = pm_n;
+      S(s_pm, k + 1) = pm_n;
       g_rat = dm_c / dm_n;
       bb = 2. * (1. + g_rat);
       dd = 3. * (pe_c + g_rat * pe_n);
@@ -191,20 +192,20 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
     } else {
       const double gam = g_rat_prev / bet;
       bet = bb - gam;
-      L(s_gam, k) = gam;
+      S(s_gam, k) = gam;
       pp_k = (dd - pp_k) / bet;  // pp(k+1)
     }
-    L(s_pp, k + 1) = pp_k;
+    S(s_pp, k + 1) = pp_k;
     g_rat_prev = g_rat;
     dm_c = dm_n; dz_c = dz_n; pm_c = pm_n; pe_c = pe_n; pem_n = pem_nn; peln_n = peln_nn;
   }
   // ---- pass B: back substitution (:1328-1332) ----
   {
-    double pp_next = L(s_pp, km + 1);
+    double pp_next = S(s_pp, km + 1);
     FV3_UNROLL4
     for (int k = km; k >= 2; k--) {
-      const double v = L(s_pp, k) - L(s_gam, k) * pp_next;
-      L(s_pp, k) = v;
+      const double v = S(s_pp, k) - S(s_gam, k) * pp_next;
+      S(s_pp, k) = v;
       pp_next = v;
     }
   }
@@ -216,13 +217,13 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
     // every interface height, pp and w value is loaded once and carried to the next level
     double z_lo = L(in.zlev, 2);
     double dz_c2 = z_lo - L(in.zlev, 1);
-    double pp_lo = L(s_pp, 1), w_c = L(in.w, 1);
+    double pp_lo = S(s_pp, 1), w_c = L(in.w, 1);
     FV3_UNROLL4
     for (int k = 1; k <= km; k++) {
       const double dmr = L(in.delp, k), dm2 = dmr * rgrav;
       const double dz2 = dz_c2;
       const double w1 = w_c;
-      const double pp_k0 = pp_lo, pp_k1 = L(s_pp, k + 1);
+      const double pp_k0 = pp_lo, pp_k1 = S(s_pp, k + 1);
       pp_lo = pp_k1;
       if (k == 1) dm1 = dm2;
       // aa(k+1), wk(k+1) need level k+1
@@ -246,18 +247,18 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
       } else if (k < km) {
         const double gam = aa_k / bet;
         bet = dm2 - (aa_k + aa_n + aa_k * gam);
-        L(s_gam, k) = gam;
+        S(s_gam, k) = gam;
         w2 = sim1 ? (dm2 * w1 + dt * (pp_k1 - pp_k0) - aa_k * w_prev) / bet
                   : (dm2 * w1 + dt * (pp_k1 - pp_k0) + wk_n - wk_k - aa_k * w_prev) / bet;
       } else {
         const double p1 = t1g * gm2_at(km) / dz2 * pem_next;  // pem(km+1)
         const double gam = aa_k / bet;
         bet = dm2 - (aa_k + p1 + aa_k * gam);
-        L(s_gam, k) = gam;
+        S(s_gam, k) = gam;
         w2 = sim1 ? (dm2 * w1 + dt * (pp_k1 - pp_k0) - p1 * ws - aa_k * w_prev) / bet
                   : (dm2 * w1 + dt * (pp_k1 - pp_k0) - wk_k + p1 * (t2 * w1 - ra * ws) - aa_k * w_prev) / bet;
       }
-      L(s_w, k) = w2;
+      S(s_w, k) = w2;
       w_prev = w2;
       w1_prev = w1;
       dz_prev = dz2;
@@ -269,26 +270,26 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
   }
   // ---- pass D: back substitution for w (:1357-1361) ----
   {
-    double w_next = L(s_w, km);
+    double w_next = S(s_w, km);
     FV3_UNROLL4
     for (int k = km - 1; k >= 1; k--) {
-      const double v = L(s_w, k) - L(s_gam, k + 1) * w_next;
-      L(s_w, k) = v;
+      const double v = S(s_w, k) - S(s_gam, k + 1) * w_next;
+      S(s_w, k) = v;
       w_next = v;
     }
   }
   // ---- pass E: pe(k+1) = pe(k) + dm2*(w2-w1)*rdt (:1373-1380 / :1508-1516); pp kept for the SIM blend ----
   {
     double pe = 0.;
-    double pp_k2 = L(s_pp, 1);
+    double pp_k2 = S(s_pp, 1);
     // s_gam is free now: keep pp there for the final blend of SIM_solver (:1531-1535)
     FV3_UNROLL4
     for (int k = 1; k <= km; k++) {
       const double dm2 = L(in.delp, k) * rgrav;
-      const double pp_n = L(s_pp, k + 1);
-      L(s_pp, k) = pe;
-      if (!sim1) L(s_gam, k) = pp_k2;
-      const double w2 = L(s_w, k), w1 = L(in.w, k);
+      const double pp_n = S(s_pp, k + 1);
+      S(s_pp, k) = pe;
+      if (!sim1) S(s_gam, k) = pp_k2;
+      const double w2 = S(s_w, k), w1 = L(in.w, k);
       if (sim1) {
         on_pe(k, pe);      // SIM1: pe2 is final here (no blend)
         pe = pe + dm2 * (w2 - w1) * rdt;
@@ -298,20 +299,20 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
       on_w(k, w2);
       pp_k2 = pp_n;
     }
-    L(s_pp, km + 1) = pe;
+    S(s_pp, km + 1) = pe;
     if (sim1) on_pe(km + 1, pe);
-    if (!sim1) L(s_gam, km + 1) = pp_k2;
+    if (!sim1) S(s_gam, km + 1) = pp_k2;
   }
   // ---- pass F: new layer thickness (:1382-1392 / :1518-1529); dz2 -> s_pm (pm2 consumed level by level)
   {
-    double pp_1 = L(s_pp, km), pp_2 = L(s_pp, km + 1), pp_0 = 0.;  // pe2(k+1), pe2(k+2) carried downwards
+    double pp_1 = S(s_pp, km), pp_2 = S(s_pp, km + 1), pp_0 = 0.;  // pe2(k+1), pe2(k+2) carried downwards
     double p1 = (pp_1 + 2. * pp_2) * r3;
     double dm_below = 0.;
     FV3_UNROLL4
     for (int k = km; k >= 1; k--) {
-      const double dm2 = L(in.delp, k) * rgrav, pm2 = L(s_pm, k);
+      const double dm2 = L(in.delp, k) * rgrav, pm2 = S(s_pm, k);
       if (k < km) {
-        pp_0 = L(s_pp, k);
+        pp_0 = S(s_pp, k);
         const double g_rat = dm2 / dm_below, bb = 2. * (1. + g_rat);
         p1 = (pp_0 + bb * pp_1 + g_rat * pp_2) * r3 - g_rat * p1;
         pp_2 = pp_1;
@@ -322,8 +323,9 @@ FV3_HD void sim_column(int km, size_t ls, const ColIn &in, double dt, const NhCo
     }
   }
   if (!sim1) {  // pe2 = pe2 + beta*(pp - pe2) (:1531-1535)
-    for (int k = 1; k <= km + 1; k++) on_pe(k, L(s_pp, k) + beta * (L(s_gam, k) - L(s_pp, k)));
+    for (int k = 1; k <= km + 1; k++) on_pe(k, S(s_pp, k) + beta * (S(s_gam, k) - S(s_pp, k)));
   }
+#undef S
 #undef L
 }
 
@@ -338,6 +340,7 @@ struct RiemSolverC {
   double *gz, *pef;
   double *s0, *s1, *s2, *s3;  // scratch slabs, A x (km+1)
   const double *q_con, *cappa;  // A x km or null (use_cond / moist_kappa)
+  int scr_blocked;              // scratch slabs in per-wavefront blocks (remap_kernels.h scr_col)
   FV3_HD void operator()(int bx, int, int, int tid, double *) const {
     const int w = g.nx + 2, ncol = w * (g.ny + 2);
     const size_t nA = g.nA();
@@ -352,8 +355,10 @@ struct RiemSolverC {
       // pef = pe2 + pem (:461-465); gz = hs - sum dz2*grav (:468-476), formed inside the solver's last two sweeps
       double pem = cn.ptop;
       double zb = hs[o];
+      const size_t so = scr_blocked ? (size_t)(c >> 6) * 64 * (km + 1) + (c & 63) : (size_t)o;
+      const size_t ss = scr_blocked ? 64 : nA;
       sim_column<MOIST>(
-          km, nA, in, dt, cn, true, true, ws[o], s0 + o, s1 + o, s2 + o, s3 + o,
+          km, nA, ss, in, dt, cn, true, true, ws[o], s0 + so, s1 + so, s2 + so, s3 + so,
           [&](int k, double pe2) {
             if (k == 1) {
               pef[o] = cn.ptop;
@@ -383,6 +388,7 @@ struct RiemSolver3 {
   int use_logp, last_call, fp_out;
   double *s0, *s1, *s2, *s3;
   const double *q_con, *cappa;  // A x km or null (use_cond / moist_kappa, nh_core.F90:96-166)
+  int scr_blocked;
   FV3_HD void operator()(int bx, int, int, int tid, double *) const {
     const int ncol = g.nx * g.ny;
     const size_t nA = g.nA(), nCC = g.nCC();
@@ -399,8 +405,10 @@ struct RiemSolver3 {
       // hydrostatic pressure functions (:132-143) and the outputs (:191-237) are formed inside the solver's last sweeps
       double pem = cn.ptop;
       double zb = zs[o];
+      const size_t so = scr_blocked ? (size_t)(c >> 6) * 64 * (km + 1) + (c & 63) : (size_t)o;
+      const size_t ss = scr_blocked ? 64 : nA;
       sim_column<MOIST>(
-          km, nA, in, dt, cn, sim1, false, ws[occ], s0 + o, s1 + o, s2 + o, s3 + o,
+          km, nA, ss, in, dt, cn, sim1, false, ws[occ], s0 + so, s1 + so, s2 + so, s3 + so,
           [&](int k, double pe2) {
             if (k == 1) {
               pk3[o] = ptk;
