@@ -1314,8 +1314,9 @@ extern "C" int fv3_apply_heat_source(fv3_ctx *c, int n_con, int hydrostatic, dou
   const Grid &g = c->g;
   if (n_con < 0 || n_con > g.npz) return fail("fv3_apply_heat_source: n_con out of range");
   if (n_con == 0) return 0;
+  // moist_kappa: the cappa of fv3_set_condensate (the array the Riemann solvers use) gives the exponent of pkz
   HeatApply kf{g, n_con, hydrostatic, bdt, delt_max, cp_air, cv_air, -rdgas / grav, rdgas / cv_air, pt, heat_source, delp,
-               delz, pkz};
+               delz, pkz, hydrostatic ? nullptr : c->cappa};
   Dim3 grid;
   grid.x = (unsigned)((g.nx * g.ny + HeatApply::CH - 1) / HeatApply::CH);
   grid.y = 1;

@@ -864,6 +864,7 @@ struct HeatApply {
   double *pt, *hs;
   const double *delp, *delz;
   double *pkz;
+  const double *cappa;  // A x npz (thermostruct%moist_kappa, dyn_core.F90:1338-1340) or null
   static constexpr int CH = 1024;
   FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
     const int k = bz + 1, n = g.nx * g.ny;
@@ -885,7 +886,8 @@ struct HeatApply {
           hs[o] = dtmp;
         }
       } else {
-        const double pz = exp(k1k * log(rdg * delp[o] / delz[c] * pt[o]));
+        const double ex = cappa ? cappa[o] / (1. - cappa[o]) : k1k;
+        const double pz = exp(ex * log(rdg * delp[o] / delz[c] * pt[o]));
         pkz[c] = pz;
         const double dtmp = hs[o] / (cv_air * delp[o]);
         pt[o] = pt[o] + fsign(dmin(delt, fabs(dtmp)), dtmp) / pz;

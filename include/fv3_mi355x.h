@@ -272,8 +272,9 @@ int fv3_geopk(fv3_ctx *ctx, double ptop, double akap, double cp_air, double ptk,
  * accum: heat_source += heat_s on the compute domain after every d_sw (d_con > 1e-5).
  * del2_cubed -- model/dyn_core.F90:2356: min(3, nmax) smoothing passes on shrinking boxes; the halo of q must be up
  *   to date on entry (the reference calls mpp_update_domains first, :2399); uses one context scratch slab.
- * apply: pt += sign(min(delt, |dT|), dT)/pkz etc. for k = 1..n_con (moist_kappa = .false.); nonhydrostatic: pkz is
- *   recomputed from delp, delz, pt (:1347); delz, pkz: CC x npz. */
+ * apply: pt += sign(min(delt, |dT|), dT)/pkz etc. for k = 1..n_con; nonhydrostatic: pkz is recomputed from delp, delz,
+ *   pt (:1347), with the exponent cappa/(1-cappa) when a cappa array is set (thermostruct%moist_kappa, :1338-1340:
+ *   fv3_set_condensate -- the array the Riemann solvers use); delz, pkz: CC x npz. */
 int fv3_heat_source_accum(fv3_ctx *ctx, double *heat_source, const double *heat_s);
 int fv3_del2_cubed(fv3_ctx *ctx, double *q, int nk, double cd, int nmax);
 int fv3_apply_heat_source(fv3_ctx *ctx, int n_con, int hydrostatic, double bdt, double delt_max, double cp_air,

@@ -168,7 +168,7 @@ int fvo_one_grad_p_hydro(const fvo_grid *g, int npz, double dt, double ptk, cons
 int fvo_del2_cubed(const fvo_grid *g, int km, double cd, int nmax, double *q);
 int fvo_apply_heat_source(const fvo_grid *g, int npz, int n_con, int hydrostatic, double bdt, double delt_max,
                           double cp_air, double cv_air, double rdgas, double grav, double *pt, double *heat_source,
-                          const double *delp, const double *delz, double *pkz);
+                          const double *delp, const double *delz, double *pkz, const double *cappa);
 int fvo_geopk(const fvo_grid *g, int km, double ptop, double akap, double cp_air, double *pe, double *peln,
               const double *delp, double *pk, double *gz, const double *hs, const double *pt, double *pkz, int CG);
 

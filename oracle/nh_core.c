@@ -669,11 +669,11 @@ int fvo_del2_cubed(const fvo_grid *g, int km, double cd, int nmax, double *q) {
 }
 
 /* Application of the dissipative heating after the substep loop, model/dyn_core.F90:1306-1355
- * (moist_kappa = .false.).  pt, delp, heat_source: A x npz; delz, pkz: CC x npz.  heat_source is overwritten
+ * cappa: A x npz (thermostruct%moist_kappa) or NULL.  pt, delp, heat_source: A x npz; delz, pkz: CC x npz.  heat_source is overwritten
  * with the applied rate where the reference does so. */
 int fvo_apply_heat_source(const fvo_grid *g, int npz, int n_con, int hydrostatic, double bdt, double delt_max,
                           double cp_air, double cv_air, double rdgas, double grav, double *pt, double *heat_source,
-                          const double *delp, const double *delz, double *pkz) {
+                          const double *delp, const double *delz, double *pkz, const double *cappa) {
   BOUNDS(g);
   int i, j, k;
   const double rdg = -rdgas / grav, k1k = rdgas / cv_air;
@@ -701,7 +701,12 @@ int fvo_apply_heat_source(const fvo_grid *g, int npz, int n_con, int hydrostatic
       for (j = js; j <= je; j++)
         for (i = is; i <= ie; i++) {
           const size_t c = (size_t)(k - 1) * nx * ny + ICC(i, j);
-          pkz[c] = exp(k1k * log(rdg * delp[A3(i, j, k)] / delz[c] * pt[A3(i, j, k)]));
+          if (cappa) { /* thermostruct%moist_kappa (:1338-1340) */
+            const double cap = cappa[A3(i, j, k)];
+            pkz[c] = exp(cap / (1. - cap) * log(rdg * delp[A3(i, j, k)] / delz[c] * pt[A3(i, j, k)]));
+          } else {
+            pkz[c] = exp(k1k * log(rdg * delp[A3(i, j, k)] / delz[c] * pt[A3(i, j, k)]));
+          }
           const double dtmp = heat_source[A3(i, j, k)] / (cv_air * delp[A3(i, j, k)]);
           pt[A3(i, j, k)] = pt[A3(i, j, k)] + copysign(fmin(delt, fabs(dtmp)), dtmp) / pkz[c];
           heat_source[A3(i, j, k)] = dtmp;

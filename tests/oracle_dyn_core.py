@@ -116,7 +116,8 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
         _fill(bd, f["heat_source"], "A")
         O.del2_cubed(g, npz, 0.20 * g.da_min, min(3, fl.nord + 1), f["heat_source"])
         O.apply_heat_source(g, npz, n_con, False, bdt, fl.delt_max, fl.cp_air, fl.cp_air - fl.rdgas, fl.rdgas, fl.grav,
-                            f["pt"], f["heat_source"], f["delp"], f["delz"], f["pkz"])
+                            f["pt"], f["heat_source"], f["delp"], f["delz"], f["pkz"],
+                            f["cappa"] if fl.moist_kappa else None)                      # :1338-1340
     return f
 
 

@@ -229,11 +229,11 @@ def del2_cubed(g, km, cd, nmax, q):
 
 
 def apply_heat_source(g, npz, n_con, hydrostatic, bdt, delt_max, cp_air, cv_air, rdgas, grav, pt, heat_source, delp, delz,
-                      pkz):
+                      pkz, cappa=None):
     gs = make_grid(g)
     assert lib().fvo_apply_heat_source(C.byref(gs), C.c_int(npz), C.c_int(n_con), C.c_int(int(hydrostatic)), _d(bdt),
                                        _d(delt_max), _d(cp_air), _d(cv_air), _d(rdgas), _d(grav), p(pt), p(heat_source),
-                                       p(delp), p(delz), p(pkz)) == 0
+                                       p(delp), p(delz), p(pkz), p(cappa) if cappa is not None else None) == 0
 
 
 def pe_halo(g, npz, ptop, pe, delp):

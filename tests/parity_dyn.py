@@ -169,7 +169,7 @@ def oracle_fv_step(g, npz, fl, dp0, st, ak, bk, q, bdt, k_split, remap_par, last
     return out
 
 
-def check_fv_cycle_moist(lib, nx=24, ny=16, npz=10, k_split=2, n_split=2, bdt=8.0, moist_kappa=True):
+def check_fv_cycle_moist(lib, nx=24, ny=16, npz=10, k_split=2, n_split=2, bdt=8.0, moist_kappa=True, flags=None):
     """A whole fv_dynamics call with use_cond (+ moist_kappa): T -> theta_m with moist_cv, q_con transported by d_sw and
     entering the Riemann solvers, moist remap, back to T on the last step.  Oracle side: the conversion in numpy, then
     the oracle-orchestrated loop."""
@@ -216,7 +216,7 @@ def check_fv_cycle_moist(lib, nx=24, ny=16, npz=10, k_split=2, n_split=2, bdt=8.
     sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
     dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
-    fl = DynFlags(n_split=n_split, ptop=N.PTOP, use_cond=True, moist_kappa=moist_kappa)
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, use_cond=True, moist_kappa=moist_kappa, **(flags or {}))
     ost = dict(st, pt=th2, q_con=q_con)
     if moist_kappa:
         ost["cappa"] = cappa

@@ -371,6 +371,11 @@ def test_fv_dynamics_call_moist(emu, moist_kappa):
     D.check_fv_cycle_moist(emu, moist_kappa=moist_kappa)
 
 
+def test_fv_dynamics_call_moist_heating(emu):
+    """the dissipative heating of dyn_core with moist_kappa: pkz from the per-cell cappa (dyn_core.F90:1338-1340)"""
+    D.check_fv_cycle_moist(emu, moist_kappa=True, flags=dict(d_con=1.0, do_vort_damp=True, vtdm4=0.06, nord=2))
+
+
 @pytest.mark.parametrize("nq", [2, 6])
 def test_remap_fillz(emu, nq):
     """flagstruct%fill: fillz (fv_fill.F90:34-137) on the remapped tracers, both tracer remap forms (nq <= 5, nq > 5)"""
