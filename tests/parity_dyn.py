@@ -97,11 +97,25 @@ def oracle_fv_step_hydro(g, npz, fl, st, ak, bk, q, bdt, k_split, remap_par):
     return out
 
 
-def check_fv_step_hydrostatic(lib, nx=24, ny=16, npz=10, nq=2, k_split=2, n_split=2, bdt=8.0):
+def check_fv_step_hydrostatic(lib, nx=24, ny=16, npz=10, nq=2, k_split=2, n_split=2, bdt=8.0, ic=None):
     from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     st, dp0 = make_state(bd, npz)
+    if ic == "test_case_1":
+        # the doubly periodic test_case = 1 of the reference's solo core (tools/test_cases.F90:4689-4711): u = v = 10,
+        # pt = 1, phis = 0, delp = 1 on i, j in 1..4 and 0 elsewhere -- here on a background of 1 (a
+        # layer without mass divides 0 by 0 in c_sw's ptc)
+        from gfdl_atmos_cubed_sphere_amd.layout import periodic_fill
+        st["u"][...] = 10.0
+        st["v"][...] = 10.0
+        st["pt"][...] = 1.0
+        st["phis"][...] = 0.0
+        st["delp"][...] = 1.0
+        ng = bd.ng
+        st["delp"][ng:ng + 4, ng:ng + 4, :] += 1.0
+        for k in range(npz):
+            periodic_fill(bd, st["delp"][:, :, k], "A")
     sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
     fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=True)

@@ -380,3 +380,9 @@ def test_fv_dynamics_call_moist_heating(emu):
 def test_remap_fillz(emu, nq):
     """flagstruct%fill: fillz (fv_fill.F90:34-137) on the remapped tracers, both tracer remap forms (nq <= 5, nq > 5)"""
     R.check_remap(emu, nq=nq, fill=True)
+
+
+def test_baseline_config1_test_case_1(emu):
+    """BASELINE configs[0]: doubly periodic 48 x 48 x 32, hydrostatic, the reference's test_case = 1 initial condition
+    (uniform flow carrying a block of mass): one dt_atmos of the k_split loop (substeps, tracer_2d, remap) vs the oracle"""
+    D.check_fv_step_hydrostatic(emu, nx=48, ny=48, npz=32, nq=1, k_split=1, n_split=3, bdt=6.0, ic="test_case_1")
