@@ -489,4 +489,5 @@ def test_baseline_config2_tile_shape(prod):
 def test_baseline_config1_test_case_1(prod):
     """BASELINE configs[0]: doubly periodic 48 x 48 x 32, hydrostatic, the reference's test_case = 1 initial condition
     (uniform flow carrying a block of mass): one dt_atmos of the k_split loop (substeps, tracer_2d, remap) vs the oracle"""
-    D.check_fv_step_hydrostatic(prod, nx=48, ny=48, npz=32, nq=1, k_split=1, n_split=3, bdt=6.0, ic="test_case_1")
+    D.check_fv_step_hydrostatic(prod, nx=48, ny=48, npz=32, nq=1, k_split=1, n_split=3, bdt=6.0, ic="test_case_1",
+                                uv_branch_flips=True)
