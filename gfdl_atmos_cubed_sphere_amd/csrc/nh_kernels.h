@@ -168,7 +168,7 @@ FV3_HD void sim_column(int km, size_t ls, size_t ss, const ColIn &in, double dt,
   double dm_c, dz_c, pm_c, pe_c, pem_n, peln_n;
   level(1, dm_c, dz_c, pm_c, pe_c, pem_n, peln_n);
   S(s_pm, 1) = pm_c;
-  double bet = 0., pp_k = 0., g_rat_prev = 0.;
+  double bet = 0., rbet = 0., pp_k = 0., g_rat_prev = 0.;
   S(s_pp, 1) = 0.;
   FV3_UNROLL4
   for (int k = 1; k <= km; k++) {
@@ -186,14 +186,18 @@ FV3_HD void sim_column(int km, size_t ls, size_t ss, const ColIn &in, double dt,
       bb = 2.;
       dd = 3. * pe_c;
     }
+    // every bet divides two numerators (pp of this level, g_rat of the next): one reciprocal, the quotients through it
+    // (correctly rounded: remap_kernels.h rcp_rn / div_rn)
     if (k == 1) {
       bet = bb;
-      pp_k = dd / bet;  // pp(2)
+      rbet = rcp_rn(bet);
+      pp_k = div_rn(dd, bet, rbet);  // pp(2)
     } else {
-      const double gam = g_rat_prev / bet;
+      const double gam = div_rn(g_rat_prev, bet, rbet);
       bet = bb - gam;
+      rbet = rcp_rn(bet);
       S(s_gam, k) = gam;
-      pp_k = (dd - pp_k) / bet;  // pp(k+1)
+      pp_k = div_rn(dd - pp_k, bet, rbet);  // pp(k+1)
     }
     S(s_pp, k + 1) = pp_k;
     g_rat_prev = g_rat;
@@ -243,20 +247,23 @@ FV3_HD void sim_column(int km, size_t ls, size_t ss, const ColIn &in, double dt,
       double w2;
       if (k == 1) {
         bet = dm2 - aa_n;
-        w2 = sim1 ? (dm2 * w1 + dt * pp_k1) / bet : (dm2 * w1 + dt * pp_k1 + wk_n) / bet;
+        rbet = rcp_rn(bet);
+        w2 = sim1 ? div_rn(dm2 * w1 + dt * pp_k1, bet, rbet) : div_rn(dm2 * w1 + dt * pp_k1 + wk_n, bet, rbet);
       } else if (k < km) {
-        const double gam = aa_k / bet;
+        const double gam = div_rn(aa_k, bet, rbet);
         bet = dm2 - (aa_k + aa_n + aa_k * gam);
+        rbet = rcp_rn(bet);
         S(s_gam, k) = gam;
-        w2 = sim1 ? (dm2 * w1 + dt * (pp_k1 - pp_k0) - aa_k * w_prev) / bet
-                  : (dm2 * w1 + dt * (pp_k1 - pp_k0) + wk_n - wk_k - aa_k * w_prev) / bet;
+        w2 = sim1 ? div_rn(dm2 * w1 + dt * (pp_k1 - pp_k0) - aa_k * w_prev, bet, rbet)
+                  : div_rn(dm2 * w1 + dt * (pp_k1 - pp_k0) + wk_n - wk_k - aa_k * w_prev, bet, rbet);
       } else {
         const double p1 = t1g * gm2_at(km) / dz2 * pem_next;  // pem(km+1)
-        const double gam = aa_k / bet;
+        const double gam = div_rn(aa_k, bet, rbet);
         bet = dm2 - (aa_k + p1 + aa_k * gam);
+        rbet = rcp_rn(bet);
         S(s_gam, k) = gam;
-        w2 = sim1 ? (dm2 * w1 + dt * (pp_k1 - pp_k0) - p1 * ws - aa_k * w_prev) / bet
-                  : (dm2 * w1 + dt * (pp_k1 - pp_k0) - wk_k + p1 * (t2 * w1 - ra * ws) - aa_k * w_prev) / bet;
+        w2 = sim1 ? div_rn(dm2 * w1 + dt * (pp_k1 - pp_k0) - p1 * ws - aa_k * w_prev, bet, rbet)
+                  : div_rn(dm2 * w1 + dt * (pp_k1 - pp_k0) - wk_k + p1 * (t2 * w1 - ra * ws) - aa_k * w_prev, bet, rbet);
       }
       S(s_w, k) = w2;
       w_prev = w2;
@@ -421,6 +428,8 @@ struct RiemSolver3 {
               return;
             }
             pem = pem + delp[(size_t)(k - 2) * nA + o];
+            // (log(pem) is also formed in the solver's first sweep; passing it through pk3 instead of recomputing it was
+            // measured: the extra store and load cost more than the log, 12.4 -> 13.5 ms per dt_atmos)
             const double pl = log(pem), pkv = exp(cn.akap * pl);
             pk3[(size_t)(k - 1) * nA + o] = use_logp ? pl : pkv;
             if (last_call) {
