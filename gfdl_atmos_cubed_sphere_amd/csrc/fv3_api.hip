@@ -546,7 +546,7 @@ extern "C" int fv3_fv_tp_2d(fv3_ctx *c, int nk, const double *q, const double *c
                             const double *ra_y, const double *mfx, const double *mfy, const double *mass, int nord,
                             double damp_c) {
   if (!c || !c->grid_ready) return fail("fv3_fv_tp_2d: context has no grid (call fv3_grid_upload)");
-  if (!tp_ord_supported(hord)) return fail("fv3_fv_tp_2d: hord=%d not supported (5,-5,6,8,10)", hord);
+  if (!tp_ord_supported_tr(hord)) return fail("fv3_fv_tp_2d: hord=%d not supported (5,-5,6,8,9,10,11,12,13)", hord);
   if (nord > 2) return fail("fv3_fv_tp_2d: nord=%d > 2", nord);
   if ((mfx == nullptr) != (mfy == nullptr)) return fail("fv3_fv_tp_2d: mfx and mfy must be given together");
   constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
@@ -631,6 +631,18 @@ static int dispatch_hord(int hord, Fn &&fn) {
     case 10: return fn(std::integral_constant<int, 10>());
   }
   return fail("unsupported hord %d", hord);
+}
+
+// tracer_2d also takes hord_tr = 9 / 13 (the same scheme), 11, 12: instantiated for the tracer kernels only
+template <class Fn>
+static int dispatch_hord_tr(int hord, Fn &&fn) {
+  switch (hord) {
+    case 9:
+    case 13: return fn(std::integral_constant<int, 9>());
+    case 11: return fn(std::integral_constant<int, 11>());
+    case 12: return fn(std::integral_constant<int, 12>());
+  }
+  return dispatch_hord(hord, fn);
 }
 
 static int ensure_mflux(fv3_ctx *c) {
@@ -1630,7 +1642,7 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
                                   const double *mfx, const double *mfy, const double *cx, const double *cy,
                                   const double *xfx, const double *yfx) {
   if (!c || !c->grid_ready || !ksplt_host) return fail("fv3_tracer_2d_step: bad context/arguments");
-  if (!tp_ord_supported(hord)) return fail("fv3_tracer_2d_step: hord=%d not supported (5,-5,6,8,10)", hord);
+  if (!tp_ord_supported_tr(hord)) return fail("fv3_tracer_2d_step: hord=%d not supported (5,-5,6,8,9,10,11,12,13)", hord);
   if (q == q_out || dp1 == dp1_out) return fail("fv3_tracer_2d_step: *_out buffers must not alias the inputs");
   if (trdm > 1.e-4 && nord_tr > 2) return fail("fv3_tracer_2d_step: nord_tr > 2");
   if (need_trc(c)) return 1;
@@ -1651,7 +1663,7 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
                                                     cy, xfx, yfx, q_out, dp1_out};
         return launch_w(c, "tracer_step", nwt, kf);
       };
-      return dispatch_hord(hord, [&](auto H) {
+      return dispatch_hord_tr(hord, [&](auto H) {
         const int nt = nq < trc_nt ? nq : trc_nt;
         if (nt == 4) return go(H, std::integral_constant<int, 4>{});
         if (nt == 3) return go(H, std::integral_constant<int, 3>{});
@@ -1660,7 +1672,7 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
     }
     MarchDims md = make_march_dims(g, seg_rows(c, c->march_tj, g.npz));
     const int nwt = md.nwaves(g.npz * nq);
-    return dispatch_hord(hord, [&](auto H) {
+    return dispatch_hord_tr(hord, [&](auto H) {
       TracerMarch<decltype(H)::value> kf{g, md, g.npz, nq, it, nsplt, c->trc_i, q, dp1, mfx, mfy, cx, cy, xfx, yfx,
                                          q_out, dp1_out};
       return launch_w(c, "tracer_step", nwt, kf);

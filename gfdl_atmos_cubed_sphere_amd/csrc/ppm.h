@@ -17,6 +17,9 @@
 namespace fv3 {
 
 inline bool tp_ord_supported(int iord) { return iord == 5 || iord == -5 || iord == 6 || iord == 8 || iord == 10; }
+// fv_tp_2d as a unit and tracer_2d also take the positive-definite / van Leer members of the monotone family:
+// 9 == 13 (unlimited + pert_ppm), 11 (ppm_fac slopes), 12 (Lin & Rood 1996 positive definite) -- tp_core.F90:604-641
+inline bool tp_ord_supported_tr(int iord) { return tp_ord_supported(iord) || iord == 9 || iord == 11 || iord == 12 || iord == 13; }
 inline bool sw_ord_supported(int iord) { return iord >= 5 && iord <= 11; }
 
 // monotone slope, tp_core.F90:570-574 == sw_core.F90:2383-2387.  s[0] is the cell.
@@ -43,6 +46,31 @@ FV3_HD double ppm_face_tp(const double *s, int st, double c, int iord, double li
       const double xt = 2. * dm0;
       bl = -fsign(dmin(fabs(xt), fabs(al0 - q0)), xt);
       br = fsign(dmin(fabs(xt), fabs(al1 - q0)), xt);
+    } else if (iord == 11) {  // :604-610, ppm_fac = 1.5
+      const double xt = 1.5 * dm0;
+      bl = -fsign(dmin(fabs(xt), fabs(al0 - q0)), xt);
+      br = fsign(dmin(fabs(xt), fabs(al1 - q0)), xt);
+    } else if (iord == 12 || iord == 9 || iord == 13) {  // :611-633 / :634-641 with pert_ppm(iv = 0), :1219-1242
+      bl = al0 - q0;
+      br = al1 - q0;
+      const bool pert = iord != 12;
+      if (pert && q0 <= 0.) {
+        bl = 0.;
+        br = 0.;
+      } else {
+        const double a4 = -3. * (bl + br), da1 = br - bl;
+        if (fabs(da1) < -a4 && q0 + 0.25 / a4 * (da1 * da1) + a4 * r12 < 0.) {
+          const bool both = pert ? (br > 0. && bl > 0.) : (br * bl > 0.);
+          if (both) {
+            br = 0.;
+            bl = 0.;
+          } else if (da1 > 0.) {
+            br = -2. * bl;
+          } else {
+            bl = -2. * br;
+          }
+        }
+      }
     } else {  // iord == 10, :585-603
       bl = al0 - q0;
       br = al1 - q0;

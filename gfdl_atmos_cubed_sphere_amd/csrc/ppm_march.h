@@ -50,6 +50,27 @@ FV3_D PCell ppm_cell_mono(const vd &qm2, const vd &qm1, const vd &q0, const vd &
     const vd xt = 2. * dm0;
     c.bl = -vsign(vmin(vabs(xt), vabs(al0 - q0)), xt);
     c.br = vsign(vmin(vabs(xt), vabs(al1 - q0)), xt);
+  } else if (ORD == 11) {  // :604-610, ppm_fac = 1.5
+    const vd xt = 1.5 * dm0;
+    c.bl = -vsign(vmin(vabs(xt), vabs(al0 - q0)), xt);
+    c.br = vsign(vmin(vabs(xt), vabs(al1 - q0)), xt);
+  } else if (ORD == 12 || ORD == 9) {  // :611-633 / :634-641 with pert_ppm(iv = 0), :1219-1242 (13 runs as 9)
+    constexpr double r12 = 1. / 12.;
+    const vd bl0 = al0 - q0, br0 = al1 - q0;
+    const vd a4 = -3. * (bl0 + br0), da1 = br0 - bl0;
+    // lanes that fail the first test may divide by a4 = 0: their value is not selected
+    const vb fix = (vabs(da1) < -a4) && (q0 + 0.25 / a4 * (da1 * da1) + a4 * r12 < 0.);
+    const vb both = (ORD == 9) ? ((br0 > 0.) && (bl0 > 0.)) : (br0 * bl0 > 0.);
+    const vb up = da1 > 0.;
+    vd bl = vsel(fix, vsel(both, vd(0.), vsel(up, bl0, -2. * br0)), bl0);
+    vd br = vsel(fix, vsel(both, vd(0.), vsel(up, -2. * bl0, br0)), br0);
+    if (ORD == 9) {
+      const vb empty = q0 <= 0.;
+      bl = vsel(empty, vd(0.), bl);
+      br = vsel(empty, vd(0.), br);
+    }
+    c.bl = bl;
+    c.br = br;
   } else {  // ORD == 10, :585-603
     constexpr double near_zero = 1.E-25;
     const vd bl0 = al0 - q0, br0 = al1 - q0;

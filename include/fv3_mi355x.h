@@ -88,7 +88,8 @@ int fv3_sync(fv3_ctx *ctx);
 /* fv_tp_2d -- model/tp_core.F90:85-87 (called from sw_core.F90:919,983,993,1014,1498,
  * nh_utils.F90:279,289, fv_tracer2d.F90:504,509).  nk slabs.  q: A; crx,xfx: CX; cry,yfx: CY;
  * ra_x: (is:ie, jsd:jed); ra_y: (isd:ied, js:je); fx,mfx: FX; fy,mfy: FY; mass: A.
- * Optional arguments are NULL / nord < 0 when absent. */
+ * Optional arguments are NULL / nord < 0 when absent.  hord: 5, -5, 6, 8, 9, 10, 11, 12, 13 (xppm / yppm, :365-641;
+ * d_sw and update_dz_d take 5, -5, 6, 8, 10). */
 int fv3_fv_tp_2d(fv3_ctx *ctx, int nk, const double *q, const double *crx, const double *cry, int hord,
                  double *fx, double *fy, const double *xfx, const double *yfx, const double *ra_x,
                  const double *ra_y, const double *mfx, const double *mfy, const double *mass, int nord,
@@ -348,7 +349,8 @@ int fv3_tracer_2d_prep(fv3_ctx *ctx, int q_split, const double *cx, const double
                        double *cmax_host /* npz, out */);
 int fv3_tracer_2d_scale(fv3_ctx *ctx, const double *frac_host /* npz */, double *cx, double *xfx, double *mfx,
                         double *cy, double *yfx, double *mfy);
-/* one sub-cycle `it` (1-based) of nsplt; q -> q_out and (if it != nsplt) dp1 -> dp1_out on the compute domain. */
+/* one sub-cycle `it` (1-based) of nsplt; q -> q_out and (if it != nsplt) dp1 -> dp1_out on the compute domain.
+ * hord (= hord_tr): as fv3_fv_tp_2d. */
 int fv3_tracer_2d_step(fv3_ctx *ctx, int it, int nsplt, const int *ksplt_host /* npz */, int nq, int hord,
                        int nord_tr, double trdm, const double *q, double *q_out, const double *dp1, double *dp1_out,
                        const double *mfx, const double *mfy, const double *cx, const double *cy, const double *xfx,

@@ -18,7 +18,7 @@ def prod():
     return L.load()  # raises if the HIP library is missing: no fallback
 
 
-@pytest.mark.parametrize("hord", [5, -5, 6, 8, 10])
+@pytest.mark.parametrize("hord", [5, -5, 6, 8, 10, 9, 11, 12, 13])
 def test_fv_tp_2d_plain(prod, hord):
     P.check_fv_tp_2d(prod, hord)
 
@@ -491,3 +491,12 @@ def test_baseline_config1_test_case_1(prod):
     (uniform flow carrying a block of mass): one dt_atmos of the k_split loop (substeps, tracer_2d, remap) vs the oracle"""
     D.check_fv_step_hydrostatic(prod, nx=48, ny=48, npz=32, nq=1, k_split=1, n_split=3, bdt=6.0, ic="test_case_1",
                                 uv_branch_flips=True)
+
+
+@pytest.mark.parametrize("hord", [9, 11, 12, 13])
+def test_tracer_2d_positive_definite_schemes(prod, hord):
+    """hord_tr = 9 / 13 (pert_ppm), 11 (ppm_fac slopes), 12 (Lin & Rood positive definite), tp_core.F90:604-641: the marching
+    kernels (one and three tracers per wavefront) and, with the first sub-cycle damped, the tile kernel"""
+    T.check_tracer_2d(prod, nq=4, hord=hord, big_courant=True)
+    T.check_tracer_2d(prod, nx=70, ny=21, npz=3, nq=1, hord=hord)
+    T.check_tracer_2d(prod, q_split=2, trdm=0.06, nord_tr=1, hord=hord)
