@@ -36,7 +36,7 @@ FV3_HD void scr_col(ColScr &c, int col, int fo, int km, size_t nA, int blocked) 
 
 FV3_HD bool kord_supported(int kord) {
   const int a = kord < 0 ? -kord : kord;
-  return a == 8 || a == 9 || a == 10 || a == 11 || a == 13;
+  return a == 8 || a == 9 || a == 10 || a == 11 || a == 13 || a == 14 || a == 15;
 }
 
 // cs_limiters for one cell (fv_operators.F90:1303-1378)
@@ -265,6 +265,12 @@ FV3_HD void cs_cell(const ProfCfg &pc, int k, double &a2v, double &a3v, double a
             a4v = 6. * a1v - 3. * (a2v + a3v);
           }
         }
+      } else if (ak == 14) {  // strict monotonicity constraint (:883-884 / :1267-1268)
+        a4v = 3. * (2. * a1v - (a2v + a3v));
+        cs_limit(e_k, a1v, a2v, a3v, a4v, 2);
+      } else if (ak == 15) {  // :885-886 / :1269-1270
+        a4v = 3. * (2. * a1v - (a2v + a3v));
+        cs_limit(false, a1v, a2v, a3v, a4v, 1);
       } else {  // 13
         a4v = 3. * (2. * a1v - (a2v + a3v));
       }
