@@ -1502,7 +1502,7 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   if (p->nq < 0 || p->nq > 64) return fail("fv3_lagrangian_to_eulerian: nq out of range");
   if (p->nq > 0 && (!kord_tr || !q)) return fail("fv3_lagrangian_to_eulerian: tracers need q and kord_tr");
   if (!kord_supported(p->kord_mt) || !kord_supported(p->kord_tm) || (!p->hydrostatic && !kord_supported(p->kord_wz)))
-    return fail("fv3_lagrangian_to_eulerian: |kord| must be one of 8,9,10,11,13,14,15");
+    return fail("fv3_lagrangian_to_eulerian: |kord| must be one of 8..15");
   if (!p->hydrostatic && p->kord_wz < 0)
     return fail("fv3_lagrangian_to_eulerian: kord_wz < 0 (iv=-3) reads an unset array element in the reference; not built");
   for (int n = 0; n < p->nq; n++)

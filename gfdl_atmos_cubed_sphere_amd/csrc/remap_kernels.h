@@ -36,7 +36,7 @@ FV3_HD void scr_col(ColScr &c, int col, int fo, int km, size_t nA, int blocked) 
 
 FV3_HD bool kord_supported(int kord) {
   const int a = kord < 0 ? -kord : kord;
-  return a == 8 || a == 9 || a == 10 || a == 11 || a == 13 || a == 14 || a == 15;
+  return a == 8 || a == 9 || a == 10 || a == 11 || a == 12 || a == 13 || a == 14 || a == 15;
 }
 
 // cs_limiters for one cell (fv_operators.F90:1303-1378)
@@ -75,7 +75,8 @@ FV3_HD void cs_limit(bool extm, double a1, double &a2, double &a3, double &a4, i
   }
 }
 
-// the unfused back-substitution + constraint + limiter sweeps (|kord| = 11 only)
+// the unfused back-substitution + constraint + limiter sweeps (|kord| = 11, 12: their limiters test the interface values
+// of both neighbouring cells)
 FV3_HD void profile_col_tail_unfused(const ColScr &c, int km, bool is_scalar, int iv, int ak, double qmin) {
   {  // back-substitution
     double qk = CS(q, km + 1);
@@ -125,6 +126,10 @@ FV3_HD void profile_col_tail_unfused(const ColScr &c, int km, bool is_scalar, in
   auto ext5 = [&](int k) {
     const double x0 = 2. * CS(a1, k) - (CS(q, k) + CS(q, k + 1));
     return fabs(x0) > fabs(CS(q, k) - CS(q, k + 1));
+  };
+  auto ext6 = [&](int k) {
+    const double x0 = 2. * CS(a1, k) - (CS(q, k) + CS(q, k + 1));
+    return fabs(3. * x0) > fabs(CS(q, k) - CS(q, k + 1));
   };
   for (int k = 1; k <= km; k++) {
     const double a1v = CS(a1, k);
@@ -180,6 +185,17 @@ FV3_HD void profile_col_tail_unfused(const ColScr &c, int km, bool is_scalar, in
         } else {
           a4v = 3. * (2. * a1v - (a2v + a3v));
         }
+      } else if (ak == 12) {  // post-AM4 case 10 (:835-866 / :1225-1256)
+        if (ext5(k)) {
+          if (ext5(k - 1) || ext5(k + 1)) {
+            a2v = a1v; a3v = a1v;
+          } else if (ext6(k - 1) || ext6(k + 1)) {
+            huynh();
+          }
+        } else if (ext6(k)) {
+          if (ext5(k - 1) || ext5(k + 1)) huynh();
+        }
+        a4v = 3. * (2. * a1v - (a2v + a3v));
       } else {  // 13
         a4v = 3. * (2. * a1v - (a2v + a3v));
       }
@@ -306,7 +322,7 @@ FV3_HD void cs_cell(const ProfCfg &pc, int k, double &a2v, double &a3v, double a
 template <class Src>
 FV3_HD ProfCfg profile_col(const ColScr &c, int km, bool is_scalar, double qs, int iv, int kord, double qmin, const Src &src) {
   const int ak = kord < 0 ? -kord : kord;
-  ProfCfg pc{km, iv, ak, is_scalar, qmin, ak != 11};
+  ProfCfg pc{km, iv, ak, is_scalar, qmin, ak != 11 && ak != 12};
 #define DP(k) (CS(pe1, (k) + 1) - CS(pe1, k))
   // ---- interface values: cubic spline tridiagonal, forward elimination ----
   if (iv == -2) {  // :572-595 / :941-964
@@ -374,7 +390,7 @@ FV3_HD ProfCfg profile_col(const ColScr &c, int km, bool is_scalar, double qs, i
     CS(q, km + 1) = qk;
   }
 #undef DP
-  if (ak == 11) {
+  if (ak == 11 || ak == 12) {
     profile_col_tail_unfused(c, km, is_scalar, iv, ak, qmin);
     return pc;
   }
@@ -978,7 +994,7 @@ struct RemapFields {
         bool side_by_side = nl > 1;
         for (int n = 0; n < nl; n++) {
           const int a = kord_tr[iq0 + n] < 0 ? -kord_tr[iq0 + n] : kord_tr[iq0 + n];
-          if (a == 11) side_by_side = false;  // |kord| = 11 keeps a2, a3, a4 in slabs (profile_col_tail_unfused)
+          if (a == 11 || a == 12) side_by_side = false;  // these keep a2, a3, a4 in slabs (profile_col_tail_unfused)
         }
         if (side_by_side) {
           ColScr cg = c;

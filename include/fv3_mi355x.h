@@ -311,7 +311,7 @@ int fv3_pt_to_theta_v(fv3_ctx *ctx, int hydrostatic, double zvir, double kappa, 
 
 /* ---- vertical remap ------------------------------------------------------------------------------------
  * Lagrangian_to_Eulerian -- model/fv_mapz.F90:56-64, call site model/fv_dynamics.F90:607.  Branches built:
- * remap_te=.false., use_cond=moist_kappa=.false., consv=0, fill=.false., |kord| in {8,9,10,11,13,14,15}, kord_wz>0.
+ * remap_te=.false., use_cond=moist_kappa=.false., consv=0, fill=.false., |kord| in 8..15, kord_wz>0.
  * All fields are updated in place (every column is independent): ps (A), pe (is-1:ie+1, npz+1, js-1:je+1),
  * delp, pt, w, omga (A x npz), q (A x npz x nq), u (U x npz), v (V x npz), delz, pkz (CC x npz),
  * pk (CC x (npz+1)), peln (is:ie, npz+1, js:je); ws (CC, in).  On return pt is theta_v again

@@ -94,7 +94,7 @@ static void cs_limiter_cell(int extm, double *a1, double *a2, double *a3, double
 int fvo_profile_column(int is_scalar, double qs, double *a4, const double *delp, int km, int iv, int kord, double qmin) {
   int k;
   const int ak = abs(kord);
-  if (!(ak == 8 || ak == 9 || ak == 10 || ak == 11 || ak == 13 || ak == 14 || ak == 15)) return FVO_ERR_UNSUPPORTED;
+  if (!(ak >= 8 && ak <= 15)) return FVO_ERR_UNSUPPORTED;
   if (!(iv == -2 || iv == -1 || iv == 0 || iv == 1)) return FVO_ERR_UNSUPPORTED;
   double *gam = dalloc(km + 3), *q = dalloc(km + 3);
   unsigned char *extm = (unsigned char *)calloc(km + 3, 1), *ext5 = (unsigned char *)calloc(km + 3, 1),
@@ -224,6 +224,18 @@ int fvo_profile_column(int is_scalar, double qs, double *a4, const double *delp,
       } else {
         A4(4, k) = 3. * (2. * A4(1, k) - (A4(2, k) + A4(3, k)));
       }
+    } else if (ak == 12) { /* post-AM4 case 10, :835-866 / :1225-1256 */
+      if (ext5[k]) {
+        if (ext5[k - 1] || ext5[k + 1]) {
+          A4(2, k) = A4(1, k);
+          A4(3, k) = A4(1, k);
+        } else if (ext6[k - 1] || ext6[k + 1]) {
+          HUYNH();
+        }
+      } else if (ext6[k]) {
+        if (ext5[k - 1] || ext5[k + 1]) HUYNH();
+      }
+      A4(4, k) = 3. * (2. * A4(1, k) - (A4(2, k) + A4(3, k)));
     } else if (ak == 14) { /* strict monotonicity constraint, :883-884 / :1267-1268 (a4(4) = 3*x0 from :703-711) */
       LIM(k, 2);
     } else if (ak == 15) { /* :885-886 / :1269-1270 */
