@@ -1,6 +1,6 @@
 // csw_march.h -- c_sw (model/sw_core.F90:79-488) as a wave-marching stencil (grid_type >= 3 branches).
 //
-// One wavefront owns 59 output columns (lanes 3..61 of a 64-column strip) of the box
+// One wavefront owns 58 output columns (lanes 3..60 of a 64-column strip) of the box
 // [is-1, ie+2] x [js-1, je+2] and marches along j.  Step t loads u(:, t), v(:, t-1), delp/pt/w(:, t-2) and
 // finishes row R = t-2 of the interpolated winds and row Q = t-3 of every output:
 //
@@ -22,7 +22,11 @@
 
 namespace fv3 {
 
-constexpr int kCswCols = 59;  // owned columns per strip: lanes 3..61
+// owned columns per strip: lanes 3..60.  Three lanes are needed on either side: ke(L-1) reaches utmp(L-3) on the left;
+// on the right the vc update at lane L takes vort(L+1) when the wind blows from there (:452-486), vort(L+1) needs
+// vc(L+1), and the 4-point interpolation vtmp(L+1) reads v(L+3).
+constexpr int kCswCols = 58;
+constexpr int kCswLast = 60;  // last owned lane
 
 inline MarchDims make_csw_dims(const Grid &g, int tj) {
   MarchDims d;
@@ -87,7 +91,7 @@ struct CswMarch {
     const vl cA = make_lanes(cl(g.isd - ilo, 0, kW - 1), cl(g.ied - ilo, 0, kW - 1));      // nid-wide rows
     const vl cV = make_lanes(cl(g.isd - ilo, 0, kW - 1), cl(g.ied + 1 - ilo, 0, kW - 1));  // (nid+1)-wide rows
     const int l0 = 3;
-    const int l2 = cl(ie + 2 - ilo, 0, kW - 3), l1 = cl(ie + 1 - ilo, 0, kW - 3);  // last owned lane: i <= ie+2 / ie+1
+    const int l2 = cl(ie + 2 - ilo, 0, kCswLast), l1 = cl(ie + 1 - ilo, 0, kCswLast);  // last owned lane: i <= ie+2 / ie+1
     const int jA = js - 1 + seg * md.tj;
     const int jB = (jA + md.tj - 1 < je + 2) ? jA + md.tj - 1 : je + 2;
     const bool nh = !a.hydrostatic;

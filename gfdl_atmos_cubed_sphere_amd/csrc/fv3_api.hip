@@ -113,12 +113,25 @@ static int fail(const char *fmt, ...) {
 
 extern "C" const char *fv3_last_error(void) { return g_err.c_str(); }
 
+// the event pair of a profiled launch; a failure is reported through fv3_last_error and leaks nothing
+static int prof_events(void **e0, void **e1) {
+  int rc = rt_event_create(e0);
+  if (rc) return fail("profiling event: %s", rt_errstr(rc));
+  rc = rt_event_create(e1);
+  if (rc) {
+    rt_event_destroy(*e0);
+    *e0 = nullptr;
+    return fail("profiling event: %s", rt_errstr(rc));
+  }
+  return 0;
+}
+
 // launch + optional event pair around it
 template <class F>
 static int launch_p(fv3_ctx *c, const char *label, Dim3 grid, size_t lds_doubles, const F &f) {
   void *e0 = nullptr, *e1 = nullptr;
   if (c->prof_on) {
-    if (rt_event_create(&e0) || rt_event_create(&e1)) return 1;
+    if (prof_events(&e0, &e1)) return 1;
     rt_event_record(e0, c->stream);
   }
   int rc = launch(grid, lds_doubles, c->stream, f);
@@ -133,7 +146,7 @@ template <int W = 0, class F>
 static int launch_c(fv3_ctx *c, const char *label, Dim3 grid, const F &f, int lanes = 0) {
   void *e0 = nullptr, *e1 = nullptr;
   if (c->prof_on) {
-    if (rt_event_create(&e0) || rt_event_create(&e1)) return 1;
+    if (prof_events(&e0, &e1)) return 1;
     rt_event_record(e0, c->stream);
   }
   int rc = launch_cols<W>(grid, c->stream, f, lanes);
@@ -148,7 +161,7 @@ template <class F>
 static int launch_w(fv3_ctx *c, const char *label, int nwaves, const F &f) {
   void *e0 = nullptr, *e1 = nullptr;
   if (c->prof_on) {
-    if (rt_event_create(&e0) || rt_event_create(&e1)) return 1;
+    if (prof_events(&e0, &e1)) return 1;
     rt_event_record(e0, c->stream);
   }
   int rc = launch_waves(nwaves, c->stream, f);
@@ -657,7 +670,11 @@ static int ensure_mflux(fv3_ctx *c) {
 // 2 = the frame around the interior box
 static bool dsw_has_interior(const fv3_ctx *c) {
   const MarchDims mf = make_march_dims(c->g, seg_rows(c, c->march_tj_fused, c->g.npz));
-  return mf.nstrips >= 3 && mf.nsegs >= 3;
+  // A strip's lanes reach 3 columns past the cells it owns and a segment 3 rows past its last row, so strip NS-2 /
+  // segment NG-2 stay clear of the halo only if the ragged last strip owns >= 3 cells and the last segment >= 3 rows;
+  // otherwise the whole domain is left to the 'rest' phase (no interior launch before the exchange has completed).
+  const int last_cols = c->g.nx - kStripCells * (mf.nstrips - 1), last_rows = c->g.ny - mf.tj * (mf.nsegs - 1);
+  return mf.nstrips >= 3 && mf.nsegs >= 3 && last_cols >= 3 && last_rows >= 3;
 }
 
 static int dsw_transport_march(fv3_ctx *c, const DswArgs &a, int region = 0) {

@@ -135,25 +135,25 @@ FV3_HD void sim_column(int km, size_t ls, size_t ss, const ColIn &in, double dt,
 #define L(p, k) (p)[(size_t)((k)-1) * ls]
 #define S(p, k) (p)[(size_t)((k)-1) * ss]   // scratch slabs: level stride ss (64 in per-wavefront blocks, see scr_col)
   // ---- pass A: pe(k), pm2(k); forward elimination for pp (:1297-1326) ----
-  double pem_k = cn.ptop, peln_k = log(cn.ptop);
+  double pem_k = cn.ptop, peln_k = dlog(cn.ptop);
   double peg_k = cn.ptop, pelng_k = peln_k;  // MOIST + q_con: dry-gas + vapour hydrostatic pressure and its log
   double z_top = L(in.zlev, 1);  // zlev(k) of the level being set up: each interface height is loaded once
   auto level = [&](int k, double &dm2, double &dz2, double &pm2, double &pe, double &pem_next, double &peln_next) {
     const double dmr = L(in.delp, k);
     pem_next = pem_k + dmr;
     if (c_grid) {
-      pm2 = dmr / log(pem_next / pem_k);  // nh_utils.F90:440
+      pm2 = dmr / dlog(pem_next / pem_k);  // nh_utils.F90:440
       peln_next = 0.;
     } else {
-      peln_next = log(pem_next);          // nh_core.F90:140,159
+      peln_next = dlog(pem_next);          // nh_core.F90:140,159
       pm2 = dmr / (peln_next - peln_k);
     }
     if (MOIST && in.qcon) {               // excluding the contribution from condensates
       const double peg_next = peg_k + dmr * (1. - L(in.qcon, k));
       if (c_grid) {
-        pm2 = (peg_next - peg_k) / log(peg_next / peg_k);      // nh_utils.F90:418,429
+        pm2 = (peg_next - peg_k) / dlog(peg_next / peg_k);      // nh_utils.F90:418,429
       } else {
-        const double pelng_next = log(peg_next);               // nh_core.F90:126-127
+        const double pelng_next = dlog(peg_next);               // nh_core.F90:126-127
         pm2 = (peg_next - peg_k) / (pelng_next - pelng_k);     // :148
         pelng_k = pelng_next;
       }
@@ -163,7 +163,7 @@ FV3_HD void sim_column(int km, size_t ls, size_t ss, const ColIn &in, double dt,
     const double z_bot = L(in.zlev, k + 1);
     dz2 = z_bot - z_top;
     z_top = z_bot;
-    pe = exp(gm2_at(k) * log(-dm2 / dz2 * rgas * L(in.pt, k))) - pm2;
+    pe = dexp(gm2_at(k) * dlog(-dm2 / dz2 * rgas * L(in.pt, k))) - pm2;
   };
   double dm_c, dz_c, pm_c, pe_c, pem_n, peln_n;
   level(1, dm_c, dz_c, pm_c, pe_c, pem_n, peln_n);
@@ -325,7 +325,7 @@ FV3_HD void sim_column(int km, size_t ls, size_t ss, const ColIn &in, double dt,
         pp_2 = pp_1;
         pp_1 = pp_0;
       }
-      on_dz(k, -dm2 * rgas * L(in.pt, k) * exp((cp2_at(k) - 1.) * log(dmax(cn.p_fac * pm2, p1 + pm2))));
+      on_dz(k, -dm2 * rgas * L(in.pt, k) * dexp((cp2_at(k) - 1.) * dlog(dmax(cn.p_fac * pm2, p1 + pm2))));
       dm_below = dm2;
     }
   }
@@ -400,7 +400,7 @@ struct RiemSolver3 {
     const int ncol = g.nx * g.ny;
     const size_t nA = g.nA(), nCC = g.nCC();
     const bool sim1 = cn.a_imp > 0.999;
-    const double peln1 = log(cn.ptop), ptk = exp(cn.akap * peln1);
+    const double peln1 = dlog(cn.ptop), ptk = dexp(cn.akap * peln1);
     FV3_COL_FOR(c, ncol) {
       const int i = g.is + c % g.nx, j = g.js + c / g.nx;
       const int o = g.iA(i, j), occ = g.iCC(i, j);
@@ -430,7 +430,7 @@ struct RiemSolver3 {
             pem = pem + delp[(size_t)(k - 2) * nA + o];
             // (log(pem) is also formed in the solver's first sweep; passing it through pk3 instead of recomputing it was
             // measured: the extra store and load cost more than the log, 12.4 -> 13.5 ms per dt_atmos)
-            const double pl = log(pem), pkv = exp(cn.akap * pl);
+            const double pl = dlog(pem), pkv = dexp(cn.akap * pl);
             pk3[(size_t)(k - 1) * nA + o] = use_logp ? pl : pkv;
             if (last_call) {
               peln[(size_t)(j - g.js) * g.nx * (km + 1) + (size_t)(k - 1) * g.nx + (i - g.is)] = pl;
@@ -747,7 +747,7 @@ struct Pk3Halo {
       double pet = ptop;
       for (int k = 1; k <= npz; k++) {
         pet = pet + delp[(size_t)(k - 1) * nA + o];
-        pk3[(size_t)k * nA + o] = use_logp ? log(pet) : exp(akap * log(pet));
+        pk3[(size_t)k * nA + o] = use_logp ? dlog(pet) : dexp(akap * dlog(pet));
       }
     }
   }
@@ -788,7 +788,7 @@ struct Geopk {  // geopk, dyn_core.F90:2202-2353 (use_cond = .false.)
     const int e = CG ? 1 : 2;
     const int w = g.nx + 2 * e, ncol = w * (g.ny + 2 * e);
     const size_t nA = g.nA(), nCC = g.nCC();
-    const double peln1 = log(ptop);
+    const double peln1 = dlog(ptop);
     FV3_COL_FOR(c, ncol) {
       const int i = g.is - e + c % w, j = g.js - e + c / w;
       const int o = g.iA(i, j);
@@ -802,8 +802,8 @@ struct Geopk {  // geopk, dyn_core.F90:2202-2353 (use_cond = .false.)
       if (in_pe) pe[pb] = ptop;
       for (int k = 2; k <= km + 1; k++) {
         p1d = p1d + delp[(size_t)(k - 2) * nA + o];
-        const double logp = log(p1d);
-        pk[(size_t)(k - 1) * nA + o] = exp(akap * logp);
+        const double logp = dlog(p1d);
+        pk[(size_t)(k - 1) * nA + o] = dexp(akap * logp);
         if (in_pe) pe[pb + (size_t)(k - 1) * (g.nx + 2)] = p1d;
         if (in_c) peln[lb + (size_t)(k - 1) * g.nx] = logp;
       }
@@ -896,7 +896,7 @@ struct HeatApply {
         }
       } else {
         const double ex = cappa ? cappa[o] / (1. - cappa[o]) : k1k;
-        const double pz = exp(ex * log(rdg * delp[o] / delz[c] * pt[o]));
+        const double pz = dexp(ex * dlog(rdg * delp[o] / delz[c] * pt[o]));
         pkz[c] = pz;
         const double dtmp = hs[o] / (cv_air * delp[o]);
         pt[o] = pt[o] + fsign(dmin(delt, fabs(dtmp)), dtmp) / pz;
@@ -1010,10 +1010,10 @@ struct PtToThetaV {  // fv_dynamics.F90:296-329, :379-399
         const double cap = mp.rdgas / (mp.rdgas + cvm / (1. + dp1));
         mp.q_con[o] = qc;
         mp.cappa[o] = cap;
-        pz = exp(cap * log(rdg * delp[o] * pt[o] * (1. + dp1) * (1. - qc) / delz[c]));
+        pz = dexp(cap * dlog(rdg * delp[o] * pt[o] * (1. + dp1) * (1. - qc) / delz[c]));
         pkz[c] = pz;
       } else {
-        pz = exp(kappa * log(rdg * delp[o] * pt[o] * (1. + dp1) / delz[c]));
+        pz = dexp(kappa * dlog(rdg * delp[o] * pt[o] * (1. + dp1) / delz[c]));
         pkz[c] = pz;
         if (mp.use_cond) qc = mp.q_con[o];
       }

@@ -860,7 +860,7 @@ struct RemapCoords {
         if (p.kord_tm < 0) {
           const double pl = peln[lnb + (size_t)(k - 1) * g.nx];
           pe1l[so] = pl;
-          pe2l[so] = (k == 1 || k == km + 1) ? pl : log(pe2k);
+          pe2l[so] = (k == 1 || k == km + 1) ? pl : dlog(pe2k);
         }
       }
     }
@@ -945,9 +945,9 @@ struct RemapFields {
                 const double cap = p.rdgas / (p.rdgas + cvm / (1. + p.r_vir * q[(size_t)(p.sphum - 1) * nA * km + o3]));
                 p.q_con[o3] = qc;
                 p.cappa[o3] = cap;
-                t = t * exp(cap / (1. - cap) * log(rrg * dpo / delz[(size_t)(k - 1) * nCC + occ] * t));
+                t = t * dexp(cap / (1. - cap) * dlog(rrg * dpo / delz[(size_t)(k - 1) * nCC + occ] * t));
               } else {
-                t = t * exp(k1k * log(rrg * dpo / delz[(size_t)(k - 1) * nCC + occ] * t));
+                t = t * dexp(k1k * dlog(rrg * dpo / delz[(size_t)(k - 1) * nCC + occ] * t));
               }
             }
           }
@@ -971,8 +971,8 @@ struct RemapFields {
           for (int k = 2; k <= km + 1; k++) CS(gam, k) = omga[(size_t)(k - 2) * nA + fo];  // pe3
           int k_next = 1;
           for (int n = 1; n <= km; n++) {
-            const double pn_t = (n == 1) ? PELN(1) : log(ak[n - 1] + bk[n - 1] * psfc);
-            const double pn_b = (n + 1 == km + 1) ? PELN(km + 1) : log(ak[n] + bk[n] * psfc);
+            const double pn_t = (n == 1) ? PELN(1) : dlog(ak[n - 1] + bk[n - 1] * psfc);
+            const double pn_b = (n + 1 == km + 1) ? PELN(km + 1) : dlog(ak[n] + bk[n] * psfc);
             const double mid = 0.5 * (pn_t + pn_b);
             for (int k = k_next; k <= km; k++) {
               const double e0 = PELN(k), e1 = PELN(k + 1);
@@ -1072,8 +1072,8 @@ struct RemapDelzFinal {
           pn_next = PELN(km + 1);
           pk_next = pk[(size_t)km * nCC + occ];
         } else {
-          pn_next = log(CS(pe2, k + 1));
-          pk_next = exp(akap * pn_next);
+          pn_next = dlog(CS(pe2, k + 1));
+          pk_next = dexp(akap * pn_next);
           PELN(k + 1) = pn_next;
           pk[(size_t)k * nCC + occ] = pk_next;
         }
@@ -1088,11 +1088,11 @@ struct RemapDelzFinal {
           const double cap = p.rdgas / (p.rdgas + cvm / (1. + p.r_vir * q[(size_t)(p.sphum - 1) * nA * km + o3]));
           p.q_con[o3] = qc;
           p.cappa[o3] = cap;
-          pkzv = exp((p.kord_tm < 0 ? cap : cap / (1. - cap)) * log(rrg * dp2 / delz[(size_t)(k - 1) * nCC + occ] * tv));
+          pkzv = dexp((p.kord_tm < 0 ? cap : cap / (1. - cap)) * dlog(rrg * dp2 / delz[(size_t)(k - 1) * nCC + occ] * tv));
         } else if (p.kord_tm < 0)
-          pkzv = exp(akap * log(rrg * dp2 / delz[(size_t)(k - 1) * nCC + occ] * tv));
+          pkzv = dexp(akap * dlog(rrg * dp2 / delz[(size_t)(k - 1) * nCC + occ] * tv));
         else
-          pkzv = exp(k1k * log(rrg * dp2 / delz[(size_t)(k - 1) * nCC + occ] * tv));
+          pkzv = dexp(k1k * dlog(rrg * dp2 / delz[(size_t)(k - 1) * nCC + occ] * tv));
         pkz[(size_t)(k - 1) * nCC + occ] = pkzv;
         double tnew = tv;
         if (p.kord_tm > 0) tnew = tnew * pkzv;  // :496-502

@@ -120,7 +120,7 @@ class FvDynamics:
                 self.dc.halo.update([(d["q_con"], "A")])                       # :464 / :487 (pack 11)
             if self.fl.moist_kappa:
                 self.dc.halo.update([(d["cappa"], "A")])                       # :465 / :488 (pack 12)
-            self.dc.run(mdt)                                                   # :493
+            self.dc.run(mdt, end_step=(n_map == self.k_split))                 # :493, last_step = (n_map == k_split)
             if self.nq:                                                        # :500-533
                 q, dp1, _ = tracer_2d(ctx, self.dc.halo, d["q"], d["q_nxt"], d["dp1"], d["dp1_nxt"], d["mfx"], d["mfy"],
                                       d["cx"], d["cy"], d["crx"], d["cry"], self.nq, self.fl.hord_tr, self.q_split,

@@ -158,6 +158,13 @@ class HaloExchanger:
             grp = self._groups[key] = (send, recv, [self._tensor(b) for b in send], [self._tensor(b) for b in recv])
         return grp
 
+    def _launch_stream(self):
+        """torch's handle of the stream the pack / unpack kernels are launched on (the context's, fv3_set_stream): the
+        'packed' event, the P2P ops and their wait() are all ordered against THIS stream, whatever torch's current one is."""
+        import torch
+        s = getattr(self.ctx, "stream", 0)
+        return torch.cuda.ExternalStream(s) if s else torch.cuda.default_stream()
+
     @property
     def overlaps(self) -> bool:
         """True when start()/finish() leave a window in which transfers are in flight (several ranks): callers split
@@ -196,7 +203,7 @@ class HaloExchanger:
             if defer and p2p and not getattr(self.ctx.lib, "host_memory", False):
                 import torch
                 entry["packed"] = torch.cuda.Event()
-                entry["packed"].record(torch.cuda.current_stream())
+                entry["packed"].record(self._launch_stream())
             else:
                 self._post(entry)
             pending.append(entry)
@@ -215,8 +222,12 @@ class HaloExchanger:
             self._comm_stream.wait_event(entry["packed"])
             with torch.cuda.stream(self._comm_stream):
                 entry["works"] = dist.batch_isend_irecv(entry["p2p"])
+        elif getattr(self.ctx.lib, "host_memory", False):
+            entry["works"] = dist.batch_isend_irecv(entry["p2p"])   # harness build: gloo on host buffers
         else:
-            entry["works"] = dist.batch_isend_irecv(entry["p2p"])   # ncclGroupStart ... ncclGroupEnd on RCCL
+            import torch
+            with torch.cuda.stream(self._launch_stream()):         # RCCL orders its stream after the pack kernel's
+                entry["works"] = dist.batch_isend_irecv(entry["p2p"])   # ncclGroupStart ... ncclGroupEnd on RCCL
 
     def post(self, pending):
         """Issue the messages of a start(..., defer=True) handle (no-op for the ones already posted)."""
@@ -231,8 +242,14 @@ class HaloExchanger:
             return
         for entry in pending:
             self._post(entry)
-            for w in entry["works"]:
-                w.wait()
+            if entry["works"] and not getattr(self.ctx.lib, "host_memory", False):
+                import torch
+                with torch.cuda.stream(self._launch_stream()):     # the unpack kernel's stream waits for the transfers
+                    for w in entry["works"]:
+                        w.wait()
+            else:
+                for w in entry["works"]:
+                    w.wait()
             self.ctx.halo_unpack(entry["part"], entry["recv"])
 
     def update(self, fields):

@@ -212,6 +212,7 @@ class Context:
         d.stretched_grid, d.lim_fac = int(grid.stretched_grid), grid.lim_fac
         self.h = _vp()
         self.lib.check(self.lib.dll.fv3_create(C.byref(d), C.byref(self.h)), "fv3_create")
+        self.stream = 0
         if stream is not None:
             self.set_stream(stream)
         gh = _GridHost()
@@ -226,6 +227,7 @@ class Context:
 
     # -- plumbing ------------------------------------------------------------------------------
     def set_stream(self, stream: int):
+        self.stream = int(stream or 0)      # raw hipStream_t of every launch of this context (0 = the null stream)
         self.lib.check(self.lib.dll.fv3_set_stream(self.h, _vp(stream)), "fv3_set_stream")
 
     def sync(self):

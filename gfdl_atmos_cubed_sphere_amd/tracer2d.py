@@ -13,6 +13,9 @@ def tracer_2d(ctx, halo, q, q_nxt, dp1, dp1_nxt, mfx, mfy, cx, cy, xfx, yfx, nq:
     npz = ctx.npz
     cmax = ctx.tracer_2d_prep(q_split, cx, cy, xfx, yfx)                      # :362-400
     if q_split == 0:
+        if dist is None and getattr(halo, "world", 1) > 1:
+            # without the reduction the ranks would sub-cycle differently and post mismatching q exchanges
+            raise ValueError("tracer_2d on several ranks needs the process group (dist=) for mp_reduce_max(cmax)")
         if dist is not None:                                                   # mp_reduce_max(cmax, npz), :405
             import torch
             t = torch.from_numpy(cmax.copy())

@@ -300,7 +300,7 @@ int fv3_rayleigh_apply(fv3_ctx *ctx, int kmax, int conserve, int hydrostatic, do
                        double *v, double *w);
 
 /* ---- fv_dynamics: T -> theta_v before the k_split loop (model/fv_dynamics.F90:284-329, :379-399; use_cond =
- * moist_kappa = .false.).  nonhydrostatic: pkz = exp(kappa*log(rdg*delp*pt*(1+zvir*qv)/delz)) is (re)computed;
+ * moist_kappa = .false. unless fv3_set_moist says otherwise).  nonhydrostatic: pkz = exp(kappa*log(rdg*delp*pt*(1+zvir*qv)/delz)) is (re)computed;
  * hydrostatic: pkz is taken as given (p_var / the previous remap).  Then pt = pt*(1+zvir*qv)/pkz on the compute
  * domain.  hydrostatic = -1: only pkz is computed and pt is left alone -- the reference evaluates pkz (:323-326) before
  * Rayleigh_Friction changes T and delz and converts afterwards with that pkz (:389-397): call with -1, apply the
@@ -311,7 +311,8 @@ int fv3_pt_to_theta_v(fv3_ctx *ctx, int hydrostatic, double zvir, double kappa, 
 
 /* ---- vertical remap ------------------------------------------------------------------------------------
  * Lagrangian_to_Eulerian -- model/fv_mapz.F90:56-64, call site model/fv_dynamics.F90:607.  Branches built:
- * remap_te=.false., use_cond=moist_kappa=.false., consv=0, fill=.false., |kord| in 8..15, kord_wz>0.
+ * remap_te=.false., consv=0, |kord| in 8..15, kord_wz>0; use_cond / moist_kappa through fv3_set_moist below,
+ * flagstruct%fill through fv3_remap_params.fill.
  * All fields are updated in place (every column is independent): ps (A), pe (is-1:ie+1, npz+1, js-1:je+1),
  * delp, pt, w, omga (A x npz), q (A x npz x nq), u (U x npz), v (V x npz), delz, pkz (CC x npz),
  * pk (CC x (npz+1)), peln (is:ie, npz+1, js:je); ws (CC, in).  On return pt is theta_v again

@@ -111,3 +111,14 @@ int fvo_rayleigh_apply(const fvo_grid *g, int kmax, int conserve, int hydrostati
   }
   return FVO_OK;
 }
+
+/* The shared deterministic exp / log (include/fv3_math.h) over arrays: lets the Python side of the tests
+ * form pressure powers with the same operation sequence as the kernels under test. */
+int fvo_exp_n(const double *x, double *y, long n) {
+  for (long i = 0; i < n; i++) y[i] = fv3_exp(x[i]);
+  return FVO_OK;
+}
+int fvo_log_n(const double *x, double *y, long n) {
+  for (long i = 0; i < n; i++) y[i] = fv3_log(x[i]);
+  return FVO_OK;
+}

@@ -33,6 +33,8 @@
 #define FVO_H
 
 #include <stddef.h>
+/* exp / log: the deterministic pair shared with the HIP kernels (include/fv3_math.h explains why) */
+#include "../include/fv3_math.h"
 
 #ifdef __cplusplus
 extern "C" {

@@ -455,11 +455,11 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
               const double qv = q[(size_t)(p->sphum - 1) * nA * km + IA3(i, j, k)];
               q_con[IA3(i, j, k)] = qc;
               cappa[IA3(i, j, k)] = p->rdgas / (p->rdgas + cvm / (1. + p->r_vir * qv));
-              pt[IA3(i, j, k)] = pt[IA3(i, j, k)] * exp(cappa[IA3(i, j, k)] / (1. - cappa[IA3(i, j, k)]) *
-                                                      log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
+              pt[IA3(i, j, k)] = pt[IA3(i, j, k)] * fv3_exp(cappa[IA3(i, j, k)] / (1. - cappa[IA3(i, j, k)]) *
+                                                      fv3_log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
             } else
               pt[IA3(i, j, k)] = pt[IA3(i, j, k)] *
-                                 exp(k1k * log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
+                                 fv3_exp(k1k * fv3_log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
           }
         }
         if (!p->hydrostatic)
@@ -473,8 +473,8 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
         pk2[1] = pk[ICC3(i, j, 1)];
         pk2[km + 1] = pk[ICC3(i, j, km + 1)];
         for (k = 2; k <= km; k++) {
-          pn2[k] = log(pe2[k]);
-          pk2[k] = exp(akap * pn2[k]);
+          pn2[k] = fv3_log(pe2[k]);
+          pk2[k] = fv3_exp(akap * pn2[k]);
         }
         /* 1) remap Tv / thetav, :362-376 */
         for (k = 1; k <= km; k++) c1[k] = pt[IA3(i, j, k)];
@@ -522,12 +522,12 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
             const double cap = p->rdgas / (p->rdgas + cvm / (1. + p->r_vir * qv));
             q_con[IA3(i, j, k)] = qc;
             cappa[IA3(i, j, k)] = cap;
-            pkz[ICC3(i, j, k)] = exp((p->kord_tm < 0 ? cap : cap / (1. - cap)) *
-                                     log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
+            pkz[ICC3(i, j, k)] = fv3_exp((p->kord_tm < 0 ? cap : cap / (1. - cap)) *
+                                     fv3_log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
           } else if (p->kord_tm < 0)
-            pkz[ICC3(i, j, k)] = exp(akap * log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
+            pkz[ICC3(i, j, k)] = fv3_exp(akap * fv3_log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
           else
-            pkz[ICC3(i, j, k)] = exp(k1k * log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
+            pkz[ICC3(i, j, k)] = fv3_exp(k1k * fv3_log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
         }
         if (p->kord_tm > 0)
           for (k = 1; k <= km; k++) pt[IA3(i, j, k)] = pt[IA3(i, j, k)] * pkz[ICC3(i, j, k)];

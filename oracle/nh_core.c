@@ -116,7 +116,7 @@ static void sim1_column(int km, double dt, double rgas, const double *gm2, const
   double p1, bet;
   const double t1g = 2. * dt * dt, rdt = 1. / dt;
   for (k = 1; k <= km; k++) {
-    pe[k] = exp(gm2[k] * log(-dm2[k] / dz2[k] * rgas * pt2[k])) - pm2[k];
+    pe[k] = fv3_exp(gm2[k] * fv3_log(-dm2[k] / dz2[k] * rgas * pt2[k])) - pm2[k];
     w1[k] = w2[k];
   }
   for (k = 1; k <= km - 1; k++) {
@@ -151,10 +151,10 @@ static void sim1_column(int km, double dt, double rgas, const double *gm2, const
   pe[1] = 0.;
   for (k = 1; k <= km; k++) pe[k + 1] = pe[k] + dm2[k] * (w2[k] - w1[k]) * rdt;
   p1 = (pe[km] + 2. * pe[km + 1]) * r3;
-  dz2[km] = -dm2[km] * rgas * pt2[km] * exp((cp2[km] - 1.) * log(dmax(p_fac * pm2[km], p1 + pm2[km])));
+  dz2[km] = -dm2[km] * rgas * pt2[km] * fv3_exp((cp2[km] - 1.) * fv3_log(dmax(p_fac * pm2[km], p1 + pm2[km])));
   for (k = km - 1; k >= 1; k--) {
     p1 = (pe[k] + bb[k] * pe[k + 1] + g_rat[k] * pe[k + 2]) * r3 - g_rat[k] * p1;
-    dz2[k] = -dm2[k] * rgas * pt2[k] * exp((cp2[k] - 1.) * log(dmax(p_fac * pm2[k], p1 + pm2[k])));
+    dz2[k] = -dm2[k] * rgas * pt2[k] * fv3_exp((cp2[k] - 1.) * fv3_log(dmax(p_fac * pm2[k], p1 + pm2[k])));
   }
   free(aa); free(bb); free(dd); free(w1); free(g_rat); free(gam); free(pp);
 }
@@ -171,7 +171,7 @@ static void sim_column(int km, double dt, double rgas, const double *gm2, const 
                rdt = 1. / dt;
   for (k = 1; k <= km; k++) {
     w1[k] = w2[k];
-    pe2[k] = exp(gm2[k] * log(-dm2[k] / dz2[k] * rgas * pt2[k])) - pm2[k];
+    pe2[k] = fv3_exp(gm2[k] * fv3_log(-dm2[k] / dz2[k] * rgas * pt2[k])) - pm2[k];
   }
   for (k = 1; k <= km - 1; k++) {
     g_rat[k] = dm2[k] / dm2[k + 1];
@@ -210,10 +210,10 @@ static void sim_column(int km, double dt, double rgas, const double *gm2, const 
   pe2[1] = 0.;
   for (k = 1; k <= km; k++) pe2[k + 1] = pe2[k] + (dm2[k] * (w2[k] - w1[k]) * rdt - beta * (pp[k + 1] - pp[k])) * ra;
   p1 = (pe2[km] + 2. * pe2[km + 1]) * r3;
-  dz2[km] = -dm2[km] * rgas * pt2[km] * exp((cp2[km] - 1.) * log(dmax(p_fac * pm2[km], p1 + pm2[km])));
+  dz2[km] = -dm2[km] * rgas * pt2[km] * fv3_exp((cp2[km] - 1.) * fv3_log(dmax(p_fac * pm2[km], p1 + pm2[km])));
   for (k = km - 1; k >= 1; k--) {
     p1 = (pe2[k] + bb[k] * pe2[k + 1] + g_rat[k] * pe2[k + 2]) * r3 - g_rat[k] * p1;
-    dz2[k] = -dm2[k] * rgas * pt2[k] * exp((cp2[k] - 1.) * log(dmax(p_fac * pm2[k], p1 + pm2[k])));
+    dz2[k] = -dm2[k] * rgas * pt2[k] * fv3_exp((cp2[k] - 1.) * fv3_log(dmax(p_fac * pm2[k], p1 + pm2[k])));
   }
   for (k = 1; k <= km + 1; k++) pe2[k] = pe2[k] + beta * (pp[k] - pe2[k]);
   free(aa); free(bb); free(dd); free(w1); free(wk); free(g_rat); free(gam); free(pp);
@@ -249,9 +249,9 @@ int fvo_riem_solver_c(const fvo_grid *g, int km, double dt, double akap, double 
       for (k = 1; k <= km; k++) {
         dz2[k] = gz[A3(i, j, k + 1)] - gz[A3(i, j, k)];
         if (q_con)
-          pm2[k] = (peg[k + 1] - peg[k]) / log(peg[k + 1] / peg[k]);
+          pm2[k] = (peg[k + 1] - peg[k]) / fv3_log(peg[k + 1] / peg[k]);
         else
-          pm2[k] = dm[k] / log(pem[k + 1] / pem[k]);
+          pm2[k] = dm[k] / fv3_log(pem[k + 1] / pem[k]);
         cp2[k] = (q_con && cappa) ? cappa[A3(i, j, k)] : akap;
         gm2[k] = 1. / (1. - cp2[k]);
         dm[k] = dm[k] * rgrav;
@@ -281,8 +281,8 @@ int fvo_riem_solver3(const fvo_grid *g, int km, double dt, double akap, double p
   int j;
   if (a_imp <= 0.5) return FVO_ERR_UNSUPPORTED;
   const double rgrav = 1. / grav;
-  const double peln1 = log(ptop);
-  const double ptk = exp(akap * peln1);
+  const double peln1 = fv3_log(ptop);
+  const double ptk = fv3_exp(akap * peln1);
 #pragma omp parallel for schedule(dynamic)
   for (j = js; j <= je; j++) {
     int i, k;
@@ -301,12 +301,12 @@ int fvo_riem_solver3(const fvo_grid *g, int km, double dt, double akap, double p
       pelng[1] = peln1;
       for (k = 2; k <= km + 1; k++) {
         pem[k] = pem[k - 1] + dm[k - 1];
-        peln2[k] = log(pem[k]);
+        peln2[k] = fv3_log(pem[k]);
         if (q_con) { /* excluding the contribution from condensates, :125-127 */
           peg[k] = peg[k - 1] + dm[k - 1] * (1. - q_con[A3(i, j, k - 1)]);
-          pelng[k] = log(peg[k]);
+          pelng[k] = fv3_log(peg[k]);
         }
-        pk3[A3(i, j, k)] = exp(akap * peln2[k]);
+        pk3[A3(i, j, k)] = fv3_exp(akap * peln2[k]);
       }
       for (k = 1; k <= km; k++) {
         if (q_con)
@@ -552,7 +552,7 @@ int fvo_pk3_halo(const fvo_grid *g, int npz, double ptop, double akap, double *p
       pet = ptop;
       for (k = 1; k <= npz; k++) {
         pet = pet + delp[A3(i, j, k)];
-        pk3[A3(i, j, k + 1)] = use_logp ? log(pet) : exp(akap * log(pet));
+        pk3[A3(i, j, k + 1)] = use_logp ? fv3_log(pet) : fv3_exp(akap * fv3_log(pet));
       }
     }
   }
@@ -563,7 +563,7 @@ int fvo_pk3_halo(const fvo_grid *g, int npz, double ptop, double akap, double *p
       pet = ptop;
       for (k = 1; k <= npz; k++) {
         pet = pet + delp[A3(i, j, k)];
-        pk3[A3(i, j, k + 1)] = use_logp ? log(pet) : exp(akap * log(pet));
+        pk3[A3(i, j, k + 1)] = use_logp ? fv3_log(pet) : fv3_exp(akap * fv3_log(pet));
       }
     }
   }
@@ -601,7 +601,7 @@ int fvo_geopk(const fvo_grid *g, int km, double ptop, double akap, double cp_air
               const double *delp, double *pk, double *gz, const double *hs, const double *pt, double *pkz, int CG) {
   BOUNDS(g);
   int j;
-  const double peln1 = log(ptop);
+  const double peln1 = fv3_log(ptop);
   const double ptk = pow(ptop, akap); /* dyn_core.F90:222 (the one place the reference uses **) */
   const int ifirst = CG ? is - 1 : is - 2, ilast = CG ? ie + 1 : ie + 2;
   const int jfirst = CG ? js - 1 : js - 2, jlast = CG ? je + 1 : je + 2;
@@ -618,8 +618,8 @@ int fvo_geopk(const fvo_grid *g, int km, double ptop, double akap, double cp_air
       if (j > js - 2 && j < je + 2 && i >= is - 1 && i <= ie + 1) PE(i, 1, j) = ptop;
       for (k = 2; k <= km + 1; k++) {
         p1d = p1d + delp[A3(i, j, k - 1)];
-        logp = log(p1d);
-        pk[A3(i, j, k)] = exp(akap * logp);
+        logp = fv3_log(p1d);
+        pk[A3(i, j, k)] = fv3_exp(akap * logp);
         if (j > js - 2 && j < je + 2) {
           if (i >= is - 1 && i <= ie + 1) PE(i, k, j) = p1d;
           if (j >= js && j <= je && i >= is && i <= ie) PELN(i, k, j) = logp;
@@ -703,9 +703,9 @@ int fvo_apply_heat_source(const fvo_grid *g, int npz, int n_con, int hydrostatic
           const size_t c = (size_t)(k - 1) * nx * ny + ICC(i, j);
           if (cappa) { /* thermostruct%moist_kappa (:1338-1340) */
             const double cap = cappa[A3(i, j, k)];
-            pkz[c] = exp(cap / (1. - cap) * log(rdg * delp[A3(i, j, k)] / delz[c] * pt[A3(i, j, k)]));
+            pkz[c] = fv3_exp(cap / (1. - cap) * fv3_log(rdg * delp[A3(i, j, k)] / delz[c] * pt[A3(i, j, k)]));
           } else {
-            pkz[c] = exp(k1k * log(rdg * delp[A3(i, j, k)] / delz[c] * pt[A3(i, j, k)]));
+            pkz[c] = fv3_exp(k1k * fv3_log(rdg * delp[A3(i, j, k)] / delz[c] * pt[A3(i, j, k)]));
           }
           const double dtmp = heat_source[A3(i, j, k)] / (cv_air * delp[A3(i, j, k)]);
           pt[A3(i, j, k)] = pt[A3(i, j, k)] + copysign(fmin(delt, fabs(dtmp)), dtmp) / pkz[c];

@@ -66,6 +66,23 @@ def lib():
     return _LIB
 
 
+def _map(fn, x):
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    y = np.empty_like(x)
+    fn(x.ctypes.data_as(_dp), y.ctypes.data_as(_dp), C.c_long(x.size))
+    return y
+
+
+def fexp(x):
+    """element-wise fv3_exp (include/fv3_math.h): the exp of the kernels and of the oracle"""
+    return _map(lib().fvo_exp_n, x)
+
+
+def flog(x):
+    """element-wise fv3_log"""
+    return _map(lib().fvo_log_n, x)
+
+
 def p(a):
     """double* of a Fortran-ordered float64 array (None -> NULL)."""
     if a is None:

@@ -134,6 +134,18 @@ def degenerate_state(bd, npz, hydrostatic, kind):
             a[...] = base * (1.0 + 0.25 * (((i // 5) + (j // 4)) % 2))
         elif kind == "checker":
             a[...] = base * (1.0 + 0.1 * ((i + j) % 2))
+        elif kind == "westward":            # every wind reversed: the upwind side is the OTHER neighbour everywhere
+            if n in ("u", "v", "w"):
+                a[...] = -smooth_state(bd, npz, hydrostatic=hydrostatic)[n]
+            else:
+                a[...] = smooth_state(bd, npz, hydrostatic=hydrostatic)[n]
+        elif kind == "swirl":               # winds of both signs, sign changes every few cells in x and in y
+            full = smooth_state(bd, npz, hydrostatic=hydrostatic)[n]
+            if n in ("u", "v"):
+                ph = 0.0 if n == "u" else 1.3
+                a[...] = 9.0 * np.sin(2 * np.pi * (i / 7.3 + j / 5.1) + ph) + (full - np.mean(full)) * 0.3
+            else:
+                a[...] = full
         for k in range(npz):
             periodic_fill(bd, a[:, :, k], stag, fill_edge=True)
     return st
@@ -213,7 +225,20 @@ def check_d_sw(lib, nx=40, ny=19, npz=4, hydrostatic=False, perturb=True, par_ov
                 None if hydrostatic else out["w_out"], out["q_con_out"] if use_cond else None, out["heat_s"],
                 out["diss_e"])
         if phases:   # the halo-overlap form: interior strips / segments first, then the rest
+            if phases == "poison":
+                # the exchange of uc, vc is in flight during 'interior' (dyn_core.F90:565-578): their halos hold junk until
+                # 'rest'.  The interior launch must not read them (ragged last strips / segments are the trap).
+                ng, keep = bd.ng, {}
+                for n in ("uc", "vc"):
+                    h = inp[n].copy(order="F")
+                    core = h[ng:ng + nx + (n == "uc"), ng:ng + ny + (n == "vc"), :].copy()
+                    h[...] = 1.0e30
+                    h[ng:ng + nx + (n == "uc"), ng:ng + ny + (n == "vc"), :] = core
+                    d[n].upload(h)
             ctx.d_sw(*args, phase="interior")
+            if phases == "poison":
+                for n in ("uc", "vc"):
+                    d[n].upload(inp[n])
             ctx.d_sw(*args, phase="rest")
         else:
             ctx.d_sw(*args)

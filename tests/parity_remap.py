@@ -93,7 +93,7 @@ def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=Fal
         ctx.lagrangian_to_eulerian(par, d["ps"], d["pe"], d["delp"], d["pkz"], d["pk"], d["u"], d["v"],
                                    None if hydrostatic else d["w"], None if hydrostatic else d["delz"], d["pt"],
                                    d.get("q"), d["peln"], d["omga"], None if hydrostatic else d["ws"])
-        tol = 1e-14 if "hostemu" in lib.path else 1e-12
+        tol = 1e-14
         r = (bd.is_, bd.ie, bd.js, bd.je)
         names = [("pt", "A", r), ("delp", "A", r), ("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)),
                  ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)), ("ps", "A", r)]

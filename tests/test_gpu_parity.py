@@ -102,7 +102,7 @@ def test_halo_fill_periodic(prod):
     P.check_halo_periodic(prod)
 
 
-# ---- nonhydrostatic column path (exp/log differ between glibc and the device library: tol 1e-12) ----
+# ---- nonhydrostatic column path (one shared exp / log: same bound as the stencils) ----
 import parity_nh as N
 
 
@@ -171,11 +171,12 @@ import parity_remap as R
                                                                     (True, True, 10, 11, 3), (False, True, -10, 13, 2),
                                                                     (False, True, -14, 14, 3), (True, False, 15, 15, 7),
                                                                     (False, False, -15, 14, 6), (False, True, 12, 12, 4),
-                                                                    (True, False, 12, 12, 7)])
+                                                                    (True, False, 12, 12, 7), (False, True, -11, 11, 3),
+                                                                    (True, False, -11, 11, 2), (False, False, -12, 12, 3),
+                                                                    (True, True, -12, 12, 2)])
 def test_remap(prod, hydrostatic, last_step, kord_tm, kord, nq):
-    # |kord| = 11, 12 with kord_tm < 0 are left to the harness suite: their limiters test |x0| > x1, which is an exact tie
-    # wherever the constrained interface value equals the layer mean, and the transformed temperature differs by an ulp
-    # between the device's exp / log and glibc's, which decides such ties differently in a few cells
+    # |kord| = 11, 12 with kord_tm < 0 (tie-sensitive limiters on the transformed temperature) are in the matrix since the
+    # kernels and the oracle share one exp / log (include/fv3_math.h)
     R.check_remap(prod, hydrostatic=hydrostatic, last_step=last_step, kord_tm=kord_tm, kord=kord, nq=nq)
 
 
@@ -495,8 +496,7 @@ def test_baseline_config2_tile_shape(prod):
 def test_baseline_config1_test_case_1(prod):
     """BASELINE configs[0]: doubly periodic 48 x 48 x 32, hydrostatic, the reference's test_case = 1 initial condition
     (uniform flow carrying a block of mass): one dt_atmos of the k_split loop (substeps, tracer_2d, remap) vs the oracle"""
-    D.check_fv_step_hydrostatic(prod, nx=48, ny=48, npz=32, nq=1, k_split=1, n_split=3, bdt=6.0, ic="test_case_1",
-                                uv_branch_flips=True)
+    D.check_fv_step_hydrostatic(prod, nx=48, ny=48, npz=32, nq=1, k_split=1, n_split=3, bdt=6.0, ic="test_case_1")
 
 
 @pytest.mark.parametrize("hord", [9, 11, 12, 13])
@@ -506,3 +506,74 @@ def test_tracer_2d_positive_definite_schemes(prod, hord):
     T.check_tracer_2d(prod, nq=4, hord=hord, big_courant=True)
     T.check_tracer_2d(prod, nx=70, ny=21, npz=3, nq=1, hord=hord)
     T.check_tracer_2d(prod, q_split=2, trdm=0.06, nord_tr=1, hord=hord)
+
+
+def test_d_sw_interior_does_not_read_halos_in_flight(prod, monkeypatch):
+    """uc, vc halos poisoned during 'interior' and restored before 'rest' (the exchange is in flight then): ragged last
+    strips / segments of 1-3 cells / rows must keep the interior launch off the halo"""
+    for nx, ny in ((130, 100), (117, 100), (175, 100)):
+        assert max(P.check_d_sw(prod, nx=nx, ny=ny, npz=3, phases="poison").values()) <= P.TOL
+    monkeypatch.setenv("FV3_MI355X_MARCH_TJ_FUSED", "8")
+    for nx, ny in ((130, 97), (131, 26), (118, 98), (119, 99)):
+        assert max(P.check_d_sw(prod, nx=nx, ny=ny, npz=3, phases="poison").values()) <= P.TOL
+
+
+# ---- the column path at BASELINE depth (L79 = configs 2 and 5, L127 = configs 3 and 4): per-wavefront blocked scratch
+# ---- slabs, register budgets and unrolling of the k loops are exercised at the depth the configurations run at
+@pytest.mark.parametrize("km", [79, 127])
+def test_nh_columns_at_baseline_depth(prod, km):
+    dims = dict(nx=200, ny=72, km=km)          # 225 wavefronts of columns, ragged last one
+    N.check_update_dz_c(prod, **dims)
+    N.check_riem_solver_c(prod, **dims)
+    N.check_riem_solver_c(prod, a_imp=0.75, **dims)
+    N.check_riem_solver3(prod, **dims)
+    N.check_riem_solver3(prod, a_imp=0.75, use_logp=True, last_call=True, fp_out=True, **dims)
+    N.check_update_dz_d(prod, **dims)
+    N.check_halos_and_geopk(prod, **dims)
+    N.check_nh_p_grad(prod, **dims)
+    N.check_p_grad_c(prod, **dims)
+
+
+@pytest.mark.parametrize("km,nq,hydrostatic,last_step,kord", [(127, 4, False, True, 9), (127, 4, False, False, 10),
+                                                              (79, 33, True, False, 9), (79, 33, True, True, 8),
+                                                              (79, 6, True, True, 11)])
+def test_remap_at_baseline_depth(prod, km, nq, hydrostatic, last_step, kord):
+    """Lagrangian_to_Eulerian at L127 with 4 tracers (config 3) and at L79 with 33 (config 5)"""
+    R.check_remap(prod, nx=200, ny=72, km=km, nq=nq, hydrostatic=hydrostatic, last_step=last_step, kord=kord,
+                  kord_tm=-kord if kord != 10 else 10)
+
+
+def test_config3_c384l127_whole_nh_step(prod):
+    """BASELINE configs[2] size: one 384 x 384 x 127 tile, nonhydrostatic (Riem_Solver3 / SIM1 path), one k_split cycle of
+    fv_dynamics (2 acoustic substeps, tracer_2d with 2 tracers, Lagrangian_to_Eulerian) against the oracle"""
+    D.check_fv_step(prod, nx=384, ny=384, npz=127, nq=2, k_split=1, n_split=2, bdt=8.0)
+
+
+def test_config4_1024_wide_strip_nh_substeps(prod):
+    """BASELINE configs[3]: a 1024-wide strip of the 1024 x 1024 x 127 doubly periodic nonhydrostatic domain (18 strips of
+    wavefronts in x), two acoustic substeps against the oracle"""
+    D.check_substeps(prod, nx=1024, ny=64, npz=127, n_split=2)
+
+
+def test_config5_c768l79_hydrostatic_step_33_tracers(prod):
+    """BASELINE configs[4] size in x and z on a reduced j extent: 768 x 96 x 79, hydrostatic, 33 tracers: one k_split cycle
+    (substeps, tracer_2d, remap) against the oracle"""
+    D.check_fv_step_hydrostatic(prod, nx=768, ny=96, npz=79, nq=33, k_split=1, n_split=2, bdt=8.0)
+
+
+@pytest.mark.parametrize("state", ["westward", "swirl"])
+@pytest.mark.parametrize("hydrostatic", [False, True])
+def test_reversed_and_mixed_winds_three_strips(prod, state, hydrostatic):
+    """u < 0 / winds of both signs on 3 strips x 2-3 segments: every upwind select takes the other neighbour, also in the
+    first and last lanes a strip owns (the default states have u > 0 everywhere)"""
+    for perturb in (False, True):
+        assert P.check_c_sw(prod, nx=130, ny=70, npz=3, hydrostatic=hydrostatic, perturb=perturb, state=state) <= P.TOL
+        assert max(P.check_d_sw(prod, nx=130, ny=70, npz=3, hydrostatic=hydrostatic, perturb=perturb, state=state).values()) <= P.TOL
+
+
+def test_reversed_winds_whole_substeps_and_tracers(prod):
+    D.check_substeps(prod, nx=130, ny=30, npz=6, n_split=2, bdt=8.0, ic="westward")
+    D.check_substeps_hydrostatic(prod, nx=96, ny=24, npz=6, n_split=2, bdt=8.0)
+    D.check_substeps_hydrostatic(prod, nx=130, ny=30, npz=6, n_split=2, bdt=8.0, ic="westward")
+    T.check_tracer_2d(prod, nx=130, ny=30, npz=3, nq=3, reverse=True)
+    T.check_tracer_2d(prod, nx=130, ny=30, npz=3, nq=4, reverse=True, big_courant=True)

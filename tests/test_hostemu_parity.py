@@ -259,6 +259,16 @@ def test_d_sw_interior_then_rest_equals_d_sw(emu):
     assert max(P.check_d_sw(emu, nx=40, ny=19, npz=3, phases=True).values()) <= P.TOL      # no interior: rest does all
 
 
+@pytest.mark.parametrize("nx,ny,tj", [(130, 100, None), (117, 100, None), (175, 100, None), (130, 97, 8), (131, 26, 8),
+                                      (118, 98, 8), (119, 99, 8)])
+def test_d_sw_interior_does_not_read_halos_in_flight(emu, nx, ny, tj, monkeypatch):
+    """uc, vc halos poisoned during 'interior' and restored before 'rest': shapes whose last strip owns 1-3 cells
+    (nx % 58 = 1, 2, 3) or whose last segment has 1-3 rows"""
+    if tj:
+        monkeypatch.setenv("FV3_MI355X_MARCH_TJ_FUSED", str(tj))
+    assert max(P.check_d_sw(emu, nx=nx, ny=ny, npz=3, phases="poison").values()) <= P.TOL
+
+
 @pytest.mark.parametrize("nx,ny", [(6, 5), (58, 48), (59, 49), (117, 97), (8, 64), (61, 4)])
 def test_march_strip_and_segment_boundaries(emu, nx, ny):
     """tiny tiles, exactly one strip / segment, one column / row more than a strip / segment, ragged last ones"""
@@ -398,3 +408,21 @@ def test_tracer_2d_positive_definite_schemes(emu, hord):
     T.check_tracer_2d(emu, nq=4, hord=hord, big_courant=True)
     T.check_tracer_2d(emu, nx=70, ny=21, npz=3, nq=1, hord=hord)
     T.check_tracer_2d(emu, q_split=2, trdm=0.06, nord_tr=1, hord=hord)
+
+
+@pytest.mark.parametrize("state", ["westward", "swirl"])
+@pytest.mark.parametrize("hydrostatic", [False, True])
+def test_reversed_and_mixed_winds_three_strips(emu, state, hydrostatic):
+    """u < 0 / winds of both signs on 3 strips x 2-3 segments: every upwind select takes the other neighbour, also in the
+    first and last lanes a strip owns (the default states have u > 0 everywhere)"""
+    for perturb in (False, True):
+        assert P.check_c_sw(emu, nx=130, ny=70, npz=3, hydrostatic=hydrostatic, perturb=perturb, state=state) <= P.TOL
+        assert max(P.check_d_sw(emu, nx=130, ny=70, npz=3, hydrostatic=hydrostatic, perturb=perturb, state=state).values()) <= P.TOL
+
+
+def test_reversed_winds_whole_substeps_and_tracers(emu):
+    D.check_substeps(emu, nx=130, ny=30, npz=6, n_split=2, bdt=8.0, ic="westward")
+    D.check_substeps_hydrostatic(emu, nx=96, ny=24, npz=6, n_split=2, bdt=8.0)
+    D.check_substeps_hydrostatic(emu, nx=130, ny=30, npz=6, n_split=2, bdt=8.0, ic="westward")
+    T.check_tracer_2d(emu, nx=130, ny=30, npz=3, nq=3, reverse=True)
+    T.check_tracer_2d(emu, nx=130, ny=30, npz=3, nq=4, reverse=True, big_courant=True)
