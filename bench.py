@@ -25,17 +25,32 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s"
 
-# algorithmic HBM bytes per cell-update (fp64, NH, nord>0, d_con=0 defaults), DESIGN.md section 4
-ALG_BYTES = {
-    "c_sw": 120.0,           # reads delp,pt,u,v,w; writes delpc,ptc,wc,uc,vc,ua,va,ut,vt,divg_d
-    "d_sw_courant": 80.0,    # reads uc,vc,cx,cy; writes crx,xfx,cry,yfx,cx,cy
-    "d_sw_transport": 128.0, # reads delp,pt,w,crx,xfx,cry,yfx,mfx,mfy; writes delp,pt,w,mfx,mfy,heat_s,diss_e
-    "d_sw_momentum": 104.0,  # reads u,v,uc,vc,divg_d,crx,xfx,cry,yfx,(delp',heat_s when d_con>0); writes u,v,delpc
+# Algorithmic HBM bytes per cell of every timed launch label of the pair (fp64, NH, nord > 0, d_con = 0; DESIGN.md
+# section 3a) and the levels that launch covers: the marching kernels run the "plain" levels, the LDS-tile kernels the
+# sponge levels whose damping branches are not in marching form (2-3 of 127 at the reference defaults).  A launch is priced
+# on the cells IT processes: frac = cells(label) * bytes / duration / 8 TB/s.
+ALG = {
+    # reads delp,pt,u,v,w; writes delpc,ptc,wc,uc,vc,ua,va,ut,vt,divg_d
+    "c_sw": (120.0, "all"),
+    # DswTransportFused: reads delp,pt,w,uc,vc; read-modify-writes mfx,mfy,cx,cy; writes delp,pt,w,crx,cry,xfx,yfx
+    # = 20 arrays of SURVEY 8(d)'s d_sw list (the 16 B of zeroed heat_source / diss_est it also writes are not counted)
+    "d_sw_fused": (160.0, "plain"),
+    # DswMomentumFused: reads u,v,uc,vc,divg_d,crx,xfx,cry,yfx; writes u,v,delpc
+    "d_sw_mom_fused": (96.0, "plain_m"),
+    # the sponge levels (LDS-tile kernels): Courant numbers / transports / momentum
+    "d_sw_courant": (80.0, "damp"),
+    "d_sw_transport": (128.0, "damp"),
+    "d_sw_momentum": (104.0, "rest_m"),
 }
-# kernels that together do the work of one logical kernel (the marching transports are one launch per field)
-GROUP = {"d_sw_delp": "d_sw_transport", "d_sw_w": "d_sw_transport", "d_sw_pt": "d_sw_transport",
-         "d_sw_qcon": "d_sw_transport", "d_sw_fused": "d_sw_transport", "d_sw_ke": "d_sw_momentum", "d_sw_mom_fused": "d_sw_momentum", "d_sw_vort": "d_sw_momentum"}
 PAIR_ALG_BYTES = 336.0       # perfectly fused c_sw+d_sw, NH
+
+
+def level_sets(lev):
+    """the level lists fv3_dsw_levels_upload forms (csrc/fv3_api.hip): which levels go to the marching kernels"""
+    npz = len(lev["nord_k"])
+    damp = [k for k in range(npz) if lev["damp_vt"][k] > 1e-4 or lev["damp_w"][k] > 1e-5 or lev["damp_t"][k] > 1e-4]
+    rest_m = [k for k in range(npz) if not (lev["nord_k"][k] == 1 and not lev["damp_vt"][k] > 1e-5 and not lev["d_con_k"][k] > 1e-5)]
+    return {"all": npz, "damp": len(damp), "plain": npz - len(damp), "rest_m": len(rest_m), "plain_m": npz - len(rest_m)}
 
 
 def parse():
@@ -51,68 +66,113 @@ def parse():
     ap.add_argument("--no-model-step", action="store_true", help="skip the SYPD (whole model step) leg")
     ap.add_argument("--nq", type=int, default=4, help="advected tracers in the SYPD leg")
     ap.add_argument("--model-step-multi", action="store_true", help="run the SYPD leg on N > 1 GPUs too")
+    ap.add_argument("--no-general", action="store_true", help="skip the second (general-metrics) measurement of the pair")
     ap.add_argument("--general-metrics", action="store_true",
                     help="FV3_MI355X_GEOM=0: read every metric row (what a cubed-sphere gridstruct needs) instead of "
                          "using the uniform-Cartesian kernels the library selects for this doubly periodic gridstruct")
     return ap.parse_args()
 
 
+def native_oracle():
+    """the CPU baseline is the C port built -O3 -march=native ON the machine that times it (the libfvo.so that
+    travels with the snapshot is the parity checker's -O2 generic build).  Same sources, same -ffp-contract=off."""
+    import ctypes
+    import subprocess
+    odir = os.path.join(ROOT, "oracle")
+    out = os.path.join(odir, "_native")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "libfvo_native.so")
+    srcs = sorted(os.path.join(odir, f) for f in os.listdir(odir) if f.endswith(".c"))
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-fopenmp", "-shared",
+                           "-o", so] + srcs + ["-lm"], stderr=subprocess.DEVNULL)
+    return ctypes.CDLL(so)
+
+
+def physical_cores():
+    """physical cores of the host (SMT siblings counted once), from /proc/cpuinfo; falls back to os.cpu_count()"""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(nx, seconds):
-    """The oracle (oracle/libfvo.so: C restatement, OpenMP over k like dyn_core.F90:436,658) timed on
-    this host's cores on a bounded sample of the same workload."""
+    """The oracle's C port (OpenMP over k like dyn_core.F90:436,658) timed on this host's physical cores on a bounded
+    sample of the same workload: 3 warm-up + timed repetitions for about `seconds` of CPU wall, median."""
+    cores = physical_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    try:   # the port's per-slab work arrays (the Fortran's stack arrays) come from malloc: keep them in the per-thread arenas
+        import ctypes                       # instead of mmap / munmap + page faults on every slab
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-3, 32 << 20)          # M_MMAP_THRESHOLD: no mmap below 32 MB
+        libc.mallopt(-1, (1 << 31) - 1)     # M_TRIM_THRESHOLD: never give arena memory back
+    except OSError:
+        pass
     import oracle_lib as O
+    try:
+        O._LIB = native_oracle()
+        build = "gcc -O3 -march=native -ffp-contract=off -fopenmp"
+    except Exception:  # noqa: BLE001   (no compiler on the box: the shipped checker build)
+        build = "gcc -O2 -mfma -ffp-contract=off -fopenmp (shipped checker build)"
     import parity_common as P
-    from fields import smooth_state
-    from gfdl_atmos_cubed_sphere_amd.layout import Bounds, periodic_fill
-    from test_oracle_properties import default_levels
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    npz = max(2, min(127, 2 * cores))
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags, level_coefficients
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    from gfdl_atmos_cubed_sphere_amd.synthetic import CSW_OUT, DSW_PAR, smooth_state
+    npz = max(2, min(127, cores))
     bd = Bounds(1, nx, 1, nx)
     g = P.make_grid(bd, False)
     st = smooth_state(bd, npz, noise=0.05)
     f = {k: v for k, v in st.items()}
-    for n, kind in P.CSW_OUT + (("mfx", "FX"), ("mfy", "FY"), ("cx", "CX"), ("cy", "CY"), ("crx", "CX"),
-                                ("cry", "CY"), ("xfx", "CX"), ("yfx", "CY"), ("heat_source", "CC"),
-                                ("diss_est", "CC")):
+    for n, kind in CSW_OUT + (("mfx", "FX"), ("mfy", "FY"), ("cx", "CX"), ("cy", "CY"), ("crx", "CX"),
+                              ("cry", "CY"), ("xfx", "CX"), ("yfx", "CY"), ("heat_source", "CC"),
+                              ("diss_est", "CC")):
         f[n] = bd.zeros(kind, npz)
-    par = dict(P.DSW_PAR)
+    par = dict(DSW_PAR)
     par.update(nord=1, nord_v=1, nord_w=1, nord_t=1, d2_bg=0., damp_v=0., damp_w=0., damp_t=0., d_con=0.,
                hydrostatic=0, use_cond=0)
-    lev = default_levels(npz)
+    lev = level_coefficients(npz, DynFlags())
     keep = {k: f[k].copy(order="F") for k in ("delp", "pt", "u", "v", "w")}
-    reps, t_used = 0, 0.0
-    times = []
-    while t_used < seconds or reps < 2:
+    t_used, times = 0.0, []
+    for rep in range(60):
         for k, v in keep.items():
             f[k][...] = v  # d_sw updates in place (reference semantics); restore the inputs
         t0 = time.perf_counter()
         O.c_sw_3d(g, npz, f, nord=1, dt2=3.0, hydrostatic=False)
         O.d_sw_3d(g, npz, par, lev, f)
         dt = time.perf_counter() - t0
-        times.append(dt)
         t_used += dt
-        reps += 1
-        if reps >= 50:
+        if rep >= 3:
+            times.append(dt)
+        if (t_used > seconds and len(times) >= 2) or (len(times) >= 10 and t_used > 0.5 * seconds):
             break
     best = float(np.median(times))
-    return {"value": nx * nx * npz / best, "unit": "cell-updates/s", "cores": cores, "kind": "port",
-            "sample": f"{nx}x{nx}x{npz} doubly periodic tile, c_sw+d_sw pair, median of {reps} reps "
-                      f"({t_used:.1f} s CPU wall), OpenMP over k on {cores} threads"}
+    return {"value": nx * nx * npz / best, "unit": "cell-updates/s", "cores": cores, "kind": "port", "build": build,
+            "sample": f"{nx}x{nx}x{npz} doubly periodic tile, c_sw+d_sw pair, 3 warm-up + median of {len(times)} reps "
+                      f"({t_used:.1f} s CPU wall), OpenMP over k on {cores} threads = the host's physical cores"}
 
 
 def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream):
     """SYPD leg: whole nonhydrostatic model steps (fv_dynamics.F90:460-665 k_split loop: n_split acoustic substeps,
     tracer_2d, Lagrangian_to_Eulerian) on the same tile, dt_atmos=225 s, k_split=2, n_split=5 (C384 settings)."""
-    import parity_dyn as D
-    import parity_nh as N
     from gfdl_atmos_cubed_sphere_amd import lib as L
+    from gfdl_atmos_cubed_sphere_amd import synthetic as N
     from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
     from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
     from gfdl_atmos_cubed_sphere_amd.layout import Bounds
     nx, npz, nq = a.nx, a.npz, a.nq
     ctx = L.Context(g, npz, stream=stream.cuda_stream)
-    st, _ = D.make_state(Bounds(1, nx, 1, nx), npz)
+    st, _ = N.balanced_nh_state(Bounds(1, nx, 1, nx), npz)
     sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
     k_split, n_split, dt_atmos = 2, 5, 225.0
@@ -183,59 +243,26 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
 
-    import parity_common as P
-    from fields import smooth_state
     from gfdl_atmos_cubed_sphere_amd import lib as L
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags, level_coefficients
+    from gfdl_atmos_cubed_sphere_amd.grid import doubly_periodic
     from gfdl_atmos_cubed_sphere_amd.halo import HaloExchanger, choose_layout
     from gfdl_atmos_cubed_sphere_amd.layout import Bounds
-    from test_oracle_properties import default_levels
+    from gfdl_atmos_cubed_sphere_amd.synthetic import CSW_OUT, DSW_PAR, smooth_state
 
     nx, npz = a.nx, a.npz
     px, py = choose_layout(world)
     # this rank's block of the (nx*px) x (nx*py) doubly periodic domain
     ix, iy = rank % px, rank // px
     bd = Bounds(1 + ix * nx, (ix + 1) * nx, 1 + iy * nx, (iy + 1) * nx)
-    from gfdl_atmos_cubed_sphere_amd.grid import doubly_periodic
     g = doubly_periodic(bd, nx * px + 1, nx * py + 1, dx_const=26000.0, dy_const=26000.0)
     stream = torch.cuda.current_stream()
-    if a.general_metrics:
-        os.environ["FV3_MI355X_GEOM"] = "0"
-    ctx = L.Context(g, npz, stream=stream.cuda_stream)
-    geom = ctx.geom
-    # FV3_BENCH_SPLIT=1: exercise the multi-rank flow (start / d_sw interior / finish / d_sw rest) on one GPU to see its cost
-    halo = HaloExchanger(ctx, px, py, rank, world, split_single=loopback or os.environ.get("FV3_BENCH_SPLIT") == "1",
-                         loopback=loopback)
-
-    st = smooth_state(Bounds(1, nx, 1, nx), npz, noise=0.05)  # same synthetic block on every rank
-    d = {k: ctx.from_host(v) for k, v in st.items()}
-    del st
-    for n, kind in P.CSW_OUT:
-        d[n] = ctx.zeros(kind, npz)
-    for n, kind in (("mfx", "FX"), ("mfy", "FY"), ("cx", "CX"), ("cy", "CY"), ("crx", "CX"), ("cry", "CY"),
-                    ("xfx", "CX"), ("yfx", "CY"), ("delp_out", "A"), ("pt_out", "A"), ("u_out", "U"),
-                    ("v_out", "V"), ("w_out", "A"), ("heat_s", "CC"), ("diss_e", "CC")):
-        d[n] = ctx.zeros(kind, npz)
-    ctx.dsw_levels(default_levels(npz))
-    dt = 22.5   # C384 acoustic step: dt_atmos 225 s / k_split 2 / n_split 5
-    par = dict(P.DSW_PAR)
-    par.update(dt=dt, hydrostatic=0, use_cond=0, hord_mt=a.hord, hord_vt=a.hord, hord_tm=a.hord, hord_dp=a.hord)
-
-    def step():
-        ctx.c_sw(d["delpc"], d["delp"], d["ptc"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"],
-                 d["va"], d["wc"], d["ut"], d["vt"], d["divg_d"], 1, 0.5 * dt, False)
-        dsw_args = (par, None, d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"],
-                    d["divg_d"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
-                    d["delp_out"], d["pt_out"], d["u_out"], d["v_out"], d["w_out"], None, d["heat_s"], d["diss_e"])
-        # start the exchange, run the part of d_sw that reads no halo while it is in flight, complete, do the rest
-        if halo.overlaps:
-            pending = halo.start([(d["uc"], "V"), (d["vc"], "U"), (d["divg_d"], "B")], defer=True)
-            ctx.d_sw(*dsw_args, phase="interior")
-            halo.post(pending)
-            halo.finish(pending)
-            ctx.d_sw(*dsw_args, phase="rest")
-        else:
-            halo.update([(d["uc"], "V"), (d["vc"], "U"), (d["divg_d"], "B")])
-            ctx.d_sw(*dsw_args)
+    cells = nx * nx * npz
+    lev = level_coefficients(npz, DynFlags())
+    nlev = level_sets(lev)
+    build = L.build_id()
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    traffic_db = json.load(open(tfile)) if os.path.exists(tfile) else {}
 
     def fence():
         torch.cuda.synchronize()
@@ -243,59 +270,119 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    cells = nx * nx * npz
-    value = cells * world * a.steps / el
-    finite = bool(np.isfinite(d["u_out"].download()).all())
+    def measure(general, steps, warmup):
+        """time `steps` c_sw -> halo -> d_sw passes on the resident state; then a separate profiled pass (HIP events
+        around every launch on its own stream) for the per-launch roofline.  general: FV3_MI355X_GEOM=0, every metric
+        row is read from memory -- what a cubed-sphere gridstruct needs -- instead of the uniform-Cartesian kernels the
+        library selects for this doubly periodic gridstruct."""
+        if general:
+            os.environ["FV3_MI355X_GEOM"] = "0"
+        else:
+            os.environ.pop("FV3_MI355X_GEOM", None)
+        ctx = L.Context(g, npz, stream=stream.cuda_stream)
+        geom = ctx.geom
+        # FV3_BENCH_SPLIT=1: exercise the multi-rank flow (start / d_sw interior / finish / d_sw rest) on one GPU
+        halo = HaloExchanger(ctx, px, py, rank, world, split_single=loopback or os.environ.get("FV3_BENCH_SPLIT") == "1",
+                             loopback=loopback)
+        st = smooth_state(Bounds(1, nx, 1, nx), npz, noise=0.05)  # same synthetic block on every rank
+        d = {k: ctx.from_host(v) for k, v in st.items()}
+        del st
+        for n, kind in CSW_OUT:
+            d[n] = ctx.zeros(kind, npz)
+        for n, kind in (("mfx", "FX"), ("mfy", "FY"), ("cx", "CX"), ("cy", "CY"), ("crx", "CX"), ("cry", "CY"),
+                        ("xfx", "CX"), ("yfx", "CY"), ("delp_out", "A"), ("pt_out", "A"), ("u_out", "U"),
+                        ("v_out", "V"), ("w_out", "A"), ("heat_s", "CC"), ("diss_e", "CC")):
+            d[n] = ctx.zeros(kind, npz)
+        ctx.dsw_levels(lev)
+        dt = 22.5   # C384 acoustic step: dt_atmos 225 s / k_split 2 / n_split 5
+        par = dict(DSW_PAR)
+        par.update(dt=dt, hydrostatic=0, use_cond=0, hord_mt=a.hord, hord_vt=a.hord, hord_tm=a.hord, hord_dp=a.hord)
 
-    # ---- per-kernel HIP-event timing (separate pass so the events do not perturb `value`) ----
-    ctx.profile(True)
-    nprof = max(3, min(10, a.steps))
-    for _ in range(nprof):
-        step()
-    rep = ctx.profile_report()
-    ctx.profile(False)
-    per_kernel, launches = {}, {}
-    grouped = {}
-    for name, (n, ms) in rep.items():
-        launches[name] = {"launches_per_step": n / nprof, "avg_ms": ms / n}
-        gname = GROUP.get(name, name)
-        grouped[gname] = grouped.get(gname, 0.0) + ms / nprof          # ms per step of the logical kernel
-    for name, ms in grouped.items():
-        if name in ALG_BYTES:
-            avg = ms * 1e-3
-            per_kernel[name] = {"avg_ms": ms, "GBps": cells * ALG_BYTES[name] / avg / 1e9,
-                                "frac": cells * ALG_BYTES[name] / avg / HBM_PEAK}
-    dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"]) if per_kernel else None
-    t_pair = sum(v["avg_ms"] for v in per_kernel.values()) * 1e-3
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if dom and os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get(dom)
-    roof = None
-    if dom:
-        ach = cells * ALG_BYTES[dom] / (per_kernel[dom]["avg_ms"] * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": ach / (HBM_PEAK / 1e9), "traffic": traffic,
-                "alg_bytes_per_cell": ALG_BYTES[dom], "avg_ms": per_kernel[dom]["avg_ms"],
-                "per_kernel": per_kernel, "launches": launches,
-                "pair": {"alg_bytes_per_cell": PAIR_ALG_BYTES, "kernels_ms": t_pair * 1e3,
-                         "frac": cells * PAIR_ALG_BYTES / t_pair / HBM_PEAK if t_pair > 0 else None,
-                         # the same against the wall clock of the timed region (the sponge-level tile kernels overlap
-                         # the marching kernels on a side stream there, so it can beat the sum of the launches)
-                         "wall_ms": el / a.steps * 1e3,
-                         "frac_wall": cells * PAIR_ALG_BYTES / (el / a.steps) / HBM_PEAK}}
+        def step():
+            ctx.c_sw(d["delpc"], d["delp"], d["ptc"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"],
+                     d["va"], d["wc"], d["ut"], d["vt"], d["divg_d"], 1, 0.5 * dt, False)
+            dsw_args = (par, None, d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"],
+                        d["divg_d"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
+                        d["delp_out"], d["pt_out"], d["u_out"], d["v_out"], d["w_out"], None, d["heat_s"], d["diss_e"])
+            # start the exchange, run the part of d_sw that reads no halo while it is in flight, complete, do the rest
+            if halo.overlaps:
+                pending = halo.start([(d["uc"], "V"), (d["vc"], "U"), (d["divg_d"], "B")], defer=True)
+                ctx.d_sw(*dsw_args, phase="interior")
+                halo.post(pending)
+                halo.finish(pending)
+                ctx.d_sw(*dsw_args, phase="rest")
+            else:
+                halo.update([(d["uc"], "V"), (d["vc"], "U"), (d["divg_d"], "B")])
+                ctx.d_sw(*dsw_args)
+
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        finite = bool(np.isfinite(d["u_out"].download()).all())
+        # ---- per-launch HIP-event timing (separate pass so the events do not perturb the timed region; the
+        # ---- sponge-level chain runs on the main stream here instead of overlapping on the side stream) ----
+        ctx.profile(True)
+        nprof = max(3, min(10, steps))
+        for _ in range(nprof):
+            step()
+        rep = ctx.profile_report()
+        ctx.profile(False)
+        ctx.close()
+        per_launch, t_sum = {}, 0.0
+        for name, (n, ms) in rep.items():
+            per_step = ms / nprof
+            t_sum += per_step
+            e = {"launches_per_step": n / nprof, "ms_per_step": per_step}
+            if name in ALG and nlev[ALG[name][1]] > 0:
+                nb, which = ALG[name]
+                c = nx * nx * nlev[which]
+                e.update(alg_bytes_per_cell=nb, levels=nlev[which], GBps=c * nb / (per_step * 1e-3) / 1e9,
+                         frac=c * nb / (per_step * 1e-3) / HBM_PEAK)
+            per_launch[name] = e
+        priced = [k for k, v in per_launch.items() if "frac" in v]
+        dom = max(priced, key=lambda k: per_launch[k]["ms_per_step"]) if priced else None
+        roof = None
+        if dom:
+            e = per_launch[dom]
+            key = f"{dom}@geom{geom}"
+            tr = traffic_db.get(key) if traffic_db.get("build_id") == build else None
+            roof = {"bound": "hbm", "kernel": dom, "achieved": e["GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": e["frac"], "traffic": tr,
+                    "traffic_note": ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, of this build "
+                                     f"(tools/pmc_hbm_pair.sh, build {build})") if tr else
+                                    (f"profiles/hbm_traffic.json is of build {traffic_db.get('build_id')}, this is {build}: "
+                                     "not reported"),
+                    "alg_bytes_per_cell": e["alg_bytes_per_cell"], "levels": e["levels"], "avg_ms": e["ms_per_step"],
+                    "per_launch": per_launch,
+                    "pair": {"alg_bytes_per_cell": PAIR_ALG_BYTES, "launches_ms": t_sum,
+                             "frac_launches": cells * PAIR_ALG_BYTES / (t_sum * 1e-3) / HBM_PEAK if t_sum > 0 else None,
+                             # against the wall clock of the timed region (there the sponge-level tile kernels overlap the
+                             # marching kernels on a side stream, so it can beat the sum of the launches)
+                             "wall_ms": el / steps * 1e3,
+                             "frac_wall": cells * PAIR_ALG_BYTES / (el / steps) / HBM_PEAK}}
+        return {"el": el, "value": cells * world * steps / el, "finite": finite, "roof": roof, "geom": geom}
+
+    GEOM = {0: "general metric rows", 1: "orthogonal (angle terms not read)", 2: "orthogonal + uniform (metric terms as scalars)"}
+    m = measure(a.general_metrics, a.steps, a.warmup)
+    el, value, finite, roof, geom = m["el"], m["value"], m["finite"], m["roof"], m["geom"]
+    # the cubed-sphere-representative pair: the same workload with every metric row read (geometry mode 0)
+    gm = None
+    if not a.general_metrics and not a.no_general:
+        try:
+            g0 = measure(True, max(10, a.steps // 3), max(3, a.warmup // 2))
+            gm = {"gridstruct": GEOM[g0["geom"]], "value": g0["value"], "ms_per_step": g0["el"] / max(10, a.steps // 3) * 1e3,
+                  "finite": g0["finite"], "roofline": g0["roof"]}
+        except Exception as e:  # noqa: BLE001
+            gm = {"error": f"{type(e).__name__}: {e}"}
 
     out = {"metric": "c_sw+d_sw cell-updates/s", "value": value, "unit": "cell-updates/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
@@ -304,12 +391,8 @@ def main():
                                   f"c_sw+d_sw pair, hord {a.hord}/{a.hord}/{a.hord}/{a.hord}, nord=1, d4_bg=0.16",
                       "layout": f"{px}x{py}", "halo": ("RCCL send/recv (loopback)" if loopback else "periodic copy") if world == 1 else "RCCL send/recv",
                       # what fv3_grid_upload found in the metric arrays (fv3_grid_geom)
-                      "gridstruct": {0: "general metric rows", 1: "orthogonal (angle terms not read)",
-                                     2: "orthogonal + uniform (metric terms as scalars)"}[geom]},
-           "finite": finite, "roofline": roof}
-    ctx.close()
-    ctx = None
-    del d
+                      "gridstruct": GEOM[geom], "build_id": build},
+           "finite": finite, "roofline": roof, "general_metrics": gm}
     # the secondary legs must never cost the headline line: a failure there is reported, not raised
     out["model_step"] = None
     # N > 1: the SYPD leg is off unless asked for (a failure on one rank would leave the others in a collective)

@@ -17,7 +17,8 @@ from .grid import GridStruct
 from .layout import Bounds
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-PRODUCT_SO = os.path.join(_HERE, "csrc", "libfv3_mi355x.so")
+_CSRC = os.path.join(_HERE, "csrc")
+PRODUCT_SO = os.path.join(_CSRC, "libfv3_mi355x.so")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -118,6 +119,20 @@ class Fv3Lib:
 
 
 _PRODUCT: Fv3Lib | None = None
+
+
+def build_id() -> str:
+    """Short hash of the kernel / C-ABI sources the product library is built from: measurements kept under profiles/
+    (HBM traffic counters) carry it so that bench.py can tell a stale file from one taken on the build it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(_CSRC, f) for f in sorted(os.listdir(_CSRC)) if f.endswith((".h", ".hip"))]
+    files += [os.path.join(root, "include", f) for f in sorted(os.listdir(os.path.join(root, "include"))) if f.endswith(".h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
 
 
 def load() -> Fv3Lib:

@@ -87,8 +87,7 @@ def check_fv_tp_2d(lib, hord, nx=40, ny=19, nk=3, perturb=True, mode="plain", no
 
 
 # ------------------------------------------------------------------------------------------------
-CSW_OUT = (("delpc", "A"), ("ptc", "A"), ("wc", "A"), ("uc", "V"), ("vc", "U"), ("ua", "A"), ("va", "A"),
-           ("ut", "A"), ("vt", "A"), ("divg_d", "B"))
+from gfdl_atmos_cubed_sphere_amd.synthetic import CSW_OUT, DSW_PAR  # noqa: E402
 
 
 def csw_valid_ranges(bd):
@@ -173,7 +172,6 @@ def check_c_sw(lib, nx=40, ny=19, npz=3, hydrostatic=False, perturb=True, dt=6.0
 
 
 # ------------------------------------------------------------------------------------------------
-DSW_PAR = dict(dt=6.0, hord_tr=8, hord_mt=10, hord_vt=10, hord_tm=10, hord_dp=10, dddmp=0.0, d4_bg=0.16, kgb=0.0)
 
 
 def check_d_sw(lib, nx=40, ny=19, npz=4, hydrostatic=False, perturb=True, par_over=None, lev_over=None,

@@ -14,12 +14,7 @@ from gfdl_atmos_cubed_sphere_amd.layout import Bounds
 from gfdl_atmos_cubed_sphere_amd.lib import GRAV, Context
 
 
-def make_state(bd, npz, seed=21):
-    s = N.nh_state(bd, npz, seed=seed, pert=0.005)
-    w = smooth_state(bd, npz, noise=0.05)
-    delz = np.asfortranarray(np.diff(s["zh"], axis=2)[bd.ng:bd.ng + bd.nx, bd.ng:bd.ng + bd.ny, :])  # zh(k+1)-zh(k) < 0
-    return dict(u=w["u"], v=w["v"], w=np.asfortranarray(0.2 * w["w"]), delp=s["delp"], pt=s["pt"], delz=delz,
-                phis=np.asfortranarray(s["zs"] * GRAV)), s["dp0"]
+from gfdl_atmos_cubed_sphere_amd.synthetic import balanced_nh_state as make_state  # noqa: E402
 
 
 def ulp_sensitivity(g, npz, fl, dp0, st, bdt, ref):

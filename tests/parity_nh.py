@@ -14,36 +14,7 @@ from gfdl_atmos_cubed_sphere_amd.layout import Bounds, periodic_fill
 from gfdl_atmos_cubed_sphere_amd.lib import CP_AIR, GRAV, KAPPA, RDGAS, Context, nh_consts
 from test_oracle_properties import default_levels
 
-PTOP = 300.0
-
-
-def nh_state(bd: Bounds, km: int, seed: int = 11, pert: float = 0.02):
-    """A nearly hydrostatic column state on the reference layout with valid halos."""
-    rng = np.random.default_rng(seed)
-    sig = np.linspace(0.0, 1.0, km + 1) ** 1.5
-    shapeA = bd.shape("A")
-    ps = 1.0e5 * (1.0 + 0.01 * rng.uniform(-1, 1, shapeA))
-    periodic_fill(bd, ps, "A")
-    pe = PTOP + (ps[:, :, None] - PTOP) * sig[None, None, :]
-    delp = np.asfortranarray(np.diff(pe, axis=2))
-    pm = delp / np.log(pe[:, :, 1:] / pe[:, :, :-1])
-    T = 300.0 - 60.0 * (1.0 - sig[None, None, 1:]) + 2.0 * rng.uniform(-1, 1, delp.shape)
-    pt = np.asfortranarray(T * pm ** (-KAPPA))
-    dz = -delp / GRAV * RDGAS * pt * pm ** (KAPPA - 1.0) * (1.0 + pert * rng.uniform(-1, 1, delp.shape))
-    zs = np.asfortranarray(50.0 * rng.uniform(0, 1, shapeA))
-    periodic_fill(bd, zs, "A")
-    for k in range(km):
-        periodic_fill(bd, pt[:, :, k], "A")
-        periodic_fill(bd, dz[:, :, k], "A")
-    zh = np.zeros(bd.shape("A", km + 1), order="F")
-    zh[:, :, km] = zs
-    for k in range(km - 1, -1, -1):
-        zh[:, :, k] = zh[:, :, k + 1] - dz[:, :, k]
-    w = np.asfortranarray(0.5 * rng.uniform(-1, 1, delp.shape))
-    for k in range(km):
-        periodic_fill(bd, w[:, :, k], "A")
-    dp0 = np.diff(PTOP + (1.0e5 - PTOP) * sig)
-    return dict(delp=delp, pt=pt, w=w, zh=zh, zs=zs, dp0=dp0)
+from gfdl_atmos_cubed_sphere_amd.synthetic import PTOP, nh_state  # noqa: E402,F401
 
 
 def _tol(lib):
