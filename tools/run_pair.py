@@ -4,13 +4,13 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-import parity_common as P
-from fields import smooth_state
 from gfdl_atmos_cubed_sphere_amd import lib as L
+from gfdl_atmos_cubed_sphere_amd import synthetic as P
+from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags, level_coefficients
+from gfdl_atmos_cubed_sphere_amd.synthetic import smooth_state
 from gfdl_atmos_cubed_sphere_amd.grid import doubly_periodic
 from gfdl_atmos_cubed_sphere_amd.halo import HaloExchanger
 from gfdl_atmos_cubed_sphere_amd.layout import Bounds
-from test_oracle_properties import default_levels
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 nx = int(sys.argv[2]) if len(sys.argv) > 2 else 384
 npz = int(sys.argv[3]) if len(sys.argv) > 3 else 127
@@ -25,7 +25,7 @@ for n, kind in (("mfx", "FX"), ("mfy", "FY"), ("cx", "CX"), ("cy", "CY"), ("crx"
                 ("yfx", "CY"), ("delp_out", "A"), ("pt_out", "A"), ("u_out", "U"), ("v_out", "V"), ("w_out", "A"),
                 ("heat_s", "CC"), ("diss_e", "CC")):
     d[n] = ctx.zeros(kind, npz)
-ctx.dsw_levels(default_levels(npz))
+ctx.dsw_levels(level_coefficients(npz, DynFlags()))
 dt = 22.5
 par = dict(P.DSW_PAR); par.update(dt=dt, hydrostatic=0, use_cond=0)
 for _ in range(reps):
