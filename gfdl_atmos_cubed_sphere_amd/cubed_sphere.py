@@ -594,6 +594,17 @@ class CubedSphere:
                 edge[name][i - 1] = d2 / (d1 + d2)
         g["edge_w"], g["edge_e"], g["edge_s"], g["edge_n"] = edge["w"], edge["e"], edge["s"], edge["n"]
         del lonlat
+        # extrap_corner factors x1 / (x2 - x1) of a2b_ord4 (a2b_edge.F90:83-112, :452-462): corners sw, se, ne, nw, the
+        # three (inner, outer) centre pairs in the reference's order
+        def fac(p0, pa, pb):
+            x1, x2 = _gcd3(a3[P(*pa)], g3[P(*p0)]), _gcd3(a3[P(*pb)], g3[P(*p0)])
+            return x1 / (x2 - x1)
+        n = npx
+        g["corner_f"] = np.array([
+            [fac((1, 1), (1, 1), (2, 2)), fac((1, 1), (0, 1), (-1, 2)), fac((1, 1), (1, 0), (2, -1))],
+            [fac((n, 1), (n - 1, 1), (n - 2, 2)), fac((n, 1), (n - 1, 0), (n - 2, -1)), fac((n, 1), (n, 1), (n + 1, 2))],
+            [fac((n, n), (n - 1, n - 1), (n - 2, n - 2)), fac((n, n), (n, n - 1), (n + 1, n - 2)), fac((n, n), (n - 1, n), (n - 2, n + 1))],
+            [fac((1, n), (1, n - 1), (2, n - 2)), fac((1, n), (0, n - 1), (-1, n - 2)), fac((1, n), (1, n), (2, n + 1))]])
 
     def finalize_pairs(self):
         """divg_v / divg_u and del6_v / del6_u get their halos from the neighbours (fv_grid_utils.F90:717-720) and the global
@@ -629,7 +640,7 @@ class CubedSphere:
         m["sin_sg"], m["cos_sg"] = F(g["sin_sg"]), F(g["cos_sg"])
         gs.da_min, gs.da_min_c = self.da_min, self.da_min_c
         gs.sw_corner = gs.se_corner = gs.ne_corner = gs.nw_corner = True
-        for n in ("edge_w", "edge_e", "edge_s", "edge_n"):
+        for n in ("edge_w", "edge_e", "edge_s", "edge_n", "corner_f"):
             m[n] = g[n]
         m["grid"], m["agrid"] = F(g["grid"]), F(g["agrid"])
         gs.tile = t

@@ -65,6 +65,11 @@ typedef struct fvo_grid {
   /* flagstruct members used by the kernels (sw_core.F90:126-127,590-591,624,964,1250) */
   double lim_fac;
   int do_diss_est, prevent_diss_cooling, do_f3d;
+  /* cubed sphere only (grid_type < 3): A -> B interpolation weights on the face edges (edge_w/e(npy), edge_s/n(npx),
+   * fv_grid_utils.F90:1121-1230) and the extrap_corner factors x1/(x2-x1) of a2b_ord4 (a2b_edge.F90:83-112, :452-462):
+   * corners sw, se, ne, nw x the three (inner, outer) cell-centre pairs in the reference's order */
+  const double *edge_w, *edge_e, *edge_s, *edge_n;
+  double corner_f[12];
 } fvo_grid;
 
 /* ---- tp_core (model/tp_core.F90) ------------------------------------------------------- */
@@ -75,6 +80,9 @@ typedef struct fvo_grid {
 int fvo_ppm_line(const double *q1, const double *c, double *flux, int is, int ie, int iord,
                  double lim_fac);
 
+int fvo_ppm_line_cs(const double *q1, const double *c, double *flux, int is, int ie, int iord,
+                    double lim_fac, const double *dxa, int npx);
+void fvo_copy_corners(const fvo_grid *g, double *q, int dir);
 /* pert_ppm (tp_core.F90:1206-1264) */
 void fvo_pert_ppm(int im, const double *a0, double *al, double *ar, int iv);
 
@@ -91,6 +99,9 @@ int fvo_deln_flux(const fvo_grid *g, int nord, double damp, const double *q, dou
 
 /* ---- sw_core (model/sw_core.F90) ------------------------------------------------------- */
 
+void fvo_fill_4corners(const fvo_grid *g, double *q, int dir);
+void fvo_fill_corners_b(const fvo_grid *g, double *q, int dir);
+void fvo_fill_corners_dgrid(const fvo_grid *g, double *x, double *y, double mySign);
 int fvo_d2a2c_vect(const fvo_grid *g, const double *u, const double *v, double *ua, double *va,
                    double *uc, double *vc, double *ut, double *vt, int dord4);
 int fvo_divergence_corner(const fvo_grid *g, const double *u, const double *v, const double *ua,

@@ -16,6 +16,9 @@ static const double near_zero = 1.E-25;
 static const double r12 = 1. / 12.;
 static const double p1 = 7. / 12.;
 static const double p2 = -1. / 12.;
+/* cubed-sphere edge formulas (tp_core.F90:54-62) */
+static const double s11 = 11. / 14., s14 = 4. / 7., s15 = 3. / 14.;
+static const double c1 = -2. / 14., c2 = 11. / 14., c3 = 5. / 14.;
 
 static inline double dmin(double a, double b) { return a < b ? a : b; }
 static inline double dmax(double a, double b) { return a > b ? a : b; }
@@ -84,8 +87,19 @@ void fvo_pert_ppm(int im, const double *a0, double *al, double *ar, int iv) {
  */
 int fvo_ppm_line(const double *q1, const double *c, double *flux, int is, int ie, int iord,
                  double lim_fac) {
+  return fvo_ppm_line_cs(q1, c, flux, is, ie, iord, lim_fac, NULL, 0);
+}
+
+/* The same with the cubed-sphere face edges (.not. bounded_domain .and. grid_type < 3): dxa[i] = the cell widths along
+ * the line (dxa(:, j) for xppm, dya(i, :) for yppm), npx = the edge index of the direction (npx / npy); the west / south
+ * edge is treated when is == 1, the east / north edge when ie + 1 == npx.  dxa == NULL: no edges (the branch above). */
+int fvo_ppm_line_cs(const double *q1, const double *c, double *flux, int is, int ie, int iord,
+                    double lim_fac, const double *dxa, int npx) {
   const int lo = is - 3, n = ie - is + 7;
-  const int is1 = is - 1, ie3 = ie + 2, ie1 = ie + 1;
+  const int cubed = dxa != NULL;
+  const int is1 = cubed ? (3 > is - 1 ? 3 : is - 1) : is - 1;               /* :349-356 */
+  const int ie3 = cubed ? (npx - 2 < ie + 2 ? npx - 2 : ie + 2) : ie + 2;
+  const int ie1 = cubed ? (npx - 3 < ie + 1 ? npx - 3 : ie + 1) : ie + 1;
   const int mord = abs(iord);
   int i;
   int rc = FVO_OK;
@@ -102,6 +116,20 @@ int fvo_ppm_line(const double *q1, const double *c, double *flux, int is, int ie
   if (iord < 7) {
     /* :369-371 */
     for (i = is1; i <= ie3; i++) al[i] = p1 * (q1[i - 1] + q1[i]) + p2 * (q1[i - 2] + q1[i + 1]);
+    if (cubed) { /* :373-386 */
+      if (is == 1) {
+        al[0] = c1 * q1[-2] + c2 * q1[-1] + c3 * q1[0];
+        al[1] = 0.5 * (((2. * dxa[0] + dxa[-1]) * q1[0] - dxa[0] * q1[-1]) / (dxa[-1] + dxa[0]) +
+                       ((2. * dxa[1] + dxa[2]) * q1[1] - dxa[1] * q1[2]) / (dxa[1] + dxa[2]));
+        al[2] = c3 * q1[1] + c2 * q1[2] + c1 * q1[3];
+      }
+      if ((ie + 1) == npx) {
+        al[npx - 1] = c1 * q1[npx - 3] + c2 * q1[npx - 2] + c3 * q1[npx - 1];
+        al[npx] = 0.5 * (((2. * dxa[npx - 1] + dxa[npx - 2]) * q1[npx - 1] - dxa[npx - 1] * q1[npx - 2]) / (dxa[npx - 2] + dxa[npx - 1]) +
+                         ((2. * dxa[npx] + dxa[npx + 1]) * q1[npx] - dxa[npx] * q1[npx + 1]) / (dxa[npx] + dxa[npx + 1]));
+        al[npx + 1] = c3 * q1[npx] + c2 * q1[npx + 1] + c1 * q1[npx + 2];
+      }
+    }
     if (iord < 0) { /* :388-392 */
       for (i = is - 1; i <= ie + 2; i++) al[i] = dmax(0., al[i]);
     }
@@ -223,6 +251,16 @@ int fvo_ppm_line(const double *q1, const double *c, double *flux, int is, int ie
           smt5[i] = 3. * fabs(b0[i]) < fabs(bl[i] - br[i]);
         }
       }
+      if (cubed && iord != 5) { /* fix edge issues, :534-546 */
+        if (is == 1) {
+          smt5[0] = bl[0] * br[0] < 0.;
+          smt5[1] = bl[1] * br[1] < 0.;
+        }
+        if ((ie + 1) == npx) {
+          smt5[npx - 1] = bl[npx - 1] * br[npx - 1] < 0.;
+          smt5[npx] = bl[npx] * br[npx] < 0.;
+        }
+      }
       for (i = is; i <= ie + 1; i++) { /* :549-558 */
         if (c[i] > 0.) {
           fx1 = (1. - c[i]) * (br[i - 1] - c[i] * b0[i - 1]);
@@ -306,6 +344,37 @@ int fvo_ppm_line(const double *q1, const double *c, double *flux, int is, int ie
   }
   if (iord == 9 || iord == 13) fvo_pert_ppm(ie1 - is1 + 1, q1 + is1, bl + is1, br + is1, 0); /* :641 */
 
+  if (cubed) { /* :643-681 */
+    if (is == 1) {
+      bl[0] = s14 * dm[-1] + s11 * (q1[-1] - q1[0]);
+      xt = 0.5 * (((2. * dxa[0] + dxa[-1]) * q1[0] - dxa[0] * q1[-1]) / (dxa[-1] + dxa[0]) +
+                  ((2. * dxa[1] + dxa[2]) * q1[1] - dxa[1] * q1[2]) / (dxa[1] + dxa[2]));
+      xt = dmax(xt, dmin(dmin(q1[-1], q1[0]), dmin(q1[1], q1[2])));
+      xt = dmin(xt, dmax(dmax(q1[-1], q1[0]), dmax(q1[1], q1[2])));
+      br[0] = xt - q1[0];
+      bl[1] = xt - q1[1];
+      xt = s15 * q1[1] + s11 * q1[2] - s14 * dm[2];
+      br[1] = xt - q1[1];
+      bl[2] = xt - q1[2];
+      br[2] = al[3] - q1[2];
+      fvo_pert_ppm(3, q1 + 0, bl + 0, br + 0, 1);
+    }
+    if ((ie + 1) == npx) {
+      bl[npx - 2] = al[npx - 2] - q1[npx - 2];
+      xt = s15 * q1[npx - 1] + s11 * q1[npx - 2] + s14 * dm[npx - 2];
+      br[npx - 2] = xt - q1[npx - 2];
+      bl[npx - 1] = xt - q1[npx - 1];
+      xt = 0.5 * (((2. * dxa[npx - 1] + dxa[npx - 2]) * q1[npx - 1] - dxa[npx - 1] * q1[npx - 2]) / (dxa[npx - 2] + dxa[npx - 1]) +
+                  ((2. * dxa[npx] + dxa[npx + 1]) * q1[npx] - dxa[npx] * q1[npx + 1]) / (dxa[npx] + dxa[npx + 1]));
+      xt = dmax(xt, dmin(dmin(q1[npx - 2], q1[npx - 1]), dmin(q1[npx], q1[npx + 1])));
+      xt = dmin(xt, dmax(dmax(q1[npx - 2], q1[npx - 1]), dmax(q1[npx], q1[npx + 1])));
+      br[npx - 1] = xt - q1[npx - 1];
+      bl[npx] = xt - q1[npx];
+      br[npx] = s11 * (q1[npx + 1] - q1[npx]) - s14 * dm[npx + 1];
+      fvo_pert_ppm(3, q1 + npx - 2, bl + npx - 2, br + npx - 2, 1);
+    }
+  }
+
   if (iord == 7) { /* :685-699 */
     for (i = is - 1; i <= ie + 1; i++) {
       b0[i] = bl[i] + br[i];
@@ -338,6 +407,44 @@ done:
 
 /* ---- 2-D helpers -------------------------------------------------------------------------- */
 
+/* copy_corners, tp_core.F90:245-322: the corner regions of the halo of q get the values the sweep in direction dir
+ * (1 = x, 2 = y) should see there.  q on the A layout.  No-op unless a corner flag is set. */
+void fvo_copy_corners(const fvo_grid *g, double *q, int dir) {
+  const int isd = g->isd, ied = g->ied, jsd = g->jsd, ng = g->ng, npx = g->npx, npy = g->npy;
+  const int nid = ied - isd + 1;
+  int i, j;
+  if (g->bounded_domain) return;
+#define QC(i, j) q[(size_t)((j)-jsd) * nid + ((i)-isd)]
+  if (dir == 1) {
+    if (g->sw_corner)
+      for (j = 1 - ng; j <= 0; j++)
+        for (i = 1 - ng; i <= 0; i++) QC(i, j) = QC(j, 1 - i);
+    if (g->se_corner)
+      for (j = 1 - ng; j <= 0; j++)
+        for (i = npx; i <= npx + ng - 1; i++) QC(i, j) = QC(npy - j, i - npx + 1);
+    if (g->ne_corner)
+      for (j = npy; j <= npy + ng - 1; j++)
+        for (i = npx; i <= npx + ng - 1; i++) QC(i, j) = QC(j, 2 * npx - 1 - i);
+    if (g->nw_corner)
+      for (j = npy; j <= npy + ng - 1; j++)
+        for (i = 1 - ng; i <= 0; i++) QC(i, j) = QC(npy - j, i - 1 + npx);
+  } else if (dir == 2) {
+    if (g->sw_corner)
+      for (j = 1 - ng; j <= 0; j++)
+        for (i = 1 - ng; i <= 0; i++) QC(i, j) = QC(1 - j, i);
+    if (g->se_corner)
+      for (j = 1 - ng; j <= 0; j++)
+        for (i = npx; i <= npx + ng - 1; i++) QC(i, j) = QC(npy + j - 1, npx - i);
+    if (g->ne_corner)
+      for (j = npy; j <= npy + ng - 1; j++)
+        for (i = npx; i <= npx + ng - 1; i++) QC(i, j) = QC(2 * npy - 1 - j, i);
+    if (g->nw_corner)
+      for (j = npy; j <= npy + ng - 1; j++)
+        for (i = 1 - ng; i <= 0; i++) QC(i, j) = QC(j + 1 - npx, npy - i);
+  }
+#undef QC
+}
+
 /* xppm over rows jfirst..jlast.  q(isd:ied, jq0:...) with leading dimension ldq and the row
  * index origin jq0; c and flux (is:ie+1, jc0:...) with leading dimension ldc. */
 static void xppm_2d(const fvo_grid *g, double *flux, const double *q, const double *c, int iord,
@@ -348,7 +455,12 @@ static void xppm_2d(const fvo_grid *g, double *flux, const double *q, const doub
     const double *qrow = q + (size_t)(j - jq0) * ldq - isd; /* qrow[i] */
     const double *crow = c + (size_t)(j - jc0) * ldc - is;
     double *frow = flux + (size_t)(j - jc0) * ldc - is;
-    fvo_ppm_line(qrow, crow, frow, is, ie, iord, g->lim_fac);
+    if (g->grid_type < 3 && !g->bounded_domain) {
+      const int nid = g->ied - isd + 1;
+      fvo_ppm_line_cs(qrow, crow, frow, is, ie, iord, g->lim_fac, g->dxa + (size_t)(j - g->jsd) * nid - isd, g->npx);
+    } else {
+      fvo_ppm_line(qrow, crow, frow, is, ie, iord, g->lim_fac);
+    }
   }
 }
 
@@ -359,15 +471,22 @@ static void yppm_2d(const fvo_grid *g, double *flux, const double *q, const doub
                     int ifirst, int ilast, int ldq, int ldc) {
   const int js = g->js, je = g->je, jsd = g->jsd, jed = g->jed, isd = g->isd;
   const int nj = jed - jsd + 1;
-  double *line = (double *)malloc(sizeof(double) * (size_t)(3 * nj + 8));
+  double *line = (double *)malloc(sizeof(double) * (size_t)(4 * nj + 12));
   double *ql = line - jsd;                /* ql[j], j in jsd..jed */
   double *cl = line + nj + 2 - js;        /* cl[j], j in js..je+1 */
   double *fl = line + 2 * nj + 4 - js;    /* fl[j] */
+  double *dl = line + 3 * nj + 8 - jsd;   /* dya(i, j), j in jsd..jed */
+  const int cubed = g->grid_type < 3 && !g->bounded_domain;
+  const int nid = g->ied - isd + 1;
   int i, j;
   for (i = ifirst; i <= ilast; i++) {
     for (j = jsd; j <= jed; j++) ql[j] = q[(size_t)(j - jsd) * ldq + (i - ifirst)];
     for (j = js; j <= je + 1; j++) cl[j] = c[(size_t)(j - js) * ldc + (i - isd)];
-    fvo_ppm_line(ql, cl, fl, js, je, jord, g->lim_fac);
+    if (cubed) {
+      for (j = jsd; j <= jed; j++) dl[j] = g->dya[(size_t)(j - jsd) * nid + (i - isd)];
+      fvo_ppm_line_cs(ql, cl, fl, js, je, jord, g->lim_fac, dl, g->npy);
+    } else
+      fvo_ppm_line(ql, cl, fl, js, je, jord, g->lim_fac);
     for (j = js; j <= je + 1; j++) flux[(size_t)(j - js) * ldq + (i - ifirst)] = fl[j];
   }
   free(line);
@@ -463,7 +582,7 @@ int fvo_fv_tp_2d(const fvo_grid *g, double *q, const double *crx, const double *
   const int nid = ied - isd + 1, njd = jed - jsd + 1, nx = ie - is + 1, ny = je - js + 1;
   int i, j, ord_in, ord_ou;
   double damp;
-  if (g->grid_type < 3 || g->bounded_domain) return FVO_ERR_UNSUPPORTED;
+  if (g->bounded_domain) return FVO_ERR_UNSUPPORTED;
 #define Q(i, j) q[(size_t)((j)-jsd) * nid + ((i)-isd)]
 #define AREA(i, j) g->area[(size_t)((j)-jsd) * nid + ((i)-isd)]
 #define XFX(i, j) xfx[(size_t)((j)-jsd) * (nx + 1) + ((i)-is)]
@@ -492,6 +611,7 @@ int fvo_fv_tp_2d(const fvo_grid *g, double *q, const double *crx, const double *
     ord_in = hord;
   ord_ou = hord;
 
+  fvo_copy_corners(g, q, 2); /* :143-145 */
   /* :147 yppm(fy2, q, cry, ord_in, isd,ied, ...) */
   yppm_2d(g, fy2, q, cry, ord_in, isd, ied, nid, nid);
   for (j = js; j <= je + 1; j++) /* :150-154 */
@@ -502,6 +622,7 @@ int fvo_fv_tp_2d(const fvo_grid *g, double *q, const double *crx, const double *
 
   /* :161 xppm(fx, q_i, crx(is,js), ord_ou, ..., js,je) */
   xppm_2d(g, fx, q_i, &crx[(size_t)(js - jsd) * (nx + 1)], ord_ou, js, je, nid, js, nx + 1, js);
+  fvo_copy_corners(g, q, 1); /* :164-166 */
   /* :168 xppm(fx2, q, crx, ord_in, ..., jsd,jed) */
   xppm_2d(g, fx2, q, crx, ord_in, jsd, jed, nid, jsd, nx + 1, jsd);
 

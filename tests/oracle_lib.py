@@ -33,6 +33,7 @@ class FvoGrid(C.Structure):
         + [(n, _dp) for n in _A + _U + _V + _B + ["rsina", "sin_sg", "cos_sg"]]
         + [("lim_fac", C.c_double), ("do_diss_est", C.c_int), ("prevent_diss_cooling", C.c_int),
            ("do_f3d", C.c_int)]
+        + [(n, _dp) for n in ["edge_w", "edge_e", "edge_s", "edge_n"]] + [("corner_f", C.c_double * 12)]
     )
 
 
@@ -107,6 +108,15 @@ def make_grid(g) -> FvoGrid:
         setattr(s, n, p(g.m[n]))
     s.lim_fac = g.lim_fac
     s.do_diss_est, s.prevent_diss_cooling, s.do_f3d = int(g.do_diss_est), int(g.prevent_diss_cooling), int(g.do_f3d)
+    if g.grid_type < 3:
+        keep = []
+        for n in ("edge_w", "edge_e", "edge_s", "edge_n"):
+            a = np.ascontiguousarray(g.m[n], dtype=np.float64)
+            keep.append(a)
+            setattr(s, n, a.ctypes.data_as(_dp))
+        for k, v in enumerate(np.asarray(g.m["corner_f"], dtype=np.float64).ravel()):
+            s.corner_f[k] = v
+        s._keep_edges = keep
     s._keep = g  # keep the numpy arrays alive
     return s
 
