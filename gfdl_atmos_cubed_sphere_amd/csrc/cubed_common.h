@@ -1,0 +1,106 @@
+// cubed_common.h -- building blocks of the cubed-sphere (grid_type < 3, one tile per face) kernels.
+//
+// The face-edge and corner rules of the reference are index rules (i == 1, j == npy, ...), a few cells deep.  The kernels in
+// cubed_csw.h / cubed_tp.h / cubed_dsw.h are written as short data-parallel PASSES over index boxes, one thread per
+// (i, j, k) point, with the intermediates of a routine in context-owned device arrays (for the band of cells next to the
+// face edges that these kernels are for, those arrays stay in L2 / Infinity Cache).  Every pass evaluates the reference's
+// expressions in the reference's order, so the results are those of the row-wise formulation bit for bit.
+#pragma once
+
+#include "fv3_common.h"
+
+namespace fv3 {
+
+// extra members of the device gridstruct that only the cubed sphere needs (fv3_grid_upload_cubed)
+struct CubedGeom {
+  const double *edge_w, *edge_e, *edge_s, *edge_n;  // A -> B interpolation weights on the face edges, (npy) / (npx), 1-based
+  const double *rsina;                              // (is:ie+1, js:je+1)
+  double corner_f[12];                              // extrap_corner factors of a2b_ord4: sw, se, ne, nw x 3 pairs
+  int ready;
+};
+
+// A pass = functor f(i, j, k) over the box [i0, i1] x [j0, j1] x [0, nk): 64 x 4 points per workgroup, i fastest.
+template <class F>
+struct BoxPass {
+  int i0, i1, j0, j1;
+  F f;
+  FV3_HD void operator()(int bx, int by, int bz, int tid, double *) const {
+    for (int t = tid; t < 256; t += kNT) {
+      const int i = i0 + bx * 64 + (t & 63), j = j0 + by * 4 + (t >> 6);
+      if (i <= i1 && j <= j1) f(i, j, bz);
+    }
+  }
+};
+
+// Level views of the reference's array kinds (Fortran indices).
+struct VA { double *p; int nid, isd, jsd; size_t n; FV3_HD double &operator()(int i, int j, int k) const { return p[(size_t)k * n + (size_t)(j - jsd) * nid + (i - isd)]; } };
+struct CA { const double *p; int nid, isd, jsd; size_t n; FV3_HD double operator()(int i, int j, int k) const { return p[(size_t)k * n + (size_t)(j - jsd) * nid + (i - isd)]; } };
+inline VA view_A(const Grid &g, double *p) { return VA{p, g.nid, g.isd, g.jsd, g.nA()}; }
+inline VA view_U(const Grid &g, double *p) { return VA{p, g.nid, g.isd, g.jsd, g.nU()}; }
+inline VA view_V(const Grid &g, double *p) { return VA{p, g.nid + 1, g.isd, g.jsd, g.nV()}; }
+inline VA view_B(const Grid &g, double *p) { return VA{p, g.nid + 1, g.isd, g.jsd, g.nB()}; }
+inline CA cview_A(const Grid &g, const double *p) { return CA{p, g.nid, g.isd, g.jsd, g.nA()}; }
+inline CA cview_U(const Grid &g, const double *p) { return CA{p, g.nid, g.isd, g.jsd, g.nU()}; }
+inline CA cview_V(const Grid &g, const double *p) { return CA{p, g.nid + 1, g.isd, g.jsd, g.nV()}; }
+inline CA cview_B(const Grid &g, const double *p) { return CA{p, g.nid + 1, g.isd, g.jsd, g.nB()}; }
+inline VA view_CX(const Grid &g, double *p) { return VA{p, g.nx + 1, g.is, g.jsd, g.nCX()}; }
+inline VA view_CY(const Grid &g, double *p) { return VA{p, g.nid, g.isd, g.js, g.nCY()}; }
+inline CA cview_CX(const Grid &g, const double *p) { return CA{p, g.nx + 1, g.is, g.jsd, g.nCX()}; }
+inline CA cview_CY(const Grid &g, const double *p) { return CA{p, g.nid, g.isd, g.js, g.nCY()}; }
+inline VA view_FX(const Grid &g, double *p) { return VA{p, g.nx + 1, g.is, g.js, g.nFX()}; }
+inline VA view_FY(const Grid &g, double *p) { return VA{p, g.nx, g.is, g.js, g.nFY()}; }
+inline CA cview_FX(const Grid &g, const double *p) { return CA{p, g.nx + 1, g.is, g.js, g.nFX()}; }
+inline CA cview_FY(const Grid &g, const double *p) { return CA{p, g.nx, g.is, g.js, g.nFY()}; }
+inline VA view_CC(const Grid &g, double *p) { return VA{p, g.nx, g.is, g.js, g.nCC()}; }
+inline CA cview_CC(const Grid &g, const double *p) { return CA{p, g.nx, g.is, g.js, g.nCC()}; }
+// 2-D metric arrays: k = 0
+#define FV3_M(view, i, j) (view)((i), (j), 0)
+
+// fill_4corners (sw_core.F90:3506-3553) as an index map: where the x- (dir 1) or y- (dir 2) sweep of c_sw / update_dz_c reads
+// a cell of a corner region, it reads the cell this returns instead.  Every face owns all four corners.
+FV3_HD void fill4_src(int dir, int npx, int npy, int &i, int &j) {
+  if (dir == 1) {
+    if (j == 0) {
+      if (i == -1) { i = 0; j = 2; } else if (i == 0) { i = 0; j = 1; }                            // sw
+      else if (i == npx + 1) { i = npx; j = 2; } else if (i == npx) { i = npx; j = 1; }           // se
+    } else if (j == npy) {
+      if (i == 0) { i = 0; j = npy - 1; } else if (i == -1) { i = 0; j = npy - 2; }                // nw
+      else if (i == npx) { i = npx; j = npy - 1; } else if (i == npx + 1) { i = npx; j = npy - 2; }  // ne
+    }
+  } else {
+    if (i == 0) {
+      if (j == 0) { i = 1; j = 0; } else if (j == -1) { i = 2; j = 0; }                            // sw
+      else if (j == npy) { i = 1; j = npy; } else if (j == npy + 1) { i = 2; j = npy; }           // nw
+    } else if (i == npx) {
+      if (j == 0) { i = npx - 1; j = 0; } else if (j == -1) { i = npx - 2; j = 0; }                // se
+      else if (j == npy) { i = npx - 1; j = npy; } else if (j == npy + 1) { i = npx - 2; j = npy; }  // ne
+    }
+  }
+}
+
+// copy_corners (tp_core.F90:245-322) as an index map: the cell a sweep in direction dir reads in place of a cell of a
+// corner region of the halo (ng = 3).
+FV3_HD void copyc_src(int dir, int npx, int npy, int &i, int &j) {
+  const bool w = i <= 0, e = i >= npx, s = j <= 0, n = j >= npy;
+  if (!((w || e) && (s || n))) return;
+  const int ii = i, jj = j;
+  if (dir == 1) {
+    if (w && s) { i = jj; j = 1 - ii; }
+    else if (e && s) { i = npy - jj; j = ii - npx + 1; }
+    else if (e && n) { i = jj; j = 2 * npx - 1 - ii; }
+    else { i = npy - jj; j = ii - 1 + npx; }
+  } else {
+    if (w && s) { i = 1 - jj; j = ii; }
+    else if (e && s) { i = npy + jj - 1; j = npx - ii; }
+    else if (e && n) { i = 2 * npy - 1 - jj; j = ii; }
+    else { i = jj + 1 - npx; j = npy - ii; }
+  }
+}
+
+// edge_interpolate4, sw_core.F90:3348-3359
+FV3_HD double edge_interpolate4(double u1, double u2, double u3, double u4, double d1, double d2, double d3, double d4) {
+  const double t1 = d1 + d2, t2 = d3 + d4;
+  return 0.5 * (((t1 + d2) * u2 - d2 * u1) / t1 + ((t2 + d3) * u3 - d3 * u4) / t2);
+}
+
+}  // namespace fv3

@@ -10,6 +10,8 @@
 
 #include "csw_kernel.h"
 #include "csw_march.h"
+#include "cubed_csw.h"
+#include "cubed_tp.h"
 #include "dsw_kernels.h"
 #include "dsw_march.h"
 #include "dsw_fused.h"
@@ -79,6 +81,10 @@ struct fv3_ctx {
   int n_plain_z, n_damp_z;
   double *ke_scr;        // B kind, npz levels: KE + damping term at the corners
   double *mflux[2];      // mass-flux scratch of the marching transports: FX kind, FY kind (npz levels)
+  // cubed sphere (grid_type < 3): edge weights / corner factors and the work arrays of the pass kernels (B x (npz+1) each)
+  CubedGeom cg;
+  double *cg_dev;
+  double *cs_scr[24];
   int march_tj;          // rows per wavefront segment of the marching kernels
   int march_tj_csw, march_tj_ke, march_tj_fused, march_tj_mom;
   int trc_nt;  // tracers per wavefront in the sub-cycle kernel (FV3_MI355X_TRACER_NT: 1..4, default 3)
@@ -207,8 +213,11 @@ extern "C" int fv3_profile_report(fv3_ctx *c, char *out, size_t cap) {
 extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   if (!dom || !out) return fail("fv3_create: null argument");
   if (dom->ng != NG) return fail("fv3_create: ng must be %d", NG);
-  if (dom->grid_type < 4)
-    return fail("fv3_create: grid_type=%d not supported (only the grid_type=4 branches are built)", dom->grid_type);
+  if (dom->grid_type == 3 || dom->grid_type < 0)
+    return fail("fv3_create: grid_type=%d not supported (4 = doubly periodic, 0..2 = cubed sphere)", dom->grid_type);
+  if (dom->grid_type < 3 && (dom->is != 1 || dom->js != 1 || dom->ie != dom->npx - 1 || dom->je != dom->npy - 1 ||
+                             dom->npx != dom->npy))
+    return fail("fv3_create: a cubed-sphere context is one whole face (layout 1 x 1 per tile): is = js = 1, ie = je = npx - 1");
   if (dom->ie < dom->is || dom->je < dom->js || dom->npz < 1) return fail("fv3_create: empty domain");
   fv3_ctx *c = new (std::nothrow) fv3_ctx();
   if (!c) return fail("fv3_create: out of host memory");
@@ -233,6 +242,9 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->klist_m = nullptr; c->n_plain_m = c->n_rest_m = 0; c->ke_scr = nullptr;
   c->klist_z = nullptr; c->n_plain_z = c->n_damp_z = 0;
   c->mflux[0] = c->mflux[1] = nullptr;
+  std::memset(&c->cg, 0, sizeof c->cg);
+  c->cg_dev = nullptr;
+  for (auto &p : c->cs_scr) p = nullptr;
   {  // tuning / fallback knobs
     const char *e = std::getenv("FV3_MI355X_MARCH");
     c->use_march = e ? std::atoi(e) : 1;
@@ -302,6 +314,8 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   if (c->lev_ext_i) rt_free(c->lev_ext_i);
   for (auto &s : c->scratch) if (s) rt_free(s);
   for (auto &s : c->mflux) if (s) rt_free(s);
+  for (auto &s : c->cs_scr) if (s) rt_free(s);
+  if (c->cg_dev) rt_free(c->cg_dev);
   if (c->stream2) rt_stream_destroy(c->stream2);
   if (c->ev_fork) rt_event_destroy(c->ev_fork);
   if (c->ev_join) rt_event_destroy(c->ev_join);
@@ -554,6 +568,82 @@ struct Tp2dKernel {
   }
 };
 
+// ---- cubed sphere (grid_type < 3): pass kernels ------------------------------------------------------------------------
+template <class F>
+static int launch_box(fv3_ctx *c, const char *label, int i0, int i1, int j0, int j1, int nk, const F &f) {
+  if (i1 < i0 || j1 < j0 || nk <= 0) return 0;
+  Dim3 grid;
+  grid.x = (unsigned)((i1 - i0 + 64) / 64);
+  grid.y = (unsigned)((j1 - j0 + 4) / 4);
+  grid.z = (unsigned)nk;
+  return launch_p(c, label, grid, 0, BoxPass<F>{i0, i1, j0, j1, f});
+}
+// n-th work array of the cubed-sphere kernels: (nid+1) x (njd+1) x (npz+1) doubles, allocated on first use
+static double *cs_scratch(fv3_ctx *c, int n) {
+  if (!c->cs_scr[n]) {
+    if (rt_malloc((void **)&c->cs_scr[n], sizeof(double) * c->g.nB() * (size_t)(c->g.npz + 1))) return nullptr;
+  }
+  return c->cs_scr[n];
+}
+static bool is_cubed(const fv3_ctx *c) { return c->g.grid_type < 3; }
+
+extern "C" int fv3_grid_upload_cubed(fv3_ctx *c, const fv3_grid_cubed *h) {
+  if (!c || !h) return fail("fv3_grid_upload_cubed: null argument");
+  if (!is_cubed(c)) return fail("fv3_grid_upload_cubed: the context is not a cubed-sphere face (grid_type < 3)");
+  if (!h->edge_w || !h->edge_e || !h->edge_s || !h->edge_n || !h->rsina) return fail("fv3_grid_upload_cubed: null array");
+  const Grid &g = c->g;
+  const size_t ne = (size_t)g.npx, nr = (size_t)(g.nx + 1) * (g.ny + 1);
+  const size_t total = 4 * ((ne + 7) & ~(size_t)7) + nr;
+  if (!c->cg_dev) RT(rt_malloc((void **)&c->cg_dev, total * sizeof(double)));
+  double *p = c->cg_dev;
+  const double *src[4] = {h->edge_w, h->edge_e, h->edge_s, h->edge_n};
+  const double **dst[4] = {&c->cg.edge_w, &c->cg.edge_e, &c->cg.edge_s, &c->cg.edge_n};
+  for (int n = 0; n < 4; n++) {
+    RT(rt_h2d(p, src[n], ne * sizeof(double), c->stream));
+    *dst[n] = p - 1;  // 1-based
+    p += (ne + 7) & ~(size_t)7;
+  }
+  RT(rt_h2d(p, h->rsina, nr * sizeof(double), c->stream));
+  c->cg.rsina = p;
+  for (int n = 0; n < 12; n++) c->cg.corner_f[n] = h->corner_f[n];
+  RT(rt_sync(c->stream));
+  c->cg.ready = 1;
+  return 0;
+}
+
+// fv_tp_2d on a cubed-sphere face: fx, fy = the fluxes of tp_core.F90:187-224 (times mfx / mfy or xfx / yfx); scratch 4..7
+static int tp2d_cubed(fv3_ctx *c, int nk, const double *q, const double *crx, const double *cry, int hord, double *fx,
+                      double *fy, const double *xfx, const double *yfx, const double *ra_x, const double *ra_y,
+                      const double *mfx, const double *mfy, const char *label = "fv_tp_2d") {
+  const Grid &g = c->g;
+  Tp2dCubedState s;
+  s.g = g; s.q = q; s.crx = crx; s.cry = cry; s.xfx = xfx; s.yfx = yfx; s.ra_x = ra_x; s.ra_y = ra_y;
+  s.mfx = mfx; s.mfy = mfy; s.fx = fx; s.fy = fy; s.hord = hord;
+  double **scr[4] = {&s.fx2, &s.fy2, &s.q_i, &s.q_j};
+  for (int n = 0; n < 4; n++)
+    if (!(*scr[n] = cs_scratch(c, 4 + n))) return fail("fv_tp_2d: out of device memory");
+  RT(launch_box(c, label, g.isd, g.ied, g.jsd, g.jed, nk, Tp2dCubedT1{s}));
+  RT(launch_box(c, label, g.isd, g.ied, g.jsd, g.jed, nk, Tp2dCubedT2{s}));
+  RT(launch_box(c, label, g.is, g.ie + 1, g.js, g.je + 1, nk, Tp2dCubedT3{s}));
+  return 0;
+}
+
+static int csw_cubed(fv3_ctx *c, const CswArgs &ca) {
+  const Grid &g = c->g;
+  double *scr[4];
+  for (int n = 0; n < 4; n++)
+    if (!(scr[n] = cs_scratch(c, n))) return fail("c_sw: out of device memory");
+  const CswCubedState s = make_csw_cubed(g, ca, scr);
+  const int npz = g.npz;
+  RT(launch_box(c, "c_sw", g.isd, g.ied, g.jsd, g.jed, npz, CswCubedP1{s}));
+  RT(launch_box(c, "c_sw", g.is - 2, g.ie + 2, g.js - 2, g.je + 2, npz, CswCubedP2{s}));
+  RT(launch_box(c, "c_sw", 0, 2, 0, 0, npz, CswCubedP2c{s}));
+  RT(launch_box(c, "c_sw", g.is - 1, g.ie + 2, g.js - 1, g.je + 2, npz, CswCubedP3{s}));
+  RT(launch_box(c, "c_sw", g.is - 1, g.ie + 1, g.js - 1, g.je + 1, npz, CswCubedP4{s}));
+  RT(launch_box(c, "c_sw", g.is - 1, g.ie + 1, g.js - 1, g.je + 1, npz, CswCubedP5{s}));
+  return 0;
+}
+
 extern "C" int fv3_fv_tp_2d(fv3_ctx *c, int nk, const double *q, const double *crx, const double *cry, int hord,
                             double *fx, double *fy, const double *xfx, const double *yfx, const double *ra_x,
                             const double *ra_y, const double *mfx, const double *mfy, const double *mass, int nord,
@@ -562,6 +652,11 @@ extern "C" int fv3_fv_tp_2d(fv3_ctx *c, int nk, const double *q, const double *c
   if (!tp_ord_supported_tr(hord)) return fail("fv3_fv_tp_2d: hord=%d not supported (5,-5,6,8,9,10,11,12,13)", hord);
   if (nord > 2) return fail("fv3_fv_tp_2d: nord=%d > 2", nord);
   if ((mfx == nullptr) != (mfy == nullptr)) return fail("fv3_fv_tp_2d: mfx and mfy must be given together");
+  if (is_cubed(c)) {
+    if (nord >= 0 && damp_c > 1.e-4) return fail("fv3_fv_tp_2d: deln_flux damping is not built for the cubed sphere yet");
+    if (nk > c->g.npz + 1) return fail("fv3_fv_tp_2d: nk > npz + 1 on a cubed-sphere context");
+    return tp2d_cubed(c, nk, q, crx, cry, hord, fx, fy, xfx, yfx, ra_x, ra_y, mfx, mfy);
+  }
   constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
   Tp2dKernel<TI, TJ> kf{c->g, q, crx, cry, xfx, yfx, ra_x, ra_y, mfx, mfy, mass, fx, fy, hord, nord, damp_c};
   Dim3 grid;
@@ -603,6 +698,10 @@ extern "C" int fv3_c_sw(fv3_ctx *c, double *delpc, const double *delp, double *p
   (void)dord4;  // ua, va are produced on is-1:ie+1 (what c_sw/d_sw read); see header
   if (!c || !c->grid_ready) return fail("fv3_c_sw: context has no grid (call fv3_grid_upload)");
   if (!hydrostatic && (!w || !wc)) return fail("fv3_c_sw: nonhydrostatic call needs w and wc");
+  if (is_cubed(c)) {
+    if (!c->cg.ready) return fail("fv3_c_sw: cubed-sphere context without fv3_grid_upload_cubed");
+    return csw_cubed(c, CswArgs{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2});
+  }
   if (c->use_march) {
     const CswArgs ca{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2};
     // rows per segment: 64 for the two-levels-per-wavefront kernel (one wavefront per SIMD); the uniform-metric kernel

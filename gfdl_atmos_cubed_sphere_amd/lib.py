@@ -30,7 +30,7 @@ _V = ["dy", "rdy", "dxc", "rdxc", "cosa_u", "sina_u", "rsin_u", "divg_v", "del6_
 _B = ["rarea_c", "fC", "cosa", "sina"]
 
 # every symbol include/fv3_mi355x.h declares (tests check the built library exports all of them)
-EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_grid_geom", "fv3_malloc",
+EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_grid_upload_cubed", "fv3_grid_geom", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
            "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report",
@@ -51,6 +51,10 @@ class _Domain(C.Structure):
 class _GridHost(C.Structure):
     _fields_ = [("da_min", C.c_double), ("da_min_c", C.c_double)] + [(n, _dp) for n in
                                                                       _A + _U + _V + _B + ["sin_sg", "cos_sg"]]
+
+
+class _GridCubed(C.Structure):
+    _fields_ = [(n, _dp) for n in ["edge_w", "edge_e", "edge_s", "edge_n", "rsina"]] + [("corner_f", C.c_double * 12)]
 
 
 class _DswParams(C.Structure):
@@ -239,6 +243,15 @@ class Context:
             setattr(gh, n, a.ctypes.data_as(_dp))
         self.lib.check(self.lib.dll.fv3_grid_upload(self.h, C.byref(gh)), "fv3_grid_upload")
         self.geom = int(self.lib.dll.fv3_grid_geom(self.h))  # 0 general, 1 orthogonal, 2 orthogonal + uniform
+        if grid.grid_type < 3:      # a face of the cubed sphere: edge weights, rsina, corner extrapolation factors
+            gc = _GridCubed()
+            for n in ("edge_w", "edge_e", "edge_s", "edge_n", "rsina"):
+                a = np.asfortranarray(grid.m[n], dtype=np.float64)
+                keep.append(a)
+                setattr(gc, n, a.ctypes.data_as(_dp))
+            for k, v in enumerate(np.asarray(grid.m["corner_f"], dtype=np.float64).ravel()):
+                gc.corner_f[k] = v
+            self.lib.check(self.lib.dll.fv3_grid_upload_cubed(self.h, C.byref(gc)), "fv3_grid_upload_cubed")
 
     # -- plumbing ------------------------------------------------------------------------------
     def set_stream(self, stream: int):

@@ -26,8 +26,9 @@
  *     the caller's to refresh (exactly where the reference calls start_group_halo_update,
  *     model/dyn_core.F90:823-825,1169).
  *   - Work is enqueued on the context's HIP stream (fv3_set_stream); nothing synchronises.
- *   - Supported branch set in this version: grid_type = 4 (doubly periodic / Cartesian branches
- *     of the reference) with array-valued metric terms, no nesting, no regional BCs.
+ *   - Supported branch sets: grid_type = 4 (doubly periodic / Cartesian branches of the reference) with array-valued
+ *     metric terms, and grid_type < 3 (a whole face of the cubed sphere per context: face edges and corners); no nesting,
+ *     no regional BCs.
  */
 #ifndef FV3_MI355X_H
 #define FV3_MI355X_H
@@ -46,7 +47,7 @@ typedef struct fv3_domain {
   int is, ie, js, je; /* compute domain (global indices of this rank's block) */
   int ng;             /* halo width, 3 (tools/fv_mp_mod.F90:61) */
   int npx, npy, npz;  /* global corner counts and number of levels */
-  int grid_type;      /* 4 */
+  int grid_type;      /* 4 = doubly periodic (Cartesian), 0..2 = a face of the cubed sphere */
   int do_diss_est, prevent_diss_cooling, stretched_grid;
   double lim_fac;
 } fv3_domain;
@@ -62,12 +63,24 @@ typedef struct fv3_grid_host {
   const double *sin_sg, *cos_sg;                                                     /* A x 9 */
 } fv3_grid_host;
 
+/* The extra gridstruct members a cubed-sphere face needs (grid_type < 3; one context = one whole face, is = js = 1,
+ * ie = je = npx - 1): the A -> B interpolation weights on the four face edges (edge_w / edge_e (npy), edge_s / edge_n (npx),
+ * model/fv_grid_utils.F90:1121-1230), rsina (is:ie+1, js:je+1) and the extrap_corner factors x1 / (x2 - x1) of a2b_ord4
+ * (model/a2b_edge.F90:83-112, :452-462; corners sw, se, ne, nw x the three centre pairs in the reference's order).
+ * HOST pointers, copied once; call after fv3_grid_upload. */
+typedef struct fv3_grid_cubed {
+  const double *edge_w, *edge_e, *edge_s, *edge_n;
+  const double *rsina;
+  double corner_f[12];
+} fv3_grid_cubed;
+
 const char *fv3_last_error(void);
 int fv3_create(const fv3_domain *dom, fv3_ctx **out);
 int fv3_destroy(fv3_ctx *ctx);
 /* stream: a hipStream_t (NULL = default stream). */
 int fv3_set_stream(fv3_ctx *ctx, void *stream);
 int fv3_grid_upload(fv3_ctx *ctx, const fv3_grid_host *g);
+int fv3_grid_upload_cubed(fv3_ctx *ctx, const fv3_grid_cubed *g);
 /* Geometry mode fv3_grid_upload found in the metric arrays (or -1 without a grid): 0 = general (every metric row is
  * read); 1 = orthogonal: cosa_s, cosa_u, cosa_v = 0 and rsin2, sina_u, sina_v, rsin_u, rsin_v, sin_sg(:,:,1:4) = 1
  * in every element, what fv_grid_utils.F90:427 / fv_grid_tools.F90:1202-1221 set for grid_type >= 3 -- the kernels
