@@ -12,6 +12,7 @@
 #include "csw_march.h"
 #include "cubed_csw.h"
 #include "cubed_tp.h"
+#include "cubed_dsw.h"
 #include "dsw_kernels.h"
 #include "dsw_march.h"
 #include "dsw_fused.h"
@@ -79,6 +80,9 @@ struct fv3_ctx {
   int n_plain_m, n_rest_m;
   int *klist_z;          // npz+1 interfaces of update_dz_d: [undamped..., damped...]
   int n_plain_z, n_damp_z;
+  int lev_max_nord;      // max over the levels of nord_k
+  bool lev_has_dcon;     // some level has d_con_k > 1e-5
+  bool lev_has_vt_damp, lev_has_w_damp;  // damp_vt / damp_t > 1e-4 resp. damp_w > 1e-5 on some level
   double *ke_scr;        // B kind, npz levels: KE + damping term at the corners
   double *mflux[2];      // mass-flux scratch of the marching transports: FX kind, FY kind (npz levels)
   // cubed sphere (grid_type < 3): edge weights / corner factors and the work arrays of the pass kernels (B x (npz+1) each)
@@ -481,6 +485,14 @@ extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
     RT(rt_h2d(c->klist_m, pm.data(), sizeof(int) * npz, c->stream));
     RT(rt_sync(c->stream));
   }
+  c->lev_max_nord = 0;
+  c->lev_has_dcon = c->lev_has_vt_damp = c->lev_has_w_damp = false;
+  for (int k = 0; k < npz; k++) {
+    c->lev_max_nord = std::max(c->lev_max_nord, lv->nord_k[k]);
+    if (lv->d_con_k[k] > 1.E-5) c->lev_has_dcon = true;
+    if (lv->damp_vt[k] > 1.E-5 || lv->damp_t[k] > 1.E-4) c->lev_has_vt_damp = true;
+    if (lv->damp_w[k] > 1.E-5) c->lev_has_w_damp = true;
+  }
   c->lev_ready = true;
   return 0;
 }
@@ -881,6 +893,53 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
   });
 }
 
+// d_sw on a cubed-sphere face (cubed_dsw.h); scratch 8..20
+static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
+  const Grid &g = c->g;
+  if (!c->cg.ready) return fail("fv3_d_sw: cubed-sphere context without fv3_grid_upload_cubed");
+  if (a.use_cond) return fail("fv3_d_sw: use_cond is not built for the cubed sphere yet");
+  if (a.dddmp >= 1.E-5) return fail("fv3_d_sw: Smagorinsky damping (dddmp > 0) is not built for the cubed sphere yet");
+  if (g.do_diss_est) return fail("fv3_d_sw: do_diss_est is not built for the cubed sphere yet");
+  if (c->lev_has_vt_damp || (!a.hydrostatic && c->lev_has_w_damp))
+    return fail("fv3_d_sw: del-2n damping of delp / w / pt / vorticity is not built for the cubed sphere yet");
+  if (c->lev_has_dcon) return fail("fv3_d_sw: dissipative heating (d_con > 0) is not built for the cubed sphere yet");
+  DswCubedState s;
+  s.g = g; s.cg = c->cg; s.a = a;
+  double **scr[13] = {&s.ut, &s.vt, &s.fx, &s.fy, &s.gxw, &s.gyw, &s.gx, &s.gy, &s.ke, &s.wk, &s.dd, &s.svc, &s.suc};
+  for (int n = 0; n < 13; n++)
+    if (!(*scr[n] = cs_scratch(c, 8 + n))) return fail("d_sw: out of device memory");
+  const int npz = g.npz, npx = g.npx, npy = g.npy;
+  const char *L = "d_sw_cubed";
+  RT(launch_box(c, L, g.isd, g.ied + 1, g.jsd, g.jed + 1, npz, DswCubedD1a{s}));
+  RT(launch_box(c, L, 0, npx, 0, npy, npz, DswCubedD1b{s}));
+  RT(launch_box(c, L, 0, 3, 0, 0, npz, DswCubedD1c{s}));
+  RT(launch_box(c, L, g.isd, g.ied, g.jsd, g.jed, npz, DswCubedD2{s}));
+  RT(tp2d_cubed(c, npz, a.delp, a.crx, a.cry, a.hord_dp, s.fx, s.fy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, L));
+  if (!a.hydrostatic)
+    RT(tp2d_cubed(c, npz, a.w, a.crx, a.cry, a.hord_vt, s.gxw, s.gyw, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, L));
+  RT(tp2d_cubed(c, npz, a.pt, a.crx, a.cry, a.hord_tm, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, L));
+  RT(launch_box(c, L, g.is, g.ie + 1, g.js, g.je + 1, npz, DswCubedD4{s}));
+  RT(launch_box(c, L, g.is, g.ie + 1, g.js, g.je + 1, npz, DswCubedD5{s}));
+  RT(launch_box(c, L, g.isd, g.ied + 1, g.jsd, g.jed + 1, npz, DswCubedD6{s}));
+  for (int n = 1; n <= c->lev_max_nord; n++) {
+    const bool may_fill = c->lev_max_nord - n != 0;   // some level may have nt /= 0 in this iteration
+    if (may_fill) RT(launch_box(c, L, 1, 3, 1, 3, npz, DswCubedFillB{s, 1, n}));
+    RT(launch_box(c, L, g.is - 3, g.ie + 3, g.js - 3, g.je + 4, npz, DswCubedDampVC{s, n, 0}));
+    if (may_fill) RT(launch_box(c, L, 1, 3, 1, 3, npz, DswCubedFillB{s, 2, n}));
+    RT(launch_box(c, L, g.is - 3, g.ie + 4, g.js - 3, g.je + 3, npz, DswCubedDampVC{s, n, 1}));
+    if (may_fill) {
+      RT(launch_box(c, L, 1, 3, 1, 3, npz, DswCubedFillD{s, 0, n}));
+      RT(launch_box(c, L, 1, 3, 1, 3, npz, DswCubedFillD{s, 1, n}));
+    }
+    RT(launch_box(c, L, g.is - 2, g.ie + 3, g.js - 2, g.je + 3, npz, DswCubedDampDiv{s, n}));
+  }
+  RT(launch_box(c, L, g.is, g.ie + 1, g.js, g.je + 1, npz, DswCubedD7{s}));
+  RT(launch_box(c, L, g.isd, g.ied, g.jsd, g.jed, npz, DswCubedD8{s}));
+  RT(tp2d_cubed(c, npz, s.wk, a.crx, a.cry, a.hord_vt, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, L));
+  RT(launch_box(c, L, g.is, g.ie + 1, g.js, g.je + 1, npz, DswCubedD9{s}));
+  return 0;
+}
+
 // phase 0: the whole routine; 1: only the part that needs no halo of uc, vc, divg_d (interior strips / segments of the
 // fused transport kernel); 2: everything else, after phase 1
 static int d_sw_impl(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const double *delp, const double *pt,
@@ -914,6 +973,10 @@ static int d_sw_impl(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const d
   a.delp_out = delp_out; a.pt_out = pt_out; a.u_out = u_out; a.v_out = v_out; a.w_out = w_out;
   a.q_con_out = q_con_out; a.heat_s = heat_s; a.diss_e = diss_e; a.delpc = delpc;
 
+  if (is_cubed(c)) {
+    if (phase == 1) return 0;  // no interior / rest split on a face: everything runs in 'rest' (or the unsplit call)
+    return dsw_cubed(c, a);
+  }
   // the fused marching kernel forms the Courant numbers itself for its levels
   const bool fused = c->use_march && c->use_fused && !a.use_cond && a.hord_dp == a.hord_tm &&
                      (a.hydrostatic || a.hord_dp == a.hord_vt);

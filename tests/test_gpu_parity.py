@@ -577,3 +577,35 @@ def test_reversed_winds_whole_substeps_and_tracers(prod):
     D.check_substeps_hydrostatic(prod, nx=130, ny=30, npz=6, n_split=2, bdt=8.0, ic="westward")
     T.check_tracer_2d(prod, nx=130, ny=30, npz=3, nq=3, reverse=True)
     T.check_tracer_2d(prod, nx=130, ny=30, npz=3, nq=4, reverse=True, big_courant=True)
+
+
+# ---- cubed sphere (grid_type < 3): the pass kernels against the oracle, all six faces ----------------------------------
+import parity_cubed as PC
+
+
+@pytest.mark.parametrize("hydrostatic", [False, True])
+def test_cubed_c_sw(prod, hydrostatic):
+    assert PC.check_c_sw(prod, npx=13, npz=3, hydrostatic=hydrostatic) <= P.TOL
+    assert PC.check_c_sw(prod, npx=49, npz=4, hydrostatic=hydrostatic) <= P.TOL          # C48 faces
+
+
+@pytest.mark.parametrize("hord", [10, 8, 5, -5, 6, 9, 11, 12, 13])
+def test_cubed_fv_tp_2d(prod, hord):
+    assert PC.check_fv_tp_2d(prod, hord, npx=25) <= P.TOL
+    assert PC.check_fv_tp_2d(prod, hord, npx=25, mass_flux=True, faces=(2, 5)) <= P.TOL
+
+
+@pytest.mark.parametrize("kw", [dict(hydrostatic=True), dict(hydrostatic=True, flags=dict(nord=2)),
+                                dict(hydrostatic=True, flags=dict(nord=3)),
+                                dict(hydrostatic=True, par_over=dict(hord_mt=5, hord_vt=5, hord_tm=5, hord_dp=5)),
+                                dict(hydrostatic=True, par_over=dict(hord_mt=6, hord_vt=6, hord_tm=6, hord_dp=-5)),
+                                dict(hydrostatic=True, par_over=dict(hord_mt=8, hord_vt=8, hord_tm=8, hord_dp=8)),
+                                dict(hydrostatic=True, par_over=dict(hord_mt=9)),
+                                dict(hydrostatic=False, flags=dict(n_sponge=-1))])
+def test_cubed_d_sw(prod, kw):
+    assert max(PC.check_d_sw(prod, npx=25, npz=3, **kw).values()) <= P.TOL
+
+
+def test_cubed_c48_pair(prod):
+    """a gnomonic C48 face set with all edges and corners: c_sw and d_sw bit for bit against the oracle"""
+    assert max(PC.check_d_sw(prod, npx=49, npz=4, hydrostatic=True).values()) <= P.TOL

@@ -426,3 +426,30 @@ def test_reversed_winds_whole_substeps_and_tracers(emu):
     D.check_substeps_hydrostatic(emu, nx=130, ny=30, npz=6, n_split=2, bdt=8.0, ic="westward")
     T.check_tracer_2d(emu, nx=130, ny=30, npz=3, nq=3, reverse=True)
     T.check_tracer_2d(emu, nx=130, ny=30, npz=3, nq=4, reverse=True, big_courant=True)
+
+
+# ---- cubed sphere (grid_type < 3): the pass kernels against the oracle, all six faces ----------------------------------
+import parity_cubed as PC
+
+
+@pytest.mark.parametrize("hydrostatic", [False, True])
+def test_cubed_c_sw(emu, hydrostatic):
+    assert PC.check_c_sw(emu, npx=13, npz=3, hydrostatic=hydrostatic) <= P.TOL
+    assert PC.check_c_sw(emu, npx=25, npz=2, hydrostatic=hydrostatic, faces=(0, 2, 5)) <= P.TOL
+
+
+@pytest.mark.parametrize("hord", [10, 8, 5, -5, 6, 9, 11, 12, 13])
+def test_cubed_fv_tp_2d(emu, hord):
+    assert PC.check_fv_tp_2d(emu, hord, faces=(0, 3)) <= P.TOL
+    assert PC.check_fv_tp_2d(emu, hord, mass_flux=True, faces=(2, 5)) <= P.TOL
+
+
+@pytest.mark.parametrize("kw", [dict(hydrostatic=True), dict(hydrostatic=True, flags=dict(nord=2)),
+                                dict(hydrostatic=True, flags=dict(nord=3), faces=(1, 4)),
+                                dict(hydrostatic=True, par_over=dict(hord_mt=5, hord_vt=5, hord_tm=5, hord_dp=5), faces=(0, 5)),
+                                dict(hydrostatic=True, par_over=dict(hord_mt=6, hord_vt=6, hord_tm=6, hord_dp=-5), faces=(2,)),
+                                dict(hydrostatic=True, par_over=dict(hord_mt=8, hord_vt=8, hord_tm=8, hord_dp=8), faces=(3,)),
+                                dict(hydrostatic=True, par_over=dict(hord_mt=9), faces=(4,)),
+                                dict(hydrostatic=False, flags=dict(n_sponge=-1))])
+def test_cubed_d_sw(emu, kw):
+    assert max(PC.check_d_sw(emu, npx=13, npz=3, **kw).values()) <= P.TOL
