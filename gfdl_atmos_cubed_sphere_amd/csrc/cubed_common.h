@@ -35,24 +35,24 @@ struct BoxPass {
 // Level views of the reference's array kinds (Fortran indices).
 struct VA { double *p; int nid, isd, jsd; size_t n; FV3_HD double &operator()(int i, int j, int k) const { return p[(size_t)k * n + (size_t)(j - jsd) * nid + (i - isd)]; } };
 struct CA { const double *p; int nid, isd, jsd; size_t n; FV3_HD double operator()(int i, int j, int k) const { return p[(size_t)k * n + (size_t)(j - jsd) * nid + (i - isd)]; } };
-inline VA view_A(const Grid &g, double *p) { return VA{p, g.nid, g.isd, g.jsd, g.nA()}; }
-inline VA view_U(const Grid &g, double *p) { return VA{p, g.nid, g.isd, g.jsd, g.nU()}; }
-inline VA view_V(const Grid &g, double *p) { return VA{p, g.nid + 1, g.isd, g.jsd, g.nV()}; }
-inline VA view_B(const Grid &g, double *p) { return VA{p, g.nid + 1, g.isd, g.jsd, g.nB()}; }
-inline CA cview_A(const Grid &g, const double *p) { return CA{p, g.nid, g.isd, g.jsd, g.nA()}; }
-inline CA cview_U(const Grid &g, const double *p) { return CA{p, g.nid, g.isd, g.jsd, g.nU()}; }
-inline CA cview_V(const Grid &g, const double *p) { return CA{p, g.nid + 1, g.isd, g.jsd, g.nV()}; }
-inline CA cview_B(const Grid &g, const double *p) { return CA{p, g.nid + 1, g.isd, g.jsd, g.nB()}; }
-inline VA view_CX(const Grid &g, double *p) { return VA{p, g.nx + 1, g.is, g.jsd, g.nCX()}; }
-inline VA view_CY(const Grid &g, double *p) { return VA{p, g.nid, g.isd, g.js, g.nCY()}; }
-inline CA cview_CX(const Grid &g, const double *p) { return CA{p, g.nx + 1, g.is, g.jsd, g.nCX()}; }
-inline CA cview_CY(const Grid &g, const double *p) { return CA{p, g.nid, g.isd, g.js, g.nCY()}; }
-inline VA view_FX(const Grid &g, double *p) { return VA{p, g.nx + 1, g.is, g.js, g.nFX()}; }
-inline VA view_FY(const Grid &g, double *p) { return VA{p, g.nx, g.is, g.js, g.nFY()}; }
-inline CA cview_FX(const Grid &g, const double *p) { return CA{p, g.nx + 1, g.is, g.js, g.nFX()}; }
-inline CA cview_FY(const Grid &g, const double *p) { return CA{p, g.nx, g.is, g.js, g.nFY()}; }
-inline VA view_CC(const Grid &g, double *p) { return VA{p, g.nx, g.is, g.js, g.nCC()}; }
-inline CA cview_CC(const Grid &g, const double *p) { return CA{p, g.nx, g.is, g.js, g.nCC()}; }
+FV3_HD VA view_A(const Grid &g, double *p) { return VA{p, g.nid, g.isd, g.jsd, g.nA()}; }
+FV3_HD VA view_U(const Grid &g, double *p) { return VA{p, g.nid, g.isd, g.jsd, g.nU()}; }
+FV3_HD VA view_V(const Grid &g, double *p) { return VA{p, g.nid + 1, g.isd, g.jsd, g.nV()}; }
+FV3_HD VA view_B(const Grid &g, double *p) { return VA{p, g.nid + 1, g.isd, g.jsd, g.nB()}; }
+FV3_HD CA cview_A(const Grid &g, const double *p) { return CA{p, g.nid, g.isd, g.jsd, g.nA()}; }
+FV3_HD CA cview_U(const Grid &g, const double *p) { return CA{p, g.nid, g.isd, g.jsd, g.nU()}; }
+FV3_HD CA cview_V(const Grid &g, const double *p) { return CA{p, g.nid + 1, g.isd, g.jsd, g.nV()}; }
+FV3_HD CA cview_B(const Grid &g, const double *p) { return CA{p, g.nid + 1, g.isd, g.jsd, g.nB()}; }
+FV3_HD VA view_CX(const Grid &g, double *p) { return VA{p, g.nx + 1, g.is, g.jsd, g.nCX()}; }
+FV3_HD VA view_CY(const Grid &g, double *p) { return VA{p, g.nid, g.isd, g.js, g.nCY()}; }
+FV3_HD CA cview_CX(const Grid &g, const double *p) { return CA{p, g.nx + 1, g.is, g.jsd, g.nCX()}; }
+FV3_HD CA cview_CY(const Grid &g, const double *p) { return CA{p, g.nid, g.isd, g.js, g.nCY()}; }
+FV3_HD VA view_FX(const Grid &g, double *p) { return VA{p, g.nx + 1, g.is, g.js, g.nFX()}; }
+FV3_HD VA view_FY(const Grid &g, double *p) { return VA{p, g.nx, g.is, g.js, g.nFY()}; }
+FV3_HD CA cview_FX(const Grid &g, const double *p) { return CA{p, g.nx + 1, g.is, g.js, g.nFX()}; }
+FV3_HD CA cview_FY(const Grid &g, const double *p) { return CA{p, g.nx, g.is, g.js, g.nFY()}; }
+FV3_HD VA view_CC(const Grid &g, double *p) { return VA{p, g.nx, g.is, g.js, g.nCC()}; }
+FV3_HD CA cview_CC(const Grid &g, const double *p) { return CA{p, g.nx, g.is, g.js, g.nCC()}; }
 // 2-D metric arrays: k = 0
 #define FV3_M(view, i, j) (view)((i), (j), 0)
 

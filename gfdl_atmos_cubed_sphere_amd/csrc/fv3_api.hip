@@ -13,6 +13,7 @@
 #include "cubed_csw.h"
 #include "cubed_tp.h"
 #include "cubed_dsw.h"
+#include "cubed_a2b.h"
 #include "dsw_kernels.h"
 #include "dsw_march.h"
 #include "dsw_fused.h"
@@ -1206,6 +1207,69 @@ extern "C" int fv3_halo_unpack(fv3_ctx *c, int nfields, const fv3_halo_field *fi
   return halo_copy(c, nfields, fields, const_cast<double *const *>(recvbuf), false);
 }
 
+// ---- table-driven halo gather: the cubed-sphere face-to-face updates (index reversal, u <-> v with sign) ---------------------
+// One entry = one halo value: ptrs[dst_sel][k * stride[dst_sel] + dst_idx] = sign * ptrs[src_sel][k * stride[src_sel] + src_idx].
+// The tables come from the host (gfdl_atmos_cubed_sphere_amd/cubed_sphere.py: CubeTopology); with all six faces on one GPU one
+// launch fills every halo of a field (pair); across GPUs the same tables drive the pack (dst = message buffer) and unpack sides.
+struct fv3_gather {
+  int n;
+  int *tab;  // device: dst_sel, dst_idx, src_sel, src_idx, sign  (5 x n)
+};
+struct GatherKernel {
+  int n;
+  const int *tab;
+  double *ptr[16];
+  size_t stride[16];
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int k = bz;
+    for (int e = bx * CH + tid; e < (bx + 1) * CH && e < n; e += kNT) {
+      const int ds = tab[e], di = tab[n + e], ss = tab[2 * n + e], si = tab[3 * n + e], sg = tab[4 * n + e];
+      const double v = ptr[ss][(size_t)k * stride[ss] + si];
+      ptr[ds][(size_t)k * stride[ds] + di] = sg < 0 ? -v : v;
+    }
+  }
+};
+extern "C" int fv3_gather_create(fv3_ctx *c, int n, const int *dst_sel, const int *dst_idx, const int *src_sel,
+                                 const int *src_idx, const int *sign, fv3_gather **out) {
+  if (!c || !out || n <= 0 || !dst_sel || !dst_idx || !src_sel || !src_idx || !sign) return fail("fv3_gather_create: bad argument");
+  for (int e = 0; e < n; e++)
+    if (dst_sel[e] < 0 || dst_sel[e] > 15 || src_sel[e] < 0 || src_sel[e] > 15) return fail("fv3_gather_create: selector out of range");
+  fv3_gather *t = new (std::nothrow) fv3_gather();
+  if (!t) return fail("fv3_gather_create: out of host memory");
+  t->n = n;
+  t->tab = nullptr;
+  if (rt_malloc((void **)&t->tab, sizeof(int) * 5 * (size_t)n)) { delete t; return fail("fv3_gather_create: out of device memory"); }
+  const int *src[5] = {dst_sel, dst_idx, src_sel, src_idx, sign};
+  for (int m = 0; m < 5; m++) RT(rt_h2d(t->tab + (size_t)m * n, src[m], sizeof(int) * (size_t)n, c->stream));
+  RT(rt_sync(c->stream));
+  *out = t;
+  return 0;
+}
+extern "C" int fv3_gather_destroy(fv3_gather *t) {
+  if (t) {
+    if (t->tab) rt_free(t->tab);
+    delete t;
+  }
+  return 0;
+}
+extern "C" int fv3_gather_run(fv3_ctx *c, const fv3_gather *t, int nk, int nptr, double *const *ptrs, const size_t *strides) {
+  if (!c || !t || !ptrs || !strides || nptr < 1 || nptr > 16 || nk < 1) return fail("fv3_gather_run: bad argument");
+  GatherKernel kf;
+  kf.n = t->n;
+  kf.tab = t->tab;
+  for (int m = 0; m < 16; m++) {
+    kf.ptr[m] = m < nptr ? ptrs[m] : nullptr;
+    kf.stride[m] = m < nptr ? strides[m] : 0;
+  }
+  Dim3 grid;
+  grid.x = (unsigned)((t->n + GatherKernel::CH - 1) / GatherKernel::CH);
+  grid.y = 1;
+  grid.z = (unsigned)nk;
+  RT(launch_p(c, "halo_gather", grid, 0, kf));
+  return 0;
+}
+
 // ================================================================================================
 // nonhydrostatic column path
 // ================================================================================================
@@ -1523,6 +1587,32 @@ extern "C" int fv3_zh_from_delz(fv3_ctx *c, const double *zs, const double *delz
   return 0;
 }
 
+// a2b_ord4 of up to four fields: the LDS-tile kernel (grid_type >= 3) or the cubed-sphere passes (scratch 0..7)
+template <int TI, int TJ>
+static int run_a2b(fv3_ctx *c, const A2BCorners<TI, TJ> &kf, int nlev_max) {
+  const Grid &g = c->g;
+  if (is_cubed(c)) {
+    if (!c->cg.ready) return fail("a2b_ord4: cubed-sphere context without fv3_grid_upload_cubed");
+    A2bCubedState s;
+    s.g = g; s.cg = c->cg; s.nf = kf.nf; s.override_mask = kf.override_mask;
+    for (int f = 0; f < 4; f++) {
+      s.in[f] = kf.in[f]; s.out[f] = kf.out[f]; s.nlev[f] = kf.nlev[f]; s.scale[f] = kf.scale[f]; s.top[f] = kf.top[f];
+      s.qx[f] = s.qy[f] = nullptr;
+      if (f < kf.nf) {
+        if (!(s.qx[f] = cs_scratch(c, 2 * f)) || !(s.qy[f] = cs_scratch(c, 2 * f + 1))) return fail("a2b_ord4: out of device memory");
+      }
+    }
+    RT(launch_box(c, "a2b_corners", 1, g.npx, 1, g.npy, nlev_max, A2bCubedPa{s}));
+    RT(launch_box(c, "a2b_corners", 1, g.npx, 1, g.npy, nlev_max, A2bCubedPb{s}));
+    return 0;
+  }
+  Dim3 grid;
+  grid.x = (unsigned)((g.nx + 1 + TI - 1) / TI);
+  grid.y = (unsigned)((g.ny + 1 + TJ - 1) / TJ);
+  grid.z = (unsigned)nlev_max;
+  return launch_p(c, "a2b_corners", grid, A2BCorners<TI, TJ>::lds_doubles, kf);
+}
+
 extern "C" int fv3_nh_p_grad(fv3_ctx *c, double *u, double *v, const double *pp, const double *gz, double gz_scale,
                              const double *delp, const double *pk, double dt, double top_value) {
   if (!c || !c->grid_ready) return fail("fv3_nh_p_grad: context has no grid");
@@ -1542,11 +1632,7 @@ extern "C" int fv3_nh_p_grad(fv3_ctx *c, double *u, double *v, const double *pp,
     kf.scale[2] = gz_scale;
     kf.top[0] = 0.; kf.top[1] = top_value; kf.top[2] = kf.top[3] = 0.;
     kf.override_mask = 3;
-    Dim3 grid;
-    grid.x = (unsigned)((g.nx + 1 + TI - 1) / TI);
-    grid.y = (unsigned)((g.ny + 1 + TJ - 1) / TJ);
-    grid.z = (unsigned)(km + 1);
-    RT(launch_p(c, "a2b_corners", grid, A2BCorners<TI, TJ>::lds_doubles, kf));
+    RT((run_a2b<TI, TJ>(c, kf, km + 1)));
   }
   {
     NhPGrad kf{g, dt, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], u, v};
@@ -1596,11 +1682,7 @@ extern "C" int fv3_one_grad_p(fv3_ctx *c, double *u, double *v, const double *pk
     for (int f = 0; f < 4; f++) { kf.scale[f] = 1.0; kf.top[f] = 0.; }
     kf.top[0] = ptk;          // pk(i,j,1) = top_value (:1950-1955)
     kf.override_mask = 1;
-    Dim3 grid;
-    grid.x = (unsigned)((g.nx + 1 + TI - 1) / TI);
-    grid.y = (unsigned)((g.ny + 1 + TJ - 1) / TJ);
-    grid.z = (unsigned)(km + 1);
-    RT(launch_p(c, "a2b_corners", grid, A2BCorners<TI, TJ>::lds_doubles, kf));
+    RT((run_a2b<TI, TJ>(c, kf, km + 1)));
   }
   {
     OneGradPHydro kf{g, dt, c->scratch[0], c->scratch[1], divg2, u, v};

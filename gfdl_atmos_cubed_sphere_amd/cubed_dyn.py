@@ -1,0 +1,125 @@
+"""The six faces of the cubed sphere on ONE GPU behind the single-domain host code: ``MultiContext`` looks like one
+``lib.Context`` (every kernel call is issued once per face on that face's context, every field is a ``FaceSet`` of six device
+arrays) and ``CubeHaloAdapter`` looks like one ``halo.HaloExchanger`` (group halo updates -> the table-driven gathers of
+``cubed_halo.CubeHalo``), so that ``dyn_core.DynCore`` / ``fv_dynamics.FvDynamics`` drive a whole sphere unchanged
+(BASELINE configs 2: C96L79 on one MI355X).  With one face per GPU each rank holds one context and the adapter's tables
+become pack / unpack lists around RCCL messages.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .cubed_halo import CubeHalo
+from .cubed_sphere import CubedSphere
+from .lib import Context
+
+
+class FaceSet:
+    """six DeviceArrays (one per face) handled as one field"""
+
+    def __init__(self, arrs):
+        self.a = list(arrs)
+        self.shape = self.a[0].shape
+
+    def __getitem__(self, t):
+        return self.a[t]
+
+    def upload(self, hosts):
+        for a, h in zip(self.a, hosts if isinstance(hosts, (list, tuple)) else [hosts] * 6):
+            a.upload(h)
+        return self
+
+    def download(self):
+        return [a.download() for a in self.a]
+
+    def zero(self):
+        for a in self.a:
+            a.zero()
+        return self
+
+    def copy_from(self, other):
+        for a, o in zip(self.a, other.a):
+            a.copy_from(o)
+        return self
+
+
+class MultiContext:
+    def __init__(self, ctxs):
+        self.ctxs = list(ctxs)
+        c0 = self.ctxs[0]
+        self.npz, self.bd, self.grid, self.lib = c0.npz, c0.bd, c0.grid, c0.lib
+        self.stream = c0.stream
+
+    def zeros(self, kind, nk=None):
+        return FaceSet([c.zeros(kind, nk) for c in self.ctxs])
+
+    def empty(self, kind, nk=None):
+        return FaceSet([c.empty(kind, nk) for c in self.ctxs])
+
+    def from_host(self, a):
+        if isinstance(a, (list, tuple)):
+            return FaceSet([c.from_host(x) for c, x in zip(self.ctxs, a)])
+        return FaceSet([c.from_host(a) for c in self.ctxs])
+
+    def sync(self):
+        for c in self.ctxs:
+            c.sync()
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+
+    def __getattr__(self, name):
+        fns = [getattr(c, name) for c in self.__dict__["ctxs"]]
+
+        def call(*args, **kw):
+            out = []
+            for t, fn in enumerate(fns):
+                a = [x[t] if isinstance(x, FaceSet) else x for x in args]
+                k = {n: (x[t] if isinstance(x, FaceSet) else x) for n, x in kw.items()}
+                out.append(fn(*a, **k))
+            return out if any(o is not None for o in out) else None
+        return call
+
+
+class CubeHaloAdapter:
+    """group halo updates of the single-domain host code -> CubeHalo gathers"""
+    overlaps = False
+    world = 1
+
+    def __init__(self, mctx: MultiContext, npx: int, topo=None):
+        self.cube = CubeHalo(mctx.ctxs, npx, topo=topo)
+
+    def update(self, fields):
+        fields = list(fields)
+        kinds = [k for _, k in fields]
+        if kinds == ["U", "V"]:
+            self.cube.update("D", (fields[0][0].a, fields[1][0].a))
+        elif kinds == ["V", "U"]:
+            self.cube.update("C", (fields[0][0].a, fields[1][0].a))
+        else:
+            for f, k in fields:
+                if k not in ("A", "B"):
+                    raise ValueError(f"no cubed-sphere halo update for a lone field of kind {k}")
+                self.cube.update(k, f.a)
+
+    def start(self, fields, defer=False):
+        self.update(fields)
+        return None
+
+    def post(self, pending):
+        pass
+
+    def finish(self, pending):
+        pass
+
+    def sync_edges(self, u, v):
+        """mpp_get_boundary(u, v) of the last substep (dyn_core.F90:1151-1163)"""
+        self.cube.update("Dedge", (u.a, v.a))
+
+
+def make_sphere_contexts(npx: int, npz: int, lib=None, sphere: CubedSphere | None = None):
+    cs = sphere or CubedSphere(npx)
+    gs = [cs.gridstruct(t) for t in range(6)]
+    ctxs = [Context(g, npz, lib=lib) for g in gs]
+    return cs, gs, MultiContext(ctxs)

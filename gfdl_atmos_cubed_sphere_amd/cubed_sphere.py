@@ -141,12 +141,52 @@ class CubeTopology:
         self._cache[kind] = out
         return out
 
+    def boundary_table(self):
+        """mpp_get_boundary of (u, v) on the D grid (dyn_core.F90:1151-1163): u(i, npy) of a face takes the value the face
+        across its north edge holds for the same edge, v(npx, j) the value of the face across the east edge.  Same row
+        format as table('D'): [face][member] with member 0 = u rows (north edge), member 1 = v rows (east edge)."""
+        if "Dedge" in self._cache:
+            return self._cache["Dedge"]
+        N, M = self.N, 2 * self.N
+        members = [("U", "x"), ("V", "y")]
+        out = []
+        for t in range(6):
+            n, ex, ey = FRAMES[t]
+            o = self._origin(t)
+            per = []
+            for m, (cls, direc) in enumerate(members):
+                rows = []
+                for s in range(1, N + 1):
+                    if m == 0:
+                        i, j, a, b, nn = s, N + 1, 2 * (s - 1) + 1, M, ey
+                    else:
+                        i, j, a, b, nn = N + 1, s, M, 2 * (s - 1) + 1, ex
+                    p = o + a * ex + b * ey
+                    t2 = next(k for k in range(6) if np.array_equal(FRAMES[k][0], nn))
+                    n2, ex2, ey2 = FRAMES[t2]
+                    q = p - self._origin(t2)
+                    a2, b2 = int(q @ ex2), int(q @ ey2)
+                    d = ex if m == 0 else ey          # the edge direction lies in both faces
+                    if abs(int(d @ ex2)) == 1:
+                        axis, sign = "x", int(d @ ex2)
+                    else:
+                        axis, sign = "y", int(d @ ey2)
+                    cls2 = _class_of(a2, b2)
+                    m2 = next(k for k, (c, dd) in enumerate(members) if c == cls2 and dd == axis)
+                    i2, j2 = (a2 - a2 % 2) // 2 + 1, (b2 - b2 % 2) // 2 + 1
+                    rows.append((self._flat(cls, i, j), t2, 0 if m2 == m else 1, self._flat(cls2, i2, j2), sign))
+                r = np.array(rows, dtype=np.int64)
+                per.append(dict(dst=r[:, 0], tile=r[:, 1], comp=r[:, 2], src=r[:, 3], sign=r[:, 4]))
+            out.append(per)
+        self._cache["Dedge"] = out
+        return out
+
     # ---- numpy halo update of all six faces (the single-process emulation of mpp_update_domains) -------------------------
     def update(self, kind: str, fields, vector: bool = True):
         """fields: for 'A' / 'B' a list of 6 arrays (ni, nj[, nk]); for 'D' / 'C' a pair (list of 6 first members, list of 6
         second members).  vector=False: SCALAR_PAIR (no sign change).  In place."""
-        tab = self.table(kind)
-        pair = kind in ("D", "C")
+        tab = self.boundary_table() if kind == "Dedge" else self.table(kind)
+        pair = kind in ("D", "C", "Dedge")
         mem = fields if pair else (fields,)
         flat = [[np.reshape(x, (x.shape[0] * x.shape[1],) + x.shape[2:], order="F") for x in lst] for lst in mem]
         # gather every source value first (a halo never feeds a halo, but keep the update order-free)

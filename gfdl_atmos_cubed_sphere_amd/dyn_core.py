@@ -103,10 +103,12 @@ class DynCore:
 
     PROGNOSTIC = (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"))
 
-    def __init__(self, ctx: Context, flags: DynFlags, dp_ref, px: int = 1, py: int = 1, rank: int = 0, world: int = 1):
+    def __init__(self, ctx: Context, flags: DynFlags, dp_ref, px: int = 1, py: int = 1, rank: int = 0, world: int = 1,
+                 halo=None):
         self.ctx, self.fl = ctx, flags
         self.npz = ctx.npz
-        self.halo = HaloExchanger(ctx, px, py, rank, world)
+        # halo: an object with HaloExchanger's interface (cubed_dyn.CubeHaloAdapter for the six faces of the sphere)
+        self.halo = halo if halo is not None else HaloExchanger(ctx, px, py, rank, world)
         npz = self.npz
         z = ctx.zeros
         d = self.d = {}
@@ -144,7 +146,10 @@ class DynCore:
         d = self.d
         for n, a in (("u", u), ("v", v), ("w", w), ("delp", delp), ("pt", pt), ("delz", delz), ("phis", phis)):
             d[n].upload(a)
-        d["zs"].upload(np.asfortranarray(phis * (1.0 / self.fl.grav)))  # dyn_core.F90:246-251
+        if isinstance(phis, (list, tuple)):   # six faces
+            d["zs"].upload([np.asfortranarray(p * (1.0 / self.fl.grav)) for p in phis])
+        else:
+            d["zs"].upload(np.asfortranarray(phis * (1.0 / self.fl.grav)))  # dyn_core.F90:246-251
 
     def get_state(self):
         return {n: self.d[n].download() for n in ("u", "v", "w", "delp", "pt", "delz", "zh", "mfx", "mfy", "cx", "cy")}
@@ -200,6 +205,8 @@ class DynCore:
             ctx.one_grad_p(d["u"], d["v"], d["pkc"], d["gz"], d["divg2"] if fl.d_ext > 0.0 else None, dt, ptk)  # :1021
             if it != n_split:
                 halo.update([(d["u"], "U"), (d["v"], "V")])
+            elif hasattr(halo, "sync_edges"):
+                halo.sync_edges(d["u"], d["v"])                               # mpp_get_boundary, :1151-1163 (cubed sphere)
         n_con = self.n_con()
         if n_con != 0 and heating:
             halo.update([(d["heat_source"], "A")])

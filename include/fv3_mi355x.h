@@ -322,6 +322,18 @@ int fv3_rayleigh_apply(fv3_ctx *ctx, int kmax, int conserve, int hydrostatic, do
 int fv3_pt_to_theta_v(fv3_ctx *ctx, int hydrostatic, double zvir, double kappa, double rdgas, double grav, double *pt,
                       const double *delp, const double *delz, const double *qv, double *pkz);
 
+/* ---- table-driven halo gather -------------------------------------------------------------------------------
+ * The face-to-face halo updates of the cubed sphere (mpp_update_domains on the six-tile mosaic, contacts
+ * tools/fv_mp_mod.F90:498-546: index reversal along an edge, u <-> v with sign for DGRID_NE / CGRID_NE pairs) as one
+ * table per field kind: entry e copies  ptrs[dst_sel[e]][k*stride + dst_idx[e]] = sign[e] * ptrs[src_sel[e]][k*stride +
+ * src_idx[e]]  for k = 0..nk-1.  Up to 16 array pointers per run (six faces x two members of a vector pair, or message
+ * buffers: the same tables drive pack and unpack across GPUs).  Tables are HOST int arrays, copied once. */
+typedef struct fv3_gather fv3_gather;
+int fv3_gather_create(fv3_ctx *ctx, int n, const int *dst_sel, const int *dst_idx, const int *src_sel, const int *src_idx,
+                      const int *sign, fv3_gather **out);
+int fv3_gather_run(fv3_ctx *ctx, const fv3_gather *t, int nk, int nptr, double *const *ptrs, const size_t *strides);
+int fv3_gather_destroy(fv3_gather *t);
+
 /* ---- vertical remap ------------------------------------------------------------------------------------
  * Lagrangian_to_Eulerian -- model/fv_mapz.F90:56-64, call site model/fv_dynamics.F90:607.  Branches built:
  * remap_te=.false., consv=0, |kord| in 8..15, kord_wz>0; use_cond / moist_kappa through fv3_set_moist below,

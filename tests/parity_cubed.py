@@ -121,3 +121,38 @@ def check_d_sw(lib, npx=13, npz=3, hydrostatic=True, faces=range(6), dt=600.0, p
         finally:
             ctx.close()
     return worst
+
+
+def check_substeps_hydrostatic(lib, npx=13, npz=4, n_split=2, bdt=600.0, flags=None):
+    """the hydrostatic acoustic substep loop on the whole sphere: six contexts behind dyn_core.DynCore (cubed_dyn.MultiContext,
+    halo updates by device gathers) against the six-face orchestration of the oracle"""
+    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynCore, DynFlags
+    cs, gs, st = CC.hydro_state(npx, npz)
+    fl = DynFlags(n_split=n_split, hydrostatic=True, d_ext=0.0, **(flags or {}))
+    ref = CC.oracle_substeps_hydro(cs, gs, fl, st, bdt, npz)
+    mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
+    worst = {}
+    try:
+        sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+        dp0 = np.diff(fl.ptop + (1.0e5 - fl.ptop) * sig)
+        dc = DynCore(mctx, fl, dp0, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        z = [np.zeros_like(s["delp"]) for s in st]
+        bd = gs[0].bd
+        dz = [bd.zeros("CC", npz) for _ in st]
+        dc.set_state([s["u"] for s in st], [s["v"] for s in st], z, [s["delp"] for s in st], [s["pt"] for s in st], dz,
+                     [s["phis"] for s in st])
+        dc.run(bdt)
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        for n, kind, rr in (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)),
+                            ("delp", "A", r), ("pt", "A", r)):
+            got = dc.d[n].download()
+            for t in range(6):
+                worst[n] = max(worst.get(n, 0.0), P.assert_close(f"face {t + 1} {n}", bd.view(got[t], kind, *rr), bd.view(ref[t][n], kind, *rr), 1e-13))
+        for n in ("mfx", "mfy", "cx", "cy", "pk", "pkz", "peln"):
+            got = dc.d[n].download()
+            for t in range(6):
+                worst[n] = max(worst.get(n, 0.0), P.assert_close(f"face {t + 1} {n}", got[t], ref[t][n], 1e-13))
+    finally:
+        mctx.close()
+    return worst

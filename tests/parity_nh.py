@@ -189,9 +189,9 @@ def check_p_grad_c(lib, nx=24, ny=13, km=5, hydrostatic=False):
         ctx.close()
 
 
-def check_nh_p_grad(lib, nx=40, ny=19, km=5):
-    bd = Bounds(1, nx, 1, ny)
-    g = P.make_grid(bd, True)
+def check_nh_p_grad(lib, nx=40, ny=19, km=5, grid=None):
+    bd = grid.bd if grid is not None else Bounds(1, nx, 1, ny)
+    g = grid if grid is not None else P.make_grid(bd, True)
     s = nh_state(bd, km)
     rng = np.random.default_rng(6)
     pe, pk, pp, gz = _pressure_fields(bd, km, s, rng)
@@ -294,10 +294,10 @@ def check_heat_source_path(lib, nx=24, ny=13, km=6, hydrostatic=False, n_con=Non
     return worst
 
 
-def check_one_grad_p(lib, nx=40, ny=19, km=5, d_ext=0.02):
+def check_one_grad_p(lib, nx=40, ny=19, km=5, d_ext=0.02, grid=None):
     """external-mode divergence field + hydrostatic one_grad_p against the oracle"""
-    bd = Bounds(1, nx, 1, ny)
-    g = P.make_grid(bd, True)
+    bd = grid.bd if grid is not None else Bounds(1, nx, 1, ny)
+    g = grid if grid is not None else P.make_grid(bd, True)
     s = nh_state(bd, km)
     rng = np.random.default_rng(16)
     pe, pk, pp, gz = _pressure_fields(bd, km, s, rng)

@@ -609,3 +609,16 @@ def test_cubed_d_sw(prod, kw):
 def test_cubed_c48_pair(prod):
     """a gnomonic C48 face set with all edges and corners: c_sw and d_sw bit for bit against the oracle"""
     assert max(PC.check_d_sw(prod, npx=49, npz=4, hydrostatic=True).values()) <= P.TOL
+
+
+def test_cubed_a2b_ord4_through_the_pressure_gradients(prod):
+    cs, gs = PC.CC.sphere(25)
+    for t in (0, 3, 5):
+        N.check_nh_p_grad(prod, km=8, grid=gs[t])
+        N.check_one_grad_p(prod, km=8, grid=gs[t], d_ext=0.0)
+
+
+def test_cubed_sphere_hydrostatic_substeps(prod):
+    """the hydrostatic acoustic substep loop on the whole sphere on one GPU (C24 and C48, six contexts, device halo gathers)"""
+    assert max(PC.check_substeps_hydrostatic(prod, npx=25, npz=6, n_split=2).values()) <= 1e-13
+    assert max(PC.check_substeps_hydrostatic(prod, npx=49, npz=8, n_split=3, bdt=450.0).values()) <= 1e-13

@@ -453,3 +453,43 @@ def test_cubed_fv_tp_2d(emu, hord):
                                 dict(hydrostatic=False, flags=dict(n_sponge=-1))])
 def test_cubed_d_sw(emu, kw):
     assert max(PC.check_d_sw(emu, npx=13, npz=3, **kw).values()) <= P.TOL
+
+
+def test_cubed_a2b_ord4_through_the_pressure_gradients(emu):
+    cs, gs = PC.CC.sphere(13)
+    for t in (0, 3):
+        N.check_nh_p_grad(emu, km=4, grid=gs[t])
+        N.check_one_grad_p(emu, km=4, grid=gs[t], d_ext=0.0)
+
+
+def test_cubed_halo_gather_equals_the_table_update(emu):
+    """the device gather (fv3_gather_run) against the numpy application of the same topology tables, every field kind"""
+    import numpy as np
+    from gfdl_atmos_cubed_sphere_amd.cubed_halo import CubeHalo
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    npx, npz = 9, 3
+    cs, gs = PC.CC.sphere(npx)
+    ctxs = [Context(g, npz, lib=emu) for g in gs]
+    try:
+        H = CubeHalo(ctxs, npx, topo=cs.topo)
+        rng = np.random.default_rng(0)
+        bd = gs[0].bd
+        for kind, kinds in (("A", ("A",)), ("B", ("B",)), ("D", ("U", "V")), ("C", ("V", "U")), ("Dedge", ("U", "V"))):
+            host = [[np.asfortranarray(rng.uniform(-1, 1, bd.shape(k, npz))) for _ in range(6)] for k in kinds]
+            dev = [[ctxs[t].from_host(a[t]) for t in range(6)] for a in host]
+            ref = [[x.copy(order="F") for x in a] for a in host]
+            cs.topo.update(kind, ref[0] if len(kinds) == 1 else (ref[0], ref[1]))
+            H.update(kind, dev[0] if len(kinds) == 1 else (dev[0], dev[1]))
+            for m in range(len(kinds)):
+                for t in range(6):
+                    assert np.array_equal(dev[m][t].download(), ref[m][t]), (kind, m, t)
+        H.close()
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_cubed_sphere_hydrostatic_substeps(emu):
+    """two acoustic substeps of the hydrostatic core on the whole C12 sphere (six contexts, device halo gathers, edge sync
+    of the last substep) against the six-face orchestration of the oracle"""
+    assert max(PC.check_substeps_hydrostatic(emu, npx=13, npz=4, n_split=2).values()) <= 1e-13
