@@ -20,7 +20,7 @@ class FvDynamics:
     def __init__(self, ctx: Context, flags: DynFlags, ak, bk, nq: int = 0, k_split: int = 1, kord_tm: int = -8,
                  kord_mt: int = 8, kord_wz: int = 8, kord_tr: int = 8, q_split: int = 0, nord_tr: int = 0, trdm2: float = 0.0, adiabatic: bool = True,
                  px: int = 1, py: int = 1, rank: int = 0, world: int = 1, dist=None, tau: float = 0.0,
-                 rf_cutoff: float = 30.0e2, c2l_ord: int = 4, moist: dict | None = None, fill: bool = False):
+                 rf_cutoff: float = 30.0e2, c2l_ord: int = 4, moist: dict | None = None, fill: bool = False, halo=None):
         ak, bk = np.asarray(ak, dtype=np.float64), np.asarray(bk, dtype=np.float64)
         dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5          # dyn_core.F90:241-244
         self.ctx, self.fl, self.nq, self.k_split, self.q_split, self.dist = ctx, flags, nq, k_split, q_split, dist
@@ -33,7 +33,7 @@ class FvDynamics:
         self.moist = None
         if flags.use_cond or flags.moist_kappa:
             self.moist = dict(moist or {}, moist_kappa=int(flags.moist_kappa), use_cond=int(flags.use_cond), sphum=1)
-        self.dc = DynCore(ctx, flags, dp_ref, px, py, rank, world)
+        self.dc = DynCore(ctx, flags, dp_ref, px, py, rank, world, halo=halo)
         ctx.set_ak_bk(ak, bk)
         npz = ctx.npz
         d = self.dc.d

@@ -191,3 +191,22 @@ def oracle_substeps_hydro(cs, gs, fl, st, bdt, npz):
         else:
             exchange_pair(cs, f, "u", "v", "Dedge")          # mpp_get_boundary, dyn_core.F90:1151-1163
     return f
+
+
+def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz):
+    """hydrostatic k_split loop on six faces over the oracle: dyn_core substeps -> Lagrangian_to_Eulerian (no tracers)"""
+    mdt = bdt / float(k_split)
+    cur = [{k: s[k].copy(order="F") for k in ("u", "v", "delp", "pt", "phis")} for s in st]
+    out = None
+    bd = gs[0].bd
+    for n_map in range(1, k_split + 1):
+        f = oracle_substeps_hydro(cs, gs, fl, cur, mdt, npz)
+        out = []
+        for t in range(6):
+            x = f[t]
+            rf = dict(ps=bd.zeros("A"), pe=x["pe"], delp=x["delp"], pkz=x["pkz"], pk=x["pk"], u=x["u"], v=x["v"], pt=x["pt"], peln=x["peln"],
+                      omga=bd.zeros("A", npz))
+            O.lagrangian_to_eulerian(gs[t], npz, dict(remap_par, last_step=0), rf, ak, bk)
+            cur[t] = dict(u=rf["u"], v=rf["v"], delp=rf["delp"], pt=rf["pt"], phis=st[t]["phis"])
+            out.append(dict(cur[t], pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"]))
+    return out

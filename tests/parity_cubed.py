@@ -156,3 +156,59 @@ def check_substeps_hydrostatic(lib, npx=13, npz=4, n_split=2, bdt=600.0, flags=N
     finally:
         mctx.close()
     return worst
+
+
+def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-12):
+    """BASELINE configs[1] in small: the Jablonowski-Williamson baroclinic wave (test_case = 13) on the whole cubed sphere,
+    hydrostatic, the reference's L79 levels (set_eta), one dt_atmos = k_split x (n_split substeps + vertical remap) on six
+    device contexts against the six-face orchestration of the oracle"""
+    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.test_cases import jablonowski_williamson, set_eta
+    cs, gs = CC.sphere(npx)
+    if npz in (79, 127):
+        ak, bk, ks, ptop = set_eta(npz)
+    else:
+        sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+        ptop = 300.0
+        ak, bk = ptop * (1.0 - sig), sig.copy()
+    st = jablonowski_williamson(cs, ak, bk, hydrostatic=True)
+    fl = DynFlags(n_split=n_split, hydrostatic=True, d_ext=0.0, ptop=float(ak[0]))
+    # T -> theta: pt = T / pkz with the hydrostatic pkz of the initial state (fv_dynamics.F90:323-329, the host's job here)
+    bd = gs[0].bd
+    ng, nx = bd.ng, bd.nx
+    for s in st:
+        pe = ak[0] + np.concatenate([np.zeros(s["delp"].shape[:2] + (1,)), np.cumsum(s["delp"], axis=2)], axis=2)
+        c = (slice(ng, ng + nx), slice(ng, ng + nx))
+        pk = O.fexp(fl.akap * O.flog(pe[c])).reshape(pe[c].shape)
+        peln = O.flog(pe[c]).reshape(pe[c].shape)
+        pkz = (pk[:, :, 1:] - pk[:, :, :-1]) / (fl.akap * (peln[:, :, 1:] - peln[:, :, :-1]))
+        s["pt"][c] = s["pt"][c] / pkz
+    mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
+    worst = {}
+    try:
+        fv = FvDynamics(mctx, fl, ak, bk, nq=0, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        ref = CC.oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, fv.remap_par, npz)
+        z = [np.zeros_like(s["delp"]) for s in st]
+        dz = [bd.zeros("CC", npz) for _ in st]
+        fv.dc.set_state([s["u"] for s in st], [s["v"] for s in st], z, [s["delp"] for s in st], [s["pt"] for s in st], dz,
+                        [s["phis"] for s in st])
+        fv.step(bdt)
+        d = fv.dc.d
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        for n, kind, rr in (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)),
+                            ("delp", "A", r), ("pt", "A", r), ("ps", "A", r)):
+            got = d[n].download()
+            for t in range(6):
+                worst[n] = max(worst.get(n, 0.0), P.assert_close(f"face {t + 1} {n}", bd.view(got[t], kind, *rr), bd.view(ref[t][n], kind, *rr), tol))
+        for n in ("pkz", "pk", "peln"):
+            got = d[n].download()
+            for t in range(6):
+                worst[n] = max(worst.get(n, 0.0), P.assert_close(f"face {t + 1} {n}", got[t], ref[t][n], tol))
+        dp = d["delp"].download()
+        s = slice(ng, ng + nx)
+        worst["finite"] = float(all(np.isfinite(x[s, s, :]).all() for x in dp))
+    finally:
+        mctx.close()
+    return worst

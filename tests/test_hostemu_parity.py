@@ -493,3 +493,9 @@ def test_cubed_sphere_hydrostatic_substeps(emu):
     """two acoustic substeps of the hydrostatic core on the whole C12 sphere (six contexts, device halo gathers, edge sync
     of the last substep) against the six-face orchestration of the oracle"""
     assert max(PC.check_substeps_hydrostatic(emu, npx=13, npz=4, n_split=2).values()) <= 1e-13
+
+
+def test_cubed_sphere_jablonowski_williamson_step(emu):
+    """test_case = 13 on a C12 sphere with the reference's L79 levels: one dt_atmos (k_split = 2: substeps + remap)"""
+    r = PC.check_jw_step(emu, npx=13, npz=79, k_split=2, n_split=2, bdt=1800.0)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
