@@ -18,6 +18,7 @@ module fv3_mi355x_mod
   public :: fv3_heat_source_accum, fv3_del2_cubed, fv3_apply_heat_source
   public :: fv3_d_sw_interior, fv3_d_sw_rest
   public :: fv3_divg2_ext, fv3_one_grad_p, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
+  public :: fv3_grid_cubed, fv3_grid_upload_cubed, fv3_gather_create, fv3_gather_run, fv3_gather_destroy
   public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_set_condensate, fv3_set_moist, fv3_moist_params
 
   type, bind(C) :: fv3_domain
@@ -33,6 +34,11 @@ module fv3_mi355x_mod
     type(c_ptr) :: dy, rdy, dxc, rdxc, cosa_u, sina_u, rsin_u, divg_v, del6_v
     type(c_ptr) :: rarea_c, fC, cosa, sina
     type(c_ptr) :: sin_sg, cos_sg
+  end type
+
+  type, bind(C) :: fv3_grid_cubed     ! extra members of a cubed-sphere face (grid_type < 3): host addresses + factors
+    type(c_ptr) :: edge_w, edge_e, edge_s, edge_n, rsina
+    real(c_double) :: corner_f(12)
   end type
 
   type, bind(C) :: fv3_dsw_params
@@ -85,6 +91,31 @@ module fv3_mi355x_mod
       import :: c_int, c_ptr, fv3_grid_host
       type(c_ptr), value :: ctx
       type(fv3_grid_host), intent(in) :: g
+    end function
+    integer(c_int) function fv3_grid_upload_cubed(ctx, g) bind(C, name="fv3_grid_upload_cubed")
+      import :: c_int, c_ptr, fv3_grid_cubed
+      type(c_ptr), value :: ctx
+      type(fv3_grid_cubed), intent(in) :: g
+    end function
+    ! table-driven halo gather (the cubed-sphere face-to-face updates): host int tables, device array pointers
+    integer(c_int) function fv3_gather_create(ctx, n, dst_sel, dst_idx, src_sel, src_idx, sgn, handle) &
+        bind(C, name="fv3_gather_create")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: n
+      integer(c_int), intent(in) :: dst_sel(*), dst_idx(*), src_sel(*), src_idx(*), sgn(*)
+      type(c_ptr), intent(out) :: handle
+    end function
+    integer(c_int) function fv3_gather_run(ctx, handle, nk, nptr, ptrs, strides) bind(C, name="fv3_gather_run")
+      import :: c_int, c_ptr, c_size_t
+      type(c_ptr), value :: ctx, handle
+      integer(c_int), value :: nk, nptr
+      type(c_ptr), intent(in) :: ptrs(*)
+      integer(c_size_t), intent(in) :: strides(*)
+    end function
+    integer(c_int) function fv3_gather_destroy(handle) bind(C, name="fv3_gather_destroy")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
     end function
     integer(c_int) function fv3_grid_geom(ctx) bind(C, name="fv3_grid_geom")
       import :: c_int, c_ptr
