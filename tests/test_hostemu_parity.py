@@ -314,8 +314,11 @@ def test_error_behaviour_of_the_c_abi(emu):
             ctx.d_sw(*args)                                            # u_out aliases u
     finally:
         ctx.close()
-    g.grid_type = 0                                                    # cubed-sphere branches are not built
+    g.grid_type = 3                                                    # not a supported geometry (4, or 0..2 = cubed sphere)
     with pytest.raises(L.Fv3Error, match="grid_type"):
+        L.Context(g, 2, lib=emu)
+    g.grid_type, g.npx, g.npy = 0, 20, 20                              # a cubed-sphere context must be one whole face
+    with pytest.raises(L.Fv3Error, match="whole face"):
         L.Context(g, 2, lib=emu)
 
 
