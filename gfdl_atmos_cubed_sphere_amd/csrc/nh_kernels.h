@@ -19,6 +19,7 @@
 #pragma once
 
 #include "fv3_common.h"
+#include "cubed_common.h"
 #include "remap_kernels.h"  // RemapPar, moist_cv
 #include "tp2d_tile.h"
 
@@ -48,37 +49,47 @@ struct UpdateDzC {
     const double bot_ratio = dp0[km - 1] / (dp0[km - 2] + dp0[km - 1]);
     FV3_COL_FOR(c, ncol) {
       const int i = g.is - 1 + c % w, j = g.js - 1 + c / w;
-      const int o = g.iA(i, j), oe = g.iA(i + 1, j), on = g.iA(i, j + 1), ow = g.iA(i - 1, j), os = g.iA(i, j - 1);
+      const int o = g.iA(i, j);
+      int oe = g.iA(i + 1, j), on = g.iA(i, j + 1), ow = g.iA(i - 1, j), os = g.iA(i, j - 1), cx_ = o, cy_ = o;
+      // flux-velocity rows are read at the true neighbours (oe, on below are re-used for the gz reads after the map)
+      const int oe_v = oe, on_v = on;
+      if (g.grid_type < 3) {
+        auto m = [&](int dir, int ii, int jj) { fill4_src(dir, g.npx, g.npy, ii, jj); return g.iA(ii, jj); };
+        ow = m(1, i - 1, j); oe = m(1, i + 1, j); cx_ = m(1, i, j);
+        os = m(2, i, j - 1); on = m(2, i, j + 1); cy_ = m(2, i, j);
+      }
       const double ar = g.area[o];
       for (int k = 1; k <= km + 1; k++) {
         double x0, x1, y0, y1;
         if (k == 1) {
           const double *a = ut, *b = ut + nA, *cc = vt, *d = vt + nA;
           x0 = a[o] + (a[o] - b[o]) * top_ratio;
-          x1 = a[oe] + (a[oe] - b[oe]) * top_ratio;
+          x1 = a[oe_v] + (a[oe_v] - b[oe_v]) * top_ratio;
           y0 = cc[o] + (cc[o] - d[o]) * top_ratio;
-          y1 = cc[on] + (cc[on] - d[on]) * top_ratio;
+          y1 = cc[on_v] + (cc[on_v] - d[on_v]) * top_ratio;
         } else if (k == km + 1) {
           const double *a = ut + (size_t)(km - 1) * nA, *b = ut + (size_t)(km - 2) * nA;
           const double *cc = vt + (size_t)(km - 1) * nA, *d = vt + (size_t)(km - 2) * nA;
           x0 = a[o] + (a[o] - b[o]) * bot_ratio;
-          x1 = a[oe] + (a[oe] - b[oe]) * bot_ratio;
+          x1 = a[oe_v] + (a[oe_v] - b[oe_v]) * bot_ratio;
           y0 = cc[o] + (cc[o] - d[o]) * bot_ratio;
-          y1 = cc[on] + (cc[on] - d[on]) * bot_ratio;
+          y1 = cc[on_v] + (cc[on_v] - d[on_v]) * bot_ratio;
         } else {
           const double int_ratio = 1. / (dp0[k - 2] + dp0[k - 1]);
           const double *a = ut + (size_t)(k - 2) * nA, *b = ut + (size_t)(k - 1) * nA;
           const double *cc = vt + (size_t)(k - 2) * nA, *d = vt + (size_t)(k - 1) * nA;
           x0 = (dp0[k - 1] * a[o] + dp0[k - 2] * b[o]) * int_ratio;
-          x1 = (dp0[k - 1] * a[oe] + dp0[k - 2] * b[oe]) * int_ratio;
+          x1 = (dp0[k - 1] * a[oe_v] + dp0[k - 2] * b[oe_v]) * int_ratio;
           y0 = (dp0[k - 1] * cc[o] + dp0[k - 2] * d[o]) * int_ratio;
-          y1 = (dp0[k - 1] * cc[on] + dp0[k - 2] * d[on]) * int_ratio;
+          y1 = (dp0[k - 1] * cc[on_v] + dp0[k - 2] * d[on_v]) * int_ratio;
         }
         const double *z = gz_in + (size_t)(k - 1) * nA;
-        const double zc = z[o];
-        const double fx0 = x0 * ((x0 > 0.) ? z[ow] : zc), fx1 = x1 * ((x1 > 0.) ? zc : z[oe]);
-        const double fy0 = y0 * ((y0 > 0.) ? z[os] : zc), fy1 = y1 * ((y1 > 0.) ? zc : z[on]);
-        gz[(size_t)(k - 1) * nA + o] = (zc * ar + fx0 - fx1 + fy0 - fy1) / (ar + x0 - x1 + y0 - y1);
+        // cubed sphere: fill_4corners(gz2, 1) before the x fluxes, (gz2, 2) before the y fluxes (nh_utils.F90:151,163), as
+        // index maps on the reads; the cell value of the update is what the second fill left (identity off the corners)
+        const double zcx = z[cx_], zcy = z[cy_];
+        const double fx0 = x0 * ((x0 > 0.) ? z[ow] : zcx), fx1 = x1 * ((x1 > 0.) ? zcx : z[oe]);
+        const double fy0 = y0 * ((y0 > 0.) ? z[os] : zcy), fy1 = y1 * ((y1 > 0.) ? zcy : z[on]);
+        gz[(size_t)(k - 1) * nA + o] = (zcy * ar + fx0 - fx1 + fy0 - fy1) / (ar + x0 - x1 + y0 - y1);
       }
       double below = gz[(size_t)km * nA + o];
       ws[o] = (zs[o] - below) * rdt;

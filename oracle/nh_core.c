@@ -43,7 +43,6 @@ int fvo_update_dz_c(const fvo_grid *g, int km, double dt, const double *dp0, con
                     const double *ut, const double *vt, double *gz, double *ws) {
   BOUNDS(g);
   int i, j, k;
-  if (g->grid_type < 3) return FVO_ERR_UNSUPPORTED;
   const double rdt = 1. / dt;
   const double top_ratio = dp0[0] / (dp0[0] + dp0[1]);
   const double bot_ratio = dp0[km - 1] / (dp0[km - 2] + dp0[km - 1]);
@@ -75,6 +74,7 @@ int fvo_update_dz_c(const fvo_grid *g, int km, double dt, const double *dp0, con
     }
     for (j = jsd; j <= jed; j++)
       for (i = isd; i <= ied; i++) gz2[IA(i, j)] = gz[A3(i, j, k)];
+    if (g->grid_type < 3) fvo_fill_4corners(g, gz2, 1); /* :151 */
     for (j = js1; j <= je1; j++)
       for (i = is1; i <= ie2; i++) {
         if (xfx[IA(i, j)] > 0.)
@@ -83,6 +83,7 @@ int fvo_update_dz_c(const fvo_grid *g, int km, double dt, const double *dp0, con
           fx[IA(i, j)] = gz2[IA(i, j)];
         fx[IA(i, j)] = xfx[IA(i, j)] * fx[IA(i, j)];
       }
+    if (g->grid_type < 3) fvo_fill_4corners(g, gz2, 2); /* :163 */
     for (j = js1; j <= je2; j++)
       for (i = is1; i <= ie1; i++) {
         if (yfx[IA(i, j)] > 0.)
@@ -395,7 +396,6 @@ int fvo_update_dz_d(const fvo_grid *g, int km, int *ndif, double *damp, int hord
                     double rdt) {
   BOUNDS(g);
   int i, j, k;
-  if (g->grid_type < 3) return FVO_ERR_UNSUPPORTED;
   const size_t nCX = (size_t)(nx + 1) * njd, nCY = (size_t)nid * (ny + 1), nA = (size_t)nid * njd;
   double *crx_adv = dalloc(nCX * (km + 1)), *xfx_adv = dalloc(nCX * (km + 1));
   double *cry_adv = dalloc(nCY * (km + 1)), *yfx_adv = dalloc(nCY * (km + 1));

@@ -35,7 +35,6 @@ int fvo_tracer_2d(const fvo_grid *g, int npz, int nq, double *q, double *dp1, do
   const size_t nA = (size_t)nid * njd, nCX = (size_t)(nx + 1) * njd, nCY = (size_t)nid * (ny + 1),
                nFX = (size_t)(nx + 1) * ny, nFY = (size_t)nx * (ny + 1);
   int i, j, k, it, iq, nsplt;
-  if (g->grid_type < 3) return -FVO_ERR_UNSUPPORTED;
 #define IA(i, j) ((size_t)((j)-jsd) * nid + ((i)-isd))
 #define IV(i, j) ((size_t)((j)-jsd) * (nid + 1) + ((i)-isd))
 #define ICX(i, j) ((size_t)((j)-jsd) * (nx + 1) + ((i)-is))
