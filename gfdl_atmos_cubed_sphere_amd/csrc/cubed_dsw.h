@@ -200,12 +200,26 @@ struct DswCubedD4 {
       ptv = ptv / dpn;
       view_A(g, s.a.delp_out)(i, j, k) = dpn;
       view_A(g, s.a.pt_out)(i, j, k) = ptv;
+      double heat = 0.;
       if (!s.a.hydrostatic) {
-        const CA gxw = cview_FX(g, s.gxw), gyw = cview_FY(g, s.gyw);
-        const double wv = dp * cview_A(g, s.a.w)(i, j, k) + (gxw(i, j, k) - gxw(i + 1, j, k) + gyw(i, j, k) - gyw(i, j + 1, k)) * ra;
-        view_A(g, s.a.w_out)(i, j, k) = wv / dpn;
+        const CA gxw = cview_FX(g, s.gxw), gyw = cview_FY(g, s.gyw), w = cview_A(g, s.a.w);
+        const double w0 = w(i, j, k);
+        const double wv = dp * w0 + (gxw(i, j, k) - gxw(i + 1, j, k) + gyw(i, j, k) - gyw(i, j + 1, k)) * ra;
+        double wn = wv / dpn;
+        const double damp_w = s.a.lv.damp_w[k];
+        if (damp_w > 1.E-5) {  // del-2 damping of w on the sponge levels (nord_w = 0): :950-982, del6_vt_flux :1640-1672
+          const double damp4 = ipow(damp_w * g.da_min_c, s.a.lv.nord_w[k] + 1), dd8 = s.a.kgb * fabs(s.a.dt);
+          const double d0 = damp4 * w0;
+          const double fx0 = g.del6_v[g.iV(i, j)] * (damp4 * w(i - 1, j, k) - d0), fx1 = g.del6_v[g.iV(i + 1, j)] * (d0 - damp4 * w(i + 1, j, k));
+          const double fy0 = g.del6_u[g.iU(i, j)] * (damp4 * w(i, j - 1, k) - d0), fy1 = g.del6_u[g.iU(i, j + 1)] * (d0 - damp4 * w(i, j + 1, k));
+          const double dw = (fx0 - fx1 + fy0 - fy1) * ra;
+          const double tmp = dw * (w0 + 0.5 * dw);
+          heat = g.prevent_diss_cooling ? dd8 - dmin(0., tmp) : dd8 - tmp;
+          wn = wn + dw;
+        }
+        view_A(g, s.a.w_out)(i, j, k) = wn;
       }
-      view_CC(g, s.a.heat_s)(i, j, k) = 0.;
+      view_CC(g, s.a.heat_s)(i, j, k) = heat;
       view_CC(g, s.a.diss_e)(i, j, k) = 0.;
     }
   }

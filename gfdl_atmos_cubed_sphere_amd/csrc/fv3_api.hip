@@ -83,7 +83,7 @@ struct fv3_ctx {
   int n_plain_z, n_damp_z;
   int lev_max_nord;      // max over the levels of nord_k
   bool lev_has_dcon;     // some level has d_con_k > 1e-5
-  bool lev_has_vt_damp, lev_has_w_damp;  // damp_vt / damp_t > 1e-4 resp. damp_w > 1e-5 on some level
+  bool lev_has_vt_damp, lev_has_w_damp, lev_has_w_damp_hi;  // damp_vt / damp_t; damp_w > 1e-5; the latter with nord_w > 0
   double *ke_scr;        // B kind, npz levels: KE + damping term at the corners
   double *mflux[2];      // mass-flux scratch of the marching transports: FX kind, FY kind (npz levels)
   // cubed sphere (grid_type < 3): edge weights / corner factors and the work arrays of the pass kernels (B x (npz+1) each)
@@ -487,12 +487,13 @@ extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
     RT(rt_sync(c->stream));
   }
   c->lev_max_nord = 0;
-  c->lev_has_dcon = c->lev_has_vt_damp = c->lev_has_w_damp = false;
+  c->lev_has_dcon = c->lev_has_vt_damp = c->lev_has_w_damp = c->lev_has_w_damp_hi = false;
   for (int k = 0; k < npz; k++) {
     c->lev_max_nord = std::max(c->lev_max_nord, lv->nord_k[k]);
     if (lv->d_con_k[k] > 1.E-5) c->lev_has_dcon = true;
     if (lv->damp_vt[k] > 1.E-5 || lv->damp_t[k] > 1.E-4) c->lev_has_vt_damp = true;
     if (lv->damp_w[k] > 1.E-5) c->lev_has_w_damp = true;
+    if (lv->damp_w[k] > 1.E-5 && lv->nord_w[k] > 0) c->lev_has_w_damp_hi = true;
   }
   c->lev_ready = true;
   return 0;
@@ -901,8 +902,8 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   if (a.use_cond) return fail("fv3_d_sw: use_cond is not built for the cubed sphere yet");
   if (a.dddmp >= 1.E-5) return fail("fv3_d_sw: Smagorinsky damping (dddmp > 0) is not built for the cubed sphere yet");
   if (g.do_diss_est) return fail("fv3_d_sw: do_diss_est is not built for the cubed sphere yet");
-  if (c->lev_has_vt_damp || (!a.hydrostatic && c->lev_has_w_damp))
-    return fail("fv3_d_sw: del-2n damping of delp / w / pt / vorticity is not built for the cubed sphere yet");
+  if (c->lev_has_vt_damp || (!a.hydrostatic && c->lev_has_w_damp_hi))
+    return fail("fv3_d_sw: del-2n damping of delp / pt / vorticity (and of w with nord_w > 0) is not built for the cubed sphere yet");
   if (c->lev_has_dcon) return fail("fv3_d_sw: dissipative heating (d_con > 0) is not built for the cubed sphere yet");
   DswCubedState s;
   s.g = g; s.cg = c->cg; s.a = a;

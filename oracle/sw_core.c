@@ -537,12 +537,13 @@ int fvo_del6_vt_flux(const fvo_grid *g, int nord, double damp, const double *q, 
   BOUNDS(g);
   int i, j, n, nt;
   const int i1 = is - 1 - nord, i2 = ie + 1 + nord, j1 = js - 1 - nord, j2 = je + 1 + nord;
-  if (g->grid_type < 3) return FVO_ERR_UNSUPPORTED;
   for (j = j1; j <= j2; j++)
     for (i = i1; i <= i2; i++) d2[IA(i, j)] = damp * q[IA(i, j)];
+  if (nord > 0) fvo_copy_corners(g, d2, 1); /* :1653 (no-op without corner flags) */
   for (j = js - nord; j <= je + nord; j++)
     for (i = is - nord; i <= ie + nord + 1; i++)
       fx2[IV(i, j)] = g->del6_v[IV(i, j)] * (d2[IA(i - 1, j)] - d2[IA(i, j)]);
+  if (nord > 0) fvo_copy_corners(g, d2, 2); /* :1666 */
   for (j = js - nord; j <= je + nord + 1; j++)
     for (i = is - nord; i <= ie + nord; i++)
       fy2[IU(i, j)] = g->del6_u[IU(i, j)] * (d2[IA(i, j - 1)] - d2[IA(i, j)]);
@@ -552,9 +553,11 @@ int fvo_del6_vt_flux(const fvo_grid *g, int nord, double damp, const double *q, 
       for (j = js - nt - 1; j <= je + nt + 1; j++)
         for (i = is - nt - 1; i <= ie + nt + 1; i++)
           d2[IA(i, j)] = (fx2[IV(i, j)] - fx2[IV(i + 1, j)] + fy2[IU(i, j)] - fy2[IU(i, j + 1)]) * g->rarea[IA(i, j)];
+      fvo_copy_corners(g, d2, 1); /* :1691 */
       for (j = js - nt; j <= je + nt; j++)
         for (i = is - nt; i <= ie + nt + 1; i++)
           fx2[IV(i, j)] = g->del6_v[IV(i, j)] * (d2[IA(i, j)] - d2[IA(i - 1, j)]);
+      fvo_copy_corners(g, d2, 2); /* :1703 */
       for (j = js - nt; j <= je + nt + 1; j++)
         for (i = is - nt; i <= ie + nt; i++)
           fy2[IU(i, j)] = g->del6_u[IU(i, j)] * (d2[IA(i, j)] - d2[IA(i, j - 1)]);
