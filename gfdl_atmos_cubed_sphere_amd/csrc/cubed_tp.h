@@ -273,4 +273,17 @@ struct Tp2dCubedT3 {
   }
 };
 
+// update_dz_d (nh_utils.F90:261-306): the new interface height from the fluxes of fv_tp_2d
+struct ZhCubedFinal {
+  Grid g;
+  const double *zh_in, *fx, *fy, *xfa, *yfa;
+  double *zh_out;
+  FV3_HD void operator()(int i, int j, int k) const {
+    const CA z = cview_A(g, zh_in), fxv = cview_FX(g, fx), fyv = cview_FY(g, fy), xf = cview_CX(g, xfa), yf = cview_CY(g, yfa);
+    const double ar = g.area[g.iA(i, j)];
+    const double rax = ar + xf(i, j, k) - xf(i + 1, j, k), ray = ar + yf(i, j, k) - yf(i, j + 1, k);
+    view_A(g, zh_out)(i, j, k) = (z(i, j, k) * ar + fxv(i, j, k) - fxv(i + 1, j, k) + fyv(i, j, k) - fyv(i, j + 1, k)) / (rax + ray - ar);
+  }
+};
+
 }  // namespace fv3

@@ -1402,6 +1402,16 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
     EdgeProfile kf2{g, km, c->ec, cry, yfx, cya, yfa, (int)g.nCY()};
     RT(launch_c(c, "edge_profile", col_grid((int)g.nCY()), kf2));
   }
+  if (is_cubed(c)) {
+    if (c->n_damp_z > 0) return fail("fv3_update_dz_d: del6_vt_flux damping of zh is not built for the cubed sphere yet");
+    double *fx = cs_scratch(c, 8), *fy = cs_scratch(c, 9);
+    if (!fx || !fy) return fail("fv3_update_dz_d: out of device memory");
+    if (tp2d_cubed(c, km + 1, zh_in, cxa, cya, hord, fx, fy, xfa, yfa, nullptr, nullptr, nullptr, nullptr, "zh_transport")) return 1;
+    RT(launch_box(c, "zh_transport", g.is, g.ie, g.js, g.je, km + 1, ZhCubedFinal{g, zh_in, fx, fy, xfa, yfa, zh_out}));
+    ZhLimit kf{g, km, rdt, zs, zh_out, ws};
+    RT(launch_c(c, "zh_limit", col_grid(g.nx * g.ny), kf));
+    return 0;
+  }
   constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
   const bool march = c->use_march != 0;
   if (march && c->n_plain_z > 0) {

@@ -292,10 +292,13 @@ class DynCore:
                           peln1 if fl.use_logp else ptk, gz_scale=fl.grav)    # :1032
             if it != n_split:
                 halo.update([(d["u"], "U"), (d["v"], "V")])                   # :1168-1169 (pack 8)
-            elif fl.use_old_omega and end_step:                               # last_step = it==n_split .and. end_step (:427)
-                # :1182-1191: omga = (pe - pem)*rdt; pem = p of the delp this substep started from (:409-421), which the
-                # ping-pong left in delp_nxt
-                ctx.omga_update(rdt, fl.ptop, d["pe"], d["delp_nxt"], d["omga"])
+            else:
+                if hasattr(halo, "sync_edges"):
+                    halo.sync_edges(d["u"], d["v"])                           # mpp_get_boundary, :1151-1163 (cubed sphere)
+                if fl.use_old_omega and end_step:                             # last_step = it==n_split .and. end_step (:427)
+                    # :1182-1191: omga = (pe - pem)*rdt; pem = p of the delp this substep started from (:409-421), which
+                    # the ping-pong left in delp_nxt
+                    ctx.omga_update(rdt, fl.ptop, d["pe"], d["delp_nxt"], d["omga"])
         # ---- dissipative heating (:296-308, :1300-1355) ----
         n_con = self.n_con()
         if n_con != 0 and heating:

@@ -137,17 +137,23 @@ def jablonowski_williamson(cs: CubedSphere, ak, bk, hydrostatic: bool = True, pe
     u1, r0 = (1.0, R / 10.0) if perturb else (0.0, 1.0)
     T_0, delta_T, lapse, eta_t, eta_s = 288.0, 480000.0, 0.005, 0.2, 1.0
 
-    def uzonal(p, z):
+    # level-independent factors are evaluated once per point set (the products keep the association of the level-wise forms)
+    def uzonal_parts(p):
         lon, lat = latlon_of(p)
-        ut = Ubar * np.cos(eta_v[z]) ** 1.5 * np.sin(2.0 * lat) ** 2.0
         r = gc_dist(pcen[0], pcen[1], lon, lat, R)
         arg = -(r / r0) ** 2.0
-        return ut + np.where(arg > -40.0, u1 * np.exp(np.maximum(arg, -40.0)), 0.0)
+        return np.sin(2.0 * lat) ** 2.0, np.where(arg > -40.0, u1 * np.exp(np.maximum(arg, -40.0)), 0.0)
 
-    def t_of(lat, z, t_mean):
+    def uzonal(parts, z):
+        return Ubar * np.cos(eta_v[z]) ** 1.5 * parts[0] + parts[1]
+
+    def t_parts(lat):
+        return ((-2.0 * (np.sin(lat) ** 6.0) * (np.cos(lat) ** 2.0 + 1.0 / 3.0) + 10.0 / 63.0) * 2.0 * Ubar,
+                ((8.0 / 5.0) * (np.cos(lat) ** 3.0) * (np.sin(lat) ** 2.0 + 2.0 / 3.0) - np.pi / 4.0) * R * om)
+
+    def t_of(parts, z, t_mean):
         return t_mean + 0.75 * (eta[z] * np.pi * Ubar / RDGAS) * np.sin(eta_v[z]) * np.sqrt(np.cos(eta_v[z])) * (
-            (-2.0 * (np.sin(lat) ** 6.0) * (np.cos(lat) ** 2.0 + 1.0 / 3.0) + 10.0 / 63.0) * 2.0 * Ubar * np.cos(eta_v[z]) ** 1.5 +
-            ((8.0 / 5.0) * (np.cos(lat) ** 3.0) * (np.sin(lat) ** 2.0 + 2.0 / 3.0) - np.pi / 4.0) * R * om)
+            parts[0] * np.cos(eta_v[z]) ** 1.5 + parts[1])
 
     def phis_of(lat):
         c = np.cos((eta_s - eta_0) * np.pi / 2.0)
@@ -182,22 +188,22 @@ def jablonowski_williamson(cs: CubedSphere, ak, bk, hydrostatic: bool = True, pe
         lat_c = latlon_of(c)[1]
         lat_a = latlon_of(a3[s, s])[1]
         lat_mx, lat_my = latlon_of(mx)[1], latlon_of(my)[1]
+        zp = [uzonal_parts(x) for x in (c[:-1, :], c[1:, :], mx, c[:, :-1], c[:, 1:], my)]
+        ec = [_east_component(a, b) for a, b in ((ee1[:-1, :], c[:-1, :]), (ee1[1:, :], c[1:, :]), (es1, mx),
+                                                 (ee2[:, :-1], c[:, :-1]), (ee2[:, 1:], c[:, 1:]), (ew2, my))]
+        tp = [t_parts(x) for x in (lat_a, lat_mx, lat_my, lat_c)]
         for z in range(npz):
-            uu1 = uzonal(c[:-1, :], z) * _east_component(ee1[:-1, :], c[:-1, :])
-            uu3 = uzonal(c[1:, :], z) * _east_component(ee1[1:, :], c[1:, :])
-            uu2 = uzonal(mx, z) * _east_component(es1, mx)
+            uu1, uu3, uu2 = uzonal(zp[0], z) * ec[0], uzonal(zp[1], z) * ec[1], uzonal(zp[2], z) * ec[2]
             u[s, sc, z] = 0.25 * (uu1 + 2.0 * uu2 + uu3)
-            vv3 = uzonal(c[:, :-1], z) * _east_component(ee2[:, :-1], c[:, :-1])
-            vv1 = uzonal(c[:, 1:], z) * _east_component(ee2[:, 1:], c[:, 1:])
-            vv2 = uzonal(my, z) * _east_component(ew2, my)
+            vv3, vv1, vv2 = uzonal(zp[3], z) * ec[3], uzonal(zp[4], z) * ec[4], uzonal(zp[5], z) * ec[5]
             v[sc, s, z] = 0.25 * (vv1 + 2.0 * vv2 + vv3)
             t_mean = T_0 * eta[z] ** (RDGAS * lapse / GRAV)
             if eta_t > eta[z]:
                 t_mean = t_mean + delta_T * (eta_t - eta[z]) ** 5.0
-            pt1 = t_of(lat_a, z, t_mean)
-            pe_ = t_of(lat_mx, z, t_mean)      # x-edge mid-points: south (j) and north (j+1) edges of the cells
-            pw_ = t_of(lat_my, z, t_mean)      # y-edge mid-points: west (i) and east (i+1)
-            pc_ = t_of(lat_c, z, t_mean)
+            pt1 = t_of(tp[0], z, t_mean)
+            pe_ = t_of(tp[1], z, t_mean)       # x-edge mid-points: south (j) and north (j+1) edges of the cells
+            pw_ = t_of(tp[2], z, t_mean)       # y-edge mid-points: west (i) and east (i+1)
+            pc_ = t_of(tp[3], z, t_mean)
             pt[s, s, z] = (0.25 * pt1 + 0.125 * (pe_[:, :-1] + pw_[1:, :] + pe_[:, 1:] + pw_[:-1, :]) +
                            0.0625 * (pc_[:-1, :-1] + pc_[1:, :-1] + pc_[1:, 1:] + pc_[:-1, 1:]))
         ps = 1.0e5

@@ -193,6 +193,114 @@ def oracle_substeps_hydro(cs, gs, fl, st, bdt, npz):
     return f
 
 
+def nh_state(npx, npz, ptop=300.0):
+    """the state of hydro_state + w and a hydrostatically balanced delz (pt = T / p**kappa: delz = -rd/g * pt * pm**kappa * d(ln p)), for the nonhydrostatic substep loop"""
+    cs, gs, st = hydro_state(npx, npz, ptop)
+    bd = gs[0].bd
+    c = (slice(bd.ng, bd.ng + bd.nx), slice(bd.ng, bd.ng + bd.ny))
+    kap, rd, grav = 2.0 / 7.0, 287.05, 9.80665
+    for t in range(6):
+        a3 = cs.grids[t]["agrid3"]
+        x = st[t]
+        pe = ptop + np.concatenate([np.zeros(x["delp"].shape[:2] + (1,)), np.cumsum(x["delp"], axis=2)], axis=2)
+        peln = np.log(pe)
+        pm = x["delp"] / (peln[:, :, 1:] - peln[:, :, :-1])      # the layer-mean pressure the Riemann solver recovers
+        x["delz"] = F((-rd / grav * x["pt"] * pm ** kap * (peln[:, :, 1:] - peln[:, :, :-1]))[c])
+        x["w"] = F(np.stack([0.2 * (scalar(a3, k + 5, npz, 0.5, 1.0) - 0.5) for k in range(npz)], axis=-1))
+    return cs, gs, st
+
+
+def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
+    """the nonhydrostatic substep loop of dyn_core (dyn_core.F90:313-1286, d_ext = 0, d_con = 0) over the oracle's routines on
+    six faces with the halo updates where dyn_core has them -- the six-face twin of oracle_dyn_core.run"""
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import level_coefficients
+    f = [{k: F(v.copy()) for k, v in s.items()} for s in st]
+    bd = gs[0].bd
+    nx, ny, ng = bd.nx, bd.ny, bd.ng
+    for t in range(6):
+        for n, kind, nk in (("delpc", "A", npz), ("ptc", "A", npz), ("uc", "V", npz), ("vc", "U", npz), ("ua", "A", npz),
+                            ("va", "A", npz), ("omga", "A", npz), ("ut", "A", npz), ("vt", "A", npz), ("divgd", "B", npz),
+                            ("gz", "A", npz + 1), ("pkc", "A", npz + 1), ("zh", "A", npz + 1), ("pk3", "A", npz + 1),
+                            ("crx", "CX", npz), ("xfx", "CX", npz), ("cry", "CY", npz), ("yfx", "CY", npz),
+                            ("mfx", "FX", npz), ("mfy", "FY", npz), ("cx", "CX", npz), ("cy", "CY", npz),
+                            ("heat_s", "CC", npz), ("diss_e", "CC", npz), ("pk", "CC", npz + 1)):
+            f[t][n] = bd.zeros(kind, nk)
+        f[t]["ws3"], f[t]["ws"] = bd.zeros("A"), bd.zeros("CC")
+        f[t]["pe"] = np.zeros((nx + 2, npz + 1, ny + 2), order="F")
+        f[t]["peln"] = np.zeros((nx, npz + 1, ny), order="F")
+        f[t]["zs"] = F(f[t]["phis"] * (1.0 / fl.grav))
+    lev = level_coefficients(npz, fl)
+    cn = dict(grav=fl.grav, rdgas=fl.rdgas, cp_air=fl.cp_air, akap=fl.akap, ptop=fl.ptop, p_fac=fl.p_fac, a_imp=fl.a_imp)
+    n_split = fl.n_split
+    dt = bdt / float(n_split)
+    dt2, rdt = 0.5 * dt, 1.0 / dt
+    ptk, peln1 = fl.ptop ** fl.akap, np.log(fl.ptop)
+    par = dict(dt=dt, hord_tr=fl.hord_tr, hord_mt=fl.hord_mt, hord_vt=fl.hord_vt, hord_tm=fl.hord_tm, hord_dp=fl.hord_dp, nord=1,
+               nord_v=1, nord_w=1, nord_t=1, dddmp=fl.dddmp, d2_bg=0.0, d4_bg=fl.d4_bg, damp_v=0.0, damp_w=0.0, damp_t=0.0, d_con=0.0,
+               kgb=fl.ke_bg, hydrostatic=0, use_cond=0)
+    ndif = np.concatenate([lev["nord_v"], lev["nord_v"][-1:]]).astype(np.int32)
+    damp = np.concatenate([lev["damp_vt"], lev["damp_vt"][-1:]])
+    exchange(cs, f, ("delp", "pt"), "A")
+    exchange_pair(cs, f, "u", "v", "D")
+    for it in range(1, n_split + 1):
+        remap_step = it == n_split
+        exchange(cs, f, ("w",), "A")
+        for t in range(6):
+            x = f[t]
+            if it == 1:
+                gz = x["gz"]
+                gz[ng:ng + nx, ng:ng + ny, npz] = x["zs"][ng:ng + nx, ng:ng + ny]
+                for k in range(npz - 1, -1, -1):
+                    gz[ng:ng + nx, ng:ng + ny, k] = gz[ng:ng + nx, ng:ng + ny, k + 1] - x["delz"][:, :, k]
+        if it == 1:
+            exchange(cs, f, ("gz",), "A")
+            for t in range(6):
+                f[t]["zh"][...] = f[t]["gz"]
+        else:
+            for t in range(6):
+                f[t]["gz"][...] = f[t]["zh"]
+        for t in range(6):
+            x = f[t]
+            cs_ = dict(delpc=x["delpc"], delp=x["delp"], ptc=x["ptc"], pt=x["pt"], u=x["u"], v=x["v"], w=x["w"], uc=x["uc"], vc=x["vc"],
+                       ua=x["ua"], va=x["va"], wc=x["omga"], ut=x["ut"], vt=x["vt"], divg_d=x["divgd"])
+            O.c_sw_3d(gs[t], npz, cs_, nord=fl.nord, dt2=dt2, hydrostatic=False)
+        if fl.nord > 0:
+            exchange(cs, f, ("divgd",), "B")
+        for t in range(6):
+            x = f[t]
+            O.update_dz_c(gs[t], npz, dt2, dp_ref, x["zs"], x["ut"], x["vt"], x["gz"], x["ws3"])
+            O.riem_solver_c(gs[t], npz, dt2, cn, x["phis"], x["omga"], x["ptc"], x["delpc"], x["gz"], x["pkc"], x["ws3"], None, None)
+            O.p_grad_c(gs[t], npz, dt2, x["delpc"], x["pkc"], x["gz"], x["uc"], x["vc"], False)
+        exchange_pair(cs, f, "uc", "vc", "C")
+        for t in range(6):
+            x = f[t]
+            ds = dict(delpc=x["vt"], delp=x["delp"], ptc=x["ptc"], pt=x["pt"], u=x["u"], v=x["v"], w=x["w"], uc=x["uc"], vc=x["vc"],
+                      ua=x["ua"], va=x["va"], divg_d=x["divgd"], mfx=x["mfx"], mfy=x["mfy"], cx=x["cx"], cy=x["cy"], crx=x["crx"],
+                      cry=x["cry"], xfx=x["xfx"], yfx=x["yfx"], heat_source=x["heat_s"], diss_est=x["diss_e"])
+            O.d_sw_3d(gs[t], npz, par, lev, ds)
+        exchange(cs, f, ("delp", "pt"), "A")
+        for t in range(6):
+            x = f[t]
+            O.update_dz_d(gs[t], npz, ndif.copy(), damp.copy(), fl.hord_tm, dp_ref, x["zs"], x["zh"], x["crx"], x["cry"], x["xfx"],
+                          x["yfx"], x["ws"], rdt)
+            O.riem_solver3(gs[t], npz, dt, cn, x["zs"], x["w"], x["delz"], x["pt"], x["delp"], x["zh"], x["pe"], x["pkc"], x["pk3"],
+                           x["pk"], x["peln"], x["ws"], fl.use_logp, remap_step, False, None, None)
+        exchange(cs, f, ("zh", "pkc"), "A")
+        for t in range(6):
+            x = f[t]
+            if remap_step:
+                O.pe_halo(gs[t], npz, fl.ptop, x["pe"], x["delp"])
+            O.pk3_halo(gs[t], npz, fl.ptop, fl.akap, x["pk3"], x["delp"], fl.use_logp)
+            i0, i1 = ng - 2, ng + nx + 2
+            x["gz"][i0:i1, i0:i1, :] = x["zh"][i0:i1, i0:i1, :] * fl.grav
+            O.nh_p_grad(gs[t], npz, x["u"], x["v"], x["pkc"], x["gz"], x["delp"], x["pk3"], dt, peln1 if fl.use_logp else ptk)
+        if it != n_split:
+            exchange_pair(cs, f, "u", "v", "D")
+        else:
+            exchange_pair(cs, f, "u", "v", "Dedge")
+    return f
+
+
 def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz):
     """hydrostatic k_split loop on six faces over the oracle: dyn_core substeps -> Lagrangian_to_Eulerian (no tracers)"""
     mdt = bdt / float(k_split)
@@ -208,5 +316,24 @@ def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz):
                       omga=bd.zeros("A", npz))
             O.lagrangian_to_eulerian(gs[t], npz, dict(remap_par, last_step=0), rf, ak, bk)
             cur[t] = dict(u=rf["u"], v=rf["v"], delp=rf["delp"], pt=rf["pt"], phis=st[t]["phis"])
+            out.append(dict(cur[t], pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"]))
+    return out
+
+
+def oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, remap_par, npz):
+    """nonhydrostatic k_split loop on six faces over the oracle: dyn_core substeps -> Lagrangian_to_Eulerian (no tracers)"""
+    mdt = bdt / float(k_split)
+    cur = [{k: s[k].copy(order="F") for k in ("u", "v", "w", "delp", "pt", "delz", "phis")} for s in st]
+    out = None
+    bd = gs[0].bd
+    for n_map in range(1, k_split + 1):
+        f = oracle_substeps_nh(cs, gs, fl, dp_ref, cur, mdt, npz)
+        out = []
+        for t in range(6):
+            x = f[t]
+            rf = dict(ps=bd.zeros("A"), pe=x["pe"], delp=x["delp"], pkz=bd.zeros("CC", npz), pk=x["pk"], u=x["u"], v=x["v"], w=x["w"],
+                      delz=x["delz"], pt=x["pt"], peln=x["peln"], omga=x["omga"], ws=x["ws"])
+            O.lagrangian_to_eulerian(gs[t], npz, dict(remap_par, last_step=0), rf, ak, bk)
+            cur[t] = dict(u=rf["u"], v=rf["v"], w=rf["w"], delp=rf["delp"], pt=rf["pt"], delz=rf["delz"], phis=st[t]["phis"])
             out.append(dict(cur[t], pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"]))
     return out

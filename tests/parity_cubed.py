@@ -158,7 +158,40 @@ def check_substeps_hydrostatic(lib, npx=13, npz=4, n_split=2, bdt=600.0, flags=N
     return worst
 
 
-def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-12):
+def check_substeps_nh(lib, npx=13, npz=5, n_split=2, bdt=300.0, flags=None, tol=1e-12):
+    """the nonhydrostatic acoustic substep loop on the whole sphere: six contexts behind dyn_core.DynCore against the six-face
+    orchestration of the oracle (c_sw, update_dz_c, riem_solver_c, p_grad_c, d_sw, update_dz_d, riem_solver3, nh_p_grad)"""
+    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynCore, DynFlags
+    cs, gs, st = CC.nh_state(npx, npz)
+    fl = DynFlags(n_split=n_split, hydrostatic=False, **(flags or {}))
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+    dp0 = np.diff(fl.ptop + (1.0e5 - fl.ptop) * sig)
+    ref = CC.oracle_substeps_nh(cs, gs, fl, dp0, st, bdt, npz)
+    mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
+    worst = {}
+    try:
+        dc = DynCore(mctx, fl, dp0, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        dc.set_state([s["u"] for s in st], [s["v"] for s in st], [s["w"] for s in st], [s["delp"] for s in st],
+                     [s["pt"] for s in st], [s["delz"] for s in st], [s["phis"] for s in st])
+        dc.run(bdt)
+        bd = gs[0].bd
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        for n, kind, rr in (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)),
+                            ("delp", "A", r), ("pt", "A", r), ("w", "A", r), ("zh", "A", r)):
+            got = dc.d[n].download()
+            for t in range(6):
+                worst[n] = max(worst.get(n, 0.0), P.assert_close(f"face {t + 1} {n}", bd.view(got[t], kind, *rr), bd.view(ref[t][n], kind, *rr), tol))
+        for n in ("delz", "mfx", "mfy", "cx", "cy", "pk", "peln"):
+            got = dc.d[n].download()
+            for t in range(6):
+                worst[n] = max(worst.get(n, 0.0), P.assert_close(f"face {t + 1} {n}", got[t], ref[t][n], tol))
+    finally:
+        mctx.close()
+    return worst
+
+
+def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-12, hydrostatic=True):
     """BASELINE configs[1] in small: the Jablonowski-Williamson baroclinic wave (test_case = 13) on the whole cubed sphere,
     hydrostatic, the reference's L79 levels (set_eta), one dt_atmos = k_split x (n_split substeps + vertical remap) on six
     device contexts against the six-face orchestration of the oracle"""
@@ -173,8 +206,9 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
         sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
         ptop = 300.0
         ak, bk = ptop * (1.0 - sig), sig.copy()
-    st = jablonowski_williamson(cs, ak, bk, hydrostatic=True)
-    fl = DynFlags(n_split=n_split, hydrostatic=True, d_ext=0.0, ptop=float(ak[0]))
+    st = jablonowski_williamson(cs, ak, bk, hydrostatic=hydrostatic)
+    CC.exchange(cs, st, ("phis",), "A")          # the model gets phis with its halo filled (init_case: mpp_update_domains(phis))
+    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, d_ext=0.0, ptop=float(ak[0]))
     # T -> theta: pt = T / pkz with the hydrostatic pkz of the initial state (fv_dynamics.F90:323-329, the host's job here)
     bd = gs[0].bd
     ng, nx = bd.ng, bd.nx
@@ -184,14 +218,22 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
         pk = O.fexp(fl.akap * O.flog(pe[c])).reshape(pe[c].shape)
         peln = O.flog(pe[c]).reshape(pe[c].shape)
         pkz = (pk[:, :, 1:] - pk[:, :, :-1]) / (fl.akap * (peln[:, :, 1:] - peln[:, :, :-1]))
+        if not hydrostatic:          # fv_dynamics.F90:385-394: pkz = (rdg * delp * pt / delz) ** kappa
+            arg = (-fl.rdgas / fl.grav) * s["delp"][c] * s["pt"][c] / s["delz"]
+            pkz = O.fexp(fl.akap * O.flog(arg)).reshape(arg.shape)
         s["pt"][c] = s["pt"][c] / pkz
     mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     worst = {}
     try:
         fv = FvDynamics(mctx, fl, ak, bk, nq=0, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
-        ref = CC.oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, fv.remap_par, npz)
-        z = [np.zeros_like(s["delp"]) for s in st]
-        dz = [bd.zeros("CC", npz) for _ in st]
+        if hydrostatic:
+            ref = CC.oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, fv.remap_par, npz)
+            z = [np.zeros_like(s["delp"]) for s in st]
+            dz = [bd.zeros("CC", npz) for _ in st]
+        else:
+            dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
+            ref = CC.oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, fv.remap_par, npz)
+            z, dz = [s["w"] for s in st], [s["delz"] for s in st]
         fv.dc.set_state([s["u"] for s in st], [s["v"] for s in st], z, [s["delp"] for s in st], [s["pt"] for s in st], dz,
                         [s["phis"] for s in st])
         fv.step(bdt)
@@ -202,13 +244,71 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
             got = d[n].download()
             for t in range(6):
                 worst[n] = max(worst.get(n, 0.0), P.assert_close(f"face {t + 1} {n}", bd.view(got[t], kind, *rr), bd.view(ref[t][n], kind, *rr), tol))
-        for n in ("pkz", "pk", "peln"):
+        for n in ("pkz", "pk", "peln") + (() if hydrostatic else ("delz",)):
             got = d[n].download()
             for t in range(6):
                 worst[n] = max(worst.get(n, 0.0), P.assert_close(f"face {t + 1} {n}", got[t], ref[t][n], tol))
+        if not hydrostatic:
+            got = d["w"].download()
+            for t in range(6):
+                worst["w"] = max(worst.get("w", 0.0), P.assert_close(f"face {t + 1} w", bd.view(got[t], "A", *r), bd.view(ref[t]["w"], "A", *r), tol))
         dp = d["delp"].download()
         s = slice(ng, ng + nx)
         worst["finite"] = float(all(np.isfinite(x[s, s, :]).all() for x in dp))
     finally:
         mctx.close()
     return worst
+
+
+def check_sphere_properties(lib, npx=97, npz=127, hydrostatic=False, k_split=1, n_split=2, bdt=225.0):
+    """size-independent checks of a whole-sphere step at sizes the oracle cannot reach: everything finite, the global air mass
+    sum(area * delp) kept to rounding (flux form; both faces of a cube edge compute the same edge flux), the winds on the shared
+    cube edges equal on both faces (mpp_get_boundary), the state moved"""
+    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.test_cases import jablonowski_williamson, set_eta
+    cs, gs = CC.sphere(npx)
+    ak, bk, ks, ptop = set_eta(npz)
+    st = jablonowski_williamson(cs, ak, bk, hydrostatic=hydrostatic)
+    CC.exchange(cs, st, ("phis",), "A")          # the model gets phis with its halo filled (init_case: mpp_update_domains(phis))
+    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, d_ext=0.0, ptop=float(ak[0]))
+    bd = gs[0].bd
+    ng, nx = bd.ng, bd.nx
+    c = (slice(ng, ng + nx), slice(ng, ng + nx))
+    for s_ in st:
+        if hydrostatic:
+            pe = ak[0] + np.concatenate([np.zeros(s_["delp"].shape[:2] + (1,)), np.cumsum(s_["delp"], axis=2)], axis=2)[c]
+            peln = np.log(pe)
+            pkz = (pe[:, :, 1:] ** fl.akap - pe[:, :, :-1] ** fl.akap) / (fl.akap * (peln[:, :, 1:] - peln[:, :, :-1]))
+        else:
+            pkz = ((-fl.rdgas / fl.grav) * s_["delp"][c] * s_["pt"][c] / s_["delz"]) ** fl.akap
+        s_["pt"][c] = s_["pt"][c] / pkz
+    area = [g.m["area"][c] for g in gs]
+    mass0 = sum(float(np.sum(a[:, :, None] * s_["delp"][c])) for a, s_ in zip(area, st))
+    mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
+    out = {}
+    try:
+        fv = FvDynamics(mctx, fl, ak, bk, nq=0, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        z = [np.zeros_like(s_["delp"]) for s_ in st] if hydrostatic else [s_["w"] for s_ in st]
+        dz = [bd.zeros("CC", npz) for _ in st] if hydrostatic else [s_["delz"] for s_ in st]
+        fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], z, [s_["delp"] for s_ in st], [s_["pt"] for s_ in st], dz,
+                        [s_["phis"] for s_ in st])
+        fv.step(bdt)
+        d = fv.dc.d
+        dp = d["delp"].download()
+        u, v = d["u"].download(), d["v"].download()
+        out["finite"] = float(all(np.isfinite(x[c]).all() for x in dp) and all(np.isfinite(bd.view(x, "U", bd.is_, bd.ie, bd.js, bd.je + 1)).all() for x in u))
+        mass1 = sum(float(np.sum(a[:, :, None] * x[c])) for a, x in zip(area, dp))
+        out["mass_drift"] = abs(mass1 - mass0) / mass0
+        out["moved"] = max(float(np.max(np.abs(x[c] - s_["delp"][c]))) for x, s_ in zip(dp, st))
+        # the shared edges: apply the table update for the boundary points to copies and compare
+        uu, vv = [x.copy(order="F") for x in u], [x.copy(order="F") for x in v]
+        cs.topo.update("Dedge", (uu, vv))
+        out["edge_mismatch"] = max(max(float(np.max(np.abs(bd.view(a, "U", bd.is_, bd.ie, bd.js, bd.je + 1) - bd.view(b, "U", bd.is_, bd.ie, bd.js, bd.je + 1))))
+                                       for a, b in zip(u, uu)),
+                                   max(float(np.max(np.abs(bd.view(a, "V", bd.is_, bd.ie + 1, bd.js, bd.je) - bd.view(b, "V", bd.is_, bd.ie + 1, bd.js, bd.je))))
+                                       for a, b in zip(v, vv)))
+    finally:
+        mctx.close()
+    return out

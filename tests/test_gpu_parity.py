@@ -611,6 +611,16 @@ def test_cubed_c48_pair(prod):
     assert max(PC.check_d_sw(prod, npx=49, npz=4, hydrostatic=True).values()) <= P.TOL
 
 
+def test_cubed_d_sw_nonhydrostatic_default(prod):
+    assert max(PC.check_d_sw(prod, npx=25, npz=4, hydrostatic=False).values()) <= P.TOL
+
+
+def test_cubed_sphere_nonhydrostatic_substeps(prod):
+    """the nonhydrostatic substep loop on the whole sphere (six contexts on one GPU) against the six-face oracle"""
+    assert max(PC.check_substeps_nh(prod, npx=25, npz=6, n_split=2).values()) <= 1e-12
+    assert max(PC.check_substeps_nh(prod, npx=49, npz=8, n_split=3, bdt=450.0).values()) <= 1e-12
+
+
 def test_cubed_a2b_ord4_through_the_pressure_gradients(prod):
     cs, gs = PC.CC.sphere(25)
     for t in (0, 3, 5):
@@ -635,3 +645,22 @@ def test_baseline_config2_c96l79_jablonowski_williamson(prod):
 def test_cubed_sphere_jw_c24(prod):
     r = PC.check_jw_step(prod, npx=25, npz=79, k_split=1, n_split=2, bdt=900.0)
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
+def test_config3_small_c96_l127_nonhydrostatic_jw(prod):
+    """BASELINE configs[2] at the size the oracle reaches: the C96 L127 nonhydrostatic baroclinic wave on the whole sphere (six
+    contexts on one MI355X), one remap cycle of three acoustic substeps, < 1e-12 against the six-face oracle"""
+    r = PC.check_jw_step(prod, npx=97, npz=127, k_split=1, n_split=3, bdt=450.0, hydrostatic=False)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
+def test_config3_c384_l127_nonhydrostatic_sphere(prod):
+    """BASELINE configs[2] at full size: C384 L127 nonhydrostatic on one MI355X (6 x 384 x 384 x 127 cells).  Past the oracle's
+    reach: finite, global air mass kept to rounding, the winds of the shared cube edges equal on both faces, the state moved"""
+    r = PC.check_sphere_properties(prod, npx=385, npz=127, hydrostatic=False, k_split=1, n_split=2, bdt=75.0)
+    assert r["finite"] == 1.0 and r["mass_drift"] < 1e-13 and r["edge_mismatch"] == 0.0 and r["moved"] > 1e-3, r
+
+
+def test_config2_c96_l79_sphere_properties(prod):
+    r = PC.check_sphere_properties(prod, npx=97, npz=79, hydrostatic=True, k_split=2, n_split=3, bdt=1800.0)
+    assert r["finite"] == 1.0 and r["mass_drift"] < 1e-13 and r["edge_mismatch"] == 0.0 and r["moved"] > 1e-3, r

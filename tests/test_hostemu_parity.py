@@ -458,6 +458,17 @@ def test_cubed_d_sw(emu, kw):
     assert max(PC.check_d_sw(emu, npx=13, npz=3, **kw).values()) <= P.TOL
 
 
+def test_cubed_d_sw_nonhydrostatic_default(emu):
+    """the default level coefficients: del-2 damping of w in the sponge layer (damp_w > 0, nord_w = 0)"""
+    assert max(PC.check_d_sw(emu, npx=13, npz=4, hydrostatic=False).values()) <= P.TOL
+
+
+def test_cubed_sphere_nonhydrostatic_substeps(emu):
+    """two substeps of the nonhydrostatic core on the whole C12 sphere: update_dz_c with fill_4corners, update_dz_d through the
+    cubed fv_tp_2d, both Riemann solvers, nh_p_grad with the cubed a2b_ord4"""
+    assert max(PC.check_substeps_nh(emu, npx=13, npz=5, n_split=2).values()) <= 1e-13
+
+
 def test_cubed_a2b_ord4_through_the_pressure_gradients(emu):
     cs, gs = PC.CC.sphere(13)
     for t in (0, 3):
@@ -501,4 +512,10 @@ def test_cubed_sphere_hydrostatic_substeps(emu):
 def test_cubed_sphere_jablonowski_williamson_step(emu):
     """test_case = 13 on a C12 sphere with the reference's L79 levels: one dt_atmos (k_split = 2: substeps + remap)"""
     r = PC.check_jw_step(emu, npx=13, npz=79, k_split=2, n_split=2, bdt=1800.0)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
+def test_cubed_sphere_jablonowski_williamson_nonhydrostatic_step(emu):
+    """BASELINE configs[2] in small: the nonhydrostatic baroclinic wave on a C12 sphere, L79, one dt_atmos (k_split = 2)"""
+    r = PC.check_jw_step(emu, npx=13, npz=79, k_split=2, n_split=2, bdt=900.0, hydrostatic=False)
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
