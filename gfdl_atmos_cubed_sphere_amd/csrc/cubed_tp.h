@@ -286,4 +286,27 @@ struct ZhCubedFinal {
   }
 };
 
+// tracer_2d (fv_tracer2d.F90:497-533): one tracer's update from the fluxes of fv_tp_2d; levels that have finished their
+// sub-cycles carry q (and dp1) over
+struct TracerCubedFinal {
+  Grid g;
+  int it, nsplt, last;
+  const int *ksplt;
+  const double *q, *dp1, *fx, *fy, *mfx, *mfy;
+  double *q_out, *dp1_out;
+  FV3_HD void operator()(int i, int j, int k) const {
+    const CA qv = cview_A(g, q), d1v = cview_A(g, dp1);
+    if (it > ksplt[k]) {
+      view_A(g, q_out)(i, j, k) = qv(i, j, k);
+      if (last && it != nsplt) view_A(g, dp1_out)(i, j, k) = d1v(i, j, k);
+      return;
+    }
+    const CA fxv = cview_FX(g, fx), fyv = cview_FY(g, fy), mx = cview_FX(g, mfx), my = cview_FY(g, mfy);
+    const double ra = g.rarea[g.iA(i, j)], d1 = d1v(i, j, k);
+    const double dp2 = d1 + (mx(i, j, k) - mx(i + 1, j, k) + my(i, j, k) - my(i, j + 1, k)) * ra;
+    view_A(g, q_out)(i, j, k) = (qv(i, j, k) * d1 + (fxv(i, j, k) - fxv(i + 1, j, k) + fyv(i, j, k) - fyv(i, j + 1, k)) * ra) / dp2;
+    if (last && it != nsplt) view_A(g, dp1_out)(i, j, k) = dp2;
+  }
+};
+
 }  // namespace fv3

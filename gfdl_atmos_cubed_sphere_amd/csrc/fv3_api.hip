@@ -1923,6 +1923,18 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
     RT(rt_h2d(c->trc_i, ksplt_host, sizeof(int) * g.npz, c->stream));
     RT(rt_sync(c->stream));
   }
+  if (is_cubed(c)) {
+    if (it == 1 && trdm > 1.e-4) return fail("fv3_tracer_2d_step: deln_flux damping (trdm) is not built for the cubed sphere yet");
+    double *fx = cs_scratch(c, 8), *fy = cs_scratch(c, 9);
+    if (!fx || !fy) return fail("fv3_tracer_2d_step: out of device memory");
+    const size_t nq3 = (size_t)g.npz * g.nA();
+    for (int iq = 0; iq < nq; iq++) {
+      if (tp2d_cubed(c, g.npz, q + iq * nq3, cx, cy, hord, fx, fy, xfx, yfx, nullptr, nullptr, mfx, mfy, "tracer_step")) return 1;
+      TracerCubedFinal kf{g, it, nsplt, iq == nq - 1, c->trc_i, q + iq * nq3, dp1, fx, fy, mfx, mfy, q_out + iq * nq3, dp1_out};
+      RT(launch_box(c, "tracer_step", g.is, g.ie, g.js, g.je, g.npz, kf));
+    }
+    return 0;
+  }
   if (c->use_march && !(it == 1 && trdm > 1.e-4)) {
     const int trc_nt = c->trc_nt;   // tracers per wavefront (1: one (tracer, level) per wavefront, TracerMarch)
     if (trc_nt > 1 && nq > 1) {

@@ -55,7 +55,7 @@ class CubeHalo:
         mem = fields if pair else (fields,)
         ptrs = [d.ptr for lst in mem for d in lst]
         shapes = [d.shape for lst in mem for d in lst]
-        nk = 1 if len(shapes[0]) == 2 else int(shapes[0][2])
+        nk = 1 if len(shapes[0]) == 2 else int(np.prod(shapes[0][2:]))     # (i, j, k) or the tracer array (i, j, k, iq)
         strides = [int(s[0] * s[1]) for s in shapes]
         n = len(ptrs)
         parr = (C.c_void_p * n)(*ptrs)

@@ -12,6 +12,8 @@ def tracer_2d(ctx, halo, q, q_nxt, dp1, dp1_nxt, mfx, mfy, cx, cy, xfx, yfx, nq:
     Returns (q, dp1, nsplt): the buffers that hold the result."""
     npz = ctx.npz
     cmax = ctx.tracer_2d_prep(q_split, cx, cy, xfx, yfx)                      # :362-400
+    if isinstance(cmax, list):       # several domains in this process (the six faces): mp_reduce_max over them, :405
+        cmax = np.max(np.stack(cmax), axis=0)
     if q_split == 0:
         if dist is None and getattr(halo, "world", 1) > 1:
             # without the reduction the ranks would sub-cycle differently and post mismatching q exchanges

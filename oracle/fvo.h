@@ -20,9 +20,11 @@
  *               which the build rules forbid.  Those operators are pinned only by the
  *               reference's conservation identities (tests/test_oracle_properties.py).
  *
- * Scope of the restated branches: grid_type >= 3 (doubly periodic / Cartesian branches) with
- * general (array-valued) metric terms, bounded_domain = .false., no nesting, no regional BCs.
- * The cubed-sphere edge/corner branches (grid_type < 3) return FVO_ERR_UNSUPPORTED.
+ * Scope of the restated branches: grid_type 4 (doubly periodic) and grid_type < 3 (the cubed sphere, one whole tile per
+ * face: the edge / corner branches of c_sw, d_sw, fv_tp_2d, xppm / yppm, xtp_u / ytp_v, a2b_ord4, update_dz_c / _d), with
+ * general (array-valued) metric terms, bounded_domain = .false., no nesting, no regional BCs.  Branches that are not
+ * restated (the cubed-sphere deln_flux / del6 damping with nord > 0, a2b_ord2, c2l on the sphere) return
+ * FVO_ERR_UNSUPPORTED.
  *
  * Array layout is the reference's (Fortran column-major, i fastest), with the exact
  * lower/upper bounds of model/fv_arrays.F90:1521-1563; see the accessor macros below.
@@ -216,6 +218,14 @@ double fvo_moist_cv(const fvo_remap_par *p, const double *qk, size_t ns, double 
 /* ---- tracer_2d (oracle/tracer2d.c) ---------------------------------------------------------------- */
 int fvo_tracer_2d(const fvo_grid *g, int npz, int nq, double *q, double *dp1, double *mfx, double *mfy, double *cx,
                   double *cy, int hord, int q_split, int nord_tr, double trdm);
+/* the pieces of tracer_2d between its reductions / halo updates (the caller's, for the six faces of the cubed sphere) */
+void fvo_tracer_2d_prep(const fvo_grid *g, int npz, int q_split, const double *cx, const double *cy, double *xfx, double *yfx,
+                        double *cmax);
+void fvo_tracer_2d_scale(const fvo_grid *g, int npz, const double *frac, double *cx, double *xfx, double *mfx, double *cy,
+                         double *yfx, double *mfy);
+void fvo_tracer_2d_step(const fvo_grid *g, int npz, int nq, int it, int nsplt, const int *ksplt, double *q, double *dp1,
+                        const double *mfx, const double *mfy, const double *cx, const double *cy, const double *xfx,
+                        const double *yfx, int hord, int nord_tr, double trdm);
 
 #ifdef __cplusplus
 }

@@ -301,39 +301,78 @@ def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
     return f
 
 
-def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz):
-    """hydrostatic k_split loop on six faces over the oracle: dyn_core substeps -> Lagrangian_to_Eulerian (no tracers)"""
+def _oracle_tracers(cs, gs, fl, npz, q, dp1, f):
+    nq = q[0].shape[3]
+    oracle_tracer_2d(cs, gs, npz, nq, q, dp1, [x["mfx"] for x in f], [x["mfy"] for x in f], [x["cx"] for x in f],
+                     [x["cy"] for x in f], fl.hord_tr, 0)
+
+
+def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz, q=None):
+    """hydrostatic k_split loop on six faces over the oracle: dyn_core substeps -> tracer_2d -> Lagrangian_to_Eulerian"""
     mdt = bdt / float(k_split)
     cur = [{k: s[k].copy(order="F") for k in ("u", "v", "delp", "pt", "phis")} for s in st]
+    q = None if q is None else [x.copy(order="F") for x in q]
     out = None
     bd = gs[0].bd
     for n_map in range(1, k_split + 1):
+        dp1 = [c["delp"].copy(order="F") for c in cur]
         f = oracle_substeps_hydro(cs, gs, fl, cur, mdt, npz)
+        if q is not None:
+            _oracle_tracers(cs, gs, fl, npz, q, dp1, f)
         out = []
         for t in range(6):
             x = f[t]
             rf = dict(ps=bd.zeros("A"), pe=x["pe"], delp=x["delp"], pkz=x["pkz"], pk=x["pk"], u=x["u"], v=x["v"], pt=x["pt"], peln=x["peln"],
                       omga=bd.zeros("A", npz))
+            if q is not None:
+                rf["q"] = q[t]
             O.lagrangian_to_eulerian(gs[t], npz, dict(remap_par, last_step=0), rf, ak, bk)
             cur[t] = dict(u=rf["u"], v=rf["v"], delp=rf["delp"], pt=rf["pt"], phis=st[t]["phis"])
-            out.append(dict(cur[t], pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"]))
+            out.append(dict(cur[t], pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"], q=None if q is None else q[t]))
     return out
 
 
-def oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, remap_par, npz):
-    """nonhydrostatic k_split loop on six faces over the oracle: dyn_core substeps -> Lagrangian_to_Eulerian (no tracers)"""
+def oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, remap_par, npz, q=None):
+    """nonhydrostatic k_split loop on six faces over the oracle: dyn_core substeps -> tracer_2d -> Lagrangian_to_Eulerian"""
     mdt = bdt / float(k_split)
     cur = [{k: s[k].copy(order="F") for k in ("u", "v", "w", "delp", "pt", "delz", "phis")} for s in st]
+    q = None if q is None else [x.copy(order="F") for x in q]
     out = None
     bd = gs[0].bd
     for n_map in range(1, k_split + 1):
+        dp1 = [c["delp"].copy(order="F") for c in cur]
         f = oracle_substeps_nh(cs, gs, fl, dp_ref, cur, mdt, npz)
+        if q is not None:
+            _oracle_tracers(cs, gs, fl, npz, q, dp1, f)
         out = []
         for t in range(6):
             x = f[t]
             rf = dict(ps=bd.zeros("A"), pe=x["pe"], delp=x["delp"], pkz=bd.zeros("CC", npz), pk=x["pk"], u=x["u"], v=x["v"], w=x["w"],
                       delz=x["delz"], pt=x["pt"], peln=x["peln"], omga=x["omga"], ws=x["ws"])
+            if q is not None:
+                rf["q"] = q[t]
             O.lagrangian_to_eulerian(gs[t], npz, dict(remap_par, last_step=0), rf, ak, bk)
             cur[t] = dict(u=rf["u"], v=rf["v"], w=rf["w"], delp=rf["delp"], pt=rf["pt"], delz=rf["delz"], phis=st[t]["phis"])
-            out.append(dict(cur[t], pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"]))
+            out.append(dict(cur[t], pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"], q=None if q is None else q[t]))
     return out
+
+
+def oracle_tracer_2d(cs, gs, npz, nq, q, dp1, mfx, mfy, cx, cy, hord, q_split=0):
+    """tracer_2d (fv_tracer2d.F90:297-557) on six faces over the oracle's pieces: the Courant-number maximum reduced over the
+    faces, the q halo updates between the sub-cycles.  q, dp1, mfx, ... are lists of six arrays, updated in place."""
+    xfx = [np.zeros_like(c) for c in cx]
+    yfx = [np.zeros_like(c) for c in cy]
+    cmax = np.max(np.stack([O.tracer_2d_prep(gs[t], npz, q_split, cx[t], cy[t], xfx[t], yfx[t]) for t in range(6)]), axis=0)
+    nsplt = int(1.0 + float(np.max(cmax))) if q_split == 0 else q_split
+    if nsplt != 1:
+        ksplt = (1.0 + cmax).astype(np.int32)
+        frac = 1.0 / ksplt.astype(np.float64)
+        for t in range(6):
+            O.tracer_2d_scale(gs[t], npz, frac, cx[t], xfx[t], mfx[t], cy[t], yfx[t], mfy[t])
+    else:
+        ksplt = np.ones(npz, dtype=np.int32)
+    for it in range(1, nsplt + 1):
+        cs.topo.update("A", q)
+        for t in range(6):
+            O.tracer_2d_step(gs[t], npz, nq, it, nsplt, ksplt, q[t], dp1[t], mfx[t], mfy[t], cx[t], cy[t], xfx[t], yfx[t], hord)
+    return nsplt

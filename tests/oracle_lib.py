@@ -321,6 +321,32 @@ def tracer_2d(g, npz, nq, q, dp1, mfx, mfy, cx, cy, hord, q_split, nord_tr, trdm
     return rc
 
 
+def tracer_2d_prep(g, npz, q_split, cx, cy, xfx, yfx):
+    import numpy as np
+    gs = make_grid(g)
+    cmax = np.zeros(npz)
+    lib().fvo_tracer_2d_prep.restype = None
+    lib().fvo_tracer_2d_prep(C.byref(gs), C.c_int(npz), C.c_int(q_split), p(cx), p(cy), p(xfx), p(yfx), p(cmax))
+    return cmax
+
+
+def tracer_2d_scale(g, npz, frac, cx, xfx, mfx, cy, yfx, mfy):
+    import numpy as np
+    gs = make_grid(g)
+    frac = np.ascontiguousarray(frac, dtype=np.float64)
+    lib().fvo_tracer_2d_scale.restype = None
+    lib().fvo_tracer_2d_scale(C.byref(gs), C.c_int(npz), p(frac), p(cx), p(xfx), p(mfx), p(cy), p(yfx), p(mfy))
+
+
+def tracer_2d_step(g, npz, nq, it, nsplt, ksplt, q, dp1, mfx, mfy, cx, cy, xfx, yfx, hord, nord_tr=0, trdm=0.0):
+    import numpy as np
+    gs = make_grid(g)
+    ks = np.ascontiguousarray(ksplt, dtype=np.int32)
+    lib().fvo_tracer_2d_step.restype = None
+    lib().fvo_tracer_2d_step(C.byref(gs), C.c_int(npz), C.c_int(nq), C.c_int(it), C.c_int(nsplt), ks.ctypes.data_as(C.c_void_p),
+                             p(q), p(dp1), p(mfx), p(mfy), p(cx), p(cy), p(xfx), p(yfx), C.c_int(hord), C.c_int(nord_tr), _d(trdm))
+
+
 # ---- fv_dynamics around the k_split loop (oracle/dyn_pre.c) -----------------------------------------
 def c2l(g, km, ord_, u, v, ua, va):
     gs = make_grid(g)

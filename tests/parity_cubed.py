@@ -191,7 +191,19 @@ def check_substeps_nh(lib, npx=13, npz=5, n_split=2, bdt=300.0, flags=None, tol=
     return worst
 
 
-def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-12, hydrostatic=True):
+def tracer_fields(cs, npz, nq):
+    """nq smooth positive tracer fields per face as functions of position (A x npz x nq, halo included)"""
+    out = []
+    for t in range(6):
+        a3 = cs.grids[t]["agrid3"]
+        lev = (np.arange(npz) / max(npz - 1, 1))[None, None, :]
+        out.append(np.asfortranarray(np.stack(
+            [(1.0 + iq) * (1.0 + 0.3 * np.sin(2.0 * a3[..., 0:1] * (1 + iq % 3) + 4.0 * lev) * np.cos(3.0 * a3[..., 1:2] - iq)
+                           + 0.2 * a3[..., 2:3] ** 2 * lev) for iq in range(nq)], axis=-1)))
+    return out
+
+
+def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-12, hydrostatic=True, nq=0):
     """BASELINE configs[1] in small: the Jablonowski-Williamson baroclinic wave (test_case = 13) on the whole cubed sphere,
     hydrostatic, the reference's L79 levels (set_eta), one dt_atmos = k_split x (n_split substeps + vertical remap) on six
     device contexts against the six-face orchestration of the oracle"""
@@ -225,17 +237,20 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
     mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     worst = {}
     try:
-        fv = FvDynamics(mctx, fl, ak, bk, nq=0, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        q0 = tracer_fields(cs, npz, nq) if nq else None
         if hydrostatic:
-            ref = CC.oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, fv.remap_par, npz)
+            ref = CC.oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, fv.remap_par, npz, q=q0)
             z = [np.zeros_like(s["delp"]) for s in st]
             dz = [bd.zeros("CC", npz) for _ in st]
         else:
             dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
-            ref = CC.oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, fv.remap_par, npz)
+            ref = CC.oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, fv.remap_par, npz, q=q0)
             z, dz = [s["w"] for s in st], [s["delz"] for s in st]
         fv.dc.set_state([s["u"] for s in st], [s["v"] for s in st], z, [s["delp"] for s in st], [s["pt"] for s in st], dz,
                         [s["phis"] for s in st])
+        if nq:
+            fv.set_tracers(q0)
         fv.step(bdt)
         d = fv.dc.d
         r = (bd.is_, bd.ie, bd.js, bd.je)
@@ -252,6 +267,12 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
             got = d["w"].download()
             for t in range(6):
                 worst["w"] = max(worst.get("w", 0.0), P.assert_close(f"face {t + 1} w", bd.view(got[t], "A", *r), bd.view(ref[t]["w"], "A", *r), tol))
+        if nq:
+            got = d["q"].download()
+            for t in range(6):
+                for iq in range(nq):
+                    worst["q"] = max(worst.get("q", 0.0), P.assert_close(f"face {t + 1} q{iq}", bd.view(got[t][:, :, :, iq], "A", *r),
+                                                                           bd.view(ref[t]["q"][:, :, :, iq], "A", *r), tol))
         dp = d["delp"].download()
         s = slice(ng, ng + nx)
         worst["finite"] = float(all(np.isfinite(x[s, s, :]).all() for x in dp))
@@ -260,7 +281,7 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
     return worst
 
 
-def check_sphere_properties(lib, npx=97, npz=127, hydrostatic=False, k_split=1, n_split=2, bdt=225.0):
+def check_sphere_properties(lib, npx=97, npz=127, hydrostatic=False, k_split=1, n_split=2, bdt=225.0, nq=0):
     """size-independent checks of a whole-sphere step at sizes the oracle cannot reach: everything finite, the global air mass
     sum(area * delp) kept to rounding (flux form; both faces of a cube edge compute the same edge flux), the winds on the shared
     cube edges equal on both faces (mpp_get_boundary), the state moved"""
@@ -289,7 +310,12 @@ def check_sphere_properties(lib, npx=97, npz=127, hydrostatic=False, k_split=1, 
     mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     out = {}
     try:
-        fv = FvDynamics(mctx, fl, ak, bk, nq=0, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        if nq:
+            q0 = tracer_fields(cs, npz, nq)
+            fv.set_tracers(q0)
+            qm0 = [sum(float(np.sum(a[:, :, None] * s_["delp"][c] * x[c][..., iq])) for a, s_, x in zip(area, st, q0)) for iq in range(nq)]
+            del q0
         z = [np.zeros_like(s_["delp"]) for s_ in st] if hydrostatic else [s_["w"] for s_ in st]
         dz = [bd.zeros("CC", npz) for _ in st] if hydrostatic else [s_["delz"] for s_ in st]
         fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], z, [s_["delp"] for s_ in st], [s_["pt"] for s_ in st], dz,
@@ -302,6 +328,11 @@ def check_sphere_properties(lib, npx=97, npz=127, hydrostatic=False, k_split=1, 
         mass1 = sum(float(np.sum(a[:, :, None] * x[c])) for a, x in zip(area, dp))
         out["mass_drift"] = abs(mass1 - mass0) / mass0
         out["moved"] = max(float(np.max(np.abs(x[c] - s_["delp"][c]))) for x, s_ in zip(dp, st))
+        if nq:      # the tracer mass sum(area * delp * q) of every tracer is kept by the flux form + the conservative remap
+            q1 = d["q"].download()
+            qm1 = [sum(float(np.sum(a[:, :, None] * x[c] * y[c][..., iq])) for a, x, y in zip(area, dp, q1)) for iq in range(nq)]
+            out["tracer_mass_drift"] = max(abs(b - a) / abs(a) for a, b in zip(qm0, qm1))
+            out["tracer_finite"] = float(all(np.isfinite(y[c]).all() for y in q1))
         # the shared edges: apply the table update for the boundary points to copies and compare
         uu, vv = [x.copy(order="F") for x in u], [x.copy(order="F") for x in v]
         cs.topo.update("Dedge", (uu, vv))
@@ -312,3 +343,45 @@ def check_sphere_properties(lib, npx=97, npz=127, hydrostatic=False, k_split=1, 
     finally:
         mctx.close()
     return out
+
+
+def check_tracer_2d(lib, npx=13, npz=4, nq=3, hord=8, q_split=0, courant_scale=1.0, dt=600.0):
+    """tracer_2d on the whole sphere with the mass fluxes / Courant numbers of one c_sw -> d_sw step of the oracle; a
+    courant_scale > 1 makes the levels sub-cycle (nsplt > 1, different ksplt per level)"""
+    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
+    from gfdl_atmos_cubed_sphere_amd.tracer2d import tracer_2d
+    cs, gs, before, after = CC.oracle_pair(npx, npz, dt=dt, hydrostatic=True)
+    bd = gs[0].bd
+    lev_scale = courant_scale * (1.0 + 0.5 * np.arange(npz) / npz) if courant_scale != 1.0 else np.ones(npz)
+    inp = []
+    for t in range(6):
+        a3 = cs.grids[t]["agrid3"]
+        q = np.stack([np.stack([CC.scalar(a3, k + 3 * iq, npz, 1.0 + iq, 0.3) * (1.0 + 0.05 * CC._ripple(a3 * (1.0 + 0.1 * iq))) for k in range(npz)], axis=-1)
+                      for iq in range(nq)], axis=-1)
+        x = dict(q=np.asfortranarray(q), dp1=before[t]["delp"].copy(order="F"))
+        for n in ("mfx", "mfy", "cx", "cy"):
+            x[n] = np.asfortranarray(after[t][n] * lev_scale[None, None, :])
+        inp.append(x)
+    ref = [{k: v.copy(order="F") for k, v in x.items()} for x in inp]
+    nsplt = CC.oracle_tracer_2d(cs, gs, npz, nq, [r["q"] for r in ref], [r["dp1"] for r in ref], [r["mfx"] for r in ref],
+                                [r["mfy"] for r in ref], [r["cx"] for r in ref], [r["cy"] for r in ref], hord, q_split)
+    mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
+    worst = {"nsplt": float(nsplt)}
+    try:
+        halo = CubeHaloAdapter(mctx, npx, topo=cs.topo)
+        d = {n: mctx.from_host([x[n] for x in inp]) for n in ("q", "dp1", "mfx", "mfy", "cx", "cy")}
+        d["q_nxt"], d["dp1_nxt"] = mctx.from_host([x["q"] * 0 for x in inp]), mctx.zeros("A", npz)
+        d["xfx"], d["yfx"] = mctx.zeros("CX", npz), mctx.zeros("CY", npz)
+        q, dp1, ns = tracer_2d(mctx, halo, d["q"], d["q_nxt"], d["dp1"], d["dp1_nxt"], d["mfx"], d["mfy"], d["cx"], d["cy"],
+                               d["xfx"], d["yfx"], nq, hord, q_split)
+        assert ns == nsplt, (ns, nsplt)
+        got = q.download()
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        for t in range(6):
+            for iq in range(nq):
+                worst["q"] = max(worst.get("q", 0.0), P.assert_close(f"face {t + 1} q{iq}", bd.view(got[t][:, :, :, iq], "A", *r),
+                                                                       bd.view(ref[t]["q"][:, :, :, iq], "A", *r)))
+        # mass-weighted tracer content is conserved by the flux form
+    finally:
+        mctx.close()
+    return worst

@@ -664,3 +664,21 @@ def test_config3_c384_l127_nonhydrostatic_sphere(prod):
 def test_config2_c96_l79_sphere_properties(prod):
     r = PC.check_sphere_properties(prod, npx=97, npz=79, hydrostatic=True, k_split=2, n_split=3, bdt=1800.0)
     assert r["finite"] == 1.0 and r["mass_drift"] < 1e-13 and r["edge_mismatch"] == 0.0 and r["moved"] > 1e-3, r
+
+
+@pytest.mark.parametrize("kw", [dict(npx=25, nq=3), dict(npx=25, courant_scale=40.0, hord=5, nq=2), dict(npx=49, npz=6, q_split=2, hord=13, nq=2)])
+def test_cubed_tracer_2d(prod, kw):
+    assert PC.check_tracer_2d(prod, **kw)["q"] <= P.TOL
+
+
+def test_config5_small_c96_l79_sphere_with_33_tracers(prod):
+    """BASELINE configs[4] at the size the oracle reaches, six faces on one GPU: C96 L79 + 33 advected tracers (fv_tracer2d),
+    one remap cycle, < 1e-12 against the six-face oracle"""
+    r = PC.check_jw_step(prod, npx=97, npz=79, k_split=1, n_split=3, bdt=450.0, hydrostatic=True, nq=33)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
+def test_config5_c192_l79_sphere_with_33_tracers_properties(prod):
+    """past the oracle's reach: air mass and the mass of every tracer kept to rounding on the whole sphere"""
+    r = PC.check_sphere_properties(prod, npx=193, npz=79, hydrostatic=True, k_split=1, n_split=3, bdt=225.0, nq=33)
+    assert r["finite"] == 1.0 and r["tracer_finite"] == 1.0 and r["mass_drift"] < 1e-13 and r["tracer_mass_drift"] < 1e-12, r

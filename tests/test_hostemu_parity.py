@@ -519,3 +519,17 @@ def test_cubed_sphere_jablonowski_williamson_nonhydrostatic_step(emu):
     """BASELINE configs[2] in small: the nonhydrostatic baroclinic wave on a C12 sphere, L79, one dt_atmos (k_split = 2)"""
     r = PC.check_jw_step(emu, npx=13, npz=79, k_split=2, n_split=2, bdt=900.0, hydrostatic=False)
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(courant_scale=40.0, hord=5, nq=2), dict(courant_scale=70.0, hord=10, nq=1, q_split=0),
+                                dict(q_split=2, hord=13, nq=1)])
+def test_cubed_tracer_2d(emu, kw):
+    """tracer_2d on the whole sphere: the Courant maximum reduced over the six faces, sub-cycled levels, q halos per sub-cycle"""
+    assert PC.check_tracer_2d(emu, **kw)["q"] <= P.TOL
+
+
+def test_cubed_sphere_jw_step_with_tracers(emu):
+    r = PC.check_jw_step(emu, npx=13, npz=79, k_split=2, n_split=2, bdt=900.0, hydrostatic=True, nq=3)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+    r = PC.check_jw_step(emu, npx=13, npz=20, k_split=1, n_split=2, bdt=900.0, hydrostatic=False, nq=2)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
