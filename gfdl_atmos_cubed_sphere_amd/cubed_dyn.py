@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .cubed_halo import CubeHalo
+from .cubed_halo import CubeHalo, CubeHaloRank
 from .cubed_sphere import CubedSphere
 from .lib import Context
 
@@ -116,6 +116,49 @@ class CubeHaloAdapter:
     def sync_edges(self, u, v):
         """mpp_get_boundary(u, v) of the last substep (dyn_core.F90:1151-1163)"""
         self.cube.update("Dedge", (u.a, v.a))
+
+
+class CubeRankAdapter:
+    """one face per rank: group halo updates of the single-domain host code -> CubeHaloRank messages (RCCL / gloo).  Scalar
+    fields of one group with the same kind and level count travel in ONE message per neighbouring face, like the
+    reference's complete=.false./.true. grouping (dyn_core.F90:823-824)."""
+    overlaps = False
+
+    def __init__(self, ctx, face: int, npx: int, dist, topo=None):
+        self.cube = CubeHaloRank(ctx, face, npx, dist, topo=topo)
+        self.world = 6
+        self.rank = face
+
+    def _groups(self, fields):
+        fields = list(fields)
+        kinds = [k for _, k in fields]
+        if kinds == ["U", "V"]:
+            return [("D", [fields[0][0], fields[1][0]])]
+        if kinds == ["V", "U"]:
+            return [("C", [fields[0][0], fields[1][0]])]
+        groups = {}
+        for f, k in fields:
+            if k not in ("A", "B"):
+                raise ValueError(f"no cubed-sphere halo update for a lone field of kind {k}")
+            groups.setdefault((k, tuple(f.shape[2:])), []).append(f)
+        return [(k, fs) for (k, _), fs in groups.items()]
+
+    def start(self, fields, defer=False):
+        return [self.cube.start(k, fs) for k, fs in self._groups(fields)]
+
+    def post(self, pending):
+        pass
+
+    def finish(self, pending):
+        for h in pending or ():
+            self.cube.finish(h)
+
+    def update(self, fields):
+        self.finish(self.start(fields))
+
+    def sync_edges(self, u, v):
+        """mpp_get_boundary(u, v) of the last substep (dyn_core.F90:1151-1163)"""
+        self.cube.update("Dedge", [u, v])
 
 
 def make_sphere_contexts(npx: int, npz: int, lib=None, sphere: CubedSphere | None = None):
