@@ -32,6 +32,55 @@ struct BoxPass {
   }
 };
 
+// The same functor over the FRAME of a face only: the points of the box whose distance to a face edge is below w (i <= w,
+// i >= npx - w, j <= w or j >= npy - w; the halo is part of the frame), for the level list klist[0 : nk) (null: identity).
+// The south / north bands are full rows of the box; the west / east bands are the columns (i0 : w) and (npx - w : i1) of the
+// rows between them, laid side by side in one 64-lane row.  Used by the hybrid path: the marching kernels own the interior
+// of a face, these passes own the frame.
+template <class F>
+struct FramePass {
+  int i0, i1, j0, j1, w, npx, npy;
+  int nby_sn;        // workgroup rows of the south + north bands
+  const int *klist;
+  F f;
+  FV3_HD void operator()(int bx, int by, int bz, int tid, double *) const {
+    const int k = klist ? klist[bz] : bz;
+    const int js1 = w < j1 ? w : j1, jn0 = (npy - w) > j0 ? (npy - w) : j0;   // south band j0..js1, north band jn0..j1
+    const int ns = js1 - j0 + 1;
+    for (int t = tid; t < 256; t += kNT) {
+      const int l = t & 63, r = t >> 6;
+      if (by < nby_sn) {
+        const int v = by * 4 + r;
+        const int j = v < ns ? j0 + v : jn0 + (v - ns);
+        const int i = i0 + bx * 64 + l;
+        if (i <= i1 && j <= j1 && (v < ns || j > js1)) f(i, j, k);
+      } else {
+        if (bx > 0) continue;
+        const int j = js1 + 1 + (by - nby_sn) * 4 + r;
+        if (j >= jn0) continue;
+        const int iw1 = w < i1 ? w : i1, ie0 = (npx - w) > i0 ? (npx - w) : i0;
+        const int nw = iw1 - i0 + 1;
+        const int i = l < nw ? i0 + l : ie0 + (l - nw);
+        if (i <= i1 && (l < nw || i > iw1)) f(i, j, k);
+      }
+    }
+  }
+};
+// level list variant of BoxPass (the levels the hybrid path leaves to the full-face passes)
+template <class F>
+struct BoxPassK {
+  int i0, i1, j0, j1;
+  const int *klist;
+  F f;
+  FV3_HD void operator()(int bx, int by, int bz, int tid, double *) const {
+    const int k = klist[bz];
+    for (int t = tid; t < 256; t += kNT) {
+      const int i = i0 + bx * 64 + (t & 63), j = j0 + by * 4 + (t >> 6);
+      if (i <= i1 && j <= j1) f(i, j, k);
+    }
+  }
+};
+
 // Level views of the reference's array kinds (Fortran indices).
 struct VA { double *p; int nid, isd, jsd; size_t n; FV3_HD double &operator()(int i, int j, int k) const { return p[(size_t)k * n + (size_t)(j - jsd) * nid + (i - isd)]; } };
 struct CA { const double *p; int nid, isd, jsd; size_t n; FV3_HD double operator()(int i, int j, int k) const { return p[(size_t)k * n + (size_t)(j - jsd) * nid + (i - isd)]; } };

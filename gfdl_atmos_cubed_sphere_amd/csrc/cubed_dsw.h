@@ -22,6 +22,10 @@ struct DswCubedState {
   double *ke;              // B layout
   double *wk;              // A layout: relative vorticity, then absolute vorticity
   double *dd, *svc, *suc;  // divergence damping work arrays (B, U, V layouts)
+  // hybrid: the passes that write the outputs of d_sw only write the points of the frame of width own_w along the face edges
+  // (0: every point); the marching kernels own the rest (DswArgs::mask_w)
+  int own_w;
+  FV3_HD bool own(int i, int j) const { return own_w == 0 || i <= own_w || i >= g.npx - own_w || j <= own_w || j >= g.npy - own_w; }
 };
 
 // D1a: contravariant winds, first layer: the interior form where it applies and the edge rows / columns that follow from
@@ -183,6 +187,7 @@ struct DswCubedD4 {
   FV3_HD void operator()(int i, int j, int k) const {
     const Grid &g = s.g;
     const CA fx = cview_FX(g, s.fx), fy = cview_FY(g, s.fy);
+    if (!s.own(i, j)) return;
     if (j <= g.je) {
       double &m = view_FX(g, s.a.mfx)(i, j, k);
       m = m + fx(i, j, k);
@@ -563,7 +568,7 @@ struct DswCubedD7 {
       const double damp2 = g.da_min_c * dmax(d2_bg, dmin(0.20, s.a.dddmp * 0.));  // dddmp < 1e-5 here: vort = 0 (:1428-1429)
       vortv = damp2 * delpc + dd8 * cview_B(g, s.dd)(i, j, k);
     }
-    if (s.a.delpc) view_A(g, s.a.delpc)(i, j, k) = delpc;
+    if (s.a.delpc && s.own(i, j)) view_A(g, s.a.delpc)(i, j, k) = delpc;
     double &kev = view_B(g, s.ke)(i, j, k);
     kev = kev + vortv;
   }
@@ -585,6 +590,7 @@ struct DswCubedD9 {
   FV3_HD void operator()(int i, int j, int k) const {
     const Grid &g = s.g;
     const CA ke = cview_B(g, s.ke), u = cview_U(g, s.a.u), v = cview_V(g, s.a.v);
+    if (!s.own(i, j)) return;
     if (i <= g.ie)
       view_U(g, s.a.u_out)(i, j, k) = u(i, j, k) * g.dx[g.iU(i, j)] + ke(i, j, k) - ke(i + 1, j, k) + cview_FY(g, s.gy)(i, j, k);
     if (j <= g.je)

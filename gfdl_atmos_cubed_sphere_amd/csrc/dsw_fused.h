@@ -106,6 +106,12 @@ struct DswTransportFused {
     const int rowA = (seg == 0) ? g.jsd : jA, rowB = seg_last ? g.jed : jB;
     const int lY0 = (strip == 0) ? s.lA0 : s.lC0, lY1 = (ilo + s.lC1 == g.ie) ? s.lA1 : s.lC1;
     const double dt = a.dt;
+    // cubed-sphere hybrid: lanes / rows of the outputs this kernel owns (DswArgs::mask_w)
+    const int mw = a.mask_w;
+    const int oC0 = mw ? (s.lC0 > mw + 1 - ilo ? s.lC0 : mw + 1 - ilo) : s.lC0;
+    const int oC1 = mw ? (s.lC1 < g.npx - mw - 1 - ilo ? s.lC1 : g.npx - mw - 1 - ilo) : s.lC1;
+    const int oF1 = mw ? (lFx1 < g.npx - mw - 1 - ilo ? lFx1 : g.npx - mw - 1 - ilo) : lFx1;
+    const int oJ0 = mw ? mw + 1 : g.jsd, oJ1 = mw ? g.npy - mw - 1 : g.jed + 1;
 
     auto load_in = [&](int r) {
       In in;
@@ -223,27 +229,27 @@ struct DswTransportFused {
       if (have_face) {
         // mass flux through y-face r-2 (tp_core.F90:222-226); carried to the next row as its south face
         const vd fym = fyd1 * sh.yf;
-        if (have_row) {
+        if (have_row && j >= oJ0 && j <= oJ1) {
           const vd fxm = fxd * xfj;  // tp_core.F90:217-221
           const vd fym0 = fym_prev, fym1 = fym;
           const long iFX = (long)g.iFX(ilo, j), iFY0 = (long)g.iFY(ilo, j), iA = (long)g.iA(ilo, j);
-          vaccum(mfx, iFX, fxm, s.lC0, lFx1);            // sw_core.F90:928-940
-          vaccum(mfy, iFY0, fym0, s.lC0, s.lC1);
+          vaccum(mfx, iFX, fxm, oC0, oF1);            // sw_core.F90:928-940
+          vaccum(mfy, iFY0, fym0, oC0, oC1);
           if (j == g.je) {
             const long iFY1 = (long)g.iFY(ilo, j + 1);
-            vstore_nt(mfy, iFY1, vload(mfy, iFY1, s.C) + fym1, s.lC0, s.lC1);
+            vstore_nt(mfy, iFY1, vload(mfy, iFY1, s.C) + fym1, oC0, oC1);
           }
           const vd dp = fd.ya.row_m3();
           const vd dpn = dp + (fxm - shl1(fxm) + fym0 - fym1) * in.ra;
-          vstore_nt(a.delp_out + oA, iA, dpn, s.lC0, s.lC1);
+          vstore_nt(a.delp_out + oA, iA, dpn, oC0, oC1);
           const vd rdpn = vrecip(dpn);
           {  // pt (sw_core.F90:1053-1066)
             const vd gx = fxp * fxm, gy0 = fyp0 * fym0, gy1 = fyp1 * fym1;
-            vstore_nt(a.pt_out + oA, iA, vdiv_r(fp.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra, dpn, rdpn), s.lC0, s.lC1);
+            vstore_nt(a.pt_out + oA, iA, vdiv_r(fp.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra, dpn, rdpn), oC0, oC1);
           }
           if (NH) {  // w (:985-989, :1262-1274)
             const vd gx = fxw * fxm, gy0 = fyw0 * fym0, gy1 = fyw1 * fym1;
-            vstore_nt(a.w_out + oA, iA, vdiv_r(fw.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra, dpn, rdpn), s.lC0, s.lC1);
+            vstore_nt(a.w_out + oA, iA, vdiv_r(fw.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra, dpn, rdpn), oC0, oC1);
           }
           const long iCC = (long)g.iCC(ilo, j);  // :943-948
           vstore_nt(a.heat_s + oCC, iCC, vd(0.), s.lC0, s.lC1);
@@ -299,6 +305,12 @@ struct DswMomentumFused {
     double *uo = a.u_out + (size_t)k * g.nU(), *vo = a.v_out + (size_t)k * g.nV();
     double *dpc = a.delpc ? a.delpc + (size_t)k * g.nA() : nullptr;
     const double dt5 = 0.5 * a.dt;
+    // cubed-sphere hybrid: lanes / rows of the outputs this kernel owns (DswArgs::mask_w)
+    const int mw = a.mask_w;
+    const int oC0 = mw ? (s.lC0 > mw + 1 - ilo ? s.lC0 : mw + 1 - ilo) : s.lC0;
+    const int oC1 = mw ? (s.lC1 < g.npx - mw - 1 - ilo ? s.lC1 : g.npx - mw - 1 - ilo) : s.lC1;
+    const int oF1 = mw ? (lFx1 < g.npx - mw - 1 - ilo ? lFx1 : g.npx - mw - 1 - ilo) : lFx1;
+    const int oJ0 = mw ? mw + 1 : g.jsd, oJ1 = mw ? g.npy - mw - 1 : g.jed + 1;
     const double d2_bg = a.lv.d2_divg[k];
     const double damp2 = g.da_min_c * dmax(d2_bg, dmin(0.20, a.dddmp * 0.));            // :1454 with vort = 0
     const double dd8 = g.stretched_grid ? g.da_min * ipow(a.d4_bg, 2) : ipow(g.da_min_c * a.d4_bg, 2);  // :1446-1450
@@ -382,10 +394,18 @@ struct DswMomentumFused {
       yv.push(in.v0);
       vd ke(0.);
       if (jc >= jA) {
-        const vd vb = dt5 * (shr1(in.vc) + in.vc);                         // :1129
+        vd vb = dt5 * (shr1(in.vc) + in.vc);                               // :1129
+        vd ub2 = dt5 * (uc_p + in.uc);                                     // :1186
+        if (a.rsina) {  // the interior of a cubed-sphere face (grid_type < 3): :1104-1106, :1168-1170
+          const int jr = jc > g.je + 1 ? g.je + 1 : jc;
+          const vd cosa = vload(g.cosa, (long)g.iB(ilo, jr), s.A);
+          const vd rsina = vload(a.rsina, (long)(jr - g.js) * (g.nx + 1) + (ilo - g.is), s.F);
+          const vd vs = shr1(in.vc) + in.vc, us = uc_p + in.uc;
+          vb = dt5 * (vs - us * cosa) * rsina;
+          ub2 = dt5 * (us - vs * cosa) * rsina;
+        }
         const vd ub = yv.face(vb, UNI ? in.rdy : rdy_p, in.rdy);           // ytp_v :1134
         const vd kev = vb * ub;                                            // :1139
-        const vd ub2 = dt5 * (uc_p + in.uc);                               // :1186
         const vd vb2 = ppm_faces_x_sw<SWC>(in.ukc, ub2, in.rdx);           // xtp_u :1191
         ke = 0.5 * (kev + ub2 * vb2);                                      // :1196
         const vd vc2 = (shl1(d_0) - d_0) * in.dgu;                         // :1392-1396
@@ -394,15 +414,15 @@ struct DswMomentumFused {
         vd lap = uc2m - uc2 + shr1(vc2) - vc2;                             // :1406-1424
         if (!g.stretched_grid) lap = lap * in.rac;
         ke = ke + (damp2 * d_0 + dd8 * lap);                               // :1455
-        if (dpc && (jc <= jB || jc == g.je + 1))
-          vstore(dpc, (long)g.iA(ilo, jc), d_0, s.lC0, lFx1);              // delpc = saved divergence (:1376-1381)
+        if (dpc && (jc <= jB || jc == g.je + 1) && jc >= oJ0 && jc <= oJ1)
+          vstore(dpc, (long)g.iA(ilo, jc), d_0, oC0, oF1);                 // delpc = saved divergence (:1376-1381)
       }
       // ---- D-grid wind update of row j (:1500-1509) ------------------------------------------------------------------------------
-      if (j >= jA) {
+      if (j >= jA && j >= oJ0 && j <= oJ1) {
         const vd ke0 = ke_p, ke1 = ke;
         const vd vtdx_j = u_j * dx_j, utdy_j = v_j * dy_j;
-        vstore(uo, oUj, vtdx_j + ke0 - shl1(ke0) + fyv0 * yf_p, s.lC0, s.lC1);
-        vstore(vo, oVj, utdy_j + ke0 - ke1 - fxv * xf_j, s.lC0, lFx1);
+        vstore(uo, oUj, vtdx_j + ke0 - shl1(ke0) + fyv0 * yf_p, oC0, oC1);
+        vstore(vo, oVj, utdy_j + ke0 - ke1 - fxv * xf_j, oC0, oF1);
         if (j == g.je) {  // the north edge row of u
           const long oU1 = (long)g.iU(ilo, j + 1);
           const vd dx_n = UNI ? vd(g.c_dx) : vload(g.dx, oU1, s.A);

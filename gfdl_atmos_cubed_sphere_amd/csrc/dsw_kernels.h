@@ -35,6 +35,11 @@ struct DswArgs {
   const double *delp, *pt, *u, *v, *w, *uc, *vc, *ua, *va, *divg_d, *q_con;
   double *mfx, *mfy, *cx, *cy, *crx, *cry, *xfx, *yfx;
   double *delp_out, *pt_out, *u_out, *v_out, *w_out, *q_con_out, *heat_s, *diss_e, *delpc;
+  // cubed-sphere hybrid (fv3_api.hip, dsw_cubed): the marching kernels run over a whole face with the interior formulas and
+  // keep their hands off the frame of width mask_w along the face edges (i <= mask_w, i >= npx - mask_w, likewise j), which
+  // the pass kernels of cubed_dsw.h own.  rsina: (is:ie+1, js:je+1), for the B-grid winds of the kinetic energy.
+  int mask_w = 0;
+  const double *rsina = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -81,6 +81,8 @@ struct fv3_ctx {
   int n_plain_m, n_rest_m;
   int *klist_z;          // npz+1 interfaces of update_dz_d: [undamped..., damped...]
   int n_plain_z, n_damp_z;
+  int cubed_frame;   // cubed-sphere hybrid: width of the frame the pass kernels own (0: passes on the whole face)
+  int cubed_reach;   // ... and how much wider the frame of the passes' intermediates is
   int lev_max_nord;      // max over the levels of nord_k
   bool lev_has_dcon;     // some level has d_con_k > 1e-5
   bool lev_has_vt_damp, lev_has_w_damp, lev_has_w_damp_hi;  // damp_vt / damp_t; damp_w > 1e-5; the latter with nord_w > 0
@@ -286,6 +288,12 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_MARCH_TJ_KE");
     c->march_tj_ke = e ? std::atoi(e) : 48;
     if (c->march_tj_ke < 1) c->march_tj_ke = 48;
+    e = std::getenv("FV3_MI355X_CUBED_FRAME");
+    c->cubed_frame = e ? std::atoi(e) : 4;
+    if (c->cubed_frame < 0) c->cubed_frame = 0;
+    e = std::getenv("FV3_MI355X_CUBED_REACH");
+    c->cubed_reach = e ? std::atoi(e) : 5;
+    if (c->cubed_reach < 1) c->cubed_reach = 5;
     e = std::getenv("FV3_MI355X_MARCH_TJ_CSW");
     c->march_tj_csw = e ? std::atoi(e) : 0;   // 0 = by geometry mode (fv3_c_sw)
     if (c->march_tj_csw < 0) c->march_tj_csw = 0;
@@ -592,6 +600,34 @@ static int launch_box(fv3_ctx *c, const char *label, int i0, int i1, int j0, int
   grid.z = (unsigned)nk;
   return launch_p(c, label, grid, 0, BoxPass<F>{i0, i1, j0, j1, f});
 }
+// where a pass runs: the whole box (w = 0) or only the frame of width w along the face edges; all levels (klist = null, nk
+// levels) or the nk levels of a device list
+struct PassRegion {
+  int w;
+  const int *klist;
+  int nk;
+};
+template <class F>
+static int launch_pass(fv3_ctx *c, const char *label, int i0, int i1, int j0, int j1, const PassRegion &rg, const F &f) {
+  if (i1 < i0 || j1 < j0 || rg.nk <= 0) return 0;
+  const Grid &g = c->g;
+  if (rg.w <= 0 || g.npy - rg.w <= rg.w + 1 || g.npx - rg.w <= rg.w + 1 || 2 * rg.w + 8 > 64) {
+    if (!rg.klist) return launch_box(c, label, i0, i1, j0, j1, rg.nk, f);
+    Dim3 grid;
+    grid.x = (unsigned)((i1 - i0 + 64) / 64);
+    grid.y = (unsigned)((j1 - j0 + 4) / 4);
+    grid.z = (unsigned)rg.nk;
+    return launch_p(c, label, grid, 0, BoxPassK<F>{i0, i1, j0, j1, rg.klist, f});
+  }
+  const int js1 = rg.w < j1 ? rg.w : j1, jn0 = (g.npy - rg.w) > j0 ? (g.npy - rg.w) : j0;
+  const int nsn = (js1 - j0 + 1) + (j1 - jn0 + 1), nmid = jn0 - js1 - 1;
+  FramePass<F> kf{i0, i1, j0, j1, rg.w, g.npx, g.npy, (nsn + 3) / 4, rg.klist, f};
+  Dim3 grid;
+  grid.x = (unsigned)((i1 - i0 + 64) / 64);
+  grid.y = (unsigned)(kf.nby_sn + (nmid > 0 ? (nmid + 3) / 4 : 0));
+  grid.z = (unsigned)rg.nk;
+  return launch_p(c, label, grid, 0, kf);
+}
 // n-th work array of the cubed-sphere kernels: (nid+1) x (njd+1) x (npz+1) doubles, allocated on first use
 static double *cs_scratch(fv3_ctx *c, int n) {
   if (!c->cs_scr[n]) {
@@ -628,17 +664,18 @@ extern "C" int fv3_grid_upload_cubed(fv3_ctx *c, const fv3_grid_cubed *h) {
 // fv_tp_2d on a cubed-sphere face: fx, fy = the fluxes of tp_core.F90:187-224 (times mfx / mfy or xfx / yfx); scratch 4..7
 static int tp2d_cubed(fv3_ctx *c, int nk, const double *q, const double *crx, const double *cry, int hord, double *fx,
                       double *fy, const double *xfx, const double *yfx, const double *ra_x, const double *ra_y,
-                      const double *mfx, const double *mfy, const char *label = "fv_tp_2d") {
+                      const double *mfx, const double *mfy, const char *label = "fv_tp_2d", const PassRegion *region = nullptr) {
   const Grid &g = c->g;
+  const PassRegion rg = region ? *region : PassRegion{0, nullptr, nk};
   Tp2dCubedState s;
   s.g = g; s.q = q; s.crx = crx; s.cry = cry; s.xfx = xfx; s.yfx = yfx; s.ra_x = ra_x; s.ra_y = ra_y;
   s.mfx = mfx; s.mfy = mfy; s.fx = fx; s.fy = fy; s.hord = hord;
   double **scr[4] = {&s.fx2, &s.fy2, &s.q_i, &s.q_j};
   for (int n = 0; n < 4; n++)
     if (!(*scr[n] = cs_scratch(c, 4 + n))) return fail("fv_tp_2d: out of device memory");
-  RT(launch_box(c, label, g.isd, g.ied, g.jsd, g.jed, nk, Tp2dCubedT1{s}));
-  RT(launch_box(c, label, g.isd, g.ied, g.jsd, g.jed, nk, Tp2dCubedT2{s}));
-  RT(launch_box(c, label, g.is, g.ie + 1, g.js, g.je + 1, nk, Tp2dCubedT3{s}));
+  RT(launch_pass(c, label, g.isd, g.ied, g.jsd, g.jed, rg, Tp2dCubedT1{s}));
+  RT(launch_pass(c, label, g.isd, g.ied, g.jsd, g.jed, rg, Tp2dCubedT2{s}));
+  RT(launch_pass(c, label, g.is, g.ie + 1, g.js, g.je + 1, rg, Tp2dCubedT3{s}));
   return 0;
 }
 
@@ -866,9 +903,12 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
           default: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<8, HORD, 2>{g, a, mf});
         }
       }
-      switch (sw_class(a.hord_mt)) {
+      switch (a.rsina ? sw_class_cubed(a.hord_mt) : sw_class(a.hord_mt)) {
         case 5: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<5, HORD>{g, a, mf});
         case 6: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<6, HORD>{g, a, mf});
+        case 108: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<108, HORD>{g, a, mf});
+        case 110: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<110, HORD>{g, a, mf});
+        case 111: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<111, HORD>{g, a, mf});
         default: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<8, HORD>{g, a, mf});
       }
     });
@@ -906,39 +946,84 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     return fail("fv3_d_sw: del-2n damping of delp / pt / vorticity (and of w with nord_w > 0) is not built for the cubed sphere yet");
   if (c->lev_has_dcon) return fail("fv3_d_sw: dissipative heating (d_con > 0) is not built for the cubed sphere yet");
   DswCubedState s;
-  s.g = g; s.cg = c->cg; s.a = a;
+  s.g = g; s.cg = c->cg; s.a = a; s.own_w = 0;
   double **scr[13] = {&s.ut, &s.vt, &s.fx, &s.fy, &s.gxw, &s.gyw, &s.gx, &s.gy, &s.ke, &s.wk, &s.dd, &s.svc, &s.suc};
   for (int n = 0; n < 13; n++)
     if (!(*scr[n] = cs_scratch(c, 8 + n))) return fail("d_sw: out of device memory");
   const int npz = g.npz, npx = g.npx, npy = g.npy;
   const char *L = "d_sw_cubed";
+  // contravariant winds of the whole face, all levels
   RT(launch_box(c, L, g.isd, g.ied + 1, g.jsd, g.jed + 1, npz, DswCubedD1a{s}));
   RT(launch_box(c, L, 0, npx, 0, npy, npz, DswCubedD1b{s}));
   RT(launch_box(c, L, 0, 3, 0, 0, npz, DswCubedD1c{s}));
-  RT(launch_box(c, L, g.isd, g.ied, g.jsd, g.jed, npz, DswCubedD2{s}));
-  RT(tp2d_cubed(c, npz, a.delp, a.crx, a.cry, a.hord_dp, s.fx, s.fy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, L));
-  if (!a.hydrostatic)
-    RT(tp2d_cubed(c, npz, a.w, a.crx, a.cry, a.hord_vt, s.gxw, s.gyw, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, L));
-  RT(tp2d_cubed(c, npz, a.pt, a.crx, a.cry, a.hord_tm, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, L));
-  RT(launch_box(c, L, g.is, g.ie + 1, g.js, g.je + 1, npz, DswCubedD4{s}));
-  RT(launch_box(c, L, g.is, g.ie + 1, g.js, g.je + 1, npz, DswCubedD5{s}));
-  RT(launch_box(c, L, g.isd, g.ied + 1, g.jsd, g.jed + 1, npz, DswCubedD6{s}));
-  for (int n = 1; n <= c->lev_max_nord; n++) {
-    const bool may_fill = c->lev_max_nord - n != 0;   // some level may have nt /= 0 in this iteration
-    if (may_fill) RT(launch_box(c, L, 1, 3, 1, 3, npz, DswCubedFillB{s, 1, n}));
-    RT(launch_box(c, L, g.is - 3, g.ie + 3, g.js - 3, g.je + 4, npz, DswCubedDampVC{s, n, 0}));
-    if (may_fill) RT(launch_box(c, L, 1, 3, 1, 3, npz, DswCubedFillB{s, 2, n}));
-    RT(launch_box(c, L, g.is - 3, g.ie + 4, g.js - 3, g.je + 3, npz, DswCubedDampVC{s, n, 1}));
-    if (may_fill) {
-      RT(launch_box(c, L, 1, 3, 1, 3, npz, DswCubedFillD{s, 0, n}));
-      RT(launch_box(c, L, 1, 3, 1, 3, npz, DswCubedFillD{s, 1, n}));
+
+  // Hybrid: away from the face edges the cubed-sphere d_sw is the general-metric stencil the marching kernels compute (with
+  // the contravariant winds above in the place of uc, vc and the non-orthogonal B-grid winds of the kinetic energy), so those
+  // kernels take the whole face and leave a frame of wo points along the edges to the passes; the passes' intermediates are
+  // formed on a frame wider by the reach of the pass chain.  Levels the marching kernels do not take (sponge-level damping,
+  // nord_k /= 1) go through the passes on the whole face.
+  const int wo = c->cubed_frame, wm = wo + c->cubed_reach;
+  const bool fits = wo > 0 && npx - 1 >= 2 * wm + 8 && npx == npy && 2 * wm + 8 <= 64;
+  const bool fused_ok = c->use_march && c->use_fused && !a.use_cond && a.hord_dp == a.hord_tm && (a.hydrostatic || a.hord_dp == a.hord_vt);
+  const bool hyb_t = fits && fused_ok && c->n_plain > 0;
+  const bool hyb_m = fits && c->use_march && c->use_fused && c->n_plain_m > 0;
+
+  auto transport = [&](const PassRegion &rg, const PassRegion &rg_out, bool courant) -> int {
+    if (rg.nk <= 0) return 0;
+    if (courant) RT(launch_pass(c, L, g.isd, g.ied, g.jsd, g.jed, PassRegion{0, rg.klist, rg.nk}, DswCubedD2{s}));
+    RT(tp2d_cubed(c, npz, a.delp, a.crx, a.cry, a.hord_dp, s.fx, s.fy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, L, &rg));
+    if (!a.hydrostatic)
+      RT(tp2d_cubed(c, npz, a.w, a.crx, a.cry, a.hord_vt, s.gxw, s.gyw, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, L, &rg));
+    RT(tp2d_cubed(c, npz, a.pt, a.crx, a.cry, a.hord_tm, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, L, &rg));
+    DswCubedState so = s;
+    so.own_w = rg_out.w;
+    RT(launch_pass(c, L, g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD4{so}));
+    return 0;
+  };
+  auto momentum = [&](const PassRegion &rg, const PassRegion &rg_out) -> int {
+    if (rg.nk <= 0) return 0;
+    DswCubedState so = s;
+    so.own_w = rg_out.w;
+    RT(launch_pass(c, L, g.is, g.ie + 1, g.js, g.je + 1, rg, DswCubedD5{s}));
+    RT(launch_pass(c, L, g.isd, g.ied + 1, g.jsd, g.jed + 1, rg, DswCubedD6{s}));
+    for (int n = 1; n <= c->lev_max_nord; n++) {
+      const bool may_fill = c->lev_max_nord - n != 0;   // some level may have nt /= 0 in this iteration
+      const PassRegion rc{0, rg.klist, rg.nk};          // the corner fills: tiny boxes
+      if (may_fill) RT(launch_pass(c, L, 1, 3, 1, 3, rc, DswCubedFillB{s, 1, n}));
+      RT(launch_pass(c, L, g.is - 3, g.ie + 3, g.js - 3, g.je + 4, rg, DswCubedDampVC{s, n, 0}));
+      if (may_fill) RT(launch_pass(c, L, 1, 3, 1, 3, rc, DswCubedFillB{s, 2, n}));
+      RT(launch_pass(c, L, g.is - 3, g.ie + 4, g.js - 3, g.je + 3, rg, DswCubedDampVC{s, n, 1}));
+      if (may_fill) {
+        RT(launch_pass(c, L, 1, 3, 1, 3, rc, DswCubedFillD{s, 0, n}));
+        RT(launch_pass(c, L, 1, 3, 1, 3, rc, DswCubedFillD{s, 1, n}));
+      }
+      RT(launch_pass(c, L, g.is - 2, g.ie + 3, g.js - 2, g.je + 3, rg, DswCubedDampDiv{s, n}));
     }
-    RT(launch_box(c, L, g.is - 2, g.ie + 3, g.js - 2, g.je + 3, npz, DswCubedDampDiv{s, n}));
+    RT(launch_pass(c, L, g.is, g.ie + 1, g.js, g.je + 1, rg, DswCubedD7{so}));
+    RT(launch_pass(c, L, g.isd, g.ied, g.jsd, g.jed, rg, DswCubedD8{s}));
+    RT(tp2d_cubed(c, npz, s.wk, a.crx, a.cry, a.hord_vt, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, L, &rg));
+    RT(launch_pass(c, L, g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD9{so}));
+    return 0;
+  };
+
+  if (hyb_t) {
+    DswArgs am = a;
+    am.uc = s.ut; am.vc = s.vt; am.mask_w = wo;
+    RT(dsw_transport_march(c, am));                       // levels klist[0 : n_plain): Courant numbers too, whole face
+    RT(transport(PassRegion{wm, c->klist, c->n_plain}, PassRegion{wo, c->klist, c->n_plain}, false));
+    RT(transport(PassRegion{0, c->klist + c->n_plain, c->n_damp}, PassRegion{0, c->klist + c->n_plain, c->n_damp}, true));
+  } else {
+    RT(transport(PassRegion{0, nullptr, npz}, PassRegion{0, nullptr, npz}, true));
   }
-  RT(launch_box(c, L, g.is, g.ie + 1, g.js, g.je + 1, npz, DswCubedD7{s}));
-  RT(launch_box(c, L, g.isd, g.ied, g.jsd, g.jed, npz, DswCubedD8{s}));
-  RT(tp2d_cubed(c, npz, s.wk, a.crx, a.cry, a.hord_vt, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, L));
-  RT(launch_box(c, L, g.is, g.ie + 1, g.js, g.je + 1, npz, DswCubedD9{s}));
+  if (hyb_m) {
+    DswArgs am = a;
+    am.mask_w = wo; am.rsina = c->cg.rsina;
+    RT(dsw_momentum_march(c, am));                        // levels klist_m[0 : n_plain_m)
+    RT(momentum(PassRegion{wm, c->klist_m, c->n_plain_m}, PassRegion{wo, c->klist_m, c->n_plain_m}));
+    RT(momentum(PassRegion{0, c->klist_m + c->n_plain_m, c->n_rest_m}, PassRegion{0, c->klist_m + c->n_plain_m, c->n_rest_m}));
+  } else {
+    RT(momentum(PassRegion{0, nullptr, npz}, PassRegion{0, nullptr, npz}));
+  }
   return 0;
 }
 

@@ -145,6 +145,34 @@ FV3_D PCell ppm_cell_sw_mono(const vd &qm2, const vd &qm1, const vd &q0, const v
   c.br = vmin(vmax3(vd(0.), pmp, lac), vmax(al1 - q0, vmin3(vd(0.), pmp, lac)));
   return c;
 }
+// the cubed-sphere branch (grid_type < 3) away from the face edges, iord = 8, 10, 11 (sw_core.F90:2381-2436; iord = 9 is the
+// form above): classes 108, 110, 111 of the marching kernels (DswMomentumFused on a cubed-sphere face)
+template <int SWC>
+FV3_D PCell ppm_cell_sw_cs(const vd &qm2, const vd &qm1, const vd &q0, const vd &qp1, const vd &qp2, const vd &dmm, const vd &dm0,
+                           const vd &dmp, const vd &al0, const vd &al1) {
+  PCell c;
+  c.q = q0;
+  if (SWC == 108) {
+    const vd xt = 2. * dm0;
+    c.bl = -vsign(vmin(vabs(xt), vabs(al0 - q0)), xt);
+    c.br = vsign(vmin(vabs(xt), vabs(al1 - q0)), xt);
+  } else if (SWC == 110) {
+    const vd bl = al0 - q0, br = al1 - q0;
+    const vb flat = vabs(dm0) < 1.E-9;
+    const vb two_dx = vabs(dmm) + vabs(dmp) < 1.E-9;
+    const vb limit = vabs(3. * (bl + br)) > vabs(bl - br);
+    const vd pmp_1 = -2. * (qp1 - q0), lac_1 = pmp_1 + 1.5 * (qp2 - qp1);
+    const vd pmp_2 = 2. * (q0 - qm1), lac_2 = pmp_2 - 1.5 * (qm1 - qm2);
+    const vd bl_l = vmin(vmax3(vd(0.), pmp_1, lac_1), vmax(bl, vmin3(vd(0.), pmp_1, lac_1)));
+    const vd br_l = vmin(vmax3(vd(0.), pmp_2, lac_2), vmax(br, vmin3(vd(0.), pmp_2, lac_2)));
+    c.bl = vsel(flat, vsel(two_dx, vd(0.), bl), vsel(limit, bl_l, bl));
+    c.br = vsel(flat, vsel(two_dx, vd(0.), br), vsel(limit, br_l, br));
+  } else {
+    c.bl = al0 - q0;
+    c.br = al1 - q0;
+  }
+  return c;
+}
 // unlimited ORD in {5, 6, 7}: sw_core.F90:2190-2243, 2337-2374
 template <int ORD>
 FV3_D PCell ppm_cell_sw_unlim(const vd &q0, const vd &al0, const vd &al1) {
@@ -253,6 +281,8 @@ struct PpmY {
 // =====================================================================================================
 // sw_core flavour (xtp_u / ytp_v).  SWC = scheme class: 5 (iord 5), 6 (iord 6, 7), 8 (iord >= 8).
 constexpr int sw_class(int iord) { return iord >= 8 ? 8 : (iord == 5 ? 5 : 6); }
+// the classes of the cubed-sphere branch away from the face edges (iord = 9 is the "other grids" form)
+constexpr int sw_class_cubed(int iord) { return iord == 8 ? 108 : (iord == 10 ? 110 : (iord == 11 ? 111 : sw_class(iord))); }
 
 template <int SWC>
 FV3_D PCell ppm_cells_x_sw(const vd &q) {
@@ -261,6 +291,7 @@ FV3_D PCell ppm_cells_x_sw(const vd &q) {
   if (SWC >= 8) {
     const vd dm0 = ppm_dm_v(qm1, q, qp1);
     const vd al0 = ppm_al_mono(qm1, q, shr1(dm0), dm0);
+    if (SWC > 100) return ppm_cell_sw_cs<SWC>(qm2, qm1, q, qp1, qp2, shr1(dm0), dm0, shl1(dm0), al0, shl1(al0));
     return ppm_cell_sw_mono(qm2, qm1, q, qp1, qp2, al0, shl1(al0));
   } else {
     const vd al0 = ppm_al_unlim<5>(qm2, qm1, q, qp1);
@@ -278,12 +309,12 @@ FV3_D vd ppm_faces_x_sw(const vd &q, const vd &c, const vd &rd) {
 template <int SWC>
 struct PpmYsw {
   vd q0, q1, q2, q3, q4;
-  vd dm2, dm3;
+  vd dm1, dm2, dm3;
   vd al2, al3;
   PCell prev, cur;
   FV3_D void init() {
     q0 = q1 = q2 = q3 = q4 = vd(0.);
-    dm2 = dm3 = vd(0.);
+    dm1 = dm2 = dm3 = vd(0.);
     al2 = al3 = vd(0.);
     prev.q = prev.bl = prev.br = vd(0.);
     cur = prev;
@@ -298,10 +329,14 @@ struct PpmYsw {
     prev = cur;
     al2 = al3;
     if (SWC >= 8) {
+      if (SWC > 100) dm1 = dm2;
       dm2 = dm3;
       dm3 = ppm_dm_v(q2, q3, q4);
       al3 = ppm_al_mono(q2, q3, dm2, dm3);
-      cur = ppm_cell_sw_mono(q0, q1, q2, q3, q4, al2, al3);
+      if (SWC > 100)
+        cur = ppm_cell_sw_cs<SWC>(q0, q1, q2, q3, q4, dm1, dm2, dm3, al2, al3);
+      else
+        cur = ppm_cell_sw_mono(q0, q1, q2, q3, q4, al2, al3);
     } else {
       al3 = ppm_al_unlim<5>(q1, q2, q3, q4);
       cur = ppm_cell_sw_unlim<SWC>(q2, al2, al3);

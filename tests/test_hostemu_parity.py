@@ -533,3 +533,30 @@ def test_cubed_sphere_jw_step_with_tracers(emu):
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
     r = PC.check_jw_step(emu, npx=13, npz=20, k_split=1, n_split=2, bdt=900.0, hydrostatic=False, nq=2)
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
+# ---- cubed-sphere hybrid: faces wide enough that the marching kernels take the interior and the passes the frame ----------------
+@pytest.mark.parametrize("kw", [dict(hydrostatic=True, npz=6), dict(hydrostatic=False, npz=12, faces=(1, 4)),
+                                dict(hydrostatic=True, npz=12, faces=(2, 5), flags=dict(nord=2)),
+                                dict(hydrostatic=True, npz=12, faces=(0,), par_over=dict(hord_mt=5, hord_vt=5, hord_tm=5, hord_dp=5)),
+                                dict(hydrostatic=True, npz=12, faces=(3,), par_over=dict(hord_mt=6, hord_vt=6, hord_tm=6, hord_dp=-5)),
+                                dict(hydrostatic=True, npz=12, faces=(4,), par_over=dict(hord_mt=8, hord_vt=8, hord_tm=8, hord_dp=8)),
+                                dict(hydrostatic=True, npz=12, faces=(5,), par_over=dict(hord_mt=9)),
+                                dict(hydrostatic=True, npz=12, faces=(1,), par_over=dict(hord_mt=11))])
+def test_cubed_hybrid_d_sw(emu, kw):
+    """C40 faces: the fused marching kernels over the whole face (interior formulas, frame masked) + the pass kernels on the
+    frame; levels 1, 2 (sponge) stay with the full-face passes.  Bit for bit the oracle's d_sw."""
+    assert max(PC.check_d_sw(emu, npx=41, **kw).values()) <= P.TOL
+
+
+def test_cubed_hybrid_substeps(emu):
+    assert max(PC.check_substeps_hydrostatic(emu, npx=33, npz=12, n_split=2).values()) <= 1e-13
+    assert max(PC.check_substeps_nh(emu, npx=33, npz=12, n_split=2).values()) <= 1e-13
+
+
+def test_cubed_hybrid_frame_width_is_not_marginal(emu, monkeypatch):
+    """the frame the passes own is 4 wide with intermediates 5 wider; 3 + 3 already reproduces the oracle (the edge rules of the
+    PPM operators touch three cells), so the defaults carry a margin"""
+    monkeypatch.setenv("FV3_MI355X_CUBED_FRAME", "3")
+    monkeypatch.setenv("FV3_MI355X_CUBED_REACH", "3")
+    assert max(PC.check_d_sw(emu, npx=41, npz=12, hydrostatic=False, faces=(0, 3)).values()) <= P.TOL
