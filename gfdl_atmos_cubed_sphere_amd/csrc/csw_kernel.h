@@ -22,6 +22,10 @@ struct CswArgs {
   const double *delp, *pt, *u, *v, *w;
   int nord, hydrostatic;
   double dt2;
+  // cubed-sphere hybrid (fv3_api.hip, csw_cubed): the marching kernel runs over a whole face with the interior formulas,
+  // leaves the frame of width mask_w along the face edges to the passes of cubed_csw.h, and does not form divg_d (the
+  // divergence of the cubed sphere is the non-orthogonal form, computed by a pass of its own)
+  int mask_w = 0;
 };
 
 template <int TI, int TJ>

@@ -90,8 +90,16 @@ struct CswMarch {
     auto cl = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
     const vl cA = make_lanes(cl(g.isd - ilo, 0, kW - 1), cl(g.ied - ilo, 0, kW - 1));      // nid-wide rows
     const vl cV = make_lanes(cl(g.isd - ilo, 0, kW - 1), cl(g.ied + 1 - ilo, 0, kW - 1));  // (nid+1)-wide rows
-    const int l0 = 3;
-    const int l2 = cl(ie + 2 - ilo, 0, kCswLast), l1 = cl(ie + 1 - ilo, 0, kCswLast);  // last owned lane: i <= ie+2 / ie+1
+    int l2 = cl(ie + 2 - ilo, 0, kCswLast), l1 = cl(ie + 1 - ilo, 0, kCswLast);  // last owned lane: i <= ie+2 / ie+1
+    // cubed-sphere hybrid: the lanes / rows of the outputs this kernel owns (CswArgs::mask_w)
+    const int mw = a.mask_w;
+    const int l0 = mw ? (3 > mw + 1 - ilo ? 3 : mw + 1 - ilo) : 3;
+    if (mw) {
+      const int lm = g.npx - mw - 1 - ilo;
+      l2 = l2 < lm ? l2 : lm;
+      l1 = l1 < lm ? l1 : lm;
+    }
+    const int oJ0 = mw ? mw + 1 : g.jsd - 1, oJ1 = mw ? g.npy - mw - 1 : g.jed + 2;
     const int jA = js - 1 + seg * md.tj;
     const int jB = (jA + md.tj - 1 < je + 2) ? jA + md.tj - 1 : je + 2;
     const bool nh = !a.hydrostatic;
@@ -161,6 +169,9 @@ struct CswMarch {
       const int tn = t < jB + 3 ? t + 1 : t;
       const CswMetrics in = mnxt;
       mnxt = load_metrics(tn);
+      vd cosav_r(0.), rsinv_r(1.);  // cubed-sphere face: vt = (vc - u*cosa_v)*rsin_v (:3340), not vt = vc (:3350)
+      if constexpr (GM == 0)
+        if (mw) { cosav_r = LU(g.cosa_v, R); rsinv_r = LU(g.rsin_v, R); }
       for (int m = 0; m < KPW; m++) {
         CswLevel &S = st[m];
         const int k = kl[m];
@@ -188,7 +199,8 @@ struct CswMarch {
         if constexpr (GM == 0) {
           ut = (uc - S.v2 * in.cosau) * in.rsinu;                                   // :3200
           ut = vsel(ut > 0., dt2 * ut * in.dy * in.sg3, dt2 * ut * in.dy * in.sg1);  // :159-167
-          vt = vsel(vc > 0., dt2 * vc * in.dx * in.sg4, dt2 * vc * in.dx * in.sg2);  // :168-176 (vt = vc, :3340)
+          if (mw) vt = (vc - S.u1 * cosav_r) * rsinv_r;
+          vt = vsel(vt > 0., dt2 * vt * in.dx * in.sg4, dt2 * vt * in.dx * in.sg2);  // :168-176 (vt = vc, :3350)
         } else {
           ut = dt2 * ut * in.dy;
           vt = dt2 * vc * in.dx;
@@ -196,7 +208,7 @@ struct CswMarch {
         const vd ucdx = uc * in.dxc;
         const vd vcdy = vc * in.dyc;
         const vd vort = in.fc + in.rac * (S.ucdx_p - ucdx - shr1(vcdy) + vcdy);  // :372-403
-        if (live[m] && R >= jA && R <= jB) {
+        if (live[m] && R >= jA && R <= jB && R >= oJ0 && R <= oJ1) {
           const long iAr = (long)g.iA(ilo, R);
           if (R <= je + 1) {
             vstore(a.ua + oA, iAr, ua, l0, l1);
@@ -212,7 +224,7 @@ struct CswMarch {
         const vd fy1_n = vt * vsel(vpos, S.dp0, S.dpp);
         const vd fyp_n = fy1_n * vsel(vpos, S.pt0, S.ptp);
         const vd fyw_n = nh ? fy1_n * vsel(vpos, S.w0, S.wp) : vd(0.);
-        if (live[m] && Q >= jA && Q <= jB) {
+        if (live[m] && Q >= jA && Q <= jB && Q >= oJ0 && Q <= oJ1) {
           const long iAq = (long)g.iA(ilo, Q);
           if (Q <= je + 1) {
             const vb upos = S.ut_p > 0.;
@@ -250,7 +262,7 @@ struct CswMarch {
         const vd dxc_q = GM == 2 ? vd(g.c_dxc) : dxc_p, dyc_q = GM == 2 ? vd(g.c_dyc) : dyc_p;
         const vd rac_q = GM == 2 ? vd(g.c_rarea_c) : rac_p;
         const vd vdxc = S.v1 * dxc_q;
-        if (live[m] && a.nord > 0 && Q >= jA && Q <= jB) {
+        if (live[m] && a.nord > 0 && !mw && Q >= jA && Q <= jB) {
           const vd uf = S.u0 * dyc_q;
           vstore(a.divg_d + oB, (long)g.iB(ilo, Q), rac_q * (S.vdxc_p - vdxc + shr1(uf) - uf), l0, l2);
         }

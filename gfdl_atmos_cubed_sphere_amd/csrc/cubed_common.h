@@ -40,28 +40,32 @@ struct BoxPass {
 template <class F>
 struct FramePass {
   int i0, i1, j0, j1, w, npx, npy;
-  int nby_sn;        // workgroup rows of the south + north bands
+  int nbx, nby_sn;   // workgroup columns / rows of the south + north bands; the west + east workgroups follow in blockIdx.x
   const int *klist;
   F f;
-  FV3_HD void operator()(int bx, int by, int bz, int tid, double *) const {
+  FV3_HD void operator()(int bflat, int, int bz, int tid, double *) const {
     const int k = klist ? klist[bz] : bz;
     const int js1 = w < j1 ? w : j1, jn0 = (npy - w) > j0 ? (npy - w) : j0;   // south band j0..js1, north band jn0..j1
     const int ns = js1 - j0 + 1;
-    for (int t = tid; t < 256; t += kNT) {
-      const int l = t & 63, r = t >> 6;
-      if (by < nby_sn) {
-        const int v = by * 4 + r;
+    const int nsn = nbx * nby_sn;
+    if (bflat < nsn) {
+      const int bx = bflat % nbx, by = bflat / nbx;
+      for (int t = tid; t < 256; t += kNT) {
+        const int v = by * 4 + (t >> 6);
         const int j = v < ns ? j0 + v : jn0 + (v - ns);
-        const int i = i0 + bx * 64 + l;
-        if (i <= i1 && j <= j1 && (v < ns || j > js1)) f(i, j, k);
-      } else {
-        if (bx > 0) continue;
-        const int j = js1 + 1 + (by - nby_sn) * 4 + r;
+        const int i = i0 + bx * 64 + (t & 63);
+        if (i <= i1 && j <= j1) f(i, j, k);
+      }
+    } else {
+      // 16 rows x 16 columns per workgroup: the west columns (i0 : w) of 16 rows, then the east columns (npx - w : i1)
+      const int iw1 = w < i1 ? w : i1, ie0 = (npx - w) > i0 ? (npx - w) : i0;
+      const int nw = iw1 - i0 + 1, ne = i1 - ie0 + 1;
+      const int bw = bflat - nsn;
+      const int side = bw & 1, jb = js1 + 1 + (bw >> 1) * 16;
+      for (int t = tid; t < 256; t += kNT) {
+        const int c = t & 15, j = jb + (t >> 4);
         if (j >= jn0) continue;
-        const int iw1 = w < i1 ? w : i1, ie0 = (npx - w) > i0 ? (npx - w) : i0;
-        const int nw = iw1 - i0 + 1;
-        const int i = l < nw ? i0 + l : ie0 + (l - nw);
-        if (i <= i1 && (l < nw || i > iw1)) f(i, j, k);
+        for (int cc = c; cc < (side ? ne : nw); cc += 16) f(side ? ie0 + cc : i0 + cc, j, k);
       }
     }
   }

@@ -16,6 +16,10 @@ struct CswCubedState {
   Grid g;
   CswArgs a;
   double *utmp, *vtmp, *ke, *vort;  // A x npz scratch
+  // hybrid: P5 writes only the points of the frame of width own_w along the face edges (0: every point), the marching kernel
+  // owns the rest (CswArgs::mask_w); P3 forms the winds (divg 0), the divergence (divg 2) or both (divg 1)
+  int own_w = 0, divg = 1;
+  FV3_HD bool own(int i, int j) const { return own_w == 0 || i <= own_w || i >= g.npx - own_w || j <= own_w || j >= g.npy - own_w; }
   // metric views
   CA cosa_s, rsin2, dxa, dya, rarea, cosa_u, rsin_u, sina_u, dy, dxc, rdxc, cosa_v, rsin_v, sina_v, dx, dyc, rdyc, rarea_c, fC;
 };
@@ -120,7 +124,7 @@ struct CswCubedP3 {
     const CA utmp = cview_A(g, s.utmp), vtmp = cview_A(g, s.vtmp), ua = cview_A(g, s.a.ua), va = cview_A(g, s.a.va);
     const CA u = cview_U(g, s.a.u), v = cview_V(g, s.a.v);
     const double dt2 = s.a.dt2;
-    if (j <= je + 1) {  // uc, ut (:3187-3255)
+    if (s.divg != 2 && j <= je + 1) {  // uc, ut (:3187-3255)
       double ucv, utv;
       if (i == 1 || i == npx) {
         utv = edge_interpolate4(ua(i - 2, j, k), ua(i - 1, j, k), ua(i, j, k), ua(i + 1, j, k), FV3_M(s.dxa, i - 2, j),
@@ -145,7 +149,7 @@ struct CswCubedP3 {
         utv = dt2 * utv * FV3_M(s.dy, i, j) * g.sinsg(i, j, 1);
       view_A(g, s.a.ut)(i, j, k) = utv;
     }
-    if (i <= ie + 1) {  // vc, vt (:3298-3334)
+    if (s.divg != 2 && i <= ie + 1) {  // vc, vt (:3298-3334)
       double vcv, vtv;
       if (j == 1 || j == npy) {
         vtv = edge_interpolate4(va(i, j - 2, k), va(i, j - 1, k), va(i, j, k), va(i, j + 1, k), FV3_M(s.dya, i, j - 2),
@@ -168,7 +172,7 @@ struct CswCubedP3 {
         vtv = dt2 * vtv * FV3_M(s.dx, i, j) * g.sinsg(i, j, 2);
       view_A(g, s.a.vt)(i, j, k) = vtv;
     }
-    if (s.a.nord > 0 && i >= is && i <= ie + 1 && j >= js && j <= je + 1) {  // divergence_corner, :1798-1843
+    if (s.divg != 0 && s.a.nord > 0 && i >= is && i <= ie + 1 && j >= js && j <= je + 1) {  // divergence_corner, :1798-1843
       auto uf = [&](int ii, int jj) {
         if (jj == 1 || jj == npy)
           return u(ii, jj, k) * FV3_M(s.dyc, ii, jj) * 0.5 * (g.sinsg(ii, jj - 1, 4) + g.sinsg(ii, jj, 2));
@@ -261,6 +265,7 @@ struct CswCubedP5 {
       fill4_src(dir, npx, npy, ii, jj);
       return q(ii, jj, k);
     };
+    if (!s.own(i, j)) return;
     {
       // x faces i, i+1 and y faces j, j+1 of the cell
       double fx1[2], fxp[2], fxw[2], fy1[2], fyp[2], fyw[2];

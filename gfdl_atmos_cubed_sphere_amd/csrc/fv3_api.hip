@@ -83,6 +83,7 @@ struct fv3_ctx {
   int n_plain_z, n_damp_z;
   int cubed_frame;   // cubed-sphere hybrid: width of the frame the pass kernels own (0: passes on the whole face)
   int cubed_reach;   // ... and how much wider the frame of the passes' intermediates is
+  int cubed_frame_c; // the frame of c_sw (d2a2c_vect has its edge forms within 4 points of an edge)
   int lev_max_nord;      // max over the levels of nord_k
   bool lev_has_dcon;     // some level has d_con_k > 1e-5
   bool lev_has_vt_damp, lev_has_w_damp, lev_has_w_damp_hi;  // damp_vt / damp_t; damp_w > 1e-5; the latter with nord_w > 0
@@ -291,6 +292,9 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_CUBED_FRAME");
     c->cubed_frame = e ? std::atoi(e) : 4;
     if (c->cubed_frame < 0) c->cubed_frame = 0;
+    e = std::getenv("FV3_MI355X_CUBED_FRAME_C");
+    c->cubed_frame_c = e ? std::atoi(e) : (c->cubed_frame ? 7 : 0);
+    if (c->cubed_frame_c < 0) c->cubed_frame_c = 0;
     e = std::getenv("FV3_MI355X_CUBED_REACH");
     c->cubed_reach = e ? std::atoi(e) : 5;
     if (c->cubed_reach < 1) c->cubed_reach = 5;
@@ -611,7 +615,7 @@ template <class F>
 static int launch_pass(fv3_ctx *c, const char *label, int i0, int i1, int j0, int j1, const PassRegion &rg, const F &f) {
   if (i1 < i0 || j1 < j0 || rg.nk <= 0) return 0;
   const Grid &g = c->g;
-  if (rg.w <= 0 || g.npy - rg.w <= rg.w + 1 || g.npx - rg.w <= rg.w + 1 || 2 * rg.w + 8 > 64) {
+  if (rg.w <= 0 || g.npy - rg.w <= rg.w + 1 || g.npx - rg.w <= rg.w + 1) {
     if (!rg.klist) return launch_box(c, label, i0, i1, j0, j1, rg.nk, f);
     Dim3 grid;
     grid.x = (unsigned)((i1 - i0 + 64) / 64);
@@ -621,10 +625,10 @@ static int launch_pass(fv3_ctx *c, const char *label, int i0, int i1, int j0, in
   }
   const int js1 = rg.w < j1 ? rg.w : j1, jn0 = (g.npy - rg.w) > j0 ? (g.npy - rg.w) : j0;
   const int nsn = (js1 - j0 + 1) + (j1 - jn0 + 1), nmid = jn0 - js1 - 1;
-  FramePass<F> kf{i0, i1, j0, j1, rg.w, g.npx, g.npy, (nsn + 3) / 4, rg.klist, f};
+  FramePass<F> kf{i0, i1, j0, j1, rg.w, g.npx, g.npy, (i1 - i0 + 64) / 64, (nsn + 3) / 4, rg.klist, f};
   Dim3 grid;
-  grid.x = (unsigned)((i1 - i0 + 64) / 64);
-  grid.y = (unsigned)(kf.nby_sn + (nmid > 0 ? (nmid + 3) / 4 : 0));
+  grid.x = (unsigned)(kf.nbx * kf.nby_sn + (nmid > 0 ? 2 * ((nmid + 15) / 16) : 0));
+  grid.y = 1;
   grid.z = (unsigned)rg.nk;
   return launch_p(c, label, grid, 0, kf);
 }
@@ -679,19 +683,38 @@ static int tp2d_cubed(fv3_ctx *c, int nk, const double *q, const double *crx, co
   return 0;
 }
 
+static int csw_march(fv3_ctx *c, const CswArgs &ca);
 static int csw_cubed(fv3_ctx *c, const CswArgs &ca) {
   const Grid &g = c->g;
   double *scr[4];
   for (int n = 0; n < 4; n++)
     if (!(scr[n] = cs_scratch(c, n))) return fail("c_sw: out of device memory");
-  const CswCubedState s = make_csw_cubed(g, ca, scr);
+  CswCubedState s = make_csw_cubed(g, ca, scr);
   const int npz = g.npz;
-  RT(launch_box(c, "c_sw", g.isd, g.ied, g.jsd, g.jed, npz, CswCubedP1{s}));
-  RT(launch_box(c, "c_sw", g.is - 2, g.ie + 2, g.js - 2, g.je + 2, npz, CswCubedP2{s}));
-  RT(launch_box(c, "c_sw", 0, 2, 0, 0, npz, CswCubedP2c{s}));
-  RT(launch_box(c, "c_sw", g.is - 1, g.ie + 2, g.js - 1, g.je + 2, npz, CswCubedP3{s}));
-  RT(launch_box(c, "c_sw", g.is - 1, g.ie + 1, g.js - 1, g.je + 1, npz, CswCubedP4{s}));
-  RT(launch_box(c, "c_sw", g.is - 1, g.ie + 1, g.js - 1, g.je + 1, npz, CswCubedP5{s}));
+  // Hybrid (see dsw_cubed): d2a2c_vect switches to its edge forms within npt = 4 points of a face edge, so the frame the
+  // passes own is wider than in d_sw.  The passes run FIRST (P3 leaves the interpolated uc, vc on the wider frame of the
+  // intermediates, which P4 / P5 read), then the marching kernel writes the points it owns, then the divergence -- the
+  // non-orthogonal form of the cubed sphere, which reads the final ua, va -- as a pass over the whole face.
+  const int wo = c->cubed_frame_c, wm = wo + c->cubed_reach;
+  const bool hyb = c->use_march && wo > 0 && g.npx == g.npy && g.npx - 1 >= 2 * wm + 8;
+  const PassRegion rm{hyb ? wm : 0, nullptr, npz}, ro{hyb ? wo : 0, nullptr, npz};
+  s.divg = hyb ? 0 : 1;
+  RT(launch_pass(c, "cswc_p1", g.isd, g.ied, g.jsd, g.jed, rm, CswCubedP1{s}));
+  RT(launch_pass(c, "cswc_p2", g.is - 2, g.ie + 2, g.js - 2, g.je + 2, rm, CswCubedP2{s}));
+  RT(launch_box(c, "cswc_p2c", 0, 2, 0, 0, npz, CswCubedP2c{s}));
+  RT(launch_pass(c, "cswc_p3", g.is - 1, g.ie + 2, g.js - 1, g.je + 2, rm, CswCubedP3{s}));
+  RT(launch_pass(c, "cswc_p4", g.is - 1, g.ie + 1, g.js - 1, g.je + 1, rm, CswCubedP4{s}));
+  s.own_w = hyb ? wo : 0;
+  RT(launch_pass(c, "cswc_p5", g.is - 1, g.ie + 1, g.js - 1, g.je + 1, ro, CswCubedP5{s}));
+  if (hyb) {
+    CswArgs cm = ca;
+    cm.mask_w = wo;
+    RT(csw_march(c, cm));
+    if (ca.nord > 0) {
+      s.divg = 2;
+      RT(launch_box(c, "cswc_div", g.is, g.ie + 1, g.js, g.je + 1, npz, CswCubedP3{s}));
+    }
+  }
   return 0;
 }
 
@@ -753,8 +776,20 @@ extern "C" int fv3_c_sw(fv3_ctx *c, double *delpc, const double *delp, double *p
     if (!c->cg.ready) return fail("fv3_c_sw: cubed-sphere context without fv3_grid_upload_cubed");
     return csw_cubed(c, CswArgs{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2});
   }
-  if (c->use_march) {
-    const CswArgs ca{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2};
+  if (c->use_march) return csw_march(c, CswArgs{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2});
+  constexpr int TI = FV3_CSW_TI, TJ = FV3_CSW_TJ;
+  CswTile<TI, TJ> kf;
+  kf.g = c->g;
+  kf.a = CswArgs{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2};
+  Dim3 grid;
+  CswTile<TI, TJ>::grid_dims(c->g, grid.x, grid.y);
+  grid.z = (unsigned)c->g.npz;
+  RT(launch_p(c, "c_sw", grid, CswTile<TI, TJ>::lds_doubles, kf));
+  return 0;
+}
+
+static int csw_march(fv3_ctx *c, const CswArgs &ca) {
+  {
     // rows per segment: 64 for the two-levels-per-wavefront kernel (one wavefront per SIMD); the uniform-metric kernel
     // (one level per wavefront, four per SIMD, bandwidth-bound) does better with many short segments (measured 16-40: 24)
     const int tj_csw = c->march_tj_csw ? c->march_tj_csw : (c->g.geom == 2 ? 24 : 64);
@@ -772,15 +807,6 @@ extern "C" int fv3_c_sw(fv3_ctx *c, double *delpc, const double *delp, double *p
     };
     return dispatch_geom(c->g.geom, go);
   }
-  constexpr int TI = FV3_CSW_TI, TJ = FV3_CSW_TJ;
-  CswTile<TI, TJ> kf;
-  kf.g = c->g;
-  kf.a = CswArgs{delpc, ptc, wc, uc, vc, ua, va, ut, vt, divg_d, delp, pt, u, v, w, nord, hydrostatic, dt2};
-  Dim3 grid;
-  CswTile<TI, TJ>::grid_dims(c->g, grid.x, grid.y);
-  grid.z = (unsigned)c->g.npz;
-  RT(launch_p(c, "c_sw", grid, CswTile<TI, TJ>::lds_doubles, kf));
-  return 0;
 }
 
 // compile-time scheme dispatch for the marching kernels
@@ -951,11 +977,11 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   for (int n = 0; n < 13; n++)
     if (!(*scr[n] = cs_scratch(c, 8 + n))) return fail("d_sw: out of device memory");
   const int npz = g.npz, npx = g.npx, npy = g.npy;
-  const char *L = "d_sw_cubed";
+  const char *L = "dswc_damp";
   // contravariant winds of the whole face, all levels
-  RT(launch_box(c, L, g.isd, g.ied + 1, g.jsd, g.jed + 1, npz, DswCubedD1a{s}));
-  RT(launch_box(c, L, 0, npx, 0, npy, npz, DswCubedD1b{s}));
-  RT(launch_box(c, L, 0, 3, 0, 0, npz, DswCubedD1c{s}));
+  RT(launch_box(c, "dswc_d1", g.isd, g.ied + 1, g.jsd, g.jed + 1, npz, DswCubedD1a{s}));
+  RT(launch_box(c, "dswc_d1b", 0, npx, 0, npy, npz, DswCubedD1b{s}));
+  RT(launch_box(c, "dswc_d1c", 0, 3, 0, 0, npz, DswCubedD1c{s}));
 
   // Hybrid: away from the face edges the cubed-sphere d_sw is the general-metric stencil the marching kernels compute (with
   // the contravariant winds above in the place of uc, vc and the non-orthogonal B-grid winds of the kinetic energy), so those
@@ -963,29 +989,29 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   // formed on a frame wider by the reach of the pass chain.  Levels the marching kernels do not take (sponge-level damping,
   // nord_k /= 1) go through the passes on the whole face.
   const int wo = c->cubed_frame, wm = wo + c->cubed_reach;
-  const bool fits = wo > 0 && npx - 1 >= 2 * wm + 8 && npx == npy && 2 * wm + 8 <= 64;
+  const bool fits = wo > 0 && npx - 1 >= 2 * wm + 8 && npx == npy;
   const bool fused_ok = c->use_march && c->use_fused && !a.use_cond && a.hord_dp == a.hord_tm && (a.hydrostatic || a.hord_dp == a.hord_vt);
   const bool hyb_t = fits && fused_ok && c->n_plain > 0;
   const bool hyb_m = fits && c->use_march && c->use_fused && c->n_plain_m > 0;
 
   auto transport = [&](const PassRegion &rg, const PassRegion &rg_out, bool courant) -> int {
     if (rg.nk <= 0) return 0;
-    if (courant) RT(launch_pass(c, L, g.isd, g.ied, g.jsd, g.jed, PassRegion{0, rg.klist, rg.nk}, DswCubedD2{s}));
-    RT(tp2d_cubed(c, npz, a.delp, a.crx, a.cry, a.hord_dp, s.fx, s.fy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, L, &rg));
+    if (courant) RT(launch_pass(c, "dswc_d2", g.isd, g.ied, g.jsd, g.jed, PassRegion{0, rg.klist, rg.nk}, DswCubedD2{s}));
+    RT(tp2d_cubed(c, npz, a.delp, a.crx, a.cry, a.hord_dp, s.fx, s.fy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, "dswc_tp", &rg));
     if (!a.hydrostatic)
-      RT(tp2d_cubed(c, npz, a.w, a.crx, a.cry, a.hord_vt, s.gxw, s.gyw, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, L, &rg));
-    RT(tp2d_cubed(c, npz, a.pt, a.crx, a.cry, a.hord_tm, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, L, &rg));
+      RT(tp2d_cubed(c, npz, a.w, a.crx, a.cry, a.hord_vt, s.gxw, s.gyw, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, "dswc_tp", &rg));
+    RT(tp2d_cubed(c, npz, a.pt, a.crx, a.cry, a.hord_tm, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, "dswc_tp", &rg));
     DswCubedState so = s;
     so.own_w = rg_out.w;
-    RT(launch_pass(c, L, g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD4{so}));
+    RT(launch_pass(c, "dswc_d4", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD4{so}));
     return 0;
   };
   auto momentum = [&](const PassRegion &rg, const PassRegion &rg_out) -> int {
     if (rg.nk <= 0) return 0;
     DswCubedState so = s;
     so.own_w = rg_out.w;
-    RT(launch_pass(c, L, g.is, g.ie + 1, g.js, g.je + 1, rg, DswCubedD5{s}));
-    RT(launch_pass(c, L, g.isd, g.ied + 1, g.jsd, g.jed + 1, rg, DswCubedD6{s}));
+    RT(launch_pass(c, "dswc_ke", g.is, g.ie + 1, g.js, g.je + 1, rg, DswCubedD5{s}));
+    RT(launch_pass(c, "dswc_d6", g.isd, g.ied + 1, g.jsd, g.jed + 1, rg, DswCubedD6{s}));
     for (int n = 1; n <= c->lev_max_nord; n++) {
       const bool may_fill = c->lev_max_nord - n != 0;   // some level may have nt /= 0 in this iteration
       const PassRegion rc{0, rg.klist, rg.nk};          // the corner fills: tiny boxes
@@ -1000,9 +1026,9 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
       RT(launch_pass(c, L, g.is - 2, g.ie + 3, g.js - 2, g.je + 3, rg, DswCubedDampDiv{s, n}));
     }
     RT(launch_pass(c, L, g.is, g.ie + 1, g.js, g.je + 1, rg, DswCubedD7{so}));
-    RT(launch_pass(c, L, g.isd, g.ied, g.jsd, g.jed, rg, DswCubedD8{s}));
-    RT(tp2d_cubed(c, npz, s.wk, a.crx, a.cry, a.hord_vt, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, L, &rg));
-    RT(launch_pass(c, L, g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD9{so}));
+    RT(launch_pass(c, "dswc_d8", g.isd, g.ied, g.jsd, g.jed, rg, DswCubedD8{s}));
+    RT(tp2d_cubed(c, npz, s.wk, a.crx, a.cry, a.hord_vt, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, "dswc_tpv", &rg));
+    RT(launch_pass(c, "dswc_d9", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD9{so}));
     return 0;
   };
 

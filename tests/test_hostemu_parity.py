@@ -549,6 +549,21 @@ def test_cubed_hybrid_d_sw(emu, kw):
     assert max(PC.check_d_sw(emu, npx=41, **kw).values()) <= P.TOL
 
 
+@pytest.mark.parametrize("hydrostatic", [False, True])
+def test_cubed_hybrid_c_sw(emu, hydrostatic):
+    """C48 faces: CswMarch over the whole face (cubed vt form, frame of 7 masked, no divergence), the passes on the frame, the
+    non-orthogonal divergence as a pass of its own"""
+    assert PC.check_c_sw(emu, npx=49, npz=3, hydrostatic=hydrostatic) <= P.TOL
+    assert PC.check_c_sw(emu, npx=49, npz=3, hydrostatic=hydrostatic, nord=0, faces=(1,)) <= P.TOL
+
+
+def test_cubed_hybrid_c_sw_frame_is_not_marginal(emu, monkeypatch):
+    """d2a2c_vect's edge forms reach six points into a face (npt = 4, the 4-point A -> C interpolation, ke, the wind update)"""
+    monkeypatch.setenv("FV3_MI355X_CUBED_FRAME_C", "6")
+    monkeypatch.setenv("FV3_MI355X_CUBED_REACH", "3")
+    assert PC.check_c_sw(emu, npx=49, npz=3, hydrostatic=False, faces=(0, 3)) <= P.TOL
+
+
 def test_cubed_hybrid_substeps(emu):
     assert max(PC.check_substeps_hydrostatic(emu, npx=33, npz=12, n_split=2).values()) <= 1e-13
     assert max(PC.check_substeps_nh(emu, npx=33, npz=12, n_split=2).values()) <= 1e-13
