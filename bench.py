@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--hord", type=int, default=10, help="hord_mt = hord_vt = hord_tm = hord_dp (reference default 10)")
     ap.add_argument("--no-model-step", action="store_true", help="skip the SYPD (whole model step) leg")
+    ap.add_argument("--no-cubed", action="store_true", help="skip the cubed-sphere leg (C384L127 face pair, whole-sphere model steps)")
     ap.add_argument("--nq", type=int, default=4, help="advected tracers in the SYPD leg")
     ap.add_argument("--model-step-multi", action="store_true", help="run the SYPD leg on N > 1 GPUs too")
     ap.add_argument("--no-general", action="store_true", help="skip the second (general-metrics) measurement of the pair")
@@ -211,6 +212,102 @@ def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream):
             "note": f"one {nx}x{nx}x{npz} doubly periodic tile per GPU ({world} tile(s)); a C384 sphere is 6 such tiles, "
                     "so this is the SYPD of a 6-GPU one-face-per-GPU run before cube-edge exchange cost",
             "kernels_ms_per_dt_atmos": {k: round(v[1], 3) for k, v in rep.items()}}
+
+
+def cubed_sphere_leg(a, torch, stream):
+    """The cubed sphere itself (grid_type 0, gnomonic C384 L127): (1) the c_sw + d_sw pair on one face -- marching kernels on
+    the face interior, pass kernels on the frame along the edges; (2) whole nonhydrostatic model steps of
+    the Jablonowski-Williamson baroclinic wave (test_case 13) on all six faces held by this ONE GPU, halo updates by device
+    gathers: the SYPD of BASELINE's metric on one MI355X."""
+    from gfdl_atmos_cubed_sphere_amd import lib as L
+    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
+    from gfdl_atmos_cubed_sphere_amd.cubed_sphere import CubedSphere
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags, level_coefficients
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    from gfdl_atmos_cubed_sphere_amd.synthetic import CSW_OUT, DSW_PAR, smooth_state
+    from gfdl_atmos_cubed_sphere_amd.test_cases import jablonowski_williamson, set_eta
+    nx, npz = a.nx, a.npz
+    npx = nx + 1
+    cs = CubedSphere(npx)
+    gs = [cs.gridstruct(t) for t in range(6)]
+    out = {"grid": f"gnomonic equidistant C{nx} L{npz}, grid_type 0"}
+    # ---- (1) the pair on one face
+    ctx = L.Context(gs[0], npz, stream=stream.cuda_stream)
+    bd = gs[0].bd
+    st = smooth_state(Bounds(1, nx, 1, nx), npz, noise=0.05)
+    d = {k: ctx.from_host(v) for k, v in st.items()}
+    del st
+    for n, kind in tuple(CSW_OUT) + (("mfx", "FX"), ("mfy", "FY"), ("cx", "CX"), ("cy", "CY"), ("crx", "CX"), ("cry", "CY"),
+                                    ("xfx", "CX"), ("yfx", "CY"), ("delp_out", "A"), ("pt_out", "A"), ("u_out", "U"), ("v_out", "V"),
+                                    ("w_out", "A"), ("heat_s", "CC"), ("diss_e", "CC")):
+        d[n] = ctx.zeros(kind, npz)
+    ctx.dsw_levels(level_coefficients(npz, DynFlags()))
+    dt = 22.5
+    par = dict(DSW_PAR)
+    par.update(dt=dt, hydrostatic=0, use_cond=0, hord_mt=a.hord, hord_vt=a.hord, hord_tm=a.hord, hord_dp=a.hord)
+
+    def pair():
+        ctx.c_sw(d["delpc"], d["delp"], d["ptc"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"], d["wc"],
+                 d["ut"], d["vt"], d["divg_d"], 1, 0.5 * dt, False)
+        ctx.d_sw(par, None, d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"], d["divg_d"], d["mfx"],
+                 d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None, d["delp_out"], d["pt_out"], d["u_out"],
+                 d["v_out"], d["w_out"], None, d["heat_s"], d["diss_e"])
+    for _ in range(5):
+        pair()
+    ctx.profile(True)
+    pair()
+    rep = ctx.profile_report()
+    ctx.profile(False)
+    torch.cuda.synchronize()
+    nrep = 20
+    t0 = time.perf_counter()
+    for _ in range(nrep):
+        pair()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / nrep * 1e3
+    cells = nx * nx * npz
+    march = sum(v[1] for k, v in rep.items() if k in ("c_sw", "d_sw_fused", "d_sw_mom_fused"))
+    out["pair_one_face"] = {"ms": ms, "cell_updates_per_s": cells / (ms * 1e-3), "alg_bytes_per_cell": PAIR_ALG_BYTES,
+                            "frac_wall": cells * PAIR_ALG_BYTES / (ms * 1e-3) / HBM_PEAK,
+                            "marching_kernels_ms": march, "pass_kernels_ms": sum(v[1] for v in rep.values()) - march,
+                            "launches": {k: [v[0], round(v[1], 4)] for k, v in rep.items()}}
+    ctx.close()
+    del d
+    # ---- (2) whole model steps on the sphere
+    ak, bk, _, _ = set_eta(npz) if npz in (79, 127) else (None, None, None, None)
+    if ak is None:
+        sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+        ak, bk = 300.0 * (1.0 - sig), sig.copy()
+    st = jablonowski_williamson(cs, ak, bk, hydrostatic=False)
+    cs.topo.update("A", [s_["phis"] for s_ in st])
+    fl = DynFlags(n_split=5, hydrostatic=False, ptop=float(ak[0]))
+    ng = bd.ng
+    c = (slice(ng, ng + nx), slice(ng, ng + nx))
+    for s_ in st:      # T -> theta_v with the nonhydrostatic pkz (fv_dynamics.F90:385-394)
+        s_["pt"][c] = s_["pt"][c] / ((-fl.rdgas / fl.grav) * s_["delp"][c] * s_["pt"][c] / s_["delz"]) ** fl.akap
+    mctx = MultiContext([L.Context(g, npz, stream=stream.cuda_stream) for g in gs])
+    k_split, dt_atmos = 2, 225.0
+    fv = FvDynamics(mctx, fl, ak, bk, nq=0, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+    fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], [s_["w"] for s_ in st], [s_["delp"] for s_ in st],
+                    [s_["pt"] for s_ in st], [s_["delz"] for s_ in st], [s_["phis"] for s_ in st])
+    del st
+    fv.step(dt_atmos)
+    torch.cuda.synchronize()
+    nrep = 2
+    t0 = time.perf_counter()
+    for _ in range(nrep):
+        fv.step(dt_atmos)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / nrep
+    dp = fv.dc.d["delp"].download()
+    out["sphere_one_gpu"] = {"sypd": dt_atmos / (365.0 * wall), "wall_s_per_dt_atmos": wall, "dt_atmos_s": dt_atmos, "k_split": k_split,
+                             "n_split": fl.n_split, "nq": 0, "cells": 6 * cells, "finite": bool(all(np.isfinite(x[c]).all() for x in dp)),
+                             "initial_condition": "test_case 13 (Jablonowski-Williamson), nonhydrostatic",
+                             "note": "all six faces on ONE MI355X (six contexts, device-gather halo updates); one face per GPU "
+                                     "is the driver's multi-GPU business"}
+    mctx.close()
+    return out
 
 
 def main():
@@ -416,6 +513,12 @@ def main():
             out["model_step"] = model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream)
         except Exception as e:  # noqa: BLE001
             out["model_step"] = {"error": f"{type(e).__name__}: {e}"}
+    out["cubed_sphere"] = None
+    if world == 1 and not a.no_cubed:
+        try:
+            out["cubed_sphere"] = cubed_sphere_leg(a, torch, stream)
+        except Exception as e:  # noqa: BLE001
+            out["cubed_sphere"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not a.no_cpu:
         try:
             out["cpu_baseline"] = cpu_baseline(nx, a.cpu_seconds)
