@@ -301,6 +301,15 @@ def cubed_sphere_leg(a, torch, stream):
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / nrep
     dp = fv.dc.d["delp"].download()
+    mctx.profile(True)
+    fv.step(dt_atmos)
+    reps = mctx.profile_report()
+    mctx.profile(False)
+    kern = {}
+    for rep in reps:
+        for k_, v in rep.items():
+            kern[k_] = kern.get(k_, 0.0) + v[1]
+    out["sphere_one_gpu_kernels_ms_per_dt_atmos"] = {k_: round(v, 2) for k_, v in sorted(kern.items(), key=lambda kv: -kv[1])}
     out["sphere_one_gpu"] = {"sypd": dt_atmos / (365.0 * wall), "wall_s_per_dt_atmos": wall, "dt_atmos_s": dt_atmos, "k_split": k_split,
                              "n_split": fl.n_split, "nq": 0, "cells": 6 * cells, "finite": bool(all(np.isfinite(x[c]).all() for x in dp)),
                              "initial_condition": "test_case 13 (Jablonowski-Williamson), nonhydrostatic",

@@ -1517,8 +1517,22 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
     if (c->n_damp_z > 0) return fail("fv3_update_dz_d: del6_vt_flux damping of zh is not built for the cubed sphere yet");
     double *fx = cs_scratch(c, 8), *fy = cs_scratch(c, 9);
     if (!fx || !fy) return fail("fv3_update_dz_d: out of device memory");
-    if (tp2d_cubed(c, km + 1, zh_in, cxa, cya, hord, fx, fy, xfa, yfa, nullptr, nullptr, nullptr, nullptr, "zh_transport")) return 1;
-    RT(launch_box(c, "zh_transport", g.is, g.ie, g.js, g.je, km + 1, ZhCubedFinal{g, zh_in, fx, fy, xfa, yfa, zh_out}));
+    // Hybrid (see dsw_cubed): the marching transport of the interface heights over the whole face, then the cubed fv_tp_2d
+    // passes on the frame along the face edges (zh_out is not an input: the passes simply overwrite the frame)
+    const int wo = c->cubed_frame, wm = wo + c->cubed_reach;
+    const bool hyb = c->use_march && wo > 0 && g.npx == g.npy && g.npx - 1 >= 2 * wm + 8;
+    if (hyb) {
+      MarchDims md = make_march_dims(g, seg_rows(c, c->march_tj, g.npz));
+      md.klist = c->klist_z;
+      const int nwz = md.nwaves(c->n_plain_z);
+      RT(dispatch_hord(hord, [&](auto H) {
+        ZhMarch<decltype(H)::value> kf{g, md, zh_in, cxa, cya, xfa, yfa, zh_out};
+        return launch_w(c, "zh_transport", nwz, kf);
+      }));
+    }
+    const PassRegion rm{hyb ? wm : 0, nullptr, km + 1}, ro{hyb ? wo : 0, nullptr, km + 1};
+    if (tp2d_cubed(c, km + 1, zh_in, cxa, cya, hord, fx, fy, xfa, yfa, nullptr, nullptr, nullptr, nullptr, "zhc_tp", &rm)) return 1;
+    RT(launch_pass(c, "zhc_fin", g.is, g.ie, g.js, g.je, ro, ZhCubedFinal{g, zh_in, fx, fy, xfa, yfa, zh_out}));
     ZhLimit kf{g, km, rdt, zs, zh_out, ws};
     RT(launch_c(c, "zh_limit", col_grid(g.nx * g.ny), kf));
     return 0;
@@ -1724,8 +1738,22 @@ static int run_a2b(fv3_ctx *c, const A2BCorners<TI, TJ> &kf, int nlev_max) {
         if (!(s.qx[f] = cs_scratch(c, 2 * f)) || !(s.qy[f] = cs_scratch(c, 2 * f + 1))) return fail("a2b_ord4: out of device memory");
       }
     }
-    RT(launch_box(c, "a2b_corners", 1, g.npx, 1, g.npy, nlev_max, A2bCubedPa{s}));
-    RT(launch_box(c, "a2b_corners", 1, g.npx, 1, g.npy, nlev_max, A2bCubedPb{s}));
+    // Hybrid: away from the face edges a2b_ord4 is the 4th-order form of the LDS-tile kernel (the one-sided forms touch
+    // qx at i <= 2, qy at j <= 2 and the corners next to them), so that kernel takes the whole face first and the passes
+    // then rewrite a frame of 4 points (qx, qy two points wider).  Outputs and inputs are distinct arrays: no masks needed.
+    const int wa = c->cubed_frame ? 4 : 0;
+    const bool hyb = wa > 0 && g.npx == g.npy && g.npx - 1 >= 2 * (wa + 3) + 8;
+    if (hyb) {
+      Dim3 grid;
+      grid.x = (unsigned)((g.nx + 1 + TI - 1) / TI);
+      grid.y = (unsigned)((g.ny + 1 + TJ - 1) / TJ);
+      grid.z = (unsigned)nlev_max;
+      A2BCorners<TI, TJ> kc = kf;
+      kc.sum_form = 1;
+      RT(launch_p(c, "a2b_corners", grid, A2BCorners<TI, TJ>::lds_doubles, kc));
+    }
+    RT(launch_pass(c, "a2bc_pa", 1, g.npx, 1, g.npy, PassRegion{hyb ? wa + 3 : 0, nullptr, nlev_max}, A2bCubedPa{s}));
+    RT(launch_pass(c, "a2bc_pb", 1, g.npx, 1, g.npy, PassRegion{hyb ? wa : 0, nullptr, nlev_max}, A2bCubedPb{s}));
     return 0;
   }
   Dim3 grid;
@@ -2034,19 +2062,7 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
     RT(rt_h2d(c->trc_i, ksplt_host, sizeof(int) * g.npz, c->stream));
     RT(rt_sync(c->stream));
   }
-  if (is_cubed(c)) {
-    if (it == 1 && trdm > 1.e-4) return fail("fv3_tracer_2d_step: deln_flux damping (trdm) is not built for the cubed sphere yet");
-    double *fx = cs_scratch(c, 8), *fy = cs_scratch(c, 9);
-    if (!fx || !fy) return fail("fv3_tracer_2d_step: out of device memory");
-    const size_t nq3 = (size_t)g.npz * g.nA();
-    for (int iq = 0; iq < nq; iq++) {
-      if (tp2d_cubed(c, g.npz, q + iq * nq3, cx, cy, hord, fx, fy, xfx, yfx, nullptr, nullptr, mfx, mfy, "tracer_step")) return 1;
-      TracerCubedFinal kf{g, it, nsplt, iq == nq - 1, c->trc_i, q + iq * nq3, dp1, fx, fy, mfx, mfy, q_out + iq * nq3, dp1_out};
-      RT(launch_box(c, "tracer_step", g.is, g.ie, g.js, g.je, g.npz, kf));
-    }
-    return 0;
-  }
-  if (c->use_march && !(it == 1 && trdm > 1.e-4)) {
+  auto march_step = [&]() -> int {
     const int trc_nt = c->trc_nt;   // tracers per wavefront (1: one (tracer, level) per wavefront, TracerMarch)
     if (trc_nt > 1 && nq > 1) {
       auto go = [&](auto H, auto NTc) -> int {
@@ -2072,7 +2088,26 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
                                          q_out, dp1_out};
       return launch_w(c, "tracer_step", nwt, kf);
     });
+  };
+  if (is_cubed(c)) {
+    if (it == 1 && trdm > 1.e-4) return fail("fv3_tracer_2d_step: deln_flux damping (trdm) is not built for the cubed sphere yet");
+    double *fx = cs_scratch(c, 8), *fy = cs_scratch(c, 9);
+    if (!fx || !fy) return fail("fv3_tracer_2d_step: out of device memory");
+    // Hybrid (see dsw_cubed): the marching kernels over the whole face (q_out, dp1_out are not inputs), then the cubed fv_tp_2d
+    // passes and the update on the frame along the face edges, tracer by tracer
+    const int wo = c->cubed_frame, wm = wo + c->cubed_reach;
+    const bool hyb = c->use_march && wo > 0 && g.npx == g.npy && g.npx - 1 >= 2 * wm + 8;
+    if (hyb) RT(march_step());
+    const PassRegion rm{hyb ? wm : 0, nullptr, g.npz}, ro{hyb ? wo : 0, nullptr, g.npz};
+    const size_t nq3 = (size_t)g.npz * g.nA();
+    for (int iq = 0; iq < nq; iq++) {
+      if (tp2d_cubed(c, g.npz, q + iq * nq3, cx, cy, hord, fx, fy, xfx, yfx, nullptr, nullptr, mfx, mfy, "trc_tp", &rm)) return 1;
+      TracerCubedFinal kf{g, it, nsplt, iq == nq - 1, c->trc_i, q + iq * nq3, dp1, fx, fy, mfx, mfy, q_out + iq * nq3, dp1_out};
+      RT(launch_pass(c, "trc_fin", g.is, g.ie, g.js, g.je, ro, kf));
+    }
+    return 0;
   }
+  if (c->use_march && !(it == 1 && trdm > 1.e-4)) return march_step();
   constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
   TracerStep<TI, TJ> kf{g, g.npz, nq, it, nsplt, hord, nord_tr, trdm, c->trc_i, q, dp1, mfx, mfy, cx, cy, xfx, yfx,
                         q_out, dp1_out};

@@ -664,6 +664,8 @@ struct A2BCorners {
   double scale[4];        // value = in * scale at load time (gz = zh*grav, dyn_core.F90:982-989); 1.0 = none
   double top[4];          // level-1 overrides (nh_p_grad :1732-1738, one_grad_p :1950-1955) ...
   int override_mask;      // ... of the fields whose bit is set
+  int sum_form = 0;       // 1: qout = 0.5*(qxx + qyy) with the two 4-point sums formed separately (the cubed-sphere branch,
+                          // a2b_edge.F90:236-286) instead of the combined sum of the grid_type >= 3 branch (:292-315)
   static constexpr int W = TI + 5, H = TJ + 5;  // corners [i0, i0+TI] need cells [i0-2, i0+TI+1]
   static constexpr int lds_doubles = W * H;
   FV3_HD void operator()(int bx, int by, int bz, int tid, double *lds) const {
@@ -698,7 +700,10 @@ struct A2BCorners {
           qx[t] = b1 * (s(i - 1, jj) + s(i, jj)) + b2 * (s(i - 2, jj) + s(i + 1, jj));
           qy[t] = b1 * (s(ii, j - 1) + s(ii, j)) + b2 * (s(ii, j - 2) + s(ii, j + 1));
         }
-        o[g.iA(i, j)] = 0.5 * (a1 * (qx[1] + qx[2] + qy[1] + qy[2]) + a2 * (qx[0] + qx[3] + qy[0] + qy[3]));
+        if (sum_form)
+          o[g.iA(i, j)] = 0.5 * ((a2 * (qx[0] + qx[3]) + a1 * (qx[1] + qx[2])) + (a2 * (qy[0] + qy[3]) + a1 * (qy[1] + qy[2])));
+        else
+          o[g.iA(i, j)] = 0.5 * (a1 * (qx[1] + qx[2] + qy[1] + qy[2]) + a2 * (qx[0] + qx[3] + qy[0] + qy[3]));
       }
     }
   }

@@ -575,3 +575,17 @@ def test_cubed_hybrid_frame_width_is_not_marginal(emu, monkeypatch):
     monkeypatch.setenv("FV3_MI355X_CUBED_FRAME", "3")
     monkeypatch.setenv("FV3_MI355X_CUBED_REACH", "3")
     assert max(PC.check_d_sw(emu, npx=41, npz=12, hydrostatic=False, faces=(0, 3)).values()) <= P.TOL
+
+
+def test_cubed_hybrid_tracers_and_pressure_gradient(emu):
+    """the other hybrids: tracer_2d (marching kernels + frame passes per tracer, sub-cycled levels), a2b_ord4 in the pressure
+    gradients (LDS-tile kernel in the sum form of the cubed branch + frame passes), update_dz_d (ZhMarch + frame) in a
+    nonhydrostatic Jablonowski-Williamson step with tracers on C32 faces"""
+    assert PC.check_tracer_2d(emu, npx=33, npz=6, nq=5, courant_scale=100.0, hord=5)["q"] <= P.TOL
+    assert PC.check_tracer_2d(emu, npx=41, npz=6, nq=2, q_split=2, hord=13)["q"] <= P.TOL
+    cs, gs = PC.CC.sphere(41)
+    for t in (0, 3, 5):
+        N.check_nh_p_grad(emu, km=4, grid=gs[t])
+        N.check_one_grad_p(emu, km=4, grid=gs[t], d_ext=0.0)
+    r = PC.check_jw_step(emu, npx=33, npz=20, k_split=1, n_split=2, bdt=900.0, hydrostatic=False, nq=2)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
