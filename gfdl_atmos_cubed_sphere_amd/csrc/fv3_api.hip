@@ -81,6 +81,7 @@ struct fv3_ctx {
   int n_plain_m, n_rest_m;
   int *klist_z;          // npz+1 interfaces of update_dz_d: [undamped..., damped...]
   int n_plain_z, n_damp_z;
+  int col_pool;      // workgroups of the pooled launches of the column solvers (0: one workgroup per 256 columns)
   int cubed_frame;   // cubed-sphere hybrid: width of the frame the pass kernels own (0: passes on the whole face)
   int cubed_reach;   // ... and how much wider the frame of the passes' intermediates is
   int cubed_frame_c; // the frame of c_sw (d2a2c_vect has its edge forms within 4 points of an edge)
@@ -289,6 +290,9 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_MARCH_TJ_KE");
     c->march_tj_ke = e ? std::atoi(e) : 48;
     if (c->march_tj_ke < 1) c->march_tj_ke = 48;
+    e = std::getenv("FV3_MI355X_COL_POOL");
+    c->col_pool = e ? std::atoi(e) : 0;
+    if (c->col_pool < 0) c->col_pool = 0;
     e = std::getenv("FV3_MI355X_CUBED_FRAME");
     c->cubed_frame = e ? std::atoi(e) : 4;
     if (c->cubed_frame < 0) c->cubed_frame = 0;
@@ -1394,6 +1398,11 @@ static int need_scratch(fv3_ctx *c, int n) {
   return 0;
 }
 
+// pooled column launch (FV3_COL_FOR_POOL): pool workgroups, or one per column block when there are fewer blocks / no pool
+static int col_pool(const fv3_ctx *c, int ncol) {
+  const int nb = (ncol + 255) / 256;
+  return (c->col_pool > 0 && c->riem_blocked && nb > c->col_pool) ? c->col_pool : 0;
+}
 static Dim3 col_grid(int ncol) {
   Dim3 gr;
   gr.x = (unsigned)((ncol + 255) / 256);
@@ -1461,14 +1470,15 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn,
   if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver_c: bad context/arguments");
   if (cn->a_imp <= 0.5) return fail("fv3_riem_solver_c: a_imp <= 0.5 (RIM_2D / SIM3p0) is not built");
   if (need_scratch(c, 4)) return 1;
+  const int ncc = (c->g.nx + 2) * (c->g.ny + 2), pool = col_pool(c, ncc);
   if (c->q_con) {
     RiemSolverC<true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, w3, pt, delp, ws, gz, pef,
-                         c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->q_con, c->cappa, c->riem_blocked};
-    RT(launch_c(c, "riem_solver_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), kf));
+                         c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->q_con, c->cappa, c->riem_blocked, pool};
+    RT(launch_c(c, "riem_solver_c", pool ? col_grid(pool * 256) : col_grid(ncc), kf));
   } else {
     RiemSolverC<false> kf{c->g, c->g.npz, dt, to_consts(cn), hs, w3, pt, delp, ws, gz, pef,
-                          c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], nullptr, nullptr, c->riem_blocked};
-    RT(launch_c(c, "riem_solver_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), kf));
+                          c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], nullptr, nullptr, c->riem_blocked, pool};
+    RT(launch_c(c, "riem_solver_c", pool ? col_grid(pool * 256) : col_grid(ncc), kf));
   }
   return 0;
 }
@@ -1481,16 +1491,17 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
   if (cn->a_imp <= 0.5) return fail("fv3_riem_solver3: a_imp <= 0.5 (RIM_2D / SIM3 / SIM3p0) is not built");
   if (last_call && (!pe || !pk || !peln)) return fail("fv3_riem_solver3: last_call needs pe, pk, peln");
   if (need_scratch(c, 4)) return 1;
+  const int ncc = c->g.nx * c->g.ny, pool = col_pool(c, ncc);
   if (c->q_con || c->cappa) {
     RiemSolver3<true> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, delz, zh, pe, ppe, pk3, pk, peln,
                          use_logp, last_call, fp_out, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3],
-                         c->q_con, c->cappa, c->riem_blocked};
-    RT(launch_c(c, "riem_solver3", col_grid(c->g.nx * c->g.ny), kf));
+                         c->q_con, c->cappa, c->riem_blocked, pool};
+    RT(launch_c(c, "riem_solver3", pool ? col_grid(pool * 256) : col_grid(ncc), kf));
   } else {
     RiemSolver3<false> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, delz, zh, pe, ppe, pk3, pk, peln,
                           use_logp, last_call, fp_out, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3],
-                          nullptr, nullptr, c->riem_blocked};
-    RT(launch_c(c, "riem_solver3", col_grid(c->g.nx * c->g.ny), kf));
+                          nullptr, nullptr, c->riem_blocked, pool};
+    RT(launch_c(c, "riem_solver3", pool ? col_grid(pool * 256) : col_grid(ncc), kf));
   }
   return 0;
 }

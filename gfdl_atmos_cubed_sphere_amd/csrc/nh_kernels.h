@@ -32,6 +32,13 @@ struct NhConsts {
 };
 
 #define FV3_COL_FOR(c, ncol) for (int c = bx * 256 + tid; c < (bx + 1) * 256 && c < (ncol); c += kNT)
+// The same with a POOL of P workgroups (P > 0: the launch has P workgroups, each takes the column blocks bx, bx + P, ...; cs is
+// the column slot of the scratch slabs: a workgroup reuses its own 256 slots for every block it takes, so the slabs of a launch
+// are P x 256 columns that stay in L2 / Infinity Cache instead of one pass through HBM per sweep of the solver).  P = 0: one
+// workgroup per column block, cs = c.
+#define FV3_COL_FOR_POOL(c, cs, ncol, P)                                            \
+  for (int bb_ = bx; bb_ < ((ncol) + 255) / 256; bb_ += ((P) > 0 ? (P) : 0x40000000)) \
+    for (int c = bb_ * 256 + tid, cs = ((P) > 0 ? bx : bb_) * 256 + tid; c < (bb_ + 1) * 256 && c < (ncol); c += kNT, cs += kNT)
 
 // ------------------------------------------------------------------------------------------------
 struct UpdateDzC {
@@ -359,10 +366,11 @@ struct RiemSolverC {
   double *s0, *s1, *s2, *s3;  // scratch slabs, A x (km+1)
   const double *q_con, *cappa;  // A x km or null (use_cond / moist_kappa)
   int scr_blocked;              // scratch slabs in per-wavefront blocks (remap_kernels.h scr_col)
+  int pool;                     // workgroups of a pooled launch (FV3_COL_FOR_POOL; needs scr_blocked), 0 = one per column block
   FV3_HD void operator()(int bx, int, int, int tid, double *) const {
     const int w = g.nx + 2, ncol = w * (g.ny + 2);
     const size_t nA = g.nA();
-    FV3_COL_FOR(c, ncol) {
+    FV3_COL_FOR_POOL(c, cs, ncol, pool) {
       const int i = g.is - 1 + c % w, j = g.js - 1 + c / w;
       const int o = g.iA(i, j);
       ColIn in{delp + o, pt + o, w3 + o, gz + o, 1.};
@@ -373,7 +381,7 @@ struct RiemSolverC {
       // pef = pe2 + pem (:461-465); gz = hs - sum dz2*grav (:468-476), formed inside the solver's last two sweeps
       double pem = cn.ptop;
       double zb = hs[o];
-      const size_t so = scr_blocked ? (size_t)(c >> 6) * 64 * (km + 1) + (c & 63) : (size_t)o;
+      const size_t so = scr_blocked ? (size_t)(cs >> 6) * 64 * (km + 1) + (cs & 63) : (size_t)o;
       const size_t ss = scr_blocked ? 64 : nA;
       sim_column<MOIST>(
           km, nA, ss, in, dt, cn, true, true, ws[o], s0 + so, s1 + so, s2 + so, s3 + so,
@@ -407,12 +415,13 @@ struct RiemSolver3 {
   double *s0, *s1, *s2, *s3;
   const double *q_con, *cappa;  // A x km or null (use_cond / moist_kappa, nh_core.F90:96-166)
   int scr_blocked;
+  int pool;
   FV3_HD void operator()(int bx, int, int, int tid, double *) const {
     const int ncol = g.nx * g.ny;
     const size_t nA = g.nA(), nCC = g.nCC();
     const bool sim1 = cn.a_imp > 0.999;
     const double peln1 = dlog(cn.ptop), ptk = dexp(cn.akap * peln1);
-    FV3_COL_FOR(c, ncol) {
+    FV3_COL_FOR_POOL(c, cs, ncol, pool) {
       const int i = g.is + c % g.nx, j = g.js + c / g.nx;
       const int o = g.iA(i, j), occ = g.iCC(i, j);
       ColIn in{delp + o, pt + o, w + o, zh + o, 1.};
@@ -423,7 +432,7 @@ struct RiemSolver3 {
       // hydrostatic pressure functions (:132-143) and the outputs (:191-237) are formed inside the solver's last sweeps
       double pem = cn.ptop;
       double zb = zs[o];
-      const size_t so = scr_blocked ? (size_t)(c >> 6) * 64 * (km + 1) + (c & 63) : (size_t)o;
+      const size_t so = scr_blocked ? (size_t)(cs >> 6) * 64 * (km + 1) + (cs & 63) : (size_t)o;
       const size_t ss = scr_blocked ? 64 : nA;
       sim_column<MOIST>(
           km, nA, ss, in, dt, cn, sim1, false, ws[occ], s0 + so, s1 + so, s2 + so, s3 + so,
