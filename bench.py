@@ -286,7 +286,10 @@ def cubed_sphere_leg(a, torch, stream):
     c = (slice(ng, ng + nx), slice(ng, ng + nx))
     for s_ in st:      # T -> theta_v with the nonhydrostatic pkz (fv_dynamics.F90:385-394)
         s_["pt"][c] = s_["pt"][c] / ((-fl.rdgas / fl.grav) * s_["delp"][c] * s_["pt"][c] / s_["delz"]) ** fl.akap
-    mctx = MultiContext([L.Context(g, npz, stream=stream.cuda_stream) for g in gs])
+    # a stream per face: the launches of different faces overlap on the GPU (the column solvers of one face are 2 300
+    # wavefronts, a quarter of what the chip holds), the halo gathers join and fork them (cubed_halo.CubeHalo)
+    fstreams = [stream] + [torch.cuda.Stream() for _ in range(5)] if os.environ.get("FV3_BENCH_FACE_STREAMS", "1") == "1" else [stream] * 6
+    mctx = MultiContext([L.Context(g, npz, stream=fs.cuda_stream) for g, fs in zip(gs, fstreams)])
     k_split, dt_atmos = 2, 225.0
     fv = FvDynamics(mctx, fl, ak, bk, nq=0, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
     fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], [s_["w"] for s_ in st], [s_["delp"] for s_ in st],

@@ -24,6 +24,26 @@ class CubeHalo:
         self.lib = self.ctx.lib
         self.topo = topo or CubeTopology(npx, ng)
         self._handles = {}
+        # faces on streams of their own (their kernels overlap on the GPU): a gather reads and writes all six faces, so the
+        # gather stream (face 1's) first waits for the other five and they wait for the gather afterwards
+        handles = [getattr(c, "stream", 0) for c in self.ctxs]
+        self._streams = None
+        if len(set(handles)) > 1 and not getattr(self.lib, "host_memory", False):
+            import torch
+            self._streams = [torch.cuda.ExternalStream(h) if h else torch.cuda.default_stream() for h in handles]
+            self._events = [torch.cuda.Event() for _ in handles]
+
+    def _fan_in(self):
+        if self._streams:
+            for t in range(1, 6):
+                self._events[t].record(self._streams[t])
+                self._streams[0].wait_event(self._events[t])
+
+    def _fan_out(self):
+        if self._streams:
+            self._events[0].record(self._streams[0])
+            for t in range(1, 6):
+                self._streams[t].wait_event(self._events[0])
 
     def _handle(self, kind: str, vector: bool):
         key = (kind, vector)
@@ -60,8 +80,10 @@ class CubeHalo:
         n = len(ptrs)
         parr = (C.c_void_p * n)(*ptrs)
         sarr = (C.c_size_t * n)(*strides)
-        self.lib.check(self.lib.dll.fv3_gather_run(self.ctx.h, self._handle(kind, vector), C.c_int(nk), C.c_int(n), parr, sarr),
-                       "fv3_gather_run")
+        handle = self._handle(kind, vector)
+        self._fan_in()
+        self.lib.check(self.lib.dll.fv3_gather_run(self.ctx.h, handle, C.c_int(nk), C.c_int(n), parr, sarr), "fv3_gather_run")
+        self._fan_out()
 
     def close(self):
         for h in self._handles.values():

@@ -203,7 +203,7 @@ def tracer_fields(cs, npz, nq):
     return out
 
 
-def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-12, hydrostatic=True, nq=0):
+def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-12, hydrostatic=True, nq=0, face_streams=False):
     """BASELINE configs[1] in small: the Jablonowski-Williamson baroclinic wave (test_case = 13) on the whole cubed sphere,
     hydrostatic, the reference's L79 levels (set_eta), one dt_atmos = k_split x (n_split substeps + vertical remap) on six
     device contexts against the six-face orchestration of the oracle"""
@@ -234,7 +234,12 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
             arg = (-fl.rdgas / fl.grav) * s["delp"][c] * s["pt"][c] / s["delz"]
             pkz = O.fexp(fl.akap * O.flog(arg)).reshape(arg.shape)
         s["pt"][c] = s["pt"][c] / pkz
-    mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
+    if face_streams:      # every face on a HIP stream of its own; the halo gathers join / fork them
+        import torch
+        streams = [torch.cuda.Stream() for _ in gs]
+        mctx = MultiContext([Context(g, npz, lib=lib, stream=st_.cuda_stream) for g, st_ in zip(gs, streams)])
+    else:
+        mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     worst = {}
     try:
         fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))

@@ -682,3 +682,10 @@ def test_config5_c192_l79_sphere_with_33_tracers_properties(prod):
     """past the oracle's reach: air mass and the mass of every tracer kept to rounding on the whole sphere"""
     r = PC.check_sphere_properties(prod, npx=193, npz=79, hydrostatic=True, k_split=1, n_split=3, bdt=225.0, nq=33)
     assert r["finite"] == 1.0 and r["tracer_finite"] == 1.0 and r["mass_drift"] < 1e-13 and r["tracer_mass_drift"] < 1e-12, r
+
+
+def test_cubed_sphere_faces_on_their_own_streams(prod):
+    """six contexts on six HIP streams (their kernels overlap on the GPU), joined and forked around every halo gather: the same
+    numbers as on one stream -- nonhydrostatic JW step with tracers on C48 L20 against the six-face oracle"""
+    r = PC.check_jw_step(prod, npx=49, npz=20, k_split=2, n_split=2, bdt=900.0, hydrostatic=False, nq=3, face_streams=True)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
