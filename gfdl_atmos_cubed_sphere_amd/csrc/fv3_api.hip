@@ -81,6 +81,15 @@ struct fv3_ctx {
   int n_plain_m, n_rest_m;
   int *klist_z;          // npz+1 interfaces of update_dz_d: [undamped..., damped...]
   int n_plain_z, n_damp_z;
+  // peer exchange (fv3_comm_*, fv3_halo_start / _complete): RCCL communicator, its stream, events, message buffers
+  void *comm;
+  int comm_rank, comm_size;
+  stream_t comm_stream;
+  void *ev_packed, *ev_arrived;
+  double *msg_send[8], *msg_recv[8];
+  size_t msg_cap[8];
+  int pend_n;
+  fv3_halo_field pend_fields[FV3_HALO_MAX_FIELDS];
   int col_pool;      // workgroups of the pooled launches of the column solvers (0: one workgroup per 256 columns)
   int cubed_frame;   // cubed-sphere hybrid: width of the frame the pass kernels own (0: passes on the whole face)
   int cubed_reach;   // ... and how much wider the frame of the passes' intermediates is
@@ -254,6 +263,9 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   std::memset(&c->cg, 0, sizeof c->cg);
   c->cg_dev = nullptr;
   for (auto &p : c->cs_scr) p = nullptr;
+  c->comm = nullptr; c->comm_rank = 0; c->comm_size = 1; c->comm_stream = nullptr; c->ev_packed = c->ev_arrived = nullptr;
+  for (int d = 0; d < 8; d++) { c->msg_send[d] = c->msg_recv[d] = nullptr; c->msg_cap[d] = 0; }
+  c->pend_n = 0;
   {  // tuning / fallback knobs
     const char *e = std::getenv("FV3_MI355X_MARCH");
     c->use_march = e ? std::atoi(e) : 1;
@@ -318,8 +330,10 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   return 0;
 }
 
+extern "C" int fv3_comm_destroy(fv3_ctx *c);
 extern "C" int fv3_destroy(fv3_ctx *c) {
   if (!c) return 0;
+  fv3_comm_destroy(c);
   if (c->dev_metrics) rt_free(c->dev_metrics);
   if (c->lev_i) rt_free(c->lev_i);
   if (c->lev_d) rt_free(c->lev_d);
@@ -1321,6 +1335,178 @@ extern "C" int fv3_halo_pack(fv3_ctx *c, int nfields, const fv3_halo_field *fiel
 }
 extern "C" int fv3_halo_unpack(fv3_ctx *c, int nfields, const fv3_halo_field *fields, const double *const recvbuf[8]) {
   return halo_copy(c, nfields, fields, const_cast<double *const *>(recvbuf), false);
+}
+
+// ---- peer exchange behind the C ABI: RCCL send / recv on a stream the context owns ------------------------------------------
+// What start_group_halo_update / complete_group_halo_update (tools/fv_mp_mod.F90:646-876) and mp_reduce_max (:1683) do over
+// FMS / MPI.  librccl is loaded at run time (dlopen) the first time a communicator is made, so the library has no link
+// dependency on it and a host process that already carries an RCCL (PyTorch) keeps using that one.
+#ifndef FV3_HOST_EMU
+#include <dlfcn.h>
+namespace {
+struct Id128 { char b[128]; };  // ncclUniqueId, passed by value
+struct RcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+int rccl_load() {
+  if (g_rccl.lib) return 0;
+  void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return fail("fv3_comm: cannot load librccl.so (%s)", dlerror());
+  auto sym = [&](const char *n) { return dlsym(h, n); };
+  *(void **)&g_rccl.GetUniqueId = sym("ncclGetUniqueId");
+  *(void **)&g_rccl.CommInitRank = sym("ncclCommInitRank");
+  *(void **)&g_rccl.CommDestroy = sym("ncclCommDestroy");
+  *(void **)&g_rccl.GroupStart = sym("ncclGroupStart");
+  *(void **)&g_rccl.GroupEnd = sym("ncclGroupEnd");
+  *(void **)&g_rccl.Send = sym("ncclSend");
+  *(void **)&g_rccl.Recv = sym("ncclRecv");
+  *(void **)&g_rccl.AllReduce = sym("ncclAllReduce");
+  *(void **)&g_rccl.GetErrorString = sym("ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Send || !g_rccl.Recv ||
+      !g_rccl.AllReduce)
+    return fail("fv3_comm: librccl.so lacks an entry point");
+  g_rccl.lib = h;
+  return 0;
+}
+constexpr int kNcclDouble = 8, kNcclMax = 2;  // ncclFloat64, ncclMax (rccl.h)
+#define NC(x)                                                                                              \
+  do {                                                                                                     \
+    int e_ = (x);                                                                                          \
+    if (e_) return fail("RCCL: %s (%s)", g_rccl.GetErrorString ? g_rccl.GetErrorString(e_) : "error", #x); \
+  } while (0)
+}  // namespace
+#endif
+
+extern "C" int fv3_comm_get_unique_id(unsigned char *id) {
+  if (!id) return fail("fv3_comm_get_unique_id: null");
+#ifdef FV3_HOST_EMU
+  std::memset(id, 0, FV3_COMM_ID_BYTES);
+  return 0;
+#else
+  if (rccl_load()) return 1;
+  NC(g_rccl.GetUniqueId(id));
+  return 0;
+#endif
+}
+
+extern "C" int fv3_comm_init(fv3_ctx *c, int rank, int nranks, const unsigned char *id) {
+  if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail("fv3_comm_init: bad argument");
+  if (c->comm) return fail("fv3_comm_init: the context already has a communicator");
+  c->comm_rank = rank;
+  c->comm_size = nranks;
+  RT(rt_stream_create(&c->comm_stream));
+  RT(rt_event_create(&c->ev_packed));
+  RT(rt_event_create(&c->ev_arrived));
+#ifdef FV3_HOST_EMU
+  if (nranks > 1) return fail("fv3_comm_init: the host-emulation build has no RCCL (one rank only)");
+  c->comm = (void *)c;
+#else
+  if (rccl_load()) return 1;
+  Id128 uid;
+  std::memcpy(uid.b, id, 128);
+  NC(g_rccl.CommInitRank(&c->comm, nranks, uid, rank));
+#endif
+  return 0;
+}
+
+extern "C" int fv3_comm_destroy(fv3_ctx *c) {
+  if (!c) return 0;
+#ifndef FV3_HOST_EMU
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+#endif
+  c->comm = nullptr;
+  for (int d = 0; d < 8; d++) {
+    if (c->msg_send[d]) rt_free(c->msg_send[d]);
+    if (c->msg_recv[d]) rt_free(c->msg_recv[d]);
+    c->msg_send[d] = c->msg_recv[d] = nullptr;
+    c->msg_cap[d] = 0;
+  }
+  if (c->ev_packed) rt_event_destroy(c->ev_packed);
+  if (c->ev_arrived) rt_event_destroy(c->ev_arrived);
+  if (c->comm_stream) rt_stream_destroy(c->comm_stream);
+  c->ev_packed = c->ev_arrived = nullptr;
+  c->comm_stream = nullptr;
+  return 0;
+}
+
+// start_group_halo_update: pack every field of the group (one kernel), then -- on the communication stream, which waits for
+// the pack kernel only -- one grouped send + receive per neighbour offset d (message d goes to the rank at offset d and fills
+// its (-d)-side halo; to[d] / from[d] are the ranks at offsets d / -d, fv3_halo_message_elems order).  Kernels launched
+// between start and complete on the context's stream overlap the transfers.
+extern "C" int fv3_halo_start(fv3_ctx *c, int nfields, const fv3_halo_field *fields, const int *to, const int *from) {
+  if (!c || !c->comm) return fail("fv3_halo_start: call fv3_comm_init first");
+  if (!fields || !to || !from || nfields < 1 || nfields > FV3_HALO_MAX_FIELDS) return fail("fv3_halo_start: bad argument");
+  if (c->pend_n) return fail("fv3_halo_start: the previous group has not been completed");
+  size_t elems[8];
+  if (fv3_halo_message_elems(c, nfields, fields, elems)) return 1;
+  for (int d = 0; d < 8; d++) {
+    if (elems[d] > c->msg_cap[d]) {
+      if (c->msg_send[d]) rt_free(c->msg_send[d]);
+      if (c->msg_recv[d]) rt_free(c->msg_recv[d]);
+      RT(rt_malloc((void **)&c->msg_send[d], sizeof(double) * elems[d]));
+      RT(rt_malloc((void **)&c->msg_recv[d], sizeof(double) * elems[d]));
+      c->msg_cap[d] = elems[d];
+    }
+  }
+  if (fv3_halo_pack(c, nfields, fields, c->msg_send)) return 1;
+  rt_event_record(c->ev_packed, c->stream);
+  rt_stream_wait_event(c->comm_stream, c->ev_packed);
+#ifdef FV3_HOST_EMU
+  for (int d = 0; d < 8; d++) {
+    if (to[d] != c->comm_rank || from[d] != c->comm_rank) return fail("fv3_halo_start: the host-emulation build has no peers");
+    RT(rt_d2d(c->msg_recv[d], c->msg_send[d], sizeof(double) * elems[d], c->comm_stream));
+  }
+#else
+  NC(g_rccl.GroupStart());
+  for (int d = 0; d < 8; d++) {
+    if (to[d] < 0 || to[d] >= c->comm_size || from[d] < 0 || from[d] >= c->comm_size) return fail("fv3_halo_start: peer out of range");
+    NC(g_rccl.Send(c->msg_send[d], elems[d], kNcclDouble, to[d], c->comm, c->comm_stream));
+    NC(g_rccl.Recv(c->msg_recv[d], elems[d], kNcclDouble, from[d], c->comm, c->comm_stream));
+  }
+  NC(g_rccl.GroupEnd());
+#endif
+  rt_event_record(c->ev_arrived, c->comm_stream);
+  for (int f = 0; f < nfields; f++) c->pend_fields[f] = fields[f];
+  c->pend_n = nfields;
+  return 0;
+}
+
+// complete_group_halo_update: the context's stream waits for the transfers and unpacks them into the halos
+extern "C" int fv3_halo_complete(fv3_ctx *c) {
+  if (!c || !c->pend_n) return fail("fv3_halo_complete: no group in flight");
+  rt_stream_wait_event(c->stream, c->ev_arrived);
+  const int n = c->pend_n;
+  c->pend_n = 0;
+  return fv3_halo_unpack(c, n, c->pend_fields, c->msg_recv);
+}
+
+// mp_reduce_max (tools/fv_mp_mod.F90:1683): element-wise maximum of n host doubles over the ranks, in place
+extern "C" int fv3_allreduce_max(fv3_ctx *c, double *buf, int n) {
+  if (!c || !c->comm || !buf || n < 1) return fail("fv3_allreduce_max: bad argument / no communicator");
+  if (c->comm_size == 1) return 0;
+#ifdef FV3_HOST_EMU
+  return fail("fv3_allreduce_max: the host-emulation build has no RCCL");
+#else
+  double *d = nullptr;
+  RT(rt_malloc((void **)&d, sizeof(double) * n));
+  RT(rt_h2d(d, buf, sizeof(double) * n, c->comm_stream));
+  NC(g_rccl.AllReduce(d, d, (size_t)n, kNcclDouble, kNcclMax, c->comm, c->comm_stream));
+  RT(rt_d2h(buf, d, sizeof(double) * n, c->comm_stream));
+  RT(rt_sync(c->comm_stream));
+  rt_free(d);
+  return 0;
+#endif
 }
 
 // ---- table-driven halo gather: the cubed-sphere face-to-face updates (index reversal, u <-> v with sign) ---------------------

@@ -58,6 +58,8 @@ module fv3_host_mod
     real(c_double), allocatable :: ak(:), bk(:)
   end type
 
+  logical, save :: host_comm = .false.
+
 contains
 
   subroutine dmalloc(p, n)
@@ -82,13 +84,39 @@ contains
     t = a; a = b; b = t
   end subroutine
 
-  !> group halo update on one rank of the doubly periodic domain (fv_mp_mod.F90:646-876, contacts :473-483)
+  !> group halo update on one rank of the doubly periodic domain (fv_mp_mod.F90:646-876, contacts :473-483).
+  !> host_comm (environment FV3_HOST_COMM=1): through the exchange behind the C ABI -- fv3_halo_start posts the eight
+  !> messages of the group on the context's RCCL communicator (every neighbour of the single rank is the rank itself),
+  !> fv3_halo_complete waits and unpacks -- which is the form the several-rank host uses (to / from = the neighbour ranks).
   subroutine halo(at, field, kind, nk)
     type(fv3_atmos), intent(in) :: at
     type(c_ptr), intent(in) :: field
     integer(c_int), intent(in) :: kind
     integer, intent(in) :: nk
-    call fv3_check(fv3_halo_fill_periodic(at%ctx, field, kind, int(nk, c_int)), 'fv3_halo_fill_periodic')
+    type(fv3_halo_field) :: hf(1)
+    integer(c_int) :: peers(8)
+    if (host_comm) then
+      hf(1)%field = field; hf(1)%kind = kind; hf(1)%nk = int(nk, c_int)
+      peers = 0_c_int
+      call fv3_check(fv3_halo_start(at%ctx, 1_c_int, hf, peers, peers), 'fv3_halo_start')
+      call fv3_check(fv3_halo_complete(at%ctx), 'fv3_halo_complete')
+    else
+      call fv3_check(fv3_halo_fill_periodic(at%ctx, field, kind, int(nk, c_int)), 'fv3_halo_fill_periodic')
+    end if
+  end subroutine
+
+  !> the communicator of the exchange behind the C ABI: rank 0 makes the id, a several-rank host broadcasts it (MPI_Bcast)
+  subroutine host_comm_init(at)
+    type(fv3_atmos), intent(in) :: at
+    integer(c_signed_char) :: id(128)
+    character(len=8) :: v
+    integer :: st
+    call get_environment_variable('FV3_HOST_COMM', v, status=st)
+    host_comm = (st == 0 .and. v(1:1) == '1')
+    if (.not. host_comm) return
+    call fv3_check(fv3_comm_get_unique_id(id), 'fv3_comm_get_unique_id')
+    call fv3_check(fv3_comm_init(at%ctx, 0_c_int, 1_c_int, id), 'fv3_comm_init')
+    print '(a)', ' fv3_host: group halo updates through fv3_halo_start / fv3_halo_complete'
   end subroutine
 
   !> Create the context, build and upload the gridstruct of the doubly periodic Cartesian tile (what
@@ -148,6 +176,7 @@ contains
     gh%rarea_c = c_loc(m_rarea); gh%fC = c_loc(m_f0); gh%cosa = c_loc(m_zero); gh%sina = c_loc(m_one)
     gh%sin_sg = c_loc(m_sg);     gh%cos_sg = c_loc(m_cg)
     call fv3_check(fv3_grid_upload(at%ctx, gh), 'fv3_grid_upload')
+    call host_comm_init(at)
 
     ! ---- device arrays ----
     nk = int(npz, c_size_t); nk1 = nk + 1

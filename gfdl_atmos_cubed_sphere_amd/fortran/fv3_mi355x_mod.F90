@@ -19,6 +19,7 @@ module fv3_mi355x_mod
   public :: fv3_d_sw_interior, fv3_d_sw_rest
   public :: fv3_divg2_ext, fv3_one_grad_p, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
   public :: fv3_grid_cubed, fv3_grid_upload_cubed, fv3_gather_create, fv3_gather_run, fv3_gather_destroy
+  public :: fv3_comm_get_unique_id, fv3_comm_init, fv3_comm_destroy, fv3_halo_start, fv3_halo_complete, fv3_allreduce_max
   public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_set_condensate, fv3_set_moist, fv3_moist_params
 
   type, bind(C) :: fv3_domain
@@ -225,6 +226,38 @@ module fv3_mi355x_mod
       integer(c_int), value :: nfields
       type(fv3_halo_field), intent(in) :: fields(*)
       type(c_ptr), intent(in) :: recvbuf(8)
+    end function
+    ! the exchange behind the C ABI (RCCL on a stream the context owns): start / complete_group_halo_update, mp_reduce_max
+    integer(c_int) function fv3_comm_get_unique_id(id) bind(C, name="fv3_comm_get_unique_id")
+      import :: c_int, c_signed_char
+      integer(c_signed_char), intent(out) :: id(128)
+    end function
+    integer(c_int) function fv3_comm_init(ctx, rank, nranks, id) bind(C, name="fv3_comm_init")
+      import :: c_int, c_ptr, c_signed_char
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: rank, nranks
+      integer(c_signed_char), intent(in) :: id(128)
+    end function
+    integer(c_int) function fv3_comm_destroy(ctx) bind(C, name="fv3_comm_destroy")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function fv3_halo_start(ctx, nfields, fields, to, from) bind(C, name="fv3_halo_start")
+      import :: c_int, c_ptr, fv3_halo_field
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nfields
+      type(fv3_halo_field), intent(in) :: fields(*)
+      integer(c_int), intent(in) :: to(8), from(8)
+    end function
+    integer(c_int) function fv3_halo_complete(ctx) bind(C, name="fv3_halo_complete")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function fv3_allreduce_max(ctx, buf, n) bind(C, name="fv3_allreduce_max")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), intent(inout) :: buf(*)
+      integer(c_int), value :: n
     end function
     integer(c_int) function fv3_omga_update(ctx, rdt, ptop, pe, delp_before, omga) bind(C, name="fv3_omga_update")
       import :: c_int, c_ptr, c_double

@@ -113,7 +113,7 @@ class HaloExchanger:
     """Device-side exchanger bound to a lib.Context (GPU)."""
 
     def __init__(self, ctx, px: int, py: int, rank: int, world: int, packed_single: bool = True,
-                 split_single: bool = False, loopback: bool = False):
+                 split_single: bool = False, loopback: bool = False, native: bool = False, unique_id: bytes | None = None):
         self.ctx, self.px, self.py, self.rank, self.world = ctx, px, py, rank, world
         # one rank: the pack/unpack kernel pair (2 launches per field group, every message is a self message) instead
         # of one periodic-copy launch per field -- fewer, larger launches (41 vs 75 us for uc+vc+divg_d at C384L127)
@@ -122,6 +122,12 @@ class HaloExchanger:
         # test mode: messages to myself also travel through torch.distributed (RCCL self send/recv), so the whole
         # multi-rank message path can be exercised on one GPU
         self.loopback = loopback
+        # native: the transfers run inside the library (fv3_halo_start / fv3_halo_complete: RCCL send / recv on a stream the
+        # context owns) instead of torch.distributed -- the path of a host without an RCCL binding (the Fortran dyn_core).
+        # unique_id: the 128 bytes of rank 0's fv3_comm_get_unique_id, distributed by the caller (one rank: made here).
+        self.native = native
+        if native:
+            ctx.comm_init(rank, world, unique_id)
         self.topo = HaloTopology(ctx.bd, px, py, rank)
         self._views = {}
         self._groups = {}
@@ -182,6 +188,16 @@ class HaloExchanger:
         stream that waits for the pack kernel only (an event recorded right after it), not for the kernels launched in
         between."""
         fields = list(fields)
+        if self.native:
+            to = [self.topo.neighbour(*d) for d in DIRECTIONS]
+            frm = [self.topo.neighbour(-d[0], -d[1]) for d in DIRECTIONS]
+            pending = []
+            for n in range(0, len(fields), 8):
+                pending.append({"native": (fields[n:n + 8], to, frm), "started": False})
+            # one group in flight at a time inside the library: the first is started here, the rest in finish()
+            self.ctx.halo_start(*pending[0]["native"])
+            pending[0]["started"] = True
+            return pending
         if self.world == 1 and not self.packed_single and not self.loopback:
             for dev, kind in fields:
                 self.ctx.halo_fill_periodic(dev, kind)
@@ -231,7 +247,7 @@ class HaloExchanger:
 
     def post(self, pending):
         """Issue the messages of a start(..., defer=True) handle (no-op for the ones already posted)."""
-        if pending is None:
+        if pending is None or self.native:
             return
         for entry in pending:
             self._post(entry)
@@ -239,6 +255,12 @@ class HaloExchanger:
     def finish(self, pending):
         """complete_group_halo_update: wait for the messages of start() and unpack them into the halos."""
         if pending is None:
+            return
+        if self.native:
+            for entry in pending:
+                if not entry["started"]:
+                    self.ctx.halo_start(*entry["native"])
+                self.ctx.halo_complete()
             return
         for entry in pending:
             self._post(entry)

@@ -33,7 +33,7 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_grid_upload_cubed", "fv3_gather_create", "fv3_gather_run", "fv3_gather_destroy", "fv3_grid_geom", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
-           "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report",
+           "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
@@ -535,6 +535,30 @@ class Context:
         ptrs = (_dp * 8)(*[b.p for b in bufs])
         self.lib.check(self.lib.dll.fv3_halo_unpack(self.h, C.c_int(len(fields)), self._halo_fields(fields), ptrs),
                        "fv3_halo_unpack")
+
+    # -- the exchange behind the C ABI (RCCL owned by the context): what a Fortran host without an RCCL binding uses ----------
+    def comm_init(self, rank: int, nranks: int, unique_id: bytes | None = None) -> bytes:
+        """fv3_comm_init; rank 0 of a one-rank run may leave unique_id out.  Returns the id used."""
+        if unique_id is None:
+            buf = (C.c_ubyte * 128)()
+            self.lib.check(self.lib.dll.fv3_comm_get_unique_id(buf), "fv3_comm_get_unique_id")
+            unique_id = bytes(buf)
+        self.lib.check(self.lib.dll.fv3_comm_init(self.h, C.c_int(rank), C.c_int(nranks), (C.c_ubyte * 128)(*unique_id)),
+                       "fv3_comm_init")
+        return unique_id
+
+    def halo_start(self, fields, to, frm):
+        """start_group_halo_update: to[d] / frm[d] = the ranks at offsets d / -d, halo.DIRECTIONS order"""
+        self.lib.check(self.lib.dll.fv3_halo_start(self.h, C.c_int(len(fields)), self._halo_fields(fields), (C.c_int * 8)(*to),
+                                                   (C.c_int * 8)(*frm)), "fv3_halo_start")
+
+    def halo_complete(self):
+        self.lib.check(self.lib.dll.fv3_halo_complete(self.h), "fv3_halo_complete")
+
+    def allreduce_max(self, a: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.float64).copy()
+        self.lib.check(self.lib.dll.fv3_allreduce_max(self.h, a.ctypes.data_as(_dp), C.c_int(a.size)), "fv3_allreduce_max")
+        return a
 
     def halo_fill_periodic(self, field: DeviceArray, kind: str):
         code = {"A": 0, "U": 1, "V": 2, "B": 3}[kind]

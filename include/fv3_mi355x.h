@@ -195,6 +195,24 @@ int fv3_halo_message_elems(fv3_ctx *ctx, int nfields, const fv3_halo_field *fiel
 int fv3_halo_pack(fv3_ctx *ctx, int nfields, const fv3_halo_field *fields, double *const sendbuf[8]);
 int fv3_halo_unpack(fv3_ctx *ctx, int nfields, const fv3_halo_field *fields, const double *const recvbuf[8]);
 
+/* The transfers behind the C ABI: RCCL peer send / recv on a second HIP stream owned by the context -- what
+ * start_group_halo_update / complete_group_halo_update (tools/fv_mp_mod.F90:646-876) do over FMS / MPI, for hosts (the
+ * Fortran dyn_core) that have no RCCL binding of their own.
+ *   fv3_comm_get_unique_id  on rank 0; the host distributes the 128 bytes with its own means (MPI_Bcast)
+ *   fv3_comm_init           every rank: ncclCommInitRank; librccl.so is loaded at run time, there is no link dependency
+ *   fv3_halo_start          pack kernel, then one grouped send + recv per neighbour offset d on the communication stream
+ *                           (to[d] / from[d]: the ranks at offsets d / -d; a rank may be its own neighbour); kernels launched
+ *                           on the context's stream before fv3_halo_complete overlap the transfers (dyn_core.F90:565-578)
+ *   fv3_halo_complete       the context's stream waits for the transfers, unpack kernel
+ *   fv3_allreduce_max       mp_reduce_max (tools/fv_mp_mod.F90:1683; tracer_2d's cmax, fv_tracer2d.F90:405): n HOST doubles, in place */
+#define FV3_COMM_ID_BYTES 128
+int fv3_comm_get_unique_id(unsigned char *id);
+int fv3_comm_init(fv3_ctx *ctx, int rank, int nranks, const unsigned char *id);
+int fv3_comm_destroy(fv3_ctx *ctx);
+int fv3_halo_start(fv3_ctx *ctx, int nfields, const fv3_halo_field *fields, const int *to, const int *from);
+int fv3_halo_complete(fv3_ctx *ctx);
+int fv3_allreduce_max(fv3_ctx *ctx, double *buf, int n);
+
 /* ---- nonhydrostatic column path --------------------------------------------------------------------
  * Physical constants live in FMS constants_mod (not part of the reference tree); the caller passes them. */
 typedef struct fv3_nh_consts {

@@ -50,7 +50,7 @@ def read_output(path, bd, npz, nq):
     return out
 
 
-def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0):
+def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, host_comm=False):
     """the same initial state through (a) the Python host and (b) the Fortran host: bit-identical states"""
     import parity_common as P
     import parity_dyn as D
@@ -87,9 +87,11 @@ def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_sp
     fin, fout = os.path.join(str(workdir), "in.bin"), os.path.join(str(workdir), "out.bin")
     write_input(fin, bd, npz, nq, n_split, k_split, nsteps, False, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak,
                 bk, st, q)
-    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, **({"FV3_HOST_COMM": "1"} if host_comm else {}))
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "geometry mode 2" in r.stdout, r.stdout
+    assert ("fv3_halo_start" in r.stdout) == bool(host_comm), r.stdout
     got = read_output(fout, bd, npz, nq)
     i0, i1, j0, j1 = bd.is_, bd.ie, bd.js, bd.je
     rng_ = {"u": ("U", i0, i1, j0, j1 + 1), "v": ("V", i0, i1 + 1, j0, j1), "w": ("A", i0, i1, j0, j1),

@@ -440,6 +440,9 @@ def test_fortran_host_drives_the_library(prod, tmp_path):
         pytest.skip("no Fortran compiler in this image")
     out = F.check_fortran_host(prod, tmp_path)
     assert "fv3_solo: done" in out
+    # ... and with every group halo update as RCCL self messages posted by the library (fv3_halo_start / _complete)
+    out = F.check_fortran_host(prod, tmp_path, host_comm=True)
+    assert "fv3_solo: done" in out
 
 
 @pytest.mark.parametrize("use_cond,moist_kappa", [(True, False), (True, True), (False, True)])
@@ -689,3 +692,56 @@ def test_cubed_sphere_faces_on_their_own_streams(prod):
     numbers as on one stream -- nonhydrostatic JW step with tracers on C48 L20 against the six-face oracle"""
     r = PC.check_jw_step(prod, npx=49, npz=20, k_split=2, n_split=2, bdt=900.0, hydrostatic=False, nq=3, face_streams=True)
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
+def test_exchange_behind_the_c_abi_rccl_self_messages(prod):
+    """fv3_comm_init (ncclCommInitRank through the run-time loaded librccl) + fv3_halo_start / fv3_halo_complete: on one GPU
+    every one of the 8 messages of a group is an RCCL send / recv to this same rank on the context's communication stream;
+    halos equal the periodic fill, a substep loop driven through it equals the oracle"""
+    from gfdl_atmos_cubed_sphere_amd.halo import HaloExchanger
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds, periodic_fill
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    bd = Bounds(1, 40, 1, 24)
+    g = P.make_grid(bd, False)
+    ctx = Context(g, 5, lib=prod)
+    try:
+        hx = HaloExchanger(ctx, 1, 1, 0, 1, native=True)
+        rng = np.random.default_rng(2)
+        host = {k: np.asfortranarray(rng.uniform(-1, 1, bd.shape(k, 5))) for k in ("A", "U", "V", "B")}
+        dev = {k: ctx.from_host(v) for k, v in host.items()}
+        for _ in range(3):
+            hx.update([(dev[k], k) for k in ("A", "U", "V", "B")])
+        for k, v in host.items():
+            ref = v.copy(order="F")
+            for n in range(5):
+                periodic_fill(bd, ref[:, :, n], k)
+            assert np.array_equal(dev[k].download(), ref), k
+        assert np.array_equal(ctx.allreduce_max(np.array([3.0, -1.0])), [3.0, -1.0])
+    finally:
+        ctx.close()
+
+
+def test_substeps_through_the_c_abi_exchange(prod):
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynCore, DynFlags
+    from gfdl_atmos_cubed_sphere_amd.halo import HaloExchanger
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    import oracle_dyn_core as OD
+    nx, ny, npz = 40, 24, 8
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    st, dp0 = D.make_state(bd, npz)
+    fl = DynFlags(n_split=2, ptop=N.PTOP)
+    ref = OD.run(g, npz, fl, dp0, st, 4.0)
+    ctx = Context(g, npz, lib=prod)
+    try:
+        dc = DynCore(ctx, fl, dp0, halo=HaloExchanger(ctx, 1, 1, 0, 1, native=True, split_single=True))
+        dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
+        dc.run(4.0)
+        got = dc.get_state()
+        for n, kind, rr in (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)),
+                            ("w", "A", (bd.is_, bd.ie, bd.js, bd.je)), ("delp", "A", (bd.is_, bd.ie, bd.js, bd.je)),
+                            ("pt", "A", (bd.is_, bd.ie, bd.js, bd.je))):
+            P.assert_close(n, bd.view(got[n], kind, *rr), bd.view(ref[n], kind, *rr), 1e-13)
+    finally:
+        ctx.close()

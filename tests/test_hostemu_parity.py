@@ -353,6 +353,9 @@ def test_fortran_host_drives_the_library(emu, tmp_path):
         pytest.skip("no Fortran compiler in this image")
     out = F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=8, nq=1)
     assert "fv3_solo: done" in out
+    # the same with the group halo updates through the exchange behind the C ABI (fv3_halo_start / fv3_halo_complete)
+    out = F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=8, nq=1, host_comm=True)
+    assert "fv3_solo: done" in out
 
 
 @pytest.mark.parametrize("use_cond,moist_kappa", [(True, False), (True, True), (False, True)])
@@ -589,3 +592,39 @@ def test_cubed_hybrid_tracers_and_pressure_gradient(emu):
         N.check_one_grad_p(emu, km=4, grid=gs[t], d_ext=0.0)
     r = PC.check_jw_step(emu, npx=33, npz=20, k_split=1, n_split=2, bdt=900.0, hydrostatic=False, nq=2)
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
+def test_exchange_behind_the_c_abi_single_rank(emu):
+    """fv3_comm_init + fv3_halo_start / fv3_halo_complete (the transfers inside the library; here the host-emulation build's
+    self copies) fill the halos of every field kind like the periodic fill, and a substep loop driven through them equals the
+    oracle"""
+    import numpy as np
+    from gfdl_atmos_cubed_sphere_amd.halo import HaloExchanger
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds, periodic_fill
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    bd = Bounds(1, 14, 1, 9)
+    g = P.make_grid(bd, False)
+    ctx = Context(g, 3, lib=emu)
+    try:
+        hx = HaloExchanger(ctx, 1, 1, 0, 1, native=True)
+        rng = np.random.default_rng(2)
+        host = {k: np.asfortranarray(rng.uniform(-1, 1, bd.shape(k, 3))) for k in ("A", "U", "V", "B")}
+        dev = {k: ctx.from_host(v) for k, v in host.items()}
+        hx.update([(dev[k], k) for k in ("A", "U", "V", "B")])
+        for k, v in host.items():
+            ref = v.copy(order="F")
+            for n in range(3):
+                periodic_fill(bd, ref[:, :, n], k)
+            assert np.array_equal(dev[k].download(), ref), k
+        # several groups (> 8 fields) and the deferred start / finish protocol of the overlapped d_sw
+        many = [(ctx.from_host(host["A"]), "A") for _ in range(11)]
+        pend = hx.start(many, defer=True)
+        hx.post(pend)
+        hx.finish(pend)
+        ref = host["A"].copy(order="F")
+        for n in range(3):
+            periodic_fill(bd, ref[:, :, n], "A")
+        assert all(np.array_equal(f.download(), ref) for f, _ in many)
+        assert np.array_equal(ctx.allreduce_max(np.array([1.0, -2.0])), [1.0, -2.0])
+    finally:
+        ctx.close()
