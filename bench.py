@@ -274,33 +274,71 @@ def cubed_sphere_leg(a, torch, stream):
                             "launches": {k: [v[0], round(v[1], 4)] for k, v in rep.items()}}
     ctx.close()
     del d
-    # ---- (2) whole model steps on the sphere
+    # ---- (2) whole model steps on the sphere: BASELINE configs[2] at the bench size, then configs[1] (C96 L79 hydrostatic)
+    out["sphere_one_gpu"], out["sphere_one_gpu_kernels_ms_per_dt_atmos"] = sphere_steps(
+        torch, stream, cs, gs, nx, npz, hydrostatic=False, k_split=2, n_split=5, dt_atmos=225.0, nrep=2)
+    try:
+        cs2 = CubedSphere(97)
+        out["config2_c96_l79_hydrostatic"], _ = sphere_steps(torch, stream, cs2, [cs2.gridstruct(t) for t in range(6)], 96, 79,
+                                                           hydrostatic=True, k_split=2, n_split=6, dt_atmos=1800.0, nrep=5)
+    except Exception as e:  # noqa: BLE001
+        out["config2_c96_l79_hydrostatic"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def sphere_steps(torch, stream, cs, gs, nx, npz, hydrostatic, k_split, n_split, dt_atmos, nrep):
+    """whole fv_dynamics steps of the Jablonowski-Williamson wave on six faces held by this one GPU -> (summary, kernel ms)"""
+    from gfdl_atmos_cubed_sphere_amd import lib as L
+    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.test_cases import jablonowski_williamson, set_eta
+    npx = nx + 1
+    cells = nx * nx * npz
+    bd = gs[0].bd
     ak, bk, _, _ = set_eta(npz) if npz in (79, 127) else (None, None, None, None)
     if ak is None:
         sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
         ak, bk = 300.0 * (1.0 - sig), sig.copy()
-    st = jablonowski_williamson(cs, ak, bk, hydrostatic=False)
+    st = jablonowski_williamson(cs, ak, bk, hydrostatic=hydrostatic)
     cs.topo.update("A", [s_["phis"] for s_ in st])
-    fl = DynFlags(n_split=5, hydrostatic=False, ptop=float(ak[0]))
+    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, ptop=float(ak[0]), **(dict(d_ext=0.0) if hydrostatic else {}))
     ng = bd.ng
     c = (slice(ng, ng + nx), slice(ng, ng + nx))
-    for s_ in st:      # T -> theta_v with the nonhydrostatic pkz (fv_dynamics.F90:385-394)
-        s_["pt"][c] = s_["pt"][c] / ((-fl.rdgas / fl.grav) * s_["delp"][c] * s_["pt"][c] / s_["delz"]) ** fl.akap
+    for s_ in st:      # T -> theta_v (fv_dynamics.F90:323-329 hydrostatic pkz, :385-394 nonhydrostatic pkz)
+        if hydrostatic:
+            pe = ak[0] + np.concatenate([np.zeros(s_["delp"].shape[:2] + (1,)), np.cumsum(s_["delp"], axis=2)], axis=2)[c]
+            peln = np.log(pe)
+            pkz = (pe[:, :, 1:] ** fl.akap - pe[:, :, :-1] ** fl.akap) / (fl.akap * (peln[:, :, 1:] - peln[:, :, :-1]))
+        else:
+            pkz = ((-fl.rdgas / fl.grav) * s_["delp"][c] * s_["pt"][c] / s_["delz"]) ** fl.akap
+        s_["pt"][c] = s_["pt"][c] / pkz
     # a stream per face: the launches of different faces overlap on the GPU (the column solvers of one face are 2 300
     # wavefronts, a quarter of what the chip holds), the halo gathers join and fork them (cubed_halo.CubeHalo)
-    fstreams = [stream] + [torch.cuda.Stream() for _ in range(5)] if os.environ.get("FV3_BENCH_FACE_STREAMS", "1") == "1" else [stream] * 6
+    fstreams = [torch.cuda.Stream() for _ in range(6)] if os.environ.get("FV3_BENCH_FACE_STREAMS", "1") == "1" else [stream] * 6
     mctx = MultiContext([L.Context(g, npz, stream=fs.cuda_stream) for g, fs in zip(gs, fstreams)])
-    k_split, dt_atmos = 2, 225.0
     fv = FvDynamics(mctx, fl, ak, bk, nq=0, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
-    fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], [s_["w"] for s_ in st], [s_["delp"] for s_ in st],
-                    [s_["pt"] for s_ in st], [s_["delz"] for s_ in st], [s_["phis"] for s_ in st])
+    zero = np.zeros_like(st[0]["delp"])
+    fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], [s_.get("w", zero) for s_ in st], [s_["delp"] for s_ in st],
+                    [s_["pt"] for s_ in st], [s_.get("delz", bd.zeros("CC", npz)) for s_ in st], [s_["phis"] for s_ in st])
     del st
     fv.step(dt_atmos)
     torch.cuda.synchronize()
-    nrep = 2
+    # the launch-bound small grids: replay the step as one HIP graph (cubed_dyn.StepGraph); eager if capture is refused
+    graph, graph_note = None, "eager launches"
+    if os.environ.get("FV3_BENCH_GRAPH", "1") == "1" and fstreams[0] is not stream:
+        try:
+            from gfdl_atmos_cubed_sphere_amd.cubed_dyn import StepGraph
+            graph = StepGraph(fv, dt_atmos, fstreams)
+            graph.replay()
+            torch.cuda.synchronize()
+            graph_note = "one HIP graph per dt_atmos (hipStreamBeginCapture over the six face streams)"
+        except Exception as e:  # noqa: BLE001
+            graph, graph_note = None, f"eager launches (graph capture refused: {type(e).__name__}: {e})"
+    step = graph.replay if graph else (lambda: fv.step(dt_atmos))
     t0 = time.perf_counter()
     for _ in range(nrep):
-        fv.step(dt_atmos)
+        step()
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / nrep
     dp = fv.dc.d["delp"].download()
@@ -312,14 +350,15 @@ def cubed_sphere_leg(a, torch, stream):
     for rep in reps:
         for k_, v in rep.items():
             kern[k_] = kern.get(k_, 0.0) + v[1]
-    out["sphere_one_gpu_kernels_ms_per_dt_atmos"] = {k_: round(v, 2) for k_, v in sorted(kern.items(), key=lambda kv: -kv[1])}
-    out["sphere_one_gpu"] = {"sypd": dt_atmos / (365.0 * wall), "wall_s_per_dt_atmos": wall, "dt_atmos_s": dt_atmos, "k_split": k_split,
-                             "n_split": fl.n_split, "nq": 0, "cells": 6 * cells, "finite": bool(all(np.isfinite(x[c]).all() for x in dp)),
-                             "initial_condition": "test_case 13 (Jablonowski-Williamson), nonhydrostatic",
-                             "note": "all six faces on ONE MI355X (six contexts, device-gather halo updates); one face per GPU "
-                                     "is the driver's multi-GPU business"}
+    kernels = {k_: round(v, 2) for k_, v in sorted(kern.items(), key=lambda kv: -kv[1])}
+    summary = {"grid": f"C{nx} L{npz}", "sypd": dt_atmos / (365.0 * wall), "wall_s_per_dt_atmos": wall, "dt_atmos_s": dt_atmos,
+               "k_split": k_split, "n_split": fl.n_split, "nq": 0, "cells": 6 * cells, "launch": graph_note,
+               "finite": bool(all(np.isfinite(x[c]).all() for x in dp)),
+               "initial_condition": "test_case 13 (Jablonowski-Williamson), " + ("hydrostatic" if hydrostatic else "nonhydrostatic"),
+               "note": "all six faces on ONE MI355X (six contexts, a HIP stream per face, device-gather halo updates); one face per "
+                       "GPU is the driver's multi-GPU business"}
     mctx.close()
-    return out
+    return summary, kernels
 
 
 def main():

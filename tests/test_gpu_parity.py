@@ -745,3 +745,11 @@ def test_substeps_through_the_c_abi_exchange(prod):
             P.assert_close(n, bd.view(got[n], kind, *rr), bd.view(ref[n], kind, *rr), 1e-13)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("hydrostatic", [True, False])
+def test_cubed_sphere_step_as_a_hip_graph(prod, hydrostatic):
+    """the whole dt_atmos of the six faces captured once (hipStreamBeginCapture over the six face streams) and replayed: the
+    numbers of the eager launches -- < 1e-12 against the six-face oracle"""
+    r = PC.check_jw_step(prod, npx=25, npz=20, k_split=2, n_split=2, bdt=900.0, hydrostatic=hydrostatic, face_streams=True, graph=True)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
