@@ -182,6 +182,7 @@ class StepGraph:
         if (fv.k_split * fv.fl.n_split) % 2:
             raise ValueError("StepGraph: k_split * n_split must be even")
         self.graph = torch.cuda.CUDAGraph()
+        self.streams = list(streams)
         s0 = streams[0]
         torch.cuda.synchronize()
         with torch.cuda.graph(self.graph, stream=s0):
@@ -196,4 +197,14 @@ class StepGraph:
                 s0.wait_event(e)
 
     def replay(self):
-        self.graph.replay()
+        """launch the graph on face 1's stream and order the other faces' streams behind it, so that whatever the host does next
+        on any face (a download, an eager kernel) sees the step finished"""
+        import torch
+        s0 = self.streams[0]
+        with torch.cuda.stream(s0):
+            self.graph.replay()
+        ev = torch.cuda.Event()
+        ev.record(s0)
+        for st in self.streams[1:]:
+            if st is not s0:
+                st.wait_event(ev)
