@@ -1,16 +1,17 @@
 !> Fortran host orchestration over the C ABI of libfv3_mi355x.so (include/fv3_mi355x.h): the counterparts of
-!> dyn_core (model/dyn_core.F90:94-1393, nonhydrostatic branch, non-nested, grid_type = 4), of tracer_2d's host part
+!> dyn_core (model/dyn_core.F90:94-1393, nonhydrostatic and hydrostatic branches, d_con heating, non-nested, grid_type = 4), of tracer_2d's host part
 !> (model/fv_tracer2d.F90:382-417, :466-541) and of the k_split loop of fv_dynamics (model/fv_dynamics.F90:460-665),
 !> written the way a maintainer would rewrite those routines around the kernels: the same order of calls and halo
 !> updates (cited line by line), every field device resident (type(c_ptr) handles from fv3_malloc), the fields that
 !> d_sw / update_dz_d / tracer_2d update in place in the reference held as ping-pong pairs.
 !>
-!> One rank of a doubly periodic domain: the group halo updates are fv3_halo_fill_periodic.  On several ranks the same
-!> places call fv3_halo_pack / the peer exchange / fv3_halo_unpack (see INTEGRATION.md); the Python host in
-!> gfdl_atmos_cubed_sphere_amd/halo.py is that exchange over RCCL.
+!> One rank of a doubly periodic domain: the group halo updates are fv3_halo_fill_periodic, or (FV3_HOST_COMM=1) the
+!> exchange behind the C ABI, fv3_halo_start / fv3_halo_complete over the context's RCCL communicator -- the form a
+!> several-rank run uses with the neighbour ranks in to / from (see INTEGRATION.md).
 !>
 !> Not reproduced (off in every BASELINE config): nesting / regional BCs, breed_vortex_inline, do_fast_phys, Ray_fast,
-!> beta > 0 (split_p_grad), the hydrostatic branch (the Python host has it), d_con heating.
+!> beta > 0 (split_p_grad).  The argument lists are this module's own (type fv3_atmos holds the device handles the
+!> reference keeps in fv_atmos_type / dyn_core's work arrays); INTEGRATION.md maps them to the reference's call sites.
 module fv3_host_mod
   use iso_c_binding
   use fv3_mi355x_mod
@@ -18,7 +19,7 @@ module fv3_host_mod
   private
   public :: fv3_flags, fv3_atmos
   public :: fv3_host_init, fv3_host_final, fv3_host_upload, fv3_host_download
-  public :: fv3_dyn_core, fv3_tracer_2d, fv3_fv_dynamics
+  public :: fv3_dyn_core, fv3_dyn_core_hydrostatic, fv3_tracer_2d, fv3_fv_dynamics
 
   integer(c_int), parameter :: KIND_A = 0, KIND_U = 1, KIND_V = 2, KIND_B = 3
   integer, parameter :: NG = 3
@@ -40,6 +41,9 @@ module fv3_host_mod
     real(c_double) :: grav = 9.80d0, rdgas = 287.04d0, akap = 2.d0/7.d0, cp_air = 287.04d0/(2.d0/7.d0)   ! constants_mod
     real(c_double) :: r_vir = 0.6077d0, t_min = 184.d0
     logical :: adiabatic = .true., fill = .false.
+    logical :: hydrostatic = .false.                  ! fv_arrays.F90:366
+    real(c_double) :: d_ext = 0.02d0, delt_max = 1.d0 ! :452, :441
+    logical :: convert_ke = .false.
   end type
 
   !> device-resident state and work arrays of one rank (fv_atmos_type members + dyn_core.F90:256-283)
@@ -49,12 +53,14 @@ module fv3_host_mod
     integer :: is, ie, js, je, isd, ied, jsd, jed, npz, nq, nx, ny
     integer(c_size_t) :: nA, nU, nV, nB, nCC, nCX, nCY, nFX, nFY
     type(fv3_nh_consts) :: cn
+    real(c_double) :: da_min = 0.d0
     ! prognostic fields and their ping-pong partners
     type(c_ptr) :: u, v, w, delp, pt, u_n, v_n, w_n, delp_n, pt_n
     type(c_ptr) :: delz, phis, zs, q, q_n, dp1, dp1_n
     ! work arrays
     type(c_ptr) :: delpc, ptc, uc, vc, ua, va, omga, ut, vt, divgd, gz, pkc, zh, zh_n, pk3
     type(c_ptr) :: crx, xfx, cry, yfx, mfx, mfy, cx, cy, heat_s, diss_e, pk, ws3, ws, pe, peln, ps, pkz
+    type(c_ptr) :: divg2, heat_source                 ! external-mode damping field (A), accumulated heat source (A x npz)
     real(c_double), allocatable :: ak(:), bk(:)
   end type
 
@@ -161,6 +167,7 @@ contains
     m_area = dx_const * dy_const; m_rarea = 1.d0 / (dx_const * dy_const)
     m_one = 1.d0; m_zero = 0.d0; m_f0 = f0_const; m_sg = 1.d0; m_cg = 0.d0
     gh%da_min = dx_const * dy_const; gh%da_min_c = dx_const * dy_const
+    at%da_min = gh%da_min
     gh%area = c_loc(m_area);   gh%rarea = c_loc(m_rarea)
     gh%dxa = c_loc(m_dx);      gh%dya = c_loc(m_dy);     gh%rdxa = c_loc(m_rdx);  gh%rdya = c_loc(m_rdy)
     gh%cosa_s = c_loc(m_zero); gh%rsin2 = c_loc(m_one);  gh%f0 = c_loc(m_f0)
@@ -200,6 +207,8 @@ contains
     call dmalloc(at%ws3, at%nA);      call dmalloc(at%ws, at%nCC)
     call dmalloc(at%pe, int(nx+2, c_size_t)*nk1*(ny+2));  call dmalloc(at%peln, int(nx, c_size_t)*nk1*ny)
     call dmalloc(at%ps, at%nA);       call dmalloc(at%pkz, at%nCC*nk)
+    call dmalloc(at%divg2, at%nA);    call dmalloc(at%heat_source, at%nA*nk)
+    call dzero(at, at%divg2, at%nA);  call dzero(at, at%heat_source, at%nA*nk); call dzero(at, at%pkz, at%nCC*nk)
     call dmalloc(at%dp1, at%nA*nk);   call dmalloc(at%dp1_n, at%nA*nk)
     at%q = c_null_ptr; at%q_n = c_null_ptr
     if (nq > 0) then
@@ -351,11 +360,19 @@ contains
     logical :: remap_step
     integer(c_int) :: last_call, use_logp
     type(c_ptr) :: ctx
+    logical :: heating
+    integer :: n_con
+    if (at%fl%hydrostatic) then
+      call fv3_dyn_core_hydrostatic(at, bdt)
+      return
+    end if
     ctx = at%ctx; npz = at%npz
     n_split = at%fl%n_split
     dt = bdt / real(n_split, c_double)
     dt2 = 0.5d0 * dt
     rdt = 1.d0 / dt
+    heating = at%fl%d_con > 1.d-5                                         ! dyn_core.F90:294
+    if (heating) call dzero(at, at%heat_source, at%nA*npz)
     ptk = at%fl%ptop ** at%fl%akap                                        ! dyn_core.F90:222
     peln1 = log(at%fl%ptop)
     use_logp = merge(1_c_int, 0_c_int, at%fl%use_logp)
@@ -387,6 +404,7 @@ contains
       call fv3_check(fv3_d_sw(ctx, par, at%vt, at%delp, at%pt, at%u, at%v, at%w, at%uc, at%vc, at%ua, at%va, at%divgd, &
                               at%mfx, at%mfy, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
                               at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, c_null_ptr, at%heat_s, at%diss_e), 'd_sw')  ! :762
+      if (heating) call fv3_check(fv3_heat_source_accum(ctx, at%heat_source, at%heat_s), 'heat_source_accum')   ! :798-803
       call swap(at%delp, at%delp_n); call swap(at%pt, at%pt_n)
       call swap(at%u, at%u_n); call swap(at%v, at%v_n); call swap(at%w, at%w_n)
       call halo(at, at%delp, KIND_A, npz); call halo(at, at%pt, KIND_A, npz)              ! :823-824 / :851 (pack 1)
@@ -407,6 +425,93 @@ contains
         call fv3_check(fv3_omga_update(ctx, rdt, at%fl%ptop, at%pe, at%delp_n, at%omga), 'omga_update')
       end if
     end do
+    ! dissipative heating (:296-308, :1300-1355)
+    n_con = host_n_con(at%fl, npz)
+    if (n_con /= 0 .and. heating) then
+      call halo(at, at%heat_source, KIND_A, npz)                                          ! del2_cubed's mpp_update_domains, :2399
+      call fv3_check(fv3_del2_cubed(ctx, at%heat_source, int(npz, c_int), 0.20d0 * at%da_min, &
+                                    int(min(3, at%fl%nord + 1), c_int)), 'del2_cubed')     ! :1301-1303
+      call fv3_check(fv3_apply_heat_source(ctx, int(n_con, c_int), 0_c_int, bdt, at%fl%delt_max, at%fl%cp_air, &
+                                           at%fl%cp_air - at%fl%rdgas, at%fl%rdgas, at%fl%grav, at%pt, at%heat_source, &
+                                           at%delp, at%delz, at%pkz), 'apply_heat_source')
+    end if
+  end subroutine
+
+  !> number of levels that receive the dissipative heating (dyn_core.F90:296-308)
+  integer function host_n_con(fl, npz) result(n_con)
+    type(fv3_flags), intent(in) :: fl
+    integer, intent(in) :: npz
+    if (fl%convert_ke .or. (fl%do_vort_damp .and. fl%vtdm4 > 1.d-4)) then
+      n_con = npz
+    else if (fl%d2_bg_k1 < 1.d-3) then
+      n_con = 0
+    else if (fl%d2_bg_k2 < 1.d-3) then
+      n_con = 1
+    else
+      n_con = 2
+    end if
+  end function
+
+  !> the substep loop with hydrostatic = .true., beta = 0 (dyn_core.F90:313-1286): geopk on the C and D grids (:480-482,
+  !> :905-907), p_grad_c (:562), the external-mode damping field (:745-747, :791-848), pk = pkc on the last substep
+  !> (:1001-1010), one_grad_p (:1021); the heating of pt afterwards with the hydrostatic pkz
+  subroutine fv3_dyn_core_hydrostatic(at, bdt)
+    type(fv3_atmos), intent(inout) :: at
+    real(c_double), intent(in) :: bdt
+    type(fv3_dsw_params) :: par
+    real(c_double) :: dt, dt2, ptk
+    integer :: it, n_split, npz, n_con
+    logical :: heating
+    type(c_ptr) :: ctx, dv2
+    ctx = at%ctx; npz = at%npz
+    n_split = at%fl%n_split
+    dt = bdt / real(n_split, c_double)
+    dt2 = 0.5d0 * dt
+    ptk = at%fl%ptop ** at%fl%akap
+    heating = at%fl%d_con > 1.d-5
+    call dzero(at, at%mfx, at%nFX*npz); call dzero(at, at%mfy, at%nFY*npz)
+    call dzero(at, at%cx, at%nCX*npz);  call dzero(at, at%cy, at%nCY*npz)
+    if (heating) call dzero(at, at%heat_source, at%nA*npz)
+    par%dt = dt; par%hord_tr = at%fl%hord_tr; par%hord_mt = at%fl%hord_mt; par%hord_vt = at%fl%hord_vt
+    par%hord_tm = at%fl%hord_tm; par%hord_dp = at%fl%hord_dp; par%dddmp = at%fl%dddmp; par%d4_bg = at%fl%d4_bg
+    par%kgb = at%fl%ke_bg; par%hydrostatic = 1; par%use_cond = 0
+    dv2 = c_null_ptr
+    if (at%fl%d_ext > 0.d0) dv2 = at%divg2
+    call halo(at, at%delp, KIND_A, npz); call halo(at, at%pt, KIND_A, npz)
+    call halo(at, at%u, KIND_U, npz);    call halo(at, at%v, KIND_V, npz)
+    do it = 1, n_split
+      call fv3_check(fv3_c_sw(ctx, at%delpc, at%delp, at%ptc, at%pt, at%u, at%v, c_null_ptr, at%uc, at%vc, at%ua, at%va, &
+                              c_null_ptr, at%ut, at%vt, at%divgd, int(at%fl%nord, c_int), dt2, 1_c_int, 1_c_int), 'c_sw')
+      if (at%fl%nord > 0) call halo(at, at%divgd, KIND_B, npz)
+      call fv3_check(fv3_geopk(ctx, at%fl%ptop, at%fl%akap, at%fl%cp_air, ptk, at%pe, at%peln, at%delpc, at%pkc, at%gz, &
+                               at%phis, at%ptc, at%pkz, 1_c_int), 'geopk (C grid)')
+      call fv3_check(fv3_p_grad_c(ctx, dt2, at%delpc, at%pkc, at%gz, at%uc, at%vc, 1_c_int), 'p_grad_c')
+      call halo(at, at%uc, KIND_V, npz); call halo(at, at%vc, KIND_U, npz)
+      call fv3_check(fv3_d_sw(ctx, par, at%vt, at%delp, at%pt, at%u, at%v, c_null_ptr, at%uc, at%vc, at%ua, at%va, at%divgd, &
+                              at%mfx, at%mfy, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
+                              at%delp_n, at%pt_n, at%u_n, at%v_n, c_null_ptr, c_null_ptr, at%heat_s, at%diss_e), 'd_sw')
+      if (heating) call fv3_check(fv3_heat_source_accum(ctx, at%heat_source, at%heat_s), 'heat_source_accum')
+      ! the external-mode damping field from the delp BEFORE d_sw (:745-747) and d_sw's divergence output (:791-848)
+      call fv3_check(fv3_divg2_ext(ctx, at%fl%d_ext, at%delp, at%vt, at%divg2), 'divg2_ext')
+      call swap(at%delp, at%delp_n); call swap(at%pt, at%pt_n); call swap(at%u, at%u_n); call swap(at%v, at%v_n)
+      call halo(at, at%delp, KIND_A, npz); call halo(at, at%pt, KIND_A, npz)
+      call fv3_check(fv3_geopk(ctx, at%fl%ptop, at%fl%akap, at%fl%cp_air, ptk, at%pe, at%peln, at%delp, at%pkc, at%gz, &
+                               at%phis, at%pt, at%pkz, 0_c_int), 'geopk')
+      if (it == n_split) call fv3_check(fv3_copy_a_to_cc(ctx, at%pkc, at%pk, int(npz + 1, c_int)), 'pk = pkc')
+      call fv3_check(fv3_one_grad_p(ctx, at%u, at%v, at%pkc, at%gz, dv2, dt, ptk), 'one_grad_p')
+      if (it /= n_split) then
+        call halo(at, at%u, KIND_U, npz); call halo(at, at%v, KIND_V, npz)
+      end if
+    end do
+    n_con = host_n_con(at%fl, npz)
+    if (n_con /= 0 .and. heating) then
+      call halo(at, at%heat_source, KIND_A, npz)
+      call fv3_check(fv3_del2_cubed(ctx, at%heat_source, int(npz, c_int), 0.20d0 * at%da_min, &
+                                    int(min(3, at%fl%nord + 1), c_int)), 'del2_cubed')
+      call fv3_check(fv3_apply_heat_source(ctx, int(n_con, c_int), 1_c_int, bdt, at%fl%delt_max, at%fl%cp_air, &
+                                           at%fl%cp_air - at%fl%rdgas, at%fl%rdgas, at%fl%grav, at%pt, at%heat_source, &
+                                           at%delp, c_null_ptr, at%pkz), 'apply_heat_source')
+    end if
   end subroutine
 
   !> tracer_2d (fv_tracer2d.F90:297-557): the host keeps the part with the cross-rank reduction and the integer
@@ -464,7 +569,7 @@ contains
     integer :: n_map
     mdt = bdt / real(at%fl%k_split, c_double)
     allocate(kord_tr(max(1, at%nq))); kord_tr = int(at%fl%kord_tr, c_int)
-    rp%hydrostatic = 0; rp%adiabatic = merge(1_c_int, 0_c_int, at%fl%adiabatic); rp%nq = int(at%nq, c_int)
+    rp%hydrostatic = merge(1_c_int, 0_c_int, at%fl%hydrostatic); rp%adiabatic = merge(1_c_int, 0_c_int, at%fl%adiabatic); rp%nq = int(at%nq, c_int)
     rp%kord_mt = int(at%fl%kord_mt, c_int); rp%kord_wz = int(at%fl%kord_wz, c_int); rp%kord_tm = int(at%fl%kord_tm, c_int)
     rp%sphum = merge(1_c_int, 0_c_int, at%nq > 0); rp%fill = merge(1_c_int, 0_c_int, at%fl%fill)
     rp%akap = at%fl%akap; rp%ptop = at%fl%ptop; rp%rdgas = at%fl%rdgas; rp%grav = at%fl%grav
@@ -474,9 +579,15 @@ contains
       call fv3_dyn_core(at, mdt)                                                                           ! :493
       if (at%nq > 0) call fv3_tracer_2d(at)                                                                ! :500-533
       rp%last_step = merge(1_c_int, 0_c_int, last_step .and. n_map == at%fl%k_split)
-      call fv3_check(fv3_lagrangian_to_eulerian(at%ctx, rp, kord_tr, at%ps, at%pe, at%delp, at%pkz, at%pk, at%u, at%v, &
-                                                at%w, at%delz, at%pt, at%q, at%peln, at%omga, at%ws), &
-                     'lagrangian_to_eulerian')                                                             ! :607
+      if (at%fl%hydrostatic) then
+        call fv3_check(fv3_lagrangian_to_eulerian(at%ctx, rp, kord_tr, at%ps, at%pe, at%delp, at%pkz, at%pk, at%u, at%v, &
+                                                  c_null_ptr, c_null_ptr, at%pt, at%q, at%peln, at%omga, c_null_ptr), &
+                       'lagrangian_to_eulerian')
+      else
+        call fv3_check(fv3_lagrangian_to_eulerian(at%ctx, rp, kord_tr, at%ps, at%pe, at%delp, at%pkz, at%pk, at%u, at%v, &
+                                                  at%w, at%delz, at%pt, at%q, at%peln, at%omga, at%ws), &
+                       'lagrangian_to_eulerian')                                                           ! :607
+      end if
     end do
   end subroutine
 

@@ -26,10 +26,11 @@ def build_solo(workdir, libdir=CSRC, libname="fv3_mi355x"):
     return exe
 
 
-def write_input(path, bd, npz, nq, n_split, k_split, nsteps, last_step, dx, dy, f0, bdt, ptop, ak, bk, st, q):
+def write_input(path, bd, npz, nq, n_split, k_split, nsteps, last_step, dx, dy, f0, bdt, ptop, ak, bk, st, q, hydrostatic=False,
+                d_con=0.0, d_ext=0.02):
     with open(path, "wb") as f:
-        np.array([bd.nx, bd.ny, npz, nq, n_split, k_split, nsteps, int(last_step)], dtype=np.int32).tofile(f)
-        np.array([dx, dy, f0, bdt, ptop], dtype=np.float64).tofile(f)
+        np.array([bd.nx, bd.ny, npz, nq, n_split, k_split, nsteps, int(last_step), int(hydrostatic)], dtype=np.int32).tofile(f)
+        np.array([dx, dy, f0, bdt, ptop, d_con, d_ext], dtype=np.float64).tofile(f)
         np.asarray(ak, dtype=np.float64).tofile(f)
         np.asarray(bk, dtype=np.float64).tofile(f)
         for n in ("u", "v", "w", "delp", "pt", "delz", "phis"):
@@ -50,7 +51,8 @@ def read_output(path, bd, npz, nq):
     return out
 
 
-def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, host_comm=False):
+def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, host_comm=False,
+                       hydrostatic=False, d_con=0.0):
     """the same initial state through (a) the Python host and (b) the Fortran host: bit-identical states"""
     import parity_common as P
     import parity_dyn as D
@@ -66,7 +68,7 @@ def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_sp
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
     rng = np.random.default_rng(5)
     q = np.asfortranarray(rng.uniform(0.0, 1.0, bd.shape("A", npz) + (nq,))) if nq else None
-    fl = DynFlags(n_split=n_split, ptop=N.PTOP)
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, d_con=d_con)
     # ---- (a) Python host ----
     ctx = Context(g, npz, lib=lib)
     try:
@@ -77,7 +79,7 @@ def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_sp
         for _ in range(nsteps):
             fv.step(bdt)
         d = fv.dc.d
-        ref = {n: d[n].download() for n in ("u", "v", "w", "delp", "pt", "delz")}
+        ref = {n: d[n].download() for n in (("u", "v", "delp", "pt") if hydrostatic else ("u", "v", "w", "delp", "pt", "delz"))}
         if nq:
             ref["q"] = d["q"].download()
     finally:
@@ -86,7 +88,7 @@ def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_sp
     exe = build_solo(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
     fin, fout = os.path.join(str(workdir), "in.bin"), os.path.join(str(workdir), "out.bin")
     write_input(fin, bd, npz, nq, n_split, k_split, nsteps, False, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak,
-                bk, st, q)
+                bk, st, q, hydrostatic=hydrostatic, d_con=d_con, d_ext=fl.d_ext)
     env = dict(os.environ, **({"FV3_HOST_COMM": "1"} if host_comm else {}))
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -443,6 +443,9 @@ def test_fortran_host_drives_the_library(prod, tmp_path):
     # ... and with every group halo update as RCCL self messages posted by the library (fv3_halo_start / _complete)
     out = F.check_fortran_host(prod, tmp_path, host_comm=True)
     assert "fv3_solo: done" in out
+    # the hydrostatic branch and the dissipative heating of both branches
+    assert "fv3_solo: done" in F.check_fortran_host(prod, tmp_path, npz=12, nq=1, hydrostatic=True, d_con=1.0)
+    assert "fv3_solo: done" in F.check_fortran_host(prod, tmp_path, npz=12, nq=0, hydrostatic=False, d_con=1.0)
 
 
 @pytest.mark.parametrize("use_cond,moist_kappa", [(True, False), (True, True), (False, True)])

@@ -356,6 +356,10 @@ def test_fortran_host_drives_the_library(emu, tmp_path):
     # the same with the group halo updates through the exchange behind the C ABI (fv3_halo_start / fv3_halo_complete)
     out = F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=8, nq=1, host_comm=True)
     assert "fv3_solo: done" in out
+    # the hydrostatic branch of dyn_core (geopk, external-mode damping, one_grad_p) and the dissipative heating of both branches
+    assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=12, nq=1, hydrostatic=True)
+    assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=12, nq=1, hydrostatic=True, d_con=1.0)
+    assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=12, nq=0, hydrostatic=False, d_con=1.0)
 
 
 @pytest.mark.parametrize("use_cond,moist_kappa", [(True, False), (True, True), (False, True)])
