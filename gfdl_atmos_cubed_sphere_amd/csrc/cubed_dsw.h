@@ -22,6 +22,11 @@ struct DswCubedState {
   double *ke;              // B layout
   double *wk;              // A layout: relative vorticity, then absolute vorticity
   double *dd, *svc, *suc;  // divergence damping work arrays (B, U, V layouts)
+  // del-2n damping and dissipative heating (cubed_damp.h; null when no level asks for them)
+  double *wfx2 = nullptr, *wfy2 = nullptr;   // del6_vt_flux of w (V / U layouts), levels with nord_w > 0
+  double *dfx2 = nullptr, *dfy2 = nullptr;   // del6_vt_flux of the relative vorticity: "ut", "vt" of sw_core.F90:1513-1515
+  double *vortv = nullptr;                   // the damping term added to ke (B layout), kept for the heating (:1462-1473)
+  double *smag = nullptr;                    // a2b_ord4 of the relative vorticity (B values on the A layout), dddmp > 0
   // hybrid: the passes that write the outputs of d_sw only write the points of the frame of width own_w along the face edges
   // (0: every point); the marching kernels own the rest (DswArgs::mask_w)
   int own_w;
@@ -214,10 +219,16 @@ struct DswCubedD4 {
         const double damp_w = s.a.lv.damp_w[k];
         if (damp_w > 1.E-5) {  // del-2 damping of w on the sponge levels (nord_w = 0): :950-982, del6_vt_flux :1640-1672
           const double damp4 = ipow(damp_w * g.da_min_c, s.a.lv.nord_w[k] + 1), dd8 = s.a.kgb * fabs(s.a.dt);
-          const double d0 = damp4 * w0;
-          const double fx0 = g.del6_v[g.iV(i, j)] * (damp4 * w(i - 1, j, k) - d0), fx1 = g.del6_v[g.iV(i + 1, j)] * (d0 - damp4 * w(i + 1, j, k));
-          const double fy0 = g.del6_u[g.iU(i, j)] * (damp4 * w(i, j - 1, k) - d0), fy1 = g.del6_u[g.iU(i, j + 1)] * (d0 - damp4 * w(i, j + 1, k));
-          const double dw = (fx0 - fx1 + fy0 - fy1) * ra;
+          double dw;
+          if (s.a.lv.nord_w[k] > 0) {  // the fluxes of the del-2n passes
+            const CA fx2 = cview_V(g, s.wfx2), fy2 = cview_U(g, s.wfy2);
+            dw = (fx2(i, j, k) - fx2(i + 1, j, k) + fy2(i, j, k) - fy2(i, j + 1, k)) * ra;
+          } else {
+            const double d0 = damp4 * w0;
+            const double fx0 = g.del6_v[g.iV(i, j)] * (damp4 * w(i - 1, j, k) - d0), fx1 = g.del6_v[g.iV(i + 1, j)] * (d0 - damp4 * w(i + 1, j, k));
+            const double fy0 = g.del6_u[g.iU(i, j)] * (damp4 * w(i, j - 1, k) - d0), fy1 = g.del6_u[g.iU(i, j + 1)] * (d0 - damp4 * w(i, j + 1, k));
+            dw = (fx0 - fx1 + fy0 - fy1) * ra;
+          }
           const double tmp = dw * (w0 + 0.5 * dw);
           heat = g.prevent_diss_cooling ? dd8 - dmin(0., tmp) : dd8 - tmp;
           wn = wn + dw;
@@ -565,10 +576,16 @@ struct DswCubedD7 {
       delpc = cview_B(g, s.a.divg_d)(i, j, k);
       const int n2 = nord + 1;
       const double dd8 = g.stretched_grid ? g.da_min * ipow(s.a.d4_bg, n2) : ipow(g.da_min_c * s.a.d4_bg, n2);
-      const double damp2 = g.da_min_c * dmax(d2_bg, dmin(0.20, s.a.dddmp * 0.));  // dddmp < 1e-5 here: vort = 0 (:1428-1429)
+      double vs = 0.;  // dddmp < 1e-5: vort = 0 (:1428-1429); else the Smagorinsky deformation (:1431-1440)
+      if (!(s.a.dddmp < 1.E-5)) {
+        const double vb = cview_A(g, s.smag)(i, j, k);
+        vs = fabs(dt) * sqrt(delpc * delpc + vb * vb);
+      }
+      const double damp2 = g.da_min_c * dmax(d2_bg, dmin(0.20, s.a.dddmp * vs));
       vortv = damp2 * delpc + dd8 * cview_B(g, s.dd)(i, j, k);
     }
     if (s.a.delpc && s.own(i, j)) view_A(g, s.a.delpc)(i, j, k) = delpc;
+    if (s.vortv) view_B(g, s.vortv)(i, j, k) = vortv;
     double &kev = view_B(g, s.ke)(i, j, k);
     kev = kev + vortv;
   }
@@ -595,6 +612,59 @@ struct DswCubedD9 {
       view_U(g, s.a.u_out)(i, j, k) = u(i, j, k) * g.dx[g.iU(i, j)] + ke(i, j, k) - ke(i + 1, j, k) + cview_FY(g, s.gy)(i, j, k);
     if (j <= g.je)
       view_V(g, s.a.v_out)(i, j, k) = v(i, j, k) * g.dy[g.iV(i, j)] + ke(i, j, k) - ke(i, j + 1, k) - cview_FX(g, s.gx)(i, j, k);
+  }
+};
+
+// D10: dissipative heating (:1462-1473, :1523-1586) of the levels with d_con_k > 1e-5, after D9 (u_out, v_out before the
+// vorticity damping fluxes are added); box (is:ie, js:je).  Where the level has no vorticity damping the reference's "ut", "vt"
+// still hold v*dy, u*dx of the vorticity computation (:1231-1236) -- reproduced.
+struct DswCubedD10 {
+  DswCubedState s;
+  FV3_HD void operator()(int i, int j, int k) const {
+    const Grid &g = s.g;
+    const double d_con = s.a.lv.d_con_k[k];
+    if (!(d_con > 1.E-5)) return;
+    const bool vdamp = s.a.lv.damp_vt[k] > 1.E-5;
+    const CA vv = cview_B(g, s.vortv), un = cview_U(g, s.a.u_out), vn = cview_V(g, s.a.v_out);
+    const CA u = cview_U(g, s.a.u), v = cview_V(g, s.a.v);
+    auto vt_ = [&](int ii, int jj) { return vdamp ? cview_U(g, s.dfy2)(ii, jj, k) : u(ii, jj, k) * g.dx[g.iU(ii, jj)]; };
+    auto ut_ = [&](int ii, int jj) { return vdamp ? cview_V(g, s.dfx2)(ii, jj, k) : v(ii, jj, k) * g.dy[g.iV(ii, jj)]; };
+    auto ub = [&](int ii, int jj) { return ((vv(ii, jj, k) - vv(ii + 1, jj, k)) + vt_(ii, jj)) * g.rdx[g.iU(ii, jj)]; };
+    auto vb = [&](int ii, int jj) { return ((vv(ii, jj, k) - vv(ii, jj + 1, k)) - ut_(ii, jj)) * g.rdy[g.iV(ii, jj)]; };
+    auto fy = [&](int ii, int jj) { return un(ii, jj, k) * g.rdx[g.iU(ii, jj)]; };
+    auto fx = [&](int ii, int jj) { return vn(ii, jj, k) * g.rdy[g.iV(ii, jj)]; };
+    const double ub0 = ub(i, j), ub1 = ub(i, j + 1), vb0 = vb(i, j), vb1 = vb(i + 1, j);
+    const double fy0 = fy(i, j), fy1 = fy(i, j + 1), fx0 = fx(i, j), fx1 = fx(i + 1, j);
+    const double gy0 = fy0 * ub0, gy1 = fy1 * ub1, gx0 = fx0 * vb0, gx1 = fx1 * vb1;
+    const double u2 = fy0 + fy1, du2 = ub0 + ub1, v2 = fx0 + fx1, dv2 = vb0 + vb1;
+    const double damp = 0.25 * d_con;
+    const double rs = g.rsin2[g.iA(i, j)], cs = g.cosa_s[g.iA(i, j)];
+    const double dpn = cview_A(g, s.a.delp_out)(i, j, k);
+    double &h = view_CC(g, s.a.heat_s)(i, j, k);
+    if (g.prevent_diss_cooling) {
+      const double tmp = rs * ((ub0 * ub0 + ub1 * ub1 + vb0 * vb0 + vb1 * vb1) + 2. * (gy0 + gy1 + gx0 + gx1) - cs * (u2 * dv2 + v2 * du2 + du2 * dv2));
+      h = dpn * (h - damp * dmin(0., tmp));
+    } else {
+      const double t2 = (ub0 * ub0 + ub1 * ub1 + vb0 * vb0 + vb1 * vb1) + 2. * (gy0 + gy1 + gx0 + gx1) - cs * (u2 * dv2 + v2 * du2 + du2 * dv2);
+      h = dpn * (h - damp * rs * t2);
+    }
+  }
+};
+
+// D11: the diffusive fluxes of the vorticity damping added to the winds (:1589-1600); box (is:ie+1, js:je+1)
+struct DswCubedD11 {
+  DswCubedState s;
+  FV3_HD void operator()(int i, int j, int k) const {
+    const Grid &g = s.g;
+    if (!(s.a.lv.damp_vt[k] > 1.E-5)) return;
+    if (i <= g.ie) {
+      double &un = view_U(g, s.a.u_out)(i, j, k);
+      un = un + cview_U(g, s.dfy2)(i, j, k);
+    }
+    if (j <= g.je) {
+      double &vn = view_V(g, s.a.v_out)(i, j, k);
+      vn = vn - cview_V(g, s.dfx2)(i, j, k);
+    }
   }
 };
 

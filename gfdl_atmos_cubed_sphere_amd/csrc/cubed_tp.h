@@ -278,11 +278,18 @@ struct ZhCubedFinal {
   Grid g;
   const double *zh_in, *fx, *fy, *xfa, *yfa;
   double *zh_out;
+  const double *damp = nullptr;                     // per level (npz + 1): del6_vt_flux damping of the levels with damp > 1e-5 ...
+  const double *fx2 = nullptr, *fy2 = nullptr;      // ... its fluxes (V / U layouts), nh_utils.F90:278-284
   FV3_HD void operator()(int i, int j, int k) const {
     const CA z = cview_A(g, zh_in), fxv = cview_FX(g, fx), fyv = cview_FY(g, fy), xf = cview_CX(g, xfa), yf = cview_CY(g, yfa);
     const double ar = g.area[g.iA(i, j)];
     const double rax = ar + xf(i, j, k) - xf(i + 1, j, k), ray = ar + yf(i, j, k) - yf(i, j + 1, k);
-    view_A(g, zh_out)(i, j, k) = (z(i, j, k) * ar + fxv(i, j, k) - fxv(i + 1, j, k) + fyv(i, j, k) - fyv(i, j + 1, k)) / (rax + ray - ar);
+    double v = (z(i, j, k) * ar + fxv(i, j, k) - fxv(i + 1, j, k) + fyv(i, j, k) - fyv(i, j + 1, k)) / (rax + ray - ar);
+    if (damp && damp[k] > 1.E-5) {
+      const CA f2 = cview_V(g, fx2), g2 = cview_U(g, fy2);
+      v = v + (f2(i, j, k) - f2(i + 1, j, k) + g2(i, j, k) - g2(i, j + 1, k)) * g.rarea[g.iA(i, j)];
+    }
+    view_A(g, zh_out)(i, j, k) = v;
   }
 };
 

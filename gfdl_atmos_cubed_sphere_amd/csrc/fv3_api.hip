@@ -13,6 +13,7 @@
 #include "cubed_csw.h"
 #include "cubed_tp.h"
 #include "cubed_dsw.h"
+#include "cubed_damp.h"
 #include "cubed_a2b.h"
 #include "dsw_kernels.h"
 #include "dsw_march.h"
@@ -95,6 +96,8 @@ struct fv3_ctx {
   int cubed_reach;   // ... and how much wider the frame of the passes' intermediates is
   int cubed_frame_c; // the frame of c_sw (d2a2c_vect has its edge forms within 4 points of an edge)
   int lev_max_nord;      // max over the levels of nord_k
+  int lev_max_nord_v, lev_max_nord_w, lev_max_nord_t;   // ... of nord_v / nord_w / nord_t over the levels where the damping is on
+  bool lev_has_damp_v4, lev_has_damp_v5, lev_has_damp_t;  // damp_vt > 1e-4 (deln of delp) / > 1e-5 (del6 of vorticity); damp_t > 1e-4
   bool lev_has_dcon;     // some level has d_con_k > 1e-5
   bool lev_has_vt_damp, lev_has_w_damp, lev_has_w_damp_hi;  // damp_vt / damp_t; damp_w > 1e-5; the latter with nord_w > 0
   double *ke_scr;        // B kind, npz levels: KE + damping term at the corners
@@ -102,7 +105,7 @@ struct fv3_ctx {
   // cubed sphere (grid_type < 3): edge weights / corner factors and the work arrays of the pass kernels (B x (npz+1) each)
   CubedGeom cg;
   double *cg_dev;
-  double *cs_scr[24];
+  double *cs_scr[32];
   int march_tj;          // rows per wavefront segment of the marching kernels
   int march_tj_csw, march_tj_ke, march_tj_fused, march_tj_mom;
   int trc_nt;  // tracers per wavefront in the sub-cycle kernel (FV3_MI355X_TRACER_NT: 1..4, default 3)
@@ -516,10 +519,15 @@ extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
     RT(rt_h2d(c->klist_m, pm.data(), sizeof(int) * npz, c->stream));
     RT(rt_sync(c->stream));
   }
-  c->lev_max_nord = 0;
+  c->lev_max_nord = c->lev_max_nord_v = c->lev_max_nord_w = c->lev_max_nord_t = 0;
   c->lev_has_dcon = c->lev_has_vt_damp = c->lev_has_w_damp = c->lev_has_w_damp_hi = false;
+  c->lev_has_damp_v4 = c->lev_has_damp_v5 = c->lev_has_damp_t = false;
   for (int k = 0; k < npz; k++) {
     c->lev_max_nord = std::max(c->lev_max_nord, lv->nord_k[k]);
+    if (lv->damp_vt[k] > 1.E-5) { c->lev_has_damp_v5 = true; c->lev_max_nord_v = std::max(c->lev_max_nord_v, lv->nord_v[k]); }
+    if (lv->damp_vt[k] > 1.E-4) c->lev_has_damp_v4 = true;
+    if (lv->damp_t[k] > 1.E-4) { c->lev_has_damp_t = true; c->lev_max_nord_t = std::max(c->lev_max_nord_t, lv->nord_t[k]); }
+    if (lv->damp_w[k] > 1.E-5) c->lev_max_nord_w = std::max(c->lev_max_nord_w, lv->nord_w[k]);
     if (lv->d_con_k[k] > 1.E-5) c->lev_has_dcon = true;
     if (lv->damp_vt[k] > 1.E-5 || lv->damp_t[k] > 1.E-4) c->lev_has_vt_damp = true;
     if (lv->damp_w[k] > 1.E-5) c->lev_has_w_damp = true;
@@ -736,6 +744,7 @@ static int csw_cubed(fv3_ctx *c, const CswArgs &ca) {
   return 0;
 }
 
+static int need_trc(fv3_ctx *c);
 extern "C" int fv3_fv_tp_2d(fv3_ctx *c, int nk, const double *q, const double *crx, const double *cry, int hord,
                             double *fx, double *fy, const double *xfx, const double *yfx, const double *ra_x,
                             const double *ra_y, const double *mfx, const double *mfy, const double *mass, int nord,
@@ -745,9 +754,32 @@ extern "C" int fv3_fv_tp_2d(fv3_ctx *c, int nk, const double *q, const double *c
   if (nord > 2) return fail("fv3_fv_tp_2d: nord=%d > 2", nord);
   if ((mfx == nullptr) != (mfy == nullptr)) return fail("fv3_fv_tp_2d: mfx and mfy must be given together");
   if (is_cubed(c)) {
-    if (nord >= 0 && damp_c > 1.e-4) return fail("fv3_fv_tp_2d: deln_flux damping is not built for the cubed sphere yet");
     if (nk > c->g.npz + 1) return fail("fv3_fv_tp_2d: nk > npz + 1 on a cubed-sphere context");
-    return tp2d_cubed(c, nk, q, crx, cry, hord, fx, fy, xfx, yfx, ra_x, ra_y, mfx, mfy);
+    if (tp2d_cubed(c, nk, q, crx, cry, hord, fx, fy, xfx, yfx, ra_x, ra_y, mfx, mfy)) return 1;
+    if (nord >= 0 && damp_c > 1.e-4 && !(mfx && !mass)) {  // deln_flux (tp_core.F90:227-239): cubed_damp.h, one order for all levels
+      if (need_trc(c)) return 1;
+      const Grid &g = c->g;
+      if (nk > g.npz) return fail("fv3_fv_tp_2d: deln_flux damping on a cubed-sphere context takes at most npz levels");
+      std::vector<int> ni(g.npz, nord);
+      std::vector<double> cd(g.npz, damp_c);
+      RT(rt_h2d(c->trc_i + g.npz, ni.data(), sizeof(int) * g.npz, c->stream));
+      RT(rt_h2d(c->trc_d + 2 * g.npz, cd.data(), sizeof(double) * g.npz, c->stream));
+      RT(rt_sync(c->stream));
+      DelnCubedState d;
+      d.g = g; d.q = q; d.mass = mfx ? mass : nullptr; d.fx = fx; d.fy = fy; d.nord = c->trc_i + g.npz; d.coef = c->trc_d + 2 * g.npz; d.thresh = 1.E-4;
+      d.corner_area = 0;
+      d.d2 = cs_scratch(c, 4); d.fx2 = cs_scratch(c, 5); d.fy2 = cs_scratch(c, 6);
+      if (!d.d2 || !d.fx2 || !d.fy2) return fail("fv3_fv_tp_2d: out of device memory");
+      const PassRegion r{0, nullptr, nk};
+      RT(launch_pass(c, "fv_tp_2d", g.isd, g.ied, g.jsd, g.jed, r, DelnCubedL1{d}));
+      RT(launch_pass(c, "fv_tp_2d", g.isd, g.ied + 1, g.jsd, g.jed + 1, r, DelnCubedL24{d, 1, 0}));
+      for (int n = 1; n <= nord; n++) {
+        RT(launch_pass(c, "fv_tp_2d", g.isd, g.ied, g.jsd, g.jed, r, DelnCubedL3{d, n}));
+        RT(launch_pass(c, "fv_tp_2d", g.isd, g.ied + 1, g.jsd, g.jed + 1, r, DelnCubedL24{d, 0, n}));
+      }
+      RT(launch_pass(c, "fv_tp_2d", g.is, g.ie + 1, g.js, g.je + 1, r, DelnCubedL5{d}));
+    }
+    return 0;
   }
   constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
   Tp2dKernel<TI, TJ> kf{c->g, q, crx, cry, xfx, yfx, ra_x, ra_y, mfx, mfy, mass, fx, fy, hord, nord, damp_c};
@@ -984,11 +1016,7 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   const Grid &g = c->g;
   if (!c->cg.ready) return fail("fv3_d_sw: cubed-sphere context without fv3_grid_upload_cubed");
   if (a.use_cond) return fail("fv3_d_sw: use_cond is not built for the cubed sphere yet");
-  if (a.dddmp >= 1.E-5) return fail("fv3_d_sw: Smagorinsky damping (dddmp > 0) is not built for the cubed sphere yet");
   if (g.do_diss_est) return fail("fv3_d_sw: do_diss_est is not built for the cubed sphere yet");
-  if (c->lev_has_vt_damp || (!a.hydrostatic && c->lev_has_w_damp_hi))
-    return fail("fv3_d_sw: del-2n damping of delp / pt / vorticity (and of w with nord_w > 0) is not built for the cubed sphere yet");
-  if (c->lev_has_dcon) return fail("fv3_d_sw: dissipative heating (d_con > 0) is not built for the cubed sphere yet");
   DswCubedState s;
   s.g = g; s.cg = c->cg; s.a = a; s.own_w = 0;
   double **scr[13] = {&s.ut, &s.vt, &s.fx, &s.fy, &s.gxw, &s.gyw, &s.gx, &s.gy, &s.ke, &s.wk, &s.dd, &s.svc, &s.suc};
@@ -996,6 +1024,37 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     if (!(*scr[n] = cs_scratch(c, 8 + n))) return fail("d_sw: out of device memory");
   const int npz = g.npz, npx = g.npx, npy = g.npy;
   const char *L = "dswc_damp";
+  // del-2n damping (cubed_damp.h): the passes of one operator; work arrays = scratch 4..6 of fv_tp_2d (free between its calls)
+  auto deln = [&](const double *q, const double *mass, double *fx, double *fy, const int *nord, const double *coef, double thresh,
+                  int corner_area, int nmax, double *out_fx2, double *out_fy2, const PassRegion &rk) -> int {
+    DelnCubedState d;
+    d.g = g; d.q = q; d.mass = mass; d.fx = fx; d.fy = fy; d.nord = nord; d.coef = coef; d.thresh = thresh; d.corner_area = corner_area;
+    d.d2 = cs_scratch(c, 4);
+    d.fx2 = out_fx2 ? out_fx2 : cs_scratch(c, 5);
+    d.fy2 = out_fy2 ? out_fy2 : cs_scratch(c, 6);
+    if (!d.d2 || !d.fx2 || !d.fy2) return fail("d_sw: out of device memory");
+    const PassRegion r{0, rk.klist, rk.nk};
+    RT(launch_pass(c, "dswc_deln", g.isd, g.ied, g.jsd, g.jed, r, DelnCubedL1{d}));
+    RT(launch_pass(c, "dswc_deln", g.isd, g.ied + 1, g.jsd, g.jed + 1, r, DelnCubedL24{d, 1, 0}));
+    for (int n = 1; n <= nmax; n++) {
+      RT(launch_pass(c, "dswc_deln", g.isd, g.ied, g.jsd, g.jed, r, DelnCubedL3{d, n}));
+      RT(launch_pass(c, "dswc_deln", g.isd, g.ied + 1, g.jsd, g.jed + 1, r, DelnCubedL24{d, 0, n}));
+    }
+    if (fx) RT(launch_pass(c, "dswc_deln", g.is, g.ie + 1, g.js, g.je + 1, r, DelnCubedL5{d}));
+    return 0;
+  };
+  if (!a.hydrostatic && c->lev_has_w_damp_hi) {
+    if (!(s.wfx2 = cs_scratch(c, 25)) || !(s.wfy2 = cs_scratch(c, 26))) return fail("d_sw: out of device memory");
+  }
+  if (c->lev_has_damp_v5) {
+    if (!(s.dfx2 = cs_scratch(c, 22)) || !(s.dfy2 = cs_scratch(c, 23))) return fail("d_sw: out of device memory");
+  }
+  if (c->lev_has_dcon) {
+    if (!(s.vortv = cs_scratch(c, 21))) return fail("d_sw: out of device memory");
+  }
+  if (!(a.dddmp < 1.E-5)) {
+    if (!(s.smag = cs_scratch(c, 24))) return fail("d_sw: out of device memory");
+  }
   // contravariant winds of the whole face, all levels
   RT(launch_box(c, "dswc_d1", g.isd, g.ied + 1, g.jsd, g.jed + 1, npz, DswCubedD1a{s}));
   RT(launch_box(c, "dswc_d1b", 0, npx, 0, npy, npz, DswCubedD1b{s}));
@@ -1010,15 +1069,21 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   const bool fits = wo > 0 && npx - 1 >= 2 * wm + 8 && npx == npy;
   const bool fused_ok = c->use_march && c->use_fused && !a.use_cond && a.hord_dp == a.hord_tm && (a.hydrostatic || a.hord_dp == a.hord_vt);
   const bool hyb_t = fits && fused_ok && c->n_plain > 0;
-  const bool hyb_m = fits && c->use_march && c->use_fused && c->n_plain_m > 0;
+  const bool hyb_m = fits && c->use_march && c->use_fused && c->n_plain_m > 0 && a.dddmp < 1.E-5;
 
   auto transport = [&](const PassRegion &rg, const PassRegion &rg_out, bool courant) -> int {
     if (rg.nk <= 0) return 0;
     if (courant) RT(launch_pass(c, "dswc_d2", g.isd, g.ied, g.jsd, g.jed, PassRegion{0, rg.klist, rg.nk}, DswCubedD2{s}));
     RT(tp2d_cubed(c, npz, a.delp, a.crx, a.cry, a.hord_dp, s.fx, s.fy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, "dswc_tp", &rg));
+    if (rg.w == 0 && c->lev_has_damp_v4)   // :919-920: deln_flux inside fv_tp_2d(delp) -- the mass fluxes carry it from here on
+      RT(deln(a.delp, nullptr, s.fx, s.fy, a.lv.nord_v, a.lv.damp_vt, 1.E-4, 0, c->lev_max_nord_v, nullptr, nullptr, rg));
     if (!a.hydrostatic)
       RT(tp2d_cubed(c, npz, a.w, a.crx, a.cry, a.hord_vt, s.gxw, s.gyw, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, "dswc_tp", &rg));
     RT(tp2d_cubed(c, npz, a.pt, a.crx, a.cry, a.hord_tm, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, "dswc_tp", &rg));
+    if (rg.w == 0 && c->lev_has_damp_t)    // :1014-1016: mass-weighted deln_flux inside fv_tp_2d(pt)
+      RT(deln(a.pt, a.delp, s.gx, s.gy, a.lv.nord_t, a.lv.damp_t, 1.E-4, 0, c->lev_max_nord_t, nullptr, nullptr, rg));
+    if (rg.w == 0 && !a.hydrostatic && c->lev_has_w_damp_hi)   // :950-982: del6_vt_flux(w); nord_w = 0 is formed inside D4
+      RT(deln(a.w, nullptr, nullptr, nullptr, a.lv.nord_w, a.lv.damp_w, 1.E-5, 1, c->lev_max_nord_w, s.wfx2, s.wfy2, rg));
     DswCubedState so = s;
     so.own_w = rg_out.w;
     RT(launch_pass(c, "dswc_d4", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD4{so}));
@@ -1043,10 +1108,24 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
       }
       RT(launch_pass(c, L, g.is - 2, g.ie + 3, g.js - 2, g.je + 3, rg, DswCubedDampDiv{s, n}));
     }
+    if (s.smag) {  // a2b_ord4 of the relative vorticity for the Smagorinsky coefficient (:1431-1440); scratch 0, 1 (c_sw's)
+      A2bCubedState t;
+      t.g = g; t.cg = c->cg; t.nf = 1; t.override_mask = 0;
+      for (int f = 0; f < 4; f++) { t.in[f] = nullptr; t.out[f] = nullptr; t.qx[f] = t.qy[f] = nullptr; t.nlev[f] = 0; t.scale[f] = 1.0; t.top[f] = 0.; }
+      t.in[0] = s.wk; t.out[0] = s.smag; t.nlev[0] = npz;
+      if (!(t.qx[0] = cs_scratch(c, 0)) || !(t.qy[0] = cs_scratch(c, 1))) return fail("d_sw: out of device memory");
+      const PassRegion r{0, rg.klist, rg.nk};
+      RT(launch_pass(c, "dswc_smag", 1, npx, 1, npy, r, A2bCubedPa{t}));
+      RT(launch_pass(c, "dswc_smag", 1, npx, 1, npy, r, A2bCubedPb{t}));
+    }
     RT(launch_pass(c, L, g.is, g.ie + 1, g.js, g.je + 1, rg, DswCubedD7{so}));
+    if (rg.w == 0 && c->lev_has_damp_v5)   // :1513-1515: del6_vt_flux of the RELATIVE vorticity (before D8 adds f0)
+      RT(deln(s.wk, nullptr, nullptr, nullptr, a.lv.nord_v, a.lv.damp_vt, 1.E-5, 1, c->lev_max_nord_v, s.dfx2, s.dfy2, rg));
     RT(launch_pass(c, "dswc_d8", g.isd, g.ied, g.jsd, g.jed, rg, DswCubedD8{s}));
     RT(tp2d_cubed(c, npz, s.wk, a.crx, a.cry, a.hord_vt, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, "dswc_tpv", &rg));
     RT(launch_pass(c, "dswc_d9", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD9{so}));
+    if (rg.w == 0 && c->lev_has_dcon) RT(launch_pass(c, "dswc_heat", g.is, g.ie, g.js, g.je, rg_out, DswCubedD10{so}));
+    if (rg.w == 0 && c->lev_has_damp_v5) RT(launch_pass(c, "dswc_d9", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD11{so}));
     return 0;
   };
 
@@ -1711,7 +1790,6 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
     RT(launch_c(c, "edge_profile", col_grid((int)g.nCY()), kf2));
   }
   if (is_cubed(c)) {
-    if (c->n_damp_z > 0) return fail("fv3_update_dz_d: del6_vt_flux damping of zh is not built for the cubed sphere yet");
     double *fx = cs_scratch(c, 8), *fy = cs_scratch(c, 9);
     if (!fx || !fy) return fail("fv3_update_dz_d: out of device memory");
     // Hybrid (see dsw_cubed): the marching transport of the interface heights over the whole face, then the cubed fv_tp_2d
@@ -1727,9 +1805,31 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
         return launch_w(c, "zh_transport", nwz, kf);
       }));
     }
-    const PassRegion rm{hyb ? wm : 0, nullptr, km + 1}, ro{hyb ? wo : 0, nullptr, km + 1};
-    if (tp2d_cubed(c, km + 1, zh_in, cxa, cya, hord, fx, fy, xfa, yfa, nullptr, nullptr, nullptr, nullptr, "zhc_tp", &rm)) return 1;
-    RT(launch_pass(c, "zhc_fin", g.is, g.ie, g.js, g.je, ro, ZhCubedFinal{g, zh_in, fx, fy, xfa, yfa, zh_out}));
+    // the plain levels (no damping: klist_z[0 : n_plain_z)): frames when the marching kernel took the interior; the levels
+    // with del6_vt_flux damping (nh_utils.F90:268-284): passes on the whole face + the damping fluxes (cubed_damp.h)
+    if (c->n_plain_z > 0) {
+      const PassRegion rm{hyb ? wm : 0, c->klist_z, c->n_plain_z}, ro{hyb ? wo : 0, c->klist_z, c->n_plain_z};
+      if (tp2d_cubed(c, km + 1, zh_in, cxa, cya, hord, fx, fy, xfa, yfa, nullptr, nullptr, nullptr, nullptr, "zhc_tp", &rm)) return 1;
+      RT(launch_pass(c, "zhc_fin", g.is, g.ie, g.js, g.je, ro, ZhCubedFinal{g, zh_in, fx, fy, xfa, yfa, zh_out}));
+    }
+    if (c->n_damp_z > 0) {
+      const PassRegion rd{0, c->klist_z + c->n_plain_z, c->n_damp_z};
+      if (tp2d_cubed(c, km + 1, zh_in, cxa, cya, hord, fx, fy, xfa, yfa, nullptr, nullptr, nullptr, nullptr, "zhc_tp", &rd)) return 1;
+      DelnCubedState d;
+      d.g = g; d.q = zh_in; d.mass = nullptr; d.fx = d.fy = nullptr; d.nord = c->lev_ext_i; d.coef = c->lev_ext_d; d.thresh = 1.E-5;
+      d.corner_area = 2;
+      d.d2 = cs_scratch(c, 4); d.fx2 = cs_scratch(c, 10); d.fy2 = cs_scratch(c, 11);
+      if (!d.d2 || !d.fx2 || !d.fy2) return fail("fv3_update_dz_d: out of device memory");
+      RT(launch_pass(c, "zhc_del6", g.isd, g.ied, g.jsd, g.jed, rd, DelnCubedL1{d}));
+      RT(launch_pass(c, "zhc_del6", g.isd, g.ied + 1, g.jsd, g.jed + 1, rd, DelnCubedL24{d, 1, 0}));
+      for (int n = 1; n <= c->lev_max_nord_v; n++) {
+        RT(launch_pass(c, "zhc_del6", g.isd, g.ied, g.jsd, g.jed, rd, DelnCubedL3{d, n}));
+        RT(launch_pass(c, "zhc_del6", g.isd, g.ied + 1, g.jsd, g.jed + 1, rd, DelnCubedL24{d, 0, n}));
+      }
+      ZhCubedFinal kf{g, zh_in, fx, fy, xfa, yfa, zh_out};
+      kf.damp = c->lev_ext_d; kf.fx2 = d.fx2; kf.fy2 = d.fy2;
+      RT(launch_pass(c, "zhc_fin", g.is, g.ie, g.js, g.je, rd, kf));
+    }
     ZhLimit kf{g, km, rdt, zs, zh_out, ws};
     RT(launch_c(c, "zh_limit", col_grid(g.nx * g.ny), kf));
     return 0;
@@ -2203,8 +2303,8 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
 // ================================================================================================
 static int need_trc(fv3_ctx *c) {
   const int npz = c->g.npz;
-  if (!c->trc_d) RT(rt_malloc((void **)&c->trc_d, sizeof(double) * 2 * npz));
-  if (!c->trc_i) RT(rt_malloc((void **)&c->trc_i, sizeof(int) * npz));
+  if (!c->trc_d) RT(rt_malloc((void **)&c->trc_d, sizeof(double) * 3 * npz));   // cmax, frac, trdm per level (cubed deln)
+  if (!c->trc_i) RT(rt_malloc((void **)&c->trc_i, sizeof(int) * 2 * npz));      // ksplt, nord_tr per level
   return 0;
 }
 
@@ -2287,18 +2387,43 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
     });
   };
   if (is_cubed(c)) {
-    if (it == 1 && trdm > 1.e-4) return fail("fv3_tracer_2d_step: deln_flux damping (trdm) is not built for the cubed sphere yet");
     double *fx = cs_scratch(c, 8), *fy = cs_scratch(c, 9);
     if (!fx || !fy) return fail("fv3_tracer_2d_step: out of device memory");
+    const bool damp = it == 1 && trdm > 1.e-4;      // fv_tracer2d.F90:497-505: deln_flux inside fv_tp_2d, mass = dp1
+    int *nord_dev = nullptr;
+    double *coef_dev = nullptr;
+    if (damp) {  // the order and the coefficient as per-level arrays (cubed_damp.h takes them per level): trc_i / trc_d slots
+      std::vector<int> ni(g.npz, nord_tr);
+      std::vector<double> cd(g.npz, trdm);
+      nord_dev = c->trc_i + g.npz;
+      coef_dev = c->trc_d + 2 * g.npz;
+      RT(rt_h2d(nord_dev, ni.data(), sizeof(int) * g.npz, c->stream));
+      RT(rt_h2d(coef_dev, cd.data(), sizeof(double) * g.npz, c->stream));
+      RT(rt_sync(c->stream));
+    }
     // Hybrid (see dsw_cubed): the marching kernels over the whole face (q_out, dp1_out are not inputs), then the cubed fv_tp_2d
     // passes and the update on the frame along the face edges, tracer by tracer
     const int wo = c->cubed_frame, wm = wo + c->cubed_reach;
-    const bool hyb = c->use_march && wo > 0 && g.npx == g.npy && g.npx - 1 >= 2 * wm + 8;
+    const bool hyb = !damp && c->use_march && wo > 0 && g.npx == g.npy && g.npx - 1 >= 2 * wm + 8;
     if (hyb) RT(march_step());
     const PassRegion rm{hyb ? wm : 0, nullptr, g.npz}, ro{hyb ? wo : 0, nullptr, g.npz};
     const size_t nq3 = (size_t)g.npz * g.nA();
     for (int iq = 0; iq < nq; iq++) {
       if (tp2d_cubed(c, g.npz, q + iq * nq3, cx, cy, hord, fx, fy, xfx, yfx, nullptr, nullptr, mfx, mfy, "trc_tp", &rm)) return 1;
+      if (damp) {
+        DelnCubedState d;
+        d.g = g; d.q = q + iq * nq3; d.mass = dp1; d.fx = fx; d.fy = fy; d.nord = nord_dev; d.coef = coef_dev; d.thresh = 1.E-4;
+        d.corner_area = 0;
+        d.d2 = cs_scratch(c, 4); d.fx2 = cs_scratch(c, 5); d.fy2 = cs_scratch(c, 6);
+        if (!d.d2 || !d.fx2 || !d.fy2) return fail("fv3_tracer_2d_step: out of device memory");
+        RT(launch_pass(c, "trc_deln", g.isd, g.ied, g.jsd, g.jed, rm, DelnCubedL1{d}));
+        RT(launch_pass(c, "trc_deln", g.isd, g.ied + 1, g.jsd, g.jed + 1, rm, DelnCubedL24{d, 1, 0}));
+        for (int n = 1; n <= nord_tr; n++) {
+          RT(launch_pass(c, "trc_deln", g.isd, g.ied, g.jsd, g.jed, rm, DelnCubedL3{d, n}));
+          RT(launch_pass(c, "trc_deln", g.isd, g.ied + 1, g.jsd, g.jed + 1, rm, DelnCubedL24{d, 0, n}));
+        }
+        RT(launch_pass(c, "trc_deln", g.is, g.ie + 1, g.js, g.je + 1, rm, DelnCubedL5{d}));
+      }
       TracerCubedFinal kf{g, it, nsplt, iq == nq - 1, c->trc_i, q + iq * nq3, dp1, fx, fy, mfx, mfy, q_out + iq * nq3, dp1_out};
       RT(launch_pass(c, "trc_fin", g.is, g.ie, g.js, g.je, ro, kf));
     }

@@ -879,6 +879,36 @@ struct Del2Pass {  // one pass of del2_cubed on the box [is-nt, ie+nt] x [js-nt,
     for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
       const int i = g.isd + idx % g.nid, j = g.jsd + idx / g.nid;
       double v = q[idx];
+      if (g.grid_type < 3) {
+        // a cubed-sphere face: the three cells around every cube corner share their mean first (dyn_core.F90:2409-2428; R),
+        // copy_corners before the x / y differences when nt > 0 (:2430, :2443) as an index map on the reads (RD); the centre
+        // of a corner-region cell is what the last copy (direction 2) left there
+        const int npx = g.npx, npy = g.npy, ie = npx - 1, je = npy - 1;
+        constexpr double r3 = 1. / 3.;
+        auto Q = [&](int ii, int jj) { return q[g.iA(ii, jj)]; };
+        auto R = [&](int ii, int jj) -> double {
+          if ((ii == 1 && jj == 1) || (ii == 0 && jj == 1) || (ii == 1 && jj == 0)) return (Q(1, 1) + Q(0, 1) + Q(1, 0)) * r3;
+          if ((ii == ie && jj == 1) || (ii == npx && jj == 1) || (ii == ie && jj == 0)) return (Q(ie, 1) + Q(npx, 1) + Q(ie, 0)) * r3;
+          if ((ii == ie && jj == je) || (ii == npx && jj == je) || (ii == ie && jj == npy)) return (Q(ie, je) + Q(npx, je) + Q(ie, npy)) * r3;
+          if ((ii == 1 && jj == je) || (ii == 0 && jj == je) || (ii == 1 && jj == npy)) return (Q(1, je) + Q(0, je) + Q(1, npy)) * r3;
+          return Q(ii, jj);
+        };
+        auto RD = [&](int dir, int ii, int jj) {
+          if (nt > 0) copyc_src(dir, npx, npy, ii, jj);
+          return R(ii, jj);
+        };
+        v = R(i, j);
+        if (i >= g.is - nt && i <= g.ie + nt && j >= g.js - nt && j <= g.je + nt) {
+          const double cx = RD(1, i, j), cy = RD(2, i, j);
+          const double fx0 = g.del6_v[g.iV(i, j)] * (RD(1, i - 1, j) - cx);
+          const double fx1 = g.del6_v[g.iV(i + 1, j)] * (cx - RD(1, i + 1, j));
+          const double fy0 = g.del6_u[g.iU(i, j)] * (RD(2, i, j - 1) - cy);
+          const double fy1 = g.del6_u[g.iU(i, j + 1)] * (cy - RD(2, i, j + 1));
+          v = cy + cd * g.rarea[idx] * (fx0 - fx1 + fy0 - fy1);
+        }
+        o[idx] = v;
+        continue;
+      }
       if (i >= g.is - nt && i <= g.ie + nt && j >= g.js - nt && j <= g.je + nt) {
         const double fx0 = g.del6_v[g.iV(i, j)] * (q[g.iA(i - 1, j)] - v);
         const double fx1 = g.del6_v[g.iV(i + 1, j)] * (v - q[g.iA(i + 1, j)]);

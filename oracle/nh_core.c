@@ -643,17 +643,42 @@ int fvo_geopk(const fvo_grid *g, int km, double ptop, double akap, double cp_air
 int fvo_del2_cubed(const fvo_grid *g, int km, double cd, int nmax, double *q) {
   BOUNDS(g);
   int k;
-  if (g->grid_type < 3) return FVO_ERR_UNSUPPORTED;
   const int ntimes = nmax < 3 ? nmax : 3;
+  const int cubed = g->grid_type < 3, npx = g->npx, npy = g->npy;
+  const double r3 = 1. / 3.;
 #pragma omp parallel for schedule(dynamic)
   for (k = 1; k <= km; k++) {
     int i, j, n;
     double *fx = dalloc((size_t)(nid + 1) * njd), *fy = dalloc((size_t)nid * (njd + 1));
     for (n = 1; n <= ntimes; n++) {
       const int nt = ntimes - n;
+      if (cubed) { /* :2409-2428: the three cells around a cube corner share their mean */
+        if (g->sw_corner) {
+          q[A3(1, 1, k)] = (q[A3(1, 1, k)] + q[A3(0, 1, k)] + q[A3(1, 0, k)]) * r3;
+          q[A3(0, 1, k)] = q[A3(1, 1, k)];
+          q[A3(1, 0, k)] = q[A3(1, 1, k)];
+        }
+        if (g->se_corner) {
+          q[A3(ie, 1, k)] = (q[A3(ie, 1, k)] + q[A3(npx, 1, k)] + q[A3(ie, 0, k)]) * r3;
+          q[A3(npx, 1, k)] = q[A3(ie, 1, k)];
+          q[A3(ie, 0, k)] = q[A3(ie, 1, k)];
+        }
+        if (g->ne_corner) {
+          q[A3(ie, je, k)] = (q[A3(ie, je, k)] + q[A3(npx, je, k)] + q[A3(ie, npy, k)]) * r3;
+          q[A3(npx, je, k)] = q[A3(ie, je, k)];
+          q[A3(ie, npy, k)] = q[A3(ie, je, k)];
+        }
+        if (g->nw_corner) {
+          q[A3(1, je, k)] = (q[A3(1, je, k)] + q[A3(0, je, k)] + q[A3(1, npy, k)]) * r3;
+          q[A3(0, je, k)] = q[A3(1, je, k)];
+          q[A3(1, npy, k)] = q[A3(1, je, k)];
+        }
+        if (nt > 0) fvo_copy_corners(g, q + A3(isd, jsd, k), 1); /* :2430 */
+      }
       for (j = js - nt; j <= je + nt; j++)
         for (i = is - nt; i <= ie + 1 + nt; i++)
           fx[IV(i, j)] = g->del6_v[IV(i, j)] * (q[A3(i - 1, j, k)] - q[A3(i, j, k)]); /* :2440 */
+      if (cubed && nt > 0) fvo_copy_corners(g, q + A3(isd, jsd, k), 2); /* :2443 */
       for (j = js - nt; j <= je + 1 + nt; j++)
         for (i = is - nt; i <= ie + nt; i++)
           fy[IU(i, j)] = g->del6_u[IU(i, j)] * (q[A3(i, j - 1, k)] - q[A3(i, j, k)]); /* :2452 */

@@ -492,8 +492,8 @@ static void yppm_2d(const fvo_grid *g, double *flux, const double *q, const doub
   free(line);
 }
 
-/* deln_flux, tp_core.F90:1267-1447 (damp_Km absent; copy_corners is a no-op because no corner
- * flag is set on a doubly periodic tile). mass may be NULL. */
+/* deln_flux, tp_core.F90:1267-1447 (damp_Km absent; copy_corners is a no-op on a doubly periodic tile, where no corner
+ * flag is set, and fills the corner cells of d2 before each sweep on a cubed-sphere face). mass may be NULL. */
 int fvo_deln_flux(const fvo_grid *g, int nord, double damp, const double *q, double *fx, double *fy,
                   const double *mass) {
   const int is = g->is, ie = g->ie, js = g->js, je = g->je;
@@ -501,7 +501,6 @@ int fvo_deln_flux(const fvo_grid *g, int nord, double damp, const double *q, dou
   const int nid = ied - isd + 1, njd = jed - jsd + 1, nx = ie - is + 1;
   int i, j, n, nt;
   double damp2;
-  if (g->grid_type < 3) return FVO_ERR_UNSUPPORTED;
 #define Q(i, j) q[(size_t)((j)-jsd) * nid + ((i)-isd)]
 #define MASS(i, j) mass[(size_t)((j)-jsd) * nid + ((i)-isd)]
 #define D2(i, j) d2[(size_t)((j)-jsd) * nid + ((i)-isd)]
@@ -524,8 +523,10 @@ int fvo_deln_flux(const fvo_grid *g, int nord, double damp, const double *q, dou
     for (j = j1; j <= j2; j++)
       for (i = i1; i <= i2; i++) D2(i, j) = Q(i, j);
   }
+  if (nord > 0) fvo_copy_corners(g, d2, 1); /* :1317 */
   for (j = js - nord; j <= je + nord; j++) /* :1321-1329 */
     for (i = is - nord; i <= ie + nord + 1; i++) FX2(i, j) = DEL6_V(i, j) * (D2(i - 1, j) - D2(i, j));
+  if (nord > 0) fvo_copy_corners(g, d2, 2); /* :1331 */
   for (j = js - nord; j <= je + nord + 1; j++) /* :1333-1341 */
     for (i = is - nord; i <= ie + nord; i++) FY2(i, j) = DEL6_U(i, j) * (D2(i, j - 1) - D2(i, j));
 
@@ -535,8 +536,10 @@ int fvo_deln_flux(const fvo_grid *g, int nord, double damp, const double *q, dou
       for (j = js - nt - 1; j <= je + nt + 1; j++)
         for (i = is - nt - 1; i <= ie + nt + 1; i++)
           D2(i, j) = (FX2(i, j) - FX2(i + 1, j) + FY2(i, j) - FY2(i, j + 1)) * RAREA(i, j);
+      fvo_copy_corners(g, d2, 1); /* :1359 */
       for (j = js - nt; j <= je + nt; j++)
         for (i = is - nt; i <= ie + nt + 1; i++) FX2(i, j) = DEL6_V(i, j) * (D2(i, j) - D2(i - 1, j));
+      fvo_copy_corners(g, d2, 2); /* :1371 */
       for (j = js - nt; j <= je + nt + 1; j++)
         for (i = is - nt; i <= ie + nt; i++) FY2(i, j) = DEL6_U(i, j) * (D2(i, j) - D2(i, j - 1));
     }

@@ -132,6 +132,27 @@ def hydro_state(npx, npz, ptop=300.0):
     return cs, gs, out
 
 
+def _n_con(fl, npz):
+    if fl.convert_ke or (fl.do_vort_damp and fl.vtdm4 > 1.0e-4):
+        return npz
+    if fl.d2_bg_k1 < 1.0e-3:
+        return 0
+    return 1 if fl.d2_bg_k2 < 1.0e-3 else 2
+
+
+def _oracle_heating(cs, gs, fl, f, npz, bdt, hydrostatic):
+    """dyn_core.F90:1300-1355 on six faces: halo update of the accumulated heat source, del2_cubed, the heating of pt"""
+    n_con = _n_con(fl, npz)
+    if n_con == 0 or not fl.d_con > 1.0e-5:
+        return
+    exchange(cs, f, ("heat_source",), "A")
+    for t in range(6):
+        x = f[t]
+        O.del2_cubed(gs[t], npz, 0.20 * gs[t].da_min, min(3, fl.nord + 1), x["heat_source"])
+        O.apply_heat_source(gs[t], npz, n_con, hydrostatic, bdt, fl.delt_max, fl.cp_air, fl.cp_air - fl.rdgas, fl.rdgas, fl.grav,
+                            x["pt"], x["heat_source"], x["delp"], x["pkz"] if hydrostatic else x["delz"], x["pkz"])
+
+
 def oracle_substeps_hydro(cs, gs, fl, st, bdt, npz):
     """the hydrostatic substep loop of dyn_core (dyn_core.F90:313-1286, beta = 0, d_ext = 0) over the oracle's routines on six
     faces, with the halo updates where dyn_core has them -- the six-face twin of oracle_dyn_core.run_hydrostatic"""
@@ -147,9 +168,11 @@ def oracle_substeps_hydro(cs, gs, fl, st, bdt, npz):
                             ("diss_e", "CC", npz), ("pk", "CC", npz + 1), ("pkz", "CC", npz)):
             f[t][n] = bd.zeros(kind, nk)
         f[t]["divg2"] = bd.zeros("A")
+        f[t]["heat_source"] = bd.zeros("A", npz)
         f[t]["pe"] = np.zeros((nx + 2, npz + 1, ny + 2), order="F")
         f[t]["peln"] = np.zeros((nx, npz + 1, ny), order="F")
     lev = level_coefficients(npz, fl)
+    heating = fl.d_con > 1.0e-5
     n_split = fl.n_split
     dt = bdt / float(n_split)
     dt2 = 0.5 * dt
@@ -179,6 +202,8 @@ def oracle_substeps_hydro(cs, gs, fl, st, bdt, npz):
                       va=x["va"], divg_d=x["divgd"], mfx=x["mfx"], mfy=x["mfy"], cx=x["cx"], cy=x["cy"], crx=x["crx"], cry=x["cry"],
                       xfx=x["xfx"], yfx=x["yfx"], heat_source=x["heat_s"], diss_est=x["diss_e"])
             O.d_sw_3d(gs[t], npz, par, lev, ds)
+            if heating:
+                x["heat_source"][i0:i0 + nx, j0:j0 + ny, :] += x["heat_s"]
         exchange(cs, f, ("delp", "pt"), "A")
         for t in range(6):
             x = f[t]
@@ -190,6 +215,7 @@ def oracle_substeps_hydro(cs, gs, fl, st, bdt, npz):
             exchange_pair(cs, f, "u", "v", "D")
         else:
             exchange_pair(cs, f, "u", "v", "Dedge")          # mpp_get_boundary, dyn_core.F90:1151-1163
+    _oracle_heating(cs, gs, fl, f, npz, bdt, True)
     return f
 
 
@@ -226,6 +252,8 @@ def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
                             ("heat_s", "CC", npz), ("diss_e", "CC", npz), ("pk", "CC", npz + 1)):
             f[t][n] = bd.zeros(kind, nk)
         f[t]["ws3"], f[t]["ws"] = bd.zeros("A"), bd.zeros("CC")
+        f[t]["heat_source"] = bd.zeros("A", npz)
+        f[t]["pkz"] = bd.zeros("CC", npz)
         f[t]["pe"] = np.zeros((nx + 2, npz + 1, ny + 2), order="F")
         f[t]["peln"] = np.zeros((nx, npz + 1, ny), order="F")
         f[t]["zs"] = F(f[t]["phis"] * (1.0 / fl.grav))
@@ -278,6 +306,8 @@ def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
                       ua=x["ua"], va=x["va"], divg_d=x["divgd"], mfx=x["mfx"], mfy=x["mfy"], cx=x["cx"], cy=x["cy"], crx=x["crx"],
                       cry=x["cry"], xfx=x["xfx"], yfx=x["yfx"], heat_source=x["heat_s"], diss_est=x["diss_e"])
             O.d_sw_3d(gs[t], npz, par, lev, ds)
+            if fl.d_con > 1.0e-5:
+                x["heat_source"][ng:ng + nx, ng:ng + ny, :] += x["heat_s"]
         exchange(cs, f, ("delp", "pt"), "A")
         for t in range(6):
             x = f[t]
@@ -298,6 +328,7 @@ def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
             exchange_pair(cs, f, "u", "v", "D")
         else:
             exchange_pair(cs, f, "u", "v", "Dedge")
+    _oracle_heating(cs, gs, fl, f, npz, bdt, False)
     return f
 
 
@@ -357,7 +388,7 @@ def oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, remap_par, n
     return out
 
 
-def oracle_tracer_2d(cs, gs, npz, nq, q, dp1, mfx, mfy, cx, cy, hord, q_split=0):
+def oracle_tracer_2d(cs, gs, npz, nq, q, dp1, mfx, mfy, cx, cy, hord, q_split=0, nord_tr=0, trdm=0.0):
     """tracer_2d (fv_tracer2d.F90:297-557) on six faces over the oracle's pieces: the Courant-number maximum reduced over the
     faces, the q halo updates between the sub-cycles.  q, dp1, mfx, ... are lists of six arrays, updated in place."""
     xfx = [np.zeros_like(c) for c in cx]
@@ -371,8 +402,11 @@ def oracle_tracer_2d(cs, gs, npz, nq, q, dp1, mfx, mfy, cx, cy, hord, q_split=0)
             O.tracer_2d_scale(gs[t], npz, frac, cx[t], xfx[t], mfx[t], cy[t], yfx[t], mfy[t])
     else:
         ksplt = np.ones(npz, dtype=np.int32)
+    if trdm > 1.0e-4:
+        cs.topo.update("A", dp1)                     # dp1_pack, fv_tracer2d.F90:466
     for it in range(1, nsplt + 1):
         cs.topo.update("A", q)
         for t in range(6):
-            O.tracer_2d_step(gs[t], npz, nq, it, nsplt, ksplt, q[t], dp1[t], mfx[t], mfy[t], cx[t], cy[t], xfx[t], yfx[t], hord)
+            O.tracer_2d_step(gs[t], npz, nq, it, nsplt, ksplt, q[t], dp1[t], mfx[t], mfy[t], cx[t], cy[t], xfx[t], yfx[t], hord,
+                             nord_tr, trdm)
     return nsplt

@@ -41,7 +41,7 @@ def check_c_sw(lib, npx=13, npz=3, hydrostatic=False, faces=range(6), dt2=300.0,
     return worst
 
 
-def check_fv_tp_2d(lib, hord, npx=13, nk=3, faces=range(6), mass_flux=False, seed=4):
+def check_fv_tp_2d(lib, hord, npx=13, nk=3, faces=range(6), mass_flux=False, seed=4, nord=-1, damp_c=0.0):
     """fv_tp_2d on every face: q and the Courant numbers / area fluxes of a real c_sw -> d_sw step of the oracle"""
     cs, gs, before, after = CC.oracle_pair(npx, nk, dt=600.0, hydrostatic=True)
     rng = np.random.default_rng(seed)
@@ -54,6 +54,7 @@ def check_fv_tp_2d(lib, hord, npx=13, nk=3, faces=range(6), mass_flux=False, see
         a = after[t]
         mfx = np.asfortranarray(rng.uniform(-1, 1, bd.shape("FX", nk)) * 1e5) if mass_flux else None
         mfy = np.asfortranarray(rng.uniform(-1, 1, bd.shape("FY", nk)) * 1e5) if mass_flux else None
+        mass = before[t]["delp"].copy(order="F") if (mass_flux and nord >= 0) else None      # deln_flux weighted with delp
         ra_x, ra_y = bd.zeros("RX", nk), bd.zeros("RY", nk)
         ng, nx = bd.ng, bd.nx
         ra_x[...] = g.m["area"][ng:ng + nx, :, None] + a["xfx"][:-1, :, :] - a["xfx"][1:, :, :]
@@ -63,14 +64,15 @@ def check_fv_tp_2d(lib, hord, npx=13, nk=3, faces=range(6), mass_flux=False, see
             sl = lambda x: None if x is None else np.asfortranarray(x[:, :, k])      # noqa: E731
             qk = np.asfortranarray(CCq[:, :, k]).copy(order="F")
             fx, fy = O.fv_tp_2d(g, qk, sl(a["crx"]), sl(a["cry"]), hord, sl(a["xfx"]), sl(a["yfx"]), sl(ra_x), sl(ra_y),
-                                mfx=sl(mfx), mfy=sl(mfy))
+                                mfx=sl(mfx), mfy=sl(mfy), mass=sl(mass), nord=nord, damp_c=damp_c)
             fx_ref[:, :, k], fy_ref[:, :, k] = fx, fy
         ctx = Context(g, nk, lib=lib)
         try:
             dfx, dfy = ctx.zeros("FX", nk), ctx.zeros("FY", nk)
             ctx.fv_tp_2d(ctx.from_host(CCq), ctx.from_host(a["crx"]), ctx.from_host(a["cry"]), hord, dfx, dfy, ctx.from_host(a["xfx"]),
                          ctx.from_host(a["yfx"]), ctx.from_host(ra_x), ctx.from_host(ra_y),
-                         None if mfx is None else ctx.from_host(mfx), None if mfy is None else ctx.from_host(mfy))
+                         None if mfx is None else ctx.from_host(mfx), None if mfy is None else ctx.from_host(mfy),
+                         None if mass is None else ctx.from_host(mass), nord, damp_c)
             worst = max(worst, P.assert_close(f"face {t + 1} fx", dfx.download(), fx_ref))
             worst = max(worst, P.assert_close(f"face {t + 1} fy", dfy.download(), fy_ref))
         finally:
@@ -113,6 +115,7 @@ def check_d_sw(lib, npx=13, npz=3, hydrostatic=True, faces=range(6), dt=600.0, p
                    ("u", out["u_out"], "U", (i0, i1, j0, j1 + 1)), ("v", out["v_out"], "V", (i0, i1 + 1, j0, j1))]
             if not hydrostatic:
                 cmp.append(("w", out["w_out"], "A", (i0, i1, j0, j1)))
+            cmp.append(("heat_source", out["heat_s"], "CC", None))      # w damping of the sponge levels, d_con heating
             for name, dev, kind, r in cmp:
                 got, ref = dev.download(), a[name]
                 if r is not None:
@@ -203,7 +206,7 @@ def tracer_fields(cs, npz, nq):
     return out
 
 
-def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-12, hydrostatic=True, nq=0, face_streams=False, graph=False):
+def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-12, hydrostatic=True, nq=0, face_streams=False, graph=False, flags=None):
     """BASELINE configs[1] in small: the Jablonowski-Williamson baroclinic wave (test_case = 13) on the whole cubed sphere,
     hydrostatic, the reference's L79 levels (set_eta), one dt_atmos = k_split x (n_split substeps + vertical remap) on six
     device contexts against the six-face orchestration of the oracle"""
@@ -220,7 +223,7 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
         ak, bk = ptop * (1.0 - sig), sig.copy()
     st = jablonowski_williamson(cs, ak, bk, hydrostatic=hydrostatic)
     CC.exchange(cs, st, ("phis",), "A")          # the model gets phis with its halo filled (init_case: mpp_update_domains(phis))
-    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, d_ext=0.0, ptop=float(ak[0]))
+    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, d_ext=0.0, ptop=float(ak[0]), **(flags or {}))
     # T -> theta: pt = T / pkz with the hydrostatic pkz of the initial state (fv_dynamics.F90:323-329, the host's job here)
     bd = gs[0].bd
     ng, nx = bd.ng, bd.nx
@@ -297,7 +300,7 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
     return worst
 
 
-def check_sphere_properties(lib, npx=97, npz=127, hydrostatic=False, k_split=1, n_split=2, bdt=225.0, nq=0):
+def check_sphere_properties(lib, npx=97, npz=127, hydrostatic=False, k_split=1, n_split=2, bdt=225.0, nq=0, flags=None):
     """size-independent checks of a whole-sphere step at sizes the oracle cannot reach: everything finite, the global air mass
     sum(area * delp) kept to rounding (flux form; both faces of a cube edge compute the same edge flux), the winds on the shared
     cube edges equal on both faces (mpp_get_boundary), the state moved"""
@@ -309,7 +312,7 @@ def check_sphere_properties(lib, npx=97, npz=127, hydrostatic=False, k_split=1, 
     ak, bk, ks, ptop = set_eta(npz)
     st = jablonowski_williamson(cs, ak, bk, hydrostatic=hydrostatic)
     CC.exchange(cs, st, ("phis",), "A")          # the model gets phis with its halo filled (init_case: mpp_update_domains(phis))
-    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, d_ext=0.0, ptop=float(ak[0]))
+    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, d_ext=0.0, ptop=float(ak[0]), **(flags or {}))
     bd = gs[0].bd
     ng, nx = bd.ng, bd.nx
     c = (slice(ng, ng + nx), slice(ng, ng + nx))
@@ -361,7 +364,7 @@ def check_sphere_properties(lib, npx=97, npz=127, hydrostatic=False, k_split=1, 
     return out
 
 
-def check_tracer_2d(lib, npx=13, npz=4, nq=3, hord=8, q_split=0, courant_scale=1.0, dt=600.0):
+def check_tracer_2d(lib, npx=13, npz=4, nq=3, hord=8, q_split=0, courant_scale=1.0, dt=600.0, nord_tr=0, trdm=0.0):
     """tracer_2d on the whole sphere with the mass fluxes / Courant numbers of one c_sw -> d_sw step of the oracle; a
     courant_scale > 1 makes the levels sub-cycle (nsplt > 1, different ksplt per level)"""
     from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
@@ -380,7 +383,7 @@ def check_tracer_2d(lib, npx=13, npz=4, nq=3, hord=8, q_split=0, courant_scale=1
         inp.append(x)
     ref = [{k: v.copy(order="F") for k, v in x.items()} for x in inp]
     nsplt = CC.oracle_tracer_2d(cs, gs, npz, nq, [r["q"] for r in ref], [r["dp1"] for r in ref], [r["mfx"] for r in ref],
-                                [r["mfy"] for r in ref], [r["cx"] for r in ref], [r["cy"] for r in ref], hord, q_split)
+                                [r["mfy"] for r in ref], [r["cx"] for r in ref], [r["cy"] for r in ref], hord, q_split, nord_tr, trdm)
     mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     worst = {"nsplt": float(nsplt)}
     try:
@@ -389,7 +392,7 @@ def check_tracer_2d(lib, npx=13, npz=4, nq=3, hord=8, q_split=0, courant_scale=1
         d["q_nxt"], d["dp1_nxt"] = mctx.from_host([x["q"] * 0 for x in inp]), mctx.zeros("A", npz)
         d["xfx"], d["yfx"] = mctx.zeros("CX", npz), mctx.zeros("CY", npz)
         q, dp1, ns = tracer_2d(mctx, halo, d["q"], d["q_nxt"], d["dp1"], d["dp1_nxt"], d["mfx"], d["mfy"], d["cx"], d["cy"],
-                               d["xfx"], d["yfx"], nq, hord, q_split)
+                               d["xfx"], d["yfx"], nq, hord, q_split, nord_tr, trdm)
         assert ns == nsplt, (ns, nsplt)
         got = q.download()
         r = (bd.is_, bd.ie, bd.js, bd.je)
@@ -400,4 +403,30 @@ def check_tracer_2d(lib, npx=13, npz=4, nq=3, hord=8, q_split=0, courant_scale=1
         # mass-weighted tracer content is conserved by the flux form
     finally:
         mctx.close()
+    return worst
+
+
+def check_del2_cubed(lib, npx=13, npz=3, nmax=3, faces=range(6)):
+    """del2_cubed (dyn_core.F90:2356) on the faces: the mean over the three cells around each cube corner, copy_corners before the
+    differences, three smoothing passes on shrinking boxes"""
+    cs, gs = CC.sphere(npx)
+    q = []
+    for t in range(6):
+        a3 = cs.grids[t]["agrid3"]
+        q.append(np.asfortranarray(np.stack([CC.scalar(a3, k, npz, 1.0, 0.5) * (1.0 + 0.3 * CC._ripple(a3)) for k in range(npz)], axis=-1)))
+    cs.topo.update("A", q)
+    worst = 0.0
+    for t in faces:
+        g, bd = gs[t], gs[t].bd
+        ref = q[t].copy(order="F")
+        O.del2_cubed(g, npz, 0.20 * g.da_min, nmax, ref)
+        ctx = Context(g, npz, lib=lib)
+        try:
+            d = ctx.from_host(q[t])
+            ctx.del2_cubed(d, 0.20 * g.da_min, nmax)
+            r = (bd.is_, bd.ie, bd.js, bd.je)
+            worst = max(worst, P.assert_close(f"face {t + 1} del2_cubed", bd.view(d.download(), "A", *r), bd.view(ref, "A", *r)))
+            assert np.max(np.abs(bd.view(ref, "A", *r) - bd.view(q[t], "A", *r))) > 1e-6
+        finally:
+            ctx.close()
     return worst

@@ -756,3 +756,33 @@ def test_cubed_sphere_step_as_a_hip_graph(prod, hydrostatic):
     numbers of the eager launches -- < 1e-12 against the six-face oracle"""
     r = PC.check_jw_step(prod, npx=25, npz=20, k_split=2, n_split=2, bdt=900.0, hydrostatic=hydrostatic, face_streams=True, graph=True)
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
+# ---- cubed sphere: the damping / heating branches a production namelist switches on ------------------------------------------------
+PROD = dict(do_vort_damp=True, vtdm4=0.06, nord=3, d_con=1.0, dddmp=0.5)
+
+
+@pytest.mark.parametrize("hydrostatic", [True, False])
+@pytest.mark.parametrize("kw", [dict(flags=dict(do_vort_damp=True, vtdm4=0.06, nord=2)), dict(flags=dict(d_con=1.0)),
+                                dict(flags=dict(dddmp=0.2, nord=2), par_over=dict(dddmp=0.2)),
+                                dict(flags=PROD, par_over=dict(dddmp=0.5))])
+def test_cubed_d_sw_damping_and_heating(prod, kw, hydrostatic):
+    assert max(PC.check_d_sw(prod, npx=25, npz=12, hydrostatic=hydrostatic, **kw).values()) <= P.TOL
+
+
+def test_cubed_del2_cubed_and_damped_transports(prod):
+    assert PC.check_del2_cubed(prod, npx=25, npz=4, nmax=3) <= P.TOL
+    for kw in (dict(nord=2, damp_c=0.05), dict(nord=2, damp_c=0.05, mass_flux=True)):
+        assert PC.check_fv_tp_2d(prod, 8, npx=25, faces=(0, 2, 5), **kw) <= P.TOL
+    assert PC.check_tracer_2d(prod, npx=25, nord_tr=2, trdm=0.1, courant_scale=40.0, hord=5, nq=2)["q"] <= P.TOL
+
+
+def test_cubed_sphere_with_production_flags(prod):
+    """nord = 3, do_vort_damp, d_con = 1, dddmp = 0.5 on the whole sphere: substeps on C24 / C48 faces (the hybrid keeps the damped
+    levels on the pass kernels), a nonhydrostatic JW step with tracers on C48 L79, and the conservation properties on C96 L79"""
+    assert max(PC.check_substeps_hydrostatic(prod, npx=25, npz=12, n_split=2, flags=PROD).values()) <= 1e-13
+    assert max(PC.check_substeps_nh(prod, npx=49, npz=12, n_split=2, bdt=450.0, flags=PROD).values()) <= 1e-12
+    r = PC.check_jw_step(prod, npx=49, npz=79, k_split=1, n_split=3, bdt=450.0, hydrostatic=False, nq=2, flags=PROD)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+    r = PC.check_sphere_properties(prod, npx=97, npz=79, hydrostatic=False, k_split=1, n_split=3, bdt=450.0, nq=2, flags=PROD)
+    assert r["finite"] == 1.0 and r["mass_drift"] < 1e-13 and r["tracer_mass_drift"] < 1e-12 and r["edge_mismatch"] == 0.0, r

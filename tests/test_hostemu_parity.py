@@ -632,3 +632,35 @@ def test_exchange_behind_the_c_abi_single_rank(emu):
         assert np.array_equal(ctx.allreduce_max(np.array([1.0, -2.0])), [1.0, -2.0])
     finally:
         ctx.close()
+
+
+# ---- cubed sphere: the damping / heating branches a production namelist switches on ------------------------------------------------
+PROD = dict(do_vort_damp=True, vtdm4=0.06, nord=3, d_con=1.0, dddmp=0.5)
+
+
+@pytest.mark.parametrize("hydrostatic", [True, False])
+@pytest.mark.parametrize("kw", [dict(flags=dict(do_vort_damp=True, vtdm4=0.06, nord=2)), dict(flags=dict(d_con=1.0)),
+                                dict(flags=dict(dddmp=0.2, nord=2), par_over=dict(dddmp=0.2)),
+                                dict(flags=PROD, par_over=dict(dddmp=0.5))])
+def test_cubed_d_sw_damping_and_heating(emu, kw, hydrostatic):
+    """deln_flux on delp / pt, del6_vt_flux on w and on the relative vorticity (copy_corners as index maps), Smagorinsky damping
+    through the cubed a2b_ord4, the dissipative heat source: d_sw on the faces against the oracle, heat_source included"""
+    assert max(PC.check_d_sw(emu, npx=13, npz=12, hydrostatic=hydrostatic, faces=(0, 3), **kw).values()) <= P.TOL
+
+
+def test_cubed_del2_cubed_and_damped_transports(emu):
+    for nmax in (1, 2, 3):
+        assert PC.check_del2_cubed(emu, nmax=nmax) <= P.TOL
+    for kw in (dict(nord=0, damp_c=0.05), dict(nord=2, damp_c=0.05), dict(nord=2, damp_c=0.05, mass_flux=True)):
+        assert PC.check_fv_tp_2d(emu, 8, faces=(0, 2, 5), **kw) <= P.TOL
+    for kw in (dict(nord_tr=1, trdm=0.1), dict(nord_tr=2, trdm=0.1, courant_scale=40.0, hord=5, nq=2)):
+        assert PC.check_tracer_2d(emu, **kw)["q"] <= P.TOL
+
+
+def test_cubed_sphere_substeps_with_production_flags(emu):
+    """nord = 3, do_vort_damp (vtdm4 = 0.06), d_con = 1, dddmp = 0.5: whole substep loops on the six faces incl. the heating of pt
+    after them (del2_cubed with the corner means) and update_dz_d's del6 damping of the interface heights"""
+    assert max(PC.check_substeps_hydrostatic(emu, npx=13, npz=12, n_split=2, flags=PROD).values()) <= 1e-13
+    assert max(PC.check_substeps_nh(emu, npx=13, npz=12, n_split=2, flags=PROD).values()) <= 1e-13
+    r = PC.check_jw_step(emu, npx=13, npz=20, k_split=2, n_split=2, bdt=900.0, hydrostatic=False, nq=2, flags=PROD)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
