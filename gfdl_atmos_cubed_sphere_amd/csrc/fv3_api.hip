@@ -1796,7 +1796,7 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
     // passes on the frame along the face edges (zh_out is not an input: the passes simply overwrite the frame)
     const int wo = c->cubed_frame, wm = wo + c->cubed_reach;
     const bool hyb = c->use_march && wo > 0 && g.npx == g.npy && g.npx - 1 >= 2 * wm + 8;
-    if (hyb) {
+    if (hyb && c->n_plain_z > 0) {
       MarchDims md = make_march_dims(g, seg_rows(c, c->march_tj, g.npz));
       md.klist = c->klist_z;
       const int nwz = md.nwaves(c->n_plain_z);
