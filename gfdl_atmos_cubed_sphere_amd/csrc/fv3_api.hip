@@ -2105,7 +2105,8 @@ extern "C" int fv3_divg2_ext(fv3_ctx *c, double d_ext, const double *delp, const
   const Grid &g = c->g;
   RT(rt_memset(divg2, 0, sizeof(double) * g.nA(), c->stream));
   if (!(d_ext > 0.)) return 0;
-  Divg2Ext kf{g, g.npz, d_ext * g.da_min_c, delp, vt, divg2};
+  if (is_cubed(c) && !c->cg.ready) return fail("fv3_divg2_ext: cubed-sphere context without fv3_grid_upload_cubed");
+  Divg2Ext kf{g, g.npz, d_ext * g.da_min_c, delp, vt, divg2, c->cg};
   RT(launch_c(c, "divg2_ext", col_grid((g.nx + 1) * (g.ny + 1)), kf));
   return 0;
 }

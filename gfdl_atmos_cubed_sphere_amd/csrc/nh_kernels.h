@@ -969,16 +969,44 @@ struct Divg2Ext {  // dyn_core.F90:745-747, :791-797, :828-848
   double d2_divg;
   const double *delp, *vt;
   double *divg2;  // A kind 2-D, corner indices
+  CubedGeom cg;   // cubed sphere: the edge weights of a2b_ord2
   FV3_HD void operator()(int bx, int, int, int tid, double *) const {
     const int w = g.nx + 1, ncol = w * (g.ny + 1);
     const size_t nA = g.nA();
+    const bool cubed = g.grid_type < 3;
+    const int npx = g.npx, npy = g.npy;
     FV3_COL_FOR(c, ncol) {
       const int i = g.is + c % w, j = g.js + c / w;
       const int o = g.iA(i, j), o00 = g.iA(i - 1, j - 1), o10 = g.iA(i, j - 1), o01 = g.iA(i - 1, j);
       double wk = 0., d2 = 0.;
       for (int k = 0; k < npz; k++) {
         const double *dp = delp + (size_t)k * nA;
-        const double ptc = 0.25 * (dp[o00] + dp[o10] + dp[o01] + dp[o]);  // a2b_ord2, a2b_edge.F90:427-433
+        double ptc;  // a2b_ord2 of delp at corner (i, j), a2b_edge.F90:329-450
+        if (!cubed || (i > 1 && i < npx && j > 1 && j < npy)) {
+          ptc = 0.25 * (dp[o00] + dp[o10] + dp[o01] + dp[o]);  // :377 / :427-433
+        } else {
+          constexpr double r3 = 1. / 3.;
+          auto DP = [&](int ii, int jj) { return dp[g.iA(ii, jj)]; };
+          if (i == 1 && j == 1)
+            ptc = r3 * (DP(1, 1) + DP(1, 0) + DP(0, 1));  // :382-385
+          else if (i == npx && j == 1)
+            ptc = r3 * (DP(npx - 1, 1) + DP(npx - 1, 0) + DP(npx, 1));
+          else if (i == npx && j == npy)
+            ptc = r3 * (DP(npx - 1, npy - 1) + DP(npx, npy - 1) + DP(npx - 1, npy));
+          else if (i == 1 && j == npy)
+            ptc = r3 * (DP(1, npy - 1) + DP(0, npy - 1) + DP(1, npy));
+          else if (i == 1 || i == npx) {  // :388-405
+            const int ia = (i == 1) ? 0 : npx - 1;
+            const double ew = (i == 1) ? cg.edge_w[j] : cg.edge_e[j];
+            const double qa = 0.5 * (DP(ia, j - 1) + DP(ia + 1, j - 1)), qb = 0.5 * (DP(ia, j) + DP(ia + 1, j));
+            ptc = ew * qa + (1. - ew) * qb;
+          } else {  // :408-425
+            const int ja = (j == 1) ? 0 : npy - 1;
+            const double es = (j == 1) ? cg.edge_s[i] : cg.edge_n[i];
+            const double qa = 0.5 * (DP(i - 1, ja) + DP(i - 1, ja + 1)), qb = 0.5 * (DP(i, ja) + DP(i, ja + 1));
+            ptc = es * qa + (1. - es) * qb;
+          }
+        }
         if (k == 0) {
           wk = ptc;
           d2 = wk * vt[o];

@@ -751,13 +751,36 @@ int fvo_divg2_ext(const fvo_grid *g, int npz, double d_ext, const double *delp, 
   for (j = jsd; j <= jed; j++)
     for (i = isd; i <= ied; i++) divg2[IA(i, j)] = 0.;
   if (!(d_ext > 0.)) return FVO_OK;
-  if (g->grid_type < 3) return FVO_ERR_UNSUPPORTED;
   const double d2_divg = d_ext * g->da_min_c;
+  const int cubed = g->grid_type < 3, npx = g->npx, npy = g->npy;
+  const double r3 = 1. / 3.;
+#define DP(i, j) delp[A3(i, j, k)]
   for (j = js; j <= je + 1; j++)
     for (i = is; i <= ie + 1; i++) {
       double wk = 0., d2 = 0.;
       for (k = 1; k <= npz; k++) {
-        const double ptc = 0.25 * (delp[A3(i - 1, j - 1, k)] + delp[A3(i, j - 1, k)] + delp[A3(i - 1, j, k)] + delp[A3(i, j, k)]);
+        double ptc; /* a2b_ord2 (a2b_edge.F90:329-450) of delp at corner (i, j) */
+        if (!cubed || (i > 1 && i < npx && j > 1 && j < npy))
+          ptc = 0.25 * (DP(i - 1, j - 1) + DP(i, j - 1) + DP(i - 1, j) + DP(i, j));
+        else if (i == 1 && j == 1)
+          ptc = r3 * (DP(1, 1) + DP(1, 0) + DP(0, 1)); /* :382-385 */
+        else if (i == npx && j == 1)
+          ptc = r3 * (DP(npx - 1, 1) + DP(npx - 1, 0) + DP(npx, 1));
+        else if (i == npx && j == npy)
+          ptc = r3 * (DP(npx - 1, npy - 1) + DP(npx, npy - 1) + DP(npx - 1, npy));
+        else if (i == 1 && j == npy)
+          ptc = r3 * (DP(1, npy - 1) + DP(0, npy - 1) + DP(1, npy));
+        else if (i == 1 || i == npx) { /* west / east edge, :388-405 */
+          const int ia = (i == 1) ? 0 : npx - 1;
+          const double ew = (i == 1) ? g->edge_w[j - 1] : g->edge_e[j - 1]; /* 1-based arrays */
+          const double qa = 0.5 * (DP(ia, j - 1) + DP(ia + 1, j - 1)), qb = 0.5 * (DP(ia, j) + DP(ia + 1, j));
+          ptc = ew * qa + (1. - ew) * qb;
+        } else { /* south / north edge, :408-425 */
+          const int ja = (j == 1) ? 0 : npy - 1;
+          const double es = (j == 1) ? g->edge_s[i - 1] : g->edge_n[i - 1];
+          const double qa = 0.5 * (DP(i - 1, ja) + DP(i - 1, ja + 1)), qb = 0.5 * (DP(i, ja) + DP(i, ja + 1));
+          ptc = es * qa + (1. - es) * qb;
+        }
         if (k == 1) {
           wk = ptc;
           d2 = wk * vt[A3(i, j, 1)];

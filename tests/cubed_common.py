@@ -201,9 +201,11 @@ def oracle_substeps_hydro(cs, gs, fl, st, bdt, npz):
             ds = dict(delpc=x["vt"], delp=x["delp"], ptc=x["ptc"], pt=x["pt"], u=x["u"], v=x["v"], uc=x["uc"], vc=x["vc"], ua=x["ua"],
                       va=x["va"], divg_d=x["divgd"], mfx=x["mfx"], mfy=x["mfy"], cx=x["cx"], cy=x["cy"], crx=x["crx"], cry=x["cry"],
                       xfx=x["xfx"], yfx=x["yfx"], heat_source=x["heat_s"], diss_est=x["diss_e"])
+            delp_old = x["delp"].copy(order="F")
             O.d_sw_3d(gs[t], npz, par, lev, ds)
             if heating:
                 x["heat_source"][i0:i0 + nx, j0:j0 + ny, :] += x["heat_s"]
+            O.divg2_ext(gs[t], npz, fl.d_ext, delp_old, x["vt"], x["divg2"])      # dyn_core.F90:745-747, :791-848
         exchange(cs, f, ("delp", "pt"), "A")
         for t in range(6):
             x = f[t]

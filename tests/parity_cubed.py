@@ -132,7 +132,7 @@ def check_substeps_hydrostatic(lib, npx=13, npz=4, n_split=2, bdt=600.0, flags=N
     from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
     from gfdl_atmos_cubed_sphere_amd.dyn_core import DynCore, DynFlags
     cs, gs, st = CC.hydro_state(npx, npz)
-    fl = DynFlags(n_split=n_split, hydrostatic=True, d_ext=0.0, **(flags or {}))
+    fl = DynFlags(n_split=n_split, hydrostatic=True, **dict(dict(d_ext=0.0), **(flags or {})))
     ref = CC.oracle_substeps_hydro(cs, gs, fl, st, bdt, npz)
     mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     worst = {}

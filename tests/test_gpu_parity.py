@@ -786,3 +786,7 @@ def test_cubed_sphere_with_production_flags(prod):
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
     r = PC.check_sphere_properties(prod, npx=97, npz=79, hydrostatic=False, k_split=1, n_split=3, bdt=450.0, nq=2, flags=PROD)
     assert r["finite"] == 1.0 and r["mass_drift"] < 1e-13 and r["tracer_mass_drift"] < 1e-12 and r["edge_mismatch"] == 0.0, r
+
+
+def test_cubed_sphere_hydrostatic_external_mode_damping(prod):
+    assert max(PC.check_substeps_hydrostatic(prod, npx=49, npz=12, n_split=2, bdt=450.0, flags=dict(d_ext=0.02)).values()) <= 1e-13

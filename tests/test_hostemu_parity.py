@@ -664,3 +664,10 @@ def test_cubed_sphere_substeps_with_production_flags(emu):
     assert max(PC.check_substeps_nh(emu, npx=13, npz=12, n_split=2, flags=PROD).values()) <= 1e-13
     r = PC.check_jw_step(emu, npx=13, npz=20, k_split=2, n_split=2, bdt=900.0, hydrostatic=False, nq=2, flags=PROD)
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
+def test_cubed_sphere_hydrostatic_external_mode_damping(emu):
+    """d_ext = 0.02 (the reference's default): a2b_ord2 of delp with its edge weights and corner means, the column-weighted
+    divergence, one_grad_p with it -- hydrostatic substeps on the six faces, pass kernels (C12) and hybrid (C32)"""
+    assert max(PC.check_substeps_hydrostatic(emu, npx=13, npz=8, n_split=2, flags=dict(d_ext=0.02)).values()) <= 1e-13
+    assert max(PC.check_substeps_hydrostatic(emu, npx=33, npz=12, n_split=2, flags=dict(d_ext=0.02)).values()) <= 1e-13
