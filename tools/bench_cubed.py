@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--npz", type=int, default=127)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--nh", action="store_true")
+    ap.add_argument("--prod", action="store_true", help="nord = 3, do_vort_damp, vtdm4 = 0.06, d_con = 1, dddmp = 0.5")
     a = ap.parse_args()
     import torch
     from gfdl_atmos_cubed_sphere_amd.cubed_sphere import CubedSphere
@@ -34,7 +35,7 @@ def main():
     t = 0
     g, bd = gs[t], gs[t].bd
     ctx = Context(g, npz)
-    fl = DynFlags(hydrostatic=not a.nh)
+    fl = DynFlags(hydrostatic=not a.nh, **(dict(do_vort_damp=True, vtdm4=0.06, nord=3, d_con=1.0, dddmp=0.5) if a.prod else {}))
     ctx.dsw_levels(level_coefficients(npz, fl))
     d = {k: ctx.from_host(v) for k, v in st[t].items()}
     for n, kind in CSW_OUT:
@@ -44,7 +45,7 @@ def main():
     out = {n: ctx.zeros(kind, npz) for n, kind in (("delp_out", "A"), ("pt_out", "A"), ("u_out", "U"), ("v_out", "V"), ("w_out", "A"),
                                                    ("heat_s", "CC"), ("diss_e", "CC"))}
     par = dict(DSW_PAR)
-    par.update(dt=30.0, hydrostatic=int(not a.nh), use_cond=0)
+    par.update(dt=30.0, hydrostatic=int(not a.nh), use_cond=0, dddmp=fl.dddmp)
     hyd = not a.nh
 
     def pair():
