@@ -207,7 +207,18 @@ def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream):
     rep = ctx.profile_report()
     ctx.profile(False)
     ctx.close()
-    return {"sypd": dt_atmos / (365.0 * wall), "wall_s_per_dt_atmos": wall, "dt_atmos_s": dt_atmos, "k_split": k_split,
+    # the column kernels against THEIR OWN algorithmic bytes (words a column kernel must read / write once per cell, DESIGN.md
+    # section 3c): what VERDICT item 8 asks to see next to the pair's roofline
+    col_alg = {"riem_solver3": 72.0, "riem_solver_c": 48.0, "nh_p_grad": 64.0, "p_grad_c": 56.0, "update_dz_c": 40.0}
+    cells = nx * nx * npz
+    col = {}
+    for k_, nb in col_alg.items():
+        if k_ in rep and rep[k_][0] > 0:
+            ms_call = rep[k_][1] / rep[k_][0]
+            col[k_] = {"ms_per_call": round(ms_call, 4), "alg_bytes_per_cell": nb, "GBps": round(cells * nb / (ms_call * 1e-3) / 1e9, 1),
+                       "frac": round(cells * nb / (ms_call * 1e-3) / HBM_PEAK, 4)}
+    return {"column_kernels": col,
+            "sypd": dt_atmos / (365.0 * wall), "wall_s_per_dt_atmos": wall, "dt_atmos_s": dt_atmos, "k_split": k_split,
             "n_split": n_split, "nq": nq, "dx_m": 26000.0, "finite": bool(np.isfinite(w).all()),
             "note": f"one {nx}x{nx}x{npz} doubly periodic tile per GPU ({world} tile(s)); a C384 sphere is 6 such tiles, "
                     "so this is the SYPD of a 6-GPU one-face-per-GPU run before cube-edge exchange cost",

@@ -27,6 +27,7 @@ struct DswCubedState {
   double *dfx2 = nullptr, *dfy2 = nullptr;   // del6_vt_flux of the relative vorticity: "ut", "vt" of sw_core.F90:1513-1515
   double *vortv = nullptr;                   // the damping term added to ke (B layout), kept for the heating (:1462-1473)
   double *smag = nullptr;                    // a2b_ord4 of the relative vorticity (B values on the A layout), dddmp > 0
+  double *gxq = nullptr, *gyq = nullptr;     // fluxes of q_con (use_cond, :992-1000)
   // hybrid: the passes that write the outputs of d_sw only write the points of the frame of width own_w along the face edges
   // (0: every point); the marching kernels own the rest (DswArgs::mask_w)
   int own_w;
@@ -234,6 +235,11 @@ struct DswCubedD4 {
           wn = wn + dw;
         }
         view_A(g, s.a.w_out)(i, j, k) = wn;
+      }
+      if (s.a.use_cond) {  // :992-1000, :1277-1283
+        const CA gq = cview_FX(g, s.gxq), hq = cview_FY(g, s.gyq);
+        const double qv = dp * cview_A(g, s.a.q_con)(i, j, k) + (gq(i, j, k) - gq(i + 1, j, k) + hq(i, j, k) - hq(i, j + 1, k)) * ra;
+        view_A(g, s.a.q_con_out)(i, j, k) = qv / dpn;
       }
       view_CC(g, s.a.heat_s)(i, j, k) = heat;
       view_CC(g, s.a.diss_e)(i, j, k) = 0.;

@@ -1015,7 +1015,6 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
 static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   const Grid &g = c->g;
   if (!c->cg.ready) return fail("fv3_d_sw: cubed-sphere context without fv3_grid_upload_cubed");
-  if (a.use_cond) return fail("fv3_d_sw: use_cond is not built for the cubed sphere yet");
   if (g.do_diss_est) return fail("fv3_d_sw: do_diss_est is not built for the cubed sphere yet");
   DswCubedState s;
   s.g = g; s.cg = c->cg; s.a = a; s.own_w = 0;
@@ -1055,6 +1054,9 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   if (!(a.dddmp < 1.E-5)) {
     if (!(s.smag = cs_scratch(c, 24))) return fail("d_sw: out of device memory");
   }
+  if (a.use_cond) {
+    if (!(s.gxq = cs_scratch(c, 27)) || !(s.gyq = cs_scratch(c, 28))) return fail("d_sw: out of device memory");
+  }
   // contravariant winds of the whole face, all levels
   RT(launch_box(c, "dswc_d1", g.isd, g.ied + 1, g.jsd, g.jed + 1, npz, DswCubedD1a{s}));
   RT(launch_box(c, "dswc_d1b", 0, npx, 0, npy, npz, DswCubedD1b{s}));
@@ -1079,6 +1081,11 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
       RT(deln(a.delp, nullptr, s.fx, s.fy, a.lv.nord_v, a.lv.damp_vt, 1.E-4, 0, c->lev_max_nord_v, nullptr, nullptr, rg));
     if (!a.hydrostatic)
       RT(tp2d_cubed(c, npz, a.w, a.crx, a.cry, a.hord_vt, s.gxw, s.gyw, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, "dswc_tp", &rg));
+    if (a.use_cond) {                      // :992-995: q_con with hord_dp, delp's mass fluxes and pt's damping
+      RT(tp2d_cubed(c, npz, a.q_con, a.crx, a.cry, a.hord_dp, s.gxq, s.gyq, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, "dswc_tp", &rg));
+      if (c->lev_has_damp_t)
+        RT(deln(a.q_con, a.delp, s.gxq, s.gyq, a.lv.nord_t, a.lv.damp_t, 1.E-4, 0, c->lev_max_nord_t, nullptr, nullptr, rg));
+    }
     RT(tp2d_cubed(c, npz, a.pt, a.crx, a.cry, a.hord_tm, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, "dswc_tp", &rg));
     if (rg.w == 0 && c->lev_has_damp_t)    // :1014-1016: mass-weighted deln_flux inside fv_tp_2d(pt)
       RT(deln(a.pt, a.delp, s.gx, s.gy, a.lv.nord_t, a.lv.damp_t, 1.E-4, 0, c->lev_max_nord_t, nullptr, nullptr, rg));

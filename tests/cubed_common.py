@@ -90,12 +90,17 @@ def dsw_work_arrays(bd, npz):
     return f
 
 
-def oracle_pair(npx, npz, dt=300.0, hydrostatic=False, par_over=None, flags=None, st=None):
+def oracle_pair(npx, npz, dt=300.0, hydrostatic=False, par_over=None, flags=None, st=None, use_cond=False):
     """c_sw on every face, the halo updates dyn_core does in between, d_sw on every face.  Returns (cs, gs, before, after)."""
     if st is None:
         cs, gs, st = global_state(npx, npz, hydrostatic)
     else:
         cs, gs = sphere(npx)
+    if use_cond:      # a condensate mixing ratio in [0, 0.02] as a function of position (halo by exchange)
+        for t in range(6):
+            a3 = cs.grids[t]["agrid3"]
+            st[t]["q_con"] = F(np.stack([0.01 * (1.0 + np.sin(3.0 * a3[..., 0] + 0.4 * k) * np.cos(2.0 * a3[..., 1])) for k in range(npz)], axis=-1))
+        exchange(cs, st, ("q_con",), "A")
     fl = DynFlags(**(flags or {}))
     c = oracle_c_sw(gs, st, npz, 0.5 * dt, hydrostatic, nord=fl.nord)
     exchange_pair(cs, c, "uc", "vc", "C")                    # dyn_core.F90:565 (CGRID_NE)
@@ -105,6 +110,10 @@ def oracle_pair(npx, npz, dt=300.0, hydrostatic=False, par_over=None, flags=None
     par.update(dt=dt, nord=1, nord_v=1, nord_w=1, nord_t=1, d2_bg=0., damp_v=0., damp_w=0., damp_t=0., d_con=0.,
                hydrostatic=int(hydrostatic), use_cond=0)
     par.update(par_over or {})
+    if use_cond:
+        par["use_cond"] = 1
+        for t in range(6):
+            c[t]["q_con"] = st[t]["q_con"].copy(order="F")
     lev = level_coefficients(npz, fl)
     before = [{k: v.copy(order="F") for k, v in f.items()} for f in c]
     for t in range(6):

@@ -790,3 +790,11 @@ def test_cubed_sphere_with_production_flags(prod):
 
 def test_cubed_sphere_hydrostatic_external_mode_damping(prod):
     assert max(PC.check_substeps_hydrostatic(prod, npx=49, npz=12, n_split=2, bdt=450.0, flags=dict(d_ext=0.02)).values()) <= 1e-13
+
+
+@pytest.mark.parametrize("hydrostatic", [True, False])
+def test_cubed_d_sw_use_cond(prod, hydrostatic):
+    """thermostruct%use_cond on a face: q_con transported with delp's mass fluxes (and pt's damping when it is on)"""
+    assert max(PC.check_d_sw(prod, npx=25, npz=12, hydrostatic=hydrostatic, faces=(0, 4), use_cond=True).values()) <= P.TOL
+    assert max(PC.check_d_sw(prod, npx=25, npz=12, hydrostatic=hydrostatic, faces=(2,), use_cond=True,
+                             flags=dict(do_vort_damp=True, vtdm4=0.06, nord=2)).values()) <= P.TOL
