@@ -14,6 +14,8 @@
  *               line -- checked against vectors produced by executing the reference's own
  *               Python restatement docs/examples/tp_core.ipynb (tests/golden/ppm1d_*.npz,
  *               generator tests/golden/make_ppm1d_golden.py).
+ *               set_eta (L79, L127; restated in the package's test_cases.py) against the reference's own stand-alone
+ *               fv_eta.F90 compiled here (oracle/Makefile target `ref` -> oracle/_ref/, tests/golden/set_eta_golden.npz).
  *   unpinned  : everything else (fv_tp_2d, c_sw, d_sw, column solvers, remap).  The reference
  *               ships no unit tests / golden vectors, and its Fortran
  *               cannot be built here without writing stand-ins for the absent FMS library,
