@@ -673,7 +673,8 @@ extern "C" int fv3_grid_upload_cubed(fv3_ctx *c, const fv3_grid_cubed *h) {
   if (!h->edge_w || !h->edge_e || !h->edge_s || !h->edge_n || !h->rsina) return fail("fv3_grid_upload_cubed: null array");
   const Grid &g = c->g;
   const size_t ne = (size_t)g.npx, nr = (size_t)(g.nx + 1) * (g.ny + 1);
-  const size_t total = 4 * ((ne + 7) & ~(size_t)7) + nr;
+  const size_t nr8 = (nr + 7) & ~(size_t)7;
+  const size_t total = 4 * ((ne + 7) & ~(size_t)7) + nr8 + 4 * g.nA();
   if (!c->cg_dev) RT(rt_malloc((void **)&c->cg_dev, total * sizeof(double)));
   double *p = c->cg_dev;
   const double *src[4] = {h->edge_w, h->edge_e, h->edge_s, h->edge_n};
@@ -685,6 +686,17 @@ extern "C" int fv3_grid_upload_cubed(fv3_ctx *c, const fv3_grid_cubed *h) {
   }
   RT(rt_h2d(p, h->rsina, nr * sizeof(double), c->stream));
   c->cg.rsina = p;
+  p += nr8;
+  c->cg.a11 = c->cg.a12 = c->cg.a21 = c->cg.a22 = nullptr;
+  if (h->a11 && h->a12 && h->a21 && h->a22) {
+    const double *am[4] = {h->a11, h->a12, h->a21, h->a22};
+    const double **ad[4] = {&c->cg.a11, &c->cg.a12, &c->cg.a21, &c->cg.a22};
+    for (int n = 0; n < 4; n++) {
+      RT(rt_h2d(p, am[n], g.nA() * sizeof(double), c->stream));
+      *ad[n] = p;
+      p += g.nA();
+    }
+  }
   for (int n = 0; n < 12; n++) c->cg.corner_f[n] = h->corner_f[n];
   RT(rt_sync(c->stream));
   c->cg.ready = 1;
@@ -1920,8 +1932,9 @@ extern "C" int fv3_c2l(fv3_ctx *c, int ord, const double *u, const double *v, do
   if (!u || !v || !ua || !va) return fail("fv3_c2l: null field");
   if (ord != 2 && ord != 4) return fail("fv3_c2l: c2l_ord must be 2 or 4");
   const Grid &g = c->g;
-  if (g.grid_type < 4) return fail("fv3_c2l: only the Cartesian (grid_type = 4) branches are built");
-  C2L kf{g, ord, 1, u, v, nullptr, ua, va, nullptr};
+  if (g.grid_type == 3) return fail("fv3_c2l: grid_type 3 is not built");
+  if (g.grid_type < 3 && !(c->cg.ready && c->cg.a11)) return fail("fv3_c2l: cubed-sphere face without a11 .. a22 (fv3_grid_upload_cubed)");
+  C2L kf{g, ord, 1, u, v, nullptr, ua, va, nullptr, c->cg};
   Dim3 grid;
   grid.x = (unsigned)((g.nx * g.ny + C2L::CH - 1) / C2L::CH);
   grid.y = 1;
@@ -1935,10 +1948,11 @@ extern "C" int fv3_rayleigh_u2f(fv3_ctx *c, int kmax, int hydrostatic, const dou
   if (!c || !c->grid_ready) return fail("fv3_rayleigh_u2f: context has no grid");
   if (!u || !v || !ua || !va || !u2f || (!hydrostatic && !w)) return fail("fv3_rayleigh_u2f: null field");
   const Grid &g = c->g;
-  if (g.grid_type < 4) return fail("fv3_rayleigh_u2f: only the Cartesian (grid_type = 4) branch is built");
+  if (g.grid_type == 3) return fail("fv3_rayleigh_u2f: grid_type 3 is not built");
+  if (g.grid_type < 3 && !(c->cg.ready && c->cg.a11)) return fail("fv3_rayleigh_u2f: cubed-sphere face without a11 .. a22");
   if (kmax < 0 || kmax > g.npz) return fail("fv3_rayleigh_u2f: kmax out of range");
   if (kmax == 0) return 0;
-  C2L kf{g, 2, hydrostatic, u, v, w, ua, va, u2f};
+  C2L kf{g, 2, hydrostatic, u, v, w, ua, va, u2f, c->cg};
   Dim3 grid;
   grid.x = (unsigned)((g.nx * g.ny + C2L::CH - 1) / C2L::CH);
   grid.y = 1;

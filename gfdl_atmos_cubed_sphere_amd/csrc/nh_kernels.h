@@ -1113,6 +1113,7 @@ struct C2L {
   int ord, hydrostatic;
   const double *u, *v, *w;
   double *ua, *va, *u2f;
+  CubedGeom cg;   // grid_type < 4: the cubed_to_latlon matrix a11 .. a22
   static constexpr int CH = 1024;
   FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
     constexpr double a1 = 0.5625, a2 = -0.0625;
@@ -1122,7 +1123,25 @@ struct C2L {
       const int i = g.is + idx % g.nx, j = g.js + idx / g.nx;
       const size_t o = (size_t)bz * g.nA() + g.iA(i, j);
       double a, b;
-      if (ord == 2) {
+      if (g.grid_type < 4) {
+        // a face of the cubed sphere (fv_grid_utils.F90:2384-2466 ord 4, :2526-2546 ord 2): the "vorticity-conserving" two-point
+        // form in the rows / columns next to the face edges (and everywhere with ord 2), 4th order inside; then the rotation to
+        // (east, north) with a11 .. a22 (which carry the factor 1/2 of the two-point sums)
+        constexpr double c1 = 1.125, c2 = -0.125;
+        double ut, vt;
+        const bool edge = ord == 2 || i == 1 || i == g.npx - 1 || j == 1 || j == g.npy - 1;
+        if (edge) {
+          const double dx0 = g.dx[g.iU(i, j)], dx1 = g.dx[g.iU(i, j + 1)], dy0 = g.dy[g.iV(i, j)], dy1 = g.dy[g.iV(i + 1, j)];
+          ut = 2. * (uk[g.iU(i, j)] * dx0 + uk[g.iU(i, j + 1)] * dx1) / (dx0 + dx1);
+          vt = 2. * (vk[g.iV(i, j)] * dy0 + vk[g.iV(i + 1, j)] * dy1) / (dy0 + dy1);
+        } else {
+          ut = c2 * (uk[g.iU(i, j - 1)] + uk[g.iU(i, j + 2)]) + c1 * (uk[g.iU(i, j)] + uk[g.iU(i, j + 1)]);
+          vt = c2 * (vk[g.iV(i - 1, j)] + vk[g.iV(i + 2, j)]) + c1 * (vk[g.iV(i, j)] + vk[g.iV(i + 1, j)]);
+        }
+        const int oa = g.iA(i, j);
+        a = cg.a11[oa] * ut + cg.a12[oa] * vt;
+        b = cg.a21[oa] * ut + cg.a22[oa] * vt;
+      } else if (ord == 2) {
         a = 0.5 * (uk[g.iU(i, j)] + uk[g.iU(i, j + 1)]);
         b = 0.5 * (vk[g.iV(i, j)] + vk[g.iV(i + 1, j)]);
       } else {

@@ -683,5 +683,14 @@ class CubedSphere:
         for n in ("edge_w", "edge_e", "edge_s", "edge_n", "corner_f"):
             m[n] = g[n]
         m["grid"], m["agrid"] = F(g["grid"]), F(g["agrid"])
+        # init_cubed_to_latlon (fv_grid_utils.F90:2255-2315): the matrix from the cell-centre covariant winds to (east, north)
+        lon, lat = g["agrid"][..., 0], g["agrid"][..., 1]
+        vlon = np.stack([-np.sin(lon), np.cos(lon), np.zeros_like(lon)], axis=-1)                       # unit_vect_latlon :2220-2243
+        vlat = np.stack([-np.sin(lat) * np.cos(lon), -np.sin(lat) * np.sin(lon), np.cos(lat)], axis=-1)
+        z11, z12 = np.sum(g["ec1"] * vlon, -1), np.sum(g["ec1"] * vlat, -1)
+        z21, z22 = np.sum(g["ec2"] * vlon, -1), np.sum(g["ec2"] * vlat, -1)
+        s5 = g["sin_sg"][..., 4]
+        m["a11"], m["a12"] = F(0.5 * z22 / s5), F(-0.5 * z12 / s5)
+        m["a21"], m["a22"] = F(-0.5 * z21 / s5), F(0.5 * z11 / s5)
         gs.tile = t
         return gs

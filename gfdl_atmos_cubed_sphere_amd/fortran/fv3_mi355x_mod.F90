@@ -40,6 +40,7 @@ module fv3_mi355x_mod
   type, bind(C) :: fv3_grid_cubed     ! extra members of a cubed-sphere face (grid_type < 3): host addresses + factors
     type(c_ptr) :: edge_w, edge_e, edge_s, edge_n, rsina
     real(c_double) :: corner_f(12)
+    type(c_ptr) :: a11 = c_null_ptr, a12 = c_null_ptr, a21 = c_null_ptr, a22 = c_null_ptr   ! cubed_to_latlon matrix (A layout)
   end type
 
   type, bind(C) :: fv3_dsw_params

@@ -54,7 +54,8 @@ class _GridHost(C.Structure):
 
 
 class _GridCubed(C.Structure):
-    _fields_ = [(n, _dp) for n in ["edge_w", "edge_e", "edge_s", "edge_n", "rsina"]] + [("corner_f", C.c_double * 12)]
+    _fields_ = [(n, _dp) for n in ["edge_w", "edge_e", "edge_s", "edge_n", "rsina"]] + [("corner_f", C.c_double * 12)] + [
+        (n, _dp) for n in ["a11", "a12", "a21", "a22"]]
 
 
 class _DswParams(C.Structure):
@@ -245,7 +246,7 @@ class Context:
         self.geom = int(self.lib.dll.fv3_grid_geom(self.h))  # 0 general, 1 orthogonal, 2 orthogonal + uniform
         if grid.grid_type < 3:      # a face of the cubed sphere: edge weights, rsina, corner extrapolation factors
             gc = _GridCubed()
-            for n in ("edge_w", "edge_e", "edge_s", "edge_n", "rsina"):
+            for n in ("edge_w", "edge_e", "edge_s", "edge_n", "rsina") + (("a11", "a12", "a21", "a22") if "a11" in grid.m else ()):
                 a = np.asfortranarray(grid.m[n], dtype=np.float64)
                 keep.append(a)
                 setattr(gc, n, a.ctypes.data_as(_dp))

@@ -72,6 +72,9 @@ typedef struct fv3_grid_cubed {
   const double *edge_w, *edge_e, *edge_s, *edge_n;
   const double *rsina;
   double corner_f[12];
+  /* cubed_to_latlon (init_cubed_to_latlon, fv_grid_utils.F90:2255-2315): a11, a12, a21, a22 on the A layout (isd:ied, jsd:jed);
+   * NULL = fv3_c2l is not used on this face */
+  const double *a11, *a12, *a21, *a22;
 } fv3_grid_cubed;
 
 const char *fv3_last_error(void);

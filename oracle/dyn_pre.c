@@ -1,8 +1,8 @@
 /*
  * oracle/dyn_pre.c -- CPU oracle (test infrastructure, see fvo.h) for the pieces of fv_dynamics around the
- * k_split loop that touch the prognostic state on a doubly periodic domain (grid_type = 4):
- *   cubed_to_latlon   tools-free part of model/fv_grid_utils.F90:2319-2561 (c2l_ord2 :2551-2558 and
- *                     c2l_ord4 :2468-2475, the "simple Cartesian geometry" branches)
+ * k_split loop that touch the prognostic state:
+ *   cubed_to_latlon   tools-free part of model/fv_grid_utils.F90:2319-2561: c2l_ord2 (:2526-2558) and c2l_ord4 (:2384-2475),
+ *                     the "simple Cartesian geometry" branches (grid_type = 4) and the cubed-sphere ones (one tile per face)
  *   Rayleigh_Friction model/fv_dynamics.F90:1126-1264 (the branch fv_dynamics takes for grid_type = 4,
  *                     :368-376), split at the halo update of u2f (:1207-1209) that the caller performs
  * Plain IEEE evaluation of the reference's expressions, no FMA contraction.
@@ -21,15 +21,38 @@
 #define U3(i, j, k) ((size_t)((k)-1) * nid * (njd + 1) + (size_t)((j)-jsd) * nid + ((i)-isd))
 #define V3(i, j, k) ((size_t)((k)-1) * (nid + 1) * njd + (size_t)((j)-jsd) * (nid + 1) + ((i)-isd))
 #define CC3(i, j, k) ((size_t)((k)-1) * nx * ny + (size_t)((j)-js) * nx + ((i)-is))
+#define IA(i, j) ((size_t)((j)-jsd) * nid + ((i)-isd))
+#define IU(i, j) ((size_t)((j)-jsd) * nid + ((i)-isd))
+#define IV(i, j) ((size_t)((j)-jsd) * (nid + 1) + ((i)-isd))
 
-/* cubed_to_latlon for grid_type >= 4.  ord 2: c2l_ord2 (:2551-2558); ord 4: c2l_ord4 (:2468-2475), which needs the
+/* cubed_to_latlon.  ord 2: c2l_ord2 (:2551-2558); ord 4: c2l_ord4 (:2468-2475), which needs the
  * halo of u, v up to date (the reference's mode > 0 update, :2372-2376, is the caller's).  u: U x km, v: V x km,
  * ua, va: A x km (written on is:ie, js:je). */
 int fvo_c2l(const fvo_grid *g, int km, int ord, const double *u, const double *v, double *ua, double *va) {
   BOUNDS(g);
   const double a1 = 0.5625, a2 = -0.0625;
   int i, j, k;
-  if (g->grid_type < 4) return FVO_ERR_UNSUPPORTED;
+  if (g->grid_type == 3) return FVO_ERR_UNSUPPORTED;
+  if (g->grid_type < 3) { /* a face of the cubed sphere: fv_grid_utils.F90:2384-2466 (ord 4), :2526-2546 (ord 2) */
+    const double c1 = 1.125, c2 = -0.125;
+    const int npx = g->npx, npy = g->npy;
+    if (!g->a11) return FVO_ERR_UNSUPPORTED;
+    for (k = 1; k <= km; k++)
+      for (j = js; j <= je; j++)
+        for (i = is; i <= ie; i++) {
+          double ut, vt;
+          if (ord == 2 || i == 1 || i == npx - 1 || j == 1 || j == npy - 1) {
+            ut = 2. * (u[U3(i, j, k)] * g->dx[IU(i, j)] + u[U3(i, j + 1, k)] * g->dx[IU(i, j + 1)]) / (g->dx[IU(i, j)] + g->dx[IU(i, j + 1)]);
+            vt = 2. * (v[V3(i, j, k)] * g->dy[IV(i, j)] + v[V3(i + 1, j, k)] * g->dy[IV(i + 1, j)]) / (g->dy[IV(i, j)] + g->dy[IV(i + 1, j)]);
+          } else {
+            ut = c2 * (u[U3(i, j - 1, k)] + u[U3(i, j + 2, k)]) + c1 * (u[U3(i, j, k)] + u[U3(i, j + 1, k)]);
+            vt = c2 * (v[V3(i - 1, j, k)] + v[V3(i + 2, j, k)]) + c1 * (v[V3(i, j, k)] + v[V3(i + 1, j, k)]);
+          }
+          ua[A3(i, j, k)] = g->a11[IA(i, j)] * ut + g->a12[IA(i, j)] * vt;
+          va[A3(i, j, k)] = g->a21[IA(i, j)] * ut + g->a22[IA(i, j)] * vt;
+        }
+    return FVO_OK;
+  }
   for (k = 1; k <= km; k++)
     for (j = js; j <= je; j++)
       for (i = is; i <= ie; i++) {

@@ -74,6 +74,7 @@ typedef struct fvo_grid {
    * corners sw, se, ne, nw x the three (inner, outer) cell-centre pairs in the reference's order */
   const double *edge_w, *edge_e, *edge_s, *edge_n;
   double corner_f[12];
+  const double *a11, *a12, *a21, *a22; /* cubed_to_latlon matrix (fv_grid_utils.F90:2255-2315), A layout; NULL = absent */
 } fvo_grid;
 
 /* ---- tp_core (model/tp_core.F90) ------------------------------------------------------- */

@@ -33,7 +33,8 @@ class FvoGrid(C.Structure):
         + [(n, _dp) for n in _A + _U + _V + _B + ["rsina", "sin_sg", "cos_sg"]]
         + [("lim_fac", C.c_double), ("do_diss_est", C.c_int), ("prevent_diss_cooling", C.c_int),
            ("do_f3d", C.c_int)]
-        + [(n, _dp) for n in ["edge_w", "edge_e", "edge_s", "edge_n"]] + [("corner_f", C.c_double * 12)]
+        + [(n, _dp) for n in ["edge_w", "edge_e", "edge_s", "edge_n"]] + [("corner_f", C.c_double * 12)] \
+        + [(n, _dp) for n in ["a11", "a12", "a21", "a22"]]
     )
 
 
@@ -116,6 +117,9 @@ def make_grid(g) -> FvoGrid:
             setattr(s, n, a.ctypes.data_as(_dp))
         for k, v in enumerate(np.asarray(g.m["corner_f"], dtype=np.float64).ravel()):
             s.corner_f[k] = v
+        if "a11" in g.m:
+            for n in ("a11", "a12", "a21", "a22"):
+                setattr(s, n, p(g.m[n]))
         s._keep_edges = keep
     s._keep = g  # keep the numpy arrays alive
     return s

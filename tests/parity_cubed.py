@@ -432,3 +432,34 @@ def check_del2_cubed(lib, npx=13, npz=3, nmax=3, faces=range(6)):
         finally:
             ctx.close()
     return worst
+
+
+def check_c2l(lib, ord_, npx=13, npz=3, faces=range(6)):
+    """cubed_to_latlon (c2l_ord2 / c2l_ord4, fv_grid_utils.F90:2330-2560) on the faces: D-grid winds -> (east, north) at the cell
+    centres; for the solid-body part of the test wind the result is the analytic zonal / meridional wind to discretisation error"""
+    cs, gs, st = CC.global_state(npx, npz, hydrostatic=True)
+    worst = 0.0
+    for t in faces:
+        g, bd = gs[t], gs[t].bd
+        ua, va = bd.zeros("A", npz), bd.zeros("A", npz)
+        O.c2l(g, npz, ord_, st[t]["u"], st[t]["v"], ua, va)
+        ctx = Context(g, npz, lib=lib)
+        try:
+            d_ua, d_va = ctx.zeros("A", npz), ctx.zeros("A", npz)
+            ctx.c2l(ord_, ctx.from_host(st[t]["u"]), ctx.from_host(st[t]["v"]), d_ua, d_va)
+            r = (bd.is_, bd.ie, bd.js, bd.je)
+            worst = max(worst, P.assert_close(f"face {t + 1} ua", bd.view(d_ua.download(), "A", *r), bd.view(ua, "A", *r)))
+            worst = max(worst, P.assert_close(f"face {t + 1} va", bd.view(d_va.download(), "A", *r), bd.view(va, "A", *r)))
+            # physics: the winds are those of CC.wind at the centres
+            a3 = cs.grids[t]["agrid3"]
+            lon, lat = cs.grids[t]["agrid"][..., 0], cs.grids[t]["agrid"][..., 1]
+            e = np.stack([-np.sin(lon), np.cos(lon), np.zeros_like(lon)], -1)
+            n = np.stack([-np.sin(lat) * np.cos(lon), -np.sin(lat) * np.sin(lon), np.cos(lat)], -1)
+            w3 = CC.wind(a3)
+            c = (slice(bd.ng, bd.ng + bd.nx), slice(bd.ng, bd.ng + bd.nx))
+            ue, vn = np.sum(w3 * e, -1)[c], np.sum(w3 * n, -1)[c]
+            assert np.max(np.abs(bd.view(ua, "A", *r)[:, :, 0] - ue)) < 0.12 * np.max(np.abs(ue)), t      # C12: coarse + the 2 % ripple
+            assert np.max(np.abs(bd.view(va, "A", *r)[:, :, 0] - vn)) < 0.12 * max(np.max(np.abs(vn)), np.max(np.abs(ue))), t
+        finally:
+            ctx.close()
+    return worst

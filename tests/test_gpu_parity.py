@@ -798,3 +798,10 @@ def test_cubed_d_sw_use_cond(prod, hydrostatic):
     assert max(PC.check_d_sw(prod, npx=25, npz=12, hydrostatic=hydrostatic, faces=(0, 4), use_cond=True).values()) <= P.TOL
     assert max(PC.check_d_sw(prod, npx=25, npz=12, hydrostatic=hydrostatic, faces=(2,), use_cond=True,
                              flags=dict(do_vort_damp=True, vtdm4=0.06, nord=2)).values()) <= P.TOL
+
+
+@pytest.mark.parametrize("c2l_ord", [2, 4])
+def test_cubed_to_latlon_on_the_sphere(prod, c2l_ord):
+    """cubed_to_latlon on the six faces (the a11 .. a22 rotation of init_cubed_to_latlon, the two-point forms next to the face
+    edges): device = oracle, and the result is the analytic (east, north) wind of the test state to discretisation error"""
+    assert PC.check_c2l(prod, c2l_ord, npx=25) <= P.TOL
