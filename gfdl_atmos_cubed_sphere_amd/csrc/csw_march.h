@@ -58,11 +58,13 @@ struct CswLevel {
   vd ua_p, va_p, uc_p, vc_p, ut_p, vt_p;  // row Q = t-3 (previous step's row R)
   vd ucdx_p, vort_p, ke_p, vdxc_p;
   vd fy1_p, fyp_p, fyw_p;     // upwind fluxes through y-face Q (delp, pt, w)
+  vd va_pp, vf_p;             // cubed-sphere divergence: va of row Q-1, vf of corner row Q-1
   FV3_D void init() {
     u0 = u1 = u2 = u3 = v0 = v1 = v2 = v3 = vt0 = vt1 = vt2 = vt3 = vd(0.);
     dp0 = dpp = pt0 = ptp = w0 = wp = vd(0.);
     ua_p = va_p = uc_p = vc_p = ut_p = vt_p = ucdx_p = vort_p = ke_p = vdxc_p = vd(0.);
     fy1_p = fyp_p = fyw_p = vd(0.);
+    va_pp = vf_p = vd(0.);
   }
 };
 
@@ -159,6 +161,7 @@ struct CswMarch {
     for (int m = 0; m < KPW; m++) st[m].init();
     // metric rows that are needed again one step later (row R becomes row Q)
     vd cosau_p(0.), dxc_p(0.), dyc_p(0.), rac_p(0.);
+    vd sg3_p(0.), sg1_p(0.), sg4_p(0.), sg2_p(0.);   // cubed-sphere divergence: the sin_sg rows of row R, used one step later
 
     // everything step t reads from memory is loaded one step ahead (software pipelining)
     CswMetrics mnxt = load_metrics(jA - 2);
@@ -170,8 +173,15 @@ struct CswMarch {
       const CswMetrics in = mnxt;
       mnxt = load_metrics(tn);
       vd cosav_r(0.), rsinv_r(1.);  // cubed-sphere face: vt = (vc - u*cosa_v)*rsin_v (:3340), not vt = vc (:3350)
+      vd csu(0.), csv(0.);          // ... and the cos_sg sums of the non-orthogonal divergence_corner at row Q (:1798-1843)
       if constexpr (GM == 0)
-        if (mw) { cosav_r = LU(g.cosa_v, R); rsinv_r = LU(g.rsin_v, R); }
+        if (mw) {
+          cosav_r = LU(g.cosa_v, R); rsinv_r = LU(g.rsin_v, R);
+          if (a.nord > 0) {
+            csu = LA(g.cos_sg + 3 * nAp, Q - 1) + LA(g.cos_sg + nAp, Q);        // cos_sg(i,j-1,4) + cos_sg(i,j,2)
+            csv = LA(g.cos_sg + 2 * nAp, Q, -1) + LA(g.cos_sg, Q);              // cos_sg(i-1,j,3) + cos_sg(i,j,1)
+          }
+        }
       for (int m = 0; m < KPW; m++) {
         CswLevel &S = st[m];
         const int k = kl[m];
@@ -266,12 +276,25 @@ struct CswMarch {
           const vd uf = S.u0 * dyc_q;
           vstore(a.divg_d + oB, (long)g.iB(ilo, Q), rac_q * (S.vdxc_p - vdxc + shr1(uf) - uf), l0, l2);
         }
+        if constexpr (GM == 0) {
+          if (mw && a.nord > 0) {  // the interior of a cubed-sphere face: the non-orthogonal form with ua, va of rows Q-1, Q
+            const vd uf = (S.u0 - 0.25 * (S.va_pp + S.va_p) * csu) * dyc_q * 0.5 * (sg4_p + sg2_p);
+            const vd vf = (S.v1 - 0.25 * (shr1(S.ua_p) + S.ua_p) * csv) * dxc_q * 0.5 * (sg3_p + sg1_p);
+            if (live[m] && Q >= jA && Q <= jB && Q >= oJ0 && Q <= oJ1)
+              vstore(a.divg_d + oB, (long)g.iB(ilo, Q), rac_q * (S.vf_p - vf + shr1(uf) - uf), l0, l2);
+            S.vf_p = vf;
+            S.va_pp = S.va_p;
+          }
+        }
         // ---- rotate the row state ------------------------------------------------------------------------------------
         S.ua_p = ua; S.va_p = va; S.uc_p = uc; S.vc_p = vc; S.ut_p = ut; S.vt_p = vt;
         S.ucdx_p = ucdx; S.vort_p = vort; S.ke_p = ke; S.vdxc_p = vdxc;
         S.fy1_p = fy1_n; S.fyp_p = fyp_n; S.fyw_p = fyw_n;
       }
-      if constexpr (GM == 0) cosau_p = in.cosau;
+      if constexpr (GM == 0) {
+        cosau_p = in.cosau;
+        sg3_p = in.sg3; sg1_p = in.sg1; sg4_p = in.sg4; sg2_p = in.sg2;
+      }
       if constexpr (GM <= 1) { dxc_p = in.dxc; dyc_p = in.dyc; rac_p = in.rac; }
     }
   }

@@ -271,7 +271,9 @@ struct DswTransportFused {
 // u, v, uc, vc, divg_d, crx, xfx, cry, yfx in; u, v, delpc out = 96 B per cell-update (was 136).
 namespace fv3 {
 
-template <int SWC, int HORD, int GM = 0>
+// CS: the interior of a cubed-sphere face (hybrid of fv3_api.hip dsw_cubed: store mask, non-orthogonal B-grid winds); a
+// compile-time switch so that the doubly periodic instantiations keep their register budget
+template <int SWC, int HORD, int GM = 0, bool CS = false>
 struct DswMomentumFused {
   static constexpr bool UNI = (GM == 2);  // orthogonal + uniform metrics: scalars instead of metric rows
   // two wavefronts per SIMD: 254 VGPRs with the general metric rows (the row-j values of the wind update are re-read at
@@ -306,11 +308,11 @@ struct DswMomentumFused {
     double *dpc = a.delpc ? a.delpc + (size_t)k * g.nA() : nullptr;
     const double dt5 = 0.5 * a.dt;
     // cubed-sphere hybrid: lanes / rows of the outputs this kernel owns (DswArgs::mask_w)
-    const int mw = a.mask_w;
-    const int oC0 = mw ? (s.lC0 > mw + 1 - ilo ? s.lC0 : mw + 1 - ilo) : s.lC0;
-    const int oC1 = mw ? (s.lC1 < g.npx - mw - 1 - ilo ? s.lC1 : g.npx - mw - 1 - ilo) : s.lC1;
-    const int oF1 = mw ? (lFx1 < g.npx - mw - 1 - ilo ? lFx1 : g.npx - mw - 1 - ilo) : lFx1;
-    const int oJ0 = mw ? mw + 1 : g.jsd, oJ1 = mw ? g.npy - mw - 1 : g.jed + 1;
+    const int mw = CS ? a.mask_w : 0;
+    const int oC0 = (CS && mw) ? (s.lC0 > mw + 1 - ilo ? s.lC0 : mw + 1 - ilo) : s.lC0;
+    const int oC1 = (CS && mw) ? (s.lC1 < g.npx - mw - 1 - ilo ? s.lC1 : g.npx - mw - 1 - ilo) : s.lC1;
+    const int oF1 = (CS && mw) ? (lFx1 < g.npx - mw - 1 - ilo ? lFx1 : g.npx - mw - 1 - ilo) : lFx1;
+    const int oJ0 = (CS && mw) ? mw + 1 : g.jsd, oJ1 = (CS && mw) ? g.npy - mw - 1 : g.jed + 1;
     const double d2_bg = a.lv.d2_divg[k];
     const double damp2 = g.da_min_c * dmax(d2_bg, dmin(0.20, a.dddmp * 0.));            // :1454 with vort = 0
     const double dd8 = g.stretched_grid ? g.da_min * ipow(a.d4_bg, 2) : ipow(g.da_min_c * a.d4_bg, 2);  // :1446-1450
@@ -396,7 +398,7 @@ struct DswMomentumFused {
       if (jc >= jA) {
         vd vb = dt5 * (shr1(in.vc) + in.vc);                               // :1129
         vd ub2 = dt5 * (uc_p + in.uc);                                     // :1186
-        if (a.rsina) {  // the interior of a cubed-sphere face (grid_type < 3): :1104-1106, :1168-1170
+        if constexpr (CS) {  // the interior of a cubed-sphere face (grid_type < 3): :1104-1106, :1168-1170
           const int jr = jc > g.je + 1 ? g.je + 1 : jc;
           const vd cosa = vload(g.cosa, (long)g.iB(ilo, jr), s.A);
           const vd rsina = vload(a.rsina, (long)(jr - g.js) * (g.nx + 1) + (ilo - g.is), s.F);

@@ -731,8 +731,8 @@ static int csw_cubed(fv3_ctx *c, const CswArgs &ca) {
   const int npz = g.npz;
   // Hybrid (see dsw_cubed): d2a2c_vect switches to its edge forms within npt = 4 points of a face edge, so the frame the
   // passes own is wider than in d_sw.  The passes run FIRST (P3 leaves the interpolated uc, vc on the wider frame of the
-  // intermediates, which P4 / P5 read), then the marching kernel writes the points it owns, then the divergence -- the
-  // non-orthogonal form of the cubed sphere, which reads the final ua, va -- as a pass over the whole face.
+  // intermediates, which P4 / P5 read), then the marching kernel writes the points it owns -- the divergence too, in the
+  // non-orthogonal form of the cubed sphere --, then the divergence of the frame, which reads the final ua, va, by the pass.
   const int wo = c->cubed_frame_c, wm = wo + c->cubed_reach;
   const bool hyb = c->use_march && wo > 0 && g.npx == g.npy && g.npx - 1 >= 2 * wm + 8;
   const PassRegion rm{hyb ? wm : 0, nullptr, npz}, ro{hyb ? wo : 0, nullptr, npz};
@@ -748,9 +748,9 @@ static int csw_cubed(fv3_ctx *c, const CswArgs &ca) {
     CswArgs cm = ca;
     cm.mask_w = wo;
     RT(csw_march(c, cm));
-    if (ca.nord > 0) {
+    if (ca.nord > 0) {  // the marching kernel formed the divergence of the points it owns; the frame by the pass
       s.divg = 2;
-      RT(launch_box(c, "cswc_div", g.is, g.ie + 1, g.js, g.je + 1, npz, CswCubedP3{s}));
+      RT(launch_pass(c, "cswc_div", g.is, g.ie + 1, g.js, g.je + 1, ro, CswCubedP3{s}));
     }
   }
   return 0;
@@ -991,12 +991,19 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
           default: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<8, HORD, 2>{g, a, mf});
         }
       }
-      switch (a.rsina ? sw_class_cubed(a.hord_mt) : sw_class(a.hord_mt)) {
+      if (a.rsina) {  // the interior of a cubed-sphere face
+        switch (sw_class_cubed(a.hord_mt)) {
+          case 5: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<5, HORD, 0, true>{g, a, mf});
+          case 6: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<6, HORD, 0, true>{g, a, mf});
+          case 108: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<108, HORD, 0, true>{g, a, mf});
+          case 110: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<110, HORD, 0, true>{g, a, mf});
+          case 111: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<111, HORD, 0, true>{g, a, mf});
+          default: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<8, HORD, 0, true>{g, a, mf});
+        }
+      }
+      switch (sw_class(a.hord_mt)) {
         case 5: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<5, HORD>{g, a, mf});
         case 6: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<6, HORD>{g, a, mf});
-        case 108: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<108, HORD>{g, a, mf});
-        case 110: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<110, HORD>{g, a, mf});
-        case 111: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<111, HORD>{g, a, mf});
         default: return launch_w(c, "d_sw_mom_fused", nwf, DswMomentumFused<8, HORD>{g, a, mf});
       }
     });

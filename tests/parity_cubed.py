@@ -294,6 +294,16 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
                 for iq in range(nq):
                     worst["q"] = max(worst.get("q", 0.0), P.assert_close(f"face {t + 1} q{iq}", bd.view(got[t][:, :, :, iq], "A", *r),
                                                                            bd.view(ref[t]["q"][:, :, :, iq], "A", *r), tol))
+        # cubed_to_latlon of the new winds (fv_dynamics.F90:911): halo update of u, v (c2l_ord4), then the rotation to (east, north)
+        fv.cubed_to_latlon()
+        ru, rv = [x["u"].copy(order="F") for x in ref], [x["v"].copy(order="F") for x in ref]
+        cs.topo.update("D", (ru, rv))
+        gua, gva = d["ua"].download(), d["va"].download()
+        for t in range(6):
+            ua, va = bd.zeros("A", npz), bd.zeros("A", npz)
+            O.c2l(gs[t], npz, fv.c2l_ord, ru[t], rv[t], ua, va)
+            worst["ua"] = max(worst.get("ua", 0.0), P.assert_close(f"face {t + 1} ua", bd.view(gua[t], "A", *r), bd.view(ua, "A", *r), tol))
+            worst["va"] = max(worst.get("va", 0.0), P.assert_close(f"face {t + 1} va", bd.view(gva[t], "A", *r), bd.view(va, "A", *r), 10 * tol))
         dp = d["delp"].download()
         s = slice(ng, ng + nx)
         worst["finite"] = float(all(np.isfinite(x[s, s, :]).all() for x in dp))
