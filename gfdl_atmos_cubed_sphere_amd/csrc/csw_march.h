@@ -73,7 +73,9 @@ struct CswLevel {
 // GM = geometry mode of the gridstruct (Grid::geom): 0 = every metric row is read; 1 = orthogonal grid (the angle
 // terms cosa_* = 0, sin* = rsin* = 1 are not read: x*1 and x - y*0 are exact); 2 = orthogonal and uniform (the
 // length / area terms are wave-uniform scalars, only fC is read).
-template <int KPW, int GM = 0>
+// CS: the interior of a cubed-sphere face (hybrid of fv3_api.hip csw_cubed: store mask, vt of d2a2c_vect's grid_type < 3 branch,
+// the non-orthogonal divergence_corner) -- a compile-time switch: the doubly periodic instantiations keep their registers
+template <int KPW, int GM = 0, bool CS = false>
 struct CswMarch {
 #ifdef FV3_CSW_TWO_WAVES
   static constexpr int kTwoWavesPerSimd = 1;
@@ -94,7 +96,7 @@ struct CswMarch {
     const vl cV = make_lanes(cl(g.isd - ilo, 0, kW - 1), cl(g.ied + 1 - ilo, 0, kW - 1));  // (nid+1)-wide rows
     int l2 = cl(ie + 2 - ilo, 0, kCswLast), l1 = cl(ie + 1 - ilo, 0, kCswLast);  // last owned lane: i <= ie+2 / ie+1
     // cubed-sphere hybrid: the lanes / rows of the outputs this kernel owns (CswArgs::mask_w)
-    const int mw = a.mask_w;
+    const int mw = CS ? a.mask_w : 0;
     const int l0 = mw ? (3 > mw + 1 - ilo ? 3 : mw + 1 - ilo) : 3;
     if (mw) {
       const int lm = g.npx - mw - 1 - ilo;
@@ -174,7 +176,7 @@ struct CswMarch {
       mnxt = load_metrics(tn);
       vd cosav_r(0.), rsinv_r(1.);  // cubed-sphere face: vt = (vc - u*cosa_v)*rsin_v (:3340), not vt = vc (:3350)
       vd csu(0.), csv(0.);          // ... and the cos_sg sums of the non-orthogonal divergence_corner at row Q (:1798-1843)
-      if constexpr (GM == 0)
+      if constexpr (GM == 0 && CS)
         if (mw) {
           cosav_r = LU(g.cosa_v, R); rsinv_r = LU(g.rsin_v, R);
           if (a.nord > 0) {
@@ -209,7 +211,7 @@ struct CswMarch {
         if constexpr (GM == 0) {
           ut = (uc - S.v2 * in.cosau) * in.rsinu;                                   // :3200
           ut = vsel(ut > 0., dt2 * ut * in.dy * in.sg3, dt2 * ut * in.dy * in.sg1);  // :159-167
-          if (mw) vt = (vc - S.u1 * cosav_r) * rsinv_r;
+          if constexpr (CS) { if (mw) vt = (vc - S.u1 * cosav_r) * rsinv_r; }
           vt = vsel(vt > 0., dt2 * vt * in.dx * in.sg4, dt2 * vt * in.dx * in.sg2);  // :168-176 (vt = vc, :3350)
         } else {
           ut = dt2 * ut * in.dy;
@@ -276,7 +278,7 @@ struct CswMarch {
           const vd uf = S.u0 * dyc_q;
           vstore(a.divg_d + oB, (long)g.iB(ilo, Q), rac_q * (S.vdxc_p - vdxc + shr1(uf) - uf), l0, l2);
         }
-        if constexpr (GM == 0) {
+        if constexpr (GM == 0 && CS) {
           if (mw && a.nord > 0) {  // the interior of a cubed-sphere face: the non-orthogonal form with ua, va of rows Q-1, Q
             const vd uf = (S.u0 - 0.25 * (S.va_pp + S.va_p) * csu) * dyc_q * 0.5 * (sg4_p + sg2_p);
             const vd vf = (S.v1 - 0.25 * (shr1(S.ua_p) + S.ua_p) * csv) * dxc_q * 0.5 * (sg3_p + sg1_p);
@@ -293,7 +295,7 @@ struct CswMarch {
       }
       if constexpr (GM == 0) {
         cosau_p = in.cosau;
-        sg3_p = in.sg3; sg1_p = in.sg1; sg4_p = in.sg4; sg2_p = in.sg2;
+        if constexpr (CS) { sg3_p = in.sg3; sg1_p = in.sg1; sg4_p = in.sg4; sg2_p = in.sg2; }
       }
       if constexpr (GM <= 1) { dxc_p = in.dxc; dyc_p = in.dyc; rac_p = in.rac; }
     }

@@ -857,9 +857,14 @@ static int csw_march(fv3_ctx *c, const CswArgs &ca) {
     const int tj_csw = c->march_tj_csw ? c->march_tj_csw : (c->g.geom == 2 ? 24 : 64);
     MarchDims md = make_csw_dims(c->g, seg_rows(c, tj_csw, c->g.npz));
     // uniform metrics: nothing to share between levels, one level per wavefront at four wavefronts per SIMD is faster
-    const int kpw = c->csw_kpw ? c->csw_kpw : (c->g.geom == 2 ? 1 : 2);
+    int kpw = c->csw_kpw ? c->csw_kpw : (c->g.geom == 2 ? 1 : 2);
+    if (ca.mask_w > 0 && kpw > 2) kpw = 2;   // the cubed-sphere instantiations: one or two levels per wavefront
     const int nkg = (c->g.npz + kpw - 1) / kpw;
     const int nw = md.nwaves(nkg);
+    if (ca.mask_w > 0) {  // the interior of a cubed-sphere face: general metrics + the cubed switches
+      if (kpw == 1) return launch_w(c, "c_sw", nw, CswMarch<1, 0, true>{c->g, ca, md, nkg});
+      return launch_w(c, "c_sw", nw, CswMarch<2, 0, true>{c->g, ca, md, nkg});
+    }
     auto go = [&](auto GMc) -> int {
       constexpr int GM = decltype(GMc)::value;
       if (kpw == 4) return launch_w(c, "c_sw", nw, CswMarch<4, GM>{c->g, ca, md, nkg});
