@@ -417,7 +417,9 @@ def main():
     g = doubly_periodic(bd, nx * px + 1, nx * py + 1, dx_const=26000.0, dy_const=26000.0)
     stream = torch.cuda.current_stream()
     cells = nx * nx * npz
-    lev = level_coefficients(npz, DynFlags())
+    # FV3_BENCH_SPONGE=0 (diagnostic): no sponge levels, every level in the marching kernels -- NOT the headline workload
+    lev = level_coefficients(npz, DynFlags(d2_bg_k1=0.0, d2_bg_k2=0.0) if os.environ.get("FV3_BENCH_SPONGE") == "0"
+                             else DynFlags())
     nlev = level_sets(lev)
     build = L.build_id()
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -565,7 +567,9 @@ def main():
                                   f"c_sw+d_sw pair, hord {a.hord}/{a.hord}/{a.hord}/{a.hord}, nord=1, d4_bg=0.16",
                       "layout": f"{px}x{py}", "halo": ("RCCL send/recv (loopback)" if loopback else "periodic copy") if world == 1 else "RCCL send/recv",
                       # what fv3_grid_upload found in the metric arrays (fv3_grid_geom)
-                      "gridstruct": GEOM[geom], "build_id": build},
+                      "gridstruct": GEOM[geom], "build_id": build,
+                      "sponge_levels": "off (FV3_BENCH_SPONGE=0, diagnostic)" if os.environ.get("FV3_BENCH_SPONGE") == "0"
+                      else "d2_bg_k1 0.20, d2_bg_k2 0.015 (2 levels)"},
            "finite": finite, "roofline": roof, "general_metrics": gm}
     # the secondary legs must never cost the headline line: a failure there is reported, not raised
     out["model_step"] = None

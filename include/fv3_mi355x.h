@@ -27,8 +27,9 @@
  *     model/dyn_core.F90:823-825,1169).
  *   - Work is enqueued on the context's HIP stream (fv3_set_stream); nothing synchronises.
  *   - Supported branch sets: grid_type = 4 (doubly periodic / Cartesian branches of the reference) with array-valued
- *     metric terms, and grid_type < 3 (a whole face of the cubed sphere per context: face edges and corners); no nesting,
- *     no regional BCs.
+ *     metric terms, and grid_type < 3 (a whole face of the cubed sphere per context: face edges and corners, the damping,
+ *     heating and condensate branches included; do_diss_est is refused there); no nesting, no regional BCs.  A branch that
+ *     is not built returns non-zero with the reason in fv3_last_error() -- never a silent fallback.
  */
 #ifndef FV3_MI355X_H
 #define FV3_MI355X_H
@@ -316,9 +317,11 @@ int fv3_apply_heat_source(fv3_ctx *ctx, int n_con, int hydrostatic, double bdt, 
                           double cv_air, double rdgas, double grav, double *pt, double *heat_source, const double *delp,
                           const double *delz, double *pkz);
 
-/* ---- fv_dynamics around the k_split loop, Cartesian (grid_type = 4) branches -------------------------------------
- * fv3_c2l = cubed_to_latlon (model/fv_grid_utils.F90:2319): c2l_ord = 2 -> c2l_ord2 (:2551-2558), 4 -> c2l_ord4
- *   (:2468-2475; the halo update of u, v that the reference does first with mode > 0, :2372-2376, is the caller's).
+/* ---- fv_dynamics around the k_split loop ---------------------------------------------------------------------------
+ * fv3_c2l = cubed_to_latlon (model/fv_grid_utils.F90:2319): c2l_ord = 2 -> c2l_ord2 (:2526-2558), 4 -> c2l_ord4
+ *   (:2384-2475; the halo update of u, v that the reference does first with mode > 0, :2372-2376, is the caller's); the
+ *   Cartesian branches on grid_type = 4, on a cubed-sphere face the two-point forms next to the face edges and the rotation
+ *   to (east, north) with a11 .. a22 of fv3_grid_cubed.
  *   u: U x npz, v: V x npz in; ua, va: A x npz out on the compute domain.  Called at fv_dynamics.F90:911.
  * Rayleigh_Friction (model/fv_dynamics.F90:1126-1264; the branch of :368-376 for grid_type = 4) is two calls around
  *   the halo update of u2f (:1207-1209), which the caller performs with its halo exchanger:
