@@ -211,7 +211,7 @@ struct DswCubedD4 {
       ptv = ptv / dpn;
       view_A(g, s.a.delp_out)(i, j, k) = dpn;
       view_A(g, s.a.pt_out)(i, j, k) = ptv;
-      double heat = 0.;
+      double heat = 0., diss = 0.;
       if (!s.a.hydrostatic) {
         const CA gxw = cview_FX(g, s.gxw), gyw = cview_FY(g, s.gyw), w = cview_A(g, s.a.w);
         const double w0 = w(i, j, k);
@@ -232,6 +232,7 @@ struct DswCubedD4 {
           }
           const double tmp = dw * (w0 + 0.5 * dw);
           heat = g.prevent_diss_cooling ? dd8 - dmin(0., tmp) : dd8 - tmp;
+          if (g.do_diss_est) diss = g.prevent_diss_cooling ? dd8 - tmp : heat;   // :964-966, :976-978
           wn = wn + dw;
         }
         view_A(g, s.a.w_out)(i, j, k) = wn;
@@ -242,7 +243,7 @@ struct DswCubedD4 {
         view_A(g, s.a.q_con_out)(i, j, k) = qv / dpn;
       }
       view_CC(g, s.a.heat_s)(i, j, k) = heat;
-      view_CC(g, s.a.diss_e)(i, j, k) = 0.;
+      view_CC(g, s.a.diss_e)(i, j, k) = diss;
     }
   }
 };
@@ -629,12 +630,13 @@ struct DswCubedD10 {
   FV3_HD void operator()(int i, int j, int k) const {
     const Grid &g = s.g;
     const double d_con = s.a.lv.d_con_k[k];
-    if (!(d_con > 1.E-5)) return;
+    const bool est = g.do_diss_est;   // :1462, :1523: every level then; "ut", "vt" are zeroed where nothing damps the vorticity (:1516-1519)
+    if (!(d_con > 1.E-5) && !est) return;
     const bool vdamp = s.a.lv.damp_vt[k] > 1.E-5;
     const CA vv = cview_B(g, s.vortv), un = cview_U(g, s.a.u_out), vn = cview_V(g, s.a.v_out);
     const CA u = cview_U(g, s.a.u), v = cview_V(g, s.a.v);
-    auto vt_ = [&](int ii, int jj) { return vdamp ? cview_U(g, s.dfy2)(ii, jj, k) : u(ii, jj, k) * g.dx[g.iU(ii, jj)]; };
-    auto ut_ = [&](int ii, int jj) { return vdamp ? cview_V(g, s.dfx2)(ii, jj, k) : v(ii, jj, k) * g.dy[g.iV(ii, jj)]; };
+    auto vt_ = [&](int ii, int jj) { return vdamp ? cview_U(g, s.dfy2)(ii, jj, k) : (est ? 0. : u(ii, jj, k) * g.dx[g.iU(ii, jj)]); };
+    auto ut_ = [&](int ii, int jj) { return vdamp ? cview_V(g, s.dfx2)(ii, jj, k) : (est ? 0. : v(ii, jj, k) * g.dy[g.iV(ii, jj)]); };
     auto ub = [&](int ii, int jj) { return ((vv(ii, jj, k) - vv(ii + 1, jj, k)) + vt_(ii, jj)) * g.rdx[g.iU(ii, jj)]; };
     auto vb = [&](int ii, int jj) { return ((vv(ii, jj, k) - vv(ii, jj + 1, k)) - ut_(ii, jj)) * g.rdy[g.iV(ii, jj)]; };
     auto fy = [&](int ii, int jj) { return un(ii, jj, k) * g.rdx[g.iU(ii, jj)]; };
@@ -647,12 +649,15 @@ struct DswCubedD10 {
     const double rs = g.rsin2[g.iA(i, j)], cs = g.cosa_s[g.iA(i, j)];
     const double dpn = cview_A(g, s.a.delp_out)(i, j, k);
     double &h = view_CC(g, s.a.heat_s)(i, j, k);
+    double &de = view_CC(g, s.a.diss_e)(i, j, k);
     if (g.prevent_diss_cooling) {
       const double tmp = rs * ((ub0 * ub0 + ub1 * ub1 + vb0 * vb0 + vb1 * vb1) + 2. * (gy0 + gy1 + gx0 + gx1) - cs * (u2 * dv2 + v2 * du2 + du2 * dv2));
-      h = dpn * (h - damp * dmin(0., tmp));
+      if (d_con > 1.E-5) h = dpn * (h - damp * dmin(0., tmp));
+      if (est) de = de - tmp;
     } else {
       const double t2 = (ub0 * ub0 + ub1 * ub1 + vb0 * vb0 + vb1 * vb1) + 2. * (gy0 + gy1 + gx0 + gx1) - cs * (u2 * dv2 + v2 * du2 + du2 * dv2);
       h = dpn * (h - damp * rs * t2);
+      if (est) de = de - rs * t2;
     }
   }
 };

@@ -1039,7 +1039,6 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
 static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   const Grid &g = c->g;
   if (!c->cg.ready) return fail("fv3_d_sw: cubed-sphere context without fv3_grid_upload_cubed");
-  if (g.do_diss_est) return fail("fv3_d_sw: do_diss_est is not built for the cubed sphere yet");
   DswCubedState s;
   s.g = g; s.cg = c->cg; s.a = a; s.own_w = 0;
   double **scr[13] = {&s.ut, &s.vt, &s.fx, &s.fy, &s.gxw, &s.gyw, &s.gx, &s.gy, &s.ke, &s.wk, &s.dd, &s.svc, &s.suc};
@@ -1072,7 +1071,8 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   if (c->lev_has_damp_v5) {
     if (!(s.dfx2 = cs_scratch(c, 22)) || !(s.dfy2 = cs_scratch(c, 23))) return fail("d_sw: out of device memory");
   }
-  if (c->lev_has_dcon) {
+  const bool heat_pass = c->lev_has_dcon || g.do_diss_est;   // :1462, :1523
+  if (heat_pass) {
     if (!(s.vortv = cs_scratch(c, 21))) return fail("d_sw: out of device memory");
   }
   if (!(a.dddmp < 1.E-5)) {
@@ -1095,7 +1095,7 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   const bool fits = wo > 0 && npx - 1 >= 2 * wm + 8 && npx == npy;
   const bool fused_ok = c->use_march && c->use_fused && !a.use_cond && a.hord_dp == a.hord_tm && (a.hydrostatic || a.hord_dp == a.hord_vt);
   const bool hyb_t = fits && fused_ok && c->n_plain > 0;
-  const bool hyb_m = fits && c->use_march && c->use_fused && c->n_plain_m > 0 && a.dddmp < 1.E-5;
+  const bool hyb_m = fits && c->use_march && c->use_fused && c->n_plain_m > 0 && a.dddmp < 1.E-5 && !g.do_diss_est;
 
   auto transport = [&](const PassRegion &rg, const PassRegion &rg_out, bool courant) -> int {
     if (rg.nk <= 0) return 0;
@@ -1155,7 +1155,7 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     RT(launch_pass(c, "dswc_d8", g.isd, g.ied, g.jsd, g.jed, rg, DswCubedD8{s}));
     RT(tp2d_cubed(c, npz, s.wk, a.crx, a.cry, a.hord_vt, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, "dswc_tpv", &rg));
     RT(launch_pass(c, "dswc_d9", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD9{so}));
-    if (rg.w == 0 && c->lev_has_dcon) RT(launch_pass(c, "dswc_heat", g.is, g.ie, g.js, g.je, rg_out, DswCubedD10{so}));
+    if (rg.w == 0 && heat_pass) RT(launch_pass(c, "dswc_heat", g.is, g.ie, g.js, g.je, rg_out, DswCubedD10{so}));
     if (rg.w == 0 && c->lev_has_damp_v5) RT(launch_pass(c, "dswc_d9", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD11{so}));
     return 0;
   };

@@ -28,7 +28,7 @@
  *   - Work is enqueued on the context's HIP stream (fv3_set_stream); nothing synchronises.
  *   - Supported branch sets: grid_type = 4 (doubly periodic / Cartesian branches of the reference) with array-valued
  *     metric terms, and grid_type < 3 (a whole face of the cubed sphere per context: face edges and corners, the damping,
- *     heating and condensate branches included; do_diss_est is refused there); no nesting, no regional BCs.  A branch that
+ *     heating, dissipation-estimate and condensate branches included); no nesting, no regional BCs.  A branch that
  *     is not built returns non-zero with the reason in fv3_last_error() -- never a silent fallback.
  */
 #ifndef FV3_MI355X_H

@@ -80,8 +80,22 @@ def check_fv_tp_2d(lib, hord, npx=13, nk=3, faces=range(6), mass_flux=False, see
     return worst
 
 
-def check_d_sw(lib, npx=13, npz=3, hydrostatic=True, faces=range(6), dt=600.0, par_over=None, flags=None, use_cond=False):
-    """c_sw (oracle) on every face -> emulated halo updates of uc, vc, divg_d -> d_sw by the oracle and by the library"""
+def check_d_sw(lib, npx=13, npz=3, hydrostatic=True, faces=range(6), dt=600.0, par_over=None, flags=None, use_cond=False,
+               grid_flags=None):
+    """c_sw (oracle) on every face -> emulated halo updates of uc, vc, divg_d -> d_sw by the oracle and by the library.
+    grid_flags: do_diss_est / prevent_diss_cooling of the gridstruct (the sphere's grids are shared: set, run, restore)"""
+    if grid_flags:
+        _, gs_ = CC.sphere(npx)
+        old = [{k: getattr(g, k) for k in grid_flags} for g in gs_]
+        for g in gs_:
+            for k, v in grid_flags.items():
+                setattr(g, k, v)
+        try:
+            return check_d_sw(lib, npx, npz, hydrostatic, faces, dt, par_over, flags, use_cond)
+        finally:
+            for g, o in zip(gs_, old):
+                for k, v in o.items():
+                    setattr(g, k, v)
     from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags, level_coefficients
     cs, gs, before, after = CC.oracle_pair(npx, npz, dt=dt, hydrostatic=hydrostatic, par_over=par_over, flags=flags, use_cond=use_cond)
     fl = DynFlags(**(flags or {}))
@@ -116,6 +130,8 @@ def check_d_sw(lib, npx=13, npz=3, hydrostatic=True, faces=range(6), dt=600.0, p
             if not hydrostatic:
                 cmp.append(("w", out["w_out"], "A", (i0, i1, j0, j1)))
             cmp.append(("heat_source", out["heat_s"], "CC", None))      # w damping of the sponge levels, d_con heating
+            if g.do_diss_est:
+                cmp.append(("diss_est", out["diss_e"], "CC", None))
             if use_cond:
                 cmp.append(("q_con", out["qc_out"], "A", (i0, i1, j0, j1)))
             for name, dev, kind, r in cmp:

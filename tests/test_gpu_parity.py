@@ -770,6 +770,15 @@ def test_cubed_d_sw_damping_and_heating(prod, kw, hydrostatic):
     assert max(PC.check_d_sw(prod, npx=25, npz=12, hydrostatic=hydrostatic, **kw).values()) <= P.TOL
 
 
+@pytest.mark.parametrize("kw", [dict(flags=dict(d_con=1.0), grid_flags=dict(do_diss_est=True, prevent_diss_cooling=False)),
+                                dict(flags=dict(), grid_flags=dict(do_diss_est=True, prevent_diss_cooling=True)),
+                                dict(flags=PROD, par_over=dict(dddmp=0.5), grid_flags=dict(do_diss_est=True, prevent_diss_cooling=True))])
+def test_cubed_d_sw_dissipation_estimate(prod, kw):
+    """do_diss_est on a cubed-sphere face (sw_core.F90:964-978, :1462, :1516-1586): diss_est of every level, with and without the
+    heating, the vorticity damping and the cooling limiter; the work arrays are zeroed where nothing damps the vorticity"""
+    assert max(PC.check_d_sw(prod, npx=25, npz=6, hydrostatic=False, faces=(1, 4), **kw).values()) <= P.TOL
+
+
 def test_cubed_del2_cubed_and_damped_transports(prod):
     assert PC.check_del2_cubed(prod, npx=25, npz=4, nmax=3) <= P.TOL
     for kw in (dict(nord=2, damp_c=0.05), dict(nord=2, damp_c=0.05, mass_flux=True)):
