@@ -1,0 +1,266 @@
+!> dyn_core with the REFERENCE'S argument list (model/dyn_core.F90:94-98), over the device-resident substep loop of
+!> fv3_host_mod: the form a model that keeps its state in host arrays with the fv_arrays layout calls without touching
+!> its own code.  Every array argument has the reference's bounds (fv_arrays.F90:1521-1563), the scalars and the derived
+!> types the reference's names.
+!>
+!> The derived types of the interface -- fv_grid_bounds_type, fv_grid_type, fv_flags_type, fv_nest_type, fv_thermo_type,
+!> fv_diag_type (fv_arrays_mod), domain2d (mpp_domains_mod), group_halo_update_type (fv_mp_mod) -- are declared in
+!> fv3_arrays_compat_mod below with the members THIS PATH READS under the reference's member names (fv_arrays.F90:75-205,
+!> :207-906, :1192-1200).  fv_arrays_mod itself cannot be compiled without FMS; inside the model a maintainer replaces
+!> `use fv3_arrays_compat_mod` by `use fv_arrays_mod` / `use mpp_domains_mod` / `use fv_mp_mod` and nothing else changes.
+!>
+!> What a call does: (first call) creates the context from bd / gridstruct / flagstruct and uploads the metric terms once;
+!> (every call) host -> device copies of the prognostic arrays, the substep loop (fv3_dyn_core: n_split substeps, the d_con
+!> heating; hydrostatic or not), device -> host copies of everything dyn_core leaves to its caller.  The copies cross PCIe
+!> (≈ 63 GB/s): this is the compatibility form; the resident form (fv3_host_mod's own fv3_fv_dynamics, which keeps the
+!> state on the device across dyn_core, tracer_2d and the remap) is the fast one.
+!>
+!> Restrictions (error stop with the reason, never a silent difference): grid_type = 4 on one rank (the cubed sphere runs
+!> through the Python host's six-face exchange, cubed_dyn.py); no nesting / regional BCs; use_cond / moist_kappa,
+!> do_diss_est and the SKEB diss_est accumulation are not carried through this wrapper.
+module fv3_arrays_compat_mod
+  use iso_c_binding
+  implicit none
+  public
+
+  type fv_grid_bounds_type                    ! fv_arrays.F90:1192-1200
+    integer :: is, ie, js, je
+    integer :: isd, ied, jsd, jed
+    integer :: isc, iec, jsc, jec
+    integer :: ng = 3
+  end type
+
+  type fv_grid_type                           ! fv_arrays.F90:75-205; shapes :1749-1881
+    real(c_double), allocatable, dimension(:,:) :: area, rarea, dxa, dya, rdxa, rdya, cosa_s, rsin2, f0       ! (isd:ied, jsd:jed)
+    real(c_double), allocatable, dimension(:,:) :: dx, rdx, dyc, rdyc, cosa_v, sina_v, rsin_v, divg_u, del6_u ! (isd:ied, jsd:jed+1)
+    real(c_double), allocatable, dimension(:,:) :: dy, rdy, dxc, rdxc, cosa_u, sina_u, rsin_u, divg_v, del6_v ! (isd:ied+1, jsd:jed)
+    real(c_double), allocatable, dimension(:,:) :: rarea_c, fC, cosa, sina                                    ! (isd:ied+1, jsd:jed+1)
+    real(c_double), allocatable, dimension(:,:,:) :: sin_sg, cos_sg                                           ! (isd:ied, jsd:jed, 9)
+    real(c_double) :: da_min = 0.d0, da_min_c = 0.d0
+    integer :: grid_type = 4
+    logical :: nested = .false., bounded_domain = .false., regional = .false., stretched_grid = .false.
+  end type
+
+  type fv_flags_type                          ! fv_arrays.F90:207-906 (the members the substep loop reads; the reference's defaults)
+    integer :: grid_type = 0
+    integer :: n_split = 0, k_split = 1, q_split = 0
+    integer :: nord = 1, nord_tr = 0
+    real(c_double) :: d4_bg = 0.16d0, d2_bg = 0.d0, d2_bg_k1 = 4.d0, d2_bg_k2 = 2.d0
+    real(c_double) :: dddmp = 0.d0, vtdm4 = 0.d0, d_con = 0.d0, ke_bg = 0.d0, trdm2 = 0.d0
+    real(c_double) :: d_ext = 0.02d0, delt_max = 1.d0, beta = 0.d0, lim_fac = 1.d0
+    real(c_double) :: a_imp = 0.75d0, p_fac = 0.05d0
+    integer :: n_sponge = 1
+    integer :: hord_mt = 10, hord_vt = 10, hord_tm = 10, hord_dp = 10, hord_tr = 8
+    integer :: kord_tm = -8, kord_mt = 8, kord_wz = 8, kord_tr = 8
+    logical :: do_vort_damp = .false., use_logp = .false., use_old_omega = .true., is_ideal_case = .false.
+    logical :: convert_ke = .false., hydrostatic = .true., adiabatic = .false., fill = .false.
+    logical :: do_diss_est = .false., prevent_diss_cooling = .false., do_f3d = .false., inline_q = .false.
+    logical :: nested = .false., regional = .false.
+  end type
+
+  type fv_nest_type
+    logical :: nested = .false.
+  end type
+
+  type fv_thermo_type
+    logical :: use_cond = .false., moist_kappa = .false.
+  end type
+
+  type fv_diag_type
+    integer :: id_divg = 0, id_ws = 0
+  end type
+
+  type domain2d                               ! mpp_domains_mod: opaque here -- one rank of a doubly periodic domain
+    integer :: pe = 0
+  end type
+
+  type group_halo_update_type                 ! fv_mp_mod.F90:646-876: the halo groups live behind fv3_halo_* / fv3_halo_fill_periodic
+    integer :: id = 0
+  end type
+end module fv3_arrays_compat_mod
+
+
+module fv3_dyn_core_mod
+  use iso_c_binding
+  use fv3_arrays_compat_mod
+  use fv3_mi355x_mod
+  use fv3_host_mod
+  implicit none
+  private
+  public :: dyn_core, dyn_core_end
+
+  type(fv3_atmos), save :: at
+  logical, save :: bound = .false.
+
+contains
+
+  subroutine dyn_core(npx, npy, npz, ng, sphum, nq, bdt, n_map, n_split, zvir, cp, akap, cappa, grav, hydrostatic, &
+                      u, v, w, delz, pt, q, delp, pe, pk, phis, ws, omga, ptop, pfull, ua, va, &
+                      uc, vc, mfx, mfy, cx, cy, pkz, peln, q_con, ak, bk, &
+                      ks, gridstruct, flagstruct, neststruct, thermostruct, idiag, bd, domain, &
+                      init_step, i_pack, end_step, heat_source, diss_est, consv, te0_2d, time_total)
+    integer, intent(in) :: npx, npy, npz, ng, nq, sphum, n_map, n_split, ks
+    real(c_double), intent(in) :: bdt, zvir, cp, akap, grav, consv, ptop
+    logical, intent(in) :: hydrostatic, init_step, end_step
+    real(c_double), intent(in) :: pfull(npz), ak(npz+1), bk(npz+1)
+    type(group_halo_update_type), intent(inout) :: i_pack(*)
+    type(fv_grid_bounds_type), intent(in) :: bd
+    real(c_double), intent(inout), target :: u(bd%isd:bd%ied, bd%jsd:bd%jed+1, npz)
+    real(c_double), intent(inout), target :: v(bd%isd:bd%ied+1, bd%jsd:bd%jed, npz)
+    real(c_double), intent(inout) :: w(bd%isd:, bd%jsd:, 1:)
+    real(c_double), intent(inout) :: delz(bd%is:, bd%js:, 1:)
+    real(c_double), intent(inout) :: cappa(bd%isd:, bd%jsd:, 1:)
+    real(c_double), intent(inout), target :: pt(bd%isd:bd%ied, bd%jsd:bd%jed, npz), delp(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
+    real(c_double), intent(inout) :: q(bd%isd:bd%ied, bd%jsd:bd%jed, npz, nq)
+    real(c_double), intent(inout), target :: heat_source(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
+    real(c_double), intent(inout) :: diss_est(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
+    real(c_double), intent(in), optional :: time_total
+    real(c_double), intent(inout), target :: phis(bd%isd:bd%ied, bd%jsd:bd%jed)
+    real(c_double), intent(inout), target :: pe(bd%is-1:bd%ie+1, npz+1, bd%js-1:bd%je+1)
+    real(c_double), intent(inout), target :: peln(bd%is:bd%ie, npz+1, bd%js:bd%je)
+    real(c_double), intent(inout), target :: pk(bd%is:bd%ie, bd%js:bd%je, npz+1)
+    real(c_double), intent(out), target :: ws(bd%is:bd%ie, bd%js:bd%je)
+    real(c_double), intent(inout), target :: omga(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
+    real(c_double), intent(inout), target :: uc(bd%isd:bd%ied+1, bd%jsd:bd%jed, npz), vc(bd%isd:bd%ied, bd%jsd:bd%jed+1, npz)
+    real(c_double), intent(inout), target, dimension(bd%isd:bd%ied, bd%jsd:bd%jed, npz) :: ua, va
+    real(c_double), intent(inout) :: q_con(bd%isd:, bd%jsd:, 1:)
+    real(c_double), intent(inout) :: te0_2d(bd%is:bd%ie, bd%js:bd%je)
+    real(c_double), intent(inout), target :: mfx(bd%is:bd%ie+1, bd%js:bd%je, npz), mfy(bd%is:bd%ie, bd%js:bd%je+1, npz)
+    real(c_double), intent(inout), target :: cx(bd%is:bd%ie+1, bd%jsd:bd%jed, npz), cy(bd%isd:bd%ied, bd%js:bd%je+1, npz)
+    real(c_double), intent(inout), target :: pkz(bd%is:bd%ie, bd%js:bd%je, npz)
+    type(fv_grid_type), intent(inout), target :: gridstruct
+    type(fv_flags_type), intent(in), target :: flagstruct
+    type(fv_nest_type), intent(inout) :: neststruct
+    type(fv_thermo_type), intent(inout), target :: thermostruct
+    type(fv_diag_type), intent(in) :: idiag
+    type(domain2d), intent(inout) :: domain
+
+    real(c_double), allocatable, target :: w_c(:,:,:), delz_c(:,:,:), zs(:,:)
+    integer(c_size_t) :: nk, nk1
+    integer :: nx, ny
+
+    if (neststruct%nested .or. gridstruct%nested .or. gridstruct%regional .or. gridstruct%bounded_domain) &
+      error stop 'dyn_core (fv3_dyn_core_mod): nested / regional domains are not built'
+    if (gridstruct%grid_type /= 4) error stop 'dyn_core (fv3_dyn_core_mod): grid_type = 4 only through this wrapper'
+    if (thermostruct%use_cond .or. thermostruct%moist_kappa) &
+      error stop 'dyn_core (fv3_dyn_core_mod): use_cond / moist_kappa are not carried through this wrapper'
+    if (flagstruct%do_diss_est) error stop 'dyn_core (fv3_dyn_core_mod): do_diss_est is not carried through this wrapper'
+    if (flagstruct%beta > 0.d0) error stop 'dyn_core (fv3_dyn_core_mod): beta > 0 (split_p_grad) is not built'
+    if (ng /= 3 .or. bd%ng /= 3) error stop 'dyn_core (fv3_dyn_core_mod): ng = 3'
+    if (.not. bound) call bind_context()
+    if (at%npz /= npz .or. at%is /= bd%is .or. at%ie /= bd%ie .or. at%js /= bd%js .or. at%je /= bd%je) &
+      error stop 'dyn_core (fv3_dyn_core_mod): the domain changed between calls'
+    at%fl%n_split = n_split
+    nx = bd%ie - bd%is + 1; ny = bd%je - bd%js + 1
+    nk = int(npz, c_size_t); nk1 = nk + 1
+
+    ! ---- host -> device: what the loop reads (dyn_core.F90:95-96: u, v, w, delz, pt, delp, phis; pkz / pe / pk / peln / omga /
+    !      ua / va are intent(inout) members the loop only partly rewrites) ----
+    call put(at%u, c_loc(u), at%nU*nk);        call put(at%v, c_loc(v), at%nV*nk)
+    call put(at%delp, c_loc(delp), at%nA*nk);  call put(at%pt, c_loc(pt), at%nA*nk)
+    call put(at%phis, c_loc(phis), at%nA)
+    allocate(zs(bd%isd:bd%ied, bd%jsd:bd%jed))
+    zs = phis * (1.d0 / grav)                                              ! dyn_core.F90:246-251
+    call put(at%zs, c_loc(zs), at%nA)
+    if (.not. hydrostatic) then
+      allocate(w_c(bd%isd:bd%ied, bd%jsd:bd%jed, npz), delz_c(bd%is:bd%ie, bd%js:bd%je, npz))   ! assumed-shape dummies: contiguous copies
+      w_c = w(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz); delz_c = delz(bd%is:bd%ie, bd%js:bd%je, 1:npz)
+      call put(at%w, c_loc(w_c), at%nA*nk);    call put(at%delz, c_loc(delz_c), at%nCC*nk)
+    end if
+    call put(at%pkz, c_loc(pkz), at%nCC*nk);   call put(at%pk, c_loc(pk), at%nCC*nk1)
+    call put(at%pe, c_loc(pe), int(nx+2, c_size_t)*nk1*(ny+2)); call put(at%peln, c_loc(peln), at%nCC*nk1)
+    call put(at%omga, c_loc(omga), at%nA*nk);  call put(at%ua, c_loc(ua), at%nA*nk); call put(at%va, c_loc(va), at%nA*nk)
+    call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
+
+    call fv3_dyn_core(at, bdt)                                             ! the substep loop (both branches), d_con heating
+
+    ! ---- device -> host ----
+    call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
+    call get(c_loc(u), at%u, at%nU*nk);        call get(c_loc(v), at%v, at%nV*nk)
+    call get(c_loc(delp), at%delp, at%nA*nk);  call get(c_loc(pt), at%pt, at%nA*nk)
+    if (.not. hydrostatic) then
+      call get(c_loc(w_c), at%w, at%nA*nk);    call get(c_loc(delz_c), at%delz, at%nCC*nk)
+      call get(c_loc(ws), at%ws, at%nCC)
+    end if
+    call get(c_loc(pkz), at%pkz, at%nCC*nk);   call get(c_loc(pk), at%pk, at%nCC*nk1)
+    call get(c_loc(pe), at%pe, int(nx+2, c_size_t)*nk1*(ny+2)); call get(c_loc(peln), at%peln, at%nCC*nk1)
+    call get(c_loc(omga), at%omga, at%nA*nk);  call get(c_loc(ua), at%ua, at%nA*nk); call get(c_loc(va), at%va, at%nA*nk)
+    call get(c_loc(uc), at%uc, at%nV*nk);      call get(c_loc(vc), at%vc, at%nU*nk)
+    call get(c_loc(mfx), at%mfx, at%nFX*nk);   call get(c_loc(mfy), at%mfy, at%nFY*nk)
+    call get(c_loc(cx), at%cx, at%nCX*nk);     call get(c_loc(cy), at%cy, at%nCY*nk)
+    if (flagstruct%d_con > 1.d-5) call get(c_loc(heat_source), at%heat_source, at%nA*nk)
+    call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
+    if (.not. hydrostatic) then
+      w(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz) = w_c; delz(bd%is:bd%ie, bd%js:bd%je, 1:npz) = delz_c
+    else
+      ws = 0.d0
+    end if
+
+  contains
+
+    subroutine put(d, h, n)
+      type(c_ptr), intent(in) :: d, h
+      integer(c_size_t), intent(in) :: n
+      call fv3_check(fv3_memcpy_h2d(at%ctx, d, h, n * 8_c_size_t), 'fv3_memcpy_h2d')
+    end subroutine
+
+    subroutine get(h, d, n)
+      type(c_ptr), intent(in) :: d, h
+      integer(c_size_t), intent(in) :: n
+      call fv3_check(fv3_memcpy_d2h(at%ctx, h, d, n * 8_c_size_t), 'fv3_memcpy_d2h')
+    end subroutine
+
+    !> first call: bounds + flags -> fv3_domain / fv3_flags, the gridstruct members by address -> fv3_grid_upload
+    subroutine bind_context()
+      type(fv3_domain) :: dom
+      type(fv3_grid_host) :: gh
+      type(fv3_flags) :: fl
+      dom%is = bd%is; dom%ie = bd%ie; dom%js = bd%js; dom%je = bd%je; dom%ng = 3
+      dom%npx = npx; dom%npy = npy; dom%npz = npz; dom%grid_type = gridstruct%grid_type
+      dom%do_diss_est = 0; dom%prevent_diss_cooling = merge(1, 0, flagstruct%prevent_diss_cooling)
+      dom%stretched_grid = merge(1, 0, gridstruct%stretched_grid); dom%lim_fac = flagstruct%lim_fac
+      gh%da_min = gridstruct%da_min;        gh%da_min_c = gridstruct%da_min_c
+      gh%area = c_loc(gridstruct%area);     gh%rarea = c_loc(gridstruct%rarea)
+      gh%dxa = c_loc(gridstruct%dxa);       gh%dya = c_loc(gridstruct%dya)
+      gh%rdxa = c_loc(gridstruct%rdxa);     gh%rdya = c_loc(gridstruct%rdya)
+      gh%cosa_s = c_loc(gridstruct%cosa_s); gh%rsin2 = c_loc(gridstruct%rsin2);   gh%f0 = c_loc(gridstruct%f0)
+      gh%dx = c_loc(gridstruct%dx);         gh%rdx = c_loc(gridstruct%rdx)
+      gh%dyc = c_loc(gridstruct%dyc);       gh%rdyc = c_loc(gridstruct%rdyc)
+      gh%cosa_v = c_loc(gridstruct%cosa_v); gh%sina_v = c_loc(gridstruct%sina_v); gh%rsin_v = c_loc(gridstruct%rsin_v)
+      gh%divg_u = c_loc(gridstruct%divg_u); gh%del6_u = c_loc(gridstruct%del6_u)
+      gh%dy = c_loc(gridstruct%dy);         gh%rdy = c_loc(gridstruct%rdy)
+      gh%dxc = c_loc(gridstruct%dxc);       gh%rdxc = c_loc(gridstruct%rdxc)
+      gh%cosa_u = c_loc(gridstruct%cosa_u); gh%sina_u = c_loc(gridstruct%sina_u); gh%rsin_u = c_loc(gridstruct%rsin_u)
+      gh%divg_v = c_loc(gridstruct%divg_v); gh%del6_v = c_loc(gridstruct%del6_v)
+      gh%rarea_c = c_loc(gridstruct%rarea_c); gh%fC = c_loc(gridstruct%fC)
+      gh%cosa = c_loc(gridstruct%cosa);     gh%sina = c_loc(gridstruct%sina)
+      gh%sin_sg = c_loc(gridstruct%sin_sg); gh%cos_sg = c_loc(gridstruct%cos_sg)
+      fl%n_split = n_split;               fl%k_split = flagstruct%k_split;   fl%q_split = flagstruct%q_split
+      fl%nord = flagstruct%nord;          fl%d4_bg = flagstruct%d4_bg;       fl%d2_bg = flagstruct%d2_bg
+      fl%d2_bg_k1 = flagstruct%d2_bg_k1;  fl%d2_bg_k2 = flagstruct%d2_bg_k2; fl%dddmp = flagstruct%dddmp
+      fl%vtdm4 = flagstruct%vtdm4;        fl%d_con = flagstruct%d_con;       fl%ke_bg = flagstruct%ke_bg
+      fl%do_vort_damp = flagstruct%do_vort_damp; fl%use_logp = flagstruct%use_logp
+      fl%use_old_omega = flagstruct%use_old_omega; fl%is_ideal_case = flagstruct%is_ideal_case
+      fl%n_sponge = flagstruct%n_sponge
+      fl%hord_mt = flagstruct%hord_mt;    fl%hord_vt = flagstruct%hord_vt;   fl%hord_tm = flagstruct%hord_tm
+      fl%hord_dp = flagstruct%hord_dp;    fl%hord_tr = flagstruct%hord_tr
+      fl%kord_tm = flagstruct%kord_tm;    fl%kord_mt = flagstruct%kord_mt;   fl%kord_wz = flagstruct%kord_wz
+      fl%kord_tr = flagstruct%kord_tr;    fl%nord_tr = flagstruct%nord_tr;   fl%trdm2 = flagstruct%trdm2
+      fl%a_imp = flagstruct%a_imp;        fl%p_fac = flagstruct%p_fac;       fl%ptop = ptop
+      fl%grav = grav;                     fl%akap = akap;                    fl%cp_air = cp
+      ! rdgas: constants_mod's, as in the reference (fv3_flags carries it as its default)
+      fl%adiabatic = flagstruct%adiabatic; fl%fill = flagstruct%fill
+      fl%hydrostatic = hydrostatic;       fl%d_ext = flagstruct%d_ext;       fl%delt_max = flagstruct%delt_max
+      fl%convert_ke = flagstruct%convert_ke
+      call fv3_host_init_grid(at, dom, gh, 0, fl, ak, bk)
+      bound = .true.
+    end subroutine
+  end subroutine dyn_core
+
+  !> release the context dyn_core bound at its first call
+  subroutine dyn_core_end()
+    if (bound) call fv3_host_final(at)
+    bound = .false.
+  end subroutine
+
+end module fv3_dyn_core_mod

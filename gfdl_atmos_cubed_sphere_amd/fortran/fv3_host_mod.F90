@@ -11,14 +11,16 @@
 !>
 !> Not reproduced (off in every BASELINE config): nesting / regional BCs, breed_vortex_inline, do_fast_phys, Ray_fast,
 !> beta > 0 (split_p_grad).  The argument lists are this module's own (type fv3_atmos holds the device handles the
-!> reference keeps in fv_atmos_type / dyn_core's work arrays); INTEGRATION.md maps them to the reference's call sites.
+!> reference keeps in fv_atmos_type / dyn_core's work arrays); INTEGRATION.md maps them to the reference's call sites,
+!> and fv3_dyn_core_mod.F90 puts dyn_core's own argument list (host arrays, gridstruct, flagstruct, bd) in front of
+!> fv3_dyn_core for callers that keep their state on the host.
 module fv3_host_mod
   use iso_c_binding
   use fv3_mi355x_mod
   implicit none
   private
   public :: fv3_flags, fv3_atmos
-  public :: fv3_host_init, fv3_host_final, fv3_host_upload, fv3_host_download
+  public :: fv3_host_init, fv3_host_init_grid, fv3_host_final, fv3_host_upload, fv3_host_download
   public :: fv3_dyn_core, fv3_dyn_core_hydrostatic, fv3_tracer_2d, fv3_fv_dynamics
 
   integer(c_int), parameter :: KIND_A = 0, KIND_U = 1, KIND_V = 2, KIND_B = 3
@@ -136,38 +138,24 @@ contains
     real(c_double), intent(in) :: ak(npz+1), bk(npz+1)
     type(fv3_domain) :: dom
     type(fv3_grid_host) :: gh
-    integer :: nid, njd, k
-    integer(c_size_t) :: n1, nk, nk1
+    integer(c_size_t) :: n1, nA
     real(c_double), allocatable, target :: m_dx(:), m_dy(:), m_rdx(:), m_rdy(:), m_area(:), m_rarea(:), m_one(:), m_zero(:), &
-                                           m_f0(:), m_sg(:), m_cg(:), dp_ref(:), r_u(:), r6_u(:), r_v(:), r6_v(:)
-
-    at%fl = fl
-    at%is = 1; at%ie = nx; at%js = 1; at%je = ny
-    at%isd = 1 - NG; at%ied = nx + NG; at%jsd = 1 - NG; at%jed = ny + NG
-    at%npz = npz; at%nq = nq; at%nx = nx; at%ny = ny
-    nid = nx + 2*NG; njd = ny + 2*NG
-    at%nA = int(nid, c_size_t) * njd;        at%nU = int(nid, c_size_t) * (njd + 1)
-    at%nV = int(nid + 1, c_size_t) * njd;    at%nB = int(nid + 1, c_size_t) * (njd + 1)
-    at%nCC = int(nx, c_size_t) * ny;         at%nCX = int(nx + 1, c_size_t) * njd
-    at%nCY = int(nid, c_size_t) * (ny + 1);  at%nFX = int(nx + 1, c_size_t) * ny
-    at%nFY = int(nx, c_size_t) * (ny + 1)
-    allocate(at%ak(npz+1), at%bk(npz+1)); at%ak = ak; at%bk = bk
+                                           m_f0(:), m_sg(:), m_cg(:), r_u(:), r6_u(:), r_v(:), r6_v(:)
 
     dom%is = 1; dom%ie = nx; dom%js = 1; dom%je = ny; dom%ng = NG
     dom%npx = nx + 1; dom%npy = ny + 1; dom%npz = npz; dom%grid_type = 4
     dom%do_diss_est = 0; dom%prevent_diss_cooling = 1; dom%stretched_grid = 0; dom%lim_fac = 1.d0
-    call fv3_check(fv3_create(dom, at%ctx), 'fv3_create')
 
     ! ---- gridstruct: every metric term is a constant on this domain; one host array per distinct value is enough,
     !      sized for the largest stagger (B) -- fv3_grid_upload copies the leading part it needs
-    n1 = at%nB
+    nA = int(nx + 2*NG, c_size_t) * (ny + 2*NG)
+    n1 = int(nx + 2*NG + 1, c_size_t) * (ny + 2*NG + 1)
     allocate(m_dx(n1), m_dy(n1), m_rdx(n1), m_rdy(n1), m_area(n1), m_rarea(n1), m_one(n1), m_zero(n1), m_f0(n1))
-    allocate(m_sg(9 * at%nA), m_cg(9 * at%nA))
+    allocate(m_sg(9 * nA), m_cg(9 * nA))
     m_dx = dx_const; m_dy = dy_const; m_rdx = 1.d0 / dx_const; m_rdy = 1.d0 / dy_const
     m_area = dx_const * dy_const; m_rarea = 1.d0 / (dx_const * dy_const)
     m_one = 1.d0; m_zero = 0.d0; m_f0 = f0_const; m_sg = 1.d0; m_cg = 0.d0
     gh%da_min = dx_const * dy_const; gh%da_min_c = dx_const * dy_const
-    at%da_min = gh%da_min
     gh%area = c_loc(m_area);   gh%rarea = c_loc(m_rarea)
     gh%dxa = c_loc(m_dx);      gh%dya = c_loc(m_dy);     gh%rdxa = c_loc(m_rdx);  gh%rdya = c_loc(m_rdy)
     gh%cosa_s = c_loc(m_zero); gh%rsin2 = c_loc(m_one);  gh%f0 = c_loc(m_f0)
@@ -182,6 +170,37 @@ contains
     gh%divg_u = c_loc(r_u); gh%del6_u = c_loc(r6_u); gh%divg_v = c_loc(r_v); gh%del6_v = c_loc(r6_v)
     gh%rarea_c = c_loc(m_rarea); gh%fC = c_loc(m_f0); gh%cosa = c_loc(m_zero); gh%sina = c_loc(m_one)
     gh%sin_sg = c_loc(m_sg);     gh%cos_sg = c_loc(m_cg)
+    call fv3_host_init_grid(at, dom, gh, nq, fl, ak, bk)
+  end subroutine
+
+  !> the general form: bounds / flags of `dom` and the gridstruct members behind `gh` (host addresses with the reference's
+  !> shapes, fv_arrays.F90:1749-1881) as the caller holds them -- what fv3_dyn_core_mod's dyn_core hands over
+  subroutine fv3_host_init_grid(at, dom, gh, nq, fl, ak, bk)
+    type(fv3_atmos), intent(inout) :: at
+    type(fv3_domain), intent(in) :: dom
+    type(fv3_grid_host), intent(in) :: gh
+    integer, intent(in) :: nq
+    type(fv3_flags), intent(in) :: fl
+    real(c_double), intent(in) :: ak(dom%npz+1), bk(dom%npz+1)
+    integer :: nid, njd, k, nx, ny, npz
+    integer(c_size_t) :: nk, nk1
+    real(c_double), allocatable :: dp_ref(:)
+
+    npz = dom%npz; nx = dom%ie - dom%is + 1; ny = dom%je - dom%js + 1
+    at%fl = fl
+    at%is = dom%is; at%ie = dom%ie; at%js = dom%js; at%je = dom%je
+    at%isd = dom%is - NG; at%ied = dom%ie + NG; at%jsd = dom%js - NG; at%jed = dom%je + NG
+    at%npz = npz; at%nq = nq; at%nx = nx; at%ny = ny
+    nid = nx + 2*NG; njd = ny + 2*NG
+    at%nA = int(nid, c_size_t) * njd;        at%nU = int(nid, c_size_t) * (njd + 1)
+    at%nV = int(nid + 1, c_size_t) * njd;    at%nB = int(nid + 1, c_size_t) * (njd + 1)
+    at%nCC = int(nx, c_size_t) * ny;         at%nCX = int(nx + 1, c_size_t) * njd
+    at%nCY = int(nid, c_size_t) * (ny + 1);  at%nFX = int(nx + 1, c_size_t) * ny
+    at%nFY = int(nx, c_size_t) * (ny + 1)
+    if (allocated(at%ak)) deallocate(at%ak, at%bk)
+    allocate(at%ak(npz+1), at%bk(npz+1)); at%ak = ak; at%bk = bk
+    at%da_min = gh%da_min
+    if (.not. c_associated(at%ctx)) call fv3_check(fv3_create(dom, at%ctx), 'fv3_create')
     call fv3_check(fv3_grid_upload(at%ctx, gh), 'fv3_grid_upload')
     call host_comm_init(at)
 

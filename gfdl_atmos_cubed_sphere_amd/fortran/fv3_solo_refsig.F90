@@ -1,0 +1,98 @@
+!> Driver of the reference-signature dyn_core (fv3_dyn_core_mod) on one doubly periodic tile: the caller's side of the
+!> drop-in -- host arrays with the fv_arrays layout, a gridstruct / flagstruct / bd filled the way fv_control and
+!> init_grid fill them for grid_type = 4 (fv_grid_tools.F90:1202-1221, fv_grid_utils.F90:427, :656-665), `nsteps` calls
+!> of dyn_core(...) with the reference's 60-odd arguments.  Same input file as fv3_solo (the tracers are ignored).
+!> output: real64 u, v, w, delp, pt, delz, mfx, cx, pkz
+program fv3_solo_refsig
+  use iso_c_binding
+  use fv3_arrays_compat_mod
+  use fv3_dyn_core_mod
+  implicit none
+  character(len=1024) :: fin, fout
+  integer(c_int) :: nx, ny, npz, nq, n_split, k_split, nsteps, last_step, ihydro
+  real(c_double) :: dxc_, dyc_, f0_, bdt, ptop, d_con, d_ext
+  real(c_double), allocatable :: ak(:), bk(:), pfull(:)
+  real(c_double), allocatable, dimension(:,:,:) :: u, v, w, delp, pt, delz, cappa, q_con, heat_source, diss_est, pe, peln, pk, &
+                                                   omga, uc, vc, ua, va, mfx, mfy, cx, cy, pkz
+  real(c_double), allocatable :: q(:,:,:,:), phis(:,:), ws(:,:), te0_2d(:,:)
+  type(fv_grid_bounds_type) :: bd
+  type(fv_grid_type), target :: gs
+  type(fv_flags_type), target :: fs
+  type(fv_nest_type) :: ns
+  type(fv_thermo_type), target :: ts
+  type(fv_diag_type) :: idiag
+  type(domain2d) :: domain
+  type(group_halo_update_type) :: i_pack(13)
+  real(c_double), parameter :: RDGAS = 287.04d0, KAPPA = 2.d0/7.d0, GRAV = 9.80d0, CP_AIR = RDGAS/KAPPA
+  integer :: un, n, isd, ied, jsd, jed
+  logical :: hydrostatic
+
+  call get_command_argument(1, fin)
+  call get_command_argument(2, fout)
+  open(newunit=un, file=trim(fin), access='stream', form='unformatted', status='old')
+  read(un) nx, ny, npz, nq, n_split, k_split, nsteps, last_step, ihydro
+  read(un) dxc_, dyc_, f0_, bdt, ptop, d_con, d_ext
+  allocate(ak(npz+1), bk(npz+1), pfull(npz))
+  read(un) ak, bk
+  hydrostatic = ihydro /= 0
+  bd%is = 1; bd%ie = nx; bd%js = 1; bd%je = ny; bd%ng = 3
+  bd%isd = -2; bd%ied = nx + 3; bd%jsd = -2; bd%jed = ny + 3
+  bd%isc = 1; bd%iec = nx; bd%jsc = 1; bd%jec = ny
+  isd = bd%isd; ied = bd%ied; jsd = bd%jsd; jed = bd%jed
+  allocate(u(isd:ied, jsd:jed+1, npz), v(isd:ied+1, jsd:jed, npz), w(isd:ied, jsd:jed, npz), delp(isd:ied, jsd:jed, npz))
+  allocate(pt(isd:ied, jsd:jed, npz), delz(nx, ny, npz), phis(isd:ied, jsd:jed))
+  read(un) u, v, w, delp, pt, delz, phis
+  close(un)
+  allocate(q(isd:ied, jsd:jed, npz, 1), cappa(isd:ied, jsd:jed, 1), q_con(isd:ied, jsd:jed, 1))
+  allocate(heat_source(isd:ied, jsd:jed, npz), diss_est(isd:ied, jsd:jed, npz))
+  allocate(pe(0:nx+1, npz+1, 0:ny+1), peln(nx, npz+1, ny), pk(nx, ny, npz+1), ws(nx, ny), te0_2d(nx, ny))
+  allocate(omga(isd:ied, jsd:jed, npz), uc(isd:ied+1, jsd:jed, npz), vc(isd:ied, jsd:jed+1, npz))
+  allocate(ua(isd:ied, jsd:jed, npz), va(isd:ied, jsd:jed, npz))
+  allocate(mfx(nx+1, ny, npz), mfy(nx, ny+1, npz), cx(nx+1, jsd:jed, npz), cy(isd:ied, ny+1, npz), pkz(nx, ny, npz))
+  q = 0.d0; cappa = 0.d0; q_con = 0.d0; heat_source = 0.d0; diss_est = 0.d0; pe = 0.d0; peln = 0.d0; pk = 0.d0; ws = 0.d0
+  te0_2d = 0.d0; omga = 0.d0; uc = 0.d0; vc = 0.d0; ua = 0.d0; va = 0.d0; mfx = 0.d0; mfy = 0.d0; cx = 0.d0; cy = 0.d0; pkz = 0.d0
+  do n = 1, npz
+    pfull(n) = 0.5d0 * (ak(n) + ak(n+1) + (bk(n) + bk(n+1)) * 1.d5)
+  end do
+
+  ! ---- gridstruct of the Cartesian doubly periodic domain ----
+  allocate(gs%area(isd:ied, jsd:jed), gs%rarea(isd:ied, jsd:jed), gs%dxa(isd:ied, jsd:jed), gs%dya(isd:ied, jsd:jed))
+  allocate(gs%rdxa(isd:ied, jsd:jed), gs%rdya(isd:ied, jsd:jed), gs%cosa_s(isd:ied, jsd:jed), gs%rsin2(isd:ied, jsd:jed))
+  allocate(gs%f0(isd:ied, jsd:jed))
+  allocate(gs%dx(isd:ied, jsd:jed+1), gs%rdx(isd:ied, jsd:jed+1), gs%dyc(isd:ied, jsd:jed+1), gs%rdyc(isd:ied, jsd:jed+1))
+  allocate(gs%cosa_v(isd:ied, jsd:jed+1), gs%sina_v(isd:ied, jsd:jed+1), gs%rsin_v(isd:ied, jsd:jed+1))
+  allocate(gs%divg_u(isd:ied, jsd:jed+1), gs%del6_u(isd:ied, jsd:jed+1))
+  allocate(gs%dy(isd:ied+1, jsd:jed), gs%rdy(isd:ied+1, jsd:jed), gs%dxc(isd:ied+1, jsd:jed), gs%rdxc(isd:ied+1, jsd:jed))
+  allocate(gs%cosa_u(isd:ied+1, jsd:jed), gs%sina_u(isd:ied+1, jsd:jed), gs%rsin_u(isd:ied+1, jsd:jed))
+  allocate(gs%divg_v(isd:ied+1, jsd:jed), gs%del6_v(isd:ied+1, jsd:jed))
+  allocate(gs%rarea_c(isd:ied+1, jsd:jed+1), gs%fC(isd:ied+1, jsd:jed+1), gs%cosa(isd:ied+1, jsd:jed+1), gs%sina(isd:ied+1, jsd:jed+1))
+  allocate(gs%sin_sg(isd:ied, jsd:jed, 9), gs%cos_sg(isd:ied, jsd:jed, 9))
+  gs%area = dxc_ * dyc_;  gs%rarea = 1.d0 / (dxc_ * dyc_);  gs%rarea_c = 1.d0 / (dxc_ * dyc_)
+  gs%dxa = dxc_; gs%dx = dxc_; gs%dxc = dxc_;  gs%rdxa = 1.d0 / dxc_; gs%rdx = 1.d0 / dxc_; gs%rdxc = 1.d0 / dxc_
+  gs%dya = dyc_; gs%dy = dyc_; gs%dyc = dyc_;  gs%rdya = 1.d0 / dyc_; gs%rdy = 1.d0 / dyc_; gs%rdyc = 1.d0 / dyc_
+  gs%cosa_s = 0.d0; gs%cosa_u = 0.d0; gs%cosa_v = 0.d0; gs%cosa = 0.d0; gs%cos_sg = 0.d0
+  gs%rsin2 = 1.d0; gs%sina_u = 1.d0; gs%sina_v = 1.d0; gs%rsin_u = 1.d0; gs%rsin_v = 1.d0; gs%sina = 1.d0; gs%sin_sg = 1.d0
+  gs%f0 = f0_; gs%fC = f0_
+  gs%divg_u = 1.d0 * dyc_ / dxc_;  gs%del6_u = 1.d0 * dxc_ / dyc_     ! sina_v*dyc/dx, sina_v*dx/dyc
+  gs%divg_v = 1.d0 * dxc_ / dyc_;  gs%del6_v = 1.d0 * dyc_ / dxc_     ! sina_u*dxc/dy, sina_u*dy/dxc
+  gs%da_min = dxc_ * dyc_; gs%da_min_c = dxc_ * dyc_; gs%grid_type = 4
+
+  ! ---- flagstruct: the namelist the other hosts of the test-suite run (dyn_core.DynFlags / fv3_flags defaults) ----
+  fs%grid_type = 4; fs%n_split = n_split; fs%k_split = k_split; fs%hydrostatic = hydrostatic
+  fs%d2_bg_k1 = 0.20d0; fs%d2_bg_k2 = 0.015d0; fs%a_imp = 1.d0; fs%d_con = d_con; fs%d_ext = d_ext
+  fs%prevent_diss_cooling = .true.; fs%adiabatic = .true.
+
+  do n = 1, nsteps
+    call dyn_core(nx + 1, ny + 1, int(npz), 3, 1, 0, bdt, 1, int(n_split), 0.d0, CP_AIR, KAPPA, cappa, GRAV, hydrostatic, &
+                  u, v, w, delz, pt, q, delp, pe, pk, phis, ws, omga, ptop, pfull, ua, va, &
+                  uc, vc, mfx, mfy, cx, cy, pkz, peln, q_con, ak, bk, &
+                  0, gs, fs, ns, ts, idiag, bd, domain, &
+                  n == 1, i_pack, n == nsteps, heat_source, diss_est, 0.d0, te0_2d)
+  end do
+  call dyn_core_end()
+
+  open(newunit=un, file=trim(fout), access='stream', form='unformatted', status='replace')
+  write(un) u, v, w, delp, pt, delz, mfx, cx, pkz
+  close(un)
+  write(*,'(a,es24.16)') 'fv3_solo_refsig: done, sum(delp) = ', sum(delp(1:nx, 1:ny, :))
+end program fv3_solo_refsig

@@ -109,3 +109,68 @@ def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_sp
         assert np.all(np.isfinite(a)), n
         assert np.array_equal(a, b), f"{n}: Fortran host and Python host differ (max abs {np.max(np.abs(a - b)):.3e})"
     return r.stdout
+
+
+def build_refsig(workdir, libdir=CSRC, libname="fv3_mi355x"):
+    """the reference-signature dyn_core (fv3_dyn_core_mod) + its driver"""
+    fc = fortran_compiler()
+    exe = os.path.join(str(workdir), "fv3_solo_refsig")
+    srcs = [os.path.join(FDIR, f) for f in ("fv3_mi355x_mod.F90", "fv3_host_mod.F90", "fv3_dyn_core_mod.F90", "fv3_solo_refsig.F90")]
+    subprocess.check_call([fc, "-O1", "-module-dir", str(workdir)] + srcs +
+                          ["-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2, bdt=6.0, hydrostatic=False, d_con=0.0):
+    """dyn_core called with the reference's argument list on host arrays (fv3_dyn_core_mod, driver fv3_solo_refsig) against the
+    Python host's DynCore.run on the same state: u, v, w, delp, pt, delz, the accumulated mass fluxes / Courant numbers (and pkz
+    when the heating or the hydrostatic branch writes it) bit-identical"""
+    import parity_common as P
+    import parity_dyn as D
+    import parity_nh as N
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynCore, DynFlags
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    st, _ = D.make_state(bd, npz)
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+    ak, bk = N.PTOP * (1.0 - sig), sig.copy()
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, d_con=d_con)
+    dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
+    ctx = Context(g, npz, lib=lib)
+    try:
+        dc = DynCore(ctx, fl, dp_ref)
+        dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
+        for _ in range(nsteps):
+            dc.run(bdt)
+        names = ("u", "v", "delp", "pt", "mfx", "cx") + (() if hydrostatic else ("w", "delz"))
+        ref = {n: dc.d[n].download() for n in names}
+        if "pkz" in dc.d and (hydrostatic or d_con > 1e-5):
+            ref["pkz"] = dc.d["pkz"].download()
+    finally:
+        ctx.close()
+    exe = build_refsig(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
+    fin, fout = os.path.join(str(workdir), "in_rs.bin"), os.path.join(str(workdir), "out_rs.bin")
+    write_input(fin, bd, npz, 0, n_split, 1, nsteps, False, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak, bk, st, None,
+                hydrostatic=hydrostatic, d_con=d_con, d_ext=fl.d_ext)
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = {}
+    with open(fout, "rb") as f:
+        for n, kind in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC"), ("mfx", "FX"), ("cx", "CX"),
+                        ("pkz", "CC")):
+            shp = bd.shape(kind, npz)
+            got[n] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+    i0, i1, j0, j1 = bd.is_, bd.ie, bd.js, bd.je
+    rng_ = {"u": ("U", i0, i1, j0, j1 + 1), "v": ("V", i0, i1 + 1, j0, j1), "w": ("A", i0, i1, j0, j1),
+            "delp": ("A", i0, i1, j0, j1), "pt": ("A", i0, i1, j0, j1)}
+    for n in ref:
+        if n in rng_:
+            kind, *r4 = rng_[n]
+            a, b = bd.view(got[n], kind, *r4), bd.view(ref[n], kind, *r4)
+        else:
+            a, b = got[n], ref[n]
+        assert np.all(np.isfinite(a)), n
+        assert np.array_equal(a, b), f"{n}: reference-signature dyn_core and the Python host differ (max abs {np.max(np.abs(a - b)):.3e})"
+    return r.stdout

@@ -362,6 +362,17 @@ def test_fortran_host_drives_the_library(emu, tmp_path):
     assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=12, nq=0, hydrostatic=False, d_con=1.0)
 
 
+def test_fortran_dyn_core_with_the_reference_argument_list(emu, tmp_path):
+    """fv3_dyn_core_mod's dyn_core: the reference's argument list (model/dyn_core.F90:94-98: host arrays with the fv_arrays bounds,
+    gridstruct / flagstruct / bd by their reference names) over the device-resident loop; both branches, with the heating"""
+    import fortran_host as F
+    if F.fortran_compiler() is None:
+        pytest.skip("no Fortran compiler in this image")
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path)
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=12, d_con=1.0)
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=12, hydrostatic=True, d_con=1.0)
+
+
 @pytest.mark.parametrize("use_cond,moist_kappa", [(True, False), (True, True), (False, True)])
 @pytest.mark.parametrize("a_imp", [1.0, 0.75])
 def test_riem_solvers_moist(emu, use_cond, moist_kappa, a_imp):
