@@ -2243,8 +2243,9 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   if (!c->akbk_ready) return fail("fv3_lagrangian_to_eulerian: call fv3_set_ak_bk first");
   if (p->nq < 0 || p->nq > 64) return fail("fv3_lagrangian_to_eulerian: nq out of range");
   if (p->nq > 0 && (!kord_tr || !q)) return fail("fv3_lagrangian_to_eulerian: tracers need q and kord_tr");
-  if (!kord_supported(p->kord_mt) || !kord_supported(p->kord_tm) || (!p->hydrostatic && !kord_supported(p->kord_wz)))
-    return fail("fv3_lagrangian_to_eulerian: |kord| must be one of 8..15");
+  // kord_mt and kord_tr reach the map routines signed, kord_tm and kord_wz as abs() (fv_mapz.F90:359-417, :553)
+  if (!kord_supported(p->kord_mt) || !kord_supported(std::abs(p->kord_tm)) || (!p->hydrostatic && !kord_supported(std::abs(p->kord_wz))))
+    return fail("fv3_lagrangian_to_eulerian: kord must be <= 15 (8..15: scalar_profile / cs_profile, <= 7: ppm_profile)");
   if (!p->hydrostatic && p->kord_wz < 0)
     return fail("fv3_lagrangian_to_eulerian: kord_wz < 0 (iv=-3) reads an unset array element in the reference; not built");
   for (int n = 0; n < p->nq; n++)

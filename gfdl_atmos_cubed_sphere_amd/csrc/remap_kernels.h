@@ -8,7 +8,8 @@
 // coalesced access across the wavefront; the data-dependent search of the mapping loop only moves
 // forward (k0 carry) and neighbouring columns move together.
 // Branches: remap_te = .false., use_cond = moist_kappa = .false., consv = 0, fill = .false.;
-// |kord| in {8,9,10,11,13}; iv in {-2,-1,0,1} (iv=-3 is undefined behaviour in the reference).
+// kord 8..15 (scalar_profile / cs_profile) and kord <= 7 (ppm_profile :1382-1639 + ppm_limiters :1642-1723, what the map
+// routines call for "kord > 7" false, with the SIGNED kord); iv in {-2,-1,0,1} (iv=-3 is undefined behaviour in the reference).
 #pragma once
 
 #include "fv3_common.h"
@@ -34,10 +35,9 @@ FV3_HD void scr_col(ColScr &c, int col, int fo, int km, size_t nA, int blocked) 
   }
 }
 
-FV3_HD bool kord_supported(int kord) {
-  const int a = kord < 0 ? -kord : kord;
-  return a == 8 || a == 9 || a == 10 || a == 11 || a == 12 || a == 13 || a == 14 || a == 15;
-}
+// what the map routines do with a kord: > 7 -> scalar_profile / cs_profile (built for 8..15), otherwise ppm_profile (any value)
+FV3_HD bool kord_supported(int kord) { return kord <= 15; }
+FV3_HD bool kord_is_ppm(int kord) { return kord <= 7; }
 
 // cs_limiters for one cell (fv_operators.F90:1303-1378)
 FV3_HD void cs_limit(bool extm, double a1, double &a2, double &a3, double &a4, int iv) {
@@ -306,6 +306,153 @@ FV3_HD void cs_cell(const ProfCfg &pc, int k, double &a2v, double &a3v, double a
     a4o = a4v;
 }
 
+// ppm_limiters for one cell (fv_operators.F90:1642-1723)
+FV3_HD void ppm_limit(double dm, double a1, double &a2, double &a3, double &a6, int lmt) {
+  constexpr double r12 = 1. / 12.;
+  if (lmt == 3) return;
+  if (lmt == 0) {
+    if (dm == 0.) {
+      a2 = a1; a3 = a1; a6 = 0.;
+    } else {
+      const double da1 = a3 - a2, da2 = da1 * da1, a6da = a6 * da1;
+      if (a6da < -da2) {
+        a6 = 3. * (a2 - a1); a3 = a2 - a6;
+      } else if (a6da > da2) {
+        a6 = 3. * (a3 - a1); a2 = a3 - a6;
+      }
+    }
+  } else if (lmt == 1) {
+    const double qmp = 2. * dm;
+    a2 = a1 - copysign(dmin(fabs(qmp), fabs(a2 - a1)), qmp);
+    a3 = a1 + copysign(dmin(fabs(qmp), fabs(a3 - a1)), qmp);
+    a6 = 3. * (2. * a1 - (a2 + a3));
+  } else if (lmt == 2) {
+    if (fabs(a3 - a2) < -a6) {
+      const double fm = a1 + 0.25 * ((a3 - a2) * (a3 - a2)) / a6 + a6 * r12;
+      if (fm < 0.) {
+        if (a1 < a3 && a1 < a2) {
+          a3 = a1; a2 = a1; a6 = 0.;
+        } else if (a3 > a2) {
+          a6 = 3. * (a2 - a1); a3 = a2 - a6;
+        } else {
+          a6 = 3. * (a3 - a1); a2 = a3 - a6;
+        }
+      }
+    }
+  }
+}
+
+// ppm_profile of one column (fv_operators.F90:1382-1639; kord <= 7).  a1 from src, the source coordinate in c.pe1; writes the
+// a2, a3, a4 slabs (the stored form of ProfCfg); dc lives in c.q, h2 in c.gam; delq, d4, df2 are formed from a1 / pe1 where
+// they are used (same expressions, same roundings as the reference's arrays).  km >= 5.
+template <class Src>
+FV3_HD ProfCfg profile_col_ppm(const ColScr &c, int km, int iv, int kord, const Src &src) {
+  ProfCfg pc{km, iv, 0, false, 0., false};
+  const int km1 = km - 1;
+  for (int k = 1; k <= km; k++) CS(a1, k) = src(k);
+  auto DP = [&](int k) { return CS(pe1, k + 1) - CS(pe1, k); };
+  auto DQ = [&](int k) { return CS(a1, k + 1) - CS(a1, k); };   // delq(k)
+  auto D4 = [&](int k) { return DP(k - 1) + DP(k); };
+  for (int k = 2; k <= km1; k++) {  // limited slopes dc(k)
+    const double am = CS(a1, k - 1), a0 = CS(a1, k), ap = CS(a1, k + 1);
+    const double c1 = (DP(k - 1) + 0.5 * DP(k)) / D4(k + 1);
+    const double c2 = (DP(k + 1) + 0.5 * DP(k)) / D4(k);
+    const double df2 = DP(k) * (c1 * DQ(k) + c2 * DQ(k - 1)) / (D4(k) + DP(k + 1));
+    const double hi = dmax(dmax(am, a0), ap) - a0, lo = a0 - dmin(dmin(am, a0), ap);
+    CS(q, k) = copysign(dmin(dmin(fabs(df2), hi), lo), df2);
+  }
+  for (int k = 3; k <= km1; k++) {  // 4th order interpolation of the provisional cell edge value
+    const double c1 = DQ(k - 1) * DP(k - 1) / D4(k);
+    const double a1_ = D4(k - 1) / (D4(k) + DP(k - 1));
+    const double a2_ = D4(k + 1) / (D4(k) + DP(k));
+    CS(a2, k) = CS(a1, k - 1) + c1 + 2. / (D4(k - 1) + D4(k + 1)) * (DP(k) * (c1 * (a1_ - a2_) + a2_ * CS(q, k - 1)) - DP(k - 1) * a1_ * CS(q, k));
+  }
+  {  // top: area preserving cubic with 2nd derivative = 0 at the boundary
+    const double d1 = DP(1), d2 = DP(2), t1 = CS(a1, 1), t2 = CS(a1, 2);
+    const double qm = (d2 * t1 + d1 * t2) / (d1 + d2);
+    const double dq = 2. * (t2 - t1) / (d1 + d2);
+    const double c1 = 4. * (CS(a2, 3) - qm - d2 * dq) / (d2 * (2. * d2 * d2 + d1 * (d2 + 3. * d1)));
+    const double c3 = dq - 0.5 * c1 * (d2 * (5. * d1 + d2) - 3. * d1 * d1);
+    double e2 = qm - 0.25 * c1 * d1 * d2 * (d2 + 3. * d1);
+    double e1 = d1 * (2. * c1 * (d1 * d1) - c3) + e2;
+    e2 = dmax(e2, dmin(t1, t2));
+    e2 = dmin(e2, dmax(t1, t2));
+    CS(q, 1) = 0.5 * (e2 - t1);
+    if (iv == 0) {
+      e1 = dmax(0., e1);
+      e2 = dmax(0., e2);
+    } else if (iv == -1) {
+      if (e1 * t1 <= 0.) e1 = 0.;
+    } else if (iv == 2 || iv == -2) {
+      e1 = t1;
+    }
+    CS(a2, 1) = e1;
+    CS(a2, 2) = e2;
+  }
+  {  // bottom
+    const double d1 = DP(km), d2 = DP(km1), b0 = CS(a1, km), b1 = CS(a1, km1);
+    const double qm = (d2 * b0 + d1 * b1) / (d1 + d2);
+    const double dq = 2. * (b1 - b0) / (d1 + d2);
+    const double c1 = (CS(a2, km1) - qm - d2 * dq) / (d2 * (2. * d2 * d2 + d1 * (d2 + 3. * d1)));
+    const double c3 = dq - 2.0 * c1 * (d2 * (5. * d1 + d2) - 3. * d1 * d1);
+    double e2 = qm - c1 * d1 * d2 * (d2 + 3. * d1);
+    double e3 = d1 * (8. * c1 * (d1 * d1) - c3) + e2;
+    e2 = dmax(e2, dmin(b0, b1));
+    e2 = dmin(e2, dmax(b0, b1));
+    CS(q, km) = 0.5 * (b0 - e2);
+    if (iv == 0) {
+      e2 = dmax(0., e2);
+      e3 = dmax(0., e3);
+    } else if (iv < 0) {
+      if (b0 * e3 <= 0.) e3 = 0.;
+    }
+    CS(a2, km) = e2;
+    CS(a3, km) = e3;
+  }
+  for (int k = 1; k <= km1; k++) CS(a3, k) = CS(a2, k + 1);   // (abs(iv) == 2 sets a4(3,1) = a4(1,1) first; this overwrites it, :1544)
+  auto finish = [&](int k, int lmt, bool form_a6) {
+    const double a1v = CS(a1, k);
+    double a2v = CS(a2, k), a3v = CS(a3, k);
+    double a6 = form_a6 ? 3. * (2. * a1v - (a2v + a3v)) : CS(a4, k);
+    ppm_limit(CS(q, k), a1v, a2v, a3v, a6, lmt);
+    CS(a2, k) = a2v; CS(a3, k) = a3v; CS(a4, k) = a6;
+  };
+  finish(1, 0, true);
+  finish(2, 0, true);
+  if (kord >= 7) {  // Huynh's 2nd constraint
+    for (int k = 2; k <= km1; k++)
+      CS(gam, k) = 2. * (CS(q, k + 1) / DP(k + 1) - CS(q, k - 1) / DP(k - 1)) / (DP(k) + 0.5 * (DP(k - 1) + DP(k + 1))) * (DP(k) * DP(k));
+    const double fac = 1.5;
+    for (int k = 3; k <= km - 2; k++) {
+      const double a1v = CS(a1, k), dck = CS(q, k);
+      const double pmp = 2. * dck;
+      double qmp = a1v + pmp;
+      double lac = a1v + fac * CS(gam, k - 1) + dck;
+      double a3v = dmin(dmax(CS(a3, k), dmin(dmin(a1v, qmp), lac)), dmax(dmax(a1v, qmp), lac));
+      qmp = a1v - pmp;
+      lac = a1v + fac * CS(gam, k + 1) - dck;
+      double a2v = dmin(dmax(CS(a2, k), dmin(dmin(a1v, qmp), lac)), dmax(dmax(a1v, qmp), lac));
+      double a6 = 3. * (2. * a1v - (a2v + a3v));
+      if (iv == 0 && kord >= 6) ppm_limit(dck, a1v, a2v, a3v, a6, 2);
+      // a3(k) = a2(k+1) is read by nothing below: cell k + 1 takes its own left edge from the a2 slab
+      CS(a2, k) = a2v; CS(a3, k) = a3v; CS(a4, k) = a6;
+    }
+  } else {
+    int lmt = kord - 3;
+    if (lmt < 0) lmt = 0;
+    if (iv == 0 && lmt > 2) lmt = 2;
+    for (int k = 3; k <= km - 2; k++) {
+      if (kord != 6)
+        finish(k, lmt, kord != 4);
+      else
+        CS(a4, k) = 3. * (2. * CS(a1, k) - (CS(a2, k) + CS(a3, k)));
+    }
+  }
+  finish(km1, 0, true);
+  finish(km, 0, true);
+  return pc;
+}
+
 // scalar_profile (is_scalar) / cs_profile of one column.  src(k) yields the layer mean a4(1,k) of the field (it is
 // called once per level, in order, and the value is kept in c.a1 for the mapping loop); the source coordinate is in
 // c.pe1.  Writes c.a2, c.a3, c.a4 (and uses c.q, c.gam).
@@ -321,6 +468,7 @@ FV3_HD void cs_cell(const ProfCfg &pc, int k, double &a2v, double &a3v, double a
 // produced yet; it keeps the unfused sweeps below.)
 template <class Src>
 FV3_HD ProfCfg profile_col(const ColScr &c, int km, bool is_scalar, double qs, int iv, int kord, double qmin, const Src &src) {
+  if (kord_is_ppm(kord)) return profile_col_ppm(c, km, iv, kord, src);   // "if (kord > 7) ... else call ppm_profile"
   const int ak = kord < 0 ? -kord : kord;
   ProfCfg pc{km, iv, ak, is_scalar, qmin, ak != 11 && ak != 12};
 #define DP(k) (CS(pe1, (k) + 1) - CS(pe1, k))
@@ -994,7 +1142,7 @@ struct RemapFields {
         bool side_by_side = nl > 1;
         for (int n = 0; n < nl; n++) {
           const int a = kord_tr[iq0 + n] < 0 ? -kord_tr[iq0 + n] : kord_tr[iq0 + n];
-          if (a == 11 || a == 12) side_by_side = false;  // these keep a2, a3, a4 in slabs (profile_col_tail_unfused)
+          if (a == 11 || a == 12 || kord_is_ppm(kord_tr[iq0 + n])) side_by_side = false;  // these keep a2, a3, a4 in slabs
         }
         if (side_by_side) {
           ColScr cg = c;

@@ -360,7 +360,8 @@ int fv3_gather_destroy(fv3_gather *t);
 
 /* ---- vertical remap ------------------------------------------------------------------------------------
  * Lagrangian_to_Eulerian -- model/fv_mapz.F90:56-64, call site model/fv_dynamics.F90:607.  Branches built:
- * remap_te=.false., consv=0, |kord| in 8..15, kord_wz>0; use_cond / moist_kappa through fv3_set_moist below,
+ * remap_te=.false., consv=0, kord <= 15 (8..15: scalar_profile / cs_profile; <= 7, the signed value as the map routines test
+ * it: ppm_profile + ppm_limiters, fv_operators.F90:1382-1723), kord_wz>0; use_cond / moist_kappa through fv3_set_moist below,
  * flagstruct%fill through fv3_remap_params.fill.
  * All fields are updated in place (every column is independent): ps (A), pe (is-1:ie+1, npz+1, js-1:je+1),
  * delp, pt, w, omga (A x npz), q (A x npz x nq), u (U x npz), v (V x npz), delz, pkz (CC x npz),

@@ -5,7 +5,7 @@
  * model/fv_mapz.F90 Lagrangian_to_Eulerian :56-845.
  * Branches restated: remap_te = .false., moist_kappa / use_cond both ways (moist_cv: fv_thermodynamics.F90:250-325),
  * consv = 0 (no energy fixer),
- * fill = .false., do_intermediate_phys = .false.; abs(kord) in {8, 9, 10, 11, 13}; iv in {-2,-1,0,1}.
+ * fill = .false., do_intermediate_phys = .false.; kord 8..15 (scalar_profile / cs_profile) and kord <= 7 (ppm_profile); iv in {-2,-1,0,1}.
  * (iv = -3, i.e. kord_wz < 0, is not restated: the reference's back-substitution reads gam(i,km), which
  * that branch never sets -- fv_operators.F90:974-993,1012-1016.)
  */
@@ -89,13 +89,154 @@ static void cs_limiter_cell(int extm, double *a1, double *a2, double *a3, double
 }
 #define LIM(k, mode) cs_limiter_cell(extm[k], &A4(1, k), &A4(2, k), &A4(3, k), &A4(4, k), mode)
 
+/* ppm_limiters for one cell, fv_operators.F90:1642-1723 (lmt 0: standard PPM, 1: Lin's full monotonicity, 2: positive
+ * definite, 3: nothing) */
+static void ppm_limiter_cell(double dm, double *a1, double *a2, double *a3, double *a6, int lmt) {
+  if (lmt == 3) return;
+  if (lmt == 0) {
+    if (dm == 0.) {
+      *a2 = *a1; *a3 = *a1; *a6 = 0.;
+    } else {
+      const double da1 = *a3 - *a2, da2 = da1 * da1, a6da = *a6 * da1;
+      if (a6da < -da2) {
+        *a6 = 3. * (*a2 - *a1); *a3 = *a2 - *a6;
+      } else if (a6da > da2) {
+        *a6 = 3. * (*a3 - *a1); *a2 = *a3 - *a6;
+      }
+    }
+  } else if (lmt == 1) {
+    const double qmp = 2. * dm;
+    *a2 = *a1 - copysign(dmin(fabs(qmp), fabs(*a2 - *a1)), qmp);
+    *a3 = *a1 + copysign(dmin(fabs(qmp), fabs(*a3 - *a1)), qmp);
+    *a6 = 3. * (2. * *a1 - (*a2 + *a3));
+  } else if (lmt == 2) {
+    if (fabs(*a3 - *a2) < -*a6) {
+      const double fmin_ = *a1 + 0.25 * ((*a3 - *a2) * (*a3 - *a2)) / *a6 + *a6 * r12;
+      if (fmin_ < 0.) {
+        if (*a1 < *a3 && *a1 < *a2) {
+          *a3 = *a1; *a2 = *a1; *a6 = 0.;
+        } else if (*a3 > *a2) {
+          *a6 = 3. * (*a2 - *a1); *a3 = *a2 - *a6;
+        } else {
+          *a6 = 3. * (*a3 - *a1); *a2 = *a3 - *a6;
+        }
+      }
+    }
+  }
+}
+#define PLIM(k, lmt) ppm_limiter_cell(dc[k], &A4(1, k), &A4(2, k), &A4(3, k), &A4(4, k), lmt)
+
+/* ppm_profile for one column, fv_operators.F90:1382-1639 (what the map routines call for kord <= 7, :87-91, :182-186, :395-399,
+ * :480-484): 4th-order edge values from limited slopes, area-preserving cubics at the top and the bottom, Huynh's 2nd
+ * constraint for kord >= 7, ppm_limiters otherwise.  Needs km >= 5 like the reference's loops. */
+static int ppm_profile_column(double *a4, const double *delp, int km, int iv, int kord) {
+  int k;
+  const int km1 = km - 1;
+  if (km < 5) return FVO_ERR_UNSUPPORTED;
+  double *dc = dalloc(km + 3), *h2 = dalloc(km + 3), *delq = dalloc(km + 3), *df2 = dalloc(km + 3), *d4 = dalloc(km + 3);
+  double c1, c2, c3, a1, a2, d1, d2, qm, dq, qmp, lac, pmp;
+  for (k = 2; k <= km; k++) {
+    delq[k - 1] = A4(1, k) - A4(1, k - 1);
+    d4[k] = delp[k - 1] + delp[k];
+  }
+  for (k = 2; k <= km1; k++) {
+    c1 = (delp[k - 1] + 0.5 * delp[k]) / d4[k + 1];
+    c2 = (delp[k + 1] + 0.5 * delp[k]) / d4[k];
+    df2[k] = delp[k] * (c1 * delq[k] + c2 * delq[k - 1]) / (d4[k] + delp[k + 1]);
+    dc[k] = copysign(dmin3(fabs(df2[k]), dmax3(A4(1, k - 1), A4(1, k), A4(1, k + 1)) - A4(1, k),
+                           A4(1, k) - dmin3(A4(1, k - 1), A4(1, k), A4(1, k + 1))), df2[k]);
+  }
+  for (k = 3; k <= km1; k++) { /* 4th order interpolation of the provisional cell edge value */
+    c1 = delq[k - 1] * delp[k - 1] / d4[k];
+    a1 = d4[k - 1] / (d4[k] + delp[k - 1]);
+    a2 = d4[k + 1] / (d4[k] + delp[k]);
+    A4(2, k) = A4(1, k - 1) + c1 + 2. / (d4[k - 1] + d4[k + 1]) * (delp[k] * (c1 * (a1 - a2) + a2 * dc[k - 1]) - delp[k - 1] * a1 * dc[k]);
+  }
+  /* top: area preserving cubic with 2nd deriv. = 0 at the boundary */
+  d1 = delp[1];
+  d2 = delp[2];
+  qm = (d2 * A4(1, 1) + d1 * A4(1, 2)) / (d1 + d2);
+  dq = 2. * (A4(1, 2) - A4(1, 1)) / (d1 + d2);
+  c1 = 4. * (A4(2, 3) - qm - d2 * dq) / (d2 * (2. * d2 * d2 + d1 * (d2 + 3. * d1)));
+  c3 = dq - 0.5 * c1 * (d2 * (5. * d1 + d2) - 3. * d1 * d1);
+  A4(2, 2) = qm - 0.25 * c1 * d1 * d2 * (d2 + 3. * d1);
+  A4(2, 1) = d1 * (2. * c1 * (d1 * d1) - c3) + A4(2, 2);
+  A4(2, 2) = dmax(A4(2, 2), dmin(A4(1, 1), A4(1, 2)));
+  A4(2, 2) = dmin(A4(2, 2), dmax(A4(1, 1), A4(1, 2)));
+  dc[1] = 0.5 * (A4(2, 2) - A4(1, 1));
+  if (iv == 0) {
+    A4(2, 1) = dmax(0., A4(2, 1));
+    A4(2, 2) = dmax(0., A4(2, 2));
+  } else if (iv == -1) {
+    if (A4(2, 1) * A4(1, 1) <= 0.) A4(2, 1) = 0.;
+  } else if (abs(iv) == 2) {
+    A4(2, 1) = A4(1, 1);
+    A4(3, 1) = A4(1, 1);
+  }
+  /* bottom */
+  d1 = delp[km];
+  d2 = delp[km1];
+  qm = (d2 * A4(1, km) + d1 * A4(1, km1)) / (d1 + d2);
+  dq = 2. * (A4(1, km1) - A4(1, km)) / (d1 + d2);
+  c1 = (A4(2, km1) - qm - d2 * dq) / (d2 * (2. * d2 * d2 + d1 * (d2 + 3. * d1)));
+  c3 = dq - 2.0 * c1 * (d2 * (5. * d1 + d2) - 3. * d1 * d1);
+  A4(2, km) = qm - c1 * d1 * d2 * (d2 + 3. * d1);
+  A4(3, km) = d1 * (8. * c1 * (d1 * d1) - c3) + A4(2, km);
+  A4(2, km) = dmax(A4(2, km), dmin(A4(1, km), A4(1, km1)));
+  A4(2, km) = dmin(A4(2, km), dmax(A4(1, km), A4(1, km1)));
+  dc[km] = 0.5 * (A4(1, km) - A4(2, km));
+  if (iv == 0) {
+    A4(2, km) = dmax(0., A4(2, km));
+    A4(3, km) = dmax(0., A4(3, km));
+  } else if (iv < 0) {
+    if (A4(1, km) * A4(3, km) <= 0.) A4(3, km) = 0.;
+  }
+  for (k = 1; k <= km1; k++) A4(3, k) = A4(2, k + 1);
+  /* top 2 and bottom 2 layers always use monotonic mapping */
+  for (k = 1; k <= 2; k++) {
+    A4(4, k) = 3. * (2. * A4(1, k) - (A4(2, k) + A4(3, k)));
+    PLIM(k, 0);
+  }
+  if (kord >= 7) { /* Huynh's 2nd constraint */
+    for (k = 2; k <= km1; k++)
+      h2[k] = 2. * (dc[k + 1] / delp[k + 1] - dc[k - 1] / delp[k - 1]) / (delp[k] + 0.5 * (delp[k - 1] + delp[k + 1])) * (delp[k] * delp[k]);
+    const double fac = 1.5;
+    for (k = 3; k <= km - 2; k++) {
+      pmp = 2. * dc[k];
+      qmp = A4(1, k) + pmp;
+      lac = A4(1, k) + fac * h2[k - 1] + dc[k];
+      A4(3, k) = dmin(dmax(A4(3, k), dmin3(A4(1, k), qmp, lac)), dmax3(A4(1, k), qmp, lac));
+      qmp = A4(1, k) - pmp;
+      lac = A4(1, k) + fac * h2[k + 1] - dc[k];
+      A4(2, k) = dmin(dmax(A4(2, k), dmin3(A4(1, k), qmp, lac)), dmax3(A4(1, k), qmp, lac));
+      A4(4, k) = 3. * (2. * A4(1, k) - (A4(2, k) + A4(3, k)));
+      if (iv == 0 && kord >= 6) PLIM(k, 2);
+    }
+  } else {
+    int lmt = kord - 3;
+    if (lmt < 0) lmt = 0;
+    if (iv == 0 && lmt > 2) lmt = 2;
+    for (k = 3; k <= km - 2; k++) {
+      if (kord != 4) A4(4, k) = 3. * (2. * A4(1, k) - (A4(2, k) + A4(3, k)));
+      if (kord != 6) PLIM(k, lmt);
+    }
+  }
+  for (k = km1; k <= km; k++) {
+    A4(4, k) = 3. * (2. * A4(1, k) - (A4(2, k) + A4(3, k)));
+    PLIM(k, 0);
+  }
+  free(dc); free(h2); free(delq); free(df2); free(d4);
+  return FVO_OK;
+}
+
 /* scalar_profile (is_scalar=1, :546-916) / cs_profile (is_scalar=0, :919-1300) for one column.
  * delp[1..km], a4 as above (A4(1,k) on entry). Returns 0 or FVO_ERR_UNSUPPORTED. */
 int fvo_profile_column(int is_scalar, double qs, double *a4, const double *delp, int km, int iv, int kord, double qmin) {
   int k;
   const int ak = abs(kord);
-  if (!(ak >= 8 && ak <= 15)) return FVO_ERR_UNSUPPORTED;
   if (!(iv == -2 || iv == -1 || iv == 0 || iv == 1)) return FVO_ERR_UNSUPPORTED;
+  if (kord <= 7) return ppm_profile_column(a4, delp, km, iv, kord); /* "if (kord > 7) ... else ppm_profile", the SIGNED kord */
+  if (!(ak >= 8 && ak <= 15)) return FVO_ERR_UNSUPPORTED;
   double *gam = dalloc(km + 3), *q = dalloc(km + 3);
   unsigned char *extm = (unsigned char *)calloc(km + 3, 1), *ext5 = (unsigned char *)calloc(km + 3, 1),
                 *ext6 = (unsigned char *)calloc(km + 3, 1);
@@ -424,7 +565,7 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
   const size_t nA = (size_t)nid * njd, nU = (size_t)nid * (njd + 1), nV = (size_t)(nid + 1) * njd, nCC = (size_t)nx * ny;
   int i, j, k, n, iq, rc = 0;
   const double k1k = p->rdgas / p->cv_air, rrg = -p->rdgas / p->grav, akap = p->akap;
-  if (p->kord_wz < 0) return FVO_ERR_UNSUPPORTED;
+  if (!p->hydrostatic && p->kord_wz < 0) return FVO_ERR_UNSUPPORTED; /* iv = -3: reads gam(i,km) unset (file header) */
   if ((p->moist_kappa || p->use_cond) && (p->hydrostatic || !q || (p->moist_kappa && (!q_con || !cappa))))
     return FVO_ERR_UNSUPPORTED;
 #define IA3(i, j, k) ((size_t)((k)-1) * nA + (size_t)((j)-jsd) * nid + ((i)-isd))

@@ -149,6 +149,16 @@ def test_remap(emu, hydrostatic, last_step, kord_tm, kord, nq):
     R.check_remap(emu, hydrostatic=hydrostatic, last_step=last_step, kord_tm=kord_tm, kord=kord, nq=nq)
 
 
+@pytest.mark.parametrize("hydrostatic,last_step,kord_tm,kord,nq", [(False, False, -7, 7, 3), (True, True, 7, 7, 6), (False, True, -6, 6, 2),
+                                                                    (True, False, 5, 5, 7), (False, False, -4, 4, 3), (False, True, 4, 3, 2),
+                                                                    (True, False, -9, -8, 2), (False, True, -10, 6, 0)])
+def test_remap_ppm_profile(emu, hydrostatic, last_step, kord_tm, kord, nq):
+    """kord <= 7: the map routines take ppm_profile + ppm_limiters (fv_operators.F90:1382-1723) instead of cs_profile: Huynh's
+    2nd constraint (7), the positive-definite / full-monotonicity / standard limiters (6, 5, 4, 3), for winds, w, T (|kord_tm|)
+    and tracers (iv = -1, -2, 1, 0); a NEGATIVE kord_mt / kord_tr also fails the reference's "kord > 7" test and lands there"""
+    R.check_remap(emu, hydrostatic=hydrostatic, last_step=last_step, kord_tm=kord_tm, kord=kord, nq=nq)
+
+
 @pytest.mark.parametrize("nt,nq,kord", [(1, 4, 9), (2, 5, 10), (3, 4, 9), (3, 5, 8), (3, 7, 10), (3, 7, 11), (3, 3, 13)])
 def test_remap_tracer_groups(emu, nt, nq, kord, monkeypatch):
     """tracers remapped side by side in groups of up to nt per thread (remap_tracers_col): even dealing (4 = 2 + 2,
