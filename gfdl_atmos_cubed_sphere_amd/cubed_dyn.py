@@ -85,6 +85,7 @@ class MultiContext:
 class CubeHaloAdapter:
     """group halo updates of the single-domain host code -> CubeHalo gathers"""
     overlaps = False
+    overlaps_groups = False
     world = 1
 
     def __init__(self, mctx: MultiContext, npx: int, topo=None):
@@ -122,7 +123,8 @@ class CubeRankAdapter:
     """one face per rank: group halo updates of the single-domain host code -> CubeHaloRank messages (RCCL / gloo).  Scalar
     fields of one group with the same kind and level count travel in ONE message per neighbouring face, like the
     reference's complete=.false./.true. grouping (dyn_core.F90:823-824)."""
-    overlaps = False
+    overlaps = False          # no interior / rest split of d_sw on a face (the frame kernels own the edges)
+    overlaps_groups = True    # start() ... finish() pairs of the substep loop keep their messages in flight across kernels
 
     def __init__(self, ctx, face: int, npx: int, dist, topo=None):
         self.cube = CubeHaloRank(ctx, face, npx, dist, topo=topo)

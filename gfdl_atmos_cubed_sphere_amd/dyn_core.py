@@ -274,19 +274,33 @@ class DynCore:
                 ctx.heat_source_accum(d["heat_source"], d["heat_s"])          # :798-803
             for n in ("delp", "pt", "u", "v", "w") + (("q_con",) if fl.use_cond else ()):
                 self._swap(n)
-            halo.update([(d["delp"], "A"), (d["pt"], "A")])                   # :823-824 / :851 (pack 1)
+            # :823-825 start / :851-852 complete (packs 1, 11).  Several ranks: the messages stay in flight while update_dz_d
+            # and Riem_Solver3 run -- neither reads a halo of delp, pt, q_con (column kernels over the compute domain; the
+            # transport of zh reads the Courant numbers and area fluxes) -- and are completed in front of pk3_halo, the
+            # first reader of delp's halo
+            grp1 = [(d["delp"], "A"), (d["pt"], "A")] + ([(d["q_con"], "A")] if fl.use_cond else [])
+            lag = bool(getattr(halo, "overlaps_groups", False))
+            pend1 = halo.start(grp1, defer=True) if lag else halo.update(grp1)
             if fl.use_cond:
-                halo.update([(d["q_con"], "A")])                              # :825 / :852 (pack 11)
                 cond()
             ctx.update_dz_d(fl.hord_tm, d["zs"], d["zh"], d["zh_nxt"], d["crx"], d["cry"], d["xfx"], d["yfx"],
                             d["ws"], rdt)                                     # :911
             self._swap("zh")
+            if lag:
+                halo.post(pend1)
             ctx.riem_solver3(dt, self.cn, d["zs"], d["w"], d["delz"], d["pt"], d["delp"], d["zh"], d["pe"], d["pkc"],
                              d["pk3"], d["pk"], d["peln"], d["ws"], fl.use_logp, remap_step, False)   # :932
-            halo.update([(d["zh"], "A"), (d["pkc"], "A")])                    # :944-950 (packs 4, 5)
+            if lag:
+                halo.finish(pend1)
+            # :944-950 (packs 4, 5) start ... complete around pe_halo / pk3_halo, which read delp only
+            grp2 = [(d["zh"], "A"), (d["pkc"], "A")]
+            pend2 = halo.start(grp2, defer=True) if lag else halo.update(grp2)
             if remap_step:
                 ctx.pe_halo(fl.ptop, d["pe"], d["delp"])                      # :952-953
             ctx.pk3_halo(fl.ptop, fl.akap, d["pk3"], d["delp"], fl.use_logp)  # :955-959
+            if lag:
+                halo.post(pend2)
+                halo.finish(pend2)
             # :982-989 gz = zh*grav is fused into nh_p_grad (gz_scale)
             ctx.nh_p_grad(d["u"], d["v"], d["pkc"], d["zh"], d["delp"], d["pk3"], dt,
                           peln1 if fl.use_logp else ptk, gz_scale=fl.grav)    # :1032

@@ -177,6 +177,13 @@ class HaloExchanger:
         d_sw into interior + rest only then -- on one rank the split would just cost launch granularity."""
         return self.world > 1 or self.split_single
 
+    @property
+    def overlaps_groups(self) -> bool:
+        """True when a start() ... finish() pair around kernels that do not read the halos in flight hides the transfers:
+        the substep loop then keeps the delp / pt (/ q_con) and the zh / pkc groups in flight across the kernels between
+        the reference's start and the first reader (dyn_core.py)"""
+        return self.world > 1 or self.split_single
+
     def start(self, fields, defer: bool = False):
         """Begin a group halo update (the reference's start_group_halo_update): pack and post the messages.  Returns a
         handle for finish().  Compute that does not read these halos may be launched in between: the transfers run on

@@ -48,6 +48,28 @@ def main():
         got = dev.download()
         assert np.array_equal(got, ref), f"halo of kind {kind} differs after the RCCL loopback exchange"
     ctx.close()
+    # the substep loop with every group halo update as RCCL messages, the delp / pt and zh / pkc groups kept in flight across
+    # update_dz_d + Riem_Solver3 and pe_halo / pk3_halo (DynCore.run with overlaps_groups): same state as the periodic copies
+    import parity_dyn as D
+    import parity_nh as N
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynCore, DynFlags
+    nx, ny, npz = 40, 24, 8
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    st, dp0 = D.make_state(bd, npz)
+    fl = DynFlags(n_split=3, ptop=N.PTOP)
+    out = []
+    for lb in (False, True):
+        ctx = L.Context(g, npz, stream=stream.cuda_stream)
+        h = HaloExchanger(ctx, 1, 1, 0, 1, loopback=True, split_single=True) if lb else None
+        dc = DynCore(ctx, fl, dp0, halo=h)
+        assert bool(getattr(dc.halo, "overlaps_groups", False)) == lb
+        dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
+        dc.run(6.0)
+        out.append(dc.get_state())
+        ctx.close()
+    for n in ("u", "v", "w", "delp", "pt", "delz"):
+        assert np.array_equal(out[0][n], out[1][n]), f"{n}: the lagged RCCL exchange changes the substeps"
     dist.destroy_process_group()
     print("rccl loopback ok")
 
