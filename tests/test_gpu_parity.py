@@ -800,6 +800,13 @@ def test_cubed_d_sw_dissipation_estimate(prod, kw):
     assert max(PC.check_d_sw(prod, npx=25, npz=6, hydrostatic=False, faces=(1, 4), **kw).values()) <= P.TOL
 
 
+@pytest.mark.parametrize("hydrostatic,conserve", [(False, True), (True, True), (False, False)])
+def test_cubed_sphere_rayleigh_friction(prod, hydrostatic, conserve):
+    """Rayleigh_Friction on the six faces: u2f through the cubed-sphere cubed_to_latlon, its halo across the cube edges, heating +
+    implicit damping of u, v, w (fv_dynamics.F90:1126-1264)"""
+    assert PC.check_rayleigh(prod, npx=25, hydrostatic=hydrostatic, conserve=conserve) <= 1e-14
+
+
 def test_cubed_del2_cubed_and_damped_transports(prod):
     assert PC.check_del2_cubed(prod, npx=25, npz=4, nmax=3) <= P.TOL
     for kw in (dict(nord=2, damp_c=0.05), dict(nord=2, damp_c=0.05, mass_flux=True)):

@@ -678,6 +678,13 @@ def test_cubed_d_sw_dissipation_estimate(emu, kw):
     assert max(PC.check_d_sw(emu, npx=13, npz=6, hydrostatic=False, faces=(1, 4), **kw).values()) <= P.TOL
 
 
+@pytest.mark.parametrize("hydrostatic,conserve", [(False, True), (True, True), (False, False)])
+def test_cubed_sphere_rayleigh_friction(emu, hydrostatic, conserve):
+    """Rayleigh_Friction on the six faces: u2f through the cubed-sphere cubed_to_latlon, its halo across the cube edges, heating +
+    implicit damping of u, v, w (fv_dynamics.F90:1126-1264)"""
+    assert PC.check_rayleigh(emu, npx=13, hydrostatic=hydrostatic, conserve=conserve) <= 1e-14
+
+
 def test_cubed_del2_cubed_and_damped_transports(emu):
     for nmax in (1, 2, 3):
         assert PC.check_del2_cubed(emu, nmax=nmax) <= P.TOL
