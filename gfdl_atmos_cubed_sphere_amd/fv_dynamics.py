@@ -55,7 +55,7 @@ class FvDynamics:
         fv_dynamics.F90:284-399 (T -> theta_v), the k_split loop, and the theta_v -> T conversion that the last remap
         does (fv_mapz.F90:793-821, last_step)."""
         d, ctx, fl = self.dc.d, self.ctx, self.fl
-        qv = d["q"].ptr if (self.nq and self.remap_par["sphum"] > 0 and not self.remap_par["adiabatic"]) else None
+        qv = d["q"] if (self.nq and self.remap_par["sphum"] > 0 and not self.remap_par["adiabatic"]) else None   # first tracer = sphum
         zvir = self.remap_par["r_vir"] if qv else 0.0
         if self.moist:
             ctx.set_moist(self.moist, d.get("q_con"), d.get("cappa"))

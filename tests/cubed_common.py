@@ -159,7 +159,8 @@ def _oracle_heating(cs, gs, fl, f, npz, bdt, hydrostatic):
         x = f[t]
         O.del2_cubed(gs[t], npz, 0.20 * gs[t].da_min, min(3, fl.nord + 1), x["heat_source"])
         O.apply_heat_source(gs[t], npz, n_con, hydrostatic, bdt, fl.delt_max, fl.cp_air, fl.cp_air - fl.rdgas, fl.rdgas, fl.grav,
-                            x["pt"], x["heat_source"], x["delp"], x["pkz"] if hydrostatic else x["delz"], x["pkz"])
+                            x["pt"], x["heat_source"], x["delp"], x["pkz"] if hydrostatic else x["delz"], x["pkz"],
+                            x["cappa"] if (fl.moist_kappa and not hydrostatic) else None)          # :1338-1340
 
 
 def oracle_substeps_hydro(cs, gs, fl, st, bdt, npz):
@@ -276,7 +277,9 @@ def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
     ptk, peln1 = fl.ptop ** fl.akap, np.log(fl.ptop)
     par = dict(dt=dt, hord_tr=fl.hord_tr, hord_mt=fl.hord_mt, hord_vt=fl.hord_vt, hord_tm=fl.hord_tm, hord_dp=fl.hord_dp, nord=1,
                nord_v=1, nord_w=1, nord_t=1, dddmp=fl.dddmp, d2_bg=0.0, d4_bg=fl.d4_bg, damp_v=0.0, damp_w=0.0, damp_t=0.0, d_con=0.0,
-               kgb=fl.ke_bg, hydrostatic=0, use_cond=0)
+               kgb=fl.ke_bg, hydrostatic=0, use_cond=int(fl.use_cond))
+    qc = lambda x: x["q_con"] if fl.use_cond else None            # nh_core.F90:96-166, nh_utils.F90:383-438
+    cap = lambda x: x["cappa"] if fl.moist_kappa else None
     ndif = np.concatenate([lev["nord_v"], lev["nord_v"][-1:]]).astype(np.int32)
     damp = np.concatenate([lev["damp_vt"], lev["damp_vt"][-1:]])
     exchange(cs, f, ("delp", "pt"), "A")
@@ -308,7 +311,7 @@ def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
         for t in range(6):
             x = f[t]
             O.update_dz_c(gs[t], npz, dt2, dp_ref, x["zs"], x["ut"], x["vt"], x["gz"], x["ws3"])
-            O.riem_solver_c(gs[t], npz, dt2, cn, x["phis"], x["omga"], x["ptc"], x["delpc"], x["gz"], x["pkc"], x["ws3"], None, None)
+            O.riem_solver_c(gs[t], npz, dt2, cn, x["phis"], x["omga"], x["ptc"], x["delpc"], x["gz"], x["pkc"], x["ws3"], qc(x), cap(x))
             O.p_grad_c(gs[t], npz, dt2, x["delpc"], x["pkc"], x["gz"], x["uc"], x["vc"], False)
         exchange_pair(cs, f, "uc", "vc", "C")
         for t in range(6):
@@ -316,16 +319,20 @@ def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
             ds = dict(delpc=x["vt"], delp=x["delp"], ptc=x["ptc"], pt=x["pt"], u=x["u"], v=x["v"], w=x["w"], uc=x["uc"], vc=x["vc"],
                       ua=x["ua"], va=x["va"], divg_d=x["divgd"], mfx=x["mfx"], mfy=x["mfy"], cx=x["cx"], cy=x["cy"], crx=x["crx"],
                       cry=x["cry"], xfx=x["xfx"], yfx=x["yfx"], heat_source=x["heat_s"], diss_est=x["diss_e"])
+            if fl.use_cond:
+                ds["q_con"] = x["q_con"]
             O.d_sw_3d(gs[t], npz, par, lev, ds)
             if fl.d_con > 1.0e-5:
                 x["heat_source"][ng:ng + nx, ng:ng + ny, :] += x["heat_s"]
         exchange(cs, f, ("delp", "pt"), "A")
+        if fl.use_cond:
+            exchange(cs, f, ("q_con",), "A")                       # dyn_core.F90:825 / :852
         for t in range(6):
             x = f[t]
             O.update_dz_d(gs[t], npz, ndif.copy(), damp.copy(), fl.hord_tm, dp_ref, x["zs"], x["zh"], x["crx"], x["cry"], x["xfx"],
                           x["yfx"], x["ws"], rdt)
             O.riem_solver3(gs[t], npz, dt, cn, x["zs"], x["w"], x["delz"], x["pt"], x["delp"], x["zh"], x["pe"], x["pkc"], x["pk3"],
-                           x["pk"], x["peln"], x["ws"], fl.use_logp, remap_step, False, None, None)
+                           x["pk"], x["peln"], x["ws"], fl.use_logp, remap_step, False, qc(x), cap(x))
         exchange(cs, f, ("zh", "pkc"), "A")
         for t in range(6):
             x = f[t]
@@ -374,15 +381,19 @@ def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz, q
     return out
 
 
-def oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, remap_par, npz, q=None):
-    """nonhydrostatic k_split loop on six faces over the oracle: dyn_core substeps -> tracer_2d -> Lagrangian_to_Eulerian"""
+def oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, remap_par, npz, q=None, last_step=False):
+    """nonhydrostatic k_split loop on six faces over the oracle: dyn_core substeps -> tracer_2d -> Lagrangian_to_Eulerian.
+    With fl.use_cond / fl.moist_kappa the faces carry q_con / cappa (halo updates at fv_dynamics.F90:464-465 / :487-488)."""
     mdt = bdt / float(k_split)
-    cur = [{k: s[k].copy(order="F") for k in ("u", "v", "w", "delp", "pt", "delz", "phis")} for s in st]
+    moist_names = (("q_con",) if fl.use_cond else ()) + (("cappa",) if fl.moist_kappa else ())
+    cur = [{k: s[k].copy(order="F") for k in ("u", "v", "w", "delp", "pt", "delz", "phis") + moist_names} for s in st]
     q = None if q is None else [x.copy(order="F") for x in q]
     out = None
     bd = gs[0].bd
     for n_map in range(1, k_split + 1):
         dp1 = [c["delp"].copy(order="F") for c in cur]
+        if moist_names:
+            exchange(cs, cur, moist_names, "A")
         f = oracle_substeps_nh(cs, gs, fl, dp_ref, cur, mdt, npz)
         if q is not None:
             _oracle_tracers(cs, gs, fl, npz, q, dp1, f)
@@ -393,8 +404,12 @@ def oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, remap_par, n
                       delz=x["delz"], pt=x["pt"], peln=x["peln"], omga=x["omga"], ws=x["ws"])
             if q is not None:
                 rf["q"] = q[t]
-            O.lagrangian_to_eulerian(gs[t], npz, dict(remap_par, last_step=0), rf, ak, bk)
+            for n in moist_names:
+                rf[n] = x[n]
+            O.lagrangian_to_eulerian(gs[t], npz, dict(remap_par, last_step=int(last_step and n_map == k_split)), rf, ak, bk)
             cur[t] = dict(u=rf["u"], v=rf["v"], w=rf["w"], delp=rf["delp"], pt=rf["pt"], delz=rf["delz"], phis=st[t]["phis"])
+            for n in moist_names:
+                cur[t][n] = rf[n]
             out.append(dict(cur[t], pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"], q=None if q is None else q[t]))
     return out
 

@@ -545,3 +545,90 @@ def check_rayleigh(lib, npx=13, npz=8, hydrostatic=False, conserve=True, tau=0.0
         for c in ctxs:
             c.close()
     return worst
+
+
+def check_jw_step_moist(lib, npx=13, npz=20, k_split=2, n_split=2, bdt=900.0, moist_kappa=True, tol=1e-12):
+    """A whole nonhydrostatic fv_dynamics call with use_cond (+ moist_kappa) on the six faces, from the JW temperature: T ->
+    theta_m with moist_cv (fv_dynamics.F90:305-317, :381-388), q_con through d_sw and into both Riemann solvers, its halo (and
+    cappa's) across the cube edges (dyn_core.F90:825, fv_dynamics.F90:464-465), the moist remap, back to T on the last step --
+    FvDynamics.step_from_temperature over MultiContext against the six-face orchestration of the oracle."""
+    import parity_nh as N
+    import parity_remap as R
+    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.lib import CP_AIR, GRAV, RDGAS
+    from gfdl_atmos_cubed_sphere_amd.test_cases import jablonowski_williamson, set_eta
+    cs, gs = CC.sphere(npx)
+    if npz in (79, 127):
+        ak, bk, ks, ptop = set_eta(npz)
+    else:
+        sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+        ak, bk = 300.0 * (1.0 - sig), sig.copy()
+    st = jablonowski_williamson(cs, ak, bk, hydrostatic=False)
+    CC.exchange(cs, st, ("phis",), "A")
+    fl = DynFlags(n_split=n_split, hydrostatic=False, d_ext=0.0, ptop=float(ak[0]), use_cond=True, moist_kappa=moist_kappa)
+    bd = gs[0].bd
+    ng, nx = bd.ng, bd.nx
+    c = (slice(ng, ng + nx), slice(ng, ng + nx))
+    nq = 7
+    mp = dict(R.MOIST6, sphum=1)
+    zvir = 0.6077
+    q0 = tracer_fields(cs, npz, nq)
+    for q in q0:                     # water species: vapour ~1 %, condensates ~0.1 %
+        q[..., 0] *= 0.01
+        for iq in range(1, 6):
+            q[..., iq] *= 0.001 / (1.0 + iq)
+    # ---- oracle side: the conversion in numpy, then the six-face loop ----
+    ost = []
+    for t in range(6):
+        s = st[t]
+        T, dpc = s["pt"], s["delp"][c]
+        dp1 = zvir * q0[t][c + (slice(None), 0)]
+        q_con, cappa = bd.zeros("A", npz), bd.zeros("A", npz)
+        cvm, qc = N.np_moist_cv(q0[t][c], mp, CP_AIR - RDGAS)
+        q_con[c] = qc
+        if moist_kappa:
+            cappa[c] = RDGAS / (RDGAS + cvm / (1.0 + dp1))
+            pkz = O.fexp(cappa[c] * O.flog((-RDGAS / GRAV) * dpc * T[c] * (1.0 + dp1) * (1.0 - qc) / s["delz"]))
+        else:
+            pkz = O.fexp(fl.akap * O.flog((-RDGAS / GRAV) * dpc * T[c] * (1.0 + dp1) / s["delz"]))
+        th = T.copy(order="F")
+        th[c] = T[c] * (1.0 + dp1) * (1.0 - qc) / pkz
+        o = dict(s, pt=th, q_con=q_con)
+        if moist_kappa:
+            o["cappa"] = cappa
+        ost.append(o)
+    mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
+    worst = {}
+    try:
+        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, adiabatic=False, moist=mp, c2l_ord=2,
+                        halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        opar = dict(fv.remap_par, **dict(mp, moist_kappa=int(moist_kappa), use_cond=1))
+        opar.pop("sphum")
+        opar["sphum"] = 1
+        dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
+        ref = CC.oracle_fv_step_nh(cs, gs, fl, dp_ref, ost, ak, bk, bdt, k_split, opar, npz, q=q0, last_step=True)
+        fv.dc.set_state([s["u"] for s in st], [s["v"] for s in st], [s["w"] for s in st], [s["delp"] for s in st],
+                        [s["pt"] for s in st], [s["delz"] for s in st], [s["phis"] for s in st])
+        fv.set_tracers(q0)
+        if not moist_kappa:          # use_cond alone: the library is told q_con (the reference keeps it from the previous step)
+            fv.dc.d["q_con"].upload([o["q_con"] for o in ost])
+        fv.step_from_temperature(bdt)
+        d = fv.dc.d
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        for n, kind, rr in (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)),
+                            ("delp", "A", r), ("pt", "A", r), ("w", "A", r)):
+            got = d[n].download()
+            for t in range(6):
+                worst[n] = max(worst.get(n, 0.0), P.assert_close(f"face {t + 1} {n}", bd.view(got[t], kind, *rr), bd.view(ref[t][n], kind, *rr), tol))
+        got = d["q"].download()
+        for t in range(6):
+            for iq in (0, 1, 5, 6):
+                worst["q"] = max(worst.get("q", 0.0), P.assert_close(f"face {t + 1} q{iq}", bd.view(got[t][:, :, :, iq], "A", *r),
+                                                                       bd.view(ref[t]["q"][:, :, :, iq], "A", *r), tol))
+        Tn = np.concatenate([bd.view(x, "A", *r).ravel() for x in d["pt"].download()])
+        assert 150.0 < Tn.min() and Tn.max() < 400.0          # pt is a temperature again
+    finally:
+        mctx.close()
+    return worst

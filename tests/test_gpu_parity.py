@@ -807,6 +807,14 @@ def test_cubed_sphere_rayleigh_friction(prod, hydrostatic, conserve):
     assert PC.check_rayleigh(prod, npx=25, hydrostatic=hydrostatic, conserve=conserve) <= 1e-14
 
 
+@pytest.mark.parametrize("moist_kappa", [True, False])
+def test_cubed_sphere_moist_fv_dynamics_call(prod, moist_kappa):
+    """use_cond (+ moist_kappa) through a whole nonhydrostatic fv_dynamics call on the six faces: moist_cv conversion, q_con in d_sw
+    and both Riemann solvers with its halo across the cube edges, moist remap, back to T (SURVEY 8(f) item 3 on the sphere)"""
+    r = PC.check_jw_step_moist(prod, npx=25, npz=20, moist_kappa=moist_kappa)
+    assert max(r.values()) <= 1e-12
+
+
 def test_cubed_del2_cubed_and_damped_transports(prod):
     assert PC.check_del2_cubed(prod, npx=25, npz=4, nmax=3) <= P.TOL
     for kw in (dict(nord=2, damp_c=0.05), dict(nord=2, damp_c=0.05, mass_flux=True)):

@@ -685,6 +685,14 @@ def test_cubed_sphere_rayleigh_friction(emu, hydrostatic, conserve):
     assert PC.check_rayleigh(emu, npx=13, hydrostatic=hydrostatic, conserve=conserve) <= 1e-14
 
 
+@pytest.mark.parametrize("moist_kappa", [True, False])
+def test_cubed_sphere_moist_fv_dynamics_call(emu, moist_kappa):
+    """use_cond (+ moist_kappa) through a whole nonhydrostatic fv_dynamics call on the six faces: moist_cv conversion, q_con in d_sw
+    and both Riemann solvers with its halo across the cube edges, moist remap, back to T (SURVEY 8(f) item 3 on the sphere)"""
+    r = PC.check_jw_step_moist(emu, npx=13, npz=12, moist_kappa=moist_kappa)
+    assert max(r.values()) <= 1e-12
+
+
 def test_cubed_del2_cubed_and_damped_transports(emu):
     for nmax in (1, 2, 3):
         assert PC.check_del2_cubed(emu, nmax=nmax) <= P.TOL
