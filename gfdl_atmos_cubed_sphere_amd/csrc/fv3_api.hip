@@ -1995,6 +1995,28 @@ extern "C" int fv3_rayleigh_apply(fv3_ctx *c, int kmax, int conserve, int hydros
   return 0;
 }
 
+extern "C" int fv3_rayleigh_super(fv3_ctx *c, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,
+                                  const double *pm, const double *rf, const double *ua, const double *va, double *pt,
+                                  double *u, double *v, double *w, const double *u00, const double *v00) {
+  if (!c || !c->grid_ready) return fail("fv3_rayleigh_super: context has no grid");
+  if (!pm || !rf || !ua || !va || !pt || !u || !v || (!hydrostatic && !w)) return fail("fv3_rayleigh_super: null argument");
+  if ((u00 == nullptr) != (v00 == nullptr)) return fail("fv3_rayleigh_super: u00 and v00 must be given together");
+  const Grid &g = c->g;
+  if (kmax < 0 || kmax > g.npz) return fail("fv3_rayleigh_super: kmax out of range");
+  if (kmax == 0) return 0;
+  if (!c->ray_d) RT(rt_malloc((void **)&c->ray_d, sizeof(double) * 2 * g.npz));
+  RT(rt_h2d(c->ray_d, pm, sizeof(double) * kmax, c->stream));
+  RT(rt_h2d(c->ray_d + g.npz, rf, sizeof(double) * kmax, c->stream));
+  RT(rt_sync(c->stream));  // pm / rf are the caller's host arrays
+  RayleighSuper kf{g, conserve, hydrostatic, cp, rg, ptop, c->ray_d, c->ray_d + g.npz, ua, va, pt, u, v, w, u00, v00};
+  Dim3 grid;
+  grid.x = (unsigned)(((g.nx + 1) * (g.ny + 1) + RayleighSuper::CH - 1) / RayleighSuper::CH);
+  grid.y = 1;
+  grid.z = (unsigned)kmax;
+  RT(launch_p(c, "rayleigh_super", grid, 0, kf));
+  return 0;
+}
+
 extern "C" int fv3_heat_source_accum(fv3_ctx *c, double *heat_source, const double *heat_s) {
   if (!c || !c->grid_ready || !heat_source || !heat_s) return fail("fv3_heat_source_accum: bad context/arguments");
   const Grid &g = c->g;

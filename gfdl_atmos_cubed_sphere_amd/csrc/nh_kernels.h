@@ -1205,6 +1205,48 @@ struct RayleighApply {
   }
 };
 
+// Rayleigh_Super (fv_dynamics.F90:1056-1121): u2f(:,:,k) = 1 / (1 + rf(k)) is a level constant, 0.5*(u2f + u2f) = u2f exactly
+struct RayleighSuper {
+  Grid g;
+  int conserve, hydrostatic;
+  double cp, rg, ptop;
+  const double *pm, *rf;  // device, kmax
+  const double *ua, *va;
+  double *pt, *u, *v, *w;
+  const double *u00, *v00;  // is_ideal_case: the t = 0 winds, or null
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int wdt = g.nx + 1, n = wdt * (g.ny + 1);
+    const double rfk = rf[bz], rcv = 1. / (cp - rg);
+    const double u2f = 1. / (1. + rfk);
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.is + idx % wdt, j = g.js + idx / wdt;
+      const bool in_i = i <= g.ie, in_j = j <= g.je;
+      const size_t o = (size_t)bz * g.nA() + g.iA(i, j), ou = (size_t)bz * g.nU() + g.iU(i, j), ov = (size_t)bz * g.nV() + g.iV(i, j);
+      if (u00) {  // :1064-1081
+        if (in_i && in_j && !hydrostatic) w[o] = w[o] / (1. + rfk);
+        if (in_i) u[ou] = (u[ou] + rfk * u00[ou]) / (1. + rfk);
+        if (in_j) v[ov] = (v[ov] + rfk * v00[ov]) / (1. + rfk);
+        continue;
+      }
+      if (in_i && in_j) {
+        if (conserve) {  // :1084-1098
+          const double a = ua[o], b = va[o];
+          if (hydrostatic) {
+            pt[o] = pt[o] + 0.5 * (a * a + b * b) * (1. - u2f * u2f) / (cp - rg * ptop / pm[bz]);
+          } else {
+            const double ww = w[o];
+            pt[o] = pt[o] + 0.5 * (a * a + b * b + ww * ww) * (1. - u2f * u2f) * rcv;
+          }
+        }
+        if (!hydrostatic) w[o] = u2f * w[o];
+      }
+      if (in_i) u[ou] = 0.5 * (u2f + u2f) * u[ou];
+      if (in_j) v[ov] = 0.5 * (u2f + u2f) * v[ov];
+    }
+  }
+};
+
 struct OmgaUpdate {  // dyn_core.F90:409-421, :1182-1191
   Grid g;
   int km;

@@ -20,7 +20,7 @@ module fv3_mi355x_mod
   public :: fv3_divg2_ext, fv3_one_grad_p, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
   public :: fv3_grid_cubed, fv3_grid_upload_cubed, fv3_gather_create, fv3_gather_run, fv3_gather_destroy
   public :: fv3_comm_get_unique_id, fv3_comm_init, fv3_comm_destroy, fv3_halo_start, fv3_halo_complete, fv3_allreduce_max
-  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_set_condensate, fv3_set_moist, fv3_moist_params
+  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_rayleigh_super, fv3_set_condensate, fv3_set_moist, fv3_moist_params
 
   type, bind(C) :: fv3_domain
     integer(c_int) :: is, ie, js, je, ng, npx, npy, npz, grid_type
@@ -286,6 +286,14 @@ module fv3_mi355x_mod
                                                u, v, w) bind(C, name="fv3_rayleigh_apply")
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: ctx, u2f, pt, delz, u, v, w
+      integer(c_int), value :: kmax, conserve, hydrostatic
+      real(c_double), value :: cp, rg, ptop
+      real(c_double), intent(in) :: pm(*), rf(*)
+    end function
+    integer(c_int) function fv3_rayleigh_super(ctx, kmax, conserve, hydrostatic, cp, rg, ptop, pm, rf, ua, va, pt, &
+                                               u, v, w, u00, v00) bind(C, name="fv3_rayleigh_super")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, ua, va, pt, u, v, w, u00, v00
       integer(c_int), value :: kmax, conserve, hydrostatic
       real(c_double), value :: cp, rg, ptop
       real(c_double), intent(in) :: pm(*), rf(*)

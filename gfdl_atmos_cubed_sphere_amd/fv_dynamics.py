@@ -87,16 +87,28 @@ class FvDynamics:
         return rf, pfull, kmax
 
     def rayleigh_friction(self, bdt: float, conserve: bool = True):
-        """Rayleigh_Friction (fv_dynamics.F90:1126-1264): two kernels around the halo update of u2f"""
+        """fv_dynamics.F90:362-371: Rayleigh_Super (:953-1124) on the cubed sphere (grid_type < 4) and in ideal cases, Rayleigh_Friction
+        (:1126-1264, two kernels around the halo update of u2f) on the Cartesian domains"""
         d, ctx, fl = self.dc.d, self.ctx, self.fl
         if self._rf is None:
             self._rf = self.rayleigh_profile(abs(bdt))
         rf, pm, kmax = self._rf
         if kmax == 0:
             return
+        hyd = fl.hydrostatic
+        if ctx.grid.grid_type < 4 or fl.is_ideal_case:
+            ideal = fl.is_ideal_case
+            if ideal and "u00" not in d:                                       # :997-1014: the winds of the first call are kept
+                d["u00"], d["v00"] = ctx.zeros("U", ctx.npz), ctx.zeros("V", ctx.npz)
+                d["u00"].copy_from(d["u"])
+                d["v00"].copy_from(d["v"])
+            ctx.c2l(2, d["u"], d["v"], d["ua"], d["va"])                       # :1040-1042
+            ctx.rayleigh_super(kmax, not ideal, hyd, fl.cp_air, fl.rdgas, fl.ptop, pm[:kmax], rf[:kmax], d["ua"], d["va"],
+                               d["pt"], d["u"], d["v"], None if hyd else d["w"], d.get("u00") if ideal else None,
+                               d.get("v00") if ideal else None)
+            return
         if "u2f" not in d:
             d["u2f"] = ctx.zeros("A", ctx.npz)
-        hyd = fl.hydrostatic
         ctx.rayleigh_u2f(kmax, hyd, d["u"], d["v"], None if hyd else d["w"], d["ua"], d["va"], d["u2f"])
         self.dc.halo.update([(d["u2f"], "A")])                             # :1207-1209
         ctx.rayleigh_apply(kmax, conserve, hyd, fl.cp_air, fl.rdgas, fl.ptop, pm[:kmax], rf[:kmax], d["u2f"], d["pt"],

@@ -33,7 +33,7 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_grid_upload_cubed", "fv3_gather_create", "fv3_gather_run", "fv3_gather_destroy", "fv3_grid_geom", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
-           "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max",
+           "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
@@ -484,6 +484,16 @@ class Context:
             self.h, C.c_int(int(kmax)), C.c_int(int(conserve)), C.c_int(int(hydrostatic)), C.c_double(cp),
             C.c_double(rg), C.c_double(ptop), pm.ctypes.data_as(_dp), rf.ctypes.data_as(_dp), u2f.p, pt.p,
             delz.p if delz is not None else None, u.p, v.p, w.p if w is not None else None), "fv3_rayleigh_apply")
+
+    def rayleigh_super(self, kmax, conserve, hydrostatic, cp, rg, ptop, pm, rf, ua, va, pt, u, v, w, u00=None, v00=None):
+        """Rayleigh_Super after cubed_to_latlon (fv_dynamics.F90:1044-1121; grid_type < 4); pm, rf: host arrays"""
+        pm = np.ascontiguousarray(pm, dtype=np.float64)
+        rf = np.ascontiguousarray(rf, dtype=np.float64)
+        self.lib.check(self.lib.dll.fv3_rayleigh_super(
+            self.h, C.c_int(int(kmax)), C.c_int(int(conserve)), C.c_int(int(hydrostatic)), C.c_double(cp),
+            C.c_double(rg), C.c_double(ptop), pm.ctypes.data_as(_dp), rf.ctypes.data_as(_dp), ua.p, va.p, pt.p, u.p, v.p,
+            w.p if w is not None else None, u00.p if u00 is not None else None, v00.p if v00 is not None else None),
+            "fv3_rayleigh_super")
 
     # ---- hydrostatic pressure gradient (dyn_core.F90:828-848, :1021, :1001-1010) ------------------------------------
     def divg2_ext(self, d_ext, delp, vt, divg2):

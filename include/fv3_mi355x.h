@@ -335,6 +335,15 @@ int fv3_rayleigh_u2f(fv3_ctx *ctx, int kmax, int hydrostatic, const double *u, c
 int fv3_rayleigh_apply(fv3_ctx *ctx, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,
                        const double *pm, const double *rf, const double *u2f, double *pt, double *delz, double *u,
                        double *v, double *w);
+/* Rayleigh_Super (model/fv_dynamics.F90:953-1124; the branch of :368-376 for grid_type < 4, bounded domains and ideal
+ * cases) after the caller's fv3_c2l(ctx, 2, u, v, ua, va) (:1040-1042): on levels 1..kmax the damping factor is the
+ * level constant 1 / (1 + rf(k)) (its halo update, :1054, moves a constant), so this is ONE call: frictional heating of
+ * pt from ua, va (, w) if conserve (:1084-1098), then u, v, w scaled (:1100-1117); with u00, v00 (is_ideal_case, the
+ * t = 0 winds the routine keeps, U / V x npz) the relaxation towards them instead (:1064-1081).  pm, rf: HOST arrays of
+ * length kmax as for fv3_rayleigh_apply; w may be NULL when hydrostatic; u00 / v00 NULL = not an ideal case. */
+int fv3_rayleigh_super(fv3_ctx *ctx, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,
+                       const double *pm, const double *rf, const double *ua, const double *va, double *pt, double *u,
+                       double *v, double *w, const double *u00, const double *v00);
 
 /* ---- fv_dynamics: T -> theta_v before the k_split loop (model/fv_dynamics.F90:284-329, :379-399; use_cond =
  * moist_kappa = .false. unless fv3_set_moist says otherwise).  nonhydrostatic: pkz = exp(kappa*log(rdg*delp*pt*(1+zvir*qv)/delz)) is (re)computed;

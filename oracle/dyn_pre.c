@@ -98,6 +98,47 @@ int fvo_rayleigh_u2f(const fvo_grid *g, int kmax, int hydrostatic, const double 
   return FVO_OK;
 }
 
+/* Rayleigh_Super, fv_dynamics.F90:953-1124, after cubed_to_latlon (:1040): u2f(:,:,k) = 1/(1+rf(k)) (its halo update moves
+ * a constant), heating if conserve, scaling of u, v, w; u00 / v00 (is_ideal_case): relaxation towards the t = 0 winds. */
+int fvo_rayleigh_super(const fvo_grid *g, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,
+                       const double *pm, const double *rf, const double *ua, const double *va, double *pt, double *u,
+                       double *v, double *w, const double *u00, const double *v00) {
+  BOUNDS(g);
+  const double rcv = 1. / (cp - rg);
+  int i, j, k;
+  for (k = 1; k <= kmax; k++) {
+    const double rfk = rf[k - 1], u2f = 1. / (1. + rfk);
+    if (u00) { /* :1064-1081 */
+      if (!hydrostatic)
+        for (j = js; j <= je; j++)
+          for (i = is; i <= ie; i++) w[A3(i, j, k)] = w[A3(i, j, k)] / (1. + rfk);
+      for (j = js; j <= je + 1; j++)
+        for (i = is; i <= ie; i++) u[U3(i, j, k)] = (u[U3(i, j, k)] + rfk * u00[U3(i, j, k)]) / (1. + rfk);
+      for (j = js; j <= je; j++)
+        for (i = is; i <= ie + 1; i++) v[V3(i, j, k)] = (v[V3(i, j, k)] + rfk * v00[V3(i, j, k)]) / (1. + rfk);
+      continue;
+    }
+    if (conserve) { /* :1084-1098 */
+      for (j = js; j <= je; j++)
+        for (i = is; i <= ie; i++) {
+          const double a = ua[A3(i, j, k)], b = va[A3(i, j, k)];
+          if (hydrostatic)
+            pt[A3(i, j, k)] = pt[A3(i, j, k)] + 0.5 * (a * a + b * b) * (1. - u2f * u2f) / (cp - rg * ptop / pm[k - 1]);
+          else
+            pt[A3(i, j, k)] = pt[A3(i, j, k)] + 0.5 * (a * a + b * b + w[A3(i, j, k)] * w[A3(i, j, k)]) * (1. - u2f * u2f) * rcv;
+        }
+    }
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie; i++) u[U3(i, j, k)] = 0.5 * (u2f + u2f) * u[U3(i, j, k)];
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie + 1; i++) v[V3(i, j, k)] = 0.5 * (u2f + u2f) * v[V3(i, j, k)];
+    if (!hydrostatic)
+      for (j = js; j <= je; j++)
+        for (i = is; i <= ie; i++) w[A3(i, j, k)] = u2f * w[A3(i, j, k)];
+  }
+  return FVO_OK;
+}
+
 /* :1211-1260 with the halo of u2f filled by the caller: frictional heating (conserve) and the implicit damping of
  * u, v, w.  u2f is overwritten with rf*sqrt(u2f/u000) on is-1:ie+1, js-1:je+1 as in the reference. */
 int fvo_rayleigh_apply(const fvo_grid *g, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,

@@ -241,5 +241,8 @@ int fvo_rayleigh_u2f(const fvo_grid *g, int kmax, int hydrostatic, const double 
 int fvo_rayleigh_apply(const fvo_grid *g, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,
                        const double *pm, const double *rf, double *u2f, double *pt, double *delz, double *u, double *v,
                        double *w);
+int fvo_rayleigh_super(const fvo_grid *g, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,
+                       const double *pm, const double *rf, const double *ua, const double *va, double *pt, double *u,
+                       double *v, double *w, const double *u00, const double *v00);
 
 #endif

@@ -374,6 +374,17 @@ def rayleigh_u2f(g, kmax, hydrostatic, u, v, w, ua, va, u2f):
                                   p(w) if w is not None else None, p(ua), p(va), p(u2f)) == 0
 
 
+def rayleigh_super(g, kmax, conserve, hydrostatic, cp, rg, ptop, pm, rf, ua, va, pt, u, v, w, u00=None, v00=None):
+    import numpy as np
+    gs = make_grid(g)
+    pm = np.ascontiguousarray(pm, dtype=np.float64)
+    rf = np.ascontiguousarray(rf, dtype=np.float64)
+    assert lib().fvo_rayleigh_super(C.byref(gs), C.c_int(kmax), C.c_int(int(conserve)), C.c_int(int(hydrostatic)), _d(cp),
+                                    _d(rg), _d(ptop), p(pm), p(rf), p(ua), p(va), p(pt), p(u), p(v),
+                                    p(w) if w is not None else None, p(u00) if u00 is not None else None,
+                                    p(v00) if v00 is not None else None) == 0
+
+
 def rayleigh_apply(g, kmax, conserve, hydrostatic, cp, rg, ptop, pm, rf, u2f, pt, delz, u, v, w):
     import numpy as np
     gs = make_grid(g)

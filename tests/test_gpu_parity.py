@@ -815,6 +815,13 @@ def test_cubed_sphere_moist_fv_dynamics_call(prod, moist_kappa):
     assert max(r.values()) <= 1e-12
 
 
+@pytest.mark.parametrize("hydrostatic,ideal", [(False, False), (True, False), (False, True)])
+def test_cubed_sphere_rayleigh_super(prod, hydrostatic, ideal):
+    """Rayleigh_Super, the form fv_dynamics applies on the cubed sphere for tau > 0 (fv_dynamics.F90:362-366, :953-1124), through the
+    host's dispatch on the six faces; is_ideal_case: relaxation towards the winds of the first call"""
+    assert PC.check_rayleigh_super(prod, npx=25, hydrostatic=hydrostatic, ideal=ideal) <= 1e-14
+
+
 def test_cubed_del2_cubed_and_damped_transports(prod):
     assert PC.check_del2_cubed(prod, npx=25, npz=4, nmax=3) <= P.TOL
     for kw in (dict(nord=2, damp_c=0.05), dict(nord=2, damp_c=0.05, mass_flux=True)):

@@ -693,6 +693,13 @@ def test_cubed_sphere_moist_fv_dynamics_call(emu, moist_kappa):
     assert max(r.values()) <= 1e-12
 
 
+@pytest.mark.parametrize("hydrostatic,ideal", [(False, False), (True, False), (False, True)])
+def test_cubed_sphere_rayleigh_super(emu, hydrostatic, ideal):
+    """Rayleigh_Super, the form fv_dynamics applies on the cubed sphere for tau > 0 (fv_dynamics.F90:362-366, :953-1124), through the
+    host's dispatch on the six faces; is_ideal_case: relaxation towards the winds of the first call"""
+    assert PC.check_rayleigh_super(emu, npx=13, hydrostatic=hydrostatic, ideal=ideal) <= 1e-14
+
+
 def test_cubed_del2_cubed_and_damped_transports(emu):
     for nmax in (1, 2, 3):
         assert PC.check_del2_cubed(emu, nmax=nmax) <= P.TOL
