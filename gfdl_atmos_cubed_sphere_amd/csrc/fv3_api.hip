@@ -2257,6 +2257,83 @@ extern "C" int fv3_set_moist(fv3_ctx *c, const fv3_moist_params *m, double *q_co
   return 0;
 }
 
+// RemapPar of the energy routines: the scalars of fv3_remap_params + the moist switches of fv3_set_moist
+static int energy_par(fv3_ctx *c, const fv3_remap_params *p, RemapPar &rp, const char *who) {
+  rp = RemapPar{p->last_step, p->hydrostatic, p->adiabatic, p->nq, p->kord_mt, p->kord_wz, p->kord_tm, p->sphum,
+                p->akap, p->ptop, p->rdgas, p->grav, p->cv_air, p->r_vir, p->cp, p->t_min,
+                0, 0, 0, 0, 0, 0, 0, 0, 0., 0., 0., nullptr, nullptr, p->fill, c->remap_blocked};
+  if (p->sphum < 0 || p->sphum > p->nq) return fail("%s: sphum out of range", who);
+  if (c->moist_on && (c->moist.moist_kappa || c->moist.use_cond)) {
+    const fv3_moist_params &m = c->moist;
+    if (p->hydrostatic) return fail("%s: moist_kappa / use_cond are nonhydrostatic branches", who);
+    if (p->sphum < 1 || (m.sphum > 0 && m.sphum != p->sphum)) return fail("%s: moist branches need sphum", who);
+    const int idx[5] = {m.liq_wat, m.rainwat, m.ice_wat, m.snowwat, m.graupel};
+    for (int n = 0; n < 5; n++)
+      if (idx[n] < 0 || idx[n] > p->nq) return fail("%s: water species index out of range", who);
+    rp.moist_kappa = m.moist_kappa; rp.use_cond = m.use_cond; rp.nwat = m.nwat;
+    rp.liq_wat = m.liq_wat; rp.rainwat = m.rainwat; rp.ice_wat = m.ice_wat; rp.snowwat = m.snowwat; rp.graupel = m.graupel;
+    rp.cv_vap = m.cv_vap; rp.c_liq = m.c_liq; rp.c_ice = m.c_ice;
+    rp.q_con = c->moist_qcon; rp.cappa = c->moist_cappa;
+    if (m.use_cond && !rp.q_con) return fail("%s: use_cond needs q_con (fv3_set_moist)", who);
+  }
+  return 0;
+}
+
+extern "C" int fv3_compute_total_energy(fv3_ctx *c, const fv3_remap_params *p, int moist_phys, const double *u,
+                                        const double *v, const double *w, const double *delz, const double *pt,
+                                        const double *delp, const double *q, const double *qc, const double *pe,
+                                        const double *peln, const double *phis, double *te_2d) {
+  if (!c || !c->grid_ready || !p) return fail("fv3_compute_total_energy: bad context/arguments");
+  if (!u || !v || !pt || !delp || !phis || !te_2d) return fail("fv3_compute_total_energy: null argument");
+  if (p->hydrostatic ? (!pe || !peln) : (!w || !delz)) return fail("fv3_compute_total_energy: null argument of the branch");
+  RemapPar rp;
+  if (energy_par(c, p, rp, "fv3_compute_total_energy")) return 1;
+  const int moist_cvm = !p->hydrostatic && moist_phys && rp.moist_kappa;
+  if (moist_cvm && !q) return fail("fv3_compute_total_energy: moist_kappa needs the tracers");
+  if (need_scratch(c, 1)) return 1;
+  const Grid &g = c->g;
+  TotalEnergy kf{g, g.npz, rp, moist_cvm, u, v, w, delz, pt, delp, q, qc, pe, peln, phis, te_2d, c->scratch[0]};
+  RT(launch_c(c, "total_energy", col_grid(g.nx * g.ny), kf));
+  return 0;
+}
+
+extern "C" int fv3_energy_fixer_sums(fv3_ctx *c, const fv3_remap_params *p, int only_sums, const double *u, const double *v,
+                                     const double *w, const double *delz, const double *pt, const double *delp,
+                                     const double *q, const double *pe, const double *peln, const double *phis,
+                                     const double *pkz, const double *pk, const double *te0_2d, double *te_2d,
+                                     double *zsum1, double *zsum0) {
+  if (!c || !c->grid_ready || !p) return fail("fv3_energy_fixer_sums: bad context/arguments");
+  if (!delp || !pkz || !zsum1 || (p->hydrostatic && (!pk || !zsum0))) return fail("fv3_energy_fixer_sums: null argument");
+  if (!only_sums) {
+    if (!u || !v || !pt || !phis || !te0_2d || !te_2d) return fail("fv3_energy_fixer_sums: null argument");
+    if (p->hydrostatic ? (!pe || !peln) : (!w || !delz)) return fail("fv3_energy_fixer_sums: null argument of the branch");
+    if (p->sphum > 0 && !q) return fail("fv3_energy_fixer_sums: sphum > 0 needs the tracers");
+  }
+  RemapPar rp;
+  if (energy_par(c, p, rp, "fv3_energy_fixer_sums")) return 1;
+  if (need_scratch(c, 1)) return 1;
+  const Grid &g = c->g;
+  EnergyFixerSums kf{g, g.npz, rp, only_sums, u, v, w, delz, pt, delp, q, pe, peln, phis, pkz, pk, te0_2d, te_2d, zsum1, zsum0, c->scratch[0]};
+  RT(launch_c(c, "energy_fixer", col_grid(g.nx * g.ny), kf));
+  return 0;
+}
+
+extern "C" int fv3_remap_finish(fv3_ctx *c, const fv3_remap_params *p, double dtmp, double *pt, const double *pkz,
+                                const double *q) {
+  if (!c || !c->grid_ready || !p || !pt || !pkz) return fail("fv3_remap_finish: bad context/arguments");
+  if (p->sphum > 0 && !q) return fail("fv3_remap_finish: sphum > 0 needs the tracers");
+  RemapPar rp;
+  if (energy_par(c, p, rp, "fv3_remap_finish")) return 1;
+  const Grid &g = c->g;
+  RemapFinish kf{g, g.npz, rp, dtmp, q, pkz, pt};
+  Dim3 grid;
+  grid.x = (unsigned)((g.nx * g.ny + RemapFinish::CH - 1) / RemapFinish::CH);
+  grid.y = 1;
+  grid.z = (unsigned)g.npz;
+  RT(launch_p(c, "remap_finish", grid, 0, kf));
+  return 0;
+}
+
 extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p, const int *kord_tr, double *ps,
                                           double *pe, double *delp, double *pkz, double *pk, double *u, double *v,
                                           double *w, double *delz, double *pt, double *q, double *peln, double *omga,

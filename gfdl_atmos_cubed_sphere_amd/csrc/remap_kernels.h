@@ -1244,7 +1244,8 @@ struct RemapDelzFinal {
         pkz[(size_t)(k - 1) * nCC + occ] = pkzv;
         double tnew = tv;
         if (p.kord_tm > 0) tnew = tnew * pkzv;  // :496-502
-        if (p.last_step) {                      // :793-821 (dtmp = 0)
+        if (p.last_step == 2) {                 // the energy fixer follows: T_v / T_m stays, fv3_remap_finish converts (:793-821)
+        } else if (p.last_step) {               // :793-821 (dtmp = 0)
           if (!p.hydrostatic && p.use_cond) {   // :806-811
             const size_t o3 = (size_t)(k - 1) * nA + fo;
             double qc;
@@ -1283,4 +1284,161 @@ struct RemapPe {
 };
 
 #undef CS
+// ---- total energy and the energy fixer of the last remap (consv_te) ----------------------------------------------------------
+// kinetic-energy bracket of a cell from the D-grid winds on its four edges (fv_thermodynamics.F90:152-155, fv_mapz.F90:679-681)
+FV3_HD double te_wind_bracket(const Grid &g, const double *u, const double *v, int i, int j, int k) {
+  const double u0 = u[(size_t)(k - 1) * g.nU() + g.iU(i, j)], u1 = u[(size_t)(k - 1) * g.nU() + g.iU(i, j + 1)];
+  const double v0 = v[(size_t)(k - 1) * g.nV() + g.iV(i, j)], v1 = v[(size_t)(k - 1) * g.nV() + g.iV(i + 1, j)];
+  return u0 * u0 + u1 * u1 + v0 * v0 + v1 * v1 - (u0 + u1) * (v0 + v1) * g.cosa_s[g.iA(i, j)];
+}
+
+// compute_total_energy (fv_thermodynamics.F90:90-225; called at fv_dynamics.F90:345 with pt = T, qc = zvir*q(sphum)): te_2d of
+// every column.  moist_cvm: the moist_phys .and. moist_kappa branch (cvm from moist_cv, :186-193).  phiz (A x (km+1)): scratch.
+struct TotalEnergy {
+  Grid g;
+  int km;
+  RemapPar p;
+  int moist_cvm;
+  const double *u, *v, *w, *delz, *pt, *delp, *q, *qc, *pe, *peln, *hs;
+  double *te_2d, *phiz;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int ncol = g.nx * g.ny;
+    const size_t nA = g.nA(), nCC = g.nCC();
+    FV3_COL_FOR2(col, ncol) {
+      const int i = g.is + col % g.nx, j = g.js + col / g.nx;
+      const int o = g.iA(i, j), occ = g.iCC(i, j);
+      const double rs2 = g.rsin2[o];
+      auto PE = [&](int k) { return pe[(size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (size_t)(k - 1) * (g.nx + 2) + (i - (g.is - 1))]; };
+      auto PELN = [&](int k) { return peln[(size_t)(j - g.js) * g.nx * (km + 1) + (size_t)(k - 1) * g.nx + (i - g.is)]; };
+      // qc = zvir * q(sphum) (fv_dynamics.F90:295-301): the caller's array, or formed here from the tracer
+      auto QC = [&](size_t o3) { return qc ? qc[o3] : ((p.sphum > 0 && !p.adiabatic && q) ? p.r_vir * q[(size_t)(p.sphum - 1) * nA * km + o3] : 0.); };
+      double te;
+      if (p.hydrostatic) {
+        double ph = hs[o];
+        for (int k = km; k >= 1; k--) {
+          const size_t o3 = (size_t)(k - 1) * nA + o;
+          const double tv = pt[o3] * (1. + QC(o3));
+          ph = ph + p.rdgas * tv * (PELN(k + 1) - PELN(k));
+        }
+        te = PE(km + 1) * hs[o] - PE(1) * ph;
+        for (int k = 1; k <= km; k++) {
+          const size_t o3 = (size_t)(k - 1) * nA + o;
+          const double tv = pt[o3] * (1. + QC(o3));
+          te = te + delp[o3] * (p.cp * tv + 0.25 * rs2 * te_wind_bracket(g, u, v, i, j, k));
+        }
+      } else {
+        double ph = hs[o];
+        phiz[(size_t)km * nA + o] = ph;
+        for (int k = km; k >= 1; k--) {
+          ph = ph - p.grav * delz[(size_t)(k - 1) * nCC + occ];
+          phiz[(size_t)(k - 1) * nA + o] = ph;
+        }
+        te = 0.;
+        for (int k = 1; k <= km; k++) {
+          const size_t o3 = (size_t)(k - 1) * nA + o;
+          double cv = p.cv_air;
+          if (moist_cvm) {
+            double qd;
+            cv = moist_cv(p, q + o3, nA * km, qd);
+          }
+          const double ww = w[o3];
+          te = te + delp[o3] * (cv * pt[o3] + 0.5 * (phiz[o3] + phiz[o3 + nA] + ww * ww + 0.5 * rs2 * te_wind_bracket(g, u, v, i, j, k)));
+        }
+      }
+      te_2d[occ] = te;
+    }
+  }
+};
+
+// The energy fixer of the last remap, fv_mapz.F90:647-734 (consv > consv_min, remap_te = .false.): te_2d := te0_2d - (total energy
+// of the remapped column), zsum1 = sum(pkz*delp), zsum0 = ptop*(pk(1) - pk(km+1)) + zsum1 (hydrostatic); pt is T_v / T_m here.
+// With use_cond q_con is rewritten from moist_cv (:701).  only_sums: the consv < -consv_min branch (:745-763).
+struct EnergyFixerSums {
+  Grid g;
+  int km;
+  RemapPar p;
+  int only_sums;
+  const double *u, *v, *w, *delz, *pt, *delp, *q, *pe, *peln, *hs, *pkz, *pk, *te0_2d;
+  double *te_2d, *zsum1, *zsum0, *phiz;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int ncol = g.nx * g.ny;
+    const size_t nA = g.nA(), nCC = g.nCC();
+    FV3_COL_FOR2(col, ncol) {
+      const int i = g.is + col % g.nx, j = g.js + col / g.nx;
+      const int o = g.iA(i, j), occ = g.iCC(i, j);
+      const double rs2 = g.rsin2[o];
+      auto PE = [&](int k) { return pe[(size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (size_t)(k - 1) * (g.nx + 2) + (i - (g.is - 1))]; };
+      auto PELN = [&](int k) { return peln[(size_t)(j - g.js) * g.nx * (km + 1) + (size_t)(k - 1) * g.nx + (i - g.is)]; };
+      if (!only_sums) {
+        double te;
+        if (p.hydrostatic) {
+          double gz = hs[o];
+          for (int k = 1; k <= km; k++) gz = gz + p.rdgas * pt[(size_t)(k - 1) * nA + o] * (PELN(k + 1) - PELN(k));
+          te = PE(km + 1) * hs[o] - PE(1) * gz;
+          for (int k = 1; k <= km; k++) {
+            const size_t o3 = (size_t)(k - 1) * nA + o;
+            te = te + delp[o3] * (p.cp * pt[o3] + 0.25 * rs2 * te_wind_bracket(g, u, v, i, j, k));
+          }
+        } else {
+          double ph = hs[o];
+          phiz[(size_t)km * nA + o] = ph;
+          for (int k = km; k >= 1; k--) {
+            ph = ph - p.grav * delz[(size_t)(k - 1) * nCC + occ];
+            phiz[(size_t)(k - 1) * nA + o] = ph;
+          }
+          te = 0.;
+          for (int k = 1; k <= km; k++) {
+            const size_t o3 = (size_t)(k - 1) * nA + o;
+            const double qv = (p.sphum > 0 && !p.adiabatic) ? q[(size_t)(p.sphum - 1) * nA * km + o3] : 0.;   // adiabatic: the caller's zvir = 0
+            const double ww = w[o3];
+            const double mech = 0.5 * (phiz[o3] + phiz[o3 + nA] + ww * ww + 0.5 * rs2 * te_wind_bracket(g, u, v, i, j, k));
+            if (p.use_cond) {
+              double qc;
+              const double cvm = moist_cv(p, q + o3, nA * km, qc);
+              p.q_con[o3] = qc;
+              te = te + delp[o3] * (cvm * pt[o3] / ((1. + p.r_vir * qv) * (1. - qc)) + mech);
+            } else {
+              te = te + delp[o3] * (p.cv_air * pt[o3] / (1. + p.r_vir * qv) + mech);
+            }
+          }
+        }
+        te_2d[occ] = te0_2d[occ] - te;
+      }
+      double z1 = pkz[occ] * delp[o];
+      for (int k = 2; k <= km; k++) z1 = z1 + pkz[(size_t)(k - 1) * nCC + occ] * delp[(size_t)(k - 1) * nA + o];
+      zsum1[occ] = z1;
+      if (p.hydrostatic) zsum0[occ] = p.ptop * (pk[occ] - pk[(size_t)km * nCC + occ]) + z1;
+    }
+  }
+};
+
+// step 9a of Lagrangian_to_Eulerian with the increment of the energy fixer (fv_mapz.F90:793-821): T_v / T_m -> T
+struct RemapFinish {
+  Grid g;
+  int km;
+  RemapPar p;
+  double dtmp;
+  const double *q, *pkz;
+  double *pt;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int n = g.nx * g.ny;
+    const size_t nA = g.nA(), nCC = g.nCC();
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.is + idx % g.nx, j = g.js + idx / g.nx;
+      const size_t o3 = (size_t)bz * nA + g.iA(i, j), c3 = (size_t)bz * nCC + g.iCC(i, j);
+      const double qv = (p.sphum > 0 && !p.adiabatic) ? q[(size_t)(p.sphum - 1) * nA * km + o3] : 0.;   // adiabatic: the caller's zvir = 0
+      if (p.hydrostatic) {
+        pt[o3] = (pt[o3] + dtmp / p.cp * pkz[c3]) / (1. + p.r_vir * qv);
+      } else if (p.use_cond) {
+        double qc;
+        const double cvm = moist_cv(p, q + o3, nA * km, qc);
+        pt[o3] = (pt[o3] + dtmp / cvm * pkz[c3]) / ((1. + p.r_vir * qv) * (1. - qc));
+      } else if (!p.adiabatic) {
+        pt[o3] = (pt[o3] + dtmp / p.cv_air * pkz[c3]) / (1. + p.r_vir * qv);
+      }
+    }
+  }
+};
+
 }  // namespace fv3

@@ -16,11 +16,15 @@ from .lib import CP_AIR, Context
 from .tracer2d import tracer_2d
 
 
+CONSV_MIN = 0.001   # fv_mapz.F90:45: below it no correction applies
+
+
 class FvDynamics:
     def __init__(self, ctx: Context, flags: DynFlags, ak, bk, nq: int = 0, k_split: int = 1, kord_tm: int = -8,
                  kord_mt: int = 8, kord_wz: int = 8, kord_tr: int = 8, q_split: int = 0, nord_tr: int = 0, trdm2: float = 0.0, adiabatic: bool = True,
                  px: int = 1, py: int = 1, rank: int = 0, world: int = 1, dist=None, tau: float = 0.0,
-                 rf_cutoff: float = 30.0e2, c2l_ord: int = 4, moist: dict | None = None, fill: bool = False, halo=None):
+                 rf_cutoff: float = 30.0e2, c2l_ord: int = 4, moist: dict | None = None, fill: bool = False, halo=None,
+                 consv_te: float = 0.0, moist_phys: bool = False, radius: float = 6.3712e6):
         ak, bk = np.asarray(ak, dtype=np.float64), np.asarray(bk, dtype=np.float64)
         dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5          # dyn_core.F90:241-244
         self.ctx, self.fl, self.nq, self.k_split, self.q_split, self.dist = ctx, flags, nq, k_split, q_split, dist
@@ -28,6 +32,10 @@ class FvDynamics:
         self.tau, self.rf_cutoff, self.c2l_ord = tau, rf_cutoff, c2l_ord
         self.ak, self.bk = ak, bk
         self._rf = None                                                    # (rf, pm, kmax): set on first use, as RF_initialized
+        # total-energy conservation (fv_dynamics.F90:345-355, fv_mapz.F90:643-772): fraction of the energy lost in a step that
+        # the last remap returns as heat (> consv_min), or a prescribed flux in W/m**2 (< -consv_min)
+        self.consv_te, self.moist_phys, self.radius = consv_te, moist_phys, radius
+        self.e_flux = 0.0
         # moist thermodynamics (flags.use_cond / flags.moist_kappa): nwat and the water-species indices for moist_cv,
         # cv_vap, c_liq, c_ice (lib.Context.set_moist)
         self.moist = None
@@ -59,6 +67,8 @@ class FvDynamics:
         zvir = self.remap_par["r_vir"] if qv else 0.0
         if self.moist:
             ctx.set_moist(self.moist, d.get("q_con"), d.get("cappa"))
+        if self.consv_te > CONSV_MIN:                                      # :345-355 (te_2d -> te0_2d of the last remap)
+            self.total_energy_before()
         conv = lambda mode: ctx.pt_to_theta_v(mode, zvir, fl.akap, fl.rdgas, fl.grav, d["pt"], d["delp"],
                                               None if fl.hydrostatic else d["delz"], qv, d["pkz"])
         if self.tau > 0.0:                                                 # :368-376 (grid_type = 4: Rayleigh_Friction)
@@ -70,6 +80,52 @@ class FvDynamics:
             conv(int(fl.hydrostatic))
         self.step(bdt, last_cycle_is_last_step=True)
         self.cubed_to_latlon()                                             # :911
+
+    # -- consv_te -------------------------------------------------------------------------------------------------
+    def total_energy_before(self):
+        """compute_total_energy at fv_dynamics.F90:345 (pt = T, before the conversion to theta_v): te0_2d of every column"""
+        d, ctx, hyd = self.dc.d, self.ctx, self.fl.hydrostatic
+        if "te0_2d" not in d:
+            for n in ("te0_2d", "te_2d", "zsum1", "zsum0"):
+                d[n] = ctx.zeros("CC")
+        if self.moist:
+            ctx.set_moist(self.moist, d.get("q_con"), d.get("cappa"))
+        ctx.compute_total_energy(self.remap_par, self.moist_phys, d["u"], d["v"], None if hyd else d["w"],
+                                 None if hyd else d["delz"], d["pt"], d["delp"], d.get("q"), None, d["pe"] if hyd else None,
+                                 d["peln"] if hyd else None, d["phis"], d["te0_2d"])
+
+    def _areas(self):
+        """area (compute domain) of every context: the weights of g_sum (area_64, fv_mapz.F90:736)"""
+        ctxs = getattr(self.ctx, "ctxs", [self.ctx])
+        out = []
+        for c in ctxs:
+            b = c.bd
+            out.append(np.asarray(c.grid.m["area"])[b.ng:b.ng + b.nx, b.ng:b.ng + b.ny])
+        return out
+
+    def _energy_fixer(self, par: dict, pdt: float):
+        """fv_mapz.F90:643-772 after the remap of the last step, then step 9a with dtmp (:793-821)"""
+        from .global_sum import g_sum
+        d, ctx, hyd = self.dc.d, self.ctx, self.fl.hydrostatic
+        only_sums = self.consv_te < 0.0
+        for n in ("te0_2d", "te_2d", "zsum1", "zsum0"):
+            if n not in d:
+                d[n] = ctx.zeros("CC")
+        ctx.energy_fixer_sums(par, only_sums, d["u"], d["v"], None if hyd else d["w"], None if hyd else d["delz"], d["pt"],
+                              d["delp"], d.get("q"), d["pe"] if hyd else None, d["peln"] if hyd else None, d["phis"], d["pkz"],
+                              d["pk"] if hyd else None, d["te0_2d"], d["te_2d"], d["zsum1"], d["zsum0"] if hyd else None)
+        aslist = lambda x: x if isinstance(x, list) else [x]
+        areas = self._areas()
+        zs = g_sum(aslist(d["zsum0" if hyd else "zsum1"].download()), areas, self.dist)
+        if only_sums:                                                      # :745-771: a prescribed flux
+            self.e_flux = self.consv_te
+            dtmp = self.e_flux * (self.fl.grav * pdt * 4.0 * np.pi * self.radius ** 2) / zs
+        else:
+            dtmp = self.consv_te * g_sum(aslist(d["te_2d"].download()), areas, self.dist)
+            self.e_flux = dtmp / (self.fl.grav * pdt * 4.0 * np.pi * self.radius ** 2)
+            dtmp = dtmp / zs
+        self.dtmp = dtmp
+        ctx.remap_finish(par, dtmp, d["pt"], d["pkz"], d.get("q"))
 
     def rayleigh_profile(self, dt: float):
         """rf(k), kmax of Rayleigh_Friction (fv_dynamics.F90:1169-1182) with pfull of fv_dynamics.F90:254-262 (p_ref = 1e5)"""
@@ -141,10 +197,13 @@ class FvDynamics:
                     d["q"], d["q_nxt"] = d["q_nxt"], d["q"]
                 if dp1 is not d["dp1"]:
                     d["dp1"], d["dp1_nxt"] = d["dp1_nxt"], d["dp1"]
-            par = dict(self.remap_par, last_step=int(last_step))
+            fixer = last_step and abs(self.consv_te) > CONSV_MIN                # fv_mapz.F90:645-647, :745
+            par = dict(self.remap_par, last_step=2 if fixer else int(last_step))
             hyd = self.fl.hydrostatic
             if self.moist:                                                     # q_con is a ping-pong pair: current buffer
                 ctx.set_moist(self.moist, d.get("q_con"), d.get("cappa"))
             ctx.lagrangian_to_eulerian(par, d["ps"], d["pe"], d["delp"], d["pkz"], d["pk"], d["u"], d["v"],
                                        None if hyd else d["w"], None if hyd else d["delz"], d["pt"], d.get("q"),
                                        d["peln"], d["omga"], None if hyd else d["ws"])   # :607
+            if fixer:
+                self._energy_fixer(par, bdt)

@@ -33,7 +33,7 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_grid_upload_cubed", "fv3_gather_create", "fv3_gather_run", "fv3_gather_destroy", "fv3_grid_geom", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
-           "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max",
+           "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_compute_total_energy", "fv3_energy_fixer_sums", "fv3_remap_finish", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
@@ -434,6 +434,35 @@ class Context:
         self.lib.check(self.lib.dll.fv3_lagrangian_to_eulerian(
             self.h, C.byref(s), kt.ctypes.data_as(_ip) if kt.size else None, ps.p, pe.p, delp.p, pkz.p, pk.p, u.p, v.p,
             _pp(w), _pp(delz), pt.p, _pp(q), peln.p, omga.p, _pp(ws)), "fv3_lagrangian_to_eulerian")
+
+    @staticmethod
+    def _remap_params(par: dict, last_step=None):
+        s = _RemapParams()
+        for k in ["last_step", "hydrostatic", "adiabatic", "nq", "kord_mt", "kord_wz", "kord_tm", "sphum", "akap", "ptop",
+                  "rdgas", "grav", "cv_air", "r_vir", "cp", "t_min"]:
+            setattr(s, k, par.get(k, 0) if k == "last_step" else par[k])
+        if last_step is not None:
+            s.last_step = int(last_step)
+        s.fill = int(par.get("fill", 0))
+        return s
+
+    # -- consv_te: compute_total_energy (fv_thermodynamics.F90:90) and the energy fixer of the last remap (fv_mapz.F90:643-821)
+    def compute_total_energy(self, par: dict, moist_phys, u, v, w, delz, pt, delp, q, qc, pe, peln, phis, te_2d):
+        s = self._remap_params(par)
+        self.lib.check(self.lib.dll.fv3_compute_total_energy(
+            self.h, C.byref(s), C.c_int(int(moist_phys)), u.p, v.p, _pp(w), _pp(delz), pt.p, delp.p, _pp(q), _pp(qc), _pp(pe),
+            _pp(peln), phis.p, te_2d.p), "fv3_compute_total_energy")
+
+    def energy_fixer_sums(self, par: dict, only_sums, u, v, w, delz, pt, delp, q, pe, peln, phis, pkz, pk, te0_2d, te_2d, zsum1,
+                          zsum0):
+        s = self._remap_params(par)
+        self.lib.check(self.lib.dll.fv3_energy_fixer_sums(
+            self.h, C.byref(s), C.c_int(int(only_sums)), u.p, v.p, _pp(w), _pp(delz), pt.p, delp.p, _pp(q), _pp(pe), _pp(peln),
+            phis.p, pkz.p, _pp(pk), _pp(te0_2d), _pp(te_2d), zsum1.p, _pp(zsum0)), "fv3_energy_fixer_sums")
+
+    def remap_finish(self, par: dict, dtmp, pt, pkz, q):
+        s = self._remap_params(par)
+        self.lib.check(self.lib.dll.fv3_remap_finish(self.h, C.byref(s), C.c_double(dtmp), pt.p, pkz.p, _pp(q)), "fv3_remap_finish")
 
     # -- tracer_2d ---------------------------------------------------------------------------------------
     def tracer_2d_prep(self, q_split, cx, cy, xfx, yfx) -> np.ndarray:

@@ -396,6 +396,29 @@ typedef struct fv3_moist_params {
 int fv3_set_moist(fv3_ctx *ctx, const fv3_moist_params *m, double *q_con, double *cappa);
 /* ak, bk: HOST arrays of length npz+1 (the hybrid coordinate, tools/fv_eta.F90). */
 int fv3_set_ak_bk(fv3_ctx *ctx, const double *ak, const double *bk);
+/* ---- total-energy conservation (consv_te) -------------------------------------------------------------------------
+ * fv3_compute_total_energy = compute_total_energy (model/fv_thermodynamics.F90:90-225; called at fv_dynamics.F90:345 before
+ *   the T -> theta_v conversion): te_2d (CC) of every column; qc = zvir*q(sphum) (A x npz, or NULL = 0), q the tracers
+ *   (read by the moist_phys .and. moist_kappa branch only), w / delz or pe / peln by branch.  The scalars come from
+ *   the fv3_remap_params structure: hydrostatic, rdgas, cp, cv_air, grav, nq, sphum, the moist switches from fv3_set_moist.
+ * The energy fixer of the last remap (model/fv_mapz.F90:643-772, :793-821) is three steps around the caller's global sums:
+ *   fv3_lagrangian_to_eulerian with last_step = 2 -- the remap of the last step WITHOUT its final T_v -> T conversion;
+ *   fv3_energy_fixer_sums -- te_2d := te0_2d - (total energy of the remapped columns) (:647-722), zsum1 = sum_k pkz*delp,
+ *     zsum0 = ptop*(pk(1) - pk(npz+1)) + zsum1 (hydrostatic) (:723-734), all CC; only_sums = 1: the sums alone (the
+ *     consv < -consv_min branch, :745-763); with use_cond q_con is rewritten from moist_cv (:701);
+ *   [caller: dtmp = consv * g_sum(te_2d) / g_sum(zsum0 | zsum1), g_sum = area-weighted reproducing sum, :736-743]
+ *   fv3_remap_finish(dtmp) -- pt = (pt + dtmp/c * pkz) / (1 + r_vir*qv) in the three forms of :793-821 (c = cp, cvm, cv_air;
+ *     nonhydrostatic adiabatic: nothing).  With adiabatic set the virtual factor is 1 (the reference's caller passes zvir = 0).
+ *   remap_te = .true. is not built. */
+int fv3_compute_total_energy(fv3_ctx *ctx, const fv3_remap_params *p, int moist_phys, const double *u, const double *v,
+                             const double *w, const double *delz, const double *pt, const double *delp, const double *q,
+                             const double *qc, const double *pe, const double *peln, const double *phis, double *te_2d);
+int fv3_energy_fixer_sums(fv3_ctx *ctx, const fv3_remap_params *p, int only_sums, const double *u, const double *v,
+                          const double *w, const double *delz, const double *pt, const double *delp, const double *q,
+                          const double *pe, const double *peln, const double *phis, const double *pkz, const double *pk,
+                          const double *te0_2d, double *te_2d, double *zsum1, double *zsum0);
+int fv3_remap_finish(fv3_ctx *ctx, const fv3_remap_params *p, double dtmp, double *pt, const double *pkz, const double *q);
+
 int fv3_lagrangian_to_eulerian(fv3_ctx *ctx, const fv3_remap_params *p, const int *kord_tr, double *ps, double *pe,
                                double *delp, double *pkz, double *pk, double *u, double *v, double *w, double *delz,
                                double *pt, double *q, double *peln, double *omga, const double *ws);

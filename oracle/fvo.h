@@ -214,6 +214,18 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
                                double *pkz, double *pk, double *u, double *v, double *w, double *delz, double *pt,
                                double *q, double *peln, double *omga, const double *ws, const double *ak,
                                const double *bk, double *q_con, double *cappa);
+/* consv_te: compute_total_energy (fv_thermodynamics.F90:90-225), the energy fixer sums (fv_mapz.F90:647-763) and step 9a with
+ * the fixer's increment (:793-821); fvo_lagrangian_to_eulerian with last_step = 2 leaves that last conversion to fvo_remap_finish */
+int fvo_compute_total_energy(const fvo_grid *g, int km, const fvo_remap_par *p, int moist_phys, const double *u,
+                             const double *v, const double *w, const double *delz, const double *pt, const double *delp,
+                             const double *q, const double *qc, const double *pe, const double *peln, const double *hs,
+                             double *te_2d);
+int fvo_energy_fixer_sums(const fvo_grid *g, int km, const fvo_remap_par *p, int only_sums, const double *u, const double *v,
+                          const double *w, const double *delz, const double *pt, const double *delp, const double *q,
+                          const double *pe, const double *peln, const double *hs, const double *pkz, const double *pk,
+                          const double *te0_2d, double *te_2d, double *zsum1, double *zsum0, double *q_con);
+int fvo_remap_finish(const fvo_grid *g, int km, const fvo_remap_par *p, double dtmp, double *pt, const double *pkz,
+                     const double *q);
 /* moist_cv for one cell (fv_thermodynamics.F90:250-325, without the t1 special case): returns cvm, sets *q_con.
  * qk points at q(i,j,k,1); species stride ns. */
 double fvo_moist_cv(const fvo_remap_par *p, const double *qk, size_t ns, double *q_con);

@@ -720,7 +720,8 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
   for (k = 2; k <= km; k++) /* :635-641 */
     for (j = js; j <= je; j++)
       for (i = is; i <= ie; i++) PE(i, k, j) = pe4[IA3(i, j, k - 1)];
-  if (p->last_step) { /* :793-821 with dtmp = 0 */
+  if (p->last_step == 2) { /* the energy fixer follows (fvo_energy_fixer_sums, fvo_remap_finish) */
+  } else if (p->last_step) { /* :793-821 with dtmp = 0 */
     if (!p->hydrostatic && p->use_cond) { /* :806-811 */
       for (k = 1; k <= km; k++)
         for (j = js; j <= je; j++)
@@ -746,4 +747,132 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
   }
   free(pe4); free(c1); free(c2); free(pe1); free(pe2); free(pn1); free(pn2); free(pk2); free(dp2); free(pe0); free(pe3);
   return rc;
+}
+
+/* ---------------------------------------------------------------------------------------------------
+ * Total energy and the energy fixer (consv_te).  Layouts as in fvo_lagrangian_to_eulerian; te_2d, zsum*: CC.
+ * ------------------------------------------------------------------------------------------------- */
+#define EBOUNDS                                                                                           \
+  const int is = g->is, ie = g->ie, js = g->js, je = g->je, ng = g->ng;                                     \
+  const int isd = is - ng, ied = ie + ng, jsd = js - ng, jed = je + ng;                                     \
+  const int nid = ied - isd + 1, njd = jed - jsd + 1, nx = ie - is + 1, ny = je - js + 1;                   \
+  const size_t nA = (size_t)nid * njd, nU = (size_t)nid * (njd + 1), nV = (size_t)(nid + 1) * njd, nCC = (size_t)nx * ny; \
+  int i, j, k;                                                                                            \
+  (void)jed; (void)nU; (void)nV; (void)nCC
+#define EA2(i, j) ((size_t)((j)-jsd) * nid + ((i)-isd))
+#define ECC2(i, j) ((size_t)((j)-js) * nx + ((i)-is))
+#define EPE(i, k, j) pe[(size_t)((j) - (js - 1)) * (nx + 2) * (km + 1) + (size_t)((k)-1) * (nx + 2) + ((i) - (is - 1))]
+#define EPELN(i, k, j) peln[(size_t)((j)-js) * nx * (km + 1) + (size_t)((k)-1) * nx + ((i)-is)]
+#define EWIND(i, j, k)                                                                                                    \
+  (u[IU3(i, j, k)] * u[IU3(i, j, k)] + u[IU3(i, j + 1, k)] * u[IU3(i, j + 1, k)] + v[IV3(i, j, k)] * v[IV3(i, j, k)] +     \
+   v[IV3(i + 1, j, k)] * v[IV3(i + 1, j, k)] -                                                                            \
+   (u[IU3(i, j, k)] + u[IU3(i, j + 1, k)]) * (v[IV3(i, j, k)] + v[IV3(i + 1, j, k)]) * g->cosa_s[EA2(i, j)])
+
+/* compute_total_energy, fv_thermodynamics.F90:90-225 (USE_COND not defined; teq not restated).  qc: A x km or NULL. */
+int fvo_compute_total_energy(const fvo_grid *g, int km, const fvo_remap_par *p, int moist_phys, const double *u,
+                             const double *v, const double *w, const double *delz, const double *pt, const double *delp,
+                             const double *q, const double *qc, const double *pe, const double *peln, const double *hs,
+                             double *te_2d) {
+  EBOUNDS;
+/* qc = zvir*q(sphum), fv_dynamics.F90:295-301: the caller's array, or formed from the tracer */
+#define QCV(i, j, k) (qc ? qc[IA3(i, j, k)] : ((p->sphum > 0 && !p->adiabatic && q) ? p->r_vir * q[(size_t)(p->sphum - 1) * nA * km + IA3(i, j, k)] : 0.))
+  double *phiz = dalloc(km + 2);
+  for (j = js; j <= je; j++)
+    for (i = is; i <= ie; i++) {
+      double te;
+      if (p->hydrostatic) {
+        phiz[km + 1] = hs[EA2(i, j)];
+        for (k = km; k >= 1; k--) {
+          const double tv = pt[IA3(i, j, k)] * (1. + QCV(i, j, k));
+          phiz[k] = phiz[k + 1] + p->rdgas * tv * (EPELN(i, k + 1, j) - EPELN(i, k, j));
+        }
+        te = EPE(i, km + 1, j) * phiz[km + 1] - EPE(i, 1, j) * phiz[1];
+        for (k = 1; k <= km; k++) {
+          const double tv = pt[IA3(i, j, k)] * (1. + QCV(i, j, k));
+          te = te + delp[IA3(i, j, k)] * (p->cp * tv + 0.25 * g->rsin2[EA2(i, j)] * EWIND(i, j, k));
+        }
+      } else {
+        phiz[km + 1] = hs[EA2(i, j)];
+        for (k = km; k >= 1; k--) phiz[k] = phiz[k + 1] - p->grav * delz[ICC3(i, j, k)];
+        te = 0.;
+        for (k = 1; k <= km; k++) {
+          double cv = p->cv_air, qd;
+          if (moist_phys && p->moist_kappa) cv = fvo_moist_cv(p, q + IA3(i, j, k), nA * km, &qd); /* :186-193 */
+          te = te + delp[IA3(i, j, k)] *
+                        (cv * pt[IA3(i, j, k)] + 0.5 * (phiz[k] + phiz[k + 1] + w[IA3(i, j, k)] * w[IA3(i, j, k)] +
+                                                        0.5 * g->rsin2[EA2(i, j)] * EWIND(i, j, k)));
+        }
+      }
+      te_2d[ECC2(i, j)] = te;
+    }
+  free(phiz);
+  return FVO_OK;
+}
+
+/* fv_mapz.F90:647-734 (consv > consv_min, remap_te = .false.) and :745-763 (only_sums) */
+int fvo_energy_fixer_sums(const fvo_grid *g, int km, const fvo_remap_par *p, int only_sums, const double *u, const double *v,
+                          const double *w, const double *delz, const double *pt, const double *delp, const double *q,
+                          const double *pe, const double *peln, const double *hs, const double *pkz, const double *pk,
+                          const double *te0_2d, double *te_2d, double *zsum1, double *zsum0, double *q_con) {
+  EBOUNDS;
+  double *phis = dalloc(km + 2);
+  const double rv = p->adiabatic ? 0. : p->r_vir; /* the reference's caller passes zvir = 0 for an adiabatic run */
+  for (j = js; j <= je; j++)
+    for (i = is; i <= ie; i++) {
+      if (!only_sums) {
+        double te;
+        if (p->hydrostatic) {
+          double gz = hs[EA2(i, j)];
+          for (k = 1; k <= km; k++) gz = gz + p->rdgas * pt[IA3(i, j, k)] * (EPELN(i, k + 1, j) - EPELN(i, k, j));
+          te = EPE(i, km + 1, j) * hs[EA2(i, j)] - EPE(i, 1, j) * gz;
+          for (k = 1; k <= km; k++)
+            te = te + delp[IA3(i, j, k)] * (p->cp * pt[IA3(i, j, k)] + 0.25 * g->rsin2[EA2(i, j)] * EWIND(i, j, k));
+        } else {
+          te = 0.;
+          phis[km + 1] = hs[EA2(i, j)];
+          for (k = km; k >= 1; k--) phis[k] = phis[k + 1] - p->grav * delz[ICC3(i, j, k)];
+          for (k = 1; k <= km; k++) {
+            const double qv = p->sphum > 0 ? q[(size_t)(p->sphum - 1) * nA * km + IA3(i, j, k)] : 0.;
+            const double mech = 0.5 * (phis[k] + phis[k + 1] + w[IA3(i, j, k)] * w[IA3(i, j, k)] +
+                                       0.5 * g->rsin2[EA2(i, j)] * EWIND(i, j, k));
+            if (p->use_cond) {
+              double qc;
+              const double cvm = fvo_moist_cv(p, q + IA3(i, j, k), nA * km, &qc);
+              q_con[IA3(i, j, k)] = qc;
+              te = te + delp[IA3(i, j, k)] * (cvm * pt[IA3(i, j, k)] / ((1. + rv * qv) * (1. - qc)) + mech);
+            } else {
+              te = te + delp[IA3(i, j, k)] * (p->cv_air * pt[IA3(i, j, k)] / (1. + rv * qv) + mech);
+            }
+          }
+        }
+        te_2d[ECC2(i, j)] = te0_2d[ECC2(i, j)] - te;
+      }
+      zsum1[ECC2(i, j)] = pkz[ICC3(i, j, 1)] * delp[IA3(i, j, 1)];
+      for (k = 2; k <= km; k++) zsum1[ECC2(i, j)] = zsum1[ECC2(i, j)] + pkz[ICC3(i, j, k)] * delp[IA3(i, j, k)];
+      if (p->hydrostatic) zsum0[ECC2(i, j)] = p->ptop * (pk[ICC3(i, j, 1)] - pk[ICC3(i, j, km + 1)]) + zsum1[ECC2(i, j)];
+    }
+  free(phis);
+  return FVO_OK;
+}
+
+/* fv_mapz.F90:793-821 with the fixer's dtmp */
+int fvo_remap_finish(const fvo_grid *g, int km, const fvo_remap_par *p, double dtmp, double *pt, const double *pkz,
+                     const double *q) {
+  EBOUNDS;
+  const double rv = p->adiabatic ? 0. : p->r_vir;
+  for (k = 1; k <= km; k++)
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie; i++) {
+        const double qv = p->sphum > 0 ? q[(size_t)(p->sphum - 1) * nA * km + IA3(i, j, k)] : 0.;
+        if (p->hydrostatic) {
+          pt[IA3(i, j, k)] = (pt[IA3(i, j, k)] + dtmp / p->cp * pkz[ICC3(i, j, k)]) / (1. + rv * qv);
+        } else if (p->use_cond) {
+          double qc;
+          const double cvm = fvo_moist_cv(p, q + IA3(i, j, k), nA * km, &qc);
+          pt[IA3(i, j, k)] = (pt[IA3(i, j, k)] + dtmp / cvm * pkz[ICC3(i, j, k)]) / ((1. + rv * qv) * (1. - qc));
+        } else if (!p->adiabatic) {
+          pt[IA3(i, j, k)] = (pt[IA3(i, j, k)] + dtmp / p->cv_air * pkz[ICC3(i, j, k)]) / (1. + rv * qv);
+        }
+      }
+  return FVO_OK;
 }

@@ -356,7 +356,7 @@ def _oracle_tracers(cs, gs, fl, npz, q, dp1, f):
                      [x["cy"] for x in f], fl.hord_tr, 0)
 
 
-def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz, q=None):
+def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz, q=None, last_step=0):
     """hydrostatic k_split loop on six faces over the oracle: dyn_core substeps -> tracer_2d -> Lagrangian_to_Eulerian"""
     mdt = bdt / float(k_split)
     cur = [{k: s[k].copy(order="F") for k in ("u", "v", "delp", "pt", "phis")} for s in st]
@@ -375,7 +375,7 @@ def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz, q
                       omga=bd.zeros("A", npz))
             if q is not None:
                 rf["q"] = q[t]
-            O.lagrangian_to_eulerian(gs[t], npz, dict(remap_par, last_step=0), rf, ak, bk)
+            O.lagrangian_to_eulerian(gs[t], npz, dict(remap_par, last_step=(int(last_step) if n_map == k_split else 0)), rf, ak, bk)
             cur[t] = dict(u=rf["u"], v=rf["v"], delp=rf["delp"], pt=rf["pt"], phis=st[t]["phis"])
             out.append(dict(cur[t], pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"], q=None if q is None else q[t]))
     return out

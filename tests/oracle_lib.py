@@ -317,6 +317,35 @@ def lagrangian_to_eulerian(g, km, par: dict, f: dict, ak, bk):
     assert rc == 0, rc
 
 
+def _remap_par(par: dict):
+    pr = RemapPar()
+    kt = np.ascontiguousarray(par.get("kord_tr", []), dtype=np.int32)
+    for k, v in par.items():
+        if k != "kord_tr":
+            setattr(pr, k, v)
+    pr.kord_tr = kt.ctypes.data_as(_ip)
+    pr._keep = kt
+    return pr
+
+
+def compute_total_energy(g, km, par, moist_phys, u, v, w, delz, pt, delp, q, qc, pe, peln, hs, te_2d):
+    gs, pr = make_grid(g), _remap_par(par)
+    assert lib().fvo_compute_total_energy(C.byref(gs), C.c_int(km), C.byref(pr), C.c_int(int(moist_phys)), p(u), p(v), p(w), p(delz),
+                                          p(pt), p(delp), p(q), p(qc), p(pe), p(peln), p(hs), p(te_2d)) == 0
+
+
+def energy_fixer_sums(g, km, par, only_sums, u, v, w, delz, pt, delp, q, pe, peln, hs, pkz, pk, te0_2d, te_2d, zsum1, zsum0, q_con=None):
+    gs, pr = make_grid(g), _remap_par(par)
+    assert lib().fvo_energy_fixer_sums(C.byref(gs), C.c_int(km), C.byref(pr), C.c_int(int(only_sums)), p(u), p(v), p(w), p(delz), p(pt),
+                                       p(delp), p(q), p(pe), p(peln), p(hs), p(pkz), p(pk), p(te0_2d), p(te_2d), p(zsum1), p(zsum0),
+                                       p(q_con)) == 0
+
+
+def remap_finish(g, km, par, dtmp, pt, pkz, q):
+    gs, pr = make_grid(g), _remap_par(par)
+    assert lib().fvo_remap_finish(C.byref(gs), C.c_int(km), C.byref(pr), _d(dtmp), p(pt), p(pkz), p(q)) == 0
+
+
 def tracer_2d(g, npz, nq, q, dp1, mfx, mfy, cx, cy, hord, q_split, nord_tr, trdm):
     gs = make_grid(g)
     rc = lib().fvo_tracer_2d(C.byref(gs), C.c_int(npz), C.c_int(nq), p(q), p(dp1), p(mfx), p(mfy), p(cx), p(cy),

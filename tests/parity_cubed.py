@@ -688,3 +688,76 @@ def check_rayleigh_super(lib, npx=13, npz=20, hydrostatic=False, ideal=False, ta
     finally:
         mctx.close()
     return worst
+
+
+def check_jw_consv(lib, npx=13, npz=20, k_split=2, n_split=2, bdt=900.0, consv_te=1.0, tol=1e-12):
+    """consv_te on the whole sphere (BASELINE config 2's kind of run: hydrostatic JW): compute_total_energy of the six faces before
+    the loop, the energy fixer after the last remap with its two area-weighted global sums over the sphere, step 9a with dtmp --
+    FvDynamics.step_from_temperature over MultiContext against the oracle's restatements and math.fsum over the six faces"""
+    import math
+    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.test_cases import jablonowski_williamson
+    cs, gs = CC.sphere(npx)
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+    ak, bk = 300.0 * (1.0 - sig), sig.copy()
+    st = jablonowski_williamson(cs, ak, bk, hydrostatic=True)
+    CC.exchange(cs, st, ("phis",), "A")
+    fl = DynFlags(n_split=n_split, hydrostatic=True, d_ext=0.0, ptop=float(ak[0]))
+    bd = gs[0].bd
+    ng, nx = bd.ng, bd.nx
+    c = (slice(ng, ng + nx), slice(ng, ng + nx))
+    pes, pelns, pkzs, ost = [], [], [], []
+    for s_ in st:                     # what p_var left in the state: pe, peln, pkz of the hydrostatic column
+        pe3 = ak[0] + np.concatenate([np.zeros((nx, nx, 1)), np.cumsum(s_["delp"][c], axis=2)], axis=2)
+        peln3 = O.flog(pe3).reshape(pe3.shape)
+        pk3 = O.fexp(fl.akap * peln3).reshape(pe3.shape)
+        pkz = np.asfortranarray((pk3[:, :, 1:] - pk3[:, :, :-1]) / (fl.akap * (peln3[:, :, 1:] - peln3[:, :, :-1])))
+        pe = np.zeros((nx + 2, npz + 1, nx + 2), order="F")
+        pe[1:-1, :, 1:-1] = np.transpose(pe3, (0, 2, 1))
+        pes.append(pe)
+        pelns.append(np.asfortranarray(np.transpose(peln3, (0, 2, 1))))
+        pkzs.append(pkz)
+        th = s_["pt"].copy(order="F")
+        th[c] = s_["pt"][c] / pkz
+        ost.append(dict(s_, pt=th))
+    mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
+    worst = {}
+    try:
+        fv = FvDynamics(mctx, fl, ak, bk, k_split=k_split, c2l_ord=2, consv_te=consv_te, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        par = dict(fv.remap_par)
+        areas = [np.asarray(g.m["area"])[c] for g in gs]
+        te0 = [bd.zeros("CC") for _ in gs]
+        for t in range(6):
+            O.compute_total_energy(gs[t], npz, par, False, st[t]["u"], st[t]["v"], None, None, st[t]["pt"], st[t]["delp"], None, None,
+                                   pes[t], pelns[t], st[t]["phis"], te0[t])
+        ref = CC.oracle_fv_step_hydro(cs, gs, fl, ost, ak, bk, bdt, k_split, par, npz, last_step=2)
+        te2, z1, z0 = ([bd.zeros("CC") for _ in gs] for _ in range(3))
+        for t in range(6):
+            x = ref[t]
+            O.energy_fixer_sums(gs[t], npz, par, False, x["u"], x["v"], None, None, x["pt"], x["delp"], None, x["pe"], x["peln"],
+                                st[t]["phis"], x["pkz"], x["pk"], te0[t], te2[t], z1[t], z0[t])
+        dtmp = consv_te * math.fsum(np.concatenate([(a * b).ravel() for a, b in zip(te2, areas)])) / \
+            math.fsum(np.concatenate([(a * b).ravel() for a, b in zip(z0, areas)]))
+        for t in range(6):
+            O.remap_finish(gs[t], npz, par, dtmp, ref[t]["pt"], ref[t]["pkz"], None)
+        z = [np.zeros_like(s_["delp"]) for s_ in st]
+        fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], z, [s_["delp"] for s_ in st], [s_["pt"] for s_ in st],
+                        [bd.zeros("CC", npz) for _ in st], [s_["phis"] for s_ in st])
+        fv.dc.d["pe"].upload(pes)
+        fv.dc.d["peln"].upload(pelns)
+        fv.dc.d["pkz"].upload(pkzs)
+        fv.step_from_temperature(bdt)
+        worst["dtmp"] = abs(fv.dtmp - dtmp) / abs(dtmp)
+        assert worst["dtmp"] < 1e-11 and abs(dtmp) > 1e-14, (fv.dtmp, dtmp)
+        d = fv.dc.d
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        for n, kind, rr in (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)), ("delp", "A", r),
+                            ("pt", "A", r)):
+            got = d[n].download()
+            for t in range(6):
+                worst[n] = max(worst.get(n, 0.0), P.assert_close(f"face {t + 1} {n}", bd.view(got[t], kind, *rr), bd.view(ref[t][n], kind, *rr), tol))
+    finally:
+        mctx.close()
+    return worst

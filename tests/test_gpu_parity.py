@@ -822,6 +822,20 @@ def test_cubed_sphere_rayleigh_super(prod, hydrostatic, ideal):
     assert PC.check_rayleigh_super(prod, npx=25, hydrostatic=hydrostatic, ideal=ideal) <= 1e-14
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(hydrostatic=True), dict(hydrostatic=True, adiabatic=True), dict(adiabatic=True),
+                                dict(consv_te=-2.0), dict(consv_te=-2.0, hydrostatic=True)])
+def test_total_energy_conservation(prod, kw):
+    """consv_te: compute_total_energy before the loop, the energy fixer of the last remap (te_2d, zsum0 / zsum1, the reproducing
+    global sums, dtmp) and the final T_v -> T step with dtmp; a prescribed flux for consv_te < 0; the energy of the final state
+    closes on the initial one"""
+    assert max(D.check_fv_cycle_consv(prod, **kw).values()) <= 1e-12
+
+
+def test_cubed_sphere_total_energy_conservation(prod):
+    """the same on the six faces (hydrostatic JW): global sums over the sphere"""
+    assert max(PC.check_jw_consv(prod, npx=25).values()) <= 1e-12
+
+
 def test_cubed_del2_cubed_and_damped_transports(prod):
     assert PC.check_del2_cubed(prod, npx=25, npz=4, nmax=3) <= P.TOL
     for kw in (dict(nord=2, damp_c=0.05), dict(nord=2, damp_c=0.05, mass_flux=True)):
