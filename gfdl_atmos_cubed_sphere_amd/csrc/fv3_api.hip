@@ -1490,6 +1490,7 @@ int rccl_load() {
   return 0;
 }
 constexpr int kNcclDouble = 8, kNcclMax = 2;  // ncclFloat64, ncclMax (rccl.h)
+constexpr int kNcclInt64 = 4, kNcclSum = 0;   // ncclInt64, ncclSum
 #define NC(x)                                                                                              \
   do {                                                                                                     \
     int e_ = (x);                                                                                          \
@@ -1617,6 +1618,59 @@ extern "C" int fv3_allreduce_max(fv3_ctx *c, double *buf, int n) {
   rt_free(d);
   return 0;
 #endif
+}
+
+// g_sum(..., reproduce = .true.) (model/fv_grid_utils.F90:2879-2925) = FMS's mpp_global_sum(flags = BITWISE_EFP_SUM): the
+// extended-fixed-point sum (Hallberg & Adcroft 2014; FMS mpp/mpp_efp.F90, a dependency outside the reference tree): every addend
+// as six integer digits of radix 2^46 (2^92 .. 2^-138), integer sums (exact: independent of order and of the rank layout),
+// carries, back to a double from the most significant digit down.  values: n HOST doubles (the caller's p*area of its compute
+// domain); with a communicator of several ranks the digits are all-reduced.  The same algorithm as global_sum.py.
+extern "C" int fv3_ordered_sum(fv3_ctx *c, const double *values, size_t n, double *sum) {
+  if (!values || !sum) return fail("fv3_ordered_sum: null argument");
+  constexpr int NI = 6, NB = 46;
+  const double R = (double)(1LL << NB);
+  const double pr[NI] = {R * R, R, 1.0, 1.0 / R, 1.0 / (R * R), 1.0 / (R * R * R)};
+  __int128 acc[NI] = {0, 0, 0, 0, 0, 0};
+  for (size_t m = 0; m < n; m++) {
+    const double a = values[m];
+    if (!(a == a) || a > 1.7e308 || a < -1.7e308) return fail("fv3_ordered_sum: non-finite addend");
+    double rs = a < 0. ? -a : a;
+    for (int i = 0; i < NI; i++) {
+      const double iv = std::floor(rs * (1.0 / pr[i]));
+      rs = rs - iv * pr[i];
+      acc[i] += a < 0. ? -(__int128)iv : (__int128)iv;
+    }
+  }
+  auto carry = [&](__int128 *d) {
+    for (int i = NI - 1; i >= 1; i--) {
+      __int128 cy = d[i] >> NB;   // arithmetic shift = floor division: the remainder is in [0, 2^46)
+      d[i] -= cy << NB;
+      d[i - 1] += cy;
+    }
+  };
+  carry(acc);
+  long long dig[NI];
+  for (int i = 0; i < NI; i++) dig[i] = (long long)acc[i];
+  if (c && c->comm && c->comm_size > 1) {
+#ifdef FV3_HOST_EMU
+    return fail("fv3_ordered_sum: the host-emulation build has no RCCL");
+#else
+    long long *d = nullptr;
+    RT(rt_malloc((void **)&d, sizeof(long long) * NI));
+    RT(rt_h2d(d, dig, sizeof(long long) * NI, c->comm_stream));
+    NC(g_rccl.AllReduce(d, d, (size_t)NI, kNcclInt64, kNcclSum, c->comm, c->comm_stream));
+    RT(rt_d2h(dig, d, sizeof(long long) * NI, c->comm_stream));
+    RT(rt_sync(c->comm_stream));
+    rt_free(d);
+    for (int i = 0; i < NI; i++) acc[i] = dig[i];
+    carry(acc);
+    for (int i = 0; i < NI; i++) dig[i] = (long long)acc[i];
+#endif
+  }
+  double r = 0.;
+  for (int i = 0; i < NI; i++) r = r + pr[i] * (double)dig[i];
+  *sum = r;
+  return 0;
 }
 
 // ---- table-driven halo gather: the cubed-sphere face-to-face updates (index reversal, u <-> v with sign) ---------------------

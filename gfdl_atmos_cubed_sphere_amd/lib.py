@@ -33,7 +33,7 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_grid_upload_cubed", "fv3_gather_create", "fv3_gather_run", "fv3_gather_destroy", "fv3_grid_geom", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
-           "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_compute_total_energy", "fv3_energy_fixer_sums", "fv3_remap_finish", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max",
+           "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_compute_total_energy", "fv3_energy_fixer_sums", "fv3_remap_finish", "fv3_ordered_sum", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
@@ -459,6 +459,13 @@ class Context:
         self.lib.check(self.lib.dll.fv3_energy_fixer_sums(
             self.h, C.byref(s), C.c_int(int(only_sums)), u.p, v.p, _pp(w), _pp(delz), pt.p, delp.p, _pp(q), _pp(pe), _pp(peln),
             phis.p, pkz.p, _pp(pk), _pp(te0_2d), _pp(te_2d), zsum1.p, _pp(zsum0)), "fv3_energy_fixer_sums")
+
+    def ordered_sum(self, values) -> float:
+        """g_sum(..., reproduce=.true.) of host values over the ranks of the context's communicator (fv3_ordered_sum)"""
+        a = np.ascontiguousarray(values, dtype=np.float64).ravel()
+        out = C.c_double(0.0)
+        self.lib.check(self.lib.dll.fv3_ordered_sum(self.h, a.ctypes.data_as(_dp), C.c_size_t(a.size), C.byref(out)), "fv3_ordered_sum")
+        return out.value
 
     def remap_finish(self, par: dict, dtmp, pt, pkz, q):
         s = self._remap_params(par)

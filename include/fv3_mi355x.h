@@ -410,6 +410,11 @@ int fv3_set_ak_bk(fv3_ctx *ctx, const double *ak, const double *bk);
  *   fv3_remap_finish(dtmp) -- pt = (pt + dtmp/c * pkz) / (1 + r_vir*qv) in the three forms of :793-821 (c = cp, cvm, cv_air;
  *     nonhydrostatic adiabatic: nothing).  With adiabatic set the virtual factor is 1 (the reference's caller passes zvir = 0).
  *   remap_te = .true. is not built. */
+/* g_sum(domain, p, ..., area, mode = 0, reproduce = .true.) (model/fv_grid_utils.F90:2879-2925; = FMS mpp_global_sum with
+ * BITWISE_EFP_SUM): the reproducing sum of n HOST doubles (the caller's p*area of its compute domain) over the ranks of the
+ * context's communicator (ctx may be NULL / without a communicator: one rank).  Extended fixed point: integer digits, exact,
+ * independent of the order of the addends and of the rank layout. */
+int fv3_ordered_sum(fv3_ctx *ctx, const double *values, size_t n, double *sum);
 int fv3_compute_total_energy(fv3_ctx *ctx, const fv3_remap_params *p, int moist_phys, const double *u, const double *v,
                              const double *w, const double *delz, const double *pt, const double *delp, const double *q,
                              const double *qc, const double *pe, const double *peln, const double *phis, double *te_2d);

@@ -831,6 +831,25 @@ def test_total_energy_conservation(prod, kw):
     assert max(D.check_fv_cycle_consv(prod, **kw).values()) <= 1e-12
 
 
+def test_ordered_sum_is_exact_and_order_independent(prod):
+    """fv3_ordered_sum (g_sum with reproduce = .true.: the extended-fixed-point sum) against math.fsum and the host's own
+    implementation (global_sum.py), on addends spread over 23 orders of magnitude, permuted and split"""
+    import math
+    from gfdl_atmos_cubed_sphere_amd.global_sum import reproducing_sum
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    ctx = Context(P.make_grid(Bounds(1, 8, 1, 8), False), 5, lib=prod)
+    try:
+        rng = np.random.default_rng(1)
+        a = rng.normal(0, 1e9, 200000) * rng.choice([1e-14, 1.0, 1e9], 200000)
+        s = ctx.ordered_sum(a)
+        assert abs(s - math.fsum(a)) <= abs(s) * 2.3e-16
+        p_ = rng.permutation(a)
+        assert ctx.ordered_sum(p_) == s == reproducing_sum([p_[:777], p_[777:90000], p_[90000:]])
+    finally:
+        ctx.close()
+
+
 def test_cubed_sphere_total_energy_conservation(prod):
     """the same on the six faces (hydrostatic JW): global sums over the sphere"""
     assert max(PC.check_jw_consv(prod, npx=25).values()) <= 1e-12

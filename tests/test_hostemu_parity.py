@@ -4,6 +4,7 @@ the GPU-less build container; the real parity gate is tests/test_gpu_parity.py (
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 import parity_common as P
@@ -707,6 +708,25 @@ def test_total_energy_conservation(emu, kw):
     global sums, dtmp) and the final T_v -> T step with dtmp; a prescribed flux for consv_te < 0; the energy of the final state
     closes on the initial one"""
     assert max(D.check_fv_cycle_consv(emu, **kw).values()) <= 1e-12
+
+
+def test_ordered_sum_is_exact_and_order_independent(emu):
+    """fv3_ordered_sum (g_sum with reproduce = .true.: the extended-fixed-point sum) against math.fsum and the host's own
+    implementation (global_sum.py), on addends spread over 23 orders of magnitude, permuted and split"""
+    import math
+    from gfdl_atmos_cubed_sphere_amd.global_sum import reproducing_sum
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    ctx = Context(P.make_grid(Bounds(1, 8, 1, 8), False), 5, lib=emu)
+    try:
+        rng = np.random.default_rng(1)
+        a = rng.normal(0, 1e9, 200000) * rng.choice([1e-14, 1.0, 1e9], 200000)
+        s = ctx.ordered_sum(a)
+        assert abs(s - math.fsum(a)) <= abs(s) * 2.3e-16
+        p_ = rng.permutation(a)
+        assert ctx.ordered_sum(p_) == s == reproducing_sum([p_[:777], p_[777:90000], p_[90000:]])
+    finally:
+        ctx.close()
 
 
 def test_cubed_sphere_total_energy_conservation(emu):
