@@ -16,6 +16,7 @@ struct CubedGeom {
   const double *edge_w, *edge_e, *edge_s, *edge_n;  // A -> B interpolation weights on the face edges, (npy) / (npx), 1-based
   const double *rsina;                              // (is:ie+1, js:je+1)
   const double *a11, *a12, *a21, *a22;              // cubed_to_latlon matrix, A layout; null = not uploaded
+  const double *ec1, *ec2, *en1, *en2;              // adv_pe's unit vectors (3 planes each: A / FY / FX layouts); null = not uploaded
   double corner_f[12];                              // extrap_corner factors of a2b_ord4: sw, se, ne, nw x 3 pairs
   int ready;
 };

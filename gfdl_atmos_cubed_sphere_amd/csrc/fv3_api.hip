@@ -674,7 +674,7 @@ extern "C" int fv3_grid_upload_cubed(fv3_ctx *c, const fv3_grid_cubed *h) {
   const Grid &g = c->g;
   const size_t ne = (size_t)g.npx, nr = (size_t)(g.nx + 1) * (g.ny + 1);
   const size_t nr8 = (nr + 7) & ~(size_t)7;
-  const size_t total = 4 * ((ne + 7) & ~(size_t)7) + nr8 + 4 * g.nA();
+  const size_t total = 4 * ((ne + 7) & ~(size_t)7) + nr8 + 4 * g.nA() + 3 * (2 * g.nA() + g.nFY() + g.nFX());
   if (!c->cg_dev) RT(rt_malloc((void **)&c->cg_dev, total * sizeof(double)));
   double *p = c->cg_dev;
   const double *src[4] = {h->edge_w, h->edge_e, h->edge_s, h->edge_n};
@@ -695,6 +695,17 @@ extern "C" int fv3_grid_upload_cubed(fv3_ctx *c, const fv3_grid_cubed *h) {
       RT(rt_h2d(p, am[n], g.nA() * sizeof(double), c->stream));
       *ad[n] = p;
       p += g.nA();
+    }
+  }
+  c->cg.ec1 = c->cg.ec2 = c->cg.en1 = c->cg.en2 = nullptr;
+  if (h->ec1 && h->ec2 && h->en1 && h->en2) {
+    const double *am[4] = {h->ec1, h->ec2, h->en1, h->en2};
+    const double **ad[4] = {&c->cg.ec1, &c->cg.ec2, &c->cg.en1, &c->cg.en2};
+    const size_t sz[4] = {3 * g.nA(), 3 * g.nA(), 3 * g.nFY(), 3 * g.nFX()};
+    for (int n = 0; n < 4; n++) {
+      RT(rt_h2d(p, am[n], sz[n] * sizeof(double), c->stream));
+      *ad[n] = p;
+      p += sz[n];
     }
   }
   for (int n = 0; n < 12; n++) c->cg.corner_f[n] = h->corner_f[n];
@@ -2206,6 +2217,23 @@ extern "C" int fv3_omga_update(fv3_ctx *c, double rdt, double ptop, const double
   if (!c || !c->grid_ready || !pe || !delp_before || !omga) return fail("fv3_omga_update: bad context/arguments");
   OmgaUpdate kf{c->g, c->g.npz, rdt, ptop, pe, delp_before, omga};
   RT(launch_c(c, "omga_update", col_grid(c->g.nx * c->g.ny), kf));
+  return 0;
+}
+
+extern "C" int fv3_adv_pe(fv3_ctx *c, double ptop, const double *ua, const double *va, const double *delp_before, double *omga) {
+  if (!c || !c->grid_ready || !ua || !va || !delp_before || !omga) return fail("fv3_adv_pe: bad context/arguments");
+  const Grid &g = c->g;
+  if (g.grid_type >= 3) return fail("fv3_adv_pe: en1 / en2 are not defined for grid_type >= 3 (fv_grid_utils.F90:628)");
+  if (!(c->cg.ready && c->cg.ec1)) return fail("fv3_adv_pe: cubed-sphere face without ec1 .. en2 (fv3_grid_upload_cubed)");
+  if (need_scratch(c, 1)) return 1;
+  PemColumns kp{g, g.npz, ptop, delp_before, c->scratch[0]};
+  RT(launch_c(c, "adv_pe_pem", col_grid((g.nx + 2) * (g.ny + 2)), kp));
+  AdvPe kf{g, c->cg, g.npz, ua, va, c->scratch[0], omga};
+  Dim3 grid;
+  grid.x = (unsigned)((g.nx * g.ny + AdvPe::CH - 1) / AdvPe::CH);
+  grid.y = 1;
+  grid.z = (unsigned)g.npz;
+  RT(launch_p(c, "adv_pe", grid, 0, kf));
   return 0;
 }
 

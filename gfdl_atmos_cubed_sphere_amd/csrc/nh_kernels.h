@@ -1020,6 +1020,84 @@ struct Divg2Ext {  // dyn_core.F90:745-747, :791-797, :828-848
   }
 };
 
+// adv_pe (dyn_core.F90:1529-1632) on a cubed-sphere face.  (1) pem(k) = ptop + sum_{m<k} delp_before(m) on (is-1:ie+1, js-1:je+1),
+// levels 1..npz+1 of an A slab; (2) one thread per cell and level: corner pressures by a2b_ord2 (a2b_edge.F90:329-425), the
+// Green's-theorem gradient projected on the wind at the level's lower interface.
+struct PemColumns {
+  Grid g;
+  int km;
+  double ptop;
+  const double *delp;
+  double *pem;  // A x (km+1)
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int w = g.nx + 2, ncol = w * (g.ny + 2);
+    const size_t nA = g.nA();
+    FV3_COL_FOR(c, ncol) {
+      const int i = g.is - 1 + c % w, j = g.js - 1 + c / w;
+      const int o = g.iA(i, j);
+      double p = ptop;
+      pem[o] = p;
+      for (int k = 1; k <= km; k++) {
+        p = p + delp[(size_t)(k - 1) * nA + o];
+        pem[(size_t)k * nA + o] = p;
+      }
+    }
+  }
+};
+
+struct AdvPe {
+  Grid g;
+  CubedGeom cg;
+  int km;
+  const double *ua, *va, *pem;
+  double *om;
+  static constexpr int CH = 1024;
+  FV3_HD double corner(const double *pin, int i, int j) const {  // a2b_ord2, grid_type < 3, not a bounded domain
+    const int npx = g.npx, npy = g.npy;
+    auto Q = [&](int ii, int jj) { return pin[g.iA(ii, jj)]; };
+    if (i > 1 && i < npx && j > 1 && j < npy) return 0.25 * (Q(i - 1, j - 1) + Q(i, j - 1) + Q(i - 1, j) + Q(i, j));
+    constexpr double r3 = 1. / 3.;
+    if (i == 1 && j == 1) return r3 * (Q(1, 1) + Q(1, 0) + Q(0, 1));
+    if (i == npx && j == 1) return r3 * (Q(npx - 1, 1) + Q(npx - 1, 0) + Q(npx, 1));
+    if (i == npx && j == npy) return r3 * (Q(npx - 1, npy - 1) + Q(npx, npy - 1) + Q(npx - 1, npy));
+    if (i == 1 && j == npy) return r3 * (Q(1, npy - 1) + Q(0, npy - 1) + Q(1, npy));
+    if (i == 1 || i == npx) {
+      const int ia = (i == 1) ? 0 : npx - 1;
+      const double ew = (i == 1) ? cg.edge_w[j] : cg.edge_e[j];
+      const double qa = 0.5 * (Q(ia, j - 1) + Q(ia + 1, j - 1)), qb = 0.5 * (Q(ia, j) + Q(ia + 1, j));
+      return ew * qa + (1. - ew) * qb;
+    }
+    const int ja = (j == 1) ? 0 : npy - 1;
+    const double es = (j == 1) ? cg.edge_s[i] : cg.edge_n[i];
+    const double qa = 0.5 * (Q(i - 1, ja) + Q(i - 1, ja + 1)), qb = 0.5 * (Q(i, ja) + Q(i, ja + 1));
+    return es * qa + (1. - es) * qb;
+  }
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int k = bz + 1, n = g.nx * g.ny;
+    const size_t nA = g.nA(), nFX = g.nFX(), nFY = g.nFY();
+    const double *pin = pem + (size_t)k * nA;  // pem(:, k+1, :)
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.is + idx % g.nx, j = g.js + idx / g.nx;
+      const size_t o = g.iA(i, j), o3 = (size_t)(k - 1) * nA + o;
+      const double up = (k == km) ? ua[o3] : 0.5 * (ua[o3] + ua[o3 + nA]);
+      const double vp = (k == km) ? va[o3] : 0.5 * (va[o3] + va[o3 + nA]);
+      const double p00 = corner(pin, i, j), p10 = corner(pin, i + 1, j), p01 = corner(pin, i, j + 1), p11 = corner(pin, i + 1, j + 1);
+      const double dxs = g.dx[g.iU(i, j)], dxn = g.dx[g.iU(i, j + 1)], dyw = g.dy[g.iV(i, j)], dye = g.dy[g.iV(i + 1, j)];
+      double dot = 0.;
+      for (int m = 0; m < 3; m++) {
+        const double v3 = up * cg.ec1[(size_t)m * nA + o] + vp * cg.ec2[(size_t)m * nA + o];
+        const double pdx_s = (p00 + p10) * dxs * cg.en1[(size_t)m * nFY + g.iFY(i, j)];
+        const double pdx_n = (p01 + p11) * dxn * cg.en1[(size_t)m * nFY + g.iFY(i, j + 1)];
+        const double pdy_w = (p00 + p01) * dyw * cg.en2[(size_t)m * nFX + g.iFX(i, j)];
+        const double pdy_e = (p10 + p11) * dye * cg.en2[(size_t)m * nFX + g.iFX(i + 1, j)];
+        const double grad = pdx_n - pdx_s - pdy_w + pdy_e;
+        dot = (m == 0) ? v3 * grad : dot + v3 * grad;
+      }
+      om[o3] = om[o3] + 0.5 * g.rarea[o] * dot;
+    }
+  }
+};
+
 struct OneGradPHydro {  // dyn_core.F90:2002-2028 on precomputed corner values of pk, gz
   Grid g;
   double dt;

@@ -692,5 +692,13 @@ class CubedSphere:
         s5 = g["sin_sg"][..., 4]
         m["a11"], m["a12"] = F(0.5 * z22 / s5), F(-0.5 * z12 / s5)
         m["a21"], m["a22"] = F(-0.5 * z21 / s5), F(0.5 * z11 / s5)
+        # unit vectors of adv_pe (dyn_core.F90:1529): ec1, ec2 at the centres (A layout x 3, get_center_vect) and the edge normals
+        # en1 (is:ie, js:je+1) = grid3(i,j) x grid3(i+1,j), en2 (is:ie+1, js:je) = grid3(i,j+1) x grid3(i,j) (fv_grid_utils.F90:632-643)
+        g3 = g["grid3"]
+        o_, n_ = self.ng, self.npx - 1
+        c0 = g3[o_:o_ + n_ + 1, o_:o_ + n_ + 1]
+        m["ec1"], m["ec2"] = F(g["ec1"]), F(g["ec2"])
+        m["en1"] = F(_unit(_cross(c0[:-1, :], c0[1:, :])))
+        m["en2"] = F(_unit(_cross(c0[:, 1:], c0[:, :-1])))
         gs.tile = t
         return gs

@@ -313,6 +313,8 @@ class DynCore:
                     # :1182-1191: omga = (pe - pem)*rdt; pem = p of the delp this substep started from (:409-421), which
                     # the ping-pong left in delp_nxt
                     ctx.omga_update(rdt, fl.ptop, d["pe"], d["delp_nxt"], d["omga"])
+                    if ctx.grid.grid_type < 3 and "en1" in ctx.grid.m:         # :1195 adv_pe (en1 / en2 exist on the cubed sphere only)
+                        ctx.adv_pe(fl.ptop, d["ua"], d["va"], d["delp_nxt"], d["omga"])
         # ---- dissipative heating (:296-308, :1300-1355) ----
         n_con = self.n_con()
         if n_con != 0 and heating:

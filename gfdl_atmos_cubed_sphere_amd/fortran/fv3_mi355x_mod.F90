@@ -20,7 +20,7 @@ module fv3_mi355x_mod
   public :: fv3_divg2_ext, fv3_one_grad_p, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
   public :: fv3_grid_cubed, fv3_grid_upload_cubed, fv3_gather_create, fv3_gather_run, fv3_gather_destroy
   public :: fv3_comm_get_unique_id, fv3_comm_init, fv3_comm_destroy, fv3_halo_start, fv3_halo_complete, fv3_allreduce_max
-  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_rayleigh_super, fv3_compute_total_energy, fv3_energy_fixer_sums, fv3_remap_finish, fv3_ordered_sum, fv3_set_condensate, fv3_set_moist, fv3_moist_params
+  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_rayleigh_super, fv3_compute_total_energy, fv3_energy_fixer_sums, fv3_remap_finish, fv3_ordered_sum, fv3_adv_pe, fv3_set_condensate, fv3_set_moist, fv3_moist_params
 
   type, bind(C) :: fv3_domain
     integer(c_int) :: is, ie, js, je, ng, npx, npy, npz, grid_type
@@ -41,6 +41,7 @@ module fv3_mi355x_mod
     type(c_ptr) :: edge_w, edge_e, edge_s, edge_n, rsina
     real(c_double) :: corner_f(12)
     type(c_ptr) :: a11 = c_null_ptr, a12 = c_null_ptr, a21 = c_null_ptr, a22 = c_null_ptr   ! cubed_to_latlon matrix (A layout)
+    type(c_ptr) :: ec1 = c_null_ptr, ec2 = c_null_ptr, en1 = c_null_ptr, en2 = c_null_ptr   ! adv_pe's unit vectors (3 planes each)
   end type
 
   type, bind(C) :: fv3_dsw_params
@@ -297,6 +298,11 @@ module fv3_mi355x_mod
       integer(c_int), value :: kmax, conserve, hydrostatic
       real(c_double), value :: cp, rg, ptop
       real(c_double), intent(in) :: pm(*), rf(*)
+    end function
+    integer(c_int) function fv3_adv_pe(ctx, ptop, ua, va, delp_before, omga) bind(C, name="fv3_adv_pe")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, ua, va, delp_before, omga
+      real(c_double), value :: ptop
     end function
     integer(c_int) function fv3_ordered_sum(ctx, values, n, total) bind(C, name="fv3_ordered_sum")
       import :: c_int, c_ptr, c_double, c_size_t

@@ -33,7 +33,7 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_grid_upload_cubed", "fv3_gather_create", "fv3_gather_run", "fv3_gather_destroy", "fv3_grid_geom", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
-           "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_compute_total_energy", "fv3_energy_fixer_sums", "fv3_remap_finish", "fv3_ordered_sum", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max",
+           "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_compute_total_energy", "fv3_energy_fixer_sums", "fv3_remap_finish", "fv3_ordered_sum", "fv3_adv_pe", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
@@ -55,7 +55,7 @@ class _GridHost(C.Structure):
 
 class _GridCubed(C.Structure):
     _fields_ = [(n, _dp) for n in ["edge_w", "edge_e", "edge_s", "edge_n", "rsina"]] + [("corner_f", C.c_double * 12)] + [
-        (n, _dp) for n in ["a11", "a12", "a21", "a22"]]
+        (n, _dp) for n in ["a11", "a12", "a21", "a22", "ec1", "ec2", "en1", "en2"]]
 
 
 class _DswParams(C.Structure):
@@ -246,7 +246,8 @@ class Context:
         self.geom = int(self.lib.dll.fv3_grid_geom(self.h))  # 0 general, 1 orthogonal, 2 orthogonal + uniform
         if grid.grid_type < 3:      # a face of the cubed sphere: edge weights, rsina, corner extrapolation factors
             gc = _GridCubed()
-            for n in ("edge_w", "edge_e", "edge_s", "edge_n", "rsina") + (("a11", "a12", "a21", "a22") if "a11" in grid.m else ()):
+            for n in ("edge_w", "edge_e", "edge_s", "edge_n", "rsina") + (("a11", "a12", "a21", "a22") if "a11" in grid.m else ()) + \
+                    (("ec1", "ec2", "en1", "en2") if "en1" in grid.m else ()):
                 a = np.asfortranarray(grid.m[n], dtype=np.float64)
                 keep.append(a)
                 setattr(gc, n, a.ctypes.data_as(_dp))
@@ -530,6 +531,10 @@ class Context:
             C.c_double(rg), C.c_double(ptop), pm.ctypes.data_as(_dp), rf.ctypes.data_as(_dp), ua.p, va.p, pt.p, u.p, v.p,
             w.p if w is not None else None, u00.p if u00 is not None else None, v00.p if v00 is not None else None),
             "fv3_rayleigh_super")
+
+    def adv_pe(self, ptop, ua, va, delp_before, omga):
+        """adv_pe (dyn_core.F90:1195, :1529-1632): the advective term of omega on a cubed-sphere face"""
+        self.lib.check(self.lib.dll.fv3_adv_pe(self.h, C.c_double(ptop), ua.p, va.p, delp_before.p, omga.p), "fv3_adv_pe")
 
     # ---- hydrostatic pressure gradient (dyn_core.F90:828-848, :1021, :1001-1010) ------------------------------------
     def divg2_ext(self, d_ext, delp, vt, divg2):

@@ -76,6 +76,9 @@ typedef struct fv3_grid_cubed {
   /* cubed_to_latlon (init_cubed_to_latlon, fv_grid_utils.F90:2255-2315): a11, a12, a21, a22 on the A layout (isd:ied, jsd:jed);
    * NULL = fv3_c2l is not used on this face */
   const double *a11, *a12, *a21, *a22;
+  /* unit vectors of adv_pe (dyn_core.F90:1529-1632), component-last planes: ec1, ec2 (get_center_vect, fv_grid_utils.F90:1738)
+   * A layout x 3; en1 (is:ie, js:je+1) x 3 and en2 (is:ie+1, js:je) x 3 (:632-643).  NULL = fv3_adv_pe is not used */
+  const double *ec1, *ec2, *en1, *en2;
 } fv3_grid_cubed;
 
 const char *fv3_last_error(void);
@@ -287,6 +290,12 @@ int fv3_omga_update(fv3_ctx *ctx, double rdt, double ptop, const double *pe, con
  *   u, v updated in place (and multiplied by rdx, rdy); pk, gz (A x (npz+1)) are NOT modified (the reference
  *   replaces them by their corner interpolants, which nothing reads afterwards); divg2 may be NULL (d_ext <= 0).
  * copy_a_to_cc -- "pk = pkc" on the last substep (:1001-1010). */
+/* adv_pe (model/dyn_core.F90:1195, :1529-1632): the advective term of omega on a cubed-sphere face, added to omga (A x npz) on
+ * the compute domain after fv3_omga_update: om += 0.5*rarea * (V3 . grad pe) with pe at the corners by a2b_ord2 of pem, the edge
+ * pressures of the state the last substep started from (delp_before with its halo, as in fv3_omga_update; pem is formed on
+ * (is-1:ie+1, js-1:je+1)); ua, va: the A-grid winds c_sw left (A x npz).  Needs ec1 .. en2 of fv3_grid_cubed.  (On grid_type = 4
+ * the reference leaves en1 / en2 unset: not defined there.) */
+int fv3_adv_pe(fv3_ctx *ctx, double ptop, const double *ua, const double *va, const double *delp_before, double *omga);
 int fv3_divg2_ext(fv3_ctx *ctx, double d_ext, const double *delp, const double *vt, double *divg2);
 int fv3_one_grad_p(fv3_ctx *ctx, double *u, double *v, const double *pk, const double *gz, const double *divg2,
                    double dt, double ptk);

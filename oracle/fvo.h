@@ -75,6 +75,7 @@ typedef struct fvo_grid {
   const double *edge_w, *edge_e, *edge_s, *edge_n;
   double corner_f[12];
   const double *a11, *a12, *a21, *a22; /* cubed_to_latlon matrix (fv_grid_utils.F90:2255-2315), A layout; NULL = absent */
+  const double *ec1, *ec2, *en1, *en2; /* adv_pe's unit vectors, component-last planes (A / (is:ie,js:je+1) / (is:ie+1,js:je)) */
 } fvo_grid;
 
 /* ---- tp_core (model/tp_core.F90) ------------------------------------------------------- */
@@ -253,6 +254,8 @@ int fvo_rayleigh_u2f(const fvo_grid *g, int kmax, int hydrostatic, const double 
 int fvo_rayleigh_apply(const fvo_grid *g, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,
                        const double *pm, const double *rf, double *u2f, double *pt, double *delz, double *u, double *v,
                        double *w);
+/* adv_pe, dyn_core.F90:1529-1632 (cubed sphere): om += 0.5*rarea*(V3 . grad pe); pem from delp_before on (is-1:ie+1, js-1:je+1) */
+int fvo_adv_pe(const fvo_grid *g, int km, double ptop, const double *ua, const double *va, const double *delp_before, double *om);
 int fvo_rayleigh_super(const fvo_grid *g, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,
                        const double *pm, const double *rf, const double *ua, const double *va, double *pt, double *u,
                        double *v, double *w, const double *u00, const double *v00);

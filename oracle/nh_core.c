@@ -843,3 +843,69 @@ int fvo_one_grad_p_hydro(const fvo_grid *g, int npz, double dt, double ptk, cons
   }
   return FVO_OK;
 }
+
+/* adv_pe, model/dyn_core.F90:1529-1632 (called at :1195 on the last substep, use_old_omega): the advective term of omega on a
+ * face of the cubed sphere.  pem (is-1:ie+1, npz+1, js-1:je+1) as dyn_core forms it at :409-421 from the delp the substep started
+ * from; a2b_ord2 (a2b_edge.F90:329-425, grid_type < 3, not bounded) written out level by level as the reference calls it. */
+int fvo_adv_pe(const fvo_grid *g, int km, double ptop, const double *ua, const double *va, const double *delp_before, double *om) {
+  BOUNDS(g);
+  if (!(g->grid_type < 3) || !g->ec1 || !g->ec2 || !g->en1 || !g->en2) return FVO_ERR_UNSUPPORTED;
+  const int npx = g->npx, npy = g->npy;
+  const size_t nA = (size_t)nid * njd, nFX = (size_t)(nx + 1) * ny, nFY = (size_t)nx * (ny + 1);
+  const double r3 = 1. / 3.;
+  int i, j, k, n;
+  double *pin = (double *)calloc(nA, sizeof(double)), *pb = (double *)calloc(nA, sizeof(double));
+  double *pemc = (double *)calloc(nA, sizeof(double)); /* running pem(:, k+1, :) on the ring (is-1:ie+1, js-1:je+1) */
+  for (j = js - 1; j <= je + 1; j++)
+    for (i = is - 1; i <= ie + 1; i++) pemc[IA(i, j)] = ptop;
+  for (k = 1; k <= km; k++) {
+    for (j = js - 1; j <= je + 1; j++)
+      for (i = is - 1; i <= ie + 1; i++) {
+        pemc[IA(i, j)] = pemc[IA(i, j)] + delp_before[A3(i, j, k)];
+        pin[IA(i, j)] = pemc[IA(i, j)];
+      }
+    /* a2b_ord2(pin, pb) */
+    {
+      const int is1 = is - 1 > 1 ? is - 1 : 1, js1 = js - 1 > 1 ? js - 1 : 1, is2 = is > 2 ? is : 2, js2 = js > 2 ? js : 2;
+      const int ie1 = ie + 1 < npx - 1 ? ie + 1 : npx - 1, je1 = je + 1 < npy - 1 ? je + 1 : npy - 1;
+      (void)is1; (void)js1;
+      for (j = js2; j <= je1; j++)
+        for (i = is2; i <= ie1; i++) pb[IA(i, j)] = 0.25 * (pin[IA(i - 1, j - 1)] + pin[IA(i, j - 1)] + pin[IA(i - 1, j)] + pin[IA(i, j)]);
+      if (is == 1 && js == 1) pb[IA(1, 1)] = r3 * (pin[IA(1, 1)] + pin[IA(1, 0)] + pin[IA(0, 1)]);
+      if (ie + 1 == npx && js == 1) pb[IA(npx, 1)] = r3 * (pin[IA(npx - 1, 1)] + pin[IA(npx - 1, 0)] + pin[IA(npx, 1)]);
+      if (ie + 1 == npx && je + 1 == npy) pb[IA(npx, npy)] = r3 * (pin[IA(npx - 1, npy - 1)] + pin[IA(npx, npy - 1)] + pin[IA(npx - 1, npy)]);
+      if (is == 1 && je + 1 == npy) pb[IA(1, npy)] = r3 * (pin[IA(1, npy - 1)] + pin[IA(0, npy - 1)] + pin[IA(1, npy)]);
+      if (is == 1)
+        for (j = js2; j <= je1; j++)
+          pb[IA(1, j)] = g->edge_w[j - 1] * (0.5 * (pin[IA(0, j - 1)] + pin[IA(1, j - 1)])) + (1. - g->edge_w[j - 1]) * (0.5 * (pin[IA(0, j)] + pin[IA(1, j)]));
+      if (ie + 1 == npx)
+        for (j = js2; j <= je1; j++)
+          pb[IA(npx, j)] = g->edge_e[j - 1] * (0.5 * (pin[IA(npx - 1, j - 1)] + pin[IA(npx, j - 1)])) +
+                           (1. - g->edge_e[j - 1]) * (0.5 * (pin[IA(npx - 1, j)] + pin[IA(npx, j)]));
+      if (js == 1)
+        for (i = is2; i <= ie1; i++)
+          pb[IA(i, 1)] = g->edge_s[i - 1] * (0.5 * (pin[IA(i - 1, 0)] + pin[IA(i - 1, 1)])) + (1. - g->edge_s[i - 1]) * (0.5 * (pin[IA(i, 0)] + pin[IA(i, 1)]));
+      if (je + 1 == npy)
+        for (i = is2; i <= ie1; i++)
+          pb[IA(i, npy)] = g->edge_n[i - 1] * (0.5 * (pin[IA(i - 1, npy - 1)] + pin[IA(i - 1, npy)])) +
+                           (1. - g->edge_n[i - 1]) * (0.5 * (pin[IA(i, npy - 1)] + pin[IA(i, npy)]));
+    }
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie; i++) {
+        const double up = (k == km) ? ua[A3(i, j, km)] : 0.5 * (ua[A3(i, j, k)] + ua[A3(i, j, k + 1)]);
+        const double vp = (k == km) ? va[A3(i, j, km)] : 0.5 * (va[A3(i, j, k)] + va[A3(i, j, k + 1)]);
+        double v3[3], grad[3];
+        for (n = 0; n < 3; n++) {
+          v3[n] = up * g->ec1[(size_t)n * nA + IA(i, j)] + vp * g->ec2[(size_t)n * nA + IA(i, j)];
+          const double pdx0 = (pb[IA(i, j)] + pb[IA(i + 1, j)]) * g->dx[IU(i, j)] * g->en1[(size_t)n * nFY + IFY(i, j)];
+          const double pdx1 = (pb[IA(i, j + 1)] + pb[IA(i + 1, j + 1)]) * g->dx[IU(i, j + 1)] * g->en1[(size_t)n * nFY + IFY(i, j + 1)];
+          const double pdy0 = (pb[IA(i, j)] + pb[IA(i, j + 1)]) * g->dy[IV(i, j)] * g->en2[(size_t)n * nFX + IFX(i, j)];
+          const double pdy1 = (pb[IA(i + 1, j)] + pb[IA(i + 1, j + 1)]) * g->dy[IV(i + 1, j)] * g->en2[(size_t)n * nFX + IFX(i + 1, j)];
+          grad[n] = pdx1 - pdx0 - pdy0 + pdy1;
+        }
+        om[A3(i, j, k)] = om[A3(i, j, k)] + 0.5 * g->rarea[IA(i, j)] * (v3[0] * grad[0] + v3[1] * grad[1] + v3[2] * grad[2]);
+      }
+  }
+  free(pin); free(pb); free(pemc);
+  return FVO_OK;
+}

@@ -34,7 +34,7 @@ class FvoGrid(C.Structure):
         + [("lim_fac", C.c_double), ("do_diss_est", C.c_int), ("prevent_diss_cooling", C.c_int),
            ("do_f3d", C.c_int)]
         + [(n, _dp) for n in ["edge_w", "edge_e", "edge_s", "edge_n"]] + [("corner_f", C.c_double * 12)] \
-        + [(n, _dp) for n in ["a11", "a12", "a21", "a22"]]
+        + [(n, _dp) for n in ["a11", "a12", "a21", "a22", "ec1", "ec2", "en1", "en2"]]
     )
 
 
@@ -119,6 +119,9 @@ def make_grid(g) -> FvoGrid:
             s.corner_f[k] = v
         if "a11" in g.m:
             for n in ("a11", "a12", "a21", "a22"):
+                setattr(s, n, p(g.m[n]))
+        if "en1" in g.m:
+            for n in ("ec1", "ec2", "en1", "en2"):
                 setattr(s, n, p(g.m[n]))
         s._keep_edges = keep
     s._keep = g  # keep the numpy arrays alive
@@ -401,6 +404,11 @@ def rayleigh_u2f(g, kmax, hydrostatic, u, v, w, ua, va, u2f):
     gs = make_grid(g)
     assert lib().fvo_rayleigh_u2f(C.byref(gs), C.c_int(kmax), C.c_int(int(hydrostatic)), p(u), p(v),
                                   p(w) if w is not None else None, p(ua), p(va), p(u2f)) == 0
+
+
+def adv_pe(g, km, ptop, ua, va, delp_before, om):
+    gs = make_grid(g)
+    assert lib().fvo_adv_pe(C.byref(gs), C.c_int(km), _d(ptop), p(ua), p(va), p(delp_before), p(om)) == 0
 
 
 def rayleigh_super(g, kmax, conserve, hydrostatic, cp, rg, ptop, pm, rf, ua, va, pt, u, v, w, u00=None, v00=None):

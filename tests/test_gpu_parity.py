@@ -855,6 +855,11 @@ def test_cubed_sphere_total_energy_conservation(prod):
     assert max(PC.check_jw_consv(prod, npx=25).values()) <= 1e-12
 
 
+def test_cubed_adv_pe(prod):
+    """the advective term of the omega diagnostic on the six faces (adv_pe, dyn_core.F90:1195, :1529-1632)"""
+    assert PC.check_adv_pe(prod, npx=25) <= 1e-14
+
+
 def test_cubed_del2_cubed_and_damped_transports(prod):
     assert PC.check_del2_cubed(prod, npx=25, npz=4, nmax=3) <= P.TOL
     for kw in (dict(nord=2, damp_c=0.05), dict(nord=2, damp_c=0.05, mass_flux=True)):

@@ -734,6 +734,11 @@ def test_cubed_sphere_total_energy_conservation(emu):
     assert max(PC.check_jw_consv(emu, npx=13).values()) <= 1e-12
 
 
+def test_cubed_adv_pe(emu):
+    """the advective term of the omega diagnostic on the six faces (adv_pe, dyn_core.F90:1195, :1529-1632)"""
+    assert PC.check_adv_pe(emu, npx=13) <= 1e-14
+
+
 def test_cubed_del2_cubed_and_damped_transports(emu):
     for nmax in (1, 2, 3):
         assert PC.check_del2_cubed(emu, nmax=nmax) <= P.TOL
