@@ -223,3 +223,87 @@ def jablonowski_williamson(cs: CubedSphere, ak, bk, hydrostatic: bool = True, pe
             d["delz"] = F(RDGAS / GRAV * pt[s, s, :] * (peln[:-1] - peln[1:])[None, None, :])
         out.append(d)
     return out
+
+
+def supercell_sounding(pk1, ps=1.0e5, kappa=2.0 / 7.0, rdgas=287.04, grav=9.80, rvgas=461.50):
+    """SuperCell_Sounding (tools/test_cases.F90:6500-6616): the Weisman & Klemp sounding on the model levels.  pk1: layer-mean
+    p**kappa of the column; returns (temperature, specific humidity) per layer.  401 height levels of 50 m, three passes of the
+    hydrostatic integration with the virtual effect, saturation by the routine's own formula (:6578)."""
+    pk1 = np.asarray(pk1, dtype=np.float64)
+    ns, nx_ = 401, 3
+    cp_air = rdgas / kappa
+    tmin, p00, qst, qv0, ztr, ttr, ptr, pt0 = 175.0, 1.0e5, 3.0e-6, 1.4e-2, 12.0e3, 213.0, 343.0, 300.0
+    zvir = rvgas / rdgas - 1.0
+    pk0 = p00 ** kappa
+    zs = 50.0 * np.arange(ns - 1, -1, -1, dtype=np.float64)           # zs(ns) = 0 at the surface
+    qs = np.full(ns, qst)
+    rh = np.full(ns, 0.25)
+    pt = np.empty(ns)
+    strat = zs > ztr
+    pt[strat] = ptr * np.exp(grav * (zs[strat] - ztr) / (cp_air * ttr))
+    fac = (zs[~strat] / ztr) ** 1.25
+    pt[~strat] = pt0 + (ptr - pt0) * fac
+    rh[~strat] = 1.0 - 0.75 * fac
+    qs[~strat] = qv0 - (qv0 - qst) * fac
+    pt = pt / pk0
+    pk = np.empty(ns)
+    pk[-1] = ps ** kappa
+    for _ in range(nx_):
+        temp1 = 0.5 * (pt[:-1] * (1.0 + zvir * qs[:-1]) + pt[1:] * (1.0 + zvir * qs[1:]))
+        dpk = grav * (zs[:-1] - zs[1:]) / (cp_air * temp1)
+        for k in range(ns - 2, -1, -1):
+            pk[k] = pk[k + 1] - dpk[k]
+        if np.any(pk <= 0.0):
+            raise FloatingPointError("Super-Cell case: pk < 0")
+        t1 = pt * pk
+        pp = np.exp(np.log(pk) / kappa)
+        qs = np.minimum(qv0, rh * (380.0 / pp * np.exp(17.27 * (t1 - 273.0) / (t1 - 36.0))))
+    tp, qp = np.empty_like(pk1), np.empty_like(pk1)
+    for k, x in enumerate(pk1):
+        if x <= pk[0]:
+            tp[k], qp[k] = pt[0] * pk[0] / x, qst
+        elif x >= pk[-1]:
+            tp[k], qp[k] = pt[-1], qs[-1]
+        else:
+            kk = int(np.searchsorted(pk, x, side="left")) - 1
+            kk = min(max(kk, 0), ns - 2)
+            f = (x - pk[kk]) / (pk[kk + 1] - pk[kk])
+            tp[k], qp[k] = pt[kk] + (pt[kk + 1] - pt[kk]) * f, qs[kk] + (qs[kk + 1] - qs[kk]) * f
+    return np.maximum(tmin, tp * pk1), qp
+
+
+def supercell(bd, npz, ak, bk, dx_const, dy_const, npx_global=None, npy_global=None, umean=25.0, bubble=True, dt_amp=2.0,
+              dt_rad=10.0e3, kappa=2.0 / 7.0, rdgas=287.04, grav=9.80, rvgas=461.50):
+    """test_case = 17 of init_double_periodic (tools/test_cases.F90:4966-5057): the doubly periodic supercell with a straight wind
+    -- the Weisman-Klemp sounding on the levels, u = Umean*tanh(z/3 km) - Umean/2, v = w = 0, hydrostatic delz from the virtual
+    temperature (p_var), a warm bubble of dt_amp K and radius dt_rad in the middle of the domain.  BASELINE config 4's initial
+    condition.  (Umean is a namelist value the reference tree does not default; 25 m/s is the Weisman-Klemp wind.)  Returns the
+    fields of this rank's block bd with halos unfilled: u, v, w, delp, pt (TEMPERATURE), delz, phis, q (A x npz x 1: vapour)."""
+    ak, bk = np.asarray(ak, dtype=np.float64), np.asarray(bk, dtype=np.float64)
+    ptop, p00 = float(ak[0]), 1000.0e2
+    zvir = rvgas / rdgas - 1.0
+    pe = ak + p00 * bk
+    peln = np.log(pe)
+    pk = np.exp(kappa * peln)
+    pk1 = (pk[1:] - pk[:-1]) / (kappa * (peln[1:] - peln[:-1]))
+    ts1, qs1 = supercell_sounding(pk1, p00, kappa, rdgas, grav, rvgas)
+    dp = (ak[1:] - ak[:-1]) + p00 * (bk[1:] - bk[:-1])
+    delz1 = (rdgas / grav) * ts1 * (1.0 + zvir * qs1) * (peln[:-1] - peln[1:])          # p_var, make_nh (negative)
+    ze1 = np.concatenate([np.cumsum((-delz1)[::-1])[::-1], [0.0]])
+    zm = 0.5 * (ze1[:-1] + ze1[1:])
+    out = {"u": bd.zeros("U", npz), "v": bd.zeros("V", npz), "w": bd.zeros("A", npz), "delp": bd.zeros("A", npz),
+           "pt": bd.zeros("A", npz), "delz": bd.zeros("CC", npz), "phis": bd.zeros("A"), "q": np.zeros(bd.shape("A", npz) + (1,), order="F")}
+    out["u"][...] = (umean * np.tanh(zm / 3.0e3) - 0.5 * umean)[None, None, :]
+    out["delp"][...] = dp[None, None, :]
+    out["pt"][...] = ts1[None, None, :]
+    out["delz"][...] = delz1[None, None, :]
+    out["q"][..., 0] = qs1[None, None, :]
+    if bubble:
+        npx = npx_global if npx_global is not None else bd.nx + 1
+        npy = npy_global if npy_global is not None else bd.ny + 1
+        ic, jc, zc = (npx - 1) // 2 + 1, (npy - 1) // 2 + 1, 1.4e3
+        ii = np.arange(bd.is_ - bd.ng, bd.ie + bd.ng + 1, dtype=np.float64)[:, None, None]
+        jj = np.arange(bd.js - bd.ng, bd.je + bd.ng + 1, dtype=np.float64)[None, :, None]
+        dist = ((zm - zc) / zc)[None, None, :] ** 2 + ((ii - ic) * dx_const / dt_rad) ** 2 + ((jj - jc) * dy_const / dt_rad) ** 2
+        out["pt"] += dt_amp * np.maximum(1.0 - np.sqrt(dist), 0.0)
+    return out

@@ -520,3 +520,61 @@ def check_fv_cycle_consv(lib, nx=24, ny=16, npz=10, k_split=2, n_split=2, bdt=8.
     finally:
         ctx.close()
     return out
+
+
+def check_supercell_step(lib, nx=48, ny=32, npz=32, k_split=1, n_split=3, bdt=9.0, dxy=1000.0, flags=None):
+    """BASELINE config 4's initial condition in small: the doubly periodic supercell (test_case = 17, tools/test_cases.F90:4966-5057:
+    Weisman-Klemp sounding, sheared wind, warm bubble, water vapour as tracer 1) through a whole nonhydrostatic fv_dynamics call
+    (T -> theta_v with the virtual effect, k_split x (n_split substeps, tracer_2d, remap), back to T) against the oracle loop"""
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.grid import doubly_periodic
+    from gfdl_atmos_cubed_sphere_amd.layout import periodic_fill
+    from gfdl_atmos_cubed_sphere_amd.lib import GRAV, KAPPA, RDGAS
+    from gfdl_atmos_cubed_sphere_amd.test_cases import supercell
+    bd = Bounds(1, nx, 1, ny)
+    g = doubly_periodic(bd, nx + 1, ny + 1, dx_const=dxy, dy_const=dxy)
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.3
+    ptop = 2000.0
+    ak, bk = ptop * (1.0 - sig), sig.copy()
+    st = supercell(bd, npz, ak, bk, dxy, dxy, dt_rad=8.0 * dxy)
+    q = st.pop("q")
+    for n, kind in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A")):
+        for k in range(npz):
+            periodic_fill(bd, st[n][:, :, k], kind)
+    for k in range(npz):
+        periodic_fill(bd, q[:, :, k, 0], "A")
+    r = (bd.is_, bd.ie, bd.js, bd.je)
+    ng = bd.ng
+    c = (slice(ng, ng + nx), slice(ng, ng + ny))
+    zvir = 0.6077
+    dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
+    fl = DynFlags(n_split=n_split, ptop=ptop, **(flags or {}))
+    T = st["pt"]
+    assert T[c].max() - np.median(T[c][:, :, -4]) > 0.5        # the bubble is there
+    dp1 = zvir * q[c + (slice(None), 0)]
+    pkz = O.fexp(KAPPA * O.flog((-RDGAS / GRAV) * st["delp"][c] * T[c] * (1.0 + dp1) / st["delz"])).reshape(dp1.shape)
+    th = T.copy(order="F")
+    th[c] = T[c] * (1.0 + dp1) / pkz
+    for k in range(npz):
+        periodic_fill(bd, th[:, :, k], "A")
+    ctx = Context(g, npz, lib=lib)
+    out = {}
+    try:
+        fv = FvDynamics(ctx, fl, ak, bk, nq=1, k_split=k_split, adiabatic=False, c2l_ord=2)
+        ref = oracle_fv_step(g, npz, fl, dp_ref, dict(st, pt=th), ak, bk, q, bdt, k_split, dict(fv.remap_par), last_step=True)
+        fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], T, st["delz"], st["phis"])
+        fv.set_tracers(q)
+        fv.step_from_temperature(bdt)
+        d = fv.dc.d
+        for n, kind in (("pt", "A"), ("delp", "A"), ("w", "A"), ("u", "U")):
+            rr = r if kind == "A" else (bd.is_, bd.ie, bd.js, bd.je + 1)
+            out[n] = P.assert_close(n, bd.view(d[n].download(), kind, *rr), bd.view(ref[n], kind, *rr), 1e-12)
+        out["q"] = P.assert_close("q", bd.view(d["q"].download()[:, :, :, 0], "A", *r), bd.view(ref["q"][:, :, :, 0], "A", *r), 1e-12)
+        w = bd.view(d["w"].download(), "A", *r)
+        assert np.all(np.isfinite(w)) and np.max(np.abs(w)) > 1e-4          # the bubble rises
+        area = dxy * dxy
+        m0, m1 = np.sum(st["delp"][c]) * area, np.sum(bd.view(d["delp"].download(), "A", *r)) * area
+        assert abs(m1 - m0) <= 1e-13 * m0                                   # the air mass of the periodic domain
+    finally:
+        ctx.close()
+    return out

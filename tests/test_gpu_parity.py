@@ -860,6 +860,12 @@ def test_cubed_adv_pe(prod):
     assert PC.check_adv_pe(prod, npx=25) <= 1e-14
 
 
+def test_config4_supercell_initial_condition(prod):
+    """BASELINE configs[3]'s initial condition (doubly periodic supercell, test_case = 17: Weisman-Klemp sounding, sheared wind, warm
+    bubble, vapour) through a whole nonhydrostatic fv_dynamics call against the oracle loop; air mass to rounding, the bubble rises"""
+    assert max(D.check_supercell_step(prod, nx=96, ny=64, npz=64).values()) <= 1e-12
+
+
 def test_cubed_del2_cubed_and_damped_transports(prod):
     assert PC.check_del2_cubed(prod, npx=25, npz=4, nmax=3) <= P.TOL
     for kw in (dict(nord=2, damp_c=0.05), dict(nord=2, damp_c=0.05, mass_flux=True)):
