@@ -742,7 +742,7 @@ def test_cubed_adv_pe(emu):
 def test_config4_supercell_initial_condition(emu):
     """BASELINE configs[3]'s initial condition (doubly periodic supercell, test_case = 17: Weisman-Klemp sounding, sheared wind, warm
     bubble, vapour) through a whole nonhydrostatic fv_dynamics call against the oracle loop; air mass to rounding, the bubble rises"""
-    assert max(D.check_supercell_step(emu, nx=32, ny=24, npz=16, n_split=2, bdt=6.0).values()) <= 1e-12
+    assert max(D.check_supercell_step(emu, nx=24, ny=16, npz=12, n_split=2, bdt=6.0).values()) <= 1e-12
 
 
 def test_cubed_del2_cubed_and_damped_transports(emu):
