@@ -56,6 +56,9 @@ module fv3_arrays_compat_mod
     logical :: convert_ke = .false., hydrostatic = .true., adiabatic = .false., fill = .false.
     logical :: do_diss_est = .false., prevent_diss_cooling = .false., do_f3d = .false., inline_q = .false.
     logical :: nested = .false., regional = .false.
+    real(c_double) :: tau = 0.d0, rf_cutoff = 30.d2
+    logical :: RF_fast = .false., consv_am = .false., do_sat_adj = .false., moist_phys = .true.
+    integer :: c2l_ord = 4, nwat = 3
   end type
 
   type fv_nest_type
@@ -74,6 +77,14 @@ module fv3_arrays_compat_mod
     integer :: pe = 0
   end type
 
+  type fv_atmos_type                          ! fv_arrays.F90:1270: only its presence in fv_dynamics' list (parent_grid) matters here
+    integer :: grid_number = 1
+  end type
+
+  type inline_mp_type                         ! fv_arrays.F90: inline microphysics diagnostics (not on this path)
+    integer :: unused = 0
+  end type
+
   type group_halo_update_type                 ! fv_mp_mod.F90:646-876: the halo groups live behind fv3_halo_* / fv3_halo_fill_periodic
     integer :: id = 0
   end type
@@ -87,10 +98,12 @@ module fv3_dyn_core_mod
   use fv3_host_mod
   implicit none
   private
-  public :: dyn_core, dyn_core_end
+  public :: dyn_core, dyn_core_end, fv_dynamics, fv_dynamics_end
 
   type(fv3_atmos), save :: at
   logical, save :: bound = .false.
+  type(fv3_atmos), save :: atf          ! fv_dynamics keeps a context of its own (it carries the tracers)
+  logical, save :: boundf = .false.
 
 contains
 
@@ -256,6 +269,203 @@ contains
       bound = .true.
     end subroutine
   end subroutine dyn_core
+
+  !> fv_dynamics with the reference's argument list (model/fv_dynamics.F90:79-85) for an adiabatic-core call: T -> theta_v
+  !> (:284-399), the k_split loop (dyn_core, tracer_2d, Lagrangian_to_Eulerian with last_step on the final cycle, :460-665),
+  !> cubed_to_latlon (:911), over the resident fv3_fv_dynamics of fv3_host_mod.  Host arrays in, host arrays out, like dyn_core
+  !> above.  error stop: consv_te, tau > 0 (the Python host carries the energy fixer and the Rayleigh damping), nesting,
+  !> use_cond / moist_kappa, consv_am, hybrid_z, grid_type /= 4.
+  subroutine fv_dynamics(npx, npy, npz, nq_tot, ng, bdt, consv_te, fill, &
+                         reproduce_sum, kappa, cp_air, zvir, ptop, ks, ncnst, n_split, &
+                         q_split, u0, v0, u, v, w, delz, hydrostatic, pt, delp, q, &
+                         ps, pe, pk, peln, pkz, phis, q_con, omga, ua, va, uc, vc, &
+                         ak, bk, mfx, mfy, cx, cy, ze0, hybrid_z, &
+                         gridstruct, flagstruct, neststruct, thermostruct, idiag, bd, &
+                         parent_grid, domain, inline_mp, heat_source, diss_est, time_total)
+    real(c_double), intent(in) :: bdt, consv_te, kappa, cp_air, zvir, ptop
+    real(c_double), intent(in), optional :: time_total
+    integer, intent(in) :: npx, npy, npz, nq_tot, ng, ks, ncnst, n_split, q_split
+    logical, intent(in) :: fill, reproduce_sum, hydrostatic, hybrid_z
+    type(fv_grid_bounds_type), intent(in) :: bd
+    real(c_double), intent(inout), dimension(bd%isd:, bd%jsd:, 1:) :: u0, v0
+    real(c_double), intent(inout), target :: u(bd%isd:bd%ied, bd%jsd:bd%jed+1, npz), v(bd%isd:bd%ied+1, bd%jsd:bd%jed, npz)
+    real(c_double), intent(inout) :: w(bd%isd:, bd%jsd:, 1:)
+    real(c_double), intent(inout), target :: pt(bd%isd:bd%ied, bd%jsd:bd%jed, npz), delp(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
+    real(c_double), intent(inout), target :: q(bd%isd:bd%ied, bd%jsd:bd%jed, npz, ncnst)
+    real(c_double), intent(inout) :: delz(bd%is:, bd%js:, 1:), ze0(bd%is:, bd%js:, 1:)
+    real(c_double), intent(inout) :: diss_est(bd%isd:bd%ied, bd%jsd:bd%jed, npz), heat_source(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
+    real(c_double), intent(inout), target :: ps(bd%isd:bd%ied, bd%jsd:bd%jed)
+    real(c_double), intent(inout), target :: pe(bd%is-1:bd%ie+1, npz+1, bd%js-1:bd%je+1)
+    real(c_double), intent(inout), target :: pk(bd%is:bd%ie, bd%js:bd%je, npz+1), peln(bd%is:bd%ie, npz+1, bd%js:bd%je)
+    real(c_double), intent(inout), target :: pkz(bd%is:bd%ie, bd%js:bd%je, npz)
+    real(c_double), intent(inout) :: q_con(bd%isd:, bd%jsd:, 1:)
+    real(c_double), intent(inout), target :: phis(bd%isd:bd%ied, bd%jsd:bd%jed), omga(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
+    real(c_double), intent(inout), target :: uc(bd%isd:bd%ied+1, bd%jsd:bd%jed, npz), vc(bd%isd:bd%ied, bd%jsd:bd%jed+1, npz)
+    real(c_double), intent(inout), target, dimension(bd%isd:bd%ied, bd%jsd:bd%jed, npz) :: ua, va
+    real(c_double), intent(in) :: ak(npz+1), bk(npz+1)
+    type(inline_mp_type), intent(inout) :: inline_mp
+    real(c_double), intent(inout), target :: mfx(bd%is:bd%ie+1, bd%js:bd%je, npz), mfy(bd%is:bd%ie, bd%js:bd%je+1, npz)
+    real(c_double), intent(inout), target :: cx(bd%is:bd%ie+1, bd%jsd:bd%jed, npz), cy(bd%isd:bd%ied, bd%js:bd%je+1, npz)
+    type(fv_grid_type), intent(inout), target :: gridstruct
+    type(fv_flags_type), intent(inout) :: flagstruct
+    type(fv_nest_type), intent(inout) :: neststruct
+    type(domain2d), intent(inout) :: domain
+    type(fv_atmos_type), pointer, intent(in) :: parent_grid
+    type(fv_diag_type), intent(in) :: idiag
+    type(fv_thermo_type), intent(inout) :: thermostruct
+
+    real(c_double), allocatable, target :: w_c(:,:,:), delz_c(:,:,:), zs(:,:)
+    integer(c_size_t) :: nk, nk1
+    integer :: nx, ny
+    type(c_ptr) :: qv
+
+    if (neststruct%nested .or. gridstruct%nested .or. gridstruct%regional .or. gridstruct%bounded_domain) &
+      error stop 'fv_dynamics (fv3_dyn_core_mod): nested / regional domains are not built'
+    if (gridstruct%grid_type /= 4) error stop 'fv_dynamics (fv3_dyn_core_mod): grid_type = 4 only through this wrapper'
+    if (thermostruct%use_cond .or. thermostruct%moist_kappa) &
+      error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond / moist_kappa are not carried through this wrapper'
+    if (abs(consv_te) > 0.001d0) error stop 'fv_dynamics (fv3_dyn_core_mod): consv_te is carried by the Python host (FvDynamics), not here'
+    if (flagstruct%tau > 0.d0) error stop 'fv_dynamics (fv3_dyn_core_mod): tau > 0 (Rayleigh damping) is carried by the Python host, not here'
+    if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%do_diss_est .or. flagstruct%beta > 0.d0) &
+      error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / do_diss_est / beta > 0 are not built'
+    if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
+    if (.not. boundf) call bind_context()
+    if (atf%npz /= npz .or. atf%nq /= nq_tot .or. atf%ie /= bd%ie .or. atf%je /= bd%je) &
+      error stop 'fv_dynamics (fv3_dyn_core_mod): the domain changed between calls'
+    atf%fl%n_split = n_split; atf%fl%q_split = q_split
+    nx = bd%ie - bd%is + 1; ny = bd%je - bd%js + 1
+    nk = int(npz, c_size_t); nk1 = nk + 1
+
+    call put(atf%u, c_loc(u), atf%nU*nk);        call put(atf%v, c_loc(v), atf%nV*nk)
+    call put(atf%delp, c_loc(delp), atf%nA*nk);  call put(atf%pt, c_loc(pt), atf%nA*nk)
+    call put(atf%phis, c_loc(phis), atf%nA)
+    allocate(zs(bd%isd:bd%ied, bd%jsd:bd%jed))
+    zs = phis * (1.d0 / atf%fl%grav)
+    call put(atf%zs, c_loc(zs), atf%nA)
+    if (.not. hydrostatic) then
+      allocate(w_c(bd%isd:bd%ied, bd%jsd:bd%jed, npz), delz_c(bd%is:bd%ie, bd%js:bd%je, npz))
+      w_c = w(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz); delz_c = delz(bd%is:bd%ie, bd%js:bd%je, 1:npz)
+      call put(atf%w, c_loc(w_c), atf%nA*nk);    call put(atf%delz, c_loc(delz_c), atf%nCC*nk)
+    end if
+    if (nq_tot > 0) call put(atf%q, c_loc(q), atf%nA*nk*nq_tot)
+    call put(atf%pkz, c_loc(pkz), atf%nCC*nk);   call put(atf%pk, c_loc(pk), atf%nCC*nk1)
+    call put(atf%pe, c_loc(pe), int(nx+2, c_size_t)*nk1*(ny+2)); call put(atf%peln, c_loc(peln), atf%nCC*nk1)
+    call put(atf%omga, c_loc(omga), atf%nA*nk)
+    call fv3_check(fv3_sync(atf%ctx), 'fv3_sync')
+
+    ! :284-399: pkz (nonhydrostatic) and pt = pt*(1 + zvir*q(sphum))/pkz
+    qv = c_null_ptr
+    if (zvir > 0.d0 .and. nq_tot > 0) qv = atf%q
+    if (hydrostatic) then
+      call fv3_check(fv3_pt_to_theta_v(atf%ctx, 1_c_int, zvir, kappa, atf%fl%rdgas, atf%fl%grav, atf%pt, atf%delp, c_null_ptr, qv, &
+                                       atf%pkz), 'fv3_pt_to_theta_v')
+    else
+      call fv3_check(fv3_pt_to_theta_v(atf%ctx, 0_c_int, zvir, kappa, atf%fl%rdgas, atf%fl%grav, atf%pt, atf%delp, atf%delz, qv, &
+                                       atf%pkz), 'fv3_pt_to_theta_v')
+    end if
+    call fv3_fv_dynamics(atf, bdt, .true.)                               ! :460-665
+    if (flagstruct%c2l_ord == 4) then                                    ! :911, fv_grid_utils.F90:2372-2376
+      call fv3_host_halo(atf, atf%u, 1, npz); call fv3_host_halo(atf, atf%v, 2, npz)
+    end if
+    call fv3_check(fv3_c2l(atf%ctx, int(flagstruct%c2l_ord, c_int), atf%u, atf%v, atf%ua, atf%va), 'fv3_c2l')
+
+    call fv3_check(fv3_sync(atf%ctx), 'fv3_sync')
+    call get(c_loc(u), atf%u, atf%nU*nk);        call get(c_loc(v), atf%v, atf%nV*nk)
+    call get(c_loc(delp), atf%delp, atf%nA*nk);  call get(c_loc(pt), atf%pt, atf%nA*nk)
+    if (.not. hydrostatic) then
+      call get(c_loc(w_c), atf%w, atf%nA*nk);    call get(c_loc(delz_c), atf%delz, atf%nCC*nk)
+    end if
+    if (nq_tot > 0) call get(c_loc(q), atf%q, atf%nA*nk*nq_tot)
+    call get(c_loc(ps), atf%ps, atf%nA)
+    call get(c_loc(pkz), atf%pkz, atf%nCC*nk);   call get(c_loc(pk), atf%pk, atf%nCC*nk1)
+    call get(c_loc(pe), atf%pe, int(nx+2, c_size_t)*nk1*(ny+2)); call get(c_loc(peln), atf%peln, atf%nCC*nk1)
+    call get(c_loc(omga), atf%omga, atf%nA*nk);  call get(c_loc(ua), atf%ua, atf%nA*nk); call get(c_loc(va), atf%va, atf%nA*nk)
+    call get(c_loc(uc), atf%uc, atf%nV*nk);      call get(c_loc(vc), atf%vc, atf%nU*nk)
+    call get(c_loc(mfx), atf%mfx, atf%nFX*nk);   call get(c_loc(mfy), atf%mfy, atf%nFY*nk)
+    call get(c_loc(cx), atf%cx, atf%nCX*nk);     call get(c_loc(cy), atf%cy, atf%nCY*nk)
+    call fv3_check(fv3_sync(atf%ctx), 'fv3_sync')
+    if (.not. hydrostatic) then
+      w(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz) = w_c; delz(bd%is:bd%ie, bd%js:bd%je, 1:npz) = delz_c
+    end if
+
+  contains
+
+    subroutine put(d, h, n)
+      type(c_ptr), intent(in) :: d, h
+      integer(c_size_t), intent(in) :: n
+      call fv3_check(fv3_memcpy_h2d(atf%ctx, d, h, n * 8_c_size_t), 'fv3_memcpy_h2d')
+    end subroutine
+
+    subroutine get(h, d, n)
+      type(c_ptr), intent(in) :: d, h
+      integer(c_size_t), intent(in) :: n
+      call fv3_check(fv3_memcpy_d2h(atf%ctx, h, d, n * 8_c_size_t), 'fv3_memcpy_d2h')
+    end subroutine
+
+    subroutine bind_context()
+      type(fv3_domain) :: dom
+      type(fv3_grid_host) :: gh
+      type(fv3_flags) :: fl
+      dom%is = bd%is; dom%ie = bd%ie; dom%js = bd%js; dom%je = bd%je; dom%ng = 3
+      dom%npx = npx; dom%npy = npy; dom%npz = npz; dom%grid_type = gridstruct%grid_type
+      dom%do_diss_est = 0; dom%prevent_diss_cooling = merge(1, 0, flagstruct%prevent_diss_cooling)
+      dom%stretched_grid = merge(1, 0, gridstruct%stretched_grid); dom%lim_fac = flagstruct%lim_fac
+      call grid_host_of(gridstruct, gh)
+      call flags_of(flagstruct, fl)
+      fl%n_split = n_split; fl%q_split = q_split; fl%ptop = ptop; fl%akap = kappa; fl%cp_air = cp_air
+      fl%hydrostatic = hydrostatic; fl%fill = fill; fl%r_vir = zvir
+      call fv3_host_init_grid(atf, dom, gh, nq_tot, fl, ak, bk)
+      boundf = .true.
+    end subroutine
+  end subroutine fv_dynamics
+
+  subroutine fv_dynamics_end()
+    if (boundf) call fv3_host_final(atf)
+    boundf = .false.
+  end subroutine
+
+  !> gridstruct members by address -> the host-pointer structure of fv3_grid_upload
+  subroutine grid_host_of(gridstruct, gh)
+    type(fv_grid_type), intent(in), target :: gridstruct
+    type(fv3_grid_host), intent(out) :: gh
+    gh%da_min = gridstruct%da_min;        gh%da_min_c = gridstruct%da_min_c
+    gh%area = c_loc(gridstruct%area);     gh%rarea = c_loc(gridstruct%rarea)
+    gh%dxa = c_loc(gridstruct%dxa);       gh%dya = c_loc(gridstruct%dya)
+    gh%rdxa = c_loc(gridstruct%rdxa);     gh%rdya = c_loc(gridstruct%rdya)
+    gh%cosa_s = c_loc(gridstruct%cosa_s); gh%rsin2 = c_loc(gridstruct%rsin2);   gh%f0 = c_loc(gridstruct%f0)
+    gh%dx = c_loc(gridstruct%dx);         gh%rdx = c_loc(gridstruct%rdx)
+    gh%dyc = c_loc(gridstruct%dyc);       gh%rdyc = c_loc(gridstruct%rdyc)
+    gh%cosa_v = c_loc(gridstruct%cosa_v); gh%sina_v = c_loc(gridstruct%sina_v); gh%rsin_v = c_loc(gridstruct%rsin_v)
+    gh%divg_u = c_loc(gridstruct%divg_u); gh%del6_u = c_loc(gridstruct%del6_u)
+    gh%dy = c_loc(gridstruct%dy);         gh%rdy = c_loc(gridstruct%rdy)
+    gh%dxc = c_loc(gridstruct%dxc);       gh%rdxc = c_loc(gridstruct%rdxc)
+    gh%cosa_u = c_loc(gridstruct%cosa_u); gh%sina_u = c_loc(gridstruct%sina_u); gh%rsin_u = c_loc(gridstruct%rsin_u)
+    gh%divg_v = c_loc(gridstruct%divg_v); gh%del6_v = c_loc(gridstruct%del6_v)
+    gh%rarea_c = c_loc(gridstruct%rarea_c); gh%fC = c_loc(gridstruct%fC)
+    gh%cosa = c_loc(gridstruct%cosa);     gh%sina = c_loc(gridstruct%sina)
+    gh%sin_sg = c_loc(gridstruct%sin_sg); gh%cos_sg = c_loc(gridstruct%cos_sg)
+  end subroutine
+
+  !> flagstruct -> the host's fv3_flags (the members with the same names)
+  subroutine flags_of(flagstruct, fl)
+    type(fv_flags_type), intent(in) :: flagstruct
+    type(fv3_flags), intent(inout) :: fl
+    fl%k_split = flagstruct%k_split;   fl%q_split = flagstruct%q_split
+    fl%nord = flagstruct%nord;          fl%d4_bg = flagstruct%d4_bg;       fl%d2_bg = flagstruct%d2_bg
+    fl%d2_bg_k1 = flagstruct%d2_bg_k1;  fl%d2_bg_k2 = flagstruct%d2_bg_k2; fl%dddmp = flagstruct%dddmp
+    fl%vtdm4 = flagstruct%vtdm4;        fl%d_con = flagstruct%d_con;       fl%ke_bg = flagstruct%ke_bg
+    fl%do_vort_damp = flagstruct%do_vort_damp; fl%use_logp = flagstruct%use_logp
+    fl%use_old_omega = flagstruct%use_old_omega; fl%is_ideal_case = flagstruct%is_ideal_case
+    fl%n_sponge = flagstruct%n_sponge
+    fl%hord_mt = flagstruct%hord_mt;    fl%hord_vt = flagstruct%hord_vt;   fl%hord_tm = flagstruct%hord_tm
+    fl%hord_dp = flagstruct%hord_dp;    fl%hord_tr = flagstruct%hord_tr
+    fl%kord_tm = flagstruct%kord_tm;    fl%kord_mt = flagstruct%kord_mt;   fl%kord_wz = flagstruct%kord_wz
+    fl%kord_tr = flagstruct%kord_tr;    fl%nord_tr = flagstruct%nord_tr;   fl%trdm2 = flagstruct%trdm2
+    fl%a_imp = flagstruct%a_imp;        fl%p_fac = flagstruct%p_fac
+    fl%adiabatic = flagstruct%adiabatic; fl%fill = flagstruct%fill
+    fl%d_ext = flagstruct%d_ext;        fl%delt_max = flagstruct%delt_max
+    fl%convert_ke = flagstruct%convert_ke
+  end subroutine
 
   !> release the context dyn_core bound at its first call
   subroutine dyn_core_end()

@@ -20,7 +20,7 @@ module fv3_host_mod
   implicit none
   private
   public :: fv3_flags, fv3_atmos
-  public :: fv3_host_init, fv3_host_init_grid, fv3_host_final, fv3_host_upload, fv3_host_download
+  public :: fv3_host_halo, fv3_host_init, fv3_host_init_grid, fv3_host_final, fv3_host_upload, fv3_host_download
   public :: fv3_dyn_core, fv3_dyn_core_hydrostatic, fv3_tracer_2d, fv3_fv_dynamics
 
   integer(c_int), parameter :: KIND_A = 0, KIND_U = 1, KIND_V = 2, KIND_B = 3
@@ -111,6 +111,14 @@ contains
     else
       call fv3_check(fv3_halo_fill_periodic(at%ctx, field, kind, int(nk, c_int)), 'fv3_halo_fill_periodic')
     end if
+  end subroutine
+
+  !> the same for callers outside this module (kind: 0 = A, 1 = U, 2 = V, 3 = B)
+  subroutine fv3_host_halo(at, field, kind, nk)
+    type(fv3_atmos), intent(in) :: at
+    type(c_ptr), intent(in) :: field
+    integer, intent(in) :: kind, nk
+    call halo(at, field, int(kind, c_int), nk)
   end subroutine
 
   !> the communicator of the exchange behind the C ABI: rank 0 makes the id, a several-rank host broadcasts it (MPI_Bcast)

@@ -3,12 +3,18 @@
 !> init_grid fill them for grid_type = 4 (fv_grid_tools.F90:1202-1221, fv_grid_utils.F90:427, :656-665), `nsteps` calls
 !> of dyn_core(...) with the reference's 60-odd arguments.  Same input file as fv3_solo (the tracers are ignored).
 !> output: real64 u, v, w, delp, pt, delz, mfx, cx, pkz
+!> With a third argument `fv_dynamics`: `nsteps` calls of fv_dynamics(...) (model/fv_dynamics.F90:79-85; pt of the file is then a
+!> TEMPERATURE, the tracers are read and transported; adiabatic: zvir = 0).  output: u, v, w, delp, pt, delz, q, ua
 program fv3_solo_refsig
   use iso_c_binding
   use fv3_arrays_compat_mod
   use fv3_dyn_core_mod
   implicit none
-  character(len=1024) :: fin, fout
+  character(len=1024) :: fin, fout, mode
+  type(fv_atmos_type), pointer :: parent_grid => null()
+  type(inline_mp_type) :: inline_mp
+  real(c_double), allocatable :: ps(:,:), u0(:,:,:), v0(:,:,:), ze0(:,:,:)
+  logical :: whole
   integer(c_int) :: nx, ny, npz, nq, n_split, k_split, nsteps, last_step, ihydro
   real(c_double) :: dxc_, dyc_, f0_, bdt, ptop, d_con, d_ext
   real(c_double), allocatable :: ak(:), bk(:), pfull(:)
@@ -29,6 +35,9 @@ program fv3_solo_refsig
 
   call get_command_argument(1, fin)
   call get_command_argument(2, fout)
+  mode = ' '
+  if (command_argument_count() >= 3) call get_command_argument(3, mode)
+  whole = trim(mode) == 'fv_dynamics'
   open(newunit=un, file=trim(fin), access='stream', form='unformatted', status='old')
   read(un) nx, ny, npz, nq, n_split, k_split, nsteps, last_step, ihydro
   read(un) dxc_, dyc_, f0_, bdt, ptop, d_con, d_ext
@@ -42,14 +51,23 @@ program fv3_solo_refsig
   allocate(u(isd:ied, jsd:jed+1, npz), v(isd:ied+1, jsd:jed, npz), w(isd:ied, jsd:jed, npz), delp(isd:ied, jsd:jed, npz))
   allocate(pt(isd:ied, jsd:jed, npz), delz(nx, ny, npz), phis(isd:ied, jsd:jed))
   read(un) u, v, w, delp, pt, delz, phis
+  if (whole .and. nq > 0) then
+    allocate(q(isd:ied, jsd:jed, npz, nq))
+    read(un) q
+  else
+    allocate(q(isd:ied, jsd:jed, npz, 1))
+    q = 0.d0
+  end if
   close(un)
-  allocate(q(isd:ied, jsd:jed, npz, 1), cappa(isd:ied, jsd:jed, 1), q_con(isd:ied, jsd:jed, 1))
+  allocate(cappa(isd:ied, jsd:jed, 1), q_con(isd:ied, jsd:jed, 1))
+  allocate(ps(isd:ied, jsd:jed), u0(isd:ied, jsd:jed+1, 1), v0(isd:ied+1, jsd:jed, 1), ze0(nx, ny, 1))
+  ps = 0.d0; u0 = 0.d0; v0 = 0.d0; ze0 = 0.d0
   allocate(heat_source(isd:ied, jsd:jed, npz), diss_est(isd:ied, jsd:jed, npz))
   allocate(pe(0:nx+1, npz+1, 0:ny+1), peln(nx, npz+1, ny), pk(nx, ny, npz+1), ws(nx, ny), te0_2d(nx, ny))
   allocate(omga(isd:ied, jsd:jed, npz), uc(isd:ied+1, jsd:jed, npz), vc(isd:ied, jsd:jed+1, npz))
   allocate(ua(isd:ied, jsd:jed, npz), va(isd:ied, jsd:jed, npz))
   allocate(mfx(nx+1, ny, npz), mfy(nx, ny+1, npz), cx(nx+1, jsd:jed, npz), cy(isd:ied, ny+1, npz), pkz(nx, ny, npz))
-  q = 0.d0; cappa = 0.d0; q_con = 0.d0; heat_source = 0.d0; diss_est = 0.d0; pe = 0.d0; peln = 0.d0; pk = 0.d0; ws = 0.d0
+  cappa = 0.d0; q_con = 0.d0; heat_source = 0.d0; diss_est = 0.d0; pe = 0.d0; peln = 0.d0; pk = 0.d0; ws = 0.d0
   te0_2d = 0.d0; omga = 0.d0; uc = 0.d0; vc = 0.d0; ua = 0.d0; va = 0.d0; mfx = 0.d0; mfy = 0.d0; cx = 0.d0; cy = 0.d0; pkz = 0.d0
   do n = 1, npz
     pfull(n) = 0.5d0 * (ak(n) + ak(n+1) + (bk(n) + bk(n+1)) * 1.d5)
@@ -82,6 +100,27 @@ program fv3_solo_refsig
   fs%d2_bg_k1 = 0.20d0; fs%d2_bg_k2 = 0.015d0; fs%a_imp = 1.d0; fs%d_con = d_con; fs%d_ext = d_ext
   fs%prevent_diss_cooling = .true.; fs%adiabatic = .true.
 
+  if (whole) then
+    fs%c2l_ord = 4
+    if (hydrostatic) pkz = 1.d0     ! the state p_var would have left: here the file's pt is theta already (pkz = 1 <=> T = theta)
+    do n = 1, nsteps
+      call fv_dynamics(nx + 1, ny + 1, int(npz), int(nq), 3, bdt, 0.d0, .false., &
+                       .false., KAPPA, CP_AIR, 0.d0, ptop, 0, max(1, int(nq)), int(n_split), &
+                       0, u0, v0, u, v, w, delz, hydrostatic, pt, delp, q, &
+                       ps, pe, pk, peln, pkz, phis, q_con, omga, ua, va, uc, vc, &
+                       ak, bk, mfx, mfy, cx, cy, ze0, .false., &
+                       gs, fs, ns, ts, idiag, bd, &
+                       parent_grid, domain, inline_mp, heat_source, diss_est)
+    end do
+    call fv_dynamics_end()
+    open(newunit=un, file=trim(fout), access='stream', form='unformatted', status='replace')
+    write(un) u, v, w, delp, pt, delz
+    if (nq > 0) write(un) q
+    write(un) ua
+    close(un)
+    write(*,'(a,es24.16)') 'fv3_solo_refsig: done, sum(delp) = ', sum(delp(1:nx, 1:ny, :))
+    stop
+  end if
   do n = 1, nsteps
     call dyn_core(nx + 1, ny + 1, int(npz), 3, 1, 0, bdt, 1, int(n_split), 0.d0, CP_AIR, KAPPA, cappa, GRAV, hydrostatic, &
                   u, v, w, delz, pt, q, delp, pe, pk, phis, ws, omga, ptop, pfull, ua, va, &

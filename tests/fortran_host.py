@@ -174,3 +174,70 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
         assert np.all(np.isfinite(a)), n
         assert np.array_equal(a, b), f"{n}: reference-signature dyn_core and the Python host differ (max abs {np.max(np.abs(a - b)):.3e})"
     return r.stdout
+
+
+def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, hydrostatic=False):
+    """fv_dynamics called with the reference's argument list on host arrays (fv3_dyn_core_mod::fv_dynamics, driver fv3_solo_refsig in
+    its fv_dynamics mode: T -> theta_v, k_split x (dyn_core, tracer_2d, remap), last_step, cubed_to_latlon) against the Python host's
+    FvDynamics.step_from_temperature on the same state: u, v, w, delp, pt (T), delz, the tracers and ua bit-identical"""
+    import parity_common as P
+    import parity_dyn as D
+    import parity_nh as N
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    st, _ = D.make_state(bd, npz)
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+    ak, bk = N.PTOP * (1.0 - sig), sig.copy()
+    rng = np.random.default_rng(5)
+    q = np.asfortranarray(rng.uniform(0.0, 1.0, bd.shape("A", npz) + (nq,))) if nq else None
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic)
+    ctx = Context(g, npz, lib=lib)
+    try:
+        fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=k_split, adiabatic=True, c2l_ord=4)
+        fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
+        if nq:
+            fv.set_tracers(q)
+        if hydrostatic:       # the hydrostatic conversion takes pkz as the state holds it: 1 here (the file's pt is theta), as in the driver
+            fv.dc.d["pkz"].upload(np.asfortranarray(np.ones(bd.shape("CC", npz))))
+        for _ in range(nsteps):
+            fv.step_from_temperature(bdt)
+        d = fv.dc.d
+        ref = {n: d[n].download() for n in (("u", "v", "delp", "pt", "ua") if hydrostatic else ("u", "v", "w", "delp", "pt", "delz", "ua"))}
+        if nq:
+            ref["q"] = d["q"].download()
+    finally:
+        ctx.close()
+    exe = build_refsig(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
+    fin, fout = os.path.join(str(workdir), "in_fd.bin"), os.path.join(str(workdir), "out_fd.bin")
+    write_input(fin, bd, npz, nq, n_split, k_split, nsteps, True, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak, bk, st, q,
+                hydrostatic=hydrostatic, d_con=0.0, d_ext=fl.d_ext)
+    r = subprocess.run([exe, fin, fout, "fv_dynamics"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = {}
+    with open(fout, "rb") as f:
+        for n, kind in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC")):
+            shp = bd.shape(kind, npz)
+            got[n] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+        if nq:
+            shp = bd.shape("A", npz) + (nq,)
+            got["q"] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+        shp = bd.shape("A", npz)
+        got["ua"] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+    i0, i1, j0, j1 = bd.is_, bd.ie, bd.js, bd.je
+    rng_ = {"u": ("U", i0, i1, j0, j1 + 1), "v": ("V", i0, i1 + 1, j0, j1), "w": ("A", i0, i1, j0, j1),
+            "delp": ("A", i0, i1, j0, j1), "pt": ("A", i0, i1, j0, j1), "ua": ("A", i0, i1, j0, j1)}
+    for n in ref:
+        if n in rng_:
+            kind, *r4 = rng_[n]
+            a, b = bd.view(got[n], kind, *r4), bd.view(ref[n], kind, *r4)
+        elif n == "q":
+            a, b = got[n][bd.ng:bd.ng + nx, bd.ng:bd.ng + ny], ref[n][bd.ng:bd.ng + nx, bd.ng:bd.ng + ny]
+        else:
+            a, b = got[n], ref[n]
+        assert np.all(np.isfinite(a)), n
+        assert np.array_equal(a, b), f"{n}: reference-signature fv_dynamics and the Python host differ (max abs {np.max(np.abs(a - b)):.3e})"
+    return r.stdout

@@ -467,6 +467,10 @@ def test_fortran_dyn_core_with_the_reference_argument_list(prod, tmp_path):
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=12, d_con=1.0)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=12, hydrostatic=True, d_con=1.0)
+    # fv_dynamics with ITS reference argument list (model/fv_dynamics.F90:79-85): T -> theta_v, the k_split loop with tracers and
+    # the remap, last_step, cubed_to_latlon
+    assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path)
+    assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, hydrostatic=True, npz=12, nq=1)
 
 
 @pytest.mark.parametrize("use_cond,moist_kappa", [(True, False), (True, True), (False, True)])
