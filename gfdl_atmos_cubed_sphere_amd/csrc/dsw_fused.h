@@ -68,8 +68,9 @@ struct Tp2dField {
 template <int HORD, bool NH, bool COURANT, int GM = 0>
 struct DswTransportFused {
   static constexpr bool UNI = (GM == 2);
-  // 330 registers with the metric rows, 272 without: one wavefront per SIMD either way (squeezing the latter into the
-  // 256 of two wavefronts costs 14 spills, gains nothing and leaves no room for the sponge-level kernels of the side stream)
+  // 330 registers with the metric rows (one wavefront per SIMD), 246-250 with uniform metrics (two: -Rpass-analysis=kernel-resource-usage).
+  // Grouping the row steps (rotation by renaming) was measured: 256 + 26 AGPRs and one wavefront, or 22-26 spills at two -- slower
+  // either way
   Grid g;
   DswArgs a;
   MarchDims md;

@@ -3,9 +3,11 @@
 the sub-cycled tracer transport (``tracer_2d``) and the vertical remap (``Lagrangian_to_Eulerian``).
 
 ``step`` expects the state in the form ``dyn_core`` works on (pt = theta_v, delz < 0); ``step_from_temperature`` is a whole
-``fv_dynamics`` call of the adiabatic core on a Cartesian domain: T -> theta_v (fv_dynamics.F90:296-399), Rayleigh_Friction
-when tau > 0 (:368-376, :1126-1264), the k_split loop, theta_v -> T in the last remap, cubed_to_latlon (:911).
-compute_total_energy / consv_te, the angular-momentum fixer and the diagnostics are SURVEY section 8(f) items not built.
+``fv_dynamics`` call on a Cartesian domain or on the six faces of the sphere: compute_total_energy when consv_te > 0 (:345), T ->
+theta_v / theta_m (fv_dynamics.F90:296-399, with moist_cv under use_cond / moist_kappa), the Rayleigh damping when tau > 0
+(:362-371: Rayleigh_Super on the cubed sphere and in ideal cases, Rayleigh_Friction otherwise), the k_split loop, the energy
+fixer and theta_v -> T in the last remap, cubed_to_latlon (:911).  The angular-momentum fixer (consv_am), nudging and the
+diagnostics (:669-803) are not built.
 """
 from __future__ import annotations
 
