@@ -16,17 +16,19 @@
  *               generator tests/golden/make_ppm1d_golden.py).
  *               set_eta (L79, L127; restated in the package's test_cases.py) against the reference's own stand-alone
  *               fv_eta.F90 compiled here (oracle/Makefile target `ref` -> oracle/_ref/, tests/golden/set_eta_golden.npz).
- *   unpinned  : everything else (fv_tp_2d, c_sw, d_sw, column solvers, remap).  The reference
+ *   unpinned  : everything else (fv_tp_2d, c_sw, d_sw, column solvers, remap incl. ppm_profile, compute_total_energy and the
+ *               energy fixer, Rayleigh_Super / _Friction, adv_pe, cubed_to_latlon).  The reference
  *               ships no unit tests / golden vectors, and its Fortran
  *               cannot be built here without writing stand-ins for the absent FMS library,
  *               which the build rules forbid.  Those operators are pinned only by the
- *               reference's conservation identities (tests/test_oracle_properties.py).
+ *               reference's conservation identities and other size-independent properties (tests/test_oracle_properties.py:
+ *               column integrals / constants / linear profiles under every remap profile family; tests/parity_*.py: global
+ *               mass on the six faces, energy closure of the fixer, the O(h^2) closure of adv_pe's uniform-pressure term).
  *
  * Scope of the restated branches: grid_type 4 (doubly periodic) and grid_type < 3 (the cubed sphere, one whole tile per
  * face: the edge / corner branches of c_sw, d_sw, fv_tp_2d, xppm / yppm, xtp_u / ytp_v, a2b_ord4, update_dz_c / _d), with
  * general (array-valued) metric terms, bounded_domain = .false., no nesting, no regional BCs.  Branches that are not
- * restated (the cubed-sphere deln_flux / del6 damping with nord > 0, a2b_ord2, c2l on the sphere) return
- * FVO_ERR_UNSUPPORTED.
+ * restated (remap_te, inline_q, beta > 0, kord_wz < 0) return FVO_ERR_UNSUPPORTED.
  *
  * Array layout is the reference's (Fortran column-major, i fastest), with the exact
  * lower/upper bounds of model/fv_arrays.F90:1521-1563; see the accessor macros below.
