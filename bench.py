@@ -43,6 +43,9 @@ ALG = {
     "d_sw_momentum": (104.0, "rest_m"),
 }
 PAIR_ALG_BYTES = 336.0       # perfectly fused c_sw+d_sw, NH
+# untimed passes before the profiled pass and the W warm-up steps (FV3_BENCH_SPINUP): the clocks of an idle MI355X take a few
+# hundred launches to settle
+SPINUP = int(os.environ.get("FV3_BENCH_SPINUP", "0"))
 
 
 def level_sets(lev):
@@ -484,7 +487,7 @@ def main():
         geom = ctx.geom
         ctx.profile(True)
         nprof = 10
-        for _ in range(3):          # untimed, unprofiled: code objects loaded, clocks up
+        for _ in range(3 + SPINUP):  # untimed, unprofiled: code objects loaded, clocks up
             step()
         ctx.profile_report()
         for _ in range(nprof):
