@@ -98,3 +98,34 @@ def test_two_ranks_with_exchange_overlap_split():
     ok = mp.get_context("spawn").Array("i", [0] * world)
     mp.spawn(_worker, args=(world, port, ok, 120, 22, 3, 8), nprocs=world, join=True)
     assert list(ok) == [1] * world
+
+
+def _sum_worker(rank, world, port, ok):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import math
+        from gfdl_atmos_cubed_sphere_amd.global_sum import reproducing_sum
+        rng = np.random.default_rng(9)
+        a = rng.normal(0, 1e9, 30000) * rng.choice([1e-14, 1.0, 1e9], 30000)        # the same array on every rank
+        cuts = [0, 11111, 30000] if world == 2 else [0, 5000, 12000, 29000, 30000]
+        s = reproducing_sum([a[cuts[rank]:cuts[rank + 1]]], dist)
+        assert s == reproducing_sum([a]) and abs(s - math.fsum(a)) <= abs(s) * 2.3e-16, (s, math.fsum(a))
+        ok[rank] = 1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_reproducing_sum_does_not_depend_on_the_rank_layout(world):
+    """g_sum(reproduce=.true.) of the energy fixer: the digits of the extended-fixed-point sum all-reduced as integers -- the sum
+    over 2 or 4 ranks of differently sized pieces equals the one-rank sum bit for bit"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ok = mp.get_context("spawn").Array("i", [0] * world)
+    mp.spawn(_sum_worker, args=(world, port, ok), nprocs=world, join=True)
+    assert list(ok) == [1] * world
