@@ -87,10 +87,10 @@ FV3_HD void ppm_cell_mono_cs(const Q &q, const D &d, int ic, int iord, int npx, 
     const double xt = 1.5 * dm0;
     bl = -fsign(dmin(fabs(xt), fabs(al0 - q0)), xt);
     br = fsign(dmin(fabs(xt), fabs(al1 - q0)), xt);
-  } else if (iord == 12 || iord == 9 || iord == 13) {
+  } else if (iord == 12 || iord == 7 || iord == 9 || iord == 13) {
     bl = al0 - q0;
     br = al1 - q0;
-    const bool pert = iord != 12;
+    const bool pert = iord != 12 && iord != 7;
     if (pert && q0 <= 0.) {
       bl = 0.;
       br = 0.;
@@ -129,6 +129,22 @@ FV3_HD void ppm_cell_mono_cs(const Q &q, const D &d, int ic, int iord, int npx, 
 template <class Q, class D>
 FV3_HD double ppm_face_cs(const Q &q, const D &d, int i, double c, int iord, int npx) {
   constexpr double r12 = 1. / 12., p1 = 7. / 12., p2 = -1. / 12., c1 = -2. / 14., c2 = 11. / 14., c3 = 5. / 14.;
+  if (iord == 7) {  // :685-699: both cells of the face, the flux form of the unlimited family
+    double blm, brm, bl0, br0;
+    ppm_cell_mono_cs(q, d, i - 1, iord, npx, blm, brm);
+    ppm_cell_mono_cs(q, d, i, iord, npx, bl0, br0);
+    const bool sm = blm * brm < 0., s0 = bl0 * br0 < 0.;
+    double fx1, flux;
+    if (c > 0.) {
+      fx1 = (1. - c) * (brm - c * (blm + brm));
+      flux = q(i - 1);
+    } else {
+      fx1 = (1. + c) * (bl0 + c * (bl0 + br0));
+      flux = q(i);
+    }
+    if (sm || s0) flux = flux + fx1;
+    return flux;
+  }
   if (iord >= 8) {
     const int ic = (c > 0.) ? i - 1 : i;
     double bl, br;

@@ -773,7 +773,7 @@ extern "C" int fv3_fv_tp_2d(fv3_ctx *c, int nk, const double *q, const double *c
                             const double *ra_y, const double *mfx, const double *mfy, const double *mass, int nord,
                             double damp_c) {
   if (!c || !c->grid_ready) return fail("fv3_fv_tp_2d: context has no grid (call fv3_grid_upload)");
-  if (!tp_ord_supported_tr(hord)) return fail("fv3_fv_tp_2d: hord=%d not supported (5,-5,6,8,9,10,11,12,13)", hord);
+  if (!tp_ord_supported_tr(hord)) return fail("fv3_fv_tp_2d: hord=%d not supported (5,-5,6,7,8,9,10,11,12,13)", hord);
   if (nord > 2) return fail("fv3_fv_tp_2d: nord=%d > 2", nord);
   if ((mfx == nullptr) != (mfy == nullptr)) return fail("fv3_fv_tp_2d: mfx and mfy must be given together");
   if (is_cubed(c)) {
@@ -904,6 +904,7 @@ static int dispatch_hord(int hord, Fn &&fn) {
 template <class Fn>
 static int dispatch_hord_tr(int hord, Fn &&fn) {
   switch (hord) {
+    case 7: return fn(std::integral_constant<int, 7>());
     case 9:
     case 13: return fn(std::integral_constant<int, 9>());
     case 11: return fn(std::integral_constant<int, 11>());
@@ -2566,7 +2567,7 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
                                   const double *mfx, const double *mfy, const double *cx, const double *cy,
                                   const double *xfx, const double *yfx) {
   if (!c || !c->grid_ready || !ksplt_host) return fail("fv3_tracer_2d_step: bad context/arguments");
-  if (!tp_ord_supported_tr(hord)) return fail("fv3_tracer_2d_step: hord=%d not supported (5,-5,6,8,9,10,11,12,13)", hord);
+  if (!tp_ord_supported_tr(hord)) return fail("fv3_tracer_2d_step: hord=%d not supported (5,-5,6,7,8,9,10,11,12,13)", hord);
   if (q == q_out || dp1 == dp1_out) return fail("fv3_tracer_2d_step: *_out buffers must not alias the inputs");
   if (trdm > 1.e-4 && nord_tr > 2) return fail("fv3_tracer_2d_step: nord_tr > 2");
   if (need_trc(c)) return 1;

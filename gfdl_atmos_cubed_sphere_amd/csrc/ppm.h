@@ -19,7 +19,7 @@ namespace fv3 {
 inline bool tp_ord_supported(int iord) { return iord == 5 || iord == -5 || iord == 6 || iord == 8 || iord == 10; }
 // fv_tp_2d as a unit and tracer_2d also take the positive-definite / van Leer members of the monotone family:
 // 9 == 13 (unlimited + pert_ppm), 11 (ppm_fac slopes), 12 (Lin & Rood 1996 positive definite) -- tp_core.F90:604-641
-inline bool tp_ord_supported_tr(int iord) { return tp_ord_supported(iord) || iord == 9 || iord == 11 || iord == 12 || iord == 13; }
+inline bool tp_ord_supported_tr(int iord) { return tp_ord_supported(iord) || iord == 7 || iord == 9 || iord == 11 || iord == 12 || iord == 13; }
 inline bool sw_ord_supported(int iord) { return iord >= 5 && iord <= 11; }
 
 // monotone slope, tp_core.F90:570-574 == sw_core.F90:2383-2387.  s[0] is the cell.
@@ -34,6 +34,39 @@ FV3_HD double ppm_dm(double qm, double q0, double qp) {
 FV3_HD double ppm_face_tp(const double *s, int st, double c, int iord, double lim_fac) {
   (void)lim_fac;
   constexpr double r3 = 1. / 3., near_zero = 1.E-25, r12 = 1. / 12., p1 = 7. / 12., p2 = -1. / 12.;
+  if (iord == 7) {  // the monotone family's edge values, the positive-definite cell of :611-633, the flux form of :685-699
+    auto cell = [&](const double *u, double &bl, double &br) {
+      const double qm2 = u[-2 * st], qm1 = u[-st], q0 = u[0], qp1 = u[st], qp2 = u[2 * st];
+      const double dmm = ppm_dm(qm2, qm1, q0), dm0 = ppm_dm(qm1, q0, qp1), dmp = ppm_dm(q0, qp1, qp2);
+      bl = (0.5 * (qm1 + q0) + r3 * (dmm - dm0)) - q0;
+      br = (0.5 * (q0 + qp1) + r3 * (dm0 - dmp)) - q0;
+      const double a4 = -3. * (bl + br), da1 = br - bl;
+      if (fabs(da1) < -a4 && q0 + 0.25 / a4 * (da1 * da1) + a4 * r12 < 0.) {
+        if (br * bl > 0.) {
+          br = 0.;
+          bl = 0.;
+        } else if (da1 > 0.) {
+          br = -2. * bl;
+        } else {
+          bl = -2. * br;
+        }
+      }
+    };
+    double blm, brm, bl0, br0;
+    cell(s - st, blm, brm);
+    cell(s, bl0, br0);
+    const bool sm = blm * brm < 0., s0 = bl0 * br0 < 0.;
+    double fx1, flux;
+    if (c > 0.) {
+      fx1 = (1. - c) * (brm - c * (blm + brm));
+      flux = s[-st];
+    } else {
+      fx1 = (1. + c) * (bl0 + c * (bl0 + br0));
+      flux = s[0];
+    }
+    if (sm || s0) flux = flux + fx1;
+    return flux;
+  }
   if (iord >= 8) {
     // upwind cell
     const double *u = (c > 0.) ? s - st : s;

@@ -54,7 +54,7 @@ FV3_D PCell ppm_cell_mono(const vd &qm2, const vd &qm1, const vd &q0, const vd &
     const vd xt = 1.5 * dm0;
     c.bl = -vsign(vmin(vabs(xt), vabs(al0 - q0)), xt);
     c.br = vsign(vmin(vabs(xt), vabs(al1 - q0)), xt);
-  } else if (ORD == 12 || ORD == 9) {  // :611-633 / :634-641 with pert_ppm(iv = 0), :1219-1242 (13 runs as 9)
+  } else if (ORD == 12 || ORD == 9 || ORD == 7) {  // :611-633 / :634-641 with pert_ppm(iv = 0), :1219-1242 (13 runs as 9)
     constexpr double r12 = 1. / 12.;
     const vd bl0 = al0 - q0, br0 = al1 - q0;
     const vd a4 = -3. * (bl0 + br0), da1 = br0 - bl0;
@@ -71,6 +71,7 @@ FV3_D PCell ppm_cell_mono(const vd &qm2, const vd &qm1, const vd &q0, const vd &
     }
     c.bl = bl;
     c.br = br;
+    if (ORD == 7) c.smt = bl * br < 0.;  // :685-689: iord = 7 takes the flux form of the unlimited family on these cells
   } else {  // ORD == 10, :585-603
     constexpr double near_zero = 1.E-25;
     const vd bl0 = al0 - q0, br0 = al1 - q0;
@@ -202,7 +203,7 @@ template <int ORD>
 FV3_D PCell ppm_cells_x(const vd &q) {
   const vd qm1 = shr1(q), qp1 = shl1(q);
   const vd qm2 = shr1(qm1), qp2 = shl1(qp1);
-  if (ORD >= 8) {
+  if (ORD >= 7) {
     const vd dm0 = ppm_dm_v(qm1, q, qp1);
     const vd dmm = shr1(dm0), dmp = shl1(dm0);
     const vd al0 = ppm_al_mono(qm1, q, dmm, dm0);
@@ -264,7 +265,7 @@ struct PpmY {
     q0 = q1; q1 = q2; q2 = q3; q3 = q4; q4 = qn;
     prev = cur;
     al2 = al3;
-    if (ORD >= 8) {
+    if (ORD >= 7) {
       dm1 = dm2; dm2 = dm3;
       dm3 = ppm_dm_v(q2, q3, q4);                 // slope of row r-1
       al3 = ppm_al_mono(q2, q3, dm2, dm3);        // edge (r-2 | r-1)

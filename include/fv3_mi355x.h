@@ -108,7 +108,7 @@ int fv3_sync(fv3_ctx *ctx);
 /* fv_tp_2d -- model/tp_core.F90:85-87 (called from sw_core.F90:919,983,993,1014,1498,
  * nh_utils.F90:279,289, fv_tracer2d.F90:504,509).  nk slabs.  q: A; crx,xfx: CX; cry,yfx: CY;
  * ra_x: (is:ie, jsd:jed); ra_y: (isd:ied, js:je); fx,mfx: FX; fy,mfy: FY; mass: A.
- * Optional arguments are NULL / nord < 0 when absent.  hord: 5, -5, 6, 8, 9, 10, 11, 12, 13 (xppm / yppm, :365-641;
+ * Optional arguments are NULL / nord < 0 when absent.  hord: 5, -5, 6, 7, 8, 9, 10, 11, 12, 13 (xppm / yppm, :365-707;
  * d_sw and update_dz_d take 5, -5, 6, 8, 10). */
 int fv3_fv_tp_2d(fv3_ctx *ctx, int nk, const double *q, const double *crx, const double *cry, int hord,
                  double *fx, double *fy, const double *xfx, const double *yfx, const double *ra_x,

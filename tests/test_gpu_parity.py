@@ -18,7 +18,7 @@ def prod():
     return L.load()  # raises if the HIP library is missing: no fallback
 
 
-@pytest.mark.parametrize("hord", [5, -5, 6, 8, 10, 9, 11, 12, 13])
+@pytest.mark.parametrize("hord", [5, -5, 6, 7, 8, 10, 9, 11, 12, 13])
 def test_fv_tp_2d_plain(prod, hord):
     P.check_fv_tp_2d(prod, hord)
 
@@ -530,7 +530,7 @@ def test_baseline_config1_test_case_1(prod):
     D.check_fv_step_hydrostatic(prod, nx=48, ny=48, npz=32, nq=1, k_split=1, n_split=3, bdt=6.0, ic="test_case_1")
 
 
-@pytest.mark.parametrize("hord", [9, 11, 12, 13])
+@pytest.mark.parametrize("hord", [7, 9, 11, 12, 13])
 def test_tracer_2d_positive_definite_schemes(prod, hord):
     """hord_tr = 9 / 13 (pert_ppm), 11 (ppm_fac slopes), 12 (Lin & Rood positive definite), tp_core.F90:604-641: the marching
     kernels (one and three tracers per wavefront) and, with the first sub-cycle damped, the tile kernel"""
@@ -620,7 +620,7 @@ def test_cubed_c_sw(prod, hydrostatic):
     assert PC.check_c_sw(prod, npx=49, npz=4, hydrostatic=hydrostatic) <= P.TOL          # C48 faces
 
 
-@pytest.mark.parametrize("hord", [10, 8, 5, -5, 6, 9, 11, 12, 13])
+@pytest.mark.parametrize("hord", [10, 8, 5, -5, 6, 7, 9, 11, 12, 13])
 def test_cubed_fv_tp_2d(prod, hord):
     assert PC.check_fv_tp_2d(prod, hord, npx=25) <= P.TOL
     assert PC.check_fv_tp_2d(prod, hord, npx=25, mass_flux=True, faces=(2, 5)) <= P.TOL

@@ -19,7 +19,7 @@ def emu():
     return Fv3Lib(os.path.join(HERE, "hostemu", "libfv3_hostemu.so"))
 
 
-@pytest.mark.parametrize("hord", [5, -5, 6, 8, 10, 9, 11, 12, 13])
+@pytest.mark.parametrize("hord", [5, -5, 6, 7, 8, 10, 9, 11, 12, 13])
 def test_fv_tp_2d_plain(emu, hord):
     P.check_fv_tp_2d(emu, hord)
 
@@ -437,7 +437,7 @@ def test_baseline_config1_test_case_1(emu):
     D.check_fv_step_hydrostatic(emu, nx=48, ny=48, npz=32, nq=1, k_split=1, n_split=3, bdt=6.0, ic="test_case_1")
 
 
-@pytest.mark.parametrize("hord", [9, 11, 12, 13])
+@pytest.mark.parametrize("hord", [7, 9, 11, 12, 13])
 def test_tracer_2d_positive_definite_schemes(emu, hord):
     """hord_tr = 9 / 13 (pert_ppm), 11 (ppm_fac slopes), 12 (Lin & Rood positive definite), tp_core.F90:604-641: the marching
     kernels (one and three tracers per wavefront) and, with the first sub-cycle damped, the tile kernel"""
@@ -474,7 +474,7 @@ def test_cubed_c_sw(emu, hydrostatic):
     assert PC.check_c_sw(emu, npx=25, npz=2, hydrostatic=hydrostatic, faces=(0, 2, 5)) <= P.TOL
 
 
-@pytest.mark.parametrize("hord", [10, 8, 5, -5, 6, 9, 11, 12, 13])
+@pytest.mark.parametrize("hord", [10, 8, 5, -5, 6, 7, 9, 11, 12, 13])
 def test_cubed_fv_tp_2d(emu, hord):
     assert PC.check_fv_tp_2d(emu, hord, faces=(0, 3)) <= P.TOL
     assert PC.check_fv_tp_2d(emu, hord, mass_flux=True, faces=(2, 5)) <= P.TOL
