@@ -2226,14 +2226,17 @@ extern "C" int fv3_adv_pe(fv3_ctx *c, double ptop, const double *ua, const doubl
   const Grid &g = c->g;
   if (g.grid_type >= 3) return fail("fv3_adv_pe: en1 / en2 are not defined for grid_type >= 3 (fv_grid_utils.F90:628)");
   if (!(c->cg.ready && c->cg.ec1)) return fail("fv3_adv_pe: cubed-sphere face without ec1 .. en2 (fv3_grid_upload_cubed)");
-  if (need_scratch(c, 1)) return 1;
+  if (need_scratch(c, 2)) return 1;
   PemColumns kp{g, g.npz, ptop, delp_before, c->scratch[0]};
   RT(launch_c(c, "adv_pe_pem", col_grid((g.nx + 2) * (g.ny + 2)), kp));
-  AdvPe kf{g, c->cg, g.npz, ua, va, c->scratch[0], omga};
   Dim3 grid;
-  grid.x = (unsigned)((g.nx * g.ny + AdvPe::CH - 1) / AdvPe::CH);
   grid.y = 1;
   grid.z = (unsigned)g.npz;
+  AdvPeCorners kc{g, c->cg, c->scratch[0], c->scratch[1]};
+  grid.x = (unsigned)(((g.nx + 1) * (g.ny + 1) + AdvPeCorners::CH - 1) / AdvPeCorners::CH);
+  RT(launch_p(c, "adv_pe_corners", grid, 0, kc));
+  AdvPe kf{g, c->cg, g.npz, ua, va, c->scratch[1], omga};
+  grid.x = (unsigned)((g.nx * g.ny + AdvPe::CH - 1) / AdvPe::CH);
   RT(launch_p(c, "adv_pe", grid, 0, kf));
   return 0;
 }

@@ -1045,12 +1045,13 @@ struct PemColumns {
   }
 };
 
-struct AdvPe {
+// (2a) the corner pressures pb(is:ie+1, js:je+1) of every level into an A slab (each corner is shared by four cells);
+// (2b) the projection, reading them back
+struct AdvPeCorners {
   Grid g;
   CubedGeom cg;
-  int km;
-  const double *ua, *va, *pem;
-  double *om;
+  const double *pem;
+  double *pb;  // A x km: pb(:, :, k) = a2b_ord2(pem(:, k+1, :))
   static constexpr int CH = 1024;
   FV3_HD double corner(const double *pin, int i, int j) const {  // a2b_ord2, grid_type < 3, not a bounded domain
     const int npx = g.npx, npy = g.npy;
@@ -1073,15 +1074,33 @@ struct AdvPe {
     return es * qa + (1. - es) * qb;
   }
   FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int w = g.nx + 1, n = w * (g.ny + 1);
+    const size_t nA = g.nA();
+    const double *pin = pem + (size_t)(bz + 1) * nA;  // pem(:, k+1, :)
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.is + idx % w, j = g.js + idx / w;
+      pb[(size_t)bz * nA + g.iA(i, j)] = corner(pin, i, j);
+    }
+  }
+};
+
+struct AdvPe {
+  Grid g;
+  CubedGeom cg;
+  int km;
+  const double *ua, *va, *pb;
+  double *om;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
     const int k = bz + 1, n = g.nx * g.ny;
     const size_t nA = g.nA(), nFX = g.nFX(), nFY = g.nFY();
-    const double *pin = pem + (size_t)k * nA;  // pem(:, k+1, :)
+    const double *pc = pb + (size_t)(k - 1) * nA;
     for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
       const int i = g.is + idx % g.nx, j = g.js + idx / g.nx;
       const size_t o = g.iA(i, j), o3 = (size_t)(k - 1) * nA + o;
       const double up = (k == km) ? ua[o3] : 0.5 * (ua[o3] + ua[o3 + nA]);
       const double vp = (k == km) ? va[o3] : 0.5 * (va[o3] + va[o3 + nA]);
-      const double p00 = corner(pin, i, j), p10 = corner(pin, i + 1, j), p01 = corner(pin, i, j + 1), p11 = corner(pin, i + 1, j + 1);
+      const double p00 = pc[o], p10 = pc[g.iA(i + 1, j)], p01 = pc[g.iA(i, j + 1)], p11 = pc[g.iA(i + 1, j + 1)];
       const double dxs = g.dx[g.iU(i, j)], dxn = g.dx[g.iU(i, j + 1)], dyw = g.dy[g.iV(i, j)], dye = g.dy[g.iV(i + 1, j)];
       double dot = 0.;
       for (int m = 0; m < 3; m++) {
