@@ -1881,10 +1881,8 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
   const int km = g.npz;
   double *cxa = c->scratch[0], *xfa = c->scratch[1], *cya = c->scratch[2], *yfa = c->scratch[3];
   {
-    EdgeProfile kf{g, km, c->ec, crx, xfx, cxa, xfa, (int)g.nCX()};
-    RT(launch_c(c, "edge_profile", col_grid((int)g.nCX()), kf));
-    EdgeProfile kf2{g, km, c->ec, cry, yfx, cya, yfa, (int)g.nCY()};
-    RT(launch_c(c, "edge_profile", col_grid((int)g.nCY()), kf2));
+    EdgeProfile kf{g, km, c->ec, crx, xfx, cxa, xfa, (int)g.nCX(), cry, yfx, cya, yfa, (int)g.nCY()};
+    RT(launch_c(c, "edge_profile", col_grid((int)(g.nCX() + g.nCY())), kf));
   }
   if (is_cubed(c)) {
     double *fx = cs_scratch(c, 8), *fy = cs_scratch(c, 9);

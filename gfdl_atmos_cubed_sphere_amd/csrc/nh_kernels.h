@@ -485,9 +485,18 @@ struct EdgeProfile {
   const double *q1, *q2;  // km levels
   double *q1e, *q2e;      // km+1 levels
   int n2d;                // points per level (nCX or nCY)
+  // a second pair of fields with its own level size (update_dz_d: crx / xfx on CX and cry / yfx on CY in ONE launch -- twice the
+  // wavefronts for a kernel whose time is the dependent chain of a division per level); n2d_b = 0: none
+  const double *q1_b = nullptr, *q2_b = nullptr;
+  double *q1e_b = nullptr, *q2e_b = nullptr;
+  int n2d_b = 0;
   FV3_HD void operator()(int bx, int, int, int tid, double *) const {
-    FV3_COL_FOR(c, n2d) {
-      const size_t ls = (size_t)n2d;
+    FV3_COL_FOR(cc, n2d + n2d_b) {
+      const bool second = cc >= n2d;
+      const int c = second ? cc - n2d : cc;
+      const size_t ls = (size_t)(second ? n2d_b : n2d);
+      const double *q1 = second ? this->q1_b : this->q1, *q2 = second ? this->q2_b : this->q2;
+      double *q1e = second ? this->q1e_b : this->q1e, *q2e = second ? this->q2e_b : this->q2e;
       double a_prev = q1[c], b_prev = q2[c];
       double a_cur = q1[ls + c], b_cur = q2[ls + c];
       double e1 = (ec.xt1_top * a_prev + a_cur) / ec.bet_top, e2 = (ec.xt1_top * b_prev + b_cur) / ec.bet_top;
