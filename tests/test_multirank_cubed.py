@@ -58,6 +58,10 @@ def _worker(rank, world, port, ok, case):
                         print("rank", rank, kind, m, "halo mismatch", flush=True)
                         good = False
             ctx.close()
+        elif case == "consv":
+            # the energy fixer with one face per rank: te_2d / zsum0 of the six faces summed through the all-reduced integer digits
+            r_ = PC.check_jw_consv(emu, npx=npx, npz=8, face=t, dist=dist)
+            good = max(r_.values()) <= 1e-12
         else:
             hydro = case == "hydro"
             cs, gs, st = CC.hydro_state(npx, npz) if hydro else CC.nh_state(npx, npz)
@@ -102,7 +106,7 @@ def _worker(rank, world, port, ok, case):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["halo", "hydro", "nh"])
+@pytest.mark.parametrize("case", ["halo", "hydro", "nh", "consv"])
 def test_one_face_per_rank_matches_the_six_face_oracle(case):
     subprocess.check_call(["make", "-C", os.path.join(HERE, "hostemu"), "-s"])
     s = socket.socket()
