@@ -419,6 +419,14 @@ def main():
     bd = Bounds(1 + ix * nx, (ix + 1) * nx, 1 + iy * nx, (iy + 1) * nx)
     g = doubly_periodic(bd, nx * px + 1, nx * py + 1, dx_const=26000.0, dy_const=26000.0)
     stream = torch.cuda.current_stream()
+    # FV3_BENCH_PAIR_GRAPH=1 (one rank, periodic copy as halo update): the pair on a stream of its own, captured into a HIP graph and
+    # replayed -- one launch per pair instead of ~10.  Measured SLOWER than the eager launches at this size (2.09-2.11 against
+    # 2.05-2.07 ms on the same box, tools/graph_probe.sh: the launches are already hidden behind 0.5-0.9 ms kernels, and the replay
+    # orders the sponge-level chain of the side stream less freely), so it is off by default; it pays where the kernels are short
+    # (the C96 sphere: cubed_dyn.StepGraph)
+    use_graph = world == 1 and not loopback and os.environ.get("FV3_BENCH_PAIR_GRAPH", "0") == "1"
+    if use_graph:
+        stream = torch.cuda.Stream()
     cells = nx * nx * npz
     # FV3_BENCH_SPONGE=0 (diagnostic): no sponge levels, every level in the marching kernels -- NOT the headline workload
     lev = level_coefficients(npz, DynFlags(d2_bg_k1=0.0, d2_bg_k2=0.0) if os.environ.get("FV3_BENCH_SPONGE") == "0"
@@ -478,6 +486,24 @@ def main():
                 halo.update([(d["uc"], "V"), (d["vc"], "U"), (d["divg_d"], "B")])
                 ctx.d_sw(*dsw_args)
 
+        step.graph = None
+        if use_graph:
+            try:
+                step()                                  # eager once: every work array of the library exists
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=stream):
+                    step()
+
+                def replay():
+                    with torch.cuda.stream(stream):
+                        gr.replay()
+                replay()
+                torch.cuda.synchronize()
+                step.graph = replay
+            except Exception as e:  # noqa: BLE001   (no capture: the eager launches are timed)
+                print(f"bench: HIP graph capture of the pair failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+                step.graph = None
         return ctx, d, step
 
     def run(ctx, d, step, steps, warmup):
@@ -494,12 +520,13 @@ def main():
             step()
         rep = ctx.profile_report()
         ctx.profile(False)
+        tstep = step.graph or step         # the captured pair (one replay = one c_sw -> halo -> d_sw), or the eager launches
         for _ in range(warmup):
-            step()
+            tstep()
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step()
+            tstep()
         fence()
         el = time.perf_counter() - t0
         if world > 1:
@@ -542,7 +569,7 @@ def main():
                              # marching kernels on a side stream, so it can beat the sum of the launches)
                              "wall_ms": el / steps * 1e3,
                              "frac_wall": cells * PAIR_ALG_BYTES / (el / steps) / HBM_PEAK}}
-        return {"el": el, "value": cells * world * steps / el, "finite": finite, "roof": roof, "geom": geom}
+        return {"el": el, "value": cells * world * steps / el, "finite": finite, "roof": roof, "geom": geom, "graph": step.graph is not None}
 
     GEOM = {0: "general metric rows", 1: "orthogonal (angle terms not read)", 2: "orthogonal + uniform (metric terms as scalars)"}
     # all host-side setup first (state generation and uploads take seconds), then the GPU work back to back: the
@@ -571,6 +598,7 @@ def main():
                       "layout": f"{px}x{py}", "halo": ("RCCL send/recv (loopback)" if loopback else "periodic copy") if world == 1 else "RCCL send/recv",
                       # what fv3_grid_upload found in the metric arrays (fv3_grid_geom)
                       "gridstruct": GEOM[geom], "build_id": build,
+                      "launch": "HIP graph: one replay per pair" if m.get("graph") else "eager launches",
                       "sponge_levels": "off (FV3_BENCH_SPONGE=0, diagnostic)" if os.environ.get("FV3_BENCH_SPONGE") == "0"
                       else "d2_bg_k1 0.20, d2_bg_k2 0.015 (2 levels)"},
            "finite": finite, "roofline": roof, "general_metrics": gm}
