@@ -187,10 +187,18 @@ class DynCore:
             ctx.geopk(fl.ptop, fl.akap, fl.cp_air, d["pe"], d["peln"], d["delpc"], d["pkc"], d["gz"], d["phis"], d["ptc"],
                       d["pkz"], True)                                         # :480-482 (CG)
             ctx.p_grad_c(dt2, d["delpc"], d["pkc"], d["gz"], d["uc"], d["vc"], True)           # :562
-            halo.update([(d["uc"], "V"), (d["vc"], "U")])
-            ctx.d_sw(par, d["vt"], d["delp"], d["pt"], d["u"], d["v"], None, d["uc"], d["vc"], d["ua"], d["va"],
-                     d["divgd"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
-                     d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], None, None, d["heat_s"], d["diss_e"])  # :762
+            dsw_args = (par, d["vt"], d["delp"], d["pt"], d["u"], d["v"], None, d["uc"], d["vc"], d["ua"], d["va"],
+                        d["divgd"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
+                        d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], None, None, d["heat_s"], d["diss_e"])
+            if halo.overlaps:      # :565 / :578 (pack 9) around the interior of d_sw (:762), as in the nonhydrostatic loop
+                pending = halo.start([(d["uc"], "V"), (d["vc"], "U")], defer=True)
+                ctx.d_sw(*dsw_args, phase="interior")
+                halo.post(pending)
+                halo.finish(pending)
+                ctx.d_sw(*dsw_args, phase="rest")
+            else:
+                halo.update([(d["uc"], "V"), (d["vc"], "U")])
+                ctx.d_sw(*dsw_args)                                           # :762
             if heating:
                 ctx.heat_source_accum(d["heat_source"], d["heat_s"])
             # external-mode damping field from the delp BEFORE d_sw (:745-747) and d_sw's divergence output (:791-848)

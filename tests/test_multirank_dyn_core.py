@@ -22,7 +22,7 @@ def _block(a, kind, bd_g, bd_l):
     return np.asfortranarray(a[ilo - ilo_g:ihi - ilo_g + 1, jlo - jlo_g:jhi - jlo_g + 1].copy())
 
 
-def _worker(rank, world, port, ok, nx=12, ny=10, npz=6, tj_fused=None):
+def _worker(rank, world, port, ok, nx=12, ny=10, npz=6, tj_fused=None, hydrostatic=False):
     if tj_fused:
         os.environ["FV3_MI355X_MARCH_TJ_FUSED"] = str(tj_fused)   # short segments: several per block
     sys.path.insert(0, HERE)
@@ -45,8 +45,8 @@ def _worker(rank, world, port, ok, nx=12, ny=10, npz=6, tj_fused=None):
         bd_g = Bounds(1, nx * px, 1, ny * py)
         g_g = P.make_grid(bd_g, False)
         st, dp0 = D.make_state(bd_g, npz)
-        fl = DynFlags(n_split=2, ptop=N.PTOP)
-        ref = OD.run(g_g, npz, fl, dp0, st, 4.0)
+        fl = DynFlags(n_split=2, ptop=N.PTOP, hydrostatic=hydrostatic)
+        ref = OD.run_hydrostatic(g_g, npz, fl, st, 4.0) if hydrostatic else OD.run(g_g, npz, fl, dp0, st, 4.0)
         ix, iy = rank % px, rank // px
         bd = Bounds(1 + ix * nx, (ix + 1) * nx, 1 + iy * ny, (iy + 1) * ny)
         g = doubly_periodic(bd, nx * px + 1, ny * py + 1)
@@ -59,9 +59,10 @@ def _worker(rank, world, port, ok, nx=12, ny=10, npz=6, tj_fused=None):
         dc.run(4.0)
         got = dc.get_state()
         good = True
-        for n, kind, rr in (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)),
-                            ("w", "A", (bd.is_, bd.ie, bd.js, bd.je)), ("delp", "A", (bd.is_, bd.ie, bd.js, bd.je)),
-                            ("pt", "A", (bd.is_, bd.ie, bd.js, bd.je)), ("zh", "A", (bd.is_, bd.ie, bd.js, bd.je))):
+        names = (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)),
+                 ("w", "A", (bd.is_, bd.ie, bd.js, bd.je)), ("delp", "A", (bd.is_, bd.ie, bd.js, bd.je)),
+                 ("pt", "A", (bd.is_, bd.ie, bd.js, bd.je)), ("zh", "A", (bd.is_, bd.ie, bd.js, bd.je)))
+        for n, kind, rr in (names[:2] + names[3:5] if hydrostatic else names):
             a = bd.view(got[n], kind, *rr)
             b = bd_g.view(ref[n], kind, *rr)
             e = P.rel_rms(a, b)
@@ -128,4 +129,18 @@ def test_reproducing_sum_does_not_depend_on_the_rank_layout(world):
     s.close()
     ok = mp.get_context("spawn").Array("i", [0] * world)
     mp.spawn(_sum_worker, args=(world, port, ok), nprocs=world, join=True)
+    assert list(ok) == [1] * world
+
+
+def test_hydrostatic_substeps_on_two_ranks_with_the_overlap_split():
+    """the hydrostatic branch of the loop on two ranks (geopk, external-mode damping, one_grad_p), d_sw split around the uc / vc
+    exchange: the union of the blocks equals the single-domain oracle"""
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostemu"), "-s"])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    ok = mp.get_context("spawn").Array("i", [0] * world)
+    mp.spawn(_worker, args=(world, port, ok, 120, 22, 3, 8, True), nprocs=world, join=True)
     assert list(ok) == [1] * world
