@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--dt-atmos", type=float, default=1800.0)
     ap.add_argument("--k-split", type=int, default=2)
     ap.add_argument("--n-split", type=int, default=6)
+    ap.add_argument("--nh", action="store_true", help="nonhydrostatic (BASELINE config 3 at --nx 384 --npz 127 --dt-atmos 225 --n-split 5)")
     a = ap.parse_args()
     import torch
     from gfdl_atmos_cubed_sphere_amd import lib as L
@@ -37,22 +38,27 @@ def main():
     gs = [cs.gridstruct(t) for t in range(6)]
     bd = gs[0].bd
     ak, bk, _, _ = set_eta(npz)
-    st = jablonowski_williamson(cs, ak, bk, hydrostatic=True)
+    hyd = not a.nh
+    st = jablonowski_williamson(cs, ak, bk, hydrostatic=hyd)
     cs.topo.update("A", [s_["phis"] for s_ in st])
-    fl = DynFlags(n_split=a.n_split, hydrostatic=True, ptop=float(ak[0]), d_ext=0.0)
+    fl = DynFlags(n_split=a.n_split, hydrostatic=hyd, ptop=float(ak[0]), **(dict(d_ext=0.0) if hyd else {}))
     ng = bd.ng
     c = (slice(ng, ng + nx), slice(ng, ng + nx))
     for s_ in st:
-        pe = ak[0] + np.concatenate([np.zeros(s_["delp"].shape[:2] + (1,)), np.cumsum(s_["delp"], axis=2)], axis=2)[c]
-        peln = np.log(pe)
-        pkz = (pe[:, :, 1:] ** fl.akap - pe[:, :, :-1] ** fl.akap) / (fl.akap * (peln[:, :, 1:] - peln[:, :, :-1]))
+        if hyd:
+            pe = ak[0] + np.concatenate([np.zeros(s_["delp"].shape[:2] + (1,)), np.cumsum(s_["delp"], axis=2)], axis=2)[c]
+            peln = np.log(pe)
+            pkz = (pe[:, :, 1:] ** fl.akap - pe[:, :, :-1] ** fl.akap) / (fl.akap * (peln[:, :, 1:] - peln[:, :, :-1]))
+        else:
+            pkz = ((-fl.rdgas / fl.grav) * s_["delp"][c] * s_["pt"][c] / s_["delz"]) ** fl.akap
         s_["pt"][c] = s_["pt"][c] / pkz
     streams = [torch.cuda.Stream() for _ in range(6)]
     mctx = MultiContext([L.Context(g, npz, stream=fs.cuda_stream) for g, fs in zip(gs, streams)])
     fv = FvDynamics(mctx, fl, ak, bk, nq=0, k_split=a.k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
     zero = np.zeros_like(st[0]["delp"])
-    fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], [zero] * 6, [s_["delp"] for s_ in st], [s_["pt"] for s_ in st],
-                    [bd.zeros("CC", npz)] * 6, [s_["phis"] for s_ in st])
+    fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], [s_.get("w", zero) for s_ in st], [s_["delp"] for s_ in st],
+                    [s_["pt"] for s_ in st], [s_.get("delz", bd.zeros("CC", npz)) for s_ in st], [s_["phis"] for s_ in st])
+    del st
     areas = [np.asarray(g.m["area"])[c] for g in gs]
 
     def diag(day):
@@ -82,7 +88,7 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     m0 = out[0]["mass"]
-    print(json.dumps({"config": f"C{nx} L{npz} hydrostatic JW (test_case 13), dt_atmos {a.dt_atmos} s, k_split {a.k_split}, n_split {a.n_split}, "
+    print(json.dumps({"config": f"C{nx} L{npz} {'hydrostatic' if hyd else 'nonhydrostatic'} JW (test_case 13), dt_atmos {a.dt_atmos} s, k_split {a.k_split}, n_split {a.n_split}, "
                                 f"whole sphere on one GPU, HIP graph", "days": a.days, "steps": nsteps, "wall_s": wall,
                       "sypd": a.days / 365.0 / (wall / 86400.0), "mass_drift_rel": abs(out[-1]["mass"] - m0) / m0,
                       "ps_min_hPa_final": out[-1]["ps_min_hPa"], "build_id": L.build_id(), "series": out}))
