@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--dt-atmos", type=float, default=1800.0)
     ap.add_argument("--k-split", type=int, default=2)
     ap.add_argument("--n-split", type=int, default=6)
+    ap.add_argument("--nq", type=int, default=0, help="advected tracers (BASELINE config 5 carries 33): smooth positive fields; eager steps")
     ap.add_argument("--nh", action="store_true", help="nonhydrostatic (BASELINE config 3 at --nx 384 --npz 127 --dt-atmos 225 --n-split 5)")
     a = ap.parse_args()
     import torch
@@ -54,7 +55,17 @@ def main():
         s_["pt"][c] = s_["pt"][c] / pkz
     streams = [torch.cuda.Stream() for _ in range(6)]
     mctx = MultiContext([L.Context(g, npz, stream=fs.cuda_stream) for g, fs in zip(gs, streams)])
-    fv = FvDynamics(mctx, fl, ak, bk, nq=0, k_split=a.k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+    nq = a.nq
+    fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=a.k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+    if nq:
+        q0 = []
+        lev = (np.arange(npz) / max(npz - 1, 1))[None, None, :]
+        for t in range(6):
+            lon, lat = cs.grids[t]["agrid"][..., 0:1], cs.grids[t]["agrid"][..., 1:2]
+            q0.append(np.asfortranarray(np.stack([(1.0 + 0.1 * iq) * (1.0 + 0.5 * np.sin((1 + iq % 3) * lon + 0.3 * iq) * np.cos(lat) ** 2
+                                                                      * np.cos(3.0 * lev)) for iq in range(nq)], axis=-1)))
+        fv.set_tracers(q0)
+        del q0
     zero = np.zeros_like(st[0]["delp"])
     fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], [s_.get("w", zero) for s_ in st], [s_["delp"] for s_ in st],
                     [s_["pt"] for s_ in st], [s_.get("delz", bd.zeros("CC", npz)) for s_ in st], [s_["phis"] for s_ in st])
@@ -66,7 +77,12 @@ def main():
         dp, u, v = d["delp"].download(), d["u"].download(), d["v"].download()
         ps = [ak[0] + np.sum(x[c], axis=2) for x in dp]
         mass = float(sum(np.sum(p_ * ar) for p_, ar in zip(ps, areas)))
-        return {"day": day, "mass": mass, "ps_min_hPa": float(min(p_.min() for p_ in ps)) / 100.0,
+        tr = {}
+        if nq:
+            q = d["q"].download()
+            tm = [float(sum(np.sum(q_[c][..., iq] * x[c] * ar[:, :, None]) for q_, x, ar in zip(q, dp, areas))) for iq in range(nq)]
+            tr = {"tracer_mass": tm, "q_min": float(min(q_[c].min() for q_ in q)), "q_max": float(max(q_[c].max() for q_ in q))}
+        return {**tr, "day": day, "mass": mass, "ps_min_hPa": float(min(p_.min() for p_ in ps)) / 100.0,
                 "ps_max_hPa": float(max(p_.max() for p_ in ps)) / 100.0,
                 "u_max": float(max(np.abs(bd.view(x, "U", bd.is_, bd.ie, bd.js, bd.je + 1)).max() for x in u)),
                 "v_max": float(max(np.abs(bd.view(x, "V", bd.is_, bd.ie + 1, bd.js, bd.je)).max() for x in v)),
@@ -74,12 +90,15 @@ def main():
     out = [diag(0.0)]
     fv.step(a.dt_atmos)                          # eager first (work arrays), then the step as a graph
     torch.cuda.synchronize()
-    graph = StepGraph(fv, a.dt_atmos, streams)
+    graph = StepGraph(fv, a.dt_atmos, streams) if nq == 0 else None      # tracer_2d reads the Courant maximum back on the host
     nsteps = int(round(a.days * 86400.0 / a.dt_atmos))
     every = int(round(43200.0 / a.dt_atmos))
     t0 = time.perf_counter()
     for n in range(2, nsteps + 1):
-        graph.replay()
+        if graph:
+            graph.replay()
+        else:
+            fv.step(a.dt_atmos)
         if n % every == 0:
             torch.cuda.synchronize()
             out.append(diag(n * a.dt_atmos / 86400.0))
@@ -89,8 +108,10 @@ def main():
     wall = time.perf_counter() - t0
     m0 = out[0]["mass"]
     print(json.dumps({"config": f"C{nx} L{npz} {'hydrostatic' if hyd else 'nonhydrostatic'} JW (test_case 13), dt_atmos {a.dt_atmos} s, k_split {a.k_split}, n_split {a.n_split}, "
-                                f"whole sphere on one GPU, HIP graph", "days": a.days, "steps": nsteps, "wall_s": wall,
+                                f"whole sphere on one GPU, {'HIP graph' if nq == 0 else str(nq) + ' tracers, eager launches'}", "days": a.days, "steps": nsteps, "wall_s": wall,
                       "sypd": a.days / 365.0 / (wall / 86400.0), "mass_drift_rel": abs(out[-1]["mass"] - m0) / m0,
+                      "nq": nq, "tracer_mass_drift_rel_max": (max(abs(b_ - a_) / abs(a_) for a_, b_ in zip(out[0]["tracer_mass"], out[-1]["tracer_mass"]))
+                                                              if nq else None),
                       "ps_min_hPa_final": out[-1]["ps_min_hPa"], "build_id": L.build_id(), "series": out}))
     mctx.close()
 
