@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--dt-atmos", type=float, default=6.0)
     ap.add_argument("--n-split", type=int, default=8)   # c_s dt / dx = 0.5 at dx = 500 m (1.0 goes unstable within 20 steps)
     ap.add_argument("--every", type=float, default=120.0)
+    ap.add_argument("--flags", type=str, default="", help="JSON of DynFlags overrides")
     a = ap.parse_args()
     from gfdl_atmos_cubed_sphere_amd import lib as L
     from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
@@ -44,7 +45,7 @@ def main():
             periodic_fill(bd, st[n][:, :, k], kind)
     for k in range(npz):
         periodic_fill(bd, q[:, :, k, 0], "A")
-    fl = DynFlags(n_split=a.n_split, ptop=ptop)
+    fl = DynFlags(n_split=a.n_split, ptop=ptop, **(json.loads(a.flags) if a.flags else {}))
     ctx = L.Context(g, npz)
     fv = FvDynamics(ctx, fl, ak, bk, nq=1, k_split=1, adiabatic=False, c2l_ord=2)
     fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
