@@ -21,7 +21,7 @@ from .layout import Bounds
 
 RADIUS = 6.3712e6      # FMS constants_mod
 OMEGA = 7.2921e-5
-BIG = 1.0e30           # big_number, fv_grid_utils.F90
+BIG = float(__import__('os').environ.get('FV3_GRID_BIG', '1.0e30'))           # big_number (1e8 in fv_grid_utils.F90:56; larger here so that a read of an unset entry shows)
 TINY = 1.0e-8          # tiny_number
 NG = 3
 

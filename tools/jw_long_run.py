@@ -96,7 +96,7 @@ def main():
     fv.step(a.dt_atmos)                          # eager first (work arrays), then the step as a graph
     torch.cuda.synchronize()
     graph = None
-    if nq == 0:                                   # (tracer_2d reads the Courant maximum back on the host: eager with tracers)
+    if nq == 0 and os.environ.get("JW_EAGER") != "1":   # (tracer_2d reads the Courant maximum back on the host: eager with tracers)
         try:
             graph = StepGraph(fv, a.dt_atmos, streams)
         except Exception as e:  # noqa: BLE001
