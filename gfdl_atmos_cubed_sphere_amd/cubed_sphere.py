@@ -487,22 +487,21 @@ class CubedSphere:
             area_c[P(npx, 1)] = _area_tri(a3[P(npx, 1)], a3[P(npx - 1, 1)], a3[P(npx - 1, 0)], R)
             area_c[P(npx, npx)] = _area_tri(a3[P(npx - 1, npx)], a3[P(npx - 1, npx - 1)], a3[P(npx, npx - 1)], R)
             area_c[P(1, npx)] = _area_tri(a3[P(1, npx)], a3[P(1, npx - 1)], a3[P(0, npx - 1)], R)
-            # face edges: twice the half cell on this face (fv_grid_tools.F90:871-936)
+            # face edges: twice the half cell on this face (fv_grid_tools.F90:871-936).  The reference's edge loops run over
+            # js..je+1 / is..ie+1, i.e. they OVERWRITE the corner triangles of grid_area with twice the half cell too
             jj = np.arange(1, npx + 1)
             for i, inner in ((1, 1), (npx, npx - 1)):
-                for j in jj:
-                    if 1 < j < npx:
-                        p1, p4 = _mid(g3[P(i, j - 1)], g3[P(i, j)]), _mid(g3[P(i, j)], g3[P(i, j + 1)])
-                        p2, p3 = a3[P(inner, j - 1)], a3[P(inner, j)]
-                        area_c[P(i, j)] = 2.0 * abs(_area(p1, p4, p2, p3, R))
+                for j in jj:                 # do j = js, je+1: the corners included (the later j blocks overwrite them)
+                    p1, p4 = _mid(g3[P(i, j - 1)], g3[P(i, j)]), _mid(g3[P(i, j)], g3[P(i, j + 1)])
+                    p2, p3 = a3[P(inner, j - 1)], a3[P(inner, j)]
+                    area_c[P(i, j)] = 2.0 * abs(_area(p1, p4, p2, p3, R))
                 for j in range(1, npx):
                     dxc[P(i, j)] = 2.0 * _gcd3(_mid(g3[P(i, j)], g3[P(i, j + 1)]), a3[P(inner, j)], R)
             for j, inner in ((1, 1), (npx, npx - 1)):
-                for i in jj:
-                    if 1 < i < npx:
-                        p1, p2 = _mid(g3[P(i - 1, j)], g3[P(i, j)]), _mid(g3[P(i, j)], g3[P(i + 1, j)])
-                        p3, p4 = a3[P(i, inner)], a3[P(i - 1, inner)]
-                        area_c[P(i, j)] = 2.0 * abs(_area(p1, p4, p2, p3, R))
+                for i in jj:                 # do i = is, ie+1: last writer at the four cube corners (:905-912, :919-926)
+                    p1, p2 = _mid(g3[P(i - 1, j)], g3[P(i, j)]), _mid(g3[P(i, j)], g3[P(i + 1, j)])
+                    p3, p4 = a3[P(i, inner)], a3[P(i - 1, inner)]
+                    area_c[P(i, j)] = 2.0 * abs(_area(p1, p4, p2, p3, R))
                 for i in range(1, npx):
                     dyc[P(i, j)] = 2.0 * _gcd3(_mid(g3[P(i, j)], g3[P(i + 1, j)]), a3[P(i, inner)], R)
             g["dxc"], g["dyc"], g["area_c"] = F(dxc), F(dyc), F(area_c)
