@@ -546,6 +546,22 @@ class CubedSphere:
         g["ec1"], g["ec2"] = ec1, ec2
         sin_sg = np.minimum(1.0, np.sqrt(np.maximum(0.0, 1.0 - cos_sg ** 2)))
         P = lambda i, j: (i + o, j + o)      # noqa: E731
+        # the first set of corner copies, sin_sg only, BEFORE the edge / corner averages (:363-394; the second set :573-612 below
+        # follows fill_ghost).  It decides sina_u(1, j <= 0), sina_v(i <= 0, 1) ... in the halo rows next to the cube corners.
+        for i in (-2, -1, 0):
+            sin_sg[P(0, i) + (2,)] = sin_sg[P(i, 1) + (1,)]
+            sin_sg[P(i, 0) + (3,)] = sin_sg[P(1, i) + (0,)]
+        for i in range(npx, npx + 3):
+            sin_sg[P(0, i) + (2,)] = sin_sg[P(npx - i, npx - 1) + (3,)]
+        for i in (-2, -1, 0):
+            sin_sg[P(i, npx) + (1,)] = sin_sg[P(1, npx + i) + (0,)]
+        for j in (-2, -1, 0):
+            sin_sg[P(npx, j) + (0,)] = sin_sg[P(npx - j, 1) + (1,)]
+        for i in range(npx, npx + 3):
+            sin_sg[P(i, 0) + (3,)] = sin_sg[P(npx - 1, npx - i) + (2,)]
+        for i in range(npx, npx + 3):
+            sin_sg[P(npx, i) + (0,)] = sin_sg[P(i, npx - 1) + (3,)]
+            sin_sg[P(i, npx) + (1,)] = sin_sg[P(npx - 1, i) + (2,)]
         F = np.asfortranarray
         cosa = np.full((nid + 1, nid + 1), BIG)
         sina = np.full((nid + 1, nid + 1), BIG)

@@ -5,20 +5,43 @@ from __future__ import annotations
 
 import numpy as np
 
+import grid_oracle as GO
 import oracle_lib as O
-from gfdl_atmos_cubed_sphere_amd.cubed_sphere import CubedSphere, _mid, _unit
-from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags, level_coefficients
-from gfdl_atmos_cubed_sphere_amd.synthetic import CSW_OUT, DSW_PAR
+from grid_oracle import level_coefficients           # model/dyn_core.F90:666-733 as the ORACLE restates it (oracle/fv_grid.c)
+from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags                    # the flag container only
+from gfdl_atmos_cubed_sphere_amd.synthetic import CSW_OUT, DSW_PAR           # field-name / default-parameter lists only
 
 F = np.asfortranarray
 _CACHE = {}
+_PTOPO = {}
+
+
+def _unit(v):
+    return v / np.sqrt(np.sum(v * v, axis=-1, keepdims=True))
+
+
+def _mid(p, q):
+    return _unit(p + q)
 
 
 def sphere(npx):
+    """(cs, gs): the six tiles as the ORACLE builds them (tests/grid_oracle.py over oracle/fv_grid.c -- geometry, metric terms,
+    halo topology, nothing from the product's cubed_sphere.py) and their gridstructs.  The parity tests hand the SAME
+    gridstructs to the product kernels (as a real integration hands them the reference's init_grid output); the product's own
+    numpy geometry is held to this one by tests/test_grid_oracle.py."""
     if npx not in _CACHE:
-        cs = CubedSphere(npx)
+        cs = GO.ref_sphere(npx)
         _CACHE[npx] = (cs, [cs.gridstruct(t) for t in range(6)])
     return _CACHE[npx]
+
+
+def product_topo(npx):
+    """the PRODUCT's halo tables (what its device gathers / message packs are built from): used for the product side of a parity
+    test only; tests/test_grid_oracle.py requires them to equal the oracle's row for row"""
+    if npx not in _PTOPO:
+        from gfdl_atmos_cubed_sphere_amd.cubed_sphere import CubeTopology
+        _PTOPO[npx] = CubeTopology(npx)
+    return _PTOPO[npx]
 
 
 def wind(p, strength=30.0):
@@ -166,7 +189,6 @@ def _oracle_heating(cs, gs, fl, f, npz, bdt, hydrostatic):
 def oracle_substeps_hydro(cs, gs, fl, st, bdt, npz):
     """the hydrostatic substep loop of dyn_core (dyn_core.F90:313-1286, beta = 0, d_ext = 0) over the oracle's routines on six
     faces, with the halo updates where dyn_core has them -- the six-face twin of oracle_dyn_core.run_hydrostatic"""
-    from gfdl_atmos_cubed_sphere_amd.dyn_core import level_coefficients
     f = [{k: F(v.copy()) for k, v in s.items()} for s in st]
     bd = gs[0].bd
     nx, ny = bd.nx, bd.ny
@@ -251,7 +273,6 @@ def nh_state(npx, npz, ptop=300.0):
 def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
     """the nonhydrostatic substep loop of dyn_core (dyn_core.F90:313-1286, d_ext = 0, d_con = 0) over the oracle's routines on
     six faces with the halo updates where dyn_core has them -- the six-face twin of oracle_dyn_core.run"""
-    from gfdl_atmos_cubed_sphere_amd.dyn_core import level_coefficients
     f = [{k: F(v.copy()) for k, v in s.items()} for s in st]
     bd = gs[0].bd
     nx, ny, ng = bd.nx, bd.ny, bd.ng

@@ -7,6 +7,7 @@ import numpy as np
 import cubed_common as CC
 import oracle_lib as O
 import parity_common as P
+from gfdl_atmos_cubed_sphere_amd import lib as L
 from gfdl_atmos_cubed_sphere_amd.lib import Context
 from gfdl_atmos_cubed_sphere_amd.synthetic import CSW_OUT
 
@@ -157,7 +158,7 @@ def check_substeps_hydrostatic(lib, npx=13, npz=4, n_split=2, bdt=600.0, flags=N
     try:
         sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
         dp0 = np.diff(fl.ptop + (1.0e5 - fl.ptop) * sig)
-        dc = DynCore(mctx, fl, dp0, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        dc = DynCore(mctx, fl, dp0, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)))
         z = [np.zeros_like(s["delp"]) for s in st]
         bd = gs[0].bd
         dz = [bd.zeros("CC", npz) for _ in st]
@@ -192,7 +193,7 @@ def check_substeps_nh(lib, npx=13, npz=5, n_split=2, bdt=300.0, flags=None, tol=
     mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     worst = {}
     try:
-        dc = DynCore(mctx, fl, dp0, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        dc = DynCore(mctx, fl, dp0, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)))
         dc.set_state([s["u"] for s in st], [s["v"] for s in st], [s["w"] for s in st], [s["delp"] for s in st],
                      [s["pt"] for s in st], [s["delz"] for s in st], [s["phis"] for s in st])
         dc.run(bdt)
@@ -231,7 +232,7 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
     from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
     from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
     from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
-    from gfdl_atmos_cubed_sphere_amd.test_cases import jablonowski_williamson, set_eta
+    from gfdl_atmos_cubed_sphere_amd.test_cases import set_eta
     cs, gs = CC.sphere(npx)
     if npz in (79, 127):
         ak, bk, ks, ptop = set_eta(npz)
@@ -239,7 +240,7 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
         sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
         ptop = 300.0
         ak, bk = ptop * (1.0 - sig), sig.copy()
-    st = jablonowski_williamson(cs, ak, bk, hydrostatic=hydrostatic)
+    st = cs.jablonowski_williamson(ak, bk, hydrostatic=hydrostatic, rdgas=L.RDGAS, grav=L.GRAV)
     CC.exchange(cs, st, ("phis",), "A")          # the model gets phis with its halo filled (init_case: mpp_update_domains(phis))
     fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, d_ext=0.0, ptop=float(ak[0]), **(flags or {}))
     # T -> theta: pt = T / pkz with the hydrostatic pkz of the initial state (fv_dynamics.F90:323-329, the host's job here)
@@ -263,7 +264,7 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
         mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     worst = {}
     try:
-        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)))
         q0 = tracer_fields(cs, npz, nq) if nq else None
         if hydrostatic:
             ref = CC.oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, fv.remap_par, npz, q=q0)
@@ -335,10 +336,10 @@ def check_sphere_properties(lib, npx=97, npz=127, hydrostatic=False, k_split=1, 
     from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
     from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
     from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
-    from gfdl_atmos_cubed_sphere_amd.test_cases import jablonowski_williamson, set_eta
+    from gfdl_atmos_cubed_sphere_amd.test_cases import set_eta
     cs, gs = CC.sphere(npx)
     ak, bk, ks, ptop = set_eta(npz)
-    st = jablonowski_williamson(cs, ak, bk, hydrostatic=hydrostatic)
+    st = cs.jablonowski_williamson(ak, bk, hydrostatic=hydrostatic, rdgas=L.RDGAS, grav=L.GRAV)
     CC.exchange(cs, st, ("phis",), "A")          # the model gets phis with its halo filled (init_case: mpp_update_domains(phis))
     fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, d_ext=0.0, ptop=float(ak[0]), **(flags or {}))
     bd = gs[0].bd
@@ -357,7 +358,7 @@ def check_sphere_properties(lib, npx=97, npz=127, hydrostatic=False, k_split=1, 
     mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     out = {}
     try:
-        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)))
         if nq:
             q0 = tracer_fields(cs, npz, nq)
             fv.set_tracers(q0)
@@ -415,7 +416,7 @@ def check_tracer_2d(lib, npx=13, npz=4, nq=3, hord=8, q_split=0, courant_scale=1
     mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     worst = {"nsplt": float(nsplt)}
     try:
-        halo = CubeHaloAdapter(mctx, npx, topo=cs.topo)
+        halo = CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx))
         d = {n: mctx.from_host([x[n] for x in inp]) for n in ("q", "dp1", "mfx", "mfy", "cx", "cy")}
         d["q_nxt"], d["dp1_nxt"] = mctx.from_host([x["q"] * 0 for x in inp]), mctx.zeros("A", npz)
         d["xfx"], d["yfx"] = mctx.zeros("CX", npz), mctx.zeros("CY", npz)
@@ -558,14 +559,14 @@ def check_jw_step_moist(lib, npx=13, npz=20, k_split=2, n_split=2, bdt=900.0, mo
     from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
     from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
     from gfdl_atmos_cubed_sphere_amd.lib import CP_AIR, GRAV, RDGAS
-    from gfdl_atmos_cubed_sphere_amd.test_cases import jablonowski_williamson, set_eta
+    from gfdl_atmos_cubed_sphere_amd.test_cases import set_eta
     cs, gs = CC.sphere(npx)
     if npz in (79, 127):
         ak, bk, ks, ptop = set_eta(npz)
     else:
         sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
         ak, bk = 300.0 * (1.0 - sig), sig.copy()
-    st = jablonowski_williamson(cs, ak, bk, hydrostatic=False)
+    st = cs.jablonowski_williamson(ak, bk, hydrostatic=False, rdgas=L.RDGAS, grav=L.GRAV)
     CC.exchange(cs, st, ("phis",), "A")
     fl = DynFlags(n_split=n_split, hydrostatic=False, d_ext=0.0, ptop=float(ak[0]), use_cond=True, moist_kappa=moist_kappa)
     bd = gs[0].bd
@@ -603,7 +604,7 @@ def check_jw_step_moist(lib, npx=13, npz=20, k_split=2, n_split=2, bdt=900.0, mo
     worst = {}
     try:
         fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, adiabatic=False, moist=mp, c2l_ord=2,
-                        halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+                        halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)))
         opar = dict(fv.remap_par, **dict(mp, moist_kappa=int(moist_kappa), use_cond=1))
         opar.pop("sphum")
         opar["sphum"] = 1
@@ -650,7 +651,7 @@ def check_rayleigh_super(lib, npx=13, npz=20, hydrostatic=False, ideal=False, ta
     mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     worst = 0.0
     try:
-        fv = FvDynamics(mctx, fl, ak, bk, tau=tau, rf_cutoff=rf_cutoff, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
+        fv = FvDynamics(mctx, fl, ak, bk, tau=tau, rf_cutoff=rf_cutoff, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)))
         rf, pm, kmax = fv.rayleigh_profile(225.0)
         assert 0 < kmax < npz
         z = w0 if not hydrostatic else [np.zeros_like(s["delp"]) for s in st]
@@ -698,11 +699,10 @@ def check_jw_consv(lib, npx=13, npz=20, k_split=2, n_split=2, bdt=900.0, consv_t
     from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
     from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
     from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
-    from gfdl_atmos_cubed_sphere_amd.test_cases import jablonowski_williamson
     cs, gs = CC.sphere(npx)
     sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
     ak, bk = 300.0 * (1.0 - sig), sig.copy()
-    st = jablonowski_williamson(cs, ak, bk, hydrostatic=True)
+    st = cs.jablonowski_williamson(ak, bk, hydrostatic=True, rdgas=L.RDGAS, grav=L.GRAV)
     CC.exchange(cs, st, ("phis",), "A")
     fl = DynFlags(n_split=n_split, hydrostatic=True, d_ext=0.0, ptop=float(ak[0]))
     bd = gs[0].bd
@@ -724,11 +724,11 @@ def check_jw_consv(lib, npx=13, npz=20, k_split=2, n_split=2, bdt=900.0, consv_t
         ost.append(dict(s_, pt=th))
     if face is None:
         mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
-        halo = CubeHaloAdapter(mctx, npx, topo=cs.topo)
+        halo = CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx))
     else:       # one face per rank: the two global sums of the fixer travel as integer digits through dist.all_reduce
         from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeRankAdapter
         mctx = Context(gs[face], npz, lib=lib)
-        halo = CubeRankAdapter(mctx, face, npx, dist, topo=cs.topo)
+        halo = CubeRankAdapter(mctx, face, npx, dist, topo=CC.product_topo(npx))
     pick = (lambda xs: xs) if face is None else (lambda xs: xs[face])
     worst = {}
     try:

@@ -518,7 +518,7 @@ def test_cubed_halo_gather_equals_the_table_update(emu):
     cs, gs = PC.CC.sphere(npx)
     ctxs = [Context(g, npz, lib=emu) for g in gs]
     try:
-        H = CubeHalo(ctxs, npx, topo=cs.topo)
+        H = CubeHalo(ctxs, npx, topo=PC.CC.product_topo(npx))
         rng = np.random.default_rng(0)
         bd = gs[0].bd
         for kind, kinds in (("A", ("A",)), ("B", ("B",)), ("D", ("U", "V")), ("C", ("V", "U")), ("Dedge", ("U", "V"))):

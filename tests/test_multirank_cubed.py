@@ -38,7 +38,7 @@ def _worker(rank, world, port, ok, case):
             # every field kind through the message path against the numpy application of the same tables
             cs, gs = CC.sphere(npx)
             ctx = Context(gs[t], npz, lib=emu)
-            halo = CubeRankAdapter(ctx, t, npx, dist, topo=cs.topo)
+            halo = CubeRankAdapter(ctx, t, npx, dist, topo=CC.product_topo(npx))
             bd = gs[0].bd
             rng = np.random.default_rng(7)          # the same global fields on every rank
             for kind, kinds in (("A", ("A",)), ("A2", ("A", "A")), ("B", ("B",)), ("D", ("U", "V")), ("C", ("V", "U")), ("Dedge", ("U", "V"))):
@@ -72,7 +72,7 @@ def _worker(rank, world, port, ok, case):
             nq = 2
             q0 = PC.tracer_fields(cs, npz, nq)
             ctx = Context(gs[t], npz, lib=emu)
-            fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=2, halo=CubeRankAdapter(ctx, t, npx, dist, topo=cs.topo), dist=dist)
+            fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=2, halo=CubeRankAdapter(ctx, t, npx, dist, topo=CC.product_topo(npx)), dist=dist)
             if hydro:
                 ref = CC.oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, 600.0, 2, fv.remap_par, npz, q=q0)
             else:
