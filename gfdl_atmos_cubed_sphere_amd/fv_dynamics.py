@@ -95,6 +95,7 @@ class FvDynamics:
         ctx.compute_total_energy(self.remap_par, self.moist_phys, d["u"], d["v"], None if hyd else d["w"],
                                  None if hyd else d["delz"], d["pt"], d["delp"], d.get("q"), None, d["pe"] if hyd else None,
                                  d["peln"] if hyd else None, d["phis"], d["te0_2d"])
+        self._te0_valid = True          # consumed (and cleared) by the energy fixer of this call's last remap
 
     def _areas(self):
         """area (compute domain) of every context: the weights of g_sum (area_64, fv_mapz.F90:736)"""
@@ -110,6 +111,13 @@ class FvDynamics:
         from .global_sum import g_sum
         d, ctx, hyd = self.dc.d, self.ctx, self.fl.hydrostatic
         only_sums = self.consv_te < 0.0
+        if not only_sums and not getattr(self, "_te0_valid", False):
+            # te_2d = te0_2d - E(remapped column): without the energy of THIS call's initial state (fv_dynamics.F90:345-355, which
+            # step_from_temperature does and a bare step() does not) dtmp would be -E / zsum, applied to pt.  A te0_2d left from an
+            # earlier call is as wrong.
+            raise RuntimeError("consv_te > 0: total_energy_before() was not called for this step (te0_2d unset or stale); "
+                               "use step_from_temperature(), or call total_energy_before() on the temperature state first")
+        self._te0_valid = False
         for n in ("te0_2d", "te_2d", "zsum1", "zsum0"):
             if n not in d:
                 d[n] = ctx.zeros("CC")

@@ -714,6 +714,36 @@ def test_total_energy_conservation(emu, kw):
     assert max(D.check_fv_cycle_consv(emu, **kw).values()) <= 1e-12
 
 
+def test_energy_fixer_refuses_an_unset_or_stale_te0(emu):
+    """a bare step(..., last_cycle_is_last_step=True) with consv_te > 0 never computed te0_2d (step_from_temperature does,
+    fv_dynamics.F90:345-355); the fixer must stop instead of applying dtmp = -E / zsum to pt, and a te0_2d of an earlier call must
+    not be reused"""
+    import numpy as np
+    from gfdl_atmos_cubed_sphere_amd import synthetic as N
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    bd, npz = Bounds(1, 16, 1, 12), 6
+    g = P.make_grid(bd, False)
+    st, _ = N.balanced_nh_state(bd, npz)
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+    ak, bk = N.PTOP * (1.0 - sig), sig.copy()
+    ctx = Context(g, npz, lib=emu)
+    try:
+        fv = FvDynamics(ctx, DynFlags(n_split=2, ptop=N.PTOP), ak, bk, nq=0, k_split=1, consv_te=1.0)
+        fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
+        with pytest.raises(RuntimeError, match="total_energy_before"):
+            fv.step(4.0, last_cycle_is_last_step=True)
+        fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
+        fv.total_energy_before()
+        fv.step(4.0, last_cycle_is_last_step=True)          # consumes te0_2d
+        with pytest.raises(RuntimeError, match="total_energy_before"):
+            fv.step(4.0, last_cycle_is_last_step=True)      # ... which is stale now
+    finally:
+        ctx.close()
+
+
 def test_ordered_sum_is_exact_and_order_independent(emu):
     """fv3_ordered_sum (g_sum with reproduce = .true.: the extended-fixed-point sum) against math.fsum and the host's own
     implementation (global_sum.py), on addends spread over 23 orders of magnitude, permuted and split"""
