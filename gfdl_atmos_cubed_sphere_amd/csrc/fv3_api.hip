@@ -21,6 +21,7 @@
 #include "fv3_common.h"
 #include "fv3_launch.h"
 #include "nh_kernels.h"
+#include "nh_fast.h"
 #include "remap_kernels.h"
 #include "tracer_kernels.h"
 #include "tp2d_tile.h"
@@ -111,6 +112,7 @@ struct fv3_ctx {
   int trc_nt;  // tracers per wavefront in the sub-cycle kernel (FV3_MI355X_TRACER_NT: 1..4, default 3)
   int remap_nt;  // tracers per thread in the remap (FV3_MI355X_REMAP_NT: 1..3, default 3)
   int riem_blocked;   // the same for the Riemann solvers' four slabs (FV3_MI355X_RIEM_SCR: 0 / 1, default 1)
+  int fast;           // fast (tolerance) mode: FV3_MI355X_FAST=1 or fv3_set_fast -- nh_fast.h instead of the parity column solvers
   int remap_blocked;  // scratch slabs of the remap in per-wavefront blocks (FV3_MI355X_REMAP_SCR: 0 / 1, default 1)
   int tj_fixed;          // an FV3_MI355X_MARCH_TJ* variable is set: take the rows per segment as given
   int csw_kpw;           // levels per wavefront in CswMarch (1 .. 4; FV3_MI355X_CSW_KPW)
@@ -300,6 +302,8 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     if (c->remap_nt < 1 || c->remap_nt > RemapFields::kGroupMax) c->remap_nt = 3;
     e = std::getenv("FV3_MI355X_RIEM_SCR");
     c->riem_blocked = e ? (std::atoi(e) != 0) : 1;
+    e = std::getenv("FV3_MI355X_FAST");
+    c->fast = e ? (std::atoi(e) != 0) : 0;
     e = std::getenv("FV3_MI355X_REMAP_SCR");
     c->remap_blocked = e ? (std::atoi(e) != 0) : 1;
     e = std::getenv("FV3_MI355X_MARCH_TJ_KE");
@@ -1827,10 +1831,22 @@ extern "C" int fv3_set_condensate(fv3_ctx *c, const double *q_con, const double 
   return 0;
 }
 
+extern "C" int fv3_set_fast(fv3_ctx *c, int on) {
+  if (!c) return fail("fv3_set_fast: null context");
+  c->fast = on != 0;
+  return 0;
+}
+
 extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn, const double *hs, const double *w3,
                                  const double *pt, const double *delp, double *gz, double *pef, const double *ws) {
   if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver_c: bad context/arguments");
   if (cn->a_imp <= 0.5) return fail("fv3_riem_solver_c: a_imp <= 0.5 (RIM_2D / SIM3p0) is not built");
+  if (c->fast && !c->q_con && c->g.npz <= 127 && c->g.npz >= 2) {   // Riem_Solver_c is SIM1 whatever a_imp is
+    RiemFast<true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
+                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0};
+    RT(launch_p(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, 3 * kFBuf, kf));
+    return 0;
+  }
   if (need_scratch(c, 4)) return 1;
   const int ncc = (c->g.nx + 2) * (c->g.ny + 2), pool = col_pool(c, ncc);
   if (c->q_con) {
@@ -1852,6 +1868,12 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
   if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver3: bad context/arguments");
   if (cn->a_imp <= 0.5) return fail("fv3_riem_solver3: a_imp <= 0.5 (RIM_2D / SIM3 / SIM3p0) is not built");
   if (last_call && (!pe || !pk || !peln)) return fail("fv3_riem_solver3: last_call needs pe, pk, peln");
+  if (c->fast && !c->q_con && !c->cappa && cn->a_imp > 0.999 && c->g.npz <= 127 && c->g.npz >= 2) {
+    RiemFast<false> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
+                       use_logp, last_call, fp_out};
+    RT(launch_p(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, 3 * kFBuf, kf));
+    return 0;
+  }
   if (need_scratch(c, 4)) return 1;
   const int ncc = c->g.nx * c->g.ny, pool = col_pool(c, ncc);
   if (c->q_con || c->cappa) {

@@ -1,0 +1,488 @@
+// nh_fast.h -- the semi-implicit column solvers with the LEVELS ACROSS THE LANES (FV3_MI355X_FAST=1, the "fast mode" SURVEY 8(d) allows
+// beside the parity mode).
+//
+//   RiemFast<false>   Riem_Solver3   model/nh_core.F90:47-241   + SIM1_solver model/nh_utils.F90:1277-1394
+//   RiemFast<true>    Riem_Solver_c  model/nh_utils.F90:323-480 + SIM1_solver
+//
+// Why: the parity kernels (nh_kernels.h sim_column) run one thread per column with k sequential.  A 384 x 384 tile has 2 304 such
+// wavefronts for 1 024 SIMDs: 2.25 dependent instruction streams per SIMD, six sweeps through HBM scratch slabs (31 word accesses per
+// cell against 9 algorithmic) -- 10-13 % of their own roofline.  Here a 16-lane row of a wavefront owns ONE column, every
+// lane 8 consecutive levels of it (km <= 127), a wavefront 4 columns, a workgroup 16 consecutive columns of a row:
+//   * fields are read once with full 128-byte segments (16 columns x 8 B per level) and transposed through LDS; no scratch slabs;
+//   * everything that is pointwise in k (three log, three exp per cell, the matrix coefficients) is evaluated with the parity kernel's
+//     own expressions, 8 independent levels per lane;
+//   * the recurrences in k -- two tridiagonal solves, the pressure sum, the p1 recurrence of the new layer thickness, the height
+//     sum -- are linear-fractional / affine maps: each lane folds its 8 levels, the 16 lanes of a row combine the folds with a
+//     4-step scan of DPP row shifts, each lane replays its levels from the incoming value (Stone's recursive doubling, blocked);
+//   * the hydrostatic pressure pem(k) = ptop + sum delp IS summed in the reference's order (one thread per column over LDS): the
+//     pressure perturbation exp(..) - pm2 is a small difference, and a last-bit change of pem would be amplified ~1e3 times in it.
+// Not bit-identical to the oracle (the solves associate differently); held to it at 1e-12 relative RMS in the prognostic fields, measured
+// ~1e-14 (tests: test_riem_fast_*).  Dry, SIM1 (a_imp > 0.999), km <= 127; anything else takes the parity kernel.
+#pragma once
+
+#include "nh_kernels.h"
+#include "spmd.h"
+
+namespace fv3 {
+
+constexpr int kFL = 8;     // levels per lane
+constexpr int kFC = 16;    // columns per workgroup (4 per wavefront)
+constexpr int kFP = 130;   // doubles per column in an LDS transposition buffer (even: 16-byte aligned rows)
+constexpr int kFBuf = kFC * kFP;
+
+#ifdef FV3_HOST_EMU
+#define FV3_WAVE_FOR(wv) for (int wv = 0; wv < 4; wv++)
+constexpr int kWvState = 4;
+#define FV3_WVI(wv) (wv)
+#define FV3_LANE_LOOP for (int l = 0; l < kW; l++)
+template <int N>
+inline vd row_shr(const vd &a, double fill) {   // lane l <- lane l - N of the same 16-lane row, `fill` where there is none
+  vd r;
+  FV3_LANE_LOOP r.v[l] = ((l & 15) >= N) ? a.v[l - N] : fill;
+  return r;
+}
+template <int N>
+inline vd row_shl(const vd &a, double fill) {
+  vd r;
+  FV3_LANE_LOOP r.v[l] = ((l & 15) + N <= 15) ? a.v[l + N] : fill;
+  return r;
+}
+inline vd vlog(const vd &a) { vd r; FV3_LANE_LOOP r.v[l] = dlog(a.v[l]); return r; }
+inline vd vexp(const vd &a) { vd r; FV3_LANE_LOOP r.v[l] = dexp(a.v[l]); return r; }
+inline vd vrcp(const vd &a) { vd r; FV3_LANE_LOOP r.v[l] = 1. / a.v[l]; return r; }
+inline vd vfma(const vd &a, const vd &b, const vd &c) { vd r; FV3_LANE_LOOP r.v[l] = __builtin_fma(a.v[l], b.v[l], c.v[l]); return r; }
+inline vd vlds_ld(const double *buf, int col0, int q) {
+  vd r;
+  FV3_LANE_LOOP r.v[l] = buf[((l >> 4) + col0) * kFP + (l & 15) * kFL + q];
+  return r;
+}
+inline void vlds_st(double *buf, int col0, int q, const vd &x) {
+  FV3_LANE_LOOP buf[((l >> 4) + col0) * kFP + (l & 15) * kFL + q] = x.v[l];
+}
+inline vb vlevel_lt(int q, int k) { vb r; FV3_LANE_LOOP r.v[l] = (l & 15) * kFL + q < k; return r; }
+inline vb vlevel_eq(int q, int k) { vb r; FV3_LANE_LOOP r.v[l] = (l & 15) * kFL + q == k; return r; }
+inline vd vcol_ld(const double *p, long o0, int col0, int ncol) {   // p[o0 + column of the lane] (clamped to the block's last column)
+  vd r;
+  FV3_LANE_LOOP { const int c = (l >> 4) + col0; r.v[l] = p[o0 + (c < ncol ? c : ncol - 1)]; }
+  return r;
+}
+#else
+#define FV3_WAVE_FOR(wv) for (int wv = (int)(threadIdx.x >> 6), once_ = 1; once_; once_ = 0)
+constexpr int kWvState = 1;
+#define FV3_WVI(wv) 0
+template <int N>
+__device__ __forceinline__ vd row_shr(vd a, double fill) {   // DPP row_shr:N, lanes without a source keep `fill`
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(a), 0x110 + N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(a), 0x110 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int N>
+__device__ __forceinline__ vd row_shl(vd a, double fill) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(a), 0x100 + N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(a), 0x100 + N, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ vd vlog(vd a) { return dlog(a); }
+__device__ __forceinline__ vd vexp(vd a) { return dexp(a); }
+// 1/x to < 1 ulp (v_rcp_f64 + two Newton steps): the solves are tolerance-mode arithmetic
+__device__ __forceinline__ vd vrcp(vd b) {
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ vd vfma(vd a, vd b, vd c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ vd vlds_ld(const double *buf, int col0, int q) {
+  const int l = (int)(threadIdx.x & 63);
+  return buf[((l >> 4) + col0) * kFP + (l & 15) * kFL + q];
+}
+__device__ __forceinline__ void vlds_st(double *buf, int col0, int q, vd x) {
+  const int l = (int)(threadIdx.x & 63);
+  buf[((l >> 4) + col0) * kFP + (l & 15) * kFL + q] = x;
+}
+__device__ __forceinline__ vb vlevel_lt(int q, int k) { return (int)(threadIdx.x & 15) * kFL + q < k; }
+__device__ __forceinline__ vb vlevel_eq(int q, int k) { return (int)(threadIdx.x & 15) * kFL + q == k; }
+__device__ __forceinline__ vd vcol_ld(const double *p, long o0, int col0, int ncol) {
+  const int c = (int)((threadIdx.x & 63) >> 4) + col0;
+  return p[o0 + (c < ncol ? c : ncol - 1)];
+}
+#endif
+
+// ---- scans over the 16 lanes of a row --------------------------------------------------------------------------------------------
+// The lane's fold of its 8 levels is the affine map x -> A x + B.  Forward: on exit (A, B) is the composition of the folds of lanes
+// 0 .. m-1 of the row (EXCLUSIVE; identity for lane 0), i.e. the map from the value entering the column to the value entering lane m.
+template <int N>
+FV3_D void affine_step_fwd(vd &A, vd &B) {
+  const vd Ap = row_shr<N>(A, 1.0), Bp = row_shr<N>(B, 0.0);   // earlier lanes first: (A, B) o (Ap, Bp)
+  B = vfma(A, Bp, B);
+  A = A * Ap;
+}
+FV3_D void affine_scan_fwd_excl(vd &A, vd &B) {
+  affine_step_fwd<1>(A, B); affine_step_fwd<2>(A, B); affine_step_fwd<4>(A, B); affine_step_fwd<8>(A, B);
+  A = row_shr<1>(A, 1.0);
+  B = row_shr<1>(B, 0.0);
+}
+template <int N>
+FV3_D void affine_step_bwd(vd &A, vd &B) {
+  const vd Ap = row_shl<N>(A, 1.0), Bp = row_shl<N>(B, 0.0);   // the lanes BELOW are applied first when marching upwards
+  B = vfma(A, Bp, B);
+  A = A * Ap;
+}
+FV3_D void affine_scan_bwd_excl(vd &A, vd &B) {
+  affine_step_bwd<1>(A, B); affine_step_bwd<2>(A, B); affine_step_bwd<4>(A, B); affine_step_bwd<8>(A, B);
+  A = row_shl<1>(A, 1.0);
+  B = row_shl<1>(B, 0.0);
+}
+FV3_D vd sum_scan_fwd_excl(vd s) {   // sum of the lane totals of lanes 0 .. m-1
+  s = s + row_shr<1>(s, 0.0); s = s + row_shr<2>(s, 0.0); s = s + row_shr<4>(s, 0.0); s = s + row_shr<8>(s, 0.0);
+  return row_shr<1>(s, 0.0);
+}
+FV3_D vd sum_scan_bwd_excl(vd s) {
+  s = s + row_shl<1>(s, 0.0); s = s + row_shl<2>(s, 0.0); s = s + row_shl<4>(s, 0.0); s = s + row_shl<8>(s, 0.0);
+  return row_shl<1>(s, 0.0);
+}
+// 2 x 2 matrices [[p, q], [r, s]] (the linear-fractional map of the Thomas pivot); later o earlier = matrix product; scaled to
+// max |entry| = 1 after every product (a Moebius map does not care, the product of 128 pivots would overflow)
+struct Mob {
+  vd p, q, r, s;
+};
+FV3_D void mob_norm(Mob &m) {
+  const vd sc = vrcp(vmax(vmax(vabs(m.p), vabs(m.q)), vmax(vabs(m.r), vabs(m.s))));
+  m.p = m.p * sc; m.q = m.q * sc; m.r = m.r * sc; m.s = m.s * sc;
+}
+template <int N>
+FV3_D void mob_step_fwd(Mob &m) {
+  const vd pp = row_shr<N>(m.p, 1.0), qp = row_shr<N>(m.q, 0.0), rp = row_shr<N>(m.r, 0.0), sp = row_shr<N>(m.s, 1.0);
+  Mob o;
+  o.p = vfma(m.p, pp, m.q * rp);
+  o.q = vfma(m.p, qp, m.q * sp);
+  o.r = vfma(m.r, pp, m.s * rp);
+  o.s = vfma(m.r, qp, m.s * sp);
+  m = o;
+  mob_norm(m);
+}
+
+// Tridiagonal systems of one column, 8 rows per lane (rows beyond the system: a = c = d = 0, b = 1; a of the first row and c of the
+// last row are 0):   a_k x_{k-1} + b_k x_k + c_k x_{k+1} = d_k.   x may alias d.
+FV3_D void tridiag_rows(const vd *a, const vd *b, const vd *c, const vd *d, vd *x) {
+  vd e[kFL], rbet[kFL];
+  // e_k = a_k c_{k-1}: the pivot recurrence bet_k = b_k - e_k / bet_{k-1}
+  e[0] = a[0] * row_shr<1>(c[kFL - 1], 0.0);
+  for (int q = 1; q < kFL; q++) e[q] = a[q] * c[q - 1];
+  // (n, d) -> (b n - e d, n): fold the lane's 8 levels
+  Mob m;
+  m.p = b[0]; m.q = -e[0]; m.r = vd(1.0); m.s = vd(0.0);
+  for (int q = 1; q < kFL; q++) {
+    const vd np = vfma(b[q], m.p, -(e[q] * m.r)), nq = vfma(b[q], m.q, -(e[q] * m.s));
+    m.r = m.p; m.s = m.q;
+    m.p = np; m.q = nq;
+  }
+  mob_norm(m);
+  mob_step_fwd<1>(m); mob_step_fwd<2>(m); mob_step_fwd<4>(m); mob_step_fwd<8>(m);
+  // pivot entering the lane = (inclusive product of the lanes before) applied to (1, 0): bet = p / r, kept as its reciprocal
+  const vd pin = row_shr<1>(m.p, 1.0), rin = row_shr<1>(m.r, 0.0);
+  vd rb = rin * vrcp(pin);
+  for (int q = 0; q < kFL; q++) {
+    rb = vrcp(vfma(-e[q], rb, b[q]));
+    rbet[q] = rb;
+  }
+  // forward substitution y_k = (d_k - a_k y_{k-1}) / bet_k
+  {
+    vd A(1.0), B(0.0);
+    for (int q = 0; q < kFL; q++) {
+      const vd al = -(a[q] * rbet[q]), be = d[q] * rbet[q];
+      B = vfma(al, B, be);
+      A = al * A;
+    }
+    affine_scan_fwd_excl(A, B);
+    vd y = B;   // the value entering the column is 0
+    for (int q = 0; q < kFL; q++) {
+      y = (d[q] - a[q] * y) * rbet[q];
+      x[q] = y;
+    }
+  }
+  // back substitution x_k = y_k - (c_k / bet_k) x_{k+1}
+  {
+    vd A(1.0), B(0.0);
+    for (int q = kFL - 1; q >= 0; q--) {
+      const vd g = -(c[q] * rbet[q]);
+      B = vfma(g, B, x[q]);
+      A = g * A;
+    }
+    affine_scan_bwd_excl(A, B);
+    vd xn = B;
+    for (int q = kFL - 1; q >= 0; q--) {
+      xn = x[q] - (c[q] * rbet[q]) * xn;
+      x[q] = xn;
+    }
+  }
+}
+
+// CG = true: Riem_Solver_c on (is-1:ie+1, js-1:je+1); false: Riem_Solver3 on the compute domain
+template <bool CG>
+struct RiemFast {
+  Grid g;
+  int km;
+  double dt;
+  NhConsts cn;
+  // inputs (names of RiemSolver3 / RiemSolverC): zs = zs / hs; wq = w / w3; zl = zh / gz (updated in place)
+  const double *zs, *pt, *delp, *ws;
+  double *wq, *zl;
+  // outputs: D grid: delz, ppe, pk3 (+ pe, pk, peln on the last call); C grid: pef
+  double *delz, *ppe, *pk3, *pe, *pk, *peln, *pef;
+  int use_logp, last_call, fp_out;
+
+  FV3_HD int i_first() const { return CG ? g.is - 1 : g.is; }
+  FV3_HD int ncols_row() const { return CG ? g.nx + 2 : g.nx; }
+  FV3_HD int nrows() const { return CG ? g.ny + 2 : g.ny; }
+  FV3_HD int nblocks_x() const { return (ncols_row() + kFC - 1) / kFC; }
+
+  // one level-major A-layout field -> LDS [column][level]; lev levels (<= 128); fill for what does not exist
+  FV3_D void stage_in(double *buf, const double *f, size_t o0, int ncol, int lev, double fill, int tid) const {
+    const size_t nA = g.nA();
+    for (int idx = tid; idx < kFC * 128; idx += kNT) {
+      const int col = idx & (kFC - 1), k = idx >> 4;
+      buf[col * kFP + k] = (k < lev && col < ncol) ? f[(size_t)k * nA + o0 + col] : fill;
+    }
+  }
+  template <class Addr>
+  FV3_D void stage_out(const double *buf, double *f, int ncol, int lev, int tid, const Addr &addr) const {
+    for (int idx = tid; idx < kFC * 128; idx += kNT) {
+      const int col = idx & (kFC - 1), k = idx >> 4;
+      if (k < lev && col < ncol) f[addr(col, k)] = buf[col * kFP + k];
+    }
+  }
+
+  FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
+    double *B0 = lds, *B1 = lds + kFBuf, *B2 = lds + 2 * kFBuf;
+    const int i0 = i_first() + bx * kFC, j = (CG ? g.js - 1 : g.js) + by;
+    const int ncol = (ncols_row() - bx * kFC < kFC) ? ncols_row() - bx * kFC : kFC;
+    const size_t nA = g.nA(), nCC = g.nCC();
+    const size_t o0 = (size_t)g.iA(i0, j);
+    const double rgrav = 1. / cn.grav, rgas = cn.rdgas, gm2 = 1. / (1. - cn.akap), cp2 = cn.akap;
+    const double t1g = 2. * dt * dt, rdt = 1. / dt;
+    constexpr double r3 = 1. / 3.;
+    vd dmr[kWvState][kFL], ptv[kWvState][kFL], pem[kWvState][kFL + 1], w1[kWvState][kFL], zv[kWvState][kFL + 1];
+    // ---- inputs: delp, pt; pem in the reference's summation order ----
+    stage_in(B0, delp, o0, ncol, km, 1.0, tid);
+    stage_in(B1, pt, o0, ncol, km, 300.0, tid);
+    FV3_SYNC();
+    for (int col = tid; col < kFC; col += kNT) {   // nh_core.F90:132-141 / nh_utils.F90:404-441: pem(k+1) = pem(k) + delp(k)
+      double p = cn.ptop;
+      B2[col * kFP] = p;
+      for (int k = 0; k < 128; k++) {
+        p = p + B0[col * kFP + k];
+        B2[col * kFP + k + 1] = p;
+      }
+    }
+    FV3_SYNC();
+    FV3_WAVE_FOR(wv) {
+      const int s = FV3_WVI(wv), c0 = wv * 4;
+      for (int q = 0; q < kFL; q++) {
+        dmr[s][q] = vlds_ld(B0, c0, q);
+        ptv[s][q] = vlds_ld(B1, c0, q);
+        pem[s][q] = vlds_ld(B2, c0, q);
+      }
+      pem[s][kFL] = vlds_ld(B2, c0, kFL);
+    }
+    FV3_SYNC();
+    stage_in(B0, wq, o0, ncol, km, 0.0, tid);
+    {  // interface heights: beyond km+1 continue downwards by 1 m per level so that the padded layers stay regular
+      for (int idx = tid; idx < kFC * 128; idx += kNT) {
+        const int col = idx & (kFC - 1), k = idx >> 4;
+        B1[col * kFP + k] = (k <= km && col < ncol) ? zl[(size_t)k * nA + o0 + col] : -1.0e3 - (double)k;
+      }
+      for (int col = tid; col < kFC; col += kNT) { B1[col * kFP + 128] = -1.0e3 - 128.; B1[col * kFP + 129] = -1.0e3 - 129.; }
+    }
+    FV3_SYNC();
+    FV3_WAVE_FOR(wv) {
+      const int s = FV3_WVI(wv), c0 = wv * 4;
+      for (int q = 0; q < kFL; q++) {
+        w1[s][q] = vlds_ld(B0, c0, q);
+        zv[s][q] = vlds_ld(B1, c0, q);
+      }
+      zv[s][kFL] = vlds_ld(B1, c0, kFL);
+    }
+    FV3_SYNC();
+    // ---- the column: everything below is per wavefront, no barrier until the outputs ----
+    FV3_WAVE_FOR(wv) {
+      const int s = FV3_WVI(wv), c0 = wv * 4;
+      vd dm[kFL], dz[kFL], pm2[kFL], pei[kFL], grat[kFL], bb[kFL], lnp[kFL + 1], X[kFL];
+      vb real[kFL], last[kFL];
+      for (int q = 0; q < kFL; q++) {
+        real[q] = vlevel_lt(q, km);
+        last[q] = vlevel_eq(q, km - 1);
+      }
+      // hydrostatic pressure functions, perturbation pressure (nh_utils.F90:1297-1300; nh_core.F90:140-159 / nh_utils.F90:440)
+      if (!CG) {
+        for (int q = 0; q < kFL; q++) lnp[q] = vlog(pem[s][q]);
+        lnp[kFL] = row_shl<1>(lnp[0], 0.0);
+      }
+      for (int q = 0; q < kFL; q++) {
+        const vd d = dmr[s][q];
+        if (CG)
+          pm2[q] = d / vlog(pem[s][q + 1] / pem[s][q]);
+        else
+          pm2[q] = d / (lnp[q + 1] - lnp[q]);
+        dm[q] = d * rgrav;
+        dz[q] = zv[s][q + 1] - zv[s][q];
+        pei[q] = vexp(gm2 * vlog(-dm[q] / dz[q] * rgas * ptv[s][q])) - pm2[q];
+      }
+      // ---- pp: forward / backward elimination of nh_utils.F90:1302-1332 as one tridiagonal system; X(k) = pp(k+1) ----
+      {
+        vd a[kFL], c[kFL], d[kFL];
+        const vd dm_nx = row_shl<1>(dm[0], 1.0), pe_nx = row_shl<1>(pei[0], 0.0);
+        for (int q = 0; q < kFL; q++) {
+          const vd dmn = (q < kFL - 1) ? dm[q + 1] : dm_nx, pen = (q < kFL - 1) ? pei[q + 1] : pe_nx;
+          const vd gr = dm[q] / dmn;
+          grat[q] = vsel(last[q], vd(0.0), gr);
+          bb[q] = vsel(last[q], vd(2.0), 2. * (1. + gr));
+          const vd dd = vsel(last[q], 3. * pei[q], 3. * (pei[q] + gr * pen));
+          a[q] = vsel(real[q] && !vlevel_eq(q, 0), vd(1.0), vd(0.0));
+          c[q] = vsel(real[q], grat[q], vd(0.0));
+          d[q] = vsel(real[q], dd, vd(0.0));
+          bb[q] = vsel(real[q], bb[q], vd(1.0));
+        }
+        tridiag_rows(a, bb, c, d, X);
+      }
+      // ---- w: nh_utils.F90:1335-1361 ----
+      vd w2[kFL];
+      {
+        vd a[kFL], b[kFL], c[kFL], d[kFL], aat[kFL];
+        const vd dz_pv = row_shr<1>(dz[kFL - 1], 1.0), X_pv = row_shr<1>(X[kFL - 1], 0.0);
+        for (int q = 0; q < kFL; q++) {   // aa at the top interface of the layer (0 at the model top)
+          const vd dzp = (q > 0) ? dz[q - 1] : dz_pv;
+          const vd aa = t1g * 0.5 * (gm2 + gm2) / (dzp + dz[q]) * pem[s][q];
+          aat[q] = vsel(real[q] && !vlevel_eq(q, 0), aa, vd(0.0));
+        }
+        const vd aat_nx = row_shl<1>(aat[0], 0.0);
+        const vd wsv = vcol_ld(ws, CG ? (long)o0 : (long)g.iCC(i0, j), c0, ncol);
+        for (int q = 0; q < kFL; q++) {
+          const vd aab = (q < kFL - 1) ? aat[q + 1] : aat_nx;
+          const vd p1c = t1g * gm2 / dz[q] * pem[s][q + 1];      // bottom layer only (:1349)
+          const vd ppt = (q > 0) ? X[q - 1] : X_pv;                // pp at the top interface of the layer
+          const vd low = vsel(last[q], p1c, aab);
+          a[q] = aat[q];
+          b[q] = vsel(real[q], dm[q] - (aat[q] + low), vd(1.0));
+          c[q] = vsel(real[q] && !last[q], aab, vd(0.0));
+          const vd rhs = dm[q] * w1[s][q] + dt * (X[q] - ppt);
+          d[q] = vsel(real[q], vsel(last[q], rhs - p1c * wsv, rhs), vd(0.0));
+        }
+        tridiag_rows(a, b, c, d, w2);
+      }
+      // ---- pe2 at the interfaces (:1373-1380): exclusive sum of dm2 (w2 - w1) / dt ----
+      vd pe2[kFL + 2];
+      {
+        vd inc[kFL], tot(0.0);
+        for (int q = 0; q < kFL; q++) {
+          inc[q] = vsel(real[q], dm[q] * (w2[q] - w1[s][q]) * rdt, vd(0.0));
+          tot = tot + inc[q];
+        }
+        vd run = sum_scan_fwd_excl(tot);
+        for (int q = 0; q < kFL; q++) {
+          pe2[q] = run;
+          run = run + inc[q];
+        }
+        pe2[kFL] = row_shl<1>(pe2[0], 0.0);
+        pe2[kFL + 1] = row_shl<1>(pe2[1], 0.0);
+        // the interface below the lane's last layer when that is the model's bottom (lane 15 has no lane below)
+        pe2[kFL] = vsel(vlevel_eq(kFL - 1, km - 1), run, pe2[kFL]);
+      }
+      // ---- p1 (upward recurrence, :1382-1392) and the new layer thickness ----
+      vd dzn[kFL];
+      {
+        vd Aq[kFL], Bq[kFL];
+        for (int q = 0; q < kFL; q++) {
+          const vd Bl = (pe2[q] + 2. * pe2[q + 1]) * r3;
+          const vd Bi = (pe2[q] + bb[q] * pe2[q + 1] + grat[q] * pe2[q + 2]) * r3;
+          Aq[q] = vsel(real[q] && !last[q], -grat[q], vd(0.0));
+          Bq[q] = vsel(real[q], vsel(last[q], Bl, Bi), vd(0.0));
+        }
+        vd A(1.0), B(0.0);
+        for (int q = kFL - 1; q >= 0; q--) {
+          B = vfma(Aq[q], B, Bq[q]);
+          A = Aq[q] * A;
+        }
+        affine_scan_bwd_excl(A, B);
+        vd p1 = B;
+        for (int q = kFL - 1; q >= 0; q--) {
+          p1 = Bq[q] + Aq[q] * p1;
+          dzn[q] = -dm[q] * rgas * ptv[s][q] * vexp((cp2 - 1.) * vlog(vmax(cn.p_fac * pm2[q], p1 + pm2[q])));
+        }
+      }
+      // ---- interface heights from the surface upwards (nh_core.F90:228-237 / nh_utils.F90:468-476) ----
+      vd zn[kFL];
+      {
+        vd tot(0.0);
+        for (int q = 0; q < kFL; q++) {
+          dzn[q] = vsel(real[q], dzn[q], vd(0.0));
+          tot = tot + (CG ? dzn[q] * cn.grav : dzn[q]);
+        }
+        const vd zsv = vcol_ld(zs, (long)o0, c0, ncol);
+        vd run = zsv - sum_scan_bwd_excl(tot);     // height of the interface below the lane's last layer
+        for (int q = kFL - 1; q >= 0; q--) {
+          run = run - (CG ? dzn[q] * cn.grav : dzn[q]);
+          zn[q] = run;
+        }
+        // interface km (the surface) sits at (lane km / 8, q = km % 8): there every layer below is padding and run == zs
+      }
+      // ---- outputs through LDS, in the fields' own layouts ----
+      for (int q = 0; q < kFL; q++) {
+        vlds_st(B0, c0, q, zn[q]);
+        if (CG) {
+          vlds_st(B1, c0, q, vsel(vlevel_eq(q, 0), vd(cn.ptop), pe2[q] + pem[s][q]));   // pef (:461-465)
+        } else {
+          vlds_st(B1, c0, q, w2[q]);
+          vlds_st(B2, c0, q, dzn[q]);
+        }
+      }
+      // keep what the second round needs
+      if (!CG) {
+        for (int q = 0; q < kFL; q++) {
+          dmr[s][q] = fp_out ? pe2[q] + pem[s][q] : pe2[q];                                                // ppe
+          ptv[s][q] = vsel(vlevel_eq(q, 0), vd(dexp(cn.akap * dlog(cn.ptop))), vexp(cn.akap * lnp[q]));   // pk
+          w1[s][q] = lnp[q];                                                                               // peln
+        }
+      }
+    }
+    FV3_SYNC();
+    stage_out(B0, zl, ncol, km + 1, tid, [&](int col, int k) { return (size_t)k * nA + o0 + col; });
+    if (CG) {
+      stage_out(B1, pef, ncol, km + 1, tid, [&](int col, int k) { return (size_t)k * nA + o0 + col; });
+      return;
+    }
+    const size_t occ0 = (size_t)g.iCC(i0, j);
+    stage_out(B1, wq, ncol, km, tid, [&](int col, int k) { return (size_t)k * nA + o0 + col; });
+    stage_out(B2, delz, ncol, km, tid, [&](int col, int k) { return (size_t)k * nCC + occ0 + col; });
+    FV3_SYNC();
+    FV3_WAVE_FOR(wv) {
+      const int s = FV3_WVI(wv), c0 = wv * 4;
+      for (int q = 0; q < kFL; q++) {
+        vlds_st(B0, c0, q, dmr[s][q]);
+        vlds_st(B1, c0, q, use_logp ? vsel(vlevel_eq(q, 0), ptv[s][q], w1[s][q]) : ptv[s][q]);   // pk3(1) = ptk either way (nh_core.F90:87)
+        if (last_call) vlds_st(B2, c0, q, ptv[s][q]);
+      }
+    }
+    FV3_SYNC();
+    stage_out(B0, ppe, ncol, km + 1, tid, [&](int col, int k) { return (size_t)k * nA + o0 + col; });
+    stage_out(B1, pk3, ncol, km + 1, tid, [&](int col, int k) { return (size_t)k * nA + o0 + col; });
+    if (!last_call) return;
+    stage_out(B2, pk, ncol, km + 1, tid, [&](int col, int k) { return (size_t)k * nCC + occ0 + col; });
+    FV3_SYNC();
+    FV3_WAVE_FOR(wv) {
+      const int s = FV3_WVI(wv), c0 = wv * 4;
+      for (int q = 0; q < kFL; q++) {
+        vlds_st(B0, c0, q, w1[s][q]);
+        vlds_st(B1, c0, q, pem[s][q]);
+      }
+    }
+    FV3_SYNC();
+    stage_out(B0, peln, ncol, km + 1, tid, [&](int col, int k) {
+      return (size_t)(j - g.js) * g.nx * (km + 1) + (size_t)k * g.nx + (i0 - g.is) + col; });
+    stage_out(B1, pe, ncol, km + 1, tid, [&](int col, int k) {
+      return (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (size_t)k * (g.nx + 2) + (i0 - (g.is - 1)) + col; });
+  }
+};
+
+}  // namespace fv3

@@ -243,6 +243,13 @@ int fv3_update_dz_c(fv3_ctx *ctx, double dt, const double *zs, const double *ut,
  * uses cappa only together with q_con. */
 int fv3_set_condensate(fv3_ctx *ctx, const double *q_con, const double *cappa);
 
+/* Precision mode of the column solvers.  0 (default): the parity kernels -- the reference's elimination order, bit-comparable with
+ * the CPU oracle.  1: fast mode ("a fast mode beside the parity mode"): Riem_Solver_c / Riem_Solver3 with the levels
+ * across the lanes and the tridiagonal / prefix recurrences as blocked parallel scans (csrc/nh_fast.h) -- same equations, different
+ * association, within 1e-12 relative RMS of the parity mode.  Also selected by the environment variable FV3_MI355X_FAST=1 at fv3_create.
+ * Moist (fv3_set_condensate) and a_imp <= 0.999 calls take the parity kernels in either mode. */
+int fv3_set_fast(fv3_ctx *ctx, int on);
+
 /* Riem_Solver_c -- model/nh_utils.F90:323, call site model/dyn_core.F90:531 (a_imp > 0.5: SIM1_solver).
  * hs, ws: A; w3 (=omga), pt (=ptc), delp (=delpc): A x npz; gz (in/out), pef (=pkc, out): A x (npz+1). */
 int fv3_riem_solver_c(fv3_ctx *ctx, double dt, const fv3_nh_consts *cn, const double *hs, const double *w3,

@@ -51,7 +51,7 @@ def moist_fields(bd, km, seed=17):
     return q_con, cappa
 
 
-def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, moist_kappa=False):
+def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, moist_kappa=False, fast=False):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     s = nh_state(bd, km)
@@ -71,18 +71,21 @@ def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, mois
     ctx = Context(g, km, lib=lib)
     try:
         d_gz, d_pef = ctx.from_host(s["zh"]), ctx.zeros("A", km + 1)
+        ctx.set_fast(fast)          # fast mode (csrc/nh_fast.h): held to the oracle at 1e-12, not bit for bit
         ctx.set_condensate(ctx.from_host(q_con) if use_cond else None, ctx.from_host(cappa) if moist_kappa else None)
         ctx.riem_solver_c(3.0, cn, ctx.from_host(hs), ctx.from_host(s["w"]), ctx.from_host(s["pt"]),
                           ctx.from_host(s["delp"]), d_gz, d_pef, ctx.from_host(ws))
         r = (bd.is_ - 1, bd.ie + 1, bd.js - 1, bd.je + 1)
-        P.assert_close("gz", bd.view(d_gz.download(), "A", *r), bd.view(gz, "A", *r), _tol(lib))
-        P.assert_close("pef", bd.view(d_pef.download(), "A", *r), bd.view(pef, "A", *r), _tol(lib))
+        tol = 1e-12 if fast else _tol(lib)
+        e1 = P.assert_close("gz", bd.view(d_gz.download(), "A", *r), bd.view(gz, "A", *r), tol)
+        e2 = P.assert_close("pef", bd.view(d_pef.download(), "A", *r), bd.view(pef, "A", *r), tol)
     finally:
         ctx.close()
+    return max(e1, e2)
 
 
 def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_call=True, fp_out=False, use_cond=False,
-                       moist_kappa=False):
+                       moist_kappa=False, fast=False):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     s = nh_state(bd, km)
@@ -104,7 +107,9 @@ def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_
                        o0["pk3"], o0["pk"], o0["peln"], ws, use_logp, last_call, fp_out)
         assert P.rel_rms(o0["delz"], o["delz"]) > 1e-8
     ctx = Context(g, km, lib=lib)
+    worst = 0.0
     try:
+        ctx.set_fast(fast)
         ctx.set_condensate(ctx.from_host(q_con) if use_cond else None, ctx.from_host(cappa) if moist_kappa else None)
         d = {k: ctx.from_host(v) for k, v in dict(w=s["w"], zh=s["zh"], delz=bd.zeros("CC", km),
                                                    ppe=bd.zeros("A", km + 1), pk3=bd.full("A", 1e40, km + 1),
@@ -115,16 +120,17 @@ def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_
                          ctx.from_host(s["delp"]), d["zh"], d["pe"], d["ppe"], d["pk3"], d["pk"], d["peln"],
                          ctx.from_host(ws), use_logp, last_call, fp_out)
         r = (bd.is_, bd.ie, bd.js, bd.je)
-        tol = _tol(lib)
+        tol = 1e-12 if fast else _tol(lib)
         for n in ("w", "zh", "ppe", "pk3"):
-            P.assert_close(n, bd.view(d[n].download(), "A", *r), bd.view(o[n], "A", *r), tol)
-        P.assert_close("delz", d["delz"].download(), o["delz"], tol)
+            worst = max(worst, P.assert_close(n, bd.view(d[n].download(), "A", *r), bd.view(o[n], "A", *r), tol))
+        worst = max(worst, P.assert_close("delz", d["delz"].download(), o["delz"], tol))
         if last_call:
-            P.assert_close("pk", d["pk"].download(), o["pk"], tol)
-            P.assert_close("peln", d["peln"].download(), o["peln"], tol)
-            P.assert_close("pe", d["pe"].download()[1:-1, :, 1:-1], o["pe"][1:-1, :, 1:-1], tol)
+            worst = max(worst, P.assert_close("pk", d["pk"].download(), o["pk"], tol))
+            worst = max(worst, P.assert_close("peln", d["peln"].download(), o["peln"], tol))
+            worst = max(worst, P.assert_close("pe", d["pe"].download()[1:-1, :, 1:-1], o["pe"][1:-1, :, 1:-1], tol))
     finally:
         ctx.close()
+    return worst
 
 
 def check_update_dz_d(lib, nx=40, ny=19, km=5, lev_over=None, hord=10):

@@ -549,6 +549,29 @@ def test_d_sw_interior_does_not_read_halos_in_flight(prod, monkeypatch):
         assert max(P.check_d_sw(prod, nx=nx, ny=ny, npz=3, phases="poison").values()) <= P.TOL
 
 
+# ---- fast (tolerance) mode of the column solvers: csrc/nh_fast.h, levels across the lanes, blocked parallel scans for the two
+# ---- tridiagonal solves and the prefix recurrences.  NOT bit-identical by construction; north_star's bar is rel-RMS < 1e-12.
+@pytest.mark.parametrize("km", [8, 32, 79, 127])
+def test_riem_fast_against_the_oracle(prod, km):
+    dims = dict(nx=200, ny=24, km=km) if km >= 79 else dict(nx=37, ny=13, km=km)     # ragged last 16-column block
+    assert N.check_riem_solver_c(prod, fast=True, **dims) <= 1e-12
+    assert N.check_riem_solver3(prod, fast=True, **dims) <= 1e-12
+    assert N.check_riem_solver3(prod, fast=True, use_logp=True, last_call=True, fp_out=True, **dims) <= 1e-12
+    assert N.check_riem_solver3(prod, fast=True, last_call=False, **dims) <= 1e-12
+
+
+def test_fast_mode_whole_steps(prod, monkeypatch):
+    """whole nonhydrostatic substep loops and an fv_dynamics cycle on the sphere with FV3_MI355X_FAST=1 (every context created under it
+    takes the fast column solvers) against the oracle-orchestrated equivalents.  w is the sensitive field (ill-conditioned implicit
+    solve, tests/test_hostemu_parity.py::test_fast_mode_substeps): <= 1e-11; everything else <= 1e-12."""
+    monkeypatch.setenv("FV3_MI355X_FAST", "1")
+    for kw in (dict(nx=48, ny=32, npz=79, n_split=3, bdt=6.0), dict(nx=40, ny=24, npz=127, n_split=2, bdt=4.0)):
+        r = D.check_substeps(prod, tol=1e-11, **kw)
+        assert r["w"] <= 1e-11 and max(v for k, v in r.items() if k != "w") <= 1e-12, r
+    r = PC.check_jw_step(prod, npx=25, npz=79, k_split=2, n_split=3, bdt=900.0, hydrostatic=False, tol=1e-10)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-10, r
+
+
 # ---- the column path at BASELINE depth (L79 = configs 2 and 5, L127 = configs 3 and 4): per-wavefront blocked scratch
 # ---- slabs, register budgets and unrolling of the k loops are exercised at the depth the configurations run at
 @pytest.mark.parametrize("km", [79, 127])
