@@ -171,6 +171,21 @@ static int launch_p(fv3_ctx *c, const char *label, Dim3 grid, size_t lds_doubles
   return rc;
 }
 
+template <class F>
+static int launch_p2(fv3_ctx *c, const char *label, Dim3 grid, size_t lds_doubles, const F &f) {
+  void *e0 = nullptr, *e1 = nullptr;
+  if (c->prof_on) {
+    if (prof_events(&e0, &e1)) return 1;
+    rt_event_record(e0, c->stream);
+  }
+  int rc = launch_2w(grid, lds_doubles, c->stream, f);
+  if (c->prof_on) {
+    rt_event_record(e1, c->stream);
+    c->prof.push_back({label, e0, e1});
+  }
+  return rc;
+}
+
 template <int W = 0, class F>
 static int launch_c(fv3_ctx *c, const char *label, Dim3 grid, const F &f, int lanes = 0) {
   void *e0 = nullptr, *e1 = nullptr;
@@ -1844,7 +1859,7 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn,
   if (c->fast && !c->q_con && c->g.npz <= 127 && c->g.npz >= 2) {   // Riem_Solver_c is SIM1 whatever a_imp is
     RiemFast<true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0};
-    RT(launch_p(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, 3 * kFBuf, kf));
+    RT(launch_p2(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
     return 0;
   }
   if (need_scratch(c, 4)) return 1;
@@ -1871,7 +1886,7 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
   if (c->fast && !c->q_con && !c->cappa && cn->a_imp > 0.999 && c->g.npz <= 127 && c->g.npz >= 2) {
     RiemFast<false> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
                        use_logp, last_call, fp_out};
-    RT(launch_p(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, 3 * kFBuf, kf));
+    RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
     return 0;
   }
   if (need_scratch(c, 4)) return 1;

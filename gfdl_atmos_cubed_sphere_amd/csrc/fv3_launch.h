@@ -29,6 +29,8 @@ inline int launch(Dim3 grid, size_t lds_doubles, stream_t, const F &f) {
       for (unsigned x = 0; x < grid.x; x++) f((int)x, (int)y, (int)z, 0, lds.data());  // order irrelevant here
   return 0;
 }
+template <class F>
+inline int launch_2w(Dim3 grid, size_t lds_doubles, stream_t s, const F &f) { return launch(grid, lds_doubles, s, f); }
 // column kernels (one thread per column)
 template <int W = 0, class F>
 inline int launch_cols(Dim3 grid, stream_t s, const F &f, int = 0) { return launch(grid, 0, s, f); }
@@ -100,6 +102,28 @@ inline int launch(Dim3 grid, size_t lds_doubles, stream_t s, const F &f) {
     }
   }
   hipLaunchKernelGGL(tile_kernel<F>, dim3(grid.z, grid.x, grid.y), dim3(kNT), bytes, s, f);
+  return (int)hipGetLastError();
+}
+// the same under a register budget of two wavefronts per SIMD (<= 256 VGPRs + AGPRs): kernels whose latency hiding needs the second
+// workgroup of a CU more than the last registers (nh_fast.h)
+template <class F>
+__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) tile_kernel_2w(const F f) {
+  extern __shared__ double fv3_lds[];
+  f((int)blockIdx.y, (int)blockIdx.z, (int)blockIdx.x, (int)threadIdx.x, fv3_lds);
+}
+template <class F>
+inline int launch_2w(Dim3 grid, size_t lds_doubles, stream_t s, const F &f) {
+  const size_t bytes = lds_doubles * sizeof(double);
+  if (bytes > 64 * 1024) {
+    static thread_local bool done = false;
+    if (!done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_kernel_2w<F>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e != hipSuccess) return (int)e;
+      done = true;
+    }
+  }
+  hipLaunchKernelGGL(tile_kernel_2w<F>, dim3(grid.z, grid.x, grid.y), dim3(kNT), bytes, s, f);
   return (int)hipGetLastError();
 }
 // Column kernels (one thread per (i,j) column, long serial k loops, no LDS): launched as 64-thread workgroups so that

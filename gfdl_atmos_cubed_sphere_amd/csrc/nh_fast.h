@@ -14,8 +14,9 @@
 //   * the recurrences in k -- two tridiagonal solves, the pressure sum, the p1 recurrence of the new layer thickness, the height
 //     sum -- are linear-fractional / affine maps: each lane folds its 8 levels, the 16 lanes of a row combine the folds with a
 //     4-step scan of DPP row shifts, each lane replays its levels from the incoming value (Stone's recursive doubling, blocked);
-//   * the hydrostatic pressure pem(k) = ptop + sum delp IS summed in the reference's order (one thread per column over LDS): the
-//     pressure perturbation exp(..) - pm2 is a small difference, and a last-bit change of pem would be amplified ~1e3 times in it.
+//   * the hydrostatic pressure pem(k) = ptop + sum delp: the lane's 8 levels in the reference's order on top of a scanned sum of the
+//     lanes above (a one-thread-per-column sum over LDS in the reference's order kept pk3 / pe / peln bit-identical but cost 19 k
+//     cycles per workgroup; the ulp it saves is below what one ulp of an interface height does to the perturbation pressure).
 // Not bit-identical to the oracle (the solves associate differently); held to it at 1e-12 relative RMS in the prognostic fields, measured
 // ~1e-14 (tests: test_riem_fast_*).  Dry, SIM1 (a_imp > 0.999), km <= 127; anything else takes the parity kernel.
 #pragma once
@@ -27,8 +28,11 @@ namespace fv3 {
 
 constexpr int kFL = 8;     // levels per lane
 constexpr int kFC = 16;    // columns per workgroup (4 per wavefront)
-constexpr int kFP = 130;   // doubles per column in an LDS transposition buffer (even: 16-byte aligned rows)
+constexpr int kFS = kFL + 1;         // doubles per 8-level chunk in LDS: 9, so that the 16 lanes of a column hit 16 different bank pairs
+constexpr int kFP = 16 * kFS + 1;   // doubles per column in an LDS transposition buffer (level k at (k / 8) * 9 + k % 8)
 constexpr int kFBuf = kFC * kFP;
+constexpr int kFNBuf = 4;           // transposition buffers per workgroup (all four inputs staged at once: one barrier)
+FV3_HD int lds_lev(int k) { return (k >> 3) * kFS + (k & 7); }
 
 #ifdef FV3_HOST_EMU
 #define FV3_WAVE_FOR(wv) for (int wv = 0; wv < 4; wv++)
@@ -53,11 +57,11 @@ inline vd vrcp(const vd &a) { vd r; FV3_LANE_LOOP r.v[l] = 1. / a.v[l]; return r
 inline vd vfma(const vd &a, const vd &b, const vd &c) { vd r; FV3_LANE_LOOP r.v[l] = __builtin_fma(a.v[l], b.v[l], c.v[l]); return r; }
 inline vd vlds_ld(const double *buf, int col0, int q) {
   vd r;
-  FV3_LANE_LOOP r.v[l] = buf[((l >> 4) + col0) * kFP + (l & 15) * kFL + q];
+  FV3_LANE_LOOP r.v[l] = buf[((l >> 4) + col0) * kFP + (l & 15) * kFS + q];
   return r;
 }
 inline void vlds_st(double *buf, int col0, int q, const vd &x) {
-  FV3_LANE_LOOP buf[((l >> 4) + col0) * kFP + (l & 15) * kFL + q] = x.v[l];
+  FV3_LANE_LOOP buf[((l >> 4) + col0) * kFP + (l & 15) * kFS + q] = x.v[l];
 }
 inline vb vlevel_lt(int q, int k) { vb r; FV3_LANE_LOOP r.v[l] = (l & 15) * kFL + q < k; return r; }
 inline vb vlevel_eq(int q, int k) { vb r; FV3_LANE_LOOP r.v[l] = (l & 15) * kFL + q == k; return r; }
@@ -82,8 +86,61 @@ __device__ __forceinline__ vd row_shl(vd a, double fill) {
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(a), 0x100 + N, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ vd vlog(vd a) { return dlog(a); }
-__device__ __forceinline__ vd vexp(vd a) { return dexp(a); }
+// fv3_log / fv3_exp (include/fv3_math.h) WITHOUT their special-case branches (zero / subnormal / negative / inf / NaN arguments, overflow
+// and underflow of exp): the arguments here are pressures, densities and their logarithms times kappa -- finite, positive, normal.  The
+// arithmetic of the main path is the same operation for operation, so the values are fv3_log's / fv3_exp's bit for bit; without the
+// branches the 8 independent levels of a lane interleave instead of running one call after the other.
+__device__ __forceinline__ vd vlog(vd x) {
+  const double LN2_HI = 0x1.62e42feep-1, LN2_LO = 0x1.a39ef35793c76p-33;
+  const long long ix = fv3m_bits(x);
+  const long long tmp = ix - 0x3fe6a09e667f3bcdLL;
+  const int k = (int)(tmp >> 52);
+  const double m = fv3m_from_bits(ix - (long long)((unsigned long long)tmp & 0xfff0000000000000ULL));
+  const double f = m - 1.0;
+  const double den = 2.0 + f;                       // in [1.7, 3.5]: the Markstein quotient below IS the IEEE quotient
+  const double s = vdiv_r(f, den, vrecip(den));
+  const double z = s * s, w = z * z;
+  double t1 = 0x1.8618618618618p-4;
+  t1 = __builtin_fma(t1, w, 0x1.e1e1e1e1e1e1ep-4);
+  t1 = __builtin_fma(t1, w, 0x1.3b13b13b13b14p-3);
+  t1 = __builtin_fma(t1, w, 0x1.c71c71c71c71cp-3);
+  t1 = __builtin_fma(t1, w, 0x1.999999999999ap-2);
+  double t2 = 0x1.642c8590b2164p-4;
+  t2 = __builtin_fma(t2, w, 0x1.af286bca1af28p-4);
+  t2 = __builtin_fma(t2, w, 0x1.1111111111111p-3);
+  t2 = __builtin_fma(t2, w, 0x1.745d1745d1746p-3);
+  t2 = __builtin_fma(t2, w, 0x1.2492492492492p-2);
+  t2 = __builtin_fma(t2, w, 0x1.5555555555555p-1);
+  const double R = __builtin_fma(t1, w, t2 * z);
+  const double hfsq = 0.5 * f * f;
+  const double kd = (double)k;
+  return kd * LN2_HI - ((hfsq - __builtin_fma(s, hfsq + R, kd * LN2_LO)) - f);
+}
+__device__ __forceinline__ vd vexp(vd x) {
+  const double INV_LN2 = 0x1.71547652b82fep+0;
+  const double LN2_HI = 0x1.62e42fefa39efp-1, LN2_LO = 0x1.abc9e3b39803fp-56;
+  const double SHIFT = 0x1.8p52;
+  const double t = x * INV_LN2 + SHIFT;
+  const double kd = t - SHIFT;
+  const int k = (int)kd;
+  double r = __builtin_fma(-kd, LN2_HI, x);
+  r = __builtin_fma(-kd, LN2_LO, r);
+  double q = 0x1.6124613a86d09p-33;
+  q = __builtin_fma(q, r, 0x1.1eed8eff8d898p-29);
+  q = __builtin_fma(q, r, 0x1.ae64567f544e4p-26);
+  q = __builtin_fma(q, r, 0x1.27e4fb7789f5cp-22);
+  q = __builtin_fma(q, r, 0x1.71de3a556c734p-19);
+  q = __builtin_fma(q, r, 0x1.a01a01a01a01ap-16);
+  q = __builtin_fma(q, r, 0x1.a01a01a01a01ap-13);
+  q = __builtin_fma(q, r, 0x1.6c16c16c16c17p-10);
+  q = __builtin_fma(q, r, 0x1.1111111111111p-7);
+  q = __builtin_fma(q, r, 0x1.5555555555555p-5);
+  q = __builtin_fma(q, r, 0x1.5555555555555p-3);
+  q = __builtin_fma(q, r, 0.5);
+  const double y = 1.0 + __builtin_fma(r * r, q, r);
+  const int k1 = k >> 1, k2 = k - k1;
+  return y * fv3m_from_bits((long long)(1023 + k1) << 52) * fv3m_from_bits((long long)(1023 + k2) << 52);
+}
 // 1/x to < 1 ulp (v_rcp_f64 + two Newton steps): the solves are tolerance-mode arithmetic
 __device__ __forceinline__ vd vrcp(vd b) {
   double y = __builtin_amdgcn_rcp(b);
@@ -95,11 +152,11 @@ __device__ __forceinline__ vd vrcp(vd b) {
 __device__ __forceinline__ vd vfma(vd a, vd b, vd c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ vd vlds_ld(const double *buf, int col0, int q) {
   const int l = (int)(threadIdx.x & 63);
-  return buf[((l >> 4) + col0) * kFP + (l & 15) * kFL + q];
+  return buf[((l >> 4) + col0) * kFP + (l & 15) * kFS + q];
 }
 __device__ __forceinline__ void vlds_st(double *buf, int col0, int q, vd x) {
   const int l = (int)(threadIdx.x & 63);
-  buf[((l >> 4) + col0) * kFP + (l & 15) * kFL + q] = x;
+  buf[((l >> 4) + col0) * kFP + (l & 15) * kFS + q] = x;
 }
 __device__ __forceinline__ vb vlevel_lt(int q, int k) { return (int)(threadIdx.x & 15) * kFL + q < k; }
 __device__ __forceinline__ vb vlevel_eq(int q, int k) { return (int)(threadIdx.x & 15) * kFL + q == k; }
@@ -108,6 +165,10 @@ __device__ __forceinline__ vd vcol_ld(const double *p, long o0, int col0, int nc
   return p[o0 + (c < ncol ? c : ncol - 1)];
 }
 #endif
+
+// a / b, correctly rounded for operands in the normal range (spmd.h vdiv_r: one reciprocal + a Markstein correction, 8 instructions
+// instead of the 14 of the compiler's IEEE division with its scale / fixup rescue): the same value as `a / b` here
+FV3_D vd vdivq(const vd &a, const vd &b) { return vdiv_r(a, b, vrecip(b)); }
 
 // ---- scans over the 16 lanes of a row --------------------------------------------------------------------------------------------
 // The lane's fold of its 8 levels is the affine map x -> A x + B.  Forward: on exit (A, B) is the composition of the folds of lanes
@@ -238,24 +299,39 @@ struct RiemFast {
   FV3_HD int nrows() const { return CG ? g.ny + 2 : g.ny; }
   FV3_HD int nblocks_x() const { return (ncols_row() + kFC - 1) / kFC; }
 
-  // one level-major A-layout field -> LDS [column][level]; lev levels (<= 128); fill for what does not exist
-  FV3_D void stage_in(double *buf, const double *f, size_t o0, int ncol, int lev, double fill, int tid) const {
+  // one level-major A-layout field -> LDS [column][level]; lev levels (<= 128); fill for what does not exist.  All loads of the
+  // workgroup's share are issued before the first LDS store (clamped addresses: no branch between them), so the four fields' 32
+  // loads per thread are in flight together instead of one HBM round trip after the other.
+  static constexpr int kIt = kFC * 128 / kNT;
+  FV3_D void stage_load(double *v, const double *f, size_t o0, int ncol, int lev, int tid) const {
     const size_t nA = g.nA();
-    for (int idx = tid; idx < kFC * 128; idx += kNT) {
-      const int col = idx & (kFC - 1), k = idx >> 4;
-      buf[col * kFP + k] = (k < lev && col < ncol) ? f[(size_t)k * nA + o0 + col] : fill;
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+    for (int it = 0; it < kIt; it++) {
+      const int idx = tid + it * kNT, col = idx & (kFC - 1), k = idx >> 4;
+      v[it] = f[(size_t)(k < lev ? k : lev - 1) * nA + o0 + (col < ncol ? col : ncol - 1)];
+    }
+  }
+  FV3_D void stage_store(double *buf, const double *v, int ncol, int lev, double fill, int tid) const {
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+    for (int it = 0; it < kIt; it++) {
+      const int idx = tid + it * kNT, col = idx & (kFC - 1), k = idx >> 4;
+      buf[col * kFP + lds_lev(k)] = (k < lev && col < ncol) ? v[it] : fill;
     }
   }
   template <class Addr>
   FV3_D void stage_out(const double *buf, double *f, int ncol, int lev, int tid, const Addr &addr) const {
     for (int idx = tid; idx < kFC * 128; idx += kNT) {
       const int col = idx & (kFC - 1), k = idx >> 4;
-      if (k < lev && col < ncol) f[addr(col, k)] = buf[col * kFP + k];
+      if (k < lev && col < ncol) f[addr(col, k)] = buf[col * kFP + lds_lev(k)];
     }
   }
 
   FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
-    double *B0 = lds, *B1 = lds + kFBuf, *B2 = lds + 2 * kFBuf;
+    double *B0 = lds, *B1 = lds + kFBuf, *B2 = lds + 2 * kFBuf, *B3 = lds + 3 * kFBuf;
     const int i0 = i_first() + bx * kFC, j = (CG ? g.js - 1 : g.js) + by;
     const int ncol = (ncols_row() - bx * kFC < kFC) ? ncols_row() - bx * kFC : kFC;
     const size_t nA = g.nA(), nCC = g.nCC();
@@ -263,17 +339,22 @@ struct RiemFast {
     const double rgrav = 1. / cn.grav, rgas = cn.rdgas, gm2 = 1. / (1. - cn.akap), cp2 = cn.akap;
     const double t1g = 2. * dt * dt, rdt = 1. / dt;
     constexpr double r3 = 1. / 3.;
-    vd dmr[kWvState][kFL], ptv[kWvState][kFL], pem[kWvState][kFL + 1], w1[kWvState][kFL], zv[kWvState][kFL + 1];
-    // ---- inputs: delp, pt; pem in the reference's summation order ----
-    stage_in(B0, delp, o0, ncol, km, 1.0, tid);
-    stage_in(B1, pt, o0, ncol, km, 300.0, tid);
-    FV3_SYNC();
-    for (int col = tid; col < kFC; col += kNT) {   // nh_core.F90:132-141 / nh_utils.F90:404-441: pem(k+1) = pem(k) + delp(k)
-      double p = cn.ptop;
-      B2[col * kFP] = p;
-      for (int k = 0; k < 128; k++) {
-        p = p + B0[col * kFP + k];
-        B2[col * kFP + k + 1] = p;
+    vd dmr[kWvState][kFL], ptv[kWvState][kFL], w1[kWvState][kFL], zv[kWvState][kFL + 1];
+    // ---- inputs: the four fields at once (their loads are in flight together), one barrier ----
+    {
+      double v0[kIt], v1[kIt], v2[kIt], v3[kIt];
+      stage_load(v0, delp, o0, ncol, km, tid);
+      stage_load(v1, pt, o0, ncol, km, tid);
+      stage_load(v2, wq, o0, ncol, km, tid);
+      stage_load(v3, zl, o0, ncol, km + 1, tid);
+      stage_store(B0, v0, ncol, km, 1.0, tid);
+      stage_store(B1, v1, ncol, km, 300.0, tid);
+      stage_store(B2, v2, ncol, km, 0.0, tid);
+      stage_store(B3, v3, ncol, km + 1, 0.0, tid);
+      // interface heights beyond km+1 continue downwards so that the padded layers stay regular (dz < 0)
+      for (int idx = tid; idx < kFC * 128; idx += kNT) {
+        const int col = idx & (kFC - 1), k = idx >> 4;
+        if (k > km || col >= ncol) B3[col * kFP + lds_lev(k)] = -1.0e4 - 10. * (double)k;
       }
     }
     FV3_SYNC();
@@ -282,52 +363,46 @@ struct RiemFast {
       for (int q = 0; q < kFL; q++) {
         dmr[s][q] = vlds_ld(B0, c0, q);
         ptv[s][q] = vlds_ld(B1, c0, q);
-        pem[s][q] = vlds_ld(B2, c0, q);
+        w1[s][q] = vlds_ld(B2, c0, q);
+        zv[s][q] = vlds_ld(B3, c0, q);
       }
-      pem[s][kFL] = vlds_ld(B2, c0, kFL);
-    }
-    FV3_SYNC();
-    stage_in(B0, wq, o0, ncol, km, 0.0, tid);
-    {  // interface heights: beyond km+1 continue downwards by 1 m per level so that the padded layers stay regular
-      for (int idx = tid; idx < kFC * 128; idx += kNT) {
-        const int col = idx & (kFC - 1), k = idx >> 4;
-        B1[col * kFP + k] = (k <= km && col < ncol) ? zl[(size_t)k * nA + o0 + col] : -1.0e3 - (double)k;
-      }
-      for (int col = tid; col < kFC; col += kNT) { B1[col * kFP + 128] = -1.0e3 - 128.; B1[col * kFP + 129] = -1.0e3 - 129.; }
-    }
-    FV3_SYNC();
-    FV3_WAVE_FOR(wv) {
-      const int s = FV3_WVI(wv), c0 = wv * 4;
-      for (int q = 0; q < kFL; q++) {
-        w1[s][q] = vlds_ld(B0, c0, q);
-        zv[s][q] = vlds_ld(B1, c0, q);
-      }
-      zv[s][kFL] = vlds_ld(B1, c0, kFL);
+      zv[s][kFL] = row_shl<1>(zv[s][0], -2.0e4);   // the interface below the lane's last layer (lane 15: a padded layer)
     }
     FV3_SYNC();
     // ---- the column: everything below is per wavefront, no barrier until the outputs ----
     FV3_WAVE_FOR(wv) {
       const int s = FV3_WVI(wv), c0 = wv * 4;
-      vd dm[kFL], dz[kFL], pm2[kFL], pei[kFL], grat[kFL], bb[kFL], lnp[kFL + 1], X[kFL];
+      vd dm[kFL], dz[kFL], pm2[kFL], pei[kFL], grat[kFL], bb[kFL], lnp[kFL + 1], X[kFL], pemv[kFL + 1];
       vb real[kFL], last[kFL];
       for (int q = 0; q < kFL; q++) {
         real[q] = vlevel_lt(q, km);
         last[q] = vlevel_eq(q, km - 1);
       }
+      {  // hydrostatic pressure at the interfaces: pem(k+1) = pem(k) + delp(k) (nh_core.F90:132-141 / nh_utils.F90:404-441), the
+         // lane's 8 levels in the reference's order on top of the scanned sum of the lanes above
+        vd tot(0.0);
+        for (int q = 0; q < kFL; q++) tot = tot + dmr[s][q];
+        vd run = cn.ptop + sum_scan_fwd_excl(tot);
+        for (int q = 0; q < kFL; q++) {
+          pemv[q] = run;
+          run = run + dmr[s][q];
+        }
+        pemv[kFL] = run;
+      }
       // hydrostatic pressure functions, perturbation pressure (nh_utils.F90:1297-1300; nh_core.F90:140-159 / nh_utils.F90:440)
       if (!CG) {
-        for (int q = 0; q < kFL; q++) lnp[q] = vlog(pem[s][q]);
+        for (int q = 0; q < kFL; q++) lnp[q] = vlog(pemv[q]);
         lnp[kFL] = row_shl<1>(lnp[0], 0.0);
       }
       for (int q = 0; q < kFL; q++) {
         const vd d = dmr[s][q];
         if (CG)
-          pm2[q] = d / vlog(pem[s][q + 1] / pem[s][q]);
+          pm2[q] = vdivq(d, vlog(vdivq(pemv[q + 1], pemv[q])));
         else
-          pm2[q] = d / (lnp[q + 1] - lnp[q]);
+          pm2[q] = vdivq(d, lnp[q + 1] - lnp[q]);
         dm[q] = d * rgrav;
         dz[q] = zv[s][q + 1] - zv[s][q];
-        pei[q] = vexp(gm2 * vlog(-dm[q] / dz[q] * rgas * ptv[s][q])) - pm2[q];
+        pei[q] = vexp(gm2 * vlog(vdivq(-dm[q], dz[q]) * rgas * ptv[s][q])) - pm2[q];
       }
       // ---- pp: forward / backward elimination of nh_utils.F90:1302-1332 as one tridiagonal system; X(k) = pp(k+1) ----
       {
@@ -335,7 +410,7 @@ struct RiemFast {
         const vd dm_nx = row_shl<1>(dm[0], 1.0), pe_nx = row_shl<1>(pei[0], 0.0);
         for (int q = 0; q < kFL; q++) {
           const vd dmn = (q < kFL - 1) ? dm[q + 1] : dm_nx, pen = (q < kFL - 1) ? pei[q + 1] : pe_nx;
-          const vd gr = dm[q] / dmn;
+          const vd gr = vdivq(dm[q], dmn);
           grat[q] = vsel(last[q], vd(0.0), gr);
           bb[q] = vsel(last[q], vd(2.0), 2. * (1. + gr));
           const vd dd = vsel(last[q], 3. * pei[q], 3. * (pei[q] + gr * pen));
@@ -353,14 +428,14 @@ struct RiemFast {
         const vd dz_pv = row_shr<1>(dz[kFL - 1], 1.0), X_pv = row_shr<1>(X[kFL - 1], 0.0);
         for (int q = 0; q < kFL; q++) {   // aa at the top interface of the layer (0 at the model top)
           const vd dzp = (q > 0) ? dz[q - 1] : dz_pv;
-          const vd aa = t1g * 0.5 * (gm2 + gm2) / (dzp + dz[q]) * pem[s][q];
+          const vd aa = vdivq(vd(t1g * 0.5 * (gm2 + gm2)), dzp + dz[q]) * pemv[q];
           aat[q] = vsel(real[q] && !vlevel_eq(q, 0), aa, vd(0.0));
         }
         const vd aat_nx = row_shl<1>(aat[0], 0.0);
         const vd wsv = vcol_ld(ws, CG ? (long)o0 : (long)g.iCC(i0, j), c0, ncol);
         for (int q = 0; q < kFL; q++) {
           const vd aab = (q < kFL - 1) ? aat[q + 1] : aat_nx;
-          const vd p1c = t1g * gm2 / dz[q] * pem[s][q + 1];      // bottom layer only (:1349)
+          const vd p1c = vdivq(vd(t1g * gm2), dz[q]) * pemv[q + 1];      // bottom layer only (:1349)
           const vd ppt = (q > 0) ? X[q - 1] : X_pv;                // pp at the top interface of the layer
           const vd low = vsel(last[q], p1c, aab);
           a[q] = aat[q];
@@ -431,7 +506,7 @@ struct RiemFast {
       for (int q = 0; q < kFL; q++) {
         vlds_st(B0, c0, q, zn[q]);
         if (CG) {
-          vlds_st(B1, c0, q, vsel(vlevel_eq(q, 0), vd(cn.ptop), pe2[q] + pem[s][q]));   // pef (:461-465)
+          vlds_st(B1, c0, q, vsel(vlevel_eq(q, 0), vd(cn.ptop), pe2[q] + pemv[q]));   // pef (:461-465)
         } else {
           vlds_st(B1, c0, q, w2[q]);
           vlds_st(B2, c0, q, dzn[q]);
@@ -440,9 +515,10 @@ struct RiemFast {
       // keep what the second round needs
       if (!CG) {
         for (int q = 0; q < kFL; q++) {
-          dmr[s][q] = fp_out ? pe2[q] + pem[s][q] : pe2[q];                                                // ppe
+          dmr[s][q] = fp_out ? pe2[q] + pemv[q] : pe2[q];                                                // ppe
           ptv[s][q] = vsel(vlevel_eq(q, 0), vd(dexp(cn.akap * dlog(cn.ptop))), vexp(cn.akap * lnp[q]));   // pk
           w1[s][q] = lnp[q];                                                                               // peln
+          zv[s][q] = pemv[q];                                                                              // pe
         }
       }
     }
@@ -474,7 +550,7 @@ struct RiemFast {
       const int s = FV3_WVI(wv), c0 = wv * 4;
       for (int q = 0; q < kFL; q++) {
         vlds_st(B0, c0, q, w1[s][q]);
-        vlds_st(B1, c0, q, pem[s][q]);
+        vlds_st(B1, c0, q, zv[s][q]);
       }
     }
     FV3_SYNC();
