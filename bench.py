@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--nx", type=int, default=384)
     ap.add_argument("--npz", type=int, default=127)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--parity-columns", action="store_true",
+                    help="whole-step legs with the parity (bit-comparable) column solvers instead of the fast mode (csrc/nh_fast.h, 1e-12)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--hord", type=int, default=10, help="hord_mt = hord_vt = hord_tm = hord_dp (reference default 10)")
     ap.add_argument("--no-model-step", action="store_true", help="skip the SYPD (whole model step) leg")
@@ -166,6 +168,24 @@ def cpu_baseline(nx, seconds):
                       f"({t_used:.1f} s CPU wall), OpenMP over k on {cores} threads = the host's physical cores"}
 
 
+class column_mode:
+    """FV3_MI355X_FAST for the contexts created inside: the whole-step legs run the column solvers in fast mode (nh_fast.h: the same
+    equations, blocked parallel scans, within 1e-12 of the parity kernels) unless --parity-columns; never leaks into later contexts"""
+
+    def __init__(self, fast):
+        self.fast = fast
+
+    def __enter__(self):
+        self.saved = os.environ.pop("FV3_MI355X_FAST", None)
+        if self.fast:
+            os.environ["FV3_MI355X_FAST"] = "1"
+
+    def __exit__(self, *exc):
+        os.environ.pop("FV3_MI355X_FAST", None)
+        if self.saved is not None:
+            os.environ["FV3_MI355X_FAST"] = self.saved
+
+
 def whole_step_roofline(cells, wall_s, n_substeps, k_split, nq, hydrostatic=False):
     """algorithmic HBM bytes of one dt_atmos: per acoustic substep the c_sw + d_sw pair (336 B/cell NH, 304
     hydrostatic) + the rest of the substep (~360 B/cell NH: update_dz_c/d, both Riemann solvers, p_grad_c, nh_p_grad, halos; ~120
@@ -179,7 +199,7 @@ def whole_step_roofline(cells, wall_s, n_substeps, k_split, nq, hydrostatic=Fals
             "formula": f"{n_substeps} x ({pair:.0f} + {rest:.0f}) + {k_split} x (144 + 16 nq) + tracer_2d, nq = {nq}"}
 
 
-def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream):
+def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=True):
     """SYPD leg: whole nonhydrostatic model steps (fv_dynamics.F90:460-665 k_split loop: n_split acoustic substeps,
     tracer_2d, Lagrangian_to_Eulerian) on the same tile, dt_atmos=225 s, k_split=2, n_split=5 (C384 settings)."""
     from gfdl_atmos_cubed_sphere_amd import lib as L
@@ -188,7 +208,8 @@ def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream):
     from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
     from gfdl_atmos_cubed_sphere_amd.layout import Bounds
     nx, npz, nq = a.nx, a.npz, a.nq
-    ctx = L.Context(g, npz, stream=stream.cuda_stream)
+    with column_mode(fast):
+        ctx = L.Context(g, npz, stream=stream.cuda_stream)
     geom_mode = ctx.geom
     st, _ = N.balanced_nh_state(Bounds(1, nx, 1, nx), npz)
     sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
@@ -234,7 +255,8 @@ def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream):
             ms_call = rep[k_][1] / rep[k_][0]
             col[k_] = {"ms_per_call": round(ms_call, 4), "alg_bytes_per_cell": nb, "GBps": round(cells * nb / (ms_call * 1e-3) / 1e9, 1),
                        "frac": round(cells * nb / (ms_call * 1e-3) / HBM_PEAK, 4)}
-    return {"column_kernels": col, "geometry": {0: "general metric rows", 1: "orthogonal", 2: "orthogonal + uniform"}.get(geom_mode),
+    return {"column_solvers": "fast mode (csrc/nh_fast.h, within 1e-12 of the parity kernels)" if fast else "parity kernels (bit-comparable with the oracle)",
+            "column_kernels": col, "geometry": {0: "general metric rows", 1: "orthogonal", 2: "orthogonal + uniform"}.get(geom_mode),
             "whole_step": whole_step_roofline(cells, wall, k_split * n_split, k_split, nq),
             "kernels_sum_ms": round(sum(v[1] for v in rep.values()), 2),
             "sypd": dt_atmos / (365.0 * wall), "wall_s_per_dt_atmos": wall, "dt_atmos_s": dt_atmos, "k_split": k_split,
@@ -306,7 +328,7 @@ def cubed_sphere_leg(a, torch, stream):
     del d
     # ---- (2) whole model steps on the sphere: BASELINE configs[2] at the bench size, then configs[1] (C96 L79 hydrostatic)
     out["sphere_one_gpu"], out["sphere_one_gpu_kernels_ms_per_dt_atmos"] = sphere_steps(
-        torch, stream, cs, gs, nx, npz, hydrostatic=False, k_split=2, n_split=5, dt_atmos=225.0, nrep=2)
+        torch, stream, cs, gs, nx, npz, hydrostatic=False, k_split=2, n_split=5, dt_atmos=225.0, nrep=2, fast=not a.parity_columns)
     try:
         cs2 = CubedSphere(97)
         out["config2_c96_l79_hydrostatic"], _ = sphere_steps(torch, stream, cs2, [cs2.gridstruct(t) for t in range(6)], 96, 79,
@@ -322,7 +344,7 @@ def _sum_reps(reps):
             yield v[1] * 1e-3
 
 
-def sphere_steps(torch, stream, cs, gs, nx, npz, hydrostatic, k_split, n_split, dt_atmos, nrep):
+def sphere_steps(torch, stream, cs, gs, nx, npz, hydrostatic, k_split, n_split, dt_atmos, nrep, fast=True):
     """whole fv_dynamics steps of the Jablonowski-Williamson wave on six faces held by this one GPU -> (summary, kernel ms)"""
     from gfdl_atmos_cubed_sphere_amd import lib as L
     from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
@@ -352,7 +374,8 @@ def sphere_steps(torch, stream, cs, gs, nx, npz, hydrostatic, k_split, n_split, 
     # a stream per face: the launches of different faces overlap on the GPU (the column solvers of one face are 2 300
     # wavefronts, a quarter of what the chip holds), the halo gathers join and fork them (cubed_halo.CubeHalo)
     fstreams = [torch.cuda.Stream() for _ in range(6)] if os.environ.get("FV3_BENCH_FACE_STREAMS", "1") == "1" else [stream] * 6
-    mctx = MultiContext([L.Context(g, npz, stream=fs.cuda_stream) for g, fs in zip(gs, fstreams)])
+    with column_mode(fast):
+        mctx = MultiContext([L.Context(g, npz, stream=fs.cuda_stream) for g, fs in zip(gs, fstreams)])
     fv = FvDynamics(mctx, fl, ak, bk, nq=0, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=cs.topo))
     zero = np.zeros_like(st[0]["delp"])
     fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], [s_.get("w", zero) for s_ in st], [s_["delp"] for s_ in st],
@@ -403,6 +426,7 @@ def sphere_steps(torch, stream, cs, gs, nx, npz, hydrostatic, k_split, n_split, 
                "kernel_breakdown": {"how": "six faces on one stream, eager launches, HIP events per launch", "wall_s": round(wall_one, 4),
                                     "kernels_sum_s": round(sum(kern_v for kern_v in _sum_reps(reps)), 4)},
                "k_split": k_split, "n_split": fl.n_split, "nq": 0, "cells": 6 * cells, "launch": graph_note,
+               "column_solvers": "fast mode (nh_fast.h)" if (fast and not hydrostatic) else "parity kernels",
                "finite": bool(all(np.isfinite(x[c]).all() for x in dp)),
                "initial_condition": "test_case 13 (Jablonowski-Williamson), " + ("hydrostatic" if hydrostatic else "nonhydrostatic"),
                "note": "all six faces on ONE MI355X (six contexts, a HIP stream per face, device-gather halo updates); one face per "
@@ -649,7 +673,10 @@ def main():
     # N > 1: the SYPD leg is off unless asked for (a failure on one rank would leave the others in a collective)
     if not a.no_model_step and (world == 1 or a.model_step_multi):
         try:
-            out["model_step"] = model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream)
+            out["model_step"] = model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=not a.parity_columns)
+            if world == 1 and not a.parity_columns:      # the same step with the parity column solvers, for the record
+                par = model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=False)
+                out["model_step"]["parity_columns"] = {k: par[k] for k in ("sypd", "wall_s_per_dt_atmos", "column_kernels")}
         except Exception as e:  # noqa: BLE001
             out["model_step"] = {"error": f"{type(e).__name__}: {e}"}
     out["cubed_sphere"] = None

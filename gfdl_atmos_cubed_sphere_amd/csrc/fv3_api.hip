@@ -12,6 +12,7 @@
 #include "csw_march.h"
 #include "cubed_csw.h"
 #include "cubed_tp.h"
+#include "cubed_tpf.h"
 #include "cubed_dsw.h"
 #include "cubed_damp.h"
 #include "cubed_a2b.h"
@@ -745,10 +746,51 @@ static int tp2d_cubed(fv3_ctx *c, int nk, const double *q, const double *crx, co
   double **scr[4] = {&s.fx2, &s.fy2, &s.q_i, &s.q_j};
   for (int n = 0; n < 4; n++)
     if (!(*scr[n] = cs_scratch(c, 4 + n))) return fail("fv_tp_2d: out of device memory");
+  // Frame launches (rg.w = the consumer's frame wo + cubed_reach): the consumers (D4, D9, the zh / tracer updates) read the fluxes of
+  // the faces of their own cells, i.e. within wo + 1 of an edge; an outer-sweep face reads q_i / q_j three cells further (wo + 4),
+  // q_i / q_j the inner fluxes one face further (wo + 5).  Each pass runs on the frame it is read on, not on the widest one.
+  PassRegion r2 = rg, r3 = rg;
+  if (rg.w > 0 && c->cubed_reach >= 5) {
+    r2.w = rg.w - (c->cubed_reach - 4);
+    r3.w = rg.w - (c->cubed_reach - 1);
+  }
   RT(launch_pass(c, label, g.isd, g.ied, g.jsd, g.jed, rg, Tp2dCubedT1{s}));
-  RT(launch_pass(c, label, g.isd, g.ied, g.jsd, g.jed, rg, Tp2dCubedT2{s}));
-  RT(launch_pass(c, label, g.is, g.ie + 1, g.js, g.je + 1, rg, Tp2dCubedT3{s}));
+  RT(launch_pass(c, label, g.isd, g.ied, g.jsd, g.jed, r2, Tp2dCubedT2{s}));
+  RT(launch_pass(c, label, g.is, g.ie + 1, g.js, g.je + 1, r3, Tp2dCubedT3{s}));
   return 0;
+}
+
+// the same on the frame of width w3 (flux points) for up to three fields in one launch (cubed_tpf.h); fields[0] is weighted with
+// xfx / yfx, the following ones with fields[0]'s fluxes; FV3_MI355X_FRAME_FUSED=0 falls back to the passes
+static int tp2d_frame_fused(fv3_ctx *c, const TpfField *fields, int nf, const double *crx, const double *cry, const double *xfx,
+                            const double *yfx, int w3, const int *klist, int nk, const char *label, bool full = false,
+                            const double *emfx = nullptr, const double *emfy = nullptr) {
+  if (nk <= 0) return 0;
+  const Grid &g = c->g;
+  Tp2dFrameFused kf;
+  kf.g = g;
+  for (int n = 0; n < 3; n++) kf.f[n] = fields[n < nf ? n : 0];
+  kf.nf = nf; kf.crx = crx; kf.cry = cry; kf.xfx = xfx; kf.yfx = yfx; kf.w3 = w3; kf.klist = klist;
+  kf.full = full ? 1 : 0;
+  kf.emfx = emfx; kf.emfy = emfy;
+  kf.nS = (g.nx + 1 + kTfT - 1) / kTfT;
+  if (full) {            // the whole face (the levels the marching kernels do not take): bands of 5 rows
+    kf.w3 = 5;
+    kf.nW = (g.ny + 1 + kf.w3 - 1) / kf.w3;
+  } else {
+    const int nmid = (g.npy - w3 - 1) - (w3 + 1) + 1;
+    kf.nW = (nmid + kTfT - 1) / kTfT;
+  }
+  Dim3 grid;
+  grid.x = (unsigned)kf.ntiles(); grid.y = 1; grid.z = (unsigned)nk;
+  return launch_p(c, label, grid, (size_t)kTfArrays * kTfMaxN, kf);
+}
+static bool frame_fused_on() {
+  static const int v = [] {
+    const char *e = std::getenv("FV3_MI355X_FRAME_FUSED");
+    return e ? std::atoi(e) : 1;
+  }();
+  return v != 0;
 }
 
 static int csw_march(fv3_ctx *c, const CswArgs &ca);
@@ -1131,6 +1173,21 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   auto transport = [&](const PassRegion &rg, const PassRegion &rg_out, bool courant) -> int {
     if (rg.nk <= 0) return 0;
     if (courant) RT(launch_pass(c, "dswc_d2", g.isd, g.ied, g.jsd, g.jed, PassRegion{0, rg.klist, rg.nk}, DswCubedD2{s}));
+    // hybrid frame: delp, w, pt in ONE LDS-tile launch; the whole-face levels too unless a deln_flux damping has to get between
+    // the transports (it changes the mass fluxes the later fields are weighted with)
+    const bool full_ok = rg.w == 0 && rg_out.w == 0 && !c->lev_has_damp_v4 && !c->lev_has_damp_t && !(c->lev_has_w_damp_hi && !a.hydrostatic);
+    if (((rg.w > 0 && rg_out.w > 0) || full_ok) && !a.use_cond && frame_fused_on()) {
+      TpfField fl[3];
+      int nf = 0;
+      fl[nf++] = TpfField{a.delp, s.fx, s.fy, a.hord_dp};
+      if (!a.hydrostatic) fl[nf++] = TpfField{a.w, s.gxw, s.gyw, a.hord_vt};
+      fl[nf++] = TpfField{a.pt, s.gx, s.gy, a.hord_tm};
+      RT(tp2d_frame_fused(c, fl, nf, a.crx, a.cry, a.xfx, a.yfx, rg_out.w + 1, rg.klist, rg.nk, "dswc_tp", rg.w == 0));
+      DswCubedState so = s;
+      so.own_w = rg_out.w;
+      RT(launch_pass(c, "dswc_d4", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD4{so}));
+      return 0;
+    }
     RT(tp2d_cubed(c, npz, a.delp, a.crx, a.cry, a.hord_dp, s.fx, s.fy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, "dswc_tp", &rg));
     if (rg.w == 0 && c->lev_has_damp_v4)   // :919-920: deln_flux inside fv_tp_2d(delp) -- the mass fluxes carry it from here on
       RT(deln(a.delp, nullptr, s.fx, s.fy, a.lv.nord_v, a.lv.damp_vt, 1.E-4, 0, c->lev_max_nord_v, nullptr, nullptr, rg));
@@ -1184,7 +1241,12 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     if (rg.w == 0 && c->lev_has_damp_v5)   // :1513-1515: del6_vt_flux of the RELATIVE vorticity (before D8 adds f0)
       RT(deln(s.wk, nullptr, nullptr, nullptr, a.lv.nord_v, a.lv.damp_vt, 1.E-5, 1, c->lev_max_nord_v, s.dfx2, s.dfy2, rg));
     RT(launch_pass(c, "dswc_d8", g.isd, g.ied, g.jsd, g.jed, rg, DswCubedD8{s}));
-    RT(tp2d_cubed(c, npz, s.wk, a.crx, a.cry, a.hord_vt, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, "dswc_tpv", &rg));
+    if (frame_fused_on()) {
+      const TpfField fl[3] = {TpfField{s.wk, s.gx, s.gy, a.hord_vt}, TpfField{}, TpfField{}};
+      RT(tp2d_frame_fused(c, fl, 1, a.crx, a.cry, a.xfx, a.yfx, rg_out.w + 1, rg.klist, rg.nk, "dswc_tpv", rg.w == 0));
+    } else {
+      RT(tp2d_cubed(c, npz, s.wk, a.crx, a.cry, a.hord_vt, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, "dswc_tpv", &rg));
+    }
     RT(launch_pass(c, "dswc_d9", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD9{so}));
     if (rg.w == 0 && heat_pass) RT(launch_pass(c, "dswc_heat", g.is, g.ie, g.js, g.je, rg_out, DswCubedD10{so}));
     if (rg.w == 0 && c->lev_has_damp_v5) RT(launch_pass(c, "dswc_d9", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD11{so}));
@@ -1941,12 +2003,22 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
     // with del6_vt_flux damping (nh_utils.F90:268-284): passes on the whole face + the damping fluxes (cubed_damp.h)
     if (c->n_plain_z > 0) {
       const PassRegion rm{hyb ? wm : 0, c->klist_z, c->n_plain_z}, ro{hyb ? wo : 0, c->klist_z, c->n_plain_z};
-      if (tp2d_cubed(c, km + 1, zh_in, cxa, cya, hord, fx, fy, xfa, yfa, nullptr, nullptr, nullptr, nullptr, "zhc_tp", &rm)) return 1;
+      if (frame_fused_on()) {
+        const TpfField fl[3] = {TpfField{zh_in, fx, fy, hord}, TpfField{}, TpfField{}};
+        RT(tp2d_frame_fused(c, fl, 1, cxa, cya, xfa, yfa, wo + 1, c->klist_z, c->n_plain_z, "zhc_tp", !hyb));
+      } else if (tp2d_cubed(c, km + 1, zh_in, cxa, cya, hord, fx, fy, xfa, yfa, nullptr, nullptr, nullptr, nullptr, "zhc_tp", &rm)) {
+        return 1;
+      }
       RT(launch_pass(c, "zhc_fin", g.is, g.ie, g.js, g.je, ro, ZhCubedFinal{g, zh_in, fx, fy, xfa, yfa, zh_out}));
     }
     if (c->n_damp_z > 0) {
       const PassRegion rd{0, c->klist_z + c->n_plain_z, c->n_damp_z};
-      if (tp2d_cubed(c, km + 1, zh_in, cxa, cya, hord, fx, fy, xfa, yfa, nullptr, nullptr, nullptr, nullptr, "zhc_tp", &rd)) return 1;
+      if (frame_fused_on()) {
+        const TpfField fl[3] = {TpfField{zh_in, fx, fy, hord}, TpfField{}, TpfField{}};
+        RT(tp2d_frame_fused(c, fl, 1, cxa, cya, xfa, yfa, 5, rd.klist, rd.nk, "zhc_tp", true));
+      } else if (tp2d_cubed(c, km + 1, zh_in, cxa, cya, hord, fx, fy, xfa, yfa, nullptr, nullptr, nullptr, nullptr, "zhc_tp", &rd)) {
+        return 1;
+      }
       DelnCubedState d;
       d.g = g; d.q = zh_in; d.mass = nullptr; d.fx = d.fy = nullptr; d.nord = c->lev_ext_i; d.coef = c->lev_ext_d; d.thresh = 1.E-5;
       d.corner_area = 2;
@@ -2664,7 +2736,12 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
     const PassRegion rm{hyb ? wm : 0, nullptr, g.npz}, ro{hyb ? wo : 0, nullptr, g.npz};
     const size_t nq3 = (size_t)g.npz * g.nA();
     for (int iq = 0; iq < nq; iq++) {
-      if (tp2d_cubed(c, g.npz, q + iq * nq3, cx, cy, hord, fx, fy, xfx, yfx, nullptr, nullptr, mfx, mfy, "trc_tp", &rm)) return 1;
+      if (frame_fused_on()) {
+        const TpfField fl[3] = {TpfField{q + iq * nq3, fx, fy, hord}, TpfField{}, TpfField{}};
+        RT(tp2d_frame_fused(c, fl, 1, cx, cy, xfx, yfx, wo + 1, nullptr, g.npz, "trc_tp", !hyb, mfx, mfy));
+      } else if (tp2d_cubed(c, g.npz, q + iq * nq3, cx, cy, hord, fx, fy, xfx, yfx, nullptr, nullptr, mfx, mfy, "trc_tp", &rm)) {
+        return 1;
+      }
       if (damp) {
         DelnCubedState d;
         d.g = g; d.q = q + iq * nq3; d.mass = dp1; d.fx = fx; d.fy = fy; d.nord = nord_dev; d.coef = coef_dev; d.thresh = 1.E-4;

@@ -20,7 +20,7 @@ module fv3_mi355x_mod
   public :: fv3_divg2_ext, fv3_one_grad_p, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
   public :: fv3_grid_cubed, fv3_grid_upload_cubed, fv3_gather_create, fv3_gather_run, fv3_gather_destroy
   public :: fv3_comm_get_unique_id, fv3_comm_init, fv3_comm_destroy, fv3_halo_start, fv3_halo_complete, fv3_allreduce_max
-  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_rayleigh_super, fv3_compute_total_energy, fv3_energy_fixer_sums, fv3_remap_finish, fv3_ordered_sum, fv3_adv_pe, fv3_set_condensate, fv3_set_moist, fv3_moist_params
+  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_rayleigh_super, fv3_compute_total_energy, fv3_energy_fixer_sums, fv3_remap_finish, fv3_ordered_sum, fv3_adv_pe, fv3_set_condensate, fv3_set_fast, fv3_set_moist, fv3_moist_params
 
   type, bind(C) :: fv3_domain
     integer(c_int) :: is, ie, js, je, ng, npx, npy, npz, grid_type
@@ -382,6 +382,11 @@ module fv3_mi355x_mod
     integer(c_int) function fv3_set_condensate(ctx, q_con, cappa) bind(C, name="fv3_set_condensate")
       import :: c_int, c_ptr
       type(c_ptr), value :: ctx, q_con, cappa
+    end function
+    integer(c_int) function fv3_set_fast(ctx, on) bind(C, name="fv3_set_fast")   ! 1: fast (tolerance) mode of the column solvers
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: on
     end function
     integer(c_int) function fv3_riem_solver_c(ctx, dt, cn, hs, w3, pt, delp, gz, pef, ws) &
         bind(C, name="fv3_riem_solver_c")
