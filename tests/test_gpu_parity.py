@@ -716,7 +716,7 @@ def test_config3_c384_l127_nonhydrostatic_sphere(prod):
 
 
 def test_config2_c96_l79_sphere_properties(prod):
-    r = PC.check_sphere_properties(prod, npx=97, npz=79, hydrostatic=True, k_split=2, n_split=3, bdt=1800.0)
+    r = PC.check_sphere_properties(prod, npx=97, npz=79, hydrostatic=True, k_split=2, n_split=6, bdt=1800.0)
     assert r["finite"] == 1.0 and r["mass_drift"] < 1e-13 and r["edge_mismatch"] == 0.0 and r["moved"] > 1e-3, r
 
 
