@@ -13,6 +13,7 @@
 #include "cubed_csw.h"
 #include "cubed_tp.h"
 #include "cubed_tpf.h"
+#include "cube_topo.h"
 #include "cubed_dsw.h"
 #include "cubed_damp.h"
 #include "cubed_a2b.h"
@@ -39,6 +40,7 @@ using namespace fv3;
 #define FV3_DSW_TJ 8
 #endif
 
+struct CubePlanDev;
 struct fv3_ctx {
   fv3_domain dom;
   Grid g;           // device view (pointers into dev_metrics)
@@ -92,6 +94,14 @@ struct fv3_ctx {
   double *msg_send[8], *msg_recv[8];
   size_t msg_cap[8];
   int pend_n;
+  // cube-edge exchange (fv3_cube_halo_start / _complete): per-kind pack / unpack plans of this face, message buffers, pending group
+  struct CubePlanDev *cube_plan[5];
+  int cube_face;
+  double *cube_send, *cube_recv;
+  size_t cube_cap_send, cube_cap_recv;
+  int cube_pend_n;
+  fv3_cube_field cube_pend[FV3_HALO_MAX_FIELDS];
+  size_t cube_roff[FV3_HALO_MAX_FIELDS][6];
   fv3_halo_field pend_fields[FV3_HALO_MAX_FIELDS];
   int col_pool;      // workgroups of the pooled launches of the column solvers (0: one workgroup per 256 columns)
   int cubed_frame;   // cubed-sphere hybrid: width of the frame the pass kernels own (0: passes on the whole face)
@@ -287,6 +297,8 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->comm = nullptr; c->comm_rank = 0; c->comm_size = 1; c->comm_stream = nullptr; c->ev_packed = c->ev_arrived = nullptr;
   for (int d = 0; d < 8; d++) { c->msg_send[d] = c->msg_recv[d] = nullptr; c->msg_cap[d] = 0; }
   c->pend_n = 0;
+  for (int n = 0; n < 5; n++) c->cube_plan[n] = nullptr;
+  c->cube_face = -1; c->cube_send = c->cube_recv = nullptr; c->cube_cap_send = c->cube_cap_recv = 0; c->cube_pend_n = 0;
   {  // tuning / fallback knobs
     const char *e = std::getenv("FV3_MI355X_MARCH");
     c->use_march = e ? std::atoi(e) : 1;
@@ -1652,6 +1664,13 @@ extern "C" int fv3_halo_start(fv3_ctx *c, int nfields, const fv3_halo_field *fie
   if (!c || !c->comm) return fail("fv3_halo_start: call fv3_comm_init first");
   if (!fields || !to || !from || nfields < 1 || nfields > FV3_HALO_MAX_FIELDS) return fail("fv3_halo_start: bad argument");
   if (c->pend_n) return fail("fv3_halo_start: the previous group has not been completed");
+  for (int d = 0; d < 8; d++) {   // checked BEFORE the pack and the group: a bad entry must not leave an RCCL group open
+#ifdef FV3_HOST_EMU
+    if (to[d] != c->comm_rank || from[d] != c->comm_rank) return fail("fv3_halo_start: the host-emulation build has no peers");
+#else
+    if (to[d] < 0 || to[d] >= c->comm_size || from[d] < 0 || from[d] >= c->comm_size) return fail("fv3_halo_start: peer out of range");
+#endif
+  }
   size_t elems[8];
   if (fv3_halo_message_elems(c, nfields, fields, elems)) return 1;
   for (int d = 0; d < 8; d++) {
@@ -1667,18 +1686,16 @@ extern "C" int fv3_halo_start(fv3_ctx *c, int nfields, const fv3_halo_field *fie
   rt_event_record(c->ev_packed, c->stream);
   rt_stream_wait_event(c->comm_stream, c->ev_packed);
 #ifdef FV3_HOST_EMU
-  for (int d = 0; d < 8; d++) {
-    if (to[d] != c->comm_rank || from[d] != c->comm_rank) return fail("fv3_halo_start: the host-emulation build has no peers");
-    RT(rt_d2d(c->msg_recv[d], c->msg_send[d], sizeof(double) * elems[d], c->comm_stream));
-  }
+  for (int d = 0; d < 8; d++) RT(rt_d2d(c->msg_recv[d], c->msg_send[d], sizeof(double) * elems[d], c->comm_stream));
 #else
   NC(g_rccl.GroupStart());
-  for (int d = 0; d < 8; d++) {
-    if (to[d] < 0 || to[d] >= c->comm_size || from[d] < 0 || from[d] >= c->comm_size) return fail("fv3_halo_start: peer out of range");
-    NC(g_rccl.Send(c->msg_send[d], elems[d], kNcclDouble, to[d], c->comm, c->comm_stream));
-    NC(g_rccl.Recv(c->msg_recv[d], elems[d], kNcclDouble, from[d], c->comm, c->comm_stream));
+  int rc = 0;
+  for (int d = 0; d < 8 && !rc; d++) {
+    rc = g_rccl.Send(c->msg_send[d], elems[d], kNcclDouble, to[d], c->comm, c->comm_stream);
+    if (!rc) rc = g_rccl.Recv(c->msg_recv[d], elems[d], kNcclDouble, from[d], c->comm, c->comm_stream);
   }
-  NC(g_rccl.GroupEnd());
+  const int rc2 = g_rccl.GroupEnd();   // the group is closed on every path
+  if (rc || rc2) return fail("RCCL: %s (halo group)", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "error");
 #endif
   rt_event_record(c->ev_arrived, c->comm_stream);
   for (int f = 0; f < nfields; f++) c->pend_fields[f] = fields[f];
@@ -1693,6 +1710,253 @@ extern "C" int fv3_halo_complete(fv3_ctx *c) {
   const int n = c->pend_n;
   c->pend_n = 0;
   return fv3_halo_unpack(c, n, c->pend_fields, c->msg_recv);
+}
+
+// ---- the cube-edge exchange: one face per rank (or several faces per rank) -------------------------------------------------------
+// mpp_update_domains on the six-tile mosaic (tools/fv_mp_mod.F90:498-546; group updates :646-876) and mpp_get_boundary of (u, v)
+// (model/dyn_core.F90:1151-1163) as peer messages: per pair of faces ONE message per group of fields; sender and receiver walk the
+// RECEIVING face's table (cube_topo.h) in the same order, so a message needs no header; the sign of the component rotation is applied
+// while packing.
+struct CubePlanDev {
+  int n_send, n_recv;
+  int *s_member, *s_sign, *s_seg, *r_member, *r_seg;   // device
+  long *s_idx, *r_idx;                                 // device
+  int send_cnt[6], recv_cnt[6], send_start[6], recv_start[6];
+};
+extern "C" long fv3_cube_table(int npx, int ng, int kind, int member, int face, long *dst, int *src_face, int *comp, long *src, int *sign) {
+  if (npx < 3 || ng < 1 || kind < 0 || kind > 4 || face < 0 || face > 5 || member < 0 || member >= CubeTopo::members(kind)) return -1;
+  const std::vector<CubeRow> rows = CubeTopo(npx, ng).table(kind, member, face);
+  if (dst)
+    for (size_t r = 0; r < rows.size(); r++) {
+      dst[r] = rows[r].dst; src_face[r] = rows[r].tile; comp[r] = rows[r].comp; src[r] = rows[r].src; sign[r] = rows[r].sign;
+    }
+  return (long)rows.size();
+}
+static int cube_plan_get(fv3_ctx *c, int face, int kind, CubePlanDev **out) {
+  if (c->cube_face >= 0 && c->cube_face != face) return fail("fv3_cube_halo: the context was planned as face %d", c->cube_face);
+  c->cube_face = face;
+  if (c->cube_plan[kind]) { *out = c->cube_plan[kind]; return 0; }
+  const CubeTopo topo(c->g.npx, NG);
+  const int nm = CubeTopo::members(kind);
+  std::vector<int> sm, ss, sseg, rm, rseg;
+  std::vector<long> si, ri;
+  CubePlanDev *p = new (std::nothrow) CubePlanDev();
+  if (!p) return fail("fv3_cube_halo: out of host memory");
+  // what this face owes face r: the rows of r's table with tile == face, r ascending, members, table order
+  for (int r = 0; r < 6; r++) {
+    p->send_start[r] = (int)si.size();
+    if (r != face)
+      for (int m = 0; m < nm; m++)
+        for (const CubeRow &row : topo.table(kind, m, r))
+          if (row.tile == face) { sm.push_back(row.comp ? 1 - m : m); si.push_back(row.src); ss.push_back(row.sign); sseg.push_back(r); }
+    p->send_cnt[r] = (int)si.size() - p->send_start[r];
+  }
+  // what this face receives from face s: the rows of its own table with tile == s, in the same order
+  std::vector<std::vector<CubeRow>> mine(nm);
+  for (int m = 0; m < nm; m++) mine[m] = topo.table(kind, m, face);
+  for (int sf = 0; sf < 6; sf++) {
+    p->recv_start[sf] = (int)ri.size();
+    for (int m = 0; m < nm; m++)
+      for (const CubeRow &row : mine[m])
+        if (row.tile == sf) { rm.push_back(m); ri.push_back(row.dst); rseg.push_back(sf); }
+    p->recv_cnt[sf] = (int)ri.size() - p->recv_start[sf];
+  }
+  p->n_send = (int)si.size();
+  p->n_recv = (int)ri.size();
+  auto up_i = [&](int **d, const std::vector<int> &h) -> int {
+    if (h.empty()) { *d = nullptr; return 0; }
+    if (rt_malloc((void **)d, sizeof(int) * h.size())) return 1;
+    return rt_h2d(*d, h.data(), sizeof(int) * h.size(), c->stream);
+  };
+  auto up_l = [&](long **d, const std::vector<long> &h) -> int {
+    if (h.empty()) { *d = nullptr; return 0; }
+    if (rt_malloc((void **)d, sizeof(long) * h.size())) return 1;
+    return rt_h2d(*d, h.data(), sizeof(long) * h.size(), c->stream);
+  };
+  if (up_i(&p->s_member, sm) || up_i(&p->s_sign, ss) || up_i(&p->s_seg, sseg) || up_l(&p->s_idx, si) || up_i(&p->r_member, rm) ||
+      up_i(&p->r_seg, rseg) || up_l(&p->r_idx, ri))
+    return fail("fv3_cube_halo: out of device memory");
+  RT(rt_sync(c->stream));
+  c->cube_plan[kind] = p;
+  *out = p;
+  return 0;
+}
+static void cube_planes(const Grid &g, int kind, size_t pl[2]) {
+  if (kind == kCubeA) pl[0] = pl[1] = g.nA();
+  else if (kind == kCubeB) pl[0] = pl[1] = g.nB();
+  else if (kind == kCubeC) { pl[0] = g.nV(); pl[1] = g.nU(); }
+  else { pl[0] = g.nU(); pl[1] = g.nV(); }
+}
+struct CubePack {   // thread per (row, level): message layout [peer][field][level][row of the peer's segment]
+  int n, nk, vector;
+  const int *member, *sign, *seg;
+  const long *idx;
+  const double *f0, *f1;
+  size_t pl0, pl1;
+  int cnt[6], start[6];
+  size_t off[6];
+  double *buf;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const long tot = (long)n * nk;
+    for (long e = (long)bx * CH + tid; e < (long)(bx + 1) * CH && e < tot; e += kNT) {
+      const int row = (int)(e % n), k = (int)(e / n), sg = seg[row];
+      double v = member[row] ? f1[(size_t)k * pl1 + idx[row]] : f0[(size_t)k * pl0 + idx[row]];
+      if (vector && sign[row] < 0) v = -v;
+      buf[off[sg] + (size_t)k * cnt[sg] + (row - start[sg])] = v;
+    }
+  }
+};
+struct CubeUnpack {
+  int n, nk;
+  const int *member, *seg;
+  const long *idx;
+  double *f0, *f1;
+  size_t pl0, pl1;
+  int cnt[6], start[6];
+  size_t off[6];
+  const double *buf;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const long tot = (long)n * nk;
+    for (long e = (long)bx * CH + tid; e < (long)(bx + 1) * CH && e < tot; e += kNT) {
+      const int row = (int)(e % n), k = (int)(e / n), sg = seg[row];
+      const double v = buf[off[sg] + (size_t)k * cnt[sg] + (row - start[sg])];
+      if (member[row]) f1[(size_t)k * pl1 + idx[row]] = v; else f0[(size_t)k * pl0 + idx[row]] = v;
+    }
+  }
+};
+// nctx contexts = the faces this rank holds (faces[] ascending); ctxs[0] carries the communicator (fv3_comm_init); face_rank[t] = the
+// rank holding face t; fields[i * nfields + f] = field f of context i (the same kinds / nk / flags on every context and rank).
+extern "C" int fv3_cube_halo_start(int nctx, fv3_ctx *const *ctxs, const int *faces, const int *face_rank, int nfields,
+                                   const fv3_cube_field *fields) {
+  if (nctx < 1 || nctx > 6 || !ctxs || !faces || !face_rank || !fields || nfields < 1 || nfields > FV3_HALO_MAX_FIELDS)
+    return fail("fv3_cube_halo_start: bad argument");
+  fv3_ctx *c0 = ctxs[0];
+  if (!c0 || !c0->comm) return fail("fv3_cube_halo_start: call fv3_comm_init on the first context");
+  // every argument is checked before anything is packed or posted (a bad peer must not leave an RCCL group open)
+  for (int i = 0; i < nctx; i++) {
+    if (!ctxs[i] || !ctxs[i]->grid_ready || ctxs[i]->g.grid_type >= 3) return fail("fv3_cube_halo_start: context %d is not a cubed-sphere face", i);
+    if (faces[i] < 0 || faces[i] > 5 || (i > 0 && faces[i] <= faces[i - 1])) return fail("fv3_cube_halo_start: faces must be ascending in 0..5");
+    if (ctxs[i]->cube_pend_n) return fail("fv3_cube_halo_start: the previous group of face %d has not been completed", faces[i]);
+    if (face_rank[faces[i]] != c0->comm_rank) return fail("fv3_cube_halo_start: face_rank does not place face %d on this rank", faces[i]);
+    for (int f = 0; f < nfields; f++) {
+      const fv3_cube_field &fd = fields[i * nfields + f];
+      if (fd.kind < 0 || fd.kind > 4 || !fd.f0 || (fd.kind >= kCubeD && !fd.f1) || fd.nk < 1) return fail("fv3_cube_halo_start: bad field %d", f);
+    }
+  }
+  for (int t = 0; t < 6; t++)
+    if (face_rank[t] < 0 || face_rank[t] >= c0->comm_size) return fail("fv3_cube_halo_start: rank of face %d out of range", t);
+  // ---- plans, buffer layout, pack ----
+  size_t soff[6][FV3_HALO_MAX_FIELDS][6], scount[6][6], rcount[6][6];
+  for (int i = 0; i < nctx; i++) {
+    fv3_ctx *c = ctxs[i];
+    CubePlanDev *pl[FV3_HALO_MAX_FIELDS];
+    for (int f = 0; f < nfields; f++)
+      if (cube_plan_get(c, faces[i], fields[i * nfields + f].kind, &pl[f])) return 1;
+    size_t so = 0, ro = 0;
+    for (int r = 0; r < 6; r++) {      // peer-major: one contiguous message per peer face
+      scount[i][r] = rcount[i][r] = 0;
+      for (int f = 0; f < nfields; f++) {
+        const int nk = fields[i * nfields + f].nk;
+        soff[i][f][r] = so;
+        so += (size_t)pl[f]->send_cnt[r] * nk;
+        scount[i][r] += (size_t)pl[f]->send_cnt[r] * nk;
+        c->cube_roff[f][r] = ro;
+        ro += (size_t)pl[f]->recv_cnt[r] * nk;
+        rcount[i][r] += (size_t)pl[f]->recv_cnt[r] * nk;
+      }
+    }
+    if (so > c->cube_cap_send) {
+      if (c->cube_send) rt_free(c->cube_send);
+      RT(rt_malloc((void **)&c->cube_send, sizeof(double) * so));
+      c->cube_cap_send = so;
+    }
+    if (ro > c->cube_cap_recv) {
+      if (c->cube_recv) rt_free(c->cube_recv);
+      RT(rt_malloc((void **)&c->cube_recv, sizeof(double) * ro));
+      c->cube_cap_recv = ro;
+    }
+    for (int f = 0; f < nfields; f++) {
+      const fv3_cube_field &fd = fields[i * nfields + f];
+      if (pl[f]->n_send == 0) continue;
+      CubePack kf;
+      kf.n = pl[f]->n_send; kf.nk = fd.nk; kf.vector = fd.scalar_pair ? 0 : 1;
+      kf.member = pl[f]->s_member; kf.sign = pl[f]->s_sign; kf.seg = pl[f]->s_seg; kf.idx = pl[f]->s_idx;
+      kf.f0 = fd.f0; kf.f1 = fd.f1 ? fd.f1 : fd.f0;
+      size_t pls[2];
+      cube_planes(c->g, fd.kind, pls);
+      kf.pl0 = pls[0]; kf.pl1 = pls[1];
+      for (int r = 0; r < 6; r++) { kf.cnt[r] = pl[f]->send_cnt[r]; kf.start[r] = pl[f]->send_start[r]; kf.off[r] = soff[i][f][r]; }
+      kf.buf = c->cube_send;
+      Dim3 grid;
+      grid.x = (unsigned)(((long)kf.n * kf.nk + CubePack::CH - 1) / CubePack::CH); grid.y = 1; grid.z = 1;
+      RT(launch_p(c, "cube_pack", grid, 0, kf));
+    }
+    if (!c->ev_packed) RT(rt_event_create(&c->ev_packed));
+    rt_event_record(c->ev_packed, c->stream);
+    rt_stream_wait_event(c0->comm_stream, c->ev_packed);
+  }
+  // ---- the messages: sends ordered by (sender face, receiver face), receives likewise -- the same order on both ends of a link ----
+#ifdef FV3_HOST_EMU
+  auto ctx_of_face = [&](int t) { for (int i = 0; i < nctx; i++) if (faces[i] == t) return i; return -1; };
+  for (int i = 0; i < nctx; i++)
+    for (int r = 0; r < 6; r++) {
+      if (!scount[i][r]) continue;
+      const int jr = ctx_of_face(r);
+      if (jr < 0) return fail("fv3_cube_halo_start: the host-emulation build has no peers (face %d is not held here)", r);
+      if (rcount[jr][faces[i]] != scount[i][r]) return fail("fv3_cube_halo_start: message size mismatch %d -> %d", faces[i], r);
+      RT(rt_d2d(ctxs[jr]->cube_recv + ctxs[jr]->cube_roff[0][faces[i]], ctxs[i]->cube_send + soff[i][0][r], sizeof(double) * scount[i][r],
+                c0->comm_stream));
+    }
+#else
+  NC(g_rccl.GroupStart());
+  int rc = 0;
+  for (int i = 0; i < nctx && !rc; i++)
+    for (int r = 0; r < 6 && !rc; r++)
+      if (scount[i][r]) rc = g_rccl.Send(ctxs[i]->cube_send + soff[i][0][r], scount[i][r], kNcclDouble, face_rank[r], c0->comm, c0->comm_stream);
+  for (int sf = 0; sf < 6 && !rc; sf++)
+    for (int i = 0; i < nctx && !rc; i++)
+      if (rcount[i][sf]) rc = g_rccl.Recv(ctxs[i]->cube_recv + ctxs[i]->cube_roff[0][sf], rcount[i][sf], kNcclDouble, face_rank[sf], c0->comm, c0->comm_stream);
+  const int rc2 = g_rccl.GroupEnd();   // closed on every path
+  if (rc || rc2) return fail("RCCL: %s (cube-edge group)", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "error");
+#endif
+  rt_event_record(c0->ev_arrived, c0->comm_stream);
+  for (int i = 0; i < nctx; i++) {
+    for (int f = 0; f < nfields; f++) ctxs[i]->cube_pend[f] = fields[i * nfields + f];
+    ctxs[i]->cube_pend_n = nfields;
+  }
+  return 0;
+}
+extern "C" int fv3_cube_halo_complete(int nctx, fv3_ctx *const *ctxs) {
+  if (nctx < 1 || !ctxs || !ctxs[0]) return fail("fv3_cube_halo_complete: bad argument");
+  fv3_ctx *c0 = ctxs[0];
+  for (int i = 0; i < nctx; i++)
+    if (!ctxs[i] || !ctxs[i]->cube_pend_n) return fail("fv3_cube_halo_complete: no group in flight");
+  for (int i = 0; i < nctx; i++) {
+    fv3_ctx *c = ctxs[i];
+    rt_stream_wait_event(c->stream, c0->ev_arrived);
+    const int nf = c->cube_pend_n;
+    c->cube_pend_n = 0;
+    for (int f = 0; f < nf; f++) {
+      const fv3_cube_field &fd = c->cube_pend[f];
+      CubePlanDev *pl = c->cube_plan[fd.kind];
+      if (!pl || pl->n_recv == 0) continue;
+      CubeUnpack kf;
+      kf.n = pl->n_recv; kf.nk = fd.nk;
+      kf.member = pl->r_member; kf.seg = pl->r_seg; kf.idx = pl->r_idx;
+      kf.f0 = fd.f0; kf.f1 = fd.f1 ? fd.f1 : fd.f0;
+      size_t pls[2];
+      cube_planes(c->g, fd.kind, pls);
+      kf.pl0 = pls[0]; kf.pl1 = pls[1];
+      for (int r = 0; r < 6; r++) { kf.cnt[r] = pl->recv_cnt[r]; kf.start[r] = pl->recv_start[r]; kf.off[r] = c->cube_roff[f][r]; }
+      kf.buf = c->cube_recv;
+      Dim3 grid;
+      grid.x = (unsigned)(((long)kf.n * kf.nk + CubeUnpack::CH - 1) / CubeUnpack::CH); grid.y = 1; grid.z = 1;
+      RT(launch_p(c, "cube_unpack", grid, 0, kf));
+    }
+  }
+  return 0;
 }
 
 // mp_reduce_max (tools/fv_mp_mod.F90:1683): element-wise maximum of n host doubles over the ranks, in place

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .cubed_halo import CubeHalo, CubeHaloRank
+from .cubed_halo import CubeHalo, CubeHaloNative, CubeHaloRank
 from .cubed_sphere import CubedSphere
 from .lib import Context
 
@@ -161,6 +161,56 @@ class CubeRankAdapter:
     def sync_edges(self, u, v):
         """mpp_get_boundary(u, v) of the last substep (dyn_core.F90:1151-1163)"""
         self.cube.update("Dedge", [u, v])
+
+
+class CubeNativeAdapter:
+    """group halo updates of the single-domain host code -> the cube-edge exchange behind the C ABI (cubed_halo.CubeHaloNative).
+    ctx: a MultiContext holding the faces of this rank (all six, or one), or a single Context of one face.  Every field of a group
+    travels in ONE message per neighbouring face (the reference's complete=.false./.true. grouping, dyn_core.F90:823-824)."""
+    overlaps = False
+    overlaps_groups = True    # start() ... finish() pairs keep their messages in flight across kernels (one group at a time)
+
+    def __init__(self, ctx, faces, face_rank, rank: int = 0, nranks: int = 1, unique_id: bytes | None = None):
+        self.multi = hasattr(ctx, "ctxs")
+        ctxs = ctx.ctxs if self.multi else [ctx]
+        self.cube = CubeHaloNative(ctxs, faces, face_rank, rank, nranks, unique_id)
+        self.world, self.rank = nranks, rank
+
+    def _members(self, f):
+        return list(f.a) if self.multi else [f]
+
+    def _groups(self, fields):
+        fields = list(fields)
+        kinds = [k for _, k in fields]
+        if kinds == ["U", "V"]:
+            return [("D", (self._members(fields[0][0]), self._members(fields[1][0])))]
+        if kinds == ["V", "U"]:
+            return [("C", (self._members(fields[0][0]), self._members(fields[1][0])))]
+        out = []
+        for f, k in fields:
+            if k not in ("A", "B"):
+                raise ValueError(f"no cubed-sphere halo update for a lone field of kind {k}")
+            out.append((k, self._members(f)))
+        return out
+
+    def start(self, fields, defer=False):
+        self.cube.start(self._groups(fields))
+        return True
+
+    def post(self, pending):
+        pass
+
+    def finish(self, pending):
+        if pending:
+            self.cube.finish()
+
+    def update(self, fields):
+        self.cube.start(self._groups(fields))
+        self.cube.finish()
+
+    def sync_edges(self, u, v):
+        """mpp_get_boundary(u, v) of the last substep (dyn_core.F90:1151-1163)"""
+        self.cube.update("Dedge", (self._members(u), self._members(v)))
 
 
 def make_sphere_contexts(npx: int, npz: int, lib=None, sphere: CubedSphere | None = None):

@@ -237,3 +237,50 @@ class CubeHaloRank:
             self.lib.dll.fv3_gather_destroy(p["pack"])
             self.lib.dll.fv3_gather_destroy(p["unpack"])
         self._plans = {}
+
+
+class CubeHaloNative:
+    """The cube-edge exchange behind the C ABI (fv3_cube_halo_start / _complete: pack kernel, grouped RCCL sends / receives on the
+    communication stream of the first context, unpack kernel; the library's own topology, csrc/cube_topo.h).  `ctxs` are the faces
+    this rank holds -- all six on one GPU (every message then travels through RCCL to the same rank: the loopback of the message
+    path) or one per rank (BASELINE config 5: six MI355X).  `unique_id`: the 128 bytes of rank 0's fv3_comm_get_unique_id,
+    distributed by the caller."""
+
+    def __init__(self, ctxs, faces, face_rank, rank: int = 0, nranks: int = 1, unique_id: bytes | None = None):
+        self.ctxs, self.faces, self.face_rank = list(ctxs), [int(f) for f in faces], [int(r) for r in face_rank]
+        assert self.faces == sorted(self.faces) and len(self.ctxs) == len(self.faces)
+        self.unique_id = self.ctxs[0].comm_init(rank, nranks, unique_id)
+        self._pending = False
+
+    def start(self, groups):
+        """groups: list of (kind, members[, scalar_pair]); members = list of per-context arrays ('A' / 'B') or a pair of such lists"""
+        from .lib import cube_halo_start
+        if self._pending:
+            raise RuntimeError("CubeHaloNative: one group in flight per context (complete the previous one first)")
+        norm = []
+        for g in groups:
+            kind, mem = g[0], g[1]
+            sp = g[2] if len(g) > 2 else False
+            if kind in ("D", "C", "Dedge"):
+                norm.append((kind, list(mem[0]), list(mem[1]), sp))
+            else:
+                norm.append((kind, list(mem), None, sp))
+        for n in range(0, len(norm), 8):
+            if n:
+                self.finish()
+            cube_halo_start(self.ctxs, self.faces, self.face_rank, norm[n:n + 8])
+            self._pending = True
+
+    def finish(self):
+        from .lib import cube_halo_complete
+        if self._pending:
+            cube_halo_complete(self.ctxs)
+            self._pending = False
+
+    def update(self, kind: str, fields, vector: bool = True):
+        """the interface of CubeHalo.update: 'A' / 'B': list of per-context arrays; pairs: (list, list)"""
+        self.start([(kind, fields, not vector)])
+        self.finish()
+
+    def close(self):
+        pass

@@ -33,7 +33,7 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_grid_upload_cubed", "fv3_gather_create", "fv3_gather_run", "fv3_gather_destroy", "fv3_grid_geom", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
-           "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_compute_total_energy", "fv3_energy_fixer_sums", "fv3_remap_finish", "fv3_ordered_sum", "fv3_adv_pe", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max",
+           "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_compute_total_energy", "fv3_energy_fixer_sums", "fv3_remap_finish", "fv3_ordered_sum", "fv3_adv_pe", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max", "fv3_cube_table", "fv3_cube_halo_start", "fv3_cube_halo_complete",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_set_fast", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
@@ -56,6 +56,52 @@ class _GridHost(C.Structure):
 class _GridCubed(C.Structure):
     _fields_ = [(n, _dp) for n in ["edge_w", "edge_e", "edge_s", "edge_n", "rsina"]] + [("corner_f", C.c_double * 12)] + [
         (n, _dp) for n in ["a11", "a12", "a21", "a22", "ec1", "ec2", "en1", "en2"]]
+
+
+class _CubeField(C.Structure):
+    _fields_ = [("kind", C.c_int), ("f0", C.c_void_p), ("f1", C.c_void_p), ("nk", C.c_int), ("scalar_pair", C.c_int)]
+
+
+CUBE_KINDS = {"A": 0, "B": 1, "D": 2, "C": 3, "Dedge": 4}
+
+
+def cube_table(lib, npx: int, kind: str, member: int, face: int, ng: int = 3):
+    """fv3_cube_table: the library's own halo topology of the cubed sphere (csrc/cube_topo.h) -> dict(dst, tile, comp, src, sign)"""
+    dll = lib.dll
+    dll.fv3_cube_table.restype = C.c_long
+    args = (C.c_int(npx), C.c_int(ng), C.c_int(CUBE_KINDS[kind]), C.c_int(member), C.c_int(face))
+    n = dll.fv3_cube_table(*args, None, None, None, None, None)
+    if n < 0:
+        raise Fv3Error("fv3_cube_table: bad argument")
+    dst, src = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+    st, cp, sg = (np.zeros(n, dtype=np.int32) for _ in range(3))
+    lp, ip = C.POINTER(C.c_long), C.POINTER(C.c_int)
+    dll.fv3_cube_table(*args, dst.ctypes.data_as(lp), st.ctypes.data_as(ip), cp.ctypes.data_as(ip), src.ctypes.data_as(lp), sg.ctypes.data_as(ip))
+    return dict(dst=dst, tile=st.astype(np.int64), comp=cp.astype(np.int64), src=src, sign=sg.astype(np.int64))
+
+
+def cube_halo_start(ctxs, faces, face_rank, groups):
+    """fv3_cube_halo_start.  ctxs: the contexts of the faces this rank holds (faces ascending; ctxs[0] has the communicator);
+    groups: list of (kind, f0s, f1s, scalar_pair) with f0s / f1s = one DeviceArray per context (f1s None for kinds 'A' / 'B')"""
+    lib = ctxs[0].lib
+    n, nf = len(ctxs), len(groups)
+    arr = (_CubeField * (n * nf))()
+    for i in range(n):
+        for f, (kind, f0s, f1s, sp) in enumerate(groups):
+            a0 = f0s[i]
+            e = arr[i * nf + f]
+            e.kind, e.f0, e.f1 = CUBE_KINDS[kind], a0.ptr, (f1s[i].ptr if f1s is not None else None)
+            e.nk = int(np.prod(a0.shape[2:])) if len(a0.shape) > 2 else 1
+            e.scalar_pair = int(bool(sp))
+    hs = (C.c_void_p * n)(*[c.h for c in ctxs])
+    lib.check(lib.dll.fv3_cube_halo_start(C.c_int(n), hs, (C.c_int * n)(*faces), (C.c_int * 6)(*face_rank), C.c_int(nf), arr),
+              "fv3_cube_halo_start")
+
+
+def cube_halo_complete(ctxs):
+    lib = ctxs[0].lib
+    n = len(ctxs)
+    lib.check(lib.dll.fv3_cube_halo_complete(C.c_int(n), (C.c_void_p * n)(*[c.h for c in ctxs])), "fv3_cube_halo_complete")
 
 
 class _DswParams(C.Structure):

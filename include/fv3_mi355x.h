@@ -220,6 +220,34 @@ int fv3_halo_start(fv3_ctx *ctx, int nfields, const fv3_halo_field *fields, cons
 int fv3_halo_complete(fv3_ctx *ctx);
 int fv3_allreduce_max(fv3_ctx *ctx, double *buf, int n);
 
+/* The cube-edge exchange: mpp_update_domains on the six-tile mosaic of the cubed sphere (tools/fv_mp_mod.F90:498-546: the 12
+ * contacts with index reversal and D / C-grid component rotation; group updates :646-876) and mpp_get_boundary of (u, v)
+ * (model/dyn_core.F90:1151-1163), one face per rank (BASELINE config 5) or several faces per rank, as RCCL peer messages on the
+ * communication stream of the first context: per pair of faces ONE message per call, whatever the number of fields.
+ *   fv3_cube_table        the rows of the halo update of one member of one face: the library's own topology (csrc/cube_topo.h),
+ *                         exposed so that a host can build gathers from it and tests can hold it to the oracle's contact-list
+ *                         derivation.  Returns the row count (arrays may be NULL to count), -1 on a bad argument.
+ *   fv3_cube_halo_start   pack (sign of the rotation applied unless scalar_pair), then the grouped sends / receives; kernels
+ *                         launched on the contexts' streams before _complete overlap the transfers.  ctxs[0] carries the
+ *                         communicator (fv3_comm_init); faces[] ascending; face_rank[6] = the rank holding each face;
+ *                         fields[i * nfields + f] = field f of context i.  Everything is validated before the first pack.
+ *   fv3_cube_halo_complete  the contexts' streams wait for the transfers, unpack into the halos. */
+#define FV3_CUBE_A 0      /* cell centres                         f0: A x nk */
+#define FV3_CUBE_B 1      /* corners                              f0: B x nk */
+#define FV3_CUBE_D 2      /* D-grid pair                          f0 = u: U x nk, f1 = v: V x nk */
+#define FV3_CUBE_C 3      /* C-grid pair                          f0 = uc: V x nk, f1 = vc: U x nk */
+#define FV3_CUBE_DEDGE 4  /* mpp_get_boundary of the D-grid pair  f0 = u, f1 = v: u(:, npy), v(npx, :) from the neighbours */
+typedef struct fv3_cube_field {
+  int kind;
+  double *f0, *f1;   /* device arrays, f1 NULL for kinds A / B */
+  int nk;
+  int scalar_pair;   /* 1: no sign change (flags = SCALAR_PAIR) */
+} fv3_cube_field;
+long fv3_cube_table(int npx, int ng, int kind, int member, int face, long *dst, int *src_face, int *comp, long *src, int *sign);
+int fv3_cube_halo_start(int nctx, fv3_ctx *const *ctxs, const int *faces, const int *face_rank, int nfields,
+                        const fv3_cube_field *fields);
+int fv3_cube_halo_complete(int nctx, fv3_ctx *const *ctxs);
+
 /* ---- nonhydrostatic column path --------------------------------------------------------------------
  * Physical constants live in FMS constants_mod (not part of the reference tree); the caller passes them. */
 typedef struct fv3_nh_consts {

@@ -225,7 +225,8 @@ def tracer_fields(cs, npz, nq):
     return out
 
 
-def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-12, hydrostatic=True, nq=0, face_streams=False, graph=False, flags=None):
+def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-12, hydrostatic=True, nq=0, face_streams=False, graph=False, flags=None,
+                  native_halo=False):
     """BASELINE configs[1] in small: the Jablonowski-Williamson baroclinic wave (test_case = 13) on the whole cubed sphere,
     hydrostatic, the reference's L79 levels (set_eta), one dt_atmos = k_split x (n_split substeps + vertical remap) on six
     device contexts against the six-face orchestration of the oracle"""
@@ -264,7 +265,12 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
         mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     worst = {}
     try:
-        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)))
+        if native_halo:      # the cube-edge exchange behind the C ABI: every message through fv3_cube_halo_start / _complete
+            from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeNativeAdapter
+            halo = CubeNativeAdapter(mctx, range(6), [0] * 6)
+        else:
+            halo = CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx))
+        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=halo)
         q0 = tracer_fields(cs, npz, nq) if nq else None
         if hydrostatic:
             ref = CC.oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, fv.remap_par, npz, q=q0)

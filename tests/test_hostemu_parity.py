@@ -840,3 +840,69 @@ def test_cubed_to_latlon_on_the_sphere(emu, c2l_ord):
     """cubed_to_latlon on the six faces (the a11 .. a22 rotation of init_cubed_to_latlon, the two-point forms next to the face
     edges): device = oracle, and the result is the analytic (east, north) wind of the test state to discretisation error"""
     assert PC.check_c2l(emu, c2l_ord, npx=13) <= P.TOL
+
+
+def test_cube_table_of_the_library_equals_the_oracle(emu):
+    """fv3_cube_table (csrc/cube_topo.h: the topology the pack / unpack lists of the cube-edge messages are built from, derived from
+    the cube's geometry) row for row against the oracle's tables (oracle/fv_grid.c: from the reference's 12 contacts)"""
+    import numpy as np
+    import grid_oracle as GO
+    from gfdl_atmos_cubed_sphere_amd.lib import cube_table
+    npx = 9
+    ref = GO.ref_sphere(npx)
+    for kind in ("A", "B", "D", "C", "Dedge"):
+        rt = ref.table(kind)
+        for t in range(6):
+            for m in range(len(rt[t])):
+                a, b = rt[t][m], cube_table(emu, npx, kind, m, t)
+                oa, ob = np.argsort(a["dst"], kind="stable"), np.argsort(b["dst"], kind="stable")
+                for k in ("dst", "tile", "comp", "src") + (("sign",) if kind in ("D", "C", "Dedge") else ()):
+                    assert np.array_equal(a[k][oa], b[k][ob]), (kind, t, m, k)
+
+
+def test_cube_edge_exchange_behind_the_c_abi(emu):
+    """fv3_cube_halo_start / _complete with the six faces in one process (the host-emulation build copies the messages; on the GPU the
+    same call routes every message through RCCL, tests/test_gpu_parity.py): every field kind, a group of several fields in one call,
+    SCALAR_PAIR, mpp_get_boundary -- against the oracle's update of the six tiles"""
+    import numpy as np
+    from gfdl_atmos_cubed_sphere_amd.cubed_halo import CubeHaloNative
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    npx, npz = 9, 3
+    cs, gs = PC.CC.sphere(npx)
+    ctxs = [Context(g, npz, lib=emu) for g in gs]
+    try:
+        H = CubeHaloNative(ctxs, range(6), [0] * 6)
+        rng = np.random.default_rng(0)
+        bd = gs[0].bd
+        mk = lambda k, nk=npz: [np.asfortranarray(rng.uniform(-1, 1, bd.shape(k, nk))) for _ in range(6)]      # noqa: E731
+        for kind, kinds, vector in (("A", ("A",), True), ("B", ("B",), True), ("D", ("U", "V"), True), ("C", ("V", "U"), True),
+                                    ("C", ("V", "U"), False), ("Dedge", ("U", "V"), True)):
+            host = [mk(k) for k in kinds]
+            dev = [[ctxs[t].from_host(a[t]) for t in range(6)] for a in host]
+            ref = [[x.copy(order="F") for x in a] for a in host]
+            cs.topo.update(kind, ref[0] if len(kinds) == 1 else (ref[0], ref[1]), vector=vector)
+            H.update(kind, dev[0] if len(kinds) == 1 else (dev[0], dev[1]), vector=vector)
+            for m in range(len(kinds)):
+                for t in range(6):
+                    assert np.array_equal(dev[m][t].download(), ref[m][t]), (kind, vector, m, t)
+        # a group: two A fields of different depth, a B field and a D pair in ONE start (one message per pair of faces)
+        a1, a2, b1, u, v = mk("A"), mk("A", 1), mk("B"), mk("U"), mk("V")
+        dev = {n: [ctxs[t].from_host(x[t]) for t in range(6)] for n, x in dict(a1=a1, a2=a2, b1=b1, u=u, v=v).items()}
+        cs.topo.update("A", a1); cs.topo.update("A", a2); cs.topo.update("B", b1); cs.topo.update("D", (u, v))
+        H.start([("A", dev["a1"]), ("A", dev["a2"]), ("B", dev["b1"]), ("D", (dev["u"], dev["v"]))])
+        H.finish()
+        for n, x in dict(a1=a1, a2=a2, b1=b1, u=u, v=v).items():
+            for t in range(6):
+                assert np.array_equal(dev[n][t].download(), x[t]), (n, t)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.parametrize("hydrostatic", [True, False])
+def test_sphere_step_through_the_cube_edge_exchange_of_the_c_abi(emu, hydrostatic):
+    """a whole fv_dynamics call on the six faces with EVERY halo update going through fv3_cube_halo_start / _complete (groups of
+    fields in one message per pair of faces, delp + pt and zh + pkc kept in flight across kernels, mpp_get_boundary at the end) --
+    the state of the device-gather run, i.e. the six-face oracle's"""
+    r = PC.check_jw_step(emu, npx=13, npz=20, k_split=1, n_split=2, bdt=900.0, hydrostatic=hydrostatic, nq=2, native_halo=True)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12, r
