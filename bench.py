@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--nx", type=int, default=384)
     ap.add_argument("--npz", type=int, default=127)
+    ap.add_argument("--periodic6", action="store_true", help="--gpus 6 as a 3x2 doubly periodic layout instead of the six cubed-sphere faces")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--parity-columns", action="store_true",
                     help="whole-step legs with the parity (bit-comparable) column solvers instead of the fast mode (csrc/nh_fast.h, 1e-12)")
@@ -435,6 +436,126 @@ def sphere_steps(torch, stream, cs, gs, nx, npz, hydrostatic, k_split, n_split, 
     return summary, kernels
 
 
+def cubed_six_ranks(a, torch, dist, rank, json_fd):
+    """BASELINE config 5's layout: `--gpus 6`, one cubed-sphere face per rank, every cube-edge message through the library's own
+    exchange (fv3_cube_halo_start / _complete: RCCL grouped send / recv over xGMI on the context's communication stream).
+    Headline = the c_sw -> exchange(uc, vc, divg_d) -> d_sw pair on the six C<nx> L<npz> faces; then whole nonhydrostatic steps of the
+    Jablonowski-Williamson wave (SYPD).  Never run on hardware yet (no 6-GPU node was available): the same exchange is tested in
+    loopback on one GPU (tests/test_gpu_parity.py::test_cube_edge_exchange_through_rccl_loopback)."""
+    import ctypes as C
+    from gfdl_atmos_cubed_sphere_amd import lib as L
+    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeNativeAdapter
+    from gfdl_atmos_cubed_sphere_amd.cubed_sphere import CubedSphere
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags, level_coefficients
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    from gfdl_atmos_cubed_sphere_amd.synthetic import CSW_OUT, DSW_PAR, smooth_state
+    from gfdl_atmos_cubed_sphere_amd.test_cases import jablonowski_williamson, set_eta
+    nx, npz = a.nx, a.npz
+    npx = nx + 1
+    cs = CubedSphere(npx)
+    g = cs.gridstruct(rank)
+    stream = torch.cuda.current_stream()
+    with column_mode(not a.parity_columns):
+        ctx = L.Context(g, npz, stream=stream.cuda_stream)
+    uid = [None]
+    if rank == 0:
+        buf = (C.c_ubyte * 128)()
+        ctx.lib.check(ctx.lib.dll.fv3_comm_get_unique_id(buf), "fv3_comm_get_unique_id")
+        uid[0] = bytes(buf)
+    dist.broadcast_object_list(uid, src=0)
+    halo = CubeNativeAdapter(ctx, [rank], list(range(6)), rank, 6, uid[0])
+    st = smooth_state(Bounds(1, nx, 1, nx), npz, noise=0.05)
+    d = {k: ctx.from_host(v) for k, v in st.items()}
+    del st
+    for n, kind in tuple(CSW_OUT) + (("mfx", "FX"), ("mfy", "FY"), ("cx", "CX"), ("cy", "CY"), ("crx", "CX"), ("cry", "CY"),
+                                    ("xfx", "CX"), ("yfx", "CY"), ("delp_out", "A"), ("pt_out", "A"), ("u_out", "U"), ("v_out", "V"),
+                                    ("w_out", "A"), ("heat_s", "CC"), ("diss_e", "CC")):
+        d[n] = ctx.zeros(kind, npz)
+    ctx.dsw_levels(level_coefficients(npz, DynFlags()))
+    dt = 22.5
+    par = dict(DSW_PAR)
+    par.update(dt=dt, hydrostatic=0, use_cond=0, hord_mt=a.hord, hord_vt=a.hord, hord_tm=a.hord, hord_dp=a.hord)
+
+    def step():
+        ctx.c_sw(d["delpc"], d["delp"], d["ptc"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"], d["wc"],
+                 d["ut"], d["vt"], d["divg_d"], 1, 0.5 * dt, False)
+        halo.cube.start([("C", ([d["uc"]], [d["vc"]])), ("B", [d["divg_d"]])])      # dyn_core.F90:451, :565: one message per edge
+        halo.cube.finish()
+        ctx.d_sw(par, None, d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"], d["divg_d"], d["mfx"],
+                 d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None, d["delp_out"], d["pt_out"], d["u_out"],
+                 d["v_out"], d["w_out"], None, d["heat_s"], d["diss_e"])
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    cells = nx * nx * npz
+    finite = bool(np.isfinite(d["u_out"].download()).all())
+    out = {"metric": "c_sw+d_sw cell-updates/s", "value": 6 * cells * a.steps / el, "unit": "cell-updates/s", "n_gpus": 6,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"gnomonic cubed sphere C{nx} L{npz}, one face per GPU (BASELINE config 5 layout), nonhydrostatic "
+                                  f"c_sw + d_sw pair, hord {a.hord}, cube-edge exchange of uc, vc, divg_d in between",
+                      "layout": "6 faces x 1x1", "halo": "fv3_cube_halo_start / _complete: RCCL grouped send / recv, one message per edge",
+                      "build_id": L.build_id()},
+           "finite": finite,
+           "roofline": {"bound": "hbm", "kernel": "pair (whole step)", "achieved": cells * PAIR_ALG_BYTES / (el / a.steps) / 1e9,
+                        "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": cells * PAIR_ALG_BYTES / (el / a.steps) / HBM_PEAK, "traffic": None,
+                        "note": "per GPU: one face's algorithmic bytes over the step's wall time (exchange included)"},
+           "cpu_baseline": None}
+    del d
+    try:        # whole model steps: BASELINE configs[2] with one face per GPU
+        ak, bk, _, _ = set_eta(npz) if npz in (79, 127) else (None, None, None, None)
+        if ak is None:
+            sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+            ak, bk = 300.0 * (1.0 - sig), sig.copy()
+        st = jablonowski_williamson(cs, ak, bk, hydrostatic=False)
+        cs.topo.update("A", [s_["phis"] for s_ in st])
+        s_ = st[rank]
+        k_split, n_split, dt_atmos = 2, 5, 225.0
+        fl = DynFlags(n_split=n_split, hydrostatic=False, ptop=float(ak[0]))
+        ng = g.bd.ng
+        c = (slice(ng, ng + nx), slice(ng, ng + nx))
+        pkz = ((-fl.rdgas / fl.grav) * s_["delp"][c] * s_["pt"][c] / s_["delz"]) ** fl.akap
+        s_["pt"][c] = s_["pt"][c] / pkz
+        fv = FvDynamics(ctx, fl, ak, bk, nq=0, k_split=k_split, halo=halo, dist=dist)
+        fv.dc.set_state(s_["u"], s_["v"], s_["w"], s_["delp"], s_["pt"], s_["delz"], s_["phis"])
+        del st
+        fv.step(dt_atmos)
+        fence()
+        nrep = 3
+        t0 = time.perf_counter()
+        for _ in range(nrep):
+            fv.step(dt_atmos)
+        fence()
+        wall = (time.perf_counter() - t0) / nrep
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        out["sphere_six_gpus"] = {"grid": f"C{nx} L{npz}", "sypd": dt_atmos / (365.0 * wall), "wall_s_per_dt_atmos": wall,
+                                  "dt_atmos_s": dt_atmos, "k_split": k_split, "n_split": n_split,
+                                  "whole_step": whole_step_roofline(cells, wall, k_split * n_split, k_split, 0),
+                                  "column_solvers": "parity kernels" if a.parity_columns else "fast mode (nh_fast.h)",
+                                  "finite": bool(np.isfinite(fv.dc.d["delp"].download()[c]).all())}
+    except Exception as e:  # noqa: BLE001
+        out["sphere_six_gpus"] = {"error": f"{type(e).__name__}: {e}"}
+    ctx.close()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
 def main():
     # HIP maps streams onto 4 hardware queues by default; the launch stream, the sponge-level side stream and RCCL's
     # stream then share queues and the kernels meant to overlap wait for each other in queue order (measured in the
@@ -464,6 +585,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+
+    if world == 6 and not a.periodic6:      # six ranks = the six faces of the cubed sphere (BASELINE config 5's layout)
+        try:
+            cubed_six_ranks(a, torch, dist, rank, json_fd)
+        finally:
+            dist.destroy_process_group()
+        return
 
     from gfdl_atmos_cubed_sphere_amd import lib as L
     from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags, level_coefficients

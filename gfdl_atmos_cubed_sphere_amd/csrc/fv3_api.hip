@@ -366,8 +366,10 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
 }
 
 extern "C" int fv3_comm_destroy(fv3_ctx *c);
+static void cube_plans_free(fv3_ctx *c);
 extern "C" int fv3_destroy(fv3_ctx *c) {
   if (!c) return 0;
+  cube_plans_free(c);
   fv3_comm_destroy(c);
   if (c->dev_metrics) rt_free(c->dev_metrics);
   if (c->lev_i) rt_free(c->lev_i);
@@ -1723,6 +1725,22 @@ struct CubePlanDev {
   long *s_idx, *r_idx;                                 // device
   int send_cnt[6], recv_cnt[6], send_start[6], recv_start[6];
 };
+static void cube_plans_free(fv3_ctx *c) {
+  for (int n = 0; n < 5; n++) {
+    CubePlanDev *p = c->cube_plan[n];
+    if (!p) continue;
+    int *ip[5] = {p->s_member, p->s_sign, p->s_seg, p->r_member, p->r_seg};
+    for (int *q : ip) if (q) rt_free(q);
+    if (p->s_idx) rt_free(p->s_idx);
+    if (p->r_idx) rt_free(p->r_idx);
+    delete p;
+    c->cube_plan[n] = nullptr;
+  }
+  if (c->cube_send) rt_free(c->cube_send);
+  if (c->cube_recv) rt_free(c->cube_recv);
+  c->cube_send = c->cube_recv = nullptr;
+  c->cube_cap_send = c->cube_cap_recv = 0;
+}
 extern "C" long fv3_cube_table(int npx, int ng, int kind, int member, int face, long *dst, int *src_face, int *comp, long *src, int *sign) {
   if (npx < 3 || ng < 1 || kind < 0 || kind > 4 || face < 0 || face > 5 || member < 0 || member >= CubeTopo::members(kind)) return -1;
   const std::vector<CubeRow> rows = CubeTopo(npx, ng).table(kind, member, face);
