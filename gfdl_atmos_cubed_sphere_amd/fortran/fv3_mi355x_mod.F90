@@ -20,6 +20,8 @@ module fv3_mi355x_mod
   public :: fv3_divg2_ext, fv3_one_grad_p, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
   public :: fv3_grid_cubed, fv3_grid_upload_cubed, fv3_gather_create, fv3_gather_run, fv3_gather_destroy
   public :: fv3_comm_get_unique_id, fv3_comm_init, fv3_comm_destroy, fv3_halo_start, fv3_halo_complete, fv3_allreduce_max
+  public :: fv3_cube_field, fv3_cube_table, fv3_cube_halo_start, fv3_cube_halo_complete
+  public :: FV3_CUBE_A, FV3_CUBE_B, FV3_CUBE_D, FV3_CUBE_C, FV3_CUBE_DEDGE
   public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_rayleigh_super, fv3_compute_total_energy, fv3_energy_fixer_sums, fv3_remap_finish, fv3_ordered_sum, fv3_adv_pe, fv3_set_condensate, fv3_set_fast, fv3_set_moist, fv3_moist_params
 
   type, bind(C) :: fv3_domain
@@ -42,6 +44,15 @@ module fv3_mi355x_mod
     real(c_double) :: corner_f(12)
     type(c_ptr) :: a11 = c_null_ptr, a12 = c_null_ptr, a21 = c_null_ptr, a22 = c_null_ptr   ! cubed_to_latlon matrix (A layout)
     type(c_ptr) :: ec1 = c_null_ptr, ec2 = c_null_ptr, en1 = c_null_ptr, en2 = c_null_ptr   ! adv_pe's unit vectors (3 planes each)
+  end type
+
+  !> one field (or vector pair) of a cube-edge exchange group (fv3_cube_halo_start)
+  integer(c_int), parameter :: FV3_CUBE_A = 0, FV3_CUBE_B = 1, FV3_CUBE_D = 2, FV3_CUBE_C = 3, FV3_CUBE_DEDGE = 4
+  type, bind(C) :: fv3_cube_field
+    integer(c_int) :: kind
+    type(c_ptr) :: f0, f1 = c_null_ptr
+    integer(c_int) :: nk
+    integer(c_int) :: scalar_pair = 0
   end type
 
   type, bind(C) :: fv3_dsw_params
@@ -254,6 +265,24 @@ module fv3_mi355x_mod
     integer(c_int) function fv3_halo_complete(ctx) bind(C, name="fv3_halo_complete")
       import :: c_int, c_ptr
       type(c_ptr), value :: ctx
+    end function
+    ! the cube-edge exchange (mpp_update_domains / mpp_get_boundary on the cubed-sphere mosaic, tools/fv_mp_mod.F90:498-546)
+    integer(c_long) function fv3_cube_table(npx, ng, kind, member, face, dst, src_face, comp, src, sgn) bind(C, name="fv3_cube_table")
+      import :: c_int, c_long, c_ptr
+      integer(c_int), value :: npx, ng, kind, member, face
+      type(c_ptr), value :: dst, src_face, comp, src, sgn
+    end function
+    integer(c_int) function fv3_cube_halo_start(nctx, ctxs, faces, face_rank, nfields, fields) bind(C, name="fv3_cube_halo_start")
+      import :: c_int, c_ptr, fv3_cube_field
+      integer(c_int), value :: nctx, nfields
+      type(c_ptr), intent(in) :: ctxs(*)
+      integer(c_int), intent(in) :: faces(*), face_rank(6)
+      type(fv3_cube_field), intent(in) :: fields(*)
+    end function
+    integer(c_int) function fv3_cube_halo_complete(nctx, ctxs) bind(C, name="fv3_cube_halo_complete")
+      import :: c_int, c_ptr
+      integer(c_int), value :: nctx
+      type(c_ptr), intent(in) :: ctxs(*)
     end function
     integer(c_int) function fv3_allreduce_max(ctx, buf, n) bind(C, name="fv3_allreduce_max")
       import :: c_int, c_ptr, c_double

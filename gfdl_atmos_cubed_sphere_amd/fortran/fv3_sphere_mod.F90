@@ -1,0 +1,399 @@
+!> Fortran host of the hot path on the CUBED SPHERE (grid_type = 0): dyn_core (model/dyn_core.F90:94-1393, nonhydrostatic and
+!> hydrostatic branches, d_con heating, non-nested) and the k_split loop of fv_dynamics (model/fv_dynamics.F90:460-665) over the
+!> faces this rank holds -- all six in one process (one GPU for the whole sphere: BASELINE configs 2, 3) or one per rank (config 5:
+!> face_rank places them) -- one library context per face (fv3_create with grid_type 0, fv3_grid_upload + fv3_grid_upload_cubed),
+!> every halo update of the loop through the cube-edge exchange behind the C ABI (fv3_cube_halo_start / _complete: the mosaic of
+!> tools/fv_mp_mod.F90:498-546 as grouped RCCL messages; fields of one group travel in ONE message per pair of faces like the
+!> reference's complete=.false./.true. grouping), mpp_get_boundary of (u, v) after the last substep (dyn_core.F90:1151-1163).
+!> Same kernels, same order, same arguments as the Python host (dyn_core.py / fv_dynamics.py over cubed_dyn.MultiContext): the
+!> test suite runs a Jablonowski-Williamson step through both and requires identical bits.
+!> The per-face state is fv3_host_mod's fv3_atmos; gridstruct comes from the caller (the reference's init_grid in an integration,
+!> the harness' arrays in fv3_solo_sphere).
+module fv3_sphere_mod
+  use iso_c_binding
+  use fv3_mi355x_mod
+  use fv3_host_mod
+  implicit none
+  private
+  public :: fv3_sphere, fv3_sphere_init_face, fv3_sphere_comm, fv3_sphere_dyn_core, fv3_sphere_fv_dynamics, fv3_sphere_final
+  public :: fv3_sphere_halo_a
+
+  type fv3_sphere
+    integer :: nf = 0                       !< faces held by this rank
+    integer(c_int) :: faces(6) = 0          !< their tile numbers 0..5, ascending
+    integer(c_int) :: face_rank(6) = 0      !< the rank holding each tile
+    type(fv3_atmos) :: f(6)
+    type(c_ptr) :: ctxs(6)
+    logical :: adv_pe = .true.              !< en1 / en2 were uploaded (fv3_grid_cubed): omga gets its advective part (dyn_core.F90:1195)
+  end type
+
+contains
+
+  !> one face: context (grid_type = 0), gridstruct, device arrays.  dom%grid_type must be 0 .. 2; gc: the cubed-sphere members.
+  subroutine fv3_sphere_init_face(sp, slot, tile, dom, gh, gc, nq, fl, ak, bk)
+    type(fv3_sphere), intent(inout) :: sp
+    integer, intent(in) :: slot, tile, nq
+    type(fv3_domain), intent(in) :: dom
+    type(fv3_grid_host), intent(in) :: gh
+    type(fv3_grid_cubed), intent(in) :: gc
+    type(fv3_flags), intent(in) :: fl
+    real(c_double), intent(in) :: ak(dom%npz+1), bk(dom%npz+1)
+    if (dom%grid_type > 2) stop 'fv3_sphere_init_face: grid_type must be 0, 1 or 2'
+    call fv3_host_init_grid(sp%f(slot), dom, gh, nq, fl, ak, bk)
+    call fv3_check(fv3_grid_upload_cubed(sp%f(slot)%ctx, gc), 'fv3_grid_upload_cubed')
+    sp%faces(slot) = int(tile, c_int)
+    sp%ctxs(slot) = sp%f(slot)%ctx
+    sp%nf = max(sp%nf, slot)
+    if (.not. c_associated(gc%en1)) sp%adv_pe = .false.
+  end subroutine
+
+  !> the communicator of the cube-edge exchange on the first face's context.  id: rank 0's fv3_comm_get_unique_id, distributed by the
+  !> caller (MPI_Bcast) when there are several ranks; one rank makes its own.
+  subroutine fv3_sphere_comm(sp, rank, nranks, face_rank, id)
+    type(fv3_sphere), intent(inout) :: sp
+    integer, intent(in) :: rank, nranks, face_rank(6)
+    integer(c_signed_char), intent(in), optional :: id(128)
+    integer(c_signed_char) :: myid(128)
+    sp%face_rank = int(face_rank, c_int)
+    if (present(id)) then
+      myid = id
+    else
+      call fv3_check(fv3_comm_get_unique_id(myid), 'fv3_comm_get_unique_id')
+    end if
+    call fv3_check(fv3_comm_init(sp%ctxs(1), int(rank, c_int), int(nranks, c_int), myid), 'fv3_comm_init')
+  end subroutine
+
+  ! ---- the cube-edge exchange of one group: up to 4 entries, each a scalar field or a vector pair of every face ----
+  subroutine exchange(sp, n, kinds, sel0, sel1, nks)
+    type(fv3_sphere), intent(inout) :: sp
+    integer, intent(in) :: n, kinds(n), sel0(n), sel1(n), nks(n)
+    type(fv3_cube_field) :: fd(6*4)
+    integer :: i, e
+    do i = 1, sp%nf
+      do e = 1, n
+        fd((i-1)*n + e)%kind = int(kinds(e), c_int)
+        fd((i-1)*n + e)%f0 = field_of(sp%f(i), sel0(e))
+        fd((i-1)*n + e)%f1 = c_null_ptr
+        if (sel1(e) > 0) fd((i-1)*n + e)%f1 = field_of(sp%f(i), sel1(e))
+        fd((i-1)*n + e)%nk = int(nks(e), c_int)
+        fd((i-1)*n + e)%scalar_pair = 0_c_int
+      end do
+    end do
+    call fv3_check(fv3_cube_halo_start(int(sp%nf, c_int), sp%ctxs, sp%faces, sp%face_rank, int(n, c_int), fd), 'fv3_cube_halo_start')
+    call fv3_check(fv3_cube_halo_complete(int(sp%nf, c_int), sp%ctxs), 'fv3_cube_halo_complete')
+  end subroutine
+
+  !> halo update of one cell-centred field given per face (for callers outside: phis after fv3_host_upload, init_case's
+  !> mpp_update_domains(phis))
+  subroutine fv3_sphere_halo_a(sp, sel, nk)
+    type(fv3_sphere), intent(inout) :: sp
+    integer, intent(in) :: sel, nk
+    call exchange(sp, 1, [FV3_CUBE_A + 0], [sel], [0], [nk])
+  end subroutine
+
+  ! field selectors (the arrays are swapped between substeps, so the pointer is looked up at every exchange)
+  function field_of(at, sel) result(p)
+    type(fv3_atmos), intent(in) :: at
+    integer, intent(in) :: sel
+    type(c_ptr) :: p
+    select case (sel)
+    case (1);  p = at%u
+    case (2);  p = at%v
+    case (3);  p = at%w
+    case (4);  p = at%delp
+    case (5);  p = at%pt
+    case (6);  p = at%zh
+    case (7);  p = at%divgd
+    case (8);  p = at%uc
+    case (9);  p = at%vc
+    case (10); p = at%pkc
+    case (11); p = at%heat_source
+    case (12); p = at%q
+    case (13); p = at%dp1
+    case (14); p = at%phis
+    case default; p = c_null_ptr
+    end select
+  end function
+
+  !> the acoustic substep loop on the faces of this rank (dyn_core.F90:313-1286)
+  subroutine fv3_sphere_dyn_core(sp, bdt, end_step)
+    type(fv3_sphere), intent(inout) :: sp
+    real(c_double), intent(in) :: bdt
+    logical, intent(in) :: end_step
+    type(fv3_dsw_params) :: par
+    real(c_double) :: dt, dt2, rdt, ptk, peln1, top
+    integer :: it, n_split, npz, i, n_con
+    logical :: remap_step, heating, hyd
+    integer(c_int) :: last_call, use_logp, ihyd
+    type(c_ptr) :: dv2
+    type(fv3_flags) :: fl
+    integer, parameter :: A = FV3_CUBE_A, B = FV3_CUBE_B, D = FV3_CUBE_D, C = FV3_CUBE_C, DE = FV3_CUBE_DEDGE
+    fl = sp%f(1)%fl
+    npz = sp%f(1)%npz
+    hyd = fl%hydrostatic
+    ihyd = merge(1_c_int, 0_c_int, hyd)
+    n_split = fl%n_split
+    dt = bdt / real(n_split, c_double)
+    dt2 = 0.5d0 * dt
+    rdt = 1.d0 / dt
+    heating = fl%d_con > 1.d-5                                              ! dyn_core.F90:294
+    ptk = fl%ptop ** fl%akap                                                ! :222
+    peln1 = log(fl%ptop)
+    use_logp = merge(1_c_int, 0_c_int, fl%use_logp)
+    top = merge(peln1, ptk, fl%use_logp)
+    par%dt = dt; par%hord_tr = fl%hord_tr; par%hord_mt = fl%hord_mt; par%hord_vt = fl%hord_vt
+    par%hord_tm = fl%hord_tm; par%hord_dp = fl%hord_dp; par%dddmp = fl%dddmp; par%d4_bg = fl%d4_bg
+    par%kgb = fl%ke_bg; par%hydrostatic = ihyd; par%use_cond = 0
+    do i = 1, sp%nf
+      associate (at => sp%f(i))
+        if (heating) call dzero(at, at%heat_source, at%nA*npz)
+        call dzero(at, at%mfx, at%nFX*npz); call dzero(at, at%mfy, at%nFY*npz)          ! :289-292
+        call dzero(at, at%cx, at%nCX*npz);  call dzero(at, at%cy, at%nCY*npz)
+      end associate
+    end do
+    ! fv_dynamics.F90:467-470: delp, pt (pack 1) and u, v (pack 8) before the first substep
+    call exchange(sp, 2, [A, A], [4, 5], [0, 0], [npz, npz])
+    call exchange(sp, 1, [D], [1], [2], [npz])
+    do it = 1, n_split
+      remap_step = it == n_split
+      last_call = merge(1_c_int, 0_c_int, remap_step)
+      if (.not. hyd) then
+        call exchange(sp, 1, [A], [3], [0], [npz])                                        ! w: :350 / :432 (pack 7)
+        if (it == 1) then                                                                 ! :353-389
+          do i = 1, sp%nf
+            call fv3_check(fv3_zh_from_delz(sp%f(i)%ctx, sp%f(i)%zs, sp%f(i)%delz, sp%f(i)%zh), 'zh_from_delz')
+          end do
+          call exchange(sp, 1, [A], [6], [0], [npz + 1])                                  ! gz halo (pack 5)
+        end if
+      end if
+      do i = 1, sp%nf
+        associate (at => sp%f(i))
+          if (hyd) then
+            call fv3_check(fv3_c_sw(at%ctx, at%delpc, at%delp, at%ptc, at%pt, at%u, at%v, c_null_ptr, at%uc, at%vc, at%ua, at%va, &
+                                    c_null_ptr, at%ut, at%vt, at%divgd, int(fl%nord, c_int), dt2, 1_c_int, 1_c_int), 'c_sw')
+          else
+            call fv3_check(fv3_c_sw(at%ctx, at%delpc, at%delp, at%ptc, at%pt, at%u, at%v, at%w, at%uc, at%vc, at%ua, at%va, &
+                                    at%omga, at%ut, at%vt, at%divgd, int(fl%nord, c_int), dt2, 0_c_int, 1_c_int), 'c_sw')   ! :439-447
+          end if
+        end associate
+      end do
+      if (fl%nord > 0) call exchange(sp, 1, [B], [7], [0], [npz])                         ! divg_d: :451 / :577 (pack 3, CORNER)
+      do i = 1, sp%nf
+        associate (at => sp%f(i))
+          if (hyd) then
+            call fv3_check(fv3_geopk(at%ctx, fl%ptop, fl%akap, fl%cp_air, ptk, at%pe, at%peln, at%delpc, at%pkc, at%gz, &
+                                     at%phis, at%ptc, at%pkz, 1_c_int), 'geopk (C grid)')
+          else
+            call fv3_check(fv3_update_dz_c(at%ctx, dt2, at%zs, at%ut, at%vt, at%zh, at%gz, at%ws3), 'update_dz_c')   ! :514-527
+            call fv3_check(fv3_riem_solver_c(at%ctx, dt2, at%cn, at%phis, at%omga, at%ptc, at%delpc, at%gz, at%pkc, at%ws3), &
+                           'riem_solver_c')                                                ! :531
+          end if
+          call fv3_check(fv3_p_grad_c(at%ctx, dt2, at%delpc, at%pkc, at%gz, at%uc, at%vc, ihyd), 'p_grad_c')     ! :562
+        end associate
+      end do
+      call exchange(sp, 1, [C], [8], [9], [npz])                                          ! uc, vc: :565 / :578 (pack 9, CGRID_NE)
+      do i = 1, sp%nf
+        associate (at => sp%f(i))
+          if (hyd) then
+            call fv3_check(fv3_d_sw(at%ctx, par, at%vt, at%delp, at%pt, at%u, at%v, c_null_ptr, at%uc, at%vc, at%ua, at%va, at%divgd, &
+                                    at%mfx, at%mfy, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
+                                    at%delp_n, at%pt_n, at%u_n, at%v_n, c_null_ptr, c_null_ptr, at%heat_s, at%diss_e), 'd_sw')
+          else
+            call fv3_check(fv3_d_sw(at%ctx, par, at%vt, at%delp, at%pt, at%u, at%v, at%w, at%uc, at%vc, at%ua, at%va, at%divgd, &
+                                    at%mfx, at%mfy, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
+                                    at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, c_null_ptr, at%heat_s, at%diss_e), 'd_sw')  ! :762
+          end if
+          if (heating) call fv3_check(fv3_heat_source_accum(at%ctx, at%heat_source, at%heat_s), 'heat_source_accum')   ! :798-803
+          if (hyd) call fv3_check(fv3_divg2_ext(at%ctx, fl%d_ext, at%delp, at%vt, at%divg2), 'divg2_ext')          ! :745-747, :791-848
+          call swap(at%delp, at%delp_n); call swap(at%pt, at%pt_n)
+          call swap(at%u, at%u_n); call swap(at%v, at%v_n)
+          if (.not. hyd) call swap(at%w, at%w_n)
+        end associate
+      end do
+      call exchange(sp, 2, [A, A], [4, 5], [0, 0], [npz, npz])                            ! delp, pt: :823-824 / :851 (pack 1)
+      if (hyd) then
+        do i = 1, sp%nf
+          associate (at => sp%f(i))
+            dv2 = c_null_ptr
+            if (fl%d_ext > 0.d0) dv2 = at%divg2
+            call fv3_check(fv3_geopk(at%ctx, fl%ptop, fl%akap, fl%cp_air, ptk, at%pe, at%peln, at%delp, at%pkc, at%gz, &
+                                     at%phis, at%pt, at%pkz, 0_c_int), 'geopk')            ! :905-907
+            if (remap_step) call fv3_check(fv3_copy_a_to_cc(at%ctx, at%pkc, at%pk, int(npz + 1, c_int)), 'pk = pkc')   ! :1001-1010
+            call fv3_check(fv3_one_grad_p(at%ctx, at%u, at%v, at%pkc, at%gz, dv2, dt, ptk), 'one_grad_p')        ! :1021
+          end associate
+        end do
+      else
+        do i = 1, sp%nf
+          associate (at => sp%f(i))
+            call fv3_check(fv3_update_dz_d(at%ctx, int(fl%hord_tm, c_int), at%zs, at%zh, at%zh_n, at%crx, at%cry, at%xfx, &
+                                           at%yfx, at%ws, rdt), 'update_dz_d')              ! :911
+            call swap(at%zh, at%zh_n)
+            call fv3_check(fv3_riem_solver3(at%ctx, dt, at%cn, at%zs, at%w, at%delz, at%pt, at%delp, at%zh, at%pe, at%pkc, &
+                                            at%pk3, at%pk, at%peln, at%ws, use_logp, last_call, 0_c_int), 'riem_solver3')  ! :932
+          end associate
+        end do
+        call exchange(sp, 2, [A, A], [6, 10], [0, 0], [npz + 1, npz + 1])                 ! zh, pkc: :944-950 (packs 4, 5)
+        do i = 1, sp%nf
+          associate (at => sp%f(i))
+            if (remap_step) call fv3_check(fv3_pe_halo(at%ctx, fl%ptop, at%pe, at%delp), 'pe_halo')            ! :952-953
+            call fv3_check(fv3_pk3_halo(at%ctx, fl%ptop, fl%akap, at%pk3, at%delp, use_logp), 'pk3_halo')      ! :955-959
+            call fv3_check(fv3_nh_p_grad(at%ctx, at%u, at%v, at%pkc, at%zh, fl%grav, at%delp, at%pk3, dt, top), 'nh_p_grad')  ! :1032
+          end associate
+        end do
+      end if
+      if (it /= n_split) then
+        call exchange(sp, 1, [D], [1], [2], [npz])                                        ! u, v: :1168-1169 (pack 8)
+      else
+        call exchange(sp, 1, [DE], [1], [2], [npz])                                       ! mpp_get_boundary: :1151-1163
+        if (.not. hyd .and. fl%use_old_omega .and. end_step) then
+          do i = 1, sp%nf
+            associate (at => sp%f(i))
+              ! :1182-1191: omga = (pe - pem) * rdt, pem from the delp this substep started with (= delp_n after the swap)
+              call fv3_check(fv3_omga_update(at%ctx, rdt, fl%ptop, at%pe, at%delp_n, at%omga), 'omga_update')
+              if (sp%adv_pe) call fv3_check(fv3_adv_pe(at%ctx, fl%ptop, at%ua, at%va, at%delp_n, at%omga), 'adv_pe')   ! :1195
+            end associate
+          end do
+        end if
+      end if
+    end do
+    ! dissipative heating (:296-308, :1300-1355)
+    n_con = host_n_con(fl, npz)
+    if (n_con /= 0 .and. heating) then
+      call exchange(sp, 1, [A], [11], [0], [npz])                                         ! del2_cubed's mpp_update_domains, :2399
+      do i = 1, sp%nf
+        associate (at => sp%f(i))
+          call fv3_check(fv3_del2_cubed(at%ctx, at%heat_source, int(npz, c_int), 0.20d0 * at%da_min, &
+                                        int(min(3, fl%nord + 1), c_int)), 'del2_cubed')    ! :1301-1303
+          if (hyd) then
+            call fv3_check(fv3_apply_heat_source(at%ctx, int(n_con, c_int), 1_c_int, bdt, fl%delt_max, fl%cp_air, &
+                                                 fl%cp_air - fl%rdgas, fl%rdgas, fl%grav, at%pt, at%heat_source, at%delp, &
+                                                 c_null_ptr, at%pkz), 'apply_heat_source')
+          else
+            call fv3_check(fv3_apply_heat_source(at%ctx, int(n_con, c_int), 0_c_int, bdt, fl%delt_max, fl%cp_air, &
+                                                 fl%cp_air - fl%rdgas, fl%rdgas, fl%grav, at%pt, at%heat_source, at%delp, &
+                                                 at%delz, at%pkz), 'apply_heat_source')
+          end if
+        end associate
+      end do
+    end if
+  end subroutine
+
+  !> tracer_2d (fv_tracer2d.F90:297-557) on the faces of this rank: the Courant maximum reduced over the faces (and, with several
+  !> ranks, over the ranks: fv3_allreduce_max = mp_reduce_max, :405)
+  subroutine sphere_tracer_2d(sp, nranks)
+    type(fv3_sphere), intent(inout) :: sp
+    integer, intent(in) :: nranks
+    real(c_double), allocatable :: cmax(:), cm(:), frac(:)
+    integer(c_int), allocatable :: ksplt(:)
+    real(c_double) :: c_global
+    integer :: nsplt, it, npz, k, i, nq
+    type(fv3_flags) :: fl
+    fl = sp%f(1)%fl
+    npz = sp%f(1)%npz; nq = sp%f(1)%nq
+    allocate(cmax(npz), cm(npz), frac(npz), ksplt(npz))
+    cmax = 0.d0
+    do i = 1, sp%nf
+      associate (at => sp%f(i))
+        call fv3_check(fv3_tracer_2d_prep(at%ctx, int(fl%q_split, c_int), at%cx, at%cy, at%xfx, at%yfx, cm), 'tracer_2d_prep')   ! :362-400
+      end associate
+      if (i == 1) then
+        cmax = cm
+      else
+        cmax = max(cmax, cm)
+      end if
+    end do
+    if (fl%q_split == 0) then
+      if (nranks > 1) call fv3_check(fv3_allreduce_max(sp%ctxs(1), cmax, int(npz, c_int)), 'fv3_allreduce_max')   ! :405
+      if (npz /= 1) then                                                                   ! :407-412
+        c_global = maxval(cmax)
+      else
+        c_global = cmax(1)
+      end if
+      nsplt = int(1.d0 + c_global)
+    else
+      nsplt = fl%q_split
+    end if
+    if (nsplt /= 1) then                                                                   ! :421-456
+      do k = 1, npz
+        ksplt(k) = int(1.d0 + cmax(k), c_int)
+        frac(k) = 1.d0 / real(ksplt(k), c_double)
+      end do
+      do i = 1, sp%nf
+        associate (at => sp%f(i))
+          call fv3_check(fv3_tracer_2d_scale(at%ctx, frac, at%cx, at%xfx, at%mfx, at%cy, at%yfx, at%mfy), 'tracer_2d_scale')
+        end associate
+      end do
+    else
+      ksplt = 1
+    end if
+    if (fl%trdm2 > 1.d-4) call exchange(sp, 1, [FV3_CUBE_A + 0], [13], [0], [npz])         ! dp1_pack, :466
+    do it = 1, nsplt                                                                        ! :471-541
+      call exchange(sp, 1, [FV3_CUBE_A + 0], [12], [0], [npz * nq])                         ! q_pack, :474 / :536
+      do i = 1, sp%nf
+        associate (at => sp%f(i))
+          call fv3_check(fv3_tracer_2d_step(at%ctx, int(it, c_int), int(nsplt, c_int), ksplt, int(nq, c_int), &
+                                            int(fl%hord_tr, c_int), int(fl%nord_tr, c_int), fl%trdm2, at%q, at%q_n, &
+                                            at%dp1, at%dp1_n, at%mfx, at%mfy, at%cx, at%cy, at%xfx, at%yfx), 'tracer_2d_step')
+          call swap(at%q, at%q_n)
+          if (it /= nsplt) call swap(at%dp1, at%dp1_n)
+        end associate
+      end do
+    end do
+  end subroutine
+
+  !> one dt_atmos: the k_split loop of fv_dynamics (fv_dynamics.F90:460-665) on the faces of this rank.  pt holds theta_v;
+  !> last_step makes the final remap return T (fv_mapz.F90:793-821).
+  subroutine fv3_sphere_fv_dynamics(sp, bdt, last_step, nranks)
+    type(fv3_sphere), intent(inout) :: sp
+    real(c_double), intent(in) :: bdt
+    logical, intent(in) :: last_step
+    integer, intent(in) :: nranks
+    type(fv3_remap_params) :: rp
+    integer(c_int), allocatable :: kord_tr(:)
+    real(c_double) :: mdt
+    integer :: n_map, i, nq
+    type(fv3_flags) :: fl
+    fl = sp%f(1)%fl
+    nq = sp%f(1)%nq
+    mdt = bdt / real(fl%k_split, c_double)
+    allocate(kord_tr(max(1, nq))); kord_tr = int(fl%kord_tr, c_int)
+    rp%hydrostatic = merge(1_c_int, 0_c_int, fl%hydrostatic); rp%adiabatic = merge(1_c_int, 0_c_int, fl%adiabatic); rp%nq = int(nq, c_int)
+    rp%kord_mt = int(fl%kord_mt, c_int); rp%kord_wz = int(fl%kord_wz, c_int); rp%kord_tm = int(fl%kord_tm, c_int)
+    rp%sphum = merge(1_c_int, 0_c_int, nq > 0); rp%fill = merge(1_c_int, 0_c_int, fl%fill)
+    rp%akap = fl%akap; rp%ptop = fl%ptop; rp%rdgas = fl%rdgas; rp%grav = fl%grav
+    rp%cv_air = fl%cp_air - fl%rdgas; rp%r_vir = fl%r_vir; rp%cp = fl%cp_air; rp%t_min = fl%t_min
+    do n_map = 1, fl%k_split
+      do i = 1, sp%nf
+        associate (at => sp%f(i))
+          call fv3_check(fv3_memcpy_d2d(at%ctx, at%dp1, at%delp, at%nA * at%npz * 8_c_size_t), 'dp1 = delp')     ! :475-481
+        end associate
+      end do
+      call fv3_sphere_dyn_core(sp, mdt, n_map == fl%k_split)                                                      ! :493
+      if (nq > 0) call sphere_tracer_2d(sp, nranks)                                                                ! :500-533
+      rp%last_step = merge(1_c_int, 0_c_int, last_step .and. n_map == fl%k_split)
+      do i = 1, sp%nf
+        associate (at => sp%f(i))
+          if (fl%hydrostatic) then
+            call fv3_check(fv3_lagrangian_to_eulerian(at%ctx, rp, kord_tr, at%ps, at%pe, at%delp, at%pkz, at%pk, at%u, at%v, &
+                                                      c_null_ptr, c_null_ptr, at%pt, at%q, at%peln, at%omga, c_null_ptr), &
+                           'lagrangian_to_eulerian')
+          else
+            call fv3_check(fv3_lagrangian_to_eulerian(at%ctx, rp, kord_tr, at%ps, at%pe, at%delp, at%pkz, at%pk, at%u, at%v, &
+                                                      at%w, at%delz, at%pt, at%q, at%peln, at%omga, at%ws), &
+                           'lagrangian_to_eulerian')                                                               ! :607
+          end if
+        end associate
+      end do
+    end do
+  end subroutine
+
+  subroutine fv3_sphere_final(sp)
+    type(fv3_sphere), intent(inout) :: sp
+    integer :: i
+    do i = 1, sp%nf
+      call fv3_host_final(sp%f(i))
+    end do
+    sp%nf = 0
+  end subroutine
+
+end module fv3_sphere_mod

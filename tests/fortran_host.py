@@ -241,3 +241,120 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
         assert np.all(np.isfinite(a)), n
         assert np.array_equal(a, b), f"{n}: reference-signature fv_dynamics and the Python host differ (max abs {np.max(np.abs(a - b)):.3e})"
     return r.stdout
+
+
+def build_solo_sphere(workdir, libdir=CSRC, libname="fv3_mi355x"):
+    fc = fortran_compiler()
+    exe = os.path.join(str(workdir), "fv3_solo_sphere")
+    srcs = [os.path.join(FDIR, f) for f in ("fv3_mi355x_mod.F90", "fv3_host_mod.F90", "fv3_sphere_mod.F90", "fv3_solo_sphere.F90")]
+    subprocess.check_call([fc, "-O1", "-module-dir", str(workdir)] + srcs +
+                          ["-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+_GH_A = ["area", "rarea", "dxa", "dya", "rdxa", "rdya", "cosa_s", "rsin2", "f0"]
+_GH_U = ["dx", "rdx", "dyc", "rdyc", "cosa_v", "sina_v", "rsin_v", "divg_u", "del6_u"]
+_GH_V = ["dy", "rdy", "dxc", "rdxc", "cosa_u", "sina_u", "rsin_u", "divg_v", "del6_v"]
+_GH_B = ["rarea_c", "fC", "cosa", "sina"]
+
+
+def check_fortran_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2, nsteps=1, bdt=900.0, hydrostatic=False, d_con=0.0):
+    """the Jablonowski-Williamson state on the six faces through (a) the Python host (FvDynamics over MultiContext, device-gather halo
+    updates) and (b) the Fortran host (fv3_sphere_mod: one context per face, every halo update through the cube-edge exchange behind
+    the C ABI, mpp_get_boundary after the last substep, adv_pe): bit-identical states on every face"""
+    import cubed_common as CC
+    import parity_cubed as PC
+    from gfdl_atmos_cubed_sphere_amd import lib as L
+    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    cs, gs = CC.sphere(npx)
+    nx = npx - 1
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+    ak, bk = 300.0 * (1.0 - sig), sig.copy()
+    st = cs.jablonowski_williamson(ak, bk, hydrostatic=hydrostatic, rdgas=L.RDGAS, grav=L.GRAV)
+    CC.exchange(cs, st, ("phis",), "A")
+    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, ptop=float(ak[0]), d_con=d_con, **(dict(d_ext=0.0) if hydrostatic else {}))
+    bd = gs[0].bd
+    ng = bd.ng
+    c = (slice(ng, ng + nx), slice(ng, ng + nx))
+    for s_ in st:          # T -> theta (the host's job before dyn_core)
+        if hydrostatic:
+            pe = ak[0] + np.concatenate([np.zeros(s_["delp"].shape[:2] + (1,)), np.cumsum(s_["delp"], axis=2)], axis=2)[c]
+            peln = np.log(pe)
+            pkz = (pe[:, :, 1:] ** fl.akap - pe[:, :, :-1] ** fl.akap) / (fl.akap * (peln[:, :, 1:] - peln[:, :, :-1]))
+            s_["w"] = np.zeros_like(s_["delp"])
+            s_["delz"] = bd.zeros("CC", npz)
+        else:
+            pkz = ((-fl.rdgas / fl.grav) * s_["delp"][c] * s_["pt"][c] / s_["delz"]) ** fl.akap
+        s_["pt"][c] = s_["pt"][c] / pkz
+    q = PC.tracer_fields(cs, npz, nq) if nq else None
+    # ---- (a) Python host ----
+    mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
+    try:
+        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)))
+        fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], [s_["w"] for s_ in st], [s_["delp"] for s_ in st],
+                        [s_["pt"] for s_ in st], [s_["delz"] for s_ in st], [s_["phis"] for s_ in st])
+        if nq:
+            fv.set_tracers(q)
+        for _ in range(nsteps):
+            fv.step(bdt)
+        d = fv.dc.d
+        names = ("u", "v", "delp", "pt") if hydrostatic else ("u", "v", "w", "delp", "pt", "delz")
+        ref = {n: d[n].download() for n in names}
+        if nq:
+            ref["q"] = d["q"].download()
+    finally:
+        mctx.close()
+    # ---- (b) Fortran host ----
+    exe = build_solo_sphere(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
+    fin, fout = os.path.join(str(workdir), "sph_in.bin"), os.path.join(str(workdir), "sph_out.bin")
+    F = lambda a: np.asfortranarray(a, dtype=np.float64).ravel(order="F")      # noqa: E731
+    with open(fin, "wb") as f:
+        np.array([npx, npz, nq, n_split, k_split, nsteps, 0, int(hydrostatic), fl.nord], dtype=np.int32).tofile(f)
+        np.array([bdt, fl.ptop, d_con, fl.d_ext, gs[0].da_min, gs[0].da_min_c, fl.d4_bg], dtype=np.float64).tofile(f)
+        np.asarray(ak, dtype=np.float64).tofile(f)
+        np.asarray(bk, dtype=np.float64).tofile(f)
+        for t in range(6):
+            m = gs[t].m
+            for grp in (_GH_A, _GH_U, _GH_V, _GH_B):
+                for n in grp:
+                    F(m[n]).tofile(f)
+            F(m["sin_sg"]).tofile(f); F(m["cos_sg"]).tofile(f)
+            for n in ("edge_w", "edge_e", "edge_s", "edge_n"):
+                np.asarray(m[n], dtype=np.float64).tofile(f)
+            F(m["rsina"]).tofile(f)
+            np.asarray(m["corner_f"], dtype=np.float64).ravel().tofile(f)
+            for n in ("a11", "a12", "a21", "a22", "ec1", "ec2", "en1", "en2"):
+                F(m[n]).tofile(f)
+            for n in ("u", "v", "w", "delp", "pt", "delz", "phis"):
+                F(st[t][n]).tofile(f)
+            if nq:
+                F(q[t]).tofile(f)
+    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "fv3_cube_halo_start" in r.stdout, r.stdout
+    i0, i1, j0, j1 = bd.is_, bd.ie, bd.js, bd.je
+    rng_ = {"u": ("U", i0, i1, j0, j1 + 1), "v": ("V", i0, i1 + 1, j0, j1), "w": ("A", i0, i1, j0, j1),
+            "delp": ("A", i0, i1, j0, j1), "pt": ("A", i0, i1, j0, j1)}
+    with open(fout, "rb") as f:
+        for t in range(6):
+            got = {}
+            for n, kind in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC")):
+                shp = bd.shape(kind, npz)
+                got[n] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+            if nq:
+                shp = bd.shape("A", npz) + (nq,)
+                got["q"] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+            for n in ref:
+                if n in rng_:
+                    kind, *r4 = rng_[n]
+                    a, b = bd.view(got[n], kind, *r4), bd.view(ref[n][t], kind, *r4)
+                elif n == "q":
+                    a, b = got[n][c], ref[n][t][c]
+                else:
+                    a, b = got[n], ref[n][t]
+                assert np.all(np.isfinite(a)), (t, n)
+                assert np.array_equal(a, b), f"face {t + 1} {n}: Fortran host and Python host differ (max abs {np.max(np.abs(a - b)):.3e})"
+    return r.stdout

@@ -458,6 +458,17 @@ def test_fortran_host_drives_the_library(prod, tmp_path):
     assert "fv3_solo: done" in F.check_fortran_host(prod, tmp_path, npz=12, nq=0, hydrostatic=False, d_con=1.0)
 
 
+def test_fortran_host_on_the_cubed_sphere(prod, tmp_path):
+    """the Fortran host on grid_type = 0 (fv3_sphere_mod + fv3_solo_sphere): six contexts in one process, every cube-edge message of
+    dyn_core / tracer_2d as RCCL send / recv behind the C ABI (fv3_cube_halo_start / _complete), mpp_get_boundary, adv_pe: a C24
+    Jablonowski-Williamson fv_dynamics call bit-identical to the Python host's (device gathers) on every face"""
+    import fortran_host as F
+    if F.fortran_compiler() is None:
+        pytest.skip("no Fortran compiler in this image")
+    assert "fv3_solo_sphere: done" in F.check_fortran_sphere(prod, tmp_path, npx=25, npz=20, nq=2, hydrostatic=False)
+    assert "fv3_solo_sphere: done" in F.check_fortran_sphere(prod, tmp_path, npx=25, npz=20, nq=0, hydrostatic=True, d_con=1.0, k_split=1)
+
+
 def test_fortran_dyn_core_with_the_reference_argument_list(prod, tmp_path):
     """fv3_dyn_core_mod's dyn_core: the reference's argument list (model/dyn_core.F90:94-98: host arrays with the fv_arrays bounds,
     gridstruct / flagstruct / bd by their reference names) over the device-resident loop; both branches, with the heating"""

@@ -906,3 +906,15 @@ def test_sphere_step_through_the_cube_edge_exchange_of_the_c_abi(emu, hydrostati
     the state of the device-gather run, i.e. the six-face oracle's"""
     r = PC.check_jw_step(emu, npx=13, npz=20, k_split=1, n_split=2, bdt=900.0, hydrostatic=hydrostatic, nq=2, native_halo=True)
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12, r
+
+
+def test_fortran_host_on_the_cubed_sphere(emu, tmp_path):
+    """the Fortran host on grid_type = 0 (fortran/fv3_sphere_mod.F90 + fv3_solo_sphere.F90, built with amdflang): one
+    context per face, fv3_grid_upload_cubed, every halo update of dyn_core / tracer_2d through the cube-edge exchange behind the C ABI,
+    mpp_get_boundary and adv_pe after the last substep -- a C12 Jablonowski-Williamson fv_dynamics call bit-identical to the Python
+    host's on every face, nonhydrostatic with tracers and hydrostatic with the dissipative heating"""
+    import fortran_host as F
+    if F.fortran_compiler() is None:
+        pytest.skip("no amdflang in this environment")
+    assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=12, nq=2, hydrostatic=False)
+    assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=12, nq=0, hydrostatic=True, d_con=1.0, k_split=1)
