@@ -2570,8 +2570,19 @@ static int run_a2b(fv3_ctx *c, const A2BCorners<TI, TJ> &kf, int nlev_max) {
   return launch_p(c, "a2b_corners", grid, A2BCorners<TI, TJ>::lds_doubles, kf);
 }
 
+static int nh_p_grad_impl(fv3_ctx *c, double *u, double *v, const double *pp, const double *gz, double gz_scale, const double *delp,
+                          const double *pk, double dt, double top_value, double beta, double *du, double *dv);
 extern "C" int fv3_nh_p_grad(fv3_ctx *c, double *u, double *v, const double *pp, const double *gz, double gz_scale,
                              const double *delp, const double *pk, double dt, double top_value) {
+  return nh_p_grad_impl(c, u, v, pp, gz, gz_scale, delp, pk, dt, top_value, 0., nullptr, nullptr);
+}
+extern "C" int fv3_split_p_grad(fv3_ctx *c, double *u, double *v, const double *pp, const double *gz, double gz_scale,
+                                const double *delp, const double *pk, double beta, double dt, double top_value, double *du, double *dv) {
+  if (!du || !dv) return fail("fv3_split_p_grad: du, dv (U / V x npz, zero before the first call) are required");
+  return nh_p_grad_impl(c, u, v, pp, gz, gz_scale, delp, pk, dt, top_value, beta, du, dv);
+}
+static int nh_p_grad_impl(fv3_ctx *c, double *u, double *v, const double *pp, const double *gz, double gz_scale, const double *delp,
+                          const double *pk, double dt, double top_value, double beta, double *du, double *dv) {
   if (!c || !c->grid_ready) return fail("fv3_nh_p_grad: context has no grid");
   if (need_scratch(c, 4)) return 1;
   const Grid &g = c->g;
@@ -2593,6 +2604,7 @@ extern "C" int fv3_nh_p_grad(fv3_ctx *c, double *u, double *v, const double *pp,
   }
   {
     NhPGrad kf{g, dt, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], u, v};
+    kf.beta = beta; kf.du = du; kf.dv = dv;
     Dim3 grid;
     grid.x = (unsigned)(((g.nx + 1) * (g.ny + 1) + NhPGrad::CH - 1) / NhPGrad::CH);
     grid.y = 1;
@@ -2641,8 +2653,19 @@ extern "C" int fv3_divg2_ext(fv3_ctx *c, double d_ext, const double *delp, const
   return 0;
 }
 
+static int one_grad_p_impl(fv3_ctx *c, double *u, double *v, const double *pk, const double *gz, const double *divg2, double dt,
+                           double ptk, double beta, double *du, double *dv);
 extern "C" int fv3_one_grad_p(fv3_ctx *c, double *u, double *v, const double *pk, const double *gz, const double *divg2,
                               double dt, double ptk) {
+  return one_grad_p_impl(c, u, v, pk, gz, divg2, dt, ptk, 0., nullptr, nullptr);
+}
+extern "C" int fv3_grad1_p_update(fv3_ctx *c, const double *divg2, double *u, double *v, const double *pk, const double *gz, double dt,
+                                  double ptk, double beta, double *du, double *dv) {
+  if (!du || !dv) return fail("fv3_grad1_p_update: du, dv (U / V x npz, zero before the first call) are required");
+  return one_grad_p_impl(c, u, v, pk, gz, divg2, dt, ptk, beta, du, dv);
+}
+static int one_grad_p_impl(fv3_ctx *c, double *u, double *v, const double *pk, const double *gz, const double *divg2, double dt,
+                           double ptk, double beta, double *du, double *dv) {
   if (!c || !c->grid_ready) return fail("fv3_one_grad_p: context has no grid");
   if (!u || !v || !pk || !gz) return fail("fv3_one_grad_p: null field");
   if (need_scratch(c, 2)) return 1;
@@ -2664,6 +2687,7 @@ extern "C" int fv3_one_grad_p(fv3_ctx *c, double *u, double *v, const double *pk
   }
   {
     OneGradPHydro kf{g, dt, c->scratch[0], c->scratch[1], divg2, u, v};
+    kf.beta = beta; kf.du = du; kf.dv = dv;
     Dim3 grid;
     grid.x = (unsigned)(((g.nx + 1) * (g.ny + 1) + OneGradPHydro::CH - 1) / OneGradPHydro::CH);
     grid.y = 1;

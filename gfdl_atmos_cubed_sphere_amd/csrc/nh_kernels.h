@@ -727,11 +727,15 @@ struct A2BCorners {
   }
 };
 
-struct NhPGrad {  // nh_p_grad :1746-1790 on precomputed corner values
+struct NhPGrad {  // nh_p_grad :1746-1790 on precomputed corner values; with du / dv: split_p_grad :1795-1900 (beta > 0)
   Grid g;
   double dt;
   const double *pp, *pk, *gz, *dpc;  // corner slabs: pp, pk, gz (npz+1 levels), delp (npz levels)
   double *u, *v;
+  // split_p_grad: the hydrostatic part of the gradient of the previous substep (U / V x npz, zero before the first call:
+  // dyn_core.F90:278-283) enters with weight beta, the current one with 1 - beta, and is stored for the next substep
+  double beta = 0.;
+  double *du = nullptr, *dv = nullptr;
   static constexpr int CH = 1024;
   FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
     const int k = bz;
@@ -747,6 +751,14 @@ struct NhPGrad {  // nh_p_grad :1746-1790 on precomputed corner values
         const double wke = pk1[oe] - pk0[oe];
         const double du1 = dt / (wk0 + wke) * ((gz1[o] - gz0[oe]) * (pk1[oe] - pk0[o]) + (gz0[o] - gz1[oe]) * (pk1[o] - pk0[oe]));
         double *p = u + (size_t)k * g.nU() + g.iU(i, j);
+        if (du) {
+          double *q = du + (size_t)k * g.nU() + g.iU(i, j);
+          const double u0 = *p + beta * *q;                                         // :1866
+          *q = du1;
+          *p = (u0 + (1. - beta) * du1 +
+                dt / (w1[o] + w1[oe]) * ((gz1[o] - gz0[oe]) * (pp1[oe] - pp0[o]) + (gz0[o] - gz1[oe]) * (pp1[o] - pp0[oe]))) *
+               g.rdx[g.iU(i, j)];
+        } else
         *p = (*p + du1 +
               dt / (w1[o] + w1[oe]) * ((gz1[o] - gz0[oe]) * (pp1[oe] - pp0[o]) + (gz0[o] - gz1[oe]) * (pp1[o] - pp0[oe]))) *
              g.rdx[g.iU(i, j)];
@@ -755,6 +767,14 @@ struct NhPGrad {  // nh_p_grad :1746-1790 on precomputed corner values
         const double wkn = pk1[on] - pk0[on];
         const double dv1 = dt / (wk0 + wkn) * ((gz1[o] - gz0[on]) * (pk1[on] - pk0[o]) + (gz0[o] - gz1[on]) * (pk1[o] - pk0[on]));
         double *p = v + (size_t)k * g.nV() + g.iV(i, j);
+        if (dv) {
+          double *q = dv + (size_t)k * g.nV() + g.iV(i, j);
+          const double v0 = *p + beta * *q;                                         // :1885
+          *q = dv1;
+          *p = (v0 + (1. - beta) * dv1 +
+                dt / (w1[o] + w1[on]) * ((gz1[o] - gz0[on]) * (pp1[on] - pp0[o]) + (gz0[o] - gz1[on]) * (pp1[o] - pp0[on]))) *
+               g.rdy[g.iV(i, j)];
+        } else
         *p = (*p + dv1 +
               dt / (w1[o] + w1[on]) * ((gz1[o] - gz0[on]) * (pp1[on] - pp0[o]) + (gz0[o] - gz1[on]) * (pp1[o] - pp0[on]))) *
              g.rdy[g.iV(i, j)];
@@ -1126,12 +1146,14 @@ struct AdvPe {
   }
 };
 
-struct OneGradPHydro {  // dyn_core.F90:2002-2028 on precomputed corner values of pk, gz
+struct OneGradPHydro {  // dyn_core.F90:2002-2028 on precomputed corner values of pk, gz; with du / dv: grad1_p_update :2033-2116
   Grid g;
   double dt;
   const double *pk, *gz;   // corner slabs, npz+1 levels
   const double *divg2;     // null = no external-mode damping
   double *u, *v;
+  double beta = 0.;
+  double *du = nullptr, *dv = nullptr;
   static constexpr int CH = 1024;
   FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
     const int k = bz;
@@ -1146,6 +1168,14 @@ struct OneGradPHydro {  // dyn_core.F90:2002-2028 on precomputed corner values o
         const double wke = pk1[oe] - pk0[oe];
         const double wk2 = divg2 ? divg2[o] - divg2[oe] : 0.;
         double *p = u + (size_t)k * g.nU() + g.iU(i, j);
+        if (du) {
+          double *q = du + (size_t)k * g.nU() + g.iU(i, j);
+          const double u0 = *p + beta * *q;                                         // :2098
+          const double d1 = dt / (wk0 + wke) * ((gz1[o] - gz0[oe]) * (pk1[oe] - pk0[o]) + (gz0[o] - gz1[oe]) * (pk1[o] - pk0[oe]));
+          *q = d1;
+          const double ud = divg2 ? u0 + divg2[o] - divg2[oe] : u0;                 // :2102, left to right
+          *p = (ud + (1. - beta) * d1) * g.rdx[g.iU(i, j)];
+        } else
         *p = g.rdx[g.iU(i, j)] * (wk2 + *p + dt / (wk0 + wke) * ((gz1[o] - gz0[oe]) * (pk1[oe] - pk0[o]) +
                                                                 (gz0[o] - gz1[oe]) * (pk1[o] - pk0[oe])));
       }
@@ -1153,6 +1183,14 @@ struct OneGradPHydro {  // dyn_core.F90:2002-2028 on precomputed corner values o
         const double wkn = pk1[on] - pk0[on];
         const double wk1 = divg2 ? divg2[o] - divg2[on] : 0.;
         double *p = v + (size_t)k * g.nV() + g.iV(i, j);
+        if (dv) {
+          double *q = dv + (size_t)k * g.nV() + g.iV(i, j);
+          const double v0 = *p + beta * *q;                                         // :2107
+          const double d1 = dt / (wk0 + wkn) * ((gz1[o] - gz0[on]) * (pk1[on] - pk0[o]) + (gz0[o] - gz1[on]) * (pk1[o] - pk0[on]));
+          *q = d1;
+          const double vd = divg2 ? v0 + divg2[o] - divg2[on] : v0;                 // :2111
+          *p = (vd + (1. - beta) * d1) * g.rdy[g.iV(i, j)];
+        } else
         *p = g.rdy[g.iV(i, j)] * (wk1 + *p + dt / (wk0 + wkn) * ((gz1[o] - gz0[on]) * (pk1[on] - pk0[o]) +
                                                                 (gz0[o] - gz1[on]) * (pk1[o] - pk0[on])));
       }

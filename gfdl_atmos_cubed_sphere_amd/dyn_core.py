@@ -7,8 +7,7 @@ each step).  All fields are device resident (``lib.DeviceArray``); fields that `
 after the call -- the halo update that follows in the reference fills the new buffer's halo.
 
 Not reproduced (off in every BASELINE config): nesting / regional BCs, ``breed_vortex_inline``,
-``do_fast_phys``, ``Ray_fast``, ``beta > 0`` (split_p_grad), ``use_old_omega`` omega diagnostics,
-``d_ext`` (hydrostatic one_grad_p only).
+``do_fast_phys``, ``Ray_fast``, ``beta < -0.1`` (one_grad_p in the nonhydrostatic loop).
 """
 from __future__ import annotations
 
@@ -38,6 +37,7 @@ class DynFlags:
     use_cond: bool = False     # thermostruct%use_cond: q_con is transported by d_sw and enters the Riemann solvers' pm2
     moist_kappa: bool = False  # thermostruct%moist_kappa: per-cell cappa in the Riemann solvers (and the remap)
     d_ext: float = 0.02      # external-mode damping (hydrostatic one_grad_p only), fv_arrays.F90:452
+    beta: float = 0.0        # > 0: split_p_grad / grad1_p_update (time-off-centred hydrostatic pressure gradient), fv_arrays.F90:403
     convert_ke: bool = False
     ke_bg: float = 0.0
     hord_mt: int = 10
@@ -135,6 +135,10 @@ class DynCore:
             d["q_con"], d["q_con_nxt"] = z("A", npz), z("A", npz)
         if flags.moist_kappa:
             d["cappa"] = z("A", npz)
+        if flags.beta < 0.0:
+            raise ValueError("beta < 0 (one_grad_p in the nonhydrostatic loop, dyn_core.F90:1029) is not part of this build")
+        if flags.beta > 1.0e-9:   # dyn_core.F90:278-283: allocated and zeroed once, kept between calls
+            d["du"], d["dv"] = z("U", npz), z("V", npz)
         self.lev = level_coefficients(npz, flags)
         ctx.dsw_levels(self.lev)
         ctx.set_dp_ref(dp_ref)
@@ -210,7 +214,11 @@ class DynCore:
                       d["pkz"], False)                                        # :905-907
             if remap_step:
                 ctx.copy_a_to_cc(d["pkc"], d["pk"])                           # pk = pkc, :1001-1010
-            ctx.one_grad_p(d["u"], d["v"], d["pkc"], d["gz"], d["divg2"] if fl.d_ext > 0.0 else None, dt, ptk)  # :1021
+            if fl.beta > 0.0:   # :1018-1019, beta_d = 0 in the first substep (:398-406)
+                ctx.grad1_p_update(d["divg2"] if fl.d_ext > 0.0 else None, d["u"], d["v"], d["pkc"], d["gz"], dt, ptk,
+                                   0.0 if it == 1 else fl.beta, d["du"], d["dv"])
+            else:
+                ctx.one_grad_p(d["u"], d["v"], d["pkc"], d["gz"], d["divg2"] if fl.d_ext > 0.0 else None, dt, ptk)  # :1021
             if it != n_split:
                 halo.update([(d["u"], "U"), (d["v"], "V")])
             elif hasattr(halo, "sync_edges"):
@@ -310,8 +318,12 @@ class DynCore:
                 halo.post(pend2)
                 halo.finish(pend2)
             # :982-989 gz = zh*grav is fused into nh_p_grad (gz_scale)
-            ctx.nh_p_grad(d["u"], d["v"], d["pkc"], d["zh"], d["delp"], d["pk3"], dt,
-                          peln1 if fl.use_logp else ptk, gz_scale=fl.grav)    # :1032
+            if fl.beta > 0.0:   # :1027-1028, beta_d = 0 in the first substep (:398-406)
+                ctx.split_p_grad(d["u"], d["v"], d["pkc"], d["zh"], d["delp"], d["pk3"], 0.0 if it == 1 else fl.beta, dt,
+                                 peln1 if fl.use_logp else ptk, d["du"], d["dv"], gz_scale=fl.grav)
+            else:
+                ctx.nh_p_grad(d["u"], d["v"], d["pkc"], d["zh"], d["delp"], d["pk3"], dt,
+                              peln1 if fl.use_logp else ptk, gz_scale=fl.grav)    # :1032
             if it != n_split:
                 halo.update([(d["u"], "U"), (d["v"], "V")])                   # :1168-1169 (pack 8)
             else:

@@ -158,7 +158,7 @@ contains
     if (thermostruct%use_cond .or. thermostruct%moist_kappa) &
       error stop 'dyn_core (fv3_dyn_core_mod): use_cond / moist_kappa are not carried through this wrapper'
     if (flagstruct%do_diss_est) error stop 'dyn_core (fv3_dyn_core_mod): do_diss_est is not carried through this wrapper'
-    if (flagstruct%beta > 0.d0) error stop 'dyn_core (fv3_dyn_core_mod): beta > 0 (split_p_grad) is not built'
+    if (flagstruct%beta < 0.d0) error stop 'dyn_core (fv3_dyn_core_mod): beta < 0 (one_grad_p in the nonhydrostatic loop) is not built'
     if (ng /= 3 .or. bd%ng /= 3) error stop 'dyn_core (fv3_dyn_core_mod): ng = 3'
     if (.not. bound) call bind_context()
     if (at%npz /= npz .or. at%is /= bd%is .or. at%ie /= bd%ie .or. at%js /= bd%js .or. at%je /= bd%je) &
@@ -264,6 +264,7 @@ contains
       ! rdgas: constants_mod's, as in the reference (fv3_flags carries it as its default)
       fl%adiabatic = flagstruct%adiabatic; fl%fill = flagstruct%fill
       fl%hydrostatic = hydrostatic;       fl%d_ext = flagstruct%d_ext;       fl%delt_max = flagstruct%delt_max
+      fl%beta = flagstruct%beta           ! du / dv live in the bound fv3_atmos between calls, like dyn_core's saved arrays (:278-283)
       fl%convert_ke = flagstruct%convert_ke
       call fv3_host_init_grid(at, dom, gh, 0, fl, ak, bk)
       bound = .true.
@@ -326,8 +327,8 @@ contains
       error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond / moist_kappa are not carried through this wrapper'
     if (abs(consv_te) > 0.001d0) error stop 'fv_dynamics (fv3_dyn_core_mod): consv_te is carried by the Python host (FvDynamics), not here'
     if (flagstruct%tau > 0.d0) error stop 'fv_dynamics (fv3_dyn_core_mod): tau > 0 (Rayleigh damping) is carried by the Python host, not here'
-    if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%do_diss_est .or. flagstruct%beta > 0.d0) &
-      error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / do_diss_est / beta > 0 are not built'
+    if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%do_diss_est .or. flagstruct%beta < 0.d0) &
+      error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / do_diss_est / beta < 0 are not built'
     if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
     if (.not. boundf) call bind_context()
     if (atf%npz /= npz .or. atf%nq /= nq_tot .or. atf%ie /= bd%ie .or. atf%je /= bd%je) &
@@ -464,6 +465,7 @@ contains
     fl%a_imp = flagstruct%a_imp;        fl%p_fac = flagstruct%p_fac
     fl%adiabatic = flagstruct%adiabatic; fl%fill = flagstruct%fill
     fl%d_ext = flagstruct%d_ext;        fl%delt_max = flagstruct%delt_max
+    fl%beta = flagstruct%beta
     fl%convert_ke = flagstruct%convert_ke
   end subroutine
 

@@ -10,7 +10,7 @@
 !> several-rank run uses with the neighbour ranks in to / from (see INTEGRATION.md).
 !>
 !> Not reproduced (off in every BASELINE config): nesting / regional BCs, breed_vortex_inline, do_fast_phys, Ray_fast,
-!> beta > 0 (split_p_grad).  The argument lists are this module's own (type fv3_atmos holds the device handles the
+!> beta < 0 (one_grad_p in the nonhydrostatic loop).  The argument lists are this module's own (type fv3_atmos holds the device handles the
 !> reference keeps in fv_atmos_type / dyn_core's work arrays); INTEGRATION.md maps them to the reference's call sites,
 !> and fv3_dyn_core_mod.F90 puts dyn_core's own argument list (host arrays, gridstruct, flagstruct, bd) in front of
 !> fv3_dyn_core for callers that keep their state on the host.
@@ -46,6 +46,7 @@ module fv3_host_mod
     logical :: adiabatic = .true., fill = .false.
     logical :: hydrostatic = .false.                  ! fv_arrays.F90:366
     real(c_double) :: d_ext = 0.02d0, delt_max = 1.d0 ! :452, :441
+    real(c_double) :: beta = 0.d0                     ! :403; > 0: split_p_grad / grad1_p_update
     logical :: convert_ke = .false.
   end type
 
@@ -64,6 +65,7 @@ module fv3_host_mod
     type(c_ptr) :: delpc, ptc, uc, vc, ua, va, omga, ut, vt, divgd, gz, pkc, zh, zh_n, pk3
     type(c_ptr) :: crx, xfx, cry, yfx, mfx, mfy, cx, cy, heat_s, diss_e, pk, ws3, ws, pe, peln, ps, pkz
     type(c_ptr) :: divg2, heat_source                 ! external-mode damping field (A), accumulated heat source (A x npz)
+    type(c_ptr) :: du = c_null_ptr, dv = c_null_ptr   ! beta > 0: the saved hydrostatic pressure gradient (dyn_core.F90:278-283)
     real(c_double), allocatable :: ak(:), bk(:)
   end type
 
@@ -238,6 +240,11 @@ contains
     call dmalloc(at%divg2, at%nA);    call dmalloc(at%heat_source, at%nA*nk)
     call dzero(at, at%divg2, at%nA);  call dzero(at, at%heat_source, at%nA*nk); call dzero(at, at%pkz, at%nCC*nk)
     call dmalloc(at%dp1, at%nA*nk);   call dmalloc(at%dp1_n, at%nA*nk)
+    if (fl%beta < 0.d0) error stop 'fv3_host_mod: beta < 0 (one_grad_p in the nonhydrostatic loop) is not built'
+    if (fl%beta > 1.d-9) then
+      call dmalloc(at%du, at%nU*nk); call dmalloc(at%dv, at%nV*nk)
+      call dzero(at, at%du, at%nU*nk); call dzero(at, at%dv, at%nV*nk)
+    end if
     at%q = c_null_ptr; at%q_n = c_null_ptr
     if (nq > 0) then
       call dmalloc(at%q, at%nA*nk*nq); call dmalloc(at%q_n, at%nA*nk*nq)
@@ -445,7 +452,12 @@ contains
       if (remap_step) call fv3_check(fv3_pe_halo(ctx, at%fl%ptop, at%pe, at%delp), 'pe_halo')   ! :952-953
       call fv3_check(fv3_pk3_halo(ctx, at%fl%ptop, at%fl%akap, at%pk3, at%delp, use_logp), 'pk3_halo')   ! :955-959
       ! :982-989 gz = zh*grav is fused into nh_p_grad (gz_scale)
-      call fv3_check(fv3_nh_p_grad(ctx, at%u, at%v, at%pkc, at%zh, at%fl%grav, at%delp, at%pk3, dt, top), 'nh_p_grad')  ! :1032
+      if (at%fl%beta > 0.d0) then     ! :1027-1028; beta_d = 0 in the first substep (:398-406)
+        call fv3_check(fv3_split_p_grad(ctx, at%u, at%v, at%pkc, at%zh, at%fl%grav, at%delp, at%pk3, merge(0.d0, at%fl%beta, it == 1), &
+                                        dt, top, at%du, at%dv), 'split_p_grad')
+      else
+        call fv3_check(fv3_nh_p_grad(ctx, at%u, at%v, at%pkc, at%zh, at%fl%grav, at%delp, at%pk3, dt, top), 'nh_p_grad')  ! :1032
+      end if
       if (it /= n_split) then
         call halo(at, at%u, KIND_U, npz); call halo(at, at%v, KIND_V, npz)                ! :1168-1169 (pack 8)
       else if (at%fl%use_old_omega) then
@@ -480,7 +492,7 @@ contains
     end if
   end function
 
-  !> the substep loop with hydrostatic = .true., beta = 0 (dyn_core.F90:313-1286): geopk on the C and D grids (:480-482,
+  !> the substep loop with hydrostatic = .true., (dyn_core.F90:313-1286): geopk on the C and D grids (:480-482,
   !> :905-907), p_grad_c (:562), the external-mode damping field (:745-747, :791-848), pk = pkc on the last substep
   !> (:1001-1010), one_grad_p (:1021); the heating of pt afterwards with the hydrostatic pkz
   subroutine fv3_dyn_core_hydrostatic(at, bdt)
@@ -526,7 +538,12 @@ contains
       call fv3_check(fv3_geopk(ctx, at%fl%ptop, at%fl%akap, at%fl%cp_air, ptk, at%pe, at%peln, at%delp, at%pkc, at%gz, &
                                at%phis, at%pt, at%pkz, 0_c_int), 'geopk')
       if (it == n_split) call fv3_check(fv3_copy_a_to_cc(ctx, at%pkc, at%pk, int(npz + 1, c_int)), 'pk = pkc')
-      call fv3_check(fv3_one_grad_p(ctx, at%u, at%v, at%pkc, at%gz, dv2, dt, ptk), 'one_grad_p')
+      if (at%fl%beta > 0.d0) then     ! :1018-1019
+        call fv3_check(fv3_grad1_p_update(ctx, dv2, at%u, at%v, at%pkc, at%gz, dt, ptk, merge(0.d0, at%fl%beta, it == 1), &
+                                          at%du, at%dv), 'grad1_p_update')
+      else
+        call fv3_check(fv3_one_grad_p(ctx, at%u, at%v, at%pkc, at%gz, dv2, dt, ptk), 'one_grad_p')
+      end if
       if (it /= n_split) then
         call halo(at, at%u, KIND_U, npz); call halo(at, at%v, KIND_V, npz)
       end if

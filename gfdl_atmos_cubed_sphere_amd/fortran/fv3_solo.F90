@@ -3,7 +3,7 @@
 !> the state back.  usage: fv3_solo <input file> <output file>   (both raw little-endian streams, see below)
 !>
 !> input : int32  nx, ny, npz, nq, n_split, k_split, nsteps, last_step, hydrostatic
-!>         real64 dx, dy, f0, bdt, ptop, d_con, d_ext ; ak(npz+1), bk(npz+1)
+!>         real64 dx, dy, f0, bdt, ptop, d_con, d_ext, beta ; ak(npz+1), bk(npz+1)
 !>         real64 u(isd:ied,jsd:jed+1,npz) v(isd:ied+1,jsd:jed,npz) w delp pt (isd:ied,jsd:jed,npz) delz(is:ie,js:je,npz)
 !>                phis(isd:ied,jsd:jed) q(isd:ied,jsd:jed,npz,nq)
 !> output: real64 u, v, w, delp, pt, delz, q in the same shapes
@@ -14,7 +14,7 @@ program fv3_solo
   implicit none
   character(len=1024) :: fin, fout
   integer(c_int) :: nx, ny, npz, nq, n_split, k_split, nsteps, last_step, hydrostatic
-  real(c_double) :: dx, dy, f0, bdt, ptop, d_con, d_ext
+  real(c_double) :: dx, dy, f0, bdt, ptop, d_con, d_ext, beta
   real(c_double), allocatable :: ak(:), bk(:), u(:,:,:), v(:,:,:), w(:,:,:), delp(:,:,:), pt(:,:,:), delz(:,:,:), phis(:,:)
   real(c_double), allocatable :: q(:,:,:,:)
   type(fv3_flags) :: fl
@@ -25,7 +25,7 @@ program fv3_solo
   call get_command_argument(2, fout)
   open(newunit=un, file=trim(fin), access='stream', form='unformatted', status='old')
   read(un) nx, ny, npz, nq, n_split, k_split, nsteps, last_step, hydrostatic
-  read(un) dx, dy, f0, bdt, ptop, d_con, d_ext
+  read(un) dx, dy, f0, bdt, ptop, d_con, d_ext, beta
   allocate(ak(npz+1), bk(npz+1))
   read(un) ak, bk
   isd = 1 - 3; ied = nx + 3; jsd = 1 - 3; jed = ny + 3
@@ -36,7 +36,7 @@ program fv3_solo
   close(un)
 
   fl%n_split = n_split; fl%k_split = k_split; fl%ptop = ptop
-  fl%hydrostatic = hydrostatic /= 0; fl%d_con = d_con; fl%d_ext = d_ext
+  fl%hydrostatic = hydrostatic /= 0; fl%d_con = d_con; fl%d_ext = d_ext; fl%beta = beta
   call fv3_host_init(at, int(nx), int(ny), int(npz), int(nq), dx, dy, f0, fl, ak, bk)
   write(*,'(a,i0)') 'fv3_solo: gridstruct geometry mode ', fv3_grid_geom(at%ctx)
   if (nq > 0) then

@@ -16,7 +16,7 @@ program fv3_solo_refsig
   real(c_double), allocatable :: ps(:,:), u0(:,:,:), v0(:,:,:), ze0(:,:,:)
   logical :: whole
   integer(c_int) :: nx, ny, npz, nq, n_split, k_split, nsteps, last_step, ihydro
-  real(c_double) :: dxc_, dyc_, f0_, bdt, ptop, d_con, d_ext
+  real(c_double) :: dxc_, dyc_, f0_, bdt, ptop, d_con, d_ext, beta
   real(c_double), allocatable :: ak(:), bk(:), pfull(:)
   real(c_double), allocatable, dimension(:,:,:) :: u, v, w, delp, pt, delz, cappa, q_con, heat_source, diss_est, pe, peln, pk, &
                                                    omga, uc, vc, ua, va, mfx, mfy, cx, cy, pkz
@@ -40,7 +40,7 @@ program fv3_solo_refsig
   whole = trim(mode) == 'fv_dynamics'
   open(newunit=un, file=trim(fin), access='stream', form='unformatted', status='old')
   read(un) nx, ny, npz, nq, n_split, k_split, nsteps, last_step, ihydro
-  read(un) dxc_, dyc_, f0_, bdt, ptop, d_con, d_ext
+  read(un) dxc_, dyc_, f0_, bdt, ptop, d_con, d_ext, beta
   allocate(ak(npz+1), bk(npz+1), pfull(npz))
   read(un) ak, bk
   hydrostatic = ihydro /= 0
@@ -97,7 +97,7 @@ program fv3_solo_refsig
 
   ! ---- flagstruct: the namelist the other hosts of the test-suite run (dyn_core.DynFlags / fv3_flags defaults) ----
   fs%grid_type = 4; fs%n_split = n_split; fs%k_split = k_split; fs%hydrostatic = hydrostatic
-  fs%d2_bg_k1 = 0.20d0; fs%d2_bg_k2 = 0.015d0; fs%a_imp = 1.d0; fs%d_con = d_con; fs%d_ext = d_ext
+  fs%d2_bg_k1 = 0.20d0; fs%d2_bg_k2 = 0.015d0; fs%a_imp = 1.d0; fs%d_con = d_con; fs%d_ext = d_ext; fs%beta = beta
   fs%prevent_diss_cooling = .true.; fs%adiabatic = .true.
 
   if (whole) then

@@ -3,7 +3,7 @@
 !> usage: fv3_solo_sphere <input file> <output file>   (raw little-endian streams)
 !>
 !> input : int32  npx, npz, nq, n_split, k_split, nsteps, last_step, hydrostatic, nord
-!>         real64 bdt, ptop, d_con, d_ext, da_min, da_min_c, d4_bg ; ak(npz+1), bk(npz+1)
+!>         real64 bdt, ptop, d_con, d_ext, da_min, da_min_c, d4_bg, beta ; ak(npz+1), bk(npz+1)
 !>         per face (six times): the gridstruct members in the order of fv3_grid_host (A-, U-, V-, B-layout arrays with halo, sin_sg and
 !>         cos_sg with 9 planes), then of fv3_grid_cubed: edge_w, edge_e, edge_s, edge_n (npx each), rsina (npx x npx), corner_f(12),
 !>         a11, a12, a21, a22 (A), ec1, ec2 (A x 3), en1 ((npx-1) x npx x 3), en2 (npx x (npx-1) x 3);
@@ -17,7 +17,7 @@ program fv3_solo_sphere
   implicit none
   character(len=1024) :: fin, fout
   integer(c_int) :: npx, npz, nq, n_split, k_split, nsteps, last_step, hydrostatic, nord
-  real(c_double) :: bdt, ptop, d_con, d_ext, da_min, da_min_c, d4_bg
+  real(c_double) :: bdt, ptop, d_con, d_ext, da_min, da_min_c, d4_bg, beta
   real(c_double), allocatable :: ak(:), bk(:)
   type gmet
     real(c_double), allocatable :: a(:,:,:), u(:,:,:), v(:,:,:), b(:,:,:), sg(:,:,:), cg(:,:,:)
@@ -40,7 +40,7 @@ program fv3_solo_sphere
   call get_command_argument(2, fout)
   open(newunit=un, file=trim(fin), access='stream', form='unformatted', status='old')
   read(un) npx, npz, nq, n_split, k_split, nsteps, last_step, hydrostatic, nord
-  read(un) bdt, ptop, d_con, d_ext, da_min, da_min_c, d4_bg
+  read(un) bdt, ptop, d_con, d_ext, da_min, da_min_c, d4_bg, beta
   allocate(ak(npz+1), bk(npz+1))
   read(un) ak, bk
   nx = npx - 1; isd = 1 - 3; ied = nx + 3
@@ -60,7 +60,7 @@ program fv3_solo_sphere
   close(un)
 
   fl%n_split = n_split; fl%k_split = k_split; fl%ptop = ptop; fl%nord = nord; fl%d4_bg = d4_bg
-  fl%hydrostatic = hydrostatic /= 0; fl%d_con = d_con; fl%d_ext = d_ext
+  fl%hydrostatic = hydrostatic /= 0; fl%d_con = d_con; fl%d_ext = d_ext; fl%beta = beta
   dom%is = 1; dom%ie = nx; dom%js = 1; dom%je = nx; dom%ng = 3; dom%npx = npx; dom%npy = npx; dom%npz = npz; dom%grid_type = 0
   dom%do_diss_est = 0; dom%prevent_diss_cooling = 1; dom%stretched_grid = 0; dom%lim_fac = 1.d0
   do t = 1, 6

@@ -219,7 +219,12 @@ contains
             call fv3_check(fv3_geopk(at%ctx, fl%ptop, fl%akap, fl%cp_air, ptk, at%pe, at%peln, at%delp, at%pkc, at%gz, &
                                      at%phis, at%pt, at%pkz, 0_c_int), 'geopk')            ! :905-907
             if (remap_step) call fv3_check(fv3_copy_a_to_cc(at%ctx, at%pkc, at%pk, int(npz + 1, c_int)), 'pk = pkc')   ! :1001-1010
-            call fv3_check(fv3_one_grad_p(at%ctx, at%u, at%v, at%pkc, at%gz, dv2, dt, ptk), 'one_grad_p')        ! :1021
+            if (fl%beta > 0.d0) then                                                         ! :1018-1019, beta_d :398-406
+              call fv3_check(fv3_grad1_p_update(at%ctx, dv2, at%u, at%v, at%pkc, at%gz, dt, ptk, merge(0.d0, fl%beta, it == 1), &
+                                                at%du, at%dv), 'grad1_p_update')
+            else
+              call fv3_check(fv3_one_grad_p(at%ctx, at%u, at%v, at%pkc, at%gz, dv2, dt, ptk), 'one_grad_p')      ! :1021
+            end if
           end associate
         end do
       else
@@ -237,7 +242,12 @@ contains
           associate (at => sp%f(i))
             if (remap_step) call fv3_check(fv3_pe_halo(at%ctx, fl%ptop, at%pe, at%delp), 'pe_halo')            ! :952-953
             call fv3_check(fv3_pk3_halo(at%ctx, fl%ptop, fl%akap, at%pk3, at%delp, use_logp), 'pk3_halo')      ! :955-959
-            call fv3_check(fv3_nh_p_grad(at%ctx, at%u, at%v, at%pkc, at%zh, fl%grav, at%delp, at%pk3, dt, top), 'nh_p_grad')  ! :1032
+            if (fl%beta > 0.d0) then                                                         ! :1027-1028
+              call fv3_check(fv3_split_p_grad(at%ctx, at%u, at%v, at%pkc, at%zh, fl%grav, at%delp, at%pk3, &
+                                              merge(0.d0, fl%beta, it == 1), dt, top, at%du, at%dv), 'split_p_grad')
+            else
+              call fv3_check(fv3_nh_p_grad(at%ctx, at%u, at%v, at%pkc, at%zh, fl%grav, at%delp, at%pk3, dt, top), 'nh_p_grad')  ! :1032
+            end if
           end associate
         end do
       end if

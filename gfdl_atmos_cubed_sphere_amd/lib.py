@@ -35,7 +35,7 @@ EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
            "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_compute_total_energy", "fv3_energy_fixer_sums", "fv3_remap_finish", "fv3_ordered_sum", "fv3_adv_pe", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max", "fv3_cube_table", "fv3_cube_halo_start", "fv3_cube_halo_complete",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_set_fast", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
-           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
+           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_split_p_grad", "fv3_grad1_p_update", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
 
 
@@ -590,6 +590,17 @@ class Context:
     # ---- hydrostatic pressure gradient (dyn_core.F90:828-848, :1021, :1001-1010) ------------------------------------
     def divg2_ext(self, d_ext, delp, vt, divg2):
         self.lib.check(self.lib.dll.fv3_divg2_ext(self.h, C.c_double(d_ext), delp.p, vt.p, divg2.p), "fv3_divg2_ext")
+
+    def split_p_grad(self, u, v, pp, gz, delp, pk, beta, dt, top_value, du, dv, gz_scale=1.0):
+        """model/dyn_core.F90:1795 split_p_grad (beta: the caller's beta_d; du, dv: U / V x npz, zero before the first call)"""
+        self.lib.check(self.lib.dll.fv3_split_p_grad(self.h, u.p, v.p, pp.p, gz.p, C.c_double(gz_scale), delp.p, pk.p, C.c_double(beta),
+                                                     C.c_double(dt), C.c_double(top_value), du.p, dv.p), "fv3_split_p_grad")
+
+    def grad1_p_update(self, divg2, u, v, pk, gz, dt, ptk, beta, du, dv):
+        """model/dyn_core.F90:2033 grad1_p_update (divg2 None: zeros)"""
+        self.lib.check(self.lib.dll.fv3_grad1_p_update(self.h, divg2.p if divg2 is not None else None, u.p, v.p, pk.p, gz.p,
+                                                       C.c_double(dt), C.c_double(ptk), C.c_double(beta), du.p, dv.p),
+                       "fv3_grad1_p_update")
 
     def one_grad_p(self, u, v, pk, gz, divg2, dt, ptk):
         self.lib.check(self.lib.dll.fv3_one_grad_p(self.h, u.p, v.p, pk.p, gz.p, divg2.p if divg2 is not None else None,

@@ -310,6 +310,12 @@ int fv3_p_grad_c(fv3_ctx *ctx, double dt2, const double *delpc, const double *pk
 int fv3_nh_p_grad(fv3_ctx *ctx, double *u, double *v, const double *pp, const double *gz, double gz_scale,
                   const double *delp, const double *pk, double dt, double top_value);
 
+/* split_p_grad -- model/dyn_core.F90:1795-1900, call site :1028 (beta > 0: the hydrostatic part of the pressure gradient split
+ * between two substeps).  Arguments of fv3_nh_p_grad plus beta (the caller's beta_d: 0 in the first substep, :398-406) and du, dv
+ * (U / V x npz, device, the caller's: zero before the first call as dyn_core.F90:278-283 allocates them; updated in place). */
+int fv3_split_p_grad(fv3_ctx *ctx, double *u, double *v, const double *pp, const double *gz, double gz_scale, const double *delp,
+                     const double *pk, double beta, double dt, double top_value, double *du, double *dv);
+
 /* omega of the last acoustic substep, local part (model/dyn_core.F90:409-421, :1182-1191, use_old_omega):
  * omga(i,j,k) = (pe(i,k+1,j) - pem(i,k+1,j)) * rdt with pem = ptop + cumulative sum of the delp the substep started
  * from (pass the pre-d_sw buffer as delp_before).  The advective term adv_pe (:1195, :1529-1630) projects on the unit
@@ -334,6 +340,11 @@ int fv3_adv_pe(fv3_ctx *ctx, double ptop, const double *ua, const double *va, co
 int fv3_divg2_ext(fv3_ctx *ctx, double d_ext, const double *delp, const double *vt, double *divg2);
 int fv3_one_grad_p(fv3_ctx *ctx, double *u, double *v, const double *pk, const double *gz, const double *divg2,
                    double dt, double ptk);
+
+/* grad1_p_update -- model/dyn_core.F90:2033-2116, call site :1019 (hydrostatic, beta > 0).  divg2: A (fv3_divg2_ext; zeros when
+ * d_ext = 0), du, dv as for fv3_split_p_grad. */
+int fv3_grad1_p_update(fv3_ctx *ctx, const double *divg2, double *u, double *v, const double *pk, const double *gz, double dt,
+                       double ptk, double beta, double *du, double *dv);
 int fv3_copy_a_to_cc(fv3_ctx *ctx, const double *src, double *dst, int nk);
 
 /* zh(npz+1) = zs; zh(k) = zh(k+1) - delz(k) on the compute domain -- model/dyn_core.F90:370-385 (it == 1). */

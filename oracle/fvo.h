@@ -186,6 +186,10 @@ int fvo_pe_halo(const fvo_grid *g, int npz, double ptop, double *pe, const doubl
 int fvo_divg2_ext(const fvo_grid *g, int npz, double d_ext, const double *delp, const double *vt, double *divg2);
 int fvo_one_grad_p_hydro(const fvo_grid *g, int npz, double dt, double ptk, const double *divg2, double *u, double *v,
                          double *pk, double *gz);
+int fvo_split_p_grad(const fvo_grid *g, int npz, double *u, double *v, double *pp, double *gz, double *delp, double *pk, double beta,
+                     double dt, double top_value, double *du, double *dv);
+int fvo_grad1_p_update(const fvo_grid *g, int npz, const double *divg2, double *u, double *v, double *pk, double *gz, double dt,
+                       double ptk, double beta, double *du, double *dv);
 int fvo_del2_cubed(const fvo_grid *g, int km, double cd, int nmax, double *q);
 int fvo_apply_heat_source(const fvo_grid *g, int npz, int n_con, int hydrostatic, double bdt, double delt_max,
                           double cp_air, double cv_air, double rdgas, double grav, double *pt, double *heat_source,

@@ -909,3 +909,116 @@ int fvo_adv_pe(const fvo_grid *g, int km, double ptop, const double *ua, const d
   free(pin); free(pb); free(pemc);
   return FVO_OK;
 }
+
+
+/* split_p_grad (model/dyn_core.F90:1795-1900): nh_p_grad with the hydrostatic part split between two substeps.  du (U x npz), dv
+ * (V x npz): dyn_core's saved arrays (zero before the first call, :278-283) */
+int fvo_split_p_grad(const fvo_grid *g, int npz, double *u, double *v, double *pp, double *gz, double *delp, double *pk, double beta,
+                     double dt, double top_value, double *du, double *dv) {
+  BOUNDS(g);
+  int k;
+  const size_t nA = (size_t)nid * njd, nV = (size_t)(nid + 1) * njd, nU = (size_t)nid * (njd + 1);
+  const double alpha = 1. - beta;
+#pragma omp parallel for schedule(dynamic)
+  for (k = 1; k <= npz + 1; k++) {
+    int i, j;
+    double *wk1 = dalloc(nA);
+    if (k == 1) {
+      for (j = js; j <= je + 1; j++)
+        for (i = is; i <= ie + 1; i++) {
+          pp[A3(i, j, 1)] = 0.;
+          pk[A3(i, j, 1)] = top_value;
+        }
+    } else {
+      fvo_a2b_ord4(g, pp + nA * (k - 1), wk1, 1);
+      fvo_a2b_ord4(g, pk + nA * (k - 1), wk1, 1);
+    }
+    fvo_a2b_ord4(g, gz + nA * (k - 1), wk1, 1);
+    free(wk1);
+  }
+#pragma omp parallel for schedule(dynamic)
+  for (k = 1; k <= npz; k++) {
+    int i, j;
+    double *wk1 = dalloc(nA), *wk = dalloc(nA);
+    fvo_a2b_ord4(g, delp + nA * (k - 1), wk1, 0);
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie + 1; i++) wk[IA(i, j)] = pk[A3(i, j, k + 1)] - pk[A3(i, j, k)];
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie; i++) {
+        double *uu = &u[nU * (k - 1) + IU(i, j)], *dd = &du[nU * (k - 1) + IU(i, j)];
+        *uu = *uu + beta * *dd;
+        *dd = dt / (wk[IA(i, j)] + wk[IA(i + 1, j)]) *
+              ((gz[A3(i, j, k + 1)] - gz[A3(i + 1, j, k)]) * (pk[A3(i + 1, j, k + 1)] - pk[A3(i, j, k)]) +
+               (gz[A3(i, j, k)] - gz[A3(i + 1, j, k + 1)]) * (pk[A3(i, j, k + 1)] - pk[A3(i + 1, j, k)]));
+        *uu = (*uu + alpha * *dd +
+               dt / (wk1[IA(i, j)] + wk1[IA(i + 1, j)]) *
+                   ((gz[A3(i, j, k + 1)] - gz[A3(i + 1, j, k)]) * (pp[A3(i + 1, j, k + 1)] - pp[A3(i, j, k)]) +
+                    (gz[A3(i, j, k)] - gz[A3(i + 1, j, k + 1)]) * (pp[A3(i, j, k + 1)] - pp[A3(i + 1, j, k)]))) *
+              g->rdx[IU(i, j)];
+      }
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie + 1; i++) {
+        double *vv = &v[nV * (k - 1) + IV(i, j)], *dd = &dv[nV * (k - 1) + IV(i, j)];
+        *vv = *vv + beta * *dd;
+        *dd = dt / (wk[IA(i, j)] + wk[IA(i, j + 1)]) *
+              ((gz[A3(i, j, k + 1)] - gz[A3(i, j + 1, k)]) * (pk[A3(i, j + 1, k + 1)] - pk[A3(i, j, k)]) +
+               (gz[A3(i, j, k)] - gz[A3(i, j + 1, k + 1)]) * (pk[A3(i, j, k + 1)] - pk[A3(i, j + 1, k)]));
+        *vv = (*vv + alpha * *dd +
+               dt / (wk1[IA(i, j)] + wk1[IA(i, j + 1)]) *
+                   ((gz[A3(i, j, k + 1)] - gz[A3(i, j + 1, k)]) * (pp[A3(i, j + 1, k + 1)] - pp[A3(i, j, k)]) +
+                    (gz[A3(i, j, k)] - gz[A3(i, j + 1, k + 1)]) * (pp[A3(i, j, k + 1)] - pp[A3(i, j + 1, k)]))) *
+              g->rdy[IV(i, j)];
+      }
+    free(wk1);
+    free(wk);
+  }
+  return 0;
+}
+
+/* grad1_p_update (model/dyn_core.F90:2033-2116) */
+int fvo_grad1_p_update(const fvo_grid *g, int npz, const double *divg2, double *u, double *v, double *pk, double *gz, double dt,
+                       double ptk, double beta, double *du, double *dv) {
+  BOUNDS(g);
+  int k;
+  const size_t nA = (size_t)nid * njd, nV = (size_t)(nid + 1) * njd, nU = (size_t)nid * (njd + 1);
+  const double alpha = 1. - beta;
+  {
+    int i, j;
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie + 1; i++) pk[A3(i, j, 1)] = ptk;
+  }
+#pragma omp parallel for schedule(dynamic)
+  for (k = 1; k <= npz + 1; k++) {
+    double *wk = dalloc(nA);
+    if (k >= 2) fvo_a2b_ord4(g, pk + nA * (k - 1), wk, 1);
+    fvo_a2b_ord4(g, gz + nA * (k - 1), wk, 1);
+    free(wk);
+  }
+#pragma omp parallel for schedule(dynamic)
+  for (k = 1; k <= npz; k++) {
+    int i, j;
+    double *wk = dalloc(nA);
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie + 1; i++) wk[IA(i, j)] = pk[A3(i, j, k + 1)] - pk[A3(i, j, k)];
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie; i++) {
+        double *uu = &u[nU * (k - 1) + IU(i, j)], *dd = &du[nU * (k - 1) + IU(i, j)];
+        *uu = *uu + beta * *dd;
+        *dd = dt / (wk[IA(i, j)] + wk[IA(i + 1, j)]) *
+              ((gz[A3(i, j, k + 1)] - gz[A3(i + 1, j, k)]) * (pk[A3(i + 1, j, k + 1)] - pk[A3(i, j, k)]) +
+               (gz[A3(i, j, k)] - gz[A3(i + 1, j, k + 1)]) * (pk[A3(i, j, k + 1)] - pk[A3(i + 1, j, k)]));
+        *uu = (*uu + divg2[IA(i, j)] - divg2[IA(i + 1, j)] + alpha * *dd) * g->rdx[IU(i, j)];
+      }
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie + 1; i++) {
+        double *vv = &v[nV * (k - 1) + IV(i, j)], *dd = &dv[nV * (k - 1) + IV(i, j)];
+        *vv = *vv + beta * *dd;
+        *dd = dt / (wk[IA(i, j)] + wk[IA(i, j + 1)]) *
+              ((gz[A3(i, j, k + 1)] - gz[A3(i, j + 1, k)]) * (pk[A3(i, j + 1, k + 1)] - pk[A3(i, j, k)]) +
+               (gz[A3(i, j, k)] - gz[A3(i, j + 1, k + 1)]) * (pk[A3(i, j, k + 1)] - pk[A3(i, j + 1, k)]));
+        *vv = (*vv + divg2[IA(i, j)] - divg2[IA(i, j + 1)] + alpha * *dd) * g->rdy[IV(i, j)];
+      }
+    free(wk);
+  }
+  return 0;
+}

@@ -187,7 +187,7 @@ def _oracle_heating(cs, gs, fl, f, npz, bdt, hydrostatic):
 
 
 def oracle_substeps_hydro(cs, gs, fl, st, bdt, npz):
-    """the hydrostatic substep loop of dyn_core (dyn_core.F90:313-1286, beta = 0, d_ext = 0) over the oracle's routines on six
+    """the hydrostatic substep loop of dyn_core (dyn_core.F90:313-1286) over the oracle's routines on six
     faces, with the halo updates where dyn_core has them -- the six-face twin of oracle_dyn_core.run_hydrostatic"""
     f = [{k: F(v.copy()) for k, v in s.items()} for s in st]
     bd = gs[0].bd
@@ -244,7 +244,13 @@ def oracle_substeps_hydro(cs, gs, fl, st, bdt, npz):
             O.geopk(gs[t], npz, fl.ptop, fl.akap, fl.cp_air, x["pe"], x["peln"], x["delp"], x["pkc"], x["gz"], x["phis"], x["pt"], x["pkz"], False)
             if it == n_split:
                 x["pk"][...] = x["pkc"][i0:i0 + nx, j0:j0 + ny, :]
-            O.one_grad_p_hydro(gs[t], npz, dt, ptk, x["divg2"], x["u"], x["v"], x["pkc"], x["gz"])
+            if fl.beta > 0.0:                                              # dyn_core.F90:1018-1019
+                for n, kind in (("du", "U"), ("dv", "V")):
+                    x.setdefault(n, bd.zeros(kind, npz))
+                O.grad1_p_update(gs[t], npz, x["divg2"], x["u"], x["v"], x["pkc"], x["gz"], dt, ptk, 0.0 if it == 1 else fl.beta,
+                                 x["du"], x["dv"])
+            else:
+                O.one_grad_p_hydro(gs[t], npz, dt, ptk, x["divg2"], x["u"], x["v"], x["pkc"], x["gz"])
         if it != n_split:
             exchange_pair(cs, f, "u", "v", "D")
         else:
@@ -362,7 +368,13 @@ def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
             O.pk3_halo(gs[t], npz, fl.ptop, fl.akap, x["pk3"], x["delp"], fl.use_logp)
             i0, i1 = ng - 2, ng + nx + 2
             x["gz"][i0:i1, i0:i1, :] = x["zh"][i0:i1, i0:i1, :] * fl.grav
-            O.nh_p_grad(gs[t], npz, x["u"], x["v"], x["pkc"], x["gz"], x["delp"], x["pk3"], dt, peln1 if fl.use_logp else ptk)
+            if fl.beta > 0.0:                                              # dyn_core.F90:1027-1028, beta_d :398-406
+                for n, kind in (("du", "U"), ("dv", "V")):
+                    x.setdefault(n, bd.zeros(kind, npz))
+                O.split_p_grad(gs[t], npz, x["u"], x["v"], x["pkc"], x["gz"], x["delp"], x["pk3"], 0.0 if it == 1 else fl.beta, dt,
+                               peln1 if fl.use_logp else ptk, x["du"], x["dv"])
+            else:
+                O.nh_p_grad(gs[t], npz, x["u"], x["v"], x["pkc"], x["gz"], x["delp"], x["pk3"], dt, peln1 if fl.use_logp else ptk)
         if it != n_split:
             exchange_pair(cs, f, "u", "v", "D")
         else:
@@ -398,6 +410,7 @@ def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz, q
                 rf["q"] = q[t]
             O.lagrangian_to_eulerian(gs[t], npz, dict(remap_par, last_step=(int(last_step) if n_map == k_split else 0)), rf, ak, bk)
             cur[t] = dict(u=rf["u"], v=rf["v"], delp=rf["delp"], pt=rf["pt"], phis=st[t]["phis"])
+            cur[t].update({n: x[n] for n in ("du", "dv") if n in x})       # dyn_core's saved arrays (dyn_core.F90:278-283)
             out.append(dict(cur[t], pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"], q=None if q is None else q[t]))
     return out
 
@@ -429,6 +442,7 @@ def oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, remap_par, n
                 rf[n] = x[n]
             O.lagrangian_to_eulerian(gs[t], npz, dict(remap_par, last_step=int(last_step and n_map == k_split)), rf, ak, bk)
             cur[t] = dict(u=rf["u"], v=rf["v"], w=rf["w"], delp=rf["delp"], pt=rf["pt"], delz=rf["delz"], phis=st[t]["phis"])
+            cur[t].update({n: x[n] for n in ("du", "dv") if n in x})
             for n in moist_names:
                 cur[t][n] = rf[n]
             out.append(dict(cur[t], pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"], q=None if q is None else q[t]))

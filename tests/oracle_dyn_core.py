@@ -97,7 +97,13 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
         O.pk3_halo(g, npz, fl.ptop, fl.akap, f["pk3"], f["delp"], fl.use_logp)
         i0, i1, j0, j1 = bd.ng - 2, bd.ng + nx + 2, bd.ng - 2, bd.ng + ny + 2
         f["gz"][i0:i1, j0:j1, :] = f["zh"][i0:i1, j0:j1, :] * fl.grav
-        O.nh_p_grad(g, npz, f["u"], f["v"], f["pkc"], f["gz"], f["delp"], f["pk3"], dt, peln1 if fl.use_logp else ptk)
+        if fl.beta > 0.0:                                                  # dyn_core.F90:1027-1028, beta_d :398-406
+            for n, kind in (("du", "U"), ("dv", "V")):
+                f.setdefault(n, bd.zeros(kind, npz))
+            O.split_p_grad(g, npz, f["u"], f["v"], f["pkc"], f["gz"], f["delp"], f["pk3"], 0.0 if it == 1 else fl.beta, dt,
+                           peln1 if fl.use_logp else ptk, f["du"], f["dv"])
+        else:
+            O.nh_p_grad(g, npz, f["u"], f["v"], f["pkc"], f["gz"], f["delp"], f["pk3"], dt, peln1 if fl.use_logp else ptk)
         if it != n_split:
             _fill(bd, f["u"], "U"); _fill(bd, f["v"], "V")
         elif fl.use_old_omega:                                             # dyn_core.F90:409-421, :1182-1191
@@ -122,7 +128,7 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
 
 
 def run_hydrostatic(g, npz: int, fl: DynFlags, st: dict, bdt: float):
-    """hydrostatic branch of the substep loop (beta = 0) over the oracle's routines.  st: u, v, delp, pt (halo'd), phis."""
+    """hydrostatic branch of the substep loop over the oracle's routines.  st: u, v, delp, pt (halo'd), phis."""
     bd: Bounds = g.bd
     f = {k: np.asfortranarray(v.copy()) for k, v in st.items()}
     nx, ny = bd.nx, bd.ny
@@ -171,7 +177,12 @@ def run_hydrostatic(g, npz: int, fl: DynFlags, st: dict, bdt: float):
                 f["pkz"], False)
         if remap_step:
             f["pk"][...] = f["pkc"][i0:i0 + nx, j0:j0 + ny, :]
-        O.one_grad_p_hydro(g, npz, dt, ptk, f["divg2"], f["u"], f["v"], f["pkc"], f["gz"])
+        if fl.beta > 0.0:                                                  # dyn_core.F90:1018-1019
+            for n, kind in (("du", "U"), ("dv", "V")):
+                f.setdefault(n, bd.zeros(kind, npz))
+            O.grad1_p_update(g, npz, f["divg2"], f["u"], f["v"], f["pkc"], f["gz"], dt, ptk, 0.0 if it == 1 else fl.beta, f["du"], f["dv"])
+        else:
+            O.one_grad_p_hydro(g, npz, dt, ptk, f["divg2"], f["u"], f["v"], f["pkc"], f["gz"])
         if it != n_split:
             _fill(bd, f["u"], "U"); _fill(bd, f["v"], "V")
     if fl.convert_ke or (fl.do_vort_damp and fl.vtdm4 > 1.0e-4):

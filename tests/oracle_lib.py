@@ -257,6 +257,18 @@ def one_grad_p_hydro(g, npz, dt, ptk, divg2, u, v, pk, gz):
     assert lib().fvo_one_grad_p_hydro(C.byref(gs), C.c_int(npz), _d(dt), _d(ptk), p(divg2), p(u), p(v), p(pk), p(gz)) == 0
 
 
+def split_p_grad(g, npz, u, v, pp, gz, delp, pk, beta, dt, top_value, du, dv):
+    gs = make_grid(g)
+    assert lib().fvo_split_p_grad(C.byref(gs), C.c_int(npz), p(u), p(v), p(pp), p(gz), p(delp), p(pk), _d(beta), _d(dt),
+                                  _d(top_value), p(du), p(dv)) == 0
+
+
+def grad1_p_update(g, npz, divg2, u, v, pk, gz, dt, ptk, beta, du, dv):
+    gs = make_grid(g)
+    assert lib().fvo_grad1_p_update(C.byref(gs), C.c_int(npz), p(divg2), p(u), p(v), p(pk), p(gz), _d(dt), _d(ptk), _d(beta),
+                                    p(du), p(dv)) == 0
+
+
 def del2_cubed(g, km, cd, nmax, q):
     gs = make_grid(g)
     assert lib().fvo_del2_cubed(C.byref(gs), C.c_int(km), _d(cd), C.c_int(nmax), p(q)) == 0

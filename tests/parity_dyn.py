@@ -85,6 +85,7 @@ def oracle_fv_step_hydro(g, npz, fl, st, ak, bk, q, bdt, k_split, remap_par, las
             rf["q"] = q
         O.lagrangian_to_eulerian(g, npz, dict(remap_par, last_step=(int(last_step) if n_map == k_split else 0)), rf, ak, bk)
         cur = dict(u=rf["u"], v=rf["v"], delp=rf["delp"], pt=rf["pt"], phis=st["phis"])
+        cur.update({n: f[n] for n in ("du", "dv") if n in f})               # dyn_core's saved arrays (dyn_core.F90:278-283)
         out = dict(cur, q=q, pkz=rf["pkz"], ps=rf["ps"], pe=rf["pe"], peln=rf["peln"], pk=rf["pk"])
     return out
 
@@ -178,6 +179,7 @@ def oracle_fv_step(g, npz, fl, dp0, st, ak, bk, q, bdt, k_split, remap_par, last
                 rf[n] = f[n]
         O.lagrangian_to_eulerian(g, npz, dict(remap_par, last_step=(int(last_step) if n_map == k_split else 0)), rf, ak, bk)
         cur = dict(u=rf["u"], v=rf["v"], w=rf["w"], delp=rf["delp"], pt=rf["pt"], delz=rf["delz"], phis=st["phis"])
+        cur.update({n: f[n] for n in ("du", "dv") if n in f})
         for n in ("q_con", "cappa"):
             if n in rf:
                 cur[n] = rf[n]
@@ -342,7 +344,7 @@ def check_fv_cycle_from_temperature(lib, nx=24, ny=16, npz=10, k_split=2, n_spli
     return out
 
 
-def check_fv_step(lib, nx=24, ny=16, npz=10, nq=2, k_split=2, n_split=2, bdt=8.0):
+def check_fv_step(lib, nx=24, ny=16, npz=10, nq=2, k_split=2, n_split=2, bdt=8.0, flags=None):
     """Whole model step (k_split x [substeps, tracer_2d, remap]) library vs oracle."""
     from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
     bd = Bounds(1, nx, 1, ny)
@@ -351,7 +353,7 @@ def check_fv_step(lib, nx=24, ny=16, npz=10, nq=2, k_split=2, n_split=2, bdt=8.0
     sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
     dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
-    fl = DynFlags(n_split=n_split, ptop=N.PTOP)
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, **(flags or {}))
     rng = np.random.default_rng(5)
     q = np.asfortranarray(rng.uniform(0.0, 1.0, bd.shape("A", npz) + (nq,))) if nq else None
     ctx = Context(g, npz, lib=lib)

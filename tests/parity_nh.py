@@ -219,6 +219,60 @@ def check_nh_p_grad(lib, nx=40, ny=19, km=5, grid=None):
         ctx.close()
 
 
+def check_split_p_grad(lib, nx=40, ny=19, km=5, beta=0.4, grid=None):
+    """split_p_grad (dyn_core.F90:1795-1900) over two calls: beta_d = 0 with du = dv = 0, then beta with the saved gradient"""
+    bd = grid.bd if grid is not None else Bounds(1, nx, 1, ny)
+    g = grid if grid is not None else P.make_grid(bd, True)
+    s = nh_state(bd, km)
+    rng = np.random.default_rng(26)
+    u = np.asfortranarray(rng.uniform(-1e4, 1e4, bd.shape("U", km)))
+    v = np.asfortranarray(rng.uniform(-1e4, 1e4, bd.shape("V", km)))
+    top = PTOP ** KAPPA
+    o = dict(u=u.copy(order="F"), v=v.copy(order="F"), du=bd.zeros("U", km), dv=bd.zeros("V", km))
+    ctx = Context(g, km, lib=lib)
+    try:
+        d_u, d_v, d_du, d_dv = ctx.from_host(u), ctx.from_host(v), ctx.zeros("U", km), ctx.zeros("V", km)
+        for call, bt in enumerate((0.0, beta, beta)):
+            pe, pk, pp, gz = _pressure_fields(bd, km, s, rng)
+            O.split_p_grad(g, km, o["u"], o["v"], pp.copy(order="F"), gz.copy(order="F"), s["delp"].copy(order="F"),
+                           pk.copy(order="F"), bt, 6.0, top, o["du"], o["dv"])
+            ctx.split_p_grad(d_u, d_v, ctx.from_host(pp), ctx.from_host(gz), ctx.from_host(s["delp"]), ctx.from_host(pk), bt, 6.0, top,
+                             d_du, d_dv)
+            for n, kind, da, r in (("u", "U", d_u, (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", d_v, (bd.is_, bd.ie + 1, bd.js, bd.je)),
+                                   ("du", "U", d_du, (bd.is_, bd.ie, bd.js, bd.je + 1)), ("dv", "V", d_dv, (bd.is_, bd.ie + 1, bd.js, bd.je))):
+                P.assert_close(f"{n} call {call}", bd.view(da.download(), kind, *r), bd.view(o[n], kind, *r), _tol(lib))
+    finally:
+        ctx.close()
+
+
+def check_grad1_p_update(lib, nx=40, ny=19, km=5, beta=0.4, d_ext=0.02, grid=None):
+    """grad1_p_update (dyn_core.F90:2033-2116) over three calls, with and without the external-mode damping field"""
+    bd = grid.bd if grid is not None else Bounds(1, nx, 1, ny)
+    g = grid if grid is not None else P.make_grid(bd, True)
+    s = nh_state(bd, km)
+    rng = np.random.default_rng(27)
+    u = np.asfortranarray(rng.uniform(-1e4, 1e4, bd.shape("U", km)))
+    v = np.asfortranarray(rng.uniform(-1e4, 1e4, bd.shape("V", km)))
+    vt = np.asfortranarray(rng.uniform(-1e-5, 1e-5, bd.shape("A", km)))
+    top = PTOP ** KAPPA
+    o = dict(u=u.copy(order="F"), v=v.copy(order="F"), du=bd.zeros("U", km), dv=bd.zeros("V", km))
+    divg2 = bd.zeros("A")
+    O.divg2_ext(g, km, d_ext, s["delp"], vt, divg2)
+    ctx = Context(g, km, lib=lib)
+    try:
+        d_u, d_v, d_du, d_dv = ctx.from_host(u), ctx.from_host(v), ctx.zeros("U", km), ctx.zeros("V", km)
+        d_d2 = ctx.from_host(divg2)
+        for call, bt in enumerate((0.0, beta, beta)):
+            pe, pk, pp, gz = _pressure_fields(bd, km, s, rng)
+            O.grad1_p_update(g, km, divg2, o["u"], o["v"], pk.copy(order="F"), gz.copy(order="F"), 6.0, top, bt, o["du"], o["dv"])
+            ctx.grad1_p_update(d_d2 if d_ext > 0 else None, d_u, d_v, ctx.from_host(pk), ctx.from_host(gz), 6.0, top, bt, d_du, d_dv)
+            for n, kind, da, r in (("u", "U", d_u, (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", d_v, (bd.is_, bd.ie + 1, bd.js, bd.je)),
+                                   ("du", "U", d_du, (bd.is_, bd.ie, bd.js, bd.je + 1)), ("dv", "V", d_dv, (bd.is_, bd.ie + 1, bd.js, bd.je))):
+                P.assert_close(f"{n} call {call}", bd.view(da.download(), kind, *r), bd.view(o[n], kind, *r), _tol(lib))
+    finally:
+        ctx.close()
+
+
 def check_halos_and_geopk(lib, nx=24, ny=13, km=6):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)

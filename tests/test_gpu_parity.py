@@ -142,6 +142,25 @@ def test_nh_p_grad(prod):
     N.check_nh_p_grad(prod, nx=96, ny=96, km=16)
 
 
+def test_split_p_grad_and_grad1_p_update(prod):
+    """beta > 0 (dyn_core.F90:1795-1900, :2033-2116): kernels over three calls, both substep loops, doubly periodic and sphere"""
+    N.check_split_p_grad(prod)
+    N.check_split_p_grad(prod, nx=96, ny=96, km=16, beta=0.25)
+    N.check_grad1_p_update(prod)
+    N.check_grad1_p_update(prod, nx=96, ny=96, km=16, d_ext=0.0)
+    D.check_substeps(prod, n_split=3, flags=dict(beta=0.4, a_imp=0.6))
+    D.check_substeps_hydrostatic(prod, n_split=3, flags=dict(beta=0.4))
+    D.check_fv_step(prod, flags=dict(beta=0.3))
+    cs, gs = PC.CC.sphere(25)
+    for t in (0, 4):
+        N.check_split_p_grad(prod, km=4, grid=gs[t])
+        N.check_grad1_p_update(prod, km=4, grid=gs[t], d_ext=0.0)
+    assert max(PC.check_substeps_nh(prod, npx=25, npz=5, n_split=3, flags=dict(beta=0.4)).values()) <= 1e-13
+    assert max(PC.check_substeps_hydrostatic(prod, npx=25, npz=4, n_split=3, flags=dict(beta=0.4)).values()) <= 1e-13
+    r = PC.check_jw_step(prod, npx=25, npz=20, k_split=2, n_split=2, bdt=900.0, hydrostatic=False, flags=dict(beta=0.4))
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
 def test_nh_halos_and_geopk(prod):
     N.check_halos_and_geopk(prod)
 
@@ -467,6 +486,7 @@ def test_fortran_host_on_the_cubed_sphere(prod, tmp_path):
         pytest.skip("no Fortran compiler in this image")
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(prod, tmp_path, npx=25, npz=20, nq=2, hydrostatic=False)
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(prod, tmp_path, npx=25, npz=20, nq=0, hydrostatic=True, d_con=1.0, k_split=1)
+    assert "fv3_solo_sphere: done" in F.check_fortran_sphere(prod, tmp_path, npx=25, npz=8, nq=0, hydrostatic=False, beta=0.4, n_split=3)
 
 
 def test_fortran_dyn_core_with_the_reference_argument_list(prod, tmp_path):
@@ -478,6 +498,8 @@ def test_fortran_dyn_core_with_the_reference_argument_list(prod, tmp_path):
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=12, d_con=1.0)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=12, hydrostatic=True, d_con=1.0)
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=8, beta=0.4)
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=8, hydrostatic=True, beta=0.4)
     # fv_dynamics with ITS reference argument list (model/fv_dynamics.F90:79-85): T -> theta_v, the k_split loop with tracers and
     # the remap, last_step, cubed_to_latlon
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path)

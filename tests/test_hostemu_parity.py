@@ -120,6 +120,25 @@ def test_nh_p_grad(emu):
     N.check_nh_p_grad(emu, nx=33, ny=9, km=3)
 
 
+def test_split_p_grad_and_grad1_p_update(emu):
+    """beta > 0 (dyn_core.F90:1795-1900, :2033-2116): kernels over three calls, then both substep loops, doubly periodic and sphere"""
+    N.check_split_p_grad(emu)
+    N.check_split_p_grad(emu, nx=33, ny=9, km=3, beta=0.25)
+    N.check_grad1_p_update(emu)
+    N.check_grad1_p_update(emu, nx=33, ny=9, km=3, d_ext=0.0)
+    D.check_substeps(emu, n_split=3, flags=dict(beta=0.4, a_imp=0.6))
+    D.check_substeps_hydrostatic(emu, n_split=3, flags=dict(beta=0.4))
+    assert D.check_fv_step(emu, flags=dict(beta=0.3)) is not None
+    cs, gs = PC.CC.sphere(13)
+    for t in (0, 4):
+        N.check_split_p_grad(emu, km=4, grid=gs[t])
+        N.check_grad1_p_update(emu, km=4, grid=gs[t], d_ext=0.0)
+    assert max(PC.check_substeps_nh(emu, npx=13, npz=5, n_split=3, flags=dict(beta=0.4)).values()) <= 1e-13
+    assert max(PC.check_substeps_hydrostatic(emu, npx=13, npz=4, n_split=3, flags=dict(beta=0.4)).values()) <= 1e-13
+    r = PC.check_jw_step(emu, npx=13, npz=20, k_split=2, n_split=2, bdt=900.0, hydrostatic=False, flags=dict(beta=0.4))
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
 def test_nh_halos_and_geopk(emu):
     N.check_halos_and_geopk(emu)
 
@@ -382,6 +401,8 @@ def test_fortran_dyn_core_with_the_reference_argument_list(emu, tmp_path):
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=12, d_con=1.0)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=12, hydrostatic=True, d_con=1.0)
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, beta=0.4)
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, hydrostatic=True, beta=0.4)
     # fv_dynamics with ITS reference argument list (model/fv_dynamics.F90:79-85): T -> theta_v, the k_split loop with tracers and
     # the remap, last_step, cubed_to_latlon
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(emu, tmp_path)
@@ -918,3 +939,4 @@ def test_fortran_host_on_the_cubed_sphere(emu, tmp_path):
         pytest.skip("no amdflang in this environment")
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=12, nq=2, hydrostatic=False)
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=12, nq=0, hydrostatic=True, d_con=1.0, k_split=1)
+    assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=8, nq=0, hydrostatic=False, beta=0.4, n_split=3)
