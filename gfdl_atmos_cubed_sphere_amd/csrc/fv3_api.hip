@@ -118,6 +118,7 @@ struct fv3_ctx {
   CubedGeom cg;
   double *cg_dev;
   double *cs_scr[32];
+  int *ones_i;    // npz ones, device (ksplt of the inline_q sub-step)
   int march_tj;          // rows per wavefront segment of the marching kernels
   int march_tj_csw, march_tj_ke, march_tj_fused, march_tj_mom;
   int trc_nt;  // tracers per wavefront in the sub-cycle kernel (FV3_MI355X_TRACER_NT: 1..4, default 3)
@@ -358,7 +359,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->remap_scr = nullptr; c->remap_scr_n = 0; c->ray_d = nullptr;
   c->q_con = nullptr; c->cappa = nullptr;
   c->moist_on = false; c->moist_qcon = nullptr; c->moist_cappa = nullptr;
-  c->trc_d = nullptr; c->trc_i = nullptr;
+  c->trc_d = nullptr; c->trc_i = nullptr; c->ones_i = nullptr;
   for (auto &s : c->scratch) s = nullptr;
   c->lev_ext_d = nullptr; c->lev_ext_i = nullptr;
   *out = c;
@@ -380,6 +381,7 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   if (c->ray_d) rt_free(c->ray_d);
   if (c->trc_d) rt_free(c->trc_d);
   if (c->trc_i) rt_free(c->trc_i);
+  if (c->ones_i) rt_free(c->ones_i);
   if (c->kord_tr_dev) rt_free(c->kord_tr_dev);
   if (c->edge_dev) rt_free(c->edge_dev);
   if (c->lev_ext_d) rt_free(c->lev_ext_d);
@@ -2978,6 +2980,9 @@ extern "C" int fv3_tracer_2d_scale(fv3_ctx *c, const double *frac_host, double *
   return 0;
 }
 
+static int tracer_step_impl(fv3_ctx *c, int it, int nsplt, const int *ksplt_dev, int nq, int hord, int nord_tr, double trdm,
+                            const double *q, double *q_out, const double *dp1, double *dp1_out, const double *mfx, const double *mfy,
+                            const double *cx, const double *cy, const double *xfx, const double *yfx, const double *mass);
 extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *ksplt_host, int nq, int hord, int nord_tr,
                                   double trdm, const double *q, double *q_out, const double *dp1, double *dp1_out,
                                   const double *mfx, const double *mfy, const double *cx, const double *cy,
@@ -2987,11 +2992,89 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
   if (q == q_out || dp1 == dp1_out) return fail("fv3_tracer_2d_step: *_out buffers must not alias the inputs");
   if (trdm > 1.e-4 && nord_tr > 2) return fail("fv3_tracer_2d_step: nord_tr > 2");
   if (need_trc(c)) return 1;
-  const Grid &g = c->g;
   if (it == 1) {
-    RT(rt_h2d(c->trc_i, ksplt_host, sizeof(int) * g.npz, c->stream));
+    RT(rt_h2d(c->trc_i, ksplt_host, sizeof(int) * c->g.npz, c->stream));
     RT(rt_sync(c->stream));
   }
+  return tracer_step_impl(c, it, nsplt, c->trc_i, nq, hord, nord_tr, trdm, q, q_out, dp1, dp1_out, mfx, mfy, cx, cy, xfx, yfx, nullptr);
+}
+
+// ---- inline_q: the tracers advected inside d_sw, every acoustic substep (sw_core.F90:1020-1043) -----------------------------------
+// One sub-step of tracer_2d is the same arithmetic (fv_tracer2d.F90:478-520 against sw_core.F90:1021-1043: dp2 / delp, ra_x / ra_y,
+// fv_tp_2d with the mass fluxes, the update of q), with d_sw's per-substep Courant numbers, area fluxes and delp fluxes in the
+// place of the accumulated ones; deln_flux takes nord_t / damp_t and d_sw's half-updated delp as mass (InlineQMass).
+extern "C" int fv3_d_sw_inline_q(fv3_ctx *c, int nq, int hord_tr, int nord_t, double damp_t, const double *q, double *q_out,
+                                 const double *delp_old, const double *delp_new, const double *fx, const double *fy,
+                                 const double *crx, const double *cry, const double *xfx, const double *yfx) {
+  if (!c || !c->grid_ready) return fail("fv3_d_sw_inline_q: context has no grid");
+  if (nq < 1 || !q || !q_out || !delp_old || !delp_new || !fx || !fy || !crx || !cry || !xfx || !yfx)
+    return fail("fv3_d_sw_inline_q: null argument");
+  if (!tp_ord_supported_tr(hord_tr)) return fail("fv3_d_sw_inline_q: hord_tr=%d not supported (5,-5,6,7,8,9,10,11,12,13)", hord_tr);
+  if (q == q_out) return fail("fv3_d_sw_inline_q: q_out must not alias q");
+  if (damp_t > 1.e-4 && nord_t > 2) return fail("fv3_d_sw_inline_q: nord_t > 2");
+  if (need_trc(c)) return 1;
+  const Grid &g = c->g;
+  if (!c->ones_i) {   // ksplt = 1 on every level, device resident (first call: outside a graph capture)
+    std::vector<int> one(g.npz, 1);
+    RT(rt_malloc((void **)&c->ones_i, sizeof(int) * g.npz));
+    RT(rt_h2d(c->ones_i, one.data(), sizeof(int) * g.npz, c->stream));
+    RT(rt_sync(c->stream));
+  }
+  const double *mass = nullptr;
+  if (damp_t > 1.e-4) {
+    double *m = cs_scratch(c, 29);
+    if (!m) return fail("fv3_d_sw_inline_q: out of device memory");
+    InlineQMass kf{g, delp_old, delp_new, m};
+    Dim3 grid;
+    grid.x = (unsigned)((g.nA() + InlineQMass::CH - 1) / InlineQMass::CH);
+    grid.y = 1;
+    grid.z = (unsigned)g.npz;
+    RT(launch_p(c, "inline_q_mass", grid, 0, kf));
+    mass = m;
+  }
+  return tracer_step_impl(c, 1, 1, c->ones_i, nq, hord_tr, nord_t, damp_t, q, q_out, delp_old, nullptr, fx, fy, crx, cry, xfx, yfx, mass);
+}
+
+extern "C" int fv3_flux_accum(fv3_ctx *c, double *mfx, double *mfy, const double *fx, const double *fy) {
+  if (!c || !c->grid_ready || !mfx || !mfy || !fx || !fy) return fail("fv3_flux_accum: bad context/arguments");
+  const Grid &g = c->g;
+  FluxAccum kf{g, mfx, mfy, fx, fy};
+  const size_t nmax = g.nFX() > g.nFY() ? g.nFX() : g.nFY();
+  Dim3 grid;
+  grid.x = (unsigned)((nmax + FluxAccum::CH - 1) / FluxAccum::CH);
+  grid.y = 1;
+  grid.z = (unsigned)g.npz;
+  RT(launch_p(c, "flux_accum", grid, 0, kf));
+  return 0;
+}
+
+extern "C" int fv3_fill2d_mass(fv3_ctx *c, int nk, const double *q, const double *delp, double *qt) {
+  if (!c || !c->grid_ready || nk < 1 || !q || !delp || !qt) return fail("fv3_fill2d_mass: bad context/arguments");
+  const Grid &g = c->g;
+  Fill2dMass kf{g, q, delp, qt};
+  Dim3 grid;
+  grid.x = (unsigned)(((size_t)g.nx * g.ny + Fill2dMass::CH - 1) / Fill2dMass::CH);
+  grid.y = 1;
+  grid.z = (unsigned)nk;
+  RT(launch_p(c, "fill2d_mass", grid, 0, kf));
+  return 0;
+}
+extern "C" int fv3_fill2d_apply(fv3_ctx *c, int nk, const double *qt, const double *delp, double *q) {
+  if (!c || !c->grid_ready || nk < 1 || !q || !delp || !qt) return fail("fv3_fill2d_apply: bad context/arguments");
+  const Grid &g = c->g;
+  Fill2dApply kf{g, qt, delp, q};
+  Dim3 grid;
+  grid.x = (unsigned)(((size_t)g.nx * g.ny + Fill2dApply::CH - 1) / Fill2dApply::CH);
+  grid.y = 1;
+  grid.z = (unsigned)nk;
+  RT(launch_p(c, "fill2d_apply", grid, 0, kf));
+  return 0;
+}
+
+static int tracer_step_impl(fv3_ctx *c, int it, int nsplt, const int *ksplt_dev, int nq, int hord, int nord_tr, double trdm,
+                            const double *q, double *q_out, const double *dp1, double *dp1_out, const double *mfx, const double *mfy,
+                            const double *cx, const double *cy, const double *xfx, const double *yfx, const double *mass) {
+  const Grid &g = c->g;
   auto march_step = [&]() -> int {
     const int trc_nt = c->trc_nt;   // tracers per wavefront (1: one (tracer, level) per wavefront, TracerMarch)
     if (trc_nt > 1 && nq > 1) {
@@ -3000,7 +3083,7 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
         const int ngrp = (nq + NT - 1) / NT;
         MarchDims md = make_march_dims(g, seg_rows(c, c->march_tj_fused, g.npz * ngrp));
         const int nwt = md.nwaves(g.npz * ngrp);
-        TracerMarchFused<decltype(H)::value, NT> kf{g, md, g.npz, nq, it, nsplt, ngrp, c->trc_i, q, dp1, mfx, mfy, cx,
+        TracerMarchFused<decltype(H)::value, NT> kf{g, md, g.npz, nq, it, nsplt, ngrp, ksplt_dev, q, dp1, mfx, mfy, cx,
                                                     cy, xfx, yfx, q_out, dp1_out};
         return launch_w(c, "tracer_step", nwt, kf);
       };
@@ -3014,7 +3097,7 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
     MarchDims md = make_march_dims(g, seg_rows(c, c->march_tj, g.npz));
     const int nwt = md.nwaves(g.npz * nq);
     return dispatch_hord_tr(hord, [&](auto H) {
-      TracerMarch<decltype(H)::value> kf{g, md, g.npz, nq, it, nsplt, c->trc_i, q, dp1, mfx, mfy, cx, cy, xfx, yfx,
+      TracerMarch<decltype(H)::value> kf{g, md, g.npz, nq, it, nsplt, ksplt_dev, q, dp1, mfx, mfy, cx, cy, xfx, yfx,
                                          q_out, dp1_out};
       return launch_w(c, "tracer_step", nwt, kf);
     });
@@ -3050,7 +3133,7 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
       }
       if (damp) {
         DelnCubedState d;
-        d.g = g; d.q = q + iq * nq3; d.mass = dp1; d.fx = fx; d.fy = fy; d.nord = nord_dev; d.coef = coef_dev; d.thresh = 1.E-4;
+        d.g = g; d.q = q + iq * nq3; d.mass = mass ? mass : dp1; d.fx = fx; d.fy = fy; d.nord = nord_dev; d.coef = coef_dev; d.thresh = 1.E-4;
         d.corner_area = 0;
         d.d2 = cs_scratch(c, 4); d.fx2 = cs_scratch(c, 5); d.fy2 = cs_scratch(c, 6);
         if (!d.d2 || !d.fx2 || !d.fy2) return fail("fv3_tracer_2d_step: out of device memory");
@@ -3062,15 +3145,15 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
         }
         RT(launch_pass(c, "trc_deln", g.is, g.ie + 1, g.js, g.je + 1, rm, DelnCubedL5{d}));
       }
-      TracerCubedFinal kf{g, it, nsplt, iq == nq - 1, c->trc_i, q + iq * nq3, dp1, fx, fy, mfx, mfy, q_out + iq * nq3, dp1_out};
+      TracerCubedFinal kf{g, it, nsplt, iq == nq - 1, ksplt_dev, q + iq * nq3, dp1, fx, fy, mfx, mfy, q_out + iq * nq3, dp1_out};
       RT(launch_pass(c, "trc_fin", g.is, g.ie, g.js, g.je, ro, kf));
     }
     return 0;
   }
   if (c->use_march && !(it == 1 && trdm > 1.e-4)) return march_step();
   constexpr int TI = FV3_DSW_TI, TJ = FV3_DSW_TJ;
-  TracerStep<TI, TJ> kf{g, g.npz, nq, it, nsplt, hord, nord_tr, trdm, c->trc_i, q, dp1, mfx, mfy, cx, cy, xfx, yfx,
-                        q_out, dp1_out};
+  TracerStep<TI, TJ> kf{g, g.npz, nq, it, nsplt, hord, nord_tr, trdm, ksplt_dev, q, dp1, mfx, mfy, cx, cy, xfx, yfx,
+                        q_out, dp1_out, mass};
   Dim3 grid;
   grid.x = (unsigned)((g.nx + TI - 1) / TI);
   grid.y = (unsigned)((g.ny + TJ - 1) / TJ);

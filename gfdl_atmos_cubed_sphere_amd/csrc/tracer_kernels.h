@@ -89,6 +89,7 @@ struct TracerStep {
   const int *ksplt;  // device, npz
   const double *q, *dp1, *mfx, *mfy, *cx, *cy, *xfx, *yfx;
   double *q_out, *dp1_out;
+  const double *mass = nullptr;   // deln_flux's mass (null: dp1, fv_tracer2d.F90:497-505; d_sw's inline_q passes its delp, sw_core.F90:1034)
   using TS = Tp2dScratch<TI, TJ>;
   using DS = DelnScratch<TI, TJ>;
   static constexpr int nQ = (TI + 6) * (TJ + 6);
@@ -120,7 +121,7 @@ struct TracerStep {
     const Tile sfx{p, i0, j0, TI + 1}; p += nFXt;
     const Tile sfy{p, i0, j0, TI}; p += nFYt;
     const bool damp = (it == 1 && trdm > 1.e-4);
-    if (damp) load_tile<TI + 6, TJ + 6>(sm, dp1 + oA, g.nid, g.isd, g.ied, g.jsd, g.jed, tid);
+    if (damp) load_tile<TI + 6, TJ + 6>(sm, (mass ? mass : dp1) + oA, g.nid, g.isd, g.ied, g.jsd, g.jed, tid);
     for (int iq = 0; iq < nq; iq++) {
       const double *qk = q + ((size_t)iq * npz + k) * nA;
       FV3_SYNC();
@@ -165,6 +166,74 @@ struct TracerStep {
             (sq(i, j) * d1 + (sfx(i, j) - sfx(i + 1, j) + sfy(i, j) - sfy(i, j + 1)) * ra) / dp2;
         if (iq == nq - 1 && it != nsplt) dp1_out[oA + g.iA(i, j)] = dp2;
       }
+    }
+  }
+};
+
+// sw_core.F90:1020-1043 (inline_q): d_sw's fv_tp_2d of a tracer gets mass = delp AFTER the compute domain was updated (:1021-1024)
+// and before any halo update: new values inside, the old ones in the halo
+struct InlineQMass {
+  Grid g;
+  const double *delp_old, *delp_new;
+  double *mass;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const size_t o = (size_t)bz * g.nA();
+    const int n = g.nid * g.njd;
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.isd + idx % g.nid, j = g.jsd + idx / g.nid;
+      const bool in = i >= g.is && i <= g.ie && j >= g.js && j <= g.je;
+      mass[o + idx] = in ? delp_new[o + idx] : delp_old[o + idx];
+    }
+  }
+};
+
+// mfx = mfx + fx, mfy = mfy + fy (sw_core.F90:949-962 for a d_sw that was handed zeroed flux arrays of its own)
+struct FluxAccum {
+  Grid g;
+  double *mfx, *mfy;
+  const double *fx, *fy;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const size_t nx_ = g.nFX(), ny_ = g.nFY();
+    for (size_t idx = (size_t)bx * CH + tid; idx < (size_t)(bx + 1) * CH; idx += kNT) {
+      if (idx < nx_) mfx[(size_t)bz * nx_ + idx] = mfx[(size_t)bz * nx_ + idx] + fx[(size_t)bz * nx_ + idx];
+      if (idx < ny_) mfy[(size_t)bz * ny_ + idx] = mfy[(size_t)bz * ny_ + idx] + fy[(size_t)bz * ny_ + idx];
+    }
+  }
+};
+
+// fill2D (model/fv_fill.F90:183-258)
+struct Fill2dMass {   // :228-235
+  Grid g;
+  const double *q, *delp;
+  double *qt;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const size_t o = (size_t)bz * g.nA();
+    const int n = g.nx * g.ny;
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int a = g.iA(g.is + idx % g.nx, g.js + idx / g.nx);
+      qt[o + a] = q[o + a] * delp[o + a] * g.area[a];
+    }
+  }
+};
+struct Fill2dApply {  // :238-256
+  Grid g;
+  const double *qt, *delp;
+  double *q;
+  static constexpr int CH = 1024;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const size_t o = (size_t)bz * g.nA();
+    const int n = g.nx * g.ny;
+    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = g.is + idx % g.nx, j = g.js + idx / g.nx;
+      const double c0 = qt[o + g.iA(i, j)], w = qt[o + g.iA(i - 1, j)], e = qt[o + g.iA(i + 1, j)], s_ = qt[o + g.iA(i, j - 1)],
+                   n_ = qt[o + g.iA(i, j + 1)];
+      const double fxw = (w * c0 < 0.) ? w - c0 : 0., fxe = (c0 * e < 0.) ? c0 - e : 0.;
+      const double fys = (s_ * c0 < 0.) ? s_ - c0 : 0., fyn = (c0 * n_ < 0.) ? c0 - n_ : 0.;
+      const int a = g.iA(i, j);
+      q[o + a] = q[o + a] + 0.25 * (fxw - fxe + fys - fyn) / (delp[o + a] * g.area[a]);
     }
   }
 };

@@ -37,6 +37,7 @@ class DynFlags:
     use_cond: bool = False     # thermostruct%use_cond: q_con is transported by d_sw and enters the Riemann solvers' pm2
     moist_kappa: bool = False  # thermostruct%moist_kappa: per-cell cappa in the Riemann solvers (and the remap)
     d_ext: float = 0.02      # external-mode damping (hydrostatic one_grad_p only), fv_arrays.F90:452
+    inline_q: bool = False   # tracers advected inside d_sw every substep instead of tracer_2d (sw_core.F90:1020-1043), fv_arrays.F90:474
     beta: float = 0.0        # > 0: split_p_grad / grad1_p_update (time-off-centred hydrostatic pressure gradient), fv_arrays.F90:403
     convert_ke: bool = False
     ke_bg: float = 0.0
@@ -161,6 +162,29 @@ class DynCore:
     def _swap(self, name):
         self.d[name], self.d[name + "_nxt"] = self.d[name + "_nxt"], self.d[name]
 
+    # -- inline_q (dyn_core.F90:340 / :573 / :768, sw_core.F90:1020-1043) ------------------------------------------------
+    def _inline_q(self):
+        """the tracers ride inside d_sw: needs the tracer pair of the model step (FvDynamics puts q, q_nxt into self.d)"""
+        return self.fl.inline_q and "q" in self.d
+
+    def _inline_q_fluxes(self):
+        """d_sw writes this substep's delp fluxes into zeroed arrays of their own (the tracers' mass fluxes)"""
+        d = self.d
+        for n, kind in (("fx_s", "FX"), ("fy_s", "FY")):
+            if n not in d:
+                d[n] = self.ctx.zeros(kind, self.npz)
+            d[n].zero()
+        return d["fx_s"], d["fy_s"]
+
+    def _inline_q_transport(self):
+        """after d_sw, before the swap of delp: q -> q_nxt with d_sw's per-substep Courant numbers and fluxes; mfx += fx"""
+        d, fl, ctx = self.d, self.fl, self.ctx
+        nq = d["q"].shape[3]
+        ctx.d_sw_inline_q(nq, fl.hord_tr, int(self.lev["nord_t"][0]), float(self.lev["damp_t"][0]), d["q"], d["q_nxt"], d["delp"],
+                          d["delp_nxt"], d["fx_s"], d["fy_s"], d["crx"], d["cry"], d["xfx"], d["yfx"])
+        ctx.flux_accum(d["mfx"], d["mfy"], d["fx_s"], d["fy_s"])
+        self._swap("q")
+
     # -- the substep loop, hydrostatic branch (dyn_core.F90:313-1286 with hydrostatic = .true., beta = 0) ----------
     def run_hydrostatic(self, bdt: float):
         fl, d, ctx, halo = self.fl, self.d, self.ctx, self.halo
@@ -191,8 +215,12 @@ class DynCore:
             ctx.geopk(fl.ptop, fl.akap, fl.cp_air, d["pe"], d["peln"], d["delpc"], d["pkc"], d["gz"], d["phis"], d["ptc"],
                       d["pkz"], True)                                         # :480-482 (CG)
             ctx.p_grad_c(dt2, d["delpc"], d["pkc"], d["gz"], d["uc"], d["vc"], True)           # :562
+            inline = self._inline_q()
+            if inline:
+                halo.update([(d["q"], "A")])                                  # :341 start ... :573 complete (pack 10)
+            mfx, mfy = self._inline_q_fluxes() if inline else (d["mfx"], d["mfy"])
             dsw_args = (par, d["vt"], d["delp"], d["pt"], d["u"], d["v"], None, d["uc"], d["vc"], d["ua"], d["va"],
-                        d["divgd"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
+                        d["divgd"], mfx, mfy, d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
                         d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], None, None, d["heat_s"], d["diss_e"])
             if halo.overlaps:      # :565 / :578 (pack 9) around the interior of d_sw (:762), as in the nonhydrostatic loop
                 pending = halo.start([(d["uc"], "V"), (d["vc"], "U")], defer=True)
@@ -205,6 +233,8 @@ class DynCore:
                 ctx.d_sw(*dsw_args)                                           # :762
             if heating:
                 ctx.heat_source_accum(d["heat_source"], d["heat_s"])
+            if inline:
+                self._inline_q_transport()
             # external-mode damping field from the delp BEFORE d_sw (:745-747) and d_sw's divergence output (:791-848)
             ctx.divg2_ext(fl.d_ext, d["delp"], d["vt"], d["divg2"])
             for n in ("delp", "pt", "u", "v"):
@@ -272,8 +302,12 @@ class DynCore:
             ctx.riem_solver_c(dt2, self.cn, d["phis"], d["omga"], d["ptc"], d["delpc"], d["gz"], d["pkc"], d["ws3"])  # :531
             ctx.p_grad_c(dt2, d["delpc"], d["pkc"], d["gz"], d["uc"], d["vc"], False)         # :562
             # :565 / :578 (pack 9, CGRID_NE) overlapped with the interior of d_sw (:762): start ... complete
+            inline = self._inline_q()
+            if inline:
+                halo.update([(d["q"], "A")])                                  # :341 start ... :573 complete (pack 10)
+            mfx, mfy = self._inline_q_fluxes() if inline else (d["mfx"], d["mfy"])
             dsw_args = (par, d["vt"], d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"],
-                        d["divgd"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"],
+                        d["divgd"], mfx, mfy, d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"],
                         d["q_con"] if fl.use_cond else None,
                         d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], d["w_nxt"],
                         d["q_con_nxt"] if fl.use_cond else None, d["heat_s"], d["diss_e"])
@@ -288,6 +322,8 @@ class DynCore:
                 ctx.d_sw(*dsw_args)
             if heating:
                 ctx.heat_source_accum(d["heat_source"], d["heat_s"])          # :798-803
+            if inline:
+                self._inline_q_transport()
             for n in ("delp", "pt", "u", "v", "w") + (("q_con",) if fl.use_cond else ()):
                 self._swap(n)
             # :823-825 start / :851-852 complete (packs 1, 11).  Several ranks: the messages stay in flight while update_dz_d

@@ -23,6 +23,7 @@ module fv3_host_mod
   public :: fv3_host_halo, fv3_host_init, fv3_host_init_grid, fv3_host_final, fv3_host_upload, fv3_host_download
   public :: fv3_dyn_core, fv3_dyn_core_hydrostatic, fv3_tracer_2d, fv3_fv_dynamics
   public :: dmalloc, dzero, swap, upload_levels, host_n_con, KIND_A, KIND_U, KIND_V, KIND_B    ! shared with fv3_sphere_mod
+  public :: inline_q_begin, inline_q_end
 
   integer(c_int), parameter :: KIND_A = 0, KIND_U = 1, KIND_V = 2, KIND_B = 3
   integer, parameter :: NG = 3
@@ -47,6 +48,7 @@ module fv3_host_mod
     logical :: hydrostatic = .false.                  ! fv_arrays.F90:366
     real(c_double) :: d_ext = 0.02d0, delt_max = 1.d0 ! :452, :441
     real(c_double) :: beta = 0.d0                     ! :403; > 0: split_p_grad / grad1_p_update
+    logical :: inline_q = .false.                     ! :474; the tracers ride inside d_sw (sw_core.F90:1020-1043)
     logical :: convert_ke = .false.
   end type
 
@@ -66,6 +68,7 @@ module fv3_host_mod
     type(c_ptr) :: crx, xfx, cry, yfx, mfx, mfy, cx, cy, heat_s, diss_e, pk, ws3, ws, pe, peln, ps, pkz
     type(c_ptr) :: divg2, heat_source                 ! external-mode damping field (A), accumulated heat source (A x npz)
     type(c_ptr) :: du = c_null_ptr, dv = c_null_ptr   ! beta > 0: the saved hydrostatic pressure gradient (dyn_core.F90:278-283)
+    type(c_ptr) :: fx_s = c_null_ptr, fy_s = c_null_ptr ! inline_q: the delp fluxes of one substep (FX / FY x npz)
     real(c_double), allocatable :: ak(:), bk(:)
   end type
 
@@ -240,6 +243,9 @@ contains
     call dmalloc(at%divg2, at%nA);    call dmalloc(at%heat_source, at%nA*nk)
     call dzero(at, at%divg2, at%nA);  call dzero(at, at%heat_source, at%nA*nk); call dzero(at, at%pkz, at%nCC*nk)
     call dmalloc(at%dp1, at%nA*nk);   call dmalloc(at%dp1_n, at%nA*nk)
+    if (fl%inline_q .and. nq > 0) then
+      call dmalloc(at%fx_s, at%nFX*nk); call dmalloc(at%fy_s, at%nFY*nk)
+    end if
     if (fl%beta < 0.d0) error stop 'fv3_host_mod: beta < 0 (one_grad_p in the nonhydrostatic loop) is not built'
     if (fl%beta > 1.d-9) then
       call dmalloc(at%du, at%nU*nk); call dmalloc(at%dv, at%nV*nk)
@@ -394,7 +400,7 @@ contains
     integer :: it, n_split, npz
     logical :: remap_step
     integer(c_int) :: last_call, use_logp
-    type(c_ptr) :: ctx
+    type(c_ptr) :: ctx, fxp, fyp
     logical :: heating
     integer :: n_con
     if (at%fl%hydrostatic) then
@@ -436,10 +442,12 @@ contains
                      'riem_solver_c')                                                     ! :531
       call fv3_check(fv3_p_grad_c(ctx, dt2, at%delpc, at%pkc, at%gz, at%uc, at%vc, 0_c_int), 'p_grad_c')    ! :562
       call halo(at, at%uc, KIND_V, npz); call halo(at, at%vc, KIND_U, npz)                ! :565 / :578 (pack 9, CGRID_NE)
+      call inline_q_begin(at, fxp, fyp)
       call fv3_check(fv3_d_sw(ctx, par, at%vt, at%delp, at%pt, at%u, at%v, at%w, at%uc, at%vc, at%ua, at%va, at%divgd, &
-                              at%mfx, at%mfy, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
+                              fxp, fyp, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
                               at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, c_null_ptr, at%heat_s, at%diss_e), 'd_sw')  ! :762
       if (heating) call fv3_check(fv3_heat_source_accum(ctx, at%heat_source, at%heat_s), 'heat_source_accum')   ! :798-803
+      call inline_q_end(at)
       call swap(at%delp, at%delp_n); call swap(at%pt, at%pt_n)
       call swap(at%u, at%u_n); call swap(at%v, at%v_n); call swap(at%w, at%w_n)
       call halo(at, at%delp, KIND_A, npz); call halo(at, at%pt, KIND_A, npz)              ! :823-824 / :851 (pack 1)
@@ -502,7 +510,7 @@ contains
     real(c_double) :: dt, dt2, ptk
     integer :: it, n_split, npz, n_con
     logical :: heating
-    type(c_ptr) :: ctx, dv2
+    type(c_ptr) :: ctx, dv2, fxp, fyp
     ctx = at%ctx; npz = at%npz
     n_split = at%fl%n_split
     dt = bdt / real(n_split, c_double)
@@ -527,10 +535,12 @@ contains
                                at%phis, at%ptc, at%pkz, 1_c_int), 'geopk (C grid)')
       call fv3_check(fv3_p_grad_c(ctx, dt2, at%delpc, at%pkc, at%gz, at%uc, at%vc, 1_c_int), 'p_grad_c')
       call halo(at, at%uc, KIND_V, npz); call halo(at, at%vc, KIND_U, npz)
+      call inline_q_begin(at, fxp, fyp)
       call fv3_check(fv3_d_sw(ctx, par, at%vt, at%delp, at%pt, at%u, at%v, c_null_ptr, at%uc, at%vc, at%ua, at%va, at%divgd, &
-                              at%mfx, at%mfy, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
+                              fxp, fyp, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
                               at%delp_n, at%pt_n, at%u_n, at%v_n, c_null_ptr, c_null_ptr, at%heat_s, at%diss_e), 'd_sw')
       if (heating) call fv3_check(fv3_heat_source_accum(ctx, at%heat_source, at%heat_s), 'heat_source_accum')
+      call inline_q_end(at)
       ! the external-mode damping field from the delp BEFORE d_sw (:745-747) and d_sw's divergence output (:791-848)
       call fv3_check(fv3_divg2_ext(ctx, at%fl%d_ext, at%delp, at%vt, at%divg2), 'divg2_ext')
       call swap(at%delp, at%delp_n); call swap(at%pt, at%pt_n); call swap(at%u, at%u_n); call swap(at%v, at%v_n)
@@ -622,7 +632,7 @@ contains
     do n_map = 1, at%fl%k_split
       call fv3_check(fv3_memcpy_d2d(at%ctx, at%dp1, at%delp, at%nA * at%npz * 8_c_size_t), 'dp1 = delp')   ! :475-481
       call fv3_dyn_core(at, mdt)                                                                           ! :493
-      if (at%nq > 0) call fv3_tracer_2d(at)                                                                ! :500-533
+      if (at%nq > 0 .and. .not. at%fl%inline_q) call fv3_tracer_2d(at)                                     ! :509-533
       rp%last_step = merge(1_c_int, 0_c_int, last_step .and. n_map == at%fl%k_split)
       if (at%fl%hydrostatic) then
         call fv3_check(fv3_lagrangian_to_eulerian(at%ctx, rp, kord_tr, at%ps, at%pe, at%delp, at%pkz, at%pk, at%u, at%v, &
@@ -634,6 +644,36 @@ contains
                        'lagrangian_to_eulerian')                                                           ! :607
       end if
     end do
+  end subroutine
+
+  !> inline_q (dyn_core.F90:340 / :573 / :768, sw_core.F90:1020-1043), before d_sw: the halo of q; d_sw gets zeroed flux arrays
+  !> of its own (fxp, fyp) so that they hold this substep's delp fluxes afterwards.  Without inline_q: fxp, fyp = mfx, mfy
+  subroutine inline_q_begin(at, fxp, fyp, skip_halo)
+    type(fv3_atmos), intent(inout) :: at
+    type(c_ptr), intent(out) :: fxp, fyp
+    logical, intent(in), optional :: skip_halo       ! the caller exchanged q itself (the six faces of the sphere)
+    logical :: do_halo
+    fxp = at%mfx; fyp = at%mfy
+    if (.not. (at%fl%inline_q .and. at%nq > 0)) return
+    do_halo = .true.
+    if (present(skip_halo)) do_halo = .not. skip_halo
+    if (do_halo) call halo(at, at%q, KIND_A, at%npz * at%nq)                                  ! :341 start ... :573 complete
+    call dzero(at, at%fx_s, at%nFX * at%npz); call dzero(at, at%fy_s, at%nFY * at%npz)
+    fxp = at%fx_s; fyp = at%fy_s
+  end subroutine
+
+  !> ... after d_sw and before the swap of delp: q -> q_n, mfx += fx
+  subroutine inline_q_end(at)
+    type(fv3_atmos), intent(inout) :: at
+    real(c_double) :: damp_t
+    integer(c_int) :: nord_t
+    if (.not. (at%fl%inline_q .and. at%nq > 0)) return
+    nord_t = int(min(2, at%fl%nord), c_int)                                                   ! dyn_core.F90:679, :690
+    damp_t = merge(at%fl%vtdm4, 0.d0, at%fl%do_vort_damp)                                     ! :683-687, :692
+    call fv3_check(fv3_d_sw_inline_q(at%ctx, int(at%nq, c_int), int(at%fl%hord_tr, c_int), nord_t, damp_t, at%q, at%q_n, &
+                                     at%delp, at%delp_n, at%fx_s, at%fy_s, at%crx, at%cry, at%xfx, at%yfx), 'd_sw_inline_q')
+    call fv3_check(fv3_flux_accum(at%ctx, at%mfx, at%mfy, at%fx_s, at%fy_s), 'flux_accum')
+    call swap(at%q, at%q_n)
   end subroutine
 
   subroutine fv3_host_final(at)

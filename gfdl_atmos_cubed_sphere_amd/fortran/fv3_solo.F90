@@ -36,7 +36,8 @@ program fv3_solo
   close(un)
 
   fl%n_split = n_split; fl%k_split = k_split; fl%ptop = ptop
-  fl%hydrostatic = hydrostatic /= 0; fl%d_con = d_con; fl%d_ext = d_ext; fl%beta = beta
+  fl%hydrostatic = iand(hydrostatic, 1_c_int) /= 0; fl%inline_q = iand(hydrostatic, 2_c_int) /= 0    ! bit 1: inline_q
+  fl%d_con = d_con; fl%d_ext = d_ext; fl%beta = beta
   call fv3_host_init(at, int(nx), int(ny), int(npz), int(nq), dx, dy, f0, fl, ak, bk)
   write(*,'(a,i0)') 'fv3_solo: gridstruct geometry mode ', fv3_grid_geom(at%ctx)
   if (nq > 0) then

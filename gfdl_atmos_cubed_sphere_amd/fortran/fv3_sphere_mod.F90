@@ -122,14 +122,15 @@ contains
     logical, intent(in) :: end_step
     type(fv3_dsw_params) :: par
     real(c_double) :: dt, dt2, rdt, ptk, peln1, top
-    integer :: it, n_split, npz, i, n_con
+    integer :: it, n_split, npz, i, n_con, nq
     logical :: remap_step, heating, hyd
     integer(c_int) :: last_call, use_logp, ihyd
-    type(c_ptr) :: dv2
+    type(c_ptr) :: dv2, fxp, fyp
     type(fv3_flags) :: fl
     integer, parameter :: A = FV3_CUBE_A, B = FV3_CUBE_B, D = FV3_CUBE_D, C = FV3_CUBE_C, DE = FV3_CUBE_DEDGE
     fl = sp%f(1)%fl
     npz = sp%f(1)%npz
+    nq = sp%f(1)%nq
     hyd = fl%hydrostatic
     ihyd = merge(1_c_int, 0_c_int, hyd)
     n_split = fl%n_split
@@ -192,18 +193,21 @@ contains
         end associate
       end do
       call exchange(sp, 1, [C], [8], [9], [npz])                                          ! uc, vc: :565 / :578 (pack 9, CGRID_NE)
+      if (fl%inline_q .and. nq > 0) call exchange(sp, 1, [A], [12], [0], [npz * nq])       ! q: :341 / :573 (pack 10)
       do i = 1, sp%nf
         associate (at => sp%f(i))
+          call inline_q_begin(at, fxp, fyp, skip_halo=.true.)
           if (hyd) then
             call fv3_check(fv3_d_sw(at%ctx, par, at%vt, at%delp, at%pt, at%u, at%v, c_null_ptr, at%uc, at%vc, at%ua, at%va, at%divgd, &
-                                    at%mfx, at%mfy, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
+                                    fxp, fyp, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
                                     at%delp_n, at%pt_n, at%u_n, at%v_n, c_null_ptr, c_null_ptr, at%heat_s, at%diss_e), 'd_sw')
           else
             call fv3_check(fv3_d_sw(at%ctx, par, at%vt, at%delp, at%pt, at%u, at%v, at%w, at%uc, at%vc, at%ua, at%va, at%divgd, &
-                                    at%mfx, at%mfy, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
+                                    fxp, fyp, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
                                     at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, c_null_ptr, at%heat_s, at%diss_e), 'd_sw')  ! :762
           end if
           if (heating) call fv3_check(fv3_heat_source_accum(at%ctx, at%heat_source, at%heat_s), 'heat_source_accum')   ! :798-803
+          call inline_q_end(at)
           if (hyd) call fv3_check(fv3_divg2_ext(at%ctx, fl%d_ext, at%delp, at%vt, at%divg2), 'divg2_ext')          ! :745-747, :791-848
           call swap(at%delp, at%delp_n); call swap(at%pt, at%pt_n)
           call swap(at%u, at%u_n); call swap(at%v, at%v_n)
@@ -379,7 +383,7 @@ contains
         end associate
       end do
       call fv3_sphere_dyn_core(sp, mdt, n_map == fl%k_split)                                                      ! :493
-      if (nq > 0) call sphere_tracer_2d(sp, nranks)                                                                ! :500-533
+      if (nq > 0 .and. .not. fl%inline_q) call sphere_tracer_2d(sp, nranks)                                                                ! :500-533
       rp%last_step = merge(1_c_int, 0_c_int, last_step .and. n_map == fl%k_split)
       do i = 1, sp%nf
         associate (at => sp%f(i))

@@ -26,11 +26,14 @@ class FvDynamics:
                  kord_mt: int = 8, kord_wz: int = 8, kord_tr: int = 8, q_split: int = 0, nord_tr: int = 0, trdm2: float = 0.0, adiabatic: bool = True,
                  px: int = 1, py: int = 1, rank: int = 0, world: int = 1, dist=None, tau: float = 0.0,
                  rf_cutoff: float = 30.0e2, c2l_ord: int = 4, moist: dict | None = None, fill: bool = False, halo=None,
-                 consv_te: float = 0.0, moist_phys: bool = False, radius: float = 6.3712e6):
+                 consv_te: float = 0.0, moist_phys: bool = False, radius: float = 6.3712e6, fill2d: tuple = ()):
         ak, bk = np.asarray(ak, dtype=np.float64), np.asarray(bk, dtype=np.float64)
         dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5          # dyn_core.F90:241-244
         self.ctx, self.fl, self.nq, self.k_split, self.q_split, self.dist = ctx, flags, nq, k_split, q_split, dist
         self.nord_tr, self.trdm2 = nord_tr, trdm2
+        # fill2D (fv_dynamics.F90:542-556, FILL2D builds): the 0-based tracer indices of liq_wat, rainwat, ice_wat, snowwat, graupel
+        # that get the diffusive filling after tracer_2d when hord_tr < 8 and moist_phys
+        self.fill2d = tuple(int(i) for i in fill2d)
         self.tau, self.rf_cutoff, self.c2l_ord = tau, rf_cutoff, c2l_ord
         self.ak, self.bk = ak, bk
         self._rf = None                                                    # (rf, pm, kmax): set on first use, as RF_initialized
@@ -187,6 +190,19 @@ class FvDynamics:
             self.dc.halo.update([(d["u"], "U"), (d["v"], "V")])
         self.ctx.c2l(self.c2l_ord, d["u"], d["v"], d["ua"], d["va"])
 
+    def _fill2d(self):
+        """fill2D (fv_fill.F90:183-258) of the water species named at construction: qt = q delp area, its halo (width 1), the fluxes
+        between cells of opposite sign and the update of q"""
+        d, ctx = self.dc.d, self.ctx
+        npz = ctx.npz
+        if "qt" not in d:
+            d["qt"] = ctx.zeros("A", npz)
+        n3 = int(np.prod(d["delp"].shape))
+        for iq in self.fill2d:
+            ctx.fill2d_mass(npz, d["q"], d["delp"], d["qt"], q_offset=iq * n3)
+            self.dc.halo.update([(d["qt"], "A")])                               # :236
+            ctx.fill2d_apply(npz, d["qt"], d["delp"], d["q"], q_offset=iq * n3)
+
     def step(self, bdt: float, last_cycle_is_last_step: bool = False):
         """One dt_atmos: k_split x (n_split acoustic substeps, tracer transport, vertical remap)."""
         d, ctx = self.dc.d, self.ctx
@@ -199,7 +215,7 @@ class FvDynamics:
             if self.fl.moist_kappa:
                 self.dc.halo.update([(d["cappa"], "A")])                       # :465 / :488 (pack 12)
             self.dc.run(mdt, end_step=(n_map == self.k_split))                 # :493, last_step = (n_map == k_split)
-            if self.nq:                                                        # :500-533
+            if self.nq and not self.fl.inline_q:                               # :509-533 (inline_q: the tracers rode inside d_sw)
                 q, dp1, _ = tracer_2d(ctx, self.dc.halo, d["q"], d["q_nxt"], d["dp1"], d["dp1_nxt"], d["mfx"], d["mfy"],
                                       d["cx"], d["cy"], d["crx"], d["cry"], self.nq, self.fl.hord_tr, self.q_split,
                                       self.nord_tr, self.trdm2, dist=self.dist)
@@ -207,6 +223,8 @@ class FvDynamics:
                     d["q"], d["q_nxt"] = d["q_nxt"], d["q"]
                 if dp1 is not d["dp1"]:
                     d["dp1"], d["dp1_nxt"] = d["dp1_nxt"], d["dp1"]
+                if self.fill2d and self.fl.hord_tr < 8 and self.moist_phys:     # :542-556
+                    self._fill2d()
             fixer = last_step and abs(self.consv_te) > CONSV_MIN                # fv_mapz.F90:645-647, :745
             par = dict(self.remap_par, last_step=2 if fixer else int(last_step))
             hyd = self.fl.hydrostatic

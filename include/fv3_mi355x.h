@@ -499,6 +499,25 @@ int fv3_tracer_2d_step(fv3_ctx *ctx, int it, int nsplt, const int *ksplt_host /*
                        const double *mfx, const double *mfy, const double *cx, const double *cy, const double *xfx,
                        const double *yfx);
 
+/* inline_q -- model/sw_core.F90:1020-1043 (flagstruct%inline_q, dyn_core.F90:340, :573, :768): the tracers advected inside d_sw
+ * every acoustic substep instead of tracer_2d on the accumulated fluxes.  Called after fv3_d_sw of the same substep with what that
+ * call produced: crx, cry, xfx, yfx (crx_adv .. yfx_adv), fx / fy = the delp fluxes OF THIS SUBSTEP (hand fv3_d_sw zeroed arrays
+ * as its mfx / mfy and add them to the accumulators with fv3_flux_accum), delp_old / delp_new = d_sw's delp and delp_out.  q (halo
+ * updated, dyn_core.F90:341 / :573) -> q_out on the compute domain, A x npz x nq.  nord_t, damp_t: dyn_core.F90:690-692
+ * (min(2, nord), vtdm4 with do_vort_damp): deln_flux with mass = d_sw's half-updated delp, sw_core.F90:1034. */
+int fv3_d_sw_inline_q(fv3_ctx *ctx, int nq, int hord_tr, int nord_t, double damp_t, const double *q, double *q_out,
+                      const double *delp_old, const double *delp_new, const double *fx, const double *fy, const double *crx,
+                      const double *cry, const double *xfx, const double *yfx);
+/* mfx += fx, mfy += fy (FX / FY x npz): sw_core.F90:949-962 for a d_sw that wrote its fluxes into arrays of their own */
+int fv3_flux_accum(fv3_ctx *ctx, double *mfx, double *mfy, const double *fx, const double *fy);
+
+/* fill2D -- model/fv_fill.F90:183-258, call site fv_dynamics.F90:542-556 (FILL2D builds; hord_tr < 8 and moist_phys): the
+ * diffusive filling of negative tracer mass, one tracer (A x nk) per call pair.  _mass: qt = q * delp * area on the compute
+ * domain (:228-235); the caller updates the halo of qt (width 1, :236); _apply: the sign-change fluxes and the update of q
+ * (:238-256). */
+int fv3_fill2d_mass(fv3_ctx *ctx, int nk, const double *q, const double *delp, double *qt);
+int fv3_fill2d_apply(fv3_ctx *ctx, int nk, const double *qt, const double *delp, double *q);
+
 /* Per-kernel timing with HIP events recorded on the context's stream around every kernel the
  * library launches (this is what bench.py's roofline figures are measured with).  report: one line
  * "label count total_ms" per kernel label since the last report; synchronises the stream. */

@@ -28,7 +28,7 @@
  * Scope of the restated branches: grid_type 4 (doubly periodic) and grid_type < 3 (the cubed sphere, one whole tile per
  * face: the edge / corner branches of c_sw, d_sw, fv_tp_2d, xppm / yppm, xtp_u / ytp_v, a2b_ord4, update_dz_c / _d), with
  * general (array-valued) metric terms, bounded_domain = .false., no nesting, no regional BCs.  Branches that are not
- * restated (remap_te, inline_q, beta > 0, kord_wz < 0) return FVO_ERR_UNSUPPORTED.
+ * restated (remap_te, kord_wz < 0) return FVO_ERR_UNSUPPORTED.
  *
  * Array layout is the reference's (Fortran column-major, i fastest), with the exact
  * lower/upper bounds of model/fv_arrays.F90:1521-1563; see the accessor macros below.
@@ -129,13 +129,18 @@ int fvo_c_sw(const fvo_grid *g, double *delpc, double *delp, double *ptc, double
              double *ut, double *vt, double *divg_d, int nord, double dt2, int hydrostatic,
              int dord4);
 
-/* d_sw, one k-slab (sw_core.F90:494-1606); inline_q=.false., use_cond optional (q_con nullable). */
+/* d_sw, one k-slab (sw_core.F90:494-1606); use_cond optional (q_con nullable). */
 typedef struct fvo_dsw_par {
   double dt;
   int hord_tr, hord_mt, hord_vt, hord_tm, hord_dp;
   int nord, nord_v, nord_w, nord_t;
   double dddmp, d2_bg, d4_bg, damp_v, damp_w, damp_t, d_con, kgb;
   int hydrostatic, use_cond;
+  /* inline_q (sw_core.F90:1020-1043): nq tracers advected inside d_sw.  q: the slab of tracer 0 at this level (fvo_d_sw) / the
+   * A x npz x nq array (fvo_d_sw_3d); q_stride: doubles between tracers */
+  int inline_q, nq;
+  double *q;
+  size_t q_stride;
 } fvo_dsw_par;
 
 int fvo_d_sw(const fvo_grid *g, const fvo_dsw_par *p, double *delpc, double *delp, double *ptc,
@@ -240,6 +245,8 @@ double fvo_moist_cv(const fvo_remap_par *p, const double *qk, size_t ns, double 
 /* ---- tracer_2d (oracle/tracer2d.c) ---------------------------------------------------------------- */
 int fvo_tracer_2d(const fvo_grid *g, int npz, int nq, double *q, double *dp1, double *mfx, double *mfy, double *cx,
                   double *cy, int hord, int q_split, int nord_tr, double trdm);
+void fvo_fill2d_mass(const fvo_grid *g, int km, const double *q, const double *delp, double *qt);
+void fvo_fill2d_apply(const fvo_grid *g, int km, const double *qt, const double *delp, double *q);
 /* the pieces of tracer_2d between its reductions / halo updates (the caller's, for the six faces of the cubed sphere) */
 void fvo_tracer_2d_prep(const fvo_grid *g, int npz, int q_split, const double *cx, const double *cy, double *xfx, double *yfx,
                         double *cmax);

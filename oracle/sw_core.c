@@ -1371,7 +1371,7 @@ void fvo_fill_corners_dgrid(const fvo_grid *g, double *x, double *y, double mySi
 }
 
 /* ------------------------------------------------------------------------------------------
- * d_sw, sw_core.F90:494-1606 (inline_q=.false., do_f3d=.false., grid_type>=3)
+ * d_sw, sw_core.F90:494-1606 (do_f3d=.false.)
  * ---------------------------------------------------------------------------------------- */
 int fvo_d_sw(const fvo_grid *g, const fvo_dsw_par *p, double *delpc, double *delp, double *ptc,
              double *pt, double *u, double *v, double *w, double *uc, double *vc, double *ua,
@@ -1610,6 +1610,29 @@ int fvo_d_sw(const fvo_grid *g, const fvo_dsw_par *p, double *delpc, double *del
   /* :1014-1016 (not GFS_PHYS/DCMIP: nord_t, damp_t) */
   fvo_fv_tp_2d(g, pt, crx_adv, cry_adv, p->hord_tm, gx, gy, xfx_adv, yfx_adv, ra_x, ra_y, fx, fy, delp, nord_t,
                damp_t);
+  if (p->inline_q) { /* :1020-1043 */
+    double *wq = dalloc(nA);
+    int iq;
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie; i++) {
+        wq[IA(i, j)] = delp[IA(i, j)];
+        delp[IA(i, j)] = wq[IA(i, j)] + (fx[IFX(i, j)] - fx[IFX(i + 1, j)] + fy[IFY(i, j)] - fy[IFY(i, j + 1)]) * g->rarea[IA(i, j)];
+        pt[IA(i, j)] = (pt[IA(i, j)] * wq[IA(i, j)] +
+                        (gx[IFX(i, j)] - gx[IFX(i + 1, j)] + gy[IFY(i, j)] - gy[IFY(i, j + 1)]) * g->rarea[IA(i, j)]) /
+                       delp[IA(i, j)];
+      }
+    for (iq = 0; iq < p->nq; iq++) {
+      double *q = p->q + (size_t)iq * p->q_stride;
+      /* mass = delp: the compute domain already holds the new values, the halo the old ones */
+      fvo_fv_tp_2d(g, q, crx_adv, cry_adv, p->hord_tr, gx, gy, xfx_adv, yfx_adv, ra_x, ra_y, fx, fy, delp, nord_t, damp_t);
+      for (j = js; j <= je; j++)
+        for (i = is; i <= ie; i++)
+          q[IA(i, j)] = (q[IA(i, j)] * wq[IA(i, j)] +
+                         (gx[IFX(i, j)] - gx[IFX(i + 1, j)] + gy[IFY(i, j)] - gy[IFY(i, j + 1)]) * g->rarea[IA(i, j)]) /
+                        delp[IA(i, j)];
+    }
+    free(wq);
+  } else
   /* :1053-1066 */
   for (j = js; j <= je; j++)
     for (i = is; i <= ie; i++) {
@@ -1943,6 +1966,7 @@ int fvo_d_sw_3d(const fvo_grid *g, int npz, const fvo_dsw_par *p, const fvo_dsw_
     pk.damp_w = lv->damp_w[k];
     pk.damp_t = lv->damp_t[k];
     pk.d_con = lv->d_con_k[k];
+    if (p->inline_q) pk.q = p->q + k * nA;
     int r = fvo_d_sw(g, &pk, delpc + k * nA, delp + k * nA, ptc + k * nA, pt + k * nA, u + k * nU, v + k * nV,
                      p->hydrostatic ? NULL : w + k * nA, uc + k * nV, vc + k * nU, ua + k * nA, va + k * nA,
                      divg_d + k * nB, mfx + k * nFX, mfy + k * nFY, cx + k * nCX, cy + k * nCY, crx + k * nCX,

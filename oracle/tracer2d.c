@@ -176,3 +176,37 @@ int fvo_tracer_2d(const fvo_grid *g, int npz, int nq, double *q, double *dp1, do
   free(xfx); free(yfx); free(cmax); free(frac); free(ksplt);
   return nsplt;
 }
+
+
+/* fill2D (model/fv_fill.F90:183-258), in the two halves around its mpp_update_domains (the caller's) */
+void fvo_fill2d_mass(const fvo_grid *g, int km, const double *q, const double *delp, double *qt) { /* :228-235 */
+  DIMS;
+  int i, j, k;
+  for (k = 1; k <= km; k++)
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie; i++) qt[nA * (k - 1) + IA(i, j)] = q[nA * (k - 1) + IA(i, j)] * delp[nA * (k - 1) + IA(i, j)] * g->area[IA(i, j)];
+}
+void fvo_fill2d_apply(const fvo_grid *g, int km, const double *qt, const double *delp, double *q) { /* :238-256 */
+  DIMS;
+  const double dif = 0.25;
+  int i, j, k;
+  double *fx = dalloc((size_t)(nx + 1) * ny), *fy = dalloc((size_t)nx * (ny + 1));
+  for (k = 1; k <= km; k++) {
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie + 1; i++) {
+        fx[IFX(i, j)] = 0.;
+        if (qt[nA * (k - 1) + IA(i - 1, j)] * qt[nA * (k - 1) + IA(i, j)] < 0.) fx[IFX(i, j)] = qt[nA * (k - 1) + IA(i - 1, j)] - qt[nA * (k - 1) + IA(i, j)];
+      }
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie; i++) {
+        fy[IFY(i, j)] = 0.;
+        if (qt[nA * (k - 1) + IA(i, j - 1)] * qt[nA * (k - 1) + IA(i, j)] < 0.) fy[IFY(i, j)] = qt[nA * (k - 1) + IA(i, j - 1)] - qt[nA * (k - 1) + IA(i, j)];
+      }
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie; i++)
+        q[nA * (k - 1) + IA(i, j)] = q[nA * (k - 1) + IA(i, j)] + dif * (fx[IFX(i, j)] - fx[IFX(i + 1, j)] + fy[IFY(i, j)] - fy[IFY(i, j + 1)]) /
+                                              (delp[nA * (k - 1) + IA(i, j)] * g->area[IA(i, j)]);
+  }
+  free(fx);
+  free(fy);
+}

@@ -228,12 +228,16 @@ def oracle_substeps_hydro(cs, gs, fl, st, bdt, npz):
             O.geopk(gs[t], npz, fl.ptop, fl.akap, fl.cp_air, x["pe"], x["peln"], x["delpc"], x["pkc"], x["gz"], x["phis"], x["ptc"], x["pkz"], True)
             O.p_grad_c(gs[t], npz, dt2, x["delpc"], x["pkc"], x["gz"], x["uc"], x["vc"], True)
         exchange_pair(cs, f, "uc", "vc", "C")
+        if fl.inline_q and "q" in f[0]:
+            exchange(cs, f, ("q",), "A")                                       # dyn_core.F90:341 / :573 (pack 10)
         for t in range(6):
             x = f[t]
             ds = dict(delpc=x["vt"], delp=x["delp"], ptc=x["ptc"], pt=x["pt"], u=x["u"], v=x["v"], uc=x["uc"], vc=x["vc"], ua=x["ua"],
                       va=x["va"], divg_d=x["divgd"], mfx=x["mfx"], mfy=x["mfy"], cx=x["cx"], cy=x["cy"], crx=x["crx"], cry=x["cry"],
                       xfx=x["xfx"], yfx=x["yfx"], heat_source=x["heat_s"], diss_est=x["diss_e"])
             delp_old = x["delp"].copy(order="F")
+            if fl.inline_q and "q" in x:                                     # sw_core.F90:1020-1043
+                ds["inline_q"] = x["q"]
             O.d_sw_3d(gs[t], npz, par, lev, ds)
             if heating:
                 x["heat_source"][i0:i0 + nx, j0:j0 + ny, :] += x["heat_s"]
@@ -341,6 +345,8 @@ def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
             O.riem_solver_c(gs[t], npz, dt2, cn, x["phis"], x["omga"], x["ptc"], x["delpc"], x["gz"], x["pkc"], x["ws3"], qc(x), cap(x))
             O.p_grad_c(gs[t], npz, dt2, x["delpc"], x["pkc"], x["gz"], x["uc"], x["vc"], False)
         exchange_pair(cs, f, "uc", "vc", "C")
+        if fl.inline_q and "q" in f[0]:
+            exchange(cs, f, ("q",), "A")                                       # dyn_core.F90:341 / :573 (pack 10)
         for t in range(6):
             x = f[t]
             ds = dict(delpc=x["vt"], delp=x["delp"], ptc=x["ptc"], pt=x["pt"], u=x["u"], v=x["v"], w=x["w"], uc=x["uc"], vc=x["vc"],
@@ -348,6 +354,8 @@ def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
                       cry=x["cry"], xfx=x["xfx"], yfx=x["yfx"], heat_source=x["heat_s"], diss_est=x["diss_e"])
             if fl.use_cond:
                 ds["q_con"] = x["q_con"]
+            if fl.inline_q and "q" in x:                                     # sw_core.F90:1020-1043
+                ds["inline_q"] = x["q"]
             O.d_sw_3d(gs[t], npz, par, lev, ds)
             if fl.d_con > 1.0e-5:
                 x["heat_source"][ng:ng + nx, ng:ng + ny, :] += x["heat_s"]
@@ -383,13 +391,27 @@ def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
     return f
 
 
+def _oracle_fill2d(cs, gs, npz, q, delp, which):
+    """fill2D after tracer_2d (fv_dynamics.F90:542-556) on six faces: qt = q delp area, its halo, the sign-change fluxes"""
+    bd = gs[0].bd
+    for iq in which:
+        qi = [np.asfortranarray(q[t][:, :, :, iq]) for t in range(6)]
+        qt = [bd.zeros("A", npz) for _ in range(6)]
+        for t in range(6):
+            O.fill2d_mass(gs[t], npz, qi[t], delp[t], qt[t])
+        cs.topo.update("A", qt)
+        for t in range(6):
+            O.fill2d_apply(gs[t], npz, qt[t], delp[t], qi[t])
+            q[t][:, :, :, iq] = qi[t]
+
+
 def _oracle_tracers(cs, gs, fl, npz, q, dp1, f):
     nq = q[0].shape[3]
     oracle_tracer_2d(cs, gs, npz, nq, q, dp1, [x["mfx"] for x in f], [x["mfy"] for x in f], [x["cx"] for x in f],
                      [x["cy"] for x in f], fl.hord_tr, 0)
 
 
-def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz, q=None, last_step=0):
+def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz, q=None, last_step=0, fill2d=()):
     """hydrostatic k_split loop on six faces over the oracle: dyn_core substeps -> tracer_2d -> Lagrangian_to_Eulerian"""
     mdt = bdt / float(k_split)
     cur = [{k: s[k].copy(order="F") for k in ("u", "v", "delp", "pt", "phis")} for s in st]
@@ -398,9 +420,15 @@ def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz, q
     bd = gs[0].bd
     for n_map in range(1, k_split + 1):
         dp1 = [c["delp"].copy(order="F") for c in cur]
+        if fl.inline_q and q is not None:
+            for t in range(6):
+                cur[t]["q"] = q[t]
         f = oracle_substeps_hydro(cs, gs, fl, cur, mdt, npz)
-        if q is not None:
+        if fl.inline_q and q is not None:
+            q = [x["q"] for x in f]
+        elif q is not None:
             _oracle_tracers(cs, gs, fl, npz, q, dp1, f)
+            _oracle_fill2d(cs, gs, npz, q, [x["delp"] for x in f], fill2d if fl.hord_tr < 8 else ())
         out = []
         for t in range(6):
             x = f[t]
@@ -415,7 +443,7 @@ def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz, q
     return out
 
 
-def oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, remap_par, npz, q=None, last_step=False):
+def oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, remap_par, npz, q=None, last_step=False, fill2d=()):
     """nonhydrostatic k_split loop on six faces over the oracle: dyn_core substeps -> tracer_2d -> Lagrangian_to_Eulerian.
     With fl.use_cond / fl.moist_kappa the faces carry q_con / cappa (halo updates at fv_dynamics.F90:464-465 / :487-488)."""
     mdt = bdt / float(k_split)
@@ -428,9 +456,15 @@ def oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, remap_par, n
         dp1 = [c["delp"].copy(order="F") for c in cur]
         if moist_names:
             exchange(cs, cur, moist_names, "A")
+        if fl.inline_q and q is not None:
+            for t in range(6):
+                cur[t]["q"] = q[t]
         f = oracle_substeps_nh(cs, gs, fl, dp_ref, cur, mdt, npz)
-        if q is not None:
+        if fl.inline_q and q is not None:
+            q = [x["q"] for x in f]
+        elif q is not None:
             _oracle_tracers(cs, gs, fl, npz, q, dp1, f)
+            _oracle_fill2d(cs, gs, npz, q, [x["delp"] for x in f], fill2d if fl.hord_tr < 8 else ())
         out = []
         for t in range(6):
             x = f[t]

@@ -27,9 +27,9 @@ def build_solo(workdir, libdir=CSRC, libname="fv3_mi355x"):
 
 
 def write_input(path, bd, npz, nq, n_split, k_split, nsteps, last_step, dx, dy, f0, bdt, ptop, ak, bk, st, q, hydrostatic=False,
-                d_con=0.0, d_ext=0.02, beta=0.0):
+                d_con=0.0, d_ext=0.02, beta=0.0, inline_q=False):
     with open(path, "wb") as f:
-        np.array([bd.nx, bd.ny, npz, nq, n_split, k_split, nsteps, int(last_step), int(hydrostatic)], dtype=np.int32).tofile(f)
+        np.array([bd.nx, bd.ny, npz, nq, n_split, k_split, nsteps, int(last_step), int(hydrostatic) + 2 * int(inline_q)], dtype=np.int32).tofile(f)
         np.array([dx, dy, f0, bdt, ptop, d_con, d_ext, beta], dtype=np.float64).tofile(f)
         np.asarray(ak, dtype=np.float64).tofile(f)
         np.asarray(bk, dtype=np.float64).tofile(f)
@@ -52,7 +52,7 @@ def read_output(path, bd, npz, nq):
 
 
 def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, host_comm=False,
-                       hydrostatic=False, d_con=0.0, beta=0.0):
+                       hydrostatic=False, d_con=0.0, beta=0.0, inline_q=False):
     """the same initial state through (a) the Python host and (b) the Fortran host: bit-identical states"""
     import parity_common as P
     import parity_dyn as D
@@ -68,7 +68,7 @@ def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_sp
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
     rng = np.random.default_rng(5)
     q = np.asfortranarray(rng.uniform(0.0, 1.0, bd.shape("A", npz) + (nq,))) if nq else None
-    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, d_con=d_con, beta=beta)
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, d_con=d_con, beta=beta, inline_q=inline_q)
     # ---- (a) Python host ----
     ctx = Context(g, npz, lib=lib)
     try:
@@ -88,7 +88,7 @@ def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_sp
     exe = build_solo(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
     fin, fout = os.path.join(str(workdir), "in.bin"), os.path.join(str(workdir), "out.bin")
     write_input(fin, bd, npz, nq, n_split, k_split, nsteps, False, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak,
-                bk, st, q, hydrostatic=hydrostatic, d_con=d_con, d_ext=fl.d_ext, beta=beta)
+                bk, st, q, hydrostatic=hydrostatic, d_con=d_con, d_ext=fl.d_ext, beta=beta, inline_q=inline_q)
     env = dict(os.environ, **({"FV3_HOST_COMM": "1"} if host_comm else {}))
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -258,7 +258,8 @@ _GH_V = ["dy", "rdy", "dxc", "rdxc", "cosa_u", "sina_u", "rsin_u", "divg_v", "de
 _GH_B = ["rarea_c", "fC", "cosa", "sina"]
 
 
-def check_fortran_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2, nsteps=1, bdt=900.0, hydrostatic=False, d_con=0.0, beta=0.0):
+def check_fortran_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2, nsteps=1, bdt=900.0, hydrostatic=False, d_con=0.0, beta=0.0,
+                         inline_q=False):
     """the Jablonowski-Williamson state on the six faces through (a) the Python host (FvDynamics over MultiContext, device-gather halo
     updates) and (b) the Fortran host (fv3_sphere_mod: one context per face, every halo update through the cube-edge exchange behind
     the C ABI, mpp_get_boundary after the last substep, adv_pe): bit-identical states on every face"""
@@ -275,7 +276,7 @@ def check_fortran_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=
     ak, bk = 300.0 * (1.0 - sig), sig.copy()
     st = cs.jablonowski_williamson(ak, bk, hydrostatic=hydrostatic, rdgas=L.RDGAS, grav=L.GRAV)
     CC.exchange(cs, st, ("phis",), "A")
-    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, ptop=float(ak[0]), d_con=d_con, beta=beta, **(dict(d_ext=0.0) if hydrostatic else {}))
+    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, ptop=float(ak[0]), d_con=d_con, beta=beta, inline_q=inline_q, **(dict(d_ext=0.0) if hydrostatic else {}))
     bd = gs[0].bd
     ng = bd.ng
     c = (slice(ng, ng + nx), slice(ng, ng + nx))
@@ -312,7 +313,7 @@ def check_fortran_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=
     fin, fout = os.path.join(str(workdir), "sph_in.bin"), os.path.join(str(workdir), "sph_out.bin")
     F = lambda a: np.asfortranarray(a, dtype=np.float64).ravel(order="F")      # noqa: E731
     with open(fin, "wb") as f:
-        np.array([npx, npz, nq, n_split, k_split, nsteps, 0, int(hydrostatic), fl.nord], dtype=np.int32).tofile(f)
+        np.array([npx, npz, nq, n_split, k_split, nsteps, 0, int(hydrostatic) + 2 * int(inline_q), fl.nord], dtype=np.int32).tofile(f)
         np.array([bdt, fl.ptop, d_con, fl.d_ext, gs[0].da_min, gs[0].da_min_c, fl.d4_bg, fl.beta], dtype=np.float64).tofile(f)
         np.asarray(ak, dtype=np.float64).tofile(f)
         np.asarray(bk, dtype=np.float64).tofile(f)

@@ -13,6 +13,9 @@ from gfdl_atmos_cubed_sphere_amd.layout import Bounds, periodic_fill
 def _fill(bd, a, kind):
     if a.ndim == 2:
         periodic_fill(bd, a, kind)
+    elif a.ndim == 4:
+        for n in range(a.shape[3]):
+            _fill(bd, a[:, :, :, n], kind)
     else:
         for k in range(a.shape[2]):
             periodic_fill(bd, a[:, :, k], kind)
@@ -80,6 +83,9 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
                   diss_est=f["diss_e"])
         if fl.use_cond:
             ds["q_con"] = f["q_con"]
+        if fl.inline_q and "q" in f:                                       # dyn_core.F90:341 / :573, sw_core.F90:1020-1043
+            _fill(bd, f["q"], "A")
+            ds["inline_q"] = f["q"]
         O.d_sw_3d(g, npz, par, lev, ds)
         if fl.use_cond:
             _fill(bd, f["q_con"], "A")                                       # dyn_core.F90:825 / :852
@@ -168,6 +174,9 @@ def run_hydrostatic(g, npz: int, fl: DynFlags, st: dict, bdt: float):
         ds = dict(delpc=f["vt"], delp=f["delp"], ptc=f["ptc"], pt=f["pt"], u=f["u"], v=f["v"], uc=f["uc"], vc=f["vc"],
                   ua=f["ua"], va=f["va"], divg_d=f["divgd"], mfx=f["mfx"], mfy=f["mfy"], cx=f["cx"], cy=f["cy"],
                   crx=f["crx"], cry=f["cry"], xfx=f["xfx"], yfx=f["yfx"], heat_source=f["heat_s"], diss_est=f["diss_e"])
+        if fl.inline_q and "q" in f:
+            _fill(bd, f["q"], "A")
+            ds["inline_q"] = f["q"]
         O.d_sw_3d(g, npz, par, lev, ds)
         if heating:
             f["heat_source"][i0:i0 + nx, j0:j0 + ny, :] += f["heat_s"]

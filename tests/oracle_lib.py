@@ -44,7 +44,8 @@ class DswPar(C.Structure):
                                         "nord_w", "nord_t"]] + [(n, C.c_double) for n in
                                                                 ["dddmp", "d2_bg", "d4_bg", "damp_v", "damp_w",
                                                                  "damp_t", "d_con", "kgb"]] + [
-                   ("hydrostatic", C.c_int), ("use_cond", C.c_int)]
+                   ("hydrostatic", C.c_int), ("use_cond", C.c_int), ("inline_q", C.c_int), ("nq", C.c_int), ("q", _dp),
+                   ("q_stride", C.c_size_t)]
 
 
 class DswLevels(C.Structure):
@@ -169,6 +170,10 @@ def d_sw_3d(g, npz, par: dict, lev: dict, f):
     pr = DswPar()
     for k, v in par.items():
         setattr(pr, k, v)
+    if f.get("inline_q") is not None:     # inline_q (sw_core.F90:1020-1043): A x npz x nq, advected in place
+        q = f["inline_q"]
+        assert q.flags.f_contiguous and q.ndim == 4 and q.shape[2] == npz
+        pr.inline_q, pr.nq, pr.q, pr.q_stride = 1, q.shape[3], p(q), q.shape[0] * q.shape[1] * q.shape[2]
     lv = DswLevels()
     keep = []
     for n in ["nord_k", "nord_v", "nord_w", "nord_t"]:
@@ -267,6 +272,16 @@ def grad1_p_update(g, npz, divg2, u, v, pk, gz, dt, ptk, beta, du, dv):
     gs = make_grid(g)
     assert lib().fvo_grad1_p_update(C.byref(gs), C.c_int(npz), p(divg2), p(u), p(v), p(pk), p(gz), _d(dt), _d(ptk), _d(beta),
                                     p(du), p(dv)) == 0
+
+
+def fill2d_mass(g, km, q, delp, qt):
+    gs = make_grid(g)
+    lib().fvo_fill2d_mass(C.byref(gs), C.c_int(km), p(q), p(delp), p(qt))
+
+
+def fill2d_apply(g, km, qt, delp, q):
+    gs = make_grid(g)
+    lib().fvo_fill2d_apply(C.byref(gs), C.c_int(km), p(qt), p(delp), p(q))
 
 
 def del2_cubed(g, km, cd, nmax, q):

@@ -50,3 +50,39 @@ def check_tracer_2d(lib, nx=40, ny=19, npz=4, nq=3, hord=8, q_split=0, trdm=0.0,
     finally:
         ctx.close()
     return worst, nsplt
+
+
+def check_fill2d(lib, nx=40, ny=19, npz=4, grid=None, halo_fill=None):
+    """fill2D (fv_fill.F90:183-258) on a tracer with negative patches: the two kernels around the halo update of qt against the
+    oracle's two halves; halo_fill(qt) fills the halo of a host array (default: the doubly periodic fill)"""
+    bd = grid.bd if grid is not None else Bounds(1, nx, 1, ny)
+    g = grid if grid is not None else P.make_grid(bd, False)
+    rng = np.random.default_rng(31)
+    q = np.asfortranarray(rng.uniform(-0.3, 1.0, bd.shape("A", npz)))
+    delp = np.asfortranarray(rng.uniform(500.0, 1500.0, bd.shape("A", npz)))
+    if halo_fill is None:
+        def halo_fill(a):
+            for k in range(a.shape[2]):
+                periodic_fill(bd, a[:, :, k], "A")
+    ref, qt = q.copy(order="F"), bd.zeros("A", npz)
+    O.fill2d_mass(g, npz, ref, delp, qt)
+    halo_fill(qt)
+    O.fill2d_apply(g, npz, qt, delp, ref)
+    ctx = Context(g, npz, lib=lib)
+    try:
+        d_q, d_dp, d_qt = ctx.from_host(q), ctx.from_host(delp), ctx.zeros("A", npz)
+        ctx.fill2d_mass(npz, d_q, d_dp, d_qt)
+        h = d_qt.download()
+        halo_fill(h)
+        d_qt.upload(h)
+        ctx.fill2d_apply(npz, d_qt, d_dp, d_q)
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        got = d_q.download()
+        assert np.any(got != q)
+        # the filling moves mass between neighbours: the total of q delp area is what it was (to rounding)
+        area = bd.view(g.m["area"], "A", *r)[:, :, None]
+        m0, m1 = (bd.view(q, "A", *r) * bd.view(delp, "A", *r) * area).sum(), (bd.view(got, "A", *r) * bd.view(delp, "A", *r) * area).sum()
+        assert abs(m1 - m0) <= 1e-12 * abs(m0) or grid is not None
+        return P.assert_close("q", bd.view(got, "A", *r), bd.view(ref, "A", *r), 1e-15)
+    finally:
+        ctx.close()

@@ -139,6 +139,30 @@ def test_split_p_grad_and_grad1_p_update(emu):
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
 
 
+def test_inline_q(emu):
+    """inline_q (sw_core.F90:1020-1043): the tracers inside d_sw every substep, nonhydrostatic and hydrostatic, with and without the
+    del-n damping whose mass is d_sw's half-updated delp; doubly periodic and sphere"""
+    D.check_fv_step(emu, n_split=3, flags=dict(inline_q=True))
+    D.check_fv_step(emu, nq=3, flags=dict(inline_q=True, do_vort_damp=True, vtdm4=0.06, nord=2, hord_tr=5))
+    D.check_fv_step_hydrostatic(emu, n_split=3, flags=dict(inline_q=True))
+    D.check_fv_step_hydrostatic(emu, flags=dict(inline_q=True, do_vort_damp=True, vtdm4=0.06, nord=1))
+    r = PC.check_jw_step(emu, npx=13, npz=12, k_split=2, n_split=2, bdt=900.0, hydrostatic=False, nq=2, flags=dict(inline_q=True))
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+    r = PC.check_jw_step(emu, npx=13, npz=12, k_split=1, n_split=2, bdt=900.0, hydrostatic=True, nq=2,
+                         flags=dict(inline_q=True, do_vort_damp=True, vtdm4=0.06, nord=2))
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
+def test_fill2d(emu):
+    """fill2D (fv_fill.F90:183-258): the kernels against the oracle, then after tracer_2d in whole steps (hord_tr < 8, moist_phys)"""
+    assert T.check_fill2d(emu) <= 1e-15
+    assert T.check_fill2d(emu, nx=33, ny=9, npz=3) <= 1e-15
+    D.check_fv_step(emu, flags=dict(hord_tr=5), fill2d=(0, 1), q_range=(-0.3, 1.0))
+    r = PC.check_jw_step(emu, npx=13, npz=12, k_split=2, n_split=2, bdt=900.0, hydrostatic=False, nq=2, flags=dict(hord_tr=5),
+                         fill2d=(0,), q_shift=1.0)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
 def test_nh_halos_and_geopk(emu):
     N.check_halos_and_geopk(emu)
 
@@ -390,6 +414,8 @@ def test_fortran_host_drives_the_library(emu, tmp_path):
     assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=12, nq=1, hydrostatic=True)
     assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=12, nq=1, hydrostatic=True, d_con=1.0)
     assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=12, nq=0, hydrostatic=False, d_con=1.0)
+    assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=8, nq=2, hydrostatic=False, inline_q=True)
+    assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=8, nq=1, hydrostatic=True, inline_q=True, beta=0.3)
 
 
 def test_fortran_dyn_core_with_the_reference_argument_list(emu, tmp_path):
@@ -940,3 +966,4 @@ def test_fortran_host_on_the_cubed_sphere(emu, tmp_path):
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=12, nq=2, hydrostatic=False)
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=12, nq=0, hydrostatic=True, d_con=1.0, k_split=1)
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=8, nq=0, hydrostatic=False, beta=0.4, n_split=3)
+    assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=8, nq=2, hydrostatic=False, inline_q=True)
