@@ -66,6 +66,9 @@ struct fv3_ctx {
   double *scratch[8];
   double *ray_d;         // pm(k), rf(k) of Rayleigh_Friction
   bool moist_on;         // fv3_set_moist: moist thermodynamics of the remap
+  bool remap_te_on;      // fv3_set_remap_te: total energy remapped in the place of T_v / theta_v
+  const double *rte_hs;  // A
+  double *rte_te;        // A x npz work array
   fv3_moist_params moist;
   double *moist_qcon, *moist_cappa;
   const double *q_con, *cappa;  // fv3_set_condensate: use_cond / moist_kappa arrays of the Riemann solvers (or null)
@@ -359,6 +362,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->remap_scr = nullptr; c->remap_scr_n = 0; c->ray_d = nullptr;
   c->q_con = nullptr; c->cappa = nullptr;
   c->moist_on = false; c->moist_qcon = nullptr; c->moist_cappa = nullptr;
+  c->remap_te_on = false; c->rte_hs = nullptr; c->rte_te = nullptr;
   c->trc_d = nullptr; c->trc_i = nullptr; c->ones_i = nullptr;
   for (auto &s : c->scratch) s = nullptr;
   c->lev_ext_d = nullptr; c->lev_ext_i = nullptr;
@@ -2812,6 +2816,7 @@ extern "C" int fv3_energy_fixer_sums(fv3_ctx *c, const fv3_remap_params *p, int 
   }
   RemapPar rp;
   if (energy_par(c, p, rp, "fv3_energy_fixer_sums")) return 1;
+  if (c->remap_te_on) { rp.remap_te = 1; rp.hs = c->rte_hs; rp.te = c->rte_te; }   // :655-663: te_2d = sum(te * delp)
   if (need_scratch(c, 1)) return 1;
   const Grid &g = c->g;
   EnergyFixerSums kf{g, g.npz, rp, only_sums, u, v, w, delz, pt, delp, q, pe, peln, phis, pkz, pk, te0_2d, te_2d, zsum1, zsum0, c->scratch[0]};
@@ -2832,6 +2837,15 @@ extern "C" int fv3_remap_finish(fv3_ctx *c, const fv3_remap_params *p, double dt
   grid.y = 1;
   grid.z = (unsigned)g.npz;
   RT(launch_p(c, "remap_finish", grid, 0, kf));
+  return 0;
+}
+
+extern "C" int fv3_set_remap_te(fv3_ctx *c, int remap_te, const double *hs, double *te) {
+  if (!c) return fail("fv3_set_remap_te: null ctx");
+  if (remap_te && (!hs || !te)) return fail("fv3_set_remap_te: remap_te needs hs (A) and te (A x npz)");
+  c->remap_te_on = remap_te != 0;
+  c->rte_hs = remap_te ? hs : nullptr;
+  c->rte_te = remap_te ? te : nullptr;
   return 0;
 }
 
@@ -2897,6 +2911,16 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
     c->remap_scr_n = need;
   }
   double *co = c->remap_scr, *sets = c->remap_scr + 8 * slab;
+  if (c->remap_te_on) {   // fv_mapz.F90:232-286: the energy of every layer from the un-remapped state; u kept for the rows above
+    if (!p->hydrostatic && (!w || !delz)) return fail("fv3_lagrangian_to_eulerian: remap_te (nonhydrostatic) needs w and delz");
+    if (p->sphum > 0 && !q) return fail("fv3_lagrangian_to_eulerian: remap_te with sphum > 0 needs the tracers");
+    double *u_old = cs_scratch(c, 30);
+    if (!u_old || need_scratch(c, 1)) return fail("fv3_lagrangian_to_eulerian: out of device memory");
+    rp.remap_te = 1; rp.hs = c->rte_hs; rp.te = c->rte_te; rp.u_old = u_old;
+    RT(fv3_memcpy_d2d(c, u_old, u, sizeof(double) * g.nU() * (size_t)km));
+    RemapTePre kf{g, km, rp, u, v, w, delz, pt, delp, q, pe, pk, peln, pkz, c->scratch[0]};
+    RT(launch_c(c, "remap_te_pre", col_grid(g.nx * g.ny), kf));
+  }
   {
     RemapCoords kf{g, km, rp, ak, bk, pe, peln, ps, co, co + slab, co + 2 * slab, co + 3 * slab};
     RT(launch_c(c, "remap_coords", col_grid(g.nx * g.ny), kf));
@@ -2925,6 +2949,10 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
               g.nA(), 0};
     RemapDelzFinal kf{g, km, rp, delp, pkz, pk, delz, pt, peln, q, s0};
     RT(launch_c(c, "remap_delz_final", col_grid(g.nx * g.ny), kf));
+  }
+  if (rp.remap_te) {   // :576-619 and the conversion of pt (:793-841)
+    RemapTePost kf{g, km, rp, ak, bk, u, v, w, delz, delp, q, pe, pk, peln, pt, pkz};
+    RT(launch_c(c, "remap_te_post", col_grid(g.nx * g.ny), kf));
   }
   {
     RemapPe kf{g, km, ak, bk, pe};

@@ -890,6 +890,12 @@ struct RemapPar {
   double *q_con, *cappa;  // A x km, written where the reference writes them (fv_mapz.F90:212-219, :463-478)
   int fill;               // flagstruct%fill: fillz on the remapped tracers
   int scr_blocked;        // layout of the scratch slabs (scr_col)
+  // flagstruct%remap_te (fv_mapz.F90:232-286, :348-360, :576-619, :655-663; fv3_set_remap_te): total energy is remapped in the
+  // place of T_v / theta_v.  hs: A; te: A x km work array (the reference's te argument); u_old: U x km copy of u before the remap
+  int remap_te = 0;
+  const double *hs = nullptr;
+  double *te = nullptr;
+  const double *u_old = nullptr;
 };
 
 // fillz of one tracer column (fv_fill.F90:34-137, default branch): q(k) at q[(k-1)*qs], dp2(k) = pe2(k+1) - pe2(k) through
@@ -981,6 +987,190 @@ FV3_HD double moist_cv(const RemapPar &p, const double *qk, size_t ns, double &q
 //   RemapPe        -- pe(k) = ak + bk*ps
 
 // source / target coordinates of the cell-centred fields (fv_mapz.F90:298-345, :363-374)
+// map1_cubic with T_VAR = 1 (total energy in log p) and conserv = .true. (fv_operators.F90:1897-2096, call site fv_mapz.F90:353-355)
+// of one column, in place in f (level stride fs).  Scratch slabs: a1 = log p of the old layer centres, q = of the new ones,
+// a2 = their old differences, a3 = the interpolated values.  pe1 / pe2: the pressure coordinates of the column.
+FV3_HD void map1_cubic_te_col(const ColScr &c, int km, double *f, size_t fs) {
+  double vsum1 = 0., vsum2 = 0.;
+  for (int k = 1; k <= km; k++) {
+    CS(a1, k) = dlog(0.5 * (CS(pe1, k) + CS(pe1, k + 1)));
+    CS(q, k) = dlog(0.5 * (CS(pe2, k) + CS(pe2, k + 1)));
+  }
+  for (int k = 1; k <= km - 1; k++) CS(a2, k) = CS(a1, k + 1) - CS(a1, k);
+  for (int k = 1; k <= km; k++) vsum1 = vsum1 + f[(size_t)(k - 1) * fs] * (CS(pe1, k + 1) - CS(pe1, k));
+  vsum1 = vsum1 / (CS(pe1, km + 1) - CS(pe1, 1));
+  auto Q1 = [&](int k) { return f[(size_t)(k - 1) * fs]; };
+  for (int k = 1; k <= km; k++) {
+    const double P = CS(q, k);
+    int lp0 = 1;
+    while (lp0 <= km && CS(a1, lp0) < P) lp0 = lp0 + 1;
+    const int lm1 = lp0 - 1 > 1 ? lp0 - 1 : 1;
+    lp0 = lp0 < km ? lp0 : km;
+    double r;
+    if (lm1 == 1 && lp0 == 1)
+      r = Q1(1) + (Q1(2) - Q1(1)) * (P - CS(a1, 1)) / (CS(a1, 2) - CS(a1, 1));
+    else if (lm1 == km && lp0 == km)
+      r = Q1(km) + (Q1(km) - Q1(km - 1)) * (P - CS(a1, km)) / (CS(a1, km) - CS(a1, km - 1));
+    else if (lm1 == 1 || lp0 == km)
+      r = Q1(lp0) + (Q1(lm1) - Q1(lp0)) * (P - CS(a1, lp0)) / (CS(a1, lm1) - CS(a1, lp0));
+    else {
+      const int lp1 = lp0 + 1, lm2 = lm1 - 1;
+      const double plp1 = CS(a1, lp1), plp0 = CS(a1, lp0), plm1 = CS(a1, lm1), plm2 = CS(a1, lm2);
+      const double dlp0 = CS(a2, lp0), dlm1 = CS(a2, lm1), dlm2 = CS(a2, lm2);
+      const double ap1 = (P - plp0) * (P - plm1) * (P - plm2) / (dlp0 * (dlp0 + dlm1) * (dlp0 + dlm1 + dlm2));
+      const double ap0 = (plp1 - P) * (P - plm1) * (P - plm2) / (dlp0 * dlm1 * (dlm1 + dlm2));
+      const double am1 = (plp1 - P) * (plp0 - P) * (P - plm2) / (dlm1 * dlm2 * (dlp0 + dlm1));
+      const double am2 = (plp1 - P) * (plp0 - P) * (plm1 - P) / (dlm2 * (dlm1 + dlm2) * (dlp0 + dlm1 + dlm2));
+      r = ap1 * Q1(lp1) + ap0 * Q1(lp0) + am1 * Q1(lm1) + am2 * Q1(lm2);
+    }
+    CS(a3, k) = r;
+  }
+  for (int k = 1; k <= km; k++) vsum2 = vsum2 + CS(a3, k) * (CS(pe2, k + 1) - CS(pe2, k));
+  vsum2 = vsum2 / (CS(pe2, km + 1) - CS(pe2, 1));
+  for (int k = 1; k <= km; k++) f[(size_t)(k - 1) * fs] = CS(a3, k) + vsum1 - vsum2;
+}
+
+FV3_HD double te_wind_bracket(const Grid &g, const double *u, const double *v, int i, int j, int k);
+FV3_HD double moist_cv(const RemapPar &p, const double *qk, size_t ns, double &q_con);
+
+// remap_te, before the remap (fv_mapz.F90:232-286): te = cp T + KE + phis of every layer from the un-remapped state; pkz as the
+// reference leaves it there (pkez :898-903 / :272, :282).  phiz: A x (km+1) scratch.
+struct RemapTePre {
+  Grid g;
+  int km;
+  RemapPar p;
+  const double *u, *v, *w, *delz, *pt, *delp, *q, *pe, *pk;
+  double *peln, *pkz, *phiz;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int ncol = g.nx * g.ny;
+    const size_t nA = g.nA(), nCC = g.nCC();
+    const double k1k = p.rdgas / p.cv_air, rrg = -p.rdgas / p.grav, akap = p.akap;
+    const double rv = p.adiabatic ? 0. : p.r_vir;   // the reference's caller passes zvir = 0 for an adiabatic run
+    FV3_COL_FOR2(col, ncol) {
+      const int i = g.is + col % g.nx, j = g.js + col / g.nx;
+      const int o = g.iA(i, j), occ = g.iCC(i, j);
+      const double rs2 = g.rsin2[o];
+      auto PE = [&](int k) { return pe[(size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (size_t)(k - 1) * (g.nx + 2) + (i - (g.is - 1))]; };
+      auto PELN = [&](int k) -> double & { return peln[(size_t)(j - g.js) * g.nx * (km + 1) + (size_t)(k - 1) * g.nx + (i - g.is)]; };
+      auto PK = [&](int k) { return pk[(size_t)(k - 1) * nCC + occ]; };
+      double ph = p.hs[o];
+      phiz[(size_t)km * nA + o] = ph;
+      if (p.hydrostatic) {
+        PELN(1) = dlog(p.ptop);
+        for (int k = km; k >= 1; k--) {
+          ph = ph + p.cp * pt[(size_t)(k - 1) * nA + o] * (PK(k + 1) - PK(k));
+          phiz[(size_t)(k - 1) * nA + o] = ph;
+        }
+        for (int k = 1; k <= km + 1; k++) phiz[(size_t)(k - 1) * nA + o] = phiz[(size_t)(k - 1) * nA + o] * PE(k);
+        for (int k = 1; k <= km; k++) {
+          const size_t o3 = (size_t)(k - 1) * nA + o;
+          const double pz = (PK(k + 1) - PK(k)) / (akap * (PELN(k + 1) - PELN(k)));
+          pkz[(size_t)(k - 1) * nCC + occ] = pz;
+          p.te[o3] = 0.25 * rs2 * te_wind_bracket(g, u, v, i, j, k) + p.cp * pt[o3] * pz + (phiz[o3 + nA] - phiz[o3]) / (PE(k + 1) - PE(k));
+        }
+      } else {
+        for (int k = km; k >= 1; k--) {
+          const size_t o3 = (size_t)(k - 1) * nA + o, c3 = (size_t)(k - 1) * nCC + occ;
+          const double qv = p.sphum > 0 ? q[(size_t)(p.sphum - 1) * nA * km + o3] : 0.;
+          const double ph1 = ph;
+          ph = ph - p.grav * delz[c3];
+          const double ww = w[o3], ke = 0.25 * rs2 * te_wind_bracket(g, u, v, i, j, k);
+          if (p.moist_kappa) {
+            double qc;
+            const double cvm = moist_cv(p, q + o3, nA * km, qc);
+            const double cap = p.rdgas / (p.rdgas + cvm / (1. + rv * qv));
+            p.q_con[o3] = qc;
+            p.cappa[o3] = cap;
+            const double pz = dexp(cap / (1. - cap) * dlog(rrg * delp[o3] / delz[c3] * pt[o3]));
+            pkz[c3] = pz;
+            p.te[o3] = cvm * pt[o3] * pz / ((1. + rv * qv) * (1. - qc)) + 0.5 * (ww * ww) + ke + 0.5 * (ph1 + ph);
+          } else {
+            const double pz = dexp(k1k * dlog(rrg * delp[o3] / delz[c3] * pt[o3]));
+            pkz[c3] = pz;
+            p.te[o3] = p.cv_air * pt[o3] * pz / (1. + rv * qv) + 0.5 * (ww * ww) + ke + 0.5 * (ph1 + ph);
+          }
+        }
+      }
+    }
+  }
+};
+
+// remap_te, after the remap of the winds (fv_mapz.F90:576-619): T_v and pkz of every layer from the remapped energy, then the
+// conversion of pt the remap ends with (:793-841).  The reference's loop over j takes the kinetic energy of row j out of te with
+// u(:, j) and v(:, j) remapped and u(:, j + 1) NOT yet (it is remapped in the next iteration): u_old supplies that row.
+struct RemapTePost {
+  Grid g;
+  int km;
+  RemapPar p;
+  const double *ak, *bk;
+  const double *u, *v, *w, *delz, *delp, *q, *pe, *pk, *peln;
+  double *pt, *pkz;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int ncol = g.nx * g.ny;
+    const size_t nA = g.nA(), nCC = g.nCC(), nU = g.nU(), nV = g.nV();
+    const double rrg = -p.rdgas / p.grav, akap = p.akap;
+    const double rv = p.adiabatic ? 0. : p.r_vir;
+    FV3_COL_FOR2(col, ncol) {
+      const int i = g.is + col % g.nx, j = g.js + col / g.nx;
+      const int o = g.iA(i, j), occ = g.iCC(i, j);
+      const double rs2 = g.rsin2[o], ca = g.cosa_s[o];
+      const size_t peb = (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1));
+      const double psfc = pe[peb + (size_t)km * (g.nx + 2)];
+      auto PELN = [&](int k) { return peln[(size_t)(j - g.js) * g.nx * (km + 1) + (size_t)(k - 1) * g.nx + (i - g.is)]; };
+      auto PK = [&](int k) { return pk[(size_t)(k - 1) * nCC + occ]; };
+      double ph = p.hs[o];
+      for (int k = km; k >= 1; k--) {
+        const size_t o3 = (size_t)(k - 1) * nA + o, c3 = (size_t)(k - 1) * nCC + occ;
+        const double u0 = u[(size_t)(k - 1) * nU + g.iU(i, j)], u1 = p.u_old[(size_t)(k - 1) * nU + g.iU(i, j + 1)];
+        const double v0 = v[(size_t)(k - 1) * nV + g.iV(i, j)], v1 = v[(size_t)(k - 1) * nV + g.iV(i + 1, j)];
+        const double ke = 0.25 * rs2 * (u0 * u0 + u1 * u1 + v0 * v0 + v1 * v1 - (u0 + u1) * (v0 + v1) * ca);
+        double tv, pz;
+        if (p.hydrostatic) {
+          const double pe2k = (k == 1) ? p.ptop : ak[k - 1] + bk[k - 1] * psfc;
+          const double dlnp = p.rdgas * (PELN(k + 1) - PELN(k));
+          const double tpe = p.te[o3] - ph - ke;
+          tv = tpe / (p.cp - pe2k * dlnp / delp[o3]);
+          pz = (PK(k + 1) - PK(k)) / (akap * (PELN(k + 1) - PELN(k)));
+          ph = ph + dlnp * tv;
+        } else {
+          const double qv = p.sphum > 0 ? q[(size_t)(p.sphum - 1) * nA * km + o3] : 0.;
+          const double ph1 = ph, ww = w[o3];
+          ph = ph1 - delz[c3] * p.grav;
+          const double tpe = p.te[o3] - 0.5 * (ph + ph1) - 0.5 * (ww * ww) - ke;
+          if (p.moist_kappa) {
+            double qc;
+            const double cvm = moist_cv(p, q + o3, nA * km, qc);
+            const double cap = p.rdgas / (p.rdgas + cvm / (1. + rv * qv));
+            p.q_con[o3] = qc;
+            p.cappa[o3] = cap;
+            tv = tpe / cvm * (1. + rv * qv) * (1. - qc);
+            pz = dexp(cap * dlog(rrg * delp[o3] / delz[c3] * tv));
+          } else {
+            tv = tpe / p.cv_air * (1. + rv * qv);
+            pz = dexp(akap * dlog(rrg * delp[o3] / delz[c3] * tv));
+          }
+        }
+        pkz[c3] = pz;
+        double tnew = tv;
+        if (p.last_step == 2) {                 // the energy fixer follows: T_v / T_m stays, fv3_remap_finish converts (:793-821)
+        } else if (p.last_step) {               // :793-821 (dtmp = 0)
+          if (!p.hydrostatic && p.use_cond) {   // :806-811
+            double qc;
+            const double cvm = moist_cv(p, q + o3, nA * km, qc);
+            tnew = (tnew + 0. / cvm * pz) / ((1. + p.r_vir * q[(size_t)(p.sphum - 1) * nA * km + o3]) * (1. - qc));
+          } else if (!p.adiabatic) {
+            const double qv = p.sphum > 0 ? q[(size_t)(p.sphum - 1) * nA * km + o3] : 0.;
+            tnew = (tnew + 0. / (p.hydrostatic ? p.cp : p.cv_air) * pz) / (1. + p.r_vir * qv);
+          }
+        } else {
+          tnew = tnew / pz;                     // :833-841
+        }
+        pt[o3] = tnew;
+      }
+    }
+  }
+};
+
 struct RemapCoords {
   Grid g;
   int km;
@@ -1005,7 +1195,8 @@ struct RemapCoords {
         const double pe2k = (k == 1) ? p.ptop : (k == km + 1 ? psfc : ak[k - 1] + bk[k - 1] * psfc);
         pe1p[so] = pe[peb + (size_t)(k - 1) * (g.nx + 2)];
         pe2p[so] = pe2k;
-        if (p.kord_tm < 0) {
+        if (p.kord_tm < 0 || p.remap_te) {
+          // (remap_te, hydrostatic: pkez sets peln(1) = log(ptop), :886-895 -- the value it holds already, dyn_core's geopk)
           const double pl = peln[lnb + (size_t)(k - 1) * g.nx];
           pe1l[so] = pl;
           pe2l[so] = (k == 1 || k == km + 1) ? pl : dlog(pe2k);
@@ -1101,8 +1292,19 @@ struct RemapFields {
           }
           return t;
         };
-        // remap T_v (log-p coordinate, :363-368) or theta_v (:370-374)
+        // remap T_v (log-p coordinate, :363-368) or theta_v (:370-374) -- or the total energy (:348-360)
         ProfCfg pc;
+        if (p.remap_te) {
+          double *te = p.te + fo;
+          if (p.kord_tm == 0) {
+            map1_cubic_te_col(c, km, te, nA);
+          } else {
+            c.pe1 = pe1l;
+            c.pe2 = pe2l;
+            pc = profile_col(c, km, true, 0., 1, akt, p.cp * p.t_min, [&](int k) { return te[(size_t)(k - 1) * nA]; });
+            map_col(c, km, false, pc, [&](int k, double v_) { te[(size_t)(k - 1) * nA] = v_; });
+          }
+        } else {
         if (p.kord_tm < 0) {
           c.pe1 = pe1l;
           c.pe2 = pe2l;
@@ -1111,6 +1313,7 @@ struct RemapFields {
           pc = profile_col(c, km, false, 0., 1, akt, 0., src_pt);
         }
         map_col(c, km, false, pc, [&](int k, double v_) { pt[(size_t)(k - 1) * nA + fo] = v_; });
+        }
         // omega (:432-443, :506-526): interpolated in the old log-p coordinate
         if (p.last_step) {
           const size_t peb = (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1));
@@ -1224,6 +1427,11 @@ struct RemapDelzFinal {
           pk_next = dexp(akap * pn_next);
           PELN(k + 1) = pn_next;
           pk[(size_t)k * nCC + occ] = pk_next;
+        }
+        if (p.remap_te) {   // T_v, pkz and the conversion of pt follow from the remapped energy (RemapTePost)
+          pn_prev = pn_next;
+          pk_prev = pk_next;
+          continue;
         }
         double pkzv;
         const double tv = pt[(size_t)(k - 1) * nA + fo];
@@ -1371,7 +1579,10 @@ struct EnergyFixerSums {
       auto PELN = [&](int k) { return peln[(size_t)(j - g.js) * g.nx * (km + 1) + (size_t)(k - 1) * g.nx + (i - g.is)]; };
       if (!only_sums) {
         double te;
-        if (p.hydrostatic) {
+        if (p.remap_te) {   // :655-663
+          te = p.te[o] * delp[o];
+          for (int k = 2; k <= km; k++) te = te + p.te[(size_t)(k - 1) * nA + o] * delp[(size_t)(k - 1) * nA + o];
+        } else if (p.hydrostatic) {
           double gz = hs[o];
           for (int k = 1; k <= km; k++) gz = gz + p.rdgas * pt[(size_t)(k - 1) * nA + o] * (PELN(k + 1) - PELN(k));
           te = PE(km + 1) * hs[o] - PE(1) * gz;

@@ -49,6 +49,7 @@ module fv3_host_mod
     real(c_double) :: d_ext = 0.02d0, delt_max = 1.d0 ! :452, :441
     real(c_double) :: beta = 0.d0                     ! :403; > 0: split_p_grad / grad1_p_update
     logical :: inline_q = .false.                     ! :474; the tracers ride inside d_sw (sw_core.F90:1020-1043)
+    logical :: remap_te = .false.                     ! :399; the remap carries total energy (fv_mapz.F90:232-286, :348-360, :576-619)
     logical :: convert_ke = .false.
   end type
 
@@ -634,6 +635,7 @@ contains
       call fv3_dyn_core(at, mdt)                                                                           ! :493
       if (at%nq > 0 .and. .not. at%fl%inline_q) call fv3_tracer_2d(at)                                     ! :509-533
       rp%last_step = merge(1_c_int, 0_c_int, last_step .and. n_map == at%fl%k_split)
+      if (at%fl%remap_te) call fv3_check(fv3_set_remap_te(at%ctx, 1_c_int, at%phis, at%dp1), 'set_remap_te')   ! te = dp1, :612
       if (at%fl%hydrostatic) then
         call fv3_check(fv3_lagrangian_to_eulerian(at%ctx, rp, kord_tr, at%ps, at%pe, at%delp, at%pkz, at%pk, at%u, at%v, &
                                                   c_null_ptr, c_null_ptr, at%pt, at%q, at%peln, at%omga, c_null_ptr), &

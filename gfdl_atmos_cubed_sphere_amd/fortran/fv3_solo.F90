@@ -37,6 +37,7 @@ program fv3_solo
 
   fl%n_split = n_split; fl%k_split = k_split; fl%ptop = ptop
   fl%hydrostatic = iand(hydrostatic, 1_c_int) /= 0; fl%inline_q = iand(hydrostatic, 2_c_int) /= 0    ! bit 1: inline_q
+  fl%remap_te = iand(hydrostatic, 4_c_int) /= 0                                                           ! bit 2: remap_te
   fl%d_con = d_con; fl%d_ext = d_ext; fl%beta = beta
   call fv3_host_init(at, int(nx), int(ny), int(npz), int(nq), dx, dy, f0, fl, ak, bk)
   write(*,'(a,i0)') 'fv3_solo: gridstruct geometry mode ', fv3_grid_geom(at%ctx)

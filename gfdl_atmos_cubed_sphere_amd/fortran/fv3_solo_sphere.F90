@@ -61,6 +61,7 @@ program fv3_solo_sphere
 
   fl%n_split = n_split; fl%k_split = k_split; fl%ptop = ptop; fl%nord = nord; fl%d4_bg = d4_bg
   fl%hydrostatic = iand(hydrostatic, 1_c_int) /= 0; fl%inline_q = iand(hydrostatic, 2_c_int) /= 0    ! bit 1: inline_q
+  fl%remap_te = iand(hydrostatic, 4_c_int) /= 0                                                           ! bit 2: remap_te
   fl%d_con = d_con; fl%d_ext = d_ext; fl%beta = beta
   dom%is = 1; dom%ie = nx; dom%js = 1; dom%je = nx; dom%ng = 3; dom%npx = npx; dom%npy = npx; dom%npz = npz; dom%grid_type = 0
   dom%do_diss_est = 0; dom%prevent_diss_cooling = 1; dom%stretched_grid = 0; dom%lim_fac = 1.d0

@@ -387,6 +387,7 @@ contains
       rp%last_step = merge(1_c_int, 0_c_int, last_step .and. n_map == fl%k_split)
       do i = 1, sp%nf
         associate (at => sp%f(i))
+          if (fl%remap_te) call fv3_check(fv3_set_remap_te(at%ctx, 1_c_int, at%phis, at%dp1), 'set_remap_te')   ! te = dp1, :612
           if (fl%hydrostatic) then
             call fv3_check(fv3_lagrangian_to_eulerian(at%ctx, rp, kord_tr, at%ps, at%pe, at%delp, at%pkz, at%pk, at%u, at%v, &
                                                       c_null_ptr, c_null_ptr, at%pt, at%q, at%peln, at%omga, c_null_ptr), &

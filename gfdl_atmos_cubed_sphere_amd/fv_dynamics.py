@@ -26,7 +26,8 @@ class FvDynamics:
                  kord_mt: int = 8, kord_wz: int = 8, kord_tr: int = 8, q_split: int = 0, nord_tr: int = 0, trdm2: float = 0.0, adiabatic: bool = True,
                  px: int = 1, py: int = 1, rank: int = 0, world: int = 1, dist=None, tau: float = 0.0,
                  rf_cutoff: float = 30.0e2, c2l_ord: int = 4, moist: dict | None = None, fill: bool = False, halo=None,
-                 consv_te: float = 0.0, moist_phys: bool = False, radius: float = 6.3712e6, fill2d: tuple = ()):
+                 consv_te: float = 0.0, moist_phys: bool = False, radius: float = 6.3712e6, fill2d: tuple = (),
+                 remap_te: bool = False):
         ak, bk = np.asarray(ak, dtype=np.float64), np.asarray(bk, dtype=np.float64)
         dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5          # dyn_core.F90:241-244
         self.ctx, self.fl, self.nq, self.k_split, self.q_split, self.dist = ctx, flags, nq, k_split, q_split, dist
@@ -34,6 +35,8 @@ class FvDynamics:
         # fill2D (fv_dynamics.F90:542-556, FILL2D builds): the 0-based tracer indices of liq_wat, rainwat, ice_wat, snowwat, graupel
         # that get the diffusive filling after tracer_2d when hord_tr < 8 and moist_phys
         self.fill2d = tuple(int(i) for i in fill2d)
+        # flagstruct%remap_te (fv_arrays.F90:399): the remap carries total energy in the place of T_v / theta_v
+        self.remap_te = bool(remap_te)
         self.tau, self.rf_cutoff, self.c2l_ord = tau, rf_cutoff, c2l_ord
         self.ak, self.bk = ak, bk
         self._rf = None                                                    # (rf, pm, kmax): set on first use, as RF_initialized
@@ -230,6 +233,8 @@ class FvDynamics:
             hyd = self.fl.hydrostatic
             if self.moist:                                                     # q_con is a ping-pong pair: current buffer
                 ctx.set_moist(self.moist, d.get("q_con"), d.get("cappa"))
+            if self.remap_te:                                                  # te = dp1, as fv_dynamics.F90:612 hands it over
+                ctx.set_remap_te(True, d["phis"], d["dp1"])
             ctx.lagrangian_to_eulerian(par, d["ps"], d["pe"], d["delp"], d["pkz"], d["pk"], d["u"], d["v"],
                                        None if hyd else d["w"], None if hyd else d["delz"], d["pt"], d.get("q"),
                                        d["peln"], d["omga"], None if hyd else d["ws"])   # :607

@@ -35,7 +35,7 @@ EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
            "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_compute_total_energy", "fv3_energy_fixer_sums", "fv3_remap_finish", "fv3_ordered_sum", "fv3_adv_pe", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max", "fv3_cube_table", "fv3_cube_halo_start", "fv3_cube_halo_complete",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_set_fast", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
-           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_split_p_grad", "fv3_grad1_p_update", "fv3_d_sw_inline_q", "fv3_flux_accum", "fv3_fill2d_mass", "fv3_fill2d_apply", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
+           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_split_p_grad", "fv3_grad1_p_update", "fv3_d_sw_inline_q", "fv3_flux_accum", "fv3_fill2d_mass", "fv3_fill2d_apply", "fv3_set_remap_te", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
 
 
@@ -541,6 +541,11 @@ class Context:
                                                        C.c_int(nq), C.c_int(hord), C.c_int(nord_tr), C.c_double(trdm),
                                                        q.p, q_out.p, dp1.p, dp1_out.p, mfx.p, mfy.p, cx.p, cy.p, xfx.p,
                                                        yfx.p), "fv3_tracer_2d_step")
+
+    def set_remap_te(self, on, hs=None, te=None):
+        """flagstruct%remap_te (fv_mapz.F90:232-286, :348-360, :576-619): hs = phis (A), te: A x npz work array"""
+        self.lib.check(self.lib.dll.fv3_set_remap_te(self.h, C.c_int(int(bool(on))), hs.p if on else None, te.p if on else None),
+                       "fv3_set_remap_te")
 
     def d_sw_inline_q(self, nq, hord_tr, nord_t, damp_t, q, q_out, delp_old, delp_new, fx, fy, crx, cry, xfx, yfx):
         """sw_core.F90:1020-1043: the tracers of one acoustic substep (after d_sw of the same substep, see the header)"""

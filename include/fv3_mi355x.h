@@ -449,6 +449,12 @@ typedef struct fv3_moist_params {
   double cv_vap, c_liq, c_ice;
 } fv3_moist_params;
 int fv3_set_moist(fv3_ctx *ctx, const fv3_moist_params *m, double *q_con, double *cappa);
+/* flagstruct%remap_te (model/fv_arrays.F90:399; fv_mapz.F90:232-286, :348-360, :576-619, :655-663): the remap carries the total
+ * energy cp T + KE + phis of every layer (map_scalar with abs(kord_tm) in log p, or map1_cubic when kord_tm = 0) in the place of
+ * T_v / theta_v, and T_v and pkz follow from it after the winds were remapped.  hs = phis (A), te: A x npz work array, both device
+ * (the reference's hs and te arguments; fv_dynamics hands it dp1 as te).  fv3_energy_fixer_sums then takes te_2d from te.  The
+ * reference's j loop reads the winds of row j + 1 before it remaps them; the library keeps a copy of u to do the same. */
+int fv3_set_remap_te(fv3_ctx *ctx, int remap_te, const double *hs, double *te);
 /* ak, bk: HOST arrays of length npz+1 (the hybrid coordinate, tools/fv_eta.F90). */
 int fv3_set_ak_bk(fv3_ctx *ctx, const double *ak, const double *bk);
 /* ---- total-energy conservation (consv_te) -------------------------------------------------------------------------

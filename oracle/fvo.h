@@ -218,6 +218,11 @@ typedef struct fvo_remap_par {
   int moist_kappa, use_cond, nwat, liq_wat, rainwat, ice_wat, snowwat, graupel;
   double cv_vap, c_liq, c_ice;
   int fill; /* flagstruct%fill: fillz on the remapped tracers (fv_operators.F90:337, fv_fill.F90:34-137) */
+  /* flagstruct%remap_te (fv_mapz.F90:232-286, :348-360, :576-619, :655-663): hs = phis (A), te: A x km work array (the
+   * reference's te argument; fv_dynamics hands it dp1) */
+  int remap_te;
+  const double *hs;
+  double *te;
 } fvo_remap_par;
 /* fillz of one column of one tracer (fv_fill.F90:34-137, the default (not DEV_GFS_PHYS) branch); q, dp: 1-based [1..km] */
 void fvo_fillz_column(int km, double *q, const double *dp);

@@ -3,7 +3,7 @@
  * model/fv_operators.F90 (scalar_profile :546-916, cs_profile :919-1300, cs_limiters :1303-1378,
  * map_scalar :40-134, map1_ppm :137-229, mapn_tracer :234-348, map1_q2 :352-443) and
  * model/fv_mapz.F90 Lagrangian_to_Eulerian :56-845.
- * Branches restated: remap_te = .false., moist_kappa / use_cond both ways (moist_cv: fv_thermodynamics.F90:250-325),
+ * Branches restated: remap_te both ways (map_scalar and map1_cubic, fv_operators.F90:1897-2096), moist_kappa / use_cond both ways (moist_cv: fv_thermodynamics.F90:250-325),
  * consv = 0 (no energy fixer),
  * fill = .false., do_intermediate_phys = .false.; kord 8..15 (scalar_profile / cs_profile) and kord <= 7 (ppm_profile); iv in {-2,-1,0,1}.
  * (iv = -3, i.e. kord_wz < 0, is not restated: the reference's back-substitution reads gam(i,km), which
@@ -556,6 +556,49 @@ double fvo_moist_cv(const fvo_remap_par *p, const double *qk, size_t ns, double 
 #undef Q
 }
 
+/* map1_cubic with T_VAR = 1 (total energy in log p) and conserv = .true. (fv_operators.F90:1897-2096, call site
+ * fv_mapz.F90:353-355), one column; 1-based pe1, pe2 [1..km+1], q1, q2 [1..km] */
+static void map1_cubic_te(int km, const double *pe1, const double *pe2, const double *q1, double *q2) {
+  double *l1 = dalloc(km + 2), *l2 = dalloc(km + 2), *dl = dalloc(km + 2);
+  double vsum1 = 0., vsum2 = 0.;
+  int k;
+  for (k = 1; k <= km; k++) {
+    l1[k] = fv3_log(0.5 * (pe1[k] + pe1[k + 1]));
+    l2[k] = fv3_log(0.5 * (pe2[k] + pe2[k + 1]));
+  }
+  for (k = 1; k <= km - 1; k++) dl[k] = l1[k + 1] - l1[k];
+  for (k = 1; k <= km; k++) vsum1 = vsum1 + q1[k] * (pe1[k + 1] - pe1[k]);
+  vsum1 = vsum1 / (pe1[km + 1] - pe1[1]);
+  for (k = 1; k <= km; k++) {
+    int lp0 = 1, lm1;
+    while (lp0 <= km) {
+      if (l1[lp0] < l2[k]) lp0 = lp0 + 1; else break;
+    }
+    lm1 = lp0 - 1 > 1 ? lp0 - 1 : 1;
+    lp0 = lp0 < km ? lp0 : km;
+    if (lm1 == 1 && lp0 == 1)
+      q2[k] = q1[1] + (q1[2] - q1[1]) * (l2[k] - l1[1]) / (l1[2] - l1[1]);
+    else if (lm1 == km && lp0 == km)
+      q2[k] = q1[km] + (q1[km] - q1[km - 1]) * (l2[k] - l1[km]) / (l1[km] - l1[km - 1]);
+    else if (lm1 == 1 || lp0 == km)
+      q2[k] = q1[lp0] + (q1[lm1] - q1[lp0]) * (l2[k] - l1[lp0]) / (l1[lm1] - l1[lp0]);
+    else {
+      const int lp1 = lp0 + 1, lm2 = lm1 - 1;
+      const double P = l2[k], plp1 = l1[lp1], plp0 = l1[lp0], plm1 = l1[lm1], plm2 = l1[lm2];
+      const double dlp0 = dl[lp0], dlm1 = dl[lm1], dlm2 = dl[lm2];
+      const double ap1 = (P - plp0) * (P - plm1) * (P - plm2) / (dlp0 * (dlp0 + dlm1) * (dlp0 + dlm1 + dlm2));
+      const double ap0 = (plp1 - P) * (P - plm1) * (P - plm2) / (dlp0 * dlm1 * (dlm1 + dlm2));
+      const double am1 = (plp1 - P) * (plp0 - P) * (P - plm2) / (dlm1 * dlm2 * (dlp0 + dlm1));
+      const double am2 = (plp1 - P) * (plp0 - P) * (plm1 - P) / (dlm2 * (dlm1 + dlm2) * (dlp0 + dlm1 + dlm2));
+      q2[k] = ap1 * q1[lp1] + ap0 * q1[lp0] + am1 * q1[lm1] + am2 * q1[lm2];
+    }
+  }
+  for (k = 1; k <= km; k++) vsum2 = vsum2 + q2[k] * (pe2[k + 1] - pe2[k]);
+  vsum2 = vsum2 / (pe2[km + 1] - pe2[1]);
+  for (k = 1; k <= km; k++) q2[k] = q2[k] + vsum1 - vsum2;
+  free(l1); free(l2); free(dl);
+}
+
 int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p, double *ps, double *pe, double *delp,
                                double *pkz, double *pk, double *u, double *v, double *w, double *delz, double *pt,
                                double *q, double *peln, double *omga, const double *ws, const double *ak,
@@ -568,12 +611,27 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
   if (!p->hydrostatic && p->kord_wz < 0) return FVO_ERR_UNSUPPORTED; /* iv = -3: reads gam(i,km) unset (file header) */
   if ((p->moist_kappa || p->use_cond) && (p->hydrostatic || !q || (p->moist_kappa && (!q_con || !cappa))))
     return FVO_ERR_UNSUPPORTED;
+  /* remap_te (:232-286, :348-360, :576-619): total energy is remapped in the place of T_v / theta_v and T_v, pkz follow from it
+   * after the winds of the row were remapped.  te: A x km (the reference's te argument: fv_dynamics hands it dp1), hs: A.
+   * The loop over j runs in order, as the reference's does without OpenMP: row j reads the winds of row j + 1 BEFORE they are
+   * remapped, both in the energy (:248-252, :275-279) and in the kinetic energy taken back out of it (:587-589, :603-617) */
+  const int remap_te = p->remap_te;
+  const double *hs = p->hs;
+  double *te = p->te;
+  const double rv = p->adiabatic ? 0. : p->r_vir; /* the reference's caller passes zvir = 0 for an adiabatic run */
+  if (remap_te && (!hs || !te)) return FVO_ERR_UNSUPPORTED;
 #define IA3(i, j, k) ((size_t)((k)-1) * nA + (size_t)((j)-jsd) * nid + ((i)-isd))
 #define IU3(i, j, k) ((size_t)((k)-1) * nU + (size_t)((j)-jsd) * nid + ((i)-isd))
 #define IV3(i, j, k) ((size_t)((k)-1) * nV + (size_t)((j)-jsd) * (nid + 1) + ((i)-isd))
 #define ICC3(i, j, k) ((size_t)((k)-1) * nCC + (size_t)((j)-js) * nx + ((i)-is))
 #define PE(i, k, j) pe[(size_t)((j) - (js - 1)) * (nx + 2) * (km + 1) + (size_t)((k)-1) * (nx + 2) + ((i) - (is - 1))]
 #define PELN(i, k, j) peln[(size_t)((j)-js) * nx * (km + 1) + (size_t)((k)-1) * nx + ((i)-is)]
+#define KE_TE(i, j, k)                                                                                                     \
+  (0.25 * g->rsin2[(size_t)((j)-jsd) * nid + ((i)-isd)] *                                                                  \
+   (u[IU3(i, j, k)] * u[IU3(i, j, k)] + u[IU3(i, j + 1, k)] * u[IU3(i, j + 1, k)] + v[IV3(i, j, k)] * v[IV3(i, j, k)] +     \
+    v[IV3(i + 1, j, k)] * v[IV3(i + 1, j, k)] -                                                                            \
+    (u[IU3(i, j, k)] + u[IU3(i, j + 1, k)]) * (v[IV3(i, j, k)] + v[IV3(i + 1, j, k)]) * g->cosa_s[(size_t)((j)-jsd) * nid + ((i)-isd)]))
+  double *phis = dalloc(km + 3);
   double *pe4 = dalloc(nA * km);
   double *c1 = dalloc(km + 3), *c2 = dalloc(km + 3), *pe1 = dalloc(km + 3), *pe2 = dalloc(km + 3), *pn1 = dalloc(km + 3),
          *pn2 = dalloc(km + 3), *pk2 = dalloc(km + 3), *dp2 = dalloc(km + 3), *pe0 = dalloc(km + 3), *pe3 = dalloc(km + 3);
@@ -585,6 +643,40 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
         pe2[km + 1] = PE(i, km + 1, j);
       }
       if (j != je + 1 && i <= ie) {
+        if (remap_te) { /* :232-286: cp T + KE + phis */
+          phis[km + 1] = hs[(size_t)(j - jsd) * nid + (i - isd)];
+          if (p->hydrostatic) {
+            PELN(i, 1, j) = fv3_log(p->ptop); /* pkez, :886-895 (ptop >= ptop_min) */
+            for (k = 1; k <= km; k++)         /* pkez, :898-903 */
+              pkz[ICC3(i, j, k)] = (pk[ICC3(i, j, k + 1)] - pk[ICC3(i, j, k)]) / (akap * (PELN(i, k + 1, j) - PELN(i, k, j)));
+            for (k = km; k >= 1; k--)
+              phis[k] = phis[k + 1] + p->cp * pt[IA3(i, j, k)] * (pk[ICC3(i, j, k + 1)] - pk[ICC3(i, j, k)]);
+            for (k = 1; k <= km + 1; k++) phis[k] = phis[k] * pe1[k];
+            for (k = 1; k <= km; k++)
+              te[IA3(i, j, k)] = KE_TE(i, j, k) + p->cp * pt[IA3(i, j, k)] * pkz[ICC3(i, j, k)] +
+                                 (phis[k + 1] - phis[k]) / (pe1[k + 1] - pe1[k]);
+          } else {
+            for (k = km; k >= 1; k--) {
+              const double qv = p->sphum > 0 ? q[(size_t)(p->sphum - 1) * nA * km + IA3(i, j, k)] : 0.;
+              phis[k] = phis[k + 1] - p->grav * delz[ICC3(i, j, k)];
+              if (p->moist_kappa) {
+                double qc;
+                const double cvm = fvo_moist_cv(p, q + IA3(i, j, k), nA * km, &qc);
+                const double cap = p->rdgas / (p->rdgas + cvm / (1. + rv * qv));
+                q_con[IA3(i, j, k)] = qc;
+                cappa[IA3(i, j, k)] = cap;
+                pkz[ICC3(i, j, k)] =
+                    fv3_exp(cap / (1. - cap) * fv3_log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
+                te[IA3(i, j, k)] = cvm * pt[IA3(i, j, k)] * pkz[ICC3(i, j, k)] / ((1. + rv * qv) * (1. - qc)) +
+                                   0.5 * (w[IA3(i, j, k)] * w[IA3(i, j, k)]) + KE_TE(i, j, k) + 0.5 * (phis[k + 1] + phis[k]);
+              } else {
+                pkz[ICC3(i, j, k)] = fv3_exp(k1k * fv3_log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
+                te[IA3(i, j, k)] = p->cv_air * pt[IA3(i, j, k)] * pkz[ICC3(i, j, k)] / (1. + rv * qv) +
+                                   0.5 * (w[IA3(i, j, k)] * w[IA3(i, j, k)]) + KE_TE(i, j, k) + 0.5 * (phis[k + 1] + phis[k]);
+              }
+            }
+          }
+        } else
         if (p->kord_tm < 0) { /* :200-229 */
           for (k = 1; k <= km; k++) {
             if (p->hydrostatic)
@@ -617,15 +709,27 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
           pn2[k] = fv3_log(pe2[k]);
           pk2[k] = fv3_exp(akap * pn2[k]);
         }
-        /* 1) remap Tv / thetav, :362-376 */
+        /* 1) remap Tv / thetav, :362-376 -- or the total energy, :348-360 */
+        if (remap_te) {
+          for (k = 1; k <= km; k++) c1[k] = te[IA3(i, j, k)];
+          if (p->kord_tm == 0) {
+            map1_cubic_te(km, pe1, pe2, c1, c2);
+          } else {
+            for (k = 1; k <= km + 1; k++) pn1[k] = PELN(i, k, j);
+            rc |= fvo_remap_column(0, km, pn1, pn2, c1, c2, 0., 1, abs(p->kord_tm), p->cp * p->t_min);
+          }
+          for (k = 1; k <= km; k++) te[IA3(i, j, k)] = c2[k];
+        }
         for (k = 1; k <= km; k++) c1[k] = pt[IA3(i, j, k)];
-        if (p->kord_tm < 0) {
+        if (remap_te) {
+        } else if (p->kord_tm < 0) {
           for (k = 1; k <= km + 1; k++) pn1[k] = PELN(i, k, j);
           rc |= fvo_remap_column(0, km, pn1, pn2, c1, c2, 0., 1, abs(p->kord_tm), p->t_min);
         } else {
           rc |= fvo_remap_column(1, km, pe1, pe2, c1, c2, 0., 1, abs(p->kord_tm), 0.);
         }
-        for (k = 1; k <= km; k++) pt[IA3(i, j, k)] = c2[k];
+        if (!remap_te)
+          for (k = 1; k <= km; k++) pt[IA3(i, j, k)] = c2[k];
         /* 2) constituents, :380-397 */
         for (iq = 1; iq <= p->nq; iq++) {
           double *qq = q + (size_t)(iq - 1) * nA * km;
@@ -653,7 +757,7 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
           PELN(i, k, j) = pn2[k];
         }
         /* 3.2) pkz, :453-503 */
-        for (k = 1; k <= km; k++) {
+        for (k = 1; k <= km && !remap_te; k++) {
           if (p->hydrostatic)
             pkz[ICC3(i, j, k)] = (pk2[k + 1] - pk2[k]) / (akap * (PELN(i, k + 1, j) - PELN(i, k, j)));
           else if (p->moist_kappa) { /* :463-478; q holds the remapped tracers here */
@@ -670,7 +774,7 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
           else
             pkz[ICC3(i, j, k)] = fv3_exp(k1k * fv3_log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
         }
-        if (p->kord_tm > 0)
+        if (p->kord_tm > 0 && !remap_te)
           for (k = 1; k <= km; k++) pt[IA3(i, j, k)] = pt[IA3(i, j, k)] * pkz[ICC3(i, j, k)];
         /* 3.3) omega, :506-526 */
         if (p->last_step) {
@@ -716,6 +820,40 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
       if (i <= ie && j <= je)
         for (k = 1; k <= km; k++) pe4[IA3(i, j, k)] = pe2[k + 1]; /* :624-628 */
     }
+    /* 4a) T_v and pkz from the remapped total energy, :576-619: u(:, j), v(:, j) are remapped, u(:, j + 1) is not yet */
+    if (remap_te && j <= je)
+      for (i = is; i <= ie; i++) {
+        phis[km + 1] = hs[(size_t)(j - jsd) * nid + (i - isd)];
+        pe2[1] = p->ptop;
+        pe2[km + 1] = PE(i, km + 1, j);
+        for (k = 2; k <= km; k++) pe2[k] = ak[k - 1] + bk[k - 1] * PE(i, km + 1, j);
+        for (k = km; k >= 1; k--) {
+          double tpe;
+          if (p->hydrostatic) {
+            const double dlnp = p->rdgas * (PELN(i, k + 1, j) - PELN(i, k, j));
+            tpe = te[IA3(i, j, k)] - phis[k + 1] - KE_TE(i, j, k);
+            pt[IA3(i, j, k)] = tpe / (p->cp - pe2[k] * dlnp / delp[IA3(i, j, k)]);
+            pkz[ICC3(i, j, k)] = (pk[ICC3(i, j, k + 1)] - pk[ICC3(i, j, k)]) / (akap * (PELN(i, k + 1, j) - PELN(i, k, j)));
+            phis[k] = phis[k + 1] + dlnp * pt[IA3(i, j, k)];
+          } else {
+            const double qv = p->sphum > 0 ? q[(size_t)(p->sphum - 1) * nA * km + IA3(i, j, k)] : 0.;
+            phis[k] = phis[k + 1] - delz[ICC3(i, j, k)] * p->grav;
+            tpe = te[IA3(i, j, k)] - 0.5 * (phis[k] + phis[k + 1]) - 0.5 * (w[IA3(i, j, k)] * w[IA3(i, j, k)]) - KE_TE(i, j, k);
+            if (p->moist_kappa) {
+              double qc;
+              const double cvm = fvo_moist_cv(p, q + IA3(i, j, k), nA * km, &qc);
+              q_con[IA3(i, j, k)] = qc;
+              cappa[IA3(i, j, k)] = p->rdgas / (p->rdgas + cvm / (1. + rv * qv));
+              pt[IA3(i, j, k)] = tpe / cvm * (1. + rv * qv) * (1. - qc);
+              pkz[ICC3(i, j, k)] =
+                  fv3_exp(cappa[IA3(i, j, k)] * fv3_log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
+            } else {
+              pt[IA3(i, j, k)] = tpe / p->cv_air * (1. + rv * qv);
+              pkz[ICC3(i, j, k)] = fv3_exp(akap * fv3_log(rrg * delp[IA3(i, j, k)] / delz[ICC3(i, j, k)] * pt[IA3(i, j, k)]));
+            }
+          }
+        }
+      }
   }
   for (k = 2; k <= km; k++) /* :635-641 */
     for (j = js; j <= je; j++)
@@ -745,6 +883,7 @@ int fvo_lagrangian_to_eulerian(const fvo_grid *g, int km, const fvo_remap_par *p
       for (j = js; j <= je; j++)
         for (i = is; i <= ie; i++) pt[IA3(i, j, k)] = pt[IA3(i, j, k)] / pkz[ICC3(i, j, k)];
   }
+  free(phis);
   free(pe4); free(c1); free(c2); free(pe1); free(pe2); free(pn1); free(pn2); free(pk2); free(dp2); free(pe0); free(pe3);
   return rc;
 }
@@ -821,7 +960,10 @@ int fvo_energy_fixer_sums(const fvo_grid *g, int km, const fvo_remap_par *p, int
     for (i = is; i <= ie; i++) {
       if (!only_sums) {
         double te;
-        if (p->hydrostatic) {
+        if (p->remap_te) { /* :655-663 */
+          te = p->te[IA3(i, j, 1)] * delp[IA3(i, j, 1)];
+          for (k = 2; k <= km; k++) te = te + p->te[IA3(i, j, k)] * delp[IA3(i, j, k)];
+        } else if (p->hydrostatic) {
           double gz = hs[EA2(i, j)];
           for (k = 1; k <= km; k++) gz = gz + p->rdgas * pt[IA3(i, j, k)] * (EPELN(i, k + 1, j) - EPELN(i, k, j));
           te = EPE(i, km + 1, j) * hs[EA2(i, j)] - EPE(i, 1, j) * gz;

@@ -436,6 +436,8 @@ def oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, remap_par, npz, q
                       omga=bd.zeros("A", npz))
             if q is not None:
                 rf["q"] = q[t]
+            if remap_par.get("remap_te"):
+                rf["hs"], rf["te"] = st[t]["phis"], bd.zeros("A", npz)
             O.lagrangian_to_eulerian(gs[t], npz, dict(remap_par, last_step=(int(last_step) if n_map == k_split else 0)), rf, ak, bk)
             cur[t] = dict(u=rf["u"], v=rf["v"], delp=rf["delp"], pt=rf["pt"], phis=st[t]["phis"])
             cur[t].update({n: x[n] for n in ("du", "dv") if n in x})       # dyn_core's saved arrays (dyn_core.F90:278-283)
@@ -474,6 +476,8 @@ def oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, remap_par, n
                 rf["q"] = q[t]
             for n in moist_names:
                 rf[n] = x[n]
+            if remap_par.get("remap_te"):
+                rf["hs"], rf["te"] = st[t]["phis"], bd.zeros("A", npz)
             O.lagrangian_to_eulerian(gs[t], npz, dict(remap_par, last_step=int(last_step and n_map == k_split)), rf, ak, bk)
             cur[t] = dict(u=rf["u"], v=rf["v"], w=rf["w"], delp=rf["delp"], pt=rf["pt"], delz=rf["delz"], phis=st[t]["phis"])
             cur[t].update({n: x[n] for n in ("du", "dv") if n in x})

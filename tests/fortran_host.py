@@ -27,9 +27,9 @@ def build_solo(workdir, libdir=CSRC, libname="fv3_mi355x"):
 
 
 def write_input(path, bd, npz, nq, n_split, k_split, nsteps, last_step, dx, dy, f0, bdt, ptop, ak, bk, st, q, hydrostatic=False,
-                d_con=0.0, d_ext=0.02, beta=0.0, inline_q=False):
+                d_con=0.0, d_ext=0.02, beta=0.0, inline_q=False, remap_te=False):
     with open(path, "wb") as f:
-        np.array([bd.nx, bd.ny, npz, nq, n_split, k_split, nsteps, int(last_step), int(hydrostatic) + 2 * int(inline_q)], dtype=np.int32).tofile(f)
+        np.array([bd.nx, bd.ny, npz, nq, n_split, k_split, nsteps, int(last_step), int(hydrostatic) + 2 * int(inline_q) + 4 * int(remap_te)], dtype=np.int32).tofile(f)
         np.array([dx, dy, f0, bdt, ptop, d_con, d_ext, beta], dtype=np.float64).tofile(f)
         np.asarray(ak, dtype=np.float64).tofile(f)
         np.asarray(bk, dtype=np.float64).tofile(f)
@@ -52,7 +52,7 @@ def read_output(path, bd, npz, nq):
 
 
 def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, host_comm=False,
-                       hydrostatic=False, d_con=0.0, beta=0.0, inline_q=False):
+                       hydrostatic=False, d_con=0.0, beta=0.0, inline_q=False, remap_te=False):
     """the same initial state through (a) the Python host and (b) the Fortran host: bit-identical states"""
     import parity_common as P
     import parity_dyn as D
@@ -72,7 +72,7 @@ def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_sp
     # ---- (a) Python host ----
     ctx = Context(g, npz, lib=lib)
     try:
-        fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=k_split)
+        fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=k_split, remap_te=remap_te)
         fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
         if nq:
             fv.set_tracers(q)
@@ -88,7 +88,7 @@ def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_sp
     exe = build_solo(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
     fin, fout = os.path.join(str(workdir), "in.bin"), os.path.join(str(workdir), "out.bin")
     write_input(fin, bd, npz, nq, n_split, k_split, nsteps, False, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak,
-                bk, st, q, hydrostatic=hydrostatic, d_con=d_con, d_ext=fl.d_ext, beta=beta, inline_q=inline_q)
+                bk, st, q, hydrostatic=hydrostatic, d_con=d_con, d_ext=fl.d_ext, beta=beta, inline_q=inline_q, remap_te=remap_te)
     env = dict(os.environ, **({"FV3_HOST_COMM": "1"} if host_comm else {}))
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -259,7 +259,7 @@ _GH_B = ["rarea_c", "fC", "cosa", "sina"]
 
 
 def check_fortran_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2, nsteps=1, bdt=900.0, hydrostatic=False, d_con=0.0, beta=0.0,
-                         inline_q=False):
+                         inline_q=False, remap_te=False):
     """the Jablonowski-Williamson state on the six faces through (a) the Python host (FvDynamics over MultiContext, device-gather halo
     updates) and (b) the Fortran host (fv3_sphere_mod: one context per face, every halo update through the cube-edge exchange behind
     the C ABI, mpp_get_boundary after the last substep, adv_pe): bit-identical states on every face"""
@@ -294,7 +294,7 @@ def check_fortran_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=
     # ---- (a) Python host ----
     mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     try:
-        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)))
+        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)), remap_te=remap_te)
         fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], [s_["w"] for s_ in st], [s_["delp"] for s_ in st],
                         [s_["pt"] for s_ in st], [s_["delz"] for s_ in st], [s_["phis"] for s_ in st])
         if nq:
@@ -313,7 +313,7 @@ def check_fortran_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=
     fin, fout = os.path.join(str(workdir), "sph_in.bin"), os.path.join(str(workdir), "sph_out.bin")
     F = lambda a: np.asfortranarray(a, dtype=np.float64).ravel(order="F")      # noqa: E731
     with open(fin, "wb") as f:
-        np.array([npx, npz, nq, n_split, k_split, nsteps, 0, int(hydrostatic) + 2 * int(inline_q), fl.nord], dtype=np.int32).tofile(f)
+        np.array([npx, npz, nq, n_split, k_split, nsteps, 0, int(hydrostatic) + 2 * int(inline_q) + 4 * int(remap_te), fl.nord], dtype=np.int32).tofile(f)
         np.array([bdt, fl.ptop, d_con, fl.d_ext, gs[0].da_min, gs[0].da_min_c, fl.d4_bg, fl.beta], dtype=np.float64).tofile(f)
         np.asarray(ak, dtype=np.float64).tofile(f)
         np.asarray(bk, dtype=np.float64).tofile(f)

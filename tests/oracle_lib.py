@@ -314,7 +314,7 @@ class RemapPar(C.Structure):
         ("kord_tr", _ip)] + [(n, C.c_double) for n in ["akap", "ptop", "rdgas", "grav", "cv_air", "r_vir", "cp", "t_min"]] + [
         ("sphum", C.c_int)] + [(n, C.c_int) for n in ["moist_kappa", "use_cond", "nwat", "liq_wat", "rainwat", "ice_wat",
                                                         "snowwat", "graupel"]] + [
-        (n, C.c_double) for n in ["cv_vap", "c_liq", "c_ice"]] + [("fill", C.c_int)]
+        (n, C.c_double) for n in ["cv_vap", "c_liq", "c_ice"]] + [("fill", C.c_int), ("remap_te", C.c_int), ("hs", _dp), ("te", _dp)]
 
 
 def remap_column(which, pe1, pe2, q1, qs, iv, kord, qmin=0.0):
@@ -334,9 +334,11 @@ def lagrangian_to_eulerian(g, km, par: dict, f: dict, ak, bk):
     pr = RemapPar()
     kt = np.ascontiguousarray(par.get("kord_tr", []), dtype=np.int32)
     for k, v in par.items():
-        if k != "kord_tr":
+        if k not in ("kord_tr", "hs", "te"):
             setattr(pr, k, v)
     pr.kord_tr = kt.ctypes.data_as(_ip)
+    if par.get("remap_te"):          # hs (A), te (A x km work array): in the dict of fields
+        pr.hs, pr.te = p(f["hs"]), p(f["te"])
     ak = np.ascontiguousarray(ak, dtype=np.float64)
     bk = np.ascontiguousarray(bk, dtype=np.float64)
     rc = lib().fvo_lagrangian_to_eulerian(C.byref(gs), C.c_int(km), C.byref(pr), p(f["ps"]), p(f["pe"]), p(f["delp"]),
@@ -351,9 +353,11 @@ def _remap_par(par: dict):
     pr = RemapPar()
     kt = np.ascontiguousarray(par.get("kord_tr", []), dtype=np.int32)
     for k, v in par.items():
-        if k != "kord_tr":
+        if k not in ("kord_tr", "hs", "te"):
             setattr(pr, k, v)
     pr.kord_tr = kt.ctypes.data_as(_ip)
+    if par.get("remap_te") and par.get("te") is not None:   # the remapped total energy (A x km) rides in the parameter dict
+        pr.te = p(par["te"])
     pr._keep = kt
     return pr
 

@@ -226,7 +226,7 @@ def tracer_fields(cs, npz, nq):
 
 
 def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-12, hydrostatic=True, nq=0, face_streams=False, graph=False, flags=None,
-                  native_halo=False, fill2d=(), q_shift=0.0):
+                  native_halo=False, fill2d=(), q_shift=0.0, remap_te=False, kord_tm=-8):
     """BASELINE configs[1] in small: the Jablonowski-Williamson baroclinic wave (test_case = 13) on the whole cubed sphere,
     hydrostatic, the reference's L79 levels (set_eta), one dt_atmos = k_split x (n_split substeps + vertical remap) on six
     device contexts against the six-face orchestration of the oracle"""
@@ -270,17 +270,19 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
             halo = CubeNativeAdapter(mctx, range(6), [0] * 6)
         else:
             halo = CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx))
-        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=halo, fill2d=fill2d, moist_phys=bool(fill2d))
+        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=halo, fill2d=fill2d, moist_phys=bool(fill2d), remap_te=remap_te,
+                        kord_tm=kord_tm)
+        rpar = dict(fv.remap_par, remap_te=int(remap_te))
         q0 = tracer_fields(cs, npz, nq) if nq else None
         if q_shift:          # patches of negative tracer mass for fill2D
             q0 = [np.asfortranarray(x - q_shift) for x in q0]
         if hydrostatic:
-            ref = CC.oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, fv.remap_par, npz, q=q0, fill2d=fill2d)
+            ref = CC.oracle_fv_step_hydro(cs, gs, fl, st, ak, bk, bdt, k_split, rpar, npz, q=q0, fill2d=fill2d)
             z = [np.zeros_like(s["delp"]) for s in st]
             dz = [bd.zeros("CC", npz) for _ in st]
         else:
             dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
-            ref = CC.oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, fv.remap_par, npz, q=q0, fill2d=fill2d)
+            ref = CC.oracle_fv_step_nh(cs, gs, fl, dp_ref, st, ak, bk, bdt, k_split, rpar, npz, q=q0, fill2d=fill2d)
             z, dz = [s["w"] for s in st], [s["delz"] for s in st]
         fv.dc.set_state([s["u"] for s in st], [s["v"] for s in st], z, [s["delp"] for s in st], [s["pt"] for s in st], dz,
                         [s["phis"] for s in st])

@@ -43,7 +43,7 @@ MOIST6 = dict(nwat=6, liq_wat=2, rainwat=3, ice_wat=4, snowwat=5, graupel=6, cv_
 
 
 def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=False, kord_tm=-8, kord=8, adiabatic=True,
-                moist_kappa=False, use_cond=False, nwat=6, fill=False):
+                moist_kappa=False, use_cond=False, nwat=6, fill=False, remap_te=False):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     moist = moist_kappa or use_cond
@@ -69,6 +69,11 @@ def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=Fal
     if moist and nwat == 3:
         mpar.update(liq_wat=2, ice_wat=3, rainwat=0, snowwat=0, graupel=0)
     opar = dict(par, **mpar)
+    if remap_te:    # flagstruct%remap_te: hs = phis, te = an A x km work array (fv_mapz.F90:232-286, :348-360, :576-619)
+        rng = np.random.default_rng(41)
+        f["hs"] = np.asfortranarray(rng.uniform(0.0, 3000.0, bd.shape("A")))
+        f["te"] = bd.zeros("A", km)
+        opar["remap_te"] = 1
     ref = {k: (v.copy(order="F") if v is not None else None) for k, v in f.items()}
     if hydrostatic:
         ref.pop("w"); ref.pop("delz"); ref.pop("ws")
@@ -90,6 +95,8 @@ def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=Fal
         d = {k: ctx.from_host(v) for k, v in f.items()}
         if moist:
             ctx.set_moist(mpar, d["q_con"], d["cappa"])
+        if remap_te:
+            ctx.set_remap_te(True, d["hs"], d["te"])
         ctx.lagrangian_to_eulerian(par, d["ps"], d["pe"], d["delp"], d["pkz"], d["pk"], d["u"], d["v"],
                                    None if hydrostatic else d["w"], None if hydrostatic else d["delz"], d["pt"],
                                    d.get("q"), d["peln"], d["omga"], None if hydrostatic else d["ws"])
@@ -110,6 +117,14 @@ def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=Fal
         if moist_kappa:
             for n in ("q_con", "cappa"):
                 worst = max(worst, P.assert_close(n, bd.view(d[n].download(), "A", *r), bd.view(ref[n], "A", *r), tol))
+        if remap_te:   # the remapped energy itself, and (the remap moved something) not the energy before the remap
+            worst = max(worst, P.assert_close("te", bd.view(d["te"].download(), "A", *r), bd.view(ref["te"], "A", *r), tol))
+            plain = {k: (v.copy(order="F") if v is not None else None) for k, v in f.items()}
+            if hydrostatic:
+                plain.pop("w"); plain.pop("delz"); plain.pop("ws")
+            O.lagrangian_to_eulerian(g, km, dict(opar, remap_te=0, kord_tm=(kord_tm if kord_tm else -9)), plain, ak, bk)
+            e = P.rel_rms(bd.view(plain["pt"], "A", *r), bd.view(ref["pt"], "A", *r))
+            assert 1e-7 < e < 2e-2, e     # another scheme for the same quantity: close, not equal
         if nq:
             got = d["q"].download()
             for iq in range(nq):

@@ -185,6 +185,24 @@ def test_fill2d(prod):
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
 
 
+def test_remap_te(prod):
+    """flagstruct%remap_te (fv_mapz.F90:232-286, :348-360, :576-619, :655-663): total energy through map_scalar (kord_tm /= 0) or
+    map1_cubic (kord_tm = 0), T_v and pkz from it; columns, then whole steps on both domains"""
+    for kw in (dict(), dict(kord_tm=9), dict(kord_tm=0), dict(hydrostatic=True), dict(hydrostatic=True, kord_tm=0),
+               dict(last_step=True, adiabatic=False), dict(hydrostatic=True, last_step=True, adiabatic=False, kord_tm=10),
+               dict(moist_kappa=True), dict(moist_kappa=True, use_cond=True, last_step=True, adiabatic=False)):
+        assert R.check_remap(prod, nx=70, ny=33, km=20, remap_te=True, **kw) <= 1e-14
+    D.check_fv_step(prod, remap_te=True)
+    D.check_fv_step(prod, remap_te=True, kord_tm=0, nq=0)
+    D.check_fv_step_hydrostatic(prod, remap_te=True)
+    D.check_fv_cycle_consv(prod, remap_te=True)                      # te_2d of the energy fixer from the remapped energy (:655-663)
+    D.check_fv_cycle_consv(prod, hydrostatic=True, remap_te=True)
+    r = PC.check_jw_step(prod, npx=25, npz=12, k_split=2, n_split=2, bdt=900.0, hydrostatic=False, nq=1, remap_te=True)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+    r = PC.check_jw_step(prod, npx=25, npz=12, k_split=1, n_split=2, bdt=900.0, hydrostatic=True, remap_te=True, kord_tm=0)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
 def test_nh_halos_and_geopk(prod):
     N.check_halos_and_geopk(prod)
 
@@ -514,6 +532,7 @@ def test_fortran_host_on_the_cubed_sphere(prod, tmp_path):
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(prod, tmp_path, npx=25, npz=20, nq=0, hydrostatic=True, d_con=1.0, k_split=1)
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(prod, tmp_path, npx=25, npz=8, nq=0, hydrostatic=False, beta=0.4, n_split=3)
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(prod, tmp_path, npx=25, npz=8, nq=2, hydrostatic=False, inline_q=True)
+    assert "fv3_solo_sphere: done" in F.check_fortran_sphere(prod, tmp_path, npx=25, npz=8, nq=1, hydrostatic=False, remap_te=True)
 
 
 def test_fortran_dyn_core_with_the_reference_argument_list(prod, tmp_path):

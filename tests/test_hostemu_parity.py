@@ -163,6 +163,24 @@ def test_fill2d(emu):
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
 
 
+def test_remap_te(emu):
+    """flagstruct%remap_te (fv_mapz.F90:232-286, :348-360, :576-619, :655-663): total energy through map_scalar (kord_tm /= 0) or
+    map1_cubic (kord_tm = 0), T_v and pkz from it; columns, then whole steps on both domains"""
+    for kw in (dict(), dict(kord_tm=9), dict(kord_tm=0), dict(hydrostatic=True), dict(hydrostatic=True, kord_tm=0),
+               dict(last_step=True, adiabatic=False), dict(hydrostatic=True, last_step=True, adiabatic=False, kord_tm=10),
+               dict(moist_kappa=True), dict(moist_kappa=True, use_cond=True, last_step=True, adiabatic=False)):
+        assert R.check_remap(emu, remap_te=True, **kw) <= 1e-14
+    D.check_fv_step(emu, remap_te=True)
+    D.check_fv_step(emu, remap_te=True, kord_tm=0, nq=0)
+    D.check_fv_step_hydrostatic(emu, remap_te=True)
+    D.check_fv_cycle_consv(emu, remap_te=True)                       # te_2d of the energy fixer from the remapped energy (:655-663)
+    D.check_fv_cycle_consv(emu, hydrostatic=True, remap_te=True)
+    r = PC.check_jw_step(emu, npx=13, npz=12, k_split=2, n_split=2, bdt=900.0, hydrostatic=False, nq=1, remap_te=True)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+    r = PC.check_jw_step(emu, npx=13, npz=12, k_split=1, n_split=2, bdt=900.0, hydrostatic=True, remap_te=True, kord_tm=0)
+    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
+
+
 def test_nh_halos_and_geopk(emu):
     N.check_halos_and_geopk(emu)
 
@@ -967,3 +985,4 @@ def test_fortran_host_on_the_cubed_sphere(emu, tmp_path):
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=12, nq=0, hydrostatic=True, d_con=1.0, k_split=1)
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=8, nq=0, hydrostatic=False, beta=0.4, n_split=3)
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=8, nq=2, hydrostatic=False, inline_q=True)
+    assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=8, nq=1, hydrostatic=False, remap_te=True)
