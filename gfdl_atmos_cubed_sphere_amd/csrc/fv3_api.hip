@@ -25,6 +25,7 @@
 #include "nh_kernels.h"
 #include "nh_fast.h"
 #include "remap_kernels.h"
+#include "remap_fast.h"
 #include "tracer_kernels.h"
 #include "tp2d_tile.h"
 
@@ -2016,6 +2017,8 @@ extern "C" int fv3_ordered_sum(fv3_ctx *c, const double *values, size_t n, doubl
     const double a = values[m];
     if (!(a == a) || a > 1.7e308 || a < -1.7e308) return fail("fv3_ordered_sum: non-finite addend");
     double rs = a < 0. ? -a : a;
+    // the range of the extended fixed point number: NUMBIT bits above the leading radix (FMS mpp_efp.F90 aborts with an overflow)
+    if (rs >= pr[0] * R) return fail("fv3_ordered_sum: addend out of the range of the extended-fixed-point sum (|a| >= 2**138)");
     for (int i = 0; i < NI; i++) {
       const double iv = std::floor(rs * (1.0 / pr[i]));
       rs = rs - iv * pr[i];
@@ -2030,6 +2033,10 @@ extern "C" int fv3_ordered_sum(fv3_ctx *c, const double *values, size_t n, doubl
     }
   };
   carry(acc);
+  // the leading digit travels as int64 through the all-reduce and comes back as a double: |d0| < 2**40 leaves room for the sum
+  // over the ranks (the guard of global_sum.py)
+  const __int128 lim = (__int128)1 << 40;
+  if (acc[0] >= lim || acc[0] <= -lim) return fail("fv3_ordered_sum: leading digit too large (|sum| >= 2**132)");
   long long dig[NI];
   for (int i = 0; i < NI; i++) dig[i] = (long long)acc[i];
   if (c && c->comm && c->comm_size > 1) {
@@ -2892,6 +2899,30 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
     rp.q_con = c->moist_qcon; rp.cappa = c->moist_cappa;
   }
   const double *ak = c->akbk, *bk = c->akbk + (km + 1);
+  // fast mode (remap_fast.h): the column in LDS, the spline by scans, the rest the parity code per (column, level)
+  bool fast = c->fast && !moist && !c->remap_te_on && !p->fill && p->kord_tm < 0 && km <= 127 && km >= 5 && kord_fast(-p->kord_tm) &&
+              kord_fast(p->kord_mt) && (p->hydrostatic || kord_fast(p->kord_wz));
+  for (int n = 0; n < p->nq && fast; n++) fast = kord_fast(kord_tr[n]);
+  if (fast) {
+    {
+      static const int dbg_ = getenv("FV3_DBG_REMAP") ? atoi(getenv("FV3_DBG_REMAP")) : 0;
+      RemapFastScalars kf{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, dbg_};
+      RT(launch_p2(c, "remap_fast_scalars", Dim3{(unsigned)kf.nblocks_x(), (unsigned)g.ny, 1}, kRLds, kf));
+    }
+    {
+      static const int dbg_ = getenv("FV3_DBG_REMAP") ? atoi(getenv("FV3_DBG_REMAP")) : 0;
+      RemapFastWind<0> kf{g, km, p->kord_mt, ak, bk, pe, u, dbg_};
+      RT(launch_p2(c, "remap_fast_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kRLds, kf));
+    }
+    {
+      static const int dbg_ = getenv("FV3_DBG_REMAP") ? atoi(getenv("FV3_DBG_REMAP")) : 0;
+      RemapFastWind<1> kf{g, km, p->kord_mt, ak, bk, pe, v, dbg_};
+      RT(launch_p2(c, "remap_fast_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kRLds, kf));
+    }
+    RemapPe kf{g, km, ak, bk, pe};
+    RT(launch_c(c, "remap_pe", col_grid(g.nx * g.ny), kf));
+    return 0;
+  }
   // field tasks: T_v, w (nonhydrostatic), u, v, tracer groups -- at most kRemapSets of them per launch, each with its own
   // seven profile slabs; eight coordinate slabs (p, log p, and the face-averaged p of u and of v) in front of them
   // the tracers run in groups of up to c->remap_nt per thread (remap_tracers_col), dealt evenly

@@ -1,0 +1,581 @@
+// remap_fast.h -- Lagrangian_to_Eulerian (model/fv_mapz.F90:56-845) with the column in LDS and the LEVELS ACROSS THE LANES
+// (FV3_MI355X_FAST=1 / fv3_set_fast, the tolerance mode of SURVEY 8(d) beside the parity kernels of remap_kernels.h).
+//
+// Why: RemapFields runs one thread per (column, field) with k sequential and keeps the spline's work arrays (a1, q, gam, a2..a4) in
+// HBM slabs: 7 slab words written and read back per cell and field against 2 algorithmic ones, two or three dependent sweeps of 127
+// levels per thread -- 7 % of the remap's own roofline (profiles/r03).  Here a workgroup owns 16 consecutive columns of a row:
+//   * a field is read once with full 128-byte segments and laid out [column][level] in LDS, its coordinates beside it;
+//   * the cubic-spline interface values (scalar_profile :572-623 / cs_profile :941-1016, fv_operators.F90) are ONE tridiagonal
+//     system of km + 1 rows: tridiag_rows of nh_fast.h (8 rows per lane, 16 lanes per column, Moebius / affine scans);
+//   * everything else is the parity kernel's own code on LDS operands, one thread per (column, level): the large-scale constraints
+//     on the interface values, cs_cell (the subgrid limiters) and the search-and-integrate loop of map_scalar / map1_ppm /
+//     mapn_tracer -- every target layer finds its first source layer by itself (the reference's k0 is the smallest l with
+//     pe1(l+1) >= pe2(k), see map_target) and adds the source layers in the reference's order;
+//   * T_v, delz and sphum stay in registers for what the remap ends with (delp, pk, peln, pkz, the conversion of pt, :426-503,
+//     :793-841), so the remap of a column is one kernel; the D-grid winds are a second one (their own coordinates, :530-573).
+// Not bit-identical: the interface values come from another elimination order (1e-15 relative); held to the oracle at 1e-12.
+// Built for: dry thermodynamics (no moist_kappa / use_cond), kord_tm < 0, every kord in 8..10 or 13..15, fill and remap_te off,
+// km <= 127.  Anything else takes the parity kernels.
+#pragma once
+
+#include "nh_fast.h"
+#include "remap_kernels.h"
+
+namespace fv3 {
+
+
+// a thread's kIt global loads first, all in flight together (clamped addresses, no branch, no LDS store in between: the compiler
+// cannot move a load across a store to LDS it cannot prove disjoint), then the stores
+#ifdef FV3_HOST_EMU
+#define FV3_LOAD_LOOP(it) for (int it = 0; it < kIt; it++)
+#else
+#define FV3_LOAD_LOOP(it) _Pragma("unroll") for (int it = 0; it < kIt; it++)
+#endif
+
+constexpr int kRP = 2 + 128 + 2;         // doubles per column of an LDS array: row r at [2 + r], r = -2 .. 129
+constexpr int kRBuf = kFC * kRP;
+constexpr int kRNBuf = 4;                // C1 (source coordinate), C2 (target coordinate), A1 (layer means), Q (interface values / out)
+constexpr int kRLds = kRNBuf * kRBuf + kFC;   // + the bottom boundary value of w per column
+
+#ifdef FV3_HOST_EMU
+inline vd vlin_ld(const double *buf, int col0, int r) {
+  vd x;
+  FV3_LANE_LOOP x.v[l] = buf[((l >> 4) + col0) * kRP + 2 + (l & 15) * kFL + r];
+  return x;
+}
+inline void vlin_st(double *buf, int col0, int r, const vd &x) {
+  FV3_LANE_LOOP buf[((l >> 4) + col0) * kRP + 2 + (l & 15) * kFL + r] = x.v[l];
+}
+inline vd vcol_lds(const double *p, int col0) { vd x; FV3_LANE_LOOP x.v[l] = p[(l >> 4) + col0]; return x; }
+#else
+__device__ __forceinline__ vd vlin_ld(const double *buf, int col0, int r) {
+  const int l = (int)(threadIdx.x & 63);
+  return buf[((l >> 4) + col0) * kRP + 2 + (l & 15) * kFL + r];
+}
+__device__ __forceinline__ void vlin_st(double *buf, int col0, int r, vd x) {
+  const int l = (int)(threadIdx.x & 63);
+  buf[((l >> 4) + col0) * kRP + 2 + (l & 15) * kFL + r] = x;
+}
+__device__ __forceinline__ vd vcol_lds(const double *p, int col0) { return p[(int)((threadIdx.x & 63) >> 4) + col0]; }
+#endif
+
+// kords the streamed form of the mapping loop handles (cs_cell): scalar_profile / cs_profile without the two-cell limiters of 11, 12
+FV3_HD bool kord_fast(int kord) {
+  const int a = kord < 0 ? -kord : kord;
+  return kord > 7 && a >= 8 && a <= 15 && a != 11 && a != 12;
+}
+
+// One target layer of the search-and-integrate loop (fv_operators.F90:93-132 == :188-227 == :402-441; tracer_form: :277-335) with
+// the arithmetic of map_col.  The reference searches from k0, the source layer the previous target layer ended in, and takes the
+// first l with pe1(l) <= pe2(k) <= pe1(l+1): that is the smallest l with pe1(l+1) >= pe2(k) (the previous layer ended at pe2(k), in
+// the first layer whose lower edge is not above it), found here from the guess l = k.  pe1, a1: 1-based columns in LDS; a2, a3: the
+// limited edge values of every source cell (cs_cell), a4 = 3 (2 a1 - (a2 + a3)) formed here (the reference stores it: equal to
+// rounding).  The quotients through one reciprocal and a Markstein correction: the values of `/` (remap_kernels.h div_rn).
+FV3_HD double map_target(const double *pe1, const double *a1, const double *a2, const double *a3, int km, bool tracer_form, int k,
+                         double p2t, double p2b) {
+  constexpr double r3 = 1. / 3., r23 = 2. / 3.;
+  int l = k;
+  while (l > 1 && pe1[l] >= p2t) l--;
+  while (l < km && pe1[l + 1] < p2t) l++;
+  const double p1t = pe1[l], p1b = pe1[l + 1];
+  const double dp1 = p1b - p1t, rdp1 = rcp_rn(dp1);
+  const double pl = div_rn(p2t - p1t, dp1, rdp1);
+  const double b2 = a2[l], b3 = a3[l], b4 = 3. * (2. * a1[l] - (b2 + b3));
+  if (p2b <= p1b) {
+    const double pr = div_rn(p2b - p1t, dp1, rdp1);
+    if (tracer_form) {
+      double fac1 = pr + pl;
+      const double fac2 = r3 * (pr * fac1 + pl * pl);
+      fac1 = 0.5 * fac1;
+      return b2 + (b4 + b3 - b2) * fac1 - b4 * fac2;
+    }
+    return b2 + 0.5 * (b4 + b3 - b2) * (pr + pl) - b4 * r3 * (pr * (pr + pl) + pl * pl);
+  }
+  double qsum;
+  if (tracer_form) {
+    const double dp = p1b - p2t;
+    double fac1 = 1. + pl;
+    const double fac2 = r3 * (1. + pl * fac1);
+    fac1 = 0.5 * fac1;
+    qsum = dp * (b2 + (b4 + b3 - b2) * fac1 - b4 * fac2);
+  } else {
+    qsum = (p1b - p2t) * (b2 + 0.5 * (b4 + b3 - b2) * (1. + pl) - b4 * (r3 * (1. + pl * (1. + pl))));
+  }
+  for (int m = l + 1; m <= km; m++) {
+    const double mt = pe1[m], mb = pe1[m + 1];
+    if (p2b > mb) {
+      qsum = qsum + (mb - mt) * a1[m];
+    } else {
+      const double dp = p2b - mt, dm = mb - mt;
+      const double esl = div_rn(dp, dm, rcp_rn(dm));
+      const double m2 = a2[m], m3 = a3[m], m4 = 3. * (2. * a1[m] - (m2 + m3));
+      if (tracer_form) {
+        const double fac1 = 0.5 * esl, fac2 = 1. - r23 * esl;
+        qsum = qsum + dp * (m2 + fac1 * (m3 - m2 + m4 * fac2));
+      } else {
+        qsum = qsum + dp * (m2 + 0.5 * esl * (m3 - m2 + m4 * (1. - r23 * esl)));
+      }
+      break;
+    }
+  }
+  const double dp2 = p2b - p2t;
+  return div_rn(qsum, dp2, rcp_rn(dp2));
+}
+
+// the machinery both kernels share: a workgroup's 16 columns in the four LDS arrays
+struct RemapFastCore {
+  int km;
+  int dbg = 0;
+  static constexpr int kIt = kFC * 128 / kNT;   // (column, level) pairs per thread
+
+  FV3_D static double *col_ptr(double *buf, int col) { return buf + col * kRP + 2; }
+
+  // pads of a coordinate array: rows -2, -1 and km+1 .. 129 continue with unit steps (layer thickness 1: the padded rows of
+  // the system stay regular); of a field array: zeros.  Called by one thread per column after the real rows are in place.
+  FV3_D void pad_coord(double *buf, int col, int nrow) const {
+    double *p = col_ptr(buf, col);
+    p[-1] = p[0] - 1.; p[-2] = p[0] - 2.;
+    for (int r = nrow; r < 130; r++) p[r] = p[nrow - 1] + (double)(r - nrow + 1);
+  }
+  FV3_D void pad_field(double *buf, int col, int nrow) const {
+    double *p = col_ptr(buf, col);
+    p[-1] = 0.; p[-2] = 0.;
+    for (int r = nrow; r < 130; r++) p[r] = 0.;
+  }
+
+  // interface values of the cubic spline: raw q(1 .. km+1) into Q.  iv = -2: scalar_profile / cs_profile with the bottom value qs
+  // given (:572-595 / :941-964), otherwise :597-623 / :967-1016.  One wavefront = 4 columns; between barriers of the caller.
+  FV3_D void spline(const double *C1, const double *A1, double *Q, const double *QS, int iv, int wv) const {
+    const int c0 = wv * 4;
+    vd e[kFL + 1], av[kFL], dpv[kFL];
+    for (int q = 0; q <= kFL; q++) e[q] = vlin_ld(C1, c0, q);
+    const vd em1 = vlin_ld(C1, c0, -1), em2 = vlin_ld(C1, c0, -2);
+    for (int q = 0; q < kFL; q++) {
+      av[q] = vlin_ld(A1, c0, q);
+      dpv[q] = e[q + 1] - e[q];
+    }
+    const vd am1v = vlin_ld(A1, c0, -1), am2v = vlin_ld(A1, c0, -2);
+    const vd dpm1v = e[0] - em1, dpm2v = em1 - em2;
+    vd a[kFL], b[kFL], c[kFL], d[kFL], x[kFL];
+    const vd qs = QS ? vcol_lds(QS, c0) : vd(0.0);
+    for (int q = 0; q < kFL; q++) {
+      const vd a_m1 = q > 0 ? av[q - 1] : am1v, a_m2 = q > 1 ? av[q - 2] : (q == 1 ? am1v : am2v);
+      const vd dp_m1 = q > 0 ? dpv[q - 1] : dpm1v, dp_m2 = q > 1 ? dpv[q - 2] : (q == 1 ? dpm1v : dpm2v);
+      const vb first = vlevel_eq(q, 0), pad = !vlevel_lt(q, km + 1);
+      const vd gr = vdivq(dp_m1, dpv[q]);          // dp(k-1) / dp(k) of row k = r + 1
+      if (iv == -2) {
+        const vb lastc = vlevel_eq(q, km - 1), bot = vlevel_eq(q, km);
+        a[q] = vsel(first || bot || pad, vd(0.0), vd(1.0));
+        b[q] = vsel(first, vd(2.0), vsel(bot || pad, vd(1.0), 2. + gr + gr));
+        c[q] = vsel(first, vd(1.0), vsel(lastc || bot || pad, vd(0.0), gr));
+        const vd rhs = 3. * (a_m1 + av[q]);
+        d[q] = vsel(first, 3. * av[q], vsel(bot, qs, vsel(pad, vd(0.0), vsel(lastc, rhs - gr * qs, rhs))));
+      } else {
+        const vb bot = vlevel_eq(q, km);
+        // top row: grat = dp(2) / dp(1) (rows 0 and 1 are the lane's own); bottom row: d4 = dp(km-1) / dp(km)
+        const vd g1 = vdivq(dpv[1], dpv[0]);
+        const vd d4b = vdivq(dp_m2, dp_m1);
+        const vd a_bot = 1. + d4b * (d4b + 1.5);
+        a[q] = vsel(first || pad, vd(0.0), vsel(bot, a_bot, vd(1.0)));
+        b[q] = vsel(first, g1 * (g1 + 0.5), vsel(bot, d4b * (d4b + 0.5), vsel(pad, vd(1.0), 2. + gr + gr)));
+        c[q] = vsel(first, 1. + g1 * (g1 + 1.5), vsel(bot || pad, vd(0.0), gr));
+        d[q] = vsel(first, (g1 + g1) * (g1 + 1.) * av[0] + av[1],
+                    vsel(bot, 2. * d4b * (d4b + 1.) * a_m1 + a_m2, vsel(pad, vd(0.0), 3. * (a_m1 + gr * av[q]))));
+      }
+    }
+    tridiag_rows(a, b, c, d, x);
+    for (int q = 0; q < kFL; q++) vlin_st(Q, c0, q, x[q]);
+  }
+
+  // large-scale constraints on the interface values (:643-680 / :1037-1073), in place in Q; one thread per (column, interface)
+  FV3_D void constrain(const double *A1, double *Q, int iv, int ak, int tid) const {
+    for (int idx = tid; idx < kFC * 128; idx += kNT) {
+      const int col = idx >> 7, k = (idx & 127) + 1;
+      if (k < 2 || k > km) continue;
+      const double *a1 = A1 + col * kRP + 2 - 1;   // a1[k], 1-based
+      double *q = Q + col * kRP + 2 - 1;
+      const double w_m1 = a1[k - 1], w_0 = a1[k];
+      double qc = q[k];
+      if (k == 2 || k == km) {
+        const double v = dmin(qc, dmax(w_m1, w_0));
+        qc = dmax(v, dmin(w_m1, w_0));
+      } else {
+        const double gm = w_m1 - a1[k - 2], gp = a1[k + 1] - w_0;
+        if (ak >= 14 || gm * gp > 0.) {
+          qc = dmin(qc, dmax(w_m1, w_0));
+          qc = dmax(qc, dmin(w_m1, w_0));
+        } else if (gm > 0.) {
+          qc = dmax(qc, dmin(w_m1, w_0));
+        } else {
+          qc = dmin(qc, dmax(w_m1, w_0));
+          if (iv == 0) qc = dmax(0., qc);
+        }
+      }
+      q[k] = qc;
+    }
+  }
+
+  // subgrid limiters (cs_cell) of every source cell, then the mapping loop of every target layer; one thread per (column, k) for
+  // both.  The limited edge values a2 / a3 replace Q / C2 for the duration of the mapping loop (the thread keeps the two target
+  // pressures of its layer in registers and puts C2 back afterwards); on return Q holds the remapped layer means.
+  FV3_D void map_all(double *C1, double *C2, double *A1, double *Q, bool is_scalar, int iv, int ak, double qmin, bool tracer_form,
+                     int tid) const {
+    double r2[kIt], r3v[kIt], pt2[kIt], pb2[kIt];
+    const ProfCfg pc{km, iv, ak, is_scalar, qmin, true};
+    for (int it = 0; it < kIt; it++) {
+      const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
+      r2[it] = r3v[it] = pt2[it] = pb2[it] = 0.;
+      if (k > km) continue;
+      const double *a1 = col_ptr(A1, col) - 1, *q = col_ptr(Q, col) - 1, *t2 = col_ptr(C2, col) - 1;
+      double a2v = q[k], a3v = q[k + 1], a4v;
+      cs_cell(pc, k, a2v, a3v, k - 2 >= 1 ? a1[k - 2] : 0., k - 1 >= 1 ? a1[k - 1] : 0., a1[k], k + 1 <= km ? a1[k + 1] : 0.,
+              k + 2 <= km ? a1[k + 2] : 0., a4v);
+      r2[it] = a2v; r3v[it] = a3v;
+      pt2[it] = t2[k]; pb2[it] = t2[k + 1];
+    }
+    FV3_SYNC();
+    for (int it = 0; it < kIt; it++) {
+      const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
+      if (k > km) continue;
+      col_ptr(Q, col)[k - 1] = r2[it];
+      col_ptr(C2, col)[k - 1] = r3v[it];
+    }
+    FV3_SYNC();
+    for (int it = 0; it < kIt; it++) {
+      const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
+      if (k > km) continue;
+      r2[it] = map_target(col_ptr(C1, col) - 1, col_ptr(A1, col) - 1, col_ptr(Q, col) - 1, col_ptr(C2, col) - 1, km, tracer_form, k,
+                          pt2[it], pb2[it]);
+    }
+    FV3_SYNC();
+    for (int it = 0; it < kIt; it++) {
+      const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
+      if (k > km) continue;
+      col_ptr(Q, col)[k - 1] = r2[it];
+      col_ptr(C2, col)[k - 1] = pt2[it];
+      if (k == km) col_ptr(C2, col)[km] = pb2[it];
+    }
+  }
+
+  // a whole field: A1 and (for iv = -2) QS are staged, C1 / C2 hold the coordinates; on return (after its last barrier) Q holds the
+  // remapped layer means
+  FV3_D void remap_field(double *C1, double *C2, double *A1, double *Q, const double *QS, bool is_scalar, int iv, int kord,
+                         double qmin, bool tracer_form, int tid) const {
+    const int ak = kord < 0 ? -kord : kord;
+    if (!(dbg & 1)) FV3_WAVE_FOR(wv) { spline(C1, A1, Q, QS, iv, wv); }
+    FV3_SYNC();
+    if (!(dbg & 2)) constrain(A1, Q, iv, ak, tid);
+    FV3_SYNC();
+    if (!(dbg & 4)) map_all(C1, C2, A1, Q, is_scalar, iv, ak, qmin, tracer_form, tid);
+    FV3_SYNC();
+  }
+};
+
+// ---- the scalars of a column: T_v, w, delz, the tracers, omega; delp, pk, peln, pkz, ps and the conversion of pt ------------------
+struct RemapFastScalars {
+  Grid g;
+  int km;
+  RemapPar p;
+  const double *ak, *bk;
+  const int *kord_tr;   // device, nq
+  const double *pe, *ws;
+  double *ps, *delp, *pkz, *pk, *delz, *pt, *peln, *w, *q, *omga;
+  int dbg = 0;
+
+  FV3_HD int nblocks_x() const { return (g.nx + kFC - 1) / kFC; }
+
+  FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
+    constexpr int kIt = RemapFastCore::kIt;
+    const RemapFastCore core{km, dbg};
+    double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf, *QS = lds + 4 * kRBuf;
+    const int i0 = g.is + bx * kFC, j = g.js + by;
+    const int ncol = (g.nx - bx * kFC < kFC) ? g.nx - bx * kFC : kFC;
+    const size_t nA = g.nA(), nCC = g.nCC();
+    const size_t o0 = (size_t)g.iA(i0, j), occ0 = (size_t)g.iCC(i0, j);
+    const size_t peb0 = (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i0 - (g.is - 1));
+    const size_t lnb0 = (size_t)(j - g.js) * g.nx * (km + 1) + (i0 - g.is);
+    const double k1k = p.rdgas / p.cv_air, rrg = -p.rdgas / p.grav, akap = p.akap;
+    const int akt = p.kord_tm < 0 ? -p.kord_tm : p.kord_tm;
+    auto clampc = [&](int col) { return col < ncol ? col : ncol - 1; };
+    // staging map: idx -> (col = idx & 15, k0 = idx >> 4): 16 consecutive threads read 16 consecutive columns of a level
+    double tnew[kIt], dznew[kIt], qv[kIt];
+    // ---- log-pressure coordinates of T_v (:340-345, :363-368): C1 = peln, C2 = pn2; the layer means: the temperature transform
+    //      (:200-229) level by level ----
+    {
+      double v_pl[kIt], v_ps[kIt], v_t[kIt], v_a[kIt], v_b[kIt], v_c[kIt];
+      FV3_LOAD_LOOP(it) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
+        const int ki = k0 <= km ? k0 : km, kc = k0 < km ? k0 : km - 1;     // interface / cell row, clamped
+        const size_t o3 = (size_t)kc * nA + o0 + cc, c3 = (size_t)kc * nCC + occ0 + cc;
+        v_ps[it] = pe[peb0 + (size_t)km * (g.nx + 2) + cc];
+        v_pl[it] = peln[lnb0 + (size_t)ki * g.nx + cc];
+        v_t[it] = pt[o3];
+        if (p.hydrostatic) {
+          v_a[it] = pk[c3 + nCC]; v_b[it] = pk[c3]; v_c[it] = peln[lnb0 + (size_t)(kc + 1) * g.nx + cc];
+        } else {
+          v_a[it] = delp[o3]; v_b[it] = delz[c3]; v_c[it] = 0.;
+        }
+      }
+      for (int it = 0; it < kIt; it++) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
+        qv[it] = 0.; dznew[it] = 0.;
+        if (k0 <= km) {
+          RemapFastCore::col_ptr(C1, col)[k0] = v_pl[it];
+          RemapFastCore::col_ptr(C2, col)[k0] = (k0 == 0 || k0 == km) ? v_pl[it] : dlog(ak[k0] + bk[k0] * v_ps[it]);
+          if (k0 == 0) ps[o0 + cc] = v_ps[it];   // :298-300
+        }
+        if (k0 < km) {
+          double t = v_t[it];
+          if (p.hydrostatic)
+            t = t * (v_a[it] - v_b[it]) / (akap * (v_c[it] - v_pl[it]));
+          else
+            t = t * dexp(k1k * dlog(rrg * v_a[it] / v_b[it] * t));
+          RemapFastCore::col_ptr(A1, col)[k0] = t;
+        }
+      }
+    }
+    FV3_SYNC();
+    for (int col = tid; col < kFC; col += kNT) {
+      core.pad_coord(C1, col, km + 1);
+      core.pad_coord(C2, col, km + 1);
+      core.pad_field(A1, col, km);
+      QS[col] = p.hydrostatic ? 0. : ws[occ0 + clampc(col)];
+    }
+    FV3_SYNC();
+    core.remap_field(C1, C2, A1, Q, nullptr, true, 1, akt, p.t_min, false, tid);
+    for (int it = 0; it < kIt; it++) {
+      const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+      tnew[it] = k0 < km ? RemapFastCore::col_ptr(Q, col)[k0] : 0.;
+    }
+    // ---- omega on the last step (:432-443, :506-526): interpolated in the old log-p coordinate (C1) to the centres of the new
+    //      layers (C2); pe3(k) = omga(k-1), pe3(1) = 0 in A1 ----
+    if (p.last_step) {
+      FV3_SYNC();
+      {
+        double v_o[kIt];
+        FV3_LOAD_LOOP(it) {
+          const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+          const int kc = k0 < 1 ? 0 : (k0 <= km ? k0 - 1 : km - 1);
+          v_o[it] = omga[(size_t)kc * nA + o0 + clampc(col)];
+        }
+        for (int it = 0; it < kIt; it++) {
+          const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+          if (k0 <= km) RemapFastCore::col_ptr(A1, col)[k0] = k0 == 0 ? 0. : v_o[it];
+        }
+      }
+      FV3_SYNC();
+      double om[kIt];
+      for (int it = 0; it < kIt; it++) {
+        const int idx = tid + it * kNT, col = idx >> 7, n = (idx & 127) + 1;
+        om[it] = 0.;
+        if (n > km) continue;
+        const double *e = RemapFastCore::col_ptr(C1, col) - 1, *t2 = RemapFastCore::col_ptr(C2, col) - 1, *p3 = RemapFastCore::col_ptr(A1, col) - 1;
+        const double mid = 0.5 * (t2[n] + t2[n + 1]);
+        int k = n;                                  // the reference's first k (from k_next) with e(k) <= mid <= e(k+1)
+        while (k > 1 && e[k] >= mid) k--;
+        while (k < km && e[k + 1] < mid) k++;
+        om[it] = p3[k] + (p3[k + 1] - p3[k]) * (mid - e[k]) / (e[k + 1] - e[k]);
+      }
+      FV3_SYNC();
+      for (int it = 0; it < kIt; it++) {
+        const int idx = tid + it * kNT, col = idx >> 7, n = (idx & 127) + 1;
+        if (n <= km) RemapFastCore::col_ptr(Q, col)[n - 1] = om[it];
+      }
+      FV3_SYNC();
+      for (int it = 0; it < kIt; it++) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+        if (k0 < km && col < ncol) omga[(size_t)k0 * nA + o0 + col] = RemapFastCore::col_ptr(Q, col)[k0];
+      }
+    }
+    FV3_SYNC();
+    // ---- pressure coordinates for everything else: C1 = pe, C2 = pe2 (:318-322) ----
+    {
+      double v_pe[kIt], v_ps[kIt], v_w[kIt];
+      FV3_LOAD_LOOP(it) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
+        const int ki = k0 <= km ? k0 : km, kc = k0 < km ? k0 : km - 1;
+        v_ps[it] = pe[peb0 + (size_t)km * (g.nx + 2) + cc];
+        v_pe[it] = pe[peb0 + (size_t)ki * (g.nx + 2) + cc];
+        v_w[it] = p.hydrostatic ? 0. : w[(size_t)kc * nA + o0 + cc];
+      }
+      for (int it = 0; it < kIt; it++) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+        if (k0 <= km) {
+          RemapFastCore::col_ptr(C1, col)[k0] = v_pe[it];
+          RemapFastCore::col_ptr(C2, col)[k0] = (k0 == 0) ? p.ptop : (k0 == km ? v_ps[it] : ak[k0] + bk[k0] * v_ps[it]);
+        }
+        if (!p.hydrostatic && k0 < km) RemapFastCore::col_ptr(A1, col)[k0] = v_w[it];
+      }
+    }
+    FV3_SYNC();
+    for (int col = tid; col < kFC; col += kNT) {
+      core.pad_coord(C1, col, km + 1);
+      core.pad_coord(C2, col, km + 1);
+      core.pad_field(A1, col, km);
+    }
+    FV3_SYNC();
+    if (!p.hydrostatic) {
+      // ---- w (:400-411): iv = -2, the bottom value ws ----
+      core.remap_field(C1, C2, A1, Q, QS, false, -2, p.kord_wz, 0., false, tid);
+      {
+        double v_dz[kIt], v_dp[kIt];
+        FV3_LOAD_LOOP(it) {
+          const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
+          const int kc = k0 < km ? k0 : km - 1;
+          v_dz[it] = delz[(size_t)kc * nCC + occ0 + cc];
+          v_dp[it] = delp[(size_t)kc * nA + o0 + cc];
+        }
+        for (int it = 0; it < kIt; it++) {
+          const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+          if (k0 < km && col < ncol) w[(size_t)k0 * nA + o0 + col] = RemapFastCore::col_ptr(Q, col)[k0];
+          // ---- delz (:292, :412-423): the specific volume -delz / delp in, delz = -q2 dp2 out ----
+          if (k0 < km) RemapFastCore::col_ptr(A1, col)[k0] = -v_dz[it] / v_dp[it];
+        }
+      }
+      FV3_SYNC();
+      core.remap_field(C1, C2, A1, Q, nullptr, false, 1, akt, 0., false, tid);
+      for (int it = 0; it < kIt; it++) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+        if (k0 < km) {
+          const double *t2 = RemapFastCore::col_ptr(C2, col);
+          dznew[it] = -RemapFastCore::col_ptr(Q, col)[k0] * (t2[k0 + 1] - t2[k0]);
+          if (col < ncol) delz[(size_t)k0 * nCC + occ0 + col] = dznew[it];
+        }
+      }
+    }
+    // ---- the tracers (:380-397) ----
+    for (int iq = 0; iq < p.nq; iq++) {
+      double *qq = q + (size_t)iq * nA * km;
+      FV3_SYNC();
+      {
+        double v_q[kIt];
+        FV3_LOAD_LOOP(it) {
+          const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+          v_q[it] = qq[(size_t)(k0 < km ? k0 : km - 1) * nA + o0 + clampc(col)];
+        }
+        for (int it = 0; it < kIt; it++) {
+          const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+          if (k0 < km) RemapFastCore::col_ptr(A1, col)[k0] = v_q[it];
+        }
+      }
+      FV3_SYNC();
+      core.remap_field(C1, C2, A1, Q, nullptr, true, 0, kord_tr[iq], 0., p.nq > 5, tid);
+      for (int it = 0; it < kIt; it++) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+        if (k0 < km) {
+          const double v = RemapFastCore::col_ptr(Q, col)[k0];
+          if (iq == p.sphum - 1) qv[it] = v;
+          if (col < ncol) qq[(size_t)k0 * nA + o0 + col] = v;
+        }
+      }
+    }
+    FV3_SYNC();
+    // ---- the new interfaces: pn2 -> A1, pk2 -> Q (:340-345); then delp, pk, peln, pkz and pt of every layer (:426-503, :793-841) ----
+    for (int it = 0; it < kIt; it++) {
+      const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
+      if (k0 <= km) {
+        double pn, pkv;
+        if (k0 == 0 || k0 == km) {
+          pn = peln[lnb0 + (size_t)k0 * g.nx + cc];
+          pkv = pk[(size_t)k0 * nCC + occ0 + cc];
+        } else {
+          pn = dlog(RemapFastCore::col_ptr(C2, col)[k0]);
+          pkv = dexp(akap * pn);
+          if (col < ncol) {
+            peln[lnb0 + (size_t)k0 * g.nx + col] = pn;
+            pk[(size_t)k0 * nCC + occ0 + col] = pkv;
+          }
+        }
+        RemapFastCore::col_ptr(A1, col)[k0] = pn;
+        RemapFastCore::col_ptr(Q, col)[k0] = pkv;
+      }
+    }
+    FV3_SYNC();
+    for (int it = 0; it < kIt; it++) {
+      const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+      if (k0 >= km || col >= ncol) continue;
+      const double *t2 = RemapFastCore::col_ptr(C2, col), *pn = RemapFastCore::col_ptr(A1, col), *pk2 = RemapFastCore::col_ptr(Q, col);
+      const size_t o3 = (size_t)k0 * nA + o0 + col, c3 = (size_t)k0 * nCC + occ0 + col;
+      const double dp2 = t2[k0 + 1] - t2[k0];
+      delp[o3] = dp2;
+      const double tv = tnew[it];
+      double pkzv;
+      if (p.hydrostatic)
+        pkzv = (pk2[k0 + 1] - pk2[k0]) / (akap * (pn[k0 + 1] - pn[k0]));
+      else
+        pkzv = dexp(akap * dlog(rrg * dp2 / dznew[it] * tv));
+      pkz[c3] = pkzv;
+      double tn = tv;
+      if (p.last_step == 2) {              // the energy fixer follows: T_v stays, fv3_remap_finish converts (:793-821)
+      } else if (p.last_step) {            // :793-821 (dtmp = 0)
+        if (!p.adiabatic) tn = (tn + 0. / (p.hydrostatic ? p.cp : p.cv_air) * pkzv) / (1. + p.r_vir * (p.sphum > 0 ? qv[it] : 0.));
+      } else {
+        tn = tn / pkzv;                    // :833-841
+      }
+      pt[o3] = tn;
+    }
+  }
+};
+
+// ---- the D-grid winds (:530-573): u on (is:ie, js:je+1), v on (is:ie+1, js:je), each on the mean pressure of its two cells ----------
+template <int WHICH>   // 0: u, 1: v
+struct RemapFastWind {
+  Grid g;
+  int km;
+  int kord_mt;
+  const double *ak, *bk, *pe;
+  double *f;
+  int dbg = 0;
+
+  FV3_HD int ncols_row() const { return WHICH == 0 ? g.nx : g.nx + 1; }
+  FV3_HD int nrows() const { return WHICH == 0 ? g.ny + 1 : g.ny; }
+  FV3_HD int nblocks_x() const { return (ncols_row() + kFC - 1) / kFC; }
+
+  FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
+    constexpr int kIt = RemapFastCore::kIt;
+    const RemapFastCore core{km, dbg};
+    double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf;
+    const int i0 = g.is + bx * kFC, j = g.js + by;
+    const int ncol = (ncols_row() - bx * kFC < kFC) ? ncols_row() - bx * kFC : kFC;
+    const size_t fs = WHICH == 0 ? g.nU() : g.nV();
+    const size_t f0 = WHICH == 0 ? (size_t)g.iU(i0, j) : (size_t)g.iV(i0, j);
+    auto PE = [&](int ii, int k0, int jj) {
+      return pe[(size_t)(jj - (g.js - 1)) * (g.nx + 2) * (km + 1) + (size_t)k0 * (g.nx + 2) + (ii - (g.is - 1))];
+    };
+    {
+      double v_a[kIt], v_b[kIt], v_sa[kIt], v_sb[kIt], v_f[kIt];
+      FV3_LOAD_LOOP(it) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = col < ncol ? col : ncol - 1;
+        const int i = i0 + cc, i2 = WHICH == 0 ? i : i - 1, j2 = WHICH == 0 ? j - 1 : j;
+        const int ki = k0 <= km ? k0 : km, kc = k0 < km ? k0 : km - 1;
+        v_a[it] = PE(i2, ki, j2); v_b[it] = PE(i, ki, j);
+        v_sa[it] = PE(i2, km, j2); v_sb[it] = PE(i, km, j);
+        v_f[it] = f[(size_t)kc * fs + f0 + cc];
+      }
+      for (int it = 0; it < kIt; it++) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+        if (k0 <= km) {
+          const double psum = v_sa[it] + v_sb[it];
+          RemapFastCore::col_ptr(C1, col)[k0] = (k0 == 0) ? v_b[it] : 0.5 * (v_a[it] + v_b[it]);
+          const double bkh = 0.5 * bk[k0];
+          RemapFastCore::col_ptr(C2, col)[k0] = (WHICH == 1 && k0 == 0) ? ak[0] : ak[k0] + bkh * psum;
+        }
+        if (k0 < km) RemapFastCore::col_ptr(A1, col)[k0] = v_f[it];
+      }
+    }
+    FV3_SYNC();
+    for (int col = tid; col < kFC; col += kNT) {
+      core.pad_coord(C1, col, km + 1);
+      core.pad_coord(C2, col, km + 1);
+      core.pad_field(A1, col, km);
+    }
+    FV3_SYNC();
+    core.remap_field(C1, C2, A1, Q, nullptr, false, -1, kord_mt, 0., false, tid);
+    for (int it = 0; it < kIt; it++) {
+      const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+      if (k0 < km && col < ncol) f[(size_t)k0 * fs + f0 + col] = RemapFastCore::col_ptr(Q, col)[k0];
+    }
+  }
+};
+
+}  // namespace fv3

@@ -31,6 +31,8 @@ def efp_digits(values) -> list[int]:
         raise FloatingPointError("reproducing sum of a non-finite field")
     sgn = np.where(a < 0.0, -1, 1).astype(np.int64)
     rs = np.abs(a)
+    if rs.size and float(rs.max()) >= _PR[0] * _R:      # the range of the format (FMS mpp_efp.F90 aborts with an overflow)
+        raise OverflowError("reproducing sum: addend out of the range of the extended-fixed-point sum (|a| >= 2**138)")
     tot = []
     for i in range(NUMINT):
         iv = np.floor(rs * _IPR[i])
@@ -64,10 +66,10 @@ def reproducing_sum(parts, dist=None) -> float:
     for a in parts:
         d = [x + y for x, y in zip(d, efp_digits(a))]
     d = _carry(d)
+    if abs(d[0]) >= (1 << 40):       # the same guard on one rank and on several, and in fv3_ordered_sum
+        raise OverflowError("reproducing sum: leading digit too large (|sum| >= 2**132)")
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         import torch
-        if abs(d[0]) >= (1 << 40):
-            raise OverflowError("reproducing sum: leading digit too large for the int64 all_reduce")
         dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
         t = torch.tensor(d, dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -196,6 +196,10 @@ class HaloExchanger:
         between."""
         fields = list(fields)
         if self.native:
+            # the library keeps ONE group in flight (fv3_halo_start refuses a second one): part of this interface, not a
+            # property of today's call order in dyn_core
+            if getattr(self, "_native_pending", None) is not None:
+                raise RuntimeError("HaloExchanger (native): start() while another group is in flight; finish() it first")
             to = [self.topo.neighbour(*d) for d in DIRECTIONS]
             frm = [self.topo.neighbour(-d[0], -d[1]) for d in DIRECTIONS]
             pending = []
@@ -204,6 +208,7 @@ class HaloExchanger:
             # one group in flight at a time inside the library: the first is started here, the rest in finish()
             self.ctx.halo_start(*pending[0]["native"])
             pending[0]["started"] = True
+            self._native_pending = pending
             return pending
         if self.world == 1 and not self.packed_single and not self.loopback:
             for dev, kind in fields:
@@ -268,6 +273,7 @@ class HaloExchanger:
                 if not entry["started"]:
                     self.ctx.halo_start(*entry["native"])
                 self.ctx.halo_complete()
+            self._native_pending = None
             return
         for entry in pending:
             self._post(entry)

@@ -163,6 +163,19 @@ def test_fill2d(emu):
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
 
 
+def test_remap_fast_against_the_oracle(emu):
+    """the tolerance mode of the remap (csrc/remap_fast.h: the column in LDS, the spline's interface values by scans, limiters and
+    mapping loop with the parity arithmetic) against the oracle at 1e-12 -- measured 1e-16"""
+    for kw in (dict(), dict(km=20, nx=33, ny=9), dict(hydrostatic=True), dict(last_step=True, adiabatic=False),
+               dict(hydrostatic=True, last_step=True, adiabatic=False, kord_tm=-10, kord=10), dict(kord=9, kord_tm=-9, nq=7),
+               dict(km=127, nx=17, ny=3, nq=1), dict(km=79, nq=4, kord=13, kord_tm=-14)):
+        assert R.check_remap(emu, fast=True, **kw) <= 1e-12
+    # what the fast kernels are not built for takes the parity kernels (and is then exact)
+    assert R.check_remap(emu, fast=True, fill=True) <= 1e-14
+    assert R.check_remap(emu, fast=True, kord_tm=9) <= 1e-14
+    assert R.check_remap(emu, fast=True, moist_kappa=True) <= 1e-14
+
+
 def test_remap_te(emu):
     """flagstruct%remap_te (fv_mapz.F90:232-286, :348-360, :576-619, :655-663): total energy through map_scalar (kord_tm /= 0) or
     map1_cubic (kord_tm = 0), T_v and pkz from it; columns, then whole steps on both domains"""
@@ -847,6 +860,14 @@ def test_ordered_sum_is_exact_and_order_independent(emu):
         assert abs(s - math.fsum(a)) <= abs(s) * 2.3e-16
         p_ = rng.permutation(a)
         assert ctx.ordered_sum(p_) == s == reproducing_sum([p_[:777], p_[777:90000], p_[90000:]])
+        # the range of the extended fixed point format: both implementations refuse what FMS aborts on (|a| >= 2**138), and a
+        # leading digit that would not survive the int64 all-reduce
+        for bad in (np.array([1.0, 2.0 ** 138]), np.full(3000, 2.0 ** 131)):
+            with pytest.raises(Exception):
+                ctx.ordered_sum(bad)
+            with pytest.raises(OverflowError):
+                reproducing_sum([bad])
+        assert ctx.ordered_sum(np.array([2.0 ** 130, 1.0, -2.0 ** 130])) == 1.0 == reproducing_sum([np.array([2.0 ** 130, 1.0, -2.0 ** 130])])
     finally:
         ctx.close()
 
