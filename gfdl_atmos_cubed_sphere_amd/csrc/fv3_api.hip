@@ -123,6 +123,8 @@ struct fv3_ctx {
   double *cg_dev;
   double *cs_scr[32];
   int *ones_i;    // npz ones, device (ksplt of the inline_q sub-step)
+  std::vector<double> host_area;   // prt_maxmin: area on the host, and g_sum's global_area
+  double global_area = 0.;
   int march_tj;          // rows per wavefront segment of the marching kernels
   int march_tj_csw, march_tj_ke, march_tj_fused, march_tj_mom;
   int trc_nt;  // tracers per wavefront in the sub-cycle kernel (FV3_MI355X_TRACER_NT: 1..4, default 3)
@@ -238,7 +240,24 @@ extern "C" int fv3_profile(fv3_ctx *c, int enable) {
   return 0;
 }
 
-extern "C" int fv3_profile_report(fv3_ctx *c, char *out, size_t cap) {
+// the reference's timer (FMS mpp_clock through timing_on / timing_off, model/dyn_core.F90, fv_dynamics.F90, fv_tracer2d.F90) a
+// kernel label of this library belongs to
+static const char *reference_timer(const char *label) {
+  auto starts = [&](const char *p) { return std::strncmp(label, p, std::strlen(p)) == 0; };
+  if (starts("c_sw") || starts("cswc_")) return "C_SW";                                   // dyn_core.F90:437
+  if (starts("d_sw") || starts("dswc_") || starts("inline_q") || starts("flux_accum")) return "D_SW";   // :659
+  if (starts("update_dz_c")) return "UPDATE_DZ_C";                                          // :512
+  if (starts("edge_profile") || starts("zh_") || starts("zhc_")) return "UPDATE_DZ";       // :909
+  if (starts("riem_solver")) return "Riem_Solver";                                          // :529, :925
+  if (starts("nh_p_grad") || starts("a2b") || starts("one_grad_p") || starts("divg2")) return "PG_D";   // :1015
+  if (starts("halo_") || starts("cube_") || starts("gather")) return "COMM_TOTAL";
+  if (starts("tracer_") || starts("trc_")) return "tracer_2d";                              // fv_dynamics.F90:521
+  if (starts("fill2d")) return "Fill2D";                                                    // :543
+  if (starts("remap_") || starts("energy_fixer") || starts("remap_finish")) return "Remapping";   // :571
+  return "DYN_CORE";   // what dyn_core runs outside its inner timers (p_grad_c, geopk, pk3_halo, heating, omega ...)
+}
+
+static int profile_report_impl(fv3_ctx *c, char *out, size_t cap, bool timers) {
   if (!c || !out || cap == 0) return fail("fv3_profile_report: bad argument");
   RT(rt_sync(c->stream));
   struct Acc { const char *label; int n; double ms; };
@@ -247,10 +266,11 @@ extern "C" int fv3_profile_report(fv3_ctx *c, char *out, size_t cap) {
     const double ms = rt_event_elapsed_ms(r.e0, r.e1);
     rt_event_destroy(r.e0);
     rt_event_destroy(r.e1);
+    const char *label = timers ? reference_timer(r.label) : r.label;
     bool found = false;
     for (auto &a : acc)
-      if (std::strcmp(a.label, r.label) == 0) { a.n++; a.ms += ms; found = true; break; }
-    if (!found) acc.push_back({r.label, 1, ms});
+      if (std::strcmp(a.label, label) == 0) { a.n++; a.ms += ms; found = true; break; }
+    if (!found) acc.push_back({label, 1, ms});
   }
   c->prof.clear();
   std::string txt;
@@ -263,6 +283,8 @@ extern "C" int fv3_profile_report(fv3_ctx *c, char *out, size_t cap) {
   std::memcpy(out, txt.c_str(), txt.size() + 1);
   return 0;
 }
+extern "C" int fv3_profile_report(fv3_ctx *c, char *out, size_t cap) { return profile_report_impl(c, out, cap, false); }
+extern "C" int fv3_profile_report_timers(fv3_ctx *c, char *out, size_t cap) { return profile_report_impl(c, out, cap, true); }
 
 extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   if (!dom || !out) return fail("fv3_create: null argument");
@@ -2058,6 +2080,51 @@ extern "C" int fv3_ordered_sum(fv3_ctx *c, const double *values, size_t n, doubl
   double r = 0.;
   for (int i = 0; i < NI; i++) r = r + pr[i] * (double)dig[i];
   *sum = r;
+  return 0;
+}
+
+// prt_maxmin / prt_mxm (tools/fv_diagnostics.F90:4213-4313): out = {max * fac, min * fac, gmean * fac}; gmean = g_sum(q(:,:,nk), area,
+// mode = 1) (fv_grid_utils.F90:2879-2925: the local sum in the reference's loop order over the global area, itself an EFP sum).  With
+// a communicator of several ranks the extrema and the sums are reduced (mp_reduce_min / _max / _sum).
+extern "C" int fv3_prt_maxmin(fv3_ctx *c, const double *q, int nk, double fac, double out[3]) {
+  if (!c || !c->grid_ready || !q || nk < 1 || !out) return fail("fv3_prt_maxmin: bad context/arguments");
+  const Grid &g = c->g;
+  double *d = nullptr;
+  RT(rt_malloc((void **)&d, sizeof(double) * 2 * nk));
+  LevelMinMax kf{g, q, d};
+  RT(launch_p(c, "prt_maxmin", Dim3{1, 1, (unsigned)nk}, 2 * kNT, kf));
+  std::vector<double> mm(2 * nk), lev(g.nA());
+  RT(rt_d2h(mm.data(), d, sizeof(double) * 2 * nk, c->stream));
+  RT(rt_d2h(lev.data(), q + (size_t)(nk - 1) * g.nA(), sizeof(double) * g.nA(), c->stream));
+  if (c->host_area.empty()) {
+    c->host_area.resize(g.nA());
+    RT(rt_d2h(c->host_area.data(), g.area, sizeof(double) * g.nA(), c->stream));
+  }
+  RT(rt_sync(c->stream));
+  rt_free(d);
+  double qmin = mm[0], qmax = mm[1];
+  for (int k = 1; k < nk; k++) {
+    qmin = mm[2 * k] < qmin ? mm[2 * k] : qmin;
+    qmax = mm[2 * k + 1] > qmax ? mm[2 * k + 1] : qmax;
+  }
+  if (c->global_area == 0.) {   // g_sum's saved global_area: mpp_global_sum(area, BITWISE_EFP_SUM)
+    std::vector<double> ar((size_t)g.nx * g.ny);
+    for (int j = g.js; j <= g.je; j++)
+      for (int i = g.is; i <= g.ie; i++) ar[(size_t)(j - g.js) * g.nx + (i - g.is)] = c->host_area[g.iA(i, j)];
+    RT(fv3_ordered_sum(c, ar.data(), ar.size(), &c->global_area));
+  }
+  double gsum = 0.;
+  for (int j = g.js; j <= g.je; j++)
+    for (int i = g.is; i <= g.ie; i++) gsum = gsum + lev[g.iA(i, j)] * c->host_area[g.iA(i, j)];
+  if (c->comm && c->comm_size > 1) {
+    double ext[2] = {qmax, -qmin};
+    RT(fv3_allreduce_max(c, ext, 2));
+    qmax = ext[0]; qmin = -ext[1];
+    RT(fv3_ordered_sum(c, &gsum, 1, &gsum));   // mp_reduce_sum of the ranks' partial sums (exact, so independent of their order)
+  }
+  out[0] = qmax * fac;
+  out[1] = qmin * fac;
+  out[2] = gsum / c->global_area * fac;
   return 0;
 }
 

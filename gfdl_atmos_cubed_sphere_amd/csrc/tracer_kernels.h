@@ -238,4 +238,36 @@ struct Fill2dApply {  // :238-256
   }
 };
 
+// prt_maxmin / prt_mxm (tools/fv_diagnostics.F90:4213-4313): minimum and maximum of one level of an A-kind field over the compute
+// domain, one workgroup per level; out[2 bz] = min, out[2 bz + 1] = max
+struct LevelMinMax {
+  Grid g;
+  const double *q;
+  double *out;
+  FV3_HD void operator()(int, int, int bz, int tid, double *lds) const {
+    const double *s = q + (size_t)bz * g.nA();
+    const int n = g.nx * g.ny;
+    double lo = s[g.iA(g.is, g.js)], hi = lo;
+    for (int idx = tid; idx < n; idx += kNT) {
+      const double v = s[g.iA(g.is + idx % g.nx, g.js + idx / g.nx)];
+      lo = v < lo ? v : lo;
+      hi = v > hi ? v : hi;
+    }
+    lds[tid] = lo;
+    lds[kNT + tid] = hi;
+    FV3_SYNC();
+    for (int st = kNT / 2; st > 0; st >>= 1) {
+      if (tid < st) {
+        lds[tid] = lds[tid + st] < lds[tid] ? lds[tid + st] : lds[tid];
+        lds[kNT + tid] = lds[kNT + tid + st] > lds[kNT + tid] ? lds[kNT + tid + st] : lds[kNT + tid];
+      }
+      FV3_SYNC();
+    }
+    if (tid == 0) {
+      out[2 * bz] = lds[0];
+      out[2 * bz + 1] = lds[kNT];
+    }
+  }
+};
+
 }  // namespace fv3

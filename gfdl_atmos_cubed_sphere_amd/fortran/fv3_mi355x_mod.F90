@@ -17,7 +17,7 @@ module fv3_mi355x_mod
   public :: fv3_halo_field, fv3_halo_message_elems, fv3_halo_pack, fv3_halo_unpack
   public :: fv3_heat_source_accum, fv3_del2_cubed, fv3_apply_heat_source
   public :: fv3_d_sw_interior, fv3_d_sw_rest
-  public :: fv3_divg2_ext, fv3_one_grad_p, fv3_grad1_p_update, fv3_split_p_grad, fv3_d_sw_inline_q, fv3_set_remap_te, fv3_flux_accum, fv3_fill2d_mass, fv3_fill2d_apply, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
+  public :: fv3_divg2_ext, fv3_one_grad_p, fv3_grad1_p_update, fv3_split_p_grad, fv3_d_sw_inline_q, fv3_set_remap_te, fv3_profile_report_timers, fv3_prt_maxmin, fv3_flux_accum, fv3_fill2d_mass, fv3_fill2d_apply, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
   public :: fv3_grid_cubed, fv3_grid_upload_cubed, fv3_gather_create, fv3_gather_run, fv3_gather_destroy
   public :: fv3_comm_get_unique_id, fv3_comm_init, fv3_comm_destroy, fv3_halo_start, fv3_halo_complete, fv3_allreduce_max
   public :: fv3_cube_field, fv3_cube_table, fv3_cube_halo_start, fv3_cube_halo_complete
@@ -380,6 +380,19 @@ module fv3_mi355x_mod
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: ctx, u, v, pp, gz, delp, pk, du, dv
       real(c_double), value :: gz_scale, beta, dt, top_value
+    end function
+    integer(c_int) function fv3_profile_report_timers(ctx, out, cap) bind(C, name="fv3_profile_report_timers")
+      import :: c_int, c_ptr, c_char, c_size_t
+      type(c_ptr), value :: ctx
+      character(kind=c_char), intent(inout) :: out(*)
+      integer(c_size_t), value :: cap
+    end function
+    integer(c_int) function fv3_prt_maxmin(ctx, q, nk, fac, out) bind(C, name="fv3_prt_maxmin")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, q
+      integer(c_int), value :: nk
+      real(c_double), value :: fac
+      real(c_double), intent(out) :: out(3)
     end function
     integer(c_int) function fv3_set_remap_te(ctx, remap_te, hs, te) bind(C, name="fv3_set_remap_te")
       import :: c_int, c_ptr

@@ -35,7 +35,7 @@ EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_pack",
            "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_compute_total_energy", "fv3_energy_fixer_sums", "fv3_remap_finish", "fv3_ordered_sum", "fv3_adv_pe", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max", "fv3_cube_table", "fv3_cube_halo_start", "fv3_cube_halo_complete",
            "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_set_fast", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
-           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_split_p_grad", "fv3_grad1_p_update", "fv3_d_sw_inline_q", "fv3_flux_accum", "fv3_fill2d_mass", "fv3_fill2d_apply", "fv3_set_remap_te", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
+           "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_split_p_grad", "fv3_grad1_p_update", "fv3_d_sw_inline_q", "fv3_flux_accum", "fv3_fill2d_mass", "fv3_fill2d_apply", "fv3_set_remap_te", "fv3_profile_report_timers", "fv3_prt_maxmin", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
 
 
@@ -383,6 +383,23 @@ class Context:
             name, n, ms = line.split()
             out[name] = (int(n), float(ms))
         return out
+
+    def profile_report_timers(self) -> dict:
+        """the same events under the reference's timing_on / timing_off names: {timer: (count, total_ms)}"""
+        buf = C.create_string_buffer(1 << 16)
+        self.lib.check(self.lib.dll.fv3_profile_report_timers(self.h, buf, C.c_size_t(len(buf))), "fv3_profile_report_timers")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms = line.split()
+            out[name] = (int(n), float(ms))
+        return out
+
+    def prt_maxmin(self, q, fac=1.0):
+        """prt_mxm (tools/fv_diagnostics.F90:4265-4313) of an A-kind field: (max, min, area mean of the last level), times fac"""
+        out = (C.c_double * 3)()
+        nk = q.shape[2] if len(q.shape) > 2 else 1
+        self.lib.check(self.lib.dll.fv3_prt_maxmin(self.h, q.p, C.c_int(nk), C.c_double(fac), out), "fv3_prt_maxmin")
+        return float(out[0]), float(out[1]), float(out[2])
 
     # -- nonhydrostatic column path -------------------------------------------------------------------
     def _cn(self, cn: dict):

@@ -529,6 +529,15 @@ int fv3_fill2d_apply(fv3_ctx *ctx, int nk, const double *qt, const double *delp,
  * "label count total_ms" per kernel label since the last report; synchronises the stream. */
 int fv3_profile(fv3_ctx *ctx, int enable);
 int fv3_profile_report(fv3_ctx *ctx, char *out, size_t cap);
+/* The same events under the reference's timer names (timing_on / timing_off: C_SW, D_SW, UPDATE_DZ_C, UPDATE_DZ, Riem_Solver, PG_D,
+ * COMM_TOTAL, tracer_2d, Fill2D, Remapping -- model/dyn_core.F90:437-1015, fv_dynamics.F90:521-571 -- and DYN_CORE for what
+ * dyn_core runs outside its inner timers): "timer count total_ms" per line.  Either report consumes the events. */
+int fv3_profile_report_timers(fv3_ctx *ctx, char *out, size_t cap);
+
+/* prt_maxmin / prt_mxm -- tools/fv_diagnostics.F90:4213-4313: out = {max * fac, min * fac, gmean * fac} of an A-kind field of nk
+ * levels over the compute domain; gmean is prt_mxm's g_sum(q(:,:,nk), area, mode = 1) (fv_grid_utils.F90:2879-2925).  Reduced
+ * over the ranks of the context's communicator (mp_reduce_min / _max / _sum).  Synchronises the stream. */
+int fv3_prt_maxmin(fv3_ctx *ctx, const double *q, int nk, double fac, double out[3]);
 
 #ifdef __cplusplus
 }

@@ -163,6 +163,48 @@ def test_fill2d(emu):
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
 
 
+def test_prt_maxmin_and_the_reference_timers(emu):
+    """f4: prt_mxm (tools/fv_diagnostics.F90:4265-4313) -- max, min and g_sum's area mean of the last level (fv_grid_utils.F90:2879-2925),
+    restated here in the reference's loop order -- and fv3_profile's events under the reference's timing_on / timing_off names"""
+    import math
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynCore, DynFlags
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    bd = Bounds(1, 37, 1, 22)
+    g = P.make_grid(bd, True)
+    rng = np.random.default_rng(8)
+    q = np.asfortranarray(rng.normal(250.0, 30.0, bd.shape("A", 7)))
+    area = np.asarray(g.m["area"])
+    ctx = Context(g, 7, lib=emu)
+    try:
+        got = ctx.prt_maxmin(ctx.from_host(q), 0.01)
+        c = (slice(bd.ng, bd.ng + bd.nx), slice(bd.ng, bd.ng + bd.ny))
+        gsum = 0.0
+        for j in range(bd.ng, bd.ng + bd.ny):          # g_sum's "quick local sum": do j; do i
+            for i in range(bd.ng, bd.ng + bd.nx):
+                gsum = gsum + q[i, j, 6] * area[i, j]
+        garea = math.fsum(area[c].ravel())
+        assert got[0] == q[c].max() * 0.01 and got[1] == q[c].min() * 0.01
+        assert abs(got[2] - gsum / garea * 0.01) <= 4e-16 * abs(got[2])
+        # the timers: a substep loop under fv3_profile, reported under the reference's names
+        st, dp0 = D.make_state(Bounds(1, 37, 1, 22), 7)
+        dc = DynCore(ctx, DynFlags(n_split=2, ptop=N.PTOP), dp0)
+        dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
+        ctx.profile(True)
+        dc.run(4.0)
+        per_kernel = ctx.profile_report()
+        dc.run(4.0)
+        timers = ctx.profile_report_timers()
+        ctx.profile(False)
+        assert set(timers) <= {"C_SW", "D_SW", "UPDATE_DZ_C", "UPDATE_DZ", "Riem_Solver", "PG_D", "COMM_TOTAL", "tracer_2d", "Fill2D", "Remapping",
+                               "DYN_CORE"}
+        assert {"C_SW", "D_SW", "UPDATE_DZ_C", "UPDATE_DZ", "Riem_Solver", "PG_D", "COMM_TOTAL"} <= set(timers)
+        assert sum(n for n, _ in timers.values()) == sum(n for n, _ in per_kernel.values())     # every launch under exactly one timer
+        assert timers["Riem_Solver"][0] == per_kernel["riem_solver3"][0] + per_kernel["riem_solver_c"][0] == 4
+    finally:
+        ctx.close()
+
+
 def test_remap_fast_against_the_oracle(emu):
     """the tolerance mode of the remap (csrc/remap_fast.h: the column in LDS, the spline's interface values by scans, limiters and
     mapping loop with the parity arithmetic) against the oracle at 1e-12 -- measured 1e-16"""
