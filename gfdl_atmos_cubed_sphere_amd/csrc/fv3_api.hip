@@ -2972,18 +2972,15 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   for (int n = 0; n < p->nq && fast; n++) fast = kord_fast(kord_tr[n]);
   if (fast) {
     {
-      static const int dbg_ = getenv("FV3_DBG_REMAP") ? atoi(getenv("FV3_DBG_REMAP")) : 0;
-      RemapFastScalars kf{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, dbg_};
+      RemapFastScalars kf{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga};
       RT(launch_p2(c, "remap_fast_scalars", Dim3{(unsigned)kf.nblocks_x(), (unsigned)g.ny, 1}, kRLds, kf));
     }
     {
-      static const int dbg_ = getenv("FV3_DBG_REMAP") ? atoi(getenv("FV3_DBG_REMAP")) : 0;
-      RemapFastWind<0> kf{g, km, p->kord_mt, ak, bk, pe, u, dbg_};
+      RemapFastWind<0> kf{g, km, p->kord_mt, ak, bk, pe, u};
       RT(launch_p2(c, "remap_fast_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kRLds, kf));
     }
     {
-      static const int dbg_ = getenv("FV3_DBG_REMAP") ? atoi(getenv("FV3_DBG_REMAP")) : 0;
-      RemapFastWind<1> kf{g, km, p->kord_mt, ak, bk, pe, v, dbg_};
+      RemapFastWind<1> kf{g, km, p->kord_mt, ak, bk, pe, v};
       RT(launch_p2(c, "remap_fast_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kRLds, kf));
     }
     RemapPe kf{g, km, ak, bk, pe};

@@ -125,7 +125,6 @@ FV3_HD double map_target(const double *pe1, const double *a1, const double *a2, 
 // the machinery both kernels share: a workgroup's 16 columns in the four LDS arrays
 struct RemapFastCore {
   int km;
-  int dbg = 0;
   static constexpr int kIt = kFC * 128 / kNT;   // (column, level) pairs per thread
 
   FV3_D static double *col_ptr(double *buf, int col) { return buf + col * kRP + 2; }
@@ -262,11 +261,11 @@ struct RemapFastCore {
   FV3_D void remap_field(double *C1, double *C2, double *A1, double *Q, const double *QS, bool is_scalar, int iv, int kord,
                          double qmin, bool tracer_form, int tid) const {
     const int ak = kord < 0 ? -kord : kord;
-    if (!(dbg & 1)) FV3_WAVE_FOR(wv) { spline(C1, A1, Q, QS, iv, wv); }
+    FV3_WAVE_FOR(wv) { spline(C1, A1, Q, QS, iv, wv); }
     FV3_SYNC();
-    if (!(dbg & 2)) constrain(A1, Q, iv, ak, tid);
+    constrain(A1, Q, iv, ak, tid);
     FV3_SYNC();
-    if (!(dbg & 4)) map_all(C1, C2, A1, Q, is_scalar, iv, ak, qmin, tracer_form, tid);
+    map_all(C1, C2, A1, Q, is_scalar, iv, ak, qmin, tracer_form, tid);
     FV3_SYNC();
   }
 };
@@ -280,13 +279,12 @@ struct RemapFastScalars {
   const int *kord_tr;   // device, nq
   const double *pe, *ws;
   double *ps, *delp, *pkz, *pk, *delz, *pt, *peln, *w, *q, *omga;
-  int dbg = 0;
 
   FV3_HD int nblocks_x() const { return (g.nx + kFC - 1) / kFC; }
 
   FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
     constexpr int kIt = RemapFastCore::kIt;
-    const RemapFastCore core{km, dbg};
+    const RemapFastCore core{km};
     double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf, *QS = lds + 4 * kRBuf;
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (g.nx - bx * kFC < kFC) ? g.nx - bx * kFC : kFC;
@@ -298,7 +296,7 @@ struct RemapFastScalars {
     const int akt = p.kord_tm < 0 ? -p.kord_tm : p.kord_tm;
     auto clampc = [&](int col) { return col < ncol ? col : ncol - 1; };
     // staging map: idx -> (col = idx & 15, k0 = idx >> 4): 16 consecutive threads read 16 consecutive columns of a level
-    double tnew[kIt], dznew[kIt], qv[kIt];
+    double tnew[kIt], dznew[kIt], qv[kIt], pn2[kIt];   // pn2: log of the new interface pressure, formed once
     // ---- log-pressure coordinates of T_v (:340-345, :363-368): C1 = peln, C2 = pn2; the layer means: the temperature transform
     //      (:200-229) level by level ----
     {
@@ -318,10 +316,11 @@ struct RemapFastScalars {
       }
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
-        qv[it] = 0.; dznew[it] = 0.;
+        qv[it] = 0.; dznew[it] = 0.; pn2[it] = 0.;
         if (k0 <= km) {
+          pn2[it] = (k0 == 0 || k0 == km) ? v_pl[it] : dlog(ak[k0] + bk[k0] * v_ps[it]);
           RemapFastCore::col_ptr(C1, col)[k0] = v_pl[it];
-          RemapFastCore::col_ptr(C2, col)[k0] = (k0 == 0 || k0 == km) ? v_pl[it] : dlog(ak[k0] + bk[k0] * v_ps[it]);
+          RemapFastCore::col_ptr(C2, col)[k0] = pn2[it];
           if (k0 == 0) ps[o0 + cc] = v_ps[it];   // :298-300
         }
         if (k0 < km) {
@@ -474,12 +473,11 @@ struct RemapFastScalars {
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
       if (k0 <= km) {
-        double pn, pkv;
+        const double pn = pn2[it];
+        double pkv;
         if (k0 == 0 || k0 == km) {
-          pn = peln[lnb0 + (size_t)k0 * g.nx + cc];
           pkv = pk[(size_t)k0 * nCC + occ0 + cc];
         } else {
-          pn = dlog(RemapFastCore::col_ptr(C2, col)[k0]);
           pkv = dexp(akap * pn);
           if (col < ncol) {
             peln[lnb0 + (size_t)k0 * g.nx + col] = pn;
@@ -525,7 +523,6 @@ struct RemapFastWind {
   int kord_mt;
   const double *ak, *bk, *pe;
   double *f;
-  int dbg = 0;
 
   FV3_HD int ncols_row() const { return WHICH == 0 ? g.nx : g.nx + 1; }
   FV3_HD int nrows() const { return WHICH == 0 ? g.ny + 1 : g.ny; }
@@ -533,7 +530,7 @@ struct RemapFastWind {
 
   FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
     constexpr int kIt = RemapFastCore::kIt;
-    const RemapFastCore core{km, dbg};
+    const RemapFastCore core{km};
     double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf;
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (ncols_row() - bx * kFC < kFC) ? ncols_row() - bx * kFC : kFC;

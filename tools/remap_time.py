@@ -1,5 +1,5 @@
 """time Lagrangian_to_Eulerian alone (parity kernels / fast mode) on a C384L127-sized tile with nq tracers: ms per kernel label per call
-(fv3_profile events).  NX, KM, NQ, FV3_DBG_REMAP from the environment."""
+(fv3_profile events).  NX, KM, NQ from the environment."""
 import os
 import sys
 
