@@ -256,7 +256,28 @@ def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=True
             ms_call = rep[k_][1] / rep[k_][0]
             col[k_] = {"ms_per_call": round(ms_call, 4), "alg_bytes_per_cell": nb, "GBps": round(cells * nb / (ms_call * 1e-3) / 1e9, 1),
                        "frac": round(cells * nb / (ms_call * 1e-3) / HBM_PEAK, 4)}
-    return {"column_solvers": "fast mode (csrc/nh_fast.h, within 1e-12 of the parity kernels)" if fast else "parity kernels (bit-comparable with the oracle)",
+    # the vertical remap as one unit (every remap_* launch of a Lagrangian_to_Eulerian call) against ITS algorithmic bytes, 144 + 16 nq
+    # per cell (whole_step_roofline); traffic: the HBM bytes rocprofv3 counted for those launches (tools/pmc_remap.sh ->
+    # profiles/hbm_traffic_remap.json, reported while the sources are the ones it was measured on)
+    ms_remap = sum(v[1] for k_, v in rep.items() if k_.startswith("remap_")) / k_split
+    if ms_remap > 0:
+        nb = 144.0 + 16.0 * nq
+        e = {"ms_per_call": round(ms_remap, 4), "alg_bytes_per_cell": nb, "GBps": round(cells * nb / (ms_remap * 1e-3) / 1e9, 1),
+             "frac": round(cells * nb / (ms_remap * 1e-3) / HBM_PEAK, 4), "traffic": None}
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic_remap.json")) as f_:
+                tr = json.load(f_)
+            from gfdl_atmos_cubed_sphere_amd import lib as _lib
+            key = "fast" if fast else "parity"
+            if tr.get("build_id") == _lib.build_id() and tr.get("shape") == [nx, nx, npz, nq] and key in tr:
+                e["traffic"] = tr[key]
+                e["traffic_over_algorithmic"] = round(tr[key] / (cells * nb), 3)
+            else:
+                e["traffic_note"] = f"profiles/hbm_traffic_remap.json is of build {tr.get('build_id')}, shape {tr.get('shape')}: not reported"
+        except (OSError, ValueError):
+            pass
+        col["remap"] = e
+    return {"column_solvers": "fast mode (csrc/nh_fast.h, remap_fast.h; within 1e-12 of the parity kernels)" if fast else "parity kernels (bit-comparable with the oracle)",
             "column_kernels": col, "geometry": {0: "general metric rows", 1: "orthogonal", 2: "orthogonal + uniform"}.get(geom_mode),
             "whole_step": whole_step_roofline(cells, wall, k_split * n_split, k_split, nq),
             "kernels_sum_ms": round(sum(v[1] for v in rep.values()), 2),

@@ -16,7 +16,7 @@
 !> state on the device across dyn_core, tracer_2d and the remap) is the fast one.
 !>
 !> Restrictions (error stop with the reason, never a silent difference): grid_type = 4 on one rank (the cubed sphere runs
-!> through the Python host's six-face exchange, cubed_dyn.py); no nesting / regional BCs; use_cond / moist_kappa,
+!> through the Python host's six-face exchange, cubed_dyn.py); no nesting / regional BCs; use_cond / moist_kappa in fv_dynamics (dyn_core carries them),
 !> do_diss_est and the SKEB diss_est accumulation are not carried through this wrapper.
 module fv3_arrays_compat_mod
   use iso_c_binding
@@ -148,15 +148,18 @@ contains
     type(fv_diag_type), intent(in) :: idiag
     type(domain2d), intent(inout) :: domain
 
-    real(c_double), allocatable, target :: w_c(:,:,:), delz_c(:,:,:), zs(:,:)
+    real(c_double), allocatable, target :: w_c(:,:,:), delz_c(:,:,:), zs(:,:), qc_c(:,:,:), cp_c(:,:,:)
+    logical :: moist
     integer(c_size_t) :: nk, nk1
     integer :: nx, ny
 
     if (neststruct%nested .or. gridstruct%nested .or. gridstruct%regional .or. gridstruct%bounded_domain) &
       error stop 'dyn_core (fv3_dyn_core_mod): nested / regional domains are not built'
     if (gridstruct%grid_type /= 4) error stop 'dyn_core (fv3_dyn_core_mod): grid_type = 4 only through this wrapper'
-    if (thermostruct%use_cond .or. thermostruct%moist_kappa) &
-      error stop 'dyn_core (fv3_dyn_core_mod): use_cond / moist_kappa are not carried through this wrapper'
+    moist = thermostruct%use_cond .or. thermostruct%moist_kappa
+    if (moist .and. hydrostatic) error stop 'dyn_core (fv3_dyn_core_mod): use_cond / moist_kappa are nonhydrostatic branches'
+    if (thermostruct%use_cond .and. size(q_con, 3) < npz) error stop 'dyn_core (fv3_dyn_core_mod): use_cond needs q_con on npz levels'
+    if (thermostruct%moist_kappa .and. size(cappa, 3) < npz) error stop 'dyn_core (fv3_dyn_core_mod): moist_kappa needs cappa on npz levels'
     if (flagstruct%do_diss_est) error stop 'dyn_core (fv3_dyn_core_mod): do_diss_est is not carried through this wrapper'
     if (flagstruct%beta < 0.d0) error stop 'dyn_core (fv3_dyn_core_mod): beta < 0 (one_grad_p in the nonhydrostatic loop) is not built'
     if (ng /= 3 .or. bd%ng /= 3) error stop 'dyn_core (fv3_dyn_core_mod): ng = 3'
@@ -183,6 +186,18 @@ contains
     call put(at%pkz, c_loc(pkz), at%nCC*nk);   call put(at%pk, c_loc(pk), at%nCC*nk1)
     call put(at%pe, c_loc(pe), int(nx+2, c_size_t)*nk1*(ny+2)); call put(at%peln, c_loc(peln), at%nCC*nk1)
     call put(at%omga, c_loc(omga), at%nA*nk);  call put(at%ua, c_loc(ua), at%nA*nk); call put(at%va, c_loc(va), at%nA*nk)
+    ! thermostruct%use_cond: q_con (halo updated by the caller, fv_dynamics.F90:464) rides through d_sw and the Riemann solvers;
+    ! moist_kappa: cappa (:465) is read by the solvers and the heating
+    if (thermostruct%use_cond) then
+      allocate(qc_c(bd%isd:bd%ied, bd%jsd:bd%jed, npz))
+      qc_c = q_con(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz)
+      call put(at%q_con, c_loc(qc_c), at%nA*nk)
+    end if
+    if (thermostruct%moist_kappa) then
+      allocate(cp_c(bd%isd:bd%ied, bd%jsd:bd%jed, npz))
+      cp_c = cappa(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz)
+      call put(at%cappa, c_loc(cp_c), at%nA*nk)
+    end if
     call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
 
     call fv3_dyn_core(at, bdt)                                             ! the substep loop (both branches), d_con heating
@@ -202,7 +217,9 @@ contains
     call get(c_loc(mfx), at%mfx, at%nFX*nk);   call get(c_loc(mfy), at%mfy, at%nFY*nk)
     call get(c_loc(cx), at%cx, at%nCX*nk);     call get(c_loc(cy), at%cy, at%nCY*nk)
     if (flagstruct%d_con > 1.d-5) call get(c_loc(heat_source), at%heat_source, at%nA*nk)
+    if (thermostruct%use_cond) call get(c_loc(qc_c), at%q_con, at%nA*nk)
     call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
+    if (thermostruct%use_cond) q_con(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz) = qc_c
     if (.not. hydrostatic) then
       w(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz) = w_c; delz(bd%is:bd%ie, bd%js:bd%je, 1:npz) = delz_c
     else
@@ -264,6 +281,7 @@ contains
       ! rdgas: constants_mod's, as in the reference (fv3_flags carries it as its default)
       fl%adiabatic = flagstruct%adiabatic; fl%fill = flagstruct%fill
       fl%hydrostatic = hydrostatic;       fl%d_ext = flagstruct%d_ext;       fl%delt_max = flagstruct%delt_max
+      fl%use_cond = thermostruct%use_cond; fl%moist_kappa = thermostruct%moist_kappa
       fl%beta = flagstruct%beta           ! du / dv live in the bound fv3_atmos between calls, like dyn_core's saved arrays (:278-283)
       fl%convert_ke = flagstruct%convert_ke
       call fv3_host_init_grid(at, dom, gh, 0, fl, ak, bk)

@@ -50,6 +50,10 @@ module fv3_host_mod
     real(c_double) :: beta = 0.d0                     ! :403; > 0: split_p_grad / grad1_p_update
     logical :: inline_q = .false.                     ! :474; the tracers ride inside d_sw (sw_core.F90:1020-1043)
     logical :: remap_te = .false.                     ! :399; the remap carries total energy (fv_mapz.F90:232-286, :348-360, :576-619)
+    ! thermostruct%use_cond / moist_kappa (nonhydrostatic): q_con transported by d_sw and taken out of the Riemann solvers' pm2,
+    ! per-cell cappa in the solvers, the heating and the remap; moist: what moist_cv needs (fv3_set_moist)
+    logical :: use_cond = .false., moist_kappa = .false.
+    type(fv3_moist_params) :: moist
     logical :: convert_ke = .false.
   end type
 
@@ -70,6 +74,7 @@ module fv3_host_mod
     type(c_ptr) :: divg2, heat_source                 ! external-mode damping field (A), accumulated heat source (A x npz)
     type(c_ptr) :: du = c_null_ptr, dv = c_null_ptr   ! beta > 0: the saved hydrostatic pressure gradient (dyn_core.F90:278-283)
     type(c_ptr) :: fx_s = c_null_ptr, fy_s = c_null_ptr ! inline_q: the delp fluxes of one substep (FX / FY x npz)
+    type(c_ptr) :: q_con = c_null_ptr, q_con_n = c_null_ptr, cappa = c_null_ptr   ! use_cond / moist_kappa (A x npz)
     real(c_double), allocatable :: ak(:), bk(:)
   end type
 
@@ -247,6 +252,11 @@ contains
     if (fl%inline_q .and. nq > 0) then
       call dmalloc(at%fx_s, at%nFX*nk); call dmalloc(at%fy_s, at%nFY*nk)
     end if
+    if (fl%use_cond .or. fl%moist_kappa) then
+      if (fl%hydrostatic) error stop 'fv3_host_mod: use_cond / moist_kappa are nonhydrostatic branches'
+      call dmalloc(at%q_con, at%nA*nk); call dmalloc(at%q_con_n, at%nA*nk); call dmalloc(at%cappa, at%nA*nk)
+      call dzero(at, at%q_con, at%nA*nk); call dzero(at, at%q_con_n, at%nA*nk); call dzero(at, at%cappa, at%nA*nk)
+    end if
     if (fl%beta < 0.d0) error stop 'fv3_host_mod: beta < 0 (one_grad_p in the nonhydrostatic loop) is not built'
     if (fl%beta > 1.d-9) then
       call dmalloc(at%du, at%nU*nk); call dmalloc(at%dv, at%nV*nk)
@@ -401,7 +411,7 @@ contains
     integer :: it, n_split, npz
     logical :: remap_step
     integer(c_int) :: last_call, use_logp
-    type(c_ptr) :: ctx, fxp, fyp
+    type(c_ptr) :: ctx, fxp, fyp, qcp, qcn
     logical :: heating
     integer :: n_con
     if (at%fl%hydrostatic) then
@@ -423,7 +433,7 @@ contains
     call dzero(at, at%cx, at%nCX*npz);  call dzero(at, at%cy, at%nCY*npz)
     par%dt = dt; par%hord_tr = at%fl%hord_tr; par%hord_mt = at%fl%hord_mt; par%hord_vt = at%fl%hord_vt
     par%hord_tm = at%fl%hord_tm; par%hord_dp = at%fl%hord_dp; par%dddmp = at%fl%dddmp; par%d4_bg = at%fl%d4_bg
-    par%kgb = at%fl%ke_bg; par%hydrostatic = 0; par%use_cond = 0
+    par%kgb = at%fl%ke_bg; par%hydrostatic = 0; par%use_cond = merge(1_c_int, 0_c_int, at%fl%use_cond)
     ! fv_dynamics.F90:467-470: halo of delp, pt (pack 1) and u, v (pack 8) before the first substep
     call halo(at, at%delp, KIND_A, npz); call halo(at, at%pt, KIND_A, npz)
     call halo(at, at%u, KIND_U, npz);    call halo(at, at%v, KIND_V, npz)
@@ -439,19 +449,29 @@ contains
                               at%omga, at%ut, at%vt, at%divgd, int(at%fl%nord, c_int), dt2, 0_c_int, 1_c_int), 'c_sw')  ! :439-447
       if (at%fl%nord > 0) call halo(at, at%divgd, KIND_B, npz)                            ! :451 / :577 (pack 3, CORNER)
       call fv3_check(fv3_update_dz_c(ctx, dt2, at%zs, at%ut, at%vt, at%zh, at%gz, at%ws3), 'update_dz_c')   ! :514-527
+      call set_condensate(at)
       call fv3_check(fv3_riem_solver_c(ctx, dt2, at%cn, at%phis, at%omga, at%ptc, at%delpc, at%gz, at%pkc, at%ws3), &
                      'riem_solver_c')                                                     ! :531
       call fv3_check(fv3_p_grad_c(ctx, dt2, at%delpc, at%pkc, at%gz, at%uc, at%vc, 0_c_int), 'p_grad_c')    ! :562
       call halo(at, at%uc, KIND_V, npz); call halo(at, at%vc, KIND_U, npz)                ! :565 / :578 (pack 9, CGRID_NE)
       call inline_q_begin(at, fxp, fyp)
+      qcp = c_null_ptr; qcn = c_null_ptr
+      if (at%fl%use_cond) then
+        qcp = at%q_con; qcn = at%q_con_n
+      end if
       call fv3_check(fv3_d_sw(ctx, par, at%vt, at%delp, at%pt, at%u, at%v, at%w, at%uc, at%vc, at%ua, at%va, at%divgd, &
-                              fxp, fyp, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
-                              at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, c_null_ptr, at%heat_s, at%diss_e), 'd_sw')  ! :762
+                              fxp, fyp, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, qcp, &
+                              at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, qcn, at%heat_s, at%diss_e), 'd_sw')  ! :762
       if (heating) call fv3_check(fv3_heat_source_accum(ctx, at%heat_source, at%heat_s), 'heat_source_accum')   ! :798-803
       call inline_q_end(at)
       call swap(at%delp, at%delp_n); call swap(at%pt, at%pt_n)
       call swap(at%u, at%u_n); call swap(at%v, at%v_n); call swap(at%w, at%w_n)
       call halo(at, at%delp, KIND_A, npz); call halo(at, at%pt, KIND_A, npz)              ! :823-824 / :851 (pack 1)
+      if (at%fl%use_cond) then
+        call swap(at%q_con, at%q_con_n)
+        call halo(at, at%q_con, KIND_A, npz)                                              ! :825 / :852 (pack 11)
+        call set_condensate(at)
+      end if
       call fv3_check(fv3_update_dz_d(ctx, int(at%fl%hord_tm, c_int), at%zs, at%zh, at%zh_n, at%crx, at%cry, at%xfx, &
                                      at%yfx, at%ws, rdt), 'update_dz_d')                  ! :911
       call swap(at%zh, at%zh_n)
@@ -632,10 +652,17 @@ contains
     rp%cv_air = at%fl%cp_air - at%fl%rdgas; rp%r_vir = at%fl%r_vir; rp%cp = at%fl%cp_air; rp%t_min = at%fl%t_min
     do n_map = 1, at%fl%k_split
       call fv3_check(fv3_memcpy_d2d(at%ctx, at%dp1, at%delp, at%nA * at%npz * 8_c_size_t), 'dp1 = delp')   ! :475-481
+      if (at%fl%use_cond) call halo(at, at%q_con, KIND_A, at%npz)                                          ! :464 / :487 (pack 11)
+      if (at%fl%moist_kappa) call halo(at, at%cappa, KIND_A, at%npz)                                       ! :465 / :488 (pack 12)
       call fv3_dyn_core(at, mdt)                                                                           ! :493
       if (at%nq > 0 .and. .not. at%fl%inline_q) call fv3_tracer_2d(at)                                     ! :509-533
       rp%last_step = merge(1_c_int, 0_c_int, last_step .and. n_map == at%fl%k_split)
       if (at%fl%remap_te) call fv3_check(fv3_set_remap_te(at%ctx, 1_c_int, at%phis, at%dp1), 'set_remap_te')   ! te = dp1, :612
+      if (at%fl%use_cond .or. at%fl%moist_kappa) then          ! q_con is a ping-pong pair: the current buffer
+        at%fl%moist%moist_kappa = merge(1_c_int, 0_c_int, at%fl%moist_kappa)
+        at%fl%moist%use_cond = merge(1_c_int, 0_c_int, at%fl%use_cond)
+        call fv3_check(fv3_set_moist(at%ctx, at%fl%moist, at%q_con, at%cappa), 'set_moist')
+      end if
       if (at%fl%hydrostatic) then
         call fv3_check(fv3_lagrangian_to_eulerian(at%ctx, rp, kord_tr, at%ps, at%pe, at%delp, at%pkz, at%pk, at%u, at%v, &
                                                   c_null_ptr, c_null_ptr, at%pt, at%q, at%peln, at%omga, c_null_ptr), &
@@ -676,6 +703,17 @@ contains
                                      at%delp, at%delp_n, at%fx_s, at%fy_s, at%crx, at%cry, at%xfx, at%yfx), 'd_sw_inline_q')
     call fv3_check(fv3_flux_accum(at%ctx, at%mfx, at%mfy, at%fx_s, at%fy_s), 'flux_accum')
     call swap(at%q, at%q_n)
+  end subroutine
+
+  !> the condensate loading and the moist kappa of the Riemann solvers and of the heating (fv3_set_condensate): the current q_con buffer
+  subroutine set_condensate(at)
+    type(fv3_atmos), intent(in) :: at
+    type(c_ptr) :: qc, cp
+    if (.not. (at%fl%use_cond .or. at%fl%moist_kappa)) return
+    qc = c_null_ptr; cp = c_null_ptr
+    if (at%fl%use_cond) qc = at%q_con
+    if (at%fl%moist_kappa) cp = at%cappa
+    call fv3_check(fv3_set_condensate(at%ctx, qc, cp), 'set_condensate')
   end subroutine
 
   subroutine fv3_host_final(at)

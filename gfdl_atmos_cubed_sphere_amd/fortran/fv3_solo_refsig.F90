@@ -31,7 +31,7 @@ program fv3_solo_refsig
   type(group_halo_update_type) :: i_pack(13)
   real(c_double), parameter :: RDGAS = 287.04d0, KAPPA = 2.d0/7.d0, GRAV = 9.80d0, CP_AIR = RDGAS/KAPPA
   integer :: un, n, isd, ied, jsd, jed
-  logical :: hydrostatic
+  logical :: hydrostatic, moist
 
   call get_command_argument(1, fin)
   call get_command_argument(2, fout)
@@ -43,7 +43,8 @@ program fv3_solo_refsig
   read(un) dxc_, dyc_, f0_, bdt, ptop, d_con, d_ext, beta
   allocate(ak(npz+1), bk(npz+1), pfull(npz))
   read(un) ak, bk
-  hydrostatic = ihydro /= 0
+  hydrostatic = iand(ihydro, 1_c_int) /= 0
+  moist = iand(ihydro, 24_c_int) /= 0           ! bits 3, 4: use_cond, moist_kappa (then q_con, cappa follow the state)
   bd%is = 1; bd%ie = nx; bd%js = 1; bd%je = ny; bd%ng = 3
   bd%isd = -2; bd%ied = nx + 3; bd%jsd = -2; bd%jed = ny + 3
   bd%isc = 1; bd%iec = nx; bd%jsc = 1; bd%jec = ny
@@ -58,8 +59,14 @@ program fv3_solo_refsig
     allocate(q(isd:ied, jsd:jed, npz, 1))
     q = 0.d0
   end if
+  if (moist) then
+    allocate(cappa(isd:ied, jsd:jed, npz), q_con(isd:ied, jsd:jed, npz))
+    read(un) q_con, cappa
+  else
+    allocate(cappa(isd:ied, jsd:jed, 1), q_con(isd:ied, jsd:jed, 1))
+    cappa = 0.d0; q_con = 0.d0
+  end if
   close(un)
-  allocate(cappa(isd:ied, jsd:jed, 1), q_con(isd:ied, jsd:jed, 1))
   allocate(ps(isd:ied, jsd:jed), u0(isd:ied, jsd:jed+1, 1), v0(isd:ied+1, jsd:jed, 1), ze0(nx, ny, 1))
   ps = 0.d0; u0 = 0.d0; v0 = 0.d0; ze0 = 0.d0
   allocate(heat_source(isd:ied, jsd:jed, npz), diss_est(isd:ied, jsd:jed, npz))
@@ -67,7 +74,7 @@ program fv3_solo_refsig
   allocate(omga(isd:ied, jsd:jed, npz), uc(isd:ied+1, jsd:jed, npz), vc(isd:ied, jsd:jed+1, npz))
   allocate(ua(isd:ied, jsd:jed, npz), va(isd:ied, jsd:jed, npz))
   allocate(mfx(nx+1, ny, npz), mfy(nx, ny+1, npz), cx(nx+1, jsd:jed, npz), cy(isd:ied, ny+1, npz), pkz(nx, ny, npz))
-  cappa = 0.d0; q_con = 0.d0; heat_source = 0.d0; diss_est = 0.d0; pe = 0.d0; peln = 0.d0; pk = 0.d0; ws = 0.d0
+  heat_source = 0.d0; diss_est = 0.d0; pe = 0.d0; peln = 0.d0; pk = 0.d0; ws = 0.d0
   te0_2d = 0.d0; omga = 0.d0; uc = 0.d0; vc = 0.d0; ua = 0.d0; va = 0.d0; mfx = 0.d0; mfy = 0.d0; cx = 0.d0; cy = 0.d0; pkz = 0.d0
   do n = 1, npz
     pfull(n) = 0.5d0 * (ak(n) + ak(n+1) + (bk(n) + bk(n+1)) * 1.d5)
@@ -99,6 +106,7 @@ program fv3_solo_refsig
   fs%grid_type = 4; fs%n_split = n_split; fs%k_split = k_split; fs%hydrostatic = hydrostatic
   fs%d2_bg_k1 = 0.20d0; fs%d2_bg_k2 = 0.015d0; fs%a_imp = 1.d0; fs%d_con = d_con; fs%d_ext = d_ext; fs%beta = beta
   fs%prevent_diss_cooling = .true.; fs%adiabatic = .true.
+  ts%use_cond = iand(ihydro, 8_c_int) /= 0; ts%moist_kappa = iand(ihydro, 16_c_int) /= 0
 
   if (whole) then
     fs%c2l_ord = 4
@@ -132,6 +140,7 @@ program fv3_solo_refsig
 
   open(newunit=un, file=trim(fout), access='stream', form='unformatted', status='replace')
   write(un) u, v, w, delp, pt, delz, mfx, cx, pkz
+  if (moist) write(un) q_con
   close(un)
   write(*,'(a,es24.16)') 'fv3_solo_refsig: done, sum(delp) = ', sum(delp(1:nx, 1:ny, :))
 end program fv3_solo_refsig

@@ -27,9 +27,10 @@ def build_solo(workdir, libdir=CSRC, libname="fv3_mi355x"):
 
 
 def write_input(path, bd, npz, nq, n_split, k_split, nsteps, last_step, dx, dy, f0, bdt, ptop, ak, bk, st, q, hydrostatic=False,
-                d_con=0.0, d_ext=0.02, beta=0.0, inline_q=False, remap_te=False):
+                d_con=0.0, d_ext=0.02, beta=0.0, inline_q=False, remap_te=False, moist=None):
     with open(path, "wb") as f:
-        np.array([bd.nx, bd.ny, npz, nq, n_split, k_split, nsteps, int(last_step), int(hydrostatic) + 2 * int(inline_q) + 4 * int(remap_te)], dtype=np.int32).tofile(f)
+        np.array([bd.nx, bd.ny, npz, nq, n_split, k_split, nsteps, int(last_step), int(hydrostatic) + 2 * int(inline_q) + 4 * int(remap_te) +
+                  (8 * int(moist["use_cond"]) + 16 * int(moist["moist_kappa"]) if moist else 0)], dtype=np.int32).tofile(f)
         np.array([dx, dy, f0, bdt, ptop, d_con, d_ext, beta], dtype=np.float64).tofile(f)
         np.asarray(ak, dtype=np.float64).tofile(f)
         np.asarray(bk, dtype=np.float64).tofile(f)
@@ -37,6 +38,9 @@ def write_input(path, bd, npz, nq, n_split, k_split, nsteps, last_step, dx, dy, 
             np.asfortranarray(st[n], dtype=np.float64).ravel(order="F").tofile(f)
         if nq:
             np.asfortranarray(q, dtype=np.float64).ravel(order="F").tofile(f)
+        if moist:
+            for n in ("q_con", "cappa"):
+                np.asfortranarray(moist[n], dtype=np.float64).ravel(order="F").tofile(f)
 
 
 def read_output(path, bd, npz, nq):
@@ -52,7 +56,7 @@ def read_output(path, bd, npz, nq):
 
 
 def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, host_comm=False,
-                       hydrostatic=False, d_con=0.0, beta=0.0, inline_q=False, remap_te=False):
+                       hydrostatic=False, d_con=0.0, beta=0.0, inline_q=False, remap_te=False, use_cond=False, moist_kappa=False):
     """the same initial state through (a) the Python host and (b) the Fortran host: bit-identical states"""
     import parity_common as P
     import parity_dyn as D
@@ -68,12 +72,28 @@ def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_sp
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
     rng = np.random.default_rng(5)
     q = np.asfortranarray(rng.uniform(0.0, 1.0, bd.shape("A", npz) + (nq,))) if nq else None
-    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, d_con=d_con, beta=beta, inline_q=inline_q)
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, d_con=d_con, beta=beta, inline_q=inline_q, use_cond=use_cond,
+                  moist_kappa=moist_kappa)
+    moist = None
+    if use_cond or moist_kappa:        # six water species in tracers 1 .. 6 (small mixing ratios), some q_con and cappa to start from
+        import parity_remap as R
+        assert nq >= 6
+        q[..., 0] *= 0.02
+        q[..., 1:6] *= 0.002
+        from gfdl_atmos_cubed_sphere_amd.lib import CP_AIR, RDGAS
+        cvm, qc = N.np_moist_cv(q, dict(R.MOIST6, sphum=1), CP_AIR - RDGAS)     # q_con and cappa as fv_dynamics.F90:305-317 forms them
+        moist = dict(use_cond=use_cond, moist_kappa=moist_kappa, q_con=np.asfortranarray(qc),
+                     cappa=np.asfortranarray(RDGAS / (RDGAS + cvm / (1.0 + 0.6077 * q[..., 0]))))
     # ---- (a) Python host ----
     ctx = Context(g, npz, lib=lib)
     try:
-        fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=k_split, remap_te=remap_te)
+        fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=k_split, remap_te=remap_te, moist=dict(R.MOIST6) if moist else None)
         fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
+        if moist:
+            if use_cond:
+                fv.dc.d["q_con"].upload(moist["q_con"])
+            if moist_kappa:
+                fv.dc.d["cappa"].upload(moist["cappa"])
         if nq:
             fv.set_tracers(q)
         for _ in range(nsteps):
@@ -88,7 +108,7 @@ def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_sp
     exe = build_solo(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
     fin, fout = os.path.join(str(workdir), "in.bin"), os.path.join(str(workdir), "out.bin")
     write_input(fin, bd, npz, nq, n_split, k_split, nsteps, False, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak,
-                bk, st, q, hydrostatic=hydrostatic, d_con=d_con, d_ext=fl.d_ext, beta=beta, inline_q=inline_q, remap_te=remap_te)
+                bk, st, q, hydrostatic=hydrostatic, d_con=d_con, d_ext=fl.d_ext, beta=beta, inline_q=inline_q, remap_te=remap_te, moist=moist)
     env = dict(os.environ, **({"FV3_HOST_COMM": "1"} if host_comm else {}))
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -121,7 +141,7 @@ def build_refsig(workdir, libdir=CSRC, libname="fv3_mi355x"):
     return exe
 
 
-def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2, bdt=6.0, hydrostatic=False, d_con=0.0, beta=0.0):
+def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2, bdt=6.0, hydrostatic=False, d_con=0.0, beta=0.0, moist=False):
     """dyn_core called with the reference's argument list on host arrays (fv3_dyn_core_mod, driver fv3_solo_refsig) against the
     Python host's DynCore.run on the same state: u, v, w, delp, pt, delz, the accumulated mass fluxes / Courant numbers (and pkz
     when the heating or the hydrostatic branch writes it) bit-identical"""
@@ -136,15 +156,32 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
     st, _ = D.make_state(bd, npz)
     sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
-    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, d_con=d_con, beta=beta)
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, d_con=d_con, beta=beta, use_cond=moist, moist_kappa=moist)
+    mo = None
+    if moist:     # q_con / cappa as moist_cv gives them for small mixing ratios of six species (halos periodic: the caller's, :464-465)
+        import parity_remap as R
+        from gfdl_atmos_cubed_sphere_amd.layout import periodic_fill
+        from gfdl_atmos_cubed_sphere_amd.lib import CP_AIR, RDGAS
+        rng = np.random.default_rng(5)
+        qq = rng.uniform(0.0, 1.0, bd.shape("A", npz) + (6,)) * np.array([0.02] + [0.002] * 5)
+        cvm, qc = N.np_moist_cv(qq, dict(R.MOIST6, sphum=1), CP_AIR - RDGAS)
+        mo = dict(use_cond=True, moist_kappa=True, q_con=np.asfortranarray(qc), cappa=np.asfortranarray(RDGAS / (RDGAS + cvm / (1.0 + 0.6077 * qq[..., 0]))))
+        for a_ in (mo["q_con"], mo["cappa"]):
+            for k in range(npz):
+                periodic_fill(bd, a_[:, :, k], "A")
     dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
     ctx = Context(g, npz, lib=lib)
     try:
         dc = DynCore(ctx, fl, dp_ref)
         dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
+        if mo:
+            dc.d["q_con"].upload(mo["q_con"])
+            dc.d["cappa"].upload(mo["cappa"])
         for _ in range(nsteps):
+            if mo:          # the halo updates fv_dynamics makes before every dyn_core call (:464-465); the driver's arrays keep theirs
+                dc.halo.update([(dc.d["q_con"], "A")])
             dc.run(bdt)
-        names = ("u", "v", "delp", "pt", "mfx", "cx") + (() if hydrostatic else ("w", "delz"))
+        names = ("u", "v", "delp", "pt", "mfx", "cx") + (() if hydrostatic else ("w", "delz")) + (("q_con",) if mo else ())
         ref = {n: dc.d[n].download() for n in names}
         if "pkz" in dc.d and (hydrostatic or d_con > 1e-5):
             ref["pkz"] = dc.d["pkz"].download()
@@ -153,18 +190,18 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
     exe = build_refsig(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
     fin, fout = os.path.join(str(workdir), "in_rs.bin"), os.path.join(str(workdir), "out_rs.bin")
     write_input(fin, bd, npz, 0, n_split, 1, nsteps, False, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak, bk, st, None,
-                hydrostatic=hydrostatic, d_con=d_con, d_ext=fl.d_ext, beta=beta)
+                hydrostatic=hydrostatic, d_con=d_con, d_ext=fl.d_ext, beta=beta, moist=mo)
     r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     got = {}
     with open(fout, "rb") as f:
         for n, kind in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC"), ("mfx", "FX"), ("cx", "CX"),
-                        ("pkz", "CC")):
+                        ("pkz", "CC")) + ((("q_con", "A"),) if mo else ()):
             shp = bd.shape(kind, npz)
             got[n] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
     i0, i1, j0, j1 = bd.is_, bd.ie, bd.js, bd.je
     rng_ = {"u": ("U", i0, i1, j0, j1 + 1), "v": ("V", i0, i1 + 1, j0, j1), "w": ("A", i0, i1, j0, j1),
-            "delp": ("A", i0, i1, j0, j1), "pt": ("A", i0, i1, j0, j1)}
+            "delp": ("A", i0, i1, j0, j1), "pt": ("A", i0, i1, j0, j1), "q_con": ("A", i0, i1, j0, j1)}
     for n in ref:
         if n in rng_:
             kind, *r4 = rng_[n]

@@ -489,6 +489,9 @@ def test_fortran_host_drives_the_library(emu, tmp_path):
     assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=12, nq=0, hydrostatic=False, d_con=1.0)
     assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=8, nq=2, hydrostatic=False, inline_q=True)
     assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=8, nq=1, hydrostatic=True, inline_q=True, beta=0.3)
+    # thermostruct%use_cond / moist_kappa through the Fortran loop: q_con in d_sw and the Riemann solvers, cappa, the moist remap
+    assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=8, nq=7, use_cond=True, moist_kappa=True, d_con=1.0)
+    assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=8, nq=6, use_cond=True)
 
 
 def test_fortran_dyn_core_with_the_reference_argument_list(emu, tmp_path):
@@ -502,6 +505,7 @@ def test_fortran_dyn_core_with_the_reference_argument_list(emu, tmp_path):
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=12, hydrostatic=True, d_con=1.0)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, beta=0.4)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, hydrostatic=True, beta=0.4)
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, moist=True, d_con=1.0)     # thermostruct%use_cond / moist_kappa
     # fv_dynamics with ITS reference argument list (model/fv_dynamics.F90:79-85): T -> theta_v, the k_split loop with tracers and
     # the remap, last_step, cubed_to_latlon
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(emu, tmp_path)
