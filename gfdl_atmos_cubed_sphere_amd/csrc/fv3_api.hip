@@ -2221,11 +2221,11 @@ extern "C" int fv3_set_dp_ref(fv3_ctx *c, const double *dp0) {
   const int km = c->g.npz;
   if (km < 2) return fail("fv3_set_dp_ref: needs npz >= 2");
   if (!c->dp0) RT(rt_malloc((void **)&c->dp0, sizeof(double) * km));
-  if (!c->edge_dev) RT(rt_malloc((void **)&c->edge_dev, sizeof(double) * 3 * km));
+  if (!c->edge_dev) RT(rt_malloc((void **)&c->edge_dev, sizeof(double) * 4 * km));
   RT(rt_h2d(c->dp0, dp0, sizeof(double) * km, c->stream));
   // edge_profile coefficients, same arithmetic as nh_utils.F90:1640-1662
-  std::vector<double> co(3 * km, 0.);
-  double *gk = co.data(), *bet = gk + km, *gam = bet + km;
+  std::vector<double> co(4 * km, 0.);
+  double *gk = co.data(), *bet = gk + km, *gam = bet + km, *rbet = gam + km;   // rbet: the fast mode's reciprocals
   const double g0 = dp0[1] / dp0[0];
   c->ec.xt1_top = 2. * g0 * (g0 + 1.);
   c->ec.bet_top = g0 * (g0 + 0.5);
@@ -2236,11 +2236,12 @@ extern "C" int fv3_set_dp_ref(fv3_ctx *c, const double *dp0) {
     gk[k - 1] = gkk;
     bet[k - 1] = 2. + 2. * gkk - gam[k - 2];
     gam[k - 1] = gkk / bet[k - 1];
+    rbet[k - 1] = 1. / bet[k - 1];
   }
   c->ec.a_bot = 1. + gkk * (gkk + 1.5);
   c->ec.xt1_bot = 2. * gkk * (gkk + 1.);
   c->ec.gk_bot = gkk;
-  RT(rt_h2d(c->edge_dev, co.data(), sizeof(double) * 3 * km, c->stream));
+  RT(rt_h2d(c->edge_dev, co.data(), sizeof(double) * 4 * km, c->stream));
   RT(rt_sync(c->stream));
   c->ec.gk = c->edge_dev;
   c->ec.bet = c->edge_dev + km;
@@ -2341,7 +2342,11 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
   const Grid &g = c->g;
   const int km = g.npz;
   double *cxa = c->scratch[0], *xfa = c->scratch[1], *cya = c->scratch[2], *yfa = c->scratch[3];
-  {
+  using EPF = EdgeProfileFast<10>;
+  if (c->fast && km >= 2 && km <= 512) {   // one sweep over k, the back substitution as truncated chains in registers (nh_fast.h)
+    EPF kf{g, km, c->ec, c->edge_dev + 3 * km, crx, xfx, cxa, xfa, (int)g.nCX(), cry, yfx, cya, yfa, (int)g.nCY()};
+    RT(launch_p(c, "edge_profile", col_grid(2 * (int)(g.nCX() + g.nCY())), EPF::lds_doubles(km), kf));
+  } else {
     EdgeProfile kf{g, km, c->ec, crx, xfx, cxa, xfa, (int)g.nCX(), cry, yfx, cya, yfa, (int)g.nCY()};
     RT(launch_c(c, "edge_profile", col_grid((int)(g.nCX() + g.nCY())), kf));
   }

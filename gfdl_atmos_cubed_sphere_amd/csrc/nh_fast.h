@@ -280,6 +280,120 @@ FV3_D void tridiag_rows(const vd *a, const vd *b, const vd *c, const vd *d, vd *
   }
 }
 
+// edge_profile (model/nh_utils.F90:1590-1696, non-uniform branch, limiter = 0) in ONE sweep over k.  The parity kernel (nh_kernels.h
+// EdgeProfile) eliminates downwards, stores the intermediate interface values, and substitutes back upwards through them: 16 field
+// passes through HBM for 8 algorithmic ones.  The coefficients depend on dp0 only, and the back substitution
+//   x_k = y_k - gam_k x_{k+1} = y_k - gam_k (y_{k+1} - gam_{k+1} (y_{k+2} - ...))
+// forgets: the product of 31 consecutive gam is below 2e-18 for the L79 / L127 levels (0.27 per level away from the top).  So a thread
+// -- one per (column, field) -- keeps the last 40 forward values of its column in registers, and every 8 levels, at level k, starts the
+// chain at y_k, runs it 31 steps down without emitting and 8 more steps emitting interfaces k-31 .. k-38 (17 operations per level;
+// exact for the last interfaces: beyond km + 1 the chain runs over virtual levels with y = 0, gam = 0).  Every input is read once,
+// every output written once.  What bounds such a kernel is the loads a thread keeps in flight: the inputs come through a rolling
+// buffer of kPre levels (slot (k-1) % kPre is refilled with level k-1+kPre as soon as level k-1 is taken; clamped addresses, no
+// branch around a load, so the wait counts stay exact), the per-level coefficients -- the same for every column -- from an LDS table
+// (as global loads they would sit in the same in-order queue as the prefetches).
+// The quotients by bet(k) through the host's correctly rounded reciprocal and a Markstein correction (the value of `/`: a plain
+// multiplication by the reciprocal moved zh by 2e-13 through the limiter switches of its transport).
+// Against the parity kernel: 3e-17 rel-RMS on zh at L79 / L127 (test_edge_profile_fast_against_the_oracle).
+FV3_HD double edge_div(double a, double b, double rb) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double q0 = a * rb;
+  const double r = __builtin_fma(-b, q0, a);
+  return __builtin_fma(r, rb, q0);
+#else
+  (void)rb;
+  return a / b;
+#endif
+}
+template <int kPre>
+struct EdgeProfileFast {
+  static constexpr int kWin = 40, kUnit = 8, kSkip = 31;   // window slots; levels per back substitution; steps before the first emitted
+  static_assert(kWin % kPre == 0 && kWin % kUnit == 0 && kSkip + kUnit <= kWin - 1, "window");
+  Grid g;
+  int km;
+  EdgeCoef ec;
+  const double *rbet;     // device, km: 1 / ec.bet correctly rounded
+  const double *q1, *q2;
+  double *q1e, *q2e;
+  int n2d;
+  const double *q1_b, *q2_b;
+  double *q1e_b, *q2e_b;
+  int n2d_b;
+  // levels the sweep runs over: whole windows, and every interface up to km + 1 emitted (interface j leaves at level j + kSkip .. )
+  FV3_HD static int kpad(int km) { return (km + 1 + kSkip + kUnit - 1 + kWin - 1) / kWin * kWin; }
+  static size_t lds_doubles(int km) { return (size_t)3 * kpad(km) + kWin + kpad(km); }
+  FV3_HD void operator()(int bx, int, int, int tid, double *lds) const {
+    const int nk = km + 1, kp = kpad(km);
+    // table[k - 1]: gk, bet, 1 / bet of level k (k = 1: the top closure; k = km + 1: the bottom one; beyond: 1), gam with kWin zeros in front
+    double *t_gk = lds, *t_bet = t_gk + kp, *t_rb = t_bet + kp, *t_gam = t_rb + kp;
+    const double xt2 = ec.gk_bot * (ec.gk_bot + 0.5) - ec.a_bot * ec.gam[km - 1];
+    for (int i = tid; i < kp; i += kNT) {
+      const bool in = i >= 1 && i < km;
+      t_gk[i] = in ? ec.gk[i] : 0.;
+      t_bet[i] = in ? ec.bet[i] : (i == 0 ? ec.bet_top : (i == km ? xt2 : 1.));
+      t_rb[i] = in ? rbet[i] : (i == 0 ? 1. / ec.bet_top : (i == km ? 1. / xt2 : 1.));
+    }
+    for (int i = tid; i < kp + kWin; i += kNT) t_gam[i] = (i >= kWin && i < kWin + km) ? ec.gam[i - kWin] : 0.;
+    FV3_SYNC();
+    const int ntot = 2 * (n2d + n2d_b);
+    for (int vt = bx * 256 + tid; vt < (bx + 1) * 256 && vt < ntot; vt += kNT) {
+      const bool second = vt >= 2 * n2d;
+      const int r = second ? vt - 2 * n2d : vt, ls_i = second ? n2d_b : n2d;
+      const int f = r >= ls_i ? 1 : 0, c = r - f * ls_i;
+      const size_t ls = (size_t)ls_i;
+      const double *__restrict__ p = second ? (f ? q2_b : q1_b) : (f ? q2 : q1);
+      double *__restrict__ o = second ? (f ? q2e_b : q1e_b) : (f ? q2e : q1e);
+      double y[kWin], nb[kPre];
+      for (int t = 0; t < kWin; t++) y[t] = 0.;
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+      for (int t = 0; t < kPre; t++) nb[t] = p[(size_t)(t < km ? t : km - 1) * ls + c];
+      double a_prev = nb[0], a_cur = a_prev, e = 0.;
+      for (int k0 = 0; k0 < kp; k0 += kWin) {
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+        for (int u = 0; u < kWin / kUnit; u++) {
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+         for (int i = 0; i < kUnit; i++) {
+          const int t = u * kUnit + i, k = k0 + t + 1;
+          const double a_new = k == 1 ? nb[1 % kPre] : nb[t % kPre];   // level k - 1 (0-based), slot (k - 1) % kPre; k = 1: levels 0 and 1
+          a_cur = k <= km ? a_new : a_cur;
+          {                                        // level k - 1 is taken (k = 1: level 0, into a_prev): refill its slot
+            const int kn = k - 1 + kPre;
+            nb[t % kPre] = p[(size_t)(kn < km ? kn : km - 1) * ls + c];
+          }
+          const double gk = t_gk[k - 1], bt = t_bet[k - 1], rb = t_rb[k - 1];
+          const double num_i = 3. * (a_prev + gk * a_cur) - e;
+          const double num_1 = ec.xt1_top * a_prev + a_cur;
+          const double num_n = ec.xt1_bot * a_cur + a_prev - ec.a_bot * e;   // a_prev = q(km-1), a_cur = q(km)
+          const double num = k == 1 ? num_1 : (k == nk ? num_n : num_i);
+          const double en = edge_div(num, bt, rb);
+          e = k <= nk ? en : 0.;
+          a_prev = (k >= 2 && k < km) ? a_cur : a_prev;
+          y[t] = e;
+         }
+         {                                         // back substitution from level k: interfaces k - kSkip - kUnit + 1 .. k - kSkip leave
+          const int t = u * kUnit + kUnit - 1, k = k0 + t + 1;
+          double x = e;
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+          for (int m = 1; m < kSkip + kUnit; m++) {
+            const int j = k - m;                   // interface of this step
+            x = y[(t - m + kWin) % kWin] - t_gam[j - 1 + kWin] * x;
+            if (m >= kSkip && j >= 1 && j <= nk) o[(size_t)(j - 1) * ls + c] = x;
+          }
+         }
+        }
+      }
+    }
+  }
+};
+
 // CG = true: Riem_Solver_c on (is-1:ie+1, js-1:je+1); false: Riem_Solver3 on the compute domain
 template <bool CG>
 struct RiemFast {

@@ -205,6 +205,14 @@ def test_prt_maxmin_and_the_reference_timers(emu):
         ctx.close()
 
 
+def test_edge_profile_fast_against_the_oracle(emu):
+    """update_dz_d with edge_profile in one sweep over k (nh_fast.h EdgeProfileFast: the back substitution as a chain truncated after
+    32 levels, where the product of the gam is below 1.2e-18) against the oracle; km + 1 a multiple of the window and not"""
+    for km in (5, 20, 79, 127):
+        N.check_update_dz_d(emu, nx=33, ny=9, km=km, fast=True)
+    N.check_update_dz_d(emu, km=40, fast=True, lev_over=dict(do_vort_damp=True, vtdm4=0.06, nord=2))
+
+
 def test_remap_fast_against_the_oracle(emu):
     """the tolerance mode of the remap (csrc/remap_fast.h: the column in LDS, the spline's interface values by scans, limiters and
     mapping loop with the parity arithmetic) against the oracle at 1e-12 -- measured 1e-16"""
