@@ -2256,7 +2256,7 @@ extern "C" int fv3_update_dz_c(fv3_ctx *c, double dt, const double *zs, const do
   if (!c->dp0_ready) return fail("fv3_update_dz_c: call fv3_set_dp_ref first");
   if (gz_in == gz) return fail("fv3_update_dz_c: gz_in and gz must not alias");
   UpdateDzC kf{c->g, c->g.npz, dt, c->dp0, zs, ut, vt, gz_in, gz, ws};
-  RT(launch_c(c, "update_dz_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), kf));
+  RT(launch_p(c, "update_dz_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), UpdateDzC::lds_doubles(c->g.npz), kf));
   return 0;
 }
 

@@ -41,6 +41,19 @@ struct NhConsts {
     for (int c = bb_ * 256 + tid, cs = ((P) > 0 ? bx : bb_) * 256 + tid; c < (bb_ + 1) * 256 && c < (ncol); c += kNT, cs += kNT)
 
 // ------------------------------------------------------------------------------------------------
+#ifdef FV3_HOST_EMU
+#define FV3_RESTRICT
+#define FV3_UNROLL4
+#else
+#define FV3_RESTRICT __restrict__
+#define FV3_UNROLL4 _Pragma("unroll 4")
+#endif
+// One sweep from the surface up: the flux-form update of a level does not depend on the other levels, and the monotonicity fix
+// (:193-199) runs from the bottom, so the thread applies it to each level as it is formed and writes gz once (the first form of this
+// kernel swept down forming gz and up again fixing it: 16 word accesses per level, 8 of them the winds of a level read for both of
+// its interfaces; here 4 + the 5 heights + 1 store).  The interface weights of dp_ref come from an LDS table: as global loads they
+// cannot be scalar (the kernel stores to global memory) and would queue with the field loads.  Values are bit for bit those of the
+// two-sweep form.
 struct UpdateDzC {
   Grid g;
   int km;
@@ -48,12 +61,23 @@ struct UpdateDzC {
   const double *dp0;  // device, km
   const double *zs, *ut, *vt, *gz_in;
   double *gz, *ws;
-  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+  static size_t lds_doubles(int km) { return 3 * (size_t)(km + 2); }
+  FV3_HD void operator()(int bx, int, int, int tid, double *lds) const {
     const int w = g.nx + 2, ncol = w * (g.ny + 2);
-    const int nA = (int)g.nA();
+    const size_t nA = g.nA();
     const double rdt = 1. / dt;
     const double top_ratio = dp0[0] / (dp0[0] + dp0[1]);
     const double bot_ratio = dp0[km - 1] / (dp0[km - 2] + dp0[km - 1]);
+    double *t_wa = lds, *t_wb = lds + km + 2, *t_ir = lds + 2 * (km + 2);   // interface k = 2 .. km: dp0(k), dp0(k-1), 1 / (dp0(k-1) + dp0(k))
+    for (int k = tid; k < km + 2; k += kNT) {
+      const bool in = k >= 2 && k <= km;
+      t_wa[k] = in ? dp0[k - 1] : 0.;
+      t_wb[k] = in ? dp0[k - 2] : 0.;
+      t_ir[k] = in ? 1. / (dp0[k - 2] + dp0[k - 1]) : 0.;
+    }
+    FV3_SYNC();
+    const double *FV3_RESTRICT U = ut, *FV3_RESTRICT V = vt, *FV3_RESTRICT Z = gz_in;
+    double *FV3_RESTRICT G = gz;
     FV3_COL_FOR(c, ncol) {
       const int i = g.is - 1 + c % w, j = g.js - 1 + c / w;
       const int o = g.iA(i, j);
@@ -66,45 +90,78 @@ struct UpdateDzC {
         os = m(2, i, j - 1); on = m(2, i, j + 1); cy_ = m(2, i, j);
       }
       const double ar = g.area[o];
-      for (int k = 1; k <= km + 1; k++) {
-        double x0, x1, y0, y1;
-        if (k == 1) {
-          const double *a = ut, *b = ut + nA, *cc = vt, *d = vt + nA;
-          x0 = a[o] + (a[o] - b[o]) * top_ratio;
-          x1 = a[oe_v] + (a[oe_v] - b[oe_v]) * top_ratio;
-          y0 = cc[o] + (cc[o] - d[o]) * top_ratio;
-          y1 = cc[on_v] + (cc[on_v] - d[on_v]) * top_ratio;
-        } else if (k == km + 1) {
-          const double *a = ut + (size_t)(km - 1) * nA, *b = ut + (size_t)(km - 2) * nA;
-          const double *cc = vt + (size_t)(km - 1) * nA, *d = vt + (size_t)(km - 2) * nA;
-          x0 = a[o] + (a[o] - b[o]) * bot_ratio;
-          x1 = a[oe_v] + (a[oe_v] - b[oe_v]) * bot_ratio;
-          y0 = cc[o] + (cc[o] - d[o]) * bot_ratio;
-          y1 = cc[on_v] + (cc[on_v] - d[on_v]) * bot_ratio;
-        } else {
-          const double int_ratio = 1. / (dp0[k - 2] + dp0[k - 1]);
-          const double *a = ut + (size_t)(k - 2) * nA, *b = ut + (size_t)(k - 1) * nA;
-          const double *cc = vt + (size_t)(k - 2) * nA, *d = vt + (size_t)(k - 1) * nA;
-          x0 = (dp0[k - 1] * a[o] + dp0[k - 2] * b[o]) * int_ratio;
-          x1 = (dp0[k - 1] * a[oe_v] + dp0[k - 2] * b[oe_v]) * int_ratio;
-          y0 = (dp0[k - 1] * cc[o] + dp0[k - 2] * d[o]) * int_ratio;
-          y1 = (dp0[k - 1] * cc[on_v] + dp0[k - 2] * d[on_v]) * int_ratio;
-        }
-        const double *z = gz_in + (size_t)(k - 1) * nA;
-        // cubed sphere: fill_4corners(gz2, 1) before the x fluxes, (gz2, 2) before the y fluxes (nh_utils.F90:151,163), as
-        // index maps on the reads; the cell value of the update is what the second fill left (identity off the corners)
-        const double zcx = z[cx_], zcy = z[cy_];
-        const double fx0 = x0 * ((x0 > 0.) ? z[ow] : zcx), fx1 = x1 * ((x1 > 0.) ? zcx : z[oe]);
-        const double fy0 = y0 * ((y0 > 0.) ? z[os] : zcy), fy1 = y1 * ((y1 > 0.) ? zcy : z[on]);
-        gz[(size_t)(k - 1) * nA + o] = (zcy * ar + fx0 - fx1 + fy0 - fy1) / (ar + x0 - x1 + y0 - y1);
+      // cubed sphere: fill_4corners(gz2, 1) before the x fluxes, (gz2, 2) before the y fluxes (nh_utils.F90:151,163), as
+      // index maps on the reads; the cell value of the update is what the second fill left (identity off the corners)
+      struct Z6 { double cx, cy, w, e, s, n; };   // the heights of one interface around the cell: all six loaded, then the upwind choice
+      struct W4 { double uo, ue, vo, vn; };       // winds of one layer at the cell and at its east / north neighbour
+      auto heights = [&](int k) {
+        const double *z = Z + (size_t)((k > 1 ? k : 1) - 1) * nA;
+        return Z6{z[cx_], z[cy_], z[ow], z[oe], z[os], z[on]};
+      };
+      auto winds = [&](int l) {
+        const size_t b = (size_t)(l > 0 ? l : 0) * nA;
+        return W4{U[b + o], U[b + oe_v], V[b + o], V[b + on_v]};
+      };
+      auto height = [&](const Z6 &z, double x0, double x1, double y0, double y1) {
+        const double fx0 = x0 * ((x0 > 0.) ? z.w : z.cx), fx1 = x1 * ((x1 > 0.) ? z.cx : z.e);
+        const double fy0 = y0 * ((y0 > 0.) ? z.s : z.cy), fy1 = y1 * ((y1 > 0.) ? z.cy : z.n);
+        return (z.cy * ar + fx0 - fx1 + fy0 - fy1) / (ar + x0 - x1 + y0 - y1);
+      };
+      // The loads of kDep interfaces ahead are in flight while one is worked on: slot s holds the heights of the interface the sweep
+      // reaches s steps from now and the winds of the layer that enters with it; a slot is refilled as soon as it is used (clamped
+      // addresses, no branch around a load).
+      constexpr int kDep = 4;
+      Z6 zb[kDep];
+      W4 wb[kDep];
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+      for (int s = 0; s < kDep; s++) {
+        zb[s] = heights(km - s);
+        wb[s] = winds(km - s - 3);
       }
-      double below = gz[(size_t)km * nA + o];
+      W4 B = winds(km - 1), A = winds(km - 2);   // interface k between layers k-1 and k (1-based): A = layer k-1, B = layer k
+      double below = height(heights(km + 1), B.uo + (B.uo - A.uo) * bot_ratio, B.ue + (B.ue - A.ue) * bot_ratio,
+                            B.vo + (B.vo - A.vo) * bot_ratio, B.vn + (B.vn - A.vn) * bot_ratio);
+      G[(size_t)km * nA + o] = below;
       ws[o] = (zs[o] - below) * rdt;
-      for (int k = km; k >= 1; k--) {
-        const double v = dmax(gz[(size_t)(k - 1) * nA + o], below + kDzMin);
-        gz[(size_t)(k - 1) * nA + o] = v;
+      auto level = [&](int k, const Z6 &z, const W4 &wn) {
+        double x0, x1, y0, y1;
+        if (k > 1) {
+          const double wa = t_wa[k], wb_ = t_wb[k], ir = t_ir[k];
+          x0 = (wa * A.uo + wb_ * B.uo) * ir; x1 = (wa * A.ue + wb_ * B.ue) * ir;
+          y0 = (wa * A.vo + wb_ * B.vo) * ir; y1 = (wa * A.vn + wb_ * B.vn) * ir;
+        } else {                                  // A = layer 1, B = layer 2
+          x0 = A.uo + (A.uo - B.uo) * top_ratio; x1 = A.ue + (A.ue - B.ue) * top_ratio;
+          y0 = A.vo + (A.vo - B.vo) * top_ratio; y1 = A.vn + (A.vn - B.vn) * top_ratio;
+        }
+        const double v = dmax(height(z, x0, x1, y0, y1), below + kDzMin);
+        G[(size_t)(k - 1) * nA + o] = v;
         below = v;
+        if (k >= 3) {                             // the layers of interface k - 1 (interface 2 leaves them to interface 1)
+          B = A;
+          A = wn;
+        }
+      };
+      int kk = km;
+      for (; kk - kDep + 1 >= 1; kk -= kDep) {
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+        for (int s = 0; s < kDep; s++) {
+          const int k = kk - s;
+          const Z6 z = zb[s];
+          const W4 wn = wb[s];
+          zb[s] = heights(k - kDep);
+          wb[s] = winds(k - kDep - 3);
+          level(k, z, wn);
+        }
       }
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+      for (int s = 0; s < kDep; s++)
+        if (kk - s >= 1) level(kk - s, zb[s], wb[s]);
     }
   }
 };
@@ -123,13 +180,6 @@ struct ColIn {
   const double *qcon = nullptr, *cappa = nullptr;
 };
 
-#ifdef FV3_HOST_EMU
-#define FV3_RESTRICT
-#define FV3_UNROLL4
-#else
-#define FV3_RESTRICT __restrict__
-#define FV3_UNROLL4 _Pragma("unroll 4")
-#endif
 // The scratch slabs never alias the inputs or each other: with that stated (and the k loops unrolled by 4) the
 // compiler issues the loads of the next levels ahead of the dependent recurrence instead of one level at a time.
 // Results are handed to the caller's sinks while the last two sweeps run (no extra passes over the scratch slabs):
