@@ -2437,11 +2437,7 @@ extern "C" int fv3_p_grad_c(fv3_ctx *c, double dt2, const double *delpc, const d
   if (!c || !c->grid_ready) return fail("fv3_p_grad_c: context has no grid");
   const Grid &g = c->g;
   PGradC kf{g, dt2, hydrostatic, delpc, pkc, gz, uc, vc};
-  Dim3 grid;
-  grid.x = (unsigned)(((g.nx + 1) * (g.ny + 1) + PGradC::CH - 1) / PGradC::CH);
-  grid.y = 1;
-  grid.z = (unsigned)g.npz;
-  RT(launch_p(c, "p_grad_c", grid, 0, kf));
+  RT(launch_c(c, "p_grad_c", col_grid(kf.ncol()), kf));
   return 0;
 }
 
@@ -2688,13 +2684,13 @@ static int nh_p_grad_impl(fv3_ctx *c, double *u, double *v, const double *pp, co
     RT((run_a2b<TI, TJ>(c, kf, km + 1)));
   }
   {
-    NhPGrad kf{g, dt, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], u, v};
-    kf.beta = beta; kf.du = du; kf.dv = dv;
-    Dim3 grid;
-    grid.x = (unsigned)(((g.nx + 1) * (g.ny + 1) + NhPGrad::CH - 1) / NhPGrad::CH);
-    grid.y = 1;
-    grid.z = (unsigned)km;
-    RT(launch_p(c, "nh_p_grad", grid, 0, kf));
+    if (du) {
+      NhPGrad<true> kf{g, dt, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], u, v, beta, du, dv};
+      RT(launch_c(c, "nh_p_grad", col_grid(kf.ncol()), kf));
+    } else {
+      NhPGrad<false> kf{g, dt, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], u, v};
+      RT(launch_c(c, "nh_p_grad", col_grid(kf.ncol()), kf));
+    }
   }
   return 0;
 }
@@ -2797,7 +2793,11 @@ extern "C" int fv3_copy_a_to_cc(fv3_ctx *c, const double *src, double *dst, int 
 extern "C" int fv3_pk3_halo(fv3_ctx *c, double ptop, double akap, double *pk3, const double *delp, int use_logp) {
   if (!c || !c->grid_ready) return fail("fv3_pk3_halo: context has no grid");
   Pk3Halo kf{c->g, c->g.npz, use_logp, ptop, akap, delp, pk3};
-  RT(launch_c(c, "pk3_halo", col_grid((c->g.nx + 4) * (c->g.ny + 4)), kf));
+  Dim3 gr;
+  gr.x = (unsigned)((kf.ring() + Pk3Halo::NC - 1) / Pk3Halo::NC);
+  gr.y = 1;
+  gr.z = 1;
+  RT(launch_p(c, "pk3_halo", gr, Pk3Halo::lds_doubles(c->g.npz), kf));
   return 0;
 }
 

@@ -642,7 +642,10 @@ struct ZhTransport {
   }
 };
 
-struct ZhLimit {  // update_dz_d :303-319
+// update_dz_d :303-319.  The heights of kDep interfaces above are in flight while one is fixed (in place: a slot is read before the
+// sweep reaches -- and may write -- its interface); an interface the fix leaves as it was (nearly all of them) is not written back.
+struct ZhLimit {
+  static constexpr int kDep = 8;
   Grid g;
   int km;
   double rdt;
@@ -654,13 +657,35 @@ struct ZhLimit {  // update_dz_d :303-319
     FV3_COL_FOR(c, ncol) {
       const int i = g.is + c % g.nx, j = g.js + c / g.nx;
       const int o = g.iA(i, j);
+      double nb[kDep];
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+      for (int s = 0; s < kDep; s++) nb[s] = zh[(size_t)(km - 1 - s > 0 ? km - 1 - s : 0) * nA + o];   // interface km - s (1-based)
       double below = zh[(size_t)km * nA + o];
       ws[g.iCC(i, j)] = (zs[o] - below) * rdt;
-      for (int k = km; k >= 1; k--) {
-        const double v = dmax(zh[(size_t)(k - 1) * nA + o], below + kDzMin);
-        zh[(size_t)(k - 1) * nA + o] = v;
+      auto fix = [&](int k, double z) {
+        const double v = dmax(z, below + kDzMin);
+        if (v != z) zh[(size_t)(k - 1) * nA + o] = v;
         below = v;
+      };
+      int k0 = km;
+      for (; k0 - kDep >= 0; k0 -= kDep) {
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+        for (int s = 0; s < kDep; s++) {
+          const int k = k0 - s;
+          const double z = nb[s];
+          nb[s] = zh[(size_t)(k - 1 - kDep > 0 ? k - 1 - kDep : 0) * nA + o];
+          fix(k, z);
+        }
       }
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+      for (int s = 0; s < kDep; s++)
+        if (k0 - s >= 1) fix(k0 - s, nb[s]);
     }
   }
 };
@@ -687,35 +712,65 @@ struct ZhFromDelz {  // dyn_core.F90:370-385: gz(npz+1) = zs; gz(k) = gz(k+1) - 
 };
 
 // ------------------------------------------------------------------------------------------------
-struct PGradC {  // p_grad_c, dyn_core.F90:1635-1694
+// p_grad_c, dyn_core.F90:1635-1694.  One thread per cell (i, j) of [is, ie+1] x [js, je+1] marching down its column (see NhPGrad
+// below): uc between the cells (i - 1, j) and (i, j), vc between (i, j - 1) and (i, j); the interface above in registers, kDep
+// interfaces ahead in flight (clamped addresses, no branch around a load).
+struct PGradC {
+  static constexpr int kDep = 4;
   Grid g;
   double dt2;
   int hydrostatic;
   const double *delpc, *pkc, *gz;
   double *uc, *vc;
-  static constexpr int CH = 1024;
-  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
-    const int k = bz;  // 0-based level
-    const size_t nA = g.nA();
-    const double *pk0 = pkc + (size_t)k * nA, *pk1 = pk0 + nA, *gz0 = gz + (size_t)k * nA, *gz1 = gz0 + nA;
-    const double *dpc = delpc + (size_t)k * nA;
-    const int w = g.nx + 1, n = w * (g.ny + 1);
-    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
-      const int i = g.is + idx % w, j = g.js + idx / w;
+  FV3_HD int ncol() const { return (g.nx + 1) * (g.ny + 1); }
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int km = g.npz, w = g.nx + 1;
+    const size_t nA = g.nA(), nU = g.nU(), nV = g.nV();
+    const double *FV3_RESTRICT PK = pkc, *FV3_RESTRICT GZ = gz, *FV3_RESTRICT DP = delpc;
+    FV3_COL_FOR(c, ncol()) {
+      const int i = g.is + c % w, j = g.js + c / w;
+      const bool do_u = j <= g.je, do_v = i <= g.ie;
       const int o = g.iA(i, j), ow = g.iA(i - 1, j), os = g.iA(i, j - 1);
-      const double wk0 = hydrostatic ? pk1[o] - pk0[o] : dpc[o];
-      if (j <= g.je) {
-        const double wkw = hydrostatic ? pk1[ow] - pk0[ow] : dpc[ow];
-        double *p = uc + (size_t)k * g.nV() + g.iV(i, j);
-        *p = *p + dt2 * g.rdxc[g.iV(i, j)] / (wkw + wk0) *
-                      ((gz1[ow] - gz0[o]) * (pk1[o] - pk0[ow]) + (gz0[ow] - gz1[o]) * (pk1[ow] - pk0[o]));
+      const int ou = g.iV(i, do_u ? j : g.je), ov = g.iU(do_v ? i : g.ie, j);
+      double *FV3_RESTRICT pu = uc + ou, *FV3_RESTRICT pv = vc + ov;
+      const double rdu = g.rdxc[ou], rdv = g.rdyc[ov];
+      struct Lev { double pk, pkw, pks, gz, gzw, gzs, dp, dpw, dps, u, v; };   // interface l + 1 and layer l (0-based)
+      auto fetch = [&](int l) {
+        const size_t o1 = (size_t)(l + 1 < km ? l + 1 : km) * nA, lc = (size_t)(l < km ? l : km - 1), o0 = lc * nA;
+        return Lev{PK[o1 + o], PK[o1 + ow], PK[o1 + os], GZ[o1 + o], GZ[o1 + ow], GZ[o1 + os],
+                   hydrostatic ? 0. : DP[o0 + o], hydrostatic ? 0. : DP[o0 + ow], hydrostatic ? 0. : DP[o0 + os], pu[lc * nV], pv[lc * nU]};
+      };
+      Lev nb[kDep];
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+      for (int s = 0; s < kDep; s++) nb[s] = fetch(s);
+      double pk0 = PK[o], pk0w = PK[ow], pk0s = PK[os], gz0 = GZ[o], gz0w = GZ[ow], gz0s = GZ[os];
+      auto layer = [&](int l, const Lev &n) {
+        const double wk0 = hydrostatic ? n.pk - pk0 : n.dp;
+        const double wkw = hydrostatic ? n.pkw - pk0w : n.dpw, wks = hydrostatic ? n.pks - pk0s : n.dps;
+        const double un = n.u + dt2 * rdu / (wkw + wk0) * ((n.gzw - gz0) * (n.pk - pk0w) + (gz0w - n.gz) * (n.pkw - pk0));
+        const double vn = n.v + dt2 * rdv / (wks + wk0) * ((n.gzs - gz0) * (n.pk - pk0s) + (gz0s - n.gz) * (n.pks - pk0));
+        if (do_u) pu[(size_t)l * nV] = un;
+        if (do_v) pv[(size_t)l * nU] = vn;
+        pk0 = n.pk; pk0w = n.pkw; pk0s = n.pks; gz0 = n.gz; gz0w = n.gzw; gz0s = n.gzs;
+      };
+      int l0 = 0;
+      for (; l0 + kDep <= km; l0 += kDep) {
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+        for (int s = 0; s < kDep; s++) {
+          const Lev n = nb[s];
+          nb[s] = fetch(l0 + s + kDep);
+          layer(l0 + s, n);
+        }
       }
-      if (i <= g.ie) {
-        const double wks = hydrostatic ? pk1[os] - pk0[os] : dpc[os];
-        double *p = vc + (size_t)k * g.nU() + g.iU(i, j);
-        *p = *p + dt2 * g.rdyc[g.iU(i, j)] / (wks + wk0) *
-                      ((gz1[os] - gz0[o]) * (pk1[o] - pk0[os]) + (gz0[os] - gz1[o]) * (pk1[os] - pk0[o]));
-      }
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+      for (int s = 0; s < kDep; s++)
+        if (l0 + s < km) layer(l0 + s, nb[s]);
     }
   }
 };
@@ -777,82 +832,140 @@ struct A2BCorners {
   }
 };
 
-struct NhPGrad {  // nh_p_grad :1746-1790 on precomputed corner values; with du / dv: split_p_grad :1795-1900 (beta > 0)
+// nh_p_grad :1746-1790 on precomputed corner values; SPLIT: split_p_grad :1795-1900 (beta > 0) -- the hydrostatic part of the
+// gradient of the previous substep (du / dv: U / V x npz, zero before the first call: dyn_core.F90:278-283) enters with weight beta,
+// the current one with 1 - beta, and is stored for the next substep.
+// One thread per corner (i, j) of [is, ie+1] x [js, je+1], marching down its column: u between the corners (i, j) and (i + 1, j), v
+// between (i, j) and (i, j + 1); the corner values of the interface above stay in registers, those of kDep interfaces ahead are in
+// flight (a rolling buffer refilled as it is used, clamped addresses).  The first form of this kernel was a launch per level: both
+// interfaces of a layer loaded by every thread, 27 loads per cell for 14.
+template <bool SPLIT>
+struct NhPGrad {
+  static constexpr int kDep = 3;
   Grid g;
   double dt;
   const double *pp, *pk, *gz, *dpc;  // corner slabs: pp, pk, gz (npz+1 levels), delp (npz levels)
   double *u, *v;
-  // split_p_grad: the hydrostatic part of the gradient of the previous substep (U / V x npz, zero before the first call:
-  // dyn_core.F90:278-283) enters with weight beta, the current one with 1 - beta, and is stored for the next substep
   double beta = 0.;
   double *du = nullptr, *dv = nullptr;
-  static constexpr int CH = 1024;
-  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
-    const int k = bz;
-    const size_t nA = g.nA();
-    const double *pp0 = pp + (size_t)k * nA, *pp1 = pp0 + nA, *pk0 = pk + (size_t)k * nA, *pk1 = pk0 + nA;
-    const double *gz0 = gz + (size_t)k * nA, *gz1 = gz0 + nA, *w1 = dpc + (size_t)k * nA;
-    const int w = g.nx + 1, n = w * (g.ny + 1);
-    for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
-      const int i = g.is + idx % w, j = g.js + idx / w;
+  FV3_HD int ncol() const { return (g.nx + 1) * (g.ny + 1); }
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int km = g.npz, w = g.nx + 1;
+    const size_t nA = g.nA(), nU = g.nU(), nV = g.nV();
+    const double *FV3_RESTRICT PP = pp, *FV3_RESTRICT PK = pk, *FV3_RESTRICT GZ = gz, *FV3_RESTRICT W1 = dpc;
+    FV3_COL_FOR(c, ncol()) {
+      const int i = g.is + c % w, j = g.js + c / w;
+      const bool do_u = i <= g.ie, do_v = j <= g.je;
       const int o = g.iA(i, j), oe = g.iA(i + 1, j), on = g.iA(i, j + 1);
-      const double wk0 = pk1[o] - pk0[o];
-      if (i <= g.ie) {
-        const double wke = pk1[oe] - pk0[oe];
-        const double du1 = dt / (wk0 + wke) * ((gz1[o] - gz0[oe]) * (pk1[oe] - pk0[o]) + (gz0[o] - gz1[oe]) * (pk1[o] - pk0[oe]));
-        double *p = u + (size_t)k * g.nU() + g.iU(i, j);
-        if (du) {
-          double *q = du + (size_t)k * g.nU() + g.iU(i, j);
-          const double u0 = *p + beta * *q;                                         // :1866
-          *q = du1;
-          *p = (u0 + (1. - beta) * du1 +
-                dt / (w1[o] + w1[oe]) * ((gz1[o] - gz0[oe]) * (pp1[oe] - pp0[o]) + (gz0[o] - gz1[oe]) * (pp1[o] - pp0[oe]))) *
-               g.rdx[g.iU(i, j)];
-        } else
-        *p = (*p + du1 +
-              dt / (w1[o] + w1[oe]) * ((gz1[o] - gz0[oe]) * (pp1[oe] - pp0[o]) + (gz0[o] - gz1[oe]) * (pp1[o] - pp0[oe]))) *
-             g.rdx[g.iU(i, j)];
+      const int ou = g.iU(do_u ? i : g.ie, j), ov = g.iV(i, do_v ? j : g.je);
+      double *FV3_RESTRICT pu = u + ou, *FV3_RESTRICT pv = v + ov;
+      double *FV3_RESTRICT qu = SPLIT ? du + ou : nullptr, *FV3_RESTRICT qv = SPLIT ? dv + ov : nullptr;
+      const double rdu = g.rdx[ou], rdv = g.rdy[ov];
+      struct Lev { double pp, ppe, ppn, pk, pke, pkn, gz, gze, gzn, w, we, wn, u, v, du, dv; };   // interface l + 1, layer l (0-based)
+      auto fetch = [&](int l) {
+        const size_t o1 = (size_t)(l + 1 < km ? l + 1 : km) * nA, lc = (size_t)(l < km ? l : km - 1), o0 = lc * nA;
+        return Lev{PP[o1 + o], PP[o1 + oe], PP[o1 + on], PK[o1 + o], PK[o1 + oe], PK[o1 + on], GZ[o1 + o], GZ[o1 + oe], GZ[o1 + on],
+                   W1[o0 + o], W1[o0 + oe], W1[o0 + on], pu[lc * nU], pv[lc * nV], SPLIT ? qu[lc * nU] : 0., SPLIT ? qv[lc * nV] : 0.};
+      };
+      Lev nb[kDep];
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+      for (int s = 0; s < kDep; s++) nb[s] = fetch(s);
+      double pp0 = PP[o], pp0e = PP[oe], pp0n = PP[on], pk0 = PK[o], pk0e = PK[oe], pk0n = PK[on], gz0 = GZ[o], gz0e = GZ[oe], gz0n = GZ[on];
+      auto layer = [&](int l, const Lev &n) {
+        const double wk0 = n.pk - pk0, wke = n.pke - pk0e, wkn = n.pkn - pk0n;
+        const double du1 = dt / (wk0 + wke) * ((n.gz - gz0e) * (n.pke - pk0) + (gz0 - n.gze) * (n.pk - pk0e));
+        const double du2 = dt / (n.w + n.we) * ((n.gz - gz0e) * (n.ppe - pp0) + (gz0 - n.gze) * (n.pp - pp0e));
+        const double dv1 = dt / (wk0 + wkn) * ((n.gz - gz0n) * (n.pkn - pk0) + (gz0 - n.gzn) * (n.pk - pk0n));
+        const double dv2 = dt / (n.w + n.wn) * ((n.gz - gz0n) * (n.ppn - pp0) + (gz0 - n.gzn) * (n.pp - pp0n));
+        double un, vn;
+        if (SPLIT) {
+          un = (n.u + beta * n.du + (1. - beta) * du1 + du2) * rdu;                 // :1866
+          vn = (n.v + beta * n.dv + (1. - beta) * dv1 + dv2) * rdv;                 // :1885
+        } else {
+          un = (n.u + du1 + du2) * rdu;
+          vn = (n.v + dv1 + dv2) * rdv;
+        }
+        if (do_u) {
+          pu[(size_t)l * nU] = un;
+          if (SPLIT) qu[(size_t)l * nU] = du1;
+        }
+        if (do_v) {
+          pv[(size_t)l * nV] = vn;
+          if (SPLIT) qv[(size_t)l * nV] = dv1;
+        }
+        pp0 = n.pp; pp0e = n.ppe; pp0n = n.ppn; pk0 = n.pk; pk0e = n.pke; pk0n = n.pkn; gz0 = n.gz; gz0e = n.gze; gz0n = n.gzn;
+      };
+      int l0 = 0;
+      for (; l0 + kDep <= km; l0 += kDep) {
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+        for (int s = 0; s < kDep; s++) {
+          const Lev n = nb[s];
+          nb[s] = fetch(l0 + s + kDep);
+          layer(l0 + s, n);
+        }
       }
-      if (j <= g.je) {
-        const double wkn = pk1[on] - pk0[on];
-        const double dv1 = dt / (wk0 + wkn) * ((gz1[o] - gz0[on]) * (pk1[on] - pk0[o]) + (gz0[o] - gz1[on]) * (pk1[o] - pk0[on]));
-        double *p = v + (size_t)k * g.nV() + g.iV(i, j);
-        if (dv) {
-          double *q = dv + (size_t)k * g.nV() + g.iV(i, j);
-          const double v0 = *p + beta * *q;                                         // :1885
-          *q = dv1;
-          *p = (v0 + (1. - beta) * dv1 +
-                dt / (w1[o] + w1[on]) * ((gz1[o] - gz0[on]) * (pp1[on] - pp0[o]) + (gz0[o] - gz1[on]) * (pp1[o] - pp0[on]))) *
-               g.rdy[g.iV(i, j)];
-        } else
-        *p = (*p + dv1 +
-              dt / (w1[o] + w1[on]) * ((gz1[o] - gz0[on]) * (pp1[on] - pp0[o]) + (gz0[o] - gz1[on]) * (pp1[o] - pp0[on]))) *
-             g.rdy[g.iV(i, j)];
-      }
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+      for (int s = 0; s < kDep; s++)
+        if (l0 + s < km) layer(l0 + s, nb[s]);
     }
   }
 };
 
 // ------------------------------------------------------------------------------------------------
 // pk3_halo / pln_halo: the 2-wide ring [is-2,ie+2]^2 minus the compute domain (dyn_core.F90:1395-1496)
+// The ring is 4 (nx + ny + 4) columns: they are enumerated compactly (a launch over the whole (nx + 4) x (ny + 4) box left two lanes
+// of most wavefronts working), and a workgroup takes NC of them in two phases: NC threads form the hydrostatic pressures of a
+// column each, in the reference's order, into LDS; then all threads take the logarithm / the power of one (column, level) each.
 struct Pk3Halo {
+  static constexpr int NC = 8;
   Grid g;
   int npz, use_logp;
   double ptop, akap;
   const double *delp;
   double *pk3;
-  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
-    const int w = g.nx + 4, ncol = w * (g.ny + 4);
+  static size_t lds_doubles(int npz) { return (size_t)NC * npz; }
+  FV3_HD int ring() const { return 4 * (g.nx + 4) + 4 * g.ny; }
+  FV3_HD int ring_column(int r) const {   // r-th column of the ring: the two rows below, the two rows above, then the sides row by row
+    const int w = g.nx + 4;
+    int i, j;
+    if (r < 2 * w) {
+      j = g.js - 2 + r / w; i = g.is - 2 + r % w;
+    } else if (r < 4 * w) {
+      r -= 2 * w;
+      j = g.je + 1 + r / w; i = g.is - 2 + r % w;
+    } else {
+      r -= 4 * w;
+      j = g.js + r / 4;
+      const int s = r % 4;
+      i = s < 2 ? g.is - 2 + s : g.ie - 1 + s;
+    }
+    return g.iA(i, j);
+  }
+  FV3_HD void operator()(int bx, int, int, int tid, double *lds) const {
     const size_t nA = g.nA();
-    FV3_COL_FOR(c, ncol) {
-      const int i = g.is - 2 + c % w, j = g.js - 2 + c / w;
-      if (i >= g.is && i <= g.ie && j >= g.js && j <= g.je) continue;
-      const int o = g.iA(i, j);
+    const int nr = ring();
+    for (int t = tid; t < NC; t += kNT) {
+      const int r = bx * NC + t;
+      if (r >= nr) continue;
+      const int o = ring_column(r);
       double pet = ptop;
       for (int k = 1; k <= npz; k++) {
         pet = pet + delp[(size_t)(k - 1) * nA + o];
-        pk3[(size_t)k * nA + o] = use_logp ? dlog(pet) : dexp(akap * dlog(pet));
+        lds[t * npz + k - 1] = pet;
       }
+    }
+    FV3_SYNC();
+    for (int idx = tid; idx < NC * npz; idx += kNT) {
+      const int t = idx % NC, k = idx / NC + 1, r = bx * NC + t;
+      if (r >= nr) continue;
+      const double pet = lds[t * npz + k - 1];
+      pk3[(size_t)k * nA + ring_column(r)] = use_logp ? dlog(pet) : dexp(akap * dlog(pet));
     }
   }
 };
