@@ -2668,7 +2668,7 @@ static int nh_p_grad_impl(fv3_ctx *c, double *u, double *v, const double *pp, co
   if (need_scratch(c, 4)) return 1;
   const Grid &g = c->g;
   const int km = g.npz;
-  constexpr int TI = 32, TJ = 8;
+  constexpr int TI = 32, TJ = 16;
   {
     A2BCorners<TI, TJ> kf;
     kf.g = g;
@@ -2752,7 +2752,7 @@ static int one_grad_p_impl(fv3_ctx *c, double *u, double *v, const double *pk, c
   if (need_scratch(c, 2)) return 1;
   const Grid &g = c->g;
   const int km = g.npz;
-  constexpr int TI = 32, TJ = 8;
+  constexpr int TI = 32, TJ = 16;
   {
     A2BCorners<TI, TJ> kf;
     kf.g = g;

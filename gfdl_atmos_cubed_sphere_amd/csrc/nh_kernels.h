@@ -814,19 +814,30 @@ struct A2BCorners {
         FV3_TILE_FOR(W, H, li, lj) { s.p[lj * W + li] = s.p[lj * W + li] * scale[f]; }
       }
       FV3_SYNC();
-      FV3_TILE_FOR(TI, TJ, li_, lj_) {
-        const int i = i0 + li_, j = j0 + lj_;
+      // a thread takes the NV corners (i, j .. j + NV - 1): their 4 x (NV + 3) cells once into registers (the 4 x 4 blocks of
+      // neighbouring corners share 12 cells, and qx / qy of one corner read the same 16), then the sums of the reference
+      constexpr int NV = 2;   // 4 (4 x 7 cells, 32 x 32 tiles) was measured slower: 0.43 against 0.40 ms
+      static_assert(TJ % 2 == 0, "A2BCorners: TJ must be even");
+      for (int idx = tid; idx < TI * (TJ / NV); idx += kNT) {
+        const int i = i0 + idx % TI, j = j0 + NV * (idx / TI);
         if (i > g.ie + 1 || j > g.je + 1) continue;
-        double qx[4], qy[4];
-        for (int t = 0; t < 4; t++) {
-          const int jj = j - 2 + t, ii = i - 2 + t;
-          qx[t] = b1 * (s(i - 1, jj) + s(i, jj)) + b2 * (s(i - 2, jj) + s(i + 1, jj));
-          qy[t] = b1 * (s(ii, j - 1) + s(ii, j)) + b2 * (s(ii, j - 2) + s(ii, j + 1));
+        double cl[NV + 3][4];
+        for (int r = 0; r < NV + 3; r++)
+          for (int t = 0; t < 4; t++) cl[r][t] = s(i - 2 + t, j - 2 + r);
+        double qxr[NV + 3];
+        for (int r = 0; r < NV + 3; r++) qxr[r] = b1 * (cl[r][1] + cl[r][2]) + b2 * (cl[r][0] + cl[r][3]);
+        for (int d = 0; d < NV; d++) {
+          if (j + d > g.je + 1) continue;
+          double qx[4], qy[4];
+          for (int t = 0; t < 4; t++) {
+            qx[t] = qxr[d + t];
+            qy[t] = b1 * (cl[d + 1][t] + cl[d + 2][t]) + b2 * (cl[d][t] + cl[d + 3][t]);
+          }
+          if (sum_form)
+            o[g.iA(i, j + d)] = 0.5 * ((a2 * (qx[0] + qx[3]) + a1 * (qx[1] + qx[2])) + (a2 * (qy[0] + qy[3]) + a1 * (qy[1] + qy[2])));
+          else
+            o[g.iA(i, j + d)] = 0.5 * (a1 * (qx[1] + qx[2] + qy[1] + qy[2]) + a2 * (qx[0] + qx[3] + qy[0] + qy[3]));
         }
-        if (sum_form)
-          o[g.iA(i, j)] = 0.5 * ((a2 * (qx[0] + qx[3]) + a1 * (qx[1] + qx[2])) + (a2 * (qy[0] + qy[3]) + a1 * (qy[1] + qy[2])));
-        else
-          o[g.iA(i, j)] = 0.5 * (a1 * (qx[1] + qx[2] + qy[1] + qy[2]) + a2 * (qx[0] + qx[3] + qy[0] + qy[3]));
       }
     }
   }
