@@ -2813,8 +2813,19 @@ extern "C" int fv3_geopk(fv3_ctx *c, double ptop, double akap, double cp_air, do
                          int CG) {
   if (!c || !c->grid_ready) return fail("fv3_geopk: context has no grid");
   const int e = CG ? 1 : 2;
+  const int ncol = (c->g.nx + 2 * e) * (c->g.ny + 2 * e);
+  static const int phased_max = [] { const char *v = std::getenv("FV3_MI355X_GEOPK_PHASED"); return v ? std::atoi(v) : 65536; }();
+  if (ncol <= phased_max && GeopkPhased::lds_doubles(c->g.npz) * sizeof(double) <= 64 * 1024) {   // small faces: phases over LDS
+    GeopkPhased kf{c->g, c->g.npz, CG, ptop, akap, cp_air, ptk, delp, hs, pt, pe, peln, pk, gz, pkz};
+    Dim3 gr;
+    gr.x = (unsigned)((ncol + GeopkPhased::NC - 1) / GeopkPhased::NC);
+    gr.y = 1;
+    gr.z = 1;
+    RT(launch_p(c, "geopk", gr, GeopkPhased::lds_doubles(c->g.npz), kf));
+    return 0;
+  }
   Geopk kf{c->g, c->g.npz, CG, ptop, akap, cp_air, ptk, delp, hs, pt, pe, peln, pk, gz, pkz};
-  RT(launch_c(c, "geopk", col_grid((c->g.nx + 2 * e) * (c->g.ny + 2 * e)), kf));
+  RT(launch_c(c, "geopk", col_grid(ncol), kf));
   return 0;
 }
 

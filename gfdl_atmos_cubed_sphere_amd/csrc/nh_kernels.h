@@ -1051,6 +1051,126 @@ struct Geopk {  // geopk, dyn_core.F90:2202-2353 (use_cond = .false.)
   }
 };
 
+// The same in phases over LDS, for faces too small to fill the chip with one thread per column (a C96 face has 157 wavefronts for
+// 1 024 SIMDs, each running 79 logarithms and powers one after the other: 130 us per call, a third of the stream time of BASELINE
+// config 2).  A workgroup takes NC consecutive columns: (a) NC threads sum the pressures of a column each, in the reference's order,
+// into LDS; (b) all threads take the logarithm and the power of one (column, interface) each and write pe, peln, pk; (c) NC threads
+// run the hydrostatic integral upwards with pk from LDS; (d) all threads form pkz.  The values are those of the kernel above bit for
+// bit (the same operations on the same operands).  The loads of the two serial phases go through rolling buffers of kDep levels.
+struct GeopkPhased {
+  static constexpr int NC = 16, kDep = 8;
+  Grid g;
+  int km, CG;
+  double ptop, akap, cp_air, ptk;
+  const double *delp, *hs, *pt;
+  double *pe, *peln, *pk, *gz, *pkz;
+  static size_t lds_doubles(int km) { return (size_t)2 * NC * (km + 1); }
+  FV3_HD int ncol() const { const int e = CG ? 1 : 2; return (g.nx + 2 * e) * (g.ny + 2 * e); }
+  FV3_HD void operator()(int bx, int, int, int tid, double *lds) const {
+    const int e = CG ? 1 : 2, nk = km + 1;
+    const int w = g.nx + 2 * e, nc = ncol();
+    const size_t nA = g.nA(), nCC = g.nCC();
+    double *P = lds, *K = lds + (size_t)NC * nk;   // [column][interface]: p, then log p; pk
+    const double *FV3_RESTRICT DP = delp, *FV3_RESTRICT PT = pt;
+    double *FV3_RESTRICT GZ = gz;
+    struct Col { int o; bool in_pe, in_c; size_t pb, lb; int icc; bool ok; };
+    auto column = [&](int t) {
+      const int c = bx * NC + t;
+      Col q;
+      q.ok = c < nc;
+      const int cc = q.ok ? c : nc - 1;
+      const int i = g.is - e + cc % w, j = g.js - e + cc / w;
+      q.o = g.iA(i, j);
+      q.in_pe = (j > g.js - 2 && j < g.je + 2 && i >= g.is - 1 && i <= g.ie + 1);
+      q.in_c = (j >= g.js && j <= g.je && i >= g.is && i <= g.ie);
+      q.pb = q.in_pe ? (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i - (g.is - 1)) : 0;
+      q.lb = q.in_c ? (size_t)(j - g.js) * g.nx * (km + 1) + (i - g.is) : 0;
+      q.icc = q.in_c ? g.iCC(i, j) : 0;
+      return q;
+    };
+    // (a) p(k) = ptop + sum delp
+    for (int t = tid; t < NC; t += kNT) {
+      const Col q = column(t);
+      double nb[kDep];
+      for (int s = 0; s < kDep; s++) nb[s] = DP[(size_t)(s < km ? s : km - 1) * nA + q.o];
+      double p1d = ptop;
+      P[t * nk] = p1d;
+      int l0 = 0;
+      for (; l0 + kDep <= km; l0 += kDep) {
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+        for (int s = 0; s < kDep; s++) {
+          const double d = nb[s];
+          const int ln = l0 + s + kDep;
+          nb[s] = DP[(size_t)(ln < km ? ln : km - 1) * nA + q.o];
+          p1d = p1d + d;
+          P[t * nk + l0 + s + 1] = p1d;
+        }
+      }
+      for (int s = 0; s < kDep; s++)
+        if (l0 + s < km) {
+          p1d = p1d + nb[s];
+          P[t * nk + l0 + s + 1] = p1d;
+        }
+    }
+    FV3_SYNC();
+    // (b) log p, p^kappa of every (column, interface)
+    const double peln1 = dlog(ptop);
+    for (int idx = tid; idx < NC * nk; idx += kNT) {
+      const int t = idx % NC, k = idx / NC;   // interface k + 1
+      const Col q = column(t);
+      const double p1d = P[t * nk + k];
+      const double logp = k == 0 ? peln1 : dlog(p1d);
+      const double pkv = k == 0 ? ptk : dexp(akap * logp);
+      P[t * nk + k] = logp;
+      K[t * nk + k] = pkv;
+      if (!q.ok) continue;
+      pk[(size_t)k * nA + q.o] = pkv;
+      if (q.in_pe) pe[q.pb + (size_t)k * (g.nx + 2)] = p1d;
+      if (q.in_c) peln[q.lb + (size_t)k * g.nx] = logp;
+    }
+    FV3_SYNC();
+    // (c) gz(k) = gz(k+1) + cp pt(k) (pk(k+1) - pk(k)), from the surface up
+    for (int t = tid; t < NC; t += kNT) {
+      const Col q = column(t);
+      if (!q.ok) continue;
+      double nb[kDep];
+      for (int s = 0; s < kDep; s++) nb[s] = PT[(size_t)(km - 1 - s > 0 ? km - 1 - s : 0) * nA + q.o];
+      double zb = hs[q.o];
+      GZ[(size_t)km * nA + q.o] = zb;
+      int k0 = km;
+      for (; k0 - kDep >= 0; k0 -= kDep) {
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+        for (int s = 0; s < kDep; s++) {
+          const int k = k0 - s;               // layer k (1-based)
+          const double ptv = nb[s];
+          nb[s] = PT[(size_t)(k - 1 - kDep > 0 ? k - 1 - kDep : 0) * nA + q.o];
+          zb = zb + cp_air * ptv * (K[t * nk + k] - K[t * nk + k - 1]);
+          GZ[(size_t)(k - 1) * nA + q.o] = zb;
+        }
+      }
+      for (int s = 0; s < kDep; s++)
+        if (k0 - s >= 1) {
+          const int k = k0 - s;
+          zb = zb + cp_air * nb[s] * (K[t * nk + k] - K[t * nk + k - 1]);
+          GZ[(size_t)(k - 1) * nA + q.o] = zb;
+        }
+    }
+    // (d) pkz (reads LDS only: no barrier needed after (c))
+    if (!CG) {
+      for (int idx = tid; idx < NC * km; idx += kNT) {
+        const int t = idx % NC, k = idx / NC + 1;
+        const Col q = column(t);
+        if (!q.ok || !q.in_c) continue;
+        pkz[(size_t)(k - 1) * nCC + q.icc] = (K[t * nk + k] - K[t * nk + k - 1]) / (akap * (P[t * nk + k] - P[t * nk + k - 1]));
+      }
+    }
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // dissipative heating after the substep loop (dyn_core.F90:798-803, :1300-1355, del2_cubed :2356-2465)
 struct HeatAccum {
