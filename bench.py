@@ -353,7 +353,7 @@ def cubed_sphere_leg(a, torch, stream):
         torch, stream, cs, gs, nx, npz, hydrostatic=False, k_split=2, n_split=5, dt_atmos=225.0, nrep=2, fast=not a.parity_columns)
     try:
         cs2 = CubedSphere(97)
-        out["config2_c96_l79_hydrostatic"], _ = sphere_steps(torch, stream, cs2, [cs2.gridstruct(t) for t in range(6)], 96, 79,
+        out["config2_c96_l79_hydrostatic"], out["config2_kernels_ms_per_dt_atmos"] = sphere_steps(torch, stream, cs2, [cs2.gridstruct(t) for t in range(6)], 96, 79,
                                                            hydrostatic=True, k_split=2, n_split=6, dt_atmos=1800.0, nrep=5)
     except Exception as e:  # noqa: BLE001
         out["config2_c96_l79_hydrostatic"] = {"error": f"{type(e).__name__}: {e}"}
