@@ -1487,6 +1487,7 @@ struct HaloStrip {  // one (message, field) pair
   long buf_off;             // element offset of this field's strip inside the message buffer
   int i0, ni, j0, nj;       // strip origin (array indices) and extent
   int pitch, slab, nk, dir; // array leading dimension, k-slab size, levels, message index
+  int si0, sj0;             // HaloSelf: origin of the strip this one is filled from (same field, same extent)
 };
 struct HaloCopy {
   HaloStrip st[8 * FV3_HALO_MAX_FIELDS];
@@ -1501,6 +1502,22 @@ struct HaloCopy {
       const int i = (int)(idx % s.ni), j = (int)((idx / s.ni) % s.nj), k = (int)(idx / ((long)s.ni * s.nj));
       double *f = s.field + (size_t)k * s.slab + (size_t)(s.j0 + j) * s.pitch + (s.i0 + i);
       if (pack) b[idx] = *f; else *f = b[idx];
+    }
+  }
+};
+
+// One rank, doubly periodic: every message is a message to myself, so the halo strip of side -d is filled straight from the send
+// strip of side d -- what pack + unpack do through a buffer, in one launch for the whole group
+struct HaloSelf {
+  HaloStrip st[8 * FV3_HALO_MAX_FIELDS];
+  static constexpr int CH = 2048;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const HaloStrip &s = st[bz];
+    const long n = (long)s.ni * s.nj * s.nk;
+    for (long idx = (long)bx * CH + tid; idx < (long)(bx + 1) * CH && idx < n; idx += kNT) {
+      const int i = (int)(idx % s.ni), j = (int)((idx / s.ni) % s.nj), k = (int)(idx / ((long)s.ni * s.nj));
+      s.field[(size_t)k * s.slab + (size_t)(s.j0 + j) * s.pitch + (s.i0 + i)] =
+          s.field[(size_t)k * s.slab + (size_t)(s.sj0 + j) * s.pitch + (s.si0 + i)];
     }
   }
 };
@@ -1574,6 +1591,25 @@ static int halo_copy(fv3_ctx *c, int nfields, const fv3_halo_field *fields, doub
   grid.y = 1;
   grid.z = (unsigned)(8 * nfields);
   RT(launch_p(c, pack ? "halo_pack" : "halo_unpack", grid, 0, hc));
+  return 0;
+}
+extern "C" int fv3_halo_periodic_group(fv3_ctx *c, int nfields, const fv3_halo_field *fields) {
+  HaloCopy src, dst;
+  size_t elems[8];
+  long maxn;
+  if (halo_build(c, nfields, fields, true, src, elems, maxn)) return 1;
+  if (halo_build(c, nfields, fields, false, dst, elems, maxn)) return 1;
+  HaloSelf hs;
+  for (int n = 0; n < 8 * nfields; n++) {   // strip n of both lists: message d, field f
+    hs.st[n] = dst.st[n];
+    hs.st[n].si0 = src.st[n].i0;
+    hs.st[n].sj0 = src.st[n].j0;
+  }
+  Dim3 grid;
+  grid.x = (unsigned)((maxn + HaloSelf::CH - 1) / HaloSelf::CH);
+  grid.y = 1;
+  grid.z = (unsigned)(8 * nfields);
+  RT(launch_p(c, "halo_periodic", grid, 0, hs));
   return 0;
 }
 extern "C" int fv3_halo_pack(fv3_ctx *c, int nfields, const fv3_halo_field *fields, double *const sendbuf[8]) {

@@ -14,7 +14,7 @@ module fv3_mi355x_mod
   public :: fv3_update_dz_d, fv3_riem_solver3, fv3_p_grad_c, fv3_nh_p_grad, fv3_zh_from_delz, fv3_pk3_halo
   public :: fv3_pe_halo, fv3_geopk, fv3_set_ak_bk, fv3_lagrangian_to_eulerian, fv3_tracer_2d_prep
   public :: fv3_tracer_2d_scale, fv3_tracer_2d_step, fv3_grid_geom
-  public :: fv3_halo_field, fv3_halo_message_elems, fv3_halo_pack, fv3_halo_unpack
+  public :: fv3_halo_field, fv3_halo_message_elems, fv3_halo_pack, fv3_halo_unpack, fv3_halo_periodic_group
   public :: fv3_heat_source_accum, fv3_del2_cubed, fv3_apply_heat_source
   public :: fv3_d_sw_interior, fv3_d_sw_rest
   public :: fv3_divg2_ext, fv3_one_grad_p, fv3_grad1_p_update, fv3_split_p_grad, fv3_d_sw_inline_q, fv3_set_remap_te, fv3_profile_report_timers, fv3_prt_maxmin, fv3_flux_accum, fv3_fill2d_mass, fv3_fill2d_apply, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
@@ -225,6 +225,12 @@ module fv3_mi355x_mod
       integer(c_int), value :: nfields
       type(fv3_halo_field), intent(in) :: fields(*)
       integer(c_size_t), intent(out) :: elems(8)
+    end function
+    integer(c_int) function fv3_halo_periodic_group(ctx, nfields, fields) bind(C, name="fv3_halo_periodic_group")
+      import :: c_int, c_ptr, fv3_halo_field
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nfields
+      type(fv3_halo_field), intent(in) :: fields(*)
     end function
     integer(c_int) function fv3_halo_pack(ctx, nfields, fields, sendbuf) bind(C, name="fv3_halo_pack")
       import :: c_int, c_ptr, fv3_halo_field

@@ -199,6 +199,10 @@ typedef struct fv3_halo_field {
   int kind, nk;
 } fv3_halo_field;
 int fv3_halo_message_elems(fv3_ctx *ctx, int nfields, const fv3_halo_field *fields, size_t elems[8]);
+/* One rank of a doubly periodic domain: the group's halos filled straight from its own opposite edges, one launch -- what
+ * fv3_halo_pack + fv3_halo_unpack do through the eight message buffers when every neighbour is the rank itself
+ * (mpp_update_domains on a 1 x 1 periodic layout, tools/fv_mp_mod.F90:473-483). */
+int fv3_halo_periodic_group(fv3_ctx *ctx, int nfields, const fv3_halo_field *fields);
 int fv3_halo_pack(fv3_ctx *ctx, int nfields, const fv3_halo_field *fields, double *const sendbuf[8]);
 int fv3_halo_unpack(fv3_ctx *ctx, int nfields, const fv3_halo_field *fields, const double *const recvbuf[8]);
 
