@@ -30,6 +30,10 @@ struct Tp2dFrameFused {
   int nf;                                // fields; f[0] is weighted with xfx / yfx, the others with f[0]'s fluxes (mass fluxes)
   const double *crx, *cry, *xfx, *yfx;   // CX / CY x nk
   const double *emfx, *emfy;             // FX / FY x nk or null: mass fluxes given by the caller weight EVERY field (tracer_2d)
+  // deln_flux of the FIRST field (tp_core.F90:228-232: delp with nord_v / damp_v inside fv_tp_2d): its raw fluxes fx2 / fy2 (V / U
+  // layout, DelnCubedL24) are added to f[0]'s fluxes on the levels with dcoef(k) > 1e-4, before they weight the other fields -- what
+  // DelnCubedL5 does between two transports of the pass path.  null: no damping.
+  const double *dfx = nullptr, *dfy = nullptr, *dcoef = nullptr;
   int w3;                                // width of the frame of flux points: i <= w3, i >= npx - w3, j <= w3, j >= npy - w3
   const int *klist;                      // levels of the launch (or null)
   int nS, nW;                            // tiles per south / north band, per west / east band
@@ -134,7 +138,8 @@ struct Tp2dFrameFused {
             auto dl = [&](int m) { return FV3_M(dxa, m, j); };
             const double fo = ppm_face_cs(ql, dl, i, cx(i, j, k), hord, npx);
             const double m = emfx ? cview_FX(g, emfx)(i, j, k) : ((n == 0) ? xf(i, j, k) : TF(mfx, i, j));
-            const double v = 0.5 * (fo + TF(fx2, i, j)) * m;
+            double v = 0.5 * (fo + TF(fx2, i, j)) * m;
+            if (n == 0 && dfx && dcoef[k] > 1.E-4) v = v + cview_V(g, dfx)(i, j, k);
             view_FX(g, f[n].fx)(i, j, k) = v;
             if (n == 0 && nf > 1) TF(mfx, i, j) = v;
           }
@@ -143,7 +148,8 @@ struct Tp2dFrameFused {
             auto dl = [&](int m) { return FV3_M(dya, i, m); };
             const double fo = ppm_face_cs(ql, dl, j, cy(i, j, k), hord, npy);
             const double m = emfy ? cview_FY(g, emfy)(i, j, k) : ((n == 0) ? yf(i, j, k) : TF(mfy, i, j));
-            const double v = 0.5 * (fo + TF(fy2, i, j)) * m;
+            double v = 0.5 * (fo + TF(fy2, i, j)) * m;
+            if (n == 0 && dfy && dcoef[k] > 1.E-4) v = v + cview_U(g, dfy)(i, j, k);
             view_FY(g, f[n].fy)(i, j, k) = v;
             if (n == 0 && nf > 1) TF(mfy, i, j) = v;
           }

@@ -807,7 +807,8 @@ static int tp2d_cubed(fv3_ctx *c, int nk, const double *q, const double *crx, co
 // xfx / yfx, the following ones with fields[0]'s fluxes; FV3_MI355X_FRAME_FUSED=0 falls back to the passes
 static int tp2d_frame_fused(fv3_ctx *c, const TpfField *fields, int nf, const double *crx, const double *cry, const double *xfx,
                             const double *yfx, int w3, const int *klist, int nk, const char *label, bool full = false,
-                            const double *emfx = nullptr, const double *emfy = nullptr) {
+                            const double *emfx = nullptr, const double *emfy = nullptr, const double *dfx = nullptr,
+                            const double *dfy = nullptr, const double *dcoef = nullptr) {
   if (nk <= 0) return 0;
   const Grid &g = c->g;
   Tp2dFrameFused kf;
@@ -816,9 +817,10 @@ static int tp2d_frame_fused(fv3_ctx *c, const TpfField *fields, int nf, const do
   kf.nf = nf; kf.crx = crx; kf.cry = cry; kf.xfx = xfx; kf.yfx = yfx; kf.w3 = w3; kf.klist = klist;
   kf.full = full ? 1 : 0;
   kf.emfx = emfx; kf.emfy = emfy;
+  kf.dfx = dfx; kf.dfy = dfy; kf.dcoef = dcoef;
   kf.nS = (g.nx + 1 + kTfT - 1) / kTfT;
   if (full) {            // the whole face (the levels the marching kernels do not take): bands of 5 rows
-    kf.w3 = 5;
+    kf.w3 = 7;
     kf.nW = (g.ny + 1 + kf.w3 - 1) / kf.w3;
   } else {
     const int nmid = (g.npy - w3 - 1) - (w3 + 1) + 1;
@@ -1218,14 +1220,25 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     if (courant) RT(launch_pass(c, "dswc_d2", g.isd, g.ied, g.jsd, g.jed, PassRegion{0, rg.klist, rg.nk}, DswCubedD2{s}));
     // hybrid frame: delp, w, pt in ONE LDS-tile launch; the whole-face levels too unless a deln_flux damping has to get between
     // the transports (it changes the mass fluxes the later fields are weighted with)
-    const bool full_ok = rg.w == 0 && rg_out.w == 0 && !c->lev_has_damp_v4 && !c->lev_has_damp_t && !(c->lev_has_w_damp_hi && !a.hydrostatic);
+    // the damped whole-face levels too: the del-2n fluxes of delp are formed first (they depend on delp alone) and the fused kernel
+    // adds them to delp's fluxes before those weight w and pt; the damping of pt is added to its fluxes afterwards, that of w goes
+    // to D4 as its own fluxes -- the order of the pass path below
+    const bool full_ok = rg.w == 0 && rg_out.w == 0;
     if (((rg.w > 0 && rg_out.w > 0) || full_ok) && !a.use_cond && frame_fused_on()) {
       TpfField fl[3];
       int nf = 0;
       fl[nf++] = TpfField{a.delp, s.fx, s.fy, a.hord_dp};
       if (!a.hydrostatic) fl[nf++] = TpfField{a.w, s.gxw, s.gyw, a.hord_vt};
       fl[nf++] = TpfField{a.pt, s.gx, s.gy, a.hord_tm};
-      RT(tp2d_frame_fused(c, fl, nf, a.crx, a.cry, a.xfx, a.yfx, rg_out.w + 1, rg.klist, rg.nk, "dswc_tp", rg.w == 0));
+      const bool dv4 = rg.w == 0 && c->lev_has_damp_v4;
+      if (dv4)   // :919-920 without the final addition: raw fluxes in scratch 5, 6
+        RT(deln(a.delp, nullptr, nullptr, nullptr, a.lv.nord_v, a.lv.damp_vt, 1.E-4, 0, c->lev_max_nord_v, nullptr, nullptr, rg));
+      RT(tp2d_frame_fused(c, fl, nf, a.crx, a.cry, a.xfx, a.yfx, rg_out.w + 1, rg.klist, rg.nk, "dswc_tp", rg.w == 0, nullptr, nullptr,
+                          dv4 ? cs_scratch(c, 5) : nullptr, dv4 ? cs_scratch(c, 6) : nullptr, dv4 ? a.lv.damp_vt : nullptr));
+      if (rg.w == 0 && c->lev_has_damp_t)    // :1014-1016: mass-weighted deln_flux inside fv_tp_2d(pt)
+        RT(deln(a.pt, a.delp, s.gx, s.gy, a.lv.nord_t, a.lv.damp_t, 1.E-4, 0, c->lev_max_nord_t, nullptr, nullptr, rg));
+      if (rg.w == 0 && !a.hydrostatic && c->lev_has_w_damp_hi)   // :950-982: del6_vt_flux(w); nord_w = 0 is formed inside D4
+        RT(deln(a.w, nullptr, nullptr, nullptr, a.lv.nord_w, a.lv.damp_w, 1.E-5, 1, c->lev_max_nord_w, s.wfx2, s.wfy2, rg));
       DswCubedState so = s;
       so.own_w = rg_out.w;
       RT(launch_pass(c, "dswc_d4", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD4{so}));
