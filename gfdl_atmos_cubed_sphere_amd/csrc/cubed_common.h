@@ -72,6 +72,22 @@ struct FramePass {
     }
   }
 };
+// a pass on the four corner squares of its box only: i within w of the west / east edge AND j within w of the south / north edge
+// (one workgroup per corner and level; w <= 12).  Used where only copy_corners separates a pass chain from its LDS-tile form.
+template <class F>
+struct CornerPass {
+  int i0, i1, j0, j1, w, npx, npy;
+  const int *klist;
+  F f;
+  FV3_HD void operator()(int corner, int, int bz, int tid, double *) const {
+    const int k = klist ? klist[bz] : bz;
+    const bool east = corner & 1, north = corner & 2;
+    const int ia = east ? ((npx - w) > i0 ? (npx - w) : i0) : i0, ib = east ? i1 : (w < i1 ? w : i1);
+    const int ja = north ? ((npy - w) > j0 ? (npy - w) : j0) : j0, jb = north ? j1 : (w < j1 ? w : j1);
+    const int ni = ib - ia + 1, nj = jb - ja + 1;
+    for (int t = tid; t < ni * nj; t += kNT) f(ia + t % ni, ja + t / ni, k);
+  }
+};
 // level list variant of BoxPass (the levels the hybrid path leaves to the full-face passes)
 template <class F>
 struct BoxPassK {

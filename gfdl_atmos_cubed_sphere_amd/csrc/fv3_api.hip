@@ -830,6 +830,13 @@ static int tp2d_frame_fused(fv3_ctx *c, const TpfField *fields, int nf, const do
   grid.x = (unsigned)kf.ntiles(); grid.y = 1; grid.z = (unsigned)nk;
   return launch_p(c, label, grid, (size_t)kTfArrays * kTfMaxN, kf);
 }
+static bool deln_fused_on() {
+  static const int v = [] {
+    const char *e = std::getenv("FV3_MI355X_DELN_FUSED");
+    return e ? std::atoi(e) : 1;
+  }();
+  return v != 0;
+}
 static bool frame_fused_on() {
   static const int v = [] {
     const char *e = std::getenv("FV3_MI355X_FRAME_FUSED");
@@ -1173,14 +1180,34 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     d.fx2 = out_fx2 ? out_fx2 : cs_scratch(c, 5);
     d.fy2 = out_fy2 ? out_fy2 : cs_scratch(c, 6);
     if (!d.d2 || !d.fx2 || !d.fy2) return fail("d_sw: out of device memory");
+    // away from the face corners: the chain in one LDS-tile launch (cubed_damp.h DelnFused); the passes keep the four corner
+    // squares of 5 flux points (what the corner maps of copy_corners can reach) and the rim of 3 their intermediates need
+    const int wo_d = 5, wm_d = wo_d + 3;
+    const bool fused_d = deln_fused_on() && nmax <= DelnFused::kMaxN && g.npx == g.npy && g.npx - 1 >= 2 * wm_d + 8;
     const PassRegion r{0, rk.klist, rk.nk};
-    RT(launch_pass(c, "dswc_deln", g.isd, g.ied, g.jsd, g.jed, r, DelnCubedL1{d}));
-    RT(launch_pass(c, "dswc_deln", g.isd, g.ied + 1, g.jsd, g.jed + 1, r, DelnCubedL24{d, 1, 0}));
+    auto pass = [&](int i0, int i1, int j0, int j1, int w, auto f) -> int {   // whole box, or its corner squares of side w
+      if (!fused_d) return launch_pass(c, "dswc_deln", i0, i1, j0, j1, r, f);
+      Dim3 gr;
+      gr.x = 4; gr.y = 1; gr.z = (unsigned)rk.nk;
+      return launch_p(c, "dswc_deln", gr, 0, CornerPass<decltype(f)>{i0, i1, j0, j1, w, g.npx, g.npy, rk.klist, f});
+    };
+    auto fused_launch = [&]() -> int {
+      if (!fused_d) return 0;
+      DelnFused kf{d, wo_d, rk.klist, fx ? 0 : 1};
+      Dim3 gr;
+      gr.x = (unsigned)((g.nx + 1 + DelnFused::TI - 1) / DelnFused::TI);
+      gr.y = (unsigned)((g.ny + 1 + DelnFused::TJ - 1) / DelnFused::TJ);
+      gr.z = (unsigned)rk.nk;
+      return launch_p(c, "dswc_deln", gr, DelnFused::lds_doubles, kf);
+    };
+    RT(pass(g.isd, g.ied, g.jsd, g.jed, wm_d, DelnCubedL1{d}));
+    RT(pass(g.isd, g.ied + 1, g.jsd, g.jed + 1, wm_d, DelnCubedL24{d, 1, 0}));
     for (int n = 1; n <= nmax; n++) {
-      RT(launch_pass(c, "dswc_deln", g.isd, g.ied, g.jsd, g.jed, r, DelnCubedL3{d, n}));
-      RT(launch_pass(c, "dswc_deln", g.isd, g.ied + 1, g.jsd, g.jed + 1, r, DelnCubedL24{d, 0, n}));
+      RT(pass(g.isd, g.ied, g.jsd, g.jed, wm_d, DelnCubedL3{d, n}));
+      RT(pass(g.isd, g.ied + 1, g.jsd, g.jed + 1, wm_d, DelnCubedL24{d, 0, n}));
     }
-    if (fx) RT(launch_pass(c, "dswc_deln", g.is, g.ie + 1, g.js, g.je + 1, r, DelnCubedL5{d}));
+    if (fx) RT(pass(g.is, g.ie + 1, g.js, g.je + 1, wo_d, DelnCubedL5{d}));
+    RT(fused_launch());
     return 0;
   };
   if (!a.hydrostatic && c->lev_has_w_damp_hi) {
