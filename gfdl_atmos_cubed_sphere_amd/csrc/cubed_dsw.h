@@ -547,6 +547,77 @@ struct DswCubedDampDiv {  // the divergence of (uc, vc), corner terms, 1/area_c;
   }
 };
 
+// The del-2n loop of the divergence (:1372-1426) in ONE launch, away from the face corners (see cubed_damp.h DelnFused for the
+// scheme): a workgroup owns 32 x 16 B-grid points at one level, stages divg_d on them grown by nord_k, and alternates the gradients
+// (DampVC) and the divergence (DampDiv) in LDS on squares that shrink by one per iteration.  fill_corners and the corner terms of the
+// divergence only reach points within nord_k of BOTH edges of a face corner: those squares stay with the passes (CornerPass).
+struct DswDampFused {
+  static constexpr int TI = 32, TJ = 16, kMaxN = 3;
+  static constexpr int PW = TI + 2 * kMaxN + 2, PH = TJ + 2 * kMaxN + 2;
+  static constexpr int lds_doubles = 3 * PW * PH;
+  DswCubedState s;
+  int wo;
+  const int *klist;
+  FV3_D void operator()(int bx, int by, int bz, int tid, double *lds) const {
+    const int k = klist ? klist[bz] : bz;
+    const Grid &g = s.g;
+    const int N = s.a.lv.nord_k[k], npx = g.npx, npy = g.npy;
+    if (N <= 0) return;
+    const int ia = g.is + bx * TI, ja = g.js + by * TJ;
+    const int ib = ia + TI - 1 < g.ie + 1 ? ia + TI - 1 : g.ie + 1, jb = ja + TJ - 1 < g.je + 1 ? ja + TJ - 1 : g.je + 1;
+    const int i0 = ia - kMaxN - 1, j0 = ja - kMaxN - 1;
+    double *dd = lds, *vc = lds + PW * PH, *uc = lds + 2 * PW * PH;
+#define TD(a, i, j) (a)[((j) - j0) * PW + ((i) - i0)]
+    {
+      const CA d0 = cview_B(g, s.a.divg_d);
+      const int ca = ia - N, cb = ib + N, ra = ja - N, rb = jb + N, nc = cb - ca + 1, nr = rb - ra + 1;
+      for (int idx = tid; idx < nc * nr; idx += kNT) {
+        const int i = ca + idx % nc, j = ra + idx / nc;
+        TD(dd, i, j) = d0(i, j, k);
+      }
+    }
+    FV3_SYNC();
+    for (int n = 1; n <= N; n++) {
+      const int nt = N - n;
+      const int ca = ia - nt, cb = ib + nt, ra = ja - nt, rb = jb + nt;   // the divergence of this iteration
+      {
+        // vc(i, j), i in [ca - 1, cb], j in [ra, rb]; uc(i, j), i in [ca, cb], j in [ra - 1, rb]
+        const int nc = cb - ca + 2, nr = rb - ra + 1;
+        for (int idx = tid; idx < nc * nr; idx += kNT) {
+          const int i = ca - 1 + idx % nc, j = ra + idx / nc;
+          TD(vc, i, j) = (TD(dd, i + 1, j) - TD(dd, i, j)) * g.divg_u[g.iU(i, j)];
+        }
+        const int nc2 = cb - ca + 1, nr2 = rb - ra + 2;
+        for (int idx = tid; idx < nc2 * nr2; idx += kNT) {
+          const int i = ca + idx % nc2, j = ra - 1 + idx / nc2;
+          TD(uc, i, j) = (TD(dd, i, j + 1) - TD(dd, i, j)) * g.divg_v[g.iV(i, j)];
+        }
+      }
+      FV3_SYNC();
+      {
+        const int nc = cb - ca + 1, nr = rb - ra + 1;
+        for (int idx = tid; idx < nc * nr; idx += kNT) {
+          const int i = ca + idx % nc, j = ra + idx / nc;
+          double d = TD(uc, i, j - 1) - TD(uc, i, j) + TD(vc, i - 1, j) - TD(vc, i, j);
+          if (!g.stretched_grid) d = d * g.rarea_c[g.iB(i, j)];
+          TD(dd, i, j) = d;
+        }
+      }
+      FV3_SYNC();
+    }
+    {
+      const VA out = view_B(g, s.dd);
+      const int nc = ib - ia + 1, nr = jb - ja + 1;
+      for (int idx = tid; idx < nc * nr; idx += kNT) {
+        const int i = ia + idx % nc, j = ja + idx / nc;
+        if ((i <= wo || i >= npx + 1 - wo) && (j <= wo || j >= npy + 1 - wo)) continue;
+        out(i, j, k) = TD(dd, i, j);
+      }
+    }
+#undef TD
+  }
+};
+
 // D7: divergence damping of the sponge levels (nord_k = 0, :1290-1371) and the final damping term added to ke (:1446-1458);
 // box (is:ie+1, js:je+1)
 struct DswCubedD7 {

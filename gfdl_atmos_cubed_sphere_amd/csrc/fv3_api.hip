@@ -1297,18 +1297,36 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     so.own_w = rg_out.w;
     RT(launch_pass(c, "dswc_ke", g.is, g.ie + 1, g.js, g.je + 1, rg, DswCubedD5{s}));
     RT(launch_pass(c, "dswc_d6", g.isd, g.ied + 1, g.jsd, g.jed + 1, rg, DswCubedD6{s}));
+    // whole-face levels: the del-2n loop in one LDS-tile launch away from the face corners (cubed_dsw.h DswDampFused); the passes
+    // keep the corner squares of 5 points (what fill_corners and the corner terms reach) and the rim their intermediates need
+    const int wo_v = 5, wm_v = wo_v + DswDampFused::kMaxN + 1;
+    const bool fused_v = rg.w == 0 && deln_fused_on() && c->lev_max_nord > 0 && c->lev_max_nord <= DswDampFused::kMaxN && npx == npy &&
+                         npx - 1 >= 2 * wm_v + 8;
+    auto vpass = [&](int i0, int i1, int j0, int j1, auto f) -> int {
+      if (!fused_v) return launch_pass(c, L, i0, i1, j0, j1, rg, f);
+      Dim3 gr;
+      gr.x = 4; gr.y = 1; gr.z = (unsigned)rg.nk;
+      return launch_p(c, L, gr, 0, CornerPass<decltype(f)>{i0, i1, j0, j1, wm_v, npx, npy, rg.klist, f});
+    };
     for (int n = 1; n <= c->lev_max_nord; n++) {
       const bool may_fill = c->lev_max_nord - n != 0;   // some level may have nt /= 0 in this iteration
       const PassRegion rc{0, rg.klist, rg.nk};          // the corner fills: tiny boxes
       if (may_fill) RT(launch_pass(c, L, 1, 3, 1, 3, rc, DswCubedFillB{s, 1, n}));
-      RT(launch_pass(c, L, g.is - 3, g.ie + 3, g.js - 3, g.je + 4, rg, DswCubedDampVC{s, n, 0}));
+      RT(vpass(g.is - 3, g.ie + 3, g.js - 3, g.je + 4, DswCubedDampVC{s, n, 0}));
       if (may_fill) RT(launch_pass(c, L, 1, 3, 1, 3, rc, DswCubedFillB{s, 2, n}));
-      RT(launch_pass(c, L, g.is - 3, g.ie + 4, g.js - 3, g.je + 3, rg, DswCubedDampVC{s, n, 1}));
+      RT(vpass(g.is - 3, g.ie + 4, g.js - 3, g.je + 3, DswCubedDampVC{s, n, 1}));
       if (may_fill) {
         RT(launch_pass(c, L, 1, 3, 1, 3, rc, DswCubedFillD{s, 0, n}));
         RT(launch_pass(c, L, 1, 3, 1, 3, rc, DswCubedFillD{s, 1, n}));
       }
-      RT(launch_pass(c, L, g.is - 2, g.ie + 3, g.js - 2, g.je + 3, rg, DswCubedDampDiv{s, n}));
+      RT(vpass(g.is - 2, g.ie + 3, g.js - 2, g.je + 3, DswCubedDampDiv{s, n}));
+    }
+    if (fused_v) {
+      Dim3 gr;
+      gr.x = (unsigned)((g.nx + 1 + DswDampFused::TI - 1) / DswDampFused::TI);
+      gr.y = (unsigned)((g.ny + 1 + DswDampFused::TJ - 1) / DswDampFused::TJ);
+      gr.z = (unsigned)rg.nk;
+      RT(launch_p(c, L, gr, DswDampFused::lds_doubles, DswDampFused{s, wo_v, rg.klist}));
     }
     if (s.smag) {  // a2b_ord4 of the relative vorticity for the Smagorinsky coefficient (:1431-1440); scratch 0, 1 (c_sw's)
       A2bCubedState t;
