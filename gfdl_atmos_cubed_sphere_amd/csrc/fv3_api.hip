@@ -1160,6 +1160,8 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
   });
 }
 
+template <int TI, int TJ>
+static int run_a2b(fv3_ctx *c, const A2BCorners<TI, TJ> &kf, int nlev_max);
 // d_sw on a cubed-sphere face (cubed_dsw.h); scratch 8..20
 static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   const Grid &g = c->g;
@@ -1334,9 +1336,18 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
       for (int f = 0; f < 4; f++) { t.in[f] = nullptr; t.out[f] = nullptr; t.qx[f] = t.qy[f] = nullptr; t.nlev[f] = 0; t.scale[f] = 1.0; t.top[f] = 0.; }
       t.in[0] = s.wk; t.out[0] = s.smag; t.nlev[0] = npz;
       if (!(t.qx[0] = cs_scratch(c, 0)) || !(t.qy[0] = cs_scratch(c, 1))) return fail("d_sw: out of device memory");
-      const PassRegion r{0, rg.klist, rg.nk};
-      RT(launch_pass(c, "dswc_smag", 1, npx, 1, npy, r, A2bCubedPa{t}));
-      RT(launch_pass(c, "dswc_smag", 1, npx, 1, npy, r, A2bCubedPb{t}));
+      if (rg.w == 0 && rg.nk == npz) {   // every level: the hybrid of nh_p_grad's a2b_ord4 (LDS-tile kernel + the passes on a frame)
+        A2BCorners<32, 16> kc;
+        kc.g = g;
+        for (int f = 0; f < 4; f++) { kc.in[f] = nullptr; kc.out[f] = nullptr; kc.nlev[f] = 0; kc.scale[f] = 1.0; kc.top[f] = 0.; }
+        kc.in[0] = s.wk; kc.out[0] = s.smag; kc.nlev[0] = npz;
+        kc.nf = 1; kc.override_mask = 0;
+        RT((run_a2b<32, 16>(c, kc, npz)));
+      } else {
+        const PassRegion r{0, rg.klist, rg.nk};
+        RT(launch_pass(c, "dswc_smag", 1, npx, 1, npy, r, A2bCubedPa{t}));
+        RT(launch_pass(c, "dswc_smag", 1, npx, 1, npy, r, A2bCubedPb{t}));
+      }
     }
     RT(launch_pass(c, L, g.is, g.ie + 1, g.js, g.je + 1, rg, DswCubedD7{so}));
     if (rg.w == 0 && c->lev_has_damp_v5)   // :1513-1515: del6_vt_flux of the RELATIVE vorticity (before D8 adds f0)
