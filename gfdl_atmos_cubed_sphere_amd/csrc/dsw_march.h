@@ -360,6 +360,55 @@ struct ZhMarch {
   }
 };
 
+// fv_tp_2d of one field with the fluxes themselves as the result (tp_core.F90:187-224 without mass fluxes: fx = 0.5 (fx + fx2) xfx):
+// the absolute vorticity of d_sw (sw_core.F90:1483-1485) on the levels the fused momentum kernel does not take.  On a cubed-sphere
+// face the values within the frame along the edges are overwritten afterwards by the frame kernel (cubed_tpf.h).
+template <int HORD>
+struct FluxMarch {
+  Grid g;
+  MarchDims md;
+  const double *q, *crx, *cry, *xfx, *yfx;
+  double *fx, *fy;   // FX / FY
+
+  struct Sink {
+    const FluxMarch &K;
+    const StripGeom &s;
+    int k, lFx1;
+    vl Fx;
+    struct In {
+      vd x0, y0, y1;
+    };
+    FV3_D In load(int j) const {
+      const Grid &g = K.g;
+      In in;
+      in.x0 = vload(K.xfx + (size_t)k * g.nCX(), (long)g.iCX(s.ilo, j), s.F);
+      in.y0 = vload(K.yfx + (size_t)k * g.nCY(), (long)g.iCY(s.ilo, j), s.A);
+      in.y1 = vload(K.yfx + (size_t)k * g.nCY(), (long)g.iCY(s.ilo, j + 1), s.A);
+      return in;
+    }
+    FV3_D void row(int j, const In &in, const vd &fxv, const vd &fyv0, const vd &fyv1) const {
+      const Grid &g = K.g;
+      const size_t oFX = (size_t)k * g.nFX(), oFY = (size_t)k * g.nFY();
+      vstore(K.fx + oFX, (long)g.iFX(s.ilo, j), fxv * in.x0, s.lC0, lFx1);
+      vstore(K.fy + oFY, (long)g.iFY(s.ilo, j), fyv0 * in.y0, s.lC0, s.lC1);
+      if (j == g.je) vstore(K.fy + oFY, (long)g.iFY(s.ilo, j + 1), fyv1 * in.y1, s.lC0, s.lC1);
+    }
+  };
+
+  FV3_D void operator()(int gid) const {
+    int strip, seg, kk;
+    md.decode(gid, strip, seg, kk);
+    const int k = md.klist ? md.klist[kk] : kk;
+    const StripGeom s = make_strip(g, strip);
+    const int jA = g.js + seg * md.tj;
+    const int jB = (jA + md.tj - 1 < g.je) ? jA + md.tj - 1 : g.je;
+    const int lFx1 = (s.ilo + s.lC1 == g.ie) ? s.lC1 + 1 : s.lC1;
+    Sink sink{*this, s, k, lFx1, make_lanes(s.lC0, lFx1)};
+    tp2d_march<HORD>(g, s, jA, jB, q + (size_t)k * g.nA(), crx + (size_t)k * g.nCX(), cry + (size_t)k * g.nCY(),
+                     xfx + (size_t)k * g.nCX(), yfx + (size_t)k * g.nCY(), sink);
+  }
+};
+
 // one sub-cycle of tracer_2d for every (tracer, level), model/fv_tracer2d.F90:471-541, without the del-2n
 // damping of the first sub-cycle (trdm <= 1e-4)
 template <int HORD>

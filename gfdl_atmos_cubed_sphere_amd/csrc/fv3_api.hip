@@ -837,6 +837,13 @@ static bool deln_fused_on() {
   }();
   return v != 0;
 }
+static bool flux_march_on() {
+  static const int v = [] {
+    const char *e = std::getenv("FV3_MI355X_FLUX_MARCH");
+    return e ? std::atoi(e) : 1;
+  }();
+  return v != 0;
+}
 static bool frame_fused_on() {
   static const int v = [] {
     const char *e = std::getenv("FV3_MI355X_FRAME_FUSED");
@@ -1353,7 +1360,19 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     if (rg.w == 0 && c->lev_has_damp_v5)   // :1513-1515: del6_vt_flux of the RELATIVE vorticity (before D8 adds f0)
       RT(deln(s.wk, nullptr, nullptr, nullptr, a.lv.nord_v, a.lv.damp_vt, 1.E-5, 1, c->lev_max_nord_v, s.dfx2, s.dfy2, rg));
     RT(launch_pass(c, "dswc_d8", g.isd, g.ied, g.jsd, g.jed, rg, DswCubedD8{s}));
-    if (frame_fused_on()) {
+    if (frame_fused_on() && rg.w == 0 && fits && c->use_march && flux_march_on()) {
+      // whole-face levels: the marching fv_tp_2d over the face, then the frame along the edges by the frame kernel (the fluxes are
+      // not an input of either: the frame kernel simply overwrites what the march left there)
+      MarchDims md = make_march_dims(g, seg_rows(c, c->march_tj, g.npz));
+      md.klist = rg.klist;
+      const int nwv = md.nwaves(rg.nk);
+      RT(dispatch_hord(a.hord_vt, [&](auto H) {
+        FluxMarch<decltype(H)::value> kf{g, md, s.wk, a.crx, a.cry, a.xfx, a.yfx, s.gx, s.gy};
+        return launch_w(c, "dswc_tpv", nwv, kf);
+      }));
+      const TpfField fl[3] = {TpfField{s.wk, s.gx, s.gy, a.hord_vt}, TpfField{}, TpfField{}};
+      RT(tp2d_frame_fused(c, fl, 1, a.crx, a.cry, a.xfx, a.yfx, wo + 1, rg.klist, rg.nk, "dswc_tpv", false));
+    } else if (frame_fused_on()) {
       const TpfField fl[3] = {TpfField{s.wk, s.gx, s.gy, a.hord_vt}, TpfField{}, TpfField{}};
       RT(tp2d_frame_fused(c, fl, 1, a.crx, a.cry, a.xfx, a.yfx, rg_out.w + 1, rg.klist, rg.nk, "dswc_tpv", rg.w == 0));
     } else {
