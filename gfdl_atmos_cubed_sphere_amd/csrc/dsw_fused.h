@@ -65,7 +65,8 @@ struct Tp2dField {
 // formed from uc, vc on the fly, used, and stored for the later consumers (crx, xfx, cry, yfx; cx, cy accumulated).
 // GM: geometry mode (Grid::geom); 2 = orthogonal and uniform: the metric terms are wave-uniform scalars and the
 // sin_sg factors (= 1) drop out -- x*1 is exact, so the results are the ones of the general kernel
-template <int HORD, bool NH, bool COURANT, int GM = 0>
+// FLUXES: see DswArgs::dfx -- the fluxes are stored instead of the updated fields
+template <int HORD, bool NH, bool COURANT, int GM = 0, bool FLUXES = false>
 struct DswTransportFused {
   static constexpr bool UNI = (GM == 2);
   // 330 registers with the metric rows (one wavefront per SIMD), 246-250 with uniform metrics (two: -Rpass-analysis=kernel-resource-usage).
@@ -229,7 +230,29 @@ struct DswTransportFused {
       fp.step(in.pt, sh, have_face, have_row, fxp, fyp0, fyp1);
       if (have_face) {
         // mass flux through y-face r-2 (tp_core.F90:222-226); carried to the next row as its south face
-        const vd fym = fyd1 * sh.yf;
+        vd fym = fyd1 * sh.yf;
+        const bool dk = FLUXES && a.dfx && a.dcoef[k] > 1.E-4;
+        if (FLUXES && dk) fym = fym + vload(a.dfy + (size_t)k * g.nU(), (long)g.iU(ilo, r - 2), s.A);   // tp_core.F90:228-232
+        if constexpr (FLUXES) {
+          if (have_row && j >= oJ0 && j <= oJ1) {
+            vd fxm = fxd * xfj;
+            if (dk) fxm = fxm + vload(a.dfx + (size_t)k * g.nV(), (long)g.iV(ilo, j), s.A);
+            const vd fym0 = fym_prev, fym1 = fym;
+            const long iFX = (long)g.iFX(ilo, j), iFY0 = (long)g.iFY(ilo, j), iFY1 = (long)g.iFY(ilo, j + 1);
+            const bool top = j == g.je;
+            vstore(a.ofx + oFX, iFX, fxm, oC0, oF1);
+            vstore(a.ofy + oFY, iFY0, fym0, oC0, oC1);
+            if (top) vstore(a.ofy + oFY, iFY1, fym1, oC0, oC1);
+            vstore(a.ogx + oFX, iFX, fxp * fxm, oC0, oF1);
+            vstore(a.ogy + oFY, iFY0, fyp0 * fym0, oC0, oC1);
+            if (top) vstore(a.ogy + oFY, iFY1, fyp1 * fym1, oC0, oC1);
+            if (NH) {
+              vstore(a.ogxw + oFX, iFX, fxw * fxm, oC0, oF1);
+              vstore(a.ogyw + oFY, iFY0, fyw0 * fym0, oC0, oC1);
+              if (top) vstore(a.ogyw + oFY, iFY1, fyw1 * fym1, oC0, oC1);
+            }
+          }
+        } else
         if (have_row && j >= oJ0 && j <= oJ1) {
           const vd fxm = fxd * xfj;  // tp_core.F90:217-221
           const vd fym0 = fym_prev, fym1 = fym;

@@ -1253,13 +1253,52 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
 
   auto transport = [&](const PassRegion &rg, const PassRegion &rg_out, bool courant) -> int {
     if (rg.nk <= 0) return 0;
-    if (courant) RT(launch_pass(c, "dswc_d2", g.isd, g.ied, g.jsd, g.jed, PassRegion{0, rg.klist, rg.nk}, DswCubedD2{s}));
+    // (a marching launch is as long as one wavefront's march whatever its size: below 16 levels -- the two sponge levels of the
+    // reference defaults -- the LDS-tile kernel over the face is quicker)
+    const bool march_flux = courant && rg.w == 0 && rg_out.w == 0 && fits && fused_ok && !a.use_cond && frame_fused_on() && flux_march_on() &&
+                            g.geom != 2 && rg.nk >= 16;
+    if (courant && !march_flux) RT(launch_pass(c, "dswc_d2", g.isd, g.ied, g.jsd, g.jed, PassRegion{0, rg.klist, rg.nk}, DswCubedD2{s}));
     // hybrid frame: delp, w, pt in ONE LDS-tile launch; the whole-face levels too unless a deln_flux damping has to get between
     // the transports (it changes the mass fluxes the later fields are weighted with)
     // the damped whole-face levels too: the del-2n fluxes of delp are formed first (they depend on delp alone) and the fused kernel
     // adds them to delp's fluxes before those weight w and pt; the damping of pt is added to its fluxes afterwards, that of w goes
     // to D4 as its own fluxes -- the order of the pass path below
     const bool full_ok = rg.w == 0 && rg_out.w == 0;
+    if (march_flux) {
+      // the damped whole-face levels on the marching kernel: Courant numbers, the three transports with delp's damping fluxes added
+      // to its mass fluxes, the FLUXES as the result (DswTransportFused<..., FLUXES>); the frame along the edges by the frame kernel,
+      // which overwrites what the march left there; the fields by D4, as after the passes
+      const bool dv4 = c->lev_has_damp_v4;
+      if (dv4) RT(deln(a.delp, nullptr, nullptr, nullptr, a.lv.nord_v, a.lv.damp_vt, 1.E-4, 0, c->lev_max_nord_v, nullptr, nullptr, rg));
+      const double *dfx = dv4 ? cs_scratch(c, 5) : nullptr, *dfy = dv4 ? cs_scratch(c, 6) : nullptr;
+      DswArgs am = a;
+      am.uc = s.ut; am.vc = s.vt; am.mask_w = wo;
+      am.dfx = dfx; am.dfy = dfy; am.dcoef = a.lv.damp_vt;
+      am.ofx = s.fx; am.ofy = s.fy; am.ogxw = s.gxw; am.ogyw = s.gyw; am.ogx = s.gx; am.ogy = s.gy;
+      MarchDims mf = make_march_dims(g, seg_rows(c, c->march_tj_fused, g.npz));
+      mf.klist = rg.klist;
+      const int nwf = mf.nwaves(rg.nk);
+      RT(dispatch_hord(a.hord_dp, [&](auto H) {
+        constexpr int HORD = decltype(H)::value;
+        if (a.hydrostatic) return launch_w(c, "dswc_tp", nwf, DswTransportFused<HORD, false, true, 0, true>{g, am, mf});
+        return launch_w(c, "dswc_tp", nwf, DswTransportFused<HORD, true, true, 0, true>{g, am, mf});
+      }));
+      TpfField fl[3];
+      int nf = 0;
+      fl[nf++] = TpfField{a.delp, s.fx, s.fy, a.hord_dp};
+      if (!a.hydrostatic) fl[nf++] = TpfField{a.w, s.gxw, s.gyw, a.hord_vt};
+      fl[nf++] = TpfField{a.pt, s.gx, s.gy, a.hord_tm};
+      RT(tp2d_frame_fused(c, fl, nf, a.crx, a.cry, a.xfx, a.yfx, wo + 1, rg.klist, rg.nk, "dswc_tp", false, nullptr, nullptr, dfx, dfy,
+                          dv4 ? a.lv.damp_vt : nullptr));
+      if (c->lev_has_damp_t)    // :1014-1016: mass-weighted deln_flux inside fv_tp_2d(pt)
+        RT(deln(a.pt, a.delp, s.gx, s.gy, a.lv.nord_t, a.lv.damp_t, 1.E-4, 0, c->lev_max_nord_t, nullptr, nullptr, rg));
+      if (!a.hydrostatic && c->lev_has_w_damp_hi)   // :950-982: del6_vt_flux(w); nord_w = 0 is formed inside D4
+        RT(deln(a.w, nullptr, nullptr, nullptr, a.lv.nord_w, a.lv.damp_w, 1.E-5, 1, c->lev_max_nord_w, s.wfx2, s.wfy2, rg));
+      DswCubedState so = s;
+      so.own_w = 0;
+      RT(launch_pass(c, "dswc_d4", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD4{so}));
+      return 0;
+    }
     if (((rg.w > 0 && rg_out.w > 0) || full_ok) && !a.use_cond && frame_fused_on()) {
       TpfField fl[3];
       int nf = 0;
@@ -1360,7 +1399,7 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     if (rg.w == 0 && c->lev_has_damp_v5)   // :1513-1515: del6_vt_flux of the RELATIVE vorticity (before D8 adds f0)
       RT(deln(s.wk, nullptr, nullptr, nullptr, a.lv.nord_v, a.lv.damp_vt, 1.E-5, 1, c->lev_max_nord_v, s.dfx2, s.dfy2, rg));
     RT(launch_pass(c, "dswc_d8", g.isd, g.ied, g.jsd, g.jed, rg, DswCubedD8{s}));
-    if (frame_fused_on() && rg.w == 0 && fits && c->use_march && flux_march_on()) {
+    if (frame_fused_on() && rg.w == 0 && fits && c->use_march && flux_march_on() && rg.nk >= 16) {
       // whole-face levels: the marching fv_tp_2d over the face, then the frame along the edges by the frame kernel (the fluxes are
       // not an input of either: the frame kernel simply overwrites what the march left there)
       MarchDims md = make_march_dims(g, seg_rows(c, c->march_tj, g.npz));

@@ -963,7 +963,7 @@ PROD = dict(do_vort_damp=True, vtdm4=0.06, nord=3, d_con=1.0, dddmp=0.5)
 def test_cubed_d_sw_damping_fused_chains(prod, hydrostatic):
     """C32 / C48 faces: the del-2n chains as one LDS-tile launch away from the corners (cubed_damp.h DelnFused), the damped whole-face
     levels through the fused transport with delp's damping fluxes as an input (cubed_tpf.h); equal to the oracle like the passes"""
-    assert max(PC.check_d_sw(prod, npx=33, npz=4, hydrostatic=hydrostatic, faces=(0, 5), flags=PROD, par_over=dict(dddmp=0.5)).values()) <= P.TOL
+    assert max(PC.check_d_sw(prod, npx=33, npz=17, hydrostatic=hydrostatic, faces=(0, 5), flags=PROD, par_over=dict(dddmp=0.5)).values()) <= P.TOL
     assert max(PC.check_d_sw(prod, npx=49, npz=5, hydrostatic=hydrostatic, faces=(2,),
                              flags=dict(do_vort_damp=True, vtdm4=0.06, nord=1)).values()) <= P.TOL
 

@@ -810,7 +810,7 @@ def test_cubed_d_sw_damping_and_heating(emu, kw, hydrostatic):
 def test_cubed_d_sw_damping_fused_chains(emu, hydrostatic):
     """the same on a C32 face, where the del-2n chains run as one LDS-tile launch away from the corners (cubed_damp.h DelnFused) and
     the damped whole-face levels take the fused transport with delp's damping fluxes as an input (cubed_tpf.h): equal to the passes"""
-    assert max(PC.check_d_sw(emu, npx=33, npz=4, hydrostatic=hydrostatic, faces=(0, 5), flags=PROD, par_over=dict(dddmp=0.5)).values()) <= P.TOL
+    assert max(PC.check_d_sw(emu, npx=33, npz=17, hydrostatic=hydrostatic, faces=(0, 5), flags=PROD, par_over=dict(dddmp=0.5)).values()) <= P.TOL
     assert max(PC.check_d_sw(emu, npx=33, npz=3, hydrostatic=hydrostatic, faces=(2,),
                              flags=dict(do_vort_damp=True, vtdm4=0.06, nord=1)).values()) <= P.TOL
 
