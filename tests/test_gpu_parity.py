@@ -1160,3 +1160,25 @@ def test_sphere_step_through_the_cube_edge_exchange_over_rccl(prod, hydrostatic)
     the six-face oracle's state"""
     r = PC.check_jw_step(prod, npx=25, npz=20, k_split=1, n_split=2, bdt=900.0, hydrostatic=hydrostatic, nq=2, native_halo=True)
     assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12, r
+
+
+def test_switched_off_paths_still_agree():
+    """the forms the round-3 kernels replaced stay in the library behind switches read once per process: the column-kernel geopk, the
+    pass chains of the damping operators and the LDS-tile transports of the damped levels, against the oracle, in their own process"""
+    import subprocess, sys, textwrap
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import parity_common as P, parity_nh as N, parity_cubed as PC
+        from gfdl_atmos_cubed_sphere_amd import lib as L
+        prod = L.load()
+        N.check_halos_and_geopk(prod)
+        PROD = dict(do_vort_damp=True, vtdm4=0.06, nord=3, d_con=1.0, dddmp=0.5)
+        for hyd in (True, False):
+            assert max(PC.check_d_sw(prod, npx=33, npz=17, hydrostatic=hyd, faces=(1,), flags=PROD, par_over=dict(dddmp=0.5)).values()) <= P.TOL
+        print("ok")
+    """) % (os.path.dirname(here), here)
+    env = dict(os.environ, FV3_MI355X_GEOPK_PHASED="0", FV3_MI355X_DELN_FUSED="0", FV3_MI355X_FLUX_MARCH="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr

@@ -1070,3 +1070,25 @@ def test_fortran_host_on_the_cubed_sphere(emu, tmp_path):
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=8, nq=0, hydrostatic=False, beta=0.4, n_split=3)
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=8, nq=2, hydrostatic=False, inline_q=True)
     assert "fv3_solo_sphere: done" in F.check_fortran_sphere(emu, tmp_path, npx=13, npz=8, nq=1, hydrostatic=False, remap_te=True)
+
+
+def test_switched_off_paths_still_agree(emu):
+    """the forms the round-3 kernels replaced stay in the library behind switches that are read once per process: the column-kernel
+    geopk (faces above FV3_MI355X_GEOPK_PHASED columns), the pass chains of the damping operators (FV3_MI355X_DELN_FUSED=0) and the
+    LDS-tile transports of the damped levels (FV3_MI355X_FLUX_MARCH=0) against the oracle, in a process of their own"""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import parity_common as P, parity_nh as N, parity_cubed as PC
+        from gfdl_atmos_cubed_sphere_amd.lib import Fv3Lib
+        emu = Fv3Lib(%r)
+        N.check_halos_and_geopk(emu)
+        PROD = dict(do_vort_damp=True, vtdm4=0.06, nord=3, d_con=1.0, dddmp=0.5)
+        for hyd in (True, False):
+            assert max(PC.check_d_sw(emu, npx=33, npz=17, hydrostatic=hyd, faces=(1,), flags=PROD, par_over=dict(dddmp=0.5)).values()) <= P.TOL
+        print("ok")
+    """) % (os.path.dirname(HERE), HERE, os.path.join(HERE, "hostemu", "libfv3_hostemu.so"))
+    env = dict(os.environ, FV3_MI355X_GEOPK_PHASED="0", FV3_MI355X_DELN_FUSED="0", FV3_MI355X_FLUX_MARCH="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
