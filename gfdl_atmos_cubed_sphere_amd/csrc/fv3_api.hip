@@ -358,7 +358,8 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_RIEM_SCR");
     c->riem_blocked = e ? (std::atoi(e) != 0) : 1;
     e = std::getenv("FV3_MI355X_FAST");
-    c->fast = e ? (std::atoi(e) != 0) : 0;
+    c->fast = e ? std::atoi(e) : 0;   // 1 = every fast kernel; otherwise a mask: 2 Riem_Solver_c, 4 Riem_Solver3, 8 edge_profile, 16 remap
+    if (c->fast == 1) c->fast = 30;
     e = std::getenv("FV3_MI355X_REMAP_SCR");
     c->remap_blocked = e ? (std::atoi(e) != 0) : 1;
     e = std::getenv("FV3_MI355X_MARCH_TJ_KE");
@@ -2436,7 +2437,7 @@ extern "C" int fv3_set_condensate(fv3_ctx *c, const double *q_con, const double 
 
 extern "C" int fv3_set_fast(fv3_ctx *c, int on) {
   if (!c) return fail("fv3_set_fast: null context");
-  c->fast = on != 0;
+  c->fast = on == 1 ? 30 : on;   // 1 = every fast kernel; otherwise a mask (2 Riem_Solver_c, 4 Riem_Solver3, 8 edge_profile, 16 remap)
   return 0;
 }
 
@@ -2444,7 +2445,7 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn,
                                  const double *pt, const double *delp, double *gz, double *pef, const double *ws) {
   if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver_c: bad context/arguments");
   if (cn->a_imp <= 0.5) return fail("fv3_riem_solver_c: a_imp <= 0.5 (RIM_2D / SIM3p0) is not built");
-  if (c->fast && !c->q_con && c->g.npz <= 127 && c->g.npz >= 2) {   // Riem_Solver_c is SIM1 whatever a_imp is
+  if ((c->fast & 2) && !c->q_con && c->g.npz <= 127 && c->g.npz >= 2) {   // Riem_Solver_c is SIM1 whatever a_imp is
     RiemFast<true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0};
     RT(launch_p2(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
@@ -2471,7 +2472,7 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
   if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver3: bad context/arguments");
   if (cn->a_imp <= 0.5) return fail("fv3_riem_solver3: a_imp <= 0.5 (RIM_2D / SIM3 / SIM3p0) is not built");
   if (last_call && (!pe || !pk || !peln)) return fail("fv3_riem_solver3: last_call needs pe, pk, peln");
-  if (c->fast && !c->q_con && !c->cappa && cn->a_imp > 0.999 && c->g.npz <= 127 && c->g.npz >= 2) {
+  if ((c->fast & 4) && !c->q_con && !c->cappa && cn->a_imp > 0.999 && c->g.npz <= 127 && c->g.npz >= 2) {
     RiemFast<false> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
                        use_logp, last_call, fp_out};
     RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
@@ -2506,7 +2507,7 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
   const int km = g.npz;
   double *cxa = c->scratch[0], *xfa = c->scratch[1], *cya = c->scratch[2], *yfa = c->scratch[3];
   using EPF = EdgeProfileFast<10>;
-  if (c->fast && km >= 2 && km <= 512) {   // one sweep over k, the back substitution as truncated chains in registers (nh_fast.h)
+  if ((c->fast & 8) && km >= 2 && km <= 512) {   // one sweep over k, the back substitution as truncated chains in registers (nh_fast.h)
     EPF kf{g, km, c->ec, c->edge_dev + 3 * km, crx, xfx, cxa, xfa, (int)g.nCX(), cry, yfx, cya, yfa, (int)g.nCY()};
     RT(launch_p(c, "edge_profile", col_grid(2 * (int)(g.nCX() + g.nCY())), EPF::lds_doubles(km), kf));
   } else {
@@ -3146,7 +3147,7 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   }
   const double *ak = c->akbk, *bk = c->akbk + (km + 1);
   // fast mode (remap_fast.h): the column in LDS, the spline by scans, the rest the parity code per (column, level)
-  bool fast = c->fast && !moist && !c->remap_te_on && !p->fill && p->kord_tm < 0 && km <= 127 && km >= 5 && kord_fast(-p->kord_tm) &&
+  bool fast = (c->fast & 16) && !moist && !c->remap_te_on && !p->fill && p->kord_tm < 0 && km <= 127 && km >= 5 && kord_fast(-p->kord_tm) &&
               kord_fast(p->kord_mt) && (p->hydrostatic || kord_fast(p->kord_wz));
   for (int n = 0; n < p->nq && fast; n++) fast = kord_fast(kord_tr[n]);
   if (fast) {

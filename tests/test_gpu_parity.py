@@ -959,6 +959,19 @@ def test_cubed_sphere_step_as_a_hip_graph(prod, hydrostatic):
 PROD = dict(do_vort_damp=True, vtdm4=0.06, nord=3, d_con=1.0, dddmp=0.5)
 
 
+@pytest.mark.parametrize("hydrostatic", [False, True])
+def test_cubed_c384_pair_vs_oracle(prod, hydrostatic):
+    """the strip / segment / frame ownership arithmetic of the cubed hybrid (CswMarch<2,0,true> + FramePass + Tp2dFrameFused
+    + the marching d_sw kernels with their store masks) is size-dependent, and C384 (7 strips x 6-8 segments, the width BASELINE
+    config 3 runs at) was held to the oracle only through mass / edge properties.  Six gnomonic C384 faces, c_sw -> halo -> d_sw:
+    two sponge + two regular levels with the default flags (marching interior + frame passes), and 18 levels with the production
+    damping set (every level damped: the del-2n chains, the flux-form march and the frame kernel), sw_core.F90:79-1606."""
+    assert PC.check_c_sw(prod, npx=385, npz=4, hydrostatic=hydrostatic) <= P.TOL
+    assert max(PC.check_d_sw(prod, npx=385, npz=4, hydrostatic=hydrostatic).values()) <= P.TOL
+    assert max(PC.check_d_sw(prod, npx=385, npz=18, hydrostatic=hydrostatic, faces=(0, 3, 5), flags=PROD,
+                             par_over=dict(dddmp=0.5)).values()) <= P.TOL
+
+
 @pytest.mark.parametrize("hydrostatic", [True, False])
 def test_cubed_d_sw_damping_fused_chains(prod, hydrostatic):
     """C32 / C48 faces: the del-2n chains as one LDS-tile launch away from the corners (cubed_damp.h DelnFused), the damped whole-face

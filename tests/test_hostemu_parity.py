@@ -623,6 +623,14 @@ def test_cubed_d_sw(emu, kw):
     assert max(PC.check_d_sw(emu, npx=13, npz=3, **kw).values()) <= P.TOL
 
 
+def test_cubed_c384_face_pair_vs_oracle(emu):
+    """one gnomonic C384 face (7 strips of wavefronts, the width of BASELINE config 3): the ownership arithmetic of the cubed hybrid --
+    marching interior with its store masks, frame passes, the fused frame kernel -- against the oracle (the GPU suite runs all six
+    faces, both branches and the production damping set: test_cubed_c384_pair_vs_oracle)"""
+    assert PC.check_c_sw(emu, npx=385, npz=3, hydrostatic=False, faces=(4,)) <= P.TOL
+    assert max(PC.check_d_sw(emu, npx=385, npz=3, hydrostatic=False, faces=(4,)).values()) <= P.TOL
+
+
 def test_cubed_d_sw_nonhydrostatic_default(emu):
     """the default level coefficients: del-2 damping of w in the sponge layer (damp_w > 0, nord_w = 0)"""
     assert max(PC.check_d_sw(emu, npx=13, npz=4, hydrostatic=False).values()) <= P.TOL
