@@ -132,6 +132,8 @@ struct fv3_ctx {
   int riem_blocked;   // the same for the Riemann solvers' four slabs (FV3_MI355X_RIEM_SCR: 0 / 1, default 1)
   int fast;           // fast (tolerance) mode: FV3_MI355X_FAST=1 or fv3_set_fast -- nh_fast.h instead of the parity column solvers
   int remap_blocked;  // scratch slabs of the remap in per-wavefront blocks (FV3_MI355X_REMAP_SCR: 0 / 1, default 1)
+  int remap_lds;      // the remap with the column in LDS (remap_fast.h; bit-identical to the slab kernels) where it is built for the
+                      // configuration (FV3_MI355X_REMAP_LDS: 0 / 1, default 1)
   int tj_fixed;          // an FV3_MI355X_MARCH_TJ* variable is set: take the rows per segment as given
   int csw_kpw;           // levels per wavefront in CswMarch (1 .. 4; FV3_MI355X_CSW_KPW)
   int use_fused;         // 1: delp + w + pt in one marching kernel when the schemes allow (FV3_MI355X_FUSED=0: off)
@@ -358,10 +360,12 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_RIEM_SCR");
     c->riem_blocked = e ? (std::atoi(e) != 0) : 1;
     e = std::getenv("FV3_MI355X_FAST");
-    c->fast = e ? std::atoi(e) : 0;   // 1 = every fast kernel; otherwise a mask: 2 Riem_Solver_c, 4 Riem_Solver3, 8 edge_profile, 16 remap
-    if (c->fast == 1) c->fast = 30;
+    c->fast = e ? std::atoi(e) : 0;   // 1 = every tolerance-mode kernel; otherwise a mask: 2 Riem_Solver_c, 4 Riem_Solver3, 8 edge_profile
+    if (c->fast == 1) c->fast = 14;
     e = std::getenv("FV3_MI355X_REMAP_SCR");
     c->remap_blocked = e ? (std::atoi(e) != 0) : 1;
+    e = std::getenv("FV3_MI355X_REMAP_LDS");
+    c->remap_lds = e ? (std::atoi(e) != 0) : 1;
     e = std::getenv("FV3_MI355X_MARCH_TJ_KE");
     c->march_tj_ke = e ? std::atoi(e) : 48;
     if (c->march_tj_ke < 1) c->march_tj_ke = 48;
@@ -2437,7 +2441,7 @@ extern "C" int fv3_set_condensate(fv3_ctx *c, const double *q_con, const double 
 
 extern "C" int fv3_set_fast(fv3_ctx *c, int on) {
   if (!c) return fail("fv3_set_fast: null context");
-  c->fast = on == 1 ? 30 : on;   // 1 = every fast kernel; otherwise a mask (2 Riem_Solver_c, 4 Riem_Solver3, 8 edge_profile, 16 remap)
+  c->fast = on == 1 ? 14 : on;   // 1 = every tolerance-mode kernel; otherwise a mask (2 Riem_Solver_c, 4 Riem_Solver3, 8 edge_profile)
   return 0;
 }
 
@@ -3146,22 +3150,23 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
     rp.q_con = c->moist_qcon; rp.cappa = c->moist_cappa;
   }
   const double *ak = c->akbk, *bk = c->akbk + (km + 1);
-  // fast mode (remap_fast.h): the column in LDS, the spline by scans, the rest the parity code per (column, level)
-  bool fast = (c->fast & 16) && !moist && !c->remap_te_on && !p->fill && p->kord_tm < 0 && km <= 127 && km >= 5 && kord_fast(-p->kord_tm) &&
+  // the column in LDS (remap_fast.h): the spline in the reference's order by hand-over rounds, the rest the slab kernels' code per
+  // (column, level); the same bits as the slab kernels below, which keep what it is not built for
+  bool fast = c->remap_lds && !moist && !c->remap_te_on && !p->fill && p->kord_tm < 0 && km <= 127 && km >= 5 && kord_fast(-p->kord_tm) &&
               kord_fast(p->kord_mt) && (p->hydrostatic || kord_fast(p->kord_wz));
   for (int n = 0; n < p->nq && fast; n++) fast = kord_fast(kord_tr[n]);
   if (fast) {
     {
       RemapFastScalars kf{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga};
-      RT(launch_p2(c, "remap_fast_scalars", Dim3{(unsigned)kf.nblocks_x(), (unsigned)g.ny, 1}, kRLds, kf));
+      RT(launch_p2(c, "remap_lds_scalars", Dim3{(unsigned)kf.nblocks_x(), (unsigned)g.ny, 1}, kRLds, kf));
     }
     {
       RemapFastWind<0> kf{g, km, p->kord_mt, ak, bk, pe, u};
-      RT(launch_p2(c, "remap_fast_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kRLds, kf));
+      RT(launch_p2(c, "remap_lds_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kRLds, kf));
     }
     {
       RemapFastWind<1> kf{g, km, p->kord_mt, ak, bk, pe, v};
-      RT(launch_p2(c, "remap_fast_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kRLds, kf));
+      RT(launch_p2(c, "remap_lds_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kRLds, kf));
     }
     RemapPe kf{g, km, ak, bk, pe};
     RT(launch_c(c, "remap_pe", col_grid(g.nx * g.ny), kf));

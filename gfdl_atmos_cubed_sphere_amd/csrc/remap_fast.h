@@ -13,7 +13,8 @@
 //     pe1(l+1) >= pe2(k), see map_target) and adds the source layers in the reference's order;
 //   * T_v, delz and sphum stay in registers for what the remap ends with (delp, pk, peln, pkz, the conversion of pt, :426-503,
 //     :793-841), so the remap of a column is one kernel; the D-grid winds are a second one (their own coordinates, :530-573).
-// Not bit-identical: the interface values come from another elimination order (1e-15 relative); held to the oracle at 1e-12.
+// BIT-IDENTICAL to the parity kernels (round 4): the elimination runs in the reference's own order -- a lane runs its 8 rows from the
+// value its neighbour hands it, round after round, until no hand-over changes any more (spline(): the recurrences forget, 3-6 rounds).
 // Built for: dry thermodynamics (no moist_kappa / use_cond), kord_tm < 0, every kord in 8..10 or 13..15, fill and remap_te off,
 // km <= 127.  Anything else takes the parity kernels.
 #pragma once
@@ -32,31 +33,74 @@ namespace fv3 {
 #define FV3_LOAD_LOOP(it) _Pragma("unroll") for (int it = 0; it < kIt; it++)
 #endif
 
-constexpr int kRP = 2 + 128 + 2;         // doubles per column of an LDS array: row r at [2 + r], r = -2 .. 129
+// A column of an LDS array: rows 0 .. 135 in chunks of 8 rows at 9 doubles (row r at [r + r / 8], nh_fast.h lds_lev: the 16 lanes of a
+// column, 8 rows apart, hit 16 different bank pairs -- 8 doubles apart they collided four at a time, SQ_LDS_BANK_CONFLICT 2.4x the
+// active LDS cycles in profiles/r03_v25_pmc_remap.csv); rows -2, -1 behind them.  156 = 28 (mod 32): the 16 columns x 4 levels a
+// wavefront stages at a time spread over all banks.
+constexpr int kRC = 17 * kFS;            // 153
+constexpr int kRP = kRC + 3;             // 156
 constexpr int kRBuf = kFC * kRP;
+FV3_HD int rix(int r) { return r + (r >> 3); }                              // r >= 0
+FV3_HD int rixn(int r) { return r >= 0 ? r + (r >> 3) : kRC + 2 + r; }      // r >= -2
+// row k (1-based) of a column
+struct RCol {
+  double *p;
+  FV3_HD double &operator[](int k) const { return p[rix(k - 1)]; }
+};
+struct RColC {
+  const double *p;
+  FV3_HD double operator[](int k) const { return p[rix(k - 1)]; }
+};
+// One byte per row in the ninth double of its chunk (the padding of the layout): which expression the subgrid limiters formed the
+// curvature a4 of cell k with (cs_cell / cs_limit, remap_kernels.h) -- map_target forms a4 again with that expression instead of keeping
+// a third array of cell coefficients in LDS: 0: 3 (2 a1 - (a2 + a3)); 1: 6 a1 - 3 (a2 + a3); 2: 3 (a2 - a1); 3: 3 (a3 - a1)
+FV3_HD unsigned char *a4_form_ptr(double *col, int k) { return reinterpret_cast<unsigned char *>(col + ((k - 1) >> 3) * kFS + kFL) + ((k - 1) & 7); }
+FV3_HD int a4_form(const double *col, int k) {
+  return reinterpret_cast<const unsigned char *>(col + ((k - 1) >> 3) * kFS + kFL)[(k - 1) & 7];
+}
+FV3_HD double a4_of(int form, double a1, double a2, double a3) {
+  switch (form) {
+    case 0: return 3. * (2. * a1 - (a2 + a3));
+    case 1: return 6. * a1 - 3. * (a2 + a3);
+    case 2: return 3. * (a2 - a1);
+    default: return 3. * (a3 - a1);
+  }
+}
+FV3_HD int a4_form_of(double a4, double a1, double a2, double a3) {   // the first expression that gives a4 bit for bit (one of them formed it)
+  if (a4 == 3. * (2. * a1 - (a2 + a3))) return 0;
+  if (a4 == 6. * a1 - 3. * (a2 + a3)) return 1;
+  if (a4 == 3. * (a2 - a1)) return 2;
+  return 3;
+}
 constexpr int kRNBuf = 4;                // C1 (source coordinate), C2 (target coordinate), A1 (layer means), Q (interface values / out)
-constexpr int kRLds = kRNBuf * kRBuf + kFC;   // + the bottom boundary value of w per column
+constexpr int kRLds = kRNBuf * kRBuf;          // 79 872 B: two workgroups per CU (the bottom value of w per column sits in C1's spare slot)
+constexpr int kRQS = kRC + 2;                  // ... [kRC + 2] of a column: the one double of the 156 the layout does not use
 
 #ifdef FV3_HOST_EMU
-inline vd vlin_ld(const double *buf, int col0, int r) {
+inline vd vlin_ld(const double *buf, int col0, int q) {      // row (lane & 15) * 8 + q of the lane's column; any q with row >= -2
   vd x;
-  FV3_LANE_LOOP x.v[l] = buf[((l >> 4) + col0) * kRP + 2 + (l & 15) * kFL + r];
+  FV3_LANE_LOOP x.v[l] = buf[((l >> 4) + col0) * kRP + rixn((l & 15) * kFL + q)];
   return x;
 }
-inline void vlin_st(double *buf, int col0, int r, const vd &x) {
-  FV3_LANE_LOOP buf[((l >> 4) + col0) * kRP + 2 + (l & 15) * kFL + r] = x.v[l];
+inline void vlin_st(double *buf, int col0, int q, const vd &x) {
+  FV3_LANE_LOOP buf[((l >> 4) + col0) * kRP + rixn((l & 15) * kFL + q)] = x.v[l];
 }
-inline vd vcol_lds(const double *p, int col0) { vd x; FV3_LANE_LOOP x.v[l] = p[(l >> 4) + col0]; return x; }
+inline vd vcol_lds(const double *p, int col0) { vd x; FV3_LANE_LOOP x.v[l] = p[((l >> 4) + col0) * kRP]; return x; }
+inline bool vany_ne(const vd &a, const vd &b) {               // some lane's bits differ
+  FV3_LANE_LOOP if (fv3m_bits(a.v[l]) != fv3m_bits(b.v[l])) return true;
+  return false;
+}
 #else
-__device__ __forceinline__ vd vlin_ld(const double *buf, int col0, int r) {
+__device__ __forceinline__ vd vlin_ld(const double *buf, int col0, int q) {
   const int l = (int)(threadIdx.x & 63);
-  return buf[((l >> 4) + col0) * kRP + 2 + (l & 15) * kFL + r];
+  return buf[((l >> 4) + col0) * kRP + rixn((l & 15) * kFL + q)];
 }
-__device__ __forceinline__ void vlin_st(double *buf, int col0, int r, vd x) {
+__device__ __forceinline__ void vlin_st(double *buf, int col0, int q, vd x) {
   const int l = (int)(threadIdx.x & 63);
-  buf[((l >> 4) + col0) * kRP + 2 + (l & 15) * kFL + r] = x;
+  buf[((l >> 4) + col0) * kRP + rixn((l & 15) * kFL + q)] = x;
 }
-__device__ __forceinline__ vd vcol_lds(const double *p, int col0) { return p[(int)((threadIdx.x & 63) >> 4) + col0]; }
+__device__ __forceinline__ vd vcol_lds(const double *p, int col0) { return p[((int)((threadIdx.x & 63) >> 4) + col0) * kRP]; }
+__device__ __forceinline__ bool vany_ne(vd a, vd b) { return __builtin_amdgcn_ballot_w64(fv3m_bits(a) != fv3m_bits(b)) != 0; }
 #endif
 
 // kords the streamed form of the mapping loop handles (cs_cell): scalar_profile / cs_profile without the two-cell limiters of 11, 12
@@ -69,9 +113,9 @@ FV3_HD bool kord_fast(int kord) {
 // the arithmetic of map_col.  The reference searches from k0, the source layer the previous target layer ended in, and takes the
 // first l with pe1(l) <= pe2(k) <= pe1(l+1): that is the smallest l with pe1(l+1) >= pe2(k) (the previous layer ended at pe2(k), in
 // the first layer whose lower edge is not above it), found here from the guess l = k.  pe1, a1: 1-based columns in LDS; a2, a3: the
-// limited edge values of every source cell (cs_cell), a4 = 3 (2 a1 - (a2 + a3)) formed here (the reference stores it: equal to
-// rounding).  The quotients through one reciprocal and a Markstein correction: the values of `/` (remap_kernels.h div_rn).
-FV3_HD double map_target(const double *pe1, const double *a1, const double *a2, const double *a3, int km, bool tracer_form, int k,
+// limited edge values of every source cell (cs_cell), a4 formed here again with the expression the limiters used (a4_form: the value
+// the reference stores, bit for bit).  The quotients through one reciprocal and a Markstein correction: the values of `/` (remap_kernels.h div_rn).
+FV3_HD double map_target(const RColC pe1, const RColC a1, const RColC a2, const RColC a3, int km, bool tracer_form, int k,
                          double p2t, double p2b) {
   constexpr double r3 = 1. / 3., r23 = 2. / 3.;
   int l = k;
@@ -80,7 +124,7 @@ FV3_HD double map_target(const double *pe1, const double *a1, const double *a2, 
   const double p1t = pe1[l], p1b = pe1[l + 1];
   const double dp1 = p1b - p1t, rdp1 = rcp_rn(dp1);
   const double pl = div_rn(p2t - p1t, dp1, rdp1);
-  const double b2 = a2[l], b3 = a3[l], b4 = 3. * (2. * a1[l] - (b2 + b3));
+  const double b2 = a2[l], b3 = a3[l], b4 = a4_of(a4_form(a1.p, l), a1[l], b2, b3);
   if (p2b <= p1b) {
     const double pr = div_rn(p2b - p1t, dp1, rdp1);
     if (tracer_form) {
@@ -108,7 +152,7 @@ FV3_HD double map_target(const double *pe1, const double *a1, const double *a2, 
     } else {
       const double dp = p2b - mt, dm = mb - mt;
       const double esl = div_rn(dp, dm, rcp_rn(dm));
-      const double m2 = a2[m], m3 = a3[m], m4 = 3. * (2. * a1[m] - (m2 + m3));
+      const double m2 = a2[m], m3 = a3[m], m4 = a4_of(a4_form(a1.p, m), a1[m], m2, m3);
       if (tracer_form) {
         const double fac1 = 0.5 * esl, fac2 = 1. - r23 * esl;
         qsum = qsum + dp * (m2 + fac1 * (m3 - m2 + m4 * fac2));
@@ -127,62 +171,135 @@ struct RemapFastCore {
   int km;
   static constexpr int kIt = kFC * 128 / kNT;   // (column, level) pairs per thread
 
-  FV3_D static double *col_ptr(double *buf, int col) { return buf + col * kRP + 2; }
+  FV3_D static RCol col(double *buf, int c) { return RCol{buf + c * kRP}; }          // [k], k 1-based
+  FV3_D static RColC colc(const double *buf, int c) { return RColC{buf + c * kRP}; }
+  FV3_D static double &at(double *buf, int c, int r) { return buf[c * kRP + rix(r)]; }   // row r >= 0 of column c
 
   // pads of a coordinate array: rows -2, -1 and km+1 .. 129 continue with unit steps (layer thickness 1: the padded rows of
   // the system stay regular); of a field array: zeros.  Called by one thread per column after the real rows are in place.
-  FV3_D void pad_coord(double *buf, int col, int nrow) const {
-    double *p = col_ptr(buf, col);
-    p[-1] = p[0] - 1.; p[-2] = p[0] - 2.;
-    for (int r = nrow; r < 130; r++) p[r] = p[nrow - 1] + (double)(r - nrow + 1);
+  FV3_D void pad_coord(double *buf, int c, int nrow) const {
+    double *p = buf + c * kRP;
+    p[rixn(-1)] = p[0] - 1.; p[rixn(-2)] = p[0] - 2.;
+    for (int r = nrow; r < 130; r++) p[rix(r)] = p[rix(nrow - 1)] + (double)(r - nrow + 1);
   }
-  FV3_D void pad_field(double *buf, int col, int nrow) const {
-    double *p = col_ptr(buf, col);
-    p[-1] = 0.; p[-2] = 0.;
-    for (int r = nrow; r < 130; r++) p[r] = 0.;
+  FV3_D void pad_field(double *buf, int c, int nrow) const {
+    double *p = buf + c * kRP;
+    p[rixn(-1)] = 0.; p[rixn(-2)] = 0.;
+    for (int r = nrow; r < 130; r++) p[rix(r)] = 0.;
   }
 
   // interface values of the cubic spline: raw q(1 .. km+1) into Q.  iv = -2: scalar_profile / cs_profile with the bottom value qs
   // given (:572-595 / :941-964), otherwise :597-623 / :967-1016.  One wavefront = 4 columns; between barriers of the caller.
+  //
+  // The reference's elimination, in the reference's order, bit for bit.  Row k (interface k; lane = (k - 1) / 8) of both forms is
+  //     bet_k = B_k - S_k gam_(k-1),   gam_k = N_k / bet_k,   q_k = (R_k - S_k q_(k-1)) / bet_k      (forward, k = 1 .. km + 1)
+  //     q_k = q_k - G_k q_(k+1)                                                                     (backward)
+  // with S = 1 in the interior (x * 1 is exact), S = a_bot in the bottom closure, and B = 1, S = 0 where the reference assigns a value
+  // outright (the top closure, q(km+1) = qs, the padded rows): then bet = 1 and the quotients are N and R themselves.  Every
+  // expression is the parity kernel's (remap_kernels.h profile_col); the quotients through a correctly rounded reciprocal and a
+  // Markstein correction = the values of `/`.  A lane runs its 8 rows from the value the lane above hands it; all lanes do so at once,
+  // ROUND AFTER ROUND, each round from the hand-overs of the one before.  After round r the lanes 0 .. r - 1 hold the sequential
+  // values (lane 0 starts from the closure), so 16 rounds are the sequential sweep; and when a round leaves every hand-over as it
+  // found it the state is the sequential one already (induction from lane 0) -- these recurrences forget (d gam_k / d gam_(k-1) =
+  // N / bet^2 ~ 0.07, d q_k / d q_(k-1) = 1 / bet ~ 0.27), so that happens after 3 - 6 rounds.
   FV3_D void spline(const double *C1, const double *A1, double *Q, const double *QS, int iv, int wv) const {
     const int c0 = wv * 4;
-    vd e[kFL + 1], av[kFL], dpv[kFL];
-    for (int q = 0; q <= kFL; q++) e[q] = vlin_ld(C1, c0, q);
-    const vd em1 = vlin_ld(C1, c0, -1), em2 = vlin_ld(C1, c0, -2);
-    for (int q = 0; q < kFL; q++) {
-      av[q] = vlin_ld(A1, c0, q);
-      dpv[q] = e[q + 1] - e[q];
-    }
-    const vd am1v = vlin_ld(A1, c0, -1), am2v = vlin_ld(A1, c0, -2);
-    const vd dpm1v = e[0] - em1, dpm2v = em1 - em2;
-    vd a[kFL], b[kFL], c[kFL], d[kFL], x[kFL];
-    const vd qs = QS ? vcol_lds(QS, c0) : vd(0.0);
-    for (int q = 0; q < kFL; q++) {
-      const vd a_m1 = q > 0 ? av[q - 1] : am1v, a_m2 = q > 1 ? av[q - 2] : (q == 1 ? am1v : am2v);
-      const vd dp_m1 = q > 0 ? dpv[q - 1] : dpm1v, dp_m2 = q > 1 ? dpv[q - 2] : (q == 1 ? dpm1v : dpm2v);
-      const vb first = vlevel_eq(q, 0), pad = !vlevel_lt(q, km + 1);
-      const vd gr = vdivq(dp_m1, dpv[q]);          // dp(k-1) / dp(k) of row k = r + 1
-      if (iv == -2) {
-        const vb lastc = vlevel_eq(q, km - 1), bot = vlevel_eq(q, km);
-        a[q] = vsel(first || bot || pad, vd(0.0), vd(1.0));
-        b[q] = vsel(first, vd(2.0), vsel(bot || pad, vd(1.0), 2. + gr + gr));
-        c[q] = vsel(first, vd(1.0), vsel(lastc || bot || pad, vd(0.0), gr));
-        const vd rhs = 3. * (a_m1 + av[q]);
-        d[q] = vsel(first, 3. * av[q], vsel(bot, qs, vsel(pad, vd(0.0), vsel(lastc, rhs - gr * qs, rhs))));
-      } else {
-        const vb bot = vlevel_eq(q, km);
-        // top row: grat = dp(2) / dp(1) (rows 0 and 1 are the lane's own); bottom row: d4 = dp(km-1) / dp(km)
-        const vd g1 = vdivq(dpv[1], dpv[0]);
-        const vd d4b = vdivq(dp_m2, dp_m1);
-        const vd a_bot = 1. + d4b * (d4b + 1.5);
-        a[q] = vsel(first || pad, vd(0.0), vsel(bot, a_bot, vd(1.0)));
-        b[q] = vsel(first, g1 * (g1 + 0.5), vsel(bot, d4b * (d4b + 0.5), vsel(pad, vd(1.0), 2. + gr + gr)));
-        c[q] = vsel(first, 1. + g1 * (g1 + 1.5), vsel(bot || pad, vd(0.0), gr));
-        d[q] = vsel(first, (g1 + g1) * (g1 + 1.) * av[0] + av[1],
-                    vsel(bot, 2. * d4b * (d4b + 1.) * a_m1 + a_m2, vsel(pad, vd(0.0), 3. * (a_m1 + gr * av[q]))));
+    vd B[kFL], N[kFL], R[kFL], S[kFL], G[kFL], bet[kFL], rb[kFL], x[kFL];
+    {
+      vd e[kFL + 1], av[kFL], dpv[kFL];
+      for (int q = 0; q <= kFL; q++) e[q] = vlin_ld(C1, c0, q);
+      const vd em1 = vlin_ld(C1, c0, -1), em2 = vlin_ld(C1, c0, -2);
+      for (int q = 0; q < kFL; q++) {
+        av[q] = vlin_ld(A1, c0, q);
+        dpv[q] = e[q + 1] - e[q];
+      }
+      const vd am1v = vlin_ld(A1, c0, -1), am2v = vlin_ld(A1, c0, -2);
+      const vd dpm1v = e[0] - em1, dpm2v = em1 - em2;
+      const vd qs = QS ? vcol_lds(QS, c0) : vd(0.0);            // QS[column * kRP]
+      for (int q = 0; q < kFL; q++) {
+        const vd a_m1 = q > 0 ? av[q - 1] : am1v, a_m2 = q > 1 ? av[q - 2] : (q == 1 ? am1v : am2v);
+        const vd dp_m1 = q > 0 ? dpv[q - 1] : dpm1v, dp_m2 = q > 1 ? dpv[q - 2] : (q == 1 ? dpm1v : dpm2v);
+        const vb first = vlevel_eq(q, 0), pad = !vlevel_lt(q, km + 1), bot = vlevel_eq(q, km);
+        const vd gr = vdivq(dp_m1, dpv[q]);          // dp(k-1) / dp(k) of row k = r + 1
+        const vd bi = 2. + gr + gr;
+        if (iv == -2) {
+          const vb lastc = vlevel_eq(q, km - 1);
+          const vb given = first || bot || pad;
+          const vd rhs = 3. * (a_m1 + av[q]);
+          B[q] = vsel(given, vd(1.0), bi);
+          S[q] = vsel(given, vd(0.0), vd(1.0));
+          N[q] = vsel(first, vd(0.5), vsel(bot || pad || lastc, vd(0.0), gr));
+          R[q] = vsel(first, 1.5 * av[q], vsel(bot, qs, vsel(pad, vd(0.0), vsel(lastc, rhs - gr * qs, rhs))));
+          G[q] = vsel(vlevel_lt(q, km - 1), vd(1.0), vd(0.0));      // back substitution on rows k <= km - 1, with gam(k+1) = this row's
+        } else {
+          // top row: grat = dp(2) / dp(1) (rows 0 and 1 are the lane's own); bottom row: d4 = dp(km-1) / dp(km)
+          const vd g1 = vdivq(dpv[1], dpv[0]);
+          const vd d4b = vdivq(dp_m2, dp_m1);
+          const vd a_bot = 1. + d4b * (d4b + 1.5);
+          B[q] = vsel(first, g1 * (g1 + 0.5), vsel(bot, d4b * (d4b + 0.5), vsel(pad, vd(1.0), bi)));
+          S[q] = vsel(first || pad, vd(0.0), vsel(bot, a_bot, vd(1.0)));
+          N[q] = vsel(first, 1. + g1 * (g1 + 1.5), vsel(bot || pad, vd(0.0), gr));
+          R[q] = vsel(first, (g1 + g1) * (g1 + 1.) * av[0] + av[1],
+                      vsel(bot, 2. * d4b * (d4b + 1.) * a_m1 + a_m2, vsel(pad, vd(0.0), 3. * (a_m1 + gr * av[q]))));
+          G[q] = vsel(vlevel_lt(q, km), vd(1.0), vd(0.0));          // rows k <= km, with gam(k)
+        }
       }
     }
-    tridiag_rows(a, b, c, d, x);
+    constexpr int kRounds = 16;
+#ifdef FV3_ROUND_STATS
+    extern long g_round_stats[3][20];
+#define FV3_RS(c, r) g_round_stats[c][r]++
+#else
+#define FV3_RS(c, r)
+#endif
+    {                                     // bet, 1 / bet, gam: G[q] becomes this row's multiplier of the back substitution
+      vd gin(0.27);
+      vd gam[kFL];
+      for (int rnd = 0; rnd < kRounds; rnd++) {
+        vd g = gin;
+        for (int q = 0; q < kFL; q++) {
+          bet[q] = B[q] - S[q] * g;
+          rb[q] = vrecip(bet[q]);
+          g = vdiv_r(N[q], bet[q], rb[q]);
+          gam[q] = g;
+        }
+        const vd gnew = row_shr<1>(g, 0.27);
+        const bool moved = vany_ne(gnew, gin);
+        gin = gnew;
+        if (!moved) { FV3_RS(0, rnd); break; }
+      }
+      for (int q = 0; q < kFL; q++) G[q] = G[q] * gam[q];
+    }
+    {                                     // forward substitution
+      vd qin(0.0);
+      for (int rnd = 0; rnd < kRounds; rnd++) {
+        vd y = qin;
+        for (int q = 0; q < kFL; q++) {
+          y = vdiv_r(R[q] - S[q] * y, bet[q], rb[q]);
+          x[q] = y;
+        }
+        const vd qnew = row_shr<1>(y, 0.0);
+        const bool moved = vany_ne(qnew, qin);
+        qin = qnew;
+        if (!moved) { FV3_RS(1, rnd); break; }
+      }
+    }
+    {                                     // back substitution
+      vd xin(0.0);
+      vd y[kFL];
+      for (int q = 0; q < kFL; q++) y[q] = x[q];
+      for (int rnd = 0; rnd < kRounds; rnd++) {
+        vd xn = xin;
+        for (int q = kFL - 1; q >= 0; q--) {
+          xn = y[q] - G[q] * xn;
+          x[q] = xn;
+        }
+        const vd xnew = row_shl<1>(xn, 0.0);
+        const bool moved = vany_ne(xnew, xin);
+        xin = xnew;
+        if (!moved) { FV3_RS(2, rnd); break; }
+      }
+    }
     for (int q = 0; q < kFL; q++) vlin_st(Q, c0, q, x[q]);
   }
 
@@ -191,8 +308,8 @@ struct RemapFastCore {
     for (int idx = tid; idx < kFC * 128; idx += kNT) {
       const int col = idx >> 7, k = (idx & 127) + 1;
       if (k < 2 || k > km) continue;
-      const double *a1 = A1 + col * kRP + 2 - 1;   // a1[k], 1-based
-      double *q = Q + col * kRP + 2 - 1;
+      const RColC a1 = colc(A1, col);   // a1[k], 1-based
+      const RCol q = RemapFastCore::col(Q, col);
       const double w_m1 = a1[k - 1], w_0 = a1[k];
       double qc = q[k];
       if (k == 2 || k == km) {
@@ -220,39 +337,42 @@ struct RemapFastCore {
   FV3_D void map_all(double *C1, double *C2, double *A1, double *Q, bool is_scalar, int iv, int ak, double qmin, bool tracer_form,
                      int tid) const {
     double r2[kIt], r3v[kIt], pt2[kIt], pb2[kIt];
+    int form[kIt];
     const ProfCfg pc{km, iv, ak, is_scalar, qmin, true};
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
       r2[it] = r3v[it] = pt2[it] = pb2[it] = 0.;
+      form[it] = 0;
       if (k > km) continue;
-      const double *a1 = col_ptr(A1, col) - 1, *q = col_ptr(Q, col) - 1, *t2 = col_ptr(C2, col) - 1;
+      const RColC a1 = colc(A1, col), q = colc(Q, col), t2 = colc(C2, col);
       double a2v = q[k], a3v = q[k + 1], a4v;
       cs_cell(pc, k, a2v, a3v, k - 2 >= 1 ? a1[k - 2] : 0., k - 1 >= 1 ? a1[k - 1] : 0., a1[k], k + 1 <= km ? a1[k + 1] : 0.,
               k + 2 <= km ? a1[k + 2] : 0., a4v);
       r2[it] = a2v; r3v[it] = a3v;
+      form[it] = a4_form_of(a4v, a1[k], a2v, a3v);
       pt2[it] = t2[k]; pb2[it] = t2[k + 1];
     }
     FV3_SYNC();
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
       if (k > km) continue;
-      col_ptr(Q, col)[k - 1] = r2[it];
-      col_ptr(C2, col)[k - 1] = r3v[it];
+      at(Q, col, k - 1) = r2[it];
+      at(C2, col, k - 1) = r3v[it];
+      *a4_form_ptr(A1 + col * kRP, k) = (unsigned char)form[it];
     }
     FV3_SYNC();
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
       if (k > km) continue;
-      r2[it] = map_target(col_ptr(C1, col) - 1, col_ptr(A1, col) - 1, col_ptr(Q, col) - 1, col_ptr(C2, col) - 1, km, tracer_form, k,
-                          pt2[it], pb2[it]);
+      r2[it] = map_target(colc(C1, col), colc(A1, col), colc(Q, col), colc(C2, col), km, tracer_form, k, pt2[it], pb2[it]);
     }
     FV3_SYNC();
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
       if (k > km) continue;
-      col_ptr(Q, col)[k - 1] = r2[it];
-      col_ptr(C2, col)[k - 1] = pt2[it];
-      if (k == km) col_ptr(C2, col)[km] = pb2[it];
+      at(Q, col, k - 1) = r2[it];
+      at(C2, col, k - 1) = pt2[it];
+      if (k == km) at(C2, col, km) = pb2[it];
     }
   }
 
@@ -285,7 +405,7 @@ struct RemapFastScalars {
   FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
     constexpr int kIt = RemapFastCore::kIt;
     const RemapFastCore core{km};
-    double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf, *QS = lds + 4 * kRBuf;
+    double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf, *QS = C1 + kRQS;   // QS[column * kRP]
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (g.nx - bx * kFC < kFC) ? g.nx - bx * kFC : kFC;
     const size_t nA = g.nA(), nCC = g.nCC();
@@ -319,8 +439,8 @@ struct RemapFastScalars {
         qv[it] = 0.; dznew[it] = 0.; pn2[it] = 0.;
         if (k0 <= km) {
           pn2[it] = (k0 == 0 || k0 == km) ? v_pl[it] : dlog(ak[k0] + bk[k0] * v_ps[it]);
-          RemapFastCore::col_ptr(C1, col)[k0] = v_pl[it];
-          RemapFastCore::col_ptr(C2, col)[k0] = pn2[it];
+          RemapFastCore::at(C1, col, k0) = v_pl[it];
+          RemapFastCore::at(C2, col, k0) = pn2[it];
           if (k0 == 0) ps[o0 + cc] = v_ps[it];   // :298-300
         }
         if (k0 < km) {
@@ -329,7 +449,7 @@ struct RemapFastScalars {
             t = t * (v_a[it] - v_b[it]) / (akap * (v_c[it] - v_pl[it]));
           else
             t = t * dexp(k1k * dlog(rrg * v_a[it] / v_b[it] * t));
-          RemapFastCore::col_ptr(A1, col)[k0] = t;
+          RemapFastCore::at(A1, col, k0) = t;
         }
       }
     }
@@ -338,13 +458,13 @@ struct RemapFastScalars {
       core.pad_coord(C1, col, km + 1);
       core.pad_coord(C2, col, km + 1);
       core.pad_field(A1, col, km);
-      QS[col] = p.hydrostatic ? 0. : ws[occ0 + clampc(col)];
+      QS[col * kRP] = p.hydrostatic ? 0. : ws[occ0 + clampc(col)];
     }
     FV3_SYNC();
     core.remap_field(C1, C2, A1, Q, nullptr, true, 1, akt, p.t_min, false, tid);
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-      tnew[it] = k0 < km ? RemapFastCore::col_ptr(Q, col)[k0] : 0.;
+      tnew[it] = k0 < km ? RemapFastCore::at(Q, col, k0) : 0.;
     }
     // ---- omega on the last step (:432-443, :506-526): interpolated in the old log-p coordinate (C1) to the centres of the new
     //      layers (C2); pe3(k) = omga(k-1), pe3(1) = 0 in A1 ----
@@ -359,7 +479,7 @@ struct RemapFastScalars {
         }
         for (int it = 0; it < kIt; it++) {
           const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-          if (k0 <= km) RemapFastCore::col_ptr(A1, col)[k0] = k0 == 0 ? 0. : v_o[it];
+          if (k0 <= km) RemapFastCore::at(A1, col, k0) = k0 == 0 ? 0. : v_o[it];
         }
       }
       FV3_SYNC();
@@ -368,7 +488,7 @@ struct RemapFastScalars {
         const int idx = tid + it * kNT, col = idx >> 7, n = (idx & 127) + 1;
         om[it] = 0.;
         if (n > km) continue;
-        const double *e = RemapFastCore::col_ptr(C1, col) - 1, *t2 = RemapFastCore::col_ptr(C2, col) - 1, *p3 = RemapFastCore::col_ptr(A1, col) - 1;
+        const RColC e = RemapFastCore::colc(C1, col), t2 = RemapFastCore::colc(C2, col), p3 = RemapFastCore::colc(A1, col);
         const double mid = 0.5 * (t2[n] + t2[n + 1]);
         int k = n;                                  // the reference's first k (from k_next) with e(k) <= mid <= e(k+1)
         while (k > 1 && e[k] >= mid) k--;
@@ -378,12 +498,12 @@ struct RemapFastScalars {
       FV3_SYNC();
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx >> 7, n = (idx & 127) + 1;
-        if (n <= km) RemapFastCore::col_ptr(Q, col)[n - 1] = om[it];
+        if (n <= km) RemapFastCore::at(Q, col, n - 1) = om[it];
       }
       FV3_SYNC();
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-        if (k0 < km && col < ncol) omga[(size_t)k0 * nA + o0 + col] = RemapFastCore::col_ptr(Q, col)[k0];
+        if (k0 < km && col < ncol) omga[(size_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);
       }
     }
     FV3_SYNC();
@@ -400,10 +520,10 @@ struct RemapFastScalars {
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 <= km) {
-          RemapFastCore::col_ptr(C1, col)[k0] = v_pe[it];
-          RemapFastCore::col_ptr(C2, col)[k0] = (k0 == 0) ? p.ptop : (k0 == km ? v_ps[it] : ak[k0] + bk[k0] * v_ps[it]);
+          RemapFastCore::at(C1, col, k0) = v_pe[it];
+          RemapFastCore::at(C2, col, k0) = (k0 == 0) ? p.ptop : (k0 == km ? v_ps[it] : ak[k0] + bk[k0] * v_ps[it]);
         }
-        if (!p.hydrostatic && k0 < km) RemapFastCore::col_ptr(A1, col)[k0] = v_w[it];
+        if (!p.hydrostatic && k0 < km) RemapFastCore::at(A1, col, k0) = v_w[it];
       }
     }
     FV3_SYNC();
@@ -426,9 +546,9 @@ struct RemapFastScalars {
         }
         for (int it = 0; it < kIt; it++) {
           const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-          if (k0 < km && col < ncol) w[(size_t)k0 * nA + o0 + col] = RemapFastCore::col_ptr(Q, col)[k0];
+          if (k0 < km && col < ncol) w[(size_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);
           // ---- delz (:292, :412-423): the specific volume -delz / delp in, delz = -q2 dp2 out ----
-          if (k0 < km) RemapFastCore::col_ptr(A1, col)[k0] = -v_dz[it] / v_dp[it];
+          if (k0 < km) RemapFastCore::at(A1, col, k0) = -v_dz[it] / v_dp[it];
         }
       }
       FV3_SYNC();
@@ -436,8 +556,7 @@ struct RemapFastScalars {
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 < km) {
-          const double *t2 = RemapFastCore::col_ptr(C2, col);
-          dznew[it] = -RemapFastCore::col_ptr(Q, col)[k0] * (t2[k0 + 1] - t2[k0]);
+          dznew[it] = -RemapFastCore::at(Q, col, k0) * (RemapFastCore::at(C2, col, k0 + 1) - RemapFastCore::at(C2, col, k0));
           if (col < ncol) delz[(size_t)k0 * nCC + occ0 + col] = dznew[it];
         }
       }
@@ -454,7 +573,7 @@ struct RemapFastScalars {
         }
         for (int it = 0; it < kIt; it++) {
           const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-          if (k0 < km) RemapFastCore::col_ptr(A1, col)[k0] = v_q[it];
+          if (k0 < km) RemapFastCore::at(A1, col, k0) = v_q[it];
         }
       }
       FV3_SYNC();
@@ -462,7 +581,7 @@ struct RemapFastScalars {
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 < km) {
-          const double v = RemapFastCore::col_ptr(Q, col)[k0];
+          const double v = RemapFastCore::at(Q, col, k0);
           if (iq == p.sphum - 1) qv[it] = v;
           if (col < ncol) qq[(size_t)k0 * nA + o0 + col] = v;
         }
@@ -484,22 +603,22 @@ struct RemapFastScalars {
             pk[(size_t)k0 * nCC + occ0 + col] = pkv;
           }
         }
-        RemapFastCore::col_ptr(A1, col)[k0] = pn;
-        RemapFastCore::col_ptr(Q, col)[k0] = pkv;
+        RemapFastCore::at(A1, col, k0) = pn;
+        RemapFastCore::at(Q, col, k0) = pkv;
       }
     }
     FV3_SYNC();
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
       if (k0 >= km || col >= ncol) continue;
-      const double *t2 = RemapFastCore::col_ptr(C2, col), *pn = RemapFastCore::col_ptr(A1, col), *pk2 = RemapFastCore::col_ptr(Q, col);
+      const RColC t2 = RemapFastCore::colc(C2, col), pn = RemapFastCore::colc(A1, col), pk2 = RemapFastCore::colc(Q, col);   // [k], 1-based: row k0 is [k0 + 1]
       const size_t o3 = (size_t)k0 * nA + o0 + col, c3 = (size_t)k0 * nCC + occ0 + col;
-      const double dp2 = t2[k0 + 1] - t2[k0];
+      const double dp2 = t2[k0 + 2] - t2[k0 + 1];
       delp[o3] = dp2;
       const double tv = tnew[it];
       double pkzv;
       if (p.hydrostatic)
-        pkzv = (pk2[k0 + 1] - pk2[k0]) / (akap * (pn[k0 + 1] - pn[k0]));
+        pkzv = (pk2[k0 + 2] - pk2[k0 + 1]) / (akap * (pn[k0 + 2] - pn[k0 + 1]));
       else
         pkzv = dexp(akap * dlog(rrg * dp2 / dznew[it] * tv));
       pkz[c3] = pkzv;
@@ -553,11 +672,11 @@ struct RemapFastWind {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 <= km) {
           const double psum = v_sa[it] + v_sb[it];
-          RemapFastCore::col_ptr(C1, col)[k0] = (k0 == 0) ? v_b[it] : 0.5 * (v_a[it] + v_b[it]);
+          RemapFastCore::at(C1, col, k0) = (k0 == 0) ? v_b[it] : 0.5 * (v_a[it] + v_b[it]);
           const double bkh = 0.5 * bk[k0];
-          RemapFastCore::col_ptr(C2, col)[k0] = (WHICH == 1 && k0 == 0) ? ak[0] : ak[k0] + bkh * psum;
+          RemapFastCore::at(C2, col, k0) = (WHICH == 1 && k0 == 0) ? ak[0] : ak[k0] + bkh * psum;
         }
-        if (k0 < km) RemapFastCore::col_ptr(A1, col)[k0] = v_f[it];
+        if (k0 < km) RemapFastCore::at(A1, col, k0) = v_f[it];
       }
     }
     FV3_SYNC();
@@ -570,7 +689,7 @@ struct RemapFastWind {
     core.remap_field(C1, C2, A1, Q, nullptr, false, -1, kord_mt, 0., false, tid);
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-      if (k0 < km && col < ncol) f[(size_t)k0 * fs + f0 + col] = RemapFastCore::col_ptr(Q, col)[k0];
+      if (k0 < km && col < ncol) f[(size_t)k0 * fs + f0 + col] = RemapFastCore::at(Q, col, k0);
     }
   }
 };

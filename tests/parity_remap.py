@@ -43,7 +43,7 @@ MOIST6 = dict(nwat=6, liq_wat=2, rainwat=3, ice_wat=4, snowwat=5, graupel=6, cv_
 
 
 def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=False, kord_tm=-8, kord=8, adiabatic=True,
-                moist_kappa=False, use_cond=False, nwat=6, fill=False, remap_te=False, fast=False):
+                moist_kappa=False, use_cond=False, nwat=6, fill=False, remap_te=False, lds=True):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     moist = moist_kappa or use_cond
@@ -89,11 +89,20 @@ def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=Fal
         O.lagrangian_to_eulerian(g, km, par, dry, ak, bk)
         n_chk = "pkz" if moist_kappa else "pt"
         assert P.rel_rms(dry[n_chk], ref[n_chk]) > 1e-6
-    ctx = Context(g, km, lib=lib)
+    import os
+    saved = os.environ.pop("FV3_MI355X_REMAP_LDS", None)
+    if not lds:
+        os.environ["FV3_MI355X_REMAP_LDS"] = "0"      # read when the context is created
+    try:
+        ctx = Context(g, km, lib=lib)
+    finally:
+        os.environ.pop("FV3_MI355X_REMAP_LDS", None)
+        if saved is not None:
+            os.environ["FV3_MI355X_REMAP_LDS"] = saved
     try:
         ctx.set_ak_bk(ak, bk)
-        if fast:      # the tolerance mode (csrc/remap_fast.h): the spline by scans, everything else the parity arithmetic
-            ctx.set_fast(True)
+        # lds: the remap with the column in LDS (csrc/remap_fast.h, the default where it is built; bit-identical to the slab kernels);
+        # False: FV3_MI355X_REMAP_LDS=0, the slab kernels (csrc/remap_kernels.h) for every configuration
         d = {k: ctx.from_host(v) for k, v in f.items()}
         if moist:
             ctx.set_moist(mpar, d["q_con"], d["cappa"])
@@ -102,7 +111,7 @@ def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=Fal
         ctx.lagrangian_to_eulerian(par, d["ps"], d["pe"], d["delp"], d["pkz"], d["pk"], d["u"], d["v"],
                                    None if hydrostatic else d["w"], None if hydrostatic else d["delz"], d["pt"],
                                    d.get("q"), d["peln"], d["omga"], None if hydrostatic else d["ws"])
-        tol = 1e-12 if fast else 1e-14
+        tol = 1e-14
         r = (bd.is_, bd.ie, bd.js, bd.je)
         names = [("pt", "A", r), ("delp", "A", r), ("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)),
                  ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)), ("ps", "A", r)]

@@ -213,17 +213,19 @@ def test_edge_profile_fast_against_the_oracle(emu):
     N.check_update_dz_d(emu, km=40, fast=True, lev_over=dict(do_vort_damp=True, vtdm4=0.06, nord=2))
 
 
-def test_remap_fast_against_the_oracle(emu):
-    """the tolerance mode of the remap (csrc/remap_fast.h: the column in LDS, the spline's interface values by scans, limiters and
-    mapping loop with the parity arithmetic) against the oracle at 1e-12 -- measured 1e-16"""
+def test_remap_in_lds_and_in_slabs(emu):
+    """Lagrangian_to_Eulerian with the column in LDS (csrc/remap_fast.h: levels across the lanes, the spline's elimination in the
+    reference's order by hand-over rounds, the limiters' curvature re-formed from a one-byte code) -- the default where it is built, and
+    BIT-IDENTICAL to the oracle like the slab kernels (csrc/remap_kernels.h), which the same cases run through with
+    FV3_MI355X_REMAP_LDS=0 and which keep what the LDS kernels are not built for (fill, kord_tm > 0, the moist branches, remap_te)"""
     for kw in (dict(), dict(km=20, nx=33, ny=9), dict(hydrostatic=True), dict(last_step=True, adiabatic=False),
                dict(hydrostatic=True, last_step=True, adiabatic=False, kord_tm=-10, kord=10), dict(kord=9, kord_tm=-9, nq=7),
-               dict(km=127, nx=17, ny=3, nq=1), dict(km=79, nq=4, kord=13, kord_tm=-14)):
-        assert R.check_remap(emu, fast=True, **kw) <= 1e-12
-    # what the fast kernels are not built for takes the parity kernels (and is then exact)
-    assert R.check_remap(emu, fast=True, fill=True) <= 1e-14
-    assert R.check_remap(emu, fast=True, kord_tm=9) <= 1e-14
-    assert R.check_remap(emu, fast=True, moist_kappa=True) <= 1e-14
+               dict(km=127, nx=17, ny=3, nq=1), dict(km=79, nq=4, kord=13, kord_tm=-14), dict(kord=15, kord_tm=-15, km=8)):
+        assert R.check_remap(emu, **kw) == 0.0
+        assert R.check_remap(emu, lds=False, **kw) == 0.0
+    assert R.check_remap(emu, fill=True) <= 1e-14
+    assert R.check_remap(emu, kord_tm=9) <= 1e-14
+    assert R.check_remap(emu, moist_kappa=True) <= 1e-14
 
 
 def test_remap_te(emu):

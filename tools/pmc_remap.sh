@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box): bash tools/pmc_remap.sh <tag>
-# The remap alone (tools/remap_time.py, C384L127 tile, 4 tracers), parity and fast kernels: HBM traffic (FETCH_SIZE doubled -- gfx950
+# The remap alone (tools/remap_time.py, C384L127 tile, 4 tracers), slab kernels and LDS kernels: HBM traffic (FETCH_SIZE doubled -- gfx950
 # correction, profiles/README.md -- and WRITE_SIZE, separate passes) and the SQ counters that say what a kernel waits for
 # -> gpurun_out/<tag>/pmc_remap.csv (kernel, counter, average per launch)
 TAG=${1:-vX}
@@ -41,7 +41,7 @@ print(json.dumps({"build_id": lib.build_id(), "shape": [384, 384, 127, 4],
                   "_note": "HBM bytes of one Lagrangian_to_Eulerian call (every remap_* launch) on a 384x384x127 tile with 4 tracers: rocprofv3 --pmc "
                            "FETCH_SIZE (KB, doubled: gfx950 correction) + WRITE_SIZE (KB), separate passes, tools/pmc_remap.sh; algorithmic: "
                            "(144 + 16 nq) B per cell = 3.90e9",
-                  "parity": total(["RemapCoords", "RemapFields", "RemapDelzFinal", "RemapPe"]),
-                  "fast": total(["RemapFastScalars", "RemapFastWind", "RemapPe"])}, indent=1))
+                  "slabs": total(["RemapCoords", "RemapFields", "RemapDelzFinal", "RemapPe"]),
+                  "lds": total(["RemapFastScalars", "RemapFastWind", "RemapPe"])}, indent=1))
 PY
 tail -n 3 /tmp/pr1.log /tmp/pr3.log > gpurun_out/$TAG/pmc_remap.log 2>&1

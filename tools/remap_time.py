@@ -1,4 +1,4 @@
-"""time Lagrangian_to_Eulerian alone (parity kernels / fast mode) on a C384L127-sized tile with nq tracers: ms per kernel label per call
+"""time Lagrangian_to_Eulerian alone (slab kernels, FV3_MI355X_REMAP_LDS=0 / the column in LDS, the default) on a C384L127-sized tile with nq tracers: ms per kernel label per call
 (fv3_profile events).  NX, KM, NQ from the environment."""
 import os
 import sys
@@ -23,10 +23,10 @@ def main():
     f, ak, bk = R.remap_state(bd, km, nq)
     par = dict(last_step=0, hydrostatic=0, adiabatic=1, nq=nq, kord_mt=8, kord_wz=8, kord_tm=-8, sphum=1 if nq else 0, akap=KAPPA, ptop=N.PTOP,
                rdgas=RDGAS, grav=GRAV, cv_air=CP_AIR - RDGAS, r_vir=0.6077, cp=CP_AIR, t_min=184.0, kord_tr=[8] * nq)
-    for fast in (False, True):
+    for lds in (False, True):
+        os.environ["FV3_MI355X_REMAP_LDS"] = "1" if lds else "0"
         ctx = L.Context(g, km)
         ctx.set_ak_bk(ak, bk)
-        ctx.set_fast(fast)
         d = {k: ctx.from_host(v) for k, v in f.items()}
         tot = {}
         for rep in range(6):
@@ -42,7 +42,7 @@ def main():
                 for label, (cnt, ms) in ctx.profile_report().items():
                     tot[label] = tot.get(label, 0.0) + ms / 4.0
                 ctx.profile(False)
-        print("fast" if fast else "parity", {k: round(v, 4) for k, v in tot.items()}, "sum", round(sum(tot.values()), 4))
+        print("lds" if lds else "slabs", {k: round(v, 4) for k, v in tot.items()}, "sum", round(sum(tot.values()), 4))
         ctx.close()
 
 
