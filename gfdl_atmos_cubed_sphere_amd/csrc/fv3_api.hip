@@ -1803,10 +1803,87 @@ constexpr int kNcclInt64 = 4, kNcclSum = 0;   // ncclInt64, ncclSum
 }  // namespace
 #endif
 
+#ifdef FV3_HOST_EMU
+// ---- the message transport of the logic harness (tests/hostemu ONLY; the product is the RCCL code above) --------------------------
+// What the exchange does around a message -- pack lists, the order of the sends and receives of a group, the unpack -- is the same
+// code in both builds; only the wire differs.  Here a message is a file in a directory named by the "unique id": the k-th message
+// rank a sends to rank b is <dir>/m_<a>_<b>_<k>, written under another name and renamed (so a reader never sees half of it); the
+// k-th receive rank b posts for a waits for exactly that file and REFUSES a message of another size.  That is the matching rule of
+// ncclSend / ncclRecv inside a group (per pair of ranks, in posting order), so several processes on the CPU exercise what a
+// loopback on one GPU cannot: a sender and a receiver that disagree about the order or the content of their messages.
+#include <sys/stat.h>
+#include <unistd.h>
+namespace {
+struct EmuComm {
+  std::string dir;
+  int rank, n;
+  std::vector<long> sseq, rseq;
+  long coll;
+};
+int emu_wait_file(const std::string &name) {
+  struct stat sb;
+  for (long spin = 0; spin < 600000; spin++) {   // up to ~2 minutes
+    if (stat(name.c_str(), &sb) == 0) return 0;
+    usleep(200);
+  }
+  return fail("host-emulation transport: %s never arrived (the peer posts its messages in another order, or died)", name.c_str());
+}
+int emu_put(const std::string &name, const void *buf, size_t bytes) {
+  const std::string tmp = name + ".tmp";
+  FILE *f = std::fopen(tmp.c_str(), "wb");
+  if (!f) return fail("host-emulation transport: cannot write %s", tmp.c_str());
+  const size_t w = bytes ? std::fwrite(buf, 1, bytes, f) : 0;
+  std::fclose(f);
+  if (w != bytes || std::rename(tmp.c_str(), name.c_str())) return fail("host-emulation transport: write of %s failed", name.c_str());
+  return 0;
+}
+int emu_get(const std::string &name, void *buf, size_t bytes, bool remove) {
+  if (emu_wait_file(name)) return 1;
+  struct stat sb;
+  if (stat(name.c_str(), &sb) || (size_t)sb.st_size != bytes)
+    return fail("host-emulation transport: %s carries %ld bytes, the receive expects %ld (the two ends of a link disagree)", name.c_str(),
+                (long)sb.st_size, (long)bytes);
+  FILE *f = std::fopen(name.c_str(), "rb");
+  if (!f) return fail("host-emulation transport: cannot read %s", name.c_str());
+  const size_t r = bytes ? std::fread(buf, 1, bytes, f) : 0;
+  std::fclose(f);
+  if (r != bytes) return fail("host-emulation transport: short read of %s", name.c_str());
+  if (remove) std::remove(name.c_str());
+  return 0;
+}
+int emu_send(EmuComm *e, const void *buf, size_t bytes, int peer) {
+  char nm[64];
+  std::snprintf(nm, sizeof nm, "/m_%d_%d_%ld", e->rank, peer, e->sseq[peer]++);
+  return emu_put(e->dir + nm, buf, bytes);
+}
+int emu_recv(EmuComm *e, void *buf, size_t bytes, int peer) {
+  char nm[64];
+  std::snprintf(nm, sizeof nm, "/m_%d_%d_%ld", peer, e->rank, e->rseq[peer]++);
+  return emu_get(e->dir + nm, buf, bytes, true);
+}
+// every rank's `bytes` of `in`, rank by rank, into out (n * bytes)
+int emu_allgather(EmuComm *e, const void *in, size_t bytes, std::vector<char> &out) {
+  char nm[64];
+  const long k = e->coll++;
+  std::snprintf(nm, sizeof nm, "/c_%ld_%d", k, e->rank);
+  if (emu_put(e->dir + nm, in, bytes)) return 1;
+  out.resize((size_t)e->n * bytes);
+  for (int r = 0; r < e->n; r++) {
+    std::snprintf(nm, sizeof nm, "/c_%ld_%d", k, r);
+    if (emu_get(e->dir + nm, out.data() + (size_t)r * bytes, bytes, false)) return 1;
+  }
+  return 0;
+}
+}  // namespace
+#endif
+
 extern "C" int fv3_comm_get_unique_id(unsigned char *id) {
   if (!id) return fail("fv3_comm_get_unique_id: null");
 #ifdef FV3_HOST_EMU
   std::memset(id, 0, FV3_COMM_ID_BYTES);
+  char tmpl[] = "/tmp/fv3emu_XXXXXX";
+  if (!mkdtemp(tmpl)) return fail("fv3_comm_get_unique_id: mkdtemp failed");
+  std::memcpy(id, tmpl, sizeof tmpl);
   return 0;
 #else
   if (rccl_load()) return 1;
@@ -1824,8 +1901,15 @@ extern "C" int fv3_comm_init(fv3_ctx *c, int rank, int nranks, const unsigned ch
   RT(rt_event_create(&c->ev_packed));
   RT(rt_event_create(&c->ev_arrived));
 #ifdef FV3_HOST_EMU
-  if (nranks > 1) return fail("fv3_comm_init: the host-emulation build has no RCCL (one rank only)");
-  c->comm = (void *)c;
+  {
+    EmuComm *e = new (std::nothrow) EmuComm();
+    if (!e) return fail("fv3_comm_init: out of host memory");
+    e->dir = id[0] ? std::string(reinterpret_cast<const char *>(id), strnlen(reinterpret_cast<const char *>(id), FV3_COMM_ID_BYTES)) : std::string();
+    e->rank = rank; e->n = nranks; e->coll = 0;
+    e->sseq.assign(nranks, 0); e->rseq.assign(nranks, 0);
+    if (nranks > 1 && e->dir.empty()) { delete e; return fail("fv3_comm_init: several ranks need the id of fv3_comm_get_unique_id"); }
+    c->comm = (void *)e;
+  }
 #else
   if (rccl_load()) return 1;
   Id128 uid;
@@ -1839,6 +1923,8 @@ extern "C" int fv3_comm_destroy(fv3_ctx *c) {
   if (!c) return 0;
 #ifndef FV3_HOST_EMU
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+#else
+  if (c->comm) delete static_cast<EmuComm *>(c->comm);
 #endif
   c->comm = nullptr;
   for (int d = 0; d < 8; d++) {
@@ -1864,11 +1950,7 @@ extern "C" int fv3_halo_start(fv3_ctx *c, int nfields, const fv3_halo_field *fie
   if (!fields || !to || !from || nfields < 1 || nfields > FV3_HALO_MAX_FIELDS) return fail("fv3_halo_start: bad argument");
   if (c->pend_n) return fail("fv3_halo_start: the previous group has not been completed");
   for (int d = 0; d < 8; d++) {   // checked BEFORE the pack and the group: a bad entry must not leave an RCCL group open
-#ifdef FV3_HOST_EMU
-    if (to[d] != c->comm_rank || from[d] != c->comm_rank) return fail("fv3_halo_start: the host-emulation build has no peers");
-#else
     if (to[d] < 0 || to[d] >= c->comm_size || from[d] < 0 || from[d] >= c->comm_size) return fail("fv3_halo_start: peer out of range");
-#endif
   }
   size_t elems[8];
   if (fv3_halo_message_elems(c, nfields, fields, elems)) return 1;
@@ -1885,7 +1967,13 @@ extern "C" int fv3_halo_start(fv3_ctx *c, int nfields, const fv3_halo_field *fie
   rt_event_record(c->ev_packed, c->stream);
   rt_stream_wait_event(c->comm_stream, c->ev_packed);
 #ifdef FV3_HOST_EMU
-  for (int d = 0; d < 8; d++) RT(rt_d2d(c->msg_recv[d], c->msg_send[d], sizeof(double) * elems[d], c->comm_stream));
+  {   // the group: every send, then every receive, each matched per peer in posting order (see the transport above)
+    EmuComm *e = static_cast<EmuComm *>(c->comm);
+    for (int d = 0; d < 8; d++)
+      if (emu_send(e, c->msg_send[d], sizeof(double) * elems[d], to[d])) return 1;
+    for (int d = 0; d < 8; d++)
+      if (emu_recv(e, c->msg_recv[d], sizeof(double) * elems[d], from[d])) return 1;
+  }
 #else
   NC(g_rccl.GroupStart());
   int rc = 0;
@@ -2114,16 +2202,15 @@ extern "C" int fv3_cube_halo_start(int nctx, fv3_ctx *const *ctxs, const int *fa
   }
   // ---- the messages: sends ordered by (sender face, receiver face), receives likewise -- the same order on both ends of a link ----
 #ifdef FV3_HOST_EMU
-  auto ctx_of_face = [&](int t) { for (int i = 0; i < nctx; i++) if (faces[i] == t) return i; return -1; };
-  for (int i = 0; i < nctx; i++)
-    for (int r = 0; r < 6; r++) {
-      if (!scount[i][r]) continue;
-      const int jr = ctx_of_face(r);
-      if (jr < 0) return fail("fv3_cube_halo_start: the host-emulation build has no peers (face %d is not held here)", r);
-      if (rcount[jr][faces[i]] != scount[i][r]) return fail("fv3_cube_halo_start: message size mismatch %d -> %d", faces[i], r);
-      RT(rt_d2d(ctxs[jr]->cube_recv + ctxs[jr]->cube_roff[0][faces[i]], ctxs[i]->cube_send + soff[i][0][r], sizeof(double) * scount[i][r],
-                c0->comm_stream));
-    }
+  {   // the same order as the RCCL group below: sends by (sender face, receiver face), receives by (sender face, receiver face)
+    EmuComm *e = static_cast<EmuComm *>(c0->comm);
+    for (int i = 0; i < nctx; i++)
+      for (int r = 0; r < 6; r++)
+        if (scount[i][r] && emu_send(e, ctxs[i]->cube_send + soff[i][0][r], sizeof(double) * scount[i][r], face_rank[r])) return 1;
+    for (int sf = 0; sf < 6; sf++)
+      for (int i = 0; i < nctx; i++)
+        if (rcount[i][sf] && emu_recv(e, ctxs[i]->cube_recv + ctxs[i]->cube_roff[0][sf], sizeof(double) * rcount[i][sf], face_rank[sf])) return 1;
+  }
 #else
   NC(g_rccl.GroupStart());
   int rc = 0;
@@ -2179,7 +2266,14 @@ extern "C" int fv3_allreduce_max(fv3_ctx *c, double *buf, int n) {
   if (!c || !c->comm || !buf || n < 1) return fail("fv3_allreduce_max: bad argument / no communicator");
   if (c->comm_size == 1) return 0;
 #ifdef FV3_HOST_EMU
-  return fail("fv3_allreduce_max: the host-emulation build has no RCCL");
+  {
+    std::vector<char> all;
+    if (emu_allgather(static_cast<EmuComm *>(c->comm), buf, sizeof(double) * n, all)) return 1;
+    const double *a = reinterpret_cast<const double *>(all.data());
+    for (int r = 0; r < c->comm_size; r++)
+      for (int m = 0; m < n; m++) buf[m] = a[(size_t)r * n + m] > buf[m] ? a[(size_t)r * n + m] : buf[m];
+    return 0;
+  }
 #else
   double *d = nullptr;
   RT(rt_malloc((void **)&d, sizeof(double) * n));
@@ -2231,7 +2325,17 @@ extern "C" int fv3_ordered_sum(fv3_ctx *c, const double *values, size_t n, doubl
   for (int i = 0; i < NI; i++) dig[i] = (long long)acc[i];
   if (c && c->comm && c->comm_size > 1) {
 #ifdef FV3_HOST_EMU
-    return fail("fv3_ordered_sum: the host-emulation build has no RCCL");
+    {
+      std::vector<char> all;
+      if (emu_allgather(static_cast<EmuComm *>(c->comm), dig, sizeof(long long) * NI, all)) return 1;
+      const long long *a = reinterpret_cast<const long long *>(all.data());
+      for (int i = 0; i < NI; i++) {
+        acc[i] = 0;
+        for (int r = 0; r < c->comm_size; r++) acc[i] += a[(size_t)r * NI + i];
+      }
+      carry(acc);
+      for (int i = 0; i < NI; i++) dig[i] = (long long)acc[i];
+    }
 #else
     long long *d = nullptr;
     RT(rt_malloc((void **)&d, sizeof(long long) * NI));
@@ -3157,8 +3261,11 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   for (int n = 0; n < p->nq && fast; n++) fast = kord_fast(kord_tr[n]);
   if (fast) {
     {
-      RemapFastScalars kf{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga};
-      RT(launch_p2(c, "remap_lds_scalars", Dim3{(unsigned)kf.nblocks_x(), (unsigned)g.ny, 1}, kRLds, kf));
+      const Dim3 gr{(unsigned)((g.nx + kFC - 1) / kFC), (unsigned)g.ny, 1};
+      if (p->hydrostatic)
+        RT(launch_p2(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<true>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga}));
+      else
+        RT(launch_p2(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<false>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga}));
     }
     {
       RemapFastWind<0> kf{g, km, p->kord_mt, ak, bk, pe, u};

@@ -33,15 +33,31 @@ namespace fv3 {
 #define FV3_LOAD_LOOP(it) _Pragma("unroll") for (int it = 0; it < kIt; it++)
 #endif
 
-// A column of an LDS array: rows 0 .. 135 in chunks of 8 rows at 9 doubles (row r at [r + r / 8], nh_fast.h lds_lev: the 16 lanes of a
-// column, 8 rows apart, hit 16 different bank pairs -- 8 doubles apart they collided four at a time, SQ_LDS_BANK_CONFLICT 2.4x the
-// active LDS cycles in profiles/r03_v25_pmc_remap.csv); rows -2, -1 behind them.  156 = 28 (mod 32): the 16 columns x 4 levels a
-// wavefront stages at a time spread over all banks.
+// A column of an LDS array, two layouts (FV3_REMAP_CHUNKED, a build-time choice; the linear one is the product's):
+//   linear  : row r at [r + 2], r = -2 .. 129, then 16 doubles = 128 one-byte codes (a4_form); 148 = 20 (mod 32): the 16 columns x 4
+//             levels a wavefront stages at a time spread over all banks.  The spline's accesses (16 lanes of a column 8 rows apart)
+//             collide four at a time -- SQ_LDS_BANK_CONFLICT 2.4x the active LDS cycles in profiles/r03_v25_pmc_remap.csv --
+//   chunked : rows 0 .. 135 in chunks of 8 at 9 doubles (row r at [r + r / 8], nh_fast.h lds_lev; the codes in the ninth doubles),
+//             rows -2, -1 behind them: those 16 lanes hit 16 different bank pairs.  Measured (profiles/r04_remap_layouts.txt): a quarter
+//             fewer conflict cycles, but every one of the ~2 400 LDS accesses of a lane pays two more integer instructions for its
+//             index and the kernel, which is bound by its VALU instructions and not by LDS, got slower.
+#ifndef FV3_REMAP_CHUNKED
+#define FV3_REMAP_CHUNKED 0
+#endif
+#if FV3_REMAP_CHUNKED
 constexpr int kRC = 17 * kFS;            // 153
 constexpr int kRP = kRC + 3;             // 156
-constexpr int kRBuf = kFC * kRP;
+constexpr int kRQS = kRC + 2;            // the one double of a column the layout does not use (the bottom value of w, in C1)
 FV3_HD int rix(int r) { return r + (r >> 3); }                              // r >= 0
 FV3_HD int rixn(int r) { return r >= 0 ? r + (r >> 3) : kRC + 2 + r; }      // r >= -2
+#else
+constexpr int kRC = 2 + 128 + 2;         // 132 rows
+constexpr int kRP = kRC + 16;            // 148
+constexpr int kRQS = kRC;                // C1 carries no codes: the bottom value of w sits in their place
+FV3_HD int rix(int r) { return r + 2; }
+FV3_HD int rixn(int r) { return r + 2; }
+#endif
+constexpr int kRBuf = kFC * kRP;
 // row k (1-based) of a column
 struct RCol {
   double *p;
@@ -51,13 +67,18 @@ struct RColC {
   const double *p;
   FV3_HD double operator[](int k) const { return p[rix(k - 1)]; }
 };
-// One byte per row in the ninth double of its chunk (the padding of the layout): which expression the subgrid limiters formed the
-// curvature a4 of cell k with (cs_cell / cs_limit, remap_kernels.h) -- map_target forms a4 again with that expression instead of keeping
+// One byte per row (chunked: in the ninth double of its chunk; linear: behind the rows): which expression the subgrid limiters formed
+// the curvature a4 of cell k with (cs_cell / cs_limit, remap_kernels.h) -- map_target forms a4 again with that expression instead of keeping
 // a third array of cell coefficients in LDS: 0: 3 (2 a1 - (a2 + a3)); 1: 6 a1 - 3 (a2 + a3); 2: 3 (a2 - a1); 3: 3 (a3 - a1)
+#if FV3_REMAP_CHUNKED
 FV3_HD unsigned char *a4_form_ptr(double *col, int k) { return reinterpret_cast<unsigned char *>(col + ((k - 1) >> 3) * kFS + kFL) + ((k - 1) & 7); }
 FV3_HD int a4_form(const double *col, int k) {
   return reinterpret_cast<const unsigned char *>(col + ((k - 1) >> 3) * kFS + kFL)[(k - 1) & 7];
 }
+#else
+FV3_HD unsigned char *a4_form_ptr(double *col, int k) { return reinterpret_cast<unsigned char *>(col + kRC) + (k - 1); }
+FV3_HD int a4_form(const double *col, int k) { return reinterpret_cast<const unsigned char *>(col + kRC)[k - 1]; }
+#endif
 FV3_HD double a4_of(int form, double a1, double a2, double a3) {
   switch (form) {
     case 0: return 3. * (2. * a1 - (a2 + a3));
@@ -73,8 +94,7 @@ FV3_HD int a4_form_of(double a4, double a1, double a2, double a3) {   // the fir
   return 3;
 }
 constexpr int kRNBuf = 4;                // C1 (source coordinate), C2 (target coordinate), A1 (layer means), Q (interface values / out)
-constexpr int kRLds = kRNBuf * kRBuf;          // 79 872 B: two workgroups per CU (the bottom value of w per column sits in C1's spare slot)
-constexpr int kRQS = kRC + 2;                  // ... [kRC + 2] of a column: the one double of the 156 the layout does not use
+constexpr int kRLds = kRNBuf * kRBuf;          // 75 776 B (chunked: 79 872): two workgroups per CU
 
 #ifdef FV3_HOST_EMU
 inline vd vlin_ld(const double *buf, int col0, int q) {      // row (lane & 15) * 8 + q of the lane's column; any q with row >= -2
@@ -179,7 +199,7 @@ struct RemapFastCore {
   // the system stay regular); of a field array: zeros.  Called by one thread per column after the real rows are in place.
   FV3_D void pad_coord(double *buf, int c, int nrow) const {
     double *p = buf + c * kRP;
-    p[rixn(-1)] = p[0] - 1.; p[rixn(-2)] = p[0] - 2.;
+    p[rixn(-1)] = p[rix(0)] - 1.; p[rixn(-2)] = p[rix(0)] - 2.;
     for (int r = nrow; r < 130; r++) p[rix(r)] = p[rix(nrow - 1)] + (double)(r - nrow + 1);
   }
   FV3_D void pad_field(double *buf, int c, int nrow) const {
@@ -216,11 +236,14 @@ struct RemapFastCore {
       const vd am1v = vlin_ld(A1, c0, -1), am2v = vlin_ld(A1, c0, -2);
       const vd dpm1v = e[0] - em1, dpm2v = em1 - em2;
       const vd qs = QS ? vcol_lds(QS, c0) : vd(0.0);            // QS[column * kRP]
+      vd grv[kFL];
+      for (int q = 0; q < kFL; q++) grv[q] = vdivq(q > 0 ? dpv[q - 1] : dpm1v, dpv[q]);      // dp(k-1) / dp(k) of row k = r + 1
+      const vd gr_up = row_shr<1>(grv[kFL - 1], 1.0);                                       // ... of the row above the lane's first
+      (void)dpm2v;
       for (int q = 0; q < kFL; q++) {
         const vd a_m1 = q > 0 ? av[q - 1] : am1v, a_m2 = q > 1 ? av[q - 2] : (q == 1 ? am1v : am2v);
-        const vd dp_m1 = q > 0 ? dpv[q - 1] : dpm1v, dp_m2 = q > 1 ? dpv[q - 2] : (q == 1 ? dpm1v : dpm2v);
         const vb first = vlevel_eq(q, 0), pad = !vlevel_lt(q, km + 1), bot = vlevel_eq(q, km);
-        const vd gr = vdivq(dp_m1, dpv[q]);          // dp(k-1) / dp(k) of row k = r + 1
+        const vd gr = grv[q];
         const vd bi = 2. + gr + gr;
         if (iv == -2) {
           const vb lastc = vlevel_eq(q, km - 1);
@@ -234,7 +257,7 @@ struct RemapFastCore {
         } else {
           // top row: grat = dp(2) / dp(1) (rows 0 and 1 are the lane's own); bottom row: d4 = dp(km-1) / dp(km)
           const vd g1 = vdivq(dpv[1], dpv[0]);
-          const vd d4b = vdivq(dp_m2, dp_m1);
+          const vd d4b = q > 0 ? grv[q - 1] : gr_up;   // dp(km-1) / dp(km) at the bottom row: the quotient of the row above
           const vd a_bot = 1. + d4b * (d4b + 1.5);
           B[q] = vsel(first, g1 * (g1 + 0.5), vsel(bot, d4b * (d4b + 0.5), vsel(pad, vd(1.0), bi)));
           S[q] = vsel(first || pad, vd(0.0), vsel(bot, a_bot, vd(1.0)));
@@ -391,6 +414,7 @@ struct RemapFastCore {
 };
 
 // ---- the scalars of a column: T_v, w, delz, the tracers, omega; delp, pk, peln, pkz, ps and the conversion of pt ------------------
+template <bool HYDRO>   // the hydrostatic flag at compile time: the other branch's loads and registers are not carried
 struct RemapFastScalars {
   Grid g;
   int km;
@@ -416,37 +440,38 @@ struct RemapFastScalars {
     const int akt = p.kord_tm < 0 ? -p.kord_tm : p.kord_tm;
     auto clampc = [&](int col) { return col < ncol ? col : ncol - 1; };
     // staging map: idx -> (col = idx & 15, k0 = idx >> 4): 16 consecutive threads read 16 consecutive columns of a level
-    double tnew[kIt], dznew[kIt], qv[kIt], pn2[kIt];   // pn2: log of the new interface pressure, formed once
+    // (what the end of the kernel needs of the remapped fields -- T_v, delz, sphum -- is written to pt / delz / q as it is formed and
+    // read back by the same thread there; the log of the new interface pressures is formed again: kept in registers through the
+    // remap of every field these 32 doubles per thread were spilled to scratch, 404 B per lane)
     // ---- log-pressure coordinates of T_v (:340-345, :363-368): C1 = peln, C2 = pn2; the layer means: the temperature transform
     //      (:200-229) level by level ----
     {
-      double v_pl[kIt], v_ps[kIt], v_t[kIt], v_a[kIt], v_b[kIt], v_c[kIt];
+      double v_pl[kIt], v_t[kIt], v_a[kIt], v_b[kIt], v_c[HYDRO ? kIt : 1];
       FV3_LOAD_LOOP(it) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
         const int ki = k0 <= km ? k0 : km, kc = k0 < km ? k0 : km - 1;     // interface / cell row, clamped
         const size_t o3 = (size_t)kc * nA + o0 + cc, c3 = (size_t)kc * nCC + occ0 + cc;
-        v_ps[it] = pe[peb0 + (size_t)km * (g.nx + 2) + cc];
         v_pl[it] = peln[lnb0 + (size_t)ki * g.nx + cc];
         v_t[it] = pt[o3];
-        if (p.hydrostatic) {
+        if (HYDRO) {
           v_a[it] = pk[c3 + nCC]; v_b[it] = pk[c3]; v_c[it] = peln[lnb0 + (size_t)(kc + 1) * g.nx + cc];
         } else {
-          v_a[it] = delp[o3]; v_b[it] = delz[c3]; v_c[it] = 0.;
+          v_a[it] = delp[o3]; v_b[it] = delz[c3];
         }
       }
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
-        qv[it] = 0.; dznew[it] = 0.; pn2[it] = 0.;
         if (k0 <= km) {
-          pn2[it] = (k0 == 0 || k0 == km) ? v_pl[it] : dlog(ak[k0] + bk[k0] * v_ps[it]);
           RemapFastCore::at(C1, col, k0) = v_pl[it];
-          RemapFastCore::at(C2, col, k0) = pn2[it];
-          if (k0 == 0) ps[o0 + cc] = v_ps[it];   // :298-300
+          // (the surface pressure of the thread's column: the same address for every it on the device -- 256 threads, 16 columns)
+          const double v_ps1 = pe[peb0 + (size_t)km * (g.nx + 2) + cc];
+          RemapFastCore::at(C2, col, k0) = (k0 == 0 || k0 == km) ? v_pl[it] : dlog(ak[k0] + bk[k0] * v_ps1);
+          if (k0 == 0) ps[o0 + cc] = v_ps1;   // :298-300
         }
         if (k0 < km) {
           double t = v_t[it];
-          if (p.hydrostatic)
-            t = t * (v_a[it] - v_b[it]) / (akap * (v_c[it] - v_pl[it]));
+          if (HYDRO)
+            t = t * (v_a[it] - v_b[it]) / (akap * (v_c[HYDRO ? it : 0] - v_pl[it]));
           else
             t = t * dexp(k1k * dlog(rrg * v_a[it] / v_b[it] * t));
           RemapFastCore::at(A1, col, k0) = t;
@@ -458,13 +483,13 @@ struct RemapFastScalars {
       core.pad_coord(C1, col, km + 1);
       core.pad_coord(C2, col, km + 1);
       core.pad_field(A1, col, km);
-      QS[col * kRP] = p.hydrostatic ? 0. : ws[occ0 + clampc(col)];
+      QS[col * kRP] = HYDRO ? 0. : ws[occ0 + clampc(col)];
     }
     FV3_SYNC();
     core.remap_field(C1, C2, A1, Q, nullptr, true, 1, akt, p.t_min, false, tid);
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-      tnew[it] = k0 < km ? RemapFastCore::at(Q, col, k0) : 0.;
+      if (k0 < km && col < ncol) pt[(size_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);   // T_v for now
     }
     // ---- omega on the last step (:432-443, :506-526): interpolated in the old log-p coordinate (C1) to the centres of the new
     //      layers (C2); pe3(k) = omga(k-1), pe3(1) = 0 in A1 ----
@@ -509,21 +534,21 @@ struct RemapFastScalars {
     FV3_SYNC();
     // ---- pressure coordinates for everything else: C1 = pe, C2 = pe2 (:318-322) ----
     {
-      double v_pe[kIt], v_ps[kIt], v_w[kIt];
+      double v_pe[kIt], v_w[kIt];
       FV3_LOAD_LOOP(it) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
         const int ki = k0 <= km ? k0 : km, kc = k0 < km ? k0 : km - 1;
-        v_ps[it] = pe[peb0 + (size_t)km * (g.nx + 2) + cc];
         v_pe[it] = pe[peb0 + (size_t)ki * (g.nx + 2) + cc];
-        v_w[it] = p.hydrostatic ? 0. : w[(size_t)kc * nA + o0 + cc];
+        v_w[it] = HYDRO ? 0. : w[(size_t)kc * nA + o0 + cc];
       }
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 <= km) {
           RemapFastCore::at(C1, col, k0) = v_pe[it];
-          RemapFastCore::at(C2, col, k0) = (k0 == 0) ? p.ptop : (k0 == km ? v_ps[it] : ak[k0] + bk[k0] * v_ps[it]);
+          const double v_ps1 = pe[peb0 + (size_t)km * (g.nx + 2) + clampc(col)];
+          RemapFastCore::at(C2, col, k0) = (k0 == 0) ? p.ptop : (k0 == km ? v_ps1 : ak[k0] + bk[k0] * v_ps1);
         }
-        if (!p.hydrostatic && k0 < km) RemapFastCore::at(A1, col, k0) = v_w[it];
+        if (!HYDRO && k0 < km) RemapFastCore::at(A1, col, k0) = v_w[it];
       }
     }
     FV3_SYNC();
@@ -533,7 +558,7 @@ struct RemapFastScalars {
       core.pad_field(A1, col, km);
     }
     FV3_SYNC();
-    if (!p.hydrostatic) {
+    if (!HYDRO) {
       // ---- w (:400-411): iv = -2, the bottom value ws ----
       core.remap_field(C1, C2, A1, Q, QS, false, -2, p.kord_wz, 0., false, tid);
       {
@@ -556,8 +581,8 @@ struct RemapFastScalars {
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 < km) {
-          dznew[it] = -RemapFastCore::at(Q, col, k0) * (RemapFastCore::at(C2, col, k0 + 1) - RemapFastCore::at(C2, col, k0));
-          if (col < ncol) delz[(size_t)k0 * nCC + occ0 + col] = dznew[it];
+          const double dzn = -RemapFastCore::at(Q, col, k0) * (RemapFastCore::at(C2, col, k0 + 1) - RemapFastCore::at(C2, col, k0));
+          if (col < ncol) delz[(size_t)k0 * nCC + occ0 + col] = dzn;
         }
       }
     }
@@ -582,54 +607,76 @@ struct RemapFastScalars {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 < km) {
           const double v = RemapFastCore::at(Q, col, k0);
-          if (iq == p.sphum - 1) qv[it] = v;
           if (col < ncol) qq[(size_t)k0 * nA + o0 + col] = v;
         }
       }
     }
     FV3_SYNC();
     // ---- the new interfaces: pn2 -> A1, pk2 -> Q (:340-345); then delp, pk, peln, pkz and pt of every layer (:426-503, :793-841) ----
-    for (int it = 0; it < kIt; it++) {
-      const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
-      if (k0 <= km) {
-        const double pn = pn2[it];
-        double pkv;
-        if (k0 == 0 || k0 == km) {
-          pkv = pk[(size_t)k0 * nCC + occ0 + cc];
-        } else {
-          pkv = dexp(akap * pn);
-          if (col < ncol) {
-            peln[lnb0 + (size_t)k0 * g.nx + col] = pn;
-            pk[(size_t)k0 * nCC + occ0 + col] = pkv;
+    {
+      double v_pl[kIt], v_pk[kIt];
+      FV3_LOAD_LOOP(it) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
+        const int ki = k0 <= km ? k0 : km, ke = (k0 == 0) ? 0 : km;
+        v_pl[it] = peln[lnb0 + (size_t)ke * g.nx + cc];
+        v_pk[it] = pk[(size_t)ke * nCC + occ0 + cc];
+        (void)ki;
+      }
+      for (int it = 0; it < kIt; it++) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+        if (k0 <= km) {
+          double pn, pkv;
+          if (k0 == 0 || k0 == km) {
+            pn = v_pl[it];
+            pkv = v_pk[it];
+          } else {
+            pn = dlog(ak[k0] + bk[k0] * pe[peb0 + (size_t)km * (g.nx + 2) + clampc(col)]);
+            pkv = dexp(akap * pn);
+            if (col < ncol) {
+              peln[lnb0 + (size_t)k0 * g.nx + col] = pn;
+              pk[(size_t)k0 * nCC + occ0 + col] = pkv;
+            }
           }
+          RemapFastCore::at(A1, col, k0) = pn;
+          RemapFastCore::at(Q, col, k0) = pkv;
         }
-        RemapFastCore::at(A1, col, k0) = pn;
-        RemapFastCore::at(Q, col, k0) = pkv;
       }
     }
     FV3_SYNC();
-    for (int it = 0; it < kIt; it++) {
-      const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-      if (k0 >= km || col >= ncol) continue;
-      const RColC t2 = RemapFastCore::colc(C2, col), pn = RemapFastCore::colc(A1, col), pk2 = RemapFastCore::colc(Q, col);   // [k], 1-based: row k0 is [k0 + 1]
-      const size_t o3 = (size_t)k0 * nA + o0 + col, c3 = (size_t)k0 * nCC + occ0 + col;
-      const double dp2 = t2[k0 + 2] - t2[k0 + 1];
-      delp[o3] = dp2;
-      const double tv = tnew[it];
-      double pkzv;
-      if (p.hydrostatic)
-        pkzv = (pk2[k0 + 2] - pk2[k0 + 1]) / (akap * (pn[k0 + 2] - pn[k0 + 1]));
-      else
-        pkzv = dexp(akap * dlog(rrg * dp2 / dznew[it] * tv));
-      pkz[c3] = pkzv;
-      double tn = tv;
-      if (p.last_step == 2) {              // the energy fixer follows: T_v stays, fv3_remap_finish converts (:793-821)
-      } else if (p.last_step) {            // :793-821 (dtmp = 0)
-        if (!p.adiabatic) tn = (tn + 0. / (p.hydrostatic ? p.cp : p.cv_air) * pkzv) / (1. + p.r_vir * (p.sphum > 0 ? qv[it] : 0.));
-      } else {
-        tn = tn / pkzv;                    // :833-841
+    {
+      const bool need_qv = p.last_step && p.last_step != 2 && !p.adiabatic && p.sphum > 0;
+      const double *qs_ = need_qv ? q + (size_t)(p.sphum - 1) * nA * km : pt;
+      double v_t[kIt], v_dz[kIt], v_q[kIt];
+      FV3_LOAD_LOOP(it) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
+        const int kc = k0 < km ? k0 : km - 1;
+        v_t[it] = pt[(size_t)kc * nA + o0 + cc];
+        v_dz[it] = HYDRO ? 1. : delz[(size_t)kc * nCC + occ0 + cc];
+        v_q[it] = qs_[(size_t)kc * nA + o0 + cc];
       }
-      pt[o3] = tn;
+      for (int it = 0; it < kIt; it++) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+        if (k0 >= km || col >= ncol) continue;
+        const RColC t2 = RemapFastCore::colc(C2, col), pn = RemapFastCore::colc(A1, col), pk2 = RemapFastCore::colc(Q, col);   // [k], 1-based: row k0 is [k0 + 1]
+        const size_t o3 = (size_t)k0 * nA + o0 + col, c3 = (size_t)k0 * nCC + occ0 + col;
+        const double dp2 = t2[k0 + 2] - t2[k0 + 1];
+        delp[o3] = dp2;
+        const double tv = v_t[it];
+        double pkzv;
+        if (HYDRO)
+          pkzv = (pk2[k0 + 2] - pk2[k0 + 1]) / (akap * (pn[k0 + 2] - pn[k0 + 1]));
+        else
+          pkzv = dexp(akap * dlog(rrg * dp2 / v_dz[it] * tv));
+        pkz[c3] = pkzv;
+        double tn = tv;
+        if (p.last_step == 2) {              // the energy fixer follows: T_v stays, fv3_remap_finish converts (:793-821)
+        } else if (p.last_step) {            // :793-821 (dtmp = 0)
+          if (!p.adiabatic) tn = (tn + 0. / (HYDRO ? p.cp : p.cv_air) * pkzv) / (1. + p.r_vir * (need_qv ? v_q[it] : 0.));
+        } else {
+          tn = tn / pkzv;                    // :833-841
+        }
+        pt[o3] = tn;
+      }
     }
   }
 };
