@@ -66,7 +66,10 @@ def parse():
     ap.add_argument("--periodic6", action="store_true", help="--gpus 6 as a 3x2 doubly periodic layout instead of the six cubed-sphere faces")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--parity-columns", action="store_true",
-                    help="whole-step legs with the parity (bit-comparable) column solvers instead of the fast mode (csrc/nh_fast.h, 1e-12)")
+                    help="(the default since round 4) whole-step legs with the parity (bit-comparable) column solvers")
+    ap.add_argument("--fast-columns", action="store_true",
+                    help="whole-step legs (SYPD) with the tolerance-mode column solvers (csrc/nh_fast.h: not bit-identical, w of a whole "
+                         "step is outside 1e-12) instead of the parity kernels; without it they are run once for the record")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--hord", type=int, default=10, help="hord_mt = hord_vt = hord_tm = hord_dp (reference default 10)")
     ap.add_argument("--no-model-step", action="store_true", help="skip the SYPD (whole model step) leg")
@@ -77,7 +80,9 @@ def parse():
     ap.add_argument("--general-metrics", action="store_true",
                     help="FV3_MI355X_GEOM=0: read every metric row (what a cubed-sphere gridstruct needs) instead of "
                          "using the uniform-Cartesian kernels the library selects for this doubly periodic gridstruct")
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.parity_columns = not a.fast_columns
+    return a
 
 
 def native_oracle():
@@ -200,7 +205,7 @@ def whole_step_roofline(cells, wall_s, n_substeps, k_split, nq, hydrostatic=Fals
             "formula": f"{n_substeps} x ({pair:.0f} + {rest:.0f}) + {k_split} x (144 + 16 nq) + tracer_2d, nq = {nq}"}
 
 
-def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=True):
+def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=True, keep_fields=False):
     """SYPD leg: whole nonhydrostatic model steps (fv_dynamics.F90:460-665 k_split loop: n_split acoustic substeps,
     tracer_2d, Lagrangian_to_Eulerian) on the same tile, dt_atmos=225 s, k_split=2, n_split=5 (C384 settings)."""
     from gfdl_atmos_cubed_sphere_amd import lib as L
@@ -229,6 +234,7 @@ def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=True
         torch.cuda.synchronize()
     fv.step(dt_atmos)
     fence()
+    first = {n: fv.dc.d[n].download() for n in ("u", "v", "w", "delp", "pt", "delz")} if keep_fields else None
     nrep = 3
     t0 = time.perf_counter()
     for _ in range(nrep):
@@ -277,8 +283,10 @@ def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=True
         except (OSError, ValueError):
             pass
         col["remap"] = e
-    return {"column_solvers": "fast mode (csrc/nh_fast.h, remap_fast.h; within 1e-12 of the parity kernels)" if fast else "parity kernels (bit-comparable with the oracle)",
-            "column_kernels": col, "geometry": {0: "general metric rows", 1: "orthogonal", 2: "orthogonal + uniform"}.get(geom_mode),
+    return {"column_solvers": "tolerance mode of the Riemann solvers and edge_profile (csrc/nh_fast.h: blocked parallel scans, NOT bit-identical; "
+                              "per call within 1e-12 of the parity kernels, whole steps: see fast_vs_parity)" if fast
+            else "parity kernels (bit-comparable with the oracle; the remap with the column in LDS is bit-identical to the slab kernels)",
+            "_first_step_fields": first, "column_kernels": col, "geometry": {0: "general metric rows", 1: "orthogonal", 2: "orthogonal + uniform"}.get(geom_mode),
             "whole_step": whole_step_roofline(cells, wall, k_split * n_split, k_split, nq),
             "kernels_sum_ms": round(sum(v[1] for v in rep.values()), 2),
             "sypd": dt_atmos / (365.0 * wall), "wall_s_per_dt_atmos": wall, "dt_atmos_s": dt_atmos, "k_split": k_split,
@@ -416,12 +424,20 @@ def sphere_steps(torch, stream, cs, gs, nx, npz, hydrostatic, k_split, n_split, 
             graph_note = "one HIP graph per dt_atmos (hipStreamBeginCapture over the six face streams)"
         except Exception as e:  # noqa: BLE001
             graph, graph_note = None, f"eager launches (graph capture refused: {type(e).__name__}: {e})"
-    step = graph.replay if graph else (lambda: fv.step(dt_atmos))
-    t0 = time.perf_counter()
-    for _ in range(nrep):
+    walls = {}
+    for how, step in (("eager", lambda: fv.step(dt_atmos)),) + ((("graph", graph.replay),) if graph else ()):
         step()
-    torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / nrep
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nrep):
+            step()
+        torch.cuda.synchronize()
+        walls[how] = (time.perf_counter() - t0) / nrep
+    # with the faces as one launch group there are six times fewer, six times larger launches: the host keeps up, and a graph replay
+    # (one stream now, nothing to overlap) is the slower of the two at C96; the faster one is the step's wall time, both are reported
+    best = min(walls, key=walls.get)
+    wall = walls[best]
+    graph_note = ("eager launches" if best == "eager" else graph_note) + "; wall s per dt_atmos " + ", ".join(f"{k_}: {v_:.4f}" for k_, v_ in walls.items())
     dp = fv.dc.d["delp"].download()
     # per-kernel breakdown: ALL six faces on ONE stream, eager (on six streams the HIP-event durations of overlapping kernels add
     # up to several times the wall time and say nothing -- VERDICT r2).  Its own wall time is reported next to the sum.
@@ -434,10 +450,13 @@ def sphere_steps(torch, stream, cs, gs, nx, npz, hydrostatic, k_split, n_split, 
     fv.step(dt_atmos)
     torch.cuda.synchronize()
     wall_one = time.perf_counter() - t0
+    if mctx.group:
+        mctx.group.stats()
     mctx.profile(True)
     fv.step(dt_atmos)
     reps = mctx.profile_report()
     mctx.profile(False)
+    grp_stats = mctx.group.stats() if mctx.group else None
     kern = {}
     for rep in reps:
         for k_, v in rep.items():
@@ -448,7 +467,9 @@ def sphere_steps(torch, stream, cs, gs, nx, npz, hydrostatic, k_split, n_split, 
                "kernel_breakdown": {"how": "six faces on one stream, eager launches, HIP events per launch", "wall_s": round(wall_one, 4),
                                     "kernels_sum_s": round(sum(kern_v for kern_v in _sum_reps(reps)), 4)},
                "k_split": k_split, "n_split": fl.n_split, "nq": 0, "cells": 6 * cells, "launch": graph_note,
-               "column_solvers": "fast mode (nh_fast.h)" if (fast and not hydrostatic) else "parity kernels",
+               "column_solvers": "tolerance mode (nh_fast.h)" if (fast and not hydrostatic) else "parity kernels",
+               "face_group": ("one launch per kernel for the six faces (fv3_group); launches of the profiled step that ran all faces "
+                              f"at once / alone: {grp_stats[0]} / {grp_stats[1]}") if grp_stats else "off: six launches per kernel",
                "finite": bool(all(np.isfinite(x[c]).all() for x in dp)),
                "initial_condition": "test_case 13 (Jablonowski-Williamson), " + ("hydrostatic" if hydrostatic else "nonhydrostatic"),
                "note": "all six faces on ONE MI355X (six contexts, a HIP stream per face, device-gather halo updates); one face per "
@@ -822,10 +843,25 @@ def main():
     # N > 1: the SYPD leg is off unless asked for (a failure on one rank would leave the others in a collective)
     if not a.no_model_step and (world == 1 or a.model_step_multi):
         try:
-            out["model_step"] = model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=not a.parity_columns)
-            if world == 1 and not a.parity_columns:      # the same step with the parity column solvers, for the record
-                par = model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=False)
-                out["model_step"]["parity_columns"] = {k: par[k] for k in ("sypd", "wall_s_per_dt_atmos", "column_kernels")}
+            # the SYPD is quoted with the PARITY column kernels (north_star's 1e-12 on whole steps holds for them by construction:
+            # bit-comparable with the oracle); the tolerance mode is run next to it for the record, with the distance of its fields
+            # from the parity run's after one dt_atmos from the same state
+            both = world == 1 and a.parity_columns
+            out["model_step"] = model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=not a.parity_columns, keep_fields=both)
+            ref = out["model_step"].pop("_first_step_fields")
+            if both:
+                tol = model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=True, keep_fields=True)
+                got = tol.pop("_first_step_fields")
+                dev = {}
+                for n in ref:
+                    num, den = float(np.sqrt(np.mean((got[n] - ref[n]) ** 2))), float(np.sqrt(np.mean(ref[n] ** 2)))
+                    dev[n] = num / den if den > 0 else num
+                del ref, got
+                out["model_step"]["tolerance_mode"] = {
+                    "sypd": tol["sypd"], "wall_s_per_dt_atmos": tol["wall_s_per_dt_atmos"], "column_solvers": tol["column_solvers"],
+                    "column_kernels": tol["column_kernels"], "fast_vs_parity": dev,
+                    "fast_vs_parity_note": "relative RMS difference of the prognostic fields after ONE dt_atmos (k_split 2 x n_split 5 "
+                                           "substeps + 2 remaps) from the same state, tolerance mode against parity kernels"}
         except Exception as e:  # noqa: BLE001
             out["model_step"] = {"error": f"{type(e).__name__}: {e}"}
     out["cubed_sphere"] = None

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <deque>
 #include <new>
 #include <type_traits>
 
@@ -141,6 +142,8 @@ struct fv3_ctx {
   bool prof_on;
   struct ProfRec { const char *label; void *e0, *e1; };
   std::vector<ProfRec> prof;
+  struct fv3_group *grp = nullptr;   // the faces one rank holds, launched together (fv3_group_create)
+  int grp_idx = 0;
 };
 
 static thread_local std::string g_err;
@@ -175,9 +178,141 @@ static int prof_events(void **e0, void **e1) {
   return 0;
 }
 
+// ---- face groups: one launch per kernel for all faces a rank holds (include/fv3_mi355x.h fv3_group_create) -------------------------
+// The host code issues every call once per face (tools/fv_mp_mod.F90's tiles of one PE; here six contexts on one MI355X).  A context
+// that belongs to a group does not launch: it queues the launch -- functor by value, grid, label -- and when every member's queue
+// holds the same kernel with the same grid at its head, ONE kernel runs them all (fv3_launch.h launch_group: the face is the slowest
+// grid index).  Stream operations of a member (memset, device copies) queue as well and run in that member's order.  Whatever reads
+// results or orders the stream against something else -- a download, a synchronisation, an event, a halo exchange -- flushes the queues
+// first (what is left runs face by face).  All members launch on the first member's stream.
+struct GrpEntry {
+  const void *tag = nullptr;   // launch kind + functor type; nullptr: a stream operation, never merged
+  int a = 0;                   // lanes (column kernels) / wavefronts (wave kernels)
+  Dim3 grid{0, 0, 0};
+  size_t lds = 0;
+  const char *label = "";
+  std::vector<double> fbuf;    // the functor's bytes
+  int (*go)(struct fv3_group *, GrpEntry *const *, int) = nullptr;
+  int op = 0;                  // 1 memset, 2 device copy
+  void *dst = nullptr;
+  const void *src = nullptr;
+  size_t bytes = 0;
+  int value = 0;
+};
+struct fv3_group {
+  int n = 0;
+  fv3_ctx *m[kGrpMax];
+  std::deque<GrpEntry> q[kGrpMax];
+  long n_merged = 0, n_single = 0;
+};
+static std::vector<fv3_group *> g_groups;
+
+template <class F, int KIND, int W>
+static const void *grp_tag() {
+  static const char t = 0;
+  return &t;
+}
+template <class F, int KIND, int W>
+static int grp_go(fv3_group *g, GrpEntry *const *e, int n) {
+  const F *fs[kGrpMax];
+  for (int m = 0; m < n; m++) fs[m] = reinterpret_cast<const F *>(e[m]->fbuf.data());
+  const stream_t s = g->m[0]->stream;
+  if constexpr (KIND == 2)
+    return launch_group_cols<W>(e[0]->grid, e[0]->a, s, fs, n);
+  else
+    return launch_group<KIND>(e[0]->grid, e[0]->lds, e[0]->a, s, fs, n);
+}
+static int grp_run(fv3_group *g, fv3_ctx *owner, GrpEntry *const *e, int n) {   // n entries of one kernel (or one stream operation)
+  const stream_t s = g->m[0]->stream;
+  if (!e[0]->tag) {
+    if (e[0]->op == 1) return rt_memset(e[0]->dst, e[0]->value, e[0]->bytes, s);
+    return rt_d2d(e[0]->dst, e[0]->src, e[0]->bytes, s);
+  }
+  void *e0 = nullptr, *e1 = nullptr;
+  if (owner->prof_on) {
+    if (prof_events(&e0, &e1)) return 1;
+    rt_event_record(e0, s);
+  }
+  const int rc = e[0]->go(g, e, n);
+  if (owner->prof_on) {
+    rt_event_record(e1, s);
+    owner->prof.push_back({e[0]->label, e0, e1});
+  }
+  if (n > 1) g->n_merged++; else g->n_single++;
+  return rc;
+}
+// force: run what is queued even where the members are not at the same kernel (face by face, each member in its own order)
+static int grp_pump(fv3_group *g, bool force) {
+  for (;;) {
+    int nonempty = 0;
+    for (int m = 0; m < g->n; m++) nonempty += !g->q[m].empty();
+    if (!nonempty) return 0;
+    if (nonempty == g->n) {
+      GrpEntry *h[kGrpMax];
+      bool same = true;
+      for (int m = 0; m < g->n; m++) {
+        h[m] = &g->q[m].front();
+        same = same && h[m]->tag && h[m]->tag == h[0]->tag && h[m]->a == h[0]->a && h[m]->lds == h[0]->lds &&
+               h[m]->grid.x == h[0]->grid.x && h[m]->grid.y == h[0]->grid.y && h[m]->grid.z == h[0]->grid.z;
+      }
+      if (same) {
+        const int rc = grp_run(g, g->m[0], h, g->n);
+        for (int m = 0; m < g->n; m++) g->q[m].pop_front();
+        if (rc) return rc;
+        continue;
+      }
+    } else if (!force) {
+      return 0;
+    }
+    for (int m = 0; m < g->n; m++) {   // heads that do not match (or a forced flush): one step of every member that has work
+      if (g->q[m].empty()) continue;
+      GrpEntry *h = &g->q[m].front();
+      const int rc = grp_run(g, g->m[m], &h, 1);
+      g->q[m].pop_front();
+      if (rc) return rc;
+    }
+  }
+}
+static int grp_flush_all() {
+  for (fv3_group *g : g_groups)
+    if (int rc = grp_pump(g, true)) return rc;
+  return 0;
+}
+template <class F, int KIND, int W = 0>
+static int grp_defer(fv3_ctx *c, const char *label, Dim3 grid, size_t lds, int a, const F &f) {
+  static_assert(std::is_trivially_copyable<F>::value, "kernel functors are plain data");
+  fv3_group *g = c->grp;
+  g->q[c->grp_idx].emplace_back();
+  GrpEntry &e = g->q[c->grp_idx].back();
+  e.tag = grp_tag<F, KIND, W>();
+  e.a = a; e.grid = grid; e.lds = lds; e.label = label;
+  e.fbuf.resize((sizeof(F) + 7) / 8);
+  std::memcpy(e.fbuf.data(), (const void *)&f, sizeof(F));
+  e.go = &grp_go<F, KIND, W>;
+  return grp_pump(g, false);
+}
+static int grp_stream_op(fv3_ctx *c, int op, void *dst, const void *src, size_t bytes, int value) {
+  if (c && c->grp) {
+    fv3_group *g = c->grp;
+    g->q[c->grp_idx].emplace_back();
+    GrpEntry &e = g->q[c->grp_idx].back();
+    e.op = op; e.dst = dst; e.src = src; e.bytes = bytes; e.value = value;
+    return grp_pump(g, false);
+  }
+  const stream_t s = c ? c->stream : nullptr;
+  return op == 1 ? rt_memset(dst, value, bytes, s) : rt_d2d(dst, src, bytes, s);
+}
+// stream calls that order the stream against the host or another stream: the queues of every group go first
+static int rtf_h2d(void *d, const void *s, size_t n, stream_t st) { if (int rc = grp_flush_all()) return rc; return rt_h2d(d, s, n, st); }
+static int rtf_d2h(void *d, const void *s, size_t n, stream_t st) { if (int rc = grp_flush_all()) return rc; return rt_d2h(d, s, n, st); }
+static int rtf_sync(stream_t st) { if (int rc = grp_flush_all()) return rc; return rt_sync(st); }
+static void rtf_event_record(void *e, stream_t st) { (void)grp_flush_all(); rt_event_record(e, st); }
+static void rtf_stream_wait_event(stream_t st, void *e) { (void)grp_flush_all(); rt_stream_wait_event(st, e); }
+
 // launch + optional event pair around it
 template <class F>
 static int launch_p(fv3_ctx *c, const char *label, Dim3 grid, size_t lds_doubles, const F &f) {
+  if (c->grp) return grp_defer<F, 0>(c, label, grid, lds_doubles, 0, f);
   void *e0 = nullptr, *e1 = nullptr;
   if (c->prof_on) {
     if (prof_events(&e0, &e1)) return 1;
@@ -193,6 +328,7 @@ static int launch_p(fv3_ctx *c, const char *label, Dim3 grid, size_t lds_doubles
 
 template <class F>
 static int launch_p2(fv3_ctx *c, const char *label, Dim3 grid, size_t lds_doubles, const F &f) {
+  if (c->grp) return grp_defer<F, 1>(c, label, grid, lds_doubles, 0, f);
   void *e0 = nullptr, *e1 = nullptr;
   if (c->prof_on) {
     if (prof_events(&e0, &e1)) return 1;
@@ -208,6 +344,7 @@ static int launch_p2(fv3_ctx *c, const char *label, Dim3 grid, size_t lds_double
 
 template <int W = 0, class F>
 static int launch_c(fv3_ctx *c, const char *label, Dim3 grid, const F &f, int lanes = 0) {
+  if (c->grp) return grp_defer<F, 2, W>(c, label, grid, 0, lanes, f);
   void *e0 = nullptr, *e1 = nullptr;
   if (c->prof_on) {
     if (prof_events(&e0, &e1)) return 1;
@@ -223,6 +360,7 @@ static int launch_c(fv3_ctx *c, const char *label, Dim3 grid, const F &f, int la
 
 template <class F>
 static int launch_w(fv3_ctx *c, const char *label, int nwaves, const F &f) {
+  if (c->grp) return grp_defer<F, 3>(c, label, Dim3{0, 0, 0}, 0, nwaves, f);
   void *e0 = nullptr, *e1 = nullptr;
   if (c->prof_on) {
     if (prof_events(&e0, &e1)) return 1;
@@ -261,7 +399,7 @@ static const char *reference_timer(const char *label) {
 
 static int profile_report_impl(fv3_ctx *c, char *out, size_t cap, bool timers) {
   if (!c || !out || cap == 0) return fail("fv3_profile_report: bad argument");
-  RT(rt_sync(c->stream));
+  RT(rtf_sync(c->stream));
   struct Acc { const char *label; int n; double ms; };
   std::vector<Acc> acc;
   for (auto &r : c->prof) {
@@ -402,6 +540,16 @@ extern "C" int fv3_comm_destroy(fv3_ctx *c);
 static void cube_plans_free(fv3_ctx *c);
 extern "C" int fv3_destroy(fv3_ctx *c) {
   if (!c) return 0;
+  if (c->grp) {   // a member that goes away: its group runs what is queued and forgets it (the group then launches face by face)
+    fv3_group *g = c->grp;
+    (void)grp_pump(g, true);
+    for (int m = 0; m < g->n; m++)
+      if (g->m[m] == c) g->m[m] = nullptr;
+    for (int m = 0; m < g->n; m++)
+      if (g->m[m]) g->m[m]->grp = nullptr;      // no longer a whole group: its remaining members launch on their own
+    g->n = 0;
+    c->grp = nullptr;
+  }
   cube_plans_free(c);
   fv3_comm_destroy(c);
   if (c->dev_metrics) rt_free(c->dev_metrics);
@@ -435,8 +583,56 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
 
 extern "C" int fv3_set_stream(fv3_ctx *c, void *stream) {
   if (!c) return fail("fv3_set_stream: null ctx");
+  if (c->grp) {   // the faces of a group launch together: one stream for all of them
+    RT(grp_pump(c->grp, true));
+    for (int m = 0; m < c->grp->n; m++) c->grp->m[m]->stream = (stream_t)stream;
+  }
   c->stream = (stream_t)stream;
   return 0;
+}
+
+// ---- fv3_group_*: the faces one rank holds, launched together --------------------------------------------------------------------
+extern "C" int fv3_group_create(fv3_ctx *const *members, int n, fv3_group **out) {
+  if (!members || !out || n < 1 || n > kGrpMax) return fail("fv3_group_create: 1 .. %d members", kGrpMax);
+  for (int m = 0; m < n; m++) {
+    if (!members[m]) return fail("fv3_group_create: null member");
+    if (members[m]->grp) return fail("fv3_group_create: member %d belongs to a group already", m);
+    for (int o = 0; o < m; o++)
+      if (members[o] == members[m]) return fail("fv3_group_create: member %d twice", m);
+  }
+  fv3_group *g = new (std::nothrow) fv3_group();
+  if (!g) return fail("fv3_group_create: out of host memory");
+  g->n = n;
+  for (int m = 0; m < n; m++) {
+    g->m[m] = members[m];
+    members[m]->grp = g;
+    members[m]->grp_idx = m;
+    members[m]->stream = members[0]->stream;
+  }
+  g_groups.push_back(g);
+  *out = g;
+  return 0;
+}
+extern "C" int fv3_group_flush(fv3_group *g) {
+  if (!g) return fail("fv3_group_flush: null group");
+  RT(grp_pump(g, true));
+  return 0;
+}
+// launches since the last call: kernels that ran all members at once, kernels (and members' steps) that ran alone
+extern "C" int fv3_group_stats(fv3_group *g, long *merged, long *single) {
+  if (!g || !merged || !single) return fail("fv3_group_stats: null argument");
+  *merged = g->n_merged; *single = g->n_single;
+  g->n_merged = g->n_single = 0;
+  return 0;
+}
+extern "C" int fv3_group_destroy(fv3_group *g) {
+  if (!g) return 0;
+  const int rc = grp_pump(g, true);
+  for (int m = 0; m < g->n; m++)
+    if (g->m[m]) g->m[m]->grp = nullptr;
+  g_groups.erase(std::remove(g_groups.begin(), g_groups.end(), g), g_groups.end());
+  delete g;
+  return rc ? fail("fv3_group_destroy: a queued launch failed") : 0;
 }
 
 extern "C" int fv3_malloc(void **dptr, size_t bytes) {
@@ -444,27 +640,28 @@ extern "C" int fv3_malloc(void **dptr, size_t bytes) {
   return 0;
 }
 extern "C" int fv3_free(void *dptr) {
+  RT(grp_flush_all());   // a queued launch of a face group may still use the buffer
   RT(rt_free(dptr));
   return 0;
 }
 extern "C" int fv3_memcpy_h2d(fv3_ctx *c, void *dst, const void *src, size_t bytes) {
-  RT(rt_h2d(dst, src, bytes, c ? c->stream : nullptr));
+  RT(rtf_h2d(dst, src, bytes, c ? c->stream : nullptr));
   return 0;
 }
 extern "C" int fv3_memcpy_d2h(fv3_ctx *c, void *dst, const void *src, size_t bytes) {
-  RT(rt_d2h(dst, src, bytes, c ? c->stream : nullptr));
+  RT(rtf_d2h(dst, src, bytes, c ? c->stream : nullptr));
   return 0;
 }
 extern "C" int fv3_memcpy_d2d(fv3_ctx *c, void *dst, const void *src, size_t bytes) {
-  RT(rt_d2d(dst, src, bytes, c ? c->stream : nullptr));
+  RT(grp_stream_op(c, 2, dst, src, bytes, 0));
   return 0;
 }
 extern "C" int fv3_memset(fv3_ctx *c, void *dst, int value, size_t bytes) {
-  RT(rt_memset(dst, value, bytes, c ? c->stream : nullptr));
+  RT(grp_stream_op(c, 1, dst, nullptr, bytes, value));
   return 0;
 }
 extern "C" int fv3_sync(fv3_ctx *c) {
-  RT(rt_sync(c ? c->stream : nullptr));
+  RT(rtf_sync(c ? c->stream : nullptr));
   return 0;
 }
 
@@ -494,7 +691,7 @@ extern "C" int fv3_grid_upload(fv3_ctx *c, const fv3_grid_host *h) {
   if (!c->dev_metrics) RT(rt_malloc((void **)&c->dev_metrics, total * sizeof(double)));
   size_t off = 0;
   for (const Item &it : items) {
-    RT(rt_h2d(c->dev_metrics + off, it.src, it.n * sizeof(double), c->stream));
+    RT(rtf_h2d(c->dev_metrics + off, it.src, it.n * sizeof(double), c->stream));
     *it.dst = c->dev_metrics + off;
     off += (it.n + 7) & ~(size_t)7;
   }
@@ -525,7 +722,7 @@ extern "C" int fv3_grid_upload(fv3_ctx *c, const fv3_grid_host *h) {
     g.geom = uniform ? 2 : (ortho ? 1 : 0);
     if (const char *e = std::getenv("FV3_MI355X_GEOM")) g.geom = std::min(g.geom, std::max(0, std::atoi(e)));
   }
-  RT(rt_sync(c->stream));  // host buffers may go away after the call returns
+  RT(rtf_sync(c->stream));  // host buffers may go away after the call returns
   c->grid_ready = true;
   return 0;
 }
@@ -544,9 +741,9 @@ extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
       // divergence damping supports nord <= 3 (halo 3), deln/del6 damping nord <= 2 (sw_core.F90:1610)
       if (iv[n][k] < 0 || iv[n][k] > (n == 0 ? 3 : 2)) return fail("fv3_dsw_levels_upload: nord out of range at k=%d", k);
     }
-    RT(rt_h2d(c->lev_i + n * npz, iv[n], sizeof(int) * npz, c->stream));
+    RT(rtf_h2d(c->lev_i + n * npz, iv[n], sizeof(int) * npz, c->stream));
   }
-  for (int n = 0; n < 5; n++) RT(rt_h2d(c->lev_d + n * npz, dv[n], sizeof(double) * npz, c->stream));
+  for (int n = 0; n < 5; n++) RT(rtf_h2d(c->lev_d + n * npz, dv[n], sizeof(double) * npz, c->stream));
   {  // ndif(km+1), damp(km+1) of update_dz_d: entry km+1 repeats entry km (nh_utils.F90:240-241)
     std::vector<int> ni(npz + 1);
     std::vector<double> nd(npz + 1);
@@ -561,12 +758,12 @@ extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
     c->n_damp_z = (int)dz.size();
     pz.insert(pz.end(), dz.begin(), dz.end());
     if (!c->klist_z) RT(rt_malloc((void **)&c->klist_z, sizeof(int) * (npz + 1)));
-    RT(rt_h2d(c->klist_z, pz.data(), sizeof(int) * (npz + 1), c->stream));
-    RT(rt_h2d(c->lev_ext_i, ni.data(), sizeof(int) * (npz + 1), c->stream));
-    RT(rt_h2d(c->lev_ext_d, nd.data(), sizeof(double) * (npz + 1), c->stream));
-    RT(rt_sync(c->stream));
+    RT(rtf_h2d(c->klist_z, pz.data(), sizeof(int) * (npz + 1), c->stream));
+    RT(rtf_h2d(c->lev_ext_i, ni.data(), sizeof(int) * (npz + 1), c->stream));
+    RT(rtf_h2d(c->lev_ext_d, nd.data(), sizeof(double) * (npz + 1), c->stream));
+    RT(rtf_sync(c->stream));
   }
-  RT(rt_sync(c->stream));
+  RT(rtf_sync(c->stream));
   {
     std::vector<int> plain, damped;
     for (int k = 0; k < npz; k++)
@@ -575,7 +772,7 @@ extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
     c->n_damp = (int)damped.size();
     plain.insert(plain.end(), damped.begin(), damped.end());
     if (!c->klist) RT(rt_malloc((void **)&c->klist, sizeof(int) * npz));
-    RT(rt_h2d(c->klist, plain.data(), sizeof(int) * npz, c->stream));
+    RT(rtf_h2d(c->klist, plain.data(), sizeof(int) * npz, c->stream));
     std::vector<int> pm, rm;
     for (int k = 0; k < npz; k++)
       ((lv->nord_k[k] == 1 && !(lv->damp_vt[k] > 1.E-5) && !(lv->d_con_k[k] > 1.E-5)) ? pm : rm).push_back(k);
@@ -584,8 +781,8 @@ extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
     pm.insert(pm.end(), rm.begin(), rm.end());
     c->side_ok = (rm == damped);
     if (!c->klist_m) RT(rt_malloc((void **)&c->klist_m, sizeof(int) * npz));
-    RT(rt_h2d(c->klist_m, pm.data(), sizeof(int) * npz, c->stream));
-    RT(rt_sync(c->stream));
+    RT(rtf_h2d(c->klist_m, pm.data(), sizeof(int) * npz, c->stream));
+    RT(rtf_sync(c->stream));
   }
   c->lev_max_nord = c->lev_max_nord_v = c->lev_max_nord_w = c->lev_max_nord_t = 0;
   c->lev_has_dcon = c->lev_has_vt_damp = c->lev_has_w_damp = c->lev_has_w_damp_hi = false;
@@ -748,11 +945,11 @@ extern "C" int fv3_grid_upload_cubed(fv3_ctx *c, const fv3_grid_cubed *h) {
   const double *src[4] = {h->edge_w, h->edge_e, h->edge_s, h->edge_n};
   const double **dst[4] = {&c->cg.edge_w, &c->cg.edge_e, &c->cg.edge_s, &c->cg.edge_n};
   for (int n = 0; n < 4; n++) {
-    RT(rt_h2d(p, src[n], ne * sizeof(double), c->stream));
+    RT(rtf_h2d(p, src[n], ne * sizeof(double), c->stream));
     *dst[n] = p - 1;  // 1-based
     p += (ne + 7) & ~(size_t)7;
   }
-  RT(rt_h2d(p, h->rsina, nr * sizeof(double), c->stream));
+  RT(rtf_h2d(p, h->rsina, nr * sizeof(double), c->stream));
   c->cg.rsina = p;
   p += nr8;
   c->cg.a11 = c->cg.a12 = c->cg.a21 = c->cg.a22 = nullptr;
@@ -760,7 +957,7 @@ extern "C" int fv3_grid_upload_cubed(fv3_ctx *c, const fv3_grid_cubed *h) {
     const double *am[4] = {h->a11, h->a12, h->a21, h->a22};
     const double **ad[4] = {&c->cg.a11, &c->cg.a12, &c->cg.a21, &c->cg.a22};
     for (int n = 0; n < 4; n++) {
-      RT(rt_h2d(p, am[n], g.nA() * sizeof(double), c->stream));
+      RT(rtf_h2d(p, am[n], g.nA() * sizeof(double), c->stream));
       *ad[n] = p;
       p += g.nA();
     }
@@ -771,13 +968,13 @@ extern "C" int fv3_grid_upload_cubed(fv3_ctx *c, const fv3_grid_cubed *h) {
     const double **ad[4] = {&c->cg.ec1, &c->cg.ec2, &c->cg.en1, &c->cg.en2};
     const size_t sz[4] = {3 * g.nA(), 3 * g.nA(), 3 * g.nFY(), 3 * g.nFX()};
     for (int n = 0; n < 4; n++) {
-      RT(rt_h2d(p, am[n], sz[n] * sizeof(double), c->stream));
+      RT(rtf_h2d(p, am[n], sz[n] * sizeof(double), c->stream));
       *ad[n] = p;
       p += sz[n];
     }
   }
   for (int n = 0; n < 12; n++) c->cg.corner_f[n] = h->corner_f[n];
-  RT(rt_sync(c->stream));
+  RT(rtf_sync(c->stream));
   c->cg.ready = 1;
   return 0;
 }
@@ -910,9 +1107,9 @@ extern "C" int fv3_fv_tp_2d(fv3_ctx *c, int nk, const double *q, const double *c
       if (nk > g.npz) return fail("fv3_fv_tp_2d: deln_flux damping on a cubed-sphere context takes at most npz levels");
       std::vector<int> ni(g.npz, nord);
       std::vector<double> cd(g.npz, damp_c);
-      RT(rt_h2d(c->trc_i + g.npz, ni.data(), sizeof(int) * g.npz, c->stream));
-      RT(rt_h2d(c->trc_d + 2 * g.npz, cd.data(), sizeof(double) * g.npz, c->stream));
-      RT(rt_sync(c->stream));
+      RT(rtf_h2d(c->trc_i + g.npz, ni.data(), sizeof(int) * g.npz, c->stream));
+      RT(rtf_h2d(c->trc_d + 2 * g.npz, cd.data(), sizeof(double) * g.npz, c->stream));
+      RT(rtf_sync(c->stream));
       DelnCubedState d;
       d.g = g; d.q = q; d.mass = mfx ? mass : nullptr; d.fx = fx; d.fy = fy; d.nord = c->trc_i + g.npz; d.coef = c->trc_d + 2 * g.npz; d.thresh = 1.E-4;
       d.corner_area = 0;
@@ -1531,7 +1728,7 @@ static int d_sw_impl(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const d
     return 0;
   }
   const int region = (phase == 2 && split) ? 2 : 0;
-  const bool side = fused && march_m && c->side_ok && c->use_side && !c->prof_on && c->n_damp > 0 && c->n_plain > 0;
+  const bool side = fused && march_m && c->side_ok && c->use_side && !c->prof_on && !c->grp && c->n_damp > 0 && c->n_plain > 0;
   if (side) {
     if (!c->stream2) {
       RT(rt_stream_create(&c->stream2));
@@ -1539,18 +1736,18 @@ static int d_sw_impl(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const d
       RT(rt_event_create(&c->ev_join));
     }
     const stream_t main_stream = c->stream;
-    rt_event_record(c->ev_fork, main_stream);
-    rt_stream_wait_event(c->stream2, c->ev_fork);
+    rtf_event_record(c->ev_fork, main_stream);
+    rtf_stream_wait_event(c->stream2, c->ev_fork);
     c->stream = c->stream2;
     int rc = courant();
     if (!rc) rc = tile_transport();
     if (!rc) rc = tile_momentum();
-    rt_event_record(c->ev_join, c->stream2);
+    rtf_event_record(c->ev_join, c->stream2);
     c->stream = main_stream;
     RT(rc);
     RT(dsw_transport_march(c, a, region));
     RT(dsw_momentum_march(c, a));
-    rt_stream_wait_event(main_stream, c->ev_join);
+    rtf_stream_wait_event(main_stream, c->ev_join);
     return 0;
   }
   RT(courant());
@@ -1964,8 +2161,8 @@ extern "C" int fv3_halo_start(fv3_ctx *c, int nfields, const fv3_halo_field *fie
     }
   }
   if (fv3_halo_pack(c, nfields, fields, c->msg_send)) return 1;
-  rt_event_record(c->ev_packed, c->stream);
-  rt_stream_wait_event(c->comm_stream, c->ev_packed);
+  rtf_event_record(c->ev_packed, c->stream);
+  rtf_stream_wait_event(c->comm_stream, c->ev_packed);
 #ifdef FV3_HOST_EMU
   {   // the group: every send, then every receive, each matched per peer in posting order (see the transport above)
     EmuComm *e = static_cast<EmuComm *>(c->comm);
@@ -1984,7 +2181,7 @@ extern "C" int fv3_halo_start(fv3_ctx *c, int nfields, const fv3_halo_field *fie
   const int rc2 = g_rccl.GroupEnd();   // the group is closed on every path
   if (rc || rc2) return fail("RCCL: %s (halo group)", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "error");
 #endif
-  rt_event_record(c->ev_arrived, c->comm_stream);
+  rtf_event_record(c->ev_arrived, c->comm_stream);
   for (int f = 0; f < nfields; f++) c->pend_fields[f] = fields[f];
   c->pend_n = nfields;
   return 0;
@@ -1993,7 +2190,7 @@ extern "C" int fv3_halo_start(fv3_ctx *c, int nfields, const fv3_halo_field *fie
 // complete_group_halo_update: the context's stream waits for the transfers and unpacks them into the halos
 extern "C" int fv3_halo_complete(fv3_ctx *c) {
   if (!c || !c->pend_n) return fail("fv3_halo_complete: no group in flight");
-  rt_stream_wait_event(c->stream, c->ev_arrived);
+  rtf_stream_wait_event(c->stream, c->ev_arrived);
   const int n = c->pend_n;
   c->pend_n = 0;
   return fv3_halo_unpack(c, n, c->pend_fields, c->msg_recv);
@@ -2069,17 +2266,17 @@ static int cube_plan_get(fv3_ctx *c, int face, int kind, CubePlanDev **out) {
   auto up_i = [&](int **d, const std::vector<int> &h) -> int {
     if (h.empty()) { *d = nullptr; return 0; }
     if (rt_malloc((void **)d, sizeof(int) * h.size())) return 1;
-    return rt_h2d(*d, h.data(), sizeof(int) * h.size(), c->stream);
+    return rtf_h2d(*d, h.data(), sizeof(int) * h.size(), c->stream);
   };
   auto up_l = [&](long **d, const std::vector<long> &h) -> int {
     if (h.empty()) { *d = nullptr; return 0; }
     if (rt_malloc((void **)d, sizeof(long) * h.size())) return 1;
-    return rt_h2d(*d, h.data(), sizeof(long) * h.size(), c->stream);
+    return rtf_h2d(*d, h.data(), sizeof(long) * h.size(), c->stream);
   };
   if (up_i(&p->s_member, sm) || up_i(&p->s_sign, ss) || up_i(&p->s_seg, sseg) || up_l(&p->s_idx, si) || up_i(&p->r_member, rm) ||
       up_i(&p->r_seg, rseg) || up_l(&p->r_idx, ri))
     return fail("fv3_cube_halo: out of device memory");
-  RT(rt_sync(c->stream));
+  RT(rtf_sync(c->stream));
   c->cube_plan[kind] = p;
   *out = p;
   return 0;
@@ -2197,8 +2394,8 @@ extern "C" int fv3_cube_halo_start(int nctx, fv3_ctx *const *ctxs, const int *fa
       RT(launch_p(c, "cube_pack", grid, 0, kf));
     }
     if (!c->ev_packed) RT(rt_event_create(&c->ev_packed));
-    rt_event_record(c->ev_packed, c->stream);
-    rt_stream_wait_event(c0->comm_stream, c->ev_packed);
+    rtf_event_record(c->ev_packed, c->stream);
+    rtf_stream_wait_event(c0->comm_stream, c->ev_packed);
   }
   // ---- the messages: sends ordered by (sender face, receiver face), receives likewise -- the same order on both ends of a link ----
 #ifdef FV3_HOST_EMU
@@ -2223,7 +2420,7 @@ extern "C" int fv3_cube_halo_start(int nctx, fv3_ctx *const *ctxs, const int *fa
   const int rc2 = g_rccl.GroupEnd();   // closed on every path
   if (rc || rc2) return fail("RCCL: %s (cube-edge group)", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "error");
 #endif
-  rt_event_record(c0->ev_arrived, c0->comm_stream);
+  rtf_event_record(c0->ev_arrived, c0->comm_stream);
   for (int i = 0; i < nctx; i++) {
     for (int f = 0; f < nfields; f++) ctxs[i]->cube_pend[f] = fields[i * nfields + f];
     ctxs[i]->cube_pend_n = nfields;
@@ -2237,7 +2434,7 @@ extern "C" int fv3_cube_halo_complete(int nctx, fv3_ctx *const *ctxs) {
     if (!ctxs[i] || !ctxs[i]->cube_pend_n) return fail("fv3_cube_halo_complete: no group in flight");
   for (int i = 0; i < nctx; i++) {
     fv3_ctx *c = ctxs[i];
-    rt_stream_wait_event(c->stream, c0->ev_arrived);
+    rtf_stream_wait_event(c->stream, c0->ev_arrived);
     const int nf = c->cube_pend_n;
     c->cube_pend_n = 0;
     for (int f = 0; f < nf; f++) {
@@ -2277,10 +2474,10 @@ extern "C" int fv3_allreduce_max(fv3_ctx *c, double *buf, int n) {
 #else
   double *d = nullptr;
   RT(rt_malloc((void **)&d, sizeof(double) * n));
-  RT(rt_h2d(d, buf, sizeof(double) * n, c->comm_stream));
+  RT(rtf_h2d(d, buf, sizeof(double) * n, c->comm_stream));
   NC(g_rccl.AllReduce(d, d, (size_t)n, kNcclDouble, kNcclMax, c->comm, c->comm_stream));
-  RT(rt_d2h(buf, d, sizeof(double) * n, c->comm_stream));
-  RT(rt_sync(c->comm_stream));
+  RT(rtf_d2h(buf, d, sizeof(double) * n, c->comm_stream));
+  RT(rtf_sync(c->comm_stream));
   rt_free(d);
   return 0;
 #endif
@@ -2339,10 +2536,10 @@ extern "C" int fv3_ordered_sum(fv3_ctx *c, const double *values, size_t n, doubl
 #else
     long long *d = nullptr;
     RT(rt_malloc((void **)&d, sizeof(long long) * NI));
-    RT(rt_h2d(d, dig, sizeof(long long) * NI, c->comm_stream));
+    RT(rtf_h2d(d, dig, sizeof(long long) * NI, c->comm_stream));
     NC(g_rccl.AllReduce(d, d, (size_t)NI, kNcclInt64, kNcclSum, c->comm, c->comm_stream));
-    RT(rt_d2h(dig, d, sizeof(long long) * NI, c->comm_stream));
-    RT(rt_sync(c->comm_stream));
+    RT(rtf_d2h(dig, d, sizeof(long long) * NI, c->comm_stream));
+    RT(rtf_sync(c->comm_stream));
     rt_free(d);
     for (int i = 0; i < NI; i++) acc[i] = dig[i];
     carry(acc);
@@ -2366,13 +2563,13 @@ extern "C" int fv3_prt_maxmin(fv3_ctx *c, const double *q, int nk, double fac, d
   LevelMinMax kf{g, q, d};
   RT(launch_p(c, "prt_maxmin", Dim3{1, 1, (unsigned)nk}, 2 * kNT, kf));
   std::vector<double> mm(2 * nk), lev(g.nA());
-  RT(rt_d2h(mm.data(), d, sizeof(double) * 2 * nk, c->stream));
-  RT(rt_d2h(lev.data(), q + (size_t)(nk - 1) * g.nA(), sizeof(double) * g.nA(), c->stream));
+  RT(rtf_d2h(mm.data(), d, sizeof(double) * 2 * nk, c->stream));
+  RT(rtf_d2h(lev.data(), q + (size_t)(nk - 1) * g.nA(), sizeof(double) * g.nA(), c->stream));
   if (c->host_area.empty()) {
     c->host_area.resize(g.nA());
-    RT(rt_d2h(c->host_area.data(), g.area, sizeof(double) * g.nA(), c->stream));
+    RT(rtf_d2h(c->host_area.data(), g.area, sizeof(double) * g.nA(), c->stream));
   }
-  RT(rt_sync(c->stream));
+  RT(rtf_sync(c->stream));
   rt_free(d);
   double qmin = mm[0], qmax = mm[1];
   for (int k = 1; k < nk; k++) {
@@ -2434,8 +2631,8 @@ extern "C" int fv3_gather_create(fv3_ctx *c, int n, const int *dst_sel, const in
   t->tab = nullptr;
   if (rt_malloc((void **)&t->tab, sizeof(int) * 5 * (size_t)n)) { delete t; return fail("fv3_gather_create: out of device memory"); }
   const int *src[5] = {dst_sel, dst_idx, src_sel, src_idx, sign};
-  for (int m = 0; m < 5; m++) RT(rt_h2d(t->tab + (size_t)m * n, src[m], sizeof(int) * (size_t)n, c->stream));
-  RT(rt_sync(c->stream));
+  for (int m = 0; m < 5; m++) RT(rtf_h2d(t->tab + (size_t)m * n, src[m], sizeof(int) * (size_t)n, c->stream));
+  RT(rtf_sync(c->stream));
   *out = t;
   return 0;
 }
@@ -2459,7 +2656,13 @@ extern "C" int fv3_gather_run(fv3_ctx *c, const fv3_gather *t, int nk, int nptr,
   grid.x = (unsigned)((t->n + GatherKernel::CH - 1) / GatherKernel::CH);
   grid.y = 1;
   grid.z = (unsigned)nk;
-  RT(launch_p(c, "halo_gather", grid, 0, kf));
+  // one launch that reads and writes every face: whatever the faces of a group have queued goes first, and it is not queued itself
+  fv3_group *grp = c->grp;
+  if (grp) RT(grp_pump(grp, true));
+  c->grp = nullptr;
+  const int rc_g = launch_p(c, "halo_gather", grid, 0, kf);
+  c->grp = grp;
+  RT(rc_g);
   return 0;
 }
 
@@ -2494,7 +2697,7 @@ extern "C" int fv3_set_dp_ref(fv3_ctx *c, const double *dp0) {
   if (km < 2) return fail("fv3_set_dp_ref: needs npz >= 2");
   if (!c->dp0) RT(rt_malloc((void **)&c->dp0, sizeof(double) * km));
   if (!c->edge_dev) RT(rt_malloc((void **)&c->edge_dev, sizeof(double) * 4 * km));
-  RT(rt_h2d(c->dp0, dp0, sizeof(double) * km, c->stream));
+  RT(rtf_h2d(c->dp0, dp0, sizeof(double) * km, c->stream));
   // edge_profile coefficients, same arithmetic as nh_utils.F90:1640-1662
   std::vector<double> co(4 * km, 0.);
   double *gk = co.data(), *bet = gk + km, *gam = bet + km, *rbet = gam + km;   // rbet: the fast mode's reciprocals
@@ -2513,8 +2716,8 @@ extern "C" int fv3_set_dp_ref(fv3_ctx *c, const double *dp0) {
   c->ec.a_bot = 1. + gkk * (gkk + 1.5);
   c->ec.xt1_bot = 2. * gkk * (gkk + 1.);
   c->ec.gk_bot = gkk;
-  RT(rt_h2d(c->edge_dev, co.data(), sizeof(double) * 4 * km, c->stream));
-  RT(rt_sync(c->stream));
+  RT(rtf_h2d(c->edge_dev, co.data(), sizeof(double) * 4 * km, c->stream));
+  RT(rtf_sync(c->stream));
   c->ec.gk = c->edge_dev;
   c->ec.bet = c->edge_dev + km;
   c->ec.gam = c->edge_dev + 2 * km;
@@ -2791,9 +2994,9 @@ extern "C" int fv3_rayleigh_apply(fv3_ctx *c, int kmax, int conserve, int hydros
   if (kmax < 0 || kmax > g.npz) return fail("fv3_rayleigh_apply: kmax out of range");
   if (kmax == 0) return 0;
   if (!c->ray_d) RT(rt_malloc((void **)&c->ray_d, sizeof(double) * 2 * g.npz));
-  RT(rt_h2d(c->ray_d, pm, sizeof(double) * kmax, c->stream));
-  RT(rt_h2d(c->ray_d + g.npz, rf, sizeof(double) * kmax, c->stream));
-  RT(rt_sync(c->stream));  // pm / rf are the caller's host arrays
+  RT(rtf_h2d(c->ray_d, pm, sizeof(double) * kmax, c->stream));
+  RT(rtf_h2d(c->ray_d + g.npz, rf, sizeof(double) * kmax, c->stream));
+  RT(rtf_sync(c->stream));  // pm / rf are the caller's host arrays
   RayleighApply kf{g, conserve, hydrostatic, cp, rg, ptop, c->ray_d, c->ray_d + g.npz, u2f, pt, delz, u, v, w};
   Dim3 grid;
   grid.x = (unsigned)(((g.nx + 1) * (g.ny + 1) + RayleighApply::CH - 1) / RayleighApply::CH);
@@ -2813,9 +3016,9 @@ extern "C" int fv3_rayleigh_super(fv3_ctx *c, int kmax, int conserve, int hydros
   if (kmax < 0 || kmax > g.npz) return fail("fv3_rayleigh_super: kmax out of range");
   if (kmax == 0) return 0;
   if (!c->ray_d) RT(rt_malloc((void **)&c->ray_d, sizeof(double) * 2 * g.npz));
-  RT(rt_h2d(c->ray_d, pm, sizeof(double) * kmax, c->stream));
-  RT(rt_h2d(c->ray_d + g.npz, rf, sizeof(double) * kmax, c->stream));
-  RT(rt_sync(c->stream));  // pm / rf are the caller's host arrays
+  RT(rtf_h2d(c->ray_d, pm, sizeof(double) * kmax, c->stream));
+  RT(rtf_h2d(c->ray_d + g.npz, rf, sizeof(double) * kmax, c->stream));
+  RT(rtf_sync(c->stream));  // pm / rf are the caller's host arrays
   RayleighSuper kf{g, conserve, hydrostatic, cp, rg, ptop, c->ray_d, c->ray_d + g.npz, ua, va, pt, u, v, w, u00, v00};
   Dim3 grid;
   grid.x = (unsigned)(((g.nx + 1) * (g.ny + 1) + RayleighSuper::CH - 1) / RayleighSuper::CH);
@@ -2853,7 +3056,7 @@ extern "C" int fv3_del2_cubed(fv3_ctx *c, double *q, int nk, double cd, int nmax
     RT(launch_p(c, "del2_cubed", grid, 0, kf));
     double *t = src; src = dst; dst = t;
   }
-  if (src != q) RT(rt_d2d(q, src, sizeof(double) * g.nA() * nk, c->stream));
+  if (src != q) RT(grp_stream_op(c, 2, q, src, sizeof(double) * g.nA() * nk, 0));
   return 0;
 }
 
@@ -2998,7 +3201,7 @@ extern "C" int fv3_adv_pe(fv3_ctx *c, double ptop, const double *ua, const doubl
 extern "C" int fv3_divg2_ext(fv3_ctx *c, double d_ext, const double *delp, const double *vt, double *divg2) {
   if (!c || !c->grid_ready || !delp || !vt || !divg2) return fail("fv3_divg2_ext: bad context/arguments");
   const Grid &g = c->g;
-  RT(rt_memset(divg2, 0, sizeof(double) * g.nA(), c->stream));
+  RT(grp_stream_op(c, 1, divg2, nullptr, sizeof(double) * g.nA(), 0));
   if (!(d_ext > 0.)) return 0;
   if (is_cubed(c) && !c->cg.ready) return fail("fv3_divg2_ext: cubed-sphere context without fv3_grid_upload_cubed");
   Divg2Ext kf{g, g.npz, d_ext * g.da_min_c, delp, vt, divg2, c->cg};
@@ -3108,9 +3311,9 @@ extern "C" int fv3_set_ak_bk(fv3_ctx *c, const double *ak, const double *bk) {
   if (!c || !ak || !bk) return fail("fv3_set_ak_bk: null argument");
   const int n = c->g.npz + 1;
   if (!c->akbk) RT(rt_malloc((void **)&c->akbk, sizeof(double) * 2 * n));
-  RT(rt_h2d(c->akbk, ak, sizeof(double) * n, c->stream));
-  RT(rt_h2d(c->akbk + n, bk, sizeof(double) * n, c->stream));
-  RT(rt_sync(c->stream));
+  RT(rtf_h2d(c->akbk, ak, sizeof(double) * n, c->stream));
+  RT(rtf_h2d(c->akbk + n, bk, sizeof(double) * n, c->stream));
+  RT(rtf_sync(c->stream));
   c->akbk_ready = true;
   return 0;
 }
@@ -3231,8 +3434,8 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   const int km = g.npz;
   if (p->nq > 0) {
     if (!c->kord_tr_dev) RT(rt_malloc((void **)&c->kord_tr_dev, sizeof(int) * 64));
-    RT(rt_h2d(c->kord_tr_dev, kord_tr, sizeof(int) * p->nq, c->stream));
-    RT(rt_sync(c->stream));
+    RT(rtf_h2d(c->kord_tr_dev, kord_tr, sizeof(int) * p->nq, c->stream));
+    RT(rtf_sync(c->stream));
   }
   RemapPar rp{p->last_step, p->hydrostatic, p->adiabatic, p->nq, p->kord_mt, p->kord_wz, p->kord_tm, p->sphum,
               p->akap, p->ptop, p->rdgas, p->grav, p->cv_air, p->r_vir, p->cp, p->t_min,
@@ -3363,7 +3566,7 @@ extern "C" int fv3_tracer_2d_prep(fv3_ctx *c, int q_split, const double *cx, con
   if (!c || !c->grid_ready) return fail("fv3_tracer_2d_prep: context has no grid");
   if (need_trc(c)) return 1;
   const Grid &g = c->g;
-  RT(rt_memset(c->trc_d, 0, sizeof(double) * g.npz, c->stream));
+  RT(grp_stream_op(c, 1, c->trc_d, nullptr, sizeof(double) * g.npz, 0));
   TracerPrep kf{g, g.npz, q_split, cx, cy, xfx, yfx, c->trc_d};
   const size_t nmax = g.nCX() > g.nCY() ? g.nCX() : g.nCY();
   Dim3 grid;
@@ -3372,8 +3575,8 @@ extern "C" int fv3_tracer_2d_prep(fv3_ctx *c, int q_split, const double *cx, con
   grid.z = (unsigned)g.npz;
   RT(launch_p(c, "tracer_prep", grid, 0, kf));
   if (cmax_host) {
-    RT(rt_d2h(cmax_host, c->trc_d, sizeof(double) * g.npz, c->stream));
-    RT(rt_sync(c->stream));
+    RT(rtf_d2h(cmax_host, c->trc_d, sizeof(double) * g.npz, c->stream));
+    RT(rtf_sync(c->stream));
   }
   return 0;
 }
@@ -3383,8 +3586,8 @@ extern "C" int fv3_tracer_2d_scale(fv3_ctx *c, const double *frac_host, double *
   if (!c || !c->grid_ready || !frac_host) return fail("fv3_tracer_2d_scale: bad context/arguments");
   if (need_trc(c)) return 1;
   const Grid &g = c->g;
-  RT(rt_h2d(c->trc_d + g.npz, frac_host, sizeof(double) * g.npz, c->stream));
-  RT(rt_sync(c->stream));
+  RT(rtf_h2d(c->trc_d + g.npz, frac_host, sizeof(double) * g.npz, c->stream));
+  RT(rtf_sync(c->stream));
   TracerScale kf{g, c->trc_d + g.npz, cx, xfx, mfx, cy, yfx, mfy};
   const size_t nmax = g.nCX() > g.nCY() ? g.nCX() : g.nCY();
   Dim3 grid;
@@ -3408,8 +3611,8 @@ extern "C" int fv3_tracer_2d_step(fv3_ctx *c, int it, int nsplt, const int *kspl
   if (trdm > 1.e-4 && nord_tr > 2) return fail("fv3_tracer_2d_step: nord_tr > 2");
   if (need_trc(c)) return 1;
   if (it == 1) {
-    RT(rt_h2d(c->trc_i, ksplt_host, sizeof(int) * c->g.npz, c->stream));
-    RT(rt_sync(c->stream));
+    RT(rtf_h2d(c->trc_i, ksplt_host, sizeof(int) * c->g.npz, c->stream));
+    RT(rtf_sync(c->stream));
   }
   return tracer_step_impl(c, it, nsplt, c->trc_i, nq, hord, nord_tr, trdm, q, q_out, dp1, dp1_out, mfx, mfy, cx, cy, xfx, yfx, nullptr);
 }
@@ -3432,8 +3635,8 @@ extern "C" int fv3_d_sw_inline_q(fv3_ctx *c, int nq, int hord_tr, int nord_t, do
   if (!c->ones_i) {   // ksplt = 1 on every level, device resident (first call: outside a graph capture)
     std::vector<int> one(g.npz, 1);
     RT(rt_malloc((void **)&c->ones_i, sizeof(int) * g.npz));
-    RT(rt_h2d(c->ones_i, one.data(), sizeof(int) * g.npz, c->stream));
-    RT(rt_sync(c->stream));
+    RT(rtf_h2d(c->ones_i, one.data(), sizeof(int) * g.npz, c->stream));
+    RT(rtf_sync(c->stream));
   }
   const double *mass = nullptr;
   if (damp_t > 1.e-4) {
@@ -3528,9 +3731,9 @@ static int tracer_step_impl(fv3_ctx *c, int it, int nsplt, const int *ksplt_dev,
       std::vector<double> cd(g.npz, trdm);
       nord_dev = c->trc_i + g.npz;
       coef_dev = c->trc_d + 2 * g.npz;
-      RT(rt_h2d(nord_dev, ni.data(), sizeof(int) * g.npz, c->stream));
-      RT(rt_h2d(coef_dev, cd.data(), sizeof(double) * g.npz, c->stream));
-      RT(rt_sync(c->stream));
+      RT(rtf_h2d(nord_dev, ni.data(), sizeof(int) * g.npz, c->stream));
+      RT(rtf_h2d(coef_dev, cd.data(), sizeof(double) * g.npz, c->stream));
+      RT(rtf_sync(c->stream));
     }
     // Hybrid (see dsw_cubed): the marching kernels over the whole face (q_out, dp1_out are not inputs), then the cubed fv_tp_2d
     // passes and the update on the frame along the face edges, tracer by tracer

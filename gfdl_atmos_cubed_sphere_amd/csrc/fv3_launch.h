@@ -40,6 +40,25 @@ inline int launch_waves(int nwaves, stream_t, const F &f) {
   for (int w = 0; w < nwaves; w++) f(w);
   return 0;
 }
+// a kernel of several faces in ONE launch (fv3_group, fv3_api.hip): here simply one face after the other
+constexpr int kGrpMax = 6;
+template <int KIND, class F>
+inline int launch_group(Dim3 grid, size_t lds_doubles, int a, stream_t s, const F *const *fs, int n) {
+  for (int m = 0; m < n; m++) {
+    int rc = 0;
+    if constexpr (KIND == 0) rc = launch(grid, lds_doubles, s, *fs[m]);
+    else if constexpr (KIND == 1) rc = launch_2w(grid, lds_doubles, s, *fs[m]);
+    else rc = launch_waves(a, s, *fs[m]);
+    if (rc) return rc;
+  }
+  return 0;
+}
+template <int W, class F>
+inline int launch_group_cols(Dim3 grid, int lanes, stream_t s, const F *const *fs, int n) {
+  for (int m = 0; m < n; m++)
+    if (int rc = launch_cols<W>(grid, s, *fs[m], lanes)) return rc;
+  return 0;
+}
 inline int rt_malloc(void **p, size_t n) {
   *p = std::malloc(n);
   return *p ? 0 : 1;
@@ -215,6 +234,107 @@ inline int launch_waves(int nwaves, stream_t s, const F &f) {
     hipLaunchKernelGGL(wave_kernel_2w<F>, grid, dim3(kNT), 0, s, f, nwaves, chunk);
   else
     hipLaunchKernelGGL(wave_kernel<F>, grid, dim3(kNT), 0, s, f, nwaves, chunk);
+  return (int)hipGetLastError();
+}
+// ---- a kernel of several faces in ONE launch (fv3_group, fv3_api.hip) -------------------------------------------------------------
+// When one GPU holds several faces of the cube (six contexts), every kernel of the step is issued once per face: at C96 a face's pass /
+// frame kernels are a few dozen workgroups for 256 CUs, and six of them one after the other cost six launch latencies for work that
+// fills a sixth of the chip.  The group launchers take the functors of all faces BY VALUE in one kernel-argument block (six functors
+// are 4-6 KB; the kernarg segment takes 60 KB, tools/probe/kernarg_probe.hip) and add the face as the slowest grid index.  The face is
+// uniform per workgroup, so the functor's members are scalar loads from the kernarg segment at a dynamic offset -- no copy, no scratch.
+constexpr int kGrpMax = 6;
+template <class F>
+struct FGroup {   // raw storage: the functors need no default constructor
+  alignas(alignof(F)) unsigned char raw[kGrpMax * sizeof(F)];
+  __device__ __forceinline__ const F &at(int m) const { return reinterpret_cast<const F *>(raw)[m]; }
+};
+template <class F>
+__global__ void __launch_bounds__(kNT) tile_kernel_g(const FGroup<F> fg, int gy) {
+  extern __shared__ double fv3_lds[];
+  const int face = (int)blockIdx.z / gy, by = (int)blockIdx.z - face * gy;
+  fg.at(face)((int)blockIdx.y, by, (int)blockIdx.x, (int)threadIdx.x, fv3_lds);
+}
+template <class F>
+__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) tile_kernel_2w_g(const FGroup<F> fg, int gy) {
+  extern __shared__ double fv3_lds[];
+  const int face = (int)blockIdx.z / gy, by = (int)blockIdx.z - face * gy;
+  fg.at(face)((int)blockIdx.y, by, (int)blockIdx.x, (int)threadIdx.x, fv3_lds);
+}
+template <class F>
+__global__ void __launch_bounds__(64) col_kernel_g(const FGroup<F> fg, int lanes) {
+  if ((int)threadIdx.x >= lanes) return;
+  const int vt = (int)blockIdx.x * lanes + (int)threadIdx.x;
+  fg.at((int)blockIdx.y)(vt >> 8, 0, 0, vt & 255, nullptr);
+}
+template <class F, int W>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) col_kernel_w_g(const FGroup<F> fg, int lanes) {
+  if ((int)threadIdx.x >= lanes) return;
+  const int vt = (int)blockIdx.x * lanes + (int)threadIdx.x;
+  fg.at((int)blockIdx.y)(vt >> 8, 0, 0, vt & 255, nullptr);
+}
+template <class F>
+__global__ void __launch_bounds__(kNT) wave_kernel_g(const FGroup<F> fg, int nwaves, int chunk) {
+  const int gid = __builtin_amdgcn_readfirstlane(wave_index(chunk));
+  if (gid < nwaves) fg.at((int)blockIdx.y)(gid);
+}
+template <class F>
+__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) wave_kernel_2w_g(const FGroup<F> fg, int nwaves, int chunk) {
+  const int gid = __builtin_amdgcn_readfirstlane(wave_index(chunk));
+  if (gid < nwaves) fg.at((int)blockIdx.y)(gid);
+}
+template <class F>
+inline void fgroup_fill(FGroup<F> &fg, const F *const *fs, int n) {
+  static_assert(std::is_trivially_copyable<F>::value, "kernel functors are plain data");
+  for (int m = 0; m < kGrpMax; m++) std::memcpy((void *)(fg.raw + (size_t)m * sizeof(F)), (const void *)fs[m < n ? m : 0], sizeof(F));
+}
+// KIND: 0 = launch, 1 = launch_2w, 3 = launch_waves (a = nwaves); column kernels: launch_group_cols
+template <int KIND, class F>
+inline int launch_group(Dim3 grid, size_t lds_doubles, int a, stream_t s, const F *const *fs, int n) {
+  FGroup<F> fg;
+  fgroup_fill(fg, fs, n);
+  if constexpr (KIND == 0 || KIND == 1) {
+    const size_t bytes = lds_doubles * sizeof(double);
+    if (bytes > 64 * 1024) {
+      static thread_local bool done = false;
+      if (!done) {
+        hipError_t e = hipFuncSetAttribute(KIND ? reinterpret_cast<const void *>(&tile_kernel_2w_g<F>)
+                                                : reinterpret_cast<const void *>(&tile_kernel_g<F>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+      }
+    }
+    const dim3 hw(grid.z, grid.x, grid.y * (unsigned)n);
+    if constexpr (KIND == 1)
+      hipLaunchKernelGGL(tile_kernel_2w_g<F>, hw, dim3(kNT), bytes, s, fg, (int)grid.y);
+    else
+      hipLaunchKernelGGL(tile_kernel_g<F>, hw, dim3(kNT), bytes, s, fg, (int)grid.y);
+    return (int)hipGetLastError();
+  } else {
+    const int wpb = kNT / 64;
+    int nblocks = (a + wpb - 1) / wpb, chunk = 0;
+    if (xcd_remap() && nblocks >= 4 * kXcds) {
+      chunk = (nblocks + kXcds - 1) / kXcds;
+      nblocks = chunk * kXcds;
+    }
+    const dim3 hw((unsigned)nblocks, (unsigned)n);
+    if constexpr (wants_two_waves<F>::value)
+      hipLaunchKernelGGL(wave_kernel_2w_g<F>, hw, dim3(kNT), 0, s, fg, a, chunk);
+    else
+      hipLaunchKernelGGL(wave_kernel_g<F>, hw, dim3(kNT), 0, s, fg, a, chunk);
+    return (int)hipGetLastError();
+  }
+}
+template <int W, class F>
+inline int launch_group_cols(Dim3 grid, int lanes_req, stream_t s, const F *const *fs, int n) {
+  FGroup<F> fg;
+  fgroup_fill(fg, fs, n);
+  const int lanes = (lanes_req > 0 && lanes_req <= 64) ? lanes_req : col_lanes();
+  const unsigned nb = (unsigned)(((size_t)grid.x * 256 + lanes - 1) / lanes);
+  if constexpr (W > 0)
+    hipLaunchKernelGGL((col_kernel_w_g<F, W>), dim3(nb, (unsigned)n), dim3(64), 0, s, fg, lanes);
+  else
+    hipLaunchKernelGGL(col_kernel_g<F>, dim3(nb, (unsigned)n), dim3(64), 0, s, fg, lanes);
   return (int)hipGetLastError();
 }
 inline int rt_malloc(void **p, size_t n) { return (int)hipMalloc(p, n); }

@@ -11,7 +11,7 @@ import numpy as np
 
 from .cubed_halo import CubeHalo, CubeHaloNative, CubeHaloRank
 from .cubed_sphere import CubedSphere
-from .lib import Context
+from .lib import Context, FaceGroup
 
 
 class FaceSet:
@@ -44,11 +44,22 @@ class FaceSet:
 
 
 class MultiContext:
-    def __init__(self, ctxs):
+    """`group` (default: on, FV3_MI355X_FACE_GROUP=0 turns it off): the contexts form an fv3_group -- every kernel the faces issue in
+    turn runs as ONE launch over all of them (lib.FaceGroup); the faces then share the first context's stream."""
+
+    def __init__(self, ctxs, group=None):
+        import os
         self.ctxs = list(ctxs)
         c0 = self.ctxs[0]
         self.npz, self.bd, self.grid, self.lib = c0.npz, c0.bd, c0.grid, c0.lib
+        if group is None:
+            group = os.environ.get("FV3_MI355X_FACE_GROUP", "1") != "0"
+        self.group = FaceGroup(self.ctxs) if (group and len(self.ctxs) > 1) else None
         self.stream = c0.stream
+
+    def flush(self):
+        if self.group:
+            self.group.flush()
 
     def zeros(self, kind, nk=None):
         return FaceSet([c.zeros(kind, nk) for c in self.ctxs])
@@ -66,6 +77,9 @@ class MultiContext:
             c.sync()
 
     def close(self):
+        if self.group:
+            self.group.close()
+            self.group = None
         for c in self.ctxs:
             c.close()
 
@@ -243,6 +257,8 @@ class StepGraph:
             for st in streams[1:]:            # fork: the other faces' streams join the capture
                 st.wait_event(ev)
             fv.step(bdt)
+            if hasattr(fv.ctx, "flush"):      # a face group: nothing stays queued past the end of the capture
+                fv.ctx.flush()
             for st in streams[1:]:            # join
                 e = torch.cuda.Event()
                 e.record(st)

@@ -8,6 +8,7 @@ module fv3_mi355x_mod
   private
   public :: fv3_domain, fv3_grid_host, fv3_dsw_params, fv3_dsw_levels
   public :: fv3_create, fv3_destroy, fv3_set_stream, fv3_grid_upload, fv3_malloc, fv3_free
+  public :: fv3_group_create, fv3_group_flush, fv3_group_stats, fv3_group_destroy
   public :: fv3_memcpy_h2d, fv3_memcpy_d2h, fv3_sync, fv3_c_sw, fv3_d_sw, fv3_fv_tp_2d
   public :: fv3_dsw_levels_upload, fv3_halo_fill_periodic, fv3_check
   public :: fv3_nh_consts, fv3_remap_params, fv3_memcpy_d2d, fv3_set_dp_ref, fv3_update_dz_c, fv3_riem_solver_c
@@ -100,6 +101,26 @@ module fv3_mi355x_mod
     integer(c_int) function fv3_set_stream(ctx, stream) bind(C, name="fv3_set_stream")
       import :: c_int, c_ptr
       type(c_ptr), value :: ctx, stream
+    end function
+    !> the faces (tiles) this rank holds, launched together: one kernel launch for all of them (include/fv3_mi355x.h)
+    integer(c_int) function fv3_group_create(members, n, grp) bind(C, name="fv3_group_create")
+      import :: c_int, c_ptr
+      type(c_ptr), intent(in) :: members(*)
+      integer(c_int), value :: n
+      type(c_ptr), intent(out) :: grp
+    end function
+    integer(c_int) function fv3_group_flush(grp) bind(C, name="fv3_group_flush")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: grp
+    end function
+    integer(c_int) function fv3_group_stats(grp, merged, single) bind(C, name="fv3_group_stats")
+      import :: c_int, c_ptr, c_long
+      type(c_ptr), value :: grp
+      integer(c_long), intent(out) :: merged, single
+    end function
+    integer(c_int) function fv3_group_destroy(grp) bind(C, name="fv3_group_destroy")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: grp
     end function
     integer(c_int) function fv3_grid_upload(ctx, g) bind(C, name="fv3_grid_upload")
       import :: c_int, c_ptr, fv3_grid_host

@@ -25,6 +25,7 @@ module fv3_sphere_mod
     type(fv3_atmos) :: f(6)
     type(c_ptr) :: ctxs(6)
     logical :: adv_pe = .true.              !< en1 / en2 were uploaded (fv3_grid_cubed): omga gets its advective part (dyn_core.F90:1195)
+    type(c_ptr) :: grp = c_null_ptr         !< the faces of this rank as one launch group (fv3_group_create), when there are several
   end type
 
 contains
@@ -61,6 +62,9 @@ contains
       call fv3_check(fv3_comm_get_unique_id(myid), 'fv3_comm_get_unique_id')
     end if
     call fv3_check(fv3_comm_init(sp%ctxs(1), int(rank, c_int), int(nranks, c_int), myid), 'fv3_comm_init')
+    ! every face is initialised by now: the faces of this rank issue each kernel in turn -> ONE launch for all of them
+    if (sp%nf > 1 .and. .not. c_associated(sp%grp)) &
+      call fv3_check(fv3_group_create(sp%ctxs, int(sp%nf, c_int), sp%grp), 'fv3_group_create')
   end subroutine
 
   ! ---- the cube-edge exchange of one group: up to 4 entries, each a scalar field or a vector pair of every face ----
@@ -405,6 +409,10 @@ contains
   subroutine fv3_sphere_final(sp)
     type(fv3_sphere), intent(inout) :: sp
     integer :: i
+    if (c_associated(sp%grp)) then
+      call fv3_check(fv3_group_destroy(sp%grp), 'fv3_group_destroy')
+      sp%grp = c_null_ptr
+    end if
     do i = 1, sp%nf
       call fv3_host_final(sp%f(i))
     end do

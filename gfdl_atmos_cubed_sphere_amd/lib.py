@@ -30,7 +30,7 @@ _V = ["dy", "rdy", "dxc", "rdxc", "cosa_u", "sina_u", "rsin_u", "divg_v", "del6_
 _B = ["rarea_c", "fC", "cosa", "sina"]
 
 # every symbol include/fv3_mi355x.h declares (tests check the built library exports all of them)
-EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_grid_upload", "fv3_grid_upload_cubed", "fv3_gather_create", "fv3_gather_run", "fv3_gather_destroy", "fv3_grid_geom", "fv3_malloc",
+EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_group_create", "fv3_group_flush", "fv3_group_stats", "fv3_group_destroy", "fv3_grid_upload", "fv3_grid_upload_cubed", "fv3_gather_create", "fv3_gather_run", "fv3_gather_destroy", "fv3_grid_geom", "fv3_malloc",
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_periodic_group", "fv3_halo_pack",
            "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_compute_total_energy", "fv3_energy_fixer_sums", "fv3_remap_finish", "fv3_ordered_sum", "fv3_adv_pe", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max", "fv3_cube_table", "fv3_cube_halo_start", "fv3_cube_halo_complete",
@@ -261,6 +261,38 @@ def _pp(x):
     return None if x is None else x.p
 
 
+class FaceGroup:
+    """fv3_group: the faces (contexts) one rank holds, launched together -- every member queues its launches, and when all of them
+    have issued the same kernel ONE launch runs them (include/fv3_mi355x.h).  The members share the first member's stream."""
+
+    def __init__(self, ctxs):
+        self.lib = ctxs[0].lib
+        self.ctxs = list(ctxs)
+        n = len(self.ctxs)
+        self.h = _vp()
+        self.lib.check(self.lib.dll.fv3_group_create((C.c_void_p * n)(*[c.h.value for c in self.ctxs]), C.c_int(n),
+                                                     C.byref(self.h)), "fv3_group_create")
+        for c in self.ctxs:
+            c.stream = self.ctxs[0].stream
+            c.group = self
+
+    def flush(self):
+        self.lib.check(self.lib.dll.fv3_group_flush(self.h), "fv3_group_flush")
+
+    def stats(self):
+        """(launches that ran all members at once, launches that ran alone) since the last call"""
+        a, b = C.c_long(0), C.c_long(0)
+        self.lib.check(self.lib.dll.fv3_group_stats(self.h, C.byref(a), C.byref(b)), "fv3_group_stats")
+        return a.value, b.value
+
+    def close(self):
+        if self.h:
+            self.lib.check(self.lib.dll.fv3_group_destroy(self.h), "fv3_group_destroy")
+            self.h = None
+            for c in self.ctxs:
+                c.group = None
+
+
 class Context:
     """fv3_ctx: one rank's block of the domain + its gridstruct on the device."""
 
@@ -270,6 +302,7 @@ class Context:
         self.bd: Bounds = grid.bd
         self.npz = npz
         self._buffers: list[DeviceArray] = []
+        self.group = None      # lib.FaceGroup this context is a member of
         d = _Domain()
         b = grid.bd
         d.is_, d.ie, d.js, d.je, d.ng = b.is_, b.ie, b.js, b.je, b.ng

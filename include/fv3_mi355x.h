@@ -87,6 +87,21 @@ int fv3_destroy(fv3_ctx *ctx);
 /* stream: a hipStream_t (NULL = default stream). */
 int fv3_set_stream(fv3_ctx *ctx, void *stream);
 int fv3_grid_upload(fv3_ctx *ctx, const fv3_grid_host *g);
+/* The faces (tiles) one rank holds, launched together.  The reference runs the tiles of a PE one after the other through the same
+ * code (tools/fv_mp_mod.F90:276-392 domain_decomp: `tile` / `ntiles_g` per PE; model/dyn_core.F90 is called once per tile the PE
+ * owns); six contexts on one MI355X would likewise issue every kernel six times, and at C96 - C384 the pass / frame kernels of a face
+ * fill a fraction of the chip.  Members of a group QUEUE their launches; when every member has issued the same kernel with the same
+ * grid, ONE launch runs all of them (the face is the slowest grid index, the functors travel by value in one kernel-argument block).
+ * The results are those of the separate launches bit for bit (the same code on the same data).  The caller issues each call for all
+ * members in turn (any order of members, the same order of calls); everything that reads results or touches another stream -- memcpy
+ * to or from the host, fv3_sync, halo exchanges, fv3_gather_run -- runs what is queued first, face by face where the members are not
+ * at the same kernel.  All members launch on the first member's stream (fv3_set_stream on any member moves all of them).
+ * fv3_group_stats: launches since the last call that ran all members at once / that ran alone. */
+typedef struct fv3_group fv3_group;
+int fv3_group_create(fv3_ctx *const *members, int n, fv3_group **out);   /* 1 <= n <= 6 */
+int fv3_group_flush(fv3_group *grp);
+int fv3_group_stats(fv3_group *grp, long *merged, long *single);
+int fv3_group_destroy(fv3_group *grp);
 int fv3_grid_upload_cubed(fv3_ctx *ctx, const fv3_grid_cubed *g);
 /* Geometry mode fv3_grid_upload found in the metric arrays (or -1 without a grid): 0 = general (every metric row is
  * read); 1 = orthogonal: cosa_s, cosa_u, cosa_v = 0 and rsin2, sina_u, sina_v, rsin_u, rsin_v, sin_sg(:,:,1:4) = 1

@@ -813,3 +813,42 @@ def check_adv_pe(lib, npx=13, npz=6, faces=range(6)):
         finally:
             ctx.close()
     return worst
+
+
+def check_face_group(lib, npx=13, npz=5, n_split=2, bdt=300.0, hydrostatic=False, flags=None):
+    """fv3_group (include/fv3_mi355x.h): the acoustic substep loop of the whole sphere with the six contexts as ONE group -- every
+    kernel the faces issue in turn runs as one launch over all of them -- against the same loop with six separate launches per kernel:
+    bit for bit the same fields; and the group did merge (nearly every launch ran all six faces at once)."""
+    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynCore, DynFlags
+    cs, gs, st = CC.hydro_state(npx, npz) if hydrostatic else CC.nh_state(npx, npz)
+    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, **(flags or {}))
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+    dp0 = np.diff(fl.ptop + (1.0e5 - fl.ptop) * sig)
+    out, stats = [], None
+    for group in (False, True):
+        mctx = MultiContext([Context(g, npz, lib=lib) for g in gs], group=group)
+        try:
+            assert (mctx.group is not None) == group
+            dc = DynCore(mctx, fl, dp0, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)))
+            bd = gs[0].bd
+            zero = [np.zeros_like(s["delp"]) for s in st]
+            dc.set_state([s["u"] for s in st], [s["v"] for s in st], zero if hydrostatic else [s["w"] for s in st],
+                         [s["delp"] for s in st], [s["pt"] for s in st],
+                         [bd.zeros("CC", npz) for _ in st] if hydrostatic else [s["delz"] for s in st], [s["phis"] for s in st])
+            if group:
+                mctx.group.stats()
+            dc.run(bdt)
+            if group:
+                mctx.flush()
+                stats = mctx.group.stats()
+            names = ("u", "v", "delp", "pt", "mfx", "mfy", "cx", "cy", "pk") + (() if hydrostatic else ("w", "zh", "delz"))
+            out.append({n: dc.d[n].download() for n in names})
+        finally:
+            mctx.close()
+    for n in out[0]:
+        for t in range(6):
+            assert np.array_equal(out[0][n][t], out[1][n][t]), f"face group: {n} of face {t + 1} differs from the separate launches"
+    merged, single = stats
+    assert merged > 0 and single <= 0.05 * merged, f"face group: {merged} merged launches, {single} single ones"
+    return stats

@@ -1197,3 +1197,13 @@ def test_switched_off_paths_still_agree():
     env = dict(os.environ, FV3_MI355X_GEOPK_PHASED="0", FV3_MI355X_DELN_FUSED="0", FV3_MI355X_FLUX_MARCH="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("hydrostatic", [False, True])
+def test_face_group_one_launch_for_six_faces(prod, hydrostatic):
+    """fv3_group: the six contexts of a sphere as one group -- every kernel the faces issue in turn is ONE launch
+    with the face as the slowest grid index and the six functors by value in the kernel arguments -- against six separate launches
+    per kernel: the same bits in every field, and nearly every launch of the substep loop ran all six faces at once.  C48 (pass
+    kernels only), C96 with the marching interior, the production damping set."""
+    PC.check_face_group(prod, npx=49, npz=8, hydrostatic=hydrostatic)
+    PC.check_face_group(prod, npx=97, npz=6, n_split=2, hydrostatic=hydrostatic, flags=PROD)

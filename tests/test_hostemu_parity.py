@@ -1102,3 +1102,12 @@ def test_switched_off_paths_still_agree(emu):
     env = dict(os.environ, FV3_MI355X_GEOPK_PHASED="0", FV3_MI355X_DELN_FUSED="0", FV3_MI355X_FLUX_MARCH="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("hydrostatic", [False, True])
+def test_face_group(emu, hydrostatic):
+    """fv3_group_create: the six faces of a sphere as one group (queued launches, one merged launch per kernel, stream operations in
+    each member's order, flushes at gathers / downloads) against six separate launches per kernel -- bit for bit, and merged"""
+    PC.check_face_group(emu, hydrostatic=hydrostatic)
+    if not hydrostatic:
+        PC.check_face_group(emu, npx=17, npz=6, n_split=3, flags=dict(do_vort_damp=True, vtdm4=0.06, nord=3, d_con=1.0))
