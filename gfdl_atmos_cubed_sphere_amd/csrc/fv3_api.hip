@@ -131,6 +131,8 @@ struct fv3_ctx {
   int trc_nt;  // tracers per wavefront in the sub-cycle kernel (FV3_MI355X_TRACER_NT: 1..4, default 3)
   int remap_nt;  // tracers per thread in the remap (FV3_MI355X_REMAP_NT: 1..3, default 3)
   int riem_blocked;   // the same for the Riemann solvers' four slabs (FV3_MI355X_RIEM_SCR: 0 / 1, default 1)
+  int riem_lds;       // the dry SIM1 Riemann solvers with the levels across the lanes, BIT-IDENTICAL to the slab kernels (nh_fast.h
+                      // RiemFast<CG, true>; FV3_MI355X_RIEM_LDS: 0 / 1, default 1)
   int fast;           // fast (tolerance) mode: FV3_MI355X_FAST=1 or fv3_set_fast -- nh_fast.h instead of the parity column solvers
   int remap_blocked;  // scratch slabs of the remap in per-wavefront blocks (FV3_MI355X_REMAP_SCR: 0 / 1, default 1)
   int remap_lds;      // the remap with the column in LDS (remap_fast.h; bit-identical to the slab kernels) where it is built for the
@@ -497,6 +499,8 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     if (c->remap_nt < 1 || c->remap_nt > RemapFields::kGroupMax) c->remap_nt = 3;
     e = std::getenv("FV3_MI355X_RIEM_SCR");
     c->riem_blocked = e ? (std::atoi(e) != 0) : 1;
+    e = std::getenv("FV3_MI355X_RIEM_LDS");
+    c->riem_lds = e ? (std::atoi(e) != 0) : 1;
     e = std::getenv("FV3_MI355X_FAST");
     c->fast = e ? std::atoi(e) : 0;   // 1 = every tolerance-mode kernel; otherwise a mask: 2 Riem_Solver_c, 4 Riem_Solver3, 8 edge_profile
     if (c->fast == 1) c->fast = 14;
@@ -2756,11 +2760,20 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn,
                                  const double *pt, const double *delp, double *gz, double *pef, const double *ws) {
   if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver_c: bad context/arguments");
   if (cn->a_imp <= 0.5) return fail("fv3_riem_solver_c: a_imp <= 0.5 (RIM_2D / SIM3p0) is not built");
-  if ((c->fast & 2) && !c->q_con && c->g.npz <= 127 && c->g.npz >= 2) {   // Riem_Solver_c is SIM1 whatever a_imp is
-    RiemFast<true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
-                      nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0};
-    RT(launch_p2(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
-    return 0;
+  if (!c->q_con && c->g.npz <= 127 && c->g.npz >= 2) {   // Riem_Solver_c is SIM1 whatever a_imp is
+    if (c->fast & 2) {         // tolerance mode: blocked parallel scans
+      RiemFast<true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
+                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0};
+      RT(launch_p2(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
+      return 0;
+    }
+    if (c->riem_lds) {         // the recurrences in the reference's order: the slab kernel's bits
+      RiemFast<true, true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
+                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0};
+      if (const char *pe_ = std::getenv("FV3_MI355X_RIEM_PROBE")) kf.probe = std::atoi(pe_);
+      RT(launch_p2(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
+      return 0;
+    }
   }
   if (need_scratch(c, 4)) return 1;
   const int ncc = (c->g.nx + 2) * (c->g.ny + 2), pool = col_pool(c, ncc);
@@ -2783,11 +2796,26 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
   if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver3: bad context/arguments");
   if (cn->a_imp <= 0.5) return fail("fv3_riem_solver3: a_imp <= 0.5 (RIM_2D / SIM3 / SIM3p0) is not built");
   if (last_call && (!pe || !pk || !peln)) return fail("fv3_riem_solver3: last_call needs pe, pk, peln");
-  if ((c->fast & 4) && !c->q_con && !c->cappa && cn->a_imp > 0.999 && c->g.npz <= 127 && c->g.npz >= 2) {
-    RiemFast<false> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
-                       use_logp, last_call, fp_out};
+  if (!c->q_con && !c->cappa && cn->a_imp <= 0.999 && c->riem_lds && c->g.npz <= 127 && c->g.npz >= 2) {   // SIM_solver (the reference's default a_imp = 0.75)
+    RiemFast<false, true, true> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
+                                   use_logp, last_call, fp_out};
     RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
     return 0;
+  }
+  if (!c->q_con && !c->cappa && cn->a_imp > 0.999 && c->g.npz <= 127 && c->g.npz >= 2) {
+    if (c->fast & 4) {
+      RiemFast<false> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
+                         use_logp, last_call, fp_out};
+      RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
+      return 0;
+    }
+    if (c->riem_lds) {
+      RiemFast<false, true> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
+                               use_logp, last_call, fp_out};
+      if (const char *pe_ = std::getenv("FV3_MI355X_RIEM_PROBE")) kf.probe = std::atoi(pe_);
+      RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
+      return 0;
+    }
   }
   if (need_scratch(c, 4)) return 1;
   const int ncc = c->g.nx * c->g.ny, pool = col_pool(c, ncc);

@@ -63,6 +63,9 @@ inline vd vlds_ld(const double *buf, int col0, int q) {
 inline void vlds_st(double *buf, int col0, int q, const vd &x) {
   FV3_LANE_LOOP buf[((l >> 4) + col0) * kFP + (l & 15) * kFS + q] = x.v[l];
 }
+inline void vlds_st_next_if(double *buf, int col0, int q, const vd &x, const vb &m) {   // level (lane's level q) + 1, where m
+  FV3_LANE_LOOP if (m.v[l]) buf[((l >> 4) + col0) * kFP + lds_lev((l & 15) * kFL + q + 1)] = x.v[l];
+}
 inline vb vlevel_lt(int q, int k) { vb r; FV3_LANE_LOOP r.v[l] = (l & 15) * kFL + q < k; return r; }
 inline vb vlevel_eq(int q, int k) { vb r; FV3_LANE_LOOP r.v[l] = (l & 15) * kFL + q == k; return r; }
 inline vd vcol_ld(const double *p, long o0, int col0, int ncol) {   // p[o0 + column of the lane] (clamped to the block's last column)
@@ -158,12 +161,30 @@ __device__ __forceinline__ void vlds_st(double *buf, int col0, int q, vd x) {
   const int l = (int)(threadIdx.x & 63);
   buf[((l >> 4) + col0) * kFP + (l & 15) * kFS + q] = x;
 }
+__device__ __forceinline__ void vlds_st_next_if(double *buf, int col0, int q, vd x, vb m) {
+  const int l = (int)(threadIdx.x & 63);
+  if (m) buf[((l >> 4) + col0) * kFP + lds_lev((l & 15) * kFL + q + 1)] = x;
+}
 __device__ __forceinline__ vb vlevel_lt(int q, int k) { return (int)(threadIdx.x & 15) * kFL + q < k; }
 __device__ __forceinline__ vb vlevel_eq(int q, int k) { return (int)(threadIdx.x & 15) * kFL + q == k; }
 __device__ __forceinline__ vd vcol_ld(const double *p, long o0, int col0, int ncol) {
   const int c = (int)((threadIdx.x & 63) >> 4) + col0;
   return p[o0 + (c < ncol ? c : ncol - 1)];
 }
+#endif
+#ifdef FV3_HOST_EMU
+inline bool vany_ne(const vd &a, const vd &b) {               // some lane's bits differ
+  FV3_LANE_LOOP if (fv3m_bits(a.v[l]) != fv3m_bits(b.v[l])) return true;
+  return false;
+}
+inline vd row_shl1_v(const vd &a, const vd &fill) {           // lane l <- lane l + 1 of its row; the row's last lane keeps its own `fill`
+  vd r;
+  FV3_LANE_LOOP r.v[l] = ((l & 15) + 1 <= 15) ? a.v[l + 1] : fill.v[l];
+  return r;
+}
+#else
+__device__ __forceinline__ bool vany_ne(vd a, vd b) { return __builtin_amdgcn_ballot_w64(fv3m_bits(a) != fv3m_bits(b)) != 0; }
+__device__ __forceinline__ vd row_shl1_v(vd a, vd fill) { return row_shl<1>(a, fill); }
 #endif
 
 // a / b, correctly rounded for operands in the normal range (spmd.h vdiv_r: one reciprocal + a Markstein correction, 8 instructions
@@ -276,6 +297,62 @@ FV3_D void tridiag_rows(const vd *a, const vd *b, const vd *c, const vd *d, vd *
     for (int q = kFL - 1; q >= 0; q--) {
       xn = x[q] - (c[q] * rbet[q]) * xn;
       x[q] = xn;
+    }
+  }
+}
+
+// The same systems in the REFERENCE'S ORDER, bit for bit (RiemFast<CG, true>; the idea of remap_fast.h spline()): row k is
+//     bet_k = b_k - a_k gam_k,   gam_(k+1) = c_k / bet_k,   y_k = (d_k - a_k y_(k-1)) / bet_k        (downwards)
+//     x_k = y_k - gam_(k+1) x_(k+1)                                                                  (upwards)
+// with a_k = 1 (x * 1 is exact) or 0 (first row, padded rows: b = 1, c = d = 0).  A lane runs its 8 rows from the value the lane above
+// hands it, all lanes at once, round after round; after round r lanes 0 .. r-1 hold the sequential values, and a round that leaves every
+// hand-over as it found it has reached them everywhere.  For a system whose elimination forgets (diagonally dominant: the pp system of
+// SIM1_solver, d gam_k / d gam_(k-1) = c / bet^2 ~ 0.1) that is after 3 - 4 rounds.  Quotients: a correctly rounded reciprocal and a
+// Markstein correction = the values of `/` (spmd.h vrecip / vdiv_r = remap_kernels.h rcp_rn / div_rn).
+FV3_D void tridiag_rounds(const vd *a, const vd *b, const vd *c, const vd *d, vd *x, const int kRounds = 16) {
+  vd bet[kFL], rb[kFL], gam[kFL], y[kFL];
+  {
+    vd gin(0.25);
+    for (int rnd = 0; rnd < kRounds; rnd++) {
+      vd g = gin;
+      for (int q = 0; q < kFL; q++) {
+        bet[q] = b[q] - a[q] * g;
+        rb[q] = vrecip(bet[q]);
+        g = vdiv_r(c[q], bet[q], rb[q]);
+        gam[q] = g;
+      }
+      const vd gnew = row_shr<1>(g, 0.25);
+      const bool moved = vany_ne(gnew, gin);
+      gin = gnew;
+      if (!moved) break;
+    }
+  }
+  {
+    vd yin(0.0);
+    for (int rnd = 0; rnd < kRounds; rnd++) {
+      vd v = yin;
+      for (int q = 0; q < kFL; q++) {
+        v = vdiv_r(d[q] - a[q] * v, bet[q], rb[q]);
+        y[q] = v;
+      }
+      const vd ynew = row_shr<1>(v, 0.0);
+      const bool moved = vany_ne(ynew, yin);
+      yin = ynew;
+      if (!moved) break;
+    }
+  }
+  {
+    vd xin(0.0);
+    for (int rnd = 0; rnd < kRounds; rnd++) {
+      vd xn = xin;
+      for (int q = kFL - 1; q >= 0; q--) {
+        xn = y[q] - gam[q] * xn;
+        x[q] = xn;
+      }
+      const vd xnew = row_shl<1>(xn, 0.0);
+      const bool moved = vany_ne(xnew, xin);
+      xin = xnew;
+      if (!moved) break;
     }
   }
 }
@@ -395,8 +472,23 @@ struct EdgeProfileFast {
 };
 
 // CG = true: Riem_Solver_c on (is-1:ie+1, js-1:je+1); false: Riem_Solver3 on the compute domain
-template <bool CG>
+//
+// EX = true (round 4): BIT-IDENTICAL to the parity kernels (nh_kernels.h sim_column), and the library's default for the dry SIM1 solver.
+// Everything pointwise in k already was the parity kernel's expression; what differed were the recurrences in k.  They now run in the
+// reference's own order:
+//   * the sums (hydrostatic pressure downwards, pe2 downwards, p1 and the heights upwards): a lane runs its 8 levels from the value
+//     its neighbour hands it, all lanes at once, round after round; after round r the first r lanes hold the sequential values, so
+//     km / 8 + 1 rounds ARE the sequential sweep (a sum forgets nothing, so no early exit) -- 10 instructions per round;
+//   * the pp system (:1302-1332): the same rounds with an early exit when no hand-over moves any more (remap_fast.h spline(): the
+//     elimination of a diagonally dominant system forgets, d gam_k / d gam_(k-1) ~ 0.1: 3 - 4 rounds);
+//   * the w system (:1335-1361) is stiff (|aa| / dm = 2 (c dt / dz)^2 ~ 1e3 .. 1e6: its elimination forgets nothing within 128 levels)
+//     and has two divisions per level: 16 rounds would cost 4 x what the sweep costs.  Its coefficients go to LDS (the transposition
+//     buffers, free by then) and ONE wavefront of the workgroup runs the 16 columns of the workgroup on 16 lanes, a lane per column,
+//     with the parity kernel's own statements (rcp_rn / div_rn); the other wavefronts wait at the barrier -- the second workgroup of
+//     the CU has the SIMDs meanwhile.
+template <bool CG, bool EX = false, bool SIM = false>
 struct RiemFast {
+  static_assert(!SIM || (EX && !CG), "SIM_solver: the D grid's Riem_Solver3 in the reference's order");
   Grid g;
   int km;
   double dt;
@@ -407,6 +499,7 @@ struct RiemFast {
   // outputs: D grid: delz, ppe, pk3 (+ pe, pk, peln on the last call); C grid: pef
   double *delz, *ppe, *pk3, *pe, *pk, *peln, *pef;
   int use_logp, last_call, fp_out;
+  int probe = 0;   // timing probe (tools/riem_time.py, FV3_MI355X_RIEM_PROBE): 1 one round per sum, 2 no w pass, 4 one round of the pp system -- WRONG results
 
   FV3_HD int i_first() const { return CG ? g.is - 1 : g.is; }
   FV3_HD int ncols_row() const { return CG ? g.nx + 2 : g.nx; }
@@ -444,6 +537,79 @@ struct RiemFast {
     }
   }
 
+  // EX: the w system of one column (SIM1_solver nh_utils.F90:1335-1361) with the parity kernel's statements (nh_kernels.h sim_column
+  // passes C and D), its rows in LDS: A = aa at the top interface of layer k (k = km: p1 of the bottom layer), D = dm, R = right-hand
+  // side.  On exit R = w2, A = gam.  Chunks of 8 levels are loaded ahead of the recurrence that consumes them.
+  FV3_D void w_column(double *A, double *D, double *R) const {
+    double bet = 1., rbet = 1., y = 0.;
+    const int nch = (km + kFL - 1) / kFL;
+    double an[kFL + 1], dn[kFL], rn[kFL];
+    for (int u = 0; u < kFL; u++) { an[u] = A[u]; dn[u] = D[u]; rn[u] = R[u]; }
+    an[kFL] = A[kFS];                                        // the row below the chunk's last: the next chunk's first word
+    for (int ch = 0; ch < nch; ch++) {
+      double ac[kFL + 1], dc[kFL], rc[kFL];
+      for (int u = 0; u <= kFL; u++) ac[u] = an[u];
+      for (int u = 0; u < kFL; u++) { dc[u] = dn[u]; rc[u] = rn[u]; }
+      if (ch + 1 < nch) {
+        const int o = (ch + 1) * kFS;
+        for (int u = 0; u < kFL; u++) { an[u] = A[o + u]; dn[u] = D[o + u]; rn[u] = R[o + u]; }
+        an[kFL] = A[o + kFS];
+      }
+      double gv[kFL], yv[kFL];
+      // (the rows of the last chunk beyond km are padding -- aa = 0, dm = 1, rhs = 0 from the pointwise part, so bet = 1 there and
+      // nothing is selected per level: the recurrence is 17 dependent instructions a level and nothing else)
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+      for (int u = 0; u < kFL; u++) {
+        const double a = ac[u], low = ac[u + 1];
+        const double gam = div_rn(a, bet, rbet);
+        bet = dc[u] - (a + low + a * gam);
+        rbet = rcp_rn(bet);
+        y = div_rn(rc[u] - a * y, bet, rbet);
+        gv[u] = gam;
+        yv[u] = y;
+      }
+      const int o = ch * kFS;
+      for (int u = 0; u < kFL; u++) {
+        A[o + u] = gv[u];
+        R[o + u] = yv[u];
+      }
+    }
+    // back substitution: w2(k) = w2(k) - gam(k+1) w2(k+1), k = km-1 .. 1
+    double wn = 0.;
+    for (int ch = nch - 1; ch >= 0; ch--) {
+      const int o = ch * kFS;
+      double yc[kFL], gc[kFL + 1];
+      for (int u = 0; u < kFL; u++) yc[u] = R[o + u];
+      for (int u = 1; u < kFL; u++) gc[u] = A[o + u];
+      gc[kFL] = A[o + kFS];                                  // gam of the next chunk's first row
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+      for (int u = kFL - 1; u >= 0; u--) {
+        const int k = ch * kFL + u;
+        const double v = k == km - 1 ? yc[u] : yc[u] - gc[u + 1] * wn;
+        wn = k <= km - 1 ? v : wn;
+        yc[u] = wn;
+      }
+      for (int u = 0; u < kFL; u++)
+        if (ch * kFL + u < km) R[o + u] = yc[u];
+    }
+  }
+  // one wavefront of the workgroup (`wave`, so that the workgroups of a CU use different SIMDs for it) runs the 16 columns, a lane each
+  FV3_D void w_columns(double *A, double *D, double *R, int wave, int tid) const {
+#ifdef FV3_HOST_EMU
+    (void)wave; (void)tid;
+    for (int col = 0; col < kFC; col++) w_column(A + col * kFP, D + col * kFP, R + col * kFP);
+#else
+    if ((tid >> 6) == wave && (tid & 63) < kFC) {
+      const int col = tid & 63;
+      w_column(A + col * kFP, D + col * kFP, R + col * kFP);
+    }
+#endif
+  }
+
   FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
     double *B0 = lds, *B1 = lds + kFBuf, *B2 = lds + 2 * kFBuf, *B3 = lds + 3 * kFBuf;
     const int i0 = i_first() + bx * kFC, j = (CG ? g.js - 1 : g.js) + by;
@@ -451,9 +617,15 @@ struct RiemFast {
     const size_t nA = g.nA(), nCC = g.nCC();
     const size_t o0 = (size_t)g.iA(i0, j);
     const double rgrav = 1. / cn.grav, rgas = cn.rdgas, gm2 = 1. / (1. - cn.akap), cp2 = cn.akap;
-    const double t1g = 2. * dt * dt, rdt = 1. / dt;
+    // SIM: SIM_solver (nh_utils.F90:1396-1537, a_imp < 1: the off-centred form) -- t1g with alpha dt, the explicit part wk of the w
+    // equation, the blend of pe2 with pp at the end; everything else is SIM1_solver
+    const double alpha = cn.a_imp, beta = 1. - alpha, ra = 1. / alpha, t2 = beta / alpha;
+    const double t1g = SIM ? 2. * ((alpha * dt) * (alpha * dt)) : 2. * dt * dt, rdt = 1. / dt;
     constexpr double r3 = 1. / 3.;
     vd dmr[kWvState][kFL], ptv[kWvState][kFL], w1[kWvState][kFL], zv[kWvState][kFL + 1];
+    vd keep_dm[kWvState][kFL], keep_pm2[kWvState][kFL], keep_grat[kWvState][kFL], keep_bb[kWvState][kFL], keep_w2[kWvState][kFL];
+    vd keep_pem[kWvState][kFL + 1], keep_lnp[kWvState][kFL + 1], keep_ppt[kWvState][SIM ? kFL + 1 : 1];
+    const int nrounds = (probe & 1) ? 1 : km / kFL + 1;   // EX: rounds after which the hand-overs of a sequential sweep over km levels are the sweep's own
     // ---- inputs: the four fields at once (their loads are in flight together), one barrier ----
     {
       double v0[kIt], v1[kIt], v2[kIt], v3[kIt];
@@ -494,14 +666,27 @@ struct RiemFast {
       }
       {  // hydrostatic pressure at the interfaces: pem(k+1) = pem(k) + delp(k) (nh_core.F90:132-141 / nh_utils.F90:404-441), the
          // lane's 8 levels in the reference's order on top of the scanned sum of the lanes above
-        vd tot(0.0);
-        for (int q = 0; q < kFL; q++) tot = tot + dmr[s][q];
-        vd run = cn.ptop + sum_scan_fwd_excl(tot);
-        for (int q = 0; q < kFL; q++) {
-          pemv[q] = run;
-          run = run + dmr[s][q];
+        if constexpr (EX) {
+          vd in(cn.ptop);
+          for (int rnd = 0; rnd < nrounds; rnd++) {
+            vd run = in;
+            for (int q = 0; q < kFL; q++) {
+              pemv[q] = run;
+              run = run + dmr[s][q];
+            }
+            pemv[kFL] = run;
+            in = row_shr<1>(run, cn.ptop);
+          }
+        } else {
+          vd tot(0.0);
+          for (int q = 0; q < kFL; q++) tot = tot + dmr[s][q];
+          vd run = cn.ptop + sum_scan_fwd_excl(tot);
+          for (int q = 0; q < kFL; q++) {
+            pemv[q] = run;
+            run = run + dmr[s][q];
+          }
+          pemv[kFL] = run;
         }
-        pemv[kFL] = run;
       }
       // hydrostatic pressure functions, perturbation pressure (nh_utils.F90:1297-1300; nh_core.F90:140-159 / nh_utils.F90:440)
       if (!CG) {
@@ -533,10 +718,12 @@ struct RiemFast {
           d[q] = vsel(real[q], dd, vd(0.0));
           bb[q] = vsel(real[q], bb[q], vd(1.0));
         }
-        tridiag_rows(a, bb, c, d, X);
+        if constexpr (EX)
+          tridiag_rounds(a, bb, c, d, X, (probe & 4) ? 1 : 16);
+        else
+          tridiag_rows(a, bb, c, d, X);
       }
       // ---- w: nh_utils.F90:1335-1361 ----
-      vd w2[kFL];
       {
         vd a[kFL], b[kFL], c[kFL], d[kFL], aat[kFL];
         const vd dz_pv = row_shr<1>(dz[kFL - 1], 1.0), X_pv = row_shr<1>(X[kFL - 1], 0.0);
@@ -556,22 +743,91 @@ struct RiemFast {
           b[q] = vsel(real[q], dm[q] - (aat[q] + low), vd(1.0));
           c[q] = vsel(real[q] && !last[q], aab, vd(0.0));
           const vd rhs = dm[q] * w1[s][q] + dt * (X[q] - ppt);
-          d[q] = vsel(real[q], vsel(last[q], rhs - p1c * wsv, rhs), vd(0.0));
+          if constexpr (SIM) {   // wk(k) = t2 aa(k) (w1(k-1) - w1(k)) at the layer's top and bottom interfaces (:1465-1466)
+            const vd w1p = (q > 0) ? w1[s][q - 1] : row_shr<1>(w1[s][kFL - 1], 0.0);
+            const vd w1n = (q < kFL - 1) ? w1[s][q + 1] : row_shl<1>(w1[s][0], 0.0);
+            const vd wkt = t2 * aat[q] * (w1p - w1[s][q]), wkb = t2 * aab * (w1[s][q] - w1n);
+            d[q] = vsel(real[q], vsel(last[q], rhs - wkt + p1c * (t2 * w1[s][q] - ra * wsv), rhs + wkb - wkt), vd(0.0));
+          } else {
+            d[q] = vsel(real[q], vsel(last[q], rhs - p1c * wsv, rhs), vd(0.0));
+          }
         }
-        tridiag_rows(a, b, c, d, w2);
+        if constexpr (EX) {
+          // coefficients of the workgroup's 16 columns -> LDS: aa at the top interface of every layer (the model's bottom interface
+          // carries p1 of the bottom layer: the "aa below" of that row), dm, the right-hand side
+          for (int q = 0; q < kFL; q++) {
+            vlds_st(B0, c0, q, aat[q]);
+            vlds_st(B1, c0, q, dm[q]);
+            vlds_st(B2, c0, q, d[q]);
+          }
+          for (int q = 0; q < kFL; q++)
+            vlds_st_next_if(B0, c0, q, vdivq(vd(t1g * gm2), dz[q]) * pemv[q + 1], last[q]);
+        } else {
+          tridiag_rows(a, b, c, d, keep_w2[s]);
+        }
       }
+      // what the second half needs stays in the per-wavefront state (registers in the product build) across the barriers of EX
+      for (int q = 0; q < kFL; q++) {
+        keep_dm[s][q] = dm[q]; keep_pm2[s][q] = pm2[q]; keep_grat[s][q] = grat[q]; keep_bb[s][q] = bb[q];
+      }
+      for (int q = 0; q <= kFL; q++) keep_pem[s][q] = pemv[q];
+      if (!CG)
+        for (int q = 0; q <= kFL; q++) keep_lnp[s][q] = lnp[q];
+      if constexpr (SIM) {   // pp at the layer's top interface (0 at the model top) and at its bottom interface
+        keep_ppt[s][0] = row_shr<1>(X[kFL - 1], 0.0);
+        for (int q = 0; q < kFL; q++) keep_ppt[s][q + 1] = X[q];
+      }
+    }
+    if constexpr (EX) {
+      FV3_SYNC();
+      if (!(probe & 2)) w_columns(B0, B1, B2, (bx + by) & 3, tid);
+      FV3_SYNC();
+    }
+    FV3_WAVE_FOR(wv) {
+      const int s = FV3_WVI(wv), c0 = wv * 4;
+      vd dm[kFL], pm2[kFL], grat[kFL], bb[kFL], lnp[kFL + 1], pemv[kFL + 1], w2[kFL];
+      vb real[kFL], last[kFL];
+      for (int q = 0; q < kFL; q++) {
+        real[q] = vlevel_lt(q, km);
+        last[q] = vlevel_eq(q, km - 1);
+      }
+      for (int q = 0; q < kFL; q++) {
+        dm[q] = keep_dm[s][q]; pm2[q] = keep_pm2[s][q]; grat[q] = keep_grat[s][q]; bb[q] = keep_bb[s][q];
+        if constexpr (EX)
+          w2[q] = vsel(real[q], vlds_ld(B2, c0, q), vd(0.0));
+        else
+          w2[q] = keep_w2[s][q];
+      }
+      for (int q = 0; q <= kFL; q++) pemv[q] = keep_pem[s][q];
+      if (!CG)
+        for (int q = 0; q <= kFL; q++) lnp[q] = keep_lnp[s][q];
       // ---- pe2 at the interfaces (:1373-1380): exclusive sum of dm2 (w2 - w1) / dt ----
       vd pe2[kFL + 2];
       {
         vd inc[kFL], tot(0.0);
         for (int q = 0; q < kFL; q++) {
-          inc[q] = vsel(real[q], dm[q] * (w2[q] - w1[s][q]) * rdt, vd(0.0));
+          if constexpr (SIM)   // :1510-1514
+            inc[q] = vsel(real[q], (dm[q] * (w2[q] - w1[s][q]) * rdt - beta * (keep_ppt[s][q + 1] - keep_ppt[s][q])) * ra, vd(0.0));
+          else
+            inc[q] = vsel(real[q], dm[q] * (w2[q] - w1[s][q]) * rdt, vd(0.0));
           tot = tot + inc[q];
         }
-        vd run = sum_scan_fwd_excl(tot);
-        for (int q = 0; q < kFL; q++) {
-          pe2[q] = run;
-          run = run + inc[q];
+        vd run = EX ? vd(0.0) : sum_scan_fwd_excl(tot);
+        if constexpr (EX) {   // pe(k+1) = pe(k) + inc(k) from 0, in the reference's order
+          vd in(0.0);
+          for (int rnd = 0; rnd < nrounds; rnd++) {
+            run = in;
+            for (int q = 0; q < kFL; q++) {
+              pe2[q] = run;
+              run = run + inc[q];
+            }
+            in = row_shr<1>(run, 0.0);
+          }
+        } else {
+          for (int q = 0; q < kFL; q++) {
+            pe2[q] = run;
+            run = run + inc[q];
+          }
         }
         pe2[kFL] = row_shl<1>(pe2[0], 0.0);
         pe2[kFL + 1] = row_shl<1>(pe2[1], 0.0);
@@ -588,17 +844,32 @@ struct RiemFast {
           Aq[q] = vsel(real[q] && !last[q], -grat[q], vd(0.0));
           Bq[q] = vsel(real[q], vsel(last[q], Bl, Bi), vd(0.0));
         }
-        vd A(1.0), B(0.0);
-        for (int q = kFL - 1; q >= 0; q--) {
-          B = vfma(Aq[q], B, Bq[q]);
-          A = Aq[q] * A;
+        vd p1v[kFL];
+        if constexpr (EX) {   // upwards from the bottom layer (its row takes nothing from below), in the reference's order
+          vd in(0.0);
+          for (int rnd = 0; rnd < nrounds; rnd++) {
+            vd p1 = in;
+            for (int q = kFL - 1; q >= 0; q--) {
+              p1 = Bq[q] + Aq[q] * p1;
+              p1v[q] = p1;
+            }
+            in = row_shl<1>(p1, 0.0);
+          }
+        } else {
+          vd A(1.0), B(0.0);
+          for (int q = kFL - 1; q >= 0; q--) {
+            B = vfma(Aq[q], B, Bq[q]);
+            A = Aq[q] * A;
+          }
+          affine_scan_bwd_excl(A, B);
+          vd p1 = B;
+          for (int q = kFL - 1; q >= 0; q--) {
+            p1 = Bq[q] + Aq[q] * p1;
+            p1v[q] = p1;
+          }
         }
-        affine_scan_bwd_excl(A, B);
-        vd p1 = B;
-        for (int q = kFL - 1; q >= 0; q--) {
-          p1 = Bq[q] + Aq[q] * p1;
-          dzn[q] = -dm[q] * rgas * ptv[s][q] * vexp((cp2 - 1.) * vlog(vmax(cn.p_fac * pm2[q], p1 + pm2[q])));
-        }
+        for (int q = kFL - 1; q >= 0; q--)
+          dzn[q] = -dm[q] * rgas * ptv[s][q] * vexp((cp2 - 1.) * vlog(vmax(cn.p_fac * pm2[q], p1v[q] + pm2[q])));
       }
       // ---- interface heights from the surface upwards (nh_core.F90:228-237 / nh_utils.F90:468-476) ----
       vd zn[kFL];
@@ -609,10 +880,22 @@ struct RiemFast {
           tot = tot + (CG ? dzn[q] * cn.grav : dzn[q]);
         }
         const vd zsv = vcol_ld(zs, (long)o0, c0, ncol);
-        vd run = zsv - sum_scan_bwd_excl(tot);     // height of the interface below the lane's last layer
-        for (int q = kFL - 1; q >= 0; q--) {
-          run = run - (CG ? dzn[q] * cn.grav : dzn[q]);
-          zn[q] = run;
+        if constexpr (EX) {   // zh(k) = zh(k+1) - dz2(k) from the surface, in the reference's order (padded layers subtract 0)
+          vd in = zsv;
+          for (int rnd = 0; rnd < nrounds; rnd++) {
+            vd run = in;
+            for (int q = kFL - 1; q >= 0; q--) {
+              run = run - (CG ? dzn[q] * cn.grav : dzn[q]);
+              zn[q] = run;
+            }
+            in = row_shl1_v(run, zsv);
+          }
+        } else {
+          vd run = zsv - sum_scan_bwd_excl(tot);     // height of the interface below the lane's last layer
+          for (int q = kFL - 1; q >= 0; q--) {
+            run = run - (CG ? dzn[q] * cn.grav : dzn[q]);
+            zn[q] = run;
+          }
         }
         // interface km (the surface) sits at (lane km / 8, q = km % 8): there every layer below is padding and run == zs
       }
@@ -629,7 +912,9 @@ struct RiemFast {
       // keep what the second round needs
       if (!CG) {
         for (int q = 0; q < kFL; q++) {
-          dmr[s][q] = fp_out ? pe2[q] + pemv[q] : pe2[q];                                                // ppe
+          vd pef_ = pe2[q];
+          if constexpr (SIM) pef_ = pe2[q] + beta * (keep_ppt[s][q] - pe2[q]);                              // :1531-1535
+          dmr[s][q] = fp_out ? pef_ + pemv[q] : pef_;                                                      // ppe
           ptv[s][q] = vsel(vlevel_eq(q, 0), vd(dexp(cn.akap * dlog(cn.ptop))), vexp(cn.akap * lnp[q]));   // pk
           w1[s][q] = lnp[q];                                                                               // peln
           zv[s][q] = pemv[q];                                                                              // pe

@@ -106,10 +106,6 @@ inline void vlin_st(double *buf, int col0, int q, const vd &x) {
   FV3_LANE_LOOP buf[((l >> 4) + col0) * kRP + rixn((l & 15) * kFL + q)] = x.v[l];
 }
 inline vd vcol_lds(const double *p, int col0) { vd x; FV3_LANE_LOOP x.v[l] = p[((l >> 4) + col0) * kRP]; return x; }
-inline bool vany_ne(const vd &a, const vd &b) {               // some lane's bits differ
-  FV3_LANE_LOOP if (fv3m_bits(a.v[l]) != fv3m_bits(b.v[l])) return true;
-  return false;
-}
 #else
 __device__ __forceinline__ vd vlin_ld(const double *buf, int col0, int q) {
   const int l = (int)(threadIdx.x & 63);
@@ -120,7 +116,6 @@ __device__ __forceinline__ void vlin_st(double *buf, int col0, int q, vd x) {
   buf[((l >> 4) + col0) * kRP + rixn((l & 15) * kFL + q)] = x;
 }
 __device__ __forceinline__ vd vcol_lds(const double *p, int col0) { return p[((int)((threadIdx.x & 63) >> 4) + col0) * kRP]; }
-__device__ __forceinline__ bool vany_ne(vd a, vd b) { return __builtin_amdgcn_ballot_w64(fv3m_bits(a) != fv3m_bits(b)) != 0; }
 #endif
 
 // kords the streamed form of the mapping loop handles (cs_cell): scalar_profile / cs_profile without the two-cell limiters of 11, 12

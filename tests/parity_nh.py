@@ -51,7 +51,22 @@ def moist_fields(bd, km, seed=17):
     return q_con, cappa
 
 
-def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, moist_kappa=False, fast=False):
+def _riem_context(g, km, lib, lds):
+    """lds: the dry SIM1 solvers with the levels across the lanes (csrc/nh_fast.h RiemFast<CG, true>, the default where it is built;
+    bit-identical to the slab kernels); False: FV3_MI355X_RIEM_LDS=0, the slab kernels (csrc/nh_kernels.h) for every configuration"""
+    import os
+    saved = os.environ.pop("FV3_MI355X_RIEM_LDS", None)
+    if not lds:
+        os.environ["FV3_MI355X_RIEM_LDS"] = "0"      # read when the context is created
+    try:
+        return Context(g, km, lib=lib)
+    finally:
+        os.environ.pop("FV3_MI355X_RIEM_LDS", None)
+        if saved is not None:
+            os.environ["FV3_MI355X_RIEM_LDS"] = saved
+
+
+def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, moist_kappa=False, fast=False, lds=True, out=None):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     s = nh_state(bd, km)
@@ -68,7 +83,7 @@ def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, mois
         gz0, pef0 = s["zh"].copy(order="F"), bd.zeros("A", km + 1)
         O.riem_solver_c(g, km, 3.0, cn, hs, s["w"], s["pt"], s["delp"], gz0, pef0, ws)
         assert P.rel_rms(pef0, pef) > 1e-8
-    ctx = Context(g, km, lib=lib)
+    ctx = _riem_context(g, km, lib, lds)
     try:
         d_gz, d_pef = ctx.from_host(s["zh"]), ctx.zeros("A", km + 1)
         ctx.set_fast(fast)          # fast mode (csrc/nh_fast.h): held to the oracle at 1e-12, not bit for bit
@@ -79,13 +94,15 @@ def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, mois
         tol = 1e-12 if fast else _tol(lib)
         e1 = P.assert_close("gz", bd.view(d_gz.download(), "A", *r), bd.view(gz, "A", *r), tol)
         e2 = P.assert_close("pef", bd.view(d_pef.download(), "A", *r), bd.view(pef, "A", *r), tol)
+        if out is not None:
+            out.update(gz=bd.view(d_gz.download(), "A", *r), pef=bd.view(d_pef.download(), "A", *r))
     finally:
         ctx.close()
     return max(e1, e2)
 
 
 def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_call=True, fp_out=False, use_cond=False,
-                       moist_kappa=False, fast=False):
+                       moist_kappa=False, fast=False, lds=True, out=None):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     s = nh_state(bd, km)
@@ -106,7 +123,7 @@ def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_
         O.riem_solver3(g, km, 6.0, cn, s["zs"], o0["w"], o0["delz"], s["pt"], s["delp"], o0["zh"], o0["pe"], o0["ppe"],
                        o0["pk3"], o0["pk"], o0["peln"], ws, use_logp, last_call, fp_out)
         assert P.rel_rms(o0["delz"], o["delz"]) > 1e-8
-    ctx = Context(g, km, lib=lib)
+    ctx = _riem_context(g, km, lib, lds)
     worst = 0.0
     try:
         ctx.set_fast(fast)
@@ -128,6 +145,10 @@ def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_
             worst = max(worst, P.assert_close("pk", d["pk"].download(), o["pk"], tol))
             worst = max(worst, P.assert_close("peln", d["peln"].download(), o["peln"], tol))
             worst = max(worst, P.assert_close("pe", d["pe"].download()[1:-1, :, 1:-1], o["pe"][1:-1, :, 1:-1], tol))
+        if out is not None:
+            out.update({n: bd.view(d[n].download(), "A", *r) for n in ("w", "zh", "ppe", "pk3")}, delz=d["delz"].download())
+            if last_call:
+                out.update(pk=d["pk"].download(), peln=d["peln"].download(), pe=d["pe"].download()[1:-1, :, 1:-1])
     finally:
         ctx.close()
     return worst
@@ -539,3 +560,21 @@ def check_pt_to_theta_v(lib, nx=30, ny=17, km=6, hydrostatic=False, moist_kappa=
     finally:
         ctx.close()
     return worst
+
+
+def check_riem_lds_bits(lib, **dims):
+    """the Riemann solvers with the levels across the lanes and the recurrences in the reference's order (nh_fast.h RiemFast<CG, true>,
+    the default) against the slab kernels (FV3_MI355X_RIEM_LDS=0): the SAME BITS in every output, both within the parity tolerance of
+    the oracle"""
+    for kw in (dict(), dict(use_logp=True, last_call=True, fp_out=True), dict(last_call=False), dict(a_imp=0.75),
+               dict(a_imp=0.75, use_logp=True, last_call=True, fp_out=True)):   # a_imp < 1: SIM_solver (RiemFast<false, true, true>)
+        a, b = {}, {}
+        check_riem_solver3(lib, out=a, **kw, **dims)
+        check_riem_solver3(lib, lds=False, out=b, **kw, **dims)
+        for n in a:
+            assert np.array_equal(a[n], b[n]), f"riem_solver3 {kw}: {n} differs from the slab kernel"
+    a, b = {}, {}
+    check_riem_solver_c(lib, out=a, **dims)
+    check_riem_solver_c(lib, lds=False, out=b, **dims)
+    for n in a:
+        assert np.array_equal(a[n], b[n]), f"riem_solver_c: {n} differs from the slab kernel"

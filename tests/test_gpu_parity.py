@@ -1207,3 +1207,13 @@ def test_face_group_one_launch_for_six_faces(prod, hydrostatic):
     kernels only), C96 with the marching interior, the production damping set."""
     PC.check_face_group(prod, npx=49, npz=8, hydrostatic=hydrostatic)
     PC.check_face_group(prod, npx=97, npz=6, n_split=2, hydrostatic=hydrostatic, flags=PROD)
+
+
+@pytest.mark.parametrize("km", [8, 32, 79, 127])
+def test_riem_lds_bit_identical_to_the_slab_kernels(prod, km):
+    """the library's default Riemann solvers (dry, SIM1): levels across the lanes, pointwise work with the parity expressions, the
+    recurrences in the reference's order -- sums and the pp system by hand-over rounds in registers, the stiff w system by one wavefront
+    over the workgroup's 16 columns in LDS (csrc/nh_fast.h RiemFast<CG, true>) -- against the slab kernels (FV3_MI355X_RIEM_LDS=0):
+    the same bits in every output (nh_utils.F90:1277-1394, nh_core.F90:47-241, nh_utils.F90:323-480)"""
+    dims = dict(nx=200, ny=24, km=km) if km >= 79 else dict(nx=37, ny=13, km=km)     # ragged last 16-column block
+    N.check_riem_lds_bits(prod, **dims)

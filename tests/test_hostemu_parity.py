@@ -1111,3 +1111,10 @@ def test_face_group(emu, hydrostatic):
     PC.check_face_group(emu, hydrostatic=hydrostatic)
     if not hydrostatic:
         PC.check_face_group(emu, npx=17, npz=6, n_split=3, flags=dict(do_vort_damp=True, vtdm4=0.06, nord=3, d_con=1.0))
+
+
+@pytest.mark.parametrize("dims", [dict(), dict(nx=37, ny=13, km=32), dict(nx=20, ny=5, km=79), dict(nx=18, ny=3, km=127), dict(km=5),
+                                  dict(km=16), dict(km=2)])
+def test_riem_lds_bit_identical_to_the_slab_kernels(emu, dims):
+    """RiemFast<CG, true> (the default of the dry SIM1 solvers): the same bits as the slab kernels in every output"""
+    N.check_riem_lds_bits(emu, **dims)

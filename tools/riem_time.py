@@ -24,8 +24,14 @@ def main():
     s = nh_state(bd, km)
     cn = nh_consts(PTOP)
     rng = np.random.default_rng(3)
-    for fast in (False, True):
+    for mode, fast, a_imp in (("slab kernels", False, 1.0), ("lds (bit-identical)", False, 1.0), ("tolerance mode", True, 1.0),
+                              ("slab kernels, SIM a_imp 0.75", False, 0.75), ("lds, SIM a_imp 0.75", False, 0.75))[int(os.environ.get("RT_FIRST", 0)):int(os.environ.get("RT_LAST", 5))]:
+        cn = nh_consts(PTOP, a_imp=a_imp)
+        os.environ.pop("FV3_MI355X_RIEM_LDS", None)
+        if mode.startswith("slab"):
+            os.environ["FV3_MI355X_RIEM_LDS"] = "0"
         ctx = L.Context(g, km)
+        os.environ.pop("FV3_MI355X_RIEM_LDS", None)
         ctx.set_fast(fast)
         d = dict(zs=ctx.from_host(s["zs"]), hs=ctx.from_host(np.asfortranarray(s["zs"] * GRAV)), w=ctx.from_host(s["w"]), pt=ctx.from_host(s["pt"]),
                  delp=ctx.from_host(s["delp"]), zh=ctx.from_host(s["zh"]), gz=ctx.from_host(s["zh"]), delz=ctx.zeros("CC", km),
@@ -53,7 +59,7 @@ def main():
                 t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
             out[name] = min(ts) * 1e3
         cells = nx * nx * km
-        print("fast" if fast else "parity", {k: round(v, 4) for k, v in out.items()},
+        print(mode, {k: round(v, 4) for k, v in out.items()},
               "frac", round(cells * 72 / (out["riem_solver3"] * 1e-3) / 8e12, 3), round(cells * 48 / (out["riem_solver_c"] * 1e-3) / 8e12, 3),
               "finite", bool(np.isfinite(d["zh"].download()).all()))
         ctx.close()
