@@ -671,6 +671,8 @@ extern "C" int fv3_sync(fv3_ctx *c) {
 
 extern "C" int fv3_grid_upload(fv3_ctx *c, const fv3_grid_host *h) {
   if (!c || !h) return fail("fv3_grid_upload: null argument");
+  c->host_area.clear();   // fv3_prt_maxmin's copies of the area and of g_sum's global area belong to the grid that goes away
+  c->global_area = 0.;
   Grid &g = c->g;
   const size_t nA = g.nA(), nU = g.nU(), nV = g.nV(), nB = g.nB();
   struct Item { const double *src; const double **dst; size_t n; };
@@ -940,6 +942,8 @@ extern "C" int fv3_grid_upload_cubed(fv3_ctx *c, const fv3_grid_cubed *h) {
   if (!c || !h) return fail("fv3_grid_upload_cubed: null argument");
   if (!is_cubed(c)) return fail("fv3_grid_upload_cubed: the context is not a cubed-sphere face (grid_type < 3)");
   if (!h->edge_w || !h->edge_e || !h->edge_s || !h->edge_n || !h->rsina) return fail("fv3_grid_upload_cubed: null array");
+  c->host_area.clear();
+  c->global_area = 0.;
   const Grid &g = c->g;
   const size_t ne = (size_t)g.npx, nr = (size_t)(g.nx + 1) * (g.ny + 1);
   const size_t nr8 = (nr + 7) & ~(size_t)7;
@@ -1374,7 +1378,7 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
 }
 
 template <int TI, int TJ>
-static int run_a2b(fv3_ctx *c, const A2BCorners<TI, TJ> &kf, int nlev_max);
+static int run_a2b(fv3_ctx *c, const A2BCorners<TI, TJ> &kf, int nlev_max, const char *who = nullptr);
 // d_sw on a cubed-sphere face (cubed_dsw.h); scratch 8..20
 static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   const Grid &g = c->g;
@@ -1594,7 +1598,7 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
         for (int f = 0; f < 4; f++) { kc.in[f] = nullptr; kc.out[f] = nullptr; kc.nlev[f] = 0; kc.scale[f] = 1.0; kc.top[f] = 0.; }
         kc.in[0] = s.wk; kc.out[0] = s.smag; kc.nlev[0] = npz;
         kc.nf = 1; kc.override_mask = 0;
-        RT((run_a2b<32, 16>(c, kc, npz)));
+        RT((run_a2b<32, 16>(c, kc, npz, "dswc_smag")));   // inside d_sw: the reference's D_SW timer, not PG_D
       } else {
         const PassRegion r{0, rg.klist, rg.nk};
         RT(launch_pass(c, "dswc_smag", 1, npx, 1, npy, r, A2bCubedPa{t}));
@@ -2238,8 +2242,7 @@ extern "C" long fv3_cube_table(int npx, int ng, int kind, int member, int face, 
 }
 static int cube_plan_get(fv3_ctx *c, int face, int kind, CubePlanDev **out) {
   if (c->cube_face >= 0 && c->cube_face != face) return fail("fv3_cube_halo: the context was planned as face %d", c->cube_face);
-  c->cube_face = face;
-  if (c->cube_plan[kind]) { *out = c->cube_plan[kind]; return 0; }
+  if (c->cube_face == face && c->cube_plan[kind]) { *out = c->cube_plan[kind]; return 0; }
   const CubeTopo topo(c->g.npx, NG);
   const int nm = CubeTopo::members(kind);
   std::vector<int> sm, ss, sseg, rm, rseg;
@@ -2277,10 +2280,21 @@ static int cube_plan_get(fv3_ctx *c, int face, int kind, CubePlanDev **out) {
     if (rt_malloc((void **)d, sizeof(long) * h.size())) return 1;
     return rtf_h2d(*d, h.data(), sizeof(long) * h.size(), c->stream);
   };
-  if (up_i(&p->s_member, sm) || up_i(&p->s_sign, ss) || up_i(&p->s_seg, sseg) || up_l(&p->s_idx, si) || up_i(&p->r_member, rm) ||
-      up_i(&p->r_seg, rseg) || up_l(&p->r_idx, ri))
-    return fail("fv3_cube_halo: out of device memory");
-  RT(rtf_sync(c->stream));
+  // built into a plan of its own: a failure frees what was uploaded and leaves the context as it was (not pinned to `face`)
+  p->s_member = p->s_sign = p->s_seg = p->r_member = p->r_seg = nullptr;
+  p->s_idx = p->r_idx = nullptr;
+  int rc_up = up_i(&p->s_member, sm) || up_i(&p->s_sign, ss) || up_i(&p->s_seg, sseg) || up_l(&p->s_idx, si) ||
+              up_i(&p->r_member, rm) || up_i(&p->r_seg, rseg) || up_l(&p->r_idx, ri);
+  if (!rc_up) rc_up = rtf_sync(c->stream);
+  if (rc_up) {
+    int *ip[5] = {p->s_member, p->s_sign, p->s_seg, p->r_member, p->r_seg};
+    for (int *q : ip) if (q) rt_free(q);
+    if (p->s_idx) rt_free(p->s_idx);
+    if (p->r_idx) rt_free(p->r_idx);
+    delete p;
+    return fail("fv3_cube_halo: the exchange plan could not be uploaded (out of device memory?)");
+  }
+  c->cube_face = face;
   c->cube_plan[kind] = p;
   *out = p;
   return 0;
@@ -2562,24 +2576,29 @@ extern "C" int fv3_ordered_sum(fv3_ctx *c, const double *values, size_t n, doubl
 extern "C" int fv3_prt_maxmin(fv3_ctx *c, const double *q, int nk, double fac, double out[3]) {
   if (!c || !c->grid_ready || !q || nk < 1 || !out) return fail("fv3_prt_maxmin: bad context/arguments");
   const Grid &g = c->g;
-  double *d = nullptr;
-  RT(rt_malloc((void **)&d, sizeof(double) * 2 * nk));
-  LevelMinMax kf{g, q, d};
-  RT(launch_p(c, "prt_maxmin", Dim3{1, 1, (unsigned)nk}, 2 * kNT, kf));
   std::vector<double> mm(2 * nk), lev(g.nA());
-  RT(rtf_d2h(mm.data(), d, sizeof(double) * 2 * nk, c->stream));
-  RT(rtf_d2h(lev.data(), q + (size_t)(nk - 1) * g.nA(), sizeof(double) * g.nA(), c->stream));
-  if (c->host_area.empty()) {
-    c->host_area.resize(g.nA());
-    RT(rtf_d2h(c->host_area.data(), g.area, sizeof(double) * g.nA(), c->stream));
+  {
+    double *d = nullptr;
+    RT(rt_malloc((void **)&d, sizeof(double) * 2 * nk));
+    struct Free { double *p; ~Free() { rt_free(p); } } free_d{d};   // on every way out
+    LevelMinMax kf{g, q, d};
+    RT(launch_p(c, "prt_maxmin", Dim3{1, 1, (unsigned)nk}, 2 * kNT, kf));
+    RT(rtf_d2h(mm.data(), d, sizeof(double) * 2 * nk, c->stream));
+    RT(rtf_d2h(lev.data(), q + (size_t)(nk - 1) * g.nA(), sizeof(double) * g.nA(), c->stream));
+    if (c->host_area.empty()) {   // (forgotten by fv3_grid_upload / fv3_grid_upload_cubed: a new grid brings a new area)
+      c->host_area.resize(g.nA());
+      RT(rtf_d2h(c->host_area.data(), g.area, sizeof(double) * g.nA(), c->stream));
+    }
+    RT(rtf_sync(c->stream));
   }
-  RT(rtf_sync(c->stream));
-  rt_free(d);
   double qmin = mm[0], qmax = mm[1];
   for (int k = 1; k < nk; k++) {
     qmin = mm[2 * k] < qmin ? mm[2 * k] : qmin;
     qmax = mm[2 * k + 1] > qmax ? mm[2 * k + 1] : qmax;
   }
+  // gmean as the reference's g_sum forms it: over the area the ranks of this context's communicator hold together.  A rank that holds
+  // several faces as separate contexts WITHOUT a communicator (six contexts on one GPU) gets the mean over the one face of `c`: the
+  // caller combines the faces (area-weighted; the faces of the gnomonic cube have equal areas).
   if (c->global_area == 0.) {   // g_sum's saved global_area: mpp_global_sum(area, BITWISE_EFP_SUM)
     std::vector<double> ar((size_t)g.nx * g.ny);
     for (int j = g.js; j <= g.je; j++)
@@ -3116,8 +3135,18 @@ extern "C" int fv3_zh_from_delz(fv3_ctx *c, const double *zs, const double *delz
 
 // a2b_ord4 of up to four fields: the LDS-tile kernel (grid_type >= 3) or the cubed-sphere passes (scratch 0..7)
 template <int TI, int TJ>
-static int run_a2b(fv3_ctx *c, const A2BCorners<TI, TJ> &kf, int nlev_max) {
+static int run_a2b(fv3_ctx *c, const A2BCorners<TI, TJ> &kf, int nlev_max, const char *who) {
   const Grid &g = c->g;
+  // the label follows the caller (reference_timer maps labels to the reference's timers by prefix)
+  const std::string l0 = who ? std::string(who) : std::string("a2b_corners"), la = who ? l0 + "_pa" : std::string("a2bc_pa"),
+                    lb = who ? l0 + "_pb" : std::string("a2bc_pb");
+  static std::vector<std::string> keep;   // labels outlive the launch (profiling records point at them)
+  auto lab = [&](const std::string &x) -> const char * {
+    for (const auto &k : keep) if (k == x) return k.c_str();
+    keep.reserve(64);
+    keep.push_back(x);
+    return keep.back().c_str();
+  };
   if (is_cubed(c)) {
     if (!c->cg.ready) return fail("a2b_ord4: cubed-sphere context without fv3_grid_upload_cubed");
     A2bCubedState s;
@@ -3141,17 +3170,17 @@ static int run_a2b(fv3_ctx *c, const A2BCorners<TI, TJ> &kf, int nlev_max) {
       grid.z = (unsigned)nlev_max;
       A2BCorners<TI, TJ> kc = kf;
       kc.sum_form = 1;
-      RT(launch_p(c, "a2b_corners", grid, A2BCorners<TI, TJ>::lds_doubles, kc));
+      RT(launch_p(c, lab(l0), grid, A2BCorners<TI, TJ>::lds_doubles, kc));
     }
-    RT(launch_pass(c, "a2bc_pa", 1, g.npx, 1, g.npy, PassRegion{hyb ? wa + 3 : 0, nullptr, nlev_max}, A2bCubedPa{s}));
-    RT(launch_pass(c, "a2bc_pb", 1, g.npx, 1, g.npy, PassRegion{hyb ? wa : 0, nullptr, nlev_max}, A2bCubedPb{s}));
+    RT(launch_pass(c, lab(la), 1, g.npx, 1, g.npy, PassRegion{hyb ? wa + 3 : 0, nullptr, nlev_max}, A2bCubedPa{s}));
+    RT(launch_pass(c, lab(lb), 1, g.npx, 1, g.npy, PassRegion{hyb ? wa : 0, nullptr, nlev_max}, A2bCubedPb{s}));
     return 0;
   }
   Dim3 grid;
   grid.x = (unsigned)((g.nx + 1 + TI - 1) / TI);
   grid.y = (unsigned)((g.ny + 1 + TJ - 1) / TJ);
   grid.z = (unsigned)nlev_max;
-  return launch_p(c, "a2b_corners", grid, A2BCorners<TI, TJ>::lds_doubles, kf);
+  return launch_p(c, lab(l0), grid, A2BCorners<TI, TJ>::lds_doubles, kf);
 }
 
 static int nh_p_grad_impl(fv3_ctx *c, double *u, double *v, const double *pp, const double *gz, double gz_scale, const double *delp,

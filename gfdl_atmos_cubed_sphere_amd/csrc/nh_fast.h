@@ -623,7 +623,7 @@ struct RiemFast {
     const double t1g = SIM ? 2. * ((alpha * dt) * (alpha * dt)) : 2. * dt * dt, rdt = 1. / dt;
     constexpr double r3 = 1. / 3.;
     vd dmr[kWvState][kFL], ptv[kWvState][kFL], w1[kWvState][kFL], zv[kWvState][kFL + 1];
-    vd keep_dm[kWvState][kFL], keep_pm2[kWvState][kFL], keep_grat[kWvState][kFL], keep_bb[kWvState][kFL], keep_w2[kWvState][kFL];
+    vd keep_pm2[kWvState][kFL], keep_grat[kWvState][kFL], keep_w2[kWvState][kFL];
     vd keep_pem[kWvState][kFL + 1], keep_lnp[kWvState][kFL + 1], keep_ppt[kWvState][SIM ? kFL + 1 : 1];
     const int nrounds = (probe & 1) ? 1 : km / kFL + 1;   // EX: rounds after which the hand-overs of a sequential sweep over km levels are the sweep's own
     // ---- inputs: the four fields at once (their loads are in flight together), one barrier ----
@@ -767,12 +767,19 @@ struct RiemFast {
         }
       }
       // what the second half needs stays in the per-wavefront state (registers in the product build) across the barriers of EX
+      // (dm and bb are re-formed from delp and grat with their own expressions; in EX the logarithms wait in the fourth LDS buffer,
+      // which the w pass does not use: 50 registers less across the barriers, at two wavefronts per SIMD they were spilled)
       for (int q = 0; q < kFL; q++) {
-        keep_dm[s][q] = dm[q]; keep_pm2[s][q] = pm2[q]; keep_grat[s][q] = grat[q]; keep_bb[s][q] = bb[q];
+        keep_pm2[s][q] = pm2[q]; keep_grat[s][q] = grat[q];
       }
       for (int q = 0; q <= kFL; q++) keep_pem[s][q] = pemv[q];
-      if (!CG)
-        for (int q = 0; q <= kFL; q++) keep_lnp[s][q] = lnp[q];
+      if (!CG) {
+        if constexpr (EX) {
+          for (int q = 0; q < kFL; q++) vlds_st(B3, c0, q, lnp[q]);
+        } else {
+          for (int q = 0; q <= kFL; q++) keep_lnp[s][q] = lnp[q];
+        }
+      }
       if constexpr (SIM) {   // pp at the layer's top interface (0 at the model top) and at its bottom interface
         keep_ppt[s][0] = row_shr<1>(X[kFL - 1], 0.0);
         for (int q = 0; q < kFL; q++) keep_ppt[s][q + 1] = X[q];
@@ -792,15 +799,23 @@ struct RiemFast {
         last[q] = vlevel_eq(q, km - 1);
       }
       for (int q = 0; q < kFL; q++) {
-        dm[q] = keep_dm[s][q]; pm2[q] = keep_pm2[s][q]; grat[q] = keep_grat[s][q]; bb[q] = keep_bb[s][q];
+        pm2[q] = keep_pm2[s][q]; grat[q] = keep_grat[s][q];
+        dm[q] = dmr[s][q] * rgrav;
+        bb[q] = vsel(real[q], vsel(last[q], vd(2.0), 2. * (1. + grat[q])), vd(1.0));
         if constexpr (EX)
           w2[q] = vsel(real[q], vlds_ld(B2, c0, q), vd(0.0));
         else
           w2[q] = keep_w2[s][q];
       }
       for (int q = 0; q <= kFL; q++) pemv[q] = keep_pem[s][q];
-      if (!CG)
-        for (int q = 0; q <= kFL; q++) lnp[q] = keep_lnp[s][q];
+      if (!CG) {
+        if constexpr (EX) {
+          for (int q = 0; q < kFL; q++) lnp[q] = vlds_ld(B3, c0, q);
+          lnp[kFL] = row_shl<1>(lnp[0], 0.0);
+        } else {
+          for (int q = 0; q <= kFL; q++) lnp[q] = keep_lnp[s][q];
+        }
+      }
       // ---- pe2 at the interfaces (:1373-1380): exclusive sum of dm2 (w2 - w1) / dt ----
       vd pe2[kFL + 2];
       {

@@ -274,8 +274,10 @@ class CubeHaloNative:
     def finish(self):
         from .lib import cube_halo_complete
         if self._pending:
-            cube_halo_complete(self.ctxs)
-            self._pending = False
+            try:
+                cube_halo_complete(self.ctxs)
+            finally:
+                self._pending = False      # also when the library refuses: it drops its pending group itself
 
     def update(self, kind: str, fields, vector: bool = True):
         """the interface of CubeHalo.update: 'A' / 'B': list of per-context arrays; pairs: (list, list)"""

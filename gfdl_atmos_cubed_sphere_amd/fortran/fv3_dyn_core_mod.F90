@@ -39,6 +39,16 @@ module fv3_arrays_compat_mod
     real(c_double) :: da_min = 0.d0, da_min_c = 0.d0
     integer :: grid_type = 4
     logical :: nested = .false., bounded_domain = .false., regional = .false., stretched_grid = .false.
+    ! the members a cubed-sphere tile adds (grid_type < 3), with the reference's shapes (fv_arrays.F90:1778-1854)
+    real(c_double), allocatable :: grid(:,:,:), agrid(:,:,:)                 ! (isd:ied+1, jsd:jed+1, 2), (isd:ied, jsd:jed, 2): lon, lat
+    real(c_double), allocatable :: edge_s(:), edge_n(:), edge_w(:), edge_e(:)   ! (npx), (npx), (npy), (npy)
+    real(c_double), allocatable :: rsina(:,:)                                ! (is:ie+1, js:je+1)
+    real(c_double), allocatable, dimension(:,:) :: a11, a12, a21, a22        ! (is-1:ie+1, js-1:je+1)
+    real(c_double), allocatable, dimension(:,:,:) :: ec1, ec2                ! (3, isd:ied, jsd:jed)
+    real(c_double), allocatable, dimension(:,:,:) :: en1, en2                ! (3, is:ie, js:je+1), (3, is:ie+1, js:je)
+    ! NOT a member of the reference's type: the extrap_corner factors of a2b_ord4, which the reference forms from grid / agrid at
+    ! every call (a2b_edge.F90:83-112, :452-462).  Left at its default they are formed from grid / agrid here, once.
+    real(c_double) :: corner_f(12) = -1.d0
   end type
 
   type fv_flags_type                          ! fv_arrays.F90:207-906 (the members the substep loop reads; the reference's defaults)
@@ -73,8 +83,14 @@ module fv3_arrays_compat_mod
     integer :: id_divg = 0, id_ws = 0
   end type
 
-  type domain2d                               ! mpp_domains_mod: opaque here -- one rank of a doubly periodic domain
-    integer :: pe = 0
+  !> mpp_domains_mod's domain2d is opaque to the dynamical core; what this path needs of it is what mpp_define_mosaic was given
+  !> (tools/fv_mp_mod.F90:498-546): which tile this call is for, which PE holds every tile, and -- with several PEs -- the
+  !> id of the exchange's communicator (rank 0's fv3_comm_get_unique_id, distributed by the caller as it distributes anything else).
+  type domain2d
+    integer :: pe = 0, npes = 1
+    integer :: tile = 1                        ! 1 .. 6
+    integer :: face_rank(6) = 0                ! the PE that holds tile n
+    integer(c_signed_char) :: comm_id(128) = 0_c_signed_char
   end type
 
   type fv_atmos_type                          ! fv_arrays.F90:1270: only its presence in fv_dynamics' list (parent_grid) matters here
@@ -96,6 +112,7 @@ module fv3_dyn_core_mod
   use fv3_arrays_compat_mod
   use fv3_mi355x_mod
   use fv3_host_mod
+  use fv3_sphere_mod
   implicit none
   private
   public :: dyn_core, dyn_core_end, fv_dynamics, fv_dynamics_end
@@ -104,6 +121,13 @@ module fv3_dyn_core_mod
   logical, save :: bound = .false.
   type(fv3_atmos), save :: atf          ! fv_dynamics keeps a context of its own (it carries the tracers)
   logical, save :: boundf = .false.
+  ! the cubed sphere (grid_type < 3): one context per tile this process holds (fv3_sphere_mod); the host arrays of every tile's call
+  type tile_arrays
+    type(c_ptr) :: u, v, w, delz, pt, delp, q, ps, pe, pk, peln, pkz, omga, ua, va, uc, vc, mfx, mfy, cx, cy
+  end type
+  type(fv3_sphere), save :: sps
+  type(tile_arrays), save :: tps(6)
+  logical, save :: bound_s(6) = .false., comm_s = .false.
 
 contains
 
@@ -308,10 +332,11 @@ contains
     type(fv_grid_bounds_type), intent(in) :: bd
     real(c_double), intent(inout), dimension(bd%isd:, bd%jsd:, 1:) :: u0, v0
     real(c_double), intent(inout), target :: u(bd%isd:bd%ied, bd%jsd:bd%jed+1, npz), v(bd%isd:bd%ied+1, bd%jsd:bd%jed, npz)
-    real(c_double), intent(inout) :: w(bd%isd:, bd%jsd:, 1:)
+    real(c_double), intent(inout), target :: w(bd%isd:, bd%jsd:, 1:)
     real(c_double), intent(inout), target :: pt(bd%isd:bd%ied, bd%jsd:bd%jed, npz), delp(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
     real(c_double), intent(inout), target :: q(bd%isd:bd%ied, bd%jsd:bd%jed, npz, ncnst)
-    real(c_double), intent(inout) :: delz(bd%is:, bd%js:, 1:), ze0(bd%is:, bd%js:, 1:)
+    real(c_double), intent(inout), target :: delz(bd%is:, bd%js:, 1:)
+    real(c_double), intent(inout) :: ze0(bd%is:, bd%js:, 1:)
     real(c_double), intent(inout) :: diss_est(bd%isd:bd%ied, bd%jsd:bd%jed, npz), heat_source(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
     real(c_double), intent(inout), target :: ps(bd%isd:bd%ied, bd%jsd:bd%jed)
     real(c_double), intent(inout), target :: pe(bd%is-1:bd%ie+1, npz+1, bd%js-1:bd%je+1)
@@ -340,11 +365,15 @@ contains
 
     if (neststruct%nested .or. gridstruct%nested .or. gridstruct%regional .or. gridstruct%bounded_domain) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): nested / regional domains are not built'
-    if (gridstruct%grid_type /= 4) error stop 'fv_dynamics (fv3_dyn_core_mod): grid_type = 4 only through this wrapper'
     if (thermostruct%use_cond .or. thermostruct%moist_kappa) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond / moist_kappa are not carried through this wrapper'
-    if (abs(consv_te) > 0.001d0) error stop 'fv_dynamics (fv3_dyn_core_mod): consv_te is carried by the Python host (FvDynamics), not here'
-    if (flagstruct%tau > 0.d0) error stop 'fv_dynamics (fv3_dyn_core_mod): tau > 0 (Rayleigh damping) is carried by the Python host, not here'
+    if (gridstruct%grid_type < 3) then
+      call fv_dynamics_sphere()
+      return
+    end if
+    if (gridstruct%grid_type /= 4) error stop 'fv_dynamics (fv3_dyn_core_mod): grid_type = 3 is not built'
+    if (abs(consv_te) > 0.001d0) error stop 'fv_dynamics (fv3_dyn_core_mod): consv_te on a doubly periodic domain is carried by the Python host (FvDynamics), not here'
+    if (flagstruct%tau > 0.d0) error stop 'fv_dynamics (fv3_dyn_core_mod): tau > 0 on a doubly periodic domain (Rayleigh_Friction) is carried by the Python host, not here'
     if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%do_diss_est .or. flagstruct%beta < 0.d0) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / do_diss_est / beta < 0 are not built'
     if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
@@ -421,6 +450,144 @@ contains
       call fv3_check(fv3_memcpy_d2h(atf%ctx, h, d, n * 8_c_size_t), 'fv3_memcpy_d2h')
     end subroutine
 
+    !> grid_type < 3: a tile of the cubed sphere.  The reference calls fv_dynamics once per tile a PE holds -- with one tile per PE
+    !> that is one call per PE, all PEs at the same time, and the halo updates inside meet in mpp_update_domains.  Here the tiles one
+    !> process holds (domain%face_rank) are given one call after the other, and the exchanges need all of them: every call binds
+    !> (first time) and uploads its tile; the call of the LAST tile this process holds runs the step for all of them -- compute_total_
+    !> energy, theta_v, Rayleigh_Super, the k_split loop with the cube-edge exchange behind fv3_cube_halo_* (RCCL between processes),
+    !> the energy fixer, cubed_to_latlon: fv3_sphere_fv_dynamics_call -- and writes the results into the arrays of every tile's call.
+    !> Those arrays are the model's state (Atm(n)%u ...): contiguous, with the reference's extents, alive until that last call.
+    subroutine fv_dynamics_sphere()
+      type(fv3_domain) :: dom
+      type(fv3_grid_host) :: gh
+      type(fv3_grid_cubed) :: gc
+      type(fv3_flags) :: fl
+      integer :: slot, nloc, t, sl
+      real(c_double), allocatable, target, save :: a4(:,:,:,:), ecp(:,:,:,:,:), en1p(:,:,:,:), en2p(:,:,:,:)
+      if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%do_diss_est .or. flagstruct%beta < 0.d0) &
+        error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / do_diss_est / beta < 0 are not built'
+      if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
+      if (domain%tile < 1 .or. domain%tile > 6) error stop 'fv_dynamics (fv3_dyn_core_mod): domain%tile must be 1 .. 6'
+      if (bd%is /= 1 .or. bd%js /= 1 .or. bd%ie /= npx - 1 .or. bd%je /= npy - 1) &
+        error stop 'fv_dynamics (fv3_dyn_core_mod): one whole tile per context (layout 1 x 1 per tile)'
+      nloc = count(domain%face_rank == domain%pe)
+      slot = count(domain%face_rank(1:domain%tile) == domain%pe)
+      if (domain%face_rank(domain%tile) /= domain%pe) error stop 'fv_dynamics (fv3_dyn_core_mod): this PE does not hold domain%tile'
+      nx = bd%ie - bd%is + 1; ny = bd%je - bd%js + 1
+      nk = int(npz, c_size_t); nk1 = nk + 1
+      if (.not. hydrostatic) then
+        if (.not. (is_contiguous(w) .and. is_contiguous(delz)) .or. size(w, 1) /= nx + 6 .or. size(w, 2) /= ny + 6 .or. &
+            size(w, 3) /= npz .or. size(delz, 1) /= nx .or. size(delz, 2) /= ny .or. size(delz, 3) /= npz) &
+          error stop 'fv_dynamics (fv3_dyn_core_mod): w / delz must be the whole contiguous arrays of the tile'
+      end if
+      if (.not. bound_s(slot)) then
+        dom%is = bd%is; dom%ie = bd%ie; dom%js = bd%js; dom%je = bd%je; dom%ng = 3
+        dom%npx = npx; dom%npy = npy; dom%npz = npz; dom%grid_type = gridstruct%grid_type
+        dom%do_diss_est = 0; dom%prevent_diss_cooling = merge(1, 0, flagstruct%prevent_diss_cooling)
+        dom%stretched_grid = merge(1, 0, gridstruct%stretched_grid); dom%lim_fac = flagstruct%lim_fac
+        call grid_host_of(gridstruct, gh)
+        ! the cubed members in the library's layouts: a11 .. a22 on the A layout, the unit vectors with the component last
+        if (.not. allocated(a4)) then
+          allocate(a4(bd%isd:bd%ied, bd%jsd:bd%jed, 4, 6), ecp(bd%isd:bd%ied, bd%jsd:bd%jed, 3, 2, 6))
+          allocate(en1p(bd%is:bd%ie, bd%js:bd%je+1, 3, 6), en2p(bd%is:bd%ie+1, bd%js:bd%je, 3, 6))
+          a4 = 0.d0
+        end if
+        a4(bd%is-1:bd%ie+1, bd%js-1:bd%je+1, 1, slot) = gridstruct%a11; a4(bd%is-1:bd%ie+1, bd%js-1:bd%je+1, 2, slot) = gridstruct%a12
+        a4(bd%is-1:bd%ie+1, bd%js-1:bd%je+1, 3, slot) = gridstruct%a21; a4(bd%is-1:bd%ie+1, bd%js-1:bd%je+1, 4, slot) = gridstruct%a22
+        do t = 1, 3
+          ecp(:, :, t, 1, slot) = gridstruct%ec1(t, :, :); ecp(:, :, t, 2, slot) = gridstruct%ec2(t, :, :)
+          en1p(:, :, t, slot) = gridstruct%en1(t, :, :);   en2p(:, :, t, slot) = gridstruct%en2(t, :, :)
+        end do
+        gc%edge_w = c_loc(gridstruct%edge_w); gc%edge_e = c_loc(gridstruct%edge_e)
+        gc%edge_s = c_loc(gridstruct%edge_s); gc%edge_n = c_loc(gridstruct%edge_n)
+        gc%rsina = c_loc(gridstruct%rsina)
+        if (gridstruct%corner_f(1) < 0.d0) call corner_factors(gridstruct, bd, npx, npy)
+        gc%corner_f = gridstruct%corner_f
+        gc%a11 = c_loc(a4(bd%isd, bd%jsd, 1, slot)); gc%a12 = c_loc(a4(bd%isd, bd%jsd, 2, slot))
+        gc%a21 = c_loc(a4(bd%isd, bd%jsd, 3, slot)); gc%a22 = c_loc(a4(bd%isd, bd%jsd, 4, slot))
+        gc%ec1 = c_loc(ecp(bd%isd, bd%jsd, 1, 1, slot)); gc%ec2 = c_loc(ecp(bd%isd, bd%jsd, 1, 2, slot))
+        gc%en1 = c_loc(en1p(bd%is, bd%js, 1, slot));     gc%en2 = c_loc(en2p(bd%is, bd%js, 1, slot))
+        call flags_of(flagstruct, fl)
+        fl%n_split = n_split; fl%q_split = q_split; fl%ptop = ptop; fl%akap = kappa; fl%cp_air = cp_air
+        fl%hydrostatic = hydrostatic; fl%fill = fill; fl%r_vir = zvir
+        call fv3_sphere_init_face(sps, slot, domain%tile - 1, dom, gh, gc, nq_tot, fl, ak, bk)
+        bound_s(slot) = .true.
+      end if
+      associate (at => sps%f(slot))
+        if (at%npz /= npz .or. at%nq /= nq_tot .or. at%ie /= bd%ie .or. at%je /= bd%je) &
+          error stop 'fv_dynamics (fv3_dyn_core_mod): the domain changed between calls'
+        at%fl%n_split = n_split; at%fl%q_split = q_split
+        call puts(at, at%u, c_loc(u), at%nU*nk);        call puts(at, at%v, c_loc(v), at%nV*nk)
+        call puts(at, at%delp, c_loc(delp), at%nA*nk);  call puts(at, at%pt, c_loc(pt), at%nA*nk)
+        call puts(at, at%phis, c_loc(phis), at%nA)
+        allocate(zs(bd%isd:bd%ied, bd%jsd:bd%jed))
+        zs = phis * (1.d0 / at%fl%grav)
+        call puts(at, at%zs, c_loc(zs), at%nA)
+        if (.not. hydrostatic) then
+          call puts(at, at%w, c_loc(w), at%nA*nk);      call puts(at, at%delz, c_loc(delz), at%nCC*nk)
+        end if
+        if (nq_tot > 0) call puts(at, at%q, c_loc(q), at%nA*nk*nq_tot)
+        call puts(at, at%pkz, c_loc(pkz), at%nCC*nk);   call puts(at, at%pk, c_loc(pk), at%nCC*nk1)
+        call puts(at, at%pe, c_loc(pe), int(nx+2, c_size_t)*nk1*(ny+2)); call puts(at, at%peln, c_loc(peln), at%nCC*nk1)
+        call puts(at, at%omga, c_loc(omga), at%nA*nk)
+        call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
+      end associate
+      tps(slot)%u = c_loc(u); tps(slot)%v = c_loc(v); tps(slot)%pt = c_loc(pt); tps(slot)%delp = c_loc(delp)
+      tps(slot)%w = c_null_ptr; tps(slot)%delz = c_null_ptr
+      if (.not. hydrostatic) then
+        tps(slot)%w = c_loc(w); tps(slot)%delz = c_loc(delz)
+      end if
+      tps(slot)%q = c_loc(q); tps(slot)%ps = c_loc(ps); tps(slot)%pe = c_loc(pe); tps(slot)%pk = c_loc(pk)
+      tps(slot)%peln = c_loc(peln); tps(slot)%pkz = c_loc(pkz); tps(slot)%omga = c_loc(omga)
+      tps(slot)%ua = c_loc(ua); tps(slot)%va = c_loc(va); tps(slot)%uc = c_loc(uc); tps(slot)%vc = c_loc(vc)
+      tps(slot)%mfx = c_loc(mfx); tps(slot)%mfy = c_loc(mfy); tps(slot)%cx = c_loc(cx); tps(slot)%cy = c_loc(cy)
+      if (slot < nloc) return                        ! the step runs in the call of the last tile this process holds
+
+      if (.not. comm_s) then
+        if (domain%npes > 1) then
+          call fv3_sphere_comm(sps, domain%pe, domain%npes, domain%face_rank, domain%comm_id)
+        else
+          call fv3_sphere_comm(sps, 0, 1, domain%face_rank)
+        end if
+        comm_s = .true.
+      end if
+      call fv3_sphere_fv_dynamics_call(sps, bdt, domain%npes, consv_te, flagstruct%tau, flagstruct%rf_cutoff, zvir, &
+                                       flagstruct%c2l_ord, flagstruct%moist_phys, 6.3712d6)         ! constants_mod: radius
+      do sl = 1, nloc
+        associate (at => sps%f(sl), tp => tps(sl))
+          call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
+          call gets(at, tp%u, at%u, at%nU*nk);        call gets(at, tp%v, at%v, at%nV*nk)
+          call gets(at, tp%delp, at%delp, at%nA*nk);  call gets(at, tp%pt, at%pt, at%nA*nk)
+          if (.not. hydrostatic) then
+            call gets(at, tp%w, at%w, at%nA*nk);      call gets(at, tp%delz, at%delz, at%nCC*nk)
+          end if
+          if (nq_tot > 0) call gets(at, tp%q, at%q, at%nA*nk*nq_tot)
+          call gets(at, tp%ps, at%ps, at%nA)
+          call gets(at, tp%pkz, at%pkz, at%nCC*nk);   call gets(at, tp%pk, at%pk, at%nCC*nk1)
+          call gets(at, tp%pe, at%pe, int(nx+2, c_size_t)*nk1*(ny+2)); call gets(at, tp%peln, at%peln, at%nCC*nk1)
+          call gets(at, tp%omga, at%omga, at%nA*nk);  call gets(at, tp%ua, at%ua, at%nA*nk); call gets(at, tp%va, at%va, at%nA*nk)
+          call gets(at, tp%uc, at%uc, at%nV*nk);      call gets(at, tp%vc, at%vc, at%nU*nk)
+          call gets(at, tp%mfx, at%mfx, at%nFX*nk);   call gets(at, tp%mfy, at%mfy, at%nFY*nk)
+          call gets(at, tp%cx, at%cx, at%nCX*nk);     call gets(at, tp%cy, at%cy, at%nCY*nk)
+          call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
+        end associate
+      end do
+    end subroutine
+
+    subroutine puts(a, d, h, n)
+      type(fv3_atmos), intent(in) :: a
+      type(c_ptr), intent(in) :: d, h
+      integer(c_size_t), intent(in) :: n
+      call fv3_check(fv3_memcpy_h2d(a%ctx, d, h, n * 8_c_size_t), 'fv3_memcpy_h2d')
+    end subroutine
+
+    subroutine gets(a, h, d, n)
+      type(fv3_atmos), intent(in) :: a
+      type(c_ptr), intent(in) :: d, h
+      integer(c_size_t), intent(in) :: n
+      call fv3_check(fv3_memcpy_d2h(a%ctx, h, d, n * 8_c_size_t), 'fv3_memcpy_d2h')
+    end subroutine
+
     subroutine bind_context()
       type(fv3_domain) :: dom
       type(fv3_grid_host) :: gh
@@ -441,6 +608,44 @@ contains
   subroutine fv_dynamics_end()
     if (boundf) call fv3_host_final(atf)
     boundf = .false.
+    if (any(bound_s)) call fv3_sphere_final(sps)
+    bound_s = .false.; comm_s = .false.
+  end subroutine
+
+  !> the extrap_corner factors x1 / (x2 - x1) of a2b_ord4 (model/a2b_edge.F90:83-112 for the four corners, extrap_corner :452-462)
+  !> from grid / agrid, with great_circle_dist of fv_grid_utils.F90:2568-2591 (radius 1): corners sw, se, ne, nw, the three
+  !> (inner, outer) cell-centre pairs in the reference's order
+  subroutine corner_factors(gridstruct, bd, npx, npy)
+    type(fv_grid_type), intent(inout) :: gridstruct
+    type(fv_grid_bounds_type), intent(in) :: bd
+    integer, intent(in) :: npx, npy
+    integer :: n
+    n = npx
+    if (npx /= npy) error stop 'corner_factors: npx = npy'
+    gridstruct%corner_f(1)  = fac(1, 1, 1, 1, 2, 2);         gridstruct%corner_f(2)  = fac(1, 1, 0, 1, -1, 2)
+    gridstruct%corner_f(3)  = fac(1, 1, 1, 0, 2, -1)
+    gridstruct%corner_f(4)  = fac(n, 1, n-1, 1, n-2, 2);     gridstruct%corner_f(5)  = fac(n, 1, n-1, 0, n-2, -1)
+    gridstruct%corner_f(6)  = fac(n, 1, n, 1, n+1, 2)
+    gridstruct%corner_f(7)  = fac(n, n, n-1, n-1, n-2, n-2); gridstruct%corner_f(8)  = fac(n, n, n, n-1, n+1, n-2)
+    gridstruct%corner_f(9)  = fac(n, n, n-1, n, n-2, n+1)
+    gridstruct%corner_f(10) = fac(1, n, 1, n-1, 2, n-2);     gridstruct%corner_f(11) = fac(1, n, 0, n-1, -1, n-2)
+    gridstruct%corner_f(12) = fac(1, n, 1, n, 2, n+1)
+  contains
+    real(c_double) function fac(i0, j0, ia, ja, ib, jb)
+      integer, intent(in) :: i0, j0, ia, ja, ib, jb
+      real(c_double) :: x1, x2
+      x1 = gcd(gridstruct%agrid(ia, ja, :), gridstruct%grid(i0, j0, :), .true.)      ! (the members carry the reference's bounds)
+      x2 = gcd(gridstruct%agrid(ib, jb, :), gridstruct%grid(i0, j0, :), .true.)
+      fac = x1 / (x2 - x1)
+    end function
+    real(c_double) function gcd(q1, q2, dummy)
+      real(c_double), intent(in) :: q1(2), q2(2)
+      logical, intent(in) :: dummy
+      real(c_double) :: p1, p2, dp, dl
+      p1 = q1(2); p2 = q2(2)
+      dp = sin(0.5d0 * (p1 - p2)); dl = sin(0.5d0 * (q1(1) - q2(1)))
+      gcd = 2.d0 * asin(sqrt(dp * dp + cos(p1) * cos(p2) * dl * dl))
+    end function
   end subroutine
 
   !> gridstruct members by address -> the host-pointer structure of fv3_grid_upload

@@ -16,6 +16,7 @@ module fv3_sphere_mod
   implicit none
   private
   public :: fv3_sphere, fv3_sphere_init_face, fv3_sphere_comm, fv3_sphere_dyn_core, fv3_sphere_fv_dynamics, fv3_sphere_final
+  public :: fv3_sphere_fv_dynamics_call
   public :: fv3_sphere_halo_a
 
   type fv3_sphere
@@ -26,6 +27,13 @@ module fv3_sphere_mod
     type(c_ptr) :: ctxs(6)
     logical :: adv_pe = .true.              !< en1 / en2 were uploaded (fv3_grid_cubed): omga gets its advective part (dyn_core.F90:1195)
     type(c_ptr) :: grp = c_null_ptr         !< the faces of this rank as one launch group (fv3_group_create), when there are several
+    ! fv3_sphere_fv_dynamics_call: the energy fixer's columns (te0_2d, te_2d, zsum1, zsum0: is:ie x js:je), the areas g_sum weighs
+    ! them with, the profile of the Rayleigh damping (set at the first use, like RF_initialized)
+    type(c_ptr) :: te0(6) = c_null_ptr, te(6) = c_null_ptr, zs1(6) = c_null_ptr, zs0(6) = c_null_ptr
+    real(c_double), allocatable :: area(:,:,:)
+    real(c_double), allocatable :: rf(:), pm(:)
+    integer :: kmax = -1
+    real(c_double) :: e_flux = 0.d0, dtmp = 0.d0
   end type
 
 contains
@@ -44,6 +52,14 @@ contains
     call fv3_check(fv3_grid_upload_cubed(sp%f(slot)%ctx, gc), 'fv3_grid_upload_cubed')
     sp%faces(slot) = int(tile, c_int)
     sp%ctxs(slot) = sp%f(slot)%ctx
+    block      ! area of the compute domain: the weights of g_sum (fv_mapz.F90:736)
+      real(c_double), pointer :: a(:,:)
+      integer :: nx, ny
+      nx = dom%ie - dom%is + 1; ny = dom%je - dom%js + 1
+      if (.not. allocated(sp%area)) allocate(sp%area(nx, ny, 6))
+      call c_f_pointer(gh%area, a, [nx + 6, ny + 6])
+      sp%area(:, :, slot) = a(4:nx+3, 4:ny+3)
+    end block
     sp%nf = max(sp%nf, slot)
     if (.not. c_associated(gc%en1)) sp%adv_pe = .false.
   end subroutine
@@ -361,11 +377,12 @@ contains
 
   !> one dt_atmos: the k_split loop of fv_dynamics (fv_dynamics.F90:460-665) on the faces of this rank.  pt holds theta_v;
   !> last_step makes the final remap return T (fv_mapz.F90:793-821).
-  subroutine fv3_sphere_fv_dynamics(sp, bdt, last_step, nranks)
+  subroutine fv3_sphere_fv_dynamics(sp, bdt, last_step, nranks, last_code)
     type(fv3_sphere), intent(inout) :: sp
     real(c_double), intent(in) :: bdt
     logical, intent(in) :: last_step
     integer, intent(in) :: nranks
+    integer, intent(in), optional :: last_code      !< what the last remap gets as last_step (2: the energy fixer follows, T_v stays)
     type(fv3_remap_params) :: rp
     integer(c_int), allocatable :: kord_tr(:)
     real(c_double) :: mdt
@@ -389,6 +406,7 @@ contains
       call fv3_sphere_dyn_core(sp, mdt, n_map == fl%k_split)                                                      ! :493
       if (nq > 0 .and. .not. fl%inline_q) call sphere_tracer_2d(sp, nranks)                                                                ! :500-533
       rp%last_step = merge(1_c_int, 0_c_int, last_step .and. n_map == fl%k_split)
+      if (present(last_code) .and. last_step .and. n_map == fl%k_split) rp%last_step = int(last_code, c_int)
       do i = 1, sp%nf
         associate (at => sp%f(i))
           if (fl%remap_te) call fv3_check(fv3_set_remap_te(at%ctx, 1_c_int, at%phis, at%dp1), 'set_remap_te')   ! te = dp1, :612
@@ -404,6 +422,189 @@ contains
         end associate
       end do
     end do
+  end subroutine
+
+  !> A whole fv_dynamics call (model/fv_dynamics.F90:79-936 for the adiabatic core) on the faces of this rank; pt holds T (T_v) on
+  !> entry and on return.  In the reference's order: compute_total_energy when consv_te > 0 (:345-355), T -> theta_v with the
+  !> virtual effect zvir q(sphum) (:296-329, :379-399), Rayleigh_Super when tau > 0 (:362-371, :953-1124: the cubed sphere takes
+  !> Rayleigh_Super), the k_split loop (:460-665) whose last remap returns T and -- with |consv_te| > consv_min -- runs the energy
+  !> fixer (fv_mapz.F90:643-772: the column sums on the device, g_sum as the reproducing sum behind fv3_ordered_sum over the faces
+  !> and ranks, dtmp applied by fv3_remap_finish :793-821), cubed_to_latlon (:911).  The same calls in the same order as the Python
+  !> host (fv_dynamics.py FvDynamics.step_from_temperature): the test suite requires identical bits.
+  subroutine fv3_sphere_fv_dynamics_call(sp, bdt, nranks, consv_te, tau, rf_cutoff, zvir, c2l_ord, moist_phys, radius)
+    type(fv3_sphere), intent(inout) :: sp
+    real(c_double), intent(in) :: bdt, consv_te, tau, rf_cutoff, zvir, radius
+    integer, intent(in) :: nranks, c2l_ord
+    logical, intent(in) :: moist_phys
+    real(c_double), parameter :: consv_min = 0.001d0, pi = 3.1415926535897931d0       ! fv_mapz.F90:45; constants_mod
+    type(fv3_flags) :: fl
+    type(fv3_remap_params) :: rp
+    type(c_ptr) :: qv, wp, dzp, pep, pelnp, pkp, zs0p
+    integer :: i, nq, npz, k, mode
+    integer(c_int) :: ihyd
+    logical :: fixer, hyd
+    real(c_double) :: zv, zsum, tesum, dtmp
+    fl = sp%f(1)%fl; nq = sp%f(1)%nq; npz = sp%f(1)%npz; hyd = fl%hydrostatic
+    ihyd = merge(1_c_int, 0_c_int, hyd)
+    call sphere_remap_params(sp, rp)
+    fixer = abs(consv_te) > consv_min
+    if (fixer .and. .not. c_associated(sp%te0(1))) then
+      do i = 1, sp%nf
+        call dmalloc(sp%te0(i), sp%f(i)%nCC); call dmalloc(sp%te(i), sp%f(i)%nCC)
+        call dmalloc(sp%zs1(i), sp%f(i)%nCC); call dmalloc(sp%zs0(i), sp%f(i)%nCC)
+        call dzero(sp%f(i), sp%te0(i), sp%f(i)%nCC); call dzero(sp%f(i), sp%te(i), sp%f(i)%nCC)
+        call dzero(sp%f(i), sp%zs1(i), sp%f(i)%nCC); call dzero(sp%f(i), sp%zs0(i), sp%f(i)%nCC)
+      end do
+    end if
+    do i = 1, sp%nf
+      associate (at => sp%f(i))
+        qv = c_null_ptr; zv = 0.d0
+        if (nq > 0 .and. .not. fl%adiabatic) then
+          qv = at%q; zv = zvir
+        end if
+        wp = at%w; dzp = at%delz; pep = c_null_ptr; pelnp = c_null_ptr
+        if (hyd) then
+          wp = c_null_ptr; dzp = c_null_ptr; pep = at%pe; pelnp = at%peln
+        end if
+        if (consv_te > consv_min) &                                                            ! :345-355 -> te0_2d
+          call fv3_check(fv3_compute_total_energy(at%ctx, rp, merge(1_c_int, 0_c_int, moist_phys), at%u, at%v, wp, dzp, at%pt, &
+                                                  at%delp, at%q, c_null_ptr, pep, pelnp, at%phis, sp%te0(i)), 'compute_total_energy')
+      end associate
+    end do
+    if (tau > 0.d0) then
+      if (sp%kmax < 0) call rayleigh_profile(sp, abs(bdt), tau, rf_cutoff)
+      if (.not. hyd) call to_theta(-1)                      ! pkz from T and delz before the damping (:323-326)
+      if (sp%kmax > 0) then
+        do i = 1, sp%nf
+          associate (at => sp%f(i))
+            wp = at%w
+            if (hyd) wp = c_null_ptr
+            call fv3_check(fv3_c2l(at%ctx, 2_c_int, at%u, at%v, at%ua, at%va), 'c2l')                          ! :1040-1042
+            call fv3_check(fv3_rayleigh_super(at%ctx, int(sp%kmax, c_int), merge(0_c_int, 1_c_int, fl%is_ideal_case), ihyd, &
+                                              fl%cp_air, fl%rdgas, fl%ptop, sp%pm, sp%rf, at%ua, at%va, at%pt, at%u, at%v, wp, &
+                                              c_null_ptr, c_null_ptr), 'rayleigh_super')
+          end associate
+        end do
+      end if
+      call to_theta(1)                                      ! :389-397 with that pkz
+    else
+      mode = 0
+      if (hyd) mode = 1
+      call to_theta(mode)
+    end if
+    if (fixer) then
+      call fv3_sphere_fv_dynamics(sp, bdt, .true., nranks, 2)       ! the last remap leaves T_v for the fixer (last_step = 2)
+      do i = 1, sp%nf
+        associate (at => sp%f(i))
+          wp = at%w; dzp = at%delz; pep = c_null_ptr; pelnp = c_null_ptr; pkp = c_null_ptr; zs0p = c_null_ptr
+          if (hyd) then
+            wp = c_null_ptr; dzp = c_null_ptr; pep = at%pe; pelnp = at%peln; pkp = at%pk; zs0p = sp%zs0(i)
+          end if
+          rp%last_step = 2_c_int
+          call fv3_check(fv3_energy_fixer_sums(at%ctx, rp, merge(1_c_int, 0_c_int, consv_te < 0.d0), at%u, at%v, wp, dzp, at%pt, &
+                                               at%delp, at%q, pep, pelnp, at%phis, at%pkz, pkp, sp%te0(i), sp%te(i), sp%zs1(i), &
+                                               zs0p), 'energy_fixer_sums')
+        end associate
+      end do
+      if (hyd) then
+        zsum = g_sum(sp%zs0)
+      else
+        zsum = g_sum(sp%zs1)
+      end if
+      if (consv_te < 0.d0) then                                                                ! :745-771: a prescribed flux
+        sp%e_flux = consv_te
+        dtmp = sp%e_flux * (fl%grav * bdt * 4.d0 * pi * radius**2) / zsum
+      else
+        tesum = g_sum(sp%te)
+        dtmp = consv_te * tesum
+        sp%e_flux = dtmp / (fl%grav * bdt * 4.d0 * pi * radius**2)
+        dtmp = dtmp / zsum
+      end if
+      sp%dtmp = dtmp
+      do i = 1, sp%nf
+        call fv3_check(fv3_remap_finish(sp%f(i)%ctx, rp, dtmp, sp%f(i)%pt, sp%f(i)%pkz, sp%f(i)%q), 'remap_finish')
+      end do
+    else
+      call fv3_sphere_fv_dynamics(sp, bdt, .true., nranks)
+    end if
+    if (c2l_ord == 4) call exchange(sp, 1, [FV3_CUBE_D + 0], [1], [2], [npz])                  ! fv_grid_utils.F90:2372-2376
+    do i = 1, sp%nf
+      call fv3_check(fv3_c2l(sp%f(i)%ctx, int(c2l_ord, c_int), sp%f(i)%u, sp%f(i)%v, sp%f(i)%ua, sp%f(i)%va), 'c2l')   ! :911
+    end do
+
+  contains
+
+    subroutine to_theta(m)
+      integer, intent(in) :: m
+      integer :: ii
+      type(c_ptr) :: q1, dz
+      real(c_double) :: z1
+      do ii = 1, sp%nf
+        q1 = c_null_ptr; z1 = 0.d0
+        if (nq > 0 .and. .not. fl%adiabatic) then
+          q1 = sp%f(ii)%q; z1 = zvir
+        end if
+        dz = sp%f(ii)%delz
+        if (hyd) dz = c_null_ptr
+        call fv3_check(fv3_pt_to_theta_v(sp%f(ii)%ctx, int(m, c_int), z1, fl%akap, fl%rdgas, fl%grav, sp%f(ii)%pt, sp%f(ii)%delp, &
+                                         dz, q1, sp%f(ii)%pkz), 'pt_to_theta_v')
+      end do
+    end subroutine
+
+    !> g_sum(domain, p, ..., area, 0, reproduce = .true.): sum(p * area) over the faces of this rank and over the ranks, exact
+    function g_sum(cols) result(tot)
+      type(c_ptr), intent(in) :: cols(6)
+      real(c_double) :: tot
+      real(c_double), allocatable, target :: h(:,:), vals(:)
+      integer :: ii, nx, ny
+      nx = sp%f(1)%nx; ny = sp%f(1)%ny
+      allocate(h(nx, ny), vals(nx * ny * sp%nf))
+      do ii = 1, sp%nf
+        call fv3_check(fv3_memcpy_d2h(sp%f(ii)%ctx, c_loc(h), cols(ii), sp%f(ii)%nCC * 8_c_size_t), 'd2h')
+        call fv3_check(fv3_sync(sp%f(ii)%ctx), 'sync')
+        vals((ii-1)*nx*ny + 1 : ii*nx*ny) = reshape(h * sp%area(:, :, ii), [nx * ny])
+      end do
+      call fv3_check(fv3_ordered_sum(sp%ctxs(1), vals, int(size(vals), c_size_t), tot), 'ordered_sum')
+    end function
+  end subroutine
+
+  !> rf(k), kmax of Rayleigh_Super / Rayleigh_Friction (fv_dynamics.F90:1016-1036, :1169-1182) with pfull of :254-262 (p_ref = 1e5)
+  subroutine rayleigh_profile(sp, dt, tau, rf_cutoff)
+    type(fv3_sphere), intent(inout) :: sp
+    real(c_double), intent(in) :: dt, tau, rf_cutoff
+    real(c_double), parameter :: pi = 3.1415926535897931d0
+    real(c_double) :: ph1, ph2, pm
+    integer :: k, npz
+    npz = sp%f(1)%npz
+    if (allocated(sp%rf)) deallocate(sp%rf, sp%pm)
+    allocate(sp%rf(npz), sp%pm(npz)); sp%rf = 0.d0; sp%kmax = 0
+    do k = 1, npz
+      ph1 = sp%f(1)%ak(k) + sp%f(1)%bk(k) * 1.d5; ph2 = sp%f(1)%ak(k+1) + sp%f(1)%bk(k+1) * 1.d5
+      sp%pm(k) = (ph2 - ph1) / log(ph2 / ph1)
+    end do
+    do k = 1, npz
+      pm = sp%pm(k)
+      if (pm < rf_cutoff) then
+        sp%rf(k) = dt / (tau * 86400.d0) * sin(0.5d0 * pi * log(rf_cutoff / pm) / log(rf_cutoff / sp%f(1)%fl%ptop))**2
+        sp%kmax = k
+      else
+        exit
+      end if
+    end do
+  end subroutine
+
+  subroutine sphere_remap_params(sp, rp)
+    type(fv3_sphere), intent(in) :: sp
+    type(fv3_remap_params), intent(out) :: rp
+    type(fv3_flags) :: fl
+    integer :: nq
+    fl = sp%f(1)%fl; nq = sp%f(1)%nq
+    rp%hydrostatic = merge(1_c_int, 0_c_int, fl%hydrostatic); rp%adiabatic = merge(1_c_int, 0_c_int, fl%adiabatic); rp%nq = int(nq, c_int)
+    rp%kord_mt = int(fl%kord_mt, c_int); rp%kord_wz = int(fl%kord_wz, c_int); rp%kord_tm = int(fl%kord_tm, c_int)
+    rp%sphum = merge(1_c_int, 0_c_int, nq > 0); rp%fill = merge(1_c_int, 0_c_int, fl%fill)
+    rp%akap = fl%akap; rp%ptop = fl%ptop; rp%rdgas = fl%rdgas; rp%grav = fl%grav
+    rp%cv_air = fl%cp_air - fl%rdgas; rp%r_vir = fl%r_vir; rp%cp = fl%cp_air; rp%t_min = fl%t_min
+    rp%last_step = 0_c_int
   end subroutine
 
   subroutine fv3_sphere_final(sp)

@@ -194,6 +194,9 @@ class HaloExchanger:
         kernel during that time instead of idling in front of it.  The messages are then issued from a communication
         stream that waits for the pack kernel only (an event recorded right after it), not for the kernels launched in
         between."""
+        # NOTE for callers: on one rank the periodic group is filled inside start() (one launch) and finish() does nothing, on several
+        # ranks finish() fills the halos -- so between start() and finish() the fields (their edges included) must not be modified and
+        # their halos not read: the MPI contract of start_group_halo_update / complete_group_halo_update, which is all that is promised.
         fields = list(fields)
         if self.native:
             # the library keeps ONE group in flight (fv3_halo_start refuses a second one): part of this interface, not a
@@ -275,11 +278,15 @@ class HaloExchanger:
         if pending is None:
             return
         if self.native:
-            for entry in pending:
-                if not entry["started"]:
-                    self.ctx.halo_start(*entry["native"])
-                self.ctx.halo_complete()
-            self._native_pending = None
+            try:
+                for entry in pending:
+                    if not entry["started"]:
+                        self.ctx.halo_start(*entry["native"])
+                    self.ctx.halo_complete()
+            finally:
+                # also when the library refuses (it drops its pending group itself): the next start() must see the original error,
+                # not "another group is in flight"
+                self._native_pending = None
             return
         for entry in pending:
             self._post(entry)

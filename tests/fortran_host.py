@@ -396,3 +396,169 @@ def check_fortran_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=
                 assert np.all(np.isfinite(a)), (t, n)
                 assert np.array_equal(a, b), f"face {t + 1} {n}: Fortran host and Python host differ (max abs {np.max(np.abs(a - b)):.3e})"
     return r.stdout
+
+
+def build_solo_refsig_sphere(workdir, libdir=CSRC, libname="fv3_mi355x"):
+    fc = fortran_compiler()
+    exe = os.path.join(str(workdir), "fv3_solo_refsig_sphere")
+    srcs = [os.path.join(FDIR, f) for f in ("fv3_mi355x_mod.F90", "fv3_host_mod.F90", "fv3_sphere_mod.F90", "fv3_dyn_core_mod.F90",
+                                            "fv3_solo_refsig_sphere.F90")]
+    subprocess.check_call([fc, "-O1", "-module-dir", str(workdir)] + srcs +
+                          ["-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2, bdt=900.0, hydrostatic=False, consv_te=1.0, tau=10.0,
+                        zvir=0.6077, face_rank=(0, 0, 0, 0, 0, 0), have_grid=False, tol=0.0):
+    """fv_dynamics WITH THE REFERENCE'S ARGUMENT LIST on the cubed sphere (fv3_dyn_core_mod.F90: one call per tile, host arrays with the
+    fv_arrays layout, gridstruct / flagstruct / bd / domain) against the Python host's whole fv_dynamics call
+    (FvDynamics.step_from_temperature over the six contexts): compute_total_energy, T -> theta_v with the virtual effect, Rayleigh_Super
+    (tau > 0), the k_split loop, the energy fixer (consv_te) and cubed_to_latlon -- identical bits on every tile (tol = 0), with the
+    tiles in one process or spread over processes (face_rank; the exchange then runs between them).  have_grid: corner_f is not
+    handed over, the wrapper forms it from grid / agrid as the reference's a2b_ord4 does (then held to `tol`)."""
+    import ctypes as C
+    import cubed_common as CC
+    import parity_cubed as PC
+    from gfdl_atmos_cubed_sphere_amd import lib as L
+    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
+    from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
+    from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    cs, gs = CC.sphere(npx)
+    nx = npx - 1
+    sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
+    ak, bk = 300.0 * (1.0 - sig), sig.copy()
+    st = cs.jablonowski_williamson(ak, bk, hydrostatic=hydrostatic, rdgas=L.RDGAS, grav=L.GRAV)      # pt = T
+    CC.exchange(cs, st, ("phis",), "A")
+    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, ptop=float(ak[0]), **(dict(d_ext=0.0) if hydrostatic else {}))
+    bd = gs[0].bd
+    ng = bd.ng
+    c = (slice(ng, ng + nx), slice(ng, ng + nx))
+    for s_ in st:
+        if hydrostatic:
+            s_["w"] = np.zeros_like(s_["delp"])
+            s_["delz"] = bd.zeros("CC", npz)
+    # what p_var (fv_grid_utils / init_case) leaves of the hydrostatic pressures: pe (is-1:ie+1, npz+1, js-1:je+1), pk, peln, pkz
+    pv = []
+    for s_ in st:
+        e = (slice(ng - 1, ng + nx + 1), slice(ng - 1, ng + nx + 1))
+        if hydrostatic:
+            pe_ = ak[0] + np.concatenate([np.zeros(s_["delp"].shape[:2] + (1,)), np.cumsum(s_["delp"], axis=2)], axis=2)
+            pec = pe_[c]
+            peln = np.log(pec)
+            pk = pec ** fl.akap
+            pkz = (pk[:, :, 1:] - pk[:, :, :-1]) / (fl.akap * (peln[:, :, 1:] - peln[:, :, :-1]))
+            pv.append(dict(pe=np.asfortranarray(np.transpose(pe_[e], (0, 2, 1))), pk=np.asfortranarray(pk),
+                           peln=np.asfortranarray(np.transpose(peln, (0, 2, 1))), pkz=np.asfortranarray(pkz)))
+        else:
+            pv.append(dict(pe=np.zeros((nx + 2, npz + 1, nx + 2), order="F"), pk=np.zeros((nx, nx, npz + 1), order="F"),
+                           peln=np.zeros((nx, npz + 1, nx), order="F"), pkz=np.zeros((nx, nx, npz), order="F")))
+    q = PC.tracer_fields(cs, npz, nq) if nq else None
+    if nq:                                  # the first tracer is the specific humidity of the virtual effect: small and positive
+        for t in range(6):
+            q[t][..., 0] = 0.01 * np.abs(q[t][..., 0]) / (1.0e-30 + np.abs(q[t][..., 0]).max())
+    moist = bool(nq) and zvir > 0.0
+    # ---- (a) Python host ----
+    mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
+    try:
+        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)),
+                        consv_te=consv_te, tau=tau, adiabatic=not moist, moist_phys=False)
+        fv.remap_par["r_vir"] = zvir if moist else fv.remap_par["r_vir"]
+        fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], [s_["w"] for s_ in st], [s_["delp"] for s_ in st],
+                        [s_["pt"] for s_ in st], [s_["delz"] for s_ in st], [s_["phis"] for s_ in st])
+        if nq:
+            fv.set_tracers(q)
+        for n in ("pe", "pk", "peln", "pkz"):
+            fv.dc.d[n].upload([p_[n] for p_ in pv])
+        fv.step_from_temperature(bdt)
+        d = fv.dc.d
+        names = ("u", "v", "delp", "pt", "ua", "va") if hydrostatic else ("u", "v", "w", "delp", "pt", "delz", "ua", "va")
+        ref = {n: d[n].download() for n in names}
+        if nq:
+            ref["q"] = d["q"].download()
+        for n in names:
+            assert all(np.all(np.isfinite(x[c])) for x in ref[n]), f"the Python host's {n} is not finite"
+        assert tau <= 0.0 or fv._rf[2] > 0, "the Rayleigh damping acts on no level of this test"
+    finally:
+        mctx.close()
+    # ---- (b) the reference's argument list ----
+    exe = build_solo_refsig_sphere(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
+    nranks = max(face_rank) + 1
+    uid = (C.c_ubyte * 128)()
+    if nranks > 1:
+        lib.check(lib.dll.fv3_comm_get_unique_id(uid), "fv3_comm_get_unique_id")
+    F = lambda a: np.asfortranarray(a, dtype=np.float64).ravel(order="F")      # noqa: E731
+    fout = os.path.join(str(workdir), "rs_out.bin")
+    procs = []
+    for rank in range(nranks):
+        fin = os.path.join(str(workdir), f"rs_in_{rank}.bin")
+        with open(fin, "wb") as f:
+            np.array([npx, npz, nq, n_split, k_split, int(hydrostatic), fl.nord, rank, nranks, int(have_grid)] + list(face_rank),
+                     dtype=np.int32).tofile(f)
+            np.array([bdt, fl.ptop, 0.0, fl.d_ext, gs[0].da_min, gs[0].da_min_c, fl.d4_bg, fl.beta, consv_te, tau, zvir if moist else 0.0],
+                     dtype=np.float64).tofile(f)
+            f.write(bytes(uid))
+            np.asarray(ak, dtype=np.float64).tofile(f)
+            np.asarray(bk, dtype=np.float64).tofile(f)
+            for t in range(6):
+                m = gs[t].m
+                for grp in (_GH_A, _GH_U, _GH_V, _GH_B):
+                    for n in grp:
+                        F(m[n]).tofile(f)
+                F(m["sin_sg"]).tofile(f); F(m["cos_sg"]).tofile(f)
+                for n in ("edge_w", "edge_e", "edge_s", "edge_n"):
+                    np.asarray(m[n], dtype=np.float64).tofile(f)
+                F(m["rsina"]).tofile(f)
+                np.asarray(m["corner_f"], dtype=np.float64).ravel().tofile(f)
+                for n in ("a11", "a12", "a21", "a22", "ec1", "ec2", "en1", "en2"):
+                    F(m[n]).tofile(f)
+                if have_grid:
+                    F(m["grid"]).tofile(f); F(m["agrid"]).tofile(f)
+                for n in ("u", "v", "w", "delp", "pt", "delz", "phis"):
+                    F(st[t][n]).tofile(f)
+                if nq:
+                    F(q[t]).tofile(f)
+                for n in ("pe", "pk", "peln", "pkz"):
+                    F(pv[t][n]).tofile(f)
+        procs.append(subprocess.Popen([exe, fin, fout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        o, _ = p.communicate(timeout=1500)
+        outs.append(o)
+        assert p.returncode == 0, o[-3000:]
+    i0, i1, j0, j1 = bd.is_, bd.ie, bd.js, bd.je
+    rng_ = {"u": ("U", i0, i1, j0, j1 + 1), "v": ("V", i0, i1 + 1, j0, j1), "w": ("A", i0, i1, j0, j1), "delp": ("A", i0, i1, j0, j1),
+            "pt": ("A", i0, i1, j0, j1), "ua": ("A", i0, i1, j0, j1), "va": ("A", i0, i1, j0, j1)}
+    worst = 0.0
+    for rank in range(nranks):
+        with open(fout + f".{rank}", "rb") as f:
+            for t in range(6):
+                if face_rank[t] != rank:
+                    continue
+                got = {}
+                for n, kind in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC")):
+                    shp = bd.shape(kind, npz)
+                    got[n] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+                if nq:
+                    shp = bd.shape("A", npz) + (nq,)
+                    got["q"] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+                for n in ("ua", "va"):
+                    shp = bd.shape("A", npz)
+                    got[n] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+                for n in ref:
+                    if n in rng_:
+                        kind, *r4 = rng_[n]
+                        a, b = bd.view(got[n], kind, *r4), bd.view(ref[n][t], kind, *r4)
+                    elif n == "q":
+                        a, b = got[n][c], ref[n][t][c]
+                    else:
+                        a, b = got[n], ref[n][t]
+                    assert np.all(np.isfinite(a)), (t, n)
+                    if tol == 0.0:
+                        assert np.array_equal(a, b), (f"tile {t + 1} {n}: fv_dynamics with the reference's argument list and the Python host differ "
+                                                      f"(max abs {np.max(np.abs(a - b)):.3e}, rel rms {np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(b ** 2)) + 1e-300):.3e})")
+                    else:
+                        e = float(np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(b ** 2)) + 1e-300))
+                        worst = max(worst, e)
+                        assert e <= tol, (t, n, e)
+    return worst

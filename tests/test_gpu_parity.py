@@ -1217,3 +1217,15 @@ def test_riem_lds_bit_identical_to_the_slab_kernels(prod, km):
     the same bits in every output (nh_utils.F90:1277-1394, nh_core.F90:47-241, nh_utils.F90:323-480)"""
     dims = dict(nx=200, ny=24, km=km) if km >= 79 else dict(nx=37, ny=13, km=km)     # ragged last 16-column block
     N.check_riem_lds_bits(prod, **dims)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(hydrostatic=True, nq=0), dict(have_grid=True, consv_te=-2.0, tau=0.0)])
+def test_fortran_fv_dynamics_with_the_reference_argument_list_on_the_sphere(prod, tmp_path, kw):
+    """VERDICT r3 item 6 (row a21): fv3_solo_refsig_sphere drives a C24 Jablonowski-Williamson fv_dynamics call with the REFERENCE'S
+    argument list (one call per tile, host arrays with the fv_arrays layout, gridstruct / flagstruct / bd / domain), consv_te = 1,
+    tau = 10 days, the virtual effect of the first tracer: six contexts in one process on this GPU (one launch group), the cube-edge
+    exchange behind the C ABI -- bit-identical to FvDynamics.step_from_temperature on every tile (fv_dynamics.F90:79-936)"""
+    import fortran_host as F
+    if F.fortran_compiler() is None:
+        pytest.skip("no Fortran compiler in this image")
+    assert F.check_refsig_sphere(prod, tmp_path, npx=25, npz=20, n_split=2, k_split=2, bdt=900.0, **kw) == 0.0
