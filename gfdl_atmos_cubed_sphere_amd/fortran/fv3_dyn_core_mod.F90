@@ -15,9 +15,15 @@
 !> (≈ 63 GB/s): this is the compatibility form; the resident form (fv3_host_mod's own fv3_fv_dynamics, which keeps the
 !> state on the device across dyn_core, tracer_2d and the remap) is the fast one.
 !>
-!> Restrictions (error stop with the reason, never a silent difference): grid_type = 4 on one rank (the cubed sphere runs
-!> through the Python host's six-face exchange, cubed_dyn.py); no nesting / regional BCs; use_cond / moist_kappa in fv_dynamics (dyn_core carries them),
-!> do_diss_est and the SKEB diss_est accumulation are not carried through this wrapper.
+!> grid_type < 3 (round 4): a tile of the CUBED SPHERE per call -- one context per tile this process holds, the cubed members of
+!> gridstruct, domain -> which tile / which PE holds which tile; the tiles of a process are given one call after the other and the
+!> call of the last one runs the step for all of them (see fv_dynamics_sphere); with several processes the exchange runs between
+!> them.  fv_dynamics there carries consv_te (compute_total_energy + the energy fixer), tau > 0 (Rayleigh_Super) and the virtual
+!> effect in Fortran.
+!>
+!> Restrictions (error stop with the reason, never a silent difference): grid_type = 4 on one rank; no nesting / regional BCs;
+!> use_cond / moist_kappa in fv_dynamics and on the sphere (dyn_core carries them on the doubly periodic domain), consv_te / tau on the
+!> doubly periodic domain, do_diss_est and the SKEB diss_est accumulation are not carried through this wrapper.
 module fv3_arrays_compat_mod
   use iso_c_binding
   implicit none
@@ -128,6 +134,12 @@ module fv3_dyn_core_mod
   type(fv3_sphere), save :: sps
   type(tile_arrays), save :: tps(6)
   logical, save :: bound_s(6) = .false., comm_s = .false.
+  type dc_tile_arrays
+    type(c_ptr) :: u, v, w, delz, pt, delp, ws, pe, pk, peln, pkz, omga, ua, va, uc, vc, mfx, mfy, cx, cy, heat_source
+  end type
+  type(fv3_sphere), save :: spd         ! dyn_core's own contexts (no tracers), as on the doubly periodic domain
+  type(dc_tile_arrays), save :: tpd(6)
+  logical, save :: bound_d(6) = .false., comm_d = .false.
 
 contains
 
@@ -144,8 +156,8 @@ contains
     type(fv_grid_bounds_type), intent(in) :: bd
     real(c_double), intent(inout), target :: u(bd%isd:bd%ied, bd%jsd:bd%jed+1, npz)
     real(c_double), intent(inout), target :: v(bd%isd:bd%ied+1, bd%jsd:bd%jed, npz)
-    real(c_double), intent(inout) :: w(bd%isd:, bd%jsd:, 1:)
-    real(c_double), intent(inout) :: delz(bd%is:, bd%js:, 1:)
+    real(c_double), intent(inout), target :: w(bd%isd:, bd%jsd:, 1:)
+    real(c_double), intent(inout), target :: delz(bd%is:, bd%js:, 1:)
     real(c_double), intent(inout) :: cappa(bd%isd:, bd%jsd:, 1:)
     real(c_double), intent(inout), target :: pt(bd%isd:bd%ied, bd%jsd:bd%jed, npz), delp(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
     real(c_double), intent(inout) :: q(bd%isd:bd%ied, bd%jsd:bd%jed, npz, nq)
@@ -179,8 +191,12 @@ contains
 
     if (neststruct%nested .or. gridstruct%nested .or. gridstruct%regional .or. gridstruct%bounded_domain) &
       error stop 'dyn_core (fv3_dyn_core_mod): nested / regional domains are not built'
-    if (gridstruct%grid_type /= 4) error stop 'dyn_core (fv3_dyn_core_mod): grid_type = 4 only through this wrapper'
     moist = thermostruct%use_cond .or. thermostruct%moist_kappa
+    if (gridstruct%grid_type < 3) then
+      call dyn_core_sphere()
+      return
+    end if
+    if (gridstruct%grid_type /= 4) error stop 'dyn_core (fv3_dyn_core_mod): grid_type = 3 is not built'
     if (moist .and. hydrostatic) error stop 'dyn_core (fv3_dyn_core_mod): use_cond / moist_kappa are nonhydrostatic branches'
     if (thermostruct%use_cond .and. size(q_con, 3) < npz) error stop 'dyn_core (fv3_dyn_core_mod): use_cond needs q_con on npz levels'
     if (thermostruct%moist_kappa .and. size(cappa, 3) < npz) error stop 'dyn_core (fv3_dyn_core_mod): moist_kappa needs cappa on npz levels'
@@ -262,6 +278,105 @@ contains
       type(c_ptr), intent(in) :: d, h
       integer(c_size_t), intent(in) :: n
       call fv3_check(fv3_memcpy_d2h(at%ctx, h, d, n * 8_c_size_t), 'fv3_memcpy_d2h')
+    end subroutine
+
+    !> grid_type < 3: a tile of the cubed sphere, as fv_dynamics below does it -- every call binds (first time) and uploads its tile,
+    !> the call of the last tile this process holds runs the substep loop for all of them (fv3_sphere_dyn_core: every halo update
+    !> through fv3_cube_halo_*, mpp_get_boundary after the last substep, adv_pe) and writes the results of every tile
+    subroutine dyn_core_sphere()
+      type(fv3_flags) :: fl
+      integer :: slot, nloc, sl
+      if (moist) error stop 'dyn_core (fv3_dyn_core_mod): use_cond / moist_kappa on the cubed sphere are not carried through this wrapper'
+      if (flagstruct%do_diss_est .or. flagstruct%beta < 0.d0) error stop 'dyn_core (fv3_dyn_core_mod): do_diss_est / beta < 0 are not built'
+      if (ng /= 3 .or. bd%ng /= 3) error stop 'dyn_core (fv3_dyn_core_mod): ng = 3'
+      if (domain%tile < 1 .or. domain%tile > 6) error stop 'dyn_core (fv3_dyn_core_mod): domain%tile must be 1 .. 6'
+      if (domain%face_rank(domain%tile) /= domain%pe) error stop 'dyn_core (fv3_dyn_core_mod): this PE does not hold domain%tile'
+      nloc = count(domain%face_rank == domain%pe)
+      slot = count(domain%face_rank(1:domain%tile) == domain%pe)
+      nx = bd%ie - bd%is + 1; ny = bd%je - bd%js + 1
+      nk = int(npz, c_size_t); nk1 = nk + 1
+      if (.not. hydrostatic) then
+        if (.not. (is_contiguous(w) .and. is_contiguous(delz)) .or. size(w, 1) /= nx + 6 .or. size(w, 2) /= ny + 6 .or. &
+            size(w, 3) /= npz .or. size(delz, 1) /= nx .or. size(delz, 2) /= ny .or. size(delz, 3) /= npz) &
+          error stop 'dyn_core (fv3_dyn_core_mod): w / delz must be the whole contiguous arrays of the tile'
+      end if
+      if (.not. bound_d(slot)) then
+        call flags_of(flagstruct, fl)
+        fl%n_split = n_split; fl%ptop = ptop; fl%grav = grav; fl%akap = akap; fl%cp_air = cp
+        fl%hydrostatic = hydrostatic
+        call bind_sphere_tile(spd, slot, domain%tile, npx, npy, npz, 0, bd, gridstruct, flagstruct, fl, ak, bk)
+        bound_d(slot) = .true.
+      end if
+      associate (a => spd%f(slot))
+        if (a%npz /= npz .or. a%ie /= bd%ie .or. a%je /= bd%je) error stop 'dyn_core (fv3_dyn_core_mod): the domain changed between calls'
+        a%fl%n_split = n_split
+        call puts(a, a%u, c_loc(u), a%nU*nk);        call puts(a, a%v, c_loc(v), a%nV*nk)
+        call puts(a, a%delp, c_loc(delp), a%nA*nk);  call puts(a, a%pt, c_loc(pt), a%nA*nk)
+        call puts(a, a%phis, c_loc(phis), a%nA)
+        allocate(zs(bd%isd:bd%ied, bd%jsd:bd%jed))
+        zs = phis * (1.d0 / grav)
+        call puts(a, a%zs, c_loc(zs), a%nA)
+        if (.not. hydrostatic) then
+          call puts(a, a%w, c_loc(w), a%nA*nk);      call puts(a, a%delz, c_loc(delz), a%nCC*nk)
+        end if
+        call puts(a, a%pkz, c_loc(pkz), a%nCC*nk);   call puts(a, a%pk, c_loc(pk), a%nCC*nk1)
+        call puts(a, a%pe, c_loc(pe), int(nx+2, c_size_t)*nk1*(ny+2)); call puts(a, a%peln, c_loc(peln), a%nCC*nk1)
+        call puts(a, a%omga, c_loc(omga), a%nA*nk);  call puts(a, a%ua, c_loc(ua), a%nA*nk); call puts(a, a%va, c_loc(va), a%nA*nk)
+        call fv3_check(fv3_sync(a%ctx), 'fv3_sync')
+      end associate
+      tpd(slot)%u = c_loc(u); tpd(slot)%v = c_loc(v); tpd(slot)%pt = c_loc(pt); tpd(slot)%delp = c_loc(delp)
+      tpd(slot)%w = c_null_ptr; tpd(slot)%delz = c_null_ptr
+      if (.not. hydrostatic) then
+        tpd(slot)%w = c_loc(w); tpd(slot)%delz = c_loc(delz)
+      end if
+      tpd(slot)%ws = c_loc(ws); tpd(slot)%pe = c_loc(pe); tpd(slot)%pk = c_loc(pk); tpd(slot)%peln = c_loc(peln)
+      tpd(slot)%pkz = c_loc(pkz); tpd(slot)%omga = c_loc(omga); tpd(slot)%ua = c_loc(ua); tpd(slot)%va = c_loc(va)
+      tpd(slot)%uc = c_loc(uc); tpd(slot)%vc = c_loc(vc); tpd(slot)%mfx = c_loc(mfx); tpd(slot)%mfy = c_loc(mfy)
+      tpd(slot)%cx = c_loc(cx); tpd(slot)%cy = c_loc(cy); tpd(slot)%heat_source = c_loc(heat_source)
+      if (slot < nloc) return                        ! the loop runs in the call of the last tile this process holds
+
+      if (.not. comm_d) then
+        if (domain%npes > 1) then
+          call fv3_sphere_comm(spd, domain%pe, domain%npes, domain%face_rank, domain%comm_id)
+        else
+          call fv3_sphere_comm(spd, 0, 1, domain%face_rank)
+        end if
+        comm_d = .true.
+      end if
+      call fv3_sphere_dyn_core(spd, bdt, end_step)
+      do sl = 1, nloc
+        associate (a => spd%f(sl), tp => tpd(sl))
+          call fv3_check(fv3_sync(a%ctx), 'fv3_sync')
+          call gets(a, tp%u, a%u, a%nU*nk);        call gets(a, tp%v, a%v, a%nV*nk)
+          call gets(a, tp%delp, a%delp, a%nA*nk);  call gets(a, tp%pt, a%pt, a%nA*nk)
+          if (.not. hydrostatic) then
+            call gets(a, tp%w, a%w, a%nA*nk);      call gets(a, tp%delz, a%delz, a%nCC*nk)
+            call gets(a, tp%ws, a%ws, a%nCC)
+          end if
+          call gets(a, tp%pkz, a%pkz, a%nCC*nk);   call gets(a, tp%pk, a%pk, a%nCC*nk1)
+          call gets(a, tp%pe, a%pe, int(nx+2, c_size_t)*nk1*(ny+2)); call gets(a, tp%peln, a%peln, a%nCC*nk1)
+          call gets(a, tp%omga, a%omga, a%nA*nk);  call gets(a, tp%ua, a%ua, a%nA*nk); call gets(a, tp%va, a%va, a%nA*nk)
+          call gets(a, tp%uc, a%uc, a%nV*nk);      call gets(a, tp%vc, a%vc, a%nU*nk)
+          call gets(a, tp%mfx, a%mfx, a%nFX*nk);   call gets(a, tp%mfy, a%mfy, a%nFY*nk)
+          call gets(a, tp%cx, a%cx, a%nCX*nk);     call gets(a, tp%cy, a%cy, a%nCY*nk)
+          if (flagstruct%d_con > 1.d-5) call gets(a, tp%heat_source, a%heat_source, a%nA*nk)
+          call fv3_check(fv3_sync(a%ctx), 'fv3_sync')
+        end associate
+      end do
+    end subroutine
+
+    subroutine puts(a, d, h, n)
+      type(fv3_atmos), intent(in) :: a
+      type(c_ptr), intent(in) :: d, h
+      integer(c_size_t), intent(in) :: n
+      call fv3_check(fv3_memcpy_h2d(a%ctx, d, h, n * 8_c_size_t), 'fv3_memcpy_h2d')
+    end subroutine
+
+    subroutine gets(a, h, d, n)
+      type(fv3_atmos), intent(in) :: a
+      type(c_ptr), intent(in) :: d, h
+      integer(c_size_t), intent(in) :: n
+      call fv3_check(fv3_memcpy_d2h(a%ctx, h, d, n * 8_c_size_t), 'fv3_memcpy_d2h')
     end subroutine
 
     !> first call: bounds + flags -> fv3_domain / fv3_flags, the gridstruct members by address -> fv3_grid_upload
@@ -458,12 +573,8 @@ contains
     !> the energy fixer, cubed_to_latlon: fv3_sphere_fv_dynamics_call -- and writes the results into the arrays of every tile's call.
     !> Those arrays are the model's state (Atm(n)%u ...): contiguous, with the reference's extents, alive until that last call.
     subroutine fv_dynamics_sphere()
-      type(fv3_domain) :: dom
-      type(fv3_grid_host) :: gh
-      type(fv3_grid_cubed) :: gc
       type(fv3_flags) :: fl
-      integer :: slot, nloc, t, sl
-      real(c_double), allocatable, target, save :: a4(:,:,:,:), ecp(:,:,:,:,:), en1p(:,:,:,:), en2p(:,:,:,:)
+      integer :: slot, nloc, sl
       if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%do_diss_est .or. flagstruct%beta < 0.d0) &
         error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / do_diss_est / beta < 0 are not built'
       if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
@@ -481,36 +592,10 @@ contains
           error stop 'fv_dynamics (fv3_dyn_core_mod): w / delz must be the whole contiguous arrays of the tile'
       end if
       if (.not. bound_s(slot)) then
-        dom%is = bd%is; dom%ie = bd%ie; dom%js = bd%js; dom%je = bd%je; dom%ng = 3
-        dom%npx = npx; dom%npy = npy; dom%npz = npz; dom%grid_type = gridstruct%grid_type
-        dom%do_diss_est = 0; dom%prevent_diss_cooling = merge(1, 0, flagstruct%prevent_diss_cooling)
-        dom%stretched_grid = merge(1, 0, gridstruct%stretched_grid); dom%lim_fac = flagstruct%lim_fac
-        call grid_host_of(gridstruct, gh)
-        ! the cubed members in the library's layouts: a11 .. a22 on the A layout, the unit vectors with the component last
-        if (.not. allocated(a4)) then
-          allocate(a4(bd%isd:bd%ied, bd%jsd:bd%jed, 4, 6), ecp(bd%isd:bd%ied, bd%jsd:bd%jed, 3, 2, 6))
-          allocate(en1p(bd%is:bd%ie, bd%js:bd%je+1, 3, 6), en2p(bd%is:bd%ie+1, bd%js:bd%je, 3, 6))
-          a4 = 0.d0
-        end if
-        a4(bd%is-1:bd%ie+1, bd%js-1:bd%je+1, 1, slot) = gridstruct%a11; a4(bd%is-1:bd%ie+1, bd%js-1:bd%je+1, 2, slot) = gridstruct%a12
-        a4(bd%is-1:bd%ie+1, bd%js-1:bd%je+1, 3, slot) = gridstruct%a21; a4(bd%is-1:bd%ie+1, bd%js-1:bd%je+1, 4, slot) = gridstruct%a22
-        do t = 1, 3
-          ecp(:, :, t, 1, slot) = gridstruct%ec1(t, :, :); ecp(:, :, t, 2, slot) = gridstruct%ec2(t, :, :)
-          en1p(:, :, t, slot) = gridstruct%en1(t, :, :);   en2p(:, :, t, slot) = gridstruct%en2(t, :, :)
-        end do
-        gc%edge_w = c_loc(gridstruct%edge_w); gc%edge_e = c_loc(gridstruct%edge_e)
-        gc%edge_s = c_loc(gridstruct%edge_s); gc%edge_n = c_loc(gridstruct%edge_n)
-        gc%rsina = c_loc(gridstruct%rsina)
-        if (gridstruct%corner_f(1) < 0.d0) call corner_factors(gridstruct, bd, npx, npy)
-        gc%corner_f = gridstruct%corner_f
-        gc%a11 = c_loc(a4(bd%isd, bd%jsd, 1, slot)); gc%a12 = c_loc(a4(bd%isd, bd%jsd, 2, slot))
-        gc%a21 = c_loc(a4(bd%isd, bd%jsd, 3, slot)); gc%a22 = c_loc(a4(bd%isd, bd%jsd, 4, slot))
-        gc%ec1 = c_loc(ecp(bd%isd, bd%jsd, 1, 1, slot)); gc%ec2 = c_loc(ecp(bd%isd, bd%jsd, 1, 2, slot))
-        gc%en1 = c_loc(en1p(bd%is, bd%js, 1, slot));     gc%en2 = c_loc(en2p(bd%is, bd%js, 1, slot))
         call flags_of(flagstruct, fl)
         fl%n_split = n_split; fl%q_split = q_split; fl%ptop = ptop; fl%akap = kappa; fl%cp_air = cp_air
         fl%hydrostatic = hydrostatic; fl%fill = fill; fl%r_vir = zvir
-        call fv3_sphere_init_face(sps, slot, domain%tile - 1, dom, gh, gc, nq_tot, fl, ak, bk)
+        call bind_sphere_tile(sps, slot, domain%tile, npx, npy, npz, nq_tot, bd, gridstruct, flagstruct, fl, ak, bk)
         bound_s(slot) = .true.
       end if
       associate (at => sps%f(slot))
@@ -612,6 +697,47 @@ contains
     bound_s = .false.; comm_s = .false.
   end subroutine
 
+  !> one tile of the cubed sphere: context (grid_type < 3), gridstruct with the cubed members in the library's layouts (a11 .. a22 on
+  !> the A layout, the unit vectors with the component last; fv3_grid_upload_cubed copies them), device arrays
+  subroutine bind_sphere_tile(sp, slot, tile, npx, npy, npz, nq, bd, gridstruct, flagstruct, fl, ak, bk)
+    type(fv3_sphere), intent(inout) :: sp
+    integer, intent(in) :: slot, tile, npx, npy, npz, nq
+    type(fv_grid_bounds_type), intent(in) :: bd
+    type(fv_grid_type), intent(inout), target :: gridstruct
+    type(fv_flags_type), intent(in) :: flagstruct
+    type(fv3_flags), intent(in) :: fl
+    real(c_double), intent(in) :: ak(npz+1), bk(npz+1)
+    type(fv3_domain) :: dom
+    type(fv3_grid_host) :: gh
+    type(fv3_grid_cubed) :: gc
+    real(c_double), allocatable, target :: a4(:,:,:), ecp(:,:,:,:), en1p(:,:,:), en2p(:,:,:)
+    integer :: t
+    dom%is = bd%is; dom%ie = bd%ie; dom%js = bd%js; dom%je = bd%je; dom%ng = 3
+    dom%npx = npx; dom%npy = npy; dom%npz = npz; dom%grid_type = gridstruct%grid_type
+    dom%do_diss_est = 0; dom%prevent_diss_cooling = merge(1, 0, flagstruct%prevent_diss_cooling)
+    dom%stretched_grid = merge(1, 0, gridstruct%stretched_grid); dom%lim_fac = flagstruct%lim_fac
+    call grid_host_of(gridstruct, gh)
+    allocate(a4(bd%isd:bd%ied, bd%jsd:bd%jed, 4), ecp(bd%isd:bd%ied, bd%jsd:bd%jed, 3, 2))
+    allocate(en1p(bd%is:bd%ie, bd%js:bd%je+1, 3), en2p(bd%is:bd%ie+1, bd%js:bd%je, 3))
+    a4 = 0.d0
+    a4(bd%is-1:bd%ie+1, bd%js-1:bd%je+1, 1) = gridstruct%a11; a4(bd%is-1:bd%ie+1, bd%js-1:bd%je+1, 2) = gridstruct%a12
+    a4(bd%is-1:bd%ie+1, bd%js-1:bd%je+1, 3) = gridstruct%a21; a4(bd%is-1:bd%ie+1, bd%js-1:bd%je+1, 4) = gridstruct%a22
+    do t = 1, 3
+      ecp(:, :, t, 1) = gridstruct%ec1(t, :, :); ecp(:, :, t, 2) = gridstruct%ec2(t, :, :)
+      en1p(:, :, t) = gridstruct%en1(t, :, :);   en2p(:, :, t) = gridstruct%en2(t, :, :)
+    end do
+    gc%edge_w = c_loc(gridstruct%edge_w); gc%edge_e = c_loc(gridstruct%edge_e)
+    gc%edge_s = c_loc(gridstruct%edge_s); gc%edge_n = c_loc(gridstruct%edge_n)
+    gc%rsina = c_loc(gridstruct%rsina)
+    if (gridstruct%corner_f(1) < 0.d0) call corner_factors(gridstruct, bd, npx, npy)
+    gc%corner_f = gridstruct%corner_f
+    gc%a11 = c_loc(a4(bd%isd, bd%jsd, 1)); gc%a12 = c_loc(a4(bd%isd, bd%jsd, 2))
+    gc%a21 = c_loc(a4(bd%isd, bd%jsd, 3)); gc%a22 = c_loc(a4(bd%isd, bd%jsd, 4))
+    gc%ec1 = c_loc(ecp(bd%isd, bd%jsd, 1, 1)); gc%ec2 = c_loc(ecp(bd%isd, bd%jsd, 1, 2))
+    gc%en1 = c_loc(en1p(bd%is, bd%js, 1));     gc%en2 = c_loc(en2p(bd%is, bd%js, 1))
+    call fv3_sphere_init_face(sp, slot, tile - 1, dom, gh, gc, nq, fl, ak, bk)
+  end subroutine
+
   !> the extrap_corner factors x1 / (x2 - x1) of a2b_ord4 (model/a2b_edge.F90:83-112 for the four corners, extrap_corner :452-462)
   !> from grid / agrid, with great_circle_dist of fv_grid_utils.F90:2568-2591 (radius 1): corners sw, se, ne, nw, the three
   !> (inner, outer) cell-centre pairs in the reference's order
@@ -696,6 +822,8 @@ contains
   subroutine dyn_core_end()
     if (bound) call fv3_host_final(at)
     bound = .false.
+    if (any(bound_d)) call fv3_sphere_final(spd)
+    bound_d = .false.; comm_d = .false.
   end subroutine
 
 end module fv3_dyn_core_mod

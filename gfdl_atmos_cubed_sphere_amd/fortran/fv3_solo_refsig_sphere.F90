@@ -11,14 +11,16 @@
 !>         corner_f(12), a11 .. a22 (A layout), ec1, ec2 (A x 3), en1, en2 (component last) [, grid, agrid when have_grid: then
 !>         corner_f is NOT handed over and fv3_dyn_core_mod forms it from grid / agrid];
 !>         then the state: u, v, w, delp, pt (TEMPERATURE), delz, phis, q, and pe, pk, peln, pkz as p_var left them
-!> output: per tile held: u, v, w, delp, pt, delz, q, ua, va
+!> output: per tile held: u, v, w, delp, pt, delz, q, ua, va, mfx, cx
 program fv3_solo_refsig_sphere
   use iso_c_binding
   use fv3_arrays_compat_mod
   use fv3_dyn_core_mod
   implicit none
   character(len=1024) :: fin, fout
-  character(len=16) :: sfx
+  character(len=16) :: sfx, what
+  type(group_halo_update_type) :: i_pack(13)
+  real(c_double), allocatable :: pfull(:), te0(:,:), cappa(:,:,:)
   integer(c_int) :: npx, npz, nq, n_split, k_split, mode, nord, rank, nranks, have_grid, face_rank(6)
   real(c_double) :: bdt, ptop, d_con, d_ext, da_min, da_min_c, d4_bg, beta, consv_te, tau, zvir
   integer(c_signed_char) :: comm_id(128)
@@ -45,6 +47,7 @@ program fv3_solo_refsig_sphere
 
   call get_command_argument(1, fin)
   call get_command_argument(2, fout)
+  call get_command_argument(3, what)          ! "dyn_core": one dyn_core call (pt = theta_v) in the place of the fv_dynamics call
   open(newunit=un, file=trim(fin), access='stream', form='unformatted', status='old')
   read(un) npx, npz, nq, n_split, k_split, mode, nord, rank, nranks, have_grid, face_rank
   read(un) bdt, ptop, d_con, d_ext, da_min, da_min_c, d4_bg, beta, consv_te, tau, zvir
@@ -112,9 +115,19 @@ program fv3_solo_refsig_sphere
   fl%hydrostatic = hydrostatic; fl%d_con = d_con; fl%d_ext = d_ext; fl%beta = beta; fl%a_imp = 1.d0
   fl%tau = tau; fl%moist_phys = .false.; fl%adiabatic = nq == 0 .or. zvir == 0.d0
   dom%pe = rank; dom%npes = nranks; dom%face_rank = face_rank; dom%comm_id = comm_id
+  allocate(pfull(npz), te0(nx, nx), cappa(1,1,1)); pfull = 0.d0; te0 = 0.d0
   do t = 1, 6
     if (face_rank(t) /= rank) cycle
     dom%tile = t
+    if (trim(what) == 'dyn_core') then
+      associate (s => st(t))
+        call dyn_core(int(npx), int(npx), int(npz), 3, 1, int(nq), bdt, 1, int(n_split), zvir, 287.04d0/(2.d0/7.d0), 2.d0/7.d0, cappa, &
+                      9.80d0, hydrostatic, s%u, s%v, s%w, s%delz, s%pt, s%q, s%delp, s%pe, s%pk, s%phis, te0, s%omga, ptop, pfull, &
+                      s%ua, s%va, s%uc, s%vc, s%mfx, s%mfy, s%cx, s%cy, s%pkz, s%peln, s%qcon, ak, bk, 0, gs(t), fl, nest, thermo, &
+                      idiag, bd, dom, .true., i_pack, .true., s%heat, s%diss, 0.d0, te0)
+      end associate
+      cycle
+    end if
     associate (s => st(t))
       call fv_dynamics(int(npx), int(npx), int(npz), int(nq), 3, bdt, consv_te, .false., .true., 2.d0/7.d0, 287.04d0/(2.d0/7.d0), zvir, &
                        ptop, 0, max(1, int(nq)), int(n_split), 0, s%u, s%v, s%u, s%v, s%w, s%delz, hydrostatic, s%pt, s%delp, s%q, &
@@ -129,9 +142,11 @@ program fv3_solo_refsig_sphere
     write(un) st(t)%u, st(t)%v, st(t)%w, st(t)%delp, st(t)%pt, st(t)%delz
     if (nq > 0) write(un) st(t)%q
     write(un) st(t)%ua, st(t)%va
+    write(un) st(t)%mfx, st(t)%cx
   end do
   close(un)
   call fv_dynamics_end()
+  call dyn_core_end()
   write(*,'(a,i0,a,i0,a,es24.16)') 'fv3_solo_refsig_sphere: rank ', rank, ' of ', nranks, ' done, sum(delp) of its first tile = ', &
     sum(st(minloc(abs(face_rank - rank), 1))%delp(1:nx, 1:nx, :))
 end program fv3_solo_refsig_sphere

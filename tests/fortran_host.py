@@ -409,7 +409,7 @@ def build_solo_refsig_sphere(workdir, libdir=CSRC, libname="fv3_mi355x"):
 
 
 def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2, bdt=900.0, hydrostatic=False, consv_te=1.0, tau=10.0,
-                        zvir=0.6077, face_rank=(0, 0, 0, 0, 0, 0), have_grid=False, tol=0.0):
+                        zvir=0.6077, face_rank=(0, 0, 0, 0, 0, 0), have_grid=False, tol=0.0, what="fv_dynamics"):
     """fv_dynamics WITH THE REFERENCE'S ARGUMENT LIST on the cubed sphere (fv3_dyn_core_mod.F90: one call per tile, host arrays with the
     fv_arrays layout, gridstruct / flagstruct / bd / domain) against the Python host's whole fv_dynamics call
     (FvDynamics.step_from_temperature over the six contexts): compute_total_energy, T -> theta_v with the virtual effect, Rayleigh_Super
@@ -453,6 +453,13 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
         else:
             pv.append(dict(pe=np.zeros((nx + 2, npz + 1, nx + 2), order="F"), pk=np.zeros((nx, nx, npz + 1), order="F"),
                            peln=np.zeros((nx, npz + 1, nx), order="F"), pkz=np.zeros((nx, nx, npz), order="F")))
+    if what == "dyn_core":                  # one dyn_core call (model/dyn_core.F90:94-98): pt is theta_v on entry, no tracers
+        nq, consv_te, tau = 0, 0.0, 0.0
+        for s_, p_ in zip(st, pv):
+            pkz = p_["pkz"] if hydrostatic else ((-fl.rdgas / fl.grav) * s_["delp"][c] * s_["pt"][c] / s_["delz"]) ** fl.akap
+            s_["pt"][c] = s_["pt"][c] / pkz
+            if not hydrostatic:
+                p_["pkz"] = np.asfortranarray(pkz)
     q = PC.tracer_fields(cs, npz, nq) if nq else None
     if nq:                                  # the first tracer is the specific humidity of the virtual effect: small and positive
         for t in range(6):
@@ -470,9 +477,14 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
             fv.set_tracers(q)
         for n in ("pe", "pk", "peln", "pkz"):
             fv.dc.d[n].upload([p_[n] for p_ in pv])
-        fv.step_from_temperature(bdt)
+        if what == "dyn_core":
+            fv.dc.run(bdt, end_step=True)
+        else:
+            fv.step_from_temperature(bdt)
         d = fv.dc.d
         names = ("u", "v", "delp", "pt", "ua", "va") if hydrostatic else ("u", "v", "w", "delp", "pt", "delz", "ua", "va")
+        if what == "dyn_core":
+            names = tuple(n for n in names if n not in ("ua", "va")) + ("mfx", "cx")
         ref = {n: d[n].download() for n in names}
         if nq:
             ref["q"] = d["q"].download()
@@ -520,7 +532,7 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
                     F(q[t]).tofile(f)
                 for n in ("pe", "pk", "peln", "pkz"):
                     F(pv[t][n]).tofile(f)
-        procs.append(subprocess.Popen([exe, fin, fout], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        procs.append(subprocess.Popen([exe, fin, fout, what], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
         o, _ = p.communicate(timeout=1500)
@@ -544,6 +556,9 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
                     got["q"] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
                 for n in ("ua", "va"):
                     shp = bd.shape("A", npz)
+                    got[n] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+                for n, kind in (("mfx", "FX"), ("cx", "CX")):
+                    shp = bd.shape(kind, npz)
                     got[n] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
                 for n in ref:
                     if n in rng_:

@@ -1122,14 +1122,16 @@ def test_riem_lds_bit_identical_to_the_slab_kernels(emu, dims):
 
 @pytest.mark.parametrize("kw", [dict(), dict(hydrostatic=True), dict(consv_te=-2.0, tau=0.0, nq=0), dict(face_rank=(0, 1, 2, 3, 4, 5)),
                                 dict(face_rank=(0, 0, 1, 1, 2, 2)), dict(face_rank=(0, 1, 0, 1, 0, 1), hydrostatic=True),
-                                dict(have_grid=True)])
+                                dict(have_grid=True), dict(what="dyn_core"), dict(what="dyn_core", hydrostatic=True),
+                                dict(what="dyn_core", face_rank=(0, 0, 1, 1, 2, 2))])
 def test_fortran_fv_dynamics_with_the_reference_argument_list_on_the_sphere(emu, tmp_path, kw):
     """VERDICT r3 item 6 (row a21): fv_dynamics with the REFERENCE'S argument list (model/fv_dynamics.F90:79-85) on grid_type = 0 --
     fv3_dyn_core_mod.F90 binds one context per tile held (fv3_grid_upload_cubed from gridstruct's own members, corner factors from
     grid / agrid with have_grid), exchanges through fv3_cube_halo_* with domain -> face_rank, and carries compute_total_energy + the
     energy fixer (consv_te > 0 and the prescribed flux < 0), Rayleigh_Super (tau = 10 days) and the virtual effect in Fortran: a C12
     Jablonowski-Williamson call bit-identical to FvDynamics.step_from_temperature on every tile -- six tiles in one process, and
-    6 x 1 / 3 x 2 / 2 x 3 tiles over PROCESSES (the exchange between them; here the harness' file transport in the place of RCCL)"""
+    6 x 1 / 3 x 2 / 2 x 3 tiles over PROCESSES (the exchange between them; here the harness' file transport in the place of RCCL).
+    what = "dyn_core": one dyn_core call with ITS reference argument list (dyn_core.F90:94-98) on the tiles, against DynCore.run"""
     import fortran_host as F
     if F.fortran_compiler() is None:
         pytest.skip("no amdflang in this environment")
