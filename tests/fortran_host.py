@@ -135,7 +135,7 @@ def build_refsig(workdir, libdir=CSRC, libname="fv3_mi355x"):
     """the reference-signature dyn_core (fv3_dyn_core_mod) + its driver"""
     fc = fortran_compiler()
     exe = os.path.join(str(workdir), "fv3_solo_refsig")
-    srcs = [os.path.join(FDIR, f) for f in ("fv3_mi355x_mod.F90", "fv3_host_mod.F90", "fv3_dyn_core_mod.F90", "fv3_solo_refsig.F90")]
+    srcs = [os.path.join(FDIR, f) for f in ("fv3_mi355x_mod.F90", "fv3_host_mod.F90", "fv3_sphere_mod.F90", "fv3_dyn_core_mod.F90", "fv3_solo_refsig.F90")]
     subprocess.check_call([fc, "-O1", "-module-dir", str(workdir)] + srcs +
                           ["-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-o", exe])
     return exe
