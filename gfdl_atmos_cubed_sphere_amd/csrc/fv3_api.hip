@@ -2779,6 +2779,12 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn,
                                  const double *pt, const double *delp, double *gz, double *pef, const double *ws) {
   if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver_c: bad context/arguments");
   if (cn->a_imp <= 0.5) return fail("fv3_riem_solver_c: a_imp <= 0.5 (RIM_2D / SIM3p0) is not built");
+  if (c->q_con && c->riem_lds && c->g.npz <= 127 && c->g.npz >= 2) {   // use_cond (+ moist_kappa) in the reference's order
+    RiemFast<true, true, false, true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
+                                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0, c->q_con, c->cappa};
+    RT(launch_p2(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
+    return 0;
+  }
   if (!c->q_con && c->g.npz <= 127 && c->g.npz >= 2) {   // Riem_Solver_c is SIM1 whatever a_imp is
     if (c->fast & 2) {         // tolerance mode: blocked parallel scans
       RiemFast<true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
@@ -2815,6 +2821,18 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
   if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver3: bad context/arguments");
   if (cn->a_imp <= 0.5) return fail("fv3_riem_solver3: a_imp <= 0.5 (RIM_2D / SIM3 / SIM3p0) is not built");
   if (last_call && (!pe || !pk || !peln)) return fail("fv3_riem_solver3: last_call needs pe, pk, peln");
+  if ((c->q_con || c->cappa) && c->riem_lds && c->g.npz <= 127 && c->g.npz >= 2) {   // use_cond / moist_kappa, SIM1 or SIM
+    if (cn->a_imp > 0.999) {
+      RiemFast<false, true, false, true> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
+                                            use_logp, last_call, fp_out, c->q_con, c->cappa};
+      RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
+    } else {
+      RiemFast<false, true, true, true> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
+                                           use_logp, last_call, fp_out, c->q_con, c->cappa};
+      RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
+    }
+    return 0;
+  }
   if (!c->q_con && !c->cappa && cn->a_imp <= 0.999 && c->riem_lds && c->g.npz <= 127 && c->g.npz >= 2) {   // SIM_solver (the reference's default a_imp = 0.75)
     RiemFast<false, true, true> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
                                    use_logp, last_call, fp_out};
@@ -2868,6 +2886,9 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
   if ((c->fast & 8) && km >= 2 && km <= 512) {   // one sweep over k, the back substitution as truncated chains in registers (nh_fast.h)
     EPF kf{g, km, c->ec, c->edge_dev + 3 * km, crx, xfx, cxa, xfa, (int)g.nCX(), cry, yfx, cya, yfa, (int)g.nCY()};
     RT(launch_p(c, "edge_profile", col_grid(2 * (int)(g.nCX() + g.nCY())), EPF::lds_doubles(km), kf));
+  } else if (c->riem_lds && km >= 3 && km <= 127) {   // levels across the lanes, the elimination in the reference's order: the slab kernel's bits
+    EdgeProfileLds kf{g, km, c->ec, c->edge_dev + 3 * km, crx, xfx, cxa, xfa, (int)g.nCX(), cry, yfx, cya, yfa, (int)g.nCY()};
+    RT(launch_p(c, "edge_profile", Dim3{(unsigned)kf.nblocks(), 1, 1}, 2 * kFBuf, kf));
   } else {
     EdgeProfile kf{g, km, c->ec, crx, xfx, cxa, xfa, (int)g.nCX(), cry, yfx, cya, yfa, (int)g.nCY()};
     RT(launch_c(c, "edge_profile", col_grid((int)(g.nCX() + g.nCY())), kf));

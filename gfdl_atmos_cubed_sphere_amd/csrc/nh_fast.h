@@ -66,6 +66,11 @@ inline void vlds_st(double *buf, int col0, int q, const vd &x) {
 inline void vlds_st_next_if(double *buf, int col0, int q, const vd &x, const vb &m) {   // level (lane's level q) + 1, where m
   FV3_LANE_LOOP if (m.v[l]) buf[((l >> 4) + col0) * kFP + lds_lev((l & 15) * kFL + q + 1)] = x.v[l];
 }
+inline vd vrow_ld(const double *t, int q, int n) {   // t[row of the lane], the row clamped to the table
+  vd r;
+  FV3_LANE_LOOP { const int k = (l & 15) * kFL + q; r.v[l] = t[k < n ? k : n - 1]; }
+  return r;
+}
 inline vb vlevel_lt(int q, int k) { vb r; FV3_LANE_LOOP r.v[l] = (l & 15) * kFL + q < k; return r; }
 inline vb vlevel_eq(int q, int k) { vb r; FV3_LANE_LOOP r.v[l] = (l & 15) * kFL + q == k; return r; }
 inline vd vcol_ld(const double *p, long o0, int col0, int ncol) {   // p[o0 + column of the lane] (clamped to the block's last column)
@@ -164,6 +169,10 @@ __device__ __forceinline__ void vlds_st(double *buf, int col0, int q, vd x) {
 __device__ __forceinline__ void vlds_st_next_if(double *buf, int col0, int q, vd x, vb m) {
   const int l = (int)(threadIdx.x & 63);
   if (m) buf[((l >> 4) + col0) * kFP + lds_lev((l & 15) * kFL + q + 1)] = x;
+}
+__device__ __forceinline__ vd vrow_ld(const double *t, int q, int n) {
+  const int k = (int)(threadIdx.x & 15) * kFL + q;
+  return t[k < n ? k : n - 1];
 }
 __device__ __forceinline__ vb vlevel_lt(int q, int k) { return (int)(threadIdx.x & 15) * kFL + q < k; }
 __device__ __forceinline__ vb vlevel_eq(int q, int k) { return (int)(threadIdx.x & 15) * kFL + q == k; }
@@ -471,6 +480,139 @@ struct EdgeProfileFast {
   }
 };
 
+// edge_profile with the LEVELS ACROSS THE LANES and the elimination in the reference's order: BIT-IDENTICAL to the slab kernel
+// (nh_kernels.h EdgeProfile) and the library's default (km <= 127).  A workgroup takes 16 consecutive columns of one of the two field
+// pairs (crx / xfx on CX, cry / yfx on CY), a 16-lane row owns a column, a lane 8 consecutive interfaces; the two fields of a pair run
+// side by side.  Row k (interface k) of the system of nh_utils.F90:1623-1660 is
+//     y_k = (R_k - S_k y_(k-1)) / bet_k  downwards,   x_k = y_k - gam_k x_(k+1)  upwards,
+// R_1 = xt1_top q(1) + q(2), R_k = 3 (q(k-1) + gk(k) q(k)), R_(km+1) = xt1_bot q(km) + q(km-1); S = 0, 1 .. 1, a_bot; the
+// coefficients depend on dp0 only (the host's tables).  A lane runs its 8 rows from the value its neighbour hands it, round after
+// round, until no hand-over moves (the recurrences forget: 1 / bet ~ gam ~ 0.27 a level, 3 - 4 rounds): then every lane holds the
+// sequential sweep's bits (tridiag_rounds above).  Quotients by the host's correctly rounded 1 / bet and a Markstein correction = the
+// values of `/`.  Every input is read once, every output written once, in 128-byte segments through LDS.
+struct EdgeProfileLds {
+  Grid g;
+  int km;
+  EdgeCoef ec;
+  const double *rbet;     // device, km: 1 / ec.bet correctly rounded
+  const double *q1, *q2;
+  double *q1e, *q2e;
+  int n2d;
+  const double *q1_b, *q2_b;
+  double *q1e_b, *q2e_b;
+  int n2d_b;
+  FV3_HD int nblk_a() const { return (n2d + kFC - 1) / kFC; }
+  FV3_HD int nblocks() const { return nblk_a() + (n2d_b + kFC - 1) / kFC; }
+  static constexpr int kIt = kFC * 128 / kNT;
+  FV3_D void operator()(int bx, int, int, int tid, double *lds) const {
+    double *B0 = lds, *B1 = lds + kFBuf;
+    const bool second = bx >= nblk_a();
+    const int blk = second ? bx - nblk_a() : bx;
+    const size_t ls = (size_t)(second ? n2d_b : n2d);
+    const double *f1 = second ? q1_b : q1, *f2 = second ? q2_b : q2;
+    double *o1 = second ? q1e_b : q1e, *o2 = second ? q2e_b : q2e;
+    const int c0g = blk * kFC;
+    const int ncol = ((int)ls - c0g < kFC) ? (int)ls - c0g : kFC;
+    {
+      double v1[kIt], v2[kIt];
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+      for (int it = 0; it < kIt; it++) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k = idx >> 4;
+        const size_t o = (size_t)(k < km ? k : km - 1) * ls + c0g + (col < ncol ? col : ncol - 1);
+        v1[it] = f1[o];
+        v2[it] = f2[o];
+      }
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+      for (int it = 0; it < kIt; it++) {
+        const int idx = tid + it * kNT, col = idx & (kFC - 1), k = idx >> 4;
+        B0[col * kFP + lds_lev(k)] = v1[it];
+        B1[col * kFP + lds_lev(k)] = v2[it];
+      }
+    }
+    FV3_SYNC();
+    const double xt2 = ec.gk_bot * (ec.gk_bot + 0.5) - ec.a_bot * ec.gam[km - 1];
+    const double r_top = 1. / ec.bet_top, r_bot = 1. / xt2;
+    FV3_WAVE_FOR(wv) {
+      const int c0 = wv * 4;
+      // the coefficients of the lane's rows (the same for every column)
+      vd bet[kFL], rb[kFL], S[kFL], G[kFL], gkv[kFL];
+      vb first[kFL], bot[kFL], mid[kFL];
+      for (int q = 0; q < kFL; q++) {
+        first[q] = vlevel_eq(q, 0);
+        bot[q] = vlevel_eq(q, km);
+        mid[q] = vlevel_lt(q, km) && !first[q];
+        const vd bt = vrow_ld(ec.bet, q, km), rbt = vrow_ld(rbet, q, km);
+        gkv[q] = vrow_ld(ec.gk, q, km);
+        bet[q] = vsel(first[q], vd(ec.bet_top), vsel(bot[q], vd(xt2), vsel(mid[q], bt, vd(1.0))));
+        rb[q] = vsel(first[q], vd(r_top), vsel(bot[q], vd(r_bot), vsel(mid[q], rbt, vd(1.0))));
+        S[q] = vsel(mid[q], vd(1.0), vsel(bot[q], vd(ec.a_bot), vd(0.0)));
+        G[q] = vsel(vlevel_lt(q, km), vrow_ld(ec.gam, q, km), vd(0.0));
+      }
+      vd x1[kFL], x2[kFL];
+      for (int f = 0; f < 2; f++) {
+        const double *B = f ? B1 : B0;
+        vd a[kFL], R[kFL], y[kFL];
+        vd *x = f ? x2 : x1;
+        for (int q = 0; q < kFL; q++) a[q] = vlds_ld(B, c0, q);
+        const vd a_up1 = row_shr<1>(a[kFL - 1], 0.0), a_up2 = row_shr<1>(a[kFL - 2], 0.0), a_dn = row_shl<1>(a[0], 0.0);
+        for (int q = 0; q < kFL; q++) {
+          const vd am1 = q > 0 ? a[q - 1] : a_up1, am2 = q > 1 ? a[q - 2] : (q == 1 ? a_up1 : a_up2);
+          const vd ap1 = q < kFL - 1 ? a[q + 1] : a_dn;
+          const vd r_first = ec.xt1_top * a[q] + ap1;                   // :1631
+          const vd r_mid = 3. * (am1 + gkv[q] * a[q]);                   // :1636
+          const vd r_bot_ = ec.xt1_bot * am1 + am2;                      // :1648 (q(km), q(km-1))
+          R[q] = vsel(first[q], r_first, vsel(bot[q], r_bot_, vsel(mid[q], r_mid, vd(0.0))));
+        }
+        {
+          vd yin(0.0);
+          for (int rnd = 0; rnd < 16; rnd++) {
+            vd v = yin;
+            for (int q = 0; q < kFL; q++) {
+              v = vdiv_r(R[q] - S[q] * v, bet[q], rb[q]);
+              y[q] = v;
+            }
+            const vd ynew = row_shr<1>(v, 0.0);
+            const bool moved = vany_ne(ynew, yin);
+            yin = ynew;
+            if (!moved) break;
+          }
+        }
+        {
+          vd xin(0.0);
+          for (int rnd = 0; rnd < 16; rnd++) {
+            vd xn = xin;
+            for (int q = kFL - 1; q >= 0; q--) {
+              xn = y[q] - G[q] * xn;
+              x[q] = xn;
+            }
+            const vd xnew = row_shl<1>(xn, 0.0);
+            const bool moved = vany_ne(xnew, xin);
+            xin = xnew;
+            if (!moved) break;
+          }
+        }
+      }
+      for (int q = 0; q < kFL; q++) {       // the wavefront's own columns: no other wavefront reads them
+        vlds_st(B0, c0, q, x1[q]);
+        vlds_st(B1, c0, q, x2[q]);
+      }
+    }
+    FV3_SYNC();
+    for (int idx = tid; idx < kFC * 128; idx += kNT) {
+      const int col = idx & (kFC - 1), k = idx >> 4;
+      if (k <= km && col < ncol) {
+        const size_t o = (size_t)k * ls + c0g + col;
+        o1[o] = B0[col * kFP + lds_lev(k)];
+        o2[o] = B1[col * kFP + lds_lev(k)];
+      }
+    }
+  }
+};
+
 // CG = true: Riem_Solver_c on (is-1:ie+1, js-1:je+1); false: Riem_Solver3 on the compute domain
 //
 // EX = true (round 4): BIT-IDENTICAL to the parity kernels (nh_kernels.h sim_column), and the library's default for the dry SIM1 solver.
@@ -486,9 +628,10 @@ struct EdgeProfileFast {
 //     buffers, free by then) and ONE wavefront of the workgroup runs the 16 columns of the workgroup on 16 lanes, a lane per column,
 //     with the parity kernel's own statements (rcp_rn / div_rn); the other wavefronts wait at the barrier -- the second workgroup of
 //     the CU has the SIMDs meanwhile.
-template <bool CG, bool EX = false, bool SIM = false>
+template <bool CG, bool EX = false, bool SIM = false, bool MOIST = false>
 struct RiemFast {
   static_assert(!SIM || (EX && !CG), "SIM_solver: the D grid's Riem_Solver3 in the reference's order");
+  static_assert(!MOIST || EX, "use_cond / moist_kappa: in the reference's order only");
   Grid g;
   int km;
   double dt;
@@ -499,6 +642,9 @@ struct RiemFast {
   // outputs: D grid: delz, ppe, pk3 (+ pe, pk, peln on the last call); C grid: pef
   double *delz, *ppe, *pk3, *pe, *pk, *peln, *pef;
   int use_logp, last_call, fp_out;
+  // MOIST: q_con (use_cond: the condensates leave the hydrostatic pressure of pm2, nh_core.F90:113-131, :145-154 / nh_utils.F90:383-396,
+  // :413-438) and cappa (moist_kappa: gm2, cp2 per cell; on the C grid only together with q_con), A x km or null
+  const double *qcon = nullptr, *cappa = nullptr;
   int probe = 0;   // timing probe (tools/riem_time.py, FV3_MI355X_RIEM_PROBE): 1 one round per sum, 2 no w pass, 4 one round of the pp system -- WRONG results
 
   FV3_HD int i_first() const { return CG ? g.is - 1 : g.is; }
@@ -655,6 +801,26 @@ struct RiemFast {
       zv[s][kFL] = row_shl<1>(zv[s][0], -2.0e4);   // the interface below the lane's last layer (lane 15: a padded layer)
     }
     FV3_SYNC();
+    const bool has_qc = MOIST && qcon != nullptr, has_cappa = MOIST && cappa != nullptr && (!CG || qcon != nullptr);
+    vd qcv[kWvState][MOIST ? kFL : 1], cpv[kWvState][MOIST ? kFL : 1];
+    if constexpr (MOIST) {
+      {
+        double v0[kIt], v1[kIt];
+        stage_load(v0, has_qc ? qcon : delp, o0, ncol, km, tid);
+        stage_load(v1, has_cappa ? cappa : delp, o0, ncol, km, tid);
+        stage_store(B0, v0, ncol, km, 0.0, tid);
+        stage_store(B1, v1, ncol, km, cn.akap, tid);
+      }
+      FV3_SYNC();
+      FV3_WAVE_FOR(wv) {
+        const int s = FV3_WVI(wv), c0 = wv * 4;
+        for (int q = 0; q < kFL; q++) {
+          qcv[s][q] = has_qc ? vlds_ld(B0, c0, q) : vd(0.0);
+          cpv[s][q] = has_cappa ? vlds_ld(B1, c0, q) : vd(cn.akap);
+        }
+      }
+      FV3_SYNC();
+    }
     // ---- the column: everything below is per wavefront, no barrier until the outputs ----
     FV3_WAVE_FOR(wv) {
       const int s = FV3_WVI(wv), c0 = wv * 4;
@@ -693,15 +859,50 @@ struct RiemFast {
         for (int q = 0; q < kFL; q++) lnp[q] = vlog(pemv[q]);
         lnp[kFL] = row_shl<1>(lnp[0], 0.0);
       }
+      vd gm2q[MOIST ? kFL : 1];
+      vd pegv[MOIST ? kFL + 1 : 1];
+      if constexpr (MOIST) {
+        for (int q = 0; q < kFL; q++) gm2q[q] = has_cappa ? vdivq(vd(1.0), 1. - cpv[s][q]) : vd(gm2);
+        if (has_qc) {     // peg(k+1) = peg(k) + delp (1 - q_con) from ptop, in the reference's order
+          vd in(cn.ptop);
+          for (int rnd = 0; rnd < nrounds; rnd++) {
+            vd run = in;
+            for (int q = 0; q < kFL; q++) {
+              pegv[q] = run;
+              run = run + dmr[s][q] * (1. - qcv[s][q]);
+            }
+            pegv[kFL] = run;
+            in = row_shr<1>(run, cn.ptop);
+          }
+        }
+      }
+      vd lng[MOIST ? kFL + 1 : 1];
+      if constexpr (MOIST) {
+        if (has_qc && !CG) {
+          for (int q = 0; q < kFL; q++) lng[q] = vlog(pegv[q]);
+          lng[kFL] = row_shl<1>(lng[0], 0.0);
+        }
+      }
       for (int q = 0; q < kFL; q++) {
         const vd d = dmr[s][q];
         if (CG)
           pm2[q] = vdivq(d, vlog(vdivq(pemv[q + 1], pemv[q])));
         else
           pm2[q] = vdivq(d, lnp[q + 1] - lnp[q]);
+        if constexpr (MOIST) {
+          if (has_qc) {     // excluding the contribution from the condensates
+            if (CG)
+              pm2[q] = vdivq(pegv[q + 1] - pegv[q], vlog(vdivq(pegv[q + 1], pegv[q])));
+            else
+              pm2[q] = vdivq(pegv[q + 1] - pegv[q], lng[q + 1] - lng[q]);
+          }
+        }
         dm[q] = d * rgrav;
         dz[q] = zv[s][q + 1] - zv[s][q];
-        pei[q] = vexp(gm2 * vlog(vdivq(-dm[q], dz[q]) * rgas * ptv[s][q])) - pm2[q];
+        if constexpr (MOIST)
+          pei[q] = vexp(gm2q[q] * vlog(vdivq(-dm[q], dz[q]) * rgas * ptv[s][q])) - pm2[q];
+        else
+          pei[q] = vexp(gm2 * vlog(vdivq(-dm[q], dz[q]) * rgas * ptv[s][q])) - pm2[q];
       }
       // ---- pp: forward / backward elimination of nh_utils.F90:1302-1332 as one tridiagonal system; X(k) = pp(k+1) ----
       {
@@ -729,14 +930,24 @@ struct RiemFast {
         const vd dz_pv = row_shr<1>(dz[kFL - 1], 1.0), X_pv = row_shr<1>(X[kFL - 1], 0.0);
         for (int q = 0; q < kFL; q++) {   // aa at the top interface of the layer (0 at the model top)
           const vd dzp = (q > 0) ? dz[q - 1] : dz_pv;
-          const vd aa = vdivq(vd(t1g * 0.5 * (gm2 + gm2)), dzp + dz[q]) * pemv[q];
+          vd aa;
+          if constexpr (MOIST) {
+            const vd gm2p = (q > 0) ? gm2q[q - 1] : row_shr<1>(gm2q[kFL - 1], gm2);
+            aa = vdivq(t1g * 0.5 * (gm2p + gm2q[q]), dzp + dz[q]) * pemv[q];
+          } else {
+            aa = vdivq(vd(t1g * 0.5 * (gm2 + gm2)), dzp + dz[q]) * pemv[q];
+          }
           aat[q] = vsel(real[q] && !vlevel_eq(q, 0), aa, vd(0.0));
         }
         const vd aat_nx = row_shl<1>(aat[0], 0.0);
         const vd wsv = vcol_ld(ws, CG ? (long)o0 : (long)g.iCC(i0, j), c0, ncol);
         for (int q = 0; q < kFL; q++) {
           const vd aab = (q < kFL - 1) ? aat[q + 1] : aat_nx;
-          const vd p1c = vdivq(vd(t1g * gm2), dz[q]) * pemv[q + 1];      // bottom layer only (:1349)
+          vd p1c;                                                        // bottom layer only (:1349)
+          if constexpr (MOIST)
+            p1c = vdivq(t1g * gm2q[q], dz[q]) * pemv[q + 1];
+          else
+            p1c = vdivq(vd(t1g * gm2), dz[q]) * pemv[q + 1];
           const vd ppt = (q > 0) ? X[q - 1] : X_pv;                // pp at the top interface of the layer
           const vd low = vsel(last[q], p1c, aab);
           a[q] = aat[q];
@@ -761,7 +972,7 @@ struct RiemFast {
             vlds_st(B2, c0, q, d[q]);
           }
           for (int q = 0; q < kFL; q++)
-            vlds_st_next_if(B0, c0, q, vdivq(vd(t1g * gm2), dz[q]) * pemv[q + 1], last[q]);
+            vlds_st_next_if(B0, c0, q, MOIST ? vdivq(t1g * gm2q[MOIST ? q : 0], dz[q]) * pemv[q + 1] : vdivq(vd(t1g * gm2), dz[q]) * pemv[q + 1], last[q]);
         } else {
           tridiag_rows(a, b, c, d, keep_w2[s]);
         }
@@ -884,7 +1095,7 @@ struct RiemFast {
           }
         }
         for (int q = kFL - 1; q >= 0; q--)
-          dzn[q] = -dm[q] * rgas * ptv[s][q] * vexp((cp2 - 1.) * vlog(vmax(cn.p_fac * pm2[q], p1v[q] + pm2[q])));
+          dzn[q] = -dm[q] * rgas * ptv[s][q] * vexp(((MOIST ? cpv[s][MOIST ? q : 0] : vd(cp2)) - 1.) * vlog(vmax(cn.p_fac * pm2[q], p1v[q] + pm2[q])));
       }
       // ---- interface heights from the surface upwards (nh_core.F90:228-237 / nh_utils.F90:468-476) ----
       vd zn[kFL];

@@ -154,7 +154,7 @@ def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_
     return worst
 
 
-def check_update_dz_d(lib, nx=40, ny=19, km=5, lev_over=None, hord=10, fast=False):
+def check_update_dz_d(lib, nx=40, ny=19, km=5, lev_over=None, hord=10, fast=False, lds=True, out=None):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, True)
     s = nh_state(bd, km)
@@ -171,7 +171,7 @@ def check_update_dz_d(lib, nx=40, ny=19, km=5, lev_over=None, hord=10, fast=Fals
     ws = bd.zeros("CC")
     rdt = 1.0 / 6.0
     O.update_dz_d(g, km, ndif, damp, hord, s["dp0"], s["zs"], zh, arr["crx"], arr["cry"], arr["xfx"], arr["yfx"], ws, rdt)
-    ctx = Context(g, km, lib=lib)
+    ctx = _riem_context(g, km, lib, lds)    # lds: edge_profile with the levels across the lanes (EdgeProfileLds); False: the slab kernel
     try:
         ctx.set_dp_ref(s["dp0"])
         ctx.dsw_levels(lev)
@@ -183,6 +183,8 @@ def check_update_dz_d(lib, nx=40, ny=19, km=5, lev_over=None, hord=10, fast=Fals
         r = (bd.is_, bd.ie, bd.js, bd.je)
         e = P.assert_close("zh", bd.view(d_out.download(), "A", *r), bd.view(zh, "A", *r), 1e-13 if fast else _tol(lib))
         P.assert_close("ws", d_ws.download(), ws, 1e-12 if fast else _tol(lib))
+        if out is not None:
+            out.update(zh=bd.view(d_out.download(), "A", *r), ws=d_ws.download())
         return e
     finally:
         ctx.close()
@@ -578,3 +580,26 @@ def check_riem_lds_bits(lib, **dims):
     check_riem_solver_c(lib, lds=False, out=b, **dims)
     for n in a:
         assert np.array_equal(a[n], b[n]), f"riem_solver_c: {n} differs from the slab kernel"
+    # use_cond / moist_kappa (RiemFast<CG, true, SIM, true>: nh_core.F90:96-166, nh_utils.F90:383-438)
+    for mk in (dict(use_cond=True), dict(moist_kappa=True), dict(use_cond=True, moist_kappa=True)):
+        for kw in (dict(use_logp=True, last_call=True, fp_out=True), dict(a_imp=0.75)):
+            a, b = {}, {}
+            check_riem_solver3(lib, out=a, **kw, **mk, **dims)
+            check_riem_solver3(lib, lds=False, out=b, **kw, **mk, **dims)
+            for n in a:
+                assert np.array_equal(a[n], b[n]), f"riem_solver3 {mk} {kw}: {n} differs from the slab kernel"
+        a, b = {}, {}
+        check_riem_solver_c(lib, out=a, **mk, **dims)
+        check_riem_solver_c(lib, lds=False, out=b, **mk, **dims)
+        for n in a:
+            assert np.array_equal(a[n], b[n]), f"riem_solver_c {mk}: {n} differs from the slab kernel"
+
+
+def check_edge_profile_lds_bits(lib, **kw):
+    """update_dz_d with edge_profile's levels across the lanes and its elimination in the reference's order (nh_fast.h EdgeProfileLds,
+    the default) against the slab kernel (FV3_MI355X_RIEM_LDS=0): the same bits in zh and ws"""
+    a, b = {}, {}
+    check_update_dz_d(lib, out=a, **kw)
+    check_update_dz_d(lib, lds=False, out=b, **kw)
+    for n in a:
+        assert np.array_equal(a[n], b[n]), f"update_dz_d {kw}: {n} differs from the slab kernel's"

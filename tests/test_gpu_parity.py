@@ -1229,3 +1229,13 @@ def test_fortran_fv_dynamics_with_the_reference_argument_list_on_the_sphere(prod
     if F.fortran_compiler() is None:
         pytest.skip("no Fortran compiler in this image")
     assert F.check_refsig_sphere(prod, tmp_path, npx=25, npz=20, n_split=2, k_split=2, bdt=900.0, **kw) == 0.0
+
+
+@pytest.mark.parametrize("kw", [dict(nx=33, ny=9, km=20), dict(nx=200, ny=24, km=79), dict(nx=200, ny=24, km=127), dict(km=3), dict(km=8),
+                                dict(km=40, lev_over=dict(do_vort_damp=True, vtdm4=0.06, nord=2))])
+def test_edge_profile_lds_bit_identical_to_the_slab_kernel(prod, kw):
+    """update_dz_d's edge_profile with the levels across the lanes and the elimination in the reference's order by hand-over rounds
+    (csrc/nh_fast.h EdgeProfileLds, the library's default; the quotients through the host's correctly rounded reciprocals and a
+    Markstein correction) against the slab kernel with its IEEE divisions (FV3_MI355X_RIEM_LDS=0): the same bits in zh and ws
+    (nh_utils.F90:1590-1696, :204-320)"""
+    N.check_edge_profile_lds_bits(prod, **kw)

@@ -1136,3 +1136,10 @@ def test_fortran_fv_dynamics_with_the_reference_argument_list_on_the_sphere(emu,
     if F.fortran_compiler() is None:
         pytest.skip("no amdflang in this environment")
     assert F.check_refsig_sphere(emu, tmp_path, npx=13, npz=12, n_split=2, k_split=2, bdt=900.0, **kw) == 0.0
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(nx=33, ny=9, km=20), dict(nx=33, ny=9, km=79), dict(nx=17, ny=5, km=127), dict(km=3), dict(km=8),
+                                dict(km=16), dict(km=40, lev_over=dict(do_vort_damp=True, vtdm4=0.06, nord=2))])
+def test_edge_profile_lds_bit_identical_to_the_slab_kernel(emu, kw):
+    """EdgeProfileLds (the default of update_dz_d's edge_profile, nh_utils.F90:1590-1696): the same bits as the slab kernel"""
+    N.check_edge_profile_lds_bits(emu, **kw)
