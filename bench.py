@@ -274,7 +274,7 @@ def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=True
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic_remap.json")) as f_:
                 tr = json.load(f_)
             from gfdl_atmos_cubed_sphere_amd import lib as _lib
-            key = "fast" if fast else "parity"
+            key = "lds"      # the remap with the column in LDS is the default of both modes (bit-identical to the slab kernels)
             if tr.get("build_id") == _lib.build_id() and tr.get("shape") == [nx, nx, npz, nq] and key in tr:
                 e["traffic"] = tr[key]
                 e["traffic_over_algorithmic"] = round(tr[key] / (cells * nb), 3)

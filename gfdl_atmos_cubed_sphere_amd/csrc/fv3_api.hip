@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <deque>
+#include <unordered_map>
 #include <new>
 #include <type_traits>
 
@@ -639,12 +640,45 @@ extern "C" int fv3_group_destroy(fv3_group *g) {
   return rc ? fail("fv3_group_destroy: a queued launch failed") : 0;
 }
 
+// Field arrays come back from hipMalloc aligned to 2 MB, i.e. every field starts at the same phase of the HBM channel interleave; a
+// stencil kernel that streams six or ten fields at the same (i, j, k) then sends all its streams to the same channels at the same
+// time.  FV3_MI355X_MALLOC_SKEW=S (bytes, a multiple of 256; default below) starts the n-th array n * S bytes (mod 64 KB) into its
+// allocation, so the streams of a kernel sit at different phases.  0: as hipMalloc returns them.
+static std::unordered_map<void *, void *> g_skewed;   // user pointer -> allocation
+static size_t malloc_skew() {
+  static const size_t v = [] {
+    const char *e = std::getenv("FV3_MI355X_MALLOC_SKEW");
+    long n = e ? std::atol(e) : 0;
+    if (n < 0) n = 0;
+    return (size_t)(n / 256 * 256);
+  }();
+  return v;
+}
 extern "C" int fv3_malloc(void **dptr, size_t bytes) {
+#ifndef FV3_HOST_EMU
+  const size_t sk = malloc_skew();
+  if (sk && bytes >= (1u << 20)) {
+    static size_t counter = 0;
+    const size_t off = (counter++ * sk) % 65536;
+    void *base = nullptr;
+    RT(rt_malloc(&base, bytes + 65536));
+    *dptr = static_cast<char *>(base) + off;
+    g_skewed[*dptr] = base;
+    return 0;
+  }
+#endif
   RT(rt_malloc(dptr, bytes));
   return 0;
 }
 extern "C" int fv3_free(void *dptr) {
   RT(grp_flush_all());   // a queued launch of a face group may still use the buffer
+  auto it = g_skewed.find(dptr);
+  if (it != g_skewed.end()) {
+    void *base = it->second;
+    g_skewed.erase(it);
+    RT(rt_free(base));
+    return 0;
+  }
   RT(rt_free(dptr));
   return 0;
 }
@@ -3492,6 +3526,10 @@ extern "C" int fv3_set_remap_te(fv3_ctx *c, int remap_te, const double *hs, doub
   return 0;
 }
 
+static int remap_probe() {
+  const char *e = std::getenv("FV3_MI355X_REMAP_PROBE");
+  return e ? std::atoi(e) : 0;
+}
 extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p, const int *kord_tr, double *ps,
                                           double *pe, double *delp, double *pkz, double *pk, double *u, double *v,
                                           double *w, double *delz, double *pt, double *q, double *peln, double *omga,
@@ -3544,9 +3582,9 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
     {
       const Dim3 gr{(unsigned)((g.nx + kFC - 1) / kFC), (unsigned)g.ny, 1};
       if (p->hydrostatic)
-        RT(launch_p2(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<true>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga}));
+        RT(launch_p2(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<true>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
       else
-        RT(launch_p2(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<false>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga}));
+        RT(launch_p2(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<false>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
     }
     {
       RemapFastWind<0> kf{g, km, p->kord_mt, ak, bk, pe, u};

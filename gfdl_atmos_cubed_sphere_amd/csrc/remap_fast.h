@@ -184,6 +184,8 @@ FV3_HD double map_target(const RColC pe1, const RColC a1, const RColC a2, const 
 // the machinery both kernels share: a workgroup's 16 columns in the four LDS arrays
 struct RemapFastCore {
   int km;
+  int probe = 0;   // timing probe (FV3_MI355X_REMAP_PROBE, tools/remap_time.py; WRONG results): 1 no spline, 2 no constraints, 4 no
+                   // subgrid limiters, 8 no mapping loop
   static constexpr int kIt = kFC * 128 / kNT;   // (column, level) pairs per thread
 
   FV3_D static RCol col(double *buf, int c) { return RCol{buf + c * kRP}; }          // [k], k 1-based
@@ -363,9 +365,10 @@ struct RemapFastCore {
       form[it] = 0;
       if (k > km) continue;
       const RColC a1 = colc(A1, col), q = colc(Q, col), t2 = colc(C2, col);
-      double a2v = q[k], a3v = q[k + 1], a4v;
-      cs_cell(pc, k, a2v, a3v, k - 2 >= 1 ? a1[k - 2] : 0., k - 1 >= 1 ? a1[k - 1] : 0., a1[k], k + 1 <= km ? a1[k + 1] : 0.,
-              k + 2 <= km ? a1[k + 2] : 0., a4v);
+      double a2v = q[k], a3v = q[k + 1], a4v = 0.;
+      if (!(probe & 4))
+        cs_cell(pc, k, a2v, a3v, k - 2 >= 1 ? a1[k - 2] : 0., k - 1 >= 1 ? a1[k - 1] : 0., a1[k], k + 1 <= km ? a1[k + 1] : 0.,
+                k + 2 <= km ? a1[k + 2] : 0., a4v);
       r2[it] = a2v; r3v[it] = a3v;
       form[it] = a4_form_of(a4v, a1[k], a2v, a3v);
       pt2[it] = t2[k]; pb2[it] = t2[k + 1];
@@ -382,7 +385,7 @@ struct RemapFastCore {
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
       if (k > km) continue;
-      r2[it] = map_target(colc(C1, col), colc(A1, col), colc(Q, col), colc(C2, col), km, tracer_form, k, pt2[it], pb2[it]);
+      if (!(probe & 8)) r2[it] = map_target(colc(C1, col), colc(A1, col), colc(Q, col), colc(C2, col), km, tracer_form, k, pt2[it], pb2[it]);
     }
     FV3_SYNC();
     for (int it = 0; it < kIt; it++) {
@@ -399,9 +402,9 @@ struct RemapFastCore {
   FV3_D void remap_field(double *C1, double *C2, double *A1, double *Q, const double *QS, bool is_scalar, int iv, int kord,
                          double qmin, bool tracer_form, int tid) const {
     const int ak = kord < 0 ? -kord : kord;
-    FV3_WAVE_FOR(wv) { spline(C1, A1, Q, QS, iv, wv); }
+    if (!(probe & 1)) { FV3_WAVE_FOR(wv) { spline(C1, A1, Q, QS, iv, wv); } }
     FV3_SYNC();
-    constrain(A1, Q, iv, ak, tid);
+    if (!(probe & 2)) constrain(A1, Q, iv, ak, tid);
     FV3_SYNC();
     map_all(C1, C2, A1, Q, is_scalar, iv, ak, qmin, tracer_form, tid);
     FV3_SYNC();
@@ -418,12 +421,13 @@ struct RemapFastScalars {
   const int *kord_tr;   // device, nq
   const double *pe, *ws;
   double *ps, *delp, *pkz, *pk, *delz, *pt, *peln, *w, *q, *omga;
+  int probe = 0;
 
   FV3_HD int nblocks_x() const { return (g.nx + kFC - 1) / kFC; }
 
   FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
     constexpr int kIt = RemapFastCore::kIt;
-    const RemapFastCore core{km};
+    const RemapFastCore core{km, probe};
     double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf, *QS = C1 + kRQS;   // QS[column * kRP]
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (g.nx - bx * kFC < kFC) ? g.nx - bx * kFC : kFC;
@@ -684,6 +688,7 @@ struct RemapFastWind {
   int kord_mt;
   const double *ak, *bk, *pe;
   double *f;
+  int probe = 0;
 
   FV3_HD int ncols_row() const { return WHICH == 0 ? g.nx : g.nx + 1; }
   FV3_HD int nrows() const { return WHICH == 0 ? g.ny + 1 : g.ny; }
@@ -691,7 +696,7 @@ struct RemapFastWind {
 
   FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
     constexpr int kIt = RemapFastCore::kIt;
-    const RemapFastCore core{km};
+    const RemapFastCore core{km, probe};
     double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf;
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (ncols_row() - bx * kFC < kFC) ? ncols_row() - bx * kFC : kFC;
