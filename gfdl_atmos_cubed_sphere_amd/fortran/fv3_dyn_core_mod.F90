@@ -21,7 +21,10 @@
 !> them.  fv_dynamics there carries consv_te (compute_total_energy + the energy fixer), tau > 0 (Rayleigh_Super) and the virtual
 !> effect in Fortran.
 !>
-!> Restrictions (error stop with the reason, never a silent difference): grid_type = 4 on one rank; no nesting / regional BCs;
+!> grid_type = 4 on several PEs (round 4): domain%layout, %pe, %npes, %comm_id -- the group halo updates through fv3_halo_start /
+!> fv3_halo_complete with the neighbour PEs, tracer_2d's mp_reduce_max through fv3_allreduce_max (fv3_host_comm_layout).
+!>
+!> Restrictions (error stop with the reason, never a silent difference): no nesting / regional BCs;
 !> use_cond / moist_kappa in fv_dynamics and on the sphere (dyn_core carries them on the doubly periodic domain), consv_te / tau on the
 !> doubly periodic domain, do_diss_est and the SKEB diss_est accumulation are not carried through this wrapper.
 module fv3_arrays_compat_mod
@@ -96,6 +99,7 @@ module fv3_arrays_compat_mod
     integer :: pe = 0, npes = 1
     integer :: tile = 1                        ! 1 .. 6
     integer :: face_rank(6) = 0                ! the PE that holds tile n
+    integer :: layout(2) = 1                   ! grid_type = 4: the px x py layout of the doubly periodic domain (PE r holds block (mod(r, px), r / px))
     integer(c_signed_char) :: comm_id(128) = 0_c_signed_char
   end type
 
@@ -203,7 +207,10 @@ contains
     if (flagstruct%do_diss_est) error stop 'dyn_core (fv3_dyn_core_mod): do_diss_est is not carried through this wrapper'
     if (flagstruct%beta < 0.d0) error stop 'dyn_core (fv3_dyn_core_mod): beta < 0 (one_grad_p in the nonhydrostatic loop) is not built'
     if (ng /= 3 .or. bd%ng /= 3) error stop 'dyn_core (fv3_dyn_core_mod): ng = 3'
-    if (.not. bound) call bind_context()
+    if (.not. bound) then
+      call bind_context()
+      if (domain%npes > 1) call fv3_host_comm_layout(at, domain%pe, domain%npes, domain%layout(1), domain%layout(2), domain%comm_id)
+    end if
     if (at%npz /= npz .or. at%is /= bd%is .or. at%ie /= bd%ie .or. at%js /= bd%js .or. at%je /= bd%je) &
       error stop 'dyn_core (fv3_dyn_core_mod): the domain changed between calls'
     at%fl%n_split = n_split
@@ -492,7 +499,10 @@ contains
     if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%do_diss_est .or. flagstruct%beta < 0.d0) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / do_diss_est / beta < 0 are not built'
     if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
-    if (.not. boundf) call bind_context()
+    if (.not. boundf) then
+      call bind_context()
+      if (domain%npes > 1) call fv3_host_comm_layout(atf, domain%pe, domain%npes, domain%layout(1), domain%layout(2), domain%comm_id)
+    end if
     if (atf%npz /= npz .or. atf%nq /= nq_tot .or. atf%ie /= bd%ie .or. atf%je /= bd%je) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): the domain changed between calls'
     atf%fl%n_split = n_split; atf%fl%q_split = q_split

@@ -20,7 +20,7 @@ module fv3_host_mod
   implicit none
   private
   public :: fv3_flags, fv3_atmos
-  public :: fv3_host_halo, fv3_host_init, fv3_host_init_grid, fv3_host_final, fv3_host_upload, fv3_host_download
+  public :: fv3_host_halo, fv3_host_init, fv3_host_init_grid, fv3_host_final, fv3_host_upload, fv3_host_download, fv3_host_comm_layout
   public :: fv3_dyn_core, fv3_dyn_core_hydrostatic, fv3_tracer_2d, fv3_fv_dynamics
   public :: dmalloc, dzero, swap, upload_levels, host_n_con, KIND_A, KIND_U, KIND_V, KIND_B    ! shared with fv3_sphere_mod
   public :: inline_q_begin, inline_q_end
@@ -76,6 +76,9 @@ module fv3_host_mod
     type(c_ptr) :: fx_s = c_null_ptr, fy_s = c_null_ptr ! inline_q: the delp fluxes of one substep (FX / FY x npz)
     type(c_ptr) :: q_con = c_null_ptr, q_con_n = c_null_ptr, cappa = c_null_ptr   ! use_cond / moist_kappa (A x npz)
     real(c_double), allocatable :: ak(:), bk(:)
+    ! several ranks of a doubly periodic px x py layout (fv3_host_comm_layout): the neighbour ranks of the eight directions
+    integer :: nranks = 1
+    integer(c_int) :: peers_to(8) = 0_c_int, peers_from(8) = 0_c_int
   end type
 
   logical, save :: host_comm = .false.
@@ -115,10 +118,14 @@ contains
     integer, intent(in) :: nk
     type(fv3_halo_field) :: hf(1)
     integer(c_int) :: peers(8)
-    if (host_comm) then
+    if (host_comm .or. at%nranks > 1) then
       hf(1)%field = field; hf(1)%kind = kind; hf(1)%nk = int(nk, c_int)
       peers = 0_c_int
-      call fv3_check(fv3_halo_start(at%ctx, 1_c_int, hf, peers, peers), 'fv3_halo_start')
+      if (at%nranks > 1) then
+        call fv3_check(fv3_halo_start(at%ctx, 1_c_int, hf, at%peers_to, at%peers_from), 'fv3_halo_start')
+      else
+        call fv3_check(fv3_halo_start(at%ctx, 1_c_int, hf, peers, peers), 'fv3_halo_start')
+      end if
       call fv3_check(fv3_halo_complete(at%ctx), 'fv3_halo_complete')
     else
       call fv3_check(fv3_halo_fill_periodic(at%ctx, field, kind, int(nk, c_int)), 'fv3_halo_fill_periodic')
@@ -131,6 +138,30 @@ contains
     type(c_ptr), intent(in) :: field
     integer, intent(in) :: kind, nk
     call halo(at, field, int(kind, c_int), nk)
+  end subroutine
+
+  !> several ranks of a doubly periodic px x py layout (tools/fv_mp_mod.F90:276-392 with io_layout 1 x 1, contacts :473-483): rank r
+  !> holds block (mod(r, px), r / px); the communicator of the exchange behind the C ABI (id: rank 0's fv3_comm_get_unique_id, broadcast
+  !> by the caller) and the neighbour ranks of the eight directions in the order of fv3_halo_message_elems (dj = -1, 0, 1 outer,
+  !> di = -1, 0, 1 inner): a message to direction d is received from direction -d
+  subroutine fv3_host_comm_layout(at, rank, nranks, px, py, id)
+    type(fv3_atmos), intent(inout) :: at
+    integer, intent(in) :: rank, nranks, px, py
+    integer(c_signed_char), intent(in) :: id(128)
+    integer :: di, dj, n, ix, iy
+    if (px * py /= nranks) error stop 'fv3_host_comm_layout: px * py must be the number of ranks'
+    call fv3_check(fv3_comm_init(at%ctx, int(rank, c_int), int(nranks, c_int), id), 'fv3_comm_init')
+    ix = mod(rank, px); iy = rank / px
+    n = 0
+    do dj = -1, 1
+      do di = -1, 1
+        if (di == 0 .and. dj == 0) cycle
+        n = n + 1
+        at%peers_to(n) = int(modulo(iy + dj, py) * px + modulo(ix + di, px), c_int)
+        at%peers_from(n) = int(modulo(iy - dj, py) * px + modulo(ix - di, px), c_int)
+      end do
+    end do
+    at%nranks = nranks
   end subroutine
 
   !> the communicator of the exchange behind the C ABI: rank 0 makes the id, a several-rank host broadcasts it (MPI_Bcast)
@@ -603,7 +634,7 @@ contains
     call fv3_check(fv3_tracer_2d_prep(at%ctx, int(at%fl%q_split, c_int), at%cx, at%cy, at%xfx, at%yfx, cmax), &
                    'tracer_2d_prep')                                                     ! :362-400
     if (at%fl%q_split == 0) then
-      ! mp_reduce_max(cmax, npz) goes here on several ranks (:405)
+      if (at%nranks > 1) call fv3_check(fv3_allreduce_max(at%ctx, cmax, int(npz, c_int)), 'mp_reduce_max')   ! :405
       if (npz /= 1) then                                                                 ! :407-412
         c_global = maxval(cmax)
       else

@@ -5,6 +5,9 @@
 !> output: real64 u, v, w, delp, pt, delz, mfx, cx, pkz
 !> With a third argument `fv_dynamics`: `nsteps` calls of fv_dynamics(...) (model/fv_dynamics.F90:79-85; pt of the file is then a
 !> TEMPERATURE, the tracers are read and transported; adiabatic: zvir = 0).  output: u, v, w, delp, pt, delz, q, ua
+!> Arguments 4 .. 8 `rank nranks px py idfile`: this process is PE `rank` of a px x py layout of the file's (global) domain -- it takes
+!> its block (halos by periodic continuation), hands domain%pe / %npes / %layout / %comm_id (the 128 bytes of idfile) to the call and
+!> writes its block to <output>.<rank>.
 program fv3_solo_refsig
   use iso_c_binding
   use fv3_arrays_compat_mod
@@ -32,12 +35,27 @@ program fv3_solo_refsig
   real(c_double), parameter :: RDGAS = 287.04d0, KAPPA = 2.d0/7.d0, GRAV = 9.80d0, CP_AIR = RDGAS/KAPPA
   integer :: un, n, isd, ied, jsd, jed
   logical :: hydrostatic, moist
+  integer :: rank, nranks, px, py, gnx, gny, i0, j0
+  character(len=1024) :: arg, idfile
+  character(len=16) :: sfx
 
   call get_command_argument(1, fin)
   call get_command_argument(2, fout)
   mode = ' '
   if (command_argument_count() >= 3) call get_command_argument(3, mode)
   whole = trim(mode) == 'fv_dynamics'
+  rank = 0; nranks = 1; px = 1; py = 1
+  if (command_argument_count() >= 8) then
+    call get_command_argument(4, arg); read(arg, *) rank
+    call get_command_argument(5, arg); read(arg, *) nranks
+    call get_command_argument(6, arg); read(arg, *) px
+    call get_command_argument(7, arg); read(arg, *) py
+    call get_command_argument(8, idfile)
+    open(newunit=un, file=trim(idfile), access='stream', form='unformatted', status='old')
+    read(un) domain%comm_id
+    close(un)
+    domain%pe = rank; domain%npes = nranks; domain%layout = [px, py]
+  end if
   open(newunit=un, file=trim(fin), access='stream', form='unformatted', status='old')
   read(un) nx, ny, npz, nq, n_split, k_split, nsteps, last_step, ihydro
   read(un) dxc_, dyc_, f0_, bdt, ptop, d_con, d_ext, beta
@@ -50,7 +68,7 @@ program fv3_solo_refsig
   bd%isc = 1; bd%iec = nx; bd%jsc = 1; bd%jec = ny
   isd = bd%isd; ied = bd%ied; jsd = bd%jsd; jed = bd%jed
   allocate(u(isd:ied, jsd:jed+1, npz), v(isd:ied+1, jsd:jed, npz), w(isd:ied, jsd:jed, npz), delp(isd:ied, jsd:jed, npz))
-  allocate(pt(isd:ied, jsd:jed, npz), delz(nx, ny, npz), phis(isd:ied, jsd:jed))
+  allocate(pt(isd:ied, jsd:jed, npz), delz(1:nx, 1:ny, npz), phis(isd:ied, jsd:jed))
   read(un) u, v, w, delp, pt, delz, phis
   if (whole .and. nq > 0) then
     allocate(q(isd:ied, jsd:jed, npz, nq))
@@ -67,6 +85,21 @@ program fv3_solo_refsig
     cappa = 0.d0; q_con = 0.d0
   end if
   close(un)
+  gnx = nx; gny = ny
+  if (nranks > 1) then      ! this PE's block of the global domain (with its halos: they lie inside the global arrays' own halos)
+    if (mod(gnx, px) /= 0 .or. mod(gny, py) /= 0) error stop 'fv3_solo_refsig: the layout must divide the domain'
+    nx = gnx / px; ny = gny / py
+    i0 = mod(rank, px) * nx; j0 = (rank / px) * ny
+    bd%is = i0 + 1; bd%ie = i0 + nx; bd%js = j0 + 1; bd%je = j0 + ny
+    bd%isd = bd%is - 3; bd%ied = bd%ie + 3; bd%jsd = bd%js - 3; bd%jed = bd%je + 3
+    bd%isc = bd%is; bd%iec = bd%ie; bd%jsc = bd%js; bd%jec = bd%je
+    isd = bd%isd; ied = bd%ied; jsd = bd%jsd; jed = bd%jed
+    call cut3(u, isd, ied, jsd, jed + 1); call cut3(v, isd, ied + 1, jsd, jed); call cut3(w, isd, ied, jsd, jed)
+    call cut3(delp, isd, ied, jsd, jed);  call cut3(pt, isd, ied, jsd, jed);    call cut3(delz, bd%is, bd%ie, bd%js, bd%je)
+    call cut2(phis, isd, ied, jsd, jed)
+    call cut4(q, isd, ied, jsd, jed)
+    call cut3(cappa, isd, ied, jsd, jed); call cut3(q_con, isd, ied, jsd, jed)
+  end if
   allocate(ps(isd:ied, jsd:jed), u0(isd:ied, jsd:jed+1, 1), v0(isd:ied+1, jsd:jed, 1), ze0(nx, ny, 1))
   ps = 0.d0; u0 = 0.d0; v0 = 0.d0; ze0 = 0.d0
   allocate(heat_source(isd:ied, jsd:jed, npz), diss_est(isd:ied, jsd:jed, npz))
@@ -112,7 +145,7 @@ program fv3_solo_refsig
     fs%c2l_ord = 4
     if (hydrostatic) pkz = 1.d0     ! the state p_var would have left: here the file's pt is theta already (pkz = 1 <=> T = theta)
     do n = 1, nsteps
-      call fv_dynamics(nx + 1, ny + 1, int(npz), int(nq), 3, bdt, 0.d0, .false., &
+      call fv_dynamics(gnx + 1, gny + 1, int(npz), int(nq), 3, bdt, 0.d0, .false., &
                        .false., KAPPA, CP_AIR, 0.d0, ptop, 0, max(1, int(nq)), int(n_split), &
                        0, u0, v0, u, v, w, delz, hydrostatic, pt, delp, q, &
                        ps, pe, pk, peln, pkz, phis, q_con, omga, ua, va, uc, vc, &
@@ -121,7 +154,9 @@ program fv3_solo_refsig
                        parent_grid, domain, inline_mp, heat_source, diss_est)
     end do
     call fv_dynamics_end()
-    open(newunit=un, file=trim(fout), access='stream', form='unformatted', status='replace')
+    sfx = ' '
+    if (nranks > 1) write(sfx, '(a,i0)') '.', rank
+    open(newunit=un, file=trim(fout)//trim(sfx), access='stream', form='unformatted', status='replace')
     write(un) u, v, w, delp, pt, delz
     if (nq > 0) write(un) q
     write(un) ua
@@ -130,7 +165,7 @@ program fv3_solo_refsig
     stop
   end if
   do n = 1, nsteps
-    call dyn_core(nx + 1, ny + 1, int(npz), 3, 1, 0, bdt, 1, int(n_split), 0.d0, CP_AIR, KAPPA, cappa, GRAV, hydrostatic, &
+    call dyn_core(gnx + 1, gny + 1, int(npz), 3, 1, 0, bdt, 1, int(n_split), 0.d0, CP_AIR, KAPPA, cappa, GRAV, hydrostatic, &
                   u, v, w, delz, pt, q, delp, pe, pk, phis, ws, omga, ptop, pfull, ua, va, &
                   uc, vc, mfx, mfy, cx, cy, pkz, peln, q_con, ak, bk, &
                   0, gs, fs, ns, ts, idiag, bd, domain, &
@@ -138,9 +173,37 @@ program fv3_solo_refsig
   end do
   call dyn_core_end()
 
-  open(newunit=un, file=trim(fout), access='stream', form='unformatted', status='replace')
+  sfx = ' '
+  if (nranks > 1) write(sfx, '(a,i0)') '.', rank
+  open(newunit=un, file=trim(fout)//trim(sfx), access='stream', form='unformatted', status='replace')
   write(un) u, v, w, delp, pt, delz, mfx, cx, pkz
   if (moist) write(un) q_con
   close(un)
   write(*,'(a,es24.16)') 'fv3_solo_refsig: done, sum(delp) = ', sum(delp(1:nx, 1:ny, :))
+contains
+  subroutine cut3(a, i1, i2, j1, j2)
+    real(c_double), allocatable, intent(inout) :: a(:,:,:)
+    integer, intent(in) :: i1, i2, j1, j2
+    real(c_double), allocatable :: t(:,:,:)
+    if (size(a, 3) == 1 .and. size(a, 1) < i2 - i1 + 1) return
+    call move_alloc(a, t)
+    allocate(a(i1:i2, j1:j2, lbound(t, 3):ubound(t, 3)))
+    a = t(i1:i2, j1:j2, :)
+  end subroutine
+  subroutine cut2(a, i1, i2, j1, j2)
+    real(c_double), allocatable, intent(inout) :: a(:,:)
+    integer, intent(in) :: i1, i2, j1, j2
+    real(c_double), allocatable :: t(:,:)
+    call move_alloc(a, t)
+    allocate(a(i1:i2, j1:j2))
+    a = t(i1:i2, j1:j2)
+  end subroutine
+  subroutine cut4(a, i1, i2, j1, j2)
+    real(c_double), allocatable, intent(inout) :: a(:,:,:,:)
+    integer, intent(in) :: i1, i2, j1, j2
+    real(c_double), allocatable :: t(:,:,:,:)
+    call move_alloc(a, t)
+    allocate(a(i1:i2, j1:j2, lbound(t, 3):ubound(t, 3), lbound(t, 4):ubound(t, 4)))
+    a = t(i1:i2, j1:j2, :, :)
+  end subroutine
 end program fv3_solo_refsig

@@ -141,7 +141,8 @@ def build_refsig(workdir, libdir=CSRC, libname="fv3_mi355x"):
     return exe
 
 
-def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2, bdt=6.0, hydrostatic=False, d_con=0.0, beta=0.0, moist=False):
+def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2, bdt=6.0, hydrostatic=False, d_con=0.0, beta=0.0, moist=False,
+                         layout=(1, 1)):
     """dyn_core called with the reference's argument list on host arrays (fv3_dyn_core_mod, driver fv3_solo_refsig) against the
     Python host's DynCore.run on the same state: u, v, w, delp, pt, delz, the accumulated mass fluxes / Courant numbers (and pkz
     when the heating or the hydrostatic branch writes it) bit-identical"""
@@ -191,29 +192,78 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
     fin, fout = os.path.join(str(workdir), "in_rs.bin"), os.path.join(str(workdir), "out_rs.bin")
     write_input(fin, bd, npz, 0, n_split, 1, nsteps, False, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak, bk, st, None,
                 hydrostatic=hydrostatic, d_con=d_con, d_ext=fl.d_ext, beta=beta, moist=mo)
-    r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    got = {}
-    with open(fout, "rb") as f:
-        for n, kind in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC"), ("mfx", "FX"), ("cx", "CX"),
-                        ("pkz", "CC")) + ((("q_con", "A"),) if mo else ()):
-            shp = bd.shape(kind, npz)
-            got[n] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
-    i0, i1, j0, j1 = bd.is_, bd.ie, bd.js, bd.je
-    rng_ = {"u": ("U", i0, i1, j0, j1 + 1), "v": ("V", i0, i1 + 1, j0, j1), "w": ("A", i0, i1, j0, j1),
-            "delp": ("A", i0, i1, j0, j1), "pt": ("A", i0, i1, j0, j1), "q_con": ("A", i0, i1, j0, j1)}
-    for n in ref:
-        if n in rng_:
-            kind, *r4 = rng_[n]
-            a, b = bd.view(got[n], kind, *r4), bd.view(ref[n], kind, *r4)
-        else:
-            a, b = got[n], ref[n]
-        assert np.all(np.isfinite(a)), n
-        assert np.array_equal(a, b), f"{n}: reference-signature dyn_core and the Python host differ (max abs {np.max(np.abs(a - b)):.3e})"
-    return r.stdout
+    spec = [(n, k, ()) for n, k in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC"), ("mfx", "FX"), ("cx", "CX"),
+                                    ("pkz", "CC")) + ((("q_con", "A"),) if mo else ())]
+    res, out = _run_refsig(lib, exe, fin, fout, "", layout, bd, npz, spec)
+    _compare_blocks(res, ref, bd, "reference-signature dyn_core")
+    return out
 
 
-def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, hydrostatic=False):
+def _run_refsig(lib, exe, fin, fout, mode, layout, bd, npz, spec):
+    """run the driver on px x py processes (or one) and read what every rank wrote: [(block Bounds, {name: array})]"""
+    import ctypes as C
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    px, py = layout
+    nranks = px * py
+    args = [exe, fin, fout] + ([mode] if mode or nranks > 1 else [])
+    if nranks == 1:
+        r = subprocess.run(args, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs, files, blocks = [r.stdout], [fout], [bd]
+    else:
+        if not mode:
+            args[3] = "dyn_core"
+        uid = (C.c_ubyte * 128)()
+        lib.check(lib.dll.fv3_comm_get_unique_id(uid), "fv3_comm_get_unique_id")
+        idf = fin + ".id"
+        with open(idf, "wb") as f:
+            f.write(bytes(uid))
+        procs = [subprocess.Popen(args + [str(rk), str(nranks), str(px), str(py), idf], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                 for rk in range(nranks)]
+        outs = []
+        for p_ in procs:
+            o, _ = p_.communicate(timeout=1500)
+            outs.append(o)
+            assert p_.returncode == 0, o[-3000:]
+        files = [fout + f".{rk}" for rk in range(nranks)]
+        bnx, bny = bd.nx // px, bd.ny // py
+        blocks = [Bounds(1 + (rk % px) * bnx, (rk % px + 1) * bnx, 1 + (rk // px) * bny, (rk // px + 1) * bny) for rk in range(nranks)]
+    res = []
+    for fn, b in zip(files, blocks):
+        got = {}
+        with open(fn, "rb") as f:
+            for n, kind, extra in spec:
+                shp = b.shape(kind, npz) + extra
+                got[n] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+        res.append((b, got))
+    return res, outs[0]
+
+
+def _compare_blocks(res, ref, bd, what):
+    """every rank's block against the same block of the single-domain reference (compute domain of every field kind)"""
+    kinds = {"u": "U", "v": "V", "w": "A", "delp": "A", "pt": "A", "q_con": "A", "ua": "A", "delz": "CC", "mfx": "FX", "cx": "CX", "pkz": "CC", "q": "A"}
+    for b, got in res:
+        for n in ref:
+            kind = kinds[n]
+            lim = dict(A=(b.is_, b.ie, b.js, b.je), U=(b.is_, b.ie, b.js, b.je + 1), V=(b.is_, b.ie + 1, b.js, b.je),
+                       CC=(b.is_, b.ie, b.js, b.je), FX=(b.is_, b.ie + 1, b.js, b.je), CX=(b.is_, b.ie + 1, b.js, b.je))[kind]
+            a = b.view(got[n], kind, *lim) if kind in ("A", "U", "V") else got[n] if kind != "CX" else got[n][:, b.ng:b.ng + b.ny]
+            if n == "q":
+                a = got[n][b.ng:b.ng + b.nx, b.ng:b.ng + b.ny]
+                r_ = ref[n][bd.ng + b.is_ - 1:bd.ng + b.ie, bd.ng + b.js - 1:bd.ng + b.je]
+            elif kind in ("A", "U", "V"):
+                r_ = bd.view(ref[n], kind, *lim)
+            elif kind == "CC":
+                r_ = ref[n][b.is_ - 1:b.ie, b.js - 1:b.je]
+            elif kind == "FX":
+                r_ = ref[n][b.is_ - 1:b.ie + 1, b.js - 1:b.je]
+            else:   # CX: (nx + 1, njd): rows jsd .. jed of the global array
+                r_ = ref[n][b.is_ - 1:b.ie + 1, bd.ng + b.js - 1:bd.ng + b.je]
+            assert np.all(np.isfinite(a)), n
+            assert np.array_equal(a, r_), f"{n} (block {b.is_}:{b.ie}, {b.js}:{b.je}): {what} and the Python host differ (max abs {np.max(np.abs(a - r_)):.3e})"
+
+
+def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, hydrostatic=False, layout=(1, 1)):
     """fv_dynamics called with the reference's argument list on host arrays (fv3_dyn_core_mod::fv_dynamics, driver fv3_solo_refsig in
     its fv_dynamics mode: T -> theta_v, k_split x (dyn_core, tracer_2d, remap), last_step, cubed_to_latlon) against the Python host's
     FvDynamics.step_from_temperature on the same state: u, v, w, delp, pt (T), delz, the tracers and ua bit-identical"""
@@ -252,32 +302,13 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
     fin, fout = os.path.join(str(workdir), "in_fd.bin"), os.path.join(str(workdir), "out_fd.bin")
     write_input(fin, bd, npz, nq, n_split, k_split, nsteps, True, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak, bk, st, q,
                 hydrostatic=hydrostatic, d_con=0.0, d_ext=fl.d_ext)
-    r = subprocess.run([exe, fin, fout, "fv_dynamics"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    got = {}
-    with open(fout, "rb") as f:
-        for n, kind in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC")):
-            shp = bd.shape(kind, npz)
-            got[n] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
-        if nq:
-            shp = bd.shape("A", npz) + (nq,)
-            got["q"] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
-        shp = bd.shape("A", npz)
-        got["ua"] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
-    i0, i1, j0, j1 = bd.is_, bd.ie, bd.js, bd.je
-    rng_ = {"u": ("U", i0, i1, j0, j1 + 1), "v": ("V", i0, i1 + 1, j0, j1), "w": ("A", i0, i1, j0, j1),
-            "delp": ("A", i0, i1, j0, j1), "pt": ("A", i0, i1, j0, j1), "ua": ("A", i0, i1, j0, j1)}
-    for n in ref:
-        if n in rng_:
-            kind, *r4 = rng_[n]
-            a, b = bd.view(got[n], kind, *r4), bd.view(ref[n], kind, *r4)
-        elif n == "q":
-            a, b = got[n][bd.ng:bd.ng + nx, bd.ng:bd.ng + ny], ref[n][bd.ng:bd.ng + nx, bd.ng:bd.ng + ny]
-        else:
-            a, b = got[n], ref[n]
-        assert np.all(np.isfinite(a)), n
-        assert np.array_equal(a, b), f"{n}: reference-signature fv_dynamics and the Python host differ (max abs {np.max(np.abs(a - b)):.3e})"
-    return r.stdout
+    spec = [(n, k, ()) for n, k in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC"))]
+    if nq:
+        spec.append(("q", "A", (nq,)))
+    spec.append(("ua", "A", ()))
+    res, out = _run_refsig(lib, exe, fin, fout, "fv_dynamics", layout, bd, npz, spec)
+    _compare_blocks(res, ref, bd, "reference-signature fv_dynamics")
+    return out
 
 
 def build_solo_sphere(workdir, libdir=CSRC, libname="fv3_mi355x"):

@@ -1143,3 +1143,15 @@ def test_fortran_fv_dynamics_with_the_reference_argument_list_on_the_sphere(emu,
 def test_edge_profile_lds_bit_identical_to_the_slab_kernel(emu, kw):
     """EdgeProfileLds (the default of update_dz_d's edge_profile, nh_utils.F90:1590-1696): the same bits as the slab kernel"""
     N.check_edge_profile_lds_bits(emu, **kw)
+
+
+@pytest.mark.parametrize("which,kw", [("dyn_core", dict(layout=(2, 1))), ("dyn_core", dict(layout=(2, 2), hydrostatic=True, d_con=1.0)),
+                                      ("fv_dynamics", dict(layout=(2, 2))), ("fv_dynamics", dict(layout=(1, 2), hydrostatic=True))])
+def test_fortran_reference_argument_lists_on_several_ranks_of_the_periodic_domain(emu, tmp_path, which, kw):
+    """dyn_core / fv_dynamics with the reference's argument lists on 2 and 4 PROCESSES of a doubly periodic layout (domain%layout, %pe,
+    %npes, %comm_id -> fv3_host_comm_layout: the group halo updates through fv3_halo_start / _complete with the neighbour PEs,
+    tracer_2d's mp_reduce_max through fv3_allreduce_max): every block bit-identical to the single-domain Python host"""
+    import fortran_host as F
+    if F.fortran_compiler() is None:
+        pytest.skip("no amdflang in this environment")
+    (F.check_fortran_refsig if which == "dyn_core" else F.check_fortran_fv_dynamics)(emu, tmp_path, **kw)
