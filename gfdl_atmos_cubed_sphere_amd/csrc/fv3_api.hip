@@ -26,6 +26,7 @@
 #include "fv3_launch.h"
 #include "nh_kernels.h"
 #include "nh_fast.h"
+#include "nh_alt.h"
 #include "remap_kernels.h"
 #include "remap_fast.h"
 #include "tracer_kernels.h"
@@ -2812,7 +2813,14 @@ extern "C" int fv3_set_fast(fv3_ctx *c, int on) {
 extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn, const double *hs, const double *w3,
                                  const double *pt, const double *delp, double *gz, double *pef, const double *ws) {
   if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver_c: bad context/arguments");
-  if (cn->a_imp <= 0.5) return fail("fv3_riem_solver_c: a_imp <= 0.5 (RIM_2D / SIM3p0) is not built");
+  if (cn->a_imp <= 0.5) {      // nh_utils.F90:449-459: a_imp < -0.01 SIM3p0_solver, otherwise RIM_2D(c_core = .true.)
+    if (c->q_con) return fail("fv3_riem_solver_c: use_cond with a_imp <= 0.5 (SIM3p0 / RIM_2D) is not built");
+    if (c->g.npz > kAltKm - 1 || c->g.npz < 2) return fail("fv3_riem_solver_c: SIM3p0 / RIM_2D are built for 2 <= npz <= %d", kAltKm - 1);
+    RiemSolverAlt<true> kf{c->g, c->g.npz, cn->a_imp < -0.01 ? 0 : 2, cn->m_split >= 1 ? cn->m_split : 1, dt, to_consts(cn), hs, pt, delp, ws,
+                           const_cast<double *>(w3), gz, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0};
+    RT(launch_c(c, "riem_solver_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), kf));
+    return 0;
+  }
   if (c->q_con && c->riem_lds && c->g.npz <= 127 && c->g.npz >= 2) {   // use_cond (+ moist_kappa) in the reference's order
     RiemFast<true, true, false, true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0, c->q_con, c->cappa};
@@ -2853,8 +2861,15 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
                                 double *pk3, double *pk, double *peln, const double *ws, int use_logp, int last_call,
                                 int fp_out) {
   if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver3: bad context/arguments");
-  if (cn->a_imp <= 0.5) return fail("fv3_riem_solver3: a_imp <= 0.5 (RIM_2D / SIM3 / SIM3p0) is not built");
   if (last_call && (!pe || !pk || !peln)) return fail("fv3_riem_solver3: last_call needs pe, pk, peln");
+  if (cn->a_imp <= 0.5) {      // nh_core.F90:169-177: a_imp < -0.999 SIM3p0_solver, < -0.5 SIM3_solver, otherwise RIM_2D
+    if (c->q_con || c->cappa) return fail("fv3_riem_solver3: use_cond / moist_kappa with a_imp <= 0.5 (SIM3 / SIM3p0 / RIM_2D) is not built");
+    if (c->g.npz > kAltKm - 1 || c->g.npz < 2) return fail("fv3_riem_solver3: SIM3 / SIM3p0 / RIM_2D are built for 2 <= npz <= %d", kAltKm - 1);
+    RiemSolverAlt<false> kf{c->g, c->g.npz, cn->a_imp < -0.999 ? 0 : (cn->a_imp < -0.5 ? 1 : 2), cn->m_split >= 1 ? cn->m_split : 1, dt,
+                            to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr, use_logp, last_call, fp_out};
+    RT(launch_c(c, "riem_solver3", col_grid(c->g.nx * c->g.ny), kf));
+    return 0;
+  }
   if ((c->q_con || c->cappa) && c->riem_lds && c->g.npz <= 127 && c->g.npz >= 2) {   // use_cond / moist_kappa, SIM1 or SIM
     if (cn->a_imp > 0.999) {
       RiemFast<false, true, false, true> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
@@ -3526,6 +3541,10 @@ extern "C" int fv3_set_remap_te(fv3_ctx *c, int remap_te, const double *hs, doub
   return 0;
 }
 
+static int remap_two_waves() {   // FV3_MI355X_REMAP_2W=0: the scalars' remap kernel without the two-wavefronts-per-SIMD register budget
+  static const int v = [] { const char *e = std::getenv("FV3_MI355X_REMAP_2W"); return e ? std::atoi(e) : 1; }();
+  return v;
+}
 static int remap_probe() {
   const char *e = std::getenv("FV3_MI355X_REMAP_PROBE");
   return e ? std::atoi(e) : 0;
@@ -3582,9 +3601,9 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
     {
       const Dim3 gr{(unsigned)((g.nx + kFC - 1) / kFC), (unsigned)g.ny, 1};
       if (p->hydrostatic)
-        RT(launch_p2(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<true>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
+        RT((remap_two_waves() ? launch_p2<RemapFastScalars<true>> : launch_p<RemapFastScalars<true>>)(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<true>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
       else
-        RT(launch_p2(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<false>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
+        RT((remap_two_waves() ? launch_p2<RemapFastScalars<false>> : launch_p<RemapFastScalars<false>>)(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<false>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
     }
     {
       RemapFastWind<0> kf{g, km, p->kord_mt, ak, bk, pe, u};

@@ -47,6 +47,7 @@ class DynFlags:
     hord_dp: int = 10
     hord_tr: int = 8
     a_imp: float = 1.0       # > 0.999: SIM1_solver in Riem_Solver3 (BASELINE north_star); reference default 0.75
+    m_split: int = 1         # flagstruct%m_split: the sub-steps of RIM_2D (a_imp <= 0.5)
     p_fac: float = 0.05
     use_logp: bool = False
     use_old_omega: bool = True
@@ -144,7 +145,7 @@ class DynCore:
         ctx.dsw_levels(self.lev)
         ctx.set_dp_ref(dp_ref)
         self.cn = nh_consts(flags.ptop, p_fac=flags.p_fac, a_imp=flags.a_imp, akap=flags.akap, grav=flags.grav,
-                            rdgas=flags.rdgas, cp_air=flags.cp_air)
+                            rdgas=flags.rdgas, cp_air=flags.cp_air, m_split=getattr(flags, "m_split", 1))
 
     # -- state I/O ------------------------------------------------------------------------------------
     def set_state(self, u, v, w, delp, pt, delz, phis):

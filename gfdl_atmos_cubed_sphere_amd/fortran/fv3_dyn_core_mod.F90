@@ -68,6 +68,7 @@ module fv3_arrays_compat_mod
     real(c_double) :: dddmp = 0.d0, vtdm4 = 0.d0, d_con = 0.d0, ke_bg = 0.d0, trdm2 = 0.d0
     real(c_double) :: d_ext = 0.02d0, delt_max = 1.d0, beta = 0.d0, lim_fac = 1.d0
     real(c_double) :: a_imp = 0.75d0, p_fac = 0.05d0
+    integer :: m_split = 0
     integer :: n_sponge = 1
     integer :: hord_mt = 10, hord_vt = 10, hord_tm = 10, hord_dp = 10, hord_tr = 8
     integer :: kord_tm = -8, kord_mt = 8, kord_wz = 8, kord_tr = 8
@@ -423,6 +424,7 @@ contains
       fl%kord_tm = flagstruct%kord_tm;    fl%kord_mt = flagstruct%kord_mt;   fl%kord_wz = flagstruct%kord_wz
       fl%kord_tr = flagstruct%kord_tr;    fl%nord_tr = flagstruct%nord_tr;   fl%trdm2 = flagstruct%trdm2
       fl%a_imp = flagstruct%a_imp;        fl%p_fac = flagstruct%p_fac;       fl%ptop = ptop
+      fl%m_split = max(1, flagstruct%m_split)
       fl%grav = grav;                     fl%akap = akap;                    fl%cp_air = cp
       ! rdgas: constants_mod's, as in the reference (fv3_flags carries it as its default)
       fl%adiabatic = flagstruct%adiabatic; fl%fill = flagstruct%fill
@@ -821,7 +823,7 @@ contains
     fl%hord_dp = flagstruct%hord_dp;    fl%hord_tr = flagstruct%hord_tr
     fl%kord_tm = flagstruct%kord_tm;    fl%kord_mt = flagstruct%kord_mt;   fl%kord_wz = flagstruct%kord_wz
     fl%kord_tr = flagstruct%kord_tr;    fl%nord_tr = flagstruct%nord_tr;   fl%trdm2 = flagstruct%trdm2
-    fl%a_imp = flagstruct%a_imp;        fl%p_fac = flagstruct%p_fac
+    fl%a_imp = flagstruct%a_imp;        fl%p_fac = flagstruct%p_fac;       fl%m_split = max(1, flagstruct%m_split)
     fl%adiabatic = flagstruct%adiabatic; fl%fill = flagstruct%fill
     fl%d_ext = flagstruct%d_ext;        fl%delt_max = flagstruct%delt_max
     fl%beta = flagstruct%beta

@@ -41,6 +41,7 @@ module fv3_host_mod
     integer :: nord_tr = 0
     real(c_double) :: trdm2 = 0.d0
     real(c_double) :: a_imp = 1.d0, p_fac = 0.05d0
+    integer :: m_split = 1                            ! :548; the sub-steps of RIM_2D (a_imp <= 0.5)
     real(c_double) :: ptop = 300.d0
     real(c_double) :: grav = 9.80d0, rdgas = 287.04d0, akap = 2.d0/7.d0, cp_air = 287.04d0/(2.d0/7.d0)   ! constants_mod
     real(c_double) :: r_vir = 0.6077d0, t_min = 184.d0
@@ -325,7 +326,7 @@ contains
     call fv3_check(fv3_set_dp_ref(at%ctx, dp_ref), 'fv3_set_dp_ref')
     call fv3_check(fv3_set_ak_bk(at%ctx, at%ak, at%bk), 'fv3_set_ak_bk')
     at%cn%grav = fl%grav; at%cn%rdgas = fl%rdgas; at%cn%cp_air = fl%cp_air; at%cn%akap = fl%akap
-    at%cn%ptop = fl%ptop; at%cn%p_fac = fl%p_fac; at%cn%a_imp = fl%a_imp
+    at%cn%ptop = fl%ptop; at%cn%p_fac = fl%p_fac; at%cn%a_imp = fl%a_imp; at%cn%m_split = int(max(1, fl%m_split), c_int)
   end subroutine
 
   !> nord_k, nord_v, nord_w, nord_t, d2_divg, damp_vt, damp_w, damp_t, d_con_k per level: the k loop of dyn_core.F90:666-733

@@ -75,6 +75,7 @@ module fv3_mi355x_mod
 
   type, bind(C) :: fv3_nh_consts      ! FMS constants_mod values + namelist scalars
     real(c_double) :: grav, rdgas, cp_air, akap, ptop, p_fac, a_imp
+    integer(c_int) :: m_split = 1       ! flagstruct%m_split: the sub-steps of RIM_2D (a_imp <= 0.5)
   end type
 
   type, bind(C) :: fv3_moist_params   ! moist_kappa / use_cond of the remap + the inputs of moist_cv

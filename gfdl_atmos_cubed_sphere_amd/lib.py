@@ -116,7 +116,7 @@ class _DswLevels(C.Structure):
 
 
 class _NhConsts(C.Structure):
-    _fields_ = [(n, C.c_double) for n in ["grav", "rdgas", "cp_air", "akap", "ptop", "p_fac", "a_imp"]]
+    _fields_ = [(n, C.c_double) for n in ["grav", "rdgas", "cp_air", "akap", "ptop", "p_fac", "a_imp"]] + [("m_split", C.c_int)]
 
 
 # FMS constants_mod (GFDL defaults, FMS 2024.03 constants/gfdl_constants.fh): not in the reference tree
@@ -124,8 +124,8 @@ GRAV, RDGAS, KAPPA = 9.80, 287.04, 2.0 / 7.0
 CP_AIR = RDGAS / KAPPA
 
 
-def nh_consts(ptop, p_fac=0.05, a_imp=1.0, akap=KAPPA, grav=GRAV, rdgas=RDGAS, cp_air=CP_AIR):
-    return dict(grav=grav, rdgas=rdgas, cp_air=cp_air, akap=akap, ptop=ptop, p_fac=p_fac, a_imp=a_imp)
+def nh_consts(ptop, p_fac=0.05, a_imp=1.0, akap=KAPPA, grav=GRAV, rdgas=RDGAS, cp_air=CP_AIR, m_split=1):
+    return dict(grav=grav, rdgas=rdgas, cp_air=cp_air, akap=akap, ptop=ptop, p_fac=p_fac, a_imp=a_imp, m_split=m_split)
 
 
 class _RemapParams(C.Structure):

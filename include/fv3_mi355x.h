@@ -271,6 +271,7 @@ int fv3_cube_halo_complete(int nctx, fv3_ctx *const *ctxs);
  * Physical constants live in FMS constants_mod (not part of the reference tree); the caller passes them. */
 typedef struct fv3_nh_consts {
   double grav, rdgas, cp_air, akap, ptop, p_fac, a_imp;
+  int m_split;   /* flagstruct%m_split: the sub-steps of RIM_2D (taken for a_imp <= 0.5, nh_core.F90:175, nh_utils.F90:452); >= 1 */
 } fv3_nh_consts;
 
 /* dp_ref(k) = ak(k+1)-ak(k) + (bk(k+1)-bk(k))*1e5 (model/dyn_core.F90:241-244), HOST array of length npz.
@@ -297,7 +298,8 @@ int fv3_set_condensate(fv3_ctx *ctx, const double *q_con, const double *cappa);
  * Moist (fv3_set_condensate) and a_imp <= 0.999 calls take the parity kernels in either mode. */
 int fv3_set_fast(fv3_ctx *ctx, int on);
 
-/* Riem_Solver_c -- model/nh_utils.F90:323, call site model/dyn_core.F90:531 (a_imp > 0.5: SIM1_solver).
+/* Riem_Solver_c -- model/nh_utils.F90:323, call site model/dyn_core.F90:531 (a_imp > 0.5: SIM1_solver; a_imp < -0.01: SIM3p0_solver;
+ * otherwise RIM_2D with cn->m_split sub-steps, nh_utils.F90:449-459).
  * hs, ws: A; w3 (=omga), pt (=ptc), delp (=delpc): A x npz; gz (in/out), pef (=pkc, out): A x (npz+1). */
 int fv3_riem_solver_c(fv3_ctx *ctx, double dt, const fv3_nh_consts *cn, const double *hs, const double *w3,
                       const double *pt, const double *delp, double *gz, double *pef, const double *ws);

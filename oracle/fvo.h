@@ -179,6 +179,16 @@ int fvo_riem_solver3(const fvo_grid *g, int km, double dt, double akap, double p
                      double *pk3, double *pk, double *peln, const double *ws, double p_fac, double a_imp,
                      int use_logp, int last_call, int fp_out, double grav, double rdgas, const double *q_con,
                      const double *cappa);
+/* the same with flagstruct%m_split (the sub-steps of RIM_2D, taken for a_imp <= 0.5; nh_utils.F90:751-982) */
+int fvo_riem_solver_c_ms(const fvo_grid *g, int km, double dt, double akap, double ptop, const double *hs,
+                         const double *w3, const double *pt, const double *delp, double *gz, double *pef,
+                         const double *ws, double p_fac, double a_imp, double grav, double rdgas, const double *q_con,
+                         const double *cappa, int m_split);
+int fvo_riem_solver3_ms(const fvo_grid *g, int km, double dt, double akap, double ptop, const double *zs, double *w,
+                        double *delz, const double *pt, const double *delp, double *zh, double *pe, double *ppe,
+                        double *pk3, double *pk, double *peln, const double *ws, double p_fac, double a_imp,
+                        int use_logp, int last_call, int fp_out, double grav, double rdgas, const double *q_con,
+                        const double *cappa, int m_split);
 int fvo_update_dz_d(const fvo_grid *g, int km, int *ndif, double *damp, int hord, const double *dp0, const double *zs,
                     double *zh, const double *crx, const double *cry, const double *xfx, const double *yfx, double *ws,
                     double rdt);

@@ -220,6 +220,260 @@ static void sim_column(int km, double dt, double rgas, const double *gm2, const 
   free(aa); free(bb); free(dd); free(w1); free(wk); free(g_rat); free(gam); free(pp);
 }
 
+/* SIM3_solver, nh_utils.F90:984-1132 (alpha = |a_imp|, scale_m = 0) and SIM3p0_solver, :1134-1274 (beta = 0; p0 != 0), one column:
+ * the full pressure at the layer centres reconstructed to the interfaces (top value pem(1), bottom with the weight of the half layer),
+ * the w system with the FULL interface pressure in its coefficients, the new thickness from the full pressure. */
+static void sim3_column(int km, double dt, double rgas, double gama, double kappa, double *pe2, const double *dm, const double *pem,
+                        double *w2, double *dz2, const double *pt2, double ws, double alpha, double p_fac, double scale_m, double grav,
+                        int p0) {
+  int k;
+  double *aa = dalloc(km + 2), *bb = dalloc(km + 2), *dd = dalloc(km + 2), *w1 = dalloc(km + 2), *wk = dalloc(km + 2),
+         *g_rat = dalloc(km + 2), *gam = dalloc(km + 2), *pp = dalloc(km + 3);
+  double p1, wk1, bet;
+  const double beta = 1. - alpha, ra = 1. / alpha, t2 = beta / alpha;
+  const double t1g = p0 ? 2. * gama * (dt * dt) : gama * 2. * ((alpha * dt) * (alpha * dt));
+  const double rdt = 1. / dt, capa1 = kappa - 1., r2g = grav / 2., r6g = grav / 6.;
+  for (k = 1; k <= km; k++) {
+    w1[k] = w2[k];
+    aa[k] = fv3_exp(gama * fv3_log(-dm[k] / dz2[k] * rgas * pt2[k]));
+  }
+  for (k = 1; k <= km - 1; k++) {
+    g_rat[k] = dm[k] / dm[k + 1];
+    bb[k] = 2. * (1. + g_rat[k]);
+    dd[k] = 3. * (aa[k] + g_rat[k] * aa[k + 1]);
+  }
+  bet = bb[1];
+  pe2[1] = pem[1];
+  pe2[2] = (dd[1] - pem[1]) / bet;
+  bb[km] = 2.;
+  dd[km] = 3. * aa[km] + r2g * dm[km];
+  for (k = 2; k <= km; k++) {
+    gam[k] = g_rat[k - 1] / bet;
+    bet = bb[k] - gam[k];
+    pe2[k + 1] = (dd[k] - pe2[k]) / bet;
+  }
+  for (k = km; k >= 2; k--) pe2[k] = pe2[k] - gam[k] * pe2[k + 1];
+  for (k = 1; k <= km + 1; k++) pp[k] = pe2[k] - pem[k];
+  for (k = 2; k <= km; k++) {
+    if (p0) {
+      aa[k] = t1g / (dz2[k - 1] + dz2[k]) * pe2[k] - scale_m * dm[1];
+    } else {
+      aa[k] = t1g / (dz2[k - 1] + dz2[k]) * pe2[k];
+      wk[k] = t2 * aa[k] * (w1[k - 1] - w1[k]);
+      aa[k] = aa[k] - scale_m * dm[1];
+    }
+  }
+  bet = dm[1] - aa[2];
+  w2[1] = p0 ? (dm[1] * w1[1] + dt * pp[2]) / bet : (dm[1] * w1[1] + dt * pp[2] + wk[2]) / bet;
+  for (k = 2; k <= km - 1; k++) {
+    gam[k] = aa[k] / bet;
+    bet = dm[k] - (aa[k] + aa[k + 1] + aa[k] * gam[k]);
+    if (p0)
+      w2[k] = (dm[k] * w1[k] + dt * (pp[k + 1] - pp[k]) - aa[k] * w2[k - 1]) / bet;
+    else
+      w2[k] = (dm[k] * w1[k] + dt * (pp[k + 1] - pp[k]) + wk[k + 1] - wk[k] - aa[k] * w2[k - 1]) / bet;
+  }
+  wk1 = t1g / dz2[km] * pe2[km + 1];
+  gam[km] = aa[km] / bet;
+  bet = dm[km] - (aa[km] + wk1 + aa[km] * gam[km]);
+  if (p0)
+    w2[km] = (dm[km] * w1[km] + dt * (pp[km + 1] - pp[km]) - wk1 * ws - aa[km] * w2[km - 1]) / bet;
+  else
+    w2[km] = (dm[km] * w1[km] + dt * (pp[km + 1] - pp[km]) - wk[km] + wk1 * (t2 * w1[km] - ra * ws) - aa[km] * w2[km - 1]) / bet;
+  for (k = km - 1; k >= 1; k--) w2[k] = w2[k] - gam[k + 1] * w2[k + 1];
+  pe2[1] = 0.;
+  for (k = 1; k <= km; k++) {
+    if (p0)
+      pe2[k + 1] = pe2[k] + dm[k] * (w2[k] - w1[k]) * rdt;
+    else
+      pe2[k + 1] = pe2[k] + (dm[k] * (w2[k] - w1[k]) * rdt - beta * (pp[k + 1] - pp[k])) * ra;
+  }
+  pe2[1] = pem[1];
+  for (k = 2; k <= km + 1; k++) pe2[k] = dmax(p_fac * pem[k], pe2[k] + pem[k]);
+  p1 = (pe2[km] + 2. * pe2[km + 1]) * r3 - r6g * dm[km];
+  dz2[km] = -dm[km] * rgas * pt2[km] * fv3_exp(capa1 * fv3_log(p1));
+  for (k = km - 1; k >= 1; k--) {
+    p1 = (pe2[k] + bb[k] * pe2[k + 1] + g_rat[k] * pe2[k + 2]) * r3 - g_rat[k] * p1;
+    dz2[k] = -dm[k] * rgas * pt2[k] * fv3_exp(capa1 * fv3_log(p1));
+  }
+  for (k = 1; k <= km + 1; k++) {
+    pe2[k] = pe2[k] - pem[k];
+    if (!p0) pe2[k] = pe2[k] + beta * (pp[k] - pe2[k]);
+  }
+  free(aa); free(bb); free(dd); free(w1); free(wk); free(g_rat); free(gam); free(pp);
+}
+
+/* RIM_2D, nh_utils.F90:751-982, one column: the Riemann invariants of every layer carried along the characteristics for ms sub-steps
+ * of bdt / ms; the layers from the top down to ks0 whose sound-crossing time exceeds bdt take the one-step form (:795-851). */
+static void rim_2d_column(int ms, double bdt, int km, double rgas, double gama, const double *gm2, double *pe2, const double *dm2,
+                          const double *pm2, double *w2, double *dz2, const double *pt2, double ws, int c_core) {
+  int k, n, ke, kt1, ktop, ks0, ks1;
+  double *m_bot = dalloc(km + 3), *m_top = dalloc(km + 3), *r_bot = dalloc(km + 3), *r_top = dalloc(km + 3), *pe1 = dalloc(km + 3),
+         *pbar = dalloc(km + 3), *wbar = dalloc(km + 3), *r_hi = dalloc(km + 2), *r_lo = dalloc(km + 2), *dz = dalloc(km + 2),
+         *wm = dalloc(km + 2), *dm = dalloc(km + 2), *dts = dalloc(km + 2), *pf1 = dalloc(km + 2), *wc = dalloc(km + 2),
+         *cm = dalloc(km + 2), *pp = dalloc(km + 2), *pt1 = dalloc(km + 2);
+  const double grg = gama * rgas, rdt = 1. / bdt, dt = bdt / (double)ms, ws2 = 2. * ws;
+  double z_frac, ptmp1, rden, pf, time_left, m_surf;
+  int done = 0;
+  for (k = 1; k <= km; k++) {
+    dz[k] = dz2[k];
+    dm[k] = dm2[k];
+    wm[k] = w2[k] * dm[k];
+    pt1[k] = pt2[k];
+  }
+  wbar[km + 1] = ws;
+  ks0 = 1;
+  if (ms > 1 && ms < 8) {
+    ks0 = km;
+    for (k = 1; k <= km; k++) {
+      rden = -rgas * dm[k] / dz[k];
+      pf1[k] = fv3_exp(gm2[k] * fv3_log(rden * pt1[k]));
+      dts[k] = -dz[k] / sqrt(grg * pf1[k] / rden);
+      if (bdt > dts[k]) {
+        ks0 = k - 1;
+        break;
+      }
+    }
+    /* ks0 = 0 (the top layer itself is crossed within bdt) reads unset locals and writes pbar(0) in the reference: undefined there;
+     * taken here as ks0 = 1, the form of every other case that leaves no layer to the one-step branch */
+    if (ks0 < 1) ks0 = 1;
+    if (ks0 != 1) {
+      for (k = 1; k <= ks0; k++) {
+        cm[k] = dm[k] / dts[k];
+        wc[k] = wm[k] / dts[k];
+        pp[k] = pf1[k] - pm2[k];
+      }
+      wbar[1] = (wc[1] + pp[1]) / cm[1];
+      for (k = 2; k <= ks0; k++) {
+        wbar[k] = (wc[k - 1] + wc[k] + pp[k] - pp[k - 1]) / (cm[k - 1] + cm[k]);
+        pbar[k] = bdt * (cm[k - 1] * wbar[k] - wc[k - 1] + pp[k - 1]);
+        pe1[k] = pbar[k];
+      }
+      if (ks0 == km) {
+        pbar[km + 1] = bdt * (cm[km] * wbar[km + 1] - wc[km] + pp[km]);
+        for (k = 1; k <= km; k++) {
+          dz2[k] = dz[k] + bdt * (wbar[k + 1] - wbar[k]);
+          if (!c_core) w2[k] = (wm[k] + pbar[k + 1] - pbar[k]) / dm[k];
+        }
+        pe2[1] = 0.;
+        for (k = 2; k <= km + 1; k++) pe2[k] = pbar[k] * rdt;
+        done = 1;
+      } else {
+        for (k = 1; k <= ks0 - 1; k++) {
+          dz2[k] = dz[k] + bdt * (wbar[k + 1] - wbar[k]);
+          if (!c_core) w2[k] = (wm[k] + pbar[k + 1] - pbar[k]) / dm[k];
+        }
+        pbar[ks0] = pbar[ks0] / (double)ms;
+      }
+    }
+  }
+  if (!done) {
+    ks1 = ks0;
+    for (n = 1; n <= ms; n++) {
+      for (k = ks1; k <= km; k++) {
+        rden = -rgas * dm[k] / dz[k];
+        pf = fv3_exp(gm2[k] * fv3_log(rden * pt1[k]));
+        dts[k] = -dz[k] / sqrt(grg * pf / rden);
+        ptmp1 = dts[k] * (pf - pm2[k]);
+        r_lo[k] = wm[k] + ptmp1;
+        r_hi[k] = wm[k] - ptmp1;
+      }
+      ktop = km;
+      for (k = ks1; k <= km; k++)
+        if (dt > dts[k]) {
+          ktop = k - 1;
+          break;
+        }
+      if (ktop >= ks1)
+        for (k = ks1; k <= ktop; k++) {
+          z_frac = dt / dts[k];
+          r_bot[k] = z_frac * r_lo[k];
+          r_top[k + 1] = z_frac * r_hi[k];
+          m_bot[k] = z_frac * dm[k];
+          m_top[k + 1] = m_bot[k];
+        }
+      if (!(ktop >= ks1 && ktop == km)) {
+        for (k = ktop + 2; k <= km + 1; k++) {
+          m_top[k] = 0.;
+          r_top[k] = 0.;
+        }
+        kt1 = ktop > 1 ? ktop : 1;
+        for (ke = km + 1; ke >= ktop + 2; ke--) {
+          time_left = dt;
+          for (k = ke - 1; k >= kt1; k--) {
+            if (time_left > dts[k]) {
+              time_left = time_left - dts[k];
+              m_top[ke] = m_top[ke] + dm[k];
+              r_top[ke] = r_top[ke] + r_hi[k];
+            } else {
+              z_frac = time_left / dts[k];
+              m_top[ke] = m_top[ke] + z_frac * dm[k];
+              r_top[ke] = r_top[ke] + z_frac * r_hi[k];
+              break;
+            }
+          }
+        }
+        for (k = ktop + 1; k <= km; k++) {
+          m_bot[k] = 0.;
+          r_bot[k] = 0.;
+        }
+        for (ke = ktop + 1; ke <= km; ke++) {
+          int next = 0;
+          time_left = dt;
+          for (k = ke; k <= km; k++) {
+            if (time_left > dts[k]) {
+              time_left = time_left - dts[k];
+              m_bot[ke] = m_bot[ke] + dm[k];
+              r_bot[ke] = r_bot[ke] + r_lo[k];
+            } else {
+              z_frac = time_left / dts[k];
+              m_bot[ke] = m_bot[ke] + z_frac * dm[k];
+              r_bot[ke] = r_bot[ke] + z_frac * r_lo[k];
+              next = 1;
+              break;
+            }
+          }
+          if (next) continue;
+          m_surf = m_bot[ke];
+          for (k = km; k >= kt1; k--) {
+            if (time_left > dts[k]) {
+              time_left = time_left - dts[k];
+              m_bot[ke] = m_bot[ke] + dm[k];
+              r_bot[ke] = r_bot[ke] - r_hi[k];
+            } else {
+              z_frac = time_left / dts[k];
+              m_bot[ke] = m_bot[ke] + z_frac * dm[k];
+              r_bot[ke] = r_bot[ke] - z_frac * r_hi[k] + (m_bot[ke] - m_surf) * ws2;
+              break;
+            }
+          }
+        }
+      }
+      if (ks1 == 1) wbar[1] = r_bot[1] / m_bot[1];
+      for (k = ks1 + 1; k <= km; k++) wbar[k] = (r_bot[k] + r_top[k]) / (m_top[k] + m_bot[k]);
+      for (k = ks1 + 1; k <= km + 1; k++) {
+        pbar[k] = m_top[k] * wbar[k] - r_top[k];
+        pe1[k] = pe1[k] + pbar[k];
+      }
+      if (n == ms) {
+        for (k = ks1; k <= km; k++) {
+          dz2[k] = dz[k] + dt * (wbar[k + 1] - wbar[k]);
+          if (!c_core) w2[k] = (wm[k] + pbar[k + 1] - pbar[k]) / dm[k];
+        }
+      } else {
+        for (k = ks1; k <= km; k++) {
+          dz[k] = dz[k] + dt * (wbar[k + 1] - wbar[k]);
+          wm[k] = wm[k] + pbar[k + 1] - pbar[k];
+        }
+      }
+    }
+    pe2[1] = 0.;
+    for (k = 2; k <= km + 1; k++) pe2[k] = pe1[k] * rdt;
+  }
+  free(m_bot); free(m_top); free(r_bot); free(r_top); free(pe1); free(pbar); free(wbar); free(r_hi); free(r_lo); free(dz); free(wm);
+  free(dm); free(dts); free(pf1); free(wc); free(cm); free(pp); free(pt1);
+}
+
 /* Riem_Solver_c, nh_utils.F90:323-480 (a_imp > 0.5 -> SIM1_solver).  q_con != NULL: use_cond = .true. (:383-396,
  * :413-438); cappa != NULL (with q_con): moist_kappa = .true. (:414-424).  hs, ws: A; w3, pt, delp, q_con, cappa: A x km;
  * gz, pef: A x (km+1). */
@@ -227,9 +481,15 @@ int fvo_riem_solver_c(const fvo_grid *g, int km, double dt, double akap, double 
                       const double *w3, const double *pt, const double *delp, double *gz, double *pef,
                       const double *ws, double p_fac, double a_imp, double grav, double rdgas, const double *q_con,
                       const double *cappa) {
+  return fvo_riem_solver_c_ms(g, km, dt, akap, ptop, hs, w3, pt, delp, gz, pef, ws, p_fac, a_imp, grav, rdgas, q_con, cappa, 1);
+}
+/* ... with m_split (the sub-steps of RIM_2D, a_imp <= 0.5) */
+int fvo_riem_solver_c_ms(const fvo_grid *g, int km, double dt, double akap, double ptop, const double *hs,
+                         const double *w3, const double *pt, const double *delp, double *gz, double *pef,
+                         const double *ws, double p_fac, double a_imp, double grav, double rdgas, const double *q_con,
+                         const double *cappa, int m_split) {
   BOUNDS(g);
   int j;
-  if (a_imp <= 0.5) return FVO_ERR_UNSUPPORTED;
   const double rgrav = 1. / grav;
   const int is1 = is - 1, ie1 = ie + 1;
 #pragma omp parallel for schedule(dynamic)
@@ -259,7 +519,12 @@ int fvo_riem_solver_c(const fvo_grid *g, int km, double dt, double akap, double 
         w2[k] = w3[A3(i, j, k)];
         pt2[k] = pt[A3(i, j, k)];
       }
-      sim1_column(km, dt, rdgas, gm2, cp2, pe2, dm, pm2, pem, w2, dz2, pt2, ws[IA(i, j)], p_fac);
+      if (a_imp < -0.01)        /* nh_utils.F90:449-459 */
+        sim3_column(km, dt, rdgas, 1. / (1. - akap), akap, pe2, dm, pem, w2, dz2, pt2, ws[IA(i, j)], 1.0, p_fac, 0.0, grav, 1);
+      else if (a_imp <= 0.5)
+        rim_2d_column(m_split, dt, km, rdgas, 1. / (1. - akap), gm2, pe2, dm, pm2, w2, dz2, pt2, ws[IA(i, j)], 1);
+      else
+        sim1_column(km, dt, rdgas, gm2, cp2, pe2, dm, pm2, pem, w2, dz2, pt2, ws[IA(i, j)], p_fac);
       for (k = 2; k <= km + 1; k++) pef[A3(i, j, k)] = pe2[k] + pem[k];
       gz[A3(i, j, km + 1)] = hs[IA(i, j)];
       for (k = km; k >= 1; k--) gz[A3(i, j, k)] = gz[A3(i, j, k + 1)] - dz2[k] * grav;
@@ -278,9 +543,16 @@ int fvo_riem_solver3(const fvo_grid *g, int km, double dt, double akap, double p
                      double *pk3, double *pk, double *peln, const double *ws, double p_fac, double a_imp,
                      int use_logp, int last_call, int fp_out, double grav, double rdgas, const double *q_con,
                      const double *cappa) {
+  return fvo_riem_solver3_ms(g, km, dt, akap, ptop, zs, w, delz, pt, delp, zh, pe, ppe, pk3, pk, peln, ws, p_fac, a_imp, use_logp,
+                             last_call, fp_out, grav, rdgas, q_con, cappa, 1);
+}
+int fvo_riem_solver3_ms(const fvo_grid *g, int km, double dt, double akap, double ptop, const double *zs, double *w,
+                        double *delz, const double *pt, const double *delp, double *zh, double *pe, double *ppe,
+                        double *pk3, double *pk, double *peln, const double *ws, double p_fac, double a_imp,
+                        int use_logp, int last_call, int fp_out, double grav, double rdgas, const double *q_con,
+                        const double *cappa, int m_split) {
   BOUNDS(g);
   int j;
-  if (a_imp <= 0.5) return FVO_ERR_UNSUPPORTED;
   const double rgrav = 1. / grav;
   const double peln1 = fv3_log(ptop);
   const double ptk = fv3_exp(akap * peln1);
@@ -320,7 +592,13 @@ int fvo_riem_solver3(const fvo_grid *g, int km, double dt, double akap, double p
         w2[k] = w[A3(i, j, k)];
         pt2[k] = pt[A3(i, j, k)];
       }
-      if (a_imp > 0.999)
+      if (a_imp < -0.999)       /* nh_core.F90:169-185 */
+        sim3_column(km, dt, rdgas, 1. / (1. - akap), akap, pe2, dm, pem, w2, dz2, pt2, ws[ICC(i, j)], 1.0, p_fac, 0.0, grav, 1);
+      else if (a_imp < -0.5)
+        sim3_column(km, dt, rdgas, 1. / (1. - akap), akap, pe2, dm, pem, w2, dz2, pt2, ws[ICC(i, j)], fabs(a_imp), p_fac, 0.0, grav, 0);
+      else if (a_imp <= 0.5)
+        rim_2d_column(m_split, dt, km, rdgas, 1. / (1. - akap), gm2, pe2, dm, pm2, w2, dz2, pt2, ws[ICC(i, j)], 0);
+      else if (a_imp > 0.999)
         sim1_column(km, dt, rdgas, gm2, cp2, pe2, dm, pm2, pem, w2, dz2, pt2, ws[ICC(i, j)], p_fac);
       else
         sim_column(km, dt, rdgas, gm2, cp2, pe2, dm, pm2, pem, w2, dz2, pt2, ws[ICC(i, j)], a_imp, p_fac, 0.0);

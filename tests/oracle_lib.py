@@ -206,19 +206,19 @@ def update_dz_c(g, km, dt, dp0, zs, ut, vt, gz, ws):
 
 def riem_solver_c(g, km, dt, cn, hs, w3, pt, delp, gz, pef, ws, q_con=None, cappa=None):
     gs = make_grid(g)
-    rc = lib().fvo_riem_solver_c(C.byref(gs), C.c_int(km), _d(dt), _d(cn["akap"]), _d(cn["ptop"]), p(hs), p(w3), p(pt),
-                                 p(delp), p(gz), p(pef), p(ws), _d(cn["p_fac"]), _d(cn["a_imp"]), _d(cn["grav"]),
-                                 _d(cn["rdgas"]), p(q_con), p(cappa))
+    rc = lib().fvo_riem_solver_c_ms(C.byref(gs), C.c_int(km), _d(dt), _d(cn["akap"]), _d(cn["ptop"]), p(hs), p(w3), p(pt),
+                                    p(delp), p(gz), p(pef), p(ws), _d(cn["p_fac"]), _d(cn["a_imp"]), _d(cn["grav"]),
+                                    _d(cn["rdgas"]), p(q_con), p(cappa), C.c_int(int(cn.get("m_split", 1))))
     assert rc == 0, rc
 
 
 def riem_solver3(g, km, dt, cn, zs, w, delz, pt, delp, zh, pe, ppe, pk3, pk, peln, ws, use_logp, last_call, fp_out,
                  q_con=None, cappa=None):
     gs = make_grid(g)
-    rc = lib().fvo_riem_solver3(C.byref(gs), C.c_int(km), _d(dt), _d(cn["akap"]), _d(cn["ptop"]), p(zs), p(w), p(delz),
-                                p(pt), p(delp), p(zh), p(pe), p(ppe), p(pk3), p(pk), p(peln), p(ws), _d(cn["p_fac"]),
-                                _d(cn["a_imp"]), C.c_int(int(use_logp)), C.c_int(int(last_call)), C.c_int(int(fp_out)),
-                                _d(cn["grav"]), _d(cn["rdgas"]), p(q_con), p(cappa))
+    rc = lib().fvo_riem_solver3_ms(C.byref(gs), C.c_int(km), _d(dt), _d(cn["akap"]), _d(cn["ptop"]), p(zs), p(w), p(delz),
+                                   p(pt), p(delp), p(zh), p(pe), p(ppe), p(pk3), p(pk), p(peln), p(ws), _d(cn["p_fac"]),
+                                   _d(cn["a_imp"]), C.c_int(int(use_logp)), C.c_int(int(last_call)), C.c_int(int(fp_out)),
+                                   _d(cn["grav"]), _d(cn["rdgas"]), p(q_con), p(cappa), C.c_int(int(cn.get("m_split", 1))))
     assert rc == 0, rc
 
 

@@ -66,11 +66,11 @@ def _riem_context(g, km, lib, lds):
             os.environ["FV3_MI355X_RIEM_LDS"] = saved
 
 
-def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, moist_kappa=False, fast=False, lds=True, out=None):
+def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, moist_kappa=False, fast=False, lds=True, out=None, m_split=1):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     s = nh_state(bd, km)
-    cn = nh_consts(PTOP, a_imp=a_imp)
+    cn = nh_consts(PTOP, a_imp=a_imp, m_split=m_split)
     rng = np.random.default_rng(3)
     ws = np.asfortranarray(0.1 * rng.uniform(-1, 1, bd.shape("A")))
     hs = np.asfortranarray(s["zs"] * GRAV)
@@ -102,11 +102,11 @@ def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, mois
 
 
 def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_call=True, fp_out=False, use_cond=False,
-                       moist_kappa=False, fast=False, lds=True, out=None):
+                       moist_kappa=False, fast=False, lds=True, out=None, m_split=1):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     s = nh_state(bd, km)
-    cn = nh_consts(PTOP, a_imp=a_imp)
+    cn = nh_consts(PTOP, a_imp=a_imp, m_split=m_split)
     rng = np.random.default_rng(4)
     ws = np.asfortranarray(0.1 * rng.uniform(-1, 1, bd.shape("CC")))
     q_con, cappa = moist_fields(bd, km)

@@ -1155,3 +1155,14 @@ def test_fortran_reference_argument_lists_on_several_ranks_of_the_periodic_domai
     if F.fortran_compiler() is None:
         pytest.skip("no amdflang in this environment")
     (F.check_fortran_refsig if which == "dyn_core" else F.check_fortran_fv_dynamics)(emu, tmp_path, **kw)
+
+
+@pytest.mark.parametrize("dims", [dict(), dict(nx=37, ny=13, km=32), dict(nx=9, ny=5, km=127), dict(km=3)])
+def test_riem_solvers_sim3_sim3p0_rim_2d(emu, dims):
+    """the other vertical solvers Riem_Solver3 / Riem_Solver_c dispatch on a_imp (nh_core.F90:169-177, nh_utils.F90:449-459):
+    SIM3p0_solver (a_imp < -0.999; C grid < -0.01, nh_utils.F90:1134-1274), SIM3_solver (a_imp < -0.5, :984-1132), RIM_2D (a_imp <= 0.5,
+    :751-982) with one, four (the one-step branch of the layers the sound wave does not cross) and ten sub-steps -- against the oracle"""
+    for a_imp, ms in ((-1.0, 1), (-0.75, 1), (0.3, 1), (0.3, 4), (0.0, 10), (-0.3, 3)):
+        assert N.check_riem_solver3(emu, a_imp=a_imp, m_split=ms, use_logp=True, last_call=True, fp_out=True, **dims) <= 1e-13
+        assert N.check_riem_solver3(emu, a_imp=a_imp, m_split=ms, last_call=False, **dims) <= 1e-13
+        assert N.check_riem_solver_c(emu, a_imp=a_imp, m_split=ms, **dims) <= 1e-13
