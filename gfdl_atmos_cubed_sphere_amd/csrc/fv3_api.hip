@@ -510,6 +510,13 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     c->remap_blocked = e ? (std::atoi(e) != 0) : 1;
     e = std::getenv("FV3_MI355X_REMAP_LDS");
     c->remap_lds = e ? (std::atoi(e) != 0) : 1;
+    // the levels-across-the-lanes kernels index the fields with 32 bits (nh_fast.h ix_t): a tile whose fields reach 2^32 bytes takes the
+    // slab kernels (1030 x 1030 x 128 is 1.1e9 bytes)
+    if ((size_t)g.nB() * (size_t)(g.npz + 2) >= ((size_t)1 << 29)) {
+      c->riem_lds = 0;
+      c->remap_lds = 0;
+      c->fast &= ~6;
+    }
     e = std::getenv("FV3_MI355X_MARCH_TJ_KE");
     c->march_tj_ke = e ? std::atoi(e) : 48;
     if (c->march_tj_ke < 1) c->march_tj_ke = 48;
@@ -2807,6 +2814,7 @@ extern "C" int fv3_set_condensate(fv3_ctx *c, const double *q_con, const double 
 extern "C" int fv3_set_fast(fv3_ctx *c, int on) {
   if (!c) return fail("fv3_set_fast: null context");
   c->fast = on == 1 ? 14 : on;   // 1 = every tolerance-mode kernel; otherwise a mask (2 Riem_Solver_c, 4 Riem_Solver3, 8 edge_profile)
+  if ((size_t)c->g.nB() * (size_t)(c->g.npz + 2) >= ((size_t)1 << 29)) c->fast &= ~6;   // 32-bit field indices (nh_fast.h ix_t)
   return 0;
 }
 
@@ -3594,7 +3602,8 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   const double *ak = c->akbk, *bk = c->akbk + (km + 1);
   // the column in LDS (remap_fast.h): the spline in the reference's order by hand-over rounds, the rest the slab kernels' code per
   // (column, level); the same bits as the slab kernels below, which keep what it is not built for
-  bool fast = c->remap_lds && !moist && !c->remap_te_on && !p->fill && p->kord_tm < 0 && km <= 127 && km >= 5 && kord_fast(-p->kord_tm) &&
+  const bool ix32 = (size_t)c->g.nB() * (size_t)(km + 1) < ((size_t)1 << 29);   // 32-bit field indices of the LDS kernels (nh_fast.h ix_t)
+  bool fast = c->remap_lds && ix32 && !moist && !c->remap_te_on && !p->fill && p->kord_tm < 0 && km <= 127 && km >= 5 && kord_fast(-p->kord_tm) &&
               kord_fast(p->kord_mt) && (p->hydrostatic || kord_fast(p->kord_wz));
   for (int n = 0; n < p->nq && fast; n++) fast = kord_fast(kord_tr[n]);
   if (fast) {

@@ -26,6 +26,9 @@
 
 namespace fv3 {
 
+// indices into the fields: 32 bits (a field of one tile is far below 2^32 bytes; the dispatch checks): one register instead of a pair per
+// (column, level) address a thread keeps, shared by the arrays of a layout, and the scalar-base form of the load / store
+using ix_t = unsigned;
 constexpr int kFL = 8;     // levels per lane
 constexpr int kFC = 16;    // columns per workgroup (4 per wavefront)
 constexpr int kFS = kFL + 1;         // doubles per 8-level chunk in LDS: 9, so that the 16 lanes of a column hit 16 different bank pairs
@@ -508,7 +511,7 @@ struct EdgeProfileLds {
     double *B0 = lds, *B1 = lds + kFBuf;
     const bool second = bx >= nblk_a();
     const int blk = second ? bx - nblk_a() : bx;
-    const size_t ls = (size_t)(second ? n2d_b : n2d);
+    const ix_t ls = (ix_t)(second ? n2d_b : n2d);
     const double *f1 = second ? q1_b : q1, *f2 = second ? q2_b : q2;
     double *o1 = second ? q1e_b : q1e, *o2 = second ? q2e_b : q2e;
     const int c0g = blk * kFC;
@@ -520,7 +523,7 @@ struct EdgeProfileLds {
 #endif
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k = idx >> 4;
-        const size_t o = (size_t)(k < km ? k : km - 1) * ls + c0g + (col < ncol ? col : ncol - 1);
+        const ix_t o = (ix_t)(k < km ? k : km - 1) * ls + c0g + (col < ncol ? col : ncol - 1);
         v1[it] = f1[o];
         v2[it] = f2[o];
       }
@@ -605,7 +608,7 @@ struct EdgeProfileLds {
     for (int idx = tid; idx < kFC * 128; idx += kNT) {
       const int col = idx & (kFC - 1), k = idx >> 4;
       if (k <= km && col < ncol) {
-        const size_t o = (size_t)k * ls + c0g + col;
+        const ix_t o = (ix_t)k * ls + c0g + col;
         o1[o] = B0[col * kFP + lds_lev(k)];
         o2[o] = B1[col * kFP + lds_lev(k)];
       }
@@ -656,14 +659,14 @@ struct RiemFast {
   // workgroup's share are issued before the first LDS store (clamped addresses: no branch between them), so the four fields' 32
   // loads per thread are in flight together instead of one HBM round trip after the other.
   static constexpr int kIt = kFC * 128 / kNT;
-  FV3_D void stage_load(double *v, const double *f, size_t o0, int ncol, int lev, int tid) const {
-    const size_t nA = g.nA();
+  FV3_D void stage_load(double *v, const double *f, ix_t o0, int ncol, int lev, int tid) const {
+    const ix_t nA = g.nA();
 #ifndef FV3_HOST_EMU
 #pragma unroll
 #endif
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx & (kFC - 1), k = idx >> 4;
-      v[it] = f[(size_t)(k < lev ? k : lev - 1) * nA + o0 + (col < ncol ? col : ncol - 1)];
+      v[it] = f[(ix_t)(k < lev ? k : lev - 1) * nA + o0 + (col < ncol ? col : ncol - 1)];
     }
   }
   FV3_D void stage_store(double *buf, const double *v, int ncol, int lev, double fill, int tid) const {
@@ -760,8 +763,8 @@ struct RiemFast {
     double *B0 = lds, *B1 = lds + kFBuf, *B2 = lds + 2 * kFBuf, *B3 = lds + 3 * kFBuf;
     const int i0 = i_first() + bx * kFC, j = (CG ? g.js - 1 : g.js) + by;
     const int ncol = (ncols_row() - bx * kFC < kFC) ? ncols_row() - bx * kFC : kFC;
-    const size_t nA = g.nA(), nCC = g.nCC();
-    const size_t o0 = (size_t)g.iA(i0, j);
+    const ix_t nA = g.nA(), nCC = g.nCC();
+    const ix_t o0 = (ix_t)g.iA(i0, j);
     const double rgrav = 1. / cn.grav, rgas = cn.rdgas, gm2 = 1. / (1. - cn.akap), cp2 = cn.akap;
     // SIM: SIM_solver (nh_utils.F90:1396-1537, a_imp < 1: the off-centred form) -- t1g with alpha dt, the explicit part wk of the w
     // equation, the blend of pe2 with pp at the end; everything else is SIM1_solver
@@ -1148,14 +1151,14 @@ struct RiemFast {
       }
     }
     FV3_SYNC();
-    stage_out(B0, zl, ncol, km + 1, tid, [&](int col, int k) { return (size_t)k * nA + o0 + col; });
+    stage_out(B0, zl, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
     if (CG) {
-      stage_out(B1, pef, ncol, km + 1, tid, [&](int col, int k) { return (size_t)k * nA + o0 + col; });
+      stage_out(B1, pef, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
       return;
     }
-    const size_t occ0 = (size_t)g.iCC(i0, j);
-    stage_out(B1, wq, ncol, km, tid, [&](int col, int k) { return (size_t)k * nA + o0 + col; });
-    stage_out(B2, delz, ncol, km, tid, [&](int col, int k) { return (size_t)k * nCC + occ0 + col; });
+    const ix_t occ0 = (ix_t)g.iCC(i0, j);
+    stage_out(B1, wq, ncol, km, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
+    stage_out(B2, delz, ncol, km, tid, [&](int col, int k) { return (ix_t)k * nCC + occ0 + col; });
     FV3_SYNC();
     FV3_WAVE_FOR(wv) {
       const int s = FV3_WVI(wv), c0 = wv * 4;
@@ -1166,10 +1169,10 @@ struct RiemFast {
       }
     }
     FV3_SYNC();
-    stage_out(B0, ppe, ncol, km + 1, tid, [&](int col, int k) { return (size_t)k * nA + o0 + col; });
-    stage_out(B1, pk3, ncol, km + 1, tid, [&](int col, int k) { return (size_t)k * nA + o0 + col; });
+    stage_out(B0, ppe, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
+    stage_out(B1, pk3, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
     if (!last_call) return;
-    stage_out(B2, pk, ncol, km + 1, tid, [&](int col, int k) { return (size_t)k * nCC + occ0 + col; });
+    stage_out(B2, pk, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nCC + occ0 + col; });
     FV3_SYNC();
     FV3_WAVE_FOR(wv) {
       const int s = FV3_WVI(wv), c0 = wv * 4;
@@ -1180,9 +1183,9 @@ struct RiemFast {
     }
     FV3_SYNC();
     stage_out(B0, peln, ncol, km + 1, tid, [&](int col, int k) {
-      return (size_t)(j - g.js) * g.nx * (km + 1) + (size_t)k * g.nx + (i0 - g.is) + col; });
+      return (ix_t)(j - g.js) * g.nx * (km + 1) + (ix_t)k * g.nx + (i0 - g.is) + col; });
     stage_out(B1, pe, ncol, km + 1, tid, [&](int col, int k) {
-      return (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (size_t)k * (g.nx + 2) + (i0 - (g.is - 1)) + col; });
+      return (ix_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (ix_t)k * (g.nx + 2) + (i0 - (g.is - 1)) + col; });
   }
 };
 

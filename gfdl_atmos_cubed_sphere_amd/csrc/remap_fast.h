@@ -93,6 +93,10 @@ FV3_HD int a4_form_of(double a4, double a1, double a2, double a3) {   // the fir
   if (a4 == 3. * (a2 - a1)) return 2;
   return 3;
 }
+// Indices into the fields are 32-bit (a field of one tile is far below 2^32 bytes; the dispatch checks): with 64-bit indices the compiler
+// keeps the eight (column, level) addresses of a thread for every array alive as 64-bit register pairs through the whole kernel and
+// spills them (88 registers at two wavefronts per SIMD, 2.8 GB of scratch traffic per call); a 32-bit index is one register, shared by the
+// arrays of a layout, and goes into the scalar-base form of the load (ix_t: nh_fast.h)
 constexpr int kRNBuf = 4;                // C1 (source coordinate), C2 (target coordinate), A1 (layer means), Q (interface values / out)
 constexpr int kRLds = kRNBuf * kRBuf;          // 75 776 B (chunked: 79 872): two workgroups per CU
 
@@ -431,10 +435,10 @@ struct RemapFastScalars {
     double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf, *QS = C1 + kRQS;   // QS[column * kRP]
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (g.nx - bx * kFC < kFC) ? g.nx - bx * kFC : kFC;
-    const size_t nA = g.nA(), nCC = g.nCC();
-    const size_t o0 = (size_t)g.iA(i0, j), occ0 = (size_t)g.iCC(i0, j);
-    const size_t peb0 = (size_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i0 - (g.is - 1));
-    const size_t lnb0 = (size_t)(j - g.js) * g.nx * (km + 1) + (i0 - g.is);
+    const ix_t nA = g.nA(), nCC = g.nCC();
+    const ix_t o0 = (ix_t)g.iA(i0, j), occ0 = (ix_t)g.iCC(i0, j);
+    const ix_t peb0 = (ix_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (i0 - (g.is - 1));
+    const ix_t lnb0 = (ix_t)(j - g.js) * g.nx * (km + 1) + (i0 - g.is);
     const double k1k = p.rdgas / p.cv_air, rrg = -p.rdgas / p.grav, akap = p.akap;
     const int akt = p.kord_tm < 0 ? -p.kord_tm : p.kord_tm;
     auto clampc = [&](int col) { return col < ncol ? col : ncol - 1; };
@@ -449,11 +453,11 @@ struct RemapFastScalars {
       FV3_LOAD_LOOP(it) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
         const int ki = k0 <= km ? k0 : km, kc = k0 < km ? k0 : km - 1;     // interface / cell row, clamped
-        const size_t o3 = (size_t)kc * nA + o0 + cc, c3 = (size_t)kc * nCC + occ0 + cc;
-        v_pl[it] = peln[lnb0 + (size_t)ki * g.nx + cc];
+        const ix_t o3 = (ix_t)kc * nA + o0 + cc, c3 = (ix_t)kc * nCC + occ0 + cc;
+        v_pl[it] = peln[lnb0 + (ix_t)ki * g.nx + cc];
         v_t[it] = pt[o3];
         if (HYDRO) {
-          v_a[it] = pk[c3 + nCC]; v_b[it] = pk[c3]; v_c[it] = peln[lnb0 + (size_t)(kc + 1) * g.nx + cc];
+          v_a[it] = pk[c3 + nCC]; v_b[it] = pk[c3]; v_c[it] = peln[lnb0 + (ix_t)(kc + 1) * g.nx + cc];
         } else {
           v_a[it] = delp[o3]; v_b[it] = delz[c3];
         }
@@ -463,7 +467,7 @@ struct RemapFastScalars {
         if (k0 <= km) {
           RemapFastCore::at(C1, col, k0) = v_pl[it];
           // (the surface pressure of the thread's column: the same address for every it on the device -- 256 threads, 16 columns)
-          const double v_ps1 = pe[peb0 + (size_t)km * (g.nx + 2) + cc];
+          const double v_ps1 = pe[peb0 + (ix_t)km * (g.nx + 2) + cc];
           RemapFastCore::at(C2, col, k0) = (k0 == 0 || k0 == km) ? v_pl[it] : dlog(ak[k0] + bk[k0] * v_ps1);
           if (k0 == 0) ps[o0 + cc] = v_ps1;   // :298-300
         }
@@ -488,7 +492,7 @@ struct RemapFastScalars {
     core.remap_field(C1, C2, A1, Q, nullptr, true, 1, akt, p.t_min, false, tid);
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-      if (k0 < km && col < ncol) pt[(size_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);   // T_v for now
+      if (k0 < km && col < ncol) pt[(ix_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);   // T_v for now
     }
     // ---- omega on the last step (:432-443, :506-526): interpolated in the old log-p coordinate (C1) to the centres of the new
     //      layers (C2); pe3(k) = omga(k-1), pe3(1) = 0 in A1 ----
@@ -499,7 +503,7 @@ struct RemapFastScalars {
         FV3_LOAD_LOOP(it) {
           const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
           const int kc = k0 < 1 ? 0 : (k0 <= km ? k0 - 1 : km - 1);
-          v_o[it] = omga[(size_t)kc * nA + o0 + clampc(col)];
+          v_o[it] = omga[(ix_t)kc * nA + o0 + clampc(col)];
         }
         for (int it = 0; it < kIt; it++) {
           const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
@@ -527,7 +531,7 @@ struct RemapFastScalars {
       FV3_SYNC();
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-        if (k0 < km && col < ncol) omga[(size_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);
+        if (k0 < km && col < ncol) omga[(ix_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);
       }
     }
     FV3_SYNC();
@@ -537,14 +541,14 @@ struct RemapFastScalars {
       FV3_LOAD_LOOP(it) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
         const int ki = k0 <= km ? k0 : km, kc = k0 < km ? k0 : km - 1;
-        v_pe[it] = pe[peb0 + (size_t)ki * (g.nx + 2) + cc];
-        v_w[it] = HYDRO ? 0. : w[(size_t)kc * nA + o0 + cc];
+        v_pe[it] = pe[peb0 + (ix_t)ki * (g.nx + 2) + cc];
+        v_w[it] = HYDRO ? 0. : w[(ix_t)kc * nA + o0 + cc];
       }
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 <= km) {
           RemapFastCore::at(C1, col, k0) = v_pe[it];
-          const double v_ps1 = pe[peb0 + (size_t)km * (g.nx + 2) + clampc(col)];
+          const double v_ps1 = pe[peb0 + (ix_t)km * (g.nx + 2) + clampc(col)];
           RemapFastCore::at(C2, col, k0) = (k0 == 0) ? p.ptop : (k0 == km ? v_ps1 : ak[k0] + bk[k0] * v_ps1);
         }
         if (!HYDRO && k0 < km) RemapFastCore::at(A1, col, k0) = v_w[it];
@@ -565,12 +569,12 @@ struct RemapFastScalars {
         FV3_LOAD_LOOP(it) {
           const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
           const int kc = k0 < km ? k0 : km - 1;
-          v_dz[it] = delz[(size_t)kc * nCC + occ0 + cc];
-          v_dp[it] = delp[(size_t)kc * nA + o0 + cc];
+          v_dz[it] = delz[(ix_t)kc * nCC + occ0 + cc];
+          v_dp[it] = delp[(ix_t)kc * nA + o0 + cc];
         }
         for (int it = 0; it < kIt; it++) {
           const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-          if (k0 < km && col < ncol) w[(size_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);
+          if (k0 < km && col < ncol) w[(ix_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);
           // ---- delz (:292, :412-423): the specific volume -delz / delp in, delz = -q2 dp2 out ----
           if (k0 < km) RemapFastCore::at(A1, col, k0) = -v_dz[it] / v_dp[it];
         }
@@ -581,7 +585,7 @@ struct RemapFastScalars {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 < km) {
           const double dzn = -RemapFastCore::at(Q, col, k0) * (RemapFastCore::at(C2, col, k0 + 1) - RemapFastCore::at(C2, col, k0));
-          if (col < ncol) delz[(size_t)k0 * nCC + occ0 + col] = dzn;
+          if (col < ncol) delz[(ix_t)k0 * nCC + occ0 + col] = dzn;
         }
       }
     }
@@ -593,7 +597,7 @@ struct RemapFastScalars {
         double v_q[kIt];
         FV3_LOAD_LOOP(it) {
           const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-          v_q[it] = qq[(size_t)(k0 < km ? k0 : km - 1) * nA + o0 + clampc(col)];
+          v_q[it] = qq[(ix_t)(k0 < km ? k0 : km - 1) * nA + o0 + clampc(col)];
         }
         for (int it = 0; it < kIt; it++) {
           const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
@@ -606,7 +610,7 @@ struct RemapFastScalars {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 < km) {
           const double v = RemapFastCore::at(Q, col, k0);
-          if (col < ncol) qq[(size_t)k0 * nA + o0 + col] = v;
+          if (col < ncol) qq[(ix_t)k0 * nA + o0 + col] = v;
         }
       }
     }
@@ -617,8 +621,8 @@ struct RemapFastScalars {
       FV3_LOAD_LOOP(it) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
         const int ki = k0 <= km ? k0 : km, ke = (k0 == 0) ? 0 : km;
-        v_pl[it] = peln[lnb0 + (size_t)ke * g.nx + cc];
-        v_pk[it] = pk[(size_t)ke * nCC + occ0 + cc];
+        v_pl[it] = peln[lnb0 + (ix_t)ke * g.nx + cc];
+        v_pk[it] = pk[(ix_t)ke * nCC + occ0 + cc];
         (void)ki;
       }
       for (int it = 0; it < kIt; it++) {
@@ -629,11 +633,11 @@ struct RemapFastScalars {
             pn = v_pl[it];
             pkv = v_pk[it];
           } else {
-            pn = dlog(ak[k0] + bk[k0] * pe[peb0 + (size_t)km * (g.nx + 2) + clampc(col)]);
+            pn = dlog(ak[k0] + bk[k0] * pe[peb0 + (ix_t)km * (g.nx + 2) + clampc(col)]);
             pkv = dexp(akap * pn);
             if (col < ncol) {
-              peln[lnb0 + (size_t)k0 * g.nx + col] = pn;
-              pk[(size_t)k0 * nCC + occ0 + col] = pkv;
+              peln[lnb0 + (ix_t)k0 * g.nx + col] = pn;
+              pk[(ix_t)k0 * nCC + occ0 + col] = pkv;
             }
           }
           RemapFastCore::at(A1, col, k0) = pn;
@@ -649,15 +653,15 @@ struct RemapFastScalars {
       FV3_LOAD_LOOP(it) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
         const int kc = k0 < km ? k0 : km - 1;
-        v_t[it] = pt[(size_t)kc * nA + o0 + cc];
-        v_dz[it] = HYDRO ? 1. : delz[(size_t)kc * nCC + occ0 + cc];
-        v_q[it] = qs_[(size_t)kc * nA + o0 + cc];
+        v_t[it] = pt[(ix_t)kc * nA + o0 + cc];
+        v_dz[it] = HYDRO ? 1. : delz[(ix_t)kc * nCC + occ0 + cc];
+        v_q[it] = qs_[(ix_t)kc * nA + o0 + cc];
       }
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 >= km || col >= ncol) continue;
         const RColC t2 = RemapFastCore::colc(C2, col), pn = RemapFastCore::colc(A1, col), pk2 = RemapFastCore::colc(Q, col);   // [k], 1-based: row k0 is [k0 + 1]
-        const size_t o3 = (size_t)k0 * nA + o0 + col, c3 = (size_t)k0 * nCC + occ0 + col;
+        const ix_t o3 = (ix_t)k0 * nA + o0 + col, c3 = (ix_t)k0 * nCC + occ0 + col;
         const double dp2 = t2[k0 + 2] - t2[k0 + 1];
         delp[o3] = dp2;
         const double tv = v_t[it];
@@ -700,10 +704,10 @@ struct RemapFastWind {
     double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf;
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (ncols_row() - bx * kFC < kFC) ? ncols_row() - bx * kFC : kFC;
-    const size_t fs = WHICH == 0 ? g.nU() : g.nV();
-    const size_t f0 = WHICH == 0 ? (size_t)g.iU(i0, j) : (size_t)g.iV(i0, j);
+    const ix_t fs = WHICH == 0 ? g.nU() : g.nV();
+    const ix_t f0 = WHICH == 0 ? (ix_t)g.iU(i0, j) : (ix_t)g.iV(i0, j);
     auto PE = [&](int ii, int k0, int jj) {
-      return pe[(size_t)(jj - (g.js - 1)) * (g.nx + 2) * (km + 1) + (size_t)k0 * (g.nx + 2) + (ii - (g.is - 1))];
+      return pe[(ix_t)(jj - (g.js - 1)) * (g.nx + 2) * (km + 1) + (ix_t)k0 * (g.nx + 2) + (ii - (g.is - 1))];
     };
     {
       double v_a[kIt], v_b[kIt], v_sa[kIt], v_sb[kIt], v_f[kIt];
@@ -713,7 +717,7 @@ struct RemapFastWind {
         const int ki = k0 <= km ? k0 : km, kc = k0 < km ? k0 : km - 1;
         v_a[it] = PE(i2, ki, j2); v_b[it] = PE(i, ki, j);
         v_sa[it] = PE(i2, km, j2); v_sb[it] = PE(i, km, j);
-        v_f[it] = f[(size_t)kc * fs + f0 + cc];
+        v_f[it] = f[(ix_t)kc * fs + f0 + cc];
       }
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
@@ -736,7 +740,7 @@ struct RemapFastWind {
     core.remap_field(C1, C2, A1, Q, nullptr, false, -1, kord_mt, 0., false, tid);
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-      if (k0 < km && col < ncol) f[(size_t)k0 * fs + f0 + col] = RemapFastCore::at(Q, col, k0);
+      if (k0 < km && col < ncol) f[(ix_t)k0 * fs + f0 + col] = RemapFastCore::at(Q, col, k0);
     }
   }
 };
