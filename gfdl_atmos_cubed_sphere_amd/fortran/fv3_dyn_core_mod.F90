@@ -25,8 +25,8 @@
 !> fv3_halo_complete with the neighbour PEs, tracer_2d's mp_reduce_max through fv3_allreduce_max (fv3_host_comm_layout).
 !>
 !> Restrictions (error stop with the reason, never a silent difference): no nesting / regional BCs;
-!> use_cond / moist_kappa in fv_dynamics and on the sphere (dyn_core carries them on the doubly periodic domain), consv_te / tau on the
-!> doubly periodic domain, do_diss_est and the SKEB diss_est accumulation are not carried through this wrapper.
+!> use_cond / moist_kappa in fv_dynamics and on the sphere (dyn_core carries them on the doubly periodic domain), do_diss_est and the
+!> SKEB diss_est accumulation are not carried through this wrapper.  consv_te and tau > 0 are carried on both domains.
 module fv3_arrays_compat_mod
   use iso_c_binding
   implicit none
@@ -485,7 +485,6 @@ contains
     real(c_double), allocatable, target :: w_c(:,:,:), delz_c(:,:,:), zs(:,:)
     integer(c_size_t) :: nk, nk1
     integer :: nx, ny
-    type(c_ptr) :: qv
 
     if (neststruct%nested .or. gridstruct%nested .or. gridstruct%regional .or. gridstruct%bounded_domain) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): nested / regional domains are not built'
@@ -496,8 +495,6 @@ contains
       return
     end if
     if (gridstruct%grid_type /= 4) error stop 'fv_dynamics (fv3_dyn_core_mod): grid_type = 3 is not built'
-    if (abs(consv_te) > 0.001d0) error stop 'fv_dynamics (fv3_dyn_core_mod): consv_te on a doubly periodic domain is carried by the Python host (FvDynamics), not here'
-    if (flagstruct%tau > 0.d0) error stop 'fv_dynamics (fv3_dyn_core_mod): tau > 0 on a doubly periodic domain (Rayleigh_Friction) is carried by the Python host, not here'
     if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%do_diss_est .or. flagstruct%beta < 0.d0) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / do_diss_est / beta < 0 are not built'
     if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
@@ -528,21 +525,11 @@ contains
     call put(atf%omga, c_loc(omga), atf%nA*nk)
     call fv3_check(fv3_sync(atf%ctx), 'fv3_sync')
 
-    ! :284-399: pkz (nonhydrostatic) and pt = pt*(1 + zvir*q(sphum))/pkz
-    qv = c_null_ptr
-    if (zvir > 0.d0 .and. nq_tot > 0) qv = atf%q
-    if (hydrostatic) then
-      call fv3_check(fv3_pt_to_theta_v(atf%ctx, 1_c_int, zvir, kappa, atf%fl%rdgas, atf%fl%grav, atf%pt, atf%delp, c_null_ptr, qv, &
-                                       atf%pkz), 'fv3_pt_to_theta_v')
-    else
-      call fv3_check(fv3_pt_to_theta_v(atf%ctx, 0_c_int, zvir, kappa, atf%fl%rdgas, atf%fl%grav, atf%pt, atf%delp, atf%delz, qv, &
-                                       atf%pkz), 'fv3_pt_to_theta_v')
-    end if
-    call fv3_fv_dynamics(atf, bdt, .true.)                               ! :460-665
-    if (flagstruct%c2l_ord == 4) then                                    ! :911, fv_grid_utils.F90:2372-2376
-      call fv3_host_halo(atf, atf%u, 1, npz); call fv3_host_halo(atf, atf%v, 2, npz)
-    end if
-    call fv3_check(fv3_c2l(atf%ctx, int(flagstruct%c2l_ord, c_int), atf%u, atf%v, atf%ua, atf%va), 'fv3_c2l')
+    ! :284-399 T -> theta_v, :345 compute_total_energy, :362-375 Rayleigh_Friction, the k_split loop :460-665 with the energy fixer of
+    ! its last remap, cubed_to_latlon :911
+    atf%fl%adiabatic = flagstruct%adiabatic .or. zvir == 0.d0 .or. nq_tot == 0
+    call fv3_fv_dynamics_call(atf, bdt, consv_te, flagstruct%tau, flagstruct%rf_cutoff, zvir, flagstruct%c2l_ord, flagstruct%moist_phys, &
+                              6.3712d6)
 
     call fv3_check(fv3_sync(atf%ctx), 'fv3_sync')
     call get(c_loc(u), atf%u, atf%nU*nk);        call get(c_loc(v), atf%v, atf%nV*nk)

@@ -21,7 +21,7 @@ module fv3_host_mod
   private
   public :: fv3_flags, fv3_atmos
   public :: fv3_host_halo, fv3_host_init, fv3_host_init_grid, fv3_host_final, fv3_host_upload, fv3_host_download, fv3_host_comm_layout
-  public :: fv3_dyn_core, fv3_dyn_core_hydrostatic, fv3_tracer_2d, fv3_fv_dynamics
+  public :: fv3_dyn_core, fv3_dyn_core_hydrostatic, fv3_tracer_2d, fv3_fv_dynamics, fv3_fv_dynamics_call
   public :: dmalloc, dzero, swap, upload_levels, host_n_con, KIND_A, KIND_U, KIND_V, KIND_B    ! shared with fv3_sphere_mod
   public :: inline_q_begin, inline_q_end
 
@@ -80,6 +80,11 @@ module fv3_host_mod
     ! several ranks of a doubly periodic px x py layout (fv3_host_comm_layout): the neighbour ranks of the eight directions
     integer :: nranks = 1
     integer(c_int) :: peers_to(8) = 0_c_int, peers_from(8) = 0_c_int
+    ! fv3_fv_dynamics_call: the energy fixer's columns, g_sum's weights, the Rayleigh profile, u2f of Rayleigh_Friction
+    type(c_ptr) :: te0 = c_null_ptr, te = c_null_ptr, zs1 = c_null_ptr, zs0 = c_null_ptr, u2f = c_null_ptr
+    real(c_double), allocatable :: area(:,:), rf(:), pm(:)
+    integer :: kmax = -1
+    real(c_double) :: e_flux = 0.d0, dtmp = 0.d0
   end type
 
   logical, save :: host_comm = .false.
@@ -254,6 +259,13 @@ contains
     at%da_min = gh%da_min
     if (.not. c_associated(at%ctx)) call fv3_check(fv3_create(dom, at%ctx), 'fv3_create')
     call fv3_check(fv3_grid_upload(at%ctx, gh), 'fv3_grid_upload')
+    block      ! area of the compute domain: the weights of g_sum (fv_mapz.F90:736)
+      real(c_double), pointer :: a(:,:)
+      if (allocated(at%area)) deallocate(at%area)
+      allocate(at%area(nx, ny))
+      call c_f_pointer(gh%area, a, [nx + 2*NG, ny + 2*NG])
+      at%area = a(NG+1:NG+nx, NG+1:NG+ny)
+    end block
     call host_comm_init(at)
 
     ! ---- device arrays ----
@@ -667,10 +679,11 @@ contains
 
   !> one dt_atmos: the k_split loop of fv_dynamics (fv_dynamics.F90:460-665): acoustic substeps, tracer transport,
   !> vertical remap.  pt holds theta_v (what dyn_core works on); last_step makes the final remap return T (fv_mapz.F90:793-821).
-  subroutine fv3_fv_dynamics(at, bdt, last_step)
+  subroutine fv3_fv_dynamics(at, bdt, last_step, last_code)
     type(fv3_atmos), intent(inout) :: at
     real(c_double), intent(in) :: bdt
     logical, intent(in) :: last_step
+    integer, intent(in), optional :: last_code      !< what the last remap gets as last_step (2: the energy fixer follows, T_v stays)
     type(fv3_remap_params) :: rp
     integer(c_int), allocatable :: kord_tr(:)
     real(c_double) :: mdt
@@ -689,6 +702,7 @@ contains
       call fv3_dyn_core(at, mdt)                                                                           ! :493
       if (at%nq > 0 .and. .not. at%fl%inline_q) call fv3_tracer_2d(at)                                     ! :509-533
       rp%last_step = merge(1_c_int, 0_c_int, last_step .and. n_map == at%fl%k_split)
+      if (present(last_code) .and. last_step .and. n_map == at%fl%k_split) rp%last_step = int(last_code, c_int)
       if (at%fl%remap_te) call fv3_check(fv3_set_remap_te(at%ctx, 1_c_int, at%phis, at%dp1), 'set_remap_te')   ! te = dp1, :612
       if (at%fl%use_cond .or. at%fl%moist_kappa) then          ! q_con is a ping-pong pair: the current buffer
         at%fl%moist%moist_kappa = merge(1_c_int, 0_c_int, at%fl%moist_kappa)
@@ -705,6 +719,125 @@ contains
                        'lagrangian_to_eulerian')                                                           ! :607
       end if
     end do
+  end subroutine
+
+  !> A whole fv_dynamics call (model/fv_dynamics.F90:79-936 for the adiabatic core) on one doubly periodic tile (or this rank's block of
+  !> it); pt holds T (T_v) on entry and on return.  compute_total_energy when consv_te > 0 (:345-355), T -> theta_v with the virtual
+  !> effect (:296-329, :379-399), Rayleigh_Friction when tau > 0 (:372-375, :1126-1264: u2f, its halo update, the damping), the k_split
+  !> loop whose last remap returns T and -- with |consv_te| > consv_min -- runs the energy fixer (fv_mapz.F90:643-772 with the
+  !> reproducing sum behind fv3_ordered_sum, :793-821), cubed_to_latlon (:911).  The calls of the Python host's
+  !> FvDynamics.step_from_temperature in its order.
+  subroutine fv3_fv_dynamics_call(at, bdt, consv_te, tau, rf_cutoff, zvir, c2l_ord, moist_phys, radius)
+    type(fv3_atmos), intent(inout) :: at
+    real(c_double), intent(in) :: bdt, consv_te, tau, rf_cutoff, zvir, radius
+    integer, intent(in) :: c2l_ord
+    logical, intent(in) :: moist_phys
+    real(c_double), parameter :: consv_min = 0.001d0, pi = 3.1415926535897931d0
+    type(fv3_remap_params) :: rp
+    type(c_ptr) :: qv, wp, dzp, pep, pelnp, pkp, zs0p
+    real(c_double) :: zv, zsum, dtmp, ph1, ph2
+    logical :: hyd, fixer
+    integer(c_int) :: ihyd
+    integer :: k
+    hyd = at%fl%hydrostatic; ihyd = merge(1_c_int, 0_c_int, hyd)
+    fixer = abs(consv_te) > consv_min
+    rp%hydrostatic = ihyd; rp%adiabatic = merge(1_c_int, 0_c_int, at%fl%adiabatic); rp%nq = int(at%nq, c_int)
+    rp%kord_mt = int(at%fl%kord_mt, c_int); rp%kord_wz = int(at%fl%kord_wz, c_int); rp%kord_tm = int(at%fl%kord_tm, c_int)
+    rp%sphum = merge(1_c_int, 0_c_int, at%nq > 0); rp%fill = merge(1_c_int, 0_c_int, at%fl%fill)
+    rp%akap = at%fl%akap; rp%ptop = at%fl%ptop; rp%rdgas = at%fl%rdgas; rp%grav = at%fl%grav
+    rp%cv_air = at%fl%cp_air - at%fl%rdgas; rp%r_vir = at%fl%r_vir; rp%cp = at%fl%cp_air; rp%t_min = at%fl%t_min
+    rp%last_step = 0_c_int
+    if (fixer .and. .not. c_associated(at%te0)) then
+      call dmalloc(at%te0, at%nCC); call dmalloc(at%te, at%nCC); call dmalloc(at%zs1, at%nCC); call dmalloc(at%zs0, at%nCC)
+      call dzero(at, at%te0, at%nCC); call dzero(at, at%te, at%nCC); call dzero(at, at%zs1, at%nCC); call dzero(at, at%zs0, at%nCC)
+    end if
+    qv = c_null_ptr; zv = 0.d0
+    if (at%nq > 0 .and. .not. at%fl%adiabatic) then
+      qv = at%q; zv = zvir
+    end if
+    wp = at%w; dzp = at%delz; pep = c_null_ptr; pelnp = c_null_ptr
+    if (hyd) then
+      wp = c_null_ptr; dzp = c_null_ptr; pep = at%pe; pelnp = at%peln
+    end if
+    if (consv_te > consv_min) &
+      call fv3_check(fv3_compute_total_energy(at%ctx, rp, merge(1_c_int, 0_c_int, moist_phys), at%u, at%v, wp, dzp, at%pt, at%delp, &
+                                              at%q, c_null_ptr, pep, pelnp, at%phis, at%te0), 'compute_total_energy')
+    if (tau > 0.d0) then
+      if (at%kmax < 0) then      ! rf(k), kmax (:1169-1182) with pfull of :254-262
+        if (allocated(at%rf)) deallocate(at%rf, at%pm)
+        allocate(at%rf(at%npz), at%pm(at%npz)); at%rf = 0.d0; at%kmax = 0
+        do k = 1, at%npz
+          ph1 = at%ak(k) + at%bk(k) * 1.d5; ph2 = at%ak(k+1) + at%bk(k+1) * 1.d5
+          at%pm(k) = (ph2 - ph1) / log(ph2 / ph1)
+        end do
+        do k = 1, at%npz
+          if (at%pm(k) < rf_cutoff) then
+            at%rf(k) = abs(bdt) / (tau * 86400.d0) * sin(0.5d0 * pi * log(rf_cutoff / at%pm(k)) / log(rf_cutoff / at%fl%ptop))**2
+            at%kmax = k
+          else
+            exit
+          end if
+        end do
+      end if
+      if (.not. hyd) call fv3_check(fv3_pt_to_theta_v(at%ctx, -1_c_int, zv, at%fl%akap, at%fl%rdgas, at%fl%grav, at%pt, at%delp, at%delz, &
+                                                      qv, at%pkz), 'pt_to_theta_v')
+      if (at%kmax > 0) then
+        if (.not. c_associated(at%u2f)) then
+          call dmalloc(at%u2f, at%nA * at%npz); call dzero(at, at%u2f, at%nA * at%npz)
+        end if
+        call fv3_check(fv3_rayleigh_u2f(at%ctx, int(at%kmax, c_int), ihyd, at%u, at%v, wp, at%ua, at%va, at%u2f), 'rayleigh_u2f')
+        call halo(at, at%u2f, KIND_A, at%npz)                                                               ! :1207-1209
+        call fv3_check(fv3_rayleigh_apply(at%ctx, int(at%kmax, c_int), 1_c_int, ihyd, at%fl%cp_air, at%fl%rdgas, at%fl%ptop, at%pm, at%rf, &
+                                          at%u2f, at%pt, dzp, at%u, at%v, wp), 'rayleigh_apply')
+      end if
+      call fv3_check(fv3_pt_to_theta_v(at%ctx, 1_c_int, zv, at%fl%akap, at%fl%rdgas, at%fl%grav, at%pt, at%delp, dzp, qv, at%pkz), &
+                     'pt_to_theta_v')
+    else
+      call fv3_check(fv3_pt_to_theta_v(at%ctx, ihyd, zv, at%fl%akap, at%fl%rdgas, at%fl%grav, at%pt, at%delp, dzp, qv, at%pkz), &
+                     'pt_to_theta_v')
+    end if
+    if (fixer) then
+      call fv3_fv_dynamics(at, bdt, .true., 2)
+      pkp = c_null_ptr; zs0p = c_null_ptr
+      if (hyd) then
+        pkp = at%pk; zs0p = at%zs0
+      end if
+      rp%last_step = 2_c_int
+      call fv3_check(fv3_energy_fixer_sums(at%ctx, rp, merge(1_c_int, 0_c_int, consv_te < 0.d0), at%u, at%v, wp, dzp, at%pt, at%delp, &
+                                           at%q, pep, pelnp, at%phis, at%pkz, pkp, at%te0, at%te, at%zs1, zs0p), 'energy_fixer_sums')
+      if (hyd) then
+        zsum = g_sum(at%zs0)
+      else
+        zsum = g_sum(at%zs1)
+      end if
+      if (consv_te < 0.d0) then
+        at%e_flux = consv_te
+        dtmp = at%e_flux * (at%fl%grav * bdt * 4.d0 * pi * radius**2) / zsum
+      else
+        dtmp = consv_te * g_sum(at%te)
+        at%e_flux = dtmp / (at%fl%grav * bdt * 4.d0 * pi * radius**2)
+        dtmp = dtmp / zsum
+      end if
+      at%dtmp = dtmp
+      call fv3_check(fv3_remap_finish(at%ctx, rp, dtmp, at%pt, at%pkz, at%q), 'remap_finish')
+    else
+      call fv3_fv_dynamics(at, bdt, .true.)
+    end if
+    if (c2l_ord == 4) then                                               ! fv_grid_utils.F90:2372-2376
+      call halo(at, at%u, KIND_U, at%npz); call halo(at, at%v, KIND_V, at%npz)
+    end if
+    call fv3_check(fv3_c2l(at%ctx, int(c2l_ord, c_int), at%u, at%v, at%ua, at%va), 'c2l')      ! :911
+  contains
+    function g_sum(col) result(tot)      ! g_sum(..., area, 0, reproduce = .true.) over this rank's block and the ranks
+      type(c_ptr), intent(in) :: col
+      real(c_double) :: tot
+      real(c_double), allocatable, target :: h(:,:), vals(:)
+      allocate(h(at%nx, at%ny), vals(at%nx * at%ny))
+      call fv3_check(fv3_memcpy_d2h(at%ctx, c_loc(h), col, at%nCC * 8_c_size_t), 'd2h')
+      call fv3_check(fv3_sync(at%ctx), 'sync')
+      vals = reshape(h * at%area, [at%nx * at%ny])
+      call fv3_check(fv3_ordered_sum(at%ctx, vals, int(size(vals), c_size_t), tot), 'ordered_sum')
+    end function
   end subroutine
 
   !> inline_q (dyn_core.F90:340 / :573 / :768, sw_core.F90:1020-1043), before d_sw: the halo of q; d_sw gets zeroed flux arrays

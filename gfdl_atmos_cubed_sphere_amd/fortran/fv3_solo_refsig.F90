@@ -19,7 +19,7 @@ program fv3_solo_refsig
   real(c_double), allocatable :: ps(:,:), u0(:,:,:), v0(:,:,:), ze0(:,:,:)
   logical :: whole
   integer(c_int) :: nx, ny, npz, nq, n_split, k_split, nsteps, last_step, ihydro
-  real(c_double) :: dxc_, dyc_, f0_, bdt, ptop, d_con, d_ext, beta
+  real(c_double) :: dxc_, dyc_, f0_, bdt, ptop, d_con, d_ext, beta, consv_te, tau
   real(c_double), allocatable :: ak(:), bk(:), pfull(:)
   real(c_double), allocatable, dimension(:,:,:) :: u, v, w, delp, pt, delz, cappa, q_con, heat_source, diss_est, pe, peln, pk, &
                                                    omga, uc, vc, ua, va, mfx, mfy, cx, cy, pkz
@@ -44,6 +44,11 @@ program fv3_solo_refsig
   mode = ' '
   if (command_argument_count() >= 3) call get_command_argument(3, mode)
   whole = trim(mode) == 'fv_dynamics'
+  consv_te = 0.d0; tau = 0.d0          ! fv_dynamics mode: FV3_SOLO_CONSV_TE / FV3_SOLO_TAU (days) in the environment
+  call get_environment_variable('FV3_SOLO_CONSV_TE', arg, status=n)
+  if (n == 0) read(arg, *) consv_te
+  call get_environment_variable('FV3_SOLO_TAU', arg, status=n)
+  if (n == 0) read(arg, *) tau
   rank = 0; nranks = 1; px = 1; py = 1
   if (command_argument_count() >= 8) then
     call get_command_argument(4, arg); read(arg, *) rank
@@ -142,10 +147,10 @@ program fv3_solo_refsig
   ts%use_cond = iand(ihydro, 8_c_int) /= 0; ts%moist_kappa = iand(ihydro, 16_c_int) /= 0
 
   if (whole) then
-    fs%c2l_ord = 4
+    fs%c2l_ord = 4; fs%tau = tau; fs%moist_phys = .false.
     if (hydrostatic) pkz = 1.d0     ! the state p_var would have left: here the file's pt is theta already (pkz = 1 <=> T = theta)
     do n = 1, nsteps
-      call fv_dynamics(gnx + 1, gny + 1, int(npz), int(nq), 3, bdt, 0.d0, .false., &
+      call fv_dynamics(gnx + 1, gny + 1, int(npz), int(nq), 3, bdt, consv_te, .false., &
                        .false., KAPPA, CP_AIR, 0.d0, ptop, 0, max(1, int(nq)), int(n_split), &
                        0, u0, v0, u, v, w, delz, hydrostatic, pt, delp, q, &
                        ps, pe, pk, peln, pkz, phis, q_con, omga, ua, va, uc, vc, &

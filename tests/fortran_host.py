@@ -263,7 +263,8 @@ def _compare_blocks(res, ref, bd, what):
             assert np.array_equal(a, r_), f"{n} (block {b.is_}:{b.ie}, {b.js}:{b.je}): {what} and the Python host differ (max abs {np.max(np.abs(a - r_)):.3e})"
 
 
-def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, hydrostatic=False, layout=(1, 1)):
+def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, hydrostatic=False, layout=(1, 1),
+                              consv_te=0.0, tau=0.0):
     """fv_dynamics called with the reference's argument list on host arrays (fv3_dyn_core_mod::fv_dynamics, driver fv3_solo_refsig in
     its fv_dynamics mode: T -> theta_v, k_split x (dyn_core, tracer_2d, remap), last_step, cubed_to_latlon) against the Python host's
     FvDynamics.step_from_temperature on the same state: u, v, w, delp, pt (T), delz, the tracers and ua bit-identical"""
@@ -284,7 +285,7 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
     fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic)
     ctx = Context(g, npz, lib=lib)
     try:
-        fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=k_split, adiabatic=True, c2l_ord=4)
+        fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=k_split, adiabatic=True, c2l_ord=4, consv_te=consv_te, tau=tau, moist_phys=False)
         fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
         if nq:
             fv.set_tracers(q)
@@ -306,7 +307,12 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
     if nq:
         spec.append(("q", "A", (nq,)))
     spec.append(("ua", "A", ()))
-    res, out = _run_refsig(lib, exe, fin, fout, "fv_dynamics", layout, bd, npz, spec)
+    os.environ["FV3_SOLO_CONSV_TE"], os.environ["FV3_SOLO_TAU"] = repr(float(consv_te)), repr(float(tau))
+    try:
+        res, out = _run_refsig(lib, exe, fin, fout, "fv_dynamics", layout, bd, npz, spec)
+    finally:
+        os.environ.pop("FV3_SOLO_CONSV_TE", None)
+        os.environ.pop("FV3_SOLO_TAU", None)
     _compare_blocks(res, ref, bd, "reference-signature fv_dynamics")
     return out
 

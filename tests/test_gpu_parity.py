@@ -1250,3 +1250,13 @@ def test_riem_solvers_sim3_sim3p0_rim_2d(prod, dims):
         assert N.check_riem_solver3(prod, a_imp=a_imp, m_split=ms, use_logp=True, last_call=True, fp_out=True, **dims) <= 1e-13
         assert N.check_riem_solver3(prod, a_imp=a_imp, m_split=ms, last_call=False, **dims) <= 1e-13
         assert N.check_riem_solver_c(prod, a_imp=a_imp, m_split=ms, **dims) <= 1e-13
+
+
+def test_fortran_fv_dynamics_reference_argument_list_with_the_energy_fixer_and_rayleigh_friction(prod, tmp_path):
+    """fv_dynamics with the reference's argument list on the doubly periodic domain with consv_te = 1 and tau = 10 days carried in Fortran
+    (fv3_fv_dynamics_call): bit-identical to FvDynamics.step_from_temperature on the GPU"""
+    import fortran_host as F
+    if F.fortran_compiler() is None:
+        pytest.skip("no Fortran compiler in this image")
+    F.check_fortran_fv_dynamics(prod, tmp_path, consv_te=1.0, tau=10.0, npz=16)
+    F.check_fortran_fv_dynamics(prod, tmp_path, consv_te=-2.0, hydrostatic=True)

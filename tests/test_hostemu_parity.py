@@ -1166,3 +1166,16 @@ def test_riem_solvers_sim3_sim3p0_rim_2d(emu, dims):
         assert N.check_riem_solver3(emu, a_imp=a_imp, m_split=ms, use_logp=True, last_call=True, fp_out=True, **dims) <= 1e-13
         assert N.check_riem_solver3(emu, a_imp=a_imp, m_split=ms, last_call=False, **dims) <= 1e-13
         assert N.check_riem_solver_c(emu, a_imp=a_imp, m_split=ms, **dims) <= 1e-13
+
+
+@pytest.mark.parametrize("kw", [dict(consv_te=1.0), dict(consv_te=1.0, tau=10.0, npz=16), dict(consv_te=-2.0, hydrostatic=True),
+                                dict(consv_te=1.0, tau=10.0, npz=16, layout=(2, 2)), dict(tau=10.0, npz=16, hydrostatic=True, layout=(2, 1))])
+def test_fortran_fv_dynamics_reference_argument_list_with_the_energy_fixer_and_rayleigh_friction(emu, tmp_path, kw):
+    """fv_dynamics with the reference's argument list on the doubly periodic domain with consv_te (compute_total_energy, the energy fixer
+    of the last remap with the reproducing sum over the ranks, the prescribed flux) and tau > 0 (Rayleigh_Friction: u2f, its halo update,
+    the damping) carried in Fortran (fv3_host_mod fv3_fv_dynamics_call), one rank and 2 / 4 processes: bit-identical to
+    FvDynamics.step_from_temperature"""
+    import fortran_host as F
+    if F.fortran_compiler() is None:
+        pytest.skip("no amdflang in this environment")
+    F.check_fortran_fv_dynamics(emu, tmp_path, **kw)
