@@ -50,24 +50,33 @@ struct FramePass {
     const int js1 = w < j1 ? w : j1, jn0 = (npy - w) > j0 ? (npy - w) : j0;   // south band j0..js1, north band jn0..j1
     const int ns = js1 - j0 + 1;
     const int nsn = nbx * nby_sn;
-    if (bflat < nsn) {
-      const int bx = bflat % nbx, by = bflat / nbx;
-      for (int t = tid; t < 256; t += kNT) {
-        const int v = by * 4 + (t >> 6);
-        const int j = v < ns ? j0 + v : jn0 + (v - ns);
-        const int i = i0 + bx * 64 + (t & 63);
-        if (i <= i1 && j <= j1) f(i, j, k);
-      }
-    } else {
-      // 16 rows x 16 columns per workgroup: the west columns (i0 : w) of 16 rows, then the east columns (npx - w : i1)
-      const int iw1 = w < i1 ? w : i1, ie0 = (npx - w) > i0 ? (npx - w) : i0;
-      const int nw = iw1 - i0 + 1, ne = i1 - ie0 + 1;
-      const int bw = bflat - nsn;
-      const int side = bw & 1, jb = js1 + 1 + (bw >> 1) * 16;
-      for (int t = tid; t < 256; t += kNT) {
-        const int c = t & 15, j = jb + (t >> 4);
-        if (j >= jn0) continue;
-        for (int cc = c; cc < (side ? ne : nw); cc += 16) f(side ? ie0 + cc : i0 + cc, j, k);
+    // ONE call site of the functor for both kinds of workgroup (inlined twice -- once per branch, the second inside a loop -- the
+    // heavier passes took 3 - 4 times the registers of their whole-face form, BoxPass: 158 against 54 for CswCubedP3, 195 against 55
+    // for DswCubedD5): the point (i, j) of round r is formed first, then the functor runs.
+    // South / north workgroup: 64 columns x 4 rows, one round.  West / east workgroup: 16 rows x 16 columns per round, the west
+    // columns (i0 : w) or the east columns (npx - w : i1) of the rows between the bands.
+    const bool sn = bflat < nsn;
+    const int iw1 = w < i1 ? w : i1, ie0 = (npx - w) > i0 ? (npx - w) : i0;
+    const int bw = bflat - nsn, side = bw & 1;
+    const int ncol = sn ? 0 : (side ? i1 - ie0 + 1 : iw1 - i0 + 1);
+    const int rounds = sn ? 1 : (ncol + 15) / 16;
+    for (int t = tid; t < 256; t += kNT) {
+      for (int r = 0; r < rounds; r++) {
+        int i, j;
+        bool ok;
+        if (sn) {
+          const int bx = bflat % nbx, by = bflat / nbx;
+          const int v = by * 4 + (t >> 6);
+          j = v < ns ? j0 + v : jn0 + (v - ns);
+          i = i0 + bx * 64 + (t & 63);
+          ok = i <= i1 && j <= j1;
+        } else {
+          const int cc = (t & 15) + 16 * r;
+          j = js1 + 1 + (bw >> 1) * 16 + (t >> 4);
+          i = (side ? ie0 : i0) + cc;
+          ok = j < jn0 && cc < ncol;
+        }
+        if (ok) f(i, j, k);
       }
     }
   }

@@ -16,6 +16,19 @@ struct CswCubedState {
   Grid g;
   CswArgs a;
   double *utmp, *vtmp, *ke, *vort;  // A x npz scratch
+  // Work copies of the outputs the passes read back (ua, va, ut, vt: A layout; uc: V; vc: U), or null: the outputs themselves (the
+  // passes alone, or the hybrid on one stream).  The passes form their intermediates on a frame WIDER than the frame they own, the
+  // outer part of it from incomplete stencils -- on one stream the marching kernel overwrites those points afterwards.  With the
+  // work copies the passes write an output only where they own it (wr) and read their own copies, so they touch nothing the marching
+  // kernel writes and the two can run side by side (fv3_api.hip csw_cubed, two lanes).
+  double *ua_w = nullptr, *va_w = nullptr, *uc_w = nullptr, *vc_w = nullptr, *ut_w = nullptr, *vt_w = nullptr;
+  FV3_HD const double *uaR() const { return ua_w ? ua_w : a.ua; }
+  FV3_HD const double *vaR() const { return va_w ? va_w : a.va; }
+  FV3_HD const double *ucR() const { return uc_w ? uc_w : a.uc; }
+  FV3_HD const double *vcR() const { return vc_w ? vc_w : a.vc; }
+  FV3_HD const double *utR() const { return ut_w ? ut_w : a.ut; }
+  FV3_HD const double *vtR() const { return vt_w ? vt_w : a.vt; }
+  FV3_HD bool wr(int i, int j) const { return !ua_w || own(i, j); }   // may a pass write the OUTPUT at (i, j)?
   // hybrid: P5 writes only the points of the frame of width own_w along the face edges (0: every point), the marching kernel
   // owns the rest (CswArgs::mask_w); P3 forms the winds (divg 0), the divergence (divg 2) or both (divg 1)
   int own_w = 0, divg = 1;
@@ -67,8 +80,15 @@ struct CswCubedP2 {
     const Grid &g = s.g;
     const CA ut = cview_A(g, s.utmp), vt = cview_A(g, s.vtmp);
     const double cs = FV3_M(s.cosa_s, i, j), rs = FV3_M(s.rsin2, i, j);
-    view_A(g, s.a.ua)(i, j, k) = (ut(i, j, k) - vt(i, j, k) * cs) * rs;
-    view_A(g, s.a.va)(i, j, k) = (vt(i, j, k) - ut(i, j, k) * cs) * rs;
+    const double uav = (ut(i, j, k) - vt(i, j, k) * cs) * rs, vav = (vt(i, j, k) - ut(i, j, k) * cs) * rs;
+    if (s.ua_w) {
+      view_A(g, s.ua_w)(i, j, k) = uav;
+      view_A(g, s.va_w)(i, j, k) = vav;
+    }
+    if (s.wr(i, j)) {
+      view_A(g, s.a.ua)(i, j, k) = uav;
+      view_A(g, s.a.va)(i, j, k) = vav;
+    }
   }
 };
 
@@ -79,7 +99,7 @@ struct CswCubedP2c {
   FV3_HD void operator()(int m, int, int k) const {
     const Grid &g = s.g;
     const int npx = g.npx, npy = g.npy, ie = g.ie, je = g.je;
-    const VA ut = view_A(g, s.utmp), vt = view_A(g, s.vtmp), ua = view_A(g, s.a.ua), va = view_A(g, s.a.va);
+    const VA ut = view_A(g, s.utmp), vt = view_A(g, s.vtmp);
     // every source below is a point no assignment of this pass writes
     {  // Xdir: i = -2..0 resp. 0..2
       const int iw = m - 2, ip = m;
@@ -95,6 +115,9 @@ struct CswCubedP2c {
       vt(npx, jw, k) = ut(ie + jw, 0, k);           // se
       vt(npx, npy + jp, k) = -ut(ie - jp, npy, k);  // ne
     }
+    // (every point below lies within two cells of a face edge: the passes own it, in the outputs and in their work copies alike)
+    for (int fam = 0; fam < (s.ua_w ? 2 : 1); fam++) {
+    const VA ua = view_A(g, fam ? s.ua_w : s.a.ua), va = view_A(g, fam ? s.va_w : s.a.va);
     if (m == 0) {
       ua(-1, 0, k) = -va(0, 2, k);  ua(0, 0, k) = -va(0, 1, k);                            // sw
       ua(npx, 0, k) = va(npx, 1, k);  ua(npx + 1, 0, k) = va(npx, 2, k);                   // se
@@ -105,6 +128,7 @@ struct CswCubedP2c {
       va(npx, 0, k) = ua(npx - 1, 0, k);  va(npx, -1, k) = ua(npx - 2, 0, k);              // se
       va(npx, npy, k) = -ua(npx - 1, npy, k);  va(npx, npy + 1, k) = -ua(npx - 2, npy, k);  // ne
       va(0, npy, k) = ua(1, npy, k);  va(0, npy + 1, k) = ua(2, npy, k);                   // nw
+    }
     }
   }
 };
@@ -121,9 +145,10 @@ struct CswCubedP3 {
     constexpr double a1 = 0.5625, a2 = -0.0625, c1 = -2. / 14., c2 = 11. / 14., c3 = 5. / 14.;
     const Grid &g = s.g;
     const int is = g.is, ie = g.ie, js = g.js, je = g.je, npx = g.npx, npy = g.npy;
-    const CA utmp = cview_A(g, s.utmp), vtmp = cview_A(g, s.vtmp), ua = cview_A(g, s.a.ua), va = cview_A(g, s.a.va);
+    const CA utmp = cview_A(g, s.utmp), vtmp = cview_A(g, s.vtmp), ua = cview_A(g, s.uaR()), va = cview_A(g, s.vaR());
     const CA u = cview_U(g, s.a.u), v = cview_V(g, s.a.v);
     const double dt2 = s.a.dt2;
+    const bool wr = s.wr(i, j);
     if (s.divg != 2 && j <= je + 1) {  // uc, ut (:3187-3255)
       double ucv, utv;
       if (i == 1 || i == npx) {
@@ -141,13 +166,15 @@ struct CswCubedP3 {
           ucv = a2 * (utmp(i - 2, j, k) + utmp(i + 1, j, k)) + a1 * (utmp(i - 1, j, k) + utmp(i, j, k));
         utv = (ucv - v(i, j, k) * FV3_M(s.cosa_u, i, j)) * FV3_M(s.rsin_u, i, j);
       }
-      view_V(g, s.a.uc)(i, j, k) = ucv;
+      if (s.uc_w) view_V(g, s.uc_w)(i, j, k) = ucv;
+      if (wr) view_V(g, s.a.uc)(i, j, k) = ucv;
       // :159-167
       if (utv > 0.)
         utv = dt2 * utv * FV3_M(s.dy, i, j) * g.sinsg(i - 1, j, 3);
       else
         utv = dt2 * utv * FV3_M(s.dy, i, j) * g.sinsg(i, j, 1);
-      view_A(g, s.a.ut)(i, j, k) = utv;
+      if (s.ut_w) view_A(g, s.ut_w)(i, j, k) = utv;
+      if (wr) view_A(g, s.a.ut)(i, j, k) = utv;
     }
     if (s.divg != 2 && i <= ie + 1) {  // vc, vt (:3298-3334)
       double vcv, vtv;
@@ -164,13 +191,15 @@ struct CswCubedP3 {
           vcv = a2 * (vtmp(i, j - 2, k) + vtmp(i, j + 1, k)) + a1 * (vtmp(i, j - 1, k) + vtmp(i, j, k));
         vtv = (vcv - u(i, j, k) * FV3_M(s.cosa_v, i, j)) * FV3_M(s.rsin_v, i, j);
       }
-      view_U(g, s.a.vc)(i, j, k) = vcv;
+      if (s.vc_w) view_U(g, s.vc_w)(i, j, k) = vcv;
+      if (wr) view_U(g, s.a.vc)(i, j, k) = vcv;
       // :168-176
       if (vtv > 0.)
         vtv = dt2 * vtv * FV3_M(s.dx, i, j) * g.sinsg(i, j - 1, 4);
       else
         vtv = dt2 * vtv * FV3_M(s.dx, i, j) * g.sinsg(i, j, 2);
-      view_A(g, s.a.vt)(i, j, k) = vtv;
+      if (s.vt_w) view_A(g, s.vt_w)(i, j, k) = vtv;
+      if (wr) view_A(g, s.a.vt)(i, j, k) = vtv;
     }
     if (s.divg != 0 && s.a.nord > 0 && i >= is && i <= ie + 1 && j >= js && j <= je + 1) {  // divergence_corner, :1798-1843
       auto uf = [&](int ii, int jj) {
@@ -202,8 +231,8 @@ struct CswCubedP4 {
   FV3_HD void operator()(int i, int j, int k) const {
     const Grid &g = s.g;
     const int is = g.is, js = g.js, npx = g.npx, npy = g.npy;
-    const CA ua = cview_A(g, s.a.ua), va = cview_A(g, s.a.va), u = cview_U(g, s.a.u), v = cview_V(g, s.a.v);
-    const CA uc = cview_V(g, s.a.uc), vc = cview_U(g, s.a.vc);
+    const CA ua = cview_A(g, s.uaR()), va = cview_A(g, s.vaR()), u = cview_U(g, s.a.u), v = cview_V(g, s.a.v);
+    const CA uc = cview_V(g, s.ucR()), vc = cview_U(g, s.vcR());
     const double dt4 = 0.5 * s.a.dt2;
     double kx, ky;
     if (ua(i, j, k) > 0.) {
@@ -258,7 +287,7 @@ struct CswCubedP5 {
     const Grid &g = s.g;
     const int is = g.is, ie = g.ie, js = g.js, je = g.je, npx = g.npx, npy = g.npy;
     const CA delp = cview_A(g, s.a.delp), pt = cview_A(g, s.a.pt), w = cview_A(g, s.a.w);
-    const CA ut = cview_A(g, s.a.ut), vt = cview_A(g, s.a.vt), u = cview_U(g, s.a.u), v = cview_V(g, s.a.v);
+    const CA ut = cview_A(g, s.utR()), vt = cview_A(g, s.vtR()), u = cview_U(g, s.a.u), v = cview_V(g, s.a.v);
     const bool nh = !s.a.hydrostatic;
     const double dt2 = s.a.dt2;
     auto rd = [&](const CA &q, int dir, int ii, int jj) {
@@ -292,7 +321,7 @@ struct CswCubedP5 {
     const CA ke = cview_A(g, s.ke), vort = cview_A(g, s.vort);
     if (i >= is && i <= ie + 1 && j >= js && j <= je) {
       const VA uc = view_V(g, s.a.uc);
-      const double ucv = uc(i, j, k);
+      const double ucv = cview_V(g, s.ucR())(i, j, k);
       double fy1;
       if (i == 1 || i == npx)
         fy1 = dt2 * v(i, j, k);
@@ -303,7 +332,7 @@ struct CswCubedP5 {
     }
     if (i >= is && i <= ie && j >= js && j <= je + 1) {
       const VA vc = view_U(g, s.a.vc);
-      const double vcv = vc(i, j, k);
+      const double vcv = cview_U(g, s.vcR())(i, j, k);
       double fx1;
       if (j == 1 || j == npy)
         fx1 = dt2 * u(i, j, k);

@@ -152,6 +152,7 @@ struct DswCubedD1c {
 // D2: Courant numbers and area fluxes (:863-902), the accumulation of cx, cy (:923-936); box (isd:ied, jsd:jed)
 struct DswCubedD2 {
   DswCubedState s;
+  int acc = 1;   // 0: no accumulation of cx, cy (the frame's own copies of the Courant numbers, fv3_api.hip dsw_cubed)
   FV3_HD void operator()(int i, int j, int k) const {
     const Grid &g = s.g;
     const double dt = s.a.dt;
@@ -166,8 +167,10 @@ struct DswCubedD2 {
       }
       view_CX(g, s.a.crx)(i, j, k) = cr;
       view_CX(g, s.a.xfx)(i, j, k) = x;
-      double &cxv = view_CX(g, s.a.cx)(i, j, k);
-      cxv = cxv + cr;
+      if (acc) {
+        double &cxv = view_CX(g, s.a.cx)(i, j, k);
+        cxv = cxv + cr;
+      }
     }
     if (j >= g.js && j <= g.je + 1) {
       double y = dt * cview_U(g, s.vt)(i, j, k), cr;
@@ -180,8 +183,10 @@ struct DswCubedD2 {
       }
       view_CY(g, s.a.cry)(i, j, k) = cr;
       view_CY(g, s.a.yfx)(i, j, k) = y;
-      double &cyv = view_CY(g, s.a.cy)(i, j, k);
-      cyv = cyv + cr;
+      if (acc) {
+        double &cyv = view_CY(g, s.a.cy)(i, j, k);
+        cyv = cyv + cr;
+      }
     }
   }
 };

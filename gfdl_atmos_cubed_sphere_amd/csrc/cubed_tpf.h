@@ -72,6 +72,7 @@ struct Tp2dFrameFused {
 #define TF(a, i, j) (a)[((j) - j0) * pw + ((i) - i0)]
     const CA area = cview_A(g, g.area), dxa = cview_A(g, g.dxa), dya = cview_A(g, g.dya);
     const CA xf = cview_CX(g, xfx), yf = cview_CY(g, yfx), cx = cview_CX(g, crx), cy = cview_CY(g, cry);
+    // (the barriers order LDS only: the fluxes a field stores are not read again here, so they drain behind the staging of the next one)
     for (int n = 0; n < nf; n++) {
       const CA q = cview_A(g, f[n].q);
       const int hord = f[n].hord, ord_in = (hord == 10) ? 8 : hord;
@@ -85,7 +86,7 @@ struct Tp2dFrameFused {
         copyc_src(2, npx, npy, ii, jj);
         TF(qy, i, j) = q(ii, jj, k);
       }
-      FV3_SYNC();
+      FV3_SYNC_LDS();
       // ---- T1: inner sweeps (tp_core.F90:143-168) on what T2 will read ----
       {
         // fx2(i, j): i in [ia, ib + 1] (faces of the q_j cells), j in [ja - 3, jb + 2] (the y lines of T3), inside (is:ie+1, jsd:jed)
@@ -107,7 +108,7 @@ struct Tp2dFrameFused {
           TF(fy2, i, j) = ppm_face_cs(ql, dl, j, cy(i, j, k), ord_in, npy);
         }
       }
-      FV3_SYNC();
+      FV3_SYNC_LDS();
       // ---- T2: q_i, q_j (:150-159, :171-178) ----
       {
         const int ua = (ia - 3 > g.isd) ? ia - 3 : g.isd, ub = (ib + 2 < g.ied) ? ib + 2 : g.ied, va = ja, vb = (jb < g.je) ? jb : g.je;
@@ -127,7 +128,7 @@ struct Tp2dFrameFused {
           TF(qj, i, j) = (TF(qx, i, j) * ar + fx10 - fx11) / (ar + x0 - x1);
         }
       }
-      FV3_SYNC();
+      FV3_SYNC_LDS();
       // ---- T3: outer sweeps, flux averaging and weighting (:161, :180, :187-224) on the rectangle ----
       {
         const int nx_ = ib - ia + 1, ny_ = jb - ja + 1;
@@ -155,7 +156,7 @@ struct Tp2dFrameFused {
           }
         }
       }
-      FV3_SYNC();
+      FV3_SYNC_LDS();
     }
 #undef TF
   }

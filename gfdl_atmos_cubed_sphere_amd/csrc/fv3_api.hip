@@ -53,6 +53,11 @@ struct fv3_ctx {
   // the marching kernels of the other levels (different levels = disjoint data)
   stream_t stream2;
   void *ev_fork, *ev_join;
+  // lanes (dsw_cubed, csw_cubed): lane 1 = launches go to stream2 -- the frame / sponge-level passes of a cubed-sphere face beside the
+  // marching kernels of its interior.  ev_mid: a second main -> side dependency inside one routine.  A face group keeps the side
+  // stream and the events on its first member.
+  int lane = 0;
+  void *ev_mid = nullptr;
   bool side_ok;          // transport and momentum route the same levels to the tile kernels
   int use_side;          // FV3_MI355X_SIDE_STREAM=0 disables
   double *dev_metrics;   // one allocation holding every metric array
@@ -124,7 +129,7 @@ struct fv3_ctx {
   // cubed sphere (grid_type < 3): edge weights / corner factors and the work arrays of the pass kernels (B x (npz+1) each)
   CubedGeom cg;
   double *cg_dev;
-  double *cs_scr[32];
+  double *cs_scr[36];
   int *ones_i;    // npz ones, device (ksplt of the inline_q sub-step)
   std::vector<double> host_area;   // prt_maxmin: area on the host, and g_sum's global_area
   double global_area = 0.;
@@ -196,8 +201,9 @@ struct GrpEntry {
   size_t lds = 0;
   const char *label = "";
   std::vector<double> fbuf;    // the functor's bytes
-  int (*go)(struct fv3_group *, GrpEntry *const *, int) = nullptr;
-  int op = 0;                  // 1 memset, 2 device copy
+  int (*go)(struct fv3_group *, GrpEntry *const *, int, stream_t) = nullptr;
+  int op = 0;                  // 1 memset, 2 device copy, 3 / 4 / 5 lane_exec (fork, mid, join)
+  int lane = 0;                // 0: the group's stream, 1: its side stream (fv3_ctx::lane when the entry was queued)
   void *dst = nullptr;
   const void *src = nullptr;
   size_t bytes = 0;
@@ -217,18 +223,32 @@ static const void *grp_tag() {
   return &t;
 }
 template <class F, int KIND, int W>
-static int grp_go(fv3_group *g, GrpEntry *const *e, int n) {
+static int grp_go(fv3_group *g, GrpEntry *const *e, int n, stream_t s) {
+  (void)g;
   const F *fs[kGrpMax];
   for (int m = 0; m < n; m++) fs[m] = reinterpret_cast<const F *>(e[m]->fbuf.data());
-  const stream_t s = g->m[0]->stream;
   if constexpr (KIND == 2)
     return launch_group_cols<W>(e[0]->grid, e[0]->a, s, fs, n);
   else
     return launch_group<KIND>(e[0]->grid, e[0]->lds, e[0]->a, s, fs, n);
 }
+// the dependencies between the two lanes of a context (or of a group's first member): 3 fork -- the side stream waits for what the
+// main stream holds now; 4 mid -- the same, a second time; 5 join -- the main stream waits for the side stream
+enum { kLaneFork = 3, kLaneMid = 4, kLaneJoin = 5 };
+static void lane_exec(fv3_ctx *o, int op) {
+  if (op == kLaneJoin) {
+    rt_event_record(o->ev_join, o->stream2);
+    rt_stream_wait_event(o->stream, o->ev_join);
+  } else {
+    void *ev = op == kLaneFork ? o->ev_fork : o->ev_mid;
+    rt_event_record(ev, o->stream);
+    rt_stream_wait_event(o->stream2, ev);
+  }
+}
 static int grp_run(fv3_group *g, fv3_ctx *owner, GrpEntry *const *e, int n) {   // n entries of one kernel (or one stream operation)
-  const stream_t s = g->m[0]->stream;
+  const stream_t s = e[0]->lane ? g->m[0]->stream2 : g->m[0]->stream;
   if (!e[0]->tag) {
+    if (e[0]->op >= kLaneFork) { lane_exec(g->m[0], e[0]->op); return 0; }
     if (e[0]->op == 1) return rt_memset(e[0]->dst, e[0]->value, e[0]->bytes, s);
     return rt_d2d(e[0]->dst, e[0]->src, e[0]->bytes, s);
   }
@@ -237,7 +257,7 @@ static int grp_run(fv3_group *g, fv3_ctx *owner, GrpEntry *const *e, int n) {   
     if (prof_events(&e0, &e1)) return 1;
     rt_event_record(e0, s);
   }
-  const int rc = e[0]->go(g, e, n);
+  const int rc = e[0]->go(g, e, n, s);
   if (owner->prof_on) {
     rt_event_record(e1, s);
     owner->prof.push_back({e[0]->label, e0, e1});
@@ -256,7 +276,7 @@ static int grp_pump(fv3_group *g, bool force) {
       bool same = true;
       for (int m = 0; m < g->n; m++) {
         h[m] = &g->q[m].front();
-        same = same && h[m]->tag && h[m]->tag == h[0]->tag && h[m]->a == h[0]->a && h[m]->lds == h[0]->lds &&
+        same = same && h[m]->tag && h[m]->tag == h[0]->tag && h[m]->a == h[0]->a && h[m]->lds == h[0]->lds && h[m]->lane == h[0]->lane &&
                h[m]->grid.x == h[0]->grid.x && h[m]->grid.y == h[0]->grid.y && h[m]->grid.z == h[0]->grid.z;
       }
       if (same) {
@@ -289,7 +309,7 @@ static int grp_defer(fv3_ctx *c, const char *label, Dim3 grid, size_t lds, int a
   g->q[c->grp_idx].emplace_back();
   GrpEntry &e = g->q[c->grp_idx].back();
   e.tag = grp_tag<F, KIND, W>();
-  e.a = a; e.grid = grid; e.lds = lds; e.label = label;
+  e.a = a; e.grid = grid; e.lds = lds; e.label = label; e.lane = c->lane;
   e.fbuf.resize((sizeof(F) + 7) / 8);
   std::memcpy(e.fbuf.data(), (const void *)&f, sizeof(F));
   e.go = &grp_go<F, KIND, W>;
@@ -300,11 +320,46 @@ static int grp_stream_op(fv3_ctx *c, int op, void *dst, const void *src, size_t 
     fv3_group *g = c->grp;
     g->q[c->grp_idx].emplace_back();
     GrpEntry &e = g->q[c->grp_idx].back();
-    e.op = op; e.dst = dst; e.src = src; e.bytes = bytes; e.value = value;
+    e.op = op; e.dst = dst; e.src = src; e.bytes = bytes; e.value = value; e.lane = c->lane;
     return grp_pump(g, false);
   }
-  const stream_t s = c ? c->stream : nullptr;
+  const stream_t s = c ? (c->lane ? c->stream2 : c->stream) : nullptr;
   return op == 1 ? rt_memset(dst, value, bytes, s) : rt_d2d(dst, src, bytes, s);
+}
+// ---- lanes ------------------------------------------------------------------------------------------------------------------------
+static stream_t lane_stream(const fv3_ctx *c) { return c->lane ? c->stream2 : c->stream; }
+// the side stream and its events, on the context itself or on the first member of its group; created on first use
+// When the two lanes pay (measured on C384 L127, tools/lanes_check.py): a face that launches on its own (one face per GPU) and is large
+// enough for its marching kernels to last -- 4.5 -> 4.1 ms per pair; C96 L32: no gain; six faces in one launch (fv3_group): the pass
+// launches are six times larger and fill the chip themselves, +-1 %, and at C96 the events cost 5 %.  FV3_MI355X_SIDE_STREAM: 0 never,
+// 1 this policy, 2 always (experiments).
+static bool lanes_pay(const fv3_ctx *c) {
+  if (!c->use_side || c->prof_on) return false;
+  if (c->use_side >= 2) return true;
+  return !c->grp && (long)c->g.nx * c->g.ny * c->g.npz >= 2000000L;
+}
+static int lane_prepare(fv3_ctx *c) {
+  fv3_ctx *o = c->grp ? c->grp->m[0] : c;
+  // (a stream of its own for the lanes, of low priority: the marching kernels of the main stream are the critical path, the passes fill
+  // what they leave; the periodic path's stream2 has the same role)
+  if (!o->stream2) {
+    static const int low = [] { const char *e = std::getenv("FV3_MI355X_SIDE_PRIO"); return e ? std::atoi(e) : 1; }();   // 0: normal priority
+    if (int rc = low ? rt_stream_create_low(&o->stream2) : rt_stream_create(&o->stream2)) return rc;
+  }
+  if (!o->ev_fork) { if (int rc = rt_event_create(&o->ev_fork)) return rc; }
+  if (!o->ev_join) { if (int rc = rt_event_create(&o->ev_join)) return rc; }
+  if (!o->ev_mid) { if (int rc = rt_event_create(&o->ev_mid)) return rc; }
+  return 0;
+}
+static int lane_op(fv3_ctx *c, int op) {   // in a group: queued, so that it keeps its place among the member's launches
+  if (c->grp) {
+    fv3_group *g = c->grp;
+    g->q[c->grp_idx].emplace_back();
+    g->q[c->grp_idx].back().op = op;
+    return grp_pump(g, false);
+  }
+  lane_exec(c, op);
+  return 0;
 }
 // stream calls that order the stream against the host or another stream: the queues of every group go first
 static int rtf_h2d(void *d, const void *s, size_t n, stream_t st) { if (int rc = grp_flush_all()) return rc; return rt_h2d(d, s, n, st); }
@@ -320,11 +375,11 @@ static int launch_p(fv3_ctx *c, const char *label, Dim3 grid, size_t lds_doubles
   void *e0 = nullptr, *e1 = nullptr;
   if (c->prof_on) {
     if (prof_events(&e0, &e1)) return 1;
-    rt_event_record(e0, c->stream);
+    rt_event_record(e0, lane_stream(c));
   }
-  int rc = launch(grid, lds_doubles, c->stream, f);
+  int rc = launch(grid, lds_doubles, lane_stream(c), f);
   if (c->prof_on) {
-    rt_event_record(e1, c->stream);
+    rt_event_record(e1, lane_stream(c));
     c->prof.push_back({label, e0, e1});
   }
   return rc;
@@ -336,11 +391,11 @@ static int launch_p2(fv3_ctx *c, const char *label, Dim3 grid, size_t lds_double
   void *e0 = nullptr, *e1 = nullptr;
   if (c->prof_on) {
     if (prof_events(&e0, &e1)) return 1;
-    rt_event_record(e0, c->stream);
+    rt_event_record(e0, lane_stream(c));
   }
-  int rc = launch_2w(grid, lds_doubles, c->stream, f);
+  int rc = launch_2w(grid, lds_doubles, lane_stream(c), f);
   if (c->prof_on) {
-    rt_event_record(e1, c->stream);
+    rt_event_record(e1, lane_stream(c));
     c->prof.push_back({label, e0, e1});
   }
   return rc;
@@ -352,11 +407,11 @@ static int launch_c(fv3_ctx *c, const char *label, Dim3 grid, const F &f, int la
   void *e0 = nullptr, *e1 = nullptr;
   if (c->prof_on) {
     if (prof_events(&e0, &e1)) return 1;
-    rt_event_record(e0, c->stream);
+    rt_event_record(e0, lane_stream(c));
   }
-  int rc = launch_cols<W>(grid, c->stream, f, lanes);
+  int rc = launch_cols<W>(grid, lane_stream(c), f, lanes);
   if (c->prof_on) {
-    rt_event_record(e1, c->stream);
+    rt_event_record(e1, lane_stream(c));
     c->prof.push_back({label, e0, e1});
   }
   return rc;
@@ -368,11 +423,11 @@ static int launch_w(fv3_ctx *c, const char *label, int nwaves, const F &f) {
   void *e0 = nullptr, *e1 = nullptr;
   if (c->prof_on) {
     if (prof_events(&e0, &e1)) return 1;
-    rt_event_record(e0, c->stream);
+    rt_event_record(e0, lane_stream(c));
   }
-  int rc = launch_waves(nwaves, c->stream, f);
+  int rc = launch_waves(nwaves, lane_stream(c), f);
   if (c->prof_on) {
-    rt_event_record(e1, c->stream);
+    rt_event_record(e1, lane_stream(c));
     c->prof.push_back({label, e0, e1});
   }
   return rc;
@@ -586,6 +641,7 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   if (c->stream2) rt_stream_destroy(c->stream2);
   if (c->ev_fork) rt_event_destroy(c->ev_fork);
   if (c->ev_join) rt_event_destroy(c->ev_join);
+  if (c->ev_mid) rt_event_destroy(c->ev_mid);
   if (c->klist) rt_free(c->klist);
   if (c->klist_m) rt_free(c->klist_m);
   if (c->klist_z) rt_free(c->klist_z);
@@ -1120,21 +1176,50 @@ static int csw_cubed(fv3_ctx *c, const CswArgs &ca) {
   const bool hyb = c->use_march && wo > 0 && g.npx == g.npy && g.npx - 1 >= 2 * wm + 8;
   const PassRegion rm{hyb ? wm : 0, nullptr, npz}, ro{hyb ? wo : 0, nullptr, npz};
   s.divg = hyb ? 0 : 1;
-  RT(launch_pass(c, "cswc_p1", g.isd, g.ied, g.jsd, g.jed, rm, CswCubedP1{s}));
-  RT(launch_pass(c, "cswc_p2", g.is - 2, g.ie + 2, g.js - 2, g.je + 2, rm, CswCubedP2{s}));
-  RT(launch_box(c, "cswc_p2c", 0, 2, 0, 0, npz, CswCubedP2c{s}));
-  RT(launch_pass(c, "cswc_p3", g.is - 1, g.ie + 2, g.js - 1, g.je + 2, rm, CswCubedP3{s}));
-  RT(launch_pass(c, "cswc_p4", g.is - 1, g.ie + 1, g.js - 1, g.je + 1, rm, CswCubedP4{s}));
-  s.own_w = hyb ? wo : 0;
-  RT(launch_pass(c, "cswc_p5", g.is - 1, g.ie + 1, g.js - 1, g.je + 1, ro, CswCubedP5{s}));
-  if (hyb) {
+  // Two lanes (round 4, see dsw_cubed): the frame passes on the side stream BESIDE the marching kernel.  The passes keep what they
+  // read back of ua, va, uc, vc, ut, vt in work copies (scratch 8 .. 13: d_sw's, free here) and write an output only where they own
+  // it (CswCubedState::wr), so every output point has one writer and the marching kernel's points are not read by them.  The
+  // divergence of the frame reads the final ua, va of both: after the join, from the outputs.
+  const bool lanes = hyb && lanes_pay(c);
+  if (lanes) {
+    double **wk[6] = {&s.ua_w, &s.va_w, &s.uc_w, &s.vc_w, &s.ut_w, &s.vt_w};
+    for (int n = 0; n < 6; n++)
+      if (!(*wk[n] = cs_scratch(c, 8 + n))) return fail("c_sw: out of device memory");
+    s.own_w = wo;
+    RT(lane_prepare(c));
+    RT(lane_op(c, kLaneFork));
     CswArgs cm = ca;
     cm.mask_w = wo;
     RT(csw_march(c, cm));
-    if (ca.nord > 0) {  // the marching kernel formed the divergence of the points it owns; the frame by the pass
-      s.divg = 2;
-      RT(launch_pass(c, "cswc_div", g.is, g.ie + 1, g.js, g.je + 1, ro, CswCubedP3{s}));
+    c->lane = 1;
+  }
+  auto passes = [&]() -> int {
+    RT(launch_pass(c, "cswc_p1", g.isd, g.ied, g.jsd, g.jed, rm, CswCubedP1{s}));
+    RT(launch_pass(c, "cswc_p2", g.is - 2, g.ie + 2, g.js - 2, g.je + 2, rm, CswCubedP2{s}));
+    RT(launch_box(c, "cswc_p2c", 0, 2, 0, 0, npz, CswCubedP2c{s}));
+    RT(launch_pass(c, "cswc_p3", g.is - 1, g.ie + 2, g.js - 1, g.je + 2, rm, CswCubedP3{s}));
+    RT(launch_pass(c, "cswc_p4", g.is - 1, g.ie + 1, g.js - 1, g.je + 1, rm, CswCubedP4{s}));
+    s.own_w = hyb ? wo : 0;
+    RT(launch_pass(c, "cswc_p5", g.is - 1, g.ie + 1, g.js - 1, g.je + 1, ro, CswCubedP5{s}));
+    return 0;
+  };
+  const int rc = passes();
+  if (lanes) {
+    c->lane = 0;
+    if (rc) return rc;
+    RT(lane_op(c, kLaneJoin));
+  } else {
+    if (rc) return rc;
+    if (hyb) {
+      CswArgs cm = ca;
+      cm.mask_w = wo;
+      RT(csw_march(c, cm));
     }
+  }
+  if (hyb && ca.nord > 0) {  // the marching kernel formed the divergence of the points it owns; the frame by the pass
+    s.divg = 2;
+    s.ua_w = s.va_w = s.uc_w = s.vc_w = s.ut_w = s.vt_w = nullptr;
+    RT(launch_pass(c, "cswc_div", g.is, g.ie + 1, g.js, g.je + 1, ro, CswCubedP3{s}));
   }
   return 0;
 }
@@ -1503,6 +1588,8 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   const bool hyb_t = fits && fused_ok && c->n_plain > 0;
   const bool hyb_m = fits && c->use_march && c->use_fused && c->n_plain_m > 0 && a.dddmp < 1.E-5 && !g.do_diss_est;
 
+  // the Courant numbers / area fluxes the passes read: d_sw's own arrays, or (two lanes) the frame's copies
+  const double *cn_crx = a.crx, *cn_cry = a.cry, *cn_xfx = a.xfx, *cn_yfx = a.yfx;
   auto transport = [&](const PassRegion &rg, const PassRegion &rg_out, bool courant) -> int {
     if (rg.nk <= 0) return 0;
     // (a marching launch is as long as one wavefront's march whatever its size: below 16 levels -- the two sponge levels of the
@@ -1540,7 +1627,7 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
       fl[nf++] = TpfField{a.delp, s.fx, s.fy, a.hord_dp};
       if (!a.hydrostatic) fl[nf++] = TpfField{a.w, s.gxw, s.gyw, a.hord_vt};
       fl[nf++] = TpfField{a.pt, s.gx, s.gy, a.hord_tm};
-      RT(tp2d_frame_fused(c, fl, nf, a.crx, a.cry, a.xfx, a.yfx, wo + 1, rg.klist, rg.nk, "dswc_tp", false, nullptr, nullptr, dfx, dfy,
+      RT(tp2d_frame_fused(c, fl, nf, cn_crx, cn_cry, cn_xfx, cn_yfx, wo + 1, rg.klist, rg.nk, "dswc_tp", false, nullptr, nullptr, dfx, dfy,
                           dv4 ? a.lv.damp_vt : nullptr));
       if (c->lev_has_damp_t)    // :1014-1016: mass-weighted deln_flux inside fv_tp_2d(pt)
         RT(deln(a.pt, a.delp, s.gx, s.gy, a.lv.nord_t, a.lv.damp_t, 1.E-4, 0, c->lev_max_nord_t, nullptr, nullptr, rg));
@@ -1560,7 +1647,7 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
       const bool dv4 = rg.w == 0 && c->lev_has_damp_v4;
       if (dv4)   // :919-920 without the final addition: raw fluxes in scratch 5, 6
         RT(deln(a.delp, nullptr, nullptr, nullptr, a.lv.nord_v, a.lv.damp_vt, 1.E-4, 0, c->lev_max_nord_v, nullptr, nullptr, rg));
-      RT(tp2d_frame_fused(c, fl, nf, a.crx, a.cry, a.xfx, a.yfx, rg_out.w + 1, rg.klist, rg.nk, "dswc_tp", rg.w == 0, nullptr, nullptr,
+      RT(tp2d_frame_fused(c, fl, nf, cn_crx, cn_cry, cn_xfx, cn_yfx, rg_out.w + 1, rg.klist, rg.nk, "dswc_tp", rg.w == 0, nullptr, nullptr,
                           dv4 ? cs_scratch(c, 5) : nullptr, dv4 ? cs_scratch(c, 6) : nullptr, dv4 ? a.lv.damp_vt : nullptr));
       if (rg.w == 0 && c->lev_has_damp_t)    // :1014-1016: mass-weighted deln_flux inside fv_tp_2d(pt)
         RT(deln(a.pt, a.delp, s.gx, s.gy, a.lv.nord_t, a.lv.damp_t, 1.E-4, 0, c->lev_max_nord_t, nullptr, nullptr, rg));
@@ -1571,17 +1658,17 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
       RT(launch_pass(c, "dswc_d4", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD4{so}));
       return 0;
     }
-    RT(tp2d_cubed(c, npz, a.delp, a.crx, a.cry, a.hord_dp, s.fx, s.fy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, "dswc_tp", &rg));
+    RT(tp2d_cubed(c, npz, a.delp, cn_crx, cn_cry, a.hord_dp, s.fx, s.fy, cn_xfx, cn_yfx, nullptr, nullptr, nullptr, nullptr, "dswc_tp", &rg));
     if (rg.w == 0 && c->lev_has_damp_v4)   // :919-920: deln_flux inside fv_tp_2d(delp) -- the mass fluxes carry it from here on
       RT(deln(a.delp, nullptr, s.fx, s.fy, a.lv.nord_v, a.lv.damp_vt, 1.E-4, 0, c->lev_max_nord_v, nullptr, nullptr, rg));
     if (!a.hydrostatic)
-      RT(tp2d_cubed(c, npz, a.w, a.crx, a.cry, a.hord_vt, s.gxw, s.gyw, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, "dswc_tp", &rg));
+      RT(tp2d_cubed(c, npz, a.w, cn_crx, cn_cry, a.hord_vt, s.gxw, s.gyw, cn_xfx, cn_yfx, nullptr, nullptr, s.fx, s.fy, "dswc_tp", &rg));
     if (a.use_cond) {                      // :992-995: q_con with hord_dp, delp's mass fluxes and pt's damping
-      RT(tp2d_cubed(c, npz, a.q_con, a.crx, a.cry, a.hord_dp, s.gxq, s.gyq, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, "dswc_tp", &rg));
+      RT(tp2d_cubed(c, npz, a.q_con, cn_crx, cn_cry, a.hord_dp, s.gxq, s.gyq, cn_xfx, cn_yfx, nullptr, nullptr, s.fx, s.fy, "dswc_tp", &rg));
       if (c->lev_has_damp_t)
         RT(deln(a.q_con, a.delp, s.gxq, s.gyq, a.lv.nord_t, a.lv.damp_t, 1.E-4, 0, c->lev_max_nord_t, nullptr, nullptr, rg));
     }
-    RT(tp2d_cubed(c, npz, a.pt, a.crx, a.cry, a.hord_tm, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, s.fx, s.fy, "dswc_tp", &rg));
+    RT(tp2d_cubed(c, npz, a.pt, cn_crx, cn_cry, a.hord_tm, s.gx, s.gy, cn_xfx, cn_yfx, nullptr, nullptr, s.fx, s.fy, "dswc_tp", &rg));
     if (rg.w == 0 && c->lev_has_damp_t)    // :1014-1016: mass-weighted deln_flux inside fv_tp_2d(pt)
       RT(deln(a.pt, a.delp, s.gx, s.gy, a.lv.nord_t, a.lv.damp_t, 1.E-4, 0, c->lev_max_nord_t, nullptr, nullptr, rg));
     if (rg.w == 0 && !a.hydrostatic && c->lev_has_w_damp_hi)   // :950-982: del6_vt_flux(w); nord_w = 0 is formed inside D4
@@ -1591,10 +1678,13 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     RT(launch_pass(c, "dswc_d4", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD4{so}));
     return 0;
   };
-  auto momentum = [&](const PassRegion &rg, const PassRegion &rg_out) -> int {
+  // part 0: the whole half; 1: what needs no Courant numbers (kinetic energy, vorticity, divergence damping: through D8); 2: the rest
+  // (the vorticity transport, the wind update, heating)
+  auto momentum = [&](const PassRegion &rg, const PassRegion &rg_out, int part) -> int {
     if (rg.nk <= 0) return 0;
     DswCubedState so = s;
     so.own_w = rg_out.w;
+    if (part != 2) {
     RT(launch_pass(c, "dswc_ke", g.is, g.ie + 1, g.js, g.je + 1, rg, DswCubedD5{s}));
     RT(launch_pass(c, "dswc_d6", g.isd, g.ied + 1, g.jsd, g.jed + 1, rg, DswCubedD6{s}));
     // whole-face levels: the del-2n loop in one LDS-tile launch away from the face corners (cubed_dsw.h DswDampFused); the passes
@@ -1651,6 +1741,8 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     if (rg.w == 0 && c->lev_has_damp_v5)   // :1513-1515: del6_vt_flux of the RELATIVE vorticity (before D8 adds f0)
       RT(deln(s.wk, nullptr, nullptr, nullptr, a.lv.nord_v, a.lv.damp_vt, 1.E-5, 1, c->lev_max_nord_v, s.dfx2, s.dfy2, rg));
     RT(launch_pass(c, "dswc_d8", g.isd, g.ied, g.jsd, g.jed, rg, DswCubedD8{s}));
+    }
+    if (part == 1) return 0;
     if (frame_fused_on() && rg.w == 0 && fits && c->use_march && flux_march_on() && rg.nk >= 16) {
       // whole-face levels: the marching fv_tp_2d over the face, then the frame along the edges by the frame kernel (the fluxes are
       // not an input of either: the frame kernel simply overwrites what the march left there)
@@ -1658,16 +1750,16 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
       md.klist = rg.klist;
       const int nwv = md.nwaves(rg.nk);
       RT(dispatch_hord(a.hord_vt, [&](auto H) {
-        FluxMarch<decltype(H)::value> kf{g, md, s.wk, a.crx, a.cry, a.xfx, a.yfx, s.gx, s.gy};
+        FluxMarch<decltype(H)::value> kf{g, md, s.wk, cn_crx, cn_cry, cn_xfx, cn_yfx, s.gx, s.gy};
         return launch_w(c, "dswc_tpv", nwv, kf);
       }));
       const TpfField fl[3] = {TpfField{s.wk, s.gx, s.gy, a.hord_vt}, TpfField{}, TpfField{}};
-      RT(tp2d_frame_fused(c, fl, 1, a.crx, a.cry, a.xfx, a.yfx, wo + 1, rg.klist, rg.nk, "dswc_tpv", false));
+      RT(tp2d_frame_fused(c, fl, 1, cn_crx, cn_cry, cn_xfx, cn_yfx, wo + 1, rg.klist, rg.nk, "dswc_tpv", false));
     } else if (frame_fused_on()) {
       const TpfField fl[3] = {TpfField{s.wk, s.gx, s.gy, a.hord_vt}, TpfField{}, TpfField{}};
-      RT(tp2d_frame_fused(c, fl, 1, a.crx, a.cry, a.xfx, a.yfx, rg_out.w + 1, rg.klist, rg.nk, "dswc_tpv", rg.w == 0));
+      RT(tp2d_frame_fused(c, fl, 1, cn_crx, cn_cry, cn_xfx, cn_yfx, rg_out.w + 1, rg.klist, rg.nk, "dswc_tpv", rg.w == 0));
     } else {
-      RT(tp2d_cubed(c, npz, s.wk, a.crx, a.cry, a.hord_vt, s.gx, s.gy, a.xfx, a.yfx, nullptr, nullptr, nullptr, nullptr, "dswc_tpv", &rg));
+      RT(tp2d_cubed(c, npz, s.wk, cn_crx, cn_cry, a.hord_vt, s.gx, s.gy, cn_xfx, cn_yfx, nullptr, nullptr, nullptr, nullptr, "dswc_tpv", &rg));
     }
     RT(launch_pass(c, "dswc_d9", g.is, g.ie + 1, g.js, g.je + 1, rg_out, DswCubedD9{so}));
     if (rg.w == 0 && heat_pass) RT(launch_pass(c, "dswc_heat", g.is, g.ie, g.js, g.je, rg_out, DswCubedD10{so}));
@@ -1675,6 +1767,72 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     return 0;
   };
 
+  // Two lanes (round 4): the marching kernels of the face interior are two long launches at one wavefront per SIMD; the ~35 pass / frame
+  // launches (9 % of the points, 40 % of the time when they ran behind them) go to the side stream and run BESIDE them.  What orders
+  // the two lanes: the passes of the levels the marching kernels do not take (the sponge levels: Courant numbers of their own, D2)
+  // and the part of the momentum frame that needs no Courant numbers only read what D1 left -> after the fork; the frame of the
+  // transports and the vorticity transport of the momentum frame read the Courant numbers the marching transport kernel writes for
+  // its levels -> after `mid`; every output point and every accumulator is owned by exactly one kernel (mask_w / own_w, disjoint
+  // levels), the passes' scratch arrays are not touched by the marching kernels.  Needs the same plain / damped level sets in both
+  // halves (side_ok); not while profiling (the per-launch events would overlap).  FV3_MI355X_SIDE_STREAM=0: one lane.
+  const bool lanes = hyb_t && hyb_m && c->side_ok && lanes_pay(c) && c->n_plain == c->n_plain_m;
+  if (lanes) {
+    RT(lane_prepare(c));
+    const PassRegion fr_in{wm, c->klist, c->n_plain}, fr_out{wo, c->klist, c->n_plain};
+    const PassRegion rest{0, c->klist + c->n_plain, c->n_damp};
+    const PassRegion frm_in{wm, c->klist_m, c->n_plain_m}, frm_out{wo, c->klist_m, c->n_plain_m};
+    const PassRegion restm{0, c->klist_m + c->n_plain_m, c->n_rest_m};
+    DswArgs am = a;
+    am.uc = s.ut; am.vc = s.vt; am.mask_w = wo;
+    // FV3_MI355X_LANE_D2=1: the frame gets Courant numbers of its own (D2 on the frame, into scratch 29 .. 32, no accumulation: cx,
+    // cy are the marching kernel's), so that EVERY pass runs beside the marching transport kernel (306 registers a wavefront: the
+    // passes' wavefronts fit beside it; the marching momentum kernel fills the register file).  Default 0: the frame's transports
+    // wait for the marching transport kernel's Courant numbers (`mid`) and run beside the momentum kernel.  Measured equal (3.99 -
+    // 4.11 against 4.01 - 4.12 ms per C384 L127 pair, profiles/r04_v2_lanes_check.txt), so the variant without the extra pass and
+    // the four extra work arrays is the default.
+    static const int lane_d2 = [] { const char *e = std::getenv("FV3_MI355X_LANE_D2"); return e ? std::atoi(e) : 0; }();
+    RT(lane_op(c, kLaneFork));
+    RT(dsw_transport_march(c, am));                       // main: levels klist[0 : n_plain), Courant numbers too, whole face
+    c->lane = 1;
+    int rc = transport(rest, rest, true);
+    if (!rc) rc = momentum(restm, restm, 0);
+    if (!rc) rc = momentum(frm_in, frm_out, 1);
+    if (!rc && lane_d2) {
+      DswCubedState sf = s;
+      double *cn[4];
+      for (int n = 0; n < 4; n++)
+        if (!(cn[n] = cs_scratch(c, 29 + n))) rc = fail("d_sw: out of device memory");
+      if (!rc) {
+        sf.a.crx = cn[0]; sf.a.cry = cn[1]; sf.a.xfx = cn[2]; sf.a.yfx = cn[3];
+        DswCubedD2 d2{sf};
+        d2.acc = 0;
+        // (the frame's passes read Courant numbers up to one face beyond the frame of their intermediates)
+        rc = launch_pass(c, "dswc_d2", g.isd, g.ied, g.jsd, g.jed, PassRegion{wm + 2, c->klist, c->n_plain}, d2);
+        cn_crx = cn[0]; cn_cry = cn[1]; cn_xfx = cn[2]; cn_yfx = cn[3];
+        if (!rc) rc = transport(fr_in, fr_out, false);
+        if (!rc) rc = momentum(frm_in, frm_out, 2);
+        cn_crx = a.crx; cn_cry = a.cry; cn_xfx = a.xfx; cn_yfx = a.yfx;
+      }
+    }
+    c->lane = 0;
+    if (rc) return rc;
+    DswArgs mm = a;
+    mm.mask_w = wo; mm.rsina = c->cg.rsina;
+    if (lane_d2) {
+      RT(lane_op(c, kLaneJoin));                          // (the frame's outputs and the marching momentum kernel's are disjoint,
+      RT(dsw_momentum_march(c, mm));                      //  but nothing runs beside that kernel anyway: join first)
+      return 0;
+    }
+    RT(lane_op(c, kLaneMid));
+    RT(dsw_momentum_march(c, mm));                        // main: levels klist_m[0 : n_plain_m)
+    c->lane = 1;
+    rc = transport(fr_in, fr_out, false);
+    if (!rc) rc = momentum(frm_in, frm_out, 2);
+    c->lane = 0;
+    if (rc) return rc;
+    RT(lane_op(c, kLaneJoin));
+    return 0;
+  }
   if (hyb_t) {
     DswArgs am = a;
     am.uc = s.ut; am.vc = s.vt; am.mask_w = wo;
@@ -1688,10 +1846,10 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     DswArgs am = a;
     am.mask_w = wo; am.rsina = c->cg.rsina;
     RT(dsw_momentum_march(c, am));                        // levels klist_m[0 : n_plain_m)
-    RT(momentum(PassRegion{wm, c->klist_m, c->n_plain_m}, PassRegion{wo, c->klist_m, c->n_plain_m}));
-    RT(momentum(PassRegion{0, c->klist_m + c->n_plain_m, c->n_rest_m}, PassRegion{0, c->klist_m + c->n_plain_m, c->n_rest_m}));
+    RT(momentum(PassRegion{wm, c->klist_m, c->n_plain_m}, PassRegion{wo, c->klist_m, c->n_plain_m}, 0));
+    RT(momentum(PassRegion{0, c->klist_m + c->n_plain_m, c->n_rest_m}, PassRegion{0, c->klist_m + c->n_plain_m, c->n_rest_m}, 0));
   } else {
-    RT(momentum(PassRegion{0, nullptr, npz}, PassRegion{0, nullptr, npz}));
+    RT(momentum(PassRegion{0, nullptr, npz}, PassRegion{0, nullptr, npz}, 0));
   }
   return 0;
 }

@@ -17,12 +17,23 @@
 #define FV3_HD inline
 #define FV3_D inline
 #define FV3_SYNC() ((void)0)
+#define FV3_SYNC_LDS() ((void)0)
 constexpr int kNT = 1;
 #else
 #include <hip/hip_runtime.h>
 #define FV3_HD __host__ __device__ __forceinline__
 #define FV3_D __device__ __forceinline__
 #define FV3_SYNC() __syncthreads()
+// A workgroup barrier that orders the LDS traffic only: __syncthreads() also waits for every global load and STORE of the wavefront
+// (s_waitcnt vmcnt(0)), i.e. a kernel that stores a field and stages the next one pays the write latency and then the read latency.
+// For phases that exchange data through LDS alone (any global location is written and read back by the SAME thread, which the
+// hardware keeps in program order) the stores may drain and prefetched loads stay in flight across the barrier.
+#define FV3_SYNC_LDS()                                               \
+  do {                                                               \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  \
+    __builtin_amdgcn_s_barrier();                                    \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");  \
+  } while (0)
 constexpr int kNT = 256;
 #endif
 

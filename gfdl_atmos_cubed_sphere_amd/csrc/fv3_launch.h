@@ -86,6 +86,7 @@ inline int rt_d2d(void *d, const void *s, size_t n, stream_t) {
 inline int rt_sync(stream_t) { return 0; }
 inline const char *rt_errstr(int) { return "host-emu error"; }
 inline int rt_stream_create(stream_t *s) { *s = nullptr; return 0; }
+inline int rt_stream_create_low(stream_t *s) { *s = nullptr; return 0; }
 inline void rt_stream_destroy(stream_t) {}
 inline void rt_stream_wait_event(stream_t, void *) {}
 inline int rt_event_create(void **e) { *e = nullptr; return 0; }
@@ -352,6 +353,12 @@ inline int rt_d2d(void *d, const void *s, size_t n, stream_t st) {
 inline int rt_sync(stream_t st) { return (int)hipStreamSynchronize(st); }
 inline const char *rt_errstr(int e) { return hipGetErrorString((hipError_t)e); }
 inline int rt_stream_create(stream_t *s) { return (int)hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+// a stream of the lowest priority: its workgroups are dispatched where the streams of normal priority leave room
+inline int rt_stream_create_low(stream_t *s) {
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return (int)hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  return (int)hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
+}
 inline void rt_stream_destroy(stream_t s) { (void)hipStreamDestroy(s); }
 inline void rt_stream_wait_event(stream_t s, void *e) { (void)hipStreamWaitEvent(s, (hipEvent_t)e, 0); }
 inline int rt_event_create(void **e) { return (int)hipEventCreate((hipEvent_t *)e); }

@@ -759,6 +759,8 @@ struct RiemFast {
 #endif
   }
 
+  // (the barriers order LDS only, FV3_SYNC_LDS: every field is read before the first and written after the last exchange through LDS,
+  // by the threads of this workgroup alone, so the output stores of one phase drain behind the transposition of the next)
   FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
     double *B0 = lds, *B1 = lds + kFBuf, *B2 = lds + 2 * kFBuf, *B3 = lds + 3 * kFBuf;
     const int i0 = i_first() + bx * kFC, j = (CG ? g.js - 1 : g.js) + by;
@@ -792,7 +794,7 @@ struct RiemFast {
         if (k > km || col >= ncol) B3[col * kFP + lds_lev(k)] = -1.0e4 - 10. * (double)k;
       }
     }
-    FV3_SYNC();
+    FV3_SYNC_LDS();
     FV3_WAVE_FOR(wv) {
       const int s = FV3_WVI(wv), c0 = wv * 4;
       for (int q = 0; q < kFL; q++) {
@@ -803,7 +805,7 @@ struct RiemFast {
       }
       zv[s][kFL] = row_shl<1>(zv[s][0], -2.0e4);   // the interface below the lane's last layer (lane 15: a padded layer)
     }
-    FV3_SYNC();
+    FV3_SYNC_LDS();
     const bool has_qc = MOIST && qcon != nullptr, has_cappa = MOIST && cappa != nullptr && (!CG || qcon != nullptr);
     vd qcv[kWvState][MOIST ? kFL : 1], cpv[kWvState][MOIST ? kFL : 1];
     if constexpr (MOIST) {
@@ -814,7 +816,7 @@ struct RiemFast {
         stage_store(B0, v0, ncol, km, 0.0, tid);
         stage_store(B1, v1, ncol, km, cn.akap, tid);
       }
-      FV3_SYNC();
+      FV3_SYNC_LDS();
       FV3_WAVE_FOR(wv) {
         const int s = FV3_WVI(wv), c0 = wv * 4;
         for (int q = 0; q < kFL; q++) {
@@ -822,7 +824,7 @@ struct RiemFast {
           cpv[s][q] = has_cappa ? vlds_ld(B1, c0, q) : vd(cn.akap);
         }
       }
-      FV3_SYNC();
+      FV3_SYNC_LDS();
     }
     // ---- the column: everything below is per wavefront, no barrier until the outputs ----
     FV3_WAVE_FOR(wv) {
@@ -1000,9 +1002,9 @@ struct RiemFast {
       }
     }
     if constexpr (EX) {
-      FV3_SYNC();
+      FV3_SYNC_LDS();
       if (!(probe & 2)) w_columns(B0, B1, B2, (bx + by) & 3, tid);
-      FV3_SYNC();
+      FV3_SYNC_LDS();
     }
     FV3_WAVE_FOR(wv) {
       const int s = FV3_WVI(wv), c0 = wv * 4;
@@ -1150,7 +1152,7 @@ struct RiemFast {
         }
       }
     }
-    FV3_SYNC();
+    FV3_SYNC_LDS();
     stage_out(B0, zl, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
     if (CG) {
       stage_out(B1, pef, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
@@ -1159,7 +1161,7 @@ struct RiemFast {
     const ix_t occ0 = (ix_t)g.iCC(i0, j);
     stage_out(B1, wq, ncol, km, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
     stage_out(B2, delz, ncol, km, tid, [&](int col, int k) { return (ix_t)k * nCC + occ0 + col; });
-    FV3_SYNC();
+    FV3_SYNC_LDS();
     FV3_WAVE_FOR(wv) {
       const int s = FV3_WVI(wv), c0 = wv * 4;
       for (int q = 0; q < kFL; q++) {
@@ -1168,12 +1170,12 @@ struct RiemFast {
         if (last_call) vlds_st(B2, c0, q, ptv[s][q]);
       }
     }
-    FV3_SYNC();
+    FV3_SYNC_LDS();
     stage_out(B0, ppe, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
     stage_out(B1, pk3, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
     if (!last_call) return;
     stage_out(B2, pk, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nCC + occ0 + col; });
-    FV3_SYNC();
+    FV3_SYNC_LDS();
     FV3_WAVE_FOR(wv) {
       const int s = FV3_WVI(wv), c0 = wv * 4;
       for (int q = 0; q < kFL; q++) {
@@ -1181,7 +1183,7 @@ struct RiemFast {
         vlds_st(B1, c0, q, zv[s][q]);
       }
     }
-    FV3_SYNC();
+    FV3_SYNC_LDS();
     stage_out(B0, peln, ncol, km + 1, tid, [&](int col, int k) {
       return (ix_t)(j - g.js) * g.nx * (km + 1) + (ix_t)k * g.nx + (i0 - g.is) + col; });
     stage_out(B1, pe, ncol, km + 1, tid, [&](int col, int k) {

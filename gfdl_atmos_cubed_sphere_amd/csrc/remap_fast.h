@@ -27,10 +27,14 @@ namespace fv3 {
 
 // a thread's kIt global loads first, all in flight together (clamped addresses, no branch, no LDS store in between: the compiler
 // cannot move a load across a store to LDS it cannot prove disjoint), then the stores
+// (tl: the thread's index, opaque to the optimizer once per loop -- fresh_tid -- so that the (column, level) addresses of a phase are
+// formed in that phase: as common subexpressions of the whole kernel they stayed alive through every field and were spilled)
 #ifdef FV3_HOST_EMU
-#define FV3_LOAD_LOOP(it) for (int it = 0; it < kIt; it++)
+inline int fresh_tid(int x) { return x; }
+#define FV3_LOAD_LOOP(it) for (int it = 0, tl = tid; it < kIt; it++)
 #else
-#define FV3_LOAD_LOOP(it) _Pragma("unroll") for (int it = 0; it < kIt; it++)
+__device__ __forceinline__ int fresh_tid(int x) { asm volatile("" : "+v"(x)); return x; }
+#define FV3_LOAD_LOOP(it) _Pragma("unroll") for (int it = 0, tl = fresh_tid(tid); it < kIt; it++)
 #endif
 
 // A column of an LDS array, two layouts (FV3_REMAP_CHUNKED, a build-time choice; the linear one is the product's):
@@ -98,7 +102,11 @@ FV3_HD int a4_form_of(double a4, double a1, double a2, double a3) {   // the fir
 // spills them (88 registers at two wavefronts per SIMD, 2.8 GB of scratch traffic per call); a 32-bit index is one register, shared by the
 // arrays of a layout, and goes into the scalar-base form of the load (ix_t: nh_fast.h)
 constexpr int kRNBuf = 4;                // C1 (source coordinate), C2 (target coordinate), A1 (layer means), Q (interface values / out)
-constexpr int kRLds = kRNBuf * kRBuf;          // 75 776 B (chunked: 79 872): two workgroups per CU
+// behind the four arrays: the level coefficients ak, bk (128 each) and the surface pressures of the 16 columns -- as global loads inside
+// the staging loops each of them cost a full `s_waitcnt vmcnt(0)` (24 dependent round trips per workgroup)
+constexpr int kRTabAk = kRNBuf * kRBuf, kRTabBk = kRTabAk + 128, kRTabPs = kRTabBk + 128;
+constexpr int kRTabKord = kRTabPs + kFC, kRKordMax = 64;   // kord of the first 64 tracers (ints)
+constexpr int kRLds = kRTabKord + kRKordMax / 2;           // 78 208 B (chunked: 82 304): two workgroups per CU
 
 #ifdef FV3_HOST_EMU
 inline vd vlin_ld(const double *buf, int col0, int q) {      // row (lane & 15) * 8 + q of the lane's column; any q with row >= -2
@@ -377,7 +385,7 @@ struct RemapFastCore {
       form[it] = a4_form_of(a4v, a1[k], a2v, a3v);
       pt2[it] = t2[k]; pb2[it] = t2[k + 1];
     }
-    FV3_SYNC();
+    FV3_SYNC_LDS();
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
       if (k > km) continue;
@@ -385,13 +393,13 @@ struct RemapFastCore {
       at(C2, col, k - 1) = r3v[it];
       *a4_form_ptr(A1 + col * kRP, k) = (unsigned char)form[it];
     }
-    FV3_SYNC();
+    FV3_SYNC_LDS();
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
       if (k > km) continue;
       if (!(probe & 8)) r2[it] = map_target(colc(C1, col), colc(A1, col), colc(Q, col), colc(C2, col), km, tracer_form, k, pt2[it], pb2[it]);
     }
-    FV3_SYNC();
+    FV3_SYNC_LDS();
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
       if (k > km) continue;
@@ -402,20 +410,29 @@ struct RemapFastCore {
   }
 
   // a whole field: A1 and (for iv = -2) QS are staged, C1 / C2 hold the coordinates; on return (after its last barrier) Q holds the
-  // remapped layer means
+  // remapped layer means.  `pre` issues the global loads of whatever the caller stages next: they are in flight while the limiters and
+  // the mapping loop run (the barriers order LDS only)
+  template <class Pre>
   FV3_D void remap_field(double *C1, double *C2, double *A1, double *Q, const double *QS, bool is_scalar, int iv, int kord,
-                         double qmin, bool tracer_form, int tid) const {
+                         double qmin, bool tracer_form, int tid, Pre &&pre) const {
     const int ak = kord < 0 ? -kord : kord;
     if (!(probe & 1)) { FV3_WAVE_FOR(wv) { spline(C1, A1, Q, QS, iv, wv); } }
-    FV3_SYNC();
+    FV3_SYNC_LDS();
     if (!(probe & 2)) constrain(A1, Q, iv, ak, tid);
-    FV3_SYNC();
+    FV3_SYNC_LDS();
+    pre();
     map_all(C1, C2, A1, Q, is_scalar, iv, ak, qmin, tracer_form, tid);
-    FV3_SYNC();
+    FV3_SYNC_LDS();
   }
 };
 
 // ---- the scalars of a column: T_v, w, delz, the tracers, omega; delp, pk, peln, pkz, ps and the conversion of pt ------------------
+// Staging (round 4, second half): the fields go through the four LDS arrays one after the other, and with __syncthreads() between the
+// phases every field paid its store latency and then the next field's load latency (the kernel with every computation switched off
+// ran at 1.3 TB/s, profiles/r04_v1_remap_probe.txt).  Now (a) the barriers order LDS only (FV3_SYNC_LDS: every global location this
+// kernel reads after writing it is read by the thread that wrote it), so stores drain behind the next phase, and (b) the inputs of the
+// NEXT field are loaded into registers just before the mapping loop of the current one (`pre` of remap_field: 8 or 16 doubles per
+// thread, not live during the spline, which is where the register budget is tight) and go to LDS when that loop is done.
 template <bool HYDRO>   // the hydrostatic flag at compile time: the other branch's loads and registers are not carried
 struct RemapFastScalars {
   Grid g;
@@ -446,12 +463,40 @@ struct RemapFastScalars {
     // (what the end of the kernel needs of the remapped fields -- T_v, delz, sphum -- is written to pt / delz / q as it is formed and
     // read back by the same thread there; the log of the new interface pressures is formed again: kept in registers through the
     // remap of every field these 32 doubles per thread were spilled to scratch, 404 B per lane)
+    double *AK = lds + kRTabAk, *BK = lds + kRTabBk, *PS = lds + kRTabPs;
+    int *KT = reinterpret_cast<int *>(lds + kRTabKord);
+    double nx0[kIt], nx1[kIt];   // the inputs of the next field, in flight during the mapping loop of the current one
+    // the pressure coordinate's source interfaces (pe) and the first field on it (w; hydrostatic: the first tracer)
+    // (every prefetch is unconditional -- a load under a branch is waited for at the join; where there is nothing to fetch the
+    // address is that of a field that exists)
+    auto load_pressures = [&]() __attribute__((always_inline)) {
+      const double *f1 = HYDRO ? (p.nq > 0 ? q : pt) : w;
+      FV3_LOAD_LOOP(it) {
+        const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
+        const int ki = k0 <= km ? k0 : km, kc = k0 < km ? k0 : km - 1;
+        nx0[it] = pe[peb0 + (ix_t)ki * (g.nx + 2) + cc];
+        nx1[it] = f1[(ix_t)kc * nA + o0 + cc];
+      }
+    };
+    auto load_tracer = [&](int iq) __attribute__((always_inline)) {
+      const double *qq = p.nq > 0 ? q + (size_t)(iq < p.nq ? iq : p.nq - 1) * nA * km : pt;
+      FV3_LOAD_LOOP(it) {
+        const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+        nx0[it] = qq[(ix_t)(k0 < km ? k0 : km - 1) * nA + o0 + clampc(col)];
+      }
+    };
     // ---- log-pressure coordinates of T_v (:340-345, :363-368): C1 = peln, C2 = pn2; the layer means: the temperature transform
     //      (:200-229) level by level ----
     {
       double v_pl[kIt], v_t[kIt], v_a[kIt], v_b[kIt], v_c[HYDRO ? kIt : 1];
+#ifndef FV3_HOST_EMU
+      // the tables: loaded in front of the fields (the counter of outstanding loads is in order), stored to LDS behind them
+      const int tn = tid & 127, tkk = tn <= km ? tn : km;
+      const double t_ak = ak[tkk], t_bk = bk[tkk], t_ps = pe[peb0 + (ix_t)km * (g.nx + 2) + clampc(tid & (kFC - 1))];
+      const int t_kord = p.nq > 0 ? kord_tr[(tid & (kRKordMax - 1)) < p.nq ? (tid & (kRKordMax - 1)) : p.nq - 1] : 0;
+#endif
       FV3_LOAD_LOOP(it) {
-        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
+        const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
         const int ki = k0 <= km ? k0 : km, kc = k0 < km ? k0 : km - 1;     // interface / cell row, clamped
         const ix_t o3 = (ix_t)kc * nA + o0 + cc, c3 = (ix_t)kc * nCC + occ0 + cc;
         v_pl[it] = peln[lnb0 + (ix_t)ki * g.nx + cc];
@@ -462,13 +507,25 @@ struct RemapFastScalars {
           v_a[it] = delp[o3]; v_b[it] = delz[c3];
         }
       }
-      for (int it = 0; it < kIt; it++) {
-        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
+#ifdef FV3_HOST_EMU
+      for (int n = 0; n < 128; n++) {
+        const int kk = n <= km ? n : km;
+        AK[n] = ak[kk]; BK[n] = bk[kk];
+        if (n < kFC) PS[n] = pe[peb0 + (ix_t)km * (g.nx + 2) + clampc(n)];   // the surface pressure of column n
+        if (n < kRKordMax) KT[n] = p.nq > 0 ? kord_tr[n < p.nq ? n : p.nq - 1] : 0;
+      }
+#else
+      if (tid < 128) { AK[tn] = t_ak; BK[tn] = t_bk; }
+      if (tid < kFC) PS[tid] = t_ps;
+      if (tid < kRKordMax) KT[tid] = t_kord;
+#endif
+      FV3_SYNC_LDS();   // AK, BK, PS, KT
+      for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
+        const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
         if (k0 <= km) {
           RemapFastCore::at(C1, col, k0) = v_pl[it];
-          // (the surface pressure of the thread's column: the same address for every it on the device -- 256 threads, 16 columns)
-          const double v_ps1 = pe[peb0 + (ix_t)km * (g.nx + 2) + cc];
-          RemapFastCore::at(C2, col, k0) = (k0 == 0 || k0 == km) ? v_pl[it] : dlog(ak[k0] + bk[k0] * v_ps1);
+          const double v_ps1 = PS[col];
+          RemapFastCore::at(C2, col, k0) = (k0 == 0 || k0 == km) ? v_pl[it] : dlog(AK[k0] + BK[k0] * v_ps1);
           if (k0 == 0) ps[o0 + cc] = v_ps1;   // :298-300
         }
         if (k0 < km) {
@@ -481,39 +538,39 @@ struct RemapFastScalars {
         }
       }
     }
-    FV3_SYNC();
+    FV3_SYNC_LDS();
     for (int col = tid; col < kFC; col += kNT) {
       core.pad_coord(C1, col, km + 1);
       core.pad_coord(C2, col, km + 1);
       core.pad_field(A1, col, km);
       QS[col * kRP] = HYDRO ? 0. : ws[occ0 + clampc(col)];
     }
-    FV3_SYNC();
-    core.remap_field(C1, C2, A1, Q, nullptr, true, 1, akt, p.t_min, false, tid);
-    for (int it = 0; it < kIt; it++) {
-      const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+    FV3_SYNC_LDS();
+    core.remap_field(C1, C2, A1, Q, nullptr, true, 1, akt, p.t_min, false, tid, [&]() __attribute__((always_inline)) { load_pressures(); });
+    for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
+      const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
       if (k0 < km && col < ncol) pt[(ix_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);   // T_v for now
     }
     // ---- omega on the last step (:432-443, :506-526): interpolated in the old log-p coordinate (C1) to the centres of the new
     //      layers (C2); pe3(k) = omga(k-1), pe3(1) = 0 in A1 ----
     if (p.last_step) {
-      FV3_SYNC();
+      FV3_SYNC_LDS();
       {
         double v_o[kIt];
         FV3_LOAD_LOOP(it) {
-          const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+          const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
           const int kc = k0 < 1 ? 0 : (k0 <= km ? k0 - 1 : km - 1);
           v_o[it] = omga[(ix_t)kc * nA + o0 + clampc(col)];
         }
-        for (int it = 0; it < kIt; it++) {
-          const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+        for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
+          const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
           if (k0 <= km) RemapFastCore::at(A1, col, k0) = k0 == 0 ? 0. : v_o[it];
         }
       }
-      FV3_SYNC();
+      FV3_SYNC_LDS();
       double om[kIt];
-      for (int it = 0; it < kIt; it++) {
-        const int idx = tid + it * kNT, col = idx >> 7, n = (idx & 127) + 1;
+      for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
+        const int idx = tl + it * kNT, col = idx >> 7, n = (idx & 127) + 1;
         om[it] = 0.;
         if (n > km) continue;
         const RColC e = RemapFastCore::colc(C1, col), t2 = RemapFastCore::colc(C2, col), p3 = RemapFastCore::colc(A1, col);
@@ -523,117 +580,102 @@ struct RemapFastScalars {
         while (k < km && e[k + 1] < mid) k++;
         om[it] = p3[k] + (p3[k + 1] - p3[k]) * (mid - e[k]) / (e[k + 1] - e[k]);
       }
-      FV3_SYNC();
-      for (int it = 0; it < kIt; it++) {
-        const int idx = tid + it * kNT, col = idx >> 7, n = (idx & 127) + 1;
+      FV3_SYNC_LDS();
+      for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
+        const int idx = tl + it * kNT, col = idx >> 7, n = (idx & 127) + 1;
         if (n <= km) RemapFastCore::at(Q, col, n - 1) = om[it];
       }
-      FV3_SYNC();
-      for (int it = 0; it < kIt; it++) {
-        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+      FV3_SYNC_LDS();
+      for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
+        const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 < km && col < ncol) omga[(ix_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);
       }
     }
-    FV3_SYNC();
-    // ---- pressure coordinates for everything else: C1 = pe, C2 = pe2 (:318-322) ----
-    {
-      double v_pe[kIt], v_w[kIt];
-      FV3_LOAD_LOOP(it) {
-        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
-        const int ki = k0 <= km ? k0 : km, kc = k0 < km ? k0 : km - 1;
-        v_pe[it] = pe[peb0 + (ix_t)ki * (g.nx + 2) + cc];
-        v_w[it] = HYDRO ? 0. : w[(ix_t)kc * nA + o0 + cc];
+    FV3_SYNC_LDS();
+    // ---- pressure coordinates for everything else: C1 = pe, C2 = pe2 (:318-322); nx0 = pe, nx1 = the first field on them ----
+    for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
+      const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+      if (k0 <= km) {
+        RemapFastCore::at(C1, col, k0) = nx0[it];
+        const double v_ps1 = PS[col];
+        RemapFastCore::at(C2, col, k0) = (k0 == 0) ? p.ptop : (k0 == km ? v_ps1 : AK[k0] + BK[k0] * v_ps1);
       }
-      for (int it = 0; it < kIt; it++) {
-        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-        if (k0 <= km) {
-          RemapFastCore::at(C1, col, k0) = v_pe[it];
-          const double v_ps1 = pe[peb0 + (ix_t)km * (g.nx + 2) + clampc(col)];
-          RemapFastCore::at(C2, col, k0) = (k0 == 0) ? p.ptop : (k0 == km ? v_ps1 : ak[k0] + bk[k0] * v_ps1);
-        }
-        if (!HYDRO && k0 < km) RemapFastCore::at(A1, col, k0) = v_w[it];
-      }
+      if ((!HYDRO || p.nq > 0) && k0 < km) RemapFastCore::at(A1, col, k0) = nx1[it];
     }
-    FV3_SYNC();
+    FV3_SYNC_LDS();
     for (int col = tid; col < kFC; col += kNT) {
       core.pad_coord(C1, col, km + 1);
       core.pad_coord(C2, col, km + 1);
       core.pad_field(A1, col, km);
     }
-    FV3_SYNC();
     if (!HYDRO) {
-      // ---- w (:400-411): iv = -2, the bottom value ws ----
-      core.remap_field(C1, C2, A1, Q, QS, false, -2, p.kord_wz, 0., false, tid);
-      {
-        double v_dz[kIt], v_dp[kIt];
+      FV3_SYNC_LDS();
+      // ---- w (:400-411): iv = -2, the bottom value ws; delz and delp come in behind its mapping loop ----
+      core.remap_field(C1, C2, A1, Q, QS, false, -2, p.kord_wz, 0., false, tid, [&]() __attribute__((always_inline)) {
         FV3_LOAD_LOOP(it) {
-          const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
+          const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
           const int kc = k0 < km ? k0 : km - 1;
-          v_dz[it] = delz[(ix_t)kc * nCC + occ0 + cc];
-          v_dp[it] = delp[(ix_t)kc * nA + o0 + cc];
+          nx0[it] = delz[(ix_t)kc * nCC + occ0 + cc];
+          nx1[it] = delp[(ix_t)kc * nA + o0 + cc];
         }
-        for (int it = 0; it < kIt; it++) {
-          const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-          if (k0 < km && col < ncol) w[(ix_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);
-          // ---- delz (:292, :412-423): the specific volume -delz / delp in, delz = -q2 dp2 out ----
-          if (k0 < km) RemapFastCore::at(A1, col, k0) = -v_dz[it] / v_dp[it];
-        }
+      });
+      for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
+        const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+        if (k0 < km && col < ncol) w[(ix_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);
+        // ---- delz (:292, :412-423): the specific volume -delz / delp in, delz = -q2 dp2 out ----
+        if (k0 < km) RemapFastCore::at(A1, col, k0) = -nx0[it] / nx1[it];
       }
-      FV3_SYNC();
-      core.remap_field(C1, C2, A1, Q, nullptr, false, 1, akt, 0., false, tid);
-      for (int it = 0; it < kIt; it++) {
-        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+      FV3_SYNC_LDS();
+      core.remap_field(C1, C2, A1, Q, nullptr, false, 1, akt, 0., false, tid, [&]() __attribute__((always_inline)) { load_tracer(0); });
+      for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
+        const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 < km) {
           const double dzn = -RemapFastCore::at(Q, col, k0) * (RemapFastCore::at(C2, col, k0 + 1) - RemapFastCore::at(C2, col, k0));
           if (col < ncol) delz[(ix_t)k0 * nCC + occ0 + col] = dzn;
+          if (p.nq > 0) RemapFastCore::at(A1, col, k0) = nx0[it];
         }
       }
     }
-    // ---- the tracers (:380-397) ----
+    // ---- the tracers (:380-397): A1 holds tracer iq when its turn comes, tracer iq + 1 comes in behind its mapping loop ----
     for (int iq = 0; iq < p.nq; iq++) {
       double *qq = q + (size_t)iq * nA * km;
-      FV3_SYNC();
-      {
-        double v_q[kIt];
-        FV3_LOAD_LOOP(it) {
-          const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-          v_q[it] = qq[(ix_t)(k0 < km ? k0 : km - 1) * nA + o0 + clampc(col)];
-        }
-        for (int it = 0; it < kIt; it++) {
-          const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-          if (k0 < km) RemapFastCore::at(A1, col, k0) = v_q[it];
-        }
-      }
-      FV3_SYNC();
-      core.remap_field(C1, C2, A1, Q, nullptr, true, 0, kord_tr[iq], 0., p.nq > 5, tid);
-      for (int it = 0; it < kIt; it++) {
-        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+      const bool more = iq + 1 < p.nq;
+      FV3_SYNC_LDS();
+      core.remap_field(C1, C2, A1, Q, nullptr, true, 0, iq < kRKordMax ? KT[iq] : kord_tr[iq], 0., p.nq > 5, tid, [&]() __attribute__((always_inline)) { load_tracer(iq + 1); });
+      for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
+        const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 < km) {
           const double v = RemapFastCore::at(Q, col, k0);
           if (col < ncol) qq[(ix_t)k0 * nA + o0 + col] = v;
+          if (more) RemapFastCore::at(A1, col, k0) = nx0[it];
         }
       }
     }
-    FV3_SYNC();
-    // ---- the new interfaces: pn2 -> A1, pk2 -> Q (:340-345); then delp, pk, peln, pkz and pt of every layer (:426-503, :793-841) ----
+    FV3_SYNC_LDS();
+    // ---- the new interfaces: pn2 -> A1, pk2 -> Q (:340-345); then delp, pk, peln, pkz and pt of every layer (:426-503, :793-841);
+    //      the loads of the last phase (T_v, delz, sphum as this thread stored them) are issued in front of the logarithms ----
     {
-      double v_pl[kIt], v_pk[kIt];
+      const bool need_qv = p.last_step && p.last_step != 2 && !p.adiabatic && p.sphum > 0;
+      const double *qs_ = need_qv ? q + (size_t)(p.sphum - 1) * nA * km : pt;
+      double v_pl[kIt], v_pk[kIt], v_t[kIt], v_dz[kIt], v_q[kIt];
       FV3_LOAD_LOOP(it) {
-        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
-        const int ki = k0 <= km ? k0 : km, ke = (k0 == 0) ? 0 : km;
+        const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
+        const int ke = (k0 == 0) ? 0 : km, kc = k0 < km ? k0 : km - 1;
         v_pl[it] = peln[lnb0 + (ix_t)ke * g.nx + cc];
         v_pk[it] = pk[(ix_t)ke * nCC + occ0 + cc];
-        (void)ki;
+        v_t[it] = pt[(ix_t)kc * nA + o0 + cc];
+        v_dz[it] = HYDRO ? 1. : delz[(ix_t)kc * nCC + occ0 + cc];
+        v_q[it] = qs_[(ix_t)kc * nA + o0 + cc];
       }
-      for (int it = 0; it < kIt; it++) {
-        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+      for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
+        const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 <= km) {
           double pn, pkv;
           if (k0 == 0 || k0 == km) {
             pn = v_pl[it];
             pkv = v_pk[it];
           } else {
-            pn = dlog(ak[k0] + bk[k0] * pe[peb0 + (ix_t)km * (g.nx + 2) + clampc(col)]);
+            pn = dlog(AK[k0] + BK[k0] * PS[col]);
             pkv = dexp(akap * pn);
             if (col < ncol) {
               peln[lnb0 + (ix_t)k0 * g.nx + col] = pn;
@@ -644,21 +686,9 @@ struct RemapFastScalars {
           RemapFastCore::at(Q, col, k0) = pkv;
         }
       }
-    }
-    FV3_SYNC();
-    {
-      const bool need_qv = p.last_step && p.last_step != 2 && !p.adiabatic && p.sphum > 0;
-      const double *qs_ = need_qv ? q + (size_t)(p.sphum - 1) * nA * km : pt;
-      double v_t[kIt], v_dz[kIt], v_q[kIt];
-      FV3_LOAD_LOOP(it) {
-        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
-        const int kc = k0 < km ? k0 : km - 1;
-        v_t[it] = pt[(ix_t)kc * nA + o0 + cc];
-        v_dz[it] = HYDRO ? 1. : delz[(ix_t)kc * nCC + occ0 + cc];
-        v_q[it] = qs_[(ix_t)kc * nA + o0 + cc];
-      }
-      for (int it = 0; it < kIt; it++) {
-        const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
+      FV3_SYNC_LDS();
+      for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
+        const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 >= km || col >= ncol) continue;
         const RColC t2 = RemapFastCore::colc(C2, col), pn = RemapFastCore::colc(A1, col), pk2 = RemapFastCore::colc(Q, col);   // [k], 1-based: row k0 is [k0 + 1]
         const ix_t o3 = (ix_t)k0 * nA + o0 + col, c3 = (ix_t)k0 * nCC + occ0 + col;
@@ -702,6 +732,7 @@ struct RemapFastWind {
     constexpr int kIt = RemapFastCore::kIt;
     const RemapFastCore core{km, probe};
     double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf;
+    double *AK = lds + kRTabAk, *BK = lds + kRTabBk;
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (ncols_row() - bx * kFC < kFC) ? ncols_row() - bx * kFC : kFC;
     const ix_t fs = WHICH == 0 ? g.nU() : g.nV();
@@ -711,6 +742,10 @@ struct RemapFastWind {
     };
     {
       double v_a[kIt], v_b[kIt], v_sa[kIt], v_sb[kIt], v_f[kIt];
+#ifndef FV3_HOST_EMU
+      const int tn = tid & 127, tkk = tn <= km ? tn : km;
+      const double t_ak = ak[tkk], t_bk = bk[tkk];
+#endif
       FV3_LOAD_LOOP(it) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = col < ncol ? col : ncol - 1;
         const int i = i0 + cc, i2 = WHICH == 0 ? i : i - 1, j2 = WHICH == 0 ? j - 1 : j;
@@ -719,25 +754,34 @@ struct RemapFastWind {
         v_sa[it] = PE(i2, km, j2); v_sb[it] = PE(i, km, j);
         v_f[it] = f[(ix_t)kc * fs + f0 + cc];
       }
+#ifdef FV3_HOST_EMU
+      for (int n = 0; n < 128; n++) {
+        const int kk = n <= km ? n : km;
+        AK[n] = ak[kk]; BK[n] = bk[kk];
+      }
+#else
+      if (tid < 128) { AK[tn] = t_ak; BK[tn] = t_bk; }
+#endif
+      FV3_SYNC_LDS();   // AK, BK
       for (int it = 0; it < kIt; it++) {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 <= km) {
           const double psum = v_sa[it] + v_sb[it];
           RemapFastCore::at(C1, col, k0) = (k0 == 0) ? v_b[it] : 0.5 * (v_a[it] + v_b[it]);
-          const double bkh = 0.5 * bk[k0];
-          RemapFastCore::at(C2, col, k0) = (WHICH == 1 && k0 == 0) ? ak[0] : ak[k0] + bkh * psum;
+          const double bkh = 0.5 * BK[k0];
+          RemapFastCore::at(C2, col, k0) = (WHICH == 1 && k0 == 0) ? AK[0] : AK[k0] + bkh * psum;
         }
         if (k0 < km) RemapFastCore::at(A1, col, k0) = v_f[it];
       }
     }
-    FV3_SYNC();
+    FV3_SYNC_LDS();
     for (int col = tid; col < kFC; col += kNT) {
       core.pad_coord(C1, col, km + 1);
       core.pad_coord(C2, col, km + 1);
       core.pad_field(A1, col, km);
     }
-    FV3_SYNC();
-    core.remap_field(C1, C2, A1, Q, nullptr, false, -1, kord_mt, 0., false, tid);
+    FV3_SYNC_LDS();
+    core.remap_field(C1, C2, A1, Q, nullptr, false, -1, kord_mt, 0., false, tid, []() {});
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
       if (k0 < km && col < ncol) f[(ix_t)k0 * fs + f0 + col] = RemapFastCore::at(Q, col, k0);

@@ -974,6 +974,23 @@ def test_cubed_c384_pair_vs_oracle(prod, hydrostatic):
                              par_over=dict(dddmp=0.5)).values()) <= P.TOL
 
 
+@pytest.mark.parametrize("lane_d2", ["1", "0"])
+def test_cubed_pair_in_two_lanes(prod, monkeypatch, lane_d2):
+    """round 4: the frame / sponge-level passes of a cubed-sphere face on the side stream BESIDE the marching kernels (fv3_api.hip
+    dsw_cubed / csw_cubed).  Forced on (FV3_MI355X_SIDE_STREAM=2: by default only a face that launches on its own and is large takes
+    the two lanes) and held to the oracle on six C96 / C384 faces -- a race between the lanes would show as a wrong frame --, then the
+    six faces as a group through whole nonhydrostatic substeps."""
+    monkeypatch.setenv("FV3_MI355X_SIDE_STREAM", "2")
+    monkeypatch.setenv("FV3_MI355X_LANE_D2", lane_d2)
+    for rep in range(3):
+        assert PC.check_c_sw(prod, npx=97, npz=16, hydrostatic=False) <= P.TOL
+        assert max(PC.check_d_sw(prod, npx=97, npz=16, hydrostatic=False).values()) <= P.TOL
+    assert PC.check_c_sw(prod, npx=385, npz=4, hydrostatic=False) <= P.TOL
+    assert max(PC.check_d_sw(prod, npx=385, npz=6, hydrostatic=False).values()) <= P.TOL
+    assert max(PC.check_d_sw(prod, npx=385, npz=6, hydrostatic=True, faces=(0, 3)).values()) <= P.TOL
+    assert max(PC.check_substeps_nh(prod, npx=49, npz=12, n_split=2).values()) <= 1e-12
+
+
 @pytest.mark.parametrize("hydrostatic", [True, False])
 def test_cubed_d_sw_damping_fused_chains(prod, hydrostatic):
     """C32 / C48 faces: the del-2n chains as one LDS-tile launch away from the corners (cubed_damp.h DelnFused), the damped whole-face

@@ -732,6 +732,21 @@ def test_cubed_hybrid_c_sw(emu, hydrostatic):
     assert PC.check_c_sw(emu, npx=49, npz=3, hydrostatic=hydrostatic, nord=0, faces=(1,)) <= P.TOL
 
 
+@pytest.mark.parametrize("lane_d2", ["1", "0"])
+def test_cubed_hybrid_two_lanes(emu, monkeypatch, lane_d2):
+    """the order of the two lanes (fv3_api.hip dsw_cubed / csw_cubed: the marching kernels first, the passes from their own work
+    copies and, for the frame's transports, Courant numbers of their own) forced on faces of any size: on this harness the launches run
+    one after the other, so what is tested is that no pass depends on the marching kernel overwriting it afterwards -- bit for bit the
+    oracle's c_sw, d_sw and substeps (sphere: the six faces as a group)"""
+    monkeypatch.setenv("FV3_MI355X_SIDE_STREAM", "2")
+    monkeypatch.setenv("FV3_MI355X_LANE_D2", lane_d2)
+    assert PC.check_c_sw(emu, npx=49, npz=3, hydrostatic=False) <= P.TOL
+    assert PC.check_c_sw(emu, npx=49, npz=3, hydrostatic=True, nord=0, faces=(1,)) <= P.TOL
+    assert max(PC.check_d_sw(emu, npx=41, hydrostatic=False, npz=12, faces=(1, 4)).values()) <= P.TOL
+    assert max(PC.check_d_sw(emu, npx=41, hydrostatic=True, npz=12, faces=(2, 5), flags=dict(nord=2)).values()) <= P.TOL
+    assert max(PC.check_substeps_nh(emu, npx=33, npz=12, n_split=2).values()) <= 1e-13
+
+
 def test_cubed_hybrid_c_sw_frame_is_not_marginal(emu, monkeypatch):
     """d2a2c_vect's edge forms reach six points into a face (npt = 4, the 4-point A -> C interpolation, ke, the wind update)"""
     monkeypatch.setenv("FV3_MI355X_CUBED_FRAME_C", "6")

@@ -25,3 +25,5 @@ PY
 bash tools/pmc_riem.sh $TAG > gpurun_out/$TAG/pmc_riem.log 2>&1
 (for p in 0 1 2 4 7; do echo probe $p; FV3_MI355X_RIEM_PROBE=$p RT_FIRST=1 RT_LAST=2 timeout 200 python tools/riem_time.py 2>&1 | grep lds; done; RT_FIRST=0 RT_LAST=5 timeout 300 python tools/riem_time.py 2>&1 | grep -E "slab|lds|tolerance") > gpurun_out/$TAG/riem_probe.txt 2>&1
 (for p in 0 1 2 4 8 15; do echo probe $p; FV3_MI355X_REMAP_PROBE=$p timeout 200 python tools/remap_time.py 2>&1 | grep -E "^lds|^slabs"; done) > gpurun_out/$TAG/remap_probe.txt 2>&1
+# round 4, second half: the two lanes of the cubed-sphere pair against the one-lane order (bit comparison + wall time, C384 L127 NH / hydrostatic)
+(NPX=385 NPZ=127 REPS=3 timeout 900 python tools/lanes_check.py; FV3_MI355X_LANE_D2=1 NPX=385 NPZ=127 REPS=2 timeout 900 python tools/lanes_check.py; NH=0 NPX=385 NPZ=127 REPS=2 timeout 900 python tools/lanes_check.py) 2>&1 | grep -E "tile|lanes_check|DIFF" > gpurun_out/$TAG/lanes_check.txt
