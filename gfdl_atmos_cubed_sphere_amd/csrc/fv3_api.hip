@@ -1519,10 +1519,10 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
   const char *L = "dswc_damp";
   // del-2n damping (cubed_damp.h): the passes of one operator; work arrays = scratch 4..6 of fv_tp_2d (free between its calls)
   auto deln = [&](const double *q, const double *mass, double *fx, double *fy, const int *nord, const double *coef, double thresh,
-                  int corner_area, int nmax, double *out_fx2, double *out_fy2, const PassRegion &rk) -> int {
+                  int corner_area, int nmax, double *out_fx2, double *out_fy2, const PassRegion &rk, int d2_slot = 4) -> int {
     DelnCubedState d;
     d.g = g; d.q = q; d.mass = mass; d.fx = fx; d.fy = fy; d.nord = nord; d.coef = coef; d.thresh = thresh; d.corner_area = corner_area;
-    d.d2 = cs_scratch(c, 4);
+    d.d2 = cs_scratch(c, d2_slot);
     d.fx2 = out_fx2 ? out_fx2 : cs_scratch(c, 5);
     d.fy2 = out_fy2 ? out_fy2 : cs_scratch(c, 6);
     if (!d.d2 || !d.fx2 || !d.fy2) return fail("d_sw: out of device memory");
@@ -1739,7 +1739,8 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     }
     RT(launch_pass(c, L, g.is, g.ie + 1, g.js, g.je + 1, rg, DswCubedD7{so}));
     if (rg.w == 0 && c->lev_has_damp_v5)   // :1513-1515: del6_vt_flux of the RELATIVE vorticity (before D8 adds f0)
-      RT(deln(s.wk, nullptr, nullptr, nullptr, a.lv.nord_v, a.lv.damp_vt, 1.E-5, 1, c->lev_max_nord_v, s.dfx2, s.dfy2, rg));
+      // (work array 33, not the transports' 4: this chain may run beside theirs, see the lanes below)
+      RT(deln(s.wk, nullptr, nullptr, nullptr, a.lv.nord_v, a.lv.damp_vt, 1.E-5, 1, c->lev_max_nord_v, s.dfx2, s.dfy2, rg, 33));
     RT(launch_pass(c, "dswc_d8", g.isd, g.ied, g.jsd, g.jed, rg, DswCubedD8{s}));
     }
     if (part == 1) return 0;
@@ -1831,6 +1832,27 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     c->lane = 0;
     if (rc) return rc;
     RT(lane_op(c, kLaneJoin));
+    return 0;
+  }
+  // Every level damped (a production namelist: nord = 3, vtdm4, d_con, dddmp -- no level for the hybrid above): the two halves of d_sw
+  // are chains of whole-face launches, and the momentum half up to the absolute vorticity (kinetic energy, vorticity, the del-2n loop of
+  // the divergence, Smagorinsky, the vorticity's del6_vt_flux) reads nothing the transport half writes -- it runs beside it on the side
+  // lane; what needs the Courant numbers (the vorticity transport, the wind update, heating) follows on the main lane after the join.
+  // The two chains share no work array (the vorticity's damping chain has its own, 33).
+  if (!hyb_t && !hyb_m && !a.use_cond && frame_fused_on() && lanes_pay(c)) {   // (the pass forms of fv_tp_2d share work arrays 4 .. 7)
+    RT(lane_prepare(c));
+    const PassRegion all{0, nullptr, npz};
+    RT(lane_op(c, kLaneFork));
+    c->lane = 1;
+    int rc = momentum(all, all, 1);
+    c->lane = 0;
+    if (rc) return rc;
+    RT(transport(all, all, true));
+    RT(lane_op(c, kLaneJoin));
+    // (the rest of the momentum half on the side lane too -- behind an event after the transports' Courant numbers, with flux arrays of
+    // its own -- was measured no faster, and it is not independent: D4 leaves the heat of the w damping in heat_source, which the
+    // heating pass adds to)
+    RT(momentum(all, all, 2));
     return 0;
   }
   if (hyb_t) {

@@ -989,6 +989,10 @@ def test_cubed_pair_in_two_lanes(prod, monkeypatch, lane_d2):
     assert max(PC.check_d_sw(prod, npx=385, npz=6, hydrostatic=False).values()) <= P.TOL
     assert max(PC.check_d_sw(prod, npx=385, npz=6, hydrostatic=True, faces=(0, 3)).values()) <= P.TOL
     assert max(PC.check_substeps_nh(prod, npx=49, npz=12, n_split=2).values()) <= 1e-12
+    # every level damped (production namelist): the momentum half up to the absolute vorticity beside the transport half
+    for rep in range(2):
+        assert max(PC.check_d_sw(prod, npx=97, npz=18, hydrostatic=False, faces=(0, 3, 5), flags=PROD, par_over=dict(dddmp=0.5)).values()) <= P.TOL
+    assert max(PC.check_d_sw(prod, npx=385, npz=18, hydrostatic=True, faces=(1,), flags=PROD, par_over=dict(dddmp=0.5)).values()) <= P.TOL
 
 
 @pytest.mark.parametrize("hydrostatic", [True, False])

@@ -745,6 +745,9 @@ def test_cubed_hybrid_two_lanes(emu, monkeypatch, lane_d2):
     assert max(PC.check_d_sw(emu, npx=41, hydrostatic=False, npz=12, faces=(1, 4)).values()) <= P.TOL
     assert max(PC.check_d_sw(emu, npx=41, hydrostatic=True, npz=12, faces=(2, 5), flags=dict(nord=2)).values()) <= P.TOL
     assert max(PC.check_substeps_nh(emu, npx=33, npz=12, n_split=2).values()) <= 1e-13
+    # every level damped (production namelist): the momentum half up to the absolute vorticity beside the transport half
+    prod_flags = dict(do_vort_damp=True, vtdm4=0.06, nord=3, d_con=1.0, dddmp=0.5)
+    assert max(PC.check_d_sw(emu, npx=41, npz=6, hydrostatic=False, faces=(0, 4), flags=prod_flags, par_over=dict(dddmp=0.5)).values()) <= P.TOL
 
 
 def test_cubed_hybrid_c_sw_frame_is_not_marginal(emu, monkeypatch):
