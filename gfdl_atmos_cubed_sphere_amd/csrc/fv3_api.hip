@@ -3525,10 +3525,15 @@ extern "C" int fv3_divg2_ext(fv3_ctx *c, double d_ext, const double *delp, const
 }
 
 static int one_grad_p_impl(fv3_ctx *c, double *u, double *v, const double *pk, const double *gz, const double *divg2, double dt,
-                           double ptk, double beta, double *du, double *dv);
+                           double ptk, double beta, double *du, double *dv, const double *delp = nullptr, double gz_scale = 1.0);
 extern "C" int fv3_one_grad_p(fv3_ctx *c, double *u, double *v, const double *pk, const double *gz, const double *divg2,
                               double dt, double ptk) {
   return one_grad_p_impl(c, u, v, pk, gz, divg2, dt, ptk, 0., nullptr, nullptr);
+}
+extern "C" int fv3_one_grad_p_nh(fv3_ctx *c, double *u, double *v, const double *pk, const double *gz, const double *divg2,
+                                 const double *delp, double dt, double ptop, double gz_scale) {
+  if (!delp) return fail("fv3_one_grad_p_nh: delp is required (the layer weights are a2b_ord4 of delp)");
+  return one_grad_p_impl(c, u, v, pk, gz, divg2, dt, ptop, 0., nullptr, nullptr, delp, gz_scale);
 }
 extern "C" int fv3_grad1_p_update(fv3_ctx *c, const double *divg2, double *u, double *v, const double *pk, const double *gz, double dt,
                                   double ptk, double beta, double *du, double *dv) {
@@ -3536,10 +3541,10 @@ extern "C" int fv3_grad1_p_update(fv3_ctx *c, const double *divg2, double *u, do
   return one_grad_p_impl(c, u, v, pk, gz, divg2, dt, ptk, beta, du, dv);
 }
 static int one_grad_p_impl(fv3_ctx *c, double *u, double *v, const double *pk, const double *gz, const double *divg2, double dt,
-                           double ptk, double beta, double *du, double *dv) {
+                           double ptk, double beta, double *du, double *dv, const double *delp, double gz_scale) {
   if (!c || !c->grid_ready) return fail("fv3_one_grad_p: context has no grid");
   if (!u || !v || !pk || !gz) return fail("fv3_one_grad_p: null field");
-  if (need_scratch(c, 2)) return 1;
+  if (need_scratch(c, delp ? 3 : 2)) return 1;
   const Grid &g = c->g;
   const int km = g.npz;
   constexpr int TI = 32, TJ = 16;
@@ -3551,14 +3556,19 @@ static int one_grad_p_impl(fv3_ctx *c, double *u, double *v, const double *pk, c
     kf.nlev[0] = kf.nlev[1] = km + 1;
     kf.nlev[2] = kf.nlev[3] = 0;
     kf.nf = 2;
+    if (delp) {               // hydrostatic = .false. (:1996-1997): the layer weights are a2b_ord4 of delp
+      kf.in[2] = delp; kf.out[2] = c->scratch[2]; kf.nlev[2] = km; kf.nf = 3;
+    }
     for (int f = 0; f < 4; f++) { kf.scale[f] = 1.0; kf.top[f] = 0.; }
-    kf.top[0] = ptk;          // pk(i,j,1) = top_value (:1950-1955)
+    kf.scale[1] = gz_scale;   // gz = zh * grav (:982-989) formed while the tile is staged, as in nh_p_grad
+    kf.top[0] = ptk;          // pk(i,j,1) = top_value (:1950-1955): ptk, or ptop where pk is the full pressure
     kf.override_mask = 1;
     RT((run_a2b<TI, TJ>(c, kf, km + 1)));
   }
   {
     OneGradPHydro kf{g, dt, c->scratch[0], c->scratch[1], divg2, u, v};
     kf.beta = beta; kf.du = du; kf.dv = dv;
+    kf.dpc = delp ? c->scratch[2] : nullptr;
     Dim3 grid;
     grid.x = (unsigned)(((g.nx + 1) * (g.ny + 1) + OneGradPHydro::CH - 1) / OneGradPHydro::CH);
     grid.y = 1;

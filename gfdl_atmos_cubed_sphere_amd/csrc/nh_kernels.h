@@ -1448,18 +1448,20 @@ struct OneGradPHydro {  // dyn_core.F90:2002-2028 on precomputed corner values o
   double *u, *v;
   double beta = 0.;
   double *du = nullptr, *dv = nullptr;
+  const double *dpc = nullptr;   // the nonhydrostatic form (hydrostatic = .false., :1996-1997): a2b_ord4 of delp, npz corner slabs, as wk
   static constexpr int CH = 1024;
   FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
     const int k = bz;
     const size_t nA = g.nA();
     const double *pk0 = pk + (size_t)k * nA, *pk1 = pk0 + nA, *gz0 = gz + (size_t)k * nA, *gz1 = gz0 + nA;
+    const double *dp = dpc ? dpc + (size_t)k * nA : nullptr;
     const int w = g.nx + 1, n = w * (g.ny + 1);
     for (int idx = bx * CH + tid; idx < (bx + 1) * CH && idx < n; idx += kNT) {
       const int i = g.is + idx % w, j = g.js + idx / w;
       const int o = g.iA(i, j), oe = g.iA(i + 1, j), on = g.iA(i, j + 1);
-      const double wk0 = pk1[o] - pk0[o];
+      const double wk0 = dp ? dp[o] : pk1[o] - pk0[o];
       if (i <= g.ie) {
-        const double wke = pk1[oe] - pk0[oe];
+        const double wke = dp ? dp[oe] : pk1[oe] - pk0[oe];
         const double wk2 = divg2 ? divg2[o] - divg2[oe] : 0.;
         double *p = u + (size_t)k * g.nU() + g.iU(i, j);
         if (du) {
@@ -1474,7 +1476,7 @@ struct OneGradPHydro {  // dyn_core.F90:2002-2028 on precomputed corner values o
                                                                 (gz0[o] - gz1[oe]) * (pk1[o] - pk0[oe])));
       }
       if (j <= g.je) {
-        const double wkn = pk1[on] - pk0[on];
+        const double wkn = dp ? dp[on] : pk1[on] - pk0[on];
         const double wk1 = divg2 ? divg2[o] - divg2[on] : 0.;
         double *p = v + (size_t)k * g.nV() + g.iV(i, j);
         if (dv) {

@@ -7,7 +7,7 @@ each step).  All fields are device resident (``lib.DeviceArray``); fields that `
 after the call -- the halo update that follows in the reference fills the new buffer's halo.
 
 Not reproduced (off in every BASELINE config): nesting / regional BCs, ``breed_vortex_inline``,
-``do_fast_phys``, ``Ray_fast``, ``beta < -0.1`` (one_grad_p in the nonhydrostatic loop).
+``do_fast_phys``, ``Ray_fast``.
 """
 from __future__ import annotations
 
@@ -137,8 +137,8 @@ class DynCore:
             d["q_con"], d["q_con_nxt"] = z("A", npz), z("A", npz)
         if flags.moist_kappa:
             d["cappa"] = z("A", npz)
-        if flags.beta < 0.0:
-            raise ValueError("beta < 0 (one_grad_p in the nonhydrostatic loop, dyn_core.F90:1029) is not part of this build")
+        if flags.beta < 0.0 and (flags.hydrostatic or flags.beta >= -0.1):
+            raise ValueError("beta < 0: only beta < -0.1 in the nonhydrostatic loop selects anything (one_grad_p, dyn_core.F90:1029)")
         if flags.beta > 1.0e-9:   # dyn_core.F90:278-283: allocated and zeroed once, kept between calls
             d["du"], d["dv"] = z("U", npz), z("V", npz)
         self.lev = level_coefficients(npz, flags)
@@ -274,6 +274,8 @@ class DynCore:
         peln1 = np.log(fl.ptop)
         for a in ("mfx", "mfy", "cx", "cy"):  # :289-292 empty the flux capacitors
             d[a].zero()
+        if fl.beta < -0.1 and fl.d_ext > 0.0 and "divg2" not in d:
+            d["divg2"] = ctx.zeros("A", None)
         heating = fl.d_con > 1.0e-5
         if heating:                            # :294
             if "heat_source" not in d:
@@ -325,6 +327,8 @@ class DynCore:
                 ctx.heat_source_accum(d["heat_source"], d["heat_s"])          # :798-803
             if inline:
                 self._inline_q_transport()
+            if fl.beta < -0.1 and fl.d_ext > 0.0:   # :745-747, :791-848: the external-mode damping field of one_grad_p (:1030)
+                ctx.divg2_ext(fl.d_ext, d["delp"], d["vt"], d["divg2"])
             for n in ("delp", "pt", "u", "v", "w") + (("q_con",) if fl.use_cond else ()):
                 self._swap(n)
             # :823-825 start / :851-852 complete (packs 1, 11).  Several ranks: the messages stay in flight while update_dz_d
@@ -342,7 +346,7 @@ class DynCore:
             if lag:
                 halo.post(pend1)
             ctx.riem_solver3(dt, self.cn, d["zs"], d["w"], d["delz"], d["pt"], d["delp"], d["zh"], d["pe"], d["pkc"],
-                             d["pk3"], d["pk"], d["peln"], d["ws"], fl.use_logp, remap_step, False)   # :932
+                             d["pk3"], d["pk"], d["peln"], d["ws"], fl.use_logp, remap_step, fl.beta < -0.1)   # :932, fp_out :939
             if lag:
                 halo.finish(pend1)
             # :944-950 (packs 4, 5) start ... complete around pe_halo / pk3_halo, which read delp only
@@ -358,6 +362,9 @@ class DynCore:
             if fl.beta > 0.0:   # :1027-1028, beta_d = 0 in the first substep (:398-406)
                 ctx.split_p_grad(d["u"], d["v"], d["pkc"], d["zh"], d["delp"], d["pk3"], 0.0 if it == 1 else fl.beta, dt,
                                  peln1 if fl.use_logp else ptk, d["du"], d["dv"], gz_scale=fl.grav)
+            elif fl.beta < -0.1:   # :1029-1030: pkc is the full pressure (fp_out), the layer weights a2b_ord4 of delp
+                ctx.one_grad_p_nh(d["u"], d["v"], d["pkc"], d["zh"], d["divg2"] if fl.d_ext > 0.0 else None, d["delp"], dt,
+                                  fl.ptop, gz_scale=fl.grav)
             else:
                 ctx.nh_p_grad(d["u"], d["v"], d["pkc"], d["zh"], d["delp"], d["pk3"], dt,
                               peln1 if fl.use_logp else ptk, gz_scale=fl.grav)    # :1032

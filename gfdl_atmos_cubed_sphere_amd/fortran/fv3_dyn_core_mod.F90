@@ -206,7 +206,8 @@ contains
     if (thermostruct%use_cond .and. size(q_con, 3) < npz) error stop 'dyn_core (fv3_dyn_core_mod): use_cond needs q_con on npz levels'
     if (thermostruct%moist_kappa .and. size(cappa, 3) < npz) error stop 'dyn_core (fv3_dyn_core_mod): moist_kappa needs cappa on npz levels'
     if (flagstruct%do_diss_est) error stop 'dyn_core (fv3_dyn_core_mod): do_diss_est is not carried through this wrapper'
-    if (flagstruct%beta < 0.d0) error stop 'dyn_core (fv3_dyn_core_mod): beta < 0 (one_grad_p in the nonhydrostatic loop) is not built'
+    if (flagstruct%beta < 0.d0 .and. (hydrostatic .or. flagstruct%beta >= -0.1d0 .or. gridstruct%grid_type < 3)) &
+      error stop 'dyn_core (fv3_dyn_core_mod): beta < 0: one_grad_p (beta < -0.1) is built for the nonhydrostatic loop of the doubly periodic domain'
     if (ng /= 3 .or. bd%ng /= 3) error stop 'dyn_core (fv3_dyn_core_mod): ng = 3'
     if (.not. bound) then
       call bind_context()

@@ -9,8 +9,8 @@
 !> exchange behind the C ABI, fv3_halo_start / fv3_halo_complete over the context's RCCL communicator -- the form a
 !> several-rank run uses with the neighbour ranks in to / from (see INTEGRATION.md).
 !>
-!> Not reproduced (off in every BASELINE config): nesting / regional BCs, breed_vortex_inline, do_fast_phys, Ray_fast,
-!> beta < 0 (one_grad_p in the nonhydrostatic loop).  The argument lists are this module's own (type fv3_atmos holds the device handles the
+!> Not reproduced (off in every BASELINE config): nesting / regional BCs, breed_vortex_inline, do_fast_phys, Ray_fast
+!> (beta < -0.1 -- one_grad_p in the nonhydrostatic loop -- is built).  The argument lists are this module's own (type fv3_atmos holds the device handles the
 !> reference keeps in fv_atmos_type / dyn_core's work arrays); INTEGRATION.md maps them to the reference's call sites,
 !> and fv3_dyn_core_mod.F90 puts dyn_core's own argument list (host arrays, gridstruct, flagstruct, bd) in front of
 !> fv3_dyn_core for callers that keep their state on the host.
@@ -301,7 +301,8 @@ contains
       call dmalloc(at%q_con, at%nA*nk); call dmalloc(at%q_con_n, at%nA*nk); call dmalloc(at%cappa, at%nA*nk)
       call dzero(at, at%q_con, at%nA*nk); call dzero(at, at%q_con_n, at%nA*nk); call dzero(at, at%cappa, at%nA*nk)
     end if
-    if (fl%beta < 0.d0) error stop 'fv3_host_mod: beta < 0 (one_grad_p in the nonhydrostatic loop) is not built'
+    if (fl%beta < 0.d0 .and. (fl%hydrostatic .or. fl%beta >= -0.1d0)) &
+      error stop 'fv3_host_mod: beta < 0: only beta < -0.1 in the nonhydrostatic loop selects anything (one_grad_p, dyn_core.F90:1029)'
     if (fl%beta > 1.d-9) then
       call dmalloc(at%du, at%nU*nk); call dmalloc(at%dv, at%nV*nk)
       call dzero(at, at%du, at%nU*nk); call dzero(at, at%dv, at%nV*nk)
@@ -455,7 +456,7 @@ contains
     integer :: it, n_split, npz
     logical :: remap_step
     integer(c_int) :: last_call, use_logp
-    type(c_ptr) :: ctx, fxp, fyp, qcp, qcn
+    type(c_ptr) :: ctx, fxp, fyp, qcp, qcn, dv2n
     logical :: heating
     integer :: n_con
     if (at%fl%hydrostatic) then
@@ -508,6 +509,9 @@ contains
                               at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, qcn, at%heat_s, at%diss_e), 'd_sw')  ! :762
       if (heating) call fv3_check(fv3_heat_source_accum(ctx, at%heat_source, at%heat_s), 'heat_source_accum')   ! :798-803
       call inline_q_end(at)
+      ! beta < -0.1: the external-mode damping field of one_grad_p (:1030) from the delp before d_sw and d_sw's divergence (:745-747, :791-848)
+      if (at%fl%beta < -0.1d0 .and. at%fl%d_ext > 0.d0) &
+        call fv3_check(fv3_divg2_ext(ctx, at%fl%d_ext, at%delp, at%vt, at%divg2), 'divg2_ext')
       call swap(at%delp, at%delp_n); call swap(at%pt, at%pt_n)
       call swap(at%u, at%u_n); call swap(at%v, at%v_n); call swap(at%w, at%w_n)
       call halo(at, at%delp, KIND_A, npz); call halo(at, at%pt, KIND_A, npz)              ! :823-824 / :851 (pack 1)
@@ -520,7 +524,8 @@ contains
                                      at%yfx, at%ws, rdt), 'update_dz_d')                  ! :911
       call swap(at%zh, at%zh_n)
       call fv3_check(fv3_riem_solver3(ctx, dt, at%cn, at%zs, at%w, at%delz, at%pt, at%delp, at%zh, at%pe, at%pkc, &
-                                      at%pk3, at%pk, at%peln, at%ws, use_logp, last_call, 0_c_int), 'riem_solver3')  ! :932
+                                      at%pk3, at%pk, at%peln, at%ws, use_logp, last_call, &
+                                      merge(1_c_int, 0_c_int, at%fl%beta < -0.1d0)), 'riem_solver3')  ! :932, fp_out :939
       call halo(at, at%zh, KIND_A, npz + 1); call halo(at, at%pkc, KIND_A, npz + 1)       ! :944-950 (packs 4, 5)
       if (remap_step) call fv3_check(fv3_pe_halo(ctx, at%fl%ptop, at%pe, at%delp), 'pe_halo')   ! :952-953
       call fv3_check(fv3_pk3_halo(ctx, at%fl%ptop, at%fl%akap, at%pk3, at%delp, use_logp), 'pk3_halo')   ! :955-959
@@ -528,6 +533,10 @@ contains
       if (at%fl%beta > 0.d0) then     ! :1027-1028; beta_d = 0 in the first substep (:398-406)
         call fv3_check(fv3_split_p_grad(ctx, at%u, at%v, at%pkc, at%zh, at%fl%grav, at%delp, at%pk3, merge(0.d0, at%fl%beta, it == 1), &
                                         dt, top, at%du, at%dv), 'split_p_grad')
+      else if (at%fl%beta < -0.1d0) then   ! :1029-1030: pkc is the full pressure, the layer weights a2b_ord4 of delp
+        dv2n = c_null_ptr
+        if (at%fl%d_ext > 0.d0) dv2n = at%divg2
+        call fv3_check(fv3_one_grad_p_nh(ctx, at%u, at%v, at%pkc, at%zh, dv2n, at%delp, dt, at%fl%ptop, at%fl%grav), 'one_grad_p (nh)')
       else
         call fv3_check(fv3_nh_p_grad(ctx, at%u, at%v, at%pkc, at%zh, at%fl%grav, at%delp, at%pk3, dt, top), 'nh_p_grad')  ! :1032
       end if

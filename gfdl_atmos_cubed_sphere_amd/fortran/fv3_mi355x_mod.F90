@@ -18,7 +18,7 @@ module fv3_mi355x_mod
   public :: fv3_halo_field, fv3_halo_message_elems, fv3_halo_pack, fv3_halo_unpack, fv3_halo_periodic_group
   public :: fv3_heat_source_accum, fv3_del2_cubed, fv3_apply_heat_source
   public :: fv3_d_sw_interior, fv3_d_sw_rest
-  public :: fv3_divg2_ext, fv3_one_grad_p, fv3_grad1_p_update, fv3_split_p_grad, fv3_d_sw_inline_q, fv3_set_remap_te, fv3_profile_report_timers, fv3_prt_maxmin, fv3_flux_accum, fv3_fill2d_mass, fv3_fill2d_apply, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
+  public :: fv3_divg2_ext, fv3_one_grad_p, fv3_one_grad_p_nh, fv3_grad1_p_update, fv3_split_p_grad, fv3_d_sw_inline_q, fv3_set_remap_te, fv3_profile_report_timers, fv3_prt_maxmin, fv3_flux_accum, fv3_fill2d_mass, fv3_fill2d_apply, fv3_copy_a_to_cc, fv3_pt_to_theta_v, fv3_omga_update
   public :: fv3_grid_cubed, fv3_grid_upload_cubed, fv3_gather_create, fv3_gather_run, fv3_gather_destroy
   public :: fv3_comm_get_unique_id, fv3_comm_init, fv3_comm_destroy, fv3_halo_start, fv3_halo_complete, fv3_allreduce_max
   public :: fv3_cube_field, fv3_cube_table, fv3_cube_halo_start, fv3_cube_halo_complete
@@ -397,6 +397,11 @@ module fv3_mi355x_mod
       import :: c_int, c_ptr, c_double
       type(c_ptr), value :: ctx, u, v, pk, gz, divg2
       real(c_double), value :: dt, ptk
+    end function
+    integer(c_int) function fv3_one_grad_p_nh(ctx, u, v, pk, gz, divg2, delp, dt, ptop, gz_scale) bind(C, name="fv3_one_grad_p_nh")
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx, u, v, pk, gz, divg2, delp
+      real(c_double), value :: dt, ptop, gz_scale
     end function
     integer(c_int) function fv3_grad1_p_update(ctx, divg2, u, v, pk, gz, dt, ptk, beta, du, dv) bind(C, name="fv3_grad1_p_update")
       import :: c_int, c_ptr, c_double

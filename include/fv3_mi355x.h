@@ -361,6 +361,12 @@ int fv3_adv_pe(fv3_ctx *ctx, double ptop, const double *ua, const double *va, co
 int fv3_divg2_ext(fv3_ctx *ctx, double d_ext, const double *delp, const double *vt, double *divg2);
 int fv3_one_grad_p(fv3_ctx *ctx, double *u, double *v, const double *pk, const double *gz, const double *divg2,
                    double dt, double ptk);
+/* one_grad_p with hydrostatic = .false. -- model/dyn_core.F90:1909-2030, the call of the NONHYDROSTATIC loop with beta < -0.1 (:1029-1030)
+ * after Riem_Solver3 left the full pressure in pkc (its `fp_out`, :939): pk(:,:,1) = ptop (:1950) and the layer weight is a2b_ord4 of
+ * delp (:1996-1997) instead of the difference of the corner pk.  pk: the full pressure (A x (npz+1), halo filled), gz: the interface
+ * heights times gz_scale (pass zh and grav: gz = zh * grav, :982-989), delp: A x npz with its halo, divg2: fv3_divg2_ext or null. */
+int fv3_one_grad_p_nh(fv3_ctx *ctx, double *u, double *v, const double *pk, const double *gz, const double *divg2,
+                      const double *delp, double dt, double ptop, double gz_scale);
 
 /* grad1_p_update -- model/dyn_core.F90:2033-2116, call site :1019 (hydrostatic, beta > 0).  divg2: A (fv3_divg2_ext; zeros when
  * d_ext = 0), du, dv as for fv3_split_p_grad. */

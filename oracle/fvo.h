@@ -201,6 +201,8 @@ int fvo_pe_halo(const fvo_grid *g, int npz, double ptop, double *pe, const doubl
 int fvo_divg2_ext(const fvo_grid *g, int npz, double d_ext, const double *delp, const double *vt, double *divg2);
 int fvo_one_grad_p_hydro(const fvo_grid *g, int npz, double dt, double ptk, const double *divg2, double *u, double *v,
                          double *pk, double *gz);
+int fvo_one_grad_p_nh(const fvo_grid *g, int npz, double dt, double ptop, const double *divg2, double *u, double *v, double *pk,
+                      double *gz, const double *delp);
 int fvo_split_p_grad(const fvo_grid *g, int npz, double *u, double *v, double *pp, double *gz, double *delp, double *pk, double beta,
                      double dt, double top_value, double *du, double *dv);
 int fvo_grad1_p_update(const fvo_grid *g, int npz, const double *divg2, double *u, double *v, double *pk, double *gz, double dt,

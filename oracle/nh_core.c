@@ -1074,8 +1074,21 @@ int fvo_divg2_ext(const fvo_grid *g, int npz, double d_ext, const double *delp, 
 
 /* one_grad_p, hydrostatic form (model/dyn_core.F90:1909-2030, call site :1021): pk = pe**kappa.  pk, gz are replaced
  * by their corner interpolants like in the reference; divg2 as produced by fvo_divg2_ext (zeros when d_ext <= 0). */
+static int one_grad_p_any(const fvo_grid *g, int npz, double dt, double ptk, const double *divg2, double *u, double *v,
+                          double *pk, double *gz, const double *delp);
 int fvo_one_grad_p_hydro(const fvo_grid *g, int npz, double dt, double ptk, const double *divg2, double *u, double *v,
                          double *pk, double *gz) {
+  return one_grad_p_any(g, npz, dt, ptk, divg2, u, v, pk, gz, NULL);
+}
+/* one_grad_p, nonhydrostatic form (hydrostatic = .false.: the call of the nonhydrostatic loop with beta < -0.1, dyn_core.F90:1029-1030,
+ * after Riem_Solver3 left the FULL pressure in pkc, :939): pk(:,:,1) = ptop (:1950) and the layer weight wk is a2b_ord4 of delp
+ * (:1997) instead of the difference of the corner pk. */
+int fvo_one_grad_p_nh(const fvo_grid *g, int npz, double dt, double ptop, const double *divg2, double *u, double *v, double *pk,
+                      double *gz, const double *delp) {
+  return one_grad_p_any(g, npz, dt, ptop, divg2, u, v, pk, gz, delp);
+}
+static int one_grad_p_any(const fvo_grid *g, int npz, double dt, double ptk, const double *divg2, double *u, double *v,
+                          double *pk, double *gz, const double *delp) {
   BOUNDS(g);
   int k;
   const size_t nA = (size_t)nid * njd, nV = (size_t)(nid + 1) * njd, nU = (size_t)nid * (njd + 1);
@@ -1095,8 +1108,15 @@ int fvo_one_grad_p_hydro(const fvo_grid *g, int npz, double dt, double ptk, cons
   for (k = 1; k <= npz; k++) {
     int i, j;
     double *wk = dalloc(nA);
-    for (j = js; j <= je + 1; j++)
-      for (i = is; i <= ie + 1; i++) wk[IA(i, j)] = pk[A3(i, j, k + 1)] - pk[A3(i, j, k)];
+    if (delp) {   /* :1996-1997: a2b_ord4(delp(k), wk) -- the layer's delp is left as it is */
+      double *dcopy = dalloc(nA);
+      memcpy(dcopy, delp + nA * (k - 1), nA * sizeof(double));
+      fvo_a2b_ord4(g, dcopy, wk, 0);
+      free(dcopy);
+    } else {
+      for (j = js; j <= je + 1; j++)
+        for (i = is; i <= ie + 1; i++) wk[IA(i, j)] = pk[A3(i, j, k + 1)] - pk[A3(i, j, k)];
+    }
     for (j = js; j <= je + 1; j++)
       for (i = is; i <= ie; i++) {
         const double wk2 = divg2[IA(i, j)] - divg2[IA(i + 1, j)];

@@ -356,9 +356,13 @@ def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
                 ds["q_con"] = x["q_con"]
             if fl.inline_q and "q" in x:                                     # sw_core.F90:1020-1043
                 ds["inline_q"] = x["q"]
+            delp_old = x["delp"].copy(order="F") if fl.beta < -0.1 else None
             O.d_sw_3d(gs[t], npz, par, lev, ds)
             if fl.d_con > 1.0e-5:
                 x["heat_source"][ng:ng + nx, ng:ng + ny, :] += x["heat_s"]
+            if fl.beta < -0.1:                                               # dyn_core.F90:745-747, :791-848 (zeros when d_ext = 0)
+                x.setdefault("divg2", bd.zeros("A"))
+                O.divg2_ext(gs[t], npz, fl.d_ext, delp_old, x["vt"], x["divg2"])
         exchange(cs, f, ("delp", "pt"), "A")
         if fl.use_cond:
             exchange(cs, f, ("q_con",), "A")                       # dyn_core.F90:825 / :852
@@ -367,7 +371,7 @@ def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
             O.update_dz_d(gs[t], npz, ndif.copy(), damp.copy(), fl.hord_tm, dp_ref, x["zs"], x["zh"], x["crx"], x["cry"], x["xfx"],
                           x["yfx"], x["ws"], rdt)
             O.riem_solver3(gs[t], npz, dt, cn, x["zs"], x["w"], x["delz"], x["pt"], x["delp"], x["zh"], x["pe"], x["pkc"], x["pk3"],
-                           x["pk"], x["peln"], x["ws"], fl.use_logp, remap_step, False, qc(x), cap(x))
+                           x["pk"], x["peln"], x["ws"], fl.use_logp, remap_step, fl.beta < -0.1, qc(x), cap(x))   # fp_out: dyn_core.F90:939
         exchange(cs, f, ("zh", "pkc"), "A")
         for t in range(6):
             x = f[t]
@@ -381,6 +385,8 @@ def oracle_substeps_nh(cs, gs, fl, dp_ref, st, bdt, npz):
                     x.setdefault(n, bd.zeros(kind, npz))
                 O.split_p_grad(gs[t], npz, x["u"], x["v"], x["pkc"], x["gz"], x["delp"], x["pk3"], 0.0 if it == 1 else fl.beta, dt,
                                peln1 if fl.use_logp else ptk, x["du"], x["dv"])
+            elif fl.beta < -0.1:                                           # dyn_core.F90:1029-1030
+                O.one_grad_p_nh(gs[t], npz, dt, fl.ptop, x["divg2"], x["u"], x["v"], x["pkc"], x["gz"], x["delp"])
             else:
                 O.nh_p_grad(gs[t], npz, x["u"], x["v"], x["pkc"], x["gz"], x["delp"], x["pk3"], dt, peln1 if fl.use_logp else ptk)
         if it != n_split:

@@ -92,11 +92,14 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
         if heating:                                                        # dyn_core.F90:798-803
             i0, j0 = bd.ng, bd.ng
             f["heat_source"][i0:i0 + nx, j0:j0 + ny, :] += f["heat_s"]
+        if fl.beta < -0.1:                                                 # dyn_core.F90:745-747, :791-848 (zeros when d_ext = 0)
+            f.setdefault("divg2", bd.zeros("A"))
+            O.divg2_ext(g, npz, fl.d_ext, delp_start, f["vt"], f["divg2"])
         _fill(bd, f["delp"], "A"); _fill(bd, f["pt"], "A")
         O.update_dz_d(g, npz, ndif.copy(), damp.copy(), fl.hord_tm, dp_ref, zs, f["zh"], f["crx"], f["cry"], f["xfx"],
                       f["yfx"], f["ws"], rdt)
         O.riem_solver3(g, npz, dt, cn, zs, f["w"], f["delz"], f["pt"], f["delp"], f["zh"], f["pe"], f["pkc"], f["pk3"],
-                       f["pk"], f["peln"], f["ws"], fl.use_logp, remap_step, False, qc(), cap())
+                       f["pk"], f["peln"], f["ws"], fl.use_logp, remap_step, fl.beta < -0.1, qc(), cap())   # fp_out: dyn_core.F90:939
         _fill(bd, f["zh"], "A"); _fill(bd, f["pkc"], "A")
         if remap_step:
             O.pe_halo(g, npz, fl.ptop, f["pe"], f["delp"])
@@ -108,6 +111,8 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
                 f.setdefault(n, bd.zeros(kind, npz))
             O.split_p_grad(g, npz, f["u"], f["v"], f["pkc"], f["gz"], f["delp"], f["pk3"], 0.0 if it == 1 else fl.beta, dt,
                            peln1 if fl.use_logp else ptk, f["du"], f["dv"])
+        elif fl.beta < -0.1:                                               # dyn_core.F90:1029-1030
+            O.one_grad_p_nh(g, npz, dt, fl.ptop, f["divg2"], f["u"], f["v"], f["pkc"], f["gz"], f["delp"])
         else:
             O.nh_p_grad(g, npz, f["u"], f["v"], f["pkc"], f["gz"], f["delp"], f["pk3"], dt, peln1 if fl.use_logp else ptk)
         if it != n_split:

@@ -262,6 +262,11 @@ def one_grad_p_hydro(g, npz, dt, ptk, divg2, u, v, pk, gz):
     assert lib().fvo_one_grad_p_hydro(C.byref(gs), C.c_int(npz), _d(dt), _d(ptk), p(divg2), p(u), p(v), p(pk), p(gz)) == 0
 
 
+def one_grad_p_nh(g, npz, dt, ptop, divg2, u, v, pk, gz, delp):
+    gs = make_grid(g)
+    assert lib().fvo_one_grad_p_nh(C.byref(gs), C.c_int(npz), _d(dt), _d(ptop), p(divg2), p(u), p(v), p(pk), p(gz), p(delp)) == 0
+
+
 def split_p_grad(g, npz, u, v, pp, gz, delp, pk, beta, dt, top_value, du, dv):
     gs = make_grid(g)
     assert lib().fvo_split_p_grad(C.byref(gs), C.c_int(npz), p(u), p(v), p(pp), p(gz), p(delp), p(pk), _d(beta), _d(dt),

@@ -299,6 +299,35 @@ def check_grad1_p_update(lib, nx=40, ny=19, km=5, beta=0.4, d_ext=0.02, grid=Non
         ctx.close()
 
 
+def check_one_grad_p_nh(lib, nx=40, ny=19, km=5, d_ext=0.02, grid=None):
+    """one_grad_p with hydrostatic = .false. (dyn_core.F90:1909-2030, the beta < -0.1 call of the nonhydrostatic loop): pk = a full
+    pressure, the layer weights a2b_ord4 of delp, gz = zh * grav formed inside"""
+    bd = grid.bd if grid is not None else Bounds(1, nx, 1, ny)
+    g = grid if grid is not None else P.make_grid(bd, True)
+    s = nh_state(bd, km)
+    rng = np.random.default_rng(31)
+    u = np.asfortranarray(rng.uniform(-1e4, 1e4, bd.shape("U", km)))
+    v = np.asfortranarray(rng.uniform(-1e4, 1e4, bd.shape("V", km)))
+    vt = np.asfortranarray(rng.uniform(-1e-5, 1e-5, bd.shape("A", km)))
+    divg2 = bd.zeros("A")
+    O.divg2_ext(g, km, d_ext, s["delp"], vt, divg2)
+    pe, pk, pp, gz = _pressure_fields(bd, km, s, rng)
+    full = np.asfortranarray(pe + pp)                  # what Riem_Solver3 leaves in pkc with fp_out
+    zh = np.asfortranarray(s["zh"])
+    gzs = np.asfortranarray(zh * GRAV)
+    o = dict(u=u.copy(order="F"), v=v.copy(order="F"))
+    O.one_grad_p_nh(g, km, 6.0, PTOP, divg2, o["u"], o["v"], full.copy(order="F"), gzs.copy(order="F"), s["delp"])
+    ctx = Context(g, km, lib=lib)
+    try:
+        d_u, d_v = ctx.from_host(u), ctx.from_host(v)
+        ctx.one_grad_p_nh(d_u, d_v, ctx.from_host(full), ctx.from_host(zh), ctx.from_host(divg2) if d_ext > 0 else None,
+                          ctx.from_host(s["delp"]), 6.0, PTOP, gz_scale=GRAV)
+        for n, kind, da, r in (("u", "U", d_u, (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", d_v, (bd.is_, bd.ie + 1, bd.js, bd.je))):
+            P.assert_close(f"one_grad_p_nh {n}", bd.view(da.download(), kind, *r), bd.view(o[n], kind, *r), _tol(lib))
+    finally:
+        ctx.close()
+
+
 def check_halos_and_geopk(lib, nx=24, ny=13, km=6):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)

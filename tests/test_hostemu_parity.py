@@ -120,6 +120,23 @@ def test_nh_p_grad(emu):
     N.check_nh_p_grad(emu, nx=33, ny=9, km=3)
 
 
+def test_one_grad_p_in_the_nonhydrostatic_loop(emu, tmp_path):
+    """beta < -0.1 (dyn_core.F90:939, :1029-1030, :1909-2030 with hydrostatic = .false.): Riem_Solver3 leaves the full pressure, one_grad_p
+    with a2b_ord4 of delp as the layer weights takes the place of nh_p_grad -- the kernel, then the substep loops, doubly periodic
+    (with and without the external-mode damping) and on the sphere"""
+    N.check_one_grad_p_nh(emu)
+    N.check_one_grad_p_nh(emu, nx=33, ny=9, km=3, d_ext=0.0)
+    D.check_substeps(emu, n_split=3, flags=dict(beta=-1.0))
+    D.check_substeps(emu, n_split=2, flags=dict(beta=-1.0, d_ext=0.0, a_imp=0.75))
+    cs, gs = PC.CC.sphere(13)
+    for t in (1, 5):
+        N.check_one_grad_p_nh(emu, km=4, grid=gs[t], d_ext=0.0)
+    assert max(PC.check_substeps_nh(emu, npx=13, npz=5, n_split=3, flags=dict(beta=-1.0)).values()) <= 1e-13
+    # ... and through the Fortran host (fv3_host_mod's loop), bit-identical to the Python host
+    import fortran_host as F
+    assert "fv3_solo: done" in F.check_fortran_host(emu, tmp_path, nx=24, ny=16, npz=8, nq=1, beta=-1.0)
+
+
 def test_split_p_grad_and_grad1_p_update(emu):
     """beta > 0 (dyn_core.F90:1795-1900, :2033-2116): kernels over three calls, then both substep loops, doubly periodic and sphere"""
     N.check_split_p_grad(emu)
