@@ -353,6 +353,9 @@ def cubed_sphere_leg(a, torch, stream):
     out["pair_one_face"] = {"ms": ms, "cell_updates_per_s": cells / (ms * 1e-3), "alg_bytes_per_cell": PAIR_ALG_BYTES,
                             "frac_wall": cells * PAIR_ALG_BYTES / (ms * 1e-3) / HBM_PEAK,
                             "marching_kernels_ms": march, "pass_kernels_ms": sum(v[1] for v in rep.values()) - march,
+                            "streams": ("ms: wall time with the frame / sponge-level passes on the side stream beside the marching kernels (two lanes, "
+                                        "DESIGN 3f; FV3_MI355X_SIDE_STREAM=0: one lane); launches: the profiled pair, which runs one lane "
+                                        "(per-launch events), so their sum exceeds ms"),
                             "launches": {k: [v[0], round(v[1], 4)] for k, v in rep.items()}}
     ctx.close()
     del d

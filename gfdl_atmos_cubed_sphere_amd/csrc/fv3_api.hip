@@ -3793,7 +3793,7 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   // the column in LDS (remap_fast.h): the spline in the reference's order by hand-over rounds, the rest the slab kernels' code per
   // (column, level); the same bits as the slab kernels below, which keep what it is not built for
   const bool ix32 = (size_t)c->g.nB() * (size_t)(km + 1) < ((size_t)1 << 29);   // 32-bit field indices of the LDS kernels (nh_fast.h ix_t)
-  bool fast = c->remap_lds && ix32 && !moist && !c->remap_te_on && !p->fill && p->kord_tm < 0 && km <= 127 && km >= 5 && kord_fast(-p->kord_tm) &&
+  bool fast = c->remap_lds && ix32 && !c->remap_te_on && p->kord_tm < 0 && km <= 127 && km >= 5 && kord_fast(-p->kord_tm) &&
               kord_fast(p->kord_mt) && (p->hydrostatic || kord_fast(p->kord_wz));
   for (int n = 0; n < p->nq && fast; n++) fast = kord_fast(kord_tr[n]);
   if (fast) {
@@ -3801,6 +3801,8 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
       const Dim3 gr{(unsigned)((g.nx + kFC - 1) / kFC), (unsigned)g.ny, 1};
       if (p->hydrostatic)
         RT((remap_two_waves() ? launch_p2<RemapFastScalars<true>> : launch_p<RemapFastScalars<true>>)(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<true>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
+      else if (moist)   // use_cond / moist_kappa (fv3_set_moist): cappa from moist_cv in the temperature transform and in pkz
+        RT((launch_p2<RemapFastScalars<false, true>>)(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<false, true>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
       else
         RT((remap_two_waves() ? launch_p2<RemapFastScalars<false>> : launch_p<RemapFastScalars<false>>)(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<false>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
     }

@@ -15,8 +15,8 @@
 //     :793-841), so the remap of a column is one kernel; the D-grid winds are a second one (their own coordinates, :530-573).
 // BIT-IDENTICAL to the parity kernels (round 4): the elimination runs in the reference's own order -- a lane runs its 8 rows from the
 // value its neighbour hands it, round after round, until no hand-over changes any more (spline(): the recurrences forget, 3-6 rounds).
-// Built for: dry thermodynamics (no moist_kappa / use_cond), kord_tm < 0, every kord in 8..10 or 13..15, fill and remap_te off,
-// km <= 127.  Anything else takes the parity kernels.
+// Built for: kord_tm < 0, every kord in 8..10 or 13..15, remap_te off, km <= 127; dry and (nonhydrostatic) moist_kappa / use_cond
+// thermodynamics, flagstruct%fill (fillz on the remapped tracers).  Anything else takes the slab kernels.
 #pragma once
 
 #include "nh_fast.h"
@@ -433,8 +433,12 @@ struct RemapFastCore {
 // kernel reads after writing it is read by the thread that wrote it), so stores drain behind the next phase, and (b) the inputs of the
 // NEXT field are loaded into registers just before the mapping loop of the current one (`pre` of remap_field: 8 or 16 doubles per
 // thread, not live during the spline, which is where the register budget is tight) and go to LDS when that loop is done.
-template <bool HYDRO>   // the hydrostatic flag at compile time: the other branch's loads and registers are not carried
+// MOIST: thermostruct%moist_kappa / use_cond (nonhydrostatic; fv3_set_moist): the temperature transform with cappa from moist_cv of
+// the un-remapped tracers (:212-219), pkz with cappa from the remapped ones (:463-478), q_con / cappa written on the way, and the
+// conversion of the last step with the condensates (:806-811) -- the slab kernels' expressions (remap_kernels.h) per (column, level)
+template <bool HYDRO, bool MOIST = false>   // the flags at compile time: the other branches' loads and registers are not carried
 struct RemapFastScalars {
+  static_assert(!(HYDRO && MOIST), "moist_kappa / use_cond are nonhydrostatic branches");
   Grid g;
   int km;
   RemapPar p;
@@ -487,6 +491,24 @@ struct RemapFastScalars {
     };
     // ---- log-pressure coordinates of T_v (:340-345, :363-368): C1 = peln, C2 = pn2; the layer means: the temperature transform
     //      (:200-229) level by level ----
+    double v_cap[MOIST ? kIt : 1];   // MOIST: cap / (1 - cap) of the thread's cells for the temperature transform
+    if constexpr (MOIST) {
+      for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
+        const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
+        const ix_t o3 = (ix_t)(k0 < km ? k0 : km - 1) * nA + o0 + cc;
+        v_cap[it] = 0.;
+        if (p.moist_kappa) {   // :212-219, from the tracers as they are before the remap
+          double qc;
+          const double cvm = moist_cv(p, q + o3, (size_t)nA * km, qc);
+          const double cap = p.rdgas / (p.rdgas + cvm / (1. + p.r_vir * q[(size_t)(p.sphum - 1) * nA * km + o3]));
+          if (k0 < km && col < ncol) {
+            p.q_con[o3] = qc;
+            p.cappa[o3] = cap;
+          }
+          v_cap[it] = cap / (1. - cap);
+        }
+      }
+    }
     {
       double v_pl[kIt], v_t[kIt], v_a[kIt], v_b[kIt], v_c[HYDRO ? kIt : 1];
 #ifndef FV3_HOST_EMU
@@ -532,6 +554,8 @@ struct RemapFastScalars {
           double t = v_t[it];
           if (HYDRO)
             t = t * (v_a[it] - v_b[it]) / (akap * (v_c[HYDRO ? it : 0] - v_pl[it]));
+          else if (MOIST && p.moist_kappa)
+            t = t * dexp(v_cap[MOIST ? it : 0] * dlog(rrg * v_a[it] / v_b[it] * t));
           else
             t = t * dexp(k1k * dlog(rrg * v_a[it] / v_b[it] * t));
           RemapFastCore::at(A1, col, k0) = t;
@@ -642,6 +666,18 @@ struct RemapFastScalars {
       const bool more = iq + 1 < p.nq;
       FV3_SYNC_LDS();
       core.remap_field(C1, C2, A1, Q, nullptr, true, 0, iq < kRKordMax ? KT[iq] : kord_tr[iq], 0., p.nq > 5, tid, [&]() __attribute__((always_inline)) { load_tracer(iq + 1); });
+      if (p.fill) {   // flagstruct%fill: fillz (fv_fill.F90:34-137) on the remapped column, sequential in k as in the reference -- one
+                      // thread per column, and only for a column that holds a negative value at all (dp2(k) = pe2(k+1) - pe2(k) from C2)
+        static_assert(!FV3_REMAP_CHUNKED, "fillz_col walks a column with unit stride");
+        for (int col = tid; col < kFC; col += kNT) {
+          double *qc = Q + col * kRP + rix(0);
+          const double *e2 = C2 + col * kRP + rix(0);
+          bool neg = false;
+          for (int k = 0; k < km; k++) neg = neg || qc[k] < 0.;
+          if (neg) fillz_col(km, qc, 1, [&](int k) { return e2[k] - e2[k - 1]; });
+        }
+        FV3_SYNC_LDS();
+      }
       for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
         const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 < km) {
@@ -696,15 +732,29 @@ struct RemapFastScalars {
         delp[o3] = dp2;
         const double tv = v_t[it];
         double pkzv;
-        if (HYDRO)
+        if (HYDRO) {
           pkzv = (pk2[k0 + 2] - pk2[k0 + 1]) / (akap * (pn[k0 + 2] - pn[k0 + 1]));
-        else
+        } else if (MOIST && p.moist_kappa) {   // :463-478: cappa from the REMAPPED tracers (this thread stored them)
+          double qc;
+          const double cvm = moist_cv(p, q + o3, (size_t)nA * km, qc);
+          const double cap = p.rdgas / (p.rdgas + cvm / (1. + p.r_vir * q[(size_t)(p.sphum - 1) * nA * km + o3]));
+          p.q_con[o3] = qc;
+          p.cappa[o3] = cap;
+          pkzv = dexp(cap * dlog(rrg * dp2 / v_dz[it] * tv));
+        } else {
           pkzv = dexp(akap * dlog(rrg * dp2 / v_dz[it] * tv));
+        }
         pkz[c3] = pkzv;
         double tn = tv;
         if (p.last_step == 2) {              // the energy fixer follows: T_v stays, fv3_remap_finish converts (:793-821)
         } else if (p.last_step) {            // :793-821 (dtmp = 0)
-          if (!p.adiabatic) tn = (tn + 0. / (HYDRO ? p.cp : p.cv_air) * pkzv) / (1. + p.r_vir * (need_qv ? v_q[it] : 0.));
+          if (MOIST && p.use_cond) {         // :806-811
+            double qc;
+            const double cvm = moist_cv(p, q + o3, (size_t)nA * km, qc);
+            tn = (tn + 0. / cvm * pkzv) / ((1. + p.r_vir * q[(size_t)(p.sphum - 1) * nA * km + o3]) * (1. - qc));
+          } else if (!p.adiabatic) {
+            tn = (tn + 0. / (HYDRO ? p.cp : p.cv_air) * pkzv) / (1. + p.r_vir * (need_qv ? v_q[it] : 0.));
+          }
         } else {
           tn = tn / pkzv;                    // :833-841
         }

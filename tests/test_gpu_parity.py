@@ -256,15 +256,25 @@ def test_remap_in_lds_and_in_slabs(prod):
     """Lagrangian_to_Eulerian with the column in LDS (csrc/remap_fast.h: levels across the lanes, the spline's elimination in the
     reference's order by hand-over rounds, the limiters' curvature re-formed from a one-byte code) -- the default where it is built, and
     BIT-IDENTICAL to the oracle like the slab kernels (csrc/remap_kernels.h), which the same cases run through with
-    FV3_MI355X_REMAP_LDS=0 and which keep what the LDS kernels are not built for (fill, kord_tm > 0, the moist branches, remap_te)"""
+    FV3_MI355X_REMAP_LDS=0 and which keep what the LDS kernels are not built for (kord_tm > 0, remap_te)"""
     for kw in (dict(), dict(km=20, nx=33, ny=9), dict(hydrostatic=True), dict(last_step=True, adiabatic=False),
                dict(hydrostatic=True, last_step=True, adiabatic=False, kord_tm=-10, kord=10), dict(kord=9, kord_tm=-9, nq=7),
                dict(km=127, nx=17, ny=3, nq=1), dict(km=79, nq=4, kord=13, kord_tm=-14), dict(kord=15, kord_tm=-15, km=8)):
         assert R.check_remap(prod, **kw) <= 1e-14
         assert R.check_remap(prod, lds=False, **kw) <= 1e-14
-    assert R.check_remap(prod, fill=True) <= 1e-14
+    # round 4, second half: use_cond / moist_kappa in the LDS kernels too (RemapFastScalars<false, true>: cappa from moist_cv of the
+    # un-remapped tracers in the temperature transform, of the remapped ones in pkz, the last step's conversion with the condensates)
+    for kw in (dict(moist_kappa=True), dict(moist_kappa=True, use_cond=True, last_step=True, kord_tm=-8, nwat=6, adiabatic=False),
+               dict(moist_kappa=False, use_cond=True, last_step=True, kord_tm=-8, nwat=6, adiabatic=False),
+               dict(moist_kappa=True, use_cond=True, kord_tm=-9, nwat=3, km=79, nx=17, ny=3)):
+        assert R.check_remap(prod, **kw) == 0.0
+        assert R.check_remap(prod, lds=False, **kw) == 0.0
+    # ... and flagstruct%fill: fillz on the column in LDS, one thread per column that holds a negative value
+    for kw in (dict(fill=True), dict(fill=True, nq=7, kord=9, kord_tm=-9), dict(fill=True, km=79, nx=17, ny=3, nq=3),
+               dict(fill=True, moist_kappa=True, use_cond=True, nwat=6)):
+        assert R.check_remap(prod, **kw) == 0.0
+        assert R.check_remap(prod, lds=False, **kw) == 0.0
     assert R.check_remap(prod, kord_tm=9) <= 1e-14
-    assert R.check_remap(prod, moist_kappa=True) <= 1e-14
 
 
 def test_remap_te(prod):
