@@ -228,7 +228,9 @@ contains
           end if
           if (heating) call fv3_check(fv3_heat_source_accum(at%ctx, at%heat_source, at%heat_s), 'heat_source_accum')   ! :798-803
           call inline_q_end(at)
-          if (hyd) call fv3_check(fv3_divg2_ext(at%ctx, fl%d_ext, at%delp, at%vt, at%divg2), 'divg2_ext')          ! :745-747, :791-848
+          ! (the nonhydrostatic loop too when one_grad_p follows: beta < -0.1, :1029-1030)
+          if (hyd .or. (fl%beta < -0.1d0 .and. fl%d_ext > 0.d0)) &
+            call fv3_check(fv3_divg2_ext(at%ctx, fl%d_ext, at%delp, at%vt, at%divg2), 'divg2_ext')                  ! :745-747, :791-848
           call swap(at%delp, at%delp_n); call swap(at%pt, at%pt_n)
           call swap(at%u, at%u_n); call swap(at%v, at%v_n)
           if (.not. hyd) call swap(at%w, at%w_n)
@@ -258,7 +260,8 @@ contains
                                            at%yfx, at%ws, rdt), 'update_dz_d')              ! :911
             call swap(at%zh, at%zh_n)
             call fv3_check(fv3_riem_solver3(at%ctx, dt, at%cn, at%zs, at%w, at%delz, at%pt, at%delp, at%zh, at%pe, at%pkc, &
-                                            at%pk3, at%pk, at%peln, at%ws, use_logp, last_call, 0_c_int), 'riem_solver3')  ! :932
+                                            at%pk3, at%pk, at%peln, at%ws, use_logp, last_call, &
+                                            merge(1_c_int, 0_c_int, fl%beta < -0.1d0)), 'riem_solver3')  ! :932, fp_out :939
           end associate
         end do
         call exchange(sp, 2, [A, A], [6, 10], [0, 0], [npz + 1, npz + 1])                 ! zh, pkc: :944-950 (packs 4, 5)
@@ -269,6 +272,10 @@ contains
             if (fl%beta > 0.d0) then                                                         ! :1027-1028
               call fv3_check(fv3_split_p_grad(at%ctx, at%u, at%v, at%pkc, at%zh, fl%grav, at%delp, at%pk3, &
                                               merge(0.d0, fl%beta, it == 1), dt, top, at%du, at%dv), 'split_p_grad')
+            else if (fl%beta < -0.1d0) then   ! :1029-1030: pkc is the full pressure, the layer weights a2b_ord4 of delp
+              dv2 = c_null_ptr
+              if (fl%d_ext > 0.d0) dv2 = at%divg2
+              call fv3_check(fv3_one_grad_p_nh(at%ctx, at%u, at%v, at%pkc, at%zh, dv2, at%delp, dt, fl%ptop, fl%grav), 'one_grad_p (nh)')
             else
               call fv3_check(fv3_nh_p_grad(at%ctx, at%u, at%v, at%pkc, at%zh, fl%grav, at%delp, at%pk3, dt, top), 'nh_p_grad')  ! :1032
             end if

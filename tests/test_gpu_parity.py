@@ -157,6 +157,7 @@ def test_one_grad_p_in_the_nonhydrostatic_loop(prod, tmp_path):
     # ... and through the Fortran host (fv3_host_mod's loop), bit-identical to the Python host
     import fortran_host as F
     assert "fv3_solo: done" in F.check_fortran_host(prod, tmp_path, nx=24, ny=16, npz=8, nq=1, beta=-1.0)
+    assert "fv3_solo_sphere: done" in F.check_fortran_sphere(prod, tmp_path, npx=13, npz=8, nq=1, n_split=2, k_split=1, beta=-1.0)
 
 
 def test_split_p_grad_and_grad1_p_update(prod):

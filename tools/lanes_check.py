@@ -68,6 +68,10 @@ def main():
     npx, npz = int(os.environ.get("NPX", 97)), int(os.environ.get("NPZ", 32))
     nh, prod, reps = os.environ.get("NH", "1") == "1", os.environ.get("PROD", "0") == "1", int(os.environ.get("REPS", 6))
     bad = 0
+    if os.environ.get("FV3_LANES_ONLY_TWO") == "1":   # (tools/lanes_timeline.sh: only the two-lane run, for a kernel trace)
+        _, ms_b = run(True, npx, npz, nh, prod, reps, 0)
+        print(f"two lanes {ms_b:.3f} ms per pair")
+        return
     for tile in (0, 3):
         a, ms_a = run(False, npx, npz, nh, prod, reps, tile)
         b, ms_b = run(True, npx, npz, nh, prod, reps, tile)
