@@ -564,7 +564,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_REMAP_SCR");
     c->remap_blocked = e ? (std::atoi(e) != 0) : 1;
     e = std::getenv("FV3_MI355X_REMAP_LDS");
-    c->remap_lds = e ? (std::atoi(e) != 0) : 1;
+    c->remap_lds = e ? std::atoi(e) : 1;   // 0: slab kernels, 1: the LDS kernels where they pay (fv3_lagrangian_to_eulerian), 2: wherever built
     // the levels-across-the-lanes kernels index the fields with 32 bits (nh_fast.h ix_t): a tile whose fields reach 2^32 bytes takes the
     // slab kernels (1030 x 1030 x 128 is 1.1e9 bytes)
     if ((size_t)g.nB() * (size_t)(g.npz + 2) >= ((size_t)1 << 29)) {
@@ -3796,6 +3796,12 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   bool fast = c->remap_lds && ix32 && !c->remap_te_on && p->kord_tm < 0 && km <= 127 && km >= 5 && kord_fast(-p->kord_tm) &&
               kord_fast(p->kord_mt) && (p->hydrostatic || kord_fast(p->kord_wz));
   for (int n = 0; n < p->nq && fast; n++) fast = kord_fast(kord_tr[n]);
+  // Where they pay: a column of the LDS kernels costs 16 lanes x 8 rows whatever km is (3290 / km ps per cell and field on the C384 /
+  // C768 tiles of tools/bench_config5.py), the slab kernels remap the tracers three at a time with one elimination and one search
+  // (33 - 36 ps per cell and field when the tracers dominate).  Measured, both ways on one box (config 5's block, 768^2 x 79 with 33
+  // tracers): 133 against 101 ms per dt_atmos for the remap, 270 against 233 ms for the step; 384^2 x 127 with 12 tracers: 14.5 against
+  // 19.0 ms.  The lines cross at km ~ 97.  FV3_MI355X_REMAP_LDS=2: the LDS kernels wherever they are built.
+  if (fast && c->remap_lds == 1 && km <= 96 && p->nq >= 8) fast = false;
   if (fast) {
     {
       const Dim3 gr{(unsigned)((g.nx + kFC - 1) / kFC), (unsigned)g.ny, 1};

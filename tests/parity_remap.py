@@ -91,8 +91,7 @@ def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=Fal
         assert P.rel_rms(dry[n_chk], ref[n_chk]) > 1e-6
     import os
     saved = os.environ.pop("FV3_MI355X_REMAP_LDS", None)
-    if not lds:
-        os.environ["FV3_MI355X_REMAP_LDS"] = "0"      # read when the context is created
+    os.environ["FV3_MI355X_REMAP_LDS"] = "2" if lds else "0"      # read when the context is created; 2: the LDS kernels wherever they are built
     try:
         ctx = Context(g, km, lib=lib)
     finally:
@@ -101,7 +100,7 @@ def check_remap(lib, nx=20, ny=11, km=12, nq=2, hydrostatic=False, last_step=Fal
             os.environ["FV3_MI355X_REMAP_LDS"] = saved
     try:
         ctx.set_ak_bk(ak, bk)
-        # lds: the remap with the column in LDS (csrc/remap_fast.h, the default where it is built; bit-identical to the slab kernels);
+        # lds: the remap with the column in LDS (csrc/remap_fast.h, the default where it is built and pays; bit-identical to the slab kernels);
         # False: FV3_MI355X_REMAP_LDS=0, the slab kernels (csrc/remap_kernels.h) for every configuration
         d = {k: ctx.from_host(v) for k, v in f.items()}
         if moist:

@@ -24,7 +24,7 @@ def main():
     par = dict(last_step=0, hydrostatic=0, adiabatic=1, nq=nq, kord_mt=8, kord_wz=8, kord_tm=-8, sphum=1 if nq else 0, akap=KAPPA, ptop=N.PTOP,
                rdgas=RDGAS, grav=GRAV, cv_air=CP_AIR - RDGAS, r_vir=0.6077, cp=CP_AIR, t_min=184.0, kord_tr=[8] * nq)
     for lds in (False, True):
-        os.environ["FV3_MI355X_REMAP_LDS"] = "1" if lds else "0"
+        os.environ["FV3_MI355X_REMAP_LDS"] = "2" if lds else "0"
         ctx = L.Context(g, km)
         ctx.set_ak_bk(ak, bk)
         d = {k: ctx.from_host(v) for k, v in f.items()}
