@@ -3801,25 +3801,38 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   // (33 - 36 ps per cell and field when the tracers dominate).  Measured, both ways on one box (config 5's block, 768^2 x 79 with 33
   // tracers): 133 against 101 ms per dt_atmos for the remap, 270 against 233 ms for the step; 384^2 x 127 with 12 tracers: 14.5 against
   // 19.0 ms.  The lines cross at km ~ 97.  FV3_MI355X_REMAP_LDS=2: the LDS kernels wherever they are built.
-  if (fast && c->remap_lds == 1 && km <= 96 && p->nq >= 8) fast = false;
+  // With 5 levels per lane (km <= 79: RemapFast...<..., 5>) no row is idle at L79 and the LDS kernels win there too; the rule is left for
+  // 80 <= km <= 96.
+  if (fast && c->remap_lds == 1 && km >= 80 && km <= 96 && p->nq >= 8) fast = false;
   if (fast) {
-    {
-      const Dim3 gr{(unsigned)((g.nx + kFC - 1) / kFC), (unsigned)g.ny, 1};
-      if (p->hydrostatic)
-        RT((remap_two_waves() ? launch_p2<RemapFastScalars<true>> : launch_p<RemapFastScalars<true>>)(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<true>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
-      else if (moist)   // use_cond / moist_kappa (fv3_set_moist): cappa from moist_cv in the temperature transform and in pkz
-        RT((launch_p2<RemapFastScalars<false, true>>)(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<false, true>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
-      else
-        RT((remap_two_waves() ? launch_p2<RemapFastScalars<false>> : launch_p<RemapFastScalars<false>>)(c, "remap_lds_scalars", gr, kRLds, RemapFastScalars<false>{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
-    }
-    {
-      RemapFastWind<0> kf{g, km, p->kord_mt, ak, bk, pe, u};
-      RT(launch_p2(c, "remap_lds_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kRLds, kf));
-    }
-    {
-      RemapFastWind<1> kf{g, km, p->kord_mt, ak, bk, pe, v};
-      RT(launch_p2(c, "remap_lds_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kRLds, kf));
-    }
+    // levels per lane: 8 (km <= 127) or 5 (km <= 79: 80 rows, no idle lane at L79)
+    auto run = [&](auto LV) -> int {
+      constexpr int L = decltype(LV)::value;
+      {
+        const Dim3 gr{(unsigned)((g.nx + kFC - 1) / kFC), (unsigned)g.ny, 1};
+        if (p->hydrostatic) {
+          using K = RemapFastScalars<true, false, L>;
+          RT((remap_two_waves() ? launch_p2<K> : launch_p<K>)(c, "remap_lds_scalars", gr, kRLds, K{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
+        } else if (moist) {   // use_cond / moist_kappa (fv3_set_moist): cappa from moist_cv in the temperature transform and in pkz
+          using K = RemapFastScalars<false, true, L>;
+          RT((launch_p2<K>)(c, "remap_lds_scalars", gr, kRLds, K{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
+        } else {
+          using K = RemapFastScalars<false, false, L>;
+          RT((remap_two_waves() ? launch_p2<K> : launch_p<K>)(c, "remap_lds_scalars", gr, kRLds, K{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
+        }
+      }
+      {
+        RemapFastWind<0, L> kf{g, km, p->kord_mt, ak, bk, pe, u};
+        RT(launch_p2(c, "remap_lds_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kRLds, kf));
+      }
+      {
+        RemapFastWind<1, L> kf{g, km, p->kord_mt, ak, bk, pe, v};
+        RT(launch_p2(c, "remap_lds_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kRLds, kf));
+      }
+      return 0;
+    };
+    if (km <= 79) RT(run(std::integral_constant<int, 5>{}));
+    else RT(run(std::integral_constant<int, 8>{}));
     RemapPe kf{g, km, ak, bk, pe};
     RT(launch_c(c, "remap_pe", col_grid(g.nx * g.ny), kf));
     return 0;

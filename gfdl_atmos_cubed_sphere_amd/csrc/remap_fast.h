@@ -108,25 +108,39 @@ constexpr int kRTabAk = kRNBuf * kRBuf, kRTabBk = kRTabAk + 128, kRTabPs = kRTab
 constexpr int kRTabKord = kRTabPs + kFC, kRKordMax = 64;   // kord of the first 64 tracers (ints)
 constexpr int kRLds = kRTabKord + kRKordMax / 2;           // 78 208 B (chunked: 82 304): two workgroups per CU
 
+// L: levels per lane (16 lanes a column).  8 holds km <= 127; 5 (80 rows) holds km <= 79 -- C96 / C768 L79 columns then leave no lane
+// idle, where 8 left 38 % of the rows empty (the remap of BASELINE config 5's block: 133 -> 85 ms)
 #ifdef FV3_HOST_EMU
-inline vd vlin_ld(const double *buf, int col0, int q) {      // row (lane & 15) * 8 + q of the lane's column; any q with row >= -2
+template <int L>
+inline vd vlin_ld(const double *buf, int col0, int q) {      // row (lane & 15) * L + q of the lane's column; any q with row >= -2
   vd x;
-  FV3_LANE_LOOP x.v[l] = buf[((l >> 4) + col0) * kRP + rixn((l & 15) * kFL + q)];
+  FV3_LANE_LOOP x.v[l] = buf[((l >> 4) + col0) * kRP + rixn((l & 15) * L + q)];
   return x;
 }
+template <int L>
 inline void vlin_st(double *buf, int col0, int q, const vd &x) {
-  FV3_LANE_LOOP buf[((l >> 4) + col0) * kRP + rixn((l & 15) * kFL + q)] = x.v[l];
+  FV3_LANE_LOOP buf[((l >> 4) + col0) * kRP + rixn((l & 15) * L + q)] = x.v[l];
 }
+template <int L>
+inline vb vrow_lt(int q, int k) { vb r; FV3_LANE_LOOP r.v[l] = (l & 15) * L + q < k; return r; }
+template <int L>
+inline vb vrow_eq(int q, int k) { vb r; FV3_LANE_LOOP r.v[l] = (l & 15) * L + q == k; return r; }
 inline vd vcol_lds(const double *p, int col0) { vd x; FV3_LANE_LOOP x.v[l] = p[((l >> 4) + col0) * kRP]; return x; }
 #else
+template <int L>
 __device__ __forceinline__ vd vlin_ld(const double *buf, int col0, int q) {
   const int l = (int)(threadIdx.x & 63);
-  return buf[((l >> 4) + col0) * kRP + rixn((l & 15) * kFL + q)];
+  return buf[((l >> 4) + col0) * kRP + rixn((l & 15) * L + q)];
 }
+template <int L>
 __device__ __forceinline__ void vlin_st(double *buf, int col0, int q, vd x) {
   const int l = (int)(threadIdx.x & 63);
-  buf[((l >> 4) + col0) * kRP + rixn((l & 15) * kFL + q)] = x;
+  buf[((l >> 4) + col0) * kRP + rixn((l & 15) * L + q)] = x;
 }
+template <int L>
+__device__ __forceinline__ vb vrow_lt(int q, int k) { return (int)(threadIdx.x & 15) * L + q < k; }
+template <int L>
+__device__ __forceinline__ vb vrow_eq(int q, int k) { return (int)(threadIdx.x & 15) * L + q == k; }
 __device__ __forceinline__ vd vcol_lds(const double *p, int col0) { return p[((int)((threadIdx.x & 63) >> 4) + col0) * kRP]; }
 #endif
 
@@ -194,11 +208,13 @@ FV3_HD double map_target(const RColC pe1, const RColC a1, const RColC a2, const 
 }
 
 // the machinery both kernels share: a workgroup's 16 columns in the four LDS arrays
-struct RemapFastCore {
+template <int L>
+struct RemapFastCoreT {
+  static constexpr int RL = 16 * L;   // rows of a column the lanes hold
   int km;
   int probe = 0;   // timing probe (FV3_MI355X_REMAP_PROBE, tools/remap_time.py; WRONG results): 1 no spline, 2 no constraints, 4 no
                    // subgrid limiters, 8 no mapping loop
-  static constexpr int kIt = kFC * 128 / kNT;   // (column, level) pairs per thread
+  static constexpr int kIt = kFC * RL / kNT;   // (column, level) pairs per thread
 
   FV3_D static RCol col(double *buf, int c) { return RCol{buf + c * kRP}; }          // [k], k 1-based
   FV3_D static RColC colc(const double *buf, int c) { return RColC{buf + c * kRP}; }
@@ -209,12 +225,12 @@ struct RemapFastCore {
   FV3_D void pad_coord(double *buf, int c, int nrow) const {
     double *p = buf + c * kRP;
     p[rixn(-1)] = p[rix(0)] - 1.; p[rixn(-2)] = p[rix(0)] - 2.;
-    for (int r = nrow; r < 130; r++) p[rix(r)] = p[rix(nrow - 1)] + (double)(r - nrow + 1);
+    for (int r = nrow; r < RL + 2; r++) p[rix(r)] = p[rix(nrow - 1)] + (double)(r - nrow + 1);
   }
   FV3_D void pad_field(double *buf, int c, int nrow) const {
     double *p = buf + c * kRP;
     p[rixn(-1)] = 0.; p[rixn(-2)] = 0.;
-    for (int r = nrow; r < 130; r++) p[rix(r)] = 0.;
+    for (int r = nrow; r < RL + 2; r++) p[rix(r)] = 0.;
   }
 
   // interface values of the cubic spline: raw q(1 .. km+1) into Q.  iv = -2: scalar_profile / cs_profile with the bottom value qs
@@ -233,36 +249,36 @@ struct RemapFastCore {
   // N / bet^2 ~ 0.07, d q_k / d q_(k-1) = 1 / bet ~ 0.27), so that happens after 3 - 6 rounds.
   FV3_D void spline(const double *C1, const double *A1, double *Q, const double *QS, int iv, int wv) const {
     const int c0 = wv * 4;
-    vd B[kFL], N[kFL], R[kFL], S[kFL], G[kFL], bet[kFL], rb[kFL], x[kFL];
+    vd B[L], N[L], R[L], S[L], G[L], bet[L], rb[L], x[L];
     {
-      vd e[kFL + 1], av[kFL], dpv[kFL];
-      for (int q = 0; q <= kFL; q++) e[q] = vlin_ld(C1, c0, q);
-      const vd em1 = vlin_ld(C1, c0, -1), em2 = vlin_ld(C1, c0, -2);
-      for (int q = 0; q < kFL; q++) {
-        av[q] = vlin_ld(A1, c0, q);
+      vd e[L + 1], av[L], dpv[L];
+      for (int q = 0; q <= L; q++) e[q] = vlin_ld<L>(C1, c0, q);
+      const vd em1 = vlin_ld<L>(C1, c0, -1), em2 = vlin_ld<L>(C1, c0, -2);
+      for (int q = 0; q < L; q++) {
+        av[q] = vlin_ld<L>(A1, c0, q);
         dpv[q] = e[q + 1] - e[q];
       }
-      const vd am1v = vlin_ld(A1, c0, -1), am2v = vlin_ld(A1, c0, -2);
+      const vd am1v = vlin_ld<L>(A1, c0, -1), am2v = vlin_ld<L>(A1, c0, -2);
       const vd dpm1v = e[0] - em1, dpm2v = em1 - em2;
       const vd qs = QS ? vcol_lds(QS, c0) : vd(0.0);            // QS[column * kRP]
-      vd grv[kFL];
-      for (int q = 0; q < kFL; q++) grv[q] = vdivq(q > 0 ? dpv[q - 1] : dpm1v, dpv[q]);      // dp(k-1) / dp(k) of row k = r + 1
-      const vd gr_up = row_shr<1>(grv[kFL - 1], 1.0);                                       // ... of the row above the lane's first
+      vd grv[L];
+      for (int q = 0; q < L; q++) grv[q] = vdivq(q > 0 ? dpv[q - 1] : dpm1v, dpv[q]);      // dp(k-1) / dp(k) of row k = r + 1
+      const vd gr_up = row_shr<1>(grv[L - 1], 1.0);                                       // ... of the row above the lane's first
       (void)dpm2v;
-      for (int q = 0; q < kFL; q++) {
+      for (int q = 0; q < L; q++) {
         const vd a_m1 = q > 0 ? av[q - 1] : am1v, a_m2 = q > 1 ? av[q - 2] : (q == 1 ? am1v : am2v);
-        const vb first = vlevel_eq(q, 0), pad = !vlevel_lt(q, km + 1), bot = vlevel_eq(q, km);
+        const vb first = vrow_eq<L>(q, 0), pad = !vrow_lt<L>(q, km + 1), bot = vrow_eq<L>(q, km);
         const vd gr = grv[q];
         const vd bi = 2. + gr + gr;
         if (iv == -2) {
-          const vb lastc = vlevel_eq(q, km - 1);
+          const vb lastc = vrow_eq<L>(q, km - 1);
           const vb given = first || bot || pad;
           const vd rhs = 3. * (a_m1 + av[q]);
           B[q] = vsel(given, vd(1.0), bi);
           S[q] = vsel(given, vd(0.0), vd(1.0));
           N[q] = vsel(first, vd(0.5), vsel(bot || pad || lastc, vd(0.0), gr));
           R[q] = vsel(first, 1.5 * av[q], vsel(bot, qs, vsel(pad, vd(0.0), vsel(lastc, rhs - gr * qs, rhs))));
-          G[q] = vsel(vlevel_lt(q, km - 1), vd(1.0), vd(0.0));      // back substitution on rows k <= km - 1, with gam(k+1) = this row's
+          G[q] = vsel(vrow_lt<L>(q, km - 1), vd(1.0), vd(0.0));      // back substitution on rows k <= km - 1, with gam(k+1) = this row's
         } else {
           // top row: grat = dp(2) / dp(1) (rows 0 and 1 are the lane's own); bottom row: d4 = dp(km-1) / dp(km)
           const vd g1 = vdivq(dpv[1], dpv[0]);
@@ -273,7 +289,7 @@ struct RemapFastCore {
           N[q] = vsel(first, 1. + g1 * (g1 + 1.5), vsel(bot || pad, vd(0.0), gr));
           R[q] = vsel(first, (g1 + g1) * (g1 + 1.) * av[0] + av[1],
                       vsel(bot, 2. * d4b * (d4b + 1.) * a_m1 + a_m2, vsel(pad, vd(0.0), 3. * (a_m1 + gr * av[q]))));
-          G[q] = vsel(vlevel_lt(q, km), vd(1.0), vd(0.0));          // rows k <= km, with gam(k)
+          G[q] = vsel(vrow_lt<L>(q, km), vd(1.0), vd(0.0));          // rows k <= km, with gam(k)
         }
       }
     }
@@ -286,10 +302,10 @@ struct RemapFastCore {
 #endif
     {                                     // bet, 1 / bet, gam: G[q] becomes this row's multiplier of the back substitution
       vd gin(0.27);
-      vd gam[kFL];
+      vd gam[L];
       for (int rnd = 0; rnd < kRounds; rnd++) {
         vd g = gin;
-        for (int q = 0; q < kFL; q++) {
+        for (int q = 0; q < L; q++) {
           bet[q] = B[q] - S[q] * g;
           rb[q] = vrecip(bet[q]);
           g = vdiv_r(N[q], bet[q], rb[q]);
@@ -300,13 +316,13 @@ struct RemapFastCore {
         gin = gnew;
         if (!moved) { FV3_RS(0, rnd); break; }
       }
-      for (int q = 0; q < kFL; q++) G[q] = G[q] * gam[q];
+      for (int q = 0; q < L; q++) G[q] = G[q] * gam[q];
     }
     {                                     // forward substitution
       vd qin(0.0);
       for (int rnd = 0; rnd < kRounds; rnd++) {
         vd y = qin;
-        for (int q = 0; q < kFL; q++) {
+        for (int q = 0; q < L; q++) {
           y = vdiv_r(R[q] - S[q] * y, bet[q], rb[q]);
           x[q] = y;
         }
@@ -318,11 +334,11 @@ struct RemapFastCore {
     }
     {                                     // back substitution
       vd xin(0.0);
-      vd y[kFL];
-      for (int q = 0; q < kFL; q++) y[q] = x[q];
+      vd y[L];
+      for (int q = 0; q < L; q++) y[q] = x[q];
       for (int rnd = 0; rnd < kRounds; rnd++) {
         vd xn = xin;
-        for (int q = kFL - 1; q >= 0; q--) {
+        for (int q = L - 1; q >= 0; q--) {
           xn = y[q] - G[q] * xn;
           x[q] = xn;
         }
@@ -332,16 +348,16 @@ struct RemapFastCore {
         if (!moved) { FV3_RS(2, rnd); break; }
       }
     }
-    for (int q = 0; q < kFL; q++) vlin_st(Q, c0, q, x[q]);
+    for (int q = 0; q < L; q++) vlin_st<L>(Q, c0, q, x[q]);
   }
 
   // large-scale constraints on the interface values (:643-680 / :1037-1073), in place in Q; one thread per (column, interface)
   FV3_D void constrain(const double *A1, double *Q, int iv, int ak, int tid) const {
-    for (int idx = tid; idx < kFC * 128; idx += kNT) {
-      const int col = idx >> 7, k = (idx & 127) + 1;
+    for (int idx = tid; idx < kFC * RL; idx += kNT) {
+      const int col = idx / RL, k = idx % RL + 1;
       if (k < 2 || k > km) continue;
       const RColC a1 = colc(A1, col);   // a1[k], 1-based
-      const RCol q = RemapFastCore::col(Q, col);
+      const RCol q = RemapFastCoreT::col(Q, col);
       const double w_m1 = a1[k - 1], w_0 = a1[k];
       double qc = q[k];
       if (k == 2 || k == km) {
@@ -372,7 +388,7 @@ struct RemapFastCore {
     int form[kIt];
     const ProfCfg pc{km, iv, ak, is_scalar, qmin, true};
     for (int it = 0; it < kIt; it++) {
-      const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
+      const int idx = tid + it * kNT, col = idx / RL, k = idx % RL + 1;
       r2[it] = r3v[it] = pt2[it] = pb2[it] = 0.;
       form[it] = 0;
       if (k > km) continue;
@@ -387,7 +403,7 @@ struct RemapFastCore {
     }
     FV3_SYNC_LDS();
     for (int it = 0; it < kIt; it++) {
-      const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
+      const int idx = tid + it * kNT, col = idx / RL, k = idx % RL + 1;
       if (k > km) continue;
       at(Q, col, k - 1) = r2[it];
       at(C2, col, k - 1) = r3v[it];
@@ -395,13 +411,13 @@ struct RemapFastCore {
     }
     FV3_SYNC_LDS();
     for (int it = 0; it < kIt; it++) {
-      const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
+      const int idx = tid + it * kNT, col = idx / RL, k = idx % RL + 1;
       if (k > km) continue;
       if (!(probe & 8)) r2[it] = map_target(colc(C1, col), colc(A1, col), colc(Q, col), colc(C2, col), km, tracer_form, k, pt2[it], pb2[it]);
     }
     FV3_SYNC_LDS();
     for (int it = 0; it < kIt; it++) {
-      const int idx = tid + it * kNT, col = idx >> 7, k = (idx & 127) + 1;
+      const int idx = tid + it * kNT, col = idx / RL, k = idx % RL + 1;
       if (k > km) continue;
       at(Q, col, k - 1) = r2[it];
       at(C2, col, k - 1) = pt2[it];
@@ -436,7 +452,7 @@ struct RemapFastCore {
 // MOIST: thermostruct%moist_kappa / use_cond (nonhydrostatic; fv3_set_moist): the temperature transform with cappa from moist_cv of
 // the un-remapped tracers (:212-219), pkz with cappa from the remapped ones (:463-478), q_con / cappa written on the way, and the
 // conversion of the last step with the condensates (:806-811) -- the slab kernels' expressions (remap_kernels.h) per (column, level)
-template <bool HYDRO, bool MOIST = false>   // the flags at compile time: the other branches' loads and registers are not carried
+template <bool HYDRO, bool MOIST = false, int L = kFL>   // the flags at compile time: the other branches' loads and registers are not carried
 struct RemapFastScalars {
   static_assert(!(HYDRO && MOIST), "moist_kappa / use_cond are nonhydrostatic branches");
   Grid g;
@@ -451,8 +467,9 @@ struct RemapFastScalars {
   FV3_HD int nblocks_x() const { return (g.nx + kFC - 1) / kFC; }
 
   FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
-    constexpr int kIt = RemapFastCore::kIt;
-    const RemapFastCore core{km, probe};
+    using Core = RemapFastCoreT<L>;
+    constexpr int kIt = Core::kIt, RL = Core::RL;
+    const Core core{km, probe};
     double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf, *QS = C1 + kRQS;   // QS[column * kRP]
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (g.nx - bx * kFC < kFC) ? g.nx - bx * kFC : kFC;
@@ -545,9 +562,9 @@ struct RemapFastScalars {
       for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
         const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4, cc = clampc(col);
         if (k0 <= km) {
-          RemapFastCore::at(C1, col, k0) = v_pl[it];
+          Core::at(C1, col, k0) = v_pl[it];
           const double v_ps1 = PS[col];
-          RemapFastCore::at(C2, col, k0) = (k0 == 0 || k0 == km) ? v_pl[it] : dlog(AK[k0] + BK[k0] * v_ps1);
+          Core::at(C2, col, k0) = (k0 == 0 || k0 == km) ? v_pl[it] : dlog(AK[k0] + BK[k0] * v_ps1);
           if (k0 == 0) ps[o0 + cc] = v_ps1;   // :298-300
         }
         if (k0 < km) {
@@ -558,7 +575,7 @@ struct RemapFastScalars {
             t = t * dexp(v_cap[MOIST ? it : 0] * dlog(rrg * v_a[it] / v_b[it] * t));
           else
             t = t * dexp(k1k * dlog(rrg * v_a[it] / v_b[it] * t));
-          RemapFastCore::at(A1, col, k0) = t;
+          Core::at(A1, col, k0) = t;
         }
       }
     }
@@ -573,7 +590,7 @@ struct RemapFastScalars {
     core.remap_field(C1, C2, A1, Q, nullptr, true, 1, akt, p.t_min, false, tid, [&]() __attribute__((always_inline)) { load_pressures(); });
     for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
       const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-      if (k0 < km && col < ncol) pt[(ix_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);   // T_v for now
+      if (k0 < km && col < ncol) pt[(ix_t)k0 * nA + o0 + col] = Core::at(Q, col, k0);   // T_v for now
     }
     // ---- omega on the last step (:432-443, :506-526): interpolated in the old log-p coordinate (C1) to the centres of the new
     //      layers (C2); pe3(k) = omga(k-1), pe3(1) = 0 in A1 ----
@@ -588,16 +605,16 @@ struct RemapFastScalars {
         }
         for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
           const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-          if (k0 <= km) RemapFastCore::at(A1, col, k0) = k0 == 0 ? 0. : v_o[it];
+          if (k0 <= km) Core::at(A1, col, k0) = k0 == 0 ? 0. : v_o[it];
         }
       }
       FV3_SYNC_LDS();
       double om[kIt];
       for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
-        const int idx = tl + it * kNT, col = idx >> 7, n = (idx & 127) + 1;
+        const int idx = tl + it * kNT, col = idx / RL, n = idx % RL + 1;
         om[it] = 0.;
         if (n > km) continue;
-        const RColC e = RemapFastCore::colc(C1, col), t2 = RemapFastCore::colc(C2, col), p3 = RemapFastCore::colc(A1, col);
+        const RColC e = Core::colc(C1, col), t2 = Core::colc(C2, col), p3 = Core::colc(A1, col);
         const double mid = 0.5 * (t2[n] + t2[n + 1]);
         int k = n;                                  // the reference's first k (from k_next) with e(k) <= mid <= e(k+1)
         while (k > 1 && e[k] >= mid) k--;
@@ -606,13 +623,13 @@ struct RemapFastScalars {
       }
       FV3_SYNC_LDS();
       for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
-        const int idx = tl + it * kNT, col = idx >> 7, n = (idx & 127) + 1;
-        if (n <= km) RemapFastCore::at(Q, col, n - 1) = om[it];
+        const int idx = tl + it * kNT, col = idx / RL, n = idx % RL + 1;
+        if (n <= km) Core::at(Q, col, n - 1) = om[it];
       }
       FV3_SYNC_LDS();
       for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
         const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-        if (k0 < km && col < ncol) omga[(ix_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);
+        if (k0 < km && col < ncol) omga[(ix_t)k0 * nA + o0 + col] = Core::at(Q, col, k0);
       }
     }
     FV3_SYNC_LDS();
@@ -620,11 +637,11 @@ struct RemapFastScalars {
     for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
       const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
       if (k0 <= km) {
-        RemapFastCore::at(C1, col, k0) = nx0[it];
+        Core::at(C1, col, k0) = nx0[it];
         const double v_ps1 = PS[col];
-        RemapFastCore::at(C2, col, k0) = (k0 == 0) ? p.ptop : (k0 == km ? v_ps1 : AK[k0] + BK[k0] * v_ps1);
+        Core::at(C2, col, k0) = (k0 == 0) ? p.ptop : (k0 == km ? v_ps1 : AK[k0] + BK[k0] * v_ps1);
       }
-      if ((!HYDRO || p.nq > 0) && k0 < km) RemapFastCore::at(A1, col, k0) = nx1[it];
+      if ((!HYDRO || p.nq > 0) && k0 < km) Core::at(A1, col, k0) = nx1[it];
     }
     FV3_SYNC_LDS();
     for (int col = tid; col < kFC; col += kNT) {
@@ -645,18 +662,18 @@ struct RemapFastScalars {
       });
       for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
         const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-        if (k0 < km && col < ncol) w[(ix_t)k0 * nA + o0 + col] = RemapFastCore::at(Q, col, k0);
+        if (k0 < km && col < ncol) w[(ix_t)k0 * nA + o0 + col] = Core::at(Q, col, k0);
         // ---- delz (:292, :412-423): the specific volume -delz / delp in, delz = -q2 dp2 out ----
-        if (k0 < km) RemapFastCore::at(A1, col, k0) = -nx0[it] / nx1[it];
+        if (k0 < km) Core::at(A1, col, k0) = -nx0[it] / nx1[it];
       }
       FV3_SYNC_LDS();
       core.remap_field(C1, C2, A1, Q, nullptr, false, 1, akt, 0., false, tid, [&]() __attribute__((always_inline)) { load_tracer(0); });
       for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
         const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 < km) {
-          const double dzn = -RemapFastCore::at(Q, col, k0) * (RemapFastCore::at(C2, col, k0 + 1) - RemapFastCore::at(C2, col, k0));
+          const double dzn = -Core::at(Q, col, k0) * (Core::at(C2, col, k0 + 1) - Core::at(C2, col, k0));
           if (col < ncol) delz[(ix_t)k0 * nCC + occ0 + col] = dzn;
-          if (p.nq > 0) RemapFastCore::at(A1, col, k0) = nx0[it];
+          if (p.nq > 0) Core::at(A1, col, k0) = nx0[it];
         }
       }
     }
@@ -681,9 +698,9 @@ struct RemapFastScalars {
       for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
         const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 < km) {
-          const double v = RemapFastCore::at(Q, col, k0);
+          const double v = Core::at(Q, col, k0);
           if (col < ncol) qq[(ix_t)k0 * nA + o0 + col] = v;
-          if (more) RemapFastCore::at(A1, col, k0) = nx0[it];
+          if (more) Core::at(A1, col, k0) = nx0[it];
         }
       }
     }
@@ -718,15 +735,15 @@ struct RemapFastScalars {
               pk[(ix_t)k0 * nCC + occ0 + col] = pkv;
             }
           }
-          RemapFastCore::at(A1, col, k0) = pn;
-          RemapFastCore::at(Q, col, k0) = pkv;
+          Core::at(A1, col, k0) = pn;
+          Core::at(Q, col, k0) = pkv;
         }
       }
       FV3_SYNC_LDS();
       for (int it = 0, tl = fresh_tid(tid); it < kIt; it++) {
         const int idx = tl + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 >= km || col >= ncol) continue;
-        const RColC t2 = RemapFastCore::colc(C2, col), pn = RemapFastCore::colc(A1, col), pk2 = RemapFastCore::colc(Q, col);   // [k], 1-based: row k0 is [k0 + 1]
+        const RColC t2 = Core::colc(C2, col), pn = Core::colc(A1, col), pk2 = Core::colc(Q, col);   // [k], 1-based: row k0 is [k0 + 1]
         const ix_t o3 = (ix_t)k0 * nA + o0 + col, c3 = (ix_t)k0 * nCC + occ0 + col;
         const double dp2 = t2[k0 + 2] - t2[k0 + 1];
         delp[o3] = dp2;
@@ -765,7 +782,7 @@ struct RemapFastScalars {
 };
 
 // ---- the D-grid winds (:530-573): u on (is:ie, js:je+1), v on (is:ie+1, js:je), each on the mean pressure of its two cells ----------
-template <int WHICH>   // 0: u, 1: v
+template <int WHICH, int L = kFL>   // 0: u, 1: v
 struct RemapFastWind {
   Grid g;
   int km;
@@ -779,8 +796,9 @@ struct RemapFastWind {
   FV3_HD int nblocks_x() const { return (ncols_row() + kFC - 1) / kFC; }
 
   FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
-    constexpr int kIt = RemapFastCore::kIt;
-    const RemapFastCore core{km, probe};
+    using Core = RemapFastCoreT<L>;
+    constexpr int kIt = Core::kIt;
+    const Core core{km, probe};
     double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf;
     double *AK = lds + kRTabAk, *BK = lds + kRTabBk;
     const int i0 = g.is + bx * kFC, j = g.js + by;
@@ -817,11 +835,11 @@ struct RemapFastWind {
         const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
         if (k0 <= km) {
           const double psum = v_sa[it] + v_sb[it];
-          RemapFastCore::at(C1, col, k0) = (k0 == 0) ? v_b[it] : 0.5 * (v_a[it] + v_b[it]);
+          Core::at(C1, col, k0) = (k0 == 0) ? v_b[it] : 0.5 * (v_a[it] + v_b[it]);
           const double bkh = 0.5 * BK[k0];
-          RemapFastCore::at(C2, col, k0) = (WHICH == 1 && k0 == 0) ? AK[0] : AK[k0] + bkh * psum;
+          Core::at(C2, col, k0) = (WHICH == 1 && k0 == 0) ? AK[0] : AK[k0] + bkh * psum;
         }
-        if (k0 < km) RemapFastCore::at(A1, col, k0) = v_f[it];
+        if (k0 < km) Core::at(A1, col, k0) = v_f[it];
       }
     }
     FV3_SYNC_LDS();
@@ -834,7 +852,7 @@ struct RemapFastWind {
     core.remap_field(C1, C2, A1, Q, nullptr, false, -1, kord_mt, 0., false, tid, []() {});
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx & (kFC - 1), k0 = idx >> 4;
-      if (k0 < km && col < ncol) f[(ix_t)k0 * fs + f0 + col] = RemapFastCore::at(Q, col, k0);
+      if (k0 < km && col < ncol) f[(ix_t)k0 * fs + f0 + col] = Core::at(Q, col, k0);
     }
   }
 };

@@ -275,6 +275,10 @@ def test_remap_in_lds_and_in_slabs(prod):
                dict(fill=True, moist_kappa=True, use_cond=True, nwat=6)):
         assert R.check_remap(prod, **kw) == 0.0
         assert R.check_remap(prod, lds=False, **kw) == 0.0
+    # 5 levels per lane up to km = 79, 8 from km = 80 (RemapFastCoreT<L>): both sides of the switch, many tracers on few levels
+    for kw in (dict(km=79, nx=17, ny=3, nq=3), dict(km=78, nx=17, ny=3, nq=1, hydrostatic=True), dict(km=80, nx=17, ny=3, nq=1),
+               dict(km=5, nx=17, ny=3), dict(km=79, nq=9, kord=9, kord_tm=-9, last_step=True, adiabatic=False)):
+        assert R.check_remap(prod, **kw) == 0.0
     assert R.check_remap(prod, kord_tm=9) <= 1e-14
 
 
