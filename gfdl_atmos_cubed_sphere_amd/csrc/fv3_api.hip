@@ -3812,22 +3812,22 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
         const Dim3 gr{(unsigned)((g.nx + kFC - 1) / kFC), (unsigned)g.ny, 1};
         if (p->hydrostatic) {
           using K = RemapFastScalars<true, false, L>;
-          RT((remap_two_waves() ? launch_p2<K> : launch_p<K>)(c, "remap_lds_scalars", gr, kRLds, K{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
+          RT((remap_two_waves() || L == 5 ? launch_p2<K> : launch_p<K>)(c, "remap_lds_scalars", gr, RLay<L>::Lds, K{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
         } else if (moist) {   // use_cond / moist_kappa (fv3_set_moist): cappa from moist_cv in the temperature transform and in pkz
           using K = RemapFastScalars<false, true, L>;
-          RT((launch_p2<K>)(c, "remap_lds_scalars", gr, kRLds, K{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
+          RT((launch_p2<K>)(c, "remap_lds_scalars", gr, RLay<L>::Lds, K{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
         } else {
           using K = RemapFastScalars<false, false, L>;
-          RT((remap_two_waves() ? launch_p2<K> : launch_p<K>)(c, "remap_lds_scalars", gr, kRLds, K{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
+          RT((remap_two_waves() || L == 5 ? launch_p2<K> : launch_p<K>)(c, "remap_lds_scalars", gr, RLay<L>::Lds, K{g, km, rp, ak, bk, c->kord_tr_dev, pe, ws, ps, delp, pkz, pk, delz, pt, peln, w, q, omga, remap_probe()}));
         }
       }
       {
         RemapFastWind<0, L> kf{g, km, p->kord_mt, ak, bk, pe, u};
-        RT(launch_p2(c, "remap_lds_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kRLds, kf));
+        RT(launch_p2(c, "remap_lds_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, RLay<L>::Lds, kf));
       }
       {
         RemapFastWind<1, L> kf{g, km, p->kord_mt, ak, bk, pe, v};
-        RT(launch_p2(c, "remap_lds_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kRLds, kf));
+        RT(launch_p2(c, "remap_lds_winds", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, RLay<L>::Lds, kf));
       }
       return 0;
     };

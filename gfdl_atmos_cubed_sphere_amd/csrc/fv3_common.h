@@ -43,6 +43,11 @@ constexpr int kNT = 256;
 
 namespace fv3 {
 
+// wavefronts per SIMD the "_2w" launchers of fv3_launch.h budget the registers of a tile functor for (amdgpu_waves_per_eu): 2 unless
+// the functor says otherwise (remap_fast.h: the 5-levels-per-lane kernels fit three workgroups per CU)
+template <class F>
+struct tile_waves { static constexpr int value = 2; };
+
 // every pressure power / log-pressure of the path goes through these two
 FV3_HD double dexp(double x) { return fv3_exp(x); }
 FV3_HD double dlog(double x) { return fv3_log(x); }

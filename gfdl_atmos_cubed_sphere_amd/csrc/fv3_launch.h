@@ -127,7 +127,7 @@ inline int launch(Dim3 grid, size_t lds_doubles, stream_t s, const F &f) {
 // the same under a register budget of two wavefronts per SIMD (<= 256 VGPRs + AGPRs): kernels whose latency hiding needs the second
 // workgroup of a CU more than the last registers (nh_fast.h)
 template <class F>
-__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) tile_kernel_2w(const F f) {
+__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(tile_waves<F>::value, tile_waves<F>::value))) tile_kernel_2w(const F f) {
   extern __shared__ double fv3_lds[];
   f((int)blockIdx.y, (int)blockIdx.z, (int)blockIdx.x, (int)threadIdx.x, fv3_lds);
 }
@@ -256,7 +256,7 @@ __global__ void __launch_bounds__(kNT) tile_kernel_g(const FGroup<F> fg, int gy)
   fg.at(face)((int)blockIdx.y, by, (int)blockIdx.x, (int)threadIdx.x, fv3_lds);
 }
 template <class F>
-__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))) tile_kernel_2w_g(const FGroup<F> fg, int gy) {
+__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(tile_waves<F>::value, tile_waves<F>::value))) tile_kernel_2w_g(const FGroup<F> fg, int gy) {
   extern __shared__ double fv3_lds[];
   const int face = (int)blockIdx.z / gy, by = (int)blockIdx.z - face * gy;
   fg.at(face)((int)blockIdx.y, by, (int)blockIdx.x, (int)threadIdx.x, fv3_lds);

@@ -37,31 +37,25 @@ __device__ __forceinline__ int fresh_tid(int x) { asm volatile("" : "+v"(x)); re
 #define FV3_LOAD_LOOP(it) _Pragma("unroll") for (int it = 0, tl = fresh_tid(tid); it < kIt; it++)
 #endif
 
-// A column of an LDS array, two layouts (FV3_REMAP_CHUNKED, a build-time choice; the linear one is the product's):
-//   linear  : row r at [r + 2], r = -2 .. 129, then 16 doubles = 128 one-byte codes (a4_form); 148 = 20 (mod 32): the 16 columns x 4
-//             levels a wavefront stages at a time spread over all banks.  The spline's accesses (16 lanes of a column 8 rows apart)
-//             collide four at a time -- SQ_LDS_BANK_CONFLICT 2.4x the active LDS cycles in profiles/r03_v25_pmc_remap.csv --
-//   chunked : rows 0 .. 135 in chunks of 8 at 9 doubles (row r at [r + r / 8], nh_fast.h lds_lev; the codes in the ninth doubles),
-//             rows -2, -1 behind them: those 16 lanes hit 16 different bank pairs.  Measured (profiles/r04_remap_layouts.txt): a quarter
-//             fewer conflict cycles, but every one of the ~2 400 LDS accesses of a lane pays two more integer instructions for its
-//             index and the kernel, which is bound by its VALU instructions and not by LDS, got slower.
-#ifndef FV3_REMAP_CHUNKED
-#define FV3_REMAP_CHUNKED 0
-#endif
-#if FV3_REMAP_CHUNKED
-constexpr int kRC = 17 * kFS;            // 153
-constexpr int kRP = kRC + 3;             // 156
-constexpr int kRQS = kRC + 2;            // the one double of a column the layout does not use (the bottom value of w, in C1)
-FV3_HD int rix(int r) { return r + (r >> 3); }                              // r >= 0
-FV3_HD int rixn(int r) { return r >= 0 ? r + (r >> 3) : kRC + 2 + r; }      // r >= -2
-#else
-constexpr int kRC = 2 + 128 + 2;         // 132 rows
-constexpr int kRP = kRC + 16;            // 148
-constexpr int kRQS = kRC;                // C1 carries no codes: the bottom value of w sits in their place
+// A column of an LDS array: row r at [r + 2], r = -2 .. 16 L + 1, then one byte per row (a4_form).  The pitch depends on the levels per
+// lane L (RLay<L>): L = 8 -> 132 rows + 16 doubles of codes = 148 (= 20 mod 32: the 16 columns x 4 levels a wavefront stages at a time
+// spread over the banks), 78 KB per workgroup, two per CU; L = 5 -> 84 rows + 10 = 94, 50 KB per workgroup, THREE per CU.  (A chunked
+// layout -- 8 rows at 9 doubles, as nh_fast.h -- took a quarter of the bank conflicts of the spline away and was slower for its index
+// arithmetic: profiles/r04_remap_layouts.txt; it is no longer carried.)
+template <int L>
+struct RLay {
+  static constexpr int RL = 16 * L;                       // rows the lanes hold
+  static constexpr int RC = 2 + RL + 2;                   // rows of a column
+  static constexpr int RP = RC + (RL + 7) / 8;            // + the codes
+  static constexpr int RQS = RC;                          // C1 carries no codes: the bottom value of w sits in their place
+  static constexpr int RBuf = kFC * RP;
+  // behind the four arrays: the level coefficients ak, bk (128 each), the surface pressures of the 16 columns and the kord of the first
+  // 64 tracers -- as global loads inside the staging loops each of them cost a full `s_waitcnt vmcnt(0)`
+  static constexpr int TabAk = 4 * RBuf, TabBk = TabAk + 128, TabPs = TabBk + 128, TabKord = TabPs + kFC;
+  static constexpr int Lds = TabKord + 32;                // doubles per workgroup
+};
 FV3_HD int rix(int r) { return r + 2; }
 FV3_HD int rixn(int r) { return r + 2; }
-#endif
-constexpr int kRBuf = kFC * kRP;
 // row k (1-based) of a column
 struct RCol {
   double *p;
@@ -74,15 +68,8 @@ struct RColC {
 // One byte per row (chunked: in the ninth double of its chunk; linear: behind the rows): which expression the subgrid limiters formed
 // the curvature a4 of cell k with (cs_cell / cs_limit, remap_kernels.h) -- map_target forms a4 again with that expression instead of keeping
 // a third array of cell coefficients in LDS: 0: 3 (2 a1 - (a2 + a3)); 1: 6 a1 - 3 (a2 + a3); 2: 3 (a2 - a1); 3: 3 (a3 - a1)
-#if FV3_REMAP_CHUNKED
-FV3_HD unsigned char *a4_form_ptr(double *col, int k) { return reinterpret_cast<unsigned char *>(col + ((k - 1) >> 3) * kFS + kFL) + ((k - 1) & 7); }
-FV3_HD int a4_form(const double *col, int k) {
-  return reinterpret_cast<const unsigned char *>(col + ((k - 1) >> 3) * kFS + kFL)[(k - 1) & 7];
-}
-#else
-FV3_HD unsigned char *a4_form_ptr(double *col, int k) { return reinterpret_cast<unsigned char *>(col + kRC) + (k - 1); }
-FV3_HD int a4_form(const double *col, int k) { return reinterpret_cast<const unsigned char *>(col + kRC)[k - 1]; }
-#endif
+FV3_HD unsigned char *a4_form_ptr(double *col, int k, int rc) { return reinterpret_cast<unsigned char *>(col + rc) + (k - 1); }
+FV3_HD int a4_form(const double *col, int k, int rc) { return reinterpret_cast<const unsigned char *>(col + rc)[k - 1]; }
 FV3_HD double a4_of(int form, double a1, double a2, double a3) {
   switch (form) {
     case 0: return 3. * (2. * a1 - (a2 + a3));
@@ -101,12 +88,7 @@ FV3_HD int a4_form_of(double a4, double a1, double a2, double a3) {   // the fir
 // keeps the eight (column, level) addresses of a thread for every array alive as 64-bit register pairs through the whole kernel and
 // spills them (88 registers at two wavefronts per SIMD, 2.8 GB of scratch traffic per call); a 32-bit index is one register, shared by the
 // arrays of a layout, and goes into the scalar-base form of the load (ix_t: nh_fast.h)
-constexpr int kRNBuf = 4;                // C1 (source coordinate), C2 (target coordinate), A1 (layer means), Q (interface values / out)
-// behind the four arrays: the level coefficients ak, bk (128 each) and the surface pressures of the 16 columns -- as global loads inside
-// the staging loops each of them cost a full `s_waitcnt vmcnt(0)` (24 dependent round trips per workgroup)
-constexpr int kRTabAk = kRNBuf * kRBuf, kRTabBk = kRTabAk + 128, kRTabPs = kRTabBk + 128;
-constexpr int kRTabKord = kRTabPs + kFC, kRKordMax = 64;   // kord of the first 64 tracers (ints)
-constexpr int kRLds = kRTabKord + kRKordMax / 2;           // 78 208 B (chunked: 82 304): two workgroups per CU
+constexpr int kRKordMax = 64;   // kord of the first 64 tracers sits in LDS (ints)
 
 // L: levels per lane (16 lanes a column).  8 holds km <= 127; 5 (80 rows) holds km <= 79 -- C96 / C768 L79 columns then leave no lane
 // idle, where 8 left 38 % of the rows empty (the remap of BASELINE config 5's block: 133 -> 85 ms)
@@ -114,34 +96,36 @@ constexpr int kRLds = kRTabKord + kRKordMax / 2;           // 78 208 B (chunked:
 template <int L>
 inline vd vlin_ld(const double *buf, int col0, int q) {      // row (lane & 15) * L + q of the lane's column; any q with row >= -2
   vd x;
-  FV3_LANE_LOOP x.v[l] = buf[((l >> 4) + col0) * kRP + rixn((l & 15) * L + q)];
+  FV3_LANE_LOOP x.v[l] = buf[((l >> 4) + col0) * RLay<L>::RP + rixn((l & 15) * L + q)];
   return x;
 }
 template <int L>
 inline void vlin_st(double *buf, int col0, int q, const vd &x) {
-  FV3_LANE_LOOP buf[((l >> 4) + col0) * kRP + rixn((l & 15) * L + q)] = x.v[l];
+  FV3_LANE_LOOP buf[((l >> 4) + col0) * RLay<L>::RP + rixn((l & 15) * L + q)] = x.v[l];
 }
 template <int L>
 inline vb vrow_lt(int q, int k) { vb r; FV3_LANE_LOOP r.v[l] = (l & 15) * L + q < k; return r; }
 template <int L>
 inline vb vrow_eq(int q, int k) { vb r; FV3_LANE_LOOP r.v[l] = (l & 15) * L + q == k; return r; }
-inline vd vcol_lds(const double *p, int col0) { vd x; FV3_LANE_LOOP x.v[l] = p[((l >> 4) + col0) * kRP]; return x; }
+template <int L>
+inline vd vcol_lds(const double *p, int col0) { vd x; FV3_LANE_LOOP x.v[l] = p[((l >> 4) + col0) * RLay<L>::RP]; return x; }
 #else
 template <int L>
 __device__ __forceinline__ vd vlin_ld(const double *buf, int col0, int q) {
   const int l = (int)(threadIdx.x & 63);
-  return buf[((l >> 4) + col0) * kRP + rixn((l & 15) * L + q)];
+  return buf[((l >> 4) + col0) * RLay<L>::RP + rixn((l & 15) * L + q)];
 }
 template <int L>
 __device__ __forceinline__ void vlin_st(double *buf, int col0, int q, vd x) {
   const int l = (int)(threadIdx.x & 63);
-  buf[((l >> 4) + col0) * kRP + rixn((l & 15) * L + q)] = x;
+  buf[((l >> 4) + col0) * RLay<L>::RP + rixn((l & 15) * L + q)] = x;
 }
 template <int L>
 __device__ __forceinline__ vb vrow_lt(int q, int k) { return (int)(threadIdx.x & 15) * L + q < k; }
 template <int L>
 __device__ __forceinline__ vb vrow_eq(int q, int k) { return (int)(threadIdx.x & 15) * L + q == k; }
-__device__ __forceinline__ vd vcol_lds(const double *p, int col0) { return p[((int)((threadIdx.x & 63) >> 4) + col0) * kRP]; }
+template <int L>
+__device__ __forceinline__ vd vcol_lds(const double *p, int col0) { return p[((int)((threadIdx.x & 63) >> 4) + col0) * RLay<L>::RP]; }
 #endif
 
 // kords the streamed form of the mapping loop handles (cs_cell): scalar_profile / cs_profile without the two-cell limiters of 11, 12
@@ -156,7 +140,7 @@ FV3_HD bool kord_fast(int kord) {
 // the first layer whose lower edge is not above it), found here from the guess l = k.  pe1, a1: 1-based columns in LDS; a2, a3: the
 // limited edge values of every source cell (cs_cell), a4 formed here again with the expression the limiters used (a4_form: the value
 // the reference stores, bit for bit).  The quotients through one reciprocal and a Markstein correction: the values of `/` (remap_kernels.h div_rn).
-FV3_HD double map_target(const RColC pe1, const RColC a1, const RColC a2, const RColC a3, int km, bool tracer_form, int k,
+FV3_HD double map_target(const RColC pe1, const RColC a1, const RColC a2, const RColC a3, int km, int rc, bool tracer_form, int k,
                          double p2t, double p2b) {
   constexpr double r3 = 1. / 3., r23 = 2. / 3.;
   int l = k;
@@ -165,7 +149,7 @@ FV3_HD double map_target(const RColC pe1, const RColC a1, const RColC a2, const 
   const double p1t = pe1[l], p1b = pe1[l + 1];
   const double dp1 = p1b - p1t, rdp1 = rcp_rn(dp1);
   const double pl = div_rn(p2t - p1t, dp1, rdp1);
-  const double b2 = a2[l], b3 = a3[l], b4 = a4_of(a4_form(a1.p, l), a1[l], b2, b3);
+  const double b2 = a2[l], b3 = a3[l], b4 = a4_of(a4_form(a1.p, l, rc), a1[l], b2, b3);
   if (p2b <= p1b) {
     const double pr = div_rn(p2b - p1t, dp1, rdp1);
     if (tracer_form) {
@@ -193,7 +177,7 @@ FV3_HD double map_target(const RColC pe1, const RColC a1, const RColC a2, const 
     } else {
       const double dp = p2b - mt, dm = mb - mt;
       const double esl = div_rn(dp, dm, rcp_rn(dm));
-      const double m2 = a2[m], m3 = a3[m], m4 = a4_of(a4_form(a1.p, m), a1[m], m2, m3);
+      const double m2 = a2[m], m3 = a3[m], m4 = a4_of(a4_form(a1.p, m, rc), a1[m], m2, m3);
       if (tracer_form) {
         const double fac1 = 0.5 * esl, fac2 = 1. - r23 * esl;
         qsum = qsum + dp * (m2 + fac1 * (m3 - m2 + m4 * fac2));
@@ -210,7 +194,8 @@ FV3_HD double map_target(const RColC pe1, const RColC a1, const RColC a2, const 
 // the machinery both kernels share: a workgroup's 16 columns in the four LDS arrays
 template <int L>
 struct RemapFastCoreT {
-  static constexpr int RL = 16 * L;   // rows of a column the lanes hold
+  using Lay = RLay<L>;
+  static constexpr int RL = Lay::RL, kRP = Lay::RP;   // rows of a column the lanes hold, pitch of a column
   int km;
   int probe = 0;   // timing probe (FV3_MI355X_REMAP_PROBE, tools/remap_time.py; WRONG results): 1 no spline, 2 no constraints, 4 no
                    // subgrid limiters, 8 no mapping loop
@@ -260,7 +245,7 @@ struct RemapFastCoreT {
       }
       const vd am1v = vlin_ld<L>(A1, c0, -1), am2v = vlin_ld<L>(A1, c0, -2);
       const vd dpm1v = e[0] - em1, dpm2v = em1 - em2;
-      const vd qs = QS ? vcol_lds(QS, c0) : vd(0.0);            // QS[column * kRP]
+      const vd qs = QS ? vcol_lds<L>(QS, c0) : vd(0.0);            // QS[column * kRP]
       vd grv[L];
       for (int q = 0; q < L; q++) grv[q] = vdivq(q > 0 ? dpv[q - 1] : dpm1v, dpv[q]);      // dp(k-1) / dp(k) of row k = r + 1
       const vd gr_up = row_shr<1>(grv[L - 1], 1.0);                                       // ... of the row above the lane's first
@@ -407,13 +392,13 @@ struct RemapFastCoreT {
       if (k > km) continue;
       at(Q, col, k - 1) = r2[it];
       at(C2, col, k - 1) = r3v[it];
-      *a4_form_ptr(A1 + col * kRP, k) = (unsigned char)form[it];
+      *a4_form_ptr(A1 + col * kRP, k, Lay::RC) = (unsigned char)form[it];
     }
     FV3_SYNC_LDS();
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx / RL, k = idx % RL + 1;
       if (k > km) continue;
-      if (!(probe & 8)) r2[it] = map_target(colc(C1, col), colc(A1, col), colc(Q, col), colc(C2, col), km, tracer_form, k, pt2[it], pb2[it]);
+      if (!(probe & 8)) r2[it] = map_target(colc(C1, col), colc(A1, col), colc(Q, col), colc(C2, col), km, Lay::RC, tracer_form, k, pt2[it], pb2[it]);
     }
     FV3_SYNC_LDS();
     for (int it = 0; it < kIt; it++) {
@@ -468,9 +453,10 @@ struct RemapFastScalars {
 
   FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
     using Core = RemapFastCoreT<L>;
-    constexpr int kIt = Core::kIt, RL = Core::RL;
+    using Lay = RLay<L>;
+    constexpr int kIt = Core::kIt, RL = Core::RL, kRP = Lay::RP, kRBuf = Lay::RBuf;
     const Core core{km, probe};
-    double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf, *QS = C1 + kRQS;   // QS[column * kRP]
+    double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf, *QS = C1 + Lay::RQS;   // QS[column * kRP]
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (g.nx - bx * kFC < kFC) ? g.nx - bx * kFC : kFC;
     const ix_t nA = g.nA(), nCC = g.nCC();
@@ -484,8 +470,8 @@ struct RemapFastScalars {
     // (what the end of the kernel needs of the remapped fields -- T_v, delz, sphum -- is written to pt / delz / q as it is formed and
     // read back by the same thread there; the log of the new interface pressures is formed again: kept in registers through the
     // remap of every field these 32 doubles per thread were spilled to scratch, 404 B per lane)
-    double *AK = lds + kRTabAk, *BK = lds + kRTabBk, *PS = lds + kRTabPs;
-    int *KT = reinterpret_cast<int *>(lds + kRTabKord);
+    double *AK = lds + Lay::TabAk, *BK = lds + Lay::TabBk, *PS = lds + Lay::TabPs;
+    int *KT = reinterpret_cast<int *>(lds + Lay::TabKord);
     double nx0[kIt], nx1[kIt];   // the inputs of the next field, in flight during the mapping loop of the current one
     // the pressure coordinate's source interfaces (pe) and the first field on it (w; hydrostatic: the first tracer)
     // (every prefetch is unconditional -- a load under a branch is waited for at the join; where there is nothing to fetch the
@@ -685,8 +671,7 @@ struct RemapFastScalars {
       core.remap_field(C1, C2, A1, Q, nullptr, true, 0, iq < kRKordMax ? KT[iq] : kord_tr[iq], 0., p.nq > 5, tid, [&]() __attribute__((always_inline)) { load_tracer(iq + 1); });
       if (p.fill) {   // flagstruct%fill: fillz (fv_fill.F90:34-137) on the remapped column, sequential in k as in the reference -- one
                       // thread per column, and only for a column that holds a negative value at all (dp2(k) = pe2(k+1) - pe2(k) from C2)
-        static_assert(!FV3_REMAP_CHUNKED, "fillz_col walks a column with unit stride");
-        for (int col = tid; col < kFC; col += kNT) {
+                for (int col = tid; col < kFC; col += kNT) {
           double *qc = Q + col * kRP + rix(0);
           const double *e2 = C2 + col * kRP + rix(0);
           bool neg = false;
@@ -797,10 +782,11 @@ struct RemapFastWind {
 
   FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
     using Core = RemapFastCoreT<L>;
-    constexpr int kIt = Core::kIt;
+    using Lay = RLay<L>;
+    constexpr int kIt = Core::kIt, kRBuf = Lay::RBuf;
     const Core core{km, probe};
     double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf;
-    double *AK = lds + kRTabAk, *BK = lds + kRTabBk;
+    double *AK = lds + Lay::TabAk, *BK = lds + Lay::TabBk;
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (ncols_row() - bx * kFC < kFC) ? ncols_row() - bx * kFC : kFC;
     const ix_t fs = WHICH == 0 ? g.nU() : g.nV();
@@ -856,5 +842,11 @@ struct RemapFastWind {
     }
   }
 };
+
+// three workgroups per CU at 5 levels per lane (50 KB of LDS each): the register budget of three wavefronts per SIMD
+template <bool HYDRO, bool MOIST>
+struct tile_waves<RemapFastScalars<HYDRO, MOIST, 5>> { static constexpr int value = 3; };
+template <int WHICH>
+struct tile_waves<RemapFastWind<WHICH, 5>> { static constexpr int value = 3; };
 
 }  // namespace fv3
