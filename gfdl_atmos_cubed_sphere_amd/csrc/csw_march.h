@@ -36,6 +36,7 @@ inline MarchDims make_csw_dims(const Grid &g, int tj) {
   d.k_fast = march_k_fast();
   d.nstrips = (g.nx + 4 + kCswCols - 1) / kCswCols;
   d.nsegs = (g.ny + 4 + tj - 1) / tj;
+  d.alt_nk = d.alt_ng = d.alt_tj = 0;
   d.set_box(0, d.nstrips, 0, d.nsegs);
   return d;
 }
@@ -87,8 +88,8 @@ struct CswMarch {
 
   FV3_D void operator()(int gid) const {
     constexpr double a1 = 0.5625, a2 = -0.0625;  // sw_core.F90:53-54
-    int strip, seg, kg;
-    md.decode(gid, strip, seg, kg);
+    int strip, seg, kg, tjw;
+    md.decode_tj(gid, strip, seg, kg, tjw);
     const int is = g.is, ie = g.ie, js = g.js, je = g.je;
     const int ilo = is - 1 + strip * kCswCols - 3;  // column of lane 0
     auto cl = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
@@ -104,8 +105,8 @@ struct CswMarch {
       l1 = l1 < lm ? l1 : lm;
     }
     const int oJ0 = mw ? mw + 1 : g.jsd - 1, oJ1 = mw ? g.npy - mw - 1 : g.jed + 2;
-    const int jA = js - 1 + seg * md.tj;
-    const int jB = (jA + md.tj - 1 < je + 2) ? jA + md.tj - 1 : je + 2;
+    const int jA = js - 1 + seg * tjw;
+    const int jB = (jA + tjw - 1 < je + 2) ? jA + tjw - 1 : je + 2;
     const bool nh = !a.hydrostatic;
     const double dt2 = a.dt2, dt4 = 0.5 * dt2;
     const long nAp = (long)g.nA();  // one sin_sg plane
@@ -116,6 +117,8 @@ struct CswMarch {
     auto LB = [&](const double *p, int j) { return vload(p, (long)g.iB(ilo, cl(j, g.jsd, g.jed + 1)), cV); };
     const vb m_uc = lane_mask(is - ilo, ie + 1 - ilo);  // columns where uc is advanced (:414-447)
     const vb m_vc = lane_mask(is - ilo, ie - ilo);      // columns where vc is advanced (:452-486)
+    // the row step has no control flow (spmd.h "branch-free rows"): the row conditions go into the stores, the lane masks into their offsets
+    const vm s1 = make_mask(l0, l1), s2 = make_mask(l0, l2);
 
     // the levels of this wavefront (the last group may be short: the surplus slot repeats the last level and
     // does not store)
@@ -155,7 +158,7 @@ struct CswMarch {
       f.v = LV(a.v + (size_t)k * g.nV(), t - 1);
       f.dp = LA(a.delp + (size_t)k * g.nA(), R);
       f.pt = LA(a.pt + (size_t)k * g.nA(), R);
-      f.w = nh ? LA(a.w + (size_t)k * g.nA(), R) : vd(0.);
+      f.w = LA((nh ? a.w : a.pt) + (size_t)k * g.nA(), R);   // hydrostatic: any valid row (no branch in the row step; wc is not stored)
       return f;
     };
 
@@ -169,6 +172,7 @@ struct CswMarch {
     CswMetrics mnxt = load_metrics(jA - 2);
     CswFields fnxt[KPW];
     for (int m = 0; m < KPW; m++) fnxt[m] = load_fields(jA - 2, kl[m]);
+    vdrain_loads();
     for (int t = jA - 2; t <= jB + 3; t++) {
       const int R = t - 2, Q = t - 3;
       const int tn = t < jB + 3 ? t + 1 : t;
@@ -220,14 +224,13 @@ struct CswMarch {
         const vd ucdx = uc * in.dxc;
         const vd vcdy = vc * in.dyc;
         const vd vort = in.fc + in.rac * (S.ucdx_p - ucdx - shr1(vcdy) + vcdy);  // :372-403
-        if (live[m] && R >= jA && R <= jB && R >= oJ0 && R <= oJ1) {
+        {
+          const bool on = live[m] && R >= jA && R <= jB && R >= oJ0 && R <= oJ1, on1 = on && R <= je + 1;
           const long iAr = (long)g.iA(ilo, R);
-          if (R <= je + 1) {
-            vstore(a.ua + oA, iAr, ua, l0, l1);
-            vstore(a.va + oA, iAr, va, l0, l1);
-            vstore(a.ut + oA, iAr, ut, l0, l2);
-          }
-          vstore(a.vt + oA, iAr, vt, l0, l1);
+          vstore_b(a.ua + oA, iAr, ua, s1, on1);
+          vstore_b(a.va + oA, iAr, va, s1, on1);
+          vstore_b(a.ut + oA, iAr, ut, s2, on1);
+          vstore_b(a.vt + oA, iAr, vt, s1, on);
         }
         // ---- row Q: KE, transport, wind update, divergence -------------------------------------------------------
         const vd ke = dt4 * (S.ua_p * vsel(S.ua_p > 0., S.uc_p, shl1(S.uc_p)) + S.va_p * vsel(S.va_p > 0., S.vc_p, vc));  // :297-366
@@ -235,55 +238,57 @@ struct CswMarch {
         const vb vpos = vt > 0.;
         const vd fy1_n = vt * vsel(vpos, S.dp0, S.dpp);
         const vd fyp_n = fy1_n * vsel(vpos, S.pt0, S.ptp);
-        const vd fyw_n = nh ? fy1_n * vsel(vpos, S.w0, S.wp) : vd(0.);
-        if (live[m] && Q >= jA && Q <= jB && Q >= oJ0 && Q <= oJ1) {
+        const vd fyw_n = fy1_n * vsel(vpos, S.w0, S.wp);
+        {
+          const bool on = live[m] && Q >= jA && Q <= jB && Q >= oJ0 && Q <= oJ1, on1 = on && Q <= je + 1;
           const long iAq = (long)g.iA(ilo, Q);
-          if (Q <= je + 1) {
-            const vb upos = S.ut_p > 0.;
-            const vd fx1 = S.ut_p * vsel(upos, shr1(S.dp0), S.dp0);
-            const vd fxp = fx1 * vsel(upos, shr1(S.pt0), S.pt0);
-            const vd ra = in.ra;
-            const vd dpc = S.dp0 + (fx1 - shl1(fx1) + S.fy1_p - fy1_n) * ra;
-            vstore(a.delpc + oA, iAq, dpc, l0, l1);
-            vstore(a.ptc + oA, iAq, (S.pt0 * S.dp0 + (fxp - shl1(fxp) + S.fyp_p - fyp_n) * ra) / dpc, l0, l1);
-            if (nh) {
-              const vd fxw = fx1 * vsel(upos, shr1(S.w0), S.w0);
-              vstore(a.wc + oA, iAq, (S.w0 * S.dp0 + (fxw - shl1(fxw) + S.fyw_p - fyw_n) * ra) / dpc, l0, l1);
-            }
-            // uc: interpolated value, advanced on [is, ie+1] x [js, je] (:414-447)
-            vd ucv = S.uc_p;
-            if (Q >= js && Q <= je) {
-              vd fy1 = dt2 * S.v1;
-              if constexpr (GM == 0) fy1 = dt2 * (S.v1 - ucv * cosau_p) / in.sinau;
-              const vd fy = vsel(fy1 > 0., S.vort_p, vort);
-              ucv = vsel(m_uc, ucv + fy1 * fy + in.rdxc * (shr1(ke) - ke), ucv);
-            }
-            vstore(a.uc + oV, (long)g.iV(ilo, Q), ucv, l0, l2);
+          const vb upos = S.ut_p > 0.;
+          const vd fx1 = S.ut_p * vsel(upos, shr1(S.dp0), S.dp0);
+          const vd fxp = fx1 * vsel(upos, shr1(S.pt0), S.pt0);
+          const vd ra = in.ra;
+          const vd dpc = S.dp0 + (fx1 - shl1(fx1) + S.fy1_p - fy1_n) * ra;
+          vstore_b(a.delpc + oA, iAq, dpc, s1, on1);
+          vstore_b(a.ptc + oA, iAq, (S.pt0 * S.dp0 + (fxp - shl1(fxp) + S.fyp_p - fyp_n) * ra) / dpc, s1, on1);
+          {
+            const vd fxw = fx1 * vsel(upos, shr1(S.w0), S.w0);
+            vstore_b((nh ? a.wc : a.ptc) + oA, iAq, (S.w0 * S.dp0 + (fxw - shl1(fxw) + S.fyw_p - fyw_n) * ra) / dpc, s1, on1 && nh);
           }
+          // uc: interpolated value, advanced on [is, ie+1] x [js, je] (:414-447)
+          vd ucv = S.uc_p;
+          {
+            const bool adv = Q >= js && Q <= je;
+            vd fy1 = dt2 * S.v1;
+            if constexpr (GM == 0) fy1 = dt2 * (S.v1 - ucv * cosau_p) / in.sinau;
+            const vd fy = vsel(fy1 > 0., S.vort_p, vort);
+            ucv = vsel(m_uc && vball(adv), ucv + fy1 * fy + in.rdxc * (shr1(ke) - ke), ucv);
+          }
+          vstore_b(a.uc + oV, (long)g.iV(ilo, Q), ucv, s2, on1);
           // vc: interpolated value, advanced on [is, ie] x [js, je+1] (:452-486)
           vd vcv = S.vc_p;
-          if (Q >= js && Q <= je + 1) {
-            vd fx1 = dt2 * S.u0;
-            if constexpr (GM == 0) fx1 = dt2 * (S.u0 - vcv * in.cosav) / in.sinav;
-            const vd fx = vsel(fx1 > 0., S.vort_p, shl1(S.vort_p));
-            vcv = vsel(m_vc, vcv - fx1 * fx + in.rdyc * (S.ke_p - ke), vcv);
+          {
+            const bool adv = Q >= js && Q <= je + 1;
+            vd fx1v = dt2 * S.u0;
+            if constexpr (GM == 0) fx1v = dt2 * (S.u0 - vcv * in.cosav) / in.sinav;
+            const vd fx = vsel(fx1v > 0., S.vort_p, shl1(S.vort_p));
+            vcv = vsel(m_vc && vball(adv), vcv - fx1v * fx + in.rdyc * (S.ke_p - ke), vcv);
           }
-          vstore(a.vc + oU, (long)g.iU(ilo, Q), vcv, l0, l1);
+          vstore_b(a.vc + oU, (long)g.iU(ilo, Q), vcv, s1, on);
         }
         // divergence at the corners of row Q (:1781-1796); v0 = v(Q-1), v1 = v(Q), u0 = u(Q)
         const vd dxc_q = GM == 2 ? vd(g.c_dxc) : dxc_p, dyc_q = GM == 2 ? vd(g.c_dyc) : dyc_p;
         const vd rac_q = GM == 2 ? vd(g.c_rarea_c) : rac_p;
         const vd vdxc = S.v1 * dxc_q;
-        if (live[m] && a.nord > 0 && !mw && Q >= jA && Q <= jB) {
+        {
+          const bool on = live[m] && a.nord > 0 && !mw && Q >= jA && Q <= jB;
           const vd uf = S.u0 * dyc_q;
-          vstore(a.divg_d + oB, (long)g.iB(ilo, Q), rac_q * (S.vdxc_p - vdxc + shr1(uf) - uf), l0, l2);
+          vstore_b(a.divg_d + oB, (long)g.iB(ilo, Q), rac_q * (S.vdxc_p - vdxc + shr1(uf) - uf), s2, on);
         }
         if constexpr (GM == 0 && CS) {
           if (mw && a.nord > 0) {  // the interior of a cubed-sphere face: the non-orthogonal form with ua, va of rows Q-1, Q
             const vd uf = (S.u0 - 0.25 * (S.va_pp + S.va_p) * csu) * dyc_q * 0.5 * (sg4_p + sg2_p);
             const vd vf = (S.v1 - 0.25 * (shr1(S.ua_p) + S.ua_p) * csv) * dxc_q * 0.5 * (sg3_p + sg1_p);
-            if (live[m] && Q >= jA && Q <= jB && Q >= oJ0 && Q <= oJ1)
-              vstore(a.divg_d + oB, (long)g.iB(ilo, Q), rac_q * (S.vf_p - vf + shr1(uf) - uf), l0, l2);
+            vstore_b(a.divg_d + oB, (long)g.iB(ilo, Q), rac_q * (S.vf_p - vf + shr1(uf) - uf), s2,
+                     live[m] && Q >= jA && Q <= jB && Q >= oJ0 && Q <= oJ1);
             S.vf_p = vf;
             S.va_pp = S.va_p;
           }

@@ -12,6 +12,11 @@
 
 #include "dsw_march.h"
 
+// 1: the row steps without control flow (spmd.h "branch-free rows"); 0 builds the general forms only (an A / B switch for variants)
+#ifndef FV3_BF
+#define FV3_BF 1
+#endif
+
 namespace fv3 {
 
 // what the three marches share at one step
@@ -88,6 +93,216 @@ struct DswTransportFused {
   };
 
   FV3_D void operator()(int gid) const {
+    if constexpr (FLUXES || !FV3_BF)
+      run_general(gid);
+    else
+      run_bf(gid);
+  }
+
+  // ---- the row step without control flow (spmd.h "branch-free rows") ------------------------------------------------------------------
+  // Every row of the segment, the warm-up rows included, runs the whole step: what the general form skips on the rows whose face / output
+  // row does not exist yet is computed on values that are never kept, and the row conditions (the Courant rows / faces and the output row
+  // are the segment's own) go into the stores -- `on` of vstore_b_nt / vaccum_z -- instead of into branches.  With no branch in the loop the
+  // compiler counts the stores in flight, and the wait for the prefetched rows becomes vmcnt(<stores of the step>) instead of vmcnt(0).
+  // The one store that belongs to a single row of the whole tile (mfy of the north face of row je) follows the loop.
+  FV3_D void run_bf(int gid) const {
+    int strip, seg, kk, tjw;
+    md.decode_tj(gid, strip, seg, kk, tjw);
+    const int k = md.klist ? md.klist[kk] : kk;
+    const StripGeom s = make_strip(g, strip);
+    const int ilo = s.ilo;
+    const int jA = g.js + seg * tjw;
+    const int jB = (jA + tjw - 1 < g.je) ? jA + tjw - 1 : g.je;
+    const int rlast = jB + 3;
+    const int lFx1 = (ilo + s.lC1 == g.ie) ? s.lC1 + 1 : s.lC1;
+    const size_t oA = (size_t)k * g.nA(), oCX = (size_t)k * g.nCX(), oCY = (size_t)k * g.nCY();
+    const size_t oFX = (size_t)k * g.nFX(), oFY = (size_t)k * g.nFY(), oCC = (size_t)k * g.nCC();
+    const double *delp = a.delp + oA, *pt = a.pt + oA, *w = NH ? a.w + oA : nullptr;
+    double *crx = a.crx + oCX, *xfx = a.xfx + oCX, *cry = a.cry + oCY, *yfx = a.yfx + oCY;
+    double *mfx = a.mfx + oFX, *mfy = a.mfy + oFY;
+    const int seg_last = (jB == g.je);
+    const int rowA = (seg == 0) ? g.jsd : jA, rowB = seg_last ? g.jed : jB;
+    const int lY0 = (strip == 0) ? s.lA0 : s.lC0, lY1 = (ilo + s.lC1 == g.ie) ? s.lA1 : s.lC1;
+    const double dt = a.dt;
+    const int mw = a.mask_w;
+    const int oC0 = mw ? (s.lC0 > mw + 1 - ilo ? s.lC0 : mw + 1 - ilo) : s.lC0;
+    const int oC1 = mw ? (s.lC1 < g.npx - mw - 1 - ilo ? s.lC1 : g.npx - mw - 1 - ilo) : s.lC1;
+    const int oF1 = mw ? (lFx1 < g.npx - mw - 1 - ilo ? lFx1 : g.npx - mw - 1 - ilo) : lFx1;
+    const int oJ0 = mw ? mw + 1 : g.jsd, oJ1 = mw ? g.npy - mw - 1 : g.jed + 1;
+    const vm mCX = make_mask(s.lC0, lFx1), mCY = make_mask(lY0, lY1), mO = make_mask(oC0, oC1), mOF = make_mask(oC0, oF1),
+             mC = make_mask(s.lC0, s.lC1);
+    // a sponge level (dyn_core.F90:703-724: nord_w = 0, damp_w = d2_divg): the del-2 damping of w and its heating (sw_core.F90:950-982,
+    // :1268-1274; del6_vt_flux :1608 with nord = 0) in the row step -- uniform metrics only; the host sends the level here only then
+    const bool wdamp = UNI && NH && a.lv.damp_w[k] > 1.E-5;
+    const double damp4 = wdamp ? a.lv.damp_w[k] * g.da_min_c : 0., dd8 = a.kgb * fabs(a.dt);
+
+    auto load_in = [&](int r) {
+      In in;
+      const long iA = (long)g.iA(ilo, r), iCX = (long)g.iCX(ilo, r);
+      in.dp = vload(delp, iA, s.A);
+      in.pt = vload(pt, iA, s.A);
+      in.w = NH ? vload(w, iA, s.A) : vd(0.);
+      in.ar = UNI ? vd(g.c_area) : vload(g.area, iA, s.A);
+      const int jf = (r - 2 < jA) ? jA : r - 2, j = (r - 3 < jA) ? jA : r - 3;
+      const long iCY = (long)g.iCY(ilo, jf);
+      if (COURANT) {
+        const long nAp = (long)g.nA();
+        in.cx = vload(a.uc + (size_t)k * g.nV(), (long)g.iV(ilo, r), s.A);
+        const long iAf = (long)g.iA(ilo, jf), iAm = (long)g.iA(ilo, jf - 1), iUf = (long)g.iU(ilo, jf);
+        in.cy = vload(a.vc + (size_t)k * g.nU(), iUf, s.A);
+        if constexpr (!UNI) {
+          in.rdxa = vload(g.rdxa, iA, s.A);
+          in.dyr = vload(g.dy, (long)g.iV(ilo, r), s.A);
+          in.sg3 = vload(g.sin_sg + 2 * nAp, iA, s.A);
+          in.sg1 = vload(g.sin_sg, iA, s.A);
+          in.rdya0 = vload(g.rdya, iAm, s.A);
+          in.rdya1 = vload(g.rdya, iAf, s.A);
+          in.dxr = vload(g.dx, iUf, s.A);
+          in.sg4 = vload(g.sin_sg + 3 * nAp, iAm, s.A);
+          in.sg2 = vload(g.sin_sg + nAp, iAf, s.A);
+        }
+      } else {
+        in.cx = vload(crx, iCX, s.F);
+        in.xf = vload(xfx, iCX, s.F);
+        in.cy = vload(cry, iCY, s.A);
+        in.yf = vload(yfx, iCY, s.A);
+        in.xfj = vload(xfx, (long)g.iCX(ilo, j), s.F);
+      }
+      if constexpr (UNI && COURANT) {
+        in.ucj = vload(a.uc + (size_t)k * g.nV(), (long)g.iV(ilo, j), s.A);  // uc of row r-3: its crx, xfx are re-formed
+      }
+      in.ra = UNI ? vd(g.c_rarea) : vload(g.rarea, (long)g.iA(ilo, j), s.C);
+      return in;
+    };
+
+    Tp2dField<HORD> fd, fw, fp;  // delp, w, pt
+    fd.init();
+    fp.init();
+    if (NH) fw.init();
+    vd ar_1(1.), ar_2(1.), ar_3(1.), cx_1(0.), cx_2(0.), cx_3(0.);  // area / crx of rows r-1 .. r-3
+    vd xf_1(0.), xf_2(0.), xf_3(0.);                                 // COURANT: xfx of rows r-1 .. r-3
+    vd yf_prev(0.), fym_prev(0.);
+    In nxt = load_in(jA - 3);
+    vdrain_loads();
+    for (int r = jA - 3; r <= rlast; r++) {
+      const In in = nxt;
+      const int j = r - 3, jf = r - 2;
+      const int jc = j < jA ? jA : j, jfc = jf < jA ? jA : jf;   // rows of the (dropped) stores / zero additions of the warm-up steps
+      // the flux capacitors cx, cy, mfx, mfy (sw_core.F90:923-940) as load - add - store: every element has one owner (strip, segment),
+      // and the old value is read at the top of the step that stores the sum.  (As L2 atomics -- no register for the old value -- the
+      // four accumulations cost 0.23 ms of the kernel's 0.90: global_atomic_add_f64 is the slowest thing a row step can do.)
+      const vd cx_o = COURANT ? vload(a.cx + oCX, (long)g.iCX(ilo, r), s.F) : vd(0.);
+      const vd cy_o = COURANT ? vload(a.cy + oCY, (long)g.iCY(ilo, jfc), s.A) : vd(0.);
+      const vd mfx_o = vload(mfx, (long)g.iFX(ilo, jc), s.F), mfy_o = vload(mfy, (long)g.iFY(ilo, jc), s.C);
+      nxt = load_in(r < rlast ? r + 1 : rlast);
+      Tp2dShared sh;
+      vd xfj = in.xfj, cxj_uni(0.);
+      if (COURANT) {
+        // x faces of row r (sw_core.F90:865, :882-888, :923-927)
+        const vd x = dt * in.cx;
+        const vb xpos = x > 0.;
+        if constexpr (UNI) {
+          sh.cx = x * g.c_rdxa;
+          sh.xf = g.c_dy * x;
+        } else {
+          sh.cx = vsel(xpos, x * shr1(in.rdxa), x * in.rdxa);
+          sh.xf = vsel(xpos, in.dyr * x * shr1(in.sg3), in.dyr * x * in.sg1);
+        }
+        {
+          const bool on = r >= rowA && r <= rowB;
+          const long iCX = (long)g.iCX(ilo, r);
+          vstore_b_nt(crx, iCX, sh.cx, mCX, on);
+          vstore_b_nt(xfx, iCX, sh.xf, mCX, on);
+          vstore_b(a.cx + oCX, iCX, cx_o + sh.cx, mCX, on);
+        }
+        // y faces of row r-2 (:894-900, :933-936)
+        const vd y = dt * in.cy;
+        const vb ypos = y > 0.;
+        if constexpr (UNI) {
+          sh.cy = y * g.c_rdya;
+          sh.yf = g.c_dx * y;
+        } else {
+          sh.cy = vsel(ypos, y * in.rdya0, y * in.rdya1);
+          sh.yf = vsel(ypos, in.dxr * y * in.sg4, in.dxr * y * in.sg2);
+        }
+        {
+          const bool on = jf >= jA && (jf <= jB || (seg_last && jf == g.je + 1));
+          const long iCY = (long)g.iCY(ilo, jfc);
+          vstore_b_nt(cry, iCY, sh.cy, mCY, on);
+          vstore_b_nt(yfx, iCY, sh.yf, mCY, on);
+          vstore_b(a.cy + oCY, iCY, cy_o + sh.cy, mCY, on);
+        }
+        if constexpr (UNI) {  // crx, xfx of row r-3 from its uc again (same expressions as at step r-3): no 3-row windows
+          const vd xj = dt * in.ucj;
+          xfj = g.c_dy * xj;
+          cxj_uni = xj * g.c_rdxa;
+        } else {
+          xfj = xf_3;
+          xf_3 = xf_2; xf_2 = xf_1; xf_1 = sh.xf;
+        }
+      } else {
+        sh.cx = in.cx; sh.xf = in.xf;
+        sh.cy = in.cy; sh.yf = in.yf;
+      }
+      sh.ar = in.ar;
+      sh.rax = in.ar + sh.xf - shl1(sh.xf);
+      sh.arj = UNI ? in.ar : ar_3;
+      sh.cxj = (UNI && COURANT) ? cxj_uni : cx_3;
+      sh.ray = sh.arj + yf_prev - sh.yf;
+      sh.rrax = vrecip(sh.rax);
+      sh.rray = vrecip(sh.ray);
+      if constexpr (!UNI) { ar_3 = ar_2; ar_2 = ar_1; ar_1 = in.ar; }
+      if constexpr (!(UNI && COURANT)) { cx_3 = cx_2; cx_2 = cx_1; cx_1 = sh.cx; }
+      vd fxd, fyd0, fyd1, fxw(0.), fyw0(0.), fyw1(0.), fxp, fyp0, fyp1;
+      fd.step(in.dp, sh, true, true, fxd, fyd0, fyd1);
+      if (NH) fw.step(in.w, sh, true, true, fxw, fyw0, fyw1);
+      fp.step(in.pt, sh, true, true, fxp, fyp0, fyp1);
+      // mass flux through y-face r-2 (tp_core.F90:222-226); carried to the next row as its south face
+      const vd fym = fyd1 * sh.yf;
+      {
+        const bool on = j >= jA && j >= oJ0 && j <= oJ1;
+        const vd fxm = fxd * xfj;  // tp_core.F90:217-221
+        const vd fym0 = fym_prev, fym1 = fym;
+        const long iFX = (long)g.iFX(ilo, jc), iFY0 = (long)g.iFY(ilo, jc), iA = (long)g.iA(ilo, jc), iCC = (long)g.iCC(ilo, jc);
+        vstore_b(mfx, iFX, mfx_o + fxm, mOF, on);
+        vstore_b(mfy, iFY0, mfy_o + fym0, mO, on);
+        const vd dp = fd.ya.row_m3();
+        const vd dpn = dp + (fxm - shl1(fxm) + fym0 - fym1) * in.ra;
+        vstore_b_nt(a.delp_out + oA, iA, dpn, mO, on);
+        const vd rdpn = vrecip(dpn);
+        {  // pt (sw_core.F90:1053-1066)
+          const vd gx = fxp * fxm, gy0 = fyp0 * fym0, gy1 = fyp1 * fym1;
+          vstore_b_nt(a.pt_out + oA, iA, vdiv_r(fp.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra, dpn, rdpn), mO, on);
+        }
+        vd hs(0.), de(0.);   // :943-948
+        if (NH) {  // w (:985-989, :1262-1274)
+          const vd gx = fxw * fxm, gy0 = fyw0 * fym0, gy1 = fyw1 * fym1;
+          vd wn = vdiv_r(fw.ya.row_m3() * dp + (gx - shl1(gx) + gy0 - gy1) * in.ra, dpn, rdpn);
+          if constexpr (UNI) {
+            if (wdamp) {  // rows j-1, j, j+1 of w are rows r-4, r-3, r-2 of the window (no memory operation in this branch)
+              const vd w0 = fw.ya.q1;
+              const vd d2m = damp4 * fw.ya.q0, d20 = damp4 * w0, d2p = damp4 * fw.ya.q2;
+              const vd fx2 = g.c_del6_v * (shr1(d20) - d20);
+              const vd dw = (fx2 - shl1(fx2) + g.c_del6_u * (d2m - d20) - g.c_del6_u * (d20 - d2p)) * in.ra;
+              const vd tmp = dw * (w0 + 0.5 * dw);   // 0.5 * [(w + dw)**2 - w**2]
+              hs = g.prevent_diss_cooling ? dd8 - vmin(vd(0.), tmp) : dd8 - tmp;
+              if (g.do_diss_est) de = dd8 - tmp;
+              wn = wn + dw;
+            }
+          }
+          vstore_b_nt(a.w_out + oA, iA, wn, mO, on);
+        }
+        vstore_b_nt(a.heat_s + oCC, iCC, hs, mC, on);
+        vstore_b_nt(a.diss_e + oCC, iCC, de, mC, on);
+      }
+      fym_prev = fym;
+      yf_prev = sh.yf;
+    }
+    // the north face of the tile's north row: the last step (face je + 1) left its mass flux in fym_prev
+    if (seg_last && g.je >= oJ0 && g.je <= oJ1) vaccum(mfy, (long)g.iFY(ilo, g.je + 1), fym_prev, oC0, oC1);
+  }
+
+  FV3_D void run_general(int gid) const {
     int strip, seg, kk;
     md.decode(gid, strip, seg, kk);
     const int k = md.klist ? md.klist[kk] : kk;
@@ -314,6 +529,184 @@ struct DswMomentumFused {
   };
 
   FV3_D void operator()(int gid) const {
+    if constexpr (FV3_BF)
+      run_bf(gid);
+    else
+      run_general(gid);
+  }
+
+  // ---- the row step without control flow (see DswTransportFused::run_bf) -------------------------------------------------------------------
+  FV3_D void run_bf(int gid) const {
+    int strip, seg, kk, tjw;
+    md.decode_tj(gid, strip, seg, kk, tjw);
+    const int k = md.klist ? md.klist[kk] : kk;
+    const StripGeom s = make_strip(g, strip);
+    const int ilo = s.ilo;
+    const int jA = g.js + seg * tjw;
+    const int jB = (jA + tjw - 1 < g.je) ? jA + tjw - 1 : g.je;
+    const int rlast = jB + 3;
+    const int lFx1 = (ilo + s.lC1 == g.ie) ? s.lC1 + 1 : s.lC1;
+    const double *u = a.u + (size_t)k * g.nU(), *v = a.v + (size_t)k * g.nV();
+    const double *uc = a.uc + (size_t)k * g.nV(), *vc = a.vc + (size_t)k * g.nU();
+    const double *dv = a.divg_d + (size_t)k * g.nB();
+    const double *crx = a.crx + (size_t)k * g.nCX(), *xfx = a.xfx + (size_t)k * g.nCX();
+    const double *cry = a.cry + (size_t)k * g.nCY(), *yfx = a.yfx + (size_t)k * g.nCY();
+    double *uo = a.u_out + (size_t)k * g.nU(), *vo = a.v_out + (size_t)k * g.nV();
+    double *dpc = a.delpc ? a.delpc + (size_t)k * g.nA() : nullptr;
+    const double dt5 = 0.5 * a.dt;
+    const int mw = CS ? a.mask_w : 0;
+    const int oC0 = (CS && mw) ? (s.lC0 > mw + 1 - ilo ? s.lC0 : mw + 1 - ilo) : s.lC0;
+    const int oC1 = (CS && mw) ? (s.lC1 < g.npx - mw - 1 - ilo ? s.lC1 : g.npx - mw - 1 - ilo) : s.lC1;
+    const int oF1 = (CS && mw) ? (lFx1 < g.npx - mw - 1 - ilo ? lFx1 : g.npx - mw - 1 - ilo) : lFx1;
+    const int oJ0 = (CS && mw) ? mw + 1 : g.jsd, oJ1 = (CS && mw) ? g.npy - mw - 1 : g.jed + 1;
+    const double d2_bg = a.lv.d2_divg[k];
+    const double damp2 = g.da_min_c * dmax(d2_bg, dmin(0.20, a.dddmp * 0.));            // :1454 with vort = 0
+    const double dd8 = g.stretched_grid ? g.da_min * ipow(a.d4_bg, 2) : ipow(g.da_min_c * a.d4_bg, 2);  // :1446-1450
+    const vm mO = make_mask(oC0, oC1), mOF = make_mask(oC0, oF1);
+    // a sponge level (dyn_core.F90:703-724: nord_k = 0): the del-2 divergence damping, with the divergence formed from the D-grid winds
+    // (sw_core.F90:1290-1371) -- on an orthogonal, uniform grid ptc = u * dyc and vort = v * dxc exactly (cosa = 0, sina = 1)
+    const bool nord0 = UNI && a.lv.nord_k[k] == 0;
+
+    auto load_in = [&](int r) {
+      In in;
+      const long oU1 = (long)g.iU(ilo, r + 1), oV = (long)g.iV(ilo, r), oA = (long)g.iA(ilo, r);
+      in.u1 = vload(u, oU1, s.A);
+      in.v0 = vload(v, oV, s.A);
+      in.v1 = vload(v, oV + 1, s.A);  // V kind has the extra column ied+1
+      in.f0 = vload(g.f0, oA, s.A);
+      if constexpr (UNI) {
+        in.dx1 = vd(g.c_dx);  in.dy0 = in.dy1 = vd(g.c_dy);
+        in.ra = vd(g.c_rarea);  in.ar = vd(g.c_area);
+      } else {
+        in.dx1 = vload(g.dx, oU1, s.A);
+        in.dy0 = vload(g.dy, oV, s.A);  in.dy1 = vload(g.dy, oV + 1, s.A);
+        in.ra = vload(g.rarea, oA, s.A);
+        in.ar = vload(g.area, oA, s.A);
+      }
+      const long oCX = (long)g.iCX(ilo, r);
+      in.cx = vload(crx, oCX, s.F);
+      in.xf = vload(xfx, oCX, s.F);
+      const int jf = (r - 2 < jA) ? jA : r - 2;
+      const long oCY = (long)g.iCY(ilo, jf);
+      in.cy = vload(cry, oCY, s.A);
+      in.yf = vload(yfx, oCY, s.A);
+      const int jc = (r - 2 < jA - 1) ? jA - 1 : r - 2;
+      const long oUc = (long)g.iU(ilo, jc), oVc = (long)g.iV(ilo, jc), oBc = (long)g.iB(ilo, jc);
+      in.vc = vload(vc, oUc, s.A);
+      in.uc = vload(uc, oVc, s.A);
+      in.ukc = vload(u, oUc, s.A);
+      in.dv = vload(dv, (long)g.iB(ilo, jc + 1), s.A);
+      if constexpr (UNI) {
+        in.rdy = vd(g.c_rdy);  in.rdx = vd(g.c_rdx);
+        in.dgu = vd(g.c_divg_u);  in.dgv = vd(g.c_divg_v);  in.rac = vd(g.c_rarea_c);
+      } else {
+        in.rdy = vload(g.rdy, oVc, s.A);
+        in.rdx = vload(g.rdx, oUc, s.A);
+        in.dgu = vload(g.divg_u, oUc, s.A);
+        in.dgv = vload(g.divg_v, oVc, s.A);
+        in.rac = vload(g.rarea_c, oBc, s.A);
+      }
+      return in;
+    };
+
+    Tp2dState<HORD, UNI> st;
+    st.init();
+    PpmYsw<SWC> yv;
+    yv.init();
+    vd vtdx_n(0.);
+    vd uc_p(0.), rdy_p(0.), dgv_p(0.), d_m(0.), d_0(0.);
+    vd ke_p(0.), yf_p(0.), fyv1_last(0.);
+    {
+      const long oU = (long)g.iU(ilo, jA - 3);
+      vtdx_n = vload(u, oU, s.A) * (UNI ? vd(g.c_dx) : vload(g.dx, oU, s.A));
+      d_0 = vload(dv, (long)g.iB(ilo, jA - 1), s.A);
+    }
+    In nxt = load_in(jA - 3);
+    vdrain_loads();
+    for (int r = jA - 3; r <= rlast; r++) {
+      const In in = nxt;
+      const int j = r - 3, jc = r - 2;
+      const int jw = j >= jA ? j : jA;
+      const long oUj = (long)g.iU(ilo, jw), oVj = (long)g.iV(ilo, jw);
+      const vd u_j = vload(u, oUj, s.A), dx_j = UNI ? vd(g.c_dx) : vload(g.dx, oUj, s.A);
+      const vd v_j = vload(v, oVj, s.A), dy_j = UNI ? vd(g.c_dy) : vload(g.dy, oVj, s.A);
+      const vd xf_j = vload(xfx, (long)g.iCX(ilo, jw), s.F);
+      nxt = load_in(r < rlast ? r + 1 : rlast);
+      // ---- absolute vorticity of row r (sw_core.F90:1231-1247, :1476-1495) -> fv_tp_2d march ---------------------------
+      const vd vt0 = vtdx_n, vt1 = in.u1 * in.dx1, ut0 = in.v0 * in.dy0, ut1 = in.v1 * in.dy1;
+      MarchIn mi;
+      mi.qn = in.ra * (vt0 - vt1 - ut0 + ut1) + in.f0;
+      mi.ar = in.ar; mi.cx = in.cx; mi.xf = in.xf; mi.cy = in.cy; mi.yf = in.yf;
+      vd fxv, fyv0, fyv1;
+      st.step(mi, true, true, fxv, fyv0, fyv1);
+      // ---- KE flux + divergence damping at corner row jc (:1078-1198, :1372-1460) -----------------------------------------
+      yv.push(in.v0);
+      vd ke(0.);
+      {
+        const int jcc = jc < jA ? jA : jc;   // the row of the metric loads / the dropped store of the warm-up steps
+        vd vb = dt5 * (shr1(in.vc) + in.vc);                               // :1129
+        vd ub2 = dt5 * (uc_p + in.uc);                                     // :1186
+        if constexpr (CS) {  // the interior of a cubed-sphere face (grid_type < 3): :1104-1106, :1168-1170
+          const int jr = jcc > g.je + 1 ? g.je + 1 : jcc;
+          const vd cosa = vload(g.cosa, (long)g.iB(ilo, jr), s.A);
+          const vd rsina = vload(a.rsina, (long)(jr - g.js) * (g.nx + 1) + (ilo - g.is), s.F);
+          const vd vs = shr1(in.vc) + in.vc, us = uc_p + in.uc;
+          vb = dt5 * (vs - us * cosa) * rsina;
+          ub2 = dt5 * (us - vs * cosa) * rsina;
+        }
+        const vd ub = yv.face(vb, UNI ? in.rdy : rdy_p, in.rdy);           // ytp_v :1134
+        const vd kev = vb * ub;                                            // :1139
+        const vd vb2 = ppm_faces_x_sw<SWC>(in.ukc, ub2, in.rdx);           // xtp_u :1191
+        ke = 0.5 * (kev + ub2 * vb2);                                      // :1196
+        const vd vc2 = (shl1(d_0) - d_0) * in.dgu;                         // :1392-1396
+        const vd uc2m = (d_0 - d_m) * (UNI ? in.dgv : dgv_p);              // :1399-1403
+        const vd uc2 = (in.dv - d_0) * in.dgv;
+        vd lap = uc2m - uc2 + shr1(vc2) - vc2;                             // :1406-1424
+        if (!g.stretched_grid) lap = lap * in.rac;
+        vd dsave = d_0;                                                    // delpc = saved divergence (:1376-1381)
+        if constexpr (UNI) {
+          if (nord0) {  // v(jc-1), v(jc) are rows r-3, r-2 of the window of ytp_v; u(jc) was loaded for xtp_u
+            const vd ptc = in.ukc * g.c_dyc;
+            dsave = g.c_rarea_c * (yv.q1 * g.c_dxc - yv.q2 * g.c_dxc + shr1(ptc) - ptc);          // :1355-1366
+            const vd damp = g.da_min_c * vmax(vd(d2_bg), vmin(vd(0.20), a.dddmp * vabs(dsave * a.dt)));
+            ke = ke + damp * dsave;                                        // :1367-1369
+          } else {
+            ke = ke + (damp2 * d_0 + dd8 * lap);                           // :1455
+          }
+        } else {
+          ke = ke + (damp2 * d_0 + dd8 * lap);
+        }
+        const bool on = dpc && jc >= jA && (jc <= jB || jc == g.je + 1) && jc >= oJ0 && jc <= oJ1;
+        vstore_b(dpc ? dpc : uo, (long)g.iA(ilo, jcc), dsave, mOF, on);
+      }
+      // ---- D-grid wind update of row j (:1500-1509) ------------------------------------------------------------------------------
+      {
+        const bool on = j >= jA && j >= oJ0 && j <= oJ1;
+        const vd ke0 = ke_p, ke1 = ke;
+        const vd vtdx_j = u_j * dx_j, utdy_j = v_j * dy_j;
+        vstore_b(uo, oUj, vtdx_j + ke0 - shl1(ke0) + fyv0 * yf_p, mO, on);
+        vstore_b(vo, oVj, utdy_j + ke0 - ke1 - fxv * xf_j, mOF, on);
+      }
+      // ---- rotate ----------------------------------------------------------------------------------------------------------------------
+      vtdx_n = vt1;
+      if (r >= jA + 1) {  // the corner row loaded at this step was a real one (jA-1 or later)
+        uc_p = in.uc;
+        if constexpr (!UNI) { rdy_p = in.rdy; dgv_p = in.dgv; }
+        d_m = d_0; d_0 = in.dv;
+      }
+      ke_p = ke;
+      yf_p = in.yf;
+      fyv1_last = fyv1;
+    }
+    // the north edge row of u: the last step (corner row je + 1, face je + 1) left ke, yfx and the face value
+    if (jB == g.je && g.je >= oJ0 && g.je <= oJ1) {
+      const long oU1 = (long)g.iU(ilo, g.je + 1);
+      const vd dx_n = UNI ? vd(g.c_dx) : vload(g.dx, oU1, s.A);
+      vstore(uo, oU1, vload(u, oU1, s.A) * dx_n + ke_p - shl1(ke_p) + fyv1_last * yf_p, s.lC0, s.lC1);
+    }
+  }
+
+  FV3_D void run_general(int gid) const {
     int strip, seg, kk;
     md.decode(gid, strip, seg, kk);
     const int k = md.klist ? md.klist[kk] : kk;

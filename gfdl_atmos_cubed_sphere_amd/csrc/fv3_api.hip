@@ -59,7 +59,14 @@ struct fv3_ctx {
   int lane = 0;
   void *ev_mid = nullptr;
   bool side_ok;          // transport and momentum route the same levels to the tile kernels
+  // the two ways of dividing the levels between the marching and the LDS-tile kernels of d_sw: [0] strict (no damping branch in the
+  // marching kernels), [1] with the sponge levels of the reference defaults (nord_k = 0, nord_w = 0: dsw_fused.h run_bf) on the marching
+  // side -- the active one (klist, n_plain, ...) is chosen per d_sw call (lev_activate)
+  struct LevSel { int *klist, *klist_m; int n_plain, n_damp, n_plain_m, n_rest_m; bool side_ok; } lev_sel[2] = {};
   int use_side;          // FV3_MI355X_SIDE_STREAM=0 disables
+  int sponge_march;      // FV3_MI355X_SPONGE_MARCH=0: the sponge levels stay on the LDS-tile kernels
+  int round_simds;       // SIMDs of the device (CUs x 4): x wavefronts per SIMD of a kernel = the wavefronts resident at once
+                         // (balance_segments); FV3_MI355X_ROUND_SIMDS overrides, 0 = no balancing
   double *dev_metrics;   // one allocation holding every metric array
   bool grid_ready;
   // per-level d_sw coefficients on the device
@@ -145,7 +152,7 @@ struct fv3_ctx {
   int remap_lds;      // the remap with the column in LDS (remap_fast.h; bit-identical to the slab kernels) where it is built for the
                       // configuration (FV3_MI355X_REMAP_LDS: 0 / 1, default 1)
   int tj_fixed;          // an FV3_MI355X_MARCH_TJ* variable is set: take the rows per segment as given
-  int csw_kpw;           // levels per wavefront in CswMarch (1 .. 4; FV3_MI355X_CSW_KPW)
+  int csw_kpw;           // levels per wavefront in CswMarch (1 or 2; FV3_MI355X_CSW_KPW)
   int use_fused;         // 1: delp + w + pt in one marching kernel when the schemes allow (FV3_MI355X_FUSED=0: off)
   int use_march;         // 0: LDS-tile kernels only (FV3_MI355X_MARCH=0)
   bool prof_on;
@@ -530,6 +537,18 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     c->use_march = e ? std::atoi(e) : 1;
     e = std::getenv("FV3_MI355X_SIDE_STREAM");
     c->use_side = e ? std::atoi(e) : 1;
+    e = std::getenv("FV3_MI355X_SPONGE_MARCH");
+    c->sponge_march = e ? std::atoi(e) : 1;
+    c->round_simds = 0;
+#ifndef FV3_HOST_EMU
+    {
+      int dev = 0, ncu = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+        c->round_simds = 4 * ncu;
+    }
+#endif
+    e = std::getenv("FV3_MI355X_ROUND_SIMDS");
+    if (e) c->round_simds = std::atoi(e);
     c->tj_fixed = 0;
     for (const char *v : {"FV3_MI355X_MARCH_TJ", "FV3_MI355X_MARCH_TJ_FUSED", "FV3_MI355X_MARCH_TJ_MOM",
                           "FV3_MI355X_MARCH_TJ_KE", "FV3_MI355X_MARCH_TJ_CSW"})
@@ -539,7 +558,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     if (c->march_tj < 1) c->march_tj = 48;
     e = std::getenv("FV3_MI355X_CSW_KPW");
     c->csw_kpw = e ? std::atoi(e) : 0;   // 0 = by geometry mode (fv3_c_sw)
-    if (c->csw_kpw < 0 || c->csw_kpw > 4) c->csw_kpw = 0;
+    if (c->csw_kpw < 0 || c->csw_kpw > 2) c->csw_kpw = 0;   // (three and four levels per wavefront were measured in round 1 and never won)
     e = std::getenv("FV3_MI355X_FUSED");
     c->use_fused = e ? std::atoi(e) : 1;
     e = std::getenv("FV3_MI355X_MARCH_TJ_FUSED");
@@ -642,8 +661,10 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   if (c->ev_fork) rt_event_destroy(c->ev_fork);
   if (c->ev_join) rt_event_destroy(c->ev_join);
   if (c->ev_mid) rt_event_destroy(c->ev_mid);
-  if (c->klist) rt_free(c->klist);
-  if (c->klist_m) rt_free(c->klist_m);
+  for (auto &ls : c->lev_sel) {
+    if (ls.klist) rt_free(ls.klist);
+    if (ls.klist_m) rt_free(ls.klist_m);
+  }
   if (c->klist_z) rt_free(c->klist_z);
   if (c->ke_scr) rt_free(c->ke_scr);
   delete c;
@@ -833,6 +854,13 @@ extern "C" int fv3_grid_upload(fv3_ctx *c, const fv3_grid_host *h) {
 
 extern "C" int fv3_grid_geom(const fv3_ctx *c) { return (c && c->grid_ready) ? c->g.geom : -1; }
 
+static void lev_activate(fv3_ctx *c, int x) {
+  const fv3_ctx::LevSel &ls = c->lev_sel[x];
+  c->klist = ls.klist; c->n_plain = ls.n_plain; c->n_damp = ls.n_damp;
+  c->klist_m = ls.klist_m; c->n_plain_m = ls.n_plain_m; c->n_rest_m = ls.n_rest_m;
+  c->side_ok = ls.side_ok;
+}
+
 extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
   if (!c || !lv) return fail("fv3_dsw_levels_upload: null argument");
   const int npz = c->g.npz;
@@ -868,26 +896,32 @@ extern "C" int fv3_dsw_levels_upload(fv3_ctx *c, const fv3_dsw_levels *lv) {
     RT(rtf_sync(c->stream));
   }
   RT(rtf_sync(c->stream));
-  {
+  for (int x = 0; x < 2; x++) {
+    fv3_ctx::LevSel &ls = c->lev_sel[x];
     std::vector<int> plain, damped;
-    for (int k = 0; k < npz; k++)
-      ((lv->damp_vt[k] > 1.E-4 || lv->damp_w[k] > 1.E-5 || lv->damp_t[k] > 1.E-4) ? damped : plain).push_back(k);
-    c->n_plain = (int)plain.size();
-    c->n_damp = (int)damped.size();
+    for (int k = 0; k < npz; k++) {
+      const bool wd = lv->damp_w[k] > 1.E-5 && !(x == 1 && lv->nord_w[k] == 0);
+      ((lv->damp_vt[k] > 1.E-4 || wd || lv->damp_t[k] > 1.E-4) ? damped : plain).push_back(k);
+    }
+    ls.n_plain = (int)plain.size();
+    ls.n_damp = (int)damped.size();
     plain.insert(plain.end(), damped.begin(), damped.end());
-    if (!c->klist) RT(rt_malloc((void **)&c->klist, sizeof(int) * npz));
-    RT(rtf_h2d(c->klist, plain.data(), sizeof(int) * npz, c->stream));
+    if (!ls.klist) RT(rt_malloc((void **)&ls.klist, sizeof(int) * npz));
+    RT(rtf_h2d(ls.klist, plain.data(), sizeof(int) * npz, c->stream));
     std::vector<int> pm, rm;
-    for (int k = 0; k < npz; k++)
-      ((lv->nord_k[k] == 1 && !(lv->damp_vt[k] > 1.E-5) && !(lv->d_con_k[k] > 1.E-5)) ? pm : rm).push_back(k);
-    c->n_plain_m = (int)pm.size();
-    c->n_rest_m = (int)rm.size();
+    for (int k = 0; k < npz; k++) {
+      const bool nk = lv->nord_k[k] == 1 || (x == 1 && lv->nord_k[k] == 0);
+      ((nk && !(lv->damp_vt[k] > 1.E-5) && !(lv->d_con_k[k] > 1.E-5)) ? pm : rm).push_back(k);
+    }
+    ls.n_plain_m = (int)pm.size();
+    ls.n_rest_m = (int)rm.size();
     pm.insert(pm.end(), rm.begin(), rm.end());
-    c->side_ok = (rm == damped);
-    if (!c->klist_m) RT(rt_malloc((void **)&c->klist_m, sizeof(int) * npz));
-    RT(rtf_h2d(c->klist_m, pm.data(), sizeof(int) * npz, c->stream));
+    ls.side_ok = (rm == damped);
+    if (!ls.klist_m) RT(rt_malloc((void **)&ls.klist_m, sizeof(int) * npz));
+    RT(rtf_h2d(ls.klist_m, pm.data(), sizeof(int) * npz, c->stream));
     RT(rtf_sync(c->stream));
   }
+  lev_activate(c, 0);
   c->lev_max_nord = c->lev_max_nord_v = c->lev_max_nord_w = c->lev_max_nord_t = 0;
   c->lev_has_dcon = c->lev_has_vt_damp = c->lev_has_w_damp = c->lev_has_w_damp_hi = false;
   c->lev_has_damp_v4 = c->lev_has_damp_v5 = c->lev_has_damp_t = false;
@@ -1274,6 +1308,13 @@ extern "C" int fv3_fv_tp_2d(fv3_ctx *c, int nk, const double *q, const double *c
 // Rows per wavefront segment: the configured value, shortened on small domains so that a launch still has a few
 // thousand wavefronts (a wavefront marches tj + 6 rows one after the other: with too few of them the launch time is that
 // serial march, not throughput).  Never below 8 rows (the 6 warm-up rows of every segment are overhead).
+// FV3_MI355X_DEBUG_SEGMENTS=1: the segmentation every marching launch of the pair ended up with, on stderr
+static void seg_report(const char *who, const MarchDims &d, int nlev) {
+  static const int on = [] { const char *e = std::getenv("FV3_MI355X_DEBUG_SEGMENTS"); return e ? std::atoi(e) : 0; }();
+  if (on)
+    std::fprintf(stderr, "[fv3 segments] %s: %d level slots x %d strips x %d segments of %d rows; first %d slots: %d segments of %d rows\n", who, nlev,
+                 d.nstrips, d.nsegs, d.tj, d.alt_nk, d.alt_ng, d.alt_tj);
+}
 static int seg_rows(const fv3_ctx *c, int tj_conf, int nlev_slots) {
   const Grid &g = c->g;
   if (c->tj_fixed) return tj_conf;
@@ -1326,17 +1367,17 @@ static int csw_march(fv3_ctx *c, const CswArgs &ca) {
     MarchDims md = make_csw_dims(c->g, seg_rows(c, tj_csw, c->g.npz));
     // uniform metrics: nothing to share between levels, one level per wavefront at four wavefronts per SIMD is faster
     int kpw = c->csw_kpw ? c->csw_kpw : (c->g.geom == 2 ? 1 : 2);
-    if (ca.mask_w > 0 && kpw > 2) kpw = 2;   // the cubed-sphere instantiations: one or two levels per wavefront
     const int nkg = (c->g.npz + kpw - 1) / kpw;
+    if (c->g.geom == 2 && kpw == 1 && !c->tj_fixed && ca.mask_w == 0)   // whole rounds of the chip at four wavefronts per SIMD
+      balance_segments(md, nkg, c->g.ny + 4, 4 * c->round_simds, md.tj);
     const int nw = md.nwaves(nkg);
+    seg_report("c_sw", md, nkg);
     if (ca.mask_w > 0) {  // the interior of a cubed-sphere face: general metrics + the cubed switches
       if (kpw == 1) return launch_w(c, "c_sw", nw, CswMarch<1, 0, true>{c->g, ca, md, nkg});
       return launch_w(c, "c_sw", nw, CswMarch<2, 0, true>{c->g, ca, md, nkg});
     }
     auto go = [&](auto GMc) -> int {
       constexpr int GM = decltype(GMc)::value;
-      if (kpw == 4) return launch_w(c, "c_sw", nw, CswMarch<4, GM>{c->g, ca, md, nkg});
-      if (kpw == 3) return launch_w(c, "c_sw", nw, CswMarch<3, GM>{c->g, ca, md, nkg});
       if (kpw == 2) return launch_w(c, "c_sw", nw, CswMarch<2, GM>{c->g, ca, md, nkg});
       return launch_w(c, "c_sw", nw, CswMarch<1, GM>{c->g, ca, md, nkg});
     };
@@ -1403,7 +1444,11 @@ static int dsw_transport_march(fv3_ctx *c, const DswArgs &a, int region = 0) {
     auto box = [&](int s0, int ns, int g0, int ng) -> int {
       if (ns <= 0 || ng <= 0) return 0;
       mf.set_box(s0, ns, g0, ng);
+      // the whole grid in one launch of the branch-free kernel (two wavefronts per SIMD): whole rounds of the chip
+      if (FV3_BF && s0 == 0 && ns == NS && g0 == 0 && ng == NG && !c->tj_fixed && a.mask_w == 0)
+        balance_segments(mf, c->n_plain, g.ny, 2 * c->round_simds, mf.tj);
       const int nwf = mf.nwaves(c->n_plain);
+      seg_report("d_sw_fused", mf, c->n_plain);
       return dispatch_hord(a.hord_dp, [&](auto H) {
         constexpr int HORD = decltype(H)::value;
         if (g.geom == 2) {
@@ -1455,7 +1500,9 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
   if (fused_m) {
     MarchDims mf = make_march_dims(g, seg_rows(c, c->march_tj_mom, g.npz));
     mf.klist = c->klist_m;
+    if (FV3_BF && !c->tj_fixed && a.mask_w == 0) balance_segments(mf, c->n_plain_m, g.ny, 2 * c->round_simds, mf.tj);
     const int nwf = mf.nwaves(c->n_plain_m);
+    seg_report("d_sw_mom_fused", mf, c->n_plain_m);
     return dispatch_hord(a.hord_vt, [&](auto H) {
       constexpr int HORD = decltype(H)::value;
       if (g.geom == 2) {
@@ -1910,6 +1957,7 @@ static int d_sw_impl(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const d
   a.q_con_out = q_con_out; a.heat_s = heat_s; a.diss_e = diss_e; a.delpc = delpc;
 
   if (is_cubed(c)) {
+    lev_activate(c, 0);
     if (phase == 1) return 0;  // no interior / rest split on a face: everything runs in 'rest' (or the unsplit call)
     return dsw_cubed(c, a);
   }
@@ -1920,6 +1968,8 @@ static int d_sw_impl(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const d
   const bool march = c->use_march != 0;
   // marching momentum: no Smagorinsky coefficient, no dissipation estimate (level conditions in klist_m)
   const bool march_m = march && a.dddmp < 1.E-5 && !g.do_diss_est;
+  // the sponge levels on the marching kernels: their branch-free forms with uniform metrics, both halves of d_sw marching
+  lev_activate(c, (FV3_BF && c->sponge_march && g.geom == 2 && fused && march_m) ? 1 : 0);
 
   auto courant = [&]() -> int {  // Courant numbers and area fluxes of the levels the fused kernel does not take
     if (fused && c->n_damp == 0) return 0;

@@ -167,6 +167,29 @@ inline void vaccum(double *p, long off, const vd &x, int lmin, int lmax) {
   for (int l = 0; l < kW; l++)
     if (l >= lmin && l <= lmax) p[off + l] = p[off + l] + x.v[l];
 }
+// ---- branch-free rows (see the device section): a uniform row pointer, stores with a lane mask in the offset,
+// an accumulation that adds zero on the lanes outside the mask
+inline const double *urow(const double *p) { return p; }
+inline double *urow(double *p) { return p; }
+struct vm {
+  int lmin, lmax;
+};
+inline vm make_mask(int lmin, int lmax) { return vm{lmin, lmax}; }
+inline void vdrain_loads() {}
+inline void vstore_b(double *p, long off, const vd &x, const vm &m, bool on = true) {
+  if (on) vstore(p, off, x, m.lmin, m.lmax);
+}
+inline void vstore_b_nt(double *p, long off, const vd &x, const vm &m, bool on = true) {
+  if (on) vstore(p, off, x, m.lmin, m.lmax);
+}
+inline void vaccum_z(double *p, long off, const vd &x, const vl &, const vm &m, bool on = true) {
+  if (on) vaccum(p, off, x, m.lmin, m.lmax);
+}
+inline vb vball(bool b) {   // a wave-uniform condition as a lane predicate
+  vb r;
+  for (int l = 0; l < kW; l++) r.v[l] = b;
+  return r;
+}
 // predicate: lane in [l0, l1]
 inline vb lane_mask(int l0, int l1) {
   vb r;
@@ -199,14 +222,34 @@ __device__ __forceinline__ vd shl1(vd a) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(a), 0x130, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
-using vl = unsigned;  // clamped lane index as a byte offset
+// clamped lane index as a byte offset.  `mutable`: vload passes the offset through an empty asm statement in place (see urow) -- the
+// value never changes, but the optimizer may not hoist its 64-bit zero-extension out of the row loop
+struct vl {
+  mutable unsigned v;
+};
 __device__ __forceinline__ vl make_lanes(int lmin, int lmax) {
   const int l = (int)(threadIdx.x & (kW - 1));
-  return (unsigned)(l < lmin ? lmin : (l > lmax ? lmax : l)) * 8u;
+  return vl{(unsigned)(l < lmin ? lmin : (l > lmax ? lmax : l)) * 8u};
+}
+// urow: the uniform row pointer made opaque to the optimizer (see "branch-free rows" below)
+typedef const double __attribute__((address_space(1))) *fv3_gcptr;   // global address space: the laundered pointer must not decay to a flat one
+typedef double __attribute__((address_space(1))) *fv3_gptr;
+typedef const char __attribute__((address_space(1))) *fv3_gcbytes;
+typedef char __attribute__((address_space(1))) *fv3_gbytes;
+__device__ __forceinline__ fv3_gcptr urow(const double *p) {
+  fv3_gcptr q = (fv3_gcptr)p;
+  asm("" : "+s"(q));
+  return q;
+}
+__device__ __forceinline__ fv3_gptr urow(double *p) {
+  fv3_gptr q = (fv3_gptr)p;
+  asm("" : "+s"(q));
+  return q;
 }
 // uniform base (SGPR pair) + per-lane unsigned 32-bit byte offset: global_load_dwordx2 v, v_off, s[base]
-__device__ __forceinline__ vd vload(const double *p, long off, vl li) {
-  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(p + off) + li);
+__device__ __forceinline__ vd vload(const double *p, long off, const vl &li) {
+  asm volatile("" : "+v"(li.v));  // keeps the zero-extension of the lane offset next to its use (a hoisted 64-bit copy defeats the saddr form)
+  return *(fv3_gcptr)((fv3_gcbytes)urow(p + off) + li.v);
 }
 __device__ __forceinline__ void vstore(double *p, long off, vd x, int lmin, int lmax) {
   const int l = (int)(threadIdx.x & (kW - 1));
@@ -243,9 +286,58 @@ __device__ __forceinline__ void vstore_nt(double *p, long off, vd x, int lmin, i
   const int l = (int)(threadIdx.x & (kW - 1));
   if (l >= lmin && l <= lmax) __builtin_nontemporal_store(x, p + off + l);
 }
+// ---- branch-free rows ------------------------------------------------------------------------------------------------------------
+// A marching kernel whose row step contains no control flow lets the compiler count the memory operations in flight: the wait for the
+// prefetched rows of the next step becomes s_waitcnt vmcnt(<stores of this step>) instead of vmcnt(0), i.e. the wavefront no longer waits
+// for its own stores / atomics to be acknowledged before it may compute (measured: the fused transport kernel without its stores runs
+// 28 % faster than with them, at 0.98x algorithmic traffic).  `if (lane in range) store` always keeps a branch (the compiler skips
+// memory instructions under an empty EXEC), so the lane masks go where the hardware takes them without EXEC:
+//  * urow(p): the uniform row pointer, opaque to the optimizer, so that loads / atomics keep the form
+//    `global_load_dwordx2 v, v_lane_off, s[row:row+1]` (otherwise the loop-invariant part base + lane is hoisted into a VGPR pair per array
+//    and every access pays a 64-bit VALU add);
+//  * vm / vstore_b: stores through a buffer resource over the row; a lane outside the mask carries the byte offset 0x80000000, beyond
+//    num_records, and the hardware drops its store (tools/probe/buf_oob.hip: the range check takes voffset + soffset against num_records);
+//  * vaccum_z: the L2 accumulation with the address clamped to valid elements and +0.0 on the lanes outside the mask (x + 0.0 == x for
+//    every x that is not -0.0, and an accumulator that starts at +0.0 never becomes -0.0).
+using vm = unsigned;  // byte offset of the lane, or 0x80000000 = masked
+__device__ __forceinline__ vm make_mask(int lmin, int lmax) {
+  const int l = (int)(threadIdx.x & (kW - 1));
+  return (l >= lmin && l <= lmax) ? (unsigned)l * 8u : 0x80000000u;
+}
+typedef unsigned fv3_u2 __attribute__((ext_vector_type(2)));
+// the resource covers the 64 lanes of ONE row (num_records = 512 bytes from the row pointer): it is rebuilt from the uniform row pointer
+// at every store -- two scalar moves beside the pointer arithmetic a global store needs as well -- instead of holding four SGPRs per
+// array for the whole loop (nine output arrays would not fit and spill into VGPR lanes)
+// Before a branch-free row loop: every load issued so far has returned.  The compiler merges the memory operations pending on the two
+// ways into the loop header; with the first row's loads still in flight on the way in, the header's wait would be the one of that
+// way -- vmcnt(<loads>), which on the back edge means "all but the youngest stores done" -- whatever the back edge allows.
+// (the two empty statements keep the loads above the wait and the loop's below it: the wait alone does not order them)
+__device__ __forceinline__ void vdrain_loads() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) expcnt(7) lgkmcnt(15)
+  asm volatile("" ::: "memory");
+}
+// `on` (wave-uniform): a row condition; off = num_records 0, every lane out of range -- a scalar select, no branch
+// (readfirstlane: the record count must be a scalar whatever the optimizer made of the condition -- a resource with a VGPR word costs a
+// waterfall loop per store)
+__device__ __forceinline__ void vstore_b(double *p, long off, vd x, vm m, bool on = true) {
+  const int nrec = __builtin_amdgcn_readfirstlane(on ? kW * 8 : 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fv3_u2, x), __builtin_amdgcn_make_buffer_rsrc(p + off, 0, nrec, 0x00020000), (int)m, 0, 0);
+}
+__device__ __forceinline__ void vstore_b_nt(double *p, long off, vd x, vm m, bool on = true) {
+  const int nrec = __builtin_amdgcn_readfirstlane(on ? kW * 8 : 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fv3_u2, x), __builtin_amdgcn_make_buffer_rsrc(p + off, 0, nrec, 0x00020000), (int)m, 0, 2);  // aux bit 1 = nt
+}
+// p + off must be a valid row whatever `on` says (the lanes add +0.0 then)
+__device__ __forceinline__ void vaccum_z(double *p, long off, vd x, const vl &clamp, vm m, bool on = true) {
+  asm volatile("" : "+v"(clamp.v));
+  const bool off_lane = (m & 0x80000000u) || !on;
+  unsafeAtomicAdd((double *)(fv3_gptr)((fv3_gbytes)urow(p + off) + clamp.v), off_lane ? 0. : x);
+}
 #endif
 
 #ifndef FV3_HOST_EMU
+__device__ __forceinline__ vb vball(bool b) { return b; }
 __device__ __forceinline__ vb lane_mask(int l0, int l1) {
   const int l = (int)(threadIdx.x & (kW - 1));
   return l >= l0 && l <= l1;

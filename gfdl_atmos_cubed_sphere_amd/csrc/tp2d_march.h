@@ -61,12 +61,38 @@ struct MarchDims {
   // segments that do not touch the halo while the halo exchange is still in flight, and the frame afterwards
   int s0, ns, g0, ng;
   int frame;         // 1: the launch covers the frame of the whole grid around its interior box instead of a box
+  // Whole rounds of the chip (balance_segments below): the first alt_nk level slots are cut into alt_ng segments of alt_tj rows instead
+  // of nsegs segments of tj rows, so that the launch has a few wavefronts less than a whole number of rounds of the resident wavefronts
+  // instead of a few more (a last round that fills 1 % of the chip costs a third of a round).  Whole-grid launches only.
+  int alt_nk, alt_ng, alt_tj;
   FV3_HD void set_box(int s0_, int ns_, int g0_, int ng_) { s0 = s0_; ns = ns_; g0 = g0_; ng = ng_; frame = 0; }
   FV3_HD void set_frame() { s0 = 0; ns = nstrips; g0 = 0; ng = nsegs; frame = 1; }
   FV3_HD int ncells() const { return frame ? nstrips * nsegs - (nstrips - 2) * (nsegs - 2) : ns * ng; }
   FV3_HD int nwaves(int npz) {
     nk = npz;
-    return ncells() * npz;
+    if (alt_nk > npz) alt_nk = npz;
+    if (frame || ns != nstrips || ng != nsegs || k_fast) alt_nk = 0;
+    return ncells() * npz - alt_nk * nstrips * (nsegs - alt_ng);
+  }
+  // decode + the rows per segment of this wavefront
+  FV3_HD void decode_tj(int gid, int &strip, int &seg, int &kk, int &tjw) const {
+    tjw = tj;
+    if (alt_nk > 0) {
+      const int w1 = alt_nk * nstrips * alt_ng;
+      if (gid < w1) {
+        strip = gid % nstrips;
+        seg = (gid / nstrips) % alt_ng;
+        kk = gid / (nstrips * alt_ng);
+        tjw = alt_tj;
+        return;
+      }
+      gid -= w1;
+      strip = gid % nstrips;
+      seg = (gid / nstrips) % nsegs;
+      kk = alt_nk + gid / (nstrips * nsegs);
+      return;
+    }
+    decode(gid, strip, seg, kk);
   }
   // t-th cell of the frame: south row, north row, then the west and east columns between them
   FV3_HD void frame_cell(int t, int &strip, int &seg) const {
@@ -113,8 +139,48 @@ inline MarchDims make_march_dims(const Grid &g, int tj) {
   d.k_fast = march_k_fast();
   d.nstrips = num_strips(g);
   d.nsegs = (g.ny + tj - 1) / tj;
+  d.alt_nk = d.alt_ng = d.alt_tj = 0;
   d.set_box(0, d.nstrips, 0, d.nsegs);
   return d;
+}
+
+// Segments for a launch of nlev level slots over `rows` rows that fills whole rounds of the chip.  round_waves = the wavefronts resident at
+// once (CUs x SIMDs x wavefronts per SIMD of the kernel), tj_conf = the configured rows per segment, warm = the warm-up steps of a segment.
+// Cost model, from the headline kernels (tools/probe/tj_sweep.py): a wavefront costs its row steps, whole rounds cost a round each, a last
+// round filled to the fraction x costs 0.3 + 0.7 x of one.  Candidates: S segments for every level, or S for most and S - 1 for the first
+// L levels with L chosen so that the total lands 0.5 % under a whole number of rounds.
+inline void balance_segments(MarchDims &d, int nlev, int rows, int round_waves, int tj_conf, int warm = 6) {
+  d.alt_nk = 0;
+  if (nlev <= 0 || round_waves <= 0) return;
+  const int S0 = (rows + tj_conf - 1) / tj_conf;
+  double best = 1e300;
+  int bS = S0, bL = 0;
+  for (int S = (S0 > 3 ? S0 - 2 : 1); S <= S0 + 2; S++) {
+    const int tjS = (rows + S - 1) / S;
+    if ((rows + tjS - 1) / tjS != S) continue;   // S segments of ceil(rows / S) rows must be S segments
+    const double total = (double)nlev * d.nstrips * S, r = total / round_waves;
+    const double whole = (double)(long)r, frac = r - whole;
+    const double plain = (whole + (frac > 0. ? 0.3 + 0.7 * frac : 0.)) * (tjS + warm);
+    if (plain < best) { best = plain; bS = S; bL = 0; }
+    if (S > 1 && whole >= 1. && frac > 0.) {
+      const int tjA = (rows + S - 2) / (S - 1);
+      if ((rows + tjA - 1) / tjA != S - 1) continue;
+      const double excess = total - whole * round_waves * 0.995;
+      const int L = (int)((excess + d.nstrips - 1) / d.nstrips);
+      if (L > 0 && 2 * L <= nlev) {
+        const double cost = whole * (tjS + warm) * (1. + (double)L / nlev * (double)(tjA - tjS) / (tjS + warm));
+        if (cost < best) { best = cost; bS = S; bL = L; }
+      }
+    }
+  }
+  d.tj = (rows + bS - 1) / bS;
+  d.nsegs = bS;
+  d.set_box(0, d.nstrips, 0, d.nsegs);
+  if (bL > 0) {
+    d.alt_nk = bL;
+    d.alt_ng = bS - 1;
+    d.alt_tj = (rows + bS - 2) / (bS - 1);
+  }
 }
 
 

@@ -307,3 +307,36 @@ def check_halo_packed(lib, nx=20, ny=12, nk=3):
             np.testing.assert_array_equal(f.download(), e, err_msg=kind)
     finally:
         ctx.close()
+
+
+def check_sponge_levels_march(lib, nx=130, ny=64, npz=4, hydrostatic=False, flags=None, par_over=None):
+    """Cartesian doubly periodic gridstruct, the reference's default level coefficients (levels 1, 2 = sponge: nord_k = 0, nord_w = 0,
+    damp_w = d2_divg, dyn_core.F90:703-724): d_sw against the oracle, AND no level left to the LDS-tile kernels -- the sponge levels run in
+    the branch-free marching kernels (dsw_fused.h run_bf) when the metrics are uniform."""
+    worst = check_d_sw(lib, nx=nx, ny=ny, npz=npz, perturb=False, hydrostatic=hydrostatic, flags=flags, par_over=par_over)
+    bd = Bounds(1, nx, 1, ny)
+    g = make_grid(bd, False)
+    for k, v in (flags or {}).items():
+        setattr(g, k, v)
+    par = dict(DSW_PAR)
+    par.update(par_over or {})
+    par["hydrostatic"], par["use_cond"] = int(hydrostatic), 0
+    st = smooth_state(bd, npz, hydrostatic=hydrostatic)
+    ctx = Context(g, npz, lib=lib)
+    try:
+        ctx.dsw_levels(default_levels(npz))
+        d = {k: ctx.from_host(v) for k, v in st.items()}
+        for n, kind in (("uc", "V"), ("vc", "U"), ("ua", "A"), ("va", "A"), ("divg_d", "B"), ("mfx", "FX"), ("mfy", "FY"), ("cx", "CX"), ("cy", "CY"),
+                        ("crx", "CX"), ("cry", "CY"), ("xfx", "CX"), ("yfx", "CY"), ("delp_out", "A"), ("pt_out", "A"), ("u_out", "U"),
+                        ("v_out", "V"), ("w_out", "A"), ("heat_s", "CC"), ("diss_e", "CC"), ("delpc", "A")):
+            d[n] = ctx.zeros(kind, npz)
+        ctx.profile(True)
+        ctx.d_sw(par, d["delpc"], d["delp"], d["pt"], d["u"], d["v"], d.get("w"), d["uc"], d["vc"], d["ua"], d["va"], d["divg_d"], d["mfx"],
+                 d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None, d["delp_out"], d["pt_out"], d["u_out"], d["v_out"],
+                 None if hydrostatic else d["w_out"], None, d["heat_s"], d["diss_e"])
+        rep = ctx.profile_report()
+        ctx.profile(False)
+    finally:
+        ctx.close()
+    assert "d_sw_fused" in rep and "d_sw_mom_fused" in rep, rep
+    return worst, rep

@@ -1229,3 +1229,32 @@ def test_fortran_fv_dynamics_reference_argument_list_with_the_energy_fixer_and_r
     if F.fortran_compiler() is None:
         pytest.skip("no amdflang in this environment")
     F.check_fortran_fv_dynamics(emu, tmp_path, **kw)
+
+
+@pytest.mark.parametrize("hydrostatic", [False, True])
+@pytest.mark.parametrize("flags", [None, dict(prevent_diss_cooling=False)])
+def test_sponge_levels_run_on_the_marching_kernels(emu, hydrostatic, flags, monkeypatch):
+    """levels 1, 2 of the default coefficients (del-2 damping of the divergence and of w, the heating of the latter) inside the branch-free
+    marching kernels on a uniform grid: the oracle's values, and no LDS-tile launch left"""
+    worst, rep = P.check_sponge_levels_march(emu, hydrostatic=hydrostatic, flags=flags)
+    assert not ({"d_sw_transport", "d_sw_momentum", "d_sw_courant"} & set(rep)), rep
+    # ... and the switch back to the tile kernels gives the same parity
+    monkeypatch.setenv("FV3_MI355X_SPONGE_MARCH", "0")
+    worst0, rep0 = P.check_sponge_levels_march(emu, hydrostatic=hydrostatic, flags=flags)
+    assert "d_sw_transport" in rep0 and "d_sw_momentum" in rep0, rep0
+
+
+def test_sponge_levels_march_smagorinsky_term(emu):
+    """dddmp > 0 keeps the nord = 1 levels off the marching momentum kernel; the sponge form carries the term (sw_core.F90:1367) -- checked
+    through the transport half, which still marches its sponge levels"""
+    P.check_d_sw(emu, nx=70, ny=30, npz=4, perturb=False, par_over=dict(dddmp=0.2))
+
+
+def test_mixed_segmentation_of_the_marching_launches(emu, monkeypatch):
+    """balance_segments (tp2d_march.h): the first levels of a launch cut into one segment less than the others, so that the launch fills
+    whole rounds of the chip.  FV3_MI355X_ROUND_SIMDS=5 makes that happen at test size in c_sw, the fused transport and the fused momentum
+    kernel (70 x 60 x 9: the first 4 level slots in 5 segments, the others in 6); the oracle's values either way"""
+    monkeypatch.setenv("FV3_MI355X_ROUND_SIMDS", "5")
+    P.check_c_sw(emu, nx=70, ny=60, npz=9, perturb=False)
+    P.check_d_sw(emu, nx=70, ny=60, npz=9, perturb=False)
+    P.check_d_sw(emu, nx=70, ny=60, npz=9, perturb=False, hydrostatic=True)
