@@ -16,6 +16,9 @@
 #ifndef FV3_BF
 #define FV3_BF 1
 #endif
+#ifndef FV3_MOM_3W
+#define FV3_MOM_3W 0
+#endif
 
 namespace fv3 {
 
@@ -292,8 +295,9 @@ struct DswTransportFused {
           }
           vstore_b_nt(a.w_out + oA, iA, wn, mO, on);
         }
-        vstore_b_nt(a.heat_s + oCC, iCC, hs, mC, on);
-        vstore_b_nt(a.diss_e + oCC, iCC, de, mC, on);
+        // (NULL: the caller does not read them -- fv3_d_sw; the stores are dropped, their row pointer is any valid one)
+        vstore_b_nt((a.heat_s ? a.heat_s : a.delp_out) + oCC, iCC, hs, mC, on && a.heat_s != nullptr);
+        vstore_b_nt((a.diss_e ? a.diss_e : a.delp_out) + oCC, iCC, de, mC, on && a.diss_e != nullptr);
       }
       fym_prev = fym;
       yf_prev = sh.yf;
@@ -518,6 +522,8 @@ struct DswMomentumFused {
   // two wavefronts per SIMD: 254 VGPRs with the general metric rows (the row-j values of the wind update are re-read at
   // the top of the step instead of being carried for three steps), 188 with uniform metrics; measured 0.735 -> 0.57 -> 0.49 ms
   static constexpr int kTwoWavesPerSimd = 1;
+  // uniform metrics, branch-free form: 179 VGPRs -- three wavefronts per SIMD at 168 cost 13 spilled registers (8 scratch accesses per row step)
+  static constexpr int kThreeWavesPerSimd = (UNI && !CS && FV3_BF) ? FV3_MOM_3W : 0;
   Grid g;
   DswArgs a;
   MarchDims md;
@@ -553,7 +559,7 @@ struct DswMomentumFused {
     const double *cry = a.cry + (size_t)k * g.nCY(), *yfx = a.yfx + (size_t)k * g.nCY();
     double *uo = a.u_out + (size_t)k * g.nU(), *vo = a.v_out + (size_t)k * g.nV();
     double *dpc = a.delpc ? a.delpc + (size_t)k * g.nA() : nullptr;
-    const double dt5 = 0.5 * a.dt;
+    const double dt5 = 0.5 * a.dt, dt = a.dt;
     const int mw = CS ? a.mask_w : 0;
     const int oC0 = (CS && mw) ? (s.lC0 > mw + 1 - ilo ? s.lC0 : mw + 1 - ilo) : s.lC0;
     const int oC1 = (CS && mw) ? (s.lC1 < g.npx - mw - 1 - ilo ? s.lC1 : g.npx - mw - 1 - ilo) : s.lC1;
@@ -583,13 +589,20 @@ struct DswMomentumFused {
         in.ra = vload(g.rarea, oA, s.A);
         in.ar = vload(g.area, oA, s.A);
       }
-      const long oCX = (long)g.iCX(ilo, r);
-      in.cx = vload(crx, oCX, s.F);
-      in.xf = vload(xfx, oCX, s.F);
-      const int jf = (r - 2 < jA) ? jA : r - 2;
-      const long oCY = (long)g.iCY(ilo, jf);
-      in.cy = vload(cry, oCY, s.A);
-      in.yf = vload(yfx, oCY, s.A);
+      if constexpr (UNI) {
+        // uniform metrics: the Courant numbers / area fluxes are re-formed from uc, vc with the expressions of the transport kernel
+        // (crx = dt uc rdxa, xfx = dy dt uc, ...: bit for bit what it stored) -- uc of row r is the one new row, vc of face r-2 is the
+        // corner row's, uc of row r-3 the carried one: five row loads less per step
+        in.cx = vload(uc, (long)g.iV(ilo, r), s.A);
+      } else {
+        const long oCX = (long)g.iCX(ilo, r);
+        in.cx = vload(crx, oCX, s.F);
+        in.xf = vload(xfx, oCX, s.F);
+        const int jf = (r - 2 < jA) ? jA : r - 2;
+        const long oCY = (long)g.iCY(ilo, jf);
+        in.cy = vload(cry, oCY, s.A);
+        in.yf = vload(yfx, oCY, s.A);
+      }
       const int jc = (r - 2 < jA - 1) ? jA - 1 : r - 2;
       const long oUc = (long)g.iU(ilo, jc), oVc = (long)g.iV(ilo, jc), oBc = (long)g.iB(ilo, jc);
       in.vc = vload(vc, oUc, s.A);
@@ -630,13 +643,24 @@ struct DswMomentumFused {
       const long oUj = (long)g.iU(ilo, jw), oVj = (long)g.iV(ilo, jw);
       const vd u_j = vload(u, oUj, s.A), dx_j = UNI ? vd(g.c_dx) : vload(g.dx, oUj, s.A);
       const vd v_j = vload(v, oVj, s.A), dy_j = UNI ? vd(g.c_dy) : vload(g.dy, oVj, s.A);
-      const vd xf_j = vload(xfx, (long)g.iCX(ilo, jw), s.F);
+      vd xf_j;
+      if constexpr (UNI) xf_j = g.c_dy * (dt * uc_p);   // uc_p = uc of row r-3 once the pipeline is full
+      else xf_j = vload(xfx, (long)g.iCX(ilo, jw), s.F);
       nxt = load_in(r < rlast ? r + 1 : rlast);
       // ---- absolute vorticity of row r (sw_core.F90:1231-1247, :1476-1495) -> fv_tp_2d march ---------------------------
       const vd vt0 = vtdx_n, vt1 = in.u1 * in.dx1, ut0 = in.v0 * in.dy0, ut1 = in.v1 * in.dy1;
       MarchIn mi;
       mi.qn = in.ra * (vt0 - vt1 - ut0 + ut1) + in.f0;
-      mi.ar = in.ar; mi.cx = in.cx; mi.xf = in.xf; mi.cy = in.cy; mi.yf = in.yf;
+      mi.ar = in.ar;
+      vd yf_r = in.yf;
+      if constexpr (UNI) {
+        const vd x = dt * in.cx, y = dt * in.vc;   // sw_core.F90:865-900 as in DswTransportFused
+        mi.cx = x * g.c_rdxa; mi.xf = g.c_dy * x;
+        mi.cy = y * g.c_rdya; mi.yf = g.c_dx * y;
+        yf_r = mi.yf;
+      } else {
+        mi.cx = in.cx; mi.xf = in.xf; mi.cy = in.cy; mi.yf = in.yf;
+      }
       vd fxv, fyv0, fyv1;
       st.step(mi, true, true, fxv, fyv0, fyv1);
       // ---- KE flux + divergence damping at corner row jc (:1078-1198, :1372-1460) -----------------------------------------
@@ -695,7 +719,7 @@ struct DswMomentumFused {
         d_m = d_0; d_0 = in.dv;
       }
       ke_p = ke;
-      yf_p = in.yf;
+      yf_p = yf_r;
       fyv1_last = fyv1;
     }
     // the north edge row of u: the last step (corner row je + 1, face je + 1) left ke, yfx and the face value

@@ -133,6 +133,7 @@ struct fv3_ctx {
   bool lev_has_vt_damp, lev_has_w_damp, lev_has_w_damp_hi;  // damp_vt / damp_t; damp_w > 1e-5; the latter with nord_w > 0
   double *ke_scr;        // B kind, npz levels: KE + damping term at the corners
   double *mflux[2];      // mass-flux scratch of the marching transports: FX kind, FY kind (npz levels)
+  double *heat_scr[2];   // heat_s / diss_e of a d_sw call whose caller passed NULL and whose levels are not all on the branch-free kernels
   // cubed sphere (grid_type < 3): edge weights / corner factors and the work arrays of the pass kernels (B x (npz+1) each)
   CubedGeom cg;
   double *cg_dev;
@@ -524,6 +525,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->klist_m = nullptr; c->n_plain_m = c->n_rest_m = 0; c->ke_scr = nullptr;
   c->klist_z = nullptr; c->n_plain_z = c->n_damp_z = 0;
   c->mflux[0] = c->mflux[1] = nullptr;
+  c->heat_scr[0] = c->heat_scr[1] = nullptr;
   std::memset(&c->cg, 0, sizeof c->cg);
   c->cg_dev = nullptr;
   for (auto &p : c->cs_scr) p = nullptr;
@@ -667,6 +669,7 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   }
   if (c->klist_z) rt_free(c->klist_z);
   if (c->ke_scr) rt_free(c->ke_scr);
+  for (double *h : c->heat_scr) if (h) rt_free(h);
   delete c;
   return 0;
 }
@@ -1500,7 +1503,8 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
   if (fused_m) {
     MarchDims mf = make_march_dims(g, seg_rows(c, c->march_tj_mom, g.npz));
     mf.klist = c->klist_m;
-    if (FV3_BF && !c->tj_fixed && a.mask_w == 0) balance_segments(mf, c->n_plain_m, g.ny, 2 * c->round_simds, mf.tj);
+    if (FV3_BF && !c->tj_fixed && a.mask_w == 0)
+      balance_segments(mf, c->n_plain_m, g.ny, ((g.geom == 2 && FV3_MOM_3W) ? 3 : 2) * c->round_simds, mf.tj);
     const int nwf = mf.nwaves(c->n_plain_m);
     seg_report("d_sw_mom_fused", mf, c->n_plain_m);
     return dispatch_hord(a.hord_vt, [&](auto H) {
@@ -1959,6 +1963,12 @@ static int d_sw_impl(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const d
   if (is_cubed(c)) {
     lev_activate(c, 0);
     if (phase == 1) return 0;  // no interior / rest split on a face: everything runs in 'rest' (or the unsplit call)
+    if (!a.heat_s || !a.diss_e) {
+      for (int n = 0; n < 2; n++)
+        if (!c->heat_scr[n]) RT(rt_malloc((void **)&c->heat_scr[n], sizeof(double) * g.nCC() * npz));
+      if (!a.heat_s) a.heat_s = c->heat_scr[0];
+      if (!a.diss_e) a.diss_e = c->heat_scr[1];
+    }
     return dsw_cubed(c, a);
   }
   // the fused marching kernel forms the Courant numbers itself for its levels
@@ -1970,6 +1980,16 @@ static int d_sw_impl(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const d
   const bool march_m = march && a.dddmp < 1.E-5 && !g.do_diss_est;
   // the sponge levels on the marching kernels: their branch-free forms with uniform metrics, both halves of d_sw marching
   lev_activate(c, (FV3_BF && c->sponge_march && g.geom == 2 && fused && march_m) ? 1 : 0);
+  // heat_s, diss_e = NULL: the caller does not read them (dyn_core.F90:798-812 reads them when d_con > 1e-5 or do_diss_est; in the
+  // reference they are 2-D work arrays private to a level).  The branch-free marching kernels then do not store them; every other kernel
+  // writes (and the damped levels' momentum kernels read) real arrays, the context's own
+  const bool all_bf = FV3_BF && fused && march_m && c->n_damp == 0 && c->n_rest_m == 0;
+  if ((!a.heat_s || !a.diss_e) && !all_bf) {
+    for (int n = 0; n < 2; n++)
+      if (!c->heat_scr[n]) RT(rt_malloc((void **)&c->heat_scr[n], sizeof(double) * g.nCC() * npz));
+    if (!a.heat_s) a.heat_s = c->heat_scr[0];
+    if (!a.diss_e) a.diss_e = c->heat_scr[1];
+  }
 
   auto courant = [&]() -> int {  // Courant numbers and area fluxes of the levels the fused kernel does not take
     if (fused && c->n_damp == 0) return 0;

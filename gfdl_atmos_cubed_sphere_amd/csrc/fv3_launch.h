@@ -217,6 +217,16 @@ __global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int gid = __builtin_amdgcn_readfirstlane(wave_index(chunk));
   if (gid < nwaves) f(gid);
 }
+// ... and of three (<= 168 VGPRs): `static constexpr int kThreeWavesPerSimd = 1;`
+template <class F>
+__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(3, 3))) wave_kernel_3w(const F f, int nwaves, int chunk) {
+  const int gid = __builtin_amdgcn_readfirstlane(wave_index(chunk));
+  if (gid < nwaves) f(gid);
+}
+template <class F, class = void>
+struct wants_three_waves : std::false_type {};
+template <class F>
+struct wants_three_waves<F, std::enable_if_t<(F::kThreeWavesPerSimd > 0)>> : std::true_type {};
 template <class F, class = void>
 struct wants_two_waves : std::false_type {};
 template <class F>
@@ -231,7 +241,9 @@ inline int launch_waves(int nwaves, stream_t s, const F &f) {
     nblocks = chunk * kXcds;
   }
   const dim3 grid((unsigned)nblocks);
-  if constexpr (wants_two_waves<F>::value)
+  if constexpr (wants_three_waves<F>::value)
+    hipLaunchKernelGGL(wave_kernel_3w<F>, grid, dim3(kNT), 0, s, f, nwaves, chunk);
+  else if constexpr (wants_two_waves<F>::value)
     hipLaunchKernelGGL(wave_kernel_2w<F>, grid, dim3(kNT), 0, s, f, nwaves, chunk);
   else
     hipLaunchKernelGGL(wave_kernel<F>, grid, dim3(kNT), 0, s, f, nwaves, chunk);
@@ -284,6 +296,11 @@ __global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(2, 2))
   if (gid < nwaves) fg.at((int)blockIdx.y)(gid);
 }
 template <class F>
+__global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(3, 3))) wave_kernel_3w_g(const FGroup<F> fg, int nwaves, int chunk) {
+  const int gid = __builtin_amdgcn_readfirstlane(wave_index(chunk));
+  if (gid < nwaves) fg.at((int)blockIdx.y)(gid);
+}
+template <class F>
 inline void fgroup_fill(FGroup<F> &fg, const F *const *fs, int n) {
   static_assert(std::is_trivially_copyable<F>::value, "kernel functors are plain data");
   for (int m = 0; m < kGrpMax; m++) std::memcpy((void *)(fg.raw + (size_t)m * sizeof(F)), (const void *)fs[m < n ? m : 0], sizeof(F));
@@ -319,7 +336,9 @@ inline int launch_group(Dim3 grid, size_t lds_doubles, int a, stream_t s, const 
       nblocks = chunk * kXcds;
     }
     const dim3 hw((unsigned)nblocks, (unsigned)n);
-    if constexpr (wants_two_waves<F>::value)
+    if constexpr (wants_three_waves<F>::value)
+      hipLaunchKernelGGL(wave_kernel_3w_g<F>, hw, dim3(kNT), 0, s, fg, a, chunk);
+    else if constexpr (wants_two_waves<F>::value)
       hipLaunchKernelGGL(wave_kernel_2w_g<F>, hw, dim3(kNT), 0, s, fg, a, chunk);
     else
       hipLaunchKernelGGL(wave_kernel_g<F>, hw, dim3(kNT), 0, s, fg, a, chunk);

@@ -222,7 +222,7 @@ class DynCore:
             mfx, mfy = self._inline_q_fluxes() if inline else (d["mfx"], d["mfy"])
             dsw_args = (par, d["vt"], d["delp"], d["pt"], d["u"], d["v"], None, d["uc"], d["vc"], d["ua"], d["va"],
                         d["divgd"], mfx, mfy, d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
-                        d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], None, None, d["heat_s"], d["diss_e"])
+                        d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], None, None, d["heat_s"] if heating else None, None)   # (read only when d_con > 1e-5, :798-812)
             if halo.overlaps:      # :565 / :578 (pack 9) around the interior of d_sw (:762), as in the nonhydrostatic loop
                 pending = halo.start([(d["uc"], "V"), (d["vc"], "U")], defer=True)
                 ctx.d_sw(*dsw_args, phase="interior")
@@ -313,7 +313,7 @@ class DynCore:
                         d["divgd"], mfx, mfy, d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"],
                         d["q_con"] if fl.use_cond else None,
                         d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], d["w_nxt"],
-                        d["q_con_nxt"] if fl.use_cond else None, d["heat_s"], d["diss_e"])
+                        d["q_con_nxt"] if fl.use_cond else None, d["heat_s"] if heating else None, None)   # (read only when d_con > 1e-5, :798-812)
             if halo.overlaps:
                 pending = halo.start([(d["uc"], "V"), (d["vc"], "U")], defer=True)
                 ctx.d_sw(*dsw_args, phase="interior")

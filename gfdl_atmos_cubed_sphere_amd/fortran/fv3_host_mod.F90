@@ -456,7 +456,7 @@ contains
     integer :: it, n_split, npz
     logical :: remap_step
     integer(c_int) :: last_call, use_logp
-    type(c_ptr) :: ctx, fxp, fyp, qcp, qcn, dv2n
+    type(c_ptr) :: ctx, fxp, fyp, qcp, qcn, dv2n, hsp
     logical :: heating
     integer :: n_con
     if (at%fl%hydrostatic) then
@@ -504,9 +504,11 @@ contains
       if (at%fl%use_cond) then
         qcp = at%q_con; qcn = at%q_con_n
       end if
+      hsp = c_null_ptr                      ! heat_s is read only when d_con > 1e-5 (:798-803); diss_e never by this host
+      if (heating) hsp = at%heat_s
       call fv3_check(fv3_d_sw(ctx, par, at%vt, at%delp, at%pt, at%u, at%v, at%w, at%uc, at%vc, at%ua, at%va, at%divgd, &
                               fxp, fyp, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, qcp, &
-                              at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, qcn, at%heat_s, at%diss_e), 'd_sw')  ! :762
+                              at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, qcn, hsp, c_null_ptr), 'd_sw')  ! :762
       if (heating) call fv3_check(fv3_heat_source_accum(ctx, at%heat_source, at%heat_s), 'heat_source_accum')   ! :798-803
       call inline_q_end(at)
       ! beta < -0.1: the external-mode damping field of one_grad_p (:1030) from the delp before d_sw and d_sw's divergence (:745-747, :791-848)

@@ -402,7 +402,7 @@ class Context:
         self.lib.check(getattr(self.lib.dll, fn)(self.h, C.byref(pr), _pp(delpc), delp.p, pt.p, u.p, v.p, _pp(w), uc.p,
                                                  vc.p, ua.p, va.p, divg_d.p, mfx.p, mfy.p, cx.p, cy.p, crx.p, cry.p,
                                                  xfx.p, yfx.p, _pp(q_con), delp_out.p, pt_out.p, u_out.p, v_out.p,
-                                                 _pp(w_out), _pp(q_con_out), heat_s.p, diss_e.p), fn)
+                                                 _pp(w_out), _pp(q_con_out), _pp(heat_s), _pp(diss_e)), fn)
 
     def profile(self, enable: bool):
         self.lib.check(self.lib.dll.fv3_profile(self.h, C.c_int(int(enable))), "fv3_profile")

@@ -166,8 +166,9 @@ int fv3_dsw_levels_upload(fv3_ctx *ctx, const fv3_dsw_levels *lv);
  * out   : crx, xfx (CX), cry, yfx (CY); delp_out, pt_out, w_out, q_con_out (A, compute domain);
  *         u_out (U, is:ie x js:je+1), v_out (V, is:ie+1 x js:je) -- still scaled by dx, dy exactly as
  *         the reference leaves them (sw_core.F90:1233,1502); heat_s, diss_e (CC, the per-call 2-D
- *         heat_source / diss_est of sw_core.F90:521-522, stacked in k); delpc (A, the saved
- *         divergence on is:ie+1 x js:je+1; may be NULL).
+ *         heat_source / diss_est of sw_core.F90:521-522, stacked in k; either may be NULL when the caller
+ *         does not read it -- dyn_core.F90:798-812 does when d_con > 1e-5 or do_diss_est); delpc (A, the
+ *         saved divergence on is:ie+1 x js:je+1; may be NULL).
  * The reference's clobbering of uc, vc, divg_d as scratch (sw_core.F90:1394-1408) is not reproduced:
  * those arrays are left unchanged. */
 int fv3_d_sw(fv3_ctx *ctx, const fv3_dsw_params *p, double *delpc, const double *delp, const double *pt,
