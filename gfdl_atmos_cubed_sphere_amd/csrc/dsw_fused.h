@@ -194,9 +194,6 @@ struct DswTransportFused {
       // the flux capacitors cx, cy, mfx, mfy (sw_core.F90:923-940) as load - add - store: every element has one owner (strip, segment),
       // and the old value is read at the top of the step that stores the sum.  (As L2 atomics -- no register for the old value -- the
       // four accumulations cost 0.23 ms of the kernel's 0.90: global_atomic_add_f64 is the slowest thing a row step can do.)
-      const vd cx_o = COURANT ? vload(a.cx + oCX, (long)g.iCX(ilo, r), s.F) : vd(0.);
-      const vd cy_o = COURANT ? vload(a.cy + oCY, (long)g.iCY(ilo, jfc), s.A) : vd(0.);
-      const vd mfx_o = vload(mfx, (long)g.iFX(ilo, jc), s.F), mfy_o = vload(mfy, (long)g.iFY(ilo, jc), s.C);
       nxt = load_in(r < rlast ? r + 1 : rlast);
       Tp2dShared sh;
       vd xfj = in.xfj, cxj_uni(0.);
@@ -216,7 +213,9 @@ struct DswTransportFused {
           const long iCX = (long)g.iCX(ilo, r);
           vstore_b_nt(crx, iCX, sh.cx, mCX, on);
           vstore_b_nt(xfx, iCX, sh.xf, mCX, on);
-          vstore_b(a.cx + oCX, iCX, cx_o + sh.cx, mCX, on);
+          // the flux capacitors cx, cy, mfx, mfy (sw_core.F90:923-940) stay L2 atomics under a lane mask: measured on one set of arrays
+          // (tools/pair_ab2.py) 0.765 ms against 0.792 as load - add - store and 1.12 as unmasked atomics adding +0.0 on the masked lanes
+          if (on) vaccum(a.cx + oCX, iCX, sh.cx, s.lC0, lFx1);
         }
         // y faces of row r-2 (:894-900, :933-936)
         const vd y = dt * in.cy;
@@ -233,7 +232,7 @@ struct DswTransportFused {
           const long iCY = (long)g.iCY(ilo, jfc);
           vstore_b_nt(cry, iCY, sh.cy, mCY, on);
           vstore_b_nt(yfx, iCY, sh.yf, mCY, on);
-          vstore_b(a.cy + oCY, iCY, cy_o + sh.cy, mCY, on);
+          if (on) vaccum(a.cy + oCY, iCY, sh.cy, lY0, lY1);
         }
         if constexpr (UNI) {  // crx, xfx of row r-3 from its uc again (same expressions as at step r-3): no 3-row windows
           const vd xj = dt * in.ucj;
@@ -267,8 +266,8 @@ struct DswTransportFused {
         const vd fxm = fxd * xfj;  // tp_core.F90:217-221
         const vd fym0 = fym_prev, fym1 = fym;
         const long iFX = (long)g.iFX(ilo, jc), iFY0 = (long)g.iFY(ilo, jc), iA = (long)g.iA(ilo, jc), iCC = (long)g.iCC(ilo, jc);
-        vstore_b(mfx, iFX, mfx_o + fxm, mOF, on);
-        vstore_b(mfy, iFY0, mfy_o + fym0, mO, on);
+        if (on) vaccum(mfx, iFX, fxm, oC0, oF1);
+        if (on) vaccum(mfy, iFY0, fym0, oC0, oC1);
         const vd dp = fd.ya.row_m3();
         const vd dpn = dp + (fxm - shl1(fxm) + fym0 - fym1) * in.ra;
         vstore_b_nt(a.delp_out + oA, iA, dpn, mO, on);

@@ -1315,7 +1315,7 @@ extern "C" int fv3_fv_tp_2d(fv3_ctx *c, int nk, const double *q, const double *c
 static void seg_report(const char *who, const MarchDims &d, int nlev) {
   static const int on = [] { const char *e = std::getenv("FV3_MI355X_DEBUG_SEGMENTS"); return e ? std::atoi(e) : 0; }();
   if (on)
-    std::fprintf(stderr, "[fv3 segments] %s: %d level slots x %d strips x %d segments of %d rows; first %d slots: %d segments of %d rows\n", who, nlev,
+    std::fprintf(stderr, "[fv3 segments] %s: %d level slots x %d strips x %d segments of %d rows; %d of the slots (spread evenly): %d segments of %d rows\n", who, nlev,
                  d.nstrips, d.nsegs, d.tj, d.alt_nk, d.alt_ng, d.alt_tj);
 }
 static int seg_rows(const fv3_ctx *c, int tj_conf, int nlev_slots) {

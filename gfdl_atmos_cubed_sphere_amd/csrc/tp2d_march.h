@@ -61,35 +61,40 @@ struct MarchDims {
   // segments that do not touch the halo while the halo exchange is still in flight, and the frame afterwards
   int s0, ns, g0, ng;
   int frame;         // 1: the launch covers the frame of the whole grid around its interior box instead of a box
-  // Whole rounds of the chip (balance_segments below): the first alt_nk level slots are cut into alt_ng segments of alt_tj rows instead
+  // Whole rounds of the chip (balance_segments below): alt_nk of the level slots are cut into alt_ng segments of alt_tj rows instead
   // of nsegs segments of tj rows, so that the launch has a few wavefronts less than a whole number of rounds of the resident wavefronts
   // instead of a few more (a last round that fills 1 % of the chip costs a third of a round).  Whole-grid launches only.
   int alt_nk, alt_ng, alt_tj;
   FV3_HD void set_box(int s0_, int ns_, int g0_, int ng_) { s0 = s0_; ns = ns_; g0 = g0_; ng = ng_; frame = 0; }
   FV3_HD void set_frame() { s0 = 0; ns = nstrips; g0 = 0; ng = nsegs; frame = 1; }
   FV3_HD int ncells() const { return frame ? nstrips * nsegs - (nstrips - 2) * (nsegs - 2) : ns * ng; }
+  // wavefronts of the level slots below kk: the alt_nk slots with one segment less are spread evenly over the nk slots (slot k is one of
+  // them when floor((k + 1) alt_nk / nk) > floor(k alt_nk / nk)) -- the XCDs take contiguous ranges of wavefront indices (wave_index), and
+  // the longer wavefronts must not all land on one of them (measured: all on XCD 0 = +10 % for the whole launch)
+  FV3_HD int alt_before(int kk) const { return (int)(((long)kk * alt_nk) / nk); }
+  FV3_HD int waves_before(int kk) const { return nstrips * (kk * nsegs - alt_before(kk) * (nsegs - alt_ng)); }
   FV3_HD int nwaves(int npz) {
     nk = npz;
     if (alt_nk > npz) alt_nk = npz;
     if (frame || ns != nstrips || ng != nsegs || k_fast) alt_nk = 0;
-    return ncells() * npz - alt_nk * nstrips * (nsegs - alt_ng);
+    if (alt_nk > 0) return waves_before(npz);
+    return ncells() * npz;
   }
   // decode + the rows per segment of this wavefront
   FV3_HD void decode_tj(int gid, int &strip, int &seg, int &kk, int &tjw) const {
     tjw = tj;
     if (alt_nk > 0) {
-      const int w1 = alt_nk * nstrips * alt_ng;
-      if (gid < w1) {
-        strip = gid % nstrips;
-        seg = (gid / nstrips) % alt_ng;
-        kk = gid / (nstrips * alt_ng);
-        tjw = alt_tj;
-        return;
+      int lo = 0, hi = nk;   // the last slot whose first wavefront is <= gid
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (waves_before(mid) <= gid) lo = mid; else hi = mid;
       }
-      gid -= w1;
-      strip = gid % nstrips;
-      seg = (gid / nstrips) % nsegs;
-      kk = alt_nk + gid / (nstrips * nsegs);
+      kk = lo;
+      const int r = gid - waves_before(kk);
+      const bool alt = alt_before(kk + 1) > alt_before(kk);
+      if (alt) tjw = alt_tj;
+      strip = r % nstrips;
+      seg = r / nstrips;
       return;
     }
     decode(gid, strip, seg, kk);
@@ -144,45 +149,32 @@ inline MarchDims make_march_dims(const Grid &g, int tj) {
   return d;
 }
 
-// Segments for a launch of nlev level slots over `rows` rows that fills whole rounds of the chip.  round_waves = the wavefronts resident at
-// once (CUs x SIMDs x wavefronts per SIMD of the kernel), tj_conf = the configured rows per segment, warm = the warm-up steps of a segment.
-// Cost model, from the headline kernels (tools/probe/tj_sweep.py): a wavefront costs its row steps, whole rounds cost a round each, a last
-// round filled to the fraction x costs 0.3 + 0.7 x of one.  Candidates: S segments for every level, or S for most and S - 1 for the first
-// L levels with L chosen so that the total lands 0.5 % under a whole number of rounds.
-inline void balance_segments(MarchDims &d, int nlev, int rows, int round_waves, int tj_conf, int warm = 6) {
+// Segments for a launch of nlev level slots over `rows` rows that does not end in a nearly empty round of the chip.  round_waves = the
+// wavefronts resident at once (CUs x SIMDs x wavefronts per SIMD of the kernel), tj_conf = the configured rows per segment.
+// The segments get equal lengths (S = ceil(rows / tj_conf) segments of ceil(rows / S) rows: no 4-row last segment); and when the launch
+// would have a few wavefronts more than a whole number of rounds -- 127 levels x 7 strips x 7 segments = 6223 = 3 x 2048 + 79: measured
+// +12 % for 1.6 % more work than 125 levels, tools/pair_ab2.py -- the first L level slots are cut into S - 1 segments, L chosen so that
+// the total lands just under the whole rounds.  (Other segment counts were measured and lose: fewer, longer segments put the wavefronts
+// of a SIMD in lockstep -- two rounds of 83- and 102-row wavefronts are 9 % slower than three of 61.)
+inline void balance_segments(MarchDims &d, int nlev, int rows, int round_waves, int tj_conf) {
   d.alt_nk = 0;
-  if (nlev <= 0 || round_waves <= 0) return;
-  const int S0 = (rows + tj_conf - 1) / tj_conf;
-  double best = 1e300;
-  int bS = S0, bL = 0;
-  for (int S = (S0 > 3 ? S0 - 2 : 1); S <= S0 + 2; S++) {
-    const int tjS = (rows + S - 1) / S;
-    if ((rows + tjS - 1) / tjS != S) continue;   // S segments of ceil(rows / S) rows must be S segments
-    const double total = (double)nlev * d.nstrips * S, r = total / round_waves;
-    const double whole = (double)(long)r, frac = r - whole;
-    const double plain = (whole + (frac > 0. ? 0.3 + 0.7 * frac : 0.)) * (tjS + warm);
-    if (plain < best) { best = plain; bS = S; bL = 0; }
-    if (S > 1 && whole >= 1. && frac > 0.) {
-      const int tjA = (rows + S - 2) / (S - 1);
-      if ((rows + tjA - 1) / tjA != S - 1) continue;
-      const double excess = total - whole * round_waves * 0.995;
-      const int L = (int)((excess + d.nstrips - 1) / d.nstrips);
-      if (L > 0 && 2 * L <= nlev) {
-        const double cost = whole * (tjS + warm) * (1. + (double)L / nlev * (double)(tjA - tjS) / (tjS + warm));
-        if (cost < best) { best = cost; bS = S; bL = L; }
-      }
-    }
-  }
-  d.tj = (rows + bS - 1) / bS;
-  d.nsegs = bS;
+  const int S = (rows + tj_conf - 1) / tj_conf;
+  d.tj = (rows + S - 1) / S;
+  d.nsegs = (rows + d.tj - 1) / d.tj;
   d.set_box(0, d.nstrips, 0, d.nsegs);
-  if (bL > 0) {
-    d.alt_nk = bL;
-    d.alt_ng = bS - 1;
-    d.alt_tj = (rows + bS - 2) / (bS - 1);
-  }
+  if (nlev <= 0 || round_waves <= 0 || d.nsegs < 2) return;
+  const long total = (long)nlev * d.nstrips * d.nsegs;
+  const long whole = total / round_waves, excess = total - whole * round_waves;
+  if (whole < 1 || excess == 0 || excess * 4 > round_waves) return;   // the last round is at least a quarter full: leave it
+  const int tjA = (rows + d.nsegs - 2) / (d.nsegs - 1);
+  if ((rows + tjA - 1) / tjA != d.nsegs - 1) return;
+  const long margin = round_waves / 64;   // a little room: the alt wavefronts run longer
+  const int L = (int)((excess + margin + d.nstrips - 1) / d.nstrips);
+  if (2 * L > nlev) return;
+  d.alt_nk = L;
+  d.alt_ng = d.nsegs - 1;
+  d.alt_tj = tjA;
 }
-
 
 // ra_x = area + xfx(i) - xfx(i+1) is formed on the fly (sw_core.F90:908-917); so is ra_y.
 struct MarchIn {

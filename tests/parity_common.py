@@ -340,3 +340,55 @@ def check_sponge_levels_march(lib, nx=130, ny=64, npz=4, hydrostatic=False, flag
         ctx.close()
     assert "d_sw_fused" in rep and "d_sw_mom_fused" in rep, rep
     return worst, rep
+
+
+def check_golden_ppm_through_fv_tp_2d(lib, iord, direction="x"):
+    """The reference-held vectors of the 1-D PPM operator (tests/golden/ppm1d_golden.npz: (q, c) -> face values, produced by executing
+    the reference's own docs/examples/tp_core.ipynb) THROUGH THE LIBRARY's fv_tp_2d -- no oracle in between.  Every vector of the scheme is
+    one level: a field that is uniform across the sweep direction on a unit Cartesian doubly periodic grid (area = 1), the other
+    direction's Courant numbers and area fluxes zero, this direction's area flux one.  Then the inner transverse update is the
+    identity (q * 1 + 0 - 0) / 1, inner and outer sweep see the same line (inner order == outer order for hord 5, -5, 6, 8:
+    tp_core.F90:136-141), 0.5 * (f + f) * 1 is f, and the flux that comes back IS the face value of xppm / yppm (tp_core.F90:324-1152)."""
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ppm1d_golden.npz"))
+    meta = [m for m in json.loads(str(z["meta"])) if m["iord"] == iord]
+    assert len(meta) == (36 if iord >= 8 else 24)
+    nl = z[meta[0]["key"] + "_q"].size            # cells along the sweep
+    nt, nk = 12, len(meta)                        # cells across it; one level per vector
+    nx, ny = (nl, nt) if direction == "x" else (nt, nl)
+    bd = Bounds(1, nx, 1, ny)
+    g = doubly_periodic(bd, nx + 1, ny + 1, dx_const=1.0, dy_const=1.0)
+    assert np.all(g.area == 1.0)
+    q = bd.zeros("A", nk)
+    crx, cry, xfx, yfx = bd.zeros("CX", nk), bd.zeros("CY", nk), bd.zeros("CX", nk), bd.zeros("CY", nk)
+    want = np.zeros((nl + 1, nk))
+    ng = bd.ng
+    for k, m in enumerate(meta):
+        ql, c, want[:, k] = z[m["key"] + "_q"], z[m["key"] + "_c"], z[m["key"] + "_flux"]
+        line = np.concatenate([ql[-ng:], ql, ql[:ng]])          # the periodic halo
+        if direction == "x":
+            q[:, :, k] = line[:, None]
+            crx[:, :, k] = c[:, None]
+            xfx[:, :, k] = 1.0
+        else:
+            q[:, :, k] = line[None, :]
+            cry[:, :, k] = c[None, :]
+            yfx[:, :, k] = 1.0
+    ctx = Context(g, nk, lib=lib)
+    try:
+        dfx, dfy = ctx.zeros("FX", nk), ctx.zeros("FY", nk)
+        ctx.fv_tp_2d(ctx.from_host(q), ctx.from_host(crx), ctx.from_host(cry), iord, dfx, dfy, ctx.from_host(xfx), ctx.from_host(yfx), nk=nk)
+        fx, fy = dfx.download(), dfy.download()
+    finally:
+        ctx.close()
+    got = fx if direction == "x" else fy               # (nl + 1, nt, nk) / (nt, nl + 1, nk)
+    other = fy if direction == "x" else fx
+    assert np.all(other == 0.0)                        # zero area flux across the sweep
+    worst = 0.0
+    for k in range(nk):
+        for t in range(nt):
+            f = got[:, t, k] if direction == "x" else got[t, :, k]
+            worst = max(worst, np.max(np.abs(f - want[:, k])) / max(1e-300, np.max(np.abs(want[:, k]))))
+    assert worst < 5e-15, (iord, direction, worst)     # observed: 0.0 -- the notebook's face values bit for bit
+    return worst

@@ -1339,9 +1339,17 @@ def test_sponge_levels_march_smagorinsky_term(prod):
 @pytest.mark.gpu
 def test_mixed_segmentation_of_the_marching_launches(prod, monkeypatch):
     """balance_segments (tp2d_march.h): the first levels of a launch cut into one segment less than the others, so that the launch fills
-    whole rounds of the chip.  FV3_MI355X_ROUND_SIMDS=5 makes that happen at test size in c_sw, the fused transport and the fused momentum
-    kernel (70 x 60 x 9: the first 4 level slots in 5 segments, the others in 6); the oracle's values either way"""
-    monkeypatch.setenv("FV3_MI355X_ROUND_SIMDS", "5")
+    whole rounds of the chip.  FV3_MI355X_ROUND_SIMDS=35 makes that happen at test size in c_sw, the fused transport and the fused momentum
+    kernel (70 x 60 x 9: the first 3 level slots in 7 segments, the others in 8); the oracle's values either way"""
+    monkeypatch.setenv("FV3_MI355X_ROUND_SIMDS", "35")
     P.check_c_sw(prod, nx=70, ny=60, npz=9, perturb=False)
     P.check_d_sw(prod, nx=70, ny=60, npz=9, perturb=False)
     P.check_d_sw(prod, nx=70, ny=60, npz=9, perturb=False, hydrostatic=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("direction", ["x", "y"])
+@pytest.mark.parametrize("iord", [5, -5, 6, 8])
+def test_golden_ppm_lines_through_fv_tp_2d(prod, iord, direction):
+    """the reference-held PPM vectors (tests/golden/, from the reference's own tp_core.ipynb) straight through the library's fv_tp_2d"""
+    P.check_golden_ppm_through_fv_tp_2d(prod, iord, direction)
