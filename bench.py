@@ -43,16 +43,20 @@ ALG = {
     "d_sw_momentum": (104.0, "rest_m"),
 }
 PAIR_ALG_BYTES = 336.0       # perfectly fused c_sw+d_sw, NH
+PAIR_ALG_BYTES_DCON0 = 320.0 # ... with d_con = 0 (the flags this bench runs): heat_source is neither read nor written (section 8d: "-16")
 # untimed passes before the profiled pass and the W warm-up steps (FV3_BENCH_SPINUP): the clocks of an idle MI355X take a few
 # hundred launches to settle
 SPINUP = int(os.environ.get("FV3_BENCH_SPINUP", "0"))
 
 
-def level_sets(lev):
-    """the level lists fv3_dsw_levels_upload forms (csrc/fv3_api.hip): which levels go to the marching kernels"""
+def level_sets(lev, sponge_march=False):
+    """the level lists fv3_dsw_levels_upload forms (csrc/fv3_api.hip): which levels go to the marching kernels.  sponge_march: the
+    selection d_sw activates with uniform metrics (lev_activate: the sponge levels' nord_k = 0 / nord_w = 0 forms are in the marching kernels)"""
     npz = len(lev["nord_k"])
-    damp = [k for k in range(npz) if lev["damp_vt"][k] > 1e-4 or lev["damp_w"][k] > 1e-5 or lev["damp_t"][k] > 1e-4]
-    rest_m = [k for k in range(npz) if not (lev["nord_k"][k] == 1 and not lev["damp_vt"][k] > 1e-5 and not lev["d_con_k"][k] > 1e-5)]
+    damp = [k for k in range(npz) if lev["damp_vt"][k] > 1e-4 or lev["damp_t"][k] > 1e-4 or
+            (lev["damp_w"][k] > 1e-5 and not (sponge_march and lev["nord_w"][k] == 0))]
+    rest_m = [k for k in range(npz) if not ((lev["nord_k"][k] == 1 or (sponge_march and lev["nord_k"][k] == 0)) and
+                                            not lev["damp_vt"][k] > 1e-5 and not lev["d_con_k"][k] > 1e-5)]
     return {"all": npz, "damp": len(damp), "plain": npz - len(damp), "rest_m": len(rest_m), "plain_m": npz - len(rest_m)}
 
 
@@ -291,7 +295,10 @@ def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=True
             "kernels_sum_ms": round(sum(v[1] for v in rep.values()), 2),
             "sypd": dt_atmos / (365.0 * wall), "wall_s_per_dt_atmos": wall, "dt_atmos_s": dt_atmos, "k_split": k_split,
             "n_split": n_split, "nq": nq, "dx_m": 26000.0, "finite": bool(np.isfinite(w).all()),
-            "note": f"one {nx}x{nx}x{npz} doubly periodic tile per GPU ({world} tile(s)); a C384 sphere is 6 such tiles, "
+            "note": f"NOT the C384 sphere: one {nx}x{nx}x{npz} doubly periodic tile per GPU ({world} tile(s)), uniform Cartesian metrics -- the "
+                    "SYPD a 6-GPU one-face-per-GPU run would have with these kernels and no cube-edge exchange; the C384 L127 sphere "
+                    "measured on ONE GPU is cubed_sphere.sphere_one_gpu (top level: c384_sphere_one_gpu_sypd); "
+                    f"one {nx}x{nx}x{npz} tile; a C384 sphere is 6 such tiles, "
                     "so this is the SYPD of a 6-GPU one-face-per-GPU run before cube-edge exchange cost",
             "kernels_ms_per_dt_atmos": {k: round(v[1], 3) for k, v in rep.items()}}
 
@@ -704,6 +711,7 @@ def main():
                         ("v_out", "V"), ("w_out", "A"), ("heat_s", "CC"), ("diss_e", "CC")):
             d[n] = ctx.zeros(kind, npz)
         ctx.dsw_levels(lev)
+        heating = bool(np.any(np.asarray(lev["d_con_k"]) > 1.0e-5))
         dt = 22.5   # C384 acoustic step: dt_atmos 225 s / k_split 2 / n_split 5
         par = dict(DSW_PAR)
         par.update(dt=dt, hydrostatic=0, use_cond=0, hord_mt=a.hord, hord_vt=a.hord, hord_tm=a.hord, hord_dp=a.hord)
@@ -713,7 +721,9 @@ def main():
                      d["va"], d["wc"], d["ut"], d["vt"], d["divg_d"], 1, 0.5 * dt, False)
             dsw_args = (par, None, d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"],
                         d["divg_d"], d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
-                        d["delp_out"], d["pt_out"], d["u_out"], d["v_out"], d["w_out"], None, d["heat_s"], d["diss_e"])
+                        d["delp_out"], d["pt_out"], d["u_out"], d["v_out"], d["w_out"], None,
+                        # d_con = 0, no do_diss_est: dyn_core reads neither (dyn_core.F90:798-812), the hosts pass NULL
+                        d["heat_s"] if heating else None, d["diss_e"] if heating else None)
             # start the exchange, run the part of d_sw that reads no halo while it is in flight, complete, do the rest
             if halo.overlaps:
                 pending = halo.start([(d["uc"], "V"), (d["vc"], "U"), (d["divg_d"], "B")], defer=True)
@@ -777,6 +787,7 @@ def main():
         # per-launch timing: in the profiled pass the sponge-level chain runs on the main stream instead of overlapping
         # the marching kernels on the side stream, so the sum of the launches can exceed the wall time of a step
         per_launch, t_sum = {}, 0.0
+        nlev = level_sets(lev, sponge_march=(geom == 2 and os.environ.get("FV3_MI355X_SPONGE_MARCH", "1") != "0"))
         for name, (n, ms) in rep.items():
             per_step = ms / nprof
             t_sum += per_step
@@ -807,7 +818,10 @@ def main():
                              # against the wall clock of the timed region (there the sponge-level tile kernels overlap the
                              # marching kernels on a side stream, so it can beat the sum of the launches)
                              "wall_ms": el / steps * 1e3,
-                             "frac_wall": cells * PAIR_ALG_BYTES / (el / steps) / HBM_PEAK}}
+                             "frac_wall": cells * PAIR_ALG_BYTES / (el / steps) / HBM_PEAK,
+                             # the same wall time priced at the bytes of the flags this run has (d_con = 0: no heat_source traffic)
+                             "alg_bytes_per_cell_d_con_0": PAIR_ALG_BYTES_DCON0,
+                             "frac_wall_d_con_0": cells * PAIR_ALG_BYTES_DCON0 / (el / steps) / HBM_PEAK}}
         return {"el": el, "value": cells * world * steps / el, "finite": finite, "roof": roof, "geom": geom, "graph": step.graph is not None}
 
     GEOM = {0: "general metric rows", 1: "orthogonal (angle terms not read)", 2: "orthogonal + uniform (metric terms as scalars)"}
@@ -839,7 +853,9 @@ def main():
                       "gridstruct": GEOM[geom], "build_id": build,
                       "launch": "HIP graph: one replay per pair" if m.get("graph") else "eager launches",
                       "sponge_levels": "off (FV3_BENCH_SPONGE=0, diagnostic)" if os.environ.get("FV3_BENCH_SPONGE") == "0"
-                      else "d2_bg_k1 0.20, d2_bg_k2 0.015 (2 levels)"},
+                      else ("d2_bg_k1 0.20, d2_bg_k2 0.015 (2 levels), inside the marching kernels (uniform metrics)" if geom == 2 and
+                            os.environ.get("FV3_MI355X_SPONGE_MARCH", "1") != "0" else "d2_bg_k1 0.20, d2_bg_k2 0.015 (2 levels), LDS-tile kernels"),
+                      "heat_source": "d_con = 0: heat_s / diss_e = NULL (nobody reads them, dyn_core.F90:798-812); pair priced at 336 B and at 320 B"},
            "finite": finite, "roofline": roof, "general_metrics": gm}
     # the secondary legs must never cost the headline line: a failure there is reported, not raised
     out["model_step"] = None
@@ -873,6 +889,12 @@ def main():
             out["cubed_sphere"] = cubed_sphere_leg(a, torch, stream)
         except Exception as e:  # noqa: BLE001
             out["cubed_sphere"] = {"error": f"{type(e).__name__}: {e}"}
+    # the numbers of the real C384 geometry beside the headline
+    cs = out.get("cubed_sphere") or {}
+    if isinstance(cs.get("pair_one_face"), dict):
+        out["pair_one_gnomonic_c384_face_ms"] = cs["pair_one_face"].get("ms")
+    if isinstance(cs.get("sphere_one_gpu"), dict):
+        out["c384_sphere_one_gpu_sypd"] = cs["sphere_one_gpu"].get("sypd")
     if rank == 0 and world == 1 and not a.no_cpu:
         try:
             out["cpu_baseline"] = cpu_baseline(nx, a.cpu_seconds)

@@ -564,8 +564,10 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     e = std::getenv("FV3_MI355X_FUSED");
     c->use_fused = e ? std::atoi(e) : 1;
     e = std::getenv("FV3_MI355X_MARCH_TJ_FUSED");
-    c->march_tj_fused = e ? std::atoi(e) : 55;
-    if (c->march_tj_fused < 1) c->march_tj_fused = 55;
+    // 48 rows (eight segments of a 384-row tile): measured on one set of arrays with all 127 levels on the marching kernels -- 0.773 ms
+    // against 0.794 for seven segments of 55 rows trimmed to whole rounds and 0.786 / 0.780 for ten / nine (tools/pair_ab2.py)
+    c->march_tj_fused = e ? std::atoi(e) : 48;
+    if (c->march_tj_fused < 1) c->march_tj_fused = 48;
     e = std::getenv("FV3_MI355X_MARCH_TJ_MOM");
     c->march_tj_mom = e ? std::atoi(e) : c->march_tj_fused;
     if (c->march_tj_mom < 1) c->march_tj_mom = c->march_tj_fused;
@@ -1371,7 +1373,7 @@ static int csw_march(fv3_ctx *c, const CswArgs &ca) {
     // uniform metrics: nothing to share between levels, one level per wavefront at four wavefronts per SIMD is faster
     int kpw = c->csw_kpw ? c->csw_kpw : (c->g.geom == 2 ? 1 : 2);
     const int nkg = (c->g.npz + kpw - 1) / kpw;
-    if (c->g.geom == 2 && kpw == 1 && !c->tj_fixed && ca.mask_w == 0)   // whole rounds of the chip at four wavefronts per SIMD
+    if (c->g.geom == 2 && kpw == 1 && ca.mask_w == 0)   // whole rounds of the chip at four wavefronts per SIMD
       balance_segments(md, nkg, c->g.ny + 4, 4 * c->round_simds, md.tj);
     const int nw = md.nwaves(nkg);
     seg_report("c_sw", md, nkg);
@@ -1448,7 +1450,7 @@ static int dsw_transport_march(fv3_ctx *c, const DswArgs &a, int region = 0) {
       if (ns <= 0 || ng <= 0) return 0;
       mf.set_box(s0, ns, g0, ng);
       // the whole grid in one launch of the branch-free kernel (two wavefronts per SIMD): whole rounds of the chip
-      if (FV3_BF && s0 == 0 && ns == NS && g0 == 0 && ng == NG && !c->tj_fixed && a.mask_w == 0)
+      if (FV3_BF && s0 == 0 && ns == NS && g0 == 0 && ng == NG && a.mask_w == 0)
         balance_segments(mf, c->n_plain, g.ny, 2 * c->round_simds, mf.tj);
       const int nwf = mf.nwaves(c->n_plain);
       seg_report("d_sw_fused", mf, c->n_plain);
@@ -1503,7 +1505,7 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
   if (fused_m) {
     MarchDims mf = make_march_dims(g, seg_rows(c, c->march_tj_mom, g.npz));
     mf.klist = c->klist_m;
-    if (FV3_BF && !c->tj_fixed && a.mask_w == 0)
+    if (FV3_BF && a.mask_w == 0)
       balance_segments(mf, c->n_plain_m, g.ny, ((g.geom == 2 && FV3_MOM_3W) ? 3 : 2) * c->round_simds, mf.tj);
     const int nwf = mf.nwaves(c->n_plain_m);
     seg_report("d_sw_mom_fused", mf, c->n_plain_m);

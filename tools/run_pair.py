@@ -34,6 +34,6 @@ for _ in range(reps):
     halo.update([(d["uc"], "V"), (d["vc"], "U"), (d["divg_d"], "B")])
     ctx.d_sw(par, None, d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"], d["divg_d"],
              d["mfx"], d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None, d["delp_out"],
-             d["pt_out"], d["u_out"], d["v_out"], d["w_out"], None, d["heat_s"], d["diss_e"])
+             d["pt_out"], d["u_out"], d["v_out"], d["w_out"], None, None, None)   # d_con = 0: heat_s, diss_e = NULL
 ctx.sync()
 print("ok")
