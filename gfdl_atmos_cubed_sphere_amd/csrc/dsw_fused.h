@@ -16,8 +16,9 @@
 #ifndef FV3_BF
 #define FV3_BF 1
 #endif
+// 1: the uniform-metric momentum kernel under the register budget of three wavefronts per SIMD (157 VGPRs, no spill): 0.392 -> 0.369 ms
 #ifndef FV3_MOM_3W
-#define FV3_MOM_3W 0
+#define FV3_MOM_3W 1
 #endif
 
 namespace fv3 {
@@ -255,10 +256,12 @@ struct DswTransportFused {
       sh.rray = vrecip(sh.ray);
       if constexpr (!UNI) { ar_3 = ar_2; ar_2 = ar_1; ar_1 = in.ar; }
       if constexpr (!(UNI && COURANT)) { cx_3 = cx_2; cx_2 = cx_1; cx_1 = sh.cx; }
-      vd fxd, fyd0, fyd1, fxw(0.), fyw0(0.), fyw1(0.), fxp, fyp0, fyp1;
-      fd.step(in.dp, sh, true, true, fxd, fyd0, fyd1);
-      if (NH) fw.step(in.w, sh, true, true, fxw, fyw0, fyw1);
-      fp.step(in.pt, sh, true, true, fxp, fyp0, fyp1);
+      // (the warm-up steps skip the sweeps whose face / row does not exist yet: branches without a memory operation inside)
+      const bool have_face = jf >= jA, have_row = j >= jA;
+      vd fxd(0.), fyd0(0.), fyd1(0.), fxw(0.), fyw0(0.), fyw1(0.), fxp(0.), fyp0(0.), fyp1(0.);
+      fd.step(in.dp, sh, have_face, have_row, fxd, fyd0, fyd1);
+      if (NH) fw.step(in.w, sh, have_face, have_row, fxw, fyw0, fyw1);
+      fp.step(in.pt, sh, have_face, have_row, fxp, fyp0, fyp1);
       // mass flux through y-face r-2 (tp_core.F90:222-226); carried to the next row as its south face
       const vd fym = fyd1 * sh.yf;
       {
@@ -521,7 +524,7 @@ struct DswMomentumFused {
   // two wavefronts per SIMD: 254 VGPRs with the general metric rows (the row-j values of the wind update are re-read at
   // the top of the step instead of being carried for three steps), 188 with uniform metrics; measured 0.735 -> 0.57 -> 0.49 ms
   static constexpr int kTwoWavesPerSimd = 1;
-  // uniform metrics, branch-free form: 179 VGPRs -- three wavefronts per SIMD at 168 cost 13 spilled registers (8 scratch accesses per row step)
+  // uniform metrics, branch-free form: 157 VGPRs -- three wavefronts per SIMD
   static constexpr int kThreeWavesPerSimd = (UNI && !CS && FV3_BF) ? FV3_MOM_3W : 0;
   Grid g;
   DswArgs a;
@@ -660,8 +663,8 @@ struct DswMomentumFused {
       } else {
         mi.cx = in.cx; mi.xf = in.xf; mi.cy = in.cy; mi.yf = in.yf;
       }
-      vd fxv, fyv0, fyv1;
-      st.step(mi, true, true, fxv, fyv0, fyv1);
+      vd fxv(0.), fyv0(0.), fyv1(0.);
+      st.step(mi, jc >= jA, j >= jA, fxv, fyv0, fyv1);   // (the warm-up steps skip the sweeps that do not exist yet: no memory operation inside)
       // ---- KE flux + divergence damping at corner row jc (:1078-1198, :1372-1460) -----------------------------------------
       yv.push(in.v0);
       vd ke(0.);

@@ -231,12 +231,28 @@ FV3_D PCell shift_cell_r(const PCell &c, bool with_flag) {
   return m;
 }
 
-// face values of one row: face l lies between lanes l-1 and l; valid faces: lanes 3..61
+// face values of one row: face l lies between lanes l-1 and l; valid faces: lanes 3..61.
+// ppm_face_v with the left cell taken through the shift inside the selects (vsel_shr) and bl + br formed per cell before the select
+// (the same two numbers added: bit for bit the value of ppm_face_v)
 template <int ORD>
 FV3_D vd ppm_faces_x(const vd &q, const vd &c) {
   const PCell p = ppm_cells_x<ORD>(q);
-  const PCell m = shift_cell_r(p, ORD < 8);
-  return ppm_face_v<ORD>(m, p, c);
+  const vb pos = c > 0.;
+  const vd s = vabs(c);
+  const vd b0 = p.bl + p.br;
+  const vd qu = vsel_shr(pos, p.q, p.q);
+  const vd x = vsel_shr(pos, p.br, p.bl);
+  const vd b0u = vsel_shr(pos, b0, b0);
+  const vd fx1 = (1. - s) * (x - s * b0u);
+  if (ORD >= 8) return qu + fx1;
+#ifdef FV3_HOST_EMU
+  vb ms;
+  ms.v[0] = false;
+  for (int l = 1; l < kW; l++) ms.v[l] = p.smt.v[l - 1];
+#else
+  const vb ms = __builtin_amdgcn_update_dpp(0, (int)p.smt, 0x138, 0xf, 0xf, true) != 0;
+#endif
+  return vsel(ms || p.smt, qu + fx1, qu);
 }
 
 // =====================================================================================================

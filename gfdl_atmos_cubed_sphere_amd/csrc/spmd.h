@@ -185,6 +185,8 @@ inline void vstore_b_nt(double *p, long off, const vd &x, const vm &m, bool on =
 inline void vaccum_z(double *p, long off, const vd &x, const vl &, const vm &m, bool on = true) {
   if (on) vaccum(p, off, x, m.lmin, m.lmax);
 }
+// m ? (value of lane l-1 of a) : b  -- on the device one v_cndmask_b32_dpp per half instead of a shift and a select
+inline vd vsel_shr(const vb &m, const vd &a, const vd &b) { return vsel(m, shr1(a), b); }
 inline vb vball(bool b) {   // a wave-uniform condition as a lane predicate
   vb r;
   for (int l = 0; l < kW; l++) r.v[l] = b;
@@ -337,6 +339,22 @@ __device__ __forceinline__ void vaccum_z(double *p, long off, vd x, const vl &cl
 #endif
 
 #ifndef FV3_HOST_EMU
+// m ? (value of lane l-1 of a, 0 in lane 0) : b.  The upwind selects of the x faces take the left cell's values through a wavefront
+// shift; v_cndmask_b32 has a DPP form (VOP2: D = VCC ? src1 : dpp(src0)), which the compiler does not form by itself (its selects carry
+// the mask in an SGPR pair, the VOP3 encoding, which has no DPP on gfx9): 2 instructions per double instead of 4.
+// s_mov + s_nop: the two wait states a DPP read needs after the VALU write of its source (the hazard recognizer does not look into asm).
+__device__ __forceinline__ vd vsel_shr(vb m, vd a, vd b) {
+  const unsigned long long nm = __builtin_amdgcn_ballot_w64(!m);
+  const int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+  int rlo, rhi;
+  asm("s_mov_b64 vcc, %4\n\ts_nop 0\n\t"
+      "v_cndmask_b32_dpp %0, %2, %5, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %1, %3, %6, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "=&v"(rlo), "=&v"(rhi)
+      : "v"(alo), "v"(ahi), "s"(nm), "v"(blo), "v"(bhi)
+      : "vcc");
+  return __hiloint2double(rhi, rlo);
+}
 __device__ __forceinline__ vb vball(bool b) { return b; }
 __device__ __forceinline__ vb lane_mask(int l0, int l1) {
   const int l = (int)(threadIdx.x & (kW - 1));
