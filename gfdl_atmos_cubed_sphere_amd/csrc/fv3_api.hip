@@ -373,8 +373,9 @@ static int lane_op(fv3_ctx *c, int op) {   // in a group: queued, so that it kee
 static int rtf_h2d(void *d, const void *s, size_t n, stream_t st) { if (int rc = grp_flush_all()) return rc; return rt_h2d(d, s, n, st); }
 static int rtf_d2h(void *d, const void *s, size_t n, stream_t st) { if (int rc = grp_flush_all()) return rc; return rt_d2h(d, s, n, st); }
 static int rtf_sync(stream_t st) { if (int rc = grp_flush_all()) return rc; return rt_sync(st); }
-static void rtf_event_record(void *e, stream_t st) { (void)grp_flush_all(); rt_event_record(e, st); }
-static void rtf_stream_wait_event(stream_t st, void *e) { (void)grp_flush_all(); rt_stream_wait_event(st, e); }
+// (int: a queued group launch that fails while it is flushed here must not be lost -- the exchange would pack and send stale data)
+static int rtf_event_record(void *e, stream_t st) { if (int rc = grp_flush_all()) return rc; rt_event_record(e, st); return 0; }
+static int rtf_stream_wait_event(stream_t st, void *e) { if (int rc = grp_flush_all()) return rc; rt_stream_wait_event(st, e); return 0; }
 
 // launch + optional event pair around it
 template <class F>
@@ -1245,8 +1246,10 @@ static int csw_cubed(fv3_ctx *c, const CswArgs &ca) {
   const int rc = passes();
   if (lanes) {
     c->lane = 0;
+    // (also after a failed launch: what the side stream already holds must be ordered before whatever the caller issues next)
+    const int rj = lane_op(c, kLaneJoin);
     if (rc) return rc;
-    RT(lane_op(c, kLaneJoin));
+    RT(rj);
   } else {
     if (rc) return rc;
     if (hyb) {
@@ -1869,7 +1872,7 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
       }
     }
     c->lane = 0;
-    if (rc) return rc;
+    if (rc) { (void)lane_op(c, kLaneJoin); return rc; }   // (a failed launch: still order the side stream's work before what follows)
     DswArgs mm = a;
     mm.mask_w = wo; mm.rsina = c->cg.rsina;
     if (lane_d2) {
@@ -1883,8 +1886,9 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     rc = transport(fr_in, fr_out, false);
     if (!rc) rc = momentum(frm_in, frm_out, 2);
     c->lane = 0;
+    const int rj = lane_op(c, kLaneJoin);
     if (rc) return rc;
-    RT(lane_op(c, kLaneJoin));
+    RT(rj);
     return 0;
   }
   // Every level damped (a production namelist: nord = 3, vtdm4, d_con, dddmp -- no level for the hybrid above): the two halves of d_sw
@@ -1899,9 +1903,10 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     c->lane = 1;
     int rc = momentum(all, all, 1);
     c->lane = 0;
+    if (!rc) rc = transport(all, all, true);
+    const int rj = lane_op(c, kLaneJoin);
     if (rc) return rc;
-    RT(transport(all, all, true));
-    RT(lane_op(c, kLaneJoin));
+    RT(rj);
     // (the rest of the momentum half on the side lane too -- behind an event after the transports' Courant numbers, with flux arrays of
     // its own -- was measured no faster, and it is not independent: D4 leaves the heat of the w damping in heat_source, which the
     // heating pass adds to)
@@ -2038,18 +2043,18 @@ static int d_sw_impl(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const d
       RT(rt_event_create(&c->ev_join));
     }
     const stream_t main_stream = c->stream;
-    rtf_event_record(c->ev_fork, main_stream);
-    rtf_stream_wait_event(c->stream2, c->ev_fork);
+    RT(rtf_event_record(c->ev_fork, main_stream));
+    RT(rtf_stream_wait_event(c->stream2, c->ev_fork));
     c->stream = c->stream2;
     int rc = courant();
     if (!rc) rc = tile_transport();
     if (!rc) rc = tile_momentum();
-    rtf_event_record(c->ev_join, c->stream2);
     c->stream = main_stream;
+    if (int rc2 = rtf_event_record(c->ev_join, c->stream2)) return rc2;
     RT(rc);
     RT(dsw_transport_march(c, a, region));
     RT(dsw_momentum_march(c, a));
-    rtf_stream_wait_event(main_stream, c->ev_join);
+    RT(rtf_stream_wait_event(main_stream, c->ev_join));
     return 0;
   }
   RT(courant());
@@ -2406,7 +2411,8 @@ extern "C" int fv3_comm_init(fv3_ctx *c, int rank, int nranks, const unsigned ch
     e->dir = id[0] ? std::string(reinterpret_cast<const char *>(id), strnlen(reinterpret_cast<const char *>(id), FV3_COMM_ID_BYTES)) : std::string();
     e->rank = rank; e->n = nranks; e->coll = 0;
     e->sseq.assign(nranks, 0); e->rseq.assign(nranks, 0);
-    if (nranks > 1 && e->dir.empty()) { delete e; return fail("fv3_comm_init: several ranks need the id of fv3_comm_get_unique_id"); }
+    // (an all-zero id has no directory: the messages would go to the filesystem root -- for one rank as well)
+    if (e->dir.empty()) { delete e; return fail("fv3_comm_init: the id of fv3_comm_get_unique_id is needed (host emulation: its directory)"); }
     c->comm = (void *)e;
   }
 #else
@@ -2423,6 +2429,7 @@ extern "C" int fv3_comm_destroy(fv3_ctx *c) {
 #ifndef FV3_HOST_EMU
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
 #else
+  // (the exchange directory /tmp/fv3emu_* stays: other ranks / contexts of the communicator may still read from it -- tests only)
   if (c->comm) delete static_cast<EmuComm *>(c->comm);
 #endif
   c->comm = nullptr;
@@ -2463,8 +2470,8 @@ extern "C" int fv3_halo_start(fv3_ctx *c, int nfields, const fv3_halo_field *fie
     }
   }
   if (fv3_halo_pack(c, nfields, fields, c->msg_send)) return 1;
-  rtf_event_record(c->ev_packed, c->stream);
-  rtf_stream_wait_event(c->comm_stream, c->ev_packed);
+  RT(rtf_event_record(c->ev_packed, c->stream));
+  RT(rtf_stream_wait_event(c->comm_stream, c->ev_packed));
 #ifdef FV3_HOST_EMU
   {   // the group: every send, then every receive, each matched per peer in posting order (see the transport above)
     EmuComm *e = static_cast<EmuComm *>(c->comm);
@@ -2483,7 +2490,7 @@ extern "C" int fv3_halo_start(fv3_ctx *c, int nfields, const fv3_halo_field *fie
   const int rc2 = g_rccl.GroupEnd();   // the group is closed on every path
   if (rc || rc2) return fail("RCCL: %s (halo group)", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "error");
 #endif
-  rtf_event_record(c->ev_arrived, c->comm_stream);
+  RT(rtf_event_record(c->ev_arrived, c->comm_stream));
   for (int f = 0; f < nfields; f++) c->pend_fields[f] = fields[f];
   c->pend_n = nfields;
   return 0;
@@ -2492,7 +2499,7 @@ extern "C" int fv3_halo_start(fv3_ctx *c, int nfields, const fv3_halo_field *fie
 // complete_group_halo_update: the context's stream waits for the transfers and unpacks them into the halos
 extern "C" int fv3_halo_complete(fv3_ctx *c) {
   if (!c || !c->pend_n) return fail("fv3_halo_complete: no group in flight");
-  rtf_stream_wait_event(c->stream, c->ev_arrived);
+  RT(rtf_stream_wait_event(c->stream, c->ev_arrived));
   const int n = c->pend_n;
   c->pend_n = 0;
   return fv3_halo_unpack(c, n, c->pend_fields, c->msg_recv);
@@ -2706,8 +2713,8 @@ extern "C" int fv3_cube_halo_start(int nctx, fv3_ctx *const *ctxs, const int *fa
       RT(launch_p(c, "cube_pack", grid, 0, kf));
     }
     if (!c->ev_packed) RT(rt_event_create(&c->ev_packed));
-    rtf_event_record(c->ev_packed, c->stream);
-    rtf_stream_wait_event(c0->comm_stream, c->ev_packed);
+    RT(rtf_event_record(c->ev_packed, c->stream));
+    RT(rtf_stream_wait_event(c0->comm_stream, c->ev_packed));
   }
   // ---- the messages: sends ordered by (sender face, receiver face), receives likewise -- the same order on both ends of a link ----
 #ifdef FV3_HOST_EMU
@@ -2732,7 +2739,7 @@ extern "C" int fv3_cube_halo_start(int nctx, fv3_ctx *const *ctxs, const int *fa
   const int rc2 = g_rccl.GroupEnd();   // closed on every path
   if (rc || rc2) return fail("RCCL: %s (cube-edge group)", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc ? rc : rc2) : "error");
 #endif
-  rtf_event_record(c0->ev_arrived, c0->comm_stream);
+  RT(rtf_event_record(c0->ev_arrived, c0->comm_stream));
   for (int i = 0; i < nctx; i++) {
     for (int f = 0; f < nfields; f++) ctxs[i]->cube_pend[f] = fields[i * nfields + f];
     ctxs[i]->cube_pend_n = nfields;
@@ -2746,7 +2753,7 @@ extern "C" int fv3_cube_halo_complete(int nctx, fv3_ctx *const *ctxs) {
     if (!ctxs[i] || !ctxs[i]->cube_pend_n) return fail("fv3_cube_halo_complete: no group in flight");
   for (int i = 0; i < nctx; i++) {
     fv3_ctx *c = ctxs[i];
-    rtf_stream_wait_event(c->stream, c0->ev_arrived);
+    RT(rtf_stream_wait_event(c->stream, c0->ev_arrived));
     const int nf = c->cube_pend_n;
     c->cube_pend_n = 0;
     for (int f = 0; f < nf; f++) {
@@ -3921,6 +3928,7 @@ extern "C" int fv3_lagrangian_to_eulerian(fv3_ctx *c, const fv3_remap_params *p,
   const size_t slab = (g.nA() > ncol_max ? g.nA() : ncol_max) * (size_t)(km + 1);
   const size_t need = slab * (size_t)(8 + kSetSlabs * nsets);
   if (c->remap_scr_n < need) {
+    RT(grp_flush_all());   // queued launches of a face group may still hold the old pointer
     if (c->remap_scr) rt_free(c->remap_scr);
     c->remap_scr = nullptr;
     c->remap_scr_n = 0;

@@ -40,7 +40,14 @@ from .layout import Bounds
 def fms_checksum(a: np.ndarray) -> str:
     """mpp_chksum of a real(8) array as fms2_io writes it: sum of the values' bit patterns as 64-bit integers, modulo 2**64"""
     bits = np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
-    return "%016X" % (int(np.sum(bits, dtype=np.uint64)) & 0xFFFFFFFFFFFFFFFF)
+    # Fortran's (Z16) edit descriptor: right-justified in 16 columns, BLANK padded (an all-zero field reads "               0")
+    return "%16X" % (int(np.sum(bits, dtype=np.uint64)) & 0xFFFFFFFFFFFFFFFF)
+
+
+def _checksum_value(text) -> int:
+    """the number a checksum attribute holds, however it is padded (blanks of (Z16), zeros of older files of this writer)"""
+    t = (text.decode() if isinstance(text, bytes) else str(text)).strip()
+    return int(t or "0", 16)
 
 
 def _axis(f, name: str, n, cart: str, units: str = "none"):
@@ -143,7 +150,7 @@ def _read_var(f, name: str, ignore_checksum: bool) -> np.ndarray:
     if not ignore_checksum and hasattr(v, "checksum"):
         want = v.checksum.decode() if isinstance(v.checksum, bytes) else str(v.checksum)
         got = fms_checksum(data)
-        if got != want.strip():
+        if _checksum_value(got) != _checksum_value(want):   # numerically: the padding of the attribute differs between writers
             raise ValueError(f"restart variable {name}: checksum {got} of the data is not the file's {want} (ignore_rst_cksum to read it anyway)")
     return np.asfortranarray(np.transpose(data))
 

@@ -458,16 +458,18 @@ def test_c384_tile_vs_oracle(prod):
     assert max(P.check_d_sw(prod, nx=384, ny=384, npz=5).values()) <= P.TOL
 
 
-def test_c384l127_flux_form_properties(prod):
-    """BASELINE size 384 x 384 x 127 on the GPU alone: size-independent properties of the pair --
-    mass conservation of d_sw (sw_core.F90:1059-1060) and consistency of the flux capacitors with the delp update"""
+@pytest.mark.parametrize("nx", [384, 1024])
+def test_c384l127_flux_form_properties(prod, nx):
+    """BASELINE sizes 384 x 384 x 127 (configs[2]'s tile) and the WHOLE 1024 x 1024 x 127 doubly periodic domain of configs[3] on one
+    GPU, on the GPU alone: size-independent properties of the pair -- mass conservation of d_sw (sw_core.F90:1059-1060) and consistency
+    of the flux capacitors with the delp update"""
     import numpy as np
     from fields import smooth_state
     from gfdl_atmos_cubed_sphere_amd.halo import HaloExchanger
     from gfdl_atmos_cubed_sphere_amd.layout import Bounds
     from gfdl_atmos_cubed_sphere_amd.lib import Context
     from test_oracle_properties import default_levels
-    nx, npz = 384, 127
+    npz = 127
     bd = Bounds(1, nx, 1, nx)
     g = P.make_grid(bd, False)   # constant metrics: a truly periodic tile
     ctx = Context(g, npz, lib=prod)
@@ -1353,3 +1355,67 @@ def test_mixed_segmentation_of_the_marching_launches(prod, monkeypatch):
 def test_golden_ppm_lines_through_fv_tp_2d(prod, iord, direction):
     """the reference-held PPM vectors (tests/golden/, from the reference's own tp_core.ipynb) straight through the library's fv_tp_2d"""
     P.check_golden_ppm_through_fv_tp_2d(prod, iord, direction)
+
+
+@pytest.mark.gpu
+def test_config5_full_gnomonic_c768l79_face_33_tracers_properties(prod):
+    """BASELINE configs[4] at FULL size on one GPU: one gnomonic C768 L79 face (768 x 768 x 79, grid_type 0, every metric row read), the
+    hydrostatic c_sw + d_sw pair and one tracer_2d step of 33 tracers.  Past the oracle's reach, and a single face has no neighbours to
+    close its mass budget with, so the properties are the local ones: every output finite; the flux-form update of delp IS the
+    divergence of the mass fluxes the call accumulated (sw_core.F90:1059-1060, :928-940) on the whole compute domain; the monotone
+    tracer scheme (hord_tr = 8) keeps every tracer inside the range it started with (fv_tracer2d.F90:471-541)."""
+    import numpy as np
+    from fields import smooth_state
+    from gfdl_atmos_cubed_sphere_amd.cubed_sphere import CubedSphere
+    from gfdl_atmos_cubed_sphere_amd.layout import Bounds
+    from gfdl_atmos_cubed_sphere_amd.lib import Context
+    from gfdl_atmos_cubed_sphere_amd.tracer2d import tracer_2d
+    from test_oracle_properties import default_levels
+    nx, npz, nq = 768, 79, 33
+    g = CubedSphere(nx + 1).gridstruct(0)
+    bd = g.bd
+    ctx = Context(g, npz, lib=prod)
+    try:
+        st = smooth_state(Bounds(1, nx, 1, nx), npz, noise=0.05, hydrostatic=True)
+        d = {k: ctx.from_host(v) for k, v in st.items()}
+        for n, kind in P.CSW_OUT:
+            d[n] = ctx.zeros(kind, npz)
+        for n, kind in (("mfx", "FX"), ("mfy", "FY"), ("cx", "CX"), ("cy", "CY"), ("crx", "CX"), ("cry", "CY"),
+                        ("xfx", "CX"), ("yfx", "CY"), ("delp_out", "A"), ("pt_out", "A"), ("u_out", "U"), ("v_out", "V")):
+            d[n] = ctx.zeros(kind, npz)
+        ctx.dsw_levels(default_levels(npz))
+        par = dict(P.DSW_PAR)
+        par.update(dt=12.5, hydrostatic=1, use_cond=0)      # C768: dt_atmos 150 s / k_split 2 / n_split 6
+        dt = par["dt"]
+        ctx.c_sw(d["delpc"], d["delp"], d["ptc"], d["pt"], d["u"], d["v"], None, d["uc"], d["vc"], d["ua"], d["va"], None, d["ut"],
+                 d["vt"], d["divg_d"], 1, 0.5 * dt, True)
+        ctx.d_sw(par, None, d["delp"], d["pt"], d["u"], d["v"], None, d["uc"], d["vc"], d["ua"], d["va"], d["divg_d"], d["mfx"], d["mfy"],
+                 d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None, d["delp_out"], d["pt_out"], d["u_out"], d["v_out"], None,
+                 None, None, None)
+        r = (bd.is_, bd.ie, bd.js, bd.je)
+        dp0 = bd.view(st["delp"], "A", *r)
+        dp1 = bd.view(d["delp_out"].download(), "A", *r)
+        mfx, mfy = d["mfx"].download(), d["mfy"].download()
+        div = (mfx[:-1] - mfx[1:] + mfy[:, :-1] - mfy[:, 1:]) * bd.view(g.rarea, "A", *r)[:, :, None]
+        assert np.all(np.isfinite(dp1)) and np.max(np.abs((dp1 - dp0) - div)) <= 1e-12 * np.max(np.abs(dp0))
+        for n in ("pt_out", "u_out", "v_out"):
+            assert np.all(np.isfinite(bd.view(d[n].download(), {"pt_out": "A", "u_out": "U", "v_out": "V"}[n], *r))), n
+        # 33 tracers through one tracer_2d call with the fluxes / Courant numbers this substep accumulated
+        rng = np.random.default_rng(5)
+        q0 = np.asfortranarray(rng.uniform(0.0, 1.0, bd.shape("A", npz) + (nq,)))
+
+        class NoHalo:      # one face alone: the halo of q holds its initial values (inside the range as well); one sub-cycle (q_split = 1)
+            world = 1
+
+            def update(self, fields):
+                pass
+        dq, dqn, dpn = ctx.from_host(q0), ctx.zeros("A", npz * nq), ctx.zeros("A", npz)
+        qr, _, nsplt = tracer_2d(ctx, NoHalo(), dq, dqn, d["delp"], dpn, d["mfx"], d["mfy"], d["cx"], d["cy"], d["xfx"], d["yfx"], nq, hord=8,
+                                 q_split=1)
+        q1 = qr.download().reshape(q0.shape, order="F")
+        inner = q1[bd.ng:bd.ng + nx, bd.ng:bd.ng + nx]
+        assert nsplt == 1 and np.all(np.isfinite(inner))
+        lo, hi = float(q0.min()), float(q0.max())
+        assert inner.min() >= lo - 1e-12 and inner.max() <= hi + 1e-12, (inner.min(), inner.max())
+    finally:
+        ctx.close()
