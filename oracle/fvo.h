@@ -13,7 +13,9 @@
  *   pinned    : 1-D PPM flux operator xppm/yppm for hord 5, -5, 6, 8, 10 on a periodic
  *               line -- checked against vectors produced by executing the reference's own
  *               Python restatement docs/examples/tp_core.ipynb (tests/golden/ppm1d_*.npz,
- *               generator tests/golden/make_ppm1d_golden.py).
+ *               generator tests/golden/make_ppm1d_golden.py).  The same vectors also go straight through the
+ *               LIBRARY's fv_tp_2d, without this oracle in between (tests/parity_common.py
+ *               check_golden_ppm_through_fv_tp_2d; -m gpu and host-emulation tests, x and y sweeps, hord 5, -5, 6, 8).
  *               set_eta (L79, L127; restated in the package's test_cases.py) against the reference's own stand-alone
  *               fv_eta.F90 compiled here (oracle/Makefile target `ref` -> oracle/_ref/, tests/golden/set_eta_golden.npz).
  *   unpinned  : everything else (fv_tp_2d, c_sw, d_sw, column solvers, remap incl. ppm_profile, compute_total_energy and the
