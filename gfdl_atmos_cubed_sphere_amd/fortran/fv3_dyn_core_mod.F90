@@ -7,7 +7,10 @@
 !> fv_diag_type (fv_arrays_mod), domain2d (mpp_domains_mod), group_halo_update_type (fv_mp_mod) -- are declared in
 !> fv3_arrays_compat_mod below with the members THIS PATH READS under the reference's member names (fv_arrays.F90:75-205,
 !> :207-906, :1192-1200).  fv_arrays_mod itself cannot be compiled without FMS; inside the model a maintainer replaces
-!> `use fv3_arrays_compat_mod` by `use fv_arrays_mod` / `use mpp_domains_mod` / `use fv_mp_mod` and nothing else changes.
+!> `use fv3_arrays_compat_mod` by `use fv_arrays_mod` / `use fv_mp_mod` for the fv_arrays types.  domain2d is opaque in FMS: this file
+!> reads it ONLY through the accessors fv3_domain_pe / _npes / _tile / _layout / _tile_pe / _comm_id of the compat module, whose bodies
+!> a maintainer re-points at mpp_pe, mpp_npes, mpp_get_tile_id, mpp_get_layout, mpp_get_tile_pelist (the call sites stay); the tracer
+!> indices come through get_tracer_index(MODEL_ATMOS, ...) as in fv_dynamics.F90:275-283 (tracer_manager_mod's in the model).
 !>
 !> What a call does: (first call) creates the context from bd / gridstruct / flagstruct and uploads the metric terms once;
 !> (every call) host -> device copies of the prognostic arrays, the substep loop (fv3_dyn_core: n_split substeps, the d_con
@@ -115,6 +118,98 @@ module fv3_arrays_compat_mod
   type group_halo_update_type                 ! fv_mp_mod.F90:646-876: the halo groups live behind fv3_halo_* / fv3_halo_fill_periodic
     integer :: id = 0
   end type
+
+  !> tracer_manager_mod's get_tracer_index as fv_dynamics uses it (fv_dynamics.F90:275-283: sphum, liq_wat, ice_wat, rainwat, snowwat,
+  !> graupel): FMS reads the indices from the field table; here the host registers them (fv3_register_tracer_index) and fv_dynamics asks
+  !> with the reference's own call.  An unregistered tracer is NO_TRACER (< 0, as FMS's).
+  integer, parameter :: MODEL_ATMOS = 1, NO_TRACER = 1 - huge(1)
+  integer, parameter, private :: max_tracers_compat = 64
+  character(len=32), private :: tracer_names_compat(max_tracers_compat) = ' '
+  integer, private :: tracer_index_compat(max_tracers_compat) = NO_TRACER, n_tracers_compat = 0
+
+contains
+
+  subroutine fv3_register_tracer_index(name, index)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: index
+    integer :: n
+    do n = 1, n_tracers_compat
+      if (trim(tracer_names_compat(n)) == trim(name)) then
+        tracer_index_compat(n) = index
+        return
+      end if
+    end do
+    if (n_tracers_compat >= max_tracers_compat) error stop 'fv3_register_tracer_index: too many tracers'
+    n_tracers_compat = n_tracers_compat + 1
+    tracer_names_compat(n_tracers_compat) = name
+    tracer_index_compat(n_tracers_compat) = index
+  end subroutine
+
+  integer function get_tracer_index(model, name)
+    integer, intent(in) :: model
+    character(len=*), intent(in) :: name
+    integer :: n
+    get_tracer_index = NO_TRACER
+    if (model /= MODEL_ATMOS) return
+    do n = 1, n_tracers_compat
+      if (trim(tracer_names_compat(n)) == trim(name)) get_tracer_index = tracer_index_compat(n)
+    end do
+  end function
+
+  !> What the dynamical core asks of a domain2d goes through accessors shaped like mpp_domains_mod's / mpp_mod's own (a maintainer's
+  !> `use mpp_domains_mod` then replaces these bodies, not the call sites): the PE of this process, the number of PEs, the tile of this
+  !> call, the io layout of the doubly periodic domain; and the two things FMS keeps inside the domain that this path needs as data --
+  !> which PE holds every tile and the id of the exchange's communicator.
+  integer function fv3_domain_pe(domain)
+    type(domain2d), intent(in) :: domain
+    fv3_domain_pe = domain%pe                  ! mpp_pe()
+  end function
+  integer function fv3_domain_npes(domain)
+    type(domain2d), intent(in) :: domain
+    fv3_domain_npes = domain%npes              ! mpp_npes()
+  end function
+  integer function fv3_domain_tile(domain)
+    type(domain2d), intent(in) :: domain
+    fv3_domain_tile = domain%tile              ! mpp_get_tile_id(domain)
+  end function
+  subroutine fv3_domain_layout(domain, layout)
+    type(domain2d), intent(in) :: domain
+    integer, intent(out) :: layout(2)
+    layout = domain%layout                     ! mpp_get_layout(domain, layout)
+  end subroutine
+  integer function fv3_domain_tile_pe(domain, tile)
+    type(domain2d), intent(in) :: domain
+    integer, intent(in) :: tile
+    fv3_domain_tile_pe = domain%face_rank(tile)   ! mpp_get_tile_pelist
+  end function
+  integer function fv3_domain_layout_of(domain, n)
+    type(domain2d), intent(in) :: domain
+    integer, intent(in) :: n
+    integer :: layout(2)
+    call fv3_domain_layout(domain, layout)
+    fv3_domain_layout_of = layout(n)
+  end function
+  integer function fv3_tiles_held(domain, upto)   ! how many of the tiles 1 .. upto this PE holds
+    type(domain2d), intent(in) :: domain
+    integer, intent(in) :: upto
+    integer :: t
+    fv3_tiles_held = 0
+    do t = 1, upto
+      if (fv3_domain_tile_pe(domain, t) == fv3_domain_pe(domain)) fv3_tiles_held = fv3_tiles_held + 1
+    end do
+  end function
+  function fv3_domain_tile_pelist(domain) result(pes)   ! the PE of every tile (mpp_get_tile_pelist, tile by tile)
+    type(domain2d), intent(in) :: domain
+    integer :: pes(6), t
+    do t = 1, 6
+      pes(t) = fv3_domain_tile_pe(domain, t)
+    end do
+  end function
+  function fv3_domain_comm_id(domain) result(id)
+    type(domain2d), intent(in) :: domain
+    integer(c_signed_char) :: id(128)
+    id = domain%comm_id
+  end function
 end module fv3_arrays_compat_mod
 
 
@@ -211,7 +306,7 @@ contains
     if (ng /= 3 .or. bd%ng /= 3) error stop 'dyn_core (fv3_dyn_core_mod): ng = 3'
     if (.not. bound) then
       call bind_context()
-      if (domain%npes > 1) call fv3_host_comm_layout(at, domain%pe, domain%npes, domain%layout(1), domain%layout(2), domain%comm_id)
+      if (fv3_domain_npes(domain) > 1) call fv3_host_comm_layout(at, fv3_domain_pe(domain), fv3_domain_npes(domain), fv3_domain_layout_of(domain, 1), fv3_domain_layout_of(domain, 2), fv3_domain_comm_id(domain))
     end if
     if (at%npz /= npz .or. at%is /= bd%is .or. at%ie /= bd%ie .or. at%js /= bd%js .or. at%je /= bd%je) &
       error stop 'dyn_core (fv3_dyn_core_mod): the domain changed between calls'
@@ -298,10 +393,10 @@ contains
       if (moist) error stop 'dyn_core (fv3_dyn_core_mod): use_cond / moist_kappa on the cubed sphere are not carried through this wrapper'
       if (flagstruct%do_diss_est .or. flagstruct%beta < 0.d0) error stop 'dyn_core (fv3_dyn_core_mod): do_diss_est / beta < 0 are not built'
       if (ng /= 3 .or. bd%ng /= 3) error stop 'dyn_core (fv3_dyn_core_mod): ng = 3'
-      if (domain%tile < 1 .or. domain%tile > 6) error stop 'dyn_core (fv3_dyn_core_mod): domain%tile must be 1 .. 6'
-      if (domain%face_rank(domain%tile) /= domain%pe) error stop 'dyn_core (fv3_dyn_core_mod): this PE does not hold domain%tile'
-      nloc = count(domain%face_rank == domain%pe)
-      slot = count(domain%face_rank(1:domain%tile) == domain%pe)
+      if (fv3_domain_tile(domain) < 1 .or. fv3_domain_tile(domain) > 6) error stop 'dyn_core (fv3_dyn_core_mod): fv3_domain_tile(domain) must be 1 .. 6'
+      if (fv3_domain_tile_pe(domain, fv3_domain_tile(domain)) /= fv3_domain_pe(domain)) error stop 'dyn_core (fv3_dyn_core_mod): this PE does not hold fv3_domain_tile(domain)'
+      nloc = fv3_tiles_held(domain, 6)
+      slot = fv3_tiles_held(domain, fv3_domain_tile(domain))
       nx = bd%ie - bd%is + 1; ny = bd%je - bd%js + 1
       nk = int(npz, c_size_t); nk1 = nk + 1
       if (.not. hydrostatic) then
@@ -313,7 +408,7 @@ contains
         call flags_of(flagstruct, fl)
         fl%n_split = n_split; fl%ptop = ptop; fl%grav = grav; fl%akap = akap; fl%cp_air = cp
         fl%hydrostatic = hydrostatic
-        call bind_sphere_tile(spd, slot, domain%tile, npx, npy, npz, 0, bd, gridstruct, flagstruct, fl, ak, bk)
+        call bind_sphere_tile(spd, slot, fv3_domain_tile(domain), npx, npy, npz, 0, bd, gridstruct, flagstruct, fl, ak, bk)
         bound_d(slot) = .true.
       end if
       associate (a => spd%f(slot))
@@ -345,10 +440,10 @@ contains
       if (slot < nloc) return                        ! the loop runs in the call of the last tile this process holds
 
       if (.not. comm_d) then
-        if (domain%npes > 1) then
-          call fv3_sphere_comm(spd, domain%pe, domain%npes, domain%face_rank, domain%comm_id)
+        if (fv3_domain_npes(domain) > 1) then
+          call fv3_sphere_comm(spd, fv3_domain_pe(domain), fv3_domain_npes(domain), fv3_domain_tile_pelist(domain), fv3_domain_comm_id(domain))
         else
-          call fv3_sphere_comm(spd, 0, 1, domain%face_rank)
+          call fv3_sphere_comm(spd, 0, 1, fv3_domain_tile_pelist(domain))
         end if
         comm_d = .true.
       end if
@@ -483,25 +578,29 @@ contains
     type(fv_diag_type), intent(in) :: idiag
     type(fv_thermo_type), intent(inout) :: thermostruct
 
-    real(c_double), allocatable, target :: w_c(:,:,:), delz_c(:,:,:), zs(:,:)
+    real(c_double), allocatable, target :: w_c(:,:,:), delz_c(:,:,:), zs(:,:), qc_c(:,:,:)
     integer(c_size_t) :: nk, nk1
     integer :: nx, ny
 
     if (neststruct%nested .or. gridstruct%nested .or. gridstruct%regional .or. gridstruct%bounded_domain) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): nested / regional domains are not built'
-    if (thermostruct%use_cond .or. thermostruct%moist_kappa) &
-      error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond / moist_kappa are not carried through this wrapper'
     if (gridstruct%grid_type < 3) then
+      if (thermostruct%use_cond .or. thermostruct%moist_kappa) &
+        error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond / moist_kappa on the cubed sphere are not carried through this wrapper'
       call fv_dynamics_sphere()
       return
     end if
+    if ((thermostruct%use_cond .or. thermostruct%moist_kappa) .and. hydrostatic) &
+      error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond / moist_kappa are nonhydrostatic branches'
+    if (thermostruct%use_cond .and. (size(q_con, 1) /= bd%ied - bd%isd + 1 .or. size(q_con, 3) < npz)) &
+      error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond needs q_con(isd:ied, jsd:jed, npz)'
     if (gridstruct%grid_type /= 4) error stop 'fv_dynamics (fv3_dyn_core_mod): grid_type = 3 is not built'
     if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%do_diss_est .or. flagstruct%beta < 0.d0) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / do_diss_est / beta < 0 are not built'
     if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
     if (.not. boundf) then
       call bind_context()
-      if (domain%npes > 1) call fv3_host_comm_layout(atf, domain%pe, domain%npes, domain%layout(1), domain%layout(2), domain%comm_id)
+      if (fv3_domain_npes(domain) > 1) call fv3_host_comm_layout(atf, fv3_domain_pe(domain), fv3_domain_npes(domain), fv3_domain_layout_of(domain, 1), fv3_domain_layout_of(domain, 2), fv3_domain_comm_id(domain))
     end if
     if (atf%npz /= npz .or. atf%nq /= nq_tot .or. atf%ie /= bd%ie .or. atf%je /= bd%je) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): the domain changed between calls'
@@ -546,10 +645,15 @@ contains
     call get(c_loc(uc), atf%uc, atf%nV*nk);      call get(c_loc(vc), atf%vc, atf%nU*nk)
     call get(c_loc(mfx), atf%mfx, atf%nFX*nk);   call get(c_loc(mfy), atf%mfy, atf%nFY*nk)
     call get(c_loc(cx), atf%cx, atf%nCX*nk);     call get(c_loc(cy), atf%cy, atf%nCY*nk)
+    if (thermostruct%use_cond) then            ! q_con as moist_cv left it (fv_dynamics.F90:305-317 and the remaps)
+      allocate(qc_c(bd%isd:bd%ied, bd%jsd:bd%jed, npz))
+      call get(c_loc(qc_c), atf%q_con, atf%nA*nk)
+    end if
     call fv3_check(fv3_sync(atf%ctx), 'fv3_sync')
     if (.not. hydrostatic) then
       w(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz) = w_c; delz(bd%is:bd%ie, bd%js:bd%je, 1:npz) = delz_c
     end if
+    if (thermostruct%use_cond) q_con(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz) = qc_c
 
   contains
 
@@ -578,12 +682,12 @@ contains
       if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%do_diss_est .or. flagstruct%beta < 0.d0) &
         error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / do_diss_est / beta < 0 are not built'
       if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
-      if (domain%tile < 1 .or. domain%tile > 6) error stop 'fv_dynamics (fv3_dyn_core_mod): domain%tile must be 1 .. 6'
+      if (fv3_domain_tile(domain) < 1 .or. fv3_domain_tile(domain) > 6) error stop 'fv_dynamics (fv3_dyn_core_mod): fv3_domain_tile(domain) must be 1 .. 6'
       if (bd%is /= 1 .or. bd%js /= 1 .or. bd%ie /= npx - 1 .or. bd%je /= npy - 1) &
         error stop 'fv_dynamics (fv3_dyn_core_mod): one whole tile per context (layout 1 x 1 per tile)'
-      nloc = count(domain%face_rank == domain%pe)
-      slot = count(domain%face_rank(1:domain%tile) == domain%pe)
-      if (domain%face_rank(domain%tile) /= domain%pe) error stop 'fv_dynamics (fv3_dyn_core_mod): this PE does not hold domain%tile'
+      nloc = fv3_tiles_held(domain, 6)
+      slot = fv3_tiles_held(domain, fv3_domain_tile(domain))
+      if (fv3_domain_tile_pe(domain, fv3_domain_tile(domain)) /= fv3_domain_pe(domain)) error stop 'fv_dynamics (fv3_dyn_core_mod): this PE does not hold fv3_domain_tile(domain)'
       nx = bd%ie - bd%is + 1; ny = bd%je - bd%js + 1
       nk = int(npz, c_size_t); nk1 = nk + 1
       if (.not. hydrostatic) then
@@ -595,7 +699,7 @@ contains
         call flags_of(flagstruct, fl)
         fl%n_split = n_split; fl%q_split = q_split; fl%ptop = ptop; fl%akap = kappa; fl%cp_air = cp_air
         fl%hydrostatic = hydrostatic; fl%fill = fill; fl%r_vir = zvir
-        call bind_sphere_tile(sps, slot, domain%tile, npx, npy, npz, nq_tot, bd, gridstruct, flagstruct, fl, ak, bk)
+        call bind_sphere_tile(sps, slot, fv3_domain_tile(domain), npx, npy, npz, nq_tot, bd, gridstruct, flagstruct, fl, ak, bk)
         bound_s(slot) = .true.
       end if
       associate (at => sps%f(slot))
@@ -629,14 +733,14 @@ contains
       if (slot < nloc) return                        ! the step runs in the call of the last tile this process holds
 
       if (.not. comm_s) then
-        if (domain%npes > 1) then
-          call fv3_sphere_comm(sps, domain%pe, domain%npes, domain%face_rank, domain%comm_id)
+        if (fv3_domain_npes(domain) > 1) then
+          call fv3_sphere_comm(sps, fv3_domain_pe(domain), fv3_domain_npes(domain), fv3_domain_tile_pelist(domain), fv3_domain_comm_id(domain))
         else
-          call fv3_sphere_comm(sps, 0, 1, domain%face_rank)
+          call fv3_sphere_comm(sps, 0, 1, fv3_domain_tile_pelist(domain))
         end if
         comm_s = .true.
       end if
-      call fv3_sphere_fv_dynamics_call(sps, bdt, domain%npes, consv_te, flagstruct%tau, flagstruct%rf_cutoff, zvir, &
+      call fv3_sphere_fv_dynamics_call(sps, bdt, fv3_domain_npes(domain), consv_te, flagstruct%tau, flagstruct%rf_cutoff, zvir, &
                                        flagstruct%c2l_ord, flagstruct%moist_phys, 6.3712d6)         ! constants_mod: radius
       do sl = 1, nloc
         associate (at => sps%f(sl), tp => tps(sl))
@@ -685,6 +789,20 @@ contains
       call flags_of(flagstruct, fl)
       fl%n_split = n_split; fl%q_split = q_split; fl%ptop = ptop; fl%akap = kappa; fl%cp_air = cp_air
       fl%hydrostatic = hydrostatic; fl%fill = fill; fl%r_vir = zvir
+      ! thermostruct%use_cond / moist_kappa (the reference's defaults, fv_arrays.F90:1226-1227): the water species as fv_dynamics.F90:275-283
+      ! finds them -- get_tracer_index -- and the heat capacities of fv_thermodynamics' moist_cv (cv_vap = 3 rvgas, c_liq, c_ice)
+      fl%use_cond = thermostruct%use_cond; fl%moist_kappa = thermostruct%moist_kappa
+      if (fl%use_cond .or. fl%moist_kappa) then
+        fl%moist%nwat = int(flagstruct%nwat, c_int)
+        fl%moist%sphum = int(max(0, get_tracer_index(MODEL_ATMOS, 'sphum')), c_int)
+        fl%moist%liq_wat = int(max(0, get_tracer_index(MODEL_ATMOS, 'liq_wat')), c_int)
+        fl%moist%ice_wat = int(max(0, get_tracer_index(MODEL_ATMOS, 'ice_wat')), c_int)
+        fl%moist%rainwat = int(max(0, get_tracer_index(MODEL_ATMOS, 'rainwat')), c_int)
+        fl%moist%snowwat = int(max(0, get_tracer_index(MODEL_ATMOS, 'snowwat')), c_int)
+        fl%moist%graupel = int(max(0, get_tracer_index(MODEL_ATMOS, 'graupel')), c_int)
+        if (fl%moist%sphum < 1) error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond / moist_kappa need the index of sphum (fv3_register_tracer_index)'
+        fl%moist%cv_vap = 3.d0 * 461.50d0; fl%moist%c_liq = 4.218d3; fl%moist%c_ice = 2.106d3
+      end if
       call fv3_host_init_grid(atf, dom, gh, nq_tot, fl, ak, bk)
       boundf = .true.
     end subroutine

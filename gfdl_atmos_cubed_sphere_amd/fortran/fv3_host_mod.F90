@@ -770,6 +770,11 @@ contains
     if (hyd) then
       wp = c_null_ptr; dzp = c_null_ptr; pep = at%pe; pelnp = at%peln
     end if
+    if (at%fl%use_cond .or. at%fl%moist_kappa) then    ! moist_cv of the conversions below and of compute_total_energy (fv_dynamics.F90:305-317)
+      at%fl%moist%moist_kappa = merge(1_c_int, 0_c_int, at%fl%moist_kappa)
+      at%fl%moist%use_cond = merge(1_c_int, 0_c_int, at%fl%use_cond)
+      call fv3_check(fv3_set_moist(at%ctx, at%fl%moist, at%q_con, at%cappa), 'set_moist')
+    end if
     if (consv_te > consv_min) &
       call fv3_check(fv3_compute_total_energy(at%ctx, rp, merge(1_c_int, 0_c_int, moist_phys), at%u, at%v, wp, dzp, at%pt, at%delp, &
                                               at%q, c_null_ptr, pep, pelnp, at%phis, at%te0), 'compute_total_energy')

@@ -35,6 +35,7 @@ program fv3_solo_refsig
   real(c_double), parameter :: RDGAS = 287.04d0, KAPPA = 2.d0/7.d0, GRAV = 9.80d0, CP_AIR = RDGAS/KAPPA
   integer :: un, n, isd, ied, jsd, jed
   logical :: hydrostatic, moist
+  real(c_double) :: zvir_ = 0.d0
   integer :: rank, nranks, px, py, gnx, gny, i0, j0
   character(len=1024) :: arg, idfile
   character(len=16) :: sfx
@@ -148,10 +149,17 @@ program fv3_solo_refsig
 
   if (whole) then
     fs%c2l_ord = 4; fs%tau = tau; fs%moist_phys = .false.
+    if (moist) then       ! the field table of the test: six water species in tracers 1 .. 6 (what FMS's tracer manager would answer)
+      fs%nwat = 6
+      call fv3_register_tracer_index('sphum', 1);   call fv3_register_tracer_index('liq_wat', 2)
+      call fv3_register_tracer_index('rainwat', 3); call fv3_register_tracer_index('ice_wat', 4)
+      call fv3_register_tracer_index('snowwat', 5); call fv3_register_tracer_index('graupel', 6)
+      fs%adiabatic = .false.; zvir_ = 0.6077d0      ! moist_cv reads the vapour: the virtual effect is on (rvgas / rdgas - 1)
+    end if
     if (hydrostatic) pkz = 1.d0     ! the state p_var would have left: here the file's pt is theta already (pkz = 1 <=> T = theta)
     do n = 1, nsteps
       call fv_dynamics(gnx + 1, gny + 1, int(npz), int(nq), 3, bdt, consv_te, .false., &
-                       .false., KAPPA, CP_AIR, 0.d0, ptop, 0, max(1, int(nq)), int(n_split), &
+                       .false., KAPPA, CP_AIR, zvir_, ptop, 0, max(1, int(nq)), int(n_split), &
                        0, u0, v0, u, v, w, delz, hydrostatic, pt, delp, q, &
                        ps, pe, pk, peln, pkz, phis, q_con, omga, ua, va, uc, vc, &
                        ak, bk, mfx, mfy, cx, cy, ze0, .false., &
@@ -165,6 +173,7 @@ program fv3_solo_refsig
     write(un) u, v, w, delp, pt, delz
     if (nq > 0) write(un) q
     write(un) ua
+    if (moist) write(un) q_con
     close(un)
     write(*,'(a,es24.16)') 'fv3_solo_refsig: done, sum(delp) = ', sum(delp(1:nx, 1:ny, :))
     stop

@@ -264,7 +264,7 @@ def _compare_blocks(res, ref, bd, what):
 
 
 def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, hydrostatic=False, layout=(1, 1),
-                              consv_te=0.0, tau=0.0):
+                              consv_te=0.0, tau=0.0, moist=False):
     """fv_dynamics called with the reference's argument list on host arrays (fv3_dyn_core_mod::fv_dynamics, driver fv3_solo_refsig in
     its fv_dynamics mode: T -> theta_v, k_split x (dyn_core, tracer_2d, remap), last_step, cubed_to_latlon) against the Python host's
     FvDynamics.step_from_temperature on the same state: u, v, w, delp, pt (T), delz, the tracers and ua bit-identical"""
@@ -282,10 +282,17 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
     rng = np.random.default_rng(5)
     q = np.asfortranarray(rng.uniform(0.0, 1.0, bd.shape("A", npz) + (nq,))) if nq else None
-    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic)
+    mo = None
+    if moist:      # thermostruct%use_cond = moist_kappa = .true. (the reference's defaults, fv_arrays.F90:1226-1227): six water species
+        import parity_remap as R
+        assert nq >= 6 and not hydrostatic
+        q[..., :6] *= 1.0e-3                       # small mixing ratios
+        mo = dict(use_cond=True, moist_kappa=True, q_con=bd.zeros("A", npz), cappa=bd.zeros("A", npz))   # fv_dynamics forms both itself
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, use_cond=moist, moist_kappa=moist)
     ctx = Context(g, npz, lib=lib)
     try:
-        fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=k_split, adiabatic=True, c2l_ord=4, consv_te=consv_te, tau=tau, moist_phys=False)
+        fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=k_split, adiabatic=not moist, c2l_ord=4, consv_te=consv_te, tau=tau, moist_phys=False,
+                        moist=dict(R.MOIST6) if moist else None)
         fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
         if nq:
             fv.set_tracers(q)
@@ -297,16 +304,20 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
         ref = {n: d[n].download() for n in (("u", "v", "delp", "pt", "ua") if hydrostatic else ("u", "v", "w", "delp", "pt", "delz", "ua"))}
         if nq:
             ref["q"] = d["q"].download()
+        if moist:
+            ref["q_con"] = d["q_con"].download()
     finally:
         ctx.close()
     exe = build_refsig(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
     fin, fout = os.path.join(str(workdir), "in_fd.bin"), os.path.join(str(workdir), "out_fd.bin")
     write_input(fin, bd, npz, nq, n_split, k_split, nsteps, True, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak, bk, st, q,
-                hydrostatic=hydrostatic, d_con=0.0, d_ext=fl.d_ext)
+                hydrostatic=hydrostatic, d_con=0.0, d_ext=fl.d_ext, moist=mo)
     spec = [(n, k, ()) for n, k in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC"))]
     if nq:
         spec.append(("q", "A", (nq,)))
     spec.append(("ua", "A", ()))
+    if moist:
+        spec.append(("q_con", "A", ()))
     os.environ["FV3_SOLO_CONSV_TE"], os.environ["FV3_SOLO_TAU"] = repr(float(consv_te)), repr(float(tau))
     try:
         res, out = _run_refsig(lib, exe, fin, fout, "fv_dynamics", layout, bd, npz, spec)

@@ -653,6 +653,10 @@ def test_fortran_dyn_core_with_the_reference_argument_list(prod, tmp_path):
     # the remap, last_step, cubed_to_latlon
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path)
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, hydrostatic=True, npz=12, nq=1)
+    # thermostruct%use_cond = moist_kappa = .true. -- the reference's DEFAULTS (fv_arrays.F90:1226-1227) -- through the reference-signature
+    # fv_dynamics: the water species by get_tracer_index, q_con / cappa formed by moist_cv inside, q_con handed back
+    assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, nq=7, moist=True)
+    assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, nq=6, moist=True, consv_te=1.0, npz=10)
 
 
 @pytest.mark.parametrize("use_cond,moist_kappa", [(True, False), (True, True), (False, True)])

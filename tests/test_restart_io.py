@@ -135,19 +135,17 @@ def test_tile_from_the_blocks_of_four_ranks(tmp_path):
     assert a == b
 
 
-def test_a_restarted_run_continues_bit_for_bit(tmp_path):
+def check_restarted_run_continues(lib, workdir, nx=16, ny=12, npz=8, nq=2):
     """two fv_dynamics calls in one go against one call, restart files, a fresh context started from them, the second call: the
-    same final state bit for bit (the reference CI's restart-reproducibility check); host-emulation build, nonhydrostatic, tracers"""
+    same final state bit for bit (the reference CI's restart-reproducibility check); nonhydrostatic, tracers"""
     import parity_common as P
     import parity_dyn as D
     import parity_nh as N
     from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
     from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
     from gfdl_atmos_cubed_sphere_amd.layout import periodic_fill
-    from gfdl_atmos_cubed_sphere_amd.lib import GRAV, KAPPA, RDGAS, Context, Fv3Lib
-    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostemu"), "-s"])
-    emu = Fv3Lib(os.path.join(HERE, "hostemu", "libfv3_hostemu.so"))
-    nx, ny, npz, nq = 16, 12, 8, 2
+    from gfdl_atmos_cubed_sphere_amd.lib import GRAV, KAPPA, RDGAS, Context
+    emu = lib
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     st, _ = D.make_state(bd, npz)
@@ -176,7 +174,7 @@ def test_a_restarted_run_continues_bit_for_bit(tmp_path):
     fv.set_tracers(q0)
     fv.step_from_temperature(8.0)
     mid = final(fv)
-    d = str(tmp_path)
+    d = str(workdir)
     RIO.write_core_levels(d, ak, bk)
     RIO.write_tile(d, bd, npz, dict(mid, phis=st["phis"]), tracers={n: mid["q"][:, :, :, i] for i, n in enumerate(names)})
     fv.step_from_temperature(8.0)
@@ -205,3 +203,19 @@ def test_a_restarted_run_continues_bit_for_bit(tmp_path):
         assert np.array_equal(bd.view(again[n], kind, *rr), bd.view(straight[n], kind, *rr)), n
     assert np.array_equal(again["delz"], straight["delz"])
     assert np.array_equal(bd.view(again["q"], "A", 1, nx, 1, ny), bd.view(straight["q"], "A", 1, nx, 1, ny))
+
+
+def test_a_restarted_run_continues_bit_for_bit(tmp_path):
+    """host-emulation build (the CPU suite)"""
+    from gfdl_atmos_cubed_sphere_amd.lib import Fv3Lib
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostemu"), "-s"])
+    check_restarted_run_continues(Fv3Lib(os.path.join(HERE, "hostemu", "libfv3_hostemu.so")), tmp_path)
+
+
+@pytest.mark.gpu
+def test_a_restarted_run_continues_bit_for_bit_on_the_gpu(tmp_path):
+    """the same through the HIP library on the MI355X, at a size with several strips and segments of the marching kernels: the device
+    state written as the reference's restart files (fv_core.res / fv_tracer.res per tile, tools/fv_io.F90:206-571), a fresh context
+    started from the files, the run continued -- bit for bit the uninterrupted run"""
+    from gfdl_atmos_cubed_sphere_amd import lib as L
+    check_restarted_run_continues(L.load(), tmp_path, nx=130, ny=70, npz=12, nq=2)
