@@ -341,7 +341,7 @@ def cubed_sphere_leg(a, torch, stream):
                  d["ut"], d["vt"], d["divg_d"], 1, 0.5 * dt, False)
         ctx.d_sw(par, None, d["delp"], d["pt"], d["u"], d["v"], d["w"], d["uc"], d["vc"], d["ua"], d["va"], d["divg_d"], d["mfx"],
                  d["mfy"], d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None, d["delp_out"], d["pt_out"], d["u_out"],
-                 d["v_out"], d["w_out"], None, d["heat_s"], d["diss_e"])
+                 d["v_out"], d["w_out"], None, None, None)     # d_con = 0: heat_s, diss_e = NULL (dyn_core.F90:798-812)
     for _ in range(5):
         pair()
     ctx.profile(True)

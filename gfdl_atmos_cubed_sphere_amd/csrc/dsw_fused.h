@@ -298,8 +298,8 @@ struct DswTransportFused {
           vstore_b_nt(a.w_out + oA, iA, wn, mO, on);
         }
         // (NULL: the caller does not read them -- fv3_d_sw; the stores are dropped, their row pointer is any valid one)
-        vstore_b_nt((a.heat_s ? a.heat_s : a.delp_out) + oCC, iCC, hs, mC, on && a.heat_s != nullptr);
-        vstore_b_nt((a.diss_e ? a.diss_e : a.delp_out) + oCC, iCC, de, mC, on && a.diss_e != nullptr);
+        vstore_b_nt((a.heat_s ? a.heat_s : a.delp_out) + oCC, iCC, hs, mC, on && a.heat_s != nullptr && !a.skip_heat);
+        vstore_b_nt((a.diss_e ? a.diss_e : a.delp_out) + oCC, iCC, de, mC, on && a.diss_e != nullptr && !a.skip_heat);
       }
       fym_prev = fym;
       yf_prev = sh.yf;

@@ -40,6 +40,9 @@ struct DswArgs {
   // the pass kernels of cubed_dsw.h own.  rsina: (is:ie+1, js:je+1), for the B-grid winds of the kinetic energy.
   int mask_w = 0;
   const double *rsina = nullptr;
+  // the caller passed heat_s / diss_e = NULL (nobody reads them) and heat_s / diss_e above are the context's scratch for the kernels that
+  // need real arrays (the damped levels' passes): the branch-free marching kernel does not store its zeros
+  int skip_heat = 0;
   // DswTransportFused<..., FLUXES = true> (the damped levels of a cubed-sphere face): the fluxes themselves are the result -- delp's
   // (with the del-2n fluxes dfx / dfy of delp added on the levels with dcoef > 1e-4, V / U layout: cubed_damp.h), w's and pt's
   // weighted with them -- and the fields are left to the pass that also applies the other damping terms (cubed_dsw.h D4)

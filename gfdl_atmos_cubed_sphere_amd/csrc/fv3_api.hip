@@ -153,6 +153,7 @@ struct fv3_ctx {
   int remap_lds;      // the remap with the column in LDS (remap_fast.h; bit-identical to the slab kernels) where it is built for the
                       // configuration (FV3_MI355X_REMAP_LDS: 0 / 1, default 1)
   int tj_fixed;          // an FV3_MI355X_MARCH_TJ* variable is set: take the rows per segment as given
+  int tj_env_fused;      // ... one of the d_sw kernels' (FV3_MI355X_MARCH_TJ_FUSED / _MOM)
   int csw_kpw;           // levels per wavefront in CswMarch (1 or 2; FV3_MI355X_CSW_KPW)
   int use_fused;         // 1: delp + w + pt in one marching kernel when the schemes allow (FV3_MI355X_FUSED=0: off)
   int use_march;         // 0: LDS-tile kernels only (FV3_MI355X_MARCH=0)
@@ -556,6 +557,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     for (const char *v : {"FV3_MI355X_MARCH_TJ", "FV3_MI355X_MARCH_TJ_FUSED", "FV3_MI355X_MARCH_TJ_MOM",
                           "FV3_MI355X_MARCH_TJ_KE", "FV3_MI355X_MARCH_TJ_CSW"})
       if (std::getenv(v)) c->tj_fixed = 1;
+    c->tj_env_fused = (std::getenv("FV3_MI355X_MARCH_TJ_FUSED") || std::getenv("FV3_MI355X_MARCH_TJ_MOM")) ? 1 : 0;
     e = std::getenv("FV3_MI355X_MARCH_TJ");
     c->march_tj = e ? std::atoi(e) : 48;
     if (c->march_tj < 1) c->march_tj = 48;
@@ -1446,7 +1448,8 @@ static int dsw_transport_march(fv3_ctx *c, const DswArgs &a, int region = 0) {
   const int nw = md.nwaves(c->n_plain);
   if (c->use_fused && !a.use_cond && a.hord_dp == a.hord_tm && (a.hydrostatic || a.hord_dp == a.hord_vt)) {
     if (c->n_plain == 0) return 0;
-    MarchDims mf = make_march_dims(g, seg_rows(c, c->march_tj_fused, g.npz));
+    // (the interior of a cubed-sphere face, six faces a launch: seven 55-row segments measured 3 % better than eight of 48 there)
+    MarchDims mf = make_march_dims(g, seg_rows(c, (a.mask_w && !c->tj_env_fused) ? 55 : c->march_tj_fused, g.npz));
     mf.klist = c->klist;
     const int NS = mf.nstrips, NG = mf.nsegs;
     auto box = [&](int s0, int ns, int g0, int ng) -> int {
@@ -1506,7 +1509,7 @@ static int dsw_momentum_march(fv3_ctx *c, const DswArgs &a, int part = 0) {
   const bool fused_m = c->use_fused != 0;
   if (!fused_m && !c->ke_scr) RT(rt_malloc((void **)&c->ke_scr, sizeof(double) * g.nB() * g.npz));
   if (fused_m) {
-    MarchDims mf = make_march_dims(g, seg_rows(c, c->march_tj_mom, g.npz));
+    MarchDims mf = make_march_dims(g, seg_rows(c, (a.mask_w && !c->tj_env_fused) ? 55 : c->march_tj_mom, g.npz));
     mf.klist = c->klist_m;
     if (FV3_BF && a.mask_w == 0)
       balance_segments(mf, c->n_plain_m, g.ny, ((g.geom == 2 && FV3_MOM_3W) ? 3 : 2) * c->round_simds, mf.tj);
@@ -1952,6 +1955,8 @@ static int d_sw_impl(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const d
   if (p->use_cond && (!q_con || !q_con_out)) return fail("fv3_d_sw: use_cond needs q_con and q_con_out");
   if (delp == delp_out || pt == pt_out || u == u_out || v == v_out || (w && w == w_out))
     return fail("fv3_d_sw: *_out buffers must not alias the inputs");
+  if ((!heat_s && c->lev_has_dcon) || (!diss_e && c->g.do_diss_est))
+    return fail("fv3_d_sw: heat_s = NULL with d_con > 1e-5 on some level / diss_e = NULL with do_diss_est: the caller reads them (dyn_core.F90:798-812)");
   const Grid &g = c->g;
   const int npz = g.npz;
   DswArgs a;
@@ -1973,6 +1978,7 @@ static int d_sw_impl(fv3_ctx *c, const fv3_dsw_params *p, double *delpc, const d
     if (!a.heat_s || !a.diss_e) {
       for (int n = 0; n < 2; n++)
         if (!c->heat_scr[n]) RT(rt_malloc((void **)&c->heat_scr[n], sizeof(double) * g.nCC() * npz));
+      a.skip_heat = (!a.heat_s && !a.diss_e) ? 1 : 0;   // the marching kernel of the face interior then stores neither
       if (!a.heat_s) a.heat_s = c->heat_scr[0];
       if (!a.diss_e) a.diss_e = c->heat_scr[1];
     }
