@@ -44,9 +44,11 @@ struct NhConsts {
 #ifdef FV3_HOST_EMU
 #define FV3_RESTRICT
 #define FV3_UNROLL4
+#define FV3_UNROLL_ALL
 #else
 #define FV3_RESTRICT __restrict__
 #define FV3_UNROLL4 _Pragma("unroll 4")
+#define FV3_UNROLL_ALL _Pragma("unroll")
 #endif
 // One sweep from the surface up: the flux-form update of a level does not depend on the other levels, and the monotonicity fix
 // (:193-199) runs from the bottom, so the thread applies it to each level as it is formed and writes gz once (the first form of this
@@ -790,16 +792,48 @@ struct A2BCorners {
   int sum_form = 0;       // 1: qout = 0.5*(qxx + qyy) with the two 4-point sums formed separately (the cubed-sphere branch,
                           // a2b_edge.F90:236-286) instead of the combined sum of the grid_type >= 3 branch (:292-315)
   static constexpr int W = TI + 5, H = TJ + 5;  // corners [i0, i0+TI] need cells [i0-2, i0+TI+1]
-  static constexpr int lds_doubles = W * H;
+  // A tile per field: the cells of every field of the level are requested together and go to LDS behind ONE barrier (that orders LDS
+  // only: inputs and outputs are distinct arrays), so no field waits for the stores of the one before it.  The first form pushed the
+  // fields through one tile, __syncthreads() (= s_waitcnt vmcnt(0): loads AND stores) on either side of every one of them.
+  static constexpr int lds_doubles = 4 * W * H;
+  static constexpr int kIt = (W * H + kNT - 1) / kNT;
   FV3_HD void operator()(int bx, int by, int bz, int tid, double *lds) const {
     constexpr double a1 = 0.5625, a2 = -0.0625, b1 = 7. / 12., b2 = -1. / 12.;
     const int k = bz;
     const int i0 = g.is + bx * TI, j0 = g.js + by * TJ;
-    const Tile s{lds, i0 - 2, j0 - 2, W};
-    for (int f = 0; f < nf; f++) {
-      if (k >= nlev[f]) continue;
+    bool act[4], ovr[4];
+    for (int f = 0; f < 4; f++) {
+      ovr[f] = f < nf && k < nlev[f] && k == 0 && ((override_mask >> f) & 1);
+      act[f] = f < nf && k < nlev[f] && !ovr[f];
+    }
+    double v[4][kIt];
+    FV3_UNROLL_ALL
+    for (int f = 0; f < 4; f++) {
+      if (!act[f]) continue;
+      const double *src = in[f] + (size_t)k * g.nA();
+      FV3_UNROLL_ALL
+      for (int it = 0; it < kIt; it++) {
+        const int idx = tid + it * kNT, li = idx % W, lj = idx / W;
+        const int i = i0 - 2 + li, j = j0 - 2 + lj;
+        v[f][it] = 0.;
+        if (idx < W * H && i >= g.isd && i <= g.ied && j >= g.jsd && j <= g.jed) v[f][it] = src[(j - g.jsd) * g.nid + (i - g.isd)];
+      }
+    }
+    FV3_UNROLL_ALL
+    for (int f = 0; f < 4; f++) {
+      if (!act[f]) continue;
+      double *t = lds + f * (W * H);
+      FV3_UNROLL_ALL
+      for (int it = 0; it < kIt; it++) {
+        const int idx = tid + it * kNT;
+        if (idx < W * H) t[idx] = scale[f] != 1.0 ? v[f][it] * scale[f] : v[f][it];
+      }
+    }
+    FV3_SYNC_LDS();
+    for (int f = 0; f < 4; f++) {
+      if (!act[f] && !ovr[f]) continue;
       double *o = out[f] + (size_t)k * g.nA();
-      if (k == 0 && ((override_mask >> f) & 1)) {
+      if (ovr[f]) {
         FV3_TILE_FOR(TI, TJ, li_, lj_) {
           const int i = i0 + li_, j = j0 + lj_;
           if (i > g.ie + 1 || j > g.je + 1) continue;
@@ -807,13 +841,7 @@ struct A2BCorners {
         }
         continue;
       }
-      FV3_SYNC();
-      load_tile<W, H>(s, in[f] + (size_t)k * g.nA(), g.nid, g.isd, g.ied, g.jsd, g.jed, tid);
-      if (scale[f] != 1.0) {
-        FV3_SYNC();
-        FV3_TILE_FOR(W, H, li, lj) { s.p[lj * W + li] = s.p[lj * W + li] * scale[f]; }
-      }
-      FV3_SYNC();
+      const Tile s{lds + f * (W * H), i0 - 2, j0 - 2, W};
       // a thread takes the NV corners (i, j .. j + NV - 1): their 4 x (NV + 3) cells once into registers (the 4 x 4 blocks of
       // neighbouring corners share 12 cells, and qx / qy of one corner read the same 16), then the sums of the reference
       constexpr int NV = 2;   // 4 (4 x 7 cells, 32 x 32 tiles) was measured slower: 0.43 against 0.40 ms
