@@ -47,6 +47,8 @@ PAIR_ALG_BYTES_DCON0 = 320.0 # ... with d_con = 0 (the flags this bench runs): h
 # untimed passes before the profiled pass and the W warm-up steps (FV3_BENCH_SPINUP): the clocks of an idle MI355X take a few
 # hundred launches to settle
 SPINUP = int(os.environ.get("FV3_BENCH_SPINUP", "0"))
+DRYRUN = os.environ.get("FV3_BENCH_DRYRUN") == "1"   # see main()
+DEV = "cpu" if DRYRUN else "cuda"
 
 
 def level_sets(lev, sponge_march=False):
@@ -246,7 +248,7 @@ def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=True
     fence()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device=DEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     wall = el / nrep
@@ -550,7 +552,7 @@ def cubed_six_ranks(a, torch, dist, rank, json_fd):
         step()
     fence()
     el = time.perf_counter() - t0
-    t = torch.tensor([el], dtype=torch.float64, device="cuda")
+    t = torch.tensor([el], dtype=torch.float64, device=DEV)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
     cells = nx * nx * npz
@@ -567,6 +569,8 @@ def cubed_six_ranks(a, torch, dist, rank, json_fd):
                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": cells * PAIR_ALG_BYTES / (el / a.steps) / HBM_PEAK, "traffic": None,
                         "note": "per GPU: one face's algorithmic bytes over the step's wall time (exchange included)"},
            "cpu_baseline": None}
+    if DRYRUN:
+        out["dry_run"] = "FV3_BENCH_DRYRUN=1: host logic harness + gloo, no GPU -- plumbing only, the numbers mean nothing"
     del d
     try:        # whole model steps: BASELINE configs[2] with one face per GPU
         ak, bk, _, _ = set_eta(npz) if npz in (79, 127) else (None, None, None, None)
@@ -593,7 +597,7 @@ def cubed_six_ranks(a, torch, dist, rank, json_fd):
             fv.step(dt_atmos)
         fence()
         wall = (time.perf_counter() - t0) / nrep
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device=DEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
         out["sphere_six_gpus"] = {"grid": f"C{nx} L{npz}", "sypd": dt_atmos / (365.0 * wall), "wall_s_per_dt_atmos": wall,
@@ -627,11 +631,25 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         a.gpus = world
+    if DRYRUN:
+        # FV3_BENCH_DRYRUN=1: the plumbing of the N-rank runs (rank layout, communicators, halo / cube-edge exchanges, the barriers, the
+        # MAX over ranks, the one JSON line) WITHOUT a GPU: the logic harness of the test-suite (the kernel sources compiled for the
+        # host) in place of the HIP library, gloo in place of RCCL.  What it prints is marked "dry_run" and measures nothing.
+        os.environ["FV3_MI355X_SO"] = os.path.join(ROOT, "tests", "hostemu", "libfv3_hostemu.so")
+
+        class _NoStream:
+            cuda_stream = 0
+        torch.cuda.set_device = lambda *x, **k: None
+        torch.cuda.synchronize = lambda *x, **k: None
+        torch.cuda.current_stream = lambda *x, **k: _NoStream()
+        torch.cuda.Stream = lambda *x, **k: _NoStream()
     torch.cuda.set_device(local)
     # FV3_BENCH_LOOPBACK=1 (one GPU): every halo message goes through RCCL to this same rank and d_sw runs in its
     # interior / rest form -- the per-step flow of the N-GPU runs, to see what the message path costs
     loopback = world == 1 and os.environ.get("FV3_BENCH_LOOPBACK") == "1"
-    if world > 1:
+    if world > 1 and DRYRUN:
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     elif loopback:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -782,7 +800,7 @@ def main():
         rep = ctx.profile_report()
         ctx.profile(False)
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            t = torch.tensor([el], dtype=torch.float64, device=DEV)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         finite = bool(np.isfinite(d["u_out"].download()).all())
@@ -795,7 +813,7 @@ def main():
             per_step = ms / nprof
             t_sum += per_step
             e = {"launches_per_step": n / nprof, "ms_per_step": per_step}
-            if name in ALG and nlev[ALG[name][1]] > 0:
+            if name in ALG and nlev[ALG[name][1]] > 0 and per_step > 0.0:
                 nb, which = ALG[name]
                 c = nx * nx * nlev[which]
                 e.update(alg_bytes_per_cell=nb, levels=nlev[which], GBps=c * nb / (per_step * 1e-3) / 1e9,
@@ -860,6 +878,8 @@ def main():
                             os.environ.get("FV3_MI355X_SPONGE_MARCH", "1") != "0" else "d2_bg_k1 0.20, d2_bg_k2 0.015 (2 levels), LDS-tile kernels"),
                       "heat_source": "d_con = 0: heat_s / diss_e = NULL (nobody reads them, dyn_core.F90:798-812); pair priced at 336 B and at 320 B"},
            "finite": finite, "roofline": roof, "general_metrics": gm}
+    if DRYRUN:
+        out["dry_run"] = "FV3_BENCH_DRYRUN=1: host logic harness + gloo, no GPU -- plumbing only, the numbers mean nothing"
     # the secondary legs must never cost the headline line: a failure there is reported, not raised
     out["model_step"] = None
     # N > 1: the SYPD leg is off unless asked for (a failure on one rank would leave the others in a collective)

@@ -81,6 +81,9 @@ struct fv3_ctx {
   bool dp0_ready;
   double *scratch[8];
   double *ray_d;         // pm(k), rf(k) of Rayleigh_Friction
+  double *rff_d;         // rff(k) of fast_tau_w_sec (npz, 1.0 below k_rf) or null; rf(k), dp(k) of Ray_fast behind it (fv3_set_ray_fast)
+  int rff_on, rayf_kmax, rayf_krf;
+  double rayf_dm;
   bool moist_on;         // fv3_set_moist: moist thermodynamics of the remap
   bool remap_te_on;      // fv3_set_remap_te: total energy remapped in the place of T_v / theta_v
   const double *rte_hs;  // A
@@ -620,6 +623,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->dp0 = nullptr; c->edge_dev = nullptr; c->dp0_ready = false;
   c->akbk = nullptr; c->kord_tr_dev = nullptr; c->akbk_ready = false;
   c->remap_scr = nullptr; c->remap_scr_n = 0; c->ray_d = nullptr;
+  c->rff_d = nullptr; c->rff_on = 0; c->rayf_kmax = -1; c->rayf_krf = 0; c->rayf_dm = 1.;
   c->q_con = nullptr; c->cappa = nullptr;
   c->moist_on = false; c->moist_qcon = nullptr; c->moist_cappa = nullptr;
   c->remap_te_on = false; c->rte_hs = nullptr; c->rte_te = nullptr;
@@ -653,6 +657,7 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   if (c->akbk) rt_free(c->akbk);
   if (c->remap_scr) rt_free(c->remap_scr);
   if (c->ray_d) rt_free(c->ray_d);
+  if (c->rff_d) rt_free(c->rff_d);
   if (c->trc_d) rt_free(c->trc_d);
   if (c->trc_i) rt_free(c->trc_i);
   if (c->ones_i) rt_free(c->ones_i);
@@ -3065,8 +3070,58 @@ extern "C" int fv3_update_dz_c(fv3_ctx *c, double dt, const double *zs, const do
   return 0;
 }
 
-static NhConsts to_consts(const fv3_nh_consts *cn) {
-  return NhConsts{cn->grav, cn->rdgas, cn->cp_air, cn->akap, cn->ptop, cn->p_fac, cn->a_imp};
+static NhConsts to_consts(const fv3_ctx *c, const fv3_nh_consts *cn) {
+  return NhConsts{cn->grav, cn->rdgas, cn->cp_air, cn->akap, cn->ptop, cn->p_fac, cn->a_imp, c->rff_on ? c->rff_d : nullptr};
+}
+
+// the three level tables behind c->rff_d: rff of fast_tau_w_sec, rf and dp of Ray_fast (npz doubles each)
+static int level_tables(fv3_ctx *c) {
+  if (c->rff_d) return 0;
+  const int n = c->g.npz;
+  RT(rt_malloc((void **)&c->rff_d, sizeof(double) * 3 * n));
+  std::vector<double> one(3 * (size_t)n, 1.0);
+  RT(rtf_h2d(c->rff_d, one.data(), sizeof(double) * 3 * n, c->stream));
+  RT(rtf_sync(c->stream));
+  return 0;
+}
+
+extern "C" int fv3_set_fast_tau_w(fv3_ctx *c, int k_rf, const double *rff) {
+  if (!c || !c->grid_ready) return fail("fv3_set_fast_tau_w: context has no grid");
+  if (k_rf < 0 || k_rf > c->g.npz || (k_rf > 0 && !rff)) return fail("fv3_set_fast_tau_w: k_rf out of range / null table");
+  c->rff_on = 0;
+  if (k_rf == 0) return 0;
+  RT(level_tables(c));
+  std::vector<double> t((size_t)c->g.npz, 1.0);
+  for (int k = 0; k < k_rf; k++) t[k] = rff[k];
+  RT(rtf_sync(c->stream));   // a solver still reading the previous table
+  RT(rtf_h2d(c->rff_d, t.data(), sizeof(double) * c->g.npz, c->stream));
+  RT(rtf_sync(c->stream));
+  c->rff_on = 1;
+  return 0;
+}
+
+extern "C" int fv3_set_ray_fast(fv3_ctx *c, int kmax, int k_rf, double dm, const double *rf, const double *dp) {
+  if (!c || !c->grid_ready) return fail("fv3_set_ray_fast: context has no grid");
+  const int n = c->g.npz;
+  if (kmax < 0 || kmax > n || k_rf < 0 || k_rf > n || !rf || !dp) return fail("fv3_set_ray_fast: kmax / k_rf out of range or null table");
+  if (k_rf > 0 && !(dm > 0.)) return fail("fv3_set_ray_fast: dm (the mass of the levels k <= k_rf) must be positive");
+  RT(level_tables(c));
+  RT(rtf_sync(c->stream));
+  RT(rtf_h2d(c->rff_d + n, rf, sizeof(double) * kmax, c->stream));
+  RT(rtf_h2d(c->rff_d + 2 * n, dp, sizeof(double) * n, c->stream));
+  RT(rtf_sync(c->stream));
+  c->rayf_kmax = kmax; c->rayf_krf = k_rf; c->rayf_dm = dm;
+  return 0;
+}
+
+extern "C" int fv3_ray_fast(fv3_ctx *c, double *u, double *v, double *w, int hydrostatic) {
+  if (!c || !c->grid_ready) return fail("fv3_ray_fast: context has no grid");
+  if (c->rayf_kmax < 0) return fail("fv3_ray_fast: call fv3_set_ray_fast first");
+  if (!u || !v || (!hydrostatic && !w)) return fail("fv3_ray_fast: null argument");
+  const Grid &g = c->g;
+  RayFast kf{g, c->rayf_kmax, c->rayf_krf, hydrostatic, c->rayf_dm, c->rff_d + g.npz, c->rff_d + 2 * g.npz, u, v, w};
+  RT(launch_c(c, "ray_fast", col_grid((g.nx + 1) * (g.ny + 1)), kf));
+  return 0;
 }
 
 extern "C" int fv3_set_condensate(fv3_ctx *c, const double *q_con, const double *cappa) {
@@ -3089,26 +3144,26 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn,
   if (cn->a_imp <= 0.5) {      // nh_utils.F90:449-459: a_imp < -0.01 SIM3p0_solver, otherwise RIM_2D(c_core = .true.)
     if (c->q_con) return fail("fv3_riem_solver_c: use_cond with a_imp <= 0.5 (SIM3p0 / RIM_2D) is not built");
     if (c->g.npz > kAltKm - 1 || c->g.npz < 2) return fail("fv3_riem_solver_c: SIM3p0 / RIM_2D are built for 2 <= npz <= %d", kAltKm - 1);
-    RiemSolverAlt<true> kf{c->g, c->g.npz, cn->a_imp < -0.01 ? 0 : 2, cn->m_split >= 1 ? cn->m_split : 1, dt, to_consts(cn), hs, pt, delp, ws,
+    RiemSolverAlt<true> kf{c->g, c->g.npz, cn->a_imp < -0.01 ? 0 : 2, cn->m_split >= 1 ? cn->m_split : 1, dt, to_consts(c, cn), hs, pt, delp, ws,
                            const_cast<double *>(w3), gz, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0};
     RT(launch_c(c, "riem_solver_c", col_grid((c->g.nx + 2) * (c->g.ny + 2)), kf));
     return 0;
   }
   if (c->q_con && c->riem_lds && c->g.npz <= 127 && c->g.npz >= 2) {   // use_cond (+ moist_kappa) in the reference's order
-    RiemFast<true, true, false, true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
+    RiemFast<true, true, false, true> kf{c->g, c->g.npz, dt, to_consts(c, cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0, c->q_con, c->cappa};
     RT(launch_p2(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
     return 0;
   }
   if (!c->q_con && c->g.npz <= 127 && c->g.npz >= 2) {   // Riem_Solver_c is SIM1 whatever a_imp is
     if (c->fast & 2) {         // tolerance mode: blocked parallel scans
-      RiemFast<true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
+      RiemFast<true> kf{c->g, c->g.npz, dt, to_consts(c, cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0};
       RT(launch_p2(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
       return 0;
     }
     if (c->riem_lds) {         // the recurrences in the reference's order: the slab kernel's bits
-      RiemFast<true, true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
+      RiemFast<true, true> kf{c->g, c->g.npz, dt, to_consts(c, cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0};
       if (const char *pe_ = std::getenv("FV3_MI355X_RIEM_PROBE")) kf.probe = std::atoi(pe_);
       RT(launch_p2(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
@@ -3118,11 +3173,11 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn,
   if (need_scratch(c, 4)) return 1;
   const int ncc = (c->g.nx + 2) * (c->g.ny + 2), pool = col_pool(c, ncc);
   if (c->q_con) {
-    RiemSolverC<true> kf{c->g, c->g.npz, dt, to_consts(cn), hs, w3, pt, delp, ws, gz, pef,
+    RiemSolverC<true> kf{c->g, c->g.npz, dt, to_consts(c, cn), hs, w3, pt, delp, ws, gz, pef,
                          c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], c->q_con, c->cappa, c->riem_blocked, pool};
     RT(launch_c(c, "riem_solver_c", pool ? col_grid(pool * 256) : col_grid(ncc), kf));
   } else {
-    RiemSolverC<false> kf{c->g, c->g.npz, dt, to_consts(cn), hs, w3, pt, delp, ws, gz, pef,
+    RiemSolverC<false> kf{c->g, c->g.npz, dt, to_consts(c, cn), hs, w3, pt, delp, ws, gz, pef,
                           c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3], nullptr, nullptr, c->riem_blocked, pool};
     RT(launch_c(c, "riem_solver_c", pool ? col_grid(pool * 256) : col_grid(ncc), kf));
   }
@@ -3139,37 +3194,37 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
     if (c->q_con || c->cappa) return fail("fv3_riem_solver3: use_cond / moist_kappa with a_imp <= 0.5 (SIM3 / SIM3p0 / RIM_2D) is not built");
     if (c->g.npz > kAltKm - 1 || c->g.npz < 2) return fail("fv3_riem_solver3: SIM3 / SIM3p0 / RIM_2D are built for 2 <= npz <= %d", kAltKm - 1);
     RiemSolverAlt<false> kf{c->g, c->g.npz, cn->a_imp < -0.999 ? 0 : (cn->a_imp < -0.5 ? 1 : 2), cn->m_split >= 1 ? cn->m_split : 1, dt,
-                            to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr, use_logp, last_call, fp_out};
+                            to_consts(c, cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr, use_logp, last_call, fp_out};
     RT(launch_c(c, "riem_solver3", col_grid(c->g.nx * c->g.ny), kf));
     return 0;
   }
   if ((c->q_con || c->cappa) && c->riem_lds && c->g.npz <= 127 && c->g.npz >= 2) {   // use_cond / moist_kappa, SIM1 or SIM
     if (cn->a_imp > 0.999) {
-      RiemFast<false, true, false, true> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
+      RiemFast<false, true, false, true> kf{c->g, c->g.npz, dt, to_consts(c, cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
                                             use_logp, last_call, fp_out, c->q_con, c->cappa};
       RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
     } else {
-      RiemFast<false, true, true, true> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
+      RiemFast<false, true, true, true> kf{c->g, c->g.npz, dt, to_consts(c, cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
                                            use_logp, last_call, fp_out, c->q_con, c->cappa};
       RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
     }
     return 0;
   }
   if (!c->q_con && !c->cappa && cn->a_imp <= 0.999 && c->riem_lds && c->g.npz <= 127 && c->g.npz >= 2) {   // SIM_solver (the reference's default a_imp = 0.75)
-    RiemFast<false, true, true> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
+    RiemFast<false, true, true> kf{c->g, c->g.npz, dt, to_consts(c, cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
                                    use_logp, last_call, fp_out};
     RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
     return 0;
   }
   if (!c->q_con && !c->cappa && cn->a_imp > 0.999 && c->g.npz <= 127 && c->g.npz >= 2) {
     if (c->fast & 4) {
-      RiemFast<false> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
+      RiemFast<false> kf{c->g, c->g.npz, dt, to_consts(c, cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
                          use_logp, last_call, fp_out};
       RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
       return 0;
     }
     if (c->riem_lds) {
-      RiemFast<false, true> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
+      RiemFast<false, true> kf{c->g, c->g.npz, dt, to_consts(c, cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
                                use_logp, last_call, fp_out};
       if (const char *pe_ = std::getenv("FV3_MI355X_RIEM_PROBE")) kf.probe = std::atoi(pe_);
       RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
@@ -3179,12 +3234,12 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
   if (need_scratch(c, 4)) return 1;
   const int ncc = c->g.nx * c->g.ny, pool = col_pool(c, ncc);
   if (c->q_con || c->cappa) {
-    RiemSolver3<true> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, delz, zh, pe, ppe, pk3, pk, peln,
+    RiemSolver3<true> kf{c->g, c->g.npz, dt, to_consts(c, cn), zs, pt, delp, ws, w, delz, zh, pe, ppe, pk3, pk, peln,
                          use_logp, last_call, fp_out, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3],
                          c->q_con, c->cappa, c->riem_blocked, pool};
     RT(launch_c(c, "riem_solver3", pool ? col_grid(pool * 256) : col_grid(ncc), kf));
   } else {
-    RiemSolver3<false> kf{c->g, c->g.npz, dt, to_consts(cn), zs, pt, delp, ws, w, delz, zh, pe, ppe, pk3, pk, peln,
+    RiemSolver3<false> kf{c->g, c->g.npz, dt, to_consts(c, cn), zs, pt, delp, ws, w, delz, zh, pe, ppe, pk3, pk, peln,
                           use_logp, last_call, fp_out, c->scratch[0], c->scratch[1], c->scratch[2], c->scratch[3],
                           nullptr, nullptr, c->riem_blocked, pool};
     RT(launch_c(c, "riem_solver3", pool ? col_grid(pool * 256) : col_grid(ncc), kf));

@@ -1022,6 +1022,7 @@ struct RiemFast {
           w2[q] = vsel(real[q], vlds_ld(B2, c0, q), vd(0.0));
         else
           w2[q] = keep_w2[s][q];
+        if (cn.rff) w2[q] = w2[q] * vrow_ld(cn.rff, q, km);   // fast_tau_w_sec: w2(k) * rff(k) behind the back substitution (nh_utils.F90:1363-1371)
       }
       for (int q = 0; q <= kFL; q++) pemv[q] = keep_pem[s][q];
       if (!CG) {

@@ -29,6 +29,9 @@ constexpr double kDzMin = 2.;  // nh_utils.F90:49
 
 struct NhConsts {
   double grav, rdgas, cp_air, akap, ptop, p_fac, a_imp;
+  // fast_tau_w_sec > 0 (nh_utils.F90:356-367, :1363-1371, :1498-1506): rff(k) of the Rayleigh damping of w inside SIM1_solver / SIM_solver,
+  // npz values on the device, 1.0 below k_rf (x * 1.0 is x: the reference's loop over k <= k_rf); null = off (fv3_set_fast_tau_w)
+  const double *rff = nullptr;
 };
 
 #define FV3_COL_FOR(c, ncol) for (int c = bx * 256 + tid; c < (bx + 1) * 256 && c < (ncol); c += kNT)
@@ -366,7 +369,9 @@ FV3_HD void sim_column(int km, size_t ls, size_t ss, const ColIn &in, double dt,
       const double pp_n = S(s_pp, k + 1);
       S(s_pp, k) = pe;
       if (!sim1) S(s_gam, k) = pp_k2;
-      const double w2 = S(s_w, k), w1 = L(in.w, k);
+      double w2 = S(s_w, k);
+      const double w1 = L(in.w, k);
+      if (cn.rff) w2 = w2 * cn.rff[k - 1];   // :1363-1371 / :1498-1506, after the back substitution
       if (sim1) {
         on_pe(k, pe);      // SIM1: pe2 is final here (no blend)
         pe = pe + dm2 * (w2 - w1) * rdt;
@@ -1732,6 +1737,42 @@ struct OmgaUpdate {  // dyn_core.F90:409-421, :1182-1191
       for (int k = 1; k <= km; k++) {
         pem = pem + delp0[(size_t)(k - 1) * nA + o];
         omga[(size_t)(k - 1) * nA + o] = (pe[peb + (size_t)k * (g.nx + 2)] - pem) * rdt;
+      }
+    }
+  }
+};
+
+// Ray_fast, dyn_core.F90:2485-2601 (RF_fast: the "inline" Rayleigh friction at the end of every acoustic substep, :1057-1060): on the
+// levels k <= kmax (pfull < rf_cutoff) u, v (and w) are scaled by rf(k) = 1 / (1 + rff(k)); what the winds of a column lose,
+// sum (1 - rf(k)) dp(k) u(k) / dm, goes back to its levels k <= k_rf (dm = sum of dp over them).  One thread per (i, j) of
+// [is, ie+1] x [js, je+1] takes the u column, the v column and the w column that start there; rf, dp: device tables (the profile and dm
+// are the host's, evaluated once in the reference's order: fv3_set_ray_fast).
+struct RayFast {
+  Grid g;
+  int kmax, k_rf, hydrostatic;
+  double dm;
+  const double *rf, *dp;
+  double *u, *v, *w;
+  FV3_HD void column(double *f, size_t ls) const {
+    double dmf = 0.;
+    for (int k = 0; k < kmax; k++) {
+      const double x = f[(size_t)k * ls];
+      dmf = dmf + (1. - rf[k]) * dp[k] * x;
+      f[(size_t)k * ls] = rf[k] * x;
+    }
+    dmf = dmf / dm;
+    for (int k = 0; k < k_rf; k++) f[(size_t)k * ls] = f[(size_t)k * ls] + dmf;
+  }
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int wd = g.nx + 1, ncol = wd * (g.ny + 1);
+    FV3_COL_FOR(c, ncol) {
+      const int i = g.is + c % wd, j = g.js + c / wd;
+      if (i <= g.ie) column(u + g.iU(i, j), g.nU());
+      if (j <= g.je) column(v + g.iV(i, j), g.nV());
+      if (!hydrostatic && i <= g.ie && j <= g.je) {
+        const size_t nA = g.nA();
+        double *wc = w + g.iA(i, j);
+        for (int k = 0; k < kmax; k++) wc[(size_t)k * nA] = rf[k] * wc[(size_t)k * nA];
       }
     }
   }

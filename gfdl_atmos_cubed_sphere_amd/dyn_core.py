@@ -58,6 +58,10 @@ class DynFlags:
     grav: float = GRAV
     rdgas: float = RDGAS
     cp_air: float = CP_AIR
+    fast_tau_w_sec: float = 0.0   # > 1e-5: Rayleigh damping of w inside SIM1 / SIM (nh_utils.F90:356-367, :1363-1371), fv_arrays.F90:702
+    rf_fast: bool = False         # RF_fast: Ray_fast at the end of every acoustic substep when tau > 0 (dyn_core.F90:1057-1060)
+    tau: float = 0.0              # days (Ray_fast; the Rayleigh_Friction / _Super of fv_dynamics is FvDynamics' own tau)
+    rf_cutoff: float = 30.0e2
 
 
 def level_coefficients(npz: int, fl: DynFlags) -> dict:
@@ -106,8 +110,13 @@ class DynCore:
     PROGNOSTIC = (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"))
 
     def __init__(self, ctx: Context, flags: DynFlags, dp_ref, px: int = 1, py: int = 1, rank: int = 0, world: int = 1,
-                 halo=None):
+                 halo=None, pfull=None, ks: int = 0):
+        """pfull (npz; fv_dynamics.F90:254-262) and ks (the levels of pure pressure) are read by fast_tau_w_sec / RF_fast only"""
         self.ctx, self.fl = ctx, flags
+        self.pfull, self.ks, self.dp_ref = (None if pfull is None else np.asarray(pfull, dtype=np.float64)), int(ks), np.asarray(dp_ref, dtype=np.float64)
+        self._rfw_ready = self._rff_ready = False
+        if (flags.fast_tau_w_sec > 1.0e-5 or (flags.rf_fast and flags.tau > 0.0)) and pfull is None:
+            raise ValueError("fast_tau_w_sec / RF_fast need pfull (and ks)")
         self.npz = ctx.npz
         # halo: an object with HaloExchanger's interface (cubed_dyn.CubeHaloAdapter for the six faces of the sphere)
         self.halo = halo if halo is not None else HaloExchanger(ctx, px, py, rank, world)
@@ -146,6 +155,49 @@ class DynCore:
         ctx.set_dp_ref(dp_ref)
         self.cn = nh_consts(flags.ptop, p_fac=flags.p_fac, a_imp=flags.a_imp, akap=flags.akap, grav=flags.grav,
                             rdgas=flags.rdgas, cp_air=flags.cp_air, m_split=getattr(flags, "m_split", 1))
+
+    # -- the damping profiles the reference evaluates on the first call and keeps ------------------------
+    def fast_tau_w_profile(self, dt_c: float):
+        """rff(1:k_rf) of nh_utils.F90:356-367: Riem_Solver_c's first call, with ITS dt (half the acoustic step)"""
+        fl, rff = self.fl, []
+        for pf in self.pfull:
+            if pf > fl.rf_cutoff:
+                break
+            rff_temp = dt_c / fl.fast_tau_w_sec * np.sin(0.5 * np.pi * np.log(fl.rf_cutoff / pf) / np.log(fl.rf_cutoff / fl.ptop)) ** 2
+            rff.append(1.0 / (1.0 + rff_temp))
+        return np.array(rff)
+
+    def ray_fast_profile(self, dt: float):
+        """(kmax, k_rf, dm, rf) of Ray_fast's first call (dyn_core.F90:2519-2545)"""
+        fl, npz = self.fl, self.npz
+        tau0 = fl.tau * 86400.0
+        rf, kmax = np.ones(npz), 1
+        for k, pf in enumerate(self.pfull):
+            if pf < fl.rf_cutoff:
+                rffk = dt / tau0 * np.sin(0.5 * np.pi * np.log(fl.rf_cutoff / pf) / np.log(fl.rf_cutoff / fl.ptop)) ** 2
+                kmax = k + 1
+                rf[k] = 1.0 / (1.0 + rffk)
+            else:
+                break
+        dm, k_rf = 0.0, 0
+        for k in range(self.ks):
+            if self.pfull[k] < fl.rf_cutoff + min(100.0, 10.0 * fl.ptop):
+                dm = dm + float(self.dp_ref[k])
+                k_rf = k + 1
+            else:
+                break
+        return kmax, k_rf, dm, rf
+
+    def _ray_fast(self, dt: float):
+        """dyn_core.F90:1057-1060"""
+        fl = self.fl
+        if not (fl.rf_fast and fl.tau > 0.0):
+            return
+        if not self._rff_ready:
+            kmax, k_rf, dm, rf = self.ray_fast_profile(abs(dt))
+            self.ctx.set_ray_fast(kmax, k_rf, dm if k_rf > 0 else 1.0, rf[:kmax], self.dp_ref)
+            self._rff_ready = True
+        self.ctx.ray_fast(self.d["u"], self.d["v"], None if fl.hydrostatic else self.d["w"], fl.hydrostatic)
 
     # -- state I/O ------------------------------------------------------------------------------------
     def set_state(self, u, v, w, delp, pt, delz, phis):
@@ -250,6 +302,7 @@ class DynCore:
                                    0.0 if it == 1 else fl.beta, d["du"], d["dv"])
             else:
                 ctx.one_grad_p(d["u"], d["v"], d["pkc"], d["gz"], d["divg2"] if fl.d_ext > 0.0 else None, dt, ptk)  # :1021
+            self._ray_fast(dt)                                                # :1057-1060
             if it != n_split:
                 halo.update([(d["u"], "U"), (d["v"], "V")])
             elif hasattr(halo, "sync_edges"):
@@ -302,6 +355,9 @@ class DynCore:
                 halo.update([(d["divgd"], "B")])                              # :451 / :577 (pack 3, CORNER)
             ctx.update_dz_c(dt2, d["zs"], d["ut"], d["vt"], d["zh"], d["gz"], d["ws3"])       # :514-527
             cond()
+            if fl.fast_tau_w_sec > 1.0e-5 and not self._rfw_ready:             # nh_utils.F90:356-367, once
+                ctx.set_fast_tau_w(self.fast_tau_w_profile(dt2))
+                self._rfw_ready = True
             ctx.riem_solver_c(dt2, self.cn, d["phis"], d["omga"], d["ptc"], d["delpc"], d["gz"], d["pkc"], d["ws3"])  # :531
             ctx.p_grad_c(dt2, d["delpc"], d["pkc"], d["gz"], d["uc"], d["vc"], False)         # :562
             # :565 / :578 (pack 9, CGRID_NE) overlapped with the interior of d_sw (:762): start ... complete
@@ -368,6 +424,7 @@ class DynCore:
             else:
                 ctx.nh_p_grad(d["u"], d["v"], d["pkc"], d["zh"], d["delp"], d["pk3"], dt,
                               peln1 if fl.use_logp else ptk, gz_scale=fl.grav)    # :1032
+            self._ray_fast(dt)                                                # :1057-1060
             if it != n_split:
                 halo.update([(d["u"], "U"), (d["v"], "V")])                   # :1168-1169 (pack 8)
             else:

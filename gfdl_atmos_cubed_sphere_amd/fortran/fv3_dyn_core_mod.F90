@@ -79,7 +79,7 @@ module fv3_arrays_compat_mod
     logical :: convert_ke = .false., hydrostatic = .true., adiabatic = .false., fill = .false.
     logical :: do_diss_est = .false., prevent_diss_cooling = .false., do_f3d = .false., inline_q = .false.
     logical :: nested = .false., regional = .false.
-    real(c_double) :: tau = 0.d0, rf_cutoff = 30.d2
+    real(c_double) :: tau = 0.d0, rf_cutoff = 30.d2, fast_tau_w_sec = 0.d0
     logical :: RF_fast = .false., consv_am = .false., do_sat_adj = .false., moist_phys = .true.
     integer :: c2l_ord = 4, nwat = 3
   end type
@@ -344,6 +344,7 @@ contains
     end if
     call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
 
+    if (.not. allocated(at%pfull)) at%pfull = pfull                        ! what Riem_Solver_c (:536) and Ray_fast (:1058) are handed
     call fv3_dyn_core(at, bdt)                                             ! the substep loop (both branches), d_con heating
 
     ! ---- device -> host ----
@@ -406,6 +407,7 @@ contains
       end if
       if (.not. bound_d(slot)) then
         call flags_of(flagstruct, fl)
+        fl%ks = ks
         fl%n_split = n_split; fl%ptop = ptop; fl%grav = grav; fl%akap = akap; fl%cp_air = cp
         fl%hydrostatic = hydrostatic
         call bind_sphere_tile(spd, slot, fv3_domain_tile(domain), npx, npy, npz, 0, bd, gridstruct, flagstruct, fl, ak, bk)
@@ -528,6 +530,8 @@ contains
       fl%use_cond = thermostruct%use_cond; fl%moist_kappa = thermostruct%moist_kappa
       fl%beta = flagstruct%beta           ! du / dv live in the bound fv3_atmos between calls, like dyn_core's saved arrays (:278-283)
       fl%convert_ke = flagstruct%convert_ke
+      fl%fast_tau_w_sec = flagstruct%fast_tau_w_sec; fl%RF_fast = flagstruct%RF_fast; fl%tau = flagstruct%tau   ! :536, :940, :1057-1060
+      fl%rf_cutoff = flagstruct%rf_cutoff; fl%ks = ks
       call fv3_host_init_grid(at, dom, gh, 0, fl, ak, bk)
       bound = .true.
     end subroutine
@@ -628,7 +632,7 @@ contains
     ! :284-399 T -> theta_v, :345 compute_total_energy, :362-375 Rayleigh_Friction, the k_split loop :460-665 with the energy fixer of
     ! its last remap, cubed_to_latlon :911
     atf%fl%adiabatic = flagstruct%adiabatic .or. zvir == 0.d0 .or. nq_tot == 0
-    call fv3_fv_dynamics_call(atf, bdt, consv_te, flagstruct%tau, flagstruct%rf_cutoff, zvir, flagstruct%c2l_ord, flagstruct%moist_phys, &
+    call fv3_fv_dynamics_call(atf, bdt, consv_te, merge(0.d0, flagstruct%tau, flagstruct%RF_fast), flagstruct%rf_cutoff, zvir, flagstruct%c2l_ord, flagstruct%moist_phys, &
                               6.3712d6)
 
     call fv3_check(fv3_sync(atf%ctx), 'fv3_sync')
@@ -697,6 +701,7 @@ contains
       end if
       if (.not. bound_s(slot)) then
         call flags_of(flagstruct, fl)
+        fl%ks = ks
         fl%n_split = n_split; fl%q_split = q_split; fl%ptop = ptop; fl%akap = kappa; fl%cp_air = cp_air
         fl%hydrostatic = hydrostatic; fl%fill = fill; fl%r_vir = zvir
         call bind_sphere_tile(sps, slot, fv3_domain_tile(domain), npx, npy, npz, nq_tot, bd, gridstruct, flagstruct, fl, ak, bk)
@@ -740,7 +745,7 @@ contains
         end if
         comm_s = .true.
       end if
-      call fv3_sphere_fv_dynamics_call(sps, bdt, fv3_domain_npes(domain), consv_te, flagstruct%tau, flagstruct%rf_cutoff, zvir, &
+      call fv3_sphere_fv_dynamics_call(sps, bdt, fv3_domain_npes(domain), consv_te, merge(0.d0, flagstruct%tau, flagstruct%RF_fast), flagstruct%rf_cutoff, zvir, &
                                        flagstruct%c2l_ord, flagstruct%moist_phys, 6.3712d6)         ! constants_mod: radius
       do sl = 1, nloc
         associate (at => sps%f(sl), tp => tps(sl))
@@ -787,6 +792,7 @@ contains
       dom%stretched_grid = merge(1, 0, gridstruct%stretched_grid); dom%lim_fac = flagstruct%lim_fac
       call grid_host_of(gridstruct, gh)
       call flags_of(flagstruct, fl)
+      fl%ks = ks
       fl%n_split = n_split; fl%q_split = q_split; fl%ptop = ptop; fl%akap = kappa; fl%cp_air = cp_air
       fl%hydrostatic = hydrostatic; fl%fill = fill; fl%r_vir = zvir
       ! thermostruct%use_cond / moist_kappa (the reference's defaults, fv_arrays.F90:1226-1227): the water species as fv_dynamics.F90:275-283
@@ -934,6 +940,8 @@ contains
     fl%d_ext = flagstruct%d_ext;        fl%delt_max = flagstruct%delt_max
     fl%beta = flagstruct%beta
     fl%convert_ke = flagstruct%convert_ke
+    fl%fast_tau_w_sec = flagstruct%fast_tau_w_sec; fl%RF_fast = flagstruct%RF_fast; fl%tau = flagstruct%tau
+    fl%rf_cutoff = flagstruct%rf_cutoff
   end subroutine
 
   !> release the context dyn_core bound at its first call

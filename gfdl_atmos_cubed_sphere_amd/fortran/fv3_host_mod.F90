@@ -23,7 +23,7 @@ module fv3_host_mod
   public :: fv3_host_halo, fv3_host_init, fv3_host_init_grid, fv3_host_final, fv3_host_upload, fv3_host_download, fv3_host_comm_layout
   public :: fv3_dyn_core, fv3_dyn_core_hydrostatic, fv3_tracer_2d, fv3_fv_dynamics, fv3_fv_dynamics_call
   public :: dmalloc, dzero, swap, upload_levels, host_n_con, KIND_A, KIND_U, KIND_V, KIND_B    ! shared with fv3_sphere_mod
-  public :: inline_q_begin, inline_q_end
+  public :: inline_q_begin, inline_q_end, host_fast_tau_w, host_ray_fast
 
   integer(c_int), parameter :: KIND_A = 0, KIND_U = 1, KIND_V = 2, KIND_B = 3
   integer, parameter :: NG = 3
@@ -56,6 +56,11 @@ module fv3_host_mod
     logical :: use_cond = .false., moist_kappa = .false.
     type(fv3_moist_params) :: moist
     logical :: convert_ke = .false.
+    ! fast_tau_w_sec > 1e-5: Rayleigh damping of w inside SIM1 / SIM (nh_utils.F90:356-367, :1363-1371); RF_fast .and. tau > 0: Ray_fast at
+    ! the end of every acoustic substep (dyn_core.F90:1057-1060, :2485-2601); ks: the levels of pure pressure (Ray_fast's k_rf)
+    real(c_double) :: fast_tau_w_sec = 0.d0, tau = 0.d0, rf_cutoff = 30.d2
+    logical :: RF_fast = .false.
+    integer :: ks = 0
   end type
 
   !> device-resident state and work arrays of one rank (fv_atmos_type members + dyn_core.F90:256-283)
@@ -77,6 +82,7 @@ module fv3_host_mod
     type(c_ptr) :: fx_s = c_null_ptr, fy_s = c_null_ptr ! inline_q: the delp fluxes of one substep (FX / FY x npz)
     type(c_ptr) :: q_con = c_null_ptr, q_con_n = c_null_ptr, cappa = c_null_ptr   ! use_cond / moist_kappa (A x npz)
     real(c_double), allocatable :: ak(:), bk(:)
+    real(c_double), allocatable :: pfull(:)           ! the caller's pfull (dyn_core's argument) for fast_tau_w_sec / Ray_fast; not set: fv_dynamics.F90:254-262
     ! several ranks of a doubly periodic px x py layout (fv3_host_comm_layout): the neighbour ranks of the eight directions
     integer :: nranks = 1
     integer(c_int) :: peers_to(8) = 0_c_int, peers_from(8) = 0_c_int
@@ -85,6 +91,7 @@ module fv3_host_mod
     real(c_double), allocatable :: area(:,:), rf(:), pm(:)
     integer :: kmax = -1
     real(c_double) :: e_flux = 0.d0, dtmp = 0.d0
+    logical :: rfw_ready = .false., rff_ready = .false.   ! RFw_initialized (nh_utils.F90:54), RFF_initialized (dyn_core.F90:84)
   end type
 
   logical, save :: host_comm = .false.
@@ -495,6 +502,7 @@ contains
       if (at%fl%nord > 0) call halo(at, at%divgd, KIND_B, npz)                            ! :451 / :577 (pack 3, CORNER)
       call fv3_check(fv3_update_dz_c(ctx, dt2, at%zs, at%ut, at%vt, at%zh, at%gz, at%ws3), 'update_dz_c')   ! :514-527
       call set_condensate(at)
+      call host_fast_tau_w(at, dt2)
       call fv3_check(fv3_riem_solver_c(ctx, dt2, at%cn, at%phis, at%omga, at%ptc, at%delpc, at%gz, at%pkc, at%ws3), &
                      'riem_solver_c')                                                     ! :531
       call fv3_check(fv3_p_grad_c(ctx, dt2, at%delpc, at%pkc, at%gz, at%uc, at%vc, 0_c_int), 'p_grad_c')    ! :562
@@ -542,6 +550,7 @@ contains
       else
         call fv3_check(fv3_nh_p_grad(ctx, at%u, at%v, at%pkc, at%zh, at%fl%grav, at%delp, at%pk3, dt, top), 'nh_p_grad')  ! :1032
       end if
+      call host_ray_fast(at, dt)                                                          ! :1057-1060
       if (it /= n_split) then
         call halo(at, at%u, KIND_U, npz); call halo(at, at%v, KIND_V, npz)                ! :1168-1169 (pack 8)
       else if (at%fl%use_old_omega) then
@@ -630,6 +639,7 @@ contains
       else
         call fv3_check(fv3_one_grad_p(ctx, at%u, at%v, at%pkc, at%gz, dv2, dt, ptk), 'one_grad_p')
       end if
+      call host_ray_fast(at, dt)                                                          ! :1057-1060
       if (it /= n_split) then
         call halo(at, at%u, KIND_U, npz); call halo(at, at%v, KIND_V, npz)
       end if
@@ -887,6 +897,80 @@ contains
   end subroutine
 
   !> the condensate loading and the moist kappa of the Riemann solvers and of the heating (fv3_set_condensate): the current q_con buffer
+  !> pfull(k) of fv_dynamics.F90:254-262 (p_ref = 1e5)
+  pure function host_pfull(at, k) result(pf)
+    type(fv3_atmos), intent(in) :: at
+    integer, intent(in) :: k
+    real(c_double) :: pf, ph1, ph2
+    if (allocated(at%pfull)) then
+      pf = at%pfull(k)
+      return
+    end if
+    ph1 = at%ak(k) + at%bk(k) * 1.d5; ph2 = at%ak(k+1) + at%bk(k+1) * 1.d5
+    pf = (ph2 - ph1) / log(ph2 / ph1)
+  end function
+
+  !> fast_tau_w_sec > 0: rff(k) on Riem_Solver_c's first call, with ITS dt (nh_utils.F90:356-367), handed to the library once
+  subroutine host_fast_tau_w(at, dt_c)
+    type(fv3_atmos), intent(inout) :: at
+    real(c_double), intent(in) :: dt_c
+    real(c_double), parameter :: pi_8 = 3.14159265358979323846d0
+    real(c_double) :: rff(at%npz), rff_temp
+    integer :: k, k_rf
+    if (.not. (at%fl%fast_tau_w_sec > 1.d-5) .or. at%rfw_ready) return
+    k_rf = 0; rff = 1.d0
+    do k = 1, at%npz
+      if (host_pfull(at, k) > at%fl%rf_cutoff) exit
+      k_rf = k
+      rff_temp = dt_c / at%fl%fast_tau_w_sec * sin(0.5d0 * pi_8 * log(at%fl%rf_cutoff / host_pfull(at, k)) / log(at%fl%rf_cutoff / at%fl%ptop))**2
+      rff(k) = 1.0d0 / (1.0d0 + rff_temp)
+    end do
+    call fv3_check(fv3_set_fast_tau_w(at%ctx, int(k_rf, c_int), rff), 'set_fast_tau_w')
+    at%rfw_ready = .true.
+  end subroutine
+
+  !> Ray_fast (dyn_core.F90:2485-2601) when RF_fast .and. tau > 0 (:1057-1060): the profile of the first call (:2519-2545), then the kernel
+  subroutine host_ray_fast(at, dt)
+    type(fv3_atmos), intent(inout) :: at
+    real(c_double), intent(in) :: dt
+    real(c_double), parameter :: sday = 86400.d0, pi = 3.1415926535897931d0
+    real(c_double) :: rf(at%npz), dp(at%npz), rffk, tau0, dm
+    integer :: k, kmax, k_rf
+    type(c_ptr) :: wp
+    if (.not. (at%fl%RF_fast .and. at%fl%tau > 0.d0)) return
+    if (.not. at%rff_ready) then
+      tau0 = at%fl%tau * sday
+      rf = 1.d0; kmax = 1
+      do k = 1, at%npz
+        dp(k) = (at%ak(k+1) - at%ak(k)) + (at%bk(k+1) - at%bk(k)) * 1.d5                  ! dp_ref, dyn_core.F90:241-244
+      end do
+      do k = 1, at%npz
+        if (host_pfull(at, k) < at%fl%rf_cutoff) then
+          rffk = abs(dt) / tau0 * sin(0.5d0 * pi * log(at%fl%rf_cutoff / host_pfull(at, k)) / log(at%fl%rf_cutoff / at%fl%ptop))**2
+          kmax = k
+          rf(k) = 1.d0 / (1.0d0 + rffk)
+        else
+          exit
+        end if
+      end do
+      dm = 0.d0; k_rf = 0
+      do k = 1, at%fl%ks
+        if (host_pfull(at, k) < at%fl%rf_cutoff + min(100.d0, 10.d0 * at%fl%ptop)) then
+          dm = dm + dp(k)
+          k_rf = k
+        else
+          exit
+        end if
+      end do
+      if (k_rf == 0) dm = 1.d0
+      call fv3_check(fv3_set_ray_fast(at%ctx, int(kmax, c_int), int(k_rf, c_int), dm, rf, dp), 'set_ray_fast')
+      at%rff_ready = .true.
+    end if
+    wp = at%w
+    if (at%fl%hydrostatic) wp = c_null_ptr
+    call fv3_check(fv3_ray_fast(at%ctx, at%u, at%v, wp, merge(1_c_int, 0_c_int, at%fl%hydrostatic)), 'ray_fast')
+  end subroutine
+
   subroutine set_condensate(at)
     type(fv3_atmos), intent(in) :: at
     type(c_ptr) :: qc, cp

@@ -23,7 +23,7 @@ module fv3_mi355x_mod
   public :: fv3_comm_get_unique_id, fv3_comm_init, fv3_comm_destroy, fv3_halo_start, fv3_halo_complete, fv3_allreduce_max
   public :: fv3_cube_field, fv3_cube_table, fv3_cube_halo_start, fv3_cube_halo_complete
   public :: FV3_CUBE_A, FV3_CUBE_B, FV3_CUBE_D, FV3_CUBE_C, FV3_CUBE_DEDGE
-  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_rayleigh_super, fv3_compute_total_energy, fv3_energy_fixer_sums, fv3_remap_finish, fv3_ordered_sum, fv3_adv_pe, fv3_set_condensate, fv3_set_fast, fv3_set_moist, fv3_moist_params
+  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_rayleigh_super, fv3_compute_total_energy, fv3_energy_fixer_sums, fv3_remap_finish, fv3_ordered_sum, fv3_adv_pe, fv3_set_condensate, fv3_set_fast, fv3_set_fast_tau_w, fv3_set_ray_fast, fv3_ray_fast, fv3_set_moist, fv3_moist_params
 
   type, bind(C) :: fv3_domain
     integer(c_int) :: is, ie, js, je, ng, npx, npy, npz, grid_type
@@ -499,6 +499,24 @@ module fv3_mi355x_mod
       import :: c_int, c_ptr
       type(c_ptr), value :: ctx
       integer(c_int), value :: on
+    end function
+    integer(c_int) function fv3_set_fast_tau_w(ctx, k_rf, rff) bind(C, name="fv3_set_fast_tau_w")   ! fast_tau_w_sec > 0: rff(1:k_rf), host
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: k_rf
+      real(c_double), intent(in) :: rff(*)
+    end function
+    integer(c_int) function fv3_set_ray_fast(ctx, kmax, k_rf, dm, rf, dp) bind(C, name="fv3_set_ray_fast")   ! Ray_fast's first call
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: kmax, k_rf
+      real(c_double), value :: dm
+      real(c_double), intent(in) :: rf(*), dp(*)
+    end function
+    integer(c_int) function fv3_ray_fast(ctx, u, v, w, hydrostatic) bind(C, name="fv3_ray_fast")   ! dyn_core.F90:1057-1060
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx, u, v, w
+      integer(c_int), value :: hydrostatic
     end function
     integer(c_int) function fv3_riem_solver_c(ctx, dt, cn, hs, w3, pt, delp, gz, pef, ws) &
         bind(C, name="fv3_riem_solver_c")

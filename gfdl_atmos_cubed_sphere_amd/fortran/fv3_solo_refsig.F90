@@ -39,6 +39,8 @@ program fv3_solo_refsig
   integer :: rank, nranks, px, py, gnx, gny, i0, j0
   character(len=1024) :: arg, idfile
   character(len=16) :: sfx
+  character(len=64) :: envbuf
+  integer :: envstat
 
   call get_command_argument(1, fin)
   call get_command_argument(2, fout)
@@ -146,6 +148,16 @@ program fv3_solo_refsig
   fs%d2_bg_k1 = 0.20d0; fs%d2_bg_k2 = 0.015d0; fs%a_imp = 1.d0; fs%d_con = d_con; fs%d_ext = d_ext; fs%beta = beta
   fs%prevent_diss_cooling = .true.; fs%adiabatic = .true.
   ts%use_cond = iand(ihydro, 8_c_int) /= 0; ts%moist_kappa = iand(ihydro, 16_c_int) /= 0
+  ! fast_tau_w_sec / RF_fast of a test: FV3_REFSIG_FAST_TAU_W (seconds), FV3_REFSIG_RF_FAST (tau in days), FV3_REFSIG_RF_CUTOFF (Pa)
+  call get_environment_variable('FV3_REFSIG_FAST_TAU_W', envbuf, status=envstat)
+  if (envstat == 0 .and. len_trim(envbuf) > 0) read(envbuf, *) fs%fast_tau_w_sec
+  call get_environment_variable('FV3_REFSIG_RF_FAST', envbuf, status=envstat)
+  if (envstat == 0 .and. len_trim(envbuf) > 0) then
+    read(envbuf, *) fs%tau
+    fs%RF_fast = .true.
+  end if
+  call get_environment_variable('FV3_REFSIG_RF_CUTOFF', envbuf, status=envstat)
+  if (envstat == 0 .and. len_trim(envbuf) > 0) read(envbuf, *) fs%rf_cutoff
 
   if (whole) then
     fs%c2l_ord = 4; fs%tau = tau; fs%moist_phys = .false.

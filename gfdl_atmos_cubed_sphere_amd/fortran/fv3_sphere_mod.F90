@@ -206,6 +206,7 @@ contains
                                      at%phis, at%ptc, at%pkz, 1_c_int), 'geopk (C grid)')
           else
             call fv3_check(fv3_update_dz_c(at%ctx, dt2, at%zs, at%ut, at%vt, at%zh, at%gz, at%ws3), 'update_dz_c')   ! :514-527
+            call host_fast_tau_w(at, dt2)
             call fv3_check(fv3_riem_solver_c(at%ctx, dt2, at%cn, at%phis, at%omga, at%ptc, at%delpc, at%gz, at%pkc, at%ws3), &
                            'riem_solver_c')                                                ! :531
           end if
@@ -251,6 +252,7 @@ contains
             else
               call fv3_check(fv3_one_grad_p(at%ctx, at%u, at%v, at%pkc, at%gz, dv2, dt, ptk), 'one_grad_p')      ! :1021
             end if
+            call host_ray_fast(at, dt)                                                      ! :1057-1060
           end associate
         end do
       else
@@ -279,6 +281,7 @@ contains
             else
               call fv3_check(fv3_nh_p_grad(at%ctx, at%u, at%v, at%pkc, at%zh, fl%grav, at%delp, at%pk3, dt, top), 'nh_p_grad')  ! :1032
             end if
+            call host_ray_fast(at, dt)                                                      ! :1057-1060
           end associate
         end do
       end if

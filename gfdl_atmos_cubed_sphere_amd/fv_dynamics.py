@@ -49,7 +49,10 @@ class FvDynamics:
         self.moist = None
         if flags.use_cond or flags.moist_kappa:
             self.moist = dict(moist or {}, moist_kappa=int(flags.moist_kappa), use_cond=int(flags.use_cond), sphum=1)
-        self.dc = DynCore(ctx, flags, dp_ref, px, py, rank, world, halo=halo)
+        ph = np.asarray(ak, dtype=np.float64) + np.asarray(bk, dtype=np.float64) * 1.0e5     # fv_dynamics.F90:254-262 (p_ref = 1e5)
+        pfull = (ph[1:] - ph[:-1]) / np.log(ph[1:] / ph[:-1])
+        ks = int(np.argmax(np.asarray(bk) != 0.0)) - 1 if np.any(np.asarray(bk) != 0.0) else len(pfull)   # the last interface of pure pressure
+        self.dc = DynCore(ctx, flags, dp_ref, px, py, rank, world, halo=halo, pfull=pfull, ks=max(ks, 0))
         ctx.set_ak_bk(ak, bk)
         npz = ctx.npz
         d = self.dc.d
@@ -79,7 +82,7 @@ class FvDynamics:
             self.total_energy_before()
         conv = lambda mode: ctx.pt_to_theta_v(mode, zvir, fl.akap, fl.rdgas, fl.grav, d["pt"], d["delp"],
                                               None if fl.hydrostatic else d["delz"], qv, d["pkz"])
-        if self.tau > 0.0:                                                 # :368-376 (grid_type = 4: Rayleigh_Friction)
+        if self.tau > 0.0 and not self.fl.rf_fast:                         # :362-376 (RF_fast: Ray_fast inside dyn_core instead) (grid_type = 4: Rayleigh_Friction)
             if not fl.hydrostatic:
                 conv(-1)                                                   # pkz from the T, delz before the friction (:323-326)
             self.rayleigh_friction(bdt)

@@ -299,6 +299,23 @@ int fv3_set_condensate(fv3_ctx *ctx, const double *q_con, const double *cappa);
  * Moist (fv3_set_condensate) and a_imp <= 0.999 calls take the parity kernels in either mode. */
 int fv3_set_fast(fv3_ctx *ctx, int on);
 
+/* flagstruct%fast_tau_w_sec > 0: the Rayleigh damping of w inside SIM1_solver / SIM_solver (model/nh_utils.F90:1363-1371, :1498-1506;
+ * the call sites hand the flag to both solvers, dyn_core.F90:536, :940).  rff: HOST array of k_rf values, the profile Riem_Solver_c
+ * evaluates ONCE on its first call (nh_utils.F90:356-367: rff(k) = 1 / (1 + dt / fast_tau_w_sec * sin^2(...)) on the levels with
+ * pfull <= rf_cutoff, with ITS dt -- half the acoustic step) and both solvers use from then on; the host evaluates it the same way
+ * (gfdl_atmos_cubed_sphere_amd/dyn_core.py fast_tau_w_profile; oracle/nh_core.c fvo_fast_tau_w_rff) and hands it over once.  Every
+ * fv3_riem_solver_c / fv3_riem_solver3 call of the context with a_imp > 0.5 then multiplies w2(k), k <= k_rf, by rff(k) behind the back
+ * substitution.  k_rf = 0: off (the default). */
+int fv3_set_fast_tau_w(fv3_ctx *ctx, int k_rf, const double *rff);
+
+/* Ray_fast -- model/dyn_core.F90:2485-2601, call site :1057-1060 (flagstruct%RF_fast and tau > 0: at the end of every acoustic
+ * substep).  fv3_set_ray_fast hands over what the routine keeps from its first call (:2519-2545): rf(1:kmax) = 1 / (1 + rff(k)) on the
+ * levels with pfull < rf_cutoff, dp(1:npz) = dp_ref, k_rf and dm = sum of dp(1:k_rf) (HOST arrays, the host's arithmetic in the
+ * reference's order).  fv3_ray_fast then scales u (U x npz), v (V x npz) and, unless hydrostatic, w (A x npz) on the levels k <= kmax by
+ * rf(k) and gives the momentum a column lost, sum (1 - rf) dp u / dm, back to its levels k <= k_rf (:2549-2597), compute domain. */
+int fv3_set_ray_fast(fv3_ctx *ctx, int kmax, int k_rf, double dm, const double *rf, const double *dp);
+int fv3_ray_fast(fv3_ctx *ctx, double *u, double *v, double *w, int hydrostatic);
+
 /* Riem_Solver_c -- model/nh_utils.F90:323, call site model/dyn_core.F90:531 (a_imp > 0.5: SIM1_solver; a_imp < -0.01: SIM3p0_solver;
  * otherwise RIM_2D with cn->m_split sub-steps, nh_utils.F90:449-459).
  * hs, ws: A; w3 (=omga), pt (=ptc), delp (=delpc): A x npz; gz (in/out), pef (=pkc, out): A x (npz+1). */

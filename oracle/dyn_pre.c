@@ -186,3 +186,75 @@ int fvo_log_n(const double *x, double *y, long n) {
   for (long i = 0; i < n; i++) y[i] = fv3_log(x[i]);
   return FVO_OK;
 }
+
+/* Ray_fast, dyn_core.F90:2485-2601.  fvo_ray_fast_profile: what the routine keeps from its first call (:2519-2545) -- rf(1:npz)
+ * (1 / (1 + rff) on the levels with pfull < rf_cutoff, 1 below), k_rf and dm = sum of dp(1:k_rf); returns kmax (the module's initial
+ * value 1 when no level is above the cutoff).  dt: abs(dt) of the acoustic step; tau in days; ks, dp = dp_ref as at the call site :1059. */
+int fvo_ray_fast_profile(int npz, int ks, double dt, double tau, double rf_cutoff, double ptop, const double *pfull, const double *dp,
+                         double *rf, int *k_rf, double *dm_out) {
+  const double sday = 86400., pi = 3.1415926535897931;
+  const double tau0 = tau * sday;
+  int k, kmax = 1;
+  double dm = 0.;
+  for (k = 0; k < npz; k++) rf[k] = 1.;
+  for (k = 1; k <= npz; k++) {
+    if (pfull[k - 1] < rf_cutoff) {
+      const double s = sin(0.5 * pi * log(rf_cutoff / pfull[k - 1]) / log(rf_cutoff / ptop));
+      const double rff = dt / tau0 * (s * s);
+      kmax = k;
+      rf[k - 1] = 1.0 / (1.0 + rff);
+    } else {
+      break;
+    }
+  }
+  *k_rf = 0;
+  for (k = 1; k <= ks; k++) {
+    const double lim = 10. * ptop < 100. ? 10. * ptop : 100.;
+    if (pfull[k - 1] < rf_cutoff + lim) {
+      dm = dm + dp[k - 1];
+      *k_rf = k;
+    } else {
+      break;
+    }
+  }
+  *dm_out = dm;
+  return kmax;
+}
+
+/* :2549-2597; u: U x npz, v: V x npz, w: A x npz (NULL when hydrostatic) */
+int fvo_ray_fast(const fvo_grid *g, int npz, int kmax, int k_rf, const double *rf, const double *dp, int hydrostatic, double *u,
+                 double *v, double *w) {
+  BOUNDS(g);
+  int i, j, k;
+  const int km = npz;
+  (void)km;
+  for (j = js; j <= je + 1; j++) {
+    double dm = 0.;
+    double *dmu = (double *)calloc((size_t)(ie - is + 3), sizeof(double)), *dmv = (double *)calloc((size_t)(ie - is + 3), sizeof(double));
+    for (k = 1; k <= k_rf; k++) dm = dm + dp[k - 1];
+    for (k = 1; k <= kmax; k++) {
+      for (i = is; i <= ie; i++) {
+        dmu[i - is] = dmu[i - is] + (1. - rf[k - 1]) * dp[k - 1] * u[U3(i, j, k)];
+        u[U3(i, j, k)] = rf[k - 1] * u[U3(i, j, k)];
+      }
+      if (j != je + 1) {
+        for (i = is; i <= ie + 1; i++) {
+          dmv[i - is] = dmv[i - is] + (1. - rf[k - 1]) * dp[k - 1] * v[V3(i, j, k)];
+          v[V3(i, j, k)] = rf[k - 1] * v[V3(i, j, k)];
+        }
+        if (!hydrostatic)
+          for (i = is; i <= ie; i++) w[A3(i, j, k)] = rf[k - 1] * w[A3(i, j, k)];
+      }
+    }
+    for (i = is; i <= ie; i++) dmu[i - is] = dmu[i - is] / dm;
+    if (j != je + 1)
+      for (i = is; i <= ie + 1; i++) dmv[i - is] = dmv[i - is] / dm;
+    for (k = 1; k <= k_rf; k++) {
+      for (i = is; i <= ie; i++) u[U3(i, j, k)] = u[U3(i, j, k)] + dmu[i - is];
+      if (j != je + 1)
+        for (i = is; i <= ie + 1; i++) v[V3(i, j, k)] = v[V3(i, j, k)] + dmv[i - is];
+    }
+    free(dmu); free(dmv);
+  }
+  return FVO_OK;
+}

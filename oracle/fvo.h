@@ -288,6 +288,13 @@ int fvo_rayleigh_apply(const fvo_grid *g, int kmax, int conserve, int hydrostati
                        double *w);
 /* adv_pe, dyn_core.F90:1529-1632 (cubed sphere): om += 0.5*rarea*(V3 . grad pe); pem from delp_before on (is-1:ie+1, js-1:je+1) */
 int fvo_adv_pe(const fvo_grid *g, int km, double ptop, const double *ua, const double *va, const double *delp_before, double *om);
+/* Ray_fast (dyn_core.F90:2485-2601) and fast_tau_w_sec (nh_utils.F90:356-367, :1363-1371, :1498-1506) */
+int fvo_ray_fast_profile(int npz, int ks, double dt, double tau, double rf_cutoff, double ptop, const double *pfull, const double *dp,
+                         double *rf, int *k_rf, double *dm_out);
+int fvo_ray_fast(const fvo_grid *g, int npz, int kmax, int k_rf, const double *rf, const double *dp, int hydrostatic, double *u,
+                 double *v, double *w);
+int fvo_fast_tau_w_rff(int km, double dt, double fast_tau_w_sec, double rf_cutoff, double ptop, const double *pfull, double *rff);
+int fvo_set_fast_tau_w(int k_rf, const double *rff);
 int fvo_rayleigh_super(const fvo_grid *g, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,
                        const double *pm, const double *rf, const double *ua, const double *va, double *pt, double *u,
                        double *v, double *w, const double *u00, const double *v00);

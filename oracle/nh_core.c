@@ -21,6 +21,33 @@ static const double dz_min = 2.; /* nh_utils.F90:49 */
 static inline double dmax(double a, double b) { return a > b ? a : b; }
 static double *dalloc(size_t n) { return (double *)calloc(n, sizeof(double)); }
 
+/* fast_tau_w_sec > 0: the module state of nh_utils.F90:53-55 (rff, k_rf, set once by Riem_Solver_c's first call, :356-367, and used
+ * by SIM1_solver :1363-1371 and SIM_solver :1498-1506 of both Riemann solvers from then on).  fvo_fast_tau_w_rff evaluates the
+ * profile (rff: km values; returns k_rf), fvo_set_fast_tau_w installs it (k_rf = 0: fast_tau_w_sec = 0, the default). */
+static int g_k_rf = 0;
+static double g_rff[512];
+int fvo_fast_tau_w_rff(int km, double dt, double fast_tau_w_sec, double rf_cutoff, double ptop, const double *pfull, double *rff) {
+  const double pi_8 = 3.14159265358979323846; /* constants_mod pi_8 */
+  int k, k_rf = 0;
+  if (!(fast_tau_w_sec > 1.e-5)) return 0;
+  for (k = 1; k <= km; k++) {
+    double s, rff_temp;
+    if (pfull[k - 1] > rf_cutoff) break;
+    k_rf = k;
+    s = sin(0.5 * pi_8 * log(rf_cutoff / pfull[k - 1]) / log(rf_cutoff / ptop));
+    rff_temp = dt / fast_tau_w_sec * (s * s);
+    rff[k - 1] = 1.0 / (1.0 + rff_temp);
+  }
+  return k_rf;
+}
+int fvo_set_fast_tau_w(int k_rf, const double *rff) {
+  int k;
+  if (k_rf < 0 || k_rf > 512) return FVO_ERR_UNSUPPORTED;
+  for (k = 0; k < k_rf; k++) g_rff[k] = rff[k];
+  g_k_rf = k_rf;
+  return FVO_OK;
+}
+
 #define BOUNDS(g)                                                                         \
   const int is = (g)->is, ie = (g)->ie, js = (g)->js, je = (g)->je;                       \
   const int isd = (g)->isd, ied = (g)->ied, jsd = (g)->jsd, jed = (g)->jed;               \
@@ -106,7 +133,7 @@ int fvo_update_dz_c(const fvo_grid *g, int km, double dt, const double *dp0, con
   return FVO_OK;
 }
 
-/* SIM1_solver, nh_utils.F90:1277-1394, one column (fast_tau_w_sec = 0).  Arrays are 1-based
+/* SIM1_solver, nh_utils.F90:1277-1394, one column (fast_tau_w_sec: fvo_set_fast_tau_w).  Arrays are 1-based
  * [1..km] / [1..km+1] (element 0 unused). */
 static void sim1_column(int km, double dt, double rgas, const double *gm2, const double *cp2, double *pe,
                         const double *dm2, const double *pm2, const double *pem, double *w2, double *dz2,
@@ -149,6 +176,7 @@ static void sim1_column(int km, double dt, double rgas, const double *gm2, const
   bet = dm2[km] - (aa[km] + p1 + aa[km] * gam[km]);
   w2[km] = (dm2[km] * w1[km] + dt * (pp[km + 1] - pp[km]) - p1 * ws - aa[km] * w2[km - 1]) / bet;
   for (k = km - 1; k >= 1; k--) w2[k] = w2[k] - gam[k + 1] * w2[k + 1];
+  for (k = 1; k <= g_k_rf && k <= km; k++) w2[k] = w2[k] * g_rff[k - 1]; /* :1363-1371 */
   pe[1] = 0.;
   for (k = 1; k <= km; k++) pe[k + 1] = pe[k] + dm2[k] * (w2[k] - w1[k]) * rdt;
   p1 = (pe[km] + 2. * pe[km + 1]) * r3;
@@ -160,7 +188,7 @@ static void sim1_column(int km, double dt, double rgas, const double *gm2, const
   free(aa); free(bb); free(dd); free(w1); free(g_rat); free(gam); free(pp);
 }
 
-/* SIM_solver, nh_utils.F90:1396-1537, one column (scale_m = 0, fast_tau_w_sec = 0). */
+/* SIM_solver, nh_utils.F90:1396-1537, one column (scale_m = 0; fast_tau_w_sec: fvo_set_fast_tau_w). */
 static void sim_column(int km, double dt, double rgas, const double *gm2, const double *cp2, double *pe2,
                        const double *dm2, const double *pm2, const double *pem, double *w2, double *dz2,
                        const double *pt2, double ws, double alpha, double p_fac, double scale_m) {
@@ -208,6 +236,7 @@ static void sim_column(int km, double dt, double rgas, const double *gm2, const 
   bet = dm2[km] - (aa[km] + wk1 + aa[km] * gam[km]);
   w2[km] = (dm2[km] * w1[km] + dt * (pp[km + 1] - pp[km]) - wk[km] + wk1 * (t2 * w1[km] - ra * ws) - aa[km] * w2[km - 1]) / bet;
   for (k = km - 1; k >= 1; k--) w2[k] = w2[k] - gam[k + 1] * w2[k + 1];
+  for (k = 1; k <= g_k_rf && k <= km; k++) w2[k] = w2[k] * g_rff[k - 1]; /* :1498-1506 */
   pe2[1] = 0.;
   for (k = 1; k <= km; k++) pe2[k + 1] = pe2[k] + (dm2[k] * (w2[k] - w1[k]) * rdt - beta * (pp[k + 1] - pp[k])) * ra;
   p1 = (pe2[km] + 2. * pe2[km + 1]) * r3;

@@ -142,7 +142,7 @@ def build_refsig(workdir, libdir=CSRC, libname="fv3_mi355x"):
 
 
 def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2, bdt=6.0, hydrostatic=False, d_con=0.0, beta=0.0, moist=False,
-                         layout=(1, 1)):
+                         layout=(1, 1), fast_tau_w_sec=0.0, rf_fast_tau=0.0):
     """dyn_core called with the reference's argument list on host arrays (fv3_dyn_core_mod, driver fv3_solo_refsig) against the
     Python host's DynCore.run on the same state: u, v, w, delp, pt, delz, the accumulated mass fluxes / Courant numbers (and pkz
     when the heating or the hydrostatic branch writes it) bit-identical"""
@@ -157,7 +157,13 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
     st, _ = D.make_state(bd, npz)
     sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
-    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, d_con=d_con, beta=beta, use_cond=moist, moist_kappa=moist)
+    # fast_tau_w_sec / RF_fast (dyn_core.F90:536, :940, :1057-1060): the driver hands dyn_core ITS pfull (the mid-level pressure of its
+    # ak, bk) and ks = 0; the profiles are evaluated on either side (libm there, numpy here), so the comparison allows rounding then
+    pfull_drv = 0.5 * (ak[:-1] + ak[1:] + (bk[:-1] + bk[1:]) * 1.0e5)
+    rf_cut = float(pfull_drv[npz // 2]) + 1.0
+    damp = fast_tau_w_sec > 0.0 or rf_fast_tau > 0.0
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, d_con=d_con, beta=beta, use_cond=moist, moist_kappa=moist,
+                  fast_tau_w_sec=fast_tau_w_sec, rf_fast=rf_fast_tau > 0.0, tau=rf_fast_tau, rf_cutoff=rf_cut if damp else 30.0e2)
     mo = None
     if moist:     # q_con / cappa as moist_cv gives them for small mixing ratios of six species (halos periodic: the caller's, :464-465)
         import parity_remap as R
@@ -173,7 +179,7 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
     dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
     ctx = Context(g, npz, lib=lib)
     try:
-        dc = DynCore(ctx, fl, dp_ref)
+        dc = DynCore(ctx, fl, dp_ref, pfull=pfull_drv if damp else None, ks=0)
         dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
         if mo:
             dc.d["q_con"].upload(mo["q_con"])
@@ -194,8 +200,30 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
                 hydrostatic=hydrostatic, d_con=d_con, d_ext=fl.d_ext, beta=beta, moist=mo)
     spec = [(n, k, ()) for n, k in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC"), ("mfx", "FX"), ("cx", "CX"),
                                     ("pkz", "CC")) + ((("q_con", "A"),) if mo else ())]
-    res, out = _run_refsig(lib, exe, fin, fout, "", layout, bd, npz, spec)
-    _compare_blocks(res, ref, bd, "reference-signature dyn_core")
+    env = {}
+    if fast_tau_w_sec > 0.0:
+        env["FV3_REFSIG_FAST_TAU_W"] = repr(float(fast_tau_w_sec))
+    if rf_fast_tau > 0.0:
+        env["FV3_REFSIG_RF_FAST"] = repr(float(rf_fast_tau))
+    if damp:
+        env["FV3_REFSIG_RF_CUTOFF"] = repr(rf_cut)
+    os.environ.update(env)
+    try:
+        res, out = _run_refsig(lib, exe, fin, fout, "", layout, bd, npz, spec)
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    _compare_blocks(res, ref, bd, "reference-signature dyn_core", tol=1e-13 if damp else None)
+    if damp:   # the damping is in the run at all
+        ctx = Context(g, npz, lib=lib)
+        try:
+            dc = DynCore(ctx, DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, d_con=d_con, beta=beta), dp_ref)
+            dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
+            for _ in range(nsteps):
+                dc.run(bdt)
+            assert P.rel_rms(dc.d["u"].download(), ref["u"]) > 1e-7
+        finally:
+            ctx.close()
     return out
 
 
@@ -239,7 +267,7 @@ def _run_refsig(lib, exe, fin, fout, mode, layout, bd, npz, spec):
     return res, outs[0]
 
 
-def _compare_blocks(res, ref, bd, what):
+def _compare_blocks(res, ref, bd, what, tol=None):
     """every rank's block against the same block of the single-domain reference (compute domain of every field kind)"""
     kinds = {"u": "U", "v": "V", "w": "A", "delp": "A", "pt": "A", "q_con": "A", "ua": "A", "delz": "CC", "mfx": "FX", "cx": "CX", "pkz": "CC", "q": "A"}
     for b, got in res:
@@ -260,6 +288,9 @@ def _compare_blocks(res, ref, bd, what):
             else:   # CX: (nx + 1, njd): rows jsd .. jed of the global array
                 r_ = ref[n][b.is_ - 1:b.ie + 1, bd.ng + b.js - 1:bd.ng + b.je]
             assert np.all(np.isfinite(a)), n
+            if tol is not None:
+                assert np.max(np.abs(a - r_)) <= tol * max(np.max(np.abs(r_)), 1e-300), f"{n}: {what} and the Python host differ beyond {tol} (max abs {np.max(np.abs(a - r_)):.3e})"
+                continue
             assert np.array_equal(a, r_), f"{n} (block {b.is_}:{b.ie}, {b.js}:{b.je}): {what} and the Python host differ (max abs {np.max(np.abs(a - r_)):.3e})"
 
 

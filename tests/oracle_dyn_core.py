@@ -21,8 +21,20 @@ def _fill(bd, a, kind):
             periodic_fill(bd, a[:, :, k], kind)
 
 
-def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
-    """st: u, v, w, delp, pt (halo'd), delz (CC x npz), phis (A).  Returns the updated state dict."""
+def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float, pfull=None, ks=0):
+    """st: u, v, w, delp, pt (halo'd), delz (CC x npz), phis (A).  Returns the updated state dict.
+    pfull, ks: for fast_tau_w_sec > 0 / RF_fast (the profiles are evaluated as on the reference's first call of a run that starts here)"""
+    rff = None
+    if fl.fast_tau_w_sec > 1.0e-5:
+        rff = O.fast_tau_w_rff(npz, 0.5 * bdt / float(fl.n_split), fl.fast_tau_w_sec, fl.rf_cutoff, fl.ptop, pfull)
+    O.set_fast_tau_w(rff)
+    try:
+        return _run(g, npz, fl, dp_ref, st, bdt, pfull, ks)
+    finally:
+        O.set_fast_tau_w(None)
+
+
+def _run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float, pfull=None, ks=0):
     bd: Bounds = g.bd
     f = {k: np.asfortranarray(v.copy()) for k, v in st.items()}
     nx, ny = bd.nx, bd.ny
@@ -115,6 +127,9 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float):
             O.one_grad_p_nh(g, npz, dt, fl.ptop, f["divg2"], f["u"], f["v"], f["pkc"], f["gz"], f["delp"])
         else:
             O.nh_p_grad(g, npz, f["u"], f["v"], f["pkc"], f["gz"], f["delp"], f["pk3"], dt, peln1 if fl.use_logp else ptk)
+        if fl.rf_fast and fl.tau > 0.0:                                    # dyn_core.F90:1057-1060
+            kmax, k_rf, _, rf = O.ray_fast_profile(npz, ks, abs(dt), fl.tau, fl.rf_cutoff, fl.ptop, pfull, dp_ref)
+            O.ray_fast(g, npz, kmax, k_rf, rf, dp_ref, False, f["u"], f["v"], f["w"])
         if it != n_split:
             _fill(bd, f["u"], "U"); _fill(bd, f["v"], "V")
         elif fl.use_old_omega:                                             # dyn_core.F90:409-421, :1182-1191

@@ -222,6 +222,41 @@ def riem_solver3(g, km, dt, cn, zs, w, delz, pt, delp, zh, pe, ppe, pk3, pk, pel
     assert rc == 0, rc
 
 
+def fast_tau_w_rff(km, dt, fast_tau_w_sec, rf_cutoff, ptop, pfull):
+    """rff(1:k_rf) of nh_utils.F90:356-367 (dt: Riem_Solver_c's, half the acoustic step)"""
+    pfull = np.ascontiguousarray(pfull, dtype=np.float64)
+    rff = np.ones(km)
+    fn = lib().fvo_fast_tau_w_rff
+    k_rf = fn(C.c_int(km), _d(dt), _d(fast_tau_w_sec), _d(rf_cutoff), _d(ptop), pfull.ctypes.data_as(_dp), rff.ctypes.data_as(_dp))
+    return rff[:k_rf].copy()
+
+
+def set_fast_tau_w(rff=None):
+    """install (None: remove) the Rayleigh damping of w inside the oracle's SIM1 / SIM solvers: module state, as in the reference"""
+    rff = np.ascontiguousarray(rff if rff is not None else [], dtype=np.float64)
+    assert lib().fvo_set_fast_tau_w(C.c_int(len(rff)), rff.ctypes.data_as(_dp)) == 0
+
+
+def ray_fast_profile(npz, ks, dt, tau, rf_cutoff, ptop, pfull, dp):
+    """(kmax, k_rf, dm, rf[npz]) of Ray_fast's first call (dyn_core.F90:2519-2545)"""
+    pfull = np.ascontiguousarray(pfull, dtype=np.float64)
+    dp = np.ascontiguousarray(dp, dtype=np.float64)
+    rf = np.ones(npz)
+    k_rf = C.c_int(0)
+    dm = C.c_double(0.0)
+    kmax = lib().fvo_ray_fast_profile(C.c_int(npz), C.c_int(ks), _d(dt), _d(tau), _d(rf_cutoff), _d(ptop), pfull.ctypes.data_as(_dp),
+                                      dp.ctypes.data_as(_dp), rf.ctypes.data_as(_dp), C.byref(k_rf), C.byref(dm))
+    return int(kmax), int(k_rf.value), float(dm.value), rf
+
+
+def ray_fast(g, npz, kmax, k_rf, rf, dp, hydrostatic, u, v, w):
+    gs = make_grid(g)
+    rf = np.ascontiguousarray(rf, dtype=np.float64)
+    dp = np.ascontiguousarray(dp, dtype=np.float64)
+    assert lib().fvo_ray_fast(C.byref(gs), C.c_int(npz), C.c_int(kmax), C.c_int(k_rf), rf.ctypes.data_as(_dp), dp.ctypes.data_as(_dp),
+                              C.c_int(int(hydrostatic)), p(u), p(v), p(w) if w is not None else None) == 0
+
+
 def update_dz_d(g, km, ndif, damp, hord, dp0, zs, zh, crx, cry, xfx, yfx, ws, rdt):
     gs = make_grid(g)
     ndif = np.ascontiguousarray(ndif, dtype=np.int32)

@@ -30,16 +30,19 @@ def ulp_sensitivity(g, npz, fl, dp0, st, bdt, ref):
     return {n: P.rel_rms(pert[n], ref[n]) for n in ("u", "v", "w", "delp", "pt", "zh", "delz", "mfx", "mfy", "cx", "cy")}
 
 
-def check_substeps(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None, tol=None, ic=None):
+def check_substeps(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None, tol=None, ic=None, pfull=None, ks=0):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     st, dp0 = make_state(bd, npz)
     apply_ic(bd, npz, st, ic)
     fl = DynFlags(n_split=n_split, ptop=N.PTOP, **(flags or {}))
-    ref = OD.run(g, npz, fl, dp0, st, bdt)
+    ref = OD.run(g, npz, fl, dp0, st, bdt, pfull=pfull, ks=ks)
+    if pfull is not None:   # fast_tau_w_sec / RF_fast really change the step
+        off = DynFlags(n_split=n_split, ptop=N.PTOP, **dict(flags or {}, fast_tau_w_sec=0.0, rf_fast=False))
+        assert P.rel_rms(OD.run(g, npz, off, dp0, st, bdt)["w"], ref["w"]) > 1e-6
     ctx = Context(g, npz, lib=lib)
     try:
-        dc = DynCore(ctx, fl, dp0)
+        dc = DynCore(ctx, fl, dp0, pfull=pfull, ks=ks)
         dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
         dc.run(bdt)
         got = dc.get_state()

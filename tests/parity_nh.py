@@ -66,7 +66,16 @@ def _riem_context(g, km, lib, lds):
             os.environ["FV3_MI355X_RIEM_LDS"] = saved
 
 
-def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, moist_kappa=False, fast=False, lds=True, out=None, m_split=1):
+def tau_w_profile(km, dt_c, tau_w=25.0):
+    """rff(1:k_rf) of fast_tau_w_sec = tau_w (nh_utils.F90:356-367) for a column whose upper half is above rf_cutoff"""
+    pfull = PTOP * 1.2 + (1.0e5 - PTOP) * (np.arange(km) + 0.5) / km
+    rff = O.fast_tau_w_rff(km, dt_c, tau_w, float(pfull[km // 2]) + 1.0, PTOP, pfull)
+    assert 0 < len(rff) <= km and np.all(rff < 1.0) and np.all(rff > 0.0)
+    return rff
+
+
+def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, moist_kappa=False, fast=False, lds=True, out=None, m_split=1,
+                        tau_w=0.0):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     s = nh_state(bd, km)
@@ -78,7 +87,16 @@ def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, mois
     pef = bd.zeros("A", km + 1)
     q_con, cappa = moist_fields(bd, km)
     q_con, cappa = (q_con if use_cond else None), (cappa if moist_kappa else None)
-    O.riem_solver_c(g, km, 3.0, cn, hs, s["w"], s["pt"], s["delp"], gz, pef, ws, q_con, cappa)
+    rff = tau_w_profile(km, 3.0, tau_w) if tau_w > 0.0 else None   # fast_tau_w_sec > 0: w2(k) * rff(k) inside SIM1_solver
+    O.set_fast_tau_w(rff)
+    try:
+        O.riem_solver_c(g, km, 3.0, cn, hs, s["w"], s["pt"], s["delp"], gz, pef, ws, q_con, cappa)
+    finally:
+        O.set_fast_tau_w(None)
+    if rff is not None:   # the damping really changes the answer
+        gz0, pef0 = s["zh"].copy(order="F"), bd.zeros("A", km + 1)
+        O.riem_solver_c(g, km, 3.0, cn, hs, s["w"], s["pt"], s["delp"], gz0, pef0, ws, q_con, cappa)
+        assert P.rel_rms(pef0, pef) > 1e-10
     if use_cond:   # the moist branch really changes the answer
         gz0, pef0 = s["zh"].copy(order="F"), bd.zeros("A", km + 1)
         O.riem_solver_c(g, km, 3.0, cn, hs, s["w"], s["pt"], s["delp"], gz0, pef0, ws)
@@ -88,6 +106,7 @@ def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, mois
         d_gz, d_pef = ctx.from_host(s["zh"]), ctx.zeros("A", km + 1)
         ctx.set_fast(fast)          # fast mode (csrc/nh_fast.h): held to the oracle at 1e-12, not bit for bit
         ctx.set_condensate(ctx.from_host(q_con) if use_cond else None, ctx.from_host(cappa) if moist_kappa else None)
+        ctx.set_fast_tau_w(rff)
         ctx.riem_solver_c(3.0, cn, ctx.from_host(hs), ctx.from_host(s["w"]), ctx.from_host(s["pt"]),
                           ctx.from_host(s["delp"]), d_gz, d_pef, ctx.from_host(ws))
         r = (bd.is_ - 1, bd.ie + 1, bd.js - 1, bd.je + 1)
@@ -102,7 +121,7 @@ def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, mois
 
 
 def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_call=True, fp_out=False, use_cond=False,
-                       moist_kappa=False, fast=False, lds=True, out=None, m_split=1):
+                       moist_kappa=False, fast=False, lds=True, out=None, m_split=1, tau_w=0.0):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     s = nh_state(bd, km)
@@ -114,8 +133,20 @@ def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_
     o = dict(w=s["w"].copy(order="F"), zh=s["zh"].copy(order="F"), delz=bd.zeros("CC", km),
              ppe=bd.zeros("A", km + 1), pk3=bd.full("A", 1e40, km + 1), pk=bd.zeros("CC", km + 1),
              pe=np.zeros((nx + 2, km + 1, ny + 2), order="F"), peln=np.zeros((nx, km + 1, ny), order="F"))
-    O.riem_solver3(g, km, 6.0, cn, s["zs"], o["w"], o["delz"], s["pt"], s["delp"], o["zh"], o["pe"], o["ppe"],
-                   o["pk3"], o["pk"], o["peln"], ws, use_logp, last_call, fp_out, q_con, cappa)
+    rff = tau_w_profile(km, 3.0, tau_w) if tau_w > 0.0 else None   # the profile is Riem_Solver_c's (half the acoustic step)
+    O.set_fast_tau_w(rff)
+    try:
+        O.riem_solver3(g, km, 6.0, cn, s["zs"], o["w"], o["delz"], s["pt"], s["delp"], o["zh"], o["pe"], o["ppe"],
+                       o["pk3"], o["pk"], o["peln"], ws, use_logp, last_call, fp_out, q_con, cappa)
+    finally:
+        O.set_fast_tau_w(None)
+    if rff is not None:   # the damping really changes the answer
+        o0 = dict(w=s["w"].copy(order="F"), zh=s["zh"].copy(order="F"), delz=bd.zeros("CC", km),
+                  ppe=bd.zeros("A", km + 1), pk3=bd.full("A", 1e40, km + 1), pk=bd.zeros("CC", km + 1),
+                  pe=np.zeros((nx + 2, km + 1, ny + 2), order="F"), peln=np.zeros((nx, km + 1, ny), order="F"))
+        O.riem_solver3(g, km, 6.0, cn, s["zs"], o0["w"], o0["delz"], s["pt"], s["delp"], o0["zh"], o0["pe"], o0["ppe"],
+                       o0["pk3"], o0["pk"], o0["peln"], ws, use_logp, last_call, fp_out, q_con, cappa)
+        assert P.rel_rms(bd.view(o0["w"], "A", bd.is_, bd.ie, bd.js, bd.je), bd.view(o["w"], "A", bd.is_, bd.ie, bd.js, bd.je)) > 1e-6
     if use_cond or moist_kappa:   # the moist branches really change the answer
         o0 = dict(w=s["w"].copy(order="F"), zh=s["zh"].copy(order="F"), delz=bd.zeros("CC", km),
                   ppe=bd.zeros("A", km + 1), pk3=bd.full("A", 1e40, km + 1), pk=bd.zeros("CC", km + 1),
@@ -133,6 +164,7 @@ def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_
                                                    pk=bd.zeros("CC", km + 1),
                                                    pe=np.zeros((nx + 2, km + 1, ny + 2), order="F"),
                                                    peln=np.zeros((nx, km + 1, ny), order="F")).items()}
+        ctx.set_fast_tau_w(rff)
         ctx.riem_solver3(6.0, cn, ctx.from_host(s["zs"]), d["w"], d["delz"], ctx.from_host(s["pt"]),
                          ctx.from_host(s["delp"]), d["zh"], d["pe"], d["ppe"], d["pk3"], d["pk"], d["peln"],
                          ctx.from_host(ws), use_logp, last_call, fp_out)
@@ -511,6 +543,41 @@ def check_c2l_and_rayleigh(lib, nx=70, ny=33, km=12, hydrostatic=False, conserve
     return worst
 
 
+def check_ray_fast(lib, nx=37, ny=19, km=12, hydrostatic=False, tau=0.5, rf_cutoff=None, ks=None):
+    """Ray_fast (dyn_core.F90:2485-2601): the profile of its first call and the damping with the momentum handed back, against the
+    oracle.  rf_cutoff: default = between levels km/2 and km/2 + 1; ks: the call site's (levels of pure pressure)"""
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    rng = np.random.default_rng(23)
+    pfull = PTOP * 1.2 + (1.0e5 - PTOP) * (np.arange(km) + 0.5) / km
+    dp = rng.uniform(500.0, 1500.0, km)
+    rf_cutoff = float(pfull[km // 2]) + 1.0 if rf_cutoff is None else rf_cutoff
+    ks = km - 2 if ks is None else ks
+    kmax, k_rf, dm, rf = O.ray_fast_profile(km, ks, 12.0, tau, rf_cutoff, PTOP, pfull, dp)
+    u = np.asfortranarray(rng.uniform(-30, 30, bd.shape("U", km)))
+    v = np.asfortranarray(rng.uniform(-30, 30, bd.shape("V", km)))
+    w = np.asfortranarray(rng.uniform(-2, 2, bd.shape("A", km)))
+    o = dict(u=u.copy(order="F"), v=v.copy(order="F"), w=w.copy(order="F"))
+    O.ray_fast(g, km, kmax, k_rf, rf, dp, hydrostatic, o["u"], o["v"], None if hydrostatic else o["w"])
+    assert P.rel_rms(o["u"], u) > 1e-6 or not np.any(rf < 1.0)
+    ctx = Context(g, km, lib=lib)
+    try:
+        d_u, d_v, d_w = ctx.from_host(u), ctx.from_host(v), ctx.from_host(w)
+        ctx.set_ray_fast(kmax, k_rf, dm if k_rf > 0 else 1.0, rf[:kmax], dp)
+        ctx.ray_fast(d_u, d_v, None if hydrostatic else d_w, hydrostatic)
+        # the reference's statements on the same operands: bit for bit (the halo rows stay as they were)
+        assert np.array_equal(d_u.download(), o["u"]) and np.array_equal(d_v.download(), o["v"]) and np.array_equal(d_w.download(), o["w"])
+        # what the levels k <= kmax lose comes back on the levels k <= k_rf: the column's momentum sum dp u is conserved to rounding
+        r = (bd.is_, bd.ie, bd.js, bd.je + 1)
+        m0 = np.einsum("ijk,k->ij", bd.view(u, "U", *r), dp)
+        m1 = np.einsum("ijk,k->ij", bd.view(d_u.download(), "U", *r), dp)
+        if k_rf > 0:
+            assert np.max(np.abs(m1 - m0)) <= 1e-11 * np.max(np.abs(m0))
+    finally:
+        ctx.close()
+    return kmax, k_rf
+
+
 def np_moist_cv(q, mp, cv_air):
     """moist_cv (fv_thermodynamics.F90:250-325) on whole arrays; q: (.., nq); returns cvm, q_con"""
     Q = lambda n: q[..., n - 1] if n > 0 else 0.0
@@ -598,17 +665,19 @@ def check_riem_lds_bits(lib, **dims):
     the default) against the slab kernels (FV3_MI355X_RIEM_LDS=0): the SAME BITS in every output, both within the parity tolerance of
     the oracle"""
     for kw in (dict(), dict(use_logp=True, last_call=True, fp_out=True), dict(last_call=False), dict(a_imp=0.75),
-               dict(a_imp=0.75, use_logp=True, last_call=True, fp_out=True)):   # a_imp < 1: SIM_solver (RiemFast<false, true, true>)
+               dict(a_imp=0.75, use_logp=True, last_call=True, fp_out=True),   # a_imp < 1: SIM_solver (RiemFast<false, true, true>)
+               dict(tau_w=25.0), dict(a_imp=0.75, tau_w=25.0)):                # fast_tau_w_sec > 0
         a, b = {}, {}
         check_riem_solver3(lib, out=a, **kw, **dims)
         check_riem_solver3(lib, lds=False, out=b, **kw, **dims)
         for n in a:
             assert np.array_equal(a[n], b[n]), f"riem_solver3 {kw}: {n} differs from the slab kernel"
-    a, b = {}, {}
-    check_riem_solver_c(lib, out=a, **dims)
-    check_riem_solver_c(lib, lds=False, out=b, **dims)
-    for n in a:
-        assert np.array_equal(a[n], b[n]), f"riem_solver_c: {n} differs from the slab kernel"
+    for kw in (dict(), dict(tau_w=25.0)):
+        a, b = {}, {}
+        check_riem_solver_c(lib, out=a, **kw, **dims)
+        check_riem_solver_c(lib, lds=False, out=b, **kw, **dims)
+        for n in a:
+            assert np.array_equal(a[n], b[n]), f"riem_solver_c {kw}: {n} differs from the slab kernel"
     # use_cond / moist_kappa (RiemFast<CG, true, SIM, true>: nh_core.F90:96-166, nh_utils.F90:383-438)
     for mk in (dict(use_cond=True), dict(moist_kappa=True), dict(use_cond=True, moist_kappa=True)):
         for kw in (dict(use_logp=True, last_call=True, fp_out=True), dict(a_imp=0.75)):

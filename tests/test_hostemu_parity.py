@@ -504,6 +504,37 @@ def test_geometry_mode_detection(emu):
             ctx.close()
 
 
+@pytest.mark.parametrize("a_imp", [1.0, 0.75])
+def test_riem_solvers_fast_tau_w_sec(emu, a_imp):
+    """fast_tau_w_sec > 0: the Rayleigh damping of w inside SIM1_solver / SIM_solver (nh_utils.F90:356-367, :1363-1371, :1498-1506),
+    the levels-across-the-lanes kernels and the slab kernels, dry and moist"""
+    N.check_riem_solver3(emu, a_imp=a_imp, tau_w=25.0)
+    N.check_riem_solver3(emu, a_imp=a_imp, tau_w=25.0, lds=False, use_logp=True, last_call=True, fp_out=True)
+    N.check_riem_solver3(emu, a_imp=a_imp, tau_w=40.0, use_cond=True, moist_kappa=True, nx=40, ny=9, km=19)
+    if a_imp > 0.999:
+        N.check_riem_solver_c(emu, tau_w=25.0)
+        N.check_riem_solver_c(emu, tau_w=25.0, lds=False)
+        N.check_riem_solver_c(emu, tau_w=25.0, use_cond=True, nx=40, ny=9, km=19)
+
+
+def test_substeps_with_fast_tau_w_sec_and_rf_fast(emu):
+    """the acoustic substeps with the Rayleigh damping of w inside the solvers and Ray_fast at their end (dyn_core.F90:536, :940, :1057-1060)"""
+    npz = 10
+    pfull = N.PTOP * 1.2 + (1.0e5 - N.PTOP) * (np.arange(npz) + 0.5) / npz
+    fl = dict(fast_tau_w_sec=40.0, rf_fast=True, tau=0.002, rf_cutoff=float(pfull[4]) + 1.0)
+    D.check_substeps(emu, npz=npz, n_split=3, bdt=6.0, flags=fl, pfull=pfull, ks=7)
+    D.check_substeps(emu, npz=npz, n_split=2, bdt=4.0, flags=dict(fl, a_imp=0.75, rf_fast=False), pfull=pfull, ks=7)
+
+
+@pytest.mark.parametrize("hydrostatic", [False, True])
+def test_ray_fast(emu, hydrostatic):
+    """Ray_fast (RF_fast, dyn_core.F90:1057-1060, :2485-2601), bit for bit; k_rf beyond kmax and no level above the cutoff too"""
+    kmax, k_rf = N.check_ray_fast(emu, hydrostatic=hydrostatic)
+    assert kmax == 7 and k_rf == 7
+    N.check_ray_fast(emu, hydrostatic=hydrostatic, nx=64, ny=5, km=7, ks=2)            # k_rf < kmax
+    assert N.check_ray_fast(emu, hydrostatic=hydrostatic, rf_cutoff=10.0) == (1, 0)    # nothing above the cutoff: rf = 1, nothing moves ...
+
+
 @pytest.mark.parametrize("hydrostatic,conserve", [(False, True), (True, True), (False, False)])
 def test_c2l_and_rayleigh_friction(emu, hydrostatic, conserve):
     """fv_dynamics around the k_split loop: cubed_to_latlon (ord 2, 4) and Rayleigh_Friction, grid_type = 4"""
@@ -546,6 +577,8 @@ def test_fortran_dyn_core_with_the_reference_argument_list(emu, tmp_path):
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=12, d_con=1.0)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=12, hydrostatic=True, d_con=1.0)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, beta=0.4)
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=10, fast_tau_w_sec=40.0, rf_fast_tau=0.002)   # fast_tau_w_sec, RF_fast
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=10, hydrostatic=True, rf_fast_tau=0.002)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, hydrostatic=True, beta=0.4)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, moist=True, d_con=1.0)     # thermostruct%use_cond / moist_kappa
     # fv_dynamics with ITS reference argument list (model/fv_dynamics.F90:79-85): T -> theta_v, the k_split loop with tracers and
