@@ -971,6 +971,14 @@ struct TracerMarchFused {
     vd ar_1(1.), ar_2(1.), ar_3(1.);  // area of rows r-1 .. r-3
     vd yf_prev(0.);
     In<NL> nxt = load_in(jA - 3);
+#if FV3_BF
+    // the row step without a branch around a store (DswTransportFused::run_bf): the warm-up steps form the update of row jA from the
+    // clamped rows they loaded and drop it (`on` = false: a buffer store with no records)
+    // (tools/tz_ab.py at C384 L127, same arrays: 4 tracers 0.86 -> 0.80 ms, 33 tracers 6.58 -> 6.43 ms per sub-cycle: the kernel is bound by
+    // the f64 issue rate of fv_tp_2d itself -- 96 G tracer-cells/s -- not by its memory waits)
+    const vm mC = make_mask(s.lC0, s.lC1);
+    vdrain_loads();
+#endif
     for (int r = jA - 3; r <= rlast; r++) {
       const In<NL> in = nxt;
       nxt = load_in(r < rlast ? r + 1 : rlast);
@@ -987,6 +995,20 @@ struct TracerMarchFused {
       ar_3 = ar_2; ar_2 = ar_1; ar_1 = in.ar;
       vd fx[NL], fy0[NL], fy1[NL];
       for (int t = 0; t < NL; t++) fd[t].step(in.q[t], sh, have_face, have_row, fx[t], fy0[t], fy1[t]);
+#if FV3_BF
+      {
+        const bool on = have_face && have_row;
+        const long iA = (long)g.iA(ilo, j < jA ? jA : j);
+        const vd dp2 = in.d1 + (in.mx - shl1(in.mx) + in.my0 - in.my1) * in.ra;                 // :517-522
+        const vd rdp2 = vrecip(dp2);
+        for (int t = 0; t < NL; t++) {
+          const vd gx = fx[t] * in.mx, gy0 = fy0[t] * in.my0, gy1 = fy1[t] * in.my1;
+          const vd qn = vdiv_r(fd[t].ya.row_m3() * in.d1 + (gx - shl1(gx) + gy0 - gy1) * in.ra, dp2, rdp2);  // :523-531
+          vstore_b_nt(q_out + qoff(t), iA, qn, mC, on);
+        }
+        vstore_b_nt(dp1_out + oA, iA, dp2, mC, on && write_dp);
+      }
+#else
       if (have_face && have_row) {
         const long iA = (long)g.iA(ilo, j);
         const vd dp2 = in.d1 + (in.mx - shl1(in.mx) + in.my0 - in.my1) * in.ra;                 // :517-522
@@ -998,6 +1020,7 @@ struct TracerMarchFused {
         }
         if (write_dp) vstore(dp1_out + oA, iA, dp2, s.lC0, s.lC1);
       }
+#endif
       if (have_face) yf_prev = sh.yf;
     }
   }

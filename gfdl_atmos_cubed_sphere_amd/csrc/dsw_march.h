@@ -312,6 +312,10 @@ struct DswVortMarch {
 namespace fv3 {
 
 // update_dz_d, model/nh_utils.F90:256-301: fv_tp_2d of one interface height + flux-form update
+#ifndef FV3_ZH_BF
+#define FV3_ZH_BF 0   // 1: the row step without a branch around a load / store (tp2d_march.h sink_branch_free).  Measured at C384 L127
+                      // (tools/tz_ab.py, same arrays): 0.299 - 0.314 ms either way -- this kernel is not held up by its waitcnt; off
+#endif
 template <int HORD>
 struct ZhMarch {
   Grid g;
@@ -345,6 +349,17 @@ struct ZhMarch {
       const vd zn = (in.z * in.ar + fx0 - shl1(fx0) + fy0 - fy1) / (rax + ray - in.ar);  // :283-299
       vstore(K.zh_out + (size_t)k * g.nA(), (long)g.iA(s.ilo, j), zn, s.lC0, s.lC1);
     }
+#if FV3_ZH_BF
+    static constexpr bool kBranchFree = true;
+    FV3_D void row_bf(int j, const In &in, const vd &fxv, const vd &fyv0, const vd &fyv1, bool on) const {
+      const Grid &g = K.g;
+      const vd x1 = shl1(in.x0);
+      const vd fx0 = fxv * in.x0, fy0 = fyv0 * in.y0, fy1 = fyv1 * in.y1;
+      const vd rax = in.ar + in.x0 - x1, ray = in.ar + in.y0 - in.y1;
+      const vd zn = (in.z * in.ar + fx0 - shl1(fx0) + fy0 - fy1) / (rax + ray - in.ar);  // :283-299
+      vstore_b(K.zh_out + (size_t)k * g.nA(), (long)g.iA(s.ilo, j), zn, make_mask(s.lC0, s.lC1), on);
+    }
+#endif
   };
 
   FV3_D void operator()(int gid) const {

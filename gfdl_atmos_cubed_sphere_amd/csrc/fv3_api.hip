@@ -81,6 +81,11 @@ struct fv3_ctx {
   bool dp0_ready;
   double *scratch[8];
   double *ray_d;         // pm(k), rf(k) of Rayleigh_Friction
+  // host-address field registry (fv3_registry_*): host array -> its device mirror and which of the two copies is current
+  struct RegEntry { const void *host; void *dev; size_t bytes; bool dev_current, host_current; };
+  std::vector<RegEntry> *reg;
+  int reg_lazy;
+  long long reg_stat[4];   // h2d copies, h2d skipped, d2h copies, d2h deferred
   double *rff_d;         // rff(k) of fast_tau_w_sec (npz, 1.0 below k_rf) or null; rf(k), dp(k) of Ray_fast behind it (fv3_set_ray_fast)
   int rff_on, rayf_kmax, rayf_krf;
   double rayf_dm;
@@ -623,6 +628,7 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
   c->dp0 = nullptr; c->edge_dev = nullptr; c->dp0_ready = false;
   c->akbk = nullptr; c->kord_tr_dev = nullptr; c->akbk_ready = false;
   c->remap_scr = nullptr; c->remap_scr_n = 0; c->ray_d = nullptr;
+  c->reg = nullptr; c->reg_lazy = 0; c->reg_stat[0] = c->reg_stat[1] = c->reg_stat[2] = c->reg_stat[3] = 0;
   c->rff_d = nullptr; c->rff_on = 0; c->rayf_kmax = -1; c->rayf_krf = 0; c->rayf_dm = 1.;
   c->q_con = nullptr; c->cappa = nullptr;
   c->moist_on = false; c->moist_qcon = nullptr; c->moist_cappa = nullptr;
@@ -658,6 +664,7 @@ extern "C" int fv3_destroy(fv3_ctx *c) {
   if (c->remap_scr) rt_free(c->remap_scr);
   if (c->ray_d) rt_free(c->ray_d);
   if (c->rff_d) rt_free(c->rff_d);
+  delete c->reg;
   if (c->trc_d) rt_free(c->trc_d);
   if (c->trc_i) rt_free(c->trc_i);
   if (c->ones_i) rt_free(c->ones_i);
@@ -786,6 +793,80 @@ extern "C" int fv3_memcpy_h2d(fv3_ctx *c, void *dst, const void *src, size_t byt
 }
 extern "C" int fv3_memcpy_d2h(fv3_ctx *c, void *dst, const void *src, size_t bytes) {
   RT(rtf_d2h(dst, src, bytes, c ? c->stream : nullptr));
+  return 0;
+}
+// ---- host-address field registry: the reference's entry points take HOST arrays the caller owns; a wrapper with the same
+// argument list copies them in and out on every call unless it knows which copy is current.  An entry is keyed by the host address.
+// Eager (the default): every put / get copies -- the caller may have touched anything.  Lazy (fv3_registry_mode(ctx, 1)): the caller
+// declares what it wrote (fv3_registry_host_touched) and asks for what it reads (fv3_registry_fetch); everything else stays on the device.
+static fv3_ctx::RegEntry *reg_find(fv3_ctx *c, const void *host, const void *dev) {
+  if (!c->reg) c->reg = new std::vector<fv3_ctx::RegEntry>();
+  for (auto &e : *c->reg)
+    if ((host && e.host == host) || (!host && dev && e.dev == dev)) return &e;
+  return nullptr;
+}
+extern "C" int fv3_registry_mode(fv3_ctx *c, int lazy) {
+  if (!c) return fail("fv3_registry_mode: null context");
+  c->reg_lazy = lazy ? 1 : 0;
+  return 0;
+}
+extern "C" int fv3_registry_put(fv3_ctx *c, void *dev, const void *host, size_t bytes) {
+  if (!c || !dev || !host) return fail("fv3_registry_put: null argument");
+  fv3_ctx::RegEntry *e = reg_find(c, host, nullptr);
+  if (e && (e->dev != dev || e->bytes != bytes)) {   // the host address is bound to another mirror now (a freed and reused array)
+    e->dev = dev; e->bytes = bytes; e->dev_current = false; e->host_current = true;
+  }
+  if (!e) {
+    c->reg->push_back(fv3_ctx::RegEntry{host, dev, bytes, false, true});
+    e = &c->reg->back();
+  }
+  if (c->reg_lazy && e->dev_current) { c->reg_stat[1]++; return 0; }
+  RT(rtf_h2d(dev, host, bytes, c->stream));
+  e->dev_current = true;
+  c->reg_stat[0]++;
+  return 0;
+}
+extern "C" int fv3_registry_get(fv3_ctx *c, void *host, const void *dev, size_t bytes) {
+  if (!c || !dev || !host) return fail("fv3_registry_get: null argument");
+  fv3_ctx::RegEntry *e = reg_find(c, host, nullptr);
+  if (!e) {
+    c->reg->push_back(fv3_ctx::RegEntry{host, const_cast<void *>(dev), bytes, true, false});
+    e = &c->reg->back();
+  } else if (e->dev != dev || e->bytes != bytes) {
+    e->dev = const_cast<void *>(dev); e->bytes = bytes; e->dev_current = true;
+  }
+  e->host_current = false;            // a kernel wrote the mirror since the host copy was current
+  e->dev_current = true;
+  if (c->reg_lazy) { c->reg_stat[3]++; return 0; }   // deferred: fv3_registry_fetch brings it when the caller reads it
+  RT(rtf_d2h(host, dev, bytes, c->stream));
+  e->host_current = true;
+  c->reg_stat[2]++;
+  return 0;
+}
+extern "C" int fv3_registry_host_touched(fv3_ctx *c, const void *host) {
+  if (!c) return fail("fv3_registry_host_touched: null context");
+  if (!c->reg) return 0;
+  for (auto &e : *c->reg)
+    if (!host || e.host == host) { e.dev_current = false; e.host_current = true; }
+  return 0;
+}
+extern "C" int fv3_registry_fetch(fv3_ctx *c, void *host) {
+  if (!c) return fail("fv3_registry_fetch: null context");
+  if (!c->reg) return 0;
+  bool any = false;
+  for (auto &e : *c->reg)
+    if ((!host || e.host == host) && !e.host_current) {
+      RT(rtf_d2h(const_cast<void *>(e.host), e.dev, e.bytes, c->stream));
+      e.host_current = true;
+      c->reg_stat[2]++;
+      any = true;
+    }
+  if (any) RT(rtf_sync(c->stream));
+  return 0;
+}
+extern "C" int fv3_registry_stats(fv3_ctx *c, long long *out4) {
+  if (!c || !out4) return fail("fv3_registry_stats: null argument");
+  for (int i = 0; i < 4; i++) out4[i] = c->reg_stat[i];
   return 0;
 }
 extern "C" int fv3_memcpy_d2d(fv3_ctx *c, void *dst, const void *src, size_t bytes) {
@@ -3470,6 +3551,28 @@ extern "C" int fv3_rayleigh_super(fv3_ctx *c, int kmax, int conserve, int hydros
   grid.y = 1;
   grid.z = (unsigned)kmax;
   RT(launch_p(c, "rayleigh_super", grid, 0, kf));
+  return 0;
+}
+
+extern "C" int fv3_compute_aam(fv3_ctx *c, double radius, double omega, double agrav, double ptop, const double *coslat, const double *ua,
+                               const double *delp, double *aam, double *m_fac, double *ps) {
+  if (!c || !c->grid_ready) return fail("fv3_compute_aam: context has no grid");
+  if (!coslat || !ua || !delp || !aam || !m_fac || !ps) return fail("fv3_compute_aam: null argument");
+  AamColumns kf{c->g, radius, omega, agrav, ptop, coslat, ua, delp, aam, m_fac, ps};
+  RT(launch_c(c, "compute_aam", col_grid(c->g.nx * c->g.ny), kf));
+  return 0;
+}
+
+extern "C" int fv3_consv_am_apply(fv3_ctx *c, double u00, const double *l2c_u, const double *l2c_v, double *u, double *v) {
+  if (!c || !c->grid_ready) return fail("fv3_consv_am_apply: context has no grid");
+  if (!l2c_u || !l2c_v || !u || !v) return fail("fv3_consv_am_apply: null argument");
+  const Grid &g = c->g;
+  ConsvAmApply kf{g, u00, l2c_u, l2c_v, u, v};
+  Dim3 grid;
+  grid.x = (unsigned)(((g.nx + 1) * (g.ny + 1) + ConsvAmApply::CH - 1) / ConsvAmApply::CH);
+  grid.y = 1;
+  grid.z = (unsigned)g.npz;
+  RT(launch_p(c, "consv_am_apply", grid, 0, kf));
   return 0;
 }
 

@@ -722,8 +722,14 @@ struct ZhFromDelz {  // dyn_core.F90:370-385: gz(npz+1) = zs; gz(k) = gz(k+1) - 
 // p_grad_c, dyn_core.F90:1635-1694.  One thread per cell (i, j) of [is, ie+1] x [js, je+1] marching down its column (see NhPGrad
 // below): uc between the cells (i - 1, j) and (i, j), vc between (i, j - 1) and (i, j); the interface above in registers, kDep
 // interfaces ahead in flight (clamped addresses, no branch around a load).
+#ifndef FV3_PGRADC_KDEP
+#define FV3_PGRADC_KDEP 4   // 3: 0.272 ms, 4: 0.272, 6: 0.292, 8: 0.291
+#endif
+#ifndef FV3_PGRAD_KDEP
+#define FV3_PGRAD_KDEP 2   // measured at C384 L127 (tools/a2b_ab.py): 2: 0.322 ms, 3: 0.350, 4: 0.344, 5: 0.352 (registers / wavefronts per SIMD)
+#endif
 struct PGradC {
-  static constexpr int kDep = 4;
+  static constexpr int kDep = FV3_PGRADC_KDEP;
   Grid g;
   double dt2;
   int hydrostatic;
@@ -885,7 +891,7 @@ struct A2BCorners {
 // interfaces of a layer loaded by every thread, 27 loads per cell for 14.
 template <bool SPLIT>
 struct NhPGrad {
-  static constexpr int kDep = 3;
+  static constexpr int kDep = FV3_PGRAD_KDEP;
   Grid g;
   double dt;
   const double *pp, *pk, *gz, *dpc;  // corner slabs: pp, pk, gz (npz+1 levels), delp (npz levels)
@@ -1774,6 +1780,51 @@ struct RayFast {
         double *wc = w + g.iA(i, j);
         for (int k = 0; k < kmax; k++) wc[(size_t)k * nA] = rf[k] * wc[(size_t)k * nA];
       }
+    }
+  }
+};
+
+// compute_aam, fv_dynamics.F90:1266-1314 (after the caller's cubed_to_latlon, :1287): one thread per column of the compute domain
+struct AamColumns {
+  Grid g;
+  double radius, omega, agrav, ptop;
+  const double *coslat, *ua, *delp;   // coslat: A (2-D) = cos(agrid(:,:,2))
+  double *aam, *m_fac, *ps;           // CC, CC, A (2-D)
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int ncol = g.nx * g.ny;
+    const size_t nA = g.nA();
+    FV3_COL_FOR(c, ncol) {
+      const int i = g.is + c % g.nx, j = g.js + c / g.nx;
+      const int o = g.iA(i, j);
+      const double r1 = radius * coslat[o], r2 = r1 * r1;
+      double a = 0., m = 0., p = ptop;
+      for (int k = 0; k < g.npz; k++) {
+        double dm = delp[(size_t)k * nA + o];
+        p = p + dm;
+        dm = dm * agrav;
+        a = a + (r2 * omega + r1 * ua[(size_t)k * nA + o]) * dm;
+        m = m + dm * r2;
+      }
+      aam[g.iCC(i, j)] = a;
+      m_fac[g.iCC(i, j)] = m;
+      ps[o] = p;
+    }
+  }
+};
+
+// consv_am, fv_dynamics.F90:784-798: u += u00 l2c_u, v += u00 l2c_v; one thread per (i, j) of [is, ie+1] x [js, je+1] and level
+struct ConsvAmApply {
+  static constexpr int CH = 256;
+  Grid g;
+  double u00;
+  const double *l2c_u, *l2c_v;   // U (2-D), V (2-D)
+  double *u, *v;
+  FV3_HD void operator()(int bx, int, int bz, int tid, double *) const {
+    const int wd = g.nx + 1, ncol = wd * (g.ny + 1);
+    for (int c = bx * CH + tid; c < (bx + 1) * CH && c < ncol; c += kNT) {
+      const int i = g.is + c % wd, j = g.js + c / wd;
+      if (i <= g.ie) u[(size_t)bz * g.nU() + g.iU(i, j)] = u[(size_t)bz * g.nU() + g.iU(i, j)] + u00 * l2c_u[g.iU(i, j)];
+      if (j <= g.je) v[(size_t)bz * g.nV() + g.iV(i, j)] = v[(size_t)bz * g.nV() + g.iV(i, j)] + u00 * l2c_v[g.iV(i, j)];
     }
   }
 };

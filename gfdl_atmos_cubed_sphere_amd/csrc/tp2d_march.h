@@ -17,6 +17,8 @@
 // Lane validity: q on all lanes it could be loaded for; x-faces on lanes 3..61, cells on lanes 3..60.
 #pragma once
 
+#include <type_traits>
+
 #include <cstdlib>
 
 #include "ppm_march.h"
@@ -261,6 +263,12 @@ struct FieldSrc {
   FV3_D vd value(const In &in) const { return in; }
 };
 
+// a sink with `static constexpr bool kBranchFree = true` and row_bf(j, in, fx, fy0, fy1, on) gets the row step without control flow
+template <class S, class = void>
+struct sink_branch_free { static constexpr bool value = false; };
+template <class S>
+struct sink_branch_free<S, std::enable_if_t<S::kBranchFree>> { static constexpr bool value = true; };
+
 // fv_tp_2d of the field produced row by row by `src`.  Software pipelining: the loads of step r+1 (and
 // the sink's loads of its next row) are issued before the arithmetic of step r.
 template <int HORD, class Src, class Sink>
@@ -273,6 +281,27 @@ FV3_D void tp2d_march_src(const Grid &g, const StripGeom &s, int jA, int jB, con
   march_load_metrics(nxt, g, s, jA, jA - 3, crx, cry, xfx, yfx);
   typename Src::In qnxt = src.load(jA - 3);
   typename Sink::In snxt = sink.load(jA);
+  if constexpr (sink_branch_free<Sink>::value) {
+    // no branch around a load or a store (a branch there costs an s_waitcnt vmcnt(0) at the top of every step, dsw_fused.h run_bf): the
+    // warm-up steps load the sink's row jA again and hand it a dropped store (`on` = false)
+    vd fxv(0.), fyv0(0.), fyv1(0.);
+    vdrain_loads();
+    for (int r = jA - 3; r <= rlast; r++) {
+      MarchIn in = nxt;
+      const typename Src::In qin = qnxt;
+      const int rn = r < rlast ? r + 1 : rlast;
+      march_load_metrics(nxt, g, s, jA, rn, crx, cry, xfx, yfx);
+      qnxt = src.load(rn);
+      in.qn = src.value(qin);
+      const int j = r - 3;
+      const bool on = j >= jA;
+      st.step(in, r - 2 >= jA, on, fxv, fyv0, fyv1);
+      const typename Sink::In sin = snxt;
+      snxt = sink.load(on ? (j < jB ? j + 1 : jB) : jA);
+      sink.row_bf(on ? j : jA, sin, fxv, fyv0, fyv1, on);
+    }
+    return;
+  }
   for (int r = jA - 3; r <= rlast; r++) {
     MarchIn in = nxt;
     const typename Src::In qin = qnxt;

@@ -222,6 +222,10 @@ module fv3_dyn_core_mod
   implicit none
   private
   public :: dyn_core, dyn_core_end, fv_dynamics, fv_dynamics_end
+  ! the host-address field registry of dyn_core on the doubly periodic domain (include/fv3_mi355x.h fv3_registry_*): lazy = the caller
+  ! declares what it wrote between the calls (fv3_host_touched) and asks for what it reads (fv3_host_fetch); the rest stays on the device
+  public :: fv3_dyn_core_registry, fv3_host_touched, fv3_host_fetch, fv3_dyn_core_registry_stats
+  logical, save :: registry_lazy = .false.
 
   type(fv3_atmos), save :: at
   logical, save :: bound = .false.
@@ -313,12 +317,13 @@ contains
     at%fl%n_split = n_split
     nx = bd%ie - bd%is + 1; ny = bd%je - bd%js + 1
     nk = int(npz, c_size_t); nk1 = nk + 1
+    call fv3_check(fv3_registry_mode(at%ctx, merge(1_c_int, 0_c_int, registry_lazy)), 'fv3_registry_mode')
 
     ! ---- host -> device: what the loop reads (dyn_core.F90:95-96: u, v, w, delz, pt, delp, phis; pkz / pe / pk / peln / omga /
     !      ua / va are intent(inout) members the loop only partly rewrites) ----
-    call put(at%u, c_loc(u), at%nU*nk);        call put(at%v, c_loc(v), at%nV*nk)
-    call put(at%delp, c_loc(delp), at%nA*nk);  call put(at%pt, c_loc(pt), at%nA*nk)
-    call put(at%phis, c_loc(phis), at%nA)
+    call rput(at%u, c_loc(u), at%nU*nk);        call rput(at%v, c_loc(v), at%nV*nk)
+    call rput(at%delp, c_loc(delp), at%nA*nk);  call rput(at%pt, c_loc(pt), at%nA*nk)
+    call rput(at%phis, c_loc(phis), at%nA)
     allocate(zs(bd%isd:bd%ied, bd%jsd:bd%jed))
     zs = phis * (1.d0 / grav)                                              ! dyn_core.F90:246-251
     call put(at%zs, c_loc(zs), at%nA)
@@ -327,9 +332,9 @@ contains
       w_c = w(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz); delz_c = delz(bd%is:bd%ie, bd%js:bd%je, 1:npz)
       call put(at%w, c_loc(w_c), at%nA*nk);    call put(at%delz, c_loc(delz_c), at%nCC*nk)
     end if
-    call put(at%pkz, c_loc(pkz), at%nCC*nk);   call put(at%pk, c_loc(pk), at%nCC*nk1)
-    call put(at%pe, c_loc(pe), int(nx+2, c_size_t)*nk1*(ny+2)); call put(at%peln, c_loc(peln), at%nCC*nk1)
-    call put(at%omga, c_loc(omga), at%nA*nk);  call put(at%ua, c_loc(ua), at%nA*nk); call put(at%va, c_loc(va), at%nA*nk)
+    call rput(at%pkz, c_loc(pkz), at%nCC*nk);   call rput(at%pk, c_loc(pk), at%nCC*nk1)
+    call rput(at%pe, c_loc(pe), int(nx+2, c_size_t)*nk1*(ny+2)); call rput(at%peln, c_loc(peln), at%nCC*nk1)
+    call rput(at%omga, c_loc(omga), at%nA*nk);  call rput(at%ua, c_loc(ua), at%nA*nk); call rput(at%va, c_loc(va), at%nA*nk)
     ! thermostruct%use_cond: q_con (halo updated by the caller, fv_dynamics.F90:464) rides through d_sw and the Riemann solvers;
     ! moist_kappa: cappa (:465) is read by the solvers and the heating
     if (thermostruct%use_cond) then
@@ -349,19 +354,19 @@ contains
 
     ! ---- device -> host ----
     call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
-    call get(c_loc(u), at%u, at%nU*nk);        call get(c_loc(v), at%v, at%nV*nk)
-    call get(c_loc(delp), at%delp, at%nA*nk);  call get(c_loc(pt), at%pt, at%nA*nk)
+    call rget(c_loc(u), at%u, at%nU*nk);        call rget(c_loc(v), at%v, at%nV*nk)
+    call rget(c_loc(delp), at%delp, at%nA*nk);  call rget(c_loc(pt), at%pt, at%nA*nk)
     if (.not. hydrostatic) then
       call get(c_loc(w_c), at%w, at%nA*nk);    call get(c_loc(delz_c), at%delz, at%nCC*nk)
-      call get(c_loc(ws), at%ws, at%nCC)
+      call rget(c_loc(ws), at%ws, at%nCC)
     end if
-    call get(c_loc(pkz), at%pkz, at%nCC*nk);   call get(c_loc(pk), at%pk, at%nCC*nk1)
-    call get(c_loc(pe), at%pe, int(nx+2, c_size_t)*nk1*(ny+2)); call get(c_loc(peln), at%peln, at%nCC*nk1)
-    call get(c_loc(omga), at%omga, at%nA*nk);  call get(c_loc(ua), at%ua, at%nA*nk); call get(c_loc(va), at%va, at%nA*nk)
-    call get(c_loc(uc), at%uc, at%nV*nk);      call get(c_loc(vc), at%vc, at%nU*nk)
-    call get(c_loc(mfx), at%mfx, at%nFX*nk);   call get(c_loc(mfy), at%mfy, at%nFY*nk)
-    call get(c_loc(cx), at%cx, at%nCX*nk);     call get(c_loc(cy), at%cy, at%nCY*nk)
-    if (flagstruct%d_con > 1.d-5) call get(c_loc(heat_source), at%heat_source, at%nA*nk)
+    call rget(c_loc(pkz), at%pkz, at%nCC*nk);   call rget(c_loc(pk), at%pk, at%nCC*nk1)
+    call rget(c_loc(pe), at%pe, int(nx+2, c_size_t)*nk1*(ny+2)); call rget(c_loc(peln), at%peln, at%nCC*nk1)
+    call rget(c_loc(omga), at%omga, at%nA*nk);  call rget(c_loc(ua), at%ua, at%nA*nk); call rget(c_loc(va), at%va, at%nA*nk)
+    call rget(c_loc(uc), at%uc, at%nV*nk);      call rget(c_loc(vc), at%vc, at%nU*nk)
+    call rget(c_loc(mfx), at%mfx, at%nFX*nk);   call rget(c_loc(mfy), at%mfy, at%nFY*nk)
+    call rget(c_loc(cx), at%cx, at%nCX*nk);     call rget(c_loc(cy), at%cy, at%nCY*nk)
+    if (flagstruct%d_con > 1.d-5) call rget(c_loc(heat_source), at%heat_source, at%nA*nk)
     if (thermostruct%use_cond) call get(c_loc(qc_c), at%q_con, at%nA*nk)
     call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
     if (thermostruct%use_cond) q_con(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz) = qc_c
@@ -383,6 +388,19 @@ contains
       type(c_ptr), intent(in) :: d, h
       integer(c_size_t), intent(in) :: n
       call fv3_check(fv3_memcpy_d2h(at%ctx, h, d, n * 8_c_size_t), 'fv3_memcpy_d2h')
+    end subroutine
+
+    ! the caller's own arrays go through the registry: copied every time (eager) or only when the other copy is not current (lazy)
+    subroutine rput(d, h, n)
+      type(c_ptr), intent(in) :: d, h
+      integer(c_size_t), intent(in) :: n
+      call fv3_check(fv3_registry_put(at%ctx, d, h, n * 8_c_size_t), 'fv3_registry_put')
+    end subroutine
+
+    subroutine rget(h, d, n)
+      type(c_ptr), intent(in) :: d, h
+      integer(c_size_t), intent(in) :: n
+      call fv3_check(fv3_registry_get(at%ctx, h, d, n * 8_c_size_t), 'fv3_registry_get')
     end subroutine
 
     !> grid_type < 3: a tile of the cubed sphere, as fv_dynamics below does it -- every call binds (first time) and uploads its tile,
@@ -942,6 +960,31 @@ contains
     fl%convert_ke = flagstruct%convert_ke
     fl%fast_tau_w_sec = flagstruct%fast_tau_w_sec; fl%RF_fast = flagstruct%RF_fast; fl%tau = flagstruct%tau
     fl%rf_cutoff = flagstruct%rf_cutoff
+  end subroutine
+
+  !> lazy = .true.: dyn_core (doubly periodic domain) copies a caller's array to the device only when the caller declared a write to it
+  !> (fv3_host_touched) or it has never been seen, and leaves the results on the device until the caller asks (fv3_host_fetch)
+  subroutine fv3_dyn_core_registry(lazy)
+    logical, intent(in) :: lazy
+    registry_lazy = lazy
+  end subroutine
+
+  !> the caller wrote this host array since the last dyn_core call (c_loc of the array; c_null_ptr: every array)
+  subroutine fv3_host_touched(host)
+    type(c_ptr), intent(in) :: host
+    if (bound) call fv3_check(fv3_registry_host_touched(at%ctx, host), 'fv3_registry_host_touched')
+  end subroutine
+
+  !> bring this host array up to date before the caller reads it (c_null_ptr: every array whose host copy is stale)
+  subroutine fv3_host_fetch(host)
+    type(c_ptr), intent(in) :: host
+    if (bound) call fv3_check(fv3_registry_fetch(at%ctx, host), 'fv3_registry_fetch')
+  end subroutine
+
+  subroutine fv3_dyn_core_registry_stats(out4)
+    integer(c_long_long), intent(out) :: out4(4)   ! h2d copies, h2d skipped, d2h copies, d2h deferred
+    out4 = 0
+    if (bound) call fv3_check(fv3_registry_stats(at%ctx, out4), 'fv3_registry_stats')
   end subroutine
 
   !> release the context dyn_core bound at its first call

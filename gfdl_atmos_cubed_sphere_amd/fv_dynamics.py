@@ -27,7 +27,7 @@ class FvDynamics:
                  px: int = 1, py: int = 1, rank: int = 0, world: int = 1, dist=None, tau: float = 0.0,
                  rf_cutoff: float = 30.0e2, c2l_ord: int = 4, moist: dict | None = None, fill: bool = False, halo=None,
                  consv_te: float = 0.0, moist_phys: bool = False, radius: float = 6.3712e6, fill2d: tuple = (),
-                 remap_te: bool = False):
+                 remap_te: bool = False, consv_am: dict | None = None):
         ak, bk = np.asarray(ak, dtype=np.float64), np.asarray(bk, dtype=np.float64)
         dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5          # dyn_core.F90:241-244
         self.ctx, self.fl, self.nq, self.k_split, self.q_split, self.dist = ctx, flags, nq, k_split, q_split, dist
@@ -44,6 +44,10 @@ class FvDynamics:
         # the last remap returns as heat (> consv_min), or a prescribed flux in W/m**2 (< -consv_min)
         self.consv_te, self.moist_phys, self.radius = consv_te, moist_phys, radius
         self.e_flux = 0.0
+        # flagstruct%consv_am (fv_dynamics.F90:358-361, :747-800): dict(coslat = cos(agrid(:,:,2)) (A), l2c_u (U), l2c_v (V), zxg (compute
+        # domain; idiag%zxg, the mountain-torque term), omega) -- host arrays of the grid (lists of six on the sphere), uploaded on first use
+        self.consv_am = consv_am
+        self.last_u00 = 0.0
         # moist thermodynamics (flags.use_cond / flags.moist_kappa): nwat and the water-species indices for moist_cv,
         # cv_vap, c_liq, c_ice (lib.Context.set_moist)
         self.moist = None
@@ -82,6 +86,8 @@ class FvDynamics:
             self.total_energy_before()
         conv = lambda mode: ctx.pt_to_theta_v(mode, zvir, fl.akap, fl.rdgas, fl.grav, d["pt"], d["delp"],
                                               None if fl.hydrostatic else d["delz"], qv, d["pkz"])
+        if self.consv_am:                                                  # :358-361: teq, ps2 of the state the step starts from
+            self._aam("teq", "ps2")
         if self.tau > 0.0 and not self.fl.rf_fast:                         # :362-376 (RF_fast: Ray_fast inside dyn_core instead) (grid_type = 4: Rayleigh_Friction)
             if not fl.hydrostatic:
                 conv(-1)                                                   # pkz from the T, delz before the friction (:323-326)
@@ -90,7 +96,40 @@ class FvDynamics:
         else:
             conv(int(fl.hydrostatic))
         self.step(bdt, last_cycle_is_last_step=True)
+        if self.consv_am:                                                  # :747-800
+            self._consv_am(bdt)
         self.cubed_to_latlon()                                             # :911
+
+    # -- consv_am -------------------------------------------------------------------------------------------------
+    def _aam(self, aam_name: str, ps_name: str):
+        """compute_aam (fv_dynamics.F90:1266-1314): cubed_to_latlon(ord 2), then aam, m_fac, ps of every column"""
+        d, ctx, fl, ca = self.dc.d, self.ctx, self.fl, self.consv_am
+        if "coslat" not in d:
+            d["coslat"], d["l2c_u"], d["l2c_v"] = ctx.from_host(ca["coslat"]), ctx.from_host(ca["l2c_u"]), ctx.from_host(ca["l2c_v"])
+            d["m_fac"] = ctx.zeros("CC")
+        for n, kind in ((aam_name, "CC"), (ps_name, "A")):
+            if n not in d:
+                d[n] = ctx.zeros(kind)
+        ctx.c2l(2, d["u"], d["v"], d["ua"], d["va"])                       # :1287 (mode 1, c2l_ord 2: no halo update)
+        ctx.compute_aam(self.radius, ca.get("omega", 7.292e-5), 1.0 / fl.grav, fl.ptop, d["coslat"], d["ua"], d["delp"], d[aam_name],
+                        d["m_fac"], d[ps_name])
+
+    def _consv_am(self, bdt: float):
+        from .global_sum import g_sum
+        d, ctx = self.dc.d, self.ctx
+        self._aam("aam2", "ps")
+        aslist = lambda x: x if isinstance(x, list) else [x]
+        areas = self._areas()
+        b = ctx.bd
+        cc = lambda a: np.asarray(a)[b.ng:b.ng + b.nx, b.ng:b.ng + b.ny]
+        te, teq, ps2, ps = (aslist(d[n].download()) for n in ("aam2", "teq", "ps2", "ps"))
+        zxg = aslist(self.consv_am["zxg"])
+        dt2 = 0.5 * bdt
+        te_2d = [t - q + dt2 * (cc(p2) + cc(p1)) * np.asarray(z) for t, q, p2, p1, z in zip(te, teq, ps2, ps, zxg)]     # :761-767
+        amdt = g_sum(te_2d, areas, self.dist)                              # :771
+        u00 = -self.radius * amdt / g_sum(aslist(d["m_fac"].download()), areas, self.dist)    # :772
+        self.last_u00 = u00
+        ctx.consv_am_apply(u00, d["l2c_u"], d["l2c_v"], d["u"], d["v"])    # :784-798
 
     # -- consv_te -------------------------------------------------------------------------------------------------
     def total_energy_before(self):

@@ -31,10 +31,10 @@ _B = ["rarea_c", "fC", "cosa", "sina"]
 
 # every symbol include/fv3_mi355x.h declares (tests check the built library exports all of them)
 EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3_group_create", "fv3_group_flush", "fv3_group_stats", "fv3_group_destroy", "fv3_grid_upload", "fv3_grid_upload_cubed", "fv3_gather_create", "fv3_gather_run", "fv3_gather_destroy", "fv3_grid_geom", "fv3_malloc",
-           "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_fv_tp_2d", "fv3_c_sw",
+           "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_registry_mode", "fv3_registry_put", "fv3_registry_get", "fv3_registry_host_touched", "fv3_registry_fetch", "fv3_registry_stats", "fv3_fv_tp_2d", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_periodic_group", "fv3_halo_pack",
            "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_compute_total_energy", "fv3_energy_fixer_sums", "fv3_remap_finish", "fv3_ordered_sum", "fv3_adv_pe", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_one_grad_p_nh", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max", "fv3_cube_table", "fv3_cube_halo_start", "fv3_cube_halo_complete",
-           "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_set_fast", "fv3_set_fast_tau_w", "fv3_set_ray_fast", "fv3_ray_fast", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
+           "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_set_fast", "fv3_set_fast_tau_w", "fv3_set_ray_fast", "fv3_ray_fast", "fv3_compute_aam", "fv3_consv_am_apply", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_split_p_grad", "fv3_grad1_p_update", "fv3_d_sw_inline_q", "fv3_flux_accum", "fv3_fill2d_mass", "fv3_fill2d_apply", "fv3_set_remap_te", "fv3_profile_report_timers", "fv3_prt_maxmin", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
 
@@ -672,6 +672,15 @@ class Context:
             C.c_double(rg), C.c_double(ptop), pm.ctypes.data_as(_dp), rf.ctypes.data_as(_dp), ua.p, va.p, pt.p, u.p, v.p,
             w.p if w is not None else None, u00.p if u00 is not None else None, v00.p if v00 is not None else None),
             "fv3_rayleigh_super")
+
+    def compute_aam(self, radius, omega, agrav, ptop, coslat, ua, delp, aam, m_fac, ps):
+        """compute_aam (fv_dynamics.F90:1266-1314) after c2l(2, ...): aam, m_fac (CC), ps (A)"""
+        self.lib.check(self.lib.dll.fv3_compute_aam(self.h, C.c_double(radius), C.c_double(omega), C.c_double(agrav), C.c_double(ptop),
+                                                    coslat.p, ua.p, delp.p, aam.p, m_fac.p, ps.p), "fv3_compute_aam")
+
+    def consv_am_apply(self, u00, l2c_u, l2c_v, u, v):
+        """fv_dynamics.F90:784-798: u += u00 l2c_u, v += u00 l2c_v"""
+        self.lib.check(self.lib.dll.fv3_consv_am_apply(self.h, C.c_double(u00), l2c_u.p, l2c_v.p, u.p, v.p), "fv3_consv_am_apply")
 
     def adv_pe(self, ptop, ua, va, delp_before, omga):
         """adv_pe (dyn_core.F90:1195, :1529-1632): the advective term of omega on a cubed-sphere face"""

@@ -120,6 +120,22 @@ int fv3_memset(fv3_ctx *ctx, void *dst, int value, size_t bytes);
 int fv3_memcpy_d2d(fv3_ctx *ctx, void *dst, const void *src, size_t bytes);
 int fv3_sync(fv3_ctx *ctx);
 
+/* Host-address field registry (SURVEY 8(b) "device-resident registry").  The reference's entry points (dyn_core, fv_dynamics) are handed
+ * HOST arrays the caller owns (fv_arrays.F90:1417), so a wrapper with their argument list copies every array in and out on every call
+ * unless it knows which copy is current.  fv3_registry_put / _get are the wrapper's h2d / d2h through an entry keyed by the host address:
+ *   eager (default): both copy every time -- the caller may have touched anything between the calls;
+ *   lazy (fv3_registry_mode(ctx, 1)): put copies only when the device mirror is not current (first use, or the caller declared a write
+ *   with fv3_registry_host_touched(ctx, host); host = NULL: every array), get only marks the host copy stale; the caller brings an array
+ *   it wants to read with fv3_registry_fetch(ctx, host) (NULL: every stale array).
+ * fv3_registry_stats: {h2d copies, h2d skipped, d2h copies, d2h deferred}.  The Fortran wrappers go through it
+ * (fortran/fv3_dyn_core_mod.F90: fv3_dyn_core_registry, fv3_host_touched, fv3_host_fetch). */
+int fv3_registry_mode(fv3_ctx *ctx, int lazy);
+int fv3_registry_put(fv3_ctx *ctx, void *dev, const void *host, size_t bytes);
+int fv3_registry_get(fv3_ctx *ctx, void *host, const void *dev, size_t bytes);
+int fv3_registry_host_touched(fv3_ctx *ctx, const void *host);
+int fv3_registry_fetch(fv3_ctx *ctx, void *host);
+int fv3_registry_stats(fv3_ctx *ctx, long long *out4);
+
 /* fv_tp_2d -- model/tp_core.F90:85-87 (called from sw_core.F90:919,983,993,1014,1498,
  * nh_utils.F90:279,289, fv_tracer2d.F90:504,509).  nk slabs.  q: A; crx,xfx: CX; cry,yfx: CY;
  * ra_x: (is:ie, jsd:jed); ra_y: (isd:ied, js:je); fx,mfx: FX; fy,mfy: FY; mass: A.
@@ -430,6 +446,16 @@ int fv3_apply_heat_source(fv3_ctx *ctx, int n_con, int hydrostatic, double bdt, 
  *   averaged to their points (:1211-1260).  pm, rf: HOST arrays of length kmax (layer-mean pressure and the damping
  *   profile of :1169-1182, which the caller evaluates once); u2f: A x kmax, read only; cp = cp_air, rg = rdgas. */
 int fv3_c2l(fv3_ctx *ctx, int c2l_ord, const double *u, const double *v, double *ua, double *va);
+/* flagstruct%consv_am -- model/fv_dynamics.F90:358-361 (before the k_split loop) and :747-800 (after it).
+ * fv3_compute_aam = compute_aam (:1266-1314) behind the caller's fv3_c2l(ctx, 2, u, v, ua, va) (:1287): per column of the compute domain
+ *   aam = sum (r^2 omega + r ua) dm, m_fac = sum dm r^2 (dm = delp * agrav, r = radius * coslat) and ps = ptop + sum delp.
+ *   coslat: A (2-D) = cos(agrid(:,:,2)) (the caller's, as gridstruct%agrid is); ua, delp: A x npz; aam, m_fac: CC; ps: A (2-D).
+ *   The caller forms te_2d - teq + dt2 (ps2 + ps) zxg, the two reproducible g_sums and u00 (:761-776) on these small 2-D fields.
+ * fv3_consv_am_apply (:784-798): u += u00 l2c_u on (is:ie, js:je+1), v += u00 l2c_v on (is:ie+1, js:je), every level;
+ *   l2c_u: U (2-D), l2c_v: V (2-D) = gridstruct%l2c_u / l2c_v (fv_grid_utils.F90:402-424) on the device. */
+int fv3_compute_aam(fv3_ctx *ctx, double radius, double omega, double agrav, double ptop, const double *coslat, const double *ua,
+                    const double *delp, double *aam, double *m_fac, double *ps);
+int fv3_consv_am_apply(fv3_ctx *ctx, double u00, const double *l2c_u, const double *l2c_v, double *u, double *v);
 int fv3_rayleigh_u2f(fv3_ctx *ctx, int kmax, int hydrostatic, const double *u, const double *v, const double *w,
                      double *ua, double *va, double *u2f);
 int fv3_rayleigh_apply(fv3_ctx *ctx, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,

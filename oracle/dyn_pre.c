@@ -258,3 +258,40 @@ int fvo_ray_fast(const fvo_grid *g, int npz, int kmax, int k_rf, const double *r
   }
   return FVO_OK;
 }
+
+/* compute_aam, fv_dynamics.F90:1266-1314, after the caller's cubed_to_latlon(ord 2) (:1287): the mass-integrated atmospheric angular
+ * momentum of every column, m_fac = sum dm r^2 and ps.  coslat = cos(agrid(:,:,2)): A (2-D); ua, delp: A x npz; aam, m_fac: CC; ps: A. */
+int fvo_compute_aam(const fvo_grid *g, int npz, double radius, double omega, double agrav, double ptop, const double *coslat,
+                    const double *ua, const double *delp, double *aam, double *m_fac, double *ps) {
+  BOUNDS(g);
+  int i, j, k;
+  for (j = js; j <= je; j++)
+    for (i = is; i <= ie; i++) {
+      const double r1 = radius * coslat[(size_t)(j - jsd) * nid + (i - isd)], r2 = r1 * r1;
+      double a = 0., m = 0., p = ptop;
+      for (k = 1; k <= npz; k++) {
+        double dm = delp[A3(i, j, k)];
+        p = p + dm;
+        dm = dm * agrav;
+        a = a + (r2 * omega + r1 * ua[A3(i, j, k)]) * dm;
+        m = m + dm * r2;
+      }
+      aam[(size_t)(j - js) * nx + (i - is)] = a;
+      m_fac[(size_t)(j - js) * nx + (i - is)] = m;
+      ps[(size_t)(j - jsd) * nid + (i - isd)] = p;
+    }
+  return FVO_OK;
+}
+
+/* consv_am, fv_dynamics.F90:784-798: u += u00 l2c_u on (is:ie, js:je+1), v += u00 l2c_v on (is:ie+1, js:je); l2c_u: U (2-D), l2c_v: V (2-D) */
+int fvo_consv_am_apply(const fvo_grid *g, int npz, double u00, const double *l2c_u, const double *l2c_v, double *u, double *v) {
+  BOUNDS(g);
+  int i, j, k;
+  for (k = 1; k <= npz; k++) {
+    for (j = js; j <= je + 1; j++)
+      for (i = is; i <= ie; i++) u[U3(i, j, k)] = u[U3(i, j, k)] + u00 * l2c_u[(size_t)(j - jsd) * nid + (i - isd)];
+    for (j = js; j <= je; j++)
+      for (i = is; i <= ie + 1; i++) v[V3(i, j, k)] = v[V3(i, j, k)] + u00 * l2c_v[(size_t)(j - jsd) * (nid + 1) + (i - isd)];
+  }
+  return FVO_OK;
+}

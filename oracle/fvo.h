@@ -288,6 +288,10 @@ int fvo_rayleigh_apply(const fvo_grid *g, int kmax, int conserve, int hydrostati
                        double *w);
 /* adv_pe, dyn_core.F90:1529-1632 (cubed sphere): om += 0.5*rarea*(V3 . grad pe); pem from delp_before on (is-1:ie+1, js-1:je+1) */
 int fvo_adv_pe(const fvo_grid *g, int km, double ptop, const double *ua, const double *va, const double *delp_before, double *om);
+/* consv_am: compute_aam (fv_dynamics.F90:1266-1314) and the wind correction (:784-798) */
+int fvo_compute_aam(const fvo_grid *g, int npz, double radius, double omega, double agrav, double ptop, const double *coslat,
+                    const double *ua, const double *delp, double *aam, double *m_fac, double *ps);
+int fvo_consv_am_apply(const fvo_grid *g, int npz, double u00, const double *l2c_u, const double *l2c_v, double *u, double *v);
 /* Ray_fast (dyn_core.F90:2485-2601) and fast_tau_w_sec (nh_utils.F90:356-367, :1363-1371, :1498-1506) */
 int fvo_ray_fast_profile(int npz, int ks, double dt, double tau, double rf_cutoff, double ptop, const double *pfull, const double *dp,
                          double *rf, int *k_rf, double *dm_out);

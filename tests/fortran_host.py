@@ -142,7 +142,7 @@ def build_refsig(workdir, libdir=CSRC, libname="fv3_mi355x"):
 
 
 def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2, bdt=6.0, hydrostatic=False, d_con=0.0, beta=0.0, moist=False,
-                         layout=(1, 1), fast_tau_w_sec=0.0, rf_fast_tau=0.0):
+                         layout=(1, 1), fast_tau_w_sec=0.0, rf_fast_tau=0.0, registry=False):
     """dyn_core called with the reference's argument list on host arrays (fv3_dyn_core_mod, driver fv3_solo_refsig) against the
     Python host's DynCore.run on the same state: u, v, w, delp, pt, delz, the accumulated mass fluxes / Courant numbers (and pkz
     when the heating or the hydrostatic branch writes it) bit-identical"""
@@ -207,6 +207,8 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
         env["FV3_REFSIG_RF_FAST"] = repr(float(rf_fast_tau))
     if damp:
         env["FV3_REFSIG_RF_CUTOFF"] = repr(rf_cut)
+    if registry:   # the lazy host-address registry: arrays the driver never writes are copied in once, results fetched once at the end
+        env["FV3_REFSIG_REGISTRY"] = "1"
     os.environ.update(env)
     try:
         res, out = _run_refsig(lib, exe, fin, fout, "", layout, bd, npz, spec)
@@ -214,6 +216,14 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
         for k in env:
             os.environ.pop(k, None)
     _compare_blocks(res, ref, bd, "reference-signature dyn_core", tol=1e-13 if damp else None)
+    import re
+    m = re.search(r"registry \(h2d copies, h2d skipped, d2h copies, d2h deferred\) (\d+) (\d+) (\d+) (\d+)", out)
+    assert m, out[-500:]
+    h2d, h2d_skip, d2h, d2h_def = (int(x) for x in m.groups())
+    if registry:
+        assert h2d == 12 and h2d_skip == 12 * (nsteps - 1) and d2h_def > 0 and d2h == d2h_def // nsteps, (h2d, h2d_skip, d2h, d2h_def)
+    else:
+        assert h2d == 12 * nsteps and h2d_skip == 0 and d2h_def == 0 and d2h > 0, (h2d, h2d_skip, d2h, d2h_def)
     if damp:   # the damping is in the run at all
         ctx = Context(g, npz, lib=lib)
         try:

@@ -222,6 +222,17 @@ def riem_solver3(g, km, dt, cn, zs, w, delz, pt, delp, zh, pe, ppe, pk3, pk, pel
     assert rc == 0, rc
 
 
+def compute_aam(g, npz, radius, omega, agrav, ptop, coslat, ua, delp, aam, m_fac, ps):
+    gs = make_grid(g)
+    assert lib().fvo_compute_aam(C.byref(gs), C.c_int(npz), _d(radius), _d(omega), _d(agrav), _d(ptop), p(coslat), p(ua), p(delp), p(aam),
+                                 p(m_fac), p(ps)) == 0
+
+
+def consv_am_apply(g, npz, u00, l2c_u, l2c_v, u, v):
+    gs = make_grid(g)
+    assert lib().fvo_consv_am_apply(C.byref(gs), C.c_int(npz), _d(u00), p(l2c_u), p(l2c_v), p(u), p(v)) == 0
+
+
 def fast_tau_w_rff(km, dt, fast_tau_w_sec, rf_cutoff, ptop, pfull):
     """rff(1:k_rf) of nh_utils.F90:356-367 (dt: Riem_Solver_c's, half the acoustic step)"""
     pfull = np.ascontiguousarray(pfull, dtype=np.float64)

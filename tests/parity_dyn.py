@@ -298,7 +298,7 @@ def check_fv_cycle_moist(lib, nx=24, ny=16, npz=10, k_split=2, n_split=2, bdt=8.
     return out
 
 
-def check_fv_cycle_from_temperature(lib, nx=24, ny=16, npz=10, k_split=2, n_split=2, bdt=8.0, tau=0.0):
+def check_fv_cycle_from_temperature(lib, nx=24, ny=16, npz=10, k_split=2, n_split=2, bdt=8.0, tau=0.0, consv_am=False):
     """A whole adiabatic fv_dynamics call: T -> theta_v (fv_dynamics.F90:284-399), k_split loop, last remap back to T.
     Oracle side: the same conversion in numpy, then the oracle-orchestrated loop with last_step on the final cycle."""
     from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
@@ -346,15 +346,43 @@ def check_fv_cycle_from_temperature(lib, nx=24, ny=16, npz=10, k_split=2, n_spli
             for k in range(npz):
                 periodic_fill(bd, a[:, :, k], kind)
         ost = dict(st, u=o_u, v=o_v, w=o_w, pt=th3, delz=o_dz)
+    ca = None
+    if consv_am:   # flagstruct%consv_am (fv_dynamics.F90:358-361, :747-800) with a made-up grid: latitudes, l2c_u / l2c_v and zxg of no sphere
+        rng = np.random.default_rng(31)
+        ca = dict(coslat=np.asfortranarray(rng.uniform(0.2, 1.0, bd.shape("A"))), l2c_u=np.asfortranarray(rng.uniform(-1, 1, bd.shape("U"))),
+                  l2c_v=np.asfortranarray(rng.uniform(-1, 1, bd.shape("V"))), zxg=rng.uniform(-1e-3, 1e-3, (nx, ny)), omega=7.292e-5)
+        radius = 6.3712e6
+        o_ua, o_va = bd.zeros("A", npz), bd.zeros("A", npz)
+        O.c2l(g, npz, 2, st["u"], st["v"], o_ua, o_va)
+        teq, mf, ps2 = bd.zeros("CC"), bd.zeros("CC"), bd.zeros("A")
+        O.compute_aam(g, npz, radius, ca["omega"], 1.0 / fl.grav, N.PTOP, ca["coslat"], o_ua, st["delp"], teq, mf, ps2)
     ctx = Context(g, npz, lib=lib)
     try:
-        fv = FvDynamics(ctx, fl, ak, bk, nq=0, k_split=k_split, tau=tau, rf_cutoff=rf_cutoff)
+        fv = FvDynamics(ctx, fl, ak, bk, nq=0, k_split=k_split, tau=tau, rf_cutoff=rf_cutoff, consv_am=ca)
         ref = oracle_fv_step(g, npz, fl, dp_ref, ost, ak, bk, None, bdt, k_split, fv.remap_par, last_step=True)
         fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], T, st["delz"], st["phis"])
         fv.step_from_temperature(bdt)
         d = fv.dc.d
         emu = "hostemu" in lib.path
         out = {}
+        if consv_am:
+            from gfdl_atmos_cubed_sphere_amd.global_sum import g_sum
+            O.c2l(g, npz, 2, ref["u"], ref["v"], o_ua, o_va)
+            te, ps1 = bd.zeros("CC"), bd.zeros("A")
+            O.compute_aam(g, npz, radius, ca["omega"], 1.0 / fl.grav, N.PTOP, ca["coslat"], o_ua, ref["delp"], te, mf, ps1)
+            cc = lambda a: a[ng:ng + nx, ng:ng + ny]
+            area = [np.asarray(g.m["area"])[ng:ng + nx, ng:ng + ny]]
+            te_2d = te - teq + 0.5 * bdt * (cc(ps2) + cc(ps1)) * ca["zxg"]
+            u00 = -radius * g_sum([te_2d], area) / g_sum([mf], area)
+            assert abs(u00) > 1e-8
+            O.consv_am_apply(g, npz, u00, ca["l2c_u"], ca["l2c_v"], ref["u"], ref["v"])
+            # u00 is a difference of column integrals ~ r^2 omega dm: what the two sides' fields differ by (<= 1e-13) is amplified in it
+            assert abs(fv.last_u00 - u00) <= 1e-7 * abs(u00), (fv.last_u00, u00)
+            for n, kind, rr in (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je))):
+                out[n] = P.assert_close(n, bd.view(d[n].download(), kind, *rr), bd.view(ref[n], kind, *rr), 1e-11)
+            out["u00_rel"] = abs(fv.last_u00 - u00) / abs(u00)
+            for n, refa in (("aam2", te), ("m_fac", mf)):
+                out[n] = P.assert_close(n, d[n].download(), refa, 1e-12)
         # cubed_to_latlon at the end (fv_dynamics.F90:911): c2l_ord4 of the final winds after their halo update
         from gfdl_atmos_cubed_sphere_amd.layout import periodic_fill as pfill
         fu, fvv = d["u"].download(), d["v"].download()

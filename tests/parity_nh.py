@@ -578,6 +578,33 @@ def check_ray_fast(lib, nx=37, ny=19, km=12, hydrostatic=False, tau=0.5, rf_cuto
     return kmax, k_rf
 
 
+def check_consv_am_kernels(lib, nx=37, ny=19, km=9):
+    """compute_aam (fv_dynamics.F90:1266-1314) and the consv_am wind correction (:784-798): the reference's statements, bit for bit"""
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    rng = np.random.default_rng(29)
+    coslat = np.asfortranarray(rng.uniform(0.05, 1.0, bd.shape("A")))
+    ua = np.asfortranarray(rng.uniform(-60, 60, bd.shape("A", km)))
+    delp = np.asfortranarray(rng.uniform(300, 1500, bd.shape("A", km)))
+    u = np.asfortranarray(rng.uniform(-30, 30, bd.shape("U", km)))
+    v = np.asfortranarray(rng.uniform(-30, 30, bd.shape("V", km)))
+    lu, lv = np.asfortranarray(rng.uniform(-1, 1, bd.shape("U"))), np.asfortranarray(rng.uniform(-1, 1, bd.shape("V")))
+    aam, mf, ps = bd.zeros("CC"), bd.zeros("CC"), bd.zeros("A")
+    O.compute_aam(g, km, 6.3712e6, 7.292e-5, 1.0 / GRAV, PTOP, coslat, ua, delp, aam, mf, ps)
+    ou, ov = u.copy(order="F"), v.copy(order="F")
+    O.consv_am_apply(g, km, 0.37, lu, lv, ou, ov)
+    ctx = Context(g, km, lib=lib)
+    try:
+        d_aam, d_mf, d_ps, d_u, d_v = ctx.zeros("CC"), ctx.zeros("CC"), ctx.zeros("A"), ctx.from_host(u), ctx.from_host(v)
+        ctx.compute_aam(6.3712e6, 7.292e-5, 1.0 / GRAV, PTOP, ctx.from_host(coslat), ctx.from_host(ua), ctx.from_host(delp), d_aam, d_mf, d_ps)
+        ctx.consv_am_apply(0.37, ctx.from_host(lu), ctx.from_host(lv), d_u, d_v)
+        assert np.array_equal(d_aam.download(), aam) and np.array_equal(d_mf.download(), mf) and np.array_equal(d_ps.download(), ps)
+        assert np.array_equal(d_u.download(), ou) and np.array_equal(d_v.download(), ov)
+        assert np.all(aam != 0.0) and P.rel_rms(ou, u) > 1e-4
+    finally:
+        ctx.close()
+
+
 def np_moist_cv(q, mp, cv_air):
     """moist_cv (fv_thermodynamics.F90:250-325) on whole arrays; q: (.., nq); returns cvm, q_con"""
     Q = lambda n: q[..., n - 1] if n > 0 else 0.0

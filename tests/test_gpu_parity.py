@@ -596,6 +596,13 @@ def test_riem_solvers_fast_tau_w_sec(prod, a_imp):
 
 
 @pytest.mark.gpu
+def test_consv_am(prod):
+    """flagstruct%consv_am: compute_aam before and after the k_split loop, the reproducible sums, u00 and the wind correction
+    (fv_dynamics.F90:358-361, :747-800, :1266-1314)"""
+    N.check_consv_am_kernels(prod)
+    D.check_fv_cycle_from_temperature(prod, consv_am=True)
+
+
 def test_substeps_with_fast_tau_w_sec_and_rf_fast(prod):
     """the acoustic substeps with the Rayleigh damping of w inside the solvers and Ray_fast at their end (dyn_core.F90:536, :940, :1057-1060)"""
     npz = 10
@@ -680,6 +687,8 @@ def test_fortran_dyn_core_with_the_reference_argument_list(prod, tmp_path):
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=12, d_con=1.0)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=12, hydrostatic=True, d_con=1.0)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=8, beta=0.4)
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=8, nsteps=3, registry=True)    # the lazy host-address registry
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=8, hydrostatic=True, d_con=1.0, registry=True)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=10, fast_tau_w_sec=40.0, rf_fast_tau=0.002)   # fast_tau_w_sec, RF_fast
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=10, hydrostatic=True, rf_fast_tau=0.002)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=8, hydrostatic=True, beta=0.4)

@@ -517,6 +517,13 @@ def test_riem_solvers_fast_tau_w_sec(emu, a_imp):
         N.check_riem_solver_c(emu, tau_w=25.0, use_cond=True, nx=40, ny=9, km=19)
 
 
+def test_consv_am(emu):
+    """flagstruct%consv_am: compute_aam before and after the k_split loop, the reproducible sums, u00 and the wind correction
+    (fv_dynamics.F90:358-361, :747-800, :1266-1314)"""
+    N.check_consv_am_kernels(emu)
+    D.check_fv_cycle_from_temperature(emu, consv_am=True)
+
+
 def test_substeps_with_fast_tau_w_sec_and_rf_fast(emu):
     """the acoustic substeps with the Rayleigh damping of w inside the solvers and Ray_fast at their end (dyn_core.F90:536, :940, :1057-1060)"""
     npz = 10
@@ -577,6 +584,8 @@ def test_fortran_dyn_core_with_the_reference_argument_list(emu, tmp_path):
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=12, d_con=1.0)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=12, hydrostatic=True, d_con=1.0)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, beta=0.4)
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, nsteps=3, registry=True)    # the lazy host-address registry
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, hydrostatic=True, d_con=1.0, registry=True)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=10, fast_tau_w_sec=40.0, rf_fast_tau=0.002)   # fast_tau_w_sec, RF_fast
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=10, hydrostatic=True, rf_fast_tau=0.002)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, hydrostatic=True, beta=0.4)

@@ -19,7 +19,7 @@ rng = np.random.default_rng(3)
 def fld(kind, nlev, lo, hi):
     return c0.from_host(np.asfortranarray(rng.uniform(lo, hi, bd.shape(kind, nlev))))
 d = dict(u=fld("U", npz, -20, 20), v=fld("V", npz, -20, 20), pp=fld("A", npz + 1, -50, 50), gz=fld("A", npz + 1, 100, 3e4),
-         delp=fld("A", npz, 500, 1500), pk=fld("A", npz + 1, 10, 50))
+         delp=fld("A", npz, 500, 1500), pk=fld("A", npz + 1, 10, 50), uc=fld("V", npz, -20, 20), vc=fld("U", npz, -20, 20))
 tot = [{} for _ in ctxs]
 for r in range(rounds + 1):
     for n, ctx in enumerate(ctxs):
@@ -27,6 +27,7 @@ for r in range(rounds + 1):
             ctx.profile(True)
         for _ in range(10):
             ctx.nh_p_grad(d["u"], d["v"], d["pp"], d["gz"], d["delp"], d["pk"], 22.5, 0.0, gz_scale=9.80665)
+            ctx.p_grad_c(11.25, d["delp"], d["pp"], d["gz"], d["uc"], d["vc"], False)
         ctx.sync()
         if r > 0:
             for k, (cnt, ms) in ctx.profile_report().items():
