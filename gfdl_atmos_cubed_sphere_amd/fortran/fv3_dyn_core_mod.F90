@@ -233,13 +233,13 @@ module fv3_dyn_core_mod
   logical, save :: boundf = .false.
   ! the cubed sphere (grid_type < 3): one context per tile this process holds (fv3_sphere_mod); the host arrays of every tile's call
   type tile_arrays
-    type(c_ptr) :: u, v, w, delz, pt, delp, q, ps, pe, pk, peln, pkz, omga, ua, va, uc, vc, mfx, mfy, cx, cy
+    type(c_ptr) :: u, v, w, delz, pt, delp, q, ps, pe, pk, peln, pkz, omga, ua, va, uc, vc, mfx, mfy, cx, cy, q_con = c_null_ptr
   end type
   type(fv3_sphere), save :: sps
   type(tile_arrays), save :: tps(6)
   logical, save :: bound_s(6) = .false., comm_s = .false.
   type dc_tile_arrays
-    type(c_ptr) :: u, v, w, delz, pt, delp, ws, pe, pk, peln, pkz, omga, ua, va, uc, vc, mfx, mfy, cx, cy, heat_source
+    type(c_ptr) :: u, v, w, delz, pt, delp, ws, pe, pk, peln, pkz, omga, ua, va, uc, vc, mfx, mfy, cx, cy, heat_source, q_con = c_null_ptr
   end type
   type(fv3_sphere), save :: spd         ! dyn_core's own contexts (no tracers), as on the doubly periodic domain
   type(dc_tile_arrays), save :: tpd(6)
@@ -276,7 +276,7 @@ contains
     real(c_double), intent(inout), target :: omga(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
     real(c_double), intent(inout), target :: uc(bd%isd:bd%ied+1, bd%jsd:bd%jed, npz), vc(bd%isd:bd%ied, bd%jsd:bd%jed+1, npz)
     real(c_double), intent(inout), target, dimension(bd%isd:bd%ied, bd%jsd:bd%jed, npz) :: ua, va
-    real(c_double), intent(inout) :: q_con(bd%isd:, bd%jsd:, 1:)
+    real(c_double), intent(inout), target :: q_con(bd%isd:, bd%jsd:, 1:)
     real(c_double), intent(inout) :: te0_2d(bd%is:bd%ie, bd%js:bd%je)
     real(c_double), intent(inout), target :: mfx(bd%is:bd%ie+1, bd%js:bd%je, npz), mfy(bd%is:bd%ie, bd%js:bd%je+1, npz)
     real(c_double), intent(inout), target :: cx(bd%is:bd%ie+1, bd%jsd:bd%jed, npz), cy(bd%isd:bd%ied, bd%js:bd%je+1, npz)
@@ -409,7 +409,12 @@ contains
     subroutine dyn_core_sphere()
       type(fv3_flags) :: fl
       integer :: slot, nloc, sl
-      if (moist) error stop 'dyn_core (fv3_dyn_core_mod): use_cond / moist_kappa on the cubed sphere are not carried through this wrapper'
+      if (moist .and. hydrostatic) error stop 'dyn_core (fv3_dyn_core_mod): use_cond / moist_kappa are nonhydrostatic branches'
+      if (thermostruct%use_cond) then     ! q_con is written back by the call of the LAST tile: the model's own array, whole and contiguous
+        if (.not. is_contiguous(q_con) .or. size(q_con, 1) /= bd%ied - bd%isd + 1 .or. size(q_con, 2) /= bd%jed - bd%jsd + 1 .or. size(q_con, 3) /= npz) &
+          error stop 'dyn_core (fv3_dyn_core_mod): use_cond on the cubed sphere needs q_con(isd:ied, jsd:jed, npz), contiguous'
+      end if
+      if (thermostruct%moist_kappa .and. size(cappa, 3) < npz) error stop 'dyn_core (fv3_dyn_core_mod): moist_kappa needs cappa on npz levels'
       if (flagstruct%do_diss_est .or. flagstruct%beta < 0.d0) error stop 'dyn_core (fv3_dyn_core_mod): do_diss_est / beta < 0 are not built'
       if (ng /= 3 .or. bd%ng /= 3) error stop 'dyn_core (fv3_dyn_core_mod): ng = 3'
       if (fv3_domain_tile(domain) < 1 .or. fv3_domain_tile(domain) > 6) error stop 'dyn_core (fv3_dyn_core_mod): fv3_domain_tile(domain) must be 1 .. 6'
@@ -428,6 +433,7 @@ contains
         fl%ks = ks
         fl%n_split = n_split; fl%ptop = ptop; fl%grav = grav; fl%akap = akap; fl%cp_air = cp
         fl%hydrostatic = hydrostatic
+        fl%use_cond = thermostruct%use_cond; fl%moist_kappa = thermostruct%moist_kappa
         call bind_sphere_tile(spd, slot, fv3_domain_tile(domain), npx, npy, npz, 0, bd, gridstruct, flagstruct, fl, ak, bk)
         bound_d(slot) = .true.
       end if
@@ -446,8 +452,18 @@ contains
         call puts(a, a%pkz, c_loc(pkz), a%nCC*nk);   call puts(a, a%pk, c_loc(pk), a%nCC*nk1)
         call puts(a, a%pe, c_loc(pe), int(nx+2, c_size_t)*nk1*(ny+2)); call puts(a, a%peln, c_loc(peln), a%nCC*nk1)
         call puts(a, a%omga, c_loc(omga), a%nA*nk);  call puts(a, a%ua, c_loc(ua), a%nA*nk); call puts(a, a%va, c_loc(va), a%nA*nk)
+        ! thermostruct%use_cond / moist_kappa: q_con, cappa of the tile (fv_dynamics updates their halos right after, :464-465: the
+        ! cube-edge exchange in front of the substep loop does it here)
+        if (thermostruct%use_cond) call puts(a, a%q_con, c_loc(q_con), a%nA*nk)
+        if (thermostruct%moist_kappa) then
+          allocate(cp_c(bd%isd:bd%ied, bd%jsd:bd%jed, npz))
+          cp_c = cappa(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz)
+          call puts(a, a%cappa, c_loc(cp_c), a%nA*nk)
+        end if
         call fv3_check(fv3_sync(a%ctx), 'fv3_sync')
       end associate
+      tpd(slot)%q_con = c_null_ptr
+      if (thermostruct%use_cond) tpd(slot)%q_con = c_loc(q_con)
       tpd(slot)%u = c_loc(u); tpd(slot)%v = c_loc(v); tpd(slot)%pt = c_loc(pt); tpd(slot)%delp = c_loc(delp)
       tpd(slot)%w = c_null_ptr; tpd(slot)%delz = c_null_ptr
       if (.not. hydrostatic) then
@@ -467,6 +483,7 @@ contains
         end if
         comm_d = .true.
       end if
+      if (moist) call fv3_sphere_halo_moist(spd)              ! what fv_dynamics does in front of dyn_core (:464-465 / :487-488)
       call fv3_sphere_dyn_core(spd, bdt, end_step)
       do sl = 1, nloc
         associate (a => spd%f(sl), tp => tpd(sl))
@@ -484,6 +501,7 @@ contains
           call gets(a, tp%mfx, a%mfx, a%nFX*nk);   call gets(a, tp%mfy, a%mfy, a%nFY*nk)
           call gets(a, tp%cx, a%cx, a%nCX*nk);     call gets(a, tp%cy, a%cy, a%nCY*nk)
           if (flagstruct%d_con > 1.d-5) call gets(a, tp%heat_source, a%heat_source, a%nA*nk)
+          if (c_associated(tp%q_con)) call gets(a, tp%q_con, a%q_con, a%nA*nk)
           call fv3_check(fv3_sync(a%ctx), 'fv3_sync')
         end associate
       end do
@@ -584,7 +602,7 @@ contains
     real(c_double), intent(inout), target :: pe(bd%is-1:bd%ie+1, npz+1, bd%js-1:bd%je+1)
     real(c_double), intent(inout), target :: pk(bd%is:bd%ie, bd%js:bd%je, npz+1), peln(bd%is:bd%ie, npz+1, bd%js:bd%je)
     real(c_double), intent(inout), target :: pkz(bd%is:bd%ie, bd%js:bd%je, npz)
-    real(c_double), intent(inout) :: q_con(bd%isd:, bd%jsd:, 1:)
+    real(c_double), intent(inout), target :: q_con(bd%isd:, bd%jsd:, 1:)
     real(c_double), intent(inout), target :: phis(bd%isd:bd%ied, bd%jsd:bd%jed), omga(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
     real(c_double), intent(inout), target :: uc(bd%isd:bd%ied+1, bd%jsd:bd%jed, npz), vc(bd%isd:bd%ied, bd%jsd:bd%jed+1, npz)
     real(c_double), intent(inout), target, dimension(bd%isd:bd%ied, bd%jsd:bd%jed, npz) :: ua, va
@@ -607,8 +625,6 @@ contains
     if (neststruct%nested .or. gridstruct%nested .or. gridstruct%regional .or. gridstruct%bounded_domain) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): nested / regional domains are not built'
     if (gridstruct%grid_type < 3) then
-      if (thermostruct%use_cond .or. thermostruct%moist_kappa) &
-        error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond / moist_kappa on the cubed sphere are not carried through this wrapper'
       call fv_dynamics_sphere()
       return
     end if
@@ -722,6 +738,7 @@ contains
         fl%ks = ks
         fl%n_split = n_split; fl%q_split = q_split; fl%ptop = ptop; fl%akap = kappa; fl%cp_air = cp_air
         fl%hydrostatic = hydrostatic; fl%fill = fill; fl%r_vir = zvir
+        call moist_flags_of(flagstruct, thermostruct, fl)
         call bind_sphere_tile(sps, slot, fv3_domain_tile(domain), npx, npy, npz, nq_tot, bd, gridstruct, flagstruct, fl, ak, bk)
         bound_s(slot) = .true.
       end if
@@ -753,6 +770,12 @@ contains
       tps(slot)%peln = c_loc(peln); tps(slot)%pkz = c_loc(pkz); tps(slot)%omga = c_loc(omga)
       tps(slot)%ua = c_loc(ua); tps(slot)%va = c_loc(va); tps(slot)%uc = c_loc(uc); tps(slot)%vc = c_loc(vc)
       tps(slot)%mfx = c_loc(mfx); tps(slot)%mfy = c_loc(mfy); tps(slot)%cx = c_loc(cx); tps(slot)%cy = c_loc(cy)
+      tps(slot)%q_con = c_null_ptr
+      if (thermostruct%use_cond) then     ! q_con as moist_cv leaves it (fv_dynamics.F90:305-317 and the remaps) goes back to the model's array
+        if (.not. is_contiguous(q_con) .or. size(q_con, 1) /= nx + 6 .or. size(q_con, 2) /= ny + 6 .or. size(q_con, 3) /= npz) &
+          error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond on the cubed sphere needs q_con(isd:ied, jsd:jed, npz), contiguous'
+        tps(slot)%q_con = c_loc(q_con)
+      end if
       if (slot < nloc) return                        ! the step runs in the call of the last tile this process holds
 
       if (.not. comm_s) then
@@ -781,6 +804,7 @@ contains
           call gets(at, tp%uc, at%uc, at%nV*nk);      call gets(at, tp%vc, at%vc, at%nU*nk)
           call gets(at, tp%mfx, at%mfx, at%nFX*nk);   call gets(at, tp%mfy, at%mfy, at%nFY*nk)
           call gets(at, tp%cx, at%cx, at%nCX*nk);     call gets(at, tp%cy, at%cy, at%nCY*nk)
+          if (c_associated(tp%q_con)) call gets(at, tp%q_con, at%q_con, at%nA*nk)
           call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
         end associate
       end do
@@ -813,20 +837,7 @@ contains
       fl%ks = ks
       fl%n_split = n_split; fl%q_split = q_split; fl%ptop = ptop; fl%akap = kappa; fl%cp_air = cp_air
       fl%hydrostatic = hydrostatic; fl%fill = fill; fl%r_vir = zvir
-      ! thermostruct%use_cond / moist_kappa (the reference's defaults, fv_arrays.F90:1226-1227): the water species as fv_dynamics.F90:275-283
-      ! finds them -- get_tracer_index -- and the heat capacities of fv_thermodynamics' moist_cv (cv_vap = 3 rvgas, c_liq, c_ice)
-      fl%use_cond = thermostruct%use_cond; fl%moist_kappa = thermostruct%moist_kappa
-      if (fl%use_cond .or. fl%moist_kappa) then
-        fl%moist%nwat = int(flagstruct%nwat, c_int)
-        fl%moist%sphum = int(max(0, get_tracer_index(MODEL_ATMOS, 'sphum')), c_int)
-        fl%moist%liq_wat = int(max(0, get_tracer_index(MODEL_ATMOS, 'liq_wat')), c_int)
-        fl%moist%ice_wat = int(max(0, get_tracer_index(MODEL_ATMOS, 'ice_wat')), c_int)
-        fl%moist%rainwat = int(max(0, get_tracer_index(MODEL_ATMOS, 'rainwat')), c_int)
-        fl%moist%snowwat = int(max(0, get_tracer_index(MODEL_ATMOS, 'snowwat')), c_int)
-        fl%moist%graupel = int(max(0, get_tracer_index(MODEL_ATMOS, 'graupel')), c_int)
-        if (fl%moist%sphum < 1) error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond / moist_kappa need the index of sphum (fv3_register_tracer_index)'
-        fl%moist%cv_vap = 3.d0 * 461.50d0; fl%moist%c_liq = 4.218d3; fl%moist%c_ice = 2.106d3
-      end if
+      call moist_flags_of(flagstruct, thermostruct, fl)
       call fv3_host_init_grid(atf, dom, gh, nq_tot, fl, ak, bk)
       boundf = .true.
     end subroutine
@@ -936,6 +947,26 @@ contains
     gh%rarea_c = c_loc(gridstruct%rarea_c); gh%fC = c_loc(gridstruct%fC)
     gh%cosa = c_loc(gridstruct%cosa);     gh%sina = c_loc(gridstruct%sina)
     gh%sin_sg = c_loc(gridstruct%sin_sg); gh%cos_sg = c_loc(gridstruct%cos_sg)
+  end subroutine
+
+  !> thermostruct%use_cond / moist_kappa (the reference's defaults, fv_arrays.F90:1226-1227): the water species as fv_dynamics.F90:275-283
+  !> finds them -- get_tracer_index -- and the heat capacities of fv_thermodynamics' moist_cv (cv_vap = 3 rvgas, c_liq, c_ice)
+  subroutine moist_flags_of(flagstruct, thermostruct, fl)
+    type(fv_flags_type), intent(in) :: flagstruct
+    type(fv_thermo_type), intent(in) :: thermostruct
+    type(fv3_flags), intent(inout) :: fl
+    fl%use_cond = thermostruct%use_cond; fl%moist_kappa = thermostruct%moist_kappa
+    if (fl%use_cond .or. fl%moist_kappa) then
+      fl%moist%nwat = int(flagstruct%nwat, c_int)
+      fl%moist%sphum = int(max(0, get_tracer_index(MODEL_ATMOS, 'sphum')), c_int)
+      fl%moist%liq_wat = int(max(0, get_tracer_index(MODEL_ATMOS, 'liq_wat')), c_int)
+      fl%moist%ice_wat = int(max(0, get_tracer_index(MODEL_ATMOS, 'ice_wat')), c_int)
+      fl%moist%rainwat = int(max(0, get_tracer_index(MODEL_ATMOS, 'rainwat')), c_int)
+      fl%moist%snowwat = int(max(0, get_tracer_index(MODEL_ATMOS, 'snowwat')), c_int)
+      fl%moist%graupel = int(max(0, get_tracer_index(MODEL_ATMOS, 'graupel')), c_int)
+      if (fl%moist%sphum < 1) error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond / moist_kappa need the index of sphum (fv3_register_tracer_index)'
+      fl%moist%cv_vap = 3.d0 * 461.50d0; fl%moist%c_liq = 4.218d3; fl%moist%c_ice = 2.106d3
+    end if
   end subroutine
 
   !> flagstruct -> the host's fv3_flags (the members with the same names)

@@ -23,7 +23,7 @@ module fv3_host_mod
   public :: fv3_host_halo, fv3_host_init, fv3_host_init_grid, fv3_host_final, fv3_host_upload, fv3_host_download, fv3_host_comm_layout
   public :: fv3_dyn_core, fv3_dyn_core_hydrostatic, fv3_tracer_2d, fv3_fv_dynamics, fv3_fv_dynamics_call
   public :: dmalloc, dzero, swap, upload_levels, host_n_con, KIND_A, KIND_U, KIND_V, KIND_B    ! shared with fv3_sphere_mod
-  public :: inline_q_begin, inline_q_end, host_fast_tau_w, host_ray_fast
+  public :: inline_q_begin, inline_q_end, host_fast_tau_w, host_ray_fast, set_condensate
 
   integer(c_int), parameter :: KIND_A = 0, KIND_U = 1, KIND_V = 2, KIND_B = 3
   integer, parameter :: NG = 3

@@ -4,14 +4,15 @@
 !> sphere) or the tiles can be spread over processes (rank / nranks / face_rank: the exchange then runs between the processes).
 !> usage: fv3_solo_refsig_sphere <input file> <output file>    (raw little-endian streams; the output gets ".<rank>" appended)
 !>
-!> input : int32  npx, npz, nq, n_split, k_split, mode (bit 0: hydrostatic), nord, rank, nranks, have_grid, face_rank(6)
+!> input : int32  npx, npz, nq, n_split, k_split, mode (bit 0: hydrostatic; bit 3: thermostruct%use_cond = moist_kappa = .true.), nord, rank, nranks, have_grid, face_rank(6)
 !>         real64 bdt, ptop, d_con, d_ext, da_min, da_min_c, d4_bg, beta, consv_te, tau, zvir
 !>         int8   comm_id(128) ; real64 ak(npz+1), bk(npz+1)
 !>         per tile (six times): the gridstruct members in the order of fv3_grid_host, then edge_w, edge_e, edge_s, edge_n, rsina,
 !>         corner_f(12), a11 .. a22 (A layout), ec1, ec2 (A x 3), en1, en2 (component last) [, grid, agrid when have_grid: then
 !>         corner_f is NOT handed over and fv3_dyn_core_mod forms it from grid / agrid];
-!>         then the state: u, v, w, delp, pt (TEMPERATURE), delz, phis, q, and pe, pk, peln, pkz as p_var left them
-!> output: per tile held: u, v, w, delp, pt, delz, q, ua, va, mfx, cx
+!>         then the state: u, v, w, delp, pt (TEMPERATURE), delz, phis, q, and pe, pk, peln, pkz as p_var left them [, q_con, cappa in the
+!>         moist dyn_core mode: fv_dynamics forms them itself]
+!> output: per tile held: u, v, w, delp, pt, delz, q, ua, va, mfx, cx [, q_con]
 program fv3_solo_refsig_sphere
   use iso_c_binding
   use fv3_arrays_compat_mod
@@ -29,7 +30,7 @@ program fv3_solo_refsig_sphere
     real(c_double), allocatable :: u(:,:,:), v(:,:,:), w(:,:,:), delp(:,:,:), pt(:,:,:), delz(:,:,:), phis(:,:), q(:,:,:,:)
     real(c_double), allocatable :: ps(:,:), pe(:,:,:), pk(:,:,:), peln(:,:,:), pkz(:,:,:), omga(:,:,:), ua(:,:,:), va(:,:,:)
     real(c_double), allocatable :: uc(:,:,:), vc(:,:,:), mfx(:,:,:), mfy(:,:,:), cx(:,:,:), cy(:,:,:), qcon(:,:,:), ze0(:,:,:)
-    real(c_double), allocatable :: heat(:,:,:), diss(:,:,:)
+    real(c_double), allocatable :: heat(:,:,:), diss(:,:,:), cappa(:,:,:)
   end type
   type(tile_state), target :: st(6)
   type(fv_grid_type), target :: gs(6)
@@ -42,7 +43,7 @@ program fv3_solo_refsig_sphere
   type(fv_atmos_type), pointer :: parent => null()
   type(inline_mp_type) :: imp
   real(c_double), allocatable :: a9(:,:,:), u9(:,:,:), v9(:,:,:), b4(:,:,:), a4(:,:,:), ec(:,:,:,:), en1(:,:,:), en2(:,:,:)
-  logical :: hydrostatic
+  logical :: hydrostatic, moist
   integer :: un, t, nx, isd, ied, c
 
   call get_command_argument(1, fin)
@@ -55,6 +56,7 @@ program fv3_solo_refsig_sphere
   allocate(ak(npz+1), bk(npz+1))
   read(un) ak, bk
   hydrostatic = iand(mode, 1_c_int) /= 0
+  moist = iand(mode, 8_c_int) /= 0
   nx = npx - 1; isd = 1 - 3; ied = nx + 3
   bd%is = 1; bd%ie = nx; bd%js = 1; bd%je = nx; bd%isd = isd; bd%ied = ied; bd%jsd = isd; bd%jed = ied
   bd%isc = 1; bd%iec = nx; bd%jsc = 1; bd%jec = nx
@@ -101,9 +103,15 @@ program fv3_solo_refsig_sphere
       allocate(s%ps(isd:ied, isd:ied), s%pe(0:nx+1, npz+1, 0:nx+1), s%pk(nx, nx, npz+1), s%peln(nx, npz+1, nx), s%pkz(nx, nx, npz))
       allocate(s%omga(isd:ied, isd:ied, npz), s%ua(isd:ied, isd:ied, npz), s%va(isd:ied, isd:ied, npz))
       allocate(s%uc(isd:ied+1, isd:ied, npz), s%vc(isd:ied, isd:ied+1, npz), s%mfx(nx+1, nx, npz), s%mfy(nx, nx+1, npz))
-      allocate(s%cx(nx+1, isd:ied, npz), s%cy(isd:ied, nx+1, npz), s%qcon(1,1,1), s%ze0(1,1,1))
+      allocate(s%cx(nx+1, isd:ied, npz), s%cy(isd:ied, nx+1, npz), s%ze0(1,1,1))
+      if (moist) then
+        allocate(s%qcon(isd:ied, isd:ied, npz), s%cappa(isd:ied, isd:ied, npz)); s%qcon = 0.d0; s%cappa = 0.d0
+      else
+        allocate(s%qcon(1,1,1), s%cappa(1,1,1))
+      end if
       allocate(s%heat(isd:ied, isd:ied, npz), s%diss(isd:ied, isd:ied, npz))
       read(un) s%pe, s%pk, s%peln, s%pkz              ! what p_var left (fv_arrays layout); zeros in a nonhydrostatic test
+      if (moist .and. trim(what) == 'dyn_core') read(un) s%qcon, s%cappa    ! dyn_core is handed both (fv_dynamics forms them: moist_cv)
       s%ps = 0.d0; s%omga = 0.d0; s%ua = 0.d0; s%va = 0.d0
       s%uc = 0.d0; s%vc = 0.d0; s%mfx = 0.d0; s%mfy = 0.d0; s%cx = 0.d0; s%cy = 0.d0; s%heat = 0.d0; s%diss = 0.d0
     end associate
@@ -114,6 +122,12 @@ program fv3_solo_refsig_sphere
   fl%d2_bg_k1 = 0.20d0; fl%d2_bg_k2 = 0.015d0                   ! the host modules' defaults (fv3_flags), as the Python host's DynFlags
   fl%hydrostatic = hydrostatic; fl%d_con = d_con; fl%d_ext = d_ext; fl%beta = beta; fl%a_imp = 1.d0
   fl%tau = tau; fl%moist_phys = .false.; fl%adiabatic = nq == 0 .or. zvir == 0.d0
+  if (moist) then         ! the field table of the test: six water species in tracers 1 .. 6 (what FMS's tracer manager would answer)
+    thermo%use_cond = .true.; thermo%moist_kappa = .true.; fl%nwat = 6; fl%adiabatic = .false.
+    call fv3_register_tracer_index('sphum', 1);   call fv3_register_tracer_index('liq_wat', 2)
+    call fv3_register_tracer_index('rainwat', 3); call fv3_register_tracer_index('ice_wat', 4)
+    call fv3_register_tracer_index('snowwat', 5); call fv3_register_tracer_index('graupel', 6)
+  end if
   dom%pe = rank; dom%npes = nranks; dom%face_rank = face_rank; dom%comm_id = comm_id
   allocate(pfull(npz), te0(nx, nx), cappa(1,1,1)); pfull = 0.d0; te0 = 0.d0
   do t = 1, 6
@@ -121,7 +135,7 @@ program fv3_solo_refsig_sphere
     dom%tile = t
     if (trim(what) == 'dyn_core') then
       associate (s => st(t))
-        call dyn_core(int(npx), int(npx), int(npz), 3, 1, int(nq), bdt, 1, int(n_split), zvir, 287.04d0/(2.d0/7.d0), 2.d0/7.d0, cappa, &
+        call dyn_core(int(npx), int(npx), int(npz), 3, 1, int(nq), bdt, 1, int(n_split), zvir, 287.04d0/(2.d0/7.d0), 2.d0/7.d0, s%cappa, &
                       9.80d0, hydrostatic, s%u, s%v, s%w, s%delz, s%pt, s%q, s%delp, s%pe, s%pk, s%phis, te0, s%omga, ptop, pfull, &
                       s%ua, s%va, s%uc, s%vc, s%mfx, s%mfy, s%cx, s%cy, s%pkz, s%peln, s%qcon, ak, bk, 0, gs(t), fl, nest, thermo, &
                       idiag, bd, dom, .true., i_pack, .true., s%heat, s%diss, 0.d0, te0)
@@ -143,6 +157,7 @@ program fv3_solo_refsig_sphere
     if (nq > 0) write(un) st(t)%q
     write(un) st(t)%ua, st(t)%va
     write(un) st(t)%mfx, st(t)%cx
+    if (moist) write(un) st(t)%qcon
   end do
   close(un)
   call fv_dynamics_end()

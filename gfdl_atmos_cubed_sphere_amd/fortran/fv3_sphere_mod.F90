@@ -17,7 +17,7 @@ module fv3_sphere_mod
   private
   public :: fv3_sphere, fv3_sphere_init_face, fv3_sphere_comm, fv3_sphere_dyn_core, fv3_sphere_fv_dynamics, fv3_sphere_final
   public :: fv3_sphere_fv_dynamics_call
-  public :: fv3_sphere_halo_a
+  public :: fv3_sphere_halo_a, fv3_sphere_halo_moist
 
   type fv3_sphere
     integer :: nf = 0                       !< faces held by this rank
@@ -111,6 +111,13 @@ contains
     call exchange(sp, 1, [FV3_CUBE_A + 0], [sel], [0], [nk])
   end subroutine
 
+  !> the halo updates of q_con (pack 11) and cappa (pack 12) fv_dynamics makes in front of every dyn_core call (fv_dynamics.F90:464-465, :487-488)
+  subroutine fv3_sphere_halo_moist(sp)
+    type(fv3_sphere), intent(inout) :: sp
+    if (sp%f(1)%fl%use_cond) call exchange(sp, 1, [FV3_CUBE_A + 0], [15], [0], [sp%f(1)%npz])
+    if (sp%f(1)%fl%moist_kappa) call exchange(sp, 1, [FV3_CUBE_A + 0], [16], [0], [sp%f(1)%npz])
+  end subroutine
+
   ! field selectors (the arrays are swapped between substeps, so the pointer is looked up at every exchange)
   function field_of(at, sel) result(p)
     type(fv3_atmos), intent(in) :: at
@@ -131,6 +138,8 @@ contains
     case (12); p = at%q
     case (13); p = at%dp1
     case (14); p = at%phis
+    case (15); p = at%q_con
+    case (16); p = at%cappa
     case default; p = c_null_ptr
     end select
   end function
@@ -145,7 +154,7 @@ contains
     integer :: it, n_split, npz, i, n_con, nq
     logical :: remap_step, heating, hyd
     integer(c_int) :: last_call, use_logp, ihyd
-    type(c_ptr) :: dv2, fxp, fyp
+    type(c_ptr) :: dv2, fxp, fyp, qcp, qcn
     type(fv3_flags) :: fl
     integer, parameter :: A = FV3_CUBE_A, B = FV3_CUBE_B, D = FV3_CUBE_D, C = FV3_CUBE_C, DE = FV3_CUBE_DEDGE
     fl = sp%f(1)%fl
@@ -164,7 +173,7 @@ contains
     top = merge(peln1, ptk, fl%use_logp)
     par%dt = dt; par%hord_tr = fl%hord_tr; par%hord_mt = fl%hord_mt; par%hord_vt = fl%hord_vt
     par%hord_tm = fl%hord_tm; par%hord_dp = fl%hord_dp; par%dddmp = fl%dddmp; par%d4_bg = fl%d4_bg
-    par%kgb = fl%ke_bg; par%hydrostatic = ihyd; par%use_cond = 0
+    par%kgb = fl%ke_bg; par%hydrostatic = ihyd; par%use_cond = merge(1_c_int, 0_c_int, fl%use_cond)
     do i = 1, sp%nf
       associate (at => sp%f(i))
         if (heating) call dzero(at, at%heat_source, at%nA*npz)
@@ -206,6 +215,7 @@ contains
                                      at%phis, at%ptc, at%pkz, 1_c_int), 'geopk (C grid)')
           else
             call fv3_check(fv3_update_dz_c(at%ctx, dt2, at%zs, at%ut, at%vt, at%zh, at%gz, at%ws3), 'update_dz_c')   ! :514-527
+            call set_condensate(at)
             call host_fast_tau_w(at, dt2)
             call fv3_check(fv3_riem_solver_c(at%ctx, dt2, at%cn, at%phis, at%omga, at%ptc, at%delpc, at%gz, at%pkc, at%ws3), &
                            'riem_solver_c')                                                ! :531
@@ -223,9 +233,13 @@ contains
                                     fxp, fyp, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
                                     at%delp_n, at%pt_n, at%u_n, at%v_n, c_null_ptr, c_null_ptr, at%heat_s, at%diss_e), 'd_sw')
           else
+            qcp = c_null_ptr; qcn = c_null_ptr
+            if (fl%use_cond) then
+              qcp = at%q_con; qcn = at%q_con_n
+            end if
             call fv3_check(fv3_d_sw(at%ctx, par, at%vt, at%delp, at%pt, at%u, at%v, at%w, at%uc, at%vc, at%ua, at%va, at%divgd, &
-                                    fxp, fyp, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
-                                    at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, c_null_ptr, at%heat_s, at%diss_e), 'd_sw')  ! :762
+                                    fxp, fyp, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, qcp, &
+                                    at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, qcn, at%heat_s, at%diss_e), 'd_sw')  ! :762
           end if
           if (heating) call fv3_check(fv3_heat_source_accum(at%ctx, at%heat_source, at%heat_s), 'heat_source_accum')   ! :798-803
           call inline_q_end(at)
@@ -235,9 +249,11 @@ contains
           call swap(at%delp, at%delp_n); call swap(at%pt, at%pt_n)
           call swap(at%u, at%u_n); call swap(at%v, at%v_n)
           if (.not. hyd) call swap(at%w, at%w_n)
+          if (fl%use_cond) call swap(at%q_con, at%q_con_n)
         end associate
       end do
       call exchange(sp, 2, [A, A], [4, 5], [0, 0], [npz, npz])                            ! delp, pt: :823-824 / :851 (pack 1)
+      if (fl%use_cond) call exchange(sp, 1, [A], [15], [0], [npz])                       ! q_con: :825 / :852 (pack 11)
       if (hyd) then
         do i = 1, sp%nf
           associate (at => sp%f(i))
@@ -258,6 +274,7 @@ contains
       else
         do i = 1, sp%nf
           associate (at => sp%f(i))
+            if (fl%use_cond) call set_condensate(at)           ! the buffer d_sw just wrote (its halo updated above)
             call fv3_check(fv3_update_dz_d(at%ctx, int(fl%hord_tm, c_int), at%zs, at%zh, at%zh_n, at%crx, at%cry, at%xfx, &
                                            at%yfx, at%ws, rdt), 'update_dz_d')              ! :911
             call swap(at%zh, at%zh_n)
@@ -413,6 +430,7 @@ contains
           call fv3_check(fv3_memcpy_d2d(at%ctx, at%dp1, at%delp, at%nA * at%npz * 8_c_size_t), 'dp1 = delp')     ! :475-481
         end associate
       end do
+      call fv3_sphere_halo_moist(sp)                                                                              ! q_con, cappa: :464-465 / :487-488
       call fv3_sphere_dyn_core(sp, mdt, n_map == fl%k_split)                                                      ! :493
       if (nq > 0 .and. .not. fl%inline_q) call sphere_tracer_2d(sp, nranks)                                                                ! :500-533
       rp%last_step = merge(1_c_int, 0_c_int, last_step .and. n_map == fl%k_split)
@@ -420,6 +438,7 @@ contains
       do i = 1, sp%nf
         associate (at => sp%f(i))
           if (fl%remap_te) call fv3_check(fv3_set_remap_te(at%ctx, 1_c_int, at%phis, at%dp1), 'set_remap_te')   ! te = dp1, :612
+          if (fl%use_cond .or. fl%moist_kappa) call sphere_set_moist(at)      ! q_con is a ping-pong pair: the current buffer
           if (fl%hydrostatic) then
             call fv3_check(fv3_lagrangian_to_eulerian(at%ctx, rp, kord_tr, at%ps, at%pe, at%delp, at%pkz, at%pk, at%u, at%v, &
                                                       c_null_ptr, c_null_ptr, at%pt, at%q, at%peln, at%omga, c_null_ptr), &
@@ -432,6 +451,14 @@ contains
         end associate
       end do
     end do
+  end subroutine
+
+  !> moist_cv's parameters and the current q_con / cappa buffers of a face (fv3_set_moist)
+  subroutine sphere_set_moist(at)
+    type(fv3_atmos), intent(inout) :: at
+    at%fl%moist%moist_kappa = merge(1_c_int, 0_c_int, at%fl%moist_kappa)
+    at%fl%moist%use_cond = merge(1_c_int, 0_c_int, at%fl%use_cond)
+    call fv3_check(fv3_set_moist(at%ctx, at%fl%moist, at%q_con, at%cappa), 'set_moist')
   end subroutine
 
   !> A whole fv_dynamics call (model/fv_dynamics.F90:79-936 for the adiabatic core) on the faces of this rank; pt holds T (T_v) on
@@ -468,6 +495,7 @@ contains
     end if
     do i = 1, sp%nf
       associate (at => sp%f(i))
+        if (fl%use_cond .or. fl%moist_kappa) call sphere_set_moist(at)   ! moist_cv of the conversions and of compute_total_energy (:305-317)
         qv = c_null_ptr; zv = 0.d0
         if (nq > 0 .and. .not. fl%adiabatic) then
           qv = at%q; zv = zvir

@@ -498,7 +498,7 @@ def build_solo_refsig_sphere(workdir, libdir=CSRC, libname="fv3_mi355x"):
 
 
 def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2, bdt=900.0, hydrostatic=False, consv_te=1.0, tau=10.0,
-                        zvir=0.6077, face_rank=(0, 0, 0, 0, 0, 0), have_grid=False, tol=0.0, what="fv_dynamics"):
+                        zvir=0.6077, face_rank=(0, 0, 0, 0, 0, 0), have_grid=False, tol=0.0, what="fv_dynamics", thermo=False):
     """fv_dynamics WITH THE REFERENCE'S ARGUMENT LIST on the cubed sphere (fv3_dyn_core_mod.F90: one call per tile, host arrays with the
     fv_arrays layout, gridstruct / flagstruct / bd / domain) against the Python host's whole fv_dynamics call
     (FvDynamics.step_from_temperature over the six contexts): compute_total_energy, T -> theta_v with the virtual effect, Rayleigh_Super
@@ -519,7 +519,12 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
     ak, bk = 300.0 * (1.0 - sig), sig.copy()
     st = cs.jablonowski_williamson(ak, bk, hydrostatic=hydrostatic, rdgas=L.RDGAS, grav=L.GRAV)      # pt = T
     CC.exchange(cs, st, ("phis",), "A")
-    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, ptop=float(ak[0]), **(dict(d_ext=0.0) if hydrostatic else {}))
+    # thermo: thermostruct%use_cond = moist_kappa = .true. (the reference's defaults, fv_arrays.F90:1226-1227) -- six water species; fv_dynamics forms
+    # q_con / cappa itself (moist_cv), dyn_core is handed them
+    assert not (thermo and hydrostatic)
+    if thermo and what == "fv_dynamics":
+        nq = max(nq, 6)
+    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, ptop=float(ak[0]), use_cond=thermo, moist_kappa=thermo, **(dict(d_ext=0.0) if hydrostatic else {}))
     bd = gs[0].bd
     ng = bd.ng
     c = (slice(ng, ng + nx), slice(ng, ng + nx))
@@ -554,11 +559,20 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
         for t in range(6):
             q[t][..., 0] = 0.01 * np.abs(q[t][..., 0]) / (1.0e-30 + np.abs(q[t][..., 0]).max())
     moist = bool(nq) and zvir > 0.0
+    qc_in = cp_in = None
+    if thermo and nq:
+        for t in range(6):
+            q[t][..., 1:6] = 1.0e-3 * np.abs(q[t][..., 1:6]) / (1.0e-30 + np.abs(q[t][..., 1:6]).max())   # small condensate mixing ratios
+    if thermo and what == "dyn_core":
+        rng = np.random.default_rng(41)
+        qc_in = [np.asfortranarray(rng.uniform(0.0, 0.01, bd.shape("A", npz))) for _ in range(6)]
+        cp_in = [np.asfortranarray(0.28 + rng.uniform(0.0, 0.005, bd.shape("A", npz))) for _ in range(6)]
     # ---- (a) Python host ----
     mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     try:
+        import parity_remap as R
         fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)),
-                        consv_te=consv_te, tau=tau, adiabatic=not moist, moist_phys=False)
+                        consv_te=consv_te, tau=tau, adiabatic=not moist, moist_phys=False, moist=dict(R.MOIST6) if thermo else None)
         fv.remap_par["r_vir"] = zvir if moist else fv.remap_par["r_vir"]
         fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], [s_["w"] for s_ in st], [s_["delp"] for s_ in st],
                         [s_["pt"] for s_ in st], [s_["delz"] for s_ in st], [s_["phis"] for s_ in st])
@@ -567,6 +581,11 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
         for n in ("pe", "pk", "peln", "pkz"):
             fv.dc.d[n].upload([p_[n] for p_ in pv])
         if what == "dyn_core":
+            if thermo:      # the halo updates fv_dynamics makes in front of dyn_core (:464-465)
+                fv.dc.d["q_con"].upload(qc_in)
+                fv.dc.d["cappa"].upload(cp_in)
+                fv.dc.halo.update([(fv.dc.d["q_con"], "A")])
+                fv.dc.halo.update([(fv.dc.d["cappa"], "A")])
             fv.dc.run(bdt, end_step=True)
         else:
             fv.step_from_temperature(bdt)
@@ -577,6 +596,9 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
         ref = {n: d[n].download() for n in names}
         if nq:
             ref["q"] = d["q"].download()
+        if thermo:
+            ref["q_con"] = d["q_con"].download()
+            assert max(float(np.max(np.abs(x[c]))) for x in ref["q_con"]) > 0.0
         for n in names:
             assert all(np.all(np.isfinite(x[c])) for x in ref[n]), f"the Python host's {n} is not finite"
         assert tau <= 0.0 or fv._rf[2] > 0, "the Rayleigh damping acts on no level of this test"
@@ -594,7 +616,7 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
     for rank in range(nranks):
         fin = os.path.join(str(workdir), f"rs_in_{rank}.bin")
         with open(fin, "wb") as f:
-            np.array([npx, npz, nq, n_split, k_split, int(hydrostatic), fl.nord, rank, nranks, int(have_grid)] + list(face_rank),
+            np.array([npx, npz, nq, n_split, k_split, int(hydrostatic) + 8 * int(thermo), fl.nord, rank, nranks, int(have_grid)] + list(face_rank),
                      dtype=np.int32).tofile(f)
             np.array([bdt, fl.ptop, 0.0, fl.d_ext, gs[0].da_min, gs[0].da_min_c, fl.d4_bg, fl.beta, consv_te, tau, zvir if moist else 0.0],
                      dtype=np.float64).tofile(f)
@@ -621,6 +643,8 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
                     F(q[t]).tofile(f)
                 for n in ("pe", "pk", "peln", "pkz"):
                     F(pv[t][n]).tofile(f)
+                if thermo and what == "dyn_core":
+                    F(qc_in[t]).tofile(f); F(cp_in[t]).tofile(f)
         procs.append(subprocess.Popen([exe, fin, fout, what], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -629,7 +653,7 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
         assert p.returncode == 0, o[-3000:]
     i0, i1, j0, j1 = bd.is_, bd.ie, bd.js, bd.je
     rng_ = {"u": ("U", i0, i1, j0, j1 + 1), "v": ("V", i0, i1 + 1, j0, j1), "w": ("A", i0, i1, j0, j1), "delp": ("A", i0, i1, j0, j1),
-            "pt": ("A", i0, i1, j0, j1), "ua": ("A", i0, i1, j0, j1), "va": ("A", i0, i1, j0, j1)}
+            "pt": ("A", i0, i1, j0, j1), "ua": ("A", i0, i1, j0, j1), "va": ("A", i0, i1, j0, j1), "q_con": ("A", i0, i1, j0, j1)}
     worst = 0.0
     for rank in range(nranks):
         with open(fout + f".{rank}", "rb") as f:
@@ -649,6 +673,9 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
                 for n, kind in (("mfx", "FX"), ("cx", "CX")):
                     shp = bd.shape(kind, npz)
                     got[n] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+                if thermo:
+                    shp = bd.shape("A", npz)
+                    got["q_con"] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
                 for n in ref:
                     if n in rng_:
                         kind, *r4 = rng_[n]

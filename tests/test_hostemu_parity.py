@@ -1219,7 +1219,8 @@ def test_riem_lds_bit_identical_to_the_slab_kernels(emu, dims):
 @pytest.mark.parametrize("kw", [dict(), dict(hydrostatic=True), dict(consv_te=-2.0, tau=0.0, nq=0), dict(face_rank=(0, 1, 2, 3, 4, 5)),
                                 dict(face_rank=(0, 0, 1, 1, 2, 2)), dict(face_rank=(0, 1, 0, 1, 0, 1), hydrostatic=True),
                                 dict(have_grid=True), dict(what="dyn_core"), dict(what="dyn_core", hydrostatic=True),
-                                dict(what="dyn_core", face_rank=(0, 0, 1, 1, 2, 2))])
+                                dict(what="dyn_core", face_rank=(0, 0, 1, 1, 2, 2)),
+                                dict(thermo=True), dict(thermo=True, what="dyn_core"), dict(thermo=True, face_rank=(0, 0, 1, 1, 2, 2))])   # use_cond = moist_kappa = .true.
 def test_fortran_fv_dynamics_with_the_reference_argument_list_on_the_sphere(emu, tmp_path, kw):
     """VERDICT r3 item 6 (row a21): fv_dynamics with the REFERENCE'S argument list (model/fv_dynamics.F90:79-85) on grid_type = 0 --
     fv3_dyn_core_mod.F90 binds one context per tile held (fv3_grid_upload_cubed from gridstruct's own members, corner factors from
