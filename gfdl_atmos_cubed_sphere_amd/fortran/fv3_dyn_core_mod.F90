@@ -28,8 +28,8 @@
 !> fv3_halo_complete with the neighbour PEs, tracer_2d's mp_reduce_max through fv3_allreduce_max (fv3_host_comm_layout).
 !>
 !> Restrictions (error stop with the reason, never a silent difference): no nesting / regional BCs;
-!> use_cond / moist_kappa in fv_dynamics and on the sphere (dyn_core carries them on the doubly periodic domain), do_diss_est and the
-!> SKEB diss_est accumulation are not carried through this wrapper.  consv_te and tau > 0 are carried on both domains.
+!> do_diss_est and the SKEB diss_est accumulation, consv_am, hybrid_z are not carried through this wrapper.  consv_te, tau > 0, RF_fast,
+!> fast_tau_w_sec and thermostruct%use_cond / moist_kappa (the reference's defaults) are carried on both domains.
 module fv3_arrays_compat_mod
   use iso_c_binding
   implicit none
