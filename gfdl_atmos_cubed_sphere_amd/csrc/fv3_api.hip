@@ -154,6 +154,7 @@ struct fv3_ctx {
   int trc_nt;  // tracers per wavefront in the sub-cycle kernel (FV3_MI355X_TRACER_NT: 1..4, default 3)
   int remap_nt;  // tracers per thread in the remap (FV3_MI355X_REMAP_NT: 1..3, default 3)
   int riem_blocked;   // the same for the Riemann solvers' four slabs (FV3_MI355X_RIEM_SCR: 0 / 1, default 1)
+  int pgrad_fused;    // nh_p_grad as ONE kernel where the domain has no face edges (NhPGradFused; FV3_MI355X_PGRAD_FUSED=0: a2b_ord4 + the gradient)
   int riem_lds;       // the dry SIM1 Riemann solvers with the levels across the lanes, BIT-IDENTICAL to the slab kernels (nh_fast.h
                       // RiemFast<CG, true>; FV3_MI355X_RIEM_LDS: 0 / 1, default 1)
   int fast;           // fast (tolerance) mode: FV3_MI355X_FAST=1 or fv3_set_fast -- nh_fast.h instead of the parity column solvers
@@ -592,6 +593,8 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     c->riem_blocked = e ? (std::atoi(e) != 0) : 1;
     e = std::getenv("FV3_MI355X_RIEM_LDS");
     c->riem_lds = e ? (std::atoi(e) != 0) : 1;
+    const char *ef = std::getenv("FV3_MI355X_PGRAD_FUSED");
+    c->pgrad_fused = ef ? (std::atoi(ef) != 0) : 1;
     e = std::getenv("FV3_MI355X_FAST");
     c->fast = e ? std::atoi(e) : 0;   // 1 = every tolerance-mode kernel; otherwise a mask: 2 Riem_Solver_c, 4 Riem_Solver3, 8 edge_profile
     if (c->fast == 1) c->fast = 14;
@@ -3698,10 +3701,22 @@ extern "C" int fv3_split_p_grad(fv3_ctx *c, double *u, double *v, const double *
 static int nh_p_grad_impl(fv3_ctx *c, double *u, double *v, const double *pp, const double *gz, double gz_scale, const double *delp,
                           const double *pk, double dt, double top_value, double beta, double *du, double *dv) {
   if (!c || !c->grid_ready) return fail("fv3_nh_p_grad: context has no grid");
-  if (need_scratch(c, 4)) return 1;
   const Grid &g = c->g;
   const int km = g.npz;
   constexpr int TI = 32, TJ = 16;
+  if (c->pgrad_fused && !du && !is_cubed(c)) {     // the corner values stay in LDS
+    // 32 x 8 corners per workgroup: one point per thread, 114 registers, 25 KB of LDS -- four workgroups per CU.  Measured at C384 L127
+    // (tools/a2b_ab.py, same arrays): 32 x 16 tiles (two points per thread, 164 registers, 43 KB: three per CU) 0.480 ms, 32 x 8 0.403;
+    // a2b_ord4 + the gradient as two kernels 0.29 + 0.32
+    constexpr int FI = 32, FJ = 8;
+    NhPGradFused<FI, FJ> kf{g, dt, gz_scale, top_value, pp, pk, gz, delp, u, v};
+    Dim3 grid;
+    grid.x = (unsigned)((g.nx + 1 + FI - 1) / FI);
+    grid.y = (unsigned)((g.ny + 1 + FJ - 1) / FJ);
+    grid.z = (unsigned)kf.nchunks();
+    return launch_p(c, "nh_p_grad", grid, NhPGradFused<FI, FJ>::lds_doubles, kf);
+  }
+  if (need_scratch(c, 4)) return 1;
   {
     A2BCorners<TI, TJ> kf;
     kf.g = g;

@@ -788,6 +788,31 @@ struct PGradC {
   }
 };
 
+// The corners (i, j) and (i, j + 1) of a2b_ord4 away from the face edges, from a tile of cells in LDS: their 4 x 5 cells once into
+// registers (the 4 x 4 blocks of neighbouring corners share 12 cells, and qx / qy of one corner read the same 16), then the sums of the
+// reference.  sum_form 0: the combined sum of the grid_type >= 3 branch (a2b_edge.F90:292-315); 1: qout = 0.5 (qxx + qyy) with the two
+// 4-point sums formed separately (the cubed-sphere branch, :236-286).
+FV3_HD void a2b_corner_pair(const Tile &s, int i, int j, int sum_form, double (&qo)[2]) {
+  constexpr double a1 = 0.5625, a2 = -0.0625, b1 = 7. / 12., b2 = -1. / 12.;
+  constexpr int NV = 2;
+  double cl[NV + 3][4];
+  for (int r = 0; r < NV + 3; r++)
+    for (int t = 0; t < 4; t++) cl[r][t] = s(i - 2 + t, j - 2 + r);
+  double qxr[NV + 3];
+  for (int r = 0; r < NV + 3; r++) qxr[r] = b1 * (cl[r][1] + cl[r][2]) + b2 * (cl[r][0] + cl[r][3]);
+  for (int d = 0; d < NV; d++) {
+    double qx[4], qy[4];
+    for (int t = 0; t < 4; t++) {
+      qx[t] = qxr[d + t];
+      qy[t] = b1 * (cl[d + 1][t] + cl[d + 2][t]) + b2 * (cl[d][t] + cl[d + 3][t]);
+    }
+    if (sum_form)
+      qo[d] = 0.5 * ((a2 * (qx[0] + qx[3]) + a1 * (qx[1] + qx[2])) + (a2 * (qy[0] + qy[3]) + a1 * (qy[1] + qy[2])));
+    else
+      qo[d] = 0.5 * (a1 * (qx[1] + qx[2] + qy[1] + qy[2]) + a2 * (qx[0] + qx[3] + qy[0] + qy[3]));
+  }
+}
+
 // a2b_ord4, doubly periodic branch (a2b_edge.F90:292-315), for up to 4 fields of one level: corner values on
 // [is, ie+1] x [js, je+1] written to separate B-position slabs stored with the A layout (corner (i,j) at iA(i,j)).
 template <int TI, int TJ>
@@ -809,7 +834,6 @@ struct A2BCorners {
   static constexpr int lds_doubles = 4 * W * H;
   static constexpr int kIt = (W * H + kNT - 1) / kNT;
   FV3_HD void operator()(int bx, int by, int bz, int tid, double *lds) const {
-    constexpr double a1 = 0.5625, a2 = -0.0625, b1 = 7. / 12., b2 = -1. / 12.;
     const int k = bz;
     const int i0 = g.is + bx * TI, j0 = g.js + by * TJ;
     bool act[4], ovr[4];
@@ -860,23 +884,10 @@ struct A2BCorners {
       for (int idx = tid; idx < TI * (TJ / NV); idx += kNT) {
         const int i = i0 + idx % TI, j = j0 + NV * (idx / TI);
         if (i > g.ie + 1 || j > g.je + 1) continue;
-        double cl[NV + 3][4];
-        for (int r = 0; r < NV + 3; r++)
-          for (int t = 0; t < 4; t++) cl[r][t] = s(i - 2 + t, j - 2 + r);
-        double qxr[NV + 3];
-        for (int r = 0; r < NV + 3; r++) qxr[r] = b1 * (cl[r][1] + cl[r][2]) + b2 * (cl[r][0] + cl[r][3]);
-        for (int d = 0; d < NV; d++) {
-          if (j + d > g.je + 1) continue;
-          double qx[4], qy[4];
-          for (int t = 0; t < 4; t++) {
-            qx[t] = qxr[d + t];
-            qy[t] = b1 * (cl[d + 1][t] + cl[d + 2][t]) + b2 * (cl[d][t] + cl[d + 3][t]);
-          }
-          if (sum_form)
-            o[g.iA(i, j + d)] = 0.5 * ((a2 * (qx[0] + qx[3]) + a1 * (qx[1] + qx[2])) + (a2 * (qy[0] + qy[3]) + a1 * (qy[1] + qy[2])));
-          else
-            o[g.iA(i, j + d)] = 0.5 * (a1 * (qx[1] + qx[2] + qy[1] + qy[2]) + a2 * (qx[0] + qx[3] + qy[0] + qy[3]));
-        }
+        double qo[NV];
+        a2b_corner_pair(s, i, j, sum_form, qo);
+        for (int d = 0; d < NV; d++)
+          if (j + d <= g.je + 1) o[g.iA(i, j + d)] = qo[d];
       }
     }
   }
@@ -966,6 +977,163 @@ struct NhPGrad {
     }
   }
 };
+
+// A store of one value per thread without a branch around it (a branch around a global store costs the loop an s_waitcnt vmcnt(0) at its
+// top, spmd.h "branch-free rows"): through a buffer resource over the level's slab (`base`: wave-uniform), a thread that must not store
+// carries an offset beyond num_records and the hardware drops its store.
+#ifdef FV3_HOST_EMU
+inline void store_if(double *base, size_t, int idx, double x, bool valid) {
+  if (valid) base[idx] = x;
+}
+#else
+typedef unsigned fv3_nh_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_if(double *base, size_t nelem, int idx, double x, bool valid) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fv3_nh_u2, x), __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(nelem * 8), 0x00020000),
+                                        valid ? idx * 8 : (int)0x80000000u, 0, 0);
+}
+#endif
+
+// nh_p_grad (dyn_core.F90:1697-1792) in ONE kernel on a domain without face edges (grid_type >= 3): a2b_ord4 of pp, pk, gz and delp and the
+// gradient that reads the corner values, which then never go to memory (A2BCorners + NhPGrad: 64 B per cell written and read back beside the
+// 64 the routine needs).  A workgroup owns a TI x TJ tile of corners and KC layers: interface after interface it stages the cells of the
+// four fields in LDS (the loads of the next interface are in flight while this one is worked on), forms the (TI + 1) x (TJ + 1) corner
+// values a thread's own corner and its east / north neighbours need into a second set of tiles, and updates u, v of the layer above from
+// them and the corner values of the interface above, which each thread kept in registers.  The arithmetic is that of the two kernels
+// (a2b_corner_pair, the statements of NhPGrad::layer): the same bits.
+#ifndef PGF_UVPRE
+#define PGF_UVPRE 0
+#endif
+template <int TI, int TJ>
+struct NhPGradFused {
+  static constexpr int KC = 16;
+  static constexpr int W = TI + 5, H = TJ + 5, CW = TI + 1, CH = TJ + 1;
+  static constexpr int lds_doubles = 4 * W * H + 4 * CW * CH;
+  static constexpr int kIt = (W * H + kNT - 1) / kNT;        // cells a thread stages per field
+  static constexpr int kPt = (TI * TJ + kNT - 1) / kNT;      // corners whose u, v a thread updates
+  static_assert(CH % 2 == 1, "NhPGradFused: the corner rows are taken in pairs and one single row");
+  Grid g;
+  double dt, gz_scale, top_value;
+  const double *pp, *pk, *gz, *delp;   // A x (npz+1), A x (npz+1), A x (npz+1), A x npz
+  double *u, *v;
+  FV3_HD int nchunks() const { return (g.npz + KC - 1) / KC; }
+  FV3_HD void operator()(int bx, int by, int bz, int tid, double *lds) const {
+    const int km = g.npz, k0 = bz * KC, k1 = (k0 + KC < km) ? k0 + KC : km;
+    const int i0 = g.is + bx * TI, j0 = g.js + by * TJ;
+    const size_t nA = g.nA(), nU = g.nU(), nV = g.nV();
+    double *cells = lds, *corn = lds + 4 * W * H;
+    double vq[4][kIt];
+    // the cells of interface l (pp, pk, gz) and of the layer above it (delp of layer l - 1; nothing at the chunk's first interface).  Every
+    // load unconditional, from an address inside the array (a load under a branch is waited for at the join); cells outside the array
+    // belong to corners outside [is, ie + 1] x [js, je + 1], whose values are dropped
+    int coff[kIt];
+    for (int it = 0; it < kIt; it++) {
+      const int e0 = tid + it * kNT, idx = e0 < W * H ? e0 : W * H - 1, li = idx % W, lj = idx / W;
+      int i = i0 - 2 + li, j = j0 - 2 + lj;
+      i = i < g.isd ? g.isd : (i > g.ied ? g.ied : i);
+      j = j < g.jsd ? g.jsd : (j > g.jed ? g.jed : j);
+      coff[it] = (j - g.jsd) * g.nid + (i - g.isd);
+    }
+    auto issue = [&](int l) {
+      const double *src[4] = {pp + (size_t)l * nA, pk + (size_t)l * nA, gz + (size_t)l * nA, delp + (size_t)(l > 0 ? l - 1 : 0) * nA};
+      FV3_UNROLL_ALL
+      for (int f = 0; f < 4; f++) {
+        FV3_UNROLL_ALL
+        for (int it = 0; it < kIt; it++) vq[f][it] = src[f][coff[it]];
+      }
+    };
+    double pv[kPt][9];   // pp, pk, gz of the interface above at the thread's corner, its east and its north neighbour
+    double rdu[kPt], rdv[kPt];
+    for (int p = 0; p < kPt; p++) {
+      const int idx = tid + p * kNT, i = i0 + idx % TI, j = j0 + idx / TI;
+      const bool in = idx < TI * TJ && i <= g.ie + 1 && j <= g.je + 1;
+      rdu[p] = (in && i <= g.ie) ? g.rdx[g.iU(i, j)] : 0.;
+      rdv[p] = (in && j <= g.je) ? g.rdy[g.iV(i, j)] : 0.;
+      for (int q = 0; q < 9; q++) pv[p][q] = 0.;
+    }
+    issue(k0);
+    for (int l = k0; l <= k1; l++) {
+      FV3_UNROLL_ALL
+      for (int f = 0; f < 4; f++) {
+        double *t = cells + f * (W * H);
+        FV3_UNROLL_ALL
+        for (int it = 0; it < kIt; it++) {
+          const int idx = tid + it * kNT;
+          if (idx < W * H) t[idx] = (f == 2 && gz_scale != 1.0) ? vq[f][it] * gz_scale : vq[f][it];
+        }
+      }
+      FV3_SYNC_LDS();
+      if (l < k1) issue(l + 1);
+#if PGF_UVPRE
+      // u, v of the layer above: requested now, used behind the corner values
+      double uo[kPt], vo[kPt];
+      for (int p = 0; p < kPt; p++) {
+        const int idx = tid + p * kNT, i = i0 + idx % TI, j = j0 + idx / TI;
+        const int iu = i < g.ie ? i : g.ie, ju = j < g.je + 1 ? j : g.je + 1, iv = i < g.ie + 1 ? i : g.ie + 1, jv = j < g.je ? j : g.je;
+        const size_t lc = (size_t)(l > 0 ? l - 1 : 0);
+        uo[p] = u[lc * nU + g.iU(iu, ju)];
+        vo[p] = v[lc * nV + g.iV(iv, jv)];
+      }
+#endif
+      // corner values of this interface (and of the layer above it) on [i0, i0 + TI] x [j0, j0 + TJ]
+      for (int f = 0; f < 4; f++) {
+        if (f == 3 && l == k0) continue;
+        double *c = corn + f * (CW * CH);
+        if (l == 0 && f < 2) {                      // nh_p_grad :1732-1738: the top interface
+          for (int idx = tid; idx < CW * CH; idx += kNT) c[idx] = f == 0 ? 0. : top_value;
+          continue;
+        }
+        const Tile s{cells + f * (W * H), i0 - 2, j0 - 2, W};
+        for (int idx = tid; idx < CW * ((CH + 1) / 2); idx += kNT) {
+          const int ci = idx % CW, cj = 2 * (idx / CW);
+          double qo[2];
+          a2b_corner_pair(s, i0 + ci, j0 + (cj + 1 < CH ? cj : cj - 1), 0, qo);   // the single last row: as the second of its pair
+          if (cj + 1 < CH) {
+            c[cj * CW + ci] = qo[0];
+            c[(cj + 1) * CW + ci] = qo[1];
+          } else {
+            c[cj * CW + ci] = qo[1];
+          }
+        }
+      }
+      FV3_SYNC_LDS();
+      const double *cpp = corn, *cpk = corn + CW * CH, *cgz = corn + 2 * CW * CH, *cw1 = corn + 3 * CW * CH;
+      for (int p = 0; p < kPt; p++) {
+        const int idx = tid + p * kNT;
+        if (idx >= TI * TJ) continue;
+        const int ci = idx % TI, cj = idx / TI, i = i0 + ci, j = j0 + cj;
+        const int o = cj * CW + ci, oe = o + 1, on = o + CW;
+        const double n_pp = cpp[o], n_ppe = cpp[oe], n_ppn = cpp[on], n_pk = cpk[o], n_pke = cpk[oe], n_pkn = cpk[on];
+        const double n_gz = cgz[o], n_gze = cgz[oe], n_gzn = cgz[on];
+        {
+          const double pp0 = pv[p][0], pp0e = pv[p][1], pp0n = pv[p][2], pk0 = pv[p][3], pk0e = pv[p][4], pk0n = pv[p][5];
+          const double gz0 = pv[p][6], gz0e = pv[p][7], gz0n = pv[p][8];
+          const double n_w = cw1[o], n_we = cw1[oe], n_wn = cw1[on];
+          const size_t lc = (size_t)(l > 0 ? l - 1 : 0);
+          const bool in = l > k0 && i <= g.ie + 1 && j <= g.je + 1;
+#if PGF_UVPRE
+          const double u0 = uo[p], v0 = vo[p];
+#else
+          const int iu = i < g.ie ? i : g.ie, ju = j < g.je + 1 ? j : g.je + 1, iv = i < g.ie + 1 ? i : g.ie + 1, jv = j < g.je ? j : g.je;
+          const double u0 = u[lc * nU + g.iU(iu, ju)], v0 = v[lc * nV + g.iV(iv, jv)];
+#endif
+          const double wk0 = n_pk - pk0, wke = n_pke - pk0e, wkn = n_pkn - pk0n;
+          const double du1 = dt / (wk0 + wke) * ((n_gz - gz0e) * (n_pke - pk0) + (gz0 - n_gze) * (n_pk - pk0e));
+          const double du2 = dt / (n_w + n_we) * ((n_gz - gz0e) * (n_ppe - pp0) + (gz0 - n_gze) * (n_pp - pp0e));
+          store_if(u + lc * nU, nU, g.iU(i, j), (u0 + du1 + du2) * rdu[p], in && i <= g.ie);
+          const double dv1 = dt / (wk0 + wkn) * ((n_gz - gz0n) * (n_pkn - pk0) + (gz0 - n_gzn) * (n_pk - pk0n));
+          const double dv2 = dt / (n_w + n_wn) * ((n_gz - gz0n) * (n_ppn - pp0) + (gz0 - n_gzn) * (n_pp - pp0n));
+          store_if(v + lc * nV, nV, g.iV(i, j), (v0 + dv1 + dv2) * rdv[p], in && j <= g.je);
+        }
+        pv[p][0] = n_pp; pv[p][1] = n_ppe; pv[p][2] = n_ppn; pv[p][3] = n_pk; pv[p][4] = n_pke; pv[p][5] = n_pkn;
+        pv[p][6] = n_gz; pv[p][7] = n_gze; pv[p][8] = n_gzn;
+      }
+    }
+  }
+};
+
+// three workgroups per CU (43 KB of LDS each): the register budget of three wavefronts per SIMD
+template <int TI, int TJ>
+struct tile_waves<NhPGradFused<TI, TJ>> { static constexpr int value = 3; };
 
 // ------------------------------------------------------------------------------------------------
 // pk3_halo / pln_halo: the 2-wide ring [is-2,ie+2]^2 minus the compute domain (dyn_core.F90:1395-1496)

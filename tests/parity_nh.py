@@ -253,7 +253,31 @@ def check_p_grad_c(lib, nx=24, ny=13, km=5, hydrostatic=False):
         ctx.close()
 
 
-def check_nh_p_grad(lib, nx=40, ny=19, km=5, grid=None):
+def check_nh_p_grad(lib, nx=40, ny=19, km=5, grid=None, out=None, fused=True):
+    """fused (the default where the domain has no face edges): NhPGradFused, a2b_ord4 and the gradient in one kernel; False
+    (FV3_MI355X_PGRAD_FUSED=0, read when the context is created): the corner values through memory"""
+    import os
+    saved = os.environ.pop("FV3_MI355X_PGRAD_FUSED", None)
+    if not fused:
+        os.environ["FV3_MI355X_PGRAD_FUSED"] = "0"
+    try:
+        return _check_nh_p_grad(lib, nx, ny, km, grid, out)
+    finally:
+        os.environ.pop("FV3_MI355X_PGRAD_FUSED", None)
+        if saved is not None:
+            os.environ["FV3_MI355X_PGRAD_FUSED"] = saved
+
+
+def check_nh_p_grad_fused_bits(lib, **dims):
+    """the one-kernel nh_p_grad against a2b_ord4 + the gradient: the same bits in u and v"""
+    a, b = {}, {}
+    check_nh_p_grad(lib, out=a, **dims)
+    check_nh_p_grad(lib, out=b, fused=False, **dims)
+    for n in a:
+        assert np.array_equal(a[n], b[n]), f"nh_p_grad {dims}: {n} of the fused kernel differs from the two-kernel path"
+
+
+def _check_nh_p_grad(lib, nx, ny, km, grid, out):
     bd = grid.bd if grid is not None else Bounds(1, nx, 1, ny)
     g = grid if grid is not None else P.make_grid(bd, True)
     s = nh_state(bd, km)
@@ -273,6 +297,8 @@ def check_nh_p_grad(lib, nx=40, ny=19, km=5, grid=None):
                        bd.view(o["u"], "U", bd.is_, bd.ie, bd.js, bd.je + 1), _tol(lib))
         P.assert_close("v", bd.view(d_v.download(), "V", bd.is_, bd.ie + 1, bd.js, bd.je),
                        bd.view(o["v"], "V", bd.is_, bd.ie + 1, bd.js, bd.je), _tol(lib))
+        if out is not None:
+            out.update(u=d_u.download(), v=d_v.download())
     finally:
         ctx.close()
 

@@ -596,6 +596,13 @@ def test_riem_solvers_fast_tau_w_sec(prod, a_imp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dims", [dict(), dict(nx=33, ny=9, km=3), dict(nx=70, ny=35, km=37), dict(nx=384, ny=96, km=127), dict(nx=64, ny=32, km=16), dict(nx=31, ny=15, km=17)])
+def test_nh_p_grad_in_one_kernel(prod, dims):
+    """NhPGradFused (a2b_ord4 of pp, pk, gz, delp and nh_p_grad in one kernel: the corner values never leave LDS) against the oracle and,
+    bit for bit, against the two-kernel path; tiles and layer chunks that end inside the domain / the column"""
+    N.check_nh_p_grad_fused_bits(prod, **dims)
+
+
 def test_consv_am(prod):
     """flagstruct%consv_am: compute_aam before and after the k_split loop, the reproducible sums, u00 and the wind correction
     (fv_dynamics.F90:358-361, :747-800, :1266-1314)"""
