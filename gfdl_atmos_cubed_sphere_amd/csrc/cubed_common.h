@@ -45,6 +45,8 @@ struct FramePass {
   int nbx, nby_sn;   // workgroup columns / rows of the south + north bands; the west + east workgroups follow in blockIdx.x
   const int *klist;
   F f;
+  int wc = 16;       // columns of a west / east workgroup's rows: 16 (x 16 rows), or 8 (x 32 rows) when neither band is wider than 8 points --
+                     // a 7-point band then leaves 1 lane in 8 idle instead of 9 in 16
   FV3_HD void operator()(int bflat, int, int bz, int tid, double *) const {
     const int k = klist ? klist[bz] : bz;
     const int js1 = w < j1 ? w : j1, jn0 = (npy - w) > j0 ? (npy - w) : j0;   // south band j0..js1, north band jn0..j1
@@ -53,13 +55,14 @@ struct FramePass {
     // ONE call site of the functor for both kinds of workgroup (inlined twice -- once per branch, the second inside a loop -- the
     // heavier passes took 3 - 4 times the registers of their whole-face form, BoxPass: 158 against 54 for CswCubedP3, 195 against 55
     // for DswCubedD5): the point (i, j) of round r is formed first, then the functor runs.
-    // South / north workgroup: 64 columns x 4 rows, one round.  West / east workgroup: 16 rows x 16 columns per round, the west
+    // South / north workgroup: 64 columns x 4 rows, one round.  West / east workgroup: 16 rows x 16 columns (32 x 8: wc) per round, the west
     // columns (i0 : w) or the east columns (npx - w : i1) of the rows between the bands.
     const bool sn = bflat < nsn;
     const int iw1 = w < i1 ? w : i1, ie0 = (npx - w) > i0 ? (npx - w) : i0;
     const int bw = bflat - nsn, side = bw & 1;
     const int ncol = sn ? 0 : (side ? i1 - ie0 + 1 : iw1 - i0 + 1);
-    const int rounds = sn ? 1 : (ncol + 15) / 16;
+    const int lg = wc == 8 ? 3 : 4;
+    const int rounds = sn ? 1 : (ncol + wc - 1) / wc;
     for (int t = tid; t < 256; t += kNT) {
       for (int r = 0; r < rounds; r++) {
         int i, j;
@@ -71,8 +74,8 @@ struct FramePass {
           i = i0 + bx * 64 + (t & 63);
           ok = i <= i1 && j <= j1;
         } else {
-          const int cc = (t & 15) + 16 * r;
-          j = js1 + 1 + (bw >> 1) * 16 + (t >> 4);
+          const int cc = (t & (wc - 1)) + wc * r;
+          j = js1 + 1 + (bw >> 1) * (256 >> lg) + (t >> lg);
           i = (side ? ie0 : i0) + cc;
           ok = j < jn0 && cc < ncol;
         }

@@ -1152,8 +1152,11 @@ static int launch_pass(fv3_ctx *c, const char *label, int i0, int i1, int j0, in
   const int js1 = rg.w < j1 ? rg.w : j1, jn0 = (g.npy - rg.w) > j0 ? (g.npy - rg.w) : j0;
   const int nsn = (js1 - j0 + 1) + (j1 - jn0 + 1), nmid = jn0 - js1 - 1;
   FramePass<F> kf{i0, i1, j0, j1, rg.w, g.npx, g.npy, (i1 - i0 + 64) / 64, (nsn + 3) / 4, rg.klist, f};
+  const int iw1 = rg.w < i1 ? rg.w : i1, ie0 = (g.npx - rg.w) > i0 ? (g.npx - rg.w) : i0;
+  kf.wc = (iw1 - i0 + 1 <= 8 && i1 - ie0 + 1 <= 8) ? 8 : 16;
+  const int we_rows = 256 / kf.wc;
   Dim3 grid;
-  grid.x = (unsigned)(kf.nbx * kf.nby_sn + (nmid > 0 ? 2 * ((nmid + 15) / 16) : 0));
+  grid.x = (unsigned)(kf.nbx * kf.nby_sn + (nmid > 0 ? 2 * ((nmid + we_rows - 1) / we_rows) : 0));
   grid.y = 1;
   grid.z = (unsigned)rg.nk;
   return launch_p(c, label, grid, 0, kf);

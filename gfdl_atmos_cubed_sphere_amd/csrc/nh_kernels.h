@@ -1131,10 +1131,6 @@ struct NhPGradFused {
   }
 };
 
-// three workgroups per CU (43 KB of LDS each): the register budget of three wavefronts per SIMD
-template <int TI, int TJ>
-struct tile_waves<NhPGradFused<TI, TJ>> { static constexpr int value = 3; };
-
 // ------------------------------------------------------------------------------------------------
 // pk3_halo / pln_halo: the 2-wide ring [is-2,ie+2]^2 minus the compute domain (dyn_core.F90:1395-1496)
 // The ring is 4 (nx + ny + 4) columns: they are enumerated compactly (a launch over the whole (nx + 4) x (ny + 4) box left two lanes
