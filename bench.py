@@ -73,9 +73,6 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--parity-columns", action="store_true",
                     help="(the default since round 4) whole-step legs with the parity (bit-comparable) column solvers")
-    ap.add_argument("--fast-columns", action="store_true",
-                    help="whole-step legs (SYPD) with the tolerance-mode column solvers (csrc/nh_fast.h: not bit-identical, w of a whole "
-                         "step is outside 1e-12) instead of the parity kernels; without it they are run once for the record")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--hord", type=int, default=10, help="hord_mt = hord_vt = hord_tm = hord_dp (reference default 10)")
     ap.add_argument("--no-model-step", action="store_true", help="skip the SYPD (whole model step) leg")
@@ -87,7 +84,7 @@ def parse():
                     help="FV3_MI355X_GEOM=0: read every metric row (what a cubed-sphere gridstruct needs) instead of "
                          "using the uniform-Cartesian kernels the library selects for this doubly periodic gridstruct")
     a = ap.parse_args()
-    a.parity_columns = not a.fast_columns
+    a.parity_columns = True   # the library has one mode of the column solvers (the tolerance mode of rounds 2 - 4 was removed in round 5)
     return a
 
 
@@ -181,21 +178,17 @@ def cpu_baseline(nx, seconds):
 
 
 class column_mode:
-    """FV3_MI355X_FAST for the contexts created inside: the whole-step legs run the column solvers in fast mode (nh_fast.h: the same
-    equations, blocked parallel scans, within 1e-12 of the parity kernels) unless --parity-columns; never leaks into later contexts"""
+    """(rounds 2 - 4: FV3_MI355X_FAST for the contexts created inside.  The tolerance mode is gone: the whole-step legs run the one mode the
+    library has, the column solvers in the reference's order)"""
 
     def __init__(self, fast):
-        self.fast = fast
+        self.fast = False
 
     def __enter__(self):
-        self.saved = os.environ.pop("FV3_MI355X_FAST", None)
-        if self.fast:
-            os.environ["FV3_MI355X_FAST"] = "1"
+        return self
 
     def __exit__(self, *exc):
-        os.environ.pop("FV3_MI355X_FAST", None)
-        if self.saved is not None:
-            os.environ["FV3_MI355X_FAST"] = self.saved
+        return False
 
 
 def whole_step_roofline(cells, wall_s, n_substeps, k_split, nq, hydrostatic=False):
@@ -289,9 +282,7 @@ def model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=True
         except (OSError, ValueError):
             pass
         col["remap"] = e
-    return {"column_solvers": "tolerance mode of the Riemann solvers and edge_profile (csrc/nh_fast.h: blocked parallel scans, NOT bit-identical; "
-                              "per call within 1e-12 of the parity kernels, whole steps: see fast_vs_parity)" if fast
-            else "parity kernels (bit-comparable with the oracle; the remap with the column in LDS is bit-identical to the slab kernels)",
+    return {"column_solvers": "parity kernels (bit-comparable with the oracle; the remap with the column in LDS is bit-identical to the slab kernels)",
             "_first_step_fields": first, "column_kernels": col, "geometry": {0: "general metric rows", 1: "orthogonal", 2: "orthogonal + uniform"}.get(geom_mode),
             "whole_step": whole_step_roofline(cells, wall, k_split * n_split, k_split, nq),
             "kernels_sum_ms": round(sum(v[1] for v in rep.values()), 2),
@@ -479,7 +470,7 @@ def sphere_steps(torch, stream, cs, gs, nx, npz, hydrostatic, k_split, n_split, 
                "kernel_breakdown": {"how": "six faces on one stream, eager launches, HIP events per launch", "wall_s": round(wall_one, 4),
                                     "kernels_sum_s": round(sum(kern_v for kern_v in _sum_reps(reps)), 4)},
                "k_split": k_split, "n_split": fl.n_split, "nq": 0, "cells": 6 * cells, "launch": graph_note,
-               "column_solvers": "tolerance mode (nh_fast.h)" if (fast and not hydrostatic) else "parity kernels",
+               "column_solvers": "parity kernels",
                "face_group": ("one launch per kernel for the six faces (fv3_group); launches of the profiled step that ran all faces "
                               f"at once / alone: {grp_stats[0]} / {grp_stats[1]}") if grp_stats else "off: six launches per kernel",
                "finite": bool(all(np.isfinite(x[c]).all() for x in dp)),
@@ -603,7 +594,7 @@ def cubed_six_ranks(a, torch, dist, rank, json_fd):
         out["sphere_six_gpus"] = {"grid": f"C{nx} L{npz}", "sypd": dt_atmos / (365.0 * wall), "wall_s_per_dt_atmos": wall,
                                   "dt_atmos_s": dt_atmos, "k_split": k_split, "n_split": n_split,
                                   "whole_step": whole_step_roofline(cells, wall, k_split * n_split, k_split, 0),
-                                  "column_solvers": "parity kernels" if a.parity_columns else "fast mode (nh_fast.h)",
+                                  "column_solvers": "parity kernels",
                                   "finite": bool(np.isfinite(fv.dc.d["delp"].download()[c]).all())}
     except Exception as e:  # noqa: BLE001
         out["sphere_six_gpus"] = {"error": f"{type(e).__name__}: {e}"}
@@ -885,25 +876,10 @@ def main():
     # N > 1: the SYPD leg is off unless asked for (a failure on one rank would leave the others in a collective)
     if not a.no_model_step and (world == 1 or a.model_step_multi):
         try:
-            # the SYPD is quoted with the PARITY column kernels (north_star's 1e-12 on whole steps holds for them by construction:
-            # bit-comparable with the oracle); the tolerance mode is run next to it for the record, with the distance of its fields
-            # from the parity run's after one dt_atmos from the same state
-            both = world == 1 and a.parity_columns
-            out["model_step"] = model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=not a.parity_columns, keep_fields=both)
-            ref = out["model_step"].pop("_first_step_fields")
-            if both:
-                tol = model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=True, keep_fields=True)
-                got = tol.pop("_first_step_fields")
-                dev = {}
-                for n in ref:
-                    num, den = float(np.sqrt(np.mean((got[n] - ref[n]) ** 2))), float(np.sqrt(np.mean(ref[n] ** 2)))
-                    dev[n] = num / den if den > 0 else num
-                del ref, got
-                out["model_step"]["tolerance_mode"] = {
-                    "sypd": tol["sypd"], "wall_s_per_dt_atmos": tol["wall_s_per_dt_atmos"], "column_solvers": tol["column_solvers"],
-                    "column_kernels": tol["column_kernels"], "fast_vs_parity": dev,
-                    "fast_vs_parity_note": "relative RMS difference of the prognostic fields after ONE dt_atmos (k_split 2 x n_split 5 "
-                                           "substeps + 2 remaps) from the same state, tolerance mode against parity kernels"}
+            # the SYPD is quoted with the library's one mode of the column kernels (north_star's 1e-12 on whole steps holds by
+            # construction: bit-comparable with the oracle)
+            out["model_step"] = model_step_leg(a, torch, dist, world, rank, px, py, bd, g, stream, fast=False, keep_fields=False)
+            out["model_step"].pop("_first_step_fields", None)
         except Exception as e:  # noqa: BLE001
             out["model_step"] = {"error": f"{type(e).__name__}: {e}"}
     out["cubed_sphere"] = None

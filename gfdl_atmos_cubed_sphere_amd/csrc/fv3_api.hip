@@ -157,7 +157,6 @@ struct fv3_ctx {
   int pgrad_fused;    // nh_p_grad as ONE kernel where the domain has no face edges (NhPGradFused; FV3_MI355X_PGRAD_FUSED=0: a2b_ord4 + the gradient)
   int riem_lds;       // the dry SIM1 Riemann solvers with the levels across the lanes, BIT-IDENTICAL to the slab kernels (nh_fast.h
                       // RiemFast<CG, true>; FV3_MI355X_RIEM_LDS: 0 / 1, default 1)
-  int fast;           // fast (tolerance) mode: FV3_MI355X_FAST=1 or fv3_set_fast -- nh_fast.h instead of the parity column solvers
   int remap_blocked;  // scratch slabs of the remap in per-wavefront blocks (FV3_MI355X_REMAP_SCR: 0 / 1, default 1)
   int remap_lds;      // the remap with the column in LDS (remap_fast.h; bit-identical to the slab kernels) where it is built for the
                       // configuration (FV3_MI355X_REMAP_LDS: 0 / 1, default 1)
@@ -595,9 +594,6 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     c->riem_lds = e ? (std::atoi(e) != 0) : 1;
     const char *ef = std::getenv("FV3_MI355X_PGRAD_FUSED");
     c->pgrad_fused = ef ? (std::atoi(ef) != 0) : 1;
-    e = std::getenv("FV3_MI355X_FAST");
-    c->fast = e ? std::atoi(e) : 0;   // 1 = every tolerance-mode kernel; otherwise a mask: 2 Riem_Solver_c, 4 Riem_Solver3, 8 edge_profile
-    if (c->fast == 1) c->fast = 14;
     e = std::getenv("FV3_MI355X_REMAP_SCR");
     c->remap_blocked = e ? (std::atoi(e) != 0) : 1;
     e = std::getenv("FV3_MI355X_REMAP_LDS");
@@ -607,7 +603,6 @@ extern "C" int fv3_create(const fv3_domain *dom, fv3_ctx **out) {
     if ((size_t)g.nB() * (size_t)(g.npz + 2) >= ((size_t)1 << 29)) {
       c->riem_lds = 0;
       c->remap_lds = 0;
-      c->fast &= ~6;
     }
     e = std::getenv("FV3_MI355X_MARCH_TJ_KE");
     c->march_tj_ke = e ? std::atoi(e) : 48;
@@ -3218,13 +3213,6 @@ extern "C" int fv3_set_condensate(fv3_ctx *c, const double *q_con, const double 
   return 0;
 }
 
-extern "C" int fv3_set_fast(fv3_ctx *c, int on) {
-  if (!c) return fail("fv3_set_fast: null context");
-  c->fast = on == 1 ? 14 : on;   // 1 = every tolerance-mode kernel; otherwise a mask (2 Riem_Solver_c, 4 Riem_Solver3, 8 edge_profile)
-  if ((size_t)c->g.nB() * (size_t)(c->g.npz + 2) >= ((size_t)1 << 29)) c->fast &= ~6;   // 32-bit field indices (nh_fast.h ix_t)
-  return 0;
-}
-
 extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn, const double *hs, const double *w3,
                                  const double *pt, const double *delp, double *gz, double *pef, const double *ws) {
   if (!c || !c->grid_ready || !cn) return fail("fv3_riem_solver_c: bad context/arguments");
@@ -3243,12 +3231,6 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn,
     return 0;
   }
   if (!c->q_con && c->g.npz <= 127 && c->g.npz >= 2) {   // Riem_Solver_c is SIM1 whatever a_imp is
-    if (c->fast & 2) {         // tolerance mode: blocked parallel scans
-      RiemFast<true> kf{c->g, c->g.npz, dt, to_consts(c, cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
-                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0};
-      RT(launch_p2(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
-      return 0;
-    }
     if (c->riem_lds) {         // the recurrences in the reference's order: the slab kernel's bits
       RiemFast<true, true> kf{c->g, c->g.npz, dt, to_consts(c, cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0};
@@ -3304,12 +3286,6 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
     return 0;
   }
   if (!c->q_con && !c->cappa && cn->a_imp > 0.999 && c->g.npz <= 127 && c->g.npz >= 2) {
-    if (c->fast & 4) {
-      RiemFast<false> kf{c->g, c->g.npz, dt, to_consts(c, cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
-                         use_logp, last_call, fp_out};
-      RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
-      return 0;
-    }
     if (c->riem_lds) {
       RiemFast<false, true> kf{c->g, c->g.npz, dt, to_consts(c, cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
                                use_logp, last_call, fp_out};
@@ -3346,11 +3322,7 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
   const Grid &g = c->g;
   const int km = g.npz;
   double *cxa = c->scratch[0], *xfa = c->scratch[1], *cya = c->scratch[2], *yfa = c->scratch[3];
-  using EPF = EdgeProfileFast<10>;
-  if ((c->fast & 8) && km >= 2 && km <= 512) {   // one sweep over k, the back substitution as truncated chains in registers (nh_fast.h)
-    EPF kf{g, km, c->ec, c->edge_dev + 3 * km, crx, xfx, cxa, xfa, (int)g.nCX(), cry, yfx, cya, yfa, (int)g.nCY()};
-    RT(launch_p(c, "edge_profile", col_grid(2 * (int)(g.nCX() + g.nCY())), EPF::lds_doubles(km), kf));
-  } else if (c->riem_lds && km >= 3 && km <= 127) {   // levels across the lanes, the elimination in the reference's order: the slab kernel's bits
+  if (c->riem_lds && km >= 3 && km <= 127) {   // levels across the lanes, the elimination in the reference's order: the slab kernel's bits
     EdgeProfileLds kf{g, km, c->ec, c->edge_dev + 3 * km, crx, xfx, cxa, xfa, (int)g.nCX(), cry, yfx, cya, yfa, (int)g.nCY()};
     RT(launch_p(c, "edge_profile", Dim3{(unsigned)kf.nblocks(), 1, 1}, 2 * kFBuf, kf));
   } else {

@@ -1,24 +1,22 @@
-// nh_fast.h -- the semi-implicit column solvers with the LEVELS ACROSS THE LANES (FV3_MI355X_FAST=1, the "fast mode" SURVEY 8(d) allows
-// beside the parity mode).
+// nh_fast.h -- the semi-implicit column solvers and edge_profile with the LEVELS ACROSS THE LANES, in the reference's order.
 //
-//   RiemFast<false>   Riem_Solver3   model/nh_core.F90:47-241   + SIM1_solver model/nh_utils.F90:1277-1394
+//   RiemFast<false>   Riem_Solver3   model/nh_core.F90:47-241   + SIM1_solver model/nh_utils.F90:1277-1394 / SIM_solver :1396-1537
 //   RiemFast<true>    Riem_Solver_c  model/nh_utils.F90:323-480 + SIM1_solver
+//   EdgeProfileLds    edge_profile   model/nh_utils.F90:1590-1696
 //
-// Why: the parity kernels (nh_kernels.h sim_column) run one thread per column with k sequential.  A 384 x 384 tile has 2 304 such
+// Why: the slab kernels (nh_kernels.h sim_column) run one thread per column with k sequential.  A 384 x 384 tile has 2 304 such
 // wavefronts for 1 024 SIMDs: 2.25 dependent instruction streams per SIMD, six sweeps through HBM scratch slabs (31 word accesses per
 // cell against 9 algorithmic) -- 10-13 % of their own roofline.  Here a 16-lane row of a wavefront owns ONE column, every
 // lane 8 consecutive levels of it (km <= 127), a wavefront 4 columns, a workgroup 16 consecutive columns of a row:
 //   * fields are read once with full 128-byte segments (16 columns x 8 B per level) and transposed through LDS; no scratch slabs;
-//   * everything that is pointwise in k (three log, three exp per cell, the matrix coefficients) is evaluated with the parity kernel's
+//   * everything that is pointwise in k (three log, three exp per cell, the matrix coefficients) is evaluated with the slab kernel's
 //     own expressions, 8 independent levels per lane;
-//   * the recurrences in k -- two tridiagonal solves, the pressure sum, the p1 recurrence of the new layer thickness, the height
-//     sum -- are linear-fractional / affine maps: each lane folds its 8 levels, the 16 lanes of a row combine the folds with a
-//     4-step scan of DPP row shifts, each lane replays its levels from the incoming value (Stone's recursive doubling, blocked);
-//   * the hydrostatic pressure pem(k) = ptop + sum delp: the lane's 8 levels in the reference's order on top of a scanned sum of the
-//     lanes above (a one-thread-per-column sum over LDS in the reference's order kept pk3 / pe / peln bit-identical but cost 19 k
-//     cycles per workgroup; the ulp it saves is below what one ulp of an interface height does to the perturbation pressure).
-// Not bit-identical to the oracle (the solves associate differently); held to it at 1e-12 relative RMS in the prognostic fields, measured
-// ~1e-14 (tests: test_riem_fast_*).  Dry, SIM1 (a_imp > 0.999), km <= 127; anything else takes the parity kernel.
+//   * the recurrences in k run in the reference's own order: hand-over rounds between the lanes for those that forget (tridiag_rounds),
+//     km / 8 + 1 rounds for the sums, one wavefront over LDS for the stiff w system (RiemFast::w_column) -- BIT-IDENTICAL to the slab
+//     kernels (DESIGN 3c "Round 4").
+// (Rounds 2 - 4 also carried a "tolerance mode" here -- the recurrences as blocked parallel scans, Stone's recursive doubling: same
+// equations, different association, 1e-14 per call but 2e-12 in w after a whole dt_atmos, outside north_star's 1e-12.  Removed in
+// round 5: the library has one mode, the one the oracle is held to bit for bit.)
 #pragma once
 
 #include "nh_kernels.h"
@@ -203,117 +201,8 @@ __device__ __forceinline__ vd row_shl1_v(vd a, vd fill) { return row_shl<1>(a, f
 // instead of the 14 of the compiler's IEEE division with its scale / fixup rescue): the same value as `a / b` here
 FV3_D vd vdivq(const vd &a, const vd &b) { return vdiv_r(a, b, vrecip(b)); }
 
-// ---- scans over the 16 lanes of a row --------------------------------------------------------------------------------------------
-// The lane's fold of its 8 levels is the affine map x -> A x + B.  Forward: on exit (A, B) is the composition of the folds of lanes
-// 0 .. m-1 of the row (EXCLUSIVE; identity for lane 0), i.e. the map from the value entering the column to the value entering lane m.
-template <int N>
-FV3_D void affine_step_fwd(vd &A, vd &B) {
-  const vd Ap = row_shr<N>(A, 1.0), Bp = row_shr<N>(B, 0.0);   // earlier lanes first: (A, B) o (Ap, Bp)
-  B = vfma(A, Bp, B);
-  A = A * Ap;
-}
-FV3_D void affine_scan_fwd_excl(vd &A, vd &B) {
-  affine_step_fwd<1>(A, B); affine_step_fwd<2>(A, B); affine_step_fwd<4>(A, B); affine_step_fwd<8>(A, B);
-  A = row_shr<1>(A, 1.0);
-  B = row_shr<1>(B, 0.0);
-}
-template <int N>
-FV3_D void affine_step_bwd(vd &A, vd &B) {
-  const vd Ap = row_shl<N>(A, 1.0), Bp = row_shl<N>(B, 0.0);   // the lanes BELOW are applied first when marching upwards
-  B = vfma(A, Bp, B);
-  A = A * Ap;
-}
-FV3_D void affine_scan_bwd_excl(vd &A, vd &B) {
-  affine_step_bwd<1>(A, B); affine_step_bwd<2>(A, B); affine_step_bwd<4>(A, B); affine_step_bwd<8>(A, B);
-  A = row_shl<1>(A, 1.0);
-  B = row_shl<1>(B, 0.0);
-}
-FV3_D vd sum_scan_fwd_excl(vd s) {   // sum of the lane totals of lanes 0 .. m-1
-  s = s + row_shr<1>(s, 0.0); s = s + row_shr<2>(s, 0.0); s = s + row_shr<4>(s, 0.0); s = s + row_shr<8>(s, 0.0);
-  return row_shr<1>(s, 0.0);
-}
-FV3_D vd sum_scan_bwd_excl(vd s) {
-  s = s + row_shl<1>(s, 0.0); s = s + row_shl<2>(s, 0.0); s = s + row_shl<4>(s, 0.0); s = s + row_shl<8>(s, 0.0);
-  return row_shl<1>(s, 0.0);
-}
-// 2 x 2 matrices [[p, q], [r, s]] (the linear-fractional map of the Thomas pivot); later o earlier = matrix product; scaled to
-// max |entry| = 1 after every product (a Moebius map does not care, the product of 128 pivots would overflow)
-struct Mob {
-  vd p, q, r, s;
-};
-FV3_D void mob_norm(Mob &m) {
-  const vd sc = vrcp(vmax(vmax(vabs(m.p), vabs(m.q)), vmax(vabs(m.r), vabs(m.s))));
-  m.p = m.p * sc; m.q = m.q * sc; m.r = m.r * sc; m.s = m.s * sc;
-}
-template <int N>
-FV3_D void mob_step_fwd(Mob &m) {
-  const vd pp = row_shr<N>(m.p, 1.0), qp = row_shr<N>(m.q, 0.0), rp = row_shr<N>(m.r, 0.0), sp = row_shr<N>(m.s, 1.0);
-  Mob o;
-  o.p = vfma(m.p, pp, m.q * rp);
-  o.q = vfma(m.p, qp, m.q * sp);
-  o.r = vfma(m.r, pp, m.s * rp);
-  o.s = vfma(m.r, qp, m.s * sp);
-  m = o;
-  mob_norm(m);
-}
-
-// Tridiagonal systems of one column, 8 rows per lane (rows beyond the system: a = c = d = 0, b = 1; a of the first row and c of the
-// last row are 0):   a_k x_{k-1} + b_k x_k + c_k x_{k+1} = d_k.   x may alias d.
-FV3_D void tridiag_rows(const vd *a, const vd *b, const vd *c, const vd *d, vd *x) {
-  vd e[kFL], rbet[kFL];
-  // e_k = a_k c_{k-1}: the pivot recurrence bet_k = b_k - e_k / bet_{k-1}
-  e[0] = a[0] * row_shr<1>(c[kFL - 1], 0.0);
-  for (int q = 1; q < kFL; q++) e[q] = a[q] * c[q - 1];
-  // (n, d) -> (b n - e d, n): fold the lane's 8 levels
-  Mob m;
-  m.p = b[0]; m.q = -e[0]; m.r = vd(1.0); m.s = vd(0.0);
-  for (int q = 1; q < kFL; q++) {
-    const vd np = vfma(b[q], m.p, -(e[q] * m.r)), nq = vfma(b[q], m.q, -(e[q] * m.s));
-    m.r = m.p; m.s = m.q;
-    m.p = np; m.q = nq;
-  }
-  mob_norm(m);
-  mob_step_fwd<1>(m); mob_step_fwd<2>(m); mob_step_fwd<4>(m); mob_step_fwd<8>(m);
-  // pivot entering the lane = (inclusive product of the lanes before) applied to (1, 0): bet = p / r, kept as its reciprocal
-  const vd pin = row_shr<1>(m.p, 1.0), rin = row_shr<1>(m.r, 0.0);
-  vd rb = rin * vrcp(pin);
-  for (int q = 0; q < kFL; q++) {
-    rb = vrcp(vfma(-e[q], rb, b[q]));
-    rbet[q] = rb;
-  }
-  // forward substitution y_k = (d_k - a_k y_{k-1}) / bet_k
-  {
-    vd A(1.0), B(0.0);
-    for (int q = 0; q < kFL; q++) {
-      const vd al = -(a[q] * rbet[q]), be = d[q] * rbet[q];
-      B = vfma(al, B, be);
-      A = al * A;
-    }
-    affine_scan_fwd_excl(A, B);
-    vd y = B;   // the value entering the column is 0
-    for (int q = 0; q < kFL; q++) {
-      y = (d[q] - a[q] * y) * rbet[q];
-      x[q] = y;
-    }
-  }
-  // back substitution x_k = y_k - (c_k / bet_k) x_{k+1}
-  {
-    vd A(1.0), B(0.0);
-    for (int q = kFL - 1; q >= 0; q--) {
-      const vd g = -(c[q] * rbet[q]);
-      B = vfma(g, B, x[q]);
-      A = g * A;
-    }
-    affine_scan_bwd_excl(A, B);
-    vd xn = B;
-    for (int q = kFL - 1; q >= 0; q--) {
-      xn = x[q] - (c[q] * rbet[q]) * xn;
-      x[q] = xn;
-    }
-  }
-}
-
-// The same systems in the REFERENCE'S ORDER, bit for bit (RiemFast<CG, true>; the idea of remap_fast.h spline()): row k is
+// Tridiagonal systems of one column, 8 rows per lane (rows beyond the system: a = c = d = 0, b = 1; a of the first row and c of the last
+// row are 0):   a_k x_{k-1} + b_k x_k + c_k x_{k+1} = d_k,   in the REFERENCE'S ORDER, bit for bit (RiemFast<CG, true>; the idea of remap_fast.h spline()): row k is
 //     bet_k = b_k - a_k gam_k,   gam_(k+1) = c_k / bet_k,   y_k = (d_k - a_k y_(k-1)) / bet_k        (downwards)
 //     x_k = y_k - gam_(k+1) x_(k+1)                                                                  (upwards)
 // with a_k = 1 (x * 1 is exact) or 0 (first row, padded rows: b = 1, c = d = 0).  A lane runs its 8 rows from the value the lane above
@@ -368,120 +257,6 @@ FV3_D void tridiag_rounds(const vd *a, const vd *b, const vd *c, const vd *d, vd
     }
   }
 }
-
-// edge_profile (model/nh_utils.F90:1590-1696, non-uniform branch, limiter = 0) in ONE sweep over k.  The parity kernel (nh_kernels.h
-// EdgeProfile) eliminates downwards, stores the intermediate interface values, and substitutes back upwards through them: 16 field
-// passes through HBM for 8 algorithmic ones.  The coefficients depend on dp0 only, and the back substitution
-//   x_k = y_k - gam_k x_{k+1} = y_k - gam_k (y_{k+1} - gam_{k+1} (y_{k+2} - ...))
-// forgets: the product of 31 consecutive gam is below 2e-18 for the L79 / L127 levels (0.27 per level away from the top).  So a thread
-// -- one per (column, field) -- keeps the last 40 forward values of its column in registers, and every 8 levels, at level k, starts the
-// chain at y_k, runs it 31 steps down without emitting and 8 more steps emitting interfaces k-31 .. k-38 (17 operations per level;
-// exact for the last interfaces: beyond km + 1 the chain runs over virtual levels with y = 0, gam = 0).  Every input is read once,
-// every output written once.  What bounds such a kernel is the loads a thread keeps in flight: the inputs come through a rolling
-// buffer of kPre levels (slot (k-1) % kPre is refilled with level k-1+kPre as soon as level k-1 is taken; clamped addresses, no
-// branch around a load, so the wait counts stay exact), the per-level coefficients -- the same for every column -- from an LDS table
-// (as global loads they would sit in the same in-order queue as the prefetches).
-// The quotients by bet(k) through the host's correctly rounded reciprocal and a Markstein correction (the value of `/`: a plain
-// multiplication by the reciprocal moved zh by 2e-13 through the limiter switches of its transport).
-// Against the parity kernel: 3e-17 rel-RMS on zh at L79 / L127 (test_edge_profile_fast_against_the_oracle).
-FV3_HD double edge_div(double a, double b, double rb) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  const double q0 = a * rb;
-  const double r = __builtin_fma(-b, q0, a);
-  return __builtin_fma(r, rb, q0);
-#else
-  (void)rb;
-  return a / b;
-#endif
-}
-template <int kPre>
-struct EdgeProfileFast {
-  static constexpr int kWin = 40, kUnit = 8, kSkip = 31;   // window slots; levels per back substitution; steps before the first emitted
-  static_assert(kWin % kPre == 0 && kWin % kUnit == 0 && kSkip + kUnit <= kWin - 1, "window");
-  Grid g;
-  int km;
-  EdgeCoef ec;
-  const double *rbet;     // device, km: 1 / ec.bet correctly rounded
-  const double *q1, *q2;
-  double *q1e, *q2e;
-  int n2d;
-  const double *q1_b, *q2_b;
-  double *q1e_b, *q2e_b;
-  int n2d_b;
-  // levels the sweep runs over: whole windows, and every interface up to km + 1 emitted (interface j leaves at level j + kSkip .. )
-  FV3_HD static int kpad(int km) { return (km + 1 + kSkip + kUnit - 1 + kWin - 1) / kWin * kWin; }
-  static size_t lds_doubles(int km) { return (size_t)3 * kpad(km) + kWin + kpad(km); }
-  FV3_HD void operator()(int bx, int, int, int tid, double *lds) const {
-    const int nk = km + 1, kp = kpad(km);
-    // table[k - 1]: gk, bet, 1 / bet of level k (k = 1: the top closure; k = km + 1: the bottom one; beyond: 1), gam with kWin zeros in front
-    double *t_gk = lds, *t_bet = t_gk + kp, *t_rb = t_bet + kp, *t_gam = t_rb + kp;
-    const double xt2 = ec.gk_bot * (ec.gk_bot + 0.5) - ec.a_bot * ec.gam[km - 1];
-    for (int i = tid; i < kp; i += kNT) {
-      const bool in = i >= 1 && i < km;
-      t_gk[i] = in ? ec.gk[i] : 0.;
-      t_bet[i] = in ? ec.bet[i] : (i == 0 ? ec.bet_top : (i == km ? xt2 : 1.));
-      t_rb[i] = in ? rbet[i] : (i == 0 ? 1. / ec.bet_top : (i == km ? 1. / xt2 : 1.));
-    }
-    for (int i = tid; i < kp + kWin; i += kNT) t_gam[i] = (i >= kWin && i < kWin + km) ? ec.gam[i - kWin] : 0.;
-    FV3_SYNC();
-    const int ntot = 2 * (n2d + n2d_b);
-    for (int vt = bx * 256 + tid; vt < (bx + 1) * 256 && vt < ntot; vt += kNT) {
-      const bool second = vt >= 2 * n2d;
-      const int r = second ? vt - 2 * n2d : vt, ls_i = second ? n2d_b : n2d;
-      const int f = r >= ls_i ? 1 : 0, c = r - f * ls_i;
-      const size_t ls = (size_t)ls_i;
-      const double *__restrict__ p = second ? (f ? q2_b : q1_b) : (f ? q2 : q1);
-      double *__restrict__ o = second ? (f ? q2e_b : q1e_b) : (f ? q2e : q1e);
-      double y[kWin], nb[kPre];
-      for (int t = 0; t < kWin; t++) y[t] = 0.;
-#ifndef FV3_HOST_EMU
-#pragma unroll
-#endif
-      for (int t = 0; t < kPre; t++) nb[t] = p[(size_t)(t < km ? t : km - 1) * ls + c];
-      double a_prev = nb[0], a_cur = a_prev, e = 0.;
-      for (int k0 = 0; k0 < kp; k0 += kWin) {
-#ifndef FV3_HOST_EMU
-#pragma unroll
-#endif
-        for (int u = 0; u < kWin / kUnit; u++) {
-#ifndef FV3_HOST_EMU
-#pragma unroll
-#endif
-         for (int i = 0; i < kUnit; i++) {
-          const int t = u * kUnit + i, k = k0 + t + 1;
-          const double a_new = k == 1 ? nb[1 % kPre] : nb[t % kPre];   // level k - 1 (0-based), slot (k - 1) % kPre; k = 1: levels 0 and 1
-          a_cur = k <= km ? a_new : a_cur;
-          {                                        // level k - 1 is taken (k = 1: level 0, into a_prev): refill its slot
-            const int kn = k - 1 + kPre;
-            nb[t % kPre] = p[(size_t)(kn < km ? kn : km - 1) * ls + c];
-          }
-          const double gk = t_gk[k - 1], bt = t_bet[k - 1], rb = t_rb[k - 1];
-          const double num_i = 3. * (a_prev + gk * a_cur) - e;
-          const double num_1 = ec.xt1_top * a_prev + a_cur;
-          const double num_n = ec.xt1_bot * a_cur + a_prev - ec.a_bot * e;   // a_prev = q(km-1), a_cur = q(km)
-          const double num = k == 1 ? num_1 : (k == nk ? num_n : num_i);
-          const double en = edge_div(num, bt, rb);
-          e = k <= nk ? en : 0.;
-          a_prev = (k >= 2 && k < km) ? a_cur : a_prev;
-          y[t] = e;
-         }
-         {                                         // back substitution from level k: interfaces k - kSkip - kUnit + 1 .. k - kSkip leave
-          const int t = u * kUnit + kUnit - 1, k = k0 + t + 1;
-          double x = e;
-#ifndef FV3_HOST_EMU
-#pragma unroll
-#endif
-          for (int m = 1; m < kSkip + kUnit; m++) {
-            const int j = k - m;                   // interface of this step
-            x = y[(t - m + kWin) % kWin] - t_gam[j - 1 + kWin] * x;
-            if (m >= kSkip && j >= 1 && j <= nk) o[(size_t)(j - 1) * ls + c] = x;
-          }
-         }
-        }
-      }
-    }
-  }
-};
 
 // edge_profile with the LEVELS ACROSS THE LANES and the elimination in the reference's order: BIT-IDENTICAL to the slab kernel
 // (nh_kernels.h EdgeProfile) and the library's default (km <= 127).  A workgroup takes 16 consecutive columns of one of the two field
@@ -618,7 +393,7 @@ struct EdgeProfileLds {
 
 // CG = true: Riem_Solver_c on (is-1:ie+1, js-1:je+1); false: Riem_Solver3 on the compute domain
 //
-// EX = true (round 4): BIT-IDENTICAL to the parity kernels (nh_kernels.h sim_column), and the library's default for the dry SIM1 solver.
+// BIT-IDENTICAL to the slab kernels (nh_kernels.h sim_column) (EX: kept as a template argument of the instantiations, always true).
 // Everything pointwise in k already was the parity kernel's expression; what differed were the recurrences in k.  They now run in the
 // reference's own order:
 //   * the sums (hydrostatic pressure downwards, pe2 downwards, p1 and the heights upwards): a lane runs its 8 levels from the value
@@ -631,10 +406,10 @@ struct EdgeProfileLds {
 //     buffers, free by then) and ONE wavefront of the workgroup runs the 16 columns of the workgroup on 16 lanes, a lane per column,
 //     with the parity kernel's own statements (rcp_rn / div_rn); the other wavefronts wait at the barrier -- the second workgroup of
 //     the CU has the SIMDs meanwhile.
-template <bool CG, bool EX = false, bool SIM = false, bool MOIST = false>
+template <bool CG, bool EX = true, bool SIM = false, bool MOIST = false>
 struct RiemFast {
-  static_assert(!SIM || (EX && !CG), "SIM_solver: the D grid's Riem_Solver3 in the reference's order");
-  static_assert(!MOIST || EX, "use_cond / moist_kappa: in the reference's order only");
+  static_assert(EX, "the tolerance mode (blocked parallel scans, not bit-identical: whole steps left 1e-12) was removed in round 5");
+  static_assert(!SIM || !CG, "SIM_solver: the D grid's Riem_Solver3");
   Grid g;
   int km;
   double dt;
@@ -774,8 +549,8 @@ struct RiemFast {
     const double t1g = SIM ? 2. * ((alpha * dt) * (alpha * dt)) : 2. * dt * dt, rdt = 1. / dt;
     constexpr double r3 = 1. / 3.;
     vd dmr[kWvState][kFL], ptv[kWvState][kFL], w1[kWvState][kFL], zv[kWvState][kFL + 1];
-    vd keep_pm2[kWvState][kFL], keep_grat[kWvState][kFL], keep_w2[kWvState][kFL];
-    vd keep_pem[kWvState][kFL + 1], keep_lnp[kWvState][kFL + 1], keep_ppt[kWvState][SIM ? kFL + 1 : 1];
+    vd keep_pm2[kWvState][kFL], keep_grat[kWvState][kFL];
+    vd keep_pem[kWvState][kFL + 1], keep_ppt[kWvState][SIM ? kFL + 1 : 1];
     const int nrounds = (probe & 1) ? 1 : km / kFL + 1;   // EX: rounds after which the hand-overs of a sequential sweep over km levels are the sweep's own
     // ---- inputs: the four fields at once (their loads are in flight together), one barrier ----
     {
@@ -837,7 +612,7 @@ struct RiemFast {
       }
       {  // hydrostatic pressure at the interfaces: pem(k+1) = pem(k) + delp(k) (nh_core.F90:132-141 / nh_utils.F90:404-441), the
          // lane's 8 levels in the reference's order on top of the scanned sum of the lanes above
-        if constexpr (EX) {
+        {
           vd in(cn.ptop);
           for (int rnd = 0; rnd < nrounds; rnd++) {
             vd run = in;
@@ -848,15 +623,6 @@ struct RiemFast {
             pemv[kFL] = run;
             in = row_shr<1>(run, cn.ptop);
           }
-        } else {
-          vd tot(0.0);
-          for (int q = 0; q < kFL; q++) tot = tot + dmr[s][q];
-          vd run = cn.ptop + sum_scan_fwd_excl(tot);
-          for (int q = 0; q < kFL; q++) {
-            pemv[q] = run;
-            run = run + dmr[s][q];
-          }
-          pemv[kFL] = run;
         }
       }
       // hydrostatic pressure functions, perturbation pressure (nh_utils.F90:1297-1300; nh_core.F90:140-159 / nh_utils.F90:440)
@@ -924,10 +690,7 @@ struct RiemFast {
           d[q] = vsel(real[q], dd, vd(0.0));
           bb[q] = vsel(real[q], bb[q], vd(1.0));
         }
-        if constexpr (EX)
-          tridiag_rounds(a, bb, c, d, X, (probe & 4) ? 1 : 16);
-        else
-          tridiag_rows(a, bb, c, d, X);
+        tridiag_rounds(a, bb, c, d, X, (probe & 4) ? 1 : 16);
       }
       // ---- w: nh_utils.F90:1335-1361 ----
       {
@@ -968,7 +731,7 @@ struct RiemFast {
             d[q] = vsel(real[q], vsel(last[q], rhs - p1c * wsv, rhs), vd(0.0));
           }
         }
-        if constexpr (EX) {
+        {
           // coefficients of the workgroup's 16 columns -> LDS: aa at the top interface of every layer (the model's bottom interface
           // carries p1 of the bottom layer: the "aa below" of that row), dm, the right-hand side
           for (int q = 0; q < kFL; q++) {
@@ -978,8 +741,6 @@ struct RiemFast {
           }
           for (int q = 0; q < kFL; q++)
             vlds_st_next_if(B0, c0, q, MOIST ? vdivq(t1g * gm2q[MOIST ? q : 0], dz[q]) * pemv[q + 1] : vdivq(vd(t1g * gm2), dz[q]) * pemv[q + 1], last[q]);
-        } else {
-          tridiag_rows(a, b, c, d, keep_w2[s]);
         }
       }
       // what the second half needs stays in the per-wavefront state (registers in the product build) across the barriers of EX
@@ -990,10 +751,8 @@ struct RiemFast {
       }
       for (int q = 0; q <= kFL; q++) keep_pem[s][q] = pemv[q];
       if (!CG) {
-        if constexpr (EX) {
+        {
           for (int q = 0; q < kFL; q++) vlds_st(B3, c0, q, lnp[q]);
-        } else {
-          for (int q = 0; q <= kFL; q++) keep_lnp[s][q] = lnp[q];
         }
       }
       if constexpr (SIM) {   // pp at the layer's top interface (0 at the model top) and at its bottom interface
@@ -1001,7 +760,7 @@ struct RiemFast {
         for (int q = 0; q < kFL; q++) keep_ppt[s][q + 1] = X[q];
       }
     }
-    if constexpr (EX) {
+    {
       FV3_SYNC_LDS();
       if (!(probe & 2)) w_columns(B0, B1, B2, (bx + by) & 3, tid);
       FV3_SYNC_LDS();
@@ -1018,19 +777,14 @@ struct RiemFast {
         pm2[q] = keep_pm2[s][q]; grat[q] = keep_grat[s][q];
         dm[q] = dmr[s][q] * rgrav;
         bb[q] = vsel(real[q], vsel(last[q], vd(2.0), 2. * (1. + grat[q])), vd(1.0));
-        if constexpr (EX)
-          w2[q] = vsel(real[q], vlds_ld(B2, c0, q), vd(0.0));
-        else
-          w2[q] = keep_w2[s][q];
+        w2[q] = vsel(real[q], vlds_ld(B2, c0, q), vd(0.0));
         if (cn.rff) w2[q] = w2[q] * vrow_ld(cn.rff, q, km);   // fast_tau_w_sec: w2(k) * rff(k) behind the back substitution (nh_utils.F90:1363-1371)
       }
       for (int q = 0; q <= kFL; q++) pemv[q] = keep_pem[s][q];
       if (!CG) {
-        if constexpr (EX) {
+        {
           for (int q = 0; q < kFL; q++) lnp[q] = vlds_ld(B3, c0, q);
           lnp[kFL] = row_shl<1>(lnp[0], 0.0);
-        } else {
-          for (int q = 0; q <= kFL; q++) lnp[q] = keep_lnp[s][q];
         }
       }
       // ---- pe2 at the interfaces (:1373-1380): exclusive sum of dm2 (w2 - w1) / dt ----
@@ -1044,8 +798,8 @@ struct RiemFast {
             inc[q] = vsel(real[q], dm[q] * (w2[q] - w1[s][q]) * rdt, vd(0.0));
           tot = tot + inc[q];
         }
-        vd run = EX ? vd(0.0) : sum_scan_fwd_excl(tot);
-        if constexpr (EX) {   // pe(k+1) = pe(k) + inc(k) from 0, in the reference's order
+        vd run(0.0);
+        {   // pe(k+1) = pe(k) + inc(k) from 0, in the reference's order
           vd in(0.0);
           for (int rnd = 0; rnd < nrounds; rnd++) {
             run = in;
@@ -1054,11 +808,6 @@ struct RiemFast {
               run = run + inc[q];
             }
             in = row_shr<1>(run, 0.0);
-          }
-        } else {
-          for (int q = 0; q < kFL; q++) {
-            pe2[q] = run;
-            run = run + inc[q];
           }
         }
         pe2[kFL] = row_shl<1>(pe2[0], 0.0);
@@ -1077,7 +826,7 @@ struct RiemFast {
           Bq[q] = vsel(real[q], vsel(last[q], Bl, Bi), vd(0.0));
         }
         vd p1v[kFL];
-        if constexpr (EX) {   // upwards from the bottom layer (its row takes nothing from below), in the reference's order
+        {   // upwards from the bottom layer (its row takes nothing from below), in the reference's order
           vd in(0.0);
           for (int rnd = 0; rnd < nrounds; rnd++) {
             vd p1 = in;
@@ -1086,18 +835,6 @@ struct RiemFast {
               p1v[q] = p1;
             }
             in = row_shl<1>(p1, 0.0);
-          }
-        } else {
-          vd A(1.0), B(0.0);
-          for (int q = kFL - 1; q >= 0; q--) {
-            B = vfma(Aq[q], B, Bq[q]);
-            A = Aq[q] * A;
-          }
-          affine_scan_bwd_excl(A, B);
-          vd p1 = B;
-          for (int q = kFL - 1; q >= 0; q--) {
-            p1 = Bq[q] + Aq[q] * p1;
-            p1v[q] = p1;
           }
         }
         for (int q = kFL - 1; q >= 0; q--)
@@ -1112,7 +849,7 @@ struct RiemFast {
           tot = tot + (CG ? dzn[q] * cn.grav : dzn[q]);
         }
         const vd zsv = vcol_ld(zs, (long)o0, c0, ncol);
-        if constexpr (EX) {   // zh(k) = zh(k+1) - dz2(k) from the surface, in the reference's order (padded layers subtract 0)
+        {   // zh(k) = zh(k+1) - dz2(k) from the surface, in the reference's order (padded layers subtract 0)
           vd in = zsv;
           for (int rnd = 0; rnd < nrounds; rnd++) {
             vd run = in;
@@ -1121,12 +858,6 @@ struct RiemFast {
               zn[q] = run;
             }
             in = row_shl1_v(run, zsv);
-          }
-        } else {
-          vd run = zsv - sum_scan_bwd_excl(tot);     // height of the interface below the lane's last layer
-          for (int q = kFL - 1; q >= 0; q--) {
-            run = run - (CG ? dzn[q] * cn.grav : dzn[q]);
-            zn[q] = run;
           }
         }
         // interface km (the surface) sits at (lane km / 8, q = km % 8): there every layer below is padding and run == zs

@@ -1,5 +1,5 @@
 // remap_fast.h -- Lagrangian_to_Eulerian (model/fv_mapz.F90:56-845) with the column in LDS and the LEVELS ACROSS THE LANES
-// (FV3_MI355X_FAST=1 / fv3_set_fast, the tolerance mode of SURVEY 8(d) beside the parity kernels of remap_kernels.h).
+// (the default where it is built; the slab kernels of remap_kernels.h take everything else: FV3_MI355X_REMAP_LDS).
 //
 // Why: RemapFields runs one thread per (column, field) with k sequential and keeps the spline's work arrays (a1, q, gam, a2..a4) in
 // HBM slabs: 7 slab words written and read back per cell and field against 2 algorithmic ones, two or three dependent sweeps of 127

@@ -308,12 +308,8 @@ int fv3_update_dz_c(fv3_ctx *ctx, double dt, const double *zs, const double *ut,
  * uses cappa only together with q_con. */
 int fv3_set_condensate(fv3_ctx *ctx, const double *q_con, const double *cappa);
 
-/* Precision mode of the column solvers.  0 (default): the parity kernels -- the reference's elimination order, bit-comparable with
- * the CPU oracle.  1: fast mode ("a fast mode beside the parity mode"): Riem_Solver_c / Riem_Solver3 with the levels
- * across the lanes and the tridiagonal / prefix recurrences as blocked parallel scans (csrc/nh_fast.h) -- same equations, different
- * association, within 1e-12 relative RMS of the parity mode.  Also selected by the environment variable FV3_MI355X_FAST=1 at fv3_create.
- * Moist (fv3_set_condensate) and a_imp <= 0.999 calls take the parity kernels in either mode. */
-int fv3_set_fast(fv3_ctx *ctx, int on);
+/* (Rounds 2 - 4 had a second, tolerance mode of the column solvers -- fv3_set_fast / FV3_MI355X_FAST: blocked parallel scans, within 1e-12 per call
+ * but 2e-12 in w after a whole dt_atmos.  Removed in round 5: one mode, the reference's elimination order, bit-comparable with the CPU oracle.) */
 
 /* flagstruct%fast_tau_w_sec > 0: the Rayleigh damping of w inside SIM1_solver / SIM_solver (model/nh_utils.F90:1363-1371, :1498-1506;
  * the call sites hand the flag to both solvers, dyn_core.F90:536, :940).  rff: HOST array of k_rf values, the profile Riem_Solver_c

@@ -74,7 +74,7 @@ def tau_w_profile(km, dt_c, tau_w=25.0):
     return rff
 
 
-def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, moist_kappa=False, fast=False, lds=True, out=None, m_split=1,
+def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, moist_kappa=False, lds=True, out=None, m_split=1,
                         tau_w=0.0):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
@@ -104,13 +104,12 @@ def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, mois
     ctx = _riem_context(g, km, lib, lds)
     try:
         d_gz, d_pef = ctx.from_host(s["zh"]), ctx.zeros("A", km + 1)
-        ctx.set_fast(fast)          # fast mode (csrc/nh_fast.h): held to the oracle at 1e-12, not bit for bit
         ctx.set_condensate(ctx.from_host(q_con) if use_cond else None, ctx.from_host(cappa) if moist_kappa else None)
         ctx.set_fast_tau_w(rff)
         ctx.riem_solver_c(3.0, cn, ctx.from_host(hs), ctx.from_host(s["w"]), ctx.from_host(s["pt"]),
                           ctx.from_host(s["delp"]), d_gz, d_pef, ctx.from_host(ws))
         r = (bd.is_ - 1, bd.ie + 1, bd.js - 1, bd.je + 1)
-        tol = 1e-12 if fast else _tol(lib)
+        tol = _tol(lib)
         e1 = P.assert_close("gz", bd.view(d_gz.download(), "A", *r), bd.view(gz, "A", *r), tol)
         e2 = P.assert_close("pef", bd.view(d_pef.download(), "A", *r), bd.view(pef, "A", *r), tol)
         if out is not None:
@@ -121,7 +120,7 @@ def check_riem_solver_c(lib, nx=24, ny=13, km=8, a_imp=1.0, use_cond=False, mois
 
 
 def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_call=True, fp_out=False, use_cond=False,
-                       moist_kappa=False, fast=False, lds=True, out=None, m_split=1, tau_w=0.0):
+                       moist_kappa=False, lds=True, out=None, m_split=1, tau_w=0.0):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     s = nh_state(bd, km)
@@ -157,7 +156,6 @@ def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_
     ctx = _riem_context(g, km, lib, lds)
     worst = 0.0
     try:
-        ctx.set_fast(fast)
         ctx.set_condensate(ctx.from_host(q_con) if use_cond else None, ctx.from_host(cappa) if moist_kappa else None)
         d = {k: ctx.from_host(v) for k, v in dict(w=s["w"], zh=s["zh"], delz=bd.zeros("CC", km),
                                                    ppe=bd.zeros("A", km + 1), pk3=bd.full("A", 1e40, km + 1),
@@ -169,7 +167,7 @@ def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_
                          ctx.from_host(s["delp"]), d["zh"], d["pe"], d["ppe"], d["pk3"], d["pk"], d["peln"],
                          ctx.from_host(ws), use_logp, last_call, fp_out)
         r = (bd.is_, bd.ie, bd.js, bd.je)
-        tol = 1e-12 if fast else _tol(lib)
+        tol = _tol(lib)
         for n in ("w", "zh", "ppe", "pk3"):
             worst = max(worst, P.assert_close(n, bd.view(d[n].download(), "A", *r), bd.view(o[n], "A", *r), tol))
         worst = max(worst, P.assert_close("delz", d["delz"].download(), o["delz"], tol))
@@ -186,7 +184,7 @@ def check_riem_solver3(lib, nx=24, ny=13, km=8, a_imp=1.0, use_logp=False, last_
     return worst
 
 
-def check_update_dz_d(lib, nx=40, ny=19, km=5, lev_over=None, hord=10, fast=False, lds=True, out=None):
+def check_update_dz_d(lib, nx=40, ny=19, km=5, lev_over=None, hord=10, lds=True, out=None):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, True)
     s = nh_state(bd, km)
@@ -207,14 +205,12 @@ def check_update_dz_d(lib, nx=40, ny=19, km=5, lev_over=None, hord=10, fast=Fals
     try:
         ctx.set_dp_ref(s["dp0"])
         ctx.dsw_levels(lev)
-        if fast:     # edge_profile in one sweep (nh_fast.h EdgeProfileFast): rounding-level differences
-            ctx.set_fast(True)
         d_out, d_ws = ctx.zeros("A", km + 1), ctx.zeros("CC")
         ctx.update_dz_d(hord, ctx.from_host(s["zs"]), ctx.from_host(s["zh"]), d_out, ctx.from_host(arr["crx"]),
                         ctx.from_host(arr["cry"]), ctx.from_host(arr["xfx"]), ctx.from_host(arr["yfx"]), d_ws, rdt)
         r = (bd.is_, bd.ie, bd.js, bd.je)
-        e = P.assert_close("zh", bd.view(d_out.download(), "A", *r), bd.view(zh, "A", *r), 1e-13 if fast else _tol(lib))
-        P.assert_close("ws", d_ws.download(), ws, 1e-12 if fast else _tol(lib))
+        e = P.assert_close("zh", bd.view(d_out.download(), "A", *r), bd.view(zh, "A", *r), _tol(lib))
+        P.assert_close("ws", d_ws.download(), ws, _tol(lib))
         if out is not None:
             out.update(zh=bd.view(d_out.download(), "A", *r), ws=d_ws.download())
         return e

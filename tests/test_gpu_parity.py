@@ -245,14 +245,6 @@ def test_prt_maxmin_and_the_reference_timers(prod):
         ctx.close()
 
 
-def test_edge_profile_fast_against_the_oracle(prod):
-    """update_dz_d with edge_profile in one sweep over k (nh_fast.h EdgeProfileFast: the back substitution as a chain truncated after
-    32 levels, where the product of the gam is below 1.2e-18) against the oracle; km + 1 a multiple of the window and not"""
-    for km in (5, 20, 79, 127):
-        N.check_update_dz_d(prod, nx=33, ny=9, km=km, fast=True)
-    N.check_update_dz_d(prod, km=40, fast=True, lev_over=dict(do_vort_damp=True, vtdm4=0.06, nord=2))
-
-
 def test_remap_in_lds_and_in_slabs(prod):
     """Lagrangian_to_Eulerian with the column in LDS (csrc/remap_fast.h: levels across the lanes, the spline's elimination in the
     reference's order by hand-over rounds, the limiters' curvature re-formed from a one-byte code) -- the default where it is built, and
@@ -784,32 +776,6 @@ def test_d_sw_interior_does_not_read_halos_in_flight(prod, monkeypatch):
     monkeypatch.setenv("FV3_MI355X_MARCH_TJ_FUSED", "8")
     for nx, ny in ((130, 97), (131, 26), (118, 98), (119, 99)):
         assert max(P.check_d_sw(prod, nx=nx, ny=ny, npz=3, phases="poison").values()) <= P.TOL
-
-
-# ---- fast (tolerance) mode of the column solvers: csrc/nh_fast.h, levels across the lanes, blocked parallel scans for the two
-# ---- tridiagonal solves and the prefix recurrences.  NOT bit-identical by construction; north_star's bar is rel-RMS < 1e-12.
-@pytest.mark.parametrize("km", [8, 32, 79, 127])
-def test_riem_fast_against_the_oracle(prod, km):
-    dims = dict(nx=200, ny=24, km=km) if km >= 79 else dict(nx=37, ny=13, km=km)     # ragged last 16-column block
-    assert N.check_riem_solver_c(prod, fast=True, **dims) <= 1e-12
-    assert N.check_riem_solver3(prod, fast=True, **dims) <= 1e-12
-    assert N.check_riem_solver3(prod, fast=True, use_logp=True, last_call=True, fp_out=True, **dims) <= 1e-12
-    assert N.check_riem_solver3(prod, fast=True, last_call=False, **dims) <= 1e-12
-
-
-def test_fast_mode_whole_steps(prod, monkeypatch):
-    """whole nonhydrostatic substep loops and an fv_dynamics cycle on the sphere with FV3_MI355X_FAST=1 (every context created under it
-    takes the fast column solvers) against the oracle-orchestrated equivalents.  w is the sensitive field (ill-conditioned implicit
-    solve, tests/test_hostemu_parity.py::test_fast_mode_substeps): <= 1e-11; everything else <= 1e-12."""
-    monkeypatch.setenv("FV3_MI355X_FAST", "1")
-    for kw in (dict(nx=48, ny=32, npz=79, n_split=3, bdt=6.0), dict(nx=40, ny=24, npz=127, n_split=2, bdt=4.0)):
-        r = D.check_substeps(prod, tol=1e-11, **kw)
-        assert r["w"] <= 1e-11 and max(v for k, v in r.items() if k != "w") <= 1e-12, r
-    # the baroclinic wave at rest in the vertical: w is ~1e-2 m/s and dt_acoustic 150 s makes the implicit w system stiff (condition
-    # number |aa| / dm2 ~ 1e6), so the re-associated solve moves w by ~2e-10 m/s absolute -- 1e-8 of its own small rms; the other
-    # prognostic fields stay within 1e-10
-    r = PC.check_jw_step(prod, npx=25, npz=79, k_split=2, n_split=3, bdt=900.0, hydrostatic=False, tol=1e-6)
-    assert r.pop("finite") == 1.0 and r.pop("w") <= 1e-7 and max(r.values()) <= 1e-10, r
 
 
 # ---- the column path at BASELINE depth (L79 = configs 2 and 5, L127 = configs 3 and 4): per-wavefront blocked scratch

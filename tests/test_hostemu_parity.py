@@ -223,14 +223,6 @@ def test_prt_maxmin_and_the_reference_timers(emu):
         ctx.close()
 
 
-def test_edge_profile_fast_against_the_oracle(emu):
-    """update_dz_d with edge_profile in one sweep over k (nh_fast.h EdgeProfileFast: the back substitution as a chain truncated after
-    32 levels, where the product of the gam is below 1.2e-18) against the oracle; km + 1 a multiple of the window and not"""
-    for km in (5, 20, 79, 127):
-        N.check_update_dz_d(emu, nx=33, ny=9, km=km, fast=True)
-    N.check_update_dz_d(emu, km=40, fast=True, lev_over=dict(do_vort_damp=True, vtdm4=0.06, nord=2))
-
-
 def test_remap_in_lds_and_in_slabs(emu):
     """Lagrangian_to_Eulerian with the column in LDS (csrc/remap_fast.h: levels across the lanes, the spline's elimination in the
     reference's order by hand-over rounds, the limiters' curvature re-formed from a one-byte code) -- the default where it is built, and
@@ -966,29 +958,6 @@ def test_total_energy_conservation(emu, kw):
     global sums, dtmp) and the final T_v -> T step with dtmp; a prescribed flux for consv_te < 0; the energy of the final state
     closes on the initial one"""
     assert max(D.check_fv_cycle_consv(emu, **kw).values()) <= 1e-12
-
-
-@pytest.mark.parametrize("km", [8, 20, 79, 127])
-def test_riem_fast_against_the_oracle(emu, km):
-    """fast mode of the column solvers (csrc/nh_fast.h): levels across the lanes, the tridiagonal solves and prefix recurrences as
-    blocked scans -- within 1e-12 of the oracle (not bit-identical by construction), ragged 16-column blocks, every output"""
-    dims = dict(nx=37, ny=5, km=km) if km < 79 else dict(nx=21, ny=3, km=km)
-    assert N.check_riem_solver_c(emu, fast=True, **dims) <= 1e-12
-    assert N.check_riem_solver3(emu, fast=True, **dims) <= 1e-12
-    assert N.check_riem_solver3(emu, fast=True, use_logp=True, last_call=True, fp_out=True, **dims) <= 1e-12
-    assert N.check_riem_solver3(emu, fast=True, last_call=False, **dims) <= 1e-12
-
-
-def test_fast_mode_substeps(emu, monkeypatch):
-    """whole substep loops under FV3_MI355X_FAST=1.  One call of a solver is within 4e-14 of the oracle (above); through a substep the
-    vertical velocity is the sensitive field: the implicit w system has a condition number ~1e3 (|aa| / dm2) and the perturbation
-    pressure exp(gamma log(rho R T)) - pm2 turns ONE ulp of an interface height (1e-16 of 1.6e4 m) into 1e-11 of itself, so any
-    re-association of the elimination moves w by ~1e-12 (measured 1.0 - 2.3e-12, not growing over 1 .. 6 substeps); every other
-    prognostic field stays below 3e-13."""
-    monkeypatch.setenv("FV3_MI355X_FAST", "1")
-    for kw in (dict(n_split=1, bdt=2.0), dict(n_split=6, bdt=12.0)):
-        r = D.check_substeps(emu, nx=24, ny=16, npz=20, tol=1e-11, **kw)
-        assert r["w"] <= 1e-11 and max(v for k, v in r.items() if k != "w") <= 1e-12, r
 
 
 def test_energy_fixer_refuses_an_unset_or_stale_te0(emu):
