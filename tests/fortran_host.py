@@ -16,14 +16,24 @@ def fortran_compiler():
     return fc if os.path.exists(fc) else None
 
 
+def _compile(workdir, name, files, libdir, libname):
+    """amdflang once per (work directory, library): a test that runs several cases of one driver compiles it once"""
+    fc = fortran_compiler()
+    exe = os.path.join(str(workdir), name)
+    stamp = exe + ".built_against"
+    want = os.path.join(libdir, "lib" + libname + ".so")
+    if os.path.exists(exe) and os.path.exists(stamp) and open(stamp).read() == want:
+        return exe
+    srcs = [os.path.join(FDIR, f) for f in files]
+    subprocess.check_call([fc, "-O1", "-module-dir", str(workdir)] + srcs + ["-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-o", exe])
+    with open(stamp, "w") as f:
+        f.write(want)
+    return exe
+
+
 def build_solo(workdir, libdir=CSRC, libname="fv3_mi355x"):
     """amdflang: interface module + host module + driver, linked against the product library"""
-    fc = fortran_compiler()
-    exe = os.path.join(str(workdir), "fv3_solo")
-    srcs = [os.path.join(FDIR, f) for f in ("fv3_mi355x_mod.F90", "fv3_host_mod.F90", "fv3_solo.F90")]
-    subprocess.check_call([fc, "-O1", "-module-dir", str(workdir)] + srcs +
-                          ["-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-o", exe])
-    return exe
+    return _compile(workdir, "fv3_solo", ('fv3_mi355x_mod.F90', 'fv3_host_mod.F90', 'fv3_solo.F90'), libdir, libname)
 
 
 def write_input(path, bd, npz, nq, n_split, k_split, nsteps, last_step, dx, dy, f0, bdt, ptop, ak, bk, st, q, hydrostatic=False,
@@ -133,12 +143,7 @@ def check_fortran_host(lib, workdir, nx=40, ny=24, npz=10, nq=2, n_split=2, k_sp
 
 def build_refsig(workdir, libdir=CSRC, libname="fv3_mi355x"):
     """the reference-signature dyn_core (fv3_dyn_core_mod) + its driver"""
-    fc = fortran_compiler()
-    exe = os.path.join(str(workdir), "fv3_solo_refsig")
-    srcs = [os.path.join(FDIR, f) for f in ("fv3_mi355x_mod.F90", "fv3_host_mod.F90", "fv3_sphere_mod.F90", "fv3_dyn_core_mod.F90", "fv3_solo_refsig.F90")]
-    subprocess.check_call([fc, "-O1", "-module-dir", str(workdir)] + srcs +
-                          ["-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-o", exe])
-    return exe
+    return _compile(workdir, "fv3_solo_refsig", ('fv3_mi355x_mod.F90', 'fv3_host_mod.F90', 'fv3_sphere_mod.F90', 'fv3_dyn_core_mod.F90', 'fv3_solo_refsig.F90'), libdir, libname)
 
 
 def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2, bdt=6.0, hydrostatic=False, d_con=0.0, beta=0.0, moist=False,
@@ -370,12 +375,7 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
 
 
 def build_solo_sphere(workdir, libdir=CSRC, libname="fv3_mi355x"):
-    fc = fortran_compiler()
-    exe = os.path.join(str(workdir), "fv3_solo_sphere")
-    srcs = [os.path.join(FDIR, f) for f in ("fv3_mi355x_mod.F90", "fv3_host_mod.F90", "fv3_sphere_mod.F90", "fv3_solo_sphere.F90")]
-    subprocess.check_call([fc, "-O1", "-module-dir", str(workdir)] + srcs +
-                          ["-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-o", exe])
-    return exe
+    return _compile(workdir, "fv3_solo_sphere", ('fv3_mi355x_mod.F90', 'fv3_host_mod.F90', 'fv3_sphere_mod.F90', 'fv3_solo_sphere.F90'), libdir, libname)
 
 
 _GH_A = ["area", "rarea", "dxa", "dya", "rdxa", "rdya", "cosa_s", "rsin2", "f0"]
@@ -488,13 +488,7 @@ def check_fortran_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=
 
 
 def build_solo_refsig_sphere(workdir, libdir=CSRC, libname="fv3_mi355x"):
-    fc = fortran_compiler()
-    exe = os.path.join(str(workdir), "fv3_solo_refsig_sphere")
-    srcs = [os.path.join(FDIR, f) for f in ("fv3_mi355x_mod.F90", "fv3_host_mod.F90", "fv3_sphere_mod.F90", "fv3_dyn_core_mod.F90",
-                                            "fv3_solo_refsig_sphere.F90")]
-    subprocess.check_call([fc, "-O1", "-module-dir", str(workdir)] + srcs +
-                          ["-L" + libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-o", exe])
-    return exe
+    return _compile(workdir, "fv3_solo_refsig_sphere", ('fv3_mi355x_mod.F90', 'fv3_host_mod.F90', 'fv3_sphere_mod.F90', 'fv3_dyn_core_mod.F90', 'fv3_solo_refsig_sphere.F90'), libdir, libname)
 
 
 def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2, bdt=900.0, hydrostatic=False, consv_te=1.0, tau=10.0,
