@@ -3227,7 +3227,7 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn,
   if (c->q_con && c->riem_lds && c->g.npz <= 127 && c->g.npz >= 2) {   // use_cond (+ moist_kappa) in the reference's order
     RiemFast<true, true, false, true> kf{c->g, c->g.npz, dt, to_consts(c, cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
                                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0, c->q_con, c->cappa};
-    RT(launch_p2(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
+    RT(launch_p2(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kf.kLdsDoubles, kf));
     return 0;
   }
   if (!c->q_con && c->g.npz <= 127 && c->g.npz >= 2) {   // Riem_Solver_c is SIM1 whatever a_imp is
@@ -3235,7 +3235,7 @@ extern "C" int fv3_riem_solver_c(fv3_ctx *c, double dt, const fv3_nh_consts *cn,
       RiemFast<true, true> kf{c->g, c->g.npz, dt, to_consts(c, cn), hs, pt, delp, ws, const_cast<double *>(w3), gz,
                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, pef, 0, 0, 0};
       if (const char *pe_ = std::getenv("FV3_MI355X_RIEM_PROBE")) kf.probe = std::atoi(pe_);
-      RT(launch_p2(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
+      RT(launch_p2(c, "riem_solver_c", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kf.kLdsDoubles, kf));
       return 0;
     }
   }
@@ -3271,18 +3271,18 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
     if (cn->a_imp > 0.999) {
       RiemFast<false, true, false, true> kf{c->g, c->g.npz, dt, to_consts(c, cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
                                             use_logp, last_call, fp_out, c->q_con, c->cappa};
-      RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
+      RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kf.kLdsDoubles, kf));
     } else {
       RiemFast<false, true, true, true> kf{c->g, c->g.npz, dt, to_consts(c, cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
                                            use_logp, last_call, fp_out, c->q_con, c->cappa};
-      RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
+      RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kf.kLdsDoubles, kf));
     }
     return 0;
   }
   if (!c->q_con && !c->cappa && cn->a_imp <= 0.999 && c->riem_lds && c->g.npz <= 127 && c->g.npz >= 2) {   // SIM_solver (the reference's default a_imp = 0.75)
     RiemFast<false, true, true> kf{c->g, c->g.npz, dt, to_consts(c, cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
                                    use_logp, last_call, fp_out};
-    RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
+    RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kf.kLdsDoubles, kf));
     return 0;
   }
   if (!c->q_con && !c->cappa && cn->a_imp > 0.999 && c->g.npz <= 127 && c->g.npz >= 2) {
@@ -3290,7 +3290,7 @@ extern "C" int fv3_riem_solver3(fv3_ctx *c, double dt, const fv3_nh_consts *cn, 
       RiemFast<false, true> kf{c->g, c->g.npz, dt, to_consts(c, cn), zs, pt, delp, ws, w, zh, delz, ppe, pk3, pe, pk, peln, nullptr,
                                use_logp, last_call, fp_out};
       if (const char *pe_ = std::getenv("FV3_MI355X_RIEM_PROBE")) kf.probe = std::atoi(pe_);
-      RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kFNBuf * kFBuf, kf));
+      RT(launch_p2(c, "riem_solver3", Dim3{(unsigned)kf.nblocks_x(), (unsigned)kf.nrows(), 1}, kf.kLdsDoubles, kf));
       return 0;
     }
   }

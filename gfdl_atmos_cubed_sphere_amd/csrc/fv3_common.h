@@ -37,29 +37,12 @@ constexpr int kNT = 1;
 constexpr int kNT = 256;
 #endif
 
-// Staggered start of a kernel's FIRST generation of workgroups.  A kernel of identical workgroups that each run load -> compute -> store
-// phases (the levels-across-the-lanes column kernels: nh_fast.h, remap_fast.h) starts every workgroup of the chip in the same phase, and
-// since they all take the same time the chip stays in step for the whole launch: every CU loads while no CU computes, then the reverse --
-// the memory system and the VALUs take turns instead of overlapping (measured: the time of such a kernel is the SUM of its memory time
-// and its issue time).  Holding back each workgroup of the first generation (flat index < n_first = resident workgroups of the chip)
-// by a pseudo-random share of one workgroup's run time spreads the phases for the rest of the launch; it costs about half a
-// workgroup's run time once.  mode 1: uniform in [0, ticks); mode 2: the second resident workgroup of every CU by ticks / 2.
-// ticks: units of the constant 100 MHz clock (s_memrealtime).
+// the thread's index, opaque to the optimizer from here on: addresses formed from it are formed again instead of living in registers
+// as common subexpressions of a whole kernel (remap_fast.h)
 #ifdef FV3_HOST_EMU
-inline void stagger_start(unsigned, unsigned, int, unsigned) {}
+inline int fresh_tid(int x) { return x; }
 #else
-__device__ __forceinline__ void stagger_start(unsigned flat, unsigned n_first, int mode, unsigned ticks) {
-  if (mode == 0 || flat >= n_first) return;
-  unsigned long long wait;
-  if (mode == 1) {
-    const unsigned h = (flat * 2654435761u) >> 22;   // 10 bits
-    wait = ((unsigned long long)h * ticks) >> 10;
-  } else {
-    wait = flat >= n_first / 2 ? ticks / 2 : 0;
-  }
-  const unsigned long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-}
+__device__ __forceinline__ int fresh_tid(int x) { asm volatile("" : "+v"(x)); return x; }
 #endif
 
 // the one exp / log of the column kernels and of their checker (see the header for why)

@@ -197,6 +197,20 @@ __device__ __forceinline__ bool vany_ne(vd a, vd b) { return __builtin_amdgcn_ba
 __device__ __forceinline__ vd row_shl1_v(vd a, vd fill) { return row_shl<1>(a, fill); }
 #endif
 
+// The column block a workgroup takes.  Consecutive workgroups of a launch go to the 8 XCDs in turn.  An A field has 3 halo columns, so
+// no 16-column block starts on a 128-byte line and neighbouring blocks share one; as neighbours in the launch they ran on different
+// XCDs and every shared line was fetched into two L2s (FETCH_SIZE 2.3 x the fields of Riem_Solver3, 2 x of the remap).  With this
+// permutation each XCD owns one contiguous range of blocks (the last nb mod 8 blocks keep their place): counter reads of a call
+// 1.39 -> 1.03 GB for Riem_Solver3, 1.23 -> 0.75 GB for Riem_Solver_c (tools/lab/riem_lab.hip, opt & 4).
+FV3_HD void xcd_block(int &bx, int &by, int nbx, int nby) {
+  const int flat = by * nbx + bx, chunk = (nbx * nby) >> 3;
+  if (flat < chunk * 8) {
+    const int lg = (flat & 7) * chunk + (flat >> 3);
+    by = lg / nbx;
+    bx = lg - by * nbx;
+  }
+}
+
 // a / b, correctly rounded for operands in the normal range (spmd.h vdiv_r: one reciprocal + a Markstein correction, 8 instructions
 // instead of the 14 of the compiler's IEEE division with its scale / fixup rescue): the same value as `a / b` here
 FV3_D vd vdivq(const vd &a, const vd &b) { return vdiv_r(a, b, vrecip(b)); }
@@ -424,9 +438,12 @@ struct RiemFast {
   // :413-438) and cappa (moist_kappa: gm2, cp2 per cell; on the C grid only together with q_con), A x km or null
   const double *qcon = nullptr, *cappa = nullptr;
   int probe = 0;   // timing probe (tools/riem_time.py, FV3_MI355X_RIEM_PROBE): 1 one round per sum, 2 no w pass, 4 one round of the pp system -- WRONG results
-  int stg_mode = 0, stg_first = 0, stg_ticks = 0;   // fv3_common.h stagger_start
-  int opt = 0;     // lab switches: 1 the pass wavefront chosen by SIMD (co-resident workgroups on different SIMDs), 2 w_column2, 4 XCD-contiguous blocks
-  int pool = 0;    // > 0 (a multiple of 8): that many persistent workgroups (block_at)
+  int opt = 7;     // A / B switches of tools/lab/riem_lab.hip (all on in the library): 1 the pass wavefront chosen by SIMD, 2 the sweep in
+                   // alternating register sets, 4 XCD-contiguous column blocks
+  long long *trace = nullptr;   // tools/lab (-DFV3_LAB_TRACE): clock64() of every wavefront at the barriers of block trace_blk
+  int trace_blk = -1;
+  // LDS: the four transposition buffers + the wavefronts' hardware ids (pass_wave)
+  static constexpr size_t kLdsDoubles = (size_t)kFNBuf * kFBuf + 8;
 
   FV3_HD int i_first() const { return CG ? g.is - 1 : g.is; }
   FV3_HD int ncols_row() const { return CG ? g.nx + 2 : g.nx; }
@@ -524,8 +541,13 @@ struct RiemFast {
         if (ch * kFL + u < km) R[o + u] = yc[u];
     }
   }
-  // the same sweep with the chunks in two register sets that alternate (no copies from "next" to "current": they were a quarter of the
-  // sweep's instructions); a padded chunk beyond the last is swept too when the number of chunks is odd (aa = 0, dm = 1, rhs = 0 there)
+  // The same sweep as the library runs it (opt & 2; w_column above is kept for the A / B of tools/lab/riem_lab.hip).  What the pass costs
+  // is ISSUE: an f64 operation takes 5.15 cycles of its SIMD whatever the active lanes (tools/lab/op_lab.hip), a level of the forward
+  // sweep is 17 of them, one a reciprocal (16 cycles) -- 100 cycles a level at best, 16 lanes busy, three wavefronts waiting.  So:
+  //   * the chunks alternate between two register sets (the copies "next -> current" were a quarter of the sweep's instructions);
+  //   * the back substitution reads its chunks one ahead, stores every row (the padded ones hold 0) and branches nowhere: 100 -> 25
+  //     cycles a level (it was 40 % of the pass: eight branches around eight stores per chunk, every load waited for on the spot);
+  //   * a padded chunk beyond the last is swept too when the number of chunks is odd (aa = 0, dm = 1, rhs = 0 there).
   FV3_D void w_chunk(const double *a, const double *dc, const double *rc, double &bet, double &rbet, double &y, double *gv, double *yv) const {
 #ifndef FV3_HOST_EMU
 #pragma unroll
@@ -569,25 +591,47 @@ struct RiemFast {
         for (int u = 0; u < kFL; u++) { A[o + u] = gv[u]; R[o + u] = yv[u]; }
       }
     }
-    // back substitution: w2(k) = w2(k) - gam(k+1) w2(k+1), k = km-1 .. 1
+    // back substitution: w2(k) = w2(k) - gam(k+1) w2(k+1), k = km-1 .. 1; rows k >= km keep 0.  Only the chunk that holds row km - 1
+    // selects per row (a select of doubles in the recurrence costs more than the recurrence: 21 cycles against 12); the chunks above
+    // it hold real rows only.
     double wn = 0.;
+    double yn[kFL], gn[kFL + 1];
+    {
+      const int o = (nch - 1) * kFS;
+      for (int u = 0; u < kFL; u++) yn[u] = R[o + u];
+      for (int u = 1; u < kFL; u++) gn[u] = A[o + u];
+      gn[kFL] = A[o + kFS];                                // gam of the next chunk's first row
+    }
     for (int ch = nch - 1; ch >= 0; ch--) {
-      const int o = ch * kFS;
       double yc[kFL], gc[kFL + 1];
-      for (int u = 0; u < kFL; u++) yc[u] = R[o + u];
-      for (int u = 1; u < kFL; u++) gc[u] = A[o + u];
-      gc[kFL] = A[o + kFS];
+      for (int u = 0; u < kFL; u++) { yc[u] = yn[u]; gc[u + 1] = gn[u + 1]; }
+      {   // the chunk above, requested before this one is swept (the topmost chunk asks for itself again)
+        const int o = (ch > 0 ? ch - 1 : 0) * kFS;
+        for (int u = 0; u < kFL; u++) yn[u] = R[o + u];
+        for (int u = 1; u < kFL; u++) gn[u] = A[o + u];
+        gn[kFL] = A[o + kFS];
+      }
+      if (ch == nch - 1) {
 #ifndef FV3_HOST_EMU
 #pragma unroll
 #endif
-      for (int u = kFL - 1; u >= 0; u--) {
-        const int k = ch * kFL + u;
-        const double v = k == km - 1 ? yc[u] : yc[u] - gc[u + 1] * wn;
-        wn = k <= km - 1 ? v : wn;
-        yc[u] = wn;
+        for (int u = kFL - 1; u >= 0; u--) {
+          const int k = ch * kFL + u;
+          const double v = k == km - 1 ? yc[u] : yc[u] - gc[u + 1] * wn;
+          wn = k <= km - 1 ? v : wn;
+          yc[u] = wn;
+        }
+      } else {
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+        for (int u = kFL - 1; u >= 0; u--) {
+          wn = yc[u] - gc[u + 1] * wn;
+          yc[u] = wn;
+        }
       }
-      for (int u = 0; u < kFL; u++)
-        if (ch * kFL + u < km) R[o + u] = yc[u];
+      const int o = ch * kFS;
+      for (int u = 0; u < kFL; u++) R[o + u] = yc[u];
     }
   }
   // one wavefront of the workgroup (`wave`, so that the workgroups of a CU use different SIMDs for it) runs the 16 columns, a lane each
@@ -604,68 +648,39 @@ struct RiemFast {
 #endif
   }
 
-  // the column block (bx, by) of logical index lg
-  FV3_D void block_of(int lg, int &bx, int &by) const {
-    const int nbx = nblocks_x();
-    by = lg / nbx;
-    bx = lg - by * nbx;
-  }
-  // The blocks a workgroup takes.  pool == 0: one workgroup per block, the hardware index p is the block (with opt & 4 permuted so that
-  // each XCD -- consecutive workgroups go to the 8 XCDs in turn -- owns one contiguous range of blocks: the two blocks that share a
-  // 128-byte line of an A field, whose 3 halo columns leave no block on a line boundary, then meet in one L2).  pool == P > 0 (a multiple
-  // of 8): P persistent workgroups; XCD x = p mod 8 owns blocks [x chunk, (x + 1) chunk), its P / 8 workgroups walk through them side by
-  // side; the nb mod 8 blocks beyond 8 chunk go to workgroups 0 .. as their last turn.
-  FV3_D int block_at(int p, int turn) const {
-    const int nb = nblocks_x() * nrows(), chunk = nb >> 3;
-    if (pool <= 0) {
-      if (turn > 0) return -1;
-      if (!(opt & 4) || p >= chunk * 8) return p;
-      return (p & 7) * chunk + (p >> 3);
-    }
-    const int per = pool >> 3, idx = (p >> 3) + turn * per;
-    if (idx < chunk) return (p & 7) * chunk + idx;
-    const bool first_beyond = turn == 0 || idx - per < chunk;   // the turn after the workgroup's last regular one
-    return first_beyond && 8 * chunk + p < nb ? 8 * chunk + p : -1;
-  }
-
   // (the barriers order LDS only, FV3_SYNC_LDS: every field is read before the first and written after the last exchange through LDS,
   // by the threads of this workgroup alone, so the output stores of one phase drain behind the transposition of the next)
+  // tools/lab (-DFV3_LAB_TRACE): where a block's time goes -- clock64() of every wavefront on either side of the barriers
+#ifdef FV3_LAB_TRACE
+#define FV3_TRACE(n) do { if (trace && by * nblocks_x() + bx == trace_blk && (tid & 63) == 0) trace[(tid >> 6) * 16 + (n)] = clock64(); } while (0)
+#else
+#define FV3_TRACE(n) ((void)0)
+#endif
   FV3_D void operator()(int bx, int by, int, int tid, double *lds) const {
     double *B0 = lds, *B1 = lds + kFBuf, *B2 = lds + 2 * kFBuf, *B3 = lds + 3 * kFBuf;
-    const int p_hw = by * nblocks_x() + bx;
-    stagger_start((unsigned)p_hw, (unsigned)stg_first, stg_mode, (unsigned)stg_ticks);
+    if (opt & 4) xcd_block(bx, by, nblocks_x(), nrows());
+    FV3_TRACE(15);
+    const int i0 = i_first() + bx * kFC, j = (CG ? g.js - 1 : g.js) + by;
+    const int ncol = (ncols_row() - bx * kFC < kFC) ? ncols_row() - bx * kFC : kFC;
     const ix_t nA = g.nA(), nCC = g.nCC();
+    const ix_t o0 = (ix_t)g.iA(i0, j);
     const double rgrav = 1. / cn.grav, rgas = cn.rdgas, gm2 = 1. / (1. - cn.akap), cp2 = cn.akap;
     // SIM: SIM_solver (nh_utils.F90:1396-1537, a_imp < 1: the off-centred form) -- t1g with alpha dt, the explicit part wk of the w
     // equation, the blend of pe2 with pp at the end; everything else is SIM1_solver
     const double alpha = cn.a_imp, beta = 1. - alpha, ra = 1. / alpha, t2 = beta / alpha;
     const double t1g = SIM ? 2. * ((alpha * dt) * (alpha * dt)) : 2. * dt * dt, rdt = 1. / dt;
     constexpr double r3 = 1. / 3.;
-    const int nrounds = (probe & 1) ? 1 : km / kFL + 1;   // EX: rounds after which the hand-overs of a sequential sweep over km levels are the sweep's own
-    // the inputs of a block are requested while the block before it is written out (pool > 0: the workgroup takes several blocks)
-    double v0[kIt], v1[kIt], v2[kIt], v3[kIt];
-    int lg = block_at(p_hw, 0), turn = 0;
-    if (lg < 0) return;
-    {
-      block_of(lg, bx, by);
-      const int nc_ = (ncols_row() - bx * kFC < kFC) ? ncols_row() - bx * kFC : kFC;
-      const ix_t o_ = (ix_t)g.iA(i_first() + bx * kFC, (CG ? g.js - 1 : g.js) + by);
-      stage_load(v0, delp, o_, nc_, km, tid);
-      stage_load(v1, pt, o_, nc_, km, tid);
-      stage_load(v2, wq, o_, nc_, km, tid);
-      stage_load(v3, zl, o_, nc_, km + 1, tid);
-    }
-    for (;;) {
-    block_of(lg, bx, by);
-    const int i0 = i_first() + bx * kFC, j = (CG ? g.js - 1 : g.js) + by;
-    const int ncol = (ncols_row() - bx * kFC < kFC) ? ncols_row() - bx * kFC : kFC;
-    const ix_t o0 = (ix_t)g.iA(i0, j);
-    const int lg_next = block_at(p_hw, turn + 1);
     vd dmr[kWvState][kFL], ptv[kWvState][kFL], w1[kWvState][kFL], zv[kWvState][kFL + 1];
     vd keep_pm2[kWvState][kFL], keep_grat[kWvState][kFL];
     vd keep_pem[kWvState][kFL + 1], keep_ppt[kWvState][SIM ? kFL + 1 : 1];
+    const int nrounds = (probe & 1) ? 1 : km / kFL + 1;   // EX: rounds after which the hand-overs of a sequential sweep over km levels are the sweep's own
     // ---- inputs: the four fields at once (their loads are in flight together), one barrier ----
     {
+      double v0[kIt], v1[kIt], v2[kIt], v3[kIt];
+      stage_load(v0, delp, o0, ncol, km, tid);
+      stage_load(v1, pt, o0, ncol, km, tid);
+      stage_load(v2, wq, o0, ncol, km, tid);
+      stage_load(v3, zl, o0, ncol, km + 1, tid);
       stage_store(B0, v0, ncol, km, 1.0, tid);
       stage_store(B1, v1, ncol, km, 300.0, tid);
       stage_store(B2, v2, ncol, km, 0.0, tid);
@@ -678,18 +693,19 @@ struct RiemFast {
     }
     int pass_wave = (bx + by) & 3;
 #ifndef FV3_HOST_EMU
-    // the wavefront that runs the w pass: two workgroups share a CU, and a pass keeps its SIMD busy for ~10 000 cycles while the other three
-    // idle -- the two passes must not meet on one SIMD.  Every wavefront posts the SIMD it runs on (HW_ID[5:4]), the first one also its
-    // wave slot (HW_ID[3:0]: co-resident workgroups hold different slots); the pass goes to the wavefront on SIMD (slot mod 4).
+    // The wavefront that runs the w pass.  Two workgroups share a CU and a pass keeps its SIMD issuing for ~15 000 cycles while the other
+    // three wait: the two passes must not meet on one SIMD.  Every wavefront posts the SIMD it runs on (HW_ID[5:4]), the first one also
+    // its wave slot (HW_ID[3:0]: co-resident workgroups hold different slots); the pass goes to the wavefront on SIMD (slot mod 4), or
+    // to wavefront (slot mod 4) should the four not sit on four SIMDs.
     int *hw = reinterpret_cast<int *>(lds + kFNBuf * kFBuf);
-    if (opt & 1) {
-      if ((tid & 63) == 0) {
-        hw[tid >> 6] = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
-        if (tid == 0) hw[4] = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-      }
+    if ((opt & 1) && (tid & 63) == 0) {
+      hw[tid >> 6] = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
+      if (tid == 0) hw[4] = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
     }
 #endif
+    FV3_TRACE(0);
     FV3_SYNC_LDS();
+    FV3_TRACE(1);
 #ifndef FV3_HOST_EMU
     if (opt & 1) {
       const int target = hw[4] & 3;
@@ -889,9 +905,13 @@ struct RiemFast {
       }
     }
     {
+      FV3_TRACE(2);
       FV3_SYNC_LDS();
+      FV3_TRACE(3);
       if (!(probe & 2)) w_columns(B0, B1, B2, pass_wave, tid);
+      FV3_TRACE(4);
       FV3_SYNC_LDS();
+      FV3_TRACE(5);
     }
     FV3_WAVE_FOR(wv) {
       const int s = FV3_WVI(wv), c0 = wv * 4;
@@ -1012,59 +1032,46 @@ struct RiemFast {
         }
       }
     }
+    FV3_TRACE(6);
     FV3_SYNC_LDS();
-    if (lg_next >= 0) {   // the next block's inputs travel while this one's outputs are written
-      int bxn, byn;
-      block_of(lg_next, bxn, byn);
-      const int nc_ = (ncols_row() - bxn * kFC < kFC) ? ncols_row() - bxn * kFC : kFC;
-      const ix_t o_ = (ix_t)g.iA(i_first() + bxn * kFC, (CG ? g.js - 1 : g.js) + byn);
-      stage_load(v0, delp, o_, nc_, km, tid);
-      stage_load(v1, pt, o_, nc_, km, tid);
-      stage_load(v2, wq, o_, nc_, km, tid);
-      stage_load(v3, zl, o_, nc_, km + 1, tid);
-    }
+    FV3_TRACE(7);
     stage_out(B0, zl, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
     if (CG) {
       stage_out(B1, pef, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
-    } else {
-      const ix_t occ0 = (ix_t)g.iCC(i0, j);
-      stage_out(B1, wq, ncol, km, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
-      stage_out(B2, delz, ncol, km, tid, [&](int col, int k) { return (ix_t)k * nCC + occ0 + col; });
-      FV3_SYNC_LDS();
-      FV3_WAVE_FOR(wv) {
-        const int s = FV3_WVI(wv), c0 = wv * 4;
-        for (int q = 0; q < kFL; q++) {
-          vlds_st(B0, c0, q, dmr[s][q]);
-          vlds_st(B1, c0, q, use_logp ? vsel(vlevel_eq(q, 0), ptv[s][q], w1[s][q]) : ptv[s][q]);   // pk3(1) = ptk either way (nh_core.F90:87)
-          if (last_call) vlds_st(B2, c0, q, ptv[s][q]);
-        }
-      }
-      FV3_SYNC_LDS();
-      stage_out(B0, ppe, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
-      stage_out(B1, pk3, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
-      if (last_call) {
-        stage_out(B2, pk, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nCC + occ0 + col; });
-        FV3_SYNC_LDS();
-        FV3_WAVE_FOR(wv) {
-          const int s = FV3_WVI(wv), c0 = wv * 4;
-          for (int q = 0; q < kFL; q++) {
-            vlds_st(B0, c0, q, w1[s][q]);
-            vlds_st(B1, c0, q, zv[s][q]);
-          }
-        }
-        FV3_SYNC_LDS();
-        stage_out(B0, peln, ncol, km + 1, tid, [&](int col, int k) {
-          return (ix_t)(j - g.js) * g.nx * (km + 1) + (ix_t)k * g.nx + (i0 - g.is) + col; });
-        stage_out(B1, pe, ncol, km + 1, tid, [&](int col, int k) {
-          return (ix_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (ix_t)k * (g.nx + 2) + (i0 - (g.is - 1)) + col; });
+      return;
+    }
+    const ix_t occ0 = (ix_t)g.iCC(i0, j);
+    stage_out(B1, wq, ncol, km, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
+    stage_out(B2, delz, ncol, km, tid, [&](int col, int k) { return (ix_t)k * nCC + occ0 + col; });
+    FV3_SYNC_LDS();
+    FV3_WAVE_FOR(wv) {
+      const int s = FV3_WVI(wv), c0 = wv * 4;
+      for (int q = 0; q < kFL; q++) {
+        vlds_st(B0, c0, q, dmr[s][q]);
+        vlds_st(B1, c0, q, use_logp ? vsel(vlevel_eq(q, 0), ptv[s][q], w1[s][q]) : ptv[s][q]);   // pk3(1) = ptk either way (nh_core.F90:87)
+        if (last_call) vlds_st(B2, c0, q, ptv[s][q]);
       }
     }
-    if (lg_next < 0) break;
-    lg = lg_next;
-    turn++;
-    FV3_SYNC_LDS();   // the buffers are read out: the next block may fill them
+    FV3_SYNC_LDS();
+    stage_out(B0, ppe, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
+    stage_out(B1, pk3, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nA + o0 + col; });
+    if (!last_call) return;
+    stage_out(B2, pk, ncol, km + 1, tid, [&](int col, int k) { return (ix_t)k * nCC + occ0 + col; });
+    FV3_SYNC_LDS();
+    FV3_WAVE_FOR(wv) {
+      const int s = FV3_WVI(wv), c0 = wv * 4;
+      for (int q = 0; q < kFL; q++) {
+        vlds_st(B0, c0, q, w1[s][q]);
+        vlds_st(B1, c0, q, zv[s][q]);
+      }
     }
+    FV3_SYNC_LDS();
+    stage_out(B0, peln, ncol, km + 1, tid, [&](int col, int k) {
+      return (ix_t)(j - g.js) * g.nx * (km + 1) + (ix_t)k * g.nx + (i0 - g.is) + col; });
+    stage_out(B1, pe, ncol, km + 1, tid, [&](int col, int k) {
+      return (ix_t)(j - (g.js - 1)) * (g.nx + 2) * (km + 1) + (ix_t)k * (g.nx + 2) + (i0 - (g.is - 1)) + col; });
   }
+#undef FV3_TRACE
 };
 
 }  // namespace fv3

@@ -30,10 +30,8 @@ namespace fv3 {
 // (tl: the thread's index, opaque to the optimizer once per loop -- fresh_tid -- so that the (column, level) addresses of a phase are
 // formed in that phase: as common subexpressions of the whole kernel they stayed alive through every field and were spilled)
 #ifdef FV3_HOST_EMU
-inline int fresh_tid(int x) { return x; }
 #define FV3_LOAD_LOOP(it) for (int it = 0, tl = tid; it < kIt; it++)
 #else
-__device__ __forceinline__ int fresh_tid(int x) { asm volatile("" : "+v"(x)); return x; }
 #define FV3_LOAD_LOOP(it) _Pragma("unroll") for (int it = 0, tl = fresh_tid(tid); it < kIt; it++)
 #endif
 
@@ -457,6 +455,7 @@ struct RemapFastScalars {
     constexpr int kIt = Core::kIt, RL = Core::RL, kRP = Lay::RP, kRBuf = Lay::RBuf;
     const Core core{km, probe};
     double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf, *QS = C1 + Lay::RQS;   // QS[column * kRP]
+    xcd_block(bx, by, nblocks_x(), g.ny);   // neighbouring column blocks share 128-byte lines: one L2 for both (nh_fast.h)
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (g.nx - bx * kFC < kFC) ? g.nx - bx * kFC : kFC;
     const ix_t nA = g.nA(), nCC = g.nCC();
@@ -787,6 +786,7 @@ struct RemapFastWind {
     const Core core{km, probe};
     double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf;
     double *AK = lds + Lay::TabAk, *BK = lds + Lay::TabBk;
+    xcd_block(bx, by, nblocks_x(), nrows());
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (ncols_row() - bx * kFC < kFC) ? ncols_row() - bx * kFC : kFC;
     const ix_t fs = WHICH == 0 ? g.nU() : g.nV();
