@@ -69,6 +69,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--nx", type=int, default=384)
     ap.add_argument("--npz", type=int, default=127)
+    ap.add_argument("--domain", type=int, default=0,
+                    help="STRONG scaling: one doubly periodic DOMAIN x DOMAIN x npz domain (BASELINE config 4: 1024) split px x py over the "
+                         "ranks; `value` is then the domain's cell-updates/s and \"scaling\" is \"strong\"")
+    ap.add_argument("--strong-domain", type=int, default=None,
+                    help="the domain of the strong-scaling leg every default run carries beside the weak-scaling headline (default 1024; 0: no leg)")
+    ap.add_argument("--strong-steps", type=int, default=10)
     ap.add_argument("--periodic6", action="store_true", help="--gpus 6 as a 3x2 doubly periodic layout instead of the six cubed-sphere faces")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--parity-columns", action="store_true",
@@ -663,10 +669,21 @@ def main():
 
     nx, npz = a.nx, a.npz
     px, py = choose_layout(world)
-    # this rank's block of the (nx*px) x (nx*py) doubly periodic domain
     ix, iy = rank % px, rank // px
-    bd = Bounds(1 + ix * nx, (ix + 1) * nx, 1 + iy * nx, (iy + 1) * nx)
-    g = doubly_periodic(bd, nx * px + 1, nx * py + 1, dx_const=26000.0, dy_const=26000.0)
+
+    def block(nxb, nyb):
+        """this rank's nxb x nyb block of the (nxb px) x (nyb py) doubly periodic domain (tools/fv_mp_mod.F90:276-392: one tile, layout px x py)"""
+        b = Bounds(1 + ix * nxb, (ix + 1) * nxb, 1 + iy * nyb, (iy + 1) * nyb)
+        return b, doubly_periodic(b, nxb * px + 1, nyb * py + 1, dx_const=26000.0, dy_const=26000.0)
+
+    # WEAK scaling (the default, `value` of the driver's --gpus N runs): every rank holds its own nx x nx block
+    # STRONG scaling (--domain D, BASELINE config 4): one D x D domain, the block shrinks with the layout
+    ny = nx
+    if a.domain:
+        if a.domain % px or a.domain % py:
+            raise SystemExit(f"bench: --domain {a.domain} does not divide over the {px} x {py} layout")
+        nx, ny = a.domain // px, a.domain // py
+    bd, g = block(nx, ny)
     stream = torch.cuda.current_stream()
     # FV3_BENCH_PAIR_GRAPH=1 (one rank, periodic copy as halo update): the pair on a stream of its own, captured into a HIP graph and
     # replayed -- one launch per pair instead of ~10.  Measured SLOWER than the eager launches at this size (2.09-2.11 against
@@ -676,7 +693,7 @@ def main():
     use_graph = world == 1 and not loopback and os.environ.get("FV3_BENCH_PAIR_GRAPH", "0") == "1"
     if use_graph:
         stream = torch.cuda.Stream()
-    cells = nx * nx * npz
+    cells = nx * ny * npz
     # FV3_BENCH_SPONGE=0 (diagnostic): no sponge levels, every level in the marching kernels -- NOT the headline workload
     lev = level_coefficients(npz, DynFlags(d2_bg_k1=0.0, d2_bg_k2=0.0) if os.environ.get("FV3_BENCH_SPONGE") == "0"
                              else DynFlags())
@@ -691,8 +708,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def setup(general):
-        """resident state + the step closure.  general: FV3_MI355X_GEOM=0, every metric row is read from memory -- what a
+    def setup(general, dom=None):
+        """resident state + the step closure.  dom = (nx, ny, g) of another block than the headline's (the strong-scaling leg).  general: FV3_MI355X_GEOM=0, every metric row is read from memory -- what a
         cubed-sphere gridstruct needs -- instead of the uniform-Cartesian kernels the library selects for this doubly
         periodic gridstruct."""
         # the switch is read when the context uploads its gridstruct; it must not leak into the contexts created later
@@ -700,8 +717,9 @@ def main():
         saved = os.environ.pop("FV3_MI355X_GEOM", None)
         if general:
             os.environ["FV3_MI355X_GEOM"] = "0"
+        nxb, nyb, gb = dom if dom else (nx, ny, g)
         try:
-            ctx = L.Context(g, npz, stream=stream.cuda_stream)
+            ctx = L.Context(gb, npz, stream=stream.cuda_stream)
         finally:
             os.environ.pop("FV3_MI355X_GEOM", None)
             if saved is not None:
@@ -710,7 +728,7 @@ def main():
         # FV3_BENCH_SPLIT=1: exercise the multi-rank flow (start / d_sw interior / finish / d_sw rest) on one GPU
         halo = HaloExchanger(ctx, px, py, rank, world, split_single=loopback or os.environ.get("FV3_BENCH_SPLIT") == "1",
                              loopback=loopback)
-        st = smooth_state(Bounds(1, nx, 1, nx), npz, noise=0.05)  # same synthetic block on every rank
+        st = smooth_state(Bounds(1, nxb, 1, nyb), npz, noise=0.05)  # same synthetic block on every rank
         d = {k: ctx.from_host(v) for k, v in st.items()}
         del st
         for n, kind in CSW_OUT:
@@ -762,6 +780,7 @@ def main():
             except Exception as e:  # noqa: BLE001   (no capture: the eager launches are timed)
                 print(f"bench: HIP graph capture of the pair failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
                 step.graph = None
+        step.block = (nxb, nyb)
         return ctx, d, step
 
     def run(ctx, d, step, steps, warmup):
@@ -769,6 +788,8 @@ def main():
         events around every launch on its own stream) for the per-launch roofline."""
         geom = ctx.geom
         nprof = 10
+        nxb, nyb = step.block
+        cells = nxb * nyb * npz
         for _ in range(3 + SPINUP):  # untimed: code objects loaded, work arrays of the library allocated
             step()
         tstep = step.graph or step         # the captured pair (one replay = one c_sw -> halo -> d_sw), or the eager launches
@@ -806,7 +827,7 @@ def main():
             e = {"launches_per_step": n / nprof, "ms_per_step": per_step}
             if name in ALG and nlev[ALG[name][1]] > 0 and per_step > 0.0:
                 nb, which = ALG[name]
-                c = nx * nx * nlev[which]
+                c = nxb * nyb * nlev[which]
                 e.update(alg_bytes_per_cell=nb, levels=nlev[which], GBps=c * nb / (per_step * 1e-3) / 1e9,
                          frac=c * nb / (per_step * 1e-3) / HBM_PEAK)
             per_launch[name] = e
@@ -857,9 +878,10 @@ def main():
 
     out = {"metric": "c_sw+d_sw cell-updates/s", "value": value, "unit": "cell-updates/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"doubly periodic {nx}x{nx}x{npz} tile per GPU (C384L127-sized), nonhydrostatic, "
-                                  f"c_sw+d_sw pair, hord {a.hord}/{a.hord}/{a.hord}/{a.hord}, nord=1, d4_bg=0.16",
+           "scaling": "strong" if a.domain else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": (f"ONE doubly periodic {a.domain}x{a.domain}x{npz} domain (BASELINE config 4) split {px}x{py}: {nx}x{ny} per GPU, "
+                                   if a.domain else f"doubly periodic {nx}x{nx}x{npz} tile per GPU (C384L127-sized), ") +
+                                  f"nonhydrostatic, c_sw+d_sw pair, hord {a.hord}/{a.hord}/{a.hord}/{a.hord}, nord=1, d4_bg=0.16",
                       "layout": f"{px}x{py}", "halo": ("RCCL send/recv (loopback)" if loopback else "periodic copy") if world == 1 else "RCCL send/recv",
                       # what fv3_grid_upload found in the metric arrays (fv3_grid_geom)
                       "gridstruct": GEOM[geom], "build_id": build,
@@ -869,6 +891,31 @@ def main():
                             os.environ.get("FV3_MI355X_SPONGE_MARCH", "1") != "0" else "d2_bg_k1 0.20, d2_bg_k2 0.015 (2 levels), LDS-tile kernels"),
                       "heat_source": "d_con = 0: heat_s / diss_e = NULL (nobody reads them, dyn_core.F90:798-812); pair priced at 336 B and at 320 B"},
            "finite": finite, "roofline": roof, "general_metrics": gm}
+    # BASELINE config 4 beside the weak-scaling headline: ONE strong_domain^2 x npz doubly periodic domain split over the same px x py
+    # layout (1024 x 1024, 512 x 1024, 512 x 512, 512 x 256 blocks at 1, 2, 4, 8 ranks).  Every rank takes part (collective halos);
+    # a failure is reported, not raised -- but it must fail on all ranks alike, so the checks are on values every rank shares.
+    out["strong_scaling"] = None
+    sd = a.strong_domain if a.strong_domain is not None else (0 if DRYRUN else 1024)   # (the dry run's host harness takes seconds per 16^2 step)
+    if not a.domain and sd and not a.general_metrics:
+        if sd % px or sd % py:
+            out["strong_scaling"] = {"error": f"{sd} does not divide over the {px} x {py} layout"}
+        else:
+            try:
+                nxs, nys = sd // px, sd // py
+                _, gs_ = block(nxs, nys)
+                s_set = setup(False, (nxs, nys, gs_))
+                sm = run(*s_set, a.strong_steps, max(2, a.strong_steps // 3))
+                del s_set
+                dom_cells = sd * sd * npz
+                out["strong_scaling"] = {
+                    "workload": f"ONE doubly periodic {sd}x{sd}x{npz} domain (BASELINE config 4) split {px}x{py}: {nxs}x{nys} per GPU",
+                    "scaling": "strong", "n_gpus": world, "steps": a.strong_steps, "ms_per_step": sm["el"] / a.strong_steps * 1e3,
+                    "value": dom_cells * a.strong_steps / sm["el"], "unit": "cell-updates/s", "finite": sm["finite"],
+                    "frac_wall_per_gpu": (dom_cells / world) * PAIR_ALG_BYTES / (sm["el"] / a.strong_steps) / HBM_PEAK,
+                    "note": "speed-up 1 -> N = value(N) / value(1) of this object across the driver's --gpus 1, 2, 4, 8 lines "
+                            "(BASELINE.md 2: >= 6x at 8); `value` of the line itself is the WEAK-scaling number"}
+            except Exception as e:  # noqa: BLE001
+                out["strong_scaling"] = {"error": f"{type(e).__name__}: {e}"}
     if DRYRUN:
         out["dry_run"] = "FV3_BENCH_DRYRUN=1: host logic harness + gloo, no GPU -- plumbing only, the numbers mean nothing"
     # the secondary legs must never cost the headline line: a failure there is reported, not raised

@@ -197,6 +197,14 @@ struct RemapFastCoreT {
   int km;
   int probe = 0;   // timing probe (FV3_MI355X_REMAP_PROBE, tools/remap_time.py; WRONG results): 1 no spline, 2 no constraints, 4 no
                    // subgrid limiters, 8 no mapping loop
+  // tools/lab (-DFV3_LAB_TRACE): clock64() of every wavefront at the phase boundaries of one block, in the order they are passed
+  long long *trace = nullptr;
+  mutable int tn = 0;
+#ifdef FV3_LAB_TRACE
+  FV3_D void mark(int tid) const { if (trace && (tid & 63) == 0) trace[(tid >> 6) * 128 + (tn < 127 ? tn : 127)] = clock64(); tn++; }
+#else
+  FV3_D void mark(int) const {}
+#endif
   static constexpr int kIt = kFC * RL / kNT;   // (column, level) pairs per thread
 
   FV3_D static RCol col(double *buf, int c) { return RCol{buf + c * kRP}; }          // [k], k 1-based
@@ -384,6 +392,7 @@ struct RemapFastCoreT {
       form[it] = a4_form_of(a4v, a1[k], a2v, a3v);
       pt2[it] = t2[k]; pb2[it] = t2[k + 1];
     }
+    mark(tid);   // limiters done
     FV3_SYNC_LDS();
     for (int it = 0; it < kIt; it++) {
       const int idx = tid + it * kNT, col = idx / RL, k = idx % RL + 1;
@@ -415,13 +424,17 @@ struct RemapFastCoreT {
   FV3_D void remap_field(double *C1, double *C2, double *A1, double *Q, const double *QS, bool is_scalar, int iv, int kord,
                          double qmin, bool tracer_form, int tid, Pre &&pre) const {
     const int ak = kord < 0 ? -kord : kord;
+    mark(tid);   // field start
     if (!(probe & 1)) { FV3_WAVE_FOR(wv) { spline(C1, A1, Q, QS, iv, wv); } }
+    mark(tid);   // spline done
     FV3_SYNC_LDS();
     if (!(probe & 2)) constrain(A1, Q, iv, ak, tid);
     FV3_SYNC_LDS();
+    mark(tid);   // constrained
     pre();
     map_all(C1, C2, A1, Q, is_scalar, iv, ak, qmin, tracer_form, tid);
     FV3_SYNC_LDS();
+    mark(tid);   // mapped
   }
 };
 
@@ -446,6 +459,9 @@ struct RemapFastScalars {
   const double *pe, *ws;
   double *ps, *delp, *pkz, *pk, *delz, *pt, *peln, *w, *q, *omga;
   int probe = 0;
+  int opt = 1;     // A / B switch of tools/lab/remap_lab.hip (on in the library): 1 XCD-contiguous column blocks
+  long long *trace = nullptr;   // tools/lab (-DFV3_LAB_TRACE): RemapFastCoreT::mark of block trace_blk
+  int trace_blk = -1;
 
   FV3_HD int nblocks_x() const { return (g.nx + kFC - 1) / kFC; }
 
@@ -453,9 +469,10 @@ struct RemapFastScalars {
     using Core = RemapFastCoreT<L>;
     using Lay = RLay<L>;
     constexpr int kIt = Core::kIt, RL = Core::RL, kRP = Lay::RP, kRBuf = Lay::RBuf;
-    const Core core{km, probe};
     double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf, *QS = C1 + Lay::RQS;   // QS[column * kRP]
-    xcd_block(bx, by, nblocks_x(), g.ny);   // neighbouring column blocks share 128-byte lines: one L2 for both (nh_fast.h)
+    if (opt & 1) xcd_block(bx, by, nblocks_x(), g.ny);   // neighbouring column blocks share 128-byte lines: one L2 for both (nh_fast.h)
+    const Core core{km, probe, by * nblocks_x() + bx == trace_blk ? trace : nullptr};
+    core.mark(tid);   // block start
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (g.nx - bx * kFC < kFC) ? g.nx - bx * kFC : kFC;
     const ix_t nA = g.nA(), nCC = g.nCC();
@@ -689,6 +706,7 @@ struct RemapFastScalars {
       }
     }
     FV3_SYNC_LDS();
+    core.mark(tid);   // fields done
     // ---- the new interfaces: pn2 -> A1, pk2 -> Q (:340-345); then delp, pk, peln, pkz and pt of every layer (:426-503, :793-841);
     //      the loads of the last phase (T_v, delz, sphum as this thread stored them) are issued in front of the logarithms ----
     {
@@ -762,6 +780,7 @@ struct RemapFastScalars {
         pt[o3] = tn;
       }
     }
+    core.mark(tid);   // block end
   }
 };
 
@@ -774,6 +793,7 @@ struct RemapFastWind {
   const double *ak, *bk, *pe;
   double *f;
   int probe = 0;
+  int opt = 1;
 
   FV3_HD int ncols_row() const { return WHICH == 0 ? g.nx : g.nx + 1; }
   FV3_HD int nrows() const { return WHICH == 0 ? g.ny + 1 : g.ny; }
@@ -786,7 +806,7 @@ struct RemapFastWind {
     const Core core{km, probe};
     double *C1 = lds, *C2 = lds + kRBuf, *A1 = lds + 2 * kRBuf, *Q = lds + 3 * kRBuf;
     double *AK = lds + Lay::TabAk, *BK = lds + Lay::TabBk;
-    xcd_block(bx, by, nblocks_x(), nrows());
+    if (opt & 1) xcd_block(bx, by, nblocks_x(), nrows());
     const int i0 = g.is + bx * kFC, j = g.js + by;
     const int ncol = (ncols_row() - bx * kFC < kFC) ? ncols_row() - bx * kFC : kFC;
     const ix_t fs = WHICH == 0 ? g.nU() : g.nV();
