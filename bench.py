@@ -422,31 +422,18 @@ def sphere_steps(torch, stream, cs, gs, nx, npz, hydrostatic, k_split, n_split, 
     del st
     fv.step(dt_atmos)
     torch.cuda.synchronize()
-    # the launch-bound small grids: replay the step as one HIP graph (cubed_dyn.StepGraph); eager if capture is refused
-    graph, graph_note = None, "eager launches"
-    if os.environ.get("FV3_BENCH_GRAPH", "1") == "1" and fstreams[0] is not stream:
-        try:
-            from gfdl_atmos_cubed_sphere_amd.cubed_dyn import StepGraph
-            graph = StepGraph(fv, dt_atmos, fstreams)
-            graph.replay()
-            torch.cuda.synchronize()
-            graph_note = "one HIP graph per dt_atmos (hipStreamBeginCapture over the six face streams)"
-        except Exception as e:  # noqa: BLE001
-            graph, graph_note = None, f"eager launches (graph capture refused: {type(e).__name__}: {e})"
-    walls = {}
-    for how, step in (("eager", lambda: fv.step(dt_atmos)),) + ((("graph", graph.replay),) if graph else ()):
-        step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(nrep):
-            step()
-        torch.cuda.synchronize()
-        walls[how] = (time.perf_counter() - t0) / nrep
-    # with the faces as one launch group there are six times fewer, six times larger launches: the host keeps up, and a graph replay
-    # (one stream now, nothing to overlap) is the slower of the two at C96; the faster one is the step's wall time, both are reported
-    best = min(walls, key=walls.get)
-    wall = walls[best]
-    graph_note = ("eager launches" if best == "eager" else graph_note) + "; wall s per dt_atmos " + ", ".join(f"{k_}: {v_:.4f}" for k_, v_ in walls.items())
+    # (eager launches.  Rounds 2 - 5 also replayed the step as one HIP graph: with the faces in one launch group there are six times
+    # fewer, six times larger launches, the host keeps up, and the replay -- one stream, nothing overlaps -- was the slower of the two,
+    # 0.061 against 0.031 s per dt_atmos at C96: removed in round 6)
+    graph_note = "eager launches"
+    fv.step(dt_atmos)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(nrep):
+        fv.step(dt_atmos)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / nrep
+    graph_note += f"; wall s per dt_atmos {wall:.4f}"
     dp = fv.dc.d["delp"].download()
     # per-kernel breakdown: ALL six faces on ONE stream, eager (on six streams the HIP-event durations of overlapping kernels add
     # up to several times the wall time and say nothing -- VERDICT r2).  Its own wall time is reported next to the sum.
@@ -685,14 +672,6 @@ def main():
         nx, ny = a.domain // px, a.domain // py
     bd, g = block(nx, ny)
     stream = torch.cuda.current_stream()
-    # FV3_BENCH_PAIR_GRAPH=1 (one rank, periodic copy as halo update): the pair on a stream of its own, captured into a HIP graph and
-    # replayed -- one launch per pair instead of ~10.  Measured SLOWER than the eager launches at this size (2.09-2.11 against
-    # 2.05-2.07 ms on the same box, tools/graph_probe.sh: the launches are already hidden behind 0.5-0.9 ms kernels, and the replay
-    # orders the sponge-level chain of the side stream less freely), so it is off by default; it pays where the kernels are short
-    # (the C96 sphere: cubed_dyn.StepGraph)
-    use_graph = world == 1 and not loopback and os.environ.get("FV3_BENCH_PAIR_GRAPH", "0") == "1"
-    if use_graph:
-        stream = torch.cuda.Stream()
     cells = nx * ny * npz
     # FV3_BENCH_SPONGE=0 (diagnostic): no sponge levels, every level in the marching kernels -- NOT the headline workload
     lev = level_coefficients(npz, DynFlags(d2_bg_k1=0.0, d2_bg_k2=0.0) if os.environ.get("FV3_BENCH_SPONGE") == "0"
@@ -762,24 +741,6 @@ def main():
                 halo.update([(d["uc"], "V"), (d["vc"], "U"), (d["divg_d"], "B")])
                 ctx.d_sw(*dsw_args)
 
-        step.graph = None
-        if use_graph:
-            try:
-                step()                                  # eager once: every work array of the library exists
-                torch.cuda.synchronize()
-                gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr, stream=stream):
-                    step()
-
-                def replay():
-                    with torch.cuda.stream(stream):
-                        gr.replay()
-                replay()
-                torch.cuda.synchronize()
-                step.graph = replay
-            except Exception as e:  # noqa: BLE001   (no capture: the eager launches are timed)
-                print(f"bench: HIP graph capture of the pair failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
-                step.graph = None
         step.block = (nxb, nyb)
         return ctx, d, step
 
@@ -792,7 +753,7 @@ def main():
         cells = nxb * nyb * npz
         for _ in range(3 + SPINUP):  # untimed: code objects loaded, work arrays of the library allocated
             step()
-        tstep = step.graph or step         # the captured pair (one replay = one c_sw -> halo -> d_sw), or the eager launches
+        tstep = step
         for _ in range(warmup):
             tstep()
         fence()
@@ -855,7 +816,7 @@ def main():
                              # the same wall time priced at the bytes of the flags this run has (d_con = 0: no heat_source traffic)
                              "alg_bytes_per_cell_d_con_0": PAIR_ALG_BYTES_DCON0,
                              "frac_wall_d_con_0": cells * PAIR_ALG_BYTES_DCON0 / (el / steps) / HBM_PEAK}}
-        return {"el": el, "value": cells * world * steps / el, "finite": finite, "roof": roof, "geom": geom, "graph": step.graph is not None}
+        return {"el": el, "value": cells * world * steps / el, "finite": finite, "roof": roof, "geom": geom}
 
     GEOM = {0: "general metric rows", 1: "orthogonal (angle terms not read)", 2: "orthogonal + uniform (metric terms as scalars)"}
     # all host-side setup first (state generation and uploads take seconds), then the GPU work back to back: the
@@ -885,7 +846,7 @@ def main():
                       "layout": f"{px}x{py}", "halo": ("RCCL send/recv (loopback)" if loopback else "periodic copy") if world == 1 else "RCCL send/recv",
                       # what fv3_grid_upload found in the metric arrays (fv3_grid_geom)
                       "gridstruct": GEOM[geom], "build_id": build,
-                      "launch": "HIP graph: one replay per pair" if m.get("graph") else "eager launches",
+                      "launch": "eager launches",
                       "sponge_levels": "off (FV3_BENCH_SPONGE=0, diagnostic)" if os.environ.get("FV3_BENCH_SPONGE") == "0"
                       else ("d2_bg_k1 0.20, d2_bg_k2 0.015 (2 levels), inside the marching kernels (uniform metrics)" if geom == 2 and
                             os.environ.get("FV3_MI355X_SPONGE_MARCH", "1") != "0" else "d2_bg_k1 0.20, d2_bg_k2 0.015 (2 levels), LDS-tile kernels"),

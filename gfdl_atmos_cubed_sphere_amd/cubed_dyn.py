@@ -232,47 +232,3 @@ def make_sphere_contexts(npx: int, npz: int, lib=None, sphere: CubedSphere | Non
     gs = [cs.gridstruct(t) for t in range(6)]
     ctxs = [Context(g, npz, lib=lib) for g in gs]
     return cs, gs, MultiContext(ctxs)
-
-
-class StepGraph:
-    """One whole fv_dynamics step of the six faces captured into a HIP graph (hipStreamBeginCapture through torch) and
-    replayed: at C96 a face's kernels take tens of microseconds, so the ~2 500 launches of a dt_atmos are bound by the
-    host's launch rate; a replay costs one launch.  Needs: nq = 0 (tracer_2d reads the Courant maximum back on the host),
-    an even number of substeps per step (the ping-pong buffers are back in place), the faces on non-default torch streams, and
-    one eager step before (so that every work array exists: allocation is not capturable)."""
-
-    def __init__(self, fv, bdt: float, streams):
-        import torch
-        if fv.nq:
-            raise ValueError("StepGraph: tracer_2d synchronises with the host (nq must be 0)")
-        if (fv.k_split * fv.fl.n_split) % 2:
-            raise ValueError("StepGraph: k_split * n_split must be even")
-        self.graph = torch.cuda.CUDAGraph()
-        self.streams = list(streams)
-        s0 = streams[0]
-        torch.cuda.synchronize()
-        with torch.cuda.graph(self.graph, stream=s0):
-            ev = torch.cuda.Event()
-            ev.record(s0)
-            for st in streams[1:]:            # fork: the other faces' streams join the capture
-                st.wait_event(ev)
-            fv.step(bdt)
-            if hasattr(fv.ctx, "flush"):      # a face group: nothing stays queued past the end of the capture
-                fv.ctx.flush()
-            for st in streams[1:]:            # join
-                e = torch.cuda.Event()
-                e.record(st)
-                s0.wait_event(e)
-
-    def replay(self):
-        """launch the graph on face 1's stream and order the other faces' streams behind it, so that whatever the host does next
-        on any face (a download, an eager kernel) sees the step finished"""
-        import torch
-        s0 = self.streams[0]
-        with torch.cuda.stream(s0):
-            self.graph.replay()
-        ev = torch.cuda.Event()
-        ev.record(s0)
-        for st in self.streams[1:]:
-            if st is not s0:
-                st.wait_event(ev)

@@ -225,7 +225,7 @@ def tracer_fields(cs, npz, nq):
     return out
 
 
-def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-12, hydrostatic=True, nq=0, face_streams=False, graph=False, flags=None,
+def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-12, hydrostatic=True, nq=0, face_streams=False, flags=None,
                   native_halo=False, fill2d=(), q_shift=0.0, remap_te=False, kord_tm=-8):
     """BASELINE configs[1] in small: the Jablonowski-Williamson baroclinic wave (test_case = 13) on the whole cubed sphere,
     hydrostatic, the reference's L79 levels (set_eta), one dt_atmos = k_split x (n_split substeps + vertical remap) on six
@@ -288,18 +288,7 @@ def check_jw_step(lib, npx=13, npz=79, k_split=1, n_split=2, bdt=600.0, tol=1e-1
                         [s["phis"] for s in st])
         if nq:
             fv.set_tracers(q0)
-        if graph:             # an eager step first (work arrays), the state again, then the step as a replayed HIP graph
-            from gfdl_atmos_cubed_sphere_amd.cubed_dyn import StepGraph
-            fv.step(bdt)
-            fv.dc.set_state([s["u"] for s in st], [s["v"] for s in st], z, [s["delp"] for s in st], [s["pt"] for s in st], dz,
-                            [s["phis"] for s in st])
-            if graph == "eager":          # (the reset logic alone, for the GPU-less harness)
-                fv.step(bdt)
-            else:
-                sg = StepGraph(fv, bdt, streams)
-                sg.replay()
-        else:
-            fv.step(bdt)
+        fv.step(bdt)
         d = fv.dc.d
         r = (bd.is_, bd.ie, bd.js, bd.je)
         for n, kind, rr in (("u", "U", (bd.is_, bd.ie, bd.js, bd.je + 1)), ("v", "V", (bd.is_, bd.ie + 1, bd.js, bd.je)),

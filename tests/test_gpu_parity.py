@@ -1004,14 +1004,6 @@ def test_substeps_through_the_c_abi_exchange(prod):
         ctx.close()
 
 
-@pytest.mark.parametrize("hydrostatic", [True, False])
-def test_cubed_sphere_step_as_a_hip_graph(prod, hydrostatic):
-    """the whole dt_atmos of the six faces captured once (hipStreamBeginCapture over the six face streams) and replayed: the
-    numbers of the eager launches -- < 1e-12 against the six-face oracle"""
-    r = PC.check_jw_step(prod, npx=25, npz=20, k_split=2, n_split=2, bdt=900.0, hydrostatic=hydrostatic, face_streams=True, graph=True)
-    assert r.pop("finite") == 1.0 and max(r.values()) <= 1e-12
-
-
 # ---- cubed sphere: the damping / heating branches a production namelist switches on ------------------------------------------------
 PROD = dict(do_vort_damp=True, vtdm4=0.06, nord=3, d_con=1.0, dddmp=0.5)
 

@@ -1,5 +1,5 @@
 """BASELINE config 2 run for real: the Jablonowski-Williamson baroclinic wave (test_case 13) on the C96 L79 hydrostatic cubed sphere,
-whole sphere on one MI355X, `--days` days of dt_atmos = 1800 s (k_split 2 x n_split 6), the step as one HIP graph.  Every 12 h:
+whole sphere on one MI355X, `--days` days of dt_atmos = 1800 s (k_split 2 x n_split 6).  Every 12 h:
 global air mass (must stay put), min / max surface pressure (JW06: the wave deepens to ~940-950 hPa around day 9), max |u|, max
 |v|.  Prints one JSON object."""
 from __future__ import annotations
@@ -31,7 +31,7 @@ def main():
     a = ap.parse_args()
     import torch
     from gfdl_atmos_cubed_sphere_amd import lib as L
-    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext, StepGraph
+    from gfdl_atmos_cubed_sphere_amd.cubed_dyn import CubeHaloAdapter, MultiContext
     from gfdl_atmos_cubed_sphere_amd.cubed_sphere import CubedSphere
     from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
     from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
@@ -93,22 +93,13 @@ def main():
                 "v_max": float(max(np.abs(bd.view(x, "V", bd.is_, bd.ie + 1, bd.js, bd.je)).max() for x in v)),
                 "finite": bool(all(np.isfinite(x[c]).all() for x in dp))}
     out = [diag(0.0)]
-    fv.step(a.dt_atmos)                          # eager first (work arrays), then the step as a graph
+    fv.step(a.dt_atmos)
     torch.cuda.synchronize()
-    graph = None
-    if nq == 0 and os.environ.get("JW_EAGER") != "1":   # (tracer_2d reads the Courant maximum back on the host: eager with tracers)
-        try:
-            graph = StepGraph(fv, a.dt_atmos, streams)
-        except Exception as e:  # noqa: BLE001
-            print(f"graph capture refused ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
     nsteps = int(round(a.days * 86400.0 / a.dt_atmos))
     every = int(round(43200.0 / a.dt_atmos))
     t0 = time.perf_counter()
     for n in range(2, nsteps + 1):
-        if graph:
-            graph.replay()
-        else:
-            fv.step(a.dt_atmos)
+        fv.step(a.dt_atmos)
         if n % every == 0:
             torch.cuda.synchronize()
             out.append(diag(n * a.dt_atmos / 86400.0))
@@ -119,7 +110,7 @@ def main():
     m0 = out[0]["mass"]
     print(json.dumps({"flags": prod or "reference defaults",
                       "config": f"C{nx} L{npz} {'hydrostatic' if hyd else 'nonhydrostatic'} JW (test_case 13), dt_atmos {a.dt_atmos} s, k_split {a.k_split}, n_split {a.n_split}, "
-                                f"whole sphere on one GPU, {'HIP graph' if nq == 0 else str(nq) + ' tracers, eager launches'}", "days": a.days, "steps": nsteps, "wall_s": wall,
+                                f"whole sphere on one GPU, {str(nq) + ' tracers, ' if nq else ''}eager launches", "days": a.days, "steps": nsteps, "wall_s": wall,
                       "sypd": a.days / 365.0 / (wall / 86400.0), "mass_drift_rel": abs(out[-1]["mass"] - m0) / m0,
                       "nq": nq, "tracer_mass_drift_rel_max": (max(abs(b_ - a_) / abs(a_) for a_, b_ in zip(out[0]["tracer_mass"], out[-1]["tracer_mass"]))
                                                               if nq else None),
