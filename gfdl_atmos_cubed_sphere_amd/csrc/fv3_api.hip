@@ -1402,6 +1402,39 @@ extern "C" int fv3_fv_tp_2d(fv3_ctx *c, int nk, const double *q, const double *c
   return 0;
 }
 
+// one thread per face of a line through ppm_face_tp, the 1-D operator of the LDS-tile kernels (ppm.h)
+struct PpmLineTile {
+  const double *h, *c;
+  double *flux;
+  int n, iord;
+  double lim_fac;
+  FV3_D void operator()(int bx, int, int, int tid, double *) const {
+    for (int f = bx * kNT + tid; f <= n; f += kNT) flux[f] = ppm_face_tp(h + f + 3, 1, c[f], iord, lim_fac);   // face f + 1 between cells f, f + 1
+  }
+};
+
+extern "C" int fv3_ppm_line(fv3_ctx *c, int iord, int which, const double *h, const double *cr, double *flux, int n) {
+  if (!c || !c->grid_ready) return fail("fv3_ppm_line: context has no grid");
+  if (!h || !cr || !flux || n < 1) return fail("fv3_ppm_line: bad arguments");
+  if (which == 0) {
+    if (!tp_ord_supported_tr(iord)) return fail("fv3_ppm_line: iord=%d not supported", iord);
+    PpmLineTile kf{h, cr, flux, n, iord, c->g.lim_fac};
+    RT(launch_p(c, "ppm_line", Dim3{1, 1, 1}, 1, kf));
+    return 0;
+  }
+  if (which != 1 && which != 2) return fail("fv3_ppm_line: which = 0 (tile operator), 1 (marching, along the lanes), 2 (marching, register window)");
+  if (which == 1 && n + 6 > 64) return fail("fv3_ppm_line: a line along the lanes holds at most 58 cells");
+  switch (iord) {
+    case 5: RT(launch_w(c, "ppm_line", 1, PpmLineMarch<5>{h, cr, flux, n, which - 1})); break;
+    case -5: RT(launch_w(c, "ppm_line", 1, PpmLineMarch<-5>{h, cr, flux, n, which - 1})); break;
+    case 6: RT(launch_w(c, "ppm_line", 1, PpmLineMarch<6>{h, cr, flux, n, which - 1})); break;
+    case 8: RT(launch_w(c, "ppm_line", 1, PpmLineMarch<8>{h, cr, flux, n, which - 1})); break;
+    case 10: RT(launch_w(c, "ppm_line", 1, PpmLineMarch<10>{h, cr, flux, n, which - 1})); break;
+    default: return fail("fv3_ppm_line: the marching operators are built for iord 5, -5, 6, 8, 10 (what d_sw and update_dz_d take)");
+  }
+  return 0;
+}
+
 // Rows per wavefront segment: the configured value, shortened on small domains so that a launch still has a few
 // thousand wavefronts (a wavefront marches tj + 6 rows one after the other: with too few of them the launch time is that
 // serial march, not throughput).  Never below 8 rows (the 6 warm-up rows of every segment are overhead).

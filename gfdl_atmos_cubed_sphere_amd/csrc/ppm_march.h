@@ -365,4 +365,35 @@ struct PpmYsw {
   }
 };
 
+// =====================================================================================================
+// fv3_ppm_line: ONE line through the 1-D operators of the marching kernels -- the unit-test surface for the reference-held vectors of
+// xppm / yppm (tests/golden/ppm1d_golden.npz), iord 10 among them: inside fv_tp_2d the inner sweep of hord 10 is ord 8
+// (tp_core.F90:136-141), so those vectors cannot pass through it unchanged.  h: the line with its 3 halo cells on either side
+// (n + 6 values, cell i at h[i + 2]), c: the n + 1 Courant numbers, flux: the n + 1 face values.
+//   along == 0: the lanes hold the line (n + 6 <= 64): ppm_faces_x, the x sweeps of the marching kernels
+//   along == 1: the register window PpmY fed cell after cell (every lane the same line): their y sweeps
+template <int ORD>
+struct PpmLineMarch {
+  const double *h, *c;
+  double *flux;
+  int n, along;
+  FV3_D void operator()(int) const {
+    if (along == 0) {
+      const vl li = make_lanes(0, n + 5), lf = make_lanes(3, n + 3);
+      const vd q = vload(h, 0, li);
+      const vd cf = vload(c, -3, lf);                       // face f = lane - 2 sits between lanes (l - 1, l): c[f - 1] = c[l - 3]
+      const vd f = ppm_faces_x<ORD>(q, cf);
+      vstore(flux, -3, f, 3, n + 3);
+    } else {
+      const vl l0 = make_lanes(0, 0);
+      PpmY<ORD> w;
+      w.init();
+      for (int r = 0; r < n + 6; r++) {
+        w.push(vload(h, r, l0));
+        if (r >= 5) vstore(flux, r - 5, w.face(vload(c, r - 5, l0)), 0, 0);   // face f = r - 4 (1-based) between cells f - 1 and f
+      }
+    }
+  }
+};
+
 }  // namespace fv3

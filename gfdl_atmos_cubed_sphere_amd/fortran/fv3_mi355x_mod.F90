@@ -9,7 +9,7 @@ module fv3_mi355x_mod
   public :: fv3_domain, fv3_grid_host, fv3_dsw_params, fv3_dsw_levels
   public :: fv3_create, fv3_destroy, fv3_set_stream, fv3_grid_upload, fv3_malloc, fv3_free
   public :: fv3_group_create, fv3_group_flush, fv3_group_stats, fv3_group_destroy
-  public :: fv3_memcpy_h2d, fv3_memcpy_d2h, fv3_sync, fv3_c_sw, fv3_d_sw, fv3_fv_tp_2d
+  public :: fv3_memcpy_h2d, fv3_memcpy_d2h, fv3_sync, fv3_c_sw, fv3_d_sw, fv3_fv_tp_2d, fv3_ppm_line
   public :: fv3_dsw_levels_upload, fv3_halo_fill_periodic, fv3_check
   public :: fv3_nh_consts, fv3_remap_params, fv3_memcpy_d2d, fv3_set_dp_ref, fv3_update_dz_c, fv3_riem_solver_c
   public :: fv3_update_dz_d, fv3_riem_solver3, fv3_p_grad_c, fv3_nh_p_grad, fv3_zh_from_delz, fv3_pk3_halo
@@ -230,6 +230,12 @@ module fv3_mi355x_mod
       type(c_ptr), value :: ctx, q, crx, cry, fx, fy, xfx, yfx, ra_x, ra_y, mfx, mfy, mass
       integer(c_int), value :: nk, hord, nord
       real(c_double), value :: damp_c
+    end function
+    !> xppm / yppm (tp_core.F90:324-1152, private there) on one line with 3 halo cells either side: a unit-test surface
+    integer(c_int) function fv3_ppm_line(ctx, iord, which, h, c, flux, n) bind(C, name="fv3_ppm_line")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx, h, c, flux
+      integer(c_int), value :: iord, which, n
     end function
     !> replaces start/complete_group_halo_update on a single-rank doubly periodic tile (fv_mp_mod.F90:646-876)
     integer(c_int) function fv3_halo_fill_periodic(ctx, field, kind, nk) bind(C, name="fv3_halo_fill_periodic")

@@ -146,6 +146,15 @@ int fv3_fv_tp_2d(fv3_ctx *ctx, int nk, const double *q, const double *crx, const
                  const double *ra_y, const double *mfx, const double *mfy, const double *mass, int nord,
                  double damp_c);
 
+/* xppm / yppm on ONE line -- model/tp_core.F90:324-712 / :715-1152 (private to tp_core_mod: the reference reaches them through
+ * fv_tp_2d only).  A unit-test surface like fv3_fv_tp_2d: the reference-held vectors of the 1-D operator (tests/golden/ppm1d_golden.npz,
+ * from the reference's docs/examples/tp_core.ipynb) go through it, iord 10 among them -- inside fv_tp_2d the inner sweep of hord 10 is
+ * ord 8 (:136-141), so its vectors cannot pass through that entry unchanged.
+ * h: the line with 3 halo cells on either side (n + 6), c: n + 1 Courant numbers, flux: n + 1 face values (device pointers).
+ * which: 0 the operator of the LDS-tile kernels (every hord of fv3_fv_tp_2d), 1 / 2 the operators of the marching kernels along
+ * the lanes (n <= 58) / through the register window (iord 5, -5, 6, 8, 10). */
+int fv3_ppm_line(fv3_ctx *ctx, int iord, int which, const double *h, const double *c, double *flux, int n);
+
 /* c_sw -- model/sw_core.F90:79-81, the k loop of model/dyn_core.F90:436-447.
  * in : delp, pt, w (A; w NULL if hydrostatic), u (U), v (V)
  * out: delpc, ptc, wc (A, valid is-1:ie+1 x js-1:je+1); uc (V), vc (U): C-grid winds advanced half a

@@ -342,6 +342,32 @@ def check_sponge_levels_march(lib, nx=130, ny=64, npz=4, hydrostatic=False, flag
     return worst, rep
 
 
+def check_golden_ppm_lines(lib, iord, which):
+    """every reference-held vector of the 1-D PPM operator (tests/golden/ppm1d_golden.npz) of scheme iord straight through fv3_ppm_line:
+    which = 0 the tile kernels' operator, 1 / 2 the marching kernels' along the lanes / through the register window.  No oracle."""
+    import json
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ppm1d_golden.npz"))
+    meta = [m for m in json.loads(str(z["meta"])) if m["iord"] == iord]
+    assert len(meta) == (36 if iord >= 8 else 24)
+    bd = Bounds(1, 8, 1, 8)
+    ctx = Context(doubly_periodic(bd, 9, 9, dx_const=1.0, dy_const=1.0), 2, lib=lib)
+    worst = 0.0
+    try:
+        for m in meta:
+            ql, c, want = z[m["key"] + "_q"], z[m["key"] + "_c"], z[m["key"] + "_flux"]
+            n = ql.size
+            h = np.concatenate([ql[-3:], ql, ql[:3]])
+            dflux = ctx.from_host(np.zeros(n + 1))
+            ctx.ppm_line(iord, which, ctx.from_host(h), ctx.from_host(np.ascontiguousarray(c)), dflux, n)
+            got = dflux.download().ravel()
+            worst = max(worst, np.max(np.abs(got - want)) / max(1e-300, np.max(np.abs(want))))
+    finally:
+        ctx.close()
+    assert worst < 5e-15, (iord, which, worst)        # observed: 0.0
+    return worst
+
+
 def check_golden_ppm_through_fv_tp_2d(lib, iord, direction="x"):
     """The reference-held vectors of the 1-D PPM operator (tests/golden/ppm1d_golden.npz: (q, c) -> face values, produced by executing
     the reference's own docs/examples/tp_core.ipynb) THROUGH THE LIBRARY's fv_tp_2d -- no oracle in between.  Every vector of the scheme is

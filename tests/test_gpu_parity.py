@@ -1372,6 +1372,14 @@ def test_golden_ppm_lines_through_fv_tp_2d(prod, iord, direction):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("which", [0, 1, 2])
+@pytest.mark.parametrize("iord", [5, -5, 6, 8, 10])
+def test_golden_ppm_lines_through_the_hip_operators(prod, iord, which):
+    """all 144 reference-held PPM vectors (hord 10 among them) through the library's three 1-D operators: fv3_ppm_line"""
+    P.check_golden_ppm_lines(prod, iord, which)
+
+
+@pytest.mark.gpu
 def test_config5_full_gnomonic_c768l79_face_33_tracers_properties(prod):
     """BASELINE configs[4] at FULL size on one GPU: one gnomonic C768 L79 face (768 x 768 x 79, grid_type 0, every metric row read), the
     hydrostatic c_sw + d_sw pair and one tracer_2d step of 33 tracers.  Past the oracle's reach, and a single face has no neighbours to

@@ -1288,3 +1288,10 @@ def test_mixed_segmentation_of_the_marching_launches(emu, monkeypatch):
 def test_golden_ppm_lines_through_fv_tp_2d(emu, iord, direction):
     """the reference-held PPM vectors (tests/golden/, from the reference's own tp_core.ipynb) straight through the library's fv_tp_2d"""
     P.check_golden_ppm_through_fv_tp_2d(emu, iord, direction)
+
+
+@pytest.mark.parametrize("which", [0, 1, 2])
+@pytest.mark.parametrize("iord", [5, -5, 6, 8, 10])
+def test_golden_ppm_lines_through_the_1d_operators(emu, iord, which):
+    """all 144 reference-held PPM vectors (hord 10 among them) through the kernel sources' three 1-D operators (fv3_ppm_line)"""
+    P.check_golden_ppm_lines(emu, iord, which)
