@@ -106,8 +106,10 @@ struct DswTransportFused {
   // ---- the row step without control flow (spmd.h "branch-free rows") ------------------------------------------------------------------
   // Every row of the segment, the warm-up rows included, runs the whole step: what the general form skips on the rows whose face / output
   // row does not exist yet is computed on values that are never kept, and the row conditions (the Courant rows / faces and the output row
-  // are the segment's own) go into the stores -- `on` of vstore_b_nt / vaccum_z -- instead of into branches.  With no branch in the loop the
-  // compiler counts the stores in flight, and the wait for the prefetched rows becomes vmcnt(<stores of the step>) instead of vmcnt(0).
+  // are the segment's own) go into the stores -- `on` of vstore_b_nt -- instead of into branches.  What keeps a (wave-uniform) branch in
+  // the loop are the four flux capacitors: they are masked L2 atomics under `if (on)` (an atomic that adds +0.0 on the rows that are
+  // not the segment's own -- spmd.h vaccum_z -- was measured slower than the branch: every row would pay four atomics).  Around them
+  // the compiler counts the stores in flight, so the wait for the prefetched rows is vmcnt(<stores of the step>) instead of vmcnt(0).
   // The one store that belongs to a single row of the whole tile (mfy of the north face of row je) follows the loop.
   FV3_D void run_bf(int gid) const {
     int strip, seg, kk, tjw;
@@ -192,9 +194,8 @@ struct DswTransportFused {
       const In in = nxt;
       const int j = r - 3, jf = r - 2;
       const int jc = j < jA ? jA : j, jfc = jf < jA ? jA : jf;   // rows of the (dropped) stores / zero additions of the warm-up steps
-      // the flux capacitors cx, cy, mfx, mfy (sw_core.F90:923-940) as load - add - store: every element has one owner (strip, segment),
-      // and the old value is read at the top of the step that stores the sum.  (As L2 atomics -- no register for the old value -- the
-      // four accumulations cost 0.23 ms of the kernel's 0.90: global_atomic_add_f64 is the slowest thing a row step can do.)
+      // (the flux capacitors cx, cy, mfx, mfy, sw_core.F90:923-940, are L2 atomics below -- global_atomic_add_f64 without return: no
+      // register for the old value, no load; every element is added to by one lane of one wavefront, so the sum is the plain IEEE one)
       nxt = load_in(r < rlast ? r + 1 : rlast);
       Tp2dShared sh;
       vd xfj = in.xfj, cxj_uni(0.);

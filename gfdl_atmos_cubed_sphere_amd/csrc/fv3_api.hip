@@ -862,6 +862,18 @@ extern "C" int fv3_registry_fetch(fv3_ctx *c, void *host) {
   if (any) RT(rtf_sync(c->stream));
   return 0;
 }
+// an entry is keyed by the HOST ADDRESS and knows nothing of the array's lifetime: a host array that is freed and allocated again at the
+// same address with the same mirror and size would still read as "device copy current" in lazy mode.  The caller that frees or rebinds
+// an array says so (host = NULL: every entry); what the host copy lacks is fetched first unless `discard`.
+extern "C" int fv3_registry_forget(fv3_ctx *c, void *host, int discard) {
+  if (!c) return fail("fv3_registry_forget: null context");
+  if (!c->reg) return 0;
+  if (!discard) RT(fv3_registry_fetch(c, host));
+  auto &v = *c->reg;
+  for (size_t n = v.size(); n-- > 0;)
+    if (!host || v[n].host == host) v.erase(v.begin() + (long)n);
+  return 0;
+}
 extern "C" int fv3_registry_stats(fv3_ctx *c, long long *out4) {
   if (!c || !out4) return fail("fv3_registry_stats: null argument");
   for (int i = 0; i < 4; i++) out4[i] = c->reg_stat[i];

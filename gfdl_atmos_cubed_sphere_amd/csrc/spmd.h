@@ -299,8 +299,9 @@ __device__ __forceinline__ void vstore_nt(double *p, long off, vd x, int lmin, i
 //    and every access pays a 64-bit VALU add);
 //  * vm / vstore_b: stores through a buffer resource over the row; a lane outside the mask carries the byte offset 0x80000000, beyond
 //    num_records, and the hardware drops its store (tools/probe/buf_oob.hip: the range check takes voffset + soffset against num_records);
-//  * vaccum_z: the L2 accumulation with the address clamped to valid elements and +0.0 on the lanes outside the mask (x + 0.0 == x for
-//    every x that is not -0.0, and an accumulator that starts at +0.0 never becomes -0.0).
+//  * vaccum_z (an A / B variant, not used by the library's kernels: slower than the wave-uniform branch around vaccum, dsw_fused.h run_bf):
+//    the L2 accumulation with the address clamped to valid elements and +0.0 on the lanes outside the mask (x + 0.0 == x for every x
+//    that is not -0.0, and an accumulator that starts at +0.0 never becomes -0.0).
 using vm = unsigned;  // byte offset of the lane, or 0x80000000 = masked
 __device__ __forceinline__ vm make_mask(int lmin, int lmax) {
   const int l = (int)(threadIdx.x & (kW - 1));

@@ -60,7 +60,7 @@ class DynFlags:
     cp_air: float = CP_AIR
     fast_tau_w_sec: float = 0.0   # > 1e-5: Rayleigh damping of w inside SIM1 / SIM (nh_utils.F90:356-367, :1363-1371), fv_arrays.F90:702
     rf_fast: bool = False         # RF_fast: Ray_fast at the end of every acoustic substep when tau > 0 (dyn_core.F90:1057-1060)
-    tau: float = 0.0              # days (Ray_fast; the Rayleigh_Friction / _Super of fv_dynamics is FvDynamics' own tau)
+    tau: float = 0.0              # days: flagstruct%tau -- Ray_fast here, Rayleigh_Friction / _Super in FvDynamics (which merges its tau argument into this)
     rf_cutoff: float = 30.0e2
 
 
@@ -157,6 +157,16 @@ class DynCore:
                             rdgas=flags.rdgas, cp_air=flags.cp_air, m_split=getattr(flags, "m_split", 1))
 
     # -- the damping profiles the reference evaluates on the first call and keeps ------------------------
+    def _diss_est_begin(self) -> bool:
+        """flagstruct%do_diss_est (the SKEB dissipation estimate; a member of the gridstruct the context uploaded): d_sw returns diss_e of
+        every level, dyn_core sums it into diss_est over the acoustic substeps (dyn_core.F90:805-811); diss_est is zeroed on the first
+        call only (init_step, :285) and keeps accumulating over the calls after it, as the reference's does."""
+        if not getattr(self.ctx.grid, "do_diss_est", False):
+            return False
+        if "diss_est" not in self.d:
+            self.d["diss_est"] = self.ctx.zeros("A", self.npz)
+        return True
+
     def fast_tau_w_profile(self, dt_c: float):
         """rff(1:k_rf) of nh_utils.F90:356-367: Riem_Solver_c's first call, with ITS dt (half the acoustic step)"""
         fl, rff = self.fl, []
@@ -255,6 +265,7 @@ class DynCore:
             if "heat_source" not in d:
                 d["heat_source"] = ctx.zeros("A", self.npz)
             d["heat_source"].zero()
+        diss = self._diss_est_begin()
         par = dict(dt=dt, hord_tr=fl.hord_tr, hord_mt=fl.hord_mt, hord_vt=fl.hord_vt, hord_tm=fl.hord_tm,
                    hord_dp=fl.hord_dp, dddmp=fl.dddmp, d4_bg=fl.d4_bg, kgb=fl.ke_bg, hydrostatic=1, use_cond=0)
         halo.update([(d["delp"], "A"), (d["pt"], "A")])
@@ -274,7 +285,8 @@ class DynCore:
             mfx, mfy = self._inline_q_fluxes() if inline else (d["mfx"], d["mfy"])
             dsw_args = (par, d["vt"], d["delp"], d["pt"], d["u"], d["v"], None, d["uc"], d["vc"], d["ua"], d["va"],
                         d["divgd"], mfx, mfy, d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"], None,
-                        d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], None, None, d["heat_s"] if heating else None, None)   # (read only when d_con > 1e-5, :798-812)
+                        d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], None, None, d["heat_s"] if heating else None,
+                        d["diss_e"] if diss else None)   # (heat_s is read only when d_con > 1e-5, diss_e with do_diss_est: :798-812)
             if halo.overlaps:      # :565 / :578 (pack 9) around the interior of d_sw (:762), as in the nonhydrostatic loop
                 pending = halo.start([(d["uc"], "V"), (d["vc"], "U")], defer=True)
                 ctx.d_sw(*dsw_args, phase="interior")
@@ -286,6 +298,8 @@ class DynCore:
                 ctx.d_sw(*dsw_args)                                           # :762
             if heating:
                 ctx.heat_source_accum(d["heat_source"], d["heat_s"])
+            if diss:
+                ctx.heat_source_accum(d["diss_est"], d["diss_e"])             # :805-811
             if inline:
                 self._inline_q_transport()
             # external-mode damping field from the delp BEFORE d_sw (:745-747) and d_sw's divergence output (:791-848)
@@ -336,6 +350,7 @@ class DynCore:
             if "pkz" not in d:
                 d["pkz"] = ctx.zeros("CC", self.npz)
             d["heat_source"].zero()
+        diss = self._diss_est_begin()
         par = dict(dt=dt, hord_tr=fl.hord_tr, hord_mt=fl.hord_mt, hord_vt=fl.hord_vt, hord_tm=fl.hord_tm,
                    hord_dp=fl.hord_dp, dddmp=fl.dddmp, d4_bg=fl.d4_bg, kgb=fl.ke_bg, hydrostatic=0,
                    use_cond=int(fl.use_cond))
@@ -369,7 +384,8 @@ class DynCore:
                         d["divgd"], mfx, mfy, d["cx"], d["cy"], d["crx"], d["cry"], d["xfx"], d["yfx"],
                         d["q_con"] if fl.use_cond else None,
                         d["delp_nxt"], d["pt_nxt"], d["u_nxt"], d["v_nxt"], d["w_nxt"],
-                        d["q_con_nxt"] if fl.use_cond else None, d["heat_s"] if heating else None, None)   # (read only when d_con > 1e-5, :798-812)
+                        d["q_con_nxt"] if fl.use_cond else None, d["heat_s"] if heating else None,
+                        d["diss_e"] if diss else None)   # (heat_s is read only when d_con > 1e-5, diss_e with do_diss_est: :798-812)
             if halo.overlaps:
                 pending = halo.start([(d["uc"], "V"), (d["vc"], "U")], defer=True)
                 ctx.d_sw(*dsw_args, phase="interior")
@@ -381,6 +397,8 @@ class DynCore:
                 ctx.d_sw(*dsw_args)
             if heating:
                 ctx.heat_source_accum(d["heat_source"], d["heat_s"])          # :798-803
+            if diss:
+                ctx.heat_source_accum(d["diss_est"], d["diss_e"])             # :805-811: diss_est(i,j,k) += diss_e(i,j)
             if inline:
                 self._inline_q_transport()
             if fl.beta < -0.1 and fl.d_ext > 0.0:   # :745-747, :791-848: the external-mode damping field of one_grad_p (:1030)

@@ -30,6 +30,19 @@ class FvDynamics:
                  remap_te: bool = False, consv_am: dict | None = None):
         ak, bk = np.asarray(ak, dtype=np.float64), np.asarray(bk, dtype=np.float64)
         dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5          # dyn_core.F90:241-244
+        # flagstruct%tau / %rf_cutoff are ONE pair in the reference: Rayleigh_Friction / _Super here (fv_dynamics.F90:362-376) and Ray_fast /
+        # fast_tau_w_sec inside dyn_core (dyn_core.F90:1057-1060) read the same numbers.  The argument and the flags' member are merged
+        # (either may carry the value; two different values are an error), so that tau > 0 with rf_fast damps through Ray_fast
+        # instead of silently not at all.
+        import dataclasses
+        if tau != 0.0 and flags.tau != 0.0 and tau != flags.tau:
+            raise ValueError(f"FvDynamics: tau = {tau} but flags.tau = {flags.tau} (flagstruct%tau is one number)")
+        tau = tau if tau != 0.0 else flags.tau
+        rf_default = DynFlags.__dataclass_fields__["rf_cutoff"].default
+        if rf_cutoff != rf_default and flags.rf_cutoff != rf_default and rf_cutoff != flags.rf_cutoff:
+            raise ValueError(f"FvDynamics: rf_cutoff = {rf_cutoff} but flags.rf_cutoff = {flags.rf_cutoff}")
+        rf_cutoff = rf_cutoff if rf_cutoff != rf_default else flags.rf_cutoff
+        flags = dataclasses.replace(flags, tau=tau, rf_cutoff=rf_cutoff)
         self.ctx, self.fl, self.nq, self.k_split, self.q_split, self.dist = ctx, flags, nq, k_split, q_split, dist
         self.nord_tr, self.trdm2 = nord_tr, trdm2
         # fill2D (fv_dynamics.F90:542-556, FILL2D builds): the 0-based tracer indices of liq_wat, rainwat, ice_wat, snowwat, graupel

@@ -128,12 +128,17 @@ int fv3_sync(fv3_ctx *ctx);
  *   with fv3_registry_host_touched(ctx, host); host = NULL: every array), get only marks the host copy stale; the caller brings an array
  *   it wants to read with fv3_registry_fetch(ctx, host) (NULL: every stale array).
  * fv3_registry_stats: {h2d copies, h2d skipped, d2h copies, d2h deferred}.  The Fortran wrappers go through it
- * (fortran/fv3_dyn_core_mod.F90: fv3_dyn_core_registry, fv3_host_touched, fv3_host_fetch). */
+ * (fortran/fv3_dyn_core_mod.F90: fv3_dyn_core_registry, fv3_host_touched, fv3_host_fetch).
+ * An entry is keyed by the host ADDRESS and does not know the array's lifetime: lazy mode needs contiguous actual arguments that stay
+ * where they are between the calls (a non-contiguous actual reaches the wrapper as a compiler temporary, i.e. as the address of a
+ * copy); an array that is deallocated or rebound is taken out with fv3_registry_forget(ctx, host, discard) (host = NULL: every entry;
+ * discard = 0 fetches what the host copy lacks first). */
 int fv3_registry_mode(fv3_ctx *ctx, int lazy);
 int fv3_registry_put(fv3_ctx *ctx, void *dev, const void *host, size_t bytes);
 int fv3_registry_get(fv3_ctx *ctx, void *host, const void *dev, size_t bytes);
 int fv3_registry_host_touched(fv3_ctx *ctx, const void *host);
 int fv3_registry_fetch(fv3_ctx *ctx, void *host);
+int fv3_registry_forget(fv3_ctx *ctx, void *host, int discard);
 int fv3_registry_stats(fv3_ctx *ctx, long long *out4);
 
 /* fv_tp_2d -- model/tp_core.F90:85-87 (called from sw_core.F90:919,983,993,1014,1498,

@@ -104,6 +104,9 @@ def _run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float, pfull=None, ks
         if heating:                                                        # dyn_core.F90:798-803
             i0, j0 = bd.ng, bd.ng
             f["heat_source"][i0:i0 + nx, j0:j0 + ny, :] += f["heat_s"]
+        if g.do_diss_est:                                                  # dyn_core.F90:805-811 (zero on the first call, :285)
+            f.setdefault("diss_est", bd.zeros("A", npz))
+            f["diss_est"][bd.ng:bd.ng + nx, bd.ng:bd.ng + ny, :] += f["diss_e"]
         if fl.beta < -0.1:                                                 # dyn_core.F90:745-747, :791-848 (zeros when d_ext = 0)
             f.setdefault("divg2", bd.zeros("A"))
             O.divg2_ext(g, npz, fl.d_ext, delp_start, f["vt"], f["divg2"])
@@ -200,6 +203,9 @@ def run_hydrostatic(g, npz: int, fl: DynFlags, st: dict, bdt: float):
         O.d_sw_3d(g, npz, par, lev, ds)
         if heating:
             f["heat_source"][i0:i0 + nx, j0:j0 + ny, :] += f["heat_s"]
+        if g.do_diss_est:                                                  # dyn_core.F90:805-811
+            f.setdefault("diss_est", bd.zeros("A", npz))
+            f["diss_est"][bd.ng:bd.ng + nx, bd.ng:bd.ng + ny, :] += f["diss_e"]
         O.divg2_ext(g, npz, fl.d_ext, delp_old, f["vt"], f["divg2"])
         _fill(bd, f["delp"], "A"); _fill(bd, f["pt"], "A")
         O.geopk(g, npz, fl.ptop, fl.akap, fl.cp_air, f["pe"], f["peln"], f["delp"], f["pkc"], f["gz"], f["phis"], f["pt"],

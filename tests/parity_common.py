@@ -342,6 +342,41 @@ def check_sponge_levels_march(lib, nx=130, ny=64, npz=4, hydrostatic=False, flag
     return worst, rep
 
 
+def check_registry_forget(lib):
+    """the host-address registry in lazy mode (include/fv3_mi355x.h): a put of a current entry is skipped; an array that was freed and
+    allocated again at the same address must leave the registry (fv3_registry_forget) or the device keeps the old values"""
+    import ctypes as C
+    bd = Bounds(1, 8, 1, 8)
+    ctx = Context(doubly_periodic(bd, 9, 9, dx_const=1.0, dy_const=1.0), 2, lib=lib)
+    try:
+        dll, h = lib.dll, ctx.h
+        host = np.arange(64, dtype=np.float64)
+        dev = ctx.from_host(np.zeros(64))
+        hp = host.ctypes.data_as(C.c_void_p)
+        nb = C.c_size_t(host.nbytes)
+        lib.check(dll.fv3_registry_mode(h, C.c_int(1)), "mode")
+        lib.check(dll.fv3_registry_put(h, dev.p, hp, nb), "put")
+        assert np.array_equal(dev.download().ravel(), host)
+        host[:] = -host                                            # "a new array at the old address"
+        lib.check(dll.fv3_registry_put(h, dev.p, hp, nb), "put")   # lazy: the entry says the mirror is current -> skipped
+        assert np.array_equal(dev.download().ravel(), -host)
+        lib.check(dll.fv3_registry_forget(h, hp, C.c_int(1)), "forget")
+        lib.check(dll.fv3_registry_put(h, dev.p, hp, nb), "put")   # no entry: copied
+        assert np.array_equal(dev.download().ravel(), host)
+        # discard = 0 brings a deferred result to the host before the entry goes
+        dev.upload(np.full(64, 7.0))
+        lib.check(dll.fv3_registry_get(h, hp, dev.p, nb), "get")   # lazy: deferred
+        assert not np.array_equal(host, np.full(64, 7.0))
+        lib.check(dll.fv3_registry_forget(h, None, C.c_int(0)), "forget")
+        assert np.array_equal(host, np.full(64, 7.0))
+        st = (C.c_longlong * 4)()
+        lib.check(dll.fv3_registry_stats(h, st), "stats")
+        assert list(st) == [2, 1, 1, 1], list(st)
+        lib.check(dll.fv3_registry_mode(h, C.c_int(0)), "mode")
+    finally:
+        ctx.close()
+
+
 def check_golden_ppm_lines(lib, iord, which):
     """every reference-held vector of the 1-D PPM operator (tests/golden/ppm1d_golden.npz) of scheme iord straight through fv3_ppm_line:
     which = 0 the tile kernels' operator, 1 / 2 the marching kernels' along the lanes / through the register window.  No oracle."""

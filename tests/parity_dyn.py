@@ -30,9 +30,12 @@ def ulp_sensitivity(g, npz, fl, dp0, st, bdt, ref):
     return {n: P.rel_rms(pert[n], ref[n]) for n in ("u", "v", "w", "delp", "pt", "zh", "delz", "mfx", "mfy", "cx", "cy")}
 
 
-def check_substeps(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None, tol=None, ic=None, pfull=None, ks=0):
+def check_substeps(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None, tol=None, ic=None, pfull=None, ks=0, do_diss_est=False):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
+    if do_diss_est:     # flagstruct%do_diss_est: a member of the gridstruct the context uploads
+        import dataclasses
+        g = dataclasses.replace(g, do_diss_est=True, prevent_diss_cooling=False)
     st, dp0 = make_state(bd, npz)
     apply_ic(bd, npz, st, ic)
     fl = DynFlags(n_split=n_split, ptop=N.PTOP, **(flags or {}))
@@ -60,6 +63,9 @@ def check_substeps(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None, tol
         out["omga"] = P.assert_close("omga", om_got, om_ref, tol)
         for n in ("mfx", "mfy", "cx", "cy"):
             out[n] = P.assert_close(n, got[n], ref[n], tols[n])
+        if do_diss_est:   # diss_est(i,j,k) summed over the acoustic substeps (dyn_core.F90:805-811)
+            assert np.max(np.abs(bd.view(ref["diss_est"], "A", *r))) > 0.0
+            out["diss_est"] = P.assert_close("diss_est", bd.view(dc.d["diss_est"].download(), "A", *r), bd.view(ref["diss_est"], "A", *r), tol)
         # sanity: the step did something and stayed sane
         assert np.all(ref["delz"] < 0) and np.max(np.abs(ref["w"])) < 50.0
     finally:
@@ -174,7 +180,7 @@ def check_fv_step_hydrostatic(lib, nx=24, ny=16, npz=10, nq=2, k_split=2, n_spli
     return out
 
 
-def oracle_fv_step(g, npz, fl, dp0, st, ak, bk, q, bdt, k_split, remap_par, last_step=False, fill2d=()):
+def oracle_fv_step(g, npz, fl, dp0, st, ak, bk, q, bdt, k_split, remap_par, last_step=False, fill2d=(), pfull=None, ks=0):
     """Oracle-orchestrated k_split loop (fv_dynamics.F90:460-665): dyn_core -> tracer_2d -> Lagrangian_to_Eulerian."""
     import oracle_lib as O
     bd = g.bd
@@ -192,7 +198,7 @@ def oracle_fv_step(g, npz, fl, dp0, st, ak, bk, q, bdt, k_split, remap_par, last
             OD._fill(bd, cur["cappa"], "A")                                  # :465 / :488
         if nq and fl.inline_q:
             cur["q"] = q
-        f = OD.run(g, npz, fl, dp0, cur, mdt)
+        f = OD.run(g, npz, fl, dp0, cur, mdt, pfull=pfull, ks=ks)
         if nq and fl.inline_q:
             q = f["q"]
         elif nq:
@@ -298,7 +304,7 @@ def check_fv_cycle_moist(lib, nx=24, ny=16, npz=10, k_split=2, n_split=2, bdt=8.
     return out
 
 
-def check_fv_cycle_from_temperature(lib, nx=24, ny=16, npz=10, k_split=2, n_split=2, bdt=8.0, tau=0.0, consv_am=False):
+def check_fv_cycle_from_temperature(lib, nx=24, ny=16, npz=10, k_split=2, n_split=2, bdt=8.0, tau=0.0, consv_am=False, rf_fast=False):
     """A whole adiabatic fv_dynamics call: T -> theta_v (fv_dynamics.F90:284-399), k_split loop, last remap back to T.
     Oracle side: the same conversion in numpy, then the oracle-orchestrated loop with last_step on the final cycle."""
     from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
@@ -323,10 +329,10 @@ def check_fv_cycle_from_temperature(lib, nx=24, ny=16, npz=10, k_split=2, n_spli
     sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
     dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
-    fl = DynFlags(n_split=n_split, ptop=N.PTOP)
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, rf_fast=rf_fast)
     rf_cutoff = 0.5 * (ak[npz // 2] + bk[npz // 2] * 1.0e5)          # the upper half of the column is damped
     ost = dict(st, pt=th2)
-    if tau > 0.0:
+    if tau > 0.0 and not rf_fast:    # (RF_fast: no Rayleigh_Friction here, Ray_fast after every acoustic substep instead -- :362, dyn_core.F90:1057)
         # Rayleigh_Friction between the pkz evaluation and the conversion (fv_dynamics.F90:323-326, :368-376, :389-397)
         from gfdl_atmos_cubed_sphere_amd.layout import periodic_fill
         ph = ak + bk * 1.0e5
@@ -359,7 +365,14 @@ def check_fv_cycle_from_temperature(lib, nx=24, ny=16, npz=10, k_split=2, n_spli
     ctx = Context(g, npz, lib=lib)
     try:
         fv = FvDynamics(ctx, fl, ak, bk, nq=0, k_split=k_split, tau=tau, rf_cutoff=rf_cutoff, consv_am=ca)
-        ref = oracle_fv_step(g, npz, fl, dp_ref, ost, ak, bk, None, bdt, k_split, fv.remap_par, last_step=True)
+        assert fv.fl.tau == tau and fv.fl.rf_cutoff == rf_cutoff        # ONE flagstruct%tau: the argument reaches dyn_core's flags
+        ph_ = ak + bk * 1.0e5                                            # fv_dynamics.F90:254-262: pfull, ks as FvDynamics forms them
+        pf_ = (ph_[1:] - ph_[:-1]) / np.log(ph_[1:] / ph_[:-1])
+        ks_ = max(int(np.argmax(bk != 0.0)) - 1, 0)
+        ref = oracle_fv_step(g, npz, fv.fl, dp_ref, ost, ak, bk, None, bdt, k_split, fv.remap_par, last_step=True, pfull=pf_, ks=ks_)
+        if rf_fast:    # the damping is in the run at all (it was silently dropped when tau lived in two places)
+            off = oracle_fv_step(g, npz, DynFlags(n_split=n_split, ptop=N.PTOP), dp_ref, ost, ak, bk, None, bdt, k_split, fv.remap_par, last_step=True)
+            assert P.rel_rms(off["u"], ref["u"]) > 1e-7
         fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], T, st["delz"], st["phis"])
         fv.step_from_temperature(bdt)
         d = fv.dc.d
@@ -443,10 +456,13 @@ def check_fv_step(lib, nx=24, ny=16, npz=10, nq=2, k_split=2, n_split=2, bdt=8.0
     return out
 
 
-def check_substeps_hydrostatic(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None, ic=None):
+def check_substeps_hydrostatic(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None, ic=None, do_diss_est=False):
     """hydrostatic substep loop (c_sw, geopk, p_grad_c, d_sw, geopk, one_grad_p with external-mode damping)"""
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
+    if do_diss_est:
+        import dataclasses
+        g = dataclasses.replace(g, do_diss_est=True, prevent_diss_cooling=False)
     st, dp0 = make_state(bd, npz)
     apply_ic(bd, npz, st, ic)
     hst = {k: st[k] for k in ("u", "v", "delp", "pt", "phis")}
@@ -468,6 +484,9 @@ def check_substeps_hydrostatic(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, fla
         for n in ("mfx", "mfy", "cx", "cy", "pk", "pkz", "peln"):
             out[n] = P.assert_close(n, d[n].download(), ref[n], tol)
         out["pe"] = P.assert_close("pe", d["pe"].download()[1:-1, :, 1:-1], ref["pe"][1:-1, :, 1:-1], tol)
+        if do_diss_est:
+            assert np.max(np.abs(bd.view(ref["diss_est"], "A", *r))) > 0.0
+            out["diss_est"] = P.assert_close("diss_est", bd.view(d["diss_est"].download(), "A", *r), bd.view(ref["diss_est"], "A", *r), tol)
     finally:
         ctx.close()
     return out

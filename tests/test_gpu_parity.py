@@ -631,6 +631,25 @@ def test_fv_dynamics_call_with_rayleigh_friction(prod):
     D.check_fv_cycle_from_temperature(prod, tau=0.01)
 
 
+def test_registry_forget(prod):
+    """a host array that is freed and allocated again at the same address leaves the lazy registry"""
+    P.check_registry_forget(prod)
+
+
+def test_dyn_core_substeps_with_do_diss_est(prod):
+    """flagstruct%do_diss_est through DynCore: d_sw's diss_e of every level summed into diss_est over the substeps (dyn_core.F90:805-811);
+    with the heating on top (d_con = 1) in the second run"""
+    D.check_substeps(prod, do_diss_est=True)
+    D.check_substeps(prod, do_diss_est=True, flags=dict(d_con=1.0), npz=10)
+    D.check_substeps_hydrostatic(prod, do_diss_est=True)
+
+
+def test_fv_dynamics_call_with_rf_fast(prod):
+    """flagstruct%tau > 0 with RF_fast given to FvDynamics: no Rayleigh_Friction (fv_dynamics.F90:362), Ray_fast after every acoustic
+    substep instead (dyn_core.F90:1057-1060) -- ONE tau for both (with tau in two places this ran undamped)"""
+    D.check_fv_cycle_from_temperature(prod, tau=0.002, rf_fast=True)
+
+
 def test_halo_messages_through_rccl_loopback():
     """the N-GPU message path (pack -> RCCL batch_isend_irecv -> unpack) on one GPU: every message is a self message"""
     import subprocess

@@ -552,6 +552,25 @@ def test_fv_dynamics_call_with_rayleigh_friction(emu):
     D.check_fv_cycle_from_temperature(emu, tau=0.01)
 
 
+def test_registry_forget(emu):
+    """a host array that is freed and allocated again at the same address leaves the lazy registry"""
+    P.check_registry_forget(emu)
+
+
+def test_dyn_core_substeps_with_do_diss_est(emu):
+    """flagstruct%do_diss_est through DynCore: d_sw's diss_e of every level summed into diss_est over the substeps (dyn_core.F90:805-811);
+    with the heating on top (d_con = 1) in the second run"""
+    D.check_substeps(emu, do_diss_est=True)
+    D.check_substeps(emu, do_diss_est=True, flags=dict(d_con=1.0), npz=10)
+    D.check_substeps_hydrostatic(emu, do_diss_est=True)
+
+
+def test_fv_dynamics_call_with_rf_fast(emu):
+    """flagstruct%tau > 0 with RF_fast given to FvDynamics: no Rayleigh_Friction (fv_dynamics.F90:362), Ray_fast after every acoustic
+    substep instead (dyn_core.F90:1057-1060) -- ONE tau for both (with tau in two places this ran undamped)"""
+    D.check_fv_cycle_from_temperature(emu, tau=0.002, rf_fast=True)
+
+
 def test_fortran_host_drives_the_library(emu, tmp_path):
     """the Fortran host (fv3_host_mod + fv3_solo, amdflang) against the host-emulation build of the same C ABI"""
     import fortran_host as F
