@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): bash tools/r5_round.sh <tag> -- the round's evidence in one call: HBM counters of the pair and of the remap (bench.py
+# usage (on the GPU box): bash tools/r6_round.sh <tag> -- the round's evidence in one call: HBM counters of the pair and of the remap (bench.py
 # reports them), the bench line, kernel-trace stats of the same command, and (round 5) the SQ counters of the pair's kernels:
 # instructions issued, wavefront / wait cycles -> gpurun_out/<tag>/pmc_sq_pair.csv
 TAG=${1:-vX}
@@ -7,6 +7,7 @@ R=$PWD
 mkdir -p gpurun_out/$TAG
 bash tools/pmc_hbm_pair.sh $TAG
 bash tools/pmc_remap.sh $TAG
+bash tools/pmc_riem.sh $TAG      # round 6: the Riemann solvers' counters every round (none were taken in round 5)
 cp gpurun_out/$TAG/hbm_traffic.json profiles/hbm_traffic.json
 cp gpurun_out/$TAG/hbm_traffic_remap.json profiles/hbm_traffic_remap.json
 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
