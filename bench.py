@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--nx", type=int, default=384)
+    ap.add_argument("--ny", type=int, default=0, help="rows of a rank's block when they differ from --nx (e.g. --nx 512 --ny 256: the block of the 8-GPU "
+                                                      "strong-scaling run of BASELINE config 4, for FV3_BENCH_LOOPBACK=1 on one GPU)")
     ap.add_argument("--npz", type=int, default=127)
     ap.add_argument("--domain", type=int, default=0,
                     help="STRONG scaling: one doubly periodic DOMAIN x DOMAIN x npz domain (BASELINE config 4: 1024) split px x py over the "
@@ -665,7 +667,7 @@ def main():
 
     # WEAK scaling (the default, `value` of the driver's --gpus N runs): every rank holds its own nx x nx block
     # STRONG scaling (--domain D, BASELINE config 4): one D x D domain, the block shrinks with the layout
-    ny = nx
+    ny = a.ny or nx
     if a.domain:
         if a.domain % px or a.domain % py:
             raise SystemExit(f"bench: --domain {a.domain} does not divide over the {px} x {py} layout")
@@ -841,7 +843,7 @@ def main():
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
            "scaling": "strong" if a.domain else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": (f"ONE doubly periodic {a.domain}x{a.domain}x{npz} domain (BASELINE config 4) split {px}x{py}: {nx}x{ny} per GPU, "
-                                   if a.domain else f"doubly periodic {nx}x{nx}x{npz} tile per GPU (C384L127-sized), ") +
+                                   if a.domain else f"doubly periodic {nx}x{ny}x{npz} tile per GPU" + (" (C384L127-sized), " if (nx, ny, npz) == (384, 384, 127) else ", ")) +
                                   f"nonhydrostatic, c_sw+d_sw pair, hord {a.hord}/{a.hord}/{a.hord}/{a.hord}, nord=1, d4_bg=0.16",
                       "layout": f"{px}x{py}", "halo": ("RCCL send/recv (loopback)" if loopback else "periodic copy") if world == 1 else "RCCL send/recv",
                       # what fv3_grid_upload found in the metric arrays (fv3_grid_geom)
