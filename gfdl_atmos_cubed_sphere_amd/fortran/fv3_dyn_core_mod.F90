@@ -28,7 +28,8 @@
 !> fv3_halo_complete with the neighbour PEs, tracer_2d's mp_reduce_max through fv3_allreduce_max (fv3_host_comm_layout).
 !>
 !> Restrictions (error stop with the reason, never a silent difference): no nesting / regional BCs;
-!> do_diss_est and the SKEB diss_est accumulation, consv_am, hybrid_z are not carried through this wrapper.  consv_te, tau > 0, RF_fast,
+!> consv_am, hybrid_z are not carried through this wrapper; do_diss_est (the SKEB diss_est accumulation) is carried on the doubly
+!> periodic domain, not on the sphere.  consv_te, tau > 0, RF_fast,
 !> fast_tau_w_sec and thermostruct%use_cond / moist_kappa (the reference's defaults) are carried on both domains.
 module fv3_arrays_compat_mod
   use iso_c_binding
@@ -266,7 +267,7 @@ contains
     real(c_double), intent(inout), target :: pt(bd%isd:bd%ied, bd%jsd:bd%jed, npz), delp(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
     real(c_double), intent(inout) :: q(bd%isd:bd%ied, bd%jsd:bd%jed, npz, nq)
     real(c_double), intent(inout), target :: heat_source(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
-    real(c_double), intent(inout) :: diss_est(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
+    real(c_double), intent(inout), target :: diss_est(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
     real(c_double), intent(in), optional :: time_total
     real(c_double), intent(inout), target :: phis(bd%isd:bd%ied, bd%jsd:bd%jed)
     real(c_double), intent(inout), target :: pe(bd%is-1:bd%ie+1, npz+1, bd%js-1:bd%je+1)
@@ -304,7 +305,6 @@ contains
     if (moist .and. hydrostatic) error stop 'dyn_core (fv3_dyn_core_mod): use_cond / moist_kappa are nonhydrostatic branches'
     if (thermostruct%use_cond .and. size(q_con, 3) < npz) error stop 'dyn_core (fv3_dyn_core_mod): use_cond needs q_con on npz levels'
     if (thermostruct%moist_kappa .and. size(cappa, 3) < npz) error stop 'dyn_core (fv3_dyn_core_mod): moist_kappa needs cappa on npz levels'
-    if (flagstruct%do_diss_est) error stop 'dyn_core (fv3_dyn_core_mod): do_diss_est is not carried through this wrapper'
     if (flagstruct%beta < 0.d0 .and. (hydrostatic .or. flagstruct%beta >= -0.1d0 .or. gridstruct%grid_type < 3)) &
       error stop 'dyn_core (fv3_dyn_core_mod): beta < 0: one_grad_p (beta < -0.1) is built for the nonhydrostatic loop of the doubly periodic domain'
     if (ng /= 3 .or. bd%ng /= 3) error stop 'dyn_core (fv3_dyn_core_mod): ng = 3'
@@ -350,6 +350,11 @@ contains
     call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
 
     if (.not. allocated(at%pfull)) at%pfull = pfull                        ! what Riem_Solver_c (:536) and Ray_fast (:1058) are handed
+    if (flagstruct%do_diss_est) then                                       ! :285 (zero on init_step), then the caller's array rides along
+      if (init_step) diss_est = 0.d0
+      call diss_est_begin(at)
+      call rput(at%diss_est, c_loc(diss_est), at%nA*nk)
+    end if
     call fv3_dyn_core(at, bdt)                                             ! the substep loop (both branches), d_con heating
 
     ! ---- device -> host ----
@@ -367,6 +372,7 @@ contains
     call rget(c_loc(mfx), at%mfx, at%nFX*nk);   call rget(c_loc(mfy), at%mfy, at%nFY*nk)
     call rget(c_loc(cx), at%cx, at%nCX*nk);     call rget(c_loc(cy), at%cy, at%nCY*nk)
     if (flagstruct%d_con > 1.d-5) call rget(c_loc(heat_source), at%heat_source, at%nA*nk)
+    if (flagstruct%do_diss_est) call rget(c_loc(diss_est), at%diss_est, at%nA*nk)
     if (thermostruct%use_cond) call get(c_loc(qc_c), at%q_con, at%nA*nk)
     call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
     if (thermostruct%use_cond) q_con(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz) = qc_c
@@ -528,7 +534,7 @@ contains
       type(fv3_flags) :: fl
       dom%is = bd%is; dom%ie = bd%ie; dom%js = bd%js; dom%je = bd%je; dom%ng = 3
       dom%npx = npx; dom%npy = npy; dom%npz = npz; dom%grid_type = gridstruct%grid_type
-      dom%do_diss_est = 0; dom%prevent_diss_cooling = merge(1, 0, flagstruct%prevent_diss_cooling)
+      dom%do_diss_est = merge(1, 0, flagstruct%do_diss_est); dom%prevent_diss_cooling = merge(1, 0, flagstruct%prevent_diss_cooling)
       dom%stretched_grid = merge(1, 0, gridstruct%stretched_grid); dom%lim_fac = flagstruct%lim_fac
       gh%da_min = gridstruct%da_min;        gh%da_min_c = gridstruct%da_min_c
       gh%area = c_loc(gridstruct%area);     gh%rarea = c_loc(gridstruct%rarea)
@@ -568,6 +574,7 @@ contains
       fl%convert_ke = flagstruct%convert_ke
       fl%fast_tau_w_sec = flagstruct%fast_tau_w_sec; fl%RF_fast = flagstruct%RF_fast; fl%tau = flagstruct%tau   ! :536, :940, :1057-1060
       fl%rf_cutoff = flagstruct%rf_cutoff; fl%ks = ks
+      fl%do_diss_est = flagstruct%do_diss_est
       call fv3_host_init_grid(at, dom, gh, 0, fl, ak, bk)
       bound = .true.
     end subroutine
@@ -597,7 +604,8 @@ contains
     real(c_double), intent(inout), target :: q(bd%isd:bd%ied, bd%jsd:bd%jed, npz, ncnst)
     real(c_double), intent(inout), target :: delz(bd%is:, bd%js:, 1:)
     real(c_double), intent(inout) :: ze0(bd%is:, bd%js:, 1:)
-    real(c_double), intent(inout) :: diss_est(bd%isd:bd%ied, bd%jsd:bd%jed, npz), heat_source(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
+    real(c_double), intent(inout), target :: diss_est(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
+    real(c_double), intent(inout) :: heat_source(bd%isd:bd%ied, bd%jsd:bd%jed, npz)
     real(c_double), intent(inout), target :: ps(bd%isd:bd%ied, bd%jsd:bd%jed)
     real(c_double), intent(inout), target :: pe(bd%is-1:bd%ie+1, npz+1, bd%js-1:bd%je+1)
     real(c_double), intent(inout), target :: pk(bd%is:bd%ie, bd%js:bd%je, npz+1), peln(bd%is:bd%ie, npz+1, bd%js:bd%je)
@@ -633,8 +641,8 @@ contains
     if (thermostruct%use_cond .and. (size(q_con, 1) /= bd%ied - bd%isd + 1 .or. size(q_con, 3) < npz)) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond needs q_con(isd:ied, jsd:jed, npz)'
     if (gridstruct%grid_type /= 4) error stop 'fv_dynamics (fv3_dyn_core_mod): grid_type = 3 is not built'
-    if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%do_diss_est .or. flagstruct%beta < 0.d0) &
-      error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / do_diss_est / beta < 0 are not built'
+    if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%beta < 0.d0) &
+      error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / beta < 0 are not built'
     if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
     if (.not. boundf) then
       call bind_context()
@@ -683,6 +691,7 @@ contains
     call get(c_loc(uc), atf%uc, atf%nV*nk);      call get(c_loc(vc), atf%vc, atf%nU*nk)
     call get(c_loc(mfx), atf%mfx, atf%nFX*nk);   call get(c_loc(mfy), atf%mfy, atf%nFY*nk)
     call get(c_loc(cx), atf%cx, atf%nCX*nk);     call get(c_loc(cy), atf%cy, atf%nCY*nk)
+    if (flagstruct%do_diss_est) call get(c_loc(diss_est), atf%diss_est, atf%nA*nk)   ! zeroed at the first cycle, summed over all of them
     if (thermostruct%use_cond) then            ! q_con as moist_cv left it (fv_dynamics.F90:305-317 and the remaps)
       allocate(qc_c(bd%isd:bd%ied, bd%jsd:bd%jed, npz))
       call get(c_loc(qc_c), atf%q_con, atf%nA*nk)
@@ -830,10 +839,11 @@ contains
       type(fv3_flags) :: fl
       dom%is = bd%is; dom%ie = bd%ie; dom%js = bd%js; dom%je = bd%je; dom%ng = 3
       dom%npx = npx; dom%npy = npy; dom%npz = npz; dom%grid_type = gridstruct%grid_type
-      dom%do_diss_est = 0; dom%prevent_diss_cooling = merge(1, 0, flagstruct%prevent_diss_cooling)
+      dom%do_diss_est = merge(1, 0, flagstruct%do_diss_est); dom%prevent_diss_cooling = merge(1, 0, flagstruct%prevent_diss_cooling)
       dom%stretched_grid = merge(1, 0, gridstruct%stretched_grid); dom%lim_fac = flagstruct%lim_fac
       call grid_host_of(gridstruct, gh)
       call flags_of(flagstruct, fl)
+      fl%do_diss_est = flagstruct%do_diss_est
       fl%ks = ks
       fl%n_split = n_split; fl%q_split = q_split; fl%ptop = ptop; fl%akap = kappa; fl%cp_air = cp_air
       fl%hydrostatic = hydrostatic; fl%fill = fill; fl%r_vir = zvir

@@ -23,7 +23,7 @@ module fv3_host_mod
   public :: fv3_host_halo, fv3_host_init, fv3_host_init_grid, fv3_host_final, fv3_host_upload, fv3_host_download, fv3_host_comm_layout
   public :: fv3_dyn_core, fv3_dyn_core_hydrostatic, fv3_tracer_2d, fv3_fv_dynamics, fv3_fv_dynamics_call
   public :: dmalloc, dzero, swap, upload_levels, host_n_con, KIND_A, KIND_U, KIND_V, KIND_B    ! shared with fv3_sphere_mod
-  public :: inline_q_begin, inline_q_end, host_fast_tau_w, host_ray_fast, set_condensate
+  public :: inline_q_begin, inline_q_end, host_fast_tau_w, host_ray_fast, set_condensate, diss_est_begin
 
   integer(c_int), parameter :: KIND_A = 0, KIND_U = 1, KIND_V = 2, KIND_B = 3
   integer, parameter :: NG = 3
@@ -61,6 +61,9 @@ module fv3_host_mod
     real(c_double) :: fast_tau_w_sec = 0.d0, tau = 0.d0, rf_cutoff = 30.d2
     logical :: RF_fast = .false.
     integer :: ks = 0
+    ! flagstruct%do_diss_est (the SKEB dissipation estimate): d_sw returns diss_e of every level, the loop sums it into diss_est
+    ! over the acoustic substeps (dyn_core.F90:805-811); also a member of the gridstruct the context uploads (fv3_domain%do_diss_est)
+    logical :: do_diss_est = .false.
   end type
 
   !> device-resident state and work arrays of one rank (fv_atmos_type members + dyn_core.F90:256-283)
@@ -78,6 +81,7 @@ module fv3_host_mod
     type(c_ptr) :: delpc, ptc, uc, vc, ua, va, omga, ut, vt, divgd, gz, pkc, zh, zh_n, pk3
     type(c_ptr) :: crx, xfx, cry, yfx, mfx, mfy, cx, cy, heat_s, diss_e, pk, ws3, ws, pe, peln, ps, pkz
     type(c_ptr) :: divg2, heat_source                 ! external-mode damping field (A), accumulated heat source (A x npz)
+    type(c_ptr) :: diss_est = c_null_ptr              ! do_diss_est: the accumulated dissipation estimate (A x npz), allocated on first use
     type(c_ptr) :: du = c_null_ptr, dv = c_null_ptr   ! beta > 0: the saved hydrostatic pressure gradient (dyn_core.F90:278-283)
     type(c_ptr) :: fx_s = c_null_ptr, fy_s = c_null_ptr ! inline_q: the delp fluxes of one substep (FX / FY x npz)
     type(c_ptr) :: q_con = c_null_ptr, q_con_n = c_null_ptr, cappa = c_null_ptr   ! use_cond / moist_kappa (A x npz)
@@ -454,6 +458,16 @@ contains
     end subroutine
   end subroutine
 
+  !> do_diss_est: the accumulator exists from the first call on, zeroed once (dyn_core.F90:285 zeroes it on init_step only: the
+  !> reference-signature wrapper hands its caller's array in and out around every call instead)
+  subroutine diss_est_begin(at)
+    type(fv3_atmos), intent(inout) :: at
+    if (.not. at%fl%do_diss_est) return
+    if (c_associated(at%diss_est)) return
+    call dmalloc(at%diss_est, at%nA*int(at%npz, c_size_t))
+    call dzero(at, at%diss_est, at%nA*int(at%npz, c_size_t))
+  end subroutine
+
   !> the acoustic substep loop, nonhydrostatic branch (dyn_core.F90:313-1286)
   subroutine fv3_dyn_core(at, bdt)
     type(fv3_atmos), intent(inout) :: at
@@ -463,7 +477,7 @@ contains
     integer :: it, n_split, npz
     logical :: remap_step
     integer(c_int) :: last_call, use_logp
-    type(c_ptr) :: ctx, fxp, fyp, qcp, qcn, dv2n, hsp
+    type(c_ptr) :: ctx, fxp, fyp, qcp, qcn, dv2n, hsp, dsp
     logical :: heating
     integer :: n_con
     if (at%fl%hydrostatic) then
@@ -477,6 +491,7 @@ contains
     rdt = 1.d0 / dt
     heating = at%fl%d_con > 1.d-5                                         ! dyn_core.F90:294
     if (heating) call dzero(at, at%heat_source, at%nA*npz)
+    call diss_est_begin(at)
     ptk = at%fl%ptop ** at%fl%akap                                        ! dyn_core.F90:222
     peln1 = log(at%fl%ptop)
     use_logp = merge(1_c_int, 0_c_int, at%fl%use_logp)
@@ -512,12 +527,14 @@ contains
       if (at%fl%use_cond) then
         qcp = at%q_con; qcn = at%q_con_n
       end if
-      hsp = c_null_ptr                      ! heat_s is read only when d_con > 1e-5 (:798-803); diss_e never by this host
+      hsp = c_null_ptr; dsp = c_null_ptr    ! heat_s is read only when d_con > 1e-5 (:798-803), diss_e with do_diss_est (:805-811)
       if (heating) hsp = at%heat_s
+      if (at%fl%do_diss_est) dsp = at%diss_e
       call fv3_check(fv3_d_sw(ctx, par, at%vt, at%delp, at%pt, at%u, at%v, at%w, at%uc, at%vc, at%ua, at%va, at%divgd, &
                               fxp, fyp, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, qcp, &
-                              at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, qcn, hsp, c_null_ptr), 'd_sw')  ! :762
+                              at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, qcn, hsp, dsp), 'd_sw')  ! :762
       if (heating) call fv3_check(fv3_heat_source_accum(ctx, at%heat_source, at%heat_s), 'heat_source_accum')   ! :798-803
+      if (at%fl%do_diss_est) call fv3_check(fv3_heat_source_accum(ctx, at%diss_est, at%diss_e), 'diss_est += diss_e')   ! :805-811
       call inline_q_end(at)
       ! beta < -0.1: the external-mode damping field of one_grad_p (:1030) from the delp before d_sw and d_sw's divergence (:745-747, :791-848)
       if (at%fl%beta < -0.1d0 .and. at%fl%d_ext > 0.d0) &
@@ -605,6 +622,7 @@ contains
     call dzero(at, at%mfx, at%nFX*npz); call dzero(at, at%mfy, at%nFY*npz)
     call dzero(at, at%cx, at%nCX*npz);  call dzero(at, at%cy, at%nCY*npz)
     if (heating) call dzero(at, at%heat_source, at%nA*npz)
+    call diss_est_begin(at)
     par%dt = dt; par%hord_tr = at%fl%hord_tr; par%hord_mt = at%fl%hord_mt; par%hord_vt = at%fl%hord_vt
     par%hord_tm = at%fl%hord_tm; par%hord_dp = at%fl%hord_dp; par%dddmp = at%fl%dddmp; par%d4_bg = at%fl%d4_bg
     par%kgb = at%fl%ke_bg; par%hydrostatic = 1; par%use_cond = 0
@@ -625,6 +643,7 @@ contains
                               fxp, fyp, at%cx, at%cy, at%crx, at%cry, at%xfx, at%yfx, c_null_ptr, &
                               at%delp_n, at%pt_n, at%u_n, at%v_n, c_null_ptr, c_null_ptr, at%heat_s, at%diss_e), 'd_sw')
       if (heating) call fv3_check(fv3_heat_source_accum(ctx, at%heat_source, at%heat_s), 'heat_source_accum')
+      if (at%fl%do_diss_est) call fv3_check(fv3_heat_source_accum(ctx, at%diss_est, at%diss_e), 'diss_est += diss_e')   ! :805-811
       call inline_q_end(at)
       ! the external-mode damping field from the delp BEFORE d_sw (:745-747) and d_sw's divergence output (:791-848)
       call fv3_check(fv3_divg2_ext(ctx, at%fl%d_ext, at%delp, at%vt, at%divg2), 'divg2_ext')
@@ -716,6 +735,10 @@ contains
     rp%sphum = merge(1_c_int, 0_c_int, at%nq > 0); rp%fill = merge(1_c_int, 0_c_int, at%fl%fill)
     rp%akap = at%fl%akap; rp%ptop = at%fl%ptop; rp%rdgas = at%fl%rdgas; rp%grav = at%fl%grav
     rp%cv_air = at%fl%cp_air - at%fl%rdgas; rp%r_vir = at%fl%r_vir; rp%cp = at%fl%cp_air; rp%t_min = at%fl%t_min
+    if (at%fl%do_diss_est) then          ! dyn_core zeroes diss_est on init_step = (n_map == 1): once per fv_dynamics call (:497, dyn_core.F90:285)
+      call diss_est_begin(at)
+      call dzero(at, at%diss_est, at%nA * int(at%npz, c_size_t))
+    end if
     do n_map = 1, at%fl%k_split
       call fv3_check(fv3_memcpy_d2d(at%ctx, at%dp1, at%delp, at%nA * at%npz * 8_c_size_t), 'dp1 = delp')   ! :475-481
       if (at%fl%use_cond) call halo(at, at%q_con, KIND_A, at%npz)                                          ! :464 / :487 (pack 11)

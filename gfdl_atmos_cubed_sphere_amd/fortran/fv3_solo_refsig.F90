@@ -160,6 +160,11 @@ program fv3_solo_refsig
   end if
   call get_environment_variable('FV3_REFSIG_RF_CUTOFF', envbuf, status=envstat)
   if (envstat == 0 .and. len_trim(envbuf) > 0) read(envbuf, *) fs%rf_cutoff
+  ! FV3_REFSIG_DISS_EST=1: flagstruct%do_diss_est (with prevent_diss_cooling off, as the SKEB configuration has it); diss_est joins the output
+  call get_environment_variable('FV3_REFSIG_DISS_EST', envbuf, status=envstat)
+  if (envstat == 0 .and. trim(envbuf) == '1') then
+    fs%do_diss_est = .true.; fs%prevent_diss_cooling = .false.
+  end if
 
   if (whole) then
     fs%c2l_ord = 4; fs%tau = tau; fs%moist_phys = .false.
@@ -188,6 +193,7 @@ program fv3_solo_refsig
     if (nq > 0) write(un) q
     write(un) ua
     if (moist) write(un) q_con
+    if (fs%do_diss_est) write(un) diss_est
     close(un)
     write(*,'(a,es24.16)') 'fv3_solo_refsig: done, sum(delp) = ', sum(delp(1:nx, 1:ny, :))
     stop
@@ -214,6 +220,7 @@ program fv3_solo_refsig
   open(newunit=un, file=trim(fout)//trim(sfx), access='stream', form='unformatted', status='replace')
   write(un) u, v, w, delp, pt, delz, mfx, cx, pkz
   if (moist) write(un) q_con
+  if (fs%do_diss_est) write(un) diss_est
   close(un)
   write(*,'(a,es24.16)') 'fv3_solo_refsig: done, sum(delp) = ', sum(delp(1:nx, 1:ny, :))
 contains

@@ -265,6 +265,8 @@ class FvDynamics:
         """One dt_atmos: k_split x (n_split acoustic substeps, tracer transport, vertical remap)."""
         d, ctx = self.dc.d, self.ctx
         mdt = bdt / float(self.k_split)
+        if "diss_est" in d:                                                    # do_diss_est: dyn_core zeroes it on init_step = (n_map == 1), :497
+            d["diss_est"].zero()
         for n_map in range(1, self.k_split + 1):
             last_step = last_cycle_is_last_step and n_map == self.k_split
             d["dp1"].copy_from(d["delp"])                                      # fv_dynamics.F90:475-481

@@ -147,7 +147,7 @@ def build_refsig(workdir, libdir=CSRC, libname="fv3_mi355x"):
 
 
 def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2, bdt=6.0, hydrostatic=False, d_con=0.0, beta=0.0, moist=False,
-                         layout=(1, 1), fast_tau_w_sec=0.0, rf_fast_tau=0.0, registry=False):
+                         layout=(1, 1), fast_tau_w_sec=0.0, rf_fast_tau=0.0, registry=False, do_diss_est=False):
     """dyn_core called with the reference's argument list on host arrays (fv3_dyn_core_mod, driver fv3_solo_refsig) against the
     Python host's DynCore.run on the same state: u, v, w, delp, pt, delz, the accumulated mass fluxes / Courant numbers (and pkz
     when the heating or the hydrostatic branch writes it) bit-identical"""
@@ -159,6 +159,9 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
     from gfdl_atmos_cubed_sphere_amd.lib import Context
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
+    if do_diss_est:     # flagstruct%do_diss_est: the SKEB dissipation estimate summed over the substeps of every call (dyn_core.F90:805-811)
+        import dataclasses
+        g = dataclasses.replace(g, do_diss_est=True, prevent_diss_cooling=False)
     st, _ = D.make_state(bd, npz)
     sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
@@ -197,6 +200,9 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
         ref = {n: dc.d[n].download() for n in names}
         if "pkz" in dc.d and (hydrostatic or d_con > 1e-5):
             ref["pkz"] = dc.d["pkz"].download()
+        if do_diss_est:
+            ref["diss_est"] = dc.d["diss_est"].download()
+            assert np.max(np.abs(ref["diss_est"])) > 0.0
     finally:
         ctx.close()
     exe = build_refsig(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
@@ -204,8 +210,10 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
     write_input(fin, bd, npz, 0, n_split, 1, nsteps, False, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak, bk, st, None,
                 hydrostatic=hydrostatic, d_con=d_con, d_ext=fl.d_ext, beta=beta, moist=mo)
     spec = [(n, k, ()) for n, k in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC"), ("mfx", "FX"), ("cx", "CX"),
-                                    ("pkz", "CC")) + ((("q_con", "A"),) if mo else ())]
+                                    ("pkz", "CC")) + ((("q_con", "A"),) if mo else ()) + ((("diss_est", "A"),) if do_diss_est else ())]
     env = {}
+    if do_diss_est:
+        env["FV3_REFSIG_DISS_EST"] = "1"
     if fast_tau_w_sec > 0.0:
         env["FV3_REFSIG_FAST_TAU_W"] = repr(float(fast_tau_w_sec))
     if rf_fast_tau > 0.0:
@@ -225,10 +233,11 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
     m = re.search(r"registry \(h2d copies, h2d skipped, d2h copies, d2h deferred\) (\d+) (\d+) (\d+) (\d+)", out)
     assert m, out[-500:]
     h2d, h2d_skip, d2h, d2h_def = (int(x) for x in m.groups())
+    n_in = 12 + (1 if do_diss_est else 0)       # arrays dyn_core is handed through the registry (diss_est rides along with do_diss_est)
     if registry:
-        assert h2d == 12 and h2d_skip == 12 * (nsteps - 1) and d2h_def > 0 and d2h == d2h_def // nsteps, (h2d, h2d_skip, d2h, d2h_def)
+        assert h2d == n_in and h2d_skip == n_in * (nsteps - 1) and d2h_def > 0 and d2h == d2h_def // nsteps, (h2d, h2d_skip, d2h, d2h_def)
     else:
-        assert h2d == 12 * nsteps and h2d_skip == 0 and d2h_def == 0 and d2h > 0, (h2d, h2d_skip, d2h, d2h_def)
+        assert h2d == n_in * nsteps and h2d_skip == 0 and d2h_def == 0 and d2h > 0, (h2d, h2d_skip, d2h, d2h_def)
     if damp:   # the damping is in the run at all
         ctx = Context(g, npz, lib=lib)
         try:
@@ -284,7 +293,7 @@ def _run_refsig(lib, exe, fin, fout, mode, layout, bd, npz, spec):
 
 def _compare_blocks(res, ref, bd, what, tol=None):
     """every rank's block against the same block of the single-domain reference (compute domain of every field kind)"""
-    kinds = {"u": "U", "v": "V", "w": "A", "delp": "A", "pt": "A", "q_con": "A", "ua": "A", "delz": "CC", "mfx": "FX", "cx": "CX", "pkz": "CC", "q": "A"}
+    kinds = {"u": "U", "v": "V", "w": "A", "delp": "A", "pt": "A", "q_con": "A", "ua": "A", "diss_est": "A", "delz": "CC", "mfx": "FX", "cx": "CX", "pkz": "CC", "q": "A"}
     for b, got in res:
         for n in ref:
             kind = kinds[n]
@@ -310,7 +319,7 @@ def _compare_blocks(res, ref, bd, what, tol=None):
 
 
 def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, hydrostatic=False, layout=(1, 1),
-                              consv_te=0.0, tau=0.0, moist=False):
+                              consv_te=0.0, tau=0.0, moist=False, do_diss_est=False):
     """fv_dynamics called with the reference's argument list on host arrays (fv3_dyn_core_mod::fv_dynamics, driver fv3_solo_refsig in
     its fv_dynamics mode: T -> theta_v, k_split x (dyn_core, tracer_2d, remap), last_step, cubed_to_latlon) against the Python host's
     FvDynamics.step_from_temperature on the same state: u, v, w, delp, pt (T), delz, the tracers and ua bit-identical"""
@@ -323,6 +332,9 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
     from gfdl_atmos_cubed_sphere_amd.lib import Context
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
+    if do_diss_est:
+        import dataclasses
+        g = dataclasses.replace(g, do_diss_est=True, prevent_diss_cooling=False)
     st, _ = D.make_state(bd, npz)
     sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
@@ -352,6 +364,9 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
             ref["q"] = d["q"].download()
         if moist:
             ref["q_con"] = d["q_con"].download()
+        if do_diss_est:      # zeroed at the first cycle of every call, summed over all k_split x n_split substeps of it
+            ref["diss_est"] = d["diss_est"].download()
+            assert np.max(np.abs(ref["diss_est"])) > 0.0
     finally:
         ctx.close()
     exe = build_refsig(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
@@ -364,12 +379,16 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
     spec.append(("ua", "A", ()))
     if moist:
         spec.append(("q_con", "A", ()))
+    if do_diss_est:
+        spec.append(("diss_est", "A", ()))
+        os.environ["FV3_REFSIG_DISS_EST"] = "1"
     os.environ["FV3_SOLO_CONSV_TE"], os.environ["FV3_SOLO_TAU"] = repr(float(consv_te)), repr(float(tau))
     try:
         res, out = _run_refsig(lib, exe, fin, fout, "fv_dynamics", layout, bd, npz, spec)
     finally:
         os.environ.pop("FV3_SOLO_CONSV_TE", None)
         os.environ.pop("FV3_SOLO_TAU", None)
+        os.environ.pop("FV3_REFSIG_DISS_EST", None)
     _compare_blocks(res, ref, bd, "reference-signature fv_dynamics")
     return out
 

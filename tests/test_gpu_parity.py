@@ -711,6 +711,8 @@ def test_fortran_dyn_core_with_the_reference_argument_list(prod, tmp_path):
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=10, hydrostatic=True, rf_fast_tau=0.002)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=8, hydrostatic=True, beta=0.4)
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=8, moist=True, d_con=1.0)     # thermostruct%use_cond / moist_kappa
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=8, do_diss_est=True, d_con=1.0)   # flagstruct%do_diss_est: diss_est in and out
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(prod, tmp_path, npz=8, hydrostatic=True, do_diss_est=True)
     # fv_dynamics with ITS reference argument list (model/fv_dynamics.F90:79-85): T -> theta_v, the k_split loop with tracers and
     # the remap, last_step, cubed_to_latlon
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path)
@@ -719,6 +721,7 @@ def test_fortran_dyn_core_with_the_reference_argument_list(prod, tmp_path):
     # fv_dynamics: the water species by get_tracer_index, q_con / cappa formed by moist_cv inside, q_con handed back
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, nq=7, moist=True)
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, nq=6, moist=True, consv_te=1.0, npz=10)
+    assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, nq=1, do_diss_est=True)     # diss_est out of fv_dynamics
 
 
 @pytest.mark.parametrize("use_cond,moist_kappa", [(True, False), (True, True), (False, True)])
