@@ -28,8 +28,8 @@
 !> fv3_halo_complete with the neighbour PEs, tracer_2d's mp_reduce_max through fv3_allreduce_max (fv3_host_comm_layout).
 !>
 !> Restrictions (error stop with the reason, never a silent difference): no nesting / regional BCs;
-!> consv_am, hybrid_z are not carried through this wrapper; do_diss_est (the SKEB diss_est accumulation) is carried on the doubly
-!> periodic domain, not on the sphere.  consv_te, tau > 0, RF_fast,
+!> hybrid_z is not carried through this wrapper; do_diss_est (the SKEB diss_est accumulation) and consv_am (gridstruct%agrid, %l2c_u,
+!> %l2c_v, idiag%zxg) are carried on the doubly periodic domain, not on the sphere.  consv_te, tau > 0, RF_fast,
 !> fast_tau_w_sec and thermostruct%use_cond / moist_kappa (the reference's defaults) are carried on both domains.
 module fv3_arrays_compat_mod
   use iso_c_binding
@@ -54,6 +54,7 @@ module fv3_arrays_compat_mod
     logical :: nested = .false., bounded_domain = .false., regional = .false., stretched_grid = .false.
     ! the members a cubed-sphere tile adds (grid_type < 3), with the reference's shapes (fv_arrays.F90:1778-1854)
     real(c_double), allocatable :: grid(:,:,:), agrid(:,:,:)                 ! (isd:ied+1, jsd:jed+1, 2), (isd:ied, jsd:jed, 2): lon, lat
+    real(c_double), allocatable :: l2c_u(:,:), l2c_v(:,:)                    ! (is:ie, js:je+1), (is:ie+1, js:je): fv_arrays.F90:112, :1812-1813 (consv_am)
     real(c_double), allocatable :: edge_s(:), edge_n(:), edge_w(:), edge_e(:)   ! (npx), (npx), (npy), (npy)
     real(c_double), allocatable :: rsina(:,:)                                ! (is:ie+1, js:je+1)
     real(c_double), allocatable, dimension(:,:) :: a11, a12, a21, a22        ! (is-1:ie+1, js-1:je+1)
@@ -95,6 +96,7 @@ module fv3_arrays_compat_mod
 
   type fv_diag_type
     integer :: id_divg = 0, id_ws = 0
+    real(c_double), allocatable :: zxg(:,:)                                  ! (isc:iec, jsc:jec): fv_arrays.F90:60 (consv_am's mountain torque term)
   end type
 
   !> mpp_domains_mod's domain2d is opaque to the dynamical core; what this path needs of it is what mpp_define_mosaic was given
@@ -641,8 +643,10 @@ contains
     if (thermostruct%use_cond .and. (size(q_con, 1) /= bd%ied - bd%isd + 1 .or. size(q_con, 3) < npz)) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond needs q_con(isd:ied, jsd:jed, npz)'
     if (gridstruct%grid_type /= 4) error stop 'fv_dynamics (fv3_dyn_core_mod): grid_type = 3 is not built'
-    if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%beta < 0.d0) &
-      error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / beta < 0 are not built'
+    if (hybrid_z .or. flagstruct%beta < 0.d0) error stop 'fv_dynamics (fv3_dyn_core_mod): hybrid_z / beta < 0 are not built'
+    if (flagstruct%consv_am .and. .not. (allocated(gridstruct%agrid) .and. allocated(gridstruct%l2c_u) .and. allocated(gridstruct%l2c_v) &
+                                         .and. allocated(idiag%zxg))) &
+      error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am needs gridstruct%agrid, %l2c_u, %l2c_v and idiag%zxg'
     if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
     if (.not. boundf) then
       call bind_context()
@@ -674,6 +678,7 @@ contains
     ! :284-399 T -> theta_v, :345 compute_total_energy, :362-375 Rayleigh_Friction, the k_split loop :460-665 with the energy fixer of
     ! its last remap, cubed_to_latlon :911
     atf%fl%adiabatic = flagstruct%adiabatic .or. zvir == 0.d0 .or. nq_tot == 0
+    if (flagstruct%consv_am .and. .not. atf%consv_am) call bind_consv_am()
     call fv3_fv_dynamics_call(atf, bdt, consv_te, merge(0.d0, flagstruct%tau, flagstruct%RF_fast), flagstruct%rf_cutoff, zvir, flagstruct%c2l_ord, flagstruct%moist_phys, &
                               6.3712d6)
 
@@ -714,6 +719,18 @@ contains
       type(c_ptr), intent(in) :: d, h
       integer(c_size_t), intent(in) :: n
       call fv3_check(fv3_memcpy_d2h(atf%ctx, h, d, n * 8_c_size_t), 'fv3_memcpy_d2h')
+    end subroutine
+
+    !> flagstruct%consv_am: cos(agrid(:,:,2)), l2c_u / l2c_v (padded with zeros to the halo'd U / V shapes the kernels index) and
+    !> idiag%zxg go to the resident loop once (fv_dynamics.F90:358-361, :747-800, :1266-1314)
+    subroutine bind_consv_am()
+      real(c_double), allocatable, target :: cl(:,:), lu(:,:), lv(:,:)
+      allocate(cl(bd%isd:bd%ied, bd%jsd:bd%jed), lu(bd%isd:bd%ied, bd%jsd:bd%jed+1), lv(bd%isd:bd%ied+1, bd%jsd:bd%jed))
+      cl = cos(gridstruct%agrid(bd%isd:bd%ied, bd%jsd:bd%jed, 2))
+      lu = 0.d0; lv = 0.d0
+      lu(bd%is:bd%ie, bd%js:bd%je+1) = gridstruct%l2c_u
+      lv(bd%is:bd%ie+1, bd%js:bd%je) = gridstruct%l2c_v
+      call fv3_host_set_consv_am(atf, cl, lu, lv, idiag%zxg)
     end subroutine
 
     !> grid_type < 3: a tile of the cubed sphere.  The reference calls fv_dynamics once per tile a PE holds -- with one tile per PE

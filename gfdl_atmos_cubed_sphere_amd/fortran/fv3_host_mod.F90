@@ -21,6 +21,7 @@ module fv3_host_mod
   private
   public :: fv3_flags, fv3_atmos
   public :: fv3_host_halo, fv3_host_init, fv3_host_init_grid, fv3_host_final, fv3_host_upload, fv3_host_download, fv3_host_comm_layout
+  public :: fv3_host_set_consv_am
   public :: fv3_dyn_core, fv3_dyn_core_hydrostatic, fv3_tracer_2d, fv3_fv_dynamics, fv3_fv_dynamics_call
   public :: dmalloc, dzero, swap, upload_levels, host_n_con, KIND_A, KIND_U, KIND_V, KIND_B    ! shared with fv3_sphere_mod
   public :: inline_q_begin, inline_q_end, host_fast_tau_w, host_ray_fast, set_condensate, diss_est_begin
@@ -95,6 +96,13 @@ module fv3_host_mod
     real(c_double), allocatable :: area(:,:), rf(:), pm(:)
     integer :: kmax = -1
     real(c_double) :: e_flux = 0.d0, dtmp = 0.d0
+    ! flagstruct%consv_am (fv_dynamics.F90:358-361, :747-800; fv3_host_set_consv_am): cos(agrid(:,:,2)) (A), gridstruct%l2c_u / l2c_v
+    ! (U / V, zero outside the compute domain) on the device, idiag%zxg of the compute domain on the host; teq, aam, m_fac (CC), ps2 (A)
+    logical :: consv_am = .false.
+    type(c_ptr) :: am_coslat = c_null_ptr, am_l2c_u = c_null_ptr, am_l2c_v = c_null_ptr
+    type(c_ptr) :: am_teq = c_null_ptr, am_aam = c_null_ptr, am_mfac = c_null_ptr, am_ps2 = c_null_ptr
+    real(c_double), allocatable :: am_zxg(:,:)
+    real(c_double) :: am_omega = 7.292d-5, u00 = 0.d0
     logical :: rfw_ready = .false., rff_ready = .false.   ! RFw_initialized (nh_utils.F90:54), RFF_initialized (dyn_core.F90:84)
   end type
 
@@ -811,6 +819,7 @@ contains
     if (consv_te > consv_min) &
       call fv3_check(fv3_compute_total_energy(at%ctx, rp, merge(1_c_int, 0_c_int, moist_phys), at%u, at%v, wp, dzp, at%pt, at%delp, &
                                               at%q, c_null_ptr, pep, pelnp, at%phis, at%te0), 'compute_total_energy')
+    if (at%consv_am) call aam(at%am_teq, at%am_ps2)                      ! :358-361: teq, ps2 of the state the step starts from
     if (tau > 0.d0) then
       if (at%kmax < 0) then      ! rf(k), kmax (:1169-1182) with pfull of :254-262
         if (allocated(at%rf)) deallocate(at%rf, at%pm)
@@ -872,11 +881,39 @@ contains
     else
       call fv3_fv_dynamics(at, bdt, .true.)
     end if
+    if (at%consv_am) call consv_am_correct()                             ! :747-800
     if (c2l_ord == 4) then                                               ! fv_grid_utils.F90:2372-2376
       call halo(at, at%u, KIND_U, at%npz); call halo(at, at%v, KIND_V, at%npz)
     end if
     call fv3_check(fv3_c2l(at%ctx, int(c2l_ord, c_int), at%u, at%v, at%ua, at%va), 'c2l')      ! :911
   contains
+    !> compute_aam (fv_dynamics.F90:1266-1314): cubed_to_latlon (mode 1, c2l_ord 2: no halo update), then aam, m_fac, ps of every column
+    subroutine aam(aam_d, ps_d)
+      type(c_ptr), intent(in) :: aam_d, ps_d
+      call fv3_check(fv3_c2l(at%ctx, 2_c_int, at%u, at%v, at%ua, at%va), 'c2l (compute_aam)')              ! :1287
+      call fv3_check(fv3_compute_aam(at%ctx, radius, at%am_omega, 1.d0 / at%fl%grav, at%fl%ptop, at%am_coslat, at%ua, at%delp, &
+                                     aam_d, at%am_mfac, ps_d), 'compute_aam')
+    end subroutine
+    !> :747-800: te_2d = aam - teq + dt2 (ps2 + ps) zxg, the two reproducing global sums, u00, u += u00 l2c_u, v += u00 l2c_v
+    subroutine consv_am_correct()
+      real(c_double), allocatable, target :: te(:,:), teq(:,:), ps2(:,:), ps1(:,:), te2(:,:)
+      real(c_double) :: amdt
+      integer :: ng_
+      call aam(at%am_aam, at%ps)
+      ng_ = at%is - at%isd
+      allocate(te(at%nx, at%ny), teq(at%nx, at%ny), te2(at%nx, at%ny))
+      allocate(ps2(at%isd:at%ied, at%jsd:at%jed), ps1(at%isd:at%ied, at%jsd:at%jed))
+      call fv3_check(fv3_memcpy_d2h(at%ctx, c_loc(te), at%am_aam, at%nCC * 8_c_size_t), 'd2h')
+      call fv3_check(fv3_memcpy_d2h(at%ctx, c_loc(teq), at%am_teq, at%nCC * 8_c_size_t), 'd2h')
+      call fv3_check(fv3_memcpy_d2h(at%ctx, c_loc(ps2), at%am_ps2, at%nA * 8_c_size_t), 'd2h')
+      call fv3_check(fv3_memcpy_d2h(at%ctx, c_loc(ps1), at%ps, at%nA * 8_c_size_t), 'd2h')
+      call fv3_check(fv3_sync(at%ctx), 'sync')
+      te2 = te - teq + (0.5d0 * bdt) * (ps2(at%is:at%ie, at%js:at%je) + ps1(at%is:at%ie, at%js:at%je)) * at%am_zxg        ! :761-767
+      call fv3_check(fv3_memcpy_h2d(at%ctx, at%am_aam, c_loc(te2), at%nCC * 8_c_size_t), 'h2d')
+      amdt = g_sum(at%am_aam)                                                                                              ! :771
+      at%u00 = -radius * amdt / g_sum(at%am_mfac)                                                                          ! :772
+      call fv3_check(fv3_consv_am_apply(at%ctx, at%u00, at%am_l2c_u, at%am_l2c_v, at%u, at%v), 'consv_am_apply')           ! :784-798
+    end subroutine
     function g_sum(col) result(tot)      ! g_sum(..., area, 0, reproduce = .true.) over this rank's block and the ranks
       type(c_ptr), intent(in) :: col
       real(c_double) :: tot
@@ -1002,6 +1039,30 @@ contains
     if (at%fl%use_cond) qc = at%q_con
     if (at%fl%moist_kappa) cp = at%cappa
     call fv3_check(fv3_set_condensate(at%ctx, qc, cp), 'set_condensate')
+  end subroutine
+
+  !> flagstruct%consv_am: what compute_aam and the correction read of the grid and of the diagnostics (fv_dynamics.F90:1266-1314,
+  !> :761-798): coslat = cos(agrid(:,:,2)) on (isd:ied, jsd:jed); l2c_u on (isd:ied, jsd:jed+1), l2c_v on (isd:ied+1, jsd:jed) (the
+  !> reference's members cover the compute domain: the caller pads with zeros); zxg on the compute domain
+  subroutine fv3_host_set_consv_am(at, coslat, l2c_u, l2c_v, zxg, omega)
+    type(fv3_atmos), intent(inout) :: at
+    real(c_double), intent(in), target, contiguous :: coslat(:,:), l2c_u(:,:), l2c_v(:,:)
+    real(c_double), intent(in) :: zxg(:,:)
+    real(c_double), intent(in), optional :: omega
+    if (.not. c_associated(at%am_coslat)) then
+      call dmalloc(at%am_coslat, at%nA); call dmalloc(at%am_l2c_u, at%nU); call dmalloc(at%am_l2c_v, at%nV)
+      call dmalloc(at%am_teq, at%nCC);   call dmalloc(at%am_aam, at%nCC);  call dmalloc(at%am_mfac, at%nCC); call dmalloc(at%am_ps2, at%nA)
+      call dzero(at, at%am_teq, at%nCC); call dzero(at, at%am_aam, at%nCC); call dzero(at, at%am_mfac, at%nCC); call dzero(at, at%am_ps2, at%nA)
+    end if
+    if (size(coslat) /= at%nA .or. size(l2c_u) /= at%nU .or. size(l2c_v) /= at%nV .or. size(zxg, 1) /= at%nx .or. size(zxg, 2) /= at%ny) &
+      error stop 'fv3_host_set_consv_am: coslat (A), l2c_u (U), l2c_v (V) with halos, zxg on the compute domain'
+    call fv3_check(fv3_memcpy_h2d(at%ctx, at%am_coslat, c_loc(coslat), at%nA * 8_c_size_t), 'h2d')
+    call fv3_check(fv3_memcpy_h2d(at%ctx, at%am_l2c_u, c_loc(l2c_u), at%nU * 8_c_size_t), 'h2d')
+    call fv3_check(fv3_memcpy_h2d(at%ctx, at%am_l2c_v, c_loc(l2c_v), at%nV * 8_c_size_t), 'h2d')
+    call fv3_check(fv3_sync(at%ctx), 'sync')
+    at%am_zxg = zxg
+    if (present(omega)) at%am_omega = omega
+    at%consv_am = .true.
   end subroutine
 
   subroutine fv3_host_final(at)

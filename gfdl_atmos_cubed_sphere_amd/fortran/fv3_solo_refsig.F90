@@ -94,6 +94,13 @@ program fv3_solo_refsig
     allocate(cappa(isd:ied, jsd:jed, 1), q_con(isd:ied, jsd:jed, 1))
     cappa = 0.d0; q_con = 0.d0
   end if
+  if (iand(ihydro, 32_c_int) /= 0) then          ! bit 5: flagstruct%consv_am -- the latitudes, l2c_u / l2c_v and idiag%zxg of the test
+    if (nranks > 1) error stop 'fv3_solo_refsig: consv_am is driven on one PE here'
+    allocate(gs%agrid(isd:ied, jsd:jed, 2), gs%l2c_u(1:nx, 1:ny+1), gs%l2c_v(1:nx+1, 1:ny), idiag%zxg(1:nx, 1:ny))
+    gs%agrid = 0.d0
+    read(un) gs%agrid(:, :, 2), gs%l2c_u, gs%l2c_v, idiag%zxg
+    fs%consv_am = .true.
+  end if
   close(un)
   gnx = nx; gny = ny
   if (nranks > 1) then      ! this PE's block of the global domain (with its halos: they lie inside the global arrays' own halos)

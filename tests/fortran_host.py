@@ -37,10 +37,10 @@ def build_solo(workdir, libdir=CSRC, libname="fv3_mi355x"):
 
 
 def write_input(path, bd, npz, nq, n_split, k_split, nsteps, last_step, dx, dy, f0, bdt, ptop, ak, bk, st, q, hydrostatic=False,
-                d_con=0.0, d_ext=0.02, beta=0.0, inline_q=False, remap_te=False, moist=None):
+                d_con=0.0, d_ext=0.02, beta=0.0, inline_q=False, remap_te=False, moist=None, consv_am=None):
     with open(path, "wb") as f:
         np.array([bd.nx, bd.ny, npz, nq, n_split, k_split, nsteps, int(last_step), int(hydrostatic) + 2 * int(inline_q) + 4 * int(remap_te) +
-                  (8 * int(moist["use_cond"]) + 16 * int(moist["moist_kappa"]) if moist else 0)], dtype=np.int32).tofile(f)
+                  (8 * int(moist["use_cond"]) + 16 * int(moist["moist_kappa"]) if moist else 0) + (32 if consv_am else 0)], dtype=np.int32).tofile(f)
         np.array([dx, dy, f0, bdt, ptop, d_con, d_ext, beta], dtype=np.float64).tofile(f)
         np.asarray(ak, dtype=np.float64).tofile(f)
         np.asarray(bk, dtype=np.float64).tofile(f)
@@ -51,6 +51,12 @@ def write_input(path, bd, npz, nq, n_split, k_split, nsteps, last_step, dx, dy, 
         if moist:
             for n in ("q_con", "cappa"):
                 np.asfortranarray(moist[n], dtype=np.float64).ravel(order="F").tofile(f)
+        if consv_am:   # agrid(:,:,2) on (isd:ied, jsd:jed), gridstruct%l2c_u (is:ie, js:je+1), %l2c_v (is:ie+1, js:je), idiag%zxg (compute domain)
+            ng = bd.ng
+            np.asfortranarray(consv_am["lat"], dtype=np.float64).ravel(order="F").tofile(f)
+            np.asfortranarray(consv_am["l2c_u"][ng:ng + bd.nx, ng:ng + bd.ny + 1], dtype=np.float64).ravel(order="F").tofile(f)
+            np.asfortranarray(consv_am["l2c_v"][ng:ng + bd.nx + 1, ng:ng + bd.ny], dtype=np.float64).ravel(order="F").tofile(f)
+            np.asfortranarray(consv_am["zxg"], dtype=np.float64).ravel(order="F").tofile(f)
 
 
 def read_output(path, bd, npz, nq):
@@ -319,7 +325,7 @@ def _compare_blocks(res, ref, bd, what, tol=None):
 
 
 def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, hydrostatic=False, layout=(1, 1),
-                              consv_te=0.0, tau=0.0, moist=False, do_diss_est=False):
+                              consv_te=0.0, tau=0.0, moist=False, do_diss_est=False, consv_am=False):
     """fv_dynamics called with the reference's argument list on host arrays (fv3_dyn_core_mod::fv_dynamics, driver fv3_solo_refsig in
     its fv_dynamics mode: T -> theta_v, k_split x (dyn_core, tracer_2d, remap), last_step, cubed_to_latlon) against the Python host's
     FvDynamics.step_from_temperature on the same state: u, v, w, delp, pt (T), delz, the tracers and ua bit-identical"""
@@ -347,10 +353,20 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
         q[..., :6] *= 1.0e-3                       # small mixing ratios
         mo = dict(use_cond=True, moist_kappa=True, q_con=bd.zeros("A", npz), cappa=bd.zeros("A", npz))   # fv_dynamics forms both itself
     fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, use_cond=moist, moist_kappa=moist)
+    ca = None
+    if consv_am:   # flagstruct%consv_am with a made-up grid (parity_dyn.check_fv_cycle_from_temperature): latitudes, l2c_u / l2c_v (zero outside
+                   # the compute domain, as the reference's members end there) and zxg of no sphere
+        rng_ = np.random.default_rng(31)
+        lat = np.asfortranarray(np.arccos(rng_.uniform(0.2, 1.0, bd.shape("A"))))
+        lu, lv = bd.zeros("U"), bd.zeros("V")
+        ng = bd.ng
+        lu[ng:ng + nx, ng:ng + ny + 1] = rng_.uniform(-1, 1, (nx, ny + 1))
+        lv[ng:ng + nx + 1, ng:ng + ny] = rng_.uniform(-1, 1, (nx + 1, ny))
+        ca = dict(lat=lat, coslat=np.asfortranarray(np.cos(lat)), l2c_u=lu, l2c_v=lv, zxg=rng_.uniform(-1e-3, 1e-3, (nx, ny)), omega=7.292e-5)
     ctx = Context(g, npz, lib=lib)
     try:
         fv = FvDynamics(ctx, fl, ak, bk, nq=nq, k_split=k_split, adiabatic=not moist, c2l_ord=4, consv_te=consv_te, tau=tau, moist_phys=False,
-                        moist=dict(R.MOIST6) if moist else None)
+                        moist=dict(R.MOIST6) if moist else None, consv_am=ca)
         fv.dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
         if nq:
             fv.set_tracers(q)
@@ -372,7 +388,7 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
     exe = build_refsig(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
     fin, fout = os.path.join(str(workdir), "in_fd.bin"), os.path.join(str(workdir), "out_fd.bin")
     write_input(fin, bd, npz, nq, n_split, k_split, nsteps, True, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak, bk, st, q,
-                hydrostatic=hydrostatic, d_con=0.0, d_ext=fl.d_ext, moist=mo)
+                hydrostatic=hydrostatic, d_con=0.0, d_ext=fl.d_ext, moist=mo, consv_am=ca)
     spec = [(n, k, ()) for n, k in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC"))]
     if nq:
         spec.append(("q", "A", (nq,)))
@@ -389,7 +405,10 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
         os.environ.pop("FV3_SOLO_CONSV_TE", None)
         os.environ.pop("FV3_SOLO_TAU", None)
         os.environ.pop("FV3_REFSIG_DISS_EST", None)
-    _compare_blocks(res, ref, bd, "reference-signature fv_dynamics")
+    # consv_am: u00 is a difference of column integrals ~ r^2 omega dm, which amplifies what cos() of the two run-time libraries differs by
+    _compare_blocks(res, ref, bd, "reference-signature fv_dynamics", tol=1e-11 if consv_am else None)
+    if consv_am:
+        assert abs(fv.last_u00) > 1e-8
     return out
 
 

@@ -619,6 +619,7 @@ def test_fortran_dyn_core_with_the_reference_argument_list(emu, tmp_path):
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(emu, tmp_path, nq=7, moist=True)
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(emu, tmp_path, nq=6, moist=True, consv_te=1.0, npz=10)
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(emu, tmp_path, nq=1, do_diss_est=True)     # diss_est out of fv_dynamics
+    assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(emu, tmp_path, nq=0, consv_am=True)        # flagstruct%consv_am
 
 
 @pytest.mark.parametrize("use_cond,moist_kappa", [(True, False), (True, True), (False, True)])
