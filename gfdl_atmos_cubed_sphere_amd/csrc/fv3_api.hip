@@ -3251,6 +3251,17 @@ extern "C" int fv3_ray_fast(fv3_ctx *c, double *u, double *v, double *w, int hyd
   return 0;
 }
 
+extern "C" int fv3_mix_dp(fv3_ctx *c, int hydrostatic, double *w, double *delp, double *pt) {
+  if (!c || !c->grid_ready) return fail("fv3_mix_dp: context has no grid");
+  if (!c->akbk_ready) return fail("fv3_mix_dp: call fv3_set_ak_bk first (dpmin is 1 %% of the reference thickness of a layer)");
+  if (!delp || !pt || (!hydrostatic && !w)) return fail("fv3_mix_dp: null argument");
+  if (c->g.npz < 2) return fail("fv3_mix_dp: needs npz >= 2");
+  const Grid &g = c->g;
+  MixDp kf{g, hydrostatic, c->akbk, c->akbk + (g.npz + 1), w, delp, pt};
+  RT(launch_c(c, "mix_dp", col_grid(g.nx * g.ny), kf));
+  return 0;
+}
+
 extern "C" int fv3_set_condensate(fv3_ctx *c, const double *q_con, const double *cappa) {
   if (!c) return fail("fv3_set_condensate: null context");
   c->q_con = q_con;

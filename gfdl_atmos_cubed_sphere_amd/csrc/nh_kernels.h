@@ -1948,6 +1948,52 @@ struct RayFast {
   }
 };
 
+// mix_dp, dyn_core.F90:2119-2200 (flagstruct%fill_dp, called behind d_sw at :820 with CG = .false.): a layer whose delp fell below
+// 1 % of its reference thickness (or is NaN: `.not. delp >= dpmin`) takes the missing mass from the layer below -- the bottom layer from
+// the one above -- and mixes pt (and w) with it.  Sequential in k within a column (the layer that gave mass is tested next): one thread
+// per column of the compute domain marching k with delp of the next layer in a register; pt and w are touched only where the fix acts.
+// ak, bk: the context's device tables (fv3_set_ak_bk); dpmin with the reference's expression, bit for bit.
+struct MixDp {
+  Grid g;
+  int hydrostatic;
+  const double *ak, *bk;
+  double *w, *delp, *pt;
+  FV3_HD void operator()(int bx, int, int, int tid, double *) const {
+    const int ncol = g.nx * g.ny, km = g.npz;
+    const size_t nA = g.nA();
+    FV3_COL_FOR(c, ncol) {
+      const int i = g.is + c % g.nx, j = g.js + c / g.nx;
+      const size_t o = (size_t)g.iA(i, j);
+      double d0 = delp[o];
+      for (int k = 0; k < km - 1; k++) {
+        const double dpmin = 0.01 * (ak[k + 1] - ak[k] + (bk[k + 1] - bk[k]) * 1.E5);
+        double d1 = delp[(size_t)(k + 1) * nA + o];
+        if (!(d0 >= dpmin)) {
+          const double dp = dpmin - d0;
+          const size_t o0 = (size_t)k * nA + o, o1 = o0 + nA;
+          pt[o0] = (pt[o0] * d0 + pt[o1] * dp) / dpmin;
+          if (!hydrostatic) w[o0] = (w[o0] * d0 + w[o1] * dp) / dpmin;
+          delp[o0] = dpmin;
+          d1 = d1 - dp;
+          delp[o1] = d1;
+        }
+        d0 = d1;
+      }
+      {   // bottom (k = km): from above
+        const double dpmin = 0.01 * (ak[km] - ak[km - 1] + (bk[km] - bk[km - 1]) * 1.E5);
+        if (!(d0 >= dpmin)) {
+          const double dp = dpmin - d0;
+          const size_t o0 = (size_t)(km - 1) * nA + o, om = o0 - nA;
+          pt[o0] = (pt[o0] * d0 + pt[om] * dp) / dpmin;
+          if (!hydrostatic) w[o0] = (w[o0] * d0 + w[om] * dp) / dpmin;
+          delp[o0] = dpmin;
+          delp[om] = delp[om] - dp;
+        }
+      }
+    }
+  }
+};
+
 // compute_aam, fv_dynamics.F90:1266-1314 (after the caller's cubed_to_latlon, :1287): one thread per column of the compute domain
 struct AamColumns {
   Grid g;

@@ -38,6 +38,7 @@ class DynFlags:
     moist_kappa: bool = False  # thermostruct%moist_kappa: per-cell cappa in the Riemann solvers (and the remap)
     d_ext: float = 0.02      # external-mode damping (hydrostatic one_grad_p only), fv_arrays.F90:452
     inline_q: bool = False   # tracers advected inside d_sw every substep instead of tracer_2d (sw_core.F90:1020-1043), fv_arrays.F90:474
+    fill_dp: bool = False    # mix_dp behind d_sw (dyn_core.F90:820, :2119-2200): thin layers borrow mass from their neighbour; needs ak, bk
     beta: float = 0.0        # > 0: split_p_grad / grad1_p_update (time-off-centred hydrostatic pressure gradient), fv_arrays.F90:403
     convert_ke: bool = False
     ke_bg: float = 0.0
@@ -110,9 +111,14 @@ class DynCore:
     PROGNOSTIC = (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"))
 
     def __init__(self, ctx: Context, flags: DynFlags, dp_ref, px: int = 1, py: int = 1, rank: int = 0, world: int = 1,
-                 halo=None, pfull=None, ks: int = 0):
-        """pfull (npz; fv_dynamics.F90:254-262) and ks (the levels of pure pressure) are read by fast_tau_w_sec / RF_fast only"""
+                 halo=None, pfull=None, ks: int = 0, akbk=None):
+        """pfull (npz; fv_dynamics.F90:254-262) and ks (the levels of pure pressure) are read by fast_tau_w_sec / RF_fast only;
+        akbk = (ak, bk) by fill_dp only (dyn_core's own arguments, dyn_core.F90:94-98; FvDynamics hands its own over)"""
         self.ctx, self.fl = ctx, flags
+        if akbk is not None:
+            ctx.set_ak_bk(np.asarray(akbk[0], dtype=np.float64), np.asarray(akbk[1], dtype=np.float64))
+        elif flags.fill_dp:
+            raise ValueError("fill_dp (mix_dp) needs ak, bk: DynCore(..., akbk=(ak, bk))")
         self.pfull, self.ks, self.dp_ref = (None if pfull is None else np.asarray(pfull, dtype=np.float64)), int(ks), np.asarray(dp_ref, dtype=np.float64)
         self._rfw_ready = self._rff_ready = False
         if (flags.fast_tau_w_sec > 1.0e-5 or (flags.rf_fast and flags.tau > 0.0)) and pfull is None:
@@ -306,6 +312,8 @@ class DynCore:
             ctx.divg2_ext(fl.d_ext, d["delp"], d["vt"], d["divg2"])
             for n in ("delp", "pt", "u", "v"):
                 self._swap(n)
+            if fl.fill_dp:
+                ctx.mix_dp(True, None, d["delp"], d["pt"])                    # :820
             halo.update([(d["delp"], "A"), (d["pt"], "A")])                   # :823-824 / :851
             ctx.geopk(fl.ptop, fl.akap, fl.cp_air, d["pe"], d["peln"], d["delp"], d["pkc"], d["gz"], d["phis"], d["pt"],
                       d["pkz"], False)                                        # :905-907
@@ -405,6 +413,8 @@ class DynCore:
                 ctx.divg2_ext(fl.d_ext, d["delp"], d["vt"], d["divg2"])
             for n in ("delp", "pt", "u", "v", "w") + (("q_con",) if fl.use_cond else ()):
                 self._swap(n)
+            if fl.fill_dp:
+                ctx.mix_dp(False, d["w"], d["delp"], d["pt"])                 # :820
             # :823-825 start / :851-852 complete (packs 1, 11).  Several ranks: the messages stay in flight while update_dz_d
             # and Riem_Solver3 run -- neither reads a halo of delp, pt, q_con (column kernels over the compute domain; the
             # transport of zh reads the Courant numbers and area fluxes) -- and are completed in front of pk3_halo, the

@@ -79,7 +79,7 @@ module fv3_arrays_compat_mod
     integer :: kord_tm = -8, kord_mt = 8, kord_wz = 8, kord_tr = 8
     logical :: do_vort_damp = .false., use_logp = .false., use_old_omega = .true., is_ideal_case = .false.
     logical :: convert_ke = .false., hydrostatic = .true., adiabatic = .false., fill = .false.
-    logical :: do_diss_est = .false., prevent_diss_cooling = .false., do_f3d = .false., inline_q = .false.
+    logical :: do_diss_est = .false., prevent_diss_cooling = .false., do_f3d = .false., inline_q = .false., fill_dp = .false.
     logical :: nested = .false., regional = .false.
     real(c_double) :: tau = 0.d0, rf_cutoff = 30.d2, fast_tau_w_sec = 0.d0
     logical :: RF_fast = .false., consv_am = .false., do_sat_adj = .false., moist_phys = .true.
@@ -577,6 +577,7 @@ contains
       fl%fast_tau_w_sec = flagstruct%fast_tau_w_sec; fl%RF_fast = flagstruct%RF_fast; fl%tau = flagstruct%tau   ! :536, :940, :1057-1060
       fl%rf_cutoff = flagstruct%rf_cutoff; fl%ks = ks
       fl%do_diss_est = flagstruct%do_diss_est
+      fl%fill_dp = flagstruct%fill_dp                                      ! dyn_core.F90:820
       call fv3_host_init_grid(at, dom, gh, 0, fl, ak, bk)
       bound = .true.
     end subroutine
@@ -1018,6 +1019,7 @@ contains
     fl%convert_ke = flagstruct%convert_ke
     fl%fast_tau_w_sec = flagstruct%fast_tau_w_sec; fl%RF_fast = flagstruct%RF_fast; fl%tau = flagstruct%tau
     fl%rf_cutoff = flagstruct%rf_cutoff
+    fl%fill_dp = flagstruct%fill_dp                                        ! dyn_core.F90:820
   end subroutine
 
   !> lazy = .true.: dyn_core (doubly periodic domain) copies a caller's array to the device only when the caller declared a write to it

@@ -65,6 +65,9 @@ module fv3_host_mod
     ! flagstruct%do_diss_est (the SKEB dissipation estimate): d_sw returns diss_e of every level, the loop sums it into diss_est
     ! over the acoustic substeps (dyn_core.F90:805-811); also a member of the gridstruct the context uploads (fv3_domain%do_diss_est)
     logical :: do_diss_est = .false.
+    ! flagstruct%fill_dp: mix_dp after d_sw (dyn_core.F90:820, :2119-2200) -- layers thinner than 1 % of their reference thickness take
+    ! mass (and the w / pt that goes with it) from a neighbour; the reference thickness is that of the ak / bk given to fv3_host_init_grid
+    logical :: fill_dp = .false.
   end type
 
   !> device-resident state and work arrays of one rank (fv_atmos_type members + dyn_core.F90:256-283)
@@ -549,6 +552,7 @@ contains
         call fv3_check(fv3_divg2_ext(ctx, at%fl%d_ext, at%delp, at%vt, at%divg2), 'divg2_ext')
       call swap(at%delp, at%delp_n); call swap(at%pt, at%pt_n)
       call swap(at%u, at%u_n); call swap(at%v, at%v_n); call swap(at%w, at%w_n)
+      if (at%fl%fill_dp) call fv3_check(fv3_mix_dp(ctx, 0_c_int, at%w, at%delp, at%pt), 'mix_dp')    ! :820
       call halo(at, at%delp, KIND_A, npz); call halo(at, at%pt, KIND_A, npz)              ! :823-824 / :851 (pack 1)
       if (at%fl%use_cond) then
         call swap(at%q_con, at%q_con_n)
@@ -656,6 +660,7 @@ contains
       ! the external-mode damping field from the delp BEFORE d_sw (:745-747) and d_sw's divergence output (:791-848)
       call fv3_check(fv3_divg2_ext(ctx, at%fl%d_ext, at%delp, at%vt, at%divg2), 'divg2_ext')
       call swap(at%delp, at%delp_n); call swap(at%pt, at%pt_n); call swap(at%u, at%u_n); call swap(at%v, at%v_n)
+      if (at%fl%fill_dp) call fv3_check(fv3_mix_dp(ctx, 1_c_int, c_null_ptr, at%delp, at%pt), 'mix_dp')   ! :820
       call halo(at, at%delp, KIND_A, npz); call halo(at, at%pt, KIND_A, npz)
       call fv3_check(fv3_geopk(ctx, at%fl%ptop, at%fl%akap, at%fl%cp_air, ptk, at%pe, at%peln, at%delp, at%pkc, at%gz, &
                                at%phis, at%pt, at%pkz, 0_c_int), 'geopk')

@@ -23,7 +23,7 @@ module fv3_mi355x_mod
   public :: fv3_comm_get_unique_id, fv3_comm_init, fv3_comm_destroy, fv3_halo_start, fv3_halo_complete, fv3_allreduce_max
   public :: fv3_cube_field, fv3_cube_table, fv3_cube_halo_start, fv3_cube_halo_complete
   public :: FV3_CUBE_A, FV3_CUBE_B, FV3_CUBE_D, FV3_CUBE_C, FV3_CUBE_DEDGE
-  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_rayleigh_super, fv3_compute_total_energy, fv3_energy_fixer_sums, fv3_remap_finish, fv3_ordered_sum, fv3_adv_pe, fv3_set_condensate, fv3_registry_mode, fv3_registry_put, fv3_registry_get, fv3_registry_host_touched, fv3_registry_fetch, fv3_registry_forget, fv3_registry_stats, fv3_set_fast_tau_w, fv3_set_ray_fast, fv3_ray_fast, fv3_compute_aam, fv3_consv_am_apply, fv3_set_moist, fv3_moist_params
+  public :: fv3_c2l, fv3_rayleigh_u2f, fv3_rayleigh_apply, fv3_rayleigh_super, fv3_compute_total_energy, fv3_energy_fixer_sums, fv3_remap_finish, fv3_ordered_sum, fv3_adv_pe, fv3_set_condensate, fv3_registry_mode, fv3_registry_put, fv3_registry_get, fv3_registry_host_touched, fv3_registry_fetch, fv3_registry_forget, fv3_registry_stats, fv3_set_fast_tau_w, fv3_set_ray_fast, fv3_ray_fast, fv3_mix_dp, fv3_compute_aam, fv3_consv_am_apply, fv3_set_moist, fv3_moist_params
 
   type, bind(C) :: fv3_domain
     integer(c_int) :: is, ie, js, je, ng, npx, npy, npz, grid_type
@@ -534,6 +534,12 @@ module fv3_mi355x_mod
       import :: c_int, c_ptr, c_long_long
       type(c_ptr), value :: ctx
       integer(c_long_long), intent(out) :: out4(4)
+    end function
+    !> replaces: if (flagstruct%fill_dp) call mix_dp(hydrostatic, w, delp, pt, npz, ak, bk, .false., fv_debug, bd, gridstruct)   dyn_core.F90:820
+    integer(c_int) function fv3_mix_dp(ctx, hydrostatic, w, delp, pt) bind(C, name="fv3_mix_dp")
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx, w, delp, pt
+      integer(c_int), value :: hydrostatic
     end function
     integer(c_int) function fv3_compute_aam(ctx, radius, omega, agrav, ptop, coslat, ua, delp, aam, m_fac, ps) bind(C, name="fv3_compute_aam")   ! consv_am
       import :: c_int, c_ptr, c_double

@@ -172,6 +172,9 @@ program fv3_solo_refsig
   if (envstat == 0 .and. trim(envbuf) == '1') then
     fs%do_diss_est = .true.; fs%prevent_diss_cooling = .false.
   end if
+  ! FV3_REFSIG_FILL_DP=1: flagstruct%fill_dp (mix_dp after d_sw, with the file's ak / bk as the reference thicknesses)
+  call get_environment_variable('FV3_REFSIG_FILL_DP', envbuf, status=envstat)
+  if (envstat == 0 .and. trim(envbuf) == '1') fs%fill_dp = .true.
 
   if (whole) then
     fs%c2l_ord = 4; fs%tau = tau; fs%moist_phys = .false.

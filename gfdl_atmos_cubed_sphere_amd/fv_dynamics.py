@@ -69,7 +69,7 @@ class FvDynamics:
         ph = np.asarray(ak, dtype=np.float64) + np.asarray(bk, dtype=np.float64) * 1.0e5     # fv_dynamics.F90:254-262 (p_ref = 1e5)
         pfull = (ph[1:] - ph[:-1]) / np.log(ph[1:] / ph[:-1])
         ks = int(np.argmax(np.asarray(bk) != 0.0)) - 1 if np.any(np.asarray(bk) != 0.0) else len(pfull)   # the last interface of pure pressure
-        self.dc = DynCore(ctx, flags, dp_ref, px, py, rank, world, halo=halo, pfull=pfull, ks=max(ks, 0))
+        self.dc = DynCore(ctx, flags, dp_ref, px, py, rank, world, halo=halo, pfull=pfull, ks=max(ks, 0), akbk=(ak, bk))
         ctx.set_ak_bk(ak, bk)
         npz = ctx.npz
         d = self.dc.d

@@ -34,7 +34,7 @@ EXPORTS = ["fv3_last_error", "fv3_create", "fv3_destroy", "fv3_set_stream", "fv3
            "fv3_free", "fv3_memcpy_h2d", "fv3_memcpy_d2h", "fv3_memcpy_d2d", "fv3_memset", "fv3_sync", "fv3_registry_mode", "fv3_registry_put", "fv3_registry_get", "fv3_registry_host_touched", "fv3_registry_fetch", "fv3_registry_forget", "fv3_registry_stats", "fv3_fv_tp_2d", "fv3_ppm_line", "fv3_c_sw",
            "fv3_dsw_levels_upload", "fv3_d_sw", "fv3_d_sw_interior", "fv3_d_sw_rest", "fv3_halo_fill_periodic", "fv3_halo_message_elems", "fv3_halo_periodic_group", "fv3_halo_pack",
            "fv3_halo_unpack", "fv3_pt_to_theta_v", "fv3_c2l", "fv3_rayleigh_u2f", "fv3_rayleigh_apply", "fv3_rayleigh_super", "fv3_compute_total_energy", "fv3_energy_fixer_sums", "fv3_remap_finish", "fv3_ordered_sum", "fv3_adv_pe", "fv3_omga_update", "fv3_divg2_ext", "fv3_one_grad_p", "fv3_one_grad_p_nh", "fv3_copy_a_to_cc", "fv3_heat_source_accum", "fv3_del2_cubed", "fv3_apply_heat_source", "fv3_profile", "fv3_profile_report", "fv3_comm_get_unique_id", "fv3_comm_init", "fv3_comm_destroy", "fv3_halo_start", "fv3_halo_complete", "fv3_allreduce_max", "fv3_cube_table", "fv3_cube_halo_start", "fv3_cube_halo_complete",
-           "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_set_fast_tau_w", "fv3_set_ray_fast", "fv3_ray_fast", "fv3_compute_aam", "fv3_consv_am_apply", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
+           "fv3_set_dp_ref", "fv3_update_dz_c", "fv3_set_condensate", "fv3_set_fast_tau_w", "fv3_set_ray_fast", "fv3_ray_fast", "fv3_mix_dp", "fv3_compute_aam", "fv3_consv_am_apply", "fv3_riem_solver_c", "fv3_update_dz_d", "fv3_riem_solver3",
            "fv3_p_grad_c", "fv3_nh_p_grad", "fv3_split_p_grad", "fv3_grad1_p_update", "fv3_d_sw_inline_q", "fv3_flux_accum", "fv3_fill2d_mass", "fv3_fill2d_apply", "fv3_set_remap_te", "fv3_profile_report_timers", "fv3_prt_maxmin", "fv3_pk3_halo", "fv3_pe_halo", "fv3_geopk", "fv3_zh_from_delz", "fv3_set_ak_bk", "fv3_set_moist", "fv3_lagrangian_to_eulerian",
            "fv3_tracer_2d_prep", "fv3_tracer_2d_scale", "fv3_tracer_2d_step"]
 
@@ -482,6 +482,10 @@ class Context:
     def ray_fast(self, u, v, w, hydrostatic):
         """Ray_fast (dyn_core.F90:2549-2597) on the compute domain; w may be None when hydrostatic"""
         self.lib.check(self.lib.dll.fv3_ray_fast(self.h, u.p, v.p, w.p if w is not None else None, C.c_int(int(hydrostatic))), "fv3_ray_fast")
+
+    def mix_dp(self, hydrostatic, w, delp, pt):
+        """mix_dp (dyn_core.F90:2119-2200; flagstruct%fill_dp, :820): thin layers borrow mass from their neighbour, pt and w mixed; in place"""
+        self.lib.check(self.lib.dll.fv3_mix_dp(self.h, C.c_int(int(hydrostatic)), w.p if w is not None else None, delp.p, pt.p), "fv3_mix_dp")
 
     def set_condensate(self, q_con=None, cappa=None):
         """use_cond / moist_kappa arrays of the following riem_solver_c / riem_solver3 calls (None = .false.)"""

@@ -341,6 +341,11 @@ int fv3_set_fast_tau_w(fv3_ctx *ctx, int k_rf, const double *rff);
  * rf(k) and gives the momentum a column lost, sum (1 - rf) dp u / dm, back to its levels k <= k_rf (:2549-2597), compute domain. */
 int fv3_set_ray_fast(fv3_ctx *ctx, int kmax, int k_rf, double dm, const double *rf, const double *dp);
 int fv3_ray_fast(fv3_ctx *ctx, double *u, double *v, double *w, int hydrostatic);
+/* mix_dp -- model/dyn_core.F90:2119-2200, called behind the d_sw loop when flagstruct%fill_dp (:820, CG = .false.): on the compute domain a
+ * layer with delp below 1 % of its reference thickness (0.01 (ak(k+1) - ak(k) + (bk(k+1) - bk(k)) 1e5); NaN counts) takes the missing mass
+ * from the layer below (the bottom layer: from above) and mixes pt (and w unless hydrostatic) with it, top to bottom.  delp, pt, w: A x npz,
+ * in place; needs fv3_set_ak_bk. */
+int fv3_mix_dp(fv3_ctx *ctx, int hydrostatic, double *w, double *delp, double *pt);
 
 /* Riem_Solver_c -- model/nh_utils.F90:323, call site model/dyn_core.F90:531 (a_imp > 0.5: SIM1_solver; a_imp < -0.01: SIM3p0_solver;
  * otherwise RIM_2D with cn->m_split sub-steps, nh_utils.F90:449-459).

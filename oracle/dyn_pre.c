@@ -295,3 +295,36 @@ int fvo_consv_am_apply(const fvo_grid *g, int npz, double u00, const double *l2c
   }
   return FVO_OK;
 }
+
+/* mix_dp, model/dyn_core.F90:2119-2200 with CG = .false. (the call of :820): loop for loop */
+int fvo_mix_dp(const fvo_grid *g, int km, int hydrostatic, const double *ak, const double *bk, double *w, double *delp, double *pt) {
+  BOUNDS(g);
+  int i, j, k;
+  for (j = js; j <= je; j++) {
+    for (k = 1; k <= km - 1; k++) {
+      const double dpmin = 0.01 * (ak[k] - ak[k - 1] + (bk[k] - bk[k - 1]) * 1.E5);
+      for (i = is; i <= ie; i++) {
+        if (!(delp[A3(i, j, k)] >= dpmin)) {
+          const double dp = dpmin - delp[A3(i, j, k)];
+          pt[A3(i, j, k)] = (pt[A3(i, j, k)] * delp[A3(i, j, k)] + pt[A3(i, j, k + 1)] * dp) / dpmin;
+          if (!hydrostatic) w[A3(i, j, k)] = (w[A3(i, j, k)] * delp[A3(i, j, k)] + w[A3(i, j, k + 1)] * dp) / dpmin;
+          delp[A3(i, j, k)] = dpmin;
+          delp[A3(i, j, k + 1)] = delp[A3(i, j, k + 1)] - dp;
+        }
+      }
+    }
+    {
+      const double dpmin = 0.01 * (ak[km] - ak[km - 1] + (bk[km] - bk[km - 1]) * 1.E5);
+      for (i = is; i <= ie; i++) {
+        if (!(delp[A3(i, j, km)] >= dpmin)) {
+          const double dp = dpmin - delp[A3(i, j, km)];
+          pt[A3(i, j, km)] = (pt[A3(i, j, km)] * delp[A3(i, j, km)] + pt[A3(i, j, km - 1)] * dp) / dpmin;
+          if (!hydrostatic) w[A3(i, j, km)] = (w[A3(i, j, km)] * delp[A3(i, j, km)] + w[A3(i, j, km - 1)] * dp) / dpmin;
+          delp[A3(i, j, km)] = dpmin;
+          delp[A3(i, j, km - 1)] = delp[A3(i, j, km - 1)] - dp;
+        }
+      }
+    }
+  }
+  return 0;
+}

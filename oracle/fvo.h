@@ -298,6 +298,8 @@ int fvo_ray_fast_profile(int npz, int ks, double dt, double tau, double rf_cutof
 int fvo_ray_fast(const fvo_grid *g, int npz, int kmax, int k_rf, const double *rf, const double *dp, int hydrostatic, double *u,
                  double *v, double *w);
 int fvo_fast_tau_w_rff(int km, double dt, double fast_tau_w_sec, double rf_cutoff, double ptop, const double *pfull, double *rff);
+/* mix_dp (dyn_core.F90:2119-2200, flagstruct%fill_dp; CG = .false.): delp, pt, w (A x km) in place */
+int fvo_mix_dp(const fvo_grid *g, int km, int hydrostatic, const double *ak, const double *bk, double *w, double *delp, double *pt);
 int fvo_set_fast_tau_w(int k_rf, const double *rff);
 int fvo_rayleigh_super(const fvo_grid *g, int kmax, int conserve, int hydrostatic, double cp, double rg, double ptop,
                        const double *pm, const double *rf, const double *ua, const double *va, double *pt, double *u,

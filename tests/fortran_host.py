@@ -153,7 +153,7 @@ def build_refsig(workdir, libdir=CSRC, libname="fv3_mi355x"):
 
 
 def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2, bdt=6.0, hydrostatic=False, d_con=0.0, beta=0.0, moist=False,
-                         layout=(1, 1), fast_tau_w_sec=0.0, rf_fast_tau=0.0, registry=False, do_diss_est=False):
+                         layout=(1, 1), fast_tau_w_sec=0.0, rf_fast_tau=0.0, registry=False, do_diss_est=False, fill_dp=False):
     """dyn_core called with the reference's argument list on host arrays (fv3_dyn_core_mod, driver fv3_solo_refsig) against the
     Python host's DynCore.run on the same state: u, v, w, delp, pt, delz, the accumulated mass fluxes / Courant numbers (and pkz
     when the heating or the hydrostatic branch writes it) bit-identical"""
@@ -171,13 +171,16 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
     st, _ = D.make_state(bd, npz)
     sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
     ak, bk = N.PTOP * (1.0 - sig), sig.copy()
+    if fill_dp:     # flagstruct%fill_dp: reference thicknesses that make about half of the cells of every layer `thin` (mix_dp acts)
+        ak, bk = D.thin_akbk(bd, npz, st["delp"])
     # fast_tau_w_sec / RF_fast (dyn_core.F90:536, :940, :1057-1060): the driver hands dyn_core ITS pfull (the mid-level pressure of its
     # ak, bk) and ks = 0; the profiles are evaluated on either side (libm there, numpy here), so the comparison allows rounding then
     pfull_drv = 0.5 * (ak[:-1] + ak[1:] + (bk[:-1] + bk[1:]) * 1.0e5)
     rf_cut = float(pfull_drv[npz // 2]) + 1.0
     damp = fast_tau_w_sec > 0.0 or rf_fast_tau > 0.0
     fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, d_con=d_con, beta=beta, use_cond=moist, moist_kappa=moist,
-                  fast_tau_w_sec=fast_tau_w_sec, rf_fast=rf_fast_tau > 0.0, tau=rf_fast_tau, rf_cutoff=rf_cut if damp else 30.0e2)
+                  fast_tau_w_sec=fast_tau_w_sec, rf_fast=rf_fast_tau > 0.0, tau=rf_fast_tau, rf_cutoff=rf_cut if damp else 30.0e2,
+                  fill_dp=fill_dp)
     mo = None
     if moist:     # q_con / cappa as moist_cv gives them for small mixing ratios of six species (halos periodic: the caller's, :464-465)
         import parity_remap as R
@@ -193,7 +196,7 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
     dp_ref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
     ctx = Context(g, npz, lib=lib)
     try:
-        dc = DynCore(ctx, fl, dp_ref, pfull=pfull_drv if damp else None, ks=0)
+        dc = DynCore(ctx, fl, dp_ref, pfull=pfull_drv if damp else None, ks=0, akbk=(ak, bk) if fill_dp else None)
         dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
         if mo:
             dc.d["q_con"].upload(mo["q_con"])
@@ -220,6 +223,8 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
     env = {}
     if do_diss_est:
         env["FV3_REFSIG_DISS_EST"] = "1"
+    if fill_dp:
+        env["FV3_REFSIG_FILL_DP"] = "1"
     if fast_tau_w_sec > 0.0:
         env["FV3_REFSIG_FAST_TAU_W"] = repr(float(fast_tau_w_sec))
     if rf_fast_tau > 0.0:
@@ -244,6 +249,16 @@ def check_fortran_refsig(lib, workdir, nx=24, ny=16, npz=8, n_split=3, nsteps=2,
         assert h2d == n_in and h2d_skip == n_in * (nsteps - 1) and d2h_def > 0 and d2h == d2h_def // nsteps, (h2d, h2d_skip, d2h, d2h_def)
     else:
         assert h2d == n_in * nsteps and h2d_skip == 0 and d2h_def == 0 and d2h > 0, (h2d, h2d_skip, d2h, d2h_def)
+    if fill_dp:   # mix_dp is in the run at all
+        ctx = Context(g, npz, lib=lib)
+        try:
+            dc = DynCore(ctx, DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, d_con=d_con, beta=beta), dp_ref)
+            dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
+            for _ in range(nsteps):
+                dc.run(bdt)
+            assert P.rel_rms(dc.d["delp"].download(), ref["delp"]) > 1e-6
+        finally:
+            ctx.close()
     if damp:   # the damping is in the run at all
         ctx = Context(g, npz, lib=lib)
         try:

@@ -21,7 +21,7 @@ def _fill(bd, a, kind):
             periodic_fill(bd, a[:, :, k], kind)
 
 
-def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float, pfull=None, ks=0):
+def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float, pfull=None, ks=0, akbk=None):
     """st: u, v, w, delp, pt (halo'd), delz (CC x npz), phis (A).  Returns the updated state dict.
     pfull, ks: for fast_tau_w_sec > 0 / RF_fast (the profiles are evaluated as on the reference's first call of a run that starts here)"""
     rff = None
@@ -29,12 +29,12 @@ def run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float, pfull=None, ks=
         rff = O.fast_tau_w_rff(npz, 0.5 * bdt / float(fl.n_split), fl.fast_tau_w_sec, fl.rf_cutoff, fl.ptop, pfull)
     O.set_fast_tau_w(rff)
     try:
-        return _run(g, npz, fl, dp_ref, st, bdt, pfull, ks)
+        return _run(g, npz, fl, dp_ref, st, bdt, pfull, ks, akbk)
     finally:
         O.set_fast_tau_w(None)
 
 
-def _run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float, pfull=None, ks=0):
+def _run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float, pfull=None, ks=0, akbk=None):
     bd: Bounds = g.bd
     f = {k: np.asfortranarray(v.copy()) for k, v in st.items()}
     nx, ny = bd.nx, bd.ny
@@ -110,6 +110,8 @@ def _run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float, pfull=None, ks
         if fl.beta < -0.1:                                                 # dyn_core.F90:745-747, :791-848 (zeros when d_ext = 0)
             f.setdefault("divg2", bd.zeros("A"))
             O.divg2_ext(g, npz, fl.d_ext, delp_start, f["vt"], f["divg2"])
+        if fl.fill_dp:                                                     # dyn_core.F90:820
+            O.mix_dp(g, npz, False, akbk[0], akbk[1], f["w"], f["delp"], f["pt"])
         _fill(bd, f["delp"], "A"); _fill(bd, f["pt"], "A")
         O.update_dz_d(g, npz, ndif.copy(), damp.copy(), fl.hord_tm, dp_ref, zs, f["zh"], f["crx"], f["cry"], f["xfx"],
                       f["yfx"], f["ws"], rdt)
@@ -156,7 +158,7 @@ def _run(g, npz: int, fl: DynFlags, dp_ref, st: dict, bdt: float, pfull=None, ks
     return f
 
 
-def run_hydrostatic(g, npz: int, fl: DynFlags, st: dict, bdt: float):
+def run_hydrostatic(g, npz: int, fl: DynFlags, st: dict, bdt: float, akbk=None):
     """hydrostatic branch of the substep loop over the oracle's routines.  st: u, v, delp, pt (halo'd), phis."""
     bd: Bounds = g.bd
     f = {k: np.asfortranarray(v.copy()) for k, v in st.items()}
@@ -207,6 +209,8 @@ def run_hydrostatic(g, npz: int, fl: DynFlags, st: dict, bdt: float):
             f.setdefault("diss_est", bd.zeros("A", npz))
             f["diss_est"][bd.ng:bd.ng + nx, bd.ng:bd.ng + ny, :] += f["diss_e"]
         O.divg2_ext(g, npz, fl.d_ext, delp_old, f["vt"], f["divg2"])
+        if fl.fill_dp:                                                     # dyn_core.F90:820
+            O.mix_dp(g, npz, True, akbk[0], akbk[1], None, f["delp"], f["pt"])
         _fill(bd, f["delp"], "A"); _fill(bd, f["pt"], "A")
         O.geopk(g, npz, fl.ptop, fl.akap, fl.cp_air, f["pe"], f["peln"], f["delp"], f["pkc"], f["gz"], f["phis"], f["pt"],
                 f["pkz"], False)

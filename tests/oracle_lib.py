@@ -268,6 +268,14 @@ def ray_fast(g, npz, kmax, k_rf, rf, dp, hydrostatic, u, v, w):
                               C.c_int(int(hydrostatic)), p(u), p(v), p(w) if w is not None else None) == 0
 
 
+def mix_dp(g, km, hydrostatic, ak, bk, w, delp, pt):
+    gs = make_grid(g)
+    ak = np.ascontiguousarray(ak, dtype=np.float64)
+    bk = np.ascontiguousarray(bk, dtype=np.float64)
+    assert lib().fvo_mix_dp(C.byref(gs), C.c_int(km), C.c_int(int(hydrostatic)), ak.ctypes.data_as(_dp), bk.ctypes.data_as(_dp),
+                            p(w) if w is not None else None, p(delp), p(pt)) == 0
+
+
 def update_dz_d(g, km, ndif, damp, hord, dp0, zs, zh, crx, cry, xfx, yfx, ws, rdt):
     gs = make_grid(g)
     ndif = np.ascontiguousarray(ndif, dtype=np.int32)

@@ -30,7 +30,15 @@ def ulp_sensitivity(g, npz, fl, dp0, st, bdt, ref):
     return {n: P.rel_rms(pert[n], ref[n]) for n in ("u", "v", "w", "delp", "pt", "zh", "delz", "mfx", "mfy", "cx", "cy")}
 
 
-def check_substeps(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None, tol=None, ic=None, pfull=None, ks=0, do_diss_est=False):
+def thin_akbk(bd, npz, delp):
+    """an (ak, bk) whose 1 % thresholds (mix_dp, dyn_core.F90:2140) sit in the middle of each layer's range of the state: about
+    half of the cells of every layer are `thin`, chains of them included"""
+    v = bd.view(delp, "A", bd.is_, bd.ie, bd.js, bd.je)
+    dref = 100.0 * 0.5 * (v.min(axis=(0, 1)) + v.max(axis=(0, 1)))
+    return np.zeros(npz + 1), np.concatenate(([0.0], np.cumsum(dref))) / 1.0e5
+
+
+def check_substeps(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None, tol=None, ic=None, pfull=None, ks=0, do_diss_est=False, akbk=None):
     bd = Bounds(1, nx, 1, ny)
     g = P.make_grid(bd, False)
     if do_diss_est:     # flagstruct%do_diss_est: a member of the gridstruct the context uploads
@@ -39,13 +47,18 @@ def check_substeps(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, flags=None, tol
     st, dp0 = make_state(bd, npz)
     apply_ic(bd, npz, st, ic)
     fl = DynFlags(n_split=n_split, ptop=N.PTOP, **(flags or {}))
-    ref = OD.run(g, npz, fl, dp0, st, bdt, pfull=pfull, ks=ks)
+    if akbk == "thin":
+        akbk = thin_akbk(bd, npz, st["delp"])
+    ref = OD.run(g, npz, fl, dp0, st, bdt, pfull=pfull, ks=ks, akbk=akbk)
+    if fl.fill_dp:          # mix_dp really acts in this run
+        import dataclasses
+        assert P.rel_rms(OD.run(g, npz, dataclasses.replace(fl, fill_dp=False), dp0, st, bdt)["delp"], ref["delp"]) > 1e-6
     if pfull is not None:   # fast_tau_w_sec / RF_fast really change the step
         off = DynFlags(n_split=n_split, ptop=N.PTOP, **dict(flags or {}, fast_tau_w_sec=0.0, rf_fast=False))
         assert P.rel_rms(OD.run(g, npz, off, dp0, st, bdt)["w"], ref["w"]) > 1e-6
     ctx = Context(g, npz, lib=lib)
     try:
-        dc = DynCore(ctx, fl, dp0, pfull=pfull, ks=ks)
+        dc = DynCore(ctx, fl, dp0, pfull=pfull, ks=ks, akbk=akbk)
         dc.set_state(st["u"], st["v"], st["w"], st["delp"], st["pt"], st["delz"], st["phis"])
         dc.run(bdt)
         got = dc.get_state()
@@ -467,10 +480,14 @@ def check_substeps_hydrostatic(lib, nx=24, ny=16, npz=8, n_split=2, bdt=4.0, fla
     apply_ic(bd, npz, st, ic)
     hst = {k: st[k] for k in ("u", "v", "delp", "pt", "phis")}
     fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=True, **(flags or {}))
-    ref = OD.run_hydrostatic(g, npz, fl, hst, bdt)
+    akbk = thin_akbk(bd, npz, st["delp"]) if fl.fill_dp else None
+    ref = OD.run_hydrostatic(g, npz, fl, hst, bdt, akbk=akbk)
+    if fl.fill_dp:
+        import dataclasses
+        assert P.rel_rms(OD.run_hydrostatic(g, npz, dataclasses.replace(fl, fill_dp=False), hst, bdt)["delp"], ref["delp"]) > 1e-6
     ctx = Context(g, npz, lib=lib)
     try:
-        dc = DynCore(ctx, fl, dp0)
+        dc = DynCore(ctx, fl, dp0, akbk=akbk)
         z = np.zeros_like(st["w"])
         dc.set_state(st["u"], st["v"], z, st["delp"], st["pt"], st["delz"], st["phis"])
         dc.run(bdt)

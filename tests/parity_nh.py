@@ -565,6 +565,48 @@ def check_c2l_and_rayleigh(lib, nx=70, ny=33, km=12, hydrostatic=False, conserve
     return worst
 
 
+def check_mix_dp(lib, nx=37, ny=19, km=12, hydrostatic=False):
+    """mix_dp (dyn_core.F90:2119-2200): a column state with layers far below 1 % of their reference thickness -- isolated ones, two in a row
+    (the second is tested after it gave mass to the first), the top, the bottom layer, a NaN -- bit for bit against the oracle"""
+    bd = Bounds(1, nx, 1, ny)
+    g = P.make_grid(bd, False)
+    rng = np.random.default_rng(17)
+    sig = np.linspace(0.0, 1.0, km + 1) ** 1.5
+    ak, bk = PTOP * (1.0 - sig), sig.copy()
+    dref = (ak[1:] - ak[:-1]) + (bk[1:] - bk[:-1]) * 1.0e5
+    delp = np.asfortranarray(dref[None, None, :] * rng.uniform(0.8, 1.2, bd.shape("A", km)))
+    thin = rng.uniform(0, 1, delp.shape) > 0.9
+    delp[thin] *= 1.0e-3
+    ng = bd.ng
+    delp[ng + 3, ng + 2, 4:6] = dref[4:6] * 1.0e-4            # two in a row
+    delp[ng + 5, ng + 4, 0] = 0.0                             # the top layer, empty
+    delp[ng + 6, ng + 1, km - 1] = dref[km - 1] * 1.0e-5      # the bottom layer
+    delp[ng + 7, ng + 7, 3] = np.nan                          # `.not. delp >= dpmin` catches NaN
+    pt = np.asfortranarray(300.0 + 30.0 * rng.uniform(-1, 1, delp.shape))
+    w = np.asfortranarray(rng.uniform(-2, 2, delp.shape))
+    o = dict(delp=delp.copy(order="F"), pt=pt.copy(order="F"), w=w.copy(order="F"))
+    O.mix_dp(g, km, hydrostatic, ak, bk, None if hydrostatic else o["w"], o["delp"], o["pt"])
+    r = (bd.is_, bd.ie, bd.js, bd.je)
+    assert np.sum(bd.view(o["delp"], "A", *r) != bd.view(delp, "A", *r)) > 50       # the fix acted
+    ctx = Context(g, km, lib=lib)
+    try:
+        ctx.set_ak_bk(ak, bk)
+        d_dp, d_pt, d_w = ctx.from_host(delp), ctx.from_host(pt), ctx.from_host(w)
+        ctx.mix_dp(hydrostatic, None if hydrostatic else d_w, d_dp, d_pt)
+        out = {}
+        for n, dv in (("delp", d_dp), ("pt", d_pt)) + (() if hydrostatic else (("w", d_w),)):
+            a, b = bd.view(dv.download(), "A", *r), bd.view(o[n], "A", *r)
+            assert np.array_equal(np.isnan(a), np.isnan(b))
+            m = ~np.isnan(b)
+            assert np.array_equal(a[m], b[m]), n
+            out[n] = 0.0
+        halo_same = dv.download()[:ng, :, :]
+        assert np.array_equal(np.isnan(d_dp.download()[:ng]), np.isnan(delp[:ng]))     # only the compute domain is touched
+    finally:
+        ctx.close()
+    return out
+
+
 def check_ray_fast(lib, nx=37, ny=19, km=12, hydrostatic=False, tau=0.5, rf_cutoff=None, ks=None):
     """Ray_fast (dyn_core.F90:2485-2601): the profile of its first call and the damping with the momentum handed back, against the
     oracle.  rf_cutoff: default = between levels km/2 and km/2 + 1; ks: the call site's (levels of pure pressure)"""

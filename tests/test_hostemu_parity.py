@@ -552,6 +552,16 @@ def test_fv_dynamics_call_with_rayleigh_friction(emu):
     D.check_fv_cycle_from_temperature(emu, tau=0.01)
 
 
+@pytest.mark.parametrize("hydrostatic", [False, True])
+def test_mix_dp(emu, hydrostatic):
+    """mix_dp (flagstruct%fill_dp, dyn_core.F90:820, :2119-2200) against the oracle, bit for bit; then inside the substep loop"""
+    N.check_mix_dp(emu, hydrostatic=hydrostatic)
+    if hydrostatic:
+        D.check_substeps_hydrostatic(emu, flags=dict(fill_dp=True))
+    else:
+        D.check_substeps(emu, flags=dict(fill_dp=True), akbk="thin")
+
+
 def test_registry_forget(emu):
     """a host array that is freed and allocated again at the same address leaves the lazy registry"""
     P.check_registry_forget(emu)
@@ -610,6 +620,8 @@ def test_fortran_dyn_core_with_the_reference_argument_list(emu, tmp_path):
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, moist=True, d_con=1.0)     # thermostruct%use_cond / moist_kappa
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, do_diss_est=True, d_con=1.0)   # flagstruct%do_diss_est: diss_est in and out
     assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, hydrostatic=True, do_diss_est=True)
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, fill_dp=True)          # flagstruct%fill_dp: mix_dp after d_sw
+    assert "fv3_solo_refsig: done" in F.check_fortran_refsig(emu, tmp_path, npz=8, hydrostatic=True, fill_dp=True)
     # fv_dynamics with ITS reference argument list (model/fv_dynamics.F90:79-85): T -> theta_v, the k_split loop with tracers and
     # the remap, last_step, cubed_to_latlon
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(emu, tmp_path)
