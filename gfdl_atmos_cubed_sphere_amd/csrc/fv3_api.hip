@@ -76,7 +76,7 @@ struct fv3_ctx {
   // optional per-kernel timing with HIP events on the launch stream (fv3_profile / fv3_profile_report)
   // nonhydrostatic path: dp_ref + edge_profile coefficients, scratch slabs (A x (npz+1) each)
   double *dp0;        // device, npz
-  double *edge_dev;   // device, 3*npz: gk, bet, gam
+  double *edge_dev;   // device, 4*npz: gk, bet, gam, 1 / bet; then EdgeProfileLds::kTabDoubles: the rows' table (nh_fast.h edge_rows)
   EdgeCoef ec;
   bool dp0_ready;
   double *scratch[8];
@@ -3158,10 +3158,11 @@ extern "C" int fv3_set_dp_ref(fv3_ctx *c, const double *dp0) {
   const int km = c->g.npz;
   if (km < 2) return fail("fv3_set_dp_ref: needs npz >= 2");
   if (!c->dp0) RT(rt_malloc((void **)&c->dp0, sizeof(double) * km));
-  if (!c->edge_dev) RT(rt_malloc((void **)&c->edge_dev, sizeof(double) * 4 * km));
+  const size_t n_edge = (size_t)4 * km + EdgeProfileLds::kTabDoubles;
+  if (!c->edge_dev) RT(rt_malloc((void **)&c->edge_dev, sizeof(double) * n_edge));
   RT(rtf_h2d(c->dp0, dp0, sizeof(double) * km, c->stream));
   // edge_profile coefficients, same arithmetic as nh_utils.F90:1640-1662
-  std::vector<double> co(4 * km, 0.);
+  std::vector<double> co(n_edge, 0.);
   double *gk = co.data(), *bet = gk + km, *gam = bet + km, *rbet = gam + km;   // rbet: the fast mode's reciprocals
   const double g0 = dp0[1] / dp0[0];
   c->ec.xt1_top = 2. * g0 * (g0 + 1.);
@@ -3178,7 +3179,8 @@ extern "C" int fv3_set_dp_ref(fv3_ctx *c, const double *dp0) {
   c->ec.a_bot = 1. + gkk * (gkk + 1.5);
   c->ec.xt1_bot = 2. * gkk * (gkk + 1.);
   c->ec.gk_bot = gkk;
-  RT(rtf_h2d(c->edge_dev, co.data(), sizeof(double) * 4 * km, c->stream));
+  if (km <= 127) edge_rows(co.data() + 4 * km, km, gk, bet, gam, rbet, c->ec.bet_top, c->ec.a_bot, c->ec.gk_bot);
+  RT(rtf_h2d(c->edge_dev, co.data(), sizeof(double) * n_edge, c->stream));
   RT(rtf_sync(c->stream));
   c->ec.gk = c->edge_dev;
   c->ec.bet = c->edge_dev + km;
@@ -3379,8 +3381,9 @@ extern "C" int fv3_update_dz_d(fv3_ctx *c, int hord, const double *zs, const dou
   const int km = g.npz;
   double *cxa = c->scratch[0], *xfa = c->scratch[1], *cya = c->scratch[2], *yfa = c->scratch[3];
   if (c->riem_lds && km >= 3 && km <= 127) {   // levels across the lanes, the elimination in the reference's order: the slab kernel's bits
-    EdgeProfileLds kf{g, km, c->ec, c->edge_dev + 3 * km, crx, xfx, cxa, xfa, (int)g.nCX(), cry, yfx, cya, yfa, (int)g.nCY()};
-    RT(launch_p(c, "edge_profile", Dim3{(unsigned)kf.nblocks(), 1, 1}, 2 * kFBuf, kf));
+    EdgeProfileLds kf{g, km, c->ec, c->edge_dev + 3 * km, crx, xfx, cxa, xfa, (int)g.nCX(), cry, yfx, cya, yfa, (int)g.nCY(),
+                      c->edge_dev + 4 * km};
+    RT(launch_p2(c, "edge_profile", Dim3{(unsigned)kf.nblocks(), 1, 1}, 2 * kFBuf, kf));
   } else {
     EdgeProfile kf{g, km, c->ec, crx, xfx, cxa, xfa, (int)g.nCX(), cry, yfx, cya, yfa, (int)g.nCY()};
     RT(launch_c(c, "edge_profile", col_grid((int)(g.nCX() + g.nCY())), kf));

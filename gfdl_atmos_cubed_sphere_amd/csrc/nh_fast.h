@@ -293,11 +293,25 @@ struct EdgeProfileLds {
   const double *q1_b, *q2_b;
   double *q1e_b, *q2e_b;
   int n2d_b;
+  // The rows' coefficients as the host tabulates them (edge_rows() below: 6 x 128 doubles -- bet, 1 / bet, S, G, gk, the factor 3 of the
+  // interior rows -- with the first, the bottom and the padded rows already in place).  tab = NULL: the wavefront builds them itself
+  // with a dozen selects of doubles per row (a select of two doubles is 21 cycles of the SIMD, tools/lab/op_lab.hip: that set-up and
+  // the three selects per row of the right-hand sides were half of the wavefront's instructions).  opt & 1: the two fields of a pair
+  // run their rounds side by side (two independent chains: 5.15 instead of 6.3 cycles an operation).  opt & 2: the blocks of an XCD
+  // are neighbours.  What the kernel waits for is memory, though (tools/lab/edge_lab.hip, C384 L127: 0.465 ms as round 5 left it and
+  // with the table alone; 0.407 with the XCD ranges; 0.356 with three workgroups per CU as well -- tile_waves below; four spill)
+  const double *tab = nullptr;
+  int opt = 3;
+  static constexpr int kTabRows = 16 * kFL, kTabDoubles = 6 * kTabRows;
   FV3_HD int nblk_a() const { return (n2d + kFC - 1) / kFC; }
   FV3_HD int nblocks() const { return nblk_a() + (n2d_b + kFC - 1) / kFC; }
   static constexpr int kIt = kFC * 128 / kNT;
   FV3_D void operator()(int bx, int, int, int tid, double *lds) const {
     double *B0 = lds, *B1 = lds + kFBuf;
+    if (opt & 2) {   // neighbouring blocks share 128-byte lines: one contiguous range of blocks per XCD (xcd_block above)
+      int by0 = 0;
+      xcd_block(bx, by0, nblocks(), 1);
+    }
     const bool second = bx >= nblk_a();
     const int blk = second ? bx - nblk_a() : bx;
     const ix_t ls = (ix_t)(second ? n2d_b : n2d);
@@ -326,6 +340,13 @@ struct EdgeProfileLds {
       }
     }
     FV3_SYNC();
+#ifdef FV3_LAB_EDGE_TABLE_ONLY
+    if (true) {
+#else
+    if (tab) {
+#endif
+      FV3_WAVE_FOR(wv) rows_from_table(wv * 4, B0, B1);
+    } else {
     const double xt2 = ec.gk_bot * (ec.gk_bot + 0.5) - ec.a_bot * ec.gam[km - 1];
     const double r_top = 1. / ec.bet_top, r_bot = 1. / xt2;
     FV3_WAVE_FOR(wv) {
@@ -393,6 +414,7 @@ struct EdgeProfileLds {
         vlds_st(B1, c0, q, x2[q]);
       }
     }
+    }
     FV3_SYNC();
     for (int idx = tid; idx < kFC * 128; idx += kNT) {
       const int col = idx & (kFC - 1), k = idx >> 4;
@@ -403,7 +425,139 @@ struct EdgeProfileLds {
       }
     }
   }
+  // right-hand sides of the lane's rows: the interior expression everywhere (3 (q(k-1) + gk q(k)), the factor 0 on the padded rows), the
+  // first row (lane 0, q = 0) and the bottom row (row km: ONE q for the whole wavefront, a scalar branch) put in place by a select each
+  FV3_D void rhs(const double *B, int c0, const vd *gkv, const vd *c3, vd *R) const {
+    vd a[kFL];
+    for (int q = 0; q < kFL; q++) a[q] = vlds_ld(B, c0, q);
+    const vd a_up1 = row_shr<1>(a[kFL - 1], 0.0), a_up2 = row_shr<1>(a[kFL - 2], 0.0);
+    const int qb = km & (kFL - 1);
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+    for (int q = 0; q < kFL; q++) {
+      const vd am1 = q > 0 ? a[q - 1] : a_up1;
+      vd r = c3[q] * (am1 + gkv[q] * a[q]);                                                   // :1636
+      if (q == 0) r = vsel(vlevel_eq(0, 0), ec.xt1_top * a[0] + a[1], r);                     // :1631
+      if (q == qb) {
+        const vd am2 = q > 1 ? a[q - 2] : (q == 1 ? a_up1 : a_up2);
+        r = vsel(vlevel_eq(q, km), ec.xt1_bot * am1 + am2, r);                                // :1648 (q(km), q(km-1))
+      }
+      R[q] = r;
+    }
+  }
+  FV3_D void rows_from_table(int c0, double *B0, double *B1) const {
+    vd bet[kFL], rb[kFL], S[kFL], G[kFL];
+    vd R1[kFL], R2[kFL];
+    {
+      vd gkv[kFL], c3[kFL];
+      for (int q = 0; q < kFL; q++) {
+        bet[q] = vrow_ld(tab, q, kTabRows);
+        rb[q] = vrow_ld(tab + kTabRows, q, kTabRows);
+        S[q] = vrow_ld(tab + 2 * kTabRows, q, kTabRows);
+        G[q] = vrow_ld(tab + 3 * kTabRows, q, kTabRows);
+        gkv[q] = vrow_ld(tab + 4 * kTabRows, q, kTabRows);
+        c3[q] = vrow_ld(tab + 5 * kTabRows, q, kTabRows);
+      }
+      rhs(B0, c0, gkv, c3, R1);
+      rhs(B1, c0, gkv, c3, R2);
+    }
+    vd y1[kFL], y2[kFL];
+#ifdef FV3_LAB_EDGE_SIDE
+    if (FV3_LAB_EDGE_SIDE) {
+#else
+    if (opt & 1) {
+#endif
+      vd in1(0.0), in2(0.0);
+      for (int rnd = 0; rnd < 16; rnd++) {
+        vd v1 = in1, v2 = in2;
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+        for (int q = 0; q < kFL; q++) {
+          v1 = vdiv_r(R1[q] - S[q] * v1, bet[q], rb[q]);
+          v2 = vdiv_r(R2[q] - S[q] * v2, bet[q], rb[q]);
+          y1[q] = v1;
+          y2[q] = v2;
+        }
+        const vd n1 = row_shr<1>(v1, 0.0), n2 = row_shr<1>(v2, 0.0);
+        const bool moved = vany_ne(n1, in1) || vany_ne(n2, in2);     // a round more than a field needs leaves it as it is
+        in1 = n1;
+        in2 = n2;
+        if (!moved) break;
+      }
+      in1 = vd(0.0);
+      in2 = vd(0.0);
+      for (int rnd = 0; rnd < 16; rnd++) {
+        vd v1 = in1, v2 = in2;
+#ifndef FV3_HOST_EMU
+#pragma unroll
+#endif
+        for (int q = kFL - 1; q >= 0; q--) {
+          v1 = y1[q] - G[q] * v1;
+          v2 = y2[q] - G[q] * v2;
+          R1[q] = v1;
+          R2[q] = v2;
+        }
+        const vd n1 = row_shl<1>(v1, 0.0), n2 = row_shl<1>(v2, 0.0);
+        const bool moved = vany_ne(n1, in1) || vany_ne(n2, in2);
+        in1 = n1;
+        in2 = n2;
+        if (!moved) break;
+      }
+    } else {
+      for (int f = 0; f < 2; f++) {
+        vd *R = f ? R2 : R1, *y = f ? y2 : y1;
+        vd in(0.0);
+        for (int rnd = 0; rnd < 16; rnd++) {
+          vd v = in;
+          for (int q = 0; q < kFL; q++) {
+            v = vdiv_r(R[q] - S[q] * v, bet[q], rb[q]);
+            y[q] = v;
+          }
+          const vd nw = row_shr<1>(v, 0.0);
+          const bool moved = vany_ne(nw, in);
+          in = nw;
+          if (!moved) break;
+        }
+        in = vd(0.0);
+        for (int rnd = 0; rnd < 16; rnd++) {
+          vd v = in;
+          for (int q = kFL - 1; q >= 0; q--) {
+            v = y[q] - G[q] * v;
+            R[q] = v;
+          }
+          const vd nw = row_shl<1>(v, 0.0);
+          const bool moved = vany_ne(nw, in);
+          in = nw;
+          if (!moved) break;
+        }
+      }
+    }
+    for (int q = 0; q < kFL; q++) {       // the wavefront's own columns: no other wavefront reads them
+      vlds_st(B0, c0, q, R1[q]);
+      vlds_st(B1, c0, q, R2[q]);
+    }
+  }
 };
+
+template <>
+struct tile_waves<EdgeProfileLds> { static constexpr int value = 3; };
+
+// The table EdgeProfileLds::tab points at (host; t: 6 x 128 doubles), from the coefficients fv3_set_dp_ref has just computed (host
+// copies gk, bet, gam, rbet of km entries each).  Row k is interface k of the system of nh_utils.F90:1623-1660.
+inline void edge_rows(double *t, int km, const double *gk, const double *bet, const double *gam, const double *rbet, double bet_top,
+                      double a_bot, double gk_bot) {
+  constexpr int n = EdgeProfileLds::kTabRows;
+  const double xt2 = gk_bot * (gk_bot + 0.5) - a_bot * gam[km - 1];
+  for (int k = 0; k < n; k++) {
+    double b = 1., r = 1., s = 0., g = 0., gkk = 0., c3 = 0.;
+    if (k == 0) { b = bet_top; r = 1. / bet_top; g = gam[0]; }
+    else if (k < km) { b = bet[k]; r = rbet[k]; s = 1.; g = gam[k]; gkk = gk[k]; c3 = 3.; }
+    else if (k == km) { b = xt2; r = 1. / xt2; s = a_bot; }
+    t[k] = b; t[n + k] = r; t[2 * n + k] = s; t[3 * n + k] = g; t[4 * n + k] = gkk; t[5 * n + k] = c3;
+  }
+}
 
 // CG = true: Riem_Solver_c on (is-1:ie+1, js-1:je+1); false: Riem_Solver3 on the compute domain
 //

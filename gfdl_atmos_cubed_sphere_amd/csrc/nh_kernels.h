@@ -1953,6 +1953,13 @@ struct RayFast {
 // the one above -- and mixes pt (and w) with it.  Sequential in k within a column (the layer that gave mass is tested next): one thread
 // per column of the compute domain marching k with delp of the next layer in a register; pt and w are touched only where the fix acts.
 // ak, bk: the context's device tables (fv3_set_ak_bk); dpmin with the reference's expression, bit for bit.
+// `.not. delp >= dpmin` (dyn_core.F90:2163 "catches NaN"): the library is compiled with -fno-honor-nans, under which !(a >= b) becomes
+// a < b and a NaN would pass (the option folds the class test v_cmp_class_f64 away as well): NaN is read off the bit pattern, an
+// integer fact the option does not touch
+FV3_HD bool mix_dp_thin(double d, double dpmin) {
+  return (fv3m_bits(d) & 0x7fffffffffffffffLL) > 0x7ff0000000000000LL || d < dpmin;
+}
+
 struct MixDp {
   Grid g;
   int hydrostatic;
@@ -1968,7 +1975,7 @@ struct MixDp {
       for (int k = 0; k < km - 1; k++) {
         const double dpmin = 0.01 * (ak[k + 1] - ak[k] + (bk[k + 1] - bk[k]) * 1.E5);
         double d1 = delp[(size_t)(k + 1) * nA + o];
-        if (!(d0 >= dpmin)) {
+        if (mix_dp_thin(d0, dpmin)) {
           const double dp = dpmin - d0;
           const size_t o0 = (size_t)k * nA + o, o1 = o0 + nA;
           pt[o0] = (pt[o0] * d0 + pt[o1] * dp) / dpmin;
@@ -1981,7 +1988,7 @@ struct MixDp {
       }
       {   // bottom (k = km): from above
         const double dpmin = 0.01 * (ak[km] - ak[km - 1] + (bk[km] - bk[km - 1]) * 1.E5);
-        if (!(d0 >= dpmin)) {
+        if (mix_dp_thin(d0, dpmin)) {
           const double dp = dpmin - d0;
           const size_t o0 = (size_t)(km - 1) * nA + o, om = o0 - nA;
           pt[o0] = (pt[o0] * d0 + pt[om] * dp) / dpmin;

@@ -28,8 +28,8 @@
 !> fv3_halo_complete with the neighbour PEs, tracer_2d's mp_reduce_max through fv3_allreduce_max (fv3_host_comm_layout).
 !>
 !> Restrictions (error stop with the reason, never a silent difference): no nesting / regional BCs;
-!> hybrid_z is not carried through this wrapper; do_diss_est (the SKEB diss_est accumulation) and consv_am (gridstruct%agrid, %l2c_u,
-!> %l2c_v, idiag%zxg) are carried on the doubly periodic domain, not on the sphere.  consv_te, tau > 0, RF_fast,
+!> hybrid_z is not carried through this wrapper; consv_am (gridstruct%agrid, %l2c_u, %l2c_v, idiag%zxg) is carried on the doubly
+!> periodic domain, not on the sphere.  do_diss_est (the SKEB diss_est accumulation), fill_dp (mix_dp), consv_te, tau > 0, RF_fast,
 !> fast_tau_w_sec and thermostruct%use_cond / moist_kappa (the reference's defaults) are carried on both domains.
 module fv3_arrays_compat_mod
   use iso_c_binding
@@ -237,12 +237,14 @@ module fv3_dyn_core_mod
   ! the cubed sphere (grid_type < 3): one context per tile this process holds (fv3_sphere_mod); the host arrays of every tile's call
   type tile_arrays
     type(c_ptr) :: u, v, w, delz, pt, delp, q, ps, pe, pk, peln, pkz, omga, ua, va, uc, vc, mfx, mfy, cx, cy, q_con = c_null_ptr
+    type(c_ptr) :: diss_est = c_null_ptr
   end type
   type(fv3_sphere), save :: sps
   type(tile_arrays), save :: tps(6)
   logical, save :: bound_s(6) = .false., comm_s = .false.
   type dc_tile_arrays
     type(c_ptr) :: u, v, w, delz, pt, delp, ws, pe, pk, peln, pkz, omga, ua, va, uc, vc, mfx, mfy, cx, cy, heat_source, q_con = c_null_ptr
+    type(c_ptr) :: diss_est = c_null_ptr
   end type
   type(fv3_sphere), save :: spd         ! dyn_core's own contexts (no tracers), as on the doubly periodic domain
   type(dc_tile_arrays), save :: tpd(6)
@@ -423,7 +425,7 @@ contains
           error stop 'dyn_core (fv3_dyn_core_mod): use_cond on the cubed sphere needs q_con(isd:ied, jsd:jed, npz), contiguous'
       end if
       if (thermostruct%moist_kappa .and. size(cappa, 3) < npz) error stop 'dyn_core (fv3_dyn_core_mod): moist_kappa needs cappa on npz levels'
-      if (flagstruct%do_diss_est .or. flagstruct%beta < 0.d0) error stop 'dyn_core (fv3_dyn_core_mod): do_diss_est / beta < 0 are not built'
+      if (flagstruct%beta < 0.d0) error stop 'dyn_core (fv3_dyn_core_mod): beta < 0 is not built on the cubed sphere'
       if (ng /= 3 .or. bd%ng /= 3) error stop 'dyn_core (fv3_dyn_core_mod): ng = 3'
       if (fv3_domain_tile(domain) < 1 .or. fv3_domain_tile(domain) > 6) error stop 'dyn_core (fv3_dyn_core_mod): fv3_domain_tile(domain) must be 1 .. 6'
       if (fv3_domain_tile_pe(domain, fv3_domain_tile(domain)) /= fv3_domain_pe(domain)) error stop 'dyn_core (fv3_dyn_core_mod): this PE does not hold fv3_domain_tile(domain)'
@@ -442,6 +444,7 @@ contains
         fl%n_split = n_split; fl%ptop = ptop; fl%grav = grav; fl%akap = akap; fl%cp_air = cp
         fl%hydrostatic = hydrostatic
         fl%use_cond = thermostruct%use_cond; fl%moist_kappa = thermostruct%moist_kappa
+        fl%do_diss_est = flagstruct%do_diss_est
         call bind_sphere_tile(spd, slot, fv3_domain_tile(domain), npx, npy, npz, 0, bd, gridstruct, flagstruct, fl, ak, bk)
         bound_d(slot) = .true.
       end if
@@ -468,8 +471,14 @@ contains
           cp_c = cappa(bd%isd:bd%ied, bd%jsd:bd%jed, 1:npz)
           call puts(a, a%cappa, c_loc(cp_c), a%nA*nk)
         end if
+        if (flagstruct%do_diss_est) then                                   ! :285 (zero on init_step), then the caller's array rides along
+          if (init_step) diss_est = 0.d0
+          call diss_est_begin(a)
+          call puts(a, a%diss_est, c_loc(diss_est), a%nA*nk)
+        end if
         call fv3_check(fv3_sync(a%ctx), 'fv3_sync')
       end associate
+      tpd(slot)%diss_est = c_loc(diss_est)
       tpd(slot)%q_con = c_null_ptr
       if (thermostruct%use_cond) tpd(slot)%q_con = c_loc(q_con)
       tpd(slot)%u = c_loc(u); tpd(slot)%v = c_loc(v); tpd(slot)%pt = c_loc(pt); tpd(slot)%delp = c_loc(delp)
@@ -509,6 +518,7 @@ contains
           call gets(a, tp%mfx, a%mfx, a%nFX*nk);   call gets(a, tp%mfy, a%mfy, a%nFY*nk)
           call gets(a, tp%cx, a%cx, a%nCX*nk);     call gets(a, tp%cy, a%cy, a%nCY*nk)
           if (flagstruct%d_con > 1.d-5) call gets(a, tp%heat_source, a%heat_source, a%nA*nk)
+          if (flagstruct%do_diss_est) call gets(a, tp%diss_est, a%diss_est, a%nA*nk)
           if (c_associated(tp%q_con)) call gets(a, tp%q_con, a%q_con, a%nA*nk)
           call fv3_check(fv3_sync(a%ctx), 'fv3_sync')
         end associate
@@ -744,8 +754,8 @@ contains
     subroutine fv_dynamics_sphere()
       type(fv3_flags) :: fl
       integer :: slot, nloc, sl
-      if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%do_diss_est .or. flagstruct%beta < 0.d0) &
-        error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / do_diss_est / beta < 0 are not built'
+      if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%beta < 0.d0) &
+        error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / beta < 0 are not built on the cubed sphere'
       if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
       if (fv3_domain_tile(domain) < 1 .or. fv3_domain_tile(domain) > 6) error stop 'fv_dynamics (fv3_dyn_core_mod): fv3_domain_tile(domain) must be 1 .. 6'
       if (bd%is /= 1 .or. bd%js /= 1 .or. bd%ie /= npx - 1 .or. bd%je /= npy - 1) &
@@ -766,6 +776,7 @@ contains
         fl%n_split = n_split; fl%q_split = q_split; fl%ptop = ptop; fl%akap = kappa; fl%cp_air = cp_air
         fl%hydrostatic = hydrostatic; fl%fill = fill; fl%r_vir = zvir
         call moist_flags_of(flagstruct, thermostruct, fl)
+        fl%do_diss_est = flagstruct%do_diss_est
         call bind_sphere_tile(sps, slot, fv3_domain_tile(domain), npx, npy, npz, nq_tot, bd, gridstruct, flagstruct, fl, ak, bk)
         bound_s(slot) = .true.
       end if
@@ -803,6 +814,7 @@ contains
           error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond on the cubed sphere needs q_con(isd:ied, jsd:jed, npz), contiguous'
         tps(slot)%q_con = c_loc(q_con)
       end if
+      tps(slot)%diss_est = c_loc(diss_est)           ! do_diss_est: zeroed at the first cycle of the call, summed over all of them
       if (slot < nloc) return                        ! the step runs in the call of the last tile this process holds
 
       if (.not. comm_s) then
@@ -832,6 +844,7 @@ contains
           call gets(at, tp%mfx, at%mfx, at%nFX*nk);   call gets(at, tp%mfy, at%mfy, at%nFY*nk)
           call gets(at, tp%cx, at%cx, at%nCX*nk);     call gets(at, tp%cy, at%cy, at%nCY*nk)
           if (c_associated(tp%q_con)) call gets(at, tp%q_con, at%q_con, at%nA*nk)
+          if (flagstruct%do_diss_est) call gets(at, tp%diss_est, at%diss_est, at%nA*nk)
           call fv3_check(fv3_sync(at%ctx), 'fv3_sync')
         end associate
       end do
@@ -895,7 +908,7 @@ contains
     integer :: t
     dom%is = bd%is; dom%ie = bd%ie; dom%js = bd%js; dom%je = bd%je; dom%ng = 3
     dom%npx = npx; dom%npy = npy; dom%npz = npz; dom%grid_type = gridstruct%grid_type
-    dom%do_diss_est = 0; dom%prevent_diss_cooling = merge(1, 0, flagstruct%prevent_diss_cooling)
+    dom%do_diss_est = merge(1, 0, flagstruct%do_diss_est); dom%prevent_diss_cooling = merge(1, 0, flagstruct%prevent_diss_cooling)
     dom%stretched_grid = merge(1, 0, gridstruct%stretched_grid); dom%lim_fac = flagstruct%lim_fac
     call grid_host_of(gridstruct, gh)
     allocate(a4(bd%isd:bd%ied, bd%jsd:bd%jed, 4), ecp(bd%isd:bd%ied, bd%jsd:bd%jed, 3, 2))

@@ -4,7 +4,8 @@
 !> sphere) or the tiles can be spread over processes (rank / nranks / face_rank: the exchange then runs between the processes).
 !> usage: fv3_solo_refsig_sphere <input file> <output file>    (raw little-endian streams; the output gets ".<rank>" appended)
 !>
-!> input : int32  npx, npz, nq, n_split, k_split, mode (bit 0: hydrostatic; bit 3: thermostruct%use_cond = moist_kappa = .true.), nord, rank, nranks, have_grid, face_rank(6)
+!> input : int32  npx, npz, nq, n_split, k_split, mode (bit 0: hydrostatic; bit 3: thermostruct%use_cond = moist_kappa = .true.; bit 4:
+!>                flagstruct%do_diss_est with prevent_diss_cooling off -- diss_est joins the output; bit 5: flagstruct%fill_dp), nord, rank, nranks, have_grid, face_rank(6)
 !>         real64 bdt, ptop, d_con, d_ext, da_min, da_min_c, d4_bg, beta, consv_te, tau, zvir
 !>         int8   comm_id(128) ; real64 ak(npz+1), bk(npz+1)
 !>         per tile (six times): the gridstruct members in the order of fv3_grid_host, then edge_w, edge_e, edge_s, edge_n, rsina,
@@ -122,6 +123,10 @@ program fv3_solo_refsig_sphere
   fl%d2_bg_k1 = 0.20d0; fl%d2_bg_k2 = 0.015d0                   ! the host modules' defaults (fv3_flags), as the Python host's DynFlags
   fl%hydrostatic = hydrostatic; fl%d_con = d_con; fl%d_ext = d_ext; fl%beta = beta; fl%a_imp = 1.d0
   fl%tau = tau; fl%moist_phys = .false.; fl%adiabatic = nq == 0 .or. zvir == 0.d0
+  if (iand(mode, 16_c_int) /= 0) then
+    fl%do_diss_est = .true.; fl%prevent_diss_cooling = .false.
+  end if
+  fl%fill_dp = iand(mode, 32_c_int) /= 0
   if (moist) then         ! the field table of the test: six water species in tracers 1 .. 6 (what FMS's tracer manager would answer)
     thermo%use_cond = .true.; thermo%moist_kappa = .true.; fl%nwat = 6; fl%adiabatic = .false.
     call fv3_register_tracer_index('sphum', 1);   call fv3_register_tracer_index('liq_wat', 2)
@@ -158,6 +163,7 @@ program fv3_solo_refsig_sphere
     write(un) st(t)%ua, st(t)%va
     write(un) st(t)%mfx, st(t)%cx
     if (moist) write(un) st(t)%qcon
+    if (fl%do_diss_est) write(un) st(t)%diss
   end do
   close(un)
   call fv_dynamics_end()

@@ -177,6 +177,7 @@ contains
     do i = 1, sp%nf
       associate (at => sp%f(i))
         if (heating) call dzero(at, at%heat_source, at%nA*npz)
+        call diss_est_begin(at)                                                         ! do_diss_est: exists (zero) from the first call on
         call dzero(at, at%mfx, at%nFX*npz); call dzero(at, at%mfy, at%nFY*npz)          ! :289-292
         call dzero(at, at%cx, at%nCX*npz);  call dzero(at, at%cy, at%nCY*npz)
       end associate
@@ -242,6 +243,7 @@ contains
                                     at%delp_n, at%pt_n, at%u_n, at%v_n, at%w_n, qcn, at%heat_s, at%diss_e), 'd_sw')  ! :762
           end if
           if (heating) call fv3_check(fv3_heat_source_accum(at%ctx, at%heat_source, at%heat_s), 'heat_source_accum')   ! :798-803
+          if (fl%do_diss_est) call fv3_check(fv3_heat_source_accum(at%ctx, at%diss_est, at%diss_e), 'diss_est += diss_e')   ! :805-811
           call inline_q_end(at)
           ! (the nonhydrostatic loop too when one_grad_p follows: beta < -0.1, :1029-1030)
           if (hyd .or. (fl%beta < -0.1d0 .and. fl%d_ext > 0.d0)) &
@@ -250,6 +252,13 @@ contains
           call swap(at%u, at%u_n); call swap(at%v, at%v_n)
           if (.not. hyd) call swap(at%w, at%w_n)
           if (fl%use_cond) call swap(at%q_con, at%q_con_n)
+          if (fl%fill_dp) then                                                            ! :820
+            if (hyd) then
+              call fv3_check(fv3_mix_dp(at%ctx, 1_c_int, c_null_ptr, at%delp, at%pt), 'mix_dp')
+            else
+              call fv3_check(fv3_mix_dp(at%ctx, 0_c_int, at%w, at%delp, at%pt), 'mix_dp')
+            end if
+          end if
         end associate
       end do
       call exchange(sp, 2, [A, A], [4, 5], [0, 0], [npz, npz])                            ! delp, pt: :823-824 / :851 (pack 1)
@@ -424,6 +433,12 @@ contains
     rp%sphum = merge(1_c_int, 0_c_int, nq > 0); rp%fill = merge(1_c_int, 0_c_int, fl%fill)
     rp%akap = fl%akap; rp%ptop = fl%ptop; rp%rdgas = fl%rdgas; rp%grav = fl%grav
     rp%cv_air = fl%cp_air - fl%rdgas; rp%r_vir = fl%r_vir; rp%cp = fl%cp_air; rp%t_min = fl%t_min
+    if (fl%do_diss_est) then      ! dyn_core zeroes diss_est on init_step = (n_map == 1): once per fv_dynamics call (:497, dyn_core.F90:285)
+      do i = 1, sp%nf
+        call diss_est_begin(sp%f(i))
+        call dzero(sp%f(i), sp%f(i)%diss_est, sp%f(i)%nA * int(sp%f(i)%npz, c_size_t))
+      end do
+    end if
     do n_map = 1, fl%k_split
       do i = 1, sp%nf
         associate (at => sp%f(i))

@@ -545,7 +545,8 @@ def build_solo_refsig_sphere(workdir, libdir=CSRC, libname="fv3_mi355x"):
 
 
 def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2, bdt=900.0, hydrostatic=False, consv_te=1.0, tau=10.0,
-                        zvir=0.6077, face_rank=(0, 0, 0, 0, 0, 0), have_grid=False, tol=0.0, what="fv_dynamics", thermo=False):
+                        zvir=0.6077, face_rank=(0, 0, 0, 0, 0, 0), have_grid=False, tol=0.0, what="fv_dynamics", thermo=False,
+                        do_diss_est=False, fill_dp=False):
     """fv_dynamics WITH THE REFERENCE'S ARGUMENT LIST on the cubed sphere (fv3_dyn_core_mod.F90: one call per tile, host arrays with the
     fv_arrays layout, gridstruct / flagstruct / bd / domain) against the Python host's whole fv_dynamics call
     (FvDynamics.step_from_temperature over the six contexts): compute_total_energy, T -> theta_v with the virtual effect, Rayleigh_Super
@@ -560,7 +561,19 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
     from gfdl_atmos_cubed_sphere_amd.dyn_core import DynFlags
     from gfdl_atmos_cubed_sphere_amd.fv_dynamics import FvDynamics
     from gfdl_atmos_cubed_sphere_amd.lib import Context
+    if do_diss_est:     # flagstruct%do_diss_est is a member of the gridstruct the contexts upload; the sphere's grids are shared: set, run, restore
+        _, gs_ = CC.sphere(npx)
+        old = [(g.do_diss_est, g.prevent_diss_cooling) for g in gs_]
+        for g in gs_:
+            g.do_diss_est, g.prevent_diss_cooling = True, False
+        try:
+            return check_refsig_sphere(lib, workdir, npx, npz, nq, n_split, k_split, bdt, hydrostatic, consv_te, tau, zvir, face_rank, have_grid, tol,
+                                       what, thermo, False, fill_dp)
+        finally:
+            for g, o in zip(gs_, old):
+                g.do_diss_est, g.prevent_diss_cooling = o
     cs, gs = CC.sphere(npx)
+    do_diss_est = bool(gs[0].do_diss_est)
     nx = npx - 1
     sig = np.linspace(0.0, 1.0, npz + 1) ** 1.5
     ak, bk = 300.0 * (1.0 - sig), sig.copy()
@@ -571,7 +584,8 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
     assert not (thermo and hydrostatic)
     if thermo and what == "fv_dynamics":
         nq = max(nq, 6)
-    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, ptop=float(ak[0]), use_cond=thermo, moist_kappa=thermo, **(dict(d_ext=0.0) if hydrostatic else {}))
+    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, ptop=float(ak[0]), use_cond=thermo, moist_kappa=thermo, fill_dp=fill_dp,
+                  **(dict(d_ext=0.0) if hydrostatic else {}))
     bd = gs[0].bd
     ng = bd.ng
     c = (slice(ng, ng + nx), slice(ng, ng + nx))
@@ -579,6 +593,17 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
         if hydrostatic:
             s_["w"] = np.zeros_like(s_["delp"])
             s_["delz"] = bd.zeros("CC", npz)
+    ak_call, bk_call = ak, bk
+    if fill_dp:     # flagstruct%fill_dp: the ak / bk dyn_core is handed have reference thicknesses in the middle of each layer's range on the
+        # sphere -- mix_dp acts on about half of the cells (the state itself keeps the levels it was built on); one dyn_core call only
+        # (fv_dynamics remaps to the levels of its ak / bk)
+        assert what == "dyn_core"
+        lo = np.min([s_["delp"][c].min(axis=(0, 1)) for s_ in st], axis=0)
+        hi = np.max([s_["delp"][c].max(axis=(0, 1)) for s_ in st], axis=0)
+        ak_call, bk_call = np.zeros(npz + 1), np.concatenate(([0.0], np.cumsum(100.0 * 0.5 * (lo + hi)))) / 1.0e5
+        ak_call[0] = 1.0          # (a positive model top)
+        dpmin = 0.01 * ((ak_call[1:] - ak_call[:-1]) + (bk_call[1:] - bk_call[:-1]) * 1.0e5)
+        assert sum(int(np.sum(s_["delp"][c] < dpmin)) for s_ in st) > 0.2 * 6 * nx * nx * npz      # mix_dp has work to do
     # what p_var (fv_grid_utils / init_case) leaves of the hydrostatic pressures: pe (is-1:ie+1, npz+1, js-1:je+1), pk, peln, pkz
     pv = []
     for s_ in st:
@@ -618,7 +643,7 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
     mctx = MultiContext([Context(g, npz, lib=lib) for g in gs])
     try:
         import parity_remap as R
-        fv = FvDynamics(mctx, fl, ak, bk, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)),
+        fv = FvDynamics(mctx, fl, ak_call, bk_call, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)),
                         consv_te=consv_te, tau=tau, adiabatic=not moist, moist_phys=False, moist=dict(R.MOIST6) if thermo else None)
         fv.remap_par["r_vir"] = zvir if moist else fv.remap_par["r_vir"]
         fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], [s_["w"] for s_ in st], [s_["delp"] for s_ in st],
@@ -646,6 +671,9 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
         if thermo:
             ref["q_con"] = d["q_con"].download()
             assert max(float(np.max(np.abs(x[c]))) for x in ref["q_con"]) > 0.0
+        if do_diss_est:
+            ref["diss_est"] = d["diss_est"].download()
+            assert max(float(np.max(np.abs(x[c]))) for x in ref["diss_est"]) > 0.0
         for n in names:
             assert all(np.all(np.isfinite(x[c])) for x in ref[n]), f"the Python host's {n} is not finite"
         assert tau <= 0.0 or fv._rf[2] > 0, "the Rayleigh damping acts on no level of this test"
@@ -663,13 +691,13 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
     for rank in range(nranks):
         fin = os.path.join(str(workdir), f"rs_in_{rank}.bin")
         with open(fin, "wb") as f:
-            np.array([npx, npz, nq, n_split, k_split, int(hydrostatic) + 8 * int(thermo), fl.nord, rank, nranks, int(have_grid)] + list(face_rank),
-                     dtype=np.int32).tofile(f)
+            np.array([npx, npz, nq, n_split, k_split, int(hydrostatic) + 8 * int(thermo) + 16 * int(do_diss_est) + 32 * int(fill_dp), fl.nord, rank,
+                      nranks, int(have_grid)] + list(face_rank), dtype=np.int32).tofile(f)
             np.array([bdt, fl.ptop, 0.0, fl.d_ext, gs[0].da_min, gs[0].da_min_c, fl.d4_bg, fl.beta, consv_te, tau, zvir if moist else 0.0],
                      dtype=np.float64).tofile(f)
             f.write(bytes(uid))
-            np.asarray(ak, dtype=np.float64).tofile(f)
-            np.asarray(bk, dtype=np.float64).tofile(f)
+            np.asarray(ak_call, dtype=np.float64).tofile(f)
+            np.asarray(bk_call, dtype=np.float64).tofile(f)
             for t in range(6):
                 m = gs[t].m
                 for grp in (_GH_A, _GH_U, _GH_V, _GH_B):
@@ -700,7 +728,8 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
         assert p.returncode == 0, o[-3000:]
     i0, i1, j0, j1 = bd.is_, bd.ie, bd.js, bd.je
     rng_ = {"u": ("U", i0, i1, j0, j1 + 1), "v": ("V", i0, i1 + 1, j0, j1), "w": ("A", i0, i1, j0, j1), "delp": ("A", i0, i1, j0, j1),
-            "pt": ("A", i0, i1, j0, j1), "ua": ("A", i0, i1, j0, j1), "va": ("A", i0, i1, j0, j1), "q_con": ("A", i0, i1, j0, j1)}
+            "pt": ("A", i0, i1, j0, j1), "ua": ("A", i0, i1, j0, j1), "va": ("A", i0, i1, j0, j1), "q_con": ("A", i0, i1, j0, j1),
+            "diss_est": ("A", i0, i1, j0, j1)}
     worst = 0.0
     for rank in range(nranks):
         with open(fout + f".{rank}", "rb") as f:
@@ -723,6 +752,9 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
                 if thermo:
                     shp = bd.shape("A", npz)
                     got["q_con"] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
+                if do_diss_est:
+                    shp = bd.shape("A", npz)
+                    got["diss_est"] = np.fromfile(f, dtype=np.float64, count=int(np.prod(shp))).reshape(shp, order="F")
                 for n in ref:
                     if n in rng_:
                         kind, *r4 = rng_[n]

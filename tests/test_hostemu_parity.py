@@ -1231,7 +1231,9 @@ def test_riem_lds_bit_identical_to_the_slab_kernels(emu, dims):
                                 dict(face_rank=(0, 0, 1, 1, 2, 2)), dict(face_rank=(0, 1, 0, 1, 0, 1), hydrostatic=True),
                                 dict(have_grid=True), dict(what="dyn_core"), dict(what="dyn_core", hydrostatic=True),
                                 dict(what="dyn_core", face_rank=(0, 0, 1, 1, 2, 2)),
-                                dict(thermo=True), dict(thermo=True, what="dyn_core"), dict(thermo=True, face_rank=(0, 0, 1, 1, 2, 2))])   # use_cond = moist_kappa = .true.
+                                dict(thermo=True), dict(thermo=True, what="dyn_core"), dict(thermo=True, face_rank=(0, 0, 1, 1, 2, 2)),   # use_cond = moist_kappa = .true.
+                                dict(do_diss_est=True), dict(do_diss_est=True, what="dyn_core", hydrostatic=True),      # flagstruct%do_diss_est: diss_est in and out
+                                dict(fill_dp=True, what="dyn_core"), dict(fill_dp=True, what="dyn_core", hydrostatic=True)])   # flagstruct%fill_dp
 def test_fortran_fv_dynamics_with_the_reference_argument_list_on_the_sphere(emu, tmp_path, kw):
     """VERDICT r3 item 6 (row a21): fv_dynamics with the REFERENCE'S argument list (model/fv_dynamics.F90:79-85) on grid_type = 0 --
     fv3_dyn_core_mod.F90 binds one context per tile held (fv3_grid_upload_cubed from gridstruct's own members, corner factors from
