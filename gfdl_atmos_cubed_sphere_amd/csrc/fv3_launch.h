@@ -152,10 +152,27 @@ inline int launch_2w(Dim3 grid, size_t lds_doubles, stream_t s, const F &f) {
 // Their k loops are chains of dependent, data-dependent loads, so what bounds them is the number of wavefronts a SIMD can
 // switch between, not lanes: with `lanes` < 64 only the first `lanes` threads of each 64-thread group take a column, which
 // multiplies the wavefronts in flight by 64 / lanes (FV3_MI355X_COL_LANES, measured best value is the default).
+// Workgroups go to the 8 XCDs in turn (linear workgroup index mod 8).  A column kernel reads its neighbours' columns (rows j - 1, j + 1
+// are six or seven 64-column workgroups away): with chunk > 0 (= workgroups per XCD) workgroup b of the first 8 chunk takes the logical
+// index (XCD of b) * chunk + b / 8, so an XCD works through one contiguous range of columns and the neighbour rows meet in its own L2
+// (FV3_MI355X_COL_XCD=0: the plain order).  `face`: the group kernels' blockIdx.y, whose workgroups continue the round-robin.
+__device__ __forceinline__ int col_block(int chunk, int face = 0) {
+  const int b = (int)blockIdx.x;
+  if (b >= chunk * 8) return b;
+  const int xcd = (b + face * (int)gridDim.x) & 7;
+  return xcd * chunk + (b >> 3);
+}
+inline int col_xcd() {
+  static const int v = [] {
+    const char *e = std::getenv("FV3_MI355X_COL_XCD");
+    return e ? std::atoi(e) : 1;
+  }();
+  return v;
+}
 template <class F>
-__global__ void __launch_bounds__(64) col_kernel(const F f, int lanes) {
+__global__ void __launch_bounds__(64) col_kernel(const F f, int lanes, int chunk) {
   if ((int)threadIdx.x >= lanes) return;
-  const int vt = (int)blockIdx.x * lanes + (int)threadIdx.x;  // virtual thread = column slot
+  const int vt = col_block(chunk) * lanes + (int)threadIdx.x;  // virtual thread = column slot
   f(vt >> 8, 0, 0, vt & 255, nullptr);
 }
 inline int col_lanes() {
@@ -169,9 +186,9 @@ inline int col_lanes() {
 // the same under a register budget of W wavefronts per SIMD (512 / W VGPRs): the column kernels wait on memory in a loop
 // that is sequential in k, so for some of them more wavefronts in flight are worth a few spilled registers
 template <class F, int W>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) col_kernel_w(const F f, int lanes) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) col_kernel_w(const F f, int lanes, int chunk) {
   if ((int)threadIdx.x >= lanes) return;
-  const int vt = (int)blockIdx.x * lanes + (int)threadIdx.x;
+  const int vt = col_block(chunk) * lanes + (int)threadIdx.x;
   f(vt >> 8, 0, 0, vt & 255, nullptr);
 }
 // lanes_req > 0: columns per wavefront of this launch (any value <= 64; the default is col_lanes())
@@ -179,10 +196,11 @@ template <int W = 0, class F>
 inline int launch_cols(Dim3 grid, stream_t s, const F &f, int lanes_req = 0) {
   const int lanes = (lanes_req > 0 && lanes_req <= 64) ? lanes_req : col_lanes();
   const unsigned nb = (unsigned)(((size_t)grid.x * 256 + lanes - 1) / lanes);
+  const int chunk = (col_xcd() && nb >= 64) ? (int)(nb >> 3) : 0;
   if constexpr (W > 0)
-    hipLaunchKernelGGL((col_kernel_w<F, W>), dim3(nb), dim3(64), 0, s, f, lanes);
+    hipLaunchKernelGGL((col_kernel_w<F, W>), dim3(nb), dim3(64), 0, s, f, lanes, chunk);
   else
-    hipLaunchKernelGGL(col_kernel<F>, dim3(nb), dim3(64), 0, s, f, lanes);
+    hipLaunchKernelGGL(col_kernel<F>, dim3(nb), dim3(64), 0, s, f, lanes, chunk);
   return (int)hipGetLastError();
 }
 // wave functors (spmd.h): independent wavefronts, 4 per workgroup, no LDS, no barriers.
@@ -274,15 +292,15 @@ __global__ void __launch_bounds__(kNT) __attribute__((amdgpu_waves_per_eu(tile_w
   fg.at(face)((int)blockIdx.y, by, (int)blockIdx.x, (int)threadIdx.x, fv3_lds);
 }
 template <class F>
-__global__ void __launch_bounds__(64) col_kernel_g(const FGroup<F> fg, int lanes) {
+__global__ void __launch_bounds__(64) col_kernel_g(const FGroup<F> fg, int lanes, int chunk) {
   if ((int)threadIdx.x >= lanes) return;
-  const int vt = (int)blockIdx.x * lanes + (int)threadIdx.x;
+  const int vt = col_block(chunk, (int)blockIdx.y) * lanes + (int)threadIdx.x;
   fg.at((int)blockIdx.y)(vt >> 8, 0, 0, vt & 255, nullptr);
 }
 template <class F, int W>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) col_kernel_w_g(const FGroup<F> fg, int lanes) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W, W))) col_kernel_w_g(const FGroup<F> fg, int lanes, int chunk) {
   if ((int)threadIdx.x >= lanes) return;
-  const int vt = (int)blockIdx.x * lanes + (int)threadIdx.x;
+  const int vt = col_block(chunk, (int)blockIdx.y) * lanes + (int)threadIdx.x;
   fg.at((int)blockIdx.y)(vt >> 8, 0, 0, vt & 255, nullptr);
 }
 template <class F>
@@ -351,10 +369,11 @@ inline int launch_group_cols(Dim3 grid, int lanes_req, stream_t s, const F *cons
   fgroup_fill(fg, fs, n);
   const int lanes = (lanes_req > 0 && lanes_req <= 64) ? lanes_req : col_lanes();
   const unsigned nb = (unsigned)(((size_t)grid.x * 256 + lanes - 1) / lanes);
+  const int chunk = (col_xcd() && nb >= 64) ? (int)(nb >> 3) : 0;
   if constexpr (W > 0)
-    hipLaunchKernelGGL((col_kernel_w_g<F, W>), dim3(nb, (unsigned)n), dim3(64), 0, s, fg, lanes);
+    hipLaunchKernelGGL((col_kernel_w_g<F, W>), dim3(nb, (unsigned)n), dim3(64), 0, s, fg, lanes, chunk);
   else
-    hipLaunchKernelGGL(col_kernel_g<F>, dim3(nb, (unsigned)n), dim3(64), 0, s, fg, lanes);
+    hipLaunchKernelGGL(col_kernel_g<F>, dim3(nb, (unsigned)n), dim3(64), 0, s, fg, lanes, chunk);
   return (int)hipGetLastError();
 }
 inline int rt_malloc(void **p, size_t n) { return (int)hipMalloc(p, n); }
