@@ -21,14 +21,17 @@ struct CubedGeom {
   int ready;
 };
 
-// A pass = functor f(i, j, k) over the box [i0, i1] x [j0, j1] x [0, nk): 64 x 4 points per workgroup, i fastest.
+// A pass = functor f(i, j, k) over the box [i0, i1] x [j0, j1] x [0, nk): 64 x `rows` points per workgroup, i fastest; a thread takes
+// rows / 4 points (rows = 16: a quarter of the workgroups, the loads of a thread's four points in flight together, one halo row in 17
+// instead of one in 5)
 template <class F>
 struct BoxPass {
   int i0, i1, j0, j1;
   F f;
+  int rows = 4;
   FV3_HD void operator()(int bx, int by, int bz, int tid, double *) const {
-    for (int t = tid; t < 256; t += kNT) {
-      const int i = i0 + bx * 64 + (t & 63), j = j0 + by * 4 + (t >> 6);
+    for (int t = tid; t < 64 * rows; t += kNT) {
+      const int i = i0 + bx * 64 + (t & 63), j = j0 + by * rows + (t >> 6);
       if (i <= i1 && j <= j1) f(i, j, bz);
     }
   }

@@ -1131,11 +1131,17 @@ struct Tp2dKernel {
 template <class F>
 static int launch_box(fv3_ctx *c, const char *label, int i0, int i1, int j0, int j1, int nk, const F &f) {
   if (i1 < i0 || j1 < j0 || nk <= 0) return 0;
+  static const int rows_env = [] {
+    const char *e = std::getenv("FV3_MI355X_BOX_ROWS");
+    const int n = e ? std::atoi(e) : 16;
+    return (n == 4 || n == 8 || n == 16) ? n : 16;
+  }();
+  const int rows = (j1 - j0 + 1 >= 64) ? rows_env : 4;
   Dim3 grid;
   grid.x = (unsigned)((i1 - i0 + 64) / 64);
-  grid.y = (unsigned)((j1 - j0 + 4) / 4);
+  grid.y = (unsigned)((j1 - j0 + rows) / rows);
   grid.z = (unsigned)nk;
-  return launch_p(c, label, grid, 0, BoxPass<F>{i0, i1, j0, j1, f});
+  return launch_p(c, label, grid, 0, BoxPass<F>{i0, i1, j0, j1, f, rows});
 }
 // where a pass runs: the whole box (w = 0) or only the frame of width w along the face edges; all levels (klist = null, nk
 // levels) or the nk levels of a device list
