@@ -28,9 +28,9 @@
 !> fv3_halo_complete with the neighbour PEs, tracer_2d's mp_reduce_max through fv3_allreduce_max (fv3_host_comm_layout).
 !>
 !> Restrictions (error stop with the reason, never a silent difference): no nesting / regional BCs;
-!> hybrid_z is not carried through this wrapper; consv_am (gridstruct%agrid, %l2c_u, %l2c_v, idiag%zxg) is carried on the doubly
-!> periodic domain, not on the sphere.  do_diss_est (the SKEB diss_est accumulation), fill_dp (mix_dp), consv_te, tau > 0, RF_fast,
-!> fast_tau_w_sec and thermostruct%use_cond / moist_kappa (the reference's defaults) are carried on both domains.
+!> hybrid_z is not carried through this wrapper, beta < 0 not on the sphere.  consv_am (gridstruct%agrid, %l2c_u, %l2c_v, idiag%zxg),
+!> do_diss_est (the SKEB diss_est accumulation), fill_dp (mix_dp), consv_te, tau > 0, RF_fast, fast_tau_w_sec and
+!> thermostruct%use_cond / moist_kappa (the reference's defaults) are carried on both domains.
 module fv3_arrays_compat_mod
   use iso_c_binding
   implicit none
@@ -689,7 +689,7 @@ contains
     ! :284-399 T -> theta_v, :345 compute_total_energy, :362-375 Rayleigh_Friction, the k_split loop :460-665 with the energy fixer of
     ! its last remap, cubed_to_latlon :911
     atf%fl%adiabatic = flagstruct%adiabatic .or. zvir == 0.d0 .or. nq_tot == 0
-    if (flagstruct%consv_am .and. .not. atf%consv_am) call bind_consv_am()
+    if (flagstruct%consv_am .and. .not. atf%consv_am) call bind_consv_am(atf)
     call fv3_fv_dynamics_call(atf, bdt, consv_te, merge(0.d0, flagstruct%tau, flagstruct%RF_fast), flagstruct%rf_cutoff, zvir, flagstruct%c2l_ord, flagstruct%moist_phys, &
                               6.3712d6)
 
@@ -734,14 +734,17 @@ contains
 
     !> flagstruct%consv_am: cos(agrid(:,:,2)), l2c_u / l2c_v (padded with zeros to the halo'd U / V shapes the kernels index) and
     !> idiag%zxg go to the resident loop once (fv_dynamics.F90:358-361, :747-800, :1266-1314)
-    subroutine bind_consv_am()
+    subroutine bind_consv_am(a)
+      type(fv3_atmos), intent(inout) :: a
       real(c_double), allocatable, target :: cl(:,:), lu(:,:), lv(:,:)
       allocate(cl(bd%isd:bd%ied, bd%jsd:bd%jed), lu(bd%isd:bd%ied, bd%jsd:bd%jed+1), lv(bd%isd:bd%ied+1, bd%jsd:bd%jed))
       cl = cos(gridstruct%agrid(bd%isd:bd%ied, bd%jsd:bd%jed, 2))
       lu = 0.d0; lv = 0.d0
       lu(bd%is:bd%ie, bd%js:bd%je+1) = gridstruct%l2c_u
       lv(bd%is:bd%ie+1, bd%js:bd%je) = gridstruct%l2c_v
-      call fv3_host_set_consv_am(atf, cl, lu, lv, idiag%zxg)
+      if (.not. allocated(gridstruct%agrid) .or. .not. allocated(gridstruct%l2c_u) .or. .not. allocated(gridstruct%l2c_v) .or. &
+          .not. allocated(idiag%zxg)) error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am reads gridstruct%agrid, %l2c_u, %l2c_v and idiag%zxg'
+      call fv3_host_set_consv_am(a, cl, lu, lv, idiag%zxg)
     end subroutine
 
     !> grid_type < 3: a tile of the cubed sphere.  The reference calls fv_dynamics once per tile a PE holds -- with one tile per PE
@@ -754,8 +757,7 @@ contains
     subroutine fv_dynamics_sphere()
       type(fv3_flags) :: fl
       integer :: slot, nloc, sl
-      if (flagstruct%consv_am .or. hybrid_z .or. flagstruct%beta < 0.d0) &
-        error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am / hybrid_z / beta < 0 are not built on the cubed sphere'
+      if (hybrid_z .or. flagstruct%beta < 0.d0) error stop 'fv_dynamics (fv3_dyn_core_mod): hybrid_z / beta < 0 are not built on the cubed sphere'
       if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
       if (fv3_domain_tile(domain) < 1 .or. fv3_domain_tile(domain) > 6) error stop 'fv_dynamics (fv3_dyn_core_mod): fv3_domain_tile(domain) must be 1 .. 6'
       if (bd%is /= 1 .or. bd%js /= 1 .or. bd%ie /= npx - 1 .or. bd%je /= npy - 1) &
@@ -780,6 +782,7 @@ contains
         call bind_sphere_tile(sps, slot, fv3_domain_tile(domain), npx, npy, npz, nq_tot, bd, gridstruct, flagstruct, fl, ak, bk)
         bound_s(slot) = .true.
       end if
+      if (flagstruct%consv_am .and. .not. sps%f(slot)%consv_am) call bind_consv_am(sps%f(slot))   ! this tile's coslat, l2c_u, l2c_v, zxg
       associate (at => sps%f(slot))
         if (at%npz /= npz .or. at%nq /= nq_tot .or. at%ie /= bd%ie .or. at%je /= bd%je) &
           error stop 'fv_dynamics (fv3_dyn_core_mod): the domain changed between calls'

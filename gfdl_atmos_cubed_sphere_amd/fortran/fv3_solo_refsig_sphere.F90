@@ -5,7 +5,8 @@
 !> usage: fv3_solo_refsig_sphere <input file> <output file>    (raw little-endian streams; the output gets ".<rank>" appended)
 !>
 !> input : int32  npx, npz, nq, n_split, k_split, mode (bit 0: hydrostatic; bit 3: thermostruct%use_cond = moist_kappa = .true.; bit 4:
-!>                flagstruct%do_diss_est with prevent_diss_cooling off -- diss_est joins the output; bit 5: flagstruct%fill_dp), nord, rank, nranks, have_grid, face_rank(6)
+!>                flagstruct%do_diss_est with prevent_diss_cooling off -- diss_est joins the output; bit 5: flagstruct%fill_dp; bit 6:
+!>                flagstruct%consv_am -- needs have_grid (agrid); l2c_u, l2c_v, zxg of every tile follow its pe .. pkz), nord, rank, nranks, have_grid, face_rank(6)
 !>         real64 bdt, ptop, d_con, d_ext, da_min, da_min_c, d4_bg, beta, consv_te, tau, zvir
 !>         int8   comm_id(128) ; real64 ak(npz+1), bk(npz+1)
 !>         per tile (six times): the gridstruct members in the order of fv3_grid_host, then edge_w, edge_e, edge_s, edge_n, rsina,
@@ -39,7 +40,7 @@ program fv3_solo_refsig_sphere
   type(fv_flags_type) :: fl
   type(fv_nest_type) :: nest
   type(fv_thermo_type) :: thermo
-  type(fv_diag_type) :: idiag
+  type(fv_diag_type) :: idiag, idg(6)
   type(domain2d) :: dom
   type(fv_atmos_type), pointer :: parent => null()
   type(inline_mp_type) :: imp
@@ -113,6 +114,10 @@ program fv3_solo_refsig_sphere
       allocate(s%heat(isd:ied, isd:ied, npz), s%diss(isd:ied, isd:ied, npz))
       read(un) s%pe, s%pk, s%peln, s%pkz              ! what p_var left (fv_arrays layout); zeros in a nonhydrostatic test
       if (moist .and. trim(what) == 'dyn_core') read(un) s%qcon, s%cappa    ! dyn_core is handed both (fv_dynamics forms them: moist_cv)
+      if (iand(mode, 64_c_int) /= 0) then                                   ! consv_am: gridstruct%l2c_u / l2c_v, idiag%zxg (fv_arrays.F90:60, :112)
+        allocate(g%l2c_u(nx, nx+1), g%l2c_v(nx+1, nx), idg(t)%zxg(nx, nx))
+        read(un) g%l2c_u, g%l2c_v, idg(t)%zxg
+      end if
       s%ps = 0.d0; s%omga = 0.d0; s%ua = 0.d0; s%va = 0.d0
       s%uc = 0.d0; s%vc = 0.d0; s%mfx = 0.d0; s%mfy = 0.d0; s%cx = 0.d0; s%cy = 0.d0; s%heat = 0.d0; s%diss = 0.d0
     end associate
@@ -127,6 +132,7 @@ program fv3_solo_refsig_sphere
     fl%do_diss_est = .true.; fl%prevent_diss_cooling = .false.
   end if
   fl%fill_dp = iand(mode, 32_c_int) /= 0
+  fl%consv_am = iand(mode, 64_c_int) /= 0
   if (moist) then         ! the field table of the test: six water species in tracers 1 .. 6 (what FMS's tracer manager would answer)
     thermo%use_cond = .true.; thermo%moist_kappa = .true.; fl%nwat = 6; fl%adiabatic = .false.
     call fv3_register_tracer_index('sphum', 1);   call fv3_register_tracer_index('liq_wat', 2)
@@ -151,7 +157,7 @@ program fv3_solo_refsig_sphere
       call fv_dynamics(int(npx), int(npx), int(npz), int(nq), 3, bdt, consv_te, .false., .true., 2.d0/7.d0, 287.04d0/(2.d0/7.d0), zvir, &
                        ptop, 0, max(1, int(nq)), int(n_split), 0, s%u, s%v, s%u, s%v, s%w, s%delz, hydrostatic, s%pt, s%delp, s%q, &
                        s%ps, s%pe, s%pk, s%peln, s%pkz, s%phis, s%qcon, s%omga, s%ua, s%va, s%uc, s%vc, ak, bk, s%mfx, s%mfy, &
-                       s%cx, s%cy, s%ze0, .false., gs(t), fl, nest, thermo, idiag, bd, parent, dom, imp, s%heat, s%diss)
+                       s%cx, s%cy, s%ze0, .false., gs(t), fl, nest, thermo, idg(t), bd, parent, dom, imp, s%heat, s%diss)
     end associate
   end do
   write(sfx, '(a,i0)') '.', rank

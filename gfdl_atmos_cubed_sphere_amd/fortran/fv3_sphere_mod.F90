@@ -524,6 +524,7 @@ contains
                                                   at%delp, at%q, c_null_ptr, pep, pelnp, at%phis, sp%te0(i)), 'compute_total_energy')
       end associate
     end do
+    if (sp%f(1)%consv_am) call aam(.true.)                    ! :358-361: teq, ps2 of the state the step starts from
     if (tau > 0.d0) then
       if (sp%kmax < 0) call rayleigh_profile(sp, abs(bdt), tau, rf_cutoff)
       if (.not. hyd) call to_theta(-1)                      ! pkz from T and delz before the damping (:323-326)
@@ -580,12 +581,69 @@ contains
     else
       call fv3_sphere_fv_dynamics(sp, bdt, .true., nranks)
     end if
+    if (sp%f(1)%consv_am) call consv_am_correct()            ! :747-800
     if (c2l_ord == 4) call exchange(sp, 1, [FV3_CUBE_D + 0], [1], [2], [npz])                  ! fv_grid_utils.F90:2372-2376
     do i = 1, sp%nf
       call fv3_check(fv3_c2l(sp%f(i)%ctx, int(c2l_ord, c_int), sp%f(i)%u, sp%f(i)%v, sp%f(i)%ua, sp%f(i)%va), 'c2l')   ! :911
     end do
 
   contains
+
+    !> compute_aam (fv_dynamics.F90:1266-1314) of every face: cubed_to_latlon (mode 1, c2l_ord 2: no halo update), then aam, m_fac, ps
+    !> of every column; first: into teq / ps2 (the state the step starts from), else into the work array / ps
+    subroutine aam(first)
+      logical, intent(in) :: first
+      integer :: ii
+      type(c_ptr) :: aam_d, ps_d
+      do ii = 1, sp%nf
+        associate (at => sp%f(ii))
+          aam_d = at%am_aam; ps_d = at%ps
+          if (first) then
+            aam_d = at%am_teq; ps_d = at%am_ps2
+          end if
+          call fv3_check(fv3_c2l(at%ctx, 2_c_int, at%u, at%v, at%ua, at%va), 'c2l (compute_aam)')          ! :1287
+          call fv3_check(fv3_compute_aam(at%ctx, radius, at%am_omega, 1.d0 / fl%grav, fl%ptop, at%am_coslat, at%ua, at%delp, &
+                                         aam_d, at%am_mfac, ps_d), 'compute_aam')
+        end associate
+      end do
+    end subroutine
+
+    !> :747-800: te_2d = aam - teq + dt2 (ps2 + ps) zxg on every face, the two reproducing global sums over the faces (and ranks), u00,
+    !> u += u00 l2c_u, v += u00 l2c_v
+    subroutine consv_am_correct()
+      real(c_double), allocatable, target :: te(:,:), teq(:,:), ps2(:,:), ps1(:,:), te2(:,:)
+      type(c_ptr) :: cols(6)
+      real(c_double) :: amdt, u00
+      integer :: ii
+      call aam(.false.)
+      cols = c_null_ptr
+      do ii = 1, sp%nf
+        associate (at => sp%f(ii))
+          allocate(te(at%nx, at%ny), teq(at%nx, at%ny), te2(at%nx, at%ny))
+          allocate(ps2(at%isd:at%ied, at%jsd:at%jed), ps1(at%isd:at%ied, at%jsd:at%jed))
+          call fv3_check(fv3_memcpy_d2h(at%ctx, c_loc(te), at%am_aam, at%nCC * 8_c_size_t), 'd2h')
+          call fv3_check(fv3_memcpy_d2h(at%ctx, c_loc(teq), at%am_teq, at%nCC * 8_c_size_t), 'd2h')
+          call fv3_check(fv3_memcpy_d2h(at%ctx, c_loc(ps2), at%am_ps2, at%nA * 8_c_size_t), 'd2h')
+          call fv3_check(fv3_memcpy_d2h(at%ctx, c_loc(ps1), at%ps, at%nA * 8_c_size_t), 'd2h')
+          call fv3_check(fv3_sync(at%ctx), 'sync')
+          te2 = te - teq + (0.5d0 * bdt) * (ps2(at%is:at%ie, at%js:at%je) + ps1(at%is:at%ie, at%js:at%je)) * at%am_zxg    ! :761-767
+          call fv3_check(fv3_memcpy_h2d(at%ctx, at%am_aam, c_loc(te2), at%nCC * 8_c_size_t), 'h2d')
+          call fv3_check(fv3_sync(at%ctx), 'sync')
+          deallocate(te, teq, te2, ps2, ps1)
+          cols(ii) = at%am_aam
+        end associate
+      end do
+      amdt = g_sum(cols)                                                                                                   ! :771
+      do ii = 1, sp%nf
+        cols(ii) = sp%f(ii)%am_mfac
+      end do
+      u00 = -radius * amdt / g_sum(cols)                                                                                   ! :772
+      do ii = 1, sp%nf
+        sp%f(ii)%u00 = u00
+        call fv3_check(fv3_consv_am_apply(sp%f(ii)%ctx, u00, sp%f(ii)%am_l2c_u, sp%f(ii)%am_l2c_v, sp%f(ii)%u, sp%f(ii)%v), &
+                       'consv_am_apply')                                                                                   ! :784-798
+      end do
+    end subroutine
 
     subroutine to_theta(m)
       integer, intent(in) :: m

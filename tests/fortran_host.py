@@ -546,7 +546,7 @@ def build_solo_refsig_sphere(workdir, libdir=CSRC, libname="fv3_mi355x"):
 
 def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2, bdt=900.0, hydrostatic=False, consv_te=1.0, tau=10.0,
                         zvir=0.6077, face_rank=(0, 0, 0, 0, 0, 0), have_grid=False, tol=0.0, what="fv_dynamics", thermo=False,
-                        do_diss_est=False, fill_dp=False):
+                        do_diss_est=False, fill_dp=False, consv_am=False):
     """fv_dynamics WITH THE REFERENCE'S ARGUMENT LIST on the cubed sphere (fv3_dyn_core_mod.F90: one call per tile, host arrays with the
     fv_arrays layout, gridstruct / flagstruct / bd / domain) against the Python host's whole fv_dynamics call
     (FvDynamics.step_from_temperature over the six contexts): compute_total_energy, T -> theta_v with the virtual effect, Rayleigh_Super
@@ -568,7 +568,7 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
             g.do_diss_est, g.prevent_diss_cooling = True, False
         try:
             return check_refsig_sphere(lib, workdir, npx, npz, nq, n_split, k_split, bdt, hydrostatic, consv_te, tau, zvir, face_rank, have_grid, tol,
-                                       what, thermo, False, fill_dp)
+                                       what, thermo, False, fill_dp, consv_am)
         finally:
             for g, o in zip(gs_, old):
                 g.do_diss_est, g.prevent_diss_cooling = o
@@ -626,6 +626,17 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
             s_["pt"][c] = s_["pt"][c] / pkz
             if not hydrostatic:
                 p_["pkz"] = np.asfortranarray(pkz)
+    ca = None
+    if consv_am:    # flagstruct%consv_am (fv_dynamics.F90:358-361, :747-800): the tiles' own latitudes (gridstruct%agrid: have_grid), made-up
+        # l2c_u / l2c_v (the reference's are projections of the east vector; any field exercises the correction) and mountain torque zxg
+        assert have_grid and what == "fv_dynamics"
+        rng = np.random.default_rng(77)
+        ca = dict(coslat=[np.asfortranarray(np.cos(g.m["agrid"][:, :, 1])) for g in gs],
+                  l2c_u=[bd.zeros("U") for _ in range(6)], l2c_v=[bd.zeros("V") for _ in range(6)],
+                  zxg=[np.asfortranarray(1.0e-3 * rng.uniform(-1, 1, (nx, nx))) for _ in range(6)])
+        for t in range(6):
+            ca["l2c_u"][t][ng:ng + nx, ng:ng + nx + 1] = rng.uniform(0.2, 1.0, (nx, nx + 1))
+            ca["l2c_v"][t][ng:ng + nx + 1, ng:ng + nx] = rng.uniform(-0.5, 0.5, (nx + 1, nx))
     q = PC.tracer_fields(cs, npz, nq) if nq else None
     if nq:                                  # the first tracer is the specific humidity of the virtual effect: small and positive
         for t in range(6):
@@ -644,7 +655,8 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
     try:
         import parity_remap as R
         fv = FvDynamics(mctx, fl, ak_call, bk_call, nq=nq, k_split=k_split, halo=CubeHaloAdapter(mctx, npx, topo=CC.product_topo(npx)),
-                        consv_te=consv_te, tau=tau, adiabatic=not moist, moist_phys=False, moist=dict(R.MOIST6) if thermo else None)
+                        consv_te=consv_te, tau=tau, adiabatic=not moist, moist_phys=False, moist=dict(R.MOIST6) if thermo else None,
+                        consv_am=ca)
         fv.remap_par["r_vir"] = zvir if moist else fv.remap_par["r_vir"]
         fv.dc.set_state([s_["u"] for s_ in st], [s_["v"] for s_ in st], [s_["w"] for s_ in st], [s_["delp"] for s_ in st],
                         [s_["pt"] for s_ in st], [s_["delz"] for s_ in st], [s_["phis"] for s_ in st])
@@ -674,6 +686,8 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
         if do_diss_est:
             ref["diss_est"] = d["diss_est"].download()
             assert max(float(np.max(np.abs(x[c]))) for x in ref["diss_est"]) > 0.0
+        if consv_am:
+            assert abs(fv.last_u00) > 1e-8, fv.last_u00           # the correction is in the run
         for n in names:
             assert all(np.all(np.isfinite(x[c])) for x in ref[n]), f"the Python host's {n} is not finite"
         assert tau <= 0.0 or fv._rf[2] > 0, "the Rayleigh damping acts on no level of this test"
@@ -691,7 +705,7 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
     for rank in range(nranks):
         fin = os.path.join(str(workdir), f"rs_in_{rank}.bin")
         with open(fin, "wb") as f:
-            np.array([npx, npz, nq, n_split, k_split, int(hydrostatic) + 8 * int(thermo) + 16 * int(do_diss_est) + 32 * int(fill_dp), fl.nord, rank,
+            np.array([npx, npz, nq, n_split, k_split, int(hydrostatic) + 8 * int(thermo) + 16 * int(do_diss_est) + 32 * int(fill_dp) + 64 * int(consv_am), fl.nord, rank,
                       nranks, int(have_grid)] + list(face_rank), dtype=np.int32).tofile(f)
             np.array([bdt, fl.ptop, 0.0, fl.d_ext, gs[0].da_min, gs[0].da_min_c, fl.d4_bg, fl.beta, consv_te, tau, zvir if moist else 0.0],
                      dtype=np.float64).tofile(f)
@@ -720,6 +734,9 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
                     F(pv[t][n]).tofile(f)
                 if thermo and what == "dyn_core":
                     F(qc_in[t]).tofile(f); F(cp_in[t]).tofile(f)
+                if consv_am:
+                    F(ca["l2c_u"][t][ng:ng + nx, ng:ng + nx + 1]).tofile(f); F(ca["l2c_v"][t][ng:ng + nx + 1, ng:ng + nx]).tofile(f)
+                    F(ca["zxg"][t]).tofile(f)
         procs.append(subprocess.Popen([exe, fin, fout, what], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
