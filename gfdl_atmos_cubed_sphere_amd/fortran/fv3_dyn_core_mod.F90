@@ -28,7 +28,7 @@
 !> fv3_halo_complete with the neighbour PEs, tracer_2d's mp_reduce_max through fv3_allreduce_max (fv3_host_comm_layout).
 !>
 !> Restrictions (error stop with the reason, never a silent difference): no nesting / regional BCs;
-!> hybrid_z is not carried through this wrapper, beta < 0 not on the sphere.  consv_am (gridstruct%agrid, %l2c_u, %l2c_v, idiag%zxg),
+!> hybrid_z is not carried through this wrapper; beta < 0 only as beta < -0.1 in a nonhydrostatic run.  consv_am (gridstruct%agrid, %l2c_u, %l2c_v, idiag%zxg),
 !> do_diss_est (the SKEB diss_est accumulation), fill_dp (mix_dp), consv_te, tau > 0, RF_fast, fast_tau_w_sec and
 !> thermostruct%use_cond / moist_kappa (the reference's defaults) are carried on both domains.
 module fv3_arrays_compat_mod
@@ -309,8 +309,8 @@ contains
     if (moist .and. hydrostatic) error stop 'dyn_core (fv3_dyn_core_mod): use_cond / moist_kappa are nonhydrostatic branches'
     if (thermostruct%use_cond .and. size(q_con, 3) < npz) error stop 'dyn_core (fv3_dyn_core_mod): use_cond needs q_con on npz levels'
     if (thermostruct%moist_kappa .and. size(cappa, 3) < npz) error stop 'dyn_core (fv3_dyn_core_mod): moist_kappa needs cappa on npz levels'
-    if (flagstruct%beta < 0.d0 .and. (hydrostatic .or. flagstruct%beta >= -0.1d0 .or. gridstruct%grid_type < 3)) &
-      error stop 'dyn_core (fv3_dyn_core_mod): beta < 0: one_grad_p (beta < -0.1) is built for the nonhydrostatic loop of the doubly periodic domain'
+    if (flagstruct%beta < 0.d0 .and. (hydrostatic .or. flagstruct%beta >= -0.1d0)) &
+      error stop 'dyn_core (fv3_dyn_core_mod): beta < 0: one_grad_p (beta < -0.1) is built for the nonhydrostatic loop'
     if (ng /= 3 .or. bd%ng /= 3) error stop 'dyn_core (fv3_dyn_core_mod): ng = 3'
     if (.not. bound) then
       call bind_context()
@@ -425,7 +425,6 @@ contains
           error stop 'dyn_core (fv3_dyn_core_mod): use_cond on the cubed sphere needs q_con(isd:ied, jsd:jed, npz), contiguous'
       end if
       if (thermostruct%moist_kappa .and. size(cappa, 3) < npz) error stop 'dyn_core (fv3_dyn_core_mod): moist_kappa needs cappa on npz levels'
-      if (flagstruct%beta < 0.d0) error stop 'dyn_core (fv3_dyn_core_mod): beta < 0 is not built on the cubed sphere'
       if (ng /= 3 .or. bd%ng /= 3) error stop 'dyn_core (fv3_dyn_core_mod): ng = 3'
       if (fv3_domain_tile(domain) < 1 .or. fv3_domain_tile(domain) > 6) error stop 'dyn_core (fv3_dyn_core_mod): fv3_domain_tile(domain) must be 1 .. 6'
       if (fv3_domain_tile_pe(domain, fv3_domain_tile(domain)) /= fv3_domain_pe(domain)) error stop 'dyn_core (fv3_dyn_core_mod): this PE does not hold fv3_domain_tile(domain)'
@@ -654,7 +653,9 @@ contains
     if (thermostruct%use_cond .and. (size(q_con, 1) /= bd%ied - bd%isd + 1 .or. size(q_con, 3) < npz)) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond needs q_con(isd:ied, jsd:jed, npz)'
     if (gridstruct%grid_type /= 4) error stop 'fv_dynamics (fv3_dyn_core_mod): grid_type = 3 is not built'
-    if (hybrid_z .or. flagstruct%beta < 0.d0) error stop 'fv_dynamics (fv3_dyn_core_mod): hybrid_z / beta < 0 are not built'
+    if (hybrid_z) error stop 'fv_dynamics (fv3_dyn_core_mod): hybrid_z is not built'
+    if (flagstruct%beta < 0.d0 .and. (hydrostatic .or. flagstruct%beta >= -0.1d0)) &
+      error stop 'fv_dynamics (fv3_dyn_core_mod): beta < 0: one_grad_p (beta < -0.1) is built for the nonhydrostatic loop'
     if (flagstruct%consv_am .and. .not. (allocated(gridstruct%agrid) .and. allocated(gridstruct%l2c_u) .and. allocated(gridstruct%l2c_v) &
                                          .and. allocated(idiag%zxg))) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): consv_am needs gridstruct%agrid, %l2c_u, %l2c_v and idiag%zxg'
@@ -757,7 +758,7 @@ contains
     subroutine fv_dynamics_sphere()
       type(fv3_flags) :: fl
       integer :: slot, nloc, sl
-      if (hybrid_z .or. flagstruct%beta < 0.d0) error stop 'fv_dynamics (fv3_dyn_core_mod): hybrid_z / beta < 0 are not built on the cubed sphere'
+      if (hybrid_z) error stop 'fv_dynamics (fv3_dyn_core_mod): hybrid_z is not built'
       if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
       if (fv3_domain_tile(domain) < 1 .or. fv3_domain_tile(domain) > 6) error stop 'fv_dynamics (fv3_dyn_core_mod): fv3_domain_tile(domain) must be 1 .. 6'
       if (bd%is /= 1 .or. bd%js /= 1 .or. bd%ie /= npx - 1 .or. bd%je /= npy - 1) &

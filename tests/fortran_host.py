@@ -340,7 +340,7 @@ def _compare_blocks(res, ref, bd, what, tol=None):
 
 
 def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, hydrostatic=False, layout=(1, 1),
-                              consv_te=0.0, tau=0.0, moist=False, do_diss_est=False, consv_am=False):
+                              consv_te=0.0, tau=0.0, moist=False, do_diss_est=False, consv_am=False, beta=0.0):
     """fv_dynamics called with the reference's argument list on host arrays (fv3_dyn_core_mod::fv_dynamics, driver fv3_solo_refsig in
     its fv_dynamics mode: T -> theta_v, k_split x (dyn_core, tracer_2d, remap), last_step, cubed_to_latlon) against the Python host's
     FvDynamics.step_from_temperature on the same state: u, v, w, delp, pt (T), delz, the tracers and ua bit-identical"""
@@ -367,7 +367,7 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
         assert nq >= 6 and not hydrostatic
         q[..., :6] *= 1.0e-3                       # small mixing ratios
         mo = dict(use_cond=True, moist_kappa=True, q_con=bd.zeros("A", npz), cappa=bd.zeros("A", npz))   # fv_dynamics forms both itself
-    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, use_cond=moist, moist_kappa=moist)
+    fl = DynFlags(n_split=n_split, ptop=N.PTOP, hydrostatic=hydrostatic, use_cond=moist, moist_kappa=moist, beta=beta)
     ca = None
     if consv_am:   # flagstruct%consv_am with a made-up grid (parity_dyn.check_fv_cycle_from_temperature): latitudes, l2c_u / l2c_v (zero outside
                    # the compute domain, as the reference's members end there) and zxg of no sphere
@@ -403,7 +403,7 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
     exe = build_refsig(workdir, libdir=os.path.dirname(lib.path), libname=os.path.basename(lib.path)[3:-3])
     fin, fout = os.path.join(str(workdir), "in_fd.bin"), os.path.join(str(workdir), "out_fd.bin")
     write_input(fin, bd, npz, nq, n_split, k_split, nsteps, True, 1000.0, 1000.0, float(g.m["f0"][0, 0]), bdt, N.PTOP, ak, bk, st, q,
-                hydrostatic=hydrostatic, d_con=0.0, d_ext=fl.d_ext, moist=mo, consv_am=ca)
+                hydrostatic=hydrostatic, d_con=0.0, d_ext=fl.d_ext, beta=beta, moist=mo, consv_am=ca)
     spec = [(n, k, ()) for n, k in (("u", "U"), ("v", "V"), ("w", "A"), ("delp", "A"), ("pt", "A"), ("delz", "CC"))]
     if nq:
         spec.append(("q", "A", (nq,)))
@@ -546,7 +546,7 @@ def build_solo_refsig_sphere(workdir, libdir=CSRC, libname="fv3_mi355x"):
 
 def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2, bdt=900.0, hydrostatic=False, consv_te=1.0, tau=10.0,
                         zvir=0.6077, face_rank=(0, 0, 0, 0, 0, 0), have_grid=False, tol=0.0, what="fv_dynamics", thermo=False,
-                        do_diss_est=False, fill_dp=False, consv_am=False):
+                        do_diss_est=False, fill_dp=False, consv_am=False, beta=0.0):
     """fv_dynamics WITH THE REFERENCE'S ARGUMENT LIST on the cubed sphere (fv3_dyn_core_mod.F90: one call per tile, host arrays with the
     fv_arrays layout, gridstruct / flagstruct / bd / domain) against the Python host's whole fv_dynamics call
     (FvDynamics.step_from_temperature over the six contexts): compute_total_energy, T -> theta_v with the virtual effect, Rayleigh_Super
@@ -568,7 +568,7 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
             g.do_diss_est, g.prevent_diss_cooling = True, False
         try:
             return check_refsig_sphere(lib, workdir, npx, npz, nq, n_split, k_split, bdt, hydrostatic, consv_te, tau, zvir, face_rank, have_grid, tol,
-                                       what, thermo, False, fill_dp, consv_am)
+                                       what, thermo, False, fill_dp, consv_am, beta)
         finally:
             for g, o in zip(gs_, old):
                 g.do_diss_est, g.prevent_diss_cooling = o
@@ -584,7 +584,7 @@ def check_refsig_sphere(lib, workdir, npx=13, npz=20, nq=2, n_split=2, k_split=2
     assert not (thermo and hydrostatic)
     if thermo and what == "fv_dynamics":
         nq = max(nq, 6)
-    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, ptop=float(ak[0]), use_cond=thermo, moist_kappa=thermo, fill_dp=fill_dp,
+    fl = DynFlags(n_split=n_split, hydrostatic=hydrostatic, ptop=float(ak[0]), use_cond=thermo, moist_kappa=thermo, fill_dp=fill_dp, beta=beta,
                   **(dict(d_ext=0.0) if hydrostatic else {}))
     bd = gs[0].bd
     ng = bd.ng

@@ -735,6 +735,7 @@ def test_fortran_dyn_core_with_the_reference_argument_list(prod, tmp_path):
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, nq=6, moist=True, consv_te=1.0, npz=10)
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, nq=1, do_diss_est=True)     # diss_est out of fv_dynamics
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, nq=0, consv_am=True)        # flagstruct%consv_am
+    assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, nq=1, beta=-1.0)             # one_grad_p in the nonhydrostatic loop (beta < -0.1)
 
 
 @pytest.mark.parametrize("use_cond,moist_kappa", [(True, False), (True, True), (False, True)])
@@ -1324,7 +1325,8 @@ def test_riem_lds_bit_identical_to_the_slab_kernels(prod, km):
 
 @pytest.mark.parametrize("kw", [dict(), dict(hydrostatic=True, nq=0), dict(have_grid=True, consv_te=-2.0, tau=0.0), dict(what="dyn_core"),
                                 dict(thermo=True), dict(thermo=True, what="dyn_core"),       # use_cond = moist_kappa = .true.
-                                dict(do_diss_est=True), dict(fill_dp=True, do_diss_est=True, what="dyn_core")])   # flagstruct%do_diss_est, %fill_dp
+                                dict(do_diss_est=True), dict(fill_dp=True, do_diss_est=True, what="dyn_core"),    # flagstruct%do_diss_est, %fill_dp
+                                dict(beta=-1.0)])                                                                 # one_grad_p (beta < -0.1)
 def test_fortran_fv_dynamics_with_the_reference_argument_list_on_the_sphere(prod, tmp_path, kw):
     """VERDICT r3 item 6 (row a21): fv3_solo_refsig_sphere drives a C24 Jablonowski-Williamson fv_dynamics call with the REFERENCE'S
     argument list (one call per tile, host arrays with the fv_arrays layout, gridstruct / flagstruct / bd / domain), consv_te = 1,

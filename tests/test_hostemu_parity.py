@@ -632,6 +632,7 @@ def test_fortran_dyn_core_with_the_reference_argument_list(emu, tmp_path):
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(emu, tmp_path, nq=6, moist=True, consv_te=1.0, npz=10)
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(emu, tmp_path, nq=1, do_diss_est=True)     # diss_est out of fv_dynamics
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(emu, tmp_path, nq=0, consv_am=True)        # flagstruct%consv_am
+    assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(emu, tmp_path, nq=1, beta=-1.0)             # one_grad_p in the nonhydrostatic loop (beta < -0.1)
 
 
 @pytest.mark.parametrize("use_cond,moist_kappa", [(True, False), (True, True), (False, True)])
@@ -1233,7 +1234,8 @@ def test_riem_lds_bit_identical_to_the_slab_kernels(emu, dims):
                                 dict(what="dyn_core", face_rank=(0, 0, 1, 1, 2, 2)),
                                 dict(thermo=True), dict(thermo=True, what="dyn_core"), dict(thermo=True, face_rank=(0, 0, 1, 1, 2, 2)),   # use_cond = moist_kappa = .true.
                                 dict(do_diss_est=True), dict(do_diss_est=True, what="dyn_core", hydrostatic=True),      # flagstruct%do_diss_est: diss_est in and out
-                                dict(fill_dp=True, what="dyn_core"), dict(fill_dp=True, what="dyn_core", hydrostatic=True)])   # flagstruct%fill_dp
+                                dict(fill_dp=True, what="dyn_core"), dict(fill_dp=True, what="dyn_core", hydrostatic=True),   # flagstruct%fill_dp
+                                dict(beta=-1.0), dict(beta=-1.0, what="dyn_core")])                                           # one_grad_p (beta < -0.1)
 def test_fortran_fv_dynamics_with_the_reference_argument_list_on_the_sphere(emu, tmp_path, kw):
     """VERDICT r3 item 6 (row a21): fv_dynamics with the REFERENCE'S argument list (model/fv_dynamics.F90:79-85) on grid_type = 0 --
     fv3_dyn_core_mod.F90 binds one context per tile held (fv3_grid_upload_cubed from gridstruct's own members, corner factors from
