@@ -28,7 +28,7 @@
 !> fv3_halo_complete with the neighbour PEs, tracer_2d's mp_reduce_max through fv3_allreduce_max (fv3_host_comm_layout).
 !>
 !> Restrictions (error stop with the reason, never a silent difference): no nesting / regional BCs;
-!> hybrid_z is not carried through this wrapper; beta < 0 only as beta < -0.1 in a nonhydrostatic run.  consv_am (gridstruct%agrid, %l2c_u, %l2c_v, idiag%zxg),
+!> hybrid_z has no effect on this path in the reference either (fv_mapz.F90:62, :128); beta < 0 only as beta < -0.1 in a nonhydrostatic run.  consv_am (gridstruct%agrid, %l2c_u, %l2c_v, idiag%zxg),
 !> do_diss_est (the SKEB diss_est accumulation), fill_dp (mix_dp), consv_te, tau > 0, RF_fast, fast_tau_w_sec and
 !> thermostruct%use_cond / moist_kappa (the reference's defaults) are carried on both domains.
 module fv3_arrays_compat_mod
@@ -595,8 +595,9 @@ contains
   !> fv_dynamics with the reference's argument list (model/fv_dynamics.F90:79-85) for an adiabatic-core call: T -> theta_v
   !> (:284-399), the k_split loop (dyn_core, tracer_2d, Lagrangian_to_Eulerian with last_step on the final cycle, :460-665),
   !> cubed_to_latlon (:911), over the resident fv3_fv_dynamics of fv3_host_mod.  Host arrays in, host arrays out, like dyn_core
-  !> above.  error stop: consv_te, tau > 0 (the Python host carries the energy fixer and the Rayleigh damping), nesting,
-  !> use_cond / moist_kappa, consv_am, hybrid_z, grid_type /= 4.
+  !> above.  Carried: consv_te (energy fixer), tau > 0 (Rayleigh_Super / Rayleigh_Friction), RF_fast, fast_tau_w_sec, use_cond /
+  !> moist_kappa, consv_am, do_diss_est, fill_dp, beta > 0 and beta < -0.1; hybrid_z and ze0 are accepted and, as in the reference's
+  !> Lagrangian_to_Eulerian (fv_mapz.F90:62, :128: declared, never read), without effect.  error stop: nesting / regional domains.
   subroutine fv_dynamics(npx, npy, npz, nq_tot, ng, bdt, consv_te, fill, &
                          reproduce_sum, kappa, cp_air, zvir, ptop, ks, ncnst, n_split, &
                          q_split, u0, v0, u, v, w, delz, hydrostatic, pt, delp, q, &
@@ -653,7 +654,8 @@ contains
     if (thermostruct%use_cond .and. (size(q_con, 1) /= bd%ied - bd%isd + 1 .or. size(q_con, 3) < npz)) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): use_cond needs q_con(isd:ied, jsd:jed, npz)'
     if (gridstruct%grid_type /= 4) error stop 'fv_dynamics (fv3_dyn_core_mod): grid_type = 3 is not built'
-    if (hybrid_z) error stop 'fv_dynamics (fv3_dyn_core_mod): hybrid_z is not built'
+    ! hybrid_z: the reference hands it on to Lagrangian_to_Eulerian (fv_dynamics.F90:615), which declares it and never reads it
+    ! (fv_mapz.F90:62, :128); ze0 likewise is not touched on this path -- both are accepted and, as there, without effect
     if (flagstruct%beta < 0.d0 .and. (hydrostatic .or. flagstruct%beta >= -0.1d0)) &
       error stop 'fv_dynamics (fv3_dyn_core_mod): beta < 0: one_grad_p (beta < -0.1) is built for the nonhydrostatic loop'
     if (flagstruct%consv_am .and. .not. (allocated(gridstruct%agrid) .and. allocated(gridstruct%l2c_u) .and. allocated(gridstruct%l2c_v) &
@@ -758,7 +760,6 @@ contains
     subroutine fv_dynamics_sphere()
       type(fv3_flags) :: fl
       integer :: slot, nloc, sl
-      if (hybrid_z) error stop 'fv_dynamics (fv3_dyn_core_mod): hybrid_z is not built'
       if (ng /= 3 .or. nq_tot > ncnst) error stop 'fv_dynamics (fv3_dyn_core_mod): ng = 3, nq_tot <= ncnst'
       if (fv3_domain_tile(domain) < 1 .or. fv3_domain_tile(domain) > 6) error stop 'fv_dynamics (fv3_dyn_core_mod): fv3_domain_tile(domain) must be 1 .. 6'
       if (bd%is /= 1 .or. bd%js /= 1 .or. bd%ie /= npx - 1 .or. bd%je /= npy - 1) &

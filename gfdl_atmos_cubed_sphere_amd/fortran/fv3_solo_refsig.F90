@@ -17,7 +17,7 @@ program fv3_solo_refsig
   type(fv_atmos_type), pointer :: parent_grid => null()
   type(inline_mp_type) :: inline_mp
   real(c_double), allocatable :: ps(:,:), u0(:,:,:), v0(:,:,:), ze0(:,:,:)
-  logical :: whole
+  logical :: whole, hyb_z
   integer(c_int) :: nx, ny, npz, nq, n_split, k_split, nsteps, last_step, ihydro
   real(c_double) :: dxc_, dyc_, f0_, bdt, ptop, d_con, d_ext, beta, consv_te, tau
   real(c_double), allocatable :: ak(:), bk(:), pfull(:)
@@ -172,6 +172,9 @@ program fv3_solo_refsig
   if (envstat == 0 .and. trim(envbuf) == '1') then
     fs%do_diss_est = .true.; fs%prevent_diss_cooling = .false.
   end if
+  ! FV3_REFSIG_HYBRID_Z=1: fv_dynamics is called with hybrid_z = .true. (as in the reference: handed on, never read)
+  call get_environment_variable('FV3_REFSIG_HYBRID_Z', envbuf, status=envstat)
+  hyb_z = envstat == 0 .and. trim(envbuf) == '1'
   ! FV3_REFSIG_FILL_DP=1: flagstruct%fill_dp (mix_dp after d_sw, with the file's ak / bk as the reference thicknesses)
   call get_environment_variable('FV3_REFSIG_FILL_DP', envbuf, status=envstat)
   if (envstat == 0 .and. trim(envbuf) == '1') fs%fill_dp = .true.
@@ -191,7 +194,7 @@ program fv3_solo_refsig
                        .false., KAPPA, CP_AIR, zvir_, ptop, 0, max(1, int(nq)), int(n_split), &
                        0, u0, v0, u, v, w, delz, hydrostatic, pt, delp, q, &
                        ps, pe, pk, peln, pkz, phis, q_con, omga, ua, va, uc, vc, &
-                       ak, bk, mfx, mfy, cx, cy, ze0, .false., &
+                       ak, bk, mfx, mfy, cx, cy, ze0, hyb_z, &
                        gs, fs, ns, ts, idiag, bd, &
                        parent_grid, domain, inline_mp, heat_source, diss_est)
     end do

@@ -340,7 +340,7 @@ def _compare_blocks(res, ref, bd, what, tol=None):
 
 
 def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2, k_split=2, nsteps=2, bdt=8.0, hydrostatic=False, layout=(1, 1),
-                              consv_te=0.0, tau=0.0, moist=False, do_diss_est=False, consv_am=False, beta=0.0):
+                              consv_te=0.0, tau=0.0, moist=False, do_diss_est=False, consv_am=False, beta=0.0, hybrid_z=False):
     """fv_dynamics called with the reference's argument list on host arrays (fv3_dyn_core_mod::fv_dynamics, driver fv3_solo_refsig in
     its fv_dynamics mode: T -> theta_v, k_split x (dyn_core, tracer_2d, remap), last_step, cubed_to_latlon) against the Python host's
     FvDynamics.step_from_temperature on the same state: u, v, w, delp, pt (T), delz, the tracers and ua bit-identical"""
@@ -414,12 +414,15 @@ def check_fortran_fv_dynamics(lib, workdir, nx=24, ny=16, npz=8, nq=2, n_split=2
         spec.append(("diss_est", "A", ()))
         os.environ["FV3_REFSIG_DISS_EST"] = "1"
     os.environ["FV3_SOLO_CONSV_TE"], os.environ["FV3_SOLO_TAU"] = repr(float(consv_te)), repr(float(tau))
+    if hybrid_z:    # handed on to Lagrangian_to_Eulerian and never read there (fv_mapz.F90:62, :128): the same results
+        os.environ["FV3_REFSIG_HYBRID_Z"] = "1"
     try:
         res, out = _run_refsig(lib, exe, fin, fout, "fv_dynamics", layout, bd, npz, spec)
     finally:
         os.environ.pop("FV3_SOLO_CONSV_TE", None)
         os.environ.pop("FV3_SOLO_TAU", None)
         os.environ.pop("FV3_REFSIG_DISS_EST", None)
+        os.environ.pop("FV3_REFSIG_HYBRID_Z", None)
     # consv_am: u00 is a difference of column integrals ~ r^2 omega dm, which amplifies what cos() of the two run-time libraries differs by
     _compare_blocks(res, ref, bd, "reference-signature fv_dynamics", tol=1e-11 if consv_am else None)
     if consv_am:

@@ -735,7 +735,7 @@ def test_fortran_dyn_core_with_the_reference_argument_list(prod, tmp_path):
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, nq=6, moist=True, consv_te=1.0, npz=10)
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, nq=1, do_diss_est=True)     # diss_est out of fv_dynamics
     assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, nq=0, consv_am=True)        # flagstruct%consv_am
-    assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, nq=1, beta=-1.0)             # one_grad_p in the nonhydrostatic loop (beta < -0.1)
+    assert "fv3_solo_refsig: done" in F.check_fortran_fv_dynamics(prod, tmp_path, nq=1, beta=-1.0, hybrid_z=True)             # one_grad_p in the nonhydrostatic loop (beta < -0.1); hybrid_z = .true. is accepted (the reference never reads it)
 
 
 @pytest.mark.parametrize("use_cond,moist_kappa", [(True, False), (True, True), (False, True)])
