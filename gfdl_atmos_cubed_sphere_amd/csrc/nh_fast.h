@@ -340,11 +340,13 @@ struct EdgeProfileLds {
       }
     }
     FV3_SYNC();
-#ifdef FV3_LAB_EDGE_TABLE_ONLY
-    if (true) {
+#ifndef FV3_LAB_EDGE_OLD_PATH
+    {   // (the library always hands the table over; the wavefront-built rows stay for the A / B of tools/lab/edge_lab.hip: compiled into
+        // the same kernel they cost the table path 20 registers and nine spills under the three-wavefront budget)
+      FV3_WAVE_FOR(wv) rows_from_table(wv * 4, B0, B1);
+    }
 #else
     if (tab) {
-#endif
       FV3_WAVE_FOR(wv) rows_from_table(wv * 4, B0, B1);
     } else {
     const double xt2 = ec.gk_bot * (ec.gk_bot + 0.5) - ec.a_bot * ec.gam[km - 1];
@@ -415,6 +417,7 @@ struct EdgeProfileLds {
       }
     }
     }
+#endif
     FV3_SYNC();
     for (int idx = tid; idx < kFC * 128; idx += kNT) {
       const int col = idx & (kFC - 1), k = idx >> 4;

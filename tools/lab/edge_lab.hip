@@ -2,6 +2,9 @@
 // the wavefront-built row coefficients against the host's table, the two fields of a pair one after the other against side by side;
 // timed and compared bit for bit.  tools/lab/build.sh edge_lab; run on the GPU box.
 //   edge_lab [nx] [km] [reps]
+#ifndef FV3_LAB_EDGE_TABLE_ONLY
+#define FV3_LAB_EDGE_OLD_PATH 1   // the rows built by the wavefront (round 5), for the comparison
+#endif
 #include "lab_common.h"
 
 #include "../../gfdl_atmos_cubed_sphere_amd/csrc/fv3_launch.h"
