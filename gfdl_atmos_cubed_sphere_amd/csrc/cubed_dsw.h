@@ -66,6 +66,58 @@ struct DswCubedD1a {
   }
 };
 
+// D1a as a tile kernel whose threads MARCH: 64 lanes along i, four groups of kRows consecutive rows; the rows of uc / vc a thread has read
+// serve two rows of results (ut(j) reads vc(j), vc(j+1); vt(j) reads uc(j-1), uc(j)), so a point costs 4 field loads and 4 metric loads
+// instead of 10 + 4.  What D1a waits for is its loads' way through the L1 (profiles/r06_pmc_pass.csv: 90 M cache-line accesses a launch,
+// 18 per 8-byte-a-lane load instruction, for 0.76 GB of HBM traffic).  The statements and their conditions are D1a's: the same bits.
+struct DswCubedD1aRows {
+  DswCubedState s;
+  static constexpr int kRows = 8;
+  FV3_HD void operator()(int bx, int by, int k, int tid, double *) const {
+    const Grid &g = s.g;
+    const int npx = g.npx, npy = g.npy;
+    const int i0 = g.isd, i1 = g.ied + 1, j0 = g.jsd, j1 = g.jed + 1;
+    const CA uc = cview_V(g, s.a.uc), vc = cview_U(g, s.a.vc);
+    const VA ut = view_V(g, s.ut), vt = view_U(g, s.vt);
+    const double dt = s.a.dt;
+    for (int t = tid; t < 256; t += kNT) {
+      const int i = i0 + bx * 64 + (t & 63);
+      const int jA = j0 + (by * 4 + (t >> 6)) * kRows;
+      if (i > i1 || jA > j1) continue;
+      const int jB = jA + kRows - 1 < j1 ? jA + kRows - 1 : j1;
+      // clamped addresses: a clamped value is one no kept result reads (the conditions below are D1a's)
+      const int iu1 = i + 1 <= g.ied + 1 ? i + 1 : g.ied + 1;            // uc(i+1, .)
+      const int ivm = i - 1 >= g.isd ? i - 1 : g.isd;                    // vc(i-1, .)
+      const int iv0 = i <= g.ied ? i : g.ied;                            // vc(i, .)
+      auto ju = [&](int j) { return j < g.jsd ? g.jsd : (j > g.jed ? g.jed : j); };
+      auto jv = [&](int j) { return j < g.jsd ? g.jsd : (j > g.jed + 1 ? g.jed + 1 : j); };
+      double ucm0 = uc(i, ju(jA - 1), k), ucm1 = uc(iu1, ju(jA - 1), k);        // row j-1
+      double vc0m = vc(ivm, jv(jA), k), vc00 = vc(iv0, jv(jA), k);              // row j
+      for (int j = jA; j <= jB; j++) {
+        const double uc00 = uc(i, ju(j), k), uc01 = uc(iu1, ju(j), k);          // row j
+        const double vc1m = vc(ivm, jv(j + 1), k), vc10 = vc(iv0, jv(j + 1), k);  // row j+1
+        if (j <= g.jed && i >= g.is - 1 && i <= g.ie + 2) {
+          if (i == 1 || i == npx) {
+            const double u0 = uc00;
+            ut(i, j, k) = (u0 * dt > 0.) ? u0 / g.sinsg(i - 1, j, 3) : u0 / g.sinsg(i, j, 1);
+          } else if (j != 0 && j != 1 && j != npy - 1 && j != npy) {
+            ut(i, j, k) = (uc00 - 0.25 * g.cosa_u[g.iV(i, j)] * (vc0m + vc00 + vc1m + vc10)) * g.rsin_u[g.iV(i, j)];
+          }
+        }
+        if (i <= g.ied && j >= g.js - 1 && j <= g.je + 2) {
+          if (j == 1 || j == npy) {
+            const double v0 = vc00;
+            vt(i, j, k) = (v0 * dt > 0.) ? v0 / g.sinsg(i, j - 1, 4) : v0 / g.sinsg(i, j, 2);
+          } else {
+            vt(i, j, k) = (vc00 - 0.25 * g.cosa_v[g.iU(i, j)] * (ucm0 + ucm1 + uc00 + uc01)) * g.rsin_v[g.iU(i, j)];
+          }
+        }
+        ucm0 = uc00; ucm1 = uc01; vc0m = vc1m; vc00 = vc10;
+      }
+    }
+  }
+};
+
 // D1b: second layer: the winds parallel to an edge in the two rows / columns next to it (:702-708, :719-724, :739-745,
 // :756-762); box (0:npx, 0:npy)
 struct DswCubedD1b {

@@ -1770,7 +1770,16 @@ static int dsw_cubed(fv3_ctx *c, const DswArgs &a) {
     if (!(s.gxq = cs_scratch(c, 27)) || !(s.gyq = cs_scratch(c, 28))) return fail("d_sw: out of device memory");
   }
   // contravariant winds of the whole face, all levels
-  RT(launch_box(c, "dswc_d1", g.isd, g.ied + 1, g.jsd, g.jed + 1, npz, DswCubedD1a{s}));
+  static const int d1_rows = [] { const char *e = std::getenv("FV3_MI355X_D1_ROWS"); return e ? std::atoi(e) : 1; }();
+  if (d1_rows) {   // the marching form (cubed_dsw.h DswCubedD1aRows); FV3_MI355X_D1_ROWS=0: the point-wise pass
+    Dim3 gr;
+    gr.x = (unsigned)((g.ied + 1 - g.isd + 64) / 64);
+    gr.y = (unsigned)((g.jed + 1 - g.jsd + 4 * DswCubedD1aRows::kRows) / (4 * DswCubedD1aRows::kRows));
+    gr.z = (unsigned)npz;
+    RT(launch_p(c, "dswc_d1", gr, 0, DswCubedD1aRows{s}));
+  } else {
+    RT(launch_box(c, "dswc_d1", g.isd, g.ied + 1, g.jsd, g.jed + 1, npz, DswCubedD1a{s}));
+  }
   RT(launch_box(c, "dswc_d1b", 0, npx, 0, npy, npz, DswCubedD1b{s}));
   RT(launch_box(c, "dswc_d1c", 0, 3, 0, 0, npz, DswCubedD1c{s}));
 
